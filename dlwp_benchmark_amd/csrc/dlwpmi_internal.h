@@ -1,0 +1,57 @@
+// Internal (non-exported) interfaces shared between the translation units of libdlwpmi.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/dlwpmi.h"
+
+// pwmlp.hip — strided/gathered channel views, optional residual and fused MSE gradient
+int dlwp_pwmlp_fwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, const float* w2,
+                      const float* b2, const dlwp_chan_dst* y, const dlwp_chan_src* res, int B,
+                      int Cin, int Ch, int Cout, int P, hipStream_t stream);
+int dlwp_pwmlp_bwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, const float* w2,
+                      const dlwp_chan_src* gy, const dlwp_chan_src* pred, const dlwp_chan_src* target,
+                      float mse_scale, const dlwp_chan_dst* gx, int gx_accumulate, float* gw1,
+                      float* gb1, float* gw2, float* gb2, int B, int Cin, int Ch, int Cout, int P,
+                      hipStream_t stream);
+
+// fno_block.hip — the three stages of a block, exposed so the trainer can interleave them
+struct dlwp_fno_plan {
+    int C, H, W, m1, m2c;
+    int C_pad, NP;            // channels padded to 16; 2*m2c padded to 16
+    // device tables (built in double on the host)
+    float2* twH;              // [m1][H]    e^{-2 pi i k_j h / H}, k_j = signed kept row frequency
+    float* FT_fwd;            // [NP][W]    forward W-axis DFT (scale 1/(H W)), n = 2 kx (+1: imag)
+    float* FT_adj;            // [NP][W]    adjoint of the inverse W-axis step (scale c_kx)
+    float* G_inv;             // [NP][W]    inverse W-axis step (c_kx cos, -c_kx sin)
+    float* G_adj;             // [NP][W]    adjoint of the forward W-axis step (scale 1/(H W))
+};
+
+// rows: x1[b][h][kx][c] (complex) = sum_w act(x[b][c][h][w]) * FT[2kx(+1)][w]
+int dlwp_fno_rows_dft(const dlwp_fno_plan* p, const float* x, int act_in, int adjoint, float2* x1,
+                      int B, hipStream_t stream);
+// per-mode stage, forward: xhat[b][j][kx][i] = sum_h x1[b][h][kx][i] twH[j][h];
+//                          y[b][j][kx][o] = sum_i xhat * wspec[j][kx][i][o]
+int dlwp_fno_mix_fwd(const dlwp_fno_plan* p, const float2* x1, const float2* wspec, float2* xhat,
+                     float2* y, int B, hipStream_t stream);
+// backward: ghat = H-step of g1; gx[b][j][kx][i] = sum_o ghat conj(w); gw += conj(xhat) ghat
+int dlwp_fno_mix_bwd(const dlwp_fno_plan* p, const float2* g1, const float2* wspec,
+                     const float2* xhat, float2* gxhat, float2* g_wspec, int B, hipStream_t stream);
+// spatial stage (one workgroup per image row, all channels).
+struct dlwp_fno_spatial_args {
+    const float* tin;        // [B,C,H,W] GEMM input (fwd: x, bwd: g_pre)
+    int act_tin;             // apply GELU to tin on load (fwd only)
+    const float2* spec;      // [B][m1][m2c][C] complex: fwd y, bwd gxhat
+    const float* wskip;      // [C][C] (fwd uses W, bwd uses W^T)
+    int transpose_w;
+    const float* bias;       // fwd only (nullable)
+    const float* pprev;      // bwd: the block input x (pre-activation if act_prev)
+    int act_prev;            // bwd: x was passed through GELU => multiply by gelu'(pprev)
+    float* out;              // [B,C,H,W]: fwd pre, bwd g_x
+    float2* x1_out;          // optional fused row DFT of the result (fwd: of gelu(out) when
+    int x1_act;              //   x1_act; bwd: adjoint table), layout [b][h][kx][c]
+    int x1_adjoint;
+    float* g_wskip;          // bwd: += g_pre . act(x)^T   (nullable)
+    float* g_bias;           // bwd: += sum g_pre          (nullable)
+    int inverse_adjoint;     // which G table: 0 = inverse step (fwd), 1 = adjoint of fwd step
+    int B;
+};
+int dlwp_fno_spatial(const dlwp_fno_plan* p, const dlwp_fno_spatial_args* a, hipStream_t stream);

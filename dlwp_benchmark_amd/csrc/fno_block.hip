@@ -1,0 +1,579 @@
+// FNO block = SpectralConv (mode-truncated rfft2 -> per-mode complex channel mixing -> irfft2)
+// + linear (1x1) skip + bias, forward and backward.  Arithmetic restated from neuralop
+// SpectralConv/FNOBlocks (third-party); reference call sites
+// `self.fno(x_t)` src/nsbench/models/fno/fno.py:38,96,246, src/dlwpbench/models/fno/fno.py:103.
+//
+// MI355X design.  Only m1 x m2c modes of the H x (W/2+1) spectrum are ever used (12 x 7 of
+// 64 x 33 at the headline config), so no FFT is run: the transform is a pruned DFT factored
+// into a W-axis step (a [C x W] x [W x 2*m2c] GEMM per image row) and an H-axis step
+// (m1 complex dot products of length H per (channel, column)).  Three kernels per block:
+//   rows   : one workgroup per image row (b,h), all channels: W-axis DFT on MFMA -> x1[b][h][kx][c]
+//   mix    : one workgroup per kept mode (j,kx): H-axis step, complex channel contraction with
+//            the mode's [C x C] weight slice (mode-major layout => contiguous 8*C*C bytes)
+//   spatial: one workgroup per image row: inverse H-step (tiny), then ONE concatenated-K MFMA
+//            GEMM  pre[o][w] = [Wskip | Y1(o,:)] . [x ; G]  (skip conv + inverse W-axis DFT),
+//            bias, and optionally the next block's `rows` stage fused on the result.
+// The backward pass reuses the same three kernels with adjoint tables.
+#include "common.cuh"
+#include "dlwpmi_internal.h"
+#include <cmath>
+#include <vector>
+
+namespace {
+
+struct SpatialDev {
+    const float* tin; const float2* spec; const float* wskip; const float* bias;
+    const float* pprev; float* out; float2* x1_out; float* g_wskip; float* g_bias;
+    const float2* twH; const float* G; const float* FT;
+    int act_tin, transpose_w, act_prev, x1_act, is_bwd;
+    int C, H, W, m1, m2c, C_pad, NP;
+};
+
+// x1s[c][n] += sum_w act(tile[c][w]) * ft[n][w]   (wave w takes 16-pixel chunks w, w+4, ...)
+template <int NCB, int NBN>
+__device__ __forceinline__ void tile_rows_dft(const float* tile, const float* ft, float* x1s, int LDP,
+                                              int NP, int nwb, bool act) {
+    const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
+    f32x4 xacc[NCB][NBN];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int nb = 0; nb < NBN; ++nb) xacc[cb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kc = w; kc < nwb; kc += 4) {
+        f32x4 b4[NBN];
+#pragma unroll
+        for (int nb = 0; nb < NBN; ++nb)
+            b4[nb] = *reinterpret_cast<const f32x4*>(&ft[(nb * 16 + r) * LDP + kc * 16 + 4 * g]);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            f32x4 a4 = *reinterpret_cast<const f32x4*>(&tile[(cb * 16 + r) * LDP + kc * 16 + 4 * g]);
+            if (act) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) a4[s] = gelu_f(a4[s]);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NBN; ++nb) xacc[cb][nb] = mfma16_chunk(a4, b4[nb], xacc[cb][nb]);
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int nb = 0; nb < NBN; ++nb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                atomicAdd(&x1s[(cb * 16 + 4 * g + j) * NP + nb * 16 + r], xacc[cb][nb][j]);
+}
+
+__device__ __forceinline__ void store_x1(const float* x1s, float2* x1_out, int b, int h, int H, int m2c,
+                                         int C, int NP) {
+    float2* dst = x1_out + ((long long)(b * H + h) * m2c) * C;
+    for (int idx = threadIdx.x; idx < m2c * C; idx += 256) {
+        const int kx = idx / C, c = idx % C;
+        dst[idx] = make_float2(x1s[c * NP + 2 * kx], x1s[c * NP + 2 * kx + 1]);
+    }
+}
+
+struct RowsDev {
+    const float* x; float2* x1; const float* FT;
+    int act, C, H, W, m2c, C_pad, NP;
+};
+
+template <int NCB, int NBN>
+__global__ __launch_bounds__(256) void fno_rows_kernel(RowsDev a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LDP = a.W + 4;
+    float* tile = smem;                    // [C_pad][LDP]
+    float* ft = tile + a.C_pad * LDP;      // [NP][LDP]
+    float* x1s = ft + a.NP * LDP;          // [C_pad][NP]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const int W4 = a.W / 4;
+    for (int idx = tid; idx < a.C_pad * W4; idx += 256) {
+        const int c = idx / W4, x4 = idx % W4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < a.C) v = *reinterpret_cast<const float4*>(&a.x[(((long long)b * a.C + c) * a.H + h) * a.W + 4 * x4]);
+        *reinterpret_cast<float4*>(&tile[c * LDP + 4 * x4]) = v;
+    }
+    for (int idx = tid; idx < a.NP * W4; idx += 256) {
+        const int n = idx / W4, x4 = idx % W4;
+        *reinterpret_cast<float4*>(&ft[n * LDP + 4 * x4]) = *reinterpret_cast<const float4*>(&a.FT[n * a.W + 4 * x4]);
+    }
+    for (int idx = tid; idx < a.C_pad * a.NP; idx += 256) x1s[idx] = 0.f;
+    __syncthreads();
+    tile_rows_dft<NCB, NBN>(tile, ft, x1s, LDP, a.NP, a.W / 16, a.act != 0);
+    __syncthreads();
+    store_x1(x1s, a.x1, b, h, a.H, a.m2c, a.C, a.NP);
+}
+
+template <int NCB, int NBN>
+__global__ __launch_bounds__(256) void fno_spatial_kernel(SpatialDev a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LDP = a.W + 4, LDK = a.C_pad + 4, LDS1 = a.NP + 4;
+    float* tin_s = smem;                          // [C_pad][LDP]
+    float* tout_s = tin_s + a.C_pad * LDP;        // [C_pad][LDP]
+    float* gs = tout_s + a.C_pad * LDP;           // [NP][LDP]
+    float* ft = gs + a.NP * LDP;                  // [NP][LDP]
+    float* ks = ft + a.NP * LDP;                  // [C_pad][LDK]
+    float* s1 = ks + a.C_pad * LDK;               // [C_pad][LDS1]
+    float* x1s = s1 + a.C_pad * LDS1;             // [C_pad][NP]
+    float* bias_s = x1s + a.C_pad * a.NP;         // [C_pad]
+    float* gks = bias_s + a.C_pad;                // [C_pad][C_pad]  (bwd)
+    float* pprev_s = gks + a.C_pad * a.C_pad;     // [C_pad][LDP]    (bwd)
+
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int r = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const int W4 = a.W / 4, nwb = a.W / 16;
+    const bool need_prev = a.is_bwd && (a.act_prev || a.g_wskip);
+
+    for (int idx = tid; idx < a.C_pad * W4; idx += 256) {
+        const int c = idx / W4, x4 = idx % W4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f), pv = v;
+        if (c < a.C) {
+            const long long off = (((long long)b * a.C + c) * a.H + h) * a.W + 4 * x4;
+            v = *reinterpret_cast<const float4*>(&a.tin[off]);
+            if (a.act_tin) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
+            if (need_prev) pv = *reinterpret_cast<const float4*>(&a.pprev[off]);
+        }
+        *reinterpret_cast<float4*>(&tin_s[c * LDP + 4 * x4]) = v;
+        if (need_prev) *reinterpret_cast<float4*>(&pprev_s[c * LDP + 4 * x4]) = pv;
+    }
+    for (int idx = tid; idx < a.NP * W4; idx += 256) {
+        const int n = idx / W4, x4 = idx % W4;
+        *reinterpret_cast<float4*>(&gs[n * LDP + 4 * x4]) = *reinterpret_cast<const float4*>(&a.G[n * a.W + 4 * x4]);
+        if (a.x1_out)
+            *reinterpret_cast<float4*>(&ft[n * LDP + 4 * x4]) = *reinterpret_cast<const float4*>(&a.FT[n * a.W + 4 * x4]);
+    }
+    for (int idx = tid; idx < a.C_pad * a.C_pad; idx += 256) {
+        const int m = idx / a.C_pad, k = idx % a.C_pad;
+        float v = 0.f;
+        if (m < a.C && k < a.C) v = a.transpose_w ? a.wskip[k * a.C + m] : a.wskip[m * a.C + k];
+        ks[m * LDK + k] = v;
+        gks[idx] = 0.f;
+    }
+    for (int idx = tid; idx < a.C_pad * a.NP; idx += 256) x1s[idx] = 0.f;
+    for (int idx = tid; idx < a.C_pad; idx += 256) bias_s[idx] = (a.bias && idx < a.C) ? a.bias[idx] : 0.f;
+    // inverse H-axis step for this row: s1[o][2kx(+1)] = sum_j spec[b][j][kx][o] * conj(twH[j][h])
+    for (int idx = tid; idx < a.C_pad * (a.NP / 2); idx += 256) {
+        const int kx = idx / a.C_pad, o = idx % a.C_pad;
+        float re = 0.f, im = 0.f;
+        if (kx < a.m2c && o < a.C) {
+            for (int j = 0; j < a.m1; ++j) {
+                const float2 v = a.spec[(((long long)b * a.m1 + j) * a.m2c + kx) * a.C + o];
+                const float2 t = a.twH[j * a.H + h];
+                re += v.x * t.x + v.y * t.y;   // v * conj(t)
+                im += v.y * t.x - v.x * t.y;
+            }
+        }
+        s1[o * LDS1 + 2 * kx] = re;
+        s1[o * LDS1 + 2 * kx + 1] = im;
+    }
+    __syncthreads();
+
+    // main concatenated-K GEMM: acc[o][w] = sum_i ks[o][i] tin[i][w] + sum_n s1[o][n] gs[n][w]
+    for (int wb = w; wb < nwb; wb += 4) {
+        f32x4 acc[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < NCB; ++kc) {
+            f32x4 b4;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) b4[s] = tin_s[(kc * 16 + 4 * g + s) * LDP + wb * 16 + r];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(&ks[(cb * 16 + r) * LDK + kc * 16 + 4 * g]);
+                acc[cb] = mfma16_chunk(a4, b4, acc[cb]);
+            }
+        }
+#pragma unroll
+        for (int nc = 0; nc < NBN; ++nc) {
+            f32x4 b4;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) b4[s] = gs[(nc * 16 + 4 * g + s) * LDP + wb * 16 + r];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(&s1[(cb * 16 + r) * LDS1 + nc * 16 + 4 * g]);
+                acc[cb] = mfma16_chunk(a4, b4, acc[cb]);
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int o = cb * 16 + 4 * g + j, x = wb * 16 + r;
+                float v = acc[cb][j];
+                if (!a.is_bwd) v += bias_s[o];
+                else if (a.act_prev) v *= gelu_grad_f(pprev_s[o * LDP + x]);
+                tout_s[o * LDP + x] = v;
+            }
+    }
+    __syncthreads();
+
+    for (int idx = tid; idx < a.C * W4; idx += 256) {
+        const int c = idx / W4, x4 = idx % W4;
+        *reinterpret_cast<float4*>(&a.out[(((long long)b * a.C + c) * a.H + h) * a.W + 4 * x4]) =
+            *reinterpret_cast<const float4*>(&tout_s[c * LDP + 4 * x4]);
+    }
+    if (a.x1_out) tile_rows_dft<NCB, NBN>(tout_s, ft, x1s, LDP, a.NP, nwb, a.x1_act != 0);
+
+    if (a.is_bwd && a.g_wskip) {
+        // gK[o][i] += sum_w g_pre[o][w] * act(x)[i][w]
+        f32x4 kacc[NCB][NCB];
+#pragma unroll
+        for (int ob = 0; ob < NCB; ++ob)
+#pragma unroll
+            for (int ib = 0; ib < NCB; ++ib) kacc[ob][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kc = w; kc < nwb; kc += 4) {
+#pragma unroll
+            for (int ib = 0; ib < NCB; ++ib) {
+                f32x4 b4 = *reinterpret_cast<const f32x4*>(&pprev_s[(ib * 16 + r) * LDP + kc * 16 + 4 * g]);
+                if (a.act_prev) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) b4[s] = gelu_f(b4[s]);
+                }
+#pragma unroll
+                for (int ob = 0; ob < NCB; ++ob) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(&tin_s[(ob * 16 + r) * LDP + kc * 16 + 4 * g]);
+                    kacc[ob][ib] = mfma16_chunk(a4, b4, kacc[ob][ib]);
+                }
+            }
+        }
+#pragma unroll
+        for (int ob = 0; ob < NCB; ++ob)
+#pragma unroll
+            for (int ib = 0; ib < NCB; ++ib)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    atomicAdd(&gks[(ob * 16 + 4 * g + j) * a.C_pad + ib * 16 + r], kacc[ob][ib][j]);
+    }
+    __syncthreads();
+    if (a.x1_out) store_x1(x1s, a.x1_out, b, h, a.H, a.m2c, a.C, a.NP);
+    if (a.is_bwd && a.g_wskip) {
+        for (int idx = tid; idx < a.C * a.C; idx += 256) {
+            const int o = idx / a.C, i = idx % a.C;
+            atomic_add_f32(&a.g_wskip[idx], gks[o * a.C_pad + i]);
+        }
+    }
+    if (a.is_bwd && a.g_bias && tid < a.C) {
+        float s = 0.f;
+        for (int x = 0; x < a.W; ++x) s += tin_s[tid * LDP + x];
+        atomic_add_f32(&a.g_bias[tid], s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+struct MixDev {
+    const float2* x1; const float2* wspec; const float2* xhat_in; float2* xhat; float2* y;
+    float2* g_wspec; const float2* twH;
+    int B, C, H, m1, m2c;
+};
+
+__device__ __forceinline__ void lds_cadd(float2* p, float re, float im) {
+    atomicAdd(&p->x, re);
+    atomicAdd(&p->y, im);
+}
+
+// H-axis step into LDS: xh[b*C+c] = sum_h x1[b][h][kx][c] * twH[j][h]
+__device__ __forceinline__ void mix_hstep(const MixDev& a, int j, int kx, float2* xh) {
+    const int BC = a.B * a.C;
+    int HS = 256 / BC;
+    if (HS < 1) HS = 1;
+    if (HS > a.H) HS = a.H;
+    for (int u = threadIdx.x; u < BC * HS; u += 256) {
+        const int bc = u % BC, hs = u / BC, b = bc / a.C, c = bc % a.C;
+        float re = 0.f, im = 0.f;
+        for (int h = hs; h < a.H; h += HS) {
+            const float2 v = a.x1[(((long long)b * a.H + h) * a.m2c + kx) * a.C + c];
+            const float2 t = a.twH[j * a.H + h];
+            re += v.x * t.x - v.y * t.y;
+            im += v.x * t.y + v.y * t.x;
+        }
+        lds_cadd(&xh[bc], re, im);
+    }
+}
+
+__global__ __launch_bounds__(256) void fno_mix_fwd_kernel(MixDev a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int BC = a.B * a.C;
+    float2* xh = reinterpret_cast<float2*>(smem);  // [BC]
+    float2* yh = xh + BC;                          // [BC]
+    const int j = blockIdx.x / a.m2c, kx = blockIdx.x % a.m2c;
+    for (int i = threadIdx.x; i < 2 * BC; i += 256) xh[i] = make_float2(0.f, 0.f);
+    __syncthreads();
+    mix_hstep(a, j, kx, xh);
+    __syncthreads();
+    for (int bc = threadIdx.x; bc < BC; bc += 256) {
+        const int b = bc / a.C, c = bc % a.C;
+        a.xhat[(((long long)b * a.m1 + j) * a.m2c + kx) * a.C + c] = xh[bc];
+    }
+    const float2* wm = a.wspec + ((long long)(j * a.m2c + kx) * a.C) * a.C;
+    int IS = 256 / BC;
+    if (IS < 1) IS = 1;
+    if (IS > a.C) IS = a.C;
+    for (int u = threadIdx.x; u < BC * IS; u += 256) {
+        const int bo = u % BC, is = u / BC, b = bo / a.C, o = bo % a.C;
+        float re = 0.f, im = 0.f;
+        for (int i = is; i < a.C; i += IS) {
+            const float2 xv = xh[b * a.C + i];
+            const float2 wv = wm[i * a.C + o];
+            re += xv.x * wv.x - xv.y * wv.y;
+            im += xv.x * wv.y + xv.y * wv.x;
+        }
+        lds_cadd(&yh[bo], re, im);
+    }
+    __syncthreads();
+    for (int bo = threadIdx.x; bo < BC; bo += 256) {
+        const int b = bo / a.C, o = bo % a.C;
+        a.y[(((long long)b * a.m1 + j) * a.m2c + kx) * a.C + o] = yh[bo];
+    }
+}
+
+__global__ __launch_bounds__(256) void fno_mix_bwd_kernel(MixDev a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int BC = a.B * a.C;
+    float2* gh = reinterpret_cast<float2*>(smem);  // [BC]  ghat
+    float2* gxh = gh + BC;                         // [BC]  grad wrt xhat
+    float2* xsv = gxh + BC;                        // [BC]  saved xhat
+    const int j = blockIdx.x / a.m2c, kx = blockIdx.x % a.m2c;
+    for (int i = threadIdx.x; i < 2 * BC; i += 256) gh[i] = make_float2(0.f, 0.f);
+    for (int bc = threadIdx.x; bc < BC; bc += 256) {
+        const int b = bc / a.C, c = bc % a.C;
+        xsv[bc] = a.xhat_in[(((long long)b * a.m1 + j) * a.m2c + kx) * a.C + c];
+    }
+    __syncthreads();
+    mix_hstep(a, j, kx, gh);
+    __syncthreads();
+    const long long wofs = ((long long)(j * a.m2c + kx) * a.C) * a.C;
+    const float2* wm = a.wspec + wofs;
+    int OS = 256 / BC;
+    if (OS < 1) OS = 1;
+    if (OS > a.C) OS = a.C;
+    for (int u = threadIdx.x; u < BC * OS; u += 256) {
+        const int bi = u % BC, os = u / BC, b = bi / a.C, i = bi % a.C;
+        float re = 0.f, im = 0.f;
+        for (int o = os; o < a.C; o += OS) {
+            const float2 gv = gh[b * a.C + o];
+            const float2 wv = wm[i * a.C + o];
+            re += gv.x * wv.x + gv.y * wv.y;   // g * conj(w)
+            im += gv.y * wv.x - gv.x * wv.y;
+        }
+        lds_cadd(&gxh[bi], re, im);
+    }
+    // weight gradient (this workgroup owns the mode slice exclusively): gw[i][o] += conj(x) g
+    float2* gw = a.g_wspec + wofs;
+    for (int idx = threadIdx.x; idx < a.C * a.C; idx += 256) {
+        const int i = idx / a.C, o = idx % a.C;
+        float re = 0.f, im = 0.f;
+        for (int b = 0; b < a.B; ++b) {
+            const float2 xv = xsv[b * a.C + i];
+            const float2 gv = gh[b * a.C + o];
+            re += xv.x * gv.x + xv.y * gv.y;
+            im += xv.x * gv.y - xv.y * gv.x;
+        }
+        float2 cur = gw[idx];
+        cur.x += re;
+        cur.y += im;
+        gw[idx] = cur;
+    }
+    __syncthreads();
+    for (int bi = threadIdx.x; bi < BC; bi += 256) {
+        const int b = bi / a.C, i = bi % a.C;
+        a.y[(((long long)b * a.m1 + j) * a.m2c + kx) * a.C + i] = gxh[bi];
+    }
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes, const char* what) {
+    return dlwp_ensure_lds(reinterpret_cast<const void*>(kernel), bytes, what);
+}
+
+template <typename T>
+int upload(T** dst, const std::vector<T>& host) {
+    DLWP_HIP(hipMalloc(reinterpret_cast<void**>(dst), host.size() * sizeof(T)));
+    DLWP_HIP(hipMemcpy(*dst, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return DLWP_OK;
+}
+
+}  // namespace
+
+extern "C" int dlwp_fno_plan_create(int C, int H, int W, int m1, int m2c, dlwp_fno_plan** out) {
+    DLWP_REQUIRE(out, DLWP_E_INVALID, "fno_plan_create: out is NULL");
+    DLWP_REQUIRE(C > 0 && H > 0 && W > 0 && m1 > 0 && m2c > 0, DLWP_E_INVALID, "fno_plan_create: bad dims");
+    DLWP_REQUIRE(W % 16 == 0, DLWP_E_UNSUPPORTED, "fno_plan_create: W must be a multiple of 16 (got %d)", W);
+    DLWP_REQUIRE(H % 2 == 0, DLWP_E_UNSUPPORTED, "fno_plan_create: H must be even (got %d)", H);
+    DLWP_REQUIRE(m1 <= H && m2c <= W / 2 + 1, DLWP_E_INVALID, "fno_plan_create: more modes than the grid has");
+    DLWP_REQUIRE(C <= 64, DLWP_E_UNSUPPORTED, "fno_plan_create: hidden_channels <= 64 supported (got %d)", C);
+    DLWP_REQUIRE(2 * m2c <= 32, DLWP_E_UNSUPPORTED, "fno_plan_create: n_modes[1]/2+1 <= 16 supported (got %d)", m2c);
+    dlwp_fno_plan* p = new dlwp_fno_plan();
+    p->C = C; p->H = H; p->W = W; p->m1 = m1; p->m2c = m2c;
+    p->C_pad = round_up(C, 16);
+    p->NP = round_up(2 * m2c, 16);
+    const double PI = 3.14159265358979323846;
+    // kept rows of the fftshift-ed spectrum (neuralop SpectralConv slicing, App. A-1)
+    const int start = H - m1, lo = start / 2;
+    std::vector<float2> tw((size_t)m1 * H);
+    for (int j = 0; j < m1; ++j) {
+        const int k = lo + j - H / 2;  // signed frequency
+        for (int h = 0; h < H; ++h) {
+            const long long kh = (((long long)k * h) % H + H) % H;
+            const double ang = -2.0 * PI * (double)kh / H;
+            tw[(size_t)j * H + h] = make_float2((float)cos(ang), (float)sin(ang));
+        }
+    }
+    std::vector<float> ft_fwd((size_t)p->NP * W, 0.f), ft_adj(ft_fwd), g_inv(ft_fwd), g_adj(ft_fwd);
+    const double inv_hw = 1.0 / ((double)H * W);
+    for (int kx = 0; kx < m2c; ++kx) {
+        const double ck = (kx == 0 || (W % 2 == 0 && kx == W / 2)) ? 1.0 : 2.0;
+        for (int w = 0; w < W; ++w) {
+            const long long kw = ((long long)kx * w) % W;
+            const double ang = 2.0 * PI * (double)kw / W;
+            const double c = cos(ang), s = sin(ang);
+            ft_fwd[(size_t)(2 * kx) * W + w] = (float)(c * inv_hw);
+            ft_fwd[(size_t)(2 * kx + 1) * W + w] = (float)(-s * inv_hw);
+            ft_adj[(size_t)(2 * kx) * W + w] = (float)(c * ck);
+            ft_adj[(size_t)(2 * kx + 1) * W + w] = (float)(-s * ck);
+            g_inv[(size_t)(2 * kx) * W + w] = (float)(c * ck);
+            g_inv[(size_t)(2 * kx + 1) * W + w] = (float)(-s * ck);
+            g_adj[(size_t)(2 * kx) * W + w] = (float)(c * inv_hw);
+            g_adj[(size_t)(2 * kx + 1) * W + w] = (float)(-s * inv_hw);
+        }
+    }
+    int rc;
+    if ((rc = upload(&p->twH, tw)) || (rc = upload(&p->FT_fwd, ft_fwd)) || (rc = upload(&p->FT_adj, ft_adj)) ||
+        (rc = upload(&p->G_inv, g_inv)) || (rc = upload(&p->G_adj, g_adj))) {
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return DLWP_OK;
+}
+
+extern "C" void dlwp_fno_plan_destroy(dlwp_fno_plan* p) {
+    if (!p) return;
+    (void)hipFree(p->twH); (void)hipFree(p->FT_fwd); (void)hipFree(p->FT_adj);
+    (void)hipFree(p->G_inv); (void)hipFree(p->G_adj);
+    delete p;
+}
+
+static size_t x1_elems(const dlwp_fno_plan* p, int B) { return (size_t)B * p->H * p->m2c * p->C; }
+static size_t spec_elems(const dlwp_fno_plan* p, int B) { return (size_t)B * p->m1 * p->m2c * p->C; }
+static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+extern "C" size_t dlwp_fno_block_workspace_bytes(const dlwp_fno_plan* p, int B) {
+    return align256(x1_elems(p, B) * sizeof(float2)) + align256(spec_elems(p, B) * sizeof(float2));
+}
+
+#define DISPATCH_NCB_NBN(NCBV, NBNV, MACRO)                      \
+    switch ((NCBV) * 10 + (NBNV)) {                              \
+        case 11: MACRO(1, 1) break; case 12: MACRO(1, 2) break;  \
+        case 21: MACRO(2, 1) break; case 22: MACRO(2, 2) break;  \
+        case 31: MACRO(3, 1) break; case 32: MACRO(3, 2) break;  \
+        case 41: MACRO(4, 1) break; case 42: MACRO(4, 2) break;  \
+        default:                                                 \
+            dlwp_set_error("fno: unsupported tile shape");       \
+            return DLWP_E_UNSUPPORTED;                           \
+    }
+
+int dlwp_fno_rows_dft(const dlwp_fno_plan* p, const float* x, int act_in, int adjoint, float2* x1, int B,
+                      hipStream_t stream) {
+    RowsDev a{x, x1, adjoint ? p->FT_adj : p->FT_fwd, act_in, p->C, p->H, p->W, p->m2c, p->C_pad, p->NP};
+    const int LDP = p->W + 4;
+    const size_t lds = sizeof(float) * ((size_t)p->C_pad * LDP + (size_t)p->NP * LDP + (size_t)p->C_pad * p->NP);
+    const dim3 grid(B * p->H), block(256);
+    int rc;
+#define LAUNCH(N, M)                                                                   \
+    if ((rc = set_lds(fno_rows_kernel<N, M>, lds, "fno_rows")) != DLWP_OK) return rc; \
+    hipLaunchKernelGGL((fno_rows_kernel<N, M>), grid, block, lds, stream, a);
+    DISPATCH_NCB_NBN(p->C_pad / 16, p->NP / 16, LAUNCH)
+#undef LAUNCH
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+static int mix_launch(const dlwp_fno_plan* p, bool bwd, MixDev& a, hipStream_t stream) {
+    const size_t lds = sizeof(float2) * (size_t)a.B * a.C * (bwd ? 3 : 2);
+    const dim3 grid(p->m1 * p->m2c), block(256);
+    int rc;
+    if (bwd) {
+        if ((rc = set_lds(fno_mix_bwd_kernel, lds, "fno_mix_bwd")) != DLWP_OK) return rc;
+        hipLaunchKernelGGL(fno_mix_bwd_kernel, grid, block, lds, stream, a);
+    } else {
+        if ((rc = set_lds(fno_mix_fwd_kernel, lds, "fno_mix_fwd")) != DLWP_OK) return rc;
+        hipLaunchKernelGGL(fno_mix_fwd_kernel, grid, block, lds, stream, a);
+    }
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+int dlwp_fno_mix_fwd(const dlwp_fno_plan* p, const float2* x1, const float2* wspec, float2* xhat, float2* y,
+                     int B, hipStream_t stream) {
+    MixDev a{x1, wspec, nullptr, xhat, y, nullptr, p->twH, B, p->C, p->H, p->m1, p->m2c};
+    return mix_launch(p, false, a, stream);
+}
+
+int dlwp_fno_mix_bwd(const dlwp_fno_plan* p, const float2* g1, const float2* wspec, const float2* xhat,
+                     float2* gxhat, float2* g_wspec, int B, hipStream_t stream) {
+    MixDev a{g1, wspec, xhat, nullptr, gxhat, g_wspec, p->twH, B, p->C, p->H, p->m1, p->m2c};
+    return mix_launch(p, true, a, stream);
+}
+
+int dlwp_fno_spatial(const dlwp_fno_plan* p, const dlwp_fno_spatial_args* s, hipStream_t stream) {
+    SpatialDev a{};
+    a.tin = s->tin; a.spec = s->spec; a.wskip = s->wskip; a.bias = s->bias; a.pprev = s->pprev;
+    a.out = s->out; a.x1_out = s->x1_out; a.g_wskip = s->g_wskip; a.g_bias = s->g_bias;
+    a.twH = p->twH;
+    a.G = s->inverse_adjoint ? p->G_adj : p->G_inv;
+    a.FT = s->x1_adjoint ? p->FT_adj : p->FT_fwd;
+    a.act_tin = s->act_tin; a.transpose_w = s->transpose_w; a.act_prev = s->act_prev;
+    a.x1_act = s->x1_act; a.is_bwd = s->inverse_adjoint;
+    a.C = p->C; a.H = p->H; a.W = p->W; a.m1 = p->m1; a.m2c = p->m2c; a.C_pad = p->C_pad; a.NP = p->NP;
+    const int LDP = p->W + 4;
+    const size_t lds = sizeof(float) * ((size_t)3 * p->C_pad * LDP + (size_t)2 * p->NP * LDP +
+                                        (size_t)p->C_pad * (p->C_pad + 4) + (size_t)p->C_pad * (p->NP + 4) +
+                                        (size_t)p->C_pad * p->NP + p->C_pad + (size_t)p->C_pad * p->C_pad);
+    const dim3 grid(s->B * p->H), block(256);
+    int rc;
+#define LAUNCH(N, M)                                                                         \
+    if ((rc = set_lds(fno_spatial_kernel<N, M>, lds, "fno_spatial")) != DLWP_OK) return rc; \
+    hipLaunchKernelGGL((fno_spatial_kernel<N, M>), grid, block, lds, stream, a);
+    DISPATCH_NCB_NBN(p->C_pad / 16, p->NP / 16, LAUNCH)
+#undef LAUNCH
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_fno_block_fwd(const dlwp_fno_plan* p, const float* x, int act_in, const float* wspec,
+                                  const float* wskip, const float* bias, float* pre, float* xhat, int B,
+                                  void* workspace, void* stream_) {
+    DLWP_REQUIRE(p && x && wspec && wskip && pre && xhat && workspace && B > 0, DLWP_E_INVALID,
+                 "fno_block_fwd: NULL argument or B<=0");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    float2* x1 = static_cast<float2*>(workspace);
+    float2* y = reinterpret_cast<float2*>(static_cast<char*>(workspace) + align256(x1_elems(p, B) * sizeof(float2)));
+    int rc;
+    if ((rc = dlwp_fno_rows_dft(p, x, act_in, 0, x1, B, stream))) return rc;
+    if ((rc = dlwp_fno_mix_fwd(p, x1, reinterpret_cast<const float2*>(wspec), reinterpret_cast<float2*>(xhat), y, B, stream))) return rc;
+    dlwp_fno_spatial_args s{};
+    s.tin = x; s.act_tin = act_in; s.spec = y; s.wskip = wskip; s.bias = bias; s.out = pre; s.B = B;
+    return dlwp_fno_spatial(p, &s, stream);
+}
+
+extern "C" int dlwp_fno_block_bwd(const dlwp_fno_plan* p, const float* x, int act_in, const float* wspec,
+                                  const float* wskip, const float* g_pre, const float* xhat, float* g_x,
+                                  float* g_wspec, float* g_wskip, float* g_bias, int B, void* workspace,
+                                  void* stream_) {
+    DLWP_REQUIRE(p && x && wspec && wskip && g_pre && xhat && g_x && g_wspec && workspace && B > 0,
+                 DLWP_E_INVALID, "fno_block_bwd: NULL argument or B<=0");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    float2* g1 = static_cast<float2*>(workspace);
+    float2* gxhat = reinterpret_cast<float2*>(static_cast<char*>(workspace) + align256(x1_elems(p, B) * sizeof(float2)));
+    int rc;
+    if ((rc = dlwp_fno_rows_dft(p, g_pre, 0, 1, g1, B, stream))) return rc;
+    if ((rc = dlwp_fno_mix_bwd(p, g1, reinterpret_cast<const float2*>(wspec), reinterpret_cast<const float2*>(xhat),
+                               gxhat, reinterpret_cast<float2*>(g_wspec), B, stream))) return rc;
+    dlwp_fno_spatial_args s{};
+    s.tin = g_pre; s.spec = gxhat; s.wskip = wskip; s.transpose_w = 1; s.pprev = x; s.act_prev = act_in;
+    s.out = g_x; s.g_wskip = g_wskip; s.g_bias = g_bias; s.inverse_adjoint = 1; s.B = B;
+    return dlwp_fno_spatial(p, &s, stream);
+}

@@ -1,0 +1,193 @@
+// Loss / optimizer pieces of the training step (reference: nn.MSELoss, clip_grad_norm_,
+// torch.optim.Adam at src/nsbench/scripts/train.py:72-74,118-127; dlwpbench train.py:126-139),
+// plus the thread-local error string and the contiguous-tensor wrappers of the C ABI.
+// All of these are HBM-bound streaming kernels: 16 B per lane, grid-stride, <= 2048 blocks.
+#include "common.cuh"
+#include "dlwpmi_internal.h"
+#include <string>
+#include <mutex>
+#include <unordered_map>
+
+static thread_local std::string g_last_error;
+
+void dlwp_set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+int dlwp_ensure_lds(const void* kernel, size_t bytes, const char* what) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, size_t> limit;
+    if (bytes > 160 * 1024) {
+        dlwp_set_error("%s: LDS request %zu exceeds the 160 KiB of a CU", what, bytes);
+        return DLWP_E_UNSUPPORTED;
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = limit.find(kernel);
+    if (it != limit.end() && it->second >= bytes) return DLWP_OK;
+    DLWP_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    limit[kernel] = bytes;
+    return DLWP_OK;
+}
+
+extern "C" const char* dlwp_last_error(void) { return g_last_error.c_str(); }
+extern "C" int dlwp_version(void) { return DLWPMI_VERSION; }
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// block-wide sum -> one atomic per block
+__device__ __forceinline__ void block_atomic_sum(float v, float* out) {
+    __shared__ float part[4];
+    v = wave_sum(v);
+    if (lane_id() == 0) part[wave_id()] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) atomic_add_f32(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void sqerr_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                    long long n, float scale, float* out) {
+    float acc = 0.f;
+    const long long n4 = n / 4;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 x = reinterpret_cast<const float4*>(a)[i];
+        const float4 y = reinterpret_cast<const float4*>(b)[i];
+        const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+        acc += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const float d = a[n4 * 4 + threadIdx.x] - b[n4 * 4 + threadIdx.x];
+        acc += d * d;
+    }
+    block_atomic_sum(acc * scale, out);
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, float* out) {
+    float acc = 0.f;
+    const long long n4 = n / 4;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 x = reinterpret_cast<const float4*>(g)[i];
+        acc += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const float d = g[n4 * 4 + threadIdx.x];
+        acc += d * d;
+    }
+    block_atomic_sum(acc, out);
+}
+
+__global__ __launch_bounds__(256) void clip_scale_kernel(float* g, long long n, const float* sumsq,
+                                                         float grad_scale, float max_norm) {
+    const float total = sqrtf(*sumsq) * fabsf(grad_scale);
+    float coef = max_norm / (total + 1e-6f);
+    coef = coef < 1.f ? coef : 1.f;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] *= coef;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   const int* step_ptr, long long n, float lr, float beta1,
+                                                   float beta2, float eps, float grad_scale, int zero_grad) {
+    const int step = *step_ptr + 1;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = 1.f - powf(beta2, (float)step);
+    const float step_size = lr / bc1;
+    const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i] * grad_scale;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        p[i] -= step_size * (mi / denom);
+        if (zero_grad) g[i] = 0.f;
+    }
+}
+
+__global__ void step_inc_kernel(int* step) { *step += 1; }
+
+int stream_grid(long long n) {
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+}  // namespace
+
+extern "C" int dlwp_sqerr_sum(const float* a, const float* b, long long n, float scale, float* loss_out,
+                              void* stream) {
+    DLWP_REQUIRE(a && b && loss_out && n >= 0, DLWP_E_INVALID, "sqerr_sum: NULL argument");
+    if (n == 0) return DLWP_OK;
+    hipLaunchKernelGGL(sqerr_kernel, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, a, b, n,
+                       scale, loss_out);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_sumsq(const float* g, long long n, float* out, void* stream) {
+    DLWP_REQUIRE(g && out && n >= 0, DLWP_E_INVALID, "sumsq: NULL argument");
+    if (n == 0) return DLWP_OK;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, g, n, out);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_clip_scale(float* g, long long n, const float* sumsq, float grad_scale, float max_norm,
+                               void* stream) {
+    DLWP_REQUIRE(g && sumsq && n >= 0, DLWP_E_INVALID, "clip_scale: NULL argument");
+    if (n == 0) return DLWP_OK;
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, g, n, sumsq,
+                       grad_scale, max_norm);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int* step,
+                              long long n, float lr, float beta1, float beta2, float eps, float grad_scale,
+                              int zero_grad, void* stream) {
+    DLWP_REQUIRE(param && grad && exp_avg && exp_avg_sq && step && n >= 0, DLWP_E_INVALID,
+                 "adam_step: NULL argument");
+    if (n > 0) {
+        hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                           exp_avg, exp_avg_sq, step, n, lr, beta1, beta2, eps, grad_scale, zero_grad);
+        DLWP_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+// ---- contiguous-tensor wrappers of the pointwise MLP
+extern "C" int dlwp_pwmlp_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                              float* y, int B, int Cin, int Ch, int Cout, int P, void* stream) {
+    DLWP_REQUIRE(x && w1 && b1 && w2 && b2 && y, DLWP_E_INVALID, "pwmlp_fwd: NULL argument");
+    dlwp_chan_src xs{x, (long long)Cin * P, P, nullptr, nullptr};
+    dlwp_chan_dst yd{y, (long long)Cout * P, P, nullptr, nullptr};
+    return dlwp_pwmlp_fwd_ex(&xs, w1, b1, w2, b2, &yd, nullptr, B, Cin, Ch, Cout, P, (hipStream_t)stream);
+}
+
+extern "C" int dlwp_pwmlp_bwd(const float* x, const float* w1, const float* b1, const float* w2, const float* gy,
+                              float* gx, float* gw1, float* gb1, float* gw2, float* gb2, int B, int Cin, int Ch,
+                              int Cout, int P, void* stream) {
+    DLWP_REQUIRE(x && w1 && b1 && w2 && gy && gw1 && gb1 && gw2 && gb2, DLWP_E_INVALID, "pwmlp_bwd: NULL argument");
+    dlwp_chan_src xs{x, (long long)Cin * P, P, nullptr, nullptr};
+    dlwp_chan_src gys{gy, (long long)Cout * P, P, nullptr, nullptr};
+    dlwp_chan_dst gxd{gx, (long long)Cin * P, P, nullptr, nullptr};
+    return dlwp_pwmlp_bwd_ex(&xs, w1, b1, w2, &gys, nullptr, nullptr, 0.f, gx ? &gxd : nullptr, 0, gw1, gb1, gw2,
+                             gb2, B, Cin, Ch, Cout, P, (hipStream_t)stream);
+}

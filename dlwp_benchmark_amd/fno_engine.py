@@ -1,0 +1,196 @@
+"""Host side of the FNO rollout path: flat parameter layout, the rollout trainer handle and
+the fused Adam step.  PyTorch provides device memory and streams only; all arithmetic is in
+libdlwpmi (include/dlwpmi.h).
+
+Reference surface mirrored here (file:line under /root/reference/src):
+  nsbench/models/fno/fno.py:193-250   TFNO2DModule (constructor kwargs, rollout forward)
+  nsbench/scripts/train.py:72-74,113-127   Adam / MSELoss / closure
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import lib as L
+
+
+def make_cfg(B, T, D, H, W, context_size, teacher_forcing_steps, hidden, lifting, projection,
+             n_layers, n_modes, out_channels=None, residual=0, aux_channels=0):
+    cfg = L.FnoCfg()
+    cfg.B, cfg.T, cfg.D, cfg.H, cfg.W = B, T, D, H, W
+    cfg.context_size = max(1, context_size)
+    cfg.teacher_forcing_steps = teacher_forcing_steps
+    cfg.hidden, cfg.lifting, cfg.projection, cfg.n_layers = hidden, lifting, projection, n_layers
+    cfg.m1, cfg.m2c = n_modes[0], n_modes[1] // 2 + 1
+    cfg.out_channels = D if out_channels is None else out_channels
+    cfg.residual, cfg.aux_channels = residual, aux_channels
+    return cfg
+
+
+class FnoParamLayout:
+    """Names, shapes and offsets of the tensors inside the flat fp32 parameter buffer.
+
+    State-dict names follow neuralop's FNO (App. A-1, unverified third-party naming); the
+    spectral weights are stored mode-major ([m1][m2c][Cin][Cout][2]) inside the buffer and are
+    converted to/from neuralop's complex [Cin,Cout,m1,m2c] by `to_state_dict`/`from_state_dict`.
+    """
+
+    def __init__(self, in_channels, hidden, lifting, projection, out_channels, n_layers, n_modes):
+        lib = L.load()
+        cfg = make_cfg(1, 1, in_channels, 16, 16, 1, 0, hidden, lifting, projection, n_layers, n_modes,
+                       out_channels=out_channels)
+        self.cfg_widths = cfg
+        self.n_layers, self.hidden = n_layers, hidden
+        self.m1, self.m2c = cfg.m1, cfg.m2c
+        size = C.c_longlong()
+
+        def off(kind, layer=0):
+            o = lib.dlwp_fno_param_offset(C.byref(cfg), kind, layer, C.byref(size))
+            return int(o), int(size.value)
+
+        self.total = off(-1)[0]
+        self.entries = {}  # name -> (offset, numel, storage shape)
+        Cin, Ch, Cp, Co, Cl = in_channels, hidden, projection, out_channels, lifting
+        self.entries["lifting.fcs.0.weight"] = (*off(L.P_LIFT_W1), (Cl, Cin))
+        self.entries["lifting.fcs.0.bias"] = (*off(L.P_LIFT_B1), (Cl,))
+        self.entries["lifting.fcs.1.weight"] = (*off(L.P_LIFT_W2), (Ch, Cl))
+        self.entries["lifting.fcs.1.bias"] = (*off(L.P_LIFT_B2), (Ch,))
+        self.entries["projection.fcs.0.weight"] = (*off(L.P_PROJ_W1), (Cp, Ch))
+        self.entries["projection.fcs.0.bias"] = (*off(L.P_PROJ_B1), (Cp,))
+        self.entries["projection.fcs.1.weight"] = (*off(L.P_PROJ_W2), (Co, Cp))
+        self.entries["projection.fcs.1.bias"] = (*off(L.P_PROJ_B2), (Co,))
+        for l in range(n_layers):
+            self.entries[f"fno_blocks.convs.weight.{l}"] = (*off(L.P_SPEC_W, l), (self.m1, self.m2c, Ch, Ch, 2))
+            self.entries[f"fno_blocks.fno_skips.{l}.weight"] = (*off(L.P_SKIP_W, l), (Ch, Ch))
+            self.entries[f"fno_blocks.convs.bias.{l}"] = (*off(L.P_SPEC_B, l), (Ch,))
+
+    def view(self, flat, name):
+        o, n, shape = self.entries[name]
+        return flat[o:o + n].view(shape)
+
+    def n_params(self):
+        return sum(n for (_, n, _) in self.entries.values())
+
+    # ---- neuralop-style state dict <-> flat buffer
+    def to_state_dict(self, flat, prefix=""):
+        sd = {}
+        for name in self.entries:
+            v = self.view(flat, name).detach()
+            if ".convs.weight." in name:
+                l = name.rsplit(".", 1)[1]
+                sd[f"{prefix}fno_blocks.convs.weight.{l}.tensor"] = torch.view_as_complex(
+                    v.contiguous()).permute(2, 3, 0, 1).contiguous()
+            elif ".convs.bias." in name:
+                continue
+            elif name.endswith("weight"):
+                sd[prefix + name] = v.reshape(*v.shape, 1, 1).clone()
+            else:
+                sd[prefix + name] = v.clone()
+        sd[f"{prefix}fno_blocks.convs.bias"] = torch.stack(
+            [self.view(flat, f"fno_blocks.convs.bias.{l}").detach() for l in range(self.n_layers)]
+        ).reshape(self.n_layers, self.hidden, 1, 1).clone()
+        return sd
+
+    def from_state_dict(self, flat, sd, prefix=""):
+        with torch.no_grad():
+            for name in self.entries:
+                dst = self.view(flat, name)
+                if ".convs.weight." in name:
+                    l = name.rsplit(".", 1)[1]
+                    w = sd[f"{prefix}fno_blocks.convs.weight.{l}.tensor"]
+                    dst.copy_(torch.view_as_real(w.permute(2, 3, 0, 1).contiguous()))
+                elif ".convs.bias." in name:
+                    l = int(name.rsplit(".", 1)[1])
+                    dst.copy_(sd[f"{prefix}fno_blocks.convs.bias"][l].reshape(-1))
+                else:
+                    dst.copy_(sd[prefix + name].reshape(dst.shape))
+
+    def init_(self, flat, generator=None):
+        """neuralop-like initialisation (App. A-1): Conv default init for the 1x1 convs,
+        N(0, 2/(Cin+Cout)) scaled spectral weights and biases."""
+        with torch.no_grad():
+            flat.zero_()
+            for name, (o, n, shape) in self.entries.items():
+                dst = self.view(flat, name)
+                if ".convs.weight." in name or ".convs.bias." in name:
+                    std = (2.0 / (2 * self.hidden)) ** 0.5
+                    dst.copy_(torch.randn(shape, generator=generator) * std)
+                elif name.endswith("weight"):
+                    bound = 1.0 / math.sqrt(shape[1])
+                    dst.copy_((torch.rand(shape, generator=generator) * 2 - 1) * bound)
+                else:
+                    fan_in = self.entries[name.replace("bias", "weight")][2][1]
+                    bound = 1.0 / math.sqrt(fan_in)
+                    dst.copy_((torch.rand(shape, generator=generator) * 2 - 1) * bound)
+
+
+class FnoRolloutTrainer:
+    """Owns a dlwp_fno_trainer handle plus the torch tensors it borrows."""
+
+    def __init__(self, cfg, params, grads, device):
+        self.lib = L.load()
+        self.cfg = cfg
+        self.device = device
+        h = C.c_void_p()
+        L.check(self.lib.dlwp_fno_trainer_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        shape = (cfg.B, cfg.T, cfg.D, cfg.H, cfg.W)
+        self.x = torch.zeros(shape, device=device)
+        self.y = torch.zeros(shape, device=device)
+        self.out = torch.zeros(shape, device=device)
+        self.loss = torch.zeros(1, device=device)
+        L.check(self.lib.dlwp_fno_trainer_bind_io(self.h, L.ptr(self.x), L.ptr(self.y), L.ptr(self.out),
+                                                  L.ptr(self.loss)))
+        self.bind(params, grads)
+
+    def bind(self, params, grads):
+        self.params, self.grads = params, grads
+        L.check(self.lib.dlwp_fno_trainer_bind(self.h, L.ptr(params), L.ptr(grads)))
+
+    def forward(self, keep_activations=False):
+        L.check(self.lib.dlwp_fno_trainer_forward(self.h, int(keep_activations), L.stream()))
+        return self.out
+
+    def backward(self, grad_out=None):
+        L.check(self.lib.dlwp_fno_trainer_backward(self.h, L.ptr(grad_out), L.stream()))
+
+    def fwd_bwd(self, use_graph=True):
+        L.check(self.lib.dlwp_fno_trainer_fwd_bwd(self.h, int(use_graph), L.stream()))
+        return self.loss
+
+    def close(self):
+        if self.h:
+            self.lib.dlwp_fno_trainer_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FusedAdam:
+    """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) on the flat buffer (train.py:72)."""
+
+    def __init__(self, params, grads, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.lib = L.load()
+        self.params, self.grads = params, grads
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.exp_avg = torch.zeros_like(params)
+        self.exp_avg_sq = torch.zeros_like(params)
+        self.step_count = torch.zeros(1, dtype=torch.int32, device=params.device)
+        self.sumsq = torch.zeros(1, device=params.device)
+
+    def clip_grad_norm_(self, max_norm, grad_scale=1.0):
+        """torch.nn.utils.clip_grad_norm_ on the flat gradient (train.py:123-125)."""
+        self.sumsq.zero_()
+        n = self.grads.numel()
+        L.check(self.lib.dlwp_sumsq(L.ptr(self.grads), n, L.ptr(self.sumsq), L.stream()))
+        L.check(self.lib.dlwp_clip_scale(L.ptr(self.grads), n, L.ptr(self.sumsq), grad_scale, max_norm, L.stream()))
+
+    def step(self, grad_scale=1.0, zero_grad=True):
+        L.check(self.lib.dlwp_adam_step(L.ptr(self.params), L.ptr(self.grads), L.ptr(self.exp_avg),
+                                        L.ptr(self.exp_avg_sq), L.ptr(self.step_count), self.params.numel(),
+                                        self.lr, self.betas[0], self.betas[1], self.eps, grad_scale,
+                                        int(zero_grad), L.stream()))

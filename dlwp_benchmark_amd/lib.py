@@ -1,0 +1,100 @@
+"""ctypes binding of libdlwpmi.so (include/dlwpmi.h).
+
+The library is the product; there is no CPU or PyTorch fallback.  Importing this module
+without the built library, or calling into it without a GPU, raises immediately.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdlwpmi.so")
+
+c_float_p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
+
+
+class ChanSrc(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("bstride", C.c_longlong), ("cstride", C.c_longlong),
+                ("tab", C.c_void_p), ("tab_bstride", C.c_void_p)]
+
+
+class FnoCfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "B", "T", "D", "H", "W", "context_size", "teacher_forcing_steps", "hidden", "lifting",
+        "projection", "n_layers", "m1", "m2c", "out_channels", "residual", "aux_channels")]
+
+
+# parameter kinds of the flat FNO parameter buffer (dlwpmi.h enum)
+P_LIFT_W1, P_LIFT_B1, P_LIFT_W2, P_LIFT_B2, P_PROJ_W1, P_PROJ_B1, P_PROJ_W2, P_PROJ_B2, \
+    P_SPEC_W, P_SKIP_W, P_SPEC_B = range(11)
+
+# every symbol include/dlwpmi.h declares: name -> (restype, argtypes)
+_V, _I, _L, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+SIGNATURES = {
+    "dlwp_version": (_I, []),
+    "dlwp_last_error": (C.c_char_p, []),
+    "dlwp_pwmlp_fwd": (_I, [_V] * 6 + [_I] * 5 + [_V]),
+    "dlwp_pwmlp_bwd": (_I, [_V] * 10 + [_I] * 5 + [_V]),
+    "dlwp_fno_plan_create": (_I, [_I] * 5 + [C.POINTER(_V)]),
+    "dlwp_fno_plan_destroy": (None, [_V]),
+    "dlwp_fno_block_workspace_bytes": (C.c_size_t, [_V, _I]),
+    "dlwp_fno_block_fwd": (_I, [_V, _V, _I, _V, _V, _V, _V, _V, _I, _V, _V]),
+    "dlwp_fno_block_bwd": (_I, [_V, _V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _I, _V, _V]),
+    "dlwp_sqerr_sum": (_I, [_V, _V, _L, _F, _V, _V]),
+    "dlwp_adam_step": (_I, [_V, _V, _V, _V, _V, _L, _F, _F, _F, _F, _F, _I, _V]),
+    "dlwp_sumsq": (_I, [_V, _L, _V, _V]),
+    "dlwp_clip_scale": (_I, [_V, _L, _V, _F, _F, _V]),
+    "dlwp_fno_param_offset": (_L, [C.POINTER(FnoCfg), _I, _I, C.POINTER(_L)]),
+    "dlwp_fno_trainer_create": (_I, [C.POINTER(FnoCfg), C.POINTER(_V)]),
+    "dlwp_fno_trainer_destroy": (None, [_V]),
+    "dlwp_fno_trainer_bind_io": (_I, [_V, _V, _V, _V, _V]),
+    "dlwp_fno_trainer_bind": (_I, [_V, _V, _V]),
+    "dlwp_fno_trainer_forward": (_I, [_V, _I, _V]),
+    "dlwp_fno_trainer_backward": (_I, [_V, _V, _V]),
+    "dlwp_fno_trainer_fwd_bwd": (_I, [_V, _I, _V]),
+}
+
+_lib = None
+
+
+class DlwpError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DlwpError(
+            f"{LIB_PATH} is missing: build it with `make` (or __graft_entry__.build()). "
+            "There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().dlwp_last_error()
+        raise DlwpError(f"libdlwpmi error {rc}: {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise DlwpError("libdlwpmi needs CUDA/HIP tensors (no CPU fallback)")
+    if not t.is_contiguous():
+        raise DlwpError("libdlwpmi needs contiguous tensors")
+    return t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

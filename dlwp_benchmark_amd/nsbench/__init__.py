@@ -1,0 +1,4 @@
+"""Mirror of src/nsbench/models/__init__.py for the hot-path models."""
+from .fno import FNOModule, TFNO2DModule  # noqa: F401
+
+__all__ = ["FNOModule", "TFNO2DModule"]

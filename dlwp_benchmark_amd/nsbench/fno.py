@@ -1,0 +1,144 @@
+"""Drop-in counterparts of the reference's Navier-Stokes FNO rollout modules.
+
+Reference (file:line under /root/reference/src):
+  nsbench/models/fno/fno.py:10-41     FNOModule     (single-frame input, no context)
+  nsbench/models/fno/fno.py:193-250   TFNO2DModule  (context frames flattened into channels;
+                                      instantiates the dense neuralop FNO, :205)
+Same constructor kwargs (extra kwargs such as `type`/`name` are swallowed), same
+`forward(x[B,T,D,H,W], teacher_forcing_steps) -> [B,T,D,H,W]`, state_dict keys under `fno.`.
+
+The rollout, its BPTT backward and the fused train step run entirely in libdlwpmi
+(dlwp_fno_trainer_*); there is no PyTorch implementation of the arithmetic in this package.
+"""
+import torch
+import torch.nn as nn
+
+from ..fno_engine import FnoParamLayout, FnoRolloutTrainer, FusedAdam, make_cfg
+
+
+class _RolloutFn(torch.autograd.Function):
+    """autograd bridge: forward = trainer rollout (activations kept), backward = BPTT kernels."""
+
+    @staticmethod
+    def forward(ctx, flat, module, trainer):
+        ctx.module, ctx.trainer = module, trainer
+        trainer.forward(keep_activations=True)
+        return trainer.out.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        module, trainer = ctx.module, ctx.trainer
+        gbuf = torch.zeros_like(module.flat_params)
+        trainer.bind(module.flat_params.data, gbuf)
+        trainer.backward(grad_out.contiguous())
+        trainer.bind(module.flat_params.data, module.flat_grad)
+        return gbuf, None, None
+
+
+class _FnoRolloutModule(nn.Module):
+    def __init__(self, n_modes, in_channels, hidden_channels, lifting_channels, projection_channels,
+                 out_channels, n_layers, context_size):
+        super().__init__()
+        if len(n_modes) != 2:
+            raise ValueError("only 2-D FNOs are on the MI355X hot path (n_modes must have 2 entries)")
+        self.n_modes = [int(m) for m in n_modes]
+        self.in_channels, self.out_channels = int(in_channels), int(out_channels)
+        self.hidden_channels, self.n_layers = int(hidden_channels), int(n_layers)
+        self.lifting_channels, self.projection_channels = int(lifting_channels), int(projection_channels)
+        self.context_size = int(context_size)
+        self.layout = FnoParamLayout(self.in_channels * max(1, self.context_size), self.hidden_channels,
+                                     self.lifting_channels, self.projection_channels, self.out_channels,
+                                     self.n_layers, self.n_modes)
+        flat = torch.empty(self.layout.total)
+        self.layout.init_(flat)
+        self.flat_params = nn.Parameter(flat)
+        self.flat_grad = None
+        self._trainers = {}
+
+    # ---- reference-compatible checkpoints (keys `fno.*`)
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        sd = self.layout.to_state_dict(self.flat_params.data, prefix=prefix + "fno.")
+        if destination is not None:
+            destination.update(sd)
+            return destination
+        return sd
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        self.layout.from_state_dict(self.flat_params.data, state_dict, prefix="fno.")
+        return torch.nn.modules.module._IncompatibleKeys([], [])
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        for tr in self._trainers.values():
+            tr.close()
+        self._trainers = {}
+        self.flat_grad = None
+        return out
+
+    def _ensure_grad(self):
+        if self.flat_grad is None or self.flat_grad.device != self.flat_params.device:
+            self.flat_grad = torch.zeros_like(self.flat_params.data)
+        self.flat_params.grad = self.flat_grad
+        return self.flat_grad
+
+    def trainer(self, B, T, H, W, teacher_forcing_steps):
+        key = (B, T, H, W, int(teacher_forcing_steps))
+        tr = self._trainers.get(key)
+        if tr is None:
+            cfg = make_cfg(B, T, self.in_channels, H, W, self.context_size, int(teacher_forcing_steps),
+                           self.hidden_channels, self.lifting_channels, self.projection_channels,
+                           self.n_layers, self.n_modes, out_channels=self.out_channels)
+            tr = FnoRolloutTrainer(cfg, self.flat_params.data, self._ensure_grad(), self.flat_params.device)
+            self._trainers[key] = tr
+        return tr
+
+    def forward(self, x: torch.Tensor, teacher_forcing_steps: int = 10) -> torch.Tensor:
+        B, T, D, H, W = x.shape
+        tf = min(int(teacher_forcing_steps), T)
+        tr = self.trainer(B, T, H, W, tf)
+        tr.x.copy_(x)
+        if torch.is_grad_enabled() and self.flat_params.requires_grad:
+            return _RolloutFn.apply(self.flat_params, self, tr)
+        tr.forward(keep_activations=False)
+        return tr.out.clone()
+
+    # ---- fused training step (forward + MSE + BPTT captured in one hipGraph, then Adam)
+    def make_optimizer(self, lr=1e-3):
+        return FusedAdam(self.flat_params.data, self._ensure_grad(), lr=lr)
+
+    def train_step(self, x, y, teacher_forcing_steps, optimizer=None, use_graph=True, clip_max_norm=None,
+                   grad_scale=1.0, allreduce=None):
+        """nsbench/scripts/train.py:117-127 on device. Returns the (device) MSE loss tensor."""
+        B, T, D, H, W = x.shape
+        tr = self.trainer(B, T, H, W, min(int(teacher_forcing_steps), T))
+        tr.x.copy_(x)
+        tr.y.copy_(y)
+        loss = tr.fwd_bwd(use_graph=use_graph)
+        if allreduce is not None:
+            allreduce(self.flat_grad)
+        if optimizer is not None:
+            if clip_max_norm is not None:
+                optimizer.clip_grad_norm_(clip_max_norm, grad_scale=grad_scale)
+            optimizer.step(grad_scale=grad_scale)
+        return loss
+
+
+class TFNO2DModule(_FnoRolloutModule):
+    """nsbench/models/fno/fno.py:193-250 (dense FNO inside despite the name)."""
+
+    def __init__(self, n_modes, in_channels, hidden_channels, lifting_channels, projection_channels, out_channels,
+                 n_layers, max_n_modes=None, rank=1.0, bias=True, context_size=10, **kwargs):
+        super().__init__(n_modes, in_channels, hidden_channels, lifting_channels, projection_channels,
+                         out_channels, n_layers, context_size)
+
+
+class FNOModule(_FnoRolloutModule):
+    """nsbench/models/fno/fno.py:10-41: one frame in, one frame out (context_size 1 rollout)."""
+
+    def __init__(self, n_modes, in_channels, hidden_channels, lifting_channels, projection_channels, out_channels,
+                 n_layers, bias=True, **kwargs):
+        super().__init__(n_modes, in_channels, hidden_channels, lifting_channels, projection_channels,
+                         out_channels, n_layers, 1)
+
+    def forward(self, x: torch.Tensor, teacher_forcing_steps: int = 50) -> torch.Tensor:
+        return super().forward(x, teacher_forcing_steps)

@@ -1,0 +1,169 @@
+/* libdlwpmi — MI355X (gfx950) native kernels for the dlwp-benchmark autoregressive rollout
+ * training path.  C ABI: plain pointers and sizes, no torch types.
+ *
+ * The reference (amazon-science/dlwp-benchmark) has no FFI of its own: its boundary is the
+ * Python nn.Module surface.  Each entry point below therefore names the
+ * reference call it replaces (file:line under /root/reference/src); the Python host side
+ * in dlwp_benchmark_amd/ binds them with ctypes and re-exposes the reference's module
+ * constructors / forward signatures.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer borrowed from the caller (never freed or retained
+ *     beyond the call, except buffers explicitly bound to a trainer);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued there, no hidden
+ *     synchronisation (graph-capture safe) unless a function says otherwise;
+ *   - return 0 on success, negative DLWP_E_* on failure; dlwp_last_error() gives the
+ *     thread-local message;
+ *   - all arithmetic is IEEE fp32 (exact-f32 MFMA), matching the reference's fp32 path.
+ */
+#ifndef DLWPMI_H
+#define DLWPMI_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DLWPMI_VERSION 100
+
+#define DLWP_OK 0
+#define DLWP_E_INVALID (-1)
+#define DLWP_E_HIP (-2)
+#define DLWP_E_UNSUPPORTED (-3)
+#define DLWP_E_NOMEM (-4)
+
+int dlwp_version(void);
+const char* dlwp_last_error(void);
+
+/* ------------------------------------------------------------------------------------ */
+/* Strided / gathered channel views.  A rollout step reads its input channels straight   */
+/* out of the trajectory buffers (observations or earlier predictions) instead of        */
+/* re-stacking them (reference: th.stack/th.cat per step, nsbench/models/fno/fno.py:     */
+/* 228-237).  Either (base,bstride,cstride) or a per-channel pointer table is used.      */
+typedef struct dlwp_chan_src {
+    const float* base;
+    long long bstride, cstride;        /* elements */
+    const float* const* tab;           /* device array [C] of sample-0 plane pointers    */
+    const long long* tab_bstride;      /* device array [C] of batch strides (elements)   */
+} dlwp_chan_src;
+typedef struct dlwp_chan_dst {
+    float* base;
+    long long bstride, cstride;
+    float* const* tab;                 /* entries may be NULL: channel skipped           */
+    const long long* tab_bstride;
+} dlwp_chan_dst;
+
+/* ------------------------------------------------------------------------------------ */
+/* Pointwise 2-layer channel MLP: y = W2 gelu(W1 x + b1) + b2 on [B,C,P] fields.         */
+/* Replaces neuralop FNO.lifting / FNO.projection (constructed at nsbench/models/fno/    */
+/* fno.py:19-27,205-215; dlwpbench/models/fno/fno.py:38-47).  w1:[Ch,Cin] b1:[Ch]        */
+/* w2:[Cout,Ch] b2:[Cout] (Conv2d 1x1 weight layout).                                    */
+int dlwp_pwmlp_fwd(const float* x, const float* w1, const float* b1, const float* w2,
+                   const float* b2, float* y, int B, int Cin, int Ch, int Cout, int P,
+                   void* stream);
+/* gx may be NULL. gw1,gb1,gw2,gb2 are ACCUMULATED into (caller zeroes them).            */
+int dlwp_pwmlp_bwd(const float* x, const float* w1, const float* b1, const float* w2,
+                   const float* gy, float* gx, float* gw1, float* gb1, float* gw2, float* gb2,
+                   int B, int Cin, int Ch, int Cout, int P, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* FNO block: pre = irfft2(W . trunc(rfft2(act(x)))) + Wskip act(x) + bias               */
+/* (neuralop FNOBlocks: SpectralConv + linear skip; call sites        */
+/* `self.fno(x_t)` nsbench/models/fno/fno.py:38,96,246, dlwpbench/models/fno/fno.py:103). */
+/* The mode-truncated transform is a pruned DFT (two small GEMMs per axis) fused with     */
+/* the skip GEMM; no full spectrum is ever formed.                                        */
+/*   x, pre : [B,C,H,W];  act_in!=0 applies GELU to x on load (x is then the previous     */
+/*            block's pre-activation);                                                    */
+/*   wspec  : [m1][m2c][Cin][Cout][2] (mode-major complex; m2c = n_modes[1]/2+1);         */
+/*   wskip  : [Cout][Cin]; bias : [C];                                                    */
+/*   xhat   : [B][m1][m2c][C][2] truncated spectrum of act(x), saved for backward.        */
+typedef struct dlwp_fno_plan dlwp_fno_plan;
+int dlwp_fno_plan_create(int C, int H, int W, int m1, int m2c, dlwp_fno_plan** out);
+void dlwp_fno_plan_destroy(dlwp_fno_plan* plan);
+/* bytes of scratch the block calls need for batch B (caller allocates, 256-B aligned)   */
+size_t dlwp_fno_block_workspace_bytes(const dlwp_fno_plan* plan, int B);
+int dlwp_fno_block_fwd(const dlwp_fno_plan* plan, const float* x, int act_in, const float* wspec,
+                       const float* wskip, const float* bias, float* pre, float* xhat, int B,
+                       void* workspace, void* stream);
+/* g_x = d loss / d x (includes the GELU derivative when act_in). g_wspec/g_wskip/g_bias */
+/* are ACCUMULATED into.                                                                  */
+int dlwp_fno_block_bwd(const dlwp_fno_plan* plan, const float* x, int act_in, const float* wspec,
+                       const float* wskip, const float* g_pre, const float* xhat, float* g_x,
+                       float* g_wspec, float* g_wskip, float* g_bias, int B, void* workspace,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Training-step pieces (nsbench/scripts/train.py:113-131: MSELoss, Adam).               */
+/* loss_out (device, 1 float) += sum((a-b)^2) * scale                                    */
+int dlwp_sqerr_sum(const float* a, const float* b, long long n, float scale, float* loss_out,
+                   void* stream);
+/* torch.optim.Adam (no weight decay / amsgrad) on a flat buffer; `step` is a device      */
+/* int32 counter incremented by the kernel; grads are multiplied by grad_scale first      */
+/* (1/world_size after a sum all-reduce) and zeroed afterwards when zero_grad != 0.       */
+int dlwp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int* step,
+                   long long n, float lr, float beta1, float beta2, float eps, float grad_scale,
+                   int zero_grad, void* stream);
+/* out (device float) = sum(g^2)   (for clip_grad_norm_, train.py:123-125)                */
+int dlwp_sumsq(const float* g, long long n, float* out, void* stream);
+/* g *= min(1, max_norm / (sqrt(*sumsq * grad_scale^2) + 1e-6))  (torch clip_grad_norm_)  */
+int dlwp_clip_scale(float* g, long long n, const float* sumsq, float grad_scale, float max_norm,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Fused FNO rollout trainer: the whole autoregressive rollout forward, MSE, and BPTT     */
+/* backward of nsbench TFNO2DModule / FNOModule (fno.py:29-41,217-250) and of the         */
+/* residual dlwpbench form (dlwpbench/models/fno/fno.py:64-106), captured into one        */
+/* hipGraph.  Parameters/gradients live in ONE flat fp32 buffer owned by the caller       */
+/* (layout: dlwp_fno_param_offset); the gradient buffer is what data-parallel ranks        */
+/* all-reduce (one flat RCCL bucket).                                                     */
+typedef struct dlwp_fno_cfg {
+    int B, T, D;            /* batch, sequence length, channels per frame (ns: D=1)       */
+    int H, W;
+    int context_size;       /* ctx frames flattened into channels (TFNO2DModule); 0/1:    */
+                            /* FNOModule single-frame form                                 */
+    int teacher_forcing_steps;
+    int hidden, lifting, projection, n_layers;
+    int m1, m2c;            /* kept modes: n_modes[0] rows, n_modes[1]/2+1 columns        */
+    int out_channels;       /* = D for ns                                                  */
+    int residual;           /* 1: out = last_frame + net(x) (dlwp form); 0: ns FNO form   */
+    int aux_channels;       /* extra per-step input channels (dlwp constants+prescribed)  */
+} dlwp_fno_cfg;
+
+enum {
+    DLWP_FNO_P_LIFT_W1 = 0, DLWP_FNO_P_LIFT_B1, DLWP_FNO_P_LIFT_W2, DLWP_FNO_P_LIFT_B2,
+    DLWP_FNO_P_PROJ_W1, DLWP_FNO_P_PROJ_B1, DLWP_FNO_P_PROJ_W2, DLWP_FNO_P_PROJ_B2,
+    DLWP_FNO_P_SPEC_W,   /* + layer: [m1][m2c][C][C][2]  */
+    DLWP_FNO_P_SKIP_W,   /* + layer: [C][C]              */
+    DLWP_FNO_P_SPEC_B    /* + layer: [C]                 */
+};
+/* element offset and size of a parameter tensor inside the flat buffer; total = offset   */
+/* returned for kind = -1.                                                                */
+long long dlwp_fno_param_offset(const dlwp_fno_cfg* cfg, int kind, int layer, long long* size);
+
+typedef struct dlwp_fno_trainer dlwp_fno_trainer;
+int dlwp_fno_trainer_create(const dlwp_fno_cfg* cfg, dlwp_fno_trainer** out);
+void dlwp_fno_trainer_destroy(dlwp_fno_trainer* tr);
+/* bind the caller's trajectory buffers (borrowed): x [B,T,D,H,W] observations, y targets  */
+/* (may be NULL when only forward / backward(grad_out) are used), out predictions, loss     */
+/* (1 device float: mean squared error, may be NULL likewise).  Synchronous (uploads the    */
+/* channel gather tables); invalidates a captured graph.                                    */
+int dlwp_fno_trainer_bind_io(dlwp_fno_trainer* tr, const float* x, const float* y, float* out,
+                             float* loss);
+/* bind the caller's flat parameter / gradient buffers (borrowed until destroy/rebind)    */
+int dlwp_fno_trainer_bind(dlwp_fno_trainer* tr, float* params, float* grads);
+/* rollout forward into the `out` buffer; keep_activations!=0 stores every net call's      */
+/* activations for a following dlwp_fno_trainer_backward (0: evaluation)                   */
+int dlwp_fno_trainer_forward(dlwp_fno_trainer* tr, int keep_activations, void* stream);
+/* BPTT backward of the last kept forward.  grad_out = d loss / d out [B,T,D,H,W], or NULL */
+/* for the fused nn.MSELoss(mean) against the `y` buffer (loss value -> `loss` buffer).    */
+/* Parameter gradients are ACCUMULATED into the bound gradient buffer.                     */
+int dlwp_fno_trainer_backward(dlwp_fno_trainer* tr, const float* grad_out, void* stream);
+/* forward(keep) + backward(NULL) in one call.                                             */
+/* use_graph!=0 captures the sequence into a hipGraph on first use and replays it.        */
+int dlwp_fno_trainer_fwd_bwd(dlwp_fno_trainer* tr, int use_graph, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DLWPMI_H */
