@@ -37,6 +37,8 @@ struct dlwp_fno_trainer {
     // graph
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    hipStream_t cap_stream = nullptr;  // capture happens on a private stream (the caller's may be the
+                                       // legacy default stream, which cannot be captured)
 };
 
 namespace {
@@ -307,6 +309,7 @@ extern "C" void dlwp_fno_trainer_destroy(dlwp_fno_trainer* tr) {
     if (!tr) return;
     if (tr->graph_exec) (void)hipGraphExecDestroy(tr->graph_exec);
     if (tr->graph) (void)hipGraphDestroy(tr->graph);
+    if (tr->cap_stream) (void)hipStreamDestroy(tr->cap_stream);
     dlwp_fno_plan_destroy(tr->plan);
     void* bufs[] = {tr->g_out, tr->h0, tr->pre, tr->xhat, tr->x1, tr->spec,
                     tr->gA, tr->gB, (void*)tr->src_tab, (void*)tr->gdst_tab, tr->bstride_tab};
@@ -351,11 +354,12 @@ extern "C" int dlwp_fno_trainer_fwd_bwd(dlwp_fno_trainer* tr, int use_graph, voi
         return enqueue_loss_backward(tr, nullptr, s);
     }
     if (!tr->graph_exec) {
-        DLWP_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        rc = enqueue_forward(tr, true, s);
-        if (!rc) rc = enqueue_loss_backward(tr, nullptr, s);
+        if (!tr->cap_stream) DLWP_HIP(hipStreamCreateWithFlags(&tr->cap_stream, hipStreamNonBlocking));
+        DLWP_HIP(hipStreamBeginCapture(tr->cap_stream, hipStreamCaptureModeThreadLocal));
+        rc = enqueue_forward(tr, true, tr->cap_stream);
+        if (!rc) rc = enqueue_loss_backward(tr, nullptr, tr->cap_stream);
         hipGraph_t graph = nullptr;
-        hipError_t e = hipStreamEndCapture(s, &graph);
+        hipError_t e = hipStreamEndCapture(tr->cap_stream, &graph);
         if (rc) {
             if (graph) (void)hipGraphDestroy(graph);
             return rc;

@@ -19,7 +19,10 @@ GRAD_TOL = 5e-4
 
 
 def rel_err(got, ref):
-    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    got, ref = got.detach().cpu(), ref.detach().cpu()
+    if got.is_complex() or ref.is_complex():
+        got, ref = torch.view_as_real(got.to(torch.complex128)), torch.view_as_real(ref.to(torch.complex128))
+    got, ref = got.double(), ref.double()
     return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
 
 
@@ -68,7 +71,7 @@ def test_pwmlp_fwd_bwd(L, cuda, B, Cin, Ch, Cout, P):
     (4, 32, 64, 64, (12, 12), 0),
     (4, 32, 64, 64, (12, 12), 1),
     (2, 20, 32, 64, (8, 9), 1),      # ragged channels, odd mode counts, non-square grid
-    (1, 8, 16, 32, (16, 32), 0),     # all rows kept and the Nyquist column included
+    (1, 8, 16, 16, (16, 16), 0),     # all rows kept and the Nyquist column included
     (2, 32, 128, 256, (12, 12), 1),  # C4-sized grid
 ])
 def test_fno_block_fwd_bwd(L, cuda, B, Cc, H, W, n_modes, act_in):
