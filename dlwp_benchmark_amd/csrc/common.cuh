@@ -64,14 +64,146 @@ __device__ __forceinline__ f32x4 mfma16_chunk(const f32x4 a, const f32x4 b, f32x
     return c;
 }
 
+// Exact (erf) GELU and its derivative, evaluated together in ~17 VALU instructions.
+// erfc via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, fp32 rounding level) with one v_rcp_f32
+// and one v_exp_f32: libm erff costs ~100 issue slots per element and made the MLP kernels
+// VALU-bound (profiles/ r01 notes).  Phi(z) = 0.5 + copysign(0.5 - q, z), q = 0.5*erfc(|z|/sqrt2)
+// (no cancellation in the negative tail).
+__device__ __forceinline__ void gelu_both(float z, float& act, float& dact) {
+    const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(z), 0.3275911f * 0.70710678118654752440f, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(z * z * (-0.5f * 1.44269504088896340736f));  // exp(-z^2/2)
+    // 0.5 * (a1 t + a2 t^2 + a3 t^3 + a4 t^4 + a5 t^5)
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f),
+                                                0.5f * 1.421413741f), 0.5f * -0.284496736f), 0.5f * 0.254829592f);
+    const float q = poly * e;
+    const float cdf = 0.5f + copysignf(0.5f - q, z);
+    act = z * cdf;
+    dact = fmaf(z * e, 0.39894228040143267794f, cdf);
+}
 __device__ __forceinline__ float gelu_f(float z) {
-    return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f));
+    float a, d;
+    gelu_both(z, a, d);
+    return a;
 }
 __device__ __forceinline__ float gelu_grad_f(float z) {
-    const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * __expf(-0.5f * z * z);
-    return cdf + z * pdf;
+    float a, d;
+    gelu_both(z, a, d);
+    return d;
 }
 
 // hardware float atomic add (no CAS loop)
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+// ---- staging helpers: batched (unrolled) 16-byte global loads -> LDS images with row padding
+// exact e / d for e*d < 2^32 (all index spaces here are < 2^21): q = umulhi(e, ceil(2^32 / d))
+struct FastDiv {
+    unsigned mul, d;
+};
+static inline FastDiv make_fastdiv(int d) {
+    FastDiv f;
+    f.d = (unsigned)d;
+    f.mul = d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d);
+    return f;
+}
+__device__ __forceinline__ int fastdiv(int e, FastDiv f) { return f.d <= 1 ? e : (int)__umulhi((unsigned)e, f.mul); }
+
+// dst[r*ld + c] = src[r*cols + c]  (TR: dst[c*ld + r]); src is a dense row-major [rows][cols] matrix.
+template <bool TR>
+__device__ __forceinline__ void stage_matrix(float* dst, int ld, const float* __restrict__ src, int rows, int cols,
+                                             FastDiv dcols, bool vec_ok) {
+    const int n = rows * cols;
+    const int n4 = vec_ok ? (n >> 2) : 0;
+#pragma unroll 4
+    for (int u = threadIdx.x; u < n4; u += blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(src)[u];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = 4 * u + k;
+            const int rr = fastdiv(e, dcols);
+            const int cc = e - rr * cols;
+            dst[TR ? cc * ld + rr : rr * ld + cc] = vv[k];
+        }
+    }
+#pragma unroll 4
+    for (int e = 4 * n4 + threadIdx.x; e < n; e += blockDim.x) {
+        const int rr = fastdiv(e, dcols);
+        const int cc = e - rr * cols;
+        dst[TR ? cc * ld + rr : rr * ld + cc] = src[e];
+    }
+}
+
+// Split staging: issue() puts up to MAXU 16-byte loads per thread in flight (no LDS traffic yet);
+// commit() scatters them into the padded LDS image.  Kernels issue ALL their independent inputs
+// first and commit afterwards, so a workgroup pays one global-memory latency instead of one per
+// input (in-kernel stamps: the serial staging phases were 40-60% of these short kernels).
+template <int MAXU>
+struct MatLoad {
+    float4 v[MAXU];
+    __device__ __forceinline__ void issue(const float* __restrict__ src, int n4, int base = 0) {
+#pragma unroll
+        for (int k = 0; k < MAXU; ++k) {
+            const int u = base + threadIdx.x + k * blockDim.x;
+            v[k] = u < n4 ? reinterpret_cast<const float4*>(src)[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    template <bool TR>
+    __device__ __forceinline__ void commit(float* dst, int ld, int cols, FastDiv dcols, int n4, int base = 0) const {
+#pragma unroll
+        for (int k = 0; k < MAXU; ++k) {
+            const int u = base + threadIdx.x + k * blockDim.x;
+            if (u < n4) {
+                const float vv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = 4 * u + q;
+                    const int rr = fastdiv(e, dcols);
+                    const int cc = e - rr * cols;
+                    dst[TR ? cc * ld + rr : rr * ld + cc] = vv[q];
+                }
+            }
+        }
+    }
+};
+// number of 16-byte units MatLoad handles for a dense [rows][cols] matrix (0 when not 16-byte loadable);
+// the remainder (and the unaligned case) goes through stage_matrix_tail.
+__device__ __forceinline__ int matload_units(int rows, int cols, bool vec_ok, int maxu) {
+    const int n4 = vec_ok ? (rows * cols) >> 2 : 0;
+    const int cap = maxu * (int)blockDim.x;
+    return n4 < cap ? n4 : cap;
+}
+template <bool TR>
+__device__ __forceinline__ void stage_matrix_tail(float* dst, int ld, const float* __restrict__ src, int rows, int cols,
+                                                  FastDiv dcols, int done4) {
+    const int n = rows * cols;
+#pragma unroll 4
+    for (int e = 4 * done4 + threadIdx.x; e < n; e += blockDim.x) {
+        const int rr = fastdiv(e, dcols);
+        const int cc = e - rr * cols;
+        dst[TR ? cc * ld + rr : rr * ld + cc] = src[e];
+    }
+}
+
+// zero the padding of an LDS image holding a [rows][cols] matrix inside [rows_pad][cols_pad] (row stride ld)
+__device__ __forceinline__ void zero_padding(float* dst, int ld, int rows, int cols, int rows_pad, int cols_pad) {
+    if (cols_pad > cols)
+        for (int rr = threadIdx.x; rr < rows; rr += blockDim.x)
+            for (int cc = cols; cc < cols_pad; ++cc) dst[rr * ld + cc] = 0.f;
+    for (int rr = rows; rr < rows_pad; ++rr)
+        for (int cc = threadIdx.x; cc < cols_pad; cc += blockDim.x) dst[rr * ld + cc] = 0.f;
+}
+
+// ---- in-kernel phase stamps (diagnostic build only: -DDLWP_STAMPS; never in the shipped library)
+#ifdef DLWP_STAMPS
+__device__ unsigned long long g_dlwp_stamps[32];
+#define DLWP_STAMP(i)                                                                         \
+    do {                                                                                      \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                            \
+            unsigned long long t__;                                                           \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");      \
+            g_dlwp_stamps[i] = t__;                                                           \
+        }                                                                                     \
+    } while (0)
+#else
+#define DLWP_STAMP(i)
+#endif

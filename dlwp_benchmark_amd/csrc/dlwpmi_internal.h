@@ -10,8 +10,13 @@ int dlwp_pwmlp_fwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, 
 int dlwp_pwmlp_bwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, const float* w2,
                       const dlwp_chan_src* gy, const dlwp_chan_src* pred, const dlwp_chan_src* target,
                       float mse_scale, const dlwp_chan_dst* gx, int gx_accumulate, float* gw1,
-                      float* gb1, float* gw2, float* gb2, int B, int Cin, int Ch, int Cout, int P,
-                      hipStream_t stream);
+                      float* gb1, float* gw2, float* gb2, float* slab, int slab_accumulate, int B, int Cin,
+                      int Ch, int Cout, int P, hipStream_t stream);
+// per-workgroup parameter-gradient slabs of pwmlp_bwd: [slab_count][slab_stride] floats
+long long dlwp_pwmlp_slab_stride(int Cin, int Ch, int Cout);
+int dlwp_pwmlp_slab_count(int B, int P);
+int dlwp_pwmlp_slab_reduce(const float* slab, int nslab, int Cin, int Ch, int Cout, float* gw1, float* gb1,
+                           float* gw2, float* gb2, hipStream_t stream);
 
 // fno_block.hip — the three stages of a block, exposed so the trainer can interleave them
 struct dlwp_fno_plan {
@@ -51,7 +56,13 @@ struct dlwp_fno_spatial_args {
     int x1_adjoint;
     float* g_wskip;          // bwd: += g_pre . act(x)^T   (nullable)
     float* g_bias;           // bwd: += sum g_pre          (nullable)
+    float* gslab;            // bwd: per-workgroup {g_wskip,g_bias} partial slab [B*H][dlwp_fno_gslab_stride]
+    int gslab_accumulate;    //      instead of same-address float atomics (0: overwrite, 1: read-modify-write)
     int inverse_adjoint;     // which G table: 0 = inverse step (fwd), 1 = adjoint of fwd step
     int B;
 };
 int dlwp_fno_spatial(const dlwp_fno_plan* p, const dlwp_fno_spatial_args* a, hipStream_t stream);
+long long dlwp_fno_gslab_stride(int C);
+// generic partial-slab fold: dst_k[i] += sum_s slab[s*stride + off_k + i]
+int dlwp_slab_reduce(const float* slab, int nslab, long long stride, float* d1, long long n1, float* d2, long long n2,
+                     float* d3, long long n3, float* d4, long long n4, hipStream_t stream);

@@ -24,12 +24,15 @@ namespace {
 struct SpatialDev {
     const float* tin; const float2* spec; const float* wskip; const float* bias;
     const float* pprev; float* out; float2* x1_out; float* g_wskip; float* g_bias;
+    float* gslab; int gslab_accumulate;   // per-workgroup {g_wskip[C*C], g_bias[C]} partials (stride C*C+C padded to 4)
     const float2* twH; const float* G; const float* FT;
-    int act_tin, transpose_w, act_prev, x1_act, is_bwd;
+    int act_tin, transpose_w, act_prev, x1_act, is_bwd, vec_w;
     int C, H, W, m1, m2c, C_pad, NP;
+    FastDiv dC;
 };
 
-// x1s[c][n] += sum_w act(tile[c][w]) * ft[n][w]   (wave w takes 16-pixel chunks w, w+4, ...)
+// x1s[wave][c][n] = partial over the wave's 16-pixel chunks (w, w+4, ...) of sum_w act(tile[c][w]) * ft[n][w];
+// store_x1 sums the four per-wave partials (no LDS float atomics: they run at <1 lane-op/clk/CU).
 template <int NCB, int NBN>
 __device__ __forceinline__ void tile_rows_dft(const float* tile, const float* ft, float* x1s, int LDP,
                                               int NP, int nwb, bool act) {
@@ -61,15 +64,21 @@ __device__ __forceinline__ void tile_rows_dft(const float* tile, const float* ft
         for (int nb = 0; nb < NBN; ++nb)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                atomicAdd(&x1s[(cb * 16 + 4 * g + j) * NP + nb * 16 + r], xacc[cb][nb][j]);
+                x1s[((w * NCB + cb) * 16 + 4 * g + j) * NP + nb * 16 + r] = xacc[cb][nb][j];
 }
 
 __device__ __forceinline__ void store_x1(const float* x1s, float2* x1_out, int b, int h, int H, int m2c,
-                                         int C, int NP) {
+                                         int C, int C_pad, int NP) {
     float2* dst = x1_out + ((long long)(b * H + h) * m2c) * C;
     for (int idx = threadIdx.x; idx < m2c * C; idx += 256) {
         const int kx = idx / C, c = idx % C;
-        dst[idx] = make_float2(x1s[c * NP + 2 * kx], x1s[c * NP + 2 * kx + 1]);
+        float re = 0.f, im = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            re += x1s[(w * C_pad + c) * NP + 2 * kx];
+            im += x1s[(w * C_pad + c) * NP + 2 * kx + 1];
+        }
+        dst[idx] = make_float2(re, im);
     }
 }
 
@@ -84,7 +93,7 @@ __global__ __launch_bounds__(256) void fno_rows_kernel(RowsDev a) {
     const int LDP = a.W + 4;
     float* tile = smem;                    // [C_pad][LDP]
     float* ft = tile + a.C_pad * LDP;      // [NP][LDP]
-    float* x1s = ft + a.NP * LDP;          // [C_pad][NP]
+    float* x1s = ft + a.NP * LDP;          // [4 waves][C_pad][NP]
     const int tid = threadIdx.x;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int W4 = a.W / 4;
@@ -98,11 +107,10 @@ __global__ __launch_bounds__(256) void fno_rows_kernel(RowsDev a) {
         const int n = idx / W4, x4 = idx % W4;
         *reinterpret_cast<float4*>(&ft[n * LDP + 4 * x4]) = *reinterpret_cast<const float4*>(&a.FT[n * a.W + 4 * x4]);
     }
-    for (int idx = tid; idx < a.C_pad * a.NP; idx += 256) x1s[idx] = 0.f;
     __syncthreads();
     tile_rows_dft<NCB, NBN>(tile, ft, x1s, LDP, a.NP, a.W / 16, a.act != 0);
     __syncthreads();
-    store_x1(x1s, a.x1, b, h, a.H, a.m2c, a.C, a.NP);
+    store_x1(x1s, a.x1, b, h, a.H, a.m2c, a.C, a.C_pad, a.NP);
 }
 
 template <int NCB, int NBN>
@@ -111,64 +119,136 @@ __global__ __launch_bounds__(256) void fno_spatial_kernel(SpatialDev a) {
     const int LDP = a.W + 4, LDK = a.C_pad + 4, LDS1 = a.NP + 4;
     float* tin_s = smem;                          // [C_pad][LDP]
     float* tout_s = tin_s + a.C_pad * LDP;        // [C_pad][LDP]
-    float* gs = tout_s + a.C_pad * LDP;           // [NP][LDP]
-    float* ft = gs + a.NP * LDP;                  // [NP][LDP]
-    float* ks = ft + a.NP * LDP;                  // [C_pad][LDK]
-    float* s1 = ks + a.C_pad * LDK;               // [C_pad][LDS1]
-    float* x1s = s1 + a.C_pad * LDS1;             // [C_pad][NP]
-    float* bias_s = x1s + a.C_pad * a.NP;         // [C_pad]
-    float* gks = bias_s + a.C_pad;                // [C_pad][C_pad]  (bwd)
-    float* pprev_s = gks + a.C_pad * a.C_pad;     // [C_pad][LDP]    (bwd)
+    float* pprev_s = tout_s + a.C_pad * LDP;      // [C_pad][LDP]    (bwd)
+    float* ft = pprev_s + a.C_pad * LDP;          // [NP][LDP]
+    float* x1s = ft + a.NP * LDP;                 // [4 waves][C_pad][NP]
+    float* bias_s = x1s + 4 * a.C_pad * a.NP;     // [C_pad]
+    float* gs = bias_s + a.C_pad;                 // [NP][LDP]       dead after the main GEMM
+    float* ks = gs + a.NP * LDP;                  // [C_pad][LDK]    dead after the main GEMM
+    float* s1 = ks + a.C_pad * LDK;               // [C_pad][LDS1]   dead after the main GEMM
+    float* gks = gs;                              // [4 waves][C_pad][C_pad] (bwd) aliases gs/ks/s1
 
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const int r = lane & 15, g = lane >> 4;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int W4 = a.W / 4, nwb = a.W / 16;
-    const bool need_prev = a.is_bwd && (a.act_prev || a.g_wskip);
+    const bool need_prev = a.is_bwd && (a.act_prev || a.g_wskip || a.gslab);
+    DLWP_STAMP(0);
+    // ---- issue phase: the first chunk of every independent input goes into registers before any LDS
+    // write, so the workgroup pays one global latency for all of them (larger shapes loop afterwards)
+    const int tile_units = a.C_pad * W4, tab_units = a.NP * W4;
+    float4 tv[2], pv[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int u = tid + 256 * k, c = u / W4, x4 = u - c * W4;
+        tv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pv[k] = tv[k];
+        if (u < tile_units && c < a.C) {
+            const long long off = (((long long)b * a.C + c) * a.H + h) * a.W + 4 * x4;
+            tv[k] = *reinterpret_cast<const float4*>(&a.tin[off]);
+            if (need_prev) pv[k] = *reinterpret_cast<const float4*>(&a.pprev[off]);
+        }
+    }
+    float4 gv = make_float4(0.f, 0.f, 0.f, 0.f), fv = gv;
+    if (tid < tab_units) {
+        gv = reinterpret_cast<const float4*>(a.G)[tid];
+        if (a.x1_out) fv = reinterpret_cast<const float4*>(a.FT)[tid];
+    }
+    MatLoad<1> lk;
+    const int nk = matload_units(a.C, a.C, a.vec_w != 0, 1);
+    lk.issue(a.wskip, nk);
+    // inverse H-axis step operands for this row: spec[b][j][kx][o], j < min(m1, 16)
+    constexpr int MJ = 16;
+    float2 sv[MJ];
+    const int d_kx = tid / a.C_pad, d_o = tid - d_kx * a.C_pad;
+    const bool d_valid = tid < a.C_pad * (a.NP / 2) && d_kx < a.m2c && d_o < a.C;
+    // unconditional loads from clamped (always valid) addresses: a select right behind each load would
+    // make the compiler wait for every load separately; invalid lanes/steps are ignored at use
+    const float2* sp = a.spec + (((long long)b * a.m1) * a.m2c + (d_valid ? d_kx : 0)) * a.C + (d_valid ? d_o : 0);
+    const long long jstride = (long long)a.m2c * a.C;
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) sv[j] = sp[(j < a.m1 ? j : a.m1 - 1) * jstride];
+    float2 twv[MJ];
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) twv[j] = a.twH[(j < a.m1 ? j : a.m1 - 1) * a.H + h];
+    const float bias_raw = a.bias ? a.bias[tid < a.C ? tid : 0] : 0.f;
+    const float bias_v = tid < a.C ? bias_raw : 0.f;
+    DLWP_STAMP(1);
 
-    for (int idx = tid; idx < a.C_pad * W4; idx += 256) {
+    // ---- commit phase
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int u = tid + 256 * k, c = u / W4, x4 = u - c * W4;
+        if (u < tile_units) {
+            float4 v = tv[k];
+            if (a.act_tin) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
+            *reinterpret_cast<float4*>(&tin_s[c * LDP + 4 * x4]) = v;
+            if (need_prev) *reinterpret_cast<float4*>(&pprev_s[c * LDP + 4 * x4]) = pv[k];
+        }
+    }
+    for (int idx = tid + 512; idx < tile_units; idx += 256) {
         const int c = idx / W4, x4 = idx % W4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f), pv = v;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f), pvv = v;
         if (c < a.C) {
             const long long off = (((long long)b * a.C + c) * a.H + h) * a.W + 4 * x4;
             v = *reinterpret_cast<const float4*>(&a.tin[off]);
             if (a.act_tin) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
-            if (need_prev) pv = *reinterpret_cast<const float4*>(&a.pprev[off]);
+            if (need_prev) pvv = *reinterpret_cast<const float4*>(&a.pprev[off]);
         }
         *reinterpret_cast<float4*>(&tin_s[c * LDP + 4 * x4]) = v;
-        if (need_prev) *reinterpret_cast<float4*>(&pprev_s[c * LDP + 4 * x4]) = pv;
+        if (need_prev) *reinterpret_cast<float4*>(&pprev_s[c * LDP + 4 * x4]) = pvv;
     }
-    for (int idx = tid; idx < a.NP * W4; idx += 256) {
+    DLWP_STAMP(2);
+    if (tid < tab_units) {
+        const int n = tid / W4, x4 = tid - n * W4;
+        *reinterpret_cast<float4*>(&gs[n * LDP + 4 * x4]) = gv;
+        if (a.x1_out) *reinterpret_cast<float4*>(&ft[n * LDP + 4 * x4]) = fv;
+    }
+    for (int idx = tid + 256; idx < tab_units; idx += 256) {
         const int n = idx / W4, x4 = idx % W4;
         *reinterpret_cast<float4*>(&gs[n * LDP + 4 * x4]) = *reinterpret_cast<const float4*>(&a.G[n * a.W + 4 * x4]);
         if (a.x1_out)
             *reinterpret_cast<float4*>(&ft[n * LDP + 4 * x4]) = *reinterpret_cast<const float4*>(&a.FT[n * a.W + 4 * x4]);
     }
-    for (int idx = tid; idx < a.C_pad * a.C_pad; idx += 256) {
-        const int m = idx / a.C_pad, k = idx % a.C_pad;
-        float v = 0.f;
-        if (m < a.C && k < a.C) v = a.transpose_w ? a.wskip[k * a.C + m] : a.wskip[m * a.C + k];
-        ks[m * LDK + k] = v;
-        gks[idx] = 0.f;
+    if (a.transpose_w) {
+        lk.commit<true>(ks, LDK, a.C, a.dC, nk);
+        stage_matrix_tail<true>(ks, LDK, a.wskip, a.C, a.C, a.dC, nk);
+    } else {
+        lk.commit<false>(ks, LDK, a.C, a.dC, nk);
+        stage_matrix_tail<false>(ks, LDK, a.wskip, a.C, a.C, a.dC, nk);
     }
-    for (int idx = tid; idx < a.C_pad * a.NP; idx += 256) x1s[idx] = 0.f;
-    for (int idx = tid; idx < a.C_pad; idx += 256) bias_s[idx] = (a.bias && idx < a.C) ? a.bias[idx] : 0.f;
+    zero_padding(ks, LDK, a.C, a.C, a.C_pad, a.C_pad);
+    if (tid < a.C_pad) bias_s[tid] = bias_v;
+    for (int idx = tid + 256; idx < a.C_pad; idx += 256) bias_s[idx] = (a.bias && idx < a.C) ? a.bias[idx] : 0.f;
+    DLWP_STAMP(3);
     // inverse H-axis step for this row: s1[o][2kx(+1)] = sum_j spec[b][j][kx][o] * conj(twH[j][h])
     for (int idx = tid; idx < a.C_pad * (a.NP / 2); idx += 256) {
-        const int kx = idx / a.C_pad, o = idx % a.C_pad;
+        const int kx = idx / a.C_pad, o = idx - kx * a.C_pad;
         float re = 0.f, im = 0.f;
         if (kx < a.m2c && o < a.C) {
-            for (int j = 0; j < a.m1; ++j) {
-                const float2 v = a.spec[(((long long)b * a.m1 + j) * a.m2c + kx) * a.C + o];
+            if (idx == tid) {
+#pragma unroll
+                for (int j = 0; j < MJ; ++j) {
+                    if (j < a.m1) {
+                        re += sv[j].x * twv[j].x + sv[j].y * twv[j].y;   // v * conj(t)
+                        im += sv[j].y * twv[j].x - sv[j].x * twv[j].y;
+                    }
+                }
+            }
+            const float2* sp2 = a.spec + (((long long)b * a.m1) * a.m2c + kx) * a.C + o;
+            for (int j = (idx == tid ? MJ : 0); j < a.m1; ++j) {
+                const float2 v = sp2[j * jstride];
                 const float2 t = a.twH[j * a.H + h];
-                re += v.x * t.x + v.y * t.y;   // v * conj(t)
+                re += v.x * t.x + v.y * t.y;
                 im += v.y * t.x - v.x * t.y;
             }
         }
         s1[o * LDS1 + 2 * kx] = re;
         s1[o * LDS1 + 2 * kx + 1] = im;
     }
+    DLWP_STAMP(4);
     __syncthreads();
+    DLWP_STAMP(5);
 
     // main concatenated-K GEMM: acc[o][w] = sum_i ks[o][i] tin[i][w] + sum_n s1[o][n] gs[n][w]
     for (int wb = w; wb < nwb; wb += 4) {
@@ -208,16 +288,20 @@ __global__ __launch_bounds__(256) void fno_spatial_kernel(SpatialDev a) {
                 tout_s[o * LDP + x] = v;
             }
     }
+    DLWP_STAMP(6);
     __syncthreads();
+    DLWP_STAMP(7);
 
     for (int idx = tid; idx < a.C * W4; idx += 256) {
         const int c = idx / W4, x4 = idx % W4;
         *reinterpret_cast<float4*>(&a.out[(((long long)b * a.C + c) * a.H + h) * a.W + 4 * x4]) =
             *reinterpret_cast<const float4*>(&tout_s[c * LDP + 4 * x4]);
     }
+    DLWP_STAMP(8);
     if (a.x1_out) tile_rows_dft<NCB, NBN>(tout_s, ft, x1s, LDP, a.NP, nwb, a.x1_act != 0);
+    DLWP_STAMP(9);
 
-    if (a.is_bwd && a.g_wskip) {
+    if (a.is_bwd && (a.g_wskip || a.gslab)) {
         // gK[o][i] += sum_w g_pre[o][w] * act(x)[i][w]
         f32x4 kacc[NCB][NCB];
 #pragma unroll
@@ -245,141 +329,212 @@ __global__ __launch_bounds__(256) void fno_spatial_kernel(SpatialDev a) {
             for (int ib = 0; ib < NCB; ++ib)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    atomicAdd(&gks[(ob * 16 + 4 * g + j) * a.C_pad + ib * 16 + r], kacc[ob][ib][j]);
+                    gks[((w * NCB + ob) * 16 + 4 * g + j) * a.C_pad + ib * 16 + r] = kacc[ob][ib][j];
     }
+    DLWP_STAMP(10);
     __syncthreads();
-    if (a.x1_out) store_x1(x1s, a.x1_out, b, h, a.H, a.m2c, a.C, a.NP);
-    if (a.is_bwd && a.g_wskip) {
+    DLWP_STAMP(11);
+    if (a.x1_out) store_x1(x1s, a.x1_out, b, h, a.H, a.m2c, a.C, a.C_pad, a.NP);
+    if (a.is_bwd && (a.g_wskip || a.gslab)) {
         for (int idx = tid; idx < a.C * a.C; idx += 256) {
-            const int o = idx / a.C, i = idx % a.C;
-            atomic_add_f32(&a.g_wskip[idx], gks[o * a.C_pad + i]);
+            const int o = fastdiv(idx, a.dC), i = idx - o * a.C;
+            float v = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) v += gks[(w2 * a.C_pad + o) * a.C_pad + i];
+            if (a.gslab) {
+                float* sl = a.gslab + (long long)blockIdx.x * (((long long)a.C * a.C + a.C + 3) & ~3LL) + idx;
+                *sl = a.gslab_accumulate ? *sl + v : v;
+            } else {
+                atomic_add_f32(&a.g_wskip[idx], v);   // all workgroups hit the same C*C words: slow, API path only
+            }
         }
     }
-    if (a.is_bwd && a.g_bias && tid < a.C) {
+    if (a.is_bwd && (a.g_bias || a.gslab) && tid < a.C) {
         float s = 0.f;
         for (int x = 0; x < a.W; ++x) s += tin_s[tid * LDP + x];
-        atomic_add_f32(&a.g_bias[tid], s);
+        if (a.gslab) {
+            float* sl = a.gslab + (long long)blockIdx.x * (((long long)a.C * a.C + a.C + 3) & ~3LL) + a.C * a.C + tid;
+            *sl = a.gslab_accumulate ? *sl + s : s;
+        } else {
+            atomic_add_f32(&a.g_bias[tid], s);
+        }
     }
+    DLWP_STAMP(12);
 }
 
 // ------------------------------------------------------------------------------------------
+// Per-mode stage.  One 512-thread workgroup per kept mode (j,kx).  Everything it reads is issued
+// as batched independent loads up front (the mode's [C][C] weight slice as 16-byte loads straight
+// into an LDS image with a +1 complex row pad, the twiddle row, then the x1 column in unrolled
+// groups of 8), because at these sizes the kernel is pure load latency.
+constexpr int MIXT = 512;
+
 struct MixDev {
     const float2* x1; const float2* wspec; const float2* xhat_in; float2* xhat; float2* y;
     float2* g_wspec; const float2* twH;
     int B, C, H, m1, m2c;
 };
 
-__device__ __forceinline__ void lds_cadd(float2* p, float re, float im) {
-    atomicAdd(&p->x, re);
-    atomicAdd(&p->y, im);
+// weight slice [C][C] complex -> LDS rows of (C+1) complex (conflict-free row AND column reads)
+__device__ __forceinline__ void mix_stage_w(const float2* wm, float2* ws, int C) {
+    const int n2 = C * C / 2;  // pairs of complex numbers (C*C is even whenever C is even)
+    if ((C & 1) == 0) {
+#pragma unroll 4
+        for (int u = threadIdx.x; u < n2; u += MIXT) {
+            const float4 v = reinterpret_cast<const float4*>(wm)[u];
+            const int e = 2 * u, i = e / C, o = e % C;
+            ws[i * (C + 1) + o] = make_float2(v.x, v.y);
+            ws[i * (C + 1) + o + 1] = make_float2(v.z, v.w);
+        }
+    } else {
+#pragma unroll 4
+        for (int e = threadIdx.x; e < C * C; e += MIXT) ws[(e / C) * (C + 1) + e % C] = wm[e];
+    }
 }
 
-// H-axis step into LDS: xh[b*C+c] = sum_h x1[b][h][kx][c] * twH[j][h]
-__device__ __forceinline__ void mix_hstep(const MixDev& a, int j, int kx, float2* xh) {
+// H-axis step into LDS partials: part[hs][b*C+c] = sum_{h = hs mod HS} x1[b][h][kx][c] * tw[h]; returns HS
+__device__ __forceinline__ int mix_hstep(const MixDev& a, int kx, const float2* tws, float2* part, int HS) {
     const int BC = a.B * a.C;
-    int HS = 256 / BC;
-    if (HS < 1) HS = 1;
-    if (HS > a.H) HS = a.H;
-    for (int u = threadIdx.x; u < BC * HS; u += 256) {
+    for (int u = threadIdx.x; u < BC * HS; u += MIXT) {
         const int bc = u % BC, hs = u / BC, b = bc / a.C, c = bc % a.C;
+        const float2* src = a.x1 + (((long long)b * a.H) * a.m2c + kx) * a.C + c;
+        const long long hstride = (long long)a.m2c * a.C;
         float re = 0.f, im = 0.f;
+#pragma unroll 8
         for (int h = hs; h < a.H; h += HS) {
-            const float2 v = a.x1[(((long long)b * a.H + h) * a.m2c + kx) * a.C + c];
-            const float2 t = a.twH[j * a.H + h];
+            const float2 v = src[h * hstride];
+            const float2 t = tws[h];
             re += v.x * t.x - v.y * t.y;
             im += v.x * t.y + v.y * t.x;
         }
-        lds_cadd(&xh[bc], re, im);
+        part[hs * BC + bc] = make_float2(re, im);
+    }
+    return HS;
+}
+
+// out[i] = sum_s part[s][i]
+__device__ __forceinline__ void mix_fold(float2* out, const float2* part, int n, int ns) {
+    for (int i = threadIdx.x; i < n; i += MIXT) {
+        float2 v = part[i];
+        for (int s = 1; s < ns; ++s) {
+            v.x += part[s * n + i].x;
+            v.y += part[s * n + i].y;
+        }
+        out[i] = v;
     }
 }
 
-__global__ __launch_bounds__(256) void fno_mix_fwd_kernel(MixDev a) {
+// number of partial slots a phase splits its reduction over (threads / outputs, clamped)
+__device__ __host__ __forceinline__ int mix_split(int outputs, int limit) {
+    int s = MIXT / outputs;
+    if (s < 1) s = 1;
+    if (s > limit) s = limit;
+    return s;
+}
+
+__global__ __launch_bounds__(MIXT) void fno_mix_fwd_kernel(MixDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int BC = a.B * a.C;
+    const int BC = a.B * a.C, C = a.C;
+    const int NS = mix_split(BC, a.H < C ? a.H : C);   // partial slots (both phases use <= NS)
     float2* xh = reinterpret_cast<float2*>(smem);  // [BC]
-    float2* yh = xh + BC;                          // [BC]
+    float2* part = xh + BC;                        // [NS][BC]
+    float2* tws = part + NS * BC;                  // [H]
+    float2* ws = tws + a.H;                        // [C][C+1]
     const int j = blockIdx.x / a.m2c, kx = blockIdx.x % a.m2c;
-    for (int i = threadIdx.x; i < 2 * BC; i += 256) xh[i] = make_float2(0.f, 0.f);
+    mix_stage_w(a.wspec + ((long long)(j * a.m2c + kx) * C) * C, ws, C);
+    for (int i = threadIdx.x; i < a.H; i += MIXT) tws[i] = a.twH[j * a.H + i];
     __syncthreads();
-    mix_hstep(a, j, kx, xh);
+    const int hs = mix_hstep(a, kx, tws, part, NS);
     __syncthreads();
-    for (int bc = threadIdx.x; bc < BC; bc += 256) {
-        const int b = bc / a.C, c = bc % a.C;
-        a.xhat[(((long long)b * a.m1 + j) * a.m2c + kx) * a.C + c] = xh[bc];
+    mix_fold(xh, part, BC, hs);
+    __syncthreads();
+    for (int bc = threadIdx.x; bc < BC; bc += MIXT) {
+        const int b = bc / C, c = bc % C;
+        a.xhat[(((long long)b * a.m1 + j) * a.m2c + kx) * C + c] = xh[bc];
     }
-    const float2* wm = a.wspec + ((long long)(j * a.m2c + kx) * a.C) * a.C;
-    int IS = 256 / BC;
-    if (IS < 1) IS = 1;
-    if (IS > a.C) IS = a.C;
-    for (int u = threadIdx.x; u < BC * IS; u += 256) {
-        const int bo = u % BC, is = u / BC, b = bo / a.C, o = bo % a.C;
+    const int IS = mix_split(BC, NS);
+    for (int u = threadIdx.x; u < BC * IS; u += MIXT) {
+        const int bo = u % BC, is = u / BC, b = bo / C, o = bo % C;
         float re = 0.f, im = 0.f;
-        for (int i = is; i < a.C; i += IS) {
-            const float2 xv = xh[b * a.C + i];
-            const float2 wv = wm[i * a.C + o];
+#pragma unroll 4
+        for (int i = is; i < C; i += IS) {
+            const float2 xv = xh[b * C + i];
+            const float2 wv = ws[i * (C + 1) + o];
             re += xv.x * wv.x - xv.y * wv.y;
             im += xv.x * wv.y + xv.y * wv.x;
         }
-        lds_cadd(&yh[bo], re, im);
+        part[is * BC + bo] = make_float2(re, im);
     }
     __syncthreads();
-    for (int bo = threadIdx.x; bo < BC; bo += 256) {
-        const int b = bo / a.C, o = bo % a.C;
-        a.y[(((long long)b * a.m1 + j) * a.m2c + kx) * a.C + o] = yh[bo];
+    for (int bo = threadIdx.x; bo < BC; bo += MIXT) {
+        const int b = bo / C, o = bo % C;
+        float2 v = part[bo];
+        for (int s2 = 1; s2 < IS; ++s2) {
+            v.x += part[s2 * BC + bo].x;
+            v.y += part[s2 * BC + bo].y;
+        }
+        a.y[(((long long)b * a.m1 + j) * a.m2c + kx) * C + o] = v;
     }
 }
 
-__global__ __launch_bounds__(256) void fno_mix_bwd_kernel(MixDev a) {
+__global__ __launch_bounds__(MIXT) void fno_mix_bwd_kernel(MixDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int BC = a.B * a.C;
+    const int BC = a.B * a.C, C = a.C;
+    const int NS = mix_split(BC, a.H < C ? a.H : C);
     float2* gh = reinterpret_cast<float2*>(smem);  // [BC]  ghat
-    float2* gxh = gh + BC;                         // [BC]  grad wrt xhat
-    float2* xsv = gxh + BC;                        // [BC]  saved xhat
+    float2* xsv = gh + BC;                         // [BC]  saved xhat
+    float2* part = xsv + BC;                       // [NS][BC]
+    float2* tws = part + NS * BC;                  // [H]
+    float2* ws = tws + a.H;                        // [C][C+1]
     const int j = blockIdx.x / a.m2c, kx = blockIdx.x % a.m2c;
-    for (int i = threadIdx.x; i < 2 * BC; i += 256) gh[i] = make_float2(0.f, 0.f);
-    for (int bc = threadIdx.x; bc < BC; bc += 256) {
-        const int b = bc / a.C, c = bc % a.C;
-        xsv[bc] = a.xhat_in[(((long long)b * a.m1 + j) * a.m2c + kx) * a.C + c];
+    const long long wofs = ((long long)(j * a.m2c + kx) * C) * C;
+    mix_stage_w(a.wspec + wofs, ws, C);
+    for (int i = threadIdx.x; i < a.H; i += MIXT) tws[i] = a.twH[j * a.H + i];
+    for (int bc = threadIdx.x; bc < BC; bc += MIXT) {
+        const int b = bc / C, c = bc % C;
+        xsv[bc] = a.xhat_in[(((long long)b * a.m1 + j) * a.m2c + kx) * C + c];
     }
+    float2* gw = a.g_wspec + wofs;  // this workgroup owns the mode's weight-gradient slice
     __syncthreads();
-    mix_hstep(a, j, kx, gh);
+    const int hs = mix_hstep(a, kx, tws, part, NS);
     __syncthreads();
-    const long long wofs = ((long long)(j * a.m2c + kx) * a.C) * a.C;
-    const float2* wm = a.wspec + wofs;
-    int OS = 256 / BC;
-    if (OS < 1) OS = 1;
-    if (OS > a.C) OS = a.C;
-    for (int u = threadIdx.x; u < BC * OS; u += 256) {
-        const int bi = u % BC, os = u / BC, b = bi / a.C, i = bi % a.C;
+    mix_fold(gh, part, BC, hs);
+    __syncthreads();
+    const int OS = mix_split(BC, NS);
+    for (int u = threadIdx.x; u < BC * OS; u += MIXT) {
+        const int bi = u % BC, os = u / BC, b = bi / C, i = bi % C;
         float re = 0.f, im = 0.f;
-        for (int o = os; o < a.C; o += OS) {
-            const float2 gv = gh[b * a.C + o];
-            const float2 wv = wm[i * a.C + o];
+#pragma unroll 4
+        for (int o = os; o < C; o += OS) {
+            const float2 gv = gh[b * C + o];
+            const float2 wv = ws[i * (C + 1) + o];
             re += gv.x * wv.x + gv.y * wv.y;   // g * conj(w)
             im += gv.y * wv.x - gv.x * wv.y;
         }
-        lds_cadd(&gxh[bi], re, im);
+        part[os * BC + bi] = make_float2(re, im);
     }
-    // weight gradient (this workgroup owns the mode slice exclusively): gw[i][o] += conj(x) g
-    float2* gw = a.g_wspec + wofs;
-    for (int idx = threadIdx.x; idx < a.C * a.C; idx += 256) {
-        const int i = idx / a.C, o = idx % a.C;
-        float re = 0.f, im = 0.f;
-        for (int b = 0; b < a.B; ++b) {
-            const float2 xv = xsv[b * a.C + i];
-            const float2 gv = gh[b * a.C + o];
-            re += xv.x * gv.x + xv.y * gv.y;
-            im += xv.x * gv.y - xv.y * gv.x;
-        }
+    // gw[i][o] += sum_b conj(xhat[b][i]) * ghat[b][o]
+#pragma unroll 2
+    for (int idx = threadIdx.x; idx < C * C; idx += MIXT) {
+        const int i = idx / C, o = idx % C;
         float2 cur = gw[idx];
-        cur.x += re;
-        cur.y += im;
+        for (int b = 0; b < a.B; ++b) {
+            const float2 xv = xsv[b * C + i];
+            const float2 gv = gh[b * C + o];
+            cur.x += xv.x * gv.x + xv.y * gv.y;
+            cur.y += xv.x * gv.y - xv.y * gv.x;
+        }
         gw[idx] = cur;
     }
     __syncthreads();
-    for (int bi = threadIdx.x; bi < BC; bi += 256) {
-        const int b = bi / a.C, i = bi % a.C;
-        a.y[(((long long)b * a.m1 + j) * a.m2c + kx) * a.C + i] = gxh[bi];
+    for (int bi = threadIdx.x; bi < BC; bi += MIXT) {
+        const int b = bi / C, i = bi % C;
+        float2 v = part[bi];
+        for (int s2 = 1; s2 < OS; ++s2) {
+            v.x += part[s2 * BC + bi].x;
+            v.y += part[s2 * BC + bi].y;
+        }
+        a.y[(((long long)b * a.m1 + j) * a.m2c + kx) * C + i] = v;
     }
 }
 
@@ -479,7 +634,7 @@ int dlwp_fno_rows_dft(const dlwp_fno_plan* p, const float* x, int act_in, int ad
                       hipStream_t stream) {
     RowsDev a{x, x1, adjoint ? p->FT_adj : p->FT_fwd, act_in, p->C, p->H, p->W, p->m2c, p->C_pad, p->NP};
     const int LDP = p->W + 4;
-    const size_t lds = sizeof(float) * ((size_t)p->C_pad * LDP + (size_t)p->NP * LDP + (size_t)p->C_pad * p->NP);
+    const size_t lds = sizeof(float) * ((size_t)p->C_pad * LDP + (size_t)p->NP * LDP + (size_t)4 * p->C_pad * p->NP);
     const dim3 grid(B * p->H), block(256);
     int rc;
 #define LAUNCH(N, M)                                                                   \
@@ -492,8 +647,13 @@ int dlwp_fno_rows_dft(const dlwp_fno_plan* p, const float* x, int act_in, int ad
 }
 
 static int mix_launch(const dlwp_fno_plan* p, bool bwd, MixDev& a, hipStream_t stream) {
-    const size_t lds = sizeof(float2) * (size_t)a.B * a.C * (bwd ? 3 : 2);
-    const dim3 grid(p->m1 * p->m2c), block(256);
+    const int BC = a.B * a.C;
+    int ns = MIXT / BC;
+    if (ns < 1) ns = 1;
+    const int lim = a.H < a.C ? a.H : a.C;
+    if (ns > lim) ns = lim;
+    const size_t lds = sizeof(float2) * ((size_t)BC * ((bwd ? 2 : 1) + ns) + a.H + (size_t)a.C * (a.C + 1));
+    const dim3 grid(p->m1 * p->m2c), block(MIXT);
     int rc;
     if (bwd) {
         if ((rc = set_lds(fno_mix_bwd_kernel, lds, "fno_mix_bwd")) != DLWP_OK) return rc;
@@ -522,16 +682,20 @@ int dlwp_fno_spatial(const dlwp_fno_plan* p, const dlwp_fno_spatial_args* s, hip
     SpatialDev a{};
     a.tin = s->tin; a.spec = s->spec; a.wskip = s->wskip; a.bias = s->bias; a.pprev = s->pprev;
     a.out = s->out; a.x1_out = s->x1_out; a.g_wskip = s->g_wskip; a.g_bias = s->g_bias;
+    a.gslab = s->gslab; a.gslab_accumulate = s->gslab_accumulate;
     a.twH = p->twH;
     a.G = s->inverse_adjoint ? p->G_adj : p->G_inv;
     a.FT = s->x1_adjoint ? p->FT_adj : p->FT_fwd;
     a.act_tin = s->act_tin; a.transpose_w = s->transpose_w; a.act_prev = s->act_prev;
     a.x1_act = s->x1_act; a.is_bwd = s->inverse_adjoint;
+    a.vec_w = (reinterpret_cast<uintptr_t>(s->wskip) & 15) == 0;
+    a.dC = make_fastdiv(p->C);
     a.C = p->C; a.H = p->H; a.W = p->W; a.m1 = p->m1; a.m2c = p->m2c; a.C_pad = p->C_pad; a.NP = p->NP;
     const int LDP = p->W + 4;
-    const size_t lds = sizeof(float) * ((size_t)3 * p->C_pad * LDP + (size_t)2 * p->NP * LDP +
-                                        (size_t)p->C_pad * (p->C_pad + 4) + (size_t)p->C_pad * (p->NP + 4) +
-                                        (size_t)p->C_pad * p->NP + p->C_pad + (size_t)p->C_pad * p->C_pad);
+    size_t dead = (size_t)p->NP * LDP + (size_t)p->C_pad * (p->C_pad + 4) + (size_t)p->C_pad * (p->NP + 4);
+    if (dead < (size_t)4 * p->C_pad * p->C_pad) dead = (size_t)4 * p->C_pad * p->C_pad;
+    const size_t lds = sizeof(float) * ((size_t)3 * p->C_pad * LDP + (size_t)p->NP * LDP +
+                                        (size_t)4 * p->C_pad * p->NP + p->C_pad + dead);
     const dim3 grid(s->B * p->H), block(256);
     int rc;
 #define LAUNCH(N, M)                                                                         \
@@ -577,3 +741,12 @@ extern "C" int dlwp_fno_block_bwd(const dlwp_fno_plan* p, const float* x, int ac
     s.out = g_x; s.g_wskip = g_wskip; s.g_bias = g_bias; s.inverse_adjoint = 1; s.B = B;
     return dlwp_fno_spatial(p, &s, stream);
 }
+
+#ifdef DLWP_STAMPS
+extern "C" int dlwp_debug_stamps_fno(unsigned long long* host_out) {
+    DLWP_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dlwp_stamps), sizeof(unsigned long long) * 32));
+    return DLWP_OK;
+}
+#endif
+
+long long dlwp_fno_gslab_stride(int C) { return ((long long)C * C + C + 3) & ~3LL; }

@@ -29,6 +29,8 @@ struct dlwp_fno_trainer {
     float2* xhat = nullptr;                  // [ncalls][NL][B,m1,m2c,C]
     float2 *x1 = nullptr, *spec = nullptr;   // work
     float *gA = nullptr, *gB = nullptr;      // work [B,C,H,W]
+    float *slab_lift = nullptr, *slab_proj = nullptr;  // per-workgroup parameter-gradient partials
+    float* slab_skip = nullptr;                        // [n_layers][B*H][gslab_stride] skip-weight / bias partials
     const float** src_tab = nullptr;         // [ncalls][Cin]
     float** gdst_tab = nullptr;              // [ncalls][Cin]
     long long* bstride_tab = nullptr;        // [Cin]
@@ -183,7 +185,8 @@ int enqueue_loss_backward(dlwp_fno_trainer* tr, const float* grad_out, hipStream
         dlwp_chan_dst gx{gcur, tr->act, HW, nullptr, nullptr};
         if ((rc = dlwp_pwmlp_bwd_ex(&ps, w.pw1, w.pb1, w.pw2, &gy, grad_out ? nullptr : &pred, grad_out ? nullptr : &targ,
                                     mse_scale, &gx, 0, g.pw1, g.pb1,
-                                    g.pw2, g.pb2, c.B, C, c.projection, c.out_channels, HW, s))) return rc;
+                                    g.pw2, g.pb2, tr->slab_proj, k != tr->ncalls - 1, c.B, C, c.projection,
+                                    c.out_channels, HW, s))) return rc;
         if ((rc = dlwp_fno_rows_dft(tr->plan, gcur, 0, 1, tr->x1, c.B, s))) return rc;
         for (int l = NL - 1; l >= 0; --l) {
             if ((rc = dlwp_fno_mix_bwd(tr->plan, tr->x1, reinterpret_cast<const float2*>(w.spec(l)),
@@ -195,7 +198,8 @@ int enqueue_loss_backward(dlwp_fno_trainer* tr, const float* grad_out, hipStream
             a.out = gnext;
             a.x1_out = l > 0 ? tr->x1 : nullptr;
             a.x1_adjoint = 1;
-            a.g_wskip = g.skip(l); a.g_bias = g.bias(l);
+            a.gslab = tr->slab_skip + (long long)l * c.B * c.H * dlwp_fno_gslab_stride(C);
+            a.gslab_accumulate = k != tr->ncalls - 1;
             a.inverse_adjoint = 1;
             a.B = c.B;
             if ((rc = dlwp_fno_spatial(tr->plan, &a, s))) return rc;
@@ -206,8 +210,19 @@ int enqueue_loss_backward(dlwp_fno_trainer* tr, const float* grad_out, hipStream
         dlwp_chan_src gh0{gcur, tr->act, HW, nullptr, nullptr};
         dlwp_chan_dst gxd{nullptr, 0, 0, tr->gdst_tab + (long long)k * tr->Cin, tr->bstride_tab};
         if ((rc = dlwp_pwmlp_bwd_ex(&xs, w.lw1, w.lb1, w.lw2, &gh0, nullptr, nullptr, 0.f, &gxd, 1, g.lw1, g.lb1,
-                                    g.lw2, g.lb2, c.B, tr->Cin, c.lifting, C, HW, s))) return rc;
+                                    g.lw2, g.lb2, tr->slab_lift, k != tr->ncalls - 1, c.B, tr->Cin, c.lifting, C,
+                                    HW, s))) return rc;
     }
+    // fold the per-workgroup partial slabs of all net calls into the gradient buffer
+    for (int l = 0; l < NL; ++l)
+        if ((rc = dlwp_slab_reduce(tr->slab_skip + (long long)l * c.B * c.H * dlwp_fno_gslab_stride(C), c.B * c.H,
+                                   dlwp_fno_gslab_stride(C), g.skip(l), (long long)C * C, g.bias(l), C, nullptr, 0,
+                                   nullptr, 0, s))) return rc;
+    const int nslab = dlwp_pwmlp_slab_count(c.B, HW);
+    if ((rc = dlwp_pwmlp_slab_reduce(tr->slab_proj, nslab, C, c.projection, c.out_channels, g.pw1, g.pb1, g.pw2,
+                                     g.pb2, s))) return rc;
+    if ((rc = dlwp_pwmlp_slab_reduce(tr->slab_lift, nslab, tr->Cin, c.lifting, C, g.lw1, g.lb1, g.lw2, g.lb2, s)))
+        return rc;
     return DLWP_OK;
 }
 
@@ -257,6 +272,11 @@ extern "C" int dlwp_fno_trainer_create(const dlwp_fno_cfg* cfg, dlwp_fno_trainer
         (rc = dmalloc(&tr->xhat, xhatB * tr->ncalls * c.n_layers)) ||
         (rc = dmalloc(&tr->x1, (size_t)c.B * c.H * c.m2c * c.hidden)) || (rc = dmalloc(&tr->spec, xhatB)) ||
         (rc = dmalloc(&tr->gA, actB)) || (rc = dmalloc(&tr->gB, actB)) ||
+        (rc = dmalloc(&tr->slab_skip, (size_t)c.n_layers * c.B * c.H * dlwp_fno_gslab_stride(c.hidden))) ||
+        (rc = dmalloc(&tr->slab_lift, (size_t)dlwp_pwmlp_slab_count(c.B, c.H * c.W) *
+                                          dlwp_pwmlp_slab_stride(tr->Cin, c.lifting, c.hidden))) ||
+        (rc = dmalloc(&tr->slab_proj, (size_t)dlwp_pwmlp_slab_count(c.B, c.H * c.W) *
+                                          dlwp_pwmlp_slab_stride(c.hidden, c.projection, c.out_channels))) ||
         (rc = dmalloc(&tr->src_tab, (size_t)tr->ncalls * tr->Cin)) ||
         (rc = dmalloc(&tr->gdst_tab, (size_t)tr->ncalls * tr->Cin)) || (rc = dmalloc(&tr->bstride_tab, (size_t)tr->Cin))) {
         dlwp_fno_trainer_destroy(tr);
@@ -311,7 +331,7 @@ extern "C" void dlwp_fno_trainer_destroy(dlwp_fno_trainer* tr) {
     if (tr->graph) (void)hipGraphDestroy(tr->graph);
     if (tr->cap_stream) (void)hipStreamDestroy(tr->cap_stream);
     dlwp_fno_plan_destroy(tr->plan);
-    void* bufs[] = {tr->g_out, tr->h0, tr->pre, tr->xhat, tr->x1, tr->spec,
+    void* bufs[] = {tr->slab_skip, tr->slab_lift, tr->slab_proj, tr->g_out, tr->h0, tr->pre, tr->xhat, tr->x1, tr->spec,
                     tr->gA, tr->gB, (void*)tr->src_tab, (void*)tr->gdst_tab, tr->bstride_tab};
     for (void* b : bufs)
         if (b) (void)hipFree(b);

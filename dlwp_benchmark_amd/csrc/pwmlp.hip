@@ -16,6 +16,8 @@
 namespace {
 
 constexpr int PT = 64;        // pixels per workgroup
+constexpr int FWD_WAVES = 8;  // 2 waves per SIMD
+constexpr int BWD_WAVES = 8;
 constexpr int LDP = PT + 4;   // LDS row stride of pixel tiles (4*LDP % 32 == 16: conflict-free B reads)
 
 __device__ __forceinline__ const float* chan_ptr(const dlwp_chan_src& s, int b, int c) {
@@ -27,6 +29,35 @@ __device__ __forceinline__ float* chan_ptr(const dlwp_chan_dst& s, int b, int c)
     return s.base ? s.base + (long long)b * s.bstride + (long long)c * s.cstride : nullptr;
 }
 
+
+// pixel tile [C_pad][PT] of a channel view -> LDS (row stride LDP); 16-byte loads along pixels
+template <typename SRC>
+__device__ __forceinline__ void stage_pixels(float* dst, const SRC& s, int b, int C, int C_pad, int p0, int P,
+                                             bool vec_ok) {
+    if (vec_ok) {
+#pragma unroll 2
+        for (int u = threadIdx.x; u < C_pad * (PT / 4); u += blockDim.x) {
+            const int c = u / (PT / 4), q = u % (PT / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < C && p0 + 4 * q < P) {
+                const float* src = chan_ptr(s, b, c);
+                if (src) v = *reinterpret_cast<const float4*>(src + p0 + 4 * q);
+            }
+            *reinterpret_cast<float4*>(&dst[c * LDP + 4 * q]) = v;
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < C_pad * PT; idx += blockDim.x) {
+            const int c = idx / PT, p = idx % PT;
+            float v = 0.f;
+            if (c < C && p0 + p < P) {
+                const float* src = chan_ptr(s, b, c);
+                if (src) v = src[p0 + p];
+            }
+            dst[c * LDP + p] = v;
+        }
+    }
+}
+
 struct FwdArgs {
     dlwp_chan_src x;
     const float *w1, *b1, *w2, *b2;
@@ -34,51 +65,59 @@ struct FwdArgs {
     dlwp_chan_src res;  // optional residual added to y (base==nullptr && tab==nullptr: none)
     int B, Cin, Ch, Cout, P, tiles_per_sample;
     int Cin_pad, Ch_pad, Cout_pad;
+    int vec_w, vec_x;   // 16-byte loads allowed for the weights / the pixel planes
+    FastDiv dCin, dCh;
 };
 
-template <int NOB>
-__global__ __launch_bounds__(256) void pwmlp_fwd_kernel(FwdArgs a) {
+// NW waves: wave w owns pixel block (w & 3) and the hidden blocks hq, hq+HQ, ... (hq = w >> 2,
+// HQ = NW/4); two or more waves per SIMD overlap one wave's GELU (VALU) with another's MFMAs.
+template <int NOB, int NW>
+__global__ __launch_bounds__(NW * 64) void pwmlp_fwd_kernel(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = NW * 64, HQ = NW / 4;
     const int LD1 = a.Cin_pad + 4, LD2 = a.Ch_pad + 4;
     float* xs = smem;
     float* w1s = xs + a.Cin_pad * LDP;
     float* w2s = w1s + a.Ch_pad * LD1;
     float* b1s = w2s + a.Cout_pad * LD2;
     float* b2s = b1s + a.Ch_pad;
+    float* outs = b2s + a.Cout_pad;  // [HQ][Cout_pad][LDP] per-hidden-group partial output tiles
 
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const int r = lane & 15, g = lane >> 4;
     const int b = blockIdx.x / a.tiles_per_sample;
     const int p0 = (blockIdx.x % a.tiles_per_sample) * PT;
 
-    for (int idx = tid; idx < a.Cin_pad * PT; idx += 256) {
-        const int c = idx / PT, p = idx % PT;
-        float v = 0.f;
-        if (c < a.Cin && p0 + p < a.P) {
-            const float* src = chan_ptr(a.x, b, c);
-            if (src) v = src[p0 + p];
-        }
-        xs[c * LDP + p] = v;
-    }
-    for (int idx = tid; idx < a.Ch_pad * a.Cin_pad; idx += 256) {
-        const int h = idx / a.Cin_pad, i = idx % a.Cin_pad;
-        w1s[h * LD1 + i] = (h < a.Ch && i < a.Cin) ? a.w1[h * a.Cin + i] : 0.f;
-    }
-    for (int idx = tid; idx < a.Cout_pad * a.Ch_pad; idx += 256) {
-        const int o = idx / a.Ch_pad, h = idx % a.Ch_pad;
-        w2s[o * LD2 + h] = (o < a.Cout && h < a.Ch) ? a.w2[o * a.Ch + h] : 0.f;
-    }
-    for (int idx = tid; idx < a.Ch_pad; idx += 256) b1s[idx] = idx < a.Ch ? a.b1[idx] : 0.f;
-    for (int idx = tid; idx < a.Cout_pad; idx += 256) b2s[idx] = idx < a.Cout ? a.b2[idx] : 0.f;
+    DLWP_STAMP(0);
+    // issue every independent global load first, then fill the LDS images
+    MatLoad<4> l2;
+    MatLoad<2> l1;
+    const int n2 = matload_units(a.Cout, a.Ch, a.vec_w != 0, 4), n1 = matload_units(a.Ch, a.Cin, a.vec_w != 0, 2);
+    l2.issue(a.w2, n2);
+    l1.issue(a.w1, n1);
+    DLWP_STAMP(1);
+    stage_pixels(xs, a.x, b, a.Cin, a.Cin_pad, p0, a.P, a.vec_x != 0);
+    DLWP_STAMP(2);
+    l2.commit<false>(w2s, LD2, a.Ch, a.dCh, n2);
+    l1.commit<false>(w1s, LD1, a.Cin, a.dCin, n1);
+    stage_matrix_tail<false>(w2s, LD2, a.w2, a.Cout, a.Ch, a.dCh, n2);
+    stage_matrix_tail<false>(w1s, LD1, a.w1, a.Ch, a.Cin, a.dCin, n1);
+    DLWP_STAMP(3);
+    zero_padding(w1s, LD1, a.Ch, a.Cin, a.Ch_pad, a.Cin_pad);
+    zero_padding(w2s, LD2, a.Cout, a.Ch, a.Cout_pad, a.Ch_pad);
+    for (int idx = tid; idx < a.Ch_pad; idx += NT) b1s[idx] = idx < a.Ch ? a.b1[idx] : 0.f;
+    for (int idx = tid; idx < a.Cout_pad; idx += NT) b2s[idx] = idx < a.Cout ? a.b2[idx] : 0.f;
+    DLWP_STAMP(4);
     __syncthreads();
+    DLWP_STAMP(5);
 
-    const int pw0 = w * 16;
+    const int pw0 = (w & 3) * 16, hq = w >> 2;
     const int nkc = a.Cin_pad / 16, nhb = a.Ch_pad / 16;
     f32x4 oacc[NOB];
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) oacc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int hb = 0; hb < nhb; ++hb) {
+    for (int hb = hq; hb < nhb; hb += HQ) {
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
         for (int kc = 0; kc < nkc; ++kc) {
             const f32x4 a4 = *reinterpret_cast<const f32x4*>(&w1s[(hb * 16 + r) * LD1 + kc * 16 + 4 * g]);
@@ -95,26 +134,57 @@ __global__ __launch_bounds__(256) void pwmlp_fwd_kernel(FwdArgs a) {
             oacc[ob] = mfma16_chunk(w4, z, oacc[ob]);
         }
     }
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            outs[(hq * a.Cout_pad + ob * 16 + 4 * g + j) * LDP + pw0 + r] = oacc[ob][j];
+        }
+    DLWP_STAMP(6);
+    __syncthreads();
+    DLWP_STAMP(7);
 
-    const int p = p0 + pw0 + r;
-    if (p < a.P) {
+    const bool has_res = a.res.base || a.res.tab;
+    if (a.vec_x) {
+        for (int u = tid; u < a.Cout * (PT / 4); u += NT) {
+            const int o = u / (PT / 4), q = u % (PT / 4), p = p0 + 4 * q;
+            if (p < a.P) {
+                float4 v = *reinterpret_cast<const float4*>(&outs[o * LDP + 4 * q]);
 #pragma unroll
-        for (int ob = 0; ob < NOB; ++ob) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int o = ob * 16 + 4 * g + j;
-                if (o < a.Cout) {
-                    float v = oacc[ob][j] + b2s[o];
-                    if (a.res.base || a.res.tab) {
-                        const float* rp = chan_ptr(a.res, b, o);
-                        if (rp) v += rp[p];
-                    }
-                    float* dst = chan_ptr(a.y, b, o);
-                    if (dst) dst[p] = v;
+                for (int h2 = 1; h2 < HQ; ++h2) {
+                    const float4 pv = *reinterpret_cast<const float4*>(&outs[(h2 * a.Cout_pad + o) * LDP + 4 * q]);
+                    v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
                 }
+                const float bb = b2s[o];
+                v.x += bb; v.y += bb; v.z += bb; v.w += bb;
+                if (has_res) {
+                    const float* rp = chan_ptr(a.res, b, o);
+                    if (rp) {
+                        const float4 rv = *reinterpret_cast<const float4*>(rp + p);
+                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                    }
+                }
+                float* dst = chan_ptr(a.y, b, o);
+                if (dst) *reinterpret_cast<float4*>(dst + p) = v;
+            }
+        }
+    } else {
+        for (int idx = tid; idx < a.Cout * PT; idx += NT) {
+            const int o = idx / PT, p = p0 + idx % PT;
+            if (p < a.P) {
+                float v = b2s[o];
+#pragma unroll
+                for (int h2 = 0; h2 < HQ; ++h2) v += outs[(h2 * a.Cout_pad + o) * LDP + idx % PT];
+                if (has_res) {
+                    const float* rp = chan_ptr(a.res, b, o);
+                    if (rp) v += rp[p];
+                }
+                float* dst = chan_ptr(a.y, b, o);
+                if (dst) dst[p] = v;
             }
         }
     }
+    DLWP_STAMP(8);
 }
 
 struct BwdArgs {
@@ -125,67 +195,79 @@ struct BwdArgs {
     float mse_scale;
     dlwp_chan_dst gx;            // nullable; per-channel nullable in table mode
     int gx_accumulate;
-    float *gw1, *gb1, *gw2, *gb2;  // accumulated with float atomics
+    float *gw1, *gb1, *gw2, *gb2;  // accumulated with float atomics (slab == nullptr)
+    // optional per-workgroup partial slab [grid][slab_stride] laid out {gw1,gb1,gw2,gb2}: plain
+    // stores (slab_accumulate == 0) or read-modify-write by the owning workgroup; deterministic and
+    // not bound by the chip-wide float-atomic rate.  dlwp_pwmlp_slab_reduce folds it into the grads.
+    float* slab;
+    long long slab_stride;
+    int slab_accumulate;
     int B, Cin, Ch, Cout, P, tiles_per_sample;
     int Cin_pad, Ch_pad, Cout_pad;
+    int vec_w, vec_x;
+    FastDiv dCin, dCh;
 };
 
-template <int NIB, int NOB>
-__global__ __launch_bounds__(256) void pwmlp_bwd_kernel(BwdArgs a) {
+__device__ __forceinline__ void grad_flush(float* slab_ptr, float* grad_ptr, bool accumulate, float v) {
+    if (slab_ptr) *slab_ptr = accumulate ? *slab_ptr + v : v;
+    else atomic_add_f32(grad_ptr, v);
+}
+
+template <int NIB, int NOB, int NW>
+__global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
+    constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int LD1 = a.Cin_pad + 4, LDT = a.Cout_pad + 4;
     float* xs = smem;                        // [Cin_pad][LDP]
     float* gys = xs + a.Cin_pad * LDP;       // [Cout_pad][LDP]
-    float* gxs = gys + a.Cout_pad * LDP;     // [Cin_pad][LDP]  cross-wave reduction of gx
-    float* w1s = gxs + a.Cin_pad * LDP;      // [Ch_pad][LD1]
+    float* w1s = gys + a.Cout_pad * LDP;     // [Ch_pad][LD1]
     float* w2ts = w1s + a.Ch_pad * LD1;      // [Ch_pad][LDT]   W2 transposed
     float* b1s = w2ts + a.Ch_pad * LDT;      // [Ch_pad]
-    float* tr = b1s + a.Ch_pad;              // [4 waves][2][16*20] transpose scratch
+    float* tr = b1s + a.Ch_pad;              // [NW waves][2][16*20] transpose scratch
 
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const int r = lane & 15, g = lane >> 4;
     const int b = blockIdx.x / a.tiles_per_sample;
     const int p0 = (blockIdx.x % a.tiles_per_sample) * PT;
 
-    for (int idx = tid; idx < a.Cin_pad * PT; idx += 256) {
-        const int c = idx / PT, p = idx % PT;
-        float v = 0.f;
-        if (c < a.Cin && p0 + p < a.P) {
-            const float* src = chan_ptr(a.x, b, c);
-            if (src) v = src[p0 + p];
-        }
-        xs[c * LDP + p] = v;
-        gxs[c * LDP + p] = 0.f;
-    }
+    MatLoad<4> l2;
+    MatLoad<4> l1;
+    const int n2 = matload_units(a.Cout, a.Ch, a.vec_w != 0, 4), n1 = matload_units(a.Ch, a.Cin, a.vec_w != 0, 4);
+    l2.issue(a.w2, n2);
+    l1.issue(a.w1, n1);
+    stage_pixels(xs, a.x, b, a.Cin, a.Cin_pad, p0, a.P, a.vec_x != 0);
     const bool has_gy = a.gy.base || a.gy.tab;
     const bool has_mse = a.pred.base || a.pred.tab;
-    for (int idx = tid; idx < a.Cout_pad * PT; idx += 256) {
-        const int c = idx / PT, p = idx % PT;
-        float v = 0.f;
-        if (c < a.Cout && p0 + p < a.P) {
-            if (has_gy) {
-                const float* src = chan_ptr(a.gy, b, c);
-                if (src) v = src[p0 + p];
+    if (has_gy && !has_mse) {
+        stage_pixels(gys, a.gy, b, a.Cout, a.Cout_pad, p0, a.P, a.vec_x != 0);
+    } else {
+        for (int idx = tid; idx < a.Cout_pad * PT; idx += NT) {
+            const int c = idx / PT, p = idx % PT;
+            float v = 0.f;
+            if (c < a.Cout && p0 + p < a.P) {
+                if (has_gy) {
+                    const float* src = chan_ptr(a.gy, b, c);
+                    if (src) v = src[p0 + p];
+                }
+                if (has_mse) {
+                    const float* pp = chan_ptr(a.pred, b, c);
+                    const float* tp = chan_ptr(a.target, b, c);
+                    v += a.mse_scale * (pp[p0 + p] - tp[p0 + p]);
+                }
             }
-            if (has_mse) {
-                const float* pp = chan_ptr(a.pred, b, c);
-                const float* tp = chan_ptr(a.target, b, c);
-                v += a.mse_scale * (pp[p0 + p] - tp[p0 + p]);
-            }
+            gys[c * LDP + p] = v;
         }
-        gys[c * LDP + p] = v;
     }
-    for (int idx = tid; idx < a.Ch_pad * a.Cin_pad; idx += 256) {
-        const int h = idx / a.Cin_pad, i = idx % a.Cin_pad;
-        w1s[h * LD1 + i] = (h < a.Ch && i < a.Cin) ? a.w1[h * a.Cin + i] : 0.f;
-    }
-    for (int idx = tid; idx < a.Ch_pad * a.Cout_pad; idx += 256) {
-        const int h = idx / a.Cout_pad, o = idx % a.Cout_pad;
-        w2ts[h * LDT + o] = (h < a.Ch && o < a.Cout) ? a.w2[o * a.Ch + h] : 0.f;
-    }
-    for (int idx = tid; idx < a.Ch_pad; idx += 256) b1s[idx] = idx < a.Ch ? a.b1[idx] : 0.f;
+    l2.commit<true>(w2ts, LDT, a.Ch, a.dCh, n2);
+    l1.commit<false>(w1s, LD1, a.Cin, a.dCin, n1);
+    stage_matrix_tail<true>(w2ts, LDT, a.w2, a.Cout, a.Ch, a.dCh, n2);
+    stage_matrix_tail<false>(w1s, LD1, a.w1, a.Ch, a.Cin, a.dCin, n1);
+    zero_padding(w1s, LD1, a.Ch, a.Cin, a.Ch_pad, a.Cin_pad);
+    zero_padding(w2ts, LDT, a.Ch, a.Cout, a.Ch_pad, a.Cout_pad);
+    for (int idx = tid; idx < a.Ch_pad; idx += NT) b1s[idx] = idx < a.Ch ? a.b1[idx] : 0.f;
     __syncthreads();
 
+    DLWP_STAMP(10);
     float* T = tr + (w * 2 + 0) * 320;
     float* T2 = tr + (w * 2 + 1) * 320;
     const int nhb = a.Ch_pad / 16;
@@ -196,7 +278,11 @@ __global__ __launch_bounds__(256) void pwmlp_bwd_kernel(BwdArgs a) {
 #pragma unroll
         for (int ib = 0; ib < NIB; ++ib) gxacc[pb][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int hb = w; hb < nhb; hb += 4) {
+    float* sl = a.slab ? a.slab + (long long)blockIdx.x * a.slab_stride : nullptr;
+    const long long o_gb1 = (long long)a.Ch * a.Cin, o_gw2 = o_gb1 + a.Ch;
+    const bool accum = sl && a.slab_accumulate != 0;
+    DLWP_STAMP(11);
+    for (int hb = w; hb < nhb; hb += NW) {
         f32x4 a1[NIB], w2t[NOB];
 #pragma unroll
         for (int kc = 0; kc < NIB; ++kc)
@@ -207,6 +293,27 @@ __global__ __launch_bounds__(256) void pwmlp_bwd_kernel(BwdArgs a) {
         float b1v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) b1v[j] = b1s[hb * 16 + 4 * g + j];
+        // prefetch this workgroup's running slab partials (read-modify-write accumulation across net calls)
+        float pgw2[NOB][4], pgw1[NIB][4], pgb1[4];
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int o = ob * 16 + 4 * g + j, h = hb * 16 + r;
+                pgw2[ob][j] = (accum && o < a.Cout && h < a.Ch) ? sl[o_gw2 + o * a.Ch + h] : 0.f;
+            }
+#pragma unroll
+        for (int ib = 0; ib < NIB; ++ib)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int h = hb * 16 + 4 * g + j, i = ib * 16 + r;
+                pgw1[ib][j] = (accum && h < a.Ch && i < a.Cin) ? sl[h * a.Cin + i] : 0.f;
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int h = hb * 16 + 4 * g + j;
+            pgb1[j] = (accum && r == 0 && h < a.Ch) ? sl[o_gb1 + h] : 0.f;
+        }
 
         f32x4 gw2acc[NOB], gw1acc[NIB];
         f32x4 gb1acc = {0.f, 0.f, 0.f, 0.f};
@@ -217,6 +324,7 @@ __global__ __launch_bounds__(256) void pwmlp_bwd_kernel(BwdArgs a) {
 
 #pragma unroll
         for (int pb = 0; pb < 4; ++pb) {
+            if (hb == w && pb == 0) DLWP_STAMP(12);
             // recompute hidden pre-activation z[h][p]
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -227,6 +335,7 @@ __global__ __launch_bounds__(256) void pwmlp_bwd_kernel(BwdArgs a) {
                 z = mfma16_chunk(a1[kc], b4, z);
             }
             f32x4 act, gz;
+            if (hb == w && pb == 0) DLWP_STAMP(13);
             // g_a[h][p] = sum_o W2[o][h] gy[o][p]
             f32x4 ga = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -243,6 +352,7 @@ __global__ __launch_bounds__(256) void pwmlp_bwd_kernel(BwdArgs a) {
                 gz[j] = ga[j] * gelu_grad_f(zz);
                 gb1acc[j] += gz[j];
             }
+            if (hb == w && pb == 0) DLWP_STAMP(14);
             // gx[i][p] += sum_h W1[h][i] gz[h][p]
 #pragma unroll
             for (int ib = 0; ib < NIB; ++ib) {
@@ -251,6 +361,7 @@ __global__ __launch_bounds__(256) void pwmlp_bwd_kernel(BwdArgs a) {
                 for (int s = 0; s < 4; ++s) a4[s] = w1s[(hb * 16 + 4 * g + s) * LD1 + ib * 16 + r];
                 gxacc[pb][ib] = mfma16_chunk(a4, gz, gxacc[pb][ib]);
             }
+            if (hb == w && pb == 0) DLWP_STAMP(15);
             // wave-private transposes: T[h][p] <- act, T2[h][p] <- gz
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -264,12 +375,14 @@ __global__ __launch_bounds__(256) void pwmlp_bwd_kernel(BwdArgs a) {
             const f32x4 gzT = *reinterpret_cast<const f32x4*>(&T2[r * 20 + 4 * g]);  // gz [h=r][p=4g+s]
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if (hb == w && pb == 0) DLWP_STAMP(16);
             // gW2[o][h] += sum_p gy[o][p] act[h][p]
 #pragma unroll
             for (int ob = 0; ob < NOB; ++ob) {
                 const f32x4 a4 = *reinterpret_cast<const f32x4*>(&gys[(ob * 16 + r) * LDP + pb * 16 + 4 * g]);
                 gw2acc[ob] = mfma16_chunk(a4, aT, gw2acc[ob]);
             }
+            if (hb == w && pb == 0) DLWP_STAMP(17);
             // gW1[h][i] += sum_p gz[h][p] x[i][p]
 #pragma unroll
             for (int ib = 0; ib < NIB; ++ib) {
@@ -277,20 +390,27 @@ __global__ __launch_bounds__(256) void pwmlp_bwd_kernel(BwdArgs a) {
                 gw1acc[ib] = mfma16_chunk(gzT, b4, gw1acc[ib]);
             }
         }
-        // flush this hidden block's parameter gradients
+        if (hb == w) DLWP_STAMP(18);
+        // flush this hidden block's parameter gradients (slab values were prefetched at the loop top)
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int o = ob * 16 + 4 * g + j, h = hb * 16 + r;
-                if (o < a.Cout && h < a.Ch) atomic_add_f32(&a.gw2[o * a.Ch + h], gw2acc[ob][j]);
+                if (o < a.Cout && h < a.Ch) {
+                    if (sl) sl[o_gw2 + o * a.Ch + h] = pgw2[ob][j] + gw2acc[ob][j];
+                    else atomic_add_f32(a.gw2 + o * a.Ch + h, gw2acc[ob][j]);
+                }
             }
 #pragma unroll
         for (int ib = 0; ib < NIB; ++ib)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int h = hb * 16 + 4 * g + j, i = ib * 16 + r;
-                if (h < a.Ch && i < a.Cin) atomic_add_f32(&a.gw1[h * a.Cin + i], gw1acc[ib][j]);
+                if (h < a.Ch && i < a.Cin) {
+                    if (sl) sl[h * a.Cin + i] = pgw1[ib][j] + gw1acc[ib][j];
+                    else atomic_add_f32(a.gw1 + h * a.Cin + i, gw1acc[ib][j]);
+                }
             }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -300,12 +420,22 @@ __global__ __launch_bounds__(256) void pwmlp_bwd_kernel(BwdArgs a) {
             v += __shfl_xor(v, 4);
             v += __shfl_xor(v, 8);
             const int h = hb * 16 + 4 * g + j;
-            if (r == 0 && h < a.Ch) atomic_add_f32(&a.gb1[h], v);
+            if (r == 0 && h < a.Ch) {
+                if (sl) sl[o_gb1 + h] = pgb1[j] + v;
+                else atomic_add_f32(a.gb1 + h, v);
+            }
         }
+        if (hb == w) DLWP_STAMP(19);
     }
 
-    // cross-wave reduction of gx through LDS
+    DLWP_STAMP(20);
+    // cross-wave reduction of gx: every wave parks its [Cin_pad][64] partial tile in LDS (the weight
+    // images are dead by now and are reused), then all threads sum the NW tiles.  (LDS float atomics
+    // run at <1 lane-op per clock per CU on gfx950 and were the slowest phase of this kernel.)
     const bool want_gx = a.gx.base || a.gx.tab;
+    DLWP_STAMP(20);
+    __syncthreads();
+    float* red = w1s;  // [NW][Cin_pad][LDP]
     if (want_gx) {
 #pragma unroll
         for (int pb = 0; pb < 4; ++pb)
@@ -313,17 +443,30 @@ __global__ __launch_bounds__(256) void pwmlp_bwd_kernel(BwdArgs a) {
             for (int ib = 0; ib < NIB; ++ib)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    atomicAdd(&gxs[(ib * 16 + 4 * g + j) * LDP + pb * 16 + r], gxacc[pb][ib][j]);
+                    red[(w * a.Cin_pad + ib * 16 + 4 * g + j) * LDP + pb * 16 + r] = gxacc[pb][ib][j];
     }
+    DLWP_STAMP(21);
     __syncthreads();
+    DLWP_STAMP(22);
     if (want_gx) {
-        for (int idx = tid; idx < a.Cin * PT; idx += 256) {
-            const int c = idx / PT, p = idx % PT;
-            if (p0 + p < a.P) {
-                float* dst = chan_ptr(a.gx, b, c);
-                if (dst) {
-                    const float v = gxs[c * LDP + p];
-                    dst[p0 + p] = a.gx_accumulate ? dst[p0 + p] + v : v;
+        for (int u = tid; u < a.Cin * (PT / 4); u += NT) {
+            const int c = u / (PT / 4), q = u % (PT / 4), p = p0 + 4 * q;
+            float* dst = chan_ptr(a.gx, b, c);
+            if (dst && p < a.P) {
+                float4 v = *reinterpret_cast<const float4*>(&red[c * LDP + 4 * q]);
+#pragma unroll
+                for (int w2 = 1; w2 < NW; ++w2) {
+                    const float4 pv = *reinterpret_cast<const float4*>(&red[(w2 * a.Cin_pad + c) * LDP + 4 * q]);
+                    v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
+                }
+                if (a.vec_x) {
+                    float4* d4 = reinterpret_cast<float4*>(dst + p);
+                    if (a.gx_accumulate) { const float4 o = *d4; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                    *d4 = v;
+                } else {
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+                    for (int k = 0; k < 4; ++k)
+                        if (p + k < a.P) dst[p + k] = a.gx_accumulate ? dst[p + k] + vv[k] : vv[k];
                 }
             }
         }
@@ -331,7 +474,30 @@ __global__ __launch_bounds__(256) void pwmlp_bwd_kernel(BwdArgs a) {
     if (tid < a.Cout) {
         float s = 0.f;
         for (int p = 0; p < PT; ++p) s += gys[tid * LDP + p];
-        atomic_add_f32(&a.gb2[tid], s);
+        const long long o_gb2 = (long long)a.Ch * a.Cin + a.Ch + (long long)a.Cout * a.Ch;
+        grad_flush(sl ? sl + o_gb2 + tid : nullptr, a.gb2 + tid, accum, s);
+    }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+template <typename V>
+bool view_vec_ok(const V& v) {
+    if (v.tab) return true;  // table views are built by the trainer from 16-byte aligned planes
+    if (!v.base) return true;
+    return aligned16(v.base) && v.bstride % 4 == 0 && v.cstride % 4 == 0;
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int nslab, long long stride,
+                                                          float* gw1, long long n1, float* gb1, long long n2,
+                                                          float* gw2, long long n3, float* gb2, long long n4) {
+    const long long n = n1 + n2 + n3 + n4;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256) {
+        float acc = 0.f;
+#pragma unroll 8
+        for (int s = 0; s < nslab; ++s) acc += slab[s * stride + idx];
+        float* dst = idx < n1 ? gw1 + idx : idx < n1 + n2 ? gb1 + (idx - n1)
+                   : idx < n1 + n2 + n3 ? gw2 + (idx - n1 - n2) : gb2 + (idx - n1 - n2 - n3);
+        *dst += acc;
     }
 }
 
@@ -353,16 +519,22 @@ int dlwp_pwmlp_fwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, 
     a.B = B; a.Cin = Cin; a.Ch = Ch; a.Cout = Cout; a.P = P;
     a.tiles_per_sample = ceil_div(P, PT);
     a.Cin_pad = round_up(Cin, 16); a.Ch_pad = round_up(Ch, 16); a.Cout_pad = round_up(Cout, 16);
+    a.vec_w = aligned16(w1) && aligned16(w2);
+    a.dCin = make_fastdiv(Cin); a.dCh = make_fastdiv(Ch);
+    a.vec_x = P % 4 == 0 && view_vec_ok(a.x);
     const int nob = a.Cout_pad / 16;
     DLWP_REQUIRE(nob <= 4 && a.Cin_pad <= 64, DLWP_E_UNSUPPORTED,
                  "pwmlp_fwd: Cin<=64 and Cout<=64 supported (got %d, %d)", Cin, Cout);
+    a.vec_x = a.vec_x && view_vec_ok(a.y) && view_vec_ok(a.res);
     const size_t lds = sizeof(float) * ((size_t)a.Cin_pad * LDP + (size_t)a.Ch_pad * (a.Cin_pad + 4) +
-                                        (size_t)a.Cout_pad * (a.Ch_pad + 4) + a.Ch_pad + a.Cout_pad);
-    const dim3 grid(B * a.tiles_per_sample), block(256);
+                                        (size_t)a.Cout_pad * (a.Ch_pad + 4) + a.Ch_pad + a.Cout_pad +
+                                        (size_t)(FWD_WAVES / 4) * a.Cout_pad * LDP);
+    constexpr int NW = FWD_WAVES;
+    const dim3 grid(B * a.tiles_per_sample), block(NW * 64);
     int rc;
-#define LAUNCH(N)                                                         \
-    if ((rc = set_lds(pwmlp_fwd_kernel<N>, lds)) != DLWP_OK) return rc;   \
-    hipLaunchKernelGGL(pwmlp_fwd_kernel<N>, grid, block, lds, stream, a);
+#define LAUNCH(N)                                                             \
+    if ((rc = set_lds(pwmlp_fwd_kernel<N, NW>, lds)) != DLWP_OK) return rc;   \
+    hipLaunchKernelGGL((pwmlp_fwd_kernel<N, NW>), grid, block, lds, stream, a);
     switch (nob) {
         case 1: LAUNCH(1) break;
         case 2: LAUNCH(2) break;
@@ -377,8 +549,8 @@ int dlwp_pwmlp_fwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, 
 int dlwp_pwmlp_bwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, const float* w2,
                       const dlwp_chan_src* gy, const dlwp_chan_src* pred, const dlwp_chan_src* target,
                       float mse_scale, const dlwp_chan_dst* gx, int gx_accumulate, float* gw1,
-                      float* gb1, float* gw2, float* gb2, int B, int Cin, int Ch, int Cout, int P,
-                      hipStream_t stream) {
+                      float* gb1, float* gw2, float* gb2, float* slab, int slab_accumulate, int B, int Cin,
+                      int Ch, int Cout, int P, hipStream_t stream) {
     DLWP_REQUIRE(B > 0 && Cin > 0 && Ch > 0 && Cout > 0 && P > 0, DLWP_E_INVALID,
                  "pwmlp_bwd: non-positive dimension");
     BwdArgs a{};
@@ -392,17 +564,24 @@ int dlwp_pwmlp_bwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, 
     a.B = B; a.Cin = Cin; a.Ch = Ch; a.Cout = Cout; a.P = P;
     a.tiles_per_sample = ceil_div(P, PT);
     a.Cin_pad = round_up(Cin, 16); a.Ch_pad = round_up(Ch, 16); a.Cout_pad = round_up(Cout, 16);
+    a.slab = slab; a.slab_stride = dlwp_pwmlp_slab_stride(Cin, Ch, Cout); a.slab_accumulate = slab_accumulate;
+    a.vec_w = aligned16(w1) && aligned16(w2);
+    a.dCin = make_fastdiv(Cin); a.dCh = make_fastdiv(Ch);
+    a.vec_x = P % 4 == 0 && view_vec_ok(a.x) && view_vec_ok(a.gy);
     const int nib = a.Cin_pad / 16, nob = a.Cout_pad / 16;
     DLWP_REQUIRE(nib <= 4 && nob <= 4, DLWP_E_UNSUPPORTED,
                  "pwmlp_bwd: Cin<=64 and Cout<=64 supported (got %d, %d)", Cin, Cout);
-    const size_t lds = sizeof(float) * ((size_t)2 * a.Cin_pad * LDP + (size_t)a.Cout_pad * LDP +
-                                        (size_t)a.Ch_pad * (a.Cin_pad + 4) +
-                                        (size_t)a.Ch_pad * (a.Cout_pad + 4) + a.Ch_pad + 4 * 2 * 320);
-    const dim3 grid(B * a.tiles_per_sample), block(256);
+    size_t wimg = (size_t)a.Ch_pad * (a.Cin_pad + 4) + (size_t)a.Ch_pad * (a.Cout_pad + 4) + a.Ch_pad +
+                  BWD_WAVES * 2 * 320;
+    const size_t red = (size_t)BWD_WAVES * a.Cin_pad * LDP;  // gx partial tiles alias the weight images
+    if (wimg < red) wimg = red;
+    const size_t lds = sizeof(float) * ((size_t)a.Cin_pad * LDP + (size_t)a.Cout_pad * LDP + wimg);
+    constexpr int NW = BWD_WAVES;
+    const dim3 grid(B * a.tiles_per_sample), block(NW * 64);
     int rc;
-#define LAUNCH(I, O)                                                       \
-    if ((rc = set_lds(pwmlp_bwd_kernel<I, O>, lds)) != DLWP_OK) return rc; \
-    hipLaunchKernelGGL((pwmlp_bwd_kernel<I, O>), grid, block, lds, stream, a);
+#define LAUNCH(I, O)                                                           \
+    if ((rc = set_lds(pwmlp_bwd_kernel<I, O, NW>, lds)) != DLWP_OK) return rc; \
+    hipLaunchKernelGGL((pwmlp_bwd_kernel<I, O, NW>), grid, block, lds, stream, a);
 #define ROW(I)                       \
     switch (nob) {                   \
         case 1: LAUNCH(I, 1) break;  \
@@ -421,3 +600,38 @@ int dlwp_pwmlp_bwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, 
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }
+
+long long dlwp_pwmlp_slab_stride(int Cin, int Ch, int Cout) {
+    const long long n = (long long)Ch * Cin + Ch + (long long)Cout * Ch + Cout;
+    return (n + 3) & ~3LL;
+}
+
+int dlwp_pwmlp_slab_count(int B, int P) { return B * ceil_div(P, PT); }
+
+int dlwp_slab_reduce(const float* slab, int nslab, long long stride, float* d1, long long n1, float* d2, long long n2,
+                     float* d3, long long n3, float* d4, long long n4, hipStream_t stream) {
+    const long long n = n1 + n2 + n3 + n4;
+    const int grid = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid), dim3(256), 0, stream, slab, nslab, stride, d1, n1, d2, n2, d3,
+                       n3, d4, n4);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+int dlwp_pwmlp_slab_reduce(const float* slab, int nslab, int Cin, int Ch, int Cout, float* gw1, float* gb1,
+                           float* gw2, float* gb2, hipStream_t stream) {
+    const long long n1 = (long long)Ch * Cin, n2 = Ch, n3 = (long long)Cout * Ch, n4 = Cout;
+    const long long n = n1 + n2 + n3 + n4;
+    const int grid = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid), dim3(256), 0, stream, slab, nslab,
+                       dlwp_pwmlp_slab_stride(Cin, Ch, Cout), gw1, n1, gb1, n2, gw2, n3, gb2, n4);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+#ifdef DLWP_STAMPS
+extern "C" int dlwp_debug_stamps_pwmlp(unsigned long long* host_out) {
+    DLWP_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dlwp_stamps), sizeof(unsigned long long) * 32));
+    return DLWP_OK;
+}
+#endif

@@ -189,5 +189,32 @@ extern "C" int dlwp_pwmlp_bwd(const float* x, const float* w1, const float* b1, 
     dlwp_chan_src gys{gy, (long long)Cout * P, P, nullptr, nullptr};
     dlwp_chan_dst gxd{gx, (long long)Cin * P, P, nullptr, nullptr};
     return dlwp_pwmlp_bwd_ex(&xs, w1, b1, w2, &gys, nullptr, nullptr, 0.f, gx ? &gxd : nullptr, 0, gw1, gb1, gw2,
-                             gb2, B, Cin, Ch, Cout, P, (hipStream_t)stream);
+                             gb2, nullptr, 0, B, Cin, Ch, Cout, P, (hipStream_t)stream);
+}
+
+// ---- debug: a chain of n dependent empty kernels (measures the per-kernel floor of a stream / graph)
+namespace { __global__ void null_kernel(int* p) { if (p && threadIdx.x == 1024) *p = 0; } }
+extern "C" int dlwp_debug_null_kernels(int n, int blocks, void* stream) {
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(null_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, nullptr);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+// ---- debug: effective shader clock during a short kernel: out[0]=delta s_memtime, out[1]=delta s_memrealtime (100 MHz)
+namespace {
+__global__ void clock_probe_kernel(unsigned long long* out, int iters) {
+    float x = threadIdx.x * 1e-3f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) x = x * 1.0001f + 0.5f;
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
+    if (x == 12345.678f) out[2] = 1;
+}
+}
+extern "C" int dlwp_debug_clock_probe(unsigned long long* out, int iters, int blocks, void* stream) {
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
 }

@@ -163,6 +163,11 @@ int dlwp_fno_trainer_backward(dlwp_fno_trainer* tr, const float* grad_out, void*
 /* use_graph!=0 captures the sequence into a hipGraph on first use and replays it.        */
 int dlwp_fno_trainer_fwd_bwd(dlwp_fno_trainer* tr, int use_graph, void* stream);
 
+/* debug: enqueue n dependent empty kernels of `blocks` workgroups (per-kernel floor probe)   */
+int dlwp_debug_null_kernels(int n, int blocks, void* stream);
+/* debug: out[0] = shader-clock ticks, out[1] = 100 MHz ticks spent in a dependent-FMA loop   */
+int dlwp_debug_clock_probe(unsigned long long* out, int iters, int blocks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
