@@ -19,7 +19,6 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 WORKLOAD = dict(name="nsbench TFNO2DModule 64x64 NS rollout (BASELINE configs[1])",
                 n_modes=[12, 12], in_channels=1, hidden_channels=32, lifting_channels=256,
                 projection_channels=256, out_channels=1, n_layers=4, context_size=10,
@@ -39,55 +38,65 @@ def parse():
     return ap.parse_args()
 
 
-def pwmlp_bwd_flops(B, HW, Cin, Ch, Cout):
-    """algorithmic FLOPs of one projection/lifting backward launch:
-    recompute W1 x, W2^T gy, W1^T gz, gy.act^T, gz.x^T -> 2*P*Ch*(3*Cin + 2*Cout)"""
-    return 2.0 * B * HW * Ch * (3 * Cin + 2 * Cout)
+PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
-def roofline_probe(device, B, reps=200):
-    """Time the dominant kernel (projection backward: pwmlp_bwd<2,1>, the same instantiation
-    and launch geometry the captured step uses) with HIP events on the launch stream."""
+def spatial_fwd_bytes(B, C, H, W, m1, m2c):
+    """algorithmic HBM bytes of one forward `spatial` launch (kernel table): read the
+    input field, write the pre-activation field, read the mixed modes, write the next block's row
+    spectrum, read skip weights + bias."""
+    field = 4.0 * B * C * H * W
+    return 2 * field + 8.0 * B * m1 * m2c * C + 8.0 * B * H * m2c * C + 4.0 * (C * C + C)
+
+
+def roofline_probe(device, B, reps=300):
+    """Time the dominant kernel of the step (rocprof: fno_spatial_kernel<2,1>, ~35% of GPU time; same
+    instantiation, grid and fused stages as inside the captured step) with HIP events on its stream."""
+    import ctypes as C_
     import torch
     from dlwp_benchmark_amd import lib as L
     lib = L.load()
     w = WORKLOAD
-    HW, Cin, Ch, Cout = w["H"] * w["W"], w["hidden_channels"], w["projection_channels"], w["out_channels"]
+    C, H, W = w["hidden_channels"], w["H"], w["W"]
+    m1, m2c = w["n_modes"][0], w["n_modes"][1] // 2 + 1
+    plan = C_.c_void_p()
+    L.check(lib.dlwp_fno_plan_create(C, H, W, m1, m2c, C_.byref(plan)))
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(B, Cin, HW, generator=g).to(device)
-    w1 = (torch.randn(Ch, Cin, generator=g) / Cin ** 0.5).to(device)
-    b1 = torch.zeros(Ch, device=device)
-    w2 = (torch.randn(Cout, Ch, generator=g) / Ch ** 0.5).to(device)
-    gy = torch.randn(B, Cout, HW, generator=g).to(device)
-    gx = torch.empty_like(x)
-    gw1, gb1, gw2, gb2 = torch.zeros_like(w1), torch.zeros_like(b1), torch.zeros_like(w2), torch.zeros(Cout, device=device)
-    stream = torch.cuda.current_stream()
+    x = torch.randn(B, C, H, W, generator=g).to(device)
+    spec = (torch.randn(B, m1, m2c, C, 2, generator=g) * 0.1).to(device)
+    wskip = (torch.randn(C, C, generator=g) / C ** 0.5).to(device)
+    bias = torch.zeros(C, device=device)
+    pre = torch.empty_like(x)
+    x1 = torch.empty(B, H, m2c, C, 2, device=device)
+    stream = torch.cuda.Stream()
 
     def launch():
-        L.check(lib.dlwp_pwmlp_bwd(L.ptr(x), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(gy), L.ptr(gx), L.ptr(gw1),
-                                   L.ptr(gb1), L.ptr(gw2), L.ptr(gb2), B, Cin, Ch, Cout, HW, stream.cuda_stream))
-    for _ in range(20):
-        launch()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record(stream)
-    for _ in range(reps):
-        launch()
-    e1.record(stream)
-    torch.cuda.synchronize()
+        L.check(lib.dlwp_fno_spatial_fwd_probe(plan, L.ptr(x), L.ptr(spec), L.ptr(wskip), L.ptr(bias), L.ptr(pre),
+                                               L.ptr(x1), B, stream.cuda_stream))
+    with torch.cuda.stream(stream):
+        for _ in range(20):
+            launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(reps):
+            launch()
+        e1.record(stream)
+        torch.cuda.synchronize()
+    lib.dlwp_fno_plan_destroy(plan)
     sec = e0.elapsed_time(e1) * 1e-3 / reps
-    flops = pwmlp_bwd_flops(B, HW, Cin, Ch, Cout)
-    achieved = flops / sec / 1e12
+    nbytes = spatial_fwd_bytes(B, C, H, W, m1, m2c)
+    achieved = nbytes / sec / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("pwmlp_bwd_kernel<2,1>")
+            traffic = json.load(open(tpath)).get("fno_spatial_kernel<2,1>")
         except Exception:
             traffic = None
-    return {"bound": "mfma", "kernel": "pwmlp_bwd_kernel<2,1> (projection backward)",
-            "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "flops_per_launch": flops,
+    return {"bound": "hbm", "kernel": "fno_spatial_kernel<2,1> (forward, inner block)",
+            "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(achieved / PEAK_HBM_GBS, 4), "bytes_per_launch": nbytes,
             "us_per_launch": round(sec * 1e6, 3), "traffic": traffic}
 
 
@@ -97,7 +106,9 @@ def cpu_baseline(B, budget_s):
     import torch
     from oracle import fno_ref
     w = WORKLOAD
-    torch.set_num_threads(os.cpu_count() or 1)
+    # more threads than this slow the small FNO ops down (measured on the 256-core GPU host: 8 -> 9.8,
+    # 16 -> 10.8, 32 -> 4.7, 64 -> 1.5 samples/s)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
     net = fno_ref.FNO(w["n_modes"], w["in_channels"] * w["context_size"], w["hidden_channels"],
                       w["lifting_channels"], w["projection_channels"], w["out_channels"], w["n_layers"], seed=1234)
     net.requires_grad_(True)

@@ -750,3 +750,14 @@ extern "C" int dlwp_debug_stamps_fno(unsigned long long* host_out) {
 #endif
 
 long long dlwp_fno_gslab_stride(int C) { return ((long long)C * C + C + 3) & ~3LL; }
+
+// one forward `spatial` launch exactly as the rollout issues it for an inner block (GELU on load,
+// fused rows-DFT of gelu(result)); exposed so bench.py can time the dominant kernel with HIP events.
+extern "C" int dlwp_fno_spatial_fwd_probe(const dlwp_fno_plan* p, const float* x, const float* spec, const float* wskip,
+                                          const float* bias, float* pre, float* x1_out, int B, void* stream) {
+    DLWP_REQUIRE(p && x && spec && wskip && pre && x1_out && B > 0, DLWP_E_INVALID, "spatial_fwd_probe: NULL argument");
+    dlwp_fno_spatial_args s{};
+    s.tin = x; s.act_tin = 1; s.spec = reinterpret_cast<const float2*>(spec); s.wskip = wskip; s.bias = bias;
+    s.out = pre; s.x1_out = reinterpret_cast<float2*>(x1_out); s.x1_act = 1; s.B = B;
+    return dlwp_fno_spatial(p, &s, static_cast<hipStream_t>(stream));
+}

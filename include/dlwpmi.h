@@ -163,6 +163,12 @@ int dlwp_fno_trainer_backward(dlwp_fno_trainer* tr, const float* grad_out, void*
 /* use_graph!=0 captures the sequence into a hipGraph on first use and replays it.        */
 int dlwp_fno_trainer_fwd_bwd(dlwp_fno_trainer* tr, int use_graph, void* stream);
 
+/* bench probe: ONE forward `spatial` launch of an inner FNO block as the rollout issues it     */
+/* (x = previous pre-activation, GELU on load; spec = [B][m1][m2c][C][2] mixed modes; fused      */
+/* W-axis DFT of gelu(pre) into x1_out [B][H][m2c][C][2]).                                       */
+int dlwp_fno_spatial_fwd_probe(const dlwp_fno_plan* plan, const float* x, const float* spec,
+                               const float* wskip, const float* bias, float* pre, float* x1_out,
+                               int B, void* stream);
 /* debug: enqueue n dependent empty kernels of `blocks` workgroups (per-kernel floor probe)   */
 int dlwp_debug_null_kernels(int n, int blocks, void* stream);
 /* debug: out[0] = shader-clock ticks, out[1] = 100 MHz ticks spent in a dependent-FMA loop   */

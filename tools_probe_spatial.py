@@ -1,0 +1,5 @@
+"""Launch only the roofline probe kernel (forward inner-block `spatial`) for PMC passes."""
+import sys
+sys.path.insert(0, '.')
+import torch, bench
+print(bench.roofline_probe(torch.device('cuda:0'), 4, reps=50))
