@@ -1,4 +1,5 @@
 """Mirror of src/nsbench/models/__init__.py for the hot-path models."""
 from .fno import FNOModule, TFNO2DModule  # noqa: F401
+from .fourcastnet import AFNONet, FourCastNet  # noqa: F401
 
-__all__ = ["FNOModule", "TFNO2DModule"]
+__all__ = ["FNOModule", "TFNO2DModule", "AFNONet", "FourCastNet"]

@@ -1,0 +1,198 @@
+"""Drop-in counterpart of the reference's FourCastNet (AFNO) rollout model.
+
+Reference (file:line under /root/reference/src/nsbench/models/fourcastnet/fourcastnet.py):
+  AFNO2D :59-126, Mlp :40-56, Block :129-165, PatchEmbed :303-316, AFNONet :186-300.
+Same constructor kwargs, `forward(x[B,T,D,H,W], teacher_forcing_steps)`, parameter names and shapes
+(state_dict keys patch_embed.proj, pos_embed, blocks.{i}.{norm1,filter.{w1,b1,w2,b2},norm2,mlp.{fc1,fc2}},
+norm, head) so reference checkpoints load.
+
+The spectral token mixer (AFNO2D: rfft2 -> block-diagonal complex MLP -> softshrink -> irfft2 ->
+residual) runs as one hand-written HIP kernel per direction (libdlwpmi dlwp_afno2d_fwd/bwd).
+Round-1 scope: LayerNorm, the token MLP, patch embedding and head still go through torch's library
+GEMMs (DESIGN.md "next").
+"""
+from functools import partial
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import lib as L
+
+
+class _AFNO2DFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, nb, lam, frac):
+        lib = L.load()
+        B, H, W, C = x.shape
+        x = x.contiguous().float()
+        n = lib.dlwp_afno2d_save_elems(B, H, W, C, nb, frac)
+        if n < 0:
+            L.check(-3)
+        xsave = torch.empty(n, device=x.device)
+        y = torch.empty_like(x)
+        L.check(lib.dlwp_afno2d_fwd(L.ptr(x), L.ptr(w1.contiguous()), L.ptr(b1.contiguous()), L.ptr(w2.contiguous()),
+                                    L.ptr(b2.contiguous()), L.ptr(y), L.ptr(xsave), B, H, W, C, nb, lam, frac, L.stream()))
+        ctx.save_for_backward(xsave, w1, b1, w2, b2)
+        ctx.cfg = (B, H, W, C, nb, lam, frac)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = L.load()
+        xsave, w1, b1, w2, b2 = ctx.saved_tensors
+        B, H, W, C, nb, lam, frac = ctx.cfg
+        gy = gy.contiguous().float()
+        gx = torch.empty_like(gy)
+        gw1, gb1, gw2, gb2 = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in (w1, b1, w2, b2)]
+        L.check(lib.dlwp_afno2d_bwd(L.ptr(gy), L.ptr(xsave), L.ptr(w1.contiguous()), L.ptr(b1.contiguous()),
+                                    L.ptr(w2.contiguous()), L.ptr(b2.contiguous()), L.ptr(gx), L.ptr(gw1), L.ptr(gb1),
+                                    L.ptr(gw2), L.ptr(gb2), B, H, W, C, nb, lam, frac, L.stream()))
+        return gx, gw1, gb1, gw2, gb2, None, None, None
+
+
+class AFNO2D(nn.Module):
+    def __init__(self, hidden_size, num_blocks=8, sparsity_threshold=0.01, hard_thresholding_fraction=1,
+                 hidden_size_factor=1):
+        super().__init__()
+        assert hidden_size % num_blocks == 0, f"hidden_size {hidden_size} should be divisble by num_blocks {num_blocks}"
+        if hidden_size_factor != 1:
+            raise NotImplementedError("hidden_size_factor != 1 is not on the MI355X hot path")
+        self.hidden_size, self.num_blocks = hidden_size, num_blocks
+        self.block_size = hidden_size // num_blocks
+        self.sparsity_threshold = sparsity_threshold
+        self.hard_thresholding_fraction = hard_thresholding_fraction
+        self.scale = 0.02
+        bs = self.block_size
+        self.w1 = nn.Parameter(self.scale * torch.randn(2, num_blocks, bs, bs))
+        self.b1 = nn.Parameter(self.scale * torch.randn(2, num_blocks, bs))
+        self.w2 = nn.Parameter(self.scale * torch.randn(2, num_blocks, bs, bs))
+        self.b2 = nn.Parameter(self.scale * torch.randn(2, num_blocks, bs))
+
+    def forward(self, x):
+        dtype = x.dtype
+        y = _AFNO2DFn.apply(x, self.w1, self.b1, self.w2, self.b2, self.num_blocks, float(self.sparsity_threshold),
+                            float(self.hard_thresholding_fraction))
+        return y.type(dtype)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+    def forward(self, x):
+        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+
+
+class Block(nn.Module):
+    def __init__(self, dim, mlp_ratio=4., drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm,
+                 double_skip=True, num_blocks=8, sparsity_threshold=0.01, hard_thresholding_fraction=1.0):
+        super().__init__()
+        if drop_path > 0.:
+            raise NotImplementedError("stochastic depth is not on the MI355X hot path (configs use 0.0)")
+        self.norm1 = norm_layer(dim)
+        self.filter = AFNO2D(dim, num_blocks, sparsity_threshold, hard_thresholding_fraction)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.double_skip = double_skip
+
+    def forward(self, x):
+        residual = x
+        x = self.filter(self.norm1(x))
+        if self.double_skip:
+            x = x + residual
+            residual = x
+        x = self.mlp(self.norm2(x))
+        return x + residual
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size=(224, 224), patch_size=(16, 16), in_chans=3, embed_dim=768):
+        super().__init__()
+        self.num_patches = (img_size[1] // patch_size[1]) * (img_size[0] // patch_size[0])
+        self.img_size, self.patch_size = img_size, patch_size
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        assert H == self.img_size[0] and W == self.img_size[1], \
+            f"Input image size ({H}*{W}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."
+        return self.proj(x).flatten(2).transpose(1, 2)
+
+
+class AFNONet(nn.Module):
+    def __init__(self, img_height=720, img_width=1440, patch_size=(16, 16), in_chans=2, out_chans=2, embed_dim=768,
+                 depth=12, mlp_ratio=4., drop_rate=0., drop_path_rate=0., num_blocks=16, sparsity_threshold=0.01,
+                 hard_thresholding_fraction=1.0, context_size: int = 1, **kwargs):
+        super().__init__()
+        self.img_size = (img_height, img_width)
+        self.patch_size = tuple(patch_size)
+        self.in_chans = in_chans * context_size
+        self.out_chans = out_chans
+        self.num_features = self.embed_dim = embed_dim
+        self.num_blocks = num_blocks
+        self.context_size = context_size
+        norm_layer = partial(nn.LayerNorm, eps=1e-6)
+        self.patch_embed = PatchEmbed(self.img_size, self.patch_size, self.in_chans, embed_dim)
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches, embed_dim))
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        self.h = self.img_size[0] // self.patch_size[0]
+        self.w = self.img_size[1] // self.patch_size[1]
+        self.blocks = nn.ModuleList([
+            Block(dim=embed_dim, mlp_ratio=mlp_ratio, drop=drop_rate, drop_path=0.0, norm_layer=norm_layer,
+                  num_blocks=num_blocks, sparsity_threshold=sparsity_threshold,
+                  hard_thresholding_fraction=hard_thresholding_fraction) for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)  # constructed but unused, as in the reference (:228, :251-261)
+        self.head = nn.Linear(embed_dim, self.out_chans * self.patch_size[0] * self.patch_size[1], bias=False)
+        nn.init.trunc_normal_(self.pos_embed, std=.02)
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def forward_features(self, x):
+        B = x.shape[0]
+        x = self.pos_drop(self.patch_embed(x) + self.pos_embed)
+        x = x.reshape(B, self.h, self.w, self.embed_dim)
+        for blk in self.blocks:
+            x = blk(x)
+        return x
+
+    def forward(self, x, teacher_forcing_steps: int = 50):
+        outs, out = [], None
+        ph, pw = self.patch_size
+        for t in range(x.shape[1]):
+            if t < teacher_forcing_steps:
+                x_t_in = x[:, max(0, t - (self.context_size - 1)):t + 1]
+            else:
+                if self.context_size == 0:
+                    x_t_in = out
+                else:
+                    ts = max(0, (teacher_forcing_steps - t - 1) + self.context_size)
+                    x_obs = x[:, teacher_forcing_steps - ts:teacher_forcing_steps]
+                    x_out = torch.stack(outs[-(self.context_size - ts):], dim=1)
+                    x_t_in = torch.cat([x_obs, x_out], dim=1)
+            if t < self.context_size - 1:
+                out = x_t_in[:, -1]
+            else:
+                B = x_t_in.shape[0]
+                x_t = self.head(self.forward_features(x_t_in.flatten(1, 2)))
+                x_t = x_t.reshape(B, self.h, self.w, ph, pw, self.out_chans).permute(0, 5, 1, 3, 2, 4)
+                out = x_t_in[:, -1] + x_t.reshape(B, self.out_chans, self.h * ph, self.w * pw)
+            outs.append(out)
+        return torch.stack(outs, dim=1)
+
+
+FourCastNet = AFNONet

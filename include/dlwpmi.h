@@ -163,6 +163,25 @@ int dlwp_fno_trainer_backward(dlwp_fno_trainer* tr, const float* grad_out, void*
 /* use_graph!=0 captures the sequence into a hipGraph on first use and replays it.        */
 int dlwp_fno_trainer_fwd_bwd(dlwp_fno_trainer* tr, int use_graph, void* stream);
 
+/* ------------------------------------------------------------------------------------ */
+/* AFNO2D spectral token mixer (FourCastNet): y = x + irfft2(softshrink(MLP_blockdiag(    */
+/* rfft2(x)))) on channels-last x [B,H,W,C].  Replaces AFNO2D.forward                     */
+/* nsbench/models/fourcastnet/fourcastnet.py:77-126 (dlwpbench twin :78-127), including   */
+/* its kept-mode window computed from H only (:92-93).  Parameter layouts are the         */
+/* reference's: w1,w2 [2,nb,bs,bs] (re/im), b1,b2 [2,nb,bs]; hidden_size_factor = 1.      */
+/* xsave: caller buffer of dlwp_afno2d_save_elems() floats holding the kept spectrum for   */
+/* the backward pass.  Round-1 limits: block size <= 16, H*kept_cols*bs <= 10240 (16x16,   */
+/* 32x64 grids); larger grids return DLWP_E_UNSUPPORTED.                                   */
+long long dlwp_afno2d_save_elems(int B, int H, int W, int C, int nb, float hard_thresholding_fraction);
+int dlwp_afno2d_fwd(const float* x, const float* w1, const float* b1, const float* w2,
+                    const float* b2, float* y, float* xsave, int B, int H, int W, int C, int nb,
+                    float sparsity_threshold, float hard_thresholding_fraction, void* stream);
+/* gx = d loss/d x (includes the residual path); gw1,gb1,gw2,gb2 are ACCUMULATED into.     */
+int dlwp_afno2d_bwd(const float* gy, const float* xsave, const float* w1, const float* b1,
+                    const float* w2, const float* b2, float* gx, float* gw1, float* gb1,
+                    float* gw2, float* gb2, int B, int H, int W, int C, int nb,
+                    float sparsity_threshold, float hard_thresholding_fraction, void* stream);
+
 /* bench probe: ONE forward `spatial` launch of an inner FNO block as the rollout issues it     */
 /* (x = previous pre-activation, GELU on load; spec = [B][m1][m2c][C][2] mixed modes; fused      */
 /* W-axis DFT of gelu(pre) into x1_out [B][H][m2c][C][2]).                                       */

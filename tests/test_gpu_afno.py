@@ -1,0 +1,80 @@
+"""GPU parity of the AFNO path against golden vectors captured from the reference's own classes
+(tests/golden/afno_golden.npz) and against the pinned oracle (oracle/afno_ref.py).
+Tolerance: 1e-4 relative (max-norm) forward, 5e-4 for gradients (fp32, north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import afno_ref
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "afno_golden.npz"))
+
+
+def t(name):
+    return torch.from_numpy(G[name])
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("tag", ["sq", "rect", "frac"])
+def test_afno2d_kernel_matches_reference_golden(cuda, tag):
+    from dlwp_benchmark_amd.nsbench.fourcastnet import AFNO2D
+    B, H, W, C, nb, frac100 = [int(v) for v in G[f"afno2d_{tag}_meta"]]
+    m = AFNO2D(C, num_blocks=nb, sparsity_threshold=0.01, hard_thresholding_fraction=frac100 / 100.0).to(cuda)
+    with torch.no_grad():
+        for n in ("w1", "b1", "w2", "b2"):
+            getattr(m, n).copy_(t(f"afno2d_{tag}_{n}"))
+    x = t(f"afno2d_{tag}_x").to(cuda).requires_grad_(True)
+    y = m(x)
+    assert rel(y, t(f"afno2d_{tag}_y")) <= 1e-4
+    y.backward(t(f"afno2d_{tag}_gy").to(cuda))
+    assert rel(x.grad, t(f"afno2d_{tag}_gx")) <= 5e-4
+    for n in ("w1", "b1", "w2", "b2"):
+        assert rel(getattr(m, n).grad, t(f"afno2d_{tag}_g{n}")) <= 5e-4, n
+
+
+def test_afno2d_kernel_matches_oracle_on_fresh_inputs(cuda):
+    from dlwp_benchmark_amd.nsbench.fourcastnet import AFNO2D
+    g = torch.Generator().manual_seed(21)
+    for (B, H, W, C, nb) in [(4, 16, 16, 64, 4), (2, 32, 64, 64, 4), (3, 8, 16, 24, 3)]:
+        m = AFNO2D(C, num_blocks=nb).to(cuda)
+        with torch.no_grad():
+            for p in m.parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+        x = torch.randn(B, H, W, C, generator=g)
+        gy = torch.randn(B, H, W, C, generator=g)
+        xr = x.clone().requires_grad_(True)
+        pr = [p.detach().cpu().clone().requires_grad_(True) for p in (m.w1, m.b1, m.w2, m.b2)]
+        yr = afno_ref.afno2d(xr, *pr, nb)
+        yr.backward(gy)
+        xd = x.to(cuda).requires_grad_(True)
+        y = m(xd)
+        y.backward(gy.to(cuda))
+        assert rel(y, yr) <= 1e-4, (B, H, W, C, nb)
+        assert rel(xd.grad, xr.grad) <= 5e-4
+        for got, ref in zip((m.w1, m.b1, m.w2, m.b2), pr):
+            assert rel(got.grad, ref.grad) <= 5e-4
+
+
+def test_afnonet_rollout_matches_reference_golden(cuda):
+    from dlwp_benchmark_amd import nsbench
+    net = nsbench.AFNONet(img_height=32, img_width=32, patch_size=(4, 4), in_chans=1, out_chans=1, embed_dim=32,
+                          depth=2, mlp_ratio=4.0, num_blocks=4, context_size=2, type="FourCastNet", name="t")
+    sd = {k[len("net_p_"):]: t(k) for k in G.files if k.startswith("net_p_")}
+    missing = net.load_state_dict(sd, strict=True)
+    net = net.to(cuda)
+    y = net(t("net_x").to(cuda), teacher_forcing_steps=3)
+    assert rel(y, t("net_y")) <= 1e-4
+    loss = torch.nn.functional.mse_loss(y, t("net_target").to(cuda))
+    assert abs(loss.item() - float(G["net_loss"])) <= 1e-4 * abs(float(G["net_loss"]))
+    loss.backward()
+    for n, p in net.named_parameters():
+        key = "net_g_" + n
+        if key in G.files:
+            assert rel(p.grad, t(key)) <= 1e-3, n
