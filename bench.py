@@ -155,14 +155,15 @@ def main():
                                  hidden_channels=w["hidden_channels"], lifting_channels=w["lifting_channels"],
                                  projection_channels=w["projection_channels"], out_channels=w["out_channels"],
                                  n_layers=w["n_layers"], context_size=w["context_size"]).to(device)
-    if world > 1:
-        dist.broadcast(model.flat_params.data, src=0)
+    from dlwp_benchmark_amd import ddp
+    ddp.broadcast_parameters(model.flat_params.data, src=0)
     opt = model.make_optimizer(lr=1e-3)
     # synthetic trajectories (seeded per rank: every rank trains on its own shard), resident in HBM
     g = torch.Generator().manual_seed(1234 + rank)
     u = torch.randn(B, w["T"] + 1, 1, w["H"], w["W"], generator=g).to(device)
     x, y = u[:, :-1].contiguous(), u[:, 1:].contiguous()
-    allreduce = (lambda gbuf: dist.all_reduce(gbuf, op=dist.ReduceOp.SUM)) if world > 1 else None
+    reducer = ddp.FlatGradAllReduce()          # one flat RCCL bucket per step (no-op at world 1)
+    allreduce = reducer if world > 1 else None
     scale = 1.0 / world
 
     def step():

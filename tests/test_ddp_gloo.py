@@ -1,0 +1,76 @@
+"""World-size-2 gloo test (CPU) of the data-parallel host logic: sharding, flat-bucket all-reduce and
+the 1/world scale give the single-process gradient ("2 ranks x b == 1 rank x 2b").
+Gradients themselves come from the CPU oracle here; on the GPU box the same reducer is fed by the HIP
+trainer (bench.py --gpus N)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dlwp_benchmark_amd import ddp
+from oracle import fno_ref
+
+CFG = dict(n_modes=[4, 4], D=1, hidden=8, lifting=16, projection=16, n_layers=2, ctx=2, tf=3, T=5, H=16, W=16)
+
+
+def _flat_grads(net):
+    return torch.cat([torch.view_as_real(p.grad).reshape(-1) if p.is_complex() else p.grad.reshape(-1)
+                      for p in net.parameters()])
+
+
+def _data(n):
+    g = torch.Generator().manual_seed(42)
+    return torch.randn(n, CFG["T"] + 3, CFG["D"], CFG["H"], CFG["W"], generator=g)
+
+
+def _grads_on(indices, epoch):
+    u = _data(8)
+    net = fno_ref.FNO(CFG["n_modes"], CFG["D"] * CFG["ctx"], CFG["hidden"], CFG["lifting"], CFG["projection"],
+                      CFG["D"], CFG["n_layers"], seed=7)
+    net.requires_grad_(True)
+    xs, ys = zip(*[ddp.ns_sample(u, int(i), epoch, CFG["T"] + 1) for i in indices])
+    fno_ref.train_step(net, torch.stack(xs), torch.stack(ys), CFG["tf"], CFG["ctx"])
+    return _flat_grads(net)
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    shard = ddp.shard_indices(8, epoch=3, rank=rank, world=world, batch=2)
+    g = _grads_on(shard[0], epoch=3)
+    scale = ddp.FlatGradAllReduce()(g)
+    if rank == 0:
+        torch.save({"grad": g * scale, "shard": shard}, out)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_rank_with_double_batch(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=False)
+    shards = [ddp.shard_indices(8, 3, r, 2, 2) for r in range(2)]
+    assert np.array_equal(got["shard"], shards[0])
+    ref = _grads_on(np.concatenate([shards[0][0], shards[1][0]]), epoch=3)
+    err = (got["grad"] - ref).abs().max() / ref.abs().max()
+    assert err < 1e-5, err
+
+
+def test_sharding_is_a_partition_with_equal_iteration_counts():
+    for world in (1, 2, 4, 8):
+        shards = [ddp.shard_indices(103, epoch=5, rank=r, world=world, batch=3) for r in range(world)]
+        assert len({s.shape for s in shards}) == 1                      # same number of iterations everywhere
+        flat = np.concatenate([s.reshape(-1) for s in shards])
+        assert len(np.unique(flat)) == len(flat)                         # no sample twice
+        assert set(flat) <= set(range(103))
+    # a sample's crop does not depend on the world size
+    assert ddp.crop_start(17, 2, 50, 20) == ddp.crop_start(17, 2, 50, 20)
+    a = ddp.epoch_permutation(10, 1)
+    assert sorted(a.tolist()) == list(range(10)) and not np.array_equal(a, ddp.epoch_permutation(10, 2))
