@@ -9,9 +9,9 @@ int dlwp_pwmlp_fwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, 
                       int Cin, int Ch, int Cout, int P, hipStream_t stream);
 int dlwp_pwmlp_bwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, const float* w2,
                       const dlwp_chan_src* gy, const dlwp_chan_src* pred, const dlwp_chan_src* target,
-                      float mse_scale, const dlwp_chan_dst* gx, int gx_accumulate, float* gw1,
-                      float* gb1, float* gw2, float* gb2, float* slab, int slab_accumulate, int B, int Cin,
-                      int Ch, int Cout, int P, hipStream_t stream);
+                      float mse_scale, const dlwp_chan_dst* gx, int gx_accumulate, const dlwp_chan_dst* gres,
+                      float* gw1, float* gb1, float* gw2, float* gb2, float* slab, int slab_accumulate, int B,
+                      int Cin, int Ch, int Cout, int P, hipStream_t stream);
 // per-workgroup parameter-gradient slabs of pwmlp_bwd: [slab_count][slab_stride] floats
 long long dlwp_pwmlp_slab_stride(int Cin, int Ch, int Cout);
 int dlwp_pwmlp_slab_count(int B, int P);

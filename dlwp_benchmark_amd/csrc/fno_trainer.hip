@@ -16,9 +16,17 @@
 struct dlwp_fno_trainer {
     dlwp_fno_cfg cfg;
     dlwp_fno_plan* plan = nullptr;
-    int ncalls = 0, Cin = 0;
-    long long frame = 0;      // D*H*W
-    long long traj = 0;       // T*D*H*W
+    int ncalls = 0, Cin = 0, T_out = 0;
+    long long frame = 0;      // D*H*W (prognostic channels per frame)
+    long long traj = 0;       // T*D*H*W           (input trajectory stride per sample)
+    long long traj_out = 0;   // T_out*D*H*W       (prediction / target stride per sample)
+    const float *constants = nullptr, *prescribed = nullptr;   // dlwp form (borrowed)
+    struct CallInfo {         // host-side plan of one net call
+        int out_slot;                       // index into out/y/g_out along their time axis
+        const float* res; long long res_bs; // residual frame added to the net output (dlwp form), or nullptr
+        float* gres; long long gres_bs;     // where the residual path sends its gradient, or nullptr
+    };
+    std::vector<CallInfo> calls;
     long long act = 0;        // C*H*W per sample
     // trajectory buffers borrowed from the caller (dlwp_fno_trainer_bind_io)
     const float *x = nullptr, *y = nullptr;
@@ -33,7 +41,7 @@ struct dlwp_fno_trainer {
     float* slab_skip = nullptr;                        // [n_layers][B*H][gslab_stride] skip-weight / bias partials
     const float** src_tab = nullptr;         // [ncalls][Cin]
     float** gdst_tab = nullptr;              // [ncalls][Cin]
-    long long* bstride_tab = nullptr;        // [Cin]
+    long long* bstride_tab = nullptr;        // [ncalls][Cin]
     // bound by the caller
     float *params = nullptr, *grads = nullptr;
     // graph
@@ -53,7 +61,9 @@ struct Layout {
 
 Layout make_layout(const dlwp_fno_cfg& c) {
     Layout L{};
-    const long long Cin = (long long)c.D * c.context_size + c.aux_channels;
+    const long long Cin = c.form == DLWP_FNO_FORM_DLWP
+                              ? (long long)c.constant_channels + (long long)(c.prescribed_channels + c.D) * c.context_size
+                              : (long long)c.D * c.context_size;
     long long o = 0;
     L.lw1 = o; o += pad4((long long)c.lifting * Cin);
     L.lb1 = o; o += pad4(c.lifting);
@@ -82,14 +92,20 @@ int check_cfg(const dlwp_fno_cfg& c) {
     DLWP_REQUIRE(c.B > 0 && c.T > 0 && c.D > 0 && c.H > 0 && c.W > 0, DLWP_E_INVALID, "fno_trainer: bad shape");
     DLWP_REQUIRE(c.context_size >= 1, DLWP_E_INVALID, "fno_trainer: context_size must be >= 1");
     DLWP_REQUIRE(c.context_size <= c.T, DLWP_E_INVALID, "fno_trainer: context_size > T");
-    DLWP_REQUIRE(c.teacher_forcing_steps >= c.context_size - 1, DLWP_E_UNSUPPORTED,
-                 "fno_trainer: teacher_forcing_steps < context_size-1 (the reference slices x with a "
-                 "negative start there, fno.py:236) is not supported");
+    DLWP_REQUIRE(c.form == DLWP_FNO_FORM_NS || c.form == DLWP_FNO_FORM_DLWP, DLWP_E_INVALID, "fno_trainer: unknown form");
+    if (c.form == DLWP_FNO_FORM_NS) {
+        DLWP_REQUIRE(c.teacher_forcing_steps >= c.context_size - 1, DLWP_E_UNSUPPORTED,
+                     "fno_trainer: teacher_forcing_steps < context_size-1 (the reference slices x with a "
+                     "negative start there, fno.py:236) is not supported");
+        DLWP_REQUIRE(c.constant_channels == 0 && c.prescribed_channels == 0, DLWP_E_INVALID,
+                     "fno_trainer: constant/prescribed channels only exist in the dlwp form");
+    } else {
+        DLWP_REQUIRE(c.context_size < c.T, DLWP_E_INVALID, "fno_trainer: dlwp form needs T > context_size");
+        DLWP_REQUIRE(c.constant_channels >= 0 && c.prescribed_channels >= 0, DLWP_E_INVALID, "fno_trainer: bad channels");
+    }
     DLWP_REQUIRE(c.n_layers >= 1 && c.hidden > 0 && c.lifting > 0 && c.projection > 0, DLWP_E_INVALID,
                  "fno_trainer: bad widths");
     DLWP_REQUIRE(c.out_channels == c.D, DLWP_E_INVALID, "fno_trainer: out_channels must equal D");
-    DLWP_REQUIRE(c.aux_channels == 0, DLWP_E_UNSUPPORTED, "fno_trainer: aux channels not supported yet");
-    DLWP_REQUIRE(c.residual == 0, DLWP_E_UNSUPPORTED, "fno_trainer: residual form not supported yet");
     DLWP_REQUIRE((c.H * c.W) % 4 == 0, DLWP_E_UNSUPPORTED, "fno_trainer: H*W must be a multiple of 4");
     return DLWP_OK;
 }
@@ -114,18 +130,18 @@ int enqueue_forward(dlwp_fno_trainer* tr, bool keep, hipStream_t s) {
     const long long actB = (long long)c.B * tr->act;
     const long long xhatB = (long long)c.B * c.m1 * c.m2c * C;
     int rc;
-    if (ctx > 1) {
+    if (c.form == DLWP_FNO_FORM_NS && ctx > 1) {
         // steps before the context is full return the latest observation (fno.py:240-243)
         DLWP_HIP(hipMemcpy2DAsync(tr->out, tr->traj * sizeof(float), tr->x, tr->traj * sizeof(float),
                                   (size_t)(ctx - 1) * tr->frame * sizeof(float), c.B, hipMemcpyDeviceToDevice, s));
     }
     for (int k = 0; k < tr->ncalls; ++k) {
-        const int t = ctx - 1 + k;
+        const dlwp_fno_trainer::CallInfo& ci = tr->calls[k];
         const int kk = keep ? k : 0;  // evaluation reuses slot 0
         float* h0 = tr->h0 + kk * actB;
         float* pre = tr->pre + (long long)kk * NL * actB;
         float2* xhat = tr->xhat + (long long)kk * NL * xhatB;
-        dlwp_chan_src xs{nullptr, 0, 0, tr->src_tab + (long long)k * tr->Cin, tr->bstride_tab};
+        dlwp_chan_src xs{nullptr, 0, 0, tr->src_tab + (long long)k * tr->Cin, tr->bstride_tab + (long long)k * tr->Cin};
         dlwp_chan_dst h0d{h0, tr->act, HW, nullptr, nullptr};
         if ((rc = dlwp_pwmlp_fwd_ex(&xs, w.lw1, w.lb1, w.lw2, w.lb2, &h0d, nullptr, c.B, tr->Cin, c.lifting, C, HW, s))) return rc;
         if ((rc = dlwp_fno_rows_dft(tr->plan, h0, 0, 0, tr->x1, c.B, s))) return rc;
@@ -143,8 +159,9 @@ int enqueue_forward(dlwp_fno_trainer* tr, bool keep, hipStream_t s) {
             if ((rc = dlwp_fno_spatial(tr->plan, &a, s))) return rc;
         }
         dlwp_chan_src ps{pre + (NL - 1) * actB, tr->act, HW, nullptr, nullptr};
-        dlwp_chan_dst od{tr->out + (long long)t * tr->frame, tr->traj, HW, nullptr, nullptr};
-        if ((rc = dlwp_pwmlp_fwd_ex(&ps, w.pw1, w.pb1, w.pw2, w.pb2, &od, nullptr, c.B, C, c.projection,
+        dlwp_chan_dst od{tr->out + (long long)ci.out_slot * tr->frame, tr->traj_out, HW, nullptr, nullptr};
+        dlwp_chan_src rs{ci.res, ci.res_bs, HW, nullptr, nullptr};  // out = last frame + net (dlwp fno.py:103)
+        if ((rc = dlwp_pwmlp_fwd_ex(&ps, w.pw1, w.pb1, w.pw2, w.pb2, &od, ci.res ? &rs : nullptr, c.B, C, c.projection,
                                     c.out_channels, HW, s))) return rc;
     }
     return DLWP_OK;
@@ -158,7 +175,7 @@ int enqueue_loss_backward(dlwp_fno_trainer* tr, const float* grad_out, hipStream
     const int HW = c.H * c.W, C = c.hidden, NL = c.n_layers, ctx = c.context_size;
     const long long actB = (long long)c.B * tr->act;
     const long long xhatB = (long long)c.B * c.m1 * c.m2c * C;
-    const long long n = (long long)c.B * tr->traj;
+    const long long n = (long long)c.B * tr->traj_out;
     int rc;
     float mse_scale = 0.f;
     if (grad_out) {
@@ -172,19 +189,21 @@ int enqueue_loss_backward(dlwp_fno_trainer* tr, const float* grad_out, hipStream
         mse_scale = 2.0f / (float)n;
     }
     for (int k = tr->ncalls - 1; k >= 0; --k) {
-        const int t = ctx - 1 + k;
+        const dlwp_fno_trainer::CallInfo& ci = tr->calls[k];
+        const long long oofs = (long long)ci.out_slot * tr->frame;
         float* h0 = tr->h0 + k * actB;
         float* pre = tr->pre + (long long)k * NL * actB;
         float2* xhat = tr->xhat + (long long)k * NL * xhatB;
         float *gcur = tr->gA, *gnext = tr->gB;
         // projection backward; upstream = accumulated closed-loop gradient + d MSE / d out[t]
         dlwp_chan_src ps{pre + (NL - 1) * actB, tr->act, HW, nullptr, nullptr};
-        dlwp_chan_src gy{tr->g_out + (long long)t * tr->frame, tr->traj, HW, nullptr, nullptr};
-        dlwp_chan_src pred{tr->out + (long long)t * tr->frame, tr->traj, HW, nullptr, nullptr};
-        dlwp_chan_src targ{tr->y + (long long)t * tr->frame, tr->traj, HW, nullptr, nullptr};
+        dlwp_chan_src gy{tr->g_out + oofs, tr->traj_out, HW, nullptr, nullptr};
+        dlwp_chan_src pred{tr->out + oofs, tr->traj_out, HW, nullptr, nullptr};
+        dlwp_chan_src targ{tr->y + oofs, tr->traj_out, HW, nullptr, nullptr};
         dlwp_chan_dst gx{gcur, tr->act, HW, nullptr, nullptr};
+        dlwp_chan_dst gr{ci.gres, ci.gres_bs, HW, nullptr, nullptr};  // identity path of the residual
         if ((rc = dlwp_pwmlp_bwd_ex(&ps, w.pw1, w.pb1, w.pw2, &gy, grad_out ? nullptr : &pred, grad_out ? nullptr : &targ,
-                                    mse_scale, &gx, 0, g.pw1, g.pb1,
+                                    mse_scale, &gx, 0, ci.gres ? &gr : nullptr, g.pw1, g.pb1,
                                     g.pw2, g.pb2, tr->slab_proj, k != tr->ncalls - 1, c.B, C, c.projection,
                                     c.out_channels, HW, s))) return rc;
         if ((rc = dlwp_fno_rows_dft(tr->plan, gcur, 0, 1, tr->x1, c.B, s))) return rc;
@@ -206,10 +225,10 @@ int enqueue_loss_backward(dlwp_fno_trainer* tr, const float* grad_out, hipStream
             float* tmp = gcur; gcur = gnext; gnext = tmp;
         }
         // lifting backward; input-channel gradients flow into the predictions that fed this step
-        dlwp_chan_src xs{nullptr, 0, 0, tr->src_tab + (long long)k * tr->Cin, tr->bstride_tab};
+        dlwp_chan_src xs{nullptr, 0, 0, tr->src_tab + (long long)k * tr->Cin, tr->bstride_tab + (long long)k * tr->Cin};
         dlwp_chan_src gh0{gcur, tr->act, HW, nullptr, nullptr};
-        dlwp_chan_dst gxd{nullptr, 0, 0, tr->gdst_tab + (long long)k * tr->Cin, tr->bstride_tab};
-        if ((rc = dlwp_pwmlp_bwd_ex(&xs, w.lw1, w.lb1, w.lw2, &gh0, nullptr, nullptr, 0.f, &gxd, 1, g.lw1, g.lb1,
+        dlwp_chan_dst gxd{nullptr, 0, 0, tr->gdst_tab + (long long)k * tr->Cin, tr->bstride_tab + (long long)k * tr->Cin};
+        if ((rc = dlwp_pwmlp_bwd_ex(&xs, w.lw1, w.lb1, w.lw2, &gh0, nullptr, nullptr, 0.f, &gxd, 1, nullptr, g.lw1, g.lb1,
                                     g.lw2, g.lb2, tr->slab_lift, k != tr->ncalls - 1, c.B, tr->Cin, c.lifting, C,
                                     HW, s))) return rc;
     }
@@ -231,7 +250,9 @@ int enqueue_loss_backward(dlwp_fno_trainer* tr, const float* grad_out, hipStream
 extern "C" long long dlwp_fno_param_offset(const dlwp_fno_cfg* cfg, int kind, int layer, long long* size) {
     const dlwp_fno_cfg& c = *cfg;
     const Layout L = make_layout(c);
-    const long long Cin = (long long)c.D * c.context_size + c.aux_channels;
+    const long long Cin = c.form == DLWP_FNO_FORM_DLWP
+                              ? (long long)c.constant_channels + (long long)(c.prescribed_channels + c.D) * c.context_size
+                              : (long long)c.D * c.context_size;
     long long off = -1, sz = 0;
     switch (kind) {
         case -1: off = L.total; sz = L.total; break;
@@ -260,12 +281,15 @@ extern "C" int dlwp_fno_trainer_create(const dlwp_fno_cfg* cfg, dlwp_fno_trainer
     tr->cfg = *cfg;
     const dlwp_fno_cfg& c = tr->cfg;
     if ((rc = dlwp_fno_plan_create(c.hidden, c.H, c.W, c.m1, c.m2c, &tr->plan))) { delete tr; return rc; }
-    tr->ncalls = c.T - (c.context_size - 1);
-    tr->Cin = c.D * c.context_size;
+    const bool dlwp = c.form == DLWP_FNO_FORM_DLWP;
+    tr->ncalls = dlwp ? c.T - c.context_size : c.T - (c.context_size - 1);
+    tr->T_out = dlwp ? c.T - c.context_size : c.T;
+    tr->Cin = dlwp ? c.constant_channels + (c.prescribed_channels + c.D) * c.context_size : c.D * c.context_size;
     tr->frame = (long long)c.D * c.H * c.W;
     tr->traj = tr->frame * c.T;
+    tr->traj_out = tr->frame * tr->T_out;
     tr->act = (long long)c.hidden * c.H * c.W;
-    const size_t n = (size_t)c.B * tr->traj, actB = (size_t)c.B * tr->act;
+    const size_t n = (size_t)c.B * tr->traj_out, actB = (size_t)c.B * tr->act;
     const size_t xhatB = (size_t)c.B * c.m1 * c.m2c * c.hidden;
     if ((rc = dmalloc(&tr->g_out, n)) ||
         (rc = dmalloc(&tr->h0, actB * tr->ncalls)) || (rc = dmalloc(&tr->pre, actB * tr->ncalls * c.n_layers)) ||
@@ -278,7 +302,7 @@ extern "C" int dlwp_fno_trainer_create(const dlwp_fno_cfg* cfg, dlwp_fno_trainer
         (rc = dmalloc(&tr->slab_proj, (size_t)dlwp_pwmlp_slab_count(c.B, c.H * c.W) *
                                           dlwp_pwmlp_slab_stride(c.hidden, c.projection, c.out_channels))) ||
         (rc = dmalloc(&tr->src_tab, (size_t)tr->ncalls * tr->Cin)) ||
-        (rc = dmalloc(&tr->gdst_tab, (size_t)tr->ncalls * tr->Cin)) || (rc = dmalloc(&tr->bstride_tab, (size_t)tr->Cin))) {
+        (rc = dmalloc(&tr->gdst_tab, (size_t)tr->ncalls * tr->Cin)) || (rc = dmalloc(&tr->bstride_tab, (size_t)tr->ncalls * tr->Cin))) {
         dlwp_fno_trainer_destroy(tr);
         return rc;
     }
@@ -297,31 +321,81 @@ extern "C" int dlwp_fno_trainer_bind_io(dlwp_fno_trainer* tr, const float* x, co
     }
     tr->x = x; tr->y = y; tr->out = out_buf; tr->loss = loss;
     const dlwp_fno_cfg& c = tr->cfg;
-    // channel gather tables: window frame j of step t comes from the observations while j < tf,
-    // from the prediction out[j-1] afterwards (fno.py:228-237)
     std::vector<const float*> src((size_t)tr->ncalls * tr->Cin);
     std::vector<float*> gdst((size_t)tr->ncalls * tr->Cin);
-    std::vector<long long> bs((size_t)tr->Cin, tr->traj);
+    std::vector<long long> bs((size_t)tr->ncalls * tr->Cin);
+    tr->calls.assign(tr->ncalls, dlwp_fno_trainer::CallInfo{0, nullptr, 0, nullptr, 0});
     const long long HW = (long long)c.H * c.W;
-    for (int k = 0; k < tr->ncalls; ++k) {
-        const int t = c.context_size - 1 + k;
-        for (int sl = 0; sl < c.context_size; ++sl) {
-            const int j = t - c.context_size + 1 + sl;
-            for (int d = 0; d < c.D; ++d) {
-                const size_t ch = (size_t)k * tr->Cin + (size_t)sl * c.D + d;
-                if (j < c.teacher_forcing_steps) {
-                    src[ch] = tr->x + (long long)j * tr->frame + d * HW;
-                    gdst[ch] = nullptr;
-                } else {
-                    src[ch] = tr->out + (long long)(j - 1) * tr->frame + d * HW;
-                    gdst[ch] = tr->g_out + (long long)(j - 1) * tr->frame + d * HW;
+    const int ctx = c.context_size;
+    if (c.form == DLWP_FNO_FORM_NS) {
+        // window frame j of step t comes from the observations while j < tf, from the prediction out[j-1]
+        // afterwards (nsbench fno.py:228-237)
+        for (int k = 0; k < tr->ncalls; ++k) {
+            const int t = ctx - 1 + k;
+            tr->calls[k].out_slot = t;
+            for (int sl = 0; sl < ctx; ++sl) {
+                const int j = t - ctx + 1 + sl;
+                for (int d = 0; d < c.D; ++d) {
+                    const size_t ch = (size_t)k * tr->Cin + (size_t)sl * c.D + d;
+                    bs[ch] = tr->traj;
+                    if (j < c.teacher_forcing_steps) {
+                        src[ch] = tr->x + (long long)j * tr->frame + d * HW;
+                        gdst[ch] = nullptr;
+                    } else {
+                        src[ch] = tr->out + (long long)(j - 1) * tr->frame + d * HW;
+                        gdst[ch] = tr->g_out + (long long)(j - 1) * tr->frame + d * HW;
+                    }
                 }
+            }
+        }
+    } else {
+        // dlwpbench fno.py:49-62,75-103: channels = [constants | prescribed frames t-ctx..t-1 | prognostic frames
+        // t-ctx..t-1]; prognostic frame j is the observation while j < ctx, the prediction out[j-ctx] afterwards;
+        // out[k] = (last prognostic frame) + net(x_t)
+        DLWP_REQUIRE(c.constant_channels == 0 || tr->constants, DLWP_E_INVALID, "fno_trainer: constants not bound");
+        DLWP_REQUIRE(c.prescribed_channels == 0 || tr->prescribed, DLWP_E_INVALID, "fno_trainer: prescribed not bound");
+        const int Cc = c.constant_channels, Cp = c.prescribed_channels, Cg = c.D;
+        for (int k = 0; k < tr->ncalls; ++k) {
+            const int t = ctx + k;
+            size_t ch = (size_t)k * tr->Cin;
+            tr->calls[k].out_slot = k;
+            for (int q = 0; q < Cc; ++q, ++ch) { src[ch] = tr->constants + q * HW; gdst[ch] = nullptr; bs[ch] = (long long)Cc * HW; }
+            for (int sl = 0; sl < ctx; ++sl)
+                for (int q = 0; q < Cp; ++q, ++ch) {
+                    src[ch] = tr->prescribed + ((long long)(t - ctx + sl) * Cp + q) * HW;
+                    gdst[ch] = nullptr;
+                    bs[ch] = (long long)c.T * Cp * HW;
+                }
+            for (int sl = 0; sl < ctx; ++sl) {
+                const int j = t - ctx + sl;
+                for (int q = 0; q < Cg; ++q, ++ch) {
+                    if (j < ctx) {
+                        src[ch] = tr->x + ((long long)j * Cg + q) * HW; gdst[ch] = nullptr; bs[ch] = tr->traj;
+                    } else {
+                        src[ch] = tr->out + ((long long)(j - ctx) * Cg + q) * HW;
+                        gdst[ch] = tr->g_out + ((long long)(j - ctx) * Cg + q) * HW;
+                        bs[ch] = tr->traj_out;
+                    }
+                }
+            }
+            const int jl = t - 1;  // residual source = last prognostic frame of the window
+            if (jl < ctx) { tr->calls[k].res = tr->x + (long long)jl * tr->frame; tr->calls[k].res_bs = tr->traj; }
+            else {
+                tr->calls[k].res = tr->out + (long long)(jl - ctx) * tr->frame; tr->calls[k].res_bs = tr->traj_out;
+                tr->calls[k].gres = tr->g_out + (long long)(jl - ctx) * tr->frame; tr->calls[k].gres_bs = tr->traj_out;
             }
         }
     }
     DLWP_HIP(hipMemcpy(tr->src_tab, src.data(), src.size() * sizeof(float*), hipMemcpyHostToDevice));
     DLWP_HIP(hipMemcpy(tr->gdst_tab, gdst.data(), gdst.size() * sizeof(float*), hipMemcpyHostToDevice));
     DLWP_HIP(hipMemcpy(tr->bstride_tab, bs.data(), bs.size() * sizeof(long long), hipMemcpyHostToDevice));
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_fno_trainer_bind_aux(dlwp_fno_trainer* tr, const float* constants, const float* prescribed) {
+    DLWP_REQUIRE(tr, DLWP_E_INVALID, "fno_trainer_bind_aux: NULL trainer");
+    tr->constants = constants;
+    tr->prescribed = prescribed;
     return DLWP_OK;
 }
 

@@ -195,6 +195,7 @@ struct BwdArgs {
     float mse_scale;
     dlwp_chan_dst gx;            // nullable; per-channel nullable in table mode
     int gx_accumulate;
+    dlwp_chan_dst gres;          // optional: gres += effective upstream gradient (identity path of a residual)
     float *gw1, *gb1, *gw2, *gb2;  // accumulated with float atomics (slab == nullptr)
     // optional per-workgroup partial slab [grid][slab_stride] laid out {gw1,gb1,gw2,gb2}: plain
     // stores (slab_accumulate == 0) or read-modify-write by the owning workgroup; deterministic and
@@ -266,6 +267,13 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
     zero_padding(w2ts, LDT, a.Ch, a.Cout, a.Ch_pad, a.Cout_pad);
     for (int idx = tid; idx < a.Ch_pad; idx += NT) b1s[idx] = idx < a.Ch ? a.b1[idx] : 0.f;
     __syncthreads();
+    if (a.gres.base || a.gres.tab) {
+        for (int idx = tid; idx < a.Cout * PT; idx += NT) {
+            const int o = idx / PT, p = idx % PT;
+            float* dst = chan_ptr(a.gres, b, o);
+            if (dst && p0 + p < a.P) dst[p0 + p] += gys[o * LDP + p];
+        }
+    }
 
     DLWP_STAMP(10);
     float* T = tr + (w * 2 + 0) * 320;
@@ -548,9 +556,9 @@ int dlwp_pwmlp_fwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, 
 
 int dlwp_pwmlp_bwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, const float* w2,
                       const dlwp_chan_src* gy, const dlwp_chan_src* pred, const dlwp_chan_src* target,
-                      float mse_scale, const dlwp_chan_dst* gx, int gx_accumulate, float* gw1,
-                      float* gb1, float* gw2, float* gb2, float* slab, int slab_accumulate, int B, int Cin,
-                      int Ch, int Cout, int P, hipStream_t stream) {
+                      float mse_scale, const dlwp_chan_dst* gx, int gx_accumulate, const dlwp_chan_dst* gres,
+                      float* gw1, float* gb1, float* gw2, float* gb2, float* slab, int slab_accumulate, int B,
+                      int Cin, int Ch, int Cout, int P, hipStream_t stream) {
     DLWP_REQUIRE(B > 0 && Cin > 0 && Ch > 0 && Cout > 0 && P > 0, DLWP_E_INVALID,
                  "pwmlp_bwd: non-positive dimension");
     BwdArgs a{};
@@ -560,6 +568,7 @@ int dlwp_pwmlp_bwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, 
     a.mse_scale = mse_scale;
     if (gx) a.gx = *gx;
     a.gx_accumulate = gx_accumulate;
+    if (gres) a.gres = *gres;
     a.gw1 = gw1; a.gb1 = gb1; a.gw2 = gw2; a.gb2 = gb2;
     a.B = B; a.Cin = Cin; a.Ch = Ch; a.Cout = Cout; a.P = P;
     a.tiles_per_sample = ceil_div(P, PT);

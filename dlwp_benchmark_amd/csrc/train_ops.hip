@@ -188,8 +188,8 @@ extern "C" int dlwp_pwmlp_bwd(const float* x, const float* w1, const float* b1, 
     dlwp_chan_src xs{x, (long long)Cin * P, P, nullptr, nullptr};
     dlwp_chan_src gys{gy, (long long)Cout * P, P, nullptr, nullptr};
     dlwp_chan_dst gxd{gx, (long long)Cin * P, P, nullptr, nullptr};
-    return dlwp_pwmlp_bwd_ex(&xs, w1, b1, w2, &gys, nullptr, nullptr, 0.f, gx ? &gxd : nullptr, 0, gw1, gb1, gw2,
-                             gb2, nullptr, 0, B, Cin, Ch, Cout, P, (hipStream_t)stream);
+    return dlwp_pwmlp_bwd_ex(&xs, w1, b1, w2, &gys, nullptr, nullptr, 0.f, gx ? &gxd : nullptr, 0, nullptr, gw1, gb1,
+                             gw2, gb2, nullptr, 0, B, Cin, Ch, Cout, P, (hipStream_t)stream);
 }
 
 // ---- debug: a chain of n dependent empty kernels (measures the per-kernel floor of a stream / graph)

@@ -15,7 +15,7 @@ from . import lib as L
 
 
 def make_cfg(B, T, D, H, W, context_size, teacher_forcing_steps, hidden, lifting, projection,
-             n_layers, n_modes, out_channels=None, residual=0, aux_channels=0):
+             n_layers, n_modes, out_channels=None, form=0, constant_channels=0, prescribed_channels=0):
     cfg = L.FnoCfg()
     cfg.B, cfg.T, cfg.D, cfg.H, cfg.W = B, T, D, H, W
     cfg.context_size = max(1, context_size)
@@ -23,7 +23,7 @@ def make_cfg(B, T, D, H, W, context_size, teacher_forcing_steps, hidden, lifting
     cfg.hidden, cfg.lifting, cfg.projection, cfg.n_layers = hidden, lifting, projection, n_layers
     cfg.m1, cfg.m2c = n_modes[0], n_modes[1] // 2 + 1
     cfg.out_channels = D if out_channels is None else out_channels
-    cfg.residual, cfg.aux_channels = residual, aux_channels
+    cfg.form, cfg.constant_channels, cfg.prescribed_channels = form, constant_channels, prescribed_channels
     return cfg
 
 
@@ -135,10 +135,20 @@ class FnoRolloutTrainer:
         L.check(self.lib.dlwp_fno_trainer_create(C.byref(cfg), C.byref(h)))
         self.h = h
         shape = (cfg.B, cfg.T, cfg.D, cfg.H, cfg.W)
+        dlwp_form = cfg.form == 1
+        t_out = cfg.T - cfg.context_size if dlwp_form else cfg.T
+        out_shape = (cfg.B, t_out, cfg.D, cfg.H, cfg.W)
         self.x = torch.zeros(shape, device=device)
-        self.y = torch.zeros(shape, device=device)
-        self.out = torch.zeros(shape, device=device)
+        self.y = torch.zeros(out_shape, device=device)
+        self.out = torch.zeros(out_shape, device=device)
         self.loss = torch.zeros(1, device=device)
+        self.constants = self.prescribed = None
+        if dlwp_form:
+            if cfg.constant_channels:
+                self.constants = torch.zeros((cfg.B, 1, cfg.constant_channels, cfg.H, cfg.W), device=device)
+            if cfg.prescribed_channels:
+                self.prescribed = torch.zeros((cfg.B, cfg.T, cfg.prescribed_channels, cfg.H, cfg.W), device=device)
+            L.check(self.lib.dlwp_fno_trainer_bind_aux(self.h, L.ptr(self.constants), L.ptr(self.prescribed)))
         L.check(self.lib.dlwp_fno_trainer_bind_io(self.h, L.ptr(self.x), L.ptr(self.y), L.ptr(self.out),
                                                   L.ptr(self.loss)))
         self.bind(params, grads)

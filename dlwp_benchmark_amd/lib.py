@@ -20,7 +20,7 @@ class ChanSrc(C.Structure):
 class FnoCfg(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "B", "T", "D", "H", "W", "context_size", "teacher_forcing_steps", "hidden", "lifting",
-        "projection", "n_layers", "m1", "m2c", "out_channels", "residual", "aux_channels")]
+        "projection", "n_layers", "m1", "m2c", "out_channels", "form", "constant_channels", "prescribed_channels")]
 
 
 # parameter kinds of the flat FNO parameter buffer (dlwpmi.h enum)
@@ -48,6 +48,7 @@ SIGNATURES = {
     "dlwp_fno_trainer_destroy": (None, [_V]),
     "dlwp_fno_trainer_bind_io": (_I, [_V, _V, _V, _V, _V]),
     "dlwp_fno_trainer_bind": (_I, [_V, _V, _V]),
+    "dlwp_fno_trainer_bind_aux": (_I, [_V, _V, _V]),
     "dlwp_fno_trainer_forward": (_I, [_V, _I, _V]),
     "dlwp_fno_trainer_backward": (_I, [_V, _V, _V]),
     "dlwp_fno_trainer_fwd_bwd": (_I, [_V, _I, _V]),

@@ -125,10 +125,16 @@ typedef struct dlwp_fno_cfg {
     int teacher_forcing_steps;
     int hidden, lifting, projection, n_layers;
     int m1, m2c;            /* kept modes: n_modes[0] rows, n_modes[1]/2+1 columns        */
-    int out_channels;       /* = D for ns                                                  */
-    int residual;           /* 1: out = last_frame + net(x) (dlwp form); 0: ns FNO form   */
-    int aux_channels;       /* extra per-step input channels (dlwp constants+prescribed)  */
+    int out_channels;       /* = D                                                         */
+    int form;               /* DLWP_FNO_FORM_NS: nsbench fno.py:217-250 (x[B,T,D,H,W] -> [B,T,D,H,W]);    */
+                            /* DLWP_FNO_FORM_DLWP: dlwpbench fno.py:64-106 (D = prognostic channels,      */
+                            /* out[k] = last frame + net([constants|prescribed|prognostic window]),       */
+                            /* k = 0..T-ctx-1, teacher_forcing_steps unused)                              */
+    int constant_channels;  /* dlwp form: channels of constants [B,1,Cc,H,W]                              */
+    int prescribed_channels;/* dlwp form: channels of prescribed [B,T,Cp,H,W]                             */
 } dlwp_fno_cfg;
+#define DLWP_FNO_FORM_NS 0
+#define DLWP_FNO_FORM_DLWP 1
 
 enum {
     DLWP_FNO_P_LIFT_W1 = 0, DLWP_FNO_P_LIFT_B1, DLWP_FNO_P_LIFT_W2, DLWP_FNO_P_LIFT_B2,
@@ -150,6 +156,10 @@ void dlwp_fno_trainer_destroy(dlwp_fno_trainer* tr);
 /* channel gather tables); invalidates a captured graph.                                    */
 int dlwp_fno_trainer_bind_io(dlwp_fno_trainer* tr, const float* x, const float* y, float* out,
                              float* loss);
+/* dlwp form only, BEFORE bind_io: constants [B,1,Cc,H,W] and prescribed [B,T,Cp,H,W]     */
+/* (NULL when the corresponding channel count is 0).  In the dlwp form x is the prognostic */
+/* trajectory [B,T,Cg,H,W] and y/out are [B,T-ctx,Cg,H,W].                                 */
+int dlwp_fno_trainer_bind_aux(dlwp_fno_trainer* tr, const float* constants, const float* prescribed);
 /* bind the caller's flat parameter / gradient buffers (borrowed until destroy/rebind)    */
 int dlwp_fno_trainer_bind(dlwp_fno_trainer* tr, float* params, float* grads);
 /* rollout forward into the `out` buffer; keep_activations!=0 stores every net call's      */

@@ -166,3 +166,31 @@ def spec_to_mode_major(w):
 def spec_from_mode_major(w):
     """real [m1,m2c,Ci,Co,2] -> complex [Ci,Co,m1,m2c]"""
     return torch.view_as_complex(w.contiguous()).permute(2, 3, 0, 1).contiguous()
+
+
+def dlwp_prepare_inputs(constants, prescribed, prognostic):
+    """FNO2DModule._prepare_inputs (dlwpbench/models/fno/fno.py:49-62)."""
+    tensors = []
+    if constants is not None:
+        tensors.append(constants[:, 0])
+    if prescribed is not None:
+        tensors.append(prescribed.flatten(1, 2))
+    if prognostic is not None:
+        tensors.append(prognostic.flatten(1, 2))
+    return torch.cat(tensors, dim=1)
+
+
+def dlwp_rollout(net, constants, prescribed, prognostic, context_size):
+    """FNO2DModule.forward (dlwpbench/models/fno/fno.py:64-106) in its clean, on-device form (the published
+    loop calls .to() on a list, App. B-1; the intent is UNet.forward, dlwpbench/models/unet/unet.py:64-111)."""
+    outs = []
+    ctx = context_size
+    for t in range(ctx, prognostic.shape[1]):
+        t_start = max(0, t - ctx)
+        if t == ctx:
+            prognostic_t = prognostic[:, t_start:t]
+        else:
+            prognostic_t = torch.cat([prognostic[:, t_start:ctx], torch.stack(outs, dim=1)[:, -ctx:]], dim=1)
+        x_t = dlwp_prepare_inputs(constants, prescribed[:, t - ctx:t] if prescribed is not None else None, prognostic_t)
+        outs.append(prognostic_t[:, -1] + net(x_t))
+    return torch.stack(outs, dim=1)
