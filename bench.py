@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
+                    "single-GPU functional test of the N>1 code path)")
+    ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (functional test only)")
     return ap.parse_args()
 
 
@@ -143,10 +146,13 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", 0 if args.share_device else local_rank)
     torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     w = WORKLOAD
     B = args.batch
