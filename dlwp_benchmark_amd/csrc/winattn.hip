@@ -1,0 +1,400 @@
+// Fused window attention (Swin W-MSA / SW-MSA core), forward and backward, fp32.
+// Reference: WindowAttention.forward src/nsbench/models/swintransformer/swin_transformer.py:123-155
+// (dlwpbench twin :122-154):  attn = softmax(q*scale @ k^T + rel_pos_bias[index] + mask) @ v.
+// The reference materialises the [B_, heads, N, N] score tensor (1 GB at the dlwpbench default
+// N = 2048), gathers the bias through an N x N index tensor and adds an N x N mask per window.
+//
+// MI355X design: flash-style, S never leaves the CU.  One workgroup = 64 queries of one (window,
+// head); keys/values stream through LDS in tiles of 64.  All products run on the exact-f32 MFMA in
+// the TRANSPOSED orientation (S^T = K Q^T: rows = keys, columns = queries), so that the score
+// accumulator is directly the B operand of O^T = V^T P^T (permuted-k trick, common.cuh) and the
+// softmax statistics of a query live in one lane.  The relative-position bias is looked up from a
+// per-head LDS copy of the table with the index computed arithmetically from token coordinates (no
+// N x N index tensor); the shift mask is `label[q] != label[k] ? -100 : 0` from a per-window label
+// vector (no N x N mask tensor).  Backward: kernel Q (dQ, dBias, D = rowsum(dO*O)) and kernel KV
+// (dK, dV), each recomputing the score tile it needs.
+#include "common.cuh"
+#include "dlwpmi_internal.h"
+
+namespace {
+
+constexpr int QT = 64, KT = 64;
+
+struct WaDev {
+    const float* qkv;          // [B_, N, 3, heads, d]
+    const float* table;        // [(2Wh-1)(2Ww-1), heads]
+    const int* labels;         // [nW, N] or nullptr
+    float* out;                // fwd: [B_, N, heads*d]
+    float* lse;                // fwd: [B_, heads, N]
+    const float* lse_in;       // bwd: saved log-sum-exp
+    const float* gout;         // bwd: [B_, N, heads*d]
+    const float* o;            // bwd: forward output
+    float* dsum;               // bwd: [B_, heads, N]  D = rowsum(gout * out)
+    float* gqkv;               // bwd: [B_, N, 3, heads, d]
+    float* gtable;             // bwd: accumulated
+    int B_, nW, N, Wh, Ww, heads, d, dp16, TB;
+    float scale;
+};
+
+__device__ __forceinline__ float wave_col_max(float v) {   // reduce over the 4 lane groups (same r)
+    v = fmaxf(v, __shfl_xor(v, 16));
+    return fmaxf(v, __shfl_xor(v, 32));
+}
+__device__ __forceinline__ float wave_col_sum(float v) {
+    v += __shfl_xor(v, 16);
+    return v + __shfl_xor(v, 32);
+}
+
+// rows [row0, row0+64) of q/k/v (which = 0/1/2) of (b, head) -> LDS tile [64][LDT], zero padded, scaled
+__device__ __forceinline__ void stage_rows(float* dst, int LDT, const float* base, long long row_stride, int row0, int N,
+                                           int d, int dp16, float scale) {
+    for (int idx = threadIdx.x; idx < 64 * dp16; idx += 256) {
+        const int row = idx / dp16, c = idx - row * dp16;
+        float v = 0.f;
+        if (row0 + row < N && c < d) v = base[(long long)(row0 + row) * row_stride + c] * scale;
+        dst[row * LDT + c] = v;
+    }
+}
+
+// score tile of one 16-key chunk against this wave's 16 queries: St[key 4g+j][query r]
+__device__ __forceinline__ f32x4 score_chunk(const float* rows_a, const float* rows_b, int LDT, int dp4) {
+    // rows_a: 16 rows (A operand, row = lane r), rows_b: 16 rows (B^T operand, row = lane r)
+    const int lane = lane_id(), r = lane & 15, g = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < dp4; k0 += 4) acc = mfma16(rows_a[r * LDT + k0 + g], rows_b[r * LDT + k0 + g], acc);
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int NDB>
+__global__ __launch_bounds__(256) void winattn_fwd_kernel(WaDev a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LDT = a.dp16 + 2;
+    float* Qs = smem;                         // [64][LDT] (scaled)
+    float* Ks = Qs + 64 * LDT;
+    float* Vs = Ks + 64 * LDT;
+    float* tb = Vs + 64 * LDT;                // [TB] bias table of this head
+    int* klab = reinterpret_cast<int*>(tb + a.TB);   // [64]
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
+    const int nqt = (a.N + QT - 1) / QT;
+    const int qt = blockIdx.x % nqt, bh = blockIdx.x / nqt, head = bh % a.heads, b = bh / a.heads;
+    const int wdw = b % a.nW;
+    const long long rs = 3LL * a.heads * a.d;
+    const float* qb = a.qkv + (long long)b * a.N * rs + head * a.d;
+    const int dp4 = (a.d + 3) & ~3;
+    stage_rows(Qs, LDT, qb, rs, qt * QT, a.N, a.d, a.dp16, a.scale);
+    for (int i = tid; i < a.TB; i += 256) tb[i] = a.table[(long long)i * a.heads + head];
+    const int q = qt * QT + w * 16 + r;                       // this lane's query (column)
+    const int qc = q < a.N ? q : a.N - 1;                      // clamped for coordinate / table indexing
+    const int qy = qc / a.Ww, qx = qc - qy * a.Ww;
+    const int qlab = (a.labels && q < a.N) ? a.labels[(long long)wdw * a.N + q] : 0;
+    float m = -1e30f, l = 0.f;
+    f32x4 oacc[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) oacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt0 = 0; kt0 < a.N; kt0 += KT) {
+        __syncthreads();
+        stage_rows(Ks, LDT, qb + a.heads * a.d, rs, kt0, a.N, a.d, a.dp16, 1.f);
+        stage_rows(Vs, LDT, qb + 2 * a.heads * a.d, rs, kt0, a.N, a.d, a.dp16, 1.f);
+        if (tid < KT) klab[tid] = (a.labels && kt0 + tid < a.N) ? a.labels[(long long)wdw * a.N + kt0 + tid] : 0;
+        __syncthreads();
+        f32x4 s[4];
+        float mx = -1e30f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            s[c] = score_chunk(Ks + 16 * c * LDT, Qs + (w * 16) * LDT, LDT, dp4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int key = kt0 + 16 * c + 4 * g + j;
+                float v = -1e30f;
+                if (key < a.N) {
+                    const int ky = key / a.Ww, kx = key - ky * a.Ww;
+                    v = s[c][j] + tb[(qy - ky + a.Wh - 1) * (2 * a.Ww - 1) + (qx - kx + a.Ww - 1)];
+                    if (a.labels && klab[16 * c + 4 * g + j] != qlab) v -= 100.f;
+                }
+                s[c][j] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+        mx = wave_col_max(mx);
+        const float m_new = fmaxf(m, mx);
+        const float corr = __expf(m - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float p = __expf(s[c][j] - m_new);
+                s[c][j] = p;
+                psum += p;
+            }
+        l = l * corr + wave_col_sum(psum);
+        m = m_new;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) oacc[db][j] *= corr;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x4 a4;
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) a4[s2] = Vs[(16 * c + 4 * g + s2) * LDT + db * 16 + r];
+                oacc[db] = mfma16_chunk(a4, s[c], oacc[db]);
+            }
+        }
+    }
+    if (q < a.N) {
+        const float inv = 1.f / l;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int dd = db * 16 + 4 * g + j;
+                if (dd < a.d) a.out[((long long)b * a.N + q) * a.heads * a.d + head * a.d + dd] = oacc[db][j] * inv;
+            }
+        if (g == 0) a.lse[((long long)b * a.heads + head) * a.N + q] = m + __logf(l);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, query side: dQ, dBias, D.  Same tiling as forward.
+template <int NDB>
+__global__ __launch_bounds__(256) void winattn_bwd_q_kernel(WaDev a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LDT = a.dp16 + 2;
+    float* Qs = smem;
+    float* Gs = Qs + 64 * LDT;                // dO rows of the query tile
+    float* Ks = Gs + 64 * LDT;
+    float* Vs = Ks + 64 * LDT;
+    float* tb = Vs + 64 * LDT;                // [TB] bias table
+    float* gtb = tb + a.TB;                   // [TB] bias-gradient partial of this workgroup
+    int* klab = reinterpret_cast<int*>(gtb + a.TB);
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
+    const int nqt = (a.N + QT - 1) / QT;
+    const int qt = blockIdx.x % nqt, bh = blockIdx.x / nqt, head = bh % a.heads, b = bh / a.heads;
+    const int wdw = b % a.nW;
+    const long long rs = 3LL * a.heads * a.d, os = (long long)a.heads * a.d;
+    const float* qb = a.qkv + (long long)b * a.N * rs + head * a.d;
+    const int dp4 = (a.d + 3) & ~3;
+    stage_rows(Qs, LDT, qb, rs, qt * QT, a.N, a.d, a.dp16, a.scale);
+    stage_rows(Gs, LDT, a.gout + (long long)b * a.N * os + head * a.d, os, qt * QT, a.N, a.d, a.dp16, 1.f);
+    for (int i = tid; i < a.TB; i += 256) { tb[i] = a.table[(long long)i * a.heads + head]; gtb[i] = 0.f; }
+    const int q = qt * QT + w * 16 + r;
+    const int qy = q / a.Ww, qx = q - qy * a.Ww;
+    const int qlab = (a.labels && q < a.N) ? a.labels[(long long)wdw * a.N + q] : 0;
+    const float lse = q < a.N ? a.lse_in[((long long)b * a.heads + head) * a.N + q] : 0.f;
+    __syncthreads();
+    // D[q] = sum_dd dO[q][dd] * O[q][dd]
+    float dpart = 0.f;
+    if (q < a.N)
+        for (int dd = g; dd < a.d; dd += 4)
+            dpart += Gs[(w * 16 + r) * LDT + dd] * a.o[((long long)b * a.N + q) * os + head * a.d + dd];
+    const float D = wave_col_sum(dpart);
+    if (q < a.N && g == 0) a.dsum[((long long)b * a.heads + head) * a.N + q] = D;
+    f32x4 dq[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) dq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt0 = 0; kt0 < a.N; kt0 += KT) {
+        __syncthreads();
+        stage_rows(Ks, LDT, qb + a.heads * a.d, rs, kt0, a.N, a.d, a.dp16, 1.f);
+        stage_rows(Vs, LDT, qb + 2 * a.heads * a.d, rs, kt0, a.N, a.d, a.dp16, 1.f);
+        if (tid < KT) klab[tid] = (a.labels && kt0 + tid < a.N) ? a.labels[(long long)wdw * a.N + kt0 + tid] : 0;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f32x4 s = score_chunk(Ks + 16 * c * LDT, Qs + (w * 16) * LDT, LDT, dp4);
+            const f32x4 dp = score_chunk(Vs + 16 * c * LDT, Gs + (w * 16) * LDT, LDT, dp4);   // dP^T = V dO^T
+            f32x4 ds;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int key = kt0 + 16 * c + 4 * g + j;
+                float v = 0.f;
+                if (key < a.N && q < a.N) {
+                    const int ky = key / a.Ww, kx = key - ky * a.Ww;
+                    const int bi = (qy - ky + a.Wh - 1) * (2 * a.Ww - 1) + (qx - kx + a.Ww - 1);
+                    float sc = s[j] + tb[bi];
+                    if (a.labels && klab[16 * c + 4 * g + j] != qlab) sc -= 100.f;
+                    const float p = __expf(sc - lse);
+                    v = p * (dp[j] - D);
+                    atomicAdd(&gtb[bi], v);
+                }
+                ds[j] = v;
+            }
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                f32x4 a4;
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) a4[s2] = Ks[(16 * c + 4 * g + s2) * LDT + db * 16 + r];
+                dq[db] = mfma16_chunk(a4, ds, dq[db]);
+            }
+        }
+    }
+    if (q < a.N) {
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int dd = db * 16 + 4 * g + j;
+                if (dd < a.d) a.gqkv[((long long)b * a.N + q) * rs + head * a.d + dd] = dq[db][j] * a.scale;
+            }
+    }
+    __syncthreads();
+    for (int i = tid; i < a.TB; i += 256) {
+        const float v = gtb[i];
+        if (v != 0.f) atomic_add_f32(&a.gtable[(long long)i * a.heads + head], v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, key side: dK, dV.  One workgroup = 64 keys (wave = 16 keys as columns), loops over query tiles.
+template <int NDB>
+__global__ __launch_bounds__(256) void winattn_bwd_kv_kernel(WaDev a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LDT = a.dp16 + 2;
+    float* Ks = smem;
+    float* Vs = Ks + 64 * LDT;
+    float* Qs = Vs + 64 * LDT;                // scaled q rows of the current query tile
+    float* Gs = Qs + 64 * LDT;
+    float* tb = Gs + 64 * LDT;
+    float* lses = tb + a.TB;                  // [64]
+    float* dss = lses + 64;                   // [64]
+    int* qlabs = reinterpret_cast<int*>(dss + 64);   // [64]
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
+    const int nkt = (a.N + KT - 1) / KT;
+    const int kt = blockIdx.x % nkt, bh = blockIdx.x / nkt, head = bh % a.heads, b = bh / a.heads;
+    const int wdw = b % a.nW;
+    const long long rs = 3LL * a.heads * a.d, os = (long long)a.heads * a.d;
+    const float* qb = a.qkv + (long long)b * a.N * rs + head * a.d;
+    const int dp4 = (a.d + 3) & ~3;
+    stage_rows(Ks, LDT, qb + a.heads * a.d, rs, kt * KT, a.N, a.d, a.dp16, 1.f);
+    stage_rows(Vs, LDT, qb + 2 * a.heads * a.d, rs, kt * KT, a.N, a.d, a.dp16, 1.f);
+    for (int i = tid; i < a.TB; i += 256) tb[i] = a.table[(long long)i * a.heads + head];
+    const int key = kt * KT + w * 16 + r;                     // this lane's key (column)
+    const int ky = key / a.Ww, kx = key - ky * a.Ww;
+    const int klabel = (a.labels && key < a.N) ? a.labels[(long long)wdw * a.N + key] : 0;
+    f32x4 dk[NDB], dv[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) { dk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db] = dk[db]; }
+
+    for (int qt0 = 0; qt0 < a.N; qt0 += QT) {
+        __syncthreads();
+        stage_rows(Qs, LDT, qb, rs, qt0, a.N, a.d, a.dp16, a.scale);
+        stage_rows(Gs, LDT, a.gout + (long long)b * a.N * os + head * a.d, os, qt0, a.N, a.d, a.dp16, 1.f);
+        if (tid < QT) {
+            const bool ok = qt0 + tid < a.N;
+            lses[tid] = ok ? a.lse_in[((long long)b * a.heads + head) * a.N + qt0 + tid] : 0.f;
+            dss[tid] = ok ? a.dsum[((long long)b * a.heads + head) * a.N + qt0 + tid] : 0.f;
+            qlabs[tid] = (a.labels && ok) ? a.labels[(long long)wdw * a.N + qt0 + tid] : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            // S[query 4g+j][key r], dP[query][key]
+            const f32x4 s = score_chunk(Qs + 16 * c * LDT, Ks + (w * 16) * LDT, LDT, dp4);
+            const f32x4 dp = score_chunk(Gs + 16 * c * LDT, Vs + (w * 16) * LDT, LDT, dp4);
+            f32x4 p, ds;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ql = 16 * c + 4 * g + j, q = qt0 + ql;
+                float pv = 0.f, dsv = 0.f;
+                if (q < a.N && key < a.N) {
+                    const int qy = q / a.Ww, qx = q - qy * a.Ww;
+                    float sc = s[j] + tb[(qy - ky + a.Wh - 1) * (2 * a.Ww - 1) + (qx - kx + a.Ww - 1)];
+                    if (a.labels && qlabs[ql] != klabel) sc -= 100.f;
+                    pv = __expf(sc - lses[ql]);
+                    dsv = pv * (dp[j] - dss[ql]);
+                }
+                p[j] = pv;
+                ds[j] = dsv;
+            }
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                f32x4 g4, q4;
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    g4[s2] = Gs[(16 * c + 4 * g + s2) * LDT + db * 16 + r];
+                    q4[s2] = Qs[(16 * c + 4 * g + s2) * LDT + db * 16 + r];
+                }
+                dv[db] = mfma16_chunk(g4, p, dv[db]);     // dV^T[dd][key] += dO^T[dd][q] P[q][key]
+                dk[db] = mfma16_chunk(q4, ds, dk[db]);    // dK^T[dd][key] += (scale q)^T[dd][q] dS[q][key]
+            }
+        }
+    }
+    if (key < a.N) {
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int dd = db * 16 + 4 * g + j;
+                if (dd < a.d) {
+                    float* base = a.gqkv + ((long long)b * a.N + key) * rs + head * a.d + dd;
+                    base[a.heads * a.d] = dk[db][j];
+                    base[2 * a.heads * a.d] = dv[db][j];
+                }
+            }
+    }
+}
+
+int wa_setup(WaDev& a, int B_, int nW, int N, int Wh, int Ww, int heads, int d, float scale, const char* who) {
+    DLWP_REQUIRE(B_ > 0 && nW > 0 && B_ % nW == 0 && N > 0 && heads > 0 && d > 0, DLWP_E_INVALID, "%s: bad shape", who);
+    DLWP_REQUIRE(N == Wh * Ww, DLWP_E_INVALID, "%s: N (%d) != Wh*Ww (%d*%d)", who, N, Wh, Ww);
+    DLWP_REQUIRE(d <= 32, DLWP_E_UNSUPPORTED, "%s: head_dim %d > 32 not supported yet", who, d);
+    a.B_ = B_; a.nW = nW; a.N = N; a.Wh = Wh; a.Ww = Ww; a.heads = heads; a.d = d; a.scale = scale;
+    a.dp16 = round_up(d, 16);
+    a.TB = (2 * Wh - 1) * (2 * Ww - 1);
+    return DLWP_OK;
+}
+
+}  // namespace
+
+extern "C" int dlwp_window_attn_fwd(const float* qkv, const float* bias_table, const int* labels, float* out,
+                                    float* lse, int B_, int nW, int N, int Wh, int Ww, int heads, int d, float scale,
+                                    void* stream) {
+    DLWP_REQUIRE(qkv && bias_table && out && lse, DLWP_E_INVALID, "window_attn_fwd: NULL argument");
+    WaDev a{};
+    int rc = wa_setup(a, B_, nW, N, Wh, Ww, heads, d, scale, "window_attn_fwd");
+    if (rc) return rc;
+    a.qkv = qkv; a.table = bias_table; a.labels = labels; a.out = out; a.lse = lse;
+    const size_t lds = sizeof(float) * ((size_t)3 * 64 * (a.dp16 + 2) + a.TB + 64);
+    const dim3 grid(B_ * heads * ((N + QT - 1) / QT)), block(256);
+    if (a.dp16 == 16) {
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_fwd_kernel<1>), lds, "window_attn_fwd"))) return rc;
+        hipLaunchKernelGGL(winattn_fwd_kernel<1>, grid, block, lds, (hipStream_t)stream, a);
+    } else {
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_fwd_kernel<2>), lds, "window_attn_fwd"))) return rc;
+        hipLaunchKernelGGL(winattn_fwd_kernel<2>, grid, block, lds, (hipStream_t)stream, a);
+    }
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, const int* labels, const float* out,
+                                    const float* lse, const float* gout, float* gqkv, float* gbias_table, float* dsum,
+                                    int B_, int nW, int N, int Wh, int Ww, int heads, int d, float scale, void* stream) {
+    DLWP_REQUIRE(qkv && bias_table && out && lse && gout && gqkv && gbias_table && dsum, DLWP_E_INVALID,
+                 "window_attn_bwd: NULL argument");
+    WaDev a{};
+    int rc = wa_setup(a, B_, nW, N, Wh, Ww, heads, d, scale, "window_attn_bwd");
+    if (rc) return rc;
+    a.qkv = qkv; a.table = bias_table; a.labels = labels; a.o = out; a.lse_in = lse; a.gout = gout; a.gqkv = gqkv;
+    a.gtable = gbias_table; a.dsum = dsum;
+    const int LDT = a.dp16 + 2;
+    const size_t lds_q = sizeof(float) * ((size_t)4 * 64 * LDT + 2 * a.TB + 64);
+    const size_t lds_kv = sizeof(float) * ((size_t)4 * 64 * LDT + a.TB + 3 * 64);
+    const dim3 grid(B_ * heads * ((N + QT - 1) / QT)), block(256);
+    if (a.dp16 == 16) {
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_bwd_q_kernel<1>), lds_q, "window_attn_bwd"))) return rc;
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_bwd_kv_kernel<1>), lds_kv, "window_attn_bwd"))) return rc;
+        hipLaunchKernelGGL(winattn_bwd_q_kernel<1>, grid, block, lds_q, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(winattn_bwd_kv_kernel<1>, grid, block, lds_kv, (hipStream_t)stream, a);
+    } else {
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_bwd_q_kernel<2>), lds_q, "window_attn_bwd"))) return rc;
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_bwd_kv_kernel<2>), lds_kv, "window_attn_bwd"))) return rc;
+        hipLaunchKernelGGL(winattn_bwd_q_kernel<2>, grid, block, lds_q, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(winattn_bwd_kv_kernel<2>, grid, block, lds_kv, (hipStream_t)stream, a);
+    }
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}

@@ -1,0 +1,283 @@
+"""Drop-in counterpart of the reference's nsbench SwinTransformer (window-attention U-Net rollout).
+
+Reference (file:line under /root/reference/src/nsbench/models/swintransformer/swin_transformer.py):
+  WindowAttention :75-155, SwinTransformerBlock :158-258, PatchMerging :261-302, BasicLayer :305-408,
+  PatchEmbed :411-452, SwinTransformer :455-706.  Constructor kwargs, forward signature and parameter /
+  buffer names are kept so reference checkpoints load (`relative_position_index` is kept as a buffer for
+  that reason only: the kernel derives the index from token coordinates).
+
+The attention core softmax(scale q k^T + bias + mask) v runs as hand-written HIP kernels
+(libdlwpmi dlwp_window_attn_fwd/bwd): scores never reach HBM, the shift mask is a per-window label
+vector instead of an N x N tensor.  Round-1 scope: LayerNorm, the Linear/Conv layers and the
+roll/pad/partition data movement still go through torch (DESIGN.md "next").
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import lib as L
+
+
+class _WindowAttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, table, labels, nW, Wh, Ww, heads, scale):
+        lib = L.load()
+        B_, N, C3 = qkv.shape
+        d = C3 // (3 * heads)
+        qkv = qkv.contiguous().float()
+        table = table.contiguous()
+        out = torch.empty(B_, N, heads * d, device=qkv.device)
+        lse = torch.empty(B_, heads, N, device=qkv.device)
+        L.check(lib.dlwp_window_attn_fwd(L.ptr(qkv), L.ptr(table), L.ptr(labels), L.ptr(out), L.ptr(lse), B_, nW, N,
+                                         Wh, Ww, heads, d, scale, L.stream()))
+        ctx.save_for_backward(qkv, table, out, lse)
+        ctx.labels, ctx.cfg = labels, (B_, nW, N, Wh, Ww, heads, d, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = L.load()
+        qkv, table, out, lse = ctx.saved_tensors
+        B_, nW, N, Wh, Ww, heads, d, scale = ctx.cfg
+        gqkv = torch.empty_like(qkv)
+        gtable = torch.zeros_like(table)
+        dsum = torch.empty_like(lse)
+        L.check(lib.dlwp_window_attn_bwd(L.ptr(qkv), L.ptr(table), L.ptr(ctx.labels), L.ptr(out), L.ptr(lse),
+                                         L.ptr(gout.contiguous().float()), L.ptr(gqkv), L.ptr(gtable), L.ptr(dsum),
+                                         B_, nW, N, Wh, Ww, heads, d, scale, L.stream()))
+        return gqkv, gtable, None, None, None, None, None, None
+
+
+def _pair(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+
+def _tokens_to_windows(x, ws):
+    B, H, W, C = x.shape
+    return x.view(B, H // ws, ws, W // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
+
+
+def _windows_to_tokens(wins, ws, H, W):
+    B = wins.shape[0] // ((H // ws) * (W // ws))
+    return wins.view(B, H // ws, W // ws, ws, ws, -1).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, -1)
+
+
+class WindowAttention(nn.Module):
+    def __init__(self, dim, window_size, num_heads, qkv_bias=True, qk_scale=None, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        if attn_drop or proj_drop:
+            raise NotImplementedError("dropout is not on the MI355X hot path (configs use 0.0)")
+        self.dim, self.window_size, self.num_heads = dim, _pair(window_size), num_heads
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        Wh, Ww = self.window_size
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * Wh - 1) * (2 * Ww - 1), num_heads))
+        ys, xs = torch.meshgrid(torch.arange(Wh), torch.arange(Ww), indexing="ij")
+        ys, xs = ys.reshape(-1), xs.reshape(-1)
+        index = (ys[:, None] - ys[None, :] + Wh - 1) * (2 * Ww - 1) + (xs[:, None] - xs[None, :] + Ww - 1)
+        self.register_buffer("relative_position_index", index)   # checkpoint compatibility only
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
+
+    def forward(self, x, labels=None, nW=1):
+        """x [nW*B, N, C]; labels: int32 [nW, N] region labels of the shift mask (None: no mask)."""
+        y = _WindowAttnFn.apply(self.qkv(x), self.relative_position_bias_table, labels, nW, self.window_size[0],
+                                self.window_size[1], self.num_heads, float(self.scale))
+        return self.proj(y)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class SwinTransformerBlock(nn.Module):
+    def __init__(self, dim, num_heads, window_size=7, shift_size=0, mlp_ratio=4., qkv_bias=True, qk_scale=None,
+                 drop=0., attn_drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm,
+                 padding_mode: str = "constant"):
+        super().__init__()
+        assert 0 <= shift_size < window_size, "shift_size must in 0-window_size"
+        if drop_path > 0.:
+            raise NotImplementedError("stochastic depth is not on the MI355X hot path (set drop_path_rate=0)")
+        self.window_size, self.shift_size, self.padding_mode = window_size, shift_size, padding_mode
+        self.norm1 = norm_layer(dim)
+        self.attn = WindowAttention(dim, _pair(window_size), num_heads, qkv_bias, qk_scale, attn_drop, drop)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.H = self.W = None
+
+    def forward(self, x, labels):
+        B, L_, C = x.shape
+        H, W, ws, sh = self.H, self.W, self.window_size, self.shift_size
+        assert L_ == H * W, "input feature has wrong size"
+        t = self.norm1(x).view(B, H, W, C)
+        t = F.pad(t, (0, 0, 0, (ws - W % ws) % ws, 0, (ws - H % ws) % ws), mode=self.padding_mode)
+        Hp, Wp = t.shape[1], t.shape[2]
+        if sh > 0:
+            t = torch.roll(t, shifts=(-sh, -sh), dims=(1, 2))
+        nW = (Hp // ws) * (Wp // ws)
+        t = self.attn(_tokens_to_windows(t, ws), labels if sh > 0 else None, nW)
+        t = _windows_to_tokens(t, ws, Hp, Wp)
+        if sh > 0:
+            t = torch.roll(t, shifts=(sh, sh), dims=(1, 2))
+        x = x + t[:, :H, :W, :].reshape(B, H * W, C)
+        return x + self.mlp(self.norm2(x))
+
+
+class PatchMerging(nn.Module):
+    def __init__(self, dim, norm_layer=nn.LayerNorm, padding_mode: str = "constant"):
+        super().__init__()
+        self.padding_mode = padding_mode
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = norm_layer(4 * dim)
+
+    def forward(self, x, H, W):
+        B, L_, C = x.shape
+        assert L_ == H * W, "input feature has wrong size"
+        x = x.view(B, H, W, C)
+        if H % 2 or W % 2:
+            x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2), mode=self.padding_mode)
+        x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)
+        return self.reduction(self.norm(x.reshape(B, -1, 4 * C)))
+
+
+class BasicLayer(nn.Module):
+    def __init__(self, dim, depth, num_heads, window_size=7, mlp_ratio=4., qkv_bias=True, qk_scale=None, drop=0.,
+                 attn_drop=0., drop_path=0., norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False,
+                 padding_mode: str = "constant"):
+        super().__init__()
+        self.window_size, self.shift_size, self.depth = window_size, window_size // 2, depth
+        self.blocks = nn.ModuleList([
+            SwinTransformerBlock(dim, num_heads, window_size, 0 if i % 2 == 0 else window_size // 2, mlp_ratio,
+                                 qkv_bias, qk_scale, drop, attn_drop,
+                                 drop_path[i] if isinstance(drop_path, list) else drop_path,
+                                 norm_layer=norm_layer, padding_mode=padding_mode) for i in range(depth)])
+        self.downsample = downsample(dim=dim, norm_layer=norm_layer, padding_mode=padding_mode) if downsample else None
+        self._labels = {}
+
+    def shift_labels(self, Hp, Wp, device):
+        """Region labels of the cyclically shifted canvas, one int32 vector per window (reference :377-393
+        builds the same regions and expands them to an [nW,N,N] -100/0 mask on every forward)."""
+        key = (Hp, Wp, str(device))
+        if key not in self._labels:
+            ws, sh = self.window_size, self.shift_size
+
+            def axis_labels(n):
+                lab = torch.zeros(n, dtype=torch.int32)
+                lab[n - ws:n - sh] = 1
+                if sh > 0:
+                    lab[n - sh:] = 2
+                return lab
+            img = axis_labels(Hp)[:, None] * 3 + axis_labels(Wp)[None, :]
+            lab = img.view(Hp // ws, ws, Wp // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws)
+            self._labels[key] = lab.contiguous().to(device)
+        return self._labels[key]
+
+    def forward(self, x, H, W):
+        ws = self.window_size
+        labels = self.shift_labels(math.ceil(H / ws) * ws, math.ceil(W / ws) * ws, x.device)
+        for blk in self.blocks:
+            blk.H, blk.W = H, W
+            x = blk(x, labels)
+        if self.downsample is not None:
+            return x, H, W, self.downsample(x, H, W), (H + 1) // 2, (W + 1) // 2
+        return x, H, W, x, H, W
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, patch_size=4, in_chans=3, embed_dim=96, norm_layer=None, padding_mode: str = "constant"):
+        super().__init__()
+        self.patch_size, self.embed_dim, self.padding_mode = _pair(patch_size), embed_dim, padding_mode
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
+        self.norm = norm_layer(embed_dim) if norm_layer is not None else None
+
+    def forward(self, x):
+        _, _, H, W = x.shape
+        ph, pw = self.patch_size
+        if W % pw:
+            x = F.pad(x, (0, pw - W % pw), mode=self.padding_mode)
+        if H % ph:
+            x = F.pad(x, (0, 0, 0, ph - H % ph), mode=self.padding_mode)
+        x = self.proj(x)
+        if self.norm is not None:
+            Wh, Ww = x.shape[2], x.shape[3]
+            x = self.norm(x.flatten(2).transpose(1, 2)).transpose(1, 2).reshape(-1, self.embed_dim, Wh, Ww)
+        return x
+
+
+_NORMS = {"nn.LayerNorm": nn.LayerNorm, "th.nn.LayerNorm": nn.LayerNorm, "torch.nn.LayerNorm": nn.LayerNorm}
+
+
+class SwinTransformer(nn.Module):
+    def __init__(self, context_size: int = 10, pretrain_img_size=224, patch_size=4, in_chans=3, out_chans=1,
+                 embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], mlp_ratio=4., qkv_bias=True,
+                 qk_scale=None, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.2, norm_layer="nn.LayerNorm",
+                 ape=False, patch_norm=True, frozen_stages=-1, use_checkpoint=False, padding_mode: str = "constant",
+                 **kwargs):
+        super().__init__()
+        if ape:
+            raise NotImplementedError("absolute position embedding is not on the MI355X hot path")
+        if drop_rate or attn_drop_rate or drop_path_rate:
+            raise NotImplementedError("dropout / stochastic depth are not on the MI355X hot path: pass "
+                                      "drop_rate=0 attn_drop_rate=0 drop_path_rate=0")
+        norm = _NORMS[norm_layer] if isinstance(norm_layer, str) else norm_layer   # registry instead of eval()
+        self.context_size, self.num_layers, self.embed_dim = context_size, len(depths), embed_dim
+        self.patch_embed = PatchEmbed(patch_size, in_chans * context_size, embed_dim, norm if patch_norm else None,
+                                      padding_mode)
+        resolution = pretrain_img_size // patch_size
+        self.layers = nn.ModuleList()
+        for i in range(self.num_layers):
+            # window = the stage's whole feature map (reference :528): global attention with a half-map shift
+            self.layers.append(BasicLayer(int(embed_dim * 2 ** i), depths[i], num_heads[i], resolution, mlp_ratio,
+                                          qkv_bias, qk_scale, norm_layer=norm,
+                                          downsample=PatchMerging if i < self.num_layers - 1 else None,
+                                          padding_mode=padding_mode))
+            resolution //= 2
+        self.num_features = [int(embed_dim * 2 ** i) for i in range(self.num_layers)]
+        for i, nf in enumerate(self.num_features):
+            self.add_module(f"norm{i}", norm(nf))
+        self.decoder = nn.ModuleList()
+        for idx, i in enumerate(reversed(range(self.num_layers))):
+            ch = int(embed_dim * 2 ** i)
+            self.decoder.append(nn.Sequential(
+                nn.ConvTranspose2d(ch if idx == 0 else 2 * ch, ch if i == 0 else ch // 2, kernel_size=2, stride=2),
+                nn.GELU()))
+        self.final = nn.Conv2d(embed_dim, out_chans, kernel_size=1)
+
+    def one_step(self, x):
+        x = self.patch_embed(x)
+        Wh, Ww = x.shape[2], x.shape[3]
+        x = x.flatten(2).transpose(1, 2)
+        feats = []
+        for i, layer in enumerate(self.layers):
+            x_out, H, W, x, Wh, Ww = layer(x, Wh, Ww)
+            x_out = getattr(self, f"norm{i}")(x_out)
+            feats.append(x_out.view(-1, H, W, self.num_features[i]).permute(0, 3, 1, 2).contiguous())
+        feats.reverse()
+        y = None
+        for idx, up in enumerate(self.decoder):
+            y = up(feats[idx] if idx == 0 else torch.cat([feats[idx], y], dim=1))
+        return self.final(y)
+
+    def forward(self, x: torch.Tensor, teacher_forcing_steps: int = 50) -> torch.Tensor:
+        outs, out, ctx = [], None, self.context_size
+        for t in range(x.shape[1]):
+            if t < teacher_forcing_steps:
+                x_t = x[:, max(0, t - (ctx - 1)):t + 1]
+            elif ctx == 0:
+                x_t = out
+            else:
+                ts = max(0, (teacher_forcing_steps - t - 1) + ctx)
+                x_t = torch.cat([x[:, teacher_forcing_steps - ts:teacher_forcing_steps],
+                                 torch.stack(outs[-(ctx - ts):], dim=1)], dim=1)
+            out = x_t[:, -1] if t < ctx - 1 else x_t[:, -1] + self.one_step(x_t.flatten(1, 2))
+            outs.append(out)
+        return torch.stack(outs, dim=1)

@@ -192,6 +192,27 @@ int dlwp_afno2d_bwd(const float* gy, const float* xsave, const float* w1, const 
                     float* gw2, float* gb2, int B, int H, int W, int C, int nb,
                     float sparsity_threshold, float hard_thresholding_fraction, void* stream);
 
+/* ------------------------------------------------------------------------------------ */
+/* Fused window attention core (Swin W-MSA / SW-MSA): out = softmax(scale q k^T + bias +  */
+/* mask) v without materialising the [B_,heads,N,N] scores.  Replaces the middle of        */
+/* WindowAttention.forward nsbench/models/swintransformer/swin_transformer.py:134-152       */
+/* (dlwpbench :133-151); the qkv / proj Linear layers stay outside.                         */
+/*   qkv    : [B_, N, 3, heads, d]  (the reference's reshape of the qkv Linear output)      */
+/*   bias_table : [(2Wh-1)(2Ww-1), heads] relative_position_bias_table (index computed       */
+/*            in-kernel from token coordinates, N = Wh*Ww row-major)                         */
+/*   labels : [nW, N] int32 region labels of the shifted-window mask or NULL; the mask       */
+/*            value is -100 where labels differ (swin_transformer.py:377-395)                */
+/*   out    : [B_, N, heads*d];  lse : [B_, heads, N] (saved for backward)                   */
+/* B_ = batch*nW with the window index fastest.  head_dim d <= 32.                           */
+int dlwp_window_attn_fwd(const float* qkv, const float* bias_table, const int* labels, float* out,
+                         float* lse, int B_, int nW, int N, int Wh, int Ww, int heads, int d,
+                         float scale, void* stream);
+/* gqkv is written; gbias_table is ACCUMULATED into; dsum: scratch [B_, heads, N].           */
+int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, const int* labels,
+                         const float* out, const float* lse, const float* gout, float* gqkv,
+                         float* gbias_table, float* dsum, int B_, int nW, int N, int Wh, int Ww,
+                         int heads, int d, float scale, void* stream);
+
 /* bench probe: ONE forward `spatial` launch of an inner FNO block as the rollout issues it     */
 /* (x = previous pre-activation, GELU on load; spec = [B][m1][m2c][C][2] mixed modes; fused      */
 /* W-axis DFT of gelu(pre) into x1_out [B][H][m2c][C][2]).                                       */

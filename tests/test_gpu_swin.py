@@ -1,0 +1,98 @@
+"""GPU parity of the window-attention path against golden vectors captured from the reference's own
+classes (tests/golden/swin_golden.npz).  Tolerance: 1e-4 forward, 5e-4 gradients (fp32, max-norm)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "swin_golden.npz"))
+
+
+def t(name):
+    return torch.from_numpy(G[name])
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def load(module, prefix):
+    sd = {k[len(prefix):]: t(k) for k in G.files if k.startswith(prefix)}
+    missing, unexpected = module.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("relative_position_index" in m for m in missing), missing
+
+
+@pytest.mark.parametrize("tag", ["nomask", "mask"])
+def test_window_attention_kernel_matches_reference_golden(cuda, tag):
+    from dlwp_benchmark_amd.nsbench.swin_transformer import WindowAttention
+    wa = WindowAttention(dim=12, window_size=(7, 7), num_heads=2)
+    load(wa, "wa_p_")
+    wa = wa.to(cuda)
+    x = t(f"wa_{tag}_x").to(cuda).requires_grad_(True)
+    labels = torch.from_numpy(G["wa_labels"]).to(cuda) if tag == "mask" else None
+    y = wa(x, labels, 4)
+    assert rel(y, t(f"wa_{tag}_y")) <= 1e-4
+    y.backward(t(f"wa_{tag}_gy").to(cuda))
+    assert rel(x.grad, t(f"wa_{tag}_gx")) <= 5e-4
+    for n, p in wa.named_parameters():
+        assert rel(p.grad, t(f"wa_{tag}_g_{n}")) <= 5e-4, n
+
+
+@pytest.mark.parametrize("tag,H,W,pm", [("28x28", 28, 28, "constant"), ("20x30", 20, 30, "circular")])
+def test_basic_layer_window7_matches_reference_golden(cuda, tag, H, W, pm):
+    from dlwp_benchmark_amd.nsbench.swin_transformer import BasicLayer
+    bl = BasicLayer(dim=8, depth=2, num_heads=2, window_size=7, padding_mode=pm)
+    load(bl, f"bl_{tag}_p_")
+    bl = bl.to(cuda)
+    x = t(f"bl_{tag}_x").to(cuda).requires_grad_(True)
+    y = bl(x, H, W)[0]
+    assert rel(y, t(f"bl_{tag}_y")) <= 1e-4
+    y.backward(t(f"bl_{tag}_gy").to(cuda))
+    assert rel(x.grad, t(f"bl_{tag}_gx")) <= 5e-4
+    for n, p in bl.named_parameters():
+        assert rel(p.grad, t(f"bl_{tag}_g_{n}")) <= 1e-3, n
+
+
+def test_swin_rollout_matches_reference_golden(cuda):
+    from dlwp_benchmark_amd.nsbench.swin_transformer import SwinTransformer
+    net = SwinTransformer(context_size=2, pretrain_img_size=32, patch_size=2, in_chans=1, out_chans=1, embed_dim=8,
+                          depths=[2, 2], num_heads=[2, 2], drop_path_rate=0.0, type="SwinTransformer", name="t")
+    load(net, "net_p_")
+    net = net.to(cuda)
+    y = net(t("net_x").to(cuda), teacher_forcing_steps=2)
+    assert rel(y, t("net_y")) <= 1e-4
+    loss = torch.nn.functional.mse_loss(y, t("net_target").to(cuda))
+    assert abs(loss.item() - float(G["net_loss"])) <= 1e-4 * abs(float(G["net_loss"]))
+    loss.backward()
+    for n, p in net.named_parameters():
+        if "net_g_" + n in G.files:
+            assert rel(p.grad, t("net_g_" + n)) <= 2e-3, n
+
+
+def test_large_window_many_tiles_matches_torch(cuda):
+    """N = 1024 tokens (window = whole 32x32 map as at nsbench stage 0), head_dim 10: 16 key tiles."""
+    from dlwp_benchmark_amd.nsbench.swin_transformer import WindowAttention
+    from oracle import swin_ref
+    g = torch.Generator().manual_seed(8)
+    wa = WindowAttention(dim=40, window_size=(32, 32), num_heads=4)
+    with torch.no_grad():
+        wa.relative_position_bias_table.copy_(torch.randn(wa.relative_position_bias_table.shape, generator=g) * 0.5)
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in wa.named_parameters()}
+    x = torch.randn(2, 1024, 40, generator=g)
+    labels = torch.randint(0, 4, (1, 1024), generator=g).to(torch.int32)
+    gy = torch.randn(2, 1024, 40, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = swin_ref.window_attention(xr, p, "", 32, 32, 4, labels)
+    yr.backward(gy)
+    wa = wa.to(cuda)
+    xd = x.to(cuda).requires_grad_(True)
+    y = wa(xd, labels.to(cuda), 1)
+    y.backward(gy.to(cuda))
+    assert rel(y, yr) <= 1e-4
+    assert rel(xd.grad, xr.grad) <= 5e-4
+    for n, q in wa.named_parameters():
+        assert rel(q.grad, p[n].grad) <= 1e-3, n
