@@ -8,8 +8,9 @@ norm, head) so reference checkpoints load.
 
 The spectral token mixer (AFNO2D: rfft2 -> block-diagonal complex MLP -> softshrink -> irfft2 ->
 residual) runs as one hand-written HIP kernel per direction (libdlwpmi dlwp_afno2d_fwd/bwd).
-Round-1 scope: LayerNorm, the token MLP, patch embedding and head still go through torch's library
-GEMMs (DESIGN.md "next").
+LayerNorm, the token MLP (GELU and residual fused in the GEMM epilogues) and the head run on libdlwpmi's
+MFMA GEMM / LayerNorm kernels (token_ops.py).  Round-1 scope: the patch-embedding convolution is still a
+torch library call (DESIGN.md "next").
 """
 from functools import partial
 
@@ -18,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import lib as L
+from ..token_ops import LayerNorm, Linear, Mlp
 
 
 class _AFNO2DFn(torch.autograd.Function):
@@ -76,22 +78,8 @@ class AFNO2D(nn.Module):
         return y.type(dtype)
 
 
-class Mlp(nn.Module):
-    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
-        super().__init__()
-        out_features = out_features or in_features
-        hidden_features = hidden_features or in_features
-        self.fc1 = nn.Linear(in_features, hidden_features)
-        self.act = act_layer()
-        self.fc2 = nn.Linear(hidden_features, out_features)
-        self.drop = nn.Dropout(drop)
-
-    def forward(self, x):
-        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
-
-
 class Block(nn.Module):
-    def __init__(self, dim, mlp_ratio=4., drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm,
+    def __init__(self, dim, mlp_ratio=4., drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=LayerNorm,
                  double_skip=True, num_blocks=8, sparsity_threshold=0.01, hard_thresholding_fraction=1.0):
         super().__init__()
         if drop_path > 0.:
@@ -108,8 +96,7 @@ class Block(nn.Module):
         if self.double_skip:
             x = x + residual
             residual = x
-        x = self.mlp(self.norm2(x))
-        return x + residual
+        return self.mlp(self.norm2(x), residual=residual)   # residual add fused into fc2's epilogue
 
 
 class PatchEmbed(nn.Module):
@@ -138,7 +125,7 @@ class AFNONet(nn.Module):
         self.num_features = self.embed_dim = embed_dim
         self.num_blocks = num_blocks
         self.context_size = context_size
-        norm_layer = partial(nn.LayerNorm, eps=1e-6)
+        norm_layer = partial(LayerNorm, eps=1e-6)
         self.patch_embed = PatchEmbed(self.img_size, self.patch_size, self.in_chans, embed_dim)
         self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches, embed_dim))
         self.pos_drop = nn.Dropout(p=drop_rate)
@@ -149,7 +136,7 @@ class AFNONet(nn.Module):
                   num_blocks=num_blocks, sparsity_threshold=sparsity_threshold,
                   hard_thresholding_fraction=hard_thresholding_fraction) for _ in range(depth)])
         self.norm = norm_layer(embed_dim)  # constructed but unused, as in the reference (:228, :251-261)
-        self.head = nn.Linear(embed_dim, self.out_chans * self.patch_size[0] * self.patch_size[1], bias=False)
+        self.head = Linear(embed_dim, self.out_chans * self.patch_size[0] * self.patch_size[1], bias=False)
         nn.init.trunc_normal_(self.pos_embed, std=.02)
         self.apply(self._init_weights)
 

@@ -8,8 +8,10 @@ Reference (file:line under /root/reference/src/nsbench/models/swintransformer/sw
 
 The attention core softmax(scale q k^T + bias + mask) v runs as hand-written HIP kernels
 (libdlwpmi dlwp_window_attn_fwd/bwd): scores never reach HBM, the shift mask is a per-window label
-vector instead of an N x N tensor.  Round-1 scope: LayerNorm, the Linear/Conv layers and the
-roll/pad/partition data movement still go through torch (DESIGN.md "next").
+vector instead of an N x N tensor.  LayerNorm, qkv/proj/MLP/merging
+Linear layers run on libdlwpmi's MFMA GEMM / LayerNorm kernels (token_ops.py).  Round-1 scope: the
+(transposed) convolutions of patch embedding / decoder and the roll/pad/partition data movement still go
+through torch (DESIGN.md "next").
 """
 import math
 
@@ -18,6 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import lib as L
+from ..token_ops import LayerNorm, Linear, Mlp
 
 
 class _WindowAttnFn(torch.autograd.Function):
@@ -77,8 +80,8 @@ class WindowAttention(nn.Module):
         ys, xs = ys.reshape(-1), xs.reshape(-1)
         index = (ys[:, None] - ys[None, :] + Wh - 1) * (2 * Ww - 1) + (xs[:, None] - xs[None, :] + Ww - 1)
         self.register_buffer("relative_position_index", index)   # checkpoint compatibility only
-        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
-        self.proj = nn.Linear(dim, dim)
+        self.qkv = Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = Linear(dim, dim)
         nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
 
     def forward(self, x, labels=None, nW=1):
@@ -88,20 +91,9 @@ class WindowAttention(nn.Module):
         return self.proj(y)
 
 
-class Mlp(nn.Module):
-    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
-        super().__init__()
-        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
-        self.act = act_layer()
-        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
-
-    def forward(self, x):
-        return self.fc2(self.act(self.fc1(x)))
-
-
 class SwinTransformerBlock(nn.Module):
     def __init__(self, dim, num_heads, window_size=7, shift_size=0, mlp_ratio=4., qkv_bias=True, qk_scale=None,
-                 drop=0., attn_drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm,
+                 drop=0., attn_drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=LayerNorm,
                  padding_mode: str = "constant"):
         super().__init__()
         assert 0 <= shift_size < window_size, "shift_size must in 0-window_size"
@@ -129,14 +121,14 @@ class SwinTransformerBlock(nn.Module):
         if sh > 0:
             t = torch.roll(t, shifts=(sh, sh), dims=(1, 2))
         x = x + t[:, :H, :W, :].reshape(B, H * W, C)
-        return x + self.mlp(self.norm2(x))
+        return self.mlp(self.norm2(x), residual=x)   # residual add fused into fc2's epilogue
 
 
 class PatchMerging(nn.Module):
-    def __init__(self, dim, norm_layer=nn.LayerNorm, padding_mode: str = "constant"):
+    def __init__(self, dim, norm_layer=LayerNorm, padding_mode: str = "constant"):
         super().__init__()
         self.padding_mode = padding_mode
-        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.reduction = Linear(4 * dim, 2 * dim, bias=False)
         self.norm = norm_layer(4 * dim)
 
     def forward(self, x, H, W):
@@ -151,7 +143,7 @@ class PatchMerging(nn.Module):
 
 class BasicLayer(nn.Module):
     def __init__(self, dim, depth, num_heads, window_size=7, mlp_ratio=4., qkv_bias=True, qk_scale=None, drop=0.,
-                 attn_drop=0., drop_path=0., norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False,
+                 attn_drop=0., drop_path=0., norm_layer=LayerNorm, downsample=None, use_checkpoint=False,
                  padding_mode: str = "constant"):
         super().__init__()
         self.window_size, self.shift_size, self.depth = window_size, window_size // 2, depth
@@ -213,7 +205,7 @@ class PatchEmbed(nn.Module):
         return x
 
 
-_NORMS = {"nn.LayerNorm": nn.LayerNorm, "th.nn.LayerNorm": nn.LayerNorm, "torch.nn.LayerNorm": nn.LayerNorm}
+_NORMS = {"nn.LayerNorm": LayerNorm, "th.nn.LayerNorm": LayerNorm, "torch.nn.LayerNorm": LayerNorm}
 
 
 class SwinTransformer(nn.Module):

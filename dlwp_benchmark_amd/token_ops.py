@@ -1,0 +1,116 @@
+"""nn.Linear / nn.LayerNorm / token-MLP counterparts whose arithmetic runs in libdlwpmi
+(dlwp_gemm, dlwp_layernorm_*, dlwp_gelu_bwd, dlwp_colsum).  They subclass the torch modules only to
+keep parameter names (`weight`, `bias`) and initialisation identical to the reference's layers
+(nsbench/models/fourcastnet/fourcastnet.py:40-56,213; swintransformer/swin_transformer.py:25-40,131,153).
+There is no torch fallback: CPU tensors are refused by lib.ptr().
+"""
+import torch
+import torch.nn as nn
+
+from . import lib as L
+
+
+def _gemm(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, bias=None, act=0, preact=None, residual=None, accumulate=0):
+    L.check(L.load().dlwp_gemm(L.ptr(A), L.ptr(B), L.ptr(C), M, N, K, lda, ldb, ldc, tA, tB, L.ptr(bias), act,
+                               L.ptr(preact), L.ptr(residual), accumulate, L.stream()))
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b) (+ residual); act = 0 none / 1 GELU."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, residual):
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1]).contiguous().float()
+        T, K = x2.shape
+        N = weight.shape[0]
+        w = weight.contiguous()
+        y = torch.empty(T, N, device=x.device)
+        z = torch.empty(T, N, device=x.device) if act else None
+        r2 = residual.reshape(-1, N).contiguous() if residual is not None else None
+        _gemm(x2, w, y, T, N, K, K, K, N, 0, 1, bias, act, z, r2)
+        ctx.save_for_backward(x2, w, z)
+        ctx.has_bias, ctx.has_res, ctx.act, ctx.shape = bias is not None, residual is not None, act, shape
+        return y.reshape(*shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = L.load()
+        x2, w, z = ctx.saved_tensors
+        T, K = x2.shape
+        N = w.shape[0]
+        g2 = gy.reshape(-1, N).contiguous().float()
+        gres = gy if ctx.has_res else None
+        if ctx.act:
+            gz = torch.empty_like(g2)
+            L.check(lib.dlwp_gelu_bwd(L.ptr(z), L.ptr(g2), L.ptr(gz), g2.numel(), L.stream()))
+            g2 = gz
+        gx = torch.empty(T, K, device=g2.device)
+        _gemm(g2, w, gx, T, K, N, N, K, K, 0, 0)                 # gx = g W
+        gw = torch.empty(N, K, device=g2.device)
+        _gemm(g2, x2, gw, N, K, T, N, K, K, 1, 0)                # gW = g^T x
+        gb = None
+        if ctx.has_bias:
+            gb = torch.zeros(N, device=g2.device)
+            L.check(lib.dlwp_colsum(L.ptr(g2), L.ptr(gb), T, N, L.stream()))
+        return gx.reshape(ctx.shape), gw, gb, None, gres
+
+
+def linear(x, weight, bias=None, act=0, residual=None):
+    return _LinearFn.apply(x, weight, bias, act, residual)
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        lib = L.load()
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1]).contiguous().float()
+        T, C_ = x2.shape
+        y = torch.empty_like(x2)
+        mean = torch.empty(T, device=x.device)
+        rstd = torch.empty(T, device=x.device)
+        L.check(lib.dlwp_layernorm_fwd(L.ptr(x2), L.ptr(gamma.contiguous()), L.ptr(beta.contiguous()), L.ptr(y),
+                                       L.ptr(mean), L.ptr(rstd), T, C_, eps, L.stream()))
+        ctx.save_for_backward(x2, gamma, mean, rstd)
+        ctx.shape = shape
+        return y.reshape(shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = L.load()
+        x2, gamma, mean, rstd = ctx.saved_tensors
+        T, C_ = x2.shape
+        g2 = gy.reshape(-1, C_).contiguous().float()
+        gx = torch.empty_like(x2)
+        gg, gb = torch.zeros_like(gamma), torch.zeros_like(gamma)
+        L.check(lib.dlwp_layernorm_bwd(L.ptr(x2), L.ptr(gamma.contiguous()), L.ptr(mean), L.ptr(rstd), L.ptr(g2),
+                                       L.ptr(gx), L.ptr(gg), L.ptr(gb), T, C_, L.stream()))
+        return gx.reshape(ctx.shape), gg, gb, None
+
+
+class Linear(nn.Linear):
+    def forward(self, x, act=0, residual=None):
+        return _LinearFn.apply(x, self.weight, self.bias, act, residual)
+
+
+class LayerNorm(nn.LayerNorm):
+    def forward(self, x):
+        return _LayerNormFn.apply(x, self.weight, self.bias, float(self.eps))
+
+
+class Mlp(nn.Module):
+    """fc1 -> GELU -> fc2 (+ residual): two MFMA GEMMs, GELU and the residual add fused in the epilogues."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        if drop:
+            raise NotImplementedError("dropout is not on the MI355X hot path (configs use 0.0)")
+        if act_layer is not nn.GELU:
+            raise NotImplementedError("only GELU token MLPs are on the hot path")
+        self.fc1 = Linear(in_features, hidden_features or in_features)
+        self.act = nn.GELU()   # kept for module-tree compatibility; applied inside fc1's epilogue
+        self.fc2 = Linear(hidden_features or in_features, out_features or in_features)
+
+    def forward(self, x, residual=None):
+        return self.fc2(self.fc1(x, act=1), residual=residual)

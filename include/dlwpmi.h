@@ -213,6 +213,28 @@ int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, const int* l
                          float* gbias_table, float* dsum, int B_, int nW, int N, int Wh, int Ww,
                          int heads, int d, float scale, void* stream);
 
+/* ------------------------------------------------------------------------------------ */
+/* Token-level building blocks of the AFNO / Swin / Pangu blocks (nn.Linear, nn.LayerNorm, */
+/* nn.GELU call sites: nsbench/models/fourcastnet/fourcastnet.py:44-46,213,233;             */
+/* nsbench/models/swintransformer/swin_transformer.py:35-39,131,153,187,194,274).           */
+/* C[M,N] (+)= epilogue(op(A)[M,K] . op(B)[K,N]); row-major with leading dimensions;         */
+/* epilogue: + bias[n], optional store of the pre-activation, act (0 none, 1 GELU),          */
+/* + residual[m,n] (same layout as C); accumulate != 0 adds into C.                          */
+int dlwp_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
+              int ldc, int transA, int transB, const float* bias, int act, float* preact,
+              const float* residual, int accumulate, void* stream);
+/* LayerNorm over the last dimension of x [T,C]; mean/rstd [T] are saved for backward.       */
+int dlwp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                       float* mean, float* rstd, int T, int C, float eps, void* stream);
+/* gx written; ggamma/gbeta ACCUMULATED into.  C <= 512.                                     */
+int dlwp_layernorm_bwd(const float* x, const float* gamma, const float* mean, const float* rstd,
+                       const float* gy, float* gx, float* ggamma, float* gbeta, int T, int C,
+                       void* stream);
+/* gz = gy * gelu'(z) (exact erf GELU)                                                       */
+int dlwp_gelu_bwd(const float* z, const float* gy, float* gz, long long n, void* stream);
+/* out[n] += sum_t g[t][n]   (bias gradients)                                                */
+int dlwp_colsum(const float* g, float* out, int T, int N, void* stream);
+
 /* bench probe: ONE forward `spatial` launch of an inner FNO block as the rollout issues it     */
 /* (x = previous pre-activation, GELU on load; spec = [B][m1][m2c][C][2] mixed modes; fused      */
 /* W-axis DFT of gelu(pre) into x1_out [B][H][m2c][C][2]).                                       */

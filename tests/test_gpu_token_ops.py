@@ -1,0 +1,61 @@
+"""GPU parity of the token-level kernels (MFMA GEMM with fused epilogue, LayerNorm, token MLP) against
+torch's CPU fp32 reference of the same ops (floating-point kernels: the oracle here is plain torch)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("T,K,N,act,res", [(1024, 64, 256, 1, False), (1024, 256, 64, 0, True), (77, 13, 29, 1, True),
+                                            (300, 96, 288, 0, False)])
+def test_linear_fwd_bwd(cuda, T, K, N, act, res):
+    from dlwp_benchmark_amd import token_ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(T, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * 0.1
+    r = torch.randn(T, N, generator=g) if res else None
+    gy = torch.randn(T, N, generator=g)
+    ref_in = [t.clone().requires_grad_(True) for t in (x, w, b)] + ([r.clone().requires_grad_(True)] if res else [])
+    y_ref = F.linear(ref_in[0], ref_in[1], ref_in[2])
+    if act:
+        y_ref = F.gelu(y_ref)
+    if res:
+        y_ref = y_ref + ref_in[3]
+    y_ref.backward(gy)
+    dev_in = [t.to(cuda).requires_grad_(True) for t in (x, w, b)] + ([r.to(cuda).requires_grad_(True)] if res else [])
+    y = token_ops.linear(dev_in[0], dev_in[1], dev_in[2], act, dev_in[3] if res else None)
+    y.backward(gy.to(cuda))
+    assert rel(y, y_ref) <= 1e-4
+    for got, ref in zip(dev_in, ref_in):
+        assert rel(got.grad, ref.grad) <= 5e-4
+
+
+@pytest.mark.parametrize("T,C,eps", [(1024, 64, 1e-6), (333, 40, 1e-5), (50, 384, 1e-5)])
+def test_layernorm_fwd_bwd(cuda, T, C, eps):
+    from dlwp_benchmark_amd import token_ops
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(T, C, generator=g) * 2 + 0.5
+    ln_ref = torch.nn.LayerNorm(C, eps=eps)
+    with torch.no_grad():
+        ln_ref.weight.copy_(torch.randn(C, generator=g))
+        ln_ref.bias.copy_(torch.randn(C, generator=g))
+    ln = token_ops.LayerNorm(C, eps=eps)
+    ln.load_state_dict(ln_ref.state_dict())
+    ln = ln.to(cuda)
+    gy = torch.randn(T, C, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ln_ref(xr).backward(gy)
+    xd = x.to(cuda).requires_grad_(True)
+    y = ln(xd)
+    y.backward(gy.to(cuda))
+    assert rel(y, ln_ref(x)) <= 1e-4
+    assert rel(xd.grad, xr.grad) <= 5e-4
+    assert rel(ln.weight.grad, ln_ref.weight.grad) <= 5e-4
+    assert rel(ln.bias.grad, ln_ref.bias.grad) <= 5e-4
