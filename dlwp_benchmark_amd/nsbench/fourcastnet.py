@@ -9,8 +9,7 @@ norm, head) so reference checkpoints load.
 The spectral token mixer (AFNO2D: rfft2 -> block-diagonal complex MLP -> softshrink -> irfft2 ->
 residual) runs as one hand-written HIP kernel per direction (libdlwpmi dlwp_afno2d_fwd/bwd).
 LayerNorm, the token MLP (GELU and residual fused in the GEMM epilogues) and the head run on libdlwpmi's
-MFMA GEMM / LayerNorm kernels (token_ops.py).  Round-1 scope: the patch-embedding convolution is still a
-torch library call (DESIGN.md "next").
+MFMA GEMM / LayerNorm kernels (token_ops.py).  The patch embedding is an unfold + the same GEMM (PatchConv2d).
 """
 from functools import partial
 
@@ -19,7 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import lib as L
-from ..token_ops import LayerNorm, Linear, Mlp
+from ..token_ops import LayerNorm, Linear, Mlp, PatchConv2d
 
 
 class _AFNO2DFn(torch.autograd.Function):
@@ -104,7 +103,7 @@ class PatchEmbed(nn.Module):
         super().__init__()
         self.num_patches = (img_size[1] // patch_size[1]) * (img_size[0] // patch_size[0])
         self.img_size, self.patch_size = img_size, patch_size
-        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.proj = PatchConv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
 
     def forward(self, x):
         B, C, H, W = x.shape

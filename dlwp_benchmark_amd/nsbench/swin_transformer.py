@@ -9,9 +9,9 @@ Reference (file:line under /root/reference/src/nsbench/models/swintransformer/sw
 The attention core softmax(scale q k^T + bias + mask) v runs as hand-written HIP kernels
 (libdlwpmi dlwp_window_attn_fwd/bwd): scores never reach HBM, the shift mask is a per-window label
 vector instead of an N x N tensor.  LayerNorm, qkv/proj/MLP/merging
-Linear layers run on libdlwpmi's MFMA GEMM / LayerNorm kernels (token_ops.py).  Round-1 scope: the
-(transposed) convolutions of patch embedding / decoder and the roll/pad/partition data movement still go
-through torch (DESIGN.md "next").
+Linear layers run on libdlwpmi's MFMA GEMM / LayerNorm kernels (token_ops.py).  Patch embedding, the U-decoder's
+stride-2 transposed convolutions (GELU fused) and the 1x1 head are unfold / pixel-shuffle + the same GEMM.
+Round-1 scope: roll / pad / window partition remain torch data movement (DESIGN.md "next").
 """
 import math
 
@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import lib as L
-from ..token_ops import LayerNorm, Linear, Mlp
+from ..token_ops import LayerNorm, Linear, Mlp, PatchConv2d, UpConvT2d
 
 
 class _WindowAttnFn(torch.autograd.Function):
@@ -188,7 +188,7 @@ class PatchEmbed(nn.Module):
     def __init__(self, patch_size=4, in_chans=3, embed_dim=96, norm_layer=None, padding_mode: str = "constant"):
         super().__init__()
         self.patch_size, self.embed_dim, self.padding_mode = _pair(patch_size), embed_dim, padding_mode
-        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
+        self.proj = PatchConv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
         self.norm = norm_layer(embed_dim) if norm_layer is not None else None
 
     def forward(self, x):
@@ -239,10 +239,12 @@ class SwinTransformer(nn.Module):
         self.decoder = nn.ModuleList()
         for idx, i in enumerate(reversed(range(self.num_layers))):
             ch = int(embed_dim * 2 ** i)
+            # nn.Sequential(ConvTranspose2d, GELU) keeps the reference's parameter names `decoder.{idx}.0.*`;
+            # the GELU is applied inside the transposed convolution's GEMM epilogue (one_step)
             self.decoder.append(nn.Sequential(
-                nn.ConvTranspose2d(ch if idx == 0 else 2 * ch, ch if i == 0 else ch // 2, kernel_size=2, stride=2),
+                UpConvT2d(ch if idx == 0 else 2 * ch, ch if i == 0 else ch // 2, kernel_size=2, stride=2),
                 nn.GELU()))
-        self.final = nn.Conv2d(embed_dim, out_chans, kernel_size=1)
+        self.final = PatchConv2d(embed_dim, out_chans, kernel_size=1)
 
     def one_step(self, x):
         x = self.patch_embed(x)
@@ -256,7 +258,7 @@ class SwinTransformer(nn.Module):
         feats.reverse()
         y = None
         for idx, up in enumerate(self.decoder):
-            y = up(feats[idx] if idx == 0 else torch.cat([feats[idx], y], dim=1))
+            y = up[0](feats[idx] if idx == 0 else torch.cat([feats[idx], y], dim=1), act=1)
         return self.final(y)
 
     def forward(self, x: torch.Tensor, teacher_forcing_steps: int = 50) -> torch.Tensor:

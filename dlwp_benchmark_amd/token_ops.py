@@ -114,3 +114,35 @@ class Mlp(nn.Module):
 
     def forward(self, x, residual=None):
         return self.fc2(self.fc1(x, act=1), residual=residual)
+
+
+class PatchConv2d(nn.Conv2d):
+    """Conv2d with kernel_size == stride (patch embedding, 1x1 heads): an unfold (pure data movement) followed by
+    the MFMA GEMM.  Parameter names/shapes are nn.Conv2d's (reference: PatchEmbed.proj fourcastnet.py:310,
+    swin_transformer.py:430; SwinTransformer.final :591)."""
+
+    def forward(self, x, act=0):
+        ph, pw = self.kernel_size
+        assert tuple(self.stride) == (ph, pw) and self.padding == (0, 0), "only kernel_size == stride, padding 0"
+        B, C_, H, W = x.shape
+        h, w = H // ph, W // pw
+        cols = x.reshape(B, C_, h, ph, w, pw).permute(0, 2, 4, 1, 3, 5).reshape(B * h * w, C_ * ph * pw)
+        y = _LinearFn.apply(cols, self.weight.reshape(self.out_channels, -1), self.bias, act, None)
+        return y.reshape(B, h, w, self.out_channels).permute(0, 3, 1, 2)
+
+
+class UpConvT2d(nn.ConvTranspose2d):
+    """ConvTranspose2d with kernel_size == stride (Swin U-decoder, swin_transformer.py:580-588): GEMM over the
+    input pixels followed by a pixel shuffle; an elementwise activation commutes with the shuffle and is fused
+    into the GEMM epilogue."""
+
+    def forward(self, x, act=0):
+        kh, kw = self.kernel_size
+        assert tuple(self.stride) == (kh, kw) and self.padding == (0, 0) and self.output_padding == (0, 0)
+        B, C_, H, W = x.shape
+        O = self.out_channels
+        tokens = x.permute(0, 2, 3, 1).reshape(B * H * W, C_)
+        wmat = self.weight.reshape(C_, O * kh * kw).t()                 # [O*kh*kw, Cin] as a Linear weight
+        bias = self.bias.repeat_interleave(kh * kw) if self.bias is not None else None
+        y = _LinearFn.apply(tokens, wmat, bias, act, None)
+        return y.reshape(B, H, W, O, kh, kw).permute(0, 3, 1, 4, 2, 5).reshape(B, O, H * kh, W * kw)
