@@ -8,9 +8,10 @@
 // head); keys/values stream through LDS in tiles of 64.  All products run on the exact-f32 MFMA in
 // the TRANSPOSED orientation (S^T = K Q^T: rows = keys, columns = queries), so that the score
 // accumulator is directly the B operand of O^T = V^T P^T (permuted-k trick, common.cuh) and the
-// softmax statistics of a query live in one lane.  The relative-position bias is looked up from a
-// per-head LDS copy of the table with the index computed arithmetically from token coordinates (no
-// N x N index tensor); the shift mask is `label[q] != label[k] ? -100 : 0` from a per-window label
+// softmax statistics of a query live in one lane.  The position bias is looked up from a per-(head,
+// window type) LDS copy of the table; its index is additive in the two tokens, idx = ia[q] + ib[k]
+// (Swin: relative offsets; Pangu: earth-specific absolute pressure/latitude + relative longitude), so
+// two N-vectors replace the N x N index tensor; the shift mask is `label[q] != label[k] ? -100 : 0` from a per-window label
 // vector (no N x N mask tensor).  Backward: kernel Q (dQ, dBias, D = rowsum(dO*O)) and kernel KV
 // (dK, dV), each recomputing the score tile it needs.
 #include "common.cuh"
@@ -24,6 +25,8 @@ struct WaDev {
     const float* qkv;          // [B_, N, 3, heads, d]
     const float* table;        // [(2Wh-1)(2Ww-1), heads]
     const int* labels;         // [nW, N] or nullptr
+    const int *ia, *ib;        // [N] each: bias index of (query q, key k) = ia[q] + ib[k]
+    int ntypes;                // bias table is [TB, ntypes, heads]; window type = window index % ntypes
     float* out;                // fwd: [B_, N, heads*d]
     float* lse;                // fwd: [B_, heads, N]
     const float* lse_in;       // bwd: saved log-sum-exp
@@ -32,7 +35,7 @@ struct WaDev {
     float* dsum;               // bwd: [B_, heads, N]  D = rowsum(gout * out)
     float* gqkv;               // bwd: [B_, N, 3, heads, d]
     float* gtable;             // bwd: accumulated
-    int B_, nW, N, Wh, Ww, heads, d, dp16, TB;
+    int B_, nW, N, heads, d, dp16, TB;
     float scale;
 };
 
@@ -75,6 +78,7 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(WaDev a) {
     float* Vs = Ks + 64 * LDT;
     float* tb = Vs + 64 * LDT;                // [TB] bias table of this head
     int* klab = reinterpret_cast<int*>(tb + a.TB);   // [64]
+    int* kbs = klab + 64;                            // [64] key part of the bias index
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
     const int nqt = (a.N + QT - 1) / QT;
     const int qt = blockIdx.x % nqt, bh = blockIdx.x / nqt, head = bh % a.heads, b = bh / a.heads;
@@ -83,10 +87,11 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(WaDev a) {
     const float* qb = a.qkv + (long long)b * a.N * rs + head * a.d;
     const int dp4 = (a.d + 3) & ~3;
     stage_rows(Qs, LDT, qb, rs, qt * QT, a.N, a.d, a.dp16, a.scale);
-    for (int i = tid; i < a.TB; i += 256) tb[i] = a.table[(long long)i * a.heads + head];
+    const long long tofs = (long long)(wdw % a.ntypes) * a.heads + head, tstr = (long long)a.ntypes * a.heads;
+    for (int i = tid; i < a.TB; i += 256) tb[i] = a.table[i * tstr + tofs];
     const int q = qt * QT + w * 16 + r;                       // this lane's query (column)
-    const int qc = q < a.N ? q : a.N - 1;                      // clamped for coordinate / table indexing
-    const int qy = qc / a.Ww, qx = qc - qy * a.Ww;
+    const int qc = q < a.N ? q : a.N - 1;                      // clamped for table indexing
+    const int qa = a.ia[qc];
     const int qlab = (a.labels && q < a.N) ? a.labels[(long long)wdw * a.N + q] : 0;
     float m = -1e30f, l = 0.f;
     f32x4 oacc[NDB];
@@ -97,7 +102,10 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(WaDev a) {
         __syncthreads();
         stage_rows(Ks, LDT, qb + a.heads * a.d, rs, kt0, a.N, a.d, a.dp16, 1.f);
         stage_rows(Vs, LDT, qb + 2 * a.heads * a.d, rs, kt0, a.N, a.d, a.dp16, 1.f);
-        if (tid < KT) klab[tid] = (a.labels && kt0 + tid < a.N) ? a.labels[(long long)wdw * a.N + kt0 + tid] : 0;
+        if (tid < KT) {
+            klab[tid] = (a.labels && kt0 + tid < a.N) ? a.labels[(long long)wdw * a.N + kt0 + tid] : 0;
+            kbs[tid] = kt0 + tid < a.N ? a.ib[kt0 + tid] : 0;
+        }
         __syncthreads();
         f32x4 s[4];
         float mx = -1e30f;
@@ -109,8 +117,7 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(WaDev a) {
                 const int key = kt0 + 16 * c + 4 * g + j;
                 float v = -1e30f;
                 if (key < a.N) {
-                    const int ky = key / a.Ww, kx = key - ky * a.Ww;
-                    v = s[c][j] + tb[(qy - ky + a.Wh - 1) * (2 * a.Ww - 1) + (qx - kx + a.Ww - 1)];
+                    v = s[c][j] + tb[qa + kbs[16 * c + 4 * g + j]];
                     if (a.labels && klab[16 * c + 4 * g + j] != qlab) v -= 100.f;
                 }
                 s[c][j] = v;
@@ -170,6 +177,7 @@ __global__ __launch_bounds__(256) void winattn_bwd_q_kernel(WaDev a) {
     float* tb = Vs + 64 * LDT;                // [TB] bias table
     float* gtb = tb + a.TB;                   // [TB] bias-gradient partial of this workgroup
     int* klab = reinterpret_cast<int*>(gtb + a.TB);
+    int* kbs = klab + 64;
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
     const int nqt = (a.N + QT - 1) / QT;
     const int qt = blockIdx.x % nqt, bh = blockIdx.x / nqt, head = bh % a.heads, b = bh / a.heads;
@@ -179,9 +187,10 @@ __global__ __launch_bounds__(256) void winattn_bwd_q_kernel(WaDev a) {
     const int dp4 = (a.d + 3) & ~3;
     stage_rows(Qs, LDT, qb, rs, qt * QT, a.N, a.d, a.dp16, a.scale);
     stage_rows(Gs, LDT, a.gout + (long long)b * a.N * os + head * a.d, os, qt * QT, a.N, a.d, a.dp16, 1.f);
-    for (int i = tid; i < a.TB; i += 256) { tb[i] = a.table[(long long)i * a.heads + head]; gtb[i] = 0.f; }
+    const long long tofs = (long long)(wdw % a.ntypes) * a.heads + head, tstr = (long long)a.ntypes * a.heads;
+    for (int i = tid; i < a.TB; i += 256) { tb[i] = a.table[i * tstr + tofs]; gtb[i] = 0.f; }
     const int q = qt * QT + w * 16 + r;
-    const int qy = q / a.Ww, qx = q - qy * a.Ww;
+    const int qa = a.ia[q < a.N ? q : a.N - 1];
     const int qlab = (a.labels && q < a.N) ? a.labels[(long long)wdw * a.N + q] : 0;
     const float lse = q < a.N ? a.lse_in[((long long)b * a.heads + head) * a.N + q] : 0.f;
     __syncthreads();
@@ -200,7 +209,10 @@ __global__ __launch_bounds__(256) void winattn_bwd_q_kernel(WaDev a) {
         __syncthreads();
         stage_rows(Ks, LDT, qb + a.heads * a.d, rs, kt0, a.N, a.d, a.dp16, 1.f);
         stage_rows(Vs, LDT, qb + 2 * a.heads * a.d, rs, kt0, a.N, a.d, a.dp16, 1.f);
-        if (tid < KT) klab[tid] = (a.labels && kt0 + tid < a.N) ? a.labels[(long long)wdw * a.N + kt0 + tid] : 0;
+        if (tid < KT) {
+            klab[tid] = (a.labels && kt0 + tid < a.N) ? a.labels[(long long)wdw * a.N + kt0 + tid] : 0;
+            kbs[tid] = kt0 + tid < a.N ? a.ib[kt0 + tid] : 0;
+        }
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -212,8 +224,7 @@ __global__ __launch_bounds__(256) void winattn_bwd_q_kernel(WaDev a) {
                 const int key = kt0 + 16 * c + 4 * g + j;
                 float v = 0.f;
                 if (key < a.N && q < a.N) {
-                    const int ky = key / a.Ww, kx = key - ky * a.Ww;
-                    const int bi = (qy - ky + a.Wh - 1) * (2 * a.Ww - 1) + (qx - kx + a.Ww - 1);
+                    const int bi = qa + kbs[16 * c + 4 * g + j];
                     float sc = s[j] + tb[bi];
                     if (a.labels && klab[16 * c + 4 * g + j] != qlab) sc -= 100.f;
                     const float p = __expf(sc - lse);
@@ -243,7 +254,7 @@ __global__ __launch_bounds__(256) void winattn_bwd_q_kernel(WaDev a) {
     __syncthreads();
     for (int i = tid; i < a.TB; i += 256) {
         const float v = gtb[i];
-        if (v != 0.f) atomic_add_f32(&a.gtable[(long long)i * a.heads + head], v);
+        if (v != 0.f) atomic_add_f32(&a.gtable[i * tstr + tofs], v);
     }
 }
 
@@ -261,6 +272,7 @@ __global__ __launch_bounds__(256) void winattn_bwd_kv_kernel(WaDev a) {
     float* lses = tb + a.TB;                  // [64]
     float* dss = lses + 64;                   // [64]
     int* qlabs = reinterpret_cast<int*>(dss + 64);   // [64]
+    int* qas = qlabs + 64;                           // [64] query part of the bias index
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
     const int nkt = (a.N + KT - 1) / KT;
     const int kt = blockIdx.x % nkt, bh = blockIdx.x / nkt, head = bh % a.heads, b = bh / a.heads;
@@ -270,9 +282,10 @@ __global__ __launch_bounds__(256) void winattn_bwd_kv_kernel(WaDev a) {
     const int dp4 = (a.d + 3) & ~3;
     stage_rows(Ks, LDT, qb + a.heads * a.d, rs, kt * KT, a.N, a.d, a.dp16, 1.f);
     stage_rows(Vs, LDT, qb + 2 * a.heads * a.d, rs, kt * KT, a.N, a.d, a.dp16, 1.f);
-    for (int i = tid; i < a.TB; i += 256) tb[i] = a.table[(long long)i * a.heads + head];
+    const long long tofs = (long long)(wdw % a.ntypes) * a.heads + head, tstr = (long long)a.ntypes * a.heads;
+    for (int i = tid; i < a.TB; i += 256) tb[i] = a.table[i * tstr + tofs];
     const int key = kt * KT + w * 16 + r;                     // this lane's key (column)
-    const int ky = key / a.Ww, kx = key - ky * a.Ww;
+    const int kbv = a.ib[key < a.N ? key : a.N - 1];
     const int klabel = (a.labels && key < a.N) ? a.labels[(long long)wdw * a.N + key] : 0;
     f32x4 dk[NDB], dv[NDB];
 #pragma unroll
@@ -287,6 +300,7 @@ __global__ __launch_bounds__(256) void winattn_bwd_kv_kernel(WaDev a) {
             lses[tid] = ok ? a.lse_in[((long long)b * a.heads + head) * a.N + qt0 + tid] : 0.f;
             dss[tid] = ok ? a.dsum[((long long)b * a.heads + head) * a.N + qt0 + tid] : 0.f;
             qlabs[tid] = (a.labels && ok) ? a.labels[(long long)wdw * a.N + qt0 + tid] : 0;
+            qas[tid] = ok ? a.ia[qt0 + tid] : 0;
         }
         __syncthreads();
 #pragma unroll
@@ -300,8 +314,7 @@ __global__ __launch_bounds__(256) void winattn_bwd_kv_kernel(WaDev a) {
                 const int ql = 16 * c + 4 * g + j, q = qt0 + ql;
                 float pv = 0.f, dsv = 0.f;
                 if (q < a.N && key < a.N) {
-                    const int qy = q / a.Ww, qx = q - qy * a.Ww;
-                    float sc = s[j] + tb[(qy - ky + a.Wh - 1) * (2 * a.Ww - 1) + (qx - kx + a.Ww - 1)];
+                    float sc = s[j] + tb[qas[ql] + kbv];
                     if (a.labels && qlabs[ql] != klabel) sc -= 100.f;
                     pv = __expf(sc - lses[ql]);
                     dsv = pv * (dp[j] - dss[ql]);
@@ -337,27 +350,28 @@ __global__ __launch_bounds__(256) void winattn_bwd_kv_kernel(WaDev a) {
     }
 }
 
-int wa_setup(WaDev& a, int B_, int nW, int N, int Wh, int Ww, int heads, int d, float scale, const char* who) {
-    DLWP_REQUIRE(B_ > 0 && nW > 0 && B_ % nW == 0 && N > 0 && heads > 0 && d > 0, DLWP_E_INVALID, "%s: bad shape", who);
-    DLWP_REQUIRE(N == Wh * Ww, DLWP_E_INVALID, "%s: N (%d) != Wh*Ww (%d*%d)", who, N, Wh, Ww);
+int wa_setup(WaDev& a, int B_, int nW, int N, int TB, int ntypes, int heads, int d, float scale, const char* who) {
+    DLWP_REQUIRE(B_ > 0 && nW > 0 && B_ % nW == 0 && N > 0 && heads > 0 && d > 0 && TB > 0 && ntypes > 0,
+                 DLWP_E_INVALID, "%s: bad shape", who);
+    DLWP_REQUIRE(nW % ntypes == 0, DLWP_E_INVALID, "%s: nW (%d) must be a multiple of ntypes (%d)", who, nW, ntypes);
     DLWP_REQUIRE(d <= 32, DLWP_E_UNSUPPORTED, "%s: head_dim %d > 32 not supported yet", who, d);
-    a.B_ = B_; a.nW = nW; a.N = N; a.Wh = Wh; a.Ww = Ww; a.heads = heads; a.d = d; a.scale = scale;
+    DLWP_REQUIRE(TB <= 12000, DLWP_E_UNSUPPORTED, "%s: bias table slice of %d entries does not fit LDS", who, TB);
+    a.B_ = B_; a.nW = nW; a.N = N; a.TB = TB; a.ntypes = ntypes; a.heads = heads; a.d = d; a.scale = scale;
     a.dp16 = round_up(d, 16);
-    a.TB = (2 * Wh - 1) * (2 * Ww - 1);
     return DLWP_OK;
 }
 
 }  // namespace
 
-extern "C" int dlwp_window_attn_fwd(const float* qkv, const float* bias_table, const int* labels, float* out,
-                                    float* lse, int B_, int nW, int N, int Wh, int Ww, int heads, int d, float scale,
-                                    void* stream) {
-    DLWP_REQUIRE(qkv && bias_table && out && lse, DLWP_E_INVALID, "window_attn_fwd: NULL argument");
+extern "C" int dlwp_window_attn_fwd(const float* qkv, const float* bias_table, const int* ia, const int* ib,
+                                    const int* labels, float* out, float* lse, int B_, int nW, int N, int TB,
+                                    int ntypes, int heads, int d, float scale, void* stream) {
+    DLWP_REQUIRE(qkv && bias_table && ia && ib && out && lse, DLWP_E_INVALID, "window_attn_fwd: NULL argument");
     WaDev a{};
-    int rc = wa_setup(a, B_, nW, N, Wh, Ww, heads, d, scale, "window_attn_fwd");
+    int rc = wa_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, "window_attn_fwd");
     if (rc) return rc;
-    a.qkv = qkv; a.table = bias_table; a.labels = labels; a.out = out; a.lse = lse;
-    const size_t lds = sizeof(float) * ((size_t)3 * 64 * (a.dp16 + 2) + a.TB + 64);
+    a.qkv = qkv; a.table = bias_table; a.ia = ia; a.ib = ib; a.labels = labels; a.out = out; a.lse = lse;
+    const size_t lds = sizeof(float) * ((size_t)3 * 64 * (a.dp16 + 2) + a.TB + 128);
     const dim3 grid(B_ * heads * ((N + QT - 1) / QT)), block(256);
     if (a.dp16 == 16) {
         if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_fwd_kernel<1>), lds, "window_attn_fwd"))) return rc;
@@ -370,19 +384,20 @@ extern "C" int dlwp_window_attn_fwd(const float* qkv, const float* bias_table, c
     return DLWP_OK;
 }
 
-extern "C" int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, const int* labels, const float* out,
-                                    const float* lse, const float* gout, float* gqkv, float* gbias_table, float* dsum,
-                                    int B_, int nW, int N, int Wh, int Ww, int heads, int d, float scale, void* stream) {
-    DLWP_REQUIRE(qkv && bias_table && out && lse && gout && gqkv && gbias_table && dsum, DLWP_E_INVALID,
+extern "C" int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, const int* ia, const int* ib,
+                                    const int* labels, const float* out, const float* lse, const float* gout,
+                                    float* gqkv, float* gbias_table, float* dsum, int B_, int nW, int N, int TB,
+                                    int ntypes, int heads, int d, float scale, void* stream) {
+    DLWP_REQUIRE(qkv && bias_table && ia && ib && out && lse && gout && gqkv && gbias_table && dsum, DLWP_E_INVALID,
                  "window_attn_bwd: NULL argument");
     WaDev a{};
-    int rc = wa_setup(a, B_, nW, N, Wh, Ww, heads, d, scale, "window_attn_bwd");
+    int rc = wa_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, "window_attn_bwd");
     if (rc) return rc;
-    a.qkv = qkv; a.table = bias_table; a.labels = labels; a.o = out; a.lse_in = lse; a.gout = gout; a.gqkv = gqkv;
+    a.qkv = qkv; a.table = bias_table; a.ia = ia; a.ib = ib; a.labels = labels; a.o = out; a.lse_in = lse; a.gout = gout; a.gqkv = gqkv;
     a.gtable = gbias_table; a.dsum = dsum;
     const int LDT = a.dp16 + 2;
-    const size_t lds_q = sizeof(float) * ((size_t)4 * 64 * LDT + 2 * a.TB + 64);
-    const size_t lds_kv = sizeof(float) * ((size_t)4 * 64 * LDT + a.TB + 3 * 64);
+    const size_t lds_q = sizeof(float) * ((size_t)4 * 64 * LDT + 2 * a.TB + 128);
+    const size_t lds_kv = sizeof(float) * ((size_t)4 * 64 * LDT + a.TB + 4 * 64);
     const dim3 grid(B_ * heads * ((N + QT - 1) / QT)), block(256);
     if (a.dp16 == 16) {
         if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_bwd_q_kernel<1>), lds_q, "window_attn_bwd"))) return rc;

@@ -24,33 +24,42 @@ from ..token_ops import LayerNorm, Linear, Mlp, PatchConv2d, UpConvT2d
 
 
 class _WindowAttnFn(torch.autograd.Function):
+    """softmax(scale q k^T + table[ia[q] + ib[k]][type] + mask) v on libdlwpmi (dlwp_window_attn_fwd/bwd)."""
+
     @staticmethod
-    def forward(ctx, qkv, table, labels, nW, Wh, Ww, heads, scale):
+    def forward(ctx, qkv, table, ia, ib, labels, nW, heads, scale):
         lib = L.load()
         B_, N, C3 = qkv.shape
         d = C3 // (3 * heads)
         qkv = qkv.contiguous().float()
         table = table.contiguous()
+        TB = table.shape[0]
+        ntypes = table.shape[1] if table.dim() == 3 else 1
         out = torch.empty(B_, N, heads * d, device=qkv.device)
         lse = torch.empty(B_, heads, N, device=qkv.device)
-        L.check(lib.dlwp_window_attn_fwd(L.ptr(qkv), L.ptr(table), L.ptr(labels), L.ptr(out), L.ptr(lse), B_, nW, N,
-                                         Wh, Ww, heads, d, scale, L.stream()))
+        L.check(lib.dlwp_window_attn_fwd(L.ptr(qkv), L.ptr(table), L.ptr(ia), L.ptr(ib), L.ptr(labels), L.ptr(out),
+                                         L.ptr(lse), B_, nW, N, TB, ntypes, heads, d, scale, L.stream()))
         ctx.save_for_backward(qkv, table, out, lse)
-        ctx.labels, ctx.cfg = labels, (B_, nW, N, Wh, Ww, heads, d, scale)
+        ctx.aux, ctx.cfg = (ia, ib, labels), (B_, nW, N, TB, ntypes, heads, d, scale)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         lib = L.load()
         qkv, table, out, lse = ctx.saved_tensors
-        B_, nW, N, Wh, Ww, heads, d, scale = ctx.cfg
+        ia, ib, labels = ctx.aux
+        B_, nW, N, TB, ntypes, heads, d, scale = ctx.cfg
         gqkv = torch.empty_like(qkv)
         gtable = torch.zeros_like(table)
         dsum = torch.empty_like(lse)
-        L.check(lib.dlwp_window_attn_bwd(L.ptr(qkv), L.ptr(table), L.ptr(ctx.labels), L.ptr(out), L.ptr(lse),
-                                         L.ptr(gout.contiguous().float()), L.ptr(gqkv), L.ptr(gtable), L.ptr(dsum),
-                                         B_, nW, N, Wh, Ww, heads, d, scale, L.stream()))
+        L.check(lib.dlwp_window_attn_bwd(L.ptr(qkv), L.ptr(table), L.ptr(ia), L.ptr(ib), L.ptr(labels), L.ptr(out),
+                                         L.ptr(lse), L.ptr(gout.contiguous().float()), L.ptr(gqkv), L.ptr(gtable),
+                                         L.ptr(dsum), B_, nW, N, TB, ntypes, heads, d, scale, L.stream()))
         return gqkv, gtable, None, None, None, None, None, None
+
+
+def window_attention_core(qkv, table, ia, ib, labels, nW, heads, scale):
+    return _WindowAttnFn.apply(qkv, table, ia, ib, labels, nW, heads, scale)
 
 
 def _pair(v):
@@ -80,14 +89,17 @@ class WindowAttention(nn.Module):
         ys, xs = ys.reshape(-1), xs.reshape(-1)
         index = (ys[:, None] - ys[None, :] + Wh - 1) * (2 * Ww - 1) + (xs[:, None] - xs[None, :] + Ww - 1)
         self.register_buffer("relative_position_index", index)   # checkpoint compatibility only
+        # the index is additive in query and key: index[q][k] = ia[q] + ib[k]
+        self.register_buffer("_ia", (ys * (2 * Ww - 1) + xs).to(torch.int32), persistent=False)
+        self.register_buffer("_ib", ((Wh - 1 - ys) * (2 * Ww - 1) + (Ww - 1 - xs)).to(torch.int32), persistent=False)
         self.qkv = Linear(dim, dim * 3, bias=qkv_bias)
         self.proj = Linear(dim, dim)
         nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
 
     def forward(self, x, labels=None, nW=1):
         """x [nW*B, N, C]; labels: int32 [nW, N] region labels of the shift mask (None: no mask)."""
-        y = _WindowAttnFn.apply(self.qkv(x), self.relative_position_bias_table, labels, nW, self.window_size[0],
-                                self.window_size[1], self.num_heads, float(self.scale))
+        y = _WindowAttnFn.apply(self.qkv(x), self.relative_position_bias_table, self._ia, self._ib, labels, nW,
+                                self.num_heads, float(self.scale))
         return self.proj(y)
 
 

@@ -193,25 +193,28 @@ int dlwp_afno2d_bwd(const float* gy, const float* xsave, const float* w1, const 
                     float sparsity_threshold, float hard_thresholding_fraction, void* stream);
 
 /* ------------------------------------------------------------------------------------ */
-/* Fused window attention core (Swin W-MSA / SW-MSA): out = softmax(scale q k^T + bias +  */
-/* mask) v without materialising the [B_,heads,N,N] scores.  Replaces the middle of        */
-/* WindowAttention.forward nsbench/models/swintransformer/swin_transformer.py:134-152       */
-/* (dlwpbench :133-151); the qkv / proj Linear layers stay outside.                         */
+/* Fused window attention core (Swin W-MSA / SW-MSA and Pangu EarthAttention3D): out =     */
+/* softmax(scale q k^T + bias + mask) v without materialising the [windows,heads,N,N]      */
+/* scores.  Replaces the middle of WindowAttention.forward nsbench/models/swintransformer/  */
+/* swin_transformer.py:134-152 (dlwpbench :133-151) and of EarthAttention3D.forward         */
+/* dlwpbench/models/panguweather/panguweather.py:186-208; qkv / proj Linear stay outside.   */
 /*   qkv    : [B_, N, 3, heads, d]  (the reference's reshape of the qkv Linear output)      */
-/*   bias_table : [(2Wh-1)(2Ww-1), heads] relative_position_bias_table (index computed       */
-/*            in-kernel from token coordinates, N = Wh*Ww row-major)                         */
+/*   bias_table : [TB, ntypes, heads]; the bias of (query q, key k) is                       */
+/*            table[ia[q] + ib[k]][window % ntypes][head]  (ia, ib: int32 [N]).  Swin:        */
+/*            ntypes = 1, ia = y(2Ww-1)+x, ib = (Wh-1-y)(2Ww-1)+(Ww-1-x); Pangu: see          */
+/*            utils/earth_position_index.py:4-45 (index additive in query and key).            */
 /*   labels : [nW, N] int32 region labels of the shifted-window mask or NULL; the mask       */
 /*            value is -100 where labels differ (swin_transformer.py:377-395)                */
 /*   out    : [B_, N, heads*d];  lse : [B_, heads, N] (saved for backward)                   */
 /* B_ = batch*nW with the window index fastest.  head_dim d <= 32.                           */
-int dlwp_window_attn_fwd(const float* qkv, const float* bias_table, const int* labels, float* out,
-                         float* lse, int B_, int nW, int N, int Wh, int Ww, int heads, int d,
-                         float scale, void* stream);
+int dlwp_window_attn_fwd(const float* qkv, const float* bias_table, const int* ia, const int* ib,
+                         const int* labels, float* out, float* lse, int B_, int nW, int N, int TB,
+                         int ntypes, int heads, int d, float scale, void* stream);
 /* gqkv is written; gbias_table is ACCUMULATED into; dsum: scratch [B_, heads, N].           */
-int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, const int* labels,
-                         const float* out, const float* lse, const float* gout, float* gqkv,
-                         float* gbias_table, float* dsum, int B_, int nW, int N, int Wh, int Ww,
-                         int heads, int d, float scale, void* stream);
+int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, const int* ia, const int* ib,
+                         const int* labels, const float* out, const float* lse, const float* gout,
+                         float* gqkv, float* gbias_table, float* dsum, int B_, int nW, int N,
+                         int TB, int ntypes, int heads, int d, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* Token-level building blocks of the AFNO / Swin / Pangu blocks (nn.Linear, nn.LayerNorm, */
