@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void fno_rows_kernel(RowsDev a) {
     store_x1(x1s, a.x1, b, h, a.H, a.m2c, a.C, a.C_pad, a.NP);
 }
 
-template <int NCB, int NBN>
+// MODE 0: forward (+bias); 1: backward with GELU' of the block input; 2: backward, input was not activated
+template <int NCB, int NBN, int MODE>
 __global__ __launch_bounds__(256) void fno_spatial_kernel(SpatialDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int LDP = a.W + 4, LDK = a.C_pad + 4, LDS1 = a.NP + 4;
@@ -168,9 +169,10 @@ __global__ __launch_bounds__(256) void fno_spatial_kernel(SpatialDev a) {
     const long long jstride = (long long)a.m2c * a.C;
 #pragma unroll
     for (int j = 0; j < MJ; ++j) sv[j] = sp[(j < a.m1 ? j : a.m1 - 1) * jstride];
-    float2 twv[MJ];
-#pragma unroll
-    for (int j = 0; j < MJ; ++j) twv[j] = a.twH[(j < a.m1 ? j : a.m1 - 1) * a.H + h];
+    // twiddles of this row: lane j (mod 16) holds tw[j]; a uniform index would become a chain of scalar loads
+    // with a wait each.  Broadcast with shuffles at use.
+    const int twj = (lane & 15) < a.m1 ? (lane & 15) : a.m1 - 1;
+    const float2 twl = a.twH[twj * a.H + h];
     const float bias_raw = a.bias ? a.bias[tid < a.C ? tid : 0] : 0.f;
     const float bias_v = tid < a.C ? bias_raw : 0.f;
     DLWP_STAMP(1);
@@ -222,19 +224,22 @@ __global__ __launch_bounds__(256) void fno_spatial_kernel(SpatialDev a) {
     for (int idx = tid + 256; idx < a.C_pad; idx += 256) bias_s[idx] = (a.bias && idx < a.C) ? a.bias[idx] : 0.f;
     DLWP_STAMP(3);
     // inverse H-axis step for this row: s1[o][2kx(+1)] = sum_j spec[b][j][kx][o] * conj(twH[j][h])
+    float twx[MJ], twy[MJ];   // broadcast the lane-held twiddles (every lane is active here)
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) { twx[j] = __shfl(twl.x, j, 16); twy[j] = __shfl(twl.y, j, 16); }
     for (int idx = tid; idx < a.C_pad * (a.NP / 2); idx += 256) {
         const int kx = idx / a.C_pad, o = idx - kx * a.C_pad;
         float re = 0.f, im = 0.f;
-        if (kx < a.m2c && o < a.C) {
-            if (idx == tid) {
+        if (idx == tid) {   // first chunk: operands already in registers
 #pragma unroll
-                for (int j = 0; j < MJ; ++j) {
-                    if (j < a.m1) {
-                        re += sv[j].x * twv[j].x + sv[j].y * twv[j].y;   // v * conj(t)
-                        im += sv[j].y * twv[j].x - sv[j].x * twv[j].y;
-                    }
+            for (int j = 0; j < MJ; ++j) {
+                if (j < a.m1) {
+                    re += sv[j].x * twx[j] + sv[j].y * twy[j];   // v * conj(t)
+                    im += sv[j].y * twx[j] - sv[j].x * twy[j];
                 }
             }
+        }
+        if (kx < a.m2c && o < a.C) {
             const float2* sp2 = a.spec + (((long long)b * a.m1) * a.m2c + kx) * a.C + o;
             for (int j = (idx == tid ? MJ : 0); j < a.m1; ++j) {
                 const float2 v = sp2[j * jstride];
@@ -243,8 +248,9 @@ __global__ __launch_bounds__(256) void fno_spatial_kernel(SpatialDev a) {
                 im += v.y * t.x - v.x * t.y;
             }
         }
-        s1[o * LDS1 + 2 * kx] = re;
-        s1[o * LDS1 + 2 * kx + 1] = im;
+        const bool ok = kx < a.m2c && o < a.C;
+        s1[o * LDS1 + 2 * kx] = ok ? re : 0.f;
+        s1[o * LDS1 + 2 * kx + 1] = ok ? im : 0.f;
     }
     DLWP_STAMP(4);
     __syncthreads();
@@ -277,14 +283,23 @@ __global__ __launch_bounds__(256) void fno_spatial_kernel(SpatialDev a) {
                 acc[cb] = mfma16_chunk(a4, b4, acc[cb]);
             }
         }
+        // epilogue: operands for all elements are fetched first, then applied (no per-element waits / branches)
+        float ep[NCB][4];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int o = cb * 16 + 4 * g + j, x = wb * 16 + r;
+                ep[cb][j] = MODE == 0 ? bias_s[o] : (MODE == 1 ? pprev_s[o * LDP + x] : 0.f);
+            }
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int o = cb * 16 + 4 * g + j, x = wb * 16 + r;
                 float v = acc[cb][j];
-                if (!a.is_bwd) v += bias_s[o];
-                else if (a.act_prev) v *= gelu_grad_f(pprev_s[o * LDP + x]);
+                if (MODE == 0) v += ep[cb][j];
+                else if (MODE == 1) v *= gelu_grad_f(ep[cb][j]);
                 tout_s[o * LDP + x] = v;
             }
     }
@@ -698,11 +713,17 @@ int dlwp_fno_spatial(const dlwp_fno_plan* p, const dlwp_fno_spatial_args* s, hip
                                         (size_t)4 * p->C_pad * p->NP + p->C_pad + dead);
     const dim3 grid(s->B * p->H), block(256);
     int rc;
-#define LAUNCH(N, M)                                                                         \
-    if ((rc = set_lds(fno_spatial_kernel<N, M>, lds, "fno_spatial")) != DLWP_OK) return rc; \
-    hipLaunchKernelGGL((fno_spatial_kernel<N, M>), grid, block, lds, stream, a);
+    const int mode = !a.is_bwd ? 0 : (a.act_prev ? 1 : 2);
+#define LAUNCH_MODE(N, M, MD)                                                                     \
+    if ((rc = set_lds(fno_spatial_kernel<N, M, MD>, lds, "fno_spatial")) != DLWP_OK) return rc; \
+    hipLaunchKernelGGL((fno_spatial_kernel<N, M, MD>), grid, block, lds, stream, a);
+#define LAUNCH(N, M)                                   \
+    if (mode == 0) { LAUNCH_MODE(N, M, 0) }            \
+    else if (mode == 1) { LAUNCH_MODE(N, M, 1) }       \
+    else { LAUNCH_MODE(N, M, 2) }
     DISPATCH_NCB_NBN(p->C_pad / 16, p->NP / 16, LAUNCH)
 #undef LAUNCH
+#undef LAUNCH_MODE
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }

@@ -218,13 +218,12 @@ template <int NIB, int NOB, int NW>
 __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
     constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int LD1 = a.Cin_pad + 4, LDT = a.Cout_pad + 4;
+    const int LD1 = a.Cin_pad + 4, LD2 = a.Ch_pad + 4;
     float* xs = smem;                        // [Cin_pad][LDP]
     float* gys = xs + a.Cin_pad * LDP;       // [Cout_pad][LDP]
     float* w1s = gys + a.Cout_pad * LDP;     // [Ch_pad][LD1]
-    float* w2ts = w1s + a.Ch_pad * LD1;      // [Ch_pad][LDT]   W2 transposed
-    float* b1s = w2ts + a.Ch_pad * LDT;      // [Ch_pad]
-    float* tr = b1s + a.Ch_pad;              // [NW waves][2][16*20] transpose scratch
+    float* w2s = w1s + a.Ch_pad * LD1;       // [Cout_pad][LD2]
+    float* b1s = w2s + a.Cout_pad * LD2;     // [Ch_pad]
 
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const int r = lane & 15, g = lane >> 4;
@@ -259,12 +258,12 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
             gys[c * LDP + p] = v;
         }
     }
-    l2.commit<true>(w2ts, LDT, a.Ch, a.dCh, n2);
+    l2.commit<false>(w2s, LD2, a.Ch, a.dCh, n2);
     l1.commit<false>(w1s, LD1, a.Cin, a.dCin, n1);
-    stage_matrix_tail<true>(w2ts, LDT, a.w2, a.Cout, a.Ch, a.dCh, n2);
+    stage_matrix_tail<false>(w2s, LD2, a.w2, a.Cout, a.Ch, a.dCh, n2);
     stage_matrix_tail<false>(w1s, LD1, a.w1, a.Ch, a.Cin, a.dCin, n1);
     zero_padding(w1s, LD1, a.Ch, a.Cin, a.Ch_pad, a.Cin_pad);
-    zero_padding(w2ts, LDT, a.Ch, a.Cout, a.Ch_pad, a.Cout_pad);
+    zero_padding(w2s, LD2, a.Cout, a.Ch, a.Cout_pad, a.Ch_pad);
     for (int idx = tid; idx < a.Ch_pad; idx += NT) b1s[idx] = idx < a.Ch ? a.b1[idx] : 0.f;
     __syncthreads();
     if (a.gres.base || a.gres.tab) {
@@ -276,8 +275,6 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
     }
 
     DLWP_STAMP(10);
-    float* T = tr + (w * 2 + 0) * 320;
-    float* T2 = tr + (w * 2 + 1) * 320;
     const int nhb = a.Ch_pad / 16;
 
     f32x4 gxacc[4][NIB];
@@ -285,46 +282,45 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
     for (int pb = 0; pb < 4; ++pb)
 #pragma unroll
         for (int ib = 0; ib < NIB; ++ib) gxacc[pb][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // identity as a permuted-k B operand: I[k = 4g+s][n = r]
+    f32x4 ident;
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) ident[s2] = (4 * g + s2 == r) ? 1.f : 0.f;
 
     float* sl = a.slab ? a.slab + (long long)blockIdx.x * a.slab_stride : nullptr;
-    const long long o_gb1 = (long long)a.Ch * a.Cin, o_gw2 = o_gb1 + a.Ch;
+    // slab layout per workgroup: [nhb][NOB][64][4] dW2 tiles | [nhb][NIB][64][4] dW1 tiles | db1[Ch_pad] | db2[Cout_pad]
+    const long long o_t1 = (long long)(a.Ch_pad / 16) * NOB * 256, o_gb1 = o_t1 + (long long)(a.Ch_pad / 16) * NIB * 256;
+    const long long o_gb2 = o_gb1 + a.Ch_pad;
     const bool accum = sl && a.slab_accumulate != 0;
     DLWP_STAMP(11);
+    // Everything below works in the TRANSPOSED orientation (rows = pixels 4g+j, column = hidden channel r):
+    // the accumulator of z^T / gz^T is then directly the B operand of the pixel contractions (dW2) and, read as an
+    // A operand, the hidden-major matrix for dW1; the one product that contracts over the hidden index (dX) gets
+    // its operand through a 4-MFMA multiplication with the identity instead of an LDS round trip.
     for (int hb = w; hb < nhb; hb += NW) {
-        f32x4 a1[NIB], w2t[NOB];
+        f32x4 w1b[NIB];        // B operand of z^T: W1[h = r][i = 4g+s]
 #pragma unroll
         for (int kc = 0; kc < NIB; ++kc)
-            a1[kc] = *reinterpret_cast<const f32x4*>(&w1s[(hb * 16 + r) * LD1 + kc * 16 + 4 * g]);
-#pragma unroll
-        for (int oc = 0; oc < NOB; ++oc)
-            w2t[oc] = *reinterpret_cast<const f32x4*>(&w2ts[(hb * 16 + r) * LDT + oc * 16 + 4 * g]);
-        float b1v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b1v[j] = b1s[hb * 16 + 4 * g + j];
-        // prefetch this workgroup's running slab partials (read-modify-write accumulation across net calls)
-        float pgw2[NOB][4], pgw1[NIB][4], pgb1[4];
+            w1b[kc] = *reinterpret_cast<const f32x4*>(&w1s[(hb * 16 + r) * LD1 + kc * 16 + 4 * g]);
+        const float b1v = b1s[hb * 16 + r];
+        // prefetch this workgroup's running slab partials (read-modify-write accumulation across net calls).
+        // The slab is private scratch, so it is laid out in ACCUMULATOR-TILE order: tile (hb, ob) holds the 4
+        // registers of every lane contiguously -> one 16-byte access per lane, 1 KiB per wave-instruction
+        // (narrow 64-byte-segment stores were issue-bound: ~350 cycles each).
+        f32x4 pgw2[NOB], pgw1[NIB];
+        float pgb1 = 0.f;
+        float* t2 = sl ? sl + ((long long)hb * NOB * 64 + lane) * 4 : nullptr;
+        float* t1 = sl ? sl + o_t1 + ((long long)hb * NIB * 64 + lane) * 4 : nullptr;
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int o = ob * 16 + 4 * g + j, h = hb * 16 + r;
-                pgw2[ob][j] = (accum && o < a.Cout && h < a.Ch) ? sl[o_gw2 + o * a.Ch + h] : 0.f;
-            }
+            pgw2[ob] = accum ? *reinterpret_cast<const f32x4*>(t2 + ob * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ib = 0; ib < NIB; ++ib)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int h = hb * 16 + 4 * g + j, i = ib * 16 + r;
-                pgw1[ib][j] = (accum && h < a.Ch && i < a.Cin) ? sl[h * a.Cin + i] : 0.f;
-            }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int h = hb * 16 + 4 * g + j;
-            pgb1[j] = (accum && r == 0 && h < a.Ch) ? sl[o_gb1 + h] : 0.f;
-        }
+            pgw1[ib] = accum ? *reinterpret_cast<const f32x4*>(t1 + ib * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (accum && g == 0) pgb1 = sl[o_gb1 + hb * 16 + r];
 
         f32x4 gw2acc[NOB], gw1acc[NIB];
-        f32x4 gb1acc = {0.f, 0.f, 0.f, 0.f};
+        float gb1acc = 0.f;
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) gw2acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -333,104 +329,106 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
 #pragma unroll
         for (int pb = 0; pb < 4; ++pb) {
             if (hb == w && pb == 0) DLWP_STAMP(12);
-            // recompute hidden pre-activation z[h][p]
-            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            // z^T[p][h] = sum_i x[i][p] W1[h][i]
+            f32x4 zt = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kc = 0; kc < NIB; ++kc) {
-                f32x4 b4;
+                f32x4 a4;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) b4[s] = xs[(kc * 16 + 4 * g + s) * LDP + pb * 16 + r];
-                z = mfma16_chunk(a1[kc], b4, z);
+                for (int s2 = 0; s2 < 4; ++s2) a4[s2] = xs[(kc * 16 + 4 * g + s2) * LDP + pb * 16 + r];
+                zt = mfma16_chunk(a4, w1b[kc], zt);
             }
-            f32x4 act, gz;
             if (hb == w && pb == 0) DLWP_STAMP(13);
-            // g_a[h][p] = sum_o W2[o][h] gy[o][p]
-            f32x4 ga = {0.f, 0.f, 0.f, 0.f};
+            // g_a^T[p][h] = sum_o gy[o][p] W2[o][h]
+            f32x4 gat = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int oc = 0; oc < NOB; ++oc) {
-                f32x4 b4;
+                f32x4 a4, b4;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) b4[s] = gys[(oc * 16 + 4 * g + s) * LDP + pb * 16 + r];
-                ga = mfma16_chunk(w2t[oc], b4, ga);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float zz = z[j] + b1v[j];
-                act[j] = gelu_f(zz);
-                gz[j] = ga[j] * gelu_grad_f(zz);
-                gb1acc[j] += gz[j];
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    a4[s2] = gys[(oc * 16 + 4 * g + s2) * LDP + pb * 16 + r];
+                    b4[s2] = w2s[(oc * 16 + 4 * g + s2) * LD2 + hb * 16 + r];
+                }
+                gat = mfma16_chunk(a4, b4, gat);
             }
             if (hb == w && pb == 0) DLWP_STAMP(14);
-            // gx[i][p] += sum_h W1[h][i] gz[h][p]
+            f32x4 actt, gzt;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float av, dv;
+                gelu_both(zt[j] + b1v, av, dv);
+                actt[j] = av;
+                gzt[j] = gat[j] * dv;
+                gb1acc += gzt[j];
+            }
+            if (hb == w && pb == 0) DLWP_STAMP(15);
+            // dW2[o][h] += sum_p gy[o][p] act^T[p][h]
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(&gys[(ob * 16 + r) * LDP + pb * 16 + 4 * g]);
+                gw2acc[ob] = mfma16_chunk(a4, actt, gw2acc[ob]);
+            }
+            // dW1[h][i] += sum_p gz[h][p] x[i][p]   (gz^T registers read as an A operand are gz)
+#pragma unroll
+            for (int ib = 0; ib < NIB; ++ib) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(&xs[(ib * 16 + r) * LDP + pb * 16 + 4 * g]);
+                gw1acc[ib] = mfma16_chunk(gzt, b4, gw1acc[ib]);
+            }
+            if (hb == w && pb == 0) DLWP_STAMP(16);
+            // gz[h][p] in accumulator layout = gz^T (as A operand) x identity
+            const f32x4 gz = mfma16_chunk(gzt, ident, f32x4{0.f, 0.f, 0.f, 0.f});
+            // dX[i][p] += sum_h W1[h][i] gz[h][p]
 #pragma unroll
             for (int ib = 0; ib < NIB; ++ib) {
                 f32x4 a4;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) a4[s] = w1s[(hb * 16 + 4 * g + s) * LD1 + ib * 16 + r];
+                for (int s2 = 0; s2 < 4; ++s2) a4[s2] = w1s[(hb * 16 + 4 * g + s2) * LD1 + ib * 16 + r];
                 gxacc[pb][ib] = mfma16_chunk(a4, gz, gxacc[pb][ib]);
             }
-            if (hb == w && pb == 0) DLWP_STAMP(15);
-            // wave-private transposes: T[h][p] <- act, T2[h][p] <- gz
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                T[(4 * g + j) * 20 + r] = act[j];
-                T2[(4 * g + j) * 20 + r] = gz[j];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const f32x4 aT = *reinterpret_cast<const f32x4*>(&T[r * 20 + 4 * g]);    // act[h=r][p=4g+s]
-            const f32x4 gzT = *reinterpret_cast<const f32x4*>(&T2[r * 20 + 4 * g]);  // gz [h=r][p=4g+s]
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (hb == w && pb == 0) DLWP_STAMP(16);
-            // gW2[o][h] += sum_p gy[o][p] act[h][p]
-#pragma unroll
-            for (int ob = 0; ob < NOB; ++ob) {
-                const f32x4 a4 = *reinterpret_cast<const f32x4*>(&gys[(ob * 16 + r) * LDP + pb * 16 + 4 * g]);
-                gw2acc[ob] = mfma16_chunk(a4, aT, gw2acc[ob]);
-            }
             if (hb == w && pb == 0) DLWP_STAMP(17);
-            // gW1[h][i] += sum_p gz[h][p] x[i][p]
-#pragma unroll
-            for (int ib = 0; ib < NIB; ++ib) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(&xs[(ib * 16 + r) * LDP + pb * 16 + 4 * g]);
-                gw1acc[ib] = mfma16_chunk(gzT, b4, gw1acc[ib]);
-            }
         }
         if (hb == w) DLWP_STAMP(18);
-        // flush this hidden block's parameter gradients (slab values were prefetched at the loop top)
+        // flush this hidden block's parameter gradients
+        if (sl) {
 #pragma unroll
-        for (int ob = 0; ob < NOB; ++ob)
+            for (int ob = 0; ob < NOB; ++ob) {
+                f32x4 v = gw2acc[ob];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int o = ob * 16 + 4 * g + j, h = hb * 16 + r;
-                if (o < a.Cout && h < a.Ch) {
-                    if (sl) sl[o_gw2 + o * a.Ch + h] = pgw2[ob][j] + gw2acc[ob][j];
-                    else atomic_add_f32(a.gw2 + o * a.Ch + h, gw2acc[ob][j]);
-                }
+                for (int j = 0; j < 4; ++j) v[j] += pgw2[ob][j];
+                *reinterpret_cast<f32x4*>(t2 + ob * 256) = v;
             }
 #pragma unroll
-        for (int ib = 0; ib < NIB; ++ib)
+            for (int ib = 0; ib < NIB; ++ib) {
+                f32x4 v = gw1acc[ib];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int h = hb * 16 + 4 * g + j, i = ib * 16 + r;
-                if (h < a.Ch && i < a.Cin) {
-                    if (sl) sl[h * a.Cin + i] = pgw1[ib][j] + gw1acc[ib][j];
-                    else atomic_add_f32(a.gw1 + h * a.Cin + i, gw1acc[ib][j]);
-                }
+                for (int j = 0; j < 4; ++j) v[j] += pgw1[ib][j];
+                *reinterpret_cast<f32x4*>(t1 + ib * 256) = v;
             }
+        } else {
+            const int hcol = hb * 16 + r;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float v = gb1acc[j];
-            v += __shfl_xor(v, 1);
-            v += __shfl_xor(v, 2);
-            v += __shfl_xor(v, 4);
-            v += __shfl_xor(v, 8);
-            const int h = hb * 16 + 4 * g + j;
-            if (r == 0 && h < a.Ch) {
-                if (sl) sl[o_gb1 + h] = pgb1[j] + v;
-                else atomic_add_f32(a.gb1 + h, v);
+            for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int o = ob * 16 + 4 * g + j;
+                    if (o < a.Cout && hcol < a.Ch) atomic_add_f32(a.gw2 + o * a.Ch + hcol, gw2acc[ob][j]);
+                }
+#pragma unroll
+            for (int ib = 0; ib < NIB; ++ib)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int h = hb * 16 + 4 * g + j, i = ib * 16 + r;
+                    if (h < a.Ch && i < a.Cin) atomic_add_f32(a.gw1 + h * a.Cin + i, gw1acc[ib][j]);
+                }
+        }
+        {
+            float v = gb1acc;                       // bias gradient of hidden channel hb*16 + r: sum the 4 lane groups
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            const int h = hb * 16 + r;
+            if (g == 0) {
+                if (sl) sl[o_gb1 + h] = pgb1 + v;
+                else if (h < a.Ch) atomic_add_f32(a.gb1 + h, v);
             }
         }
         if (hb == w) DLWP_STAMP(19);
@@ -482,7 +480,6 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
     if (tid < a.Cout) {
         float s = 0.f;
         for (int p = 0; p < PT; ++p) s += gys[tid * LDP + p];
-        const long long o_gb2 = (long long)a.Ch * a.Cin + a.Ch + (long long)a.Cout * a.Ch;
         grad_flush(sl ? sl + o_gb2 + tid : nullptr, a.gb2 + tid, accum, s);
     }
 }
@@ -505,6 +502,39 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
         for (int s = 0; s < nslab; ++s) acc += slab[s * stride + idx];
         float* dst = idx < n1 ? gw1 + idx : idx < n1 + n2 ? gb1 + (idx - n1)
                    : idx < n1 + n2 + n3 ? gw2 + (idx - n1 - n2) : gb2 + (idx - n1 - n2 - n3);
+        *dst += acc;
+    }
+}
+
+// fold the accumulator-tile slabs of pwmlp_bwd into the gradients (un-permutes the tile order)
+__global__ __launch_bounds__(256) void pwmlp_slab_reduce_kernel(const float* __restrict__ slab, int nslab, long long stride,
+                                                                int Cin, int Ch, int Cout, int nob, int nib, int Ch_pad,
+                                                                float* gw1, float* gb1, float* gw2, float* gb2) {
+    const long long n1 = (long long)Ch * Cin, n2 = Ch, n3 = (long long)Cout * Ch, n4 = Cout, n = n1 + n2 + n3 + n4;
+    const long long o_t1 = (long long)(Ch_pad / 16) * nob * 256, o_gb1 = o_t1 + (long long)(Ch_pad / 16) * nib * 256;
+    const long long o_gb2 = o_gb1 + Ch_pad;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256) {
+        long long off;
+        float* dst;
+        if (idx < n1) {                       // dW1[h][i]: tile (hb, ib), register j = h%4, lane = (h%16/4)*16 + i%16
+            const int h = (int)(idx / Cin), i = (int)(idx % Cin);
+            off = o_t1 + (((long long)(h / 16) * nib + i / 16) * 64 + ((h % 16) / 4) * 16 + i % 16) * 4 + h % 4;
+            dst = gw1 + idx;
+        } else if (idx < n1 + n2) {
+            off = o_gb1 + (idx - n1);
+            dst = gb1 + (idx - n1);
+        } else if (idx < n1 + n2 + n3) {       // dW2[o][h]: tile (hb, ob), register j = o%4, lane = (o%16/4)*16 + h%16
+            const long long e = idx - n1 - n2;
+            const int o = (int)(e / Ch), h = (int)(e % Ch);
+            off = (((long long)(h / 16) * nob + o / 16) * 64 + ((o % 16) / 4) * 16 + h % 16) * 4 + o % 4;
+            dst = gw2 + e;
+        } else {
+            off = o_gb2 + (idx - n1 - n2 - n3);
+            dst = gb2 + (idx - n1 - n2 - n3);
+        }
+        float acc = 0.f;
+#pragma unroll 8
+        for (int s = 0; s < nslab; ++s) acc += slab[s * stride + off];
         *dst += acc;
     }
 }
@@ -580,8 +610,7 @@ int dlwp_pwmlp_bwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, 
     const int nib = a.Cin_pad / 16, nob = a.Cout_pad / 16;
     DLWP_REQUIRE(nib <= 4 && nob <= 4, DLWP_E_UNSUPPORTED,
                  "pwmlp_bwd: Cin<=64 and Cout<=64 supported (got %d, %d)", Cin, Cout);
-    size_t wimg = (size_t)a.Ch_pad * (a.Cin_pad + 4) + (size_t)a.Ch_pad * (a.Cout_pad + 4) + a.Ch_pad +
-                  BWD_WAVES * 2 * 320;
+    size_t wimg = (size_t)a.Ch_pad * (a.Cin_pad + 4) + (size_t)a.Cout_pad * (a.Ch_pad + 4) + a.Ch_pad;
     const size_t red = (size_t)BWD_WAVES * a.Cin_pad * LDP;  // gx partial tiles alias the weight images
     if (wimg < red) wimg = red;
     const size_t lds = sizeof(float) * ((size_t)a.Cin_pad * LDP + (size_t)a.Cout_pad * LDP + wimg);
@@ -611,8 +640,8 @@ int dlwp_pwmlp_bwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, 
 }
 
 long long dlwp_pwmlp_slab_stride(int Cin, int Ch, int Cout) {
-    const long long n = (long long)Ch * Cin + Ch + (long long)Cout * Ch + Cout;
-    return (n + 3) & ~3LL;
+    const long long nhb = round_up(Ch, 16) / 16, nib = round_up(Cin, 16) / 16, nob = round_up(Cout, 16) / 16;
+    return nhb * (nob + nib) * 256 + round_up(Ch, 16) + round_up(Cout, 16);
 }
 
 int dlwp_pwmlp_slab_count(int B, int P) { return B * ceil_div(P, PT); }
@@ -629,11 +658,11 @@ int dlwp_slab_reduce(const float* slab, int nslab, long long stride, float* d1, 
 
 int dlwp_pwmlp_slab_reduce(const float* slab, int nslab, int Cin, int Ch, int Cout, float* gw1, float* gb1,
                            float* gw2, float* gb2, hipStream_t stream) {
-    const long long n1 = (long long)Ch * Cin, n2 = Ch, n3 = (long long)Cout * Ch, n4 = Cout;
-    const long long n = n1 + n2 + n3 + n4;
+    const long long n = (long long)Ch * Cin + Ch + (long long)Cout * Ch + Cout;
     const int grid = (int)((n + 255) / 256);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid), dim3(256), 0, stream, slab, nslab,
-                       dlwp_pwmlp_slab_stride(Cin, Ch, Cout), gw1, n1, gb1, n2, gw2, n3, gb2, n4);
+    hipLaunchKernelGGL(pwmlp_slab_reduce_kernel, dim3(grid), dim3(256), 0, stream, slab, nslab,
+                       dlwp_pwmlp_slab_stride(Cin, Ch, Cout), Cin, Ch, Cout, round_up(Cout, 16) / 16, round_up(Cin, 16) / 16,
+                       round_up(Ch, 16), gw1, gb1, gw2, gb2);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }

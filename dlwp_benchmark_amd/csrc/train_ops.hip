@@ -192,6 +192,27 @@ extern "C" int dlwp_pwmlp_bwd(const float* x, const float* w1, const float* b1, 
                              gw2, gb2, nullptr, 0, B, Cin, Ch, Cout, P, (hipStream_t)stream);
 }
 
+// same as dlwp_pwmlp_bwd, but the parameter gradients go to a per-workgroup partial slab (the path the rollout
+// trainer uses); fold with dlwp_pwmlp_slab_fold.
+extern "C" long long dlwp_pwmlp_slab_floats(int B, int Cin, int Ch, int Cout, int P) {
+    return (long long)dlwp_pwmlp_slab_count(B, P) * dlwp_pwmlp_slab_stride(Cin, Ch, Cout);
+}
+extern "C" int dlwp_pwmlp_bwd_slab(const float* x, const float* w1, const float* b1, const float* w2, const float* gy,
+                                   float* gx, float* slab, int slab_accumulate, int B, int Cin, int Ch, int Cout, int P,
+                                   void* stream) {
+    DLWP_REQUIRE(x && w1 && b1 && w2 && gy && slab, DLWP_E_INVALID, "pwmlp_bwd_slab: NULL argument");
+    dlwp_chan_src xs{x, (long long)Cin * P, P, nullptr, nullptr};
+    dlwp_chan_src gys{gy, (long long)Cout * P, P, nullptr, nullptr};
+    dlwp_chan_dst gxd{gx, (long long)Cin * P, P, nullptr, nullptr};
+    return dlwp_pwmlp_bwd_ex(&xs, w1, b1, w2, &gys, nullptr, nullptr, 0.f, gx ? &gxd : nullptr, 0, nullptr, nullptr,
+                             nullptr, nullptr, nullptr, slab, slab_accumulate, B, Cin, Ch, Cout, P, (hipStream_t)stream);
+}
+extern "C" int dlwp_pwmlp_slab_fold(const float* slab, float* gw1, float* gb1, float* gw2, float* gb2, int B, int Cin,
+                                    int Ch, int Cout, int P, void* stream) {
+    DLWP_REQUIRE(slab && gw1 && gb1 && gw2 && gb2, DLWP_E_INVALID, "pwmlp_slab_fold: NULL argument");
+    return dlwp_pwmlp_slab_reduce(slab, dlwp_pwmlp_slab_count(B, P), Cin, Ch, Cout, gw1, gb1, gw2, gb2, (hipStream_t)stream);
+}
+
 // ---- debug: a chain of n dependent empty kernels (measures the per-kernel floor of a stream / graph)
 namespace { __global__ void null_kernel(int* p) { if (p && threadIdx.x == 1024) *p = 0; } }
 extern "C" int dlwp_debug_null_kernels(int n, int blocks, void* stream) {

@@ -34,6 +34,9 @@ SIGNATURES = {
     "dlwp_last_error": (C.c_char_p, []),
     "dlwp_pwmlp_fwd": (_I, [_V] * 6 + [_I] * 5 + [_V]),
     "dlwp_pwmlp_bwd": (_I, [_V] * 10 + [_I] * 5 + [_V]),
+    "dlwp_pwmlp_slab_floats": (_L, [_I] * 5),
+    "dlwp_pwmlp_bwd_slab": (_I, [_V] * 7 + [_I] * 6 + [_V]),
+    "dlwp_pwmlp_slab_fold": (_I, [_V] * 5 + [_I] * 5 + [_V]),
     "dlwp_fno_plan_create": (_I, [_I] * 5 + [C.POINTER(_V)]),
     "dlwp_fno_plan_destroy": (None, [_V]),
     "dlwp_fno_block_workspace_bytes": (C.c_size_t, [_V, _I]),

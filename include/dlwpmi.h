@@ -67,6 +67,17 @@ int dlwp_pwmlp_bwd(const float* x, const float* w1, const float* b1, const float
                    const float* gy, float* gx, float* gw1, float* gb1, float* gw2, float* gb2,
                    int B, int Cin, int Ch, int Cout, int P, void* stream);
 
+/* Variant used inside the rollout: parameter gradients are written to a per-workgroup     */
+/* partial slab of dlwp_pwmlp_slab_floats() floats (plain stores when slab_accumulate == 0, */
+/* read-modify-write by the owning workgroup otherwise: deterministic, not bound by the     */
+/* chip-wide float-atomic rate) and folded into the gradients by dlwp_pwmlp_slab_fold.      */
+long long dlwp_pwmlp_slab_floats(int B, int Cin, int Ch, int Cout, int P);
+int dlwp_pwmlp_bwd_slab(const float* x, const float* w1, const float* b1, const float* w2,
+                        const float* gy, float* gx, float* slab, int slab_accumulate, int B,
+                        int Cin, int Ch, int Cout, int P, void* stream);
+int dlwp_pwmlp_slab_fold(const float* slab, float* gw1, float* gb1, float* gw2, float* gb2, int B,
+                         int Cin, int Ch, int Cout, int P, void* stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* FNO block: pre = irfft2(W . trunc(rfft2(act(x)))) + Wskip act(x) + bias               */
 /* (neuralop FNOBlocks: SpectralConv + linear skip; call sites        */
