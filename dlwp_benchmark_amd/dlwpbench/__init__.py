@@ -1,5 +1,5 @@
 """Mirror of src/dlwpbench/models/__init__.py for the hot-path models."""
-from .fno import FNO2DModule  # noqa: F401
+from .fno import FNO2DModule, TFNO2DModule  # noqa: F401
 from .panguweather import PanguWeather  # noqa: F401
 
-__all__ = ["FNO2DModule", "PanguWeather"]
+__all__ = ["FNO2DModule", "TFNO2DModule", "PanguWeather"]

@@ -71,3 +71,87 @@ class FNO2DModule(_FnoRolloutModule):
                 optimizer.clip_grad_norm_(clip_max_norm, grad_scale=grad_scale)
             optimizer.step(grad_scale=grad_scale)
         return loss
+
+
+class _CompositeAdam:
+    """FusedAdam on the flat buffer + one FusedAdam per Tucker tensor (same hyper-parameters)."""
+
+    def __init__(self, main, extra):
+        self.main, self.extra = main, extra
+
+    def clip_grad_norm_(self, max_norm, grad_scale=1.0):
+        raise NotImplementedError("gradient clipping over Tucker factors is not built yet")
+
+    def step(self, grad_scale=1.0, zero_grad=True):
+        self.main.step(grad_scale=grad_scale, zero_grad=zero_grad)
+        for opt in self.extra:
+            opt.step(grad_scale=grad_scale, zero_grad=zero_grad)
+
+
+class TFNO2DModule(FNO2DModule):
+    """dlwpbench/models/fno/fno.py:109-146: FNO2DModule whose spectral weights are Tucker-factorised
+    (neuralop TFNO, `rank` = fraction of the dense parameter count; configs/model/fno.yaml:11).  The factors are
+    the parameters; the dense mode-major weights inside the flat buffer are derived from them once per step by
+    libdlwpmi's complex mode-product kernels and their gradient is pushed back through the same kernels."""
+
+    def __init__(self, n_modes=[12, 12], constant_channels=4, prescribed_channels=1, prognostic_channels=8,
+                 hidden_channels=32, lifting_channels=256, projection_channels=256, n_layers=4, max_n_modes=None,
+                 bias=True, context_size=10, rank=0.5, **kwargs):
+        super().__init__(n_modes, constant_channels, prescribed_channels, prognostic_channels, hidden_channels,
+                         lifting_channels, projection_channels, n_layers, max_n_modes, bias, context_size)
+        from ..tucker import TuckerSpectralWeight
+        std = (2.0 / (2 * self.hidden_channels)) ** 0.5
+        self.tucker = torch.nn.ModuleList([
+            TuckerSpectralWeight(self.hidden_channels, self.hidden_channels, self.layout.m1, self.layout.m2c, rank, std)
+            for _ in range(self.n_layers)])
+
+    def _spec_names(self):
+        return [f"fno_blocks.convs.weight.{l}" for l in range(self.n_layers)]
+
+    def _refresh_dense(self):
+        dense = [tw.dense_mode_major() for tw in self.tucker]
+        with torch.no_grad():
+            for name, d in zip(self._spec_names(), dense):
+                self.layout.view(self.flat_params.data, name).copy_(d)
+        return dense
+
+    def forward(self, constants=None, prescribed=None, prognostic=None):
+        if torch.is_grad_enabled():
+            raise NotImplementedError("TFNO2DModule trains through train_step(); call forward under torch.no_grad()")
+        self._refresh_dense()
+        return super().forward(constants, prescribed, prognostic)
+
+    def make_optimizer(self, lr=1e-3):
+        from ..fno_engine import FusedAdam
+        extra = []
+        for p in self.tucker.parameters():
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            extra.append(FusedAdam(p.data.view(-1), p.grad.view(-1), lr=lr))
+        return _CompositeAdam(super().make_optimizer(lr), extra)
+
+    def train_step(self, constants, prescribed, prognostic, target, optimizer=None, use_graph=True,
+                   clip_max_norm=None, grad_scale=1.0, allreduce=None):
+        dense = self._refresh_dense()
+        loss = super().train_step(constants, prescribed, prognostic, target, optimizer=None, use_graph=use_graph)
+        grads = [self.layout.view(self.flat_grad, name).clone() for name in self._spec_names()]
+        torch.autograd.backward(dense, grads)
+        if allreduce is not None:
+            allreduce(self.flat_grad)
+            for p in self.tucker.parameters():
+                allreduce(p.grad)
+        if optimizer is not None:
+            optimizer.step(grad_scale=grad_scale)
+        return loss
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        sd = super().state_dict(prefix=prefix)
+        for l in range(self.n_layers):
+            sd.pop(f"{prefix}fno.fno_blocks.convs.weight.{l}.tensor", None)
+            sd[f"{prefix}fno.fno_blocks.convs.weight.{l}.core"] = self.tucker[l].core.detach().clone()
+            for k, f in enumerate(self.tucker[l].factors):
+                sd[f"{prefix}fno.fno_blocks.convs.weight.{l}.factors.{k}"] = f.detach().clone()
+        if destination is not None:
+            destination.update(sd)
+            return destination
+        return sd

@@ -63,6 +63,8 @@ SIGNATURES = {
     "dlwp_layernorm_bwd": (_I, [_V] * 8 + [_I, _I, _V]),
     "dlwp_gelu_bwd": (_I, [_V, _V, _V, _L, _V]),
     "dlwp_colsum": (_I, [_V, _V, _I, _I, _V]),
+    "dlwp_cmode_product": (_I, [_V, _V, _V, _I, _I, _I, _I, _V]),
+    "dlwp_cmode_product_bwd": (_I, [_V] * 5 + [_I] * 4 + [_V]),
     "dlwp_window_attn_fwd": (_I, [_V] * 7 + [_I] * 7 + [_F, _V]),
     "dlwp_window_attn_bwd": (_I, [_V] * 11 + [_I] * 7 + [_F, _V]),
     "dlwp_fno_spatial_fwd_probe": (_I, [_V, _V, _V, _V, _V, _V, _V, _I, _V]),

@@ -249,6 +249,16 @@ int dlwp_gelu_bwd(const float* z, const float* gy, float* gz, long long n, void*
 /* out[n] += sum_t g[t][n]   (bias gradients)                                                */
 int dlwp_colsum(const float* g, float* out, int T, int N, void* stream);
 
+/* ------------------------------------------------------------------------------------ */
+/* Complex mode-n product for Tucker-factorised spectral weights (TFNO, dlwpbench/models/   */
+/* fno/fno.py:136-146): out[O,N,I] = sum_r in[O,r,I] * U[N,r]; complex = interleaved re/im. */
+/* The factorised weight core x1 U_i x2 U_o x3 U_x x4 U_y is expanded into the dense layout   */
+/* of dlwp_fno_block_* once per optimizer step.  _bwd writes gin and gU.                      */
+int dlwp_cmode_product(const float* in, const float* U, float* out, int O, int R, int N, int I,
+                       void* stream);
+int dlwp_cmode_product_bwd(const float* in, const float* U, const float* gout, float* gin,
+                           float* gU, int O, int R, int N, int I, void* stream);
+
 /* bench probe: ONE forward `spatial` launch of an inner FNO block as the rollout issues it     */
 /* (x = previous pre-activation, GELU on load; spec = [B][m1][m2c][C][2] mixed modes; fused      */
 /* W-axis DFT of gelu(pre) into x1_out [B][H][m2c][C][2]).                                       */
