@@ -388,16 +388,17 @@ struct MixDev {
     const float2* x1; const float2* wspec; const float2* xhat_in; float2* xhat; float2* y;
     float2* g_wspec; const float2* twH;
     int B, C, H, m1, m2c;
+    FastDiv dC, dBC, dBC2;   // exact division by C, B*C, B*C/2 without the ~40-instruction integer divide
 };
 
 // weight slice [C][C] complex -> LDS rows of (C+1) complex (conflict-free row AND column reads)
-__device__ __forceinline__ void mix_stage_w(const float2* wm, float2* ws, int C) {
+__device__ __forceinline__ void mix_stage_w(const float2* wm, float2* ws, int C, FastDiv dC) {
     const int n2 = C * C / 2;  // pairs of complex numbers (C*C is even whenever C is even)
     if ((C & 1) == 0) {
 #pragma unroll 4
         for (int u = threadIdx.x; u < n2; u += MIXT) {
             const float4 v = reinterpret_cast<const float4*>(wm)[u];
-            const int e = 2 * u, i = e / C, o = e % C;
+            const int e = 2 * u, i = fastdiv(e, dC), o = e - i * C;
             ws[i * (C + 1) + o] = make_float2(v.x, v.y);
             ws[i * (C + 1) + o + 1] = make_float2(v.z, v.w);
         }
@@ -407,11 +408,69 @@ __device__ __forceinline__ void mix_stage_w(const float2* wm, float2* ws, int C)
     }
 }
 
-// H-axis step into LDS partials: part[hs][b*C+c] = sum_{h = hs mod HS} x1[b][h][kx][c] * tw[h]; returns HS
+// H-axis step, fast path (C even): every thread owns TWO adjacent channels (one 16-byte load per image row) and
+// the rows h = hs, hs+HS, ...; loads are issued in batches of 8 BEFORE the twiddles are needed, so the weight
+// slice, the twiddle row and the first x1 batch share one global-memory latency.
+struct HstepLoads {
+    float4 v[8];
+    int bc2, hs, b, c, nh;
+};
+__device__ __forceinline__ void mix_hstep_issue(const MixDev& a, int kx, int HS, HstepLoads& L, int h0) {
+    const int BC2 = a.B * a.C / 2;
+    const int u = threadIdx.x;
+    L.hs = fastdiv(u, a.dBC2); L.bc2 = u - L.hs * BC2;
+    L.b = fastdiv(2 * L.bc2, a.dC); L.c = 2 * L.bc2 - L.b * a.C;
+    const bool act = u < BC2 * HS;
+    const float2* src = a.x1 + (((long long)L.b * a.H) * a.m2c + kx) * a.C + L.c;
+    const long long hstride = (long long)a.m2c * a.C;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int h = h0 + L.hs + q * HS;
+        const int hc = (act && h < a.H) ? h : 0;                       // clamped: always a valid address
+        L.v[q] = *reinterpret_cast<const float4*>(src + hc * hstride);
+    }
+}
+__device__ __forceinline__ void mix_hstep_accum(const MixDev& a, int HS, const HstepLoads& L, const float2* tws, int h0,
+                                                float2& s0, float2& s1) {
+    float2 tq[8];   // all LDS reads first: at this occupancy a read-then-use loop pays the LDS latency per iteration
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int h = h0 + L.hs + q * HS;
+        tq[q] = tws[h < a.H ? h : 0];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int h = h0 + L.hs + q * HS;
+        if (h < a.H) {
+            const float2 t = tq[q];
+            s0.x += L.v[q].x * t.x - L.v[q].y * t.y;
+            s0.y += L.v[q].x * t.y + L.v[q].y * t.x;
+            s1.x += L.v[q].z * t.x - L.v[q].w * t.y;
+            s1.y += L.v[q].z * t.y + L.v[q].w * t.x;
+        }
+    }
+}
+// whole fast H-step after the first batch has been issued; returns the number of partial slots
+__device__ __forceinline__ int mix_hstep_fast(const MixDev& a, int kx, int HS, HstepLoads& L, const float2* tws, float2* part) {
+    const int BC = a.B * a.C, BC2 = BC / 2;
+    float2 s0 = make_float2(0.f, 0.f), s1 = s0;
+    mix_hstep_accum(a, HS, L, tws, 0, s0, s1);
+    for (int h0 = 8 * HS; h0 < a.H; h0 += 8 * HS) {
+        mix_hstep_issue(a, kx, HS, L, h0);
+        mix_hstep_accum(a, HS, L, tws, h0, s0, s1);
+    }
+    if ((int)threadIdx.x < BC2 * HS) {
+        part[L.hs * BC + 2 * L.bc2] = s0;
+        part[L.hs * BC + 2 * L.bc2 + 1] = s1;
+    }
+    return HS;
+}
+
+// H-axis step into LDS partials (generic path): part[hs][b*C+c] = sum_{h = hs mod HS} x1[b][h][kx][c] * tw[h]; returns HS
 __device__ __forceinline__ int mix_hstep(const MixDev& a, int kx, const float2* tws, float2* part, int HS) {
     const int BC = a.B * a.C;
     for (int u = threadIdx.x; u < BC * HS; u += MIXT) {
-        const int bc = u % BC, hs = u / BC, b = bc / a.C, c = bc % a.C;
+        const int hs = fastdiv(u, a.dBC), bc = u - hs * BC, b = fastdiv(bc, a.dC), c = bc - b * a.C;
         const float2* src = a.x1 + (((long long)b * a.H) * a.m2c + kx) * a.C + c;
         const long long hstride = (long long)a.m2c * a.C;
         float re = 0.f, im = 0.f;
@@ -430,15 +489,27 @@ __device__ __forceinline__ int mix_hstep(const MixDev& a, int kx, const float2* 
 // out[i] = sum_s part[s][i]
 __device__ __forceinline__ void mix_fold(float2* out, const float2* part, int n, int ns) {
     for (int i = threadIdx.x; i < n; i += MIXT) {
-        float2 v = part[i];
-        for (int s = 1; s < ns; ++s) {
-            v.x += part[s * n + i].x;
-            v.y += part[s * n + i].y;
+        float2 v = make_float2(0.f, 0.f);
+        for (int s0 = 0; s0 < ns; s0 += 8) {
+            float2 p[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) p[q] = part[(s0 + q < ns ? s0 + q : 0) * n + i];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (s0 + q < ns) { v.x += p[q].x; v.y += p[q].y; }
         }
         out[i] = v;
     }
 }
 
+// partial slots of the fast H-step: threads / (B*C/2), clamped to [1, H]
+__device__ __host__ __forceinline__ int mix_slots2(int B, int C, int H) {
+    const int bc2 = B * C / 2;
+    int s = bc2 > 0 ? MIXT / bc2 : 1;
+    if (s < 1) s = 1;
+    if (s > H) s = H;
+    return s;
+}
 // number of partial slots a phase splits its reduction over (threads / outputs, clamped)
 __device__ __host__ __forceinline__ int mix_split(int outputs, int limit) {
     int s = MIXT / outputs;
@@ -451,104 +522,150 @@ __global__ __launch_bounds__(MIXT) void fno_mix_fwd_kernel(MixDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int BC = a.B * a.C, C = a.C;
     const int NS = mix_split(BC, a.H < C ? a.H : C);   // partial slots (both phases use <= NS)
+    const int NS2 = mix_slots2(a.B, C, a.H);           // partial slots of the two-channels-per-thread H-step
     float2* xh = reinterpret_cast<float2*>(smem);  // [BC]
-    float2* part = xh + BC;                        // [NS][BC]
-    float2* tws = part + NS * BC;                  // [H]
+    float2* part = xh + BC;                        // [max(NS, NS2)][BC]
+    float2* tws = part + (NS > NS2 ? NS : NS2) * BC;   // [H]
     float2* ws = tws + a.H;                        // [C][C+1]
     const int j = blockIdx.x / a.m2c, kx = blockIdx.x % a.m2c;
-    mix_stage_w(a.wspec + ((long long)(j * a.m2c + kx) * C) * C, ws, C);
+    const bool fast = (C % 2 == 0) && (BC / 2) * NS2 <= MIXT && NS2 >= 1;
+    DLWP_STAMP(16);
+    HstepLoads hl;
+    if (fast) mix_hstep_issue(a, kx, NS2, hl, 0);            // x1 loads in flight before anything is waited for
+    mix_stage_w(a.wspec + ((long long)(j * a.m2c + kx) * C) * C, ws, C, a.dC);
     for (int i = threadIdx.x; i < a.H; i += MIXT) tws[i] = a.twH[j * a.H + i];
+    DLWP_STAMP(17);
     __syncthreads();
-    const int hs = mix_hstep(a, kx, tws, part, NS);
+    DLWP_STAMP(18);
+    const int hs = fast ? mix_hstep_fast(a, kx, NS2, hl, tws, part) : mix_hstep(a, kx, tws, part, NS);
+    DLWP_STAMP(19);
     __syncthreads();
+    DLWP_STAMP(20);
     mix_fold(xh, part, BC, hs);
     __syncthreads();
+    DLWP_STAMP(21);
     for (int bc = threadIdx.x; bc < BC; bc += MIXT) {
-        const int b = bc / C, c = bc % C;
+        const int b = fastdiv(bc, a.dC), c = bc - b * C;
         a.xhat[(((long long)b * a.m1 + j) * a.m2c + kx) * C + c] = xh[bc];
     }
     const int IS = mix_split(BC, NS);
     for (int u = threadIdx.x; u < BC * IS; u += MIXT) {
-        const int bo = u % BC, is = u / BC, b = bo / C, o = bo % C;
+        const int is = fastdiv(u, a.dBC), bo = u - is * BC, b = fastdiv(bo, a.dC), o = bo - b * C;
         float re = 0.f, im = 0.f;
-#pragma unroll 4
-        for (int i = is; i < C; i += IS) {
-            const float2 xv = xh[b * C + i];
-            const float2 wv = ws[i * (C + 1) + o];
-            re += xv.x * wv.x - xv.y * wv.y;
-            im += xv.x * wv.y + xv.y * wv.x;
+        for (int i0 = is; i0 < C; i0 += 8 * IS) {
+            float2 xv[8], wv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = i0 + q * IS < C ? i0 + q * IS : is;
+                xv[q] = xh[b * C + i];
+                wv[q] = ws[i * (C + 1) + o];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (i0 + q * IS < C) {
+                    re += xv[q].x * wv[q].x - xv[q].y * wv[q].y;
+                    im += xv[q].x * wv[q].y + xv[q].y * wv[q].x;
+                }
         }
         part[is * BC + bo] = make_float2(re, im);
     }
+    DLWP_STAMP(22);
     __syncthreads();
+    DLWP_STAMP(23);
     for (int bo = threadIdx.x; bo < BC; bo += MIXT) {
-        const int b = bo / C, o = bo % C;
-        float2 v = part[bo];
-        for (int s2 = 1; s2 < IS; ++s2) {
-            v.x += part[s2 * BC + bo].x;
-            v.y += part[s2 * BC + bo].y;
-        }
+        const int b = fastdiv(bo, a.dC), o = bo - b * C;
+        float2 p[8], v = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) p[q] = part[(q < IS ? q : 0) * BC + bo];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q < IS) { v.x += p[q].x; v.y += p[q].y; }
+        for (int s2 = 8; s2 < IS; ++s2) { v.x += part[s2 * BC + bo].x; v.y += part[s2 * BC + bo].y; }
         a.y[(((long long)b * a.m1 + j) * a.m2c + kx) * C + o] = v;
     }
+    DLWP_STAMP(24);
 }
 
 __global__ __launch_bounds__(MIXT) void fno_mix_bwd_kernel(MixDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int BC = a.B * a.C, C = a.C;
     const int NS = mix_split(BC, a.H < C ? a.H : C);
+    const int NS2 = mix_slots2(a.B, C, a.H);
     float2* gh = reinterpret_cast<float2*>(smem);  // [BC]  ghat
     float2* xsv = gh + BC;                         // [BC]  saved xhat
-    float2* part = xsv + BC;                       // [NS][BC]
-    float2* tws = part + NS * BC;                  // [H]
+    float2* part = xsv + BC;                       // [max(NS, NS2)][BC]
+    float2* tws = part + (NS > NS2 ? NS : NS2) * BC;   // [H]
     float2* ws = tws + a.H;                        // [C][C+1]
     const int j = blockIdx.x / a.m2c, kx = blockIdx.x % a.m2c;
     const long long wofs = ((long long)(j * a.m2c + kx) * C) * C;
-    mix_stage_w(a.wspec + wofs, ws, C);
+    const bool fast = (C % 2 == 0) && (BC / 2) * NS2 <= MIXT && NS2 >= 1;
+    HstepLoads hl;
+    if (fast) mix_hstep_issue(a, kx, NS2, hl, 0);
+    mix_stage_w(a.wspec + wofs, ws, C, a.dC);
     for (int i = threadIdx.x; i < a.H; i += MIXT) tws[i] = a.twH[j * a.H + i];
     for (int bc = threadIdx.x; bc < BC; bc += MIXT) {
-        const int b = bc / C, c = bc % C;
+        const int b = fastdiv(bc, a.dC), c = bc - b * C;
         xsv[bc] = a.xhat_in[(((long long)b * a.m1 + j) * a.m2c + kx) * C + c];
     }
     float2* gw = a.g_wspec + wofs;  // this workgroup owns the mode's weight-gradient slice
     __syncthreads();
-    const int hs = mix_hstep(a, kx, tws, part, NS);
+    const int hs = fast ? mix_hstep_fast(a, kx, NS2, hl, tws, part) : mix_hstep(a, kx, tws, part, NS);
     __syncthreads();
     mix_fold(gh, part, BC, hs);
     __syncthreads();
     const int OS = mix_split(BC, NS);
     for (int u = threadIdx.x; u < BC * OS; u += MIXT) {
-        const int bi = u % BC, os = u / BC, b = bi / C, i = bi % C;
+        const int os = fastdiv(u, a.dBC), bi = u - os * BC, b = fastdiv(bi, a.dC), i = bi - b * C;
         float re = 0.f, im = 0.f;
-#pragma unroll 4
-        for (int o = os; o < C; o += OS) {
-            const float2 gv = gh[b * C + o];
-            const float2 wv = ws[i * (C + 1) + o];
-            re += gv.x * wv.x + gv.y * wv.y;   // g * conj(w)
-            im += gv.y * wv.x - gv.x * wv.y;
+        for (int o0 = os; o0 < C; o0 += 8 * OS) {
+            float2 gv[8], wv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int o = o0 + q * OS < C ? o0 + q * OS : os;
+                gv[q] = gh[b * C + o];
+                wv[q] = ws[i * (C + 1) + o];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (o0 + q * OS < C) {
+                    re += gv[q].x * wv[q].x + gv[q].y * wv[q].y;   // g * conj(w)
+                    im += gv[q].y * wv[q].x - gv[q].x * wv[q].y;
+                }
         }
         part[os * BC + bi] = make_float2(re, im);
     }
     // gw[i][o] += sum_b conj(xhat[b][i]) * ghat[b][o]
 #pragma unroll 2
     for (int idx = threadIdx.x; idx < C * C; idx += MIXT) {
-        const int i = idx / C, o = idx % C;
+        const int i = fastdiv(idx, a.dC), o = idx - i * C;
         float2 cur = gw[idx];
-        for (int b = 0; b < a.B; ++b) {
-            const float2 xv = xsv[b * C + i];
-            const float2 gv = gh[b * C + o];
-            cur.x += xv.x * gv.x + xv.y * gv.y;
-            cur.y += xv.x * gv.y - xv.y * gv.x;
+        for (int b0 = 0; b0 < a.B; b0 += 4) {
+            float2 xv[4], gv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int b = b0 + q < a.B ? b0 + q : 0;
+                xv[q] = xsv[b * C + i];
+                gv[q] = gh[b * C + o];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (b0 + q < a.B) {
+                    cur.x += xv[q].x * gv[q].x + xv[q].y * gv[q].y;
+                    cur.y += xv[q].x * gv[q].y - xv[q].y * gv[q].x;
+                }
         }
         gw[idx] = cur;
     }
     __syncthreads();
     for (int bi = threadIdx.x; bi < BC; bi += MIXT) {
-        const int b = bi / C, i = bi % C;
-        float2 v = part[bi];
-        for (int s2 = 1; s2 < OS; ++s2) {
-            v.x += part[s2 * BC + bi].x;
-            v.y += part[s2 * BC + bi].y;
-        }
+        const int b = fastdiv(bi, a.dC), i = bi - b * C;
+        float2 p[8], v = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) p[q] = part[(q < OS ? q : 0) * BC + bi];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q < OS) { v.x += p[q].x; v.y += p[q].y; }
+        for (int s2 = 8; s2 < OS; ++s2) { v.x += part[s2 * BC + bi].x; v.y += part[s2 * BC + bi].y; }
         a.y[(((long long)b * a.m1 + j) * a.m2c + kx) * C + i] = v;
     }
 }
@@ -667,6 +784,8 @@ static int mix_launch(const dlwp_fno_plan* p, bool bwd, MixDev& a, hipStream_t s
     if (ns < 1) ns = 1;
     const int lim = a.H < a.C ? a.H : a.C;
     if (ns > lim) ns = lim;
+    const int ns2 = mix_slots2(a.B, a.C, a.H);
+    if (ns2 > ns) ns = ns2;
     const size_t lds = sizeof(float2) * ((size_t)BC * ((bwd ? 2 : 1) + ns) + a.H + (size_t)a.C * (a.C + 1));
     const dim3 grid(p->m1 * p->m2c), block(MIXT);
     int rc;
@@ -683,13 +802,15 @@ static int mix_launch(const dlwp_fno_plan* p, bool bwd, MixDev& a, hipStream_t s
 
 int dlwp_fno_mix_fwd(const dlwp_fno_plan* p, const float2* x1, const float2* wspec, float2* xhat, float2* y,
                      int B, hipStream_t stream) {
-    MixDev a{x1, wspec, nullptr, xhat, y, nullptr, p->twH, B, p->C, p->H, p->m1, p->m2c};
+    MixDev a{x1, wspec, nullptr, xhat, y, nullptr, p->twH, B, p->C, p->H, p->m1, p->m2c,
+             make_fastdiv(p->C), make_fastdiv(B * p->C), make_fastdiv(B * p->C / 2 > 0 ? B * p->C / 2 : 1)};
     return mix_launch(p, false, a, stream);
 }
 
 int dlwp_fno_mix_bwd(const dlwp_fno_plan* p, const float2* g1, const float2* wspec, const float2* xhat,
                      float2* gxhat, float2* g_wspec, int B, hipStream_t stream) {
-    MixDev a{g1, wspec, xhat, nullptr, gxhat, g_wspec, p->twH, B, p->C, p->H, p->m1, p->m2c};
+    MixDev a{g1, wspec, xhat, nullptr, gxhat, g_wspec, p->twH, B, p->C, p->H, p->m1, p->m2c,
+             make_fastdiv(p->C), make_fastdiv(B * p->C), make_fastdiv(B * p->C / 2 > 0 ? B * p->C / 2 : 1)};
     return mix_launch(p, true, a, stream);
 }
 

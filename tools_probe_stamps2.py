@@ -19,6 +19,7 @@ def stamps():
 for it in range(3):
     lib.dlwp_fno_block_fwd(plan,x.data_ptr(),1,w.data_ptr(),k.data_ptr(),bb.data_ptr(),pre.data_ptr(),xhat.data_ptr(),B,ws.data_ptr(),None); torch.cuda.synchronize()
 print("spatial fwd phases", *stamps())
+buf=(C.c_ulonglong*32)(); lib.dlwp_debug_stamps_fno(buf); t=list(buf); print("mix fwd stamps 16..24 deltas", [t[i+1]-t[i] for i in range(16,24)], "total", t[24]-t[16])
 for it in range(3):
     lib.dlwp_fno_block_bwd(plan,x.data_ptr(),1,w.data_ptr(),k.data_ptr(),g.data_ptr(),xhat.data_ptr(),gx.data_ptr(),gw.data_ptr(),gk.data_ptr(),gb.data_ptr(),B,ws.data_ptr(),None); torch.cuda.synchronize()
 print("spatial bwd phases", *stamps())
