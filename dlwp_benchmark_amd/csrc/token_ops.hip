@@ -9,28 +9,108 @@
 //
 // GEMM: C[M,N] = epilogue(op(A)[M,K] . op(B)[K,N]), row-major operands with leading dimensions and
 // transpose flags so that the three products of a Linear layer (y = x W^T, gx = gy W, gW = gy^T x)
-// use one kernel.  64x64 output tile per workgroup, K-step 16, four waves of 32x32 (2x2 MFMA
-// 16x16x4 f32 blocks, permuted-k operand order), operands staged through LDS.
+// use one kernel family.  64x64 output tile per workgroup, K-step 32, four waves of 32x32 (2x2 MFMA
+// 16x16x4 f32 blocks, permuted-k operand order).  Operand tiles are fetched with 16-byte loads along
+// whichever dimension is contiguous in memory, kept in the matching LDS layout ([row][k] -> one b128
+// fragment read, [k][row] -> four b32 reads), and double-buffered: the global loads of K-step i+1 are in
+// flight while step i runs on the matrix cores, one barrier per step.  Reductions over the token
+// dimension (gW: K = tokens, few output tiles) are split along K across workgroups (grid.z) and
+// combined with float atomics into a zeroed C.
 #include "common.cuh"
 #include "dlwpmi_internal.h"
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 16;
-constexpr int LDA = BK + 4;    // As[m][k]: b128 fragment reads stay 16-byte aligned
-constexpr int LDB = BN + 4;    // Bs[k][n]: 4*LDB % 32 == 16 -> conflict-free b32 reads
+constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int LDK = BK + 4;    // [row][k] layout: 16-byte aligned rows
+constexpr int LDR = BM + 4;    // [k][row] layout
+constexpr int TILE_FLOATS = BM * LDK;   // >= BK * LDR
 
 struct GemmDev {
     const float *A, *B, *bias, *residual;
-    float *C, *preact;
-    int M, N, K, lda, ldb, ldc, transA, transB, act, accumulate;
+    float *C, *preact, *rowsum;
+    int M, N, K, lda, ldb, ldc, act, accumulate, kchunk, splits;
 };
 
+// One 64 x 32 operand tile.  KC: k is the contiguous dimension in memory (element (row, k) at
+// base[row * ld + k]); otherwise the row index is contiguous (base[k * ld + row]).
+template <bool KC, bool VEC>
+struct TileIO {
+    float v[8];
+    __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int row0, int nrows, int k0, int kend) {
+        const int tid = threadIdx.x;
+        if (VEC) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int f = tid + 256 * q;
+                const int row = KC ? (f >> 3) : 4 * (f & 15), k = KC ? 4 * (f & 7) : (f >> 4);
+                const bool ok = row0 + row < nrows && k0 + k < kend;
+                const long long off = KC ? (long long)(row0 + row) * ld + k0 + k : (long long)(k0 + k) * ld + row0 + row;
+                f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ok) t = *reinterpret_cast<const f32x4*>(base + off);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) v[4 * q + s] = t[s];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int f = tid + 256 * q;
+                const int row = KC ? (f >> 5) : (f & 63), k = KC ? (f & 31) : (f >> 6);
+                const bool ok = row0 + row < nrows && k0 + k < kend;
+                const long long off = KC ? (long long)(row0 + row) * ld + k0 + k : (long long)(k0 + k) * ld + row0 + row;
+                v[q] = ok ? base[off] : 0.f;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float* S) const {
+        const int tid = threadIdx.x;
+        if (VEC) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int f = tid + 256 * q;
+                const int row = KC ? (f >> 3) : 4 * (f & 15), k = KC ? 4 * (f & 7) : (f >> 4);
+                *reinterpret_cast<f32x4*>(&S[KC ? row * LDK + k : k * LDR + row]) =
+                    f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int f = tid + 256 * q;
+                const int row = KC ? (f >> 5) : (f & 63), k = KC ? (f & 31) : (f >> 6);
+                S[KC ? row * LDK + k : k * LDR + row] = v[q];
+            }
+        }
+    }
+    // MFMA fragment of chunk c (k = 16c + 4g + s) for the 16 rows starting at rb
+    static __device__ __forceinline__ f32x4 frag(const float* S, int rb, int c, int r, int g) {
+        if (KC) return *reinterpret_cast<const f32x4*>(&S[(rb + r) * LDK + 16 * c + 4 * g]);
+        f32x4 o;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) o[s] = S[(16 * c + 4 * g + s) * LDR + rb + r];
+        return o;
+    }
+};
+
+// (appended to gemm_kernel's epilogue through this helper to keep the kernel body readable)
+__device__ __forceinline__ void gemm_rowsum_flush(const GemmDev& a, const float (&rsum)[2], int m0, int wm, int w, int r, int g) {
+    if (!a.rowsum || blockIdx.x != 0 || (w & 1)) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float v = rsum[i];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        const int m = m0 + wm + 16 * i + r;
+        if (g == 0 && m < a.M) atomic_add_f32(&a.rowsum[m], v);
+    }
+}
+
+template <bool AKC, bool BKC, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
-    __shared__ __attribute__((aligned(16))) float As[BM * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
-    const int tid = threadIdx.x, lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
+    __shared__ __attribute__((aligned(16))) float As[2][TILE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][TILE_FLOATS];
+    const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
     const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
     f32x4 acc[2][2];
 #pragma unroll
@@ -38,42 +118,42 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int k0 = 0; k0 < a.K; k0 += BK) {
-        // stage A tile [BM][BK]: thread mapping follows the contiguous dimension of the source
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int idx = tid + q * 256;
-            int m, k;
-            if (a.transA) { m = idx % BM; k = idx / BM; } else { k = idx % BK; m = idx / BK; }
-            float v = 0.f;
-            if (m0 + m < a.M && k0 + k < a.K)
-                v = a.transA ? a.A[(long long)(k0 + k) * a.lda + m0 + m] : a.A[(long long)(m0 + m) * a.lda + k0 + k];
-            As[m * LDA + k] = v;
+    float rsum[2] = {0.f, 0.f};     // sum over k of op(A) rows wm + 16 i + r (this lane's k slots)
+    TileIO<AKC, VEC> ta;
+    TileIO<BKC, VEC> tb;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    ta.load(a.A, a.lda, m0, a.M, kbeg, kend);
+    tb.load(a.B, a.ldb, n0, a.N, kbeg, kend);
+    ta.store(As[0]);
+    tb.store(Bs[0]);
+    __syncthreads();
+    for (int it = 0; it < nk; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < nk) {
+            ta.load(a.A, a.lda, m0, a.M, kbeg + (it + 1) * BK, kend);
+            tb.load(a.B, a.ldb, n0, a.N, kbeg + (it + 1) * BK, kend);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int idx = tid + q * 256;
-            int k, n;
-            if (a.transB) { k = idx % BK; n = idx / BK; } else { n = idx % BN; k = idx / BN; }
-            float v = 0.f;
-            if (n0 + n < a.N && k0 + k < a.K)
-                v = a.transB ? a.B[(long long)(n0 + n) * a.ldb + k0 + k] : a.B[(long long)(k0 + k) * a.ldb + n0 + n];
-            Bs[k * LDB + n] = v;
+        for (int c = 0; c < 2; ++c) {
+            f32x4 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = TileIO<AKC, VEC>::frag(As[cur], wm + 16 * i, c, r, g);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = TileIO<BKC, VEC>::frag(Bs[cur], wn + 16 * j, c, r, g);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                rsum[i] += (af[i][0] + af[i][1]) + (af[i][2] + af[i][3]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16_chunk(af[i], bf[j], acc[i][j]);
+            }
         }
-        __syncthreads();
-        f32x4 af[2], bf[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[(wm + i * 16 + r) * LDA + 4 * g]);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) bf[j][s] = Bs[(4 * g + s) * LDB + wn + j * 16 + r];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = mfma16_chunk(af[i], bf[j], acc[i][j]);
+        if (it + 1 < nk) {
+            ta.store(As[cur ^ 1]);
+            tb.store(Bs[cur ^ 1]);
+        }
         __syncthreads();
     }
+    gemm_rowsum_flush(a, rsum, m0, wm, w, r, g);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -84,6 +164,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
                 if (m < a.M && n < a.N) {
                     const long long o = (long long)m * a.ldc + n;
                     float v = acc[i][j][q];
+                    if (a.splits > 1) { atomic_add_f32(&a.C[o], v); continue; }   // C zeroed (or accumulate)
                     if (a.bias) v += a.bias[n];
                     if (a.preact) a.preact[o] = v;
                     if (a.act == 1) v = gelu_f(v);
@@ -91,6 +172,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
                     a.C[o] = a.accumulate ? a.C[o] + v : v;
                 }
             }
+}
+
+template <bool AKC, bool BKC>
+void gemm_launch(const GemmDev& a, bool vec, dim3 grid, hipStream_t s) {
+    if (vec) hipLaunchKernelGGL((gemm_kernel<AKC, BKC, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<AKC, BKC, false>), grid, dim3(256), 0, s, a);
 }
 
 // ---- LayerNorm over the last dimension: one wave per row
@@ -118,6 +205,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 }
 
 // gx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)); ggamma/gbeta partials via atomics
+template <int NQ>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gy, float* __restrict__ gx,
@@ -130,10 +218,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const int lane = lane_id(), w = wave_id();
     const int row0 = blockIdx.x * rows_per_block;
     // each wave owns the columns c = lane, lane+64, ... for its rows; accumulate column partials in registers
-    // (C <= 64*8 assumed by the host wrapper), then add them to LDS once per wave
-    float pg[8], pb[8];
+    // (C <= 64*NQ, checked by the host wrapper), then add them to LDS once per wave
+    float pg[NQ], pb[NQ];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { pg[q] = 0.f; pb[q] = 0.f; }
+    for (int q = 0; q < NQ; ++q) { pg[q] = 0.f; pb[q] = 0.f; }
     for (int rr = w; rr < rows_per_block; rr += 4) {
         const int row = row0 + rr;
         if (row >= T) break;
@@ -142,7 +230,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         const float* gr = gy + (long long)row * C;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int c = lane + 64 * q;
             if (c < C) {
                 const float xh = (xr[c] - mu) * rs, gg = gr[c] * gamma[c];
@@ -155,7 +243,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         s1 = wave_sum64(s1) / C;
         s2 = wave_sum64(s2) / C;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int c = lane + 64 * q;
             if (c < C) {
                 const float xh = (xr[c] - mu) * rs;
@@ -167,7 +255,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     for (int ww = 0; ww < 4; ++ww) {
         if (w == ww) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 const int c = lane + 64 * q;
                 if (c < C) { sg[c] += pg[q]; sb[c] += pb[q]; }
             }
@@ -206,11 +294,27 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g
 
 extern "C" int dlwp_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                          int transA, int transB, const float* bias, int act, float* preact, const float* residual,
-                         int accumulate, void* stream) {
+                         int accumulate, float* rowsum, void* stream) {
     DLWP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, DLWP_E_INVALID, "gemm: NULL argument or empty shape");
     DLWP_REQUIRE(act == 0 || act == 1, DLWP_E_INVALID, "gemm: act must be 0 (none) or 1 (gelu)");
-    GemmDev a{A, B, bias, residual, C, preact, M, N, K, lda, ldb, ldc, transA, transB, act, accumulate};
-    hipLaunchKernelGGL(gemm_kernel, dim3(ceil_div(N, BN), ceil_div(M, BM)), dim3(256), 0, (hipStream_t)stream, a);
+    const bool epilogue = bias || act || preact || residual;
+    const int tiles = ceil_div(N, BN) * ceil_div(M, BM);
+    int splits = 1;
+    if (!epilogue && tiles < 256 && K >= 8 * BK) splits = std::min(ceil_div(512, tiles), K / (4 * BK));
+    int kchunk = ceil_div(ceil_div(K, splits), BK) * BK;
+    splits = ceil_div(K, kchunk);
+    if (splits > 1 && !accumulate) DLWP_HIP(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, (hipStream_t)stream));
+    GemmDev a{A, B, bias, residual, C, preact, rowsum, M, N, K, lda, ldb, ldc, act, accumulate, kchunk, splits};
+    // 16-byte loads need every row start and every k (or row) group of four to be aligned and whole
+    const bool vec = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && lda % 4 == 0 && ldb % 4 == 0 && K % 4 == 0 &&
+                     (transA ? M % 4 == 0 : true) && (transB ? true : N % 4 == 0);
+    const dim3 grid(ceil_div(N, BN), ceil_div(M, BM), splits);
+    const hipStream_t s = (hipStream_t)stream;
+    // A is k-contiguous when not transposed ([M][K]); B is k-contiguous when transposed ([N][K])
+    if (!transA && transB) gemm_launch<true, true>(a, vec, grid, s);
+    else if (!transA && !transB) gemm_launch<true, false>(a, vec, grid, s);
+    else if (transA && transB) gemm_launch<false, true>(a, vec, grid, s);
+    else gemm_launch<false, false>(a, vec, grid, s);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }
@@ -228,10 +332,21 @@ extern "C" int dlwp_layernorm_bwd(const float* x, const float* gamma, const floa
                                   const float* gy, float* gx, float* ggamma, float* gbeta, int T, int C, void* stream) {
     DLWP_REQUIRE(x && gamma && mean && rstd && gy && gx && ggamma && gbeta && T > 0 && C > 0, DLWP_E_INVALID,
                  "layernorm_bwd: bad argument");
-    DLWP_REQUIRE(C <= 512, DLWP_E_UNSUPPORTED, "layernorm_bwd: C <= 512 supported (got %d)", C);
-    const int rpb = 64;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(ceil_div(T, rpb)), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
-                       x, gamma, mean, rstd, gy, gx, ggamma, gbeta, T, C, rpb);
+    DLWP_REQUIRE(C <= 2048, DLWP_E_UNSUPPORTED, "layernorm_bwd: C <= 2048 supported (got %d)", C);
+    // enough workgroups to fill the chip; each wave then walks rpb / 4 rows serially
+    int rpb = 64;
+    while (rpb > 4 && ceil_div(T, rpb) < 512) rpb >>= 1;
+    const dim3 grid(ceil_div(T, rpb));
+    const size_t lds = 2 * C * sizeof(float);
+    if (C <= 512)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, dim3(256), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, gx,
+                           ggamma, gbeta, T, C, rpb);
+    else if (C <= 1024)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<16>, grid, dim3(256), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, gx,
+                           ggamma, gbeta, T, C, rpb);
+    else
+        hipLaunchKernelGGL(layernorm_bwd_kernel<32>, grid, dim3(256), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, gx,
+                           ggamma, gbeta, T, C, rpb);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }

@@ -72,6 +72,19 @@ __global__ __launch_bounds__(256) void sqerr_kernel(const float* __restrict__ a,
     block_atomic_sum(acc * scale, out);
 }
 
+// loss += mean((a-b)^2), g = 2 (a-b) / n  (torch.nn.MSELoss forward + backward in one pass)
+__global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       long long n, float inv_n, float* out, float* __restrict__ g) {
+    float acc = 0.f;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float d = a[i] - b[i];
+        acc += d * d;
+        g[i] = 2.f * inv_n * d;
+    }
+    block_atomic_sum(acc * inv_n, out);
+}
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, float* out) {
     float acc = 0.f;
     const long long n4 = n / 4;
@@ -135,6 +148,15 @@ extern "C" int dlwp_sqerr_sum(const float* a, const float* b, long long n, float
     if (n == 0) return DLWP_OK;
     hipLaunchKernelGGL(sqerr_kernel, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, a, b, n,
                        scale, loss_out);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_mse_fwd_bwd(const float* pred, const float* target, long long n, float* loss_out, float* grad,
+                                void* stream) {
+    DLWP_REQUIRE(pred && target && loss_out && grad && n > 0, DLWP_E_INVALID, "mse_fwd_bwd: NULL argument or n <= 0");
+    hipLaunchKernelGGL(mse_grad_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, pred, target, n,
+                       1.0f / (float)n, loss_out, grad);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }

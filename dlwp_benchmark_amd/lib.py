@@ -43,6 +43,7 @@ SIGNATURES = {
     "dlwp_fno_block_fwd": (_I, [_V, _V, _I, _V, _V, _V, _V, _V, _I, _V, _V]),
     "dlwp_fno_block_bwd": (_I, [_V, _V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _I, _V, _V]),
     "dlwp_sqerr_sum": (_I, [_V, _V, _L, _F, _V, _V]),
+    "dlwp_mse_fwd_bwd": (_I, [_V, _V, _L, _V, _V, _V]),
     "dlwp_adam_step": (_I, [_V, _V, _V, _V, _V, _L, _F, _F, _F, _F, _F, _I, _V]),
     "dlwp_sumsq": (_I, [_V, _L, _V, _V]),
     "dlwp_clip_scale": (_I, [_V, _L, _V, _F, _F, _V]),
@@ -58,7 +59,7 @@ SIGNATURES = {
     "dlwp_afno2d_save_elems": (_L, [_I, _I, _I, _I, _I, _F]),
     "dlwp_afno2d_fwd": (_I, [_V] * 7 + [_I] * 5 + [_F, _F, _V]),
     "dlwp_afno2d_bwd": (_I, [_V] * 11 + [_I] * 5 + [_F, _F, _V]),
-    "dlwp_gemm": (_I, [_V, _V, _V] + [_I] * 8 + [_V, _I, _V, _V, _I, _V]),
+    "dlwp_gemm": (_I, [_V, _V, _V] + [_I] * 8 + [_V, _I, _V, _V, _I, _V, _V]),
     "dlwp_layernorm_fwd": (_I, [_V] * 6 + [_I, _I, _F, _V]),
     "dlwp_layernorm_bwd": (_I, [_V] * 8 + [_I, _I, _V]),
     "dlwp_gelu_bwd": (_I, [_V, _V, _V, _L, _V]),

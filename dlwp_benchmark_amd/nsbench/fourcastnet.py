@@ -18,7 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import lib as L
-from ..token_ops import LayerNorm, Linear, Mlp, PatchConv2d
+from ..token_ops import LayerNorm, Linear, Mlp, PatchConv2d, _grad_slot
 
 
 class _AFNO2DFn(torch.autograd.Function):
@@ -36,6 +36,7 @@ class _AFNO2DFn(torch.autograd.Function):
                                     L.ptr(b2.contiguous()), L.ptr(y), L.ptr(xsave), B, H, W, C, nb, lam, frac, L.stream()))
         ctx.save_for_backward(xsave, w1, b1, w2, b2)
         ctx.cfg = (B, H, W, C, nb, lam, frac)
+        ctx.slots = [_grad_slot(t) for t in (w1, b1, w2, b2)]
         return y
 
     @staticmethod
@@ -45,10 +46,14 @@ class _AFNO2DFn(torch.autograd.Function):
         B, H, W, C, nb, lam, frac = ctx.cfg
         gy = gy.contiguous().float()
         gx = torch.empty_like(gy)
-        gw1, gb1, gw2, gb2 = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in (w1, b1, w2, b2)]
+        fused = all(sl is not None for sl in ctx.slots)    # kernel accumulates: write straight into .grad
+        gw1, gb1, gw2, gb2 = ctx.slots if fused else [torch.zeros_like(t, memory_format=torch.contiguous_format)
+                                                      for t in (w1, b1, w2, b2)]
         L.check(lib.dlwp_afno2d_bwd(L.ptr(gy), L.ptr(xsave), L.ptr(w1.contiguous()), L.ptr(b1.contiguous()),
                                     L.ptr(w2.contiguous()), L.ptr(b2.contiguous()), L.ptr(gx), L.ptr(gw1), L.ptr(gb1),
                                     L.ptr(gw2), L.ptr(gb2), B, H, W, C, nb, lam, frac, L.stream()))
+        if fused:
+            return gx, None, None, None, None, None, None, None
         return gx, gw1, gb1, gw2, gb2, None, None, None
 
 

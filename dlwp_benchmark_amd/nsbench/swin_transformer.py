@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import lib as L
-from ..token_ops import LayerNorm, Linear, Mlp, PatchConv2d, UpConvT2d
+from ..token_ops import _grad_slot, LayerNorm, Linear, Mlp, PatchConv2d, UpConvT2d
 
 
 class _WindowAttnFn(torch.autograd.Function):
@@ -32,7 +32,7 @@ class _WindowAttnFn(torch.autograd.Function):
         B_, N, C3 = qkv.shape
         d = C3 // (3 * heads)
         qkv = qkv.contiguous().float()
-        table = table.contiguous()
+        table_param, table = table, table.contiguous()
         TB = table.shape[0]
         ntypes = table.shape[1] if table.dim() == 3 else 1
         out = torch.empty(B_, N, heads * d, device=qkv.device)
@@ -41,6 +41,7 @@ class _WindowAttnFn(torch.autograd.Function):
                                          L.ptr(lse), B_, nW, N, TB, ntypes, heads, d, scale, L.stream()))
         ctx.save_for_backward(qkv, table, out, lse)
         ctx.aux, ctx.cfg = (ia, ib, labels), (B_, nW, N, TB, ntypes, heads, d, scale)
+        ctx.tslot = _grad_slot(table_param)
         return out
 
     @staticmethod
@@ -50,12 +51,12 @@ class _WindowAttnFn(torch.autograd.Function):
         ia, ib, labels = ctx.aux
         B_, nW, N, TB, ntypes, heads, d, scale = ctx.cfg
         gqkv = torch.empty_like(qkv)
-        gtable = torch.zeros_like(table)
+        gtable = ctx.tslot if ctx.tslot is not None else torch.zeros_like(table)   # kernel accumulates
         dsum = torch.empty_like(lse)
         L.check(lib.dlwp_window_attn_bwd(L.ptr(qkv), L.ptr(table), L.ptr(ia), L.ptr(ib), L.ptr(labels), L.ptr(out),
                                          L.ptr(lse), L.ptr(gout.contiguous().float()), L.ptr(gqkv), L.ptr(gtable),
                                          L.ptr(dsum), B_, nW, N, TB, ntypes, heads, d, scale, L.stream()))
-        return gqkv, gtable, None, None, None, None, None, None
+        return gqkv, (None if ctx.tslot is not None else gtable), None, None, None, None, None, None
 
 
 def window_attention_core(qkv, table, ia, ib, labels, nW, heads, scale):

@@ -10,9 +10,18 @@ import torch.nn as nn
 from . import lib as L
 
 
-def _gemm(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, bias=None, act=0, preact=None, residual=None, accumulate=0):
+def _gemm(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, bias=None, act=0, preact=None, residual=None, accumulate=0,
+          rowsum=None):
     L.check(L.load().dlwp_gemm(L.ptr(A), L.ptr(B), L.ptr(C), M, N, K, lda, ldb, ldc, tA, tB, L.ptr(bias), act,
-                               L.ptr(preact), L.ptr(residual), accumulate, L.stream()))
+                               L.ptr(preact), L.ptr(residual), accumulate, L.ptr(rowsum), L.stream()))
+
+
+def _grad_slot(p):
+    """The preallocated gradient buffer of a leaf parameter (train_engine.flatten_parameters), or None.
+    When present, backward kernels accumulate straight into it (no temporary, no autograd add)."""
+    if isinstance(p, torch.nn.Parameter) and p.grad is not None and p.grad.is_contiguous():
+        return p.grad
+    return None
 
 
 class _LinearFn(torch.autograd.Function):
@@ -31,6 +40,8 @@ class _LinearFn(torch.autograd.Function):
         _gemm(x2, w, y, T, N, K, K, K, N, 0, 1, bias, act, z, r2)
         ctx.save_for_backward(x2, w, z)
         ctx.has_bias, ctx.has_res, ctx.act, ctx.shape = bias is not None, residual is not None, act, shape
+        ctx.wslot = _grad_slot(weight)
+        ctx.bslot = _grad_slot(bias) if bias is not None else None
         return y.reshape(*shape[:-1], N)
 
     @staticmethod
@@ -47,12 +58,18 @@ class _LinearFn(torch.autograd.Function):
             g2 = gz
         gx = torch.empty(T, K, device=g2.device)
         _gemm(g2, w, gx, T, K, N, N, K, K, 0, 0)                 # gx = g W
-        gw = torch.empty(N, K, device=g2.device)
-        _gemm(g2, x2, gw, N, K, T, N, K, K, 1, 0)                # gW = g^T x
-        gb = None
+        # gW = g^T x, with the bias gradient (column sums of g) produced by the same kernel; both go straight
+        # into the parameters' gradient buffers when those exist (fused gradient accumulation)
+        gw, gb = None, None
         if ctx.has_bias:
-            gb = torch.zeros(N, device=g2.device)
-            L.check(lib.dlwp_colsum(L.ptr(g2), L.ptr(gb), T, N, L.stream()))
+            gb = ctx.bslot if ctx.bslot is not None else torch.zeros(N, device=g2.device)
+        if ctx.wslot is not None:
+            _gemm(g2, x2, ctx.wslot, N, K, T, N, K, K, 1, 0, accumulate=1, rowsum=gb)
+        else:
+            gw = torch.empty(N, K, device=g2.device)
+            _gemm(g2, x2, gw, N, K, T, N, K, K, 1, 0, rowsum=gb)
+        if ctx.bslot is not None:
+            gb = None
         return gx.reshape(ctx.shape), gw, gb, None, gres
 
 
@@ -74,6 +91,7 @@ class _LayerNormFn(torch.autograd.Function):
                                        L.ptr(mean), L.ptr(rstd), T, C_, eps, L.stream()))
         ctx.save_for_backward(x2, gamma, mean, rstd)
         ctx.shape = shape
+        ctx.slots = (_grad_slot(gamma), _grad_slot(beta))
         return y.reshape(shape)
 
     @staticmethod
@@ -83,9 +101,12 @@ class _LayerNormFn(torch.autograd.Function):
         T, C_ = x2.shape
         g2 = gy.reshape(-1, C_).contiguous().float()
         gx = torch.empty_like(x2)
-        gg, gb = torch.zeros_like(gamma), torch.zeros_like(gamma)
+        fused = ctx.slots[0] is not None and ctx.slots[1] is not None
+        gg, gb = ctx.slots if fused else (torch.zeros_like(gamma), torch.zeros_like(gamma))
         L.check(lib.dlwp_layernorm_bwd(L.ptr(x2), L.ptr(gamma.contiguous()), L.ptr(mean), L.ptr(rstd), L.ptr(g2),
                                        L.ptr(gx), L.ptr(gg), L.ptr(gb), T, C_, L.stream()))
+        if fused:
+            return gx.reshape(ctx.shape), None, None, None
         return gx.reshape(ctx.shape), gg, gb, None
 
 

@@ -1,0 +1,141 @@
+"""Train-step engine for the modules whose backward runs through autograd over libdlwpmi ops
+(AFNONet, SwinTransformer, PanguWeather): the counterpart of the reference's inner training loop
+(nsbench/scripts/train.py:113-131, dlwpbench/scripts/train.py:222-262) with the MI355X-specific parts:
+
+* all parameters live in ONE flat fp32 buffer (and all gradients in another), so the optimizer is one
+  dlwp_adam_step launch and data-parallel training needs one RCCL all-reduce (no bucketing logic);
+* forward rollout + MSE + backward + optimizer are captured once into a hipGraph (torch.cuda.CUDAGraph is the
+  plumbing that owns the capture stream and the private memory pool) and replayed per batch, which removes the
+  per-op host dispatch that otherwise dominates these launch-bound models.
+
+torch is used for memory, streams and graph capture; every arithmetic kernel in the captured step is either a
+libdlwpmi kernel or a torch data-movement op (permute/roll/pad/cat copies, gradient accumulation adds).
+"""
+import torch
+
+from . import lib as L
+from .fno_engine import FusedAdam
+
+
+def flatten_parameters(module):
+    """Re-point every parameter of `module` (and its .grad) at a slice of one flat buffer.
+    Returns (flat_params, flat_grads).  Parameter names, shapes and values are unchanged."""
+    params = [p for p in module.parameters() if p.requires_grad]
+    if not params:
+        raise ValueError("module has no trainable parameters")
+    dev = params[0].device
+    if dev.type != "cuda":
+        raise L.DlwpError("flatten_parameters: move the module to the GPU first (no CPU path)")
+    # 4-float (16-byte) aligned slices: the GEMM's vector loads need aligned weight matrices
+    offs, n = [], 0
+    for p in params:
+        offs.append(n)
+        n += (p.numel() + 3) // 4 * 4
+    flat = torch.zeros(n, device=dev)
+    grad = torch.zeros(n, device=dev)
+    for p, o in zip(params, offs):
+        flat[o:o + p.numel()].copy_(p.data.reshape(-1))
+        p.data = flat[o:o + p.numel()].view(p.shape)
+        p.grad = grad[o:o + p.numel()].view(p.shape)
+    return flat, grad
+
+
+class _SqErr(torch.autograd.Function):
+    """mean((a - b)^2) with the gradient produced by the same kernel (dlwp_mse_fwd_bwd)."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        pred = pred.contiguous()
+        target = target.contiguous()
+        loss = torch.zeros(1, device=pred.device)
+        g = torch.empty_like(pred)
+        L.check(L.load().dlwp_mse_fwd_bwd(L.ptr(pred), L.ptr(target), pred.numel(), L.ptr(loss), L.ptr(g), L.stream()))
+        ctx.save_for_backward(g)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gl):
+        (g,) = ctx.saved_tensors
+        return g * gl, None
+
+
+def mse_loss(pred, target):
+    return _SqErr.apply(pred, target)
+
+
+class GraphedTrainStep:
+    """Captures `loss = mse(model(**inputs), target); loss.backward(); [all-reduce]; adam` and replays it.
+
+    inputs/target given at construction fix the shapes; `__call__(inputs, target)` copies a new batch into the
+    static buffers and replays.  With `allreduce` (ddp.FlatGradAllReduce) the capture is split into
+    forward+backward | all-reduce (eager, RCCL) | optimizer so that the collective stays outside the graph.
+    """
+
+    def __init__(self, model, inputs, target, lr=1e-3, clip_max_norm=None, allreduce=None, grad_scale=1.0,
+                 use_graph=True, call=None):
+        self.model = model
+        self.flat, self.grad = flatten_parameters(model)
+        self.opt = FusedAdam(self.flat, self.grad, lr=lr)
+        self.inputs = {k: v.clone() for k, v in inputs.items()}
+        self.target = target.clone()
+        self.clip, self.allreduce, self.grad_scale = clip_max_norm, allreduce, grad_scale
+        self.call = call or (lambda m, kw: m(**kw))
+        self.loss = torch.zeros((), device=self.flat.device)
+        self.use_graph = use_graph
+        self.g_fb = self.g_opt = None
+        if use_graph:
+            self._capture()
+
+    def _fwd_bwd(self):
+        out = self.call(self.model, self.inputs)
+        loss = mse_loss(out, self.target)
+        loss.backward()
+        self.loss.copy_(loss.detach())
+
+    def _optimize(self):
+        if self.clip is not None:
+            self.opt.clip_grad_norm_(self.clip, grad_scale=self.grad_scale)
+        self.opt.step(grad_scale=self.grad_scale)
+
+    def _capture(self):
+        # warm-up on a side stream (allocator + lazy initialisation), then restore the untouched state
+        flat0 = self.flat.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self._fwd_bwd()
+                self.grad.zero_()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.flat.copy_(flat0)
+        self.g_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fb):
+            self._fwd_bwd()
+            if self.allreduce is None:
+                self._optimize()
+        if self.allreduce is not None:
+            self.g_opt = torch.cuda.CUDAGraph()
+            pool = self.g_fb.pool()
+            with torch.cuda.graph(self.g_opt, pool=pool):
+                self._optimize()
+        # the capture itself does not run the kernels; moments/step are still zero, gradients too
+        self.grad.zero_()
+
+    def __call__(self, inputs=None, target=None):
+        if inputs is not None:
+            for k, v in inputs.items():
+                self.inputs[k].copy_(v)
+        if target is not None:
+            self.target.copy_(target)
+        if not self.use_graph:
+            self._fwd_bwd()
+            if self.allreduce is not None:
+                self.allreduce(self.grad)
+            self._optimize()
+            return self.loss
+        self.g_fb.replay()
+        if self.allreduce is not None:
+            self.allreduce(self.grad)
+            self.g_opt.replay()
+        return self.loss

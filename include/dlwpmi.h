@@ -109,6 +109,10 @@ int dlwp_fno_block_bwd(const dlwp_fno_plan* plan, const float* x, int act_in, co
 /* loss_out (device, 1 float) += sum((a-b)^2) * scale                                    */
 int dlwp_sqerr_sum(const float* a, const float* b, long long n, float scale, float* loss_out,
                    void* stream);
+/* nn.MSELoss forward + backward in one pass (train.py:113,119-122):                      */
+/* loss_out (device, 1 float) += mean((pred-target)^2); grad = 2 (pred-target) / n        */
+int dlwp_mse_fwd_bwd(const float* pred, const float* target, long long n, float* loss_out,
+                     float* grad, void* stream);
 /* torch.optim.Adam (no weight decay / amsgrad) on a flat buffer; `step` is a device      */
 /* int32 counter incremented by the kernel; grads are multiplied by grad_scale first      */
 /* (1/world_size after a sum all-reduce) and zeroed afterwards when zero_grad != 0.       */
@@ -233,10 +237,13 @@ int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, const int* i
 /* nsbench/models/swintransformer/swin_transformer.py:35-39,131,153,187,194,274).           */
 /* C[M,N] (+)= epilogue(op(A)[M,K] . op(B)[K,N]); row-major with leading dimensions;         */
 /* epilogue: + bias[n], optional store of the pre-activation, act (0 none, 1 GELU),          */
-/* + residual[m,n] (same layout as C); accumulate != 0 adds into C.                          */
+/* + residual[m,n] (same layout as C); accumulate != 0 adds into C.  rowsum (optional, [M]): */
+/* rowsum[m] += sum_k op(A)[m,k] -- the bias gradient of a Linear layer comes out of the      */
+/* weight-gradient product gW = gy^T x for free.  Reductions with few output tiles are split  */
+/* along K across workgroups and combined with float atomics (summation order not fixed).     */
 int dlwp_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
               int ldc, int transA, int transB, const float* bias, int act, float* preact,
-              const float* residual, int accumulate, void* stream);
+              const float* residual, int accumulate, float* rowsum, void* stream);
 /* LayerNorm over the last dimension of x [T,C]; mean/rstd [T] are saved for backward.       */
 int dlwp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                        float* mean, float* rstd, int T, int C, float eps, void* stream);

@@ -59,3 +59,48 @@ def test_layernorm_fwd_bwd(cuda, T, C, eps):
     assert rel(xd.grad, xr.grad) <= 5e-4
     assert rel(ln.weight.grad, ln_ref.weight.grad) <= 5e-4
     assert rel(ln.bias.grad, ln_ref.bias.grad) <= 5e-4
+
+
+@pytest.mark.parametrize("T,K,N", [(4096, 40, 120), (8192, 192, 768), (515, 52, 36), (257, 13, 29)])
+def test_linear_fused_grad_accumulation(cuda, T, K, N):
+    """Parameters with a preallocated .grad (train_engine.flatten_parameters) receive their gradients straight from
+    the kernels (split-K weight-gradient GEMM with the bias gradient as a by-product), accumulated over two uses."""
+    from dlwp_benchmark_amd import token_ops
+    g = torch.Generator().manual_seed(5)
+    lin_ref = torch.nn.Linear(K, N)
+    lin = token_ops.Linear(K, N)
+    lin.load_state_dict(lin_ref.state_dict())
+    lin = lin.to(cuda)
+    x1, x2 = torch.randn(T, K, generator=g), torch.randn(T, K, generator=g)
+    gy = torch.randn(T, N, generator=g)
+    (lin_ref(x1) + 0.5 * lin_ref(x2)).backward(gy)
+    for p in lin.parameters():
+        p.grad = torch.zeros_like(p)
+    slots = [p.grad.data_ptr() for p in lin.parameters()]
+    (lin(x1.to(cuda)) + 0.5 * lin(x2.to(cuda))).backward(gy.to(cuda))
+    assert [p.grad.data_ptr() for p in lin.parameters()] == slots
+    assert rel(lin.weight.grad, lin_ref.weight.grad) <= 5e-4
+    assert rel(lin.bias.grad, lin_ref.bias.grad) <= 5e-4
+
+
+@pytest.mark.parametrize("T,C", [(4096, 40), (2048, 768), (100, 1536)])
+def test_layernorm_fused_grad_accumulation(cuda, T, C):
+    from dlwp_benchmark_amd import token_ops
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(T, C, generator=g)
+    gy = torch.randn(T, C, generator=g)
+    ln_ref = torch.nn.LayerNorm(C)
+    with torch.no_grad():
+        ln_ref.weight.copy_(torch.randn(C, generator=g))
+    ln = token_ops.LayerNorm(C)
+    ln.load_state_dict(ln_ref.state_dict())
+    ln = ln.to(cuda)
+    xr = x.clone().requires_grad_(True)
+    ln_ref(xr).backward(gy)
+    for p in ln.parameters():
+        p.grad = torch.zeros_like(p)
+    xd = x.to(cuda).requires_grad_(True)
+    ln(xd).backward(gy.to(cuda))
+    assert rel(xd.grad, xr.grad) <= 5e-4
+    assert rel(ln.weight.grad, ln_ref.weight.grad) <= 5e-4
+    assert rel(ln.bias.grad, ln_ref.bias.grad) <= 5e-4

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Supplementary measurements (not the headline metric): train-step throughput of the AFNO, Swin and Pangu
+rollout models built on libdlwpmi's kernels, at the reference's nsbench / dlwpbench shapes.  The step is
+forward rollout + MSE + backward (autograd over the HIP ops) + one fused Adam launch on the flat parameter
+buffer, captured into a hipGraph by train_engine.GraphedTrainStep (--no-graph: eager dispatch).
+
+    python tools_bench_models.py [afno|swin|pangu|all] [--steps N]
+"""
+import argparse
+import json
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from dlwp_benchmark_amd import dlwpbench, nsbench  # noqa: E402
+from dlwp_benchmark_amd.train_engine import GraphedTrainStep  # noqa: E402
+
+
+def run(name, model, make_batch, steps, warmup=3, use_graph=True, call=None):
+    dev = torch.device("cuda:0")
+    model = model.to(dev).train()
+    inputs, target, B = make_batch(dev)
+    step = GraphedTrainStep(model, inputs, target, lr=1e-3, use_graph=use_graph, call=call)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"model": name, "graph": use_graph, "samples_per_s": round(B * steps / dt, 2),
+                      "ms_per_step": round(dt / steps * 1e3, 3), "batch": B, "loss": loss.item(),
+                      "n_params": sum(p.numel() for p in model.parameters())}), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which", nargs="?", default="all")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--no-graph", action="store_true")
+    a = ap.parse_args()
+    g = torch.Generator().manual_seed(1234)
+    if a.which in ("afno", "all"):
+        # nsbench configs/model/fourcastnet.yaml with the paper runs' context 10 (train_commands.txt:112-115), T=20, tf=10
+        m = nsbench.AFNONet(img_height=64, img_width=64, patch_size=(4, 4), in_chans=1, out_chans=1, embed_dim=64, depth=4,
+                            mlp_ratio=4.0, num_blocks=4, context_size=10)
+
+        def batch(dev):
+            u = torch.randn(4, 21, 1, 64, 64, generator=g).to(dev)
+            return {"x": u[:, :-1].contiguous()}, u[:, 1:].contiguous(), 4
+        run("nsbench AFNONet 64x64 p4 E64 depth4 ctx10 T20", m, batch, a.steps, use_graph=not a.no_graph,
+            call=lambda mod, kw: mod(kw["x"], 10))
+    if a.which in ("swin", "all"):
+        m = nsbench.SwinTransformer(context_size=10, pretrain_img_size=64, patch_size=2, in_chans=1, out_chans=1,
+                                    embed_dim=40, depths=[4, 4], num_heads=[4, 4], drop_path_rate=0.0)
+
+        def batch(dev):
+            u = torch.randn(4, 21, 1, 64, 64, generator=g).to(dev)
+            return {"x": u[:, :-1].contiguous()}, u[:, 1:].contiguous(), 4
+        run("nsbench SwinTransformer 64x64 p2 E40 depths[4,4] ctx10 T20", m, batch, a.steps, use_graph=not a.no_graph,
+            call=lambda mod, kw: mod(kw["x"], 10))
+    if a.which in ("pangu", "all"):
+        # dlwpbench configs/model/panguweather.yaml at 32x64 with 5 prognostic variables (BASELINE configs[2] shapes)
+        m = dlwpbench.PanguWeather(constant_channels=4, prescribed_channels=1, prognostic_channels=5, embed_dim=192,
+                                   num_heads=(6, 12, 12, 6), window_size=(2, 6, 12), patch_size=(1, 1), n_lat=32, n_lon=64,
+                                   context_size=1)
+        m.eval_drop_path = True
+
+        def batch(dev):
+            kw = dict(constants=torch.randn(1, 1, 4, 32, 64, generator=g).to(dev),
+                      prescribed=torch.randn(1, 5, 1, 32, 64, generator=g).to(dev),
+                      prognostic=torch.randn(1, 5, 5, 32, 64, generator=g).to(dev))
+            return kw, torch.randn(1, 4, 5, 32, 64, generator=g).to(dev), 1
+        run("dlwpbench PanguWeather 32x64 E192 window(2,6,12) B1 T5", m, batch, a.steps, use_graph=not a.no_graph)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Time the window-attention kernels alone at Swin / Pangu shapes (diagnostic)."""
+import sys
+import torch
+sys.path.insert(0, ".")
+from dlwp_benchmark_amd import lib as L
+
+lib = L.load()
+dev = torch.device("cuda:0")
+
+
+def run(B_, nW, N, heads, d, TB, masked, iters=50):
+    g = torch.Generator().manual_seed(0)
+    qkv = torch.randn(B_, N, 3, heads, d, generator=g).to(dev)
+    table = (torch.randn(TB, heads, generator=g) * 0.02).to(dev)
+    ia = torch.randint(0, TB // 2, (N,), generator=g, dtype=torch.int32).to(dev)
+    ib = torch.randint(0, TB // 2, (N,), generator=g, dtype=torch.int32).to(dev)
+    labels = torch.randint(0, 3, (nW, N), generator=g, dtype=torch.int32).to(dev) if masked else None
+    out = torch.empty(B_, N, heads * d, device=dev)
+    lse = torch.empty(B_, heads, N, device=dev)
+    gout = torch.randn_like(out)
+    gqkv = torch.empty_like(qkv)
+    gtable = torch.zeros_like(table)
+    dsum = torch.empty_like(lse)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def fwd():
+        L.check(lib.dlwp_window_attn_fwd(L.ptr(qkv), L.ptr(table), L.ptr(ia), L.ptr(ib), L.ptr(labels), L.ptr(out), L.ptr(lse),
+                                         B_, nW, N, TB, 1, heads, d, d ** -0.5, st))
+
+    def bwd():
+        L.check(lib.dlwp_window_attn_bwd(L.ptr(qkv), L.ptr(table), L.ptr(ia), L.ptr(ib), L.ptr(labels), L.ptr(out), L.ptr(lse),
+                                         L.ptr(gout), L.ptr(gqkv), L.ptr(gtable), L.ptr(dsum),
+                                         B_, nW, N, TB, 1, heads, d, d ** -0.5, st))
+    res = []
+    for f in (fwd, bwd):
+        for _ in range(3):
+            f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) / iters * 1e3)
+    print(f"B_={B_:5d} nW={nW:3d} N={N:5d} heads={heads} d={d:3d} TB={TB:5d} masked={int(masked)}: fwd {res[0]:8.1f} us  bwd {res[1]:8.1f} us")
+
+
+run(1, 1, 49, 4, 10, 169, False)
+run(100, 25, 49, 4, 10, 169, False)
+run(100, 25, 49, 4, 10, 169, True)
+run(400, 25, 49, 4, 10, 169, True)
+run(36, 9, 49, 4, 20, 169, True)
+run(64, 16, 64, 4, 16, 225, True)
+run(16, 16, 144, 6, 32, 3312, True)     # Pangu-like window (2,6,12)
