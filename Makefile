@@ -19,10 +19,18 @@ build/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.cuh) $(wildcard $(CSRC)/*.h) inclu
 $(LIB): $(OBJS)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -o $@
 
+# diagnostic build with in-kernel phase stamps (DLWP_STAMP in common.cuh); never loaded by the package
+STAMP_OBJS := $(patsubst $(CSRC)/%.hip,build_stamps/%.o,$(SRCS))
+build_stamps/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.cuh) $(wildcard $(CSRC)/*.h) include/dlwpmi.h
+	@mkdir -p build_stamps
+	$(HIPCC) $(HIPFLAGS) -DDLWP_STAMPS -c $< -o $@
+stamps: $(STAMP_OBJS)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(STAMP_OBJS) -o dlwp_benchmark_amd/libdlwpmi_stamps.so
+
 oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -rf build $(LIB)
+	rm -rf build build_stamps $(LIB) dlwp_benchmark_amd/libdlwpmi_stamps.so
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean stamps

@@ -333,9 +333,11 @@ extern "C" int dlwp_layernorm_bwd(const float* x, const float* gamma, const floa
     DLWP_REQUIRE(x && gamma && mean && rstd && gy && gx && ggamma && gbeta && T > 0 && C > 0, DLWP_E_INVALID,
                  "layernorm_bwd: bad argument");
     DLWP_REQUIRE(C <= 2048, DLWP_E_UNSUPPORTED, "layernorm_bwd: C <= 2048 supported (got %d)", C);
-    // enough workgroups to fill the chip; each wave then walks rpb / 4 rows serially
+    // Every workgroup ends with 2C float atomics on the same addresses, which serialise at ~25 ns each, so the
+    // tail costs (number of workgroups) x 25 ns whatever C is: ~128-256 workgroups balance that against the rows
+    // each wave walks serially.
     int rpb = 64;
-    while (rpb > 4 && ceil_div(T, rpb) < 512) rpb >>= 1;
+    while (rpb > 4 && ceil_div(T, rpb) < 128) rpb >>= 1;
     const dim3 grid(ceil_div(T, rpb));
     const size_t lds = 2 * C * sizeof(float);
     if (C <= 512)

@@ -20,6 +20,7 @@
 namespace {
 
 constexpr int QT = 64, KT = 64;
+constexpr int LDV = 64 + 4;    // transposed tiles [dd][token]: 16-byte aligned rows
 
 struct WaDev {
     const float* qkv;          // [B_, N, 3, heads, d]
@@ -35,8 +36,10 @@ struct WaDev {
     float* dsum;               // bwd: [B_, heads, N]  D = rowsum(gout * out)
     float* gqkv;               // bwd: [B_, N, 3, heads, d]
     float* gtable;             // bwd: accumulated
+    float* slab;               // bwd: optional [workgroups][TB] bias-gradient partials (folded by winattn_fold_kernel)
     int B_, nW, N, heads, d, dp16, TB;
     float scale;
+    FastDiv dd;                // division by d
 };
 
 __device__ __forceinline__ float wave_col_max(float v) {   // reduce over the 4 lane groups (same r)
@@ -48,23 +51,78 @@ __device__ __forceinline__ float wave_col_sum(float v) {
     return v + __shfl_xor(v, 32);
 }
 
-// rows [row0, row0+64) of q/k/v (which = 0/1/2) of (b, head) -> LDS tile [64][LDT], zero padded, scaled
-__device__ __forceinline__ void stage_rows(float* dst, int LDT, const float* base, long long row_stride, int row0, int N,
-                                           int d, int dp16, float scale) {
-    for (int idx = threadIdx.x; idx < 64 * dp16; idx += 256) {
-        const int row = idx / dp16, c = idx - row * dp16;
-        float v = 0.f;
-        if (row0 + row < N && c < d) v = base[(long long)(row0 + row) * row_stride + c] * scale;
-        dst[row * LDT + c] = v;
+// 64 token rows x d columns of q / k / v / dO, fetched with all loads in flight (issue) and written to LDS
+// later (commit), so that the next tile's HBM latency hides behind the current tile's matrix work.
+// Out-of-range rows are clamped for the load and zeroed at commit.  NL = ceil(64 * d / 256) loads per thread.
+template <int NL>
+struct RowTile {
+    float v[NL];
+    __device__ __forceinline__ void issue(const float* __restrict__ base, long long row_stride, int row0, int N, int d,
+                                          FastDiv dd) {
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            const int idx = threadIdx.x + 256 * q;
+            const int row = fastdiv(idx, dd), c = idx - row * d;
+            const int grow = min(row0 + min(row, 63), N - 1);
+            v[q] = base[(long long)grow * row_stride + c];
+        }
+    }
+    // rows[token][dd] (ld LDT) and / or cols[dd][token] (ld LDV); either may be nullptr
+    __device__ __forceinline__ void commit(float* rows, int LDT, float* cols, int row0, int N, int d, FastDiv dd,
+                                           float scale) const {
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            const int idx = threadIdx.x + 256 * q;
+            const int row = fastdiv(idx, dd), c = idx - row * d;
+            if (row < 64) {
+                const float val = row0 + row < N ? v[q] * scale : 0.f;
+                if (rows) rows[row * LDT + c] = val;
+                if (cols) cols[c * LDV + row] = val;
+            }
+        }
+    }
+};
+
+// per-token scalars of a 64-token tile (labels, bias-index parts, lse, D), one per thread of the first wave
+struct TokVals {
+    int lab, bidx;
+    float lse, ds;
+};
+
+// this (window type, head)'s slice of the bias table [TB][ntypes][heads] -> LDS.  The slice is a strided gather
+// (one cache line per entry): keep eight loads in flight per thread instead of one.
+__device__ __forceinline__ void load_table(float* tb, const float* __restrict__ table, int TB, long long tstr,
+                                           long long tofs) {
+    for (int i0 = threadIdx.x; i0 < TB; i0 += 256 * 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = table[(long long)min(i0 + 256 * u, TB - 1) * tstr + tofs];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (i0 + 256 * u < TB) tb[i0 + 256 * u] = v[u];
     }
 }
 
-// score tile of one 16-key chunk against this wave's 16 queries: St[key 4g+j][query r]
-__device__ __forceinline__ f32x4 score_chunk(const float* rows_a, const float* rows_b, int LDT, int dp4) {
-    // rows_a: 16 rows (A operand, row = lane r), rows_b: 16 rows (B^T operand, row = lane r)
-    const int lane = lane_id(), r = lane & 15, g = lane >> 4;
+// Bias-gradient partials are accumulated in LDS as 64-bit fixed point (2^-40 resolution, |sum| < 2^23):
+// gfx950's LDS float atomic add runs at ~0.3 lane-ops/clk/CU, the 64-bit integer add at 5-7 (tools_micro/
+// lds_atomics.hip, profiles/README.md), and integer addition makes the partial independent of the order in
+// which the waves arrive.  The rounding step (4.5e-13 absolute per term) is below fp32 accumulation error for
+// any gradient that matters.
+constexpr float FX_SCALE = 1099511627776.f;   // 2^40
+__device__ __forceinline__ void fx_add(unsigned long long* acc, float v) {
+    atomicAdd(acc, (unsigned long long)(long long)llrintf(v * FX_SCALE));
+}
+__device__ __forceinline__ float fx_get(unsigned long long v) { return (float)(long long)v * (1.f / FX_SCALE); }
+
+__device__ __forceinline__ f32x4 ldsv(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ int4 ldsi(const int* p) { return *reinterpret_cast<const int4*>(p); }
+
+// score tile of one 16-row chunk against this wave's 16 columns: acc[j] = sum_dd A[16c + 4g + j][dd] * Bfrag[dd][r]
+template <int NDB>
+__device__ __forceinline__ f32x4 score_chunk(const float* rows_a, int LDT, const f32x4 (&bfrag)[NDB], int r, int g) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < dp4; k0 += 4) acc = mfma16(rows_a[r * LDT + k0 + g], rows_b[r * LDT + k0 + g], acc);
+#pragma unroll
+    for (int cc = 0; cc < NDB; ++cc) acc = mfma16_chunk(ldsv(&rows_a[r * LDT + 16 * cc + 4 * g]), bfrag[cc], acc);
     return acc;
 }
 
@@ -72,54 +130,81 @@ __device__ __forceinline__ f32x4 score_chunk(const float* rows_a, const float* r
 template <int NDB>
 __global__ __launch_bounds__(256) void winattn_fwd_kernel(WaDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int LDT = a.dp16 + 2;
+    constexpr int NL = 4 * NDB, LDT = 16 * NDB + 4, DP = 16 * NDB;
     float* Qs = smem;                         // [64][LDT] (scaled)
-    float* Ks = Qs + 64 * LDT;
-    float* Vs = Ks + 64 * LDT;
-    float* tb = Vs + 64 * LDT;                // [TB] bias table of this head
-    int* klab = reinterpret_cast<int*>(tb + a.TB);   // [64]
-    int* kbs = klab + 64;                            // [64] key part of the bias index
+    float* Kb = Qs + 64 * LDT;                // [2][64][LDT]
+    float* Vt = Kb + 2 * 64 * LDT;            // [2][DP][LDV]   v transposed
+    int* klab = reinterpret_cast<int*>(Vt + 2 * DP * LDV);   // [2][64]
+    int* kbs = klab + 128;                                   // [2][64] key part of the bias index
+    float* tb = reinterpret_cast<float*>(kbs + 128);         // [TB] bias table of this head
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
     const int nqt = (a.N + QT - 1) / QT;
     const int qt = blockIdx.x % nqt, bh = blockIdx.x / nqt, head = bh % a.heads, b = bh / a.heads;
     const int wdw = b % a.nW;
     const long long rs = 3LL * a.heads * a.d;
     const float* qb = a.qkv + (long long)b * a.N * rs + head * a.d;
-    const int dp4 = (a.d + 3) & ~3;
-    stage_rows(Qs, LDT, qb, rs, qt * QT, a.N, a.d, a.dp16, a.scale);
+    const float* kbase = qb + a.heads * a.d;
+    const float* vbase = qb + 2 * a.heads * a.d;
+    const int* labw = a.labels ? a.labels + (long long)wdw * a.N : nullptr;
+
+    RowTile<NL> tq, tk, tv;
+    TokVals kv;
+    auto issue_tile = [&](int kt0) {
+        tk.issue(kbase, rs, kt0, a.N, a.d, a.dd);
+        tv.issue(vbase, rs, kt0, a.N, a.d, a.dd);
+        if (tid < KT) {
+            const int key = min(kt0 + tid, a.N - 1);
+            kv.lab = labw ? labw[key] : 0;
+            kv.bidx = a.ib[key];
+        }
+    };
+    auto commit_tile = [&](int kt0, int buf) {
+        tk.commit(Kb + buf * 64 * LDT, LDT, nullptr, kt0, a.N, a.d, a.dd, 1.f);
+        tv.commit(nullptr, LDT, Vt + buf * DP * LDV, kt0, a.N, a.d, a.dd, 1.f);
+        if (tid < KT) { klab[buf * 64 + tid] = kv.lab; kbs[buf * 64 + tid] = kv.bidx; }
+    };
+    tq.issue(qb, rs, qt * QT, a.N, a.d, a.dd);
+    issue_tile(0);
+    // zero the tiles once: padded columns (dd >= d) stay zero for the whole kernel
+    for (int i = tid; i < (3 * 64 * LDT + 2 * DP * LDV) / 4; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const long long tofs = (long long)(wdw % a.ntypes) * a.heads + head, tstr = (long long)a.ntypes * a.heads;
-    for (int i = tid; i < a.TB; i += 256) tb[i] = a.table[i * tstr + tofs];
+    load_table(tb, a.table, a.TB, tstr, tofs);
     const int q = qt * QT + w * 16 + r;                       // this lane's query (column)
     const int qc = q < a.N ? q : a.N - 1;                      // clamped for table indexing
     const int qa = a.ia[qc];
-    const int qlab = (a.labels && q < a.N) ? a.labels[(long long)wdw * a.N + q] : 0;
+    const int qlab = labw ? labw[qc] : 0;
+    __syncthreads();
+    tq.commit(Qs, LDT, nullptr, qt * QT, a.N, a.d, a.dd, a.scale);
+    commit_tile(0, 0);
+    __syncthreads();
+    f32x4 qf[NDB];
+#pragma unroll
+    for (int cc = 0; cc < NDB; ++cc) qf[cc] = ldsv(&Qs[(w * 16 + r) * LDT + 16 * cc + 4 * g]);
     float m = -1e30f, l = 0.f;
     f32x4 oacc[NDB];
 #pragma unroll
     for (int db = 0; db < NDB; ++db) oacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int kt0 = 0; kt0 < a.N; kt0 += KT) {
-        __syncthreads();
-        stage_rows(Ks, LDT, qb + a.heads * a.d, rs, kt0, a.N, a.d, a.dp16, 1.f);
-        stage_rows(Vs, LDT, qb + 2 * a.heads * a.d, rs, kt0, a.N, a.d, a.dp16, 1.f);
-        if (tid < KT) {
-            klab[tid] = (a.labels && kt0 + tid < a.N) ? a.labels[(long long)wdw * a.N + kt0 + tid] : 0;
-            kbs[tid] = kt0 + tid < a.N ? a.ib[kt0 + tid] : 0;
-        }
-        __syncthreads();
+    int buf = 0;
+    for (int kt0 = 0; kt0 < a.N; kt0 += KT, buf ^= 1) {
+        const bool more = kt0 + KT < a.N;
+        if (more) issue_tile(kt0 + KT);
+        const float* Kc = Kb + buf * 64 * LDT;
+        const float* Vc = Vt + buf * DP * LDV;
         f32x4 s[4];
         float mx = -1e30f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            s[c] = score_chunk(Ks + 16 * c * LDT, Qs + (w * 16) * LDT, LDT, dp4);
+            s[c] = score_chunk<NDB>(Kc + 16 * c * LDT, LDT, qf, r, g);
+            const int4 kb4 = ldsi(&kbs[buf * 64 + 16 * c + 4 * g]);
+            const int4 kl4 = ldsi(&klab[buf * 64 + 16 * c + 4 * g]);
+            const int kbv[4] = {kb4.x, kb4.y, kb4.z, kb4.w}, klv[4] = {kl4.x, kl4.y, kl4.z, kl4.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int key = kt0 + 16 * c + 4 * g + j;
-                float v = -1e30f;
-                if (key < a.N) {
-                    v = s[c][j] + tb[qa + kbs[16 * c + 4 * g + j]];
-                    if (a.labels && klab[16 * c + 4 * g + j] != qlab) v -= 100.f;
-                }
+                float v = s[c][j] + tb[qa + kbv[j]];
+                if (labw && klv[j] != qlab) v -= 100.f;
+                v = key < a.N ? v : -1e30f;
                 s[c][j] = v;
                 mx = fmaxf(mx, v);
             }
@@ -143,13 +228,10 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(WaDev a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) oacc[db][j] *= corr;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                f32x4 a4;
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) a4[s2] = Vs[(16 * c + 4 * g + s2) * LDT + db * 16 + r];
-                oacc[db] = mfma16_chunk(a4, s[c], oacc[db]);
-            }
+            for (int c = 0; c < 4; ++c) oacc[db] = mfma16_chunk(ldsv(&Vc[(16 * db + r) * LDV + 16 * c + 4 * g]), s[c], oacc[db]);
         }
+        if (more) commit_tile(kt0 + KT, buf ^ 1);
+        __syncthreads();
     }
     if (q < a.N) {
         const float inv = 1.f / l;
@@ -169,79 +251,125 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(WaDev a) {
 template <int NDB>
 __global__ __launch_bounds__(256) void winattn_bwd_q_kernel(WaDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int LDT = a.dp16 + 2;
-    float* Qs = smem;
-    float* Gs = Qs + 64 * LDT;                // dO rows of the query tile
-    float* Ks = Gs + 64 * LDT;
-    float* Vs = Ks + 64 * LDT;
-    float* tb = Vs + 64 * LDT;                // [TB] bias table
-    float* gtb = tb + a.TB;                   // [TB] bias-gradient partial of this workgroup
-    int* klab = reinterpret_cast<int*>(gtb + a.TB);
-    int* kbs = klab + 64;
+    constexpr int NL = 4 * NDB, LDT = 16 * NDB + 4, DP = 16 * NDB;
+    float* Qs = smem;                         // [64][LDT] scaled q
+    float* Gs = Qs + 64 * LDT;                // [64][LDT] dO rows of the query tile
+    float* Kb = Gs + 64 * LDT;                // [2][64][LDT]
+    float* Vb = Kb + 2 * 64 * LDT;            // [2][64][LDT]
+    float* Kt = Vb + 2 * 64 * LDT;            // [2][DP][LDV]  k transposed (A operand of dQ)
+    int* klab = reinterpret_cast<int*>(Kt + 2 * DP * LDV);
+    int* kbs = klab + 128;
+    float* tb = reinterpret_cast<float*>(kbs + 128);     // [TB] bias table
+    unsigned long long* gtb = reinterpret_cast<unsigned long long*>(tb + ((a.TB + 1) & ~1));   // [TB] fixed-point partial
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
     const int nqt = (a.N + QT - 1) / QT;
     const int qt = blockIdx.x % nqt, bh = blockIdx.x / nqt, head = bh % a.heads, b = bh / a.heads;
     const int wdw = b % a.nW;
     const long long rs = 3LL * a.heads * a.d, os = (long long)a.heads * a.d;
     const float* qb = a.qkv + (long long)b * a.N * rs + head * a.d;
-    const int dp4 = (a.d + 3) & ~3;
-    stage_rows(Qs, LDT, qb, rs, qt * QT, a.N, a.d, a.dp16, a.scale);
-    stage_rows(Gs, LDT, a.gout + (long long)b * a.N * os + head * a.d, os, qt * QT, a.N, a.d, a.dp16, 1.f);
+    const float* kbase = qb + a.heads * a.d;
+    const float* vbase = qb + 2 * a.heads * a.d;
+    const float* gbase = a.gout + (long long)b * a.N * os + head * a.d;
+    const int* labw = a.labels ? a.labels + (long long)wdw * a.N : nullptr;
+
+    DLWP_STAMP(0);
+    RowTile<NL> tq, tg, tk, tv;
+    TokVals kv;
+    auto issue_tile = [&](int kt0) {
+        tk.issue(kbase, rs, kt0, a.N, a.d, a.dd);
+        tv.issue(vbase, rs, kt0, a.N, a.d, a.dd);
+        if (tid < KT) {
+            const int key = min(kt0 + tid, a.N - 1);
+            kv.lab = labw ? labw[key] : 0;
+            kv.bidx = a.ib[key];
+        }
+    };
+    auto commit_tile = [&](int kt0, int buf) {
+        tk.commit(Kb + buf * 64 * LDT, LDT, Kt + buf * DP * LDV, kt0, a.N, a.d, a.dd, 1.f);
+        tv.commit(Vb + buf * 64 * LDT, LDT, nullptr, kt0, a.N, a.d, a.dd, 1.f);
+        if (tid < KT) { klab[buf * 64 + tid] = kv.lab; kbs[buf * 64 + tid] = kv.bidx; }
+    };
+    tq.issue(qb, rs, qt * QT, a.N, a.d, a.dd);
+    tg.issue(gbase, os, qt * QT, a.N, a.d, a.dd);
+    issue_tile(0);
+    DLWP_STAMP(13);
+    for (int i = tid; i < (6 * 64 * LDT + 2 * DP * LDV) / 4; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    DLWP_STAMP(14);
     const long long tofs = (long long)(wdw % a.ntypes) * a.heads + head, tstr = (long long)a.ntypes * a.heads;
-    for (int i = tid; i < a.TB; i += 256) { tb[i] = a.table[i * tstr + tofs]; gtb[i] = 0.f; }
+    load_table(tb, a.table, a.TB, tstr, tofs);
+    DLWP_STAMP(15);
+    for (int i = tid; i < a.TB; i += 256) gtb[i] = 0ull;
+    DLWP_STAMP(16);
     const int q = qt * QT + w * 16 + r;
-    const int qa = a.ia[q < a.N ? q : a.N - 1];
-    const int qlab = (a.labels && q < a.N) ? a.labels[(long long)wdw * a.N + q] : 0;
-    const float lse = q < a.N ? a.lse_in[((long long)b * a.heads + head) * a.N + q] : 0.f;
+    const int qc = q < a.N ? q : a.N - 1;
+    const int qa = a.ia[qc];
+    const int qlab = labw ? labw[qc] : 0;
+    const float lse = a.lse_in[((long long)b * a.heads + head) * a.N + qc];
+    float orow[4 * NDB];                      // O[q][g + 4 u]: this lane's share of D = sum_dd dO[q][dd] O[q][dd]
+#pragma unroll
+    for (int u = 0; u < 4 * NDB; ++u) orow[u] = a.o[((long long)b * a.N + qc) * os + head * a.d + min(g + 4 * u, a.d - 1)];
+    DLWP_STAMP(1);
     __syncthreads();
+    DLWP_STAMP(2);
+    tq.commit(Qs, LDT, nullptr, qt * QT, a.N, a.d, a.dd, a.scale);
+    tg.commit(Gs, LDT, nullptr, qt * QT, a.N, a.d, a.dd, 1.f);
+    commit_tile(0, 0);
+    __syncthreads();
+    DLWP_STAMP(3);
     // D[q] = sum_dd dO[q][dd] * O[q][dd]
     float dpart = 0.f;
-    if (q < a.N)
-        for (int dd = g; dd < a.d; dd += 4)
-            dpart += Gs[(w * 16 + r) * LDT + dd] * a.o[((long long)b * a.N + q) * os + head * a.d + dd];
+#pragma unroll
+    for (int u = 0; u < 4 * NDB; ++u)
+        if (g + 4 * u < a.d) dpart += Gs[(w * 16 + r) * LDT + g + 4 * u] * orow[u];     // rows q >= N of Gs are zero
     const float D = wave_col_sum(dpart);
     if (q < a.N && g == 0) a.dsum[((long long)b * a.heads + head) * a.N + q] = D;
-    f32x4 dq[NDB];
+    f32x4 qf[NDB], gf[NDB], dq[NDB];
 #pragma unroll
-    for (int db = 0; db < NDB; ++db) dq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int cc = 0; cc < NDB; ++cc) {
+        qf[cc] = ldsv(&Qs[(w * 16 + r) * LDT + 16 * cc + 4 * g]);
+        gf[cc] = ldsv(&Gs[(w * 16 + r) * LDT + 16 * cc + 4 * g]);
+        dq[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
-    for (int kt0 = 0; kt0 < a.N; kt0 += KT) {
-        __syncthreads();
-        stage_rows(Ks, LDT, qb + a.heads * a.d, rs, kt0, a.N, a.d, a.dp16, 1.f);
-        stage_rows(Vs, LDT, qb + 2 * a.heads * a.d, rs, kt0, a.N, a.d, a.dp16, 1.f);
-        if (tid < KT) {
-            klab[tid] = (a.labels && kt0 + tid < a.N) ? a.labels[(long long)wdw * a.N + kt0 + tid] : 0;
-            kbs[tid] = kt0 + tid < a.N ? a.ib[kt0 + tid] : 0;
-        }
-        __syncthreads();
+    DLWP_STAMP(4);
+    int buf = 0;
+    for (int kt0 = 0; kt0 < a.N; kt0 += KT, buf ^= 1) {
+        const bool more = kt0 + KT < a.N;
+        if (kt0 == 0) DLWP_STAMP(5);
+        if (more) issue_tile(kt0 + KT);
+        if (kt0 == 0) DLWP_STAMP(6);
+        const float* Kc = Kb + buf * 64 * LDT;
+        const float* Vc = Vb + buf * 64 * LDT;
+        const float* Ktc = Kt + buf * DP * LDV;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            f32x4 s = score_chunk(Ks + 16 * c * LDT, Qs + (w * 16) * LDT, LDT, dp4);
-            const f32x4 dp = score_chunk(Vs + 16 * c * LDT, Gs + (w * 16) * LDT, LDT, dp4);   // dP^T = V dO^T
+            const f32x4 s = score_chunk<NDB>(Kc + 16 * c * LDT, LDT, qf, r, g);
+            const f32x4 dp = score_chunk<NDB>(Vc + 16 * c * LDT, LDT, gf, r, g);   // dP^T = V dO^T
+            const int4 kb4 = ldsi(&kbs[buf * 64 + 16 * c + 4 * g]);
+            const int4 kl4 = ldsi(&klab[buf * 64 + 16 * c + 4 * g]);
+            const int kbv[4] = {kb4.x, kb4.y, kb4.z, kb4.w}, klv[4] = {kl4.x, kl4.y, kl4.z, kl4.w};
             f32x4 ds;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int key = kt0 + 16 * c + 4 * g + j;
-                float v = 0.f;
-                if (key < a.N && q < a.N) {
-                    const int bi = qa + kbs[16 * c + 4 * g + j];
-                    float sc = s[j] + tb[bi];
-                    if (a.labels && klab[16 * c + 4 * g + j] != qlab) sc -= 100.f;
-                    const float p = __expf(sc - lse);
-                    v = p * (dp[j] - D);
-                    atomicAdd(&gtb[bi], v);
-                }
+                const int bi = qa + kbv[j];
+                float sc = s[j] + tb[bi];
+                if (labw && klv[j] != qlab) sc -= 100.f;
+                const float p = __expf(sc - lse);
+                const float v = (key < a.N && q < a.N) ? p * (dp[j] - D) : 0.f;
+                if (key < a.N && q < a.N) fx_add(&gtb[bi], v);
                 ds[j] = v;
             }
 #pragma unroll
-            for (int db = 0; db < NDB; ++db) {
-                f32x4 a4;
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) a4[s2] = Ks[(16 * c + 4 * g + s2) * LDT + db * 16 + r];
-                dq[db] = mfma16_chunk(a4, ds, dq[db]);
-            }
+            for (int db = 0; db < NDB; ++db) dq[db] = mfma16_chunk(ldsv(&Ktc[(16 * db + r) * LDV + 16 * c + 4 * g]), ds, dq[db]);
         }
+        if (kt0 == 0) DLWP_STAMP(7);
+        if (more) commit_tile(kt0 + KT, buf ^ 1);
+        if (kt0 == 0) DLWP_STAMP(8);
+        __syncthreads();
+        if (kt0 == 0) DLWP_STAMP(9);
     }
+    DLWP_STAMP(10);
     if (q < a.N) {
 #pragma unroll
         for (int db = 0; db < NDB; ++db)
@@ -251,11 +379,34 @@ __global__ __launch_bounds__(256) void winattn_bwd_q_kernel(WaDev a) {
                 if (dd < a.d) a.gqkv[((long long)b * a.N + q) * rs + head * a.d + dd] = dq[db][j] * a.scale;
             }
     }
-    __syncthreads();
-    for (int i = tid; i < a.TB; i += 256) {
-        const float v = gtb[i];
-        if (v != 0.f) atomic_add_f32(&a.gtable[i * tstr + tofs], v);
+    DLWP_STAMP(11);
+    if (a.slab) {
+        // plain coalesced stores; winattn_fold_kernel sums the partials of every (head, window type)
+        for (int i = tid; i < a.TB; i += 256) a.slab[(long long)blockIdx.x * a.TB + i] = fx_get(gtb[i]);
+    } else {
+        for (int i = tid; i < a.TB; i += 256) {
+            if (gtb[i] != 0ull) atomic_add_f32(&a.gtable[i * tstr + tofs], fx_get(gtb[i]));
+        }
     }
+    DLWP_STAMP(12);
+}
+
+// gtable[t][type][head] += sum over the workgroups (window b, query tile) with b % ntypes == type
+constexpr int FOLD_CH = 32;
+__global__ __launch_bounds__(256) void winattn_fold_kernel(const float* __restrict__ slab, float* gtable, int TB, int ntypes,
+                                                           int heads, int nqt, int n_items) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int ty = blockIdx.y % ntypes, head = blockIdx.y / ntypes;
+    if (t >= TB) return;
+    const int i0 = blockIdx.z * FOLD_CH, i1 = min(n_items, i0 + FOLD_CH);
+    float acc = 0.f;
+#pragma unroll 8
+    for (int it = i0; it < i1; ++it) {
+        const int m = it / nqt, qt = it - m * nqt;
+        const long long wg = ((long long)(ty + ntypes * m) * heads + head) * nqt + qt;
+        acc += slab[wg * TB + t];
+    }
+    atomic_add_f32(&gtable[((long long)t * ntypes + ty) * heads + head], acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -263,77 +414,108 @@ __global__ __launch_bounds__(256) void winattn_bwd_q_kernel(WaDev a) {
 template <int NDB>
 __global__ __launch_bounds__(256) void winattn_bwd_kv_kernel(WaDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int LDT = a.dp16 + 2;
-    float* Ks = smem;
-    float* Vs = Ks + 64 * LDT;
-    float* Qs = Vs + 64 * LDT;                // scaled q rows of the current query tile
-    float* Gs = Qs + 64 * LDT;
-    float* tb = Gs + 64 * LDT;
-    float* lses = tb + a.TB;                  // [64]
-    float* dss = lses + 64;                   // [64]
-    int* qlabs = reinterpret_cast<int*>(dss + 64);   // [64]
-    int* qas = qlabs + 64;                           // [64] query part of the bias index
+    constexpr int NL = 4 * NDB, LDT = 16 * NDB + 4, DP = 16 * NDB;
+    float* Ks = smem;                         // [64][LDT]
+    float* Vs = Ks + 64 * LDT;                // [64][LDT]
+    float* Qb = Vs + 64 * LDT;                // [2][64][LDT] scaled q rows of the current query tile
+    float* Gb = Qb + 2 * 64 * LDT;            // [2][64][LDT]
+    float* Qt = Gb + 2 * 64 * LDT;            // [2][DP][LDV]
+    float* Gt = Qt + 2 * DP * LDV;            // [2][DP][LDV]
+    float* lses = Gt + 2 * DP * LDV;          // [2][64]
+    float* dss = lses + 128;                  // [2][64]
+    int* qlabs = reinterpret_cast<int*>(dss + 128);   // [2][64]
+    int* qas = qlabs + 128;                           // [2][64] query part of the bias index
+    float* tb = reinterpret_cast<float*>(qas + 128);
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
     const int nkt = (a.N + KT - 1) / KT;
     const int kt = blockIdx.x % nkt, bh = blockIdx.x / nkt, head = bh % a.heads, b = bh / a.heads;
     const int wdw = b % a.nW;
     const long long rs = 3LL * a.heads * a.d, os = (long long)a.heads * a.d;
     const float* qb = a.qkv + (long long)b * a.N * rs + head * a.d;
-    const int dp4 = (a.d + 3) & ~3;
-    stage_rows(Ks, LDT, qb + a.heads * a.d, rs, kt * KT, a.N, a.d, a.dp16, 1.f);
-    stage_rows(Vs, LDT, qb + 2 * a.heads * a.d, rs, kt * KT, a.N, a.d, a.dp16, 1.f);
-    const long long tofs = (long long)(wdw % a.ntypes) * a.heads + head, tstr = (long long)a.ntypes * a.heads;
-    for (int i = tid; i < a.TB; i += 256) tb[i] = a.table[i * tstr + tofs];
-    const int key = kt * KT + w * 16 + r;                     // this lane's key (column)
-    const int kbv = a.ib[key < a.N ? key : a.N - 1];
-    const int klabel = (a.labels && key < a.N) ? a.labels[(long long)wdw * a.N + key] : 0;
-    f32x4 dk[NDB], dv[NDB];
-#pragma unroll
-    for (int db = 0; db < NDB; ++db) { dk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db] = dk[db]; }
+    const float* gbase = a.gout + (long long)b * a.N * os + head * a.d;
+    const int* labw = a.labels ? a.labels + (long long)wdw * a.N : nullptr;
+    const long long stat = ((long long)b * a.heads + head) * a.N;
 
-    for (int qt0 = 0; qt0 < a.N; qt0 += QT) {
-        __syncthreads();
-        stage_rows(Qs, LDT, qb, rs, qt0, a.N, a.d, a.dp16, a.scale);
-        stage_rows(Gs, LDT, a.gout + (long long)b * a.N * os + head * a.d, os, qt0, a.N, a.d, a.dp16, 1.f);
+    RowTile<NL> tk, tv, tq, tg;
+    TokVals qv;
+    auto issue_tile = [&](int qt0) {
+        tq.issue(qb, rs, qt0, a.N, a.d, a.dd);
+        tg.issue(gbase, os, qt0, a.N, a.d, a.dd);
         if (tid < QT) {
-            const bool ok = qt0 + tid < a.N;
-            lses[tid] = ok ? a.lse_in[((long long)b * a.heads + head) * a.N + qt0 + tid] : 0.f;
-            dss[tid] = ok ? a.dsum[((long long)b * a.heads + head) * a.N + qt0 + tid] : 0.f;
-            qlabs[tid] = (a.labels && ok) ? a.labels[(long long)wdw * a.N + qt0 + tid] : 0;
-            qas[tid] = ok ? a.ia[qt0 + tid] : 0;
+            const int qq = min(qt0 + tid, a.N - 1);
+            qv.lab = labw ? labw[qq] : 0;
+            qv.bidx = a.ia[qq];
+            qv.lse = a.lse_in[stat + qq];
+            qv.ds = a.dsum[stat + qq];
         }
-        __syncthreads();
+    };
+    auto commit_tile = [&](int qt0, int buf) {
+        tq.commit(Qb + buf * 64 * LDT, LDT, Qt + buf * DP * LDV, qt0, a.N, a.d, a.dd, a.scale);
+        tg.commit(Gb + buf * 64 * LDT, LDT, Gt + buf * DP * LDV, qt0, a.N, a.d, a.dd, 1.f);
+        if (tid < QT) {
+            lses[buf * 64 + tid] = qv.lse; dss[buf * 64 + tid] = qv.ds;
+            qlabs[buf * 64 + tid] = qv.lab; qas[buf * 64 + tid] = qv.bidx;
+        }
+    };
+    tk.issue(qb + a.heads * a.d, rs, kt * KT, a.N, a.d, a.dd);
+    tv.issue(qb + 2 * a.heads * a.d, rs, kt * KT, a.N, a.d, a.dd);
+    issue_tile(0);
+    for (int i = tid; i < (6 * 64 * LDT + 4 * DP * LDV) / 4; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const long long tofs = (long long)(wdw % a.ntypes) * a.heads + head, tstr = (long long)a.ntypes * a.heads;
+    load_table(tb, a.table, a.TB, tstr, tofs);
+    const int key = kt * KT + w * 16 + r;                     // this lane's key (column)
+    const int kc = key < a.N ? key : a.N - 1;
+    const int kbv = a.ib[kc];
+    const int klabel = labw ? labw[kc] : 0;
+    __syncthreads();
+    tk.commit(Ks, LDT, nullptr, kt * KT, a.N, a.d, a.dd, 1.f);
+    tv.commit(Vs, LDT, nullptr, kt * KT, a.N, a.d, a.dd, 1.f);
+    commit_tile(0, 0);
+    __syncthreads();
+    f32x4 kf[NDB], vf[NDB], dk[NDB], dv[NDB];
+#pragma unroll
+    for (int cc = 0; cc < NDB; ++cc) {
+        kf[cc] = ldsv(&Ks[(w * 16 + r) * LDT + 16 * cc + 4 * g]);
+        vf[cc] = ldsv(&Vs[(w * 16 + r) * LDT + 16 * cc + 4 * g]);
+        dk[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dv[cc] = dk[cc];
+    }
+
+    int buf = 0;
+    for (int qt0 = 0; qt0 < a.N; qt0 += QT, buf ^= 1) {
+        const bool more = qt0 + QT < a.N;
+        if (more) issue_tile(qt0 + QT);
+        const float* Qc = Qb + buf * 64 * LDT;
+        const float* Gc = Gb + buf * 64 * LDT;
+        const float* Qtc = Qt + buf * DP * LDV;
+        const float* Gtc = Gt + buf * DP * LDV;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             // S[query 4g+j][key r], dP[query][key]
-            const f32x4 s = score_chunk(Qs + 16 * c * LDT, Ks + (w * 16) * LDT, LDT, dp4);
-            const f32x4 dp = score_chunk(Gs + 16 * c * LDT, Vs + (w * 16) * LDT, LDT, dp4);
+            const f32x4 s = score_chunk<NDB>(Qc + 16 * c * LDT, LDT, kf, r, g);
+            const f32x4 dp = score_chunk<NDB>(Gc + 16 * c * LDT, LDT, vf, r, g);
+            const int o4 = buf * 64 + 16 * c + 4 * g;
+            const f32x4 ls4 = ldsv(&lses[o4]), dd4 = ldsv(&dss[o4]);
+            const int4 ql4 = ldsi(&qlabs[o4]), qa4 = ldsi(&qas[o4]);
+            const int qlv[4] = {ql4.x, ql4.y, ql4.z, ql4.w}, qav[4] = {qa4.x, qa4.y, qa4.z, qa4.w};
             f32x4 p, ds;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int ql = 16 * c + 4 * g + j, q = qt0 + ql;
-                float pv = 0.f, dsv = 0.f;
-                if (q < a.N && key < a.N) {
-                    float sc = s[j] + tb[qas[ql] + kbv];
-                    if (a.labels && qlabs[ql] != klabel) sc -= 100.f;
-                    pv = __expf(sc - lses[ql]);
-                    dsv = pv * (dp[j] - dss[ql]);
-                }
+                const int q = qt0 + 16 * c + 4 * g + j;
+                float sc = s[j] + tb[qav[j] + kbv];
+                if (labw && qlv[j] != klabel) sc -= 100.f;
+                const float pv = (q < a.N && key < a.N) ? __expf(sc - ls4[j]) : 0.f;
                 p[j] = pv;
-                ds[j] = dsv;
+                ds[j] = pv * (dp[j] - dd4[j]);
             }
 #pragma unroll
             for (int db = 0; db < NDB; ++db) {
-                f32x4 g4, q4;
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) {
-                    g4[s2] = Gs[(16 * c + 4 * g + s2) * LDT + db * 16 + r];
-                    q4[s2] = Qs[(16 * c + 4 * g + s2) * LDT + db * 16 + r];
-                }
-                dv[db] = mfma16_chunk(g4, p, dv[db]);     // dV^T[dd][key] += dO^T[dd][q] P[q][key]
-                dk[db] = mfma16_chunk(q4, ds, dk[db]);    // dK^T[dd][key] += (scale q)^T[dd][q] dS[q][key]
+                dv[db] = mfma16_chunk(ldsv(&Gtc[(16 * db + r) * LDV + 16 * c + 4 * g]), p, dv[db]);    // dV^T += dO^T P
+                dk[db] = mfma16_chunk(ldsv(&Qtc[(16 * db + r) * LDV + 16 * c + 4 * g]), ds, dk[db]);   // dK^T += (scale q)^T dS
             }
         }
+        if (more) commit_tile(qt0 + QT, buf ^ 1);
+        __syncthreads();
     }
     if (key < a.N) {
 #pragma unroll
@@ -355,9 +537,10 @@ int wa_setup(WaDev& a, int B_, int nW, int N, int TB, int ntypes, int heads, int
                  DLWP_E_INVALID, "%s: bad shape", who);
     DLWP_REQUIRE(nW % ntypes == 0, DLWP_E_INVALID, "%s: nW (%d) must be a multiple of ntypes (%d)", who, nW, ntypes);
     DLWP_REQUIRE(d <= 32, DLWP_E_UNSUPPORTED, "%s: head_dim %d > 32 not supported yet", who, d);
-    DLWP_REQUIRE(TB <= 12000, DLWP_E_UNSUPPORTED, "%s: bias table slice of %d entries does not fit LDS", who, TB);
+    DLWP_REQUIRE(TB <= 7500, DLWP_E_UNSUPPORTED, "%s: bias table slice of %d entries does not fit LDS", who, TB);
     a.B_ = B_; a.nW = nW; a.N = N; a.TB = TB; a.ntypes = ntypes; a.heads = heads; a.d = d; a.scale = scale;
     a.dp16 = round_up(d, 16);
+    a.dd = make_fastdiv(d);
     return DLWP_OK;
 }
 
@@ -371,7 +554,7 @@ extern "C" int dlwp_window_attn_fwd(const float* qkv, const float* bias_table, c
     int rc = wa_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, "window_attn_fwd");
     if (rc) return rc;
     a.qkv = qkv; a.table = bias_table; a.ia = ia; a.ib = ib; a.labels = labels; a.out = out; a.lse = lse;
-    const size_t lds = sizeof(float) * ((size_t)3 * 64 * (a.dp16 + 2) + a.TB + 128);
+    const size_t lds = sizeof(float) * ((size_t)3 * 64 * (a.dp16 + 4) + 2 * a.dp16 * LDV + 256 + a.TB);
     const dim3 grid(B_ * heads * ((N + QT - 1) / QT)), block(256);
     if (a.dp16 == 16) {
         if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_fwd_kernel<1>), lds, "window_attn_fwd"))) return rc;
@@ -386,18 +569,18 @@ extern "C" int dlwp_window_attn_fwd(const float* qkv, const float* bias_table, c
 
 extern "C" int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, const int* ia, const int* ib,
                                     const int* labels, const float* out, const float* lse, const float* gout,
-                                    float* gqkv, float* gbias_table, float* dsum, int B_, int nW, int N, int TB,
-                                    int ntypes, int heads, int d, float scale, void* stream) {
+                                    float* gqkv, float* gbias_table, float* dsum, float* slab, int B_, int nW, int N,
+                                    int TB, int ntypes, int heads, int d, float scale, void* stream) {
     DLWP_REQUIRE(qkv && bias_table && ia && ib && out && lse && gout && gqkv && gbias_table && dsum, DLWP_E_INVALID,
                  "window_attn_bwd: NULL argument");
     WaDev a{};
     int rc = wa_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, "window_attn_bwd");
     if (rc) return rc;
     a.qkv = qkv; a.table = bias_table; a.ia = ia; a.ib = ib; a.labels = labels; a.o = out; a.lse_in = lse; a.gout = gout; a.gqkv = gqkv;
-    a.gtable = gbias_table; a.dsum = dsum;
-    const int LDT = a.dp16 + 2;
-    const size_t lds_q = sizeof(float) * ((size_t)4 * 64 * LDT + 2 * a.TB + 128);
-    const size_t lds_kv = sizeof(float) * ((size_t)4 * 64 * LDT + a.TB + 4 * 64);
+    a.gtable = gbias_table; a.dsum = dsum; a.slab = slab;
+    const int LDT = a.dp16 + 4;
+    const size_t lds_q = sizeof(float) * ((size_t)6 * 64 * LDT + 2 * a.dp16 * LDV + 256 + 3 * (size_t)((a.TB + 1) & ~1));
+    const size_t lds_kv = sizeof(float) * ((size_t)6 * 64 * LDT + 4 * a.dp16 * LDV + 512 + a.TB);
     const dim3 grid(B_ * heads * ((N + QT - 1) / QT)), block(256);
     if (a.dp16 == 16) {
         if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_bwd_q_kernel<1>), lds_q, "window_attn_bwd"))) return rc;
@@ -410,6 +593,23 @@ extern "C" int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, c
         hipLaunchKernelGGL(winattn_bwd_q_kernel<2>, grid, block, lds_q, (hipStream_t)stream, a);
         hipLaunchKernelGGL(winattn_bwd_kv_kernel<2>, grid, block, lds_kv, (hipStream_t)stream, a);
     }
+    if (slab) {
+        const int nqt = (N + QT - 1) / QT, n_items = (B_ / ntypes) * nqt;
+        hipLaunchKernelGGL(winattn_fold_kernel, dim3((TB + 255) / 256, heads * ntypes, (n_items + FOLD_CH - 1) / FOLD_CH),
+                           dim3(256), 0, (hipStream_t)stream, slab, gbias_table, TB, ntypes, heads, nqt, n_items);
+    }
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }
+
+extern "C" long long dlwp_window_attn_bwd_slab_floats(int B_, int N, int heads, int TB) {
+    if (B_ <= 0 || N <= 0 || heads <= 0 || TB <= 0) return -1;
+    return (long long)B_ * heads * ((N + QT - 1) / QT) * TB;
+}
+
+#ifdef DLWP_STAMPS
+extern "C" int dlwp_debug_stamps_winattn(unsigned long long* host_out) {
+    DLWP_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dlwp_stamps), sizeof(unsigned long long) * 32));
+    return DLWP_OK;
+}
+#endif

@@ -53,9 +53,10 @@ class _WindowAttnFn(torch.autograd.Function):
         gqkv = torch.empty_like(qkv)
         gtable = ctx.tslot if ctx.tslot is not None else torch.zeros_like(table)   # kernel accumulates
         dsum = torch.empty_like(lse)
+        slab = torch.empty(lib.dlwp_window_attn_bwd_slab_floats(B_, N, heads, TB), device=qkv.device)
         L.check(lib.dlwp_window_attn_bwd(L.ptr(qkv), L.ptr(table), L.ptr(ia), L.ptr(ib), L.ptr(labels), L.ptr(out),
                                          L.ptr(lse), L.ptr(gout.contiguous().float()), L.ptr(gqkv), L.ptr(gtable),
-                                         L.ptr(dsum), B_, nW, N, TB, ntypes, heads, d, scale, L.stream()))
+                                         L.ptr(dsum), L.ptr(slab), B_, nW, N, TB, ntypes, heads, d, scale, L.stream()))
         return gqkv, (None if ctx.tslot is not None else gtable), None, None, None, None, None, None
 
 

@@ -226,10 +226,14 @@ int dlwp_window_attn_fwd(const float* qkv, const float* bias_table, const int* i
                          const int* labels, float* out, float* lse, int B_, int nW, int N, int TB,
                          int ntypes, int heads, int d, float scale, void* stream);
 /* gqkv is written; gbias_table is ACCUMULATED into; dsum: scratch [B_, heads, N].           */
+/* slab: optional scratch of dlwp_window_attn_bwd_slab_floats() floats -- the workgroups then */
+/* store their bias-gradient partials there and a fold kernel sums them (one atomic per       */
+/* FOLD chunk instead of TB atomics per workgroup); NULL: direct atomics.                     */
+long long dlwp_window_attn_bwd_slab_floats(int B_, int N, int heads, int TB);
 int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, const int* ia, const int* ib,
                          const int* labels, const float* out, const float* lse, const float* gout,
-                         float* gqkv, float* gbias_table, float* dsum, int B_, int nW, int N,
-                         int TB, int ntypes, int heads, int d, float scale, void* stream);
+                         float* gqkv, float* gbias_table, float* dsum, float* slab, int B_, int nW,
+                         int N, int TB, int ntypes, int heads, int d, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* Token-level building blocks of the AFNO / Swin / Pangu blocks (nn.Linear, nn.LayerNorm, */

@@ -18,11 +18,11 @@ from dlwp_benchmark_amd import dlwpbench, nsbench  # noqa: E402
 from dlwp_benchmark_amd.train_engine import GraphedTrainStep  # noqa: E402
 
 
-def run(name, model, make_batch, steps, warmup=3, use_graph=True, call=None):
+def run(name, model, make_batch, steps, warmup=3, use_graph=True, call=None, lr=1e-3):
     dev = torch.device("cuda:0")
     model = model.to(dev).train()
     inputs, target, B = make_batch(dev)
-    step = GraphedTrainStep(model, inputs, target, lr=1e-3, use_graph=use_graph, call=call)
+    step = GraphedTrainStep(model, inputs, target, lr=lr, use_graph=use_graph, call=call)
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -74,7 +74,7 @@ def main():
                       prescribed=torch.randn(1, 5, 1, 32, 64, generator=g).to(dev),
                       prognostic=torch.randn(1, 5, 5, 32, 64, generator=g).to(dev))
             return kw, torch.randn(1, 4, 5, 32, 64, generator=g).to(dev), 1
-        run("dlwpbench PanguWeather 32x64 E192 window(2,6,12) B1 T5", m, batch, a.steps, use_graph=not a.no_graph)
+        run("dlwpbench PanguWeather 32x64 E192 window(2,6,12) B1 T5", m, batch, a.steps, use_graph=not a.no_graph, lr=1e-4)
 
 
 if __name__ == "__main__":

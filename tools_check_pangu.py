@@ -7,10 +7,10 @@ def make():
     torch.manual_seed(0)
     m = _make()
     for mod in m.modules():
-        if isinstance(mod, dlwpbench.panguweather.DropPath):
+        if isinstance(mod, dlwpbench.panguweather.DropPath) and DP is not None:
             mod.p = DP
     return m
-DP = 0.0
+DP = None if len(sys.argv) > 1 and sys.argv[1] == "droppath" else 0.0
 def _make():
     return dlwpbench.PanguWeather(constant_channels=4, prescribed_channels=1, prognostic_channels=5, embed_dim=192,
                                   num_heads=(6, 12, 12, 6), window_size=(2, 6, 12), patch_size=(1, 1), n_lat=32, n_lon=64,

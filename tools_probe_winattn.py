@@ -22,6 +22,7 @@ def run(B_, nW, N, heads, d, TB, masked, iters=50):
     gqkv = torch.empty_like(qkv)
     gtable = torch.zeros_like(table)
     dsum = torch.empty_like(lse)
+    slab = torch.empty(lib.dlwp_window_attn_bwd_slab_floats(B_, N, heads, TB), device=dev)
     st = torch.cuda.current_stream().cuda_stream
 
     def fwd():
@@ -30,7 +31,7 @@ def run(B_, nW, N, heads, d, TB, masked, iters=50):
 
     def bwd():
         L.check(lib.dlwp_window_attn_bwd(L.ptr(qkv), L.ptr(table), L.ptr(ia), L.ptr(ib), L.ptr(labels), L.ptr(out), L.ptr(lse),
-                                         L.ptr(gout), L.ptr(gqkv), L.ptr(gtable), L.ptr(dsum),
+                                         L.ptr(gout), L.ptr(gqkv), L.ptr(gtable), L.ptr(dsum), L.ptr(slab),
                                          B_, nW, N, TB, 1, heads, d, d ** -0.5, st))
     res = []
     for f in (fwd, bwd):
