@@ -252,11 +252,13 @@ template <int NDB>
 __global__ __launch_bounds__(256) void winattn_bwd_q_kernel(WaDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NL = 4 * NDB, LDT = 16 * NDB + 4, DP = 16 * NDB;
-    float* Qs = smem;                         // [64][LDT] scaled q
-    float* Gs = Qs + 64 * LDT;                // [64][LDT] dO rows of the query tile
-    float* Kb = Gs + 64 * LDT;                // [2][64][LDT]
+    float* Kb = smem;                         // [2][64][LDT]
     float* Vb = Kb + 2 * 64 * LDT;            // [2][64][LDT]
     float* Kt = Vb + 2 * 64 * LDT;            // [2][DP][LDV]  k transposed (A operand of dQ)
+    // q (scaled) and dO rows of the query tile are only needed until their MFMA fragments sit in registers: they
+    // borrow the second K / V buffers, which the pipeline first writes at the end of iteration 0
+    float* Qs = Kb + 64 * LDT;                // [64][LDT]
+    float* Gs = Vb + 64 * LDT;                // [64][LDT]
     int* klab = reinterpret_cast<int*>(Kt + 2 * DP * LDV);
     int* kbs = klab + 128;
     float* tb = reinterpret_cast<float*>(kbs + 128);     // [TB] bias table
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(256) void winattn_bwd_q_kernel(WaDev a) {
     tg.issue(gbase, os, qt * QT, a.N, a.d, a.dd);
     issue_tile(0);
     DLWP_STAMP(13);
-    for (int i = tid; i < (6 * 64 * LDT + 2 * DP * LDV) / 4; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < (4 * 64 * LDT + 2 * DP * LDV) / 4; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     DLWP_STAMP(14);
     const long long tofs = (long long)(wdw % a.ntypes) * a.heads + head, tstr = (long long)a.ntypes * a.heads;
     load_table(tb, a.table, a.TB, tstr, tofs);
@@ -330,6 +332,7 @@ __global__ __launch_bounds__(256) void winattn_bwd_q_kernel(WaDev a) {
         gf[cc] = ldsv(&Gs[(w * 16 + r) * LDT + 16 * cc + 4 * g]);
         dq[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    __syncthreads();                          // Qs / Gs are dead from here on (their storage is tile buffer 1)
 
     DLWP_STAMP(4);
     int buf = 0;
@@ -537,7 +540,7 @@ int wa_setup(WaDev& a, int B_, int nW, int N, int TB, int ntypes, int heads, int
                  DLWP_E_INVALID, "%s: bad shape", who);
     DLWP_REQUIRE(nW % ntypes == 0, DLWP_E_INVALID, "%s: nW (%d) must be a multiple of ntypes (%d)", who, nW, ntypes);
     DLWP_REQUIRE(d <= 32, DLWP_E_UNSUPPORTED, "%s: head_dim %d > 32 not supported yet", who, d);
-    DLWP_REQUIRE(TB <= 7500, DLWP_E_UNSUPPORTED, "%s: bias table slice of %d entries does not fit LDS", who, TB);
+    DLWP_REQUIRE(TB <= 9000, DLWP_E_UNSUPPORTED, "%s: bias table slice of %d entries does not fit LDS", who, TB);
     a.B_ = B_; a.nW = nW; a.N = N; a.TB = TB; a.ntypes = ntypes; a.heads = heads; a.d = d; a.scale = scale;
     a.dp16 = round_up(d, 16);
     a.dd = make_fastdiv(d);
@@ -579,7 +582,7 @@ extern "C" int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, c
     a.qkv = qkv; a.table = bias_table; a.ia = ia; a.ib = ib; a.labels = labels; a.o = out; a.lse_in = lse; a.gout = gout; a.gqkv = gqkv;
     a.gtable = gbias_table; a.dsum = dsum; a.slab = slab;
     const int LDT = a.dp16 + 4;
-    const size_t lds_q = sizeof(float) * ((size_t)6 * 64 * LDT + 2 * a.dp16 * LDV + 256 + 3 * (size_t)((a.TB + 1) & ~1));
+    const size_t lds_q = sizeof(float) * ((size_t)4 * 64 * LDT + 2 * a.dp16 * LDV + 256 + 3 * (size_t)((a.TB + 1) & ~1));
     const size_t lds_kv = sizeof(float) * ((size_t)6 * 64 * LDT + 4 * a.dp16 * LDV + 512 + a.TB);
     const dim3 grid(B_ * heads * ((N + QT - 1) / QT)), block(256);
     if (a.dp16 == 16) {

@@ -70,12 +70,28 @@ def _pair(v):
 
 def _tokens_to_windows(x, ws):
     B, H, W, C = x.shape
-    return x.view(B, H // ws, ws, W // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
+    wh, ww = ws
+    return x.view(B, H // wh, wh, W // ww, ww, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, wh * ww, C)
 
 
 def _windows_to_tokens(wins, ws, H, W):
-    B = wins.shape[0] // ((H // ws) * (W // ws))
-    return wins.view(B, H // ws, W // ws, ws, ws, -1).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, -1)
+    wh, ww = ws
+    B = wins.shape[0] // ((H // wh) * (W // ww))
+    return wins.view(B, H // wh, W // ww, wh, ww, -1).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, -1)
+
+
+def _pad_hw(t, pad_h, pad_w, modes, dims_last=False):
+    """Pad the H (bottom) and W (right) axes of [B,H,W,C] (or [B,C,H,W] with dims_last) with per-axis modes."""
+    mode_h, mode_w = modes
+    if not (pad_h or pad_w):
+        return t
+    if mode_h == mode_w:
+        return F.pad(t, (0, pad_w, 0, pad_h) if dims_last else (0, 0, 0, pad_w, 0, pad_h), mode=mode_h)
+    if pad_w:
+        t = F.pad(t, (0, pad_w) if dims_last else (0, 0, 0, pad_w), mode=mode_w)
+    if pad_h:
+        t = F.pad(t, (0, 0, 0, pad_h) if dims_last else (0, 0, 0, 0, 0, pad_h), mode=mode_h)
+    return t
 
 
 class WindowAttention(nn.Module):
@@ -110,10 +126,13 @@ class SwinTransformerBlock(nn.Module):
                  drop=0., attn_drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=LayerNorm,
                  padding_mode: str = "constant"):
         super().__init__()
-        assert 0 <= shift_size < window_size, "shift_size must in 0-window_size"
+        # window / shift are (h, w) pairs; an int means a square window (nsbench).  padding_mode: one mode or a
+        # (mode_h, mode_w) pair (dlwpbench: constant latitude, circular longitude)
+        window_size, shift_size = _pair(window_size), _pair(shift_size)
+        assert all(0 <= s < w for s, w in zip(shift_size, window_size)), "shift_size must in 0-window_size"
         if drop_path > 0.:
             raise NotImplementedError("stochastic depth is not on the MI355X hot path (set drop_path_rate=0)")
-        self.window_size, self.shift_size, self.padding_mode = window_size, shift_size, padding_mode
+        self.window_size, self.shift_size, self.padding_mode = window_size, shift_size, _pair(padding_mode)
         self.norm1 = norm_layer(dim)
         self.attn = WindowAttention(dim, _pair(window_size), num_heads, qkv_bias, qk_scale, attn_drop, drop)
         self.norm2 = norm_layer(dim)
@@ -125,15 +144,16 @@ class SwinTransformerBlock(nn.Module):
         H, W, ws, sh = self.H, self.W, self.window_size, self.shift_size
         assert L_ == H * W, "input feature has wrong size"
         t = self.norm1(x).view(B, H, W, C)
-        t = F.pad(t, (0, 0, 0, (ws - W % ws) % ws, 0, (ws - H % ws) % ws), mode=self.padding_mode)
+        t = _pad_hw(t, (ws[0] - H % ws[0]) % ws[0], (ws[1] - W % ws[1]) % ws[1], self.padding_mode)
         Hp, Wp = t.shape[1], t.shape[2]
-        if sh > 0:
-            t = torch.roll(t, shifts=(-sh, -sh), dims=(1, 2))
-        nW = (Hp // ws) * (Wp // ws)
-        t = self.attn(_tokens_to_windows(t, ws), labels if sh > 0 else None, nW)
+        shifted = sh[0] > 0 or sh[1] > 0
+        if shifted:
+            t = torch.roll(t, shifts=(-sh[0], -sh[1]), dims=(1, 2))
+        nW = (Hp // ws[0]) * (Wp // ws[1])
+        t = self.attn(_tokens_to_windows(t, ws), labels if shifted else None, nW)
         t = _windows_to_tokens(t, ws, Hp, Wp)
-        if sh > 0:
-            t = torch.roll(t, shifts=(sh, sh), dims=(1, 2))
+        if shifted:
+            t = torch.roll(t, shifts=(sh[0], sh[1]), dims=(1, 2))
         x = x + t[:, :H, :W, :].reshape(B, H * W, C)
         return self.mlp(self.norm2(x), residual=x)   # residual add fused into fc2's epilogue
 
@@ -141,7 +161,7 @@ class SwinTransformerBlock(nn.Module):
 class PatchMerging(nn.Module):
     def __init__(self, dim, norm_layer=LayerNorm, padding_mode: str = "constant"):
         super().__init__()
-        self.padding_mode = padding_mode
+        self.padding_mode = _pair(padding_mode)
         self.reduction = Linear(4 * dim, 2 * dim, bias=False)
         self.norm = norm_layer(4 * dim)
 
@@ -149,8 +169,7 @@ class PatchMerging(nn.Module):
         B, L_, C = x.shape
         assert L_ == H * W, "input feature has wrong size"
         x = x.view(B, H, W, C)
-        if H % 2 or W % 2:
-            x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2), mode=self.padding_mode)
+        x = _pad_hw(x, H % 2, W % 2, self.padding_mode)
         x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)
         return self.reduction(self.norm(x.reshape(B, -1, 4 * C)))
 
@@ -160,9 +179,10 @@ class BasicLayer(nn.Module):
                  attn_drop=0., drop_path=0., norm_layer=LayerNorm, downsample=None, use_checkpoint=False,
                  padding_mode: str = "constant"):
         super().__init__()
-        self.window_size, self.shift_size, self.depth = window_size, window_size // 2, depth
+        window_size = tuple(int(v) for v in _pair(window_size))
+        self.window_size, self.shift_size, self.depth = window_size, (window_size[0] // 2, window_size[1] // 2), depth
         self.blocks = nn.ModuleList([
-            SwinTransformerBlock(dim, num_heads, window_size, 0 if i % 2 == 0 else window_size // 2, mlp_ratio,
+            SwinTransformerBlock(dim, num_heads, window_size, (0, 0) if i % 2 == 0 else self.shift_size, mlp_ratio,
                                  qkv_bias, qk_scale, drop, attn_drop,
                                  drop_path[i] if isinstance(drop_path, list) else drop_path,
                                  norm_layer=norm_layer, padding_mode=padding_mode) for i in range(depth)])
@@ -176,20 +196,20 @@ class BasicLayer(nn.Module):
         if key not in self._labels:
             ws, sh = self.window_size, self.shift_size
 
-            def axis_labels(n):
+            def axis_labels(n, w, s):
                 lab = torch.zeros(n, dtype=torch.int32)
-                lab[n - ws:n - sh] = 1
-                if sh > 0:
-                    lab[n - sh:] = 2
+                lab[n - w:n - s] = 1
+                if s > 0:
+                    lab[n - s:] = 2
                 return lab
-            img = axis_labels(Hp)[:, None] * 3 + axis_labels(Wp)[None, :]
-            lab = img.view(Hp // ws, ws, Wp // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws)
+            img = axis_labels(Hp, ws[0], sh[0])[:, None] * 3 + axis_labels(Wp, ws[1], sh[1])[None, :]
+            lab = img.view(Hp // ws[0], ws[0], Wp // ws[1], ws[1]).permute(0, 2, 1, 3).reshape(-1, ws[0] * ws[1])
             self._labels[key] = lab.contiguous().to(device)
         return self._labels[key]
 
     def forward(self, x, H, W):
         ws = self.window_size
-        labels = self.shift_labels(math.ceil(H / ws) * ws, math.ceil(W / ws) * ws, x.device)
+        labels = self.shift_labels(math.ceil(H / ws[0]) * ws[0], math.ceil(W / ws[1]) * ws[1], x.device)
         for blk in self.blocks:
             blk.H, blk.W = H, W
             x = blk(x, labels)
@@ -201,17 +221,14 @@ class BasicLayer(nn.Module):
 class PatchEmbed(nn.Module):
     def __init__(self, patch_size=4, in_chans=3, embed_dim=96, norm_layer=None, padding_mode: str = "constant"):
         super().__init__()
-        self.patch_size, self.embed_dim, self.padding_mode = _pair(patch_size), embed_dim, padding_mode
+        self.patch_size, self.embed_dim, self.padding_mode = _pair(patch_size), embed_dim, _pair(padding_mode)
         self.proj = PatchConv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
         self.norm = norm_layer(embed_dim) if norm_layer is not None else None
 
     def forward(self, x):
         _, _, H, W = x.shape
         ph, pw = self.patch_size
-        if W % pw:
-            x = F.pad(x, (0, pw - W % pw), mode=self.padding_mode)
-        if H % ph:
-            x = F.pad(x, (0, 0, 0, ph - H % ph), mode=self.padding_mode)
+        x = _pad_hw(x, (ph - H % ph) % ph, (pw - W % pw) % pw, self.padding_mode, dims_last=True)
         x = self.proj(x)
         if self.norm is not None:
             Wh, Ww = x.shape[2], x.shape[3]

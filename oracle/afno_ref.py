@@ -102,3 +102,50 @@ def afnonet(x, p, cfg, teacher_forcing_steps):
             out = x_t_in[:, -1] + afnonet_step(x_t_in.flatten(1, 2), p, cfg)
         outs.append(out)
     return torch.stack(outs, dim=1)
+
+
+# ---- dlwpbench twin (src/dlwpbench/models/fourcastnet/fourcastnet.py:215-361) ------------------------------
+def dlwp_prepare_inputs(constants, prescribed, prognostic):
+    """_prepare_inputs :299-311: constants[:,0] | prescribed "b (t c) h w" | prognostic "b (t c) h w"."""
+    parts = [] if constants is None else [constants[:, 0]]
+    if prescribed is not None:
+        parts.append(prescribed.flatten(1, 2))
+    if prognostic is not None:
+        parts.append(prognostic.flatten(1, 2))
+    return torch.cat(parts, dim=1)
+
+
+def dlwp_rollout(one_step, ctx, constants, prescribed, prognostic):
+    """The dlwpbench loop in its working form (UNet.forward unet.py:64-111; the AFNONet copy :313-361 calls
+    `.to()` on a list at the second lead time): out_t = prog_t[:, -1] + net(x_t), t = ctx .. T-1."""
+    outs = []
+    for t in range(ctx, prognostic.shape[1]):
+        if t == ctx:
+            prog_t = prognostic[:, max(0, t - ctx):t]
+        else:
+            prog_t = torch.cat([prognostic[:, max(0, t - ctx):ctx], torch.stack(outs, dim=1)[:, -ctx:]], dim=1)
+        x_t = dlwp_prepare_inputs(constants, prescribed[:, t - ctx:t] if prescribed is not None else None, prog_t)
+        outs.append(prog_t[:, -1] + one_step(x_t))
+    return torch.stack(outs, dim=1)
+
+
+def dlwp_afnonet_step(x_in, p, cfg):
+    """forward_features :287-297 (+pos_embed only if use_pos_embed) + head + un-patchify :344-357."""
+    ph, pw = cfg["patch_size"]
+    B = x_in.shape[0]
+    h, w = cfg["img_height"] // ph, cfg["img_width"] // pw
+    t = F.conv2d(x_in, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], stride=(ph, pw))
+    t = t.flatten(2).transpose(1, 2)
+    if "pos_embed" in p:
+        t = t + p["pos_embed"]
+    t = t.reshape(B, h, w, cfg["embed_dim"])
+    for i in range(cfg["depth"]):
+        t = block(t, p, f"blocks.{i}.", cfg["num_blocks"], cfg.get("sparsity_threshold", 0.01),
+                  cfg.get("hard_thresholding_fraction", 1.0))
+    t = F.linear(t, p["head.weight"])
+    co = cfg["prognostic_channels"]
+    return t.reshape(B, h, w, ph, pw, co).permute(0, 5, 1, 3, 2, 4).reshape(B, co, h * ph, w * pw)
+
+
+def dlwp_afnonet(constants, prescribed, prognostic, p, cfg):
+    return dlwp_rollout(lambda x: dlwp_afnonet_step(x, p, cfg), cfg["context_size"], constants, prescribed, prognostic)

@@ -146,3 +146,96 @@ def swin_rollout(x, p, cfg, teacher_forcing_steps):
         out = x_t[:, -1] if t < ctx - 1 else x_t[:, -1] + swin_one_step(x_t.flatten(1, 2), p, cfg)
         outs.append(out)
     return torch.stack(outs, dim=1)
+
+
+# ---- dlwpbench twin (src/dlwpbench/models/swintransformer/swin_transformer.py) ----------------------------------
+# Same layers with (h, w) window pairs (:52-69, :383-399); every stage's window is its whole feature map
+# (resolution = (H/p, W/p), halved per stage, :542-571), so no window padding is ever applied -- with smaller windows
+# the reference's pads land on the wrong axes (:218-222) and BasicLayer raises.
+def partition2(x, ws):
+    B, H, W, C = x.shape
+    return x.view(B, H // ws[0], ws[0], W // ws[1], ws[1], C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws[0] * ws[1], C)
+
+
+def unpartition2(wins, ws, H, W):
+    B = wins.shape[0] // ((H // ws[0]) * (W // ws[1]))
+    return wins.view(B, H // ws[0], W // ws[1], ws[0], ws[1], -1).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, -1)
+
+
+def shift_labels2(Hp, Wp, ws, shift):
+    img = torch.zeros(1, Hp, Wp, 1)
+    cnt = 0
+    for hs in (slice(0, -ws[0]), slice(-ws[0], -shift[0]), slice(-shift[0], None)):
+        for wsl in (slice(0, -ws[1]), slice(-ws[1], -shift[1]), slice(-shift[1], None)):
+            img[:, hs, wsl, :] = cnt
+            cnt += 1
+    return partition2(img, ws).reshape(-1, ws[0] * ws[1]).to(torch.int32)
+
+
+def dlwp_swin_block(x, p, pre, H, W, ws, shift, heads, labels):
+    B, L, C = x.shape
+    assert H % ws[0] == 0 and W % ws[1] == 0, "dlwpbench windows are whole feature maps"
+    shortcut = x
+    x = F.layer_norm(x, (C,), p[pre + "norm1.weight"], p[pre + "norm1.bias"]).view(B, H, W, C)
+    shifted = shift[0] > 0 or shift[1] > 0
+    if shifted:
+        x = torch.roll(x, shifts=(-shift[0], -shift[1]), dims=(1, 2))
+    wins = window_attention(partition2(x, ws), p, pre + "attn.", ws[0], ws[1], heads, labels if shifted else None)
+    x = unpartition2(wins, ws, H, W)
+    if shifted:
+        x = torch.roll(x, shifts=(shift[0], shift[1]), dims=(1, 2))
+    x = shortcut + x.reshape(B, H * W, C)
+    return x + mlp(F.layer_norm(x, (C,), p[pre + "norm2.weight"], p[pre + "norm2.bias"]), p, pre + "mlp.")
+
+
+def dlwp_basic_layer(x, p, pre, H, W, ws, depth, heads, downsample):
+    shift = (ws[0] // 2, ws[1] // 2)
+    labels = shift_labels2(H, W, ws, shift)
+    for i in range(depth):
+        x = dlwp_swin_block(x, p, f"{pre}blocks.{i}.", H, W, ws, (0, 0) if i % 2 == 0 else shift, heads, labels)
+    if downsample:
+        return x, H, W, patch_merging(x, p, pre + "downsample.", H, W), (H + 1) // 2, (W + 1) // 2
+    return x, H, W, x, H, W
+
+
+def dlwp_swin_one_step(x, p, cfg):
+    """SwinTransformer.one_step (:645-677) with the dlwpbench constructor (:494-608): decoder stage 0 (the last
+    transposed convolution) has kernel = stride = patch_size, the others 2 (:593-594)."""
+    ps, E, depths, heads = cfg["patch_size"], cfg["embed_dim"], cfg["depths"], cfg["num_heads"]
+    x = F.conv2d(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], stride=ps)
+    Wh, Ww = x.shape[2], x.shape[3]
+    x = x.flatten(2).transpose(1, 2)
+    if cfg.get("patch_norm", True):
+        x = F.layer_norm(x, (E,), p["patch_embed.norm.weight"], p["patch_embed.norm.bias"])
+    res = (cfg["img_height"] // ps, cfg["img_width"] // ps)
+    outs = []
+    for i in range(len(depths)):
+        x_out, H, W, x, Wh, Ww = dlwp_basic_layer(x, p, f"layers.{i}.", Wh, Ww, res, depths[i], heads[i], i < len(depths) - 1)
+        C = E * 2 ** i
+        x_out = F.layer_norm(x_out, (C,), p[f"norm{i}.weight"], p[f"norm{i}.bias"])
+        outs.append(x_out.view(-1, H, W, C).permute(0, 3, 1, 2))
+        res = (res[0] // 2, res[1] // 2)
+    outs = outs[::-1]
+    x_out = None
+    for idx in range(len(depths)):
+        x_in = outs[idx] if idx == 0 else torch.cat([outs[idx], x_out], dim=1)
+        stride = ps if idx == len(depths) - 1 else 2
+        x_out = F.gelu(F.conv_transpose2d(x_in, p[f"decoder.{idx}.0.weight"], p[f"decoder.{idx}.0.bias"], stride=stride))
+    return F.conv2d(x_out, p["final.weight"], p["final.bias"])
+
+
+def dlwp_swin(constants, prescribed, prognostic, p, cfg):
+    """The dlwpbench rollout in its working form (UNet.forward unet.py:64-111; the copy at :694-737 raises at the
+    second lead time): out_t = prog_t[:, -1] + one_step(x_t)."""
+    ctx, outs = cfg["context_size"], []
+    for t in range(ctx, prognostic.shape[1]):
+        if t == ctx:
+            prog_t = prognostic[:, max(0, t - ctx):t]
+        else:
+            prog_t = torch.cat([prognostic[:, max(0, t - ctx):ctx], torch.stack(outs, dim=1)[:, -ctx:]], dim=1)
+        parts = [] if constants is None else [constants[:, 0]]
+        if prescribed is not None:
+            parts.append(prescribed[:, t - ctx:t].flatten(1, 2))
+        parts.append(prog_t.flatten(1, 2))
+        outs.append(prog_t[:, -1] + dlwp_swin_one_step(torch.cat(parts, dim=1), p, cfg))
+    return torch.stack(outs, dim=1)

@@ -78,3 +78,30 @@ def test_afnonet_rollout_matches_reference_golden(cuda):
         key = "net_g_" + n
         if key in G.files:
             assert rel(p.grad, t(key)) <= 1e-3, n
+
+
+# ---- dlwpbench twin --------------------------------------------------------------------------------------
+GD = np.load(os.path.join(os.path.dirname(__file__), "golden", "dlwp_afno_golden.npz"))
+DLWP_CFG = {"one": dict(img_height=16, img_width=32, patch_size=(2, 2), constant_channels=2, prescribed_channels=1,
+                        prognostic_channels=3, embed_dim=32, depth=2, mlp_ratio=2.0, num_blocks=4, context_size=1),
+            "multi": dict(img_height=16, img_width=32, patch_size=(4, 4), constant_channels=2, prescribed_channels=1,
+                          prognostic_channels=2, embed_dim=32, depth=2, mlp_ratio=2.0, num_blocks=4, context_size=2,
+                          use_pos_embed=False)}
+
+
+@pytest.mark.parametrize("tag", ["one", "multi"])
+def test_dlwp_afnonet_matches_reference_golden(cuda, tag):
+    from dlwp_benchmark_amd import dlwpbench
+    td = lambda n: torch.from_numpy(GD[f"{tag}_{n}"])   # noqa: E731
+    net = dlwpbench.AFNONet(**DLWP_CFG[tag])
+    sd = {k[len(tag) + 3:]: torch.from_numpy(GD[k]) for k in GD.files if k.startswith(f"{tag}_p_")}
+    net.load_state_dict(sd, strict=True)
+    net = net.to(cuda).train()
+    y = net(constants=td("constants").to(cuda), prescribed=td("prescribed").to(cuda), prognostic=td("prognostic").to(cuda))
+    assert rel(y, td("y")) <= 1e-4
+    loss = torch.nn.functional.mse_loss(y, td("target").to(cuda))
+    assert abs(loss.item() - float(GD[f"{tag}_loss"])) <= 1e-4 * abs(float(GD[f"{tag}_loss"]))
+    loss.backward()
+    for n, p in net.named_parameters():
+        if f"{tag}_g_{n}" in GD.files:
+            assert rel(p.grad, td(f"g_{n}")) <= 1e-3, n

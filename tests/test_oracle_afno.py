@@ -65,3 +65,26 @@ def test_afnonet_rollout_matches_reference():
             assert rel(v.grad, t("net_g_" + n)) < 1e-4, n
         else:
             assert v.grad is None  # AFNONet.norm is never used by the reference forward
+
+
+# ---- dlwpbench twin --------------------------------------------------------------------------------------
+GD = np.load(os.path.join(os.path.dirname(__file__), "golden", "dlwp_afno_golden.npz"))
+DLWP_CFG = {"one": dict(img_height=16, img_width=32, patch_size=(2, 2), prognostic_channels=3, embed_dim=32, depth=2,
+                        num_blocks=4, context_size=1),
+            "multi": dict(img_height=16, img_width=32, patch_size=(4, 4), prognostic_channels=2, embed_dim=32, depth=2,
+                          num_blocks=4, context_size=2)}
+
+
+@pytest.mark.parametrize("tag", ["one", "multi"])
+def test_dlwp_afnonet_matches_reference(tag):
+    """`one`: the reference's own forward(); `multi`: the reference's layers driven by the clean loop."""
+    td = lambda n: torch.from_numpy(GD[f"{tag}_{n}"])   # noqa: E731
+    p = {k[len(tag) + 3:]: torch.from_numpy(GD[k]).clone().requires_grad_(True) for k in GD.files if k.startswith(f"{tag}_p_")}
+    y = afno_ref.dlwp_afnonet(td("constants"), td("prescribed"), td("prognostic"), p, DLWP_CFG[tag])
+    assert rel(y.detach(), td("y")) < 1e-5
+    loss = torch.nn.functional.mse_loss(y, td("target"))
+    assert abs(loss.item() - float(GD[f"{tag}_loss"])) < 1e-5 * abs(float(GD[f"{tag}_loss"]))
+    loss.backward()
+    for n, v in p.items():
+        if f"{tag}_g_{n}" in GD.files:
+            assert rel(v.grad, td(f"g_{n}")) < 1e-4, n

@@ -58,3 +58,24 @@ def test_swin_rollout_matches_reference():
     for n, v in p.items():
         if "net_g_" + n in G.files:
             assert rel(v.grad, t("net_g_" + n)) < 2e-4, n
+
+
+# ---- dlwpbench twin --------------------------------------------------------------------------------------
+GD = np.load(os.path.join(os.path.dirname(__file__), "golden", "dlwp_swin_golden.npz"))
+DLWP_CFG = {"one": dict(context_size=1, img_height=16, img_width=32, patch_size=2, embed_dim=8, depths=[2, 2], num_heads=[2, 2]),
+            "multi": dict(context_size=2, img_height=16, img_width=32, patch_size=1, embed_dim=8, depths=[2, 2], num_heads=[2, 2])}
+
+
+@pytest.mark.parametrize("tag", ["one", "multi"])
+def test_dlwp_swin_matches_reference(tag):
+    """`one`: the reference's own forward(); `multi`: the reference's one_step() driven by the clean loop."""
+    td = lambda n: torch.from_numpy(GD[f"{tag}_{n}"])   # noqa: E731
+    p = {k[len(tag) + 3:]: torch.from_numpy(GD[k]).clone().requires_grad_(True) for k in GD.files if k.startswith(f"{tag}_p_")}
+    y = swin_ref.dlwp_swin(td("constants"), td("prescribed"), td("prognostic"), p, DLWP_CFG[tag])
+    assert rel(y.detach(), td("y")) < 1e-5
+    loss = torch.nn.functional.mse_loss(y, td("target"))
+    assert abs(loss.item() - float(GD[f"{tag}_loss"])) < 1e-5 * abs(float(GD[f"{tag}_loss"]))
+    loss.backward()
+    for n, v in p.items():
+        if f"{tag}_g_{n}" in GD.files:
+            assert rel(v.grad, td(f"g_{n}")) < 2e-4, n

@@ -55,3 +55,4 @@ run(400, 25, 49, 4, 10, 169, True)
 run(36, 9, 49, 4, 20, 169, True)
 run(64, 16, 64, 4, 16, 225, True)
 run(16, 16, 144, 6, 32, 3312, True)     # Pangu-like window (2,6,12)
+run(4, 1, 2048, 4, 24, 8001, True, iters=10)   # dlwpbench Swin default: whole 32x64 map per window
