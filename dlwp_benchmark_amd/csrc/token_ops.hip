@@ -30,6 +30,9 @@ struct GemmDev {
     const float *A, *B, *bias, *residual;
     float *C, *preact, *rowsum;
     int M, N, K, lda, ldb, ldc, act, accumulate, kchunk, splits;
+    // strided-batched mode (nbatch > 1, no split-K): batch z = z1 * nb2 + z2, operand offsets z1 * s?1 + z2 * s?2
+    int nbatch, nb2, res_pre;
+    long long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
 };
 
 // One 64 x 32 operand tile.  KC: k is the contiguous dimension in memory (element (row, k) at
@@ -110,7 +113,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
     __shared__ __attribute__((aligned(16))) float Bs[2][TILE_FLOATS];
     const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
+    int kbeg = blockIdx.z * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
+    if (a.nbatch > 1) {
+        const int z1 = blockIdx.z / a.nb2, z2 = blockIdx.z - z1 * a.nb2;
+        a.A += z1 * a.sA1 + z2 * a.sA2;
+        a.B += z1 * a.sB1 + z2 * a.sB2;
+        const long long oc = z1 * a.sC1 + z2 * a.sC2;
+        a.C += oc;
+        if (a.preact) a.preact += oc;
+        if (a.residual) a.residual += z1 * a.sR1 + z2 * a.sR2;
+        kbeg = 0;
+        kend = a.K;
+    }
     const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
     f32x4 acc[2][2];
 #pragma unroll
@@ -166,9 +180,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
                     float v = acc[i][j][q];
                     if (a.splits > 1) { atomic_add_f32(&a.C[o], v); continue; }   // C zeroed (or accumulate)
                     if (a.bias) v += a.bias[n];
+                    if (a.residual && a.res_pre) v += a.residual[o];
                     if (a.preact) a.preact[o] = v;
                     if (a.act == 1) v = gelu_f(v);
-                    if (a.residual) v += a.residual[o];
+                    if (a.residual && !a.res_pre) v += a.residual[o];
                     a.C[o] = a.accumulate ? a.C[o] + v : v;
                 }
             }
@@ -292,6 +307,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g
 
 }  // namespace
 
+static int gemm_dispatch(GemmDev& a, int transA, int transB, void* stream) {
+    // 16-byte loads need every row start and every k (or row) group of four to be aligned and whole
+    bool vec = ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.B % 16 == 0) && a.lda % 4 == 0 && a.ldb % 4 == 0 && a.K % 4 == 0 &&
+               (transA ? a.M % 4 == 0 : true) && (transB ? true : a.N % 4 == 0);
+    if (a.nbatch > 1) vec = vec && a.sA1 % 4 == 0 && a.sA2 % 4 == 0 && a.sB1 % 4 == 0 && a.sB2 % 4 == 0;
+    const dim3 grid(ceil_div(a.N, BN), ceil_div(a.M, BM), a.nbatch > 1 ? a.nbatch : a.splits);
+    const hipStream_t s = (hipStream_t)stream;
+    // A is k-contiguous when not transposed ([M][K]); B is k-contiguous when transposed ([N][K])
+    if (!transA && transB) gemm_launch<true, true>(a, vec, grid, s);
+    else if (!transA && !transB) gemm_launch<true, false>(a, vec, grid, s);
+    else if (transA && transB) gemm_launch<false, true>(a, vec, grid, s);
+    else gemm_launch<false, false>(a, vec, grid, s);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
 extern "C" int dlwp_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                          int transA, int transB, const float* bias, int act, float* preact, const float* residual,
                          int accumulate, float* rowsum, void* stream) {
@@ -304,19 +335,24 @@ extern "C" int dlwp_gemm(const float* A, const float* B, float* C, int M, int N,
     int kchunk = ceil_div(ceil_div(K, splits), BK) * BK;
     splits = ceil_div(K, kchunk);
     if (splits > 1 && !accumulate) DLWP_HIP(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, (hipStream_t)stream));
-    GemmDev a{A, B, bias, residual, C, preact, rowsum, M, N, K, lda, ldb, ldc, act, accumulate, kchunk, splits};
-    // 16-byte loads need every row start and every k (or row) group of four to be aligned and whole
-    const bool vec = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && lda % 4 == 0 && ldb % 4 == 0 && K % 4 == 0 &&
-                     (transA ? M % 4 == 0 : true) && (transB ? true : N % 4 == 0);
-    const dim3 grid(ceil_div(N, BN), ceil_div(M, BM), splits);
-    const hipStream_t s = (hipStream_t)stream;
-    // A is k-contiguous when not transposed ([M][K]); B is k-contiguous when transposed ([N][K])
-    if (!transA && transB) gemm_launch<true, true>(a, vec, grid, s);
-    else if (!transA && !transB) gemm_launch<true, false>(a, vec, grid, s);
-    else if (transA && transB) gemm_launch<false, true>(a, vec, grid, s);
-    else gemm_launch<false, false>(a, vec, grid, s);
-    DLWP_LAUNCH_CHECK();
-    return DLWP_OK;
+    GemmDev a{A, B, bias, residual, C, preact, rowsum, M, N, K, lda, ldb, ldc, act, accumulate, kchunk, splits,
+              1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    return gemm_dispatch(a, transA, transB, stream);
+}
+
+extern "C" int dlwp_gemm_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                 int transA, int transB, int nb1, int nb2, long long sA1, long long sA2, long long sB1,
+                                 long long sB2, long long sC1, long long sC2, const float* bias, int act, float* preact,
+                                 const float* residual, long long sR1, long long sR2, int res_before_act, int accumulate,
+                                 void* stream) {
+    DLWP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && nb1 > 0 && nb2 > 0, DLWP_E_INVALID,
+                 "gemm_batched: NULL argument or empty shape");
+    DLWP_REQUIRE(act == 0 || act == 1, DLWP_E_INVALID, "gemm_batched: act must be 0 (none) or 1 (gelu)");
+    DLWP_REQUIRE((long long)nb1 * nb2 <= 65535, DLWP_E_UNSUPPORTED, "gemm_batched: more than 65535 batches (%d x %d)", nb1, nb2);
+    const int kchunk = ceil_div(K, BK) * BK;
+    GemmDev a{A, B, bias, residual, C, preact, nullptr, M, N, K, lda, ldb, ldc, act, accumulate, kchunk, 1,
+              nb1 * nb2, nb2, res_before_act, sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2};
+    return gemm_dispatch(a, transA, transB, stream);
 }
 
 extern "C" int dlwp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,

@@ -1,0 +1,133 @@
+"""dlwpbench SFNO2DModule (src/dlwpbench/models/fno/fno.py:150-259) on libdlwpmi.
+
+The reference wraps `torch_harmonics.examples.sfno.SphericalFourierNeuralOperatorNet` (third party, absent here;
+PARITY UNPINNED).  `SphericalFourierNeuralOperatorNet` below restates that network on the kernels
+of ../sht.py: activations are channels-last tokens [B, H, W, C] from the encoder to the decoder, every 1x1 convolution is
+the MFMA GEMM with its bias / GELU / residual epilogue, the spherical transforms and the per-degree complex weights are
+strided-batched GEMMs.  Constructor keys, forward signature and the `sfno.` state_dict root are SFNO2DModule's; the
+rollout is the dlwpbench loop in its working form (rollout.py).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from ..sht import InverseRealSHT, RealSHT, dhconv
+from ..token_ops import Conv1x1
+from .rollout import rollout
+
+
+class _SpectralFilter(nn.Module):
+    """SHT -> per-degree complex weight ("bixy,iox->boxy") -> inverse SHT; also returns the residual on the output
+    grid (the input itself when both grids have the same size)."""
+
+    def __init__(self, forward_transform, inverse_transform, in_channels, out_channels, gain=2.0):
+        super().__init__()
+        self.fwd, self.inv = forward_transform, inverse_transform
+        self.resample = (forward_transform.nlat, forward_transform.nlon) != (inverse_transform.nlat, inverse_transform.nlon)
+        scale = math.sqrt(gain / in_channels)
+        self.weight = nn.Parameter(scale * torch.randn(in_channels, out_channels, inverse_transform.lmax, 2))
+
+    def forward(self, x):
+        X = self.fwd(x)
+        residual = self.inv(X) if self.resample else x
+        return self.inv(dhconv(X, self.weight)), residual
+
+
+class _MLP(nn.Module):
+    def __init__(self, in_features, hidden_features, out_features):
+        super().__init__()
+        self.fc1 = Conv1x1(in_features, hidden_features)
+        self.fc2 = Conv1x1(hidden_features, out_features)
+
+    def forward(self, x, residual=None):
+        return self.fc2(self.fc1(x, act=1), residual=residual)
+
+
+class _Block(nn.Module):
+    def __init__(self, forward_transform, inverse_transform, dim, mlp_ratio=2.0, inner_skip="linear", outer_skip="identity",
+                 use_mlp=True):
+        super().__init__()
+        if inner_skip not in ("linear", "none") or outer_skip not in ("identity", "none"):
+            raise NotImplementedError("inner_skip in {linear, none} and outer_skip in {identity, none} are implemented")
+        self.filter = _SpectralFilter(forward_transform, inverse_transform, dim, dim, gain=1.0 if inner_skip == "linear" else 2.0)
+        self.inner_skip = Conv1x1(dim, dim) if inner_skip == "linear" else None
+        self.mlp = _MLP(dim, int(dim * mlp_ratio), dim) if use_mlp else None
+        self.outer = outer_skip == "identity"
+
+    def forward(self, x):
+        y, residual = self.filter(x)
+        if self.inner_skip is not None:
+            y = self.inner_skip(residual, act=1, residual=y, res_pre=True)      # GELU(y + W residual + b) in one GEMM
+        else:
+            y = torch.nn.functional.gelu(y)
+        if self.mlp is not None:
+            return self.mlp(y, residual=residual if self.outer else None)       # outer skip in fc2's epilogue
+        return y + residual if self.outer else y
+
+
+class SphericalFourierNeuralOperatorNet(nn.Module):
+    def __init__(self, spectral_transform="sht", operator_type="driscoll-healy", img_size=(128, 256), grid="equiangular",
+                 scale_factor=3, in_chans=3, out_chans=3, embed_dim=256, num_layers=4, mlp_ratio=2.0,
+                 hard_thresholding_fraction=1.0, factorization=None, rank=1.0, big_skip=False, pos_embed=False, use_mlp=True,
+                 normalization_layer="none", inner_skip="linear", outer_skip="identity", **kwargs):
+        super().__init__()
+        if spectral_transform != "sht" or operator_type != "driscoll-healy":
+            raise NotImplementedError("only spectral_transform='sht' with operator_type='driscoll-healy' (sfno.yaml)")
+        if factorization not in (None, "none", "None", "dense", "ComplexDense"):
+            raise NotImplementedError("factorised spectral weights are not implemented (sfno.yaml: factorization null)")
+        if normalization_layer not in (None, "none", "None"):
+            raise NotImplementedError("normalization_layer other than 'none' is not implemented (sfno.yaml:19)")
+        self.img_size, self.big_skip = tuple(img_size), bool(big_skip)
+        H, W = self.img_size
+        self.h, self.w = H // scale_factor, W // scale_factor
+        modes = min(int(self.h * hard_thresholding_fraction), int(self.w // 2 * hard_thresholding_fraction))
+        self.encoder = nn.ModuleList([Conv1x1(in_chans, embed_dim), nn.GELU(), Conv1x1(embed_dim, embed_dim, bias=False)])
+        self.pos_embed = nn.Parameter(torch.zeros(1, embed_dim, H, W)) if pos_embed else None
+        down = RealSHT(H, W, modes, modes, grid)
+        up = InverseRealSHT(H, W, modes, modes, grid)
+        trans = RealSHT(self.h, self.w, modes, modes, "legendre-gauss")
+        itrans = InverseRealSHT(self.h, self.w, modes, modes, "legendre-gauss")
+        self.blocks = nn.ModuleList([
+            _Block(down if i == 0 else trans, up if i == num_layers - 1 else itrans, embed_dim, mlp_ratio, inner_skip,
+                   outer_skip, use_mlp) for i in range(num_layers)])
+        self.decoder = nn.ModuleList([Conv1x1(embed_dim + self.big_skip * in_chans, embed_dim), nn.GELU(),
+                                      Conv1x1(embed_dim, out_chans, bias=False)])
+
+    def forward(self, x):
+        """x [B, in_chans, H, W] -> [B, out_chans, H, W]."""
+        B, _, H, W = x.shape
+        tok_in = x.permute(0, 2, 3, 1).contiguous()
+        pos = None
+        if self.pos_embed is not None:
+            pos = self.pos_embed.permute(0, 2, 3, 1).expand(B, H, W, -1)
+        t = self.encoder[2](self.encoder[0](tok_in, act=1), residual=pos)
+        for blk in self.blocks:
+            t = blk(t)
+        if self.big_skip:
+            t = torch.cat([t, tok_in], dim=-1)
+        y = self.decoder[2](self.decoder[0](t, act=1))
+        return y.permute(0, 3, 1, 2)
+
+
+SFNO = SphericalFourierNeuralOperatorNet
+
+
+class SFNO2DModule(nn.Module):
+    def __init__(self, constant_channels: int = 4, prescribed_channels: int = 1, prognostic_channels: int = 8,
+                 spectral_transform="sht", grid="legendre-gauss", num_layers=4, scale_factor=3, embed_dim=256,
+                 operator_type="driscoll-healy", context_size: int = 1, height: int = 32, width: int = 64,
+                 hard_thresholding_fraction: float = 1.0, factorization: str = None, rank: float = 1.0, big_skip: bool = False,
+                 pos_embed: bool = False, use_mlp: bool = False, normalization_layer: str = None, **kwargs):
+        super().__init__()
+        self.context_size = context_size
+        in_channels = constant_channels + (prescribed_channels + prognostic_channels) * context_size
+        self.sfno = SFNO(in_chans=in_channels, out_chans=prognostic_channels, spectral_transform=spectral_transform,
+                         img_size=(height, width), grid=grid, num_layers=num_layers, scale_factor=scale_factor,
+                         embed_dim=embed_dim, operator_type=operator_type,
+                         hard_thresholding_fraction=hard_thresholding_fraction, factorization=factorization, rank=rank,
+                         big_skip=big_skip, pos_embed=pos_embed, use_mlp=use_mlp, normalization_layer=normalization_layer)
+
+    def forward(self, constants: torch.Tensor = None, prescribed: torch.Tensor = None,
+                prognostic: torch.Tensor = None) -> torch.Tensor:
+        return rollout(self.sfno, self.context_size, constants, prescribed, prognostic)

@@ -1,0 +1,211 @@
+"""Real spherical harmonic transforms and the SFNO spectral convolution on libdlwpmi's batched MFMA GEMM.
+
+Reference: `torch_harmonics.RealSHT / InverseRealSHT` and the "driscoll-healy" spectral layer used by
+`torch_harmonics.examples.sfno.SphericalFourierNeuralOperatorNet`, which the reference constructs at
+src/dlwpbench/models/fno/fno.py:183-200 and models/fourcastnet/fourcastnet.py:411-428.  torch-harmonics (git 13aa492,
+README.md:42-52) is NOT in this image, so the algorithm is restated from its published definition (SURVEY.md App. A-2,
+PARITY UNPINNED); correctness of the transforms is established analytically (tests/test_sht.py).
+
+Definitions (colatitude nodes theta_k from the north pole, quadrature weights w_k, P~_l^m orthonormal associated
+Legendre functions with Condon-Shortley phase):
+    RealSHT:         X[l, m] = sum_k w_k P~_l^m(cos theta_k) * (2 pi / nlon) sum_n x[k, n] e^{-2 pi i m n / nlon}
+    InverseRealSHT:  x[k, n] = irfft_n( sum_l P~_l^m(cos theta_k) X[l, m] ),  "forward" norm (no 1/nlon on the inverse)
+
+MI355X mapping.  Tensors are channels-last, x [B, nlat, nlon, C], and the spectrum is degree-major,
+X [lmax, B, mmax, 2 (re|im), C].  Each transform is two strided-batched GEMMs against small constant tables:
+    longitude DFT    T[b, k][(m, re|im)][c] = F[(m, re|im)][n]        . x[b, k][n][c]        batch (b, k)
+    Legendre         X[l][b, m][(re|im, c)] = W[m][l][k]              . T[b][k][m][(re|im, c)] batch (b, m)
+(and the transposes for the inverse and for both backward passes), so the whole SFNO block -- transforms, the
+per-degree complex weights (one batched GEMM over l on the [[Wr, Wi], [-Wi, Wr]] image), the 1x1-convolution skip and
+MLP -- runs on one kernel family.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from .token_ops import _gemm_batched, _grad_slot
+
+
+# ---- tables (float64 on the host, stored as fp32 buffers) -----------------------------------------------------------
+def legendre_gauss_weights(n):
+    """Gauss-Legendre nodes (ascending in cos theta) and weights on [-1, 1]."""
+    x, w = np.polynomial.legendre.leggauss(n)
+    return x, w
+
+
+def clenshaw_curtiss_weights(n):
+    """Clenshaw-Curtis nodes cos(pi j / (n-1)) (ascending, both poles included) and weights on [-1, 1]."""
+    assert n > 1
+    n1 = n - 1
+    theta = np.pi * np.arange(n) / n1
+    x = -np.cos(theta)                                  # ascending from -1 to 1
+    w = np.zeros(n)
+    for k in range(n):
+        s = 0.0
+        for j in range(1, n1 // 2 + 1):
+            b = 1.0 if 2 * j == n1 else 2.0
+            s += b / (4.0 * j * j - 1.0) * np.cos(2.0 * j * theta[k])
+        c = 1.0 if k in (0, n1) else 2.0
+        w[k] = c / n1 * (1.0 - s)
+    return x, w
+
+
+def legpoly(mmax, lmax, x):
+    """Orthonormal associated Legendre functions P~_l^m(x) as [mmax, lmax, len(x)] (zero for l < m), with the
+    Condon-Shortley phase: the three-term recurrence in l seeded on the diagonal."""
+    nmax = max(mmax, lmax)
+    vdm = np.zeros((nmax, nmax, len(x)), dtype=np.float64)
+    vdm[0, 0, :] = 1.0 / np.sqrt(4.0 * np.pi)
+    for l in range(1, nmax):
+        vdm[l - 1, l, :] = np.sqrt(2 * l + 1) * x * vdm[l - 1, l - 1, :]
+        vdm[l, l, :] = np.sqrt((2 * l + 1) * (1 + x) * (1 - x) / 2 / l) * vdm[l - 1, l - 1, :]
+    for l in range(2, nmax):
+        for m in range(0, l - 1):
+            vdm[m, l, :] = (x * np.sqrt((2 * l - 1) / (l - m) * (2 * l + 1) / (l + m)) * vdm[m, l - 1, :]
+                            - np.sqrt((l + m - 1) / (l - m) * (2 * l + 1) / (2 * l - 3) * (l - m - 1) / (l + m)) * vdm[m, l - 2, :])
+    vdm = vdm[:mmax, :lmax].copy()
+    vdm[1::2] *= -1.0
+    return vdm
+
+
+def sht_tables(nlat, nlon, lmax, mmax, grid):
+    """(F [2 mmax, nlon], Wf [mmax, lmax, nlat], Pinv [mmax, lmax, nlat], G [nlon, 2 mmax]) in float64."""
+    if grid == "legendre-gauss":
+        cost, w = legendre_gauss_weights(nlat)
+    elif grid == "equiangular":
+        cost, w = clenshaw_curtiss_weights(nlat)
+    else:
+        raise NotImplementedError(f"grid {grid!r}: only 'legendre-gauss' and 'equiangular' are on the MI355X hot path")
+    theta = np.flip(np.arccos(cost))                    # colatitude, north pole first
+    pct = legpoly(mmax, lmax, np.cos(theta))
+    Wf = pct * w[None, None, :]
+    n = np.arange(nlon)
+    m = np.arange(mmax)
+    ang = 2.0 * np.pi * np.outer(m, n) / nlon           # [mmax, nlon]
+    F = np.empty((2 * mmax, nlon))
+    F[0::2] = 2.0 * np.pi / nlon * np.cos(ang)
+    F[1::2] = -2.0 * np.pi / nlon * np.sin(ang)
+    c = np.where((m == 0) | (2 * m == nlon), 1.0, 2.0)  # irfft doubles the interior orders
+    G = np.empty((nlon, 2 * mmax))
+    G[:, 0::2] = (c[:, None] * np.cos(ang)).T
+    G[:, 1::2] = (-c[:, None] * np.sin(ang)).T
+    return F, Wf, pct, G
+
+
+# ---- y = table . x as a strided-batched GEMM, backward = transposed table -------------------------------------------
+class _TableGemm(torch.autograd.Function):
+    """y[z] = op(A[z]) . x[z] for every batch z = (z1, z2); A is a constant table.  `spec` holds the GEMM shape
+    (M, N, K), A's leading dimension / transpose flag / batch strides, the row strides and batch strides of x and y,
+    and the output tensor shape."""
+
+    @staticmethod
+    def forward(ctx, x, table, spec):
+        x = x.contiguous()
+        y = torch.empty(spec["out_shape"], device=x.device)
+        _gemm_batched(table, x, y, spec["M"], spec["N"], spec["K"], spec["lda"], spec["ldx"], spec["ldy"], spec["tA"], 0,
+                      spec["nb1"], spec["nb2"], spec["sA"], spec["sX"], spec["sY"])
+        ctx.spec, ctx.table, ctx.in_shape = spec, table, x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        s = ctx.spec
+        gx = torch.empty(ctx.in_shape, device=gy.device)
+        _gemm_batched(ctx.table, gy.contiguous(), gx, s["K"], s["N"], s["M"], s["lda"], s["ldy"], s["ldx"], 1 - s["tA"], 0,
+                      s["nb1"], s["nb2"], s["sA"], s["sY"], s["sX"])
+        return gx, None, None
+
+
+class RealSHT(nn.Module):
+    """x [B, nlat, nlon, C] -> X [lmax, B, mmax, 2, C] (re, im planes)."""
+
+    def __init__(self, nlat, nlon, lmax=None, mmax=None, grid="legendre-gauss"):
+        super().__init__()
+        self.nlat, self.nlon, self.grid = nlat, nlon, grid
+        self.lmax = lmax or nlat
+        self.mmax = mmax or nlon // 2 + 1
+        F, Wf, _, _ = sht_tables(nlat, nlon, self.lmax, self.mmax, grid)
+        self.register_buffer("dft", torch.from_numpy(F).float().contiguous(), persistent=False)
+        self.register_buffer("weights", torch.from_numpy(Wf).float().contiguous(), persistent=False)
+
+    def forward(self, x):
+        B, K, N, C = x.shape
+        assert K == self.nlat and N == self.nlon, "input grid does not match the transform"
+        M, Lm = self.mmax, self.lmax
+        lon = dict(M=2 * M, N=C, K=N, lda=N, tA=0, ldx=C, ldy=C, nb1=B * K, nb2=1, sA=(0, 0), sX=(N * C, 0),
+                   sY=(2 * M * C, 0), out_shape=(B, K, M, 2, C))
+        t = _TableGemm.apply(x, self.dft, lon)
+        leg = dict(M=Lm, N=2 * C, K=K, lda=K, tA=0, ldx=2 * M * C, ldy=B * M * 2 * C, nb1=B, nb2=M, sA=(0, Lm * K),
+                   sX=(K * 2 * M * C, 2 * C), sY=(M * 2 * C, 2 * C), out_shape=(Lm, B, M, 2, C))
+        return _TableGemm.apply(t, self.weights, leg)
+
+
+class InverseRealSHT(nn.Module):
+    """X [lmax, B, mmax, 2, C] -> x [B, nlat, nlon, C]."""
+
+    def __init__(self, nlat, nlon, lmax=None, mmax=None, grid="legendre-gauss"):
+        super().__init__()
+        self.nlat, self.nlon, self.grid = nlat, nlon, grid
+        self.lmax = lmax or nlat
+        self.mmax = mmax or nlon // 2 + 1
+        _, _, P, G = sht_tables(nlat, nlon, self.lmax, self.mmax, grid)
+        self.register_buffer("pct", torch.from_numpy(P).float().contiguous(), persistent=False)
+        self.register_buffer("idft", torch.from_numpy(G).float().contiguous(), persistent=False)
+
+    def forward(self, X):
+        Lm, B, M, _, C = X.shape
+        assert Lm == self.lmax and M == self.mmax, "spectrum does not match the transform"
+        K, N = self.nlat, self.nlon
+        leg = dict(M=K, N=2 * C, K=Lm, lda=K, tA=1, ldx=B * M * 2 * C, ldy=2 * M * C, nb1=B, nb2=M, sA=(0, Lm * K),
+                   sX=(M * 2 * C, 2 * C), sY=(K * 2 * M * C, 2 * C), out_shape=(B, K, M, 2, C))
+        t = _TableGemm.apply(X, self.pct, leg)
+        lon = dict(M=N, N=C, K=2 * M, lda=2 * M, tA=0, ldx=C, ldy=C, nb1=B * K, nb2=1, sA=(0, 0), sX=(2 * M * C, 0),
+                   sY=(N * C, 0), out_shape=(B, K, N, C))
+        return _TableGemm.apply(t, self.idft, lon)
+
+
+# ---- per-degree complex weights ---------------------------------------------------------------------------------
+class _DHConvFn(torch.autograd.Function):
+    """Y[l, r, (re|im, o)] = sum_i X[l, r, (re|im, i)] * W[i, o, l] (complex), r = (b, m) rows."""
+
+    @staticmethod
+    def forward(ctx, X, w):
+        lib = L.load()
+        Lm, B, M, _, Cin = X.shape
+        Cout = w.shape[1]
+        assert w.shape == (Cin, Cout, Lm, 2), f"weight {tuple(w.shape)} does not match spectrum {tuple(X.shape)}"
+        X = X.contiguous()
+        wexp = torch.empty(Lm, 2 * Cin, 2 * Cout, device=X.device)
+        L.check(lib.dlwp_cweight_expand(L.ptr(w.contiguous()), L.ptr(wexp), Cin, Cout, Lm, L.stream()))
+        R = B * M
+        Y = torch.empty(Lm, B, M, 2, Cout, device=X.device)
+        _gemm_batched(X, wexp, Y, R, 2 * Cout, 2 * Cin, 2 * Cin, 2 * Cout, 2 * Cout, 0, 0, Lm, 1, (R * 2 * Cin, 0),
+                      (4 * Cin * Cout, 0), (R * 2 * Cout, 0))
+        ctx.save_for_backward(X, wexp)
+        ctx.wslot, ctx.wshape = _grad_slot(w), w.shape
+        return Y
+
+    @staticmethod
+    def backward(ctx, gY):
+        lib = L.load()
+        X, wexp = ctx.saved_tensors
+        Lm, B, M, _, Cin = X.shape
+        Cout = ctx.wshape[1]
+        R = B * M
+        gY = gY.contiguous()
+        gX = torch.empty_like(X)
+        # gX[l] = gY[l] . wexp[l]^T
+        _gemm_batched(gY, wexp, gX, R, 2 * Cin, 2 * Cout, 2 * Cout, 2 * Cout, 2 * Cin, 0, 1, Lm, 1, (R * 2 * Cout, 0),
+                      (4 * Cin * Cout, 0), (R * 2 * Cin, 0))
+        # gexp[l] = X[l]^T . gY[l], folded into the complex parameter's gradient
+        gexp = torch.empty_like(wexp)
+        _gemm_batched(X, gY, gexp, 2 * Cin, 2 * Cout, R, 2 * Cin, 2 * Cout, 2 * Cout, 1, 0, Lm, 1, (R * 2 * Cin, 0),
+                      (R * 2 * Cout, 0), (4 * Cin * Cout, 0))
+        gw = ctx.wslot if ctx.wslot is not None else torch.zeros(ctx.wshape, device=X.device)
+        L.check(lib.dlwp_cweight_fold(L.ptr(gexp), L.ptr(gw), Cin, Cout, Lm, L.stream()))
+        return gX, (None if ctx.wslot is not None else gw)
+
+
+def dhconv(X, w):
+    return _DHConvFn.apply(X, w)

@@ -24,22 +24,34 @@ def _grad_slot(p):
     return None
 
 
+def _gemm_batched(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, act=0,
+                  preact=None, residual=None, sR=(0, 0), res_pre=0, accumulate=0):
+    L.check(L.load().dlwp_gemm_batched(L.ptr(A), L.ptr(B), L.ptr(C), M, N, K, lda, ldb, ldc, tA, tB, nb1, nb2, sA[0], sA[1],
+                                       sB[0], sB[1], sC[0], sC[1], L.ptr(bias), act, L.ptr(preact), L.ptr(residual), sR[0],
+                                       sR[1], res_pre, accumulate, L.stream()))
+
+
 class _LinearFn(torch.autograd.Function):
-    """y = act(x W^T + b) (+ residual); act = 0 none / 1 GELU."""
+    """y = act(x W^T + b) + residual, or with res_pre y = act(x W^T + b + residual); act = 0 none / 1 GELU.
+    weight is [N, K] or a 1x1 convolution weight [N, K, 1, 1] (same memory)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act, residual):
+    def forward(ctx, x, weight, bias, act, residual, res_pre=False):
         shape = x.shape
         x2 = x.reshape(-1, shape[-1]).contiguous().float()
         T, K = x2.shape
         N = weight.shape[0]
-        w = weight.contiguous()
+        w = weight.contiguous().reshape(N, -1)
         y = torch.empty(T, N, device=x.device)
         z = torch.empty(T, N, device=x.device) if act else None
         r2 = residual.reshape(-1, N).contiguous() if residual is not None else None
-        _gemm(x2, w, y, T, N, K, K, K, N, 0, 1, bias, act, z, r2)
+        if res_pre:
+            _gemm_batched(x2, w, y, T, N, K, K, K, N, 0, 1, bias=bias, act=act, preact=z, residual=r2, res_pre=1)
+        else:
+            _gemm(x2, w, y, T, N, K, K, K, N, 0, 1, bias, act, z, r2)
         ctx.save_for_backward(x2, w, z)
         ctx.has_bias, ctx.has_res, ctx.act, ctx.shape = bias is not None, residual is not None, act, shape
+        ctx.res_pre, ctx.wshape = bool(res_pre) and act, weight.shape
         ctx.wslot = _grad_slot(weight)
         ctx.bslot = _grad_slot(bias) if bias is not None else None
         return y.reshape(*shape[:-1], N)
@@ -56,6 +68,8 @@ class _LinearFn(torch.autograd.Function):
             gz = torch.empty_like(g2)
             L.check(lib.dlwp_gelu_bwd(L.ptr(z), L.ptr(g2), L.ptr(gz), g2.numel(), L.stream()))
             g2 = gz
+            if ctx.res_pre and ctx.has_res:      # the residual sits inside the activation
+                gres = gz.reshape(gy.shape)
         gx = torch.empty(T, K, device=g2.device)
         _gemm(g2, w, gx, T, K, N, N, K, K, 0, 0)                 # gx = g W
         # gW = g^T x, with the bias gradient (column sums of g) produced by the same kernel; both go straight
@@ -68,13 +82,25 @@ class _LinearFn(torch.autograd.Function):
         else:
             gw = torch.empty(N, K, device=g2.device)
             _gemm(g2, x2, gw, N, K, T, N, K, K, 1, 0, rowsum=gb)
+            gw = gw.reshape(ctx.wshape)
         if ctx.bslot is not None:
             gb = None
-        return gx.reshape(ctx.shape), gw, gb, None, gres
+        return gx.reshape(ctx.shape), gw, gb, None, gres, None
 
 
-def linear(x, weight, bias=None, act=0, residual=None):
-    return _LinearFn.apply(x, weight, bias, act, residual)
+def linear(x, weight, bias=None, act=0, residual=None, res_pre=False):
+    return _LinearFn.apply(x, weight, bias, act, residual, res_pre)
+
+
+class Conv1x1(nn.Conv2d):
+    """nn.Conv2d(kernel_size=1) parameters (weight [out, in, 1, 1]) applied to channels-last tokens [..., in]:
+    one MFMA GEMM with the bias / GELU / residual epilogue."""
+
+    def __init__(self, in_channels, out_channels, bias=True):
+        super().__init__(in_channels, out_channels, kernel_size=1, bias=bias)
+
+    def forward(self, tokens, act=0, residual=None, res_pre=False):
+        return _LinearFn.apply(tokens, self.weight, self.bias, act, residual, res_pre)
 
 
 class _LayerNormFn(torch.autograd.Function):
@@ -112,7 +138,7 @@ class _LayerNormFn(torch.autograd.Function):
 
 class Linear(nn.Linear):
     def forward(self, x, act=0, residual=None):
-        return _LinearFn.apply(x, self.weight, self.bias, act, residual)
+        return _LinearFn.apply(x, self.weight, self.bias, act, residual, False)
 
 
 class LayerNorm(nn.LayerNorm):
@@ -148,7 +174,7 @@ class PatchConv2d(nn.Conv2d):
         B, C_, H, W = x.shape
         h, w = H // ph, W // pw
         cols = x.reshape(B, C_, h, ph, w, pw).permute(0, 2, 4, 1, 3, 5).reshape(B * h * w, C_ * ph * pw)
-        y = _LinearFn.apply(cols, self.weight.reshape(self.out_channels, -1), self.bias, act, None)
+        y = _LinearFn.apply(cols, self.weight.reshape(self.out_channels, -1), self.bias, act, None, False)
         return y.reshape(B, h, w, self.out_channels).permute(0, 3, 1, 2)
 
 
@@ -165,5 +191,5 @@ class UpConvT2d(nn.ConvTranspose2d):
         tokens = x.permute(0, 2, 3, 1).reshape(B * H * W, C_)
         wmat = self.weight.reshape(C_, O * kh * kw).t()                 # [O*kh*kw, Cin] as a Linear weight
         bias = self.bias.repeat_interleave(kh * kw) if self.bias is not None else None
-        y = _LinearFn.apply(tokens, wmat, bias, act, None)
+        y = _LinearFn.apply(tokens, wmat, bias, act, None, False)
         return y.reshape(B, H, W, O, kh, kw).permute(0, 3, 1, 4, 2, 5).reshape(B, O, H * kh, W * kw)

@@ -248,6 +248,25 @@ int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, const int* i
 int dlwp_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
               int ldc, int transA, int transB, const float* bias, int act, float* preact,
               const float* residual, int accumulate, float* rowsum, void* stream);
+/* Strided-batched form: batch z = z1*nb2 + z2 (z1 < nb1, z2 < nb2) works on A + z1*sA1 +      */
+/* z2*sA2, B + z1*sB1 + z2*sB2, C (and residual) likewise; strides in floats, 0 = shared.     */
+/* res_before_act != 0 adds the residual before the activation: C = act(A.B + bias + res);    */
+/* preact (optional, C's layout and strides) receives the value the activation is applied to.  */
+/* Used for the spherical transforms (per-order Legendre matrices) and the per-degree SFNO     */
+/* spectral weights, where one launch covers every (sample, order) or degree.                  */
+int dlwp_gemm_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda,
+                      int ldb, int ldc, int transA, int transB, int nb1, int nb2, long long sA1,
+                      long long sA2, long long sB1, long long sB2, long long sC1, long long sC2,
+                      const float* bias, int act, float* preact, const float* residual,
+                      long long sR1, long long sR2, int res_before_act, int accumulate,
+                      void* stream);
+/* SFNO "driscoll-healy" spectral weights (torch_harmonics, constructed at                    */
+/* src/dlwpbench/models/fno/fno.py:183-200): w [Cin][Cout][L][2] complex, one matrix per       */
+/* degree l.  expand: wexp[l] = [[Wr, Wi], [-Wi, Wr]] as a real [2Cin][2Cout] matrix, so that   */
+/* the complex contraction "bixy,iox->boxy" is one dlwp_gemm_batched over l on rows            */
+/* [Xr | Xi]; fold: gw += the complex gradient read back from the [L][2Cin][2Cout] GEMM result. */
+int dlwp_cweight_expand(const float* w, float* wexp, int Cin, int Cout, int L, void* stream);
+int dlwp_cweight_fold(const float* gexp, float* gw, int Cin, int Cout, int L, void* stream);
 /* LayerNorm over the last dimension of x [T,C]; mean/rstd [T] are saved for backward.       */
 int dlwp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                        float* mean, float* rstd, int T, int C, float eps, void* stream);

@@ -1,0 +1,120 @@
+"""GPU parity of the spherical path (batched-GEMM SHT, per-degree complex weights, SFNO network and rollout) against
+the CPU oracle oracle/sfno_ref.py (torch rfft + einsum restatement of torch-harmonics; PARITY UNPINNED, see its
+header).  Tolerance: 1e-4 relative (max-norm) forward, 1e-3 gradients (fp32)."""
+import pytest
+import torch
+
+from oracle import sfno_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def spec_to_complex(X):
+    """[L, B, M, 2, C] -> complex [B, C, L, M]"""
+    return torch.complex(X[..., 0, :], X[..., 1, :]).permute(1, 3, 0, 2)
+
+
+@pytest.mark.parametrize("nlat,nlon,lmax,grid,B,C", [(32, 64, 32, "equiangular", 2, 8), (32, 64, 32, "legendre-gauss", 1, 12),
+                                                      (16, 32, 11, "legendre-gauss", 3, 5), (19, 40, 19, "equiangular", 2, 7)])
+def test_sht_and_inverse_match_oracle(cuda, nlat, nlon, lmax, grid, B, C):
+    from dlwp_benchmark_amd import sht
+    o = sfno_ref.SHT(nlat, nlon, lmax, lmax, grid)
+    fwd = sht.RealSHT(nlat, nlon, lmax, lmax, grid).to(cuda)
+    inv = sht.InverseRealSHT(nlat, nlon, lmax, lmax, grid).to(cuda)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, nlat, nlon, generator=g)
+    xr = x.clone().requires_grad_(True)
+    Xr = o.forward(xr)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(cuda).requires_grad_(True)
+    X = fwd(xd)
+    assert X.shape == (lmax, B, lmax, 2, C)
+    assert rel(torch.view_as_real(spec_to_complex(X).contiguous()), torch.view_as_real(Xr.detach())) <= 1e-4
+    # inverse and the gradients of the composition
+    yr = o.inverse(Xr)
+    y = inv(X)
+    assert rel(y.permute(0, 3, 1, 2), yr) <= 1e-4
+    gy = torch.randn(B, C, nlat, nlon, generator=g)
+    yr.backward(gy)
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().to(cuda))
+    assert rel(xd.grad.permute(0, 3, 1, 2), xr.grad) <= 1e-3
+
+
+def test_dhconv_matches_einsum(cuda):
+    from dlwp_benchmark_amd import sht
+    g = torch.Generator().manual_seed(6)
+    Lm, B, M, Cin, Cout = 12, 3, 12, 20, 28
+    X = torch.randn(Lm, B, M, 2, Cin, generator=g)
+    w = torch.randn(Cin, Cout, Lm, 2, generator=g) * 0.2
+    gY = torch.randn(Lm, B, M, 2, Cout, generator=g)
+    Xr, wr = X.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    Yr = torch.einsum("bixy,iox->boxy", spec_to_complex(Xr), torch.view_as_complex(wr))
+    Yr.backward(spec_to_complex(gY))
+    Xd, wd = X.to(cuda).requires_grad_(True), w.to(cuda).requires_grad_(True)
+    Y = sht.dhconv(Xd, wd)
+    Y.backward(gY.to(cuda))
+    assert rel(torch.view_as_real(spec_to_complex(Y).contiguous()), torch.view_as_real(Yr.detach())) <= 1e-4
+    assert rel(Xd.grad, Xr.grad) <= 1e-3
+    assert rel(wd.grad, wr.grad) <= 1e-3
+
+
+CFG = dict(constant_channels=2, prescribed_channels=1, prognostic_channels=3, grid="equiangular", num_layers=3, scale_factor=1,
+           embed_dim=16, context_size=1, height=16, width=32, big_skip=True, pos_embed=True, use_mlp=True,
+           normalization_layer="none")
+
+
+@pytest.mark.parametrize("over", [dict(), dict(context_size=2, scale_factor=2, big_skip=False, pos_embed=False)])
+def test_sfno2d_rollout_matches_oracle(cuda, over):
+    from dlwp_benchmark_amd import dlwpbench
+    cfg = dict(CFG, **over)
+    torch.manual_seed(9)
+    net = dlwpbench.SFNO2DModule(**cfg)
+    with torch.no_grad():
+        if net.sfno.pos_embed is not None:
+            net.sfno.pos_embed.normal_(0, 0.5)
+    g = torch.Generator().manual_seed(10)
+    T, ctx, H, W = cfg["context_size"] + 3, cfg["context_size"], cfg["height"], cfg["width"]
+    constants = torch.randn(2, 1, 2, H, W, generator=g)
+    prescribed = torch.randn(2, T, 1, H, W, generator=g)
+    prognostic = torch.randn(2, T, 3, H, W, generator=g)
+    target = torch.randn(2, T - ctx, 3, H, W, generator=g)
+    p = {k[len("sfno."):]: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    yr = sfno_ref.sfno2d_rollout(constants, prescribed, prognostic, p, cfg)
+    torch.nn.functional.mse_loss(yr, target).backward()
+    net = net.to(cuda).train()
+    y = net(constants=constants.to(cuda), prescribed=prescribed.to(cuda), prognostic=prognostic.to(cuda))
+    assert rel(y, yr) <= 1e-4
+    torch.nn.functional.mse_loss(y, target.to(cuda)).backward()
+    for n, q in net.named_parameters():
+        assert rel(q.grad, p[n[len("sfno."):]].grad) <= 2e-3, n
+
+
+def test_sfno_graphed_train_step(cuda):
+    """Flat parameters + fused gradient accumulation + hipGraph replay follow the eager torch.optim.Adam trajectory."""
+    from dlwp_benchmark_amd import dlwpbench
+    from dlwp_benchmark_amd.train_engine import GraphedTrainStep, mse_loss
+    g = torch.Generator().manual_seed(12)
+    kw = dict(constants=torch.randn(2, 1, 2, 16, 32, generator=g).to(cuda), prescribed=torch.randn(2, 4, 1, 16, 32, generator=g).to(cuda),
+              prognostic=torch.randn(2, 4, 3, 16, 32, generator=g).to(cuda))
+    target = torch.randn(2, 3, 3, 16, 32, generator=g).to(cuda)
+
+    def make():
+        torch.manual_seed(13)
+        return dlwpbench.SFNO2DModule(**CFG).to(cuda).train()
+    ref = make()
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    ref_losses = []
+    for _ in range(4):
+        opt.zero_grad(set_to_none=True)
+        loss = mse_loss(ref(**kw), target)
+        loss.backward()
+        opt.step()
+        ref_losses.append(loss.item())
+    step = GraphedTrainStep(make(), kw, target, lr=1e-3, use_graph=True)
+    losses = [step().item() for _ in range(4)]
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) <= 5e-4 * abs(b), (losses, ref_losses)

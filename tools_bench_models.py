@@ -4,7 +4,7 @@ rollout models built on libdlwpmi's kernels, at the reference's nsbench / dlwpbe
 forward rollout + MSE + backward (autograd over the HIP ops) + one fused Adam launch on the flat parameter
 buffer, captured into a hipGraph by train_engine.GraphedTrainStep (--no-graph: eager dispatch).
 
-    python tools_bench_models.py [afno|swin|pangu|all] [--steps N]
+    python tools_bench_models.py [afno|swin|sfno|pangu|all] [--steps N]
 """
 import argparse
 import json
@@ -62,6 +62,19 @@ def main():
             return {"x": u[:, :-1].contiguous()}, u[:, 1:].contiguous(), 4
         run("nsbench SwinTransformer 64x64 p2 E40 depths[4,4] ctx10 T20", m, batch, a.steps, use_graph=not a.no_graph,
             call=lambda mod, kw: mod(kw["x"], 10))
+    if a.which in ("sfno", "all"):
+        # BASELINE configs[2] (C3): dlwpbench SFNO2DModule, configs/model/sfno.yaml with 5 prognostic variables, 32x64
+        for B in ((4, 16) if a.which == "sfno" else (16,)):
+            m = dlwpbench.SFNO2DModule(constant_channels=4, prescribed_channels=1, prognostic_channels=5, grid="equiangular",
+                                       num_layers=4, scale_factor=1, embed_dim=256, context_size=1, height=32, width=64,
+                                       big_skip=True, pos_embed=True, use_mlp=True, normalization_layer="none")
+
+            def batch(dev, B=B):
+                kw = dict(constants=torch.randn(B, 1, 4, 32, 64, generator=g).to(dev),
+                          prescribed=torch.randn(B, 5, 1, 32, 64, generator=g).to(dev),
+                          prognostic=torch.randn(B, 5, 5, 32, 64, generator=g).to(dev))
+                return kw, torch.randn(B, 4, 5, 32, 64, generator=g).to(dev), B
+            run(f"dlwpbench SFNO2DModule 32x64 E256 L4 (C3) B{B} T5", m, batch, a.steps, use_graph=not a.no_graph)
     if a.which in ("pangu", "all"):
         # dlwpbench configs/model/panguweather.yaml at 32x64 with 5 prognostic variables (BASELINE configs[2] shapes)
         m = dlwpbench.PanguWeather(constant_channels=4, prescribed_channels=1, prognostic_channels=5, embed_dim=192,
