@@ -79,3 +79,63 @@ class AFNONet(nn.Module):
 
 
 FourCastNet = AFNONet
+
+
+class SFNONet(nn.Module):
+    """FourCastNetv2 = SFNONet (src/dlwpbench/models/fourcastnet/fourcastnet.py:364-527, models/__init__.py:7): patch
+    embedding -> (+ pos_embed) -> SFNO (embed_dim -> embed_dim, see sfno.py; third-party network, PARITY UNPINNED) ->
+    head -> un-patchify, in the dlwpbench rollout.  The reference builds the inner SFNO for img_size = (img_height,
+    img_width) but feeds it the patch grid (:411-415, :455-457), so only patch_size (1, 1) is shape-consistent there;
+    here the SFNO is built for the patch grid, which coincides with the reference whenever the reference runs."""
+
+    def __init__(self, img_height=720, img_width=1440, patch_size=(16, 16), constant_channels: int = 4,
+                 prescribed_channels: int = 0, prognostic_channels: int = 1, spectral_transform="sht", grid="legendre-gauss",
+                 num_layers=4, scale_factor=3, embed_dim=768, operator_type="driscoll-healy", drop_rate=0., num_blocks=16,
+                 hard_thresholding_fraction=1.0, factorization: str = None, rank: float = 1.0, big_skip: bool = False,
+                 use_pos_embed: bool = True, use_mlp: bool = False, normalization_layer: str = None, context_size: int = 1,
+                 **kwargs):
+        super().__init__()
+        from .sfno import SFNO
+        if drop_rate:
+            raise NotImplementedError("dropout is not on the MI355X hot path (configs use 0.0)")
+        self.img_size, self.patch_size = (img_height, img_width), tuple(patch_size)
+        self.in_chans = constant_channels + (prescribed_channels + prognostic_channels) * context_size
+        self.out_chans = prognostic_channels
+        self.num_features = self.embed_dim = embed_dim
+        self.context_size, self.use_pos_embed = context_size, use_pos_embed
+        self.patch_embed = PatchEmbed(self.img_size, self.patch_size, self.in_chans, embed_dim)
+        if use_pos_embed:
+            self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches, embed_dim))
+        self.h, self.w = self.img_size[0] // self.patch_size[0], self.img_size[1] // self.patch_size[1]
+        self.sfno = SFNO(in_chans=embed_dim, out_chans=embed_dim, spectral_transform=spectral_transform,
+                         img_size=(self.h, self.w), grid=grid, num_layers=num_layers, scale_factor=scale_factor,
+                         embed_dim=embed_dim, operator_type=operator_type,
+                         hard_thresholding_fraction=hard_thresholding_fraction, factorization=factorization, rank=rank,
+                         big_skip=big_skip, pos_embed=use_pos_embed, use_mlp=use_mlp, normalization_layer=normalization_layer)
+        self.norm = LayerNorm(embed_dim, eps=1e-6)   # constructed but unused, as in the reference (:430, :449-458)
+        self.head = Linear(embed_dim, self.out_chans * self.patch_size[0] * self.patch_size[1], bias=False)
+        if use_pos_embed:
+            nn.init.trunc_normal_(self.pos_embed, std=.02)
+        nn.init.trunc_normal_(self.head.weight, std=.02)
+
+    def forward_features(self, x):
+        B = x.shape[0]
+        x = self.patch_embed(x)
+        if self.use_pos_embed:
+            x = x + self.pos_embed
+        x = x.reshape(B, self.h, self.w, self.embed_dim).permute(0, 3, 1, 2)
+        return self.sfno(x).permute(0, 2, 3, 1)
+
+    def forward_one_step(self, x):
+        B = x.shape[0]
+        ph, pw = self.patch_size
+        t = self.head(self.forward_features(x))
+        t = t.reshape(B, self.h, self.w, ph, pw, self.out_chans).permute(0, 5, 1, 3, 2, 4)
+        return t.reshape(B, self.out_chans, self.h * ph, self.w * pw)
+
+    def forward(self, constants: torch.Tensor = None, prescribed: torch.Tensor = None,
+                prognostic: torch.Tensor = None) -> torch.Tensor:
+        return rollout(self.forward_one_step, self.context_size, constants, prescribed, prognostic)
+
+
+FourCastNetv2 = SFNONet
