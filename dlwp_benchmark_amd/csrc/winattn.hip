@@ -104,7 +104,7 @@ __device__ __forceinline__ void load_table(float* tb, const float* __restrict__ 
 }
 
 // Bias-gradient partials are accumulated in LDS as 64-bit fixed point (2^-40 resolution, |sum| < 2^23):
-// gfx950's LDS float atomic add runs at ~0.3 lane-ops/clk/CU, the 64-bit integer add at 5-7 (tools_micro/
+// gfx950's LDS float atomic add runs at ~0.3 lane-ops/clk/CU, the 64-bit integer add at 5-7 (tools/micro/
 // lds_atomics.hip, profiles/README.md), and integer addition makes the partial independent of the order in
 // which the waves arrive.  The rounding step (4.5e-13 absolute per term) is below fp32 accumulation error for
 // any gradient that matters.

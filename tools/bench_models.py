@@ -4,7 +4,7 @@ rollout models built on libdlwpmi's kernels, at the reference's nsbench / dlwpbe
 forward rollout + MSE + backward (autograd over the HIP ops) + one fused Adam launch on the flat parameter
 buffer, captured into a hipGraph by train_engine.GraphedTrainStep (--no-graph: eager dispatch).
 
-    python tools_bench_models.py [afno|swin|sfno|pangu|all] [--steps N]
+    python tools/bench_models.py [afno|swin|sfno|pangu|all] [--steps N]
 """
 import argparse
 import json
@@ -13,7 +13,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 from dlwp_benchmark_amd import dlwpbench, nsbench  # noqa: E402
 from dlwp_benchmark_amd.train_engine import GraphedTrainStep  # noqa: E402
 

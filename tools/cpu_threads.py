@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 import torch
 from oracle import fno_ref
 import bench

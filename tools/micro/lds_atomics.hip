@@ -1,5 +1,5 @@
 // Microbenchmark: LDS atomic-add throughput on gfx950 (float vs u32 vs u64), random and strided addresses.
-// Build: hipcc -O3 --offload-arch=gfx950 -munsafe-fp-atomics tools_micro/lds_atomics.hip -o tools_micro/lds_atomics
+// Build: hipcc -O3 --offload-arch=gfx950 -munsafe-fp-atomics tools/micro/lds_atomics.hip -o tools/micro/lds_atomics
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,7 +1,7 @@
 import ctypes as C, sys
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 import torch
-lib = C.CDLL('dlwp_benchmark_amd/libdlwpmi_stamps.so')
+lib = C.CDLL(__import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..', 'dlwp_benchmark_amd', 'libdlwpmi_stamps.so'))
 V=C.c_void_p; I=C.c_int
 lib.dlwp_pwmlp_fwd.argtypes=[V]*6+[I]*5+[V]; lib.dlwp_pwmlp_fwd.restype=I
 lib.dlwp_debug_stamps_pwmlp.argtypes=[V]; lib.dlwp_debug_stamps_pwmlp.restype=I

@@ -1,7 +1,7 @@
 import ctypes as C, sys
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 import torch
-lib = C.CDLL('dlwp_benchmark_amd/libdlwpmi_stamps.so')
+lib = C.CDLL(__import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..', 'dlwp_benchmark_amd', 'libdlwpmi_stamps.so'))
 V=C.c_void_p; I=C.c_int
 lib.dlwp_fno_plan_create.argtypes=[I]*5+[C.POINTER(V)]
 lib.dlwp_fno_block_workspace_bytes.argtypes=[V,I]; lib.dlwp_fno_block_workspace_bytes.restype=C.c_size_t

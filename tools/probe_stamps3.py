@@ -1,7 +1,7 @@
 import ctypes as C, sys
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 import torch
-lib = C.CDLL('dlwp_benchmark_amd/libdlwpmi_stamps.so')
+lib = C.CDLL(__import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..', 'dlwp_benchmark_amd', 'libdlwpmi_stamps.so'))
 V=C.c_void_p; I=C.c_int
 lib.dlwp_pwmlp_slab_floats.argtypes=[I]*5; lib.dlwp_pwmlp_slab_floats.restype=C.c_longlong
 lib.dlwp_pwmlp_bwd_slab.argtypes=[V]*7+[I]*6+[V]

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Phase stamps of winattn_bwd_q_kernel (needs `make stamps`)."""
 import ctypes as C, sys
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 import torch
-lib = C.CDLL('dlwp_benchmark_amd/libdlwpmi_stamps.so')
+lib = C.CDLL(__import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..', 'dlwp_benchmark_amd', 'libdlwpmi_stamps.so'))
 V, I, F = C.c_void_p, C.c_int, C.c_float
 lib.dlwp_window_attn_fwd.argtypes = [V] * 7 + [I] * 7 + [F, V]
 lib.dlwp_window_attn_bwd.argtypes = [V] * 12 + [I] * 7 + [F, V]

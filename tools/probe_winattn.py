@@ -2,7 +2,7 @@
 """Time the window-attention kernels alone at Swin / Pangu shapes (diagnostic)."""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 from dlwp_benchmark_amd import lib as L
 
 lib = L.load()
