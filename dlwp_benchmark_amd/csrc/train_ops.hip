@@ -85,6 +85,42 @@ __global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__
     block_atomic_sum(acc * inv_n, out);
 }
 
+// Evaluation metrics (nsbench/scripts/evaluate.py:232-257, dlwpbench/scripts/evaluate.py:494-546): error moments per
+// group g of a [B][G][H][W] pair, optionally weighted per row h (latitude weights) and relative to a climatology c:
+//   m[0][g] = sum w (o-t)^2   m[1][g] = sum w |o-t|   m[2][g] = sum w (o-c)(t-c)   m[3][g] = sum w (o-c)^2   m[4][g] = sum w (t-c)^2
+__global__ __launch_bounds__(256) void error_moments_kernel(const float* __restrict__ o, const float* __restrict__ t,
+                                                            const float* __restrict__ c, const float* __restrict__ roww, int B,
+                                                            int G, int H, int W, float* m) {
+    const int g = blockIdx.x;
+    const long long hw = (long long)H * W, per = (long long)B * hw;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+    for (long long e = (long long)blockIdx.y * 256 + threadIdx.x; e < per; e += (long long)gridDim.y * 256) {
+        const long long b = e / hw, r = e - b * hw;
+        const long long idx = (b * G + g) * hw + r;
+        const float w = roww ? roww[r / W] : 1.f;
+        const float ov = o[idx], tv = t[idx], d = ov - tv;
+        a0 += w * d * d;
+        a1 += w * fabsf(d);
+        if (c) {
+            const float oc = ov - c[idx], tc = tv - c[idx];
+            a2 += w * oc * tc;
+            a3 += w * oc * oc;
+            a4 += w * tc * tc;
+        }
+    }
+    block_atomic_sum(a0, m + g);
+    __syncthreads();                       // block_atomic_sum reuses one LDS scratch
+    block_atomic_sum(a1, m + G + g);
+    if (c) {
+        __syncthreads();
+        block_atomic_sum(a2, m + 2 * G + g);
+        __syncthreads();
+        block_atomic_sum(a3, m + 3 * G + g);
+        __syncthreads();
+        block_atomic_sum(a4, m + 4 * G + g);
+    }
+}
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, float* out) {
     float acc = 0.f;
     const long long n4 = n / 4;
@@ -157,6 +193,18 @@ extern "C" int dlwp_mse_fwd_bwd(const float* pred, const float* target, long lon
     DLWP_REQUIRE(pred && target && loss_out && grad && n > 0, DLWP_E_INVALID, "mse_fwd_bwd: NULL argument or n <= 0");
     hipLaunchKernelGGL(mse_grad_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, pred, target, n,
                        1.0f / (float)n, loss_out, grad);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_error_moments(const float* out, const float* target, const float* climatology, const float* row_weights,
+                                  int B, int G, int H, int W, float* moments, void* stream) {
+    DLWP_REQUIRE(out && target && moments && B > 0 && G > 0 && H > 0 && W > 0, DLWP_E_INVALID, "error_moments: bad argument");
+    DLWP_REQUIRE(G <= 65535, DLWP_E_UNSUPPORTED, "error_moments: more than 65535 groups");
+    const long long per = (long long)B * H * W;
+    const int ny = (int)std::max<long long>(1, std::min<long long>(64, per / 4096));
+    hipLaunchKernelGGL(error_moments_kernel, dim3(G, ny), dim3(256), 0, (hipStream_t)stream, out, target, climatology,
+                       row_weights, B, G, H, W, moments);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }

@@ -44,6 +44,7 @@ SIGNATURES = {
     "dlwp_fno_block_bwd": (_I, [_V, _V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _I, _V, _V]),
     "dlwp_sqerr_sum": (_I, [_V, _V, _L, _F, _V, _V]),
     "dlwp_mse_fwd_bwd": (_I, [_V, _V, _L, _V, _V, _V]),
+    "dlwp_error_moments": (_I, [_V, _V, _V, _V, _I, _I, _I, _I, _V, _V]),
     "dlwp_adam_step": (_I, [_V, _V, _V, _V, _V, _L, _F, _F, _F, _F, _F, _I, _V]),
     "dlwp_sumsq": (_I, [_V, _L, _V, _V]),
     "dlwp_clip_scale": (_I, [_V, _L, _V, _F, _F, _V]),

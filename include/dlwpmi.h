@@ -113,6 +113,14 @@ int dlwp_sqerr_sum(const float* a, const float* b, long long n, float scale, flo
 /* loss_out (device, 1 float) += mean((pred-target)^2); grad = 2 (pred-target) / n        */
 int dlwp_mse_fwd_bwd(const float* pred, const float* target, long long n, float* loss_out,
                      float* grad, void* stream);
+/* Evaluation metrics (nsbench/scripts/evaluate.py:232-257: RMSE / accumulated error per time */
+/* step; dlwpbench/scripts/evaluate.py:494-546: latitude-weighted RMSE and ACC per (time,      */
+/* variable)).  out/target/climatology are [B][G][H][W]; row_weights [H] or NULL (= 1);         */
+/* climatology may be NULL.  moments [5][G] (device) is ACCUMULATED into:                       */
+/*   sum w (o-t)^2 | sum w |o-t| | sum w (o-c)(t-c) | sum w (o-c)^2 | sum w (t-c)^2             */
+int dlwp_error_moments(const float* out, const float* target, const float* climatology,
+                       const float* row_weights, int B, int G, int H, int W, float* moments,
+                       void* stream);
 /* torch.optim.Adam (no weight decay / amsgrad) on a flat buffer; `step` is a device      */
 /* int32 counter incremented by the kernel; grads are multiplied by grad_scale first      */
 /* (1/world_size after a sum all-reduce) and zeroed afterwards when zero_grad != 0.       */
