@@ -376,3 +376,49 @@ extern "C" int dlwp_afno2d_bwd(const float* gy, const float* xsave, const float*
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// General-grid AFNO2D ("tiled" path, python: afno_tiled.py): when the block spectrum does not fit LDS (e.g. the
+// FourCastNet-scale 90x180 token grid with 768 channels, or 720x1440 at patch 1) the transforms run as strided-batched
+// MFMA GEMMs against DFT tables and the per-mode block-diagonal complex MLP as batched GEMMs over the channel blocks.
+// For that, the complex block weights w [2][nb][bs][bs] (re, im planes, AFNO2D.w1 / .w2 fourcastnet.py:70-75) are
+// expanded to the four real matrices of  [Or | Oi] = [Xr | Xi] . [[Wr, Wi], [-Wi, Wr]]:
+//     wq[ri][ro][blk][i][o],  ri = input plane, ro = output plane
+namespace {
+
+__global__ __launch_bounds__(256) void afno_wq_expand_kernel(const float* __restrict__ w, float* __restrict__ wq, long long n) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const float wr = w[e], wi = w[n + e];
+        wq[e] = wr;              // [0][0]
+        wq[n + e] = wi;          // [0][1]
+        wq[2 * n + e] = -wi;     // [1][0]
+        wq[3 * n + e] = wr;      // [1][1]
+    }
+}
+
+__global__ __launch_bounds__(256) void afno_wq_fold_kernel(const float* __restrict__ gq, float* __restrict__ gw, long long n) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        gw[e] += gq[e] + gq[3 * n + e];
+        gw[n + e] += gq[n + e] - gq[2 * n + e];
+    }
+}
+
+}  // namespace
+
+extern "C" int dlwp_afno_wq_expand(const float* w, float* wq, int nb, int bs_in, int bs_out, void* stream) {
+    DLWP_REQUIRE(w && wq && nb > 0 && bs_in > 0 && bs_out > 0, DLWP_E_INVALID, "afno_wq_expand: bad argument");
+    const long long n = (long long)nb * bs_in * bs_out;
+    hipLaunchKernelGGL(afno_wq_expand_kernel, dim3((int)std::min<long long>((n + 255) / 256, 2048)), dim3(256), 0,
+                       (hipStream_t)stream, w, wq, n);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_afno_wq_fold(const float* gq, float* gw, int nb, int bs_in, int bs_out, void* stream) {
+    DLWP_REQUIRE(gq && gw && nb > 0 && bs_in > 0 && bs_out > 0, DLWP_E_INVALID, "afno_wq_fold: bad argument");
+    const long long n = (long long)nb * bs_in * bs_out;
+    hipLaunchKernelGGL(afno_wq_fold_kernel, dim3((int)std::min<long long>((n + 255) / 256, 2048)), dim3(256), 0,
+                       (hipStream_t)stream, gq, gw, n);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}

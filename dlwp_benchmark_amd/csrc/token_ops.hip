@@ -32,8 +32,17 @@ struct GemmDev {
     int M, N, K, lda, ldb, ldc, act, accumulate, kchunk, splits;
     // strided-batched mode (nbatch > 1, no split-K): batch z = z1 * nb2 + z2, operand offsets z1 * s?1 + z2 * s?2
     int nbatch, nb2, res_pre;
-    long long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
+    long long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2, sBi1, sBi2;
+    float act_param;           // soft-shrink threshold (act == 3)
 };
+
+// epilogue activations: 0 none, 1 GELU (erf), 2 ReLU, 3 soft-shrink(lambda)
+__device__ __forceinline__ float apply_act(float v, int act, float lam) {
+    if (act == 1) return gelu_f(v);
+    if (act == 2) return fmaxf(v, 0.f);
+    if (act == 3) return v > lam ? v - lam : (v < -lam ? v + lam : 0.f);
+    return v;
+}
 
 // One 64 x 32 operand tile.  KC: k is the contiguous dimension in memory (element (row, k) at
 // base[row * ld + k]); otherwise the row index is contiguous (base[k * ld + row]).
@@ -113,18 +122,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
     __shared__ __attribute__((aligned(16))) float Bs[2][TILE_FLOATS];
     const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    int kbeg = blockIdx.z * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
+    int zs = blockIdx.z;
     if (a.nbatch > 1) {
-        const int z1 = blockIdx.z / a.nb2, z2 = blockIdx.z - z1 * a.nb2;
+        const int zb = zs / a.splits;                 // batch index; zs % splits = K split within the batch
+        zs -= zb * a.splits;
+        const int z1 = zb / a.nb2, z2 = zb - z1 * a.nb2;
         a.A += z1 * a.sA1 + z2 * a.sA2;
         a.B += z1 * a.sB1 + z2 * a.sB2;
         const long long oc = z1 * a.sC1 + z2 * a.sC2;
         a.C += oc;
         if (a.preact) a.preact += oc;
         if (a.residual) a.residual += z1 * a.sR1 + z2 * a.sR2;
-        kbeg = 0;
-        kend = a.K;
+        if (a.bias) a.bias += z1 * a.sBi1 + z2 * a.sBi2;
     }
+    const int kbeg = zs * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
     const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
     f32x4 acc[2][2];
 #pragma unroll
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
                     if (a.bias) v += a.bias[n];
                     if (a.residual && a.res_pre) v += a.residual[o];
                     if (a.preact) a.preact[o] = v;
-                    if (a.act == 1) v = gelu_f(v);
+                    v = apply_act(v, a.act, a.act_param);
                     if (a.residual && !a.res_pre) v += a.residual[o];
                     a.C[o] = a.accumulate ? a.C[o] + v : v;
                 }
@@ -283,6 +294,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
+// gz = gy * act'(z): act 1 GELU, 2 ReLU, 3 soft-shrink(lam)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ z, const float* __restrict__ gy,
+                                                      float* __restrict__ gz, long long n, int act, float lam) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float v = z[i];
+        float d = 1.f;
+        if (act == 1) d = gelu_grad_f(v);
+        else if (act == 2) d = v > 0.f ? 1.f : 0.f;
+        else if (act == 3) d = (v > lam || v < -lam) ? 1.f : 0.f;
+        gz[i] = gy[i] * d;
+    }
+}
+
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ z, const float* __restrict__ gy,
                                                        float* __restrict__ gz, long long n) {
     const long long stride = (long long)gridDim.x * 256;
@@ -312,7 +337,7 @@ static int gemm_dispatch(GemmDev& a, int transA, int transB, void* stream) {
     bool vec = ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.B % 16 == 0) && a.lda % 4 == 0 && a.ldb % 4 == 0 && a.K % 4 == 0 &&
                (transA ? a.M % 4 == 0 : true) && (transB ? true : a.N % 4 == 0);
     if (a.nbatch > 1) vec = vec && a.sA1 % 4 == 0 && a.sA2 % 4 == 0 && a.sB1 % 4 == 0 && a.sB2 % 4 == 0;
-    const dim3 grid(ceil_div(a.N, BN), ceil_div(a.M, BM), a.nbatch > 1 ? a.nbatch : a.splits);
+    const dim3 grid(ceil_div(a.N, BN), ceil_div(a.M, BM), a.nbatch * a.splits);
     const hipStream_t s = (hipStream_t)stream;
     // A is k-contiguous when not transposed ([M][K]); B is k-contiguous when transposed ([N][K])
     if (!transA && transB) gemm_launch<true, true>(a, vec, grid, s);
@@ -336,22 +361,36 @@ extern "C" int dlwp_gemm(const float* A, const float* B, float* C, int M, int N,
     splits = ceil_div(K, kchunk);
     if (splits > 1 && !accumulate) DLWP_HIP(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, (hipStream_t)stream));
     GemmDev a{A, B, bias, residual, C, preact, rowsum, M, N, K, lda, ldb, ldc, act, accumulate, kchunk, splits,
-              1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+              1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.f};
     return gemm_dispatch(a, transA, transB, stream);
 }
 
 extern "C" int dlwp_gemm_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                                  int transA, int transB, int nb1, int nb2, long long sA1, long long sA2, long long sB1,
-                                 long long sB2, long long sC1, long long sC2, const float* bias, int act, float* preact,
-                                 const float* residual, long long sR1, long long sR2, int res_before_act, int accumulate,
-                                 void* stream) {
+                                 long long sB2, long long sC1, long long sC2, const float* bias, long long sBi1,
+                                 long long sBi2, int act, float act_param, float* preact, const float* residual,
+                                 long long sR1, long long sR2, int res_before_act, int accumulate, void* stream) {
     DLWP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && nb1 > 0 && nb2 > 0, DLWP_E_INVALID,
                  "gemm_batched: NULL argument or empty shape");
-    DLWP_REQUIRE(act == 0 || act == 1, DLWP_E_INVALID, "gemm_batched: act must be 0 (none) or 1 (gelu)");
-    DLWP_REQUIRE((long long)nb1 * nb2 <= 65535, DLWP_E_UNSUPPORTED, "gemm_batched: more than 65535 batches (%d x %d)", nb1, nb2);
-    const int kchunk = ceil_div(K, BK) * BK;
-    GemmDev a{A, B, bias, residual, C, preact, nullptr, M, N, K, lda, ldb, ldc, act, accumulate, kchunk, 1,
-              nb1 * nb2, nb2, res_before_act, sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2};
+    DLWP_REQUIRE(act >= 0 && act <= 3, DLWP_E_INVALID, "gemm_batched: act must be 0 (none), 1 (gelu), 2 (relu) or 3 (softshrink)");
+    // reductions over a long K with few output tiles (weight gradients of block-diagonal layers): split K inside every
+    // batch and combine with float atomics, like the plain entry
+    const bool epilogue = bias || act || preact || residual;
+    const long long tiles = (long long)ceil_div(N, BN) * ceil_div(M, BM) * nb1 * nb2;
+    int splits = 1;
+    if (!epilogue && tiles < 256 && K >= 8 * BK) splits = (int)std::min<long long>(ceil_div(512, (int)tiles), K / (4 * BK));
+    int kchunk = ceil_div(ceil_div(K, splits), BK) * BK;
+    splits = ceil_div(K, kchunk);
+    DLWP_REQUIRE((long long)nb1 * nb2 * splits <= 65535, DLWP_E_UNSUPPORTED, "gemm_batched: more than 65535 batches (%d x %d)", nb1, nb2);
+    if (splits > 1 && !accumulate) {
+        // C must start from zero: every batch's [M x N] block (row pitch ldc)
+        for (int z1 = 0; z1 < nb1; ++z1)
+            for (int z2 = 0; z2 < nb2; ++z2)
+                DLWP_HIP(hipMemset2DAsync(C + z1 * sC1 + z2 * sC2, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M,
+                                          (hipStream_t)stream));
+    }
+    GemmDev a{A, B, bias, residual, C, preact, nullptr, M, N, K, lda, ldb, ldc, act, accumulate, kchunk, splits,
+              nb1 * nb2, nb2, res_before_act, sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2, sBi1, sBi2, act_param};
     return gemm_dispatch(a, transA, transB, stream);
 }
 
@@ -395,6 +434,16 @@ extern "C" int dlwp_gelu_bwd(const float* z, const float* gy, float* gz, long lo
     long long blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, z, gy, gz, n);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_act_bwd(const float* z, const float* gy, float* gz, long long n, int act, float act_param, void* stream) {
+    DLWP_REQUIRE(z && gy && gz && n >= 0 && act >= 1 && act <= 3, DLWP_E_INVALID, "act_bwd: bad argument");
+    if (n == 0) return DLWP_OK;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, z, gy, gz, n, act, act_param);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }

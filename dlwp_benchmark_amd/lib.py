@@ -60,8 +60,11 @@ SIGNATURES = {
     "dlwp_afno2d_save_elems": (_L, [_I, _I, _I, _I, _I, _F]),
     "dlwp_afno2d_fwd": (_I, [_V] * 7 + [_I] * 5 + [_F, _F, _V]),
     "dlwp_afno2d_bwd": (_I, [_V] * 11 + [_I] * 5 + [_F, _F, _V]),
+    "dlwp_afno_wq_expand": (_I, [_V, _V, _I, _I, _I, _V]),
+    "dlwp_afno_wq_fold": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_gemm": (_I, [_V, _V, _V] + [_I] * 8 + [_V, _I, _V, _V, _I, _V, _V]),
-    "dlwp_gemm_batched": (_I, [_V, _V, _V] + [_I] * 10 + [_L] * 6 + [_V, _I, _V, _V, _L, _L, _I, _I, _V]),
+    "dlwp_gemm_batched": (_I, [_V, _V, _V] + [_I] * 10 + [_L] * 6 + [_V, _L, _L, _I, _F, _V, _V, _L, _L, _I, _I, _V]),
+    "dlwp_act_bwd": (_I, [_V, _V, _V, _L, _I, _F, _V]),
     "dlwp_cweight_expand": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_cweight_fold": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_layernorm_fwd": (_I, [_V] * 6 + [_I, _I, _F, _V]),

@@ -64,6 +64,7 @@ class AFNO2D(nn.Module):
         assert hidden_size % num_blocks == 0, f"hidden_size {hidden_size} should be divisble by num_blocks {num_blocks}"
         if hidden_size_factor != 1:
             raise NotImplementedError("hidden_size_factor != 1 is not on the MI355X hot path")
+        self.path = "auto"      # "fused" (LDS-resident kernel), "tiled" (batched GEMMs, any grid) or "auto"
         self.hidden_size, self.num_blocks = hidden_size, num_blocks
         self.block_size = hidden_size // num_blocks
         self.sparsity_threshold = sparsity_threshold
@@ -77,8 +78,18 @@ class AFNO2D(nn.Module):
 
     def forward(self, x):
         dtype = x.dtype
-        y = _AFNO2DFn.apply(x, self.w1, self.b1, self.w2, self.b2, self.num_blocks, float(self.sparsity_threshold),
-                            float(self.hard_thresholding_fraction))
+        B, H, W, C = x.shape
+        path = self.path
+        if path == "auto":      # the fused kernel keeps a block's half spectrum in LDS: small grids, block size <= 16
+            fits = L.load().dlwp_afno2d_save_elems(B, H, W, C, self.num_blocks, float(self.hard_thresholding_fraction)) >= 0
+            path = "fused" if fits else "tiled"
+        if path == "tiled":
+            from ..afno_tiled import afno2d_tiled
+            y = afno2d_tiled(x, self.w1, self.b1, self.w2, self.b2, self.num_blocks, float(self.sparsity_threshold),
+                             float(self.hard_thresholding_fraction))
+        else:
+            y = _AFNO2DFn.apply(x, self.w1, self.b1, self.w2, self.b2, self.num_blocks, float(self.sparsity_threshold),
+                                float(self.hard_thresholding_fraction))
         return y.type(dtype)
 
 

@@ -95,26 +95,40 @@ def sht_tables(nlat, nlon, lmax, mmax, grid):
 
 # ---- y = table . x as a strided-batched GEMM, backward = transposed table -------------------------------------------
 class _TableGemm(torch.autograd.Function):
-    """y[z] = op(A[z]) . x[z] for every batch z = (z1, z2); A is a constant table.  `spec` holds the GEMM shape
-    (M, N, K), A's leading dimension / transpose flag / batch strides, the row strides and batch strides of x and y,
-    and the output tensor shape."""
+    """y[z] = sum_p op(A_p[z]) . x_p[z] (+ residual) for every batch z = (z1, z2); A is a constant table.  `spec` holds
+    the GEMM shape (M, N, K), A's leading dimension / transpose flag / batch strides, the row strides and batch strides
+    of x and y, the output tensor shape and optionally `passes`: element offsets (oA, oX) of the K-slices that are
+    accumulated (a contraction index spread over two planes of x).  The backward pass applies the transposed slices."""
 
     @staticmethod
-    def forward(ctx, x, table, spec):
+    def forward(ctx, x, table, spec, residual=None):
         x = x.contiguous()
         y = torch.empty(spec["out_shape"], device=x.device)
-        _gemm_batched(table, x, y, spec["M"], spec["N"], spec["K"], spec["lda"], spec["ldx"], spec["ldy"], spec["tA"], 0,
-                      spec["nb1"], spec["nb2"], spec["sA"], spec["sX"], spec["sY"])
-        ctx.spec, ctx.table, ctx.in_shape = spec, table, x.shape
+        passes = spec.get("passes", ((0, 0),))
+        for i, (oA, oX) in enumerate(passes):
+            last = i == len(passes) - 1
+            _gemm_batched(table, x, y, spec["M"], spec["N"], spec["K"], spec["lda"], spec["ldx"], spec["ldy"], spec["tA"], 0,
+                          spec["nb1"], spec["nb2"], spec["sA"], spec["sX"], spec["sY"], accumulate=int(i > 0), oA=oA, oB=oX,
+                          residual=residual.contiguous() if (residual is not None and last) else None, sR=spec["sY"])
+        ctx.spec, ctx.table, ctx.in_shape, ctx.has_res = spec, table, x.shape, residual is not None
         return y
 
     @staticmethod
     def backward(ctx, gy):
         s = ctx.spec
+        gy = gy.contiguous()
         gx = torch.empty(ctx.in_shape, device=gy.device)
-        _gemm_batched(ctx.table, gy.contiguous(), gx, s["K"], s["N"], s["M"], s["lda"], s["ldy"], s["ldx"], 1 - s["tA"], 0,
-                      s["nb1"], s["nb2"], s["sA"], s["sY"], s["sX"])
-        return gx, None, None
+        shared = s["nb2"] > 1 and s["sX"][1] == 0      # x[z1] feeds every z2: its gradient is a sum over z2
+        for oA, oX in s.get("passes", ((0, 0),)):
+            if not shared:
+                _gemm_batched(ctx.table, gy, gx, s["K"], s["N"], s["M"], s["lda"], s["ldy"], s["ldx"], 1 - s["tA"], 0,
+                              s["nb1"], s["nb2"], s["sA"], s["sY"], s["sX"], oA=oA, oC=oX)
+                continue
+            for z2 in range(s["nb2"]):
+                _gemm_batched(ctx.table, gy, gx, s["K"], s["N"], s["M"], s["lda"], s["ldy"], s["ldx"], 1 - s["tA"], 0,
+                              s["nb1"], 1, (s["sA"][0], 0), (s["sY"][0], 0), (s["sX"][0], 0), accumulate=int(z2 > 0),
+                              oA=oA + z2 * s["sA"][1], oB=z2 * s["sY"][1], oC=oX)
+        return gx, None, None, (gy if ctx.has_res else None)
 
 
 class RealSHT(nn.Module):
@@ -135,10 +149,10 @@ class RealSHT(nn.Module):
         M, Lm = self.mmax, self.lmax
         lon = dict(M=2 * M, N=C, K=N, lda=N, tA=0, ldx=C, ldy=C, nb1=B * K, nb2=1, sA=(0, 0), sX=(N * C, 0),
                    sY=(2 * M * C, 0), out_shape=(B, K, M, 2, C))
-        t = _TableGemm.apply(x, self.dft, lon)
+        t = _TableGemm.apply(x, self.dft, lon, None)
         leg = dict(M=Lm, N=2 * C, K=K, lda=K, tA=0, ldx=2 * M * C, ldy=B * M * 2 * C, nb1=B, nb2=M, sA=(0, Lm * K),
                    sX=(K * 2 * M * C, 2 * C), sY=(M * 2 * C, 2 * C), out_shape=(Lm, B, M, 2, C))
-        return _TableGemm.apply(t, self.weights, leg)
+        return _TableGemm.apply(t, self.weights, leg, None)
 
 
 class InverseRealSHT(nn.Module):
@@ -159,10 +173,10 @@ class InverseRealSHT(nn.Module):
         K, N = self.nlat, self.nlon
         leg = dict(M=K, N=2 * C, K=Lm, lda=K, tA=1, ldx=B * M * 2 * C, ldy=2 * M * C, nb1=B, nb2=M, sA=(0, Lm * K),
                    sX=(M * 2 * C, 2 * C), sY=(K * 2 * M * C, 2 * C), out_shape=(B, K, M, 2, C))
-        t = _TableGemm.apply(X, self.pct, leg)
+        t = _TableGemm.apply(X, self.pct, leg, None)
         lon = dict(M=N, N=C, K=2 * M, lda=2 * M, tA=0, ldx=C, ldy=C, nb1=B * K, nb2=1, sA=(0, 0), sX=(2 * M * C, 0),
                    sY=(N * C, 0), out_shape=(B, K, N, C))
-        return _TableGemm.apply(t, self.idft, lon)
+        return _TableGemm.apply(t, self.idft, lon, None)
 
 
 # ---- per-degree complex weights ---------------------------------------------------------------------------------

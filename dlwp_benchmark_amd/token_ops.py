@@ -24,11 +24,19 @@ def _grad_slot(p):
     return None
 
 
+def _dptr(t, offset=0):
+    """Device pointer of `t` advanced by `offset` floats (views into bigger buffers are passed as base + offset)."""
+    return None if t is None else L.ptr(t) + 4 * offset
+
+
 def _gemm_batched(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, act=0,
-                  preact=None, residual=None, sR=(0, 0), res_pre=0, accumulate=0):
-    L.check(L.load().dlwp_gemm_batched(L.ptr(A), L.ptr(B), L.ptr(C), M, N, K, lda, ldb, ldc, tA, tB, nb1, nb2, sA[0], sA[1],
-                                       sB[0], sB[1], sC[0], sC[1], L.ptr(bias), act, L.ptr(preact), L.ptr(residual), sR[0],
-                                       sR[1], res_pre, accumulate, L.stream()))
+                  preact=None, residual=None, sR=(0, 0), res_pre=0, accumulate=0, sBi=(0, 0), act_param=0.0, oA=0, oB=0, oC=0,
+                  oR=0, oBi=0):
+    """dlwp_gemm_batched; o* are element offsets into the (contiguous) buffers (preact shares C's offset)."""
+    L.check(L.load().dlwp_gemm_batched(_dptr(A, oA), _dptr(B, oB), _dptr(C, oC), M, N, K, lda, ldb, ldc, tA, tB, nb1, nb2,
+                                       sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], _dptr(bias, oBi), sBi[0], sBi[1], act,
+                                       act_param, _dptr(preact, oC), _dptr(residual, oR), sR[0], sR[1], res_pre, accumulate,
+                                       L.stream()))
 
 
 class _LinearFn(torch.autograd.Function):

@@ -243,6 +243,14 @@ int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, const int* i
                          float* gqkv, float* gbias_table, float* dsum, float* slab, int B_, int nW,
                          int N, int TB, int ntypes, int heads, int d, float scale, void* stream);
 
+/* General-grid AFNO2D (grids whose block spectrum does not fit LDS): the transforms run as     */
+/* dlwp_gemm_batched against DFT tables and the per-mode block MLP as batched GEMMs over the     */
+/* channel blocks, on the real image of the complex block weights w [2][nb][bs_in][bs_out]       */
+/* (fourcastnet.py:70-75): wq[ri][ro][blk][i][o] = {Wr, Wi; -Wi, Wr}.  fold ACCUMULATES the     */
+/* complex gradient from a wq-shaped gradient.                                                   */
+int dlwp_afno_wq_expand(const float* w, float* wq, int nb, int bs_in, int bs_out, void* stream);
+int dlwp_afno_wq_fold(const float* gq, float* gw, int nb, int bs_in, int bs_out, void* stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* Token-level building blocks of the AFNO / Swin / Pangu blocks (nn.Linear, nn.LayerNorm, */
 /* nn.GELU call sites: nsbench/models/fourcastnet/fourcastnet.py:44-46,213,233;             */
@@ -260,14 +268,16 @@ int dlwp_gemm(const float* A, const float* B, float* C, int M, int N, int K, int
 /* z2*sA2, B + z1*sB1 + z2*sB2, C (and residual) likewise; strides in floats, 0 = shared.     */
 /* res_before_act != 0 adds the residual before the activation: C = act(A.B + bias + res);    */
 /* preact (optional, C's layout and strides) receives the value the activation is applied to.  */
+/* act: 0 none, 1 GELU, 2 ReLU, 3 soft-shrink(act_param); bias has its own batch strides.       */
+/* Without an epilogue, long-K products with few output tiles are split along K (atomics).      */
 /* Used for the spherical transforms (per-order Legendre matrices) and the per-degree SFNO     */
 /* spectral weights, where one launch covers every (sample, order) or degree.                  */
 int dlwp_gemm_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda,
                       int ldb, int ldc, int transA, int transB, int nb1, int nb2, long long sA1,
                       long long sA2, long long sB1, long long sB2, long long sC1, long long sC2,
-                      const float* bias, int act, float* preact, const float* residual,
-                      long long sR1, long long sR2, int res_before_act, int accumulate,
-                      void* stream);
+                      const float* bias, long long sBi1, long long sBi2, int act, float act_param,
+                      float* preact, const float* residual, long long sR1, long long sR2,
+                      int res_before_act, int accumulate, void* stream);
 /* SFNO "driscoll-healy" spectral weights (torch_harmonics, constructed at                    */
 /* src/dlwpbench/models/fno/fno.py:183-200): w [Cin][Cout][L][2] complex, one matrix per       */
 /* degree l.  expand: wexp[l] = [[Wr, Wi], [-Wi, Wr]] as a real [2Cin][2Cout] matrix, so that   */
@@ -284,6 +294,9 @@ int dlwp_layernorm_bwd(const float* x, const float* gamma, const float* mean, co
                        void* stream);
 /* gz = gy * gelu'(z) (exact erf GELU)                                                       */
 int dlwp_gelu_bwd(const float* z, const float* gy, float* gz, long long n, void* stream);
+/* gz = gy * act'(z) for the epilogue activations of dlwp_gemm_batched (1 GELU, 2 ReLU, 3 soft-shrink) */
+int dlwp_act_bwd(const float* z, const float* gy, float* gz, long long n, int act, float act_param,
+                 void* stream);
 /* out[n] += sum_t g[t][n]   (bias gradients)                                                */
 int dlwp_colsum(const float* g, float* out, int T, int N, void* stream);
 

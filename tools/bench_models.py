@@ -4,7 +4,7 @@ rollout models built on libdlwpmi's kernels, at the reference's nsbench / dlwpbe
 forward rollout + MSE + backward (autograd over the HIP ops) + one fused Adam launch on the flat parameter
 buffer, captured into a hipGraph by train_engine.GraphedTrainStep (--no-graph: eager dispatch).
 
-    python tools/bench_models.py [afno|swin|sfno|pangu|all] [--steps N]
+    python tools/bench_models.py [afno|afno_tiled|afno_fcn|swin|sfno|pangu|all] [--steps N]
 """
 import argparse
 import json
@@ -53,6 +53,30 @@ def main():
             return {"x": u[:, :-1].contiguous()}, u[:, 1:].contiguous(), 4
         run("nsbench AFNONet 64x64 p4 E64 depth4 ctx10 T20", m, batch, a.steps, use_graph=not a.no_graph,
             call=lambda mod, kw: mod(kw["x"], 10))
+    if a.which in ("afno_tiled",):
+        # same nsbench config through the general-grid (batched GEMM) AFNO2D path
+        m = nsbench.AFNONet(img_height=64, img_width=64, patch_size=(4, 4), in_chans=1, out_chans=1, embed_dim=64, depth=4,
+                            mlp_ratio=4.0, num_blocks=4, context_size=10)
+        for mod in m.modules():
+            if hasattr(mod, "path"):
+                mod.path = "tiled"
+
+        def batch(dev):
+            u = torch.randn(4, 21, 1, 64, 64, generator=g).to(dev)
+            return {"x": u[:, :-1].contiguous()}, u[:, 1:].contiguous(), 4
+        run("nsbench AFNONet 64x64 p4 E64 depth4 ctx10 T20 (tiled AFNO2D)", m, batch, a.steps, use_graph=not a.no_graph,
+            call=lambda mod, kw: mod(kw["x"], 10))
+    if a.which in ("afno_fcn",):
+        # FourCastNet-paper scale (BASELINE C5 grid): dlwpbench AFNONet 720x1440, patch 8, E=768, depth 12, 16 blocks
+        m = dlwpbench.AFNONet(img_height=720, img_width=1440, patch_size=(8, 8), constant_channels=4, prescribed_channels=1,
+                              prognostic_channels=8, embed_dim=768, depth=12, mlp_ratio=4.0, num_blocks=16, context_size=1)
+
+        def batch(dev):
+            kw = dict(constants=torch.randn(1, 1, 4, 720, 1440, generator=g).to(dev),
+                      prescribed=torch.randn(1, 2, 1, 720, 1440, generator=g).to(dev),
+                      prognostic=torch.randn(1, 2, 8, 720, 1440, generator=g).to(dev))
+            return kw, torch.randn(1, 1, 8, 720, 1440, generator=g).to(dev), 1
+        run("dlwpbench AFNONet 720x1440 p8 E768 depth12 nb16 B1 T2", m, batch, a.steps, use_graph=not a.no_graph)
     if a.which in ("swin", "all"):
         m = nsbench.SwinTransformer(context_size=10, pretrain_img_size=64, patch_size=2, in_chans=1, out_chans=1,
                                     embed_dim=40, depths=[4, 4], num_heads=[4, 4], drop_path_rate=0.0)
