@@ -16,15 +16,20 @@
 // flight while step i runs on the matrix cores, one barrier per step.  Reductions over the token
 // dimension (gW: K = tokens, few output tiles) are split along K across workgroups (grid.z) and
 // combined with float atomics into a zeroed C.
+#include <cstdlib>
 #include "common.cuh"
 #include "dlwpmi_internal.h"
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int BK = 32;
 constexpr int LDK = BK + 4;    // [row][k] layout: 16-byte aligned rows
-constexpr int LDR = BM + 4;    // [k][row] layout
-constexpr int TILE_FLOATS = BM * LDK;   // >= BK * LDR
+// tile edge 64 * T (T = 1: 64 x 64 per workgroup, T = 2: 128 x 128 for the large products)
+template <int T> struct Tile {
+    static constexpr int ROWS = 64 * T;
+    static constexpr int LDR = ROWS + 4;                                   // [k][row] layout
+    static constexpr int FLOATS = ROWS * LDK > BK * LDR ? ROWS * LDK : BK * LDR;
+};
 
 struct GemmDev {
     const float *A, *B, *bias, *residual;
@@ -44,18 +49,28 @@ __device__ __forceinline__ float apply_act(float v, int act, float lam) {
     return v;
 }
 
-// One 64 x 32 operand tile.  KC: k is the contiguous dimension in memory (element (row, k) at
+// One (64 T) x 32 operand tile.  KC: k is the contiguous dimension in memory (element (row, k) at
 // base[row * ld + k]); otherwise the row index is contiguous (base[k * ld + row]).
-template <bool KC, bool VEC>
+template <bool KC, bool VEC, int T>
 struct TileIO {
-    float v[8];
+    static constexpr int ROWS = Tile<T>::ROWS, LDR = Tile<T>::LDR;
+    float v[8 * T];
+    static __device__ __forceinline__ void coords(int f, int& row, int& k) {
+        if (VEC) {
+            if (KC) { row = f >> 3; k = 4 * (f & 7); }
+            else { row = 4 * (f % (16 * T)); k = f / (16 * T); }
+        } else {
+            if (KC) { row = f >> 5; k = f & 31; }
+            else { row = f % ROWS; k = f / ROWS; }
+        }
+    }
     __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int row0, int nrows, int k0, int kend) {
         const int tid = threadIdx.x;
         if (VEC) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int f = tid + 256 * q;
-                const int row = KC ? (f >> 3) : 4 * (f & 15), k = KC ? 4 * (f & 7) : (f >> 4);
+            for (int q = 0; q < 2 * T; ++q) {
+                int row, k;
+                coords(tid + 256 * q, row, k);
                 const bool ok = row0 + row < nrows && k0 + k < kend;
                 const long long off = KC ? (long long)(row0 + row) * ld + k0 + k : (long long)(k0 + k) * ld + row0 + row;
                 f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -65,9 +80,9 @@ struct TileIO {
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int f = tid + 256 * q;
-                const int row = KC ? (f >> 5) : (f & 63), k = KC ? (f & 31) : (f >> 6);
+            for (int q = 0; q < 8 * T; ++q) {
+                int row, k;
+                coords(tid + 256 * q, row, k);
                 const bool ok = row0 + row < nrows && k0 + k < kend;
                 const long long off = KC ? (long long)(row0 + row) * ld + k0 + k : (long long)(k0 + k) * ld + row0 + row;
                 v[q] = ok ? base[off] : 0.f;
@@ -78,17 +93,17 @@ struct TileIO {
         const int tid = threadIdx.x;
         if (VEC) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int f = tid + 256 * q;
-                const int row = KC ? (f >> 3) : 4 * (f & 15), k = KC ? 4 * (f & 7) : (f >> 4);
+            for (int q = 0; q < 2 * T; ++q) {
+                int row, k;
+                coords(tid + 256 * q, row, k);
                 *reinterpret_cast<f32x4*>(&S[KC ? row * LDK + k : k * LDR + row]) =
                     f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int f = tid + 256 * q;
-                const int row = KC ? (f >> 5) : (f & 63), k = KC ? (f & 31) : (f >> 6);
+            for (int q = 0; q < 8 * T; ++q) {
+                int row, k;
+                coords(tid + 256 * q, row, k);
                 S[KC ? row * LDK + k : k * LDR + row] = v[q];
             }
         }
@@ -103,11 +118,12 @@ struct TileIO {
     }
 };
 
-// (appended to gemm_kernel's epilogue through this helper to keep the kernel body readable)
-__device__ __forceinline__ void gemm_rowsum_flush(const GemmDev& a, const float (&rsum)[2], int m0, int wm, int w, int r, int g) {
+// bias gradient by-product: sum over k of op(A) rows (see dlwp_gemm's rowsum)
+template <int T>
+__device__ __forceinline__ void gemm_rowsum_flush(const GemmDev& a, const float (&rsum)[2 * T], int m0, int wm, int w, int r, int g) {
     if (!a.rowsum || blockIdx.x != 0 || (w & 1)) return;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2 * T; ++i) {
         float v = rsum[i];
         v += __shfl_xor(v, 16);
         v += __shfl_xor(v, 32);
@@ -116,12 +132,14 @@ __device__ __forceinline__ void gemm_rowsum_flush(const GemmDev& a, const float 
     }
 }
 
-template <bool AKC, bool BKC, bool VEC>
+template <bool AKC, bool BKC, bool VEC, int T>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
-    __shared__ __attribute__((aligned(16))) float As[2][TILE_FLOATS];
-    __shared__ __attribute__((aligned(16))) float Bs[2][TILE_FLOATS];
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    constexpr int TF = Tile<T>::FLOATS, BMN = Tile<T>::ROWS, NT16 = 2 * T;   // 16-row MFMA tiles per wave and direction
+    float* As = gsm;                 // [2][TF]
+    float* Bs = gsm + 2 * TF;        // [2][TF]
     const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = blockIdx.y * BMN, n0 = blockIdx.x * BMN;
     int zs = blockIdx.z;
     if (a.nbatch > 1) {
         const int zb = zs / a.splits;                 // batch index; zs % splits = K split within the batch
@@ -136,21 +154,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
         if (a.bias) a.bias += z1 * a.sBi1 + z2 * a.sBi2;
     }
     const int kbeg = zs * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
-    const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
-    f32x4 acc[2][2];
+    const int wm = (w >> 1) * 32 * T, wn = (w & 1) * 32 * T;
+    f32x4 acc[NT16][NT16];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NT16; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float rsum[2] = {0.f, 0.f};     // sum over k of op(A) rows wm + 16 i + r (this lane's k slots)
-    TileIO<AKC, VEC> ta;
-    TileIO<BKC, VEC> tb;
+    float rsum[NT16];                // sum over k of op(A) rows wm + 16 i + r (this lane's k slots)
+#pragma unroll
+    for (int i = 0; i < NT16; ++i) rsum[i] = 0.f;
+    TileIO<AKC, VEC, T> ta;
+    TileIO<BKC, VEC, T> tb;
     const int nk = (kend - kbeg + BK - 1) / BK;
     ta.load(a.A, a.lda, m0, a.M, kbeg, kend);
     tb.load(a.B, a.ldb, n0, a.N, kbeg, kend);
-    ta.store(As[0]);
-    tb.store(Bs[0]);
+    ta.store(As);
+    tb.store(Bs);
     __syncthreads();
     for (int it = 0; it < nk; ++it) {
         const int cur = it & 1;
@@ -160,29 +180,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            f32x4 af[2], bf[2];
+            f32x4 af[NT16], bf[NT16];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = TileIO<AKC, VEC>::frag(As[cur], wm + 16 * i, c, r, g);
+            for (int i = 0; i < NT16; ++i) af[i] = TileIO<AKC, VEC, T>::frag(As + cur * TF, wm + 16 * i, c, r, g);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = TileIO<BKC, VEC>::frag(Bs[cur], wn + 16 * j, c, r, g);
+            for (int j = 0; j < NT16; ++j) bf[j] = TileIO<BKC, VEC, T>::frag(Bs + cur * TF, wn + 16 * j, c, r, g);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NT16; ++i) {
                 rsum[i] += (af[i][0] + af[i][1]) + (af[i][2] + af[i][3]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16_chunk(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < NT16; ++j) acc[i][j] = mfma16_chunk(af[i], bf[j], acc[i][j]);
             }
         }
         if (it + 1 < nk) {
-            ta.store(As[cur ^ 1]);
-            tb.store(Bs[cur ^ 1]);
+            ta.store(As + (cur ^ 1) * TF);
+            tb.store(Bs + (cur ^ 1) * TF);
         }
         __syncthreads();
     }
-    gemm_rowsum_flush(a, rsum, m0, wm, w, r, g);
+    gemm_rowsum_flush<T>(a, rsum, m0, wm, w, r, g);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NT16; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT16; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int m = m0 + wm + i * 16 + 4 * g + q, n = n0 + wn + j * 16 + r;
@@ -200,10 +220,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
             }
 }
 
+template <bool AKC, bool BKC, bool VEC, int T>
+int gemm_launch_t(const GemmDev& a, dim3 grid, hipStream_t s) {
+    const size_t lds = sizeof(float) * 4 * Tile<T>::FLOATS;
+    int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_kernel<AKC, BKC, VEC, T>), lds, "gemm");
+    if (rc) return rc;
+    hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, T>), grid, dim3(256), lds, s, a);
+    return DLWP_OK;
+}
+
 template <bool AKC, bool BKC>
-void gemm_launch(const GemmDev& a, bool vec, dim3 grid, hipStream_t s) {
-    if (vec) hipLaunchKernelGGL((gemm_kernel<AKC, BKC, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((gemm_kernel<AKC, BKC, false>), grid, dim3(256), 0, s, a);
+int gemm_launch(const GemmDev& a, bool vec, int T, hipStream_t s) {
+    const int edge = 64 * T;
+    const dim3 grid(ceil_div(a.N, edge), ceil_div(a.M, edge), a.nbatch * a.splits);
+    if (T == 2) return vec ? gemm_launch_t<AKC, BKC, true, 2>(a, grid, s) : gemm_launch_t<AKC, BKC, false, 2>(a, grid, s);
+    return vec ? gemm_launch_t<AKC, BKC, true, 1>(a, grid, s) : gemm_launch_t<AKC, BKC, false, 1>(a, grid, s);
 }
 
 // ---- LayerNorm over the last dimension: one wave per row
@@ -332,18 +363,29 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g
 
 }  // namespace
 
-static int gemm_dispatch(GemmDev& a, int transA, int transB, void* stream) {
+// Tile edge selection.  The 128 x 128 instantiation (T = 2) needs ~200 VGPRs and 74 KB of LDS, i.e. two waves per SIMD,
+// and measured 5-7 % SLOWER than 64 x 64 (T = 1: ~104 VGPRs, four waves per SIMD hide the LDS fragment reads behind the
+// other waves' MFMAs) on the SFNO (M = 512-32768, N = K = 256-512) and FourCastNet-scale (16200 x 3072 x 768) products,
+// so it is only used when DLWP_GEMM_TILE=128 asks for it (kept for re-measurement with bf16 operands).
+static int gemm_tile_for(int M, int N, long long nbatch) {
+    static const int forced = [] { const char* e = getenv("DLWP_GEMM_TILE"); return e && atoi(e) == 128 ? 2 : 1; }();
+    if (forced == 1 || M < 128 || N < 128) return 1;
+    return (long long)ceil_div(M, 128) * ceil_div(N, 128) * nbatch >= 224 ? 2 : 1;
+}
+
+static int gemm_dispatch(GemmDev& a, int transA, int transB, int T, void* stream) {
     // 16-byte loads need every row start and every k (or row) group of four to be aligned and whole
     bool vec = ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.B % 16 == 0) && a.lda % 4 == 0 && a.ldb % 4 == 0 && a.K % 4 == 0 &&
                (transA ? a.M % 4 == 0 : true) && (transB ? true : a.N % 4 == 0);
     if (a.nbatch > 1) vec = vec && a.sA1 % 4 == 0 && a.sA2 % 4 == 0 && a.sB1 % 4 == 0 && a.sB2 % 4 == 0;
-    const dim3 grid(ceil_div(a.N, BN), ceil_div(a.M, BM), a.nbatch * a.splits);
     const hipStream_t s = (hipStream_t)stream;
+    int rc;
     // A is k-contiguous when not transposed ([M][K]); B is k-contiguous when transposed ([N][K])
-    if (!transA && transB) gemm_launch<true, true>(a, vec, grid, s);
-    else if (!transA && !transB) gemm_launch<true, false>(a, vec, grid, s);
-    else if (transA && transB) gemm_launch<false, true>(a, vec, grid, s);
-    else gemm_launch<false, false>(a, vec, grid, s);
+    if (!transA && transB) rc = gemm_launch<true, true>(a, vec, T, s);
+    else if (!transA && !transB) rc = gemm_launch<true, false>(a, vec, T, s);
+    else if (transA && transB) rc = gemm_launch<false, true>(a, vec, T, s);
+    else rc = gemm_launch<false, false>(a, vec, T, s);
+    if (rc) return rc;
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }
@@ -354,7 +396,8 @@ extern "C" int dlwp_gemm(const float* A, const float* B, float* C, int M, int N,
     DLWP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, DLWP_E_INVALID, "gemm: NULL argument or empty shape");
     DLWP_REQUIRE(act == 0 || act == 1, DLWP_E_INVALID, "gemm: act must be 0 (none) or 1 (gelu)");
     const bool epilogue = bias || act || preact || residual;
-    const int tiles = ceil_div(N, BN) * ceil_div(M, BM);
+    const int T = gemm_tile_for(M, N, 1);
+    const int tiles = ceil_div(N, 64 * T) * ceil_div(M, 64 * T);
     int splits = 1;
     if (!epilogue && tiles < 256 && K >= 8 * BK) splits = std::min(ceil_div(512, tiles), K / (4 * BK));
     int kchunk = ceil_div(ceil_div(K, splits), BK) * BK;
@@ -362,7 +405,7 @@ extern "C" int dlwp_gemm(const float* A, const float* B, float* C, int M, int N,
     if (splits > 1 && !accumulate) DLWP_HIP(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, (hipStream_t)stream));
     GemmDev a{A, B, bias, residual, C, preact, rowsum, M, N, K, lda, ldb, ldc, act, accumulate, kchunk, splits,
               1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.f};
-    return gemm_dispatch(a, transA, transB, stream);
+    return gemm_dispatch(a, transA, transB, T, stream);
 }
 
 extern "C" int dlwp_gemm_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
@@ -376,7 +419,8 @@ extern "C" int dlwp_gemm_batched(const float* A, const float* B, float* C, int M
     // reductions over a long K with few output tiles (weight gradients of block-diagonal layers): split K inside every
     // batch and combine with float atomics, like the plain entry
     const bool epilogue = bias || act || preact || residual;
-    const long long tiles = (long long)ceil_div(N, BN) * ceil_div(M, BM) * nb1 * nb2;
+    const int T = gemm_tile_for(M, N, (long long)nb1 * nb2);
+    const long long tiles = (long long)ceil_div(N, 64 * T) * ceil_div(M, 64 * T) * nb1 * nb2;
     int splits = 1;
     if (!epilogue && tiles < 256 && K >= 8 * BK) splits = (int)std::min<long long>(ceil_div(512, (int)tiles), K / (4 * BK));
     int kchunk = ceil_div(ceil_div(K, splits), BK) * BK;
@@ -391,7 +435,7 @@ extern "C" int dlwp_gemm_batched(const float* A, const float* B, float* C, int M
     }
     GemmDev a{A, B, bias, residual, C, preact, nullptr, M, N, K, lda, ldb, ldc, act, accumulate, kchunk, splits,
               nb1 * nb2, nb2, res_before_act, sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2, sBi1, sBi2, act_param};
-    return gemm_dispatch(a, transA, transB, stream);
+    return gemm_dispatch(a, transA, transB, T, stream);
 }
 
 extern "C" int dlwp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
