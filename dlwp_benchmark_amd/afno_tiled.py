@@ -100,10 +100,10 @@ class _BlockComplexLinear(torch.autograd.Function):
             _gemm_batched(gP, wq, gX, T, bsi, bso, Co, bso, C, 0, 1, nb, 2, (bso, 0), (bsi * bso, 2 * n), (bsi, T * C),
                           accumulate=ro, oA=ro * T * Co, oB=ro * n)
         # gwq[ri][ro][blk] = X[ri][:, blk]^T . gP[ro][:, blk]   (K = tokens: split along K inside the kernel)
-        gwq = torch.empty_like(wq)
+        gwq = torch.zeros_like(wq)        # one fill; the split-K partial sums are accumulated with atomics
         for ri in range(2):
             _gemm_batched(X, gP, gwq, bsi, bso, T, C, Co, bso, 1, 0, nb, 2, (bsi, 0), (bso, T * Co), (bsi * bso, n),
-                          oA=ri * T * C, oC=ri * 2 * n)
+                          accumulate=1, oA=ri * T * C, oC=ri * 2 * n)
         wslot, bslot = ctx.slots
         gw = wslot if wslot is not None else torch.zeros(ctx.shapes[0], device=X.device)
         L.check(lib.dlwp_afno_wq_fold(L.ptr(gwq), L.ptr(gw), nb, bsi, bso, L.stream()))

@@ -41,6 +41,13 @@ struct GemmDev {
     float act_param;           // soft-shrink threshold (act == 3)
 };
 
+// bf16-operand mode (dlwp_set_gemm_precision(1)): operands are rounded to bf16 when a tile is committed to LDS and
+// multiplied by v_mfma_f32_16x16x32_bf16 (16x the fp32 MFMA rate) with fp32 accumulation -- the arithmetic of the
+// reference's bf16-autocast runs (BASELINE configs C3-C5); tensors in HBM stay fp32.  LDS tiles are [row][k] bf16.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int LDKB = BK + 8;   // bf16 elements per LDS row (80 bytes: 16-byte aligned fragments)
+
 // epilogue activations: 0 none, 1 GELU (erf), 2 ReLU, 3 soft-shrink(lambda)
 __device__ __forceinline__ float apply_act(float v, int act, float lam) {
     if (act == 1) return gelu_f(v);
@@ -108,6 +115,39 @@ struct TileIO {
             }
         }
     }
+    // bf16 images: [row][k] (row pitch LDKB) when k is contiguous in memory, [k][row] (row pitch LDRB) otherwise, so
+    // that every float4 fetched from HBM becomes one packed 8-byte LDS write either way
+    static constexpr int LDRB = ROWS + 8;
+    __device__ __forceinline__ void store_bf16(__bf16* S) const {
+        const int tid = threadIdx.x;
+        if (VEC) {
+#pragma unroll
+            for (int q = 0; q < 2 * T; ++q) {
+                int row, k;
+                coords(tid + 256 * q, row, k);
+                *reinterpret_cast<bf16x4*>(&S[KC ? row * LDKB + k : k * LDRB + row]) =
+                    bf16x4{(__bf16)v[4 * q], (__bf16)v[4 * q + 1], (__bf16)v[4 * q + 2], (__bf16)v[4 * q + 3]};
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8 * T; ++q) {
+                int row, k;
+                coords(tid + 256 * q, row, k);
+                S[KC ? row * LDKB + k : k * LDRB + row] = (__bf16)v[q];
+            }
+        }
+    }
+    // bf16 MFMA fragment: lane (r, g) holds row rb + r, k = 8g .. 8g+7 of the 32-deep K-step.  From the [k][row] image
+    // it comes through two hardware transpose reads (ds_read_b64_tr_b16: per 16-lane group a 4 x 16 block, lane 4q+p
+    // addresses block row q / columns 4p.., lane i receives column i; tools/micro/tr_read.hip) -- EXEC is all ones here.
+    static __device__ __forceinline__ bf16x8 frag_bf16(const __bf16* S, int rb, int r, int g) {
+        if (KC) return *reinterpret_cast<const bf16x8*>(&S[(rb + r) * LDKB + 8 * g]);
+        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+        const __bf16* p0 = &S[(8 * g + (r >> 2)) * LDRB + rb + 4 * (r & 3)];
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * LDRB));
+        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
     // MFMA fragment of chunk c (k = 16c + 4g + s) for the 16 rows starting at rb
     static __device__ __forceinline__ f32x4 frag(const float* S, int rb, int c, int r, int g) {
         if (KC) return *reinterpret_cast<const f32x4*>(&S[(rb + r) * LDK + 16 * c + 4 * g]);
@@ -132,10 +172,11 @@ __device__ __forceinline__ void gemm_rowsum_flush(const GemmDev& a, const float 
     }
 }
 
-template <bool AKC, bool BKC, bool VEC, int T>
+template <bool AKC, bool BKC, bool VEC, int T, bool BF>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
-    constexpr int TF = Tile<T>::FLOATS, BMN = Tile<T>::ROWS, NT16 = 2 * T;   // 16-row MFMA tiles per wave and direction
+    constexpr int BMN = Tile<T>::ROWS, NT16 = 2 * T;   // 16-row MFMA tiles per wave and direction
+    constexpr int TF = BF ? BMN * LDKB / 2 : Tile<T>::FLOATS;                // tile size in floats (bf16: two per float)
     float* As = gsm;                 // [2][TF]
     float* Bs = gsm + 2 * TF;        // [2][TF]
     const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
@@ -169,8 +210,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
     const int nk = (kend - kbeg + BK - 1) / BK;
     ta.load(a.A, a.lda, m0, a.M, kbeg, kend);
     tb.load(a.B, a.ldb, n0, a.N, kbeg, kend);
-    ta.store(As);
-    tb.store(Bs);
+    if constexpr (BF) {
+        ta.store_bf16(reinterpret_cast<__bf16*>(As));
+        tb.store_bf16(reinterpret_cast<__bf16*>(Bs));
+    } else {
+        ta.store(As);
+        tb.store(Bs);
+    }
     __syncthreads();
     for (int it = 0; it < nk; ++it) {
         const int cur = it & 1;
@@ -178,6 +224,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
             ta.load(a.A, a.lda, m0, a.M, kbeg + (it + 1) * BK, kend);
             tb.load(a.B, a.ldb, n0, a.N, kbeg + (it + 1) * BK, kend);
         }
+        if constexpr (BF) {
+            bf16x8 af[NT16], bf[NT16];
+#pragma unroll
+            for (int i = 0; i < NT16; ++i) af[i] = TileIO<AKC, VEC, T>::frag_bf16(reinterpret_cast<const __bf16*>(As + cur * TF), wm + 16 * i, r, g);
+#pragma unroll
+            for (int j = 0; j < NT16; ++j) bf[j] = TileIO<BKC, VEC, T>::frag_bf16(reinterpret_cast<const __bf16*>(Bs + cur * TF), wn + 16 * j, r, g);
+#pragma unroll
+            for (int i = 0; i < NT16; ++i) {
+                if (a.rowsum) {
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) rsum[i] += (float)af[i][s];
+                }
+#pragma unroll
+                for (int j = 0; j < NT16; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             f32x4 af[NT16], bf[NT16];
@@ -193,8 +255,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
             }
         }
         if (it + 1 < nk) {
-            ta.store(As + (cur ^ 1) * TF);
-            tb.store(Bs + (cur ^ 1) * TF);
+            if constexpr (BF) {
+                ta.store_bf16(reinterpret_cast<__bf16*>(As + (cur ^ 1) * TF));
+                tb.store_bf16(reinterpret_cast<__bf16*>(Bs + (cur ^ 1) * TF));
+            } else {
+                ta.store(As + (cur ^ 1) * TF);
+                tb.store(Bs + (cur ^ 1) * TF);
+            }
         }
         __syncthreads();
     }
@@ -220,21 +287,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
             }
 }
 
-template <bool AKC, bool BKC, bool VEC, int T>
+template <bool AKC, bool BKC, bool VEC, int T, bool BF>
 int gemm_launch_t(const GemmDev& a, dim3 grid, hipStream_t s) {
-    const size_t lds = sizeof(float) * 4 * Tile<T>::FLOATS;
-    int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_kernel<AKC, BKC, VEC, T>), lds, "gemm");
+    const size_t lds = BF ? sizeof(float) * 4 * (Tile<T>::ROWS * LDKB / 2) : sizeof(float) * 4 * Tile<T>::FLOATS;
+    int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_kernel<AKC, BKC, VEC, T, BF>), lds, "gemm");
     if (rc) return rc;
-    hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, T>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, T, BF>), grid, dim3(256), lds, s, a);
     return DLWP_OK;
 }
+
+int g_gemm_bf16 = 0;    // dlwp_set_gemm_precision
 
 template <bool AKC, bool BKC>
 int gemm_launch(const GemmDev& a, bool vec, int T, hipStream_t s) {
     const int edge = 64 * T;
     const dim3 grid(ceil_div(a.N, edge), ceil_div(a.M, edge), a.nbatch * a.splits);
-    if (T == 2) return vec ? gemm_launch_t<AKC, BKC, true, 2>(a, grid, s) : gemm_launch_t<AKC, BKC, false, 2>(a, grid, s);
-    return vec ? gemm_launch_t<AKC, BKC, true, 1>(a, grid, s) : gemm_launch_t<AKC, BKC, false, 1>(a, grid, s);
+    if (g_gemm_bf16) {
+        if (T == 2) return vec ? gemm_launch_t<AKC, BKC, true, 2, true>(a, grid, s) : gemm_launch_t<AKC, BKC, false, 2, true>(a, grid, s);
+        return vec ? gemm_launch_t<AKC, BKC, true, 1, true>(a, grid, s) : gemm_launch_t<AKC, BKC, false, 1, true>(a, grid, s);
+    }
+    if (T == 2) return vec ? gemm_launch_t<AKC, BKC, true, 2, false>(a, grid, s) : gemm_launch_t<AKC, BKC, false, 2, false>(a, grid, s);
+    return vec ? gemm_launch_t<AKC, BKC, true, 1, false>(a, grid, s) : gemm_launch_t<AKC, BKC, false, 1, false>(a, grid, s);
 }
 
 // ---- LayerNorm over the last dimension: one wave per row
@@ -390,6 +463,14 @@ static int gemm_dispatch(GemmDev& a, int transA, int transB, int T, void* stream
     return DLWP_OK;
 }
 
+extern "C" int dlwp_set_gemm_precision(int mode) {
+    DLWP_REQUIRE(mode == 0 || mode == 1, DLWP_E_INVALID, "set_gemm_precision: 0 = fp32 operands, 1 = bf16 operands (fp32 accumulate)");
+    g_gemm_bf16 = mode;
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_get_gemm_precision(void) { return g_gemm_bf16; }
+
 extern "C" int dlwp_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                          int transA, int transB, const float* bias, int act, float* preact, const float* residual,
                          int accumulate, float* rowsum, void* stream) {
@@ -455,8 +536,10 @@ extern "C" int dlwp_layernorm_bwd(const float* x, const float* gamma, const floa
     // Every workgroup ends with 2C float atomics on the same addresses, which serialise at ~25 ns each, so the
     // tail costs (number of workgroups) x 25 ns whatever C is: ~128-256 workgroups balance that against the rows
     // each wave walks serially.
+    // each wave then walks serially (one wave per SIMD hides no latency).  Large inputs get up to ~1024 workgroups.
+    const long long want = std::min<long long>(1024, std::max<long long>(128, (long long)T * C / 16384));
     int rpb = 64;
-    while (rpb > 4 && ceil_div(T, rpb) < 128) rpb >>= 1;
+    while (rpb > 4 && ceil_div(T, rpb) < want) rpb >>= 1;
     const dim3 grid(ceil_div(T, rpb));
     const size_t lds = 2 * C * sizeof(float);
     if (C <= 512)

@@ -62,6 +62,8 @@ SIGNATURES = {
     "dlwp_afno2d_bwd": (_I, [_V] * 11 + [_I] * 5 + [_F, _F, _V]),
     "dlwp_afno_wq_expand": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_afno_wq_fold": (_I, [_V, _V, _I, _I, _I, _V]),
+    "dlwp_set_gemm_precision": (_I, [_I]),
+    "dlwp_get_gemm_precision": (_I, []),
     "dlwp_gemm": (_I, [_V, _V, _V] + [_I] * 8 + [_V, _I, _V, _V, _I, _V, _V]),
     "dlwp_gemm_batched": (_I, [_V, _V, _V] + [_I] * 10 + [_L] * 6 + [_V, _L, _L, _I, _F, _V, _V, _L, _L, _I, _I, _V]),
     "dlwp_act_bwd": (_I, [_V, _V, _V, _L, _I, _F, _V]),
@@ -126,3 +128,27 @@ def ptr(t):
 def stream():
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+class gemm_precision:
+    """Context manager / setter for the GEMM operand precision: "fp32" (default, exact fp32 MFMA) or "bf16"
+    (bf16 operands, fp32 accumulation: the reference's bf16-autocast arithmetic)."""
+
+    MODES = {"fp32": 0, "bf16": 1}
+
+    def __init__(self, mode):
+        self.mode = self.MODES[mode]
+
+    def __enter__(self):
+        lib = load()
+        self.prev = lib.dlwp_get_gemm_precision()
+        check(lib.dlwp_set_gemm_precision(self.mode))
+        return self
+
+    def __exit__(self, *exc):
+        check(load().dlwp_set_gemm_precision(self.prev))
+        return False
+
+
+def set_gemm_precision(mode):
+    check(load().dlwp_set_gemm_precision(gemm_precision.MODES[mode]))

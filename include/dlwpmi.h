@@ -264,6 +264,12 @@ int dlwp_afno_wq_fold(const float* gq, float* gw, int nb, int bs_in, int bs_out,
 int dlwp_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
               int ldc, int transA, int transB, const float* bias, int act, float* preact,
               const float* residual, int accumulate, float* rowsum, void* stream);
+/* Operand precision of dlwp_gemm / dlwp_gemm_batched, process-wide: 0 (default) = exact fp32 */
+/* MFMA; 1 = operands rounded to bf16 in LDS, v_mfma_f32_16x16x32_bf16, fp32 accumulation --   */
+/* the arithmetic of the reference's bf16-autocast runs (BASELINE C3-C5).  HBM tensors stay     */
+/* fp32 either way.                                                                             */
+int dlwp_set_gemm_precision(int mode);
+int dlwp_get_gemm_precision(void);
 /* Strided-batched form: batch z = z1*nb2 + z2 (z1 < nb1, z2 < nb2) works on A + z1*sA1 +      */
 /* z2*sA2, B + z1*sB1 + z2*sB2, C (and residual) likewise; strides in floats, 0 = shared.     */
 /* res_before_act != 0 adds the residual before the activation: C = act(A.B + bias + res);    */

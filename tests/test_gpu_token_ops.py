@@ -104,3 +104,31 @@ def test_layernorm_fused_grad_accumulation(cuda, T, C):
     assert rel(xd.grad, xr.grad) <= 5e-4
     assert rel(ln.weight.grad, ln_ref.weight.grad) <= 5e-4
     assert rel(ln.bias.grad, ln_ref.bias.grad) <= 5e-4
+
+
+@pytest.mark.parametrize("T,K,N", [(1024, 256, 512), (300, 96, 288), (77, 13, 29)])
+def test_linear_bf16_operand_mode(cuda, T, K, N):
+    """dlwp_set_gemm_precision(bf16): operands rounded to bf16, fp32 accumulation -- equals an fp32 product of the
+    bf16-rounded operands up to summation order."""
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd import token_ops
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(T, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * 0.1
+    gy = torch.randn(T, N, generator=g)
+    rb = lambda t: t.bfloat16().float()    # noqa: E731
+    xr, wr = rb(x).requires_grad_(True), rb(w).requires_grad_(True)
+    y_ref = F.linear(xr, wr, b)
+    xd, wd, bd = (t.to(cuda).requires_grad_(True) for t in (x, w, b))
+    with L.gemm_precision("bf16"):
+        y = token_ops.linear(xd, wd, bd)
+        y.backward(gy.to(cuda))
+    assert L.load().dlwp_get_gemm_precision() == 0
+    assert rel(y, y_ref) <= 1e-5
+    # backward products round gy / x / w to bf16 as well
+    gx_ref = rb(gy) @ rb(w)
+    gw_ref = rb(gy).t() @ rb(x)
+    assert rel(xd.grad, gx_ref) <= 1e-5
+    assert rel(wd.grad, gw_ref) <= 1e-4
+    assert rel(bd.grad, rb(gy).sum(0)) <= 1e-4

@@ -18,6 +18,9 @@ from dlwp_benchmark_amd import dlwpbench, nsbench  # noqa: E402
 from dlwp_benchmark_amd.train_engine import GraphedTrainStep  # noqa: E402
 
 
+PRECISION = "fp32"
+
+
 def run(name, model, make_batch, steps, warmup=3, use_graph=True, call=None, lr=1e-3):
     dev = torch.device("cuda:0")
     model = model.to(dev).train()
@@ -31,7 +34,7 @@ def run(name, model, make_batch, steps, warmup=3, use_graph=True, call=None, lr=
         loss = step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps({"model": name, "graph": use_graph, "samples_per_s": round(B * steps / dt, 2),
+    print(json.dumps({"model": name, "graph": use_graph, "gemm_precision": PRECISION, "samples_per_s": round(B * steps / dt, 2),
                       "ms_per_step": round(dt / steps * 1e3, 3), "batch": B, "loss": loss.item(),
                       "n_params": sum(p.numel() for p in model.parameters())}), flush=True)
 
@@ -41,7 +44,13 @@ def main():
     ap.add_argument("which", nargs="?", default="all")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="GEMM operand precision (bf16: the reference's autocast arithmetic for C3-C5; fp32 accumulation)")
     a = ap.parse_args()
+    from dlwp_benchmark_amd import lib as L
+    L.set_gemm_precision(a.precision)
+    global PRECISION
+    PRECISION = a.precision
     g = torch.Generator().manual_seed(1234)
     if a.which in ("afno", "all"):
         # nsbench configs/model/fourcastnet.yaml with the paper runs' context 10 (train_commands.txt:112-115), T=20, tf=10
