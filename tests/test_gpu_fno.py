@@ -155,6 +155,12 @@ def _oracle_flat_grad(oracle, module):
     dict(B=2, T=6, D=1, H=32, W=32, ctx=3, tf=4, hidden=16, lifting=32, projection=32, n_layers=2, n_modes=(8, 8)),
     dict(B=2, T=5, D=2, H=32, W=64, ctx=2, tf=2, hidden=20, lifting=48, projection=24, n_layers=3, n_modes=(6, 10)),
     dict(B=4, T=12, D=1, H=64, W=64, ctx=10, tf=10, hidden=32, lifting=256, projection=256, n_layers=4, n_modes=(12, 12)),
+    # edge cases of the rollout windowing (fno.py:217-250): a single net call (T == ctx), fully teacher-forced (tf == T),
+    # context 1 with one observed frame, odd batch sizes
+    dict(B=1, T=4, D=1, H=32, W=32, ctx=4, tf=4, hidden=16, lifting=32, projection=32, n_layers=1, n_modes=(8, 8)),
+    dict(B=3, T=7, D=1, H=32, W=32, ctx=2, tf=7, hidden=16, lifting=32, projection=32, n_layers=2, n_modes=(8, 8)),
+    dict(B=5, T=6, D=1, H=32, W=32, ctx=1, tf=1, hidden=8, lifting=16, projection=16, n_layers=2, n_modes=(4, 4)),
+    dict(B=2, T=9, D=1, H=16, W=16, ctx=3, tf=3, hidden=24, lifting=40, projection=40, n_layers=2, n_modes=(8, 8)),
 ])
 def test_rollout_train_step_matches_oracle(cuda, cfg):
     oracle, module = _oracle_and_module(cuda, cfg["n_modes"], cfg["D"], cfg["hidden"], cfg["lifting"],
