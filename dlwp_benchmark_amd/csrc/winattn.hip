@@ -418,10 +418,12 @@ template <int NDB>
 __global__ __launch_bounds__(256) void winattn_bwd_kv_kernel(WaDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NL = 4 * NDB, LDT = 16 * NDB + 4, DP = 16 * NDB;
-    float* Ks = smem;                         // [64][LDT]
-    float* Vs = Ks + 64 * LDT;                // [64][LDT]
-    float* Qb = Vs + 64 * LDT;                // [2][64][LDT] scaled q rows of the current query tile
+    float* Qb = smem;                         // [2][64][LDT] scaled q rows of the current query tile
     float* Gb = Qb + 2 * 64 * LDT;            // [2][64][LDT]
+    // this workgroup's k / v rows are only needed until their fragments sit in registers: they borrow the second
+    // q / dO buffers, which the pipeline first writes at the end of iteration 0
+    float* Ks = Qb + 64 * LDT;                // [64][LDT]
+    float* Vs = Gb + 64 * LDT;                // [64][LDT]
     float* Qt = Gb + 2 * 64 * LDT;            // [2][DP][LDV]
     float* Gt = Qt + 2 * DP * LDV;            // [2][DP][LDV]
     float* lses = Gt + 2 * DP * LDV;          // [2][64]
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(256) void winattn_bwd_kv_kernel(WaDev a) {
     tk.issue(qb + a.heads * a.d, rs, kt * KT, a.N, a.d, a.dd);
     tv.issue(qb + 2 * a.heads * a.d, rs, kt * KT, a.N, a.d, a.dd);
     issue_tile(0);
-    for (int i = tid; i < (6 * 64 * LDT + 4 * DP * LDV) / 4; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < (4 * 64 * LDT + 4 * DP * LDV) / 4; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const long long tofs = (long long)(wdw % a.ntypes) * a.heads + head, tstr = (long long)a.ntypes * a.heads;
     load_table(tb, a.table, a.TB, tstr, tofs);
     const int key = kt * KT + w * 16 + r;                     // this lane's key (column)
@@ -483,6 +485,7 @@ __global__ __launch_bounds__(256) void winattn_bwd_kv_kernel(WaDev a) {
         dk[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
         dv[cc] = dk[cc];
     }
+    __syncthreads();                          // Ks / Vs are dead from here on (their storage is tile buffer 1)
 
     int buf = 0;
     for (int qt0 = 0; qt0 < a.N; qt0 += QT, buf ^= 1) {
@@ -539,7 +542,7 @@ int wa_setup(WaDev& a, int B_, int nW, int N, int TB, int ntypes, int heads, int
     DLWP_REQUIRE(B_ > 0 && nW > 0 && B_ % nW == 0 && N > 0 && heads > 0 && d > 0 && TB > 0 && ntypes > 0,
                  DLWP_E_INVALID, "%s: bad shape", who);
     DLWP_REQUIRE(nW % ntypes == 0, DLWP_E_INVALID, "%s: nW (%d) must be a multiple of ntypes (%d)", who, nW, ntypes);
-    DLWP_REQUIRE(d <= 32, DLWP_E_UNSUPPORTED, "%s: head_dim %d > 32 not supported yet", who, d);
+    DLWP_REQUIRE(d <= 64, DLWP_E_UNSUPPORTED, "%s: head_dim %d > 64 not supported yet", who, d);
     DLWP_REQUIRE(TB <= 9000, DLWP_E_UNSUPPORTED, "%s: bias table slice of %d entries does not fit LDS", who, TB);
     a.B_ = B_; a.nW = nW; a.N = N; a.TB = TB; a.ntypes = ntypes; a.heads = heads; a.d = d; a.scale = scale;
     a.dp16 = round_up(d, 16);
@@ -559,13 +562,18 @@ extern "C" int dlwp_window_attn_fwd(const float* qkv, const float* bias_table, c
     a.qkv = qkv; a.table = bias_table; a.ia = ia; a.ib = ib; a.labels = labels; a.out = out; a.lse = lse;
     const size_t lds = sizeof(float) * ((size_t)3 * 64 * (a.dp16 + 4) + 2 * a.dp16 * LDV + 256 + a.TB);
     const dim3 grid(B_ * heads * ((N + QT - 1) / QT)), block(256);
-    if (a.dp16 == 16) {
-        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_fwd_kernel<1>), lds, "window_attn_fwd"))) return rc;
-        hipLaunchKernelGGL(winattn_fwd_kernel<1>, grid, block, lds, (hipStream_t)stream, a);
-    } else {
-        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_fwd_kernel<2>), lds, "window_attn_fwd"))) return rc;
-        hipLaunchKernelGGL(winattn_fwd_kernel<2>, grid, block, lds, (hipStream_t)stream, a);
+#define WA_FWD(NDB)                                                                                                          \
+    do {                                                                                                                  \
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_fwd_kernel<NDB>), lds, "window_attn_fwd"))) return rc; \
+        hipLaunchKernelGGL(winattn_fwd_kernel<NDB>, grid, block, lds, (hipStream_t)stream, a);                          \
+    } while (0)
+    switch (a.dp16 / 16) {
+        case 1: WA_FWD(1); break;
+        case 2: WA_FWD(2); break;
+        case 3: WA_FWD(3); break;
+        default: WA_FWD(4); break;
     }
+#undef WA_FWD
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }
@@ -583,19 +591,22 @@ extern "C" int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, c
     a.gtable = gbias_table; a.dsum = dsum; a.slab = slab;
     const int LDT = a.dp16 + 4;
     const size_t lds_q = sizeof(float) * ((size_t)4 * 64 * LDT + 2 * a.dp16 * LDV + 256 + 3 * (size_t)((a.TB + 1) & ~1));
-    const size_t lds_kv = sizeof(float) * ((size_t)6 * 64 * LDT + 4 * a.dp16 * LDV + 512 + a.TB);
+    const size_t lds_kv = sizeof(float) * ((size_t)4 * 64 * LDT + 4 * a.dp16 * LDV + 512 + a.TB);
     const dim3 grid(B_ * heads * ((N + QT - 1) / QT)), block(256);
-    if (a.dp16 == 16) {
-        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_bwd_q_kernel<1>), lds_q, "window_attn_bwd"))) return rc;
-        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_bwd_kv_kernel<1>), lds_kv, "window_attn_bwd"))) return rc;
-        hipLaunchKernelGGL(winattn_bwd_q_kernel<1>, grid, block, lds_q, (hipStream_t)stream, a);
-        hipLaunchKernelGGL(winattn_bwd_kv_kernel<1>, grid, block, lds_kv, (hipStream_t)stream, a);
-    } else {
-        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_bwd_q_kernel<2>), lds_q, "window_attn_bwd"))) return rc;
-        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_bwd_kv_kernel<2>), lds_kv, "window_attn_bwd"))) return rc;
-        hipLaunchKernelGGL(winattn_bwd_q_kernel<2>, grid, block, lds_q, (hipStream_t)stream, a);
-        hipLaunchKernelGGL(winattn_bwd_kv_kernel<2>, grid, block, lds_kv, (hipStream_t)stream, a);
+#define WA_BWD(NDB)                                                                                                             \
+    do {                                                                                                                     \
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_bwd_q_kernel<NDB>), lds_q, "window_attn_bwd"))) return rc;  \
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_bwd_kv_kernel<NDB>), lds_kv, "window_attn_bwd"))) return rc; \
+        hipLaunchKernelGGL(winattn_bwd_q_kernel<NDB>, grid, block, lds_q, (hipStream_t)stream, a);                         \
+        hipLaunchKernelGGL(winattn_bwd_kv_kernel<NDB>, grid, block, lds_kv, (hipStream_t)stream, a);                       \
+    } while (0)
+    switch (a.dp16 / 16) {
+        case 1: WA_BWD(1); break;
+        case 2: WA_BWD(2); break;
+        case 3: WA_BWD(3); break;
+        default: WA_BWD(4); break;
     }
+#undef WA_BWD
     if (slab) {
         const int nqt = (N + QT - 1) / QT, n_items = (B_ / ntypes) * nqt;
         hipLaunchKernelGGL(winattn_fold_kernel, dim3((TB + 255) / 256, heads * ntypes, (n_items + FOLD_CH - 1) / FOLD_CH),

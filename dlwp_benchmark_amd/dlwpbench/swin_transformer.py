@@ -21,7 +21,10 @@ class SwinTransformer(nn.Module):
                  context_size: int = 1, img_height=224, img_width=196, patch_size=4, embed_dim=96, depths=[2, 2, 6, 2],
                  num_heads=[3, 6, 12, 24], mlp_ratio=4., qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0.,
                  drop_path_rate=0.2, norm_layer="nn.LayerNorm", ape=False, patch_norm=True, frozen_stages=-1,
-                 use_checkpoint=False, mesh="equirectangular", **kwargs):
+                 use_checkpoint=False, mesh="equirectangular", window_size=None, **kwargs):
+        """window_size (extra kwarg, not in the reference): None = the reference behaviour (whole-map windows); an int or
+        (h, w) pair gives classic Swin windows with the CORRECT per-axis padding (constant latitude, circular longitude) --
+        the reference's own block cannot run that case."""
         super().__init__()
         if mesh != "equirectangular":
             raise NotImplementedError("only the equirectangular mesh is on the MI355X hot path (healpix needs dgl)")
@@ -39,10 +42,11 @@ class SwinTransformer(nn.Module):
         res = (img_height // patch_size, img_width // patch_size)
         self.layers = nn.ModuleList()
         for i in range(self.num_layers):
-            if i < self.num_layers - 1 and (res[0] % 2 or res[1] % 2):
+            if window_size is None and i < self.num_layers - 1 and (res[0] % 2 or res[1] % 2):
                 raise NotImplementedError(f"stage {i} feature map {res} is odd: the reference's window padding is broken "
                                           "there (swin_transformer.py:218-222, SURVEY App. B-6)")
-            self.layers.append(BasicLayer(int(embed_dim * 2 ** i), depths[i], num_heads[i], res, mlp_ratio, qkv_bias,
+            self.layers.append(BasicLayer(int(embed_dim * 2 ** i), depths[i], num_heads[i],
+                                          res if window_size is None else window_size, mlp_ratio, qkv_bias,
                                           qk_scale, norm_layer=norm,
                                           downsample=PatchMerging if i < self.num_layers - 1 else None,
                                           padding_mode=pad_modes))

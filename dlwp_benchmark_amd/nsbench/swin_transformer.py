@@ -244,7 +244,9 @@ class SwinTransformer(nn.Module):
                  embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], mlp_ratio=4., qkv_bias=True,
                  qk_scale=None, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.2, norm_layer="nn.LayerNorm",
                  ape=False, patch_norm=True, frozen_stages=-1, use_checkpoint=False, padding_mode: str = "constant",
-                 **kwargs):
+                 window_size=None, **kwargs):
+        """window_size (extra kwarg, not in the reference): None = the reference behaviour (every stage attends over its
+        whole feature map, :528); an int gives classic Swin windows (e.g. 7 for BASELINE C4) with padding to multiples."""
         super().__init__()
         if ape:
             raise NotImplementedError("absolute position embedding is not on the MI355X hot path")
@@ -259,7 +261,8 @@ class SwinTransformer(nn.Module):
         self.layers = nn.ModuleList()
         for i in range(self.num_layers):
             # window = the stage's whole feature map (reference :528): global attention with a half-map shift
-            self.layers.append(BasicLayer(int(embed_dim * 2 ** i), depths[i], num_heads[i], resolution, mlp_ratio,
+            self.layers.append(BasicLayer(int(embed_dim * 2 ** i), depths[i], num_heads[i],
+                                          resolution if window_size is None else window_size, mlp_ratio,
                                           qkv_bias, qk_scale, norm_layer=norm,
                                           downsample=PatchMerging if i < self.num_layers - 1 else None,
                                           padding_mode=padding_mode))

@@ -229,7 +229,7 @@ int dlwp_afno2d_bwd(const float* gy, const float* xsave, const float* w1, const 
 /*   labels : [nW, N] int32 region labels of the shifted-window mask or NULL; the mask       */
 /*            value is -100 where labels differ (swin_transformer.py:377-395)                */
 /*   out    : [B_, N, heads*d];  lse : [B_, heads, N] (saved for backward)                   */
-/* B_ = batch*nW with the window index fastest.  head_dim d <= 32.                           */
+/* B_ = batch*nW with the window index fastest.  head_dim d <= 64.                           */
 int dlwp_window_attn_fwd(const float* qkv, const float* bias_table, const int* ia, const int* ib,
                          const int* labels, float* out, float* lse, int B_, int nW, int N, int TB,
                          int ntypes, int heads, int d, float scale, void* stream);

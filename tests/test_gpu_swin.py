@@ -98,6 +98,33 @@ def test_large_window_many_tiles_matches_torch(cuda):
         assert rel(q.grad, p[n].grad) <= 1e-3, n
 
 
+@pytest.mark.parametrize("Wh,Ww,dim,heads,B_,nW", [(7, 7, 192, 4, 6, 3), (16, 32, 192, 4, 2, 1), (8, 8, 256, 4, 4, 2), (5, 9, 80, 2, 3, 1)])
+def test_head_dims_up_to_64_match_oracle(cuda, Wh, Ww, dim, heads, B_, nW):
+    """head_dim 40 / 48 / 64 (three and four 16-wide MFMA blocks per row): dlwpbench Swin stage 1 has 192 / 4 = 48."""
+    from dlwp_benchmark_amd.nsbench.swin_transformer import WindowAttention
+    from oracle import swin_ref
+    g = torch.Generator().manual_seed(18)
+    N = Wh * Ww
+    wa = WindowAttention(dim=dim, window_size=(Wh, Ww), num_heads=heads)
+    with torch.no_grad():
+        wa.relative_position_bias_table.copy_(torch.randn(wa.relative_position_bias_table.shape, generator=g) * 0.5)
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in wa.named_parameters()}
+    x = torch.randn(B_, N, dim, generator=g)
+    labels = torch.randint(0, 3, (nW, N), generator=g).to(torch.int32)
+    gy = torch.randn(B_, N, dim, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = swin_ref.window_attention(xr, p, "", Wh, Ww, heads, labels)
+    yr.backward(gy)
+    wa = wa.to(cuda)
+    xd = x.to(cuda).requires_grad_(True)
+    y = wa(xd, labels.to(cuda), nW)
+    y.backward(gy.to(cuda))
+    assert rel(y, yr) <= 1e-4
+    assert rel(xd.grad, xr.grad) <= 5e-4
+    for n, q in wa.named_parameters():
+        assert rel(q.grad, p[n].grad) <= 1e-3, n
+
+
 # ---- dlwpbench twin --------------------------------------------------------------------------------------
 GD = np.load(os.path.join(os.path.dirname(__file__), "golden", "dlwp_swin_golden.npz"))
 DLWP_CFG = {"one": dict(constant_channels=2, prescribed_channels=1, prognostic_channels=3, context_size=1, img_height=16,

@@ -4,7 +4,7 @@ rollout models built on libdlwpmi's kernels, at the reference's nsbench / dlwpbe
 forward rollout + MSE + backward (autograd over the HIP ops) + one fused Adam launch on the flat parameter
 buffer, captured into a hipGraph by train_engine.GraphedTrainStep (--no-graph: eager dispatch).
 
-    python tools/bench_models.py [afno|afno_tiled|afno_fcn|swin|sfno|pangu|all] [--steps N]
+    python tools/bench_models.py [afno|afno_tiled|afno_fcn|swin|swin_c4|sfno|pangu|pangu_c4|all] [--steps N]
 """
 import argparse
 import json
@@ -95,6 +95,29 @@ def main():
             return {"x": u[:, :-1].contiguous()}, u[:, 1:].contiguous(), 4
         run("nsbench SwinTransformer 64x64 p2 E40 depths[4,4] ctx10 T20", m, batch, a.steps, use_graph=not a.no_graph,
             call=lambda mod, kw: mod(kw["x"], 10))
+    if a.which in ("swin_c4",):
+        # BASELINE C4 shapes: dlwpbench SwinTransformer 128x256, window 7 (extra kwarg), E=96, depths [4,4], heads [4,4]
+        m = dlwpbench.SwinTransformer(constant_channels=4, prescribed_channels=1, prognostic_channels=8, context_size=1,
+                                      img_height=128, img_width=256, patch_size=1, embed_dim=96, depths=[4, 4],
+                                      num_heads=[4, 4], drop_path_rate=0.0, window_size=7)
+
+        def batch(dev):
+            kw = dict(constants=torch.randn(2, 1, 4, 128, 256, generator=g).to(dev),
+                      prescribed=torch.randn(2, 2, 1, 128, 256, generator=g).to(dev),
+                      prognostic=torch.randn(2, 2, 8, 128, 256, generator=g).to(dev))
+            return kw, torch.randn(2, 1, 8, 128, 256, generator=g).to(dev), 2
+        run("dlwpbench SwinTransformer 128x256 window7 E96 depths[4,4] (C4) B2 T2", m, batch, a.steps, use_graph=not a.no_graph)
+    if a.which in ("pangu_c4",):
+        m = dlwpbench.PanguWeather(constant_channels=4, prescribed_channels=1, prognostic_channels=8, embed_dim=192,
+                                   num_heads=(6, 12, 12, 6), window_size=(2, 7, 7), patch_size=(1, 1), n_lat=128, n_lon=256,
+                                   context_size=1)
+
+        def batch(dev):
+            kw = dict(constants=torch.randn(1, 1, 4, 128, 256, generator=g).to(dev),
+                      prescribed=torch.randn(1, 2, 1, 128, 256, generator=g).to(dev),
+                      prognostic=torch.randn(1, 2, 8, 128, 256, generator=g).to(dev))
+            return kw, torch.randn(1, 1, 8, 128, 256, generator=g).to(dev), 1
+        run("dlwpbench PanguWeather 128x256 window(2,7,7) E192 (C4) B1 T2", m, batch, a.steps, use_graph=not a.no_graph, lr=1e-4)
     if a.which in ("sfno", "all"):
         # BASELINE configs[2] (C3): dlwpbench SFNO2DModule, configs/model/sfno.yaml with 5 prognostic variables, 32x64
         for B in ((4, 16) if a.which == "sfno" else (16,)):
