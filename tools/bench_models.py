@@ -4,7 +4,7 @@ rollout models built on libdlwpmi's kernels, at the reference's nsbench / dlwpbe
 forward rollout + MSE + backward (autograd over the HIP ops) + one fused Adam launch on the flat parameter
 buffer, captured into a hipGraph by train_engine.GraphedTrainStep (--no-graph: eager dispatch).
 
-    python tools/bench_models.py [afno|afno_tiled|afno_fcn|swin|swin_c4|sfno|pangu|pangu_c4|all] [--steps N]
+    python tools/bench_models.py [afno|afno_tiled|afno_fcn|swin|swin_c4|swin_dlwp|sfno|pangu|pangu_c4|all] [--steps N]
 """
 import argparse
 import json
@@ -107,6 +107,19 @@ def main():
                       prognostic=torch.randn(2, 2, 8, 128, 256, generator=g).to(dev))
             return kw, torch.randn(2, 1, 8, 128, 256, generator=g).to(dev), 2
         run("dlwpbench SwinTransformer 128x256 window7 E96 depths[4,4] (C4) B2 T2", m, batch, a.steps, use_graph=not a.no_graph)
+    if a.which in ("swin_dlwp",):
+        # dlwpbench configs/model/swintransformer.yaml as shipped: 32x64, patch 1, whole-map windows (N = 2048 at stage 0)
+        m = dlwpbench.SwinTransformer(constant_channels=4, prescribed_channels=1, prognostic_channels=8, context_size=1,
+                                      img_height=32, img_width=64, patch_size=1, embed_dim=96, depths=[4, 4], num_heads=[4, 4],
+                                      drop_path_rate=0.0)
+
+        def batch(dev):
+            kw = dict(constants=torch.randn(4, 1, 4, 32, 64, generator=g).to(dev),
+                      prescribed=torch.randn(4, 5, 1, 32, 64, generator=g).to(dev),
+                      prognostic=torch.randn(4, 5, 8, 32, 64, generator=g).to(dev))
+            return kw, torch.randn(4, 4, 8, 32, 64, generator=g).to(dev), 4
+        run("dlwpbench SwinTransformer 32x64 p1 E96 depths[4,4] whole-map windows B4 T5", m, batch, a.steps,
+            use_graph=not a.no_graph)
     if a.which in ("pangu_c4",):
         m = dlwpbench.PanguWeather(constant_channels=4, prescribed_channels=1, prognostic_channels=8, embed_dim=192,
                                    num_heads=(6, 12, 12, 6), window_size=(2, 7, 7), patch_size=(1, 1), n_lat=128, n_lon=256,

@@ -13,7 +13,13 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/tools/probe_spatial.py > /dev/null 2>&1
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write fno_spatial_kernel $O/traffic.json "fno_spatial_kernel<2,1>" > $O/traffic.log 2>&1
 timeout 600 python3 $R/tools/bench_models.py all --steps 10 > $O/models.jsonl 2> $O/models.err
-for m in afno swin sfno pangu; do
+for m in swin_dlwp swin_c4 pangu_c4 afno_fcn; do
+  timeout 300 python3 $R/tools/bench_models.py $m --steps 5 2>> $O/models.err | grep '"model"' >> $O/models.jsonl
+done
+for m in sfno afno_fcn; do
+  timeout 300 python3 $R/tools/bench_models.py $m --steps 5 --precision bf16 2>> $O/models.err | grep '"model"' >> $O/models.jsonl
+done
+for m in afno swin sfno pangu afno_fcn; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$m -- python3 $R/tools/bench_models.py $m --steps 5 > /dev/null 2>&1
 done
 find $O -name "*_kernel_trace.csv" -delete
