@@ -45,3 +45,32 @@ def test_graphed_step_matches_eager(cuda, make):
             assert abs(a - b) <= 2e-4 * abs(b), (use_graph, losses, ref_losses)
         for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
             assert (p - q).abs().max().item() <= 2e-4, (use_graph, n)
+
+
+def test_graphed_step_with_allreduce_split_capture(cuda):
+    """With a gradient all-reduce the capture is split (forward+backward | all-reduce | optimizer).  One-rank process
+    group: the reduce is the identity, so the trajectory must equal the single-graph one."""
+    import os
+    import torch.distributed as dist
+    from dlwp_benchmark_amd import ddp
+    from dlwp_benchmark_amd.train_engine import GraphedTrainStep
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        created = True
+    try:
+        g = torch.Generator().manual_seed(11)
+        u = torch.randn(2, 7, 1, 16, 16, generator=g).to(cuda)
+        x, y = u[:, :-1].contiguous(), u[:, 1:].contiguous()
+        call = lambda m, kw: m(kw["x"], 2)   # noqa: E731
+        plain = GraphedTrainStep(_afno().to(cuda).train(), {"x": x}, y, lr=1e-3, call=call)
+        split = GraphedTrainStep(_afno().to(cuda).train(), {"x": x}, y, lr=1e-3, call=call, allreduce=ddp.FlatGradAllReduce())
+        for _ in range(3):
+            a, b = plain().item(), split().item()
+            assert abs(a - b) <= 1e-5 * abs(a), (a, b)
+        assert (plain.flat - split.flat).abs().max().item() <= 1e-5
+    finally:
+        if created:
+            dist.destroy_process_group()
