@@ -19,6 +19,11 @@ void dlwp_set_error(const char* fmt, ...);
 // raise a kernel's dynamic-LDS limit once (cached per kernel, so steady-state launches and
 // graph capture never call hipFuncSetAttribute)
 int dlwp_ensure_lds(const void* kernel, size_t bytes, const char* what);
+// Zero fills as ordinary kernels.  hipMemsetAsync / hipMemset2DAsync nodes captured into a hipGraph were seen to write a
+// garbage pattern instead of zero on later replays once other allocations had happened in the process (ROCm 7.2,
+// intermittent; DESIGN.md §4 "lessons"), so nothing on a capturable path uses the runtime's memset.
+int dlwp_zero_f32(float* p, long long n, void* stream);
+int dlwp_zero_2d_f32(float* p, long long ld, int rows, int cols, void* stream);
 
 #define DLWP_HIP(call)                                                              \
     do {                                                                            \

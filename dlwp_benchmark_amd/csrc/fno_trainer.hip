@@ -183,9 +183,9 @@ int enqueue_loss_backward(dlwp_fno_trainer* tr, const float* grad_out, hipStream
         DLWP_HIP(hipMemcpyAsync(tr->g_out, grad_out, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     } else {
         // fused nn.MSELoss(reduction="mean") against the trainer's target buffer
-        DLWP_HIP(hipMemsetAsync(tr->loss, 0, sizeof(float), s));
+        if ((rc = dlwp_zero_f32(tr->loss, 1, s))) return rc;
         if ((rc = dlwp_sqerr_sum(tr->out, tr->y, n, 1.0f / (float)n, tr->loss, s))) return rc;
-        DLWP_HIP(hipMemsetAsync(tr->g_out, 0, n * sizeof(float), s));
+        if ((rc = dlwp_zero_f32(tr->g_out, n, s))) return rc;
         mse_scale = 2.0f / (float)n;
     }
     for (int k = tr->ncalls - 1; k >= 0; --k) {

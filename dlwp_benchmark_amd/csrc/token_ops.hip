@@ -483,7 +483,10 @@ extern "C" int dlwp_gemm(const float* A, const float* B, float* C, int M, int N,
     if (!epilogue && tiles < 256 && K >= 8 * BK) splits = std::min(ceil_div(512, tiles), K / (4 * BK));
     int kchunk = ceil_div(ceil_div(K, splits), BK) * BK;
     splits = ceil_div(K, kchunk);
-    if (splits > 1 && !accumulate) DLWP_HIP(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, (hipStream_t)stream));
+    if (splits > 1 && !accumulate) {
+        const int zrc = dlwp_zero_2d_f32(C, ldc, M, N, stream);
+        if (zrc) return zrc;
+    }
     GemmDev a{A, B, bias, residual, C, preact, rowsum, M, N, K, lda, ldb, ldc, act, accumulate, kchunk, splits,
               1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.f};
     return gemm_dispatch(a, transA, transB, T, stream);
@@ -511,8 +514,7 @@ extern "C" int dlwp_gemm_batched(const float* A, const float* B, float* C, int M
         // C must start from zero: every batch's [M x N] block (row pitch ldc)
         for (int z1 = 0; z1 < nb1; ++z1)
             for (int z2 = 0; z2 < nb2; ++z2)
-                DLWP_HIP(hipMemset2DAsync(C + z1 * sC1 + z2 * sC2, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M,
-                                          (hipStream_t)stream));
+                if (int zrc = dlwp_zero_2d_f32(C + z1 * sC1 + z2 * sC2, ldc, M, N, stream)) return zrc;
     }
     GemmDev a{A, B, bias, residual, C, preact, nullptr, M, N, K, lda, ldb, ldc, act, accumulate, kchunk, splits,
               nb1 * nb2, nb2, res_before_act, sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2, sBi1, sBi2, act_param};

@@ -121,6 +121,19 @@ __global__ __launch_bounds__(256) void error_moments_kernel(const float* __restr
     }
 }
 
+__global__ __launch_bounds__(256) void zero_kernel(float* __restrict__ p, long long n) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void zero_2d_kernel(float* __restrict__ p, long long ld, int rows, int cols) {
+    const long long n = (long long)rows * cols, stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const long long r = i / cols;
+        p[r * ld + (i - r * cols)] = 0.f;
+    }
+}
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, float* out) {
     float acc = 0.f;
     const long long n4 = n / 4;
@@ -205,6 +218,22 @@ extern "C" int dlwp_error_moments(const float* out, const float* target, const f
     const int ny = (int)std::max<long long>(1, std::min<long long>(64, per / 4096));
     hipLaunchKernelGGL(error_moments_kernel, dim3(G, ny), dim3(256), 0, (hipStream_t)stream, out, target, climatology,
                        row_weights, B, G, H, W, moments);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+int dlwp_zero_f32(float* p, long long n, void* stream) {
+    if (n <= 0) return DLWP_OK;
+    hipLaunchKernelGGL(zero_kernel, dim3((int)std::min<long long>((n + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream, p, n);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+int dlwp_zero_2d_f32(float* p, long long ld, int rows, int cols, void* stream) {
+    const long long n = (long long)rows * cols;
+    if (n <= 0) return DLWP_OK;
+    hipLaunchKernelGGL(zero_2d_kernel, dim3((int)std::min<long long>((n + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream, p, ld,
+                       rows, cols);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }

@@ -1,0 +1,106 @@
+"""The caller of the hot path: the nsbench training script's epoch loop, validation and checkpoint policy
+(src/nsbench/scripts/train.py:57-175, utils/utils.py:11-39) around the fused train step.
+
+What is kept: Adam(lr) with CosineAnnealingLR(T_max = epochs) stepped once per epoch (:72-73,171), MSE criterion, the
+validation pass without gradients (:137-147), the `_last` / `_best` checkpoint policy (:150-156: a new best validation
+error writes `<name>_best.ckpt`, anything else and the final epoch write `<name>_last.ckpt`), the checkpoint dictionary
+(model_state_dict, optimizer_state_dict, scheduler_state_dict, epoch + 1, iteration, best_val_error) and resuming from
+`_last` (:78-87).  What differs: batches come from the seeded rank-sharded permutation of ddp.py instead of a shuffling
+DataLoader, the step is the captured hipGraph, scalars are returned / printed instead of written to TensorBoard, and the
+checkpoint is written synchronously (the reference's writer thread reads live parameters while the next epoch trains,
+App. B-10).
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import ddp
+from .evaluate import error_moments
+
+
+def cosine_lr(base_lr, epoch, t_max, eta_min=0.0):
+    """torch.optim.lr_scheduler.CosineAnnealingLR in closed form."""
+    return eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * epoch / t_max)) / 2
+
+
+def _optimizer_state(opt):
+    return {"exp_avg": opt.exp_avg.cpu(), "exp_avg_sq": opt.exp_avg_sq.cpu(), "step": opt.step_count.cpu(), "lr": opt.lr,
+            "betas": opt.betas, "eps": opt.eps, "layout": "flat (dlwp_benchmark_amd.fno_engine.FusedAdam)"}
+
+
+def write_checkpoint(model, optimizer, scheduler_state, epoch, iteration, best_val_error, dst_path):
+    """utils.write_checkpoint (:11-39): same keys; the optimizer entry holds the flat Adam moments."""
+    os.makedirs(os.path.dirname(dst_path), exist_ok=True)
+    torch.save({"model_state_dict": {k: v.cpu() for k, v in model.state_dict().items()},
+                "optimizer_state_dict": _optimizer_state(optimizer), "scheduler_state_dict": scheduler_state,
+                "epoch": epoch + 1, "iteration": iteration, "best_val_error": best_val_error}, dst_path)
+
+
+def load_checkpoint(path, model, optimizer=None):
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    model.load_state_dict(ck["model_state_dict"])
+    if optimizer is not None and isinstance(ck.get("optimizer_state_dict"), dict) and "exp_avg" in ck["optimizer_state_dict"]:
+        st = ck["optimizer_state_dict"]
+        optimizer.exp_avg.copy_(st["exp_avg"])
+        optimizer.exp_avg_sq.copy_(st["exp_avg_sq"])
+        optimizer.step_count.copy_(st["step"])
+    return ck
+
+
+@torch.no_grad()
+def validation_mse(model, u_val, sequence_length, batch_size, teacher_forcing_steps, device):
+    """MSE over every validation sample's first window (train.py:137-147 concatenates all outputs, then one MSE)."""
+    tot, cnt = 0.0, 0
+    for i0 in range(0, u_val.shape[0], batch_size):
+        seq = u_val[i0:i0 + batch_size, :sequence_length].to(device)
+        x, y = seq[:, :-1].contiguous(), seq[:, 1:].contiguous()
+        y_hat = model(x, teacher_forcing_steps)
+        B, T, D, H, W = y_hat.shape
+        m = error_moments(y_hat.reshape(B, T, D * H, W), y.reshape(B, T, D * H, W))
+        tot += m[0].sum().item()
+        cnt += y_hat.numel()
+    return tot / max(cnt, 1)
+
+
+def train_ns(model, u_train, u_val, name="model", epochs=10, batch_size=4, sequence_length=21, learning_rate=1e-3,
+             teacher_forcing_steps=10, val_teacher_forcing_steps=None, noise=0.0, clip_gradients=False, seed=1234,
+             out_dir="outputs", save_model=True, continue_training=False, verbose=False):
+    """Train an nsbench FNO-family module (anything with make_optimizer / train_step) on trajectories u [N, T, D, H, W].
+    Returns a list of per-epoch dicts(epoch, lr, train_mse, val_mse)."""
+    device = next(model.parameters()).device
+    rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+    world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    opt = model.make_optimizer(lr=learning_rate)
+    reducer = ddp.FlatGradAllReduce() if world > 1 else None
+    ckpt_last = os.path.join(out_dir, name, "checkpoints", f"{name}_last.ckpt")
+    epoch0, iteration, best = 0, 0, float("inf")
+    if continue_training:
+        ck = load_checkpoint(ckpt_last, model, opt)
+        epoch0, iteration, best = ck["epoch"], ck["iteration"], ck["best_val_error"]
+    vtf = teacher_forcing_steps if val_teacher_forcing_steps is None else val_teacher_forcing_steps
+    log = []
+    for epoch in range(epoch0, epochs):
+        opt.lr = cosine_lr(learning_rate, epoch, epochs)
+        losses = []
+        for idx in ddp.shard_indices(u_train.shape[0], epoch, rank, world, batch_size, seed):
+            xs, ys = zip(*(ddp.ns_sample(u_train, int(i), epoch, sequence_length, noise, seed) for i in idx))
+            x, y = torch.stack(xs).to(device), torch.stack(ys).to(device)
+            loss = model.train_step(x, y, teacher_forcing_steps, optimizer=opt, grad_scale=1.0 / world, allreduce=reducer,
+                                    clip_max_norm=opt.lr if clip_gradients else None)     # clip threshold = lr (:123-125)
+            losses.append(loss.clone())   # the step returns its persistent loss buffer; clones stay on the device (no sync)
+            iteration += 1
+        train_mse = torch.stack(losses).mean().item() if losses else float("nan")
+        val_mse = validation_mse(model, u_val, sequence_length, batch_size, vtf, device)
+        if save_model and rank == 0:
+            sched = {"T_max": epochs, "last_epoch": epoch, "base_lrs": [learning_rate], "_last_lr": [opt.lr]}
+            if val_mse > best or epoch == epochs - 1:
+                dst = ckpt_last
+            else:
+                best, dst = val_mse, ckpt_last.replace("last", "best")
+            write_checkpoint(model, opt, sched, epoch, iteration, best, dst)
+        log.append({"epoch": epoch, "lr": opt.lr, "train_mse": train_mse, "val_mse": val_mse})
+        if verbose and rank == 0:
+            print(f"Epoch {str(epoch).zfill(3)}/{epochs}\tMSE train: {train_mse:.2E}\tMSE val: {val_mse:.2E}")
+    return log

@@ -1,0 +1,59 @@
+"""The epoch loop around the fused step (train_loop.py): learning on generated Navier-Stokes data, the _last/_best
+checkpoint policy and an exact resume."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(cuda):
+    from dlwp_benchmark_amd import nsbench
+    torch.manual_seed(7)
+    return nsbench.TFNO2DModule(n_modes=[8, 8], in_channels=1, hidden_channels=16, lifting_channels=32, projection_channels=32,
+                                out_channels=1, n_layers=2, context_size=2).to(cuda)
+
+
+def test_training_learns_checkpoints_and_resumes(cuda, tmp_path):
+    from dlwp_benchmark_amd import nsdata, train_loop
+    data = nsdata.generate_data(resolution=32, n_samples=10, batch_size=10, max_simulation_time=10, delta_t=1e-2, seed=3)
+    u = torch.from_numpy(data["u"])
+    u = (u - u.mean()) / u.std()
+    u_train, u_val = u[:8], u[8:]
+    kw = dict(batch_size=4, sequence_length=9, learning_rate=5e-3, teacher_forcing_steps=4, out_dir=str(tmp_path), name="t")
+    log = train_loop.train_ns(_model(cuda), u_train, u_val, epochs=6, **kw)
+    assert log[-1]["train_mse"] < log[0]["train_mse"] and log[-1]["val_mse"] < log[0]["val_mse"], log
+    assert abs(log[0]["lr"] - 5e-3) < 1e-12 and log[-1]["lr"] < log[0]["lr"]
+    ck_dir = os.path.join(str(tmp_path), "t", "checkpoints")
+    assert os.path.exists(os.path.join(ck_dir, "t_last.ckpt")) and os.path.exists(os.path.join(ck_dir, "t_best.ckpt"))
+    ck = torch.load(os.path.join(ck_dir, "t_last.ckpt"), weights_only=False)
+    assert set(ck) == {"model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "epoch", "iteration", "best_val_error"}
+    assert ck["epoch"] == 6 and ck["iteration"] == 12
+    assert any(k.startswith("fno.") for k in ck["model_state_dict"])
+    # resume: epochs 0-2, stop, continue_training for epochs 3-5 == the uninterrupted run (seeded batches, restored Adam
+    # moments / step count; the cosine schedule is a function of (epoch, total epochs))
+    out2 = str(tmp_path / "resume")
+
+    class Stop(Exception):
+        pass
+
+    first = _model(cuda)
+    orig = train_loop.write_checkpoint
+
+    def stop_after_epoch_2(model, optimizer, sched, epoch, iteration, best, dst):
+        orig(model, optimizer, sched, epoch, iteration, best, os.path.join(out2, "t", "checkpoints", "t_last.ckpt"))
+        if epoch == 2:
+            raise Stop
+
+    train_loop.write_checkpoint = stop_after_epoch_2
+    try:
+        with pytest.raises(Stop):
+            train_loop.train_ns(first, u_train, u_val, epochs=6, **dict(kw, out_dir=out2))
+    finally:
+        train_loop.write_checkpoint = orig
+    log_b = train_loop.train_ns(_model(cuda), u_train, u_val, epochs=6, continue_training=True, **dict(kw, out_dir=out2))
+    assert [e["epoch"] for e in log_b] == [3, 4, 5]
+    for a_, b_ in zip(log[3:], log_b):
+        assert abs(a_["train_mse"] - b_["train_mse"]) <= 1e-4 * abs(a_["train_mse"]), (log, log_b)
+        assert abs(a_["val_mse"] - b_["val_mse"]) <= 1e-4 * abs(a_["val_mse"])
