@@ -1,0 +1,163 @@
+// Window partition / reverse for shifted-window attention as single gather kernels.
+// Reference (each of these is a separate full-tensor copy there): SwinTransformerBlock.forward
+// src/nsbench/models/swintransformer/swin_transformer.py:213-250 (F.pad -> torch.roll -> window_partition ... window_reverse ->
+// torch.roll -> crop), EarthSpecificBlock.forward src/dlwpbench/models/panguweather/panguweather.py:283-317 (ZeroPad3d ->
+// roll -> window_partition ... window_reverse -> roll -> crop3d).
+//
+// tokens x [B][D0][D1][D2][C]  <->  windows [B * nW][N = w0 w1 w2][C]
+// padded canvas P_d = f_d + D_d + back pad (a multiple of w_d); rolled[i] = padded[(i + s_d) mod P_d] (torch.roll by -s_d);
+// window (i0,i1,i2) sits at index i0*sw0 + i1*sw1 + i2*sw2 inside a sample's nW windows (Swin: row-major; Pangu:
+// longitude-major, panguweather utils window_partition).  Padding per axis: constant zero or circular.
+//   gather : windows[...] = rolled padded x           (forward of partition; also the adjoint of reverse)
+//   scatter: x[b][q] = windows at the rolled position of q + f   (forward of reverse + crop; with `dup` it sums every padded
+//            copy of q, which is the adjoint of a circularly padded gather)
+#include "common.cuh"
+#include "dlwpmi_internal.h"
+
+namespace {
+
+struct WinDev {
+    const float* src;
+    float* dst;
+    int B, C, D[3], P[3], f[3], s[3], w[3], nw[3], circ[3];
+    long long sw[3];
+    int nW, N, dup;
+    FastDiv dC4, dN, dnW, dw12, dw2, dnw12, dnw2, dD2, dD1, dD0, dwd[3];   // umulhi divisions (index spaces < 2^31 / 256 per step)
+};
+
+__device__ __forceinline__ int pmod(int a, int m) { a %= m; return a < 0 ? a + m : a; }
+
+// one thread per (output token, 4 channels)
+__global__ __launch_bounds__(256) void win_gather_kernel(WinDev a) {
+    const int C4 = a.C >> 2;
+    const long long total = (long long)a.B * a.nW * a.N * C4;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int tok = fastdiv((int)e, a.dC4);
+        const int c4 = (int)e - tok * C4;
+        const int bw = fastdiv(tok, a.dN);
+        const int n = tok - bw * a.N;
+        const int b = fastdiv(bw, a.dnW), wlin = bw - b * a.nW;      // canonical (i0,i1,i2) row-major
+        const int i0 = fastdiv(wlin, a.dnw12), r1 = wlin - i0 * a.nw[1] * a.nw[2], i1 = fastdiv(r1, a.dnw2), i2 = r1 - i1 * a.nw[2];
+        const int j0 = fastdiv(n, a.dw12), r2 = n - j0 * a.w[1] * a.w[2], j1 = fastdiv(r2, a.dw2), j2 = r2 - j1 * a.w[2];
+        const int ii[3] = {i0, i1, i2}, jj[3] = {j0, j1, j2};
+        int q[3];
+        bool ok = true;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int p = pmod(ii[d] * a.w[d] + jj[d] + a.s[d], a.P[d]);
+            int v = p - a.f[d];
+            if (a.circ[d]) v = pmod(v, a.D[d]);
+            else ok = ok && v >= 0 && v < a.D[d];
+            q[d] = v;
+        }
+        f32x4 val = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok) val = *reinterpret_cast<const f32x4*>(a.src + ((((long long)b * a.D[0] + q[0]) * a.D[1] + q[1]) * a.D[2] + q[2]) * a.C + 4 * c4);
+        const long long wout = (long long)b * a.nW + i0 * a.sw[0] + i1 * a.sw[1] + i2 * a.sw[2];
+        *reinterpret_cast<f32x4*>(a.dst + (wout * a.N + n) * a.C + 4 * c4) = val;
+        (void)tok;
+    }
+}
+
+__device__ __forceinline__ f32x4 win_read(const WinDev& a, int b, const int (&p)[3], int c4) {
+    int i[3], j[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int r = pmod(p[d] - a.s[d], a.P[d]);
+        i[d] = fastdiv(r, a.dwd[d]);
+        j[d] = r - i[d] * a.w[d];
+    }
+    const long long wout = (long long)b * a.nW + i[0] * a.sw[0] + i[1] * a.sw[1] + i[2] * a.sw[2];
+    const int n = (j[0] * a.w[1] + j[1]) * a.w[2] + j[2];
+    return *reinterpret_cast<const f32x4*>(a.src + (wout * a.N + n) * a.C + 4 * c4);
+}
+
+__global__ __launch_bounds__(256) void win_scatter_kernel(WinDev a) {
+    const int C4 = a.C >> 2;
+    const long long total = (long long)a.B * a.D[0] * a.D[1] * a.D[2] * C4;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int tok = fastdiv((int)e, a.dC4);
+        const int c4 = (int)e - tok * C4;
+        const int t1 = fastdiv(tok, a.dD2);
+        const int q2 = tok - t1 * a.D[2];
+        const int t0 = fastdiv(t1, a.dD1);
+        const int q1 = t1 - t0 * a.D[1];
+        const int b = fastdiv(t0, a.dD0), q0 = t0 - b * a.D[0];
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!a.dup) {
+            const int p[3] = {q0 + a.f[0], q1 + a.f[1], q2 + a.f[2]};
+            acc = win_read(a, b, p, c4);
+        } else {
+            // every padded position that holds a copy of (q0,q1,q2): p_d = q_d + f_d + k D_d inside [0, P_d), circular axes only
+            for (int p0 = q0 + a.f[0] - (a.circ[0] ? ((q0 + a.f[0]) / a.D[0]) * a.D[0] : 0); p0 < a.P[0]; p0 += a.D[0]) {
+                for (int p1 = q1 + a.f[1] - (a.circ[1] ? ((q1 + a.f[1]) / a.D[1]) * a.D[1] : 0); p1 < a.P[1]; p1 += a.D[1]) {
+                    for (int p2 = q2 + a.f[2] - (a.circ[2] ? ((q2 + a.f[2]) / a.D[2]) * a.D[2] : 0); p2 < a.P[2]; p2 += a.D[2]) {
+                        const int p[3] = {p0, p1, p2};
+                        const f32x4 v = win_read(a, b, p, c4);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[k] += v[k];
+                        if (!a.circ[2]) break;
+                    }
+                    if (!a.circ[1]) break;
+                }
+                if (!a.circ[0]) break;
+            }
+        }
+        *reinterpret_cast<f32x4*>(a.dst + (long long)tok * a.C + 4 * c4) = acc;
+    }
+}
+
+int win_setup(WinDev& a, const float* src, float* dst, int B, int C, const int* D, const int* P, const int* f, const int* s,
+              const int* w, const long long* sw, const int* circ, const char* who) {
+    DLWP_REQUIRE(src && dst && D && P && f && s && w && sw && circ && B > 0 && C > 0, DLWP_E_INVALID, "%s: bad argument", who);
+    DLWP_REQUIRE(C % 4 == 0, DLWP_E_UNSUPPORTED, "%s: channel count %d must be a multiple of 4", who, C);
+    a.src = src; a.dst = dst; a.B = B; a.C = C; a.nW = 1; a.N = 1;
+    for (int d = 0; d < 3; ++d) {
+        DLWP_REQUIRE(D[d] > 0 && w[d] > 0 && P[d] >= D[d] + f[d] && P[d] % w[d] == 0 && f[d] >= 0, DLWP_E_INVALID,
+                     "%s: axis %d: size %d, front pad %d, padded %d, window %d are inconsistent", who, d, D[d], f[d], P[d], w[d]);
+        a.D[d] = D[d]; a.P[d] = P[d]; a.f[d] = f[d]; a.s[d] = ((s[d] % P[d]) + P[d]) % P[d]; a.w[d] = w[d]; a.nw[d] = P[d] / w[d];
+        a.sw[d] = sw[d]; a.circ[d] = circ[d] != 0;
+        a.nW *= a.nw[d]; a.N *= w[d];
+        a.dwd[d] = make_fastdiv(w[d]);
+    }
+    const long long toks_w = (long long)B * a.nW * a.N, toks_x = (long long)B * D[0] * D[1] * D[2], C4 = C / 4;
+    const long long total = std::max(toks_w, toks_x) * C4;
+    // the umulhi divisions are exact while numerator * divisor < 2^32 (common.cuh FastDiv)
+    const long long lim = 1ll << 32;
+    const bool fits = total < (1ll << 31) && total * C4 < lim && toks_w * a.N < lim && (long long)B * a.nW * a.nW < lim &&
+                      toks_x * D[2] < lim && (long long)B * D[0] * D[1] * D[1] < lim && (long long)B * D[0] * D[0] < lim &&
+                      (long long)a.N * w[1] * w[2] < lim && (long long)a.nW * a.nw[1] * a.nw[2] < lim;
+    DLWP_REQUIRE(fits, DLWP_E_UNSUPPORTED, "%s: %lld vector elements exceed the 32-bit index arithmetic of this kernel; split the batch", who, total);
+    a.dC4 = make_fastdiv(C / 4); a.dN = make_fastdiv(a.N); a.dnW = make_fastdiv(a.nW);
+    a.dw12 = make_fastdiv(w[1] * w[2]); a.dw2 = make_fastdiv(w[2]);
+    a.dnw12 = make_fastdiv(a.nw[1] * a.nw[2]); a.dnw2 = make_fastdiv(a.nw[2]);
+    a.dD2 = make_fastdiv(D[2]); a.dD1 = make_fastdiv(D[1]); a.dD0 = make_fastdiv(D[0]);
+    return DLWP_OK;
+}
+
+int grid_for(long long n) { return (int)std::min<long long>((n + 255) / 256, 8192); }
+
+}  // namespace
+
+extern "C" int dlwp_window_gather(const float* x, float* windows, int B, int C, const int* dims, const int* padded,
+                                  const int* front, const int* shift, const int* window, const long long* wstride,
+                                  const int* circular, void* stream) {
+    WinDev a{};
+    int rc = win_setup(a, x, windows, B, C, dims, padded, front, shift, window, wstride, circular, "window_gather");
+    if (rc) return rc;
+    hipLaunchKernelGGL(win_gather_kernel, dim3(grid_for((long long)B * a.nW * a.N * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_window_scatter(const float* windows, float* x, int B, int C, const int* dims, const int* padded,
+                                   const int* front, const int* shift, const int* window, const long long* wstride,
+                                   const int* circular, int sum_copies, void* stream) {
+    WinDev a{};
+    int rc = win_setup(a, windows, x, B, C, dims, padded, front, shift, window, wstride, circular, "window_scatter");
+    if (rc) return rc;
+    a.dup = sum_copies != 0;
+    hipLaunchKernelGGL(win_scatter_kernel, dim3(grid_for((long long)B * dims[0] * dims[1] * dims[2] * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, a);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}

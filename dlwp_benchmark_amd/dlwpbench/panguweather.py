@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..nsbench.swin_transformer import window_attention_core
+from ..window_ops import WindowSpec, partition, reverse
 from ..token_ops import LayerNorm, Linear, Mlp, PatchConv2d, UpConvT2d
 
 _DEFAULT_SHIFT = (1, 3, 6)   # panguweather.py:243
@@ -106,6 +107,8 @@ class EarthSpecificBlock(nn.Module):
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
         self.roll = bool(self.shift_size[0] and self.shift_size[1] and self.shift_size[2])
+        self._wspec = WindowSpec(self.input_resolution, self.window_size, front=(p[4], p[2], p[0]), back=(p[5], p[3], p[1]),
+                                 order=(2, 0, 1))      # windows longitude-major (utils window_partition)
         labels = None
         if self.roll:
             Pl, Lat, Lon = self.pad_resolution
@@ -128,6 +131,18 @@ class EarthSpecificBlock(nn.Module):
         B, L_, C = x.shape
         assert L_ == Pl * Lat * Lon, "input feature has wrong size"
         p, win, sh = self.padding, self.window_size, self.shift_size
+        if C % 4 == 0:
+            # ZeroPad3d + roll + partition and reverse + roll back + crop3d as one gather kernel each.  The forward roll
+            # uses the latitude shift for the longitude axis, the backward roll the longitude shift (reference :291 vs :310)
+            spec = self._wspec
+            fwd_shift = (sh[0], sh[1], sh[1]) if self.roll else (0, 0, 0)
+            rev_shift = sh if self.roll else (0, 0, 0)
+            t = self.attn(partition(self.norm1(x), spec, fwd_shift), self._labels if self.roll else None, spec.nW)
+            t = reverse(t, spec, B, rev_shift)
+            x = x + self.drop_path(t)
+            if isinstance(self.drop_path, DropPath) and self.drop_path.p > 0 and self.training:
+                return x + self.drop_path(self.mlp(self.norm2(x)))
+            return self.mlp(self.norm2(x), residual=x)
         t = self.norm1(x).view(B, Pl, Lat, Lon, C)
         t = F.pad(t.permute(0, 4, 1, 2, 3), p).permute(0, 2, 3, 4, 1)
         Plp, Latp, Lonp = self.pad_resolution

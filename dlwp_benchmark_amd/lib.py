@@ -64,6 +64,8 @@ SIGNATURES = {
     "dlwp_afno_wq_fold": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_set_gemm_precision": (_I, [_I]),
     "dlwp_get_gemm_precision": (_I, []),
+    "dlwp_window_gather": (_I, [_V, _V, _I, _I] + [_V] * 7 + [_V]),
+    "dlwp_window_scatter": (_I, [_V, _V, _I, _I] + [_V] * 7 + [_I, _V]),
     "dlwp_gemm": (_I, [_V, _V, _V] + [_I] * 8 + [_V, _I, _V, _V, _I, _V, _V]),
     "dlwp_gemm_batched": (_I, [_V, _V, _V] + [_I] * 10 + [_L] * 6 + [_V, _L, _L, _I, _F, _V, _V, _L, _L, _I, _I, _V]),
     "dlwp_act_bwd": (_I, [_V, _V, _V, _L, _I, _F, _V]),

@@ -21,6 +21,7 @@ import torch.nn.functional as F
 
 from .. import lib as L
 from ..token_ops import _grad_slot, LayerNorm, Linear, Mlp, PatchConv2d, UpConvT2d
+from ..window_ops import WindowSpec, partition, reverse
 
 
 class _WindowAttnFn(torch.autograd.Function):
@@ -143,10 +144,16 @@ class SwinTransformerBlock(nn.Module):
         B, L_, C = x.shape
         H, W, ws, sh = self.H, self.W, self.window_size, self.shift_size
         assert L_ == H * W, "input feature has wrong size"
+        shifted = sh[0] > 0 or sh[1] > 0
+        if C % 4 == 0:
+            # pad + roll + partition and reverse + roll back + crop are one gather kernel each (window_ops.py)
+            spec = self._spec(H, W)
+            t = self.attn(partition(self.norm1(x), spec), labels if shifted else None, spec.nW)
+            x = x + reverse(t, spec, B)
+            return self.mlp(self.norm2(x), residual=x)
         t = self.norm1(x).view(B, H, W, C)
         t = _pad_hw(t, (ws[0] - H % ws[0]) % ws[0], (ws[1] - W % ws[1]) % ws[1], self.padding_mode)
         Hp, Wp = t.shape[1], t.shape[2]
-        shifted = sh[0] > 0 or sh[1] > 0
         if shifted:
             t = torch.roll(t, shifts=(-sh[0], -sh[1]), dims=(1, 2))
         nW = (Hp // ws[0]) * (Wp // ws[1])
@@ -156,6 +163,15 @@ class SwinTransformerBlock(nn.Module):
             t = torch.roll(t, shifts=(sh[0], sh[1]), dims=(1, 2))
         x = x + t[:, :H, :W, :].reshape(B, H * W, C)
         return self.mlp(self.norm2(x), residual=x)   # residual add fused into fc2's epilogue
+
+    def _spec(self, H, W):
+        key = (H, W)
+        if getattr(self, "_spec_key", None) != key:
+            ws, sh = self.window_size, self.shift_size
+            self._spec_val = WindowSpec((1, H, W), (1, ws[0], ws[1]), back=(0, (ws[0] - H % ws[0]) % ws[0], (ws[1] - W % ws[1]) % ws[1]),
+                                        shift=(0, sh[0], sh[1]), modes=("constant", self.padding_mode[0], self.padding_mode[1]))
+            self._spec_key = key
+        return self._spec_val
 
 
 class PatchMerging(nn.Module):

@@ -1,0 +1,99 @@
+"""Window partition / reverse for shifted-window attention on libdlwpmi's gather kernels (csrc/window_ops.hip):
+pad + roll + partition is ONE kernel, reverse + roll back + crop another (the reference runs each as a separate
+full-tensor copy: nsbench swin_transformer.py:213-250, dlwpbench panguweather.py:283-317).
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+
+class WindowSpec:
+    """Geometry of one partition: token grid `dims` (3 axes, leading 1s for 2-D), window sizes, front / back pads,
+    roll shift, per-axis padding mode ("constant" | "circular") and the order of the windows inside a sample
+    (`order`: axes from slowest to fastest, e.g. (0, 1, 2) row-major for Swin, (2, 0, 1) longitude-major for Pangu)."""
+
+    def __init__(self, dims, window, front=(0, 0, 0), back=(0, 0, 0), shift=(0, 0, 0), modes=("constant",) * 3, order=(0, 1, 2)):
+        self.dims, self.window, self.front, self.shift = tuple(dims), tuple(window), tuple(front), tuple(shift)
+        self.padded = tuple(f + d + b for f, d, b in zip(front, dims, back))
+        assert all(p % w == 0 for p, w in zip(self.padded, window)), "padded grid must be a multiple of the window"
+        self.nwin = tuple(p // w for p, w in zip(self.padded, window))
+        self.nW = self.nwin[0] * self.nwin[1] * self.nwin[2]
+        self.N = window[0] * window[1] * window[2]
+        self.circ = tuple(int(m == "circular") for m in modes)
+        stride, s = [0, 0, 0], 1
+        for ax in reversed(order):
+            stride[ax] = s
+            s *= self.nwin[ax]
+        self.wstride = tuple(stride)
+        i3, l3 = C.c_int * 3, C.c_longlong * 3
+        self._c = (i3(*self.dims), i3(*self.padded), i3(*self.front), i3(*self.window), l3(*self.wstride), i3(*self.circ))
+
+    def c_args(self, shift):
+        d, p, f, w, sw, circ = self._c
+        return d, p, f, (C.c_int * 3)(*shift), w, sw, circ
+
+
+def _gather(x, spec, shift, circ_override=None):
+    B, Cc = x.shape[0], x.shape[-1]
+    out = torch.empty(B * spec.nW, spec.N, Cc, device=x.device)
+    d, p, f, s, w, sw, circ = spec.c_args(shift)
+    if circ_override is not None:
+        circ = (C.c_int * 3)(*circ_override)
+    L.check(L.load().dlwp_window_gather(L.ptr(x), L.ptr(out), B, Cc, d, p, f, s, w, sw, circ, L.stream()))
+    return out
+
+
+def _scatter(wins, spec, shift, B, sum_copies):
+    Cc = wins.shape[-1]
+    out = torch.empty(B, spec.dims[0] * spec.dims[1] * spec.dims[2], Cc, device=wins.device)
+    d, p, f, s, w, sw, circ = spec.c_args(shift)
+    L.check(L.load().dlwp_window_scatter(L.ptr(wins), L.ptr(out), B, Cc, d, p, f, s, w, sw, circ, int(sum_copies), L.stream()))
+    return out
+
+
+class _PartitionFn(torch.autograd.Function):
+    """tokens [B, L, C] -> windows [B * nW, N, C] of the padded, rolled canvas."""
+
+    @staticmethod
+    def forward(ctx, x, spec, shift):
+        ctx.spec, ctx.shift, ctx.B = spec, shift, x.shape[0]
+        return _gather(x.contiguous().float(), spec, shift)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _scatter(g.contiguous(), ctx.spec, ctx.shift, ctx.B, sum_copies=any(ctx.spec.circ)), None, None
+
+
+class _ReverseFn(torch.autograd.Function):
+    """windows [B * nW, N, C] -> tokens [B, L, C]: un-roll by `shift`, drop the padding."""
+
+    @staticmethod
+    def forward(ctx, wins, spec, shift, B):
+        ctx.spec, ctx.shift = spec, shift
+        return _scatter(wins.contiguous().float(), spec, shift, B, sum_copies=False)
+
+    @staticmethod
+    def backward(ctx, g):
+        # padded positions were dropped: they receive zero gradient whatever the padding mode of the forward partition
+        return _gather(g.contiguous(), ctx.spec, ctx.shift, circ_override=(0, 0, 0)), None, None, None
+
+
+def _identity(spec, shift):
+    """One window = the whole unpadded, unshifted grid: tokens and windows are the same array."""
+    return spec.nW == 1 and spec.padded == spec.dims and not any(s % p for s, p in zip(shift, spec.padded))
+
+
+def partition(x, spec, shift=None):
+    shift = tuple(spec.shift if shift is None else shift)
+    if _identity(spec, shift):
+        return x.reshape(x.shape[0], spec.N, x.shape[-1])
+    return _PartitionFn.apply(x, spec, shift)
+
+
+def reverse(wins, spec, B, shift=None):
+    shift = tuple(spec.shift if shift is None else shift)
+    if _identity(spec, shift):
+        return wins.reshape(B, spec.N, wins.shape[-1])
+    return _ReverseFn.apply(wins, spec, shift, B)

@@ -251,6 +251,23 @@ int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, const int* i
 int dlwp_afno_wq_expand(const float* w, float* wq, int nb, int bs_in, int bs_out, void* stream);
 int dlwp_afno_wq_fold(const float* gq, float* gw, int nb, int bs_in, int bs_out, void* stream);
 
+/* Window partition / reverse of shifted-window attention as one gather each (the reference  */
+/* runs pad, roll, partition / reverse, roll, crop as separate full-tensor copies:             */
+/* nsbench swin_transformer.py:213-250, dlwpbench panguweather.py:283-317).                    */
+/* tokens x [B][D0][D1][D2][C] <-> windows [B*nW][w0*w1*w2][C]; all arrays have 3 entries       */
+/* (use 1 for unused leading axes): dims D, padded sizes P (multiples of the window), front     */
+/* pads, roll shifts s (rolled[i] = padded[(i + s) mod P], i.e. torch.roll by -s), window sizes, */
+/* strides of the window-grid index inside a sample's nW windows, circular (1) or zero (0)       */
+/* padding per axis.  scatter with sum_copies != 0 sums every padded copy of a token (adjoint    */
+/* of a circularly padded gather).  C must be a multiple of 4.                                   */
+int dlwp_window_gather(const float* x, float* windows, int B, int C, const int* dims,
+                       const int* padded, const int* front, const int* shift, const int* window,
+                       const long long* wstride, const int* circular, void* stream);
+int dlwp_window_scatter(const float* windows, float* x, int B, int C, const int* dims,
+                        const int* padded, const int* front, const int* shift, const int* window,
+                        const long long* wstride, const int* circular, int sum_copies,
+                        void* stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* Token-level building blocks of the AFNO / Swin / Pangu blocks (nn.Linear, nn.LayerNorm, */
 /* nn.GELU call sites: nsbench/models/fourcastnet/fourcastnet.py:44-46,213,233;             */
