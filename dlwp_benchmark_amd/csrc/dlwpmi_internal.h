@@ -7,6 +7,14 @@
 int dlwp_pwmlp_fwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, const float* w2,
                       const float* b2, const dlwp_chan_dst* y, const dlwp_chan_src* res, int B,
                       int Cin, int Ch, int Cout, int P, hipStream_t stream);
+// as dlwp_pwmlp_fwd_ex, plus (x1_out != nullptr) the W-axis pruned DFT of every finished output row written to x1_out
+// in dlwp_fno_rows_dft's layout -- the lifting MLP then feeds the first spectral block without a rows launch
+struct dlwp_fno_plan;
+bool dlwp_pwmlp_rows_fusable(const dlwp_fno_plan* plan, int Cout, int P);
+int dlwp_pwmlp_fwd_rows_ex(const dlwp_chan_src* x, const float* w1, const float* b1, const float* w2,
+                           const float* b2, const dlwp_chan_dst* y, const dlwp_chan_src* res, int B,
+                           int Cin, int Ch, int Cout, int P, const dlwp_fno_plan* rows_plan, float2* x1_out,
+                           hipStream_t stream);
 int dlwp_pwmlp_bwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, const float* w2,
                       const dlwp_chan_src* gy, const dlwp_chan_src* pred, const dlwp_chan_src* target,
                       float mse_scale, const dlwp_chan_dst* gx, int gx_accumulate, const dlwp_chan_dst* gres,

@@ -143,8 +143,10 @@ int enqueue_forward(dlwp_fno_trainer* tr, bool keep, hipStream_t s) {
         float2* xhat = tr->xhat + (long long)kk * NL * xhatB;
         dlwp_chan_src xs{nullptr, 0, 0, tr->src_tab + (long long)k * tr->Cin, tr->bstride_tab + (long long)k * tr->Cin};
         dlwp_chan_dst h0d{h0, tr->act, HW, nullptr, nullptr};
-        if ((rc = dlwp_pwmlp_fwd_ex(&xs, w.lw1, w.lb1, w.lw2, w.lb2, &h0d, nullptr, c.B, tr->Cin, c.lifting, C, HW, s))) return rc;
-        if ((rc = dlwp_fno_rows_dft(tr->plan, h0, 0, 0, tr->x1, c.B, s))) return rc;
+        // lifting MLP with the first block's W-axis DFT in its epilogue where the shapes allow (one launch less per net
+        // call); otherwise the callee runs the separate rows kernel
+        if ((rc = dlwp_pwmlp_fwd_rows_ex(&xs, w.lw1, w.lb1, w.lw2, w.lb2, &h0d, nullptr, c.B, tr->Cin, c.lifting, C, HW,
+                                         tr->plan, tr->x1, s))) return rc;
         for (int l = 0; l < NL; ++l) {
             if ((rc = dlwp_fno_mix_fwd(tr->plan, tr->x1, reinterpret_cast<const float2*>(w.spec(l)),
                                        xhat + l * xhatB, tr->spec, c.B, s))) return rc;

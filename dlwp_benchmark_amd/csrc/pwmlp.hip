@@ -12,6 +12,7 @@
 // with one hardware float atomic per element per workgroup.
 #include "common.cuh"
 #include "dlwpmi_internal.h"
+#include "fno_rows.cuh"
 
 namespace {
 
@@ -67,6 +68,10 @@ struct FwdArgs {
     int Cin_pad, Ch_pad, Cout_pad;
     int vec_w, vec_x;   // 16-byte loads allowed for the weights / the pixel planes
     FastDiv dCin, dCh;
+    // optional fused W-axis DFT of the output row (lifting MLP -> first spectral block): needs PT == W, NP == 16
+    float2* x1_out;
+    const float* FT;
+    int rows_H, m2c;
 };
 
 // NW waves: wave w owns pixel block (w & 3) and the hidden blocks hq, hq+HQ, ... (hq = w >> 2,
@@ -95,6 +100,8 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_fwd_kernel(FwdArgs a) {
     const int n2 = matload_units(a.Cout, a.Ch, a.vec_w != 0, 4), n1 = matload_units(a.Ch, a.Cin, a.vec_w != 0, 2);
     l2.issue(a.w2, n2);
     l1.issue(a.w1, n1);
+    float4 ftv = make_float4(0.f, 0.f, 0.f, 0.f);          // DFT table [16][PT] of the fused rows step
+    if (a.x1_out && tid < 16 * (PT / 4)) ftv = reinterpret_cast<const float4*>(a.FT)[tid];
     DLWP_STAMP(1);
     stage_pixels(xs, a.x, b, a.Cin, a.Cin_pad, p0, a.P, a.vec_x != 0);
     DLWP_STAMP(2);
@@ -166,7 +173,20 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_fwd_kernel(FwdArgs a) {
                 }
                 float* dst = chan_ptr(a.y, b, o);
                 if (dst) *reinterpret_cast<float4*>(dst + p) = v;
+                if (a.x1_out) *reinterpret_cast<float4*>(&outs[o * LDP + 4 * q]) = v;   // finished row tile, in place
             }
+        }
+        if (a.x1_out) {
+            // W-axis pruned DFT of the finished row, so that the first spectral block needs no separate rows kernel.
+            // The W2 image is dead: it hosts the table and the per-wave partial spectra.
+            float* ft = w2s;                       // [16][LDP]
+            float* x1s = w2s + 16 * LDP;           // [4 waves][Cout_pad][16]
+            if (tid < 16 * (PT / 4)) *reinterpret_cast<float4*>(&ft[(tid / (PT / 4)) * LDP + 4 * (tid % (PT / 4))]) = ftv;
+            for (int idx = a.Cout * LDP + tid; idx < a.Cout_pad * LDP; idx += NT) outs[idx] = 0.f;
+            __syncthreads();
+            if (w < 4) tile_rows_dft<NOB, 1>(outs, ft, x1s, LDP, 16, PT / 16, false);
+            __syncthreads();
+            store_x1(x1s, a.x1_out, b, (int)(blockIdx.x % a.tiles_per_sample), a.rows_H, a.m2c, a.Cout, a.Cout_pad, 16);
         }
     } else {
         for (int idx = tid; idx < a.Cout * PT; idx += NT) {
@@ -549,6 +569,17 @@ int set_lds(K kernel, size_t bytes) {
 int dlwp_pwmlp_fwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, const float* w2,
                       const float* b2, const dlwp_chan_dst* y, const dlwp_chan_src* res, int B,
                       int Cin, int Ch, int Cout, int P, hipStream_t stream) {
+    return dlwp_pwmlp_fwd_rows_ex(x, w1, b1, w2, b2, y, res, B, Cin, Ch, Cout, P, nullptr, nullptr, stream);
+}
+
+bool dlwp_pwmlp_rows_fusable(const dlwp_fno_plan* p, int Cout, int P) {
+    return p && p->W == PT && p->NP == 16 && p->C == Cout && P == p->H * p->W && p->C_pad <= 64;
+}
+
+int dlwp_pwmlp_fwd_rows_ex(const dlwp_chan_src* x, const float* w1, const float* b1, const float* w2,
+                           const float* b2, const dlwp_chan_dst* y, const dlwp_chan_src* res, int B,
+                           int Cin, int Ch, int Cout, int P, const dlwp_fno_plan* rows_plan, float2* x1_out,
+                           hipStream_t stream) {
     DLWP_REQUIRE(B > 0 && Cin > 0 && Ch > 0 && Cout > 0 && P > 0, DLWP_E_INVALID,
                  "pwmlp_fwd: non-positive dimension");
     FwdArgs a{};
@@ -564,6 +595,14 @@ int dlwp_pwmlp_fwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, 
     DLWP_REQUIRE(nob <= 4 && a.Cin_pad <= 64, DLWP_E_UNSUPPORTED,
                  "pwmlp_fwd: Cin<=64 and Cout<=64 supported (got %d, %d)", Cin, Cout);
     a.vec_x = a.vec_x && view_vec_ok(a.y) && view_vec_ok(a.res);
+    bool rows_after = false;
+    if (x1_out) {
+        DLWP_REQUIRE(rows_plan && y->base, DLWP_E_INVALID, "pwmlp_fwd: the rows DFT needs a plan and a dense output");
+        const bool fuse = dlwp_pwmlp_rows_fusable(rows_plan, Cout, P) && a.vec_x &&
+                          (size_t)a.Cout_pad * (a.Ch_pad + 4) >= (size_t)16 * LDP + (size_t)4 * a.Cout_pad * 16;
+        if (fuse) { a.x1_out = x1_out; a.FT = rows_plan->FT_fwd; a.rows_H = rows_plan->H; a.m2c = rows_plan->m2c; }
+        else rows_after = true;       // shapes the epilogue cannot host: separate rows kernel, same result
+    }
     const size_t lds = sizeof(float) * ((size_t)a.Cin_pad * LDP + (size_t)a.Ch_pad * (a.Cin_pad + 4) +
                                         (size_t)a.Cout_pad * (a.Ch_pad + 4) + a.Ch_pad + a.Cout_pad +
                                         (size_t)(FWD_WAVES / 4) * a.Cout_pad * LDP);
@@ -581,6 +620,7 @@ int dlwp_pwmlp_fwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, 
     }
 #undef LAUNCH
     DLWP_LAUNCH_CHECK();
+    if (rows_after) return dlwp_fno_rows_dft(rows_plan, y->base, 0, 0, x1_out, B, stream);
     return DLWP_OK;
 }
 
