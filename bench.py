@@ -38,6 +38,11 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
                     "single-GPU functional test of the N>1 code path)")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (functional test only)")
+    ap.add_argument("--workload", default="fno", choices=["fno", "sfno"],
+                    help="fno: BASELINE configs[1] (default, the headline line); sfno: configs[2], dlwpbench SFNO2DModule 32x64, "
+                         "5 prognostic variables, sfno.yaml widths, sequence length 5 (4 lead times)")
+    ap.add_argument("--precision", default=None, choices=["fp32", "bf16"],
+                    help="GEMM operand precision of the sfno workload (default bf16 = the reference's autocast, fp32 accumulate)")
     return ap.parse_args()
 
 
@@ -133,8 +138,151 @@ def cpu_baseline(B, budget_s):
             f"torch {torch.__version__} CPU fp32, oracle/fno_ref.py"}
 
 
+SFNO_WORKLOAD = dict(name="dlwpbench SFNO2DModule 32x64 WeatherBench shapes (BASELINE configs[2])",
+                     model=dict(constant_channels=4, prescribed_channels=1, prognostic_channels=5, grid="equiangular", num_layers=4,
+                                scale_factor=1, embed_dim=256, context_size=1, height=32, width=64, big_skip=True, pos_embed=True,
+                                use_mlp=True, normalization_layer="none"), T=5, H=32, W=64)
+PEAK_MFMA_TF = {"fp32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md dense peaks
+
+
+def sfno_gemm_probe(device, B, precision, reps=100):
+    """Dominant kernel of the SFNO step (rocprof: gemm_kernel, ~80 % of GPU time): the block MLP's first layer
+    [B*H*W, 256] x [256, 512] with bias + GELU epilogue, timed with HIP events on its launch stream."""
+    import torch
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.token_ops import _gemm
+    M, K, N = B * 32 * 64, 256, 512
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(M, K, generator=g).to(device)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(device)
+    b = torch.zeros(N, device=device)
+    y, z = torch.empty(M, N, device=device), torch.empty(M, N, device=device)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        for _ in range(10):
+            _gemm(x, w, y, M, N, K, K, K, N, 0, 1, b, 1, z, None)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(reps):
+            _gemm(x, w, y, M, N, K, K, K, N, 0, 1, b, 1, z, None)
+        e1.record(stream)
+        torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    flops = 2.0 * M * N * K
+    peak = PEAK_MFMA_TF[precision]
+    return {"bound": "mfma", "kernel": f"gemm_kernel (MLP fc1 {M}x{N}x{K}, bias+GELU epilogue, {precision} operands)",
+            "achieved": round(flops / sec / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(flops / sec / 1e12 / peak, 4),
+            "flops_per_launch": flops, "us_per_launch": round(sec * 1e6, 3), "traffic": None}
+
+
+def sfno_cpu_baseline(B, budget_s):
+    """oracle/sfno_ref.py (CPU restatement; torch-harmonics is not installable here: kind="port") on the host cores."""
+    import torch
+    from oracle import sfno_ref
+    from dlwp_benchmark_amd import dlwpbench
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    cfg = SFNO_WORKLOAD["model"]
+    torch.manual_seed(1234)
+    net = dlwpbench.SFNO2DModule(**cfg)          # parameter container only (CPU tensors); the arithmetic is the oracle's
+    p = {k[len("sfno."):]: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    opt = torch.optim.Adam(list(p.values()), lr=1e-3)
+    g = torch.Generator().manual_seed(1234)
+    T = SFNO_WORKLOAD["T"]
+    kw = (torch.randn(B, 1, 4, 32, 64, generator=g), torch.randn(B, T, 1, 32, 64, generator=g), torch.randn(B, T, 5, 32, 64, generator=g))
+    target = torch.randn(B, T - 1, 5, 32, 64, generator=g)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.mse_loss(sfno_ref.sfno2d_rollout(*kw, p, cfg), target)
+        loss.backward()
+        opt.step()
+    step()
+    t0, n = time.perf_counter(), 0
+    while True:
+        step()
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 50:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(B * n / dt, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} train steps of the same workload (batch {B}, {T - 1} lead times) after 1 warm-up, torch "
+                      f"{torch.__version__} CPU fp32, oracle/sfno_ref.py"}
+
+
+def main_sfno(args):
+    """BASELINE configs[2]: one step = 4-lead-time rollout + MSE + backward + all-reduce (N>1) + fused Adam, captured in a
+    hipGraph by train_engine.GraphedTrainStep."""
+    import torch
+    import torch.distributed as dist
+    from dlwp_benchmark_amd import ddp, dlwpbench, lib as L
+    from dlwp_benchmark_amd.train_engine import GraphedTrainStep
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    device = torch.device("cuda", 0 if args.share_device else local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device) if args.backend == "nccl" else dist.init_process_group(args.backend)
+    precision = args.precision or "bf16"
+    L.set_gemm_precision(precision)
+    w, B = SFNO_WORKLOAD, args.batch
+    torch.manual_seed(1234)
+    model = dlwpbench.SFNO2DModule(**w["model"]).to(device).train()
+    g = torch.Generator().manual_seed(1234 + rank)
+    T = w["T"]
+    kw = dict(constants=torch.randn(B, 1, 4, 32, 64, generator=g).to(device),
+              prescribed=torch.randn(B, T, 1, 32, 64, generator=g).to(device),
+              prognostic=torch.randn(B, T, 5, 32, 64, generator=g).to(device))
+    target = torch.randn(B, T - 1, 5, 32, 64, generator=g).to(device)
+    step = GraphedTrainStep(model, kw, target, lr=1e-3, use_graph=not args.no_graph,
+                            allreduce=ddp.FlatGradAllReduce() if world > 1 else None, grad_scale=1.0 / world)
+    ddp.broadcast_parameters(step.flat, src=0)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    if rank == 0:
+        line = {"metric": "train samples/sec (SFNO 32x64 rollout step: fwd + MSE + backward + Adam)",
+                "value": round(world * B * args.steps / dt, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if precision == "bf16" else "f32",
+                "data": "synthetic N(0,1) fields (z-scored WeatherBench shapes), random-init weights (no dataset/checkpoint access)",
+                "config": {"workload": w["name"], "per_gpu_batch": B, "global_batch": B * world, "sequence_length": T,
+                           "net_calls_per_sample": T - 1, "embed_dim": 256, "num_layers": 4, "grid": [32, 64],
+                           "gemm_operands": precision, "accumulate": "fp32", "parallelism": f"dp{world}",
+                           "hip_graph": not args.no_graph},
+                "backbone_calls_per_s": round(world * B * args.steps * (T - 1) / dt, 1), "final_loss": loss.item()}
+        if world == 1 and not args.no_roofline:
+            line["roofline"] = sfno_gemm_probe(device, B, precision)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = sfno_cpu_baseline(B, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.workload == "sfno":
+        return main_sfno(args)
     import torch
     import torch.distributed as dist
     from dlwp_benchmark_amd import nsbench

@@ -37,6 +37,7 @@ struct GemmDev {
     int M, N, K, lda, ldb, ldc, act, accumulate, kchunk, splits;
     // strided-batched mode (nbatch > 1, no split-K): batch z = z1 * nb2 + z2, operand offsets z1 * s?1 + z2 * s?2
     int nbatch, nb2, res_pre;
+    int vec_epi;               // epilogue through an LDS tile with 16-byte global accesses (alignment checked on the host)
     long long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2, sBi1, sBi2;
     float act_param;           // soft-shrink threshold (act == 3)
 };
@@ -266,6 +267,56 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
         __syncthreads();
     }
     gemm_rowsum_flush<T>(a, rsum, m0, wm, w, r, g);
+    if constexpr (T == 1) {
+        if (a.vec_epi) {
+            // The accumulator layout gives each lane 4 rows x 1 column: stored directly, a wave-instruction touches four
+            // 64-byte row segments (issue-bound, ~2 TB/s on the MLP epilogues).  Through an LDS tile every global access of
+            // the epilogue (C, residual, pre-activation) becomes a 16-byte one on 256-byte contiguous rows.
+            constexpr int LDE = 64 + 4;
+            float* tile = gsm;                          // the operand buffers are dead (loop ended with a barrier)
+#pragma unroll
+            for (int i = 0; i < NT16; ++i)
+#pragma unroll
+                for (int j = 0; j < NT16; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tile[(wm + i * 16 + 4 * g + q) * LDE + wn + j * 16 + r] = acc[i][j][q];
+            __syncthreads();
+            const int tid = threadIdx.x, c4 = tid & 15;
+            const int n = n0 + 4 * c4;
+            f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.bias && n < a.N) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int row = (tid >> 4) + 16 * pass, m = m0 + row;
+                if (m < a.M && n < a.N) {
+                    const long long o = (long long)m * a.ldc + n;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(&tile[row * LDE + 4 * c4]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] += bv[k];
+                    f32x4 rv = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (a.residual) rv = *reinterpret_cast<const f32x4*>(a.residual + o);
+                    if (a.res_pre) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] += rv[k];
+                    }
+                    if (a.preact) *reinterpret_cast<f32x4*>(a.preact + o) = v;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], a.act, a.act_param);
+                    if (!a.res_pre) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] += rv[k];
+                    }
+                    if (a.accumulate) {
+                        const f32x4 cv = *reinterpret_cast<const f32x4*>(a.C + o);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] += cv[k];
+                    }
+                    *reinterpret_cast<f32x4*>(a.C + o) = v;
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NT16; ++i)
 #pragma unroll
@@ -451,6 +502,11 @@ static int gemm_dispatch(GemmDev& a, int transA, int transB, int T, void* stream
     bool vec = ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.B % 16 == 0) && a.lda % 4 == 0 && a.ldb % 4 == 0 && a.K % 4 == 0 &&
                (transA ? a.M % 4 == 0 : true) && (transB ? true : a.N % 4 == 0);
     if (a.nbatch > 1) vec = vec && a.sA1 % 4 == 0 && a.sA2 % 4 == 0 && a.sB1 % 4 == 0 && a.sB2 % 4 == 0;
+    a.vec_epi = T == 1 && a.splits == 1 && a.N % 4 == 0 && a.ldc % 4 == 0 && (uintptr_t)a.C % 16 == 0 &&
+                (!a.bias || (uintptr_t)a.bias % 16 == 0) && (!a.residual || (uintptr_t)a.residual % 16 == 0) &&
+                (!a.preact || (uintptr_t)a.preact % 16 == 0);
+    if (a.nbatch > 1)
+        a.vec_epi = a.vec_epi && a.sC1 % 4 == 0 && a.sC2 % 4 == 0 && a.sR1 % 4 == 0 && a.sR2 % 4 == 0 && a.sBi1 % 4 == 0 && a.sBi2 % 4 == 0;
     const hipStream_t s = (hipStream_t)stream;
     int rc;
     // A is k-contiguous when not transposed ([M][K]); B is k-contiguous when transposed ([N][K])
@@ -488,7 +544,7 @@ extern "C" int dlwp_gemm(const float* A, const float* B, float* C, int M, int N,
         if (zrc) return zrc;
     }
     GemmDev a{A, B, bias, residual, C, preact, rowsum, M, N, K, lda, ldb, ldc, act, accumulate, kchunk, splits,
-              1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.f};
+              1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.f};
     return gemm_dispatch(a, transA, transB, T, stream);
 }
 
@@ -517,7 +573,7 @@ extern "C" int dlwp_gemm_batched(const float* A, const float* B, float* C, int M
                 if (int zrc = dlwp_zero_2d_f32(C + z1 * sC1 + z2 * sC2, ldc, M, N, stream)) return zrc;
     }
     GemmDev a{A, B, bias, residual, C, preact, nullptr, M, N, K, lda, ldb, ldc, act, accumulate, kchunk, splits,
-              nb1 * nb2, nb2, res_before_act, sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2, sBi1, sBi2, act_param};
+              nb1 * nb2, nb2, res_before_act, 0, sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2, sBi1, sBi2, act_param};
     return gemm_dispatch(a, transA, transB, T, stream);
 }
 
