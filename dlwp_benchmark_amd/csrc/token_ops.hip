@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
     TileIO<AKC, VEC, T> ta;
     TileIO<BKC, VEC, T> tb;
     const int nk = (kend - kbeg + BK - 1) / BK;
+    DLWP_STAMP(0);
     ta.load(a.A, a.lda, m0, a.M, kbeg, kend);
     tb.load(a.B, a.ldb, n0, a.N, kbeg, kend);
     if constexpr (BF) {
@@ -219,8 +220,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
         tb.store(Bs);
     }
     __syncthreads();
+    DLWP_STAMP(1);
     for (int it = 0; it < nk; ++it) {
         const int cur = it & 1;
+        if (it == 1) DLWP_STAMP(2);
+        if (it == 2) DLWP_STAMP(3);
         if (it + 1 < nk) {
             ta.load(a.A, a.lda, m0, a.M, kbeg + (it + 1) * BK, kend);
             tb.load(a.B, a.ldb, n0, a.N, kbeg + (it + 1) * BK, kend);
@@ -266,6 +270,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
         }
         __syncthreads();
     }
+    DLWP_STAMP(4);
     gemm_rowsum_flush<T>(a, rsum, m0, wm, w, r, g);
     if constexpr (T == 1) {
         if (a.vec_epi) {
@@ -314,6 +319,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
                     *reinterpret_cast<f32x4*>(a.C + o) = v;
                 }
             }
+            DLWP_STAMP(5);
             return;
         }
     }
@@ -641,3 +647,10 @@ extern "C" int dlwp_colsum(const float* g, float* out, int T, int N, void* strea
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }
+
+#ifdef DLWP_STAMPS
+extern "C" int dlwp_debug_stamps_gemm(unsigned long long* host_out) {
+    DLWP_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dlwp_stamps), sizeof(unsigned long long) * 32));
+    return DLWP_OK;
+}
+#endif
