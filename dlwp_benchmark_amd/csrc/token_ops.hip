@@ -37,6 +37,7 @@ struct GemmDev {
     int M, N, K, lda, ldb, ldc, act, accumulate, kchunk, splits;
     // strided-batched mode (nbatch > 1, no split-K): batch z = z1 * nb2 + z2, operand offsets z1 * s?1 + z2 * s?2
     int nbatch, nb2, res_pre;
+    int ntn, ntm;              // column / row tile counts (1-D tile grid, see the XCD-aware order in the kernel)
     int vec_epi;               // epilogue through an LDS tile with 16-byte global accesses (alignment checked on the host)
     long long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2, sBi1, sBi2;
     float act_param;           // soft-shrink threshold (act == 3)
@@ -161,8 +162,8 @@ struct TileIO {
 
 // bias gradient by-product: sum over k of op(A) rows (see dlwp_gemm's rowsum)
 template <int T>
-__device__ __forceinline__ void gemm_rowsum_flush(const GemmDev& a, const float (&rsum)[2 * T], int m0, int wm, int w, int r, int g) {
-    if (!a.rowsum || blockIdx.x != 0 || (w & 1)) return;
+__device__ __forceinline__ void gemm_rowsum_flush(const GemmDev& a, const float (&rsum)[2 * T], int m0, int n0, int wm, int w, int r, int g) {
+    if (!a.rowsum || n0 != 0 || (w & 1)) return;
 #pragma unroll
     for (int i = 0; i < 2 * T; ++i) {
         float v = rsum[i];
@@ -181,7 +182,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
     float* As = gsm;                 // [2][TF]
     float* Bs = gsm + 2 * TF;        // [2][TF]
     const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.y * BMN, n0 = blockIdx.x * BMN;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so consecutive ids never
+    // share an L2.  Remap so that every XCD walks a contiguous range of tiles, row-panel by row-panel: the A panel that the
+    // ntn column tiles of one row panel share is then fetched into ONE L2 instead of eight.
+    int tile_id = blockIdx.x;
+    {
+        const int nt = gridDim.x, full = (nt / 8) * 8;
+        if (tile_id < full) tile_id = (tile_id % 8) * (nt / 8) + tile_id / 8;
+    }
+    // inside an XCD's range: groups of 8 row panels, column tile by column tile, so that the ~128 workgroups an XCD runs
+    // at a time form a compact block (8 A panels x 16 B panels in flight) instead of one long row or column
+    constexpr int GM = 8;
+    const int grp = tile_id / (GM * a.ntn), within = tile_id - grp * GM * a.ntn;
+    const int rows_in = min(GM, a.ntm - grp * GM);
+    const int nt_ = within / rows_in, mt = grp * GM + (within - nt_ * rows_in);
+    const int m0 = mt * BMN, n0 = nt_ * BMN;
     int zs = blockIdx.z;
     if (a.nbatch > 1) {
         const int zb = zs / a.splits;                 // batch index; zs % splits = K split within the batch
@@ -271,7 +286,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
         __syncthreads();
     }
     DLWP_STAMP(4);
-    gemm_rowsum_flush<T>(a, rsum, m0, wm, w, r, g);
+    gemm_rowsum_flush<T>(a, rsum, m0, n0, wm, w, r, g);
     if constexpr (T == 1) {
         if (a.vec_epi) {
             // The accumulator layout gives each lane 4 rows x 1 column: stored directly, a wave-instruction touches four
@@ -356,9 +371,12 @@ int gemm_launch_t(const GemmDev& a, dim3 grid, hipStream_t s) {
 int g_gemm_bf16 = 0;    // dlwp_set_gemm_precision
 
 template <bool AKC, bool BKC>
-int gemm_launch(const GemmDev& a, bool vec, int T, hipStream_t s) {
+int gemm_launch(const GemmDev& a_in, bool vec, int T, hipStream_t s) {
     const int edge = 64 * T;
-    const dim3 grid(ceil_div(a.N, edge), ceil_div(a.M, edge), a.nbatch * a.splits);
+    GemmDev a = a_in;
+    a.ntn = ceil_div(a.N, edge);
+    a.ntm = ceil_div(a.M, edge);
+    const dim3 grid(a.ntn * a.ntm, 1, a.nbatch * a.splits);
     if (g_gemm_bf16) {
         if (T == 2) return vec ? gemm_launch_t<AKC, BKC, true, 2, true>(a, grid, s) : gemm_launch_t<AKC, BKC, false, 2, true>(a, grid, s);
         return vec ? gemm_launch_t<AKC, BKC, true, 1, true>(a, grid, s) : gemm_launch_t<AKC, BKC, false, 1, true>(a, grid, s);
@@ -550,7 +568,7 @@ extern "C" int dlwp_gemm(const float* A, const float* B, float* C, int M, int N,
         if (zrc) return zrc;
     }
     GemmDev a{A, B, bias, residual, C, preact, rowsum, M, N, K, lda, ldb, ldc, act, accumulate, kchunk, splits,
-              1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.f};
+              1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.f};
     return gemm_dispatch(a, transA, transB, T, stream);
 }
 
@@ -579,7 +597,7 @@ extern "C" int dlwp_gemm_batched(const float* A, const float* B, float* C, int M
                 if (int zrc = dlwp_zero_2d_f32(C + z1 * sC1 + z2 * sC2, ldc, M, N, stream)) return zrc;
     }
     GemmDev a{A, B, bias, residual, C, preact, nullptr, M, N, K, lda, ldb, ldc, act, accumulate, kchunk, splits,
-              nb1 * nb2, nb2, res_before_act, 0, sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2, sBi1, sBi2, act_param};
+              nb1 * nb2, nb2, res_before_act, 0, 0, 0, sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2, sBi1, sBi2, act_param};
     return gemm_dispatch(a, transA, transB, T, stream);
 }
 
