@@ -477,7 +477,14 @@ __global__ __launch_bounds__(MIXT) void fno_mix_fwd_kernel(MixDev a) {
     float2* part = xh + BC;                        // [max(NS, NS2)][BC]
     float2* tws = part + (NS > NS2 ? NS : NS2) * BC;   // [H]
     float2* ws = tws + a.H;                        // [C][C+1]
-    const int j = blockIdx.x / a.m2c, kx = blockIdx.x % a.m2c;
+    // XCD-aware mode order: workgroups go round-robin to the 8 XCDs; give every XCD a contiguous range of (kx, j) so that
+    // the m1 row frequencies of one column kx -- which read the same x1 slice -- meet in one L2
+    int mode = blockIdx.x;
+    {
+        const int nm = gridDim.x, full = (nm / 8) * 8;
+        if (mode < full) mode = (mode % 8) * (nm / 8) + mode / 8;
+    }
+    const int kx = mode / a.m1, j = mode - kx * a.m1;
     const bool fast = (C % 2 == 0) && (BC / 2) * NS2 <= MIXT && NS2 >= 1;
     DLWP_STAMP(16);
     HstepLoads hl;
@@ -546,7 +553,14 @@ __global__ __launch_bounds__(MIXT) void fno_mix_bwd_kernel(MixDev a) {
     float2* part = xsv + BC;                       // [max(NS, NS2)][BC]
     float2* tws = part + (NS > NS2 ? NS : NS2) * BC;   // [H]
     float2* ws = tws + a.H;                        // [C][C+1]
-    const int j = blockIdx.x / a.m2c, kx = blockIdx.x % a.m2c;
+    // XCD-aware mode order: workgroups go round-robin to the 8 XCDs; give every XCD a contiguous range of (kx, j) so that
+    // the m1 row frequencies of one column kx -- which read the same x1 slice -- meet in one L2
+    int mode = blockIdx.x;
+    {
+        const int nm = gridDim.x, full = (nm / 8) * 8;
+        if (mode < full) mode = (mode % 8) * (nm / 8) + mode / 8;
+    }
+    const int kx = mode / a.m1, j = mode - kx * a.m1;
     const long long wofs = ((long long)(j * a.m2c + kx) * C) * C;
     const bool fast = (C % 2 == 0) && (BC / 2) * NS2 <= MIXT && NS2 >= 1;
     HstepLoads hl;

@@ -422,48 +422,65 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     __syncthreads();
     const int lane = lane_id(), w = wave_id();
     const int row0 = blockIdx.x * rows_per_block;
-    // each wave owns the columns c = lane, lane+64, ... for its rows; accumulate column partials in registers
-    // (C <= 64*NQ, checked by the host wrapper), then add them to LDS once per wave
-    float pg[NQ], pb[NQ];
+    // each wave owns the columns c = lane, lane+64, ... (C <= 64*NQ, checked by the host wrapper) of its rows and keeps the
+    // column partials in registers.  The next row's loads are in flight while the current row is reduced (one wave per SIMD
+    // would otherwise pay a full memory latency per row); loads use clamped addresses, masks are applied afterwards.
+    float pg[NQ], pb[NQ], gam[NQ], xv[NQ], gv[NQ], xn[NQ], gn[NQ];
+    bool okc[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) { pg[q] = 0.f; pb[q] = 0.f; }
+    for (int q = 0; q < NQ; ++q) {
+        pg[q] = 0.f; pb[q] = 0.f;
+        okc[q] = lane + 64 * q < C;
+        gam[q] = okc[q] ? gamma[min(lane + 64 * q, C - 1)] : 0.f;
+    }
+    auto load_row = [&](int row, float (&X)[NQ], float (&G)[NQ], float& mu, float& rs) {
+        const int rc = min(row, T - 1);
+        const float* xr = x + (long long)rc * C;
+        const float* gr = gy + (long long)rc * C;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = min(lane + 64 * q, C - 1);
+            X[q] = xr[c];
+            G[q] = gr[c];
+        }
+        mu = mean[rc];
+        rs = rstd[rc];
+    };
+    float mu, rs, mun = 0.f, rsn = 0.f;
+    load_row(row0 + w, xv, gv, mu, rs);
     for (int rr = w; rr < rows_per_block; rr += 4) {
         const int row = row0 + rr;
         if (row >= T) break;
-        const float mu = mean[row], rs = rstd[row];
-        const float* xr = x + (long long)row * C;
-        const float* gr = gy + (long long)row * C;
-        float s1 = 0.f, s2 = 0.f;
+        const bool more = rr + 4 < rows_per_block && row + 4 < T;
+        if (more) load_row(row + 4, xn, gn, mun, rsn);
+        float s1 = 0.f, s2 = 0.f, xh[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int c = lane + 64 * q;
-            if (c < C) {
-                const float xh = (xr[c] - mu) * rs, gg = gr[c] * gamma[c];
-                s1 += gg;
-                s2 += gg * xh;
-                pg[q] += gr[c] * xh;
-                pb[q] += gr[c];
-            }
+            const float g0 = okc[q] ? gv[q] : 0.f;
+            xh[q] = okc[q] ? (xv[q] - mu) * rs : 0.f;
+            const float gg = g0 * gam[q];
+            s1 += gg;
+            s2 += gg * xh[q];
+            pg[q] += g0 * xh[q];
+            pb[q] += g0;
         }
         s1 = wave_sum64(s1) / C;
         s2 = wave_sum64(s2) / C;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int c = lane + 64 * q;
-            if (c < C) {
-                const float xh = (xr[c] - mu) * rs;
-                gx[(long long)row * C + c] = rs * (gr[c] * gamma[c] - s1 - xh * s2);
-            }
+        for (int q = 0; q < NQ; ++q)
+            if (okc[q]) gx[(long long)row * C + lane + 64 * q] = rs * (gv[q] * gam[q] - s1 - xh[q] * s2);
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { xv[q] = xn[q]; gv[q] = gn[q]; }
+            mu = mun; rs = rsn;
         }
     }
     // combine the four waves' column partials one wave at a time (no LDS float atomics)
     for (int ww = 0; ww < 4; ++ww) {
         if (w == ww) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int c = lane + 64 * q;
-                if (c < C) { sg[c] += pg[q]; sb[c] += pb[q]; }
-            }
+            for (int q = 0; q < NQ; ++q)
+                if (okc[q]) { sg[lane + 64 * q] += pg[q]; sb[lane + 64 * q] += pb[q]; }
         }
         __syncthreads();
     }
@@ -619,20 +636,21 @@ extern "C" int dlwp_layernorm_bwd(const float* x, const float* gamma, const floa
     // tail costs (number of workgroups) x 25 ns whatever C is: ~128-256 workgroups balance that against the rows
     // each wave walks serially.
     // each wave then walks serially (one wave per SIMD hides no latency).  Large inputs get up to ~1024 workgroups.
-    const long long want = std::min<long long>(1024, std::max<long long>(128, (long long)T * C / 16384));
+    const long long want = std::min<long long>(512, std::max<long long>(128, (long long)T * C / 16384));
     int rpb = 64;
     while (rpb > 4 && ceil_div(T, rpb) < want) rpb >>= 1;
     const dim3 grid(ceil_div(T, rpb));
     const size_t lds = 2 * C * sizeof(float);
-    if (C <= 512)
-        hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, dim3(256), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, gx,
-                           ggamma, gbeta, T, C, rpb);
-    else if (C <= 1024)
-        hipLaunchKernelGGL(layernorm_bwd_kernel<16>, grid, dim3(256), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, gx,
-                           ggamma, gbeta, T, C, rpb);
-    else
-        hipLaunchKernelGGL(layernorm_bwd_kernel<32>, grid, dim3(256), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, gx,
-                           ggamma, gbeta, T, C, rpb);
+#define LN_BWD(NQ)                                                                                                   \
+    hipLaunchKernelGGL(layernorm_bwd_kernel<NQ>, grid, dim3(256), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, gx, \
+                       ggamma, gbeta, T, C, rpb)
+    if (C <= 64) LN_BWD(1);
+    else if (C <= 128) LN_BWD(2);
+    else if (C <= 256) LN_BWD(4);
+    else if (C <= 512) LN_BWD(8);
+    else if (C <= 1024) LN_BWD(16);
+    else LN_BWD(32);
+#undef LN_BWD
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }
