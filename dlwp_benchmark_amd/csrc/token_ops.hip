@@ -637,7 +637,7 @@ extern "C" int dlwp_layernorm_bwd(const float* x, const float* gamma, const floa
     // each wave walks serially.
     // each wave then walks serially (one wave per SIMD hides no latency).  Large inputs get up to ~1024 workgroups.
     const long long want = std::min<long long>(512, std::max<long long>(128, (long long)T * C / 16384));
-    int rpb = 64;
+    int rpb = 256;
     while (rpb > 4 && ceil_div(T, rpb) < want) rpb >>= 1;
     const dim3 grid(ceil_div(T, rpb));
     const size_t lds = 2 * C * sizeof(float);
