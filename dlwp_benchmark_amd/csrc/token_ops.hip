@@ -50,7 +50,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int LDKB = BK + 8;   // bf16 elements per LDS row (80 bytes: 16-byte aligned fragments)
 
-// epilogue activations: 0 none, 1 GELU (erf), 2 ReLU, 3 soft-shrink(lambda)
+// epilogue activations: 0 none, 1 GELU (erf), 2 ReLU, 3 soft-shrink(lambda); 4 is the backward form
+// v * GELU'(aux) with aux read through the `residual` view (the saved pre-activation): the product g W of a Linear layer
+// then leaves the kernel already multiplied by the derivative of the activation that fed it (no separate gelu_bwd pass)
+constexpr int ACT_GELU_GRAD_MUL = 4;
 __device__ __forceinline__ float apply_act(float v, int act, float lam) {
     if (act == 1) return gelu_f(v);
     if (act == 2) return fmaxf(v, 0.f);
@@ -315,16 +318,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
                     for (int k = 0; k < 4; ++k) v[k] += bv[k];
                     f32x4 rv = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (a.residual) rv = *reinterpret_cast<const f32x4*>(a.residual + o);
-                    if (a.res_pre) {
+                    if (a.act == ACT_GELU_GRAD_MUL) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] += rv[k];
-                    }
-                    if (a.preact) *reinterpret_cast<f32x4*>(a.preact + o) = v;
+                        for (int k = 0; k < 4; ++k) v[k] *= gelu_grad_f(rv[k]);
+                    } else {
+                        if (a.res_pre) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], a.act, a.act_param);
-                    if (!a.res_pre) {
+                            for (int k = 0; k < 4; ++k) v[k] += rv[k];
+                        }
+                        if (a.preact) *reinterpret_cast<f32x4*>(a.preact + o) = v;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] += rv[k];
+                        for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], a.act, a.act_param);
+                        if (!a.res_pre) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k] += rv[k];
+                        }
                     }
                     if (a.accumulate) {
                         const f32x4 cv = *reinterpret_cast<const f32x4*>(a.C + o);
@@ -350,10 +358,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
                     float v = acc[i][j][q];
                     if (a.splits > 1) { atomic_add_f32(&a.C[o], v); continue; }   // C zeroed (or accumulate)
                     if (a.bias) v += a.bias[n];
-                    if (a.residual && a.res_pre) v += a.residual[o];
-                    if (a.preact) a.preact[o] = v;
-                    v = apply_act(v, a.act, a.act_param);
-                    if (a.residual && !a.res_pre) v += a.residual[o];
+                    if (a.act == ACT_GELU_GRAD_MUL) {
+                        v *= gelu_grad_f(a.residual[o]);
+                    } else {
+                        if (a.residual && a.res_pre) v += a.residual[o];
+                        if (a.preact) a.preact[o] = v;
+                        v = apply_act(v, a.act, a.act_param);
+                        if (a.residual && !a.res_pre) v += a.residual[o];
+                    }
                     a.C[o] = a.accumulate ? a.C[o] + v : v;
                 }
             }
@@ -596,7 +608,10 @@ extern "C" int dlwp_gemm_batched(const float* A, const float* B, float* C, int M
                                  long long sR1, long long sR2, int res_before_act, int accumulate, void* stream) {
     DLWP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && nb1 > 0 && nb2 > 0, DLWP_E_INVALID,
                  "gemm_batched: NULL argument or empty shape");
-    DLWP_REQUIRE(act >= 0 && act <= 3, DLWP_E_INVALID, "gemm_batched: act must be 0 (none), 1 (gelu), 2 (relu) or 3 (softshrink)");
+    DLWP_REQUIRE(act >= 0 && act <= 4, DLWP_E_INVALID,
+                 "gemm_batched: act must be 0 (none), 1 (gelu), 2 (relu), 3 (softshrink) or 4 (multiply by GELU'(residual))");
+    DLWP_REQUIRE(act != ACT_GELU_GRAD_MUL || (residual && !preact), DLWP_E_INVALID,
+                 "gemm_batched: act 4 reads the saved pre-activation through `residual` and writes no `preact`");
     // reductions over a long K with few output tiles (weight gradients of block-diagonal layers): split K inside every
     // batch and combine with float atomics, like the plain entry
     const bool epilogue = bias || act || preact || residual;

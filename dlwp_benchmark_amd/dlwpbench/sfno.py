@@ -12,8 +12,8 @@ import math
 import torch
 import torch.nn as nn
 
-from ..sht import InverseRealSHT, RealSHT, dhconv
-from ..token_ops import Conv1x1
+from ..sht import InverseRealSHT, RealSHT, dhconv, spectral_weight_scope
+from ..token_ops import Conv1x1, mlp, skip_mlp
 from .rollout import rollout
 
 
@@ -41,7 +41,7 @@ class _MLP(nn.Module):
         self.fc2 = Conv1x1(hidden_features, out_features)
 
     def forward(self, x, residual=None):
-        return self.fc2(self.fc1(x, act=1), residual=residual)
+        return mlp(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, residual)
 
 
 class _Block(nn.Module):
@@ -57,6 +57,10 @@ class _Block(nn.Module):
 
     def forward(self, x):
         y, residual = self.filter(x)
+        if self.inner_skip is not None and self.mlp is not None and y.shape == residual.shape:
+            m = self.mlp                                                        # whole block tail as one autograd node
+            return skip_mlp(y, residual, self.inner_skip.weight, self.inner_skip.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight,
+                            m.fc2.bias, self.outer)
         if self.inner_skip is not None:
             y = self.inner_skip(residual, act=1, residual=y, res_pre=True)      # GELU(y + W residual + b) in one GEMM
         else:
@@ -101,12 +105,12 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         pos = None
         if self.pos_embed is not None:
             pos = self.pos_embed.permute(0, 2, 3, 1).expand(B, H, W, -1)
-        t = self.encoder[2](self.encoder[0](tok_in, act=1), residual=pos)
+        t = mlp(tok_in, self.encoder[0].weight, self.encoder[0].bias, self.encoder[2].weight, None, pos)
         for blk in self.blocks:
             t = blk(t)
         if self.big_skip:
             t = torch.cat([t, tok_in], dim=-1)
-        y = self.decoder[2](self.decoder[0](t, act=1))
+        y = mlp(t, self.decoder[0].weight, self.decoder[0].bias, self.decoder[2].weight, None)
         return y.permute(0, 3, 1, 2)
 
 
@@ -130,4 +134,5 @@ class SFNO2DModule(nn.Module):
 
     def forward(self, constants: torch.Tensor = None, prescribed: torch.Tensor = None,
                 prognostic: torch.Tensor = None) -> torch.Tensor:
-        return rollout(self.sfno, self.context_size, constants, prescribed, prognostic)
+        with spectral_weight_scope():      # every lead time applies the same weights: one expanded image per layer
+            return rollout(self.sfno, self.context_size, constants, prescribed, prognostic)

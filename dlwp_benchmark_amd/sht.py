@@ -180,24 +180,63 @@ class InverseRealSHT(nn.Module):
 
 
 # ---- per-degree complex weights ---------------------------------------------------------------------------------
+_wexp_scope = None          # {id(w): expanded image} while a spectral_weight_scope is open
+_pending_folds = {}         # {id(w): (accumulated expanded gradient, gradient slot, shape)} during one backward pass
+
+
+class spectral_weight_scope:
+    """Within the scope the parameters cannot change (one rollout forward: every lead time applies the same weights), so
+    the [[Wr, Wi], [-Wi, Wr]] image of each spectral weight is built once and shared by all net calls."""
+
+    def __enter__(self):
+        global _wexp_scope
+        self._outer = _wexp_scope
+        if _wexp_scope is None:
+            _wexp_scope = {}
+        return self
+
+    def __exit__(self, *exc):
+        global _wexp_scope
+        _wexp_scope = self._outer
+        return False
+
+
+def _expanded_weight(w):
+    lib = L.load()
+    if _wexp_scope is not None and id(w) in _wexp_scope:
+        return _wexp_scope[id(w)][0]
+    Cin, Cout, Lm, _ = w.shape
+    wexp = torch.empty(Lm, 2 * Cin, 2 * Cout, device=w.device)
+    L.check(lib.dlwp_cweight_expand(L.ptr(w.contiguous()), L.ptr(wexp), Cin, Cout, Lm, L.stream()))
+    if _wexp_scope is not None:
+        _wexp_scope[id(w)] = (wexp, w)          # keeps w alive, so the id stays unique inside the scope
+    return wexp
+
+
+def _fold_pending():
+    """End of a backward pass: fold every accumulated expanded gradient into its complex parameter's gradient slot."""
+    lib = L.load()
+    for gexp, slot, shape in _pending_folds.values():
+        L.check(lib.dlwp_cweight_fold(L.ptr(gexp), L.ptr(slot), shape[0], shape[1], shape[2], L.stream()))
+    _pending_folds.clear()
+
+
 class _DHConvFn(torch.autograd.Function):
     """Y[l, r, (re|im, o)] = sum_i X[l, r, (re|im, i)] * W[i, o, l] (complex), r = (b, m) rows."""
 
     @staticmethod
     def forward(ctx, X, w):
-        lib = L.load()
         Lm, B, M, _, Cin = X.shape
         Cout = w.shape[1]
         assert w.shape == (Cin, Cout, Lm, 2), f"weight {tuple(w.shape)} does not match spectrum {tuple(X.shape)}"
         X = X.contiguous()
-        wexp = torch.empty(Lm, 2 * Cin, 2 * Cout, device=X.device)
-        L.check(lib.dlwp_cweight_expand(L.ptr(w.contiguous()), L.ptr(wexp), Cin, Cout, Lm, L.stream()))
+        wexp = _expanded_weight(w)
         R = B * M
         Y = torch.empty(Lm, B, M, 2, Cout, device=X.device)
         _gemm_batched(X, wexp, Y, R, 2 * Cout, 2 * Cin, 2 * Cin, 2 * Cout, 2 * Cout, 0, 0, Lm, 1, (R * 2 * Cin, 0),
                       (4 * Cin * Cout, 0), (R * 2 * Cout, 0))
         ctx.save_for_backward(X, wexp)
-        ctx.wslot, ctx.wshape = _grad_slot(w), w.shape
+        ctx.wslot, ctx.wshape, ctx.wid = _grad_slot(w), w.shape, id(w)
         return Y
 
     @staticmethod
@@ -212,13 +251,25 @@ class _DHConvFn(torch.autograd.Function):
         # gX[l] = gY[l] . wexp[l]^T
         _gemm_batched(gY, wexp, gX, R, 2 * Cin, 2 * Cout, 2 * Cout, 2 * Cout, 2 * Cin, 0, 1, Lm, 1, (R * 2 * Cout, 0),
                       (4 * Cin * Cout, 0), (R * 2 * Cin, 0))
-        # gexp[l] = X[l]^T . gY[l], folded into the complex parameter's gradient
-        gexp = torch.empty_like(wexp)
+        # gexp[l] = X[l]^T . gY[l].  With a preallocated gradient slot the expanded gradients of every application of
+        # this weight in the backward pass (one per lead time) are summed by the GEMM itself and folded into the
+        # complex parameter once, when the pass ends.
+        first = ctx.wid not in _pending_folds
+        if ctx.wslot is not None:
+            if first:
+                if not _pending_folds:
+                    torch.autograd.Variable._execution_engine.queue_callback(_fold_pending)
+                _pending_folds[ctx.wid] = (torch.empty_like(wexp), ctx.wslot, (Cin, Cout, Lm))
+            gexp = _pending_folds[ctx.wid][0]
+        else:
+            gexp = torch.empty_like(wexp)
         _gemm_batched(X, gY, gexp, 2 * Cin, 2 * Cout, R, 2 * Cin, 2 * Cout, 2 * Cout, 1, 0, Lm, 1, (R * 2 * Cin, 0),
-                      (R * 2 * Cout, 0), (4 * Cin * Cout, 0))
-        gw = ctx.wslot if ctx.wslot is not None else torch.zeros(ctx.wshape, device=X.device)
+                      (R * 2 * Cout, 0), (4 * Cin * Cout, 0), accumulate=int(ctx.wslot is not None and not first))
+        if ctx.wslot is not None:
+            return gX, None
+        gw = torch.zeros(ctx.wshape, device=X.device)
         L.check(lib.dlwp_cweight_fold(L.ptr(gexp), L.ptr(gw), Cin, Cout, Lm, L.stream()))
-        return gX, (None if ctx.wslot is not None else gw)
+        return gX, gw
 
 
 def dhconv(X, w):

@@ -96,6 +96,122 @@ class _LinearFn(torch.autograd.Function):
         return gx.reshape(ctx.shape), gw, gb, None, gres, None
 
 
+def _weight_grad(g2, x2, weight_slot, bias_slot, has_bias, wshape):
+    """gW = g^T x with the bias gradient (column sums of g) as a by-product of the same kernel; both land straight in
+    the parameters' gradient buffers when those exist.  Returns (gw, gb) for autograd (None where a slot was used)."""
+    T, N = g2.shape
+    K = x2.shape[1]
+    gb = None
+    if has_bias:
+        gb = bias_slot if bias_slot is not None else torch.zeros(N, device=g2.device)
+    if weight_slot is not None:
+        _gemm(g2, x2, weight_slot, N, K, T, N, K, K, 1, 0, accumulate=1, rowsum=gb)
+        gw = None
+    else:
+        gw = torch.empty(N, K, device=g2.device)
+        _gemm(g2, x2, gw, N, K, T, N, K, K, 1, 0, rowsum=gb)
+        gw = gw.reshape(wshape)
+    return gw, (None if bias_slot is not None else gb)
+
+
+class _MlpFn(torch.autograd.Function):
+    """y = fc2(GELU(fc1 x)) (+ residual) as ONE autograd node (reference: Mlp.forward, nsbench/models/fourcastnet/
+    fourcastnet.py:50-56, swintransformer/swin_transformer.py:42-48).  Forward: two GEMMs (bias + GELU, bias + residual
+    epilogues).  Backward: four GEMMs and nothing else -- the product g W2 leaves its kernel already multiplied by
+    GELU'(z) (epilogue act 4), so the hidden-width gradient is written once and never re-read by an elementwise pass."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual):
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1]).contiguous().float()
+        T, K = x2.shape
+        Hd, N = w1.shape[0], w2.shape[0]
+        w1m, w2m = w1.contiguous().reshape(Hd, -1), w2.contiguous().reshape(N, -1)
+        h = torch.empty(T, Hd, device=x.device)
+        z = torch.empty(T, Hd, device=x.device)
+        _gemm(x2, w1m, h, T, Hd, K, K, K, Hd, 0, 1, b1, 1, z, None)
+        y = torch.empty(T, N, device=x.device)
+        r2 = residual.reshape(-1, N).contiguous() if residual is not None else None
+        _gemm(h, w2m, y, T, N, Hd, Hd, Hd, N, 0, 1, b2, 0, None, r2)
+        ctx.save_for_backward(x2, w1m, w2m, z, h)
+        ctx.shape, ctx.has_res = shape, residual is not None
+        ctx.w1shape, ctx.w2shape = w1.shape, w2.shape
+        ctx.slots = (_grad_slot(w1), _grad_slot(b1) if b1 is not None else None,
+                     _grad_slot(w2), _grad_slot(b2) if b2 is not None else None)
+        ctx.has_b = (b1 is not None, b2 is not None)
+        return y.reshape(*shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w1m, w2m, z, h = ctx.saved_tensors
+        T, K = x2.shape
+        Hd, N = w1m.shape[0], w2m.shape[0]
+        g2 = gy.reshape(-1, N).contiguous().float()
+        gh = torch.empty(T, Hd, device=g2.device)
+        _gemm_batched(g2, w2m, gh, T, Hd, N, N, Hd, Hd, 0, 0, act=4, residual=z)     # (g W2) * GELU'(z)
+        gw2, gb2 = _weight_grad(g2, h, ctx.slots[2], ctx.slots[3], ctx.has_b[1], ctx.w2shape)
+        gx = torch.empty(T, K, device=g2.device)
+        _gemm(gh, w1m, gx, T, K, Hd, Hd, K, K, 0, 0)
+        gw1, gb1 = _weight_grad(gh, x2, ctx.slots[0], ctx.slots[1], ctx.has_b[0], ctx.w1shape)
+        return gx.reshape(ctx.shape), gw1, gb1, gw2, gb2, (gy if ctx.has_res else None)
+
+
+def mlp(x, w1, b1, w2, b2, residual=None):
+    return _MlpFn.apply(x, w1, b1, w2, b2, residual)
+
+
+class _SkipMlpFn(torch.autograd.Function):
+    """out = fc2(GELU(fc1 t)) (+ x),  t = GELU(y + skip(x)): the tail of an SFNO block (inner linear skip, activation,
+    MLP, outer identity skip) as ONE autograd node: three GEMMs forward, six GEMMs backward, both GELU
+    derivatives applied in GEMM epilogues (act 4) and the outer skip's gradient added by the epilogue of the inner
+    skip's input-gradient product -- no elementwise kernel and no autograd accumulation on the token tensors."""
+
+    @staticmethod
+    def forward(ctx, y, x, ws, bs, w1, b1, w2, b2, outer):
+        shape = x.shape
+        C = shape[-1]
+        x2 = x.reshape(-1, C).contiguous().float()
+        y2 = y.reshape(-1, C).contiguous().float()
+        T = x2.shape[0]
+        Hd, N = w1.shape[0], w2.shape[0]
+        wsm, w1m, w2m = ws.contiguous().reshape(C, -1), w1.contiguous().reshape(Hd, -1), w2.contiguous().reshape(N, -1)
+        t = torch.empty(T, C, device=x.device)
+        z0 = torch.empty(T, C, device=x.device)
+        _gemm_batched(x2, wsm, t, T, C, C, C, C, C, 0, 1, bias=bs, act=1, preact=z0, residual=y2, res_pre=1)
+        h = torch.empty(T, Hd, device=x.device)
+        z1 = torch.empty(T, Hd, device=x.device)
+        _gemm(t, w1m, h, T, Hd, C, C, C, Hd, 0, 1, b1, 1, z1, None)
+        out = torch.empty(T, N, device=x.device)
+        _gemm(h, w2m, out, T, N, Hd, Hd, Hd, N, 0, 1, b2, 0, None, x2 if outer else None)
+        ctx.save_for_backward(x2, wsm, w1m, w2m, z0, t, z1, h)
+        ctx.shape, ctx.outer = shape, bool(outer)
+        ctx.wshapes = (ws.shape, w1.shape, w2.shape)
+        ctx.slots = tuple(_grad_slot(p) if p is not None else None for p in (ws, bs, w1, b1, w2, b2))
+        ctx.has_b = (bs is not None, b1 is not None, b2 is not None)
+        return out.reshape(*shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, gout):
+        x2, wsm, w1m, w2m, z0, t, z1, h = ctx.saved_tensors
+        T, C = x2.shape
+        Hd, N = w1m.shape[0], w2m.shape[0]
+        g2 = gout.reshape(-1, N).contiguous().float()
+        gh = torch.empty(T, Hd, device=g2.device)
+        _gemm_batched(g2, w2m, gh, T, Hd, N, N, Hd, Hd, 0, 0, act=4, residual=z1)      # (g W2) * GELU'(z1)
+        gw2, gb2 = _weight_grad(g2, h, ctx.slots[4], ctx.slots[5], ctx.has_b[2], ctx.wshapes[2])
+        gt = torch.empty(T, C, device=g2.device)
+        _gemm_batched(gh, w1m, gt, T, C, Hd, Hd, C, C, 0, 0, act=4, residual=z0)       # (gh W1) * GELU'(z0) = d/d(y + skip)
+        gw1, gb1 = _weight_grad(gh, t, ctx.slots[2], ctx.slots[3], ctx.has_b[1], ctx.wshapes[1])
+        gx = torch.empty(T, C, device=g2.device)
+        _gemm_batched(gt, wsm, gx, T, C, C, C, C, C, 0, 0, residual=g2 if ctx.outer else None)   # + outer skip
+        gws, gbs = _weight_grad(gt, x2, ctx.slots[0], ctx.slots[1], ctx.has_b[0], ctx.wshapes[0])
+        return gt.reshape(ctx.shape), gx.reshape(ctx.shape), gws, gbs, gw1, gb1, gw2, gb2, None
+
+
+def skip_mlp(y, x, ws, bs, w1, b1, w2, b2, outer=True):
+    return _SkipMlpFn.apply(y, x, ws, bs, w1, b1, w2, b2, outer)
+
+
 def linear(x, weight, bias=None, act=0, residual=None, res_pre=False):
     return _LinearFn.apply(x, weight, bias, act, residual, res_pre)
 
@@ -168,7 +284,7 @@ class Mlp(nn.Module):
         self.fc2 = Linear(hidden_features or in_features, out_features or in_features)
 
     def forward(self, x, residual=None):
-        return self.fc2(self.fc1(x, act=1), residual=residual)
+        return _MlpFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, residual)
 
 
 class PatchConv2d(nn.Conv2d):

@@ -292,6 +292,9 @@ int dlwp_get_gemm_precision(void);
 /* res_before_act != 0 adds the residual before the activation: C = act(A.B + bias + res);    */
 /* preact (optional, C's layout and strides) receives the value the activation is applied to.  */
 /* act: 0 none, 1 GELU, 2 ReLU, 3 soft-shrink(act_param); bias has its own batch strides.       */
+/* act 4 is the backward form C = (A.B) * GELU'(z) with the saved pre-activation z passed as    */
+/* `residual` (preact must be NULL): gx = g W of a Linear layer arrives already multiplied by  */
+/* the derivative of the GELU that produced its input (token-MLP backward, no gelu_bwd pass).  */
 /* Without an epilogue, long-K products with few output tiles are split along K (atomics).      */
 /* Used for the spherical transforms (per-order Legendre matrices) and the per-degree SFNO     */
 /* spectral weights, where one launch covers every (sample, order) or degree.                  */
