@@ -48,7 +48,11 @@ struct GemmDev {
 // reference's bf16-autocast runs (BASELINE configs C3-C5); tensors in HBM stay fp32.  LDS tiles are [row][k] bf16.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-constexpr int LDKB = BK + 8;   // bf16 elements per LDS row (80 bytes: 16-byte aligned fragments)
+constexpr int BKB = 32;        // K-step of the bf16-operand mode.  A 64-deep step (fewer barriers, twice the bytes in flight
+                               // per workgroup) was measured: 136 instead of 104 registers drop the occupancy from 4 to 3
+                               // waves per SIMD and the net effect is -13 % ... +10 % depending on the shape (8192x512x256:
+                               // 14.1 -> 16.2 us, 8192x256x512: 15.1 -> 13.6 us), so the 32-deep step stays
+constexpr int LDKB = BKB + 8;  // bf16 elements per LDS row (80 bytes: 16-byte aligned fragments)
 
 // epilogue activations: 0 none, 1 GELU (erf), 2 ReLU, 3 soft-shrink(lambda); 4 is the backward form
 // v * GELU'(aux) with aux read through the `residual` view (the saved pre-activation): the product g W of a Linear layer
@@ -63,16 +67,16 @@ __device__ __forceinline__ float apply_act(float v, int act, float lam) {
 
 // One (64 T) x 32 operand tile.  KC: k is the contiguous dimension in memory (element (row, k) at
 // base[row * ld + k]); otherwise the row index is contiguous (base[k * ld + row]).
-template <bool KC, bool VEC, int T>
+template <bool KC, bool VEC, int T, int BKT>
 struct TileIO {
-    static constexpr int ROWS = Tile<T>::ROWS, LDR = Tile<T>::LDR;
-    float v[8 * T];
+    static constexpr int ROWS = Tile<T>::ROWS, LDR = Tile<T>::LDR, KM = BKT / 32;
+    float v[8 * T * KM];
     static __device__ __forceinline__ void coords(int f, int& row, int& k) {
         if (VEC) {
-            if (KC) { row = f >> 3; k = 4 * (f & 7); }
+            if (KC) { row = f / (BKT / 4); k = 4 * (f % (BKT / 4)); }
             else { row = 4 * (f % (16 * T)); k = f / (16 * T); }
         } else {
-            if (KC) { row = f >> 5; k = f & 31; }
+            if (KC) { row = f / BKT; k = f % BKT; }
             else { row = f % ROWS; k = f / ROWS; }
         }
     }
@@ -80,7 +84,7 @@ struct TileIO {
         const int tid = threadIdx.x;
         if (VEC) {
 #pragma unroll
-            for (int q = 0; q < 2 * T; ++q) {
+            for (int q = 0; q < 2 * T * KM; ++q) {
                 int row, k;
                 coords(tid + 256 * q, row, k);
                 const bool ok = row0 + row < nrows && k0 + k < kend;
@@ -92,7 +96,7 @@ struct TileIO {
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 8 * T; ++q) {
+            for (int q = 0; q < 8 * T * KM; ++q) {
                 int row, k;
                 coords(tid + 256 * q, row, k);
                 const bool ok = row0 + row < nrows && k0 + k < kend;
@@ -102,10 +106,11 @@ struct TileIO {
         }
     }
     __device__ __forceinline__ void store(float* S) const {
+        static_assert(BKT == BK, "the fp32 LDS images are laid out for the 32-deep K-step");
         const int tid = threadIdx.x;
         if (VEC) {
 #pragma unroll
-            for (int q = 0; q < 2 * T; ++q) {
+            for (int q = 0; q < 2 * T * KM; ++q) {
                 int row, k;
                 coords(tid + 256 * q, row, k);
                 *reinterpret_cast<f32x4*>(&S[KC ? row * LDK + k : k * LDR + row]) =
@@ -113,7 +118,7 @@ struct TileIO {
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 8 * T; ++q) {
+            for (int q = 0; q < 8 * T * KM; ++q) {
                 int row, k;
                 coords(tid + 256 * q, row, k);
                 S[KC ? row * LDK + k : k * LDR + row] = v[q];
@@ -127,7 +132,7 @@ struct TileIO {
         const int tid = threadIdx.x;
         if (VEC) {
 #pragma unroll
-            for (int q = 0; q < 2 * T; ++q) {
+            for (int q = 0; q < 2 * T * KM; ++q) {
                 int row, k;
                 coords(tid + 256 * q, row, k);
                 *reinterpret_cast<bf16x4*>(&S[KC ? row * LDKB + k : k * LDRB + row]) =
@@ -135,20 +140,20 @@ struct TileIO {
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 8 * T; ++q) {
+            for (int q = 0; q < 8 * T * KM; ++q) {
                 int row, k;
                 coords(tid + 256 * q, row, k);
                 S[KC ? row * LDKB + k : k * LDRB + row] = (__bf16)v[q];
             }
         }
     }
-    // bf16 MFMA fragment: lane (r, g) holds row rb + r, k = 8g .. 8g+7 of the 32-deep K-step.  From the [k][row] image
+    // bf16 MFMA fragment of chunk c: lane (r, g) holds row rb + r, k = 32c + 8g .. 32c + 8g+7 of the K-step.  From the [k][row] image
     // it comes through two hardware transpose reads (ds_read_b64_tr_b16: per 16-lane group a 4 x 16 block, lane 4q+p
     // addresses block row q / columns 4p.., lane i receives column i; tools/micro/tr_read.hip) -- EXEC is all ones here.
-    static __device__ __forceinline__ bf16x8 frag_bf16(const __bf16* S, int rb, int r, int g) {
-        if (KC) return *reinterpret_cast<const bf16x8*>(&S[(rb + r) * LDKB + 8 * g]);
+    static __device__ __forceinline__ bf16x8 frag_bf16(const __bf16* S, int rb, int c, int r, int g) {
+        if (KC) return *reinterpret_cast<const bf16x8*>(&S[(rb + r) * LDKB + 32 * c + 8 * g]);
         typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-        const __bf16* p0 = &S[(8 * g + (r >> 2)) * LDRB + rb + 4 * (r & 3)];
+        const __bf16* p0 = &S[(32 * c + 8 * g + (r >> 2)) * LDRB + rb + 4 * (r & 3)];
         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0));
         const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * LDRB));
         return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -181,7 +186,9 @@ template <bool AKC, bool BKC, bool VEC, int T, bool BF>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     constexpr int BMN = Tile<T>::ROWS, NT16 = 2 * T;   // 16-row MFMA tiles per wave and direction
-    constexpr int TF = BF ? BMN * LDKB / 2 : Tile<T>::FLOATS;                // tile size in floats (bf16: two per float)
+    constexpr int BKT = BF ? BKB : BK;
+    // tile size in floats (bf16: two elements per float; the larger of the [row][k] and [k][row] images)
+    constexpr int TF = BF ? (BMN * LDKB > BKB * (BMN + 8) ? BMN * LDKB : BKB * (BMN + 8)) / 2 : Tile<T>::FLOATS;
     float* As = gsm;                 // [2][TF]
     float* Bs = gsm + 2 * TF;        // [2][TF]
     const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
@@ -224,9 +231,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
     float rsum[NT16];                // sum over k of op(A) rows wm + 16 i + r (this lane's k slots)
 #pragma unroll
     for (int i = 0; i < NT16; ++i) rsum[i] = 0.f;
-    TileIO<AKC, VEC, T> ta;
-    TileIO<BKC, VEC, T> tb;
-    const int nk = (kend - kbeg + BK - 1) / BK;
+    TileIO<AKC, VEC, T, BKT> ta;
+    TileIO<BKC, VEC, T, BKT> tb;
+    const int nk = (kend - kbeg + BKT - 1) / BKT;
     DLWP_STAMP(0);
     ta.load(a.A, a.lda, m0, a.M, kbeg, kend);
     tb.load(a.B, a.ldb, n0, a.N, kbeg, kend);
@@ -244,32 +251,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
         if (it == 1) DLWP_STAMP(2);
         if (it == 2) DLWP_STAMP(3);
         if (it + 1 < nk) {
-            ta.load(a.A, a.lda, m0, a.M, kbeg + (it + 1) * BK, kend);
-            tb.load(a.B, a.ldb, n0, a.N, kbeg + (it + 1) * BK, kend);
+            ta.load(a.A, a.lda, m0, a.M, kbeg + (it + 1) * BKT, kend);
+            tb.load(a.B, a.ldb, n0, a.N, kbeg + (it + 1) * BKT, kend);
         }
         if constexpr (BF) {
-            bf16x8 af[NT16], bf[NT16];
 #pragma unroll
-            for (int i = 0; i < NT16; ++i) af[i] = TileIO<AKC, VEC, T>::frag_bf16(reinterpret_cast<const __bf16*>(As + cur * TF), wm + 16 * i, r, g);
+            for (int c = 0; c < BKT / 32; ++c) {
+                bf16x8 af[NT16], bf[NT16];
 #pragma unroll
-            for (int j = 0; j < NT16; ++j) bf[j] = TileIO<BKC, VEC, T>::frag_bf16(reinterpret_cast<const __bf16*>(Bs + cur * TF), wn + 16 * j, r, g);
+                for (int i = 0; i < NT16; ++i) af[i] = TileIO<AKC, VEC, T, BKT>::frag_bf16(reinterpret_cast<const __bf16*>(As + cur * TF), wm + 16 * i, c, r, g);
 #pragma unroll
-            for (int i = 0; i < NT16; ++i) {
-                if (a.rowsum) {
+                for (int j = 0; j < NT16; ++j) bf[j] = TileIO<BKC, VEC, T, BKT>::frag_bf16(reinterpret_cast<const __bf16*>(Bs + cur * TF), wn + 16 * j, c, r, g);
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) rsum[i] += (float)af[i][s];
+                for (int i = 0; i < NT16; ++i) {
+                    if (a.rowsum) {
+#pragma unroll
+                        for (int s = 0; s < 8; ++s) rsum[i] += (float)af[i][s];
+                    }
+#pragma unroll
+                    for (int j = 0; j < NT16; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
                 }
-#pragma unroll
-                for (int j = 0; j < NT16; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
         } else
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             f32x4 af[NT16], bf[NT16];
 #pragma unroll
-            for (int i = 0; i < NT16; ++i) af[i] = TileIO<AKC, VEC, T>::frag(As + cur * TF, wm + 16 * i, c, r, g);
+            for (int i = 0; i < NT16; ++i) af[i] = TileIO<AKC, VEC, T, BKT>::frag(As + cur * TF, wm + 16 * i, c, r, g);
 #pragma unroll
-            for (int j = 0; j < NT16; ++j) bf[j] = TileIO<BKC, VEC, T>::frag(Bs + cur * TF, wn + 16 * j, c, r, g);
+            for (int j = 0; j < NT16; ++j) bf[j] = TileIO<BKC, VEC, T, BKT>::frag(Bs + cur * TF, wn + 16 * j, c, r, g);
 #pragma unroll
             for (int i = 0; i < NT16; ++i) {
                 rsum[i] += (af[i][0] + af[i][1]) + (af[i][2] + af[i][3]);
@@ -373,7 +383,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
 
 template <bool AKC, bool BKC, bool VEC, int T, bool BF>
 int gemm_launch_t(const GemmDev& a, dim3 grid, hipStream_t s) {
-    const size_t lds = BF ? sizeof(float) * 4 * (Tile<T>::ROWS * LDKB / 2) : sizeof(float) * 4 * Tile<T>::FLOATS;
+    constexpr int RW = Tile<T>::ROWS;
+    const size_t lds = BF ? sizeof(float) * 4 * ((RW * LDKB > BKB * (RW + 8) ? RW * LDKB : BKB * (RW + 8)) / 2)
+                          : sizeof(float) * 4 * Tile<T>::FLOATS;
     int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_kernel<AKC, BKC, VEC, T, BF>), lds, "gemm");
     if (rc) return rc;
     hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, T, BF>), grid, dim3(256), lds, s, a);

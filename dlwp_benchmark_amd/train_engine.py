@@ -72,7 +72,7 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model, inputs, target, lr=1e-3, clip_max_norm=None, allreduce=None, grad_scale=1.0,
-                 use_graph=True, call=None):
+                 use_graph=True, call=None, graph_optimizer=True):
         self.model = model
         self.flat, self.grad = flatten_parameters(model)
         self.opt = FusedAdam(self.flat, self.grad, lr=lr)
@@ -82,6 +82,9 @@ class GraphedTrainStep:
         self.call = call or (lambda m, kw: m(**kw))
         self.loss = torch.zeros((), device=self.flat.device)
         self.use_graph = use_graph
+        # graph_optimizer=False keeps clip + Adam outside the capture (two eager launches): the learning rate and the clip
+        # threshold are launch arguments, so a schedule that changes them per epoch needs them re-read at every step
+        self.graph_optimizer = graph_optimizer
         self.g_fb = self.g_opt = None
         if use_graph:
             self._capture()
@@ -112,9 +115,9 @@ class GraphedTrainStep:
         self.g_fb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_fb):
             self._fwd_bwd()
-            if self.allreduce is None:
+            if self.allreduce is None and self.graph_optimizer:
                 self._optimize()
-        if self.allreduce is not None:
+        if self.allreduce is not None and self.graph_optimizer:
             self.g_opt = torch.cuda.CUDAGraph()
             pool = self.g_fb.pool()
             with torch.cuda.graph(self.g_opt, pool=pool):
@@ -137,5 +140,8 @@ class GraphedTrainStep:
         self.g_fb.replay()
         if self.allreduce is not None:
             self.allreduce(self.grad)
+        if self.g_opt is not None:
             self.g_opt.replay()
+        elif self.allreduce is not None or not self.graph_optimizer:
+            self._optimize()
         return self.loss

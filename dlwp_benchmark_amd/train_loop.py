@@ -104,3 +104,76 @@ def train_ns(model, u_train, u_val, name="model", epochs=10, batch_size=4, seque
         if verbose and rank == 0:
             print(f"Epoch {str(epoch).zfill(3)}/{epochs}\tMSE train: {train_mse:.2E}\tMSE val: {val_mse:.2E}")
     return log
+
+
+@torch.no_grad()
+def validation_mse_dlwp(model, dataset, batch_size, device):
+    """dlwpbench/scripts/train.py:236-252: MSE over the concatenated outputs of every validation sample."""
+    from . import wbdata
+    tot, cnt = 0.0, 0
+    was_training = model.training
+    model.eval()
+    for i0 in range(0, len(dataset), batch_size):
+        c, p, g, t = wbdata.to_device_batch([dataset[i] for i in range(i0, min(i0 + batch_size, len(dataset)))], device)
+        y_hat = model(constants=c, prescribed=p, prognostic=g)
+        B, T, D, H, W = y_hat.shape
+        m = error_moments(y_hat.reshape(B, T, D * H, W), t.reshape(B, T, D * H, W))
+        tot += m[0].sum().item()
+        cnt += y_hat.numel()
+    model.train(was_training)
+    return tot / max(cnt, 1)
+
+
+def train_dlwp(model, train_dataset, val_dataset, name="model", epochs=10, batch_size=4, learning_rate=1e-3,
+               clip_gradients=False, gradient_accumulation_steps=1, seed=1234, out_dir="outputs", save_model=True,
+               use_graph=True, verbose=False):
+    """The dlwpbench training script's epoch loop (src/dlwpbench/scripts/train.py:104-197) around the captured step of
+    train_engine.GraphedTrainStep, for any dlwpbench module (forward(constants, prescribed, prognostic)): batches of
+    `WeatherBenchDataset.__getitem__` tuples (wbdata.WeatherBenchArrays) from the seeded rank-sharded permutation, MSE,
+    Adam with the cosine schedule stepped per epoch (:194), optional clipping at max_norm = current learning rate
+    (:230-232), validation without gradients, the `_last` / `_best` checkpoint policy (:255-266).  One process per GPU; with
+    torch.distributed initialised the flat gradient is all-reduced once per step.  Returns per-epoch dicts."""
+    from . import wbdata
+    from .train_engine import GraphedTrainStep
+    if gradient_accumulation_steps != 1:
+        # the reference sums un-scaled micro-batch gradients and clips after every micro-backward (:214-233); the captured
+        # step has no micro-batch loop yet
+        raise NotImplementedError("train_dlwp: gradient_accumulation_steps > 1 is not built (use a smaller batch_size)")
+    device = next(model.parameters()).device
+    rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+    world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    reducer = ddp.FlatGradAllReduce() if world > 1 else None
+    ckpt_last = os.path.join(out_dir, name, "checkpoints", f"{name}_last.ckpt")
+    step, iteration, best, log = None, 0, float("inf"), []
+
+    def kwargs_of(c, p, g):
+        return {k: v for k, v in (("constants", c), ("prescribed", p), ("prognostic", g)) if v is not None}
+
+    for epoch in range(epochs):
+        lr = cosine_lr(learning_rate, epoch, epochs)
+        losses = []
+        for idx in wbdata.shard_batches(train_dataset, epoch, rank, world, batch_size, seed):
+            c, p, g, t = wbdata.to_device_batch([train_dataset[int(i)] for i in idx], device)
+            if step is None:
+                step = GraphedTrainStep(model, kwargs_of(c, p, g), t, lr=lr, allreduce=reducer, grad_scale=1.0 / world,
+                                        use_graph=use_graph, graph_optimizer=False,
+                                        clip_max_norm=lr if clip_gradients else None)
+                if world > 1:
+                    ddp.broadcast_parameters(step.flat, src=0)
+            step.opt.lr = lr
+            step.clip = lr if clip_gradients else None
+            losses.append(step(kwargs_of(c, p, g), t).clone())
+            iteration += 1
+        train_mse = torch.stack(losses).mean().item() if losses else float("nan")
+        val_mse = validation_mse_dlwp(model, val_dataset, batch_size, device)
+        if save_model and rank == 0 and step is not None:
+            sched = {"T_max": epochs, "last_epoch": epoch, "base_lrs": [learning_rate], "_last_lr": [lr]}
+            if val_mse > best or epoch == epochs - 1:
+                dst = ckpt_last
+            else:
+                best, dst = val_mse, ckpt_last.replace("last", "best")
+            write_checkpoint(model, step.opt, sched, epoch, iteration, best, dst)
+        log.append({"epoch": epoch, "lr": lr, "train_mse": train_mse, "val_mse": val_mse})
+        if verbose and rank == 0:
+            print(f"Epoch {str(epoch).zfill(3)}/{epochs}\tMSE train: {train_mse:.2E}\tMSE val: {val_mse:.2E}")
+    return log

@@ -132,3 +132,76 @@ def test_linear_bf16_operand_mode(cuda, T, K, N):
     assert rel(xd.grad, gx_ref) <= 1e-5
     assert rel(wd.grad, gw_ref) <= 1e-4
     assert rel(bd.grad, rb(gy).sum(0)) <= 1e-4
+
+
+@pytest.mark.parametrize("T,C,Hd,N,res,slots", [(1024, 64, 256, 64, True, True), (300, 96, 192, 96, True, False),
+                                                  (77, 13, 29, 13, False, False), (512, 128, 256, 40, False, True)])
+def test_mlp_single_node(cuda, T, C, Hd, N, res, slots):
+    """token_ops.mlp: fc2(GELU(fc1 x)) (+ residual) with the GELU derivative applied in the epilogue of the g W2 product
+    (GEMM act 4); checked against torch's fp32 autograd, with and without preallocated gradient slots."""
+    from dlwp_benchmark_amd import token_ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(T, C, generator=g)
+    w1, b1 = torch.randn(Hd, C, generator=g) / C ** 0.5, torch.randn(Hd, generator=g) * 0.1
+    w2, b2 = torch.randn(N, Hd, generator=g) / Hd ** 0.5, torch.randn(N, generator=g) * 0.1
+    r = torch.randn(T, N, generator=g) if res else None
+    gy = torch.randn(T, N, generator=g)
+    ref = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)] + ([r.clone().requires_grad_(True)] if res else [])
+    y_ref = F.linear(F.gelu(F.linear(ref[0], ref[1], ref[2])), ref[3], ref[4])
+    if res:
+        y_ref = y_ref + ref[5]
+    y_ref.backward(gy)
+    dev = [t.to(cuda).requires_grad_(True) for t in (x, w1, b1, w2, b2)] + ([r.to(cuda).requires_grad_(True)] if res else [])
+    params = [torch.nn.Parameter(t.detach()) for t in dev[1:5]]
+    if slots:                                   # fused accumulation straight into the gradient buffers, on top of a value
+        for p in params:
+            p.grad = torch.full_like(p, 0.25)
+    y = token_ops.mlp(dev[0], *params, dev[5] if res else None)
+    y.backward(gy.to(cuda))
+    assert rel(y, y_ref) <= 1e-4
+    assert rel(dev[0].grad, ref[0].grad) <= 5e-4
+    for p, q in zip(params, ref[1:5]):
+        assert rel(p.grad - (0.25 if slots else 0.0), q.grad) <= 5e-4
+    if res:
+        assert rel(dev[5].grad, ref[5].grad) <= 1e-6
+
+
+@pytest.mark.parametrize("T,C,Hd,outer", [(1024, 64, 128, True), (260, 48, 96, False)])
+def test_skip_mlp_single_node(cuda, T, C, Hd, outer):
+    """token_ops.skip_mlp (tail of an SFNO block): out = fc2(GELU(fc1 t)) (+ x), t = GELU(y + skip(x))."""
+    from dlwp_benchmark_amd import token_ops
+    g = torch.Generator().manual_seed(4)
+    mk = lambda *s: torch.randn(*s, generator=g)      # noqa: E731
+    y, x = mk(T, C), mk(T, C)
+    ws, bs = mk(C, C) / C ** 0.5, mk(C) * 0.1
+    w1, b1 = mk(Hd, C) / C ** 0.5, mk(Hd) * 0.1
+    w2, b2 = mk(C, Hd) / Hd ** 0.5, mk(C) * 0.1
+    gout = mk(T, C)
+    ref = [t.clone().requires_grad_(True) for t in (y, x, ws, bs, w1, b1, w2, b2)]
+    t_ref = F.gelu(ref[0] + F.linear(ref[1], ref[2], ref[3]))
+    o_ref = F.linear(F.gelu(F.linear(t_ref, ref[4], ref[5])), ref[6], ref[7])
+    if outer:
+        o_ref = o_ref + ref[1]
+    o_ref.backward(gout)
+    dev = [t.to(cuda).requires_grad_(True) for t in (y, x, ws, bs, w1, b1, w2, b2)]
+    out = token_ops.skip_mlp(*dev, outer)
+    out.backward(gout.to(cuda))
+    assert rel(out, o_ref) <= 1e-4
+    for got, want in zip(dev, ref):
+        assert rel(got.grad, want.grad) <= 5e-4
+
+
+def test_gemm_bf16_deep_k(cuda):
+    """bf16-operand mode with K not a multiple of the 64-deep K-step and transposed operands (weight-gradient product,
+    split-K path included): equals the fp32 product of the bf16-rounded operands."""
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.token_ops import _gemm
+    g = torch.Generator().manual_seed(9)
+    rb = lambda t: t.bfloat16().float()    # noqa: E731
+    for (M, N, K) in [(128, 192, 4000), (200, 72, 100), (64, 64, 36)]:
+        A = torch.randn(K, M, generator=g)          # op(A) = A^T [M, K]
+        B = torch.randn(K, N, generator=g)
+        C_ = torch.empty(M, N, device=cuda)
+        with L.gemm_precision("bf16"):
+            _gemm(A.to(cuda), B.to(cuda), C_, M, N, K, M, N, N, 1, 0)
+        assert rel(C_, rb(A).t() @ rb(B)) <= 2e-5

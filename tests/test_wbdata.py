@@ -1,0 +1,87 @@
+"""WeatherBench sample assembly (dlwp half of SURVEY.md §8 row D-shard) against the reference's index arithmetic, restated by
+hand from src/dlwpbench/data/datasets/datasets.py:320-398 on fields whose values encode (variable, time)."""
+import numpy as np
+import torch
+
+from dlwp_benchmark_amd import wbdata
+
+
+def coded_fields(n_time, H=4, W=8):
+    """value = 1000 * variable_id + time index, so every returned frame can be traced."""
+    t = np.arange(n_time, dtype=np.float32)[:, None, None] * np.ones((1, H, W), dtype=np.float32)
+    return {"t2m": 1000 + t, "u10": 2000 + t, "z": {500: 3000 + t, 700: 4000 + t}, "tisr": 5000 + t,
+            "orography": np.full((H, W), 7.0, dtype=np.float32), "lsm": np.full((H, W), 8.0, dtype=np.float32)}
+
+
+PROG = {"t2m": [], "z": [500, 700], "u10": []}
+
+
+def test_len_and_windows():
+    L, ctx = 5, 2
+    ds = wbdata.WeatherBenchArrays(coded_fields(23), PROG, ["tisr"], ["orography", "lsm"], sequence_length=L, context_size=ctx)
+    assert len(ds) == (23 - L) // L                                   # datasets.py:322-323
+    constants, prescribed, prognostic, target = ds[2]
+    t0 = 2 * L                                                        # item * sequence_length (:335)
+    assert constants.shape == (1, 2, 4, 8) and constants[0, 0, 0, 0] == 7.0 and constants[0, 1, 0, 0] == 8.0
+    assert prescribed.shape == (L, 1, 4, 8)
+    assert np.array_equal(prescribed[:, 0, 0, 0], 5000 + np.arange(t0, t0 + L))
+    # channel order = dict order, levels expanded in place (:368-384)
+    assert prognostic.shape == (L, 4, 4, 8)
+    assert np.array_equal(prognostic[0, :, 0, 0], [1000 + t0, 3000 + t0, 4000 + t0, 2000 + t0])
+    assert np.array_equal(prognostic[:, 0, 0, 0], 1000 + np.arange(t0, t0 + L))
+    # target = window[1:][ctx:] -> first target frame is t0 + 1 + ctx (the off-by-one of App. B-9, kept)
+    assert target.shape == (L - ctx, 4, 4, 8)
+    assert np.array_equal(target[:, 0, 0, 0], 1000 + np.arange(t0 + 1 + ctx, t0 + L + 1))
+    assert prognostic.dtype == np.float32 and target.dtype == np.float32
+
+
+def test_absent_inputs_are_nan_dummies_and_collate_to_none():
+    ds = wbdata.WeatherBenchArrays(coded_fields(12), {"t2m": []}, sequence_length=3)
+    c, p, g, t = ds[0]
+    assert isinstance(c, float) and np.isnan(c) and isinstance(p, float) and np.isnan(p)     # :318, :366
+    batch = wbdata.to_device_batch([ds[0], ds[1]], "cpu")
+    assert batch[0] is None and batch[1] is None
+    assert batch[2].shape == (2, 3, 1, 4, 8) and batch[3].shape == (2, 2, 1, 4, 8)
+
+
+def test_normalisation_uses_per_level_statistics():
+    stats = {"t2m": {"mean": 1000.0, "std": 2.0}, "z": {"level": {500: {"mean": 3000.0, "std": 4.0}, 700: {"mean": 4000.0, "std": 8.0}}},
+             "u10": {"mean": 2000.0, "std": 1.0}, "tisr": {"mean": 5000.0, "std": 5.0}, "orography": {"mean": 7.0, "std": 1.0},
+             "lsm": {"mean": 0.0, "std": 2.0}}
+    ds = wbdata.WeatherBenchArrays(coded_fields(12), PROG, ["tisr"], ["orography", "lsm"], sequence_length=3, normalize=True,
+                                   stats=stats)
+    c, p, g, t = ds[1]
+    assert c[0, 0, 0, 0] == 0.0 and c[0, 1, 0, 0] == 4.0
+    assert np.allclose(p[:, 0, 0, 0], np.arange(3, 6) / 5.0)
+    assert np.allclose(g[0, :, 0, 0], [3 / 2.0, 3 / 4.0, 3 / 8.0, 3.0])
+
+
+def test_noise_is_added_to_inputs_only_and_seeded_per_item():
+    ds = wbdata.WeatherBenchArrays(coded_fields(12), {"t2m": []}, sequence_length=3, noise=0.5, seed=7)
+    clean = wbdata.WeatherBenchArrays(coded_fields(12), {"t2m": []}, sequence_length=3)
+    a, b = ds[1], ds[1]
+    assert np.array_equal(a[2], b[2])                                 # same item -> same noise whatever rank draws it
+    assert not np.array_equal(a[2], ds[0][2] + 3)                     # different items -> different streams
+    assert np.array_equal(a[3], clean[1][3])                          # targets are noise free (:392-393)
+    d = a[2] - clean[1][2]
+    assert 0.1 < d.std() < 1.5
+
+
+def test_sharding_is_a_partition_independent_of_world_size():
+    fields, prog, presc, const = wbdata.synthetic_fields(64, 8, 16)
+    ds = wbdata.WeatherBenchArrays(fields, prog, presc, const, sequence_length=5, normalize=True)
+    n = len(ds)
+    one = wbdata.shard_batches(ds, epoch=3, rank=0, world=1, batch=1).ravel()
+    two = np.concatenate([wbdata.shard_batches(ds, 3, r, 2, 1).ravel() for r in range(2)])
+    assert sorted(one.tolist()) == list(range(n)) and sorted(two.tolist()) == sorted(one.tolist())[: len(two)] or set(two) <= set(one)
+    c, p, g, t = ds[int(one[0])]
+    assert c.shape == (1, 4, 8, 16) and p.shape == (5, 1, 8, 16) and g.shape == (5, 8, 8, 16) and t.shape == (4, 8, 8, 16)
+    assert abs(float(g.mean())) < 1.0 and 0.3 < float(g.std()) < 3.0   # z-scored synthetic fields
+
+
+def test_zero_fill_past_the_end_of_the_record():
+    # a window that starts inside the record but is shorter than the sequence is padded with zeros (:386-389)
+    ds = wbdata.WeatherBenchArrays(coded_fields(7), {"t2m": []}, sequence_length=5)
+    ds.n_time = 100                                                   # pretend the index space is longer than the stored data
+    c, p, g, t = ds[1]                                                # t0 = 5: only 2 frames exist
+    assert g.shape[0] == 4 and np.array_equal(g[:, 0, 0, 0], [1005, 1006, 0, 0])
