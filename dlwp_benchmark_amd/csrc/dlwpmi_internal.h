@@ -71,6 +71,17 @@ struct dlwp_fno_spatial_args {
 };
 int dlwp_fno_spatial(const dlwp_fno_plan* p, const dlwp_fno_spatial_args* a, hipStream_t stream);
 long long dlwp_fno_gslab_stride(int C);
+// every partial slab of a training step folded by ONE launch (slab-parallel, coalesced):
+//   plain job  (pwmlp == 0): d1[i] += sum_s slab[s*stride + i] (i < n1), d2[i] += sum_s slab[s*stride + n1 + i] (i < n2)
+//   pwmlp job  (pwmlp != 0): the accumulator-tile slabs of dlwp_pwmlp_bwd_ex -> d1 = gw1, d2 = gb1, d3 = gw2, d4 = gb2
+struct dlwp_fold_job {
+    const float* slab;
+    int nslab, pwmlp;
+    long long stride, n1, n2;      // plain jobs
+    int Cin, Ch, Cout;             // pwmlp jobs
+    float *d1, *d2, *d3, *d4;
+};
+int dlwp_fold_slabs(const dlwp_fold_job* jobs, int njobs, hipStream_t stream);
 // generic partial-slab fold: dst_k[i] += sum_s slab[s*stride + off_k + i]
 int dlwp_slab_reduce(const float* slab, int nslab, long long stride, float* d1, long long n1, float* d2, long long n2,
                      float* d3, long long n3, float* d4, long long n4, hipStream_t stream);

@@ -125,6 +125,18 @@ __global__ __launch_bounds__(256) void fno_spatial_kernel(SpatialDev a) {
     const float2 twl = a.twH[twj * a.H + h];
     const float bias_raw = a.bias ? a.bias[tid < a.C ? tid : 0] : 0.f;
     const float bias_v = tid < a.C ? bias_raw : 0.f;
+    // running partials of this workgroup's gradient slab (read-modify-write across net calls): fetched here, with every
+    // other input, instead of in front of the final store (a dependent global round trip at the very end of the kernel)
+    constexpr int SLQ = 4;
+    float slab_old[SLQ], slab_b_old = 0.f;
+#pragma unroll
+    for (int k = 0; k < SLQ; ++k) slab_old[k] = 0.f;
+    const long long slab_off = (long long)blockIdx.x * (((long long)a.C * a.C + a.C + 3) & ~3LL);
+    if (a.is_bwd && a.gslab && a.gslab_accumulate) {
+#pragma unroll
+        for (int k = 0; k < SLQ; ++k) slab_old[k] = a.gslab[slab_off + min(tid + 256 * k, a.C * a.C - 1)];
+        slab_b_old = a.gslab[slab_off + a.C * a.C + min(tid, a.C - 1)];
+    }
     DLWP_STAMP(1);
 
     // ---- commit phase
@@ -301,14 +313,19 @@ __global__ __launch_bounds__(256) void fno_spatial_kernel(SpatialDev a) {
     DLWP_STAMP(11);
     if (a.x1_out) store_x1(x1s, a.x1_out, b, h, a.H, a.m2c, a.C, a.C_pad, a.NP);
     if (a.is_bwd && (a.g_wskip || a.gslab)) {
-        for (int idx = tid; idx < a.C * a.C; idx += 256) {
+        int kq = 0;
+        for (int idx = tid; idx < a.C * a.C; idx += 256, ++kq) {
             const int o = fastdiv(idx, a.dC), i = idx - o * a.C;
             float v = 0.f;
 #pragma unroll
             for (int w2 = 0; w2 < 4; ++w2) v += gks[(w2 * a.C_pad + o) * a.C_pad + i];
             if (a.gslab) {
-                float* sl = a.gslab + (long long)blockIdx.x * (((long long)a.C * a.C + a.C + 3) & ~3LL) + idx;
-                *sl = a.gslab_accumulate ? *sl + v : v;
+                float* sl = a.gslab + slab_off + idx;
+                float old = 0.f;
+                if (a.gslab_accumulate) {
+                    old = kq == 0 ? slab_old[0] : kq == 1 ? slab_old[1] : kq == 2 ? slab_old[2] : kq == 3 ? slab_old[3] : *sl;
+                }
+                *sl = old + v;
             } else {
                 atomic_add_f32(&a.g_wskip[idx], v);   // all workgroups hit the same C*C words: slow, API path only
             }
@@ -318,8 +335,7 @@ __global__ __launch_bounds__(256) void fno_spatial_kernel(SpatialDev a) {
         float s = 0.f;
         for (int x = 0; x < a.W; ++x) s += tin_s[tid * LDP + x];
         if (a.gslab) {
-            float* sl = a.gslab + (long long)blockIdx.x * (((long long)a.C * a.C + a.C + 3) & ~3LL) + a.C * a.C + tid;
-            *sl = a.gslab_accumulate ? *sl + s : s;
+            a.gslab[slab_off + a.C * a.C + tid] = (a.gslab_accumulate ? slab_b_old : 0.f) + s;
         } else {
             atomic_add_f32(&a.g_bias[tid], s);
         }

@@ -11,6 +11,7 @@
 // of every net call are kept in HBM (a few MB each, far below 288 GB) for BPTT.
 #include "common.cuh"
 #include "dlwpmi_internal.h"
+#include <algorithm>
 #include <vector>
 
 struct dlwp_fno_trainer {
@@ -234,16 +235,26 @@ int enqueue_loss_backward(dlwp_fno_trainer* tr, const float* grad_out, hipStream
                                     g.lw2, g.lb2, tr->slab_lift, k != tr->ncalls - 1, c.B, tr->Cin, c.lifting, C,
                                     HW, s))) return rc;
     }
-    // fold the per-workgroup partial slabs of all net calls into the gradient buffer
-    for (int l = 0; l < NL; ++l)
-        if ((rc = dlwp_slab_reduce(tr->slab_skip + (long long)l * c.B * c.H * dlwp_fno_gslab_stride(C), c.B * c.H,
-                                   dlwp_fno_gslab_stride(C), g.skip(l), (long long)C * C, g.bias(l), C, nullptr, 0,
-                                   nullptr, 0, s))) return rc;
+    // fold the per-workgroup partial slabs of all net calls into the gradient buffer: one launch when the job table holds
+    // them all (n_layers + 2 jobs), otherwise layer by layer
     const int nslab = dlwp_pwmlp_slab_count(c.B, HW);
-    if ((rc = dlwp_pwmlp_slab_reduce(tr->slab_proj, nslab, C, c.projection, c.out_channels, g.pw1, g.pb1, g.pw2,
-                                     g.pb2, s))) return rc;
-    if ((rc = dlwp_pwmlp_slab_reduce(tr->slab_lift, nslab, tr->Cin, c.lifting, C, g.lw1, g.lb1, g.lw2, g.lb2, s)))
-        return rc;
+    std::vector<dlwp_fold_job> jobs;
+    for (int l = 0; l < NL; ++l) {
+        dlwp_fold_job q{};
+        q.slab = tr->slab_skip + (long long)l * c.B * c.H * dlwp_fno_gslab_stride(C);
+        q.nslab = c.B * c.H; q.stride = dlwp_fno_gslab_stride(C);
+        q.d1 = g.skip(l); q.n1 = (long long)C * C; q.d2 = g.bias(l); q.n2 = C;
+        jobs.push_back(q);
+    }
+    dlwp_fold_job qp{}, ql{};
+    qp.slab = tr->slab_proj; qp.nslab = nslab; qp.pwmlp = 1; qp.Cin = C; qp.Ch = c.projection; qp.Cout = c.out_channels;
+    qp.d1 = g.pw1; qp.d2 = g.pb1; qp.d3 = g.pw2; qp.d4 = g.pb2;
+    ql.slab = tr->slab_lift; ql.nslab = nslab; ql.pwmlp = 1; ql.Cin = tr->Cin; ql.Ch = c.lifting; ql.Cout = C;
+    ql.d1 = g.lw1; ql.d2 = g.lb1; ql.d3 = g.lw2; ql.d4 = g.lb2;
+    jobs.push_back(qp);
+    jobs.push_back(ql);
+    for (size_t k = 0; k < jobs.size(); k += 8)
+        if ((rc = dlwp_fold_slabs(jobs.data() + k, (int)std::min<size_t>(8, jobs.size() - k), s))) return rc;
     return DLWP_OK;
 }
 

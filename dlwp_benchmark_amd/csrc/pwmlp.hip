@@ -559,6 +559,84 @@ __global__ __launch_bounds__(256) void pwmlp_slab_reduce_kernel(const float* __r
     }
 }
 
+// ---- one launch that folds EVERY partial slab of a training step into the gradient buffer.
+// The separate folds above walk the slab dimension serially (256 dependent-free but serial loads per thread, 12-17 us per
+// launch, six launches per step).  Here a workgroup owns 64 consecutive slab offsets (coalesced 256-byte rows) and its four
+// waves each sum a quarter of the slabs, 16 loads in flight per lane, combined through LDS; the destination of an offset
+// is found by inverting the slab layout (tile order of pwmlp_bwd, plain order of the skip-weight slabs).
+constexpr int FOLD_MAX_JOBS = 8;
+struct FoldJobDev {
+    const float* slab;
+    long long stride;           // floats between consecutive slabs
+    int nslab, kind;            // kind 0: plain {d1[n1] | d2[n2]}; 1: pwmlp accumulator-tile layout
+    int blk0, nblk;             // block range of this job inside the launch
+    float *d1, *d2, *d3, *d4;   // kind 0: d1, d2;  kind 1: gw1, gb1, gw2, gb2
+    int n1, n2;                 // kind 0 segment lengths
+    int Cin, Ch, Cout, nob, nib, Ch_pad, Cout_pad;
+};
+struct FoldArgs {
+    FoldJobDev j[FOLD_MAX_JOBS];
+    int njobs;
+};
+
+__device__ __forceinline__ float* fold_dst(const FoldJobDev& J, long long off) {
+    if (J.kind == 0) {
+        if (off < J.n1) return J.d1 + off;
+        if (off < (long long)J.n1 + J.n2) return J.d2 + (off - J.n1);
+        return nullptr;
+    }
+    const long long o_t1 = (long long)(J.Ch_pad / 16) * J.nob * 256, o_gb1 = o_t1 + (long long)(J.Ch_pad / 16) * J.nib * 256;
+    const long long o_gb2 = o_gb1 + J.Ch_pad;
+    if (off < o_t1) {            // dW2 tile (hb, ob): lane = (o%16/4)*16 + h%16, register j = o%4
+        const int j = (int)(off & 3), lane = (int)((off >> 2) & 63), t = (int)(off >> 8);
+        const int hb = t / J.nob, ob = t - hb * J.nob;
+        const int o = ob * 16 + (lane >> 4) * 4 + j, h = hb * 16 + (lane & 15);
+        return (o < J.Cout && h < J.Ch) ? J.d3 + (long long)o * J.Ch + h : nullptr;
+    }
+    if (off < o_gb1) {           // dW1 tile (hb, ib): lane = (h%16/4)*16 + i%16, register j = h%4
+        const long long e = off - o_t1;
+        const int j = (int)(e & 3), lane = (int)((e >> 2) & 63), t = (int)(e >> 8);
+        const int hb = t / J.nib, ib = t - hb * J.nib;
+        const int h = hb * 16 + (lane >> 4) * 4 + j, i = ib * 16 + (lane & 15);
+        return (h < J.Ch && i < J.Cin) ? J.d1 + (long long)h * J.Cin + i : nullptr;
+    }
+    if (off < o_gb2) {
+        const int h = (int)(off - o_gb1);
+        return h < J.Ch ? J.d2 + h : nullptr;
+    }
+    const int o = (int)(off - o_gb2);
+    return o < J.Cout ? J.d4 + o : nullptr;
+}
+
+__global__ __launch_bounds__(256) void fold_slabs_kernel(FoldArgs a) {
+    __shared__ float part[4][64];
+    int ji = 0;
+#pragma unroll
+    for (int k = 1; k < FOLD_MAX_JOBS; ++k)
+        if (k < a.njobs && (int)blockIdx.x >= a.j[k].blk0) ji = k;
+    const FoldJobDev& J = a.j[ji];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long off = (long long)((int)blockIdx.x - J.blk0) * 64 + lane;
+    float* dst = off < J.stride ? fold_dst(J, off) : nullptr;
+    float acc = 0.f;
+    if (dst) {
+        const int per = (J.nslab + 3) / 4, s0 = w * per, s1 = min(J.nslab, s0 + per);
+        const float* p = J.slab + off;
+        int s = s0;
+        for (; s + 16 <= s1; s += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = p[(long long)(s + u) * J.stride];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc += v[u];
+        }
+        for (; s < s1; ++s) acc += p[(long long)s * J.stride];
+    }
+    part[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && dst) *dst += (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
     return dlwp_ensure_lds(reinterpret_cast<const void*>(kernel), bytes, "pwmlp");
@@ -685,6 +763,36 @@ long long dlwp_pwmlp_slab_stride(int Cin, int Ch, int Cout) {
 }
 
 int dlwp_pwmlp_slab_count(int B, int P) { return B * ceil_div(P, PT); }
+
+int dlwp_fold_slabs(const dlwp_fold_job* jobs, int njobs, hipStream_t stream) {
+    DLWP_REQUIRE(jobs && njobs >= 1 && njobs <= FOLD_MAX_JOBS, DLWP_E_INVALID, "fold_slabs: 1..%d jobs", FOLD_MAX_JOBS);
+    FoldArgs a{};
+    a.njobs = njobs;
+    int blocks = 0;
+    for (int k = 0; k < njobs; ++k) {
+        const dlwp_fold_job& q = jobs[k];
+        FoldJobDev& J = a.j[k];
+        DLWP_REQUIRE(q.slab && q.nslab > 0, DLWP_E_INVALID, "fold_slabs: job %d has no slab", k);
+        J.slab = q.slab; J.nslab = q.nslab; J.kind = q.pwmlp ? 1 : 0;
+        if (q.pwmlp) {
+            J.stride = dlwp_pwmlp_slab_stride(q.Cin, q.Ch, q.Cout);
+            J.Cin = q.Cin; J.Ch = q.Ch; J.Cout = q.Cout;
+            J.nob = round_up(q.Cout, 16) / 16; J.nib = round_up(q.Cin, 16) / 16;
+            J.Ch_pad = round_up(q.Ch, 16); J.Cout_pad = round_up(q.Cout, 16);
+            J.d1 = q.d1; J.d2 = q.d2; J.d3 = q.d3; J.d4 = q.d4;
+            DLWP_REQUIRE(q.d1 && q.d2 && q.d3 && q.d4, DLWP_E_INVALID, "fold_slabs: job %d needs gw1, gb1, gw2, gb2", k);
+        } else {
+            J.stride = q.stride; J.d1 = q.d1; J.d2 = q.d2; J.n1 = (int)q.n1; J.n2 = (int)q.n2;
+            DLWP_REQUIRE(q.d1 && q.n1 + q.n2 <= q.stride, DLWP_E_INVALID, "fold_slabs: job %d segments exceed the stride", k);
+        }
+        J.blk0 = blocks;
+        J.nblk = (int)((J.stride + 63) / 64);
+        blocks += J.nblk;
+    }
+    hipLaunchKernelGGL(fold_slabs_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
 
 int dlwp_slab_reduce(const float* slab, int nslab, long long stride, float* d1, long long n1, float* d2, long long n2,
                      float* d3, long long n3, float* d4, long long n4, hipStream_t stream) {
