@@ -20,6 +20,14 @@ int dlwp_pwmlp_bwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, 
                       float mse_scale, const dlwp_chan_dst* gx, int gx_accumulate, const dlwp_chan_dst* gres,
                       float* gw1, float* gb1, float* gw2, float* gb2, float* slab, int slab_accumulate, int B,
                       int Cin, int Ch, int Cout, int P, hipStream_t stream);
+// as dlwp_pwmlp_bwd_ex, plus (x1_out != nullptr) the adjoint W-axis DFT of every finished gx row written to x1_out
+// (dlwp_fno_rows_dft(plan, gx, 0, 1, ...)'s result): the projection backward feeds the last block's backward directly
+int dlwp_pwmlp_bwd_rows_ex(const dlwp_chan_src* x, const float* w1, const float* b1, const float* w2,
+                           const dlwp_chan_src* gy, const dlwp_chan_src* pred, const dlwp_chan_src* target,
+                           float mse_scale, const dlwp_chan_dst* gx, int gx_accumulate, const dlwp_chan_dst* gres,
+                           float* gw1, float* gb1, float* gw2, float* gb2, float* slab, int slab_accumulate, int B,
+                           int Cin, int Ch, int Cout, int P, const dlwp_fno_plan* rows_plan, float2* x1_out,
+                           hipStream_t stream);
 // per-workgroup parameter-gradient slabs of pwmlp_bwd: [slab_count][slab_stride] floats
 long long dlwp_pwmlp_slab_stride(int Cin, int Ch, int Cout);
 int dlwp_pwmlp_slab_count(int B, int P);

@@ -205,11 +205,12 @@ int enqueue_loss_backward(dlwp_fno_trainer* tr, const float* grad_out, hipStream
         dlwp_chan_src targ{tr->y + oofs, tr->traj_out, HW, nullptr, nullptr};
         dlwp_chan_dst gx{gcur, tr->act, HW, nullptr, nullptr};
         dlwp_chan_dst gr{ci.gres, ci.gres_bs, HW, nullptr, nullptr};  // identity path of the residual
-        if ((rc = dlwp_pwmlp_bwd_ex(&ps, w.pw1, w.pb1, w.pw2, &gy, grad_out ? nullptr : &pred, grad_out ? nullptr : &targ,
-                                    mse_scale, &gx, 0, ci.gres ? &gr : nullptr, g.pw1, g.pb1,
-                                    g.pw2, g.pb2, tr->slab_proj, k != tr->ncalls - 1, c.B, C, c.projection,
-                                    c.out_channels, HW, s))) return rc;
-        if ((rc = dlwp_fno_rows_dft(tr->plan, gcur, 0, 1, tr->x1, c.B, s))) return rc;
+        // the adjoint W-axis DFT of the finished gradient rows rides in the epilogue where the shapes allow (one launch
+        // less per net call); otherwise the callee runs the separate rows kernel
+        if ((rc = dlwp_pwmlp_bwd_rows_ex(&ps, w.pw1, w.pb1, w.pw2, &gy, grad_out ? nullptr : &pred,
+                                         grad_out ? nullptr : &targ, mse_scale, &gx, 0, ci.gres ? &gr : nullptr, g.pw1,
+                                         g.pb1, g.pw2, g.pb2, tr->slab_proj, k != tr->ncalls - 1, c.B, C, c.projection,
+                                         c.out_channels, HW, tr->plan, tr->x1, s))) return rc;
         for (int l = NL - 1; l >= 0; --l) {
             if ((rc = dlwp_fno_mix_bwd(tr->plan, tr->x1, reinterpret_cast<const float2*>(w.spec(l)),
                                        xhat + l * xhatB, tr->spec, reinterpret_cast<float2*>(g.spec(l)), c.B, s))) return rc;

@@ -227,6 +227,11 @@ struct BwdArgs {
     int Cin_pad, Ch_pad, Cout_pad;
     int vec_w, vec_x;
     FastDiv dCin, dCh;
+    // optional fused W-axis DFT (adjoint table) of the finished gx row -- projection backward -> last spectral block's
+    // backward without a separate rows launch; needs PT == W, NP == 16, dense gx, gx_accumulate == 0
+    float2* x1_out;
+    const float* FT;
+    int rows_H, m2c;
 };
 
 __device__ __forceinline__ void grad_flush(float* slab_ptr, float* grad_ptr, bool accumulate, float v) {
@@ -255,6 +260,8 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
     const int n2 = matload_units(a.Cout, a.Ch, a.vec_w != 0, 4), n1 = matload_units(a.Ch, a.Cin, a.vec_w != 0, 4);
     l2.issue(a.w2, n2);
     l1.issue(a.w1, n1);
+    float4 ftv = make_float4(0.f, 0.f, 0.f, 0.f);          // DFT table [16][PT] of the fused rows step
+    if (a.x1_out && tid < 16 * (PT / 4)) ftv = reinterpret_cast<const float4*>(a.FT)[tid];
     stage_pixels(xs, a.x, b, a.Cin, a.Cin_pad, p0, a.P, a.vec_x != 0);
     const bool has_gy = a.gy.base || a.gy.tab;
     const bool has_mse = a.pred.base || a.pred.tab;
@@ -489,6 +496,7 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
                     float4* d4 = reinterpret_cast<float4*>(dst + p);
                     if (a.gx_accumulate) { const float4 o = *d4; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
                     *d4 = v;
+                    if (a.x1_out) *reinterpret_cast<float4*>(&xs[c * LDP + 4 * q]) = v;   // finished row tile (x is dead)
                 } else {
                     const float vv[4] = {v.x, v.y, v.z, v.w};
                     for (int k = 0; k < 4; ++k)
@@ -501,6 +509,19 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
         float s = 0.f;
         for (int p = 0; p < PT; ++p) s += gys[tid * LDP + p];
         grad_flush(sl ? sl + o_gb2 + tid : nullptr, a.gb2 + tid, accum, s);
+    }
+    if (a.x1_out) {
+        // W-axis pruned DFT of the finished gradient row.  The partial-tile region is dead after the barrier: it hosts the
+        // table and the per-wave partial spectra.
+        __syncthreads();
+        float* x1s = red;                          // [4 waves][Cin_pad][16]
+        float* ft = red + 4 * a.Cin_pad * 16;      // [16][LDP]
+        if (tid < 16 * (PT / 4)) *reinterpret_cast<float4*>(&ft[(tid / (PT / 4)) * LDP + 4 * (tid % (PT / 4))]) = ftv;
+        for (int idx = a.Cin * LDP + tid; idx < a.Cin_pad * LDP; idx += NT) xs[idx] = 0.f;
+        __syncthreads();
+        if (w < 4) tile_rows_dft<NIB, 1>(xs, ft, x1s, LDP, 16, PT / 16, false);
+        __syncthreads();
+        store_x1(x1s, a.x1_out, b, (int)(blockIdx.x % a.tiles_per_sample), a.rows_H, a.m2c, a.Cin, a.Cin_pad, 16);
     }
 }
 
@@ -707,6 +728,16 @@ int dlwp_pwmlp_bwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, 
                       float mse_scale, const dlwp_chan_dst* gx, int gx_accumulate, const dlwp_chan_dst* gres,
                       float* gw1, float* gb1, float* gw2, float* gb2, float* slab, int slab_accumulate, int B,
                       int Cin, int Ch, int Cout, int P, hipStream_t stream) {
+    return dlwp_pwmlp_bwd_rows_ex(x, w1, b1, w2, gy, pred, target, mse_scale, gx, gx_accumulate, gres, gw1, gb1, gw2, gb2,
+                                  slab, slab_accumulate, B, Cin, Ch, Cout, P, nullptr, nullptr, stream);
+}
+
+int dlwp_pwmlp_bwd_rows_ex(const dlwp_chan_src* x, const float* w1, const float* b1, const float* w2,
+                           const dlwp_chan_src* gy, const dlwp_chan_src* pred, const dlwp_chan_src* target,
+                           float mse_scale, const dlwp_chan_dst* gx, int gx_accumulate, const dlwp_chan_dst* gres,
+                           float* gw1, float* gb1, float* gw2, float* gb2, float* slab, int slab_accumulate, int B,
+                           int Cin, int Ch, int Cout, int P, const dlwp_fno_plan* rows_plan, float2* x1_out,
+                           hipStream_t stream) {
     DLWP_REQUIRE(B > 0 && Cin > 0 && Ch > 0 && Cout > 0 && P > 0, DLWP_E_INVALID,
                  "pwmlp_bwd: non-positive dimension");
     BwdArgs a{};
@@ -728,6 +759,16 @@ int dlwp_pwmlp_bwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, 
     const int nib = a.Cin_pad / 16, nob = a.Cout_pad / 16;
     DLWP_REQUIRE(nib <= 4 && nob <= 4, DLWP_E_UNSUPPORTED,
                  "pwmlp_bwd: Cin<=64 and Cout<=64 supported (got %d, %d)", Cin, Cout);
+    bool rows_after = false;
+    if (x1_out) {
+        DLWP_REQUIRE(rows_plan && gx && gx->base && !gx_accumulate, DLWP_E_INVALID,
+                     "pwmlp_bwd: the rows DFT needs a plan and a dense, overwritten gx");
+        const bool fuse = dlwp_pwmlp_rows_fusable(rows_plan, Cin, P) && a.vec_x && view_vec_ok(a.gx) &&
+                          gx->bstride == (long long)Cin * P && gx->cstride == P &&
+                          (size_t)BWD_WAVES * a.Cin_pad * LDP >= (size_t)4 * a.Cin_pad * 16 + (size_t)16 * LDP;
+        if (fuse) { a.x1_out = x1_out; a.FT = rows_plan->FT_adj; a.rows_H = rows_plan->H; a.m2c = rows_plan->m2c; }
+        else rows_after = true;       // shapes the epilogue cannot host: separate rows kernel, same result
+    }
     size_t wimg = (size_t)a.Ch_pad * (a.Cin_pad + 4) + (size_t)a.Cout_pad * (a.Ch_pad + 4) + a.Ch_pad;
     const size_t red = (size_t)BWD_WAVES * a.Cin_pad * LDP;  // gx partial tiles alias the weight images
     if (wimg < red) wimg = red;
@@ -754,6 +795,7 @@ int dlwp_pwmlp_bwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, 
 #undef ROW
 #undef LAUNCH
     DLWP_LAUNCH_CHECK();
+    if (rows_after) return dlwp_fno_rows_dft(rows_plan, gx->base, 0, 1, x1_out, B, stream);
     return DLWP_OK;
 }
 
