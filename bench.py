@@ -315,7 +315,10 @@ def main():
     # synthetic trajectories (seeded per rank: every rank trains on its own shard), resident in HBM
     g = torch.Generator().manual_seed(1234 + rank)
     u = torch.randn(B, w["T"] + 1, 1, w["H"], w["W"], generator=g).to(device)
-    x, y = u[:, :-1].contiguous(), u[:, 1:].contiguous()
+    # the batch is staged in the buffers the captured step reads (where a loader's host-to-device copy would land)
+    x, y = model.io_buffers(B, w["T"], w["H"], w["W"], w["teacher_forcing_steps"])
+    x.copy_(u[:, :-1])
+    y.copy_(u[:, 1:])
     reducer = ddp.FlatGradAllReduce()          # one flat RCCL bucket per step (no-op at world 1)
     allreduce = reducer if world > 1 else None
     scale = 1.0 / world

@@ -123,7 +123,8 @@ P resolve(float* base, const Layout& L) {
              base + L.pw2, base + L.pb2, base, L};
 }
 
-int enqueue_forward(dlwp_fno_trainer* tr, bool keep, hipStream_t s) {
+// fused: the caller is the fused train step -- the loss / g_out zero fills ride with the copy of the untouched frames
+int enqueue_forward(dlwp_fno_trainer* tr, bool keep, hipStream_t s, bool fused = false) {
     const dlwp_fno_cfg& c = tr->cfg;
     const Layout L = make_layout(c);
     const P w = resolve(tr->params, L);
@@ -131,9 +132,13 @@ int enqueue_forward(dlwp_fno_trainer* tr, bool keep, hipStream_t s) {
     const long long actB = (long long)c.B * tr->act;
     const long long xhatB = (long long)c.B * c.m1 * c.m2c * C;
     int rc;
-    if (c.form == DLWP_FNO_FORM_NS && ctx > 1) {
+    const bool copy_head = c.form == DLWP_FNO_FORM_NS && ctx > 1;
+    if (fused) {
+        if ((rc = dlwp_rollout_prep(tr->loss, tr->g_out, (long long)c.B * tr->traj_out, tr->out, tr->x, tr->traj_out, tr->traj,
+                                    copy_head ? (long long)(ctx - 1) * tr->frame : 0, c.B, s))) return rc;
+    } else if (copy_head) {
         // steps before the context is full return the latest observation (fno.py:240-243)
-        DLWP_HIP(hipMemcpy2DAsync(tr->out, tr->traj * sizeof(float), tr->x, tr->traj * sizeof(float),
+        DLWP_HIP(hipMemcpy2DAsync(tr->out, tr->traj_out * sizeof(float), tr->x, tr->traj * sizeof(float),
                                   (size_t)(ctx - 1) * tr->frame * sizeof(float), c.B, hipMemcpyDeviceToDevice, s));
     }
     for (int k = 0; k < tr->ncalls; ++k) {
@@ -170,7 +175,7 @@ int enqueue_forward(dlwp_fno_trainer* tr, bool keep, hipStream_t s) {
     return DLWP_OK;
 }
 
-int enqueue_loss_backward(dlwp_fno_trainer* tr, const float* grad_out, hipStream_t s) {
+int enqueue_loss_backward(dlwp_fno_trainer* tr, const float* grad_out, hipStream_t s, bool fused = false) {
     const dlwp_fno_cfg& c = tr->cfg;
     const Layout L = make_layout(c);
     const P w = resolve(tr->params, L);
@@ -186,9 +191,9 @@ int enqueue_loss_backward(dlwp_fno_trainer* tr, const float* grad_out, hipStream
         DLWP_HIP(hipMemcpyAsync(tr->g_out, grad_out, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     } else {
         // fused nn.MSELoss(reduction="mean") against the trainer's target buffer
-        if ((rc = dlwp_zero_f32(tr->loss, 1, s))) return rc;
+        if (!fused && (rc = dlwp_zero_f32(tr->loss, 1, s))) return rc;
         if ((rc = dlwp_sqerr_sum(tr->out, tr->y, n, 1.0f / (float)n, tr->loss, s))) return rc;
-        if ((rc = dlwp_zero_f32(tr->g_out, n, s))) return rc;
+        if (!fused && (rc = dlwp_zero_f32(tr->g_out, n, s))) return rc;
         mse_scale = 2.0f / (float)n;
     }
     for (int k = tr->ncalls - 1; k >= 0; --k) {
@@ -458,14 +463,14 @@ extern "C" int dlwp_fno_trainer_fwd_bwd(dlwp_fno_trainer* tr, int use_graph, voi
     hipStream_t s = (hipStream_t)stream_;
     int rc;
     if (!use_graph) {
-        if ((rc = enqueue_forward(tr, true, s))) return rc;
-        return enqueue_loss_backward(tr, nullptr, s);
+        if ((rc = enqueue_forward(tr, true, s, true))) return rc;
+        return enqueue_loss_backward(tr, nullptr, s, true);
     }
     if (!tr->graph_exec) {
         if (!tr->cap_stream) DLWP_HIP(hipStreamCreateWithFlags(&tr->cap_stream, hipStreamNonBlocking));
         DLWP_HIP(hipStreamBeginCapture(tr->cap_stream, hipStreamCaptureModeThreadLocal));
-        rc = enqueue_forward(tr, true, tr->cap_stream);
-        if (!rc) rc = enqueue_loss_backward(tr, nullptr, tr->cap_stream);
+        rc = enqueue_forward(tr, true, tr->cap_stream, true);
+        if (!rc) rc = enqueue_loss_backward(tr, nullptr, tr->cap_stream, true);
         hipGraph_t graph = nullptr;
         hipError_t e = hipStreamEndCapture(tr->cap_stream, &graph);
         if (rc) {

@@ -102,6 +102,12 @@ class _FnoRolloutModule(nn.Module):
         tr.forward(keep_activations=False)
         return tr.out.clone()
 
+    def io_buffers(self, B, T, H, W, teacher_forcing_steps):
+        """The (x, y) device buffers the captured step of this shape reads: a loader that lands its host-to-device copy
+        here (and passes them to train_step) saves the two device-to-device copies per step."""
+        tr = self.trainer(B, T, H, W, min(int(teacher_forcing_steps), T))
+        return tr.x, tr.y
+
     # ---- fused training step (forward + MSE + BPTT captured in one hipGraph, then Adam)
     def make_optimizer(self, lr=1e-3):
         return FusedAdam(self.flat_params.data, self._ensure_grad(), lr=lr)
@@ -111,8 +117,10 @@ class _FnoRolloutModule(nn.Module):
         """nsbench/scripts/train.py:117-127 on device. Returns the (device) MSE loss tensor."""
         B, T, D, H, W = x.shape
         tr = self.trainer(B, T, H, W, min(int(teacher_forcing_steps), T))
-        tr.x.copy_(x)
-        tr.y.copy_(y)
+        if x.data_ptr() != tr.x.data_ptr():      # batches staged straight into io_buffers() need no device copy
+            tr.x.copy_(x)
+        if y.data_ptr() != tr.y.data_ptr():
+            tr.y.copy_(y)
         loss = tr.fwd_bwd(use_graph=use_graph)
         if allreduce is not None:
             allreduce(self.flat_grad)
