@@ -1,0 +1,153 @@
+"""BASELINE.json's configurations at FULL size, through properties that need no CPU oracle run of that size
+(the small-shape parity tests against the pinned oracles / golden vectors are in the per-model files):
+
+* sample independence  -- the path has no cross-sample coupling (the premise of the data-parallel sharding):
+  out(batch)[i] == out(sample i alone);
+* determinism          -- two evaluations give bit-identical outputs (no atomics-order dependence in the forward pass);
+* directional gradient -- d loss / d theta . v from the backward kernels equals the central finite difference of the loss
+  along a random parameter direction v (fp32, tolerance 2e-2 relative: the difference quotient itself is only
+  accurate to ~1e-3 in fp32);
+* domain identities    -- SHT round trip of a band-limited field at the C3 grid and width.
+
+C2 (nsbench TFNO2DModule 64x64, hidden 32, 4 layers) is compared with its oracle at full size in test_gpu_fno.py.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def directional_check(model, make_loss, eps=1e-2, tol=2e-2, seed=0):
+    """(grad . v) from backward vs (L(theta + eps v) - L(theta - eps v)) / (2 eps), v a random unit direction."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    for p in params:
+        p.grad = None
+    loss = make_loss()
+    loss.backward()
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    vs = [torch.randn(p.shape, generator=g).to(p.device) for p in params]
+    norm = torch.sqrt(sum((v * v).sum() for v in vs))
+    vs = [v / norm for v in vs]
+    analytic = sum((p.grad * v).sum() for p, v in zip(params, vs)).item()
+    with torch.no_grad():
+        for p, v in zip(params, vs):
+            p.add_(eps * v)
+        lp = make_loss().item()
+        for p, v in zip(params, vs):
+            p.sub_(2 * eps * v)
+        lm = make_loss().item()
+        for p, v in zip(params, vs):
+            p.add_(eps * v)
+    numeric = (lp - lm) / (2 * eps)
+    assert abs(analytic - numeric) <= tol * max(abs(numeric), abs(analytic), 1e-6), (analytic, numeric)
+
+
+def dlwp_inputs(B, T, Cg, H, W, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    return dict(constants=torch.randn(B, 1, 4, H, W, generator=g).to(dev),
+                prescribed=torch.randn(B, T, 1, H, W, generator=g).to(dev),
+                prognostic=torch.randn(B, T, Cg, H, W, generator=g).to(dev))
+
+
+def sample_independence(model, kw, tol=2e-6):
+    with torch.no_grad():
+        full = model(**kw)
+        again = model(**kw)
+        assert torch.equal(full, again), "forward is not deterministic"
+        for i in range(kw["prognostic"].shape[0]):
+            one = model(**{k: v[i:i + 1] for k, v in kw.items()})
+            assert rel(one[0], full[i]) <= tol, f"sample {i} depends on the rest of the batch"
+
+
+# ---- C3: dlwpbench SFNO2DModule, WeatherBench 5.625 deg (32x64), 5 prognostic variables, sfno.yaml widths ---------------
+def c3_model(dev):
+    from dlwp_benchmark_amd import dlwpbench
+    torch.manual_seed(11)
+    m = dlwpbench.SFNO2DModule(constant_channels=4, prescribed_channels=1, prognostic_channels=5, grid="equiangular",
+                               num_layers=4, scale_factor=1, embed_dim=256, context_size=1, height=32, width=64,
+                               big_skip=True, pos_embed=True, use_mlp=True, normalization_layer="none").to(dev)
+    with torch.no_grad():
+        m.sfno.pos_embed.normal_(0, 0.02)
+    return m
+
+
+def test_c3_sfno_full_size_properties(cuda):
+    m = c3_model(cuda)
+    kw = dlwp_inputs(3, 3, 5, 32, 64, 21, cuda)
+    sample_independence(m, kw)
+    target = torch.randn(3, 2, 5, 32, 64, generator=torch.Generator().manual_seed(5)).to(cuda)
+    directional_check(m, lambda: torch.nn.functional.mse_loss(m(**kw), target))
+
+
+def test_c3_sht_round_trip_at_full_width(cuda):
+    """iSHT(SHT(x)) = x for a field synthesised from a spectrum (band-limited by construction), 256 channels, both grids."""
+    from dlwp_benchmark_amd import sht
+    for grid in ("equiangular", "legendre-gauss"):
+        fwd = sht.RealSHT(32, 64, 32, 32, grid).to(cuda)
+        inv = sht.InverseRealSHT(32, 64, 32, 32, grid).to(cuda)
+        g = torch.Generator().manual_seed(3)
+        X = torch.randn(32, 2, 32, 2, 256, generator=g)
+        l, mm = torch.arange(32)[:, None], torch.arange(32)[None, :]
+        X = X * (mm <= l)[:, None, :, None, None]              # only m <= l exist
+        X[:, :, 0, 1, :] = 0                                   # order 0 is real
+        if grid == "equiangular":
+            X[16:] = 0     # Clenshaw-Curtis on 32 nodes is exact to degree 31: the analysis integrates P_l P_l', so l <= 15
+        x = inv(X.to(cuda))
+        X2 = fwd(x)
+        x2 = inv(X2)
+        assert rel(x2, x) <= 2e-5, grid
+
+
+def test_c3_bf16_operand_mode_stays_close_to_fp32(cuda):
+    from dlwp_benchmark_amd import lib as L
+    m = c3_model(cuda)
+    kw = dlwp_inputs(2, 2, 5, 32, 64, 22, cuda)
+    with torch.no_grad():
+        ref = m(**kw)
+        with L.gemm_precision("bf16"):
+            low = m(**kw)
+    assert rel(low, ref) <= 3e-2          # bf16 operands (8 mantissa bits), fp32 accumulation, 4 blocks deep
+
+
+# ---- C4: window attention on WeatherBench 1.40625 deg (128x256), window 7 ---------------------------------------------------
+def test_c4_swin_window7_full_size_properties(cuda):
+    from dlwp_benchmark_amd import dlwpbench
+    torch.manual_seed(12)
+    m = dlwpbench.SwinTransformer(constant_channels=4, prescribed_channels=1, prognostic_channels=8, context_size=1,
+                                  img_height=128, img_width=256, patch_size=1, embed_dim=96, depths=[4, 4], num_heads=[4, 4],
+                                  drop_path_rate=0.0, window_size=7).to(cuda)
+    kw = dlwp_inputs(2, 2, 8, 128, 256, 31, cuda)
+    sample_independence(m, kw, tol=1e-5)
+    target = torch.randn(2, 1, 8, 128, 256, generator=torch.Generator().manual_seed(6)).to(cuda)
+    directional_check(m, lambda: torch.nn.functional.mse_loss(m(**kw), target))
+
+
+def test_c4_pangu_window277_full_size_properties(cuda):
+    from dlwp_benchmark_amd import dlwpbench
+    torch.manual_seed(13)
+    m = dlwpbench.PanguWeather(constant_channels=4, prescribed_channels=1, prognostic_channels=8, embed_dim=192,
+                               num_heads=(6, 12, 12, 6), window_size=(2, 7, 7), patch_size=(1, 1), n_lat=128, n_lon=256,
+                               context_size=1).to(cuda)
+    m.eval()                                                   # DropPath off: the stochastic depth mask is not a property
+    kw = dlwp_inputs(2, 2, 8, 128, 256, 32, cuda)
+    sample_independence(m, kw, tol=1e-5)
+    target = torch.randn(2, 1, 8, 128, 256, generator=torch.Generator().manual_seed(7)).to(cuda)
+    directional_check(m, lambda: torch.nn.functional.mse_loss(m(**kw), target), eps=5e-3)
+
+
+# ---- C5: FourCastNet AFNO on the ERA5 0.25 deg grid (720 x 1440; 721 has no usable patch divisor) ----------
+def test_c5_afno_era5_grid_properties(cuda):
+    from dlwp_benchmark_amd import dlwpbench
+    torch.manual_seed(14)
+    m = dlwpbench.AFNONet(img_height=720, img_width=1440, patch_size=(8, 8), constant_channels=4, prescribed_channels=1,
+                          prognostic_channels=8, embed_dim=768, depth=2, mlp_ratio=4.0, num_blocks=16,
+                          context_size=1).to(cuda)
+    kw = dlwp_inputs(2, 2, 8, 720, 1440, 33, cuda)
+    sample_independence(m, kw, tol=1e-5)
+    target = torch.randn(2, 1, 8, 720, 1440, generator=torch.Generator().manual_seed(8)).to(cuda)
+    directional_check(m, lambda: torch.nn.functional.mse_loss(m(**kw), target))
