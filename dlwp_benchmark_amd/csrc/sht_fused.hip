@@ -25,6 +25,9 @@ namespace {
 
 constexpr int CB = 16;          // channels per workgroup
 constexpr int GRP = 8;          // orders (analysis) / latitudes (synthesis) per workgroup
+constexpr int NW = 16;          // waves per workgroup: four per SIMD hide each other's LDS round trips and dependent MFMA
+                                // chains (C3 step with these kernels forced on in bf16 GEMM mode: 4 waves 623, 8 waves 652,
+                                // 16 waves 661 samples/s)
 constexpr int XLD = CB + 4;     // row stride of [row][16 channel] tiles (lanes l / l+16 of a half-wave on different banks)
 
 struct ShtDev {
@@ -33,26 +36,52 @@ struct ShtDev {
     const float* T1;            // analysis: A1 [2M][N];      synthesis: S1t [M][K][L]
     const float* T2;            // analysis: A2 [M][L][K];    synthesis: S2t [N][2M]
     int B, K, N, C, M, L;
-    int Kp, Lp, Np, Qp;         // padded to 16 (zero-filled in LDS)
+    int Kp, Lp, Np, Qp;         // padded to 16 (zero-filled operands)
+    FastDiv dQ4;                // division by 2M/4 (table staging of the synthesis kernel)
 };
 
-__device__ __forceinline__ int pad16(int v) { return (v + 15) & ~15; }
+// 16 contiguous bytes of a table row, or zeros past the row's end (row lengths are multiples of 4, rows 16-byte aligned);
+// the address is clamped so that the load itself is unconditional
+__device__ __forceinline__ f32x4 table4(const float* __restrict__ row, int col, int ncols, bool row_ok) {
+    const bool ok = row_ok && col + 3 < ncols;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + (ok ? col : 0));
+    return ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// A 16 x 16 accumulator tile (lane (r, g) holds rows 4g+j, column r) leaves through a wave-private LDS tile so that every
+// lane stores 16 bytes (row = lane / 4): one wave-instruction per tile instead of four 64-byte-segment dword stores each.
+// dst_row(row) -> pointer of the 16-channel row in global memory, or nullptr for rows outside the tensor.
+template <typename F>
+__device__ __forceinline__ void store_tile16(const f32x4 acc, float* wt, int lane, F dst_row) {
+    const int r = lane & 15, g = lane >> 4;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wt[(4 * g + j) * XLD + r] = acc[j];
+    __builtin_amdgcn_wave_barrier();
+    const int row = lane >> 2, c4 = lane & 3;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(&wt[row * XLD + 4 * c4]);
+    float* d = dst_row(row);
+    if (d) *reinterpret_cast<f32x4*>(d + 4 * c4) = v;
+    __builtin_amdgcn_wave_barrier();
+}
+
+constexpr int MAXCH = 8;        // 16-wide chunks of a longitude row (nlon <= 128)
+constexpr int MAXKC = 4;        // 16-wide chunks of a latitude / degree row (nlat, lmax <= 64)
 
 // ---------------------------------------------------------------------------------------------------------------------
-// analysis: grid (C/16, M/8, B)
-__global__ __launch_bounds__(256) void sht_analysis_kernel(ShtDev a) {
+// analysis: grid (C/16, M/8, B).  Tables never touch LDS: the A1 rows of this workgroup's 16 (order, re|im) pairs stay in
+// registers for the whole latitude loop, the A2 fragments of the next (order, degree tile) are fetched while the current
+// one is multiplied.
+__global__ __launch_bounds__(NW * 64) void sht_analysis_kernel(ShtDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int NLD = a.Np + 4, KLD = a.Kp + 4;
-    float* A1s = smem;                                   // [16 q][NLD]
-    float* A2s = A1s + 16 * NLD;                         // [GRP][Lp][KLD]
-    float* Ts = A2s + GRP * a.Lp * KLD;                  // [Kp][16 q][XLD]
-    float* xs = Ts + a.Kp * 16 * XLD;                    // [4 waves][Np][XLD]
+    float* Ts = smem;                                    // [Kp][16 q][XLD]
+    float* xs = Ts + a.Kp * 16 * XLD;                    // [NW waves][Np][XLD]
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
     const int c0 = blockIdx.x * CB, m0 = blockIdx.y * GRP, b = blockIdx.z;
     float* xw = xs + w * a.Np * XLD;
+    const int nch = a.Np / 16, kch = a.Kp / 16, ltn = a.Lp / 16;
 
-    // this wave's latitudes: k = w, w+4, ...; a tile is x[b][k][0:N][c0:c0+16] (N rows of 64 bytes), 4 rows per 16 lanes
-    const long long xrow = a.C;
+    // this wave's latitudes: k = w, w+4, ...; a tile is x[b][k][0:N][c0:c0+16] (N rows of 64 bytes)
     const float* xb = a.in + (long long)b * a.K * a.N * a.C + c0;
     const int nld4 = (a.N * (CB / 4) + 63) / 64;         // float4 per lane and tile (N = 64 -> 4)
     float4 pre[8];
@@ -60,9 +89,9 @@ __global__ __launch_bounds__(256) void sht_analysis_kernel(ShtDev a) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int idx = lane + 64 * u, n = idx >> 2, c4 = idx & 3;
-            pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (u < nld4 && n < a.N && k < a.K)
-                pre[u] = *reinterpret_cast<const float4*>(xb + ((long long)k * a.N + n) * xrow + 4 * c4);
+            const bool ok = u < nld4 && n < a.N && k < a.K;
+            const float4 v = *reinterpret_cast<const float4*>(xb + ((long long)(ok ? k : 0) * a.N + (ok ? n : 0)) * a.C + 4 * c4);
+            pre[u] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto commit = [&]() {
@@ -73,29 +102,37 @@ __global__ __launch_bounds__(256) void sht_analysis_kernel(ShtDev a) {
         }
     };
     issue(w);
-    // tables: A1 rows q = 2 m0 .. 2 m0 + 15 ([16][N] contiguous), A2 [GRP][L][K] contiguous from m0
-    for (int e = tid; e < 16 * a.Np; e += 256) {
-        const int q = e / a.Np, n = e - q * a.Np;
-        A1s[q * NLD + n] = n < a.N ? a.T1[(long long)(2 * m0 + q) * a.N + n] : 0.f;
+    f32x4 a1[MAXCH];
+    {
+        const float* row = a.T1 + (long long)(2 * m0 + r) * a.N;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) a1[c] = c < nch ? table4(row, 16 * c + 4 * g, a.N, true) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int e = tid; e < GRP * a.Lp * a.Kp; e += 256) {
-        const int ml = e / (a.Lp * a.Kp), rem = e - ml * a.Lp * a.Kp, l = rem / a.Kp, k = rem - l * a.Kp;
-        A2s[(ml * a.Lp + l) * KLD + k] = (l < a.L && k < a.K) ? a.T2[((long long)(m0 + ml) * a.L + l) * a.K + k] : 0.f;
-    }
-    for (int e = tid; e < (a.Kp - a.K) * 16 * XLD; e += 256) Ts[a.K * 16 * XLD + e] = 0.f;      // padded latitudes
-    __syncthreads();
+    // A2 fragments of (order ml, degree tile lt): rows l = 16 lt + r, columns k
+    f32x4 a2c[MAXKC], a2n[MAXKC];
+    auto issue_a2 = [&](int ml, int lt) {
+        const int l = 16 * lt + r;
+        const bool row_ok = l < a.L && m0 + ml < a.M;
+        const float* row = a.T2 + ((long long)(m0 + (row_ok ? ml : 0)) * a.L + (row_ok ? l : 0)) * a.K;
+#pragma unroll
+        for (int c = 0; c < MAXKC; ++c) a2n[c] = c < kch ? table4(row, 16 * c + 4 * g, a.K, row_ok) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    issue_a2(w, 0);
+    for (int e = tid; e < (a.Kp - a.K) * 16 * XLD; e += NW * 64) Ts[a.K * 16 * XLD + e] = 0.f;      // padded latitudes
 
     // ---- stage 1: T[k][q][c] = sum_n A1[q][n] x[k][n][c]
-    for (int k = w; k < a.K; k += 4) {
+    for (int k = w; k < a.K; k += NW) {
         commit();
-        if (k + 4 < a.K) issue(k + 4);
+        if (k + NW < a.K) issue(k + NW);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int n0 = 0; n0 < a.Np; n0 += 16) {
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&A1s[r * NLD + n0 + 4 * g]);
-            f32x4 b4;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) b4[s] = xw[(n0 + 4 * g + s) * XLD + r];
-            acc = mfma16_chunk(a4, b4, acc);
+        for (int c = 0; c < MAXCH; ++c) {
+            if (c < nch) {
+                f32x4 b4;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) b4[s] = xw[(16 * c + 4 * g + s) * XLD + r];
+                acc = mfma16_chunk(a1[c], b4, acc);
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) Ts[(k * 16 + 4 * g + j) * XLD + r] = acc[j];
@@ -103,61 +140,71 @@ __global__ __launch_bounds__(256) void sht_analysis_kernel(ShtDev a) {
     __syncthreads();
 
     // ---- stage 2: X[l][m][ri][c] = sum_k A2[m][l][k] T[k][2m+ri][c]
-    for (int ml = w; ml < GRP; ml += 4) {
+    for (int ml = w; ml < GRP; ml += NW) {
         const int m = m0 + ml;
-        if (m >= a.M) break;
-        for (int lt = 0; lt < a.Lp / 16; ++lt) {
+        for (int lt = 0; lt < ltn; ++lt) {
+#pragma unroll
+            for (int c = 0; c < MAXKC; ++c) a2c[c] = a2n[c];
+            if (lt + 1 < ltn) issue_a2(ml, lt + 1);
+            else if (ml + NW < GRP) issue_a2(ml + NW, 0);
             f32x4 acc[2];
             acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
             acc[1] = acc[0];
-            for (int k0 = 0; k0 < a.Kp; k0 += 16) {
-                const f32x4 a4 = *reinterpret_cast<const f32x4*>(&A2s[(ml * a.Lp + lt * 16 + r) * KLD + k0 + 4 * g]);
 #pragma unroll
-                for (int ri = 0; ri < 2; ++ri) {
-                    f32x4 b4;
+            for (int c = 0; c < MAXKC; ++c) {
+                if (c < kch) {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) b4[s] = Ts[((k0 + 4 * g + s) * 16 + 2 * ml + ri) * XLD + r];
-                    acc[ri] = mfma16_chunk(a4, b4, acc[ri]);
+                    for (int ri = 0; ri < 2; ++ri) {
+                        f32x4 b4;
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) b4[s] = Ts[((16 * c + 4 * g + s) * 16 + 2 * ml + ri) * XLD + r];
+                        acc[ri] = mfma16_chunk(a2c[c], b4, acc[ri]);
+                    }
                 }
             }
 #pragma unroll
             for (int ri = 0; ri < 2; ++ri)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int l = lt * 16 + 4 * g + j;
-                    if (l < a.L) a.out[((((long long)l * a.B + b) * a.M + m) * 2 + ri) * a.C + c0 + r] = acc[ri][j];
-                }
+                store_tile16(acc[ri], xw, lane, [&](int row) -> float* {
+                    const int l = 16 * lt + row;
+                    return (l < a.L && m < a.M) ? a.out + ((((long long)l * a.B + b) * a.M + m) * 2 + ri) * a.C + c0 : nullptr;
+                });
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// synthesis: grid (C/16, ceil(K/8), B)
-__global__ __launch_bounds__(256) void sht_synthesis_kernel(ShtDev a) {
+// synthesis: grid (C/16, ceil(K/8), B).  S1 fragments (8 latitudes x degrees of one order) travel with the order's field
+// tile; S2 (every order is contracted by every workgroup) is an LDS image filled with 16-byte copies.
+__global__ __launch_bounds__(NW * 64) void sht_synthesis_kernel(ShtDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int Q = 2 * a.M;
-    const int LLD = a.Lp + 4, QLD = a.Qp + 4;
-    float* S1s = smem;                                   // [M][GRP][LLD]    S1s[m][kl][l] = S1[m][l][k0 + kl]
-    float* S2s = S1s + a.M * GRP * LLD;                  // [Np][QLD]        S2s[n][q]     = S2[q][n]
+    const int Q = 2 * a.M, QLD = a.Qp + 4;
+    float* S2s = smem;                                   // [Np][QLD]        S2s[n][q] = S2[q][n]
     float* Ts = S2s + a.Np * QLD;                        // [GRP][Qp][XLD]
-    float* xs = Ts + GRP * a.Qp * XLD;                   // [4 waves][2 Lp][XLD]   rows (l, ri)
+    float* xs = Ts + GRP * a.Qp * XLD;                   // [NW waves][2 Lp][XLD]   rows (l, ri)
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
     const int c0 = blockIdx.x * CB, k0g = blockIdx.y * GRP, b = blockIdx.z;
     float* xw = xs + w * 2 * a.Lp * XLD;
+    const int lch = a.Lp / 16, qch = a.Qp / 16;
 
     // this wave's orders: m = w, w+4, ...; a tile is X[0:L][b][m][0:2][c0:c0+16]: 2 L rows of 64 bytes
     const float* Xb = a.in + (((long long)b * a.M) * 2) * a.C + c0;
     const long long lstride = (long long)a.B * a.M * 2 * a.C;
     const int nld4 = (2 * a.L * (CB / 4) + 63) / 64;     // L = 32 -> 4
     float4 pre[8];
+    f32x4 s1n[MAXKC], s1c[MAXKC];
     auto issue = [&](int m) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int idx = lane + 64 * u, row = idx >> 2, c4 = idx & 3, l = row >> 1, ri = row & 1;
-            pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (u < nld4 && l < a.L && m < a.M)
-                pre[u] = *reinterpret_cast<const float4*>(Xb + l * lstride + ((long long)m * 2 + ri) * a.C + 4 * c4);
+            const bool ok = u < nld4 && l < a.L && m < a.M;
+            const float4 v = *reinterpret_cast<const float4*>(Xb + (ok ? l : 0) * lstride + ((long long)(ok ? m : 0) * 2 + ri) * a.C + 4 * c4);
+            pre[u] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        const int k = k0g + r;
+        const bool row_ok = r < GRP && k < a.K && m < a.M;
+        const float* srow = a.T1 + ((long long)(row_ok ? m : 0) * a.K + (row_ok ? k : 0)) * a.L;
+#pragma unroll
+        for (int c = 0; c < MAXKC; ++c) s1n[c] = c < lch ? table4(srow, 16 * c + 4 * g, a.L, row_ok) : f32x4{0.f, 0.f, 0.f, 0.f};
     };
     auto commit = [&]() {
 #pragma unroll
@@ -165,41 +212,39 @@ __global__ __launch_bounds__(256) void sht_synthesis_kernel(ShtDev a) {
             const int idx = lane + 64 * u, row = idx >> 2, c4 = idx & 3;
             if (u < nld4 && row < 2 * a.Lp) *reinterpret_cast<float4*>(&xw[row * XLD + 4 * c4]) = pre[u];
         }
+#pragma unroll
+        for (int c = 0; c < MAXKC; ++c) s1c[c] = s1n[c];
     };
     issue(w);
-    for (int e = tid; e < a.M * GRP * a.Lp; e += 256) {
-        const int m = e / (GRP * a.Lp), rem = e - m * GRP * a.Lp, kl = rem / a.Lp, l = rem - kl * a.Lp;
-        const int k = k0g + kl;
-        S1s[(m * GRP + kl) * LLD + l] = (l < a.L && k < a.K) ? a.T1[((long long)m * a.K + k) * a.L + l] : 0.f;
-    }
-    for (int e = tid; e < a.Np * a.Qp; e += 256) {
-        const int n = e / a.Qp, q = e - n * a.Qp;
-        S2s[n * QLD + q] = (n < a.N && q < Q) ? a.T2[(long long)n * Q + q] : 0.f;
-    }
-    for (int e = tid; e < GRP * (a.Qp - Q) * XLD; e += 256) {       // padded orders
-        const int kl = e / ((a.Qp - Q) * XLD), rem = e - kl * (a.Qp - Q) * XLD;
-        Ts[(kl * a.Qp + Q) * XLD + rem] = 0.f;
+    {   // S2t [N][Q] -> S2s rows of QLD floats (Q is a multiple of 16: orders come in groups of 8); rows n >= N are zero
+        const int q4n = Q / 4;
+        for (int u = tid; u < a.Np * q4n; u += NW * 64) {
+            const int n = fastdiv(u, a.dQ4), q4 = u - n * q4n;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n < a.N) v = *reinterpret_cast<const f32x4*>(a.T2 + (long long)n * Q + 4 * q4);
+            *reinterpret_cast<f32x4*>(&S2s[n * QLD + 4 * q4]) = v;
+        }
     }
     // rows of the wave tile beyond 2 L stay zero for the whole kernel
     for (int e = lane; e < (2 * a.Lp - 2 * a.L) * XLD; e += 64) xw[2 * a.L * XLD + e] = 0.f;
-    __syncthreads();
 
     // ---- stage 1: T[kl][2m+ri][c] = sum_l S1[m][l][k0g+kl] X[l][m][ri][c]   (rows kl < 8 of the 16-row tile are real)
-    for (int m = w; m < a.M; m += 4) {
+    for (int m = w; m < a.M; m += NW) {
         commit();
-        if (m + 4 < a.M) issue(m + 4);
+        if (m + NW < a.M) issue(m + NW);
         f32x4 acc[2];
         acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc[1] = acc[0];
-        for (int l0 = 0; l0 < a.Lp; l0 += 16) {
-            f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
-            if (r < GRP) a4 = *reinterpret_cast<const f32x4*>(&S1s[(m * GRP + r) * LLD + l0 + 4 * g]);
 #pragma unroll
-            for (int ri = 0; ri < 2; ++ri) {
-                f32x4 b4;
+        for (int c = 0; c < MAXKC; ++c) {
+            if (c < lch) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) b4[s] = xw[((l0 + 4 * g + s) * 2 + ri) * XLD + r];
-                acc[ri] = mfma16_chunk(a4, b4, acc[ri]);
+                for (int ri = 0; ri < 2; ++ri) {
+                    f32x4 b4;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) b4[s] = xw[((16 * c + 4 * g + s) * 2 + ri) * XLD + r];
+                    acc[ri] = mfma16_chunk(s1c[c], b4, acc[ri]);
+                }
             }
         }
         if (g < GRP / 4) {
@@ -212,45 +257,46 @@ __global__ __launch_bounds__(256) void sht_synthesis_kernel(ShtDev a) {
     __syncthreads();
 
     // ---- stage 2: x[k][n][c] = sum_q S2[q][n] T[kl][q][c]
-    for (int kl = w; kl < GRP; kl += 4) {
+    for (int kl = w; kl < GRP; kl += NW) {
         const int k = k0g + kl;
-        if (k >= a.K) break;
         for (int nt = 0; nt < a.Np / 16; ++nt) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int q0 = 0; q0 < a.Qp; q0 += 16) {
-                const f32x4 a4 = *reinterpret_cast<const f32x4*>(&S2s[(nt * 16 + r) * QLD + q0 + 4 * g]);
+            for (int c = 0; c < qch; ++c) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(&S2s[(nt * 16 + r) * QLD + 16 * c + 4 * g]);
                 f32x4 b4;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) b4[s] = Ts[(kl * a.Qp + q0 + 4 * g + s) * XLD + r];
+                for (int s = 0; s < 4; ++s) b4[s] = Ts[(kl * a.Qp + 16 * c + 4 * g + s) * XLD + r];
                 acc = mfma16_chunk(a4, b4, acc);
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = nt * 16 + 4 * g + j;
-                if (n < a.N) a.out[(((long long)b * a.K + k) * a.N + n) * a.C + c0 + r] = acc[j];
-            }
+            store_tile16(acc, xw, lane, [&](int row) -> float* {
+                const int n = nt * 16 + row;
+                return (n < a.N && k < a.K) ? a.out + (((long long)b * a.K + k) * a.N + n) * a.C + c0 : nullptr;
+            });
         }
     }
 }
 
 size_t analysis_lds(int K, int N, int L) {
-    const int Kp = round_up(K, 16), Np = round_up(N, 16), Lp = round_up(L, 16);
-    return sizeof(float) * ((size_t)16 * (Np + 4) + (size_t)GRP * Lp * (Kp + 4) + (size_t)Kp * 16 * XLD + (size_t)4 * Np * XLD);
+    const int Kp = round_up(K, 16), Np = round_up(N, 16);
+    (void)L;
+    return sizeof(float) * ((size_t)Kp * 16 * XLD + (size_t)NW * Np * XLD);
 }
 size_t synthesis_lds(int N, int M, int L) {
     const int Np = round_up(N, 16), Lp = round_up(L, 16), Qp = round_up(2 * M, 16);
-    return sizeof(float) * ((size_t)M * GRP * (Lp + 4) + (size_t)Np * (Qp + 4) + (size_t)GRP * Qp * XLD + (size_t)4 * 2 * Lp * XLD);
+    return sizeof(float) * ((size_t)Np * (Qp + 4) + (size_t)GRP * Qp * XLD + (size_t)NW * 2 * Lp * XLD);
 }
 constexpr size_t LDS_LIMIT = 156 * 1024;
 
 bool shape_ok(int K, int N, int C, int M, int L) {
-    // 8 float4 per lane cover a wave tile of at most 128 rows of 16 channels; orders come in groups of 8
-    return C % CB == 0 && M % GRP == 0 && N <= 128 && 2 * L <= 128 && K >= 1 && L >= 1 &&
-           analysis_lds(K, N, L) <= LDS_LIMIT && synthesis_lds(N, M, L) <= LDS_LIMIT;
+    // 8 float4 per lane cover a wave tile of at most 128 rows of 16 channels; orders come in groups of 8; table rows
+    // (lengths nlon, nlat, lmax) are read as 16-byte fragments, at most MAXCH / MAXKC chunks of 16 per row
+    return C % CB == 0 && M % GRP == 0 && N <= 16 * MAXCH && L <= 16 * MAXKC && K <= 16 * MAXKC && N % 4 == 0 && K % 4 == 0 &&
+           L % 4 == 0 && K >= 4 && L >= 4 && analysis_lds(K, N, L) <= LDS_LIMIT && synthesis_lds(N, M, L) <= LDS_LIMIT;
 }
 
 ShtDev make(const float* in, const float* t1, const float* t2, float* out, int B, int K, int N, int C, int M, int L) {
-    ShtDev a{in, out, t1, t2, B, K, N, C, M, L, round_up(K, 16), round_up(L, 16), round_up(N, 16), round_up(2 * M, 16)};
+    ShtDev a{in, out, t1, t2, B, K, N, C, M, L, round_up(K, 16), round_up(L, 16), round_up(N, 16), round_up(2 * M, 16),
+             make_fastdiv(2 * M / 4)};
     return a;
 }
 
@@ -265,13 +311,13 @@ extern "C" int dlwp_sht_analysis(const float* x, const float* A1, const float* A
     DLWP_REQUIRE(x && A1 && A2 && X && B > 0, DLWP_E_INVALID, "sht_analysis: NULL argument or empty batch");
     DLWP_REQUIRE(shape_ok(nlat, nlon, C, mmax, lmax), DLWP_E_UNSUPPORTED,
                  "sht_analysis: shape (nlat %d, nlon %d, C %d, mmax %d, lmax %d) is outside the fused kernel's range "
-                 "(C %% 16, mmax %% 8, nlon <= 128, lmax <= 64, tables within LDS): use the GEMM path", nlat, nlon, C, mmax, lmax);
+                 "(C %% 16, mmax %% 8, nlon <= 128, nlat and lmax <= 64, all multiples of 4): use the GEMM path", nlat, nlon, C, mmax, lmax);
     DLWP_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && B <= 65535, DLWP_E_INVALID, "sht_analysis: x must be 16-byte aligned");
     const ShtDev a = make(x, A1, A2, X, B, nlat, nlon, C, mmax, lmax);
     const size_t lds = analysis_lds(nlat, nlon, lmax);
     int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(sht_analysis_kernel), lds, "sht_analysis");
     if (rc) return rc;
-    hipLaunchKernelGGL(sht_analysis_kernel, dim3(C / CB, mmax / GRP, B), dim3(256), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(sht_analysis_kernel, dim3(C / CB, mmax / GRP, B), dim3(NW * 64), lds, (hipStream_t)stream, a);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }
@@ -281,13 +327,13 @@ extern "C" int dlwp_sht_synthesis(const float* X, const float* S1t, const float*
     DLWP_REQUIRE(X && S1t && S2t && x && B > 0, DLWP_E_INVALID, "sht_synthesis: NULL argument or empty batch");
     DLWP_REQUIRE(shape_ok(nlat, nlon, C, mmax, lmax), DLWP_E_UNSUPPORTED,
                  "sht_synthesis: shape (nlat %d, nlon %d, C %d, mmax %d, lmax %d) is outside the fused kernel's range "
-                 "(C %% 16, mmax %% 8, nlon <= 128, lmax <= 64, tables within LDS): use the GEMM path", nlat, nlon, C, mmax, lmax);
+                 "(C %% 16, mmax %% 8, nlon <= 128, nlat and lmax <= 64, all multiples of 4): use the GEMM path", nlat, nlon, C, mmax, lmax);
     DLWP_REQUIRE((reinterpret_cast<uintptr_t>(X) & 15) == 0 && B <= 65535, DLWP_E_INVALID, "sht_synthesis: X must be 16-byte aligned");
     const ShtDev a = make(X, S1t, S2t, x, B, nlat, nlon, C, mmax, lmax);
     const size_t lds = synthesis_lds(nlon, mmax, lmax);
     int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(sht_synthesis_kernel), lds, "sht_synthesis");
     if (rc) return rc;
-    hipLaunchKernelGGL(sht_synthesis_kernel, dim3(C / CB, ceil_div(nlat, GRP), B), dim3(256), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(sht_synthesis_kernel, dim3(C / CB, ceil_div(nlat, GRP), B), dim3(NW * 64), lds, (hipStream_t)stream, a);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }

@@ -69,6 +69,9 @@ SIGNATURES = {
     "dlwp_gemm": (_I, [_V, _V, _V] + [_I] * 8 + [_V, _I, _V, _V, _I, _V, _V]),
     "dlwp_gemm_batched": (_I, [_V, _V, _V] + [_I] * 10 + [_L] * 6 + [_V, _L, _L, _I, _F, _V, _V, _L, _L, _I, _I, _V]),
     "dlwp_act_bwd": (_I, [_V, _V, _V, _L, _I, _F, _V]),
+    "dlwp_sht_fused_supported": (_I, [_I] * 5),
+    "dlwp_sht_analysis": (_I, [_V, _V, _V, _V] + [_I] * 6 + [_V]),
+    "dlwp_sht_synthesis": (_I, [_V, _V, _V, _V] + [_I] * 6 + [_V]),
     "dlwp_cweight_expand": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_cweight_fold": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_layernorm_fwd": (_I, [_V] * 6 + [_I, _I, _F, _V]),

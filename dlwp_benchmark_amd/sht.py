@@ -19,6 +19,8 @@ X [lmax, B, mmax, 2 (re|im), C].  Each transform is two strided-batched GEMMs ag
 per-degree complex weights (one batched GEMM over l on the [[Wr, Wi], [-Wi, Wr]] image), the 1x1-convolution skip and
 MLP -- runs on one kernel family.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -131,22 +133,86 @@ class _TableGemm(torch.autograd.Function):
         return gx, None, None, (gy if ctx.has_res else None)
 
 
-class RealSHT(nn.Module):
-    """x [B, nlat, nlon, C] -> X [lmax, B, mmax, 2, C] (re, im planes)."""
+def _fused_ok(nlat, nlon, C, mmax, lmax):
+    """Single-launch kernels (csrc/sht_fused.hip, exact-f32 MFMA) or two strided-batched GEMMs?  Measured on the C3 step
+    (B=4): with fp32 GEMM operands the fused transforms win (526 vs 512 samples/s); with bf16 GEMM operands the two table
+    GEMMs run on the 16x faster bf16 MFMA and the fused fp32 kernels only tie at B=4 (656 vs 658) and lose at B=16 (1097 vs
+    1180).  Hence: fused in fp32 mode, GEMMs in bf16 mode; DLWP_SHT_FUSED=0/1 overrides (A/B runs)."""
+    lib = L.load()
+    if not lib.dlwp_sht_fused_supported(nlat, nlon, C, mmax, lmax):
+        return False
+    env = os.environ.get("DLWP_SHT_FUSED")
+    if env is not None:
+        return env != "0"
+    return lib.dlwp_get_gemm_precision() == 0
 
-    def __init__(self, nlat, nlon, lmax=None, mmax=None, grid="legendre-gauss"):
+
+class _FusedAnalysis(torch.autograd.Function):
+    """X = analysis(x; A1, A2) in one launch (csrc/sht_fused.hip); backward = synthesis with the transposed tables."""
+
+    @staticmethod
+    def forward(ctx, x, A1, A2, A2t, A1t, mmax, lmax):
+        x = x.contiguous()
+        B, K, N, C = x.shape
+        X = torch.empty(lmax, B, mmax, 2, C, device=x.device)
+        L.check(L.load().dlwp_sht_analysis(L.ptr(x), L.ptr(A1), L.ptr(A2), L.ptr(X), B, K, N, C, mmax, lmax, L.stream()))
+        ctx.tabs, ctx.dims = (A2t, A1t), (B, K, N, C, mmax, lmax)
+        return X
+
+    @staticmethod
+    def backward(ctx, gX):
+        B, K, N, C, mmax, lmax = ctx.dims
+        gX = gX.contiguous()
+        gx = torch.empty(B, K, N, C, device=gX.device)
+        L.check(L.load().dlwp_sht_synthesis(L.ptr(gX), L.ptr(ctx.tabs[0]), L.ptr(ctx.tabs[1]), L.ptr(gx), B, K, N, C, mmax,
+                                            lmax, L.stream()))
+        return gx, None, None, None, None, None, None
+
+
+class _FusedSynthesis(torch.autograd.Function):
+    """x = synthesis(X; S1, S2) in one launch; backward = analysis(A1 = S2, A2 = S1)."""
+
+    @staticmethod
+    def forward(ctx, X, S1t, S2t, S2, S1, nlat, nlon):
+        X = X.contiguous()
+        Lm, B, M, _, C = X.shape
+        x = torch.empty(B, nlat, nlon, C, device=X.device)
+        L.check(L.load().dlwp_sht_synthesis(L.ptr(X), L.ptr(S1t), L.ptr(S2t), L.ptr(x), B, nlat, nlon, C, M, Lm, L.stream()))
+        ctx.tabs, ctx.dims = (S2, S1), (B, nlat, nlon, C, M, Lm)
+        return x
+
+    @staticmethod
+    def backward(ctx, gx):
+        B, K, N, C, M, Lm = ctx.dims
+        gx = gx.contiguous()
+        gX = torch.empty(Lm, B, M, 2, C, device=gx.device)
+        L.check(L.load().dlwp_sht_analysis(L.ptr(gx), L.ptr(ctx.tabs[0]), L.ptr(ctx.tabs[1]), L.ptr(gX), B, K, N, C, M, Lm,
+                                           L.stream()))
+        return gX, None, None, None, None, None, None
+
+
+class RealSHT(nn.Module):
+    """x [B, nlat, nlon, C] -> X [lmax, B, mmax, 2, C] (re, im planes).  One fused launch where the shape fits
+    (dlwp_sht_fused_supported), two strided-batched GEMMs otherwise; `fused=False` forces the GEMM path."""
+
+    def __init__(self, nlat, nlon, lmax=None, mmax=None, grid="legendre-gauss", fused=True):
         super().__init__()
-        self.nlat, self.nlon, self.grid = nlat, nlon, grid
+        self.nlat, self.nlon, self.grid, self.fused = nlat, nlon, grid, fused
         self.lmax = lmax or nlat
         self.mmax = mmax or nlon // 2 + 1
         F, Wf, _, _ = sht_tables(nlat, nlon, self.lmax, self.mmax, grid)
         self.register_buffer("dft", torch.from_numpy(F).float().contiguous(), persistent=False)
         self.register_buffer("weights", torch.from_numpy(Wf).float().contiguous(), persistent=False)
+        # transposed copies for the fused backward (synthesis reads S1t [m][k][l], S2t [n][q])
+        self.register_buffer("dft_t", torch.from_numpy(F.T.copy()).float().contiguous(), persistent=False)
+        self.register_buffer("weights_t", torch.from_numpy(Wf.transpose(0, 2, 1).copy()).float().contiguous(), persistent=False)
 
     def forward(self, x):
         B, K, N, C = x.shape
         assert K == self.nlat and N == self.nlon, "input grid does not match the transform"
         M, Lm = self.mmax, self.lmax
+        if self.fused and x.is_cuda and _fused_ok(K, N, C, M, Lm):
+            return _FusedAnalysis.apply(x, self.dft, self.weights, self.weights_t, self.dft_t, M, Lm)
         lon = dict(M=2 * M, N=C, K=N, lda=N, tA=0, ldx=C, ldy=C, nb1=B * K, nb2=1, sA=(0, 0), sX=(N * C, 0),
                    sY=(2 * M * C, 0), out_shape=(B, K, M, 2, C))
         t = _TableGemm.apply(x, self.dft, lon, None)
@@ -156,21 +222,25 @@ class RealSHT(nn.Module):
 
 
 class InverseRealSHT(nn.Module):
-    """X [lmax, B, mmax, 2, C] -> x [B, nlat, nlon, C]."""
+    """X [lmax, B, mmax, 2, C] -> x [B, nlat, nlon, C].  Fused / GEMM paths as in RealSHT."""
 
-    def __init__(self, nlat, nlon, lmax=None, mmax=None, grid="legendre-gauss"):
+    def __init__(self, nlat, nlon, lmax=None, mmax=None, grid="legendre-gauss", fused=True):
         super().__init__()
-        self.nlat, self.nlon, self.grid = nlat, nlon, grid
+        self.nlat, self.nlon, self.grid, self.fused = nlat, nlon, grid, fused
         self.lmax = lmax or nlat
         self.mmax = mmax or nlon // 2 + 1
         _, _, P, G = sht_tables(nlat, nlon, self.lmax, self.mmax, grid)
         self.register_buffer("pct", torch.from_numpy(P).float().contiguous(), persistent=False)
         self.register_buffer("idft", torch.from_numpy(G).float().contiguous(), persistent=False)
+        self.register_buffer("pct_t", torch.from_numpy(P.transpose(0, 2, 1).copy()).float().contiguous(), persistent=False)
+        self.register_buffer("idft_t", torch.from_numpy(G.T.copy()).float().contiguous(), persistent=False)
 
     def forward(self, X):
         Lm, B, M, _, C = X.shape
         assert Lm == self.lmax and M == self.mmax, "spectrum does not match the transform"
         K, N = self.nlat, self.nlon
+        if self.fused and X.is_cuda and _fused_ok(K, N, C, M, Lm):
+            return _FusedSynthesis.apply(X, self.pct_t, self.idft, self.idft_t, self.pct, K, N)
         leg = dict(M=K, N=2 * C, K=Lm, lda=K, tA=1, ldx=B * M * 2 * C, ldy=2 * M * C, nb1=B, nb2=M, sA=(0, Lm * K),
                    sX=(M * 2 * C, 2 * C), sY=(K * 2 * M * C, 2 * C), out_shape=(B, K, M, 2, C))
         t = _TableGemm.apply(X, self.pct, leg, None)

@@ -304,6 +304,25 @@ int dlwp_gemm_batched(const float* A, const float* B, float* C, int M, int N, in
                       const float* bias, long long sBi1, long long sBi2, int act, float act_param,
                       float* preact, const float* residual, long long sR1, long long sR2,
                       int res_before_act, int accumulate, void* stream);
+/* Fused real spherical harmonic transforms on channels-last fields (torch_harmonics.RealSHT /  */
+/* InverseRealSHT, constructed at src/dlwpbench/models/fno/fno.py:183-200 and                   */
+/* models/fourcastnet/fourcastnet.py:411-428): longitude DFT and Legendre   */
+/* transform in one launch, the (latitude x order) plane stays in LDS.                          */
+/*   analysis : x [B][nlat][nlon][C] -> X [lmax][B][mmax][2][C]                                 */
+/*              T[k][q][c] = sum_n A1[q][n] x[b][k][n][c]   (A1 [2 mmax][nlon], q = 2m + re|im)  */
+/*              X[l][b][m][ri][c] = sum_k A2[m][l][k] T[k][2m+ri][c]   (A2 [mmax][lmax][nlat])   */
+/*   synthesis: X -> x, T[k][2m+ri][c] = sum_l S1[m][l][k] X[l][b][m][ri][c],                   */
+/*              x[b][k][n][c] = sum_q S2[q][n] T[k][q][c]; tables given TRANSPOSED:             */
+/*              S1t [mmax][nlat][lmax], S2t [nlon][2 mmax].                                     */
+/* The adjoint of analysis(A1, A2) is synthesis(S1 = A2, S2 = A1) and vice versa (backward      */
+/* passes).  dlwp_sht_fused_supported tells whether a shape fits (C % 16 == 0, mmax % 8 == 0,   */
+/* nlon <= 128, nlat <= 64, lmax <= 64, all multiples of 4; tables 16-byte aligned); other      */
+/* shapes use dlwp_gemm_batched.                                                                */
+int dlwp_sht_fused_supported(int nlat, int nlon, int C, int mmax, int lmax);
+int dlwp_sht_analysis(const float* x, const float* A1, const float* A2, float* X, int B, int nlat,
+                      int nlon, int C, int mmax, int lmax, void* stream);
+int dlwp_sht_synthesis(const float* X, const float* S1t, const float* S2t, float* x, int B, int nlat,
+                       int nlon, int C, int mmax, int lmax, void* stream);
 /* SFNO "driscoll-healy" spectral weights (torch_harmonics, constructed at                    */
 /* src/dlwpbench/models/fno/fno.py:183-200): w [Cin][Cout][L][2] complex, one matrix per       */
 /* degree l.  expand: wexp[l] = [[Wr, Wi], [-Wi, Wr]] as a real [2Cin][2Cout] matrix, so that   */

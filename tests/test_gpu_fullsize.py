@@ -5,8 +5,8 @@
   out(batch)[i] == out(sample i alone);
 * determinism          -- two evaluations give bit-identical outputs (no atomics-order dependence in the forward pass);
 * directional gradient -- d loss / d theta . v from the backward kernels equals the central finite difference of the loss
-  along a random parameter direction v (fp32, tolerance 2e-2 relative: the difference quotient itself is only
-  accurate to ~1e-3 in fp32);
+  along v = normalise(gradient direction + random direction) (fp32, tolerance 2e-2 relative: the difference quotient
+  itself is only accurate to ~1e-3 in fp32);
 * domain identities    -- SHT round trip of a band-limited field at the C3 grid and width.
 
 C2 (nsbench TFNO2DModule 64x64, hidden 32, 4 layers) is compared with its oracle at full size in test_gpu_fno.py.
@@ -29,8 +29,14 @@ def directional_check(model, make_loss, eps=1e-2, tol=2e-2, seed=0):
         p.grad = None
     loss = make_loss()
     loss.backward()
+    params = [p for p in params if p.grad is not None]       # parameters the configuration does not use stay out
+    # direction = (normalised gradient + random unit vector), normalised: a purely random direction in ~10^6 dimensions has
+    # a derivative so small that the fp32 difference quotient of an O(1) loss is rounding noise (seen: 5 % scatter)
     g = torch.Generator(device="cpu").manual_seed(seed)
-    vs = [torch.randn(p.shape, generator=g).to(p.device) for p in params]
+    us = [torch.randn(p.shape, generator=g).to(p.device) for p in params]
+    un = torch.sqrt(sum((u * u).sum() for u in us))
+    gn = torch.sqrt(sum((p.grad * p.grad).sum() for p in params)).clamp_min(1e-30)
+    vs = [p.grad / gn + u / un for p, u in zip(params, us)]
     norm = torch.sqrt(sum((v * v).sum() for v in vs))
     vs = [v / norm for v in vs]
     analytic = sum((p.grad * v).sum() for p, v in zip(params, vs)).item()
@@ -87,20 +93,21 @@ def test_c3_sfno_full_size_properties(cuda):
 def test_c3_sht_round_trip_at_full_width(cuda):
     """iSHT(SHT(x)) = x for a field synthesised from a spectrum (band-limited by construction), 256 channels, both grids."""
     from dlwp_benchmark_amd import sht
-    for grid in ("equiangular", "legendre-gauss"):
-        fwd = sht.RealSHT(32, 64, 32, 32, grid).to(cuda)
-        inv = sht.InverseRealSHT(32, 64, 32, 32, grid).to(cuda)
+    # Gauss-Legendre on 32 nodes integrates degree <= 63 exactly: every degree l < 32 survives the round trip.  Clenshaw-
+    # Curtis (the "equiangular" grid) is exact to degree 31 only, and the analysis integrates products P_l P_l': the round
+    # trip is an identity for transforms truncated at lmax = 16.
+    for grid, lmax in (("legendre-gauss", 32), ("equiangular", 16)):
+        fwd = sht.RealSHT(32, 64, lmax, lmax, grid).to(cuda)
+        inv = sht.InverseRealSHT(32, 64, lmax, lmax, grid).to(cuda)
         g = torch.Generator().manual_seed(3)
-        X = torch.randn(32, 2, 32, 2, 256, generator=g)
-        l, mm = torch.arange(32)[:, None], torch.arange(32)[None, :]
+        X = torch.randn(lmax, 2, lmax, 2, 256, generator=g)
+        l, mm = torch.arange(lmax)[:, None], torch.arange(lmax)[None, :]
         X = X * (mm <= l)[:, None, :, None, None]              # only m <= l exist
         X[:, :, 0, 1, :] = 0                                   # order 0 is real
-        if grid == "equiangular":
-            X[16:] = 0     # Clenshaw-Curtis on 32 nodes is exact to degree 31: the analysis integrates P_l P_l', so l <= 15
         x = inv(X.to(cuda))
         X2 = fwd(x)
-        x2 = inv(X2)
-        assert rel(x2, x) <= 2e-5, grid
+        assert rel(X2, X) <= 2e-5, grid
+        assert rel(inv(X2), x) <= 2e-5, grid
 
 
 def test_c3_bf16_operand_mode_stays_close_to_fp32(cuda):

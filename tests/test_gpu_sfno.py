@@ -20,7 +20,10 @@ def spec_to_complex(X):
 
 
 @pytest.mark.parametrize("nlat,nlon,lmax,grid,B,C", [(32, 64, 32, "equiangular", 2, 8), (32, 64, 32, "legendre-gauss", 1, 12),
-                                                      (16, 32, 11, "legendre-gauss", 3, 5), (19, 40, 19, "equiangular", 2, 7)])
+                                                      (16, 32, 11, "legendre-gauss", 3, 5), (19, 40, 19, "equiangular", 2, 7),
+                                                      # channel counts / order counts the fused single-launch kernels take
+                                                      (32, 64, 32, "equiangular", 2, 16), (32, 64, 32, "legendre-gauss", 1, 48),
+                                                      (16, 32, 16, "legendre-gauss", 3, 32), (24, 48, 16, "equiangular", 2, 16)])
 def test_sht_and_inverse_match_oracle(cuda, nlat, nlon, lmax, grid, B, C):
     from dlwp_benchmark_amd import sht
     o = sfno_ref.SHT(nlat, nlon, lmax, lmax, grid)
@@ -42,6 +45,33 @@ def test_sht_and_inverse_match_oracle(cuda, nlat, nlon, lmax, grid, B, C):
     yr.backward(gy)
     y.backward(gy.permute(0, 2, 3, 1).contiguous().to(cuda))
     assert rel(xd.grad.permute(0, 3, 1, 2), xr.grad) <= 1e-3
+
+
+@pytest.mark.parametrize("nlat,nlon,lmax,grid,B,C", [(32, 64, 32, "equiangular", 4, 256), (24, 48, 16, "legendre-gauss", 3, 32),
+                                                      (20, 64, 24, "equiangular", 2, 16)])
+def test_fused_sht_kernels_equal_the_gemm_path(cuda, nlat, nlon, lmax, grid, B, C):
+    """csrc/sht_fused.hip (one launch per transform, intermediate in LDS) against the two-GEMM path of the same tables:
+    forward and both backward passes (each backward is the other fused kernel with transposed tables); ragged latitude
+    counts (padding to 16) included."""
+    from dlwp_benchmark_amd import lib as L, sht
+    assert L.load().dlwp_sht_fused_supported(nlat, nlon, C, lmax, lmax) == 1
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(B, nlat, nlon, C, generator=g).to(cuda)
+    gX = torch.randn(lmax, B, lmax, 2, C, generator=g).to(cuda)
+    gx = torch.randn(B, nlat, nlon, C, generator=g).to(cuda)
+    res = {}
+    for fused in (True, False):
+        fwd = sht.RealSHT(nlat, nlon, lmax, lmax, grid, fused=fused).to(cuda)
+        inv = sht.InverseRealSHT(nlat, nlon, lmax, lmax, grid, fused=fused).to(cuda)
+        xa = x.clone().requires_grad_(True)
+        X = fwd(xa)
+        X.backward(gX)
+        Xb = gX.clone().requires_grad_(True)
+        y = inv(Xb)
+        y.backward(gx)
+        res[fused] = (X.detach(), xa.grad, y.detach(), Xb.grad)
+    for a_, b_ in zip(res[True], res[False]):
+        assert rel(a_, b_) <= 2e-5
 
 
 def test_dhconv_matches_einsum(cuda):

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Time the pieces of one SFNO block at the C3 shapes (B=16, 32x64, C=256): SHT, spectral weights, inverse SHT, skip, MLP."""
+"""Time the pieces of one SFNO block at the C3 shapes (32x64, C=256): SHT, spectral weights, inverse SHT, skip, MLP.
+    python tools/probe_sfno_parts.py [fp32|bf16] [B=16] [fused|gemm]"""
 import sys
 sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 import torch
@@ -7,11 +8,12 @@ from dlwp_benchmark_amd import sht, lib as L
 from dlwp_benchmark_amd.token_ops import Conv1x1
 
 dev = torch.device("cuda:0")
-B, H, W, C = 16, 32, 64, 256
+B, H, W, C = (int(sys.argv[2]) if len(sys.argv) > 2 else 16), 32, 64, 256
+FUSED = (sys.argv[3] != "gemm") if len(sys.argv) > 3 else True
 prec = sys.argv[1] if len(sys.argv) > 1 else "fp32"
 L.set_gemm_precision(prec)
-fwd = sht.RealSHT(H, W, 32, 32, "equiangular").to(dev)
-inv = sht.InverseRealSHT(H, W, 32, 32, "equiangular").to(dev)
+fwd = sht.RealSHT(H, W, 32, 32, "equiangular", fused=FUSED).to(dev)
+inv = sht.InverseRealSHT(H, W, 32, 32, "equiangular", fused=FUSED).to(dev)
 x = torch.randn(B, H, W, C, device=dev, requires_grad=True)
 w = (torch.randn(C, C, 32, 2, device=dev) * 0.05).requires_grad_(True)
 skip = Conv1x1(C, C).to(dev)
