@@ -93,6 +93,3 @@ int dlwp_fold_slabs(const dlwp_fold_job* jobs, int njobs, hipStream_t stream);
 // train_ops.hip -- start of a fused rollout step in one launch: *loss = 0, g_out[0:n] = 0, out[b][0:row] = x[b][0:row]
 int dlwp_rollout_prep(float* loss, float* g_out, long long n, float* out, const float* x, long long out_bs, long long x_bs,
                       long long row, int B, hipStream_t stream);
-// generic partial-slab fold: dst_k[i] += sum_s slab[s*stride + off_k + i]
-int dlwp_slab_reduce(const float* slab, int nslab, long long stride, float* d1, long long n1, float* d2, long long n2,
-                     float* d3, long long n3, float* d4, long long n4, hipStream_t stream);

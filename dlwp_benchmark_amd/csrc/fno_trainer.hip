@@ -180,7 +180,7 @@ int enqueue_loss_backward(dlwp_fno_trainer* tr, const float* grad_out, hipStream
     const Layout L = make_layout(c);
     const P w = resolve(tr->params, L);
     const P g = resolve(tr->grads, L);
-    const int HW = c.H * c.W, C = c.hidden, NL = c.n_layers, ctx = c.context_size;
+    const int HW = c.H * c.W, C = c.hidden, NL = c.n_layers;
     const long long actB = (long long)c.B * tr->act;
     const long long xhatB = (long long)c.B * c.m1 * c.m2c * C;
     const long long n = (long long)c.B * tr->traj_out;

@@ -533,56 +533,9 @@ bool view_vec_ok(const V& v) {
     return aligned16(v.base) && v.bstride % 4 == 0 && v.cstride % 4 == 0;
 }
 
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int nslab, long long stride,
-                                                          float* gw1, long long n1, float* gb1, long long n2,
-                                                          float* gw2, long long n3, float* gb2, long long n4) {
-    const long long n = n1 + n2 + n3 + n4;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256) {
-        float acc = 0.f;
-#pragma unroll 8
-        for (int s = 0; s < nslab; ++s) acc += slab[s * stride + idx];
-        float* dst = idx < n1 ? gw1 + idx : idx < n1 + n2 ? gb1 + (idx - n1)
-                   : idx < n1 + n2 + n3 ? gw2 + (idx - n1 - n2) : gb2 + (idx - n1 - n2 - n3);
-        *dst += acc;
-    }
-}
-
-// fold the accumulator-tile slabs of pwmlp_bwd into the gradients (un-permutes the tile order)
-__global__ __launch_bounds__(256) void pwmlp_slab_reduce_kernel(const float* __restrict__ slab, int nslab, long long stride,
-                                                                int Cin, int Ch, int Cout, int nob, int nib, int Ch_pad,
-                                                                float* gw1, float* gb1, float* gw2, float* gb2) {
-    const long long n1 = (long long)Ch * Cin, n2 = Ch, n3 = (long long)Cout * Ch, n4 = Cout, n = n1 + n2 + n3 + n4;
-    const long long o_t1 = (long long)(Ch_pad / 16) * nob * 256, o_gb1 = o_t1 + (long long)(Ch_pad / 16) * nib * 256;
-    const long long o_gb2 = o_gb1 + Ch_pad;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256) {
-        long long off;
-        float* dst;
-        if (idx < n1) {                       // dW1[h][i]: tile (hb, ib), register j = h%4, lane = (h%16/4)*16 + i%16
-            const int h = (int)(idx / Cin), i = (int)(idx % Cin);
-            off = o_t1 + (((long long)(h / 16) * nib + i / 16) * 64 + ((h % 16) / 4) * 16 + i % 16) * 4 + h % 4;
-            dst = gw1 + idx;
-        } else if (idx < n1 + n2) {
-            off = o_gb1 + (idx - n1);
-            dst = gb1 + (idx - n1);
-        } else if (idx < n1 + n2 + n3) {       // dW2[o][h]: tile (hb, ob), register j = o%4, lane = (o%16/4)*16 + h%16
-            const long long e = idx - n1 - n2;
-            const int o = (int)(e / Ch), h = (int)(e % Ch);
-            off = (((long long)(h / 16) * nob + o / 16) * 64 + ((o % 16) / 4) * 16 + h % 16) * 4 + o % 4;
-            dst = gw2 + e;
-        } else {
-            off = o_gb2 + (idx - n1 - n2 - n3);
-            dst = gb2 + (idx - n1 - n2 - n3);
-        }
-        float acc = 0.f;
-#pragma unroll 8
-        for (int s = 0; s < nslab; ++s) acc += slab[s * stride + off];
-        *dst += acc;
-    }
-}
-
 // ---- one launch that folds EVERY partial slab of a training step into the gradient buffer.
-// The separate folds above walk the slab dimension serially (256 dependent-free but serial loads per thread, 12-17 us per
-// launch, six launches per step).  Here a workgroup owns 64 consecutive slab offsets (coalesced 256-byte rows) and its four
+// (The first version folded each slab set with its own launch, every thread walking the slab dimension serially: 256
+// dependent-free but serial loads per thread, 12-17 us per launch, six launches per step.)  A workgroup owns 64 consecutive slab offsets (coalesced 256-byte rows) and its four
 // waves each sum a quarter of the slabs, 16 loads in flight per lane, combined through LDS; the destination of an offset
 // is found by inverting the slab layout (tile order of pwmlp_bwd, plain order of the skip-weight slabs).
 constexpr int FOLD_MAX_JOBS = 8;
@@ -836,25 +789,12 @@ int dlwp_fold_slabs(const dlwp_fold_job* jobs, int njobs, hipStream_t stream) {
     return DLWP_OK;
 }
 
-int dlwp_slab_reduce(const float* slab, int nslab, long long stride, float* d1, long long n1, float* d2, long long n2,
-                     float* d3, long long n3, float* d4, long long n4, hipStream_t stream) {
-    const long long n = n1 + n2 + n3 + n4;
-    const int grid = (int)((n + 255) / 256);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid), dim3(256), 0, stream, slab, nslab, stride, d1, n1, d2, n2, d3,
-                       n3, d4, n4);
-    DLWP_LAUNCH_CHECK();
-    return DLWP_OK;
-}
-
 int dlwp_pwmlp_slab_reduce(const float* slab, int nslab, int Cin, int Ch, int Cout, float* gw1, float* gb1,
                            float* gw2, float* gb2, hipStream_t stream) {
-    const long long n = (long long)Ch * Cin + Ch + (long long)Cout * Ch + Cout;
-    const int grid = (int)((n + 255) / 256);
-    hipLaunchKernelGGL(pwmlp_slab_reduce_kernel, dim3(grid), dim3(256), 0, stream, slab, nslab,
-                       dlwp_pwmlp_slab_stride(Cin, Ch, Cout), Cin, Ch, Cout, round_up(Cout, 16) / 16, round_up(Cin, 16) / 16,
-                       round_up(Ch, 16), gw1, gb1, gw2, gb2);
-    DLWP_LAUNCH_CHECK();
-    return DLWP_OK;
+    dlwp_fold_job q{};
+    q.slab = slab; q.nslab = nslab; q.pwmlp = 1; q.Cin = Cin; q.Ch = Ch; q.Cout = Cout;
+    q.d1 = gw1; q.d2 = gb1; q.d3 = gw2; q.d4 = gb2;
+    return dlwp_fold_slabs(&q, 1, stream);
 }
 
 #ifdef DLWP_STAMPS
