@@ -209,6 +209,16 @@ __device__ unsigned long long g_dlwp_stamps[32];
             g_dlwp_stamps[i] = t__;                                                           \
         }                                                                                     \
     } while (0)
+// per-wave variant: lane 0 of every wave of workgroup 0 records slot base + wave
+#define DLWP_STAMP_WAVE(base)                                                                 \
+    do {                                                                                      \
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {                                     \
+            unsigned long long t__;                                                           \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");      \
+            g_dlwp_stamps[(base) + (threadIdx.x >> 6)] = t__;                                 \
+        }                                                                                     \
+    } while (0)
 #else
 #define DLWP_STAMP(i)
+#define DLWP_STAMP_WAVE(base)
 #endif

@@ -324,7 +324,14 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
     // the accumulator of z^T / gz^T is then directly the B operand of the pixel contractions (dW2) and, read as an
     // A operand, the hidden-major matrix for dW1; the one product that contracts over the hidden index (dX) gets
     // its operand through a 4-MFMA multiplication with the identity instead of an LDS round trip.
+    // Two waves share each SIMD's matrix pipe and the older one (waves 0-3) wins the arbitration on every instruction: in-kernel
+    // stamps showed waves 0-3 leaving this loop after 20 k cycles and waves 4-7 after 29 k, with the barrier behind it waiting for
+    // the slowest.  The younger half therefore runs the FIRST half of its hidden blocks at raised priority (priority outranks
+    // age) and the second half at the default, so that both halves arrive together.
+    const int hb_half = w + NW * (((nhb - w + NW - 1) / NW) / 2);     // first hidden block of this wave's second half
+    if (w >= NW / 2) __builtin_amdgcn_s_setprio(1);
     for (int hb = w; hb < nhb; hb += NW) {
+        if (w >= NW / 2 && hb == hb_half) __builtin_amdgcn_s_setprio(0);
         f32x4 w1b[NIB];        // B operand of z^T: W1[h = r][i = 4g+s]
 #pragma unroll
         for (int kc = 0; kc < NIB; ++kc)
@@ -461,7 +468,9 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
         if (hb == w) DLWP_STAMP(19);
     }
 
+    __builtin_amdgcn_s_setprio(0);
     DLWP_STAMP(20);
+    DLWP_STAMP_WAVE(24);      // end of every wave's main loop (slots 24..31)
     // cross-wave reduction of gx: every wave parks its [Cin_pad][64] partial tile in LDS (the weight
     // images are dead by now and are reused), then all threads sum the NW tiles.  (LDS float atomics
     // run at <1 lane-op per clock per CU on gfx950 and were the slowest phase of this kernel.)

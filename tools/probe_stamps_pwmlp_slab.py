@@ -22,3 +22,4 @@ for (B, Cin, Ch, Cout, P) in [(4, 10, 256, 32, 4096), (4, 32, 256, 1, 4096)]:
     lib.dlwp_debug_stamps_pwmlp(buf)
     t = list(buf)
     print("bwd slab", (B, Cin, Ch, Cout, P), "stamps 10..22 deltas:", [t[i + 1] - t[i] for i in range(10, 22)], "total", t[22] - t[10])
+    print("   end of main loop per wave, cycles after stamp 10:", [t[24 + w] - t[10] for w in range(8)])
