@@ -17,7 +17,8 @@
 namespace {
 
 constexpr int PT = 64;        // pixels per workgroup
-constexpr int FWD_WAVES = 8;  // 2 waves per SIMD
+constexpr int FWD_WAVES = 16; // 4 waves per SIMD: the forward kernel needs 54 VGPRs and its main loop is bound by the dependent
+                              // z -> GELU -> second-GEMM chain of a wave, not by the matrix pipe (8 waves: 1993, 16 waves: 2007 samples/s)
 constexpr int BWD_WAVES = 8;
 constexpr int LDP = PT + 4;   // LDS row stride of pixel tiles (4*LDP % 32 == 16: conflict-free B reads)
 
