@@ -18,9 +18,11 @@
 
 namespace {
 
-constexpr int NT = 256;
-constexpr int MAXQ = 40;   // column-pass outputs per thread held in registers
-constexpr int RS = 4;      // image rows staged per row-pass step
+constexpr int NT = 1024;   // only B * nb workgroups exist (16 at the nsbench shape): the chain is a sequence of thread-parallel
+                           // passes, so the workgroup is as wide as the hardware allows (256 threads: 356, 1024: 470 samples/s
+                           // on the nsbench AFNONet step; 16 rows per row-pass step instead of 4: 483)
+constexpr int MAXQ = 10;   // column-pass outputs per thread held in registers
+constexpr int RS = 16;     // image rows staged per row-pass step
 
 struct AfnoDev {
     const float* x;        // fwd: input x; bwd: upstream gradient gy
