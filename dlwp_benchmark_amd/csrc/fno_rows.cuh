@@ -42,7 +42,7 @@ __device__ __forceinline__ void tile_rows_dft(const float* tile, const float* ft
 __device__ __forceinline__ void store_x1(const float* x1s, float2* x1_out, int b, int h, int H, int m2c,
                                          int C, int C_pad, int NP) {
     float2* dst = x1_out + ((long long)(b * H + h) * m2c) * C;
-    for (int idx = threadIdx.x; idx < m2c * C; idx += 256) {
+    for (int idx = threadIdx.x; idx < m2c * C; idx += blockDim.x) {
         const int kx = idx / C, c = idx % C;
         float re = 0.f, im = 0.f;
 #pragma unroll

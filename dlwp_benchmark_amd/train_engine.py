@@ -125,6 +125,29 @@ class GraphedTrainStep:
         # the capture itself does not run the kernels; moments/step are still zero, gradients too
         self.grad.zero_()
 
+    # ---- micro-batch form (dlwpbench/scripts/train.py:214-233: gradients of the micro-batches are SUMMED un-scaled, the
+    # optional clip acts on the running sum after every micro-backward, one optimizer step per batch)
+    def accumulate(self, inputs, target):
+        """forward + loss + backward of one micro-batch; gradients add to what earlier micro-batches left."""
+        for k, v in inputs.items():
+            self.inputs[k].copy_(v)
+        self.target.copy_(target)
+        if self.use_graph:
+            if self.graph_optimizer and self.allreduce is None:
+                raise L.DlwpError("accumulate(): build the step with graph_optimizer=False (the optimizer must not be in the capture)")
+            self.g_fb.replay()
+        else:
+            self._fwd_bwd()
+        if self.clip is not None:
+            self.opt.clip_grad_norm_(self.clip, grad_scale=1.0)
+        return self.loss
+
+    def apply(self):
+        """all-reduce (if any) + Adam on the accumulated gradients."""
+        if self.allreduce is not None:
+            self.allreduce(self.grad)
+        self.opt.step(grad_scale=self.grad_scale)
+
     def __call__(self, inputs=None, target=None):
         if inputs is not None:
             for k, v in inputs.items():

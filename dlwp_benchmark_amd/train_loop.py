@@ -131,14 +131,16 @@ def train_dlwp(model, train_dataset, val_dataset, name="model", epochs=10, batch
     train_engine.GraphedTrainStep, for any dlwpbench module (forward(constants, prescribed, prognostic)): batches of
     `WeatherBenchDataset.__getitem__` tuples (wbdata.WeatherBenchArrays) from the seeded rank-sharded permutation, MSE,
     Adam with the cosine schedule stepped per epoch (:194), optional clipping at max_norm = current learning rate
-    (:230-232), validation without gradients, the `_last` / `_best` checkpoint policy (:255-266).  One process per GPU; with
+    (:230-232), micro-batch gradient accumulation (:206-233), validation without gradients, the `_last` / `_best` checkpoint
+    policy (:255-266).  One process per GPU; with
     torch.distributed initialised the flat gradient is all-reduced once per step.  Returns per-epoch dicts."""
     from . import wbdata
     from .train_engine import GraphedTrainStep
-    if gradient_accumulation_steps != 1:
-        # the reference sums un-scaled micro-batch gradients and clips after every micro-backward (:214-233); the captured
-        # step has no micro-batch loop yet
-        raise NotImplementedError("train_dlwp: gradient_accumulation_steps > 1 is not built (use a smaller batch_size)")
+    # micro-batches as in the reference (:206-233): split_size = max(1, batch // steps); every micro-batch's mean loss is
+    # back-propagated un-scaled (the gradients are summed), the clip acts after every micro-backward, one Adam step per batch
+    micro = max(1, batch_size // max(1, gradient_accumulation_steps))
+    if batch_size % micro != 0:
+        raise NotImplementedError("train_dlwp: batch_size must be a multiple of the micro-batch size (static step shapes)")
     device = next(model.parameters()).device
     rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
     world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
@@ -154,15 +156,22 @@ def train_dlwp(model, train_dataset, val_dataset, name="model", epochs=10, batch
         losses = []
         for idx in wbdata.shard_batches(train_dataset, epoch, rank, world, batch_size, seed):
             c, p, g, t = wbdata.to_device_batch([train_dataset[int(i)] for i in idx], device)
+            sl = lambda v, i: None if v is None else v[i:i + micro]      # noqa: E731
             if step is None:
-                step = GraphedTrainStep(model, kwargs_of(c, p, g), t, lr=lr, allreduce=reducer, grad_scale=1.0 / world,
-                                        use_graph=use_graph, graph_optimizer=False,
+                step = GraphedTrainStep(model, kwargs_of(sl(c, 0), sl(p, 0), sl(g, 0)), t[:micro], lr=lr, allreduce=reducer,
+                                        grad_scale=1.0 / world, use_graph=use_graph, graph_optimizer=False,
                                         clip_max_norm=lr if clip_gradients else None)
                 if world > 1:
                     ddp.broadcast_parameters(step.flat, src=0)
             step.opt.lr = lr
             step.clip = lr if clip_gradients else None
-            losses.append(step(kwargs_of(c, p, g), t).clone())
+            if micro == batch_size:
+                loss = step(kwargs_of(c, p, g), t)
+            else:
+                for i in range(0, batch_size, micro):
+                    loss = step.accumulate(kwargs_of(sl(c, i), sl(p, i), sl(g, i)), t[i:i + micro])
+                step.apply()
+            losses.append(loss.clone())
             iteration += 1
         train_mse = torch.stack(losses).mean().item() if losses else float("nan")
         val_mse = validation_mse_dlwp(model, val_dataset, batch_size, device)

@@ -74,3 +74,34 @@ def test_graphed_step_with_allreduce_split_capture(cuda):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_micro_batch_accumulation_sums_unscaled_gradients(cuda, use_graph):
+    """GraphedTrainStep.accumulate / apply (dlwpbench/scripts/train.py:214-233): the gradients of the micro-batches are
+    summed un-scaled and one Adam step follows -- equal to eager autograd over the same micro-batches + torch Adam."""
+    from dlwp_benchmark_amd.train_engine import GraphedTrainStep, mse_loss
+    g = torch.Generator().manual_seed(12)
+    u = torch.randn(4, 7, 1, 16, 16, generator=g).to(cuda)
+    x, y = u[:, :-1].contiguous(), u[:, 1:].contiguous()
+    call = lambda m, kw: m(kw["x"], 2)   # noqa: E731
+    ref = _afno().to(cuda).train()
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    opt.zero_grad(set_to_none=True)
+    for i in (0, 2):
+        mse_loss(ref(x[i:i + 2], 2), y[i:i + 2]).backward()
+    ref_grads = {k: p.grad.clone() for k, p in ref.named_parameters() if p.grad is not None}
+    opt.step()
+    model = _afno().to(cuda).train()
+    step = GraphedTrainStep(model, {"x": x[:2]}, y[:2], lr=1e-3, use_graph=use_graph, call=call, graph_optimizer=False)
+    for i in (0, 2):
+        step.accumulate({"x": x[i:i + 2]}, y[i:i + 2])
+    for k, p in model.named_parameters():
+        if k not in ref_grads:
+            continue
+        scale = ref_grads[k].abs().max().clamp_min(1e-12)
+        assert ((p.grad - ref_grads[k]).abs().max() / scale).item() <= 2e-4, k
+    step.apply()
+    for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        assert ((p - q).abs().max() / q.abs().max().clamp_min(1e-12)).item() <= 2e-4, k
+    assert step.grad.abs().max().item() == 0.0          # Adam zeroes the accumulated gradients
