@@ -209,6 +209,25 @@ __device__ unsigned long long g_dlwp_stamps[32];
             g_dlwp_stamps[i] = t__;                                                           \
         }                                                                                     \
     } while (0)
+// span of a whole launch on the constant-rate 100 MHz clock (comparable across XCDs): earliest first instruction and
+// latest last instruction over ALL workgroups (slots: begin = min, end = max)
+__device__ unsigned long long g_dlwp_span[2] = {~0ull, 0ull};
+#define DLWP_SPAN_BEGIN()                                                                     \
+    do {                                                                                      \
+        if (threadIdx.x == 0) {                                                               \
+            unsigned long long t__;                                                           \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");  \
+            atomicMin(&g_dlwp_span[0], t__);                                                  \
+        }                                                                                     \
+    } while (0)
+#define DLWP_SPAN_END()                                                                       \
+    do {                                                                                      \
+        if ((threadIdx.x & 63) == 0) {                                                        \
+            unsigned long long t__;                                                           \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");  \
+            atomicMax(&g_dlwp_span[1], t__);                                                  \
+        }                                                                                     \
+    } while (0)
 // per-wave variant: lane 0 of every wave of workgroup 0 records slot base + wave
 #define DLWP_STAMP_WAVE(base)                                                                 \
     do {                                                                                      \
@@ -221,4 +240,6 @@ __device__ unsigned long long g_dlwp_stamps[32];
 #else
 #define DLWP_STAMP(i)
 #define DLWP_STAMP_WAVE(base)
+#define DLWP_SPAN_BEGIN()
+#define DLWP_SPAN_END()
 #endif

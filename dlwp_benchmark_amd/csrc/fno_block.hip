@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void fno_spatial_kernel(SpatialDev a) {
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int W4 = a.W / 4, nwb = a.W / 16;
     const bool need_prev = a.is_bwd && (a.act_prev || a.g_wskip || a.gslab);
+    DLWP_SPAN_BEGIN();
     DLWP_STAMP(0);
     // ---- issue phase: the first chunk of every independent input goes into registers before any LDS
     // write, so the workgroup pays one global latency for all of them (larger shapes loop afterwards)
@@ -341,6 +342,7 @@ __global__ __launch_bounds__(256) void fno_spatial_kernel(SpatialDev a) {
         }
     }
     DLWP_STAMP(12);
+    DLWP_SPAN_END();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -865,6 +867,14 @@ extern "C" int dlwp_fno_block_bwd(const dlwp_fno_plan* p, const float* x, int ac
 }
 
 #ifdef DLWP_STAMPS
+extern "C" int dlwp_debug_span_fno(unsigned long long* host_out, int reset) {
+    DLWP_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dlwp_span), sizeof(unsigned long long) * 2));
+    if (reset) {
+        const unsigned long long init[2] = {~0ull, 0ull};
+        DLWP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dlwp_span), init, sizeof(init)));
+    }
+    return DLWP_OK;
+}
 extern "C" int dlwp_debug_stamps_fno(unsigned long long* host_out) {
     DLWP_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dlwp_stamps), sizeof(unsigned long long) * 32));
     return DLWP_OK;
