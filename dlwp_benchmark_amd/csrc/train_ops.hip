@@ -349,6 +349,28 @@ extern "C" int dlwp_debug_null_kernels(int n, int blocks, void* stream) {
     return DLWP_OK;
 }
 
+// ---- debug: a chain of n dependent kernels whose every wave spins for `cycles` shader cycles, with a chosen grid, block size
+// and dynamic LDS size: what a launch costs beyond its body as a function of the number and size of its workgroups
+namespace {
+__global__ void spin_kernel(int cycles, int* sink) {
+    extern __shared__ float spin_lds[];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) spin_lds[0] = 1.f;
+    while ((long long)(__builtin_amdgcn_s_memtime() - t0) < cycles) __builtin_amdgcn_s_sleep(1);
+    if (sink && spin_lds[0] == 3.f) *sink = 1;
+}
+}  // namespace
+extern "C" int dlwp_debug_spin_kernels(int n, int blocks, int threads, int cycles, int lds_bytes, void* stream) {
+    DLWP_REQUIRE(n > 0 && blocks > 0 && threads > 0 && threads <= 1024 && cycles >= 0 && cycles < (1 << 24) && lds_bytes >= 4,
+                 DLWP_E_INVALID, "debug_spin_kernels: bad argument");
+    int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(spin_kernel), (size_t)lds_bytes, "spin");
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i)
+        hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(threads), (size_t)lds_bytes, (hipStream_t)stream, cycles, nullptr);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
 // ---- debug: effective shader clock during a short kernel: out[0]=delta s_memtime, out[1]=delta s_memrealtime (100 MHz)
 namespace {
 __global__ void clock_probe_kernel(unsigned long long* out, int iters) {

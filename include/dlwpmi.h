@@ -363,6 +363,8 @@ int dlwp_fno_spatial_fwd_probe(const dlwp_fno_plan* plan, const float* x, const 
                                int B, void* stream);
 /* debug: enqueue n dependent empty kernels of `blocks` workgroups (per-kernel floor probe)   */
 int dlwp_debug_null_kernels(int n, int blocks, void* stream);
+/* same with a body: every wave spins for `cycles` shader cycles; grid, block size and dynamic LDS chosen by the caller */
+int dlwp_debug_spin_kernels(int n, int blocks, int threads, int cycles, int lds_bytes, void* stream);
 /* debug: out[0] = shader-clock ticks, out[1] = 100 MHz ticks spent in a dependent-FMA loop   */
 int dlwp_debug_clock_probe(unsigned long long* out, int iters, int blocks, void* stream);
 
