@@ -18,7 +18,7 @@ timeout 600 python3 $R/tools/bench_models.py all --steps 10 > $O/models.jsonl 2>
 for m in swin_dlwp swin_c4 pangu_c4 afno_fcn; do
   timeout 300 python3 $R/tools/bench_models.py $m --steps 5 2>> $O/models.err | grep '"model"' >> $O/models.jsonl
 done
-for m in sfno afno_fcn; do
+for m in sfno afno_fcn swin_c4 pangu_c4; do
   timeout 300 python3 $R/tools/bench_models.py $m --steps 5 --precision bf16 2>> $O/models.err | grep '"model"' >> $O/models.jsonl
 done
 for m in afno swin sfno pangu afno_fcn; do
