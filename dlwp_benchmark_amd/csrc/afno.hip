@@ -146,6 +146,7 @@ __global__ __launch_bounds__(NT) void afno2d_kernel(AfnoDev a) {
     const int tid = threadIdx.x;
     const int b = blockIdx.x / a.nb, blk = blockIdx.x % a.nb;
     const float s = rsqrtf((float)(H * W));
+    DLWP_STAMP(0);
 
     for (int i = tid; i < W; i += NT) { float sn, cs; sincospif(2.f * i / W, &sn, &cs); twW[i] = make_float2(cs, sn); }
     for (int i = tid; i < H; i += NT) { float sn, cs; sincospif(2.f * i / H, &sn, &cs); twH[i] = make_float2(cs, sn); }
@@ -164,8 +165,11 @@ __global__ __launch_bounds__(NT) void afno2d_kernel(AfnoDev a) {
     __syncthreads();
 
     // forward transform of x (fwd) / adjoint of the inverse transform applied to gy (bwd)
+    DLWP_STAMP(1);
     row_pass_fwd(a, a.x, b, blk, S, stage, twW, s, BWD);
+    DLWP_STAMP(2);
     col_pass<false>(a, S, twH);
+    DLWP_STAMP(3);
 
     // ---- per-mode mixer on the kept window; chunks of MC = NT / bs modes, one thread per (mode, channel)
     const int R = a.r1 - a.r0, nmodes = R * c1, MC = NT / bs;
@@ -176,7 +180,10 @@ __global__ __launch_bounds__(NT) void afno2d_kernel(AfnoDev a) {
     const int ml = tid / bs, ch = tid - ml * bs;                 // local mode, channel
     float2* xs_base = a.xsave + ((long long)(b * a.nb + blk) * nmodes) * bs;
     float gw1a_r = 0.f, gw1a_i = 0.f, gw2a_r = 0.f, gw2a_i = 0.f, gb1r = 0.f, gb1i = 0.f, gb2r = 0.f, gb2i = 0.f;
-    const int pi_ = tid / bs, po_ = tid - pi_ * bs;              // (i,o) pair owned for weight gradients (bs*bs <= NT)
+    // weight gradients: thread = ((i,o) pair, part); the NT / (bs*bs) parts split the modes of a chunk between them (with
+    // one part, 256 of the 1024 threads walked 64 modes each: a third of the backward mixer)
+    const int npart = NT / (bs * bs), wpart = tid / (bs * bs), wpair = tid - wpart * bs * bs;
+    const int pi_ = wpair / bs, po_ = wpair - pi_ * bs;
     for (int m0 = 0; m0 < nmodes; m0 += MC) {
         const int m = m0 + ml;
         const bool valid = ml < MC && m < nmodes;
@@ -264,9 +271,9 @@ __global__ __launch_bounds__(NT) void afno2d_kernel(AfnoDev a) {
                 sp[ch] = gx;
             }
             // weight gradients for the (i,o) pair this thread owns: gW2 += conj(o1[i]) g2[o]; gW1 += conj(x[i]) gz[o]
-            if (pi_ < bs) {
+            if (wpart < npart) {
                 const int mc = min(MC, nmodes - m0);
-                for (int q = 0; q < mc; ++q) {
+                for (int q = wpart; q < mc; q += npart) {
                     const float2 a1 = o1c[q * bs + pi_], g2v = g2c[q * bs + po_];
                     gw2a_r += a1.x * g2v.x + a1.y * g2v.y;
                     gw2a_i += a1.x * g2v.y - a1.y * g2v.x;
@@ -278,6 +285,7 @@ __global__ __launch_bounds__(NT) void afno2d_kernel(AfnoDev a) {
             __syncthreads();
         }
     }
+    DLWP_STAMP(4);
     // zero everything outside the kept row window (columns >= c1 are never formed)
     for (int o = tid; o < H * c1 * bs; o += NT) {
         const int h = o / (c1 * bs);
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(NT) void afno2d_kernel(AfnoDev a) {
     }
     __syncthreads();
     if (BWD) {
-        if (pi_ < bs) {
+        if (wpart < npart) {
             const int wofs = (blk * bs + pi_) * bs + po_;
             atomic_add_f32(&a.gw1[wofs], gw1a_r);
             atomic_add_f32(&a.gw1[a.nb * bs * bs + wofs], gw1a_i);
@@ -306,9 +314,12 @@ __global__ __launch_bounds__(NT) void afno2d_kernel(AfnoDev a) {
         }
         __syncthreads();
     }
+    DLWP_STAMP(5);
     col_pass<true>(a, S, twH);
+    DLWP_STAMP(6);
     // inverse rows + residual: fwd = irfft (interior columns doubled); bwd = adjoint of rfft (no doubling)
     row_pass_inv(a, a.y, a.x, b, blk, S, twW, s, !BWD);
+    DLWP_STAMP(7);
 }
 
 size_t afno_lds_bytes(int H, int W, int bs, int c1) {
@@ -424,3 +435,10 @@ extern "C" int dlwp_afno_wq_fold(const float* gq, float* gw, int nb, int bs_in, 
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }
+
+#ifdef DLWP_STAMPS
+extern "C" int dlwp_debug_stamps_afno(unsigned long long* host_out) {
+    DLWP_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dlwp_stamps), sizeof(unsigned long long) * 32));
+    return DLWP_OK;
+}
+#endif
