@@ -22,6 +22,8 @@ constexpr int NT = 1024;   // only B * nb workgroups exist (16 at the nsbench sh
                            // passes, so the workgroup is as wide as the hardware allows (256 threads: 356, 1024: 470 samples/s
                            // on the nsbench AFNONet step; 16 rows per row-pass step instead of 4: 483)
 constexpr int MAXQ = 10;   // column-pass outputs per thread held in registers
+constexpr int ELD = 36;     // row stride of the 32 x 32 weight images (conflict-free row and column fragment reads)
+constexpr int TLD = 36;     // row stride of the mixer's [16 modes][32] wave tiles
 constexpr int RS = 16;     // image rows staged per row-pass step
 
 struct AfnoDev {
@@ -31,6 +33,7 @@ struct AfnoDev {
     const float *w1, *b1, *w2, *b2;   // [2][nb][bs][bs], [2][nb][bs], ...
     float *gw1, *gb1, *gw2, *gb2;     // bwd (atomic accumulate)
     int B, H, W, C, nb, bs, r0, r1, c1;
+    int nwm;               // waves that run the mixer (each owns 4 wave tiles in the staging region)
     float lambda;
     FastDiv dbs, dc1;
 };
@@ -137,12 +140,10 @@ __global__ __launch_bounds__(NT) void afno2d_kernel(AfnoDev a) {
     float2* S = reinterpret_cast<float2*>(smem);                 // [H][c1][bs]
     float2* twW = S + H * c1 * bs;                               // [W]  e^{+2 pi i n / W}
     float2* twH = twW + W;                                       // [H]
-    float* w1r = reinterpret_cast<float*>(twH + H);              // [bs][bs] each: w1 re/im, w2 re/im
-    float* w1i = w1r + bs * bs;
-    float* w2r = w1i + bs * bs;
-    float* w2i = w2r + bs * bs;
-    float* bsm = w2i + bs * bs;                                  // b1 re, b1 im, b2 re, b2 im  [4][bs]
-    float* stage = bsm + 4 * bs;                                 // [RS][W][bs] row staging; reused as mixer scratch
+    float* E1 = reinterpret_cast<float*>(twH + H);               // [32][ELD] real image of W1: rows (i, re|im), cols (o, re|im)
+    float* E2 = E1 + 32 * ELD;                                   // same for W2
+    float* bsm = E2 + 32 * ELD;                                  // [2][32] biases of layer 1 / 2 in (o, re|im) order
+    float* stage = bsm + 64;                                     // [RS][W][bs] row staging; reused as the mixer's wave tiles
     const int tid = threadIdx.x;
     const int b = blockIdx.x / a.nb, blk = blockIdx.x % a.nb;
     const float s = rsqrtf((float)(H * W));
@@ -150,17 +151,24 @@ __global__ __launch_bounds__(NT) void afno2d_kernel(AfnoDev a) {
 
     for (int i = tid; i < W; i += NT) { float sn, cs; sincospif(2.f * i / W, &sn, &cs); twW[i] = make_float2(cs, sn); }
     for (int i = tid; i < H; i += NT) { float sn, cs; sincospif(2.f * i / H, &sn, &cs); twH[i] = make_float2(cs, sn); }
-    for (int i = tid; i < bs * bs; i += NT) {
-        w1r[i] = a.w1[(0 * a.nb + blk) * bs * bs + i];
-        w1i[i] = a.w1[(1 * a.nb + blk) * bs * bs + i];
-        w2r[i] = a.w2[(0 * a.nb + blk) * bs * bs + i];
-        w2i[i] = a.w2[(1 * a.nb + blk) * bs * bs + i];
+    // complex [bs x bs] weights as real [2 bs x 2 bs] images, zero-padded to 32 x 32:
+    //   (xr, xi) . [[Wr, Wi], [-Wi, Wr]] = (Re(x W), Im(x W));  the transposed image is the map g -> g . conj(W)^T
+    for (int e = tid; e < 32 * 32; e += NT) {
+        const int kr = e >> 5, nc = e & 31, i = kr >> 1, ri = kr & 1, o = nc >> 1, ro = nc & 1;
+        float v1 = 0.f, v2 = 0.f;
+        if (i < bs && o < bs) {
+            const int plane = ri ^ ro;                            // same parts -> real plane, mixed -> imaginary plane
+            const float sg = (ri == 1 && ro == 0) ? -1.f : 1.f;
+            v1 = sg * a.w1[(plane * a.nb + blk) * bs * bs + i * bs + o];
+            v2 = sg * a.w2[(plane * a.nb + blk) * bs * bs + i * bs + o];
+        }
+        E1[kr * ELD + nc] = v1;
+        E2[kr * ELD + nc] = v2;
     }
-    for (int i = tid; i < bs; i += NT) {
-        bsm[i] = a.b1[(0 * a.nb + blk) * bs + i];
-        bsm[bs + i] = a.b1[(1 * a.nb + blk) * bs + i];
-        bsm[2 * bs + i] = a.b2[(0 * a.nb + blk) * bs + i];
-        bsm[3 * bs + i] = a.b2[(1 * a.nb + blk) * bs + i];
+    for (int e = tid; e < 64; e += NT) {
+        const int layer = e >> 5, nc = e & 31, o = nc >> 1, ro = nc & 1;
+        const float* bp = layer ? a.b2 : a.b1;
+        bsm[e] = o < bs ? bp[(ro * a.nb + blk) * bs + o] : 0.f;
     }
     __syncthreads();
 
@@ -171,120 +179,142 @@ __global__ __launch_bounds__(NT) void afno2d_kernel(AfnoDev a) {
     col_pass<false>(a, S, twH);
     DLWP_STAMP(3);
 
-    // ---- per-mode mixer on the kept window; chunks of MC = NT / bs modes, one thread per (mode, channel)
-    const int R = a.r1 - a.r0, nmodes = R * c1, MC = NT / bs;
-    float2* o1c = reinterpret_cast<float2*>(stage);             // [MC][bs]
-    float2* g2c = o1c + MC * bs;                                 // [MC][bs]  (bwd)
-    float2* z1c = g2c + MC * bs;                                 // [MC][bs]  (bwd)
-    float2* xc = z1c + MC * bs;                                  // [MC][bs]  (bwd) saved spectrum chunk
-    const int ml = tid / bs, ch = tid - ml * bs;                 // local mode, channel
-    float2* xs_base = a.xsave + ((long long)(b * a.nb + blk) * nmodes) * bs;
-    float gw1a_r = 0.f, gw1a_i = 0.f, gw2a_r = 0.f, gw2a_i = 0.f, gb1r = 0.f, gb1i = 0.f, gb2r = 0.f, gb2i = 0.f;
-    // weight gradients: thread = ((i,o) pair, part); the NT / (bs*bs) parts split the modes of a chunk between them (with
-    // one part, 256 of the 1024 threads walked 64 modes each: a third of the backward mixer)
-    const int npart = NT / (bs * bs), wpart = tid / (bs * bs), wpair = tid - wpart * bs * bs;
-    const int pi_ = wpair / bs, po_ = wpair - pi_ * bs;
-    for (int m0 = 0; m0 < nmodes; m0 += MC) {
-        const int m = m0 + ml;
-        const bool valid = ml < MC && m < nmodes;
-        const int row = a.r0 + (valid ? m / c1 : 0), col = valid ? m % c1 : 0;
-        float2* sp = S + (row * c1 + col) * bs;
-        if (!BWD) {
-            float2 xv = make_float2(0.f, 0.f);
-            if (valid) { xv = sp[ch]; xs_base[(long long)m * bs + ch] = xv; }
-            __syncthreads();                                      // everyone has read its x before o1 overwrites nothing yet
-            // layer 1: z1[o] = sum_i x[i] W1[i][o] + b1[o]; o1 = relu(re), relu(im)
-            float2 z = make_float2(bsm[ch], bsm[bs + ch]);
-            if (valid)
-                for (int i = 0; i < bs; ++i) {
-                    const float2 v = sp[i];
-                    const float wr = w1r[i * bs + ch], wi = w1i[i * bs + ch];
-                    z.x += v.x * wr - v.y * wi;
-                    z.y += v.y * wr + v.x * wi;
+    // ---- per-mode mixer on the kept window, on the matrix cores.  The kept modes are the contiguous rows
+    // [r0 c1, r1 c1) of S, each 2 bs floats (re, im interleaved) = one row of a [modes x 2 bs] real matrix; a wave takes
+    // tiles of 16 modes through the whole two-layer chain (and its backward) on wave-private LDS tiles: no workgroup
+    // barrier inside the mixer.  D layout of a 16 x 16 accumulator tile: lane (r, g) holds rows (modes) 4g+j, column r.
+    const int R = a.r1 - a.r0, nmodes = R * c1, K2 = 2 * bs, ntiles = (nmodes + 15) / 16;
+    const int lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
+    float* Srow0 = reinterpret_cast<float*>(S + a.r0 * c1 * bs);          // [nmodes][K2]
+    float* xs_base = reinterpret_cast<float*>(a.xsave + ((long long)(b * a.nb + blk) * nmodes) * bs);   // [nmodes][K2]
+    float* wt = stage + w * (4 * 16 * TLD);                                 // this wave's tiles
+    float* Xt = wt, *O1t = wt + 16 * TLD, *G2t = wt + 2 * 16 * TLD, *GZt = wt + 3 * 16 * TLD;
+    f32x4 gw1e[2][2], gw2e[2][2];                                           // expanded weight-gradient tiles [(i,ri)][(o,ro)]
+    float gb1p[2] = {0.f, 0.f}, gb2p[2] = {0.f, 0.f};                       // bias-gradient partials of column n = r + 16 nt
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) { gw1e[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; gw2e[mt][nt] = gw1e[mt][nt]; }
+
+    // tile[16][32] . E (or E^T) -> two 16 x 16 accumulator tiles; bias: added per column (nullptr: none)
+    auto tile_gemm = [&](const float* tile, const float* E, bool transposed, const float* bias, f32x4 (&acc)[2]) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float bv = bias ? bias[16 * nt + r] : 0.f;
+            acc[nt] = f32x4{bv, bv, bv, bv};
+        }
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&tile[r * TLD + 16 * kc + 4 * g]);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                f32x4 b4;
+                if (transposed) {
+                    b4 = *reinterpret_cast<const f32x4*>(&E[(16 * nt + r) * ELD + 16 * kc + 4 * g]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) b4[q] = E[(16 * kc + 4 * g + q) * ELD + 16 * nt + r];
                 }
-            if (ml < MC) o1c[ml * bs + ch] = make_float2(fmaxf(z.x, 0.f), fmaxf(z.y, 0.f));
-            __syncthreads();
-            float2 o2 = make_float2(bsm[2 * bs + ch], bsm[3 * bs + ch]);
-            if (valid) {
-                for (int i = 0; i < bs; ++i) {
-                    const float2 v = o1c[ml * bs + i];
-                    const float wr = w2r[i * bs + ch], wi = w2i[i * bs + ch];
-                    o2.x += v.x * wr - v.y * wi;
-                    o2.y += v.y * wr + v.x * wi;
-                }
-                sp[ch] = make_float2(softshrink(o2.x, a.lambda), softshrink(o2.y, a.lambda));
+                acc[nt] = mfma16_chunk(a4, b4, acc[nt]);
             }
-            __syncthreads();
-        } else {
-            // recompute layer 1 / layer 2 pre-activations from the saved spectrum
-            float2 xv = make_float2(0.f, 0.f), gF = xv;
-            if (valid) { xv = xs_base[(long long)m * bs + ch]; gF = sp[ch]; }
-            if (ml < MC) xc[ml * bs + ch] = xv;
-            __syncthreads();
-            float2 z = make_float2(bsm[ch], bsm[bs + ch]);
-            if (valid)
-                for (int i = 0; i < bs; ++i) {
-                    const float2 v = xc[ml * bs + i];
-                    const float wr = w1r[i * bs + ch], wi = w1i[i * bs + ch];
-                    z.x += v.x * wr - v.y * wi;
-                    z.y += v.y * wr + v.x * wi;
-                }
-            const float2 o1 = make_float2(fmaxf(z.x, 0.f), fmaxf(z.y, 0.f));
-            if (ml < MC) o1c[ml * bs + ch] = valid ? o1 : make_float2(0.f, 0.f);
-            __syncthreads();
-            float2 o2 = make_float2(bsm[2 * bs + ch], bsm[3 * bs + ch]);
-            if (valid)
-                for (int i = 0; i < bs; ++i) {
-                    const float2 v = o1c[ml * bs + i];
-                    const float wr = w2r[i * bs + ch], wi = w2i[i * bs + ch];
-                    o2.x += v.x * wr - v.y * wi;
-                    o2.y += v.y * wr + v.x * wi;
-                }
-            // softshrink backward (re and im independently)
-            float2 g2 = make_float2(0.f, 0.f);
-            if (valid) g2 = make_float2(fabsf(o2.x) > a.lambda ? gF.x : 0.f, fabsf(o2.y) > a.lambda ? gF.y : 0.f);
-            if (ml < MC) g2c[ml * bs + ch] = g2;
-            gb2r += g2.x; gb2i += g2.y;
-            __syncthreads();
-            // gO1[i=ch] = sum_o g2[o] conj(W2[i][o]); ReLU backward on re/im independently
-            float2 g1 = make_float2(0.f, 0.f);
-            if (valid)
-                for (int o = 0; o < bs; ++o) {
-                    const float2 gv = g2c[ml * bs + o];
-                    const float wr = w2r[ch * bs + o], wi = w2i[ch * bs + o];
-                    g1.x += gv.x * wr + gv.y * wi;
-                    g1.y += gv.y * wr - gv.x * wi;
-                }
-            const float2 gz = make_float2(z.x > 0.f ? g1.x : 0.f, z.y > 0.f ? g1.y : 0.f);
-            if (ml < MC) z1c[ml * bs + ch] = valid ? gz : make_float2(0.f, 0.f);
-            gb1r += valid ? gz.x : 0.f; gb1i += valid ? gz.y : 0.f;
-            __syncthreads();
-            // gX[i=ch] = sum_o gz[o] conj(W1[i][o])  -> back into the spectrum buffer
-            if (valid) {
-                float2 gx = make_float2(0.f, 0.f);
-                for (int o = 0; o < bs; ++o) {
-                    const float2 gv = z1c[ml * bs + o];
-                    const float wr = w1r[ch * bs + o], wi = w1i[ch * bs + o];
-                    gx.x += gv.x * wr + gv.y * wi;
-                    gx.y += gv.y * wr - gv.x * wi;
-                }
-                sp[ch] = gx;
+        }
+    };
+    auto put_tile = [&](float* tile, const f32x4 (&v)[2]) {             // accumulator layout -> [mode][32] tile
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tile[(4 * g + j) * TLD + 16 * nt + r] = v[nt][j];
+        __builtin_amdgcn_wave_barrier();
+    };
+    // G[(i,ri)][(o,ro)] += sum_modes A[mode][(i,ri)] B[mode][(o,ro)]
+    auto outer_acc = [&](const float* At, const float* Bt, f32x4 (&G)[2][2]) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x4 a4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a4[q] = At[(4 * g + q) * TLD + 16 * mt + r];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                f32x4 b4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b4[q] = Bt[(4 * g + q) * TLD + 16 * nt + r];
+                G[mt][nt] = mfma16_chunk(a4, b4, G[mt][nt]);
             }
-            // weight gradients for the (i,o) pair this thread owns: gW2 += conj(o1[i]) g2[o]; gW1 += conj(x[i]) gz[o]
-            if (wpart < npart) {
-                const int mc = min(MC, nmodes - m0);
-                for (int q = wpart; q < mc; q += npart) {
-                    const float2 a1 = o1c[q * bs + pi_], g2v = g2c[q * bs + po_];
-                    gw2a_r += a1.x * g2v.x + a1.y * g2v.y;
-                    gw2a_i += a1.x * g2v.y - a1.y * g2v.x;
-                    const float2 xq = xc[q * bs + pi_], gzv = z1c[q * bs + po_];
-                    gw1a_r += xq.x * gzv.x + xq.y * gzv.y;
-                    gw1a_i += xq.x * gzv.y - xq.y * gzv.x;
+        }
+    };
+
+    if (w < a.nwm) {
+        for (int t = w; t < ntiles; t += a.nwm) {
+            const int m0 = 16 * t;
+            // X tile: forward from the spectrum (and saved for the backward pass), backward from the saved copy
+            {
+                const float* src = BWD ? xs_base : Srow0;
+                __builtin_amdgcn_wave_barrier();
+                for (int e = lane; e < 16 * 32; e += 64) {
+                    const int mr = e >> 5, k = e & 31;
+                    float v = 0.f;
+                    if (m0 + mr < nmodes && k < K2) {
+                        v = src[(long long)(m0 + mr) * K2 + k];
+                        if (!BWD) xs_base[(long long)(m0 + mr) * K2 + k] = v;
+                    }
+                    Xt[mr * TLD + k] = v;
                 }
+                __builtin_amdgcn_wave_barrier();
             }
-            __syncthreads();
+            f32x4 z1[2], z2[2], o1[2];
+            tile_gemm(Xt, E1, false, bsm, z1);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o1[nt][j] = fmaxf(z1[nt][j], 0.f);
+            put_tile(O1t, o1);
+            tile_gemm(O1t, E2, false, bsm + 32, z2);
+            if (!BWD) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int mr = 4 * g + j, n = 16 * nt + r;
+                        if (m0 + mr < nmodes && n < K2) Srow0[(long long)(m0 + mr) * K2 + n] = softshrink(z2[nt][j], a.lambda);
+                    }
+            } else {
+                // softshrink backward on the incoming spectrum gradient, then back through layer 2 and the ReLU
+                f32x4 g2[2], go1[2], gz[2], gx[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int mr = 4 * g + j, n = 16 * nt + r;
+                        const bool ok = m0 + mr < nmodes && n < K2;
+                        const float gf = ok ? Srow0[(long long)(m0 + mr) * K2 + n] : 0.f;
+                        g2[nt][j] = fabsf(z2[nt][j]) > a.lambda ? gf : 0.f;
+                        gb2p[nt] += g2[nt][j];
+                    }
+                put_tile(G2t, g2);
+                tile_gemm(G2t, E2, true, nullptr, go1);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        gz[nt][j] = z1[nt][j] > 0.f ? go1[nt][j] : 0.f;
+                        gb1p[nt] += gz[nt][j];
+                    }
+                put_tile(GZt, gz);
+                tile_gemm(GZt, E1, true, nullptr, gx);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int mr = 4 * g + j, n = 16 * nt + r;
+                        if (m0 + mr < nmodes && n < K2) Srow0[(long long)(m0 + mr) * K2 + n] = gx[nt][j];
+                    }
+                outer_acc(O1t, G2t, gw2e);       // gW2 += conj(o1)^T g2, gW1 += conj(x)^T gz  (in the real image)
+                outer_acc(Xt, GZt, gw1e);
+            }
         }
     }
+    __syncthreads();
     DLWP_STAMP(4);
     // zero everything outside the kept row window (columns >= c1 are never formed)
     for (int o = tid; o < H * c1 * bs; o += NT) {
@@ -293,26 +323,41 @@ __global__ __launch_bounds__(NT) void afno2d_kernel(AfnoDev a) {
     }
     __syncthreads();
     if (BWD) {
-        if (wpart < npart) {
-            const int wofs = (blk * bs + pi_) * bs + po_;
-            atomic_add_f32(&a.gw1[wofs], gw1a_r);
-            atomic_add_f32(&a.gw1[a.nb * bs * bs + wofs], gw1a_i);
-            atomic_add_f32(&a.gw2[wofs], gw2a_r);
-            atomic_add_f32(&a.gw2[a.nb * bs * bs + wofs], gw2a_i);
+        if (w < a.nwm) {
+            // fold the real image of the weight gradients back into complex planes and add to the parameters' gradients:
+            // G[(i,ri)][(o,ro)]: gWr[i][o] = G[(i,0)][(o,0)] + G[(i,1)][(o,1)], gWi[i][o] = G[(i,0)][(o,1)] - G[(i,1)][(o,0)].
+            // Lane (r, g) holds rows (i,ri) = 4g+j of column n = (o,ro) = 16 nt + r: ri = j & 1, the partner column is in lane r^1.
+            auto fold = [&](const f32x4 (&G)[2][2], float* gw) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int jp = 0; jp < 2; ++jp) {
+                            const float g0 = G[mt][nt][2 * jp], g1 = G[mt][nt][2 * jp + 1];      // rows (i, re), (i, im)
+                            const float p0 = __shfl_xor(g0, 1), p1 = __shfl_xor(g1, 1);          // partner column o, other part
+                            const int i = (16 * mt + 4 * g + 2 * jp) >> 1, n = 16 * nt + r, o = n >> 1, ro = n & 1;
+                            // ro == 0: this lane has (o,re): real = g0 + partner's g1 ; ro == 1: imag = g0 - partner's g1
+                            const float val = ro == 0 ? g0 + p1 : g0 - p1;
+                            (void)p0;
+                            if (i < bs && o < bs) atomic_add_f32(&gw[(ro * a.nb + blk) * bs * bs + i * bs + o], val);
+                        }
+            };
+            fold(gw1e, a.gw1);
+            fold(gw2e, a.gw2);
+            // bias gradients: sum the four lane groups (modes) of each column, one atomic per (wave, column)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float v1 = gb1p[nt], v2 = gb2p[nt];
+                v1 += __shfl_xor(v1, 16); v1 += __shfl_xor(v1, 32);
+                v2 += __shfl_xor(v2, 16); v2 += __shfl_xor(v2, 32);
+                const int n = 16 * nt + r, o = n >> 1, ro = n & 1;
+                if (g == 0 && o < bs) {
+                    atomic_add_f32(&a.gb1[(ro * a.nb + blk) * bs + o], v1);
+                    atomic_add_f32(&a.gb2[(ro * a.nb + blk) * bs + o], v2);
+                }
+            }
         }
-        // bias gradients: reduce over the threads that share a channel (stride bs) through LDS
-        float* red = stage;                                       // [4][NT]
-        red[tid] = gb1r; red[NT + tid] = gb1i; red[2 * NT + tid] = gb2r; red[3 * NT + tid] = gb2i;
-        __syncthreads();
-        if (tid < bs) {
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            for (int q = tid; q < NT; q += bs) { s0 += red[q]; s1 += red[NT + q]; s2 += red[2 * NT + q]; s3 += red[3 * NT + q]; }
-            atomic_add_f32(&a.gb1[blk * bs + tid], s0);
-            atomic_add_f32(&a.gb1[a.nb * bs + blk * bs + tid], s1);
-            atomic_add_f32(&a.gb2[blk * bs + tid], s2);
-            atomic_add_f32(&a.gb2[a.nb * bs + blk * bs + tid], s3);
-        }
-        __syncthreads();
     }
     DLWP_STAMP(5);
     col_pass<true>(a, S, twH);
@@ -322,11 +367,19 @@ __global__ __launch_bounds__(NT) void afno2d_kernel(AfnoDev a) {
     DLWP_STAMP(7);
 }
 
-size_t afno_lds_bytes(int H, int W, int bs, int c1) {
-    const size_t stage = (size_t)RS * W * bs;
-    size_t scratch = (size_t)4 * (NT / bs) * bs * 2;  // mixer chunks (float2)
-    if (scratch < (size_t)4 * NT) scratch = 4 * NT;
-    return sizeof(float) * ((size_t)2 * H * c1 * bs + 2 * (W + H) + 4 * bs * bs + 4 * bs + (stage > scratch ? stage : scratch));
+constexpr size_t AFNO_LDS_LIMIT = 156 * 1024;
+// floats in front of the staging region, and the staging region itself (row staging, later nwm x 4 wave tiles of the mixer)
+size_t afno_fixed_floats(int H, int W, int bs, int c1) { return (size_t)2 * H * c1 * bs + 2 * (W + H) + 2 * 32 * ELD + 64; }
+int afno_mixer_waves(int H, int W, int bs, int c1, int ntiles) {
+    const size_t room = AFNO_LDS_LIMIT / sizeof(float) - afno_fixed_floats(H, W, bs, c1);
+    int nwm = (int)(room / (4 * 16 * TLD));
+    if (nwm > NT / 64) nwm = NT / 64;
+    if (nwm > ntiles) nwm = ntiles;
+    return nwm;
+}
+size_t afno_lds_bytes(int H, int W, int bs, int c1, int nwm) {
+    const size_t stage = (size_t)RS * W * bs, tiles = (size_t)nwm * 4 * 16 * TLD;
+    return sizeof(float) * (afno_fixed_floats(H, W, bs, c1) + (stage > tiles ? stage : tiles));
 }
 
 int afno_setup(AfnoDev& a, int B, int H, int W, int C, int nb, float frac, const char* who) {
@@ -337,13 +390,14 @@ int afno_setup(AfnoDev& a, int B, int H, int W, int C, int nb, float frac, const
     a.r1 = total + kept > H ? H : total + kept;
     a.c1 = kept < W / 2 + 1 ? kept : W / 2 + 1;
     DLWP_REQUIRE(kept > 0, DLWP_E_INVALID, "%s: hard_thresholding_fraction keeps no mode", who);
-    DLWP_REQUIRE(a.bs <= 64 && NT % a.bs == 0 && a.bs * a.bs <= NT * 16, DLWP_E_UNSUPPORTED,
-                 "%s: block size %d unsupported (must divide 256, <= 64)", who, a.bs);
-    DLWP_REQUIRE(a.bs * a.bs <= NT, DLWP_E_UNSUPPORTED, "%s: block size %d > 16 not supported yet", who, a.bs);
+    DLWP_REQUIRE(a.bs <= 16, DLWP_E_UNSUPPORTED, "%s: block size %d > 16: use the tiled (batched GEMM) path", who, a.bs);
     DLWP_REQUIRE(H * a.c1 * a.bs <= MAXQ * NT, DLWP_E_UNSUPPORTED,
                  "%s: grid %dx%d with block size %d exceeds the LDS-resident AFNO kernel (tiled FFT path not built yet)",
                  who, H, W, a.bs);
     a.dbs = make_fastdiv(a.bs); a.dc1 = make_fastdiv(a.c1);
+    a.nwm = afno_mixer_waves(H, W, a.bs, a.c1, ((a.r1 - a.r0) * a.c1 + 15) / 16);
+    DLWP_REQUIRE(a.nwm >= 1 && afno_lds_bytes(H, W, a.bs, a.c1, a.nwm) <= AFNO_LDS_LIMIT, DLWP_E_UNSUPPORTED,
+                 "%s: grid %dx%d with block size %d does not fit the LDS-resident AFNO kernel: use the tiled path", who, H, W, a.bs);
     return DLWP_OK;
 }
 
@@ -364,7 +418,7 @@ extern "C" int dlwp_afno2d_fwd(const float* x, const float* w1, const float* b1,
     if (rc) return rc;
     a.x = x; a.y = y; a.xsave = reinterpret_cast<float2*>(xsave); a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
     a.lambda = sparsity_threshold;
-    const size_t lds = afno_lds_bytes(H, W, a.bs, a.c1);
+    const size_t lds = afno_lds_bytes(H, W, a.bs, a.c1, a.nwm);
     if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(afno2d_kernel<false>), lds, "afno2d_fwd"))) return rc;
     hipLaunchKernelGGL(afno2d_kernel<false>, dim3(B * nb), dim3(NT), lds, (hipStream_t)stream, a);
     DLWP_LAUNCH_CHECK();
@@ -383,7 +437,7 @@ extern "C" int dlwp_afno2d_bwd(const float* gy, const float* xsave, const float*
     a.x = gy; a.y = gx; a.xsave = const_cast<float2*>(reinterpret_cast<const float2*>(xsave));
     a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.gw1 = gw1; a.gb1 = gb1; a.gw2 = gw2; a.gb2 = gb2;
     a.lambda = sparsity_threshold;
-    const size_t lds = afno_lds_bytes(H, W, a.bs, a.c1);
+    const size_t lds = afno_lds_bytes(H, W, a.bs, a.c1, a.nwm);
     if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(afno2d_kernel<true>), lds, "afno2d_bwd"))) return rc;
     hipLaunchKernelGGL(afno2d_kernel<true>, dim3(B * nb), dim3(NT), lds, (hipStream_t)stream, a);
     DLWP_LAUNCH_CHECK();
