@@ -21,7 +21,6 @@ namespace {
 constexpr int NT = 1024;   // only B * nb workgroups exist (16 at the nsbench shape): the chain is a sequence of thread-parallel
                            // passes, so the workgroup is as wide as the hardware allows (256 threads: 356, 1024: 470 samples/s
                            // on the nsbench AFNONet step; 16 rows per row-pass step instead of 4: 483)
-constexpr int MAXQ = 10;   // column-pass outputs per thread held in registers
 constexpr int ELD = 36;     // row stride of the 32 x 32 weight images (conflict-free row and column fragment reads)
 constexpr int TLD = 36;     // row stride of the mixer's [16 modes][32] wave tiles
 constexpr int RS = 16;     // image rows staged per row-pass step
@@ -35,99 +34,140 @@ struct AfnoDev {
     int B, H, W, C, nb, bs, r0, r1, c1;
     int nwm;               // waves that run the mixer (each owns 4 wave tiles in the staging region)
     float lambda;
-    FastDiv dbs, dc1;
+    FastDiv dbs, dc1, dW, dH;
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a*conj(b)
 
-// rows: S[h][kw][ch] = scale(kw) * sum_w src[b][h][w][blk ch] * e^{-2 pi i kw w / W}
-__device__ __forceinline__ void row_pass_fwd(const AfnoDev& a, const float* src, int b, int blk, float2* S, float* stage,
+// ---- the four DFT passes as small MFMA products.  S is addressed as floats: Sf[((h c1 + kw) bs + ch) 2 + (re|im)].
+// The transform matrices are never stored: a lane builds its A fragment (row m = r, four consecutive k) from the twiddle
+// tables twW / twH in LDS.  B fragments (k = 4g+q, column ch = r) come straight from the staged rows / the spectrum;
+// padded k read a clamped (finite) element that the zero A entry cancels, padded columns are computed and dropped.
+__device__ __forceinline__ int modn(int x, int n, FastDiv d) { return x - fastdiv(x, d) * n; }
+
+// rows: S[h][kw][ch] = ck(kw) sum_w src[b][h][w][blk ch] e^{-2 pi i kw w / W};  per image row a [2 c1 x W] . [W x bs] product
+__device__ __forceinline__ void row_pass_fwd(const AfnoDev& a, const float* src, int b, int blk, float* Sf, float* stage,
                                              const float2* twW, float s, bool weight_ck) {
     const int tid = threadIdx.x, bs = a.bs, c1 = a.c1, W = a.W;
+    const int lane = tid & 63, wv = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int Mt = (2 * c1 + 15) / 16, Kc = (W + 15) / 16, chc = min(r, bs - 1);
     for (int h0 = 0; h0 < a.H; h0 += RS) {
         const int nr = min(RS, a.H - h0);
         for (int idx = tid; idx < nr * W * bs; idx += NT) {
-            const int ch = idx % bs, rw = idx / bs;           // rw = r*W + w
-            const int r = rw / W, w = rw - r * W;
-            stage[idx] = src[(((long long)b * a.H + h0 + r) * W + w) * a.C + blk * bs + ch];
+            const int rw = fastdiv(idx, a.dbs), ch = idx - rw * bs;       // rw = r*W + w
+            stage[idx] = src[(((long long)b * a.H + h0) * W + rw) * a.C + blk * bs + ch];
         }
         __syncthreads();
-        for (int o = tid; o < nr * c1 * bs; o += NT) {
-            const int ch = fastdiv(o, a.dbs) , t2 = ch;       // o = (r*c1 + kw)*bs + ch
-            const int chn = o - t2 * bs;
-            const int r = fastdiv(t2, a.dc1), kw = t2 - r * c1;
-            float re = 0.f, im = 0.f;
-            int ti = 0;
-            const float* row = stage + (r * W) * bs + chn;
-            for (int w = 0; w < W; ++w) {
-                const float v = row[w * bs];
-                const float2 t = twW[ti];
-                re += v * t.x;
-                im -= v * t.y;                                  // e^{-i theta}
-                ti += kw;
-                if (ti >= W) ti -= W;
+        for (int u = wv; u < nr * Mt; u += NT / 64) {
+            const int hr = u / Mt, mt = u - hr * Mt;
+            const int m = 16 * mt + r, kw = m >> 1, ri = m & 1;            // A row of this lane
+            const float ck = kw >= c1 ? 0.f : ((weight_ck && !(kw == 0 || (W % 2 == 0 && kw == W / 2))) ? 2.f * s : s);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int kc = 0; kc < Kc; ++kc) {
+                f32x4 a4, b4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int w = 16 * kc + 4 * g + q, wc = min(w, W - 1);
+                    const float2 t = twW[modn(kw * wc, W, a.dW)];
+                    a4[q] = w < W ? ck * (ri ? -t.y : t.x) : 0.f;
+                    b4[q] = stage[(hr * W + wc) * bs + chc];
+                }
+                acc = mfma16_chunk(a4, b4, acc);
             }
-            const float ck = (weight_ck && !(kw == 0 || (W % 2 == 0 && kw == W / 2))) ? 2.f * s : s;
-            S[((h0 + r) * c1 + kw) * bs + chn] = make_float2(re * ck, im * ck);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int mo = 16 * mt + 4 * g + j, kwo = mo >> 1;
+                if (kwo < c1 && r < bs) Sf[(((h0 + hr) * c1 + kwo) * bs + r) * 2 + (mo & 1)] = acc[j];
+            }
         }
         __syncthreads();
     }
 }
 
-// columns, in place: S[kh][kw][ch] = sum_h S[h][kw][ch] * e^{-/+ 2 pi i kh h / H}
+// columns, in place: S[kh][kw][ch] = sum_h S[h][kw][ch] e^{-/+ 2 pi i kh h / H};  per kept column kw a real
+// [2H x 2H] . [2H x bs] product; the wave that owns the column reads all of it before writing any of it back
 template <bool INVERSE>
-__device__ __forceinline__ void col_pass(const AfnoDev& a, float2* S, const float2* twH) {
-    const int tid = threadIdx.x, H = a.H, per_row = a.c1 * a.bs, total = H * per_row;
-    float2 acc[MAXQ];
+__device__ __forceinline__ void col_pass(const AfnoDev& a, float* Sf, const float2* twH) {
+    const int tid = threadIdx.x, bs = a.bs, c1 = a.c1, H = a.H;
+    const int lane = tid & 63, wv = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int Mt = (2 * H + 15) / 16, chc = min(r, bs - 1);              // Mt <= 8 (H <= 64)
+    for (int kw = wv; kw < c1; kw += NT / 64) {
+        f32x4 acc[8];
 #pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
-        const int o = tid + q * NT;
-        acc[q] = make_float2(0.f, 0.f);
-        if (o < total) {
-            const int kh = o / per_row, rest = o - kh * per_row;
-            float re = 0.f, im = 0.f;
-            int ti = 0;
-            for (int h = 0; h < H; ++h) {
-                const float2 v = S[h * per_row + rest];
-                float2 t = twH[ti];
-                if (!INVERSE) t.y = -t.y;                       // forward: e^{-i theta}
-                re += v.x * t.x - v.y * t.y;
-                im += v.x * t.y + v.y * t.x;
-                ti += kh;
-                if (ti >= H) ti -= H;
+        for (int mt = 0; mt < 8; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kc = 0; kc < Mt; ++kc) {
+            f32x4 b4;
+            int hq[4], riq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 16 * kc + 4 * g + q;
+                hq[q] = k >> 1; riq[q] = k & 1;
+                b4[q] = Sf[((min(hq[q], H - 1) * c1 + kw) * bs + chc) * 2 + riq[q]];
             }
-            acc[q] = make_float2(re, im);
-        }
-    }
-    __syncthreads();
 #pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
-        const int o = tid + q * NT;
-        if (o < total) S[o] = acc[q];
+            for (int mt = 0; mt < 8; ++mt) {
+                if (mt < Mt) {
+                    const int m = 16 * mt + r, kh = m >> 1, ro = m & 1;
+                    f32x4 a4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float2 t = twH[modn(min(kh, H - 1) * min(hq[q], H - 1), H, a.dH)];
+                        // forward (e^{-i th}): re = a c + b s, im = b c - a s;  inverse (e^{+i th}): re = a c - b s, im = a s + b c
+                        const float sn = INVERSE ? -t.y : t.y;
+                        const float v = ro == 0 ? (riq[q] == 0 ? t.x : sn) : (riq[q] == 0 ? -sn : t.x);
+                        a4[q] = (kh < H && hq[q] < H) ? v : 0.f;
+                    }
+                    acc[mt] = mfma16_chunk(a4, b4, acc[mt]);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            if (mt < Mt) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int mo = 16 * mt + 4 * g + j, kho = mo >> 1;
+                    if (kho < H && r < bs) Sf[((kho * c1 + kw) * bs + r) * 2 + (mo & 1)] = acc[mt][j];
+                }
+            }
+        }
     }
     __syncthreads();
 }
 
-// rows inverse: dst[b][h][w][ch] = res[b][h][w][ch] + s * sum_kw c(kw) Re(S[h][kw][ch] e^{+2 pi i kw w / W})
-__device__ __forceinline__ void row_pass_inv(const AfnoDev& a, float* dst, const float* res, int b, int blk, const float2* S,
+// rows inverse: dst[b][h][w][ch] = res[b][h][w][ch] + s sum_kw c(kw) Re(S[h][kw][ch] e^{+2 pi i kw w / W});  per image row
+// a [W x 2 c1] . [2 c1 x bs] product
+__device__ __forceinline__ void row_pass_inv(const AfnoDev& a, float* dst, const float* res, int b, int blk, const float* Sf,
                                              const float2* twW, float s, bool weight_ck) {
     const int tid = threadIdx.x, bs = a.bs, c1 = a.c1, W = a.W;
-    for (int o = tid; o < a.H * W * bs; o += NT) {
-        const int ch = o % bs, hw = o / bs, h = hw / W, w = hw - h * W;
-        float accv = 0.f;
-        int ti = 0;
-        const float2* sp = S + (h * c1) * bs + ch;
-        for (int kw = 0; kw < c1; ++kw) {
-            const float2 v = sp[kw * bs];
-            const float2 t = twW[ti];
-            const float ck = (weight_ck && !(kw == 0 || (W % 2 == 0 && kw == W / 2))) ? 2.f : 1.f;
-            accv += ck * (v.x * t.x - v.y * t.y);               // Re(v e^{+i theta})
-            ti += w;
-            if (ti >= W) ti -= W;
+    const int lane = tid & 63, wv = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int Mt = (W + 15) / 16, Kc = (2 * c1 + 15) / 16, chc = min(r, bs - 1);
+    for (int u = wv; u < a.H * Mt; u += NT / 64) {
+        const int h = u / Mt, mt = u - h * Mt;
+        const int wr = 16 * mt + r, wrc = min(wr, W - 1);                   // A row of this lane: output column w
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int kc = 0; kc < Kc; ++kc) {
+            f32x4 a4, b4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 16 * kc + 4 * g + q, kw = k >> 1, ri = k & 1, kwc = min(kw, c1 - 1);
+                const float2 t = twW[modn(kwc * wrc, W, a.dW)];
+                const float ck = (weight_ck && !(kw == 0 || (W % 2 == 0 && kw == W / 2))) ? 2.f : 1.f;
+                a4[q] = (kw < c1 && wr < W) ? s * ck * (ri ? -t.y : t.x) : 0.f;     // Re((x + i y)(c + i s)) = x c - y s
+                b4[q] = Sf[((h * c1 + kwc) * bs + chc) * 2 + ri];
+            }
+            acc = mfma16_chunk(a4, b4, acc);
         }
-        const long long g = (((long long)b * a.H + h) * W + w) * a.C + blk * bs + ch;
-        dst[g] = res[g] + s * accv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int wo = 16 * mt + 4 * g + j;
+            if (wo < W && r < bs) {
+                const long long gi = (((long long)b * a.H + h) * W + wo) * a.C + blk * bs + r;
+                dst[gi] = res[gi] + acc[j];
+            }
+        }
     }
 }
 
@@ -174,9 +214,10 @@ __global__ __launch_bounds__(NT) void afno2d_kernel(AfnoDev a) {
 
     // forward transform of x (fwd) / adjoint of the inverse transform applied to gy (bwd)
     DLWP_STAMP(1);
-    row_pass_fwd(a, a.x, b, blk, S, stage, twW, s, BWD);
+    float* Sf = reinterpret_cast<float*>(S);
+    row_pass_fwd(a, a.x, b, blk, Sf, stage, twW, s, BWD);
     DLWP_STAMP(2);
-    col_pass<false>(a, S, twH);
+    col_pass<false>(a, Sf, twH);
     DLWP_STAMP(3);
 
     // ---- per-mode mixer on the kept window, on the matrix cores.  The kept modes are the contiguous rows
@@ -360,10 +401,10 @@ __global__ __launch_bounds__(NT) void afno2d_kernel(AfnoDev a) {
         }
     }
     DLWP_STAMP(5);
-    col_pass<true>(a, S, twH);
+    col_pass<true>(a, Sf, twH);
     DLWP_STAMP(6);
     // inverse rows + residual: fwd = irfft (interior columns doubled); bwd = adjoint of rfft (no doubling)
-    row_pass_inv(a, a.y, a.x, b, blk, S, twW, s, !BWD);
+    row_pass_inv(a, a.y, a.x, b, blk, Sf, twW, s, !BWD);
     DLWP_STAMP(7);
 }
 
@@ -391,10 +432,8 @@ int afno_setup(AfnoDev& a, int B, int H, int W, int C, int nb, float frac, const
     a.c1 = kept < W / 2 + 1 ? kept : W / 2 + 1;
     DLWP_REQUIRE(kept > 0, DLWP_E_INVALID, "%s: hard_thresholding_fraction keeps no mode", who);
     DLWP_REQUIRE(a.bs <= 16, DLWP_E_UNSUPPORTED, "%s: block size %d > 16: use the tiled (batched GEMM) path", who, a.bs);
-    DLWP_REQUIRE(H * a.c1 * a.bs <= MAXQ * NT, DLWP_E_UNSUPPORTED,
-                 "%s: grid %dx%d with block size %d exceeds the LDS-resident AFNO kernel (tiled FFT path not built yet)",
-                 who, H, W, a.bs);
-    a.dbs = make_fastdiv(a.bs); a.dc1 = make_fastdiv(a.c1);
+    DLWP_REQUIRE(H <= 64 && W <= 1024, DLWP_E_UNSUPPORTED, "%s: grid %dx%d: the LDS-resident AFNO kernel takes H <= 64", who, H, W);
+    a.dbs = make_fastdiv(a.bs); a.dc1 = make_fastdiv(a.c1); a.dW = make_fastdiv(W); a.dH = make_fastdiv(H);
     a.nwm = afno_mixer_waves(H, W, a.bs, a.c1, ((a.r1 - a.r0) * a.c1 + 15) / 16);
     DLWP_REQUIRE(a.nwm >= 1 && afno_lds_bytes(H, W, a.bs, a.c1, a.nwm) <= AFNO_LDS_LIMIT, DLWP_E_UNSUPPORTED,
                  "%s: grid %dx%d with block size %d does not fit the LDS-resident AFNO kernel: use the tiled path", who, H, W, a.bs);
