@@ -5,13 +5,13 @@
 // rows [tm-km, tm+km) x cols [0, km) with tm = H//2+1, km = int(tm*frac) (computed from H only,
 // :92-93 — reproduced exactly) -> zeros elsewhere -> softshrink -> irfft2(ortho) -> + x.
 //
-// MI355X design (round 1, grids whose block spectrum fits LDS: 16x16 nsbench, 32x64 dlwpbench):
-// one workgroup per (sample, channel block).  The block's half spectrum [H][c1][bs] stays in LDS for
-// the whole chain  row DFT -> column DFT -> mixer -> inverse column -> inverse row (+residual):
-// x is read once, y is written once, nothing else touches HBM except the kept spectrum saved for the
-// backward pass.  Only the c1 = km columns that survive the mode window are ever computed (pruned
-// DFT); DFTs are direct O(N^2) sums with LDS twiddle tables (N <= 64).  The backward pass reuses the
-// same chain on gy with the adjoint scalings.
+// MI355X design (grids whose block spectrum fits LDS: 16x16 nsbench, 32x64 dlwpbench): one workgroup of 16 waves per
+// (sample, channel block).  The block's half spectrum [H][c1][bs] stays in LDS for the whole chain
+// row DFT -> column DFT -> mixer -> inverse column -> inverse row (+residual): x is read once, y is written once, nothing
+// else touches HBM except the kept spectrum saved for the backward pass.  Only the c1 = km columns that survive the mode
+// window are ever computed (pruned DFT).  Every stage is a small exact-f32 MFMA product: the DFT passes with transform
+// fragments built on the fly from LDS twiddle tables (N <= 64: no stored DFT matrices), the block-diagonal complex MLP on
+// real images of the weights.  The backward pass reuses the same chain on gy with the adjoint scalings.
 #include "common.cuh"
 #include "dlwpmi_internal.h"
 #include <cmath>
