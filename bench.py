@@ -47,6 +47,7 @@ def parse():
 
 
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+PEAK_MFMA_TF = {"fp32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md dense peaks
 
 
 def spatial_fwd_bytes(B, C, H, W, m1, m2c):
@@ -108,6 +109,46 @@ def roofline_probe(device, B, reps=300):
             "us_per_launch": round(sec * 1e6, 3), "traffic": traffic}
 
 
+def mfma_probe(device, B, reps=200):
+    """Second roofline figure (north_star: MFMA utilisation next to the HBM figure): the step's matrix-core kernels are the
+    lifting / projection MLPs (37 % of GPU time).  Times the lifting backward (`pwmlp_bwd_kernel<1,2>`, slab mode as in the
+    step) with HIP events on its launch stream; FLOPs = 2 P Ch (3 Cin + 2 Cout): z, g_a, dW2, dW1, dX products, padding and
+    the in-register transposition not counted."""
+    import torch
+    from dlwp_benchmark_amd import lib as L
+    lib = L.load()
+    w = WORKLOAD
+    Cin, Ch, Cout, P = w["in_channels"] * w["context_size"], w["lifting_channels"], w["hidden_channels"], w["H"] * w["W"]
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, Cin, P, generator=g).to(device)
+    w1 = (torch.randn(Ch, Cin, generator=g) / Cin ** 0.5).to(device)
+    b1 = torch.zeros(Ch, device=device)
+    w2 = (torch.randn(Cout, Ch, generator=g) / Ch ** 0.5).to(device)
+    gy = torch.randn(B, Cout, P, generator=g).to(device)
+    gx = torch.empty_like(x)
+    slab = torch.zeros(lib.dlwp_pwmlp_slab_floats(B, Cin, Ch, Cout, P), device=device)
+    stream = torch.cuda.Stream()
+
+    def launch():
+        L.check(lib.dlwp_pwmlp_bwd_slab(L.ptr(x), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(gy), L.ptr(gx), L.ptr(slab), 1, B, Cin,
+                                        Ch, Cout, P, stream.cuda_stream))
+    with torch.cuda.stream(stream):
+        for _ in range(20):
+            launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(reps):
+            launch()
+        e1.record(stream)
+        torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    flops = 2.0 * B * P * Ch * (3 * Cin + 2 * Cout)
+    return {"bound": "mfma", "kernel": "pwmlp_bwd_kernel<1,2> (lifting MLP backward, slab mode)", "achieved": round(flops / sec / 1e12, 2),
+            "peak": PEAK_MFMA_TF["fp32"], "unit": "TFLOP/s", "frac": round(flops / sec / 1e12 / PEAK_MFMA_TF["fp32"], 4),
+            "flops_per_launch": flops, "us_per_launch": round(sec * 1e6, 3)}
+
+
 def cpu_baseline(B, budget_s):
     """The oracle (CPU restatement of the reference path: neuralop is not installable here, so
     kind="port") timed on the host cores: same workload, same step (fwd + MSE + BPTT + Adam)."""
@@ -142,7 +183,6 @@ SFNO_WORKLOAD = dict(name="dlwpbench SFNO2DModule 32x64 WeatherBench shapes (BAS
                      model=dict(constant_channels=4, prescribed_channels=1, prognostic_channels=5, grid="equiangular", num_layers=4,
                                 scale_factor=1, embed_dim=256, context_size=1, height=32, width=64, big_skip=True, pos_embed=True,
                                 use_mlp=True, normalization_layer="none"), T=5, H=32, W=64)
-PEAK_MFMA_TF = {"fp32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md dense peaks
 
 
 def sfno_gemm_probe(device, B, precision, reps=100):
@@ -365,6 +405,7 @@ def main():
         }
         if world == 1 and not args.no_roofline:
             line["roofline"] = roofline_probe(device, B)
+            line["roofline_mfma"] = mfma_probe(device, B)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(B, args.cpu_seconds)
         print(json.dumps(line), flush=True)
