@@ -19,7 +19,9 @@ namespace {
 constexpr int PT = 64;        // pixels per workgroup
 constexpr int FWD_WAVES = 16; // 4 waves per SIMD: the forward kernel needs 54 VGPRs and its main loop is bound by the dependent
                               // z -> GELU -> second-GEMM chain of a wave, not by the matrix pipe (8 waves: 1993, 16 waves: 2007 samples/s)
-constexpr int BWD_WAVES = 8;
+constexpr int BWD_STREAMS = 1; // hidden blocks in flight per wave of the backward kernel.  2 (with 4 waves, one per SIMD, 352 VGPRs)
+                               // was measured: 1884 samples/s against 2020 for 8 waves x 1 stream (plain 4 waves: 1858)
+constexpr int BWD_WAVES = BWD_STREAMS == 2 ? 4 : 8;
 constexpr int LDP = PT + 4;   // LDS row stride of pixel tiles (4*LDP % 32 == 16: conflict-free B reads)
 
 __device__ __forceinline__ const float* chan_ptr(const dlwp_chan_src& s, int b, int c) {
@@ -325,119 +327,113 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
     // the accumulator of z^T / gz^T is then directly the B operand of the pixel contractions (dW2) and, read as an
     // A operand, the hidden-major matrix for dW1; the one product that contracts over the hidden index (dX) gets
     // its operand through a 4-MFMA multiplication with the identity instead of an LDS round trip.
-    // Two waves share each SIMD's matrix pipe and the older one (waves 0-3) wins the arbitration on every instruction: in-kernel
-    // stamps showed waves 0-3 leaving this loop after 20 k cycles and waves 4-7 after 29 k, with the barrier behind it waiting for
-    // the slowest.  The younger half therefore runs the FIRST half of its hidden blocks at raised priority (priority outranks
-    // age) and the second half at the default, so that both halves arrive together.
-    const int hb_half = w + NW * (((nhb - w + NW - 1) / NW) / 2);     // first hidden block of this wave's second half
-    if (w >= NW / 2) __builtin_amdgcn_s_setprio(1);
-    for (int hb = w; hb < nhb; hb += NW) {
-        if (w >= NW / 2 && hb == hb_half) __builtin_amdgcn_s_setprio(0);
+    // One hidden block's state while its four pixel blocks are processed.
+    struct HbState {
         f32x4 w1b[NIB];        // B operand of z^T: W1[h = r][i = 4g+s]
+        float b1v;
+        f32x4 pgw2[NOB], pgw1[NIB];   // running slab partials (read-modify-write accumulation across net calls)
+        float pgb1;
+        f32x4 gw2acc[NOB], gw1acc[NIB];
+        float gb1acc;
+        float *t2, *t1;
+        int hb;
+    };
+    auto hb_begin = [&](HbState& st, int hb) {
+        st.hb = hb;
 #pragma unroll
         for (int kc = 0; kc < NIB; ++kc)
-            w1b[kc] = *reinterpret_cast<const f32x4*>(&w1s[(hb * 16 + r) * LD1 + kc * 16 + 4 * g]);
-        const float b1v = b1s[hb * 16 + r];
-        // prefetch this workgroup's running slab partials (read-modify-write accumulation across net calls).
+            st.w1b[kc] = *reinterpret_cast<const f32x4*>(&w1s[(hb * 16 + r) * LD1 + kc * 16 + 4 * g]);
+        st.b1v = b1s[hb * 16 + r];
         // The slab is private scratch, so it is laid out in ACCUMULATOR-TILE order: tile (hb, ob) holds the 4
         // registers of every lane contiguously -> one 16-byte access per lane, 1 KiB per wave-instruction
-        // (narrow 64-byte-segment stores were issue-bound: ~350 cycles each).
-        f32x4 pgw2[NOB], pgw1[NIB];
-        float pgb1 = 0.f;
-        float* t2 = sl ? sl + ((long long)hb * NOB * 64 + lane) * 4 : nullptr;
-        float* t1 = sl ? sl + o_t1 + ((long long)hb * NIB * 64 + lane) * 4 : nullptr;
+        // (narrow 64-byte-segment stores were issue-bound: ~350 cycles each).  The old values are fetched here.
+        st.pgb1 = 0.f;
+        st.t2 = sl ? sl + ((long long)hb * NOB * 64 + lane) * 4 : nullptr;
+        st.t1 = sl ? sl + o_t1 + ((long long)hb * NIB * 64 + lane) * 4 : nullptr;
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob)
-            pgw2[ob] = accum ? *reinterpret_cast<const f32x4*>(t2 + ob * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+            st.pgw2[ob] = accum ? *reinterpret_cast<const f32x4*>(st.t2 + ob * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ib = 0; ib < NIB; ++ib)
-            pgw1[ib] = accum ? *reinterpret_cast<const f32x4*>(t1 + ib * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (accum && g == 0) pgb1 = sl[o_gb1 + hb * 16 + r];
-
-        f32x4 gw2acc[NOB], gw1acc[NIB];
-        float gb1acc = 0.f;
+            st.pgw1[ib] = accum ? *reinterpret_cast<const f32x4*>(st.t1 + ib * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (accum && g == 0) st.pgb1 = sl[o_gb1 + hb * 16 + r];
+        st.gb1acc = 0.f;
 #pragma unroll
-        for (int ob = 0; ob < NOB; ++ob) gw2acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ob = 0; ob < NOB; ++ob) st.gw2acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ib = 0; ib < NIB; ++ib) gw1acc[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-
+        for (int ib = 0; ib < NIB; ++ib) st.gw1acc[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto hb_step = [&](HbState& st, int pb) {
+        const int hb = st.hb;
+        // z^T[p][h] = sum_i x[i][p] W1[h][i]
+        f32x4 zt = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int pb = 0; pb < 4; ++pb) {
-            if (hb == w && pb == 0) DLWP_STAMP(12);
-            // z^T[p][h] = sum_i x[i][p] W1[h][i]
-            f32x4 zt = {0.f, 0.f, 0.f, 0.f};
+        for (int kc = 0; kc < NIB; ++kc) {
+            f32x4 a4;
 #pragma unroll
-            for (int kc = 0; kc < NIB; ++kc) {
-                f32x4 a4;
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) a4[s2] = xs[(kc * 16 + 4 * g + s2) * LDP + pb * 16 + r];
-                zt = mfma16_chunk(a4, w1b[kc], zt);
-            }
-            if (hb == w && pb == 0) DLWP_STAMP(13);
-            // g_a^T[p][h] = sum_o gy[o][p] W2[o][h]
-            f32x4 gat = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int oc = 0; oc < NOB; ++oc) {
-                f32x4 a4, b4;
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) {
-                    a4[s2] = gys[(oc * 16 + 4 * g + s2) * LDP + pb * 16 + r];
-                    b4[s2] = w2s[(oc * 16 + 4 * g + s2) * LD2 + hb * 16 + r];
-                }
-                gat = mfma16_chunk(a4, b4, gat);
-            }
-            if (hb == w && pb == 0) DLWP_STAMP(14);
-            f32x4 actt, gzt;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float av, dv;
-                gelu_both(zt[j] + b1v, av, dv);
-                actt[j] = av;
-                gzt[j] = gat[j] * dv;
-                gb1acc += gzt[j];
-            }
-            if (hb == w && pb == 0) DLWP_STAMP(15);
-            // dW2[o][h] += sum_p gy[o][p] act^T[p][h]
-#pragma unroll
-            for (int ob = 0; ob < NOB; ++ob) {
-                const f32x4 a4 = *reinterpret_cast<const f32x4*>(&gys[(ob * 16 + r) * LDP + pb * 16 + 4 * g]);
-                gw2acc[ob] = mfma16_chunk(a4, actt, gw2acc[ob]);
-            }
-            // dW1[h][i] += sum_p gz[h][p] x[i][p]   (gz^T registers read as an A operand are gz)
-#pragma unroll
-            for (int ib = 0; ib < NIB; ++ib) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(&xs[(ib * 16 + r) * LDP + pb * 16 + 4 * g]);
-                gw1acc[ib] = mfma16_chunk(gzt, b4, gw1acc[ib]);
-            }
-            if (hb == w && pb == 0) DLWP_STAMP(16);
-            // gz[h][p] in accumulator layout = gz^T (as A operand) x identity
-            const f32x4 gz = mfma16_chunk(gzt, ident, f32x4{0.f, 0.f, 0.f, 0.f});
-            // dX[i][p] += sum_h W1[h][i] gz[h][p]
-#pragma unroll
-            for (int ib = 0; ib < NIB; ++ib) {
-                f32x4 a4;
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) a4[s2] = w1s[(hb * 16 + 4 * g + s2) * LD1 + ib * 16 + r];
-                gxacc[pb][ib] = mfma16_chunk(a4, gz, gxacc[pb][ib]);
-            }
-            if (hb == w && pb == 0) DLWP_STAMP(17);
+            for (int s2 = 0; s2 < 4; ++s2) a4[s2] = xs[(kc * 16 + 4 * g + s2) * LDP + pb * 16 + r];
+            zt = mfma16_chunk(a4, st.w1b[kc], zt);
         }
-        if (hb == w) DLWP_STAMP(18);
-        // flush this hidden block's parameter gradients
+        // g_a^T[p][h] = sum_o gy[o][p] W2[o][h]
+        f32x4 gat = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int oc = 0; oc < NOB; ++oc) {
+            f32x4 a4, b4;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                a4[s2] = gys[(oc * 16 + 4 * g + s2) * LDP + pb * 16 + r];
+                b4[s2] = w2s[(oc * 16 + 4 * g + s2) * LD2 + hb * 16 + r];
+            }
+            gat = mfma16_chunk(a4, b4, gat);
+        }
+        f32x4 actt, gzt;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float av, dv;
+            gelu_both(zt[j] + st.b1v, av, dv);
+            actt[j] = av;
+            gzt[j] = gat[j] * dv;
+            st.gb1acc += gzt[j];
+        }
+        // dW2[o][h] += sum_p gy[o][p] act^T[p][h]
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&gys[(ob * 16 + r) * LDP + pb * 16 + 4 * g]);
+            st.gw2acc[ob] = mfma16_chunk(a4, actt, st.gw2acc[ob]);
+        }
+        // dW1[h][i] += sum_p gz[h][p] x[i][p]   (gz^T registers read as an A operand are gz)
+#pragma unroll
+        for (int ib = 0; ib < NIB; ++ib) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(&xs[(ib * 16 + r) * LDP + pb * 16 + 4 * g]);
+            st.gw1acc[ib] = mfma16_chunk(gzt, b4, st.gw1acc[ib]);
+        }
+        // gz[h][p] in accumulator layout = gz^T (as A operand) x identity
+        const f32x4 gz = mfma16_chunk(gzt, ident, f32x4{0.f, 0.f, 0.f, 0.f});
+        // dX[i][p] += sum_h W1[h][i] gz[h][p]
+#pragma unroll
+        for (int ib = 0; ib < NIB; ++ib) {
+            f32x4 a4;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) a4[s2] = w1s[(hb * 16 + 4 * g + s2) * LD1 + ib * 16 + r];
+            gxacc[pb][ib] = mfma16_chunk(a4, gz, gxacc[pb][ib]);
+        }
+    };
+    auto hb_flush = [&](HbState& st) {
+        const int hb = st.hb;
         if (sl) {
 #pragma unroll
             for (int ob = 0; ob < NOB; ++ob) {
-                f32x4 v = gw2acc[ob];
+                f32x4 v = st.gw2acc[ob];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] += pgw2[ob][j];
-                *reinterpret_cast<f32x4*>(t2 + ob * 256) = v;
+                for (int j = 0; j < 4; ++j) v[j] += st.pgw2[ob][j];
+                *reinterpret_cast<f32x4*>(st.t2 + ob * 256) = v;
             }
 #pragma unroll
             for (int ib = 0; ib < NIB; ++ib) {
-                f32x4 v = gw1acc[ib];
+                f32x4 v = st.gw1acc[ib];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] += pgw1[ib][j];
-                *reinterpret_cast<f32x4*>(t1 + ib * 256) = v;
+                for (int j = 0; j < 4; ++j) v[j] += st.pgw1[ib][j];
+                *reinterpret_cast<f32x4*>(st.t1 + ib * 256) = v;
             }
         } else {
             const int hcol = hb * 16 + r;
@@ -446,29 +442,59 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int o = ob * 16 + 4 * g + j;
-                    if (o < a.Cout && hcol < a.Ch) atomic_add_f32(a.gw2 + o * a.Ch + hcol, gw2acc[ob][j]);
+                    if (o < a.Cout && hcol < a.Ch) atomic_add_f32(a.gw2 + o * a.Ch + hcol, st.gw2acc[ob][j]);
                 }
 #pragma unroll
             for (int ib = 0; ib < NIB; ++ib)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int h = hb * 16 + 4 * g + j, i = ib * 16 + r;
-                    if (h < a.Ch && i < a.Cin) atomic_add_f32(a.gw1 + h * a.Cin + i, gw1acc[ib][j]);
+                    if (h < a.Ch && i < a.Cin) atomic_add_f32(a.gw1 + h * a.Cin + i, st.gw1acc[ib][j]);
                 }
         }
-        {
-            float v = gb1acc;                       // bias gradient of hidden channel hb*16 + r: sum the 4 lane groups
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            const int h = hb * 16 + r;
-            if (g == 0) {
-                if (sl) sl[o_gb1 + h] = pgb1 + v;
-                else if (h < a.Ch) atomic_add_f32(a.gb1 + h, v);
-            }
+        float v = st.gb1acc;                       // bias gradient of hidden channel hb*16 + r: sum the 4 lane groups
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        const int h = hb * 16 + r;
+        if (g == 0) {
+            if (sl) sl[o_gb1 + h] = st.pgb1 + v;
+            else if (h < a.Ch) atomic_add_f32(a.gb1 + h, v);
         }
-        if (hb == w) DLWP_STAMP(19);
+    };
+    if constexpr (BWD_STREAMS == 2) {
+        // one wave per SIMD, two hidden blocks in flight per wave: the pixel blocks of both are interleaved in program order,
+        // so that one block's GELU / dependent MFMA chains fill the other's gaps (no reliance on SIMD arbitration)
+        for (int hb = w; hb < nhb; hb += 2 * NW) {
+            HbState sa, sb;
+            const bool two = hb + NW < nhb;
+            hb_begin(sa, hb);
+            if (two) hb_begin(sb, hb + NW);
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                hb_step(sa, pb);
+                if (two) hb_step(sb, pb);
+            }
+            hb_flush(sa);
+            if (two) hb_flush(sb);
+        }
+    } else {
+        // Two waves share each SIMD's matrix pipe; in-kernel stamps showed waves 0-3 leaving this loop after 20 k cycles and
+        // waves 4-7 after 29 k, with the barrier behind it waiting for the slowest.  The younger half runs the FIRST half of
+        // its hidden blocks at raised priority and the second half at the default (moves the skew by < 2 k cycles).
+        const int hb_half = w + NW * (((nhb - w + NW - 1) / NW) / 2);     // first hidden block of this wave's second half
+        if (w >= NW / 2) __builtin_amdgcn_s_setprio(1);
+        for (int hb = w; hb < nhb; hb += NW) {
+            if (w >= NW / 2 && hb == hb_half) __builtin_amdgcn_s_setprio(0);
+            HbState st;
+            hb_begin(st, hb);
+            if (hb == w) DLWP_STAMP(12);
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) hb_step(st, pb);
+            if (hb == w) DLWP_STAMP(18);
+            hb_flush(st);
+            if (hb == w) DLWP_STAMP(19);
+        }
     }
-
     __builtin_amdgcn_s_setprio(0);
     DLWP_STAMP(20);
     DLWP_STAMP_WAVE(24);      // end of every wave's main loop (slots 24..31)
