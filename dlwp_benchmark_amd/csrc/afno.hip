@@ -54,9 +54,29 @@ __device__ __forceinline__ void row_pass_fwd(const AfnoDev& a, const float* src,
     const int Mt = (2 * c1 + 15) / 16, Kc = (W + 15) / 16, chc = min(r, bs - 1);
     for (int h0 = 0; h0 < a.H; h0 += RS) {
         const int nr = min(RS, a.H - h0);
-        for (int idx = tid; idx < nr * W * bs; idx += NT) {
-            const int rw = fastdiv(idx, a.dbs), ch = idx - rw * bs;       // rw = r*W + w
-            stage[idx] = src[(((long long)b * a.H + h0) * W + rw) * a.C + blk * bs + ch];
+        if ((bs & 3) == 0 && (a.C & 3) == 0) {
+            // 16-byte loads, all of a thread's loads in flight before the first LDS store (a load -> store loop pays one
+            // global latency per iteration)
+            const int bs4 = bs >> 2, n4 = nr * W * bs4;
+            float4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i4 = min(tid + q * NT, n4 - 1), rw = i4 / bs4, c4 = i4 - rw * bs4;
+                v[q] = *reinterpret_cast<const float4*>(&src[(((long long)b * a.H + h0) * W + rw) * a.C + blk * bs + 4 * c4]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (tid + q * NT < n4) *reinterpret_cast<float4*>(&stage[4 * (tid + q * NT)]) = v[q];
+            for (int i4 = tid + 4 * NT; i4 < n4; i4 += NT) {
+                const int rw = i4 / bs4, c4 = i4 - rw * bs4;
+                *reinterpret_cast<float4*>(&stage[4 * i4]) =
+                    *reinterpret_cast<const float4*>(&src[(((long long)b * a.H + h0) * W + rw) * a.C + blk * bs + 4 * c4]);
+            }
+        } else {
+            for (int idx = tid; idx < nr * W * bs; idx += NT) {
+                const int rw = fastdiv(idx, a.dbs), ch = idx - rw * bs;       // rw = r*W + w
+                stage[idx] = src[(((long long)b * a.H + h0) * W + rw) * a.C + blk * bs + ch];
+            }
         }
         __syncthreads();
         for (int u = wv; u < nr * Mt; u += NT / 64) {
@@ -292,14 +312,19 @@ __global__ __launch_bounds__(NT) void afno2d_kernel(AfnoDev a) {
             {
                 const float* src = BWD ? xs_base : Srow0;
                 __builtin_amdgcn_wave_barrier();
-                for (int e = lane; e < 16 * 32; e += 64) {
-                    const int mr = e >> 5, k = e & 31;
-                    float v = 0.f;
-                    if (m0 + mr < nmodes && k < K2) {
-                        v = src[(long long)(m0 + mr) * K2 + k];
-                        if (!BWD) xs_base[(long long)(m0 + mr) * K2 + k] = v;
-                    }
-                    Xt[mr * TLD + k] = v;
+                float xv[8];          // all eight loads in flight first (the backward source is global memory)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int e = lane + 64 * q, mr = e >> 5, k = e & 31;
+                    const bool ok = m0 + mr < nmodes && k < K2;
+                    const float v = src[ok ? (long long)(m0 + mr) * K2 + k : 0];
+                    xv[q] = ok ? v : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int e = lane + 64 * q, mr = e >> 5, k = e & 31;
+                    if (!BWD && m0 + mr < nmodes && k < K2) xs_base[(long long)(m0 + mr) * K2 + k] = xv[q];
+                    Xt[mr * TLD + k] = xv[q];
                 }
                 __builtin_amdgcn_wave_barrier();
             }
