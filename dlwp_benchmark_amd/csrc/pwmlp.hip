@@ -8,8 +8,12 @@
 // (Ch x 64) never leave registers: the accumulator of GEMM1 (rows = hidden channel 4g+j,
 // col = pixel) is directly the B operand of GEMM2 when the A operand (W2) is read with the
 // matching permuted-k order (common.cuh: mfma16_chunk).  Backward recomputes the hidden
-// layer, keeps weight-gradient partials in registers over the 64 pixels and flushes them
-// with one hardware float atomic per element per workgroup.
+// layer, keeps weight-gradient partials in registers over the 64 pixels and leaves them in a
+// per-workgroup slab in accumulator-tile order (plain 16-byte stores; one slab-parallel launch
+// folds every slab of a training step, fold_slabs_kernel below); without a slab they go out as
+// hardware float atomics (API path).  The forward kernel can append the W-axis DFT of its output
+// rows (lifting -> first spectral block), the backward kernel the adjoint DFT of its input
+// gradient rows (projection backward -> last spectral block's backward).
 #include "common.cuh"
 #include "dlwpmi_internal.h"
 #include "fno_rows.cuh"
