@@ -74,3 +74,52 @@ def test_sharding_is_a_partition_with_equal_iteration_counts():
     assert ddp.crop_start(17, 2, 50, 20) == ddp.crop_start(17, 2, 50, 20)
     a = ddp.epoch_permutation(10, 1)
     assert sorted(a.tolist()) == list(range(10)) and not np.array_equal(a, ddp.epoch_permutation(10, 2))
+
+
+# ---- dlwp half: WeatherBench batches sharded over two ranks, gradients reduced over gloo -------------------------------------
+def _dlwp_grad(items):
+    """Flat gradient of a one-step MSE (residual + 1x1 convolution stand-in model, plain torch on the CPU) on dataset items."""
+    from dlwp_benchmark_amd import wbdata
+    fields, prog, presc, const = wbdata.synthetic_fields(40, 8, 16, prognostic={"t2m": [], "z": [500]}, seed=9)
+    ds = wbdata.WeatherBenchArrays(fields, prog, presc, const, sequence_length=2, normalize=True, context_size=1, noise=0.1,
+                                   seed=77)
+    c, p, g, t = wbdata.to_device_batch([ds[int(i)] for i in items], "cpu")
+    gen = torch.Generator().manual_seed(5)
+    w = (torch.randn(2, 4 + 1 + 2, generator=gen) * 0.3).requires_grad_(True)      # a stand-in linear "model": 1x1 conv
+    x = torch.cat([c[:, 0].expand(len(items), -1, -1, -1), p[:, 0], g[:, 0]], dim=1)          # [B, 7, H, W]
+    out = g[:, 0] + torch.einsum("oc,bchw->bohw", w, x)
+    loss = torch.nn.functional.mse_loss(out.unsqueeze(1), t)
+    loss.backward()
+    return w.grad.reshape(-1).clone(), ds
+
+
+def _dlwp_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from dlwp_benchmark_amd import wbdata
+    _, ds = _dlwp_grad([0])
+    shard = wbdata.shard_batches(ds, epoch=1, rank=rank, world=world, batch=3)
+    g, _ = _dlwp_grad(shard[0])
+    scale = ddp.FlatGradAllReduce()(g)
+    if rank == 0:
+        torch.save({"grad": g * scale, "shard": shard}, out)
+    dist.destroy_process_group()
+
+
+def test_dlwp_batches_two_ranks_equal_one_rank(tmp_path):
+    """wbdata sharding + per-item seeded noise + flat all-reduce: 2 ranks x 3 samples == 1 rank x the same 6 samples."""
+    from dlwp_benchmark_amd import wbdata
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_dlwp_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=False)
+    _, ds = _dlwp_grad([0])
+    shards = [wbdata.shard_batches(ds, 1, r, 2, 3) for r in range(2)]
+    assert np.array_equal(got["shard"], shards[0])
+    ref, _ = _dlwp_grad(np.concatenate([shards[0][0], shards[1][0]]))
+    err = (got["grad"] - ref).abs().max() / ref.abs().max()
+    assert err < 1e-5, err
