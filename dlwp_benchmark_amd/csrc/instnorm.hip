@@ -1,0 +1,145 @@
+// Instance normalisation of channels-last token fields: per (sample, channel) statistics over the H*W tokens.
+// Reference call site: torch_harmonics' SphericalFourierNeuralOperatorNet(normalization_layer="instance_norm")
+// -> nn.InstanceNorm2d(embed_dim, eps=1e-6, affine=True, track_running_stats=False) around every block
+// (third-party arithmetic), selected by the shipped src/dlwpbench/configs/model/fourcastnetv2.yaml:23
+// and constructed at src/dlwpbench/models/fourcastnet/fourcastnet.py:411-428.
+//
+// Layout x [B][P][C] (C contiguous): lanes run along the channels (coalesced 256-byte rows), waves along the tokens.
+// Statistics are column sums over P, so they are split over many workgroups (grid.z) and combined with float atomics
+// into a [B][C][2] table; the streaming apply kernels read that table.  HBM-bound: x is read twice, y written once.
+#include "common.cuh"
+#include "dlwpmi_internal.h"
+
+namespace {
+
+constexpr int ROWS_PER_WG = 128;
+
+// MODE 0: sums of (x - K) and (x - K)^2 with the shift K = x[b][0][c] (no cancellation for |mean| >> std)
+// MODE 1: sums of g and g * xhat (xhat from the saved mean / rstd)
+template <int MODE>
+__global__ __launch_bounds__(256) void instnorm_sums_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                            const float* __restrict__ stats, float* sums, int P, int C) {
+    __shared__ float red[2][4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, b = blockIdx.y;
+    const int p0 = blockIdx.z * ROWS_PER_WG, p1 = min(P, p0 + ROWS_PER_WG);
+    const bool ok = c < C;
+    const int cc = ok ? c : C - 1;
+    const float* xb = x + (long long)b * P * C + cc;
+    float k = 0.f, rs = 0.f;
+    if (MODE == 0) k = xb[0];
+    else { k = stats[((long long)b * C + cc) * 2]; rs = stats[((long long)b * C + cc) * 2 + 1]; }
+    const float* gb = MODE == 1 ? g + (long long)b * P * C + cc : nullptr;
+    float s1 = 0.f, s2 = 0.f;
+    for (int p = p0 + w; p < p1; p += 16) {          // 4 rows in flight per wave
+        float xv[4], gv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pp = min(p + 4 * q, p1 - 1);
+            xv[q] = xb[(long long)pp * C];
+            gv[q] = MODE == 1 ? gb[(long long)pp * C] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (p + 4 * q < p1) {
+                if (MODE == 0) { const float d = xv[q] - k; s1 += d; s2 += d * d; }
+                else { s1 += gv[q]; s2 += gv[q] * (xv[q] - k) * rs; }
+            }
+    }
+    red[0][w][lane] = s1;
+    red[1][w][lane] = s2;
+    __syncthreads();
+    if (w == 0 && ok) {
+        const float a = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+        const float q2 = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+        atomic_add_f32(&sums[((long long)b * C + c) * 2], a);
+        atomic_add_f32(&sums[((long long)b * C + c) * 2 + 1], q2);
+    }
+}
+
+// (sum (x-K), sum (x-K)^2) -> (mean, rstd), in place
+__global__ __launch_bounds__(256) void instnorm_finish_kernel(const float* __restrict__ x, float* stats, int B, int P, int C,
+                                                              float eps) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C;
+    const float k = x[(long long)b * P * C + c];
+    const float m1 = stats[2 * i] / P, m2 = stats[2 * i + 1] / P;
+    const float var = fmaxf(m2 - m1 * m1, 0.f);       // biased variance, as nn.InstanceNorm2d
+    stats[2 * i] = k + m1;
+    stats[2 * i + 1] = rsqrtf(var + eps);
+}
+
+// y = (x - mean) rstd gamma + beta (+ residual)
+__global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ res,
+                                                             const float* __restrict__ stats, float* __restrict__ y, int P, int C) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, b = blockIdx.y;
+    if (c >= C) return;
+    const float mu = stats[((long long)b * C + c) * 2], rs = stats[((long long)b * C + c) * 2 + 1];
+    const float a = rs * gamma[c], sh = beta[c] - mu * a;
+    const int p0 = blockIdx.z * ROWS_PER_WG, p1 = min(P, p0 + ROWS_PER_WG);
+    for (int p = p0 + w; p < p1; p += 4) {
+        const long long o = ((long long)b * P + p) * C + c;
+        float v = fmaf(x[o], a, sh);
+        if (res) v += res[o];
+        y[o] = v;
+    }
+}
+
+// gx = rstd gamma (g - S1/P - xhat S2/P); the z == 0 workgroups add the parameter gradients
+__global__ __launch_bounds__(256) void instnorm_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ stats, const float* __restrict__ g,
+                                                                 const float* __restrict__ sums, float* __restrict__ gx,
+                                                                 float* ggamma, float* gbeta, int P, int C) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, b = blockIdx.y;
+    if (c >= C) return;
+    const long long bc = (long long)b * C + c;
+    const float mu = stats[2 * bc], rs = stats[2 * bc + 1];
+    const float s1 = sums[2 * bc], s2 = sums[2 * bc + 1];
+    const float a = rs * gamma[c], m1 = s1 / P, m2 = s2 / P;
+    const int p0 = blockIdx.z * ROWS_PER_WG, p1 = min(P, p0 + ROWS_PER_WG);
+    for (int p = p0 + w; p < p1; p += 4) {
+        const long long o = ((long long)b * P + p) * C + c;
+        const float xh = (x[o] - mu) * rs;
+        gx[o] = a * (g[o] - m1 - xh * m2);
+    }
+    if (blockIdx.z == 0 && w == 0) {
+        atomic_add_f32(&ggamma[c], s2);
+        atomic_add_f32(&gbeta[c], s1);
+    }
+}
+
+}  // namespace
+
+extern "C" int dlwp_instnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                                 float* stats, int B, int P, int C, float eps, void* stream_) {
+    DLWP_REQUIRE(x && gamma && beta && y && stats && B > 0 && P > 0 && C > 0, DLWP_E_INVALID, "instnorm_fwd: bad argument");
+    DLWP_REQUIRE(B <= 65535, DLWP_E_UNSUPPORTED, "instnorm_fwd: at most 65535 samples");
+    hipStream_t s = (hipStream_t)stream_;
+    int rc = dlwp_zero_f32(stats, (long long)B * C * 2, stream_);
+    if (rc) return rc;
+    const dim3 grid(ceil_div(C, 64), B, ceil_div(P, ROWS_PER_WG));
+    hipLaunchKernelGGL(instnorm_sums_kernel<0>, grid, dim3(256), 0, s, x, (const float*)nullptr, (const float*)nullptr, stats, P, C);
+    hipLaunchKernelGGL(instnorm_finish_kernel, dim3(ceil_div(B * C, 256)), dim3(256), 0, s, x, stats, B, P, C, eps);
+    hipLaunchKernelGGL(instnorm_apply_kernel, grid, dim3(256), 0, s, x, gamma, beta, residual, stats, y, P, C);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_instnorm_bwd(const float* x, const float* gamma, const float* stats, const float* gy, float* gx,
+                                 float* ggamma, float* gbeta, float* work, int B, int P, int C, void* stream_) {
+    DLWP_REQUIRE(x && gamma && stats && gy && gx && ggamma && gbeta && work && B > 0 && P > 0 && C > 0, DLWP_E_INVALID,
+                 "instnorm_bwd: bad argument");
+    DLWP_REQUIRE(B <= 65535, DLWP_E_UNSUPPORTED, "instnorm_bwd: at most 65535 samples");
+    hipStream_t s = (hipStream_t)stream_;
+    int rc = dlwp_zero_f32(work, (long long)B * C * 2, stream_);
+    if (rc) return rc;
+    const dim3 grid(ceil_div(C, 64), B, ceil_div(P, ROWS_PER_WG));
+    hipLaunchKernelGGL(instnorm_sums_kernel<1>, grid, dim3(256), 0, s, x, gy, stats, work, P, C);
+    hipLaunchKernelGGL(instnorm_bwd_apply_kernel, grid, dim3(256), 0, s, x, gamma, stats, gy, work, gx, ggamma, gbeta, P, C);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}

@@ -4,6 +4,7 @@
 // All of these are HBM-bound streaming kernels: 16 B per lane, grid-stride, <= 2048 blocks.
 #include "common.cuh"
 #include "dlwpmi_internal.h"
+#include <algorithm>
 #include <string>
 #include <mutex>
 #include <unordered_map>
@@ -253,6 +254,48 @@ int dlwp_zero_2d_f32(float* p, long long ld, int rows, int cols, void* stream) {
     if (n <= 0) return DLWP_OK;
     hipLaunchKernelGGL(zero_2d_kernel, dim3((int)std::min<long long>((n + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream, p, ld,
                        rows, cols);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+namespace {
+// out[b][i] = (x ? x[b][i] : 0) + s[b] * t[b][i]; one sample's row is n floats (n % 4 == 0: 16-byte accesses)
+__global__ __launch_bounds__(256) void scale_rows_add_kernel(const float* __restrict__ t, const float* __restrict__ s,
+                                                             const float* __restrict__ x, float* __restrict__ out,
+                                                             long long n4, int vec) {
+    const int b = blockIdx.y;
+    const float sc = s[b];
+    const long long stride = (long long)gridDim.x * 256;
+    if (vec) {
+        const float4* t4 = reinterpret_cast<const float4*>(t) + (long long)b * n4;
+        const float4* x4 = x ? reinterpret_cast<const float4*>(x) + (long long)b * n4 : nullptr;
+        float4* o4 = reinterpret_cast<float4*>(out) + (long long)b * n4;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+            float4 v = t4[i];
+            float4 r = x4 ? x4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            r.x = fmaf(sc, v.x, r.x); r.y = fmaf(sc, v.y, r.y); r.z = fmaf(sc, v.z, r.z); r.w = fmaf(sc, v.w, r.w);
+            o4[i] = r;
+        }
+    } else {      // n4 = n here
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+            const long long o = (long long)b * n4 + i;
+            out[o] = fmaf(sc, t[o], x ? x[o] : 0.f);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int dlwp_scale_rows_add(const float* t, const float* scale, const float* x, float* out, int B, long long n,
+                                   void* stream) {
+    DLWP_REQUIRE(t && scale && out && B > 0 && n > 0, DLWP_E_INVALID, "scale_rows_add: bad argument");
+    DLWP_REQUIRE(B <= 65535, DLWP_E_UNSUPPORTED, "scale_rows_add: at most 65535 rows (got %d)", B);
+    const bool vec = n % 4 == 0 && ((uintptr_t)t % 16 == 0) && ((uintptr_t)out % 16 == 0) && (!x || (uintptr_t)x % 16 == 0);
+    const long long units = vec ? n / 4 : n;
+    long long bx = (units + 255) / 256;
+    const long long cap = std::max<long long>(1, 2048 / B);
+    if (bx > cap) bx = cap;
+    hipLaunchKernelGGL(scale_rows_add_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, t, scale, x,
+                       out, units, vec ? 1 : 0);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }

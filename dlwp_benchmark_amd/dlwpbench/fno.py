@@ -37,7 +37,7 @@ class FNO2DModule(_FnoRolloutModule):
                            constant_channels=self.constant_channels, prescribed_channels=self.prescribed_channels)
             tr = FnoRolloutTrainer(cfg, self.flat_params.data, self._ensure_grad(), self.flat_params.device)
             self._trainers[key] = tr
-        return tr
+        return self._bind(tr)
 
     def _load(self, tr, constants, prescribed, prognostic):
         tr.x.copy_(prognostic)
@@ -115,10 +115,18 @@ class TFNO2DModule(FNO2DModule):
                 self.layout.view(self.flat_params.data, name).copy_(d)
         return dense
 
+    def _derived_names(self):
+        return self._spec_names()
+
     def forward(self, constants=None, prescribed=None, prognostic=None):
-        if torch.is_grad_enabled():
-            raise NotImplementedError("TFNO2DModule trains through train_step(); call forward under torch.no_grad()")
-        self._refresh_dense()
+        dense = self._refresh_dense()
+        if torch.is_grad_enabled() and self.flat_params.requires_grad:
+            # autograd path (train_engine.GraphedTrainStep, train_loop.train_dlwp): the BPTT kernels leave the gradient of
+            # the dense weights in the flat gradient buffer; _RolloutFn hands it to the mode-product graph of the factors
+            B, T, _, H, W = prognostic.shape
+            tr = self.trainer(B, T, H, W)
+            self._load(tr, constants, prescribed, prognostic)
+            return _RolloutFn.apply(self.flat_params, self, tr, *dense)
         return super().forward(constants, prescribed, prognostic)
 
     def make_optimizer(self, lr=1e-3):

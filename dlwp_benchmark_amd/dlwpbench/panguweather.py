@@ -18,24 +18,9 @@ import torch.nn.functional as F
 
 from ..nsbench.swin_transformer import window_attention_core
 from ..window_ops import WindowSpec, partition, reverse
-from ..token_ops import LayerNorm, Linear, Mlp, PatchConv2d, UpConvT2d
+from ..token_ops import DropPath, LayerNorm, Linear, Mlp, PatchConv2d, UpConvT2d
 
 _DEFAULT_SHIFT = (1, 3, 6)   # panguweather.py:243
-
-
-class DropPath(nn.Module):
-    """Stochastic depth (timm semantics); the reference hard-codes rates np.linspace(0, 0.2, 8) (:405)."""
-
-    def __init__(self, p=0.0):
-        super().__init__()
-        self.p = float(p)
-
-    def forward(self, x):
-        if not self.training or self.p == 0.0:
-            return x
-        keep = 1.0 - self.p
-        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
-        return x * mask / keep
 
 
 def _pad3d(res, window):
@@ -139,9 +124,10 @@ class EarthSpecificBlock(nn.Module):
             rev_shift = sh if self.roll else (0, 0, 0)
             t = self.attn(partition(self.norm1(x), spec, fwd_shift), self._labels if self.roll else None, spec.nW)
             t = reverse(t, spec, B, rev_shift)
-            x = x + self.drop_path(t)
-            if isinstance(self.drop_path, DropPath) and self.drop_path.p > 0 and self.training:
-                return x + self.drop_path(self.mlp(self.norm2(x)))
+            if self.drop_path.active:            # stochastic depth: per-sample scale fused with the residual adds
+                x = self.drop_path(t, residual=x)
+                return self.drop_path(self.mlp(self.norm2(x)), residual=x)
+            x = x + t
             return self.mlp(self.norm2(x), residual=x)
         t = self.norm1(x).view(B, Pl, Lat, Lon, C)
         t = F.pad(t.permute(0, 4, 1, 2, 3), p).permute(0, 2, 3, 4, 1)
@@ -154,9 +140,10 @@ class EarthSpecificBlock(nn.Module):
         if self.roll:
             t = torch.roll(t, shifts=sh, dims=(1, 2, 3))
         t = t[:, p[4]:Plp - p[5], p[2]:Latp - p[3], p[0]:Lonp - p[1], :].reshape(B, Pl * Lat * Lon, C)
-        x = x + self.drop_path(t)
-        if isinstance(self.drop_path, DropPath) and self.drop_path.p > 0 and self.training:
-            return x + self.drop_path(self.mlp(self.norm2(x)))
+        if self.drop_path.active:
+            x = self.drop_path(t, residual=x)
+            return self.drop_path(self.mlp(self.norm2(x)), residual=x)
+        x = x + t
         return self.mlp(self.norm2(x), residual=x)
 
 

@@ -13,7 +13,9 @@ import torch
 import torch.nn as nn
 
 from ..sht import InverseRealSHT, RealSHT, dhconv, spectral_weight_scope
-from ..token_ops import Conv1x1, mlp, skip_mlp
+from functools import partial
+
+from ..token_ops import Conv1x1, InstanceNorm, add_tokens, mlp, skip_mlp
 from .rollout import rollout
 
 
@@ -45,29 +47,39 @@ class _MLP(nn.Module):
 
 
 class _Block(nn.Module):
+    """norm0 -> spectral filter (+ residual on the output grid) -> + inner skip -> GELU -> norm1 -> [MLP] -> + outer skip
+    (torch_harmonics SphericalFourierNeuralOperatorBlock, App. A-2; the residual is the NORMALISED block input)."""
+
     def __init__(self, forward_transform, inverse_transform, dim, mlp_ratio=2.0, inner_skip="linear", outer_skip="identity",
-                 use_mlp=True):
+                 use_mlp=True, norm=None):
         super().__init__()
-        if inner_skip not in ("linear", "none") or outer_skip not in ("identity", "none"):
-            raise NotImplementedError("inner_skip in {linear, none} and outer_skip in {identity, none} are implemented")
-        self.filter = _SpectralFilter(forward_transform, inverse_transform, dim, dim, gain=1.0 if inner_skip == "linear" else 2.0)
-        self.inner_skip = Conv1x1(dim, dim) if inner_skip == "linear" else None
+        if inner_skip != "linear" or outer_skip not in ("identity", "none"):
+            raise NotImplementedError("inner_skip='linear' with outer_skip in {identity, none} is what the SFNO network "
+                                      "builds (App. A-2)")
+        self.norm0 = norm(dim) if norm is not None else None
+        self.filter = _SpectralFilter(forward_transform, inverse_transform, dim, dim, gain=1.0)
+        self.inner_skip = Conv1x1(dim, dim)
+        self.norm1 = norm(dim) if norm is not None else None
         self.mlp = _MLP(dim, int(dim * mlp_ratio), dim) if use_mlp else None
         self.outer = outer_skip == "identity"
 
     def forward(self, x):
+        if self.norm0 is not None:
+            x = self.norm0(x)
         y, residual = self.filter(x)
-        if self.inner_skip is not None and self.mlp is not None and y.shape == residual.shape:
+        if self.norm1 is None and self.mlp is not None and y.shape == residual.shape:
             m = self.mlp                                                        # whole block tail as one autograd node
             return skip_mlp(y, residual, self.inner_skip.weight, self.inner_skip.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight,
                             m.fc2.bias, self.outer)
-        if self.inner_skip is not None:
-            y = self.inner_skip(residual, act=1, residual=y, res_pre=True)      # GELU(y + W residual + b) in one GEMM
-        else:
-            y = torch.nn.functional.gelu(y)
+        y = self.inner_skip(residual, act=1, residual=y, res_pre=True)          # GELU(y + W residual + b) in one GEMM
+        outer = residual if self.outer else None
+        if self.norm1 is not None:
+            if self.mlp is None:
+                return self.norm1(y, residual=outer)                            # outer skip inside the normalisation kernel
+            y = self.norm1(y)
         if self.mlp is not None:
-            return self.mlp(y, residual=residual if self.outer else None)       # outer skip in fc2's epilogue
-        return y + residual if self.outer else y
+            return self.mlp(y, residual=outer)                                  # outer skip in fc2's epilogue
+        return add_tokens(y, outer) if outer is not None else y
 
 
 class SphericalFourierNeuralOperatorNet(nn.Module):
@@ -80,8 +92,13 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
             raise NotImplementedError("only spectral_transform='sht' with operator_type='driscoll-healy' (sfno.yaml)")
         if factorization not in (None, "none", "None", "dense", "ComplexDense"):
             raise NotImplementedError("factorised spectral weights are not implemented (sfno.yaml: factorization null)")
-        if normalization_layer not in (None, "none", "None"):
-            raise NotImplementedError("normalization_layer other than 'none' is not implemented (sfno.yaml:19)")
+        if normalization_layer in (None, "none", "None"):
+            norm = None
+        elif normalization_layer == "instance_norm":      # fourcastnetv2.yaml:23: nn.InstanceNorm2d(embed_dim, eps=1e-6, affine)
+            norm = partial(InstanceNorm, eps=1e-6)
+        else:
+            raise NotImplementedError(f"normalization_layer {normalization_layer!r}: the shipped configs use 'none' "
+                                      "(sfno.yaml:19) and 'instance_norm' (fourcastnetv2.yaml:23)")
         self.img_size, self.big_skip = tuple(img_size), bool(big_skip)
         H, W = self.img_size
         self.h, self.w = H // scale_factor, W // scale_factor
@@ -94,7 +111,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         itrans = InverseRealSHT(self.h, self.w, modes, modes, "legendre-gauss")
         self.blocks = nn.ModuleList([
             _Block(down if i == 0 else trans, up if i == num_layers - 1 else itrans, embed_dim, mlp_ratio, inner_skip,
-                   outer_skip, use_mlp) for i in range(num_layers)])
+                   outer_skip, use_mlp, norm) for i in range(num_layers)])
         self.decoder = nn.ModuleList([Conv1x1(embed_dim + self.big_skip * in_chans, embed_dim), nn.GELU(),
                                       Conv1x1(embed_dim, out_chans, bias=False)])
 

@@ -30,10 +30,11 @@ class SwinTransformer(nn.Module):
             raise NotImplementedError("only the equirectangular mesh is on the MI355X hot path (healpix needs dgl)")
         if ape:
             raise NotImplementedError("absolute position embedding is not on the MI355X hot path")
-        if drop_rate or attn_drop_rate or drop_path_rate:
-            raise NotImplementedError("dropout / stochastic depth are not on the MI355X hot path: pass "
-                                      "drop_rate=0 attn_drop_rate=0 drop_path_rate=0")
+        if drop_rate or attn_drop_rate:
+            raise NotImplementedError("dropout is not on the MI355X hot path (the shipped config uses drop_rate 0 and "
+                                      "attn_drop_rate 0)")
         norm = _NORMS[norm_layer] if isinstance(norm_layer, str) else norm_layer
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]    # stochastic depth decay rule (:552)
         self.context_size, self.num_layers, self.embed_dim = context_size, len(depths), embed_dim
         self.img_height, self.img_width, self.mesh = img_height, img_width, mesh
         in_chans = constant_channels + (prescribed_channels + prognostic_channels) * context_size
@@ -47,7 +48,7 @@ class SwinTransformer(nn.Module):
                                           "there (swin_transformer.py:218-222, SURVEY App. B-6)")
             self.layers.append(BasicLayer(int(embed_dim * 2 ** i), depths[i], num_heads[i],
                                           res if window_size is None else window_size, mlp_ratio, qkv_bias,
-                                          qk_scale, norm_layer=norm,
+                                          qk_scale, drop_path=dpr[sum(depths[:i]):sum(depths[:i + 1])], norm_layer=norm,
                                           downsample=PatchMerging if i < self.num_layers - 1 else None,
                                           padding_mode=pad_modes))
             res = (res[0] // 2, res[1] // 2)

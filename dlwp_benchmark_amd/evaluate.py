@@ -21,10 +21,12 @@ def error_moments(outputs, targets, climatology=None, row_weights=None):
     """outputs / targets / climatology [B, G, H, W] on the GPU -> moments [5, G] (see dlwpmi.h)."""
     B, G, H, W = outputs.shape
     m = torch.zeros(5, G, device=outputs.device)
-    L.check(L.load().dlwp_error_moments(L.ptr(outputs.contiguous()), L.ptr(targets.contiguous()),
-                                        L.ptr(climatology.contiguous()) if climatology is not None else None,
-                                        L.ptr(row_weights.contiguous()) if row_weights is not None else None, B, G, H, W,
-                                        L.ptr(m), L.stream()))
+    # the contiguous copies stay bound to locals until the launch is enqueued: a temporary freed between two ptr() calls
+    # could hand its block to the next .contiguous() and alias both arguments
+    o, t = outputs.contiguous(), targets.contiguous()
+    c = climatology.contiguous() if climatology is not None else None
+    w = row_weights.contiguous() if row_weights is not None else None
+    L.check(L.load().dlwp_error_moments(L.ptr(o), L.ptr(t), L.ptr(c), L.ptr(w), B, G, H, W, L.ptr(m), L.stream()))
     return m
 
 

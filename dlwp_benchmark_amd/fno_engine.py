@@ -131,6 +131,7 @@ class FnoRolloutTrainer:
         self.lib = L.load()
         self.cfg = cfg
         self.device = device
+        self.generation = 0       # bumped by every activation-keeping forward (nsbench/fno.py:_RolloutFn)
         h = C.c_void_p()
         L.check(self.lib.dlwp_fno_trainer_create(C.byref(cfg), C.byref(h)))
         self.h = h

@@ -76,8 +76,11 @@ SIGNATURES = {
     "dlwp_cweight_fold": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_layernorm_fwd": (_I, [_V] * 6 + [_I, _I, _F, _V]),
     "dlwp_layernorm_bwd": (_I, [_V] * 8 + [_I, _I, _V]),
+    "dlwp_instnorm_fwd": (_I, [_V] * 6 + [_I, _I, _I, _F, _V]),
+    "dlwp_instnorm_bwd": (_I, [_V] * 8 + [_I, _I, _I, _V]),
     "dlwp_gelu_bwd": (_I, [_V, _V, _V, _L, _V]),
     "dlwp_colsum": (_I, [_V, _V, _I, _I, _V]),
+    "dlwp_scale_rows_add": (_I, [_V, _V, _V, _V, _I, _L, _V]),
     "dlwp_cmode_product": (_I, [_V, _V, _V, _I, _I, _I, _I, _V]),
     "dlwp_cmode_product_bwd": (_I, [_V] * 5 + [_I] * 4 + [_V]),
     "dlwp_window_attn_fwd": (_I, [_V] * 7 + [_I] * 7 + [_F, _V]),

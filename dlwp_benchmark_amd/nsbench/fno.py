@@ -17,22 +17,50 @@ from ..fno_engine import FnoParamLayout, FnoRolloutTrainer, FusedAdam, make_cfg
 
 
 class _RolloutFn(torch.autograd.Function):
-    """autograd bridge: forward = trainer rollout (activations kept), backward = BPTT kernels."""
+    """autograd bridge: forward = trainer rollout (activations kept), backward = BPTT kernels.
+
+    The shape-keyed trainer holds ONE set of BPTT activations; every forward stamps a generation number on it and backward
+    refuses to run against another forward's activations (two outstanding forwards of one shape -- e.g.
+    crit(m(x1)) + crit(m(x2)), or a validation forward between forward and backward -- would otherwise differentiate the
+    wrong rollout without any error)."""
 
     @staticmethod
-    def forward(ctx, flat, module, trainer):
-        ctx.module, ctx.trainer = module, trainer
+    def forward(ctx, flat, module, trainer, *derived):
+        """derived: tensors the spectral weights inside `flat` were computed from (TFNO: the dense mode-major weights
+        rebuilt from the Tucker factors); backward hands them the gradient of the corresponding flat-buffer entries."""
+        ctx.module, ctx.trainer, ctx.n_derived = module, trainer, len(derived)
+        trainer.generation += 1
+        ctx.generation = trainer.generation
         trainer.forward(keep_activations=True)
         return trainer.out.clone()
 
     @staticmethod
     def backward(ctx, grad_out):
         module, trainer = ctx.module, ctx.trainer
-        gbuf = torch.zeros_like(module.flat_params)
-        trainer.bind(module.flat_params.data, gbuf)
+        if ctx.generation != trainer.generation:
+            raise RuntimeError(
+                "FNO rollout: another forward of the same shape ran before this backward; its BPTT activations were "
+                "overwritten (one outstanding forward per (B, T, H, W, teacher_forcing) shape is supported -- call "
+                "backward() before the next forward, or run the second forward under torch.no_grad() AFTER backward)")
+        slot = module._grad_slot()
+        if slot is not None:
+            # the kernels ACCUMULATE parameter gradients: straight into the parameter's own flat .grad buffer, which is what
+            # the trainer is bound to (no temporary, no rebinding -> a captured step graph stays valid)
+            gbuf, ret = slot, None
+            module._bind(trainer)
+            if ctx.n_derived:        # derived entries are not parameters: their gradient region is scratch
+                for name in module._derived_names():
+                    module.layout.view(gbuf, name).zero_()
+        else:
+            gbuf = ret = torch.zeros_like(module.flat_params.data)
+            trainer.bind(module.flat_params.data, gbuf)     # rebound to the parameter's .grad on the next use (_bind)
         trainer.backward(grad_out.contiguous())
-        trainer.bind(module.flat_params.data, module.flat_grad)
-        return gbuf, None, None
+        gder = ()
+        if ctx.n_derived:
+            gder = tuple(module.layout.view(gbuf, name).clone() for name in module._derived_names())
+            for name in module._derived_names():     # keep them out of the flat gradient's norm / Adam moments
+                module.layout.view(gbuf, name).zero_()
+        return (ret, None, None) + gder
 
 
 class _FnoRolloutModule(nn.Module):
@@ -76,10 +104,37 @@ class _FnoRolloutModule(nn.Module):
         return out
 
     def _ensure_grad(self):
-        if self.flat_grad is None or self.flat_grad.device != self.flat_params.device:
-            self.flat_grad = torch.zeros_like(self.flat_params.data)
-        self.flat_params.grad = self.flat_grad
+        """The flat gradient buffer the trainers accumulate into.  An existing contiguous `.grad` of the flat parameter
+        (e.g. the slice train_engine.flatten_parameters pointed it at) is ADOPTED, never replaced: whoever owns that buffer
+        (GraphedTrainStep's optimizer, a data-parallel reducer) must see the BPTT gradients."""
+        g = self.flat_params.grad
+        if g is not None and g.is_contiguous() and g.shape == self.flat_params.shape and g.device == self.flat_params.device:
+            self.flat_grad = g
+        else:
+            if (self.flat_grad is None or self.flat_grad.device != self.flat_params.device
+                    or self.flat_grad.shape != self.flat_params.shape):
+                self.flat_grad = torch.zeros_like(self.flat_params.data)
+            self.flat_params.grad = self.flat_grad
         return self.flat_grad
+
+    def _derived_names(self):
+        return []
+
+    def _grad_slot(self):
+        g = self.flat_params.grad
+        if g is not None and g.is_contiguous() and g.shape == self.flat_params.shape:
+            self.flat_grad = g
+            return g
+        return None
+
+    def _bind(self, tr):
+        """(Re)bind a trainer to the CURRENT parameter / gradient storage.  `p.data = ...` (flatten_parameters, a
+        checkpoint loader) moves the storage without going through _apply, so the pointers are compared on every use;
+        rebinding drops the trainer's captured graph (dlwp_fno_trainer_bind)."""
+        g = self._ensure_grad()
+        if tr.params.data_ptr() != self.flat_params.data.data_ptr() or tr.grads.data_ptr() != g.data_ptr():
+            tr.bind(self.flat_params.data, g)
+        return tr
 
     def trainer(self, B, T, H, W, teacher_forcing_steps):
         key = (B, T, H, W, int(teacher_forcing_steps))
@@ -90,7 +145,7 @@ class _FnoRolloutModule(nn.Module):
                            self.n_layers, self.n_modes, out_channels=self.out_channels)
             tr = FnoRolloutTrainer(cfg, self.flat_params.data, self._ensure_grad(), self.flat_params.device)
             self._trainers[key] = tr
-        return tr
+        return self._bind(tr)
 
     def forward(self, x: torch.Tensor, teacher_forcing_steps: int = 10) -> torch.Tensor:
         B, T, D, H, W = x.shape

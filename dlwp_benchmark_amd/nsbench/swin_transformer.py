@@ -11,7 +11,8 @@ The attention core softmax(scale q k^T + bias + mask) v runs as hand-written HIP
 vector instead of an N x N tensor.  LayerNorm, qkv/proj/MLP/merging
 Linear layers run on libdlwpmi's MFMA GEMM / LayerNorm kernels (token_ops.py).  Patch embedding, the U-decoder's
 stride-2 transposed convolutions (GELU fused) and the 1x1 head are unfold / pixel-shuffle + the same GEMM.
-Round-1 scope: roll / pad / window partition remain torch data movement (DESIGN.md "next").
+Pad + roll + window partition (and the reverse) are one libdlwpmi gather kernel each (window_ops.py); stochastic depth
+(drop_path_rate, shipped default 0.2) is a per-sample scale fused with the residual add (token_ops.DropPath).
 """
 import math
 
@@ -20,7 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import lib as L
-from ..token_ops import _grad_slot, LayerNorm, Linear, Mlp, PatchConv2d, UpConvT2d
+from ..token_ops import _grad_slot, DropPath, LayerNorm, Linear, Mlp, PatchConv2d, UpConvT2d
 from ..window_ops import WindowSpec, partition, reverse
 
 
@@ -55,8 +56,9 @@ class _WindowAttnFn(torch.autograd.Function):
         gtable = ctx.tslot if ctx.tslot is not None else torch.zeros_like(table)   # kernel accumulates
         dsum = torch.empty_like(lse)
         slab = torch.empty(lib.dlwp_window_attn_bwd_slab_floats(B_, N, heads, TB), device=qkv.device)
+        g = gout.contiguous().float()  # kept alive until the launch is enqueued
         L.check(lib.dlwp_window_attn_bwd(L.ptr(qkv), L.ptr(table), L.ptr(ia), L.ptr(ib), L.ptr(labels), L.ptr(out),
-                                         L.ptr(lse), L.ptr(gout.contiguous().float()), L.ptr(gqkv), L.ptr(gtable),
+                                         L.ptr(lse), L.ptr(g), L.ptr(gqkv), L.ptr(gtable),
                                          L.ptr(dsum), L.ptr(slab), B_, nW, N, TB, ntypes, heads, d, scale, L.stream()))
         return gqkv, (None if ctx.tslot is not None else gtable), None, None, None, None, None, None
 
@@ -131,11 +133,11 @@ class SwinTransformerBlock(nn.Module):
         # (mode_h, mode_w) pair (dlwpbench: constant latitude, circular longitude)
         window_size, shift_size = _pair(window_size), _pair(shift_size)
         assert all(0 <= s < w for s, w in zip(shift_size, window_size)), "shift_size must in 0-window_size"
-        if drop_path > 0.:
-            raise NotImplementedError("stochastic depth is not on the MI355X hot path (set drop_path_rate=0)")
         self.window_size, self.shift_size, self.padding_mode = window_size, shift_size, _pair(padding_mode)
         self.norm1 = norm_layer(dim)
         self.attn = WindowAttention(dim, _pair(window_size), num_heads, qkv_bias, qk_scale, attn_drop, drop)
+        # reference :193: DropPath(drop_path) if drop_path > 0. else nn.Identity() -- no parameters either way
+        self.drop_path = DropPath(drop_path)
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
         self.H = self.W = None
@@ -148,8 +150,11 @@ class SwinTransformerBlock(nn.Module):
         if C % 4 == 0:
             # pad + roll + partition and reverse + roll back + crop are one gather kernel each (window_ops.py)
             spec = self._spec(H, W)
-            t = self.attn(partition(self.norm1(x), spec), labels if shifted else None, spec.nW)
-            x = x + reverse(t, spec, B)
+            t = reverse(self.attn(partition(self.norm1(x), spec), labels if shifted else None, spec.nW), spec, B)
+            if self.drop_path.active:        # training with stochastic depth (:255-256): per-sample scale + residual add
+                x = self.drop_path(t, residual=x)
+                return self.drop_path(self.mlp(self.norm2(x)), residual=x)
+            x = x + t
             return self.mlp(self.norm2(x), residual=x)
         t = self.norm1(x).view(B, H, W, C)
         t = _pad_hw(t, (ws[0] - H % ws[0]) % ws[0], (ws[1] - W % ws[1]) % ws[1], self.padding_mode)
@@ -161,7 +166,11 @@ class SwinTransformerBlock(nn.Module):
         t = _windows_to_tokens(t, ws, Hp, Wp)
         if shifted:
             t = torch.roll(t, shifts=(sh[0], sh[1]), dims=(1, 2))
-        x = x + t[:, :H, :W, :].reshape(B, H * W, C)
+        t = t[:, :H, :W, :].reshape(B, H * W, C)
+        if self.drop_path.active:
+            x = self.drop_path(t, residual=x)
+            return self.drop_path(self.mlp(self.norm2(x)), residual=x)
+        x = x + t
         return self.mlp(self.norm2(x), residual=x)   # residual add fused into fc2's epilogue
 
     def _spec(self, H, W):
@@ -266,10 +275,11 @@ class SwinTransformer(nn.Module):
         super().__init__()
         if ape:
             raise NotImplementedError("absolute position embedding is not on the MI355X hot path")
-        if drop_rate or attn_drop_rate or drop_path_rate:
-            raise NotImplementedError("dropout / stochastic depth are not on the MI355X hot path: pass "
-                                      "drop_rate=0 attn_drop_rate=0 drop_path_rate=0")
+        if drop_rate or attn_drop_rate:
+            raise NotImplementedError("dropout is not on the MI355X hot path (the shipped configs use drop_rate 0 and "
+                                      "attn_drop_rate 0)")
         norm = _NORMS[norm_layer] if isinstance(norm_layer, str) else norm_layer   # registry instead of eval()
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]    # stochastic depth decay rule (:542)
         self.context_size, self.num_layers, self.embed_dim = context_size, len(depths), embed_dim
         self.patch_embed = PatchEmbed(patch_size, in_chans * context_size, embed_dim, norm if patch_norm else None,
                                       padding_mode)
@@ -279,7 +289,8 @@ class SwinTransformer(nn.Module):
             # window = the stage's whole feature map (reference :528): global attention with a half-map shift
             self.layers.append(BasicLayer(int(embed_dim * 2 ** i), depths[i], num_heads[i],
                                           resolution if window_size is None else window_size, mlp_ratio,
-                                          qkv_bias, qk_scale, norm_layer=norm,
+                                          qkv_bias, qk_scale, drop_path=dpr[sum(depths[:i]):sum(depths[:i + 1])],
+                                          norm_layer=norm,
                                           downsample=PatchMerging if i < self.num_layers - 1 else None,
                                           padding_mode=padding_mode))
             resolution //= 2

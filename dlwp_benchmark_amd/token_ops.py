@@ -260,6 +260,115 @@ class _LayerNormFn(torch.autograd.Function):
         return gx.reshape(ctx.shape), gg, gb, None
 
 
+class _ScaleRowsAddFn(torch.autograd.Function):
+    """out[b] = residual[b] + scale[b] * t[b] (residual optional): one streaming kernel (dlwp_scale_rows_add); the
+    backward of the branch is the same kernel without the residual."""
+
+    @staticmethod
+    def forward(ctx, t, scale, residual):
+        t2 = t.contiguous().float()
+        r2 = residual.contiguous().float() if residual is not None else None
+        B = t2.shape[0]
+        out = torch.empty_like(t2)
+        L.check(L.load().dlwp_scale_rows_add(L.ptr(t2), L.ptr(scale), L.ptr(r2), L.ptr(out), B, t2.numel() // B, L.stream()))
+        ctx.save_for_backward(scale)
+        ctx.has_res = residual is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (scale,) = ctx.saved_tensors
+        g2 = g.contiguous().float()
+        B = g2.shape[0]
+        gt = torch.empty_like(g2)
+        L.check(L.load().dlwp_scale_rows_add(L.ptr(g2), L.ptr(scale), None, L.ptr(gt), B, g2.numel() // B, L.stream()))
+        return gt, None, (g if ctx.has_res else None)
+
+
+def add_tokens(a, b):
+    """a + b on [B, ...] token tensors through libdlwpmi (dlwp_scale_rows_add with unit scales)."""
+    return _ScaleRowsAddFn.apply(a, torch.ones(a.shape[0], device=a.device), b)
+
+
+class DropPath(nn.Module):
+    """Stochastic depth per sample (timm.models.layers.DropPath, used at nsbench/models/swintransformer/
+    swin_transformer.py:193,255-256, dlwpbench twin :192,261-262 and panguweather.py:262-323): in training mode the whole
+    residual branch of a sample is dropped with probability p and the survivors are scaled by 1 / (1 - p).  The Bernoulli
+    draw is torch's (B numbers); applying it is one libdlwpmi kernel fused with the residual add.  `active` tells the
+    blocks whether to take this path at all (eval mode / p = 0 keep the residual inside the GEMM epilogues)."""
+
+    def __init__(self, drop_prob=0.0, scale_by_keep=True):
+        super().__init__()
+        self.p = self.drop_prob = float(drop_prob)
+        self.scale_by_keep = scale_by_keep
+
+    @property
+    def active(self):
+        return self.training and self.p > 0.0
+
+    def forward(self, t, residual=None):
+        if not self.active:
+            return t if residual is None else residual + t
+        keep = 1.0 - self.p
+        mask = torch.empty(t.shape[0], device=t.device, dtype=torch.float32).bernoulli_(keep)
+        if keep > 0.0 and self.scale_by_keep:
+            mask = mask / keep
+        return _ScaleRowsAddFn.apply(t, mask, residual)
+
+    def extra_repr(self):
+        return f"drop_prob={self.p:0.3f}"
+
+
+class _InstanceNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, residual):
+        lib = L.load()
+        shape = x.shape
+        B, C_ = shape[0], shape[-1]
+        x3 = x.reshape(B, -1, C_).contiguous().float()
+        P = x3.shape[1]
+        r3 = residual.reshape(B, -1, C_).contiguous().float() if residual is not None else None
+        y = torch.empty_like(x3)
+        stats = torch.empty(B, C_, 2, device=x.device)
+        L.check(lib.dlwp_instnorm_fwd(L.ptr(x3), L.ptr(gamma.contiguous()), L.ptr(beta.contiguous()), L.ptr(r3), L.ptr(y),
+                                      L.ptr(stats), B, P, C_, eps, L.stream()))
+        ctx.save_for_backward(x3, gamma, stats)
+        ctx.shape, ctx.has_res = shape, residual is not None
+        ctx.slots = (_grad_slot(gamma), _grad_slot(beta))
+        return y.reshape(shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = L.load()
+        x3, gamma, stats = ctx.saved_tensors
+        B, P, C_ = x3.shape
+        g3 = gy.reshape(B, P, C_).contiguous().float()
+        gx = torch.empty_like(x3)
+        work = torch.empty(B, C_, 2, device=x3.device)
+        fused = ctx.slots[0] is not None and ctx.slots[1] is not None
+        gg, gb = ctx.slots if fused else (torch.zeros_like(gamma), torch.zeros_like(gamma))
+        L.check(lib.dlwp_instnorm_bwd(L.ptr(x3), L.ptr(gamma.contiguous()), L.ptr(stats), L.ptr(g3), L.ptr(gx), L.ptr(gg),
+                                      L.ptr(gb), L.ptr(work), B, P, C_, L.stream()))
+        gres = gy if ctx.has_res else None
+        if fused:
+            return gx.reshape(ctx.shape), None, None, None, gres
+        return gx.reshape(ctx.shape), gg, gb, None, gres
+
+
+class InstanceNorm(nn.Module):
+    """nn.InstanceNorm2d(num_features, eps, affine=True, track_running_stats=False) on channels-last tokens
+    [B, H, W, C] (statistics per sample and channel over the H*W tokens); parameter names `weight` / `bias` as torch's."""
+
+    def __init__(self, num_features, eps=1e-6):
+        super().__init__()
+        self.num_features, self.eps = num_features, eps
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+
+    def forward(self, x, residual=None):
+        return _InstanceNormFn.apply(x, self.weight, self.bias, float(self.eps), residual)
+
+
 class Linear(nn.Linear):
     def forward(self, x, act=0, residual=None):
         return _LinearFn.apply(x, self.weight, self.bias, act, residual, False)

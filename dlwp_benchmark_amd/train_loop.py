@@ -12,6 +12,7 @@ App. B-10).
 """
 import math
 import os
+import warnings
 
 import numpy as np
 import torch
@@ -25,27 +26,94 @@ def cosine_lr(base_lr, epoch, t_max, eta_min=0.0):
     return eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * epoch / t_max)) / 2
 
 
-def _optimizer_state(opt):
-    return {"exp_avg": opt.exp_avg.cpu(), "exp_avg_sq": opt.exp_avg_sq.cpu(), "step": opt.step_count.cpu(), "lr": opt.lr,
-            "betas": opt.betas, "eps": opt.eps, "layout": "flat (dlwp_benchmark_amd.fno_engine.FusedAdam)"}
+def _named_moment_views(model, opt):
+    """[(name, exp_avg view, exp_avg_sq view)] per named parameter, in the reference's shapes: the flat Adam moments of
+    fno_engine.FusedAdam sliced the way the parameters are laid out in the flat buffer."""
+    if hasattr(model, "layout") and hasattr(model, "flat_params") and opt.exp_avg.numel() == model.flat_params.numel():
+        a = model.layout.to_state_dict(opt.exp_avg, prefix="fno.")
+        b = model.layout.to_state_dict(opt.exp_avg_sq, prefix="fno.")
+        return [(k, a[k], b[k]) for k in a]
+    base, out = opt.params.data_ptr(), []
+    for name, p in model.named_parameters():
+        off = (p.data.data_ptr() - base) // 4
+        if not (0 <= off and off + p.numel() <= opt.params.numel()):
+            continue
+        out.append((name, opt.exp_avg[off:off + p.numel()].view(p.shape), opt.exp_avg_sq[off:off + p.numel()].view(p.shape)))
+    return out
+
+
+def _optimizer_state(model, opt):
+    """torch.optim.Adam.state_dict() layout (state / param_groups per parameter index, utils.py:33-39 stores exactly
+    optimizer.state_dict()), built from the flat moments; `param_names` (extra key, ignored by torch) records which
+    parameter each index is."""
+    opt = getattr(opt, "main", opt)          # dlwpbench TFNO2DModule: flat part of the composite optimizer
+    views = _named_moment_views(model, opt)
+    step = float(opt.step_count.item())
+    state = {i: {"step": torch.tensor(step), "exp_avg": a.detach().cpu().clone(), "exp_avg_sq": b.detach().cpu().clone()}
+             for i, (_, a, b) in enumerate(views)}
+    group = {"lr": opt.lr, "betas": tuple(opt.betas), "eps": opt.eps, "weight_decay": 0, "amsgrad": False, "maximize": False,
+             "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+             "params": list(range(len(views)))}
+    return {"state": state, "param_groups": [group], "param_names": [n for n, _, _ in views]}
 
 
 def write_checkpoint(model, optimizer, scheduler_state, epoch, iteration, best_val_error, dst_path):
-    """utils.write_checkpoint (:11-39): same keys; the optimizer entry holds the flat Adam moments."""
+    """utils.write_checkpoint (:11-39): same keys; the optimizer entry has torch.optim.Adam's state_dict layout."""
     os.makedirs(os.path.dirname(dst_path), exist_ok=True)
     torch.save({"model_state_dict": {k: v.cpu() for k, v in model.state_dict().items()},
-                "optimizer_state_dict": _optimizer_state(optimizer), "scheduler_state_dict": scheduler_state,
+                "optimizer_state_dict": _optimizer_state(model, optimizer), "scheduler_state_dict": scheduler_state,
                 "epoch": epoch + 1, "iteration": iteration, "best_val_error": best_val_error}, dst_path)
 
 
-def load_checkpoint(path, model, optimizer=None):
-    ck = torch.load(path, map_location="cpu", weights_only=False)
-    model.load_state_dict(ck["model_state_dict"])
-    if optimizer is not None and isinstance(ck.get("optimizer_state_dict"), dict) and "exp_avg" in ck["optimizer_state_dict"]:
-        st = ck["optimizer_state_dict"]
+def _load_optimizer_state(st, model, optimizer, path):
+    optimizer = getattr(optimizer, "main", optimizer)
+    if "exp_avg" in st:                                   # round-1 flat layout
         optimizer.exp_avg.copy_(st["exp_avg"])
         optimizer.exp_avg_sq.copy_(st["exp_avg_sq"])
         optimizer.step_count.copy_(st["step"])
+        return True
+    if not st.get("state"):
+        return False
+    views = _named_moment_views(model, optimizer)
+    names = st.get("param_names")
+    # reference files carry no names: parameter index = registration order, which the drop-in modules keep
+    index = {n: i for i, n in enumerate(names)} if names else {n: i for i, (n, _, _) in enumerate(views)}
+    found = {}
+    for name, a, _ in views:
+        ent = st["state"].get(index.get(name, -1))
+        if ent is not None and tuple(ent["exp_avg"].shape) == tuple(a.shape):
+            found[name] = ent
+    if len(found) != len(views):
+        warnings.warn(f"{path}: optimizer state matches {len(found)} of {len(views)} parameters; the others restart from "
+                      "zero moments")
+    if not found:
+        return False
+    if hasattr(model, "layout") and hasattr(model, "flat_params"):
+        if len(found) != len(views):
+            return False                                  # the FNO converter needs every tensor
+        # the FNO layout converts (complex, mode-major) on the way out: write back through the same converter
+        model.layout.from_state_dict(optimizer.exp_avg, {n: e["exp_avg"].to(optimizer.exp_avg.device) for n, e in found.items()},
+                                     prefix="fno.")
+        model.layout.from_state_dict(optimizer.exp_avg_sq,
+                                     {n: e["exp_avg_sq"].to(optimizer.exp_avg.device) for n, e in found.items()}, prefix="fno.")
+    else:
+        for name, a, b in views:
+            if name in found:
+                a.copy_(found[name]["exp_avg"].to(a.device))
+                b.copy_(found[name]["exp_avg_sq"].to(b.device))
+    optimizer.step_count.fill_(int(max(float(e["step"]) for e in found.values())))
+    return True
+
+
+def load_checkpoint(path, model, optimizer=None):
+    """Reads this package's checkpoints and the reference's (utils.py:33-39: tensors, scalars and plain containers only, so
+    the restricted unpickler is enough)."""
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    model.load_state_dict(ck["model_state_dict"])
+    if optimizer is not None:
+        st = ck.get("optimizer_state_dict")
+        if not (isinstance(st, dict) and _load_optimizer_state(st, model, optimizer, path)):
+            warnings.warn(f"{path}: no usable optimizer state; Adam restarts from zero moments and step 0")
     return ck
 
 
@@ -79,6 +147,13 @@ def train_ns(model, u_train, u_val, name="model", epochs=10, batch_size=4, seque
     if continue_training:
         ck = load_checkpoint(ckpt_last, model, opt)
         epoch0, iteration, best = ck["epoch"], ck["iteration"], ck["best_val_error"]
+    if world > 1:
+        # replicas must start identical: the module initialises from the process-global RNG, and a resumed rank 0 must
+        # hand its Adam state to the others as well (the all-reduced gradient is applied by every rank)
+        ddp.broadcast_parameters(model.flat_params.data, src=0)
+        o = getattr(opt, "main", opt)
+        for t in (o.exp_avg, o.exp_avg_sq, o.step_count):
+            ddp.broadcast_parameters(t, src=0)
     vtf = teacher_forcing_steps if val_teacher_forcing_steps is None else val_teacher_forcing_steps
     log = []
     for epoch in range(epoch0, epochs):
@@ -126,7 +201,7 @@ def validation_mse_dlwp(model, dataset, batch_size, device):
 
 def train_dlwp(model, train_dataset, val_dataset, name="model", epochs=10, batch_size=4, learning_rate=1e-3,
                clip_gradients=False, gradient_accumulation_steps=1, seed=1234, out_dir="outputs", save_model=True,
-               use_graph=True, verbose=False):
+               use_graph=True, verbose=False, continue_training=False):
     """The dlwpbench training script's epoch loop (src/dlwpbench/scripts/train.py:104-197) around the captured step of
     train_engine.GraphedTrainStep, for any dlwpbench module (forward(constants, prescribed, prognostic)): batches of
     `WeatherBenchDataset.__getitem__` tuples (wbdata.WeatherBenchArrays) from the seeded rank-sharded permutation, MSE,
@@ -147,13 +222,20 @@ def train_dlwp(model, train_dataset, val_dataset, name="model", epochs=10, batch
     reducer = ddp.FlatGradAllReduce() if world > 1 else None
     ckpt_last = os.path.join(out_dir, name, "checkpoints", f"{name}_last.ckpt")
     step, iteration, best, log = None, 0, float("inf"), []
+    epoch0, resume = 0, None
+    if continue_training:           # dlwpbench/scripts/train.py:60-71: model, optimizer, epoch, iteration, best error
+        resume = torch.load(ckpt_last, map_location="cpu", weights_only=True)
+        model.load_state_dict(resume["model_state_dict"])
+        epoch0, iteration, best = resume["epoch"], resume["iteration"], resume["best_val_error"]
 
     def kwargs_of(c, p, g):
         return {k: v for k, v in (("constants", c), ("prescribed", p), ("prognostic", g)) if v is not None}
 
-    for epoch in range(epochs):
+    for epoch in range(epoch0, epochs):
         lr = cosine_lr(learning_rate, epoch, epochs)
         losses = []
+        if hasattr(train_dataset, "set_epoch"):
+            train_dataset.set_epoch(epoch)
         for idx in wbdata.shard_batches(train_dataset, epoch, rank, world, batch_size, seed):
             c, p, g, t = wbdata.to_device_batch([train_dataset[int(i)] for i in idx], device)
             sl = lambda v, i: None if v is None else v[i:i + micro]      # noqa: E731
@@ -161,8 +243,15 @@ def train_dlwp(model, train_dataset, val_dataset, name="model", epochs=10, batch
                 step = GraphedTrainStep(model, kwargs_of(sl(c, 0), sl(p, 0), sl(g, 0)), t[:micro], lr=lr, allreduce=reducer,
                                         grad_scale=1.0 / world, use_graph=use_graph, graph_optimizer=False,
                                         clip_max_norm=lr if clip_gradients else None)
+                if resume is not None:
+                    st = resume.get("optimizer_state_dict")
+                    if not (isinstance(st, dict) and _load_optimizer_state(st, model, step.opt, ckpt_last)):
+                        warnings.warn(f"{ckpt_last}: no usable optimizer state; Adam restarts from zero moments")
+                    resume = None
                 if world > 1:
                     ddp.broadcast_parameters(step.flat, src=0)
+                    for t in (step.opt.exp_avg, step.opt.exp_avg_sq, step.opt.step_count):
+                        ddp.broadcast_parameters(t, src=0)
             step.opt.lr = lr
             step.clip = lr if clip_gradients else None
             if micro == batch_size:

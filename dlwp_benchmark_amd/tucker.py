@@ -61,7 +61,8 @@ class _ModeProduct(torch.autograd.Function):
         x, U = ctx.saved_tensors
         O, R, N, I = ctx.dims
         gin, gU = torch.empty_like(x), torch.empty_like(U)
-        L.check(L.load().dlwp_cmode_product_bwd(L.ptr(x), L.ptr(U), L.ptr(gout.contiguous()), L.ptr(gin), L.ptr(gU),
+        g = gout.contiguous()          # kept alive until the launch is enqueued
+        L.check(L.load().dlwp_cmode_product_bwd(L.ptr(x), L.ptr(U), L.ptr(g), L.ptr(gin), L.ptr(gU),
                                                 O, R, N, I, L.stream()))
         return gin, gU, None
 

@@ -58,6 +58,7 @@ class WeatherBenchArrays(torch.utils.data.Dataset):
         self.context_size = int(context_size)
         self.stats = STATISTICS if stats is None else stats
         self.seed = seed           # None: numpy's global generator like the reference (:393); an int: per-item streams
+        self.epoch = 0             # set_epoch(): part of the noise seed
         first = next(iter(self.prognostic_variable_names_and_levels))
         lv = self.prognostic_variable_names_and_levels[first]
         self.n_time = len(self.fields[first][lv[0]] if lv else self.fields[first])
@@ -71,6 +72,10 @@ class WeatherBenchArrays(torch.utils.data.Dataset):
     @staticmethod
     def _norm(a, st):
         return (a - st["mean"]) / st["std"]
+
+    def set_epoch(self, epoch):
+        """Seeded mode only: makes the noise stream of every item epoch-dependent (like ddp.ns_sample)."""
+        self.epoch = int(epoch)
 
     def __len__(self):
         return (self.n_time - self.sequence_length) // self.sequence_length            # :322-323
@@ -103,7 +108,9 @@ class WeatherBenchArrays(torch.utils.data.Dataset):
         if self.seed is None:
             eps = np.random.randn(*prognostic[:-1].shape)
         else:                       # DDP: the noise of a sample must not depend on which rank draws it (ddp.py)
-            eps = np.random.default_rng([self.seed, int(item)]).standard_normal(prognostic[:-1].shape)
+            # per-(epoch, item) stream: the perturbation of a sample changes from epoch to epoch (set_epoch) and does not
+            # depend on the number of ranks
+            eps = np.random.default_rng([self.seed, int(self.epoch), int(item)]).standard_normal(prognostic[:-1].shape)
         prognostic = prognostic[:-1] + np.float32(eps * self.noise)                     # :393
         return self.constants, prescribed, prognostic, target[self.context_size:]       # :395
 

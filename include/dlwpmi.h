@@ -337,11 +337,28 @@ int dlwp_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
 int dlwp_layernorm_bwd(const float* x, const float* gamma, const float* mean, const float* rstd,
                        const float* gy, float* gx, float* ggamma, float* gbeta, int T, int C,
                        void* stream);
+/* Instance normalisation of channels-last tokens x [B][P][C]: per (sample, channel) mean / biased       */
+/* variance over the P = H*W tokens, y = (x - mean) rstd gamma + beta (+ residual, same layout, optional).  */
+/* Replaces nn.InstanceNorm2d(embed_dim, eps, affine=True) inside torch_harmonics' SFNO                      */
+/* (normalization_layer="instance_norm": src/dlwpbench/configs/model/fourcastnetv2.yaml:23, constructed at   */
+/* src/dlwpbench/models/fourcastnet/fourcastnet.py:411-428).  stats [B][C][2] receives (mean, rstd).         */
+int dlwp_instnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual,
+                      float* y, float* stats, int B, int P, int C, float eps, void* stream);
+/* gx written; ggamma / gbeta ACCUMULATED into; work: scratch [B][C][2].                                    */
+int dlwp_instnorm_bwd(const float* x, const float* gamma, const float* stats, const float* gy, float* gx,
+                      float* ggamma, float* gbeta, float* work, int B, int P, int C, void* stream);
 /* gz = gy * gelu'(z) (exact erf GELU)                                                       */
 int dlwp_gelu_bwd(const float* z, const float* gy, float* gz, long long n, void* stream);
 /* gz = gy * act'(z) for the epilogue activations of dlwp_gemm_batched (1 GELU, 2 ReLU, 3 soft-shrink) */
 int dlwp_act_bwd(const float* z, const float* gy, float* gz, long long n, int act, float act_param,
                  void* stream);
+/* Stochastic depth (timm DropPath: src/nsbench/models/swintransformer/swin_transformer.py:193,   */
+/* 255-256; dlwpbench twin :192,261-262; panguweather.py:262-323): the per-sample keep mask, already    */
+/* divided by the keep probability, scales a residual branch: out[b][i] = x[b][i] + scale[b] t[b][i]    */
+/* (x may be NULL: plain scaling, which is also the backward of the branch: gt = scale[b] g).           */
+/* t, x, out: [B][n]; scale: [B] device floats.                                                          */
+int dlwp_scale_rows_add(const float* t, const float* scale, const float* x, float* out, int B,
+                        long long n, void* stream);
 /* out[n] += sum_t g[t][n]   (bias gradients)                                                */
 int dlwp_colsum(const float* g, float* out, int T, int N, void* stream);
 

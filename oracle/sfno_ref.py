@@ -119,6 +119,8 @@ def sfno_net(x, p, cfg):
         fwd_t = down if i == 0 else inner
         inv_t = down if i == n_layers - 1 else inner
         pre = f"blocks.{i}."
+        if pre + "norm0.weight" in p:             # nn.InstanceNorm2d(embed_dim, eps=1e-6, affine=True) (App. A-2)
+            t = F.instance_norm(t, weight=p[pre + "norm0.weight"], bias=p[pre + "norm0.bias"], eps=1e-6)
         res = t
         X = fwd_t.forward(t)
         if (fwd_t.nlat, fwd_t.nlon) != (inv_t.nlat, inv_t.nlon):
@@ -129,6 +131,8 @@ def sfno_net(x, p, cfg):
         if pre + "inner_skip.weight" in p:
             t = t + conv1x1(res, p, pre + "inner_skip")
         t = F.gelu(t)
+        if pre + "norm1.weight" in p:
+            t = F.instance_norm(t, weight=p[pre + "norm1.weight"], bias=p[pre + "norm1.bias"], eps=1e-6)
         if pre + "mlp.fc1.weight" in p:
             t = conv1x1(F.gelu(conv1x1(t, p, pre + "mlp.fc1")), p, pre + "mlp.fc2")
         t = t + res

@@ -179,3 +179,42 @@ def test_sfnonet_fourcastnetv2_matches_oracle_composition(cuda):
     net = net.to(cuda)
     y = net(constants=constants.to(cuda), prescribed=prescribed.to(cuda), prognostic=prognostic.to(cuda))
     assert rel(y, yr) <= 1e-4
+
+
+def test_sfnonet_shipped_fourcastnetv2_options_match_oracle(cuda):
+    """The option set of the shipped fourcastnetv2.yaml (instance_norm, use_mlp False, big_skip False, legendre-gauss data
+    grid) against the oracle's sfno_net, forward and every gradient."""
+    import torch.nn.functional as F
+    from dlwp_benchmark_amd import dlwpbench
+    torch.manual_seed(31)
+    cfg = dict(img_height=16, img_width=32, patch_size=(1, 1), constant_channels=2, prescribed_channels=1, prognostic_channels=3,
+               grid="legendre-gauss", num_layers=3, scale_factor=1, embed_dim=16, big_skip=False, use_pos_embed=True,
+               use_mlp=False, normalization_layer="instance_norm", context_size=1)
+    net = dlwpbench.FourCastNetv2(**cfg)
+    with torch.no_grad():
+        for n, q in net.named_parameters():
+            if "norm0" in n or "norm1" in n:
+                q.add_(0.3 * torch.randn_like(q))           # affine parameters away from (1, 0)
+    g = torch.Generator().manual_seed(32)
+    constants = torch.randn(2, 1, 2, 16, 32, generator=g)
+    prescribed = torch.randn(2, 2, 1, 16, 32, generator=g)
+    prognostic = torch.randn(2, 2, 3, 16, 32, generator=g)
+    target = torch.randn(2, 1, 3, 16, 32, generator=g)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in net.state_dict().items()}
+    p = {k[len("sfno."):]: v for k, v in sd.items() if k.startswith("sfno.")}
+    assert "blocks.0.norm0.weight" in p and "blocks.0.mlp.fc1.weight" not in p
+    ocfg = dict(height=16, width=32, scale_factor=1, grid="legendre-gauss", num_layers=3, big_skip=False)
+    x_t = torch.cat([constants[:, 0], prescribed[:, 0:1].flatten(1, 2), prognostic[:, 0:1].flatten(1, 2)], dim=1)
+    e = F.conv2d(x_t, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"])
+    e = (e.flatten(2).transpose(1, 2) + sd["pos_embed"]).reshape(2, 16, 32, 16).permute(0, 3, 1, 2)
+    z = F.linear(sfno_ref.sfno_net(e, p, ocfg).permute(0, 2, 3, 1), sd["head.weight"]).permute(0, 3, 1, 2)
+    yr = (prognostic[:, 0] + z)[:, None]
+    F.mse_loss(yr, target).backward()
+    net = net.to(cuda).train()
+    y = net(constants=constants.to(cuda), prescribed=prescribed.to(cuda), prognostic=prognostic.to(cuda))
+    assert rel(y, yr) <= 1e-4
+    F.mse_loss(y, target.to(cuda)).backward()
+    for n, q in net.named_parameters():
+        if q.grad is None or sd[n].grad is None:
+            continue
+        assert rel(q.grad, sd[n].grad) <= 2e-3, n
