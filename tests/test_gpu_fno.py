@@ -336,3 +336,125 @@ def test_two_live_trainers_do_not_disturb_each_other(cuda):
             b = m2.train_step(x, y, 4, optimizer=opt2).item()
             assert abs(a - b) <= 1e-5 * abs(b) and 0 < a < 10, (a, b, ref)
         del junk
+
+
+# ---- HIP trainer vs vectors produced by executing the reference's own rollout classes
+# (tests/golden/make_fno_driver_golden.py; the backbone inside is the oracle's FNO, the drivers are the reference's)
+import os
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "fno_driver_golden.npz")
+
+
+def _golden_state_dict(G, tag, n_layers):
+    sd, biases = {}, []
+    for key in G.files:
+        if not key.startswith(f"{tag}/p/"):
+            continue
+        name = key[len(f"{tag}/p/"):]
+        a = torch.from_numpy(G[key])
+        if ".convs.weight." in name:
+            sd[f"fno.{name}.tensor"] = torch.view_as_complex(a.contiguous())
+        elif ".convs.bias." in name:
+            continue
+        elif name.endswith("weight"):
+            sd["fno." + name] = a[:, :, None, None]
+        else:
+            sd["fno." + name] = a
+    sd["fno.fno_blocks.convs.bias"] = torch.stack(
+        [torch.from_numpy(G[f"{tag}/p/fno_blocks.convs.bias.{l}"]) for l in range(n_layers)])[:, :, None, None]
+    return sd
+
+
+def _golden_flat_grad(G, tag, module):
+    lay = module.layout
+    flat = torch.zeros(lay.total)
+    for name in lay.entries:
+        a = torch.from_numpy(G[f"{tag}/g/{name}"])
+        dst = lay.view(flat, name)
+        if ".convs.weight." in name:
+            dst.copy_(fno_ref.spec_to_mode_major(torch.view_as_complex(a.contiguous())))
+        else:
+            dst.copy_(a.reshape(dst.shape))
+    return flat
+
+
+@pytest.mark.parametrize("tag", ["ns_a", "ns_b", "ns_c", "ns_d", "ns_e"])
+def test_ns_trainer_matches_reference_driver_golden(cuda, tag):
+    from dlwp_benchmark_amd import nsbench
+    G = np.load(GOLD)
+    ctx, tf, hidden, layers, m1, m2 = [int(v) for v in G[f"{tag}/cfg"]]
+    module = nsbench.TFNO2DModule(n_modes=[m1, m2], in_channels=1, hidden_channels=hidden, lifting_channels=16,
+                                  projection_channels=16, out_channels=1, n_layers=layers, context_size=ctx)
+    module.load_state_dict(_golden_state_dict(G, tag, layers))
+    module = module.to(cuda)
+    x, y = torch.from_numpy(G[f"{tag}/x"]).to(cuda), torch.from_numpy(G[f"{tag}/y"]).to(cuda)
+    with torch.no_grad():
+        out = module(x, teacher_forcing_steps=tf)
+    assert rel_err(out, torch.from_numpy(G[f"{tag}/out"])) <= FWD_TOL
+    module.flat_grad.zero_()
+    loss = module.train_step(x, y, tf, optimizer=None, use_graph=True)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(G[f"{tag}/loss"])) <= 1e-4 * abs(float(G[f"{tag}/loss"]))
+    assert rel_err(module.flat_grad, _golden_flat_grad(G, tag, module)) <= GRAD_TOL
+
+
+def test_ns_single_frame_trainer_matches_reference_driver_golden(cuda):
+    from dlwp_benchmark_amd import nsbench
+    G = np.load(GOLD)
+    module = nsbench.FNOModule(n_modes=[6, 6], in_channels=1, hidden_channels=8, lifting_channels=16, projection_channels=16,
+                               out_channels=1, n_layers=2)
+    module.load_state_dict(_golden_state_dict(G, "ns_single", 2))
+    module = module.to(cuda)
+    x, y = torch.from_numpy(G["ns_single/x"]).to(cuda), torch.from_numpy(G["ns_single/y"]).to(cuda)
+    with torch.no_grad():
+        assert rel_err(module(x, teacher_forcing_steps=3), torch.from_numpy(G["ns_single/out"])) <= FWD_TOL
+    module.flat_grad.zero_()
+    module.train_step(x, y, 3, optimizer=None, use_graph=False)
+    assert rel_err(module.flat_grad, _golden_flat_grad(G, "ns_single", module)) <= GRAD_TOL
+
+
+@pytest.mark.parametrize("tag", ["dl_a", "dl_b", "dl_c"])
+def test_dlwp_trainer_matches_reference_driver_golden(cuda, tag):
+    from dlwp_benchmark_amd import dlwpbench
+    G = np.load(GOLD)
+    ctx, Cc, Cp, Cg, hidden, layers, m1, m2 = [int(v) for v in G[f"{tag}/cfg"]]
+    module = dlwpbench.FNO2DModule(n_modes=[m1, m2], constant_channels=Cc, prescribed_channels=Cp, prognostic_channels=Cg,
+                                   hidden_channels=hidden, lifting_channels=16, projection_channels=16, n_layers=layers,
+                                   context_size=ctx)
+    module.load_state_dict(_golden_state_dict(G, tag, layers))
+    module = module.to(cuda)
+    dev = lambda k: torch.from_numpy(G[f"{tag}/{k}"]).to(cuda) if f"{tag}/{k}" in G.files else None   # noqa: E731
+    const, presc, prog, target = dev("constants"), dev("prescribed"), dev("prognostic"), dev("target")
+    with torch.no_grad():
+        out = module(const, presc, prog)
+    assert rel_err(out, torch.from_numpy(G[f"{tag}/out"])) <= FWD_TOL
+    module.flat_grad.zero_()
+    loss = module.train_step(const, presc, prog, target, use_graph=False)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(G[f"{tag}/loss"])) <= 1e-4 * abs(float(G[f"{tag}/loss"]))
+    assert rel_err(module.flat_grad, _golden_flat_grad(G, tag, module)) <= GRAD_TOL
+
+
+def test_headline_config_parity_at_the_benchmarked_horizon(cuda):
+    """BASELINE configs[1] exactly as bench.py runs it: TFNO2DModule 64x64, B=4, T=20, context 10, teacher forcing 10 ->
+    11 net calls, 10 of them closed loop.  Forward <= 1e-4 relative (north_star) after ten closed-loop steps of error
+    growth; loss and gradients against the oracle's autograd."""
+    cfg = dict(B=4, T=20, D=1, H=64, W=64, ctx=10, tf=10, hidden=32, lifting=256, projection=256, n_layers=4, n_modes=(12, 12))
+    oracle, module = _oracle_and_module(cuda, cfg["n_modes"], cfg["D"], cfg["hidden"], cfg["lifting"], cfg["projection"],
+                                        cfg["n_layers"], cfg["ctx"])
+    g = torch.Generator().manual_seed(1234)
+    u = torch.randn(cfg["B"], cfg["T"] + 1, 1, 64, 64, generator=g)
+    x, y = u[:, :-1].contiguous(), u[:, 1:].contiguous()
+    oracle.requires_grad_(True)
+    loss_ref, yhat_ref = fno_ref.train_step(oracle, x, y, cfg["tf"], cfg["ctx"])
+    with torch.no_grad():
+        yhat = module(x.to(cuda), teacher_forcing_steps=cfg["tf"])
+    assert rel_err(yhat, yhat_ref) <= FWD_TOL
+    assert rel_err(yhat[:, -1], yhat_ref[:, -1]) <= FWD_TOL          # the last (10th closed-loop) frame on its own
+    module.flat_grad.zero_()
+    loss = module.train_step(x.to(cuda), y.to(cuda), cfg["tf"], optimizer=None, use_graph=True)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item())
+    assert rel_err(module.flat_grad, _oracle_flat_grad(oracle, module)) <= GRAD_TOL

@@ -70,3 +70,79 @@ def test_single_frame_rollout_equals_context_one():
 def test_mode_major_roundtrip():
     w = torch.randn(3, 5, 4, 3, dtype=torch.complex64)
     assert torch.equal(fno_ref.spec_from_mode_major(fno_ref.spec_to_mode_major(w)), w)
+
+
+# ---- the in-tree rollout drivers, pinned by vectors produced by EXECUTING the reference's classes
+# (tests/golden/make_fno_driver_golden.py: reference TFNO2DModule / FNOModule / FNO2DModule around a stub neuralop FNO)
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "fno_driver_golden.npz")
+
+
+def golden_net(G, tag, in_channels, out_channels):
+    """oracle FNO carrying the golden's parameters; returns (net, names)."""
+    ctx, _, hidden, layers, m1, m2 = [int(v) for v in G[f"{tag}/cfg"][:6]] if not tag.startswith("dl") else \
+        (0, 0, int(G[f"{tag}/cfg"][4]), int(G[f"{tag}/cfg"][5]), int(G[f"{tag}/cfg"][6]), int(G[f"{tag}/cfg"][7]))
+    net = fno_ref.FNO([m1, m2], in_channels, hidden, 16, 16, out_channels, layers)
+    for name in list(net.params):
+        a = torch.from_numpy(G[f"{tag}/p/{name}"])
+        net.params[name] = torch.view_as_complex(a.contiguous()) if ".convs.weight." in name else a
+    return net
+
+
+def golden_grad(G, tag, name):
+    a = torch.from_numpy(G[f"{tag}/g/{name}"])
+    return torch.view_as_complex(a.contiguous()) if ".convs.weight." in name else a
+
+
+def close(a, b, tol=1e-5):
+    if a.is_complex():
+        a, b = torch.view_as_real(a), torch.view_as_real(b)
+    return ((a.double() - b.double()).abs().max() <= tol * b.double().abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("tag", ["ns_a", "ns_b", "ns_c", "ns_d", "ns_e"])
+def test_ns_rollout_restatement_equals_the_reference_driver(tag):
+    G = np.load(GOLD)
+    ctx, tf = int(G[f"{tag}/cfg"][0]), int(G[f"{tag}/cfg"][1])
+    net = golden_net(G, tag, ctx, 1).requires_grad_(True)
+    x = torch.from_numpy(G[f"{tag}/x"]).requires_grad_(True)
+    y = torch.from_numpy(G[f"{tag}/y"])
+    out = fno_ref.ns_rollout(net, x, tf, ctx)
+    assert close(out, torch.from_numpy(G[f"{tag}/out"]))
+    loss = torch.nn.functional.mse_loss(out, y)
+    assert abs(loss.item() - float(G[f"{tag}/loss"])) <= 1e-6 * abs(float(G[f"{tag}/loss"]))
+    loss.backward()
+    assert close(x.grad, torch.from_numpy(G[f"{tag}/gx"]))
+    for name, p in net.params.items():
+        assert close(p.grad, golden_grad(G, tag, name)), name
+
+
+def test_ns_single_frame_restatement_equals_the_reference_driver():
+    G = np.load(GOLD)
+    net = golden_net(G, "ns_single", 1, 1).requires_grad_(True)
+    out = fno_ref.ns_rollout_single(net, torch.from_numpy(G["ns_single/x"]), 3)
+    assert close(out, torch.from_numpy(G["ns_single/out"]))
+    torch.nn.functional.mse_loss(out, torch.from_numpy(G["ns_single/y"])).backward()
+    for name, p in net.params.items():
+        assert close(p.grad, golden_grad(G, "ns_single", name)), name
+
+
+@pytest.mark.parametrize("tag", ["dl_a", "dl_b", "dl_c"])
+def test_dlwp_rollout_restatement_equals_the_reference_driver(tag):
+    G = np.load(GOLD)
+    ctx, Cc, Cp, Cg = [int(v) for v in G[f"{tag}/cfg"][:4]]
+    net = golden_net(G, tag, Cc + (Cp + Cg) * ctx, Cg).requires_grad_(True)
+    const = torch.from_numpy(G[f"{tag}/constants"]) if Cc else None
+    presc = torch.from_numpy(G[f"{tag}/prescribed"]) if Cp else None
+    prog = torch.from_numpy(G[f"{tag}/prognostic"])
+    out = fno_ref.dlwp_rollout(net, const, presc, prog, ctx)
+    assert close(out, torch.from_numpy(G[f"{tag}/out"]))
+    # the reference's published forward (one lead time) gave the same first step
+    assert close(out[:, :1], torch.from_numpy(G[f"{tag}/one_step"]))
+    torch.nn.functional.mse_loss(out, torch.from_numpy(G[f"{tag}/target"])).backward()
+    for name, p in net.params.items():
+        assert close(p.grad, golden_grad(G, tag, name)), name
