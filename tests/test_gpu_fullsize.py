@@ -158,3 +158,46 @@ def test_c5_afno_era5_grid_properties(cuda):
     sample_independence(m, kw, tol=1e-5)
     target = torch.randn(2, 1, 8, 720, 1440, generator=torch.Generator().manual_seed(8)).to(cuda)
     directional_check(m, lambda: torch.nn.functional.mse_loss(m(**kw), target))
+
+
+# ---- C5 on the grid BASELINE.json names: 721 x 1440.  The reference PatchEmbed takes per-axis patches
+# (dlwpbench/models/fourcastnet/fourcastnet.py:528-541) and h = H // p (:255), so (7, 8) -> 103 x 180 tokens is the legal
+# 721-row configuration with an ERA5-sized token grid (103 is prime: no radix decomposition, the tiled DFT-GEMM path).
+# patch (1, 1) on this grid is the rFFT2 kernel's job (csrc/fft2d.hip), see test_gpu_fft.py.
+C5_721 = dict(img_height=721, img_width=1440, patch_size=(7, 8), constant_channels=4, prescribed_channels=1,
+              prognostic_channels=8, mlp_ratio=4.0, context_size=1)
+
+
+def test_c5_afno_721x1440_matches_oracle_at_small_width(cuda):
+    """Whole dlwpbench AFNONet on 721 x 1440 (patch (7, 8), 103 x 180 tokens) against the pinned AFNO oracle, embed 16."""
+    from dlwp_benchmark_amd import dlwpbench
+    from oracle import afno_ref
+    torch.manual_seed(15)
+    cfg = dict(C5_721, embed_dim=16, depth=2, num_blocks=4)
+    m = dlwpbench.AFNONet(**cfg)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "filter" in n:
+                p.mul_(10.0)                       # 0.02-scaled mixer weights would hide the spectral path behind the skip
+    kw = dlwp_inputs(1, 2, 8, 721, 1440, 34, "cpu")
+    target = torch.randn(1, 1, 8, 721, 1440, generator=torch.Generator().manual_seed(9))
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    yr = afno_ref.dlwp_afnonet(kw["constants"], kw["prescribed"], kw["prognostic"], p, cfg)
+    torch.nn.functional.mse_loss(yr, target).backward()
+    m = m.to(cuda)
+    y = m(**{k: v.to(cuda) for k, v in kw.items()})
+    assert rel(y, yr) <= 1e-4
+    torch.nn.functional.mse_loss(y, target.to(cuda)).backward()
+    for n, q in m.named_parameters():
+        if q.grad is not None and p[n].grad is not None:
+            assert rel(q.grad, p[n].grad) <= 2e-3, n
+
+
+def test_c5_afno_721x1440_full_width_properties(cuda):
+    from dlwp_benchmark_amd import dlwpbench
+    torch.manual_seed(16)
+    m = dlwpbench.AFNONet(**dict(C5_721, embed_dim=768, depth=2, num_blocks=16)).to(cuda)
+    kw = dlwp_inputs(2, 2, 8, 721, 1440, 35, cuda)
+    sample_independence(m, kw, tol=1e-5)
+    target = torch.randn(2, 1, 8, 721, 1440, generator=torch.Generator().manual_seed(10)).to(cuda)
+    directional_check(m, lambda: torch.nn.functional.mse_loss(m(**kw), target))
