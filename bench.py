@@ -31,6 +31,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (reference: training.batch_size=4)")
+    ap.add_argument("--hidden", type=int, default=None, help="hidden_channels of the fno workload (default 32 = the headline; "
+                    "the published sweep runs 2 ... 217, src/nsbench/scripts/train_commands.txt:83-91)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -103,7 +105,9 @@ def roofline_probe(device, B, reps=300):
             traffic = json.load(open(tpath)).get("fno_spatial_kernel<2,1>")
         except Exception:
             traffic = None
-    return {"bound": "hbm", "kernel": "fno_spatial_kernel<2,1> (forward, inner block)",
+    kname = "fno_spatial_kernel<2,1> (forward, inner block)" if C <= 64 else \
+        "fno_spatial_wide_kernel<0,1> + fno_rows_wide_kernel (forward, inner block)"
+    return {"bound": "hbm", "kernel": kname,
             "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(achieved / PEAK_HBM_GBS, 4), "bytes_per_launch": nbytes,
             "us_per_launch": round(sec * 1e6, 3), "traffic": traffic}
@@ -147,6 +151,50 @@ def mfma_probe(device, B, reps=200):
     return {"bound": "mfma", "kernel": "pwmlp_bwd_kernel<1,2> (lifting MLP backward, slab mode)", "achieved": round(flops / sec / 1e12, 2),
             "peak": PEAK_MFMA_TF["fp32"], "unit": "TFLOP/s", "frac": round(flops / sec / 1e12 / PEAK_MFMA_TF["fp32"], 4),
             "flops_per_launch": flops, "us_per_launch": round(sec * 1e6, 3)}
+
+
+def mix_probe(device, B, reps=300):
+    """Third roofline figure (north_star: MFMA utilisation on the spectral contraction): one forward per-mode launch
+    (fno_mix_fwd_kernel: H-axis step + the mode-truncated complex weight contraction on v_mfma_f32_16x16x4_f32), timed with
+    HIP events on its launch stream.  FLOPs: contraction 8 B C^2 per mode + H-axis step 8 B C H per mode; bytes: the x1
+    slices (read once per kept column in the ideal case), the weights, xhat and y."""
+    import ctypes as C_
+    import torch
+    from dlwp_benchmark_amd import lib as L
+    lib = L.load()
+    w = WORKLOAD
+    C, H, W = w["hidden_channels"], w["H"], w["W"]
+    m1, m2c = w["n_modes"][0], w["n_modes"][1] // 2 + 1
+    plan = C_.c_void_p()
+    L.check(lib.dlwp_fno_plan_create(C, H, W, m1, m2c, C_.byref(plan)))
+    g = torch.Generator().manual_seed(0)
+    x1 = torch.randn(B, H, m2c, C, 2, generator=g).to(device)
+    wspec = (torch.randn(m1, m2c, C, C, 2, generator=g) / C ** 0.5).to(device)
+    xhat = torch.empty(B, m1, m2c, C, 2, device=device)
+    y = torch.empty(B, m1, m2c, C, 2, device=device)
+    stream = torch.cuda.Stream()
+
+    def launch():
+        L.check(lib.dlwp_fno_mix_fwd_probe(plan, L.ptr(x1), L.ptr(wspec), L.ptr(xhat), L.ptr(y), B, stream.cuda_stream))
+    with torch.cuda.stream(stream):
+        for _ in range(20):
+            launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(reps):
+            launch()
+        e1.record(stream)
+        torch.cuda.synchronize()
+    lib.dlwp_fno_plan_destroy(plan)
+    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    modes = m1 * m2c
+    flops = 8.0 * B * C * C * modes + 8.0 * B * C * H * modes
+    nbytes = 8.0 * (B * H * m2c * C + modes * C * C + 2 * B * modes * C)
+    return {"bound": "mfma", "kernel": "fno_mix_fwd_kernel (H-axis step + per-mode complex contraction on MFMA)",
+            "achieved": round(flops / sec / 1e12, 3), "peak": PEAK_MFMA_TF["fp32"], "unit": "TFLOP/s",
+            "frac": round(flops / sec / 1e12 / PEAK_MFMA_TF["fp32"], 5), "flops_per_launch": flops,
+            "bytes_per_launch": nbytes, "GBps": round(nbytes / sec / 1e9, 1), "us_per_launch": round(sec * 1e6, 3)}
 
 
 def cpu_baseline(B, budget_s):
@@ -343,6 +391,9 @@ def main():
             dist.init_process_group(args.backend)
 
     w = WORKLOAD
+    if args.hidden is not None:
+        w["hidden_channels"] = args.hidden
+        w["name"] = w["name"].replace("(BASELINE configs[1])", f"(BASELINE configs[1] at hidden_channels {args.hidden})")
     B = args.batch
     torch.manual_seed(1234)
     model = nsbench.TFNO2DModule(n_modes=w["n_modes"], in_channels=w["in_channels"],
@@ -405,7 +456,9 @@ def main():
         }
         if world == 1 and not args.no_roofline:
             line["roofline"] = roofline_probe(device, B)
-            line["roofline_mfma"] = mfma_probe(device, B)
+            if w["hidden_channels"] <= 64:          # the fused lifting kernel exists for narrow layers only
+                line["roofline_mfma"] = mfma_probe(device, B)
+            line["roofline_mix"] = mix_probe(device, B)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(B, args.cpu_seconds)
         print(json.dumps(line), flush=True)

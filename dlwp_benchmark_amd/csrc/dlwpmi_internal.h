@@ -93,3 +93,43 @@ int dlwp_fold_slabs(const dlwp_fold_job* jobs, int njobs, hipStream_t stream);
 // train_ops.hip -- start of a fused rollout step in one launch: *loss = 0, g_out[0:n] = 0, out[b][0:row] = x[b][0:row]
 int dlwp_rollout_prep(float* loss, float* g_out, long long n, float* out, const float* x, long long out_bs, long long x_bs,
                       long long row, int B, hipStream_t stream);
+
+// token_ops.hip -- the MFMA GEMM with the channels-first extensions of the wide FNO path (fno_wide.hip).
+// C_z[M][N] (+)= epilogue(op(A_z)[M][K] . op(B_z)[K][N]), z < nb, operand z at base + z * s? (0 = shared).  Batches that share
+// the output (sC == 0, nb > 1) and long-K products are combined with float atomics (C zeroed first unless accumulate).
+struct dlwp_gemm_args {
+    const float *A, *B;
+    float* C;
+    int M, N, K, lda, ldb, ldc, transA, transB;
+    int nb;
+    long long sA, sB, sC, sR;
+    const float* bias;       // [N], or [M] when bias_row
+    int bias_row;
+    int act;                 // 0 none, 1 GELU, 4: C = (A.B) * GELU'(residual)
+    float* preact;           // optional store of the value the activation is applied to (C's layout)
+    const float* residual;   // C's layout, stride sR; added before (res_before_act) or after the activation
+    int res_before_act, accumulate;
+    int act_b;               // GELU applied to the B operand on load
+    float* rowsum;           // optional [M]: += sum_k op(A)[m][k] over every batch (bias gradients)
+};
+int dlwp_gemm_run(const dlwp_gemm_args& g, hipStream_t stream);
+
+// fno_wide.hip -- hidden_channels > 64 (the fused kernels keep all channels of a row in LDS and stop at 64)
+inline bool dlwp_fno_is_wide(const dlwp_fno_plan* p) { return p->C_pad > 64; }
+int dlwp_fno_rows_dft_wide(const dlwp_fno_plan* p, const float* x, int act_in, int adjoint, float2* x1, int B,
+                           hipStream_t stream);
+int dlwp_fno_spatial_wide(const dlwp_fno_plan* p, const dlwp_fno_spatial_args* a, hipStream_t stream);
+int dlwp_fno_skip_wgrad(const dlwp_fno_plan* p, const float* g_pre, const float* x, int act_x, float* g_wskip, float* g_bias,
+                        int B, hipStream_t stream);
+int dlwp_gather_channels(const float* const* src_tab, const long long* bstride_tab, float* dense, int B, int C, long long P,
+                         hipStream_t stream);
+int dlwp_scatter_add_channels(float* const* dst_tab, const long long* bstride_tab, const float* dense, int B, int C, long long P,
+                              hipStream_t stream);
+int dlwp_proj_gy(const float* g_out, const float* pred, const float* target, float mse_scale, float* gy, float* gres,
+                 long long bs_out, long long bs_res, long long CP, int B, hipStream_t stream);
+int dlwp_cfmlp_fwd(const float* x, long long x_bs, const float* w1, const float* b1, const float* w2, const float* b2, float* y,
+                   long long y_bs, const float* res, long long res_bs, float* zpre, float* act, int B, int Cin, int Ch, int Cout,
+                   int P, hipStream_t stream);
+int dlwp_cfmlp_bwd(const float* x, long long x_bs, const float* w1, const float* w2, const float* gy, long long gy_bs,
+                   const float* zpre, const float* act, float* gx, long long gx_bs, float* gz, float* gw1, float* gb1, float* gw2,
+                   float* gb2, int B, int Cin, int Ch, int Cout, int P, hipStream_t stream);

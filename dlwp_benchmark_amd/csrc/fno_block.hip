@@ -359,23 +359,6 @@ struct MixDev {
     FastDiv dC, dBC, dBC2;   // exact division by C, B*C, B*C/2 without the ~40-instruction integer divide
 };
 
-// weight slice [C][C] complex -> LDS rows of (C+1) complex (conflict-free row AND column reads)
-__device__ __forceinline__ void mix_stage_w(const float2* wm, float2* ws, int C, FastDiv dC) {
-    const int n2 = C * C / 2;  // pairs of complex numbers (C*C is even whenever C is even)
-    if ((C & 1) == 0) {
-#pragma unroll 4
-        for (int u = threadIdx.x; u < n2; u += MIXT) {
-            const float4 v = reinterpret_cast<const float4*>(wm)[u];
-            const int e = 2 * u, i = fastdiv(e, dC), o = e - i * C;
-            ws[i * (C + 1) + o] = make_float2(v.x, v.y);
-            ws[i * (C + 1) + o + 1] = make_float2(v.z, v.w);
-        }
-    } else {
-#pragma unroll 4
-        for (int e = threadIdx.x; e < C * C; e += MIXT) ws[(e / C) * (C + 1) + e % C] = wm[e];
-    }
-}
-
 // H-axis step, fast path (C even): every thread owns TWO adjacent channels (one 16-byte load per image row) and
 // the rows h = hs, hs+HS, ...; loads are issued in batches of 8 BEFORE the twiddles are needed, so the weight
 // slice, the twiddle row and the first x1 batch share one global-memory latency.
@@ -486,15 +469,116 @@ __device__ __host__ __forceinline__ int mix_split(int outputs, int limit) {
     return s;
 }
 
+// ---- the per-mode complex channel contraction on the matrix cores (exact-f32 v_mfma_f32_16x16x4_f32).
+// A complex product y[b][o] = sum_i x[b][i] w[i][o] is ONE real GEMM with the real and imaginary planes of the SAMPLE side
+// stacked along M and the (re, im) pair of the weight interleaved along K:
+//     rows (b, re) = [ xr_i, -xi_i ]_i      rows (b, im) = [ xi_i, xr_i ]_i      B[k = 2i + ri][n = o] = w[i][o][ri]
+// => 8 B C^2 flops, every weight element read exactly once, M = 2 B rows (8 of the 16 tile rows at the headline batch of 4;
+// full at B >= 8).  The weight slice is read ONCE per workgroup, so it is not staged through LDS at all: every lane fetches its
+// B fragments (two 8-byte loads per 16-deep K chunk, 128 contiguous bytes per 16 lanes) straight from global memory / L2 into
+// registers -- for narrow layers (<= 8 fragments per wave) before the H-axis step, so that the weight latency hides behind it.
+// The same scheme gives the backward products: gx = ghat conj(w)^T (B[k = 2o + ri][n = i] = w[i][o][ri]) and the weight
+// gradient gw[i][o] += sum_b conj(xhat[b][i]) ghat[b][o] (K = 2 B, one 16x16x4 instruction per pair of samples).
+constexpr int MIX_PRE = 8;     // weight fragments a wave may hold before the H-axis step
+
+// A fragment of chunk kc for tile row m = 16 mt + r: element s <-> k = 16 kc + 4 g + s, complex index i = 8 kc + 2 g + s / 2.
+// CONJ = 0: rows (b, re) = (x, -y), (b, im) = (y, x)      [x * w]
+// CONJ = 1: rows (b, re) = (x, y),  (b, im) = (y, -x)     [x * conj(w)]
+template <int CONJ>
+__device__ __forceinline__ f32x4 mix_afrag(const float2* xh, int B, int C, int mt, int kc, int r, int g) {
+    const int m = 16 * mt + r, b = m >> 1, part = m & 1, i0 = 8 * kc + 2 * g;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (b < B) {
+        const float2 v0 = i0 < C ? xh[b * C + i0] : make_float2(0.f, 0.f);
+        const float2 v1 = i0 + 1 < C ? xh[b * C + i0 + 1] : make_float2(0.f, 0.f);
+        if (CONJ == 0) a = part ? f32x4{v0.y, v0.x, v1.y, v1.x} : f32x4{v0.x, -v0.y, v1.x, -v1.y};
+        else a = part ? f32x4{v0.y, -v0.x, v1.y, -v1.x} : f32x4{v0.x, v0.y, v1.x, v1.y};
+    }
+    return a;
+}
+// B fragment of chunk kc for tile column n = 16 nt + r.  TRW = 0: w[i = 8 kc + 2 g (+1)][o = n]; TRW = 1: w[i = n][o = 8 kc + 2 g (+1)].
+// Loads are unconditional from clamped addresses (selects afterwards), so that a group of them is in flight together.
+template <int TRW>
+__device__ __forceinline__ f32x4 mix_bfrag(const float2* wm, int C, int nt, int kc, int r, int g) {
+    const int n = 16 * nt + r, k0 = 8 * kc + 2 * g;
+    const int nc = n < C ? n : C - 1, k0c = k0 < C ? k0 : C - 1, k1c = k0 + 1 < C ? k0 + 1 : C - 1;
+    const float2 w0 = TRW ? wm[(long long)nc * C + k0c] : wm[(long long)k0c * C + nc];
+    const float2 w1 = TRW ? wm[(long long)nc * C + k1c] : wm[(long long)k1c * C + nc];
+    const bool ok0 = n < C && k0 < C, ok1 = n < C && k0 + 1 < C;
+    return f32x4{ok0 ? w0.x : 0.f, ok0 ? w0.y : 0.f, ok1 ? w1.x : 0.f, ok1 ? w1.y : 0.f};
+}
+
+// store one accumulator tile: rows 4g .. 4g+3 = samples 2g, 2g+1 (+ 8 mt), (re, im) each; column n = 16 nt + r
+__device__ __forceinline__ void mix_store_tile(float2* out, long long ostride_b, const f32x4 acc, int B, int C, int nt, int mt,
+                                               int r, int g) {
+    const int n = 16 * nt + r, b0 = 8 * mt + 2 * g;
+    if (n < C) {
+        if (b0 < B) out[(long long)b0 * ostride_b + n] = make_float2(acc[0], acc[1]);
+        if (b0 + 1 < B) out[(long long)(b0 + 1) * ostride_b + n] = make_float2(acc[2], acc[3]);
+    }
+}
+
+// out[b][n] (complex, global, index base + n) = sum over the K chunks of A(xh) . B(w) for every column tile this wave owns
+// (tiles w, w + NW, ...).  have_pre: the fragments of the wave's FIRST tile were fetched before the H-axis step (pre[kc]).
+template <int CONJ, int TRW>
+__device__ __forceinline__ void mix_contract(const float2* xh, const float2* wm, float2* out, long long ostride_b, int B, int C,
+                                             const f32x4 (&pre)[MIX_PRE], bool have_pre) {
+    const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
+    constexpr int NW = MIXT / 64;
+    const int ntn = (C + 15) / 16, nkc = (2 * C + 15) / 16, nmt = (2 * B + 15) / 16;
+    int nt = w;
+    if (have_pre && nt < ntn) {
+        for (int mt = 0; mt < nmt; ++mt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < MIX_PRE; ++q)
+                if (q < nkc) acc = mfma16_chunk(mix_afrag<CONJ>(xh, B, C, mt, q, r, g), pre[q], acc);
+            mix_store_tile(out, ostride_b, acc, B, C, nt, mt, r, g);
+        }
+        nt += NW;
+    }
+    for (; nt < ntn; nt += NW) {
+        for (int mt0 = 0; mt0 < nmt; mt0 += 2) {           // two row tiles share every weight fragment (B > 8)
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+            for (int kc0 = 0; kc0 < nkc; kc0 += 4) {
+                f32x4 bf[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bf[q] = mix_bfrag<TRW>(wm, C, nt, min(kc0 + q, nkc - 1), r, g);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (kc0 + q < nkc) {
+                        acc0 = mfma16_chunk(mix_afrag<CONJ>(xh, B, C, mt0, kc0 + q, r, g), bf[q], acc0);
+                        if (mt0 + 1 < nmt) acc1 = mfma16_chunk(mix_afrag<CONJ>(xh, B, C, mt0 + 1, kc0 + q, r, g), bf[q], acc1);
+                    }
+            }
+            mix_store_tile(out, ostride_b, acc0, B, C, nt, mt0, r, g);
+            if (mt0 + 1 < nmt) mix_store_tile(out, ostride_b, acc1, B, C, nt, mt0 + 1, r, g);
+        }
+    }
+}
+// the fragments of this wave's first column tile (every K chunk), when they fit MIX_PRE registers sets: narrow layers
+template <int TRW>
+__device__ __forceinline__ bool mix_prefetch(const float2* wm, int C, f32x4 (&pre)[MIX_PRE]) {
+    const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
+    const int ntn = (C + 15) / 16, nkc = (2 * C + 15) / 16;
+#pragma unroll
+    for (int q = 0; q < MIX_PRE; ++q) pre[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nkc > MIX_PRE) return false;                       // wide layers stream every fragment inside the loop
+    if (w < ntn) {
+#pragma unroll
+        for (int q = 0; q < MIX_PRE; ++q) pre[q] = mix_bfrag<TRW>(wm, C, w, min(q, nkc - 1), r, g);
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(MIXT) void fno_mix_fwd_kernel(MixDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int BC = a.B * a.C, C = a.C;
-    const int NS = mix_split(BC, a.H < C ? a.H : C);   // partial slots (both phases use <= NS)
+    const int NS = mix_split(BC, a.H < C ? a.H : C);   // partial slots of the generic H-step
     const int NS2 = mix_slots2(a.B, C, a.H);           // partial slots of the two-channels-per-thread H-step
     float2* xh = reinterpret_cast<float2*>(smem);  // [BC]
     float2* part = xh + BC;                        // [max(NS, NS2)][BC]
     float2* tws = part + (NS > NS2 ? NS : NS2) * BC;   // [H]
-    float2* ws = tws + a.H;                        // [C][C+1]
     // XCD-aware mode order: workgroups go round-robin to the 8 XCDs; give every XCD a contiguous range of (kx, j) so that
     // the m1 row frequencies of one column kx -- which read the same x1 slice -- meet in one L2
     int mode = blockIdx.x;
@@ -504,10 +588,12 @@ __global__ __launch_bounds__(MIXT) void fno_mix_fwd_kernel(MixDev a) {
     }
     const int kx = mode / a.m1, j = mode - kx * a.m1;
     const bool fast = (C % 2 == 0) && (BC / 2) * NS2 <= MIXT && NS2 >= 1;
+    const float2* wm = a.wspec + ((long long)(j * a.m2c + kx) * C) * C;
     DLWP_STAMP(16);
     HstepLoads hl;
     if (fast) mix_hstep_issue(a, kx, NS2, hl, 0);            // x1 loads in flight before anything is waited for
-    mix_stage_w(a.wspec + ((long long)(j * a.m2c + kx) * C) * C, ws, C, a.dC);
+    f32x4 pre[MIX_PRE];
+    const bool have_pre = mix_prefetch<0>(wm, C, pre);       // ... and this wave's weight fragments
     for (int i = threadIdx.x; i < a.H; i += MIXT) tws[i] = a.twH[j * a.H + i];
     DLWP_STAMP(17);
     __syncthreads();
@@ -519,45 +605,12 @@ __global__ __launch_bounds__(MIXT) void fno_mix_fwd_kernel(MixDev a) {
     mix_fold(xh, part, BC, hs);
     __syncthreads();
     DLWP_STAMP(21);
+    const long long mofs = ((long long)j * a.m2c + kx) * C, bstr = (long long)a.m1 * a.m2c * C;
     for (int bc = threadIdx.x; bc < BC; bc += MIXT) {
         const int b = fastdiv(bc, a.dC), c = bc - b * C;
-        a.xhat[(((long long)b * a.m1 + j) * a.m2c + kx) * C + c] = xh[bc];
+        a.xhat[b * bstr + mofs + c] = xh[bc];
     }
-    const int IS = mix_split(BC, NS);
-    for (int u = threadIdx.x; u < BC * IS; u += MIXT) {
-        const int is = fastdiv(u, a.dBC), bo = u - is * BC, b = fastdiv(bo, a.dC), o = bo - b * C;
-        float re = 0.f, im = 0.f;
-        for (int i0 = is; i0 < C; i0 += 8 * IS) {
-            float2 xv[8], wv[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int i = i0 + q * IS < C ? i0 + q * IS : is;
-                xv[q] = xh[b * C + i];
-                wv[q] = ws[i * (C + 1) + o];
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (i0 + q * IS < C) {
-                    re += xv[q].x * wv[q].x - xv[q].y * wv[q].y;
-                    im += xv[q].x * wv[q].y + xv[q].y * wv[q].x;
-                }
-        }
-        part[is * BC + bo] = make_float2(re, im);
-    }
-    DLWP_STAMP(22);
-    __syncthreads();
-    DLWP_STAMP(23);
-    for (int bo = threadIdx.x; bo < BC; bo += MIXT) {
-        const int b = fastdiv(bo, a.dC), o = bo - b * C;
-        float2 p[8], v = make_float2(0.f, 0.f);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) p[q] = part[(q < IS ? q : 0) * BC + bo];
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (q < IS) { v.x += p[q].x; v.y += p[q].y; }
-        for (int s2 = 8; s2 < IS; ++s2) { v.x += part[s2 * BC + bo].x; v.y += part[s2 * BC + bo].y; }
-        a.y[(((long long)b * a.m1 + j) * a.m2c + kx) * C + o] = v;
-    }
+    mix_contract<0, 0>(xh, wm, a.y + mofs, bstr, a.B, C, pre, have_pre);
     DLWP_STAMP(24);
 }
 
@@ -570,9 +623,6 @@ __global__ __launch_bounds__(MIXT) void fno_mix_bwd_kernel(MixDev a) {
     float2* xsv = gh + BC;                         // [BC]  saved xhat
     float2* part = xsv + BC;                       // [max(NS, NS2)][BC]
     float2* tws = part + (NS > NS2 ? NS : NS2) * BC;   // [H]
-    float2* ws = tws + a.H;                        // [C][C+1]
-    // XCD-aware mode order: workgroups go round-robin to the 8 XCDs; give every XCD a contiguous range of (kx, j) so that
-    // the m1 row frequencies of one column kx -- which read the same x1 slice -- meet in one L2
     int mode = blockIdx.x;
     {
         const int nm = gridDim.x, full = (nm / 8) * 8;
@@ -581,13 +631,16 @@ __global__ __launch_bounds__(MIXT) void fno_mix_bwd_kernel(MixDev a) {
     const int kx = mode / a.m1, j = mode - kx * a.m1;
     const long long wofs = ((long long)(j * a.m2c + kx) * C) * C;
     const bool fast = (C % 2 == 0) && (BC / 2) * NS2 <= MIXT && NS2 >= 1;
+    const float2* wm = a.wspec + wofs;
     HstepLoads hl;
     if (fast) mix_hstep_issue(a, kx, NS2, hl, 0);
-    mix_stage_w(a.wspec + wofs, ws, C, a.dC);
+    f32x4 pre[MIX_PRE];
+    const bool have_pre = mix_prefetch<1>(wm, C, pre);
     for (int i = threadIdx.x; i < a.H; i += MIXT) tws[i] = a.twH[j * a.H + i];
+    const long long mofs = ((long long)j * a.m2c + kx) * C, bstr = (long long)a.m1 * a.m2c * C;
     for (int bc = threadIdx.x; bc < BC; bc += MIXT) {
         const int b = fastdiv(bc, a.dC), c = bc - b * C;
-        xsv[bc] = a.xhat_in[(((long long)b * a.m1 + j) * a.m2c + kx) * C + c];
+        xsv[bc] = a.xhat_in[b * bstr + mofs + c];
     }
     float2* gw = a.g_wspec + wofs;  // this workgroup owns the mode's weight-gradient slice
     __syncthreads();
@@ -595,60 +648,41 @@ __global__ __launch_bounds__(MIXT) void fno_mix_bwd_kernel(MixDev a) {
     __syncthreads();
     mix_fold(gh, part, BC, hs);
     __syncthreads();
-    const int OS = mix_split(BC, NS);
-    for (int u = threadIdx.x; u < BC * OS; u += MIXT) {
-        const int os = fastdiv(u, a.dBC), bi = u - os * BC, b = fastdiv(bi, a.dC), i = bi - b * C;
-        float re = 0.f, im = 0.f;
-        for (int o0 = os; o0 < C; o0 += 8 * OS) {
-            float2 gv[8], wv[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int o = o0 + q * OS < C ? o0 + q * OS : os;
-                gv[q] = gh[b * C + o];
-                wv[q] = ws[i * (C + 1) + o];
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (o0 + q * OS < C) {
-                    re += gv[q].x * wv[q].x + gv[q].y * wv[q].y;   // g * conj(w)
-                    im += gv[q].y * wv[q].x - gv[q].x * wv[q].y;
-                }
-        }
-        part[os * BC + bi] = make_float2(re, im);
-    }
-    // gw[i][o] += sum_b conj(xhat[b][i]) * ghat[b][o]
-#pragma unroll 2
-    for (int idx = threadIdx.x; idx < C * C; idx += MIXT) {
-        const int i = fastdiv(idx, a.dC), o = idx - i * C;
-        float2 cur = gw[idx];
-        for (int b0 = 0; b0 < a.B; b0 += 4) {
-            float2 xv[4], gv[4];
+    // gx[b][i] = sum_o ghat[b][o] conj(w[i][o])
+    mix_contract<1, 1>(gh, wm, a.y + mofs, bstr, a.B, C, pre, have_pre);
+    // gw[i][o] += sum_b conj(xhat[b][i]) ghat[b][o]: tile [16 i x 16 o], K = 2 B, k = 2 b' + ri on the lane group g
+    {
+        const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
+        constexpr int NW = MIXT / 64;
+        const int nt = (C + 15) / 16, ri = g & 1;
+        // tiles are dealt from the LAST wave downwards: the first waves are busy with the gx column tiles above
+        for (int t = NW - 1 - w; t < nt * nt; t += NW) {
+            const int it = t / nt, ot = t - it * nt;
+            const int i = 16 * it + r, o = 16 * ot + r;          // A row (i) / B column (o) of this lane
+            float2 old[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int b = b0 + q < a.B ? b0 + q : 0;
-                xv[q] = xsv[b * C + i];
-                gv[q] = gh[b * C + o];
+                const int io = min(16 * it + 4 * g + q, C - 1);
+                old[q] = gw[(long long)io * C + min(o, C - 1)];
             }
+            f32x4 are = {0.f, 0.f, 0.f, 0.f}, aim = {0.f, 0.f, 0.f, 0.f};
+            for (int b0 = 0; b0 < a.B; b0 += 2) {
+                const int b = b0 + (g >> 1);
+                const bool okb = b < a.B;
+                const float2 xv = (okb && i < C) ? xsv[b * C + i] : make_float2(0.f, 0.f);
+                const float2 gv = (okb && o < C) ? gh[b * C + o] : make_float2(0.f, 0.f);
+                const float av = ri ? xv.y : xv.x;
+                are = mfma16(av, ri ? gv.y : gv.x, are);         // xr gr + xi gi
+                aim = mfma16(av, ri ? -gv.x : gv.y, aim);        // xr gi - xi gr
+            }
+            if (o < C) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (b0 + q < a.B) {
-                    cur.x += xv[q].x * gv[q].x + xv[q].y * gv[q].y;
-                    cur.y += xv[q].x * gv[q].y - xv[q].y * gv[q].x;
+                for (int q = 0; q < 4; ++q) {
+                    const int io = 16 * it + 4 * g + q;
+                    if (io < C) gw[(long long)io * C + o] = make_float2(old[q].x + are[q], old[q].y + aim[q]);
                 }
+            }
         }
-        gw[idx] = cur;
-    }
-    __syncthreads();
-    for (int bi = threadIdx.x; bi < BC; bi += MIXT) {
-        const int b = fastdiv(bi, a.dC), i = bi - b * C;
-        float2 p[8], v = make_float2(0.f, 0.f);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) p[q] = part[(q < OS ? q : 0) * BC + bi];
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (q < OS) { v.x += p[q].x; v.y += p[q].y; }
-        for (int s2 = 8; s2 < OS; ++s2) { v.x += part[s2 * BC + bi].x; v.y += part[s2 * BC + bi].y; }
-        a.y[(((long long)b * a.m1 + j) * a.m2c + kx) * C + i] = v;
     }
 }
 
@@ -672,7 +706,7 @@ extern "C" int dlwp_fno_plan_create(int C, int H, int W, int m1, int m2c, dlwp_f
     DLWP_REQUIRE(W % 16 == 0, DLWP_E_UNSUPPORTED, "fno_plan_create: W must be a multiple of 16 (got %d)", W);
     DLWP_REQUIRE(H % 2 == 0, DLWP_E_UNSUPPORTED, "fno_plan_create: H must be even (got %d)", H);
     DLWP_REQUIRE(m1 <= H && m2c <= W / 2 + 1, DLWP_E_INVALID, "fno_plan_create: more modes than the grid has");
-    DLWP_REQUIRE(C <= 64, DLWP_E_UNSUPPORTED, "fno_plan_create: hidden_channels <= 64 supported (got %d)", C);
+    DLWP_REQUIRE(C <= 1024, DLWP_E_UNSUPPORTED, "fno_plan_create: hidden_channels <= 1024 supported (got %d)", C);
     DLWP_REQUIRE(2 * m2c <= 32, DLWP_E_UNSUPPORTED, "fno_plan_create: n_modes[1]/2+1 <= 16 supported (got %d)", m2c);
     dlwp_fno_plan* p = new dlwp_fno_plan();
     p->C = C; p->H = H; p->W = W; p->m1 = m1; p->m2c = m2c;
@@ -746,6 +780,7 @@ extern "C" size_t dlwp_fno_block_workspace_bytes(const dlwp_fno_plan* p, int B) 
 
 int dlwp_fno_rows_dft(const dlwp_fno_plan* p, const float* x, int act_in, int adjoint, float2* x1, int B,
                       hipStream_t stream) {
+    if (dlwp_fno_is_wide(p)) return dlwp_fno_rows_dft_wide(p, x, act_in, adjoint, x1, B, stream);
     RowsDev a{x, x1, adjoint ? p->FT_adj : p->FT_fwd, act_in, p->C, p->H, p->W, p->m2c, p->C_pad, p->NP};
     const int LDP = p->W + 4;
     const size_t lds = sizeof(float) * ((size_t)p->C_pad * LDP + (size_t)p->NP * LDP + (size_t)4 * p->C_pad * p->NP);
@@ -768,7 +803,7 @@ static int mix_launch(const dlwp_fno_plan* p, bool bwd, MixDev& a, hipStream_t s
     if (ns > lim) ns = lim;
     const int ns2 = mix_slots2(a.B, a.C, a.H);
     if (ns2 > ns) ns = ns2;
-    const size_t lds = sizeof(float2) * ((size_t)BC * ((bwd ? 2 : 1) + ns) + a.H + (size_t)a.C * (a.C + 1));
+    const size_t lds = sizeof(float2) * ((size_t)BC * ((bwd ? 2 : 1) + ns) + a.H);
     const dim3 grid(p->m1 * p->m2c), block(MIXT);
     int rc;
     if (bwd) {
@@ -797,6 +832,17 @@ int dlwp_fno_mix_bwd(const dlwp_fno_plan* p, const float2* g1, const float2* wsp
 }
 
 int dlwp_fno_spatial(const dlwp_fno_plan* p, const dlwp_fno_spatial_args* s, hipStream_t stream) {
+    if (dlwp_fno_is_wide(p)) {
+        // channel-blocked form: the fused by-products (next block's row DFT, skip-weight / bias gradients) are separate launches
+        int rc = dlwp_fno_spatial_wide(p, s, stream);
+        if (rc) return rc;
+        if (s->inverse_adjoint && (s->g_wskip || s->g_bias)) {
+            DLWP_REQUIRE(s->g_wskip && s->g_bias && !s->gslab, DLWP_E_INVALID, "fno_spatial (wide): needs g_wskip and g_bias, no slab");
+            if ((rc = dlwp_fno_skip_wgrad(p, s->tin, s->pprev, s->act_prev, s->g_wskip, s->g_bias, s->B, stream))) return rc;
+        }
+        if (s->x1_out) return dlwp_fno_rows_dft_wide(p, s->out, s->x1_act, s->x1_adjoint, s->x1_out, s->B, stream);
+        return DLWP_OK;
+    }
     SpatialDev a{};
     a.tin = s->tin; a.spec = s->spec; a.wskip = s->wskip; a.bias = s->bias; a.pprev = s->pprev;
     a.out = s->out; a.x1_out = s->x1_out; a.g_wskip = s->g_wskip; a.g_bias = s->g_bias;
@@ -892,4 +938,13 @@ extern "C" int dlwp_fno_spatial_fwd_probe(const dlwp_fno_plan* p, const float* x
     s.tin = x; s.act_tin = 1; s.spec = reinterpret_cast<const float2*>(spec); s.wskip = wskip; s.bias = bias;
     s.out = pre; s.x1_out = reinterpret_cast<float2*>(x1_out); s.x1_act = 1; s.B = B;
     return dlwp_fno_spatial(p, &s, static_cast<hipStream_t>(stream));
+}
+
+// one forward per-mode launch (H-axis step + complex channel contraction on MFMA) exactly as the rollout issues it; exposed
+// so bench.py can time the spectral contraction with HIP events (roofline_mix)
+extern "C" int dlwp_fno_mix_fwd_probe(const dlwp_fno_plan* p, const float* x1, const float* wspec, float* xhat, float* y, int B,
+                                      void* stream) {
+    DLWP_REQUIRE(p && x1 && wspec && xhat && y && B > 0, DLWP_E_INVALID, "mix_fwd_probe: NULL argument");
+    return dlwp_fno_mix_fwd(p, reinterpret_cast<const float2*>(x1), reinterpret_cast<const float2*>(wspec),
+                            reinterpret_cast<float2*>(xhat), reinterpret_cast<float2*>(y), B, static_cast<hipStream_t>(stream));
 }

@@ -40,6 +40,13 @@ struct dlwp_fno_trainer {
     float *gA = nullptr, *gB = nullptr;      // work [B,C,H,W]
     float *slab_lift = nullptr, *slab_proj = nullptr;  // per-workgroup parameter-gradient partials
     float* slab_skip = nullptr;                        // [n_layers][B*H][gslab_stride] skip-weight / bias partials
+    // wide layers (hidden > 64, fno_wide.hip): dense lifting inputs and the stored hidden activations of both MLPs
+    bool wide = false;
+    float *xin = nullptr;                    // [ncalls][B][Cin][HW]
+    float *zl = nullptr, *al = nullptr;      // [ncalls][B][lifting][HW]   pre-activation / GELU of the lifting MLP
+    float *zp = nullptr, *ap = nullptr;      // [ncalls][B][projection][HW]
+    float *gz = nullptr;                     // work [B][max(lifting, projection)][HW]
+    float *gyb = nullptr, *gxin = nullptr;   // work [B][D][HW], [B][Cin][HW]
     const float** src_tab = nullptr;         // [ncalls][Cin]
     float** gdst_tab = nullptr;              // [ncalls][Cin]
     long long* bstride_tab = nullptr;        // [ncalls][Cin]
@@ -147,6 +154,34 @@ int enqueue_forward(dlwp_fno_trainer* tr, bool keep, hipStream_t s, bool fused =
         float* h0 = tr->h0 + kk * actB;
         float* pre = tr->pre + (long long)kk * NL * actB;
         float2* xhat = tr->xhat + (long long)kk * NL * xhatB;
+        if (tr->wide) {
+            // channel-blocked kernels + channels-first GEMM MLPs (fno_wide.hip); same dataflow as below
+            const long long xinB = (long long)c.B * tr->Cin * HW, zlB = (long long)c.B * c.lifting * HW,
+                            zpB = (long long)c.B * c.projection * HW;
+            float* xin = tr->xin + kk * xinB;
+            if ((rc = dlwp_gather_channels(tr->src_tab + (long long)k * tr->Cin, tr->bstride_tab + (long long)k * tr->Cin, xin,
+                                           c.B, tr->Cin, HW, s))) return rc;
+            if ((rc = dlwp_cfmlp_fwd(xin, (long long)tr->Cin * HW, w.lw1, w.lb1, w.lw2, w.lb2, h0, tr->act, nullptr, 0,
+                                     tr->zl + kk * zlB, tr->al + kk * zlB, c.B, tr->Cin, c.lifting, C, HW, s))) return rc;
+            if ((rc = dlwp_fno_rows_dft(tr->plan, h0, 0, 0, tr->x1, c.B, s))) return rc;
+            for (int l = 0; l < NL; ++l) {
+                if ((rc = dlwp_fno_mix_fwd(tr->plan, tr->x1, reinterpret_cast<const float2*>(w.spec(l)),
+                                           xhat + l * xhatB, tr->spec, c.B, s))) return rc;
+                dlwp_fno_spatial_args a{};
+                a.tin = l == 0 ? h0 : pre + (l - 1) * actB;
+                a.act_tin = l > 0;
+                a.spec = tr->spec; a.wskip = w.skip(l); a.bias = w.bias(l);
+                a.out = pre + l * actB;
+                a.x1_out = l < NL - 1 ? tr->x1 : nullptr;
+                a.x1_act = 1;
+                a.B = c.B;
+                if ((rc = dlwp_fno_spatial(tr->plan, &a, s))) return rc;
+            }
+            if ((rc = dlwp_cfmlp_fwd(pre + (NL - 1) * actB, tr->act, w.pw1, w.pb1, w.pw2, w.pb2,
+                                     tr->out + (long long)ci.out_slot * tr->frame, tr->traj_out, ci.res, ci.res_bs,
+                                     tr->zp + kk * zpB, tr->ap + kk * zpB, c.B, C, c.projection, c.out_channels, HW, s))) return rc;
+            continue;
+        }
         dlwp_chan_src xs{nullptr, 0, 0, tr->src_tab + (long long)k * tr->Cin, tr->bstride_tab + (long long)k * tr->Cin};
         dlwp_chan_dst h0d{h0, tr->act, HW, nullptr, nullptr};
         // lifting MLP with the first block's W-axis DFT in its epilogue where the shapes allow (one launch less per net
@@ -203,6 +238,39 @@ int enqueue_loss_backward(dlwp_fno_trainer* tr, const float* grad_out, hipStream
         float* pre = tr->pre + (long long)k * NL * actB;
         float2* xhat = tr->xhat + (long long)k * NL * xhatB;
         float *gcur = tr->gA, *gnext = tr->gB;
+        if (tr->wide) {
+            const long long xinB = (long long)c.B * tr->Cin * HW, zlB = (long long)c.B * c.lifting * HW,
+                            zpB = (long long)c.B * c.projection * HW, CP = (long long)c.out_channels * HW;
+            // upstream of the projection = accumulated closed-loop gradient + d MSE / d out[t]; identity path of the residual
+            if ((rc = dlwp_proj_gy(tr->g_out + oofs, grad_out ? nullptr : tr->out + oofs, grad_out ? nullptr : tr->y + oofs,
+                                   mse_scale, tr->gyb, ci.gres, tr->traj_out, ci.gres_bs, CP, c.B, s))) return rc;
+            if ((rc = dlwp_cfmlp_bwd(pre + (NL - 1) * actB, tr->act, w.pw1, w.pw2, tr->gyb, CP, tr->zp + k * zpB,
+                                     tr->ap + k * zpB, gcur, tr->act, tr->gz, g.pw1, g.pb1, g.pw2, g.pb2, c.B, C, c.projection,
+                                     c.out_channels, HW, s))) return rc;
+            if ((rc = dlwp_fno_rows_dft(tr->plan, gcur, 0, 1, tr->x1, c.B, s))) return rc;
+            for (int l = NL - 1; l >= 0; --l) {
+                if ((rc = dlwp_fno_mix_bwd(tr->plan, tr->x1, reinterpret_cast<const float2*>(w.spec(l)),
+                                           xhat + l * xhatB, tr->spec, reinterpret_cast<float2*>(g.spec(l)), c.B, s))) return rc;
+                dlwp_fno_spatial_args a{};
+                a.tin = gcur; a.spec = tr->spec; a.wskip = w.skip(l); a.transpose_w = 1;
+                a.pprev = l == 0 ? h0 : pre + (l - 1) * actB;
+                a.act_prev = l > 0;
+                a.out = gnext;
+                a.x1_out = l > 0 ? tr->x1 : nullptr;
+                a.x1_adjoint = 1;
+                a.g_wskip = g.skip(l); a.g_bias = g.bias(l);
+                a.inverse_adjoint = 1;
+                a.B = c.B;
+                if ((rc = dlwp_fno_spatial(tr->plan, &a, s))) return rc;
+                float* tmp = gcur; gcur = gnext; gnext = tmp;
+            }
+            if ((rc = dlwp_cfmlp_bwd(tr->xin + k * xinB, (long long)tr->Cin * HW, w.lw1, w.lw2, gcur, tr->act, tr->zl + k * zlB,
+                                     tr->al + k * zlB, tr->gxin, (long long)tr->Cin * HW, tr->gz, g.lw1, g.lb1, g.lw2, g.lb2, c.B,
+                                     tr->Cin, c.lifting, C, HW, s))) return rc;
+            if ((rc = dlwp_scatter_add_channels(tr->gdst_tab + (long long)k * tr->Cin, tr->bstride_tab + (long long)k * tr->Cin,
+                                                tr->gxin, c.B, tr->Cin, HW, s))) return rc;
+            continue;
+        }
         // projection backward; upstream = accumulated closed-loop gradient + d MSE / d out[t]
         dlwp_chan_src ps{pre + (NL - 1) * actB, tr->act, HW, nullptr, nullptr};
         dlwp_chan_src gy{tr->g_out + oofs, tr->traj_out, HW, nullptr, nullptr};
@@ -241,6 +309,7 @@ int enqueue_loss_backward(dlwp_fno_trainer* tr, const float* grad_out, hipStream
                                     g.lw2, g.lb2, tr->slab_lift, k != tr->ncalls - 1, c.B, tr->Cin, c.lifting, C,
                                     HW, s))) return rc;
     }
+    if (tr->wide) return DLWP_OK;       // the GEMMs accumulated straight into the gradient buffer
     // fold the per-workgroup partial slabs of all net calls into the gradient buffer: one launch when the job table holds
     // them all (n_layers + 2 jobs), otherwise layer by layer
     const int nslab = dlwp_pwmlp_slab_count(c.B, HW);
@@ -310,16 +379,28 @@ extern "C" int dlwp_fno_trainer_create(const dlwp_fno_cfg* cfg, dlwp_fno_trainer
     tr->act = (long long)c.hidden * c.H * c.W;
     const size_t n = (size_t)c.B * tr->traj_out, actB = (size_t)c.B * tr->act;
     const size_t xhatB = (size_t)c.B * c.m1 * c.m2c * c.hidden;
+    tr->wide = dlwp_fno_is_wide(tr->plan);
+    if (tr->wide) {
+        const size_t HW = (size_t)c.H * c.W, nc = (size_t)tr->ncalls;
+        if ((rc = dmalloc(&tr->xin, nc * c.B * tr->Cin * HW)) || (rc = dmalloc(&tr->zl, nc * c.B * c.lifting * HW)) ||
+            (rc = dmalloc(&tr->al, nc * c.B * c.lifting * HW)) || (rc = dmalloc(&tr->zp, nc * c.B * c.projection * HW)) ||
+            (rc = dmalloc(&tr->ap, nc * c.B * c.projection * HW)) ||
+            (rc = dmalloc(&tr->gz, (size_t)c.B * std::max(c.lifting, c.projection) * HW)) ||
+            (rc = dmalloc(&tr->gyb, (size_t)c.B * c.out_channels * HW)) || (rc = dmalloc(&tr->gxin, (size_t)c.B * tr->Cin * HW))) {
+            dlwp_fno_trainer_destroy(tr);
+            return rc;
+        }
+    }
     if ((rc = dmalloc(&tr->g_out, n)) ||
         (rc = dmalloc(&tr->h0, actB * tr->ncalls)) || (rc = dmalloc(&tr->pre, actB * tr->ncalls * c.n_layers)) ||
         (rc = dmalloc(&tr->xhat, xhatB * tr->ncalls * c.n_layers)) ||
         (rc = dmalloc(&tr->x1, (size_t)c.B * c.H * c.m2c * c.hidden)) || (rc = dmalloc(&tr->spec, xhatB)) ||
         (rc = dmalloc(&tr->gA, actB)) || (rc = dmalloc(&tr->gB, actB)) ||
-        (rc = dmalloc(&tr->slab_skip, (size_t)c.n_layers * c.B * c.H * dlwp_fno_gslab_stride(c.hidden))) ||
-        (rc = dmalloc(&tr->slab_lift, (size_t)dlwp_pwmlp_slab_count(c.B, c.H * c.W) *
-                                          dlwp_pwmlp_slab_stride(tr->Cin, c.lifting, c.hidden))) ||
-        (rc = dmalloc(&tr->slab_proj, (size_t)dlwp_pwmlp_slab_count(c.B, c.H * c.W) *
-                                          dlwp_pwmlp_slab_stride(c.hidden, c.projection, c.out_channels))) ||
+        (!tr->wide && ((rc = dmalloc(&tr->slab_skip, (size_t)c.n_layers * c.B * c.H * dlwp_fno_gslab_stride(c.hidden))) ||
+                       (rc = dmalloc(&tr->slab_lift, (size_t)dlwp_pwmlp_slab_count(c.B, c.H * c.W) *
+                                                         dlwp_pwmlp_slab_stride(tr->Cin, c.lifting, c.hidden))) ||
+                       (rc = dmalloc(&tr->slab_proj, (size_t)dlwp_pwmlp_slab_count(c.B, c.H * c.W) *
+                                                         dlwp_pwmlp_slab_stride(c.hidden, c.projection, c.out_channels))))) ||
         (rc = dmalloc(&tr->src_tab, (size_t)tr->ncalls * tr->Cin)) ||
         (rc = dmalloc(&tr->gdst_tab, (size_t)tr->ncalls * tr->Cin)) || (rc = dmalloc(&tr->bstride_tab, (size_t)tr->ncalls * tr->Cin))) {
         dlwp_fno_trainer_destroy(tr);
@@ -425,7 +506,8 @@ extern "C" void dlwp_fno_trainer_destroy(dlwp_fno_trainer* tr) {
     if (tr->cap_stream) (void)hipStreamDestroy(tr->cap_stream);
     dlwp_fno_plan_destroy(tr->plan);
     void* bufs[] = {tr->slab_skip, tr->slab_lift, tr->slab_proj, tr->g_out, tr->h0, tr->pre, tr->xhat, tr->x1, tr->spec,
-                    tr->gA, tr->gB, (void*)tr->src_tab, (void*)tr->gdst_tab, tr->bstride_tab};
+                    tr->gA, tr->gB, (void*)tr->src_tab, (void*)tr->gdst_tab, tr->bstride_tab, tr->xin, tr->zl, tr->al, tr->zp,
+                    tr->ap, tr->gz, tr->gyb, tr->gxin};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     delete tr;

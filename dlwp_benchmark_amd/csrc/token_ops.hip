@@ -16,6 +16,7 @@
 // flight while step i runs on the matrix cores, one barrier per step.  Reductions over the token
 // dimension (gW: K = tokens, few output tiles) are split along K across workgroups (grid.z) and
 // combined with float atomics into a zeroed C.
+#include <algorithm>
 #include <cstdlib>
 #include "common.cuh"
 #include "dlwpmi_internal.h"
@@ -41,6 +42,11 @@ struct GemmDev {
     int vec_epi;               // epilogue through an LDS tile with 16-byte global accesses (alignment checked on the host)
     long long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2, sBi1, sBi2;
     float act_param;           // soft-shrink threshold (act == 3)
+    // channels-first extensions (the wide FNO path, fno_wide.hip: C[out channel][pixel] = W . X per sample)
+    int bias_row;              // bias indexed by the output ROW m (1x1 convolution on [C, H*W] fields) instead of the column
+    int act_b;                 // GELU applied to the B operand when its tile is committed to LDS (weight gradient of a layer
+                               // whose input was activated on load: gW = g . gelu(x)^T without a stored gelu(x))
+    int atomic_out;            // every workgroup ADDS its tile with float atomics (batches that share one output matrix)
 };
 
 // bf16-operand mode (dlwp_set_gemm_precision(1)): operands are rounded to bf16 when a tile is committed to LDS and
@@ -104,6 +110,10 @@ struct TileIO {
                 v[q] = ok ? base[off] : 0.f;
             }
         }
+    }
+    __device__ __forceinline__ void apply_gelu() {
+#pragma unroll
+        for (int q = 0; q < 8 * T * KM; ++q) v[q] = gelu_f(v[q]);      // gelu(0) = 0: out-of-range zeros stay zero
     }
     __device__ __forceinline__ void store(float* S) const {
         static_assert(BKT == BK, "the fp32 LDS images are laid out for the 32-deep K-step");
@@ -182,7 +192,8 @@ __device__ __forceinline__ void gemm_rowsum_flush(const GemmDev& a, const float 
     }
 }
 
-template <bool AKC, bool BKC, bool VEC, int T, bool BF>
+// VEC bit 0: 16-byte loads for the A tile, bit 1: for the B tile (alignment checked per operand on the host)
+template <bool AKC, bool BKC, int VEC, int T, bool BF>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     constexpr int BMN = Tile<T>::ROWS, NT16 = 2 * T;   // 16-row MFMA tiles per wave and direction
@@ -231,12 +242,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
     float rsum[NT16];                // sum over k of op(A) rows wm + 16 i + r (this lane's k slots)
 #pragma unroll
     for (int i = 0; i < NT16; ++i) rsum[i] = 0.f;
-    TileIO<AKC, VEC, T, BKT> ta;
-    TileIO<BKC, VEC, T, BKT> tb;
+    constexpr bool VA = (VEC & 1) != 0, VB = (VEC & 2) != 0;
+    TileIO<AKC, VA, T, BKT> ta;
+    TileIO<BKC, VB, T, BKT> tb;
     const int nk = (kend - kbeg + BKT - 1) / BKT;
     DLWP_STAMP(0);
     ta.load(a.A, a.lda, m0, a.M, kbeg, kend);
     tb.load(a.B, a.ldb, n0, a.N, kbeg, kend);
+    if (a.act_b) tb.apply_gelu();
     if constexpr (BF) {
         ta.store_bf16(reinterpret_cast<__bf16*>(As));
         tb.store_bf16(reinterpret_cast<__bf16*>(Bs));
@@ -259,9 +272,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
             for (int c = 0; c < BKT / 32; ++c) {
                 bf16x8 af[NT16], bf[NT16];
 #pragma unroll
-                for (int i = 0; i < NT16; ++i) af[i] = TileIO<AKC, VEC, T, BKT>::frag_bf16(reinterpret_cast<const __bf16*>(As + cur * TF), wm + 16 * i, c, r, g);
+                for (int i = 0; i < NT16; ++i) af[i] = TileIO<AKC, VA, T, BKT>::frag_bf16(reinterpret_cast<const __bf16*>(As + cur * TF), wm + 16 * i, c, r, g);
 #pragma unroll
-                for (int j = 0; j < NT16; ++j) bf[j] = TileIO<BKC, VEC, T, BKT>::frag_bf16(reinterpret_cast<const __bf16*>(Bs + cur * TF), wn + 16 * j, c, r, g);
+                for (int j = 0; j < NT16; ++j) bf[j] = TileIO<BKC, VB, T, BKT>::frag_bf16(reinterpret_cast<const __bf16*>(Bs + cur * TF), wn + 16 * j, c, r, g);
 #pragma unroll
                 for (int i = 0; i < NT16; ++i) {
                     if (a.rowsum) {
@@ -277,9 +290,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
         for (int c = 0; c < 2; ++c) {
             f32x4 af[NT16], bf[NT16];
 #pragma unroll
-            for (int i = 0; i < NT16; ++i) af[i] = TileIO<AKC, VEC, T, BKT>::frag(As + cur * TF, wm + 16 * i, c, r, g);
+            for (int i = 0; i < NT16; ++i) af[i] = TileIO<AKC, VA, T, BKT>::frag(As + cur * TF, wm + 16 * i, c, r, g);
 #pragma unroll
-            for (int j = 0; j < NT16; ++j) bf[j] = TileIO<BKC, VEC, T, BKT>::frag(Bs + cur * TF, wn + 16 * j, c, r, g);
+            for (int j = 0; j < NT16; ++j) bf[j] = TileIO<BKC, VB, T, BKT>::frag(Bs + cur * TF, wn + 16 * j, c, r, g);
 #pragma unroll
             for (int i = 0; i < NT16; ++i) {
                 rsum[i] += (af[i][0] + af[i][1]) + (af[i][2] + af[i][3]);
@@ -288,6 +301,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
             }
         }
         if (it + 1 < nk) {
+            if (a.act_b) tb.apply_gelu();
             if constexpr (BF) {
                 ta.store_bf16(reinterpret_cast<__bf16*>(As + (cur ^ 1) * TF));
                 tb.store_bf16(reinterpret_cast<__bf16*>(Bs + (cur ^ 1) * TF));
@@ -317,13 +331,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
             const int tid = threadIdx.x, c4 = tid & 15;
             const int n = n0 + 4 * c4;
             f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (a.bias && n < a.N) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+            if (a.bias && !a.bias_row && n < a.N) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
                 const int row = (tid >> 4) + 16 * pass, m = m0 + row;
                 if (m < a.M && n < a.N) {
                     const long long o = (long long)m * a.ldc + n;
                     f32x4 v = *reinterpret_cast<const f32x4*>(&tile[row * LDE + 4 * c4]);
+                    if (a.bias && a.bias_row) { const float br = a.bias[m]; bv = f32x4{br, br, br, br}; }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] += bv[k];
                     f32x4 rv = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -366,8 +381,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
                 if (m < a.M && n < a.N) {
                     const long long o = (long long)m * a.ldc + n;
                     float v = acc[i][j][q];
-                    if (a.splits > 1) { atomic_add_f32(&a.C[o], v); continue; }   // C zeroed (or accumulate)
-                    if (a.bias) v += a.bias[n];
+                    if (a.splits > 1 || a.atomic_out) { atomic_add_f32(&a.C[o], v); continue; }   // C zeroed (or accumulate)
+                    if (a.bias) v += a.bias[a.bias_row ? m : n];
                     if (a.act == ACT_GELU_GRAD_MUL) {
                         v *= gelu_grad_f(a.residual[o]);
                     } else {
@@ -381,7 +396,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
             }
 }
 
-template <bool AKC, bool BKC, bool VEC, int T, bool BF>
+template <bool AKC, bool BKC, int VEC, int T, bool BF>
 int gemm_launch_t(const GemmDev& a, dim3 grid, hipStream_t s) {
     constexpr int RW = Tile<T>::ROWS;
     const size_t lds = BF ? sizeof(float) * 4 * ((RW * LDKB > BKB * (RW + 8) ? RW * LDKB : BKB * (RW + 8)) / 2)
@@ -395,18 +410,29 @@ int gemm_launch_t(const GemmDev& a, dim3 grid, hipStream_t s) {
 int g_gemm_bf16 = 0;    // dlwp_set_gemm_precision
 
 template <bool AKC, bool BKC>
-int gemm_launch(const GemmDev& a_in, bool vec, int T, hipStream_t s) {
+int gemm_launch(const GemmDev& a_in, int vec, int T, hipStream_t s) {
     const int edge = 64 * T;
     GemmDev a = a_in;
     a.ntn = ceil_div(a.N, edge);
     a.ntm = ceil_div(a.M, edge);
     const dim3 grid(a.ntn * a.ntm, 1, a.nbatch * a.splits);
-    if (g_gemm_bf16) {
-        if (T == 2) return vec ? gemm_launch_t<AKC, BKC, true, 2, true>(a, grid, s) : gemm_launch_t<AKC, BKC, false, 2, true>(a, grid, s);
-        return vec ? gemm_launch_t<AKC, BKC, true, 1, true>(a, grid, s) : gemm_launch_t<AKC, BKC, false, 1, true>(a, grid, s);
+    if (T == 2 && vec != 3) vec = 0;      // the 128-wide tile exists for fully aligned operands only
+#define GEMM_VEC_SWITCH(TT, BFV)                                                          \
+    switch (vec) {                                                                         \
+        case 3: return gemm_launch_t<AKC, BKC, 3, TT, BFV>(a, grid, s);                   \
+        case 2: if (TT == 1) return gemm_launch_t<AKC, BKC, 2, 1, BFV>(a, grid, s);       \
+                return gemm_launch_t<AKC, BKC, 0, TT, BFV>(a, grid, s);                   \
+        case 1: if (TT == 1) return gemm_launch_t<AKC, BKC, 1, 1, BFV>(a, grid, s);       \
+                return gemm_launch_t<AKC, BKC, 0, TT, BFV>(a, grid, s);                   \
+        default: return gemm_launch_t<AKC, BKC, 0, TT, BFV>(a, grid, s);                  \
     }
-    if (T == 2) return vec ? gemm_launch_t<AKC, BKC, true, 2, false>(a, grid, s) : gemm_launch_t<AKC, BKC, false, 2, false>(a, grid, s);
-    return vec ? gemm_launch_t<AKC, BKC, true, 1, false>(a, grid, s) : gemm_launch_t<AKC, BKC, false, 1, false>(a, grid, s);
+    if (g_gemm_bf16) {
+        if (T == 2) { GEMM_VEC_SWITCH(2, true) }
+        GEMM_VEC_SWITCH(1, true)
+    }
+    if (T == 2) { GEMM_VEC_SWITCH(2, false) }
+    GEMM_VEC_SWITCH(1, false)
+#undef GEMM_VEC_SWITCH
 }
 
 // ---- LayerNorm over the last dimension: one wave per row
@@ -563,15 +589,21 @@ static int gemm_tile_for(int M, int N, long long nbatch) {
 }
 
 static int gemm_dispatch(GemmDev& a, int transA, int transB, int T, void* stream) {
-    // 16-byte loads need every row start and every k (or row) group of four to be aligned and whole
-    bool vec = ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.B % 16 == 0) && a.lda % 4 == 0 && a.ldb % 4 == 0 && a.K % 4 == 0 &&
-               (transA ? a.M % 4 == 0 : true) && (transB ? true : a.N % 4 == 0);
-    if (a.nbatch > 1) vec = vec && a.sA1 % 4 == 0 && a.sA2 % 4 == 0 && a.sB1 % 4 == 0 && a.sB2 % 4 == 0;
-    a.vec_epi = T == 1 && a.splits == 1 && a.N % 4 == 0 && a.ldc % 4 == 0 && (uintptr_t)a.C % 16 == 0 &&
-                (!a.bias || (uintptr_t)a.bias % 16 == 0) && (!a.residual || (uintptr_t)a.residual % 16 == 0) &&
+    // 16-byte loads need every row start and every group of four along the contiguous dimension to be aligned and whole;
+    // decided per operand (a weight matrix with an odd row length must not force scalar loads on the activations)
+    bool vecA = ((uintptr_t)a.A % 16 == 0) && a.lda % 4 == 0 && (transA ? a.M % 4 == 0 : a.K % 4 == 0);
+    bool vecB = ((uintptr_t)a.B % 16 == 0) && a.ldb % 4 == 0 && (transB ? a.K % 4 == 0 : a.N % 4 == 0);
+    if (a.nbatch > 1) {
+        vecA = vecA && a.sA1 % 4 == 0 && a.sA2 % 4 == 0;
+        vecB = vecB && a.sB1 % 4 == 0 && a.sB2 % 4 == 0;
+    }
+    const int vec = (vecA ? 1 : 0) | (vecB ? 2 : 0);
+    a.vec_epi = T == 1 && a.splits == 1 && !a.atomic_out && a.N % 4 == 0 && a.ldc % 4 == 0 && (uintptr_t)a.C % 16 == 0 &&
+                (!a.bias || a.bias_row || (uintptr_t)a.bias % 16 == 0) && (!a.residual || (uintptr_t)a.residual % 16 == 0) &&
                 (!a.preact || (uintptr_t)a.preact % 16 == 0);
     if (a.nbatch > 1)
-        a.vec_epi = a.vec_epi && a.sC1 % 4 == 0 && a.sC2 % 4 == 0 && a.sR1 % 4 == 0 && a.sR2 % 4 == 0 && a.sBi1 % 4 == 0 && a.sBi2 % 4 == 0;
+        a.vec_epi = a.vec_epi && a.sC1 % 4 == 0 && a.sC2 % 4 == 0 && a.sR1 % 4 == 0 && a.sR2 % 4 == 0 &&
+                    (a.bias_row || (a.sBi1 % 4 == 0 && a.sBi2 % 4 == 0));
     const hipStream_t s = (hipStream_t)stream;
     int rc;
     // A is k-contiguous when not transposed ([M][K]); B is k-contiguous when transposed ([N][K])
@@ -582,6 +614,30 @@ static int gemm_dispatch(GemmDev& a, int transA, int transB, int T, void* stream
     if (rc) return rc;
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
+}
+
+// internal entry for the channels-first (wide FNO) path: everything dlwp_gemm_batched does plus row bias, GELU on the B
+// operand, a bias-gradient row sum and batches that accumulate into one shared output (dlwpmi_internal.h)
+int dlwp_gemm_run(const dlwp_gemm_args& g, hipStream_t stream) {
+    DLWP_REQUIRE(g.A && g.B && g.C && g.M > 0 && g.N > 0 && g.K > 0 && g.nb >= 1, DLWP_E_INVALID, "gemm_run: bad argument");
+    const bool epilogue = g.bias || g.act || g.preact || g.residual;
+    const bool shared_out = g.nb > 1 && g.sC == 0;
+    DLWP_REQUIRE(!(shared_out && epilogue), DLWP_E_INVALID, "gemm_run: batches sharing one output take no epilogue");
+    const long long tiles = (long long)ceil_div(g.N, 64) * ceil_div(g.M, 64) * g.nb;
+    int splits = 1;
+    if (!epilogue && tiles < 256 && g.K >= 8 * BK) splits = (int)std::min<long long>(ceil_div(512, (int)tiles), g.K / (4 * BK));
+    int kchunk = ceil_div(ceil_div(g.K, splits), BK) * BK;
+    splits = ceil_div(g.K, kchunk);
+    DLWP_REQUIRE((long long)g.nb * splits <= 65535, DLWP_E_UNSUPPORTED, "gemm_run: more than 65535 batches x splits");
+    const bool atomic = shared_out || splits > 1;
+    if (atomic && !g.accumulate) {
+        for (int z = 0; z < (shared_out ? 1 : g.nb); ++z)
+            if (int zrc = dlwp_zero_2d_f32(g.C + z * g.sC, g.ldc, g.M, g.N, stream)) return zrc;
+    }
+    GemmDev a{g.A, g.B, g.bias, g.residual, g.C, g.preact, g.rowsum, g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.act,
+              g.accumulate, kchunk, splits, g.nb, 1, g.res_before_act, 0, 0, 0, g.sA, 0, g.sB, 0, g.sC, 0, g.sR, 0, 0, 0, 0.f,
+              g.bias_row, g.act_b, shared_out ? 1 : 0};
+    return gemm_dispatch(a, g.transA, g.transB, 1, stream);
 }
 
 extern "C" int dlwp_set_gemm_precision(int mode) {
@@ -609,7 +665,7 @@ extern "C" int dlwp_gemm(const float* A, const float* B, float* C, int M, int N,
         if (zrc) return zrc;
     }
     GemmDev a{A, B, bias, residual, C, preact, rowsum, M, N, K, lda, ldb, ldc, act, accumulate, kchunk, splits,
-              1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.f};
+              1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.f, 0, 0, 0};
     return gemm_dispatch(a, transA, transB, T, stream);
 }
 
@@ -641,7 +697,7 @@ extern "C" int dlwp_gemm_batched(const float* A, const float* B, float* C, int M
                 if (int zrc = dlwp_zero_2d_f32(C + z1 * sC1 + z2 * sC2, ldc, M, N, stream)) return zrc;
     }
     GemmDev a{A, B, bias, residual, C, preact, nullptr, M, N, K, lda, ldb, ldc, act, accumulate, kchunk, splits,
-              nb1 * nb2, nb2, res_before_act, 0, 0, 0, sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2, sBi1, sBi2, act_param};
+              nb1 * nb2, nb2, res_before_act, 0, 0, 0, sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2, sBi1, sBi2, act_param, 0, 0, 0};
     return gemm_dispatch(a, transA, transB, T, stream);
 }
 

@@ -87,6 +87,7 @@ SIGNATURES = {
     "dlwp_window_attn_bwd": (_I, [_V] * 12 + [_I] * 7 + [_F, _V]),
     "dlwp_window_attn_bwd_slab_floats": (_L, [_I] * 4),
     "dlwp_fno_spatial_fwd_probe": (_I, [_V, _V, _V, _V, _V, _V, _V, _I, _V]),
+    "dlwp_fno_mix_fwd_probe": (_I, [_V, _V, _V, _V, _V, _I, _V]),
     "dlwp_debug_null_kernels": (_I, [_I, _I, _V]),
     "dlwp_debug_spin_kernels": (_I, [_I, _I, _I, _I, _I, _V]),
     "dlwp_debug_clock_probe": (_I, [_V, _I, _I, _V]),

@@ -378,6 +378,10 @@ int dlwp_cmode_product_bwd(const float* in, const float* U, const float* gout, f
 int dlwp_fno_spatial_fwd_probe(const dlwp_fno_plan* plan, const float* x, const float* spec,
                                const float* wskip, const float* bias, float* pre, float* x1_out,
                                int B, void* stream);
+/* bench probe: ONE forward per-mode launch (H-axis step of x1 [B][H][m2c][C][2] + the mode-truncated complex channel      */
+/* contraction with wspec on the matrix cores) -> xhat, y [B][m1][m2c][C][2].                                               */
+int dlwp_fno_mix_fwd_probe(const dlwp_fno_plan* plan, const float* x1, const float* wspec, float* xhat,
+                           float* y, int B, void* stream);
 /* debug: enqueue n dependent empty kernels of `blocks` workgroups (per-kernel floor probe)   */
 int dlwp_debug_null_kernels(int n, int blocks, void* stream);
 /* same with a body: every wave spins for `cycles` shader cycles; grid, block size and dynamic LDS chosen by the caller */

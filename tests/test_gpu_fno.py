@@ -73,6 +73,12 @@ def test_pwmlp_fwd_bwd(L, cuda, B, Cin, Ch, Cout, P):
     (2, 20, 32, 64, (8, 9), 1),      # ragged channels, odd mode counts, non-square grid
     (1, 8, 16, 16, (16, 16), 0),     # all rows kept and the Nyquist column included
     (2, 32, 128, 256, (12, 12), 1),  # C4-sized grid
+    # wide layers (hidden_channels > 64: channel-blocked row / spatial kernels, weight slice streamed into MFMA fragments)
+    (2, 77, 32, 32, (12, 12), 1),
+    (4, 217, 64, 64, (12, 12), 1),
+    (3, 100, 32, 64, (8, 9), 0),
+    (9, 80, 16, 16, (6, 6), 1),      # more than 8 samples: two MFMA row tiles in the mode contraction
+    (12, 32, 32, 32, (8, 8), 1),     # the same on the fused narrow path
 ])
 def test_fno_block_fwd_bwd(L, cuda, B, Cc, H, W, n_modes, act_in):
     lib = L.load()
@@ -458,3 +464,73 @@ def test_headline_config_parity_at_the_benchmarked_horizon(cuda):
     torch.cuda.synchronize()
     assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item())
     assert rel_err(module.flat_grad, _oracle_flat_grad(oracle, module)) <= GRAD_TOL
+
+
+# the hidden widths of the reference's published TFNO2D sweep (src/nsbench/scripts/train_commands.txt:83-91: 2, 8, 27, 38,
+# 54, 77, 108, 154, 217 <-> 5k .. 32M parameters, plot_results.py:58); 4 layers, 12 x 12 modes, lifting / projection 256
+@pytest.mark.parametrize("hidden", [2, 8, 27, 38, 54, 77, 108, 154, 217])
+def test_published_sweep_widths_match_oracle(cuda, hidden):
+    cfg = dict(B=2, T=4, D=1, H=32, W=32, ctx=2, tf=2, hidden=hidden, lifting=256, projection=256, n_layers=4, n_modes=(12, 12))
+    oracle, module = _oracle_and_module(cuda, cfg["n_modes"], cfg["D"], cfg["hidden"], cfg["lifting"], cfg["projection"],
+                                        cfg["n_layers"], cfg["ctx"])
+    g = torch.Generator().manual_seed(1000 + hidden)
+    u = torch.randn(cfg["B"], cfg["T"] + 1, 1, cfg["H"], cfg["W"], generator=g)
+    x, y = u[:, :-1].contiguous(), u[:, 1:].contiguous()
+    oracle.requires_grad_(True)
+    loss_ref, yhat_ref = fno_ref.train_step(oracle, x, y, cfg["tf"], cfg["ctx"])
+    with torch.no_grad():
+        yhat = module(x.to(cuda), teacher_forcing_steps=cfg["tf"])
+    assert rel_err(yhat, yhat_ref) <= FWD_TOL
+    gref = _oracle_flat_grad(oracle, module)
+    for use_graph in (False, True):
+        module.flat_grad.zero_()
+        loss = module.train_step(x.to(cuda), y.to(cuda), cfg["tf"], optimizer=None, use_graph=use_graph)
+        torch.cuda.synchronize()
+        assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item())
+        assert rel_err(module.flat_grad, gref) <= GRAD_TOL
+        for name in module.layout.entries:
+            assert rel_err(module.layout.view(module.flat_grad, name), module.layout.view(gref, name)) <= 2e-3, name
+
+
+def test_wide_dlwp_form_matches_oracle(cuda):
+    """dlwpbench FNO2DModule at hidden 96 (wide path): constants / prescribed / prognostic gather, residual output, closed loop."""
+    from dlwp_benchmark_amd import dlwpbench
+    cfg = dict(B=2, T=4, Cc=4, Cp=1, Cg=5, H=32, W=64, ctx=1, hidden=96, lifting=128, projection=128, n_layers=2, n_modes=(12, 12))
+    Cin = cfg["Cc"] + (cfg["Cp"] + cfg["Cg"]) * cfg["ctx"]
+    oracle = fno_ref.FNO(cfg["n_modes"], Cin, cfg["hidden"], cfg["lifting"], cfg["projection"], cfg["Cg"], cfg["n_layers"], seed=78)
+    module = dlwpbench.FNO2DModule(n_modes=list(cfg["n_modes"]), constant_channels=cfg["Cc"], prescribed_channels=cfg["Cp"],
+                                   prognostic_channels=cfg["Cg"], hidden_channels=cfg["hidden"], lifting_channels=cfg["lifting"],
+                                   projection_channels=cfg["projection"], n_layers=cfg["n_layers"], context_size=cfg["ctx"])
+    sd = {}
+    for k, v in oracle.params.items():
+        if ".convs.weight." in k:
+            sd["fno." + k + ".tensor"] = v
+        elif ".convs.bias." in k:
+            continue
+        elif k.endswith("weight"):
+            sd["fno." + k] = v[:, :, None, None]
+        else:
+            sd["fno." + k] = v
+    sd["fno.fno_blocks.convs.bias"] = torch.stack(
+        [oracle.params[f"fno_blocks.convs.bias.{l}"] for l in range(cfg["n_layers"])])[:, :, None, None]
+    module.load_state_dict(sd)
+    module = module.to(cuda)
+    g = torch.Generator().manual_seed(6)
+    B, T, H, W = cfg["B"], cfg["T"], cfg["H"], cfg["W"]
+    constants = torch.randn(B, 1, cfg["Cc"], H, W, generator=g)
+    prescribed = torch.randn(B, T, cfg["Cp"], H, W, generator=g)
+    prognostic = torch.randn(B, T, cfg["Cg"], H, W, generator=g)
+    target = torch.randn(B, T - cfg["ctx"], cfg["Cg"], H, W, generator=g)
+    oracle.requires_grad_(True)
+    y_ref = fno_ref.dlwp_rollout(oracle, constants, prescribed, prognostic, cfg["ctx"])
+    loss_ref = torch.nn.functional.mse_loss(y_ref, target)
+    loss_ref.backward()
+    with torch.no_grad():
+        y = module(constants.to(cuda), prescribed.to(cuda), prognostic.to(cuda))
+    assert rel_err(y, y_ref) <= FWD_TOL
+    gref = _oracle_flat_grad(oracle, module)
+    module.flat_grad.zero_()
+    loss = module.train_step(constants.to(cuda), prescribed.to(cuda), prognostic.to(cuda), target.to(cuda), use_graph=True)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item())
+    assert rel_err(module.flat_grad, gref) <= GRAD_TOL

@@ -217,4 +217,7 @@ def test_sfnonet_shipped_fourcastnetv2_options_match_oracle(cuda):
     for n, q in net.named_parameters():
         if q.grad is None or sd[n].grad is None:
             continue
+        if sd[n].grad.abs().max() < 1e-8:          # mathematically zero (a per-channel shift in front of the next block's
+            assert q.grad.abs().max() < 1e-6, n    # instance norm): both sides hold rounding noise only
+            continue
         assert rel(q.grad, sd[n].grad) <= 2e-3, n

@@ -73,17 +73,18 @@ def test_drop_path_statistics_determinism_and_gradient(cuda):
     torch.manual_seed(77)
     y2 = dp(t, residual=x)
     assert torch.equal(y1, y2)
-    scale = ((y1 - x) / t).detach()                       # per element; constant within a sample
-    per_sample = scale[:, 0, 0]
-    assert torch.allclose(scale, per_sample[:, None, None].expand_as(scale), atol=1e-5)
+    d = (y1 - x).detach()
+    per_sample = ((d * t.detach()).sum(dim=(1, 2)) / (t.detach() ** 2).sum(dim=(1, 2)))       # least-squares scale per sample
+    assert torch.allclose(d, per_sample[:, None, None] * t.detach(), atol=1e-5)              # constant within a sample
     kept = per_sample > 0.5
-    assert torch.allclose(per_sample[kept], torch.full_like(per_sample[kept], 1 / 0.75), atol=1e-5)
-    assert torch.all(per_sample[~kept].abs() < 1e-6)
+    assert torch.allclose(per_sample[kept], torch.full_like(per_sample[kept], 1 / 0.75), atol=1e-4)
+    assert torch.all(per_sample[~kept].abs() < 1e-5)
     assert abs(kept.float().mean().item() - 0.75) < 0.03   # 4096 draws: 3 sigma ~ 0.02
     gy = torch.randn_like(y1)
     y1.backward(gy)
     assert torch.allclose(x.grad, gy)
-    assert torch.allclose(t.grad, gy * per_sample[:, None, None], atol=1e-6)
+    exact = torch.where(kept, torch.full_like(per_sample, 1 / 0.75), torch.zeros_like(per_sample))
+    assert torch.allclose(t.grad, gy * exact[:, None, None], atol=1e-6)
     dp.eval()
     assert torch.equal(dp(t), t)
 
@@ -121,8 +122,12 @@ def test_instance_norm_matches_torch(cuda, B, H, W, C):
     gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
     beta = torch.randn(C, generator=g).requires_grad_(True)
     gy = torch.randn(B, H, W, C, generator=g)
-    yr = torch.nn.functional.instance_norm(x.permute(0, 3, 1, 2), weight=gamma, bias=beta, eps=1e-6).permute(0, 2, 3, 1) + res
+    # the reference leaf is a CONTIGUOUS channels-first copy: torch's CPU instance_norm backward returns wrong input gradients
+    # for a permuted (non-contiguous) input with batch size 1 (tools/debug_instnorm.py: it disagrees with the closed form)
+    xcf = x.detach().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    yr = torch.nn.functional.instance_norm(xcf, weight=gamma, bias=beta, eps=1e-6).permute(0, 2, 3, 1) + res
     yr.backward(gy)
+    x_grad = xcf.grad.permute(0, 2, 3, 1)
     m = InstanceNorm(C, eps=1e-6).to(cuda)
     with torch.no_grad():
         m.weight.copy_(gamma)
@@ -135,7 +140,7 @@ def test_instance_norm_matches_torch(cuda, B, H, W, C):
         a, b = a.detach().double().cpu(), b.detach().double().cpu()
         return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
     assert rel(y, yr) <= 1e-4
-    assert rel(xd.grad, x.grad) <= 1e-3
+    assert rel(xd.grad, x_grad) <= 1e-3
     assert rel(rd.grad, res.grad) <= 1e-6
     assert rel(m.weight.grad, gamma.grad) <= 1e-3
     assert rel(m.bias.grad, beta.grad) <= 1e-3
