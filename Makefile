@@ -17,7 +17,7 @@ build/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.cuh) $(wildcard $(CSRC)/*.h) inclu
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -o $@
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -ldl -o $@
 
 # diagnostic build with in-kernel phase stamps (DLWP_STAMP in common.cuh); never loaded by the package
 STAMP_OBJS := $(patsubst $(CSRC)/%.hip,build_stamps/%.o,$(SRCS))
@@ -25,7 +25,7 @@ build_stamps/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.cuh) $(wildcard $(CSRC)/*.h
 	@mkdir -p build_stamps
 	$(HIPCC) $(HIPFLAGS) -DDLWP_STAMPS -c $< -o $@
 stamps: $(STAMP_OBJS)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(STAMP_OBJS) -o dlwp_benchmark_amd/libdlwpmi_stamps.so
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(STAMP_OBJS) -ldl -o dlwp_benchmark_amd/libdlwpmi_stamps.so
 
 oracle:
 	$(MAKE) -C oracle

@@ -473,13 +473,30 @@ __device__ __host__ __forceinline__ int mix_split(int outputs, int limit) {
 // A complex product y[b][o] = sum_i x[b][i] w[i][o] is ONE real GEMM with the real and imaginary planes of the SAMPLE side
 // stacked along M and the (re, im) pair of the weight interleaved along K:
 //     rows (b, re) = [ xr_i, -xi_i ]_i      rows (b, im) = [ xi_i, xr_i ]_i      B[k = 2i + ri][n = o] = w[i][o][ri]
-// => 8 B C^2 flops, every weight element read exactly once, M = 2 B rows (8 of the 16 tile rows at the headline batch of 4;
-// full at B >= 8).  The weight slice is read ONCE per workgroup, so it is not staged through LDS at all: every lane fetches its
-// B fragments (two 8-byte loads per 16-deep K chunk, 128 contiguous bytes per 16 lanes) straight from global memory / L2 into
-// registers -- for narrow layers (<= 8 fragments per wave) before the H-axis step, so that the weight latency hides behind it.
-// The same scheme gives the backward products: gx = ghat conj(w)^T (B[k = 2o + ri][n = i] = w[i][o][ri]) and the weight
-// gradient gw[i][o] += sum_b conj(xhat[b][i]) ghat[b][o] (K = 2 B, one 16x16x4 instruction per pair of samples).
-constexpr int MIX_PRE = 8;     // weight fragments a wave may hold before the H-axis step
+// => 8 B C^2 flops, every weight element used exactly once, M = 2 B rows (8 of the 16 tile rows at the headline batch of 4;
+// full at B >= 8).  The same scheme gives the backward products: gx = ghat conj(w)^T (B[k = 2o + ri][n = i] = w[i][o][ri])
+// and the weight gradient gw[i][o] += sum_b conj(xhat[b][i]) ghat[b][o] (K = 2 B: one 16x16x4 instruction per pair of samples).
+// Weight operand: narrow layers (C <= 64) stage the mode's [C][C] slice in LDS with ONE 16-byte load per thread, in flight
+// together with the x1 loads of the H-axis step (rows padded by one complex number: conflict-free 8-byte fragment reads along
+// rows and columns); wide layers read every fragment once, straight from global memory / L2 into registers (two 8-byte loads
+// per 16-deep K chunk, 128 contiguous bytes per 16 lanes) -- a 217-channel slice is 377 KB and is used once per workgroup.
+
+// weight slice [C][C] complex -> LDS rows of (C+1) complex
+__device__ __forceinline__ void mix_stage_w(const float2* wm, float2* ws, int C, FastDiv dC) {
+    const int n2 = C * C / 2;  // pairs of complex numbers (C*C is even whenever C is even)
+    if ((C & 1) == 0) {
+#pragma unroll 4
+        for (int u = threadIdx.x; u < n2; u += MIXT) {
+            const float4 v = reinterpret_cast<const float4*>(wm)[u];
+            const int e = 2 * u, i = fastdiv(e, dC), o = e - i * C;
+            ws[i * (C + 1) + o] = make_float2(v.x, v.y);
+            ws[i * (C + 1) + o + 1] = make_float2(v.z, v.w);
+        }
+    } else {
+#pragma unroll 4
+        for (int e = threadIdx.x; e < C * C; e += MIXT) ws[(e / C) * (C + 1) + e % C] = wm[e];
+    }
+}
 
 // A fragment of chunk kc for tile row m = 16 mt + r: element s <-> k = 16 kc + 4 g + s, complex index i = 8 kc + 2 g + s / 2.
 // CONJ = 0: rows (b, re) = (x, -y), (b, im) = (y, x)      [x * w]
@@ -496,14 +513,15 @@ __device__ __forceinline__ f32x4 mix_afrag(const float2* xh, int B, int C, int m
     }
     return a;
 }
-// B fragment of chunk kc for tile column n = 16 nt + r.  TRW = 0: w[i = 8 kc + 2 g (+1)][o = n]; TRW = 1: w[i = n][o = 8 kc + 2 g (+1)].
-// Loads are unconditional from clamped addresses (selects afterwards), so that a group of them is in flight together.
+// B fragment of chunk kc for tile column n = 16 nt + r from a [C][pitch] complex image (LDS: pitch C + 1; global: pitch C).
+// TRW = 0: w[i = 8 kc + 2 g (+1)][o = n]; TRW = 1: w[i = n][o = 8 kc + 2 g (+1)].  Loads are unconditional from clamped
+// addresses (selects afterwards), so that a group of them is in flight together.
 template <int TRW>
-__device__ __forceinline__ f32x4 mix_bfrag(const float2* wm, int C, int nt, int kc, int r, int g) {
+__device__ __forceinline__ f32x4 mix_bfrag(const float2* wm, int pitch, int C, int nt, int kc, int r, int g) {
     const int n = 16 * nt + r, k0 = 8 * kc + 2 * g;
     const int nc = n < C ? n : C - 1, k0c = k0 < C ? k0 : C - 1, k1c = k0 + 1 < C ? k0 + 1 : C - 1;
-    const float2 w0 = TRW ? wm[(long long)nc * C + k0c] : wm[(long long)k0c * C + nc];
-    const float2 w1 = TRW ? wm[(long long)nc * C + k1c] : wm[(long long)k1c * C + nc];
+    const float2 w0 = TRW ? wm[(long long)nc * pitch + k0c] : wm[(long long)k0c * pitch + nc];
+    const float2 w1 = TRW ? wm[(long long)nc * pitch + k1c] : wm[(long long)k1c * pitch + nc];
     const bool ok0 = n < C && k0 < C, ok1 = n < C && k0 + 1 < C;
     return f32x4{ok0 ? w0.x : 0.f, ok0 ? w0.y : 0.f, ok1 ? w1.x : 0.f, ok1 ? w1.y : 0.f};
 }
@@ -518,59 +536,35 @@ __device__ __forceinline__ void mix_store_tile(float2* out, long long ostride_b,
     }
 }
 
-// out[b][n] (complex, global, index base + n) = sum over the K chunks of A(xh) . B(w) for every column tile this wave owns
-// (tiles w, w + NW, ...).  have_pre: the fragments of the wave's FIRST tile were fetched before the H-axis step (pre[kc]).
+// out[b][n] (complex, global, index base + n) = sum over the K chunks of A(xh) . B(w); work items = (column tile, pair of row
+// tiles), dealt to the waves round-robin
 template <int CONJ, int TRW>
-__device__ __forceinline__ void mix_contract(const float2* xh, const float2* wm, float2* out, long long ostride_b, int B, int C,
-                                             const f32x4 (&pre)[MIX_PRE], bool have_pre) {
+__device__ __forceinline__ void mix_contract(const float2* xh, const float2* wm, int pitch, float2* out, long long ostride_b,
+                                             int B, int C) {
     const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
     constexpr int NW = MIXT / 64;
-    const int ntn = (C + 15) / 16, nkc = (2 * C + 15) / 16, nmt = (2 * B + 15) / 16;
-    int nt = w;
-    if (have_pre && nt < ntn) {
-        for (int mt = 0; mt < nmt; ++mt) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int ntn = (C + 15) / 16, nkc = (2 * C + 15) / 16, nmt = (2 * B + 15) / 16, nmp = (nmt + 1) / 2;
+    for (int item = w; item < ntn * nmp; item += NW) {
+        const int nt = item % ntn, mt0 = 2 * (item / ntn);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;     // two row tiles share every weight fragment (B > 8)
+        for (int kc0 = 0; kc0 < nkc; kc0 += 4) {
+            f32x4 bf[4];
 #pragma unroll
-            for (int q = 0; q < MIX_PRE; ++q)
-                if (q < nkc) acc = mfma16_chunk(mix_afrag<CONJ>(xh, B, C, mt, q, r, g), pre[q], acc);
-            mix_store_tile(out, ostride_b, acc, B, C, nt, mt, r, g);
+            for (int q = 0; q < 4; ++q) bf[q] = mix_bfrag<TRW>(wm, pitch, C, nt, min(kc0 + q, nkc - 1), r, g);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (kc0 + q < nkc) {
+                    acc0 = mfma16_chunk(mix_afrag<CONJ>(xh, B, C, mt0, kc0 + q, r, g), bf[q], acc0);
+                    if (mt0 + 1 < nmt) acc1 = mfma16_chunk(mix_afrag<CONJ>(xh, B, C, mt0 + 1, kc0 + q, r, g), bf[q], acc1);
+                }
         }
-        nt += NW;
+        mix_store_tile(out, ostride_b, acc0, B, C, nt, mt0, r, g);
+        if (mt0 + 1 < nmt) mix_store_tile(out, ostride_b, acc1, B, C, nt, mt0 + 1, r, g);
     }
-    for (; nt < ntn; nt += NW) {
-        for (int mt0 = 0; mt0 < nmt; mt0 += 2) {           // two row tiles share every weight fragment (B > 8)
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-            for (int kc0 = 0; kc0 < nkc; kc0 += 4) {
-                f32x4 bf[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) bf[q] = mix_bfrag<TRW>(wm, C, nt, min(kc0 + q, nkc - 1), r, g);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (kc0 + q < nkc) {
-                        acc0 = mfma16_chunk(mix_afrag<CONJ>(xh, B, C, mt0, kc0 + q, r, g), bf[q], acc0);
-                        if (mt0 + 1 < nmt) acc1 = mfma16_chunk(mix_afrag<CONJ>(xh, B, C, mt0 + 1, kc0 + q, r, g), bf[q], acc1);
-                    }
-            }
-            mix_store_tile(out, ostride_b, acc0, B, C, nt, mt0, r, g);
-            if (mt0 + 1 < nmt) mix_store_tile(out, ostride_b, acc1, B, C, nt, mt0 + 1, r, g);
-        }
-    }
-}
-// the fragments of this wave's first column tile (every K chunk), when they fit MIX_PRE registers sets: narrow layers
-template <int TRW>
-__device__ __forceinline__ bool mix_prefetch(const float2* wm, int C, f32x4 (&pre)[MIX_PRE]) {
-    const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
-    const int ntn = (C + 15) / 16, nkc = (2 * C + 15) / 16;
-#pragma unroll
-    for (int q = 0; q < MIX_PRE; ++q) pre[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (nkc > MIX_PRE) return false;                       // wide layers stream every fragment inside the loop
-    if (w < ntn) {
-#pragma unroll
-        for (int q = 0; q < MIX_PRE; ++q) pre[q] = mix_bfrag<TRW>(wm, C, w, min(q, nkc - 1), r, g);
-    }
-    return true;
 }
 
+// LDSW: the mode's weight slice is staged in LDS (narrow layers)
+template <bool LDSW>
 __global__ __launch_bounds__(MIXT) void fno_mix_fwd_kernel(MixDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int BC = a.B * a.C, C = a.C;
@@ -579,6 +573,7 @@ __global__ __launch_bounds__(MIXT) void fno_mix_fwd_kernel(MixDev a) {
     float2* xh = reinterpret_cast<float2*>(smem);  // [BC]
     float2* part = xh + BC;                        // [max(NS, NS2)][BC]
     float2* tws = part + (NS > NS2 ? NS : NS2) * BC;   // [H]
+    float2* ws = tws + a.H;                        // [C][C+1]   (LDSW)
     // XCD-aware mode order: workgroups go round-robin to the 8 XCDs; give every XCD a contiguous range of (kx, j) so that
     // the m1 row frequencies of one column kx -- which read the same x1 slice -- meet in one L2
     int mode = blockIdx.x;
@@ -592,8 +587,7 @@ __global__ __launch_bounds__(MIXT) void fno_mix_fwd_kernel(MixDev a) {
     DLWP_STAMP(16);
     HstepLoads hl;
     if (fast) mix_hstep_issue(a, kx, NS2, hl, 0);            // x1 loads in flight before anything is waited for
-    f32x4 pre[MIX_PRE];
-    const bool have_pre = mix_prefetch<0>(wm, C, pre);       // ... and this wave's weight fragments
+    if (LDSW) mix_stage_w(wm, ws, C, a.dC);
     for (int i = threadIdx.x; i < a.H; i += MIXT) tws[i] = a.twH[j * a.H + i];
     DLWP_STAMP(17);
     __syncthreads();
@@ -610,10 +604,12 @@ __global__ __launch_bounds__(MIXT) void fno_mix_fwd_kernel(MixDev a) {
         const int b = fastdiv(bc, a.dC), c = bc - b * C;
         a.xhat[b * bstr + mofs + c] = xh[bc];
     }
-    mix_contract<0, 0>(xh, wm, a.y + mofs, bstr, a.B, C, pre, have_pre);
+    if (LDSW) mix_contract<0, 0>(xh, ws, C + 1, a.y + mofs, bstr, a.B, C);
+    else mix_contract<0, 0>(xh, wm, C, a.y + mofs, bstr, a.B, C);
     DLWP_STAMP(24);
 }
 
+template <bool LDSW>
 __global__ __launch_bounds__(MIXT) void fno_mix_bwd_kernel(MixDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int BC = a.B * a.C, C = a.C;
@@ -623,6 +619,7 @@ __global__ __launch_bounds__(MIXT) void fno_mix_bwd_kernel(MixDev a) {
     float2* xsv = gh + BC;                         // [BC]  saved xhat
     float2* part = xsv + BC;                       // [max(NS, NS2)][BC]
     float2* tws = part + (NS > NS2 ? NS : NS2) * BC;   // [H]
+    float2* ws = tws + a.H;                        // [C][C+1]   (LDSW)
     int mode = blockIdx.x;
     {
         const int nm = gridDim.x, full = (nm / 8) * 8;
@@ -634,8 +631,7 @@ __global__ __launch_bounds__(MIXT) void fno_mix_bwd_kernel(MixDev a) {
     const float2* wm = a.wspec + wofs;
     HstepLoads hl;
     if (fast) mix_hstep_issue(a, kx, NS2, hl, 0);
-    f32x4 pre[MIX_PRE];
-    const bool have_pre = mix_prefetch<1>(wm, C, pre);
+    if (LDSW) mix_stage_w(wm, ws, C, a.dC);
     for (int i = threadIdx.x; i < a.H; i += MIXT) tws[i] = a.twH[j * a.H + i];
     const long long mofs = ((long long)j * a.m2c + kx) * C, bstr = (long long)a.m1 * a.m2c * C;
     for (int bc = threadIdx.x; bc < BC; bc += MIXT) {
@@ -648,14 +644,13 @@ __global__ __launch_bounds__(MIXT) void fno_mix_bwd_kernel(MixDev a) {
     __syncthreads();
     mix_fold(gh, part, BC, hs);
     __syncthreads();
-    // gx[b][i] = sum_o ghat[b][o] conj(w[i][o])
-    mix_contract<1, 1>(gh, wm, a.y + mofs, bstr, a.B, C, pre, have_pre);
-    // gw[i][o] += sum_b conj(xhat[b][i]) ghat[b][o]: tile [16 i x 16 o], K = 2 B, k = 2 b' + ri on the lane group g
+    // gw[i][o] += sum_b conj(xhat[b][i]) ghat[b][o]: tile [16 i x 16 o], K = 2 B, k = 2 b' + ri on the lane group g.
+    // Tiles are dealt from the LAST wave downwards and the gx column tiles below from the first wave upwards, so that at
+    // narrow widths (4 + 2 work items for 8 waves) no wave gets both.
     {
         const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
         constexpr int NW = MIXT / 64;
         const int nt = (C + 15) / 16, ri = g & 1;
-        // tiles are dealt from the LAST wave downwards: the first waves are busy with the gx column tiles above
         for (int t = NW - 1 - w; t < nt * nt; t += NW) {
             const int it = t / nt, ot = t - it * nt;
             const int i = 16 * it + r, o = 16 * ot + r;          // A row (i) / B column (o) of this lane
@@ -684,6 +679,9 @@ __global__ __launch_bounds__(MIXT) void fno_mix_bwd_kernel(MixDev a) {
             }
         }
     }
+    // gx[b][i] = sum_o ghat[b][o] conj(w[i][o])
+    if (LDSW) mix_contract<1, 1>(gh, ws, C + 1, a.y + mofs, bstr, a.B, C);
+    else mix_contract<1, 1>(gh, wm, C, a.y + mofs, bstr, a.B, C);
 }
 
 template <typename K>
@@ -803,16 +801,21 @@ static int mix_launch(const dlwp_fno_plan* p, bool bwd, MixDev& a, hipStream_t s
     if (ns > lim) ns = lim;
     const int ns2 = mix_slots2(a.B, a.C, a.H);
     if (ns2 > ns) ns = ns2;
-    const size_t lds = sizeof(float2) * ((size_t)BC * ((bwd ? 2 : 1) + ns) + a.H);
+    const bool ldsw = a.C <= 64;                    // the [C][C+1] complex weight image fits beside the H-step partials
+    const size_t lds = sizeof(float2) * ((size_t)BC * ((bwd ? 2 : 1) + ns) + a.H + (ldsw ? (size_t)a.C * (a.C + 1) : 0));
     const dim3 grid(p->m1 * p->m2c), block(MIXT);
     int rc;
+#define MIX_LAUNCH(KERNEL, NAME)                                                    \
+    do {                                                                            \
+        if ((rc = set_lds(KERNEL, lds, NAME)) != DLWP_OK) return rc;                \
+        hipLaunchKernelGGL(KERNEL, grid, block, lds, stream, a);                    \
+    } while (0)
     if (bwd) {
-        if ((rc = set_lds(fno_mix_bwd_kernel, lds, "fno_mix_bwd")) != DLWP_OK) return rc;
-        hipLaunchKernelGGL(fno_mix_bwd_kernel, grid, block, lds, stream, a);
+        if (ldsw) MIX_LAUNCH(fno_mix_bwd_kernel<true>, "fno_mix_bwd"); else MIX_LAUNCH(fno_mix_bwd_kernel<false>, "fno_mix_bwd");
     } else {
-        if ((rc = set_lds(fno_mix_fwd_kernel, lds, "fno_mix_fwd")) != DLWP_OK) return rc;
-        hipLaunchKernelGGL(fno_mix_fwd_kernel, grid, block, lds, stream, a);
+        if (ldsw) MIX_LAUNCH(fno_mix_fwd_kernel<true>, "fno_mix_fwd"); else MIX_LAUNCH(fno_mix_fwd_kernel<false>, "fno_mix_fwd");
     }
+#undef MIX_LAUNCH
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }

@@ -542,7 +542,7 @@ int wa_setup(WaDev& a, int B_, int nW, int N, int TB, int ntypes, int heads, int
     DLWP_REQUIRE(B_ > 0 && nW > 0 && B_ % nW == 0 && N > 0 && heads > 0 && d > 0 && TB > 0 && ntypes > 0,
                  DLWP_E_INVALID, "%s: bad shape", who);
     DLWP_REQUIRE(nW % ntypes == 0, DLWP_E_INVALID, "%s: nW (%d) must be a multiple of ntypes (%d)", who, nW, ntypes);
-    DLWP_REQUIRE(d <= 64, DLWP_E_UNSUPPORTED, "%s: head_dim %d > 64 not supported yet", who, d);
+    DLWP_REQUIRE(d <= 64, DLWP_E_UNSUPPORTED, "%s: head_dim %d > 64: use the GEMM form (dlwp_window_softmax_fwd/bwd)", who, d);
     DLWP_REQUIRE(TB <= 9000, DLWP_E_UNSUPPORTED, "%s: bias table slice of %d entries does not fit LDS", who, TB);
     a.B_ = B_; a.nW = nW; a.N = N; a.TB = TB; a.ntypes = ntypes; a.heads = heads; a.d = d; a.scale = scale;
     a.dp16 = round_up(d, 16);
@@ -619,6 +619,111 @@ extern "C" int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, c
 extern "C" long long dlwp_window_attn_bwd_slab_floats(int B_, int N, int heads, int TB) {
     if (B_ <= 0 || N <= 0 || heads <= 0 || TB <= 0) return -1;
     return (long long)B_ * heads * ((N + QT - 1) / QT) * TB;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Head dimensions above 64 (deep stages of the nsbench Swin U-Net: the shipped swintransformer.yaml reaches head_dim 192
+// and the paper's 4-stage runs 112 -- always on the 8 x 8 / 4 x 4 token maps of the last stages, src/nsbench/configs/model/
+// swintransformer.yaml:8-14, scripts/train_commands.txt:105-109): q k^T and p v run as strided-batched MFMA GEMMs
+// (dlwp_gemm_batched) around these two row kernels, with the [B_, heads, N, N] scores in HBM (N <= 1024 tokens).
+//   fwd: P = softmax(scale S + table[ia[q] + ib[k]][type][head] + mask)        (in place)
+//   bwd: dS = P (dP - rowsum(P dP)); gtable += dS; dP <- scale dS              (in place)
+namespace {
+struct RowSmDev {
+    float* s; const float* p; const float* table; float* gtable; const int *ia, *ib, *labels;
+    int B_, nW, N, ntypes, heads;
+    float scale;
+};
+template <bool BWD>
+__global__ __launch_bounds__(256) void winattn_rows_kernel(RowSmDev a) {
+    const int lane = lane_id();
+    const long long row = (long long)blockIdx.x * 4 + wave_id();
+    const long long nrows = (long long)a.B_ * a.heads * a.N;
+    if (row >= nrows) return;
+    const int q = (int)(row % a.N);
+    const long long bh = row / a.N;
+    const int head = (int)(bh % a.heads), b = (int)(bh / a.heads), wdw = b % a.nW;
+    const long long tstr = (long long)a.ntypes * a.heads, tofs = (long long)(wdw % a.ntypes) * a.heads + head;
+    const int* labw = a.labels ? a.labels + (long long)wdw * a.N : nullptr;
+    float* srow = a.s + row * a.N;
+    constexpr int NQ = 16;                       // N <= 1024
+    float v[NQ];
+    if (!BWD) {
+        const int qa = a.ia[q], qlab = labw ? labw[q] : 0;
+        float m = -1e30f;
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int k = lane + 64 * u;
+            v[u] = -1e30f;
+            if (k < a.N) {
+                float x = srow[k] * a.scale + a.table[(long long)(qa + a.ib[k]) * tstr + tofs];
+                if (labw && labw[k] != qlab) x -= 100.f;
+                v[u] = x;
+                m = fmaxf(m, x);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float l = 0.f;
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            v[u] = lane + 64 * u < a.N ? __expf(v[u] - m) : 0.f;
+            l += v[u];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+        const float inv = 1.f / l;
+#pragma unroll
+        for (int u = 0; u < NQ; ++u)
+            if (lane + 64 * u < a.N) srow[lane + 64 * u] = v[u] * inv;
+    } else {
+        const float* prow = a.p + row * a.N;
+        const int qa = a.ia[q];
+        float pv[NQ], dot = 0.f;
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int k = lane + 64 * u;
+            pv[u] = k < a.N ? prow[k] : 0.f;
+            v[u] = k < a.N ? srow[k] : 0.f;
+            dot += pv[u] * v[u];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int k = lane + 64 * u;
+            if (k < a.N) {
+                const float ds = pv[u] * (v[u] - dot);
+                atomic_add_f32(&a.gtable[(long long)(qa + a.ib[k]) * tstr + tofs], ds);
+                srow[k] = ds * a.scale;
+            }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int dlwp_window_softmax_fwd(float* s, const float* bias_table, const int* ia, const int* ib, const int* labels,
+                                       int B_, int nW, int N, int ntypes, int heads, float scale, void* stream) {
+    DLWP_REQUIRE(s && bias_table && ia && ib && B_ > 0 && nW > 0 && B_ % nW == 0 && N > 0 && heads > 0 && ntypes > 0,
+                 DLWP_E_INVALID, "window_softmax_fwd: bad argument");
+    DLWP_REQUIRE(N <= 1024, DLWP_E_UNSUPPORTED, "window_softmax_fwd: at most 1024 tokens per window (got %d)", N);
+    RowSmDev a{s, nullptr, bias_table, nullptr, ia, ib, labels, B_, nW, N, ntypes, heads, scale};
+    const long long rows = (long long)B_ * heads * N;
+    hipLaunchKernelGGL(winattn_rows_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_window_softmax_bwd(const float* p, float* dp, float* gbias_table, const int* ia, const int* ib, int B_,
+                                       int nW, int N, int ntypes, int heads, float scale, void* stream) {
+    DLWP_REQUIRE(p && dp && gbias_table && ia && ib && B_ > 0 && nW > 0 && B_ % nW == 0 && N > 0 && heads > 0 && ntypes > 0,
+                 DLWP_E_INVALID, "window_softmax_bwd: bad argument");
+    DLWP_REQUIRE(N <= 1024, DLWP_E_UNSUPPORTED, "window_softmax_bwd: at most 1024 tokens per window (got %d)", N);
+    RowSmDev a{dp, p, nullptr, gbias_table, ia, ib, nullptr, B_, nW, N, ntypes, heads, scale};
+    const long long rows = (long long)B_ * heads * N;
+    hipLaunchKernelGGL(winattn_rows_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
 }
 
 #ifdef DLWP_STAMPS

@@ -66,3 +66,180 @@ class FlatGradAllReduce:
 def broadcast_parameters(flat_params, src=0, group=None):
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat_params, src=src, group=group)
+
+
+def _fail(what, exc):
+    """A failed collective leaves the replicas inconsistent: report on stderr and end this rank with a non-zero exit code
+    (no elastic recovery on this path; the launcher -- torchrun -- then tears the other ranks down)."""
+    import os
+    import sys
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    print(f"[dlwp_benchmark_amd.ddp] rank {rank}: {what} failed: {type(exc).__name__}: {exc}", file=sys.stderr, flush=True)
+    sys.stderr.flush()
+    os._exit(13)
+
+
+class FlatGradAllReduceChecked(FlatGradAllReduce):
+    """FlatGradAllReduce that turns a collective error (peer died, timeout, RCCL failure) into exit code 13."""
+
+    def __call__(self, flat_grad):
+        try:
+            return super().__call__(flat_grad)
+        except Exception as exc:          # noqa: BLE001 -- torch raises RuntimeError / DistBackendError / DistNetworkError
+            _fail("gradient all-reduce", exc)
+
+
+class BucketedGradAllReduce:
+    """Gradient all-reduce in buckets launched DURING backward (north_star: "all-reduce of gradients over xGMI overlapped
+    with backward"), for the autograd-driven models whose parameters live in one flat buffer
+    (train_engine.flatten_parameters): AFNONet / SwinTransformer / PanguWeather at the 1-lead-time C4 / C5 configurations
+    carry 114 - 288 MB of fp32 gradients, and the last layers' gradients are final long before the first layers'.
+
+    Units = the sub-modules of `model` (children of ModuleLists expanded); a unit's parameters occupy one contiguous span of
+    the flat gradient buffer.  A unit is FINAL once the backward pass has left it as often as the forward pass entered it
+    (a module used T times in a rollout: T forward pre-hooks, T full-backward hooks); a hook that fires without input
+    gradients (a module fed by data only) fires on entry, not on exit, and is ignored.  Consecutive spans are grouped into
+    buckets of >= `bucket_bytes`; a bucket is reduced as soon as ALL its units are final -- no assumption about the order in
+    which autograd visits the modules.  Reductions are asynchronous (`async_op=True`: RCCL's stream waits for the kernels
+    enqueued so far, later backward kernels overlap).  `finish()` reduces everything no hook released (the first unit, gaps
+    between spans such as position embeddings owned by the parent), waits for all reductions and resets the counters.
+    The FNO rollout modules keep ONE bucket (FlatGradAllReduce): BPTT accumulates every parameter gradient over all net
+    calls, so nothing is final before backward ends.
+    """
+
+    def __init__(self, model, flat_grad, bucket_bytes=25 * 2 ** 20, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.flat_grad = flat_grad
+        base, total = flat_grad.data_ptr(), flat_grad.numel()
+        spans = []                                    # (lo, hi, module): element range of the unit's parameters
+        for unit in self._units(model):
+            ps = [p for p in unit.parameters() if p.requires_grad and p.grad is not None]
+            if not ps:
+                continue
+            lo = min((p.grad.data_ptr() - base) // 4 for p in ps)
+            hi = max((p.grad.data_ptr() - base) // 4 + p.numel() for p in ps)
+            if 0 <= lo and hi <= total and sum(p.numel() for p in ps) + 4 * len(ps) >= hi - lo:     # contiguous up to padding
+                spans.append((lo, hi, unit))
+        spans.sort(key=lambda t: t[0])
+        spans = [sp for k, sp in enumerate(spans) if k == 0 or sp[0] >= spans[k - 1][1]]       # drop overlapping units
+        self.buckets = []                             # dict(lo, hi, units)
+        for lo, hi, unit in spans:
+            last = self.buckets[-1] if self.buckets else None
+            if last and (last["hi"] - last["lo"]) * 4 < bucket_bytes and lo - last["hi"] <= 4:
+                last["hi"] = hi
+                last["units"].append(unit)
+            else:
+                self.buckets.append({"lo": lo, "hi": hi, "units": [unit]})
+        self.leftover, pos = [], 0                    # ranges outside every bucket: reduced by finish()
+        for bk in self.buckets:
+            if bk["lo"] > pos:
+                self.leftover.append((pos, bk["lo"]))
+            pos = bk["hi"]
+        if pos < total:
+            self.leftover.append((pos, total))
+        self._unit_bucket, self._fwd, self._bwd = {}, {}, {}
+        self._handles, self._works = [], []
+        for j, bk in enumerate(self.buckets):
+            for unit in bk["units"]:
+                self._unit_bucket[id(unit)] = j
+                self._fwd[id(unit)] = self._bwd[id(unit)] = 0
+                self._handles.append(unit.register_forward_pre_hook(self._on_forward))
+                self._handles.append(unit.register_full_backward_hook(self._on_backward))
+        self._done = [False] * len(self.buckets)
+
+    @staticmethod
+    def _units(model):
+        import torch.nn as nn
+        out = []
+        for child in model.children():
+            if isinstance(child, (nn.ModuleList, nn.Sequential)):
+                out.extend(BucketedGradAllReduce._units(child))
+            else:
+                out.append(child)
+        return out
+
+    def _on_forward(self, module, args):
+        import torch
+        if torch.is_grad_enabled():
+            self._fwd[id(module)] += 1
+
+    def _on_backward(self, module, grad_input, grad_output):
+        if all(g is None for g in grad_input):
+            return                                    # fired on ENTRY (no input needs a gradient): parameters not final yet
+        k = id(module)
+        self._bwd[k] += 1
+        j = self._unit_bucket[k]
+        if not self._done[j] and all(self._bwd[id(u)] >= self._fwd[id(u)] > 0 for u in self.buckets[j]["units"]):
+            self._launch(self.buckets[j]["lo"], self.buckets[j]["hi"])
+            self._done[j] = True
+
+    def _launch(self, lo, hi):
+        if self.world == 1 or hi <= lo:
+            return
+        try:
+            self._works.append(dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        except Exception as exc:          # noqa: BLE001
+            _fail("bucketed gradient all-reduce", exc)
+
+    def finish(self):
+        """Reduce what no hook released, wait for every reduction, reset the counters.  Returns Adam's scale 1 / world."""
+        self.overlapped = sum(self._done)             # buckets that went out during backward (diagnostics / tests)
+        for j, bk in enumerate(self.buckets):
+            if not self._done[j]:
+                self._launch(bk["lo"], bk["hi"])
+        for lo, hi in self.leftover:
+            self._launch(lo, hi)
+        try:
+            for w in self._works:
+                w.wait()
+        except Exception as exc:          # noqa: BLE001
+            _fail("bucketed gradient all-reduce", exc)
+        self._works = []
+        self._done = [False] * len(self.buckets)
+        for k in self._fwd:
+            self._fwd[k] = self._bwd[k] = 0
+        return 1.0 / self.world
+
+    def __call__(self, flat_grad=None):
+        return self.finish()
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+
+class RcclComm:
+    """The C ABI's own RCCL communicator (include/dlwpmi.h: dlwp_comm_*), for hosts that do not route the exchange through
+    torch.distributed.  The 128-byte unique id travels over whatever side channel the host has; here: an already initialised
+    torch.distributed group of ANY backend (gloo is enough) or, at world 1, nothing at all."""
+
+    def __init__(self, rank=0, world=1, group=None):
+        import ctypes as C
+        from . import lib as L
+        self.L, self.lib = L, L.load()
+        uid = (C.c_char * 128)()
+        if rank == 0:
+            L.check(self.lib.dlwp_comm_unique_id(C.cast(uid, C.c_void_p)))
+        if world > 1:
+            box = [bytes(uid)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            uid = (C.c_char * 128).from_buffer_copy(box[0])
+        h = C.c_void_p()
+        L.check(self.lib.dlwp_comm_create(C.cast(uid, C.c_void_p), rank, world, C.byref(h)))
+        self.h, self.rank, self.world = h, rank, world
+
+    def all_reduce(self, flat):
+        self.L.check(self.lib.dlwp_comm_allreduce(self.h, self.L.ptr(flat), flat.numel(), self.L.stream()))
+        return 1.0 / self.world
+
+    __call__ = all_reduce
+
+    def broadcast(self, flat, root=0):
+        self.L.check(self.lib.dlwp_comm_broadcast(self.h, self.L.ptr(flat), flat.numel(), root, self.L.stream()))
+
+    def close(self):
+        if self.h:
+            self.lib.dlwp_comm_destroy(self.h)
+            self.h = None

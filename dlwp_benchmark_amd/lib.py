@@ -86,7 +86,14 @@ SIGNATURES = {
     "dlwp_window_attn_fwd": (_I, [_V] * 7 + [_I] * 7 + [_F, _V]),
     "dlwp_window_attn_bwd": (_I, [_V] * 12 + [_I] * 7 + [_F, _V]),
     "dlwp_window_attn_bwd_slab_floats": (_L, [_I] * 4),
+    "dlwp_window_softmax_fwd": (_I, [_V] * 5 + [_I] * 5 + [_F, _V]),
+    "dlwp_window_softmax_bwd": (_I, [_V] * 5 + [_I] * 5 + [_F, _V]),
     "dlwp_fno_spatial_fwd_probe": (_I, [_V, _V, _V, _V, _V, _V, _V, _I, _V]),
+    "dlwp_comm_unique_id": (_I, [_V]),
+    "dlwp_comm_create": (_I, [_V, _I, _I, C.POINTER(_V)]),
+    "dlwp_comm_destroy": (None, [_V]),
+    "dlwp_comm_allreduce": (_I, [_V, _V, _L, _V]),
+    "dlwp_comm_broadcast": (_I, [_V, _V, _L, _I, _V]),
     "dlwp_fno_mix_fwd_probe": (_I, [_V, _V, _V, _V, _V, _I, _V]),
     "dlwp_debug_null_kernels": (_I, [_I, _I, _V]),
     "dlwp_debug_spin_kernels": (_I, [_I, _I, _I, _I, _I, _V]),

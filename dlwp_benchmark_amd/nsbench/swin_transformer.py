@@ -21,12 +21,14 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import lib as L
-from ..token_ops import _grad_slot, DropPath, LayerNorm, Linear, Mlp, PatchConv2d, UpConvT2d
+from ..token_ops import _gemm_batched, _grad_slot, DropPath, LayerNorm, Linear, Mlp, PatchConv2d, UpConvT2d
 from ..window_ops import WindowSpec, partition, reverse
 
 
 class _WindowAttnFn(torch.autograd.Function):
-    """softmax(scale q k^T + table[ia[q] + ib[k]][type] + mask) v on libdlwpmi (dlwp_window_attn_fwd/bwd)."""
+    """softmax(scale q k^T + table[ia[q] + ib[k]][type] + mask) v on libdlwpmi: the fused flash-style kernels
+    (dlwp_window_attn_fwd/bwd, head_dim <= 64) or, for the wide heads of the deep U-Net stages (small token maps), batched
+    MFMA GEMMs around the row-softmax kernels (dlwp_window_softmax_fwd/bwd)."""
 
     @staticmethod
     def forward(ctx, qkv, table, ia, ib, labels, nW, heads, scale):
@@ -38,25 +40,53 @@ class _WindowAttnFn(torch.autograd.Function):
         TB = table.shape[0]
         ntypes = table.shape[1] if table.dim() == 3 else 1
         out = torch.empty(B_, N, heads * d, device=qkv.device)
+        ctx.aux, ctx.cfg = (ia, ib, labels), (B_, nW, N, TB, ntypes, heads, d, scale)
+        ctx.tslot = _grad_slot(table_param)
+        ctx.wide = d > 64
+        if ctx.wide:
+            if N > 1024 or d % 4:
+                raise L.DlwpError(f"window attention: head_dim {d} > 64 needs N <= 1024 tokens and head_dim % 4 == 0 (N = {N})")
+            rs, hd = 3 * heads * d, heads * d
+            p = torch.empty(B_, heads, N, N, device=qkv.device)
+            _gemm_batched(qkv, qkv, p, N, N, d, rs, rs, N, 0, 1, B_, heads, (N * rs, d), (N * rs, d), (heads * N * N, N * N),
+                          oB=hd)                                                   # s = q k^T
+            L.check(lib.dlwp_window_softmax_fwd(L.ptr(p), L.ptr(table), L.ptr(ia), L.ptr(ib), L.ptr(labels), B_, nW, N, ntypes,
+                                                heads, scale, L.stream()))
+            _gemm_batched(p, qkv, out, N, d, N, N, rs, hd, 0, 0, B_, heads, (heads * N * N, N * N), (N * rs, d), (N * hd, d),
+                          oB=2 * hd)                                               # o = p v
+            ctx.save_for_backward(qkv, table, p)
+            return out
         lse = torch.empty(B_, heads, N, device=qkv.device)
         L.check(lib.dlwp_window_attn_fwd(L.ptr(qkv), L.ptr(table), L.ptr(ia), L.ptr(ib), L.ptr(labels), L.ptr(out),
                                          L.ptr(lse), B_, nW, N, TB, ntypes, heads, d, scale, L.stream()))
         ctx.save_for_backward(qkv, table, out, lse)
-        ctx.aux, ctx.cfg = (ia, ib, labels), (B_, nW, N, TB, ntypes, heads, d, scale)
-        ctx.tslot = _grad_slot(table_param)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         lib = L.load()
-        qkv, table, out, lse = ctx.saved_tensors
         ia, ib, labels = ctx.aux
         B_, nW, N, TB, ntypes, heads, d, scale = ctx.cfg
+        g = gout.contiguous().float()  # kept alive until the launch is enqueued
+        if ctx.wide:
+            qkv, table, p = ctx.saved_tensors
+            gtable = ctx.tslot if ctx.tslot is not None else torch.zeros_like(table)   # kernel accumulates
+            rs, hd = 3 * heads * d, heads * d
+            gqkv = torch.empty_like(qkv)
+            sP, sQ, sO = (heads * N * N, N * N), (N * rs, d), (N * hd, d)
+            _gemm_batched(p, g, gqkv, N, d, N, N, hd, rs, 1, 0, B_, heads, sP, sO, sQ, oC=2 * hd)     # dv = p^T do
+            dp = torch.empty_like(p)
+            _gemm_batched(g, qkv, dp, N, N, d, hd, rs, N, 0, 1, B_, heads, sO, sQ, sP, oB=2 * hd)     # dp = do v^T
+            L.check(lib.dlwp_window_softmax_bwd(L.ptr(p), L.ptr(dp), L.ptr(gtable), L.ptr(ia), L.ptr(ib), B_, nW, N, ntypes,
+                                                heads, scale, L.stream()))                            # dp <- scale ds
+            _gemm_batched(dp, qkv, gqkv, N, d, N, N, rs, rs, 0, 0, B_, heads, sP, sQ, sQ, oB=hd)      # dq = ds k
+            _gemm_batched(dp, qkv, gqkv, N, d, N, N, rs, rs, 1, 0, B_, heads, sP, sQ, sQ, oC=hd)      # dk = ds^T q
+            return gqkv, (None if ctx.tslot is not None else gtable), None, None, None, None, None, None
+        qkv, table, out, lse = ctx.saved_tensors
         gqkv = torch.empty_like(qkv)
         gtable = ctx.tslot if ctx.tslot is not None else torch.zeros_like(table)   # kernel accumulates
         dsum = torch.empty_like(lse)
         slab = torch.empty(lib.dlwp_window_attn_bwd_slab_floats(B_, N, heads, TB), device=qkv.device)
-        g = gout.contiguous().float()  # kept alive until the launch is enqueued
         L.check(lib.dlwp_window_attn_bwd(L.ptr(qkv), L.ptr(table), L.ptr(ia), L.ptr(ib), L.ptr(labels), L.ptr(out),
                                          L.ptr(lse), L.ptr(g), L.ptr(gqkv), L.ptr(gtable),
                                          L.ptr(dsum), L.ptr(slab), B_, nW, N, TB, ntypes, heads, d, scale, L.stream()))

@@ -78,6 +78,9 @@ class GraphedTrainStep:
         self.opt = FusedAdam(self.flat, self.grad, lr=lr)
         self.inputs = {k: v.clone() for k, v in inputs.items()}
         self.target = target.clone()
+        if use_graph and hasattr(allreduce, "finish"):
+            raise L.DlwpError("a bucketed reducer (ddp.BucketedGradAllReduce) launches collectives from backward hooks: build "
+                              "the step with use_graph=False (the overlap replaces the capture for the large 1-step models)")
         self.clip, self.allreduce, self.grad_scale = clip_max_norm, allreduce, grad_scale
         self.call = call or (lambda m, kw: m(**kw))
         self.loss = torch.zeros((), device=self.flat.device)

@@ -243,6 +243,16 @@ int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, const int* i
                          float* gqkv, float* gbias_table, float* dsum, float* slab, int B_, int nW,
                          int N, int TB, int ntypes, int heads, int d, float scale, void* stream);
 
+/* Head dimensions above 64 (deep stages of the nsbench Swin U-Net: the shipped swintransformer.yaml reaches    */
+/* head_dim 192 on its 4 x 4 token map): the host runs q k^T and p v as dlwp_gemm_batched around these two row      */
+/* kernels, with the scores s / p [B_, heads, N, N] in HBM (N <= 1024).                                              */
+/*   fwd (in place): p = softmax(scale s + table[ia[q] + ib[k]][window % ntypes][head] + mask)                      */
+/*   bwd (in place): ds = p (dp - rowsum(p dp)); gbias_table += ds; dp <- scale ds                                  */
+int dlwp_window_softmax_fwd(float* s, const float* bias_table, const int* ia, const int* ib, const int* labels,
+                            int B_, int nW, int N, int ntypes, int heads, float scale, void* stream);
+int dlwp_window_softmax_bwd(const float* p, float* dp, float* gbias_table, const int* ia, const int* ib, int B_,
+                            int nW, int N, int ntypes, int heads, float scale, void* stream);
+
 /* General-grid AFNO2D (grids whose block spectrum does not fit LDS): the transforms run as     */
 /* dlwp_gemm_batched against DFT tables and the per-mode block MLP as batched GEMMs over the     */
 /* channel blocks, on the real image of the complex block weights w [2][nb][bs_in][bs_out]       */
@@ -371,6 +381,23 @@ int dlwp_cmode_product(const float* in, const float* U, float* out, int O, int R
                        void* stream);
 int dlwp_cmode_product_bwd(const float* in, const float* U, const float* gout, float* gin,
                            float* gU, int O, int R, int N, int I, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Data-parallel exchange over RCCL (xGMI).  The reference trains single-process            */
+/* (nsbench/scripts/train.py:36,66); sharding trajectory samples over the GPUs of a node is a  */
+/* build addition whose only collective is ONE sum all-reduce of the flat fp32  */
+/* gradient buffer per optimizer step (then Adam with grad_scale = 1 / world).  One communicator */
+/* per process / GPU: rank 0 calls dlwp_comm_unique_id and hands the 128 bytes to every rank     */
+/* (any side channel), every rank calls dlwp_comm_create (blocks until all have joined).         */
+/* Collectives are enqueued on the caller's stream.  librccl is loaded at the first call.        */
+typedef struct dlwp_comm dlwp_comm;
+int dlwp_comm_unique_id(void* out128);
+int dlwp_comm_create(const void* unique_id128, int rank, int world, dlwp_comm** out);
+void dlwp_comm_destroy(dlwp_comm* comm);
+/* buf[0:n] <- sum over ranks (in place)                                                   */
+int dlwp_comm_allreduce(dlwp_comm* comm, float* buf, long long n, void* stream);
+/* buf[0:n] <- root's buf (initial parameters, Adam state on resume)                       */
+int dlwp_comm_broadcast(dlwp_comm* comm, float* buf, long long n, int root, void* stream);
 
 /* bench probe: ONE forward `spatial` launch of an inner FNO block as the rollout issues it     */
 /* (x = previous pre-activation, GELU on load; spec = [B][m1][m2c][C][2] mixed modes; fused      */

@@ -123,3 +123,31 @@ def test_dlwp_batches_two_ranks_equal_one_rank(tmp_path):
     ref, _ = _dlwp_grad(np.concatenate([shards[0][0], shards[1][0]]))
     err = (got["grad"] - ref).abs().max() / ref.abs().max()
     assert err < 1e-5, err
+
+
+# ---- a failed collective ends the rank with a non-zero exit code ("rank exits non-zero on RCCL error")
+def _failing_worker(rank, world, port):
+    import datetime
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=20))
+    g = torch.ones(1000)
+    ddp.FlatGradAllReduceChecked()(g)              # a first, healthy step
+    if rank == 1:
+        os._exit(0)                                # the peer dies between two steps
+    ddp.FlatGradAllReduceChecked()(g)              # rank 0: the collective fails -> os._exit(13)
+    os._exit(0)                                    # not reached
+
+
+def test_collective_error_exits_non_zero():
+    ctx = mp.get_context("spawn")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+    assert procs[1].exitcode == 0
+    assert procs[0].exitcode == 13, procs[0].exitcode

@@ -122,12 +122,16 @@ def test_instance_norm_matches_torch(cuda, B, H, W, C):
     gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
     beta = torch.randn(C, generator=g).requires_grad_(True)
     gy = torch.randn(B, H, W, C, generator=g)
-    # the reference leaf is a CONTIGUOUS channels-first copy: torch's CPU instance_norm backward returns wrong input gradients
-    # for a permuted (non-contiguous) input with batch size 1 (tools/debug_instnorm.py: it disagrees with the closed form)
-    xcf = x.detach().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
-    yr = torch.nn.functional.instance_norm(xcf, weight=gamma, bias=beta, eps=1e-6).permute(0, 2, 3, 1) + res
-    yr.backward(gy)
-    x_grad = xcf.grad.permute(0, 2, 3, 1)
+    # reference: the definition of nn.InstanceNorm2d(affine=True) written out in float64 and differentiated by autograd
+    # (biased variance over H x W per sample and channel).  torch's fused CPU instance_norm backward disagrees with this
+    # closed form when the batch size is 1 (tools/debug_instnorm.py), so it is not used as the reference here.
+    xd64 = x.detach().double().requires_grad_(True)
+    g64, b64, r64 = (t.detach().double().requires_grad_(True) for t in (gamma, beta, res))
+    mu = xd64.mean(dim=(1, 2), keepdim=True)
+    var = ((xd64 - mu) ** 2).mean(dim=(1, 2), keepdim=True)
+    yr = (xd64 - mu) / torch.sqrt(var + 1e-6) * g64 + b64 + r64
+    yr.backward(gy.double())
+    x_grad = xd64.grad
     m = InstanceNorm(C, eps=1e-6).to(cuda)
     with torch.no_grad():
         m.weight.copy_(gamma)
@@ -141,6 +145,6 @@ def test_instance_norm_matches_torch(cuda, B, H, W, C):
         return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
     assert rel(y, yr) <= 1e-4
     assert rel(xd.grad, x_grad) <= 1e-3
-    assert rel(rd.grad, res.grad) <= 1e-6
-    assert rel(m.weight.grad, gamma.grad) <= 1e-3
-    assert rel(m.bias.grad, beta.grad) <= 1e-3
+    assert rel(rd.grad, r64.grad) <= 1e-6
+    assert rel(m.weight.grad, g64.grad) <= 1e-3
+    assert rel(m.bias.grad, b64.grad) <= 1e-3
