@@ -1,0 +1,436 @@
+// rFFT2 / irFFT2 of real fields, any size, with the butterflies staged in LDS.
+// Reference call sites: torch.fft.rfft2(x, dim=(1, 2), norm="ortho") / irfft2 over the MIDDLE dims of a channels-last
+// [B, H, W, C] tensor in AFNO2D.forward (src/nsbench/models/fourcastnet/fourcastnet.py:84,123; dlwpbench twin :85,124),
+// and rfftn / irfftn(norm="forward") over the last two dims of [B, C, H, W] inside neuralop's SpectralConv (third party,
+// SURVEY.md App. A-1).  The pruned-DFT GEMMs of fno_block.hip / afno.hip / afno_tiled.py cover mode-truncated layers on
+// small grids; this is the general path: patch-1 AFNO on 128 x 256 or 721 x 1440 (721 = 7 * 103) needs all modes of a grid
+// where a dense DFT is quadratic.
+//
+// MI355X design.  A 2-D transform is two passes over HBM (W axis, then H axis), each an HBM-bound streaming kernel:
+//   * one workgroup = one signal position range x IB "inner" lanes that are CONTIGUOUS in memory (channels-last: channels;
+//     channels-first: the kept columns), so every global access of a pass is a coalesced row of IB complex numbers;
+//   * the workgroup's [N][IB] complex tile lives in LDS (row pitch IB + 1: conflict-free column walks); a mixed-radix
+//     Stockham FFT runs on it IN PLACE: per pass every thread accumulates its outputs in registers (one output = R complex
+//     multiply-adds against the twiddle table, also in LDS), barrier, writes them back, barrier.  Radices come from the
+//     factorisation of N (4, 2, 3, 5, 7, then whatever prime is left: 721 -> 7 x 103 costs 110 multiply-adds per point, still
+//     linear in N); no transposes, no global scratch between the butterfly passes;
+//   * real transforms pack TWO real signals into one complex one (two adjacent channels channels-last: a float2 load IS the
+//     packed sample; two adjacent rows channels-first) and split / merge the Hermitian halves on the way out / in;
+//   * normalisation, the Hermitian weights of the adjoint transforms (interior bins count twice) and the
+//     real-part selection ride in the store / load stages: no extra pass for the backward transforms.
+#include "common.cuh"
+#include "dlwpmi_internal.h"
+#include <cmath>
+#include <vector>
+
+namespace {
+
+constexpr int MAXRAD = 16;
+
+struct FftAxis {
+    int N, nrad, IB, logIB;          // signal length, number of passes, inner lanes per workgroup (power of two)
+    int rad[MAXRAD];
+    FastDiv dp[MAXRAD], dM[MAXRAD];  // division by p (product of the earlier radices) and by M = p * R
+    const float2* tab;               // [N] e^{-2 pi i n / N} (device)
+};
+
+// In-place mixed-radix Stockham FFT of buf[N][IB + 1] (complex, LDS); tabs [N] twiddles in LDS; sg = -1 forward, +1 inverse.
+// Output m = blk * M + q * p + k  <-  sum_r in[(blk * p + k) + r * N / R] * w^(r * (k + q * p)),  w = e^{sg 2 pi i / M}.
+template <int OUTS, int NT>
+__device__ __forceinline__ void lds_fft(float2* buf, const float2* tabs, const FftAxis& f, float sg) {
+    const int IBP = f.IB + 1, total = f.N << f.logIB, tid = threadIdx.x;
+    int p = 1;
+    for (int s = 0; s < f.nrad; ++s) {
+        const int R = f.rad[s], t = f.N / R, M = p * R, step = f.N / M;
+        float2 acc[OUTS];
+#pragma unroll
+        for (int u = 0; u < OUTS; ++u) {
+            const int e = tid + u * NT;
+            float ar = 0.f, ai = 0.f;
+            if (e < total) {
+                const int lane = e & (f.IB - 1), m = e >> f.logIB;
+                const int blk = fastdiv(m, f.dM[s]), rem = m - blk * M, q = fastdiv(rem, f.dp[s]), k = rem - q * p;
+                const float2* xin = buf + (blk * p + k) * IBP + lane;
+                const int cs = (k + q * p) * step, tstride = t * IBP;
+                int es = 0;
+                for (int r = 0; r < R; ++r) {
+                    const float2 v = xin[r * tstride];
+                    const float2 w = tabs[es];
+                    const float wy = sg * w.y;          // table holds e^{-i...}: sg = -1 keeps it, +1 conjugates
+                    ar += v.x * w.x + v.y * wy;         // v * (w.x - i wy)  with wy = sg * w.y and w.y = -sin
+                    ai += v.y * w.x - v.x * wy;
+                    es += cs;
+                    if (es >= f.N) es -= f.N;
+                }
+            }
+            acc[u] = make_float2(ar, ai);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < OUTS; ++u) {
+            const int e = tid + u * NT;
+            if (e < total) buf[(e >> f.logIB) * IBP + (e & (f.IB - 1))] = acc[u];
+        }
+        __syncthreads();
+        p = M;
+    }
+}
+
+struct FftIO {
+    FftAxis ax;
+    const float* in; float* out;
+    long long outer;          // number of outer units (grid.y)
+    int C, H, W, Wc;          // C: channels (CL) / unused (CF)
+    long long nrows;          // CF real passes: B * C * H rows
+    long long J;              // C2C: inner contiguous length (complex), axis stride = J
+    float scale, w_int;       // output scale; weight of the interior (non-DC, non-Nyquist) bins
+    float sg;                 // C2C direction
+};
+
+__device__ __forceinline__ void load_table(float2* tabs, const FftAxis& f) {
+    for (int i = threadIdx.x; i < f.N; i += blockDim.x) tabs[i] = f.tab[i];
+}
+
+// ---- W-axis real -> complex.  CF = false: channels-last, lanes = channel pairs of row (b, h) = blockIdx.y;
+//      CF = true: channels-first, lanes = pairs of image rows (2 IB consecutive rows per workgroup, blockIdx.y).
+template <int OUTS, int NT, bool CF>
+__global__ __launch_bounds__(NT) void fft_r2c_kernel(FftIO a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const FftAxis& f = a.ax;
+    const int IBP = f.IB + 1, W = f.N, Wh = W / 2;
+    float2* buf = reinterpret_cast<float2*>(smem);   // [W][IBP]
+    float2* tabs = buf + W * IBP;                    // [W]
+    load_table(tabs, f);
+    const long long o = blockIdx.y;
+    const int c0 = CF ? 0 : blockIdx.x * 2 * f.IB;
+    const long long r0 = CF ? o * 2 * f.IB : 0;
+    // packed load: z[w] = x1[w] + i x2[w]
+    if (!CF) {
+        const int nl = min(f.IB, (a.C - c0) / 2);
+        const float* src = a.in + o * W * a.C + c0;
+        for (int e = threadIdx.x; e < W << f.logIB; e += NT) {
+            const int lane = e & (f.IB - 1), w = e >> f.logIB;
+            float2 v = make_float2(0.f, 0.f);
+            if (lane < nl) v = *reinterpret_cast<const float2*>(src + (long long)w * a.C + 2 * lane);
+            buf[w * IBP + lane] = v;
+        }
+    } else {
+        for (int e = threadIdx.x; e < W * 2 * f.IB; e += NT) {      // threads run along w: coalesced rows
+            const int rr = e / W, w = e - rr * W;
+            const long long row = r0 + rr;
+            const float v = row < a.nrows ? a.in[row * W + w] : 0.f;
+            float* dst = reinterpret_cast<float*>(&buf[w * IBP + (rr >> 1)]);
+            dst[rr & 1] = v;
+        }
+    }
+    __syncthreads();
+    lds_fft<OUTS, NT>(buf, tabs, f, -1.f);
+    // split the two spectra: X1 = (Z_k + conj Z_{W-k}) / 2,  X2 = -i (Z_k - conj Z_{W-k}) / 2
+    if (!CF) {
+        const int nl = min(f.IB, (a.C - c0) / 2);
+        float* dst = a.out + (o * a.Wc * a.C + c0) * 2;
+        for (int e = threadIdx.x; e < (Wh + 1) << f.logIB; e += NT) {
+            const int lane = e & (f.IB - 1), k = e >> f.logIB;
+            if (lane >= nl) continue;
+            const float2 zk = buf[k * IBP + lane], zm = buf[(k ? W - k : 0) * IBP + lane];
+            const bool edge = k == 0 || 2 * k == W;
+            const float s = 0.5f * a.scale * (edge ? 1.f : a.w_int);
+            const float4 v = make_float4(s * (zk.x + zm.x), s * (zk.y - zm.y), s * (zk.y + zm.y), s * (zm.x - zk.x));
+            *reinterpret_cast<float4*>(dst + ((long long)k * a.C + 2 * lane) * 2) = v;
+        }
+    } else {
+        for (int e = threadIdx.x; e < (Wh + 1) * 2 * f.IB; e += NT) {     // threads run along k
+            const int rr = e / (Wh + 1), k = e - rr * (Wh + 1);
+            const long long row = r0 + rr;
+            if (row >= a.nrows) continue;
+            const float2 zk = buf[k * IBP + (rr >> 1)], zm = buf[(k ? W - k : 0) * IBP + (rr >> 1)];
+            const bool edge = k == 0 || 2 * k == W;
+            const float s = 0.5f * a.scale * (edge ? 1.f : a.w_int);
+            const float2 v = (rr & 1) ? make_float2(s * (zk.y + zm.y), s * (zm.x - zk.x)) : make_float2(s * (zk.x + zm.x), s * (zk.y - zm.y));
+            reinterpret_cast<float2*>(a.out)[row * a.Wc + k] = v;
+        }
+    }
+}
+
+// ---- W-axis complex (Hermitian half) -> real
+template <int OUTS, int NT, bool CF>
+__global__ __launch_bounds__(NT) void fft_c2r_kernel(FftIO a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const FftAxis& f = a.ax;
+    const int IBP = f.IB + 1, W = f.N, Wh = W / 2;
+    float2* buf = reinterpret_cast<float2*>(smem);
+    float2* tabs = buf + W * IBP;
+    load_table(tabs, f);
+    const long long o = blockIdx.y;
+    const int c0 = CF ? 0 : blockIdx.x * 2 * f.IB;
+    const long long r0 = CF ? o * 2 * f.IB : 0;
+    // merge: Z_k = Y1_k + i Y2_k, Z_{W-k} = conj(Y1_k) + i conj(Y2_k); DC / Nyquist use the real parts only
+    if (!CF) {
+        const int nl = min(f.IB, (a.C - c0) / 2);
+        const float* src = a.in + (o * a.Wc * a.C + c0) * 2;
+        for (int e = threadIdx.x; e < (Wh + 1) << f.logIB; e += NT) {
+            const int lane = e & (f.IB - 1), k = e >> f.logIB;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lane < nl) v = *reinterpret_cast<const float4*>(src + ((long long)k * a.C + 2 * lane) * 2);
+            const bool edge = k == 0 || 2 * k == W;
+            const float wk = edge ? 1.f : a.w_int;
+            float y1x = wk * v.x, y1y = edge ? 0.f : wk * v.y, y2x = wk * v.z, y2y = edge ? 0.f : wk * v.w;
+            buf[k * IBP + lane] = make_float2(y1x - y2y, y1y + y2x);
+            if (!edge) buf[(W - k) * IBP + lane] = make_float2(y1x + y2y, y2x - y1y);
+        }
+    } else {
+        // zero first (pairs are assembled by two threads each), then accumulate the two rows of every pair
+        for (int e = threadIdx.x; e < W * IBP; e += NT) buf[e] = make_float2(0.f, 0.f);
+        __syncthreads();
+        for (int e = threadIdx.x; e < (Wh + 1) * f.IB; e += NT) {          // one thread builds a whole pair: no races
+            const int lane = e / (Wh + 1), k = e - lane * (Wh + 1);
+            const long long ra = r0 + 2 * lane, rb = ra + 1;
+            const float2 y1 = ra < a.nrows ? reinterpret_cast<const float2*>(a.in)[ra * a.Wc + k] : make_float2(0.f, 0.f);
+            const float2 y2 = rb < a.nrows ? reinterpret_cast<const float2*>(a.in)[rb * a.Wc + k] : make_float2(0.f, 0.f);
+            const bool edge = k == 0 || 2 * k == W;
+            const float wk = edge ? 1.f : a.w_int;
+            const float y1x = wk * y1.x, y1y = edge ? 0.f : wk * y1.y, y2x = wk * y2.x, y2y = edge ? 0.f : wk * y2.y;
+            buf[k * IBP + lane] = make_float2(y1x - y2y, y1y + y2x);
+            if (!edge) buf[(W - k) * IBP + lane] = make_float2(y1x + y2y, y2x - y1y);
+        }
+    }
+    __syncthreads();
+    lds_fft<OUTS, NT>(buf, tabs, f, +1.f);
+    if (!CF) {
+        const int nl = min(f.IB, (a.C - c0) / 2);
+        float* dst = a.out + o * W * a.C + c0;
+        for (int e = threadIdx.x; e < W << f.logIB; e += NT) {
+            const int lane = e & (f.IB - 1), w = e >> f.logIB;
+            if (lane >= nl) continue;
+            const float2 z = buf[w * IBP + lane];
+            *reinterpret_cast<float2*>(dst + (long long)w * a.C + 2 * lane) = make_float2(a.scale * z.x, a.scale * z.y);
+        }
+    } else {
+        for (int e = threadIdx.x; e < W * 2 * f.IB; e += NT) {
+            const int rr = e / W, w = e - rr * W;
+            const long long row = r0 + rr;
+            if (row >= a.nrows) continue;
+            const float2 z = buf[w * IBP + (rr >> 1)];
+            a.out[row * W + w] = a.scale * ((rr & 1) ? z.y : z.x);
+        }
+    }
+}
+
+// ---- complex -> complex along an axis of stride J (the H axis of both layouts): element (o, n, j) at ((o * N + n) * J + j)
+template <int OUTS, int NT>
+__global__ __launch_bounds__(NT) void fft_c2c_kernel(FftIO a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const FftAxis& f = a.ax;
+    const int IBP = f.IB + 1, N = f.N;
+    float2* buf = reinterpret_cast<float2*>(smem);
+    float2* tabs = buf + N * IBP;
+    load_table(tabs, f);
+    const long long o = blockIdx.y, j0 = (long long)blockIdx.x * f.IB;
+    const int nl = (int)min((long long)f.IB, a.J - j0);
+    const float2* src = reinterpret_cast<const float2*>(a.in) + o * N * a.J + j0;
+    for (int e = threadIdx.x; e < N << f.logIB; e += NT) {
+        const int lane = e & (f.IB - 1), n = e >> f.logIB;
+        buf[n * IBP + lane] = lane < nl ? src[(long long)n * a.J + lane] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    lds_fft<OUTS, NT>(buf, tabs, f, a.sg);
+    float2* dst = reinterpret_cast<float2*>(a.out) + o * N * a.J + j0;
+    for (int e = threadIdx.x; e < N << f.logIB; e += NT) {
+        const int lane = e & (f.IB - 1), n = e >> f.logIB;
+        if (lane < nl) {
+            const float2 z = buf[n * IBP + lane];
+            dst[(long long)n * a.J + lane] = make_float2(a.scale * z.x, a.scale * z.y);
+        }
+    }
+}
+
+int factorise(int N, int* rad) {
+    int n = 0;
+    auto take = [&](int r) { while (N % r == 0 && n < MAXRAD) { rad[n++] = r; N /= r; } };
+    take(4); take(2); take(3); take(5); take(7);
+    for (int p = 11; N > 1 && n < MAXRAD; p += 2) take(p);
+    return N == 1 ? n : -1;
+}
+
+}  // namespace
+
+struct dlwp_fft_plan {
+    int H, W;
+    FftAxis axW, axH;         // IB chosen per axis from the LDS budget
+    float2 *tabW, *tabH;
+};
+
+namespace {
+
+int make_axis(FftAxis& ax, int N, float2** tab_dev, int ib_cap) {
+    ax.N = N;
+    ax.nrad = factorise(N, ax.rad);
+    DLWP_REQUIRE(ax.nrad > 0, DLWP_E_UNSUPPORTED, "fft: cannot factorise %d into at most %d radices", N, MAXRAD);
+    int p = 1;
+    for (int s = 0; s < ax.nrad; ++s) {
+        ax.dp[s] = make_fastdiv(p);
+        ax.dM[s] = make_fastdiv(p * ax.rad[s]);
+        p *= ax.rad[s];
+    }
+    // inner lanes: the widest power of two whose [N][IB + 1] tile plus the table fits ~150 KB of LDS
+    int ib = ib_cap;
+    while (ib > 1 && (size_t)N * (ib + 2) * sizeof(float2) > 150 * 1024) ib >>= 1;
+    DLWP_REQUIRE((size_t)N * (ib + 2) * sizeof(float2) <= 150 * 1024, DLWP_E_UNSUPPORTED, "fft: axis length %d does not fit LDS", N);
+    ax.IB = ib;
+    ax.logIB = 0;
+    while ((1 << ax.logIB) < ib) ++ax.logIB;
+    std::vector<float2> tab(N);
+    const double PI = 3.14159265358979323846;
+    for (int n = 0; n < N; ++n) tab[n] = make_float2((float)cos(2.0 * PI * n / N), (float)-sin(2.0 * PI * n / N));
+    DLWP_HIP(hipMalloc(reinterpret_cast<void**>(tab_dev), N * sizeof(float2)));
+    DLWP_HIP(hipMemcpy(*tab_dev, tab.data(), N * sizeof(float2), hipMemcpyHostToDevice));
+    ax.tab = *tab_dev;
+    return DLWP_OK;
+}
+
+size_t axis_lds(const FftAxis& ax) { return (size_t)ax.N * (ax.IB + 2) * sizeof(float2); }
+
+// thread count and outputs-per-thread bucket of an axis
+struct LaunchShape { int nt, outs; };
+LaunchShape shape_of(const FftAxis& ax) {
+    const int total = ax.N * ax.IB;
+    const int nt = total > 4096 ? 512 : 256;
+    const int need = ceil_div(total, nt);
+    const int buckets[] = {2, 4, 8, 16, 24, 32};
+    for (int b : buckets)
+        if (need <= b) return {nt, b};
+    return {nt, -1};
+}
+
+#define FFT_DISPATCH(KERNEL_T, EXTRA, sh, grid, lds, stream, io)                                                       \
+    do {                                                                                                               \
+        int rc__ = DLWP_OK;                                                                                            \
+        auto go = [&](auto kern, int nt) {                                                                             \
+            if ((rc__ = dlwp_ensure_lds(reinterpret_cast<const void*>(kern), lds, "fft"))) return;                     \
+            hipLaunchKernelGGL(kern, grid, dim3(nt), lds, stream, io);                                                 \
+        };                                                                                                             \
+        if (sh.nt == 256) {                                                                                            \
+            switch (sh.outs) {                                                                                         \
+                case 2: go(KERNEL_T<2, 256 EXTRA>, 256); break;                                                        \
+                case 4: go(KERNEL_T<4, 256 EXTRA>, 256); break;                                                        \
+                case 8: go(KERNEL_T<8, 256 EXTRA>, 256); break;                                                        \
+                default: go(KERNEL_T<16, 256 EXTRA>, 256); break;                                                      \
+            }                                                                                                          \
+        } else {                                                                                                       \
+            switch (sh.outs) {                                                                                         \
+                case 16: go(KERNEL_T<16, 512 EXTRA>, 512); break;                                                      \
+                case 24: go(KERNEL_T<24, 512 EXTRA>, 512); break;                                                      \
+                default: go(KERNEL_T<32, 512 EXTRA>, 512); break;                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+        if (rc__) return rc__;                                                                                         \
+    } while (0)
+#define COMMA_TRUE , true
+#define COMMA_FALSE , false
+#define NOTHING
+
+int run_w_real(const dlwp_fft_plan* p, bool to_complex, bool cf, const float* in, float* out, int B, int C, float scale,
+               float w_int, hipStream_t stream) {
+    FftIO io{};
+    io.ax = p->axW; io.in = in; io.out = out; io.C = C; io.H = p->H; io.W = p->W; io.Wc = p->W / 2 + 1;
+    io.scale = scale; io.w_int = w_int;
+    dim3 grid;
+    if (cf) {
+        io.nrows = (long long)B * C * p->H;
+        const long long nblk = (io.nrows + 2 * io.ax.IB - 1) / (2 * io.ax.IB);
+        DLWP_REQUIRE(nblk <= 65535LL * 32768, DLWP_E_UNSUPPORTED, "fft: too many rows");
+        DLWP_REQUIRE(nblk <= 65535, DLWP_E_UNSUPPORTED, "fft (channels-first): more than 65535 row blocks per call (%lld)", nblk);
+        grid = dim3(1, (unsigned)nblk);
+    } else {
+        DLWP_REQUIRE(C % 2 == 0, DLWP_E_UNSUPPORTED, "fft (channels-last): the channel count must be even (got %d)", C);
+        DLWP_REQUIRE((long long)B * p->H <= 65535, DLWP_E_UNSUPPORTED, "fft (channels-last): B * H > 65535 rows per call");
+        grid = dim3(ceil_div(C, 2 * io.ax.IB), B * p->H);
+    }
+    const LaunchShape sh = shape_of(io.ax);
+    DLWP_REQUIRE(sh.outs > 0, DLWP_E_UNSUPPORTED, "fft: axis of length %d needs more than 32 outputs per thread", io.ax.N);
+    const size_t lds = axis_lds(io.ax);
+    if (to_complex) {
+        if (cf) FFT_DISPATCH(fft_r2c_kernel, COMMA_TRUE, sh, grid, lds, stream, io);
+        else FFT_DISPATCH(fft_r2c_kernel, COMMA_FALSE, sh, grid, lds, stream, io);
+    } else {
+        if (cf) FFT_DISPATCH(fft_c2r_kernel, COMMA_TRUE, sh, grid, lds, stream, io);
+        else FFT_DISPATCH(fft_c2r_kernel, COMMA_FALSE, sh, grid, lds, stream, io);
+    }
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+int run_h_c2c(const dlwp_fft_plan* p, const float* in, float* out, long long outer, long long J, float sg, float scale,
+              hipStream_t stream) {
+    FftIO io{};
+    io.ax = p->axH; io.in = in; io.out = out; io.J = J; io.sg = sg; io.scale = scale;
+    DLWP_REQUIRE(outer <= 65535, DLWP_E_UNSUPPORTED, "fft: more than 65535 outer slices per call (%lld)", outer);
+    const dim3 grid((unsigned)((J + io.ax.IB - 1) / io.ax.IB), (unsigned)outer);
+    const LaunchShape sh = shape_of(io.ax);
+    DLWP_REQUIRE(sh.outs > 0, DLWP_E_UNSUPPORTED, "fft: axis of length %d needs more than 32 outputs per thread", io.ax.N);
+    const size_t lds = axis_lds(io.ax);
+    FFT_DISPATCH(fft_c2c_kernel, NOTHING, sh, grid, lds, stream, io);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+void norm_scales(int norm, int H, int W, float& sW_f, float& sH_f, float& sW_i, float& sH_i) {
+    // forward / inverse scale per axis for torch's norm = "backward" (0), "ortho" (1), "forward" (2)
+    if (norm == 1) { sW_f = sW_i = 1.f / sqrtf((float)W); sH_f = sH_i = 1.f / sqrtf((float)H); }
+    else if (norm == 2) { sW_f = 1.f / W; sH_f = 1.f / H; sW_i = sH_i = 1.f; }
+    else { sW_f = sH_f = 1.f; sW_i = 1.f / W; sH_i = 1.f / H; }
+}
+
+}  // namespace
+
+extern "C" int dlwp_fft_plan_create(int H, int W, dlwp_fft_plan** out) {
+    DLWP_REQUIRE(out && H > 0 && W > 1, DLWP_E_INVALID, "fft_plan_create: bad shape");
+    dlwp_fft_plan* p = new dlwp_fft_plan();
+    p->H = H; p->W = W; p->tabW = p->tabH = nullptr;
+    int rc;
+    if ((rc = make_axis(p->axW, W, &p->tabW, 8)) || (rc = make_axis(p->axH, H, &p->tabH, 16))) {
+        dlwp_fft_plan_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return DLWP_OK;
+}
+
+extern "C" void dlwp_fft_plan_destroy(dlwp_fft_plan* p) {
+    if (!p) return;
+    if (p->tabW) (void)hipFree(p->tabW);
+    if (p->tabH) (void)hipFree(p->tabH);
+    delete p;
+}
+
+// layout 0: channels-last x [B][H][W][C] <-> X [B][H][W/2+1][C][2]; layout 1: channels-first x [B][C][H][W] <-> X [B][C][H][W/2+1][2]
+extern "C" int dlwp_rfft2(const dlwp_fft_plan* p, const float* x, float* X, int B, int C, int layout, int norm, int adjoint,
+                          void* stream_) {
+    DLWP_REQUIRE(p && x && X && B > 0 && C > 0 && (layout == 0 || layout == 1) && norm >= 0 && norm <= 2, DLWP_E_INVALID,
+                 "rfft2: bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    float sWf, sHf, sWi, sHi;
+    norm_scales(norm, p->H, p->W, sWf, sHf, sWi, sHi);
+    const int Wc = p->W / 2 + 1;
+    // plain: X = s_f R x.  adjoint: gX = (irfft2)^H gx = s_i R_2 gx (interior bins weighted twice)
+    int rc = run_w_real(p, true, layout == 1, x, X, B, C, adjoint ? sWi : sWf, adjoint ? 2.f : 1.f, stream);
+    if (rc) return rc;
+    const long long outer = layout == 0 ? B : (long long)B * C, J = layout == 0 ? (long long)Wc * C : Wc;
+    return run_h_c2c(p, X, X, outer, J, -1.f, adjoint ? sHi : sHf, stream);
+}
+
+// work: scratch of X's size (the H-axis pass must not overwrite the caller's spectrum)
+extern "C" int dlwp_irfft2(const dlwp_fft_plan* p, const float* X, float* x, float* work, int B, int C, int layout, int norm,
+                           int adjoint, void* stream_) {
+    DLWP_REQUIRE(p && x && X && work && B > 0 && C > 0 && (layout == 0 || layout == 1) && norm >= 0 && norm <= 2, DLWP_E_INVALID,
+                 "irfft2: bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    float sWf, sHf, sWi, sHi;
+    norm_scales(norm, p->H, p->W, sWf, sHf, sWi, sHi);
+    const int Wc = p->W / 2 + 1;
+    const long long outer = layout == 0 ? B : (long long)B * C, J = layout == 0 ? (long long)Wc * C : Wc;
+    // plain: x = s_i Q X.  adjoint: gx = (rfft2)^H gX = s_f Q_{1/2} gX (interior bins weighted by one half)
+    int rc = run_h_c2c(p, X, work, outer, J, +1.f, adjoint ? sHf : sHi, stream);
+    if (rc) return rc;
+    return run_w_real(p, false, layout == 1, work, x, B, C, adjoint ? sWf : sWi, adjoint ? 0.5f : 1.f, stream);
+}

@@ -170,7 +170,8 @@ class BucketedGradAllReduce:
         k = id(module)
         self._bwd[k] += 1
         j = self._unit_bucket[k]
-        if not self._done[j] and all(self._bwd[id(u)] >= self._fwd[id(u)] > 0 for u in self.buckets[j]["units"]):
+        units = self.buckets[j]["units"]        # a unit the forward pass never entered (fwd == 0) receives no gradient at all
+        if not self._done[j] and all(self._bwd[id(u)] >= self._fwd[id(u)] for u in units):
             self._launch(self.buckets[j]["lo"], self.buckets[j]["hi"])
             self._done[j] = True
 

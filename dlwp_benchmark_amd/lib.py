@@ -89,6 +89,10 @@ SIGNATURES = {
     "dlwp_window_softmax_fwd": (_I, [_V] * 5 + [_I] * 5 + [_F, _V]),
     "dlwp_window_softmax_bwd": (_I, [_V] * 5 + [_I] * 5 + [_F, _V]),
     "dlwp_fno_spatial_fwd_probe": (_I, [_V, _V, _V, _V, _V, _V, _V, _I, _V]),
+    "dlwp_fft_plan_create": (_I, [_I, _I, C.POINTER(_V)]),
+    "dlwp_fft_plan_destroy": (None, [_V]),
+    "dlwp_rfft2": (_I, [_V, _V, _V, _I, _I, _I, _I, _I, _V]),
+    "dlwp_irfft2": (_I, [_V, _V, _V, _V, _I, _I, _I, _I, _I, _V]),
     "dlwp_comm_unique_id": (_I, [_V]),
     "dlwp_comm_create": (_I, [_V, _I, _I, C.POINTER(_V)]),
     "dlwp_comm_destroy": (None, [_V]),

@@ -253,6 +253,27 @@ int dlwp_window_softmax_fwd(float* s, const float* bias_table, const int* ia, co
 int dlwp_window_softmax_bwd(const float* p, float* dp, float* gbias_table, const int* ia, const int* ib, int B_,
                             int nW, int N, int ntypes, int heads, float scale, void* stream);
 
+/* ------------------------------------------------------------------------------------ */
+/* rFFT2 / irFFT2 of real fields of ANY size, butterflies staged in LDS (mixed-radix Stockham */
+/* per axis: radices 4, 2, 3, 5, 7 and whatever prime is left, e.g. 721 = 7 x 103).  Replaces  */
+/* torch.fft.rfft2 / irfft2(x, dim=(1, 2), norm="ortho") on channels-last [B, H, W, C] tensors  */
+/* (AFNO2D.forward, nsbench/models/fourcastnet/fourcastnet.py:84,123; dlwpbench twin :85,124)   */
+/* and rfftn / irfftn(norm="forward") over the last dims of [B, C, H, W] (neuralop SpectralConv, */
+/* App. A-1).  layout 0: x [B][H][W][C] <-> X [B][H][W/2+1][C][2] (C even);                      */
+/* layout 1: x [B][C][H][W] <-> X [B][C][H][W/2+1][2].  norm: 0 "backward", 1 "ortho",           */
+/* 2 "forward" (torch.fft's meaning).  adjoint != 0 selects the transposed transform of the       */
+/* OTHER direction with the same norm, i.e. the backward pass:                  */
+/*   dlwp_irfft2(adjoint=1): gX (spectrum) -> gx = rfft2^H gX   (interior bins weigh one half)     */
+/*   dlwp_rfft2 (adjoint=1): gx (field)    -> gX = irfft2^H gx  (interior bins weigh two)          */
+/* DC / Nyquist imaginary parts are ignored by irfft2, as in torch.  work: scratch of X's size.    */
+typedef struct dlwp_fft_plan dlwp_fft_plan;
+int dlwp_fft_plan_create(int H, int W, dlwp_fft_plan** out);
+void dlwp_fft_plan_destroy(dlwp_fft_plan* plan);
+int dlwp_rfft2(const dlwp_fft_plan* plan, const float* x, float* X, int B, int C, int layout, int norm,
+               int adjoint, void* stream);
+int dlwp_irfft2(const dlwp_fft_plan* plan, const float* X, float* x, float* work, int B, int C, int layout,
+                int norm, int adjoint, void* stream);
+
 /* General-grid AFNO2D (grids whose block spectrum does not fit LDS): the transforms run as     */
 /* dlwp_gemm_batched against DFT tables and the per-mode block MLP as batched GEMMs over the     */
 /* channel blocks, on the real image of the complex block weights w [2][nb][bs_in][bs_out]       */
