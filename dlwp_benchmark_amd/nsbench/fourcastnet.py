@@ -21,6 +21,9 @@ from .. import lib as L
 from ..token_ops import LayerNorm, Linear, Mlp, PatchConv2d, _grad_slot
 
 
+FFT_MIN_TOKENS = 262144     # token grids from this size on take the rFFT2 path in "auto" mode (see AFNO2D.forward)
+
+
 class _AFNO2DFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, nb, lam, frac):
@@ -64,7 +67,9 @@ class AFNO2D(nn.Module):
         assert hidden_size % num_blocks == 0, f"hidden_size {hidden_size} should be divisble by num_blocks {num_blocks}"
         if hidden_size_factor != 1:
             raise NotImplementedError("hidden_size_factor != 1 is not on the MI355X hot path")
-        self.path = "auto"      # "fused" (LDS-resident kernel), "tiled" (batched GEMMs, any grid) or "auto"
+        # "fused" (LDS-resident kernel), "tiled" (dense DFT as batched GEMMs, any grid), "fft" (LDS-staged rFFT2 kernels,
+        # any grid, even channel count) or "auto"
+        self.path = "auto"
         self.hidden_size, self.num_blocks = hidden_size, num_blocks
         self.block_size = hidden_size // num_blocks
         self.sparsity_threshold = sparsity_threshold
@@ -82,8 +87,17 @@ class AFNO2D(nn.Module):
         path = self.path
         if path == "auto":      # the fused kernel keeps a block's half spectrum in LDS: small grids, block size <= 16
             fits = L.load().dlwp_afno2d_save_elems(B, H, W, C, self.num_blocks, float(self.hard_thresholding_fraction)) >= 0
-            path = "fused" if fits else "tiled"
-        if path == "tiled":
+            # beyond the LDS-resident kernel (profiles/r02_fft_bench.txt, forward + backward): the dense-DFT GEMMs ride the
+            # matrix cores and stay ahead of the FFT path up to 256 x 512 tokens when the grid is a multiple of 4 (aligned
+            # 16-byte operand loads); on other grids (103 x 180: 18.5 ms vs 2.05 ms) and on grids where a dense DFT is out
+            # of the question (721 x 1440 at patch 1) the rFFT2 kernels take over
+            big = H * W >= FFT_MIN_TOKENS or H % 4 != 0 or W % 4 != 0
+            path = "fused" if fits else ("fft" if big and C % 2 == 0 else "tiled")
+        if path == "fft":
+            from ..afno_tiled import afno2d_fft
+            y = afno2d_fft(x, self.w1, self.b1, self.w2, self.b2, self.num_blocks, float(self.sparsity_threshold),
+                           float(self.hard_thresholding_fraction))
+        elif path == "tiled":
             from ..afno_tiled import afno2d_tiled
             y = afno2d_tiled(x, self.w1, self.b1, self.w2, self.b2, self.num_blocks, float(self.sparsity_threshold),
                              float(self.hard_thresholding_fraction))

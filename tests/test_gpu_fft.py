@@ -1,0 +1,67 @@
+"""rFFT2 / irFFT2 kernels (csrc/fft2d.hip) against torch.fft on the CPU (the fp32 reference of a floating-point kernel):
+channels-last "ortho" (the AFNO2D call, fourcastnet.py:84,123) and channels-first "forward" (neuralop's SpectralConv),
+power-of-two, mixed-radix and prime-factor sizes up to BASELINE C5's 721 x 1440, forward values and the adjoints used as
+backward passes.  Tolerance 1e-5 relative to the max norm."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+SHAPES = [(2, 64, 64, 8), (1, 128, 256, 16), (1, 32, 64, 6), (2, 30, 36, 4), (1, 103, 180, 4), (1, 45, 50, 2), (1, 721, 1440, 2),
+          (3, 16, 9, 2), (1, 7, 11, 4)]
+
+
+@pytest.mark.parametrize("B,H,W,C", SHAPES)
+@pytest.mark.parametrize("layout,norm", [("channels_last", "ortho"), ("channels_first", "forward"), ("channels_last", "backward")])
+def test_rfft2_irfft2_match_torch(cuda, B, H, W, C, layout, norm):
+    from dlwp_benchmark_amd import fft
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    cl = layout == "channels_last"
+    x = torch.randn((B, H, W, C) if cl else (B, C, H, W), generator=g)
+    dims = (1, 2) if cl else (2, 3)
+    Xr = torch.fft.rfft2(x.double(), dim=dims, norm=norm)
+    X = fft.rfft2(x.to(cuda), layout, norm)
+    assert X.shape[-1] == 2
+    assert rel(torch.view_as_complex(X.cpu().contiguous()), Xr) <= TOL
+    # inverse of a generic Hermitian half spectrum (imaginary parts of DC / Nyquist set at random: torch ignores them too)
+    Y = torch.randn(*Xr.shape, 2, generator=g)
+    yr = torch.fft.irfft2(torch.view_as_complex(Y.double()), s=(H, W), dim=dims, norm=norm)
+    y = fft.irfft2(Y.to(cuda), W, layout, norm)
+    assert rel(y, yr) <= TOL
+    # round trip
+    assert rel(fft.irfft2(X, W, layout, norm), x) <= 2 * TOL
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 24, 4), (1, 64, 64, 8), (1, 21, 30, 2), (1, 103, 180, 2)])
+@pytest.mark.parametrize("layout,norm", [("channels_last", "ortho"), ("channels_first", "forward")])
+def test_fft_backward_passes_are_the_adjoints(cuda, B, H, W, C, layout, norm):
+    """<rfft2 x, G> == <x, rfft2^H G> and the same for irfft2, against torch autograd on the CPU (real pairs)."""
+    from dlwp_benchmark_amd import fft
+    g = torch.Generator().manual_seed(7)
+    cl = layout == "channels_last"
+    dims = (1, 2) if cl else (2, 3)
+    x = torch.randn((B, H, W, C) if cl else (B, C, H, W), generator=g)
+    xr = x.double().requires_grad_(True)
+    Xr = torch.view_as_real(torch.fft.rfft2(xr, dim=dims, norm=norm))
+    G = torch.randn(Xr.shape, generator=g)
+    (Xr * G.double()).sum().backward()
+    xd = x.to(cuda).requires_grad_(True)
+    X = fft.rfft2(xd, layout, norm)
+    (X * G.to(cuda)).sum().backward()
+    assert rel(xd.grad, xr.grad) <= TOL
+    Y = torch.randn(Xr.shape, generator=g)
+    Yr = Y.double().requires_grad_(True)
+    yr = torch.fft.irfft2(torch.view_as_complex(Yr), s=(H, W), dim=dims, norm=norm)
+    Gy = torch.randn(yr.shape, generator=g)
+    (yr * Gy.double()).sum().backward()
+    Yd = Y.to(cuda).requires_grad_(True)
+    y = fft.irfft2(Yd, W, layout, norm)
+    (y * Gy.to(cuda)).sum().backward()
+    assert rel(Yd.grad, Yr.grad) <= TOL
