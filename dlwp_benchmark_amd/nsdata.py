@@ -83,6 +83,48 @@ def navier_stokes_2d(w0, f, visc, T, delta_t=1e-4, record_steps=1):
     return sol, sol_t
 
 
+def navier_stokes_2d_hip(w0, f, visc, T, delta_t=1e-4, record_steps=1):
+    """The same solver on the GPU with every transform on libdlwpmi's LDS-staged rFFT2 / irFFT2 kernels (fft.py,
+    csrc/fft2d.hip; channels-first, norm "backward") in fp32 -- the precision the reference's torch-1.6 solver ran in.  The
+    state is the Hermitian HALF spectrum [B, n, n/2+1]; the four inverse transforms of a step (velocity components and
+    vorticity gradients) are one batched call.  The point-wise spectral algebra between the transforms is torch elementwise
+    work: this is the data tool of SURVEY.md §8f.2, not the training hot path."""
+    from . import fft
+    n, dev, B = w0.shape[-1], w0.device, w0.shape[0]
+    steps = math.ceil(T / delta_t)
+
+    def r2c(x):                                            # [B, C, n, n] -> complex [B, C, n, n/2+1]
+        return torch.view_as_complex(fft.rfft2(x.float().contiguous(), "channels_first", "backward"))
+
+    def c2r(X):
+        return fft.irfft2(torch.view_as_real(X).contiguous(), n, "channels_first", "backward")
+
+    w_h = r2c(w0[:, None])[:, 0]
+    f_h = r2c((f if f.dim() == 3 else f[None]).float()[:, None].to(dev))[:, 0]
+    record_time = math.floor(steps / record_steps)
+    k_x, k_y, k_max = _wavenumbers(n, dev)
+    k_x, k_y = k_x[:, : n // 2 + 1].float(), k_y[:, : n // 2 + 1].float()
+    lap = 4 * math.pi ** 2 * (k_x ** 2 + k_y ** 2)
+    lap[0, 0] = 1.0
+    dealias = ((k_y.abs() <= (2.0 / 3.0) * k_max) & (k_x.abs() <= (2.0 / 3.0) * k_max)).float().unsqueeze(0)
+    ikx, iky = torch.complex(torch.zeros_like(k_x), 2 * math.pi * k_x), torch.complex(torch.zeros_like(k_y), 2 * math.pi * k_y)
+    sol = torch.zeros(*w0.shape, record_steps, device=dev)
+    sol_t = torch.zeros(record_steps, device=dev)
+    cn_num, cn_den = 1.0 - 0.5 * delta_t * visc * lap, 1.0 + 0.5 * delta_t * visc * lap
+    c, t = 0, 0.0
+    for j in range(steps):
+        psi_h = w_h / lap
+        fields = c2r(torch.stack((iky * psi_h, -ikx * psi_h, ikx * w_h, iky * w_h), dim=1))     # q, v, w_x, w_y
+        F_h = dealias * r2c((fields[:, 0] * fields[:, 2] + fields[:, 1] * fields[:, 3])[:, None])[:, 0]
+        w_h = (-delta_t * F_h + delta_t * f_h + cn_num * w_h) / cn_den
+        t += delta_t
+        if (j + 1) % record_time == 0 and c < record_steps:
+            sol[..., c] = c2r(w_h[:, None])[:, 0]
+            sol_t[c] = t
+            c += 1
+    return sol, sol_t
+
+
 def forcing(resolution, forcing_multiplicator=2.0, device=None):
     t = torch.linspace(0, 1, resolution + 1, device=device, dtype=torch.float64)[:-1]
     X, Y = torch.meshgrid(t, t, indexing="ij")
@@ -105,7 +147,8 @@ def generate_data(resolution=64, n_samples=1000, batch_size=50, max_simulation_t
     sol_t = None
     for c in range(0, (n_samples // batch_size) * batch_size, batch_size):
         w0 = grf.sample(batch_size)
-        sol, sol_t = navier_stokes_2d(w0, f, viscosity, max_simulation_time, delta_t, record_steps)
+        solver = navier_stokes_2d_hip if device.type == "cuda" else navier_stokes_2d
+        sol, sol_t = solver(w0, f, viscosity, max_simulation_time, delta_t, record_steps)
         a[c:c + batch_size] = w0.cpu()
         u[c:c + batch_size] = sol.permute(0, 3, 1, 2).unsqueeze(2).cpu()
     attrs = {"info": "Incompressible Navier-Stokes data", "viscosity": viscosity, "delta_t": "%.e" % delta_t,
