@@ -34,14 +34,101 @@ struct FftAxis {
     const float2* tab;               // [N] e^{-2 pi i n / N} (device)
 };
 
+__device__ __forceinline__ float2 cmul(float2 a, float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
+// multiply by sg * i  (sg = -1: forward transform's -i, +1: inverse's +i)
+__device__ __forceinline__ float2 muli(float2 a, float sg) { return make_float2(-sg * a.y, sg * a.x); }
+
+// DFT of length R in registers, v[q] = sum_r u[r] e^{sg 2 pi i q r / R}  (R = 2, 3, 4, 5)
+template <int R>
+__device__ __forceinline__ void dft_small(float2 (&u)[R], float sg) {
+    if constexpr (R == 2) {
+        const float2 a = u[0], b = u[1];
+        u[0] = make_float2(a.x + b.x, a.y + b.y);
+        u[1] = make_float2(a.x - b.x, a.y - b.y);
+    } else if constexpr (R == 4) {
+        const float2 s02 = make_float2(u[0].x + u[2].x, u[0].y + u[2].y), d02 = make_float2(u[0].x - u[2].x, u[0].y - u[2].y);
+        const float2 s13 = make_float2(u[1].x + u[3].x, u[1].y + u[3].y), d13 = muli(make_float2(u[1].x - u[3].x, u[1].y - u[3].y), sg);
+        u[0] = make_float2(s02.x + s13.x, s02.y + s13.y);
+        u[1] = make_float2(d02.x + d13.x, d02.y + d13.y);
+        u[2] = make_float2(s02.x - s13.x, s02.y - s13.y);
+        u[3] = make_float2(d02.x - d13.x, d02.y - d13.y);
+    } else if constexpr (R == 3) {
+        const float c = -0.5f, s_ = sg * 0.86602540378443864676f;
+        const float2 t1 = make_float2(u[1].x + u[2].x, u[1].y + u[2].y), t2 = make_float2(u[1].x - u[2].x, u[1].y - u[2].y);
+        const float2 m = make_float2(u[0].x + c * t1.x, u[0].y + c * t1.y), n = make_float2(-s_ * t2.y, s_ * t2.x);   // i s t2
+        u[0] = make_float2(u[0].x + t1.x, u[0].y + t1.y);
+        u[1] = make_float2(m.x + n.x, m.y + n.y);
+        u[2] = make_float2(m.x - n.x, m.y - n.y);
+    } else {
+        static_assert(R == 5, "register butterflies exist for radix 2, 3, 4, 5");
+        const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+        const float s1 = sg * 0.95105651629515357212f, s2 = sg * 0.58778525229247312917f;
+        const float2 a14 = make_float2(u[1].x + u[4].x, u[1].y + u[4].y), b14 = make_float2(u[1].x - u[4].x, u[1].y - u[4].y);
+        const float2 a23 = make_float2(u[2].x + u[3].x, u[2].y + u[3].y), b23 = make_float2(u[2].x - u[3].x, u[2].y - u[3].y);
+        const float2 m1 = make_float2(u[0].x + c1 * a14.x + c2 * a23.x, u[0].y + c1 * a14.y + c2 * a23.y);
+        const float2 m2 = make_float2(u[0].x + c2 * a14.x + c1 * a23.x, u[0].y + c2 * a14.y + c1 * a23.y);
+        const float2 n1 = make_float2(-(s1 * b14.y + s2 * b23.y), s1 * b14.x + s2 * b23.x);      // i (s1 b14 + s2 b23)
+        const float2 n2 = make_float2(-(s2 * b14.y - s1 * b23.y), s2 * b14.x - s1 * b23.x);      // i (s2 b14 - s1 b23)
+        u[0] = make_float2(u[0].x + a14.x + a23.x, u[0].y + a14.y + a23.y);
+        u[1] = make_float2(m1.x + n1.x, m1.y + n1.y);
+        u[4] = make_float2(m1.x - n1.x, m1.y - n1.y);
+        u[2] = make_float2(m2.x + n2.x, m2.y + n2.y);
+        u[3] = make_float2(m2.x - n2.x, m2.y - n2.y);
+    }
+}
+
+// One Stockham pass of radix R with the butterflies in registers: work item = (butterfly i < N / R, lane); inputs
+// x[i + r N / R] times the twiddles w^(r k) (k = i mod p), outputs y[blk p R + q p + k].  LDS traffic per output: one data read
+// plus (R - 1) / R table reads -- against 2 R for the generic pass below.
+template <int R, int OUTS, int NT>
+__device__ __forceinline__ void pass_small(float2* buf, const float2* tabs, const FftAxis& f, int s, int p, float sg) {
+    constexpr int NB = (OUTS + R - 1) / R;
+    const int IBP = f.IB + 1, t = f.N / R, M = p * R, step = f.N / M, nitems = t << f.logIB, tid = threadIdx.x;
+    float2 u[NB][R];
+    int obase[NB];
+#pragma unroll
+    for (int ub = 0; ub < NB; ++ub) {
+        const int e = tid + ub * NT;
+        obase[ub] = -1;
+        if (e < nitems) {
+            const int lane = e & (f.IB - 1), i = e >> f.logIB;
+            const int blk = fastdiv(i, f.dp[s]), k = i - blk * p;
+            const float2* xin = buf + i * IBP + lane;
+#pragma unroll
+            for (int r = 0; r < R; ++r) u[ub][r] = xin[r * t * IBP];
+#pragma unroll
+            for (int r = 1; r < R; ++r) {
+                float2 w = tabs[r * k * step];
+                w.y *= -sg;                                  // table holds e^{-i theta}
+                u[ub][r] = cmul(u[ub][r], w);
+            }
+            dft_small<R>(u[ub], sg);
+            obase[ub] = (blk * M + k) * IBP + lane;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ub = 0; ub < NB; ++ub)
+        if (obase[ub] >= 0) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) buf[obase[ub] + q * p * IBP] = u[ub][q];
+        }
+    __syncthreads();
+}
+
 // In-place mixed-radix Stockham FFT of buf[N][IB + 1] (complex, LDS); tabs [N] twiddles in LDS; sg = -1 forward, +1 inverse.
-// Output m = blk * M + q * p + k  <-  sum_r in[(blk * p + k) + r * N / R] * w^(r * (k + q * p)),  w = e^{sg 2 pi i / M}.
+// Radices 2, 3, 4, 5 use register butterflies (pass_small); any other radix (7, 11, ... 103 ...) the generic pass: one output
+// per work item, m = blk * M + q * p + k  <-  sum_r in[(blk * p + k) + r * N / R] * w^(r * (k + q * p)),  w = e^{sg 2 pi i / M}.
 template <int OUTS, int NT>
 __device__ __forceinline__ void lds_fft(float2* buf, const float2* tabs, const FftAxis& f, float sg) {
     const int IBP = f.IB + 1, total = f.N << f.logIB, tid = threadIdx.x;
     int p = 1;
     for (int s = 0; s < f.nrad; ++s) {
         const int R = f.rad[s], t = f.N / R, M = p * R, step = f.N / M;
+        if (R == 4) { pass_small<4, OUTS, NT>(buf, tabs, f, s, p, sg); p = M; continue; }
+        if (R == 2) { pass_small<2, OUTS, NT>(buf, tabs, f, s, p, sg); p = M; continue; }
+        if (R == 3) { pass_small<3, OUTS, NT>(buf, tabs, f, s, p, sg); p = M; continue; }
+        if (R == 5) { pass_small<5, OUTS, NT>(buf, tabs, f, s, p, sg); p = M; continue; }
         float2 acc[OUTS];
 #pragma unroll
         for (int u = 0; u < OUTS; ++u) {

@@ -10,8 +10,10 @@ DataLoader, the step is the captured hipGraph, scalars are returned / printed in
 checkpoint is written synchronously (the reference's writer thread reads live parameters while the next epoch trains,
 App. B-10).
 """
+import json
 import math
 import os
+import time
 import warnings
 
 import numpy as np
@@ -19,6 +21,34 @@ import torch
 
 from . import ddp
 from .evaluate import error_moments
+
+
+class ScalarLog:
+    """The scalars the reference sends to TensorBoard -- tags "Epoch", "Learning Rate", "MSE/training" (per iteration) and
+    "MSE/validation" (per epoch), each with global_step = the iteration counter (nsbench/scripts/train.py:104-106,128,147;
+    dlwpbench/scripts/train.py:107-108,140,163) -- as JSON lines `<out_dir>/<name>/tensorboard/scalars.jsonl`, one
+    {"tag", "value", "step", "wall_time"} object per add_scalar call (tensorboard is not installed in this image; the file
+    converts one to one).  Device scalars are kept as tensors and written at `flush()` (end of an epoch): no host
+    synchronisation inside the training loop."""
+
+    def __init__(self, out_dir, name, enabled=True):
+        self.path = os.path.join(out_dir, name, "tensorboard", "scalars.jsonl") if enabled else None
+        self._rows = []
+        if self.path:
+            os.makedirs(os.path.dirname(self.path), exist_ok=True)
+
+    def add_scalar(self, tag, scalar_value, global_step):
+        if self.path:
+            self._rows.append((tag, scalar_value, int(global_step), time.time()))
+
+    def flush(self):
+        if not self.path or not self._rows:
+            return
+        with open(self.path, "a") as f:
+            for tag, v, step, wall in self._rows:
+                f.write(json.dumps({"tag": tag, "value": float(v.item() if torch.is_tensor(v) else v), "step": step,
+                                    "wall_time": wall}) + "\n")
+        self._rows = []
 
 
 def cosine_lr(base_lr, epoch, t_max, eta_min=0.0):
@@ -134,7 +164,7 @@ def validation_mse(model, u_val, sequence_length, batch_size, teacher_forcing_st
 
 def train_ns(model, u_train, u_val, name="model", epochs=10, batch_size=4, sequence_length=21, learning_rate=1e-3,
              teacher_forcing_steps=10, val_teacher_forcing_steps=None, noise=0.0, clip_gradients=False, seed=1234,
-             out_dir="outputs", save_model=True, continue_training=False, verbose=False):
+             out_dir="outputs", save_model=True, continue_training=False, verbose=False, log_scalars=True):
     """Train an nsbench FNO-family module (anything with make_optimizer / train_step) on trajectories u [N, T, D, H, W].
     Returns a list of per-epoch dicts(epoch, lr, train_mse, val_mse)."""
     device = next(model.parameters()).device
@@ -156,8 +186,11 @@ def train_ns(model, u_train, u_val, name="model", epochs=10, batch_size=4, seque
             ddp.broadcast_parameters(t, src=0)
     vtf = teacher_forcing_steps if val_teacher_forcing_steps is None else val_teacher_forcing_steps
     log = []
+    writer = ScalarLog(out_dir, name, enabled=log_scalars and save_model and rank == 0)
     for epoch in range(epoch0, epochs):
         opt.lr = cosine_lr(learning_rate, epoch, epochs)
+        writer.add_scalar("Epoch", epoch, iteration)
+        writer.add_scalar("Learning Rate", opt.lr, iteration)
         losses = []
         for idx in ddp.shard_indices(u_train.shape[0], epoch, rank, world, batch_size, seed):
             xs, ys = zip(*(ddp.ns_sample(u_train, int(i), epoch, sequence_length, noise, seed) for i in idx))
@@ -165,9 +198,12 @@ def train_ns(model, u_train, u_val, name="model", epochs=10, batch_size=4, seque
             loss = model.train_step(x, y, teacher_forcing_steps, optimizer=opt, grad_scale=1.0 / world, allreduce=reducer,
                                     clip_max_norm=opt.lr if clip_gradients else None)     # clip threshold = lr (:123-125)
             losses.append(loss.clone())   # the step returns its persistent loss buffer; clones stay on the device (no sync)
+            writer.add_scalar("MSE/training", losses[-1], iteration)
             iteration += 1
         train_mse = torch.stack(losses).mean().item() if losses else float("nan")
         val_mse = validation_mse(model, u_val, sequence_length, batch_size, vtf, device)
+        writer.add_scalar("MSE/validation", val_mse, iteration)
+        writer.flush()
         if save_model and rank == 0:
             sched = {"T_max": epochs, "last_epoch": epoch, "base_lrs": [learning_rate], "_last_lr": [opt.lr]}
             if val_mse > best or epoch == epochs - 1:
@@ -201,7 +237,7 @@ def validation_mse_dlwp(model, dataset, batch_size, device):
 
 def train_dlwp(model, train_dataset, val_dataset, name="model", epochs=10, batch_size=4, learning_rate=1e-3,
                clip_gradients=False, gradient_accumulation_steps=1, seed=1234, out_dir="outputs", save_model=True,
-               use_graph=True, verbose=False, continue_training=False):
+               use_graph=True, verbose=False, continue_training=False, log_scalars=True):
     """The dlwpbench training script's epoch loop (src/dlwpbench/scripts/train.py:104-197) around the captured step of
     train_engine.GraphedTrainStep, for any dlwpbench module (forward(constants, prescribed, prognostic)): batches of
     `WeatherBenchDataset.__getitem__` tuples (wbdata.WeatherBenchArrays) from the seeded rank-sharded permutation, MSE,
@@ -231,8 +267,11 @@ def train_dlwp(model, train_dataset, val_dataset, name="model", epochs=10, batch
     def kwargs_of(c, p, g):
         return {k: v for k, v in (("constants", c), ("prescribed", p), ("prognostic", g)) if v is not None}
 
+    writer = ScalarLog(out_dir, name, enabled=log_scalars and save_model and rank == 0)
     for epoch in range(epoch0, epochs):
         lr = cosine_lr(learning_rate, epoch, epochs)
+        writer.add_scalar("Epoch", epoch, iteration)
+        writer.add_scalar("Learning Rate", lr, iteration)
         losses = []
         if hasattr(train_dataset, "set_epoch"):
             train_dataset.set_epoch(epoch)
@@ -261,9 +300,12 @@ def train_dlwp(model, train_dataset, val_dataset, name="model", epochs=10, batch
                     loss = step.accumulate(kwargs_of(sl(c, i), sl(p, i), sl(g, i)), t[i:i + micro])
                 step.apply()
             losses.append(loss.clone())
+            writer.add_scalar("MSE/training", losses[-1], iteration)
             iteration += 1
         train_mse = torch.stack(losses).mean().item() if losses else float("nan")
         val_mse = validation_mse_dlwp(model, val_dataset, batch_size, device)
+        writer.add_scalar("MSE/validation", val_mse, iteration)
+        writer.flush()
         if save_model and rank == 0 and step is not None:
             sched = {"T_max": epochs, "last_epoch": epoch, "base_lrs": [learning_rate], "_last_lr": [lr]}
             if val_mse > best or epoch == epochs - 1:

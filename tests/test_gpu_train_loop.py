@@ -31,6 +31,17 @@ def test_training_learns_checkpoints_and_resumes(cuda, tmp_path):
     assert set(ck) == {"model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "epoch", "iteration", "best_val_error"}
     assert ck["epoch"] == 6 and ck["iteration"] == 12
     assert any(k.startswith("fno.") for k in ck["model_state_dict"])
+    # the optimizer entry has torch.optim.Adam's state_dict layout (utils.py:33-39 stores optimizer.state_dict())
+    ost = ck["optimizer_state_dict"]
+    assert set(ost) >= {"state", "param_groups"} and ost["param_groups"][0]["betas"] == (0.9, 0.999)
+    assert len(ost["state"]) == len(ost["param_groups"][0]["params"]) and float(ost["state"][0]["step"]) == 12.0
+    # scalars with the reference's TensorBoard tags (train.py:104-106,128,147)
+    import json
+    rows = [json.loads(l) for l in open(os.path.join(str(tmp_path), "t", "tensorboard", "scalars.jsonl"))]
+    tags = {r["tag"] for r in rows}
+    assert tags == {"Epoch", "Learning Rate", "MSE/training", "MSE/validation"}
+    assert sum(r["tag"] == "MSE/training" for r in rows) == 12 and sum(r["tag"] == "MSE/validation" for r in rows) == 6
+    assert [r["step"] for r in rows if r["tag"] == "Epoch"] == [0, 2, 4, 6, 8, 10]
     # resume: epochs 0-2, stop, continue_training for epochs 3-5 == the uninterrupted run (seeded batches, restored Adam
     # moments / step count; the cosine schedule is a function of (epoch, total epochs))
     out2 = str(tmp_path / "resume")

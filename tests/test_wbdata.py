@@ -85,3 +85,34 @@ def test_zero_fill_past_the_end_of_the_record():
     ds.n_time = 100                                                   # pretend the index space is longer than the stored data
     c, p, g, t = ds[1]                                                # t0 = 5: only 2 frames exist
     assert g.shape[0] == 4 and np.array_equal(g[:, 0, 0, 0], [1005, 1006, 0, 0])
+
+
+def test_full_sample_equals_hand_built_tensors():
+    """Every element of a sample against tensors built by explicit loops over the reference's index arithmetic
+    (datasets.py:335-395): item * L windows, dict-ordered variables with levels expanded in place, per-level z-scores,
+    inputs = window[:-1], targets = window[1:][ctx:] (first target two steps after the last context frame, App. B-9)."""
+    rng = np.random.default_rng(3)
+    n_time, H, W, L, ctx = 31, 3, 5, 6, 2
+    fields = {"t2m": rng.normal(280, 10, (n_time, H, W)).astype(np.float32),
+              "z": {500: rng.normal(54000, 3000, (n_time, H, W)).astype(np.float32),
+                    850: rng.normal(14000, 1000, (n_time, H, W)).astype(np.float32)},
+              "tisr": rng.uniform(0, 4e6, (n_time, H, W)).astype(np.float32), "lsm": rng.uniform(0, 1, (H, W)).astype(np.float32)}
+    prog = {"z": [850, 500], "t2m": []}
+    stats = {"t2m": {"mean": 278.0, "std": 21.0}, "z": {"level": {500: {"mean": 54000.0, "std": 3300.0}, 850: {"mean": 13700.0, "std": 1470.0}}},
+             "tisr": {"mean": 1074504.0, "std": 1439846.0}, "lsm": {"mean": 0.33, "std": 0.45}}
+    ds = wbdata.WeatherBenchArrays(fields, prog, ["tisr"], ["lsm"], sequence_length=L, normalize=True, context_size=ctx, stats=stats)
+    for item in range(len(ds)):
+        t0 = item * L
+        exp_presc = np.zeros((L, 1, H, W), np.float32)
+        for t in range(L):
+            exp_presc[t, 0] = (fields["tisr"][t0 + t] - stats["tisr"]["mean"]) / stats["tisr"]["std"]
+        window = np.zeros((L + 1, 3, H, W), np.float32)
+        for t in range(L + 1):
+            window[t, 0] = (fields["z"][850][t0 + t] - stats["z"]["level"][850]["mean"]) / stats["z"]["level"][850]["std"]
+            window[t, 1] = (fields["z"][500][t0 + t] - stats["z"]["level"][500]["mean"]) / stats["z"]["level"][500]["std"]
+            window[t, 2] = (fields["t2m"][t0 + t] - stats["t2m"]["mean"]) / stats["t2m"]["std"]
+        c, p, g, t_ = ds[item]
+        assert np.allclose(c, ((fields["lsm"] - 0.33) / 0.45)[None, None], atol=1e-6)
+        assert np.allclose(p, exp_presc, atol=1e-6)
+        assert np.allclose(g, window[:-1], atol=1e-6)
+        assert np.allclose(t_, window[1:][ctx:], atol=1e-6) and t_.shape[0] == L - ctx
