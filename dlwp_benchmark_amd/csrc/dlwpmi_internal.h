@@ -38,6 +38,7 @@ int dlwp_pwmlp_slab_reduce(const float* slab, int nslab, int Cin, int Ch, int Co
 struct dlwp_fno_plan {
     int C, H, W, m1, m2c;
     int C_pad, NP;            // channels padded to 16; 2*m2c padded to 16
+    int force_wide;           // use the channel-blocked kernels whatever the width (3-D plans: hundreds of row frequencies)
     // device tables (built in double on the host)
     float2* twH;              // [m1][H]    e^{-2 pi i k_j h / H}, k_j = signed kept row frequency
     float* FT_fwd;            // [NP][W]    forward W-axis DFT (scale 1/(H W)), n = 2 kx (+1: imag)
@@ -115,7 +116,7 @@ struct dlwp_gemm_args {
 int dlwp_gemm_run(const dlwp_gemm_args& g, hipStream_t stream);
 
 // fno_wide.hip -- hidden_channels > 64 (the fused kernels keep all channels of a row in LDS and stop at 64)
-inline bool dlwp_fno_is_wide(const dlwp_fno_plan* p) { return p->C_pad > 64; }
+inline bool dlwp_fno_is_wide(const dlwp_fno_plan* p) { return p->C_pad > 64 || p->force_wide; }
 int dlwp_fno_rows_dft_wide(const dlwp_fno_plan* p, const float* x, int act_in, int adjoint, float2* x1, int B,
                            hipStream_t stream);
 int dlwp_fno_spatial_wide(const dlwp_fno_plan* p, const dlwp_fno_spatial_args* a, hipStream_t stream);
@@ -129,7 +130,7 @@ int dlwp_proj_gy(const float* g_out, const float* pred, const float* target, flo
                  long long bs_out, long long bs_res, long long CP, int B, hipStream_t stream);
 int dlwp_cfmlp_fwd(const float* x, long long x_bs, const float* w1, const float* b1, const float* w2, const float* b2, float* y,
                    long long y_bs, const float* res, long long res_bs, float* zpre, float* act, int B, int Cin, int Ch, int Cout,
-                   int P, hipStream_t stream);
+                   int P, hipStream_t stream, long long x_cs = 0);      // x_cs: channel stride of x (0 = P)
 int dlwp_cfmlp_bwd(const float* x, long long x_bs, const float* w1, const float* w2, const float* gy, long long gy_bs,
                    const float* zpre, const float* act, float* gx, long long gx_bs, float* gz, float* gw1, float* gb1, float* gw2,
-                   float* gb2, int B, int Cin, int Ch, int Cout, int P, hipStream_t stream);
+                   float* gb2, int B, int Cin, int Ch, int Cout, int P, hipStream_t stream, long long x_cs = 0, long long gx_cs = 0);

@@ -698,32 +698,43 @@ int upload(T** dst, const std::vector<T>& host) {
 
 }  // namespace
 
-extern "C" int dlwp_fno_plan_create(int C, int H, int W, int m1, int m2c, dlwp_fno_plan** out) {
+// kept signed frequencies of an fftshift-ed axis of length n (neuralop SpectralConv slicing, App. A-1)
+static std::vector<int> kept_freqs(int n, int m) {
+    const int start = n - m, lo = start / 2;
+    std::vector<int> k(m);
+    for (int j = 0; j < m; ++j) k[j] = lo + j - n / 2;
+    return k;
+}
+
+// T == 1: the 2-D plan.  T > 1: the (T*H) x W image of a [T][H][W] volume with m0*m1 separable (time, row) frequencies.
+static int plan_create_impl(int C, int T, int H, int W, int m0, int m1, int m2c, dlwp_fno_plan** out) {
     DLWP_REQUIRE(out, DLWP_E_INVALID, "fno_plan_create: out is NULL");
-    DLWP_REQUIRE(C > 0 && H > 0 && W > 0 && m1 > 0 && m2c > 0, DLWP_E_INVALID, "fno_plan_create: bad dims");
+    DLWP_REQUIRE(C > 0 && T > 0 && H > 0 && W > 0 && m0 > 0 && m1 > 0 && m2c > 0, DLWP_E_INVALID, "fno_plan_create: bad dims");
     DLWP_REQUIRE(W % 16 == 0, DLWP_E_UNSUPPORTED, "fno_plan_create: W must be a multiple of 16 (got %d)", W);
     DLWP_REQUIRE(H % 2 == 0, DLWP_E_UNSUPPORTED, "fno_plan_create: H must be even (got %d)", H);
-    DLWP_REQUIRE(m1 <= H && m2c <= W / 2 + 1, DLWP_E_INVALID, "fno_plan_create: more modes than the grid has");
+    DLWP_REQUIRE(T == 1 || T % 2 == 0, DLWP_E_UNSUPPORTED, "fno_plan_create3d: the time axis must be even (got %d)", T);
+    DLWP_REQUIRE(m1 <= H && m0 <= T && m2c <= W / 2 + 1, DLWP_E_INVALID, "fno_plan_create: more modes than the grid has");
     DLWP_REQUIRE(C <= 1024, DLWP_E_UNSUPPORTED, "fno_plan_create: hidden_channels <= 1024 supported (got %d)", C);
-    DLWP_REQUIRE(2 * m2c <= 32, DLWP_E_UNSUPPORTED, "fno_plan_create: n_modes[1]/2+1 <= 16 supported (got %d)", m2c);
+    DLWP_REQUIRE(2 * m2c <= 32, DLWP_E_UNSUPPORTED, "fno_plan_create: n_modes[-1]/2+1 <= 16 supported (got %d)", m2c);
     dlwp_fno_plan* p = new dlwp_fno_plan();
-    p->C = C; p->H = H; p->W = W; p->m1 = m1; p->m2c = m2c;
+    const int HH = T * H, MM = m0 * m1;
+    p->C = C; p->H = HH; p->W = W; p->m1 = MM; p->m2c = m2c;
     p->C_pad = round_up(C, 16);
     p->NP = round_up(2 * m2c, 16);
+    p->force_wide = T > 1;
     const double PI = 3.14159265358979323846;
-    // kept rows of the fftshift-ed spectrum (neuralop SpectralConv slicing, App. A-1)
-    const int start = H - m1, lo = start / 2;
-    std::vector<float2> tw((size_t)m1 * H);
-    for (int j = 0; j < m1; ++j) {
-        const int k = lo + j - H / 2;  // signed frequency
-        for (int h = 0; h < H; ++h) {
-            const long long kh = (((long long)k * h) % H + H) % H;
-            const double ang = -2.0 * PI * (double)kh / H;
-            tw[(size_t)j * H + h] = make_float2((float)cos(ang), (float)sin(ang));
-        }
-    }
+    const std::vector<int> kt = kept_freqs(T, m0), kh = kept_freqs(H, m1);
+    std::vector<float2> tw((size_t)MM * HH);
+    for (int a = 0; a < m0; ++a)
+        for (int j = 0; j < m1; ++j)
+            for (int t = 0; t < T; ++t)
+                for (int h = 0; h < H; ++h) {
+                    const long long at = (((long long)kt[a] * t) % T + T) % T, ah = (((long long)kh[j] * h) % H + H) % H;
+                    const double ang = -2.0 * PI * ((double)at / T + (double)ah / H);
+                    tw[((size_t)a * m1 + j) * HH + (size_t)t * H + h] = make_float2((float)cos(ang), (float)sin(ang));
+                }
     std::vector<float> ft_fwd((size_t)p->NP * W, 0.f), ft_adj(ft_fwd), g_inv(ft_fwd), g_adj(ft_fwd);
-    const double inv_hw = 1.0 / ((double)H * W);
+    const double inv_hw = 1.0 / ((double)HH * W);
     for (int kx = 0; kx < m2c; ++kx) {
         const double ck = (kx == 0 || (W % 2 == 0 && kx == W / 2)) ? 1.0 : 2.0;
         for (int w = 0; w < W; ++w) {
@@ -748,6 +759,15 @@ extern "C" int dlwp_fno_plan_create(int C, int H, int W, int m1, int m2c, dlwp_f
     }
     *out = p;
     return DLWP_OK;
+}
+
+extern "C" int dlwp_fno_plan_create(int C, int H, int W, int m1, int m2c, dlwp_fno_plan** out) {
+    return plan_create_impl(C, 1, H, W, 1, m1, m2c, out);
+}
+
+extern "C" int dlwp_fno_plan_create3d(int C, int T, int H, int W, int m0, int m1, int m2c, dlwp_fno_plan** out) {
+    DLWP_REQUIRE(T > 1, DLWP_E_INVALID, "fno_plan_create3d: T must be > 1 (use dlwp_fno_plan_create for images)");
+    return plan_create_impl(C, T, H, W, m0, m1, m2c, out);
 }
 
 extern "C" void dlwp_fno_plan_destroy(dlwp_fno_plan* p) {

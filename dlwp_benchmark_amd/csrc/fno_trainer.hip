@@ -63,15 +63,23 @@ namespace {
 
 long long pad4(long long n) { return (n + 3) & ~3LL; }
 
+// DLWP_FNO_FORM_NS_CONTEXT3D: the block kernels see a (ctx * H) x W image with m0 * m1 row frequencies (plan_create3d)
+bool is_ctx3d(const dlwp_fno_cfg& c) { return c.form == DLWP_FNO_FORM_NS_CONTEXT3D; }
+int eff_H(const dlwp_fno_cfg& c) { return is_ctx3d(c) ? c.context_size * c.H : c.H; }
+int eff_m1(const dlwp_fno_cfg& c) { return is_ctx3d(c) ? c.m0 * c.m1 : c.m1; }
+// channels the lifting layer reads / entries of a net call's gather table
+long long lift_cin(const dlwp_fno_cfg& c) {
+    if (c.form == DLWP_FNO_FORM_DLWP) return (long long)c.constant_channels + (long long)(c.prescribed_channels + c.D) * c.context_size;
+    return is_ctx3d(c) ? c.D : (long long)c.D * c.context_size;
+}
+
 struct Layout {
     long long lw1, lb1, lw2, lb2, pw1, pb1, pw2, pb2, layers, per_layer, spec_sz, skip_sz, bias_sz, total;
 };
 
 Layout make_layout(const dlwp_fno_cfg& c) {
     Layout L{};
-    const long long Cin = c.form == DLWP_FNO_FORM_DLWP
-                              ? (long long)c.constant_channels + (long long)(c.prescribed_channels + c.D) * c.context_size
-                              : (long long)c.D * c.context_size;
+    const long long Cin = lift_cin(c);
     long long o = 0;
     L.lw1 = o; o += pad4((long long)c.lifting * Cin);
     L.lb1 = o; o += pad4(c.lifting);
@@ -82,7 +90,7 @@ Layout make_layout(const dlwp_fno_cfg& c) {
     L.pw2 = o; o += pad4((long long)c.out_channels * c.projection);
     L.pb2 = o; o += pad4(c.out_channels);
     L.layers = o;
-    L.spec_sz = (long long)c.m1 * c.m2c * c.hidden * c.hidden * 2;
+    L.spec_sz = (long long)eff_m1(c) * c.m2c * c.hidden * c.hidden * 2;
     L.skip_sz = (long long)c.hidden * c.hidden;
     L.bias_sz = c.hidden;
     L.per_layer = pad4(L.spec_sz) + pad4(L.skip_sz) + pad4(L.bias_sz);
@@ -100,8 +108,13 @@ int check_cfg(const dlwp_fno_cfg& c) {
     DLWP_REQUIRE(c.B > 0 && c.T > 0 && c.D > 0 && c.H > 0 && c.W > 0, DLWP_E_INVALID, "fno_trainer: bad shape");
     DLWP_REQUIRE(c.context_size >= 1, DLWP_E_INVALID, "fno_trainer: context_size must be >= 1");
     DLWP_REQUIRE(c.context_size <= c.T, DLWP_E_INVALID, "fno_trainer: context_size > T");
-    DLWP_REQUIRE(c.form == DLWP_FNO_FORM_NS || c.form == DLWP_FNO_FORM_DLWP, DLWP_E_INVALID, "fno_trainer: unknown form");
-    if (c.form == DLWP_FNO_FORM_NS) {
+    DLWP_REQUIRE(c.form == DLWP_FNO_FORM_NS || c.form == DLWP_FNO_FORM_DLWP || c.form == DLWP_FNO_FORM_NS_CONTEXT3D, DLWP_E_INVALID,
+                 "fno_trainer: unknown form");
+    if (is_ctx3d(c)) {
+        DLWP_REQUIRE(c.m0 >= 1 && c.m0 <= c.context_size && c.context_size >= 2, DLWP_E_INVALID,
+                     "fno_trainer: context3d form needs 1 <= m0 <= context_size and context_size >= 2");
+    }
+    if (c.form == DLWP_FNO_FORM_NS || is_ctx3d(c)) {
         DLWP_REQUIRE(c.teacher_forcing_steps >= c.context_size - 1, DLWP_E_UNSUPPORTED,
                      "fno_trainer: teacher_forcing_steps < context_size-1 (the reference slices x with a "
                      "negative start there, fno.py:236) is not supported");
@@ -136,10 +149,12 @@ int enqueue_forward(dlwp_fno_trainer* tr, bool keep, hipStream_t s, bool fused =
     const Layout L = make_layout(c);
     const P w = resolve(tr->params, L);
     const int HW = c.H * c.W, C = c.hidden, NL = c.n_layers, ctx = c.context_size;
+    const bool v3d = is_ctx3d(c);
+    const int P = v3d ? ctx * HW : HW, LCin = (int)lift_cin(c);      // pixels of a hidden field; channels the lifting layer reads
     const long long actB = (long long)c.B * tr->act;
-    const long long xhatB = (long long)c.B * c.m1 * c.m2c * C;
+    const long long xhatB = (long long)c.B * eff_m1(c) * c.m2c * C;
     int rc;
-    const bool copy_head = c.form == DLWP_FNO_FORM_NS && ctx > 1;
+    const bool copy_head = (c.form == DLWP_FNO_FORM_NS || v3d) && ctx > 1;
     if (fused) {
         if ((rc = dlwp_rollout_prep(tr->loss, tr->g_out, (long long)c.B * tr->traj_out, tr->out, tr->x, tr->traj_out, tr->traj,
                                     copy_head ? (long long)(ctx - 1) * tr->frame : 0, c.B, s))) return rc;
@@ -156,13 +171,15 @@ int enqueue_forward(dlwp_fno_trainer* tr, bool keep, hipStream_t s, bool fused =
         float2* xhat = tr->xhat + (long long)kk * NL * xhatB;
         if (tr->wide) {
             // channel-blocked kernels + channels-first GEMM MLPs (fno_wide.hip); same dataflow as below
-            const long long xinB = (long long)c.B * tr->Cin * HW, zlB = (long long)c.B * c.lifting * HW,
+            // (3-D context form: the gather table holds D * ctx frame planes = the [D][ctx * HW] volume the lifting layer
+            // reads as D channels of P = ctx * HW pixels; the projection runs on the LAST time slice only, fno.py:96)
+            const long long xinB = (long long)c.B * tr->Cin * HW, zlB = (long long)c.B * c.lifting * P,
                             zpB = (long long)c.B * c.projection * HW;
             float* xin = tr->xin + kk * xinB;
             if ((rc = dlwp_gather_channels(tr->src_tab + (long long)k * tr->Cin, tr->bstride_tab + (long long)k * tr->Cin, xin,
                                            c.B, tr->Cin, HW, s))) return rc;
             if ((rc = dlwp_cfmlp_fwd(xin, (long long)tr->Cin * HW, w.lw1, w.lb1, w.lw2, w.lb2, h0, tr->act, nullptr, 0,
-                                     tr->zl + kk * zlB, tr->al + kk * zlB, c.B, tr->Cin, c.lifting, C, HW, s))) return rc;
+                                     tr->zl + kk * zlB, tr->al + kk * zlB, c.B, LCin, c.lifting, C, P, s))) return rc;
             if ((rc = dlwp_fno_rows_dft(tr->plan, h0, 0, 0, tr->x1, c.B, s))) return rc;
             for (int l = 0; l < NL; ++l) {
                 if ((rc = dlwp_fno_mix_fwd(tr->plan, tr->x1, reinterpret_cast<const float2*>(w.spec(l)),
@@ -177,9 +194,9 @@ int enqueue_forward(dlwp_fno_trainer* tr, bool keep, hipStream_t s, bool fused =
                 a.B = c.B;
                 if ((rc = dlwp_fno_spatial(tr->plan, &a, s))) return rc;
             }
-            if ((rc = dlwp_cfmlp_fwd(pre + (NL - 1) * actB, tr->act, w.pw1, w.pb1, w.pw2, w.pb2,
+            if ((rc = dlwp_cfmlp_fwd(pre + (NL - 1) * actB + (P - HW), tr->act, w.pw1, w.pb1, w.pw2, w.pb2,
                                      tr->out + (long long)ci.out_slot * tr->frame, tr->traj_out, ci.res, ci.res_bs,
-                                     tr->zp + kk * zpB, tr->ap + kk * zpB, c.B, C, c.projection, c.out_channels, HW, s))) return rc;
+                                     tr->zp + kk * zpB, tr->ap + kk * zpB, c.B, C, c.projection, c.out_channels, HW, s, P))) return rc;
             continue;
         }
         dlwp_chan_src xs{nullptr, 0, 0, tr->src_tab + (long long)k * tr->Cin, tr->bstride_tab + (long long)k * tr->Cin};
@@ -216,8 +233,10 @@ int enqueue_loss_backward(dlwp_fno_trainer* tr, const float* grad_out, hipStream
     const P w = resolve(tr->params, L);
     const P g = resolve(tr->grads, L);
     const int HW = c.H * c.W, C = c.hidden, NL = c.n_layers;
+    const bool v3d = is_ctx3d(c);
+    const int P = v3d ? c.context_size * HW : HW, LCin = (int)lift_cin(c);
     const long long actB = (long long)c.B * tr->act;
-    const long long xhatB = (long long)c.B * c.m1 * c.m2c * C;
+    const long long xhatB = (long long)c.B * eff_m1(c) * c.m2c * C;
     const long long n = (long long)c.B * tr->traj_out;
     int rc;
     float mse_scale = 0.f;
@@ -239,14 +258,16 @@ int enqueue_loss_backward(dlwp_fno_trainer* tr, const float* grad_out, hipStream
         float2* xhat = tr->xhat + (long long)k * NL * xhatB;
         float *gcur = tr->gA, *gnext = tr->gB;
         if (tr->wide) {
-            const long long xinB = (long long)c.B * tr->Cin * HW, zlB = (long long)c.B * c.lifting * HW,
+            const long long xinB = (long long)c.B * tr->Cin * HW, zlB = (long long)c.B * c.lifting * P,
                             zpB = (long long)c.B * c.projection * HW, CP = (long long)c.out_channels * HW;
             // upstream of the projection = accumulated closed-loop gradient + d MSE / d out[t]; identity path of the residual
             if ((rc = dlwp_proj_gy(tr->g_out + oofs, grad_out ? nullptr : tr->out + oofs, grad_out ? nullptr : tr->y + oofs,
                                    mse_scale, tr->gyb, ci.gres, tr->traj_out, ci.gres_bs, CP, c.B, s))) return rc;
-            if ((rc = dlwp_cfmlp_bwd(pre + (NL - 1) * actB, tr->act, w.pw1, w.pw2, tr->gyb, CP, tr->zp + k * zpB,
-                                     tr->ap + k * zpB, gcur, tr->act, tr->gz, g.pw1, g.pb1, g.pw2, g.pb2, c.B, C, c.projection,
-                                     c.out_channels, HW, s))) return rc;
+            // 3-D context form: only the last time slice of the volume reaches the projection -- the rest of its gradient is zero
+            if (v3d && (rc = dlwp_zero_f32(gcur, actB, s))) return rc;
+            if ((rc = dlwp_cfmlp_bwd(pre + (NL - 1) * actB + (P - HW), tr->act, w.pw1, w.pw2, tr->gyb, CP, tr->zp + k * zpB,
+                                     tr->ap + k * zpB, gcur + (P - HW), tr->act, tr->gz, g.pw1, g.pb1, g.pw2, g.pb2, c.B, C,
+                                     c.projection, c.out_channels, HW, s, P, P))) return rc;
             if ((rc = dlwp_fno_rows_dft(tr->plan, gcur, 0, 1, tr->x1, c.B, s))) return rc;
             for (int l = NL - 1; l >= 0; --l) {
                 if ((rc = dlwp_fno_mix_bwd(tr->plan, tr->x1, reinterpret_cast<const float2*>(w.spec(l)),
@@ -266,7 +287,7 @@ int enqueue_loss_backward(dlwp_fno_trainer* tr, const float* grad_out, hipStream
             }
             if ((rc = dlwp_cfmlp_bwd(tr->xin + k * xinB, (long long)tr->Cin * HW, w.lw1, w.lw2, gcur, tr->act, tr->zl + k * zlB,
                                      tr->al + k * zlB, tr->gxin, (long long)tr->Cin * HW, tr->gz, g.lw1, g.lb1, g.lw2, g.lb2, c.B,
-                                     tr->Cin, c.lifting, C, HW, s))) return rc;
+                                     LCin, c.lifting, C, P, s))) return rc;
             if ((rc = dlwp_scatter_add_channels(tr->gdst_tab + (long long)k * tr->Cin, tr->bstride_tab + (long long)k * tr->Cin,
                                                 tr->gxin, c.B, tr->Cin, HW, s))) return rc;
             continue;
@@ -338,9 +359,7 @@ int enqueue_loss_backward(dlwp_fno_trainer* tr, const float* grad_out, hipStream
 extern "C" long long dlwp_fno_param_offset(const dlwp_fno_cfg* cfg, int kind, int layer, long long* size) {
     const dlwp_fno_cfg& c = *cfg;
     const Layout L = make_layout(c);
-    const long long Cin = c.form == DLWP_FNO_FORM_DLWP
-                              ? (long long)c.constant_channels + (long long)(c.prescribed_channels + c.D) * c.context_size
-                              : (long long)c.D * c.context_size;
+    const long long Cin = lift_cin(c);
     long long off = -1, sz = 0;
     switch (kind) {
         case -1: off = L.total; sz = L.total; break;
@@ -368,24 +387,27 @@ extern "C" int dlwp_fno_trainer_create(const dlwp_fno_cfg* cfg, dlwp_fno_trainer
     dlwp_fno_trainer* tr = new dlwp_fno_trainer();
     tr->cfg = *cfg;
     const dlwp_fno_cfg& c = tr->cfg;
-    if ((rc = dlwp_fno_plan_create(c.hidden, c.H, c.W, c.m1, c.m2c, &tr->plan))) { delete tr; return rc; }
+    if (is_ctx3d(c)) rc = dlwp_fno_plan_create3d(c.hidden, c.context_size, c.H, c.W, c.m0, c.m1, c.m2c, &tr->plan);
+    else rc = dlwp_fno_plan_create(c.hidden, c.H, c.W, c.m1, c.m2c, &tr->plan);
+    if (rc) { delete tr; return rc; }
     const bool dlwp = c.form == DLWP_FNO_FORM_DLWP;
     tr->ncalls = dlwp ? c.T - c.context_size : c.T - (c.context_size - 1);
     tr->T_out = dlwp ? c.T - c.context_size : c.T;
+    // entries of a net call's channel gather table: every (channel, frame) plane the lifting layer reads
     tr->Cin = dlwp ? c.constant_channels + (c.prescribed_channels + c.D) * c.context_size : c.D * c.context_size;
     tr->frame = (long long)c.D * c.H * c.W;
     tr->traj = tr->frame * c.T;
     tr->traj_out = tr->frame * tr->T_out;
-    tr->act = (long long)c.hidden * c.H * c.W;
+    tr->act = (long long)c.hidden * eff_H(c) * c.W;
     const size_t n = (size_t)c.B * tr->traj_out, actB = (size_t)c.B * tr->act;
-    const size_t xhatB = (size_t)c.B * c.m1 * c.m2c * c.hidden;
+    const size_t xhatB = (size_t)c.B * eff_m1(c) * c.m2c * c.hidden;
     tr->wide = dlwp_fno_is_wide(tr->plan);
     if (tr->wide) {
-        const size_t HW = (size_t)c.H * c.W, nc = (size_t)tr->ncalls;
-        if ((rc = dmalloc(&tr->xin, nc * c.B * tr->Cin * HW)) || (rc = dmalloc(&tr->zl, nc * c.B * c.lifting * HW)) ||
-            (rc = dmalloc(&tr->al, nc * c.B * c.lifting * HW)) || (rc = dmalloc(&tr->zp, nc * c.B * c.projection * HW)) ||
+        const size_t HW = (size_t)c.H * c.W, nc = (size_t)tr->ncalls, Pl = (size_t)eff_H(c) * c.W;
+        if ((rc = dmalloc(&tr->xin, nc * c.B * tr->Cin * HW)) || (rc = dmalloc(&tr->zl, nc * c.B * c.lifting * Pl)) ||
+            (rc = dmalloc(&tr->al, nc * c.B * c.lifting * Pl)) || (rc = dmalloc(&tr->zp, nc * c.B * c.projection * HW)) ||
             (rc = dmalloc(&tr->ap, nc * c.B * c.projection * HW)) ||
-            (rc = dmalloc(&tr->gz, (size_t)c.B * std::max(c.lifting, c.projection) * HW)) ||
+            (rc = dmalloc(&tr->gz, (size_t)c.B * std::max((size_t)c.lifting * Pl, (size_t)c.projection * HW))) ||
             (rc = dmalloc(&tr->gyb, (size_t)c.B * c.out_channels * HW)) || (rc = dmalloc(&tr->gxin, (size_t)c.B * tr->Cin * HW))) {
             dlwp_fno_trainer_destroy(tr);
             return rc;
@@ -394,7 +416,7 @@ extern "C" int dlwp_fno_trainer_create(const dlwp_fno_cfg* cfg, dlwp_fno_trainer
     if ((rc = dmalloc(&tr->g_out, n)) ||
         (rc = dmalloc(&tr->h0, actB * tr->ncalls)) || (rc = dmalloc(&tr->pre, actB * tr->ncalls * c.n_layers)) ||
         (rc = dmalloc(&tr->xhat, xhatB * tr->ncalls * c.n_layers)) ||
-        (rc = dmalloc(&tr->x1, (size_t)c.B * c.H * c.m2c * c.hidden)) || (rc = dmalloc(&tr->spec, xhatB)) ||
+        (rc = dmalloc(&tr->x1, (size_t)c.B * eff_H(c) * c.m2c * c.hidden)) || (rc = dmalloc(&tr->spec, xhatB)) ||
         (rc = dmalloc(&tr->gA, actB)) || (rc = dmalloc(&tr->gB, actB)) ||
         (!tr->wide && ((rc = dmalloc(&tr->slab_skip, (size_t)c.n_layers * c.B * c.H * dlwp_fno_gslab_stride(c.hidden))) ||
                        (rc = dmalloc(&tr->slab_lift, (size_t)dlwp_pwmlp_slab_count(c.B, c.H * c.W) *
@@ -427,16 +449,17 @@ extern "C" int dlwp_fno_trainer_bind_io(dlwp_fno_trainer* tr, const float* x, co
     tr->calls.assign(tr->ncalls, dlwp_fno_trainer::CallInfo{0, nullptr, 0, nullptr, 0});
     const long long HW = (long long)c.H * c.W;
     const int ctx = c.context_size;
-    if (c.form == DLWP_FNO_FORM_NS) {
+    if (c.form == DLWP_FNO_FORM_NS || is_ctx3d(c)) {
         // window frame j of step t comes from the observations while j < tf, from the prediction out[j-1]
-        // afterwards (nsbench fno.py:228-237)
+        // afterwards (nsbench fno.py:228-237; the context form :77-87 builds the same window and transposes it to
+        // [B, D, ctx, H, W]: plane order (d, frame) instead of (frame, d))
         for (int k = 0; k < tr->ncalls; ++k) {
             const int t = ctx - 1 + k;
             tr->calls[k].out_slot = t;
             for (int sl = 0; sl < ctx; ++sl) {
                 const int j = t - ctx + 1 + sl;
                 for (int d = 0; d < c.D; ++d) {
-                    const size_t ch = (size_t)k * tr->Cin + (size_t)sl * c.D + d;
+                    const size_t ch = (size_t)k * tr->Cin + (is_ctx3d(c) ? (size_t)d * ctx + sl : (size_t)sl * c.D + d);
                     bs[ch] = tr->traj;
                     if (j < c.teacher_forcing_steps) {
                         src[ch] = tr->x + (long long)j * tr->frame + d * HW;

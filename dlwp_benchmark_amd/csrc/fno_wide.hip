@@ -320,9 +320,9 @@ int dlwp_proj_gy(const float* g_out, const float* pred, const float* target, flo
 // ---- y = W2 gelu(W1 x + b1) + b2 (+ res) on [B][C][P] fields as two GEMMs per sample; zpre / act [B][Ch][P] are kept
 int dlwp_cfmlp_fwd(const float* x, long long x_bs, const float* w1, const float* b1, const float* w2, const float* b2, float* y,
                    long long y_bs, const float* res, long long res_bs, float* zpre, float* act, int B, int Cin, int Ch, int Cout,
-                   int P, hipStream_t stream) {
+                   int P, hipStream_t stream, long long x_cs) {
     dlwp_gemm_args g{};
-    g.A = w1; g.B = x; g.C = act; g.M = Ch; g.N = P; g.K = Cin; g.lda = Cin; g.ldb = P; g.ldc = P;
+    g.A = w1; g.B = x; g.C = act; g.M = Ch; g.N = P; g.K = Cin; g.lda = Cin; g.ldb = x_cs ? (int)x_cs : P; g.ldc = P;
     g.nb = B; g.sA = 0; g.sB = x_bs; g.sC = (long long)Ch * P; g.bias = b1; g.bias_row = 1; g.act = 1; g.preact = zpre;
     int rc = dlwp_gemm_run(g, stream);
     if (rc) return rc;
@@ -336,7 +336,7 @@ int dlwp_cfmlp_fwd(const float* x, long long x_bs, const float* w1, const float*
 // ACCUMULATED into; gz: scratch [B][Ch][P]
 int dlwp_cfmlp_bwd(const float* x, long long x_bs, const float* w1, const float* w2, const float* gy, long long gy_bs,
                    const float* zpre, const float* act, float* gx, long long gx_bs, float* gz, float* gw1, float* gb1, float* gw2,
-                   float* gb2, int B, int Cin, int Ch, int Cout, int P, hipStream_t stream) {
+                   float* gb2, int B, int Cin, int Ch, int Cout, int P, hipStream_t stream, long long x_cs, long long gx_cs) {
     int rc;
     dlwp_gemm_args a{};           // gz = (W2^T gy) * GELU'(zpre)
     a.A = w2; a.B = gy; a.C = gz; a.M = Ch; a.N = P; a.K = Cout; a.lda = Ch; a.ldb = P; a.ldc = P; a.transA = 1;
@@ -348,12 +348,12 @@ int dlwp_cfmlp_bwd(const float* x, long long x_bs, const float* w1, const float*
     if ((rc = dlwp_gemm_run(w2g, stream))) return rc;
     if (gx) {                     // gx = W1^T gz
         dlwp_gemm_args b{};
-        b.A = w1; b.B = gz; b.C = gx; b.M = Cin; b.N = P; b.K = Ch; b.lda = Cin; b.ldb = P; b.ldc = P; b.transA = 1;
+        b.A = w1; b.B = gz; b.C = gx; b.M = Cin; b.N = P; b.K = Ch; b.lda = Cin; b.ldb = P; b.ldc = gx_cs ? (int)gx_cs : P; b.transA = 1;
         b.nb = B; b.sB = (long long)Ch * P; b.sC = gx_bs;
         if ((rc = dlwp_gemm_run(b, stream))) return rc;
     }
     dlwp_gemm_args w1g{};         // gW1 += gz x^T, gb1 += rowsum(gz)
-    w1g.A = gz; w1g.B = x; w1g.C = gw1; w1g.M = Ch; w1g.N = Cin; w1g.K = P; w1g.lda = P; w1g.ldb = P; w1g.ldc = Cin;
+    w1g.A = gz; w1g.B = x; w1g.C = gw1; w1g.M = Ch; w1g.N = Cin; w1g.K = P; w1g.lda = P; w1g.ldb = x_cs ? (int)x_cs : P; w1g.ldc = Cin;
     w1g.transB = 1; w1g.nb = B; w1g.sA = (long long)Ch * P; w1g.sB = x_bs; w1g.sC = 0; w1g.accumulate = 1; w1g.rowsum = gb1;
     return dlwp_gemm_run(w1g, stream);
 }

@@ -21,7 +21,11 @@ def make_cfg(B, T, D, H, W, context_size, teacher_forcing_steps, hidden, lifting
     cfg.context_size = max(1, context_size)
     cfg.teacher_forcing_steps = teacher_forcing_steps
     cfg.hidden, cfg.lifting, cfg.projection, cfg.n_layers = hidden, lifting, projection, n_layers
-    cfg.m1, cfg.m2c = n_modes[0], n_modes[1] // 2 + 1
+    if len(n_modes) == 3:          # 3-D (time, y, x) FNO of the context form (DLWP_FNO_FORM_NS_CONTEXT3D = 2)
+        cfg.m0, cfg.m1, cfg.m2c = n_modes[0], n_modes[1], n_modes[2] // 2 + 1
+        form = 2
+    else:
+        cfg.m0, cfg.m1, cfg.m2c = 0, n_modes[0], n_modes[1] // 2 + 1
     cfg.out_channels = D if out_channels is None else out_channels
     cfg.form, cfg.constant_channels, cfg.prescribed_channels = form, constant_channels, prescribed_channels
     return cfg
@@ -37,11 +41,15 @@ class FnoParamLayout:
 
     def __init__(self, in_channels, hidden, lifting, projection, out_channels, n_layers, n_modes):
         lib = L.load()
-        cfg = make_cfg(1, 1, in_channels, 16, 16, 1, 0, hidden, lifting, projection, n_layers, n_modes,
-                       out_channels=out_channels)
+        three_d = len(n_modes) == 3
+        # 3-D context form: the lifting layer reads `in_channels` channels of a (context x H x W) volume and the spectral
+        # weights carry m0 * m1 "row" frequencies (include/dlwpmi.h: DLWP_FNO_FORM_NS_CONTEXT3D)
+        cfg = make_cfg(1, max(2, n_modes[0]) if three_d else 1, in_channels, 16, 16, n_modes[0] if three_d else 1, 0, hidden,
+                       lifting, projection, n_layers, n_modes, out_channels=out_channels)
         self.cfg_widths = cfg
         self.n_layers, self.hidden = n_layers, hidden
-        self.m1, self.m2c = cfg.m1, cfg.m2c
+        self.m0 = cfg.m0
+        self.m1, self.m2c = (cfg.m0 * cfg.m1 if three_d else cfg.m1), cfg.m2c
         size = C.c_longlong()
 
         def off(kind, layer=0):
@@ -78,17 +86,19 @@ class FnoParamLayout:
             v = self.view(flat, name).detach()
             if ".convs.weight." in name:
                 l = name.rsplit(".", 1)[1]
-                sd[f"{prefix}fno_blocks.convs.weight.{l}.tensor"] = torch.view_as_complex(
-                    v.contiguous()).permute(2, 3, 0, 1).contiguous()
+                w = torch.view_as_complex(v.contiguous()).permute(2, 3, 0, 1).contiguous()         # [Ci, Co, m1, m2c]
+                if self.m0:                                                                         # [Ci, Co, m0, m1, m2c]
+                    w = w.reshape(w.shape[0], w.shape[1], self.m0, self.m1 // self.m0, self.m2c)
+                sd[f"{prefix}fno_blocks.convs.weight.{l}.tensor"] = w
             elif ".convs.bias." in name:
                 continue
-            elif name.endswith("weight"):
-                sd[prefix + name] = v.reshape(*v.shape, 1, 1).clone()
+            elif name.endswith("weight"):                # 1x1 (2-D) / 1x1x1 (3-D) convolution weights
+                sd[prefix + name] = v.reshape(*v.shape, *([1, 1, 1] if self.m0 else [1, 1])).clone()
             else:
                 sd[prefix + name] = v.clone()
         sd[f"{prefix}fno_blocks.convs.bias"] = torch.stack(
             [self.view(flat, f"fno_blocks.convs.bias.{l}").detach() for l in range(self.n_layers)]
-        ).reshape(self.n_layers, self.hidden, 1, 1).clone()
+        ).reshape(self.n_layers, self.hidden, *([1, 1, 1] if self.m0 else [1, 1])).clone()
         return sd
 
     def from_state_dict(self, flat, sd, prefix=""):
@@ -98,6 +108,8 @@ class FnoParamLayout:
                 if ".convs.weight." in name:
                     l = name.rsplit(".", 1)[1]
                     w = sd[f"{prefix}fno_blocks.convs.weight.{l}.tensor"]
+                    if self.m0:
+                        w = w.reshape(w.shape[0], w.shape[1], self.m1, self.m2c)
                     dst.copy_(torch.view_as_real(w.permute(2, 3, 0, 1).contiguous()))
                 elif ".convs.bias." in name:
                     l = int(name.rsplit(".", 1)[1])

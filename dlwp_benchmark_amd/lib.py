@@ -20,7 +20,7 @@ class ChanSrc(C.Structure):
 class FnoCfg(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "B", "T", "D", "H", "W", "context_size", "teacher_forcing_steps", "hidden", "lifting",
-        "projection", "n_layers", "m1", "m2c", "out_channels", "form", "constant_channels", "prescribed_channels")]
+        "projection", "n_layers", "m1", "m2c", "out_channels", "form", "constant_channels", "prescribed_channels", "m0")]
 
 
 # parameter kinds of the flat FNO parameter buffer (dlwpmi.h enum)
@@ -38,6 +38,7 @@ SIGNATURES = {
     "dlwp_pwmlp_bwd_slab": (_I, [_V] * 7 + [_I] * 6 + [_V]),
     "dlwp_pwmlp_slab_fold": (_I, [_V] * 5 + [_I] * 5 + [_V]),
     "dlwp_fno_plan_create": (_I, [_I] * 5 + [C.POINTER(_V)]),
+    "dlwp_fno_plan_create3d": (_I, [_I] * 7 + [C.POINTER(_V)]),
     "dlwp_fno_plan_destroy": (None, [_V]),
     "dlwp_fno_block_workspace_bytes": (C.c_size_t, [_V, _I]),
     "dlwp_fno_block_fwd": (_I, [_V, _V, _I, _V, _V, _V, _V, _V, _I, _V, _V]),

@@ -67,16 +67,17 @@ class _FnoRolloutModule(nn.Module):
     def __init__(self, n_modes, in_channels, hidden_channels, lifting_channels, projection_channels,
                  out_channels, n_layers, context_size):
         super().__init__()
-        if len(n_modes) != 2:
-            raise ValueError("only 2-D FNOs are on the MI355X hot path (n_modes must have 2 entries)")
+        if len(n_modes) not in (2, 3):
+            raise ValueError("n_modes must have 2 entries (FNOModule / TFNO2DModule) or 3 (FNOContextModule)")
         self.n_modes = [int(m) for m in n_modes]
         self.in_channels, self.out_channels = int(in_channels), int(out_channels)
         self.hidden_channels, self.n_layers = int(hidden_channels), int(n_layers)
         self.lifting_channels, self.projection_channels = int(lifting_channels), int(projection_channels)
         self.context_size = int(context_size)
-        self.layout = FnoParamLayout(self.in_channels * max(1, self.context_size), self.hidden_channels,
-                                     self.lifting_channels, self.projection_channels, self.out_channels,
-                                     self.n_layers, self.n_modes)
+        # 3-D context form: the window is a volume, the lifting layer reads the D channels of it
+        lift_in = self.in_channels if len(self.n_modes) == 3 else self.in_channels * max(1, self.context_size)
+        self.layout = FnoParamLayout(lift_in, self.hidden_channels, self.lifting_channels, self.projection_channels,
+                                     self.out_channels, self.n_layers, self.n_modes)
         flat = torch.empty(self.layout.total)
         self.layout.init_(flat)
         self.flat_params = nn.Parameter(flat)
@@ -204,4 +205,22 @@ class FNOModule(_FnoRolloutModule):
                          out_channels, n_layers, 1)
 
     def forward(self, x: torch.Tensor, teacher_forcing_steps: int = 50) -> torch.Tensor:
+        return super().forward(x, teacher_forcing_steps)
+
+
+class FNOContextModule(_FnoRolloutModule):
+    """nsbench/models/fno/fno.py:44-100 (the shipped configs/model/fno.yaml): a 3-D (time, y, x) FNO over the context window
+    [B, D, ctx, H, W] whose last time slice is the prediction; the context length IS n_modes[0] (:54 -- the YAML's
+    `context_size` is swallowed by **kwargs).  On libdlwpmi the (time, y) transform pair is one separable
+    dense DFT: the block kernels see a (ctx * H) x W image with n_modes[0] * n_modes[1] row frequencies
+    (DLWP_FNO_FORM_NS_CONTEXT3D, include/dlwpmi.h)."""
+
+    def __init__(self, n_modes, in_channels, hidden_channels, lifting_channels, projection_channels, out_channels, n_layers,
+                 max_n_modes=None, bias=True, **kwargs):
+        if len(n_modes) != 3:
+            raise ValueError("FNOContextModule takes three n_modes (time, y, x)")
+        super().__init__(n_modes, in_channels, hidden_channels, lifting_channels, projection_channels, out_channels, n_layers,
+                         int(n_modes[0]))
+
+    def forward(self, x: torch.Tensor, teacher_forcing_steps: int = 15) -> torch.Tensor:
         return super().forward(x, teacher_forcing_steps)

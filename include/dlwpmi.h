@@ -91,6 +91,10 @@ int dlwp_pwmlp_slab_fold(const float* slab, float* gw1, float* gb1, float* gw2, 
 /*   xhat   : [B][m1][m2c][C][2] truncated spectrum of act(x), saved for backward.        */
 typedef struct dlwp_fno_plan dlwp_fno_plan;
 int dlwp_fno_plan_create(int C, int H, int W, int m1, int m2c, dlwp_fno_plan** out);
+/* 3-D (time, y, x) blocks on [B,C,T,H,W] volumes (nsbench FNOContextModule / neuralop FNO with three n_modes): the plan  */
+/* treats the volume as a (T*H) x W image with m0*m1 kept row frequencies (separable product twiddles); x, pre:            */
+/* [B,C,T*H,W]; wspec [m0*m1][m2c][Cin][Cout][2]; xhat [B][m0*m1][m2c][C][2].                                             */
+int dlwp_fno_plan_create3d(int C, int T, int H, int W, int m0, int m1, int m2c, dlwp_fno_plan** out);
 void dlwp_fno_plan_destroy(dlwp_fno_plan* plan);
 /* bytes of scratch the block calls need for batch B (caller allocates, 256-B aligned)   */
 size_t dlwp_fno_block_workspace_bytes(const dlwp_fno_plan* plan, int B);
@@ -155,9 +159,16 @@ typedef struct dlwp_fno_cfg {
                             /* k = 0..T-ctx-1, teacher_forcing_steps unused)                              */
     int constant_channels;  /* dlwp form: channels of constants [B,1,Cc,H,W]                              */
     int prescribed_channels;/* dlwp form: channels of prescribed [B,T,Cp,H,W]                             */
+    int m0;                 /* DLWP_FNO_FORM_NS_CONTEXT3D: kept TEMPORAL modes n_modes[0] (m1 = n_modes[1] rows,  */
+                            /* m2c = n_modes[2]/2+1 columns); 0 for the 2-D forms                                 */
 } dlwp_fno_cfg;
 #define DLWP_FNO_FORM_NS 0
 #define DLWP_FNO_FORM_DLWP 1
+/* nsbench FNOContextModule (fno.py:44-100): the context window [B, ctx, D, H, W] is a [B, D, ctx, H, W] VOLUME for a     */
+/* 3-D (time, y, x) FNO and the last time slice of the result is the prediction; context_size = n_modes[0] (:54).         */
+/* The (time, y) transform pair is one dense separable DFT: the block kernels see a (ctx*H) x W image with m0*m1 kept     */
+/* "row" frequencies whose twiddles are products e^{-2 pi i (kt t/ctx + ky h/H)}; spectral weights [m0*m1][m2c][C][C][2].  */
+#define DLWP_FNO_FORM_NS_CONTEXT3D 2
 
 enum {
     DLWP_FNO_P_LIFT_W1 = 0, DLWP_FNO_P_LIFT_B1, DLWP_FNO_P_LIFT_W2, DLWP_FNO_P_LIFT_B2,

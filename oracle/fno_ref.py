@@ -194,3 +194,94 @@ def dlwp_rollout(net, constants, prescribed, prognostic, context_size):
         x_t = dlwp_prepare_inputs(constants, prescribed[:, t - ctx:t] if prescribed is not None else None, prognostic_t)
         outs.append(prognostic_t[:, -1] + net(x_t))
     return torch.stack(outs, dim=1)
+
+
+# ---- 3-D (time, y, x) FNO of nsbench FNOContextModule (src/nsbench/models/fno/fno.py:44-100: `FNO(n_modes=[12, 12, 12], ...)`
+# applied to the context window as a [B, D, T, H, W] volume, output = last time slice).  Same third-party arithmetic as the
+# 2-D case (neuralop SpectralConv is dimension-generic, App. A-1; PARITY UNPINNED), one more transformed axis.
+def spectral_conv3d(x, weight, bias, n_modes):
+    """x [B,Ci,T,H,W] real; weight complex [Ci,Co,m0,m1,m2c]; bias [Co] or None."""
+    B, Ci, T, H, W = x.shape
+    m0, m1, m2c = n_modes[0], n_modes[1], n_modes[2] // 2 + 1
+    X = torch.fft.rfftn(x, dim=(-3, -2, -1), norm="forward")
+    X = torch.fft.fftshift(X, dim=(-3, -2))
+    out = torch.zeros(B, weight.shape[1], T, H, W // 2 + 1, dtype=X.dtype)
+    s0, s1, s2 = _mode_slices(T, m0), _mode_slices(H, m1), slice(None, min(m2c, W // 2 + 1))
+    out[:, :, s0, s1, s2] = torch.einsum("bixyz,ioxyz->boxyz", X[:, :, s0, s1, s2], weight)
+    out = torch.fft.ifftshift(out, dim=(-3, -2))
+    y = torch.fft.irfftn(out, s=(T, H, W), dim=(-3, -2, -1), norm="forward")
+    if bias is not None:
+        y = y + bias.view(1, -1, 1, 1, 1)
+    return y
+
+
+class FNO3d:
+    """Dense 3-D FNO (neuralop.models.FNO with three n_modes, as constructed at nsbench/models/fno/fno.py:56-65)."""
+
+    def __init__(self, n_modes, in_channels, hidden_channels, lifting_channels, projection_channels, out_channels, n_layers,
+                 seed=1234, dtype=torch.float32):
+        self.n_modes, self.n_layers, self.hidden = list(n_modes), n_layers, hidden_channels
+        g = torch.Generator().manual_seed(seed)
+        m0, m1, m2c = n_modes[0], n_modes[1], n_modes[2] // 2 + 1
+
+        def conv_init(co, ci):
+            bound = 1.0 / math.sqrt(ci)
+            w = (torch.rand(co, ci, generator=g, dtype=torch.float64) * 2 - 1) * bound
+            b = (torch.rand(co, generator=g, dtype=torch.float64) * 2 - 1) * bound
+            return w.to(dtype), b.to(dtype)
+
+        p = {}
+        p["lifting.fcs.0.weight"], p["lifting.fcs.0.bias"] = conv_init(lifting_channels, in_channels)
+        p["lifting.fcs.1.weight"], p["lifting.fcs.1.bias"] = conv_init(hidden_channels, lifting_channels)
+        p["projection.fcs.0.weight"], p["projection.fcs.0.bias"] = conv_init(projection_channels, hidden_channels)
+        p["projection.fcs.1.weight"], p["projection.fcs.1.bias"] = conv_init(out_channels, projection_channels)
+        std = (2.0 / (hidden_channels + hidden_channels)) ** 0.5
+        for l in range(n_layers):
+            w = torch.randn(hidden_channels, hidden_channels, m0, m1, m2c, 2, generator=g, dtype=torch.float64) * std
+            p[f"fno_blocks.convs.weight.{l}"] = torch.view_as_complex(w.contiguous()).to(
+                torch.complex64 if dtype == torch.float32 else torch.complex128)
+            p[f"fno_blocks.fno_skips.{l}.weight"] = conv_init(hidden_channels, hidden_channels)[0]
+            p[f"fno_blocks.convs.bias.{l}"] = (torch.randn(hidden_channels, generator=g, dtype=torch.float64) * std).to(dtype)
+        self.params = p
+
+    def parameters(self):
+        return list(self.params.values())
+
+    def requires_grad_(self, flag=True):
+        for v in self.params.values():
+            v.requires_grad_(flag)
+        return self
+
+    def __call__(self, x):
+        """x [B, Cin, T, H, W] -> [B, Cout, T, H, W]"""
+        p = self.params
+        c3 = lambda t, w, b: F.conv3d(t, w[:, :, None, None, None], b)   # noqa: E731
+        h = c3(F.gelu(c3(x, p["lifting.fcs.0.weight"], p["lifting.fcs.0.bias"])), p["lifting.fcs.1.weight"], p["lifting.fcs.1.bias"])
+        for l in range(self.n_layers):
+            h = spectral_conv3d(h, p[f"fno_blocks.convs.weight.{l}"], p[f"fno_blocks.convs.bias.{l}"], self.n_modes) + \
+                c3(h, p[f"fno_blocks.fno_skips.{l}.weight"], None)
+            if l < self.n_layers - 1:
+                h = F.gelu(h)
+        return c3(F.gelu(c3(h, p["projection.fcs.0.weight"], p["projection.fcs.0.bias"])), p["projection.fcs.1.weight"],
+                  p["projection.fcs.1.bias"])
+
+
+def ns_rollout_context(net, x, teacher_forcing_steps, context_size):
+    """Line-by-line restatement of FNOContextModule.forward (nsbench/models/fno/fno.py:67-100): the window is transposed to
+    [B, D, T, H, W], run through the 3-D net, and the LAST time slice is the prediction."""
+    outs, out = [], None
+    for t in range(x.shape[1]):
+        if t < teacher_forcing_steps:
+            x_t = x[:, max(0, t - (context_size - 1)):t + 1]
+        else:
+            if context_size == 0:
+                x_t = out
+            else:
+                ts = max(0, (teacher_forcing_steps - t - 1) + context_size)
+                x_obs = x[:, teacher_forcing_steps - ts:teacher_forcing_steps]
+                x_out = torch.stack(outs[-(context_size - ts):], dim=1)
+                x_t = torch.cat([x_obs, x_out], dim=1)
+        x_t = torch.transpose(x_t, 1, 2)
+        out = x_t[:, :, -1] if t < context_size - 1 else net(x_t)[:, :, -1]
+        outs.append(out)
+    return torch.stack(outs, dim=1)

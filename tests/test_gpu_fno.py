@@ -534,3 +534,65 @@ def test_wide_dlwp_form_matches_oracle(cuda):
     torch.cuda.synchronize()
     assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item())
     assert rel_err(module.flat_grad, gref) <= GRAD_TOL
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, T=6, D=1, H=16, W=16, n_modes=(4, 6, 6), hidden=8, lifting=16, projection=16, n_layers=2, tf=5),
+    dict(B=1, T=5, D=2, H=16, W=32, n_modes=(2, 4, 8), hidden=12, lifting=16, projection=16, n_layers=1, tf=3),
+    dict(B=2, T=8, D=1, H=16, W=16, n_modes=(6, 16, 16), hidden=72, lifting=32, projection=32, n_layers=2, tf=6),
+])
+def test_fno_context_module_3d_matches_oracle(cuda, cfg):
+    """nsbench FNOContextModule (3-D FNO over the context volume, last time slice out; fno.py:44-100) against the oracle's
+    rfftn-based restatement: rollout outputs, loss and every gradient."""
+    from dlwp_benchmark_amd import nsbench
+    nm, D = list(cfg["n_modes"]), cfg["D"]
+    ctx = nm[0]
+    oracle = fno_ref.FNO3d(nm, D, cfg["hidden"], cfg["lifting"], cfg["projection"], D, cfg["n_layers"], seed=321)
+    module = nsbench.FNOContextModule(n_modes=nm, in_channels=D, hidden_channels=cfg["hidden"], lifting_channels=cfg["lifting"],
+                                      projection_channels=cfg["projection"], out_channels=D, n_layers=cfg["n_layers"],
+                                      context_size=10, type="FNOContextModule", name="t")
+    assert module.context_size == ctx
+    sd = {}
+    for k, v in oracle.params.items():
+        if ".convs.weight." in k:
+            sd["fno." + k + ".tensor"] = v
+        elif ".convs.bias." in k:
+            continue
+        elif k.endswith("weight"):
+            sd["fno." + k] = v[:, :, None, None, None]
+        else:
+            sd["fno." + k] = v
+    sd["fno.fno_blocks.convs.bias"] = torch.stack(
+        [oracle.params[f"fno_blocks.convs.bias.{l}"] for l in range(cfg["n_layers"])])[:, :, None, None, None]
+    module.load_state_dict(sd)
+    back = module.state_dict()
+    assert back["fno.fno_blocks.convs.weight.0.tensor"].shape == oracle.params["fno_blocks.convs.weight.0"].shape
+    module = module.to(cuda)
+    g = torch.Generator().manual_seed(17)
+    u = torch.randn(cfg["B"], cfg["T"] + 1, D, cfg["H"], cfg["W"], generator=g)
+    x, y = u[:, :-1].contiguous(), u[:, 1:].contiguous()
+    oracle.requires_grad_(True)
+    y_ref = fno_ref.ns_rollout_context(oracle, x, cfg["tf"], ctx)
+    loss_ref = torch.nn.functional.mse_loss(y_ref, y)
+    loss_ref.backward()
+    with torch.no_grad():
+        yh = module(x.to(cuda), teacher_forcing_steps=cfg["tf"])
+    assert rel_err(yh, y_ref) <= FWD_TOL
+    lay = module.layout
+    gref = torch.zeros(lay.total)
+    for name in lay.entries:
+        gr = oracle.params[name].grad
+        dst = lay.view(gref, name)
+        if ".convs.weight." in name:
+            Ci, Co = gr.shape[:2]
+            dst.copy_(fno_ref.spec_to_mode_major(gr.reshape(Ci, Co, -1, gr.shape[-1])))
+        else:
+            dst.copy_(gr.reshape(dst.shape))
+    for use_graph in (False, True):
+        module.flat_grad.zero_()
+        loss = module.train_step(x.to(cuda), y.to(cuda), cfg["tf"], optimizer=None, use_graph=use_graph)
+        torch.cuda.synchronize()
+        assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item())
+        assert rel_err(module.flat_grad, gref) <= GRAD_TOL
+        for name in lay.entries:
+            assert rel_err(lay.view(module.flat_grad, name), lay.view(gref, name)) <= 2e-3, name
