@@ -115,9 +115,11 @@ __global__ __launch_bounds__(256) void fno_spatial_wide_kernel(WideSpatialDev a)
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool active = 16 * w < wv;           // wave w owns pixels 16 w .. 16 w + 15 of the segment
-    for (int ic0 = 0; ic0 < a.C; ic0 += KBLK) {
-        // issue every load of the chunk, then commit (one global latency per chunk)
-        float4 tv[4];
+    // K loop over 64-channel chunks, register-prefetched: the global loads of chunk i+1 are in flight while chunk i runs on
+    // the matrix cores (one LDS image per operand, two barriers per chunk)
+    float4 tv[4];
+    float kv[16];
+    auto issue = [&](int ic0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int u = tid + 256 * q, i = u / (WSEG / 4), p4 = u - i * (WSEG / 4);
@@ -125,7 +127,6 @@ __global__ __launch_bounds__(256) void fno_spatial_wide_kernel(WideSpatialDev a)
             if (ic0 + i < a.C && 4 * p4 < wv)
                 tv[q] = *reinterpret_cast<const float4*>(&a.tin[((long long)b * a.C + ic0 + i) * HW + (long long)h * a.W + w0 + 4 * p4]);
         }
-        float kv[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int u = tid + 256 * q, hi = u >> 6, lo = u & 63;       // lo runs along the contiguous index of wskip
@@ -134,7 +135,8 @@ __global__ __launch_bounds__(256) void fno_spatial_wide_kernel(WideSpatialDev a)
             const long long src = a.transpose_w ? (long long)(ic0 + i) * a.C + ob0 + o : (long long)(ob0 + o) * a.C + ic0 + i;
             kv[q] = ok ? a.wskip[src] : 0.f;
         }
-        __syncthreads();                        // previous chunk's fragments are consumed (first pass: s1 / gs are written)
+    };
+    auto commit = [&]() {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int u = tid + 256 * q, i = u / (WSEG / 4), p4 = u - i * (WSEG / 4);
@@ -148,7 +150,13 @@ __global__ __launch_bounds__(256) void fno_spatial_wide_kernel(WideSpatialDev a)
             const int o = a.transpose_w ? lo : hi, i = a.transpose_w ? hi : lo;
             ks[o * LDKW + i] = kv[q];
         }
-        __syncthreads();
+    };
+    issue(0);
+    commit();
+    __syncthreads();                            // s1 / gs / the first chunk are in LDS
+    for (int ic0 = 0; ic0 < a.C; ic0 += KBLK) {
+        const bool more = ic0 + KBLK < a.C;
+        if (more) issue(ic0 + KBLK);
         if (active) {
 #pragma unroll
             for (int kc = 0; kc < KBLK / 16; ++kc) {
@@ -159,6 +167,11 @@ __global__ __launch_bounds__(256) void fno_spatial_wide_kernel(WideSpatialDev a)
                 for (int cb = 0; cb < 4; ++cb)
                     acc[cb] = mfma16_chunk(*reinterpret_cast<const f32x4*>(&ks[(cb * 16 + r) * LDKW + kc * 16 + 4 * g]), b4, acc[cb]);
             }
+        }
+        if (more) {
+            __syncthreads();                    // every wave has consumed the current chunk
+            commit();
+            __syncthreads();
         }
     }
     if (active) {
