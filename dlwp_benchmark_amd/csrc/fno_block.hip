@@ -540,12 +540,13 @@ __device__ __forceinline__ void mix_store_tile(float2* out, long long ostride_b,
 // tiles), dealt to the waves round-robin
 template <int CONJ, int TRW>
 __device__ __forceinline__ void mix_contract(const float2* xh, const float2* wm, int pitch, float2* out, long long ostride_b,
-                                             int B, int C) {
+                                             int B, int C, int nt_begin = 0, int nt_end = 1 << 30) {
     const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
     constexpr int NW = MIXT / 64;
-    const int ntn = (C + 15) / 16, nkc = (2 * C + 15) / 16, nmt = (2 * B + 15) / 16, nmp = (nmt + 1) / 2;
+    const int nkc = (2 * C + 15) / 16, nmt = (2 * B + 15) / 16, nmp = (nmt + 1) / 2;
+    const int ntn = min((C + 15) / 16, nt_end) - nt_begin;        // column tiles [nt_begin, nt_end) of this workgroup
     for (int item = w; item < ntn * nmp; item += NW) {
-        const int nt = item % ntn, mt0 = 2 * (item / ntn);
+        const int nt = nt_begin + item % ntn, mt0 = 2 * (item / ntn);
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;     // two row tiles share every weight fragment (B > 8)
         for (int kc0 = 0; kc0 < nkc; kc0 += 4) {
             f32x4 bf[4];
@@ -682,6 +683,136 @@ __global__ __launch_bounds__(MIXT) void fno_mix_bwd_kernel(MixDev a) {
     // gx[b][i] = sum_o ghat[b][o] conj(w[i][o])
     if (LDSW) mix_contract<1, 1>(gh, ws, C + 1, a.y + mofs, bstr, a.B, C);
     else mix_contract<1, 1>(gh, wm, C, a.y + mofs, bstr, a.B, C);
+}
+
+// ---- wide layers (and 3-D plans): the per-mode stage as TWO launches, so that the weight stream can be split over the chip.
+// The fused kernel above has one workgroup per mode: at 217 channels each streams a 377 KB weight slice alone (84 workgroups on
+// 256 CUs, 0.9 TB/s), and splitting it would make every part re-read the mode's x1 slice for the H-axis step.
+//   hstep : xhat[b][j][kx][c] = sum_h twH[j][h] x1[b][h][kx][c] on the matrix cores -- per kept column kx it is the complex GEMM
+//           [m1 x H] . [H x C] with the row-frequency twiddles as the A operand (rows (j, re) = [tr, -ti], (j, im) = [ti, tr],
+//           K = (h, re|im) interleaved), x1 read ONCE; one wave = (sample, column, 16 channels, pair of 16-row tiles)
+//   cmix  : the complex channel contraction of mix_contract, grid = modes x column-tile groups; backward: gx and the weight
+//           gradient for the group's rows of the weight slice (contiguous rows: read once, updated in place)
+struct HstepDev {
+    const float2* x1; const float2* twH; float2* out;
+    int B, C, H, m1, m2c, ntc, nmp;       // ntc = channel tiles, nmp = pairs of 16-row (j, re|im) tiles
+};
+
+__global__ __launch_bounds__(256) void fno_hstep_kernel(HstepDev a) {
+    const int lane = lane_id(), r = lane & 15, g = lane >> 4;
+    long long item = (long long)blockIdx.x * 4 + wave_id();
+    const long long nitems = (long long)a.B * a.m2c * a.ntc * a.nmp;
+    if (item >= nitems) return;
+    const int mp = (int)(item % a.nmp); item /= a.nmp;
+    const int ct = (int)(item % a.ntc); item /= a.ntc;
+    const int kx = (int)(item % a.m2c), b = (int)(item / a.m2c);
+    const int c = 16 * ct + r, cc = c < a.C ? c : a.C - 1;
+    const float2* xb = a.x1 + (((long long)b * a.H) * a.m2c + kx) * a.C + cc;
+    const long long hstride = (long long)a.m2c * a.C;
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const int nkc = (2 * a.H + 15) / 16;
+    for (int kc0 = 0; kc0 < nkc; kc0 += 4) {
+        f32x4 bf[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {          // B fragment: x1 rows h0, h0 + 1 (clamped loads, masked afterwards)
+            const int h0 = 8 * (kc0 + q) + 2 * g;
+            const float2 v0 = xb[(long long)min(h0, a.H - 1) * hstride], v1 = xb[(long long)min(h0 + 1, a.H - 1) * hstride];
+            const bool ok0 = h0 < a.H && c < a.C, ok1 = h0 + 1 < a.H && c < a.C;
+            bf[q] = f32x4{ok0 ? v0.x : 0.f, ok0 ? v0.y : 0.f, ok1 ? v1.x : 0.f, ok1 ? v1.y : 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int h0 = 8 * (kc0 + q) + 2 * g;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {      // A fragment of row m = (j, part): twiddles of rows h0, h0 + 1
+                const int m = 16 * (2 * mp + t) + r, j = m >> 1, part = m & 1;
+                f32x4 af = {0.f, 0.f, 0.f, 0.f};
+                if (j < a.m1 && h0 < a.H) {
+                    const float2 t0 = a.twH[(long long)j * a.H + h0];
+                    const float2 t1 = h0 + 1 < a.H ? a.twH[(long long)j * a.H + h0 + 1] : make_float2(0.f, 0.f);
+                    af = part ? f32x4{t0.y, t0.x, t1.y, t1.x} : f32x4{t0.x, -t0.y, t1.x, -t1.y};
+                }
+                acc[t] = mfma16_chunk(af, bf[q], acc[t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {              // rows 4g .. 4g+3 = frequencies j0, j0 + 1, (re, im) each
+        const int j0 = 8 * (2 * mp + t) + 2 * g;
+        if (c < a.C) {
+            if (j0 < a.m1) a.out[(((long long)b * a.m1 + j0) * a.m2c + kx) * a.C + c] = make_float2(acc[t][0], acc[t][1]);
+            if (j0 + 1 < a.m1) a.out[(((long long)b * a.m1 + j0 + 1) * a.m2c + kx) * a.C + c] = make_float2(acc[t][2], acc[t][3]);
+        }
+    }
+}
+
+struct CmixDev {
+    const float2* xhat; const float2* ghat; const float2* wspec; float2* y; float2* g_wspec;
+    int B, C, m1, m2c, tiles_per_wg;
+    FastDiv dC;
+};
+
+// forward: y[b][mode][o] = sum_i xhat[b][mode][i] w[mode][i][o] for the workgroup's column tiles
+__global__ __launch_bounds__(MIXT) void fno_cmix_fwd_kernel(CmixDev a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float2* xh = reinterpret_cast<float2*>(smem);      // [B][C]
+    const int C = a.C, mode = blockIdx.x;
+    const long long mofs = (long long)mode * C, bstr = (long long)a.m1 * a.m2c * C;
+    for (int bc = threadIdx.x; bc < a.B * C; bc += MIXT) {
+        const int b = fastdiv(bc, a.dC), c = bc - b * C;
+        xh[bc] = a.xhat[b * bstr + mofs + c];
+    }
+    __syncthreads();
+    const int nt0 = blockIdx.y * a.tiles_per_wg;
+    mix_contract<0, 0>(xh, a.wspec + mofs * C, C, a.y + mofs, bstr, a.B, C, nt0, nt0 + a.tiles_per_wg);
+}
+
+// backward: gx[b][mode][i] = sum_o ghat[b][o] conj(w[i][o]) and gw[i][o] += sum_b conj(xhat[b][i]) ghat[b][o] for the workgroup's rows i
+__global__ __launch_bounds__(MIXT) void fno_cmix_bwd_kernel(CmixDev a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float2* gh = reinterpret_cast<float2*>(smem);      // [B][C]
+    float2* xsv = gh + a.B * a.C;                      // [B][C]
+    const int C = a.C, mode = blockIdx.x;
+    const long long mofs = (long long)mode * C, bstr = (long long)a.m1 * a.m2c * C;
+    for (int bc = threadIdx.x; bc < a.B * C; bc += MIXT) {
+        const int b = fastdiv(bc, a.dC), c = bc - b * C;
+        gh[bc] = a.ghat[b * bstr + mofs + c];
+        xsv[bc] = a.xhat[b * bstr + mofs + c];
+    }
+    __syncthreads();
+    const int nt = (C + 15) / 16, it0 = blockIdx.y * a.tiles_per_wg, it1 = min(nt, it0 + a.tiles_per_wg);
+    const float2* wm = a.wspec + mofs * C;
+    float2* gw = a.g_wspec + mofs * C;
+    mix_contract<1, 1>(gh, wm, C, a.y + mofs, bstr, a.B, C, it0, it1);
+    {
+        const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
+        constexpr int NW = MIXT / 64;
+        const int ri = g & 1;
+        for (int t = NW - 1 - w; t < (it1 - it0) * nt; t += NW) {
+            const int it = it0 + t / nt, ot = t % nt;
+            const int i = 16 * it + r, o = 16 * ot + r;
+            float2 old[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) old[q] = gw[(long long)min(16 * it + 4 * g + q, C - 1) * C + min(o, C - 1)];
+            f32x4 are = {0.f, 0.f, 0.f, 0.f}, aim = {0.f, 0.f, 0.f, 0.f};
+            for (int b0 = 0; b0 < a.B; b0 += 2) {
+                const int b = b0 + (g >> 1);
+                const bool okb = b < a.B;
+                const float2 xv = (okb && i < C) ? xsv[b * C + i] : make_float2(0.f, 0.f);
+                const float2 gv = (okb && o < C) ? gh[b * C + o] : make_float2(0.f, 0.f);
+                const float av = ri ? xv.y : xv.x;
+                are = mfma16(av, ri ? gv.y : gv.x, are);
+                aim = mfma16(av, ri ? -gv.x : gv.y, aim);
+            }
+            if (o < C) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int io = 16 * it + 4 * g + q;
+                    if (io < C) gw[(long long)io * C + o] = make_float2(old[q].x + are[q], old[q].y + aim[q]);
+                }
+            }
+        }
+    }
 }
 
 template <typename K>
@@ -840,15 +971,61 @@ static int mix_launch(const dlwp_fno_plan* p, bool bwd, MixDev& a, hipStream_t s
     return DLWP_OK;
 }
 
+static int hstep_launch(const dlwp_fno_plan* p, const float2* x1, float2* out, int B, hipStream_t stream) {
+    HstepDev a{x1, p->twH, out, B, p->C, p->H, p->m1, p->m2c, ceil_div(p->C, 16), ceil_div(ceil_div(2 * p->m1, 16), 2)};
+    const long long items = (long long)B * p->m2c * a.ntc * a.nmp;
+    hipLaunchKernelGGL(fno_hstep_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, a);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+// column-tile groups per mode: enough workgroups to cover the chip about twice (every group streams its own part of the slice)
+static int cmix_tiles_per_wg(const dlwp_fno_plan* p) {
+    const int nt = ceil_div(p->C, 16), modes = p->m1 * p->m2c;
+    int groups = ceil_div(512, modes);
+    if (groups > nt) groups = nt;
+    if (groups < 1) groups = 1;
+    return ceil_div(nt, groups);
+}
+
 int dlwp_fno_mix_fwd(const dlwp_fno_plan* p, const float2* x1, const float2* wspec, float2* xhat, float2* y,
                      int B, hipStream_t stream) {
+    if (dlwp_fno_is_wide(p)) {
+        int rc = hstep_launch(p, x1, xhat, B, stream);
+        if (rc) return rc;
+        CmixDev a{xhat, nullptr, wspec, y, nullptr, B, p->C, p->m1, p->m2c, cmix_tiles_per_wg(p), make_fastdiv(p->C)};
+        const size_t lds = sizeof(float2) * (size_t)B * p->C;
+        if ((rc = set_lds(fno_cmix_fwd_kernel, lds, "fno_cmix_fwd")) != DLWP_OK) return rc;
+        hipLaunchKernelGGL(fno_cmix_fwd_kernel, dim3(p->m1 * p->m2c, ceil_div(ceil_div(p->C, 16), a.tiles_per_wg)), dim3(MIXT), lds,
+                           stream, a);
+        DLWP_LAUNCH_CHECK();
+        return DLWP_OK;
+    }
     MixDev a{x1, wspec, nullptr, xhat, y, nullptr, p->twH, B, p->C, p->H, p->m1, p->m2c,
              make_fastdiv(p->C), make_fastdiv(B * p->C), make_fastdiv(B * p->C / 2 > 0 ? B * p->C / 2 : 1)};
     return mix_launch(p, false, a, stream);
 }
 
+// (wide layers: the H-step result ghat [B][m1][m2c][C] is produced in gxhat and moved into the storage of g1 -- dead once the
+// H-step has read it, and at least as large since m1 <= H -- because the contraction reads ghat of ALL channels while it
+// writes gx into gxhat; the caller's g1 buffer is therefore overwritten)
 int dlwp_fno_mix_bwd(const dlwp_fno_plan* p, const float2* g1, const float2* wspec, const float2* xhat,
                      float2* gxhat, float2* g_wspec, int B, hipStream_t stream) {
+    if (dlwp_fno_is_wide(p)) {
+        DLWP_REQUIRE(p->m1 <= p->H, DLWP_E_INVALID, "fno_mix_bwd: more row frequencies than rows");
+        int rc = hstep_launch(p, g1, gxhat, B, stream);
+        if (rc) return rc;
+        const size_t n = (size_t)B * p->m1 * p->m2c * p->C;
+        float2* ghat = const_cast<float2*>(g1);
+        DLWP_HIP(hipMemcpyAsync(ghat, gxhat, n * sizeof(float2), hipMemcpyDeviceToDevice, stream));
+        CmixDev a{xhat, ghat, wspec, gxhat, g_wspec, B, p->C, p->m1, p->m2c, cmix_tiles_per_wg(p), make_fastdiv(p->C)};
+        const size_t lds = sizeof(float2) * (size_t)2 * B * p->C;
+        if ((rc = set_lds(fno_cmix_bwd_kernel, lds, "fno_cmix_bwd")) != DLWP_OK) return rc;
+        hipLaunchKernelGGL(fno_cmix_bwd_kernel, dim3(p->m1 * p->m2c, ceil_div(ceil_div(p->C, 16), a.tiles_per_wg)), dim3(MIXT), lds,
+                           stream, a);
+        DLWP_LAUNCH_CHECK();
+        return DLWP_OK;
+    }
     MixDev a{g1, wspec, xhat, nullptr, gxhat, g_wspec, p->twH, B, p->C, p->H, p->m1, p->m2c,
              make_fastdiv(p->C), make_fastdiv(B * p->C), make_fastdiv(B * p->C / 2 > 0 ? B * p->C / 2 : 1)};
     return mix_launch(p, true, a, stream);

@@ -201,3 +201,37 @@ def test_c5_afno_721x1440_full_width_properties(cuda):
     sample_independence(m, kw, tol=1e-5)
     target = torch.randn(2, 1, 8, 721, 1440, generator=torch.Generator().manual_seed(10)).to(cuda)
     directional_check(m, lambda: torch.nn.functional.mse_loss(m(**kw), target))
+
+
+# ---- bf16-operand mode (the reference's autocast arithmetic for BASELINE C3-C5) stays close to fp32 at C4 and C5 sizes too
+def test_c4_bf16_operand_mode_stays_close_to_fp32(cuda):
+    from dlwp_benchmark_amd import dlwpbench, lib as L
+    torch.manual_seed(17)
+    swin = dlwpbench.SwinTransformer(constant_channels=4, prescribed_channels=1, prognostic_channels=8, context_size=1,
+                                     img_height=128, img_width=256, patch_size=1, embed_dim=96, depths=[4, 4], num_heads=[4, 4],
+                                     drop_path_rate=0.0, window_size=7).to(cuda).eval()
+    pangu = dlwpbench.PanguWeather(constant_channels=4, prescribed_channels=1, prognostic_channels=8, embed_dim=192,
+                                   num_heads=(6, 12, 12, 6), window_size=(2, 7, 7), patch_size=(1, 1), n_lat=128, n_lon=256,
+                                   context_size=1).to(cuda).eval()
+    kw = dlwp_inputs(1, 2, 8, 128, 256, 36, cuda)
+    for m in (swin, pangu):
+        with torch.no_grad():
+            ref = m(**kw)
+            with L.gemm_precision("bf16"):
+                low = m(**kw)
+        # the increment net(x) is what the GEMMs compute; compare it, not the residual-dominated output
+        inc_ref, inc_low = ref - kw["prognostic"][:, :1], low - kw["prognostic"][:, :1]
+        assert rel(inc_low, inc_ref) <= 4e-2, type(m).__name__      # bf16 operands (8 mantissa bits), fp32 accumulation
+
+
+def test_c5_bf16_operand_mode_stays_close_to_fp32(cuda):
+    from dlwp_benchmark_amd import dlwpbench, lib as L
+    torch.manual_seed(18)
+    m = dlwpbench.AFNONet(**dict(C5_721, embed_dim=768, depth=4, num_blocks=16)).to(cuda).eval()
+    kw = dlwp_inputs(1, 2, 8, 721, 1440, 37, cuda)
+    with torch.no_grad():
+        ref = m(**kw)
+        with L.gemm_precision("bf16"):
+            low = m(**kw)
+    inc_ref, inc_low = ref - kw["prognostic"][:, :1], low - kw["prognostic"][:, :1]
+    assert rel(inc_low, inc_ref) <= 4e-2
