@@ -21,7 +21,7 @@ timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write fno_spatial_kernel $O/traffic.json "fno_spatial_kernel<2,1>" > $O/traffic.log 2>&1
 echo "probes done"
 timeout 400 python3 $R/tools/bench_fft.py > $O/fft_bench.txt 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_fft -- python3 $R/tools/bench_fft.py > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_fft -- python3 $R/tools/probe_fft.py > /dev/null 2>&1
 timeout 400 python3 $R/bench.py --workload sfno > $O/bench_line_sfno.json 2> $O/bench_sfno.err
 timeout 900 python3 $R/tools/bench_models.py all --steps 10 > $O/models.jsonl 2> $O/models.err
 for m in afno swin pangu; do
