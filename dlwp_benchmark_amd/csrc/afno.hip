@@ -27,6 +27,7 @@ constexpr int RS = 16;     // image rows staged per row-pass step
 
 struct AfnoDev {
     const float* x;        // fwd: input x; bwd: upstream gradient gy
+    const float* res2;     // fwd, optional: a second residual added to the output (the block's double skip)
     float* y;              // fwd: output; bwd: gx
     float2* xsave;         // [B][nb][R][c1][bs] kept spectrum of x (fwd writes, bwd reads)
     const float *w1, *b1, *w2, *b2;   // [2][nb][bs][bs], [2][nb][bs], ...
@@ -159,8 +160,8 @@ __device__ __forceinline__ void col_pass(const AfnoDev& a, float* Sf, const floa
 
 // rows inverse: dst[b][h][w][ch] = res[b][h][w][ch] + s sum_kw c(kw) Re(S[h][kw][ch] e^{+2 pi i kw w / W});  per image row
 // a [W x 2 c1] . [2 c1 x bs] product
-__device__ __forceinline__ void row_pass_inv(const AfnoDev& a, float* dst, const float* res, int b, int blk, const float* Sf,
-                                             const float2* twW, float s, bool weight_ck) {
+__device__ __forceinline__ void row_pass_inv(const AfnoDev& a, float* dst, const float* res, const float* res2, int b, int blk,
+                                             const float* Sf, const float2* twW, float s, bool weight_ck) {
     const int tid = threadIdx.x, bs = a.bs, c1 = a.c1, W = a.W;
     const int lane = tid & 63, wv = tid >> 6, r = lane & 15, g = lane >> 4;
     const int Mt = (W + 15) / 16, Kc = (2 * c1 + 15) / 16, chc = min(r, bs - 1);
@@ -185,7 +186,7 @@ __device__ __forceinline__ void row_pass_inv(const AfnoDev& a, float* dst, const
             const int wo = 16 * mt + 4 * g + j;
             if (wo < W && r < bs) {
                 const long long gi = (((long long)b * a.H + h) * W + wo) * a.C + blk * bs + r;
-                dst[gi] = res[gi] + acc[j];
+                dst[gi] = res[gi] + acc[j] + (res2 ? res2[gi] : 0.f);
             }
         }
     }
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(NT) void afno2d_kernel(AfnoDev a) {
     col_pass<true>(a, Sf, twH);
     DLWP_STAMP(6);
     // inverse rows + residual: fwd = irfft (interior columns doubled); bwd = adjoint of rfft (no doubling)
-    row_pass_inv(a, a.y, a.x, b, blk, Sf, twW, s, !BWD);
+    row_pass_inv(a, a.y, a.x, BWD ? nullptr : a.res2, b, blk, Sf, twW, s, !BWD);
     DLWP_STAMP(7);
 }
 
@@ -473,20 +474,27 @@ extern "C" long long dlwp_afno2d_save_elems(int B, int H, int W, int C, int nb, 
     return (long long)B * nb * (a.r1 - a.r0) * a.c1 * a.bs * 2;
 }
 
-extern "C" int dlwp_afno2d_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
-                               float* y, float* xsave, int B, int H, int W, int C, int nb, float sparsity_threshold,
-                               float hard_thresholding_fraction, void* stream) {
+extern "C" int dlwp_afno2d_fwd_res(const float* x, const float* residual, const float* w1, const float* b1, const float* w2,
+                                   const float* b2, float* y, float* xsave, int B, int H, int W, int C, int nb,
+                                   float sparsity_threshold, float hard_thresholding_fraction, void* stream) {
     DLWP_REQUIRE(x && w1 && b1 && w2 && b2 && y && xsave, DLWP_E_INVALID, "afno2d_fwd: NULL argument");
     AfnoDev a{};
     int rc = afno_setup(a, B, H, W, C, nb, hard_thresholding_fraction, "afno2d_fwd");
     if (rc) return rc;
-    a.x = x; a.y = y; a.xsave = reinterpret_cast<float2*>(xsave); a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
+    a.x = x; a.res2 = residual; a.y = y; a.xsave = reinterpret_cast<float2*>(xsave); a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
     a.lambda = sparsity_threshold;
     const size_t lds = afno_lds_bytes(H, W, a.bs, a.c1, a.nwm);
     if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(afno2d_kernel<false>), lds, "afno2d_fwd"))) return rc;
     hipLaunchKernelGGL(afno2d_kernel<false>, dim3(B * nb), dim3(NT), lds, (hipStream_t)stream, a);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
+}
+
+extern "C" int dlwp_afno2d_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                               float* y, float* xsave, int B, int H, int W, int C, int nb, float sparsity_threshold,
+                               float hard_thresholding_fraction, void* stream) {
+    return dlwp_afno2d_fwd_res(x, nullptr, w1, b1, w2, b2, y, xsave, B, H, W, C, nb, sparsity_threshold,
+                               hard_thresholding_fraction, stream);
 }
 
 extern "C" int dlwp_afno2d_bwd(const float* gy, const float* xsave, const float* w1, const float* b1, const float* w2,

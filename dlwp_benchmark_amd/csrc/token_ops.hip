@@ -459,12 +459,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
-// gx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)); ggamma/gbeta partials via atomics
+// gx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)) (+ gadd: the gradient that reached x along the residual
+// branch of a pre-norm block, so the two paths meet here instead of in a separate add); ggamma/gbeta partials via atomics
 template <int NQ>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            const float* __restrict__ gy, float* __restrict__ gx,
-                                                            float* ggamma, float* gbeta, int T, int C, int rows_per_block) {
+                                                            const float* __restrict__ gy, const float* __restrict__ gadd,
+                                                            float* __restrict__ gx, float* ggamma, float* gbeta, int T, int C,
+                                                            int rows_per_block) {
     extern __shared__ float sm[];            // [2][C] per-block partial of ggamma, gbeta
     float* sg = sm;
     float* sb = sm + C;
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     // each wave owns the columns c = lane, lane+64, ... (C <= 64*NQ, checked by the host wrapper) of its rows and keeps the
     // column partials in registers.  The next row's loads are in flight while the current row is reduced (one wave per SIMD
     // would otherwise pay a full memory latency per row); loads use clamped addresses, masks are applied afterwards.
-    float pg[NQ], pb[NQ], gam[NQ], xv[NQ], gv[NQ], xn[NQ], gn[NQ];
+    float pg[NQ], pb[NQ], gam[NQ], xv[NQ], gv[NQ], av[NQ], xn[NQ], gn[NQ], an[NQ];
     bool okc[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -483,26 +485,28 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         okc[q] = lane + 64 * q < C;
         gam[q] = okc[q] ? gamma[min(lane + 64 * q, C - 1)] : 0.f;
     }
-    auto load_row = [&](int row, float (&X)[NQ], float (&G)[NQ], float& mu, float& rs) {
+    auto load_row = [&](int row, float (&X)[NQ], float (&G)[NQ], float (&A)[NQ], float& mu, float& rs) {
         const int rc = min(row, T - 1);
         const float* xr = x + (long long)rc * C;
         const float* gr = gy + (long long)rc * C;
+        const float* ar = gadd ? gadd + (long long)rc * C : nullptr;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int c = min(lane + 64 * q, C - 1);
             X[q] = xr[c];
             G[q] = gr[c];
+            A[q] = ar ? ar[c] : 0.f;
         }
         mu = mean[rc];
         rs = rstd[rc];
     };
     float mu, rs, mun = 0.f, rsn = 0.f;
-    load_row(row0 + w, xv, gv, mu, rs);
+    load_row(row0 + w, xv, gv, av, mu, rs);
     for (int rr = w; rr < rows_per_block; rr += 4) {
         const int row = row0 + rr;
         if (row >= T) break;
         const bool more = rr + 4 < rows_per_block && row + 4 < T;
-        if (more) load_row(row + 4, xn, gn, mun, rsn);
+        if (more) load_row(row + 4, xn, gn, an, mun, rsn);
         float s1 = 0.f, s2 = 0.f, xh[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -518,10 +522,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         s2 = wave_sum64(s2) / C;
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
-            if (okc[q]) gx[(long long)row * C + lane + 64 * q] = rs * (gv[q] * gam[q] - s1 - xh[q] * s2);
+            if (okc[q]) gx[(long long)row * C + lane + 64 * q] = rs * (gv[q] * gam[q] - s1 - xh[q] * s2) + av[q];
         if (more) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) { xv[q] = xn[q]; gv[q] = gn[q]; }
+            for (int q = 0; q < NQ; ++q) { xv[q] = xn[q]; gv[q] = gn[q]; av[q] = an[q]; }
             mu = mun; rs = rsn;
         }
     }
@@ -710,8 +714,9 @@ extern "C" int dlwp_layernorm_fwd(const float* x, const float* gamma, const floa
     return DLWP_OK;
 }
 
-extern "C" int dlwp_layernorm_bwd(const float* x, const float* gamma, const float* mean, const float* rstd,
-                                  const float* gy, float* gx, float* ggamma, float* gbeta, int T, int C, void* stream) {
+extern "C" int dlwp_layernorm_bwd_res(const float* x, const float* gamma, const float* mean, const float* rstd,
+                                      const float* gy, const float* gadd, float* gx, float* ggamma, float* gbeta, int T,
+                                      int C, void* stream) {
     DLWP_REQUIRE(x && gamma && mean && rstd && gy && gx && ggamma && gbeta && T > 0 && C > 0, DLWP_E_INVALID,
                  "layernorm_bwd: bad argument");
     DLWP_REQUIRE(C <= 2048, DLWP_E_UNSUPPORTED, "layernorm_bwd: C <= 2048 supported (got %d)", C);
@@ -725,8 +730,8 @@ extern "C" int dlwp_layernorm_bwd(const float* x, const float* gamma, const floa
     const dim3 grid(ceil_div(T, rpb));
     const size_t lds = 2 * C * sizeof(float);
 #define LN_BWD(NQ)                                                                                                   \
-    hipLaunchKernelGGL(layernorm_bwd_kernel<NQ>, grid, dim3(256), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, gx, \
-                       ggamma, gbeta, T, C, rpb)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<NQ>, grid, dim3(256), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, gadd, \
+                       gx, ggamma, gbeta, T, C, rpb)
     if (C <= 64) LN_BWD(1);
     else if (C <= 128) LN_BWD(2);
     else if (C <= 256) LN_BWD(4);
@@ -736,6 +741,11 @@ extern "C" int dlwp_layernorm_bwd(const float* x, const float* gamma, const floa
 #undef LN_BWD
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
+}
+
+extern "C" int dlwp_layernorm_bwd(const float* x, const float* gamma, const float* mean, const float* rstd,
+                                  const float* gy, float* gx, float* ggamma, float* gbeta, int T, int C, void* stream) {
+    return dlwp_layernorm_bwd_res(x, gamma, mean, rstd, gy, nullptr, gx, ggamma, gbeta, T, C, stream);
 }
 
 extern "C" int dlwp_gelu_bwd(const float* z, const float* gy, float* gz, long long n, void* stream) {

@@ -262,13 +262,14 @@ namespace {
 // out[b][i] = (x ? x[b][i] : 0) + s[b] * t[b][i]; one sample's row is n floats (n % 4 == 0: 16-byte accesses)
 __global__ __launch_bounds__(256) void scale_rows_add_kernel(const float* __restrict__ t, const float* __restrict__ s,
                                                              const float* __restrict__ x, float* __restrict__ out,
-                                                             long long n4, int vec) {
+                                                             long long n4, int vec, int x_shared) {
     const int b = blockIdx.y;
-    const float sc = s[b];
+    const float sc = s ? s[b] : 1.f;
+    if (x && !x_shared) x += (long long)b * n4 * (vec ? 4 : 1);      // x_shared: one row for every sample (broadcast add)
     const long long stride = (long long)gridDim.x * 256;
     if (vec) {
         const float4* t4 = reinterpret_cast<const float4*>(t) + (long long)b * n4;
-        const float4* x4 = x ? reinterpret_cast<const float4*>(x) + (long long)b * n4 : nullptr;
+        const float4* x4 = x ? reinterpret_cast<const float4*>(x) : nullptr;
         float4* o4 = reinterpret_cast<float4*>(out) + (long long)b * n4;
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
             float4 v = t4[i];
@@ -279,15 +280,15 @@ __global__ __launch_bounds__(256) void scale_rows_add_kernel(const float* __rest
     } else {      // n4 = n here
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
             const long long o = (long long)b * n4 + i;
-            out[o] = fmaf(sc, t[o], x ? x[o] : 0.f);
+            out[o] = fmaf(sc, t[o], x ? x[i] : 0.f);
         }
     }
 }
 }  // namespace
 
-extern "C" int dlwp_scale_rows_add(const float* t, const float* scale, const float* x, float* out, int B, long long n,
-                                   void* stream) {
-    DLWP_REQUIRE(t && scale && out && B > 0 && n > 0, DLWP_E_INVALID, "scale_rows_add: bad argument");
+static int scale_rows_add_impl(const float* t, const float* scale, const float* x, float* out, int B, long long n, int x_shared,
+                               void* stream) {
+    DLWP_REQUIRE(t && out && B > 0 && n > 0, DLWP_E_INVALID, "scale_rows_add: bad argument");
     DLWP_REQUIRE(B <= 65535, DLWP_E_UNSUPPORTED, "scale_rows_add: at most 65535 rows (got %d)", B);
     const bool vec = n % 4 == 0 && ((uintptr_t)t % 16 == 0) && ((uintptr_t)out % 16 == 0) && (!x || (uintptr_t)x % 16 == 0);
     const long long units = vec ? n / 4 : n;
@@ -295,9 +296,19 @@ extern "C" int dlwp_scale_rows_add(const float* t, const float* scale, const flo
     const long long cap = std::max<long long>(1, 2048 / B);
     if (bx > cap) bx = cap;
     hipLaunchKernelGGL(scale_rows_add_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, t, scale, x,
-                       out, units, vec ? 1 : 0);
+                       out, units, vec ? 1 : 0, x_shared);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
+}
+
+extern "C" int dlwp_scale_rows_add(const float* t, const float* scale, const float* x, float* out, int B, long long n,
+                                   void* stream) {
+    return scale_rows_add_impl(t, scale, x, out, B, n, 0, stream);
+}
+
+extern "C" int dlwp_add_bcast(const float* t, const float* p, float* out, int B, long long n, void* stream) {
+    DLWP_REQUIRE(p, DLWP_E_INVALID, "add_bcast: NULL argument");
+    return scale_rows_add_impl(t, nullptr, p, out, B, n, 1, stream);
 }
 
 extern "C" int dlwp_sumsq(const float* g, long long n, float* out, void* stream) {

@@ -18,6 +18,7 @@ namespace {
 
 struct WinDev {
     const float* src;
+    const float* res;      // scatter only, optional: a residual in token layout added to the result (the block's skip connection)
     float* dst;
     int B, C, D[3], P[3], f[3], s[3], w[3], nw[3], circ[3];
     long long sw[3];
@@ -102,7 +103,48 @@ __global__ __launch_bounds__(256) void win_scatter_kernel(WinDev a) {
                 if (!a.circ[0]) break;
             }
         }
+        if (a.res) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(a.res + (long long)tok * a.C + 4 * c4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += r[k];
+        }
         *reinterpret_cast<f32x4*>(a.dst + (long long)tok * a.C + 4 * c4) = acc;
+    }
+}
+
+// Patch merging gather (PatchMerging.forward, src/nsbench/models/swintransformer/swin_transformer.py:291-312; dlwpbench twin):
+// out[b][i][j][q C + c] = x[b][2 i + (q & 1)][2 j + (q >> 1)][c], zero beyond an odd H / W -- the reference's pad + four strided
+// slices + cat.  BWD is the adjoint: gx[b][h][w][c] = g[b][h / 2][w / 2][((w & 1) * 2 + (h & 1)) C + c].
+template <bool BWD, int VEC>
+__global__ __launch_bounds__(256) void patch_merge_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int H, int W,
+                                                          int C) {
+    const int H2 = (H + 1) / 2, W2 = (W + 1) / 2, CV = C / VEC;
+    const long long total = BWD ? (long long)B * H * W * CV : (long long)B * H2 * W2 * 4 * CV;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int c = (int)(e % CV) * VEC;
+        long long r = e / CV;
+        int h, w, q;
+        if (BWD) {
+            w = (int)(r % W); r /= W;
+            h = (int)(r % H); r /= H;
+            q = (w & 1) * 2 + (h & 1);
+        } else {
+            q = (int)(r & 3); r >>= 2;
+            const int j = (int)(r % W2); r /= W2;
+            const int i = (int)(r % H2); r /= H2;
+            h = 2 * i + (q & 1); w = 2 * j + (q >> 1);
+        }
+        const int b = (int)r;
+        const long long xo = (((long long)b * H + h) * W + w) * C + c;
+        const long long mo = ((((long long)b * H2 + h / 2) * W2 + w / 2) * 4 + q) * C + c;
+        if (BWD) {
+            if (VEC == 4) *reinterpret_cast<f32x4*>(dst + xo) = *reinterpret_cast<const f32x4*>(src + mo);
+            else dst[xo] = src[mo];
+        } else {
+            const bool ok = h < H && w < W;
+            if (VEC == 4) *reinterpret_cast<f32x4*>(dst + mo) = ok ? *reinterpret_cast<const f32x4*>(src + xo) : f32x4{0.f, 0.f, 0.f, 0.f};
+            else dst[mo] = ok ? src[xo] : 0.f;
+        }
     }
 }
 
@@ -152,9 +194,34 @@ extern "C" int dlwp_window_gather(const float* x, float* windows, int B, int C, 
 extern "C" int dlwp_window_scatter(const float* windows, float* x, int B, int C, const int* dims, const int* padded,
                                    const int* front, const int* shift, const int* window, const long long* wstride,
                                    const int* circular, int sum_copies, void* stream) {
+    return dlwp_window_scatter_add(windows, nullptr, x, B, C, dims, padded, front, shift, window, wstride, circular, sum_copies,
+                                   stream);
+}
+
+extern "C" int dlwp_patch_merge(const float* src, float* dst, int B, int H, int W, int C, int backward, void* stream) {
+    DLWP_REQUIRE(src && dst && B > 0 && H > 0 && W > 0 && C > 0, DLWP_E_INVALID, "patch_merge: bad argument");
+    const bool vec = C % 4 == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0;
+    const long long H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+    const long long total = (backward ? (long long)B * H * W : (long long)B * H2 * W2 * 4) * (vec ? C / 4 : C);
+    const dim3 grid(grid_for(total));
+    if (backward) {
+        if (vec) hipLaunchKernelGGL((patch_merge_kernel<true, 4>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, B, H, W, C);
+        else hipLaunchKernelGGL((patch_merge_kernel<true, 1>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, B, H, W, C);
+    } else {
+        if (vec) hipLaunchKernelGGL((patch_merge_kernel<false, 4>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, B, H, W, C);
+        else hipLaunchKernelGGL((patch_merge_kernel<false, 1>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, B, H, W, C);
+    }
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_window_scatter_add(const float* windows, const float* residual, float* x, int B, int C, const int* dims,
+                                       const int* padded, const int* front, const int* shift, const int* window,
+                                       const long long* wstride, const int* circular, int sum_copies, void* stream) {
     WinDev a{};
     int rc = win_setup(a, windows, x, B, C, dims, padded, front, shift, window, wstride, circular, "window_scatter");
     if (rc) return rc;
+    a.res = residual;
     a.dup = sum_copies != 0;
     hipLaunchKernelGGL(win_scatter_kernel, dim3(grid_for((long long)B * dims[0] * dims[1] * dims[2] * (C / 4))), dim3(256), 0,
                        (hipStream_t)stream, a);

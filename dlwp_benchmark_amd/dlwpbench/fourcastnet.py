@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from ..nsbench.fourcastnet import Block, PatchEmbed
-from ..token_ops import LayerNorm, Linear
+from ..token_ops import LayerNorm, Linear, add_pos_embed
 from .rollout import rollout
 
 
@@ -59,7 +59,7 @@ class AFNONet(nn.Module):
         B = x.shape[0]
         x = self.patch_embed(x)
         if self.use_pos_embed:
-            x = x + self.pos_embed
+            x = add_pos_embed(x, self.pos_embed)
         x = x.reshape(B, self.h, self.w, self.embed_dim)
         for blk in self.blocks:
             x = blk(x)
@@ -75,7 +75,9 @@ class AFNONet(nn.Module):
 
     def forward(self, constants: torch.Tensor = None, prescribed: torch.Tensor = None,
                 prognostic: torch.Tensor = None) -> torch.Tensor:
-        return rollout(self.forward_one_step, self.context_size, constants, prescribed, prognostic)
+        # the head's patch tokens go to the rollout as they are: un-patching rides the window-advance kernel
+        return rollout(lambda x: self.head(self.forward_features(x)), self.context_size, constants, prescribed, prognostic,
+                       patch=self.patch_size)
 
 
 FourCastNet = AFNONet
@@ -122,7 +124,7 @@ class SFNONet(nn.Module):
         B = x.shape[0]
         x = self.patch_embed(x)
         if self.use_pos_embed:
-            x = x + self.pos_embed
+            x = add_pos_embed(x, self.pos_embed)
         x = x.reshape(B, self.h, self.w, self.embed_dim).permute(0, 3, 1, 2)
         return self.sfno(x).permute(0, 2, 3, 1)
 

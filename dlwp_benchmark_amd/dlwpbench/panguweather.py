@@ -18,7 +18,8 @@ import torch.nn.functional as F
 
 from ..nsbench.swin_transformer import window_attention_core
 from ..window_ops import WindowSpec, partition, reverse
-from ..token_ops import DropPath, LayerNorm, Linear, Mlp, PatchConv2d, UpConvT2d
+from .rollout import rollout
+from ..token_ops import DropPath, DropPathPool, LayerNorm, Linear, Mlp, PatchConv2d, UpConvT2d, norm_fork
 
 _DEFAULT_SHIFT = (1, 3, 6)   # panguweather.py:243
 
@@ -122,13 +123,14 @@ class EarthSpecificBlock(nn.Module):
             spec = self._wspec
             fwd_shift = (sh[0], sh[1], sh[1]) if self.roll else (0, 0, 0)
             rev_shift = sh if self.roll else (0, 0, 0)
-            t = self.attn(partition(self.norm1(x), spec, fwd_shift), self._labels if self.roll else None, spec.nW)
-            t = reverse(t, spec, B, rev_shift)
+            # skip connections leave the LayerNorm nodes (norm_fork): their gradients join the LayerNorm backward kernels
+            skip, t = norm_fork(self.norm1, x)
+            t = self.attn(partition(t, spec, fwd_shift), self._labels if self.roll else None, spec.nW)
             if self.drop_path.active:            # stochastic depth: per-sample scale fused with the residual adds
-                x = self.drop_path(t, residual=x)
-                return self.drop_path(self.mlp(self.norm2(x)), residual=x)
-            x = x + t
-            return self.mlp(self.norm2(x), residual=x)
+                skip, t = norm_fork(self.norm2, self.drop_path(reverse(t, spec, B, rev_shift), residual=skip))
+                return self.drop_path(self.mlp(t), residual=skip)
+            skip, t = norm_fork(self.norm2, reverse(t, spec, B, rev_shift, residual=skip))
+            return self.mlp(t, residual=skip)
         t = self.norm1(x).view(B, Pl, Lat, Lon, C)
         t = F.pad(t.permute(0, 4, 1, 2, 3), p).permute(0, 2, 3, 4, 1)
         Plp, Latp, Lonp = self.pad_resolution
@@ -255,6 +257,9 @@ class PanguWeather(nn.Module):
         self.patchrecovery2d = PatchRecovery2D((n_lat, n_lon), patch_size, 2 * embed_dim, prognostic_channels)
 
     def forward_one_step(self, x):
+        if getattr(self, "_drop_pool", None) is None:      # built lazily: after construction, copies and loads
+            object.__setattr__(self, "_drop_pool", DropPathPool(self))
+        self._drop_pool.draw(x.shape[0], x.device)        # every block's stochastic-depth mask for this call, one draw
         x = self.patchembed2d(x).unsqueeze(2)
         B, C, Pl, Lat, Lon = x.shape
         x = x.reshape(B, C, -1).transpose(1, 2)
@@ -266,15 +271,4 @@ class PanguWeather(nn.Module):
 
     def forward(self, constants: torch.Tensor = None, prescribed: torch.Tensor = None,
                 prognostic: torch.Tensor = None) -> torch.Tensor:
-        outs, ctx = [], self.context_size
-        for t in range(ctx, prognostic.shape[1]):
-            if t == ctx:
-                prog_t = prognostic[:, max(0, t - ctx):t]
-            else:
-                prog_t = torch.cat([prognostic[:, max(0, t - ctx):ctx], torch.stack(outs, dim=1)[:, -ctx:]], dim=1)
-            parts = [] if constants is None else [constants[:, 0]]
-            if prescribed is not None:
-                parts.append(prescribed[:, t - ctx:t].flatten(1, 2))
-            parts.append(prog_t.flatten(1, 2))
-            outs.append(prog_t[:, -1] + self.forward_one_step(torch.cat(parts, dim=1)))
-        return torch.stack(outs, dim=1)
+        return rollout(self.forward_one_step, self.context_size, constants, prescribed, prognostic)

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from ..nsbench.swin_transformer import _NORMS, BasicLayer, PatchEmbed, PatchMerging
-from ..token_ops import PatchConv2d, UpConvT2d
+from ..token_ops import DropPathPool, PatchConv2d, UpConvT2d
 from .rollout import rollout
 
 
@@ -64,6 +64,9 @@ class SwinTransformer(nn.Module):
         self.final = PatchConv2d(embed_dim, prognostic_channels, kernel_size=1)
 
     def one_step(self, x):
+        if getattr(self, "_drop_pool", None) is None:      # built lazily: after construction, copies and loads
+            object.__setattr__(self, "_drop_pool", DropPathPool(self))
+        self._drop_pool.draw(x.shape[0], x.device)        # every block's stochastic-depth mask for this call, one draw
         x = self.patch_embed(x)
         Wh, Ww = x.shape[2], x.shape[3]
         x = x.flatten(2).transpose(1, 2)

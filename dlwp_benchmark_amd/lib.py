@@ -60,6 +60,7 @@ SIGNATURES = {
     "dlwp_fno_trainer_fwd_bwd": (_I, [_V, _I, _V]),
     "dlwp_afno2d_save_elems": (_L, [_I, _I, _I, _I, _I, _F]),
     "dlwp_afno2d_fwd": (_I, [_V] * 7 + [_I] * 5 + [_F, _F, _V]),
+    "dlwp_afno2d_fwd_res": (_I, [_V] * 8 + [_I] * 5 + [_F, _F, _V]),
     "dlwp_afno2d_bwd": (_I, [_V] * 11 + [_I] * 5 + [_F, _F, _V]),
     "dlwp_afno_wq_expand": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_afno_wq_fold": (_I, [_V, _V, _I, _I, _I, _V]),
@@ -67,6 +68,10 @@ SIGNATURES = {
     "dlwp_get_gemm_precision": (_I, []),
     "dlwp_window_gather": (_I, [_V, _V, _I, _I] + [_V] * 7 + [_V]),
     "dlwp_window_scatter": (_I, [_V, _V, _I, _I] + [_V] * 7 + [_I, _V]),
+    "dlwp_window_scatter_add": (_I, [_V, _V, _V, _I, _I] + [_V] * 7 + [_I, _V]),
+    "dlwp_patch_merge": (_I, [_V, _V, _I, _I, _I, _I, _I, _V]),
+    "dlwp_window_advance_fwd": (_I, [_V, _L, _V, _V, _V, _I, _I, _L] + [_I] * 6 + [_V]),
+    "dlwp_window_advance_bwd": (_I, [_V, _V, _L, _V, _L, _V, _V, _I, _I, _L] + [_I] * 6 + [_V]),
     "dlwp_gemm": (_I, [_V, _V, _V] + [_I] * 8 + [_V, _I, _V, _V, _I, _V, _V]),
     "dlwp_gemm_batched": (_I, [_V, _V, _V] + [_I] * 10 + [_L] * 6 + [_V, _L, _L, _I, _F, _V, _V, _L, _L, _I, _I, _V]),
     "dlwp_act_bwd": (_I, [_V, _V, _V, _L, _I, _F, _V]),
@@ -77,11 +82,13 @@ SIGNATURES = {
     "dlwp_cweight_fold": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_layernorm_fwd": (_I, [_V] * 6 + [_I, _I, _F, _V]),
     "dlwp_layernorm_bwd": (_I, [_V] * 8 + [_I, _I, _V]),
+    "dlwp_layernorm_bwd_res": (_I, [_V] * 9 + [_I, _I, _V]),
     "dlwp_instnorm_fwd": (_I, [_V] * 6 + [_I, _I, _I, _F, _V]),
     "dlwp_instnorm_bwd": (_I, [_V] * 8 + [_I, _I, _I, _V]),
     "dlwp_gelu_bwd": (_I, [_V, _V, _V, _L, _V]),
     "dlwp_colsum": (_I, [_V, _V, _I, _I, _V]),
     "dlwp_scale_rows_add": (_I, [_V, _V, _V, _V, _I, _L, _V]),
+    "dlwp_add_bcast": (_I, [_V, _V, _V, _I, _L, _V]),
     "dlwp_cmode_product": (_I, [_V, _V, _V, _I, _I, _I, _I, _V]),
     "dlwp_cmode_product_bwd": (_I, [_V] * 5 + [_I] * 4 + [_V]),
     "dlwp_window_attn_fwd": (_I, [_V] * 7 + [_I] * 7 + [_F, _V]),

@@ -18,7 +18,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import lib as L
-from ..token_ops import LayerNorm, Linear, Mlp, PatchConv2d, _grad_slot
+from ..rollout_ops import ns_rollout
+from ..token_ops import LayerNorm, Linear, Mlp, PatchConv2d, _grad_slot, add_pos_embed, add_tokens, norm_fork
 
 
 FFT_MIN_TOKENS = 262144     # token grids from this size on take the rFFT2 path in "auto" mode (see AFNO2D.forward)
@@ -26,19 +27,22 @@ FFT_MIN_TOKENS = 262144     # token grids from this size on take the rFFT2 path 
 
 class _AFNO2DFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, nb, lam, frac):
+    def forward(ctx, x, w1, b1, w2, b2, nb, lam, frac, residual=None):
         lib = L.load()
         B, H, W, C = x.shape
         x = x.contiguous().float()
+        res = residual.reshape(x.shape).contiguous().float() if residual is not None else None
         n = lib.dlwp_afno2d_save_elems(B, H, W, C, nb, frac)
         if n < 0:
             L.check(-3)
         xsave = torch.empty(n, device=x.device)
         y = torch.empty_like(x)
-        L.check(lib.dlwp_afno2d_fwd(L.ptr(x), L.ptr(w1.contiguous()), L.ptr(b1.contiguous()), L.ptr(w2.contiguous()),
-                                    L.ptr(b2.contiguous()), L.ptr(y), L.ptr(xsave), B, H, W, C, nb, lam, frac, L.stream()))
+        L.check(lib.dlwp_afno2d_fwd_res(L.ptr(x), L.ptr(res), L.ptr(w1.contiguous()), L.ptr(b1.contiguous()),
+                                        L.ptr(w2.contiguous()), L.ptr(b2.contiguous()), L.ptr(y), L.ptr(xsave), B, H, W, C, nb,
+                                        lam, frac, L.stream()))
         ctx.save_for_backward(xsave, w1, b1, w2, b2)
         ctx.cfg = (B, H, W, C, nb, lam, frac)
+        ctx.has_res = residual is not None
         ctx.slots = [_grad_slot(t) for t in (w1, b1, w2, b2)]
         return y
 
@@ -55,9 +59,10 @@ class _AFNO2DFn(torch.autograd.Function):
         L.check(lib.dlwp_afno2d_bwd(L.ptr(gy), L.ptr(xsave), L.ptr(w1.contiguous()), L.ptr(b1.contiguous()),
                                     L.ptr(w2.contiguous()), L.ptr(b2.contiguous()), L.ptr(gx), L.ptr(gw1), L.ptr(gb1),
                                     L.ptr(gw2), L.ptr(gb2), B, H, W, C, nb, lam, frac, L.stream()))
+        gres = gy if ctx.has_res else None         # the skip's gradient is the upstream gradient itself
         if fused:
-            return gx, None, None, None, None, None, None, None
-        return gx, gw1, gb1, gw2, gb2, None, None, None
+            return gx, None, None, None, None, None, None, None, gres
+        return gx, gw1, gb1, gw2, gb2, None, None, None, gres
 
 
 class AFNO2D(nn.Module):
@@ -81,7 +86,8 @@ class AFNO2D(nn.Module):
         self.w2 = nn.Parameter(self.scale * torch.randn(2, num_blocks, bs, bs))
         self.b2 = nn.Parameter(self.scale * torch.randn(2, num_blocks, bs))
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """AFNO2D(x) (+ residual: the block's outer skip, added by the fused kernel's epilogue)."""
         dtype = x.dtype
         B, H, W, C = x.shape
         path = self.path
@@ -102,8 +108,10 @@ class AFNO2D(nn.Module):
             y = afno2d_tiled(x, self.w1, self.b1, self.w2, self.b2, self.num_blocks, float(self.sparsity_threshold),
                              float(self.hard_thresholding_fraction))
         else:
-            y = _AFNO2DFn.apply(x, self.w1, self.b1, self.w2, self.b2, self.num_blocks, float(self.sparsity_threshold),
-                                float(self.hard_thresholding_fraction))
+            return _AFNO2DFn.apply(x, self.w1, self.b1, self.w2, self.b2, self.num_blocks, float(self.sparsity_threshold),
+                                   float(self.hard_thresholding_fraction), residual).type(dtype)
+        if residual is not None:
+            y = add_tokens(y, residual)
         return y.type(dtype)
 
 
@@ -120,12 +128,15 @@ class Block(nn.Module):
         self.double_skip = double_skip
 
     def forward(self, x):
-        residual = x
-        x = self.filter(self.norm1(x))
+        # reference :156-165.  Both skips are fused: the first into the filter kernel's epilogue, the second into fc2's; the
+        # gradients of the skip branches join the LayerNorm backward kernels (LayerNorm.fork)
         if self.double_skip:
-            x = x + residual
-            residual = x
-        return self.mlp(self.norm2(x), residual=residual)   # residual add fused into fc2's epilogue
+            residual, t = norm_fork(self.norm1, x)
+            residual, t = norm_fork(self.norm2, self.filter(t, residual=residual))
+        else:
+            residual, t = norm_fork(self.norm1, x)
+            t = self.norm2(self.filter(t))
+        return self.mlp(t, residual=residual)
 
 
 class PatchEmbed(nn.Module):
@@ -180,35 +191,17 @@ class AFNONet(nn.Module):
 
     def forward_features(self, x):
         B = x.shape[0]
-        x = self.pos_drop(self.patch_embed(x) + self.pos_embed)
+        x = self.pos_drop(add_pos_embed(self.patch_embed(x), self.pos_embed))
         x = x.reshape(B, self.h, self.w, self.embed_dim)
         for blk in self.blocks:
             x = blk(x)
         return x
 
     def forward(self, x, teacher_forcing_steps: int = 50):
-        outs, out = [], None
-        ph, pw = self.patch_size
-        for t in range(x.shape[1]):
-            if t < teacher_forcing_steps:
-                x_t_in = x[:, max(0, t - (self.context_size - 1)):t + 1]
-            else:
-                if self.context_size == 0:
-                    x_t_in = out
-                else:
-                    ts = max(0, (teacher_forcing_steps - t - 1) + self.context_size)
-                    x_obs = x[:, teacher_forcing_steps - ts:teacher_forcing_steps]
-                    x_out = torch.stack(outs[-(self.context_size - ts):], dim=1)
-                    x_t_in = torch.cat([x_obs, x_out], dim=1)
-            if t < self.context_size - 1:
-                out = x_t_in[:, -1]
-            else:
-                B = x_t_in.shape[0]
-                x_t = self.head(self.forward_features(x_t_in.flatten(1, 2)))
-                x_t = x_t.reshape(B, self.h, self.w, ph, pw, self.out_chans).permute(0, 5, 1, 3, 2, 4)
-                out = x_t_in[:, -1] + x_t.reshape(B, self.out_chans, self.h * ph, self.w * pw)
-            outs.append(out)
-        return torch.stack(outs, dim=1)
+        # reference :262-300.  The head's patch tokens [B, h*w, ph*pw*out] are un-patched, added to the newest frame and
+        # appended to the sliding window by one kernel (rollout_ops.advance)
+        return ns_rollout(lambda x_t: self.head(self.forward_features(x_t)), x, teacher_forcing_steps, self.context_size,
+                          patch=self.patch_size)
 
 
 FourCastNet = AFNONet

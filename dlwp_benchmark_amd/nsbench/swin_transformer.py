@@ -21,8 +21,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import lib as L
-from ..token_ops import _gemm_batched, _grad_slot, DropPath, LayerNorm, Linear, Mlp, PatchConv2d, UpConvT2d
-from ..window_ops import WindowSpec, partition, reverse
+from ..rollout_ops import ns_rollout
+from ..token_ops import _gemm_batched, _grad_slot, DropPath, DropPathPool, LayerNorm, Linear, Mlp, PatchConv2d, UpConvT2d, norm_fork
+from ..window_ops import WindowSpec, partition, patch_merge, reverse
 
 
 class _WindowAttnFn(torch.autograd.Function):
@@ -179,13 +180,16 @@ class SwinTransformerBlock(nn.Module):
         shifted = sh[0] > 0 or sh[1] > 0
         if C % 4 == 0:
             # pad + roll + partition and reverse + roll back + crop are one gather kernel each (window_ops.py)
+            # the skip connections leave the LayerNorm nodes (norm_fork) so that their gradients join the LayerNorm backward
+            # kernels; the first residual add rides the reverse kernel, the second fc2's epilogue
             spec = self._spec(H, W)
-            t = reverse(self.attn(partition(self.norm1(x), spec), labels if shifted else None, spec.nW), spec, B)
+            skip, t = norm_fork(self.norm1, x)
+            t = self.attn(partition(t, spec), labels if shifted else None, spec.nW)
             if self.drop_path.active:        # training with stochastic depth (:255-256): per-sample scale + residual add
-                x = self.drop_path(t, residual=x)
-                return self.drop_path(self.mlp(self.norm2(x)), residual=x)
-            x = x + t
-            return self.mlp(self.norm2(x), residual=x)
+                skip, t = norm_fork(self.norm2, self.drop_path(reverse(t, spec, B), residual=skip))
+                return self.drop_path(self.mlp(t), residual=skip)
+            skip, t = norm_fork(self.norm2, reverse(t, spec, B, residual=skip))
+            return self.mlp(t, residual=skip)
         t = self.norm1(x).view(B, H, W, C)
         t = _pad_hw(t, (ws[0] - H % ws[0]) % ws[0], (ws[1] - W % ws[1]) % ws[1], self.padding_mode)
         Hp, Wp = t.shape[1], t.shape[2]
@@ -224,8 +228,12 @@ class PatchMerging(nn.Module):
         B, L_, C = x.shape
         assert L_ == H * W, "input feature has wrong size"
         x = x.view(B, H, W, C)
-        x = _pad_hw(x, H % 2, W % 2, self.padding_mode)
-        x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)
+        zero_pad = (not H % 2 or self.padding_mode[0] == "constant") and (not W % 2 or self.padding_mode[1] == "constant")
+        if zero_pad:      # pad + four strided slices + cat as one gather kernel
+            x = patch_merge(x)
+        else:
+            x = _pad_hw(x, H % 2, W % 2, self.padding_mode)
+            x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)
         return self.reduction(self.norm(x.reshape(B, -1, 4 * C)))
 
 
@@ -338,6 +346,9 @@ class SwinTransformer(nn.Module):
         self.final = PatchConv2d(embed_dim, out_chans, kernel_size=1)
 
     def one_step(self, x):
+        if getattr(self, "_drop_pool", None) is None:      # built lazily: after construction, copies and loads
+            object.__setattr__(self, "_drop_pool", DropPathPool(self))
+        self._drop_pool.draw(x.shape[0], x.device)        # every block's stochastic-depth mask for this call, one draw
         x = self.patch_embed(x)
         Wh, Ww = x.shape[2], x.shape[3]
         x = x.flatten(2).transpose(1, 2)
@@ -353,16 +364,5 @@ class SwinTransformer(nn.Module):
         return self.final(y)
 
     def forward(self, x: torch.Tensor, teacher_forcing_steps: int = 50) -> torch.Tensor:
-        outs, out, ctx = [], None, self.context_size
-        for t in range(x.shape[1]):
-            if t < teacher_forcing_steps:
-                x_t = x[:, max(0, t - (ctx - 1)):t + 1]
-            elif ctx == 0:
-                x_t = out
-            else:
-                ts = max(0, (teacher_forcing_steps - t - 1) + ctx)
-                x_t = torch.cat([x[:, teacher_forcing_steps - ts:teacher_forcing_steps],
-                                 torch.stack(outs[-(ctx - ts):], dim=1)], dim=1)
-            out = x_t[:, -1] if t < ctx - 1 else x_t[:, -1] + self.one_step(x_t.flatten(1, 2))
-            outs.append(out)
-        return torch.stack(outs, dim=1)
+        # reference :597-640; the sliding window is advanced by one kernel per lead time (rollout_ops.advance)
+        return ns_rollout(self.one_step, x, teacher_forcing_steps, self.context_size)

@@ -228,8 +228,12 @@ class Conv1x1(nn.Conv2d):
 
 
 class _LayerNormFn(torch.autograd.Function):
+    """LayerNorm over the last dimension.  With fork=True the node returns (x, LN(x)): the pre-norm residual blocks
+    (`x + f(norm(x))`) take their skip connection from the first output, so that the gradient of the residual branch and the
+    LayerNorm backward meet inside dlwp_layernorm_bwd_res -- one kernel, no elementwise add on the autograd thread."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, fork=False):
         lib = L.load()
         shape = x.shape
         x2 = x.reshape(-1, shape[-1]).contiguous().float()
@@ -240,24 +244,30 @@ class _LayerNormFn(torch.autograd.Function):
         L.check(lib.dlwp_layernorm_fwd(L.ptr(x2), L.ptr(gamma.contiguous()), L.ptr(beta.contiguous()), L.ptr(y),
                                        L.ptr(mean), L.ptr(rstd), T, C_, eps, L.stream()))
         ctx.save_for_backward(x2, gamma, mean, rstd)
-        ctx.shape = shape
+        ctx.shape, ctx.fork = shape, fork
         ctx.slots = (_grad_slot(gamma), _grad_slot(beta))
+        if fork:
+            return x.view_as(x), y.reshape(shape)
         return y.reshape(shape)
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, *grads):
         lib = L.load()
+        gres, gy = grads if ctx.fork else (None, grads[0])
+        if gy is None:                      # only the skip output was used
+            return gres, None, None, None, None
         x2, gamma, mean, rstd = ctx.saved_tensors
         T, C_ = x2.shape
         g2 = gy.reshape(-1, C_).contiguous().float()
+        r2 = gres.reshape(-1, C_).contiguous().float() if gres is not None else None
         gx = torch.empty_like(x2)
         fused = ctx.slots[0] is not None and ctx.slots[1] is not None
         gg, gb = ctx.slots if fused else (torch.zeros_like(gamma), torch.zeros_like(gamma))
-        L.check(lib.dlwp_layernorm_bwd(L.ptr(x2), L.ptr(gamma.contiguous()), L.ptr(mean), L.ptr(rstd), L.ptr(g2),
-                                       L.ptr(gx), L.ptr(gg), L.ptr(gb), T, C_, L.stream()))
+        L.check(lib.dlwp_layernorm_bwd_res(L.ptr(x2), L.ptr(gamma.contiguous()), L.ptr(mean), L.ptr(rstd), L.ptr(g2),
+                                           L.ptr(r2), L.ptr(gx), L.ptr(gg), L.ptr(gb), T, C_, L.stream()))
         if fused:
-            return gx.reshape(ctx.shape), None, None, None
-        return gx.reshape(ctx.shape), gg, gb, None
+            return gx.reshape(ctx.shape), None, None, None, None
+        return gx.reshape(ctx.shape), gg, gb, None, None
 
 
 class _ScaleRowsAddFn(torch.autograd.Function):
@@ -285,9 +295,59 @@ class _ScaleRowsAddFn(torch.autograd.Function):
         return gt, None, (g if ctx.has_res else None)
 
 
+class _AddFn(torch.autograd.Function):
+    """a + b (same shape) as one dlwp_scale_rows_add launch without scales; both gradients are the upstream gradient itself."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a2, b2 = a.contiguous().float(), b.contiguous().float()
+        out = torch.empty_like(a2)
+        L.check(L.load().dlwp_scale_rows_add(L.ptr(a2), None, L.ptr(b2), L.ptr(out), 1, a2.numel(), L.stream()))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
 def add_tokens(a, b):
-    """a + b on [B, ...] token tensors through libdlwpmi (dlwp_scale_rows_add with unit scales)."""
-    return _ScaleRowsAddFn.apply(a, torch.ones(a.shape[0], device=a.device), b)
+    """a + b on equally shaped token tensors through libdlwpmi."""
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return _AddFn.apply(a, b)
+
+
+class _AddBcastFn(torch.autograd.Function):
+    """tokens [B, ...] + a parameter [1, ...] broadcast over the batch (position embedding).  The parameter's gradient is the
+    batch sum of the upstream gradient, accumulated straight into its .grad when that buffer exists."""
+
+    @staticmethod
+    def forward(ctx, t, p):
+        t2 = t.contiguous().float()
+        B = t2.shape[0]
+        assert p.numel() * B == t2.numel(), (tuple(t.shape), tuple(p.shape))
+        out = torch.empty_like(t2)
+        L.check(L.load().dlwp_add_bcast(L.ptr(t2), L.ptr(p.contiguous()), L.ptr(out), B, p.numel(), L.stream()))
+        ctx.slot, ctx.pshape = _grad_slot(p), p.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g2 = g.contiguous().float()
+        B = g2.shape[0]
+        n = g2.numel() // B
+        gp = ctx.slot if ctx.slot is not None else torch.zeros(ctx.pshape, device=g.device)
+        L.check(L.load().dlwp_colsum(L.ptr(g2), L.ptr(gp), B, n, L.stream()))
+        return g, (None if ctx.slot is not None else gp)
+
+
+def add_pos_embed(tokens, pos):
+    """tokens [B, P, E] + pos [1, P, E]."""
+    return _AddBcastFn.apply(tokens, pos)
+
+
+def norm_fork(norm, x):
+    """(skip, norm(x)) of a pre-norm residual block; LayerNorm.fork where the norm layer offers it."""
+    return norm.fork(x) if hasattr(norm, "fork") else (x, norm(x))
 
 
 class DropPath(nn.Module):
@@ -301,6 +361,7 @@ class DropPath(nn.Module):
         super().__init__()
         self.p = self.drop_prob = float(drop_prob)
         self.scale_by_keep = scale_by_keep
+        self._pool, self._pool_index = None, 0
 
     @property
     def active(self):
@@ -309,14 +370,50 @@ class DropPath(nn.Module):
     def forward(self, t, residual=None):
         if not self.active:
             return t if residual is None else residual + t
-        keep = 1.0 - self.p
-        mask = torch.empty(t.shape[0], device=t.device, dtype=torch.float32).bernoulli_(keep)
-        if keep > 0.0 and self.scale_by_keep:
-            mask = mask / keep
+        mask = self._pool.take(self._pool_index, t.shape[0]) if self._pool is not None else None
+        if mask is None:
+            keep = 1.0 - self.p
+            mask = torch.empty(t.shape[0], device=t.device, dtype=torch.float32).bernoulli_(keep)
+            if keep > 0.0 and self.scale_by_keep:
+                mask = mask / keep
         return _ScaleRowsAddFn.apply(t, mask, residual)
 
     def extra_repr(self):
         return f"drop_prob={self.p:0.3f}"
+
+
+class DropPathPool:
+    """The keep masks of ALL DropPath modules of a model for one network call, drawn together: one Bernoulli kernel and one
+    scaling kernel per call instead of two per block (the masks are independent per block and per sample either way; each
+    block keeps its own drop probability).  The model calls draw() at the top of its one-step forward in training mode; a mask
+    is handed out once per draw, so a DropPath called outside that protocol falls back to drawing its own."""
+
+    USES = 2      # a block applies its DropPath twice per call (attention branch, MLP branch): independent masks for both
+
+    def __init__(self, model):
+        self.mods = [m for m in model.modules() if isinstance(m, DropPath) and m.p > 0.0]
+        for i, m in enumerate(self.mods):
+            m._pool, m._pool_index = self, i
+        self._probs = self._inv = self._masks = None
+        self._taken = []
+
+    def draw(self, batch, device):
+        if not self.mods or not self.mods[0].training:
+            return
+        if self._probs is None or self._probs.shape[1] != batch or self._probs.device != torch.device(device):
+            keep = torch.tensor([1.0 - m.p for m in self.mods for _ in range(self.USES)], dtype=torch.float32)
+            inv = torch.tensor([1.0 / (1.0 - m.p) if (m.p < 1.0 and m.scale_by_keep) else 1.0
+                                for m in self.mods for _ in range(self.USES)])
+            self._probs = keep[:, None].expand(keep.numel(), batch).contiguous().to(device)
+            self._inv = inv[:, None].to(device)
+        self._masks = torch.bernoulli(self._probs) * self._inv
+        self._taken = [0] * len(self.mods)
+
+    def take(self, i, batch):
+        if self._masks is None or self._taken[i] >= self.USES or self._masks.shape[1] != batch:
+            return None
+        self._taken[i] += 1
+        return self._masks[self.USES * i + self._taken[i] - 1]
 
 
 class _InstanceNormFn(torch.autograd.Function):
@@ -378,6 +475,10 @@ class LayerNorm(nn.LayerNorm):
     def forward(self, x):
         return _LayerNormFn.apply(x, self.weight, self.bias, float(self.eps))
 
+    def fork(self, x):
+        """(x, norm(x)) for a pre-norm residual block: use the first item as the skip connection (see _LayerNormFn)."""
+        return _LayerNormFn.apply(x, self.weight, self.bias, float(self.eps), True)
+
 
 class Mlp(nn.Module):
     """fc1 -> GELU -> fc2 (+ residual): two MFMA GEMMs, GELU and the residual add fused in the epilogues."""
@@ -407,7 +508,8 @@ class PatchConv2d(nn.Conv2d):
         B, C_, H, W = x.shape
         h, w = H // ph, W // pw
         cols = x.reshape(B, C_, h, ph, w, pw).permute(0, 2, 4, 1, 3, 5).reshape(B * h * w, C_ * ph * pw)
-        y = _LinearFn.apply(cols, self.weight.reshape(self.out_channels, -1), self.bias, act, None, False)
+        # the Parameter itself ([O, C, ph, pw]: the same memory as the [O, C*ph*pw] matrix) so that its gradient lands in .grad
+        y = _LinearFn.apply(cols, self.weight, self.bias, act, None, False)
         return y.reshape(B, h, w, self.out_channels).permute(0, 3, 1, 2)
 
 

@@ -45,11 +45,12 @@ def _gather(x, spec, shift, circ_override=None):
     return out
 
 
-def _scatter(wins, spec, shift, B, sum_copies):
+def _scatter(wins, spec, shift, B, sum_copies, residual=None):
     Cc = wins.shape[-1]
     out = torch.empty(B, spec.dims[0] * spec.dims[1] * spec.dims[2], Cc, device=wins.device)
     d, p, f, s, w, sw, circ = spec.c_args(shift)
-    L.check(L.load().dlwp_window_scatter(L.ptr(wins), L.ptr(out), B, Cc, d, p, f, s, w, sw, circ, int(sum_copies), L.stream()))
+    L.check(L.load().dlwp_window_scatter_add(L.ptr(wins), L.ptr(residual), L.ptr(out), B, Cc, d, p, f, s, w, sw, circ,
+                                             int(sum_copies), L.stream()))
     return out
 
 
@@ -67,17 +68,20 @@ class _PartitionFn(torch.autograd.Function):
 
 
 class _ReverseFn(torch.autograd.Function):
-    """windows [B * nW, N, C] -> tokens [B, L, C]: un-roll by `shift`, drop the padding."""
+    """windows [B * nW, N, C] -> tokens [B, L, C]: un-roll by `shift`, drop the padding (+ residual [B, L, C]: the block's skip
+    connection, added by the same kernel; its gradient is the upstream gradient itself)."""
 
     @staticmethod
-    def forward(ctx, wins, spec, shift, B):
-        ctx.spec, ctx.shift = spec, shift
-        return _scatter(wins.contiguous().float(), spec, shift, B, sum_copies=False)
+    def forward(ctx, wins, spec, shift, B, residual=None):
+        ctx.spec, ctx.shift, ctx.has_res = spec, shift, residual is not None
+        res = residual.reshape(B, -1, wins.shape[-1]).contiguous().float() if residual is not None else None
+        return _scatter(wins.contiguous().float(), spec, shift, B, sum_copies=False, residual=res)
 
     @staticmethod
     def backward(ctx, g):
         # padded positions were dropped: they receive zero gradient whatever the padding mode of the forward partition
-        return _gather(g.contiguous(), ctx.spec, ctx.shift, circ_override=(0, 0, 0)), None, None, None
+        return (_gather(g.contiguous(), ctx.spec, ctx.shift, circ_override=(0, 0, 0)), None, None, None,
+                g if ctx.has_res else None)
 
 
 def _identity(spec, shift):
@@ -92,8 +96,38 @@ def partition(x, spec, shift=None):
     return _PartitionFn.apply(x, spec, shift)
 
 
-def reverse(wins, spec, B, shift=None):
+def reverse(wins, spec, B, shift=None, residual=None):
     shift = tuple(spec.shift if shift is None else shift)
     if _identity(spec, shift):
-        return wins.reshape(B, spec.N, wins.shape[-1])
-    return _ReverseFn.apply(wins, spec, shift, B)
+        y = wins.reshape(B, spec.N, wins.shape[-1])
+        if residual is None:
+            return y
+        from .token_ops import add_tokens
+        return add_tokens(y, residual.reshape(y.shape))
+    return _ReverseFn.apply(wins, spec, shift, B, residual)
+
+
+class _PatchMergeFn(torch.autograd.Function):
+    """tokens [B, H, W, C] -> [B, ceil(H/2), ceil(W/2), 4C] (dlwp_patch_merge: zero pad + the reference's four strided slices
+    + cat, swin_transformer.py:291-312, as one gather kernel; the backward pass is its adjoint gather)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, H, W, Cc = x.shape
+        x = x.contiguous().float()
+        out = torch.empty(B, (H + 1) // 2, (W + 1) // 2, 4 * Cc, device=x.device)
+        L.check(L.load().dlwp_patch_merge(L.ptr(x), L.ptr(out), B, H, W, Cc, 0, L.stream()))
+        ctx.shape = (B, H, W, Cc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H, W, Cc = ctx.shape
+        g = g.contiguous().float()
+        gx = torch.empty(B, H, W, Cc, device=g.device)
+        L.check(L.load().dlwp_patch_merge(L.ptr(g), L.ptr(gx), B, H, W, Cc, 1, L.stream()))
+        return gx
+
+
+def patch_merge(x):
+    return _PatchMergeFn.apply(x)

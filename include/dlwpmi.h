@@ -220,6 +220,13 @@ long long dlwp_afno2d_save_elems(int B, int H, int W, int C, int nb, float hard_
 int dlwp_afno2d_fwd(const float* x, const float* w1, const float* b1, const float* w2,
                     const float* b2, float* y, float* xsave, int B, int H, int W, int C, int nb,
                     float sparsity_threshold, float hard_thresholding_fraction, void* stream);
+/* The same with the block's outer skip folded in (Block.forward, fourcastnet.py:156-160:   */
+/* `x = filter(norm1(x)); x = x + residual`): y = AFNO2D(x) + residual, residual [B,H,W,C]   */
+/* nullable.  Its gradient is the upstream gradient itself; dlwp_afno2d_bwd is unchanged.    */
+int dlwp_afno2d_fwd_res(const float* x, const float* residual, const float* w1, const float* b1,
+                        const float* w2, const float* b2, float* y, float* xsave, int B, int H,
+                        int W, int C, int nb, float sparsity_threshold,
+                        float hard_thresholding_fraction, void* stream);
 /* gx = d loss/d x (includes the residual path); gw1,gb1,gw2,gb2 are ACCUMULATED into.     */
 int dlwp_afno2d_bwd(const float* gy, const float* xsave, const float* w1, const float* b1,
                     const float* w2, const float* b2, float* gx, float* gw1, float* gb1,
@@ -309,6 +316,36 @@ int dlwp_window_scatter(const float* windows, float* x, int B, int C, const int*
                         const int* padded, const int* front, const int* shift, const int* window,
                         const long long* wstride, const int* circular, int sum_copies,
                         void* stream);
+/* dlwp_window_scatter with the block's skip connection folded in: x = residual + reverse(windows)  */
+/* (`x = shortcut + drop_path(x)` after window_reverse / roll / crop, swin_transformer.py:250-255 and */
+/* panguweather.py:317-319); residual [B][D0*D1*D2][C] nullable.                                      */
+int dlwp_window_scatter_add(const float* windows, const float* residual, float* x, int B, int C,
+                            const int* dims, const int* padded, const int* front, const int* shift,
+                            const int* window, const long long* wstride, const int* circular,
+                            int sum_copies, void* stream);
+/* Patch merging gather (PatchMerging.forward, src/nsbench/models/swintransformer/swin_transformer.py:291-312 */
+/* and the dlwpbench twin): tokens x [B][H][W][C] -> [B][ceil(H/2)][ceil(W/2)][4C] with channel blocks in the    */
+/* reference's concat order (0,0), (1,0), (0,1), (1,1) and zeros beyond an odd H / W (its constant pad).        */
+/* backward != 0 runs the adjoint: src is the gradient [B][H2][W2][4C], dst the gradient [B][H][W][C].          */
+int dlwp_patch_merge(const float* src, float* dst, int B, int H, int W, int C, int backward, void* stream);
+/* One lead time of an autoregressive rollout on its sliding input window (csrc/rollout_ops.hip; the reference  */
+/* rebuilds the window with stack + cat + add on every step: src/nsbench/models/fourcastnet/fourcastnet.py:     */
+/* 262-300, swintransformer/swin_transformer.py:597-640, src/dlwpbench/models/unet/unet.py:64-111):              */
+/*   next[b][j] = win[b][j+1] (j < ctx-1);  next[b][ctx-1] = out[b] = win[b][ctx-1] + delta[b].                  */
+/* win: [B][ctx][frame] with a batch stride in floats (a slice of the data tensor qualifies); next (nullable:    */
+/* last step) [B][ctx][frame]; out [B][frame].  delta_layout 0: delta is [B][frame]; 1: delta holds the patch    */
+/* tokens of a linear head, [B][H/ph][W/pw][ph][pw][D] with frame = D*H*W (AFNONet.head output, :296-298).        */
+int dlwp_window_advance_fwd(const float* win, long long win_batch_stride, const float* delta, float* next,
+                            float* out, int B, int ctx, long long frame, int delta_layout, int D, int H,
+                            int W, int ph, int pw, void* stream);
+/* Its adjoint, which also sums the gradients that reach the window from its (up to) three readers: g_next from  */
+/* the following advance [B][ctx][frame], g_net from the network that read the window (batch stride given: a     */
+/* channel slice of a wider input gradient qualifies), g_out from the loss ([B][frame], batch stride given).      */
+/* Any of the three may be NULL.  g_win (nullable: the window was data) [B][ctx][frame]; g_delta in delta's layout. */
+int dlwp_window_advance_bwd(const float* g_next, const float* g_net, long long net_batch_stride,
+                            const float* g_out, long long out_batch_stride, float* g_win, float* g_delta,
+                            int B, int ctx, long long frame, int delta_layout, int D, int H, int W, int ph,
+                            int pw, void* stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* Token-level building blocks of the AFNO / Swin / Pangu blocks (nn.Linear, nn.LayerNorm, */
@@ -375,10 +412,17 @@ int dlwp_cweight_fold(const float* gexp, float* gw, int Cin, int Cout, int L, vo
 /* LayerNorm over the last dimension of x [T,C]; mean/rstd [T] are saved for backward.       */
 int dlwp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                        float* mean, float* rstd, int T, int C, float eps, void* stream);
-/* gx written; ggamma/gbeta ACCUMULATED into.  C <= 512.                                     */
+/* gx written; ggamma/gbeta ACCUMULATED into.  C <= 2048.                                    */
 int dlwp_layernorm_bwd(const float* x, const float* gamma, const float* mean, const float* rstd,
                        const float* gy, float* gx, float* ggamma, float* gbeta, int T, int C,
                        void* stream);
+/* The same with gx = (LayerNorm backward) + gadd [T,C] (nullable): in the pre-norm residual   */
+/* blocks (`x + f(norm(x))`: nsbench fourcastnet.py:156-165, swin_transformer.py:229-256;       */
+/* dlwpbench panguweather.py:143-159) the gradient of the block input is the sum of the residual */
+/* branch's and the norm's -- formed here instead of by a separate elementwise add.              */
+int dlwp_layernorm_bwd_res(const float* x, const float* gamma, const float* mean, const float* rstd,
+                           const float* gy, const float* gadd, float* gx, float* ggamma,
+                           float* gbeta, int T, int C, void* stream);
 /* Instance normalisation of channels-last tokens x [B][P][C]: per (sample, channel) mean / biased       */
 /* variance over the P = H*W tokens, y = (x - mean) rstd gamma + beta (+ residual, same layout, optional).  */
 /* Replaces nn.InstanceNorm2d(embed_dim, eps, affine=True) inside torch_harmonics' SFNO                      */
@@ -398,9 +442,13 @@ int dlwp_act_bwd(const float* z, const float* gy, float* gz, long long n, int ac
 /* 255-256; dlwpbench twin :192,261-262; panguweather.py:262-323): the per-sample keep mask, already    */
 /* divided by the keep probability, scales a residual branch: out[b][i] = x[b][i] + scale[b] t[b][i]    */
 /* (x may be NULL: plain scaling, which is also the backward of the branch: gt = scale[b] g).           */
-/* t, x, out: [B][n]; scale: [B] device floats.                                                          */
+/* t, x, out: [B][n]; scale: [B] device floats, or NULL for unit scales (a plain fused add).              */
 int dlwp_scale_rows_add(const float* t, const float* scale, const float* x, float* out, int B,
                         long long n, void* stream);
+/* out[b][i] = t[b][i] + p[i]: a learned position embedding [n] added to every sample's tokens   */
+/* (`x = patch_embed(x) + pos_embed`, src/nsbench/models/fourcastnet/fourcastnet.py:253; dlwpbench */
+/* twin).  Its parameter gradient is dlwp_colsum over the batch.                                   */
+int dlwp_add_bcast(const float* t, const float* p, float* out, int B, long long n, void* stream);
 /* out[n] += sum_t g[t][n]   (bias gradients)                                                */
 int dlwp_colsum(const float* g, float* out, int T, int N, void* stream);
 

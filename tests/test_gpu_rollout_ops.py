@@ -1,0 +1,215 @@
+"""The fused rollout window (rollout_ops.advance / ns_rollout / dlwpbench.rollout), patch merging, the LayerNorm fork and the
+pooled stochastic-depth masks against literal torch restatements of the reference loops (the loops themselves are quoted in
+the docstrings of the functions under test)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _legacy_ns(one_step, x, tf, ctx):
+    """nsbench AFNONet.forward / SwinTransformer.forward restated with torch ops (fourcastnet.py:262-300)."""
+    outs, out = [], None
+    for t in range(x.shape[1]):
+        if t < tf:
+            x_t = x[:, max(0, t - (ctx - 1)):t + 1]
+        else:
+            ts = max(0, (tf - t - 1) + ctx)
+            x_t = torch.cat([x[:, tf - ts:tf], torch.stack(outs[-(ctx - ts):], dim=1)], dim=1)
+        out = x_t[:, -1] if t < ctx - 1 else x_t[:, -1] + one_step(x_t.flatten(1, 2))
+        outs.append(out)
+    return torch.stack(outs, dim=1)
+
+
+def _legacy_dlwp(one_step, ctx, constants, prescribed, prognostic):
+    """UNet.forward (dlwpbench unet.py:64-111) restated with torch ops."""
+    outs = []
+    for t in range(ctx, prognostic.shape[1]):
+        if t == ctx:
+            prog_t = prognostic[:, max(0, t - ctx):t]
+        else:
+            prog_t = torch.cat([prognostic[:, max(0, t - ctx):ctx], torch.stack(outs, dim=1)[:, -ctx:]], dim=1)
+        parts = [] if constants is None else [constants[:, 0]]
+        if prescribed is not None:
+            parts.append(prescribed[:, t - ctx:t].flatten(1, 2))
+        parts.append(prog_t.flatten(1, 2))
+        outs.append(prog_t[:, -1] + one_step(torch.cat(parts, dim=1)))
+    return torch.stack(outs, dim=1)
+
+
+class _Net(torch.nn.Module):
+    """A small differentiable stand-in for the network: channel mixing + a smooth nonlinearity (torch ops only)."""
+
+    def __init__(self, cin, cout, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.w = torch.nn.Parameter(0.3 * torch.randn(cout, cin, generator=g))
+
+    def forward(self, x):
+        return torch.tanh(torch.einsum("oc,bchw->bohw", self.w, x))
+
+
+@pytest.mark.parametrize("T,tf,ctx,D", [(8, 3, 3, 1), (9, 4, 2, 2), (7, 1, 1, 1), (6, 10, 3, 1), (12, 5, 5, 1), (6, 2, 4, 1)])
+def test_ns_rollout_matches_reference_loop(T, tf, ctx, D):
+    from dlwp_benchmark_amd.rollout_ops import ns_rollout
+    dev = _dev()
+    g = torch.Generator().manual_seed(T * 100 + tf * 10 + ctx)
+    x = torch.randn(3, T, D, 8, 12, generator=g).to(dev)
+    wt = torch.randn(3, T, D, 8, 12, generator=g).to(dev)
+    res = []
+    for fn in (_legacy_ns, ns_rollout):
+        net = _Net(ctx * D, D, 5).to(dev)
+
+        def one_step(x_t):
+            if x_t.shape[1] < ctx * D:          # warm-up windows shorter than ctx never reach the network in the reference
+                raise AssertionError("short window reached the network")
+            return net(x_t)
+        out = fn(one_step, x, tf, ctx)
+        (out * wt).sum().backward()
+        res.append((out.detach(), net.w.grad.clone()))
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("ctx,T,cc,cp", [(1, 4, 2, 1), (2, 6, 0, 0), (3, 7, 3, 2), (2, 3, 1, 0)])
+def test_dlwp_rollout_matches_reference_loop(ctx, T, cc, cp):
+    from dlwp_benchmark_amd.dlwpbench.rollout import rollout
+    dev = _dev()
+    g = torch.Generator().manual_seed(ctx * 10 + T)
+    B, Cg, H, W = 2, 3, 6, 10
+    constants = torch.randn(B, 1, cc, H, W, generator=g).to(dev) if cc else None
+    prescribed = torch.randn(B, T, cp, H, W, generator=g).to(dev) if cp else None
+    prognostic = torch.randn(B, T, Cg, H, W, generator=g).to(dev)
+    wt = torch.randn(B, T - ctx, Cg, H, W, generator=g).to(dev)
+    res = []
+    for fn in (_legacy_dlwp, rollout):
+        net = _Net(cc + ctx * (cp + Cg), Cg, 9).to(dev)
+        out = fn(net, ctx, constants, prescribed, prognostic)
+        (out * wt).sum().backward()
+        res.append((out.detach(), net.w.grad.clone()))
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("D,H,W,ph,pw", [(1, 8, 12, 2, 4), (3, 6, 6, 3, 2), (2, 4, 8, 1, 1)])
+def test_advance_patch_layout(D, H, W, ph, pw):
+    """delta given as the patch tokens of a linear head equals un-patching with permute + reshape (fourcastnet.py:296-298)."""
+    from dlwp_benchmark_amd.rollout_ops import advance
+    dev = _dev()
+    g = torch.Generator().manual_seed(D * H + W)
+    B, ctx, h, w = 2, 3, H // ph, W // pw
+    data = torch.randn(B, 7, D, H, W, generator=g).to(dev)
+    tok0 = torch.randn(B, h * w, ph * pw * D, generator=g).to(dev)
+    wn, wo = torch.randn(B, ctx, D, H, W, generator=g).to(dev), torch.randn(B, D, H, W, generator=g).to(dev)
+    wf = torch.randn(B, ctx * D, H, W, generator=g).to(dev)
+    res = []
+    for fused in (False, True):
+        win = data[:, 2:2 + ctx].clone().requires_grad_()
+        tok = tok0.clone().requires_grad_()
+        if fused:
+            nxt, flat, out = advance(win, tok, True, patch=(ph, pw))
+        else:
+            delta = tok.reshape(B, h, w, ph, pw, D).permute(0, 5, 1, 3, 2, 4).reshape(B, D, H, W)
+            out = win[:, -1] + delta
+            nxt = torch.cat([win[:, 1:], out[:, None]], dim=1)
+            flat = nxt.flatten(1, 2)
+        ((nxt * wn).sum() + (out * wo).sum() + (flat * wf).sum()).backward()
+        res.append((nxt.detach(), out.detach(), win.grad.clone(), tok.grad.clone()))
+    for a, b in zip(*res):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_advance_strided_window_and_partial_grads():
+    """A data slice as the window (batch stride != ctx * frame), no gradient for the window, only some outputs used."""
+    from dlwp_benchmark_amd.rollout_ops import advance
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 9, 2, 4, 6, generator=g).to(dev)
+    delta = torch.randn(3, 2, 4, 6, generator=g).to(dev).requires_grad_()
+    nxt, flat, out = advance(x[:, 2:5], delta, True)
+    assert torch.equal(out, x[:, 4] + delta.detach())
+    assert torch.equal(nxt[:, :2], x[:, 3:5]) and torch.equal(nxt[:, 2], out)
+    assert flat.shape == (3, 6, 4, 6) and flat.data_ptr() == nxt.data_ptr()
+    wf = torch.randn_like(flat)
+    (flat[:, 1:] * wf[:, 1:]).sum().backward()                 # a channel slice of the network input's gradient
+    assert torch.allclose(delta.grad, wf.view(3, 3, 2, 4, 6)[:, 2], atol=1e-6)
+    n2, f2, o2 = advance(x[:, 0:3], delta, False)
+    assert n2 is None and f2 is None and torch.equal(o2, x[:, 2] + delta.detach())
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 6, 8), (1, 7, 5, 4), (3, 5, 8, 6), (1, 1, 1, 3)])
+def test_patch_merge(B, H, W, C):
+    from dlwp_benchmark_amd.window_ops import patch_merge
+    import torch.nn.functional as F
+    dev = _dev()
+    g = torch.Generator().manual_seed(H * 10 + W)
+    x0 = torch.randn(B, H, W, C, generator=g).to(dev)
+    wt = torch.randn(B, (H + 1) // 2, (W + 1) // 2, 4 * C, generator=g).to(dev)
+    res = []
+    for fused in (False, True):
+        x = x0.clone().requires_grad_()
+        if fused:
+            y = patch_merge(x)
+        else:
+            xp = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+            y = torch.cat([xp[:, 0::2, 0::2], xp[:, 1::2, 0::2], xp[:, 0::2, 1::2], xp[:, 1::2, 1::2]], -1)
+        (y * wt).sum().backward()
+        res.append((y.detach(), x.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("T,C", [(37, 40), (64, 192), (5, 6)])
+def test_layernorm_fork(T, C):
+    """(x, LN(x)) from one node: values equal LayerNorm's, and the skip gradient is summed inside the backward kernel."""
+    from dlwp_benchmark_amd.token_ops import LayerNorm
+    dev = _dev()
+    g = torch.Generator().manual_seed(T + C)
+    ln = LayerNorm(C).to(dev)
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(C, generator=g)); ln.bias.copy_(torch.randn(C, generator=g))
+    x0 = torch.randn(2, T, C, generator=g).to(dev)
+    w1, w2 = torch.randn(2, T, C, generator=g).to(dev), torch.randn(2, T, C, generator=g).to(dev)
+    x = x0.clone().requires_grad_()
+    skip, y = ln.fork(x)
+    ((skip * w1).sum() + (y * w2).sum()).backward()
+    xr = x0.double().cpu().requires_grad_()
+    yr = torch.nn.functional.layer_norm(xr, (C,), ln.weight.double().cpu(), ln.bias.double().cpu(), ln.eps)
+    ((xr * w1.double().cpu()).sum() + (yr * w2.double().cpu()).sum()).backward()
+    assert torch.equal(skip.detach(), x0)
+    assert torch.allclose(y.detach().double().cpu(), yr.detach(), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(x.grad.double().cpu(), xr.grad, rtol=1e-4, atol=1e-4)
+    x2 = x0.clone().requires_grad_()          # only the skip output used: the node passes the gradient through
+    s2, _ = ln.fork(x2)
+    (s2 * w1).sum().backward()
+    assert torch.equal(x2.grad, w1)
+
+
+def test_droppath_pool_masks():
+    """One draw serves every block with its own keep probability; survivors are scaled by 1/keep; draws are reproducible."""
+    from dlwp_benchmark_amd.token_ops import DropPath, DropPathPool
+    dev = _dev()
+    model = torch.nn.ModuleList([DropPath(p) for p in (0.0, 0.1, 0.5, 0.9)]).to(dev).train()
+    pool = DropPathPool(model)
+    assert len(pool.mods) == 3
+    B = 4096
+    t = torch.ones(B, 4, device=dev)
+    torch.manual_seed(11)
+    pool.draw(B, dev)
+    ys = [m(t) for m in model]
+    assert torch.equal(ys[0], t)
+    for m, y in zip(list(model)[1:], ys[1:]):
+        keep = 1.0 - m.p
+        vals = y[:, 0]
+        assert torch.all((vals == 0) | torch.isclose(vals, torch.tensor(1.0 / keep, device=dev)))
+        assert abs((vals != 0).float().mean().item() - keep) < 0.04
+    assert not torch.equal(ys[1] != 0, ys[2] != 0)
+    torch.manual_seed(11)
+    pool.draw(B, dev)
+    again = [m(t) for m in model]
+    assert all(torch.equal(a, b) for a, b in zip(ys, again))
+    y3 = model[2](t)                         # the mask of this draw was handed out already: the module draws its own
+    assert not torch.equal(y3, again[2])
