@@ -47,7 +47,11 @@ struct GemmDev {
     int act_b;                 // GELU applied to the B operand when its tile is committed to LDS (weight gradient of a layer
                                // whose input was activated on load: gW = g . gelu(x)^T without a stored gelu(x))
     int atomic_out;            // every workgroup ADDS its tile with float atomics (batches that share one output matrix)
+    // storage types (dlwp_gemm_mixed): bit 0 A, bit 1 B, bit 2 C and preact, bit 3 residual hold bf16 in memory (the pointers
+    // above are then __bf16*, leading dimensions and batch strides stay in elements).  Accumulation and epilogue run in fp32.
+    int dt;
 };
+constexpr int DT_A = 1, DT_B = 2, DT_C = 4, DT_R = 8;
 
 // bf16-operand mode (dlwp_set_gemm_precision(1)): operands are rounded to bf16 when a tile is committed to LDS and
 // multiplied by v_mfma_f32_16x16x32_bf16 (16x the fp32 MFMA rate) with fp32 accumulation -- the arithmetic of the
@@ -73,10 +77,41 @@ __device__ __forceinline__ float apply_act(float v, int act, float lam) {
 
 // One (64 T) x 32 operand tile.  KC: k is the contiguous dimension in memory (element (row, k) at
 // base[row * ld + k]); otherwise the row index is contiguous (base[k * ld + row]).
-template <bool KC, bool VEC, int T, int BKT>
+// S16: the operand is a bf16 array, fully aligned (bf16-operand mode only): one 16-byte load carries 8 elements and goes to
+// the LDS image as it is -- half the load instructions of the fp32 source, no conversion.
+template <bool KC, bool VEC, int T, int BKT, bool S16 = false>
 struct TileIO {
     static constexpr int ROWS = Tile<T>::ROWS, LDR = Tile<T>::LDR, KM = BKT / 32;
-    float v[8 * T * KM];
+    static constexpr int LDRB = ROWS + 8;
+    float v[S16 ? 1 : 8 * T * KM];
+    bf16x8 h[S16 ? T * KM : 1];
+    static __device__ __forceinline__ void coords16(int f, int& row, int& k) {
+        if (KC) { row = f / (BKT / 8); k = 8 * (f % (BKT / 8)); }
+        else { row = 8 * (f % (8 * T)); k = f / (8 * T); }
+    }
+    __device__ __forceinline__ void load16(const float* __restrict__ base, int ld, int row0, int nrows, int k0, int kend) {
+        const __bf16* __restrict__ hb = reinterpret_cast<const __bf16*>(base);
+#pragma unroll
+        for (int q = 0; q < T * KM; ++q) {
+            int row, k;
+            coords16(threadIdx.x + 256 * q, row, k);
+            const bool ok = row0 + row < nrows && k0 + k < kend;        // rows / k come in whole groups of 8 (host check)
+            const long long off = KC ? (long long)(row0 + row) * ld + k0 + k : (long long)(k0 + k) * ld + row0 + row;
+            bf16x8 t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (__bf16)0.f;
+            if (ok) t = *reinterpret_cast<const bf16x8*>(hb + off);
+            h[q] = t;
+        }
+    }
+    __device__ __forceinline__ void store16(__bf16* S) const {
+#pragma unroll
+        for (int q = 0; q < T * KM; ++q) {
+            int row, k;
+            coords16(threadIdx.x + 256 * q, row, k);
+            *reinterpret_cast<bf16x8*>(&S[KC ? row * LDKB + k : k * LDRB + row]) = h[q];
+        }
+    }
     static __device__ __forceinline__ void coords(int f, int& row, int& k) {
         if (VEC) {
             if (KC) { row = f / (BKT / 4); k = 4 * (f % (BKT / 4)); }
@@ -86,8 +121,10 @@ struct TileIO {
             else { row = f % ROWS; k = f / ROWS; }
         }
     }
-    __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int row0, int nrows, int k0, int kend) {
+    // bf: the operand is stored as bf16 (same coordinates, 8-byte instead of 16-byte vector loads, widened in registers)
+    __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int row0, int nrows, int k0, int kend, bool bf) {
         const int tid = threadIdx.x;
+        const __bf16* __restrict__ hb = reinterpret_cast<const __bf16*>(base);
         if (VEC) {
 #pragma unroll
             for (int q = 0; q < 2 * T * KM; ++q) {
@@ -96,7 +133,15 @@ struct TileIO {
                 const bool ok = row0 + row < nrows && k0 + k < kend;
                 const long long off = KC ? (long long)(row0 + row) * ld + k0 + k : (long long)(k0 + k) * ld + row0 + row;
                 f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (ok) t = *reinterpret_cast<const f32x4*>(base + off);
+                if (ok) {
+                    if (bf) {
+                        const bf16x4 hv = *reinterpret_cast<const bf16x4*>(hb + off);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) t[s] = (float)hv[s];
+                    } else {
+                        t = *reinterpret_cast<const f32x4*>(base + off);
+                    }
+                }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) v[4 * q + s] = t[s];
             }
@@ -107,7 +152,7 @@ struct TileIO {
                 coords(tid + 256 * q, row, k);
                 const bool ok = row0 + row < nrows && k0 + k < kend;
                 const long long off = KC ? (long long)(row0 + row) * ld + k0 + k : (long long)(k0 + k) * ld + row0 + row;
-                v[q] = ok ? base[off] : 0.f;
+                v[q] = ok ? (bf ? (float)hb[off] : base[off]) : 0.f;
             }
         }
     }
@@ -137,7 +182,6 @@ struct TileIO {
     }
     // bf16 images: [row][k] (row pitch LDKB) when k is contiguous in memory, [k][row] (row pitch LDRB) otherwise, so
     // that every float4 fetched from HBM becomes one packed 8-byte LDS write either way
-    static constexpr int LDRB = ROWS + 8;
     __device__ __forceinline__ void store_bf16(__bf16* S) const {
         const int tid = threadIdx.x;
         if (VEC) {
@@ -193,7 +237,8 @@ __device__ __forceinline__ void gemm_rowsum_flush(const GemmDev& a, const float 
 }
 
 // VEC bit 0: 16-byte loads for the A tile, bit 1: for the B tile (alignment checked per operand on the host)
-template <bool AKC, bool BKC, int VEC, int T, bool BF>
+// S16M bit 0 / 1: operand A / B is an aligned bf16 array read through TileIO's 16-byte path (BF kernels only)
+template <bool AKC, bool BKC, int VEC, int T, bool BF, int S16M = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     constexpr int BMN = Tile<T>::ROWS, NT16 = 2 * T;   // 16-row MFMA tiles per wave and direction
@@ -223,12 +268,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
         const int zb = zs / a.splits;                 // batch index; zs % splits = K split within the batch
         zs -= zb * a.splits;
         const int z1 = zb / a.nb2, z2 = zb - z1 * a.nb2;
-        a.A += z1 * a.sA1 + z2 * a.sA2;
-        a.B += z1 * a.sB1 + z2 * a.sB2;
+        // element offsets; a bf16 operand advances by half the bytes
+        auto adv = [](const float* p, long long off, bool bf) {
+            return bf ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(p) + off) : p + off;
+        };
+        a.A = adv(a.A, z1 * a.sA1 + z2 * a.sA2, a.dt & DT_A);
+        a.B = adv(a.B, z1 * a.sB1 + z2 * a.sB2, a.dt & DT_B);
         const long long oc = z1 * a.sC1 + z2 * a.sC2;
-        a.C += oc;
-        if (a.preact) a.preact += oc;
-        if (a.residual) a.residual += z1 * a.sR1 + z2 * a.sR2;
+        a.C = const_cast<float*>(adv(a.C, oc, a.dt & DT_C));
+        if (a.preact) a.preact = const_cast<float*>(adv(a.preact, oc, a.dt & DT_C));
+        if (a.residual) a.residual = adv(a.residual, z1 * a.sR1 + z2 * a.sR2, a.dt & DT_R);
         if (a.bias) a.bias += z1 * a.sBi1 + z2 * a.sBi2;
     }
     const int kbeg = zs * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
@@ -243,16 +292,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
 #pragma unroll
     for (int i = 0; i < NT16; ++i) rsum[i] = 0.f;
     constexpr bool VA = (VEC & 1) != 0, VB = (VEC & 2) != 0;
-    TileIO<AKC, VA, T, BKT> ta;
-    TileIO<BKC, VB, T, BKT> tb;
+    constexpr bool SA = BF && (S16M & 1), SB = BF && (S16M & 2);
+    TileIO<AKC, VA, T, BKT, SA> ta;
+    TileIO<BKC, VB, T, BKT, SB> tb;
     const int nk = (kend - kbeg + BKT - 1) / BKT;
     DLWP_STAMP(0);
-    ta.load(a.A, a.lda, m0, a.M, kbeg, kend);
-    tb.load(a.B, a.ldb, n0, a.N, kbeg, kend);
-    if (a.act_b) tb.apply_gelu();
+    const bool abf = a.dt & DT_A, bbf = a.dt & DT_B;
+    if constexpr (SA) ta.load16(a.A, a.lda, m0, a.M, kbeg, kend); else ta.load(a.A, a.lda, m0, a.M, kbeg, kend, abf);
+    if constexpr (SB) tb.load16(a.B, a.ldb, n0, a.N, kbeg, kend); else tb.load(a.B, a.ldb, n0, a.N, kbeg, kend, bbf);
+    if constexpr (!SB) { if (a.act_b) tb.apply_gelu(); }
     if constexpr (BF) {
-        ta.store_bf16(reinterpret_cast<__bf16*>(As));
-        tb.store_bf16(reinterpret_cast<__bf16*>(Bs));
+        if constexpr (SA) ta.store16(reinterpret_cast<__bf16*>(As)); else ta.store_bf16(reinterpret_cast<__bf16*>(As));
+        if constexpr (SB) tb.store16(reinterpret_cast<__bf16*>(Bs)); else tb.store_bf16(reinterpret_cast<__bf16*>(Bs));
     } else {
         ta.store(As);
         tb.store(Bs);
@@ -264,8 +315,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
         if (it == 1) DLWP_STAMP(2);
         if (it == 2) DLWP_STAMP(3);
         if (it + 1 < nk) {
-            ta.load(a.A, a.lda, m0, a.M, kbeg + (it + 1) * BKT, kend);
-            tb.load(a.B, a.ldb, n0, a.N, kbeg + (it + 1) * BKT, kend);
+            if constexpr (SA) ta.load16(a.A, a.lda, m0, a.M, kbeg + (it + 1) * BKT, kend);
+            else ta.load(a.A, a.lda, m0, a.M, kbeg + (it + 1) * BKT, kend, abf);
+            if constexpr (SB) tb.load16(a.B, a.ldb, n0, a.N, kbeg + (it + 1) * BKT, kend);
+            else tb.load(a.B, a.ldb, n0, a.N, kbeg + (it + 1) * BKT, kend, bbf);
         }
         if constexpr (BF) {
 #pragma unroll
@@ -301,10 +354,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
             }
         }
         if (it + 1 < nk) {
-            if (a.act_b) tb.apply_gelu();
+            if constexpr (!SB) { if (a.act_b) tb.apply_gelu(); }
             if constexpr (BF) {
-                ta.store_bf16(reinterpret_cast<__bf16*>(As + (cur ^ 1) * TF));
-                tb.store_bf16(reinterpret_cast<__bf16*>(Bs + (cur ^ 1) * TF));
+                if constexpr (SA) ta.store16(reinterpret_cast<__bf16*>(As + (cur ^ 1) * TF));
+                else ta.store_bf16(reinterpret_cast<__bf16*>(As + (cur ^ 1) * TF));
+                if constexpr (SB) tb.store16(reinterpret_cast<__bf16*>(Bs + (cur ^ 1) * TF));
+                else tb.store_bf16(reinterpret_cast<__bf16*>(Bs + (cur ^ 1) * TF));
             } else {
                 ta.store(As + (cur ^ 1) * TF);
                 tb.store(Bs + (cur ^ 1) * TF);
@@ -342,7 +397,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] += bv[k];
                     f32x4 rv = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (a.residual) rv = *reinterpret_cast<const f32x4*>(a.residual + o);
+                    if (a.residual) {
+                        if (a.dt & DT_R) {
+                            const bf16x4 hv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.residual) + o);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) rv[k] = (float)hv[k];
+                        } else {
+                            rv = *reinterpret_cast<const f32x4*>(a.residual + o);
+                        }
+                    }
+                    auto put = [&](float* dst, const f32x4& val) {
+                        if (a.dt & DT_C)
+                            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(dst) + o) =
+                                bf16x4{(__bf16)val[0], (__bf16)val[1], (__bf16)val[2], (__bf16)val[3]};
+                        else
+                            *reinterpret_cast<f32x4*>(dst + o) = val;
+                    };
                     if (a.act == ACT_GELU_GRAD_MUL) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[k] *= gelu_grad_f(rv[k]);
@@ -351,7 +421,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
 #pragma unroll
                             for (int k = 0; k < 4; ++k) v[k] += rv[k];
                         }
-                        if (a.preact) *reinterpret_cast<f32x4*>(a.preact + o) = v;
+                        if (a.preact) put(a.preact, v);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], a.act, a.act_param);
                         if (!a.res_pre) {
@@ -359,12 +429,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
                             for (int k = 0; k < 4; ++k) v[k] += rv[k];
                         }
                     }
-                    if (a.accumulate) {
+                    if (a.accumulate) {          // fp32 outputs only (checked on the host)
                         const f32x4 cv = *reinterpret_cast<const f32x4*>(a.C + o);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[k] += cv[k];
                     }
-                    *reinterpret_cast<f32x4*>(a.C + o) = v;
+                    put(a.C, v);
                 }
             }
             DLWP_STAMP(5);
@@ -383,27 +453,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
                     float v = acc[i][j][q];
                     if (a.splits > 1 || a.atomic_out) { atomic_add_f32(&a.C[o], v); continue; }   // C zeroed (or accumulate)
                     if (a.bias) v += a.bias[a.bias_row ? m : n];
+                    const float rres = !a.residual ? 0.f
+                                       : (a.dt & DT_R) ? (float)reinterpret_cast<const __bf16*>(a.residual)[o] : a.residual[o];
+                    auto put1 = [&](float* dst, float val) {
+                        if (a.dt & DT_C) reinterpret_cast<__bf16*>(dst)[o] = (__bf16)val;
+                        else dst[o] = val;
+                    };
                     if (a.act == ACT_GELU_GRAD_MUL) {
-                        v *= gelu_grad_f(a.residual[o]);
+                        v *= gelu_grad_f(rres);
                     } else {
-                        if (a.residual && a.res_pre) v += a.residual[o];
-                        if (a.preact) a.preact[o] = v;
+                        if (a.res_pre) v += rres;
+                        if (a.preact) put1(a.preact, v);
                         v = apply_act(v, a.act, a.act_param);
-                        if (a.residual && !a.res_pre) v += a.residual[o];
+                        if (!a.res_pre) v += rres;
                     }
-                    a.C[o] = a.accumulate ? a.C[o] + v : v;
+                    put1(a.C, a.accumulate ? a.C[o] + v : v);
                 }
             }
 }
 
-template <bool AKC, bool BKC, int VEC, int T, bool BF>
+template <bool AKC, bool BKC, int VEC, int T, bool BF, int S16M = 0>
 int gemm_launch_t(const GemmDev& a, dim3 grid, hipStream_t s) {
     constexpr int RW = Tile<T>::ROWS;
     const size_t lds = BF ? sizeof(float) * 4 * ((RW * LDKB > BKB * (RW + 8) ? RW * LDKB : BKB * (RW + 8)) / 2)
                           : sizeof(float) * 4 * Tile<T>::FLOATS;
-    int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_kernel<AKC, BKC, VEC, T, BF>), lds, "gemm");
+    int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_kernel<AKC, BKC, VEC, T, BF, S16M>), lds, "gemm");
     if (rc) return rc;
-    hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, T, BF>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, T, BF, S16M>), grid, dim3(256), lds, s, a);
     return DLWP_OK;
 }
 
@@ -417,6 +493,25 @@ int gemm_launch(const GemmDev& a_in, int vec, int T, hipStream_t s) {
     a.ntm = ceil_div(a.M, edge);
     const dim3 grid(a.ntn * a.ntm, 1, a.nbatch * a.splits);
     if (T == 2 && vec != 3) vec = 0;      // the 128-wide tile exists for fully aligned operands only
+    // bf16 arrays in memory (dlwp_gemm_mixed): whole groups of 8 along the contiguous dimension and 16-byte aligned -> the
+    // 16-byte path; otherwise TileIO::load widens them element-wise (correct, slower)
+    if (g_gemm_bf16 && vec == 3 && (a.dt & (DT_A | DT_B)) && !a.act_b) {
+        auto ok16 = [&](const float* p, int ld, bool kc, int rows, long long s1, long long s2) {
+            return (uintptr_t)p % 16 == 0 && ld % 8 == 0 && (kc ? a.K % 8 == 0 && a.kchunk % 8 == 0 : rows % 8 == 0) &&
+                   (a.nbatch == 1 || (s1 % 8 == 0 && s2 % 8 == 0));
+        };
+        const int m16 = (((a.dt & DT_A) && ok16(a.A, a.lda, AKC, a.M, a.sA1, a.sA2)) ? 1 : 0) |
+                        (((a.dt & DT_B) && ok16(a.B, a.ldb, BKC, a.N, a.sB1, a.sB2)) ? 2 : 0);
+#define GEMM_S16(TT)                                                                       \
+        switch (m16) {                                                                     \
+            case 1: return gemm_launch_t<AKC, BKC, 3, TT, true, 1>(a, grid, s);           \
+            case 2: return gemm_launch_t<AKC, BKC, 3, TT, true, 2>(a, grid, s);           \
+            case 3: return gemm_launch_t<AKC, BKC, 3, TT, true, 3>(a, grid, s);           \
+            default: break;                                                                \
+        }
+        if (T == 2) { GEMM_S16(2) } else { GEMM_S16(1) }
+#undef GEMM_S16
+    }
 #define GEMM_VEC_SWITCH(TT, BFV)                                                          \
     switch (vec) {                                                                         \
         case 3: return gemm_launch_t<AKC, BKC, 3, TT, BFV>(a, grid, s);                   \
@@ -445,7 +540,7 @@ __device__ __forceinline__ float wave_sum64(float v) {
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd, int T,
-                                                            int C, float eps) {
+                                                            int C, float eps, int y_bf16) {
     const int row = blockIdx.x * 4 + wave_id(), lane = lane_id();
     if (row >= T) return;
     const float* xr = x + (long long)row * C;
@@ -455,7 +550,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     float v = 0.f;
     for (int c = lane; c < C; c += 64) { const float d = xr[c] - mu; v += d * d; }
     const float rs = rsqrtf(wave_sum64(v) / C + eps);
-    for (int c = lane; c < C; c += 64) y[(long long)row * C + c] = (xr[c] - mu) * rs * gamma[c] + beta[c];
+    if (y_bf16) {         // the output feeds a GEMM under bf16 storage: rounded once here instead of in every tile load
+        __bf16* yh = reinterpret_cast<__bf16*>(y);
+        for (int c = lane; c < C; c += 64) yh[(long long)row * C + c] = (__bf16)((xr[c] - mu) * rs * gamma[c] + beta[c]);
+    } else {
+        for (int c = lane; c < C; c += 64) y[(long long)row * C + c] = (xr[c] - mu) * rs * gamma[c] + beta[c];
+    }
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
@@ -586,17 +686,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g
 // and measured 5-7 % SLOWER than 64 x 64 (T = 1: ~104 VGPRs, four waves per SIMD hide the LDS fragment reads behind the
 // other waves' MFMAs) on the SFNO (M = 512-32768, N = K = 256-512) and FourCastNet-scale (16200 x 3072 x 768) products,
 // so it is only used when DLWP_GEMM_TILE=128 asks for it (kept for re-measurement with bf16 operands).
-static int gemm_tile_for(int M, int N, long long nbatch) {
-    static const int forced = [] { const char* e = getenv("DLWP_GEMM_TILE"); return e && atoi(e) == 128 ? 2 : 1; }();
-    if (forced == 1 || M < 128 || N < 128) return 1;
-    return (long long)ceil_div(M, 128) * ceil_div(N, 128) * nbatch >= 224 ? 2 : 1;
+// With both operands stored as bf16 (16-byte loads, 4 staging registers per operand) the picture changes for deep products:
+// profiles/r02_gemm_bench.txt, 16200 x 3072 x 768: 395 -> 479 TFLOP/s, 16200 x 768 x 3072 (gx): 438 -> 656; at K = 256-512
+// (SFNO) the 128 tile still loses (264 -> 176), so it is taken from K = 768 on.
+static int gemm_tile_for(int M, int N, long long nbatch, int K = 0, int dt = 0) {
+    static const int forced = [] { const char* e = getenv("DLWP_GEMM_TILE"); return e ? (atoi(e) == 128 ? 2 : 1) : 0; }();
+    if (M < 128 || N < 128) return 1;
+    const bool fills = (long long)ceil_div(M, 128) * ceil_div(N, 128) * nbatch >= 224;
+    if (forced) return forced == 2 && fills ? 2 : 1;
+    return g_gemm_bf16 && (dt & 3) == 3 && K >= 768 && fills ? 2 : 1;
 }
 
 static int gemm_dispatch(GemmDev& a, int transA, int transB, int T, void* stream) {
     // 16-byte loads need every row start and every group of four along the contiguous dimension to be aligned and whole;
     // decided per operand (a weight matrix with an odd row length must not force scalar loads on the activations)
-    bool vecA = ((uintptr_t)a.A % 16 == 0) && a.lda % 4 == 0 && (transA ? a.M % 4 == 0 : a.K % 4 == 0);
-    bool vecB = ((uintptr_t)a.B % 16 == 0) && a.ldb % 4 == 0 && (transB ? a.K % 4 == 0 : a.N % 4 == 0);
+    bool vecA = ((uintptr_t)a.A % ((a.dt & DT_A) ? 8 : 16) == 0) && a.lda % 4 == 0 && (transA ? a.M % 4 == 0 : a.K % 4 == 0);
+    bool vecB = ((uintptr_t)a.B % ((a.dt & DT_B) ? 8 : 16) == 0) && a.ldb % 4 == 0 && (transB ? a.K % 4 == 0 : a.N % 4 == 0);
     if (a.nbatch > 1) {
         vecA = vecA && a.sA1 % 4 == 0 && a.sA2 % 4 == 0;
         vecB = vecB && a.sB1 % 4 == 0 && a.sB2 % 4 == 0;
@@ -652,13 +757,20 @@ extern "C" int dlwp_set_gemm_precision(int mode) {
 
 extern "C" int dlwp_get_gemm_precision(void) { return g_gemm_bf16; }
 
-extern "C" int dlwp_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                         int transA, int transB, const float* bias, int act, float* preact, const float* residual,
-                         int accumulate, float* rowsum, void* stream) {
+static int dtypes_ok(int dt, int accumulate, const char* who) {
+    DLWP_REQUIRE(dt >= 0 && dt < 16, DLWP_E_INVALID, "%s: dtypes is a mask of 1 (A) | 2 (B) | 4 (C, preact) | 8 (residual)", who);
+    DLWP_REQUIRE(!((dt & DT_C) && accumulate), DLWP_E_INVALID, "%s: accumulation needs an fp32 output", who);
+    return DLWP_OK;
+}
+
+static int gemm_impl(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                     int transA, int transB, const float* bias, int act, float* preact, const float* residual,
+                     int accumulate, float* rowsum, int dt, void* stream) {
     DLWP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, DLWP_E_INVALID, "gemm: NULL argument or empty shape");
     DLWP_REQUIRE(act == 0 || act == 1, DLWP_E_INVALID, "gemm: act must be 0 (none) or 1 (gelu)");
-    const bool epilogue = bias || act || preact || residual;
-    const int T = gemm_tile_for(M, N, 1);
+    if (int drc = dtypes_ok(dt, accumulate, "gemm")) return drc;
+    const bool epilogue = bias || act || preact || residual || (dt & DT_C);      // a bf16 output takes no split-K atomics
+    const int T = gemm_tile_for(M, N, 1, K, dt);
     const int tiles = ceil_div(N, 64 * T) * ceil_div(M, 64 * T);
     int splits = 1;
     if (!epilogue && tiles < 256 && K >= 8 * BK) splits = std::min(ceil_div(512, tiles), K / (4 * BK));
@@ -670,24 +782,39 @@ extern "C" int dlwp_gemm(const float* A, const float* B, float* C, int M, int N,
     }
     GemmDev a{A, B, bias, residual, C, preact, rowsum, M, N, K, lda, ldb, ldc, act, accumulate, kchunk, splits,
               1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.f, 0, 0, 0};
+    a.dt = dt;
     return gemm_dispatch(a, transA, transB, T, stream);
 }
 
-extern "C" int dlwp_gemm_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                                 int transA, int transB, int nb1, int nb2, long long sA1, long long sA2, long long sB1,
-                                 long long sB2, long long sC1, long long sC2, const float* bias, long long sBi1,
-                                 long long sBi2, int act, float act_param, float* preact, const float* residual,
-                                 long long sR1, long long sR2, int res_before_act, int accumulate, void* stream) {
+extern "C" int dlwp_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                         int transA, int transB, const float* bias, int act, float* preact, const float* residual,
+                         int accumulate, float* rowsum, void* stream) {
+    return gemm_impl(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, bias, act, preact, residual, accumulate, rowsum, 0, stream);
+}
+
+extern "C" int dlwp_gemm_mixed(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                               int transA, int transB, const float* bias, int act, void* preact, const void* residual,
+                               int accumulate, float* rowsum, int dtypes, void* stream) {
+    return gemm_impl((const float*)A, (const float*)B, (float*)C, M, N, K, lda, ldb, ldc, transA, transB, bias, act,
+                     (float*)preact, (const float*)residual, accumulate, rowsum, dtypes, stream);
+}
+
+static int gemm_batched_impl(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                             int transA, int transB, int nb1, int nb2, long long sA1, long long sA2, long long sB1,
+                             long long sB2, long long sC1, long long sC2, const float* bias, long long sBi1,
+                             long long sBi2, int act, float act_param, float* preact, const float* residual,
+                             long long sR1, long long sR2, int res_before_act, int accumulate, int dt, void* stream) {
     DLWP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && nb1 > 0 && nb2 > 0, DLWP_E_INVALID,
                  "gemm_batched: NULL argument or empty shape");
+    if (int drc = dtypes_ok(dt, accumulate, "gemm_batched")) return drc;
     DLWP_REQUIRE(act >= 0 && act <= 4, DLWP_E_INVALID,
                  "gemm_batched: act must be 0 (none), 1 (gelu), 2 (relu), 3 (softshrink) or 4 (multiply by GELU'(residual))");
     DLWP_REQUIRE(act != ACT_GELU_GRAD_MUL || (residual && !preact), DLWP_E_INVALID,
                  "gemm_batched: act 4 reads the saved pre-activation through `residual` and writes no `preact`");
     // reductions over a long K with few output tiles (weight gradients of block-diagonal layers): split K inside every
     // batch and combine with float atomics, like the plain entry
-    const bool epilogue = bias || act || preact || residual;
-    const int T = gemm_tile_for(M, N, (long long)nb1 * nb2);
+    const bool epilogue = bias || act || preact || residual || (dt & DT_C);
+    const int T = gemm_tile_for(M, N, (long long)nb1 * nb2, K, dt);
     const long long tiles = (long long)ceil_div(N, 64 * T) * ceil_div(M, 64 * T) * nb1 * nb2;
     int splits = 1;
     if (!epilogue && tiles < 256 && K >= 8 * BK) splits = (int)std::min<long long>(ceil_div(512, (int)tiles), K / (4 * BK));
@@ -702,16 +829,63 @@ extern "C" int dlwp_gemm_batched(const float* A, const float* B, float* C, int M
     }
     GemmDev a{A, B, bias, residual, C, preact, nullptr, M, N, K, lda, ldb, ldc, act, accumulate, kchunk, splits,
               nb1 * nb2, nb2, res_before_act, 0, 0, 0, sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2, sBi1, sBi2, act_param, 0, 0, 0};
+    a.dt = dt;
     return gemm_dispatch(a, transA, transB, T, stream);
+}
+
+extern "C" int dlwp_gemm_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                 int transA, int transB, int nb1, int nb2, long long sA1, long long sA2, long long sB1,
+                                 long long sB2, long long sC1, long long sC2, const float* bias, long long sBi1,
+                                 long long sBi2, int act, float act_param, float* preact, const float* residual,
+                                 long long sR1, long long sR2, int res_before_act, int accumulate, void* stream) {
+    return gemm_batched_impl(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, nb1, nb2, sA1, sA2, sB1, sB2, sC1, sC2, bias, sBi1,
+                             sBi2, act, act_param, preact, residual, sR1, sR2, res_before_act, accumulate, 0, stream);
+}
+
+extern "C" int dlwp_gemm_batched_mixed(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                       int transA, int transB, int nb1, int nb2, long long sA1, long long sA2, long long sB1,
+                                       long long sB2, long long sC1, long long sC2, const float* bias, long long sBi1,
+                                       long long sBi2, int act, float act_param, void* preact, const void* residual,
+                                       long long sR1, long long sR2, int res_before_act, int accumulate, int dtypes,
+                                       void* stream) {
+    return gemm_batched_impl((const float*)A, (const float*)B, (float*)C, M, N, K, lda, ldb, ldc, transA, transB, nb1, nb2, sA1,
+                             sA2, sB1, sB2, sC1, sC2, bias, sBi1, sBi2, act, act_param, (float*)preact, (const float*)residual,
+                             sR1, sR2, res_before_act, accumulate, dtypes, stream);
+}
+
+namespace {
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long long n) {
+    const long long n4 = n / 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+        reinterpret_cast<bf16x4*>(dst)[i] = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    }
+    for (long long i = 4 * n4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = (__bf16)src[i];
+}
+}  // namespace
+
+extern "C" int dlwp_cast_bf16(const float* src, void* dst, long long n, void* stream) {
+    DLWP_REQUIRE(src && dst && n >= 0, DLWP_E_INVALID, "cast_bf16: bad argument");
+    DLWP_REQUIRE((uintptr_t)src % 16 == 0 && (uintptr_t)dst % 8 == 0, DLWP_E_INVALID, "cast_bf16: buffers must be 16 / 8 byte aligned");
+    if (n == 0) return DLWP_OK;
+    const long long blocks = std::min<long long>((n / 4 + 255) / 256 + 1, 4096);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, n);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_layernorm_fwd_ex(const float* x, const float* gamma, const float* beta, void* y, float* mean,
+                                     float* rstd, int T, int C, float eps, int y_bf16, void* stream) {
+    DLWP_REQUIRE(x && gamma && beta && y && mean && rstd && T > 0 && C > 0, DLWP_E_INVALID, "layernorm_fwd: bad argument");
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ceil_div(T, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (float*)y,
+                       mean, rstd, T, C, eps, y_bf16 ? 1 : 0);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
 }
 
 extern "C" int dlwp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                                   float* rstd, int T, int C, float eps, void* stream) {
-    DLWP_REQUIRE(x && gamma && beta && y && mean && rstd && T > 0 && C > 0, DLWP_E_INVALID, "layernorm_fwd: bad argument");
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ceil_div(T, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
-                       mean, rstd, T, C, eps);
-    DLWP_LAUNCH_CHECK();
-    return DLWP_OK;
+    return dlwp_layernorm_fwd_ex(x, gamma, beta, y, mean, rstd, T, C, eps, 0, stream);
 }
 
 extern "C" int dlwp_layernorm_bwd_res(const float* x, const float* gamma, const float* mean, const float* rstd,

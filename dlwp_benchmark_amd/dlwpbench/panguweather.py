@@ -127,9 +127,9 @@ class EarthSpecificBlock(nn.Module):
             skip, t = norm_fork(self.norm1, x)
             t = self.attn(partition(t, spec, fwd_shift), self._labels if self.roll else None, spec.nW)
             if self.drop_path.active:            # stochastic depth: per-sample scale fused with the residual adds
-                skip, t = norm_fork(self.norm2, self.drop_path(reverse(t, spec, B, rev_shift), residual=skip))
+                skip, t = norm_fork(self.norm2, self.drop_path(reverse(t, spec, B, rev_shift), residual=skip), gemm_input=True)
                 return self.drop_path(self.mlp(t), residual=skip)
-            skip, t = norm_fork(self.norm2, reverse(t, spec, B, rev_shift, residual=skip))
+            skip, t = norm_fork(self.norm2, reverse(t, spec, B, rev_shift, residual=skip), gemm_input=True)
             return self.mlp(t, residual=skip)
         t = self.norm1(x).view(B, Pl, Lat, Lon, C)
         t = F.pad(t.permute(0, 4, 1, 2, 3), p).permute(0, 2, 3, 4, 1)

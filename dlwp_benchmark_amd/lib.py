@@ -73,6 +73,9 @@ SIGNATURES = {
     "dlwp_window_advance_fwd": (_I, [_V, _L, _V, _V, _V, _I, _I, _L] + [_I] * 6 + [_V]),
     "dlwp_window_advance_bwd": (_I, [_V, _V, _L, _V, _L, _V, _V, _I, _I, _L] + [_I] * 6 + [_V]),
     "dlwp_gemm": (_I, [_V, _V, _V] + [_I] * 8 + [_V, _I, _V, _V, _I, _V, _V]),
+    "dlwp_gemm_mixed": (_I, [_V, _V, _V] + [_I] * 8 + [_V, _I, _V, _V, _I, _V, _I, _V]),
+    "dlwp_gemm_batched_mixed": (_I, [_V, _V, _V] + [_I] * 10 + [_L] * 6 + [_V, _L, _L, _I, _F, _V, _V, _L, _L, _I, _I, _I, _V]),
+    "dlwp_cast_bf16": (_I, [_V, _V, _L, _V]),
     "dlwp_gemm_batched": (_I, [_V, _V, _V] + [_I] * 10 + [_L] * 6 + [_V, _L, _L, _I, _F, _V, _V, _L, _L, _I, _I, _V]),
     "dlwp_act_bwd": (_I, [_V, _V, _V, _L, _I, _F, _V]),
     "dlwp_sht_fused_supported": (_I, [_I] * 5),
@@ -81,6 +84,7 @@ SIGNATURES = {
     "dlwp_cweight_expand": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_cweight_fold": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_layernorm_fwd": (_I, [_V] * 6 + [_I, _I, _F, _V]),
+    "dlwp_layernorm_fwd_ex": (_I, [_V] * 6 + [_I, _I, _F, _I, _V]),
     "dlwp_layernorm_bwd": (_I, [_V] * 8 + [_I, _I, _V]),
     "dlwp_layernorm_bwd_res": (_I, [_V] * 9 + [_I, _I, _V]),
     "dlwp_instnorm_fwd": (_I, [_V] * 6 + [_I, _I, _I, _F, _V]),
@@ -181,3 +185,31 @@ class gemm_precision:
 
 def set_gemm_precision(mode):
     check(load().dlwp_set_gemm_precision(gemm_precision.MODES[mode]))
+
+
+# ---- bf16 storage (BASELINE configs C3-C5 train under bf16 autocast).  "bf16": the token MLPs keep their hidden activations,
+# pre-activations and hidden gradients as bf16 in HBM and read a per-step bf16 copy of the weights (train_engine keeps it
+# next to the fp32 master weights); sums, epilogues, LayerNorm / softmax statistics, the residual stream and every parameter
+# gradient stay fp32.  Only meaningful with gemm precision "bf16" (the matrix units round the operands to bf16 anyway).
+_STORAGE = "fp32"
+SHADOW_ACTIVE = False      # set by train_engine while a step runs: the bf16 weight copies are current
+
+
+def set_storage(mode):
+    global _STORAGE
+    if mode not in ("fp32", "bf16"):
+        raise ValueError("storage mode must be 'fp32' or 'bf16'")
+    if mode == "bf16" and load().dlwp_get_gemm_precision() != 1:
+        raise DlwpError("bf16 storage goes with bf16 GEMM operands: call set_gemm_precision('bf16') first")
+    _STORAGE = mode
+
+
+def storage_bf16():
+    return _STORAGE == "bf16"
+
+
+def shadow(p):
+    """The current bf16 copy of parameter `p` (same shape), or None when there is none / it may be stale."""
+    if not (SHADOW_ACTIVE and _STORAGE == "bf16"):
+        return None
+    return getattr(p, "_dlwp_bf16", None)

@@ -132,7 +132,7 @@ class Block(nn.Module):
         # gradients of the skip branches join the LayerNorm backward kernels (LayerNorm.fork)
         if self.double_skip:
             residual, t = norm_fork(self.norm1, x)
-            residual, t = norm_fork(self.norm2, self.filter(t, residual=residual))
+            residual, t = norm_fork(self.norm2, self.filter(t, residual=residual), gemm_input=True)
         else:
             residual, t = norm_fork(self.norm1, x)
             t = self.norm2(self.filter(t))

@@ -186,9 +186,9 @@ class SwinTransformerBlock(nn.Module):
             skip, t = norm_fork(self.norm1, x)
             t = self.attn(partition(t, spec), labels if shifted else None, spec.nW)
             if self.drop_path.active:        # training with stochastic depth (:255-256): per-sample scale + residual add
-                skip, t = norm_fork(self.norm2, self.drop_path(reverse(t, spec, B), residual=skip))
+                skip, t = norm_fork(self.norm2, self.drop_path(reverse(t, spec, B), residual=skip), gemm_input=True)
                 return self.drop_path(self.mlp(t), residual=skip)
-            skip, t = norm_fork(self.norm2, reverse(t, spec, B, residual=skip))
+            skip, t = norm_fork(self.norm2, reverse(t, spec, B, residual=skip), gemm_input=True)
             return self.mlp(t, residual=skip)
         t = self.norm1(x).view(B, H, W, C)
         t = _pad_hw(t, (ws[0] - H % ws[0]) % ws[0], (ws[1] - W % ws[1]) % ws[1], self.padding_mode)

@@ -10,10 +10,37 @@ import torch.nn as nn
 from . import lib as L
 
 
+_BF = torch.bfloat16
+
+
+def _dtypes(A, B, C, preact, residual):
+    """Storage mask of dlwp_gemm_mixed: 1 A, 2 B, 4 C (+ preact), 8 residual are bf16 arrays."""
+    if preact is not None and preact.dtype != C.dtype:
+        raise L.DlwpError("gemm: preact must have the output's storage type")
+    return (1 if A.dtype == _BF else 0) | (2 if B.dtype == _BF else 0) | (4 if C.dtype == _BF else 0) | \
+        (8 if residual is not None and residual.dtype == _BF else 0)
+
+
 def _gemm(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, bias=None, act=0, preact=None, residual=None, accumulate=0,
           rowsum=None):
+    dt = _dtypes(A, B, C, preact, residual)
+    if dt:
+        L.check(L.load().dlwp_gemm_mixed(L.ptr(A), L.ptr(B), L.ptr(C), M, N, K, lda, ldb, ldc, tA, tB, L.ptr(bias), act,
+                                         L.ptr(preact), L.ptr(residual), accumulate, L.ptr(rowsum), dt, L.stream()))
+        return
     L.check(L.load().dlwp_gemm(L.ptr(A), L.ptr(B), L.ptr(C), M, N, K, lda, ldb, ldc, tA, tB, L.ptr(bias), act,
                                L.ptr(preact), L.ptr(residual), accumulate, L.ptr(rowsum), L.stream()))
+
+
+def _wmat(w, rows):
+    """(matrix the forward / input-gradient GEMMs read, fp32 matrix): the bf16 shadow of `w` when the engine keeps one."""
+    w32 = w.contiguous().reshape(rows, -1)
+    sh = L.shadow(w)
+    return (sh.reshape(rows, -1) if sh is not None else w32), w32
+
+
+def _act_dtype():
+    return _BF if (L.storage_bf16() and L.SHADOW_ACTIVE) else torch.float32
 
 
 def _grad_slot(p):
@@ -25,14 +52,21 @@ def _grad_slot(p):
 
 
 def _dptr(t, offset=0):
-    """Device pointer of `t` advanced by `offset` floats (views into bigger buffers are passed as base + offset)."""
-    return None if t is None else L.ptr(t) + 4 * offset
+    """Device pointer of `t` advanced by `offset` elements (views into bigger buffers are passed as base + offset)."""
+    return None if t is None else L.ptr(t) + t.element_size() * offset
 
 
 def _gemm_batched(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, act=0,
                   preact=None, residual=None, sR=(0, 0), res_pre=0, accumulate=0, sBi=(0, 0), act_param=0.0, oA=0, oB=0, oC=0,
                   oR=0, oBi=0):
     """dlwp_gemm_batched; o* are element offsets into the (contiguous) buffers (preact shares C's offset)."""
+    dt = _dtypes(A, B, C, preact, residual)
+    if dt:
+        L.check(L.load().dlwp_gemm_batched_mixed(_dptr(A, oA), _dptr(B, oB), _dptr(C, oC), M, N, K, lda, ldb, ldc, tA, tB, nb1,
+                                                 nb2, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], _dptr(bias, oBi), sBi[0],
+                                                 sBi[1], act, act_param, _dptr(preact, oC), _dptr(residual, oR), sR[0],
+                                                 sR[1], res_pre, accumulate, dt, L.stream()))
+        return
     L.check(L.load().dlwp_gemm_batched(_dptr(A, oA), _dptr(B, oB), _dptr(C, oC), M, N, K, lda, ldb, ldc, tA, tB, nb1, nb2,
                                        sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], _dptr(bias, oBi), sBi[0], sBi[1], act,
                                        act_param, _dptr(preact, oC), _dptr(residual, oR), sR[0], sR[1], res_pre, accumulate,
@@ -46,10 +80,12 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act, residual, res_pre=False):
         shape = x.shape
-        x2 = x.reshape(-1, shape[-1]).contiguous().float()
+        x2 = x.reshape(-1, shape[-1]).contiguous()
+        if x2.dtype != _BF:               # a bf16 input comes from a LayerNorm that wrote it for this GEMM (bf16 storage)
+            x2 = x2.float()
         T, K = x2.shape
         N = weight.shape[0]
-        w = weight.contiguous().reshape(N, -1)
+        w, _ = _wmat(weight, N)             # the bf16 copy under bf16 storage (forward and input-gradient products)
         y = torch.empty(T, N, device=x.device)
         z = torch.empty(T, N, device=x.device) if act else None
         r2 = residual.reshape(-1, N).contiguous() if residual is not None else None
@@ -123,12 +159,16 @@ class _MlpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, residual):
         shape = x.shape
-        x2 = x.reshape(-1, shape[-1]).contiguous().float()
+        x2 = x.reshape(-1, shape[-1]).contiguous()
+        if x2.dtype != _BF:               # a bf16 input comes from a LayerNorm that wrote it for this GEMM (bf16 storage)
+            x2 = x2.float()
         T, K = x2.shape
         Hd, N = w1.shape[0], w2.shape[0]
-        w1m, w2m = w1.contiguous().reshape(Hd, -1), w2.contiguous().reshape(N, -1)
-        h = torch.empty(T, Hd, device=x.device)
-        z = torch.empty(T, Hd, device=x.device)
+        # bf16 storage (lib.set_storage): h, z live in HBM as bf16 and the GEMMs read the engine's bf16 weight copies
+        (w1m, _), (w2m, _) = _wmat(w1, Hd), _wmat(w2, N)
+        adt = _act_dtype()
+        h = torch.empty(T, Hd, device=x.device, dtype=adt)
+        z = torch.empty(T, Hd, device=x.device, dtype=adt)
         _gemm(x2, w1m, h, T, Hd, K, K, K, Hd, 0, 1, b1, 1, z, None)
         y = torch.empty(T, N, device=x.device)
         r2 = residual.reshape(-1, N).contiguous() if residual is not None else None
@@ -147,7 +187,7 @@ class _MlpFn(torch.autograd.Function):
         T, K = x2.shape
         Hd, N = w1m.shape[0], w2m.shape[0]
         g2 = gy.reshape(-1, N).contiguous().float()
-        gh = torch.empty(T, Hd, device=g2.device)
+        gh = torch.empty(T, Hd, device=g2.device, dtype=h.dtype)
         _gemm_batched(g2, w2m, gh, T, Hd, N, N, Hd, Hd, 0, 0, act=4, residual=z)     # (g W2) * GELU'(z)
         gw2, gb2 = _weight_grad(g2, h, ctx.slots[2], ctx.slots[3], ctx.has_b[1], ctx.w2shape)
         gx = torch.empty(T, K, device=g2.device)
@@ -174,12 +214,13 @@ class _SkipMlpFn(torch.autograd.Function):
         y2 = y.reshape(-1, C).contiguous().float()
         T = x2.shape[0]
         Hd, N = w1.shape[0], w2.shape[0]
-        wsm, w1m, w2m = ws.contiguous().reshape(C, -1), w1.contiguous().reshape(Hd, -1), w2.contiguous().reshape(N, -1)
+        (wsm, _), (w1m, _), (w2m, _) = _wmat(ws, C), _wmat(w1, Hd), _wmat(w2, N)
+        adt = _act_dtype()                  # bf16 storage: the hidden-width tensors h, z1 (and gh) are bf16 in HBM
         t = torch.empty(T, C, device=x.device)
         z0 = torch.empty(T, C, device=x.device)
         _gemm_batched(x2, wsm, t, T, C, C, C, C, C, 0, 1, bias=bs, act=1, preact=z0, residual=y2, res_pre=1)
-        h = torch.empty(T, Hd, device=x.device)
-        z1 = torch.empty(T, Hd, device=x.device)
+        h = torch.empty(T, Hd, device=x.device, dtype=adt)
+        z1 = torch.empty(T, Hd, device=x.device, dtype=adt)
         _gemm(t, w1m, h, T, Hd, C, C, C, Hd, 0, 1, b1, 1, z1, None)
         out = torch.empty(T, N, device=x.device)
         _gemm(h, w2m, out, T, N, Hd, Hd, Hd, N, 0, 1, b2, 0, None, x2 if outer else None)
@@ -196,7 +237,7 @@ class _SkipMlpFn(torch.autograd.Function):
         T, C = x2.shape
         Hd, N = w1m.shape[0], w2m.shape[0]
         g2 = gout.reshape(-1, N).contiguous().float()
-        gh = torch.empty(T, Hd, device=g2.device)
+        gh = torch.empty(T, Hd, device=g2.device, dtype=h.dtype)
         _gemm_batched(g2, w2m, gh, T, Hd, N, N, Hd, Hd, 0, 0, act=4, residual=z1)      # (g W2) * GELU'(z1)
         gw2, gb2 = _weight_grad(g2, h, ctx.slots[4], ctx.slots[5], ctx.has_b[2], ctx.wshapes[2])
         gt = torch.empty(T, C, device=g2.device)
@@ -233,16 +274,18 @@ class _LayerNormFn(torch.autograd.Function):
     LayerNorm backward meet inside dlwp_layernorm_bwd_res -- one kernel, no elementwise add on the autograd thread."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, fork=False):
+    def forward(ctx, x, gamma, beta, eps, fork=False, gemm_input=False):
         lib = L.load()
         shape = x.shape
         x2 = x.reshape(-1, shape[-1]).contiguous().float()
         T, C_ = x2.shape
-        y = torch.empty_like(x2)
+        # gemm_input: the caller promises that only GEMMs read the output -- under bf16 storage it is then written as bf16
+        lowp = gemm_input and _act_dtype() == _BF
+        y = torch.empty_like(x2, dtype=_BF if lowp else torch.float32)
         mean = torch.empty(T, device=x.device)
         rstd = torch.empty(T, device=x.device)
-        L.check(lib.dlwp_layernorm_fwd(L.ptr(x2), L.ptr(gamma.contiguous()), L.ptr(beta.contiguous()), L.ptr(y),
-                                       L.ptr(mean), L.ptr(rstd), T, C_, eps, L.stream()))
+        L.check(lib.dlwp_layernorm_fwd_ex(L.ptr(x2), L.ptr(gamma.contiguous()), L.ptr(beta.contiguous()), L.ptr(y),
+                                          L.ptr(mean), L.ptr(rstd), T, C_, eps, int(lowp), L.stream()))
         ctx.save_for_backward(x2, gamma, mean, rstd)
         ctx.shape, ctx.fork = shape, fork
         ctx.slots = (_grad_slot(gamma), _grad_slot(beta))
@@ -255,7 +298,7 @@ class _LayerNormFn(torch.autograd.Function):
         lib = L.load()
         gres, gy = grads if ctx.fork else (None, grads[0])
         if gy is None:                      # only the skip output was used
-            return gres, None, None, None, None
+            return gres, None, None, None, None, None
         x2, gamma, mean, rstd = ctx.saved_tensors
         T, C_ = x2.shape
         g2 = gy.reshape(-1, C_).contiguous().float()
@@ -266,8 +309,8 @@ class _LayerNormFn(torch.autograd.Function):
         L.check(lib.dlwp_layernorm_bwd_res(L.ptr(x2), L.ptr(gamma.contiguous()), L.ptr(mean), L.ptr(rstd), L.ptr(g2),
                                            L.ptr(r2), L.ptr(gx), L.ptr(gg), L.ptr(gb), T, C_, L.stream()))
         if fused:
-            return gx.reshape(ctx.shape), None, None, None, None
-        return gx.reshape(ctx.shape), gg, gb, None, None
+            return gx.reshape(ctx.shape), None, None, None, None, None
+        return gx.reshape(ctx.shape), gg, gb, None, None, None
 
 
 class _ScaleRowsAddFn(torch.autograd.Function):
@@ -345,9 +388,9 @@ def add_pos_embed(tokens, pos):
     return _AddBcastFn.apply(tokens, pos)
 
 
-def norm_fork(norm, x):
+def norm_fork(norm, x, gemm_input=False):
     """(skip, norm(x)) of a pre-norm residual block; LayerNorm.fork where the norm layer offers it."""
-    return norm.fork(x) if hasattr(norm, "fork") else (x, norm(x))
+    return norm.fork(x, gemm_input) if hasattr(norm, "fork") else (x, norm(x))
 
 
 class DropPath(nn.Module):
@@ -472,12 +515,13 @@ class Linear(nn.Linear):
 
 
 class LayerNorm(nn.LayerNorm):
-    def forward(self, x):
-        return _LayerNormFn.apply(x, self.weight, self.bias, float(self.eps))
+    def forward(self, x, gemm_input=False):
+        return _LayerNormFn.apply(x, self.weight, self.bias, float(self.eps), False, gemm_input)
 
-    def fork(self, x):
-        """(x, norm(x)) for a pre-norm residual block: use the first item as the skip connection (see _LayerNormFn)."""
-        return _LayerNormFn.apply(x, self.weight, self.bias, float(self.eps), True)
+    def fork(self, x, gemm_input=False):
+        """(x, norm(x)) for a pre-norm residual block: use the first item as the skip connection (see _LayerNormFn).
+        gemm_input=True: nothing but GEMMs (Linear / Mlp) reads norm(x); it may then be stored as bf16 (lib.set_storage)."""
+        return _LayerNormFn.apply(x, self.weight, self.bias, float(self.eps), True, gemm_input)
 
 
 class Mlp(nn.Module):

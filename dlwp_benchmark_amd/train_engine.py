@@ -37,7 +37,21 @@ def flatten_parameters(module):
         flat[o:o + p.numel()].copy_(p.data.reshape(-1))
         p.data = flat[o:o + p.numel()].view(p.shape)
         p.grad = grad[o:o + p.numel()].view(p.shape)
+    if L.storage_bf16():
+        # the bf16 copy the GEMMs read (lib.shadow): same offsets, refreshed from the fp32 master weights by one cast launch
+        # at the top of every step (refresh_bf16_weights)
+        flat16 = torch.zeros(n, device=dev, dtype=torch.bfloat16)
+        for p, o in zip(params, offs):
+            p._dlwp_bf16 = flat16[o:o + p.numel()].view(p.shape)
+        module._dlwp_flat16 = (flat, flat16)
     return flat, grad
+
+
+def refresh_bf16_weights(module):
+    pair = getattr(module, "_dlwp_flat16", None)
+    if pair is not None:
+        flat, flat16 = pair
+        L.check(L.load().dlwp_cast_bf16(L.ptr(flat), L.ptr(flat16), flat.numel(), L.stream()))
 
 
 class _SqErr(torch.autograd.Function):
@@ -93,9 +107,14 @@ class GraphedTrainStep:
             self._capture()
 
     def _fwd_bwd(self):
-        out = self.call(self.model, self.inputs)
-        loss = mse_loss(out, self.target)
-        loss.backward()
+        refresh_bf16_weights(self.model)          # no-op unless lib.set_storage("bf16") was active at construction
+        prev, L.SHADOW_ACTIVE = L.SHADOW_ACTIVE, True
+        try:
+            out = self.call(self.model, self.inputs)
+            loss = mse_loss(out, self.target)
+            loss.backward()
+        finally:
+            L.SHADOW_ACTIVE = prev
         self.loss.copy_(loss.detach())
 
     def _optimize(self):

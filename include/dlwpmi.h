@@ -383,6 +383,24 @@ int dlwp_gemm_batched(const float* A, const float* B, float* C, int M, int N, in
                       const float* bias, long long sBi1, long long sBi2, int act, float act_param,
                       float* preact, const float* residual, long long sR1, long long sR2,
                       int res_before_act, int accumulate, void* stream);
+/* bf16 STORAGE for the token GEMMs (BASELINE configs C3-C5 train under bf16 autocast: activations and the   */
+/* weights the matrix units read are bf16 in the reference, src/dlwpbench/scripts/train.py:120-135 autocast).   */
+/* dlwp_gemm / dlwp_gemm_batched with a storage mask `dtypes`: 1 = A, 2 = B, 4 = C and preact, 8 = residual   */
+/* point at bf16 (2-byte) arrays; leading dimensions and batch strides stay in ELEMENTS.  Products accumulate  */
+/* in fp32 and the epilogue (bias, activation, residual) runs in fp32 before the output is rounded.  A bf16    */
+/* output cannot be accumulated into and is never split along K.  Unset bits are fp32 as before.               */
+int dlwp_gemm_mixed(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb,
+                    int ldc, int transA, int transB, const float* bias, int act, void* preact,
+                    const void* residual, int accumulate, float* rowsum, int dtypes, void* stream);
+int dlwp_gemm_batched_mixed(const void* A, const void* B, void* C, int M, int N, int K, int lda,
+                            int ldb, int ldc, int transA, int transB, int nb1, int nb2,
+                            long long sA1, long long sA2, long long sB1, long long sB2,
+                            long long sC1, long long sC2, const float* bias, long long sBi1,
+                            long long sBi2, int act, float act_param, void* preact,
+                            const void* residual, long long sR1, long long sR2, int res_before_act,
+                            int accumulate, int dtypes, void* stream);
+/* dst[i] = bf16(src[i]) (round to nearest even): the per-step bf16 copy of the flat fp32 master weights.     */
+int dlwp_cast_bf16(const float* src, void* dst, long long n, void* stream);
 /* Fused real spherical harmonic transforms on channels-last fields (torch_harmonics.RealSHT /  */
 /* InverseRealSHT, constructed at src/dlwpbench/models/fno/fno.py:183-200 and                   */
 /* models/fourcastnet/fourcastnet.py:411-428): longitude DFT and Legendre   */
@@ -412,6 +430,10 @@ int dlwp_cweight_fold(const float* gexp, float* gw, int Cin, int Cout, int L, vo
 /* LayerNorm over the last dimension of x [T,C]; mean/rstd [T] are saved for backward.       */
 int dlwp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                        float* mean, float* rstd, int T, int C, float eps, void* stream);
+/* The same with the output stored as bf16 (y_bf16 != 0: y is a 2-byte array) for LayerNorms whose only   */
+/* reader is a GEMM under bf16 storage (dlwp_gemm_mixed); statistics and the backward pass stay fp32.       */
+int dlwp_layernorm_fwd_ex(const float* x, const float* gamma, const float* beta, void* y, float* mean,
+                          float* rstd, int T, int C, float eps, int y_bf16, void* stream);
 /* gx written; ggamma/gbeta ACCUMULATED into.  C <= 2048.                                    */
 int dlwp_layernorm_bwd(const float* x, const float* gamma, const float* mean, const float* rstd,
                        const float* gy, float* gx, float* ggamma, float* gbeta, int T, int C,

@@ -1,0 +1,150 @@
+"""bf16 STORAGE for the token GEMMs (dlwp_gemm_mixed, dlwp_cast_bf16, lib.set_storage): a bf16 array in memory must give
+exactly what the bf16-operand GEMM gives on the same values held in fp32 (the matrix units round the operands to bf16 either
+way), outputs are the fp32 results rounded once, and a train step with bf16 hidden activations + the engine's bf16 weight copy
+stays within bf16 rounding of the fp32-storage step."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def _call(lib, L, A, B, C, M, N, K, tA, tB, bias, act, preact, residual, dt):
+    lda = A.shape[1]
+    ldb = B.shape[1]
+    L.check(lib.dlwp_gemm_mixed(L.ptr(A), L.ptr(B), L.ptr(C), M, N, K, lda, ldb, N, tA, tB, L.ptr(bias), act, L.ptr(preact),
+                                L.ptr(residual), 0, None, dt, L.stream()))
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 192, 128), (100, 72, 52), (77, 29, 13), (64, 256, 1000)])
+@pytest.mark.parametrize("tA,tB", [(0, 1), (0, 0), (1, 0), (1, 1)])
+def test_gemm_mixed_equals_fp32_storage_of_rounded_values(cuda, M, N, K, tA, tB):
+    from dlwp_benchmark_amd import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + N + K + 2 * tA + tB)
+    A = torch.randn((K, M) if tA else (M, K), generator=g).to(cuda)
+    B = torch.randn((N, K) if tB else (K, N), generator=g).to(cuda)
+    bias = torch.randn(N, generator=g).to(cuda)
+    res = torch.randn(M, N, generator=g).to(cuda)
+    A16, B16, R16 = A.to(BF), B.to(BF), res.to(BF)
+    with L.gemm_precision("bf16"):
+        # reference: fp32 arrays holding the bf16-rounded values, fp32 outputs
+        C0, Z0 = torch.empty(M, N, device=cuda), torch.empty(M, N, device=cuda)
+        _call(lib, L, A16.float(), B16.float(), C0, M, N, K, tA, tB, bias, 1, Z0, R16.float(), 0)
+        for dt in (1, 2, 3, 4, 8, 15, 7, 11):
+            a = A16 if dt & 1 else A16.float()
+            b = B16 if dt & 2 else B16.float()
+            r = R16 if dt & 8 else R16.float()
+            C = torch.empty(M, N, device=cuda, dtype=BF if dt & 4 else torch.float32)
+            Z = torch.empty_like(C)
+            _call(lib, L, a, b, C, M, N, K, tA, tB, bias, 1, Z, r, dt)
+            if dt & 4:
+                assert torch.equal(C, C0.to(BF)) and torch.equal(Z, Z0.to(BF)), dt
+            else:
+                assert torch.equal(C, C0) and torch.equal(Z, Z0), dt
+        # act 4 (multiply by GELU'(saved pre-activation)) with a bf16 pre-activation
+        G0 = torch.empty(M, N, device=cuda)
+        Af, Bf, Rf = A16.float(), B16.float(), R16.float()          # kept alive across the launch
+        L.check(lib.dlwp_gemm_batched_mixed(L.ptr(Af), L.ptr(Bf), L.ptr(G0), M, N, K, A.shape[1], B.shape[1], N,
+                                            tA, tB, 1, 1, 0, 0, 0, 0, 0, 0, None, 0, 0, 4, 0.0, None, L.ptr(Rf), 0, 0,
+                                            0, 0, 0, L.stream()))
+        G = torch.empty(M, N, device=cuda, dtype=BF)
+        L.check(lib.dlwp_gemm_batched_mixed(L.ptr(A16), L.ptr(B16), L.ptr(G), M, N, K, A.shape[1], B.shape[1], N, tA, tB, 1, 1,
+                                            0, 0, 0, 0, 0, 0, None, 0, 0, 4, 0.0, None, L.ptr(R16), 0, 0, 0, 0, 15, L.stream()))
+        assert torch.equal(G, G0.to(BF))
+
+
+def test_gemm_mixed_batched_strides_are_elements(cuda):
+    from dlwp_benchmark_amd import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(5)
+    nb, M, N, K = 3, 40, 24, 36
+    A = torch.randn(nb, M, K, generator=g).to(cuda).to(BF)
+    B = torch.randn(nb, N, K, generator=g).to(cuda).to(BF)
+    C = torch.empty(nb, M, N, device=cuda, dtype=BF)
+    with L.gemm_precision("bf16"):
+        L.check(lib.dlwp_gemm_batched_mixed(L.ptr(A), L.ptr(B), L.ptr(C), M, N, K, K, K, N, 0, 1, nb, 1, M * K, 0, N * K, 0,
+                                            M * N, 0, None, 0, 0, 0, 0.0, None, None, 0, 0, 0, 0, 7, L.stream()))
+    ref = torch.einsum("bmk,bnk->bmn", A.double(), B.double())
+    assert ((C.double() - ref).abs().max() / ref.abs().max()).item() < 1e-2      # one bf16 rounding of the output
+
+
+def test_gemm_mixed_refuses_accumulating_into_bf16(cuda):
+    from dlwp_benchmark_amd import lib as L
+    lib = L.load()
+    A = torch.zeros(8, 8, device=cuda)
+    C = torch.zeros(8, 8, device=cuda, dtype=BF)
+    rc = lib.dlwp_gemm_mixed(L.ptr(A), L.ptr(A), L.ptr(C), 8, 8, 8, 8, 8, 8, 0, 1, None, 0, None, None, 1, None, 4, L.stream())
+    assert rc != 0 and b"fp32 output" in lib.dlwp_last_error()
+
+
+@pytest.mark.parametrize("n", [1, 7, 4096, 100003])
+def test_cast_bf16_rounds_like_torch(cuda, n):
+    from dlwp_benchmark_amd import lib as L
+    g = torch.Generator().manual_seed(n)
+    x = (torch.randn(n, generator=g) * 10 ** torch.randint(-6, 6, (n,), generator=g).float()).to(cuda)
+    y = torch.empty(n, device=cuda, dtype=BF)
+    L.check(L.load().dlwp_cast_bf16(L.ptr(x), L.ptr(y), n, L.stream()))
+    assert torch.equal(y, x.to(BF))
+
+
+class _Toy(torch.nn.Module):
+    """LayerNorm -> token MLP (+ residual) -> linear head: the building blocks whose storage changes."""
+
+    def __init__(self, E=64, Hd=256, out=8):
+        super().__init__()
+        from dlwp_benchmark_amd.token_ops import LayerNorm, Linear, Mlp
+        self.norm, self.mlp, self.head = LayerNorm(E), Mlp(E, Hd), Linear(E, out)
+
+    def forward(self, x):
+        skip, t = self.norm.fork(x)
+        return self.head(self.mlp(t, residual=skip))
+
+
+def test_train_step_with_bf16_storage_tracks_fp32_storage(cuda):
+    """Same bf16-operand arithmetic, hidden activations / weight copies stored as bf16: the losses of a few Adam steps agree
+    with the fp32-storage run to bf16 rounding, and the stored tensors really are bf16."""
+    from dlwp_benchmark_amd import lib as L, token_ops
+    from dlwp_benchmark_amd.train_engine import GraphedTrainStep
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(4, 300, 64, generator=g).to(cuda)
+    y = torch.randn(4, 300, 8, generator=g).to(cuda)
+    losses = {}
+    seen = {"fp32": set(), "bf16": set()}
+    orig = token_ops._gemm
+    mode = "fp32"
+
+    def spy(A, B, C, *a, **kw):
+        seen[mode].add((A.dtype, B.dtype, C.dtype))
+        return orig(A, B, C, *a, **kw)
+    with L.gemm_precision("bf16"):
+        for mode in ("fp32", "bf16"):
+            L.set_storage(mode)
+            try:
+                torch.manual_seed(0)
+                m = _Toy().to(cuda)
+                token_ops._gemm = spy
+                step = GraphedTrainStep(m, {"x": x}, y, lr=1e-2)
+                losses[mode] = [step().item() for _ in range(6)]
+                if mode == "bf16":
+                    w = m.mlp.fc1.weight
+                    assert w._dlwp_bf16.dtype == BF and w._dlwp_bf16.shape == w.shape and w._dlwp_bf16.abs().sum().item() > 0
+                    # the copy is refreshed at the top of a step: it holds the weights the LAST step started from
+                    assert ((w._dlwp_bf16.float() - w.detach()).abs().max() < 0.05).item()
+            finally:
+                token_ops._gemm = orig
+                L.set_storage("fp32")
+    f32 = torch.float32
+    assert seen["fp32"] == {(f32, f32, f32)}
+    # fc1: x (fp32) . W1 (bf16 copy) -> h (bf16);  fc2: h . W2 -> y (fp32);  gx: gh (bf16) . W1;  gW1: gh^T x;  gW2: g^T h
+    assert {(f32, BF, BF), (BF, BF, f32), (BF, f32, f32), (f32, BF, f32)} <= seen["bf16"]
+    a, b = torch.tensor(losses["fp32"]), torch.tensor(losses["bf16"])
+    assert a[-1] < a[0]                       # it trains
+    assert ((a - b).abs() / a).max().item() < 2e-2, (losses["fp32"], losses["bf16"])
+
+
+def test_bf16_storage_needs_bf16_operands(cuda):
+    from dlwp_benchmark_amd import lib as L
+    with pytest.raises(L.DlwpError):
+        L.set_storage("bf16")

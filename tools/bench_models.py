@@ -19,6 +19,7 @@ from dlwp_benchmark_amd.train_engine import GraphedTrainStep  # noqa: E402
 
 
 PRECISION = "fp32"
+STORAGE = "fp32"
 
 
 def run(name, model, make_batch, steps, warmup=3, use_graph=True, call=None, lr=1e-3):
@@ -34,7 +35,7 @@ def run(name, model, make_batch, steps, warmup=3, use_graph=True, call=None, lr=
         loss = step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps({"model": name, "graph": use_graph, "gemm_precision": PRECISION, "samples_per_s": round(B * steps / dt, 2),
+    print(json.dumps({"model": name, "graph": use_graph, "gemm_precision": PRECISION, "storage": STORAGE, "samples_per_s": round(B * steps / dt, 2),
                       "ms_per_step": round(dt / steps * 1e3, 3), "batch": B, "loss": loss.item(),
                       "n_params": sum(p.numel() for p in model.parameters())}), flush=True)
 
@@ -46,9 +47,15 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="GEMM operand precision (bf16: the reference's autocast arithmetic for C3-C5; fp32 accumulation)")
+    ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16: hidden activations of the token MLPs and a per-step copy of the weights live in HBM as bf16 "
+                         "(needs --precision bf16)")
     a = ap.parse_args()
     from dlwp_benchmark_amd import lib as L
     L.set_gemm_precision(a.precision)
+    L.set_storage(a.storage)
+    global STORAGE
+    STORAGE = a.storage
     global PRECISION
     PRECISION = a.precision
     g = torch.Generator().manual_seed(1234)
