@@ -689,10 +689,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g
 // With both operands stored as bf16 (16-byte loads, 4 staging registers per operand) the picture changes for deep products:
 // profiles/r02_gemm_bench.txt, 16200 x 3072 x 768: 395 -> 479 TFLOP/s, 16200 x 768 x 3072 (gx): 438 -> 656; at K = 256-512
 // (SFNO) the 128 tile still loses (264 -> 176), so it is taken from K = 768 on.
-static int gemm_tile_for(int M, int N, long long nbatch, int K = 0, int dt = 0) {
+// can_split: no epilogue, so a long K may be cut into slices (weight gradients: few output tiles, K = tokens) -- the slices
+// fill the chip where the tiles alone would not.
+static int gemm_tile_for(int M, int N, long long nbatch, int K = 0, int dt = 0, bool can_split = false) {
     static const int forced = [] { const char* e = getenv("DLWP_GEMM_TILE"); return e ? (atoi(e) == 128 ? 2 : 1) : 0; }();
     if (M < 128 || N < 128) return 1;
-    const bool fills = (long long)ceil_div(M, 128) * ceil_div(N, 128) * nbatch >= 224;
+    const long long tiles = (long long)ceil_div(M, 128) * ceil_div(N, 128) * nbatch;
+    const bool fills = tiles * (can_split ? std::max(1, K / (4 * BK)) : 1) >= 224;
     if (forced) return forced == 2 && fills ? 2 : 1;
     return g_gemm_bf16 && (dt & 3) == 3 && K >= 768 && fills ? 2 : 1;
 }
@@ -770,7 +773,7 @@ static int gemm_impl(const float* A, const float* B, float* C, int M, int N, int
     DLWP_REQUIRE(act == 0 || act == 1, DLWP_E_INVALID, "gemm: act must be 0 (none) or 1 (gelu)");
     if (int drc = dtypes_ok(dt, accumulate, "gemm")) return drc;
     const bool epilogue = bias || act || preact || residual || (dt & DT_C);      // a bf16 output takes no split-K atomics
-    const int T = gemm_tile_for(M, N, 1, K, dt);
+    const int T = gemm_tile_for(M, N, 1, K, dt, !epilogue);
     const int tiles = ceil_div(N, 64 * T) * ceil_div(M, 64 * T);
     int splits = 1;
     if (!epilogue && tiles < 256 && K >= 8 * BK) splits = std::min(ceil_div(512, tiles), K / (4 * BK));
@@ -814,7 +817,7 @@ static int gemm_batched_impl(const float* A, const float* B, float* C, int M, in
     // reductions over a long K with few output tiles (weight gradients of block-diagonal layers): split K inside every
     // batch and combine with float atomics, like the plain entry
     const bool epilogue = bias || act || preact || residual || (dt & DT_C);
-    const int T = gemm_tile_for(M, N, (long long)nb1 * nb2, K, dt);
+    const int T = gemm_tile_for(M, N, (long long)nb1 * nb2, K, dt, !epilogue);
     const long long tiles = (long long)ceil_div(N, 64 * T) * ceil_div(M, 64 * T) * nb1 * nb2;
     int splits = 1;
     if (!epilogue && tiles < 256 && K >= 8 * BK) splits = (int)std::min<long long>(ceil_div(512, (int)tiles), K / (4 * BK));

@@ -25,6 +25,7 @@ constexpr int LDV = 64 + 4;    // transposed tiles [dd][token]: 16-byte aligned 
 struct WaDev {
     const float* qkv;          // [B_, N, 3, heads, d]
     const float* table;        // [(2Wh-1)(2Ww-1), heads]
+    const float* table_t;      // optional: the same table packed as [ntypes][heads][TB] (dlwp_window_attn_pack_table)
     const int* labels;         // [nW, N] or nullptr
     const int *ia, *ib;        // [N] each: bias index of (query q, key k) = ia[q] + ib[k]
     int ntypes;                // bias table is [TB, ntypes, heads]; window type = window index % ntypes
@@ -92,7 +93,12 @@ struct TokVals {
 // this (window type, head)'s slice of the bias table [TB][ntypes][heads] -> LDS.  The slice is a strided gather
 // (one cache line per entry): keep eight loads in flight per thread instead of one.
 __device__ __forceinline__ void load_table(float* tb, const float* __restrict__ table, int TB, long long tstr,
-                                           long long tofs) {
+                                           long long tofs, const float* __restrict__ packed = nullptr) {
+    if (packed) {          // contiguous slice of the packed table: coalesced, TB * 4 bytes instead of TB cache lines
+        const float* src = packed + tofs * TB;
+        for (int i = threadIdx.x; i < TB; i += 256) tb[i] = src[i];
+        return;
+    }
     for (int i0 = threadIdx.x; i0 < TB; i0 += 256 * 16) {
         float v[16];
 #pragma unroll
@@ -127,14 +133,18 @@ __device__ __forceinline__ f32x4 score_chunk(const float* rows_a, int LDT, const
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int NDB>
+// NBUF = 2: key / value tiles double-buffered (the next tile's LDS commit overlaps the current tile's matrix work, one barrier
+// per tile).  NBUF = 1 (windows of at most 128 tokens, i.e. one or two tiles): a single buffer and two barriers per tile --
+// the workgroup needs ~40 % less LDS, so twice as many of them are resident per CU, which is what hides latency when every
+// workgroup is this short (Swin 7 x 7 = 49, Pangu 2 x 7 x 7 = 98 tokens per window: profiles/r02_winattn_probe.txt).
+template <int NDB, int NBUF>
 __global__ __launch_bounds__(256) void winattn_fwd_kernel(WaDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NL = 4 * NDB, LDT = 16 * NDB + 4, DP = 16 * NDB;
     float* Qs = smem;                         // [64][LDT] (scaled)
-    float* Kb = Qs + 64 * LDT;                // [2][64][LDT]
-    float* Vt = Kb + 2 * 64 * LDT;            // [2][DP][LDV]   v transposed
-    int* klab = reinterpret_cast<int*>(Vt + 2 * DP * LDV);   // [2][64]
+    float* Kb = Qs + 64 * LDT;                // [NBUF][64][LDT]
+    float* Vt = Kb + NBUF * 64 * LDT;         // [NBUF][DP][LDV]   v transposed
+    int* klab = reinterpret_cast<int*>(Vt + NBUF * DP * LDV);   // [2][64]
     int* kbs = klab + 128;                                   // [2][64] key part of the bias index
     float* tb = reinterpret_cast<float*>(kbs + 128);         // [TB] bias table of this head
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
@@ -166,9 +176,9 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(WaDev a) {
     tq.issue(qb, rs, qt * QT, a.N, a.d, a.dd);
     issue_tile(0);
     // zero the tiles once: padded columns (dd >= d) stay zero for the whole kernel
-    for (int i = tid; i < (3 * 64 * LDT + 2 * DP * LDV) / 4; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < ((1 + NBUF) * 64 * LDT + NBUF * DP * LDV) / 4; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const long long tofs = (long long)(wdw % a.ntypes) * a.heads + head, tstr = (long long)a.ntypes * a.heads;
-    load_table(tb, a.table, a.TB, tstr, tofs);
+    load_table(tb, a.table, a.TB, tstr, tofs, a.table_t);
     const int q = qt * QT + w * 16 + r;                       // this lane's query (column)
     const int qc = q < a.N ? q : a.N - 1;                      // clamped for table indexing
     const int qa = a.ia[qc];
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(WaDev a) {
     for (int db = 0; db < NDB; ++db) oacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int buf = 0;
-    for (int kt0 = 0; kt0 < a.N; kt0 += KT, buf ^= 1) {
+    for (int kt0 = 0; kt0 < a.N; kt0 += KT, buf = NBUF == 2 ? buf ^ 1 : 0) {
         const bool more = kt0 + KT < a.N;
         if (more) issue_tile(kt0 + KT);
         const float* Kc = Kb + buf * 64 * LDT;
@@ -230,7 +240,8 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(WaDev a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) oacc[db] = mfma16_chunk(ldsv(&Vc[(16 * db + r) * LDV + 16 * c + 4 * g]), s[c], oacc[db]);
         }
-        if (more) commit_tile(kt0 + KT, buf ^ 1);
+        if (NBUF == 1) __syncthreads();          // every wave is done reading the tile that is about to be overwritten
+        if (more) commit_tile(kt0 + KT, NBUF == 2 ? buf ^ 1 : 0);
         __syncthreads();
     }
     if (q < a.N) {
@@ -248,18 +259,19 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(WaDev a) {
 
 // ------------------------------------------------------------------------------------------------
 // backward, query side: dQ, dBias, D.  Same tiling as forward.
-template <int NDB>
+template <int NDB, int NBUF>
 __global__ __launch_bounds__(256) void winattn_bwd_q_kernel(WaDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NL = 4 * NDB, LDT = 16 * NDB + 4, DP = 16 * NDB;
-    float* Kb = smem;                         // [2][64][LDT]
-    float* Vb = Kb + 2 * 64 * LDT;            // [2][64][LDT]
-    float* Kt = Vb + 2 * 64 * LDT;            // [2][DP][LDV]  k transposed (A operand of dQ)
+    float* Kb = smem;                         // [NBUF][64][LDT]
+    float* Vb = Kb + NBUF * 64 * LDT;         // [NBUF][64][LDT]
+    float* Kt = Vb + NBUF * 64 * LDT;         // [NBUF][DP][LDV]  k transposed (A operand of dQ)
     // q (scaled) and dO rows of the query tile are only needed until their MFMA fragments sit in registers: they
-    // borrow the second K / V buffers, which the pipeline first writes at the end of iteration 0
-    float* Qs = Kb + 64 * LDT;                // [64][LDT]
-    float* Gs = Vb + 64 * LDT;                // [64][LDT]
-    int* klab = reinterpret_cast<int*>(Kt + 2 * DP * LDV);
+    // borrow the second K / V buffers, which the pipeline first writes at the end of iteration 0 (NBUF = 1: the only
+    // buffers, and key tile 0 is committed after the fragments are out)
+    float* Qs = Kb + (NBUF - 1) * 64 * LDT;   // [64][LDT]
+    float* Gs = Vb + (NBUF - 1) * 64 * LDT;   // [64][LDT]
+    int* klab = reinterpret_cast<int*>(Kt + NBUF * DP * LDV);
     int* kbs = klab + 128;
     float* tb = reinterpret_cast<float*>(kbs + 128);     // [TB] bias table
     unsigned long long* gtb = reinterpret_cast<unsigned long long*>(tb + ((a.TB + 1) & ~1));   // [TB] fixed-point partial
@@ -295,10 +307,10 @@ __global__ __launch_bounds__(256) void winattn_bwd_q_kernel(WaDev a) {
     tg.issue(gbase, os, qt * QT, a.N, a.d, a.dd);
     issue_tile(0);
     DLWP_STAMP(13);
-    for (int i = tid; i < (4 * 64 * LDT + 2 * DP * LDV) / 4; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < (2 * NBUF * 64 * LDT + NBUF * DP * LDV) / 4; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     DLWP_STAMP(14);
     const long long tofs = (long long)(wdw % a.ntypes) * a.heads + head, tstr = (long long)a.ntypes * a.heads;
-    load_table(tb, a.table, a.TB, tstr, tofs);
+    load_table(tb, a.table, a.TB, tstr, tofs, a.table_t);
     DLWP_STAMP(15);
     for (int i = tid; i < a.TB; i += 256) gtb[i] = 0ull;
     DLWP_STAMP(16);
@@ -315,7 +327,7 @@ __global__ __launch_bounds__(256) void winattn_bwd_q_kernel(WaDev a) {
     DLWP_STAMP(2);
     tq.commit(Qs, LDT, nullptr, qt * QT, a.N, a.d, a.dd, a.scale);
     tg.commit(Gs, LDT, nullptr, qt * QT, a.N, a.d, a.dd, 1.f);
-    commit_tile(0, 0);
+    if (NBUF == 2) commit_tile(0, 0);
     __syncthreads();
     DLWP_STAMP(3);
     // D[q] = sum_dd dO[q][dd] * O[q][dd]
@@ -333,10 +345,14 @@ __global__ __launch_bounds__(256) void winattn_bwd_q_kernel(WaDev a) {
         dq[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();                          // Qs / Gs are dead from here on (their storage is tile buffer 1)
+    if (NBUF == 1) {                          // ... or the only buffer: key tile 0 goes in now
+        commit_tile(0, 0);
+        __syncthreads();
+    }
 
     DLWP_STAMP(4);
     int buf = 0;
-    for (int kt0 = 0; kt0 < a.N; kt0 += KT, buf ^= 1) {
+    for (int kt0 = 0; kt0 < a.N; kt0 += KT, buf = NBUF == 2 ? buf ^ 1 : 0) {
         const bool more = kt0 + KT < a.N;
         if (kt0 == 0) DLWP_STAMP(5);
         if (more) issue_tile(kt0 + KT);
@@ -367,7 +383,8 @@ __global__ __launch_bounds__(256) void winattn_bwd_q_kernel(WaDev a) {
             for (int db = 0; db < NDB; ++db) dq[db] = mfma16_chunk(ldsv(&Ktc[(16 * db + r) * LDV + 16 * c + 4 * g]), ds, dq[db]);
         }
         if (kt0 == 0) DLWP_STAMP(7);
-        if (more) commit_tile(kt0 + KT, buf ^ 1);
+        if (NBUF == 1) __syncthreads();
+        if (more) commit_tile(kt0 + KT, NBUF == 2 ? buf ^ 1 : 0);
         if (kt0 == 0) DLWP_STAMP(8);
         __syncthreads();
         if (kt0 == 0) DLWP_STAMP(9);
@@ -414,19 +431,20 @@ __global__ __launch_bounds__(256) void winattn_fold_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------------------
 // backward, key side: dK, dV.  One workgroup = 64 keys (wave = 16 keys as columns), loops over query tiles.
-template <int NDB>
+template <int NDB, int NBUF>
 __global__ __launch_bounds__(256) void winattn_bwd_kv_kernel(WaDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NL = 4 * NDB, LDT = 16 * NDB + 4, DP = 16 * NDB;
-    float* Qb = smem;                         // [2][64][LDT] scaled q rows of the current query tile
-    float* Gb = Qb + 2 * 64 * LDT;            // [2][64][LDT]
+    float* Qb = smem;                         // [NBUF][64][LDT] scaled q rows of the current query tile
+    float* Gb = Qb + NBUF * 64 * LDT;         // [NBUF][64][LDT]
     // this workgroup's k / v rows are only needed until their fragments sit in registers: they borrow the second
-    // q / dO buffers, which the pipeline first writes at the end of iteration 0
-    float* Ks = Qb + 64 * LDT;                // [64][LDT]
-    float* Vs = Gb + 64 * LDT;                // [64][LDT]
-    float* Qt = Gb + 2 * 64 * LDT;            // [2][DP][LDV]
-    float* Gt = Qt + 2 * DP * LDV;            // [2][DP][LDV]
-    float* lses = Gt + 2 * DP * LDV;          // [2][64]
+    // q / dO buffers, which the pipeline first writes at the end of iteration 0 (NBUF = 1: the only buffers; query tile 0
+    // is committed after the fragments are out)
+    float* Ks = Qb + (NBUF - 1) * 64 * LDT;   // [64][LDT]
+    float* Vs = Gb + (NBUF - 1) * 64 * LDT;   // [64][LDT]
+    float* Qt = Gb + NBUF * 64 * LDT;         // [NBUF][DP][LDV]
+    float* Gt = Qt + NBUF * DP * LDV;         // [NBUF][DP][LDV]
+    float* lses = Gt + NBUF * DP * LDV;       // [2][64]
     float* dss = lses + 128;                  // [2][64]
     int* qlabs = reinterpret_cast<int*>(dss + 128);   // [2][64]
     int* qas = qlabs + 128;                           // [2][64] query part of the bias index
@@ -465,9 +483,9 @@ __global__ __launch_bounds__(256) void winattn_bwd_kv_kernel(WaDev a) {
     tk.issue(qb + a.heads * a.d, rs, kt * KT, a.N, a.d, a.dd);
     tv.issue(qb + 2 * a.heads * a.d, rs, kt * KT, a.N, a.d, a.dd);
     issue_tile(0);
-    for (int i = tid; i < (4 * 64 * LDT + 4 * DP * LDV) / 4; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < (2 * NBUF * 64 * LDT + 2 * NBUF * DP * LDV) / 4; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const long long tofs = (long long)(wdw % a.ntypes) * a.heads + head, tstr = (long long)a.ntypes * a.heads;
-    load_table(tb, a.table, a.TB, tstr, tofs);
+    load_table(tb, a.table, a.TB, tstr, tofs, a.table_t);
     const int key = kt * KT + w * 16 + r;                     // this lane's key (column)
     const int kc = key < a.N ? key : a.N - 1;
     const int kbv = a.ib[kc];
@@ -475,7 +493,7 @@ __global__ __launch_bounds__(256) void winattn_bwd_kv_kernel(WaDev a) {
     __syncthreads();
     tk.commit(Ks, LDT, nullptr, kt * KT, a.N, a.d, a.dd, 1.f);
     tv.commit(Vs, LDT, nullptr, kt * KT, a.N, a.d, a.dd, 1.f);
-    commit_tile(0, 0);
+    if (NBUF == 2) commit_tile(0, 0);
     __syncthreads();
     f32x4 kf[NDB], vf[NDB], dk[NDB], dv[NDB];
 #pragma unroll
@@ -486,9 +504,13 @@ __global__ __launch_bounds__(256) void winattn_bwd_kv_kernel(WaDev a) {
         dv[cc] = dk[cc];
     }
     __syncthreads();                          // Ks / Vs are dead from here on (their storage is tile buffer 1)
+    if (NBUF == 1) {
+        commit_tile(0, 0);
+        __syncthreads();
+    }
 
     int buf = 0;
-    for (int qt0 = 0; qt0 < a.N; qt0 += QT, buf ^= 1) {
+    for (int qt0 = 0; qt0 < a.N; qt0 += QT, buf = NBUF == 2 ? buf ^ 1 : 0) {
         const bool more = qt0 + QT < a.N;
         if (more) issue_tile(qt0 + QT);
         const float* Qc = Qb + buf * 64 * LDT;
@@ -520,7 +542,8 @@ __global__ __launch_bounds__(256) void winattn_bwd_kv_kernel(WaDev a) {
                 dk[db] = mfma16_chunk(ldsv(&Qtc[(16 * db + r) * LDV + 16 * c + 4 * g]), ds, dk[db]);   // dK^T += (scale q)^T dS
             }
         }
-        if (more) commit_tile(qt0 + QT, buf ^ 1);
+        if (NBUF == 1) __syncthreads();
+        if (more) commit_tile(qt0 + QT, NBUF == 2 ? buf ^ 1 : 0);
         __syncthreads();
     }
     if (key < a.N) {
@@ -552,60 +575,101 @@ int wa_setup(WaDev& a, int B_, int nW, int N, int TB, int ntypes, int heads, int
 
 }  // namespace
 
-extern "C" int dlwp_window_attn_fwd(const float* qkv, const float* bias_table, const int* ia, const int* ib,
-                                    const int* labels, float* out, float* lse, int B_, int nW, int N, int TB,
-                                    int ntypes, int heads, int d, float scale, void* stream) {
+namespace {
+__global__ __launch_bounds__(256) void pack_table_kernel(const float* __restrict__ table, float* __restrict__ packed, int TB, int TH) {
+    // packed[th][t] = table[t][th]; a 32 x 32 tile through LDS so that both sides are coalesced
+    __shared__ float tile[32][33];
+    const int t0 = blockIdx.x * 32, h0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int t = t0 + j, h = h0 + tx;
+        tile[j][tx] = (t < TB && h < TH) ? table[(long long)t * TH + h] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int h = h0 + j, t = t0 + tx;
+        if (t < TB && h < TH) packed[(long long)h * TB + t] = tile[tx][j];
+    }
+}
+}  // namespace
+
+extern "C" int dlwp_window_attn_pack_table(const float* bias_table, float* packed, int TB, int ntypes, int heads, void* stream) {
+    DLWP_REQUIRE(bias_table && packed && TB > 0 && ntypes > 0 && heads > 0, DLWP_E_INVALID, "window_attn_pack_table: bad argument");
+    const int TH = ntypes * heads;
+    hipLaunchKernelGGL(pack_table_kernel, dim3((TB + 31) / 32, (TH + 31) / 32), dim3(256), 0, (hipStream_t)stream, bias_table,
+                       packed, TB, TH);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_window_attn_fwd_packed(const float* qkv, const float* bias_table, const float* packed_table, const int* ia,
+                                           const int* ib, const int* labels, float* out, float* lse, int B_, int nW, int N,
+                                           int TB, int ntypes, int heads, int d, float scale, void* stream) {
     DLWP_REQUIRE(qkv && bias_table && ia && ib && out && lse, DLWP_E_INVALID, "window_attn_fwd: NULL argument");
     WaDev a{};
+    a.table_t = packed_table;
     int rc = wa_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, "window_attn_fwd");
     if (rc) return rc;
     a.qkv = qkv; a.table = bias_table; a.ia = ia; a.ib = ib; a.labels = labels; a.out = out; a.lse = lse;
-    const size_t lds = sizeof(float) * ((size_t)3 * 64 * (a.dp16 + 4) + 2 * a.dp16 * LDV + 256 + a.TB);
+    const int nbuf = N <= 128 ? 1 : 2;         // short windows: single-buffered tiles, more workgroups per CU
+    const size_t lds = sizeof(float) * ((size_t)(1 + nbuf) * 64 * (a.dp16 + 4) + (size_t)nbuf * a.dp16 * LDV + 256 + a.TB);
     const dim3 grid(B_ * heads * ((N + QT - 1) / QT)), block(256);
-#define WA_FWD(NDB)                                                                                                          \
+#define WA_FWD_B(NDB, NB)                                                                                                    \
     do {                                                                                                                  \
-        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_fwd_kernel<NDB>), lds, "window_attn_fwd"))) return rc; \
-        hipLaunchKernelGGL(winattn_fwd_kernel<NDB>, grid, block, lds, (hipStream_t)stream, a);                          \
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_fwd_kernel<NDB, NB>), lds, "window_attn_fwd"))) return rc; \
+        hipLaunchKernelGGL((winattn_fwd_kernel<NDB, NB>), grid, block, lds, (hipStream_t)stream, a);                    \
     } while (0)
+#define WA_FWD(NDB) do { if (nbuf == 1) WA_FWD_B(NDB, 1); else WA_FWD_B(NDB, 2); } while (0)
     switch (a.dp16 / 16) {
         case 1: WA_FWD(1); break;
         case 2: WA_FWD(2); break;
         case 3: WA_FWD(3); break;
         default: WA_FWD(4); break;
     }
+#undef WA_FWD_B
 #undef WA_FWD
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }
 
-extern "C" int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, const int* ia, const int* ib,
-                                    const int* labels, const float* out, const float* lse, const float* gout,
-                                    float* gqkv, float* gbias_table, float* dsum, float* slab, int B_, int nW, int N,
-                                    int TB, int ntypes, int heads, int d, float scale, void* stream) {
+extern "C" int dlwp_window_attn_fwd(const float* qkv, const float* bias_table, const int* ia, const int* ib,
+                                    const int* labels, float* out, float* lse, int B_, int nW, int N, int TB,
+                                    int ntypes, int heads, int d, float scale, void* stream) {
+    return dlwp_window_attn_fwd_packed(qkv, bias_table, nullptr, ia, ib, labels, out, lse, B_, nW, N, TB, ntypes, heads, d, scale,
+                                       stream);
+}
+
+extern "C" int dlwp_window_attn_bwd_packed(const float* qkv, const float* bias_table, const float* packed_table, const int* ia,
+                                           const int* ib, const int* labels, const float* out, const float* lse,
+                                           const float* gout, float* gqkv, float* gbias_table, float* dsum, float* slab, int B_,
+                                           int nW, int N, int TB, int ntypes, int heads, int d, float scale, void* stream) {
     DLWP_REQUIRE(qkv && bias_table && ia && ib && out && lse && gout && gqkv && gbias_table && dsum, DLWP_E_INVALID,
                  "window_attn_bwd: NULL argument");
     WaDev a{};
+    a.table_t = packed_table;
     int rc = wa_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, "window_attn_bwd");
     if (rc) return rc;
     a.qkv = qkv; a.table = bias_table; a.ia = ia; a.ib = ib; a.labels = labels; a.o = out; a.lse_in = lse; a.gout = gout; a.gqkv = gqkv;
     a.gtable = gbias_table; a.dsum = dsum; a.slab = slab;
     const int LDT = a.dp16 + 4;
-    const size_t lds_q = sizeof(float) * ((size_t)4 * 64 * LDT + 2 * a.dp16 * LDV + 256 + 3 * (size_t)((a.TB + 1) & ~1));
-    const size_t lds_kv = sizeof(float) * ((size_t)4 * 64 * LDT + 4 * a.dp16 * LDV + 512 + a.TB);
+    const int nbuf = N <= 128 ? 1 : 2;
+    const size_t lds_q = sizeof(float) * ((size_t)2 * nbuf * 64 * LDT + (size_t)nbuf * a.dp16 * LDV + 256 + 3 * (size_t)((a.TB + 1) & ~1));
+    const size_t lds_kv = sizeof(float) * ((size_t)2 * nbuf * 64 * LDT + (size_t)2 * nbuf * a.dp16 * LDV + 512 + a.TB);
     const dim3 grid(B_ * heads * ((N + QT - 1) / QT)), block(256);
-#define WA_BWD(NDB)                                                                                                             \
+#define WA_BWD_B(NDB, NB)                                                                                                       \
     do {                                                                                                                     \
-        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_bwd_q_kernel<NDB>), lds_q, "window_attn_bwd"))) return rc;  \
-        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_bwd_kv_kernel<NDB>), lds_kv, "window_attn_bwd"))) return rc; \
-        hipLaunchKernelGGL(winattn_bwd_q_kernel<NDB>, grid, block, lds_q, (hipStream_t)stream, a);                         \
-        hipLaunchKernelGGL(winattn_bwd_kv_kernel<NDB>, grid, block, lds_kv, (hipStream_t)stream, a);                       \
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_bwd_q_kernel<NDB, NB>), lds_q, "window_attn_bwd"))) return rc;  \
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_bwd_kv_kernel<NDB, NB>), lds_kv, "window_attn_bwd"))) return rc; \
+        hipLaunchKernelGGL((winattn_bwd_q_kernel<NDB, NB>), grid, block, lds_q, (hipStream_t)stream, a);                   \
+        hipLaunchKernelGGL((winattn_bwd_kv_kernel<NDB, NB>), grid, block, lds_kv, (hipStream_t)stream, a);                 \
     } while (0)
+#define WA_BWD(NDB) do { if (nbuf == 1) WA_BWD_B(NDB, 1); else WA_BWD_B(NDB, 2); } while (0)
     switch (a.dp16 / 16) {
         case 1: WA_BWD(1); break;
         case 2: WA_BWD(2); break;
         case 3: WA_BWD(3); break;
         default: WA_BWD(4); break;
     }
+#undef WA_BWD_B
 #undef WA_BWD
     if (slab) {
         const int nqt = (N + QT - 1) / QT, n_items = (B_ / ntypes) * nqt;
@@ -614,6 +678,14 @@ extern "C" int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, c
     }
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
+}
+
+extern "C" int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, const int* ia, const int* ib,
+                                    const int* labels, const float* out, const float* lse, const float* gout,
+                                    float* gqkv, float* gbias_table, float* dsum, float* slab, int B_, int nW, int N,
+                                    int TB, int ntypes, int heads, int d, float scale, void* stream) {
+    return dlwp_window_attn_bwd_packed(qkv, bias_table, nullptr, ia, ib, labels, out, lse, gout, gqkv, gbias_table, dsum, slab, B_,
+                                       nW, N, TB, ntypes, heads, d, scale, stream);
 }
 
 extern "C" long long dlwp_window_attn_bwd_slab_floats(int B_, int N, int heads, int TB) {

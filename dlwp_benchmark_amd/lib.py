@@ -97,6 +97,9 @@ SIGNATURES = {
     "dlwp_cmode_product_bwd": (_I, [_V] * 5 + [_I] * 4 + [_V]),
     "dlwp_window_attn_fwd": (_I, [_V] * 7 + [_I] * 7 + [_F, _V]),
     "dlwp_window_attn_bwd": (_I, [_V] * 12 + [_I] * 7 + [_F, _V]),
+    "dlwp_window_attn_pack_table": (_I, [_V, _V, _I, _I, _I, _V]),
+    "dlwp_window_attn_fwd_packed": (_I, [_V] * 8 + [_I] * 7 + [_F, _V]),
+    "dlwp_window_attn_bwd_packed": (_I, [_V] * 13 + [_I] * 7 + [_F, _V]),
     "dlwp_window_attn_bwd_slab_floats": (_L, [_I] * 4),
     "dlwp_window_softmax_fwd": (_I, [_V] * 5 + [_I] * 5 + [_F, _V]),
     "dlwp_window_softmax_bwd": (_I, [_V] * 5 + [_I] * 5 + [_F, _V]),

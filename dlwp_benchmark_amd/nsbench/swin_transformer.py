@@ -58,8 +58,15 @@ class _WindowAttnFn(torch.autograd.Function):
             ctx.save_for_backward(qkv, table, p)
             return out
         lse = torch.empty(B_, heads, N, device=qkv.device)
-        L.check(lib.dlwp_window_attn_fwd(L.ptr(qkv), L.ptr(table), L.ptr(ia), L.ptr(ib), L.ptr(labels), L.ptr(out),
-                                         L.ptr(lse), B_, nW, N, TB, ntypes, heads, d, scale, L.stream()))
+        # earth-specific tables ([TB, types, heads]): one transposed copy per call, so that the workgroups read their
+        # (type, head) slice contiguously instead of one cache line per entry
+        packed = None
+        if ntypes > 1:
+            packed = torch.empty(ntypes * heads * TB, device=qkv.device)
+            L.check(lib.dlwp_window_attn_pack_table(L.ptr(table), L.ptr(packed), TB, ntypes, heads, L.stream()))
+        L.check(lib.dlwp_window_attn_fwd_packed(L.ptr(qkv), L.ptr(table), L.ptr(packed), L.ptr(ia), L.ptr(ib), L.ptr(labels),
+                                                L.ptr(out), L.ptr(lse), B_, nW, N, TB, ntypes, heads, d, scale, L.stream()))
+        ctx.packed = packed
         ctx.save_for_backward(qkv, table, out, lse)
         return out
 
@@ -88,9 +95,9 @@ class _WindowAttnFn(torch.autograd.Function):
         gtable = ctx.tslot if ctx.tslot is not None else torch.zeros_like(table)   # kernel accumulates
         dsum = torch.empty_like(lse)
         slab = torch.empty(lib.dlwp_window_attn_bwd_slab_floats(B_, N, heads, TB), device=qkv.device)
-        L.check(lib.dlwp_window_attn_bwd(L.ptr(qkv), L.ptr(table), L.ptr(ia), L.ptr(ib), L.ptr(labels), L.ptr(out),
-                                         L.ptr(lse), L.ptr(g), L.ptr(gqkv), L.ptr(gtable),
-                                         L.ptr(dsum), L.ptr(slab), B_, nW, N, TB, ntypes, heads, d, scale, L.stream()))
+        L.check(lib.dlwp_window_attn_bwd_packed(L.ptr(qkv), L.ptr(table), L.ptr(ctx.packed), L.ptr(ia), L.ptr(ib), L.ptr(labels),
+                                                L.ptr(out), L.ptr(lse), L.ptr(g), L.ptr(gqkv), L.ptr(gtable), L.ptr(dsum),
+                                                L.ptr(slab), B_, nW, N, TB, ntypes, heads, d, scale, L.stream()))
         return gqkv, (None if ctx.tslot is not None else gtable), None, None, None, None, None, None
 
 

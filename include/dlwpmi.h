@@ -255,6 +255,21 @@ int dlwp_window_attn_fwd(const float* qkv, const float* bias_table, const int* i
 /* slab: optional scratch of dlwp_window_attn_bwd_slab_floats() floats -- the workgroups then */
 /* store their bias-gradient partials there and a fold kernel sums them (one atomic per       */
 /* FOLD chunk instead of TB atomics per workgroup); NULL: direct atomics.                     */
+/* Earth-specific tables (Pangu: [TB][window types][heads], a head's slice strided by types*heads floats) make   */
+/* every workgroup gather its slice one cache line per entry.  pack_table writes the transposed copy               */
+/* packed[type][head][TB] once per call; the *_packed entries read contiguous slices from it (packed_table NULL:    */
+/* the strided gather, as in the plain entries).  The gradient still goes to the reference-layout gbias_table.      */
+int dlwp_window_attn_pack_table(const float* bias_table, float* packed, int TB, int ntypes, int heads,
+                                void* stream);
+int dlwp_window_attn_fwd_packed(const float* qkv, const float* bias_table, const float* packed_table,
+                                const int* ia, const int* ib, const int* labels, float* out, float* lse,
+                                int B_, int nW, int N, int TB, int ntypes, int heads, int d, float scale,
+                                void* stream);
+int dlwp_window_attn_bwd_packed(const float* qkv, const float* bias_table, const float* packed_table,
+                                const int* ia, const int* ib, const int* labels, const float* out,
+                                const float* lse, const float* gout, float* gqkv, float* gbias_table,
+                                float* dsum, float* slab, int B_, int nW, int N, int TB, int ntypes,
+                                int heads, int d, float scale, void* stream);
 long long dlwp_window_attn_bwd_slab_floats(int B_, int N, int heads, int TB);
 int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, const int* ia, const int* ib,
                          const int* labels, const float* out, const float* lse, const float* gout,
