@@ -134,3 +134,13 @@ int dlwp_cfmlp_fwd(const float* x, long long x_bs, const float* w1, const float*
 int dlwp_cfmlp_bwd(const float* x, long long x_bs, const float* w1, const float* w2, const float* gy, long long gy_bs,
                    const float* zpre, const float* act, float* gx, long long gx_bs, float* gz, float* gw1, float* gb1, float* gw2,
                    float* gb2, int B, int Cin, int Ch, int Cout, int P, hipStream_t stream, long long x_cs = 0, long long gx_cs = 0);
+
+// csrc/winattn_small.hip: the wave-per-(window, head) attention kernels for many short windows (<= 128 tokens, head_dim <= 32);
+// dlwp_window_attn_fwd / bwd route to them when dlwp_winattn_small_applies().
+bool dlwp_winattn_small_applies(int N, int d, long long pairs);
+int dlwp_winattn_small_fwd(const float* qkv, const float* table, const float* packed, const int* ia, const int* ib,
+                           const int* labels, float* out, float* lse, int B_, int nW, int N, int TB, int ntypes, int heads, int d,
+                           float scale, void* stream);
+int dlwp_winattn_small_bwd(const float* qkv, const float* table, const float* packed, const int* ia, const int* ib,
+                           const int* labels, const float* out, const float* lse, const float* gout, float* gqkv, float* gtable,
+                           int B_, int nW, int N, int TB, int ntypes, int heads, int d, float scale, void* stream);

@@ -14,6 +14,7 @@
 // two N-vectors replace the N x N index tensor; the shift mask is `label[q] != label[k] ? -100 : 0` from a per-window label
 // vector (no N x N mask tensor).  Backward: kernel Q (dQ, dBias, D = rowsum(dO*O)) and kernel KV
 // (dK, dV), each recomputing the score tile it needs.
+#include <cstdlib>
 #include "common.cuh"
 #include "dlwpmi_internal.h"
 
@@ -609,6 +610,9 @@ extern "C" int dlwp_window_attn_fwd_packed(const float* qkv, const float* bias_t
     a.table_t = packed_table;
     int rc = wa_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, "window_attn_fwd");
     if (rc) return rc;
+    if (dlwp_winattn_small_applies(N, d, (long long)B_ * heads) && !getenv("DLWP_WINATTN_TILED"))
+        return dlwp_winattn_small_fwd(qkv, bias_table, packed_table, ia, ib, labels, out, lse, B_, nW, N, TB, ntypes, heads, d,
+                                      scale, stream);
     a.qkv = qkv; a.table = bias_table; a.ia = ia; a.ib = ib; a.labels = labels; a.out = out; a.lse = lse;
     const int nbuf = N <= 128 ? 1 : 2;         // short windows: single-buffered tiles, more workgroups per CU
     const size_t lds = sizeof(float) * ((size_t)(1 + nbuf) * 64 * (a.dp16 + 4) + (size_t)nbuf * a.dp16 * LDV + 256 + a.TB);
@@ -648,6 +652,9 @@ extern "C" int dlwp_window_attn_bwd_packed(const float* qkv, const float* bias_t
     a.table_t = packed_table;
     int rc = wa_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, "window_attn_bwd");
     if (rc) return rc;
+    if (dlwp_winattn_small_applies(N, d, (long long)B_ * heads) && !getenv("DLWP_WINATTN_TILED"))
+        return dlwp_winattn_small_bwd(qkv, bias_table, packed_table, ia, ib, labels, out, lse, gout, gqkv, gbias_table, B_, nW, N,
+                                      TB, ntypes, heads, d, scale, stream);
     a.qkv = qkv; a.table = bias_table; a.ia = ia; a.ib = ib; a.labels = labels; a.o = out; a.lse_in = lse; a.gout = gout; a.gqkv = gqkv;
     a.gtable = gbias_table; a.dsum = dsum; a.slab = slab;
     const int LDT = a.dp16 + 4;

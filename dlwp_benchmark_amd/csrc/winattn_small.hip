@@ -1,0 +1,469 @@
+// Window attention for SHORT windows (N <= 128 tokens: Swin 7 x 7 = 49, Pangu 2 x 7 x 7 = 98), forward and backward, fp32:
+// one WAVE owns one (window, head) and keeps everything in registers.
+//
+// Reference: WindowAttention.forward src/nsbench/models/swintransformer/swin_transformer.py:123-155 (dlwpbench twin :122-154),
+// EarthAttention3D src/dlwpbench/models/panguweather/panguweather.py:166-246:
+//   attn = softmax(q * scale @ k^T + bias_table[index] + mask) @ v.
+//
+// Why a second kernel family next to winattn.hip (64 queries per workgroup, keys streamed through LDS tiles): at these window
+// sizes a workgroup of that design spends its life in prologue latency (LDS zero-fill, tile commits, three barriers per 64
+// keys) for ~100 matrix instructions, 23-59 % of its 64 x 64 tiles are padding, and its 38-86 KB of LDS keep 1-4 workgroups
+// per CU (profiles/r02_winattn_probe.txt: 8436 workgroups, 193 us forward at the Pangu C4 shape = 3 % of the fp32 MFMA rate).
+// Here the operands of every product are MFMA fragments loaded straight from global memory (a window's q, k, v are 5-12 KB:
+// L1 / L2 resident after the first touch), there is no barrier after the shared bias-table slice is staged, a workgroup is
+// four independent waves = four windows of the same (window type, head), and LDS holds the table slice only.
+//
+// Products, all on v_mfma_f32_16x16x4_f32 through the permuted-k chunk of common.cuh, tokens padded to NC chunks of 16:
+//   S^T[key][q] = K Q^T           A = K row fragment, B = Q row fragment          (accumulator: 4 keys x 1 query per lane)
+//   O^T[dd][q]  = V^T P^T         A = V column fragment (4 strided loads), B = the S^T accumulator itself
+// so that a query's softmax statistics live in the four lanes that share r = lane & 15.  The backward pass evaluates the score
+// tile in both orientations (S^T for dQ and dBias, S for dK and dV; swapping the A and B fragments transposes the accumulator),
+// which costs matrix work that this regime has to spare and avoids any transposition through LDS:
+//   dP^T = V dO^T,  dS^T = P^T (dP^T - D),  dQ^T += K^T dS^T ;   dP = dO V^T,  dS = P (dP - D),  dV^T += dO^T P,  dK^T += Q^T dS.
+// dBias partials are summed per workgroup in LDS (64-bit fixed point, see winattn.hip) and flushed with float atomics.
+#include "common.cuh"
+#include "dlwpmi_internal.h"
+
+namespace {
+
+struct WsDev {
+    const float* qkv;          // [B_, N, 3, heads, d]
+    const float* table;        // [TB, ntypes, heads]
+    const float* table_t;      // optional packed copy [ntypes][heads][TB]
+    const int* labels;         // [nW, N] or nullptr
+    const int *ia, *ib;        // bias index of (q, k) = ia[q] + ib[k]
+    float *out, *lse;          // fwd: [B_, N, heads*d], [B_, heads, N]
+    const float *lse_in, *gout, *o;
+    float *gqkv, *gtable;
+    int B_, nW, N, heads, d, TB, ntypes, M, groups;
+    float scale;
+};
+
+__device__ __forceinline__ float col_max4(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
+__device__ __forceinline__ float col_sum4(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
+
+// four consecutive channels dd0 .. dd0+3 of token `tok` (zero beyond the window / the head dimension)
+template <bool VEC>
+__device__ __forceinline__ f32x4 row_frag(const float* __restrict__ base, long long stride, int tok, int N, int dd0, int d) {
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tok < N) {
+        const float* p = base + (long long)tok * stride + dd0;
+        if (VEC) {
+            if (dd0 < d) v = *reinterpret_cast<const f32x4*>(p);       // d % 4 == 0: a vector is whole or absent
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (dd0 + s < d) v[s] = p[s];
+        }
+    }
+    return v;
+}
+// channel dd of the four consecutive tokens tok0 .. tok0+3
+__device__ __forceinline__ f32x4 col_frag(const float* __restrict__ base, long long stride, int tok0, int N, int dd, int d) {
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (dd < d) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (tok0 + s < N) v[s] = base[(long long)(tok0 + s) * stride + dd];
+    }
+    return v;
+}
+
+constexpr float FXS = 1099511627776.f;   // 2^40 (fixed-point dBias partials, see winattn.hip)
+__device__ __forceinline__ void fx_add_s(unsigned long long* acc, float v) {
+    atomicAdd(acc, (unsigned long long)(long long)llrintf(v * FXS));
+}
+
+// workgroup -> (window type, head, group of four windows of that type); wave -> window
+struct Who {
+    int head, ty, b, wdw;
+    bool valid;
+    long long tofs, tstr;
+};
+__device__ __forceinline__ Who who_am_i(const WsDev& a) {
+    Who w;
+    const int grp = blockIdx.x % a.groups, th = blockIdx.x / a.groups;
+    w.ty = th % a.ntypes;
+    w.head = th / a.ntypes;
+    const int m = grp * 4 + wave_id();
+    w.valid = m < a.M;
+    w.b = w.ty + a.ntypes * min(m, a.M - 1);
+    w.wdw = w.b % a.nW;
+    w.tofs = (long long)w.ty * a.heads + w.head;
+    w.tstr = (long long)a.ntypes * a.heads;
+    return w;
+}
+__device__ __forceinline__ void stage_table(float* tb, const WsDev& a, const Who& w) {
+    if (a.table_t) {
+        for (int i = threadIdx.x; i < a.TB; i += 256) tb[i] = a.table_t[w.tofs * a.TB + i];
+    } else {
+        for (int i = threadIdx.x; i < a.TB; i += 256) tb[i] = a.table[(long long)i * w.tstr + w.tofs];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int NC, int NDB, bool VEC>
+__global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tb = smem;                                         // [TB] bias-table slice of this (type, head)
+    const int lane = lane_id(), r = lane & 15, g = lane >> 4;
+    const Who w = who_am_i(a);
+    stage_table(tb, a, w);
+    __syncthreads();
+    if (!w.valid) return;
+    const int N = a.N, d = a.d;
+    const long long rs = 3LL * a.heads * d, os = (long long)a.heads * d;
+    const float* qb = a.qkv + (long long)w.b * N * rs + w.head * d;
+    const float* kb = qb + a.heads * d;
+    const float* vb = qb + 2 * a.heads * d;
+    const int* labw = a.labels ? a.labels + (long long)w.wdw * N : nullptr;
+
+    f32x4 kf[NC][NDB], vt[NDB][NC];
+    int kbi[NC][4], klb[NC][4];
+#pragma unroll
+    for (int kc = 0; kc < NC; ++kc) {
+#pragma unroll
+        for (int cc = 0; cc < NDB; ++cc) kf[kc][cc] = row_frag<VEC>(kb, rs, 16 * kc + r, N, 16 * cc + 4 * g, d);
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) vt[db][kc] = col_frag(vb, rs, 16 * kc + 4 * g, N, 16 * db + r, d);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int key = min(16 * kc + 4 * g + j, N - 1);
+            kbi[kc][j] = a.ib[key];
+            klb[kc][j] = labw ? labw[key] : 0;
+        }
+    }
+#pragma unroll 1
+    for (int qc = 0; qc < NC; ++qc) {
+        if (16 * qc >= N) break;
+        const int q = 16 * qc + r, qcl = min(q, N - 1);
+        const int qa = a.ia[qcl], qlab = labw ? labw[qcl] : 0;
+        f32x4 qf[NDB];
+#pragma unroll
+        for (int cc = 0; cc < NDB; ++cc) {
+            qf[cc] = row_frag<VEC>(qb, rs, q, N, 16 * cc + 4 * g, d);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qf[cc][s] *= a.scale;
+        }
+        f32x4 s[NC];
+        float mx = -1e30f;
+#pragma unroll
+        for (int kc = 0; kc < NC; ++kc) {
+            s[kc] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int cc = 0; cc < NDB; ++cc) s[kc] = mfma16_chunk(kf[kc][cc], qf[cc], s[kc]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = s[kc][j] + tb[qa + kbi[kc][j]];
+                if (labw && klb[kc][j] != qlab) v -= 100.f;
+                v = 16 * kc + 4 * g + j < N ? v : -1e30f;
+                s[kc][j] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+        mx = col_max4(mx);
+        float l = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < NC; ++kc)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float p = __expf(s[kc][j] - mx);
+                s[kc][j] = p;
+                l += p;
+            }
+        l = col_sum4(l);
+        const float inv = 1.f / l;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kc = 0; kc < NC; ++kc) o = mfma16_chunk(vt[db][kc], s[kc], o);
+            const int dd = 16 * db + 4 * g;
+            if (q < N) {
+                float* dst = a.out + ((long long)w.b * N + q) * os + w.head * d + dd;
+                if (VEC) {
+                    if (dd < d) *reinterpret_cast<f32x4*>(dst) = f32x4{o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (dd + j < d) dst[j] = o[j] * inv;
+                }
+            }
+        }
+        if (g == 0 && q < N) a.lse[((long long)w.b * a.heads + w.head) * N + q] = mx + __logf(l);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// Two passes over the (query chunk, key chunk) pairs, both with runtime loops so that only one pair's fragments are live
+// (a single fused pass holds dK^T and dV^T of every key chunk and lands at 256 VGPRs):
+//   pass Q: for each query chunk, over the key chunks: S^T, dP^T -> dS^T -> dQ^T and dBias; D[q] goes to a wave-private LDS row
+//   pass K: for each key chunk, over the query chunks: S, dP -> P, dS -> dV^T, dK^T
+template <int NDB, bool VEC>
+__global__ __launch_bounds__(256) void winattn_small_bwd_kernel(WsDev a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tb = smem;                                                                        // [TB]
+    unsigned long long* gtb = reinterpret_cast<unsigned long long*>(tb + ((a.TB + 1) & ~1));   // [TB] fixed-point dBias partial
+    float* Dw = reinterpret_cast<float*>(gtb + a.TB) + 128 * wave_id();                       // [128] D of this wave's window
+    const int lane = lane_id(), r = lane & 15, g = lane >> 4;
+    const Who w = who_am_i(a);
+    stage_table(tb, a, w);
+    for (int i = threadIdx.x; i < a.TB; i += 256) gtb[i] = 0ull;
+    __syncthreads();
+    const int N = a.N, d = a.d, NCr = (N + 15) / 16;
+    const long long rs = 3LL * a.heads * d, os = (long long)a.heads * d;
+    if (w.valid) {
+        const float* qb = a.qkv + (long long)w.b * N * rs + w.head * d;
+        const float* kb = qb + a.heads * d;
+        const float* vb = qb + 2 * a.heads * d;
+        const float* gb = a.gout + (long long)w.b * N * os + w.head * d;
+        const float* ob = a.o + (long long)w.b * N * os + w.head * d;
+        float* gq = a.gqkv + (long long)w.b * N * rs + w.head * d;
+        const int* labw = a.labels ? a.labels + (long long)w.wdw * N : nullptr;
+        const long long stat = ((long long)w.b * a.heads + w.head) * N;
+
+        // Both passes prefetch the next pair's fragments into registers while the current pair runs on the matrix cores:
+        // the operands come from L1 / L2 (a window is 5-12 KB per matrix), whose latency one wave cannot hide otherwise.
+        struct KeySide {       // everything pass Q needs from key chunk kc
+            f32x4 kf[NDB], vf[NDB], kt[NDB];
+            int kb[4], kl[4];
+        };
+        auto load_keys = [&](int kc, KeySide& t) {
+#pragma unroll
+            for (int cc = 0; cc < NDB; ++cc) {
+                t.kf[cc] = row_frag<VEC>(kb, rs, 16 * kc + r, N, 16 * cc + 4 * g, d);
+                t.vf[cc] = row_frag<VEC>(vb, rs, 16 * kc + r, N, 16 * cc + 4 * g, d);
+                t.kt[cc] = col_frag(kb, rs, 16 * kc + 4 * g, N, 16 * cc + r, d);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int keyc = min(16 * kc + 4 * g + j, N - 1);
+                t.kb[j] = a.ib[keyc];
+                t.kl[j] = labw ? labw[keyc] : 0;
+            }
+        };
+        struct QuerySide {     // everything pass K needs from query chunk qc
+            f32x4 qf[NDB], gf[NDB], qt[NDB], gt[NDB];
+            int qa[4], ql[4];
+            float lse[4];
+        };
+        auto load_queries = [&](int qc, QuerySide& t) {
+#pragma unroll
+            for (int cc = 0; cc < NDB; ++cc) {
+                t.qf[cc] = row_frag<VEC>(qb, rs, 16 * qc + r, N, 16 * cc + 4 * g, d);
+                t.gf[cc] = row_frag<VEC>(gb, os, 16 * qc + r, N, 16 * cc + 4 * g, d);
+                t.qt[cc] = col_frag(qb, rs, 16 * qc + 4 * g, N, 16 * cc + r, d);
+                t.gt[cc] = col_frag(gb, os, 16 * qc + 4 * g, N, 16 * cc + r, d);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int qqc = min(16 * qc + 4 * g + j, N - 1);
+                t.qa[j] = a.ia[qqc];
+                t.ql[j] = labw ? labw[qqc] : 0;
+                t.lse[j] = a.lse_in[stat + qqc];
+            }
+        };
+
+        // ---- pass Q
+#pragma unroll 1
+        for (int qc = 0; qc < NCr; ++qc) {
+            const int q = 16 * qc + r, qcl = min(q, N - 1);
+            const int qa = a.ia[qcl], ql = labw ? labw[qcl] : 0;
+            const float lse = a.lse_in[stat + qcl];
+            KeySide cur, nxt;
+            load_keys(0, cur);
+            f32x4 qf[NDB], gf[NDB], dq[NDB];
+            float dpart = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < NDB; ++cc) {
+                qf[cc] = row_frag<VEC>(qb, rs, q, N, 16 * cc + 4 * g, d);
+                gf[cc] = row_frag<VEC>(gb, os, q, N, 16 * cc + 4 * g, d);
+                const f32x4 of = row_frag<VEC>(ob, os, q, N, 16 * cc + 4 * g, d);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    dpart += gf[cc][s] * of[s];
+                    qf[cc][s] *= a.scale;
+                }
+                dq[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            const float D = col_sum4(dpart);                          // D[q] = sum_dd dO[q][dd] O[q][dd]
+            if (g == 0) Dw[q] = D;                                     // q < 128 always
+#pragma unroll 1
+            for (int kc = 0; kc < NCr; ++kc) {
+                if (kc + 1 < NCr) load_keys(kc + 1, nxt);
+                f32x4 sT = f32x4{0.f, 0.f, 0.f, 0.f}, dpT = sT;
+#pragma unroll
+                for (int cc = 0; cc < NDB; ++cc) {
+                    sT = mfma16_chunk(cur.kf[cc], qf[cc], sT);
+                    dpT = mfma16_chunk(cur.vf[cc], gf[cc], dpT);
+                }
+                f32x4 dsT;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                          // rows = keys 16 kc + 4g + j, column = query r
+                    const int key = 16 * kc + 4 * g + j;
+                    const int bi = qa + cur.kb[j];
+                    float sc = sT[j] + tb[bi];
+                    if (labw && cur.kl[j] != ql) sc -= 100.f;
+                    const bool ok = key < N && q < N;
+                    const float v = ok ? __expf(sc - lse) * (dpT[j] - D) : 0.f;
+                    if (ok) fx_add_s(&gtb[bi], v);
+                    dsT[j] = v;
+                }
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) dq[db] = mfma16_chunk(cur.kt[db], dsT, dq[db]);   // dQ^T[dd][q] += K^T dS^T
+                cur = nxt;
+            }
+            if (q < N) {
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) {
+                    const int dd = 16 * db + 4 * g;
+                    float* dst = gq + (long long)q * rs + dd;
+                    if (VEC) {
+                        if (dd < d) *reinterpret_cast<f32x4*>(dst) = f32x4{dq[db][0] * a.scale, dq[db][1] * a.scale, dq[db][2] * a.scale, dq[db][3] * a.scale};
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (dd + j < d) dst[j] = dq[db][j] * a.scale;
+                    }
+                }
+            }
+        }
+        // ---- pass K (Dw was written by this wave: LDS operations of a wave complete in order)
+#pragma unroll 1
+        for (int kc = 0; kc < NCr; ++kc) {
+            const int key = 16 * kc + r, keyc = min(key, N - 1);
+            const int kbi = a.ib[keyc], kl = labw ? labw[keyc] : 0;
+            QuerySide cur, nxt;
+            load_queries(0, cur);
+            f32x4 kf[NDB], vf[NDB], dk[NDB], dv[NDB];
+#pragma unroll
+            for (int cc = 0; cc < NDB; ++cc) {
+                kf[cc] = row_frag<VEC>(kb, rs, key, N, 16 * cc + 4 * g, d);
+                vf[cc] = row_frag<VEC>(vb, rs, key, N, 16 * cc + 4 * g, d);
+                dk[cc] = dv[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll 1
+            for (int qc = 0; qc < NCr; ++qc) {
+                if (qc + 1 < NCr) load_queries(qc + 1, nxt);
+                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
+#pragma unroll
+                for (int cc = 0; cc < NDB; ++cc) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { cur.qf[cc][t] *= a.scale; cur.qt[cc][t] *= a.scale; }
+                    s = mfma16_chunk(cur.qf[cc], kf[cc], s);          // rows = queries 16 qc + 4g + j, column = key r
+                    dp = mfma16_chunk(cur.gf[cc], vf[cc], dp);
+                }
+                f32x4 p, ds;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int qq = 16 * qc + 4 * g + j, qqc = min(qq, N - 1);
+                    float sc = s[j] + tb[cur.qa[j] + kbi];
+                    if (labw && cur.ql[j] != kl) sc -= 100.f;
+                    const float pv = (qq < N && key < N) ? __expf(sc - cur.lse[j]) : 0.f;
+                    p[j] = pv;
+                    ds[j] = pv * (dp[j] - Dw[qqc]);
+                }
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) {
+                    dv[db] = mfma16_chunk(cur.gt[db], p, dv[db]);     // dV^T += dO^T P
+                    dk[db] = mfma16_chunk(cur.qt[db], ds, dk[db]);    // dK^T += (scale Q)^T dS
+                }
+                cur = nxt;
+            }
+            if (key < N) {
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) {
+                    const int dd = 16 * db + 4 * g;
+                    float* dst = gq + (long long)key * rs + dd;
+                    if (VEC) {
+                        if (dd < d) {
+                            *reinterpret_cast<f32x4*>(dst + a.heads * d) = dk[db];
+                            *reinterpret_cast<f32x4*>(dst + 2 * a.heads * d) = dv[db];
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (dd + j < d) { dst[a.heads * d + j] = dk[db][j]; dst[2 * a.heads * d + j] = dv[db][j]; }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.TB; i += 256)
+        if (gtb[i] != 0ull) atomic_add_f32(&a.gtable[(long long)i * w.tstr + w.tofs], (float)(long long)gtb[i] * (1.f / FXS));
+}
+
+int ws_setup(WsDev& a, int B_, int nW, int N, int TB, int ntypes, int heads, int d, float scale) {
+    a.B_ = B_; a.nW = nW; a.N = N; a.TB = TB; a.ntypes = ntypes; a.heads = heads; a.d = d; a.scale = scale;
+    a.M = B_ / ntypes;
+    a.groups = (a.M + 3) / 4;
+    return DLWP_OK;
+}
+
+}  // namespace
+
+// Shapes this family takes: at most 128 tokens per window, head_dim <= 32, and enough (window, head) pairs that one wave per
+// pair fills the chip -- a single wave walks its pairs of 16 x 16 tiles serially (L1 / L2 latency per step, one prefetch deep),
+// so with few windows the tiled kernels of winattn.hip (a workgroup per 64 queries) finish sooner.  Measured
+// (profiles/r02_winattn_probe.txt, forward / backward us, tiled -> this family):  1406 windows x 4 heads, N = 49, d = 24:
+// 86 / 264 -> 54 / 249;  703 x 6, N = 98, d = 32: 193 / 727 -> 149 / 643;  100 x 4, N = 49, d = 10: 8 / 26 -> 11 / 51.
+bool dlwp_winattn_small_applies(int N, int d, long long pairs) { return N <= 128 && d <= 32 && pairs >= 2048; }
+
+#define WS_DISPATCH(KERNEL, lds)                                                                                          \
+    do {                                                                                                                  \
+        const int nc = (N + 15) / 16, ndb = (d + 15) / 16;                                                                \
+        const bool vec = d % 4 == 0;                                                                                      \
+        const dim3 grid((unsigned)(heads * ntypes * a.groups)), block(256);                                               \
+        auto go = [&](auto knl) -> int {                                                                                  \
+            int rc2 = dlwp_ensure_lds(reinterpret_cast<const void*>(knl), lds, #KERNEL);                                  \
+            if (rc2) return rc2;                                                                                          \
+            hipLaunchKernelGGL(knl, grid, block, lds, (hipStream_t)stream, a);                                            \
+            return DLWP_OK;                                                                                               \
+        };                                                                                                                \
+        int rc3 = DLWP_OK;                                                                                                \
+        if (ndb == 1) {                                                                                                   \
+            if (nc <= 4) rc3 = vec ? go(KERNEL<4, 1, true>) : go(KERNEL<4, 1, false>);                                    \
+            else rc3 = vec ? go(KERNEL<8, 1, true>) : go(KERNEL<8, 1, false>);                                            \
+        } else {                                                                                                          \
+            if (nc <= 4) rc3 = vec ? go(KERNEL<4, 2, true>) : go(KERNEL<4, 2, false>);                                    \
+            else rc3 = vec ? go(KERNEL<8, 2, true>) : go(KERNEL<8, 2, false>);                                            \
+        }                                                                                                                 \
+        if (rc3) return rc3;                                                                                              \
+    } while (0)
+
+int dlwp_winattn_small_fwd(const float* qkv, const float* table, const float* packed, const int* ia, const int* ib,
+                           const int* labels, float* out, float* lse, int B_, int nW, int N, int TB, int ntypes, int heads, int d,
+                           float scale, void* stream) {
+    WsDev a{};
+    ws_setup(a, B_, nW, N, TB, ntypes, heads, d, scale);
+    a.qkv = qkv; a.table = table; a.table_t = packed; a.ia = ia; a.ib = ib; a.labels = labels; a.out = out; a.lse = lse;
+    const size_t lds = sizeof(float) * (size_t)TB;
+    WS_DISPATCH(winattn_small_fwd_kernel, lds);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+int dlwp_winattn_small_bwd(const float* qkv, const float* table, const float* packed, const int* ia, const int* ib,
+                           const int* labels, const float* out, const float* lse, const float* gout, float* gqkv, float* gtable,
+                           int B_, int nW, int N, int TB, int ntypes, int heads, int d, float scale, void* stream) {
+    WsDev a{};
+    ws_setup(a, B_, nW, N, TB, ntypes, heads, d, scale);
+    a.qkv = qkv; a.table = table; a.table_t = packed; a.ia = ia; a.ib = ib; a.labels = labels; a.o = out; a.lse_in = lse;
+    a.gout = gout; a.gqkv = gqkv; a.gtable = gtable;
+    const size_t lds = sizeof(float) * (3 * (size_t)((TB + 1) & ~1) + 4 * 128);
+    const bool vec = d % 4 == 0;
+    const dim3 grid((unsigned)(heads * ntypes * a.groups)), block(256);
+    auto go = [&](auto knl) -> int {
+        int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(knl), lds, "winattn_small_bwd");
+        if (rc) return rc;
+        hipLaunchKernelGGL(knl, grid, block, lds, (hipStream_t)stream, a);
+        return DLWP_OK;
+    };
+    int rc;
+    if (d <= 16) rc = vec ? go(winattn_small_bwd_kernel<1, true>) : go(winattn_small_bwd_kernel<1, false>);
+    else rc = vec ? go(winattn_small_bwd_kernel<2, true>) : go(winattn_small_bwd_kernel<2, false>);
+    if (rc) return rc;
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}

@@ -156,3 +156,36 @@ def test_dlwp_swin_matches_reference_golden(cuda, tag):
     for n, p in net.named_parameters():
         if f"{tag}_g_{n}" in GD.files:
             assert rel(p.grad, td(f"g_{n}")) <= 2e-3, n
+
+
+@pytest.mark.parametrize("Wh,Ww,pl,d,heads,B_,nW,ntypes,masked", [(7, 7, 1, 24, 4, 640, 20, 1, True), (7, 7, 2, 32, 6, 360, 30, 5, True),
+                                                                   (7, 7, 1, 10, 4, 600, 12, 1, False), (8, 8, 1, 16, 8, 300, 4, 2, True)])
+def test_many_short_windows_wave_kernels_match_tiled_kernels(cuda, monkeypatch, Wh, Ww, pl, d, heads, B_, nW, ntypes, masked):
+    """Above 2048 (window, head) pairs windows of at most 128 tokens take the wave-per-window kernels (csrc/winattn_small.hip);
+    DLWP_WINATTN_TILED=1 forces the tiled kernels, which the goldens above pin: both must agree, forward and backward."""
+    from dlwp_benchmark_amd.nsbench.swin_transformer import window_attention_core
+    assert B_ * heads >= 2048
+    N = pl * Wh * Ww
+    TB = 3 * N
+    g = torch.Generator().manual_seed(N + d + heads)
+    qkv0 = torch.randn(B_, N, 3 * heads * d, generator=g).to(cuda)
+    table0 = (0.5 * torch.randn(TB, ntypes, heads, generator=g)).to(cuda)
+    if ntypes == 1:
+        table0 = table0[:, 0].contiguous()
+    ia = torch.randint(0, TB // 2, (N,), generator=g, dtype=torch.int32).to(cuda)
+    ib = torch.randint(0, TB // 2, (N,), generator=g, dtype=torch.int32).to(cuda)
+    labels = torch.randint(0, 3, (nW, N), generator=g, dtype=torch.int32).to(cuda) if masked else None
+    gy = torch.randn(B_, N, heads * d, generator=g).to(cuda)
+    res = []
+    for tiled in (True, False):
+        if tiled:
+            monkeypatch.setenv("DLWP_WINATTN_TILED", "1")
+        else:
+            monkeypatch.delenv("DLWP_WINATTN_TILED", raising=False)
+        qkv, table = qkv0.clone().requires_grad_(), table0.clone().requires_grad_()
+        y = window_attention_core(qkv, table, ia, ib, labels, nW, heads, d ** -0.5)
+        y.backward(gy)
+        res.append((y.detach(), qkv.grad, table.grad))
+    assert rel(res[1][0], res[0][0]) <= 2e-5
+    assert rel(res[1][1], res[0][1]) <= 1e-4
+    assert rel(res[1][2], res[0][2]) <= 1e-4

@@ -27,6 +27,16 @@ timeout 900 python3 $R/tools/bench_models.py all --steps 10 > $O/models.jsonl 2>
 for m in afno swin pangu; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$m -- python3 $R/tools/bench_models.py $m --steps 5 > /dev/null 2>&1
 done
+# round-2 additions: ATen audit of the three C1-size steps, GEMM / window-attention micro-benchmarks, fp32 / bf16-operand /
+# bf16-storage lines of the C3-C5 scale models and the kernel statistics of the bf16-storage C4 / C5 steps
+for m in afno swin pangu; do timeout 200 python3 $R/tools/aten_audit.py $m > $O/aten_audit_$m.txt 2>&1; done
+timeout 300 python3 $R/tools/bench_gemm.py > $O/gemm_bench.txt 2>&1
+DLWP_GEMM_TILE=128 timeout 300 python3 $R/tools/bench_gemm.py > $O/gemm_bench_tile128.txt 2>&1
+timeout 300 python3 $R/tools/probe_winattn.py > $O/winattn_probe.txt 2>&1
+timeout 900 bash $R/tools/bench_bf16_r02.sh > /dev/null 2>&1; cp $R/gpurun_out/bf16_r02.jsonl $O/bf16_models.jsonl
+for m in afno_fcn pangu_c4 swin_c4; do
+  timeout 250 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bf16s_$m -- python3 $R/tools/bench_models.py $m --steps 3 --precision bf16 --storage bf16 > /dev/null 2>&1
+done
 find $O -name "*_kernel_trace.csv" -delete
 find $O -name "*counter_collection.csv" -size +4M -delete
 echo "=== lines"; cat $O/bench_line.json; cat $O/bench_line_h217.json; cat $O/traffic.log; cat $O/models.jsonl
