@@ -515,13 +515,14 @@ class Linear(nn.Linear):
 
 
 class LayerNorm(nn.LayerNorm):
-    def forward(self, x, gemm_input=False):
-        return _LayerNormFn.apply(x, self.weight, self.bias, float(self.eps), False, gemm_input)
+    def forward(self, x, gemm_input=False, fork=False):
+        return _LayerNormFn.apply(x, self.weight, self.bias, float(self.eps), fork, gemm_input)
 
     def fork(self, x, gemm_input=False):
         """(x, norm(x)) for a pre-norm residual block: use the first item as the skip connection (see _LayerNormFn).
-        gemm_input=True: nothing but GEMMs (Linear / Mlp) reads norm(x); it may then be stored as bf16 (lib.set_storage)."""
-        return _LayerNormFn.apply(x, self.weight, self.bias, float(self.eps), True, gemm_input)
+        gemm_input=True: nothing but GEMMs (Linear / Mlp) reads norm(x); it may then be stored as bf16 (lib.set_storage).
+        Goes through __call__ so that module hooks (ddp.BucketedGradAllReduce counts entries and exits) see the call."""
+        return self(x, gemm_input, True)
 
 
 class Mlp(nn.Module):
