@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--workload", default="fno", choices=["fno", "sfno"],
                     help="fno: BASELINE configs[1] (default, the headline line); sfno: configs[2], dlwpbench SFNO2DModule 32x64, "
                          "5 prognostic variables, sfno.yaml widths, sequence length 5 (4 lead times)")
+    ap.add_argument("--storage", default=None, choices=["fp32", "bf16"],
+                    help="sfno workload: storage of GEMM-to-GEMM activations and of the weight copy the GEMMs read (default: bf16 "
+                         "with bf16 operands)")
     ap.add_argument("--precision", default=None, choices=["fp32", "bf16"],
                     help="GEMM operand precision of the sfno workload (default bf16 = the reference's autocast, fp32 accumulate)")
     return ap.parse_args()
@@ -319,6 +322,10 @@ def main_sfno(args):
         dist.init_process_group("nccl", device_id=device) if args.backend == "nccl" else dist.init_process_group(args.backend)
     precision = args.precision or "bf16"
     L.set_gemm_precision(precision)
+    # bf16 arithmetic goes with bf16 storage of the GEMM-to-GEMM tensors and of the weight copy the GEMMs read (lib.set_storage);
+    # fp32 master weights, gradients, statistics and the residual stream stay fp32.  --storage fp32 keeps everything in fp32 arrays
+    storage = args.storage or ("bf16" if precision == "bf16" else "fp32")
+    L.set_storage(storage)
     w, B = SFNO_WORKLOAD, args.batch
     torch.manual_seed(1234)
     model = dlwpbench.SFNO2DModule(**w["model"]).to(device).train()
@@ -357,7 +364,7 @@ def main_sfno(args):
                 "data": "synthetic N(0,1) fields (z-scored WeatherBench shapes), random-init weights (no dataset/checkpoint access)",
                 "config": {"workload": w["name"], "per_gpu_batch": B, "global_batch": B * world, "sequence_length": T,
                            "net_calls_per_sample": T - 1, "embed_dim": 256, "num_layers": 4, "grid": [32, 64],
-                           "gemm_operands": precision, "accumulate": "fp32", "parallelism": f"dp{world}",
+                           "gemm_operands": precision, "storage": storage, "accumulate": "fp32", "parallelism": f"dp{world}",
                            "hip_graph": not args.no_graph},
                 "backbone_calls_per_s": round(world * B * args.steps * (T - 1) / dt, 1), "final_loss": loss.item()}
         if world == 1 and not args.no_roofline:

@@ -103,23 +103,25 @@ class _TableGemm(torch.autograd.Function):
     accumulated (a contraction index spread over two planes of x).  The backward pass applies the transposed slices."""
 
     @staticmethod
-    def forward(ctx, x, table, spec, residual=None):
+    def forward(ctx, x, table, spec, residual=None, out_dtype=torch.float32):
+        # out_dtype bfloat16 (bf16 storage, lib.set_storage): the result only feeds another GEMM of the transform chain
         x = x.contiguous()
-        y = torch.empty(spec["out_shape"], device=x.device)
+        y = torch.empty(spec["out_shape"], device=x.device, dtype=out_dtype)
         passes = spec.get("passes", ((0, 0),))
+        assert len(passes) == 1 or out_dtype == torch.float32, "multi-pass accumulation needs an fp32 output"
         for i, (oA, oX) in enumerate(passes):
             last = i == len(passes) - 1
             _gemm_batched(table, x, y, spec["M"], spec["N"], spec["K"], spec["lda"], spec["ldx"], spec["ldy"], spec["tA"], 0,
                           spec["nb1"], spec["nb2"], spec["sA"], spec["sX"], spec["sY"], accumulate=int(i > 0), oA=oA, oB=oX,
                           residual=residual.contiguous() if (residual is not None and last) else None, sR=spec["sY"])
-        ctx.spec, ctx.table, ctx.in_shape, ctx.has_res = spec, table, x.shape, residual is not None
+        ctx.spec, ctx.table, ctx.in_shape, ctx.has_res, ctx.in_dtype = spec, table, x.shape, residual is not None, x.dtype
         return y
 
     @staticmethod
     def backward(ctx, gy):
         s = ctx.spec
         gy = gy.contiguous()
-        gx = torch.empty(ctx.in_shape, device=gy.device)
+        gx = torch.empty(ctx.in_shape, device=gy.device, dtype=ctx.in_dtype)      # the gradient has its tensor's storage type
         shared = s["nb2"] > 1 and s["sX"][1] == 0      # x[z1] feeds every z2: its gradient is a sum over z2
         for oA, oX in s.get("passes", ((0, 0),)):
             if not shared:
@@ -130,7 +132,25 @@ class _TableGemm(torch.autograd.Function):
                 _gemm_batched(ctx.table, gy, gx, s["K"], s["N"], s["M"], s["lda"], s["ldy"], s["ldx"], 1 - s["tA"], 0,
                               s["nb1"], 1, (s["sA"][0], 0), (s["sY"][0], 0), (s["sX"][0], 0), accumulate=int(z2 > 0),
                               oA=oA + z2 * s["sA"][1], oB=z2 * s["sY"][1], oC=oX)
-        return gx, None, None, (gy if ctx.has_res else None)
+        return gx, None, None, (gy if ctx.has_res else None), None
+
+
+def _chain_dtype():
+    """Storage type of the tensors that live only between two GEMMs of the transform chain (bf16 under lib.set_storage)."""
+    return torch.bfloat16 if (L.storage_bf16() and L.SHADOW_ACTIVE) else torch.float32
+
+
+def _table(mod, name, dtype):
+    """The transform table `name` of module `mod` in the chain's storage type (a bf16 copy of the constant is made once)."""
+    t = getattr(mod, name)
+    if dtype == torch.float32:
+        return t
+    key = "_bf16_" + name
+    c = mod.__dict__.get(key)
+    if c is None or c.device != t.device:
+        c = t.to(torch.bfloat16)
+        mod.__dict__[key] = c
+    return c
 
 
 def _fused_ok(nlat, nlon, C, mmax, lmax):
@@ -215,10 +235,11 @@ class RealSHT(nn.Module):
             return _FusedAnalysis.apply(x, self.dft, self.weights, self.weights_t, self.dft_t, M, Lm)
         lon = dict(M=2 * M, N=C, K=N, lda=N, tA=0, ldx=C, ldy=C, nb1=B * K, nb2=1, sA=(0, 0), sX=(N * C, 0),
                    sY=(2 * M * C, 0), out_shape=(B, K, M, 2, C))
-        t = _TableGemm.apply(x, self.dft, lon, None)
+        cd = _chain_dtype()
+        t = _TableGemm.apply(x, _table(self, "dft", cd), lon, None, cd)
         leg = dict(M=Lm, N=2 * C, K=K, lda=K, tA=0, ldx=2 * M * C, ldy=B * M * 2 * C, nb1=B, nb2=M, sA=(0, Lm * K),
                    sX=(K * 2 * M * C, 2 * C), sY=(M * 2 * C, 2 * C), out_shape=(Lm, B, M, 2, C))
-        return _TableGemm.apply(t, self.weights, leg, None)
+        return _TableGemm.apply(t, _table(self, "weights", cd), leg, None, cd)
 
 
 class InverseRealSHT(nn.Module):
@@ -243,10 +264,11 @@ class InverseRealSHT(nn.Module):
             return _FusedSynthesis.apply(X, self.pct_t, self.idft, self.idft_t, self.pct, K, N)
         leg = dict(M=K, N=2 * C, K=Lm, lda=K, tA=1, ldx=B * M * 2 * C, ldy=2 * M * C, nb1=B, nb2=M, sA=(0, Lm * K),
                    sX=(M * 2 * C, 2 * C), sY=(K * 2 * M * C, 2 * C), out_shape=(B, K, M, 2, C))
-        t = _TableGemm.apply(X, self.pct, leg, None)
+        cd = _chain_dtype()
+        t = _TableGemm.apply(X, _table(self, "pct", cd), leg, None, cd)
         lon = dict(M=N, N=C, K=2 * M, lda=2 * M, tA=0, ldx=C, ldy=C, nb1=B * K, nb2=1, sA=(0, 0), sX=(2 * M * C, 0),
                    sY=(N * C, 0), out_shape=(B, K, N, C))
-        return _TableGemm.apply(t, self.idft, lon, None)
+        return _TableGemm.apply(t, _table(self, "idft", cd), lon, None)       # back on the grid: fp32 (residual stream)
 
 
 # ---- per-degree complex weights ---------------------------------------------------------------------------------
@@ -278,6 +300,10 @@ def _expanded_weight(w):
     Cin, Cout, Lm, _ = w.shape
     wexp = torch.empty(Lm, 2 * Cin, 2 * Cout, device=w.device)
     L.check(lib.dlwp_cweight_expand(L.ptr(w.contiguous()), L.ptr(wexp), Cin, Cout, Lm, L.stream()))
+    if _chain_dtype() == torch.bfloat16:         # the GEMMs read a bf16 image (built once per rollout inside the scope)
+        w16 = torch.empty_like(wexp, dtype=torch.bfloat16)
+        L.check(lib.dlwp_cast_bf16(L.ptr(wexp), L.ptr(w16), wexp.numel(), L.stream()))
+        wexp = w16
     if _wexp_scope is not None:
         _wexp_scope[id(w)] = (wexp, w)          # keeps w alive, so the id stays unique inside the scope
     return wexp
@@ -302,7 +328,7 @@ class _DHConvFn(torch.autograd.Function):
         X = X.contiguous()
         wexp = _expanded_weight(w)
         R = B * M
-        Y = torch.empty(Lm, B, M, 2, Cout, device=X.device)
+        Y = torch.empty(Lm, B, M, 2, Cout, device=X.device, dtype=X.dtype)        # bf16 spectra stay bf16
         _gemm_batched(X, wexp, Y, R, 2 * Cout, 2 * Cin, 2 * Cin, 2 * Cout, 2 * Cout, 0, 0, Lm, 1, (R * 2 * Cin, 0),
                       (4 * Cin * Cout, 0), (R * 2 * Cout, 0))
         ctx.save_for_backward(X, wexp)
@@ -329,10 +355,10 @@ class _DHConvFn(torch.autograd.Function):
             if first:
                 if not _pending_folds:
                     torch.autograd.Variable._execution_engine.queue_callback(_fold_pending)
-                _pending_folds[ctx.wid] = (torch.empty_like(wexp), ctx.wslot, (Cin, Cout, Lm))
+                _pending_folds[ctx.wid] = (torch.empty_like(wexp, dtype=torch.float32), ctx.wslot, (Cin, Cout, Lm))
             gexp = _pending_folds[ctx.wid][0]
         else:
-            gexp = torch.empty_like(wexp)
+            gexp = torch.empty_like(wexp, dtype=torch.float32)
         _gemm_batched(X, gY, gexp, 2 * Cin, 2 * Cout, R, 2 * Cin, 2 * Cout, 2 * Cout, 1, 0, Lm, 1, (R * 2 * Cin, 0),
                       (R * 2 * Cout, 0), (4 * Cin * Cout, 0), accumulate=int(ctx.wslot is not None and not first))
         if ctx.wslot is not None:

@@ -148,3 +148,44 @@ def test_bf16_storage_needs_bf16_operands(cuda):
     from dlwp_benchmark_amd import lib as L
     with pytest.raises(L.DlwpError):
         L.set_storage("bf16")
+
+
+def test_sfno_train_step_with_bf16_storage_tracks_fp32_storage(cuda):
+    """C3-shaped SFNO (smaller width): with bf16 storage the transform chain keeps its GEMM-to-GEMM intermediates (longitude
+    spectra, Legendre spectra, filtered spectra) and the expanded spectral weights as bf16; the loss trajectory must follow the
+    fp32-storage run (same bf16-operand arithmetic) to bf16 rounding, and the chain really runs on bf16 arrays."""
+    from dlwp_benchmark_amd import dlwpbench, lib as L, sht, token_ops
+    from dlwp_benchmark_amd.train_engine import GraphedTrainStep
+    g = torch.Generator().manual_seed(8)
+    B, T = 2, 3
+    kw = dict(constants=torch.randn(B, 1, 4, 32, 64, generator=g).to(cuda), prescribed=torch.randn(B, T, 1, 32, 64, generator=g).to(cuda),
+              prognostic=torch.randn(B, T, 5, 32, 64, generator=g).to(cuda))
+    target = torch.randn(B, T - 1, 5, 32, 64, generator=g).to(cuda)
+    seen = {"fp32": set(), "bf16": set()}
+    orig = sht._gemm_batched
+    mode = "fp32"
+
+    def spy(A, Bm, C, *a, **k):
+        seen[mode].add((A.dtype, Bm.dtype, C.dtype))
+        return orig(A, Bm, C, *a, **k)
+    losses = {}
+    with L.gemm_precision("bf16"):
+        for mode in ("fp32", "bf16"):
+            L.set_storage(mode)
+            try:
+                torch.manual_seed(3)
+                m = dlwpbench.SFNO2DModule(constant_channels=4, prescribed_channels=1, prognostic_channels=5, grid="equiangular",
+                                           num_layers=2, scale_factor=1, embed_dim=64, context_size=1, height=32, width=64,
+                                           big_skip=True, pos_embed=True, use_mlp=True, normalization_layer="none").to(cuda)
+                sht._gemm_batched = spy
+                step = GraphedTrainStep(m, kw, target, lr=2e-3)
+                losses[mode] = [step().item() for _ in range(5)]
+            finally:
+                sht._gemm_batched = orig
+                L.set_storage("fp32")
+    f32 = torch.float32
+    assert seen["fp32"] == {(f32, f32, f32)}
+    assert (BF, BF, BF) in seen["bf16"] and (BF, f32, BF) in seen["bf16"] and (BF, BF, f32) in seen["bf16"]
+    a, b = torch.tensor(losses["fp32"]), torch.tensor(losses["bf16"])
+    assert a[-1] < a[0]
+    assert ((a - b).abs() / a).max().item() < 3e-2, (losses["fp32"], losses["bf16"])
