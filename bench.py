@@ -238,7 +238,7 @@ SFNO_WORKLOAD = dict(name="dlwpbench SFNO2DModule 32x64 WeatherBench shapes (BAS
                                 use_mlp=True, normalization_layer="none"), T=5, H=32, W=64)
 
 
-def sfno_gemm_probe(device, B, precision, reps=100):
+def sfno_gemm_probe(device, B, precision, reps=100, storage="fp32"):
     """Dominant kernel of the SFNO step (rocprof: gemm_kernel, ~80 % of GPU time): the block MLP's first layer
     [B*H*W, 256] x [256, 512] with bias + GELU epilogue, timed with HIP events on its launch stream."""
     import torch
@@ -250,6 +250,8 @@ def sfno_gemm_probe(device, B, precision, reps=100):
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(device)
     b = torch.zeros(N, device=device)
     y, z = torch.empty(M, N, device=device), torch.empty(M, N, device=device)
+    if storage == "bf16":         # as in the step: weight copy, hidden activation and pre-activation are bf16 arrays
+        w, y, z = w.to(torch.bfloat16), y.to(torch.bfloat16), z.to(torch.bfloat16)
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         for _ in range(10):
@@ -264,7 +266,7 @@ def sfno_gemm_probe(device, B, precision, reps=100):
     sec = e0.elapsed_time(e1) * 1e-3 / reps
     flops = 2.0 * M * N * K
     peak = PEAK_MFMA_TF[precision]
-    return {"bound": "mfma", "kernel": f"gemm_kernel (MLP fc1 {M}x{N}x{K}, bias+GELU epilogue, {precision} operands)",
+    return {"bound": "mfma", "kernel": f"gemm_kernel (MLP fc1 {M}x{N}x{K}, bias+GELU epilogue, {precision} operands, {storage} storage of W / h / z)",
             "achieved": round(flops / sec / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(flops / sec / 1e12 / peak, 4),
             "flops_per_launch": flops, "us_per_launch": round(sec * 1e6, 3), "traffic": None}
 
@@ -368,7 +370,7 @@ def main_sfno(args):
                            "hip_graph": not args.no_graph},
                 "backbone_calls_per_s": round(world * B * args.steps * (T - 1) / dt, 1), "final_loss": loss.item()}
         if world == 1 and not args.no_roofline:
-            line["roofline"] = sfno_gemm_probe(device, B, precision)
+            line["roofline"] = sfno_gemm_probe(device, B, precision, storage=storage)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = sfno_cpu_baseline(B, args.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -62,7 +62,10 @@ constexpr int BKB = 32;        // K-step of the bf16-operand mode.  A 64-deep st
                                // per workgroup) was measured: 136 instead of 104 registers drop the occupancy from 4 to 3
                                // waves per SIMD and the net effect is -13 % ... +10 % depending on the shape (8192x512x256:
                                // 14.1 -> 16.2 us, 8192x256x512: 15.1 -> 13.6 us), so the 32-deep step stays
-constexpr int LDKB = BKB + 8;  // bf16 elements per LDS row (80 bytes: 16-byte aligned fragments)
+// K-step of a bf16-operand kernel: 64 only for the 128 x 128 weight-gradient product of two bf16 arrays (both operands
+// row-contiguous, K = tokens, split-K): 16200-deep 3072 x 768: 300 -> 410 TFLOP/s.  Everywhere else the doubled LDS image
+// halves the workgroups per CU and loses (16200 x 3072 x 768 forward: 479 -> 392; profiles/r02_gemm_bench.txt).
+constexpr int gemm_bf_kstep(int s16m, int T, bool akc, bool bkc) { return s16m == 3 && T == 2 && !akc && !bkc ? 64 : BKB; }
 
 // epilogue activations: 0 none, 1 GELU (erf), 2 ReLU, 3 soft-shrink(lambda); 4 is the backward form
 // v * GELU'(aux) with aux read through the `residual` view (the saved pre-activation): the product g W of a Linear layer
@@ -83,6 +86,7 @@ template <bool KC, bool VEC, int T, int BKT, bool S16 = false>
 struct TileIO {
     static constexpr int ROWS = Tile<T>::ROWS, LDR = Tile<T>::LDR, KM = BKT / 32;
     static constexpr int LDRB = ROWS + 8;
+    static constexpr int LDKT = BKT + 8;      // bf16 [row][k] image: row pitch for this K-step (16-byte aligned fragments)
     float v[S16 ? 1 : 8 * T * KM];
     bf16x8 h[S16 ? T * KM : 1];
     static __device__ __forceinline__ void coords16(int f, int& row, int& k) {
@@ -109,7 +113,7 @@ struct TileIO {
         for (int q = 0; q < T * KM; ++q) {
             int row, k;
             coords16(threadIdx.x + 256 * q, row, k);
-            *reinterpret_cast<bf16x8*>(&S[KC ? row * LDKB + k : k * LDRB + row]) = h[q];
+            *reinterpret_cast<bf16x8*>(&S[KC ? row * LDKT + k : k * LDRB + row]) = h[q];
         }
     }
     static __device__ __forceinline__ void coords(int f, int& row, int& k) {
@@ -189,7 +193,7 @@ struct TileIO {
             for (int q = 0; q < 2 * T * KM; ++q) {
                 int row, k;
                 coords(tid + 256 * q, row, k);
-                *reinterpret_cast<bf16x4*>(&S[KC ? row * LDKB + k : k * LDRB + row]) =
+                *reinterpret_cast<bf16x4*>(&S[KC ? row * LDKT + k : k * LDRB + row]) =
                     bf16x4{(__bf16)v[4 * q], (__bf16)v[4 * q + 1], (__bf16)v[4 * q + 2], (__bf16)v[4 * q + 3]};
             }
         } else {
@@ -197,7 +201,7 @@ struct TileIO {
             for (int q = 0; q < 8 * T * KM; ++q) {
                 int row, k;
                 coords(tid + 256 * q, row, k);
-                S[KC ? row * LDKB + k : k * LDRB + row] = (__bf16)v[q];
+                S[KC ? row * LDKT + k : k * LDRB + row] = (__bf16)v[q];
             }
         }
     }
@@ -205,7 +209,7 @@ struct TileIO {
     // it comes through two hardware transpose reads (ds_read_b64_tr_b16: per 16-lane group a 4 x 16 block, lane 4q+p
     // addresses block row q / columns 4p.., lane i receives column i; tools/micro/tr_read.hip) -- EXEC is all ones here.
     static __device__ __forceinline__ bf16x8 frag_bf16(const __bf16* S, int rb, int c, int r, int g) {
-        if (KC) return *reinterpret_cast<const bf16x8*>(&S[(rb + r) * LDKB + 32 * c + 8 * g]);
+        if (KC) return *reinterpret_cast<const bf16x8*>(&S[(rb + r) * LDKT + 32 * c + 8 * g]);
         typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
         const __bf16* p0 = &S[(32 * c + 8 * g + (r >> 2)) * LDRB + rb + 4 * (r & 3)];
         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0));
@@ -242,9 +246,11 @@ template <bool AKC, bool BKC, int VEC, int T, bool BF, int S16M = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     constexpr int BMN = Tile<T>::ROWS, NT16 = 2 * T;   // 16-row MFMA tiles per wave and direction
-    constexpr int BKT = BF ? BKB : BK;
+    // K-step: 32, or 64 when both operands are bf16 arrays (S16M == 3: four staging registers per operand and K-step instead
+    // of sixteen, so the deeper step no longer costs occupancy -- and it halves the barriers per K)
+    constexpr int BKT = BF ? gemm_bf_kstep(S16M, T, AKC, BKC) : BK;
     // tile size in floats (bf16: two elements per float; the larger of the [row][k] and [k][row] images)
-    constexpr int TF = BF ? (BMN * LDKB > BKB * (BMN + 8) ? BMN * LDKB : BKB * (BMN + 8)) / 2 : Tile<T>::FLOATS;
+    constexpr int TF = BF ? (BMN * (BKT + 8) > BKT * (BMN + 8) ? BMN * (BKT + 8) : BKT * (BMN + 8)) / 2 : Tile<T>::FLOATS;
     float* As = gsm;                 // [2][TF]
     float* Bs = gsm + 2 * TF;        // [2][TF]
     const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
@@ -475,7 +481,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
 template <bool AKC, bool BKC, int VEC, int T, bool BF, int S16M = 0>
 int gemm_launch_t(const GemmDev& a, dim3 grid, hipStream_t s) {
     constexpr int RW = Tile<T>::ROWS;
-    const size_t lds = BF ? sizeof(float) * 4 * ((RW * LDKB > BKB * (RW + 8) ? RW * LDKB : BKB * (RW + 8)) / 2)
+    constexpr int KS = gemm_bf_kstep(S16M, T, AKC, BKC);
+    const size_t lds = BF ? sizeof(float) * 4 * ((RW * (KS + 8) > KS * (RW + 8) ? RW * (KS + 8) : KS * (RW + 8)) / 2)
                           : sizeof(float) * 4 * Tile<T>::FLOATS;
     int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_kernel<AKC, BKC, VEC, T, BF, S16M>), lds, "gemm");
     if (rc) return rc;

@@ -43,6 +43,21 @@ def _act_dtype():
     return _BF if (L.storage_bf16() and L.SHADOW_ACTIVE) else torch.float32
 
 
+LOWP_MIN_DEPTH = 768
+
+
+def _lowp(t, depth):
+    """Under bf16 storage: a bf16 copy of an fp32 GEMM operand that is read by two products (one cast launch, then both
+    products take the 16-byte bf16 path).  The matrix units round fp32 operands to bf16 anyway, so the results are unchanged.
+    `depth` = the other dimension of those products: the cast is one more pass over t, the saving grows with depth -- measured
+    break-even between 512 (SFNO MLP: 12.5 -> 13.2 ms with the casts) and 768 (Pangu C4: 22.9 -> 22.6; AFNO 3072: 30.3 -> 28.4)."""
+    if t is None or t.dtype == _BF or _act_dtype() != _BF or depth < LOWP_MIN_DEPTH:
+        return t
+    out = torch.empty_like(t, dtype=_BF)
+    L.check(L.load().dlwp_cast_bf16(L.ptr(t), L.ptr(out), t.numel(), L.stream()))
+    return out
+
+
 def _grad_slot(p):
     """The preallocated gradient buffer of a leaf parameter (train_engine.flatten_parameters), or None.
     When present, backward kernels accumulate straight into it (no temporary, no autograd add)."""
@@ -86,6 +101,8 @@ class _LinearFn(torch.autograd.Function):
         T, K = x2.shape
         N = weight.shape[0]
         w, _ = _wmat(weight, N)             # the bf16 copy under bf16 storage (forward and input-gradient products)
+        if w.dtype == _BF:
+            x2 = _lowp(x2, N)               # read by the forward product and by gW = g^T x
         y = torch.empty(T, N, device=x.device)
         z = torch.empty(T, N, device=x.device) if act else None
         r2 = residual.reshape(-1, N).contiguous() if residual is not None else None
@@ -114,6 +131,8 @@ class _LinearFn(torch.autograd.Function):
             g2 = gz
             if ctx.res_pre and ctx.has_res:      # the residual sits inside the activation
                 gres = gz.reshape(gy.shape)
+        if w.dtype == _BF:
+            g2 = _lowp(g2, K)                    # read by both products below
         gx = torch.empty(T, K, device=g2.device)
         _gemm(g2, w, gx, T, K, N, N, K, K, 0, 0)                 # gx = g W
         # gW = g^T x, with the bias gradient (column sums of g) produced by the same kernel; both go straight
@@ -167,6 +186,8 @@ class _MlpFn(torch.autograd.Function):
         # bf16 storage (lib.set_storage): h, z live in HBM as bf16 and the GEMMs read the engine's bf16 weight copies
         (w1m, _), (w2m, _) = _wmat(w1, Hd), _wmat(w2, N)
         adt = _act_dtype()
+        if adt == _BF:
+            x2 = _lowp(x2, Hd)              # read by fc1 and by gW1 = gh^T x
         h = torch.empty(T, Hd, device=x.device, dtype=adt)
         z = torch.empty(T, Hd, device=x.device, dtype=adt)
         _gemm(x2, w1m, h, T, Hd, K, K, K, Hd, 0, 1, b1, 1, z, None)
@@ -187,6 +208,8 @@ class _MlpFn(torch.autograd.Function):
         T, K = x2.shape
         Hd, N = w1m.shape[0], w2m.shape[0]
         g2 = gy.reshape(-1, N).contiguous().float()
+        if h.dtype == _BF:
+            g2 = _lowp(g2, Hd)                   # read by gh = g W2 and gW2 = g^T h
         gh = torch.empty(T, Hd, device=g2.device, dtype=h.dtype)
         _gemm_batched(g2, w2m, gh, T, Hd, N, N, Hd, Hd, 0, 0, act=4, residual=z)     # (g W2) * GELU'(z)
         gw2, gb2 = _weight_grad(g2, h, ctx.slots[2], ctx.slots[3], ctx.has_b[1], ctx.w2shape)
@@ -236,7 +259,8 @@ class _SkipMlpFn(torch.autograd.Function):
         x2, wsm, w1m, w2m, z0, t, z1, h = ctx.saved_tensors
         T, C = x2.shape
         Hd, N = w1m.shape[0], w2m.shape[0]
-        g2 = gout.reshape(-1, N).contiguous().float()
+        g32 = gout.reshape(-1, N).contiguous().float()
+        g2 = _lowp(g32, Hd) if h.dtype == _BF else g32      # read by gh = g W2 and gW2 = g^T h
         gh = torch.empty(T, Hd, device=g2.device, dtype=h.dtype)
         _gemm_batched(g2, w2m, gh, T, Hd, N, N, Hd, Hd, 0, 0, act=4, residual=z1)      # (g W2) * GELU'(z1)
         gw2, gb2 = _weight_grad(g2, h, ctx.slots[4], ctx.slots[5], ctx.has_b[2], ctx.wshapes[2])
@@ -244,7 +268,7 @@ class _SkipMlpFn(torch.autograd.Function):
         _gemm_batched(gh, w1m, gt, T, C, Hd, Hd, C, C, 0, 0, act=4, residual=z0)       # (gh W1) * GELU'(z0) = d/d(y + skip)
         gw1, gb1 = _weight_grad(gh, t, ctx.slots[2], ctx.slots[3], ctx.has_b[1], ctx.wshapes[1])
         gx = torch.empty(T, C, device=g2.device)
-        _gemm_batched(gt, wsm, gx, T, C, C, C, C, C, 0, 0, residual=g2 if ctx.outer else None)   # + outer skip
+        _gemm_batched(gt, wsm, gx, T, C, C, C, C, C, 0, 0, residual=g32 if ctx.outer else None)   # + outer skip
         gws, gbs = _weight_grad(gt, x2, ctx.slots[0], ctx.slots[1], ctx.has_b[0], ctx.wshapes[0])
         return gt.reshape(ctx.shape), gx.reshape(ctx.shape), gws, gbs, gw1, gb1, gw2, gb2, None
 
