@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gy, const float* __restrict__ gadd,
                                                             float* __restrict__ gx, float* ggamma, float* gbeta, int T, int C,
-                                                            int rows_per_block) {
+                                                            int rows_per_block, int gy_bf16) {
     extern __shared__ float sm[];            // [2][C] per-block partial of ggamma, gbeta
     float* sg = sm;
     float* sb = sm + C;
@@ -596,12 +596,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         const int rc = min(row, T - 1);
         const float* xr = x + (long long)rc * C;
         const float* gr = gy + (long long)rc * C;
+        const __bf16* gh = reinterpret_cast<const __bf16*>(gy) + (long long)rc * C;      // gy_bf16: the upstream gradient is a bf16 array
         const float* ar = gadd ? gadd + (long long)rc * C : nullptr;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int c = min(lane + 64 * q, C - 1);
             X[q] = xr[c];
-            G[q] = gr[c];
+            G[q] = gy_bf16 ? (float)gh[c] : gr[c];
             A[q] = ar ? ar[c] : 0.f;
         }
         mu = mean[rc];
@@ -898,9 +899,9 @@ extern "C" int dlwp_layernorm_fwd(const float* x, const float* gamma, const floa
     return dlwp_layernorm_fwd_ex(x, gamma, beta, y, mean, rstd, T, C, eps, 0, stream);
 }
 
-extern "C" int dlwp_layernorm_bwd_res(const float* x, const float* gamma, const float* mean, const float* rstd,
-                                      const float* gy, const float* gadd, float* gx, float* ggamma, float* gbeta, int T,
-                                      int C, void* stream) {
+static int layernorm_bwd_impl(const float* x, const float* gamma, const float* mean, const float* rstd, const float* gy,
+                              const float* gadd, float* gx, float* ggamma, float* gbeta, int T, int C, int gy_bf16,
+                              void* stream) {
     DLWP_REQUIRE(x && gamma && mean && rstd && gy && gx && ggamma && gbeta && T > 0 && C > 0, DLWP_E_INVALID,
                  "layernorm_bwd: bad argument");
     DLWP_REQUIRE(C <= 2048, DLWP_E_UNSUPPORTED, "layernorm_bwd: C <= 2048 supported (got %d)", C);
@@ -915,7 +916,7 @@ extern "C" int dlwp_layernorm_bwd_res(const float* x, const float* gamma, const 
     const size_t lds = 2 * C * sizeof(float);
 #define LN_BWD(NQ)                                                                                                   \
     hipLaunchKernelGGL(layernorm_bwd_kernel<NQ>, grid, dim3(256), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, gadd, \
-                       gx, ggamma, gbeta, T, C, rpb)
+                       gx, ggamma, gbeta, T, C, rpb, gy_bf16)
     if (C <= 64) LN_BWD(1);
     else if (C <= 128) LN_BWD(2);
     else if (C <= 256) LN_BWD(4);
@@ -927,9 +928,21 @@ extern "C" int dlwp_layernorm_bwd_res(const float* x, const float* gamma, const 
     return DLWP_OK;
 }
 
+extern "C" int dlwp_layernorm_bwd_res(const float* x, const float* gamma, const float* mean, const float* rstd,
+                                      const float* gy, const float* gadd, float* gx, float* ggamma, float* gbeta, int T,
+                                      int C, void* stream) {
+    return layernorm_bwd_impl(x, gamma, mean, rstd, gy, gadd, gx, ggamma, gbeta, T, C, 0, stream);
+}
+
+extern "C" int dlwp_layernorm_bwd_ex(const float* x, const float* gamma, const float* mean, const float* rstd, const void* gy,
+                                     int gy_bf16, const float* gadd, float* gx, float* ggamma, float* gbeta, int T, int C,
+                                     void* stream) {
+    return layernorm_bwd_impl(x, gamma, mean, rstd, (const float*)gy, gadd, gx, ggamma, gbeta, T, C, gy_bf16 ? 1 : 0, stream);
+}
+
 extern "C" int dlwp_layernorm_bwd(const float* x, const float* gamma, const float* mean, const float* rstd,
                                   const float* gy, float* gx, float* ggamma, float* gbeta, int T, int C, void* stream) {
-    return dlwp_layernorm_bwd_res(x, gamma, mean, rstd, gy, nullptr, gx, ggamma, gbeta, T, C, stream);
+    return layernorm_bwd_impl(x, gamma, mean, rstd, gy, nullptr, gx, ggamma, gbeta, T, C, 0, stream);
 }
 
 extern "C" int dlwp_gelu_bwd(const float* z, const float* gy, float* gz, long long n, void* stream) {

@@ -113,6 +113,7 @@ class _LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x2, w, z)
         ctx.has_bias, ctx.has_res, ctx.act, ctx.shape = bias is not None, residual is not None, act, shape
         ctx.res_pre, ctx.wshape = bool(res_pre) and act, weight.shape
+        ctx.in_dtype = x.dtype if x.dtype == _BF else torch.float32
         ctx.wslot = _grad_slot(weight)
         ctx.bslot = _grad_slot(bias) if bias is not None else None
         return y.reshape(*shape[:-1], N)
@@ -133,7 +134,7 @@ class _LinearFn(torch.autograd.Function):
                 gres = gz.reshape(gy.shape)
         if w.dtype == _BF:
             g2 = _lowp(g2, K)                    # read by both products below
-        gx = torch.empty(T, K, device=g2.device)
+        gx = torch.empty(T, K, device=g2.device, dtype=ctx.in_dtype)   # a bf16 input (LayerNorm output) takes a bf16 gradient
         _gemm(g2, w, gx, T, K, N, N, K, K, 0, 0)                 # gx = g W
         # gW = g^T x, with the bias gradient (column sums of g) produced by the same kernel; both go straight
         # into the parameters' gradient buffers when those exist (fused gradient accumulation)
@@ -196,6 +197,7 @@ class _MlpFn(torch.autograd.Function):
         _gemm(h, w2m, y, T, N, Hd, Hd, Hd, N, 0, 1, b2, 0, None, r2)
         ctx.save_for_backward(x2, w1m, w2m, z, h)
         ctx.shape, ctx.has_res = shape, residual is not None
+        ctx.in_dtype = x.dtype if x.dtype == _BF else torch.float32
         ctx.w1shape, ctx.w2shape = w1.shape, w2.shape
         ctx.slots = (_grad_slot(w1), _grad_slot(b1) if b1 is not None else None,
                      _grad_slot(w2), _grad_slot(b2) if b2 is not None else None)
@@ -213,7 +215,7 @@ class _MlpFn(torch.autograd.Function):
         gh = torch.empty(T, Hd, device=g2.device, dtype=h.dtype)
         _gemm_batched(g2, w2m, gh, T, Hd, N, N, Hd, Hd, 0, 0, act=4, residual=z)     # (g W2) * GELU'(z)
         gw2, gb2 = _weight_grad(g2, h, ctx.slots[2], ctx.slots[3], ctx.has_b[1], ctx.w2shape)
-        gx = torch.empty(T, K, device=g2.device)
+        gx = torch.empty(T, K, device=g2.device, dtype=ctx.in_dtype)   # a bf16 input (LayerNorm output) takes a bf16 gradient
         _gemm(gh, w1m, gx, T, K, Hd, Hd, K, K, 0, 0)
         gw1, gb1 = _weight_grad(gh, x2, ctx.slots[0], ctx.slots[1], ctx.has_b[0], ctx.w1shape)
         return gx.reshape(ctx.shape), gw1, gb1, gw2, gb2, (gy if ctx.has_res else None)
@@ -325,13 +327,15 @@ class _LayerNormFn(torch.autograd.Function):
             return gres, None, None, None, None, None
         x2, gamma, mean, rstd = ctx.saved_tensors
         T, C_ = x2.shape
-        g2 = gy.reshape(-1, C_).contiguous().float()
+        g2 = gy.reshape(-1, C_).contiguous()          # bf16 when the (bf16) output fed a GEMM: read as it is
+        if g2.dtype != _BF:
+            g2 = g2.float()
         r2 = gres.reshape(-1, C_).contiguous().float() if gres is not None else None
         gx = torch.empty_like(x2)
         fused = ctx.slots[0] is not None and ctx.slots[1] is not None
         gg, gb = ctx.slots if fused else (torch.zeros_like(gamma), torch.zeros_like(gamma))
-        L.check(lib.dlwp_layernorm_bwd_res(L.ptr(x2), L.ptr(gamma.contiguous()), L.ptr(mean), L.ptr(rstd), L.ptr(g2),
-                                           L.ptr(r2), L.ptr(gx), L.ptr(gg), L.ptr(gb), T, C_, L.stream()))
+        L.check(lib.dlwp_layernorm_bwd_ex(L.ptr(x2), L.ptr(gamma.contiguous()), L.ptr(mean), L.ptr(rstd), L.ptr(g2),
+                                          int(g2.dtype == _BF), L.ptr(r2), L.ptr(gx), L.ptr(gg), L.ptr(gb), T, C_, L.stream()))
         if fused:
             return gx.reshape(ctx.shape), None, None, None, None, None
         return gx.reshape(ctx.shape), gg, gb, None, None, None

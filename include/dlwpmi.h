@@ -449,6 +449,11 @@ int dlwp_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
 /* reader is a GEMM under bf16 storage (dlwp_gemm_mixed); statistics and the backward pass stay fp32.       */
 int dlwp_layernorm_fwd_ex(const float* x, const float* gamma, const float* beta, void* y, float* mean,
                           float* rstd, int T, int C, float eps, int y_bf16, void* stream);
+/* Backward of a LayerNorm whose bf16 output fed a GEMM: the upstream gradient arrives as a bf16 array      */
+/* (gy_bf16 != 0) straight from that GEMM's input-gradient product; gadd as in dlwp_layernorm_bwd_res.      */
+int dlwp_layernorm_bwd_ex(const float* x, const float* gamma, const float* mean, const float* rstd,
+                          const void* gy, int gy_bf16, const float* gadd, float* gx, float* ggamma,
+                          float* gbeta, int T, int C, void* stream);
 /* gx written; ggamma/gbeta ACCUMULATED into.  C <= 2048.                                    */
 int dlwp_layernorm_bwd(const float* x, const float* gamma, const float* mean, const float* rstd,
                        const float* gy, float* gx, float* ggamma, float* gbeta, int T, int C,
