@@ -4,7 +4,7 @@ rollout models built on libdlwpmi's kernels, at the reference's nsbench / dlwpbe
 forward rollout + MSE + backward (autograd over the HIP ops) + one fused Adam launch on the flat parameter
 buffer, captured into a hipGraph by train_engine.GraphedTrainStep (--no-graph: eager dispatch).
 
-    python tools/bench_models.py [afno|afno_tiled|afno_fcn|swin|swin_c4|swin_dlwp|sfno|pangu|pangu_c4|all] [--steps N]
+    python tools/bench_models.py [afno|afno_tiled|afno_fcn|afno_c5p1|swin|swin_c4|swin_dlwp|sfno|pangu|pangu_c4|all] [--steps N]
 """
 import argparse
 import json
@@ -93,6 +93,19 @@ def main():
                       prognostic=torch.randn(1, 2, 8, 720, 1440, generator=g).to(dev))
             return kw, torch.randn(1, 1, 8, 720, 1440, generator=g).to(dev), 1
         run("dlwpbench AFNONet 720x1440 p8 E768 depth12 nb16 B1 T2", m, batch, a.steps, use_graph=not a.no_graph)
+    if a.which in ("afno_c5p1",):
+        # BASELINE C5 as worded: the shipped dlwpbench fourcastnet.yaml (patch [1, 1], E=64, depth 4, 4 blocks) on the ERA5 0.25 deg
+        # grid 721 x 1440 = 1.04 M tokens: the AFNO filter runs on the LDS-staged rFFT2 kernels (721 = 7 * 103: generic prime pass)
+        m = dlwpbench.AFNONet(img_height=721, img_width=1440, patch_size=(1, 1), constant_channels=4, prescribed_channels=1,
+                              prognostic_channels=8, embed_dim=64, depth=4, mlp_ratio=4.0, num_blocks=4, context_size=1)
+
+        def batch(dev):
+            kw = dict(constants=torch.randn(1, 1, 4, 721, 1440, generator=g).to(dev),
+                      prescribed=torch.randn(1, 2, 1, 721, 1440, generator=g).to(dev),
+                      prognostic=torch.randn(1, 2, 8, 721, 1440, generator=g).to(dev))
+            return kw, torch.randn(1, 1, 8, 721, 1440, generator=g).to(dev), 1
+        run("dlwpbench AFNONet 721x1440 p1 E64 depth4 nb4 (shipped fourcastnet.yaml on the C5 grid) B1 T2", m, batch, a.steps,
+            use_graph=not a.no_graph)
     if a.which in ("swin", "all"):
         m = nsbench.SwinTransformer(context_size=10, pretrain_img_size=64, patch_size=2, in_chans=1, out_chans=1,
                                     embed_dim=40, depths=[4, 4], num_heads=[4, 4], drop_path_rate=0.0)
