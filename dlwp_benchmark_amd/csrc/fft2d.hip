@@ -32,6 +32,10 @@ struct FftAxis {
     int rad[MAXRAD];
     FastDiv dp[MAXRAD], dM[MAXRAD];  // division by p (product of the earlier radices) and by M = p * R
     const float2* tab;               // [N] e^{-2 pi i n / N} (device)
+    // last radix R >= 16 (a large prime: 103 of 721): its DFT as a real GEMM on the matrix cores.  amat: [2][2 RP][2 RP] floats
+    // (device; forward, inverse), the real image [[Fr, -Fi], [Fi, Fr]] of F[q][r] = e^{sg 2 pi i q r / R} padded to RP = 8-multiple
+    const float* amat;
+    int rp;
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
@@ -116,10 +120,108 @@ __device__ __forceinline__ void pass_small(float2* buf, const float2* tabs, cons
     __syncthreads();
 }
 
+// Last Stockham pass for a LARGE prime radix R (p = N / R butterflies per lane) on the matrix cores.  The generic pass costs R
+// complex multiply-adds per output on the VALU with two LDS reads each (721 = 7 x 103: 110 per point, 2.2 of the 2.4 ms of a
+// 721 x 1440 x 64 transform; with this pass the transform takes 1.33 ms, the pass itself now bound by the fp32 MFMA rate:
+// 28 GFLOP of real-GEMM work per 721-row pass).  Here: (1) the inputs take their twiddles w^(r k) in place; (2) out[q p + k] = sum_r F[q][r]
+// in[k + p r] is the real GEMM  [Yr; Yi] = [[Fr, -Fi], [Fi, Fr]] . [Xr; Xi]  with M = K = 2 RP rows and one column per (k, lane):
+// A fragments come from the precomputed matrix in L2 (16 bytes per lane and 16-deep chunk, every wave owns one or two 16-row
+// panels and re-uses its fragment for all column tiles), B fragments from the LDS tile; (3) the accumulators overwrite the tile.
+template <int NT>
+__device__ __forceinline__ void pass_prime_mfma(float2* buf, const float2* tabs, const FftAxis& f, int s, int p, float sg) {
+    constexpr int NW = NT / 64, GNT = 4;            // column tiles per group: 32 accumulator registers
+    const int R = f.rad[s], RP = f.rp, K2 = 2 * RP, IBP = f.IB + 1, tid = threadIdx.x;
+    const int ncols = p << f.logIB, ntn = (ncols + 15) >> 4, ntm = K2 >> 4;
+    const int lane = tid & 63, wv = tid >> 6, rl = lane & 15, g = lane >> 4;
+    for (int e = tid; e < f.N << f.logIB; e += NT) {
+        const int ln = e & (f.IB - 1), idx = e >> f.logIB;
+        const int r = fastdiv(idx, f.dp[s]), k = idx - r * p;
+        if (r && k) {
+            float2 w = tabs[r * k];              // r k < N: the last pass has M = N, step = 1
+            w.y *= -sg;                          // table holds e^{-i theta}
+            buf[idx * IBP + ln] = cmul(buf[idx * IBP + ln], w);
+        }
+    }
+    const float* A = f.amat + (sg > 0.f ? (long long)K2 * K2 : 0);
+    const int mt0 = wv, mt1 = wv + NW;
+    const bool has0 = mt0 < ntm, has1 = mt1 < ntm;
+    // this wave's one or two 16-row panels of the matrix: fragments come from L2 with the next two chunks' loads in flight
+    const float* A0 = A + (long long)(16 * mt0 + rl) * K2 + 4 * g;
+    const float* A1 = A + (long long)(16 * (has1 ? mt1 : mt0) + rl) * K2 + 4 * g;
+    __syncthreads();                                  // twiddled inputs visible
+    // Columns (k, lane) are independent -- column c reads and writes only rows {k + p r} of lane c -- so the tile is updated in
+    // place one group of GNT column tiles at a time: compute the group (all waves), barrier, overwrite, barrier.
+    for (int nt0 = 0; nt0 < ntn; nt0 += GNT) {
+        f32x4 acc[2][GNT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < GNT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (has0) {
+            f32x4 p0 = *reinterpret_cast<const f32x4*>(A0), p1 = *reinterpret_cast<const f32x4*>(A1);
+            f32x4 q0 = p0, q1 = p1;
+            if (ntm > 1) { q0 = *reinterpret_cast<const f32x4*>(A0 + 16); q1 = *reinterpret_cast<const f32x4*>(A1 + 16); }
+#pragma unroll 1
+            for (int kc = 0; kc < ntm; ++kc) {
+                const f32x4 a0 = p0, a1 = p1;
+                p0 = q0; p1 = q1;
+                if (kc + 2 < ntm) {
+                    q0 = *reinterpret_cast<const f32x4*>(A0 + 16 * (kc + 2));
+                    q1 = *reinterpret_cast<const f32x4*>(A1 + 16 * (kc + 2));
+                }
+                int roff[4];
+                bool im[4], okk[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {     // this lane's four K slots: plane (re | im) and input index r
+                    const int kk = 16 * kc + 4 * g + q;
+                    im[q] = kk >= RP;
+                    const int r = kk - (im[q] ? RP : 0);
+                    okk[q] = r < R;
+                    roff[q] = p * min(r, R - 1) * IBP;
+                }
+#pragma unroll
+                for (int j = 0; j < GNT; ++j) {
+                    const int nt = nt0 + j;
+                    if (nt < ntn) {
+                        const int n = 16 * nt + rl, nc = min(n, ncols - 1);
+                        const int k = nc >> f.logIB, ln = nc & (f.IB - 1);
+                        const float* col = reinterpret_cast<const float*>(buf + k * IBP + ln);
+                        f32x4 b;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) b[q] = (okk[q] && n < ncols) ? col[2 * roff[q] + (im[q] ? 1 : 0)] : 0.f;
+                        acc[0][j] = mfma16_chunk(a0, b, acc[0][j]);
+                        if (has1) acc[1][j] = mfma16_chunk(a1, b, acc[1][j]);
+                    }
+                }
+            }
+        }
+        __syncthreads();                              // every wave is done reading this column group
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mt = i ? mt1 : mt0;
+            if (mt < ntm) {
+#pragma unroll
+                for (int j = 0; j < GNT; ++j) {
+                    const int n = 16 * (nt0 + j) + rl;
+                    if (nt0 + j < ntn && n < ncols) {
+                        const int k = n >> f.logIB, ln = n & (f.IB - 1);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int m = 16 * mt + 4 * g + jj, pl = m >= RP ? 1 : 0, q = m - pl * RP;
+                            if (q < R) reinterpret_cast<float*>(buf + (q * p + k) * IBP + ln)[pl] = acc[i][j][jj];
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // In-place mixed-radix Stockham FFT of buf[N][IB + 1] (complex, LDS); tabs [N] twiddles in LDS; sg = -1 forward, +1 inverse.
 // Radices 2, 3, 4, 5 use register butterflies (pass_small); any other radix (7, 11, ... 103 ...) the generic pass: one output
 // per work item, m = blk * M + q * p + k  <-  sum_r in[(blk * p + k) + r * N / R] * w^(r * (k + q * p)),  w = e^{sg 2 pi i / M}.
-template <int OUTS, int NT>
+template <int OUTS, int NT, bool PRIME = false>
 __device__ __forceinline__ void lds_fft(float2* buf, const float2* tabs, const FftAxis& f, float sg) {
     const int IBP = f.IB + 1, total = f.N << f.logIB, tid = threadIdx.x;
     int p = 1;
@@ -129,6 +231,9 @@ __device__ __forceinline__ void lds_fft(float2* buf, const float2* tabs, const F
         if (R == 2) { pass_small<2, OUTS, NT>(buf, tabs, f, s, p, sg); p = M; continue; }
         if (R == 3) { pass_small<3, OUTS, NT>(buf, tabs, f, s, p, sg); p = M; continue; }
         if (R == 5) { pass_small<5, OUTS, NT>(buf, tabs, f, s, p, sg); p = M; continue; }
+        if constexpr (PRIME) {      // instantiated only for plans with a large last prime: the pass costs 64 accumulator registers
+            if (s == f.nrad - 1) { pass_prime_mfma<NT>(buf, tabs, f, s, p, sg); p = M; continue; }
+        }
         float2 acc[OUTS];
 #pragma unroll
         for (int u = 0; u < OUTS; ++u) {
@@ -180,7 +285,7 @@ __device__ __forceinline__ void load_table(float2* tabs, const FftAxis& f) {
 
 // ---- W-axis real -> complex.  CF = false: channels-last, lanes = channel pairs of row (b, h) = blockIdx.y;
 //      CF = true: channels-first, lanes = pairs of image rows (2 IB consecutive rows per workgroup, blockIdx.y).
-template <int OUTS, int NT, bool CF>
+template <int OUTS, int NT, bool CF, bool PRIME = false>
 __global__ __launch_bounds__(NT) void fft_r2c_kernel(FftIO a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const FftAxis& f = a.ax;
@@ -211,7 +316,7 @@ __global__ __launch_bounds__(NT) void fft_r2c_kernel(FftIO a) {
         }
     }
     __syncthreads();
-    lds_fft<OUTS, NT>(buf, tabs, f, -1.f);
+    lds_fft<OUTS, NT, PRIME>(buf, tabs, f, -1.f);
     // split the two spectra: X1 = (Z_k + conj Z_{W-k}) / 2,  X2 = -i (Z_k - conj Z_{W-k}) / 2
     if (!CF) {
         const int nl = min(f.IB, (a.C - c0) / 2);
@@ -240,7 +345,7 @@ __global__ __launch_bounds__(NT) void fft_r2c_kernel(FftIO a) {
 }
 
 // ---- W-axis complex (Hermitian half) -> real
-template <int OUTS, int NT, bool CF>
+template <int OUTS, int NT, bool CF, bool PRIME = false>
 __global__ __launch_bounds__(NT) void fft_c2r_kernel(FftIO a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const FftAxis& f = a.ax;
@@ -282,7 +387,7 @@ __global__ __launch_bounds__(NT) void fft_c2r_kernel(FftIO a) {
         }
     }
     __syncthreads();
-    lds_fft<OUTS, NT>(buf, tabs, f, +1.f);
+    lds_fft<OUTS, NT, PRIME>(buf, tabs, f, +1.f);
     if (!CF) {
         const int nl = min(f.IB, (a.C - c0) / 2);
         float* dst = a.out + o * W * a.C + c0;
@@ -304,7 +409,7 @@ __global__ __launch_bounds__(NT) void fft_c2r_kernel(FftIO a) {
 }
 
 // ---- complex -> complex along an axis of stride J (the H axis of both layouts): element (o, n, j) at ((o * N + n) * J + j)
-template <int OUTS, int NT>
+template <int OUTS, int NT, bool PRIME = false>
 __global__ __launch_bounds__(NT) void fft_c2c_kernel(FftIO a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const FftAxis& f = a.ax;
@@ -320,7 +425,7 @@ __global__ __launch_bounds__(NT) void fft_c2c_kernel(FftIO a) {
         buf[n * IBP + lane] = lane < nl ? src[(long long)n * a.J + lane] : make_float2(0.f, 0.f);
     }
     __syncthreads();
-    lds_fft<OUTS, NT>(buf, tabs, f, a.sg);
+    lds_fft<OUTS, NT, PRIME>(buf, tabs, f, a.sg);
     float2* dst = reinterpret_cast<float2*>(a.out) + o * N * a.J + j0;
     for (int e = threadIdx.x; e < N << f.logIB; e += NT) {
         const int lane = e & (f.IB - 1), n = e >> f.logIB;
@@ -345,12 +450,15 @@ struct dlwp_fft_plan {
     int H, W;
     FftAxis axW, axH;         // IB chosen per axis from the LDS budget
     float2 *tabW, *tabH;
+    float *amatW, *amatH;     // DFT matrices of a large last prime radix (pass_prime_mfma), or nullptr
 };
 
 namespace {
 
-int make_axis(FftAxis& ax, int N, float2** tab_dev, int ib_cap) {
+int make_axis(FftAxis& ax, int N, float2** tab_dev, float** amat_dev, int ib_cap) {
     ax.N = N;
+    ax.amat = nullptr;
+    ax.rp = 0;
     ax.nrad = factorise(N, ax.rad);
     DLWP_REQUIRE(ax.nrad > 0, DLWP_E_UNSUPPORTED, "fft: cannot factorise %d into at most %d radices", N, MAXRAD);
     int p = 1;
@@ -362,6 +470,7 @@ int make_axis(FftAxis& ax, int N, float2** tab_dev, int ib_cap) {
     // inner lanes: the widest power of two whose [N][IB + 1] tile plus the table fits ~150 KB of LDS
     int ib = ib_cap;
     while (ib > 1 && (size_t)N * (ib + 2) * sizeof(float2) > 150 * 1024) ib >>= 1;
+
     DLWP_REQUIRE((size_t)N * (ib + 2) * sizeof(float2) <= 150 * 1024, DLWP_E_UNSUPPORTED, "fft: axis length %d does not fit LDS", N);
     ax.IB = ib;
     ax.logIB = 0;
@@ -372,6 +481,29 @@ int make_axis(FftAxis& ax, int N, float2** tab_dev, int ib_cap) {
     DLWP_HIP(hipMalloc(reinterpret_cast<void**>(tab_dev), N * sizeof(float2)));
     DLWP_HIP(hipMemcpy(*tab_dev, tab.data(), N * sizeof(float2), hipMemcpyHostToDevice));
     ax.tab = *tab_dev;
+    // a large prime as the last radix: its DFT matrix for the matrix-core pass.  Limits of pass_prime_mfma: at most two 16-row
+    // panels per wave (2 RP <= 16 panels with 512 threads: R <= 128)
+    const int R = ax.rad[ax.nrad - 1];
+    const int RP = (R + 7) / 8 * 8, nthreads = N * ib > 4096 ? 512 : 256;
+    if (R >= 16 && nthreads == 512 && 2 * RP / 16 <= 2 * (nthreads / 64)) {
+        const int K2 = 2 * RP;
+        std::vector<float> am(2 * (size_t)K2 * K2, 0.f);
+        for (int dir = 0; dir < 2; ++dir) {
+            const double sgd = dir ? 1.0 : -1.0;
+            for (int m = 0; m < K2; ++m)
+                for (int kk = 0; kk < K2; ++kk) {
+                    const int po = m / RP, q = m % RP, pi = kk / RP, r = kk % RP;
+                    if (q >= R || r >= R) continue;
+                    const double th = 2.0 * PI * (double)(((long long)q * r) % R) / R;
+                    const double Fr = cos(th), Fi = sgd * sin(th);
+                    am[((size_t)dir * K2 + m) * K2 + kk] = (float)(po == 0 ? (pi == 0 ? Fr : -Fi) : (pi == 0 ? Fi : Fr));
+                }
+        }
+        DLWP_HIP(hipMalloc(reinterpret_cast<void**>(amat_dev), am.size() * sizeof(float)));
+        DLWP_HIP(hipMemcpy(*amat_dev, am.data(), am.size() * sizeof(float), hipMemcpyHostToDevice));
+        ax.amat = *amat_dev;
+        ax.rp = RP;
+    }
     return DLWP_OK;
 }
 
@@ -402,6 +534,12 @@ LaunchShape shape_of(const FftAxis& ax) {
                 case 4: go(KERNEL_T<4, 256 EXTRA>, 256); break;                                                        \
                 case 8: go(KERNEL_T<8, 256 EXTRA>, 256); break;                                                        \
                 default: go(KERNEL_T<16, 256 EXTRA>, 256); break;                                                      \
+            }                                                                                                          \
+        } else if (io.ax.amat) {       /* large last prime radix on the matrix cores (pass_prime_mfma) */                \
+            switch (sh.outs) {                                                                                         \
+                case 16: go(KERNEL_T<16, 512 EXTRA, true>, 512); break;                                                \
+                case 24: go(KERNEL_T<24, 512 EXTRA, true>, 512); break;                                                \
+                default: go(KERNEL_T<32, 512 EXTRA, true>, 512); break;                                                \
             }                                                                                                          \
         } else {                                                                                                       \
             switch (sh.outs) {                                                                                         \
@@ -473,9 +611,9 @@ void norm_scales(int norm, int H, int W, float& sW_f, float& sH_f, float& sW_i, 
 extern "C" int dlwp_fft_plan_create(int H, int W, dlwp_fft_plan** out) {
     DLWP_REQUIRE(out && H > 0 && W > 1, DLWP_E_INVALID, "fft_plan_create: bad shape");
     dlwp_fft_plan* p = new dlwp_fft_plan();
-    p->H = H; p->W = W; p->tabW = p->tabH = nullptr;
+    p->H = H; p->W = W; p->tabW = p->tabH = nullptr; p->amatW = p->amatH = nullptr;
     int rc;
-    if ((rc = make_axis(p->axW, W, &p->tabW, 8)) || (rc = make_axis(p->axH, H, &p->tabH, 16))) {
+    if ((rc = make_axis(p->axW, W, &p->tabW, &p->amatW, 8)) || (rc = make_axis(p->axH, H, &p->tabH, &p->amatH, 16))) {
         dlwp_fft_plan_destroy(p);
         return rc;
     }
@@ -487,6 +625,8 @@ extern "C" void dlwp_fft_plan_destroy(dlwp_fft_plan* p) {
     if (!p) return;
     if (p->tabW) (void)hipFree(p->tabW);
     if (p->tabH) (void)hipFree(p->tabH);
+    if (p->amatW) (void)hipFree(p->amatW);
+    if (p->amatH) (void)hipFree(p->amatH);
     delete p;
 }
 
