@@ -148,6 +148,55 @@ __global__ __launch_bounds__(256) void patch_merge_kernel(const float* __restric
     }
 }
 
+// Transposed convolution with kernel == stride on channels-last tokens (Swin U-decoder: nn.ConvTranspose2d(k, stride k) + GELU,
+// src/nsbench/models/swintransformer/swin_transformer.py:580-588): the GEMM y[m][(o, i, j)] = x[m] . W[c][(o, i, j)] leaves the
+// matrix cores in (pixel, o, i, j) order; this kernel adds the bias, applies the activation and interleaves the k x k blocks
+// into the up-sampled token grid out[b][h k + i][w k + j][coff + o] (row pitch ctot: the result can land inside the concat
+// buffer of the next decoder level).  One thread per (pixel m, channel o): its k*k inputs are contiguous, every store is
+// coalesced over o.  BWD: gy = gout * act'(y + bias) back in GEMM order, bias gradient summed per workgroup in LDS.
+template <bool BWD>
+__global__ __launch_bounds__(256) void upconv_shuffle_kernel(const float* __restrict__ y, const float* __restrict__ bias,
+                                                             const float* __restrict__ gout, float* __restrict__ dst,
+                                                             float* gbias, int B, int H, int W, int O, int kh, int kw, int ctot,
+                                                             int coff, int act) {
+    extern __shared__ float gb_s[];           // BWD: [O]
+    const int kk = kh * kw;
+    if (BWD) {
+        for (int i = threadIdx.x; i < O; i += 256) gb_s[i] = 0.f;
+        __syncthreads();
+    }
+    const long long total = (long long)B * H * W * O;
+    const int Ho = H * kh, Wo = W * kw;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int o = (int)(e % O);
+        long long m = e / O;
+        const int w = (int)(m % W);
+        const long long r = m / W;
+        const int h = (int)(r % H), b = (int)(r / H);
+        const float bo = bias ? bias[o] : 0.f;
+        const float* yp = y + m * (long long)O * kk + (long long)o * kk;
+        float gsum = 0.f;
+        for (int ij = 0; ij < kk; ++ij) {
+            const int i = ij / kw, j = ij - i * kw;
+            const long long po = (((long long)b * Ho + h * kh + i) * Wo + w * kw + j) * ctot + coff + o;
+            const float z = yp[ij] + bo;
+            if (BWD) {
+                const float g = gout[po] * (act == 1 ? gelu_grad_f(z) : 1.f);
+                dst[m * (long long)O * kk + (long long)o * kk + ij] = g;
+                gsum += g;
+            } else {
+                dst[po] = act == 1 ? gelu_f(z) : z;
+            }
+        }
+        if (BWD && gbias) atomicAdd(&gb_s[o], gsum);
+    }
+    if (BWD && gbias) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < O; i += 256)
+            if (gb_s[i] != 0.f) atomic_add_f32(&gbias[i], gb_s[i]);
+    }
+}
+
 int win_setup(WinDev& a, const float* src, float* dst, int B, int C, const int* D, const int* P, const int* f, const int* s,
               const int* w, const long long* sw, const int* circ, const char* who) {
     DLWP_REQUIRE(src && dst && D && P && f && s && w && sw && circ && B > 0 && C > 0, DLWP_E_INVALID, "%s: bad argument", who);
@@ -196,6 +245,23 @@ extern "C" int dlwp_window_scatter(const float* windows, float* x, int B, int C,
                                    const int* circular, int sum_copies, void* stream) {
     return dlwp_window_scatter_add(windows, nullptr, x, B, C, dims, padded, front, shift, window, wstride, circular, sum_copies,
                                    stream);
+}
+
+extern "C" int dlwp_upconv_shuffle(const float* y, const float* bias, const float* gout, float* dst, float* gbias, int B, int H,
+                                   int W, int O, int kh, int kw, int ctot, int coff, int act, int backward, void* stream) {
+    DLWP_REQUIRE(y && dst && B > 0 && H > 0 && W > 0 && O > 0 && kh > 0 && kw > 0 && ctot >= coff + O && coff >= 0 &&
+                     (act == 0 || act == 1) && (!backward || gout),
+                 DLWP_E_INVALID, "upconv_shuffle: bad argument");
+    const long long total = (long long)B * H * W * O;
+    const dim3 grid(grid_for(total));
+    if (backward)
+        hipLaunchKernelGGL(upconv_shuffle_kernel<true>, grid, dim3(256), O * sizeof(float), (hipStream_t)stream, y, bias, gout, dst,
+                           gbias, B, H, W, O, kh, kw, ctot, coff, act);
+    else
+        hipLaunchKernelGGL(upconv_shuffle_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, y, bias, gout, dst, gbias, B, H,
+                           W, O, kh, kw, ctot, coff, act);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
 }
 
 extern "C" int dlwp_patch_merge(const float* src, float* dst, int B, int H, int W, int C, int backward, void* stream) {

@@ -70,16 +70,19 @@ class SwinTransformer(nn.Module):
         x = self.patch_embed(x)
         Wh, Ww = x.shape[2], x.shape[3]
         x = x.flatten(2).transpose(1, 2)
+        # U-decoder on channels-last tokens (reference :580-591 / one_step): stage outputs stay [B, H, W, C], the transposed
+        # convolutions are a GEMM + one interleave kernel each, the 1 x 1 head is a GEMM; NCHW only for the returned frame
         feats = []
         for i, layer in enumerate(self.layers):
             x_out, H, W, x, Wh, Ww = layer(x, Wh, Ww)
             x_out = getattr(self, f"norm{i}")(x_out)
-            feats.append(x_out.view(-1, H, W, self.num_features[i]).permute(0, 3, 1, 2).contiguous())
+            feats.append(x_out.reshape(-1, H, W, self.num_features[i]))
         feats.reverse()
         y = None
         for idx, up in enumerate(self.decoder):
-            y = up[0](feats[idx] if idx == 0 else torch.cat([feats[idx], y], dim=1), act=1)   # GELU in the GEMM epilogue
-        return self.final(y)
+            y = up[0].forward_tokens(feats[idx] if idx == 0 else torch.cat([feats[idx], y], dim=-1), act=1)   # GELU fused
+        y = self.final.forward_tokens(y)                      # [B, H, W, out]
+        return y.permute(0, 3, 1, 2)
 
     def forward(self, constants: torch.Tensor = None, prescribed: torch.Tensor = None,
                 prognostic: torch.Tensor = None) -> torch.Tensor:

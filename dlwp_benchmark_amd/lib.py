@@ -70,6 +70,7 @@ SIGNATURES = {
     "dlwp_window_scatter": (_I, [_V, _V, _I, _I] + [_V] * 7 + [_I, _V]),
     "dlwp_window_scatter_add": (_I, [_V, _V, _V, _I, _I] + [_V] * 7 + [_I, _V]),
     "dlwp_patch_merge": (_I, [_V, _V, _I, _I, _I, _I, _I, _V]),
+    "dlwp_upconv_shuffle": (_I, [_V] * 5 + [_I] * 10 + [_V]),
     "dlwp_window_advance_fwd": (_I, [_V, _L, _V, _V, _V, _I, _I, _L] + [_I] * 6 + [_V]),
     "dlwp_window_advance_bwd": (_I, [_V, _V, _L, _V, _L, _V, _V, _I, _I, _L] + [_I] * 6 + [_V]),
     "dlwp_gemm": (_I, [_V, _V, _V] + [_I] * 8 + [_V, _I, _V, _V, _I, _V, _V]),

@@ -585,6 +585,60 @@ class PatchConv2d(nn.Conv2d):
         y = _LinearFn.apply(cols, self.weight, self.bias, act, None, False)
         return y.reshape(B, h, w, self.out_channels).permute(0, 3, 1, 2)
 
+    def forward_tokens(self, x, act=0):
+        """1 x 1 form on channels-last tokens [B, H, W, Cin] -> [B, H, W, O]: the GEMM alone (no unfold copy)."""
+        assert tuple(self.kernel_size) == (1, 1) and tuple(self.stride) == (1, 1)
+        return _LinearFn.apply(x, self.weight, self.bias, act, None, False)
+
+
+class _UpConvTokensFn(torch.autograd.Function):
+    """ConvTranspose2d(kernel == stride) + activation on channels-last tokens [B, H, W, Cin] -> [B, H kh, W kw, O]: one GEMM in
+    the weight's own [Cin][O kh kw] layout (no transposed copy), then dlwp_upconv_shuffle (bias + activation + k x k interleave,
+    one launch).  Backward: the adjoint shuffle (with the activation's derivative and the bias gradient), then gx = gy W^T and
+    gW += x^T gy straight into the weight's gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        B, H, W_, Cin = x.shape
+        O, kh, kw = weight.shape[1], weight.shape[2], weight.shape[3]
+        N = O * kh * kw
+        x2 = x.reshape(-1, Cin).contiguous().float()
+        M = x2.shape[0]
+        wsh = L.shadow(weight)
+        wm = (wsh if wsh is not None else weight.contiguous()).reshape(Cin, N)
+        y = torch.empty(M, N, device=x.device)
+        _gemm(x2, wm, y, M, N, Cin, Cin, N, N, 0, 0)
+        out = torch.empty(B, H * kh, W_ * kw, O, device=x.device)
+        L.check(L.load().dlwp_upconv_shuffle(L.ptr(y), L.ptr(bias), None, L.ptr(out), None, B, H, W_, O, kh, kw, O, 0, act, 0,
+                                             L.stream()))
+        ctx.save_for_backward(x2, wm, y, bias)
+        ctx.cfg = (B, H, W_, Cin, O, kh, kw, act)
+        ctx.wslot, ctx.bslot, ctx.wshape = _grad_slot(weight), (_grad_slot(bias) if bias is not None else None), weight.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x2, wm, y, bias = ctx.saved_tensors
+        B, H, W_, Cin, O, kh, kw, act = ctx.cfg
+        M, N = x2.shape[0], O * kh * kw
+        g = gout.contiguous().float()
+        gy = torch.empty(M, N, device=g.device)
+        gb = None
+        if bias is not None:
+            gb = ctx.bslot if ctx.bslot is not None else torch.zeros(O, device=g.device)
+        L.check(L.load().dlwp_upconv_shuffle(L.ptr(y), L.ptr(bias), L.ptr(g), L.ptr(gy), L.ptr(gb), B, H, W_, O, kh, kw, O, 0, act, 1,
+                                             L.stream()))
+        gx = torch.empty(M, Cin, device=g.device)
+        _gemm(gy, wm, gx, M, Cin, N, N, N, Cin, 0, 1)                       # gx = gy W^T
+        if ctx.wslot is not None:
+            _gemm(x2, gy, ctx.wslot, Cin, N, M, Cin, N, N, 1, 0, accumulate=1)  # gW += x^T gy, in the parameter's layout
+            gw = None
+        else:
+            gw = torch.empty(Cin, N, device=g.device)
+            _gemm(x2, gy, gw, Cin, N, M, Cin, N, N, 1, 0)
+            gw = gw.reshape(ctx.wshape)
+        return gx.reshape(B, H, W_, Cin), gw, (None if (bias is None or ctx.bslot is not None) else gb), None
+
 
 class UpConvT2d(nn.ConvTranspose2d):
     """ConvTranspose2d with kernel_size == stride (Swin U-decoder, swin_transformer.py:580-588): GEMM over the
@@ -601,3 +655,9 @@ class UpConvT2d(nn.ConvTranspose2d):
         bias = self.bias.repeat_interleave(kh * kw) if self.bias is not None else None
         y = _LinearFn.apply(tokens, wmat, bias, act, None, False)
         return y.reshape(B, H, W, O, kh, kw).permute(0, 3, 1, 4, 2, 5).reshape(B, O, H * kh, W * kw)
+
+    def forward_tokens(self, x, act=0):
+        """Channels-last form: x [B, H, W, Cin] -> [B, H kh, W kw, O] without NCHW round trips (see _UpConvTokensFn)."""
+        kh, kw = self.kernel_size
+        assert tuple(self.stride) == (kh, kw) and self.padding == (0, 0) and self.output_padding == (0, 0)
+        return _UpConvTokensFn.apply(x, self.weight, self.bias, act)

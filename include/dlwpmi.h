@@ -338,6 +338,14 @@ int dlwp_window_scatter_add(const float* windows, const float* residual, float* 
                             const int* dims, const int* padded, const int* front, const int* shift,
                             const int* window, const long long* wstride, const int* circular,
                             int sum_copies, void* stream);
+/* Epilogue of a transposed convolution with kernel == stride on channels-last tokens (the Swin U-decoder's          */
+/* nn.ConvTranspose2d(k, stride k) + GELU, src/nsbench/models/swintransformer/swin_transformer.py:580-588, dlwpbench  */
+/* twin): y [B*H*W][O*kh*kw] is the GEMM x . W[Cin][O*kh*kw] in the weight's own layout; forward: dst[b][h kh+i][w kw+j] */
+/* [coff+o] = act(y + bias[o]) with pixel pitch ctot (dst may be the concat buffer of the next level), act 0 none / 1     */
+/* GELU; backward != 0: dst = gy [B*H*W][O*kh*kw] = gout * act'(y + bias), gbias[o] += its sums (nullable).               */
+int dlwp_upconv_shuffle(const float* y, const float* bias, const float* gout, float* dst, float* gbias,
+                        int B, int H, int W, int O, int kh, int kw, int ctot, int coff, int act,
+                        int backward, void* stream);
 /* Patch merging gather (PatchMerging.forward, src/nsbench/models/swintransformer/swin_transformer.py:291-312 */
 /* and the dlwpbench twin): tokens x [B][H][W][C] -> [B][ceil(H/2)][ceil(W/2)][4C] with channel blocks in the    */
 /* reference's concat order (0,0), (1,0), (0,1), (1,1) and zeros beyond an odd H / W (its constant pad).        */
