@@ -205,3 +205,32 @@ def test_gemm_bf16_deep_k(cuda):
         with L.gemm_precision("bf16"):
             _gemm(A.to(cuda), B.to(cuda), C_, M, N, K, M, N, N, 1, 0)
         assert rel(C_, rb(A).t() @ rb(B)) <= 2e-5
+
+
+@pytest.mark.parametrize("B,H,W,Cin,O,k,act", [(2, 8, 6, 16, 8, 2, 1), (1, 5, 7, 12, 10, 2, 0), (3, 4, 4, 8, 5, 1, 1), (2, 3, 5, 6, 4, 3, 1)])
+def test_upconv_tokens_matches_conv_transpose(cuda, B, H, W, Cin, O, k, act):
+    """UpConvT2d.forward_tokens (GEMM in the weight's layout + dlwp_upconv_shuffle) against nn.ConvTranspose2d (+ GELU) on NCHW."""
+    from dlwp_benchmark_amd import token_ops
+    g = torch.Generator().manual_seed(B * 100 + H * 10 + k)
+    ref = torch.nn.ConvTranspose2d(Cin, O, kernel_size=k, stride=k)
+    with torch.no_grad():
+        ref.weight.copy_(torch.randn(ref.weight.shape, generator=g) * 0.3)
+        ref.bias.copy_(torch.randn(O, generator=g))
+    up = token_ops.UpConvT2d(Cin, O, kernel_size=k, stride=k)
+    up.load_state_dict(ref.state_dict())
+    up = up.to(cuda)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    gy = torch.randn(B, H * k, W * k, O, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr.permute(0, 3, 1, 2))
+    if act:
+        yr = F.gelu(yr)
+    yr = yr.permute(0, 2, 3, 1)
+    yr.backward(gy)
+    xd = x.to(cuda).requires_grad_(True)
+    y = up.forward_tokens(xd, act=act)
+    y.backward(gy.to(cuda))
+    assert rel(y, yr) <= 1e-4
+    assert rel(xd.grad, xr.grad) <= 5e-4
+    assert rel(up.weight.grad, ref.weight.grad) <= 5e-4
+    assert rel(up.bias.grad, ref.bias.grad) <= 5e-4
