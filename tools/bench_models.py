@@ -4,7 +4,7 @@ rollout models built on libdlwpmi's kernels, at the reference's nsbench / dlwpbe
 forward rollout + MSE + backward (autograd over the HIP ops) + one fused Adam launch on the flat parameter
 buffer, captured into a hipGraph by train_engine.GraphedTrainStep (--no-graph: eager dispatch).
 
-    python tools/bench_models.py [afno|afno_tiled|afno_fcn|afno_c5p1|swin|swin_c4|swin_dlwp|sfno|pangu|pangu_c4|all] [--steps N]
+    python tools/bench_models.py [fno_dlwp|tfno_dlwp|fno_ctx|afno|afno_tiled|afno_fcn|afno_c5p1|swin|swin_c4|swin_dlwp|sfno|pangu|pangu_c4|all] [--steps N]
 """
 import argparse
 import json
@@ -40,6 +40,22 @@ def run(name, model, make_batch, steps, warmup=3, use_graph=True, call=None, lr=
                       "n_params": sum(p.numel() for p in model.parameters())}), flush=True)
 
 
+def run_fno(name, module, step_fn, B, steps, warmup=3):
+    """FNO-family modules carry their own fused trainer (fno_engine): time module.train_step + the fused Adam."""
+    opt = module.make_optimizer(lr=1e-3)
+    for _ in range(warmup):
+        step_fn(opt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step_fn(opt)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"model": name, "graph": True, "gemm_precision": "fp32", "storage": "fp32", "samples_per_s": round(B * steps / dt, 2),
+                      "ms_per_step": round(dt / steps * 1e3, 3), "batch": B, "loss": float(loss),
+                      "n_params": sum(p.numel() for p in module.parameters())}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("which", nargs="?", default="all")
@@ -59,6 +75,33 @@ def main():
     global PRECISION
     PRECISION = a.precision
     g = torch.Generator().manual_seed(1234)
+    dev0 = torch.device("cuda:0")
+    if a.which in ("fno_dlwp", "tfno_dlwp"):
+        # dlwpbench configs/model/fno.yaml on WeatherBench 5.625 deg shapes (8 prognostic variables), T = 5; tfno_dlwp: the
+        # Tucker-factorised weights (rank 0.8) of dlwp TFNO2DModule, fno_dlwp: the dense FNO2DModule
+        cls = dlwpbench.TFNO2DModule if a.which == "tfno_dlwp" else dlwpbench.FNO2DModule
+        kw = dict(constant_channels=4, prescribed_channels=1, prognostic_channels=8, n_modes=[12, 12], hidden_channels=32,
+                  lifting_channels=256, projection_channels=256, n_layers=4, context_size=1)
+        if a.which == "tfno_dlwp":
+            kw["rank"] = 0.8
+        m = cls(**kw).to(dev0)
+        B, T = 16, 5
+        c = torch.randn(B, 1, 4, 32, 64, generator=g).to(dev0)
+        pr = torch.randn(B, T, 1, 32, 64, generator=g).to(dev0)
+        pg = torch.randn(B, T, 8, 32, 64, generator=g).to(dev0)
+        tg = torch.randn(B, T - 1, 8, 32, 64, generator=g).to(dev0)
+        run_fno(f"dlwpbench {cls.__name__} 32x64 hidden32 L4 modes12" + (" rank0.8" if a.which == "tfno_dlwp" else "") + f" B{B} T{T}",
+                m, lambda opt: m.train_step(c, pr, pg, tg, optimizer=opt), B, a.steps)
+    if a.which in ("fno_ctx",):
+        # nsbench configs/model/fno.yaml as shipped: FNOContextModule, n_modes [12, 12, 12] (context 12 = n_modes[0]), 1 layer:
+        # a 3-D FNO over (context, H, W) inside the closed-loop rollout, T = 20, teacher forcing 12
+        m = nsbench.FNOContextModule(n_modes=[12, 12, 12], in_channels=1, hidden_channels=32, lifting_channels=256,
+                                     projection_channels=256, out_channels=1, n_layers=1, context_size=10).to(dev0)
+        B, T = 4, 20
+        u = torch.randn(B, T + 1, 1, 64, 64, generator=g).to(dev0)
+        x, y = u[:, :-1].contiguous(), u[:, 1:].contiguous()
+        run_fno("nsbench FNOContextModule 64x64 modes[12,12,12] hidden32 L1 (3-D FNO over the context) B4 T20",
+                m, lambda opt: m.train_step(x, y, 12, optimizer=opt), B, a.steps)
     if a.which in ("afno", "all"):
         # nsbench configs/model/fourcastnet.yaml with the paper runs' context 10 (train_commands.txt:112-115), T=20, tf=10
         m = nsbench.AFNONet(img_height=64, img_width=64, patch_size=(4, 4), in_chans=1, out_chans=1, embed_dim=64, depth=4,
