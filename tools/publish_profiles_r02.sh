@@ -4,7 +4,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 T=r02
 F=$R/gpurun_out/final_r02
 P=$R/profiles
-stats() { ls "$F/$1"/*/*kernel_stats.csv 2>/dev/null | head -1; }
+stats() { ls -t "$F/$1"/*/*kernel_stats.csv 2>/dev/null | head -1; }
 cp "$F/bench_line.json" "$P/${T}_bench_line.json"
 cp "$F/bench_line_h217.json" "$P/${T}_bench_line_hidden217.json"
 cp "$F/bench_line_sfno.json" "$P/${T}_bench_line_sfno.json"
