@@ -69,6 +69,23 @@ __device__ __forceinline__ f32x4 mfma16_chunk(const f32x4 a, const f32x4 b, f32x
     return c;
 }
 
+// The same chunk with bf16 operands (fp32 accumulation): v_mfma_f32_16x16x16_bf16 takes exactly the fragment layout of the
+// permuted-k chunk -- lane (r, g) supplies A[m=r][k=4g..4g+3] and B[k=4g..4g+3][n=r] -- so ONE instruction (8 cycles) replaces the
+// four fp32 ones (4 x 32 cycles).  Used where the run asks for bf16 matrix arithmetic (dlwp_set_gemm_precision(1)): window
+// attention's Q K^T, P V and their backward products; softmax statistics, bias and accumulators stay fp32.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <bool BF>
+__device__ __forceinline__ f32x4 mfma16_chunk_p(const f32x4 a, const f32x4 b, f32x4 c) {
+    if constexpr (BF) {
+        typedef __bf16 bh4 __attribute__((ext_vector_type(4)));
+        const bh4 ah = {(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3]};
+        const bh4 bh = {(__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, ah), __builtin_bit_cast(s16x4, bh), c, 0, 0, 0);
+    } else {
+        return mfma16_chunk(a, b, c);
+    }
+}
+
 // Exact (erf) GELU and its derivative, evaluated together in ~17 VALU instructions.
 // erfc via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, fp32 rounding level) with one v_rcp_f32
 // and one v_exp_f32: libm erff costs ~100 issue slots per element and made the MLP kernels

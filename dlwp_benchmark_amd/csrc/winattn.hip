@@ -125,11 +125,11 @@ __device__ __forceinline__ f32x4 ldsv(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ int4 ldsi(const int* p) { return *reinterpret_cast<const int4*>(p); }
 
 // score tile of one 16-row chunk against this wave's 16 columns: acc[j] = sum_dd A[16c + 4g + j][dd] * Bfrag[dd][r]
-template <int NDB>
+template <int NDB, bool BF>
 __device__ __forceinline__ f32x4 score_chunk(const float* rows_a, int LDT, const f32x4 (&bfrag)[NDB], int r, int g) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int cc = 0; cc < NDB; ++cc) acc = mfma16_chunk(ldsv(&rows_a[r * LDT + 16 * cc + 4 * g]), bfrag[cc], acc);
+    for (int cc = 0; cc < NDB; ++cc) acc = mfma16_chunk_p<BF>(ldsv(&rows_a[r * LDT + 16 * cc + 4 * g]), bfrag[cc], acc);
     return acc;
 }
 
@@ -138,7 +138,7 @@ __device__ __forceinline__ f32x4 score_chunk(const float* rows_a, int LDT, const
 // per tile).  NBUF = 1 (windows of at most 128 tokens, i.e. one or two tiles): a single buffer and two barriers per tile --
 // the workgroup needs ~40 % less LDS, so twice as many of them are resident per CU, which is what hides latency when every
 // workgroup is this short (Swin 7 x 7 = 49, Pangu 2 x 7 x 7 = 98 tokens per window: profiles/r02_winattn_probe.txt).
-template <int NDB, int NBUF>
+template <int NDB, int NBUF, bool BF>
 __global__ __launch_bounds__(256) void winattn_fwd_kernel(WaDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NL = 4 * NDB, LDT = 16 * NDB + 4, DP = 16 * NDB;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(WaDev a) {
         float mx = -1e30f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            s[c] = score_chunk<NDB>(Kc + 16 * c * LDT, LDT, qf, r, g);
+            s[c] = score_chunk<NDB, BF>(Kc + 16 * c * LDT, LDT, qf, r, g);
             const int4 kb4 = ldsi(&kbs[buf * 64 + 16 * c + 4 * g]);
             const int4 kl4 = ldsi(&klab[buf * 64 + 16 * c + 4 * g]);
             const int kbv[4] = {kb4.x, kb4.y, kb4.z, kb4.w}, klv[4] = {kl4.x, kl4.y, kl4.z, kl4.w};
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(WaDev a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) oacc[db][j] *= corr;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) oacc[db] = mfma16_chunk(ldsv(&Vc[(16 * db + r) * LDV + 16 * c + 4 * g]), s[c], oacc[db]);
+            for (int c = 0; c < 4; ++c) oacc[db] = mfma16_chunk_p<BF>(ldsv(&Vc[(16 * db + r) * LDV + 16 * c + 4 * g]), s[c], oacc[db]);
         }
         if (NBUF == 1) __syncthreads();          // every wave is done reading the tile that is about to be overwritten
         if (more) commit_tile(kt0 + KT, NBUF == 2 ? buf ^ 1 : 0);
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(WaDev a) {
 
 // ------------------------------------------------------------------------------------------------
 // backward, query side: dQ, dBias, D.  Same tiling as forward.
-template <int NDB, int NBUF>
+template <int NDB, int NBUF, bool BF>
 __global__ __launch_bounds__(256) void winattn_bwd_q_kernel(WaDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NL = 4 * NDB, LDT = 16 * NDB + 4, DP = 16 * NDB;
@@ -363,8 +363,8 @@ __global__ __launch_bounds__(256) void winattn_bwd_q_kernel(WaDev a) {
         const float* Ktc = Kt + buf * DP * LDV;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const f32x4 s = score_chunk<NDB>(Kc + 16 * c * LDT, LDT, qf, r, g);
-            const f32x4 dp = score_chunk<NDB>(Vc + 16 * c * LDT, LDT, gf, r, g);   // dP^T = V dO^T
+            const f32x4 s = score_chunk<NDB, BF>(Kc + 16 * c * LDT, LDT, qf, r, g);
+            const f32x4 dp = score_chunk<NDB, BF>(Vc + 16 * c * LDT, LDT, gf, r, g);   // dP^T = V dO^T
             const int4 kb4 = ldsi(&kbs[buf * 64 + 16 * c + 4 * g]);
             const int4 kl4 = ldsi(&klab[buf * 64 + 16 * c + 4 * g]);
             const int kbv[4] = {kb4.x, kb4.y, kb4.z, kb4.w}, klv[4] = {kl4.x, kl4.y, kl4.z, kl4.w};
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void winattn_bwd_q_kernel(WaDev a) {
                 ds[j] = v;
             }
 #pragma unroll
-            for (int db = 0; db < NDB; ++db) dq[db] = mfma16_chunk(ldsv(&Ktc[(16 * db + r) * LDV + 16 * c + 4 * g]), ds, dq[db]);
+            for (int db = 0; db < NDB; ++db) dq[db] = mfma16_chunk_p<BF>(ldsv(&Ktc[(16 * db + r) * LDV + 16 * c + 4 * g]), ds, dq[db]);
         }
         if (kt0 == 0) DLWP_STAMP(7);
         if (NBUF == 1) __syncthreads();
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void winattn_fold_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------------------
 // backward, key side: dK, dV.  One workgroup = 64 keys (wave = 16 keys as columns), loops over query tiles.
-template <int NDB, int NBUF>
+template <int NDB, int NBUF, bool BF>
 __global__ __launch_bounds__(256) void winattn_bwd_kv_kernel(WaDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NL = 4 * NDB, LDT = 16 * NDB + 4, DP = 16 * NDB;
@@ -521,8 +521,8 @@ __global__ __launch_bounds__(256) void winattn_bwd_kv_kernel(WaDev a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             // S[query 4g+j][key r], dP[query][key]
-            const f32x4 s = score_chunk<NDB>(Qc + 16 * c * LDT, LDT, kf, r, g);
-            const f32x4 dp = score_chunk<NDB>(Gc + 16 * c * LDT, LDT, vf, r, g);
+            const f32x4 s = score_chunk<NDB, BF>(Qc + 16 * c * LDT, LDT, kf, r, g);
+            const f32x4 dp = score_chunk<NDB, BF>(Gc + 16 * c * LDT, LDT, vf, r, g);
             const int o4 = buf * 64 + 16 * c + 4 * g;
             const f32x4 ls4 = ldsv(&lses[o4]), dd4 = ldsv(&dss[o4]);
             const int4 ql4 = ldsi(&qlabs[o4]), qa4 = ldsi(&qas[o4]);
@@ -539,8 +539,8 @@ __global__ __launch_bounds__(256) void winattn_bwd_kv_kernel(WaDev a) {
             }
 #pragma unroll
             for (int db = 0; db < NDB; ++db) {
-                dv[db] = mfma16_chunk(ldsv(&Gtc[(16 * db + r) * LDV + 16 * c + 4 * g]), p, dv[db]);    // dV^T += dO^T P
-                dk[db] = mfma16_chunk(ldsv(&Qtc[(16 * db + r) * LDV + 16 * c + 4 * g]), ds, dk[db]);   // dK^T += (scale q)^T dS
+                dv[db] = mfma16_chunk_p<BF>(ldsv(&Gtc[(16 * db + r) * LDV + 16 * c + 4 * g]), p, dv[db]);    // dV^T += dO^T P
+                dk[db] = mfma16_chunk_p<BF>(ldsv(&Qtc[(16 * db + r) * LDV + 16 * c + 4 * g]), ds, dk[db]);   // dK^T += (scale q)^T dS
             }
         }
         if (NBUF == 1) __syncthreads();
@@ -617,12 +617,17 @@ extern "C" int dlwp_window_attn_fwd_packed(const float* qkv, const float* bias_t
     const int nbuf = N <= 128 ? 1 : 2;         // short windows: single-buffered tiles, more workgroups per CU
     const size_t lds = sizeof(float) * ((size_t)(1 + nbuf) * 64 * (a.dp16 + 4) + (size_t)nbuf * a.dp16 * LDV + 256 + a.TB);
     const dim3 grid(B_ * heads * ((N + QT - 1) / QT)), block(256);
-#define WA_FWD_B(NDB, NB)                                                                                                    \
+    const bool bf = dlwp_get_gemm_precision() == 1;      // bf16 matrix arithmetic asked for: bf16 MFMA operands, fp32 everything else
+#define WA_FWD_B(NDB, NB, BFV)                                                                                                \
     do {                                                                                                                  \
-        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_fwd_kernel<NDB, NB>), lds, "window_attn_fwd"))) return rc; \
-        hipLaunchKernelGGL((winattn_fwd_kernel<NDB, NB>), grid, block, lds, (hipStream_t)stream, a);                    \
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_fwd_kernel<NDB, NB, BFV>), lds, "window_attn_fwd"))) return rc; \
+        hipLaunchKernelGGL((winattn_fwd_kernel<NDB, NB, BFV>), grid, block, lds, (hipStream_t)stream, a);               \
     } while (0)
-#define WA_FWD(NDB) do { if (nbuf == 1) WA_FWD_B(NDB, 1); else WA_FWD_B(NDB, 2); } while (0)
+#define WA_FWD(NDB)                                                                                                       \
+    do {                                                                                                                  \
+        if (bf) { if (nbuf == 1) WA_FWD_B(NDB, 1, true); else WA_FWD_B(NDB, 2, true); }                                   \
+        else { if (nbuf == 1) WA_FWD_B(NDB, 1, false); else WA_FWD_B(NDB, 2, false); }                                    \
+    } while (0)
     switch (a.dp16 / 16) {
         case 1: WA_FWD(1); break;
         case 2: WA_FWD(2); break;
@@ -662,14 +667,19 @@ extern "C" int dlwp_window_attn_bwd_packed(const float* qkv, const float* bias_t
     const size_t lds_q = sizeof(float) * ((size_t)2 * nbuf * 64 * LDT + (size_t)nbuf * a.dp16 * LDV + 256 + 3 * (size_t)((a.TB + 1) & ~1));
     const size_t lds_kv = sizeof(float) * ((size_t)2 * nbuf * 64 * LDT + (size_t)2 * nbuf * a.dp16 * LDV + 512 + a.TB);
     const dim3 grid(B_ * heads * ((N + QT - 1) / QT)), block(256);
-#define WA_BWD_B(NDB, NB)                                                                                                       \
+    const bool bf = dlwp_get_gemm_precision() == 1;
+#define WA_BWD_B(NDB, NB, BFV)                                                                                                   \
     do {                                                                                                                     \
-        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_bwd_q_kernel<NDB, NB>), lds_q, "window_attn_bwd"))) return rc;  \
-        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_bwd_kv_kernel<NDB, NB>), lds_kv, "window_attn_bwd"))) return rc; \
-        hipLaunchKernelGGL((winattn_bwd_q_kernel<NDB, NB>), grid, block, lds_q, (hipStream_t)stream, a);                   \
-        hipLaunchKernelGGL((winattn_bwd_kv_kernel<NDB, NB>), grid, block, lds_kv, (hipStream_t)stream, a);                 \
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_bwd_q_kernel<NDB, NB, BFV>), lds_q, "window_attn_bwd"))) return rc;  \
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_bwd_kv_kernel<NDB, NB, BFV>), lds_kv, "window_attn_bwd"))) return rc; \
+        hipLaunchKernelGGL((winattn_bwd_q_kernel<NDB, NB, BFV>), grid, block, lds_q, (hipStream_t)stream, a);              \
+        hipLaunchKernelGGL((winattn_bwd_kv_kernel<NDB, NB, BFV>), grid, block, lds_kv, (hipStream_t)stream, a);            \
     } while (0)
-#define WA_BWD(NDB) do { if (nbuf == 1) WA_BWD_B(NDB, 1); else WA_BWD_B(NDB, 2); } while (0)
+#define WA_BWD(NDB)                                                                                                          \
+    do {                                                                                                                     \
+        if (bf) { if (nbuf == 1) WA_BWD_B(NDB, 1, true); else WA_BWD_B(NDB, 2, true); }                                      \
+        else { if (nbuf == 1) WA_BWD_B(NDB, 1, false); else WA_BWD_B(NDB, 2, false); }                                       \
+    } while (0)
     switch (a.dp16 / 16) {
         case 1: WA_BWD(1); break;
         case 2: WA_BWD(2); break;

@@ -102,7 +102,7 @@ __device__ __forceinline__ void stage_table(float* tb, const WsDev& a, const Who
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int NC, int NDB, bool VEC>
+template <int NC, int NDB, bool VEC, bool BF>
 __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tb = smem;                                         // [TB] bias-table slice of this (type, head)
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
         for (int kc = 0; kc < NC; ++kc) {
             s[kc] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int cc = 0; cc < NDB; ++cc) s[kc] = mfma16_chunk(kf[kc][cc], qf[cc], s[kc]);
+            for (int cc = 0; cc < NDB; ++cc) s[kc] = mfma16_chunk_p<BF>(kf[kc][cc], qf[cc], s[kc]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float v = s[kc][j] + tb[qa + kbi[kc][j]];
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
         for (int db = 0; db < NDB; ++db) {
             f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kc = 0; kc < NC; ++kc) o = mfma16_chunk(vt[db][kc], s[kc], o);
+            for (int kc = 0; kc < NC; ++kc) o = mfma16_chunk_p<BF>(vt[db][kc], s[kc], o);
             const int dd = 16 * db + 4 * g;
             if (q < N) {
                 float* dst = a.out + ((long long)w.b * N + q) * os + w.head * d + dd;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
 // (a single fused pass holds dK^T and dV^T of every key chunk and lands at 256 VGPRs):
 //   pass Q: for each query chunk, over the key chunks: S^T, dP^T -> dS^T -> dQ^T and dBias; D[q] goes to a wave-private LDS row
 //   pass K: for each key chunk, over the query chunks: S, dP -> P, dS -> dV^T, dK^T
-template <int NDB, bool VEC>
+template <int NDB, bool VEC, bool BF>
 __global__ __launch_bounds__(256) void winattn_small_bwd_kernel(WsDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tb = smem;                                                                        // [TB]
@@ -294,8 +294,8 @@ __global__ __launch_bounds__(256) void winattn_small_bwd_kernel(WsDev a) {
                 f32x4 sT = f32x4{0.f, 0.f, 0.f, 0.f}, dpT = sT;
 #pragma unroll
                 for (int cc = 0; cc < NDB; ++cc) {
-                    sT = mfma16_chunk(cur.kf[cc], qf[cc], sT);
-                    dpT = mfma16_chunk(cur.vf[cc], gf[cc], dpT);
+                    sT = mfma16_chunk_p<BF>(cur.kf[cc], qf[cc], sT);
+                    dpT = mfma16_chunk_p<BF>(cur.vf[cc], gf[cc], dpT);
                 }
                 f32x4 dsT;
 #pragma unroll
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void winattn_small_bwd_kernel(WsDev a) {
                     dsT[j] = v;
                 }
 #pragma unroll
-                for (int db = 0; db < NDB; ++db) dq[db] = mfma16_chunk(cur.kt[db], dsT, dq[db]);   // dQ^T[dd][q] += K^T dS^T
+                for (int db = 0; db < NDB; ++db) dq[db] = mfma16_chunk_p<BF>(cur.kt[db], dsT, dq[db]);   // dQ^T[dd][q] += K^T dS^T
                 cur = nxt;
             }
             if (q < N) {
@@ -350,8 +350,8 @@ __global__ __launch_bounds__(256) void winattn_small_bwd_kernel(WsDev a) {
                 for (int cc = 0; cc < NDB; ++cc) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) { cur.qf[cc][t] *= a.scale; cur.qt[cc][t] *= a.scale; }
-                    s = mfma16_chunk(cur.qf[cc], kf[cc], s);          // rows = queries 16 qc + 4g + j, column = key r
-                    dp = mfma16_chunk(cur.gf[cc], vf[cc], dp);
+                    s = mfma16_chunk_p<BF>(cur.qf[cc], kf[cc], s);          // rows = queries 16 qc + 4g + j, column = key r
+                    dp = mfma16_chunk_p<BF>(cur.gf[cc], vf[cc], dp);
                 }
                 f32x4 p, ds;
 #pragma unroll
@@ -365,8 +365,8 @@ __global__ __launch_bounds__(256) void winattn_small_bwd_kernel(WsDev a) {
                 }
 #pragma unroll
                 for (int db = 0; db < NDB; ++db) {
-                    dv[db] = mfma16_chunk(cur.gt[db], p, dv[db]);     // dV^T += dO^T P
-                    dk[db] = mfma16_chunk(cur.qt[db], ds, dk[db]);    // dK^T += (scale Q)^T dS
+                    dv[db] = mfma16_chunk_p<BF>(cur.gt[db], p, dv[db]);     // dV^T += dO^T P
+                    dk[db] = mfma16_chunk_p<BF>(cur.qt[db], ds, dk[db]);    // dK^T += (scale Q)^T dS
                 }
                 cur = nxt;
             }
@@ -422,12 +422,21 @@ bool dlwp_winattn_small_applies(int N, int d, long long pairs) { return N <= 128
             return DLWP_OK;                                                                                               \
         };                                                                                                                \
         int rc3 = DLWP_OK;                                                                                                \
-        if (ndb == 1) {                                                                                                   \
-            if (nc <= 4) rc3 = vec ? go(KERNEL<4, 1, true>) : go(KERNEL<4, 1, false>);                                    \
-            else rc3 = vec ? go(KERNEL<8, 1, true>) : go(KERNEL<8, 1, false>);                                            \
+        const bool bf = dlwp_get_gemm_precision() == 1;      /* bf16 matrix arithmetic asked for: bf16 MFMA operands */   \
+        if (bf) {                                                                                                         \
+            if (ndb == 1) {                                                                                               \
+                if (nc <= 4) rc3 = vec ? go(KERNEL<4, 1, true, true>) : go(KERNEL<4, 1, false, true>);                    \
+                else rc3 = vec ? go(KERNEL<8, 1, true, true>) : go(KERNEL<8, 1, false, true>);                            \
+            } else {                                                                                                      \
+                if (nc <= 4) rc3 = vec ? go(KERNEL<4, 2, true, true>) : go(KERNEL<4, 2, false, true>);                    \
+                else rc3 = vec ? go(KERNEL<8, 2, true, true>) : go(KERNEL<8, 2, false, true>);                            \
+            }                                                                                                             \
+        } else if (ndb == 1) {                                                                                            \
+            if (nc <= 4) rc3 = vec ? go(KERNEL<4, 1, true, false>) : go(KERNEL<4, 1, false, false>);                      \
+            else rc3 = vec ? go(KERNEL<8, 1, true, false>) : go(KERNEL<8, 1, false, false>);                              \
         } else {                                                                                                          \
-            if (nc <= 4) rc3 = vec ? go(KERNEL<4, 2, true>) : go(KERNEL<4, 2, false>);                                    \
-            else rc3 = vec ? go(KERNEL<8, 2, true>) : go(KERNEL<8, 2, false>);                                            \
+            if (nc <= 4) rc3 = vec ? go(KERNEL<4, 2, true, false>) : go(KERNEL<4, 2, false, false>);                      \
+            else rc3 = vec ? go(KERNEL<8, 2, true, false>) : go(KERNEL<8, 2, false, false>);                              \
         }                                                                                                                 \
         if (rc3) return rc3;                                                                                              \
     } while (0)
@@ -461,8 +470,13 @@ int dlwp_winattn_small_bwd(const float* qkv, const float* table, const float* pa
         return DLWP_OK;
     };
     int rc;
-    if (d <= 16) rc = vec ? go(winattn_small_bwd_kernel<1, true>) : go(winattn_small_bwd_kernel<1, false>);
-    else rc = vec ? go(winattn_small_bwd_kernel<2, true>) : go(winattn_small_bwd_kernel<2, false>);
+    if (dlwp_get_gemm_precision() == 1) {
+        if (d <= 16) rc = vec ? go(winattn_small_bwd_kernel<1, true, true>) : go(winattn_small_bwd_kernel<1, false, true>);
+        else rc = vec ? go(winattn_small_bwd_kernel<2, true, true>) : go(winattn_small_bwd_kernel<2, false, true>);
+    } else {
+        if (d <= 16) rc = vec ? go(winattn_small_bwd_kernel<1, true, false>) : go(winattn_small_bwd_kernel<1, false, false>);
+        else rc = vec ? go(winattn_small_bwd_kernel<2, true, false>) : go(winattn_small_bwd_kernel<2, false, false>);
+    }
     if (rc) return rc;
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;

@@ -189,3 +189,32 @@ def test_many_short_windows_wave_kernels_match_tiled_kernels(cuda, monkeypatch, 
     assert rel(res[1][0], res[0][0]) <= 2e-5
     assert rel(res[1][1], res[0][1]) <= 1e-4
     assert rel(res[1][2], res[0][2]) <= 1e-4
+
+
+@pytest.mark.parametrize("N_side,d,heads,B_,nW", [(7, 24, 4, 16, 4), (7, 24, 4, 640, 20), (12, 32, 2, 3, 1), (16, 16, 4, 2, 2)])
+def test_window_attention_bf16_matrix_arithmetic_stays_close(cuda, N_side, d, heads, B_, nW):
+    """dlwp_set_gemm_precision(1): Q K^T, P V and the backward products run on v_mfma_f32_16x16x16_bf16 (bf16 operands, fp32
+    accumulation; softmax, bias and statistics fp32) in the tiled kernels and in the wave-per-window kernels.  The result
+    must stay within bf16 rounding of the fp32 kernels (the reference under autocast does these matmuls in bf16)."""
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.nsbench.swin_transformer import window_attention_core
+    N = N_side * N_side
+    TB = 3 * N
+    g = torch.Generator().manual_seed(N + d)
+    qkv0 = torch.randn(B_, N, 3 * heads * d, generator=g).to(cuda)
+    table0 = (0.5 * torch.randn(TB, heads, generator=g)).to(cuda)
+    ia = torch.randint(0, TB // 2, (N,), generator=g, dtype=torch.int32).to(cuda)
+    ib = torch.randint(0, TB // 2, (N,), generator=g, dtype=torch.int32).to(cuda)
+    labels = torch.randint(0, 3, (nW, N), generator=g, dtype=torch.int32).to(cuda)
+    gy = torch.randn(B_, N, heads * d, generator=g).to(cuda)
+    res = []
+    for mode in ("fp32", "bf16"):
+        with L.gemm_precision(mode):
+            qkv, table = qkv0.clone().requires_grad_(), table0.clone().requires_grad_()
+            y = window_attention_core(qkv, table, ia, ib, labels, nW, heads, d ** -0.5)
+            y.backward(gy)
+        res.append((y.detach(), qkv.grad, table.grad))
+    assert rel(res[1][0], res[0][0]) <= 2e-2
+    assert rel(res[1][1], res[0][1]) <= 3e-2
+    assert rel(res[1][2], res[0][2]) <= 3e-2
+    assert not torch.equal(res[1][0], res[0][0])          # the bf16 path really ran
