@@ -40,15 +40,18 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
                     "single-GPU functional test of the N>1 code path)")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (functional test only)")
-    ap.add_argument("--workload", default="fno", choices=["fno", "sfno"],
+    ap.add_argument("--workload", default="fno", choices=["fno", "sfno", "pangu", "swin", "afno"],
                     help="fno: BASELINE configs[1] (default, the headline line); sfno: configs[2], dlwpbench SFNO2DModule 32x64, "
-                         "5 prognostic variables, sfno.yaml widths, sequence length 5 (4 lead times)")
+                         "5 prognostic variables, sfno.yaml widths, sequence length 5 (4 lead times); pangu / swin: configs[3] "
+                         "(128x256, window 7); afno: configs[4] grid (FourCastNet 720x1440, patch 8, E=768, depth 12)")
     ap.add_argument("--storage", default=None, choices=["fp32", "bf16"],
                     help="sfno workload: storage of GEMM-to-GEMM activations and of the weight copy the GEMMs read (default: bf16 "
                          "with bf16 operands)")
     ap.add_argument("--precision", default=None, choices=["fp32", "bf16"],
                     help="GEMM operand precision of the sfno workload (default bf16 = the reference's autocast, fp32 accumulate)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    a.batch_given = any(x == "--batch" or x.startswith("--batch=") for x in sys.argv[1:])
+    return a
 
 
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
@@ -238,13 +241,37 @@ SFNO_WORKLOAD = dict(name="dlwpbench SFNO2DModule 32x64 WeatherBench shapes (BAS
                                 use_mlp=True, normalization_layer="none"), T=5, H=32, W=64)
 
 
-def sfno_gemm_probe(device, B, precision, reps=100, storage="fp32"):
-    """Dominant kernel of the SFNO step (rocprof: gemm_kernel, ~80 % of GPU time): the block MLP's first layer
-    [B*H*W, 256] x [256, 512] with bias + GELU epilogue, timed with HIP events on its launch stream."""
+# BASELINE configs[3] and [4] as further --workload choices (supplementary lines: the headline is configs[1]).  model kwargs are the
+# shipped dlwpbench YAMLs at the grids BASELINE names; one lead time per step (sequence length 2), as the dlwpbench training runs.
+DLWP_WORKLOADS = {
+    "sfno": dict(cls="SFNO2DModule", name=SFNO_WORKLOAD["name"], model=SFNO_WORKLOAD["model"], T=5, H=32, W=64, Cg=5, batch=4,
+                 storage="bf16", gemm=(32 * 64, 512, 256), metric="train samples/sec (SFNO 32x64 rollout step: fwd + MSE + backward + Adam)"),
+    "pangu": dict(cls="PanguWeather", name="dlwpbench PanguWeather 128x256 window (2,7,7) (BASELINE configs[3])",
+                  model=dict(constant_channels=4, prescribed_channels=1, prognostic_channels=8, embed_dim=192, num_heads=(6, 12, 12, 6),
+                             window_size=(2, 7, 7), patch_size=(1, 1), n_lat=128, n_lon=256, context_size=1),
+                  T=2, H=128, W=256, Cg=8, batch=1, storage="bf16", gemm=(128 * 256, 768, 192), lr=1e-4,
+                  metric="train samples/sec (Pangu-Weather 128x256 window-7 step: fwd + MSE + backward + Adam)"),
+    "swin": dict(cls="SwinTransformer", name="dlwpbench SwinTransformer 128x256 window 7 (BASELINE configs[3])",
+                 model=dict(constant_channels=4, prescribed_channels=1, prognostic_channels=8, context_size=1, img_height=128,
+                            img_width=256, patch_size=1, embed_dim=96, depths=[4, 4], num_heads=[4, 4], drop_path_rate=0.2,
+                            window_size=7),
+                 T=2, H=128, W=256, Cg=8, batch=2, storage="fp32", gemm=(128 * 256, 384, 96),
+                 metric="train samples/sec (Swin 128x256 window-7 step: fwd + MSE + backward + Adam)"),
+    "afno": dict(cls="AFNONet", name="dlwpbench AFNONet (FourCastNet) 720x1440 patch 8 E768 depth 12 (BASELINE configs[4] grid)",
+                 model=dict(img_height=720, img_width=1440, patch_size=(8, 8), constant_channels=4, prescribed_channels=1,
+                            prognostic_channels=8, embed_dim=768, depth=12, mlp_ratio=4.0, num_blocks=16, context_size=1),
+                 T=2, H=720, W=1440, Cg=8, batch=1, storage="bf16", gemm=(90 * 180, 3072, 768),
+                 metric="train samples/sec (FourCastNet AFNO 720x1440 step: fwd + MSE + backward + Adam)"),
+}
+
+
+def sfno_gemm_probe(device, B, precision, reps=100, storage="fp32", shape=(32 * 64, 512, 256)):
+    """Dominant kernel family of the token models (rocprof: gemm_kernel): the block MLP's first layer [B*tokens, K] x [K, N]
+    with bias + GELU epilogue (SFNO: 2048 tokens, 256 -> 512), timed with HIP events on its launch stream."""
     import torch
     from dlwp_benchmark_amd import lib as L
     from dlwp_benchmark_amd.token_ops import _gemm
-    M, K, N = B * 32 * 64, 256, 512
+    M, N, K = B * shape[0], shape[1], shape[2]
     g = torch.Generator().manual_seed(0)
     x = torch.randn(M, K, generator=g).to(device)
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(device)
@@ -306,8 +333,9 @@ def sfno_cpu_baseline(B, budget_s):
 
 
 def main_sfno(args):
-    """BASELINE configs[2]: one step = 4-lead-time rollout + MSE + backward + all-reduce (N>1) + fused Adam, captured in a
-    hipGraph by train_engine.GraphedTrainStep."""
+    """BASELINE configs[2] (sfno) and the supplementary configs[3] / [4] lines (pangu, swin, afno): one step = rollout + MSE +
+    backward + all-reduce (N>1) + fused Adam through train_engine.GraphedTrainStep (captured in a hipGraph at N = 1 and for the
+    flat reducer; the 28-72 M parameter models use the bucketed reducer launched from backward hooks at N > 1: eager step)."""
     import torch
     import torch.distributed as dist
     from dlwp_benchmark_amd import ddp, dlwpbench, lib as L
@@ -322,23 +350,28 @@ def main_sfno(args):
     torch.cuda.set_device(device)
     if world > 1:
         dist.init_process_group("nccl", device_id=device) if args.backend == "nccl" else dist.init_process_group(args.backend)
+    w = DLWP_WORKLOADS[args.workload]
     precision = args.precision or "bf16"
     L.set_gemm_precision(precision)
-    # bf16 arithmetic goes with bf16 storage of the GEMM-to-GEMM tensors and of the weight copy the GEMMs read (lib.set_storage);
-    # fp32 master weights, gradients, statistics and the residual stream stay fp32.  --storage fp32 keeps everything in fp32 arrays
-    storage = args.storage or ("bf16" if precision == "bf16" else "fp32")
+    # bf16 arithmetic goes with bf16 storage of the GEMM-to-GEMM tensors and of the weight copy the GEMMs read (lib.set_storage)
+    # where the products are deep enough for it to pay (not at Swin's E = 96); fp32 master weights, gradients, statistics and the
+    # residual stream stay fp32.  --storage overrides
+    storage = args.storage or (w["storage"] if precision == "bf16" else "fp32")
     L.set_storage(storage)
-    w, B = SFNO_WORKLOAD, args.batch
+    B = args.batch if args.batch_given else w["batch"]
+    H, W_, Cg, T = w["H"], w["W"], w["Cg"], w["T"]
     torch.manual_seed(1234)
-    model = dlwpbench.SFNO2DModule(**w["model"]).to(device).train()
+    model = getattr(dlwpbench, w["cls"])(**w["model"]).to(device).train()
     g = torch.Generator().manual_seed(1234 + rank)
-    T = w["T"]
-    kw = dict(constants=torch.randn(B, 1, 4, 32, 64, generator=g).to(device),
-              prescribed=torch.randn(B, T, 1, 32, 64, generator=g).to(device),
-              prognostic=torch.randn(B, T, 5, 32, 64, generator=g).to(device))
-    target = torch.randn(B, T - 1, 5, 32, 64, generator=g).to(device)
-    step = GraphedTrainStep(model, kw, target, lr=1e-3, use_graph=not args.no_graph,
-                            allreduce=ddp.FlatGradAllReduce() if world > 1 else None, grad_scale=1.0 / world)
+    kw = dict(constants=torch.randn(B, 1, 4, H, W_, generator=g).to(device),
+              prescribed=torch.randn(B, T, 1, H, W_, generator=g).to(device),
+              prognostic=torch.randn(B, T, Cg, H, W_, generator=g).to(device))
+    target = torch.randn(B, T - 1, Cg, H, W_, generator=g).to(device)
+    bucketed = world > 1 and args.workload != "sfno"          # 114-288 MB of gradients: overlap the reduction with backward
+    step = GraphedTrainStep(model, kw, target, lr=w.get("lr", 1e-3), use_graph=not args.no_graph and not bucketed,
+                            allreduce=ddp.FlatGradAllReduce() if (world > 1 and not bucketed) else None, grad_scale=1.0 / world)
+    if bucketed:
+        step.allreduce = ddp.BucketedGradAllReduce(model, step.grad)
     ddp.broadcast_parameters(step.flat, src=0)
     for _ in range(args.warmup):
         step()
@@ -359,20 +392,24 @@ def main_sfno(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     if rank == 0:
-        line = {"metric": "train samples/sec (SFNO 32x64 rollout step: fwd + MSE + backward + Adam)",
+        line = {"metric": w["metric"],
                 "value": round(world * B * args.steps / dt, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if precision == "bf16" else "f32",
                 "data": "synthetic N(0,1) fields (z-scored WeatherBench shapes), random-init weights (no dataset/checkpoint access)",
                 "config": {"workload": w["name"], "per_gpu_batch": B, "global_batch": B * world, "sequence_length": T,
-                           "net_calls_per_sample": T - 1, "embed_dim": 256, "num_layers": 4, "grid": [32, 64],
+                           "net_calls_per_sample": T - 1, "grid": [H, W_],
+                           "n_params": sum(p.numel() for p in model.parameters()),
                            "gemm_operands": precision, "storage": storage, "accumulate": "fp32", "parallelism": f"dp{world}",
-                           "hip_graph": not args.no_graph},
+                           "hip_graph": not args.no_graph and not bucketed,
+                           "grad_reduce": "bucketed, from backward hooks" if bucketed else ("flat" if world > 1 else "none")},
                 "backbone_calls_per_s": round(world * B * args.steps * (T - 1) / dt, 1), "final_loss": loss.item()}
         if world == 1 and not args.no_roofline:
-            line["roofline"] = sfno_gemm_probe(device, B, precision, storage=storage)
-        if world == 1 and not args.no_cpu_baseline:
+            line["roofline"] = sfno_gemm_probe(device, B, precision, storage=storage, shape=w["gemm"])
+        if world == 1 and not args.no_cpu_baseline and args.workload == "sfno":
             line["cpu_baseline"] = sfno_cpu_baseline(B, args.cpu_seconds)
+        elif world == 1:
+            line["cpu_baseline"] = None       # a CPU step of the 28-72 M parameter models at these grids takes minutes: not sampled
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -380,7 +417,7 @@ def main_sfno(args):
 
 def main():
     args = parse()
-    if args.workload == "sfno":
+    if args.workload != "fno":
         return main_sfno(args)
     import torch
     import torch.distributed as dist

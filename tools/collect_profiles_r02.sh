@@ -23,6 +23,7 @@ echo "probes done"
 timeout 400 python3 $R/tools/bench_fft.py > $O/fft_bench.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_fft -- python3 $R/tools/probe_fft.py > /dev/null 2>&1
 timeout 400 python3 $R/bench.py --workload sfno > $O/bench_line_sfno.json 2> $O/bench_sfno.err
+for wl in swin pangu afno; do timeout 300 python3 $R/bench.py --workload $wl --steps 20 --warmup 3 > $O/bench_line_$wl.json 2>> $O/bench_sfno.err; done
 timeout 900 python3 $R/tools/bench_models.py all --steps 10 > $O/models.jsonl 2> $O/models.err
 for m in fno_dlwp tfno_dlwp fno_ctx swin_dlwp; do timeout 250 python3 $R/tools/bench_models.py $m --steps 20 >> $O/models.jsonl 2>> $O/models.err; done
 timeout 400 python3 $R/tools/bench_models.py afno_c5p1 --steps 3 >> $O/models.jsonl 2>> $O/models.err

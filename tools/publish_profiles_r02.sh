@@ -8,6 +8,7 @@ stats() { ls -t "$F/$1"/*/*kernel_stats.csv 2>/dev/null | head -1; }
 cp "$F/bench_line.json" "$P/${T}_bench_line.json"
 cp "$F/bench_line_h217.json" "$P/${T}_bench_line_hidden217.json"
 cp "$F/bench_line_sfno.json" "$P/${T}_bench_line_sfno.json"
+for wl in swin pangu afno; do [ -s "$F/bench_line_$wl.json" ] && cp "$F/bench_line_$wl.json" "$P/${T}_bench_line_$wl.json"; done
 cp "$F/models.jsonl" "$P/${T}_models_bench.jsonl"
 cp "$F/traffic.json" "$P/traffic.json"
 cp "$F/fft_bench.txt" "$P/${T}_fft_bench.txt"
