@@ -277,8 +277,8 @@ def sfno_gemm_probe(device, B, precision, reps=100, storage="fp32", shape=(32 * 
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(device)
     b = torch.zeros(N, device=device)
     y, z = torch.empty(M, N, device=device), torch.empty(M, N, device=device)
-    if storage == "bf16":         # as in the step: weight copy, hidden activation and pre-activation are bf16 arrays
-        w, y, z = w.to(torch.bfloat16), y.to(torch.bfloat16), z.to(torch.bfloat16)
+    if storage == "bf16":         # as in the step: LayerNorm output, weight copy, hidden activation and pre-activation are bf16 arrays
+        x, w, y, z = x.to(torch.bfloat16), w.to(torch.bfloat16), y.to(torch.bfloat16), z.to(torch.bfloat16)
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         for _ in range(10):
@@ -293,7 +293,7 @@ def sfno_gemm_probe(device, B, precision, reps=100, storage="fp32", shape=(32 * 
     sec = e0.elapsed_time(e1) * 1e-3 / reps
     flops = 2.0 * M * N * K
     peak = PEAK_MFMA_TF[precision]
-    return {"bound": "mfma", "kernel": f"gemm_kernel (MLP fc1 {M}x{N}x{K}, bias+GELU epilogue, {precision} operands, {storage} storage of W / h / z)",
+    return {"bound": "mfma", "kernel": f"gemm_kernel (MLP fc1 {M}x{N}x{K}, bias+GELU epilogue, {precision} operands, {storage} storage of x / W / h / z)",
             "achieved": round(flops / sec / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(flops / sec / 1e12 / peak, 4),
             "flops_per_launch": flops, "us_per_launch": round(sec * 1e6, 3), "traffic": None}
 
