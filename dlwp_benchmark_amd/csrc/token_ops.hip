@@ -375,27 +375,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
     }
     DLWP_STAMP(4);
     gemm_rowsum_flush<T>(a, rsum, m0, n0, wm, w, r, g);
-    if constexpr (T == 1) {
+    {
         if (a.vec_epi) {
             // The accumulator layout gives each lane 4 rows x 1 column: stored directly, a wave-instruction touches four
-            // 64-byte row segments (issue-bound, ~2 TB/s on the MLP epilogues).  Through an LDS tile every global access of
-            // the epilogue (C, residual, pre-activation) becomes a 16-byte one on 256-byte contiguous rows.
-            constexpr int LDE = 64 + 4;
+            // 64-byte row segments (issue-bound, ~2 TB/s on the MLP epilogues; 2-byte scalar stores with a bf16 output).  Through
+            // an LDS tile every global access of the epilogue (C, residual, pre-activation) becomes a 16-byte (bf16: 8-byte) one
+            // on contiguous rows.  The 128 x 128 tile goes through the (dead) operand buffers in two halves of 64 rows.
+            constexpr int EC = 64 * T, LDE = EC + 4, C4 = EC / 4, RPP = 256 / C4, NPASS = 64 / RPP;
             float* tile = gsm;                          // the operand buffers are dead (loop ended with a barrier)
-#pragma unroll
-            for (int i = 0; i < NT16; ++i)
-#pragma unroll
-                for (int j = 0; j < NT16; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) tile[(wm + i * 16 + 4 * g + q) * LDE + wn + j * 16 + r] = acc[i][j][q];
-            __syncthreads();
-            const int tid = threadIdx.x, c4 = tid & 15;
+            const int tid = threadIdx.x, c4 = tid % C4;
             const int n = n0 + 4 * c4;
             f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
             if (a.bias && !a.bias_row && n < a.N) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int row = (tid >> 4) + 16 * pass, m = m0 + row;
+            for (int half = 0; half < T; ++half) {
+                if (half) __syncthreads();              // the previous half has been read out
+                if (wm / 64 == half) {
+                    const int wl = wm - 64 * half;
+#pragma unroll
+                    for (int i = 0; i < NT16; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT16; ++j)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) tile[(wl + i * 16 + 4 * g + q) * LDE + wn + j * 16 + r] = acc[i][j][q];
+                }
+                __syncthreads();
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int row = tid / C4 + RPP * pass, m = m0 + 64 * half + row;
                 if (m < a.M && n < a.N) {
                     const long long o = (long long)m * a.ldc + n;
                     f32x4 v = *reinterpret_cast<const f32x4*>(&tile[row * LDE + 4 * c4]);
@@ -443,6 +450,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
                     put(a.C, v);
                 }
             }
+            }       // half
             DLWP_STAMP(5);
             return;
         }
@@ -718,7 +726,7 @@ static int gemm_dispatch(GemmDev& a, int transA, int transB, int T, void* stream
         vecB = vecB && a.sB1 % 4 == 0 && a.sB2 % 4 == 0;
     }
     const int vec = (vecA ? 1 : 0) | (vecB ? 2 : 0);
-    a.vec_epi = T == 1 && a.splits == 1 && !a.atomic_out && a.N % 4 == 0 && a.ldc % 4 == 0 && (uintptr_t)a.C % 16 == 0 &&
+    a.vec_epi = a.splits == 1 && !a.atomic_out && a.N % 4 == 0 && a.ldc % 4 == 0 && (uintptr_t)a.C % 16 == 0 &&
                 (!a.bias || a.bias_row || (uintptr_t)a.bias % 16 == 0) && (!a.residual || (uintptr_t)a.residual % 16 == 0) &&
                 (!a.preact || (uintptr_t)a.preact % 16 == 0);
     if (a.nbatch > 1)
