@@ -1,0 +1,76 @@
+"""Error behaviour of the C ABI on a CPU-only box: every entry point validates its arguments on the host before anything touches
+a GPU, returns a negative code and leaves a message in the thread-local dlwp_last_error().  Round-2 entries."""
+import ctypes as C
+import os
+
+import pytest
+
+
+@pytest.fixture(scope="module")
+def h():
+    from dlwp_benchmark_amd import lib as L
+    if not os.path.exists(L.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return L.load()
+
+
+FAKE = 0x1000      # a non-NULL pointer value: validation must fail on the SHAPES before it is ever dereferenced
+
+
+def err(h):
+    return h.dlwp_last_error().decode()
+
+
+def test_gemm_mixed_rejects_bad_dtypes_and_bf16_accumulation(h):
+    assert h.dlwp_gemm_mixed(FAKE, FAKE, FAKE, 8, 8, 8, 8, 8, 8, 0, 1, None, 0, None, None, 0, None, 16, None) < 0
+    assert "mask" in err(h)
+    assert h.dlwp_gemm_mixed(FAKE, FAKE, FAKE, 8, 8, 8, 8, 8, 8, 0, 1, None, 0, None, None, 1, None, 4, None) < 0
+    assert "fp32 output" in err(h)
+    assert h.dlwp_gemm_mixed(None, FAKE, FAKE, 8, 8, 8, 8, 8, 8, 0, 1, None, 0, None, None, 0, None, 0, None) < 0
+    assert h.dlwp_gemm_mixed(FAKE, FAKE, FAKE, 0, 8, 8, 8, 8, 8, 0, 1, None, 0, None, None, 0, None, 0, None) < 0
+
+
+def test_window_advance_rejects_inconsistent_shapes(h):
+    # batch stride smaller than ctx * frame
+    assert h.dlwp_window_advance_fwd(FAKE, 10, FAKE, FAKE, FAKE, 2, 3, 16, 0, 0, 0, 0, 0, 0, None) < 0
+    assert "batch stride" in err(h)
+    # patch layout whose D*H*W does not match the frame
+    assert h.dlwp_window_advance_fwd(FAKE, 48, FAKE, FAKE, FAKE, 2, 3, 16, 1, 1, 4, 5, 2, 1, None) < 0
+    assert "patch layout" in err(h)
+    assert h.dlwp_window_advance_fwd(None, 48, FAKE, FAKE, FAKE, 2, 3, 16, 0, 0, 0, 0, 0, 0, None) < 0
+    assert h.dlwp_window_advance_bwd(None, None, 0, None, 0, None, None, 2, 3, 16, 0, 0, 0, 0, 0, 0, None) < 0
+    assert "g_delta" in err(h)
+    assert h.dlwp_window_advance_bwd(None, None, 0, FAKE, 16, None, FAKE, 0, 3, 16, 0, 0, 0, 0, 0, 0, None) < 0
+
+
+def test_data_movement_entries_reject_null_and_empty(h):
+    assert h.dlwp_patch_merge(None, FAKE, 1, 4, 4, 8, 0, None) < 0
+    assert h.dlwp_patch_merge(FAKE, FAKE, 1, 0, 4, 8, 0, None) < 0
+    assert h.dlwp_upconv_shuffle(FAKE, None, None, FAKE, None, 1, 4, 4, 8, 2, 2, 4, 0, 1, 0, None) < 0      # ctot < coff + O
+    assert h.dlwp_upconv_shuffle(FAKE, None, None, FAKE, None, 1, 4, 4, 8, 2, 2, 8, 0, 1, 1, None) < 0      # backward without gout
+    assert h.dlwp_add_bcast(FAKE, None, FAKE, 2, 16, None) < 0
+    assert h.dlwp_cast_bf16(None, FAKE, 16, None) < 0
+    assert h.dlwp_cast_bf16(0x1004, FAKE, 16, None) < 0                                                     # misaligned source
+    assert "aligned" in err(h)
+    assert h.dlwp_window_attn_pack_table(FAKE, None, 10, 2, 2, None) < 0
+    assert h.dlwp_layernorm_fwd_ex(None, FAKE, FAKE, FAKE, FAKE, FAKE, 4, 8, C.c_float(1e-5), 1, None) < 0
+    assert h.dlwp_layernorm_bwd_ex(FAKE, FAKE, FAKE, FAKE, None, 1, None, FAKE, FAKE, FAKE, 4, 8, None) < 0
+
+
+def test_fft_plan_rejects_bad_shapes(h):
+    out = C.c_void_p()
+    assert h.dlwp_fft_plan_create(0, 8, C.byref(out)) < 0
+    assert h.dlwp_fft_plan_create(8, 1, C.byref(out)) < 0
+    assert h.dlwp_fft_plan_create(8, 8, None) < 0
+
+
+def test_window_attention_rejects_bad_shapes(h):
+    # nW must divide B_, ntypes must divide nW, head_dim <= 64 in the fused kernels
+    args = lambda B_, nW, N, TB, nt, heads, d: (FAKE, FAKE, None, FAKE, FAKE, None, FAKE, FAKE, B_, nW, N, TB, nt, heads, d,  # noqa: E731
+                                               C.c_float(0.1), None)
+    assert h.dlwp_window_attn_fwd_packed(*args(5, 2, 49, 169, 1, 4, 16)) < 0
+    assert h.dlwp_window_attn_fwd_packed(*args(4, 2, 49, 169, 3, 4, 16)) < 0
+    assert "ntypes" in err(h)
+    assert h.dlwp_window_attn_fwd_packed(*args(4, 2, 49, 169, 1, 4, 96)) < 0
+    assert "head_dim" in err(h)
