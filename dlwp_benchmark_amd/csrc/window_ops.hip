@@ -159,41 +159,48 @@ __global__ __launch_bounds__(256) void upconv_shuffle_kernel(const float* __rest
                                                              const float* __restrict__ gout, float* __restrict__ dst,
                                                              float* gbias, int B, int H, int W, int O, int kh, int kw, int ctot,
                                                              int coff, int act) {
-    extern __shared__ float gb_s[];           // BWD: [O]
-    const int kk = kh * kw;
-    if (BWD) {
-        for (int i = threadIdx.x; i < O; i += 256) gb_s[i] = 0.f;
-        __syncthreads();
-    }
-    const long long total = (long long)B * H * W * O;
-    const int Ho = H * kh, Wo = W * kw;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const int o = (int)(e % O);
-        long long m = e / O;
-        const int w = (int)(m % W);
-        const long long r = m / W;
-        const int h = (int)(r % H), b = (int)(r / H);
-        const float bo = bias ? bias[o] : 0.f;
-        const float* yp = y + m * (long long)O * kk + (long long)o * kk;
+    __shared__ float red[256];                // BWD: per-thread bias-gradient partials, [pixel slot][channel]
+    const int kk = kh * kw, Ho = H * kh, Wo = W * kw;
+    const long long Mtot = (long long)B * H * W;
+    // a thread keeps ONE channel for all its pixels (its bias-gradient partial stays in a register): OT channels x PPB pixels
+    // per workgroup step, consecutive threads on consecutive channels (coalesced)
+    const int OT = O < 256 ? O : 256, PPB = 256 / OT;
+    const int ol = threadIdx.x % OT, ms = threadIdx.x / OT;
+    for (int ob = 0; ob < O; ob += OT) {          // one pass unless O > 256; the bound is uniform (barriers inside)
+        const int o = ob + ol;
+        const bool ov = o < O;
+        const float bo = (bias && ov) ? bias[o] : 0.f;
         float gsum = 0.f;
-        for (int ij = 0; ij < kk; ++ij) {
-            const int i = ij / kw, j = ij - i * kw;
-            const long long po = (((long long)b * Ho + h * kh + i) * Wo + w * kw + j) * ctot + coff + o;
-            const float z = yp[ij] + bo;
-            if (BWD) {
-                const float g = gout[po] * (act == 1 ? gelu_grad_f(z) : 1.f);
-                dst[m * (long long)O * kk + (long long)o * kk + ij] = g;
-                gsum += g;
-            } else {
-                dst[po] = act == 1 ? gelu_f(z) : z;
+        if (ms < PPB && ov) {
+            for (long long m = (long long)blockIdx.x * PPB + ms; m < Mtot; m += (long long)gridDim.x * PPB) {
+                const int w = (int)(m % W);
+                const long long r = m / W;
+                const int h = (int)(r % H), b = (int)(r / H);
+                const long long yo = m * (long long)O * kk + (long long)o * kk;
+                for (int ij = 0; ij < kk; ++ij) {
+                    const int i = ij / kw, j = ij - i * kw;
+                    const long long po = (((long long)b * Ho + h * kh + i) * Wo + w * kw + j) * ctot + coff + o;
+                    const float z = y[yo + ij] + bo;
+                    if (BWD) {
+                        const float g = gout[po] * (act == 1 ? gelu_grad_f(z) : 1.f);
+                        dst[yo + ij] = g;
+                        gsum += g;
+                    } else {
+                        dst[po] = act == 1 ? gelu_f(z) : z;
+                    }
+                }
             }
         }
-        if (BWD && gbias) atomicAdd(&gb_s[o], gsum);
-    }
-    if (BWD && gbias) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < O; i += 256)
-            if (gb_s[i] != 0.f) atomic_add_f32(&gbias[i], gb_s[i]);
+        if (BWD && gbias) {
+            red[threadIdx.x] = gsum;
+            __syncthreads();
+            if (threadIdx.x < OT && ov) {         // here ms == 0: o = ob + threadIdx.x
+                float t = 0.f;
+                for (int q = 0; q < PPB; ++q) t += red[q * OT + threadIdx.x];
+                if (t != 0.f) atomic_add_f32(&gbias[o], t);
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -253,9 +260,9 @@ extern "C" int dlwp_upconv_shuffle(const float* y, const float* bias, const floa
                      (act == 0 || act == 1) && (!backward || gout),
                  DLWP_E_INVALID, "upconv_shuffle: bad argument");
     const long long total = (long long)B * H * W * O;
-    const dim3 grid(grid_for(total));
+    const dim3 grid(std::min(grid_for(total), 2048));
     if (backward)
-        hipLaunchKernelGGL(upconv_shuffle_kernel<true>, grid, dim3(256), O * sizeof(float), (hipStream_t)stream, y, bias, gout, dst,
+        hipLaunchKernelGGL(upconv_shuffle_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, y, bias, gout, dst,
                            gbias, B, H, W, O, kh, kw, ctot, coff, act);
     else
         hipLaunchKernelGGL(upconv_shuffle_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, y, bias, gout, dst, gbias, B, H,
