@@ -680,6 +680,116 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) gz[i] = gy[i] * gelu_grad_f(z[i]);
 }
 
+// ---- LayerNorm for narrow rows (C % 4 == 0, C <= 256): a lane owns four consecutive channels (16-byte accesses), LPR lanes
+// share a row and a wave works on 64 / LPR rows at once.  The wave-per-row kernels above leave 25-60 % of a wave idle at C = 40
+// ... 96 (Swin stages) and move 4 bytes per lane and instruction: 1.6 TB/s at 65536 x 96; this form reaches the HBM regime.
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ y,
+                                                                float* __restrict__ mean, float* __restrict__ rstd, int T, int C,
+                                                                float eps, int y_bf16) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = lane_id(), l = lane % LPR, rr = lane / LPR;
+    const long long row = ((long long)blockIdx.x * 4 + wave_id()) * RPW + rr;
+    const bool okc = 4 * l < C, ok = okc && row < T;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f}, gm = v, bt = v;
+    if (ok) v = *reinterpret_cast<const f32x4*>(x + row * C + 4 * l);
+    if (okc) { gm = *reinterpret_cast<const f32x4*>(gamma + 4 * l); bt = *reinterpret_cast<const f32x4*>(beta + 4 * l); }
+    const float mu = row_sum<LPR>((v[0] + v[1]) + (v[2] + v[3])) / C;
+    f32x4 d;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = okc ? v[k] - mu : 0.f;
+    const float rs = rsqrtf(row_sum<LPR>((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) / C + eps);
+    if (ok) {
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = d[k] * rs * gm[k] + bt[k];
+        if (y_bf16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(y) + row * C + 4 * l) = bf16x4{(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+        else *reinterpret_cast<f32x4*>(y + row * C + 4 * l) = o;
+        if (l == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gy, const float* __restrict__ gadd,
+                                                                float* __restrict__ gx, float* ggamma, float* gbeta, int T, int C,
+                                                                int rows_per_block, int gy_bf16) {
+    extern __shared__ float sm[];            // [2][C] per-block partial of ggamma, gbeta
+    constexpr int RPW = 64 / LPR;
+    for (int c = threadIdx.x; c < 2 * C; c += 256) sm[c] = 0.f;
+    __syncthreads();
+    const int lane = lane_id(), w = wave_id(), l = lane % LPR, rr = lane / LPR;
+    const bool okc = 4 * l < C;
+    f32x4 gm = f32x4{0.f, 0.f, 0.f, 0.f}, pg = gm, pb = gm;
+    if (okc) gm = *reinterpret_cast<const f32x4*>(gamma + 4 * l);
+    const long long row0 = (long long)blockIdx.x * rows_per_block;
+    const __bf16* gh = reinterpret_cast<const __bf16*>(gy);
+    for (int it = w * RPW; it < rows_per_block; it += 4 * RPW) {
+        const long long row = row0 + it + rr;
+        const bool ok = okc && row < T && it + rr < rows_per_block;
+        f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f}, gv = xv, av = xv;
+        float mu = 0.f, rs = 0.f;
+        if (ok) {
+            const long long o = row * C + 4 * l;
+            xv = *reinterpret_cast<const f32x4*>(x + o);
+            if (gy_bf16) {
+                const bf16x4 hv = *reinterpret_cast<const bf16x4*>(gh + o);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gv[k] = (float)hv[k];
+            } else {
+                gv = *reinterpret_cast<const f32x4*>(gy + o);
+            }
+            if (gadd) av = *reinterpret_cast<const f32x4*>(gadd + o);
+            mu = mean[row];
+            rs = rstd[row];
+        }
+        f32x4 xh, gg;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            xh[k] = ok ? (xv[k] - mu) * rs : 0.f;
+            gg[k] = gv[k] * gm[k];
+            s1 += gg[k];
+            s2 += gg[k] * xh[k];
+            pg[k] += gv[k] * xh[k];
+            pb[k] += gv[k];
+        }
+        s1 = row_sum<LPR>(s1) / C;
+        s2 = row_sum<LPR>(s2) / C;
+        if (ok) {
+            f32x4 o4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o4[k] = rs * (gg[k] - s1 - xh[k] * s2) + av[k];
+            *reinterpret_cast<f32x4*>(gx + row * C + 4 * l) = o4;
+        }
+    }
+    // fold the row slots of a wave (lanes l, l + LPR, ...), then the four waves one after the other (no LDS float atomics)
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { pg[k] += __shfl_xor(pg[k], o); pb[k] += __shfl_xor(pb[k], o); }
+    for (int ww = 0; ww < 4; ++ww) {
+        if (w == ww && rr == 0 && okc) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sm[4 * l + k] += pg[k]; sm[C + 4 * l + k] += pb[k]; }
+        }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < C; c += 256) {
+        atomic_add_f32(&ggamma[c], sm[c]);
+        atomic_add_f32(&gbeta[c], sm[C + c]);
+    }
+}
+
 // out[n] += sum_t g[t][n]
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, float* out, int T, int N, int rows_per_block) {
     const int n = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
@@ -896,6 +1006,17 @@ extern "C" int dlwp_cast_bf16(const float* src, void* dst, long long n, void* st
 extern "C" int dlwp_layernorm_fwd_ex(const float* x, const float* gamma, const float* beta, void* y, float* mean,
                                      float* rstd, int T, int C, float eps, int y_bf16, void* stream) {
     DLWP_REQUIRE(x && gamma && beta && y && mean && rstd && T > 0 && C > 0, DLWP_E_INVALID, "layernorm_fwd: bad argument");
+    const bool narrow = C % 4 == 0 && C <= 256 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 8 == 0 && (uintptr_t)gamma % 16 == 0 &&
+                        (uintptr_t)beta % 16 == 0 && (y_bf16 || (uintptr_t)y % 16 == 0);
+    if (narrow) {
+        const int lpr = C <= 32 ? 8 : C <= 64 ? 16 : C <= 128 ? 32 : 64;
+#define LN_FWD_V(LPR) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<LPR>, dim3(ceil_div(T, 4 * (64 / LPR))), dim3(256), 0, (hipStream_t)stream, \
+                                          x, gamma, beta, (float*)y, mean, rstd, T, C, eps, y_bf16 ? 1 : 0)
+        if (lpr == 8) LN_FWD_V(8); else if (lpr == 16) LN_FWD_V(16); else if (lpr == 32) LN_FWD_V(32); else LN_FWD_V(64);
+#undef LN_FWD_V
+        DLWP_LAUNCH_CHECK();
+        return DLWP_OK;
+    }
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ceil_div(T, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (float*)y,
                        mean, rstd, T, C, eps, y_bf16 ? 1 : 0);
     DLWP_LAUNCH_CHECK();
@@ -922,6 +1043,16 @@ static int layernorm_bwd_impl(const float* x, const float* gamma, const float* m
     while (rpb > 4 && ceil_div(T, rpb) < want) rpb >>= 1;
     const dim3 grid(ceil_div(T, rpb));
     const size_t lds = 2 * C * sizeof(float);
+    const bool narrow = C % 4 == 0 && C <= 256 && (uintptr_t)x % 16 == 0 && (uintptr_t)gy % 8 == 0 && (uintptr_t)gx % 16 == 0 &&
+                        (uintptr_t)gamma % 16 == 0 && (gy_bf16 || (uintptr_t)gy % 16 == 0) && (!gadd || (uintptr_t)gadd % 16 == 0);
+    if (narrow) {
+#define LN_BWD_V(LPR) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<LPR>, grid, dim3(256), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, \
+                                          gadd, gx, ggamma, gbeta, T, C, rpb, gy_bf16)
+        if (C <= 32) LN_BWD_V(8); else if (C <= 64) LN_BWD_V(16); else if (C <= 128) LN_BWD_V(32); else LN_BWD_V(64);
+#undef LN_BWD_V
+        DLWP_LAUNCH_CHECK();
+        return DLWP_OK;
+    }
 #define LN_BWD(NQ)                                                                                                   \
     hipLaunchKernelGGL(layernorm_bwd_kernel<NQ>, grid, dim3(256), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, gadd, \
                        gx, ggamma, gbeta, T, C, rpb, gy_bf16)
