@@ -29,29 +29,35 @@ struct RcclApi {
     rccl_result_t (*AllReduce)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
     rccl_result_t (*Broadcast)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(rccl_result_t) = nullptr;
+    char why[256] = "not attempted";             // the loader's message, captured once where the failure happened
 };
 
+RcclApi g_rccl;
+
 RcclApi* rccl() {
-    static RcclApi api;
     static std::once_flag once;
     static bool ok = false;
     std::call_once(once, [] {
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names) {
-            api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-            if (api.handle) break;
+            g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (g_rccl.handle) break;
+            const char* e = dlerror();                // reading clears the loader's state: read once, keep the last one
+            snprintf(g_rccl.why, sizeof(g_rccl.why), "%s", e ? e : "dlopen failed");
         }
-        if (!api.handle) return;
-        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.handle, "ncclGetUniqueId"));
-        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.handle, "ncclCommInitRank"));
-        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
-        api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.handle, "ncclAllReduce"));
-        api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(dlsym(api.handle, "ncclBroadcast"));
-        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
-        ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.Broadcast && api.GetErrorString;
+        if (!g_rccl.handle) return;
+        g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(g_rccl.handle, "ncclGetUniqueId"));
+        g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(g_rccl.handle, "ncclCommInitRank"));
+        g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(g_rccl.handle, "ncclCommDestroy"));
+        g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(g_rccl.handle, "ncclAllReduce"));
+        g_rccl.Broadcast = reinterpret_cast<decltype(g_rccl.Broadcast)>(dlsym(g_rccl.handle, "ncclBroadcast"));
+        g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(g_rccl.handle, "ncclGetErrorString"));
+        ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllReduce && g_rccl.Broadcast && g_rccl.GetErrorString;
+        if (!ok) snprintf(g_rccl.why, sizeof(g_rccl.why), "librccl was loaded but lacks one of the nccl* entry points");
     });
-    return ok ? &api : nullptr;
+    return ok ? &g_rccl : nullptr;
 }
+
 
 #define DLWP_RCCL(api, call)                                                                   \
     do {                                                                                       \
@@ -72,7 +78,7 @@ struct dlwp_comm {
 extern "C" int dlwp_comm_unique_id(void* out128) {
     DLWP_REQUIRE(out128, DLWP_E_INVALID, "comm_unique_id: NULL argument");
     RcclApi* api = rccl();
-    DLWP_REQUIRE(api, DLWP_E_UNSUPPORTED, "comm_unique_id: librccl.so could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing");
+    DLWP_REQUIRE(api, DLWP_E_UNSUPPORTED, "comm_unique_id: librccl.so could not be loaded (%s)", g_rccl.why);
     DLWP_RCCL(api, api->GetUniqueId(static_cast<rccl_unique_id*>(out128)));
     return DLWP_OK;
 }
@@ -80,7 +86,7 @@ extern "C" int dlwp_comm_unique_id(void* out128) {
 extern "C" int dlwp_comm_create(const void* unique_id128, int rank, int world, dlwp_comm** out) {
     DLWP_REQUIRE(unique_id128 && out && world >= 1 && rank >= 0 && rank < world, DLWP_E_INVALID, "comm_create: bad argument");
     RcclApi* api = rccl();
-    DLWP_REQUIRE(api, DLWP_E_UNSUPPORTED, "comm_create: librccl.so could not be loaded");
+    DLWP_REQUIRE(api, DLWP_E_UNSUPPORTED, "comm_create: librccl.so could not be loaded (%s)", g_rccl.why);
     rccl_unique_id id;
     memcpy(&id, unique_id128, sizeof(id));
     rccl_comm_t c = nullptr;
@@ -99,7 +105,7 @@ extern "C" int dlwp_comm_allreduce(dlwp_comm* c, float* buf, long long n, void* 
     DLWP_REQUIRE(c && buf && n >= 0, DLWP_E_INVALID, "comm_allreduce: bad argument");
     if (n == 0) return DLWP_OK;
     RcclApi* api = rccl();
-    DLWP_REQUIRE(api, DLWP_E_UNSUPPORTED, "comm_allreduce: librccl.so could not be loaded");
+    DLWP_REQUIRE(api, DLWP_E_UNSUPPORTED, "comm_allreduce: librccl.so could not be loaded (%s)", g_rccl.why);
     DLWP_RCCL(api, api->AllReduce(buf, buf, (size_t)n, RCCL_FLOAT32, RCCL_SUM, c->comm, static_cast<hipStream_t>(stream)));
     return DLWP_OK;
 }
@@ -108,7 +114,7 @@ extern "C" int dlwp_comm_broadcast(dlwp_comm* c, float* buf, long long n, int ro
     DLWP_REQUIRE(c && buf && n >= 0 && root >= 0 && root < c->world, DLWP_E_INVALID, "comm_broadcast: bad argument");
     if (n == 0) return DLWP_OK;
     RcclApi* api = rccl();
-    DLWP_REQUIRE(api, DLWP_E_UNSUPPORTED, "comm_broadcast: librccl.so could not be loaded");
+    DLWP_REQUIRE(api, DLWP_E_UNSUPPORTED, "comm_broadcast: librccl.so could not be loaded (%s)", g_rccl.why);
     DLWP_RCCL(api, api->Broadcast(buf, buf, (size_t)n, RCCL_FLOAT32, root, c->comm, static_cast<hipStream_t>(stream)));
     return DLWP_OK;
 }

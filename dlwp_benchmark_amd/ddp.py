@@ -122,7 +122,12 @@ class BucketedGradAllReduce:
             if 0 <= lo and hi <= total and sum(p.numel() for p in ps) + 4 * len(ps) >= hi - lo:     # contiguous up to padding
                 spans.append((lo, hi, unit))
         spans.sort(key=lambda t: t[0])
-        spans = [sp for k, sp in enumerate(spans) if k == 0 or sp[0] >= spans[k - 1][1]]       # drop overlapping units
+        kept, end = [], 0                             # drop units that overlap an already KEPT span (tied / shared parameters)
+        for sp in spans:
+            if sp[0] >= end:
+                kept.append(sp)
+                end = sp[1]
+        spans = kept
         self.buckets = []                             # dict(lo, hi, units)
         for lo, hi, unit in spans:
             last = self.buckets[-1] if self.buckets else None
@@ -138,6 +143,16 @@ class BucketedGradAllReduce:
             pos = bk["hi"]
         if pos < total:
             self.leftover.append((pos, total))
+        cover = sorted([(bk["lo"], bk["hi"]) for bk in self.buckets] + self.leftover)
+        assert all(a[1] == b[0] for a, b in zip(cover, cover[1:])) and (not cover or (cover[0][0] == 0 and cover[-1][1] == total)), \
+            "buckets + leftover must tile the flat gradient buffer exactly once"
+        # Gradients must be FINAL when a unit's backward hook fires.  Two paths break that: modules that defer a gradient
+        # write to the end of the backward pass (class attribute `deferred_grad_writes`, e.g. the SFNO spectral filter whose
+        # expanded-weight gradient is folded by an engine callback, sht._fold_pending), and micro-batch accumulation (later
+        # micro-batches add local gradients on top of an already reduced sum).  In both cases `hold` keeps every bucket
+        # back and finish() reduces the whole buffer once.
+        self.deferred = any(getattr(m, "deferred_grad_writes", False) for m in model.modules())
+        self.hold = self.deferred
         self._unit_bucket, self._fwd, self._bwd = {}, {}, {}
         self._handles, self._works = [], []
         for j, bk in enumerate(self.buckets):
@@ -171,7 +186,7 @@ class BucketedGradAllReduce:
         self._bwd[k] += 1
         j = self._unit_bucket[k]
         units = self.buckets[j]["units"]        # a unit the forward pass never entered (fwd == 0) receives no gradient at all
-        if not self._done[j] and all(self._bwd[id(u)] >= self._fwd[id(u)] for u in units):
+        if not self.hold and not self._done[j] and all(self._bwd[id(u)] >= self._fwd[id(u)] for u in units):
             self._launch(self.buckets[j]["lo"], self.buckets[j]["hi"])
             self._done[j] = True
 
@@ -186,6 +201,7 @@ class BucketedGradAllReduce:
     def finish(self):
         """Reduce what no hook released, wait for every reduction, reset the counters.  Returns Adam's scale 1 / world."""
         self.overlapped = sum(self._done)             # buckets that went out during backward (diagnostics / tests)
+        self.hold = self.deferred                     # a micro-batch hold ends with the reduction
         for j, bk in enumerate(self.buckets):
             if not self._done[j]:
                 self._launch(bk["lo"], bk["hi"])

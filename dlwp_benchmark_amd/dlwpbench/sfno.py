@@ -23,6 +23,10 @@ class _SpectralFilter(nn.Module):
     """SHT -> per-degree complex weight ("bixy,iox->boxy") -> inverse SHT; also returns the residual on the output
     grid (the input itself when both grids have the same size)."""
 
+    # the weight gradient reaches the flat buffer in an end-of-backward engine callback (sht._fold_pending), i.e. AFTER this
+    # module's backward hook: a bucketed gradient reducer must not release it early (ddp.BucketedGradAllReduce.deferred)
+    deferred_grad_writes = True
+
     def __init__(self, forward_transform, inverse_transform, in_channels, out_channels, gain=2.0):
         super().__init__()
         self.fwd, self.inv = forward_transform, inverse_transform

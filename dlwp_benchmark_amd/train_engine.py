@@ -154,6 +154,8 @@ class GraphedTrainStep:
         for k, v in inputs.items():
             self.inputs[k].copy_(v)
         self.target.copy_(target)
+        if hasattr(self.allreduce, "hold"):           # bucketed reducer: gradients are final only after the LAST micro-batch
+            self.allreduce.hold = True                # (reset by its finish(), i.e. by apply())
         if self.use_graph:
             if self.graph_optimizer and self.allreduce is None:
                 raise L.DlwpError("accumulate(): build the step with graph_optimizer=False (the optimizer must not be in the capture)")

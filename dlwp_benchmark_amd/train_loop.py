@@ -182,8 +182,8 @@ def train_ns(model, u_train, u_val, name="model", epochs=10, batch_size=4, seque
         # hand its Adam state to the others as well (the all-reduced gradient is applied by every rank)
         ddp.broadcast_parameters(model.flat_params.data, src=0)
         o = getattr(opt, "main", opt)
-        for t in (o.exp_avg, o.exp_avg_sq, o.step_count):
-            ddp.broadcast_parameters(t, src=0)
+        for buf in (o.exp_avg, o.exp_avg_sq, o.step_count):
+            ddp.broadcast_parameters(buf, src=0)
     vtf = teacher_forcing_steps if val_teacher_forcing_steps is None else val_teacher_forcing_steps
     log = []
     writer = ScalarLog(out_dir, name, enabled=log_scalars and save_model and rank == 0)
@@ -289,8 +289,8 @@ def train_dlwp(model, train_dataset, val_dataset, name="model", epochs=10, batch
                     resume = None
                 if world > 1:
                     ddp.broadcast_parameters(step.flat, src=0)
-                    for t in (step.opt.exp_avg, step.opt.exp_avg_sq, step.opt.step_count):
-                        ddp.broadcast_parameters(t, src=0)
+                    for buf in (step.opt.exp_avg, step.opt.exp_avg_sq, step.opt.step_count):   # not `t`: that is the target
+                        ddp.broadcast_parameters(buf, src=0)
             step.opt.lr = lr
             step.clip = lr if clip_gradients else None
             if micro == batch_size:

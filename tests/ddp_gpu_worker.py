@@ -32,7 +32,50 @@ def afno(seed):
                            mlp_ratio=2.0, num_blocks=4, context_size=2)
 
 
+def dlwp_case(seed=3):
+    """Small WeatherBench-shaped datasets + an SFNO2DModule: shared by the 2-rank train_dlwp run below and by the
+    single-process run of the global batch in tests/test_gpu_ddp.py."""
+    from dlwp_benchmark_amd import dlwpbench, wbdata
+    fields, prog, presc, const = wbdata.synthetic_fields(6 * 8 + 8, 16, 32, prognostic={"t2m": [], "z": [500]}, seed=5)
+    kw = dict(prognostic_variable_names_and_levels=prog, prescribed_variable_names=presc, constant_names=const,
+              sequence_length=4, normalize=True, context_size=1)
+
+    def cut(lo, hi):
+        return {k: (v[lo:hi] if not isinstance(v, dict) and v.ndim == 3 else
+                    ({l: a[lo:hi] for l, a in v.items()} if isinstance(v, dict) else v)) for k, v in fields.items()}
+    train, val = wbdata.WeatherBenchArrays(cut(0, 40), **kw), wbdata.WeatherBenchArrays(cut(40, None), **kw)
+    torch.manual_seed(seed)
+    model = dlwpbench.SFNO2DModule(constant_channels=4, prescribed_channels=1, prognostic_channels=2, grid="equiangular",
+                                   num_layers=2, scale_factor=1, embed_dim=16, context_size=1, height=16, width=32,
+                                   big_skip=True, pos_embed=True, use_mlp=True, normalization_layer="none")
+    return model, train, val
+
+
+def dlwp_main(out_dir):
+    """train_loop.train_dlwp at world 2 (ranks share cuda:0): one epoch, then continue_training for a second one -- the
+    resume path hands rank 0's Adam state to the other rank.  Every rank stores its final parameters; the parent test compares
+    them with a single-process run at the global batch."""
+    from dlwp_benchmark_amd import train_loop
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    for phase, (epochs, cont) in enumerate(((1, False), (2, True))):
+        model, train, val = dlwp_case(seed=3 + rank)           # replicas start different: train_dlwp must broadcast
+        model = model.to(dev)
+        dist.barrier()                                         # rank 0's checkpoint of the previous phase is on disk
+        log = train_loop.train_dlwp(model, train, val, name="w", epochs=epochs, batch_size=2, learning_rate=2e-3,
+                                    out_dir=out_dir, continue_training=cont, clip_gradients=True)
+        dist.barrier()
+    from dlwp_benchmark_amd.train_engine import flatten_parameters
+    torch.save({"flat": flatten_parameters(model)[0].detach().cpu(), "log": log}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0)
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "dlwp":
+        dlwp_main(sys.argv[2])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dev = torch.device("cuda:0")
     dist.init_process_group("gloo", rank=rank, world_size=world)

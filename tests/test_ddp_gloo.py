@@ -151,3 +151,68 @@ def test_collective_error_exits_non_zero():
         p.join(timeout=120)
     assert procs[1].exitcode == 0
     assert procs[0].exitcode == 13, procs[0].exitcode
+
+
+# ---- bucketed reducer: host logic on CPU tensors (world 1: no collective runs, the bookkeeping is what is tested) ------------
+def _flat_model(tied=False, deferred=False):
+    import torch.nn as nn
+
+    class Leaf(nn.Module):
+        def __init__(self, n):
+            super().__init__()
+            self.w = nn.Parameter(torch.ones(n))
+
+        def forward(self, x):
+            return x * self.w.sum()
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b, self.c = Leaf(100), Leaf(10), Leaf(10)
+
+        def forward(self, x):
+            return self.c(self.b(self.a(x)))
+
+    net = Net()
+    if deferred:
+        net.b.deferred_grad_writes = True
+    flat = torch.zeros(120)
+    if tied:      # spans [0,100], [50,60], [70,80]: b and c live INSIDE a's span (shared storage)
+        offs = {"a": 0, "b": 50, "c": 70}
+    else:
+        offs = {"a": 0, "b": 100, "c": 110}
+    for name, off in offs.items():
+        p = getattr(net, name).w
+        p.grad = flat[off:off + p.numel()]
+    return net, flat
+
+
+def test_bucketed_reducer_keeps_only_spans_disjoint_from_kept_ones_and_tiles_the_buffer():
+    net, flat = _flat_model(tied=True)
+    red = ddp.BucketedGradAllReduce(net, flat, bucket_bytes=1)
+    spans = [(b["lo"], b["hi"]) for b in red.buckets]
+    assert spans == [(0, 100)], spans                      # [70,80] must not survive because its neighbour [50,60] was dropped
+    cover = sorted(spans + red.leftover)
+    assert cover[0][0] == 0 and cover[-1][1] == flat.numel() and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+
+
+def test_bucketed_reducer_holds_every_bucket_for_deferred_gradient_writes_and_for_micro_batches():
+    x = torch.ones(3, requires_grad=True)
+    net, flat = _flat_model()
+    red = ddp.BucketedGradAllReduce(net, flat, bucket_bytes=1)
+    assert not red.deferred and len(red.buckets) == 3
+    net(x).sum().backward()
+    assert sum(red._done) >= 2                             # b and c are final before backward reaches a
+    red.finish()
+    red.hold = True                                        # what GraphedTrainStep.accumulate() sets per micro-batch
+    net(x).sum().backward()
+    assert sum(red._done) == 0
+    red.finish()
+    assert red.overlapped == 0 and red.hold is False       # the hold ends with the reduction
+    net2, flat2 = _flat_model(deferred=True)
+    red2 = ddp.BucketedGradAllReduce(net2, flat2, bucket_bytes=1)
+    assert red2.deferred and red2.hold
+    net2(x).sum().backward()
+    assert sum(red2._done) == 0
+    red2.finish()
+    assert red2.hold                                       # permanent for such models

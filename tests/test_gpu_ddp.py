@@ -30,6 +30,47 @@ def test_two_ranks_sharing_the_gpu_equal_one_rank_with_the_global_batch(cuda):
     assert "fno trainer" in outs[0] and "bucketed reducer" in outs[0]
 
 
+def _run_ranks(args, port, world=2, timeout=600):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable] + args, env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} exit {p.returncode}:\n{out[-4000:]}"
+    return outs
+
+
+def test_train_dlwp_two_ranks_with_resume_equal_one_rank_with_the_global_batch(cuda, tmp_path):
+    """train_loop.train_dlwp end to end at world 2 (parameter + Adam-state broadcast, flat all-reduce, clipping, checkpoint by
+    rank 0, continue_training on both ranks) against the uninterrupted single-process run of the global batch."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ddp_gpu_worker as W
+    from dlwp_benchmark_amd import train_loop
+    from dlwp_benchmark_amd.train_engine import flatten_parameters
+    out = str(tmp_path / "two")
+    os.makedirs(out)
+    _run_ranks([os.path.join(ROOT, "tests", "ddp_gpu_worker.py"), "dlwp", out], 29581)
+    got = [torch.load(os.path.join(out, f"rank{r}.pt"), weights_only=False) for r in range(2)]
+    assert torch.equal(got[0]["flat"], got[1]["flat"])                 # replicas stay identical
+    model, train, val = W.dlwp_case(seed=3)
+    model = model.to(cuda)
+    log = train_loop.train_dlwp(model, train, val, name="one", epochs=2, batch_size=4, learning_rate=2e-3,
+                                out_dir=str(tmp_path), clip_gradients=True)
+    ref = flatten_parameters(model)[0].detach().cpu()
+    e = ((got[0]["flat"] - ref).abs().max() / ref.abs().max()).item()
+    assert e <= 5e-5, e
+    assert [r["epoch"] for r in got[0]["log"]] == [1]                  # the resumed run trained epoch 1 only
+    assert abs(got[0]["log"][-1]["val_mse"] - log[-1]["val_mse"]) <= 1e-4 * abs(log[-1]["val_mse"])
+
+
 def test_rccl_communicator_of_the_c_abi_at_world_one(cuda):
     from dlwp_benchmark_amd import ddp
     comm = ddp.RcclComm(rank=0, world=1)

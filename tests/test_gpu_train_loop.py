@@ -94,3 +94,43 @@ def test_dlwp_training_from_the_weatherbench_loader(cuda, tmp_path):
     ck = torch.load(os.path.join(str(tmp_path), "w", "checkpoints", "w_last.ckpt"), weights_only=False)
     assert ck["epoch"] == 4 and ck["iteration"] == 4 * (len(train) // 4)
     assert any(k.startswith("sfno.") for k in ck["model_state_dict"])
+
+
+def test_dlwp_resume_equals_the_uninterrupted_run(cuda, tmp_path):
+    """train_dlwp: epochs 0-1, then continue_training for epochs 2-3 == four uninterrupted epochs (model, lazily restored
+    Adam moments / step count, iteration counter; micro-batch accumulation on the way)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import ddp_gpu_worker as W
+    from dlwp_benchmark_amd import train_loop
+    from dlwp_benchmark_amd.train_engine import flatten_parameters
+    kw = dict(batch_size=4, learning_rate=2e-3, gradient_accumulation_steps=2, clip_gradients=True)
+    model, train, val = W.dlwp_case(seed=3)
+    log = train_loop.train_dlwp(model.to(cuda), train, val, name="u", epochs=4, out_dir=str(tmp_path), **kw)
+    ref = flatten_parameters(model)[0].detach().clone()
+
+    class Stop(Exception):
+        pass
+
+    orig = train_loop.write_checkpoint
+    dst_last = os.path.join(str(tmp_path), "r", "checkpoints", "r_last.ckpt")
+
+    def stop_after_epoch_1(model, optimizer, sched, epoch, iteration, best, dst):
+        orig(model, optimizer, sched, epoch, iteration, best, dst_last)
+        if epoch == 1:
+            raise Stop
+
+    train_loop.write_checkpoint = stop_after_epoch_1
+    try:
+        with pytest.raises(Stop):
+            m1, _, _ = W.dlwp_case(seed=3)
+            train_loop.train_dlwp(m1.to(cuda), train, val, name="r", epochs=4, out_dir=str(tmp_path), **kw)
+    finally:
+        train_loop.write_checkpoint = orig
+    m2, _, _ = W.dlwp_case(seed=11)                     # different initial weights: everything must come from the checkpoint
+    log_b = train_loop.train_dlwp(m2.to(cuda), train, val, name="r", epochs=4, out_dir=str(tmp_path), continue_training=True, **kw)
+    assert [e["epoch"] for e in log_b] == [2, 3]
+    for a_, b_ in zip(log[2:], log_b):
+        assert abs(a_["train_mse"] - b_["train_mse"]) <= 1e-4 * abs(a_["train_mse"]), (log, log_b)
+    got = flatten_parameters(m2)[0].detach()
+    assert ((got - ref).abs().max() / ref.abs().max()).item() <= 2e-5
