@@ -15,6 +15,14 @@ int dlwp_pwmlp_fwd_rows_ex(const dlwp_chan_src* x, const float* w1, const float*
                            const float* b2, const dlwp_chan_dst* y, const dlwp_chan_src* res, int B,
                            int Cin, int Ch, int Cout, int P, const dlwp_fno_plan* rows_plan, float2* x1_out,
                            hipStream_t stream);
+// projection MLP of one net call chained with the lifting MLP (+ rows DFT) of the next in one launch; next_ch[o] = input channel
+// of the second MLP fed by output channel o of the first (-1: none).  DLWP_E_UNSUPPORTED (error string untouched) when the
+// shapes do not allow it: the caller issues the two launches instead.
+int dlwp_pwmlp_fwd_chain_ex(const dlwp_chan_src* x1v, const float* w11, const float* b11, const float* w12, const float* b12,
+                            const dlwp_chan_dst* y1, const dlwp_chan_src* res1, int Cin1, int Ch1, int Cout1,
+                            const dlwp_chan_src* x2v, const float* w21, const float* b21, const float* w22, const float* b22,
+                            const dlwp_chan_dst* y2, int Cin2, int Ch2, int Cout2, const signed char* next_ch, int B, int P,
+                            const dlwp_fno_plan* rows_plan, float2* x1_out, hipStream_t stream);
 int dlwp_pwmlp_bwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, const float* w2,
                       const dlwp_chan_src* gy, const dlwp_chan_src* pred, const dlwp_chan_src* target,
                       float mse_scale, const dlwp_chan_dst* gx, int gx_accumulate, const dlwp_chan_dst* gres,

@@ -50,6 +50,9 @@ struct dlwp_fno_trainer {
     const float** src_tab = nullptr;         // [ncalls][Cin]
     float** gdst_tab = nullptr;              // [ncalls][Cin]
     long long* bstride_tab = nullptr;        // [ncalls][Cin]
+    std::vector<const float*> h_src;         // host copies of the tables (which window planes are earlier predictions:
+    std::vector<float*> h_gdst;              //  the chained projection -> lifting launches hand those over in LDS)
+    std::vector<long long> h_bs;
     // bound by the caller
     float *params = nullptr, *grads = nullptr;
     // graph
@@ -163,6 +166,7 @@ int enqueue_forward(dlwp_fno_trainer* tr, bool keep, hipStream_t s, bool fused =
         DLWP_HIP(hipMemcpy2DAsync(tr->out, tr->traj_out * sizeof(float), tr->x, tr->traj * sizeof(float),
                                   (size_t)(ctx - 1) * tr->frame * sizeof(float), c.B, hipMemcpyDeviceToDevice, s));
     }
+    bool lifted = false;             // the lifting MLP of call k has already run (chained behind call k - 1's projection)
     for (int k = 0; k < tr->ncalls; ++k) {
         const dlwp_fno_trainer::CallInfo& ci = tr->calls[k];
         const int kk = keep ? k : 0;  // evaluation reuses slot 0
@@ -199,12 +203,16 @@ int enqueue_forward(dlwp_fno_trainer* tr, bool keep, hipStream_t s, bool fused =
                                      tr->zp + kk * zpB, tr->ap + kk * zpB, c.B, C, c.projection, c.out_channels, HW, s, P))) return rc;
             continue;
         }
-        dlwp_chan_src xs{nullptr, 0, 0, tr->src_tab + (long long)k * tr->Cin, tr->bstride_tab + (long long)k * tr->Cin};
-        dlwp_chan_dst h0d{h0, tr->act, HW, nullptr, nullptr};
         // lifting MLP with the first block's W-axis DFT in its epilogue where the shapes allow (one launch less per net
-        // call); otherwise the callee runs the separate rows kernel
-        if ((rc = dlwp_pwmlp_fwd_rows_ex(&xs, w.lw1, w.lb1, w.lw2, w.lb2, &h0d, nullptr, c.B, tr->Cin, c.lifting, C, HW,
-                                         tr->plan, tr->x1, s))) return rc;
+        // call); otherwise the callee runs the separate rows kernel.  From the second call on it has normally already run,
+        // chained behind the previous call's projection (below).
+        if (!lifted) {
+            dlwp_chan_src xs{nullptr, 0, 0, tr->src_tab + (long long)k * tr->Cin, tr->bstride_tab + (long long)k * tr->Cin};
+            dlwp_chan_dst h0d{h0, tr->act, HW, nullptr, nullptr};
+            if ((rc = dlwp_pwmlp_fwd_rows_ex(&xs, w.lw1, w.lb1, w.lw2, w.lb2, &h0d, nullptr, c.B, tr->Cin, c.lifting, C, HW,
+                                             tr->plan, tr->x1, s))) return rc;
+        }
+        lifted = false;
         for (int l = 0; l < NL; ++l) {
             if ((rc = dlwp_fno_mix_fwd(tr->plan, tr->x1, reinterpret_cast<const float2*>(w.spec(l)),
                                        xhat + l * xhatB, tr->spec, c.B, s))) return rc;
@@ -219,8 +227,26 @@ int enqueue_forward(dlwp_fno_trainer* tr, bool keep, hipStream_t s, bool fused =
             if ((rc = dlwp_fno_spatial(tr->plan, &a, s))) return rc;
         }
         dlwp_chan_src ps{pre + (NL - 1) * actB, tr->act, HW, nullptr, nullptr};
-        dlwp_chan_dst od{tr->out + (long long)ci.out_slot * tr->frame, tr->traj_out, HW, nullptr, nullptr};
+        float* oplane = tr->out + (long long)ci.out_slot * tr->frame;
+        dlwp_chan_dst od{oplane, tr->traj_out, HW, nullptr, nullptr};
         dlwp_chan_src rs{ci.res, ci.res_bs, HW, nullptr, nullptr};  // out = last frame + net (dlwp fno.py:103)
+        if (k + 1 < tr->ncalls && c.out_channels <= 8) {
+            // projection of this call chained with the lifting of the next: the frame(s) just produced go to the next window in LDS
+            signed char next_ch[8];
+            for (int o = 0; o < 8; ++o) next_ch[o] = -1;
+            const size_t t1 = (size_t)(k + 1) * tr->Cin;
+            for (int o = 0; o < c.out_channels; ++o)
+                for (int ch = 0; ch < tr->Cin; ++ch)
+                    if (tr->h_src[t1 + ch] == oplane + (long long)o * HW && tr->h_bs[t1 + ch] == tr->traj_out) next_ch[o] = (signed char)ch;
+            const int k1 = keep ? k + 1 : 0;
+            dlwp_chan_src xs1{nullptr, 0, 0, tr->src_tab + (long long)(k + 1) * tr->Cin, tr->bstride_tab + (long long)(k + 1) * tr->Cin};
+            dlwp_chan_dst h0d1{tr->h0 + k1 * actB, tr->act, HW, nullptr, nullptr};
+            rc = dlwp_pwmlp_fwd_chain_ex(&ps, w.pw1, w.pb1, w.pw2, w.pb2, &od, ci.res ? &rs : nullptr, C, c.projection, c.out_channels,
+                                         &xs1, w.lw1, w.lb1, w.lw2, w.lb2, &h0d1, tr->Cin, c.lifting, C, next_ch, c.B, HW,
+                                         tr->plan, tr->x1, s);
+            if (rc == DLWP_OK) { lifted = true; continue; }
+            if (rc != DLWP_E_UNSUPPORTED) return rc;
+        }
         if ((rc = dlwp_pwmlp_fwd_ex(&ps, w.pw1, w.pb1, w.pw2, w.pb2, &od, ci.res ? &rs : nullptr, c.B, C, c.projection,
                                     c.out_channels, HW, s))) return rc;
     }
@@ -509,6 +535,7 @@ extern "C" int dlwp_fno_trainer_bind_io(dlwp_fno_trainer* tr, const float* x, co
             }
         }
     }
+    tr->h_src = src; tr->h_gdst = gdst; tr->h_bs = bs;
     DLWP_HIP(hipMemcpy(tr->src_tab, src.data(), src.size() * sizeof(float*), hipMemcpyHostToDevice));
     DLWP_HIP(hipMemcpy(tr->gdst_tab, gdst.data(), gdst.size() * sizeof(float*), hipMemcpyHostToDevice));
     DLWP_HIP(hipMemcpy(tr->bstride_tab, bs.data(), bs.size() * sizeof(long long), hipMemcpyHostToDevice));

@@ -11,7 +11,10 @@
 // layer, keeps weight-gradient partials in registers over the 64 pixels and leaves them in a
 // per-workgroup slab in accumulator-tile order (plain 16-byte stores; one slab-parallel launch
 // folds every slab of a training step, fold_slabs_kernel below); without a slab they go out as
-// hardware float atomics (API path).  The forward kernel can append the W-axis DFT of its output
+// hardware float atomics (API path).  The backward kernel's waves own their hidden blocks alone, so they read their weight
+// fragments straight from L2 into registers (no LDS images; measured equal to the staged form, 22.1 / 20.6 us, and it frees
+// 55 KB of LDS); the forward kernel's four pixel-block waves share every fragment, there the LDS images stay (the register
+// form re-read each fragment four times through L1: 14.9 / 12.4 us against 11.4 / 10.1).  The forward kernel can append the W-axis DFT of its output
 // rows (lifting -> first spectral block), the backward kernel the adjoint DFT of its input
 // gradient rows (projection backward -> last spectral block's backward).
 #include "common.cuh"
@@ -23,9 +26,8 @@ namespace {
 constexpr int PT = 64;        // pixels per workgroup
 constexpr int FWD_WAVES = 16; // 4 waves per SIMD: the forward kernel needs 54 VGPRs and its main loop is bound by the dependent
                               // z -> GELU -> second-GEMM chain of a wave, not by the matrix pipe (8 waves: 1993, 16 waves: 2007 samples/s)
-constexpr int BWD_STREAMS = 1; // hidden blocks in flight per wave of the backward kernel.  2 (with 4 waves, one per SIMD, 352 VGPRs)
-                               // was measured: 1884 samples/s against 2020 for 8 waves x 1 stream (plain 4 waves: 1858)
-constexpr int BWD_WAVES = BWD_STREAMS == 2 ? 4 : 8;
+constexpr int BWD_WAVES = 8;   // (4 waves with two hidden blocks in flight each, 352 VGPRs, was measured: 1884 samples/s against 2020;
+                               // plain 4 waves: 1858)
 constexpr int LDP = PT + 4;   // LDS row stride of pixel tiles (4*LDP % 32 == 16: conflict-free B reads)
 
 __device__ __forceinline__ const float* chan_ptr(const dlwp_chan_src& s, int b, int c) {
@@ -38,14 +40,47 @@ __device__ __forceinline__ float* chan_ptr(const dlwp_chan_dst& s, int b, int c)
 }
 
 
+// MFMA fragments of a dense row-major [R][K] matrix straight from global memory (L2 / L1 resident weights), zero outside the
+// matrix.  Loads are unconditional from clamped addresses with the select afterwards, so that a group of them is in flight
+// together.  frag_row: element s = M[row][k + s] (vec: K % 4 == 0 and a 16-byte aligned base, k a multiple of 4);
+// frag_col: element s = M[row + s][col].
+__device__ __forceinline__ f32x4 frag_row(const float* __restrict__ M, int R, int K, int row, int k, bool vec) {
+    f32x4 v;
+    if (vec) {
+        const bool ok = row < R && k < K;
+        v = *reinterpret_cast<const f32x4*>(M + (ok ? (long long)row * K + k : 0));
+        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bool ok = row < R && k + s < K;
+            const float x = M[ok ? (long long)row * K + k + s : 0];
+            v[s] = ok ? x : 0.f;
+        }
+    }
+    return v;
+}
+__device__ __forceinline__ f32x4 frag_col(const float* __restrict__ M, int R, int K, int row, int col) {
+    f32x4 v;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const bool ok = row + s < R && col < K;
+        const float x = M[ok ? (long long)(row + s) * K + col : 0];
+        v[s] = ok ? x : 0.f;
+    }
+    return v;
+}
+
 // pixel tile [C_pad][PT] of a channel view -> LDS (row stride LDP); 16-byte loads along pixels
+// (channels in `skip` are left alone: a fused producer in the same workgroup writes them)
 template <typename SRC>
 __device__ __forceinline__ void stage_pixels(float* dst, const SRC& s, int b, int C, int C_pad, int p0, int P,
-                                             bool vec_ok) {
+                                             bool vec_ok, unsigned long long skip = 0ull) {
     if (vec_ok) {
 #pragma unroll 2
         for (int u = threadIdx.x; u < C_pad * (PT / 4); u += blockDim.x) {
             const int c = u / (PT / 4), q = u % (PT / 4);
+            if (c < 64 && ((skip >> c) & 1ull)) continue;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (c < C && p0 + 4 * q < P) {
                 const float* src = chan_ptr(s, b, c);
@@ -56,6 +91,7 @@ __device__ __forceinline__ void stage_pixels(float* dst, const SRC& s, int b, in
     } else {
         for (int idx = threadIdx.x; idx < C_pad * PT; idx += blockDim.x) {
             const int c = idx / PT, p = idx % PT;
+            if (c < 64 && ((skip >> c) & 1ull)) continue;
             float v = 0.f;
             if (c < C && p0 + p < P) {
                 const float* src = chan_ptr(s, b, c);
@@ -81,50 +117,58 @@ struct FwdArgs {
     int rows_H, m2c;
 };
 
+// ---- forward MLP of one 64-pixel tile, in pieces that a kernel strings together (the single-MLP kernel below; the chained
+// projection -> next lifting kernel further down): issue (global loads into registers) -> commit (LDS images) -> barrier ->
+// compute (both GEMMs) -> barrier -> finish (reduce the hidden groups' partial tiles, bias, residual, store, optional rows DFT).
+struct FwdLds {
+    float *xs, *w1s, *w2s, *b1s, *b2s, *outs;
+};
+// LDS floats of one MLP: input tile, the two weight images, biases (the partial output tiles `outs` are counted separately)
+__host__ __device__ __forceinline__ size_t fwd_lds_floats(int Cin_pad, int Ch_pad, int Cout_pad) {
+    return (size_t)Cin_pad * LDP + (size_t)Ch_pad * (Cin_pad + 4) + (size_t)Cout_pad * (Ch_pad + 4) + Ch_pad + Cout_pad;
+}
+__device__ __forceinline__ FwdLds fwd_carve(float* base, const FwdArgs& a, float* outs) {
+    FwdLds L;
+    L.xs = base;
+    L.w1s = L.xs + a.Cin_pad * LDP;
+    L.w2s = L.w1s + a.Ch_pad * (a.Cin_pad + 4);
+    L.b1s = L.w2s + a.Cout_pad * (a.Ch_pad + 4);
+    L.b2s = L.b1s + a.Ch_pad;
+    L.outs = outs ? outs : L.b2s + a.Cout_pad;      // [HQ][Cout_pad][LDP] per-hidden-group partial output tiles
+    return L;
+}
+struct FwdLoads {
+    MatLoad<4> l2;
+    MatLoad<2> l1;
+    float4 ftv;          // DFT table [16][PT] of the fused rows step
+    int n1, n2;
+};
+__device__ __forceinline__ void fwd_issue(const FwdArgs& a, FwdLoads& q) {
+    q.n2 = matload_units(a.Cout, a.Ch, a.vec_w != 0, 4);
+    q.n1 = matload_units(a.Ch, a.Cin, a.vec_w != 0, 2);
+    q.l2.issue(a.w2, q.n2);
+    q.l1.issue(a.w1, q.n1);
+    q.ftv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.x1_out && threadIdx.x < 16 * (PT / 4)) q.ftv = reinterpret_cast<const float4*>(a.FT)[threadIdx.x];
+}
+__device__ __forceinline__ void fwd_commit(const FwdArgs& a, const FwdLds& L, const FwdLoads& q) {
+    const int LD1 = a.Cin_pad + 4, LD2 = a.Ch_pad + 4, tid = threadIdx.x, NT = blockDim.x;
+    q.l2.commit<false>(L.w2s, LD2, a.Ch, a.dCh, q.n2);
+    q.l1.commit<false>(L.w1s, LD1, a.Cin, a.dCin, q.n1);
+    stage_matrix_tail<false>(L.w2s, LD2, a.w2, a.Cout, a.Ch, a.dCh, q.n2);
+    stage_matrix_tail<false>(L.w1s, LD1, a.w1, a.Ch, a.Cin, a.dCin, q.n1);
+    zero_padding(L.w1s, LD1, a.Ch, a.Cin, a.Ch_pad, a.Cin_pad);
+    zero_padding(L.w2s, LD2, a.Cout, a.Ch, a.Cout_pad, a.Ch_pad);
+    for (int idx = tid; idx < a.Ch_pad; idx += NT) L.b1s[idx] = idx < a.Ch ? a.b1[idx] : 0.f;
+    for (int idx = tid; idx < a.Cout_pad; idx += NT) L.b2s[idx] = idx < a.Cout ? a.b2[idx] : 0.f;
+}
 // NW waves: wave w owns pixel block (w & 3) and the hidden blocks hq, hq+HQ, ... (hq = w >> 2,
 // HQ = NW/4); two or more waves per SIMD overlap one wave's GELU (VALU) with another's MFMAs.
 template <int NOB, int NW>
-__global__ __launch_bounds__(NW * 64) void pwmlp_fwd_kernel(FwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NT = NW * 64, HQ = NW / 4;
+__device__ __forceinline__ void fwd_compute(const FwdArgs& a, const FwdLds& L) {
+    constexpr int HQ = NW / 4;
     const int LD1 = a.Cin_pad + 4, LD2 = a.Ch_pad + 4;
-    float* xs = smem;
-    float* w1s = xs + a.Cin_pad * LDP;
-    float* w2s = w1s + a.Ch_pad * LD1;
-    float* b1s = w2s + a.Cout_pad * LD2;
-    float* b2s = b1s + a.Ch_pad;
-    float* outs = b2s + a.Cout_pad;  // [HQ][Cout_pad][LDP] per-hidden-group partial output tiles
-
-    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
-    const int r = lane & 15, g = lane >> 4;
-    const int b = blockIdx.x / a.tiles_per_sample;
-    const int p0 = (blockIdx.x % a.tiles_per_sample) * PT;
-
-    DLWP_STAMP(0);
-    // issue every independent global load first, then fill the LDS images
-    MatLoad<4> l2;
-    MatLoad<2> l1;
-    const int n2 = matload_units(a.Cout, a.Ch, a.vec_w != 0, 4), n1 = matload_units(a.Ch, a.Cin, a.vec_w != 0, 2);
-    l2.issue(a.w2, n2);
-    l1.issue(a.w1, n1);
-    float4 ftv = make_float4(0.f, 0.f, 0.f, 0.f);          // DFT table [16][PT] of the fused rows step
-    if (a.x1_out && tid < 16 * (PT / 4)) ftv = reinterpret_cast<const float4*>(a.FT)[tid];
-    DLWP_STAMP(1);
-    stage_pixels(xs, a.x, b, a.Cin, a.Cin_pad, p0, a.P, a.vec_x != 0);
-    DLWP_STAMP(2);
-    l2.commit<false>(w2s, LD2, a.Ch, a.dCh, n2);
-    l1.commit<false>(w1s, LD1, a.Cin, a.dCin, n1);
-    stage_matrix_tail<false>(w2s, LD2, a.w2, a.Cout, a.Ch, a.dCh, n2);
-    stage_matrix_tail<false>(w1s, LD1, a.w1, a.Ch, a.Cin, a.dCin, n1);
-    DLWP_STAMP(3);
-    zero_padding(w1s, LD1, a.Ch, a.Cin, a.Ch_pad, a.Cin_pad);
-    zero_padding(w2s, LD2, a.Cout, a.Ch, a.Cout_pad, a.Ch_pad);
-    for (int idx = tid; idx < a.Ch_pad; idx += NT) b1s[idx] = idx < a.Ch ? a.b1[idx] : 0.f;
-    for (int idx = tid; idx < a.Cout_pad; idx += NT) b2s[idx] = idx < a.Cout ? a.b2[idx] : 0.f;
-    DLWP_STAMP(4);
-    __syncthreads();
-    DLWP_STAMP(5);
-
+    const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
     const int pw0 = (w & 3) * 16, hq = w >> 2;
     const int nkc = a.Cin_pad / 16, nhb = a.Ch_pad / 16;
     f32x4 oacc[NOB];
@@ -134,17 +178,17 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_fwd_kernel(FwdArgs a) {
     for (int hb = hq; hb < nhb; hb += HQ) {
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
         for (int kc = 0; kc < nkc; ++kc) {
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&w1s[(hb * 16 + r) * LD1 + kc * 16 + 4 * g]);
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&L.w1s[(hb * 16 + r) * LD1 + kc * 16 + 4 * g]);
             f32x4 b4;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) b4[s] = xs[(kc * 16 + 4 * g + s) * LDP + pw0 + r];
+            for (int s = 0; s < 4; ++s) b4[s] = L.xs[(kc * 16 + 4 * g + s) * LDP + pw0 + r];
             z = mfma16_chunk(a4, b4, z);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) z[j] = gelu_f(z[j] + b1s[hb * 16 + 4 * g + j]);
+        for (int j = 0; j < 4; ++j) z[j] = gelu_f(z[j] + L.b1s[hb * 16 + 4 * g + j]);
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
-            const f32x4 w4 = *reinterpret_cast<const f32x4*>(&w2s[(ob * 16 + r) * LD2 + hb * 16 + 4 * g]);
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(&L.w2s[(ob * 16 + r) * LD2 + hb * 16 + 4 * g]);
             oacc[ob] = mfma16_chunk(w4, z, oacc[ob]);
         }
     }
@@ -152,12 +196,17 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_fwd_kernel(FwdArgs a) {
     for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            outs[(hq * a.Cout_pad + ob * 16 + 4 * g + j) * LDP + pw0 + r] = oacc[ob][j];
+            L.outs[(hq * a.Cout_pad + ob * 16 + 4 * g + j) * LDP + pw0 + r] = oacc[ob][j];
         }
-    DLWP_STAMP(6);
-    __syncthreads();
-    DLWP_STAMP(7);
-
+}
+// next_xs / next_ch: a chained MLP's input tile in LDS and, per output channel, the input channel of that tile the finished
+// values are copied to (-1: none) -- the consumer then never reads them back from global memory
+template <int NOB, int NW>
+__device__ __forceinline__ void fwd_finish(const FwdArgs& a, const FwdLds& L, const float4 ftv, int b, int p0, int tile,
+                                           float* next_xs = nullptr, const signed char* next_ch = nullptr) {
+    constexpr int NT = NW * 64, HQ = NW / 4;
+    const int tid = threadIdx.x, w = wave_id();
+    float* outs = L.outs;
     const bool has_res = a.res.base || a.res.tab;
     if (a.vec_x) {
         for (int u = tid; u < a.Cout * (PT / 4); u += NT) {
@@ -169,7 +218,7 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_fwd_kernel(FwdArgs a) {
                     const float4 pv = *reinterpret_cast<const float4*>(&outs[(h2 * a.Cout_pad + o) * LDP + 4 * q]);
                     v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
                 }
-                const float bb = b2s[o];
+                const float bb = L.b2s[o];
                 v.x += bb; v.y += bb; v.z += bb; v.w += bb;
                 if (has_res) {
                     const float* rp = chan_ptr(a.res, b, o);
@@ -181,25 +230,26 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_fwd_kernel(FwdArgs a) {
                 float* dst = chan_ptr(a.y, b, o);
                 if (dst) *reinterpret_cast<float4*>(dst + p) = v;
                 if (a.x1_out) *reinterpret_cast<float4*>(&outs[o * LDP + 4 * q]) = v;   // finished row tile, in place
+                if (next_xs && o < 8 && next_ch[o] >= 0) *reinterpret_cast<float4*>(&next_xs[next_ch[o] * LDP + 4 * q]) = v;
             }
         }
         if (a.x1_out) {
             // W-axis pruned DFT of the finished row, so that the first spectral block needs no separate rows kernel.
             // The W2 image is dead: it hosts the table and the per-wave partial spectra.
-            float* ft = w2s;                       // [16][LDP]
-            float* x1s = w2s + 16 * LDP;           // [4 waves][Cout_pad][16]
+            float* ft = L.w2s;                       // [16][LDP]
+            float* x1s = L.w2s + 16 * LDP;           // [4 waves][Cout_pad][16]
             if (tid < 16 * (PT / 4)) *reinterpret_cast<float4*>(&ft[(tid / (PT / 4)) * LDP + 4 * (tid % (PT / 4))]) = ftv;
             for (int idx = a.Cout * LDP + tid; idx < a.Cout_pad * LDP; idx += NT) outs[idx] = 0.f;
             __syncthreads();
             if (w < 4) tile_rows_dft<NOB, 1>(outs, ft, x1s, LDP, 16, PT / 16, false);
             __syncthreads();
-            store_x1(x1s, a.x1_out, b, (int)(blockIdx.x % a.tiles_per_sample), a.rows_H, a.m2c, a.Cout, a.Cout_pad, 16);
+            store_x1(x1s, a.x1_out, b, tile, a.rows_H, a.m2c, a.Cout, a.Cout_pad, 16);
         }
     } else {
         for (int idx = tid; idx < a.Cout * PT; idx += NT) {
             const int o = idx / PT, p = p0 + idx % PT;
             if (p < a.P) {
-                float v = b2s[o];
+                float v = L.b2s[o];
 #pragma unroll
                 for (int h2 = 0; h2 < HQ; ++h2) v += outs[(h2 * a.Cout_pad + o) * LDP + idx % PT];
                 if (has_res) {
@@ -211,7 +261,66 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_fwd_kernel(FwdArgs a) {
             }
         }
     }
+}
+
+template <int NOB, int NW>
+__global__ __launch_bounds__(NW * 64) void pwmlp_fwd_kernel(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const FwdLds L = fwd_carve(smem, a, nullptr);
+    const int b = blockIdx.x / a.tiles_per_sample, tile = blockIdx.x % a.tiles_per_sample;
+    const int p0 = tile * PT;
+    DLWP_STAMP(0);
+    // issue every independent global load first, then fill the LDS images
+    FwdLoads q;
+    fwd_issue(a, q);
+    DLWP_STAMP(1);
+    stage_pixels(L.xs, a.x, b, a.Cin, a.Cin_pad, p0, a.P, a.vec_x != 0);
+    DLWP_STAMP(2);
+    fwd_commit(a, L, q);
+    DLWP_STAMP(4);
+    __syncthreads();
+    DLWP_STAMP(5);
+    fwd_compute<NOB, NW>(a, L);
+    DLWP_STAMP(6);
+    __syncthreads();
+    DLWP_STAMP(7);
+    fwd_finish<NOB, NW>(a, L, q.ftv, b, p0, tile);
     DLWP_STAMP(8);
+}
+
+// Projection of net call k chained with the lifting of net call k + 1 (both pointwise, the same 64-pixel tile): the rollout's
+// closed loop feeds the frame the projection has just produced straight into the next lifting layer's input tile, in LDS;
+// one launch, one prologue (both weight sets are requested together) instead of two, and the frame is not read back.
+struct ChainArgs {
+    FwdArgs p, l;
+    signed char next_ch[8];        // output channel o of the first MLP -> input channel of the second (-1: none)
+    unsigned long long skip;       // input channels of the second MLP that come from the first
+};
+template <int NOB1, int NOB2, int NW>
+__global__ __launch_bounds__(NW * 64) void pwmlp_fwd_chain_kernel(ChainArgs c) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int HQ = NW / 4;
+    // first MLP with its partial tiles, then the second MLP whose partial tiles alias the first one's W1 image (dead by then)
+    const FwdLds P = fwd_carve(smem, c.p, nullptr);
+    float* base2 = P.outs + HQ * c.p.Cout_pad * LDP;
+    const FwdLds Lq = fwd_carve(base2, c.l, P.w1s);
+    const int b = blockIdx.x / c.p.tiles_per_sample, tile = blockIdx.x % c.p.tiles_per_sample;
+    const int p0 = tile * PT;
+    FwdLoads qp, ql;
+    fwd_issue(c.p, qp);
+    fwd_issue(c.l, ql);
+    stage_pixels(P.xs, c.p.x, b, c.p.Cin, c.p.Cin_pad, p0, c.p.P, c.p.vec_x != 0);
+    stage_pixels(Lq.xs, c.l.x, b, c.l.Cin, c.l.Cin_pad, p0, c.l.P, c.l.vec_x != 0, c.skip);
+    fwd_commit(c.p, P, qp);
+    fwd_commit(c.l, Lq, ql);
+    __syncthreads();
+    fwd_compute<NOB1, NW>(c.p, P);
+    __syncthreads();
+    fwd_finish<NOB1, NW>(c.p, P, qp.ftv, b, p0, tile, Lq.xs, c.next_ch);
+    __syncthreads();
+    fwd_compute<NOB2, NW>(c.l, Lq);
+    __syncthreads();
+    fwd_finish<NOB2, NW>(c.l, Lq, ql.ftv, b, p0, tile);
 }
 
 struct BwdArgs {
@@ -250,23 +359,37 @@ template <int NIB, int NOB, int NW>
 __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
     constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int LD1 = a.Cin_pad + 4, LD2 = a.Ch_pad + 4;
     float* xs = smem;                        // [Cin_pad][LDP]
     float* gys = xs + a.Cin_pad * LDP;       // [Cout_pad][LDP]
-    float* w1s = gys + a.Cout_pad * LDP;     // [Ch_pad][LD1]
-    float* w2s = w1s + a.Ch_pad * LD1;       // [Cout_pad][LD2]
-    float* b1s = w2s + a.Cout_pad * LD2;     // [Ch_pad]
+    float* red = gys + a.Cout_pad * LDP;     // [NW][Cin_pad][LDP] gx partial tiles; later the rows-DFT table / partial spectra
 
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const int r = lane & 15, g = lane >> 4;
     const int b = blockIdx.x / a.tiles_per_sample;
     const int p0 = (blockIdx.x % a.tiles_per_sample) * PT;
 
-    MatLoad<4> l2;
-    MatLoad<4> l1;
-    const int n2 = matload_units(a.Cout, a.Ch, a.vec_w != 0, 4), n1 = matload_units(a.Ch, a.Cin, a.vec_w != 0, 4);
-    l2.issue(a.w2, n2);
-    l1.issue(a.w1, n1);
+    const int nhb = a.Ch_pad / 16;
+    const bool vec1 = a.vec_w != 0 && (a.Cin & 3) == 0;
+    DLWP_STAMP(9);
+    // weight fragments of one hidden block, straight from L2: W1 rows (B operand of z^T), b1, W2 columns of the block (B operand
+    // of g_a^T), W1 columns (A operand of dX).  A wave owns its hidden blocks alone, so every fragment is read once per workgroup.
+    struct HbW {
+        f32x4 w1b[NIB], w2c[NOB], w1c[NIB];
+        float b1v;
+    };
+    auto load_hb = [&](int hb, HbW& h) {
+#pragma unroll
+        for (int kc = 0; kc < NIB; ++kc) h.w1b[kc] = frag_row(a.w1, a.Ch, a.Cin, hb * 16 + r, kc * 16 + 4 * g, vec1);
+#pragma unroll
+        for (int oc = 0; oc < NOB; ++oc) h.w2c[oc] = frag_col(a.w2, a.Cout, a.Ch, oc * 16 + 4 * g, hb * 16 + r);
+#pragma unroll
+        for (int ib = 0; ib < NIB; ++ib) h.w1c[ib] = frag_col(a.w1, a.Ch, a.Cin, hb * 16 + 4 * g, ib * 16 + r);
+        const bool okh = hb * 16 + r < a.Ch;
+        const float bv = a.b1[okh ? hb * 16 + r : 0];
+        h.b1v = okh ? bv : 0.f;
+    };
+    HbW wcur;
+    load_hb(w < nhb ? w : 0, wcur);                        // in flight while the pixel tiles are staged
     float4 ftv = make_float4(0.f, 0.f, 0.f, 0.f);          // DFT table [16][PT] of the fused rows step
     if (a.x1_out && tid < 16 * (PT / 4)) ftv = reinterpret_cast<const float4*>(a.FT)[tid];
     stage_pixels(xs, a.x, b, a.Cin, a.Cin_pad, p0, a.P, a.vec_x != 0);
@@ -292,13 +415,6 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
             gys[c * LDP + p] = v;
         }
     }
-    l2.commit<false>(w2s, LD2, a.Ch, a.dCh, n2);
-    l1.commit<false>(w1s, LD1, a.Cin, a.dCin, n1);
-    stage_matrix_tail<false>(w2s, LD2, a.w2, a.Cout, a.Ch, a.dCh, n2);
-    stage_matrix_tail<false>(w1s, LD1, a.w1, a.Ch, a.Cin, a.dCin, n1);
-    zero_padding(w1s, LD1, a.Ch, a.Cin, a.Ch_pad, a.Cin_pad);
-    zero_padding(w2s, LD2, a.Cout, a.Ch, a.Cout_pad, a.Ch_pad);
-    for (int idx = tid; idx < a.Ch_pad; idx += NT) b1s[idx] = idx < a.Ch ? a.b1[idx] : 0.f;
     __syncthreads();
     if (a.gres.base || a.gres.tab) {
         for (int idx = tid; idx < a.Cout * PT; idx += NT) {
@@ -309,7 +425,6 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
     }
 
     DLWP_STAMP(10);
-    const int nhb = a.Ch_pad / 16;
 
     f32x4 gxacc[4][NIB];
 #pragma unroll
@@ -333,8 +448,6 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
     // its operand through a 4-MFMA multiplication with the identity instead of an LDS round trip.
     // One hidden block's state while its four pixel blocks are processed.
     struct HbState {
-        f32x4 w1b[NIB];        // B operand of z^T: W1[h = r][i = 4g+s]
-        float b1v;
         f32x4 pgw2[NOB], pgw1[NIB];   // running slab partials (read-modify-write accumulation across net calls)
         float pgb1;
         f32x4 gw2acc[NOB], gw1acc[NIB];
@@ -344,10 +457,6 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
     };
     auto hb_begin = [&](HbState& st, int hb) {
         st.hb = hb;
-#pragma unroll
-        for (int kc = 0; kc < NIB; ++kc)
-            st.w1b[kc] = *reinterpret_cast<const f32x4*>(&w1s[(hb * 16 + r) * LD1 + kc * 16 + 4 * g]);
-        st.b1v = b1s[hb * 16 + r];
         // The slab is private scratch, so it is laid out in ACCUMULATOR-TILE order: tile (hb, ob) holds the 4
         // registers of every lane contiguously -> one 16-byte access per lane, 1 KiB per wave-instruction
         // (narrow 64-byte-segment stores were issue-bound: ~350 cycles each).  The old values are fetched here.
@@ -367,60 +476,65 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
 #pragma unroll
         for (int ib = 0; ib < NIB; ++ib) st.gw1acc[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    auto hb_step = [&](HbState& st, int pb) {
-        const int hb = st.hb;
-        // z^T[p][h] = sum_i x[i][p] W1[h][i]
-        f32x4 zt = {0.f, 0.f, 0.f, 0.f};
+    // One pixel block in two stages, software-pipelined by the caller: stage A (z^T and g_a^T, MFMA only) of block pb + 1 is
+    // issued in front of stage B (GELU on the VALU, then the products that need it) of block pb, and the k-steps of
+    // independent accumulators are interleaved (a 16x16x4 MFMA that accumulates into its predecessor's result issues every 40
+    // cycles instead of 32).  Measured: neither changes the kernel (22.4 / 20.4 us before and after) -- on one SIMD the exact-f32
+    // MFMA and ordinary VALU instructions do not co-execute at all (tools/micro/mfma_valu_coexec.hip: 257 k + 177 k cycles
+    // apart, 433 k together), so the main loop costs MFMA cycles PLUS GELU cycles however they are ordered.
+    auto hb_stage_a = [&](const HbW& hw, int pb, f32x4& zt, f32x4& gat) {
+        // z^T[p][h] = sum_i x[i][p] W1[h][i];  g_a^T[p][h] = sum_o gy[o][p] W2[o][h]
+        f32x4 az[NIB], ag[NOB];
 #pragma unroll
-        for (int kc = 0; kc < NIB; ++kc) {
-            f32x4 a4;
+        for (int kc = 0; kc < NIB; ++kc)
 #pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) a4[s2] = xs[(kc * 16 + 4 * g + s2) * LDP + pb * 16 + r];
-            zt = mfma16_chunk(a4, st.w1b[kc], zt);
-        }
-        // g_a^T[p][h] = sum_o gy[o][p] W2[o][h]
-        f32x4 gat = {0.f, 0.f, 0.f, 0.f};
+            for (int s2 = 0; s2 < 4; ++s2) az[kc][s2] = xs[(kc * 16 + 4 * g + s2) * LDP + pb * 16 + r];
 #pragma unroll
-        for (int oc = 0; oc < NOB; ++oc) {
-            f32x4 a4, b4;
+        for (int oc = 0; oc < NOB; ++oc)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) ag[oc][s2] = gys[(oc * 16 + 4 * g + s2) * LDP + pb * 16 + r];
+        zt = f32x4{0.f, 0.f, 0.f, 0.f};
+        gat = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int NMAX = NIB > NOB ? NIB : NOB;
+#pragma unroll
+        for (int c = 0; c < NMAX; ++c)
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) {
-                a4[s2] = gys[(oc * 16 + 4 * g + s2) * LDP + pb * 16 + r];
-                b4[s2] = w2s[(oc * 16 + 4 * g + s2) * LD2 + hb * 16 + r];
+                if (c < NIB) zt = mfma16(az[c][s2], hw.w1b[c][s2], zt);
+                if (c < NOB) gat = mfma16(ag[c][s2], hw.w2c[c][s2], gat);
             }
-            gat = mfma16_chunk(a4, b4, gat);
-        }
+    };
+    auto hb_stage_b = [&](HbState& st, const HbW& hw, int pb, const f32x4 zt, const f32x4 gat) {
         f32x4 actt, gzt;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float av, dv;
-            gelu_both(zt[j] + st.b1v, av, dv);
+            gelu_both(zt[j] + hw.b1v, av, dv);
             actt[j] = av;
             gzt[j] = gat[j] * dv;
             st.gb1acc += gzt[j];
         }
-        // dW2[o][h] += sum_p gy[o][p] act^T[p][h]
+        // dW2[o][h] += sum_p gy[o][p] act^T[p][h];  dW1[h][i] += sum_p gz[h][p] x[i][p]  (gz^T registers read as an A operand
+        // are gz);  gz[h][p] in accumulator layout = gz^T (as A operand) x identity
+        f32x4 a2[NOB], b1f[NIB];
 #pragma unroll
-        for (int ob = 0; ob < NOB; ++ob) {
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&gys[(ob * 16 + r) * LDP + pb * 16 + 4 * g]);
-            st.gw2acc[ob] = mfma16_chunk(a4, actt, st.gw2acc[ob]);
-        }
-        // dW1[h][i] += sum_p gz[h][p] x[i][p]   (gz^T registers read as an A operand are gz)
+        for (int ob = 0; ob < NOB; ++ob) a2[ob] = *reinterpret_cast<const f32x4*>(&gys[(ob * 16 + r) * LDP + pb * 16 + 4 * g]);
 #pragma unroll
-        for (int ib = 0; ib < NIB; ++ib) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(&xs[(ib * 16 + r) * LDP + pb * 16 + 4 * g]);
-            st.gw1acc[ib] = mfma16_chunk(gzt, b4, st.gw1acc[ib]);
+        for (int ib = 0; ib < NIB; ++ib) b1f[ib] = *reinterpret_cast<const f32x4*>(&xs[(ib * 16 + r) * LDP + pb * 16 + 4 * g]);
+        f32x4 gz = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            gz = mfma16(gzt[s2], ident[s2], gz);
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) st.gw2acc[ob] = mfma16(a2[ob][s2], actt[s2], st.gw2acc[ob]);
+#pragma unroll
+            for (int ib = 0; ib < NIB; ++ib) st.gw1acc[ib] = mfma16(gzt[s2], b1f[ib][s2], st.gw1acc[ib]);
         }
-        // gz[h][p] in accumulator layout = gz^T (as A operand) x identity
-        const f32x4 gz = mfma16_chunk(gzt, ident, f32x4{0.f, 0.f, 0.f, 0.f});
         // dX[i][p] += sum_h W1[h][i] gz[h][p]
 #pragma unroll
-        for (int ib = 0; ib < NIB; ++ib) {
-            f32x4 a4;
+        for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) a4[s2] = w1s[(hb * 16 + 4 * g + s2) * LD1 + ib * 16 + r];
-            gxacc[pb][ib] = mfma16_chunk(a4, gz, gxacc[pb][ib]);
-        }
+            for (int ib = 0; ib < NIB; ++ib) gxacc[pb][ib] = mfma16(hw.w1c[ib][s2], gz[s2], gxacc[pb][ib]);
     };
     auto hb_flush = [&](HbState& st) {
         const int hb = st.hb;
@@ -465,23 +579,7 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
             else if (h < a.Ch) atomic_add_f32(a.gb1 + h, v);
         }
     };
-    if constexpr (BWD_STREAMS == 2) {
-        // one wave per SIMD, two hidden blocks in flight per wave: the pixel blocks of both are interleaved in program order,
-        // so that one block's GELU / dependent MFMA chains fill the other's gaps (no reliance on SIMD arbitration)
-        for (int hb = w; hb < nhb; hb += 2 * NW) {
-            HbState sa, sb;
-            const bool two = hb + NW < nhb;
-            hb_begin(sa, hb);
-            if (two) hb_begin(sb, hb + NW);
-#pragma unroll
-            for (int pb = 0; pb < 4; ++pb) {
-                hb_step(sa, pb);
-                if (two) hb_step(sb, pb);
-            }
-            hb_flush(sa);
-            if (two) hb_flush(sb);
-        }
-    } else {
+    {
         // Two waves share each SIMD's matrix pipe; in-kernel stamps showed waves 0-3 leaving this loop after 20 k cycles and
         // waves 4-7 after 29 k, with the barrier behind it waiting for the slowest.  The younger half runs the FIRST half of
         // its hidden blocks at raised priority and the second half at the default (moves the skew by < 2 k cycles).
@@ -492,9 +590,19 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
             HbState st;
             hb_begin(st, hb);
             if (hb == w) DLWP_STAMP(12);
+            f32x4 zt, gat;
+            hb_stage_a(wcur, 0, zt, gat);
 #pragma unroll
-            for (int pb = 0; pb < 4; ++pb) hb_step(st, pb);
+            for (int pb = 0; pb < 4; ++pb) {
+                f32x4 ztn = zt, gatn = gat;
+                if (pb < 3) hb_stage_a(wcur, pb + 1, ztn, gatn);
+                hb_stage_b(st, wcur, pb, zt, gat);
+                zt = ztn; gat = gatn;
+            }
             if (hb == w) DLWP_STAMP(18);
+            // the next block's fragments are requested here, behind the last use of the current ones: their latency overlaps the
+            // slab stores and the next hb_begin, and they add no live registers to the pixel-block loop
+            if (hb + NW < nhb) load_hb(hb + NW, wcur);
             hb_flush(st);
             if (hb == w) DLWP_STAMP(19);
         }
@@ -508,7 +616,6 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
     const bool want_gx = a.gx.base || a.gx.tab;
     DLWP_STAMP(20);
     __syncthreads();
-    float* red = w1s;  // [NW][Cin_pad][LDP]
     if (want_gx) {
 #pragma unroll
         for (int pb = 0; pb < 4; ++pb)
@@ -563,6 +670,7 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
         __syncthreads();
         store_x1(x1s, a.x1_out, b, (int)(blockIdx.x % a.tiles_per_sample), a.rows_H, a.m2c, a.Cin, a.Cin_pad, 16);
     }
+    DLWP_STAMP(23);
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -668,13 +776,14 @@ bool dlwp_pwmlp_rows_fusable(const dlwp_fno_plan* p, int Cout, int P) {
     return p && p->W == PT && p->NP == 16 && p->C == Cout && P == p->H * p->W && p->C_pad <= 64;
 }
 
-int dlwp_pwmlp_fwd_rows_ex(const dlwp_chan_src* x, const float* w1, const float* b1, const float* w2,
-                           const float* b2, const dlwp_chan_dst* y, const dlwp_chan_src* res, int B,
-                           int Cin, int Ch, int Cout, int P, const dlwp_fno_plan* rows_plan, float2* x1_out,
-                           hipStream_t stream) {
+// fills and validates the launch arguments of one forward MLP; rows_after: the rows DFT was asked for but the epilogue
+// cannot host it (the caller runs the separate rows kernel)
+static int fwd_make_args(FwdArgs& a, const dlwp_chan_src* x, const float* w1, const float* b1, const float* w2,
+                         const float* b2, const dlwp_chan_dst* y, const dlwp_chan_src* res, int B, int Cin, int Ch, int Cout,
+                         int P, const dlwp_fno_plan* rows_plan, float2* x1_out, bool& rows_after) {
     DLWP_REQUIRE(B > 0 && Cin > 0 && Ch > 0 && Cout > 0 && P > 0, DLWP_E_INVALID,
                  "pwmlp_fwd: non-positive dimension");
-    FwdArgs a{};
+    a = FwdArgs{};
     a.x = *x; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = *y;
     if (res) a.res = *res;
     a.B = B; a.Cin = Cin; a.Ch = Ch; a.Cout = Cout; a.P = P;
@@ -687,7 +796,7 @@ int dlwp_pwmlp_fwd_rows_ex(const dlwp_chan_src* x, const float* w1, const float*
     DLWP_REQUIRE(nob <= 4 && a.Cin_pad <= 64, DLWP_E_UNSUPPORTED,
                  "pwmlp_fwd: Cin<=64 and Cout<=64 supported (got %d, %d)", Cin, Cout);
     a.vec_x = a.vec_x && view_vec_ok(a.y) && view_vec_ok(a.res);
-    bool rows_after = false;
+    rows_after = false;
     if (x1_out) {
         DLWP_REQUIRE(rows_plan && y->base, DLWP_E_INVALID, "pwmlp_fwd: the rows DFT needs a plan and a dense output");
         const bool fuse = dlwp_pwmlp_rows_fusable(rows_plan, Cout, P) && a.vec_x &&
@@ -695,12 +804,21 @@ int dlwp_pwmlp_fwd_rows_ex(const dlwp_chan_src* x, const float* w1, const float*
         if (fuse) { a.x1_out = x1_out; a.FT = rows_plan->FT_fwd; a.rows_H = rows_plan->H; a.m2c = rows_plan->m2c; }
         else rows_after = true;       // shapes the epilogue cannot host: separate rows kernel, same result
     }
-    const size_t lds = sizeof(float) * ((size_t)a.Cin_pad * LDP + (size_t)a.Ch_pad * (a.Cin_pad + 4) +
-                                        (size_t)a.Cout_pad * (a.Ch_pad + 4) + a.Ch_pad + a.Cout_pad +
-                                        (size_t)(FWD_WAVES / 4) * a.Cout_pad * LDP);
+    return DLWP_OK;
+}
+
+int dlwp_pwmlp_fwd_rows_ex(const dlwp_chan_src* x, const float* w1, const float* b1, const float* w2,
+                           const float* b2, const dlwp_chan_dst* y, const dlwp_chan_src* res, int B,
+                           int Cin, int Ch, int Cout, int P, const dlwp_fno_plan* rows_plan, float2* x1_out,
+                           hipStream_t stream) {
+    FwdArgs a;
+    bool rows_after;
+    int rc = fwd_make_args(a, x, w1, b1, w2, b2, y, res, B, Cin, Ch, Cout, P, rows_plan, x1_out, rows_after);
+    if (rc) return rc;
+    const int nob = a.Cout_pad / 16;
+    const size_t lds = sizeof(float) * (fwd_lds_floats(a.Cin_pad, a.Ch_pad, a.Cout_pad) + (size_t)(FWD_WAVES / 4) * a.Cout_pad * LDP);
     constexpr int NW = FWD_WAVES;
     const dim3 grid(B * a.tiles_per_sample), block(NW * 64);
-    int rc;
 #define LAUNCH(N)                                                             \
     if ((rc = set_lds(pwmlp_fwd_kernel<N, NW>, lds)) != DLWP_OK) return rc;   \
     hipLaunchKernelGGL((pwmlp_fwd_kernel<N, NW>), grid, block, lds, stream, a);
@@ -713,6 +831,46 @@ int dlwp_pwmlp_fwd_rows_ex(const dlwp_chan_src* x, const float* w1, const float*
 #undef LAUNCH
     DLWP_LAUNCH_CHECK();
     if (rows_after) return dlwp_fno_rows_dft(rows_plan, y->base, 0, 0, x1_out, B, stream);
+    return DLWP_OK;
+}
+
+// Two forward MLPs on the same pixel tiles in ONE launch (projection of a net call -> lifting of the next one): the second
+// MLP's input channels that ARE output channels of the first (matched by plane pointer and batch stride in the caller's
+// channel table) are handed over in LDS.  Returns DLWP_E_UNSUPPORTED without touching the error string when the shapes do not
+// allow the chain (the caller then issues the two launches separately).
+int dlwp_pwmlp_fwd_chain_ex(const dlwp_chan_src* x1v, const float* w11, const float* b11, const float* w12, const float* b12,
+                            const dlwp_chan_dst* y1, const dlwp_chan_src* res1, int Cin1, int Ch1, int Cout1,
+                            const dlwp_chan_src* x2v, const float* w21, const float* b21, const float* w22, const float* b22,
+                            const dlwp_chan_dst* y2, int Cin2, int Ch2, int Cout2, const signed char* next_ch, int B, int P,
+                            const dlwp_fno_plan* rows_plan, float2* x1_out, hipStream_t stream) {
+    ChainArgs c{};
+    bool ra1, ra2;
+    int rc = fwd_make_args(c.p, x1v, w11, b11, w12, b12, y1, res1, B, Cin1, Ch1, Cout1, P, nullptr, nullptr, ra1);
+    if (rc) return rc;
+    if ((rc = fwd_make_args(c.l, x2v, w21, b21, w22, b22, y2, nullptr, B, Cin2, Ch2, Cout2, P, rows_plan, x1_out, ra2))) return rc;
+    constexpr int NW = FWD_WAVES, HQ = NW / 4;
+    const size_t lds = sizeof(float) * (fwd_lds_floats(c.p.Cin_pad, c.p.Ch_pad, c.p.Cout_pad) + (size_t)HQ * c.p.Cout_pad * LDP +
+                                        fwd_lds_floats(c.l.Cin_pad, c.l.Ch_pad, c.l.Cout_pad));
+    const bool alias_ok = (size_t)HQ * c.l.Cout_pad * LDP <= (size_t)c.p.Ch_pad * (c.p.Cin_pad + 4);
+    const int nob1 = c.p.Cout_pad / 16, nob2 = c.l.Cout_pad / 16;
+    if (ra2 || !c.p.vec_x || !c.l.vec_x || Cout1 > 8 || !alias_ok || lds > 160 * 1024 || nob1 != 1 || nob2 > 2) return DLWP_E_UNSUPPORTED;
+    c.skip = 0;
+    for (int o = 0; o < 8; ++o) {
+        c.next_ch[o] = o < Cout1 ? next_ch[o] : (signed char)-1;
+        if (c.next_ch[o] >= 0) {
+            if (c.next_ch[o] >= Cin2) return DLWP_E_UNSUPPORTED;
+            c.skip |= 1ull << c.next_ch[o];
+        }
+    }
+    const dim3 grid(B * c.p.tiles_per_sample), block(NW * 64);
+    if (nob2 == 1) {
+        if ((rc = set_lds(pwmlp_fwd_chain_kernel<1, 1, NW>, lds)) != DLWP_OK) return rc;
+        hipLaunchKernelGGL((pwmlp_fwd_chain_kernel<1, 1, NW>), grid, block, lds, stream, c);
+    } else {
+        if ((rc = set_lds(pwmlp_fwd_chain_kernel<1, 2, NW>, lds)) != DLWP_OK) return rc;
+        hipLaunchKernelGGL((pwmlp_fwd_chain_kernel<1, 2, NW>), grid, block, lds, stream, c);
+    }
+    DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }
 
@@ -746,7 +904,7 @@ int dlwp_pwmlp_bwd_rows_ex(const dlwp_chan_src* x, const float* w1, const float*
     a.tiles_per_sample = ceil_div(P, PT);
     a.Cin_pad = round_up(Cin, 16); a.Ch_pad = round_up(Ch, 16); a.Cout_pad = round_up(Cout, 16);
     a.slab = slab; a.slab_stride = dlwp_pwmlp_slab_stride(Cin, Ch, Cout); a.slab_accumulate = slab_accumulate;
-    a.vec_w = aligned16(w1) && aligned16(w2);
+    a.vec_w = aligned16(w1);
     a.dCin = make_fastdiv(Cin); a.dCh = make_fastdiv(Ch);
     a.vec_x = P % 4 == 0 && view_vec_ok(a.x) && view_vec_ok(a.gy);
     const int nib = a.Cin_pad / 16, nob = a.Cout_pad / 16;
@@ -762,10 +920,8 @@ int dlwp_pwmlp_bwd_rows_ex(const dlwp_chan_src* x, const float* w1, const float*
         if (fuse) { a.x1_out = x1_out; a.FT = rows_plan->FT_adj; a.rows_H = rows_plan->H; a.m2c = rows_plan->m2c; }
         else rows_after = true;       // shapes the epilogue cannot host: separate rows kernel, same result
     }
-    size_t wimg = (size_t)a.Ch_pad * (a.Cin_pad + 4) + (size_t)a.Cout_pad * (a.Ch_pad + 4) + a.Ch_pad;
-    const size_t red = (size_t)BWD_WAVES * a.Cin_pad * LDP;  // gx partial tiles alias the weight images
-    if (wimg < red) wimg = red;
-    const size_t lds = sizeof(float) * ((size_t)a.Cin_pad * LDP + (size_t)a.Cout_pad * LDP + wimg);
+    const size_t red = (size_t)BWD_WAVES * a.Cin_pad * LDP;  // gx partial tiles (host the rows-DFT scratch afterwards)
+    const size_t lds = sizeof(float) * ((size_t)a.Cin_pad * LDP + (size_t)a.Cout_pad * LDP + red);
     constexpr int NW = BWD_WAVES;
     const dim3 grid(B * a.tiles_per_sample), block(NW * 64);
     int rc;

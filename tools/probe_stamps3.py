@@ -16,4 +16,8 @@ for (B,Cin,Ch,Cout,P) in [(4,10,256,32,4096),(4,32,256,1,4096)]:
             lib.dlwp_pwmlp_bwd_slab(x.data_ptr(),w1.data_ptr(),b1.data_ptr(),w2.data_ptr(),gy.data_ptr(),gx.data_ptr(),slab.data_ptr(),acc,B,Cin,Ch,Cout,P,None)
             torch.cuda.synchronize()
         buf=(C.c_ulonglong*32)(); lib.dlwp_debug_stamps_pwmlp(buf); t=list(buf)
-        print("bwd slab acc=%d"%acc,(B,Cin,Ch,Cout,P), [t[i+1]-t[i] for i in range(10,22)], "total", t[22]-t[10])
+        names = {9: "entry", 10: "tiles staged+barrier", 11: "init", 12: "hb_begin(0)", 18: "4 pixel blocks", 19: "flush", 20: "main loop end (wave 0)",
+                 21: "gx partials->LDS", 22: "barrier", 23: "gx reduce+store, db2, rows DFT"}
+        ks = [9, 10, 11, 12, 18, 19, 20, 21, 22, 23]
+        print("bwd slab acc=%d" % acc, (B, Cin, Ch, Cout, P), "cycles:", {names[k1]: t[k1] - t[k0] for k0, k1 in zip(ks, ks[1:])}, "total", t[23] - t[9],
+              "wave ends (from entry):", [t[24 + w] - t[9] for w in range(8)])
