@@ -1,6 +1,5 @@
-# Build libdlwpmi.so (HIP kernels + C ABI, gfx950 only) and the CPU oracle helpers.
+# Build libdlwpmi.so (HIP kernels + C ABI, gfx950 only).  The oracle (oracle/*.py) is numpy / torch-CPU code: nothing to compile.
 #   make            -> dlwp_benchmark_amd/libdlwpmi.so
-#   make oracle     -> oracle/_build/liboracle_fno.so   (plain C restatement, CPU)
 HIPCC      ?= /opt/rocm/bin/hipcc
 ARCH       ?= gfx950
 CSRC       := dlwp_benchmark_amd/csrc
@@ -27,10 +26,7 @@ build_stamps/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.cuh) $(wildcard $(CSRC)/*.h
 stamps: $(STAMP_OBJS)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(STAMP_OBJS) -ldl -o dlwp_benchmark_amd/libdlwpmi_stamps.so
 
-oracle:
-	$(MAKE) -C oracle
-
 clean:
 	rm -rf build build_stamps $(LIB) dlwp_benchmark_amd/libdlwpmi_stamps.so
 
-.PHONY: all oracle clean stamps
+.PHONY: all clean stamps

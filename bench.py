@@ -33,6 +33,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (reference: training.batch_size=4)")
     ap.add_argument("--hidden", type=int, default=None, help="hidden_channels of the fno workload (default 32 = the headline; "
                     "the published sweep runs 2 ... 217, src/nsbench/scripts/train_commands.txt:83-91)")
+    ap.add_argument("--T", type=int, default=None, help="frames per trajectory of the fno workload (default 20 = the headline; the "
+                    "reference's own protocol is sequence_length 50 -> --T 49: 40 net calls per sample, "
+                    "src/nsbench/configs/training/default.yaml:6, scripts/train_commands.txt:83)")
+    ap.add_argument("--no-secondary", action="store_true", help="fno workload at N=1: do not append the short SFNO (configs[2]) run "
+                    "as the line's \"secondary\" object")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -40,10 +45,11 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
                     "single-GPU functional test of the N>1 code path)")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (functional test only)")
-    ap.add_argument("--workload", default="fno", choices=["fno", "sfno", "pangu", "swin", "afno"],
+    ap.add_argument("--workload", default="fno", choices=["fno", "sfno", "pangu", "swin", "afno", "afno721"],
                     help="fno: BASELINE configs[1] (default, the headline line); sfno: configs[2], dlwpbench SFNO2DModule 32x64, "
                          "5 prognostic variables, sfno.yaml widths, sequence length 5 (4 lead times); pangu / swin: configs[3] "
-                         "(128x256, window 7); afno: configs[4] grid (FourCastNet 720x1440, patch 8, E=768, depth 12)")
+                         "(128x256, window 7); afno: configs[4] grid (FourCastNet 720x1440, patch 8, E=768, depth 12); afno721: the "
+                         "same network on the 721x1440 grid BASELINE names, patch (7, 8) -> 103 x 180 tokens")
     ap.add_argument("--storage", default=None, choices=["fp32", "bf16"],
                     help="sfno workload: storage of GEMM-to-GEMM activations and of the weight copy the GEMMs read (default: bf16 "
                          "with bf16 operands)")
@@ -262,6 +268,11 @@ DLWP_WORKLOADS = {
                             prognostic_channels=8, embed_dim=768, depth=12, mlp_ratio=4.0, num_blocks=16, context_size=1),
                  T=2, H=720, W=1440, Cg=8, batch=1, storage="bf16", gemm=(90 * 180, 3072, 768),
                  metric="train samples/sec (FourCastNet AFNO 720x1440 step: fwd + MSE + backward + Adam)"),
+    "afno721": dict(cls="AFNONet", name="dlwpbench AFNONet (FourCastNet) 721x1440 patch (7,8) E768 depth 12 (BASELINE configs[4])",
+                    model=dict(img_height=721, img_width=1440, patch_size=(7, 8), constant_channels=4, prescribed_channels=1,
+                               prognostic_channels=8, embed_dim=768, depth=12, mlp_ratio=4.0, num_blocks=16, context_size=1),
+                    T=2, H=721, W=1440, Cg=8, batch=1, storage="bf16", gemm=(103 * 180, 3072, 768),
+                    metric="train samples/sec (FourCastNet AFNO 721x1440 step: fwd + MSE + backward + Adam)"),
 }
 
 
@@ -293,9 +304,17 @@ def sfno_gemm_probe(device, B, precision, reps=100, storage="fp32", shape=(32 * 
     sec = e0.elapsed_time(e1) * 1e-3 / reps
     flops = 2.0 * M * N * K
     peak = PEAK_MFMA_TF[precision]
-    return {"bound": "mfma", "kernel": f"gemm_kernel (MLP fc1 {M}x{N}x{K}, bias+GELU epilogue, {precision} operands, {storage} storage of x / W / h / z)",
-            "achieved": round(flops / sec / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(flops / sec / 1e12 / peak, 4),
-            "flops_per_launch": flops, "us_per_launch": round(sec * 1e6, 3), "traffic": None}
+    # both roofs: a shallow product (SFNO: K = 256) moves more bytes than it has flops for -- algorithmic bytes = x and W read once,
+    # the activated output and the stored pre-activation written once
+    nbytes = float(x.element_size() * M * K + w.element_size() * N * K + (y.element_size() + z.element_size()) * M * N + 4 * N)
+    f_mfma, f_hbm = flops / sec / 1e12 / peak, nbytes / sec / 1e9 / PEAK_HBM_GBS
+    out = {"bound": "mfma" if f_mfma >= f_hbm else "hbm",
+           "kernel": f"gemm_kernel (MLP fc1 {M}x{N}x{K}, bias+GELU epilogue, {precision} operands, {storage} storage of x / W / h / z)",
+           "flops_per_launch": flops, "bytes_per_launch": nbytes, "us_per_launch": round(sec * 1e6, 3), "traffic": None,
+           "mfma": {"achieved": round(flops / sec / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(f_mfma, 4)},
+           "hbm": {"achieved": round(nbytes / sec / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(f_hbm, 4)}}
+    out.update(out[out["bound"]])          # the contract's achieved / peak / unit / frac = the roof that binds this shape
+    return out
 
 
 def sfno_cpu_baseline(B, budget_s):
@@ -333,9 +352,16 @@ def sfno_cpu_baseline(B, budget_s):
 
 
 def main_sfno(args):
+    line = run_dlwp(args, args.workload, args.steps, args.warmup, init_dist=True)
+    if line is not None:
+        print(json.dumps(line), flush=True)
+
+
+def run_dlwp(args, workload, steps, warmup, init_dist, roofline=True, cpu=True):
     """BASELINE configs[2] (sfno) and the supplementary configs[3] / [4] lines (pangu, swin, afno): one step = rollout + MSE +
     backward + all-reduce (N>1) + fused Adam through train_engine.GraphedTrainStep (captured in a hipGraph at N = 1 and for the
-    flat reducer; the 28-72 M parameter models use the bucketed reducer launched from backward hooks at N > 1: eager step)."""
+    flat reducer; the 28-72 M parameter models use the bucketed reducer launched from backward hooks at N > 1: eager step).
+    Returns the JSON line (rank 0) or None."""
     import torch
     import torch.distributed as dist
     from dlwp_benchmark_amd import ddp, dlwpbench, lib as L
@@ -348,9 +374,9 @@ def main_sfno(args):
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     device = torch.device("cuda", 0 if args.share_device else local_rank)
     torch.cuda.set_device(device)
-    if world > 1:
+    if world > 1 and init_dist:
         dist.init_process_group("nccl", device_id=device) if args.backend == "nccl" else dist.init_process_group(args.backend)
-    w = DLWP_WORKLOADS[args.workload]
+    w = DLWP_WORKLOADS[workload]
     precision = args.precision or "bf16"
     L.set_gemm_precision(precision)
     # bf16 arithmetic goes with bf16 storage of the GEMM-to-GEMM tensors and of the weight copy the GEMMs read (lib.set_storage)
@@ -358,7 +384,7 @@ def main_sfno(args):
     # residual stream stay fp32.  --storage overrides
     storage = args.storage or (w["storage"] if precision == "bf16" else "fp32")
     L.set_storage(storage)
-    B = args.batch if args.batch_given else w["batch"]
+    B = args.batch if (args.batch_given and workload == args.workload) else w["batch"]
     H, W_, Cg, T = w["H"], w["W"], w["Cg"], w["T"]
     torch.manual_seed(1234)
     model = getattr(dlwpbench, w["cls"])(**w["model"]).to(device).train()
@@ -367,20 +393,22 @@ def main_sfno(args):
               prescribed=torch.randn(B, T, 1, H, W_, generator=g).to(device),
               prognostic=torch.randn(B, T, Cg, H, W_, generator=g).to(device))
     target = torch.randn(B, T - 1, Cg, H, W_, generator=g).to(device)
-    bucketed = world > 1 and args.workload != "sfno"          # 114-288 MB of gradients: overlap the reduction with backward
+    # 114-288 MB of gradients: overlap the reduction with backward (the reducer itself holds every bucket back for models whose
+    # gradient writes are deferred to the end of backward, e.g. SFNO's spectral weights: ddp.BucketedGradAllReduce.deferred)
+    bucketed = world > 1 and workload != "sfno"
     step = GraphedTrainStep(model, kw, target, lr=w.get("lr", 1e-3), use_graph=not args.no_graph and not bucketed,
                             allreduce=ddp.FlatGradAllReduce() if (world > 1 and not bucketed) else None, grad_scale=1.0 / world)
     if bucketed:
         step.allreduce = ddp.BucketedGradAllReduce(model, step.grad)
     ddp.broadcast_parameters(step.flat, src=0)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = step()
     torch.cuda.synchronize()
     if world > 1:
@@ -391,10 +419,11 @@ def main_sfno(args):
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+    line = None
     if rank == 0:
         line = {"metric": w["metric"],
-                "value": round(world * B * args.steps / dt, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-                "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+                "value": round(world * B * steps / dt, 3), "unit": "samples/s", "n_gpus": world, "steps": steps,
+                "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if precision == "bf16" else "f32",
                 "data": "synthetic N(0,1) fields (z-scored WeatherBench shapes), random-init weights (no dataset/checkpoint access)",
                 "config": {"workload": w["name"], "per_gpu_batch": B, "global_batch": B * world, "sequence_length": T,
@@ -403,16 +432,16 @@ def main_sfno(args):
                            "gemm_operands": precision, "storage": storage, "accumulate": "fp32", "parallelism": f"dp{world}",
                            "hip_graph": not args.no_graph and not bucketed,
                            "grad_reduce": "bucketed, from backward hooks" if bucketed else ("flat" if world > 1 else "none")},
-                "backbone_calls_per_s": round(world * B * args.steps * (T - 1) / dt, 1), "final_loss": loss.item()}
-        if world == 1 and not args.no_roofline:
+                "backbone_calls_per_s": round(world * B * steps * (T - 1) / dt, 1), "final_loss": loss.item()}
+        if world == 1 and not args.no_roofline and roofline:
             line["roofline"] = sfno_gemm_probe(device, B, precision, storage=storage, shape=w["gemm"])
-        if world == 1 and not args.no_cpu_baseline and args.workload == "sfno":
+        if world == 1 and not args.no_cpu_baseline and cpu and workload == "sfno":
             line["cpu_baseline"] = sfno_cpu_baseline(B, args.cpu_seconds)
-        elif world == 1:
+        elif world == 1 and cpu:
             line["cpu_baseline"] = None       # a CPU step of the 28-72 M parameter models at these grids takes minutes: not sampled
-        print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 and init_dist:
         dist.destroy_process_group()
+    return line
 
 
 def main():
@@ -442,6 +471,9 @@ def main():
     if args.hidden is not None:
         w["hidden_channels"] = args.hidden
         w["name"] = w["name"].replace("(BASELINE configs[1])", f"(BASELINE configs[1] at hidden_channels {args.hidden})")
+    if args.T is not None:
+        w["T"] = args.T
+        w["name"] = w["name"].replace("(BASELINE configs[1]", f"(T={args.T}: {args.T - w['context_size'] + 1} net calls per sample; BASELINE configs[1]")
     B = args.batch
     torch.manual_seed(1234)
     model = nsbench.TFNO2DModule(n_modes=w["n_modes"], in_channels=w["in_channels"],
@@ -509,6 +541,14 @@ def main():
             line["roofline_mix"] = mix_probe(device, B)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(B, args.cpu_seconds)
+        if world == 1 and not args.no_secondary and args.hidden is None and args.T is None:
+            # the other half of BASELINE's metric ("FNO 64^2, SFNO 32x64") in the same driver-timed record: a short run of
+            # configs[2] with its own roofline object (python bench.py --workload sfno prints the full line)
+            del model, opt
+            torch.cuda.empty_cache()
+            sec = run_dlwp(args, "sfno", steps=40, warmup=5, init_dist=False, cpu=False)
+            line["secondary"] = {k: sec[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config",
+                                                     "roofline") if k in sec}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

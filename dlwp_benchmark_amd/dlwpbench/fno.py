@@ -80,7 +80,17 @@ class _CompositeAdam:
         self.main, self.extra = main, extra
 
     def clip_grad_norm_(self, max_norm, grad_scale=1.0):
-        raise NotImplementedError("gradient clipping over Tucker factors is not built yet")
+        """torch.nn.utils.clip_grad_norm_ over the module's parameters = the flat buffer (whose derived dense spectral slices
+        carry a zeroed gradient by now, TFNO2DModule.train_step) + every Tucker core / factor: ONE global norm
+        (dlwpbench/scripts/train.py:230-232, `clip_gradients: True` in configs/training/default.yaml:3), one scale for all."""
+        from .. import lib as L
+        lib, ss = self.main.lib, self.main.sumsq
+        ss.zero_()
+        opts = [self.main] + list(self.extra)
+        for o in opts:                               # dlwp_sumsq accumulates into the one-float buffer
+            L.check(lib.dlwp_sumsq(L.ptr(o.grads), o.grads.numel(), L.ptr(ss), L.stream()))
+        for o in opts:
+            L.check(lib.dlwp_clip_scale(L.ptr(o.grads), o.grads.numel(), L.ptr(ss), grad_scale, max_norm, L.stream()))
 
     def step(self, grad_scale=1.0, zero_grad=True):
         self.main.step(grad_scale=grad_scale, zero_grad=zero_grad)
@@ -144,11 +154,17 @@ class TFNO2DModule(FNO2DModule):
         loss = super().train_step(constants, prescribed, prognostic, target, optimizer=None, use_graph=use_graph)
         grads = [self.layout.view(self.flat_grad, name).clone() for name in self._spec_names()]
         torch.autograd.backward(dense, grads)
+        # the dense spectral weights are derived tensors, not parameters: their gradient has been handed to the factors and
+        # must neither count in the clipping norm nor move the (re-derived every step) dense copy
+        for name in self._spec_names():
+            self.layout.view(self.flat_grad, name).zero_()
         if allreduce is not None:
             allreduce(self.flat_grad)
             for p in self.tucker.parameters():
                 allreduce(p.grad)
         if optimizer is not None:
+            if clip_max_norm is not None:
+                optimizer.clip_grad_norm_(clip_max_norm, grad_scale=grad_scale)
             optimizer.step(grad_scale=grad_scale)
         return loss
 

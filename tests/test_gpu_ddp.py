@@ -104,3 +104,23 @@ def test_bucketed_reducer_hooks_release_buckets_during_backward(cuda):
     assert len(red.buckets) >= 4 and red.overlapped >= len(red.buckets) - 1
     with pytest.raises(Exception):
         GraphedTrainStep(model, {"x": x}, y, lr=1e-3, use_graph=True, allreduce=red, call=lambda m, kw: m(kw["x"], 2))
+
+
+def test_bench_n_greater_than_one_branch_runs_as_two_ranks(cuda):
+    """bench.py's own N > 1 code path (rendezvous, per-rank shards, barrier-bracketed timing, MAX over ranks, rank-0 line) as
+    two fresh processes that share cuda:0 over gloo -- the driver launches the same file one rank per GPU over RCCL."""
+    import json
+    outs = _run_ranks([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "3",
+                       "--warmup", "1", "--no-cpu-baseline", "--no-roofline"], 29583)
+    lines = [l for l in outs[0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not any(l.startswith("{") for l in outs[1].splitlines())      # ONE line, from rank 0
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["global_batch"] == 2 * line["config"]["per_gpu_batch"] and line["config"]["parallelism"] == "dp2"
+    assert abs(line["value"] - 2 * line["config"]["per_gpu_batch"] * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-2 * line["value"]
+    assert "secondary" not in line and "roofline" not in line
+    # the autograd-driven models' branch (bucketed reducer from backward hooks; SFNO: held buckets)
+    outs = _run_ranks([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "2",
+                       "--warmup", "1", "--workload", "sfno", "--no-cpu-baseline", "--no-roofline"], 29585)
+    line = json.loads([l for l in outs[0].splitlines() if l.startswith("{")][0])
+    assert line["n_gpus"] == 2 and line["config"]["grad_reduce"] == "flat" and line["value"] > 0

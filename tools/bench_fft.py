@@ -1,13 +1,15 @@
 """rFFT2 / irFFT2 kernel rates and the AFNO2D path crossover (dense DFT GEMMs vs FFT).  HIP-event timing on the launch
-stream.  Algorithmic HBM bytes of one 2-D transform = two passes: W axis (read the real field, write the half spectrum) +
-H axis (read and write the half spectrum).
-    python tools/bench_fft.py > gpurun_out/r02_fft_bench.txt"""
+stream.  TWO byte conventions per transform: "in+out" = the minimum any implementation moves (read the real field once, write
+the half spectrum once) and "two-pass" = what this implementation's two launches move (W axis: real field in, half spectrum
+out; H axis: half spectrum in and out).  Fractions are of the 8 TB/s HBM roof.
+    python tools/bench_fft.py > gpurun_out/r03_fft_bench.txt      (from any directory)"""
+import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from dlwp_benchmark_amd import fft  # noqa: E402
 from dlwp_benchmark_amd.nsbench.fourcastnet import AFNO2D  # noqa: E402
 
@@ -36,9 +38,11 @@ for (B, H, W, C) in [(4, 64, 64, 64), (4, 32, 64, 64), (4, 128, 256, 64), (2, 12
     tf = timeit(lambda: fft.rfft2(x))
     ti = timeit(lambda: fft.irfft2(X, W))
     real_b, spec_b = 4.0 * B * H * W * C, 8.0 * B * H * Wc * C
-    bytes_f = real_b + 3 * spec_b
-    print(f"rfft2  {B}x{H}x{W}x{C}: {tf * 1e6:9.1f} us  {bytes_f / tf / 1e9:8.1f} GB/s algorithmic   "
-          f"irfft2: {ti * 1e6:9.1f} us  {bytes_f / ti / 1e9:8.1f} GB/s", flush=True)
+    bytes_min, bytes_2p = real_b + spec_b, real_b + 3 * spec_b
+    print(f"rfft2  {B}x{H}x{W}x{C}: {tf * 1e6:9.1f} us  in+out {bytes_min / tf / 1e9:7.1f} GB/s ({bytes_min / tf / 8e12:.3f} of HBM)  "
+          f"two-pass {bytes_2p / tf / 1e9:7.1f} GB/s ({bytes_2p / tf / 8e12:.3f})   "
+          f"irfft2: {ti * 1e6:9.1f} us  in+out {bytes_min / ti / 1e9:7.1f} GB/s ({bytes_min / ti / 8e12:.3f})  "
+          f"two-pass {bytes_2p / ti / 1e9:7.1f} GB/s ({bytes_2p / ti / 8e12:.3f})", flush=True)
     # torch.fft (rocFFT) as a comparator, same layout
     tt = timeit(lambda: torch.fft.rfft2(x, dim=(1, 2), norm="ortho"))
     print(f"       torch.fft.rfft2 (rocFFT) comparator: {tt * 1e6:9.1f} us", flush=True)
