@@ -148,7 +148,7 @@ int dlwp_cfmlp_bwd(const float* x, long long x_bs, const float* w1, const float*
 bool dlwp_winattn_small_applies(int N, int d, long long pairs);
 int dlwp_winattn_small_fwd(const float* qkv, const float* table, const float* packed, const int* ia, const int* ib,
                            const int* labels, float* out, float* lse, int B_, int nW, int N, int TB, int ntypes, int heads, int d,
-                           float scale, void* stream);
+                           float scale, int q_lo, int q_hi, void* stream);
 int dlwp_winattn_small_bwd(const float* qkv, const float* table, const float* packed, const int* ia, const int* ib,
                            const int* labels, const float* out, const float* lse, const float* gout, float* gqkv, float* gtable,
-                           int B_, int nW, int N, int TB, int ntypes, int heads, int d, float scale, void* stream);
+                           int B_, int nW, int N, int TB, int ntypes, int heads, int d, float scale, int q_lo, int q_hi, void* stream);

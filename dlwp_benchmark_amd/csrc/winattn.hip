@@ -605,14 +605,26 @@ extern "C" int dlwp_window_attn_pack_table(const float* bias_table, float* packe
 extern "C" int dlwp_window_attn_fwd_packed(const float* qkv, const float* bias_table, const float* packed_table, const int* ia,
                                            const int* ib, const int* labels, float* out, float* lse, int B_, int nW, int N,
                                            int TB, int ntypes, int heads, int d, float scale, void* stream) {
+    return dlwp_window_attn_fwd_qrange(qkv, bias_table, packed_table, ia, ib, labels, out, lse, B_, nW, N, TB, ntypes, heads, d, scale,
+                                       0, N, stream);
+}
+
+// As dlwp_window_attn_fwd_packed, for windows whose tokens outside [q_lo, q_hi) are PADDING that the caller crops afterwards
+// (Pangu's pressure-level pad: one of the two planes of every (2,7,7) window): those tokens still act as keys / values, but
+// their own attention rows are neither needed (forward) nor do they receive a gradient (backward), so the kernels that can
+// skip them do; rows of `out` / `lse` outside the range are then left unwritten.  The tiled kernels compute everything.
+extern "C" int dlwp_window_attn_fwd_qrange(const float* qkv, const float* bias_table, const float* packed_table, const int* ia,
+                                           const int* ib, const int* labels, float* out, float* lse, int B_, int nW, int N,
+                                           int TB, int ntypes, int heads, int d, float scale, int q_lo, int q_hi, void* stream) {
     DLWP_REQUIRE(qkv && bias_table && ia && ib && out && lse, DLWP_E_INVALID, "window_attn_fwd: NULL argument");
+    DLWP_REQUIRE(q_lo >= 0 && q_hi <= N && q_lo < q_hi, DLWP_E_INVALID, "window_attn_fwd: query range [%d, %d) outside [0, %d)", q_lo, q_hi, N);
     WaDev a{};
     a.table_t = packed_table;
     int rc = wa_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, "window_attn_fwd");
     if (rc) return rc;
     if (dlwp_winattn_small_applies(N, d, (long long)B_ * heads) && !getenv("DLWP_WINATTN_TILED"))
         return dlwp_winattn_small_fwd(qkv, bias_table, packed_table, ia, ib, labels, out, lse, B_, nW, N, TB, ntypes, heads, d,
-                                      scale, stream);
+                                      scale, q_lo, q_hi, stream);
     a.qkv = qkv; a.table = bias_table; a.ia = ia; a.ib = ib; a.labels = labels; a.out = out; a.lse = lse;
     const int nbuf = N <= 128 ? 1 : 2;         // short windows: single-buffered tiles, more workgroups per CU
     const size_t lds = sizeof(float) * ((size_t)(1 + nbuf) * 64 * (a.dp16 + 4) + (size_t)nbuf * a.dp16 * LDV + 256 + a.TB);
@@ -651,15 +663,28 @@ extern "C" int dlwp_window_attn_bwd_packed(const float* qkv, const float* bias_t
                                            const int* ib, const int* labels, const float* out, const float* lse,
                                            const float* gout, float* gqkv, float* gbias_table, float* dsum, float* slab, int B_,
                                            int nW, int N, int TB, int ntypes, int heads, int d, float scale, void* stream) {
+    return dlwp_window_attn_bwd_qrange(qkv, bias_table, packed_table, ia, ib, labels, out, lse, gout, gqkv, gbias_table, dsum, slab,
+                                       B_, nW, N, TB, ntypes, heads, d, scale, 0, N, stream);
+}
+
+// backward of dlwp_window_attn_fwd_qrange: `gout` rows outside [q_lo, q_hi) are taken as zero (they are: the caller crops those
+// tokens); the query gradient of those rows is written as zero, their key / value gradients are complete.  The tiled kernels
+// read every row of `out` / `lse` / `gout`: with them the forward must have been the tiled one too (same dispatch rule).
+extern "C" int dlwp_window_attn_bwd_qrange(const float* qkv, const float* bias_table, const float* packed_table, const int* ia,
+                                           const int* ib, const int* labels, const float* out, const float* lse,
+                                           const float* gout, float* gqkv, float* gbias_table, float* dsum, float* slab, int B_,
+                                           int nW, int N, int TB, int ntypes, int heads, int d, float scale, int q_lo, int q_hi,
+                                           void* stream) {
     DLWP_REQUIRE(qkv && bias_table && ia && ib && out && lse && gout && gqkv && gbias_table && dsum, DLWP_E_INVALID,
                  "window_attn_bwd: NULL argument");
+    DLWP_REQUIRE(q_lo >= 0 && q_hi <= N && q_lo < q_hi, DLWP_E_INVALID, "window_attn_bwd: query range [%d, %d) outside [0, %d)", q_lo, q_hi, N);
     WaDev a{};
     a.table_t = packed_table;
     int rc = wa_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, "window_attn_bwd");
     if (rc) return rc;
     if (dlwp_winattn_small_applies(N, d, (long long)B_ * heads) && !getenv("DLWP_WINATTN_TILED"))
         return dlwp_winattn_small_bwd(qkv, bias_table, packed_table, ia, ib, labels, out, lse, gout, gqkv, gbias_table, B_, nW, N,
-                                      TB, ntypes, heads, d, scale, stream);
+                                      TB, ntypes, heads, d, scale, q_lo, q_hi, stream);
     a.qkv = qkv; a.table = bias_table; a.ia = ia; a.ib = ib; a.labels = labels; a.o = out; a.lse_in = lse; a.gout = gout; a.gqkv = gqkv;
     a.gtable = gbias_table; a.dsum = dsum; a.slab = slab;
     const int LDT = a.dp16 + 4;

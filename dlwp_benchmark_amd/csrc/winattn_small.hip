@@ -36,6 +36,8 @@ struct WsDev {
     const float *lse_in, *gout, *o;
     float *gqkv, *gtable;
     int B_, nW, N, heads, d, TB, ntypes, M, groups;
+    int qc_lo, qc_hi;          // query chunks (of 16 tokens) to compute; the rest are padded positions whose outputs nobody reads
+                               // and whose upstream gradient is zero (Pangu: half of every window, dlwp_window_attn_fwd_qrange)
     float scale;
 };
 
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
         }
     }
 #pragma unroll 1
-    for (int qc = 0; qc < NC; ++qc) {
+    for (int qc = a.qc_lo; qc < a.qc_hi; ++qc) {
         if (16 * qc >= N) break;
         const int q = 16 * qc + r, qcl = min(q, N - 1);
         const int qa = a.ia[qcl], qlab = labw ? labw[qcl] : 0;
@@ -264,9 +266,24 @@ __global__ __launch_bounds__(256) void winattn_small_bwd_kernel(WsDev a) {
             }
         };
 
-        // ---- pass Q
-#pragma unroll 1
+        // ---- pass Q  (query chunks outside [qc_lo, qc_hi) carry no upstream gradient: their dQ rows are zero)
+        const int qlo = a.qc_lo, qhi = min(a.qc_hi, NCr);
         for (int qc = 0; qc < NCr; ++qc) {
+            if (qc >= qlo && qc < qhi) continue;
+            const int q = 16 * qc + r;
+            if (q < N) {
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) {
+                    const int dd = 16 * db + 4 * g;
+                    float* dst = gq + (long long)q * rs + dd;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (dd + j < d) dst[j] = 0.f;
+                }
+            }
+        }
+#pragma unroll 1
+        for (int qc = qlo; qc < qhi; ++qc) {
             const int q = 16 * qc + r, qcl = min(q, N - 1);
             const int qa = a.ia[qcl], ql = labw ? labw[qcl] : 0;
             const float lse = a.lse_in[stat + qcl];
@@ -334,7 +351,7 @@ __global__ __launch_bounds__(256) void winattn_small_bwd_kernel(WsDev a) {
             const int key = 16 * kc + r, keyc = min(key, N - 1);
             const int kbi = a.ib[keyc], kl = labw ? labw[keyc] : 0;
             QuerySide cur, nxt;
-            load_queries(0, cur);
+            load_queries(qlo, cur);
             f32x4 kf[NDB], vf[NDB], dk[NDB], dv[NDB];
 #pragma unroll
             for (int cc = 0; cc < NDB; ++cc) {
@@ -343,8 +360,8 @@ __global__ __launch_bounds__(256) void winattn_small_bwd_kernel(WsDev a) {
                 dk[cc] = dv[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll 1
-            for (int qc = 0; qc < NCr; ++qc) {
-                if (qc + 1 < NCr) load_queries(qc + 1, nxt);
+            for (int qc = qlo; qc < qhi; ++qc) {
+                if (qc + 1 < qhi) load_queries(qc + 1, nxt);
                 f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
 #pragma unroll
                 for (int cc = 0; cc < NDB; ++cc) {
@@ -394,8 +411,12 @@ __global__ __launch_bounds__(256) void winattn_small_bwd_kernel(WsDev a) {
         if (gtb[i] != 0ull) atomic_add_f32(&a.gtable[(long long)i * w.tstr + w.tofs], (float)(long long)gtb[i] * (1.f / FXS));
 }
 
-int ws_setup(WsDev& a, int B_, int nW, int N, int TB, int ntypes, int heads, int d, float scale) {
+int ws_setup(WsDev& a, int B_, int nW, int N, int TB, int ntypes, int heads, int d, float scale, int q_lo, int q_hi) {
     a.B_ = B_; a.nW = nW; a.N = N; a.TB = TB; a.ntypes = ntypes; a.heads = heads; a.d = d; a.scale = scale;
+    const int nc = (N + 15) / 16;
+    a.qc_lo = q_lo < 0 ? 0 : q_lo / 16;
+    a.qc_hi = (q_hi < 0 || q_hi > N) ? nc : (q_hi + 15) / 16;
+    if (a.qc_lo >= a.qc_hi) { a.qc_lo = 0; a.qc_hi = nc; }
     a.M = B_ / ntypes;
     a.groups = (a.M + 3) / 4;
     return DLWP_OK;
@@ -443,9 +464,9 @@ bool dlwp_winattn_small_applies(int N, int d, long long pairs) { return N <= 128
 
 int dlwp_winattn_small_fwd(const float* qkv, const float* table, const float* packed, const int* ia, const int* ib,
                            const int* labels, float* out, float* lse, int B_, int nW, int N, int TB, int ntypes, int heads, int d,
-                           float scale, void* stream) {
+                           float scale, int q_lo, int q_hi, void* stream) {
     WsDev a{};
-    ws_setup(a, B_, nW, N, TB, ntypes, heads, d, scale);
+    ws_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, q_lo, q_hi);
     a.qkv = qkv; a.table = table; a.table_t = packed; a.ia = ia; a.ib = ib; a.labels = labels; a.out = out; a.lse = lse;
     const size_t lds = sizeof(float) * (size_t)TB;
     WS_DISPATCH(winattn_small_fwd_kernel, lds);
@@ -455,9 +476,9 @@ int dlwp_winattn_small_fwd(const float* qkv, const float* table, const float* pa
 
 int dlwp_winattn_small_bwd(const float* qkv, const float* table, const float* packed, const int* ia, const int* ib,
                            const int* labels, const float* out, const float* lse, const float* gout, float* gqkv, float* gtable,
-                           int B_, int nW, int N, int TB, int ntypes, int heads, int d, float scale, void* stream) {
+                           int B_, int nW, int N, int TB, int ntypes, int heads, int d, float scale, int q_lo, int q_hi, void* stream) {
     WsDev a{};
-    ws_setup(a, B_, nW, N, TB, ntypes, heads, d, scale);
+    ws_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, q_lo, q_hi);
     a.qkv = qkv; a.table = table; a.table_t = packed; a.ia = ia; a.ib = ib; a.labels = labels; a.o = out; a.lse_in = lse;
     a.gout = gout; a.gqkv = gqkv; a.gtable = gtable;
     const size_t lds = sizeof(float) * (3 * (size_t)((TB + 1) & ~1) + 4 * 128);

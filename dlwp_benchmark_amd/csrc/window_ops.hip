@@ -19,6 +19,8 @@ namespace {
 struct WinDev {
     const float* src;
     const float* res;      // scatter only, optional: a residual in token layout added to the result (the block's skip connection)
+    const float* fill;     // gather only, optional [C]: value of the padded positions instead of zero (a Linear layer applied
+                           // BEFORE the padding puts its bias there: Linear(0) = bias, see dlwp_window_gather_fill)
     float* dst;
     int B, C, D[3], P[3], f[3], s[3], w[3], nw[3], circ[3];
     long long sw[3];
@@ -53,9 +55,51 @@ __global__ __launch_bounds__(256) void win_gather_kernel(WinDev a) {
         }
         f32x4 val = f32x4{0.f, 0.f, 0.f, 0.f};
         if (ok) val = *reinterpret_cast<const f32x4*>(a.src + ((((long long)b * a.D[0] + q[0]) * a.D[1] + q[1]) * a.D[2] + q[2]) * a.C + 4 * c4);
+        else if (a.fill) val = *reinterpret_cast<const f32x4*>(a.fill + 4 * c4);
         const long long wout = (long long)b * a.nW + i0 * a.sw[0] + i1 * a.sw[1] + i2 * a.sw[2];
         *reinterpret_cast<f32x4*>(a.dst + (wout * a.N + n) * a.C + 4 * c4) = val;
         (void)tok;
+    }
+}
+
+// out[c] += sum over the PADDED positions of windows[.][.][c]: the adjoint of the `fill` of win_gather_kernel (gradient of the
+// bias that stands at the padded positions).  A workgroup walks a slice of the window tokens; thread = (token lane, channel quad).
+__global__ __launch_bounds__(256) void win_pad_colsum_kernel(WinDev a, float* out) {
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [lanes][C]
+    const int C4 = a.C >> 2;
+    const int lanes = 256 / C4 > 0 ? 256 / C4 : 1;                   // token lanes per workgroup (C4 <= 256)
+    const int c4 = threadIdx.x % C4, tl = threadIdx.x / C4;
+    const long long ntok = (long long)a.B * a.nW * a.N;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tl < lanes) {
+        for (long long tok = (long long)blockIdx.x * lanes + tl; tok < ntok; tok += (long long)gridDim.x * lanes) {
+            // the same walk as win_gather_kernel: canonical (sample, window (i0,i1,i2) row-major, token) -> padded position
+            const int bw = fastdiv((int)tok, a.dN), n = (int)tok - bw * a.N;
+            const int b = fastdiv(bw, a.dnW), wlin = bw - b * a.nW;
+            const int i0 = fastdiv(wlin, a.dnw12), r1 = wlin - i0 * a.nw[1] * a.nw[2], i1 = fastdiv(r1, a.dnw2), i2 = r1 - i1 * a.nw[2];
+            const int j0 = fastdiv(n, a.dw12), r2 = n - j0 * a.w[1] * a.w[2], j1 = fastdiv(r2, a.dw2), j2 = r2 - j1 * a.w[2];
+            const int ii[3] = {i0, i1, i2}, jj[3] = {j0, j1, j2};
+            bool ok = true;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int v = pmod(ii[d] * a.w[d] + jj[d] + a.s[d], a.P[d]) - a.f[d];
+                if (!a.circ[d]) ok = ok && v >= 0 && v < a.D[d];
+            }
+            if (!ok) {
+                const long long wout = (long long)b * a.nW + i0 * a.sw[0] + i1 * a.sw[1] + i2 * a.sw[2];
+                const f32x4 v = *reinterpret_cast<const f32x4*>(a.src + (wout * a.N + n) * a.C + 4 * c4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] += v[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[tl * a.C + 4 * c4 + k] = acc[k];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.C; c += 256) {
+        float t = 0.f;
+        for (int l = 0; l < lanes; ++l) t += red[l * a.C + c];
+        if (t != 0.f) atomic_add_f32(&out[c], t);
     }
 }
 
@@ -243,6 +287,39 @@ extern "C" int dlwp_window_gather(const float* x, float* windows, int B, int C, 
     int rc = win_setup(a, x, windows, B, C, dims, padded, front, shift, window, wstride, circular, "window_gather");
     if (rc) return rc;
     hipLaunchKernelGGL(win_gather_kernel, dim3(grid_for((long long)B * a.nW * a.N * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+// partition of a tensor that a token-wise Linear layer has ALREADY been applied to: the padded positions hold `fill` (= that
+// layer's bias) instead of zero.  Linear commutes with the gather, so "pad, then Linear over every window token" (reference:
+// panguweather.py:283-292, EarthAttention3D.qkv on the padded windows) equals "Linear over the real tokens, then pad with the
+// bias" -- and the GEMM runs on the real tokens only (Pangu 128 x 256, window (2,7,7): 32,768 instead of 68,894 rows).
+extern "C" int dlwp_window_gather_fill(const float* x, const float* fill, float* windows, int B, int C, const int* dims,
+                                       const int* padded, const int* front, const int* shift, const int* window,
+                                       const long long* wstride, const int* circular, void* stream) {
+    WinDev a{};
+    int rc = win_setup(a, x, windows, B, C, dims, padded, front, shift, window, wstride, circular, "window_gather_fill");
+    if (rc) return rc;
+    DLWP_REQUIRE(!fill || (reinterpret_cast<uintptr_t>(fill) & 15) == 0, DLWP_E_INVALID, "window_gather_fill: fill must be 16-byte aligned");
+    a.fill = fill;
+    hipLaunchKernelGGL(win_gather_kernel, dim3(grid_for((long long)B * a.nW * a.N * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+// gfill[c] += sum of g_windows[.][.][c] over the padded (non-circular) positions: gradient of dlwp_window_gather_fill's fill
+extern "C" int dlwp_window_pad_colsum(const float* g_windows, float* gfill, int B, int C, const int* dims, const int* padded,
+                                      const int* front, const int* shift, const int* window, const long long* wstride,
+                                      const int* circular, void* stream) {
+    WinDev a{};
+    int rc = win_setup(a, g_windows, gfill, B, C, dims, padded, front, shift, window, wstride, circular, "window_pad_colsum");
+    if (rc) return rc;
+    DLWP_REQUIRE(C / 4 <= 256, DLWP_E_UNSUPPORTED, "window_pad_colsum: at most 1024 channels");
+    const int lanes = 256 / (C / 4);
+    const long long ntok = (long long)B * a.nW * a.N;
+    const int grid = (int)std::min<long long>((ntok + lanes * 8 - 1) / (lanes * 8), 2048);
+    hipLaunchKernelGGL(win_pad_colsum_kernel, dim3(grid), dim3(256), sizeof(float) * (size_t)lanes * C, (hipStream_t)stream, a, gfill);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }

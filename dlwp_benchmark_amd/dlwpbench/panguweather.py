@@ -75,6 +75,11 @@ class EarthAttention3D(nn.Module):
                                   self.num_heads, float(self.scale))
         return self.proj(y)
 
+    def core(self, qkv_windows, labels, n_windows, qrange):
+        """attention on windows of an already projected qkv tensor [B*nW, N, 3C] (EarthSpecificBlock's real-token flow)"""
+        return window_attention_core(qkv_windows, self.earth_position_bias_table, self._ia, self._ib, labels, n_windows,
+                                     self.num_heads, float(self.scale), qrange)
+
 
 class EarthSpecificBlock(nn.Module):
     def __init__(self, dim, input_resolution, num_heads, window_size=None, shift_size=None, mlp_ratio=4., qkv_bias=True,
@@ -111,6 +116,22 @@ class EarthSpecificBlock(nn.Module):
                    + axis(Lon, win[2], sh[2], extra=sh[2])[None, None, :])
             labels = _partition(img[None, ..., None].float(), win).reshape(-1, win[0] * win[1] * win[2]).to(torch.int32)
         self.register_buffer("_labels", labels, persistent=False)
+        # Padded tokens: the reference zero-pads AFTER norm1 and runs qkv / attention / proj on every window token, then crops
+        # (:283-317).  With one pressure level padded to a window of two, half of every window is padding (C4: 68,894 window
+        # tokens for 32,768 real ones).  Exactly equivalent and cheaper: qkv on the real tokens, pad the qkv tensor with the qkv
+        # BIAS (Linear(0) = bias), attend with the padded tokens as keys / values only (their own rows are cropped: no output
+        # needed, zero gradient), crop, then proj on the real tokens.  _qrange = hull of the window positions that hold a real
+        # token in ANY window (the query rows worth computing).
+        Pl, Lat, Lon = self.input_resolution
+        real = F.pad(torch.ones(1, 1, Pl, Lat, Lon), p).permute(0, 2, 3, 4, 1)
+        if self.roll:
+            sh = self.shift_size
+            real = torch.roll(real, shifts=(-sh[0], -sh[1], -sh[1]), dims=(1, 2, 3))      # the forward roll (:291)
+        anyreal = _partition(real, self.window_size).reshape(-1, self.window_size[0] * self.window_size[1] * self.window_size[2]).amax(0)
+        idx = torch.nonzero(anyreal > 0).reshape(-1)
+        self._qrange = (int(idx.min()), int(idx.max()) + 1)
+        n_pad = self.pad_resolution[0] * self.pad_resolution[1] * self.pad_resolution[2]
+        self.real_token_flow = n_pad >= 1.25 * Pl * Lat * Lon
 
     def forward(self, x):
         Pl, Lat, Lon = self.input_resolution
@@ -124,6 +145,16 @@ class EarthSpecificBlock(nn.Module):
             fwd_shift = (sh[0], sh[1], sh[1]) if self.roll else (0, 0, 0)
             rev_shift = sh if self.roll else (0, 0, 0)
             # skip connections leave the LayerNorm nodes (norm_fork): their gradients join the LayerNorm backward kernels
+            if self.real_token_flow:
+                skip, t = norm_fork(self.norm1, x, gemm_input=True)
+                qkv = partition(self.attn.qkv(t), spec, fwd_shift, fill=self.attn.qkv.bias)
+                t = self.attn.core(qkv, self._labels if self.roll else None, spec.nW, self._qrange)
+                if self.drop_path.active:
+                    t = self.attn.proj(reverse(t, spec, B, rev_shift))
+                    skip, t = norm_fork(self.norm2, self.drop_path(t, residual=skip), gemm_input=True)
+                    return self.drop_path(self.mlp(t), residual=skip)
+                skip, t = norm_fork(self.norm2, self.attn.proj(reverse(t, spec, B, rev_shift), residual=skip), gemm_input=True)
+                return self.mlp(t, residual=skip)
             skip, t = norm_fork(self.norm1, x)
             t = self.attn(partition(t, spec, fwd_shift), self._labels if self.roll else None, spec.nW)
             if self.drop_path.active:            # stochastic depth: per-sample scale fused with the residual adds

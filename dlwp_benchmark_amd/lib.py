@@ -67,6 +67,8 @@ SIGNATURES = {
     "dlwp_set_gemm_precision": (_I, [_I]),
     "dlwp_get_gemm_precision": (_I, []),
     "dlwp_window_gather": (_I, [_V, _V, _I, _I] + [_V] * 7 + [_V]),
+    "dlwp_window_gather_fill": (_I, [_V, _V, _V, _I, _I] + [_V] * 7 + [_V]),
+    "dlwp_window_pad_colsum": (_I, [_V, _V, _I, _I] + [_V] * 7 + [_V]),
     "dlwp_window_scatter": (_I, [_V, _V, _I, _I] + [_V] * 7 + [_I, _V]),
     "dlwp_window_scatter_add": (_I, [_V, _V, _V, _I, _I] + [_V] * 7 + [_I, _V]),
     "dlwp_patch_merge": (_I, [_V, _V, _I, _I, _I, _I, _I, _V]),
@@ -102,6 +104,8 @@ SIGNATURES = {
     "dlwp_window_attn_pack_table": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_window_attn_fwd_packed": (_I, [_V] * 8 + [_I] * 7 + [_F, _V]),
     "dlwp_window_attn_bwd_packed": (_I, [_V] * 13 + [_I] * 7 + [_F, _V]),
+    "dlwp_window_attn_fwd_qrange": (_I, [_V] * 8 + [_I] * 7 + [_F, _I, _I, _V]),
+    "dlwp_window_attn_bwd_qrange": (_I, [_V] * 13 + [_I] * 7 + [_F, _I, _I, _V]),
     "dlwp_window_attn_bwd_slab_floats": (_L, [_I] * 4),
     "dlwp_window_softmax_fwd": (_I, [_V] * 5 + [_I] * 5 + [_F, _V]),
     "dlwp_window_softmax_bwd": (_I, [_V] * 5 + [_I] * 5 + [_F, _V]),

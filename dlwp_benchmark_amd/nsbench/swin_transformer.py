@@ -32,9 +32,10 @@ class _WindowAttnFn(torch.autograd.Function):
     MFMA GEMMs around the row-softmax kernels (dlwp_window_softmax_fwd/bwd)."""
 
     @staticmethod
-    def forward(ctx, qkv, table, ia, ib, labels, nW, heads, scale):
+    def forward(ctx, qkv, table, ia, ib, labels, nW, heads, scale, qrange=None):
         lib = L.load()
         B_, N, C3 = qkv.shape
+        ctx.qrange = (0, N) if qrange is None else (int(qrange[0]), int(qrange[1]))
         d = C3 // (3 * heads)
         qkv = qkv.contiguous().float()
         table_param, table = table, table.contiguous()
@@ -64,8 +65,9 @@ class _WindowAttnFn(torch.autograd.Function):
         if ntypes > 1:
             packed = torch.empty(ntypes * heads * TB, device=qkv.device)
             L.check(lib.dlwp_window_attn_pack_table(L.ptr(table), L.ptr(packed), TB, ntypes, heads, L.stream()))
-        L.check(lib.dlwp_window_attn_fwd_packed(L.ptr(qkv), L.ptr(table), L.ptr(packed), L.ptr(ia), L.ptr(ib), L.ptr(labels),
-                                                L.ptr(out), L.ptr(lse), B_, nW, N, TB, ntypes, heads, d, scale, L.stream()))
+        L.check(lib.dlwp_window_attn_fwd_qrange(L.ptr(qkv), L.ptr(table), L.ptr(packed), L.ptr(ia), L.ptr(ib), L.ptr(labels),
+                                                L.ptr(out), L.ptr(lse), B_, nW, N, TB, ntypes, heads, d, scale,
+                                                ctx.qrange[0], ctx.qrange[1], L.stream()))
         ctx.packed = packed
         ctx.save_for_backward(qkv, table, out, lse)
         return out
@@ -89,20 +91,23 @@ class _WindowAttnFn(torch.autograd.Function):
                                                 heads, scale, L.stream()))                            # dp <- scale ds
             _gemm_batched(dp, qkv, gqkv, N, d, N, N, rs, rs, 0, 0, B_, heads, sP, sQ, sQ, oB=hd)      # dq = ds k
             _gemm_batched(dp, qkv, gqkv, N, d, N, N, rs, rs, 1, 0, B_, heads, sP, sQ, sQ, oC=hd)      # dk = ds^T q
-            return gqkv, (None if ctx.tslot is not None else gtable), None, None, None, None, None, None
+            return gqkv, (None if ctx.tslot is not None else gtable), None, None, None, None, None, None, None
         qkv, table, out, lse = ctx.saved_tensors
         gqkv = torch.empty_like(qkv)
         gtable = ctx.tslot if ctx.tslot is not None else torch.zeros_like(table)   # kernel accumulates
         dsum = torch.empty_like(lse)
         slab = torch.empty(lib.dlwp_window_attn_bwd_slab_floats(B_, N, heads, TB), device=qkv.device)
-        L.check(lib.dlwp_window_attn_bwd_packed(L.ptr(qkv), L.ptr(table), L.ptr(ctx.packed), L.ptr(ia), L.ptr(ib), L.ptr(labels),
+        L.check(lib.dlwp_window_attn_bwd_qrange(L.ptr(qkv), L.ptr(table), L.ptr(ctx.packed), L.ptr(ia), L.ptr(ib), L.ptr(labels),
                                                 L.ptr(out), L.ptr(lse), L.ptr(g), L.ptr(gqkv), L.ptr(gtable), L.ptr(dsum),
-                                                L.ptr(slab), B_, nW, N, TB, ntypes, heads, d, scale, L.stream()))
-        return gqkv, (None if ctx.tslot is not None else gtable), None, None, None, None, None, None
+                                                L.ptr(slab), B_, nW, N, TB, ntypes, heads, d, scale, ctx.qrange[0], ctx.qrange[1],
+                                                L.stream()))
+        return gqkv, (None if ctx.tslot is not None else gtable), None, None, None, None, None, None, None
 
 
-def window_attention_core(qkv, table, ia, ib, labels, nW, heads, scale):
-    return _WindowAttnFn.apply(qkv, table, ia, ib, labels, nW, heads, scale)
+def window_attention_core(qkv, table, ia, ib, labels, nW, heads, scale, qrange=None):
+    """qrange (lo, hi): window tokens outside it are padding the caller crops afterwards -- still keys / values, but their own
+    rows may be left uncomputed (dlwp_window_attn_fwd_qrange)."""
+    return _WindowAttnFn.apply(qkv, table, ia, ib, labels, nW, heads, scale, qrange)
 
 
 def _pair(v):

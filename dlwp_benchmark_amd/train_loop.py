@@ -164,9 +164,10 @@ def validation_mse(model, u_val, sequence_length, batch_size, teacher_forcing_st
 
 def train_ns(model, u_train, u_val, name="model", epochs=10, batch_size=4, sequence_length=21, learning_rate=1e-3,
              teacher_forcing_steps=10, val_teacher_forcing_steps=None, noise=0.0, clip_gradients=False, seed=1234,
-             out_dir="outputs", save_model=True, continue_training=False, verbose=False, log_scalars=True):
+             out_dir="outputs", save_model=True, continue_training=False, verbose=False, log_scalars=True, stop_epoch=None):
     """Train an nsbench FNO-family module (anything with make_optimizer / train_step) on trajectories u [N, T, D, H, W].
-    Returns a list of per-epoch dicts(epoch, lr, train_mse, val_mse)."""
+    Returns a list of per-epoch dicts(epoch, lr, train_mse, val_mse).  stop_epoch: leave after that many epochs of the
+    `epochs`-long schedule with a `_last` checkpoint written (a long run split over several processes: continue_training)."""
     device = next(model.parameters()).device
     rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
     world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
@@ -211,9 +212,13 @@ def train_ns(model, u_train, u_val, name="model", epochs=10, batch_size=4, seque
             else:
                 best, dst = val_mse, ckpt_last.replace("last", "best")
             write_checkpoint(model, opt, sched, epoch, iteration, best, dst)
+            if stop_epoch is not None and epoch + 1 >= stop_epoch and dst != ckpt_last:
+                write_checkpoint(model, opt, sched, epoch, iteration, best, ckpt_last)     # the resume point must be current
         log.append({"epoch": epoch, "lr": opt.lr, "train_mse": train_mse, "val_mse": val_mse})
         if verbose and rank == 0:
             print(f"Epoch {str(epoch).zfill(3)}/{epochs}\tMSE train: {train_mse:.2E}\tMSE val: {val_mse:.2E}")
+        if stop_epoch is not None and epoch + 1 >= stop_epoch:
+            break
     return log
 
 

@@ -67,6 +67,40 @@ class _PartitionFn(torch.autograd.Function):
         return _scatter(g.contiguous(), ctx.spec, ctx.shift, ctx.B, sum_copies=any(ctx.spec.circ)), None, None
 
 
+class _PartitionFillFn(torch.autograd.Function):
+    """partition of a tensor a token-wise Linear layer has already produced: padded positions hold `fill` (the layer's bias)
+    instead of zero (dlwp_window_gather_fill); the fill's gradient is the column sum over the padded positions."""
+
+    @staticmethod
+    def forward(ctx, x, fill, spec, shift):
+        ctx.spec, ctx.shift, ctx.B = spec, shift, x.shape[0]
+        assert not any(spec.circ), "fill applies to constant padding"
+        x = x.contiguous().float()
+        B, Cc = x.shape[0], x.shape[-1]
+        out = torch.empty(B * spec.nW, spec.N, Cc, device=x.device)
+        d, p, f, s, w, sw, circ = spec.c_args(shift)
+        fl = fill.detach().contiguous().float()
+        L.check(L.load().dlwp_window_gather_fill(L.ptr(x), L.ptr(fl), L.ptr(out), B, Cc, d, p, f, s, w, sw, circ, L.stream()))
+        ctx.fill_slot = _fill_slot(fill)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        spec = ctx.spec
+        gx = _scatter(g, spec, ctx.shift, ctx.B, sum_copies=False)
+        gfill = ctx.fill_slot if ctx.fill_slot is not None else torch.zeros(g.shape[-1], device=g.device)
+        d, p, f, s, w, sw, circ = spec.c_args(ctx.shift)
+        L.check(L.load().dlwp_window_pad_colsum(L.ptr(g), L.ptr(gfill), ctx.B, g.shape[-1], d, p, f, s, w, sw, circ, L.stream()))
+        return gx, (None if ctx.fill_slot is not None else gfill), None, None
+
+
+def _fill_slot(fill):
+    """the parameter's slice of the flat gradient buffer (train_engine.flatten_parameters): kernels accumulate straight into it"""
+    from .token_ops import _grad_slot
+    return _grad_slot(fill)
+
+
 class _ReverseFn(torch.autograd.Function):
     """windows [B * nW, N, C] -> tokens [B, L, C]: un-roll by `shift`, drop the padding (+ residual [B, L, C]: the block's skip
     connection, added by the same kernel; its gradient is the upstream gradient itself)."""
@@ -89,10 +123,13 @@ def _identity(spec, shift):
     return spec.nW == 1 and spec.padded == spec.dims and not any(s % p for s, p in zip(shift, spec.padded))
 
 
-def partition(x, spec, shift=None):
+def partition(x, spec, shift=None, fill=None):
+    """fill [C]: value of the padded positions (a bias), see _PartitionFillFn; None: zero"""
     shift = tuple(spec.shift if shift is None else shift)
     if _identity(spec, shift):
         return x.reshape(x.shape[0], spec.N, x.shape[-1])
+    if fill is not None:
+        return _PartitionFillFn.apply(x, fill, spec, shift)
     return _PartitionFn.apply(x, spec, shift)
 
 

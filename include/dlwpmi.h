@@ -270,6 +270,19 @@ int dlwp_window_attn_bwd_packed(const float* qkv, const float* bias_table, const
                                 const float* lse, const float* gout, float* gqkv, float* gbias_table,
                                 float* dsum, float* slab, int B_, int nW, int N, int TB, int ntypes,
                                 int heads, int d, float scale, void* stream);
+/* Windows whose tokens outside [q_lo, q_hi) are padding that the caller crops (Pangu's pressure-level pad,           */
+/* src/dlwpbench/models/panguweather/panguweather.py:283-317: one plane of every (2,7,7) window): the padded tokens  */
+/* stay keys / values, their own rows are skipped where the kernel family can (out / lse rows outside the range are  */
+/* then unwritten; gout rows outside it are taken as zero; their gqkv query part is written as zero).                */
+int dlwp_window_attn_fwd_qrange(const float* qkv, const float* bias_table, const float* packed_table,
+                                const int* ia, const int* ib, const int* labels, float* out, float* lse,
+                                int B_, int nW, int N, int TB, int ntypes, int heads, int d, float scale,
+                                int q_lo, int q_hi, void* stream);
+int dlwp_window_attn_bwd_qrange(const float* qkv, const float* bias_table, const float* packed_table,
+                                const int* ia, const int* ib, const int* labels, const float* out,
+                                const float* lse, const float* gout, float* gqkv, float* gbias_table,
+                                float* dsum, float* slab, int B_, int nW, int N, int TB, int ntypes,
+                                int heads, int d, float scale, int q_lo, int q_hi, void* stream);
 long long dlwp_window_attn_bwd_slab_floats(int B_, int N, int heads, int TB);
 int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, const int* ia, const int* ib,
                          const int* labels, const float* out, const float* lse, const float* gout,
@@ -327,6 +340,17 @@ int dlwp_afno_wq_fold(const float* gq, float* gw, int nb, int bs_in, int bs_out,
 int dlwp_window_gather(const float* x, float* windows, int B, int C, const int* dims,
                        const int* padded, const int* front, const int* shift, const int* window,
                        const long long* wstride, const int* circular, void* stream);
+/* dlwp_window_gather on a tensor that a token-wise Linear layer has already produced: the padded positions hold  */
+/* `fill` [C] (that layer's bias; NULL: zero) -- "pad, then Linear on every window token" == "Linear on the real    */
+/* tokens, then pad with the bias" (reference: the qkv projection of EarthAttention3D on the zero-padded windows,   */
+/* panguweather.py:283-292,176), so the GEMM runs on the real tokens only.  dlwp_window_pad_colsum is the fill's    */
+/* adjoint: gfill[c] += sum over the padded positions of g_windows[..][c].                                         */
+int dlwp_window_gather_fill(const float* x, const float* fill, float* windows, int B, int C, const int* dims,
+                            const int* padded, const int* front, const int* shift, const int* window,
+                            const long long* wstride, const int* circular, void* stream);
+int dlwp_window_pad_colsum(const float* g_windows, float* gfill, int B, int C, const int* dims,
+                           const int* padded, const int* front, const int* shift, const int* window,
+                           const long long* wstride, const int* circular, void* stream);
 int dlwp_window_scatter(const float* windows, float* x, int B, int C, const int* dims,
                         const int* padded, const int* front, const int* shift, const int* window,
                         const long long* wstride, const int* circular, int sum_copies,

@@ -1,0 +1,59 @@
+"""Pangu's padded window tokens (src/dlwpbench/models/panguweather/panguweather.py:283-317: ZeroPad3d after norm1, qkv / attention
+/ proj on every window token, crop3d): the real-token flow -- qkv on the real tokens, the qkv tensor padded with the qkv bias,
+padded tokens as keys / values only, proj after the crop -- must equal the reference-order flow exactly, forward and backward."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def test_partition_with_fill_and_its_adjoint(cuda):
+    from dlwp_benchmark_amd.window_ops import WindowSpec, partition
+    spec = WindowSpec((1, 9, 12), (2, 4, 5), front=(0, 1, 1), back=(1, 2, 2), order=(2, 0, 1))
+    torch.manual_seed(0)
+    B, C = 2, 8
+    x = torch.randn(B, 9 * 12, C, device=cuda, requires_grad=True)
+    fill = torch.randn(C, device=cuda, requires_grad=True)
+    for shift in ((0, 0, 0), (1, 2, 2)):
+        plain = partition(x, spec, shift)
+        pads = partition(torch.ones_like(x), spec, shift)[..., :1] == 0          # [B*nW, N, 1]
+        got = partition(x, spec, shift, fill=fill)
+        want = torch.where(pads, fill.expand_as(plain), plain)
+        assert torch.equal(got, want)
+        g = torch.randn_like(got)
+        gx, gf = torch.autograd.grad(got, (x, fill), g)
+        gx_ref, gf_ref = torch.autograd.grad(want, (x, fill), g)
+        assert rel(gx, gx_ref) <= 1e-6 and rel(gf, gf_ref) <= 1e-5
+        assert int(pads.sum()) > 0
+
+
+@pytest.mark.parametrize("B,res,heads,dim", [(8, (1, 30, 60), 6, 96),      # 8 * 45 windows * 6 heads: the wave-per-window kernels
+                                              (1, (1, 30, 60), 6, 96),      # few windows: the tiled kernels (range ignored)
+                                              (2, (2, 20, 30), 4, 64)])     # no pressure-level pad: lat / lon pads only
+@pytest.mark.parametrize("shifted", [False, True])
+def test_real_token_flow_equals_reference_order(cuda, B, res, heads, dim, shifted):
+    from dlwp_benchmark_amd.dlwpbench.panguweather import EarthSpecificBlock
+    torch.manual_seed(5)
+    blk = EarthSpecificBlock(dim, res, heads, (2, 7, 7), None if shifted else (0, 0, 0)).to(cuda)
+    with torch.no_grad():
+        blk.attn.earth_position_bias_table.normal_(0, 0.5)
+        blk.attn.qkv.bias.normal_(0, 0.5)
+    L_ = res[0] * res[1] * res[2]
+    x = torch.randn(B, L_, dim, device=cuda, requires_grad=True)
+    g = torch.randn(B, L_, dim, device=cuda)
+    outs = {}
+    for flow in (False, True):
+        blk.real_token_flow = flow
+        blk.zero_grad(set_to_none=True)
+        y = blk(x)
+        grads = torch.autograd.grad(y, [x] + list(blk.parameters()), g)
+        outs[flow] = (y.detach().clone(), [t.clone() for t in grads])
+    assert rel(outs[True][0], outs[False][0]) <= 2e-5
+    names = ["x"] + [n for n, _ in blk.named_parameters()]
+    for n, a, b in zip(names, outs[True][1], outs[False][1]):
+        assert rel(a, b) <= 2e-4, n

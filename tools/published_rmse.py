@@ -1,0 +1,113 @@
+"""The only external numbers for the (otherwise unpinned) FNO arithmetic and the Navier-Stokes generator: the test RMSEs the
+reference published for experiment 1 (src/nsbench/scripts/plot_results.py:76,82; Re = 1e3, 64 x 64, n = 1000 / 50 / 200, t = 50):
+persistence 0.5993, TFNO2D L4 0.0139 at hidden 8 (50 k parameters) and 0.0055 at hidden 27 (500 k).
+
+  --phase persistence : generate the test split with nsdata (GPU leg, the reference's CLI settings: viscosity 1e-3, alpha 2.0,
+                        tau 7, forcing multiplicator 2, delta_t 1e-3, T 50, 50 snapshots; src/nsbench/README.md) and evaluate the
+                        persistence forecast of scripts/build_persistence.py (tf 10) with scripts/evaluate.py's RMSE
+  --phase train       : the published training command (scripts/train_commands.txt:84-85: TFNO2DModule, 4 layers, modes [12,12],
+                        batch 4, sequence length 50, teacher forcing 10, noise 0, no clipping, lr 1e-3 cosine over 500 epochs) through
+                        train_loop.train_ns; --stop-epoch splits the run over several GPU-box calls (checkpoint under --out)
+  --phase eval        : test RMSE (overall / teacher forcing / closed loop, tf 10) of the _best and _last checkpoints
+
+Results are appended as JSON lines to <out>/published_rmse.jsonl."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from dlwp_benchmark_amd import evaluate, nsbench, nsdata, train_loop  # noqa: E402
+
+PUBLISHED = {"persistence": 0.5993, 8: 0.0139, 27: 0.0055, 2: 0.0632}
+SEEDS = {"train": 11, "val": 12, "test": 13}
+N = {"train": 1000, "val": 50, "test": 200}
+
+
+def split(name, dev, n=None, alpha=2.0, seed=None):
+    t0 = time.time()
+    n = n or N[name]
+    d = nsdata.generate_data(resolution=64, n_samples=n, batch_size=n, max_simulation_time=50, delta_t=1e-3, viscosity=1e-3,
+                             alpha=alpha, tau=7.0, forcing_multiplicator=2.0, device=dev, seed=SEEDS[name] if seed is None else seed)
+    u = torch.from_numpy(d["u"])
+    print(f"generated {name}: {tuple(u.shape)} in {time.time() - t0:.1f} s, std {u.std():.4f}", flush=True)
+    return u
+
+
+def model_of(hidden, dev):
+    torch.manual_seed(1234)
+    return nsbench.TFNO2DModule(n_modes=[12, 12], in_channels=1, hidden_channels=hidden, lifting_channels=256,
+                                projection_channels=256, out_channels=1, n_layers=4, context_size=10).to(dev)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--phase", required=True, choices=["persistence", "train", "eval"])
+    ap.add_argument("--hidden", type=int, default=8)
+    ap.add_argument("--epochs", type=int, default=500)
+    ap.add_argument("--stop-epoch", type=int, default=None)
+    ap.add_argument("--n-train", type=int, default=None)
+    ap.add_argument("--alpha", type=float, default=2.5, help="GRF alpha of the initial condition: 2.5 = the reference generator's "
+                    "generate_data() default and its source comment 'a=2.5 for 64x64' (its argparse default is 2.0); the published "
+                    "persistence RMSE 0.5993 is reproduced with 2.5 (closed-loop RMSE 0.603), not with 2.0 (0.618)")
+    ap.add_argument("--seeds", type=int, default=1, help="persistence phase: that many independent test splits (sampling scatter)")
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "published_rmse"))
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    os.makedirs(a.out, exist_ok=True)
+    log = os.path.join(a.out, "published_rmse.jsonl")
+    name = f"tfno2d64_d{a.hidden}_12-12_l4_sl50_tf10_cl40_noise0"
+
+    def emit(rec):
+        print(json.dumps(rec), flush=True)
+        with open(log, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+
+    if a.phase == "persistence":
+        for k in range(a.seeds):
+            u = split("test", dev, alpha=a.alpha, seed=SEEDS["test"] + 100 * k).to(dev)
+            x, y = u[:, :-1], u[:, 1:]
+            tf = 10
+            out = x.clone()                                 # build_persistence.py:25-27
+            out[:, tf:] = x[:, tf - 1:tf]
+            m = evaluate.ns_metrics(out.contiguous(), y.contiguous(), tf)
+            emit({"what": f"persistence, test split (n 200, t 50, Re 1e3, GRF alpha {a.alpha}, seed {SEEDS['test'] + 100 * k}), teacher forcing 10",
+                  "published_rmse": PUBLISHED["persistence"], **{k2: round(v, 4) for k2, v in m.items()}, "field_std": round(u.std().item(), 4)})
+        return
+    if a.phase == "train":
+        # the splits stay ON the device: assembling a batch with torch.stack on the GPU box's host cores cost 14 ms per call
+        # (60 ms per iteration against a 7 ms step)
+        u_train, u_val = split("train", dev, a.n_train, alpha=a.alpha).to(dev), split("val", dev, alpha=a.alpha).to(dev)
+        model = model_of(a.hidden, dev)
+        cont = os.path.exists(os.path.join(a.out, name, "checkpoints", f"{name}_last.ckpt"))
+        t0 = time.time()
+        lg = train_loop.train_ns(model, u_train, u_val, name=name, epochs=a.epochs, batch_size=4, sequence_length=50, learning_rate=1e-3,
+                                 teacher_forcing_steps=10, noise=0.0, clip_gradients=False, out_dir=a.out, continue_training=cont,
+                                 verbose=False, log_scalars=False, stop_epoch=a.stop_epoch)
+        dt = time.time() - t0
+        emit({"what": f"train {name}", "epochs_done": lg[-1]["epoch"] + 1 if lg else None, "of": a.epochs, "resumed": cont,
+              "seconds": round(dt, 1), "s_per_epoch": round(dt / max(len(lg), 1), 2), "n_params": sum(p.numel() for p in model.parameters()),
+              "train_mse": lg[-1]["train_mse"] if lg else None, "val_mse": lg[-1]["val_mse"] if lg else None})
+        return
+    u = split("test", dev, alpha=a.alpha)
+    x, y = u[:, :-1].contiguous(), u[:, 1:].contiguous()
+    for tag in ("best", "last"):
+        path = os.path.join(a.out, name, "checkpoints", f"{name}_{tag}.ckpt")
+        if not os.path.exists(path):
+            continue
+        model = model_of(a.hidden, dev)
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        model.load_state_dict(ck["model_state_dict"])
+        batches = [(x[i:i + 8].to(dev), y[i:i + 8].to(dev)) for i in range(0, x.shape[0], 8)]
+        m = evaluate.evaluate_ns(model, batches, 10)
+        emit({"what": f"test RMSE of {name} ({tag} checkpoint, epoch {ck['epoch']})", "published_rmse": PUBLISHED.get(a.hidden),
+              **{k: round(v, 5) for k, v in m.items()}, "ratio_to_published": round(m["rmse"] / PUBLISHED[a.hidden], 3) if a.hidden in PUBLISHED else None})
+
+
+if __name__ == "__main__":
+    main()
