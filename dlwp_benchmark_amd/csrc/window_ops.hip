@@ -62,18 +62,28 @@ __global__ __launch_bounds__(256) void win_gather_kernel(WinDev a) {
     }
 }
 
-// out[c] += sum over the PADDED positions of windows[.][.][c]: the adjoint of the `fill` of win_gather_kernel (gradient of the
-// bias that stands at the padded positions).  A workgroup walks a slice of the window tokens; thread = (token lane, channel quad).
-__global__ __launch_bounds__(256) void win_pad_colsum_kernel(WinDev a, float* out) {
-    extern __shared__ __attribute__((aligned(16))) float red[];      // [lanes][C]
-    const int C4 = a.C >> 2;
-    const int lanes = 256 / C4 > 0 ? 256 / C4 : 1;                   // token lanes per workgroup (C4 <= 256)
-    const int c4 = threadIdx.x % C4, tl = threadIdx.x / C4;
+// out[c] += sum over the PADDED positions of windows[.][.][c], channels c >= c_lo: the adjoint of the `fill` of
+// win_gather_kernel (gradient of the bias that stands at the padded positions).  A workgroup takes 256 window tokens at a time:
+// every thread classifies ONE token (the index walk of win_gather_kernel, once per token instead of once per channel quad) and
+// appends the padded ones to a list in LDS; then thread = (list lane, channel quad) streams the listed rows.
+__global__ __launch_bounds__(256) void win_pad_colsum_kernel(WinDev a, float* out, int c_lo) {
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [lanes][4 cw] partial sums | list[256] | count
+    const int q_lo = c_lo >> 2, C4 = (a.C >> 2) - q_lo;              // channel quads to sum
+    const int cw = C4 < 256 ? C4 : 256;                              // quads handled per thread column
+    const int lanes = 256 / cw;                                      // list lanes per workgroup
+    const int nq = (C4 + cw - 1) / cw;                               // quads per thread (<= 4: at most 4096 channels)
+    int* list = reinterpret_cast<int*>(red + (size_t)lanes * cw * 4 * nq);
+    int* count = list + 256;
+    const int cq = threadIdx.x % cw, tl = threadIdx.x / cw;
     const long long ntok = (long long)a.B * a.nW * a.N;
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (tl < lanes) {
-        for (long long tok = (long long)blockIdx.x * lanes + tl; tok < ntok; tok += (long long)gridDim.x * lanes) {
-            // the same walk as win_gather_kernel: canonical (sample, window (i0,i1,i2) row-major, token) -> padded position
+    f32x4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long long base = (long long)blockIdx.x * 256; base < ntok; base += (long long)gridDim.x * 256) {
+        if (threadIdx.x == 0) *count = 0;
+        __syncthreads();
+        const long long tok = base + threadIdx.x;
+        if (tok < ntok) {
             const int bw = fastdiv((int)tok, a.dN), n = (int)tok - bw * a.N;
             const int b = fastdiv(bw, a.dnW), wlin = bw - b * a.nW;
             const int i0 = fastdiv(wlin, a.dnw12), r1 = wlin - i0 * a.nw[1] * a.nw[2], i1 = fastdiv(r1, a.dnw2), i2 = r1 - i1 * a.nw[2];
@@ -87,19 +97,55 @@ __global__ __launch_bounds__(256) void win_pad_colsum_kernel(WinDev a, float* ou
             }
             if (!ok) {
                 const long long wout = (long long)b * a.nW + i0 * a.sw[0] + i1 * a.sw[1] + i2 * a.sw[2];
-                const f32x4 v = *reinterpret_cast<const f32x4*>(a.src + (wout * a.N + n) * a.C + 4 * c4);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) acc[k] += v[k];
+                list[atomicAdd(count, 1)] = (int)(wout * a.N + n);          // row index (< 2^31: win_setup)
             }
         }
+        __syncthreads();
+        const int np = *count;
+        if (tl < lanes) {
+            // eight listed rows in flight per thread (a read-then-add loop pays the L2 latency once per row)
+            for (int e0 = tl; e0 < np; e0 += 8 * lanes) {
+                const float* rows[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) red[tl * a.C + 4 * c4 + k] = acc[k];
+                for (int t = 0; t < 8; ++t) {
+                    const int e = e0 + t * lanes;
+                    rows[t] = a.src + (long long)list[e < np ? e : e0] * a.C + 4 * q_lo;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c4 = cq + u * cw;
+                    if (u < nq && c4 < C4) {
+                        f32x4 v[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) v[t] = *reinterpret_cast<const f32x4*>(rows[t] + 4 * c4);
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+                            if (e0 + t * lanes < np) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) acc[u][k] += v[t][k];
+                            }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tl < lanes) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u < nq)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) red[((tl * nq + u) * cw + cq) * 4 + k] = acc[u][k];
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < a.C; c += 256) {
-        float t = 0.f;
-        for (int l = 0; l < lanes; ++l) t += red[l * a.C + c];
-        if (t != 0.f) atomic_add_f32(&out[c], t);
+    for (int e = threadIdx.x; e < 4 * cw * nq; e += 256) {
+        const int u = e / (4 * cw), r = e - u * 4 * cw;                 // quad group u, element r = 4 cq + k
+        const int c = 4 * (u * cw) + r;
+        if (c < 4 * C4) {
+            float t = 0.f;
+            for (int l = 0; l < lanes; ++l) t += red[(l * nq + u) * cw * 4 + r];
+            if (t != 0.f) atomic_add_f32(&out[c_lo + c], t);
+        }
     }
 }
 
@@ -308,18 +354,22 @@ extern "C" int dlwp_window_gather_fill(const float* x, const float* fill, float*
     return DLWP_OK;
 }
 
-// gfill[c] += sum of g_windows[.][.][c] over the padded (non-circular) positions: gradient of dlwp_window_gather_fill's fill
+// gfill[c] += sum of g_windows[.][.][c] over the padded (non-circular) positions, channels c >= c_lo (a multiple of 4): gradient
+// of dlwp_window_gather_fill's fill.  c_lo lets the caller skip channels whose padded rows are known to be zero (the query third of
+// a qkv gradient whose padded rows were not computed, dlwp_window_attn_bwd_qrange).
 extern "C" int dlwp_window_pad_colsum(const float* g_windows, float* gfill, int B, int C, const int* dims, const int* padded,
                                       const int* front, const int* shift, const int* window, const long long* wstride,
-                                      const int* circular, void* stream) {
+                                      const int* circular, int c_lo, void* stream) {
     WinDev a{};
     int rc = win_setup(a, g_windows, gfill, B, C, dims, padded, front, shift, window, wstride, circular, "window_pad_colsum");
     if (rc) return rc;
-    DLWP_REQUIRE(C / 4 <= 256, DLWP_E_UNSUPPORTED, "window_pad_colsum: at most 1024 channels");
-    const int lanes = 256 / (C / 4);
+    DLWP_REQUIRE(c_lo >= 0 && c_lo < C && c_lo % 4 == 0, DLWP_E_INVALID, "window_pad_colsum: c_lo must be a multiple of 4 inside [0, C)");
+    const int C4 = (C - c_lo) / 4, cw = std::min(C4, 256), lanes = 256 / cw, nq = (C4 + cw - 1) / cw;
+    DLWP_REQUIRE(nq <= 4, DLWP_E_UNSUPPORTED, "window_pad_colsum: at most 4096 channels");
     const long long ntok = (long long)B * a.nW * a.N;
-    const int grid = (int)std::min<long long>((ntok + lanes * 8 - 1) / (lanes * 8), 2048);
-    hipLaunchKernelGGL(win_pad_colsum_kernel, dim3(grid), dim3(256), sizeof(float) * (size_t)lanes * C, (hipStream_t)stream, a, gfill);
+    const int grid = (int)std::max<long long>(1, std::min<long long>((ntok + 255) / 256, 1024));
+    const size_t lds = sizeof(float) * (size_t)lanes * cw * 4 * nq + sizeof(int) * 260;
+    hipLaunchKernelGGL(win_pad_colsum_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, gfill, c_lo);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }

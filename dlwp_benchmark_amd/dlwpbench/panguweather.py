@@ -122,14 +122,22 @@ class EarthSpecificBlock(nn.Module):
         # BIAS (Linear(0) = bias), attend with the padded tokens as keys / values only (their own rows are cropped: no output
         # needed, zero gradient), crop, then proj on the real tokens.  _qrange = hull of the window positions that hold a real
         # token in ANY window (the query rows worth computing).
+        # The rows worth computing are the window positions crop3d KEEPS.  In shifted blocks the reference rolls the longitude
+        # forward by the LATITUDE shift and back by the longitude shift (:291 vs :310, reproduced), so the kept positions are
+        # not the ones the real tokens were put at: the hull covers both, and the padded positions that are kept receive a
+        # non-zero query gradient (-> the fill's adjoint sums all three thirds of the qkv gradient there).
         Pl, Lat, Lon = self.input_resolution
         real = F.pad(torch.ones(1, 1, Pl, Lat, Lon), p).permute(0, 2, 3, 4, 1)
+        nwin = self.window_size[0] * self.window_size[1] * self.window_size[2]
+        canv = [real]
         if self.roll:
             sh = self.shift_size
-            real = torch.roll(real, shifts=(-sh[0], -sh[1], -sh[1]), dims=(1, 2, 3))      # the forward roll (:291)
-        anyreal = _partition(real, self.window_size).reshape(-1, self.window_size[0] * self.window_size[1] * self.window_size[2]).amax(0)
+            canv = [torch.roll(real, shifts=(-sh[0], -sh[1], -sh[1]), dims=(1, 2, 3)),     # where the tokens go (:291)
+                    torch.roll(real, shifts=(-sh[0], -sh[1], -sh[2]), dims=(1, 2, 3))]     # what the crop keeps (:310)
+        anyreal = sum(_partition(c, self.window_size).reshape(-1, nwin).amax(0) for c in canv)
         idx = torch.nonzero(anyreal > 0).reshape(-1)
         self._qrange = (int(idx.min()), int(idx.max()) + 1)
+        self._kept_are_real = len(canv) == 1 or bool(torch.equal(canv[0], canv[1]))
         n_pad = self.pad_resolution[0] * self.pad_resolution[1] * self.pad_resolution[2]
         self.real_token_flow = n_pad >= 1.25 * Pl * Lat * Lon
 
@@ -147,7 +155,9 @@ class EarthSpecificBlock(nn.Module):
             # skip connections leave the LayerNorm nodes (norm_fork): their gradients join the LayerNorm backward kernels
             if self.real_token_flow:
                 skip, t = norm_fork(self.norm1, x, gemm_input=True)
-                qkv = partition(self.attn.qkv(t), spec, fwd_shift, fill=self.attn.qkv.bias)
+                # (where the crop keeps exactly the positions of the real tokens, every padded row has a zero query gradient --
+                # its upstream gradient is zero -- and the fill's adjoint sums the k and v thirds only)
+                qkv = partition(self.attn.qkv(t), spec, fwd_shift, fill=self.attn.qkv.bias, fill_grad_from=C if self._kept_are_real else 0)
                 t = self.attn.core(qkv, self._labels if self.roll else None, spec.nW, self._qrange)
                 if self.drop_path.active:
                     t = self.attn.proj(reverse(t, spec, B, rev_shift))

@@ -68,7 +68,7 @@ SIGNATURES = {
     "dlwp_get_gemm_precision": (_I, []),
     "dlwp_window_gather": (_I, [_V, _V, _I, _I] + [_V] * 7 + [_V]),
     "dlwp_window_gather_fill": (_I, [_V, _V, _V, _I, _I] + [_V] * 7 + [_V]),
-    "dlwp_window_pad_colsum": (_I, [_V, _V, _I, _I] + [_V] * 7 + [_V]),
+    "dlwp_window_pad_colsum": (_I, [_V, _V, _I, _I] + [_V] * 7 + [_I, _V]),
     "dlwp_window_scatter": (_I, [_V, _V, _I, _I] + [_V] * 7 + [_I, _V]),
     "dlwp_window_scatter_add": (_I, [_V, _V, _V, _I, _I] + [_V] * 7 + [_I, _V]),
     "dlwp_patch_merge": (_I, [_V, _V, _I, _I, _I, _I, _I, _V]),

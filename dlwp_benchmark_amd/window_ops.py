@@ -72,8 +72,8 @@ class _PartitionFillFn(torch.autograd.Function):
     instead of zero (dlwp_window_gather_fill); the fill's gradient is the column sum over the padded positions."""
 
     @staticmethod
-    def forward(ctx, x, fill, spec, shift):
-        ctx.spec, ctx.shift, ctx.B = spec, shift, x.shape[0]
+    def forward(ctx, x, fill, spec, shift, c_lo=0):
+        ctx.spec, ctx.shift, ctx.B, ctx.c_lo = spec, shift, x.shape[0], int(c_lo)
         assert not any(spec.circ), "fill applies to constant padding"
         x = x.contiguous().float()
         B, Cc = x.shape[0], x.shape[-1]
@@ -91,8 +91,9 @@ class _PartitionFillFn(torch.autograd.Function):
         gx = _scatter(g, spec, ctx.shift, ctx.B, sum_copies=False)
         gfill = ctx.fill_slot if ctx.fill_slot is not None else torch.zeros(g.shape[-1], device=g.device)
         d, p, f, s, w, sw, circ = spec.c_args(ctx.shift)
-        L.check(L.load().dlwp_window_pad_colsum(L.ptr(g), L.ptr(gfill), ctx.B, g.shape[-1], d, p, f, s, w, sw, circ, L.stream()))
-        return gx, (None if ctx.fill_slot is not None else gfill), None, None
+        L.check(L.load().dlwp_window_pad_colsum(L.ptr(g), L.ptr(gfill), ctx.B, g.shape[-1], d, p, f, s, w, sw, circ, ctx.c_lo,
+                                                L.stream()))
+        return gx, (None if ctx.fill_slot is not None else gfill), None, None, None
 
 
 def _fill_slot(fill):
@@ -123,13 +124,14 @@ def _identity(spec, shift):
     return spec.nW == 1 and spec.padded == spec.dims and not any(s % p for s, p in zip(shift, spec.padded))
 
 
-def partition(x, spec, shift=None, fill=None):
-    """fill [C]: value of the padded positions (a bias), see _PartitionFillFn; None: zero"""
+def partition(x, spec, shift=None, fill=None, fill_grad_from=0):
+    """fill [C]: value of the padded positions (a bias), see _PartitionFillFn; None: zero.  fill_grad_from: channels below it are
+    known to receive zero gradient at the padded positions (skipped by the fill's adjoint)."""
     shift = tuple(spec.shift if shift is None else shift)
     if _identity(spec, shift):
         return x.reshape(x.shape[0], spec.N, x.shape[-1])
     if fill is not None:
-        return _PartitionFillFn.apply(x, fill, spec, shift)
+        return _PartitionFillFn.apply(x, fill, spec, shift, fill_grad_from)
     return _PartitionFn.apply(x, spec, shift)
 
 

@@ -344,13 +344,14 @@ int dlwp_window_gather(const float* x, float* windows, int B, int C, const int* 
 /* `fill` [C] (that layer's bias; NULL: zero) -- "pad, then Linear on every window token" == "Linear on the real    */
 /* tokens, then pad with the bias" (reference: the qkv projection of EarthAttention3D on the zero-padded windows,   */
 /* panguweather.py:283-292,176), so the GEMM runs on the real tokens only.  dlwp_window_pad_colsum is the fill's    */
-/* adjoint: gfill[c] += sum over the padded positions of g_windows[..][c].                                         */
+/* adjoint: gfill[c] += sum over the padded positions of g_windows[..][c] for c >= c_lo (a multiple of 4; lets the   */
+/* caller skip channels whose padded rows are known to be zero).                                                   */
 int dlwp_window_gather_fill(const float* x, const float* fill, float* windows, int B, int C, const int* dims,
                             const int* padded, const int* front, const int* shift, const int* window,
                             const long long* wstride, const int* circular, void* stream);
 int dlwp_window_pad_colsum(const float* g_windows, float* gfill, int B, int C, const int* dims,
                            const int* padded, const int* front, const int* shift, const int* window,
-                           const long long* wstride, const int* circular, void* stream);
+                           const long long* wstride, const int* circular, int c_lo, void* stream);
 int dlwp_window_scatter(const float* windows, float* x, int B, int C, const int* dims,
                         const int* padded, const int* front, const int* shift, const int* window,
                         const long long* wstride, const int* circular, int sum_copies,

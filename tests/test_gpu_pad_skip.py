@@ -12,11 +12,12 @@ def rel(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
-def test_partition_with_fill_and_its_adjoint(cuda):
+@pytest.mark.parametrize("C", [8, 1152])          # 1152 = qkv width of Pangu's deep stages: more channel quads than threads
+def test_partition_with_fill_and_its_adjoint(cuda, C):
     from dlwp_benchmark_amd.window_ops import WindowSpec, partition
     spec = WindowSpec((1, 9, 12), (2, 4, 5), front=(0, 1, 1), back=(1, 2, 2), order=(2, 0, 1))
     torch.manual_seed(0)
-    B, C = 2, 8
+    B = 2
     x = torch.randn(B, 9 * 12, C, device=cuda, requires_grad=True)
     fill = torch.randn(C, device=cuda, requires_grad=True)
     for shift in ((0, 0, 0), (1, 2, 2)):
