@@ -411,6 +411,265 @@ __global__ __launch_bounds__(256) void winattn_small_bwd_kernel(WsDev a) {
         if (gtb[i] != 0ull) atomic_add_f32(&a.gtable[(long long)i * w.tstr + w.tofs], (float)(long long)gtb[i] * (1.f / FXS));
 }
 
+// ------------------------------------------------------------------------------------------------ LDS-staged bf16 family
+// (round 3) The register-fragment kernels above fetch every MFMA fragment of every 16 x 16 tile pair from global memory: a
+// row fragment touches 16 rows 2304 B apart, a column fragment is four strided dword loads, and one wave walks 28 - 49 tile
+// pairs twice in the backward pass -- the kernel is bound by L1 transactions, not by arithmetic (Pangu C4 layer 1: 638 us for
+// 18 GFLOP).  In bf16 matrix mode the operands are rounded to bf16 anyway, so here a WORKGROUP owns one (window, head):
+// its four waves stage q (pre-scaled), k, v, dO of the window ONCE, coalesced (128 B per token and matrix), as bf16 rows of
+// 72 B in LDS (<= 37 KB), together with D = rowsum(dO o), the row statistics, the bias-index vectors and the labels; the
+// tile walk then reads row fragments as one ds_read_b64 and column fragments as four ds_read_u16.  The arithmetic, its order
+// and the roundings are those of the register-fragment kernels in bf16 mode.  Waves split the query chunks (pass Q) and the key
+// chunks (pass K).  BACKWARD only: the forward pass reads each operand once per query chunk and the same construction measured
+// SLOWER there (93 vs 63 us at the C4 layer-1 shape: the staging is 265 MB of HBM traffic per launch either way), so the
+// forward stays on the register-fragment kernel.  Where the backward time goes (timing switches, same shape, 272 us): staging
+// + zero fill + flush 69 us, pass Q 102 us (49 of them the fixed-point LDS atomics of the bias gradient), pass K 77 us -- the
+// passes are bound by VALU bookkeeping per 16 x 16 tile (index vectors, masks, exponentials, fragment packing), ~2 k SIMD cycles
+// per tile pair for 6 - 8 MFMAs.
+typedef unsigned short bf16_t;
+constexpr int LDB = 36;        // bf16 elements per staged row (32 + 4: 72 B, 8-byte aligned, rows 18 banks apart)
+
+__device__ __forceinline__ f32x4 mfma_bf(const s16x4 a, const s16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ s16x4 pack_bf(const f32x4 v) {
+    typedef __bf16 bh4 __attribute__((ext_vector_type(4)));
+    const bh4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    return __builtin_bit_cast(s16x4, h);
+}
+// row fragment: four consecutive channels of one staged row; column fragment: one channel of four consecutive rows
+__device__ __forceinline__ s16x4 lds_row(const bf16_t* m, int row, int c0) { return *reinterpret_cast<const s16x4*>(m + row * LDB + c0); }
+__device__ __forceinline__ s16x4 lds_col(const bf16_t* m, int row0, int c) {
+    s16x4 v;
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) v[s2] = (short)m[(row0 + s2) * LDB + c];
+    return v;
+}
+
+struct LdsWin {
+    bf16_t *Q, *K, *V, *G;
+    float *D, *lse, *tb;
+    int *ia, *ib, *lab;
+    unsigned long long* gtb;
+};
+__device__ __forceinline__ LdsWin lds_carve(void* smem, int NR, int TB, bool bwd) {
+    LdsWin L;
+    bf16_t* h = reinterpret_cast<bf16_t*>(smem);
+    L.Q = h; L.K = L.Q + NR * LDB; L.V = L.K + NR * LDB; L.G = L.V + NR * LDB;
+    float* f = reinterpret_cast<float*>(L.G + (bwd ? NR * LDB : 0));
+    L.D = f; L.lse = f + NR;
+    L.ia = reinterpret_cast<int*>(f + 2 * NR); L.ib = L.ia + NR; L.lab = L.ib + NR;
+    L.tb = reinterpret_cast<float*>(L.lab + NR);
+    L.gtb = reinterpret_cast<unsigned long long*>(L.tb + ((TB + 1) & ~1));
+    return L;
+}
+static size_t lds_bytes(int NR, int TB, bool bwd) {
+    return (size_t)(bwd ? 4 : 3) * NR * LDB * 2 + (size_t)5 * NR * 4 + (size_t)((TB + 1) & ~1) * 4 + (bwd ? (size_t)TB * 8 : 0);
+}
+// A workgroup owns one (window type, head) and walks the windows m = grp, grp + groups, ... of that type one after the other:
+// the bias-table slice is staged once and the bias-gradient partials are flushed once per workgroup (one workgroup per window
+// meant 2548 global float atomics per window on 37-way shared addresses at the Pangu C4 shape: the flush, not the arithmetic,
+// set the kernel's time).
+__device__ __forceinline__ Who who_lds(const WsDev& a, int& grp) {
+    Who w;
+    grp = blockIdx.x % a.groups;
+    const int th = blockIdx.x / a.groups;
+    w.ty = th % a.ntypes;
+    w.head = th / a.ntypes;
+    w.valid = true;
+    w.b = w.ty;
+    w.wdw = 0;
+    w.tofs = (long long)w.ty * a.heads + w.head;
+    w.tstr = (long long)a.ntypes * a.heads;
+    return w;
+}
+__device__ __forceinline__ void who_window(const WsDev& a, Who& w, int m) {
+    w.b = w.ty + a.ntypes * m;
+    w.wdw = w.b % a.nW;
+}
+// stage the window: q (x scale), k, v [, dO, D = rowsum(dO o), lse] + index vectors; 8 threads per token (16 B each)
+template <bool BWD>
+__device__ __forceinline__ void lds_stage(const WsDev& a, const Who& w, const LdsWin& L, int NR) {
+    const int N = a.N, d = a.d, tid = threadIdx.x, ch = tid & 7;
+    const long long rs = 3LL * a.heads * d, os = (long long)a.heads * d;
+    const float* qb = a.qkv + (long long)w.b * N * rs + w.head * d;
+    const float* gb = BWD ? a.gout + (long long)w.b * N * os + w.head * d : nullptr;
+    const float* ob = BWD ? a.o + (long long)w.b * N * os + w.head * d : nullptr;
+    const long long stat = ((long long)w.b * a.heads + w.head) * N;
+    for (int tok = tid >> 3; tok < NR; tok += 32) {
+        const bool ok = tok < N && 4 * ch < d;
+        const int tc = tok < N ? tok : N - 1, cc = 4 * ch < d ? 4 * ch : 0;        // clamped: unconditional loads
+        const float* row = qb + (long long)tc * rs + cc;
+        f32x4 q = *reinterpret_cast<const f32x4*>(row);
+        f32x4 k = *reinterpret_cast<const f32x4*>(row + a.heads * d);
+        f32x4 v = *reinterpret_cast<const f32x4*>(row + 2 * a.heads * d);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f}, o = g;
+        if (BWD) {
+            g = *reinterpret_cast<const f32x4*>(gb + (long long)tc * os + cc);
+            o = *reinterpret_cast<const f32x4*>(ob + (long long)tc * os + cc);
+        }
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if (!ok) { q = z; k = z; v = z; g = z; o = z; }
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) q[s2] *= a.scale;
+        *reinterpret_cast<s16x4*>(L.Q + tok * LDB + 4 * ch) = pack_bf(q);
+        *reinterpret_cast<s16x4*>(L.K + tok * LDB + 4 * ch) = pack_bf(k);
+        *reinterpret_cast<s16x4*>(L.V + tok * LDB + 4 * ch) = pack_bf(v);
+        if (BWD) {
+            *reinterpret_cast<s16x4*>(L.G + tok * LDB + 4 * ch) = pack_bf(g);
+            float dp = g[0] * o[0] + g[1] * o[1] + g[2] * o[2] + g[3] * o[3];
+            dp += __shfl_xor(dp, 1); dp += __shfl_xor(dp, 2); dp += __shfl_xor(dp, 4);
+            if (ch == 0) L.D[tok] = dp;
+        }
+    }
+    const int* labw = a.labels ? a.labels + (long long)w.wdw * N : nullptr;
+    for (int t = tid; t < NR; t += 256) {
+        const int tc = t < N ? t : N - 1;
+        L.ia[t] = a.ia[tc];
+        L.ib[t] = a.ib[tc];
+        L.lab[t] = labw ? labw[tc] : 0;
+        if (BWD) L.lse[t] = a.lse_in[stat + tc];
+    }
+}
+
+template <int NDB>
+__global__ __launch_bounds__(256) void winattn_lds_bwd_kernel(WsDev a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int N = a.N, d = a.d, NCr = (N + 15) / 16, NR = 16 * NCr;
+    const LdsWin L = lds_carve(smem, NR, a.TB, true);
+    int grp;
+    Who w = who_lds(a, grp);
+    stage_table(L.tb, a, w);
+    for (int i = threadIdx.x; i < a.TB; i += 256) L.gtb[i] = 0ull;
+    const int lane = lane_id(), r = lane & 15, g = lane >> 4, wv = wave_id();
+    const long long rs = 3LL * a.heads * d;
+    const bool masked = a.labels != nullptr;
+    const int qlo = a.qc_lo, qhi = min(a.qc_hi, NCr);
+    for (int m = grp; m < a.M; m += a.groups) {
+    who_window(a, w, m);
+    __syncthreads();                       // the previous window's fragments have been read (and tb / gtb are initialised)
+    lds_stage<true>(a, w, L, NR);
+    float* gq = a.gqkv + (long long)w.b * N * rs + w.head * d;
+    // query rows outside the computed chunks: zero query gradient (they carry no upstream gradient)
+    for (int e = threadIdx.x; e < N * (d >> 2); e += 256) {
+        const int tok = e / (d >> 2), c4 = e - tok * (d >> 2), qc = tok >> 4;
+        if (qc < qlo || qc >= qhi) *reinterpret_cast<f32x4*>(gq + (long long)tok * rs + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    // ---- pass Q: dS^T = P^T (dP^T - D), dQ^T += K^T dS^T, dBias
+    for (int qc = qlo + wv; qc < qhi; qc += 4) {
+        const int q = 16 * qc + r;
+        const int qa = L.ia[q], ql = L.lab[q];
+        const float lse = L.lse[q], D = L.D[q];
+        s16x4 qf[NDB], gf[NDB];
+        f32x4 dq[NDB];
+#pragma unroll
+        for (int cc = 0; cc < NDB; ++cc) {
+            qf[cc] = lds_row(L.Q, q, 16 * cc + 4 * g);
+            gf[cc] = lds_row(L.G, q, 16 * cc + 4 * g);
+            dq[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll 1
+        for (int kc = 0; kc < NCr; ++kc) {
+            f32x4 sT = f32x4{0.f, 0.f, 0.f, 0.f}, dpT = sT;
+#pragma unroll
+            for (int cc = 0; cc < NDB; ++cc) {
+                sT = mfma_bf(lds_row(L.K, 16 * kc + r, 16 * cc + 4 * g), qf[cc], sT);
+                dpT = mfma_bf(lds_row(L.V, 16 * kc + r, 16 * cc + 4 * g), gf[cc], dpT);
+            }
+            f32x4 dsT;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                          // rows = keys 16 kc + 4g + j, column = query r
+                const int key = 16 * kc + 4 * g + j;
+                const int bi = qa + L.ib[key];
+                float sc = sT[j] + L.tb[bi];
+                if (masked && L.lab[key] != ql) sc -= 100.f;
+                const bool ok = key < N && q < N;
+                const float v = ok ? __expf(sc - lse) * (dpT[j] - D) : 0.f;
+                if (ok) fx_add_s(&L.gtb[bi], v);
+                dsT[j] = v;
+            }
+            const s16x4 dsb = pack_bf(dsT);
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) dq[db] = mfma_bf(lds_col(L.K, 16 * kc + 4 * g, 16 * db + r), dsb, dq[db]);
+        }
+        if (q < N) {
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const int dd = 16 * db + 4 * g;
+                if (dd < d) *reinterpret_cast<f32x4*>(gq + (long long)q * rs + dd) = f32x4{dq[db][0] * a.scale, dq[db][1] * a.scale, dq[db][2] * a.scale, dq[db][3] * a.scale};
+            }
+        }
+    }
+    // ---- pass K: dS = P (dP - D), dV^T += dO^T P, dK^T += (scale Q)^T dS      (D and the statistics were staged: no dependency on pass Q)
+    for (int kc = wv; kc < NCr; kc += 4) {
+        const int key = 16 * kc + r;
+        const int kbi = L.ib[key], kl = L.lab[key];
+        s16x4 kf[NDB], vf[NDB];
+        f32x4 dk[NDB], dv[NDB];
+#pragma unroll
+        for (int cc = 0; cc < NDB; ++cc) {
+            kf[cc] = lds_row(L.K, key, 16 * cc + 4 * g);
+            vf[cc] = lds_row(L.V, key, 16 * cc + 4 * g);
+            dk[cc] = dv[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll 1
+        for (int qc = qlo; qc < qhi; ++qc) {
+            f32x4 sc4 = f32x4{0.f, 0.f, 0.f, 0.f}, dp = sc4;
+#pragma unroll
+            for (int cc = 0; cc < NDB; ++cc) {
+                sc4 = mfma_bf(lds_row(L.Q, 16 * qc + r, 16 * cc + 4 * g), kf[cc], sc4);      // rows = queries 16 qc + 4g + j, column = key r
+                dp = mfma_bf(lds_row(L.G, 16 * qc + r, 16 * cc + 4 * g), vf[cc], dp);
+            }
+            f32x4 p, ds;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int qq = 16 * qc + 4 * g + j;
+                float sc = sc4[j] + L.tb[L.ia[qq] + kbi];
+                if (masked && L.lab[qq] != kl) sc -= 100.f;
+                const float pv = (qq < N && key < N) ? __expf(sc - L.lse[qq]) : 0.f;
+                p[j] = pv;
+                ds[j] = pv * (dp[j] - L.D[qq]);
+            }
+            const s16x4 pb = pack_bf(p), dsb = pack_bf(ds);
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                dv[db] = mfma_bf(lds_col(L.G, 16 * qc + 4 * g, 16 * db + r), pb, dv[db]);      // dV^T += dO^T P
+                dk[db] = mfma_bf(lds_col(L.Q, 16 * qc + 4 * g, 16 * db + r), dsb, dk[db]);     // dK^T += (scale Q)^T dS
+            }
+        }
+        if (key < N) {
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const int dd = 16 * db + 4 * g;
+                if (dd < d) {
+                    float* dst = gq + (long long)key * rs + dd;
+                    *reinterpret_cast<f32x4*>(dst + a.heads * d) = dk[db];
+                    *reinterpret_cast<f32x4*>(dst + 2 * a.heads * d) = dv[db];
+                }
+            }
+        }
+    }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.TB; i += 256)
+        if (L.gtb[i] != 0ull) atomic_add_f32(&a.gtable[(long long)i * w.tstr + w.tofs], (float)(long long)L.gtb[i] * (1.f / FXS));
+}
+
+// windows of one (type, head) per workgroup: enough workgroups to fill the chip about three times over
+// (Pangu C4 layer 1, 4218 (window, head) pairs, tools/probe_winattn_c4.py: 768 workgroups 277 us, 1536: 272, 3072: 288, one per
+// window: 370; the register-fragment kernel: 338)
+static int lds_groups(int M, int heads, int ntypes) {
+    static const int env = [] { const char* e = getenv("DLWP_WINATTN_WG_BWD"); return e ? atoi(e) : 0; }();
+    const long long g = ((long long)(env ? env : 1536) + heads * ntypes - 1) / (heads * ntypes);
+    return g < 1 ? 1 : (g > M ? M : (int)g);
+}
+
+// the LDS-staged family takes the bf16 matrix mode with 16-byte loadable head slices
+static bool lds_family_applies(int N, int d) {
+    return dlwp_get_gemm_precision() == 1 && d % 4 == 0 && d <= 32 && N <= 128 && !getenv("DLWP_WINATTN_NOLDS");
+}
+
 int ws_setup(WsDev& a, int B_, int nW, int N, int TB, int ntypes, int heads, int d, float scale, int q_lo, int q_hi) {
     a.B_ = B_; a.nW = nW; a.N = N; a.TB = TB; a.ntypes = ntypes; a.heads = heads; a.d = d; a.scale = scale;
     const int nc = (N + 15) / 16;
@@ -481,6 +740,22 @@ int dlwp_winattn_small_bwd(const float* qkv, const float* table, const float* pa
     ws_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, q_lo, q_hi);
     a.qkv = qkv; a.table = table; a.table_t = packed; a.ia = ia; a.ib = ib; a.labels = labels; a.o = out; a.lse_in = lse;
     a.gout = gout; a.gqkv = gqkv; a.gtable = gtable;
+    if (lds_family_applies(N, d)) {
+        const int nc = (N + 15) / 16;
+        const size_t lb = lds_bytes(16 * nc, TB, true);
+        a.groups = lds_groups(a.M, heads, ntypes);
+        const dim3 grid((unsigned)(heads * ntypes * a.groups)), block(256);
+        auto go = [&](auto knl) -> int {
+            int rc2 = dlwp_ensure_lds(reinterpret_cast<const void*>(knl), lb, "winattn_lds_bwd");
+            if (rc2) return rc2;
+            hipLaunchKernelGGL(knl, grid, block, lb, (hipStream_t)stream, a);
+            return DLWP_OK;
+        };
+        const int rc3 = d <= 16 ? go(winattn_lds_bwd_kernel<1>) : go(winattn_lds_bwd_kernel<2>);
+        if (rc3) return rc3;
+        DLWP_LAUNCH_CHECK();
+        return DLWP_OK;
+    }
     const size_t lds = sizeof(float) * (3 * (size_t)((TB + 1) & ~1) + 4 * 128);
     const bool vec = d % 4 == 0;
     const dim3 grid((unsigned)(heads * ntypes * a.groups)), block(256);

@@ -234,3 +234,17 @@ def test_upconv_tokens_matches_conv_transpose(cuda, B, H, W, Cin, O, k, act):
     assert rel(xd.grad, xr.grad) <= 5e-4
     assert rel(up.weight.grad, ref.weight.grad) <= 5e-4
     assert rel(up.bias.grad, ref.bias.grad) <= 5e-4
+
+
+@pytest.mark.parametrize("T,N", [(3, 1000003), (4, 4096), (16, 64), (17, 64), (1000, 768), (16200, 3072), (33, 7), (257, 1028)])
+def test_colsum_accumulates_the_column_sums(cuda, T, N):
+    """dlwp_colsum: out[n] += sum_t g[t][n] -- the flat form (T <= 16: batch sum behind a position embedding's gradient, no
+    atomics) and the tall form (row slabs, 16-byte loads when aligned, float atomics), aligned and odd widths."""
+    from dlwp_benchmark_amd import lib as L
+    g = torch.Generator().manual_seed(T + N)
+    x = torch.randn(T, N, generator=g).to(cuda)
+    out = torch.randn(N, generator=g).to(cuda)
+    want = out.double() + x.double().sum(0)
+    L.check(L.load().dlwp_colsum(L.ptr(x), L.ptr(out), T, N, L.stream()))
+    torch.cuda.synchronize()
+    assert ((out.double() - want).abs().max() / want.abs().max()).item() <= 2e-6
