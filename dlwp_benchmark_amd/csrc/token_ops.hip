@@ -500,8 +500,217 @@ int gemm_launch_t(const GemmDev& a, dim3 grid, hipStream_t s) {
 
 int g_gemm_bf16 = 0;    // dlwp_set_gemm_precision
 
+// ---- (round 3) both operands bf16 arrays, both k-contiguous ("NT": y = x W^T): 128 x 128 x 64 tiles staged by LDS-DMA.
+// The register-staged kernel above spends a K-step of 32 on 4 global loads + 4 ds_write_b128 + a barrier per 16 MFMAs and
+// reaches ~480 TFLOP/s at the FourCastNet shapes (19 % of the bf16 peak).  Here a K-step is 64 deep (32 MFMAs per wave), the
+// operand tiles go global -> LDS with global_load_lds_dwordx4 (no staging registers, no LDS store pass), two stages, the loads of
+// step k + 1 in flight across the barriers of step k (raw s_barrier + counted vmcnt: cdna_hip_programming.md section 5,
+// "Pipelining across barriers").  LDS image of an operand tile: [128 rows][64 bf16] in 16-byte chunks, chunk c of row r stored
+// at chunk position c ^ ((r >> 1) & 7) -- the LDS side of an LDS-DMA is lane-linear, so the permutation is applied to the
+// per-lane GLOBAL address; a 16-lane group of a ds_read_b128 fragment read then covers all 64 banks.
+// Epilogue = the register-staged kernel's (bias, residual before / after the activation, GELU, GELU' multiply, stored
+// pre-activation, fp32 or bf16 output, accumulate), through an LDS tile in two halves of 64 rows.
+// BKC = false ("NN": gx = g W with W [N][K] read as the [k][n] operand): the B tile is [64 k][128 n], chunk c of k-row kr stored at
+// chunk position c ^ (2 (kr & 3)); its MFMA fragments come through the hardware transpose read (ds_read_b64_tr_b16, as in
+// TileIO::frag_bf16): per 16-lane group four k-rows x 32 bytes, 32 different banks.
+constexpr int GT = 128, GK = 64;
+template <bool BKC>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(GemmDev a) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    __bf16* lds = reinterpret_cast<__bf16*>(gsm);          // [2 stages][A | B][128][64]
+    constexpr int TILE = GT * GK;                          // bf16 elements of one operand tile (16 KB)
+    const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4, tid = threadIdx.x;
+    int tile_id = blockIdx.x;
+    {
+        const int nt = gridDim.x, full = (nt / 8) * 8;     // XCD-aware order, as in gemm_kernel
+        if (tile_id < full) tile_id = (tile_id % 8) * (nt / 8) + tile_id / 8;
+    }
+    constexpr int GM = 8;
+    const int grp = tile_id / (GM * a.ntn), within = tile_id - grp * GM * a.ntn;
+    const int rows_in = min(GM, a.ntm - grp * GM);
+    const int nt_ = within / rows_in, mt = grp * GM + (within - nt_ * rows_in);
+    const int m0 = mt * GT, n0 = nt_ * GT;
+    const __bf16* A = reinterpret_cast<const __bf16*>(a.A);
+    const __bf16* B = reinterpret_cast<const __bf16*>(a.B);
+    // per-lane source rows / chunks of the four LDS-DMA instructions per operand: LDS chunk p = (4 i + w) * 64 + lane holds
+    // logical chunk (p & 7) ^ ((row >> 1) & 7) of row p >> 3 (rows past the matrix edge re-read the last row: never stored)
+    const __bf16* asrc[4];
+    const __bf16* bsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = (4 * i + w) * 64 + lane, row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
+        asrc[i] = A + (long long)min(m0 + row, a.M - 1) * a.lda + 8 * c;
+        if (BKC) {
+            bsrc[i] = B + (long long)min(n0 + row, a.N - 1) * a.ldb + 8 * c;
+        } else {
+            const int kr = p >> 4, cn = (p & 15) ^ (2 * (kr & 3));        // k-row of the tile, logical 8-column chunk
+            bsrc[i] = B + (long long)kr * a.ldb + min(n0 + 8 * cn, a.N - 8);
+        }
+    }
+    auto issue = [&](int stage, int k0) {
+        __bf16* As = lds + stage * 2 * TILE;
+        __bf16* Bs = As + TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // wave-uniform LDS base of this instruction; the hardware adds lane * 16 bytes
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(As + (4 * i + w) * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + (BKC ? (long long)k0 : (long long)k0 * a.ldb)),
+                                             (__attribute__((address_space(3))) void*)(Bs + (4 * i + w) * 512), 16, 0, 0);
+        }
+    };
+    const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = a.K / GK;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) {
+            issue((kt + 1) & 1, (kt + 1) * GK);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this step's eight DMAs have landed; the next step's stay in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                              // ... for every wave of the workgroup
+        asm volatile("" ::: "memory");
+        const __bf16* As = lds + (kt & 1) * 2 * TILE;
+        const __bf16* Bs = As + TILE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wm + 16 * i + r, c = (4 * kk + g) ^ ((row >> 1) & 7);
+                af[i] = *reinterpret_cast<const bf16x8*>(As + row * GK + 8 * c);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (BKC) {
+                    const int row = wn + 16 * j + r, c = (4 * kk + g) ^ ((row >> 1) & 7);
+                    bf[j] = *reinterpret_cast<const bf16x8*>(Bs + row * GK + 8 * c);
+                } else {
+                    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+                    const int kr = 32 * kk + 8 * g + (r >> 2), nn = wn + 16 * j + 4 * (r & 3);      // (kr & 3) == (kr + 4) & 3
+                    const __bf16* p0 = Bs + kr * GT + 8 * ((nn >> 3) ^ (2 * (kr & 3))) + (nn & 4);
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * GT));
+                    bf[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // every wave has read this stage before it is refilled
+    }
+    // ---- epilogue (two halves of 64 rows through the dead operand buffers; 16-byte global accesses)
+    constexpr int LDE = GT + 4, C4 = GT / 4, RPP = 256 / C4, NPASS = 64 / RPP;
+    float* tile = gsm;
+    const int c4 = tid % C4, n = n0 + 4 * c4;
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias && n < a.N) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();
+        if (wm / 64 == half) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tile[(i * 16 + 4 * g + q) * LDE + wn + j * 16 + r] = acc[i][j][q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int row = tid / C4 + RPP * pass, m = m0 + 64 * half + row;
+            if (m < a.M && n < a.N) {
+                const long long o = (long long)m * a.ldc + n;
+                f32x4 v = *reinterpret_cast<const f32x4*>(&tile[row * LDE + 4 * c4]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] += bv[k];
+                f32x4 rv = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (a.residual) {
+                    if (a.dt & DT_R) {
+                        const bf16x4 hv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.residual) + o);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) rv[k] = (float)hv[k];
+                    } else {
+                        rv = *reinterpret_cast<const f32x4*>(a.residual + o);
+                    }
+                }
+                auto put = [&](float* dst, const f32x4& val) {
+                    if (a.dt & DT_C)
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(dst) + o) =
+                            bf16x4{(__bf16)val[0], (__bf16)val[1], (__bf16)val[2], (__bf16)val[3]};
+                    else
+                        *reinterpret_cast<f32x4*>(dst + o) = val;
+                };
+                if (a.act == ACT_GELU_GRAD_MUL) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] *= gelu_grad_f(rv[k]);
+                } else {
+                    if (a.res_pre) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] += rv[k];
+                    }
+                    if (a.preact) put(a.preact, v);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], a.act, a.act_param);
+                    if (!a.res_pre) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] += rv[k];
+                    }
+                }
+                if (a.accumulate) {
+                    const f32x4 cv = *reinterpret_cast<const f32x4*>(a.C + o);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] += cv[k];
+                }
+                put(a.C, v);
+            }
+        }
+    }
+}
+
+// shapes the LDS-DMA kernel takes: both operands bf16 arrays with k contiguous and 16-byte aligned rows, K a multiple of 64, one
+// plain product (no split-K / batches / row sums / row bias), the aligned epilogue, enough tiles to be worth 128 x 128
+static bool gemm_glds_applies(const GemmDev& a, bool akc, bool bkc) {
+    static const bool off = getenv("DLWP_GEMM_NOGLDS") != nullptr;
+    if (off || !g_gemm_bf16 || !akc || (a.dt & (DT_A | DT_B)) != (DT_A | DT_B)) return false;
+    if (a.K % GK || a.lda % 8 || a.ldb % 8 || (uintptr_t)a.A % 16 || (uintptr_t)a.B % 16) return false;
+    if (!bkc && a.N % 8) return false;
+    if (a.splits != 1 || a.nbatch != 1 || a.atomic_out || a.rowsum || a.bias_row || a.act_b || !a.vec_epi) return false;
+    // at least one workgroup per CU and four K-steps: below that the 64 x 64 kernel's shorter prologue wins (measured,
+    // profiles/r03_gemm_bench.txt: Pangu 8192 x 192 x 768 104 vs 120 TFLOP/s, 2048 x 1536 x 384 77 vs 93)
+    return a.K >= 4 * GK && (long long)ceil_div(a.M, GT) * ceil_div(a.N, GT) >= 256;
+}
+static int gemm_glds_launch(const GemmDev& a_in, bool bkc, hipStream_t s) {
+    GemmDev a = a_in;
+    a.ntn = ceil_div(a.N, GT);
+    a.ntm = ceil_div(a.M, GT);
+    const size_t lds = (size_t)2 * 2 * GT * GK * 2;            // 64 KB (the epilogue's 64 x 132 fp32 half tile fits inside)
+    int rc;
+    if (bkc) {
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_glds_kernel<true>), lds, "gemm_glds"))) return rc;
+        hipLaunchKernelGGL(gemm_glds_kernel<true>, dim3(a.ntn * a.ntm), dim3(256), lds, s, a);
+    } else {
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_glds_kernel<false>), lds, "gemm_glds"))) return rc;
+        hipLaunchKernelGGL(gemm_glds_kernel<false>, dim3(a.ntn * a.ntm), dim3(256), lds, s, a);
+    }
+    return DLWP_OK;
+}
+
+
+
 template <bool AKC, bool BKC>
 int gemm_launch(const GemmDev& a_in, int vec, int T, hipStream_t s) {
+    if (gemm_glds_applies(a_in, AKC, BKC)) return gemm_glds_launch(a_in, BKC, s);
     const int edge = 64 * T;
     GemmDev a = a_in;
     a.ntn = ceil_div(a.N, edge);

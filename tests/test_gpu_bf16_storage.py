@@ -189,3 +189,51 @@ def test_sfno_train_step_with_bf16_storage_tracks_fp32_storage(cuda):
     a, b = torch.tensor(losses["fp32"]), torch.tensor(losses["bf16"])
     assert a[-1] < a[0]
     assert ((a - b).abs() / a).max().item() < 3e-2, (losses["fp32"], losses["bf16"])
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 384, 192), (8192, 576, 192), (130, 128, 64), (4100, 768, 3072)])
+@pytest.mark.parametrize("epi", ["plain", "bias_gelu_preact_bf16", "residual_fp32", "gelu_grad_mul", "res_pre_accumulate"])
+def test_lds_dma_bf16_gemm_matches_the_register_staged_kernel(cuda, monkeypatch, M, N, K, epi):
+    """y = x W^T with both operands bf16 arrays: the 128 x 128 x 64 LDS-DMA kernel (csrc/token_ops.hip, gemm_glds_nt_kernel)
+    against the register-staged kernel (DLWP_GEMM_NOGLDS is read once per process, so the oracle here is a float64 product of
+    the bf16-rounded operands) for every epilogue the token layers use, with edge tiles in M and N."""
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.token_ops import _gemm, _gemm_batched
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(cuda).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(cuda).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g).to(cuda)
+    ref = x.double() @ w.double().T
+    with L.gemm_precision("bf16"):
+        if epi == "plain":
+            y = torch.empty(M, N, device=cuda)
+            _gemm(x, w, y, M, N, K, K, K, N, 0, 1)
+            want = ref
+        elif epi == "bias_gelu_preact_bf16":
+            y = torch.empty(M, N, device=cuda, dtype=torch.bfloat16)
+            z = torch.empty(M, N, device=cuda, dtype=torch.bfloat16)
+            _gemm(x, w, y, M, N, K, K, K, N, 0, 1, bias, 1, z, None)
+            pre = ref + bias.double()
+            assert ((z.double() - pre).abs().max() / pre.abs().max()).item() <= 1e-2
+            want = torch.nn.functional.gelu(pre)
+        elif epi == "residual_fp32":
+            r = torch.randn(M, N, generator=g).to(cuda)
+            y = torch.empty(M, N, device=cuda)
+            _gemm(x, w, y, M, N, K, K, K, N, 0, 1, bias, 0, None, r)
+            want = ref + bias.double() + r.double()
+        elif epi == "gelu_grad_mul":
+            zz = torch.randn(M, N, generator=g).to(cuda).to(torch.bfloat16)
+            y = torch.empty(M, N, device=cuda, dtype=torch.bfloat16)
+            _gemm_batched(x, w, y, M, N, K, K, K, N, 0, 1, act=4, residual=zz)
+            zd = zz.double().requires_grad_()
+            (gd,) = torch.autograd.grad(torch.nn.functional.gelu(zd).sum(), zd)
+            want = ref * gd
+        else:
+            r = torch.randn(M, N, generator=g).to(cuda)
+            y = torch.randn(M, N, generator=g).to(cuda)
+            y0 = y.double().clone()
+            _gemm_batched(x, w, y, M, N, K, K, K, N, 0, 1, bias=bias, act=1, residual=r, res_pre=1, accumulate=1)
+            want = y0 + torch.nn.functional.gelu(ref + bias.double() + r.double())
+    torch.cuda.synchronize()
+    tol = 1e-2 if y.dtype == torch.bfloat16 else 2e-5
+    assert ((y.double() - want).abs().max() / want.abs().max()).item() <= tol

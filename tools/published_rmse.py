@@ -106,7 +106,8 @@ def main():
         batches = [(x[i:i + 8].to(dev), y[i:i + 8].to(dev)) for i in range(0, x.shape[0], 8)]
         m = evaluate.evaluate_ns(model, batches, 10)
         emit({"what": f"test RMSE of {name} ({tag} checkpoint, epoch {ck['epoch']})", "published_rmse": PUBLISHED.get(a.hidden),
-              **{k: round(v, 5) for k, v in m.items()}, "ratio_to_published": round(m["rmse"] / PUBLISHED[a.hidden], 3) if a.hidden in PUBLISHED else None})
+              **{k: round(v, 5) for k, v in m.items()},
+              "ratio_closed_loop_to_published": round(m["rmse_cl"] / PUBLISHED[a.hidden], 3) if a.hidden in PUBLISHED else None})
 
 
 if __name__ == "__main__":
