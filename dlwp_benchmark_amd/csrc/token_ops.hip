@@ -508,6 +508,10 @@ int g_gemm_bf16 = 0;    // dlwp_set_gemm_precision
 // "Pipelining across barriers").  LDS image of an operand tile: [128 rows][64 bf16] in 16-byte chunks, chunk c of row r stored
 // at chunk position c ^ ((r >> 1) & 7) -- the LDS side of an LDS-DMA is lane-linear, so the permutation is applied to the
 // per-lane GLOBAL address; a 16-lane group of a ds_read_b128 fragment read then covers all 64 banks.
+// A weight-gradient ("TN", both tiles [k][row], K = tokens) variant was built and measured as well: unsplit it has 96 - 144
+// workgroups, one per CU, and a K-step costs ~1.4 us per workgroup whatever the pipeline depth (two or three stages: 364 us at
+// 3072 x 768 x 16200 against 183 us for the register-staged split-K kernel) -- the activation products only win because two
+// workgroups per CU cover each other; the weight gradients stay on gemm_kernel.
 // Epilogue = the register-staged kernel's (bias, residual before / after the activation, GELU, GELU' multiply, stored
 // pre-activation, fp32 or bf16 output, accumulate), through an LDS tile in two halves of 64 rows.
 // BKC = false ("NN": gx = g W with W [N][K] read as the [k][n] operand): the B tile is [64 k][128 n], chunk c of k-row kr stored at
@@ -686,6 +690,8 @@ static bool gemm_glds_applies(const GemmDev& a, bool akc, bool bkc) {
     if (a.K % GK || a.lda % 8 || a.ldb % 8 || (uintptr_t)a.A % 16 || (uintptr_t)a.B % 16) return false;
     if (!bkc && a.N % 8) return false;
     if (a.splits != 1 || a.nbatch != 1 || a.atomic_out || a.rowsum || a.bias_row || a.act_b || !a.vec_epi) return false;
+    static const bool force = getenv("DLWP_GEMM_GLDS_FORCE") != nullptr;          // measurement: skip the shape heuristic below
+    if (force) return a.M >= GT && a.N >= GT;
     // at least one workgroup per CU and four K-steps: below that the 64 x 64 kernel's shorter prologue wins (measured,
     // profiles/r03_gemm_bench.txt: Pangu 8192 x 192 x 768 104 vs 120 TFLOP/s, 2048 x 1536 x 384 77 vs 93)
     return a.K >= 4 * GK && (long long)ceil_div(a.M, GT) * ceil_div(a.N, GT) >= 256;

@@ -135,7 +135,13 @@ __global__ __launch_bounds__(256) void zero_2d_kernel(float* __restrict__ p, lon
     }
 }
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, float* out) {
+// The squared norm behind gradient clipping must come out BIT-IDENTICAL on every data-parallel rank (the ranks hold the same
+// all-reduced gradient; a last-bit difference in the clipping coefficient makes the replicas drift apart): float atomics add
+// the block partials in arrival order, so the partials go to a scratch array and a one-block kernel adds them in index order.
+// (One scratch per device: calls on different streams at the same time would share it; the training paths use one stream.)
+constexpr int SUMSQ_MAX_BLOCKS = 4096;
+__device__ float g_sumsq_partial[SUMSQ_MAX_BLOCKS];
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, float* part_out) {
     float acc = 0.f;
     const long long n4 = n / 4;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -147,7 +153,23 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
         const float d = g[n4 * 4 + threadIdx.x];
         acc += d * d;
     }
-    block_atomic_sum(acc, out);
+    __shared__ float part[4];
+    acc = wave_sum(acc);
+    if (lane_id() == 0) part[wave_id()] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part_out[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* __restrict__ part_in, int nblocks, float* out) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 256) acc += part_in[i];      // fixed order per thread
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {                                    // fixed tree
+        if ((int)threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out += red[0];
 }
 
 __global__ __launch_bounds__(256) void clip_scale_kernel(float* g, long long n, const float* sumsq,
@@ -314,7 +336,11 @@ extern "C" int dlwp_add_bcast(const float* t, const float* p, float* out, int B,
 extern "C" int dlwp_sumsq(const float* g, long long n, float* out, void* stream) {
     DLWP_REQUIRE(g && out && n >= 0, DLWP_E_INVALID, "sumsq: NULL argument");
     if (n == 0) return DLWP_OK;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, g, n, out);
+    const int blocks = std::min(stream_grid(n / 4 + 1), SUMSQ_MAX_BLOCKS);
+    static float* scratch = nullptr;                 // resolved once (never inside a stream capture after the first call)
+    if (!scratch) DLWP_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&scratch), HIP_SYMBOL(g_sumsq_partial)));
+    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, scratch);
+    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, blocks, out);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }

@@ -237,3 +237,38 @@ def test_lds_dma_bf16_gemm_matches_the_register_staged_kernel(cuda, monkeypatch,
     torch.cuda.synchronize()
     tol = 1e-2 if y.dtype == torch.bfloat16 else 2e-5
     assert ((y.double() - want).abs().max() / want.abs().max()).item() <= tol
+
+
+@pytest.mark.parametrize("M,N,K", [(3072, 768, 16200), (768, 3072, 4100), (1536, 1152, 2048)])
+def test_weight_gradient_gemm_of_bf16_arrays(cuda, M, N, K):
+    """gW = g^T x with both operands bf16 arrays (K = tokens, not a multiple of the K-step): split-K with float atomics into an
+    fp32 gradient that already holds a value, and the bias gradient (column sums of g) as a by-product."""
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.token_ops import _gemm
+    gen = torch.Generator().manual_seed(M + K)
+    g = torch.randn(K, M, generator=gen).to(cuda).to(torch.bfloat16)
+    x = torch.randn(K, N, generator=gen).to(cuda).to(torch.bfloat16)
+    gw = torch.randn(M, N, generator=gen).to(cuda)
+    gb = torch.randn(M, generator=gen).to(cuda)
+    want_w = gw.double() + g.double().T @ x.double()
+    want_b = gb.double() + g.double().sum(0)
+    with L.gemm_precision("bf16"):
+        _gemm(g, x, gw, M, N, K, M, N, N, 1, 0, accumulate=1, rowsum=gb)
+    torch.cuda.synchronize()
+    assert ((gw.double() - want_w).abs().max() / want_w.abs().max()).item() <= 2e-5
+    assert ((gb.double() - want_b).abs().max() / want_b.abs().max()).item() <= 2e-5
+
+
+def test_clipping_norm_is_bit_reproducible(cuda):
+    """dlwp_sumsq adds its block partials in index order: the same gradient gives the same bits every time (data-parallel ranks
+    compute the clipping coefficient independently from the same all-reduced gradient)."""
+    from dlwp_benchmark_amd import lib as L
+    lib = L.load()
+    g = torch.randn(3_000_017, device=cuda)
+    outs = []
+    for _ in range(5):
+        o = torch.zeros(1, device=cuda)
+        L.check(lib.dlwp_sumsq(L.ptr(g), g.numel(), L.ptr(o), L.stream()))
+        outs.append(o.item())
+    assert len(set(outs)) == 1
+    assert abs(outs[0] - float((g.double() ** 2).sum())) <= 1e-5 * outs[0]

@@ -17,6 +17,9 @@ BF = torch.bfloat16
 SHAPES = [  # (tokens T, out N, in K, label)
     (16200, 3072, 768, "C5 AFNO fc1"), (16200, 768, 3072, "C5 AFNO fc2"),
     (32768, 512, 256, "C3 SFNO mlp fc1 B16"), (32768, 256, 512, "C3 SFNO mlp fc2 B16"),
+    (8192, 512, 256, "C3 SFNO mlp fc1 B4"), (8192, 256, 512, "C3 SFNO mlp fc2 B4"),
+    (32768, 576, 192, "C4 Pangu qkv (layer1)"), (32768, 768, 192, "C4 Pangu fc1 (layer1, real tokens)"),
+    (8192, 1536, 384, "C4 Pangu fc1 (layer2, real tokens)"),
     (8192, 768, 192, "C4 Pangu fc1 (layer1)"), (2048, 1536, 384, "C4 Pangu fc1 (layer2)"),
     (32768, 384, 96, "C4 Swin fc1 (stage 1)"),
 ]
