@@ -309,7 +309,9 @@ def sfno_gemm_probe(device, B, precision, reps=100, storage="fp32", shape=(32 * 
     nbytes = float(x.element_size() * M * K + w.element_size() * N * K + (y.element_size() + z.element_size()) * M * N + 4 * N)
     f_mfma, f_hbm = flops / sec / 1e12 / peak, nbytes / sec / 1e9 / PEAK_HBM_GBS
     out = {"bound": "mfma" if f_mfma >= f_hbm else "hbm",
-           "kernel": f"gemm_kernel (MLP fc1 {M}x{N}x{K}, bias+GELU epilogue, {precision} operands, {storage} storage of x / W / h / z)",
+           "kernel": f"block-MLP fc1 GEMM {M}x{N}x{K} with the bias + GELU + stored pre-activation epilogue, {precision} operands, {storage} "
+                     f"storage of x / W / h / z (gemm_glds_kernel when both operands are bf16 arrays, K >= 256 and >= 256 output tiles; "
+                     f"gemm_kernel otherwise)",
            "flops_per_launch": flops, "bytes_per_launch": nbytes, "us_per_launch": round(sec * 1e6, 3), "traffic": None,
            "mfma": {"achieved": round(flops / sec / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(f_mfma, 4)},
            "hbm": {"achieved": round(nbytes / sec / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(f_hbm, 4)}}

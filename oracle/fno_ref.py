@@ -208,7 +208,10 @@ def spectral_conv3d(x, weight, bias, n_modes):
     out = torch.zeros(B, weight.shape[1], T, H, W // 2 + 1, dtype=X.dtype)
     s0, s1, s2 = _mode_slices(T, m0), _mode_slices(H, m1), slice(None, min(m2c, W // 2 + 1))
     out[:, :, s0, s1, s2] = torch.einsum("bixyz,ioxyz->boxyz", X[:, :, s0, s1, s2], weight)
-    out = torch.fft.ifftshift(out, dim=(-3, -2))
+    # fftshift on the way back too, as in the 2-D form above: the upstream SpectralConv of the pinned neuralop commit applies
+    # torch.fft.fftshift in both directions (recalled, not verifiable here: neuralop is absent); on even sizes -- every shipped
+    # and tested configuration -- fftshift and ifftshift are the same permutation
+    out = torch.fft.fftshift(out, dim=(-3, -2))
     y = torch.fft.irfftn(out, s=(T, H, W), dim=(-3, -2, -1), norm="forward")
     if bias is not None:
         y = y + bias.view(1, -1, 1, 1, 1)
