@@ -512,6 +512,8 @@ int g_gemm_bf16 = 0;    // dlwp_set_gemm_precision
 // workgroups, one per CU, and a K-step costs ~1.4 us per workgroup whatever the pipeline depth (two or three stages: 364 us at
 // 3072 x 768 x 16200 against 183 us for the register-staged split-K kernel) -- the activation products only win because two
 // workgroups per CU cover each other; the weight gradients stay on gemm_kernel.
+// A four-stage ring (128 KB, three K-steps of loads in flight, one workgroup per CU) was measured too: 25 - 60 % slower wherever
+// two workgroups per CU fit, equal at the 256-tile shapes -- the second workgroup hides more than the deeper ring does.
 // Epilogue = the register-staged kernel's (bias, residual before / after the activation, GELU, GELU' multiply, stored
 // pre-activation, fp32 or bf16 output, accumulate), through an LDS tile in two halves of 64 rows.
 // BKC = false ("NN": gx = g W with W [N][K] read as the [k][n] operand): the B tile is [64 k][128 n], chunk c of k-row kr stored at
@@ -1112,6 +1114,11 @@ static int gemm_dispatch(GemmDev& a, int transA, int transB, int T, void* stream
                     (a.bias_row || (a.sBi1 % 4 == 0 && a.sBi2 % 4 == 0));
     const hipStream_t s = (hipStream_t)stream;
     int rc;
+    static const bool trace = getenv("DLWP_GEMM_TRACE") != nullptr;      // shape census of an eager step: sort | uniq -c
+    if (trace)
+        fprintf(stderr, "gemm %c%c M=%d N=%d K=%d nb=%lld splits=%d dt=%d vec=%d epi=%d bias=%d res=%d act=%d rowsum=%d\n", transA ? 'T' : 'N',
+                transB ? 'T' : 'N', a.M, a.N, a.K, (long long)a.nbatch, a.splits, a.dt, vec, (int)a.vec_epi, a.bias != nullptr,
+                a.residual != nullptr, a.act, a.rowsum != nullptr);
     // A is k-contiguous when not transposed ([M][K]); B is k-contiguous when transposed ([N][K])
     if (!transA && transB) rc = gemm_launch<true, true>(a, vec, T, s);
     else if (!transA && !transB) rc = gemm_launch<true, false>(a, vec, T, s);
