@@ -520,11 +520,13 @@ int g_gemm_bf16 = 0;    // dlwp_set_gemm_precision
 // chunk position c ^ (2 (kr & 3)); its MFMA fragments come through the hardware transpose read (ds_read_b64_tr_b16, as in
 // TileIO::frag_bf16): per 16-lane group four k-rows x 32 bytes, 32 different banks.
 constexpr int GT = 128, GK = 64;
-template <bool BKC>
+template <bool BKC, int KD>                                // KD = depth of a K-step: 64 (two workgroups per CU) or 32 (three / four)
 __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmDev a) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
-    __bf16* lds = reinterpret_cast<__bf16*>(gsm);          // [2 stages][A | B][128][64]
-    constexpr int TILE = GT * GK;                          // bf16 elements of one operand tile (16 KB)
+    __bf16* lds = reinterpret_cast<__bf16*>(gsm);          // [2 stages][A | B][128][KD]
+    constexpr int TILE = GT * KD;                          // bf16 elements of one operand tile
+    constexpr int NI = KD / 16;                            // LDS-DMA instructions per wave, operand and stage
+    constexpr int CPR = KD / 8, LCPR = KD == 64 ? 3 : 2;   // 16-byte chunks per k-contiguous row
     const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4, tid = threadIdx.x;
     int tile_id = blockIdx.x;
     {
@@ -538,13 +540,16 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmDev a) {
     const int m0 = mt * GT, n0 = nt_ * GT;
     const __bf16* A = reinterpret_cast<const __bf16*>(a.A);
     const __bf16* B = reinterpret_cast<const __bf16*>(a.B);
-    // per-lane source rows / chunks of the four LDS-DMA instructions per operand: LDS chunk p = (4 i + w) * 64 + lane holds
-    // logical chunk (p & 7) ^ ((row >> 1) & 7) of row p >> 3 (rows past the matrix edge re-read the last row: never stored)
-    const __bf16* asrc[4];
-    const __bf16* bsrc[4];
+    // chunk swizzle of a k-contiguous row: a 16-lane group of a ds_read_b128 fragment read (16 rows, one chunk column) must
+    // cover 16 different 16-byte slots of the 256-byte bank row: 128-byte rows pair up, 64-byte rows come four to a bank row
+    auto sw = [](int row) { return KD == 64 ? (row >> 1) & 7 : (row >> 2) & 3; };
+    // per-lane source rows / chunks of the LDS-DMA instructions per operand: LDS chunk p = (4 i + w) * 64 + lane holds logical
+    // chunk (p % CPR) ^ sw(row) of row p / CPR (rows past the matrix edge re-read the last row: never stored)
+    const __bf16* asrc[NI];
+    const __bf16* bsrc[NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int p = (4 * i + w) * 64 + lane, row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
+    for (int i = 0; i < NI; ++i) {
+        const int p = (4 * i + w) * 64 + lane, row = p >> LCPR, c = (p & (CPR - 1)) ^ sw(row);
         asrc[i] = A + (long long)min(m0 + row, a.M - 1) * a.lda + 8 * c;
         if (BKC) {
             bsrc[i] = B + (long long)min(n0 + row, a.N - 1) * a.ldb + 8 * c;
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmDev a) {
         __bf16* As = lds + stage * 2 * TILE;
         __bf16* Bs = As + TILE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             // wave-uniform LDS base of this instruction; the hardware adds lane * 16 bytes
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + k0),
                                              (__attribute__((address_space(3))) void*)(As + (4 * i + w) * 512), 16, 0, 0);
@@ -571,12 +576,14 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmDev a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nk = a.K / GK;
+    const int nk = a.K / KD;
     issue(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) {
-            issue((kt + 1) & 1, (kt + 1) * GK);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this step's eight DMAs have landed; the next step's stay in flight
+            issue((kt + 1) & 1, (kt + 1) * KD);
+            // this step's DMAs have landed; the next step's stay in flight
+            if (KD == 64) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -585,18 +592,18 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmDev a) {
         const __bf16* As = lds + (kt & 1) * 2 * TILE;
         const __bf16* Bs = As + TILE;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < KD / 32; ++kk) {
             bf16x8 af[4], bf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = wm + 16 * i + r, c = (4 * kk + g) ^ ((row >> 1) & 7);
-                af[i] = *reinterpret_cast<const bf16x8*>(As + row * GK + 8 * c);
+                const int row = wm + 16 * i + r, c = (4 * kk + g) ^ sw(row);
+                af[i] = *reinterpret_cast<const bf16x8*>(As + row * KD + 8 * c);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (BKC) {
-                    const int row = wn + 16 * j + r, c = (4 * kk + g) ^ ((row >> 1) & 7);
-                    bf[j] = *reinterpret_cast<const bf16x8*>(Bs + row * GK + 8 * c);
+                    const int row = wn + 16 * j + r, c = (4 * kk + g) ^ sw(row);
+                    bf[j] = *reinterpret_cast<const bf16x8*>(Bs + row * KD + 8 * c);
                 } else {
                     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
                     const int kr = 32 * kk + 8 * g + (r >> 2), nn = wn + 16 * j + 4 * (r & 3);      // (kr & 3) == (kr + 4) & 3
@@ -684,12 +691,177 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmDev a) {
     }
 }
 
+// ---- weight gradients ("TN": gW = g^T x, both operands [k = tokens][row]): both tiles are [KD k][128] images with the NN
+// kernel's B-tile swizzle and both fragments come through the transposing read.  K is split over blockIdx.z (fp32 atomic adds
+// into the zeroed / accumulating output, as gemm_kernel's split-K); the token count need not be a multiple of the K-step: the
+// DMAs of a partial last step re-read row K - 1 and the A fragments of k >= K are zeroed.  rowsum (bias gradient) = sum over k
+// of the A fragments, flushed by the n0 == 0 tiles.
+template <int KD>
+__global__ __launch_bounds__(256) void gemm_glds_tn_kernel(GemmDev a) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    __bf16* lds = reinterpret_cast<__bf16*>(gsm);          // [2 stages][A | B][KD][128]
+    constexpr int TILE = GT * KD, NI = KD / 16;
+    const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
+    int tile_id = blockIdx.x;
+    {
+        const int nt = gridDim.x, full = (nt / 8) * 8;
+        if (tile_id < full) tile_id = (tile_id % 8) * (nt / 8) + tile_id / 8;
+    }
+    const int mt = tile_id / a.ntn, nt_ = tile_id - mt * a.ntn;
+    const int m0 = mt * GT, n0 = nt_ * GT;
+    const int kbeg = blockIdx.z * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
+    const __bf16* A = reinterpret_cast<const __bf16*>(a.A);
+    const __bf16* B = reinterpret_cast<const __bf16*>(a.B);
+    int krow[NI], acol[NI], bcol[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int p = (4 * i + w) * 64 + lane, kr = p >> 4, c = (p & 15) ^ (2 * (kr & 3));
+        krow[i] = kr;
+        acol[i] = min(m0 + 8 * c, a.M - 8);
+        bcol[i] = min(n0 + 8 * c, a.N - 8);
+    }
+    auto issue = [&](int stage, int k0) {
+        __bf16* As = lds + stage * 2 * TILE;
+        __bf16* Bs = As + TILE;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const long long kk = min(k0 + krow[i], a.K - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + kk * a.lda + acol[i]),
+                                             (__attribute__((address_space(3))) void*)(As + (4 * i + w) * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + kk * a.ldb + bcol[i]),
+                                             (__attribute__((address_space(3))) void*)(Bs + (4 * i + w) * 512), 16, 0, 0);
+        }
+    };
+    const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float rsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool want_rsum = a.rowsum && n0 == 0 && !(w & 1);
+    const int nk = (kend - kbeg + KD - 1) / KD;
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    auto frag = [&](const __bf16* tile, int col0, int kk) {      // rows col0 + r of the operand, k = 32 kk + 8 g .. + 7
+        const int kr = 32 * kk + 8 * g + (r >> 2), cc = col0 + 4 * (r & 3);
+        const __bf16* p0 = tile + kr * GT + 8 * ((cc >> 3) ^ (2 * (kr & 3))) + (cc & 4);
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * GT));
+        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    if (nk > 0) issue(0, kbeg);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int k0 = kbeg + kt * KD;
+        if (kt + 1 < nk) {
+            issue((kt + 1) & 1, k0 + KD);
+            if (KD == 64) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const __bf16* As = lds + (kt & 1) * 2 * TILE;
+        const __bf16* Bs = As + TILE;
+        const bool tail = k0 + KD > kend;
+#pragma unroll
+        for (int kk = 0; kk < KD / 32; ++kk) {
+            bf16x8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = frag(As, wm + 16 * i, kk);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = frag(Bs, wn + 16 * j, kk);
+            if (tail) {
+                const int kl = kend - (k0 + 32 * kk + 8 * g);        // this lane's fragment elements e >= kl lie past the end
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (e >= kl) af[i][e] = (__bf16)0.f;
+            }
+            if (want_rsum) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rsum[i] += (float)af[i][e];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    if (want_rsum) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = rsum[i];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            const int m = m0 + wm + 16 * i + r;
+            if (g == 0 && m < a.M) atomic_add_f32(&a.rowsum[m], v);
+        }
+    }
+    const bool atomic = a.splits > 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + wm + i * 16 + 4 * g + q, n = n0 + wn + j * 16 + r;
+                if (m < a.M && n < a.N) {
+                    float* dst = a.C + (long long)m * a.ldc + n;
+                    if (atomic) atomic_add_f32(dst, acc[i][j][q]);          // C zeroed by the caller (or accumulating)
+                    else *dst = a.accumulate ? *dst + acc[i][j][q] : acc[i][j][q];
+                }
+            }
+}
+
+// weight-gradient products the TN kernel takes: both operands bf16 arrays [k][row], fp32 output, no epilogue, one batch, the
+// caller already prepared for split-K (zeroed or accumulating output)
+static bool gemm_glds_tn_applies(const GemmDev& a) {
+    static const bool off = getenv("DLWP_GEMM_NOGLDS") != nullptr || getenv("DLWP_GEMM_NOGLDS_TN") != nullptr;
+    if (off || !g_gemm_bf16 || (a.dt & (DT_A | DT_B | DT_C | DT_R)) != (DT_A | DT_B)) return false;
+    if (a.M % 8 || a.N % 8 || a.lda % 8 || a.ldb % 8 || (uintptr_t)a.A % 16 || (uintptr_t)a.B % 16) return false;
+    if (a.nbatch != 1 || a.atomic_out || a.bias || a.residual || a.preact || a.act || a.act_b || a.bias_row) return false;
+    return a.M >= GT && a.N >= GT && a.K >= 1024 && a.splits > 1;
+}
+static int gemm_glds_tn_launch(const GemmDev& a_in, hipStream_t s) {
+    GemmDev a = a_in;
+    a.ntn = ceil_div(a.N, GT);
+    a.ntm = ceil_div(a.M, GT);
+    // K-step depth and slices from the sweep in profiles/r03_gemm_glds_tn.txt: the grid should fill the resident slots once (a second,
+    // partial round costs as much as a full one): 64 deep = 64 KB of LDS, two workgroups per CU; 32 deep = 32 KB and 160 VGPRs, three
+    // per CU, which pays once there are enough output tiles (FourCastNet's 3072 x 768: 120 us against 133)
+    static const char* kd_env = getenv("DLWP_GEMM_GLDS_TN_KD");
+    const bool shallow = kd_env ? atoi(kd_env) == 32 : a.ntn * a.ntm >= 96;
+    const int kd = shallow ? 32 : 64;
+    static const char* wg_env = getenv("DLWP_GEMM_GLDS_TN_WGS");
+    const int slots = wg_env ? atoi(wg_env) : (shallow ? 768 : 448);
+    int splits = std::max(1, std::min(slots / (a.ntn * a.ntm), a.K / (4 * kd)));
+    a.kchunk = ceil_div(ceil_div(a.K, splits), kd) * kd;
+    a.splits = std::max(2, ceil_div(a.K, a.kchunk));             // > 1: the atomic epilogue (the caller zeroed C for its own split)
+    const size_t lds = (size_t)2 * 2 * GT * kd * 2;
+    const dim3 grid(a.ntn * a.ntm, 1, ceil_div(a.K, a.kchunk));
+    int rc;
+    if (shallow) {
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_glds_tn_kernel<32>), lds, "gemm_glds_tn"))) return rc;
+        hipLaunchKernelGGL(gemm_glds_tn_kernel<32>, grid, dim3(256), lds, s, a);
+    } else {
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_glds_tn_kernel<64>), lds, "gemm_glds_tn"))) return rc;
+        hipLaunchKernelGGL(gemm_glds_tn_kernel<64>, grid, dim3(256), lds, s, a);
+    }
+    return DLWP_OK;
+}
+
 // shapes the LDS-DMA kernel takes: both operands bf16 arrays with k contiguous and 16-byte aligned rows, K a multiple of 64, one
 // plain product (no split-K / batches / row sums / row bias), the aligned epilogue, enough tiles to be worth 128 x 128
 static bool gemm_glds_applies(const GemmDev& a, bool akc, bool bkc) {
     static const bool off = getenv("DLWP_GEMM_NOGLDS") != nullptr;
     if (off || !g_gemm_bf16 || !akc || (a.dt & (DT_A | DT_B)) != (DT_A | DT_B)) return false;
-    if (a.K % GK || a.lda % 8 || a.ldb % 8 || (uintptr_t)a.A % 16 || (uintptr_t)a.B % 16) return false;
+    if (a.K % 32 || a.lda % 8 || a.ldb % 8 || (uintptr_t)a.A % 16 || (uintptr_t)a.B % 16) return false;
     if (!bkc && a.N % 8) return false;
     if (a.splits != 1 || a.nbatch != 1 || a.atomic_out || a.rowsum || a.bias_row || a.act_b || !a.vec_epi) return false;
     static const bool force = getenv("DLWP_GEMM_GLDS_FORCE") != nullptr;          // measurement: skip the shape heuristic below
@@ -702,15 +874,22 @@ static int gemm_glds_launch(const GemmDev& a_in, bool bkc, hipStream_t s) {
     GemmDev a = a_in;
     a.ntn = ceil_div(a.N, GT);
     a.ntm = ceil_div(a.M, GT);
-    const size_t lds = (size_t)2 * 2 * GT * GK * 2;            // 64 KB (the epilogue's 64 x 132 fp32 half tile fits inside)
+    static const char* kd_env = getenv("DLWP_GEMM_GLDS_KD");
+    // depth of a K-step (profiles/r03_gemm_glds_kd.txt): 32 deep leaves room for three or four workgroups per CU, which wins for
+    // y = x W^T up to K ~ 1000 (16200 x 3072 x 768: 122 -> 110 us) and for gx = g W with at least four column tiles (16200 x 768 x 3072:
+    // 122 -> 96 us, 8192^3: 841 -> 945 TFLOP/s); the deep, long products stay at 64 (8192^3 y: 1001 TFLOP/s against 828)
+    const bool shallow = a.K % GK != 0 || (kd_env ? atoi(kd_env) == 32 : (bkc ? a.K <= 1024 : a.N >= 512));
+    // 64 KB at KD = 64 (the epilogue's 64 x 132 fp32 half tile fits inside); 33 KB (that half tile) at KD = 32
+    const size_t lds = shallow ? sizeof(float) * 64 * (GT + 4) : (size_t)2 * 2 * GT * GK * 2;
     int rc;
-    if (bkc) {
-        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_glds_kernel<true>), lds, "gemm_glds"))) return rc;
-        hipLaunchKernelGGL(gemm_glds_kernel<true>, dim3(a.ntn * a.ntm), dim3(256), lds, s, a);
-    } else {
-        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_glds_kernel<false>), lds, "gemm_glds"))) return rc;
-        hipLaunchKernelGGL(gemm_glds_kernel<false>, dim3(a.ntn * a.ntm), dim3(256), lds, s, a);
-    }
+#define GLDS_GO(BKC_, KD_)                                                                                              \
+    do {                                                                                                                \
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_glds_kernel<BKC_, KD_>), lds, "gemm_glds"))) return rc; \
+        hipLaunchKernelGGL((gemm_glds_kernel<BKC_, KD_>), dim3(a.ntn * a.ntm), dim3(256), lds, s, a);                     \
+    } while (0)
+    if (bkc) { if (shallow) GLDS_GO(true, 32); else GLDS_GO(true, 64); }
+    else     { if (shallow) GLDS_GO(false, 32); else GLDS_GO(false, 64); }
+#undef GLDS_GO
     return DLWP_OK;
 }
 
@@ -719,6 +898,7 @@ static int gemm_glds_launch(const GemmDev& a_in, bool bkc, hipStream_t s) {
 template <bool AKC, bool BKC>
 int gemm_launch(const GemmDev& a_in, int vec, int T, hipStream_t s) {
     if (gemm_glds_applies(a_in, AKC, BKC)) return gemm_glds_launch(a_in, BKC, s);
+    if (!AKC && !BKC && gemm_glds_tn_applies(a_in)) return gemm_glds_tn_launch(a_in, s);
     const int edge = 64 * T;
     GemmDev a = a_in;
     a.ntn = ceil_div(a.N, edge);

@@ -239,7 +239,7 @@ def test_lds_dma_bf16_gemm_matches_the_register_staged_kernel(cuda, monkeypatch,
     assert ((y.double() - want).abs().max() / want.abs().max()).item() <= tol
 
 
-@pytest.mark.parametrize("M,N,K", [(3072, 768, 16200), (768, 3072, 4100), (1536, 1152, 2048)])
+@pytest.mark.parametrize("M,N,K", [(3072, 768, 16200), (768, 3072, 4100), (1536, 1152, 2048), (200, 136, 5000), (128, 128, 1027)])
 def test_weight_gradient_gemm_of_bf16_arrays(cuda, M, N, K):
     """gW = g^T x with both operands bf16 arrays (K = tokens, not a multiple of the K-step): split-K with float atomics into an
     fp32 gradient that already holds a value, and the bias gradient (column sums of g) as a by-product."""

@@ -23,6 +23,8 @@ SHAPES = [  # (tokens T, out N, in K, label)
     (8192, 768, 192, "C4 Pangu fc1 (layer1)"), (2048, 1536, 384, "C4 Pangu fc1 (layer2)"),
     (32768, 384, 96, "C4 Swin fc1 (stage 1)"),
 ]
+if os.environ.get("DLWP_BENCH_GEMM_CUBES"):      # structure ceiling of the kernels, away from the model shapes
+    SHAPES = [(4096, 4096, 4096, "cube 4k"), (8192, 8192, 8192, "cube 8k")] + SHAPES[:2]
 
 
 def timeit(fn, n=20):
@@ -57,8 +59,9 @@ def main():
             y = torch.empty(T, N, device=dev, dtype=xs.dtype)
             gx = torch.empty(T, K, device=dev, dtype=xs.dtype)
             gw = torch.empty(N, K, device=dev)
-            rows["y=xW^T"].append(timeit(lambda: _gemm(xs, ws, y, T, N, K, K, K, N, 0, 1)))
-            rows["gx=gW"].append(timeit(lambda: _gemm(gs, ws, gx, T, K, N, N, K, K, 0, 0)))
+            only_gw = os.environ.get("DLWP_BENCH_GEMM_ONLY") == "gW"      # sweeps of the weight-gradient kernel
+            rows["y=xW^T"].append(1e9 if only_gw else timeit(lambda: _gemm(xs, ws, y, T, N, K, K, K, N, 0, 1)))
+            rows["gx=gW"].append(1e9 if only_gw else timeit(lambda: _gemm(gs, ws, gx, T, K, N, N, K, K, 0, 0)))
             rows["gW=g^Tx"].append(timeit(lambda: _gemm(gs, xs, gw, N, K, T, N, K, K, 1, 0)))
         L.set_gemm_precision("fp32")
         for prod, ts in rows.items():
