@@ -142,18 +142,18 @@ def afno2d_fft(x, w1, b1, w2, b2, num_blocks, sparsity_threshold=0.01, hard_thre
     """AFNO2D on the LDS-staged rFFT2 / irFFT2 kernels (fft.py, csrc/fft2d.hip) instead of dense DFT GEMMs: linear-ish in the
     grid size, so this is the path of patch-1 grids (dlwpbench fourcastnet.yaml: patch_size [1, 1]; 128 x 256, 721 x 1440).
     x [B, H, W, C] -> AFNO2D(x) including the residual `+ x`; the block-diagonal complex MLP on the kept modes is the same
-    batched-GEMM node as in the tiled path (planar re | im spectra), the kept window is cut out of / written back into the
-    half spectrum by torch copies (data movement only)."""
+    batched-GEMM node as in the tiled path (planar re | im spectra); the transforms themselves read / write the kept window in
+    that layout (fft.rfft2_planar / irfft2_planar)."""
     from . import fft
     from .token_ops import add_tokens
     B, H, W, C = x.shape
     x = x.contiguous().float()
     r0, r1, c1 = kept_window(H, W, hard_thresholding_fraction)
     R = r1 - r0
-    X = fft.rfft2(x, "channels_last", "ortho")                                   # [B, H, W/2+1, C, 2]
-    planar = X[:, r0:r1, :c1].permute(4, 0, 1, 2, 3).reshape(2, B * R * c1, C)
+    # the transforms read / write the kept window in the planar layout of the block GEMMs: no window copies, no zero fill, and
+    # the H pass of the forward transform skips the columns outside the window
+    win = (r0, r1, c1)
+    planar = fft.rfft2_planar(x, "ortho", win).view(2, B * R * c1, C)
     o1 = _BlockComplexLinear.apply(planar, w1, b1, 2, 0.0)
     o2 = _BlockComplexLinear.apply(o1, w2, b2, 3, float(sparsity_threshold))
-    Y = torch.zeros_like(X)                                                      # modes outside the window are zero (:98-117)
-    Y[:, r0:r1, :c1] = o2.reshape(2, B, R, c1, C).permute(1, 2, 3, 4, 0)
-    return add_tokens(fft.irfft2(Y, W, "channels_last", "ortho"), x)
+    return add_tokens(fft.irfft2_planar(o2.view(2, B, R, c1, C), H, W, "ortho", win), x)

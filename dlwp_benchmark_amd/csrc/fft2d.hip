@@ -277,6 +277,11 @@ struct FftIO {
     long long J;              // C2C: inner contiguous length (complex), axis stride = J
     float scale, w_int;       // output scale; weight of the interior (non-DC, non-Nyquist) bins
     float sg;                 // C2C direction
+    // C2C: plane == 0: interleaved (re, im) pairs, element (o, n, j) at (o * N + n) * J + j.  Otherwise that side is a planar
+    // WINDOW of the spectrum, rows r0 <= n < r1 and inner positions j < Jw: re at (o * (r1 - r0) + n - r0) * Jw + j, im `plane`
+    // floats further; read: everything outside the window is zero; written: only the window is
+    long long plane_in, plane_out, Jw;
+    int r0, r1;
 };
 
 __device__ __forceinline__ void load_table(float2* tabs, const FftAxis& f) {
@@ -419,19 +424,48 @@ __global__ __launch_bounds__(NT) void fft_c2c_kernel(FftIO a) {
     load_table(tabs, f);
     const long long o = blockIdx.y, j0 = (long long)blockIdx.x * f.IB;
     const int nl = (int)min((long long)f.IB, a.J - j0);
-    const float2* src = reinterpret_cast<const float2*>(a.in) + o * N * a.J + j0;
+    const long long base = o * N * a.J + j0;
+    const int R = a.r1 - a.r0;
+    const long long wbase = o * R * a.Jw + j0;
+    float2* dst = reinterpret_cast<float2*>(a.out) + base;
+    if (a.plane_in && j0 >= a.Jw) {                   // a column block outside the window: its transform is zero
+        for (int e = threadIdx.x; e < N << f.logIB; e += NT) {
+            const int lane = e & (f.IB - 1), n = e >> f.logIB;
+            if (lane < nl) dst[(long long)n * a.J + lane] = make_float2(0.f, 0.f);
+        }
+        return;
+    }
+    const float2* src = reinterpret_cast<const float2*>(a.in) + base;
     for (int e = threadIdx.x; e < N << f.logIB; e += NT) {
         const int lane = e & (f.IB - 1), n = e >> f.logIB;
-        buf[n * IBP + lane] = lane < nl ? src[(long long)n * a.J + lane] : make_float2(0.f, 0.f);
+        float2 z = make_float2(0.f, 0.f);
+        if (lane < nl) {
+            if (a.plane_in) {
+                if (n >= a.r0 && n < a.r1 && j0 + lane < a.Jw) {
+                    const long long i = wbase + (long long)(n - a.r0) * a.Jw + lane;
+                    z = make_float2(a.in[i], a.in[a.plane_in + i]);
+                }
+            } else {
+                z = src[(long long)n * a.J + lane];
+            }
+        }
+        buf[n * IBP + lane] = z;
     }
     __syncthreads();
     lds_fft<OUTS, NT, PRIME>(buf, tabs, f, a.sg);
-    float2* dst = reinterpret_cast<float2*>(a.out) + o * N * a.J + j0;
     for (int e = threadIdx.x; e < N << f.logIB; e += NT) {
         const int lane = e & (f.IB - 1), n = e >> f.logIB;
         if (lane < nl) {
             const float2 z = buf[n * IBP + lane];
-            dst[(long long)n * a.J + lane] = make_float2(a.scale * z.x, a.scale * z.y);
+            if (a.plane_out) {
+                if (n >= a.r0 && n < a.r1 && j0 + lane < a.Jw) {
+                    const long long i = wbase + (long long)(n - a.r0) * a.Jw + lane;
+                    a.out[i] = a.scale * z.x;
+                    a.out[a.plane_out + i] = a.scale * z.y;
+                }
+            } else {
+                dst[(long long)n * a.J + lane] = make_float2(a.scale * z.x, a.scale * z.y);
+            }
         }
     }
 }
@@ -586,9 +620,11 @@ int run_w_real(const dlwp_fft_plan* p, bool to_complex, bool cf, const float* in
 }
 
 int run_h_c2c(const dlwp_fft_plan* p, const float* in, float* out, long long outer, long long J, float sg, float scale,
-              hipStream_t stream) {
+              hipStream_t stream, long long plane_in = 0, long long plane_out = 0, int r0 = 0, int r1 = 0, long long Jw = 0) {
     FftIO io{};
     io.ax = p->axH; io.in = in; io.out = out; io.J = J; io.sg = sg; io.scale = scale;
+    io.plane_in = plane_in; io.plane_out = plane_out; io.r0 = r0; io.r1 = r1; io.Jw = Jw;
+    if (plane_out) J = Jw;            // only the window's columns are transformed
     DLWP_REQUIRE(outer <= 65535, DLWP_E_UNSUPPORTED, "fft: more than 65535 outer slices per call (%lld)", outer);
     const dim3 grid((unsigned)((J + io.ax.IB - 1) / io.ax.IB), (unsigned)outer);
     const LaunchShape sh = shape_of(io.ax);
@@ -660,4 +696,41 @@ extern "C" int dlwp_irfft2(const dlwp_fft_plan* p, const float* X, float* x, flo
     int rc = run_h_c2c(p, X, work, outer, J, +1.f, adjoint ? sHf : sHi, stream);
     if (rc) return rc;
     return run_w_real(p, false, layout == 1, work, x, B, C, adjoint ? sWf : sWi, adjoint ? 0.5f : 1.f, stream);
+}
+
+// Channels-last transforms with a WINDOW of the half spectrum as two planes, X [2 (re | im)][B][r1 - r0][c1][C]: rows r0 <= kh < r1
+// and columns kw < c1 of rfft2's [B][H][W/2+1][C] -- the operand of the AFNO mixer's block-diagonal GEMMs on the kept modes
+// (afno_tiled._BlockComplexLinear), so that no torch copy or zero fill stands between the transforms and the products
+// (reference: torch.fft.rfft2, the slice x[:, total_modes-kept_modes:total_modes+kept_modes, :kept_modes] and irfft2 of the
+// zero-initialised o2, src/dlwpbench/models/fourcastnet/fourcastnet.py:85-124).  The H pass of the forward transform only runs
+// over the kept columns; the inverse reads zeros outside the window.  adjoint: as dlwp_rfft2 / dlwp_irfft2 (the adjoint of the
+// windowed inverse is the windowed forward transform and vice versa).  work: scratch of the FULL half spectrum's size.
+extern "C" int dlwp_rfft2_planar(const dlwp_fft_plan* p, const float* x, float* X, float* work, int B, int C, int r0, int r1, int c1,
+                                 int norm, int adjoint, void* stream_) {
+    DLWP_REQUIRE(p && x && X && work && B > 0 && C > 0 && norm >= 0 && norm <= 2, DLWP_E_INVALID, "rfft2_planar: bad argument");
+    const int Wc = p->W / 2 + 1;
+    DLWP_REQUIRE(0 <= r0 && r0 < r1 && r1 <= p->H && c1 >= 1 && c1 <= Wc, DLWP_E_INVALID, "rfft2_planar: window [%d, %d) x %d outside %d x %d",
+                 r0, r1, c1, p->H, Wc);
+    hipStream_t stream = (hipStream_t)stream_;
+    float sWf, sHf, sWi, sHi;
+    norm_scales(norm, p->H, p->W, sWf, sHf, sWi, sHi);
+    int rc = run_w_real(p, true, false, x, work, B, C, adjoint ? sWi : sWf, adjoint ? 2.f : 1.f, stream);
+    if (rc) return rc;
+    const long long J = (long long)Wc * C, Jw = (long long)c1 * C;
+    return run_h_c2c(p, work, X, B, J, -1.f, adjoint ? sHi : sHf, stream, 0, (long long)B * (r1 - r0) * Jw, r0, r1, Jw);
+}
+
+extern "C" int dlwp_irfft2_planar(const dlwp_fft_plan* p, const float* X, float* x, float* work, int B, int C, int r0, int r1, int c1,
+                                  int norm, int adjoint, void* stream_) {
+    DLWP_REQUIRE(p && x && X && work && B > 0 && C > 0 && norm >= 0 && norm <= 2, DLWP_E_INVALID, "irfft2_planar: bad argument");
+    const int Wc = p->W / 2 + 1;
+    DLWP_REQUIRE(0 <= r0 && r0 < r1 && r1 <= p->H && c1 >= 1 && c1 <= Wc, DLWP_E_INVALID, "irfft2_planar: window [%d, %d) x %d outside %d x %d",
+                 r0, r1, c1, p->H, Wc);
+    hipStream_t stream = (hipStream_t)stream_;
+    float sWf, sHf, sWi, sHi;
+    norm_scales(norm, p->H, p->W, sWf, sHf, sWi, sHi);
+    const long long J = (long long)Wc * C, Jw = (long long)c1 * C;
+    int rc = run_h_c2c(p, X, work, B, J, +1.f, adjoint ? sHf : sHi, stream, (long long)B * (r1 - r0) * Jw, 0, r0, r1, Jw);
+    if (rc) return rc;
+    return run_w_real(p, false, false, work, x, B, C, adjoint ? sWf : sWi, adjoint ? 0.5f : 1.f, stream);
 }

@@ -92,3 +92,66 @@ def rfft2(x, layout="channels_last", norm="ortho"):
 def irfft2(X, W, layout="channels_last", norm="ortho"):
     """Inverse of rfft2 for an output width W (the height is X's)."""
     return _IRFFT2.apply(X, int(W), LAYOUTS[layout], NORMS[norm])
+
+
+# ---- channels-last transforms with a planar WINDOW of the spectrum, [2 (re | im), B, r1 - r0, c1, C] (csrc/fft2d.hip,
+# dlwp_rfft2_planar): the kept modes in the layout the AFNO mixer's block GEMMs read and write (afno_tiled.afno2d_fft)
+def _run_r2c_planar(x, win, norm, adjoint):
+    B, H, W, Cc = x.shape
+    r0, r1, c1 = win
+    X = torch.empty(2, B, r1 - r0, c1, Cc, device=x.device)
+    work = torch.empty(B, H, W // 2 + 1, Cc, 2, device=x.device)
+    L.check(L.load().dlwp_rfft2_planar(_plan(H, W), L.ptr(x), L.ptr(X), L.ptr(work), B, Cc, r0, r1, c1, norm, adjoint, L.stream()))
+    return X
+
+
+def _run_c2r_planar(X, H, W, win, norm, adjoint):
+    _, B, _, _, Cc = X.shape
+    r0, r1, c1 = win
+    x = torch.empty(B, H, W, Cc, device=X.device)
+    work = torch.empty(B, H, W // 2 + 1, Cc, 2, device=X.device)
+    L.check(L.load().dlwp_irfft2_planar(_plan(H, W), L.ptr(X), L.ptr(x), L.ptr(work), B, Cc, r0, r1, c1, norm, adjoint, L.stream()))
+    return x
+
+
+class _RFFT2Planar(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, win, norm):
+        x = x.contiguous().float()
+        ctx.cfg = (win, norm, x.shape[1], x.shape[2])
+        return _run_r2c_planar(x, win, norm, 0)
+
+    @staticmethod
+    def backward(ctx, gX):
+        win, norm, H, W = ctx.cfg
+        return _run_c2r_planar(gX.contiguous().float(), H, W, win, norm, 1), None, None
+
+
+class _IRFFT2Planar(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, H, W, win, norm):
+        ctx.cfg = (win, norm)
+        return _run_c2r_planar(X.contiguous().float(), H, W, win, norm, 0)
+
+    @staticmethod
+    def backward(ctx, gx):
+        win, norm = ctx.cfg
+        return _run_r2c_planar(gx.contiguous().float(), win, norm, 1), None, None, None, None
+
+
+def _window(H, W, window):
+    r0, r1, c1 = (0, H, W // 2 + 1) if window is None else (int(v) for v in window)
+    if not (0 <= r0 < r1 <= H and 1 <= c1 <= W // 2 + 1):
+        raise L.DlwpError(f"spectrum window rows [{r0}, {r1}) x {c1} columns outside {H} x {W // 2 + 1}")
+    return r0, r1, c1
+
+
+def rfft2_planar(x, norm="ortho", window=None):
+    """x [B, H, W, C] -> [2, B, r1 - r0, c1, C]: plane 0 the real parts of torch.fft.rfft2(x, dim=(1, 2), norm=norm)[:, r0:r1, :c1],
+    plane 1 the imaginary parts; window = (r0, r1, c1), default the whole half spectrum."""
+    return _RFFT2Planar.apply(x, _window(x.shape[1], x.shape[2], window), NORMS[norm])
+
+
+def irfft2_planar(X, H, W, norm="ortho", window=None):
+    """irfft2 (output H x W) of the spectrum that equals X inside the window and zero outside."""
+    return _IRFFT2Planar.apply(X, int(H), int(W), _window(int(H), int(W), window), NORMS[norm])

@@ -319,6 +319,17 @@ int dlwp_rfft2(const dlwp_fft_plan* plan, const float* x, float* X, int B, int C
                int adjoint, void* stream);
 int dlwp_irfft2(const dlwp_fft_plan* plan, const float* X, float* x, float* work, int B, int C, int layout,
                 int norm, int adjoint, void* stream);
+/* The channels-last pair with a WINDOW of the half spectrum as two planes,                          */
+/* X [2 (re | im)][B][r1 - r0][c1][C] = rows r0 <= kh < r1, columns kw < c1 of rfft2's [B][H][W/2+1][C]: */
+/* the kept modes AFNO2D's block-diagonal complex MLP works on (fourcastnet.py:85-124: rfft2, the slice */
+/* x[:, total_modes-kept_modes:total_modes+kept_modes, :kept_modes], irfft2 of the zero-initialised     */
+/* result), in the planar layout of the real batched GEMMs that replace the complex einsums -- no copy  */
+/* or zero fill between transform and products.  irfft2_planar reads zeros outside the window; adjoint  */
+/* as above.  work: scratch of the FULL half spectrum's size (2 B H (W/2+1) C floats).                  */
+int dlwp_rfft2_planar(const dlwp_fft_plan* plan, const float* x, float* X, float* work, int B, int C, int r0, int r1,
+                      int c1, int norm, int adjoint, void* stream);
+int dlwp_irfft2_planar(const dlwp_fft_plan* plan, const float* X, float* x, float* work, int B, int C, int r0, int r1,
+                       int c1, int norm, int adjoint, void* stream);
 
 /* General-grid AFNO2D (grids whose block spectrum does not fit LDS): the transforms run as     */
 /* dlwp_gemm_batched against DFT tables and the per-mode block MLP as batched GEMMs over the     */

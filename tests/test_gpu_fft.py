@@ -65,3 +65,37 @@ def test_fft_backward_passes_are_the_adjoints(cuda, B, H, W, C, layout, norm):
     y = fft.irfft2(Yd, W, layout, norm)
     (y * Gy.to(cuda)).sum().backward()
     assert rel(Yd.grad, Yr.grad) <= TOL
+
+
+@pytest.mark.parametrize("B,H,W,C,win", [(2, 16, 24, 4, None), (1, 90, 180, 8, (0, 90, 46)), (1, 103, 180, 2, (21, 83, 31)),
+                                         (2, 7, 11, 4, (2, 6, 3)), (1, 45, 64, 40, (9, 37, 14))])
+def test_planar_window_transforms_match_torch(cuda, B, H, W, C, win):
+    """rfft2_planar / irfft2_planar (a window of the half spectrum as [2 (re | im), B, rows, cols, C], the AFNO mixer's GEMM
+    operand) against torch.fft on the CPU with the reference's slicing / zero-initialised inverse (fourcastnet.py:85-124):
+    values both ways and both backward passes."""
+    from dlwp_benchmark_amd import fft
+    g = torch.Generator().manual_seed(H + W)
+    r0, r1, c1 = win or (0, H, W // 2 + 1)
+    x = torch.randn(B, H, W, C, generator=g)
+    xr = x.double().requires_grad_(True)
+    Xr = torch.view_as_real(torch.fft.rfft2(xr, dim=(1, 2), norm="ortho")[:, r0:r1, :c1]).permute(4, 0, 1, 2, 3)
+    G = torch.randn(Xr.shape, generator=g)
+    (Xr * G.double()).sum().backward()
+    xd = x.to(cuda).requires_grad_(True)
+    X = fft.rfft2_planar(xd, "ortho", win)
+    assert X.shape == (2, B, r1 - r0, c1, C)
+    (X * G.to(cuda)).sum().backward()
+    assert rel(X, Xr) <= TOL
+    assert rel(xd.grad, xr.grad) <= TOL
+    Y = torch.randn(Xr.shape, generator=g)
+    Yr = Y.double().requires_grad_(True)
+    full = torch.nn.functional.pad(Yr.permute(1, 2, 3, 4, 0), (0, 0, 0, 0, 0, W // 2 + 1 - c1, r0, H - r1))     # zero outside the window
+    full = torch.view_as_complex(full.contiguous())
+    yr = torch.fft.irfft2(full, s=(H, W), dim=(1, 2), norm="ortho")
+    Gy = torch.randn(yr.shape, generator=g)
+    (yr * Gy.double()).sum().backward()
+    Yd = Y.to(cuda).requires_grad_(True)
+    y = fft.irfft2_planar(Yd, H, W, "ortho", win)
+    (y * Gy.to(cuda)).sum().backward()
+    assert rel(y, yr) <= TOL
+    assert rel(Yd.grad, Yr.grad) <= TOL
