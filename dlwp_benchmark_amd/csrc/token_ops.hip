@@ -1187,6 +1187,104 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
     }
 }
 
+// Wide rows (256 < C <= 1024, C % 4 == 0; FourCastNet's 768, Pangu's 384): a lane owns NV float4 groups of a row (16-byte accesses
+// instead of the scalar kernel's 4-byte ones), a wave walks its rows with the next row's loads in flight, and the grid is sized to
+// the resident slots (a workgroup's 2 C column partials end in float atomics on the same 2 C addresses: their number, not C, sets
+// the tail -- the scalar kernel's 1013 workgroups at 16200 x 768 spent a third of its 79 us there).
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                 const float* __restrict__ gy, const float* __restrict__ gadd,
+                                                                 float* __restrict__ gx, float* ggamma, float* gbeta, int T, int C,
+                                                                 int rows_per_block, int gy_bf16) {
+    extern __shared__ float sm[];            // [2][C] per-block partial of ggamma, gbeta
+    for (int c = threadIdx.x; c < 2 * C; c += 256) sm[c] = 0.f;
+    __syncthreads();
+    const int lane = lane_id(), w = wave_id();
+    const long long row0 = (long long)blockIdx.x * rows_per_block;
+    const __bf16* gh = reinterpret_cast<const __bf16*>(gy);
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 gm[NV], pg[NV], pb[NV], xv[NV], gv[NV], av[NV], xn[NV], gn[NV], an[NV];
+    bool okc[NV];
+    int col[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        okc[q] = 4 * lane + 256 * q < C;
+        col[q] = okc[q] ? 4 * lane + 256 * q : 0;          // clamped: loads of a masked group read (and ignore) column 0
+        gm[q] = okc[q] ? *reinterpret_cast<const f32x4*>(gamma + col[q]) : zero;
+        pg[q] = zero; pb[q] = zero;
+    }
+    auto load_row = [&](long long row, f32x4 (&X)[NV], f32x4 (&G)[NV], f32x4 (&A)[NV], float& mu, float& rs) {
+        const long long rc = min(row, (long long)T - 1) * C;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            X[q] = *reinterpret_cast<const f32x4*>(x + rc + col[q]);
+            if (gy_bf16) {
+                const bf16x4 hv = *reinterpret_cast<const bf16x4*>(gh + rc + col[q]);
+                G[q] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+            } else {
+                G[q] = *reinterpret_cast<const f32x4*>(gy + rc + col[q]);
+            }
+            A[q] = gadd ? *reinterpret_cast<const f32x4*>(gadd + rc + col[q]) : zero;
+        }
+        mu = mean[min(row, (long long)T - 1)];
+        rs = rstd[min(row, (long long)T - 1)];
+    };
+    float mu, rs, mun = 0.f, rsn = 0.f;
+    load_row(row0 + w, xv, gv, av, mu, rs);
+    const float invC = 1.f / C;
+    for (int rr = w; rr < rows_per_block; rr += 4) {
+        const long long row = row0 + rr;
+        if (row >= T) break;
+        const bool more = rr + 4 < rows_per_block && row + 4 < T;
+        if (more) load_row(row + 4, xn, gn, an, mun, rsn);
+        float s1 = 0.f, s2 = 0.f;
+        f32x4 xh[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float g0 = okc[q] ? gv[q][k] : 0.f;
+                xh[q][k] = okc[q] ? (xv[q][k] - mu) * rs : 0.f;
+                const float gg = g0 * gm[q][k];
+                s1 += gg;
+                s2 += gg * xh[q][k];
+                pg[q][k] += g0 * xh[q][k];
+                pb[q][k] += g0;
+            }
+        s1 = wave_sum64(s1) * invC;
+        s2 = wave_sum64(s2) * invC;
+#pragma unroll
+        for (int q = 0; q < NV; ++q)
+            if (okc[q]) {
+                f32x4 o4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o4[k] = rs * (gv[q][k] * gm[q][k] - s1 - xh[q][k] * s2) + av[q][k];
+                *reinterpret_cast<f32x4*>(gx + row * C + col[q]) = o4;
+            }
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) { xv[q] = xn[q]; gv[q] = gn[q]; av[q] = an[q]; }
+            mu = mun; rs = rsn;
+        }
+    }
+    for (int ww = 0; ww < 4; ++ww) {          // the four waves' column partials, one wave at a time (no LDS float atomics)
+        if (w == ww) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q)
+                if (okc[q]) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { sm[col[q] + k] += pg[q][k]; sm[C + col[q] + k] += pb[q][k]; }
+                }
+        }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < C; c += 256) {
+        atomic_add_f32(&ggamma[c], sm[c]);
+        atomic_add_f32(&gbeta[c], sm[C + c]);
+    }
+}
+
 // out[n] += sum_t g[t][n].  Tall matrices (T > 16): a workgroup sums a slab of rows for 256 columns -- 16-byte loads, eight
 // independent rows in flight per thread (the first version walked its rows one dependent-free but serial 4-byte load at a
 // time: 28 us per call at the FourCastNet-scale shapes, 4.9 % of that step) -- and adds its partial with float atomics.
@@ -1493,13 +1591,30 @@ static int layernorm_bwd_impl(const float* x, const float* gamma, const float* m
     // tail costs (number of workgroups) x 25 ns whatever C is: ~128-256 workgroups balance that against the rows
     // each wave walks serially.
     // each wave then walks serially (one wave per SIMD hides no latency).  Large inputs get up to ~1024 workgroups.
-    const long long want = std::min<long long>(512, std::max<long long>(128, (long long)T * C / 16384));
+    static const char* want_env = getenv("DLWP_LN_BWD_WANT");
+    const long long want = want_env ? atoi(want_env) : std::min<long long>(512, std::max<long long>(256, (long long)T * C / 16384));
     int rpb = 256;
     while (rpb > 4 && ceil_div(T, rpb) < want) rpb >>= 1;
     const dim3 grid(ceil_div(T, rpb));
     const size_t lds = 2 * C * sizeof(float);
     const bool narrow = C % 4 == 0 && C <= 256 && (uintptr_t)x % 16 == 0 && (uintptr_t)gy % 8 == 0 && (uintptr_t)gx % 16 == 0 &&
                         (uintptr_t)gamma % 16 == 0 && (gy_bf16 || (uintptr_t)gy % 16 == 0) && (!gadd || (uintptr_t)gadd % 16 == 0);
+    const bool wide = C % 4 == 0 && C > 256 && C <= 1024 && (uintptr_t)x % 16 == 0 && (uintptr_t)gx % 16 == 0 &&
+                      (uintptr_t)gamma % 16 == 0 && (uintptr_t)gy % (gy_bf16 ? 8 : 16) == 0 && (!gadd || (uintptr_t)gadd % 16 == 0);
+    static const bool no_wide = getenv("DLWP_LN_BWD_NOWIDE") != nullptr;
+    if (wide && !no_wide) {
+        // one round of resident workgroups (~110 VGPRs: four per CU at most; 512-768 keep the atomic tail short)
+        static const char* wg_env = getenv("DLWP_LN_BWD_WGS");
+        const int slots = wg_env ? atoi(wg_env) : 384;
+        const int rpw = std::max(4, ceil_div(ceil_div(T, slots), 4) * 4);
+        const dim3 gridw(ceil_div(T, rpw));
+#define LN_BWD_W(NV) hipLaunchKernelGGL(layernorm_bwd_wide_kernel<NV>, gridw, dim3(256), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, \
+                                        gadd, gx, ggamma, gbeta, T, C, rpw, gy_bf16)
+        if (C <= 512) LN_BWD_W(2); else if (C <= 768) LN_BWD_W(3); else LN_BWD_W(4);
+#undef LN_BWD_W
+        DLWP_LAUNCH_CHECK();
+        return DLWP_OK;
+    }
     if (narrow) {
 #define LN_BWD_V(LPR) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<LPR>, grid, dim3(256), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, \
                                           gadd, gx, ggamma, gbeta, T, C, rpb, gy_bf16)
