@@ -113,6 +113,57 @@ class _BlockComplexLinear(torch.autograd.Function):
         return gX, (None if wslot is not None else gw), (None if bslot is not None else gb), None, None
 
 
+class _BlockComplexLinearBP(torch.autograd.Function):
+    """The same layer on block-planar spectra X [T, nb, 2 (re | im), bs_in] (fft.rfft2_planar(block=bs_in)): with the weights as
+    one real [2 bs_in, 2 bs_out] matrix per channel block (dlwp_afno_wq_expand_bp) the layer is ONE batched GEMM with bias,
+    activation and stored pre-activation in its epilogue, and so is each of its two gradients (the planar form above takes two
+    accumulating passes per product, one per input plane)."""
+
+    @staticmethod
+    def forward(ctx, X, w, b, act, lam):
+        lib = L.load()
+        T = X.shape[0]
+        _, nb, bsi, bso = w.shape
+        C, Co = nb * bsi, nb * bso
+        X = X.contiguous().view(T, 2 * C)
+        wq = torch.empty(nb, 2 * bsi, 2 * bso, device=X.device)
+        bq = torch.empty(2 * Co, device=X.device)
+        L.check(lib.dlwp_afno_wq_expand_bp(L.ptr(w.contiguous()), L.ptr(b.contiguous()), L.ptr(wq), L.ptr(bq), nb, bsi, bso, L.stream()))
+        O = torch.empty(T, 2 * Co, device=X.device)
+        P = torch.empty(T, 2 * Co, device=X.device) if act else None
+        _gemm_batched(X, wq, O, T, 2 * bso, 2 * bsi, 2 * C, 2 * bso, 2 * Co, 0, 0, nb, 1, (2 * bsi, 0), (4 * bsi * bso, 0), (2 * bso, 0),
+                      bias=bq, sBi=(2 * bso, 0), act=act, act_param=lam, preact=P)
+        ctx.save_for_backward(X, wq, P)
+        ctx.cfg = (T, C, Co, nb, bsi, bso, act, lam)
+        ctx.slots = (_grad_slot(w), _grad_slot(b))
+        ctx.shapes = (w.shape, b.shape)
+        return O.view(T, nb, 2, bso)
+
+    @staticmethod
+    def backward(ctx, gO):
+        lib = L.load()
+        X, wq, P = ctx.saved_tensors
+        T, C, Co, nb, bsi, bso, act, lam = ctx.cfg
+        gO = gO.contiguous().view(T, 2 * Co)
+        if act:
+            gP = torch.empty_like(gO)
+            L.check(lib.dlwp_act_bwd(L.ptr(P), L.ptr(gO), L.ptr(gP), gO.numel(), act, lam, L.stream()))
+        else:
+            gP = gO
+        gX = torch.empty_like(X)                 # gX[:, blk] = gP[:, blk] . wq[blk]^T
+        _gemm_batched(gP, wq, gX, T, 2 * bsi, 2 * bso, 2 * Co, 2 * bso, 2 * C, 0, 1, nb, 1, (2 * bso, 0), (4 * bsi * bso, 0), (2 * bsi, 0))
+        gwq = torch.zeros_like(wq)               # gwq[blk] = X[:, blk]^T . gP[:, blk]   (K = tokens: split along K inside the kernel)
+        _gemm_batched(X, gP, gwq, 2 * bsi, 2 * bso, T, 2 * C, 2 * Co, 2 * bso, 1, 0, nb, 1, (2 * bsi, 0), (2 * bso, 0), (4 * bsi * bso, 0),
+                      accumulate=1)
+        gbq = torch.zeros(2 * Co, device=X.device)
+        L.check(lib.dlwp_colsum(L.ptr(gP), L.ptr(gbq), T, 2 * Co, L.stream()))
+        wslot, bslot = ctx.slots
+        gw = wslot if wslot is not None else torch.zeros(ctx.shapes[0], device=X.device)
+        gb = bslot if bslot is not None else torch.zeros(ctx.shapes[1], device=X.device)
+        L.check(lib.dlwp_afno_wq_fold_bp(L.ptr(gwq), L.ptr(gbq), L.ptr(gw), L.ptr(gb), nb, bsi, bso, L.stream()))
+        return gX.view(T, nb, 2, bsi), (None if wslot is not None else gw), (None if bslot is not None else gb), None, None
+
+
 def afno2d_tiled(x, w1, b1, w2, b2, num_blocks, sparsity_threshold=0.01, hard_thresholding_fraction=1.0):
     """x [B, H, W, C] -> AFNO2D(x) including the residual `+ x`."""
     B, H, W, C = x.shape
@@ -153,6 +204,13 @@ def afno2d_fft(x, w1, b1, w2, b2, num_blocks, sparsity_threshold=0.01, hard_thre
     # the transforms read / write the kept window in the planar layout of the block GEMMs: no window copies, no zero fill, and
     # the H pass of the forward transform skips the columns outside the window
     win = (r0, r1, c1)
+    nb, bs = w1.shape[1], w1.shape[2]
+    if bs >= 2 and w2.shape[3] == bs:
+        # block-planar spectra: one batched GEMM per layer and gradient
+        X = fft.rfft2_planar(x, "ortho", win, block=bs).view(B * R * c1, nb, 2, bs)
+        o1 = _BlockComplexLinearBP.apply(X, w1, b1, 2, 0.0)
+        o2 = _BlockComplexLinearBP.apply(o1, w2, b2, 3, float(sparsity_threshold))
+        return add_tokens(fft.irfft2_planar(o2.view(B, R, c1, nb, 2, bs), H, W, "ortho", win, block=bs), x)
     planar = fft.rfft2_planar(x, "ortho", win).view(2, B * R * c1, C)
     o1 = _BlockComplexLinear.apply(planar, w1, b1, 2, 0.0)
     o2 = _BlockComplexLinear.apply(o1, w2, b2, 3, float(sparsity_threshold))

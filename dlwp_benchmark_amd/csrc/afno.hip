@@ -542,7 +542,61 @@ __global__ __launch_bounds__(256) void afno_wq_fold_kernel(const float* __restri
     }
 }
 
+// block-planar image (tokens [T][blk][re | im][bs]): wq [blk][ri][i][ro][o] -- one real 2 bs_in x 2 bs_out matrix per channel block,
+// so the complex block MLP is ONE batched real GEMM per layer -- and the bias in the same order, bq [blk][ro][o]
+__global__ __launch_bounds__(256) void afno_wq_expand_bp_kernel(const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ wq,
+                                                                float* __restrict__ bq, int nb, int bsi, int bso) {
+    const long long n = (long long)nb * bsi * bso;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const int o = (int)(e % bso), i = (int)((e / bso) % bsi), blk = (int)(e / ((long long)bso * bsi));
+        const float wr = w[e], wi = w[n + e];
+        float* q = wq + (long long)blk * 4 * bsi * bso;
+        q[((0 * bsi + i) * 2 + 0) * bso + o] = wr;
+        q[((0 * bsi + i) * 2 + 1) * bso + o] = wi;
+        q[((1 * bsi + i) * 2 + 0) * bso + o] = -wi;
+        q[((1 * bsi + i) * 2 + 1) * bso + o] = wr;
+        if (e < 2LL * nb * bso) {                        // bias [ro][blk][o] -> [blk][ro][o]
+            const int oo = (int)(e % bso), bb = (int)((e / bso) % nb), ro = (int)(e / ((long long)bso * nb));
+            bq[((long long)bb * 2 + ro) * bso + oo] = b[e];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void afno_wq_fold_bp_kernel(const float* __restrict__ gq, const float* __restrict__ gbq, float* __restrict__ gw,
+                                                              float* __restrict__ gb, int nb, int bsi, int bso) {
+    const long long n = (long long)nb * bsi * bso;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const int o = (int)(e % bso), i = (int)((e / bso) % bsi), blk = (int)(e / ((long long)bso * bsi));
+        const float* q = gq + (long long)blk * 4 * bsi * bso;
+        gw[e] += q[((0 * bsi + i) * 2 + 0) * bso + o] + q[((1 * bsi + i) * 2 + 1) * bso + o];
+        gw[n + e] += q[((0 * bsi + i) * 2 + 1) * bso + o] - q[((1 * bsi + i) * 2 + 0) * bso + o];
+        if (e < 2LL * nb * bso) {
+            const int oo = (int)(e % bso), bb = (int)((e / bso) % nb), ro = (int)(e / ((long long)bso * nb));
+            gb[e] += gbq[((long long)bb * 2 + ro) * bso + oo];
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int dlwp_afno_wq_expand_bp(const float* w, const float* b, float* wq, float* bq, int nb, int bs_in, int bs_out, void* stream) {
+    DLWP_REQUIRE(w && b && wq && bq && nb > 0 && bs_in > 0 && bs_out > 0, DLWP_E_INVALID, "afno_wq_expand_bp: bad argument");
+    DLWP_REQUIRE(bs_in >= 2, DLWP_E_UNSUPPORTED, "afno_wq_expand_bp: block size 1");      // the bias rides on the first 2 nb bs_out elements
+    const long long n = (long long)nb * bs_in * bs_out;
+    hipLaunchKernelGGL(afno_wq_expand_bp_kernel, dim3((int)std::min<long long>((n + 255) / 256, 2048)), dim3(256), 0,
+                       (hipStream_t)stream, w, b, wq, bq, nb, bs_in, bs_out);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_afno_wq_fold_bp(const float* gq, const float* gbq, float* gw, float* gb, int nb, int bs_in, int bs_out, void* stream) {
+    DLWP_REQUIRE(gq && gbq && gw && gb && nb > 0 && bs_in >= 2 && bs_out > 0, DLWP_E_INVALID, "afno_wq_fold_bp: bad argument");
+    const long long n = (long long)nb * bs_in * bs_out;
+    hipLaunchKernelGGL(afno_wq_fold_bp_kernel, dim3((int)std::min<long long>((n + 255) / 256, 2048)), dim3(256), 0,
+                       (hipStream_t)stream, gq, gbq, gw, gb, nb, bs_in, bs_out);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
 
 extern "C" int dlwp_afno_wq_expand(const float* w, float* wq, int nb, int bs_in, int bs_out, void* stream) {
     DLWP_REQUIRE(w && wq && nb > 0 && bs_in > 0 && bs_out > 0, DLWP_E_INVALID, "afno_wq_expand: bad argument");

@@ -280,8 +280,10 @@ struct FftIO {
     // C2C: plane == 0: interleaved (re, im) pairs, element (o, n, j) at (o * N + n) * J + j.  Otherwise that side is a planar
     // WINDOW of the spectrum, rows r0 <= n < r1 and inner positions j < Jw: re at (o * (r1 - r0) + n - r0) * Jw + j, im `plane`
     // floats further; read: everything outside the window is zero; written: only the window is
+    // bs > 0: the planar side is "block-planar" instead, tokens [.][blk][re | im][bs]: element (t, c) at t * 2 C + (c / bs) * 2 bs +
+    // c % bs, im bs floats further (the operand layout of the one-GEMM-per-layer AFNO block MLP, afno_tiled._BlockComplexLinearBP)
     long long plane_in, plane_out, Jw;
-    int r0, r1;
+    int r0, r1, bs;
 };
 
 __device__ __forceinline__ void load_table(float2* tabs, const FftAxis& f) {
@@ -426,7 +428,6 @@ __global__ __launch_bounds__(NT) void fft_c2c_kernel(FftIO a) {
     const int nl = (int)min((long long)f.IB, a.J - j0);
     const long long base = o * N * a.J + j0;
     const int R = a.r1 - a.r0;
-    const long long wbase = o * R * a.Jw + j0;
     float2* dst = reinterpret_cast<float2*>(a.out) + base;
     if (a.plane_in && j0 >= a.Jw) {                   // a column block outside the window: its transform is zero
         for (int e = threadIdx.x; e < N << f.logIB; e += NT) {
@@ -435,15 +436,27 @@ __global__ __launch_bounds__(NT) void fft_c2c_kernel(FftIO a) {
         }
         return;
     }
+    // window side: element of row n and this thread's column j = j0 + lane (NT is a multiple of IB: the lane of a thread is fixed)
+    const int mylane = threadIdx.x & (f.IB - 1);
+    const long long jj = j0 + mylane;
+    long long wcol = jj, wim = a.plane_in ? a.plane_in : a.plane_out;
+    int wmul = 1;
+    if (a.bs) {
+        const int c = (int)(jj % a.C);
+        wcol = (jj - c) * 2 + (c / a.bs) * 2 * a.bs + c % a.bs;
+        wim = a.bs;
+        wmul = 2;
+    }
+    const long long wrow0 = o * R * a.Jw * wmul;
     const float2* src = reinterpret_cast<const float2*>(a.in) + base;
     for (int e = threadIdx.x; e < N << f.logIB; e += NT) {
         const int lane = e & (f.IB - 1), n = e >> f.logIB;
         float2 z = make_float2(0.f, 0.f);
         if (lane < nl) {
             if (a.plane_in) {
-                if (n >= a.r0 && n < a.r1 && j0 + lane < a.Jw) {
-                    const long long i = wbase + (long long)(n - a.r0) * a.Jw + lane;
-                    z = make_float2(a.in[i], a.in[a.plane_in + i]);
+                if (n >= a.r0 && n < a.r1 && jj < a.Jw) {
+                    const long long i = wrow0 + (long long)(n - a.r0) * a.Jw * wmul + wcol;
+                    z = make_float2(a.in[i], a.in[wim + i]);
                 }
             } else {
                 z = src[(long long)n * a.J + lane];
@@ -458,10 +471,10 @@ __global__ __launch_bounds__(NT) void fft_c2c_kernel(FftIO a) {
         if (lane < nl) {
             const float2 z = buf[n * IBP + lane];
             if (a.plane_out) {
-                if (n >= a.r0 && n < a.r1 && j0 + lane < a.Jw) {
-                    const long long i = wbase + (long long)(n - a.r0) * a.Jw + lane;
+                if (n >= a.r0 && n < a.r1 && jj < a.Jw) {
+                    const long long i = wrow0 + (long long)(n - a.r0) * a.Jw * wmul + wcol;
                     a.out[i] = a.scale * z.x;
-                    a.out[a.plane_out + i] = a.scale * z.y;
+                    a.out[wim + i] = a.scale * z.y;
                 }
             } else {
                 dst[(long long)n * a.J + lane] = make_float2(a.scale * z.x, a.scale * z.y);
@@ -620,10 +633,11 @@ int run_w_real(const dlwp_fft_plan* p, bool to_complex, bool cf, const float* in
 }
 
 int run_h_c2c(const dlwp_fft_plan* p, const float* in, float* out, long long outer, long long J, float sg, float scale,
-              hipStream_t stream, long long plane_in = 0, long long plane_out = 0, int r0 = 0, int r1 = 0, long long Jw = 0) {
+              hipStream_t stream, long long plane_in = 0, long long plane_out = 0, int r0 = 0, int r1 = 0, long long Jw = 0,
+              int C = 0, int bs = 0) {
     FftIO io{};
     io.ax = p->axH; io.in = in; io.out = out; io.J = J; io.sg = sg; io.scale = scale;
-    io.plane_in = plane_in; io.plane_out = plane_out; io.r0 = r0; io.r1 = r1; io.Jw = Jw;
+    io.plane_in = plane_in; io.plane_out = plane_out; io.r0 = r0; io.r1 = r1; io.Jw = Jw; io.C = C; io.bs = bs;
     if (plane_out) J = Jw;            // only the window's columns are transformed
     DLWP_REQUIRE(outer <= 65535, DLWP_E_UNSUPPORTED, "fft: more than 65535 outer slices per call (%lld)", outer);
     const dim3 grid((unsigned)((J + io.ax.IB - 1) / io.ax.IB), (unsigned)outer);
@@ -705,32 +719,35 @@ extern "C" int dlwp_irfft2(const dlwp_fft_plan* p, const float* X, float* x, flo
 // zero-initialised o2, src/dlwpbench/models/fourcastnet/fourcastnet.py:85-124).  The H pass of the forward transform only runs
 // over the kept columns; the inverse reads zeros outside the window.  adjoint: as dlwp_rfft2 / dlwp_irfft2 (the adjoint of the
 // windowed inverse is the windowed forward transform and vice versa).  work: scratch of the FULL half spectrum's size.
+// bs > 0: X is block-planar instead, [B][r1 - r0][c1][C / bs][2 (re | im)][bs] (FftIO::bs).
 extern "C" int dlwp_rfft2_planar(const dlwp_fft_plan* p, const float* x, float* X, float* work, int B, int C, int r0, int r1, int c1,
-                                 int norm, int adjoint, void* stream_) {
+                                 int bs, int norm, int adjoint, void* stream_) {
     DLWP_REQUIRE(p && x && X && work && B > 0 && C > 0 && norm >= 0 && norm <= 2, DLWP_E_INVALID, "rfft2_planar: bad argument");
     const int Wc = p->W / 2 + 1;
     DLWP_REQUIRE(0 <= r0 && r0 < r1 && r1 <= p->H && c1 >= 1 && c1 <= Wc, DLWP_E_INVALID, "rfft2_planar: window [%d, %d) x %d outside %d x %d",
                  r0, r1, c1, p->H, Wc);
+    DLWP_REQUIRE(bs >= 0 && (bs == 0 || C % bs == 0), DLWP_E_INVALID, "planar fft: channel block %d does not divide C = %d", bs, C);
     hipStream_t stream = (hipStream_t)stream_;
     float sWf, sHf, sWi, sHi;
     norm_scales(norm, p->H, p->W, sWf, sHf, sWi, sHi);
     int rc = run_w_real(p, true, false, x, work, B, C, adjoint ? sWi : sWf, adjoint ? 2.f : 1.f, stream);
     if (rc) return rc;
     const long long J = (long long)Wc * C, Jw = (long long)c1 * C;
-    return run_h_c2c(p, work, X, B, J, -1.f, adjoint ? sHi : sHf, stream, 0, (long long)B * (r1 - r0) * Jw, r0, r1, Jw);
+    return run_h_c2c(p, work, X, B, J, -1.f, adjoint ? sHi : sHf, stream, 0, (long long)B * (r1 - r0) * Jw, r0, r1, Jw, C, bs);
 }
 
 extern "C" int dlwp_irfft2_planar(const dlwp_fft_plan* p, const float* X, float* x, float* work, int B, int C, int r0, int r1, int c1,
-                                  int norm, int adjoint, void* stream_) {
+                                  int bs, int norm, int adjoint, void* stream_) {
     DLWP_REQUIRE(p && x && X && work && B > 0 && C > 0 && norm >= 0 && norm <= 2, DLWP_E_INVALID, "irfft2_planar: bad argument");
     const int Wc = p->W / 2 + 1;
     DLWP_REQUIRE(0 <= r0 && r0 < r1 && r1 <= p->H && c1 >= 1 && c1 <= Wc, DLWP_E_INVALID, "irfft2_planar: window [%d, %d) x %d outside %d x %d",
                  r0, r1, c1, p->H, Wc);
+    DLWP_REQUIRE(bs >= 0 && (bs == 0 || C % bs == 0), DLWP_E_INVALID, "planar fft: channel block %d does not divide C = %d", bs, C);
     hipStream_t stream = (hipStream_t)stream_;
     float sWf, sHf, sWi, sHi;
     norm_scales(norm, p->H, p->W, sWf, sHf, sWi, sHi);
     const long long J = (long long)Wc * C, Jw = (long long)c1 * C;
-    int rc = run_h_c2c(p, X, work, B, J, +1.f, adjoint ? sHf : sHi, stream, (long long)B * (r1 - r0) * Jw, 0, r0, r1, Jw);
+    int rc = run_h_c2c(p, X, work, B, J, +1.f, adjoint ? sHf : sHi, stream, (long long)B * (r1 - r0) * Jw, 0, r0, r1, Jw, C, bs);
     if (rc) return rc;
     return run_w_real(p, false, false, work, x, B, C, adjoint ? sWf : sWi, adjoint ? 0.5f : 1.f, stream);
 }

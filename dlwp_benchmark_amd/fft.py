@@ -96,47 +96,48 @@ def irfft2(X, W, layout="channels_last", norm="ortho"):
 
 # ---- channels-last transforms with a planar WINDOW of the spectrum, [2 (re | im), B, r1 - r0, c1, C] (csrc/fft2d.hip,
 # dlwp_rfft2_planar): the kept modes in the layout the AFNO mixer's block GEMMs read and write (afno_tiled.afno2d_fft)
-def _run_r2c_planar(x, win, norm, adjoint):
+def _run_r2c_planar(x, win, bs, norm, adjoint):
     B, H, W, Cc = x.shape
     r0, r1, c1 = win
-    X = torch.empty(2, B, r1 - r0, c1, Cc, device=x.device)
+    X = torch.empty((B, r1 - r0, c1, Cc // bs, 2, bs) if bs else (2, B, r1 - r0, c1, Cc), device=x.device)
     work = torch.empty(B, H, W // 2 + 1, Cc, 2, device=x.device)
-    L.check(L.load().dlwp_rfft2_planar(_plan(H, W), L.ptr(x), L.ptr(X), L.ptr(work), B, Cc, r0, r1, c1, norm, adjoint, L.stream()))
+    L.check(L.load().dlwp_rfft2_planar(_plan(H, W), L.ptr(x), L.ptr(X), L.ptr(work), B, Cc, r0, r1, c1, bs, norm, adjoint, L.stream()))
     return X
 
 
-def _run_c2r_planar(X, H, W, win, norm, adjoint):
-    _, B, _, _, Cc = X.shape
+def _run_c2r_planar(X, H, W, win, bs, norm, adjoint):
+    B = X.shape[0] if bs else X.shape[1]
+    Cc = X.shape[3] * bs if bs else X.shape[4]
     r0, r1, c1 = win
     x = torch.empty(B, H, W, Cc, device=X.device)
     work = torch.empty(B, H, W // 2 + 1, Cc, 2, device=X.device)
-    L.check(L.load().dlwp_irfft2_planar(_plan(H, W), L.ptr(X), L.ptr(x), L.ptr(work), B, Cc, r0, r1, c1, norm, adjoint, L.stream()))
+    L.check(L.load().dlwp_irfft2_planar(_plan(H, W), L.ptr(X), L.ptr(x), L.ptr(work), B, Cc, r0, r1, c1, bs, norm, adjoint, L.stream()))
     return x
 
 
 class _RFFT2Planar(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, win, norm):
+    def forward(ctx, x, win, bs, norm):
         x = x.contiguous().float()
-        ctx.cfg = (win, norm, x.shape[1], x.shape[2])
-        return _run_r2c_planar(x, win, norm, 0)
+        ctx.cfg = (win, bs, norm, x.shape[1], x.shape[2])
+        return _run_r2c_planar(x, win, bs, norm, 0)
 
     @staticmethod
     def backward(ctx, gX):
-        win, norm, H, W = ctx.cfg
-        return _run_c2r_planar(gX.contiguous().float(), H, W, win, norm, 1), None, None
+        win, bs, norm, H, W = ctx.cfg
+        return _run_c2r_planar(gX.contiguous().float(), H, W, win, bs, norm, 1), None, None, None
 
 
 class _IRFFT2Planar(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, X, H, W, win, norm):
-        ctx.cfg = (win, norm)
-        return _run_c2r_planar(X.contiguous().float(), H, W, win, norm, 0)
+    def forward(ctx, X, H, W, win, bs, norm):
+        ctx.cfg = (win, bs, norm)
+        return _run_c2r_planar(X.contiguous().float(), H, W, win, bs, norm, 0)
 
     @staticmethod
     def backward(ctx, gx):
-        win, norm = ctx.cfg
-        return _run_r2c_planar(gx.contiguous().float(), win, norm, 1), None, None, None, None
+        win, bs, norm = ctx.cfg
+        return _run_r2c_planar(gx.contiguous().float(), win, bs, norm, 1), None, None, None, None, None
 
 
 def _window(H, W, window):
@@ -146,12 +147,15 @@ def _window(H, W, window):
     return r0, r1, c1
 
 
-def rfft2_planar(x, norm="ortho", window=None):
+def rfft2_planar(x, norm="ortho", window=None, block=0):
     """x [B, H, W, C] -> [2, B, r1 - r0, c1, C]: plane 0 the real parts of torch.fft.rfft2(x, dim=(1, 2), norm=norm)[:, r0:r1, :c1],
-    plane 1 the imaginary parts; window = (r0, r1, c1), default the whole half spectrum."""
-    return _RFFT2Planar.apply(x, _window(x.shape[1], x.shape[2], window), NORMS[norm])
+    plane 1 the imaginary parts; window = (r0, r1, c1), default the whole half spectrum.  block = bs > 0 (a divisor of C): the
+    block-planar layout [B, r1 - r0, c1, C // bs, 2, bs] instead (channel block, re | im, channel within the block)."""
+    if block and x.shape[3] % block:
+        raise L.DlwpError(f"rfft2_planar: channel block {block} does not divide C = {x.shape[3]}")
+    return _RFFT2Planar.apply(x, _window(x.shape[1], x.shape[2], window), int(block), NORMS[norm])
 
 
-def irfft2_planar(X, H, W, norm="ortho", window=None):
-    """irfft2 (output H x W) of the spectrum that equals X inside the window and zero outside."""
-    return _IRFFT2Planar.apply(X, int(H), int(W), _window(int(H), int(W), window), NORMS[norm])
+def irfft2_planar(X, H, W, norm="ortho", window=None, block=0):
+    """irfft2 (output H x W) of the spectrum that equals X inside the window and zero outside (X in rfft2_planar's layout)."""
+    return _IRFFT2Planar.apply(X, int(H), int(W), _window(int(H), int(W), window), int(block), NORMS[norm])

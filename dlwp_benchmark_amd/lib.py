@@ -114,8 +114,10 @@ SIGNATURES = {
     "dlwp_fft_plan_destroy": (None, [_V]),
     "dlwp_rfft2": (_I, [_V, _V, _V, _I, _I, _I, _I, _I, _V]),
     "dlwp_irfft2": (_I, [_V, _V, _V, _V, _I, _I, _I, _I, _I, _V]),
-    "dlwp_rfft2_planar": (_I, [_V, _V, _V, _V] + [_I] * 7 + [_V]),
-    "dlwp_irfft2_planar": (_I, [_V, _V, _V, _V] + [_I] * 7 + [_V]),
+    "dlwp_rfft2_planar": (_I, [_V, _V, _V, _V] + [_I] * 8 + [_V]),
+    "dlwp_irfft2_planar": (_I, [_V, _V, _V, _V] + [_I] * 8 + [_V]),
+    "dlwp_afno_wq_expand_bp": (_I, [_V, _V, _V, _V, _I, _I, _I, _V]),
+    "dlwp_afno_wq_fold_bp": (_I, [_V, _V, _V, _V, _I, _I, _I, _V]),
     "dlwp_comm_unique_id": (_I, [_V]),
     "dlwp_comm_create": (_I, [_V, _I, _I, C.POINTER(_V)]),
     "dlwp_comm_destroy": (None, [_V]),

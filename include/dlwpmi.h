@@ -326,10 +326,12 @@ int dlwp_irfft2(const dlwp_fft_plan* plan, const float* X, float* x, float* work
 /* result), in the planar layout of the real batched GEMMs that replace the complex einsums -- no copy  */
 /* or zero fill between transform and products.  irfft2_planar reads zeros outside the window; adjoint  */
 /* as above.  work: scratch of the FULL half spectrum's size (2 B H (W/2+1) C floats).                  */
+/* bs > 0 (a divisor of C): block-planar instead, X [B][r1 - r0][c1][C / bs][2 (re | im)][bs] -- with   */
+/* dlwp_afno_wq_expand_bp's weights the complex block MLP of a layer is ONE real batched GEMM.          */
 int dlwp_rfft2_planar(const dlwp_fft_plan* plan, const float* x, float* X, float* work, int B, int C, int r0, int r1,
-                      int c1, int norm, int adjoint, void* stream);
+                      int c1, int bs, int norm, int adjoint, void* stream);
 int dlwp_irfft2_planar(const dlwp_fft_plan* plan, const float* X, float* x, float* work, int B, int C, int r0, int r1,
-                       int c1, int norm, int adjoint, void* stream);
+                       int c1, int bs, int norm, int adjoint, void* stream);
 
 /* General-grid AFNO2D (grids whose block spectrum does not fit LDS): the transforms run as     */
 /* dlwp_gemm_batched against DFT tables and the per-mode block MLP as batched GEMMs over the     */
@@ -338,6 +340,12 @@ int dlwp_irfft2_planar(const dlwp_fft_plan* plan, const float* X, float* x, floa
 /* complex gradient from a wq-shaped gradient.                                                   */
 int dlwp_afno_wq_expand(const float* w, float* wq, int nb, int bs_in, int bs_out, void* stream);
 int dlwp_afno_wq_fold(const float* gq, float* gw, int nb, int bs_in, int bs_out, void* stream);
+/* Block-planar form (tokens [T][blk][re | im][bs], dlwp_rfft2_planar with bs > 0): wq [blk][ri][i][ro][o], one  */
+/* real 2 bs_in x 2 bs_out matrix per channel block, and the bias b [2][nb][bs_out] reordered to bq [blk][ro][o]; */
+/* fold ACCUMULATES both gradients (gw, gb in the reference's parameter layouts, fourcastnet.py:70-75).           */
+int dlwp_afno_wq_expand_bp(const float* w, const float* b, float* wq, float* bq, int nb, int bs_in, int bs_out, void* stream);
+int dlwp_afno_wq_fold_bp(const float* gq, const float* gbq, float* gw, float* gb, int nb, int bs_in, int bs_out,
+                         void* stream);
 
 /* Window partition / reverse of shifted-window attention as one gather each (the reference  */
 /* runs pad, roll, partition / reverse, roll, crop as separate full-tensor copies:             */

@@ -67,9 +67,10 @@ def test_fft_backward_passes_are_the_adjoints(cuda, B, H, W, C, layout, norm):
     assert rel(Yd.grad, Yr.grad) <= TOL
 
 
-@pytest.mark.parametrize("B,H,W,C,win", [(2, 16, 24, 4, None), (1, 90, 180, 8, (0, 90, 46)), (1, 103, 180, 2, (21, 83, 31)),
-                                         (2, 7, 11, 4, (2, 6, 3)), (1, 45, 64, 40, (9, 37, 14))])
-def test_planar_window_transforms_match_torch(cuda, B, H, W, C, win):
+@pytest.mark.parametrize("B,H,W,C,win,bs", [(2, 16, 24, 4, None, 0), (1, 90, 180, 8, (0, 90, 46), 0), (1, 103, 180, 2, (21, 83, 31), 0),
+                                            (2, 7, 11, 4, (2, 6, 3), 0), (1, 45, 64, 40, (9, 37, 14), 8), (2, 16, 24, 12, None, 4),
+                                            (1, 90, 180, 96, (0, 90, 46), 48), (2, 7, 11, 6, (2, 6, 3), 2)])
+def test_planar_window_transforms_match_torch(cuda, B, H, W, C, win, bs):
     """rfft2_planar / irfft2_planar (a window of the half spectrum as [2 (re | im), B, rows, cols, C], the AFNO mixer's GEMM
     operand) against torch.fft on the CPU with the reference's slicing / zero-initialised inverse (fourcastnet.py:85-124):
     values both ways and both backward passes."""
@@ -82,9 +83,16 @@ def test_planar_window_transforms_match_torch(cuda, B, H, W, C, win):
     G = torch.randn(Xr.shape, generator=g)
     (Xr * G.double()).sum().backward()
     xd = x.to(cuda).requires_grad_(True)
-    X = fft.rfft2_planar(xd, "ortho", win)
-    assert X.shape == (2, B, r1 - r0, c1, C)
-    (X * G.to(cuda)).sum().backward()
+    def to_layout(t):          # planar [2, B, R, c1, C] -> the layout under test
+        return t.reshape(2, B, r1 - r0, c1, C // bs, bs).permute(1, 2, 3, 4, 0, 5) if bs else t
+
+    def from_layout(t):
+        return t.permute(4, 0, 1, 2, 3, 5).reshape(2, B, r1 - r0, c1, C) if bs else t
+
+    X = fft.rfft2_planar(xd, "ortho", win, block=bs)
+    assert X.shape == ((B, r1 - r0, c1, C // bs, 2, bs) if bs else (2, B, r1 - r0, c1, C))
+    (X * to_layout(G.to(cuda))).sum().backward()
+    X = from_layout(X)
     assert rel(X, Xr) <= TOL
     assert rel(xd.grad, xr.grad) <= TOL
     Y = torch.randn(Xr.shape, generator=g)
@@ -94,8 +102,8 @@ def test_planar_window_transforms_match_torch(cuda, B, H, W, C, win):
     yr = torch.fft.irfft2(full, s=(H, W), dim=(1, 2), norm="ortho")
     Gy = torch.randn(yr.shape, generator=g)
     (yr * Gy.double()).sum().backward()
-    Yd = Y.to(cuda).requires_grad_(True)
-    y = fft.irfft2_planar(Yd, H, W, "ortho", win)
+    Yd = to_layout(Y.to(cuda)).contiguous().requires_grad_(True)
+    y = fft.irfft2_planar(Yd, H, W, "ortho", win, block=bs)
     (y * Gy.to(cuda)).sum().backward()
     assert rel(y, yr) <= TOL
-    assert rel(Yd.grad, Yr.grad) <= TOL
+    assert rel(from_layout(Yd.grad), Yr.grad) <= TOL
