@@ -516,6 +516,11 @@ int make_axis(FftAxis& ax, int N, float2** tab_dev, float** amat_dev, int ib_cap
     }
     // inner lanes: the widest power of two whose [N][IB + 1] tile plus the table fits ~150 KB of LDS
     int ib = ib_cap;
+    // a large prime last radix (103 of 721 / 7 = 103 rows of the 721 x 1440 patch grid) runs on the matrix cores only in the
+    // 512-thread shape (N * IB > 4096): widen the lanes until it does (103 x 16 lanes: generic pass, 213 us per planar
+    // transform of 103 x 180 x 768; 103 x 64: 149 us)
+    if (ax.rad[ax.nrad - 1] >= 16)
+        while (N * ib <= 4096 && (size_t)N * (2 * ib + 2) * sizeof(float2) <= 150 * 1024) ib <<= 1;
     while (ib > 1 && (size_t)N * (ib + 2) * sizeof(float2) > 150 * 1024) ib >>= 1;
 
     DLWP_REQUIRE((size_t)N * (ib + 2) * sizeof(float2) <= 150 * 1024, DLWP_E_UNSUPPORTED, "fft: axis length %d does not fit LDS", N);
@@ -663,7 +668,11 @@ extern "C" int dlwp_fft_plan_create(int H, int W, dlwp_fft_plan** out) {
     dlwp_fft_plan* p = new dlwp_fft_plan();
     p->H = H; p->W = W; p->tabW = p->tabH = nullptr; p->amatW = p->amatH = nullptr;
     int rc;
-    if ((rc = make_axis(p->axW, W, &p->tabW, &p->amatW, 8)) || (rc = make_axis(p->axH, H, &p->tabH, &p->amatH, 16))) {
+    // inner lanes per workgroup: W axis 8 channel PAIRS = 64 bytes of a channels-last row per w, H axis 16 complex = 128 bytes
+    static const char* ibw = getenv("DLWP_FFT_IBW");
+    static const char* ibh = getenv("DLWP_FFT_IBH");
+    if ((rc = make_axis(p->axW, W, &p->tabW, &p->amatW, ibw ? atoi(ibw) : 8)) ||
+        (rc = make_axis(p->axH, H, &p->tabH, &p->amatH, ibh ? atoi(ibh) : 16))) {
         dlwp_fft_plan_destroy(p);
         return rc;
     }
