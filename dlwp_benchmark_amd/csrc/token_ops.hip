@@ -738,8 +738,11 @@ __global__ __launch_bounds__(256) void gemm_glds_tn_kernel(GemmDev a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // bias-gradient by-product: the row sums of the A tile are the same for every column tile -- each column tile's workgroups take
+    // the K-steps kt = nt_ (mod ntn), so the extra VALU work (it does not overlap the MFMAs) is spread evenly instead of making
+    // the n0 == 0 workgroups the slow ones of the round
     float rsum[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool want_rsum = a.rowsum && n0 == 0 && !(w & 1);
+    const bool has_rsum = a.rowsum && !(w & 1);
     const int nk = (kend - kbeg + KD - 1) / KD;
     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
     auto frag = [&](const __bf16* tile, int col0, int kk) {      // rows col0 + r of the operand, k = 32 kk + 8 g .. + 7
@@ -779,7 +782,7 @@ __global__ __launch_bounds__(256) void gemm_glds_tn_kernel(GemmDev a) {
                     for (int e = 0; e < 8; ++e)
                         if (e >= kl) af[i][e] = (__bf16)0.f;
             }
-            if (want_rsum) {
+            if (has_rsum && kt % a.ntn == nt_) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -793,7 +796,7 @@ __global__ __launch_bounds__(256) void gemm_glds_tn_kernel(GemmDev a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
-    if (want_rsum) {
+    if (has_rsum) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float v = rsum[i];

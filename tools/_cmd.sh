@@ -1,5 +1,3 @@
 set -e
 mkdir -p gpurun_out
-python tools/probe_fft_ib.py 2>&1 | grep -v amdgpu
-python -m pytest tests/test_gpu_fft.py tests/test_gpu_afno.py -q -x -m gpu 2>&1 | tail -3
-for wl in afno721; do python bench.py --workload $wl --steps 20 --warmup 3 --no-roofline --no-cpu-baseline; done > gpurun_out/models_new.jsonl 2>&1
+for wl in afno pangu; do python bench.py --workload $wl --steps 20 --warmup 3 --no-roofline --no-cpu-baseline; done > gpurun_out/models_new.jsonl 2>&1
