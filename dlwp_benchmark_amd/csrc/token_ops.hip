@@ -50,6 +50,7 @@ struct GemmDev {
     // storage types (dlwp_gemm_mixed): bit 0 A, bit 1 B, bit 2 C and preact, bit 3 residual hold bf16 in memory (the pointers
     // above are then __bf16*, leading dimensions and batch strides stay in elements).  Accumulation and epilogue run in fp32.
     int dt;
+    float* slab;               // gemm_glds_tn_kernel: [K slices][M][N] partial products (plain stores; gemm_slab_reduce_kernel adds them)
 };
 constexpr int DT_A = 1, DT_B = 2, DT_C = 4, DT_R = 8;
 
@@ -807,6 +808,8 @@ __global__ __launch_bounds__(256) void gemm_glds_tn_kernel(GemmDev a) {
         }
     }
     const bool atomic = a.splits > 1;
+    float* out = a.slab ? a.slab + (long long)blockIdx.z * a.M * a.N : a.C;
+    const int ldo = a.slab ? a.N : a.ldc;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -815,11 +818,56 @@ __global__ __launch_bounds__(256) void gemm_glds_tn_kernel(GemmDev a) {
             for (int q = 0; q < 4; ++q) {
                 const int m = m0 + wm + i * 16 + 4 * g + q, n = n0 + wn + j * 16 + r;
                 if (m < a.M && n < a.N) {
-                    float* dst = a.C + (long long)m * a.ldc + n;
+                    float* dst = out + (long long)m * ldo + n;
+                    if (a.slab) { *dst = acc[i][j][q]; continue; }
                     if (atomic) atomic_add_f32(dst, acc[i][j][q]);          // C zeroed by the caller (or accumulating)
                     else *dst = a.accumulate ? *dst + acc[i][j][q] : acc[i][j][q];
                 }
             }
+}
+
+// C (+)= sum over the K slices of the slab, in slice order (bit-reproducible, unlike the float atomics it replaces: the atomic
+// epilogue of the sliced kernel cost 25-30 % of its time, profiles/r03_gemm_glds_tn.txt)
+__global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, int M, int N, int ldc,
+                                                               int slices, int accumulate) {
+    const int n4 = N / 4;
+    const long long total = (long long)M * n4, plane = (long long)M * N;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int m = (int)(e / n4), n = (int)(e - (long long)m * n4) * 4;
+        const float* sp = slab + (long long)m * N + n;
+        f32x4 v = *reinterpret_cast<const f32x4*>(sp);
+        for (int z = 1; z < slices; ++z) {
+            const f32x4 u = *reinterpret_cast<const f32x4*>(sp + z * plane);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += u[k];
+        }
+        float* cp = C + (long long)m * ldc + n;
+        if (accumulate) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += cp[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cp[k] = v[k];
+    }
+}
+
+// scratch for the slices: one per device context, grown outside stream captures only (a capture that would need a larger one
+// keeps the atomic epilogue).  As with dlwp_sumsq's partials, calls on different streams at the same time would share it: the
+// training paths issue their GEMMs on one stream (the warm-up steps before a graph capture size it).
+static float* g_tn_slab = nullptr;
+static size_t g_tn_slab_bytes = 0;
+static float* tn_slab_for(hipStream_t s, size_t bytes) {
+    if (g_tn_slab && g_tn_slab_bytes >= bytes) return g_tn_slab;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+    if (g_tn_slab) {
+        if (hipDeviceSynchronize() != hipSuccess || hipFree(g_tn_slab) != hipSuccess) return nullptr;
+        g_tn_slab = nullptr;
+        g_tn_slab_bytes = 0;
+    }
+    if (hipMalloc(reinterpret_cast<void**>(&g_tn_slab), bytes) != hipSuccess) { (void)hipGetLastError(); g_tn_slab = nullptr; return nullptr; }
+    g_tn_slab_bytes = bytes;
+    return g_tn_slab;
 }
 
 // weight-gradient products the TN kernel takes: both operands bf16 arrays [k][row], fp32 output, no epilogue, one batch, the
@@ -848,6 +896,10 @@ static int gemm_glds_tn_launch(const GemmDev& a_in, hipStream_t s) {
     a.splits = std::max(2, ceil_div(a.K, a.kchunk));             // > 1: the atomic epilogue (the caller zeroed C for its own split)
     const size_t lds = (size_t)2 * 2 * GT * kd * 2;
     const dim3 grid(a.ntn * a.ntm, 1, ceil_div(a.K, a.kchunk));
+    static const bool no_slab = getenv("DLWP_GEMM_TN_ATOMIC") != nullptr;
+    // few output tiles cut into many slices (SFNO's 512 x 256: 8 tiles x 32) read more slab in the reduction than the atomics cost
+    a.slab = (no_slab || a.ntn * a.ntm < 24 || a.N % 4 || a.ldc % 4 || (uintptr_t)a.C % 16) ? nullptr
+                                                                         : tn_slab_for(s, sizeof(float) * grid.z * (size_t)a.M * a.N);
     int rc;
     if (shallow) {
         if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_glds_tn_kernel<32>), lds, "gemm_glds_tn"))) return rc;
@@ -855,6 +907,12 @@ static int gemm_glds_tn_launch(const GemmDev& a_in, hipStream_t s) {
     } else {
         if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_glds_tn_kernel<64>), lds, "gemm_glds_tn"))) return rc;
         hipLaunchKernelGGL(gemm_glds_tn_kernel<64>, grid, dim3(256), lds, s, a);
+    }
+    if (a.slab) {
+        // the caller zeroed C for its own split-K when it does not accumulate: adding to it is the same either way
+        const long long units = (long long)a.M * (a.N / 4);
+        hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)std::min<long long>((units + 255) / 256, 2048)), dim3(256), 0, s,
+                           a.slab, a.C, a.M, a.N, a.ldc, (int)grid.z, 1);
     }
     return DLWP_OK;
 }
