@@ -113,55 +113,86 @@ class _BlockComplexLinear(torch.autograd.Function):
         return gX, (None if wslot is not None else gw), (None if bslot is not None else gb), None, None
 
 
-class _BlockComplexLinearBP(torch.autograd.Function):
-    """The same layer on block-planar spectra X [T, nb, 2 (re | im), bs_in] (fft.rfft2_planar(block=bs_in)): with the weights as
-    one real [2 bs_in, 2 bs_out] matrix per channel block (dlwp_afno_wq_expand_bp) the layer is ONE batched GEMM with bias,
-    activation and stored pre-activation in its epilogue, and so is each of its two gradients (the planar form above takes two
-    accumulating passes per product, one per input plane)."""
+def _bp_layer_forward(X, w, b, act, lam):
+    """One complex block-diagonal layer on block-planar spectra X [T, 2 C] (tokens [T][blk][re | im][bs_in],
+    fft.rfft2_planar(block=bs_in)): with the weights as one real [2 bs_in, 2 bs_out] matrix per channel block
+    (dlwp_afno_wq_expand_bp) the layer is ONE batched GEMM with bias, activation and stored pre-activation in its epilogue (the
+    planar form above takes two accumulating passes per product, one per input plane).  Returns (O, wq, P)."""
+    lib = L.load()
+    T = X.shape[0]
+    _, nb, bsi, bso = w.shape
+    C, Co = nb * bsi, nb * bso
+    wq = torch.empty(nb, 2 * bsi, 2 * bso, device=X.device)
+    bq = torch.empty(2 * Co, device=X.device)
+    L.check(lib.dlwp_afno_wq_expand_bp(L.ptr(w.contiguous()), L.ptr(b.contiguous()), L.ptr(wq), L.ptr(bq), nb, bsi, bso, L.stream()))
+    O = torch.empty(T, 2 * Co, device=X.device)
+    P = torch.empty(T, 2 * Co, device=X.device) if act else None
+    _gemm_batched(X, wq, O, T, 2 * bso, 2 * bsi, 2 * C, 2 * bso, 2 * Co, 0, 0, nb, 1, (2 * bsi, 0), (4 * bsi * bso, 0), (2 * bso, 0),
+                  bias=bq, sBi=(2 * bso, 0), act=act, act_param=lam, preact=P)
+    return O, wq, P
+
+
+def _bp_layer_backward(X, wq, P, gO, act, lam, wshape, bshape, wslot, bslot):
+    """Gradients of _bp_layer_forward: one batched GEMM each for gX and the block weights, one column sum for the bias; the
+    parameter gradients are ACCUMULATED into the flat-gradient slots when the parameters have them.  Returns (gX, gw, gb) with
+    gw / gb None when they went into a slot."""
+    lib = L.load()
+    T = X.shape[0]
+    _, nb, bsi, bso = wshape
+    C, Co = nb * bsi, nb * bso
+    if act:
+        gP = torch.empty_like(gO)
+        L.check(lib.dlwp_act_bwd(L.ptr(P), L.ptr(gO), L.ptr(gP), gO.numel(), act, lam, L.stream()))
+    else:
+        gP = gO
+    gX = torch.empty_like(X)                 # gX[:, blk] = gP[:, blk] . wq[blk]^T
+    _gemm_batched(gP, wq, gX, T, 2 * bsi, 2 * bso, 2 * Co, 2 * bso, 2 * C, 0, 1, nb, 1, (2 * bso, 0), (4 * bsi * bso, 0), (2 * bsi, 0))
+    nq = nb * 4 * bsi * bso
+    gq = torch.zeros(nq + 2 * Co, device=X.device)      # [gwq | gbq]: one fill; split-K partial sums / column sums accumulate
+    # gwq[blk] = X[:, blk]^T . gP[:, blk]   (K = tokens: split along K inside the kernel)
+    _gemm_batched(X, gP, gq, 2 * bsi, 2 * bso, T, 2 * C, 2 * Co, 2 * bso, 1, 0, nb, 1, (2 * bsi, 0), (2 * bso, 0), (4 * bsi * bso, 0),
+                  accumulate=1)
+    L.check(lib.dlwp_colsum(L.ptr(gP), L.ptr(gq) + 4 * nq, T, 2 * Co, L.stream()))
+    gw = wslot if wslot is not None else torch.zeros(wshape, device=X.device)
+    gb = bslot if bslot is not None else torch.zeros(bshape, device=X.device)
+    L.check(lib.dlwp_afno_wq_fold_bp(L.ptr(gq), L.ptr(gq) + 4 * nq, L.ptr(gw), L.ptr(gb), nb, bsi, bso, L.stream()))
+    return gX, (None if wslot is not None else gw), (None if bslot is not None else gb)
+
+
+class _AfnoFftFilterFn(torch.autograd.Function):
+    """AFNO2D on the FFT path as ONE autograd node: rfft2 (kept window, block-planar) -> complex block MLP (ReLU, soft-shrink) ->
+    irfft2 + x, the skip added in the inverse transform's store; backward mirrors it and adds the gradient that arrived along the
+    skip in the store of the last transform -- no separate residual add, no autograd accumulation at the fork of x
+    (reference: AFNO2D.forward, src/dlwpbench/models/fourcastnet/fourcastnet.py:77-126)."""
 
     @staticmethod
-    def forward(ctx, X, w, b, act, lam):
-        lib = L.load()
-        T = X.shape[0]
-        _, nb, bsi, bso = w.shape
-        C, Co = nb * bsi, nb * bso
-        X = X.contiguous().view(T, 2 * C)
-        wq = torch.empty(nb, 2 * bsi, 2 * bso, device=X.device)
-        bq = torch.empty(2 * Co, device=X.device)
-        L.check(lib.dlwp_afno_wq_expand_bp(L.ptr(w.contiguous()), L.ptr(b.contiguous()), L.ptr(wq), L.ptr(bq), nb, bsi, bso, L.stream()))
-        O = torch.empty(T, 2 * Co, device=X.device)
-        P = torch.empty(T, 2 * Co, device=X.device) if act else None
-        _gemm_batched(X, wq, O, T, 2 * bso, 2 * bsi, 2 * C, 2 * bso, 2 * Co, 0, 0, nb, 1, (2 * bsi, 0), (4 * bsi * bso, 0), (2 * bso, 0),
-                      bias=bq, sBi=(2 * bso, 0), act=act, act_param=lam, preact=P)
-        ctx.save_for_backward(X, wq, P)
-        ctx.cfg = (T, C, Co, nb, bsi, bso, act, lam)
-        ctx.slots = (_grad_slot(w), _grad_slot(b))
-        ctx.shapes = (w.shape, b.shape)
-        return O.view(T, nb, 2, bso)
+    def forward(ctx, x, w1, b1, w2, b2, win, lam):
+        from . import fft
+        B, H, W, C = x.shape
+        r0, r1, c1 = win
+        bs = w1.shape[2]
+        x = x.contiguous().float()
+        X = fft._run_r2c_planar(x, win, bs, fft.NORMS["ortho"], 0).view(B * (r1 - r0) * c1, 2 * C)
+        O1, wq1, P1 = _bp_layer_forward(X, w1, b1, 2, 0.0)
+        O2, wq2, P2 = _bp_layer_forward(O1, w2, b2, 3, lam)
+        y = fft._run_c2r_planar(O2.view(B, r1 - r0, c1, C // bs, 2, bs), H, W, win, bs, fft.NORMS["ortho"], 0, residual=x)
+        ctx.save_for_backward(X, wq1, P1, O1, wq2, P2)
+        ctx.cfg = (B, H, W, C, win, bs, lam, w1.shape, b1.shape, w2.shape, b2.shape)
+        ctx.slots = tuple(_grad_slot(p) for p in (w1, b1, w2, b2))
+        return y
 
     @staticmethod
-    def backward(ctx, gO):
-        lib = L.load()
-        X, wq, P = ctx.saved_tensors
-        T, C, Co, nb, bsi, bso, act, lam = ctx.cfg
-        gO = gO.contiguous().view(T, 2 * Co)
-        if act:
-            gP = torch.empty_like(gO)
-            L.check(lib.dlwp_act_bwd(L.ptr(P), L.ptr(gO), L.ptr(gP), gO.numel(), act, lam, L.stream()))
-        else:
-            gP = gO
-        gX = torch.empty_like(X)                 # gX[:, blk] = gP[:, blk] . wq[blk]^T
-        _gemm_batched(gP, wq, gX, T, 2 * bsi, 2 * bso, 2 * Co, 2 * bso, 2 * C, 0, 1, nb, 1, (2 * bso, 0), (4 * bsi * bso, 0), (2 * bsi, 0))
-        gwq = torch.zeros_like(wq)               # gwq[blk] = X[:, blk]^T . gP[:, blk]   (K = tokens: split along K inside the kernel)
-        _gemm_batched(X, gP, gwq, 2 * bsi, 2 * bso, T, 2 * C, 2 * Co, 2 * bso, 1, 0, nb, 1, (2 * bsi, 0), (2 * bso, 0), (4 * bsi * bso, 0),
-                      accumulate=1)
-        gbq = torch.zeros(2 * Co, device=X.device)
-        L.check(lib.dlwp_colsum(L.ptr(gP), L.ptr(gbq), T, 2 * Co, L.stream()))
-        wslot, bslot = ctx.slots
-        gw = wslot if wslot is not None else torch.zeros(ctx.shapes[0], device=X.device)
-        gb = bslot if bslot is not None else torch.zeros(ctx.shapes[1], device=X.device)
-        L.check(lib.dlwp_afno_wq_fold_bp(L.ptr(gwq), L.ptr(gbq), L.ptr(gw), L.ptr(gb), nb, bsi, bso, L.stream()))
-        return gX.view(T, nb, 2, bsi), (None if wslot is not None else gw), (None if bslot is not None else gb), None, None
+    def backward(ctx, gy):
+        from . import fft
+        X, wq1, P1, O1, wq2, P2 = ctx.saved_tensors
+        B, H, W, C, win, bs, lam, w1s, b1s, w2s, b2s = ctx.cfg
+        r0, r1, c1 = win
+        gy = gy.contiguous().float()
+        gO2 = fft._run_r2c_planar(gy, win, bs, fft.NORMS["ortho"], 1).view(X.shape[0], -1)
+        gO1, gw2, gb2 = _bp_layer_backward(O1, wq2, P2, gO2, 3, lam, w2s, b2s, ctx.slots[2], ctx.slots[3])
+        gX, gw1, gb1 = _bp_layer_backward(X, wq1, P1, gO1, 2, 0.0, w1s, b1s, ctx.slots[0], ctx.slots[1])
+        gx = fft._run_c2r_planar(gX.view(B, r1 - r0, c1, C // bs, 2, bs), H, W, win, bs, fft.NORMS["ortho"], 1, residual=gy)
+        return gx, gw1, gb1, gw2, gb2, None, None
 
 
 def afno2d_tiled(x, w1, b1, w2, b2, num_blocks, sparsity_threshold=0.01, hard_thresholding_fraction=1.0):
@@ -206,11 +237,8 @@ def afno2d_fft(x, w1, b1, w2, b2, num_blocks, sparsity_threshold=0.01, hard_thre
     win = (r0, r1, c1)
     nb, bs = w1.shape[1], w1.shape[2]
     if bs >= 2 and w2.shape[3] == bs:
-        # block-planar spectra: one batched GEMM per layer and gradient
-        X = fft.rfft2_planar(x, "ortho", win, block=bs).view(B * R * c1, nb, 2, bs)
-        o1 = _BlockComplexLinearBP.apply(X, w1, b1, 2, 0.0)
-        o2 = _BlockComplexLinearBP.apply(o1, w2, b2, 3, float(sparsity_threshold))
-        return add_tokens(fft.irfft2_planar(o2.view(B, R, c1, nb, 2, bs), H, W, "ortho", win, block=bs), x)
+        # block-planar spectra: one batched GEMM per layer and gradient, the whole filter one autograd node
+        return _AfnoFftFilterFn.apply(x, w1, b1, w2, b2, win, float(sparsity_threshold))
     planar = fft.rfft2_planar(x, "ortho", win).view(2, B * R * c1, C)
     o1 = _BlockComplexLinear.apply(planar, w1, b1, 2, 0.0)
     o2 = _BlockComplexLinear.apply(o1, w2, b2, 3, float(sparsity_threshold))

@@ -271,6 +271,7 @@ __device__ __forceinline__ void lds_fft(float2* buf, const float2* tabs, const F
 struct FftIO {
     FftAxis ax;
     const float* in; float* out;
+    const float* res;         // channels-last C2R: added to the output (a residual connection around the transform pair), or null
     long long outer;          // number of outer units (grid.y)
     int C, H, W, Wc;          // C: channels (CL) / unused (CF)
     long long nrows;          // CF real passes: B * C * H rows
@@ -363,6 +364,17 @@ __global__ __launch_bounds__(NT) void fft_c2r_kernel(FftIO a) {
     const long long o = blockIdx.y;
     const int c0 = CF ? 0 : blockIdx.x * 2 * f.IB;
     const long long r0 = CF ? o * 2 * f.IB : 0;
+    // the residual values this thread adds in its stores: loaded first, so that their latency lies under the transform
+    float2 resv[OUTS];
+    if (!CF && a.res) {
+        const int nl = min(f.IB, (a.C - c0) / 2);
+        const float* rsrc = a.res + o * W * a.C + c0;
+#pragma unroll
+        for (int u = 0; u < OUTS; ++u) {
+            const int e = threadIdx.x + u * NT, lane = e & (f.IB - 1), w = e >> f.logIB;
+            resv[u] = (w < W && lane < nl) ? *reinterpret_cast<const float2*>(rsrc + (long long)w * a.C + 2 * lane) : make_float2(0.f, 0.f);
+        }
+    }
     // merge: Z_k = Y1_k + i Y2_k, Z_{W-k} = conj(Y1_k) + i conj(Y2_k); DC / Nyquist use the real parts only
     if (!CF) {
         const int nl = min(f.IB, (a.C - c0) / 2);
@@ -398,11 +410,14 @@ __global__ __launch_bounds__(NT) void fft_c2r_kernel(FftIO a) {
     if (!CF) {
         const int nl = min(f.IB, (a.C - c0) / 2);
         float* dst = a.out + o * W * a.C + c0;
-        for (int e = threadIdx.x; e < W << f.logIB; e += NT) {
-            const int lane = e & (f.IB - 1), w = e >> f.logIB;
-            if (lane >= nl) continue;
+#pragma unroll
+        for (int u = 0; u < OUTS; ++u) {            // OUTS * NT >= W * IB (shape_of)
+            const int e = threadIdx.x + u * NT, lane = e & (f.IB - 1), w = e >> f.logIB;
+            if (w >= W || lane >= nl) continue;
             const float2 z = buf[w * IBP + lane];
-            *reinterpret_cast<float2*>(dst + (long long)w * a.C + 2 * lane) = make_float2(a.scale * z.x, a.scale * z.y);
+            float2 v = make_float2(a.scale * z.x, a.scale * z.y);
+            if (a.res) { v.x += resv[u].x; v.y += resv[u].y; }
+            *reinterpret_cast<float2*>(dst + (long long)w * a.C + 2 * lane) = v;
         }
     } else {
         for (int e = threadIdx.x; e < W * 2 * f.IB; e += NT) {
@@ -607,9 +622,9 @@ LaunchShape shape_of(const FftAxis& ax) {
 #define NOTHING
 
 int run_w_real(const dlwp_fft_plan* p, bool to_complex, bool cf, const float* in, float* out, int B, int C, float scale,
-               float w_int, hipStream_t stream) {
+               float w_int, hipStream_t stream, const float* res = nullptr) {
     FftIO io{};
-    io.ax = p->axW; io.in = in; io.out = out; io.C = C; io.H = p->H; io.W = p->W; io.Wc = p->W / 2 + 1;
+    io.ax = p->axW; io.in = in; io.out = out; io.res = res; io.C = C; io.H = p->H; io.W = p->W; io.Wc = p->W / 2 + 1;
     io.scale = scale; io.w_int = w_int;
     dim3 grid;
     if (cf) {
@@ -728,7 +743,9 @@ extern "C" int dlwp_irfft2(const dlwp_fft_plan* p, const float* X, float* x, flo
 // zero-initialised o2, src/dlwpbench/models/fourcastnet/fourcastnet.py:85-124).  The H pass of the forward transform only runs
 // over the kept columns; the inverse reads zeros outside the window.  adjoint: as dlwp_rfft2 / dlwp_irfft2 (the adjoint of the
 // windowed inverse is the windowed forward transform and vice versa).  work: scratch of the FULL half spectrum's size.
-// bs > 0: X is block-planar instead, [B][r1 - r0][c1][C / bs][2 (re | im)][bs] (FftIO::bs).
+// bs > 0: X is block-planar instead, [B][r1 - r0][c1][C / bs][2 (re | im)][bs] (FftIO::bs).  irfft2_planar's residual (field-shaped, or
+// null) is added to its output: the skip connection around AFNO2D's transform pair, and in the backward pass the gradient that
+// reached the input along that skip.
 extern "C" int dlwp_rfft2_planar(const dlwp_fft_plan* p, const float* x, float* X, float* work, int B, int C, int r0, int r1, int c1,
                                  int bs, int norm, int adjoint, void* stream_) {
     DLWP_REQUIRE(p && x && X && work && B > 0 && C > 0 && norm >= 0 && norm <= 2, DLWP_E_INVALID, "rfft2_planar: bad argument");
@@ -745,8 +762,8 @@ extern "C" int dlwp_rfft2_planar(const dlwp_fft_plan* p, const float* x, float* 
     return run_h_c2c(p, work, X, B, J, -1.f, adjoint ? sHi : sHf, stream, 0, (long long)B * (r1 - r0) * Jw, r0, r1, Jw, C, bs);
 }
 
-extern "C" int dlwp_irfft2_planar(const dlwp_fft_plan* p, const float* X, float* x, float* work, int B, int C, int r0, int r1, int c1,
-                                  int bs, int norm, int adjoint, void* stream_) {
+extern "C" int dlwp_irfft2_planar(const dlwp_fft_plan* p, const float* X, float* x, float* work, const float* residual, int B, int C,
+                                  int r0, int r1, int c1, int bs, int norm, int adjoint, void* stream_) {
     DLWP_REQUIRE(p && x && X && work && B > 0 && C > 0 && norm >= 0 && norm <= 2, DLWP_E_INVALID, "irfft2_planar: bad argument");
     const int Wc = p->W / 2 + 1;
     DLWP_REQUIRE(0 <= r0 && r0 < r1 && r1 <= p->H && c1 >= 1 && c1 <= Wc, DLWP_E_INVALID, "irfft2_planar: window [%d, %d) x %d outside %d x %d",
@@ -758,5 +775,5 @@ extern "C" int dlwp_irfft2_planar(const dlwp_fft_plan* p, const float* X, float*
     const long long J = (long long)Wc * C, Jw = (long long)c1 * C;
     int rc = run_h_c2c(p, X, work, B, J, +1.f, adjoint ? sHf : sHi, stream, (long long)B * (r1 - r0) * Jw, 0, r0, r1, Jw, C, bs);
     if (rc) return rc;
-    return run_w_real(p, false, false, work, x, B, C, adjoint ? sWf : sWi, adjoint ? 0.5f : 1.f, stream);
+    return run_w_real(p, false, false, work, x, B, C, adjoint ? sWf : sWi, adjoint ? 0.5f : 1.f, stream, residual);
 }

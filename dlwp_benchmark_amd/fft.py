@@ -105,13 +105,16 @@ def _run_r2c_planar(x, win, bs, norm, adjoint):
     return X
 
 
-def _run_c2r_planar(X, H, W, win, bs, norm, adjoint):
+def _run_c2r_planar(X, H, W, win, bs, norm, adjoint, residual=None):
     B = X.shape[0] if bs else X.shape[1]
     Cc = X.shape[3] * bs if bs else X.shape[4]
     r0, r1, c1 = win
     x = torch.empty(B, H, W, Cc, device=X.device)
     work = torch.empty(B, H, W // 2 + 1, Cc, 2, device=X.device)
-    L.check(L.load().dlwp_irfft2_planar(_plan(H, W), L.ptr(X), L.ptr(x), L.ptr(work), B, Cc, r0, r1, c1, bs, norm, adjoint, L.stream()))
+    if residual is not None and (tuple(residual.shape) != (B, H, W, Cc) or residual.dtype != torch.float32 or not residual.is_contiguous()):
+        raise L.DlwpError("irfft2_planar: the residual must be a contiguous fp32 field of the output's shape")
+    L.check(L.load().dlwp_irfft2_planar(_plan(H, W), L.ptr(X), L.ptr(x), L.ptr(work), L.ptr(residual) if residual is not None else None,
+                                        B, Cc, r0, r1, c1, bs, norm, adjoint, L.stream()))
     return x
 
 

@@ -330,8 +330,10 @@ int dlwp_irfft2(const dlwp_fft_plan* plan, const float* X, float* x, float* work
 /* dlwp_afno_wq_expand_bp's weights the complex block MLP of a layer is ONE real batched GEMM.          */
 int dlwp_rfft2_planar(const dlwp_fft_plan* plan, const float* x, float* X, float* work, int B, int C, int r0, int r1,
                       int c1, int bs, int norm, int adjoint, void* stream);
-int dlwp_irfft2_planar(const dlwp_fft_plan* plan, const float* X, float* x, float* work, int B, int C, int r0, int r1,
-                       int c1, int bs, int norm, int adjoint, void* stream);
+/* residual (field-shaped [B][H][W][C], or NULL) is added to irfft2_planar's output: AFNO2D's `x + bias` skip    */
+/* (fourcastnet.py:126) in the forward pass, the gradient arriving along that skip in the backward pass.      */
+int dlwp_irfft2_planar(const dlwp_fft_plan* plan, const float* X, float* x, float* work, const float* residual, int B,
+                       int C, int r0, int r1, int c1, int bs, int norm, int adjoint, void* stream);
 
 /* General-grid AFNO2D (grids whose block spectrum does not fit LDS): the transforms run as     */
 /* dlwp_gemm_batched against DFT tables and the per-mode block MLP as batched GEMMs over the     */

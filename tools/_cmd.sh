@@ -1,5 +1,4 @@
 set -e
-python -m pytest tests/test_gpu_bf16_storage.py -q -x -m gpu 2>&1 | tail -2
-for wl in afno pangu swin; do python bench.py --workload $wl --steps 20 --warmup 3 --no-roofline --no-cpu-baseline; done > gpurun_out/models_new.jsonl 2>&1
-python bench.py --workload sfno --steps 40 --warmup 5 --no-roofline --no-cpu-baseline >> gpurun_out/models_new.jsonl 2>&1
-python bench.py --workload sfno --batch 16 --steps 40 --warmup 5 --no-roofline --no-cpu-baseline >> gpurun_out/models_new.jsonl 2>&1
+mkdir -p gpurun_out
+python -m pytest tests/test_gpu_fft.py tests/test_gpu_afno.py -q -x -m gpu 2>&1 | tail -3
+for wl in afno afno721; do python bench.py --workload $wl --steps 20 --warmup 3 --no-roofline --no-cpu-baseline; done > gpurun_out/models_new.jsonl 2>&1
