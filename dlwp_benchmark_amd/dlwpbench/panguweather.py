@@ -220,7 +220,8 @@ class DownSample(nn.Module):
     def forward(self, x):
         B, N, C = x.shape
         (ipl, ilat, ilon), (opl, olat, olon) = self.input_resolution, self.output_resolution
-        x = F.pad(x.reshape(B, ipl, ilat, ilon, C).permute(0, 4, 1, 2, 3), self.padding).permute(0, 2, 3, 4, 1)
+        if any(self.padding):
+            x = F.pad(x.reshape(B, ipl, ilat, ilon, C).permute(0, 4, 1, 2, 3), self.padding).permute(0, 2, 3, 4, 1)
         x = x.reshape(B, ipl, olat, 2, olon, 2, C).permute(0, 1, 2, 4, 3, 5, 6).reshape(B, opl * olat * olon, 4 * C)
         return self.linear(self.norm(x))
 
@@ -276,6 +277,14 @@ class PatchRecovery2D(nn.Module):
         ph, pw = H - self.img_size[0], W - self.img_size[1]
         return out[:, :, ph // 2:H - (ph - ph // 2), pw // 2:W - (pw - pw // 2)]
 
+    def forward_tokens(self, tokens):
+        """The same on channels-last tokens [B, Lat, Lon, C] (the layout the blocks produce): no NCHW round trip of the 2 E wide
+        feature map; only the (few-channel) output is permuted."""
+        out = self.conv.forward_tokens(tokens)                       # [B, H, W, O]
+        H, W = out.shape[1], out.shape[2]
+        ph, pw = H - self.img_size[0], W - self.img_size[1]
+        return out[:, ph // 2:H - (ph - ph // 2), pw // 2:W - (pw - pw // 2)].permute(0, 3, 1, 2)
+
 
 class PanguWeather(nn.Module):
     def __init__(self, constant_channels: int = 4, prescribed_channels: int = 0, prognostic_channels: int = 1,
@@ -307,8 +316,10 @@ class PanguWeather(nn.Module):
         x = self.layer1(x)
         skip = x
         x = self.layer4(self.upsample(self.layer3(self.layer2(self.downsample(x)))))
-        out = torch.cat([x, skip], dim=-1).transpose(1, 2).reshape(B, -1, Pl, Lat, Lon)
-        return self.patchrecovery2d(out[:, :, 0].contiguous())
+        # reference: cat -> [B, 2E, Pl, Lat, Lon] -> level 0 -> ConvTranspose2d (panguweather.py:318-321); tokens are ordered
+        # (pl, lat, lon), so level 0 is the first Lat * Lon of them and the transposed convolution reads them as they lie
+        out = torch.cat([x, skip], dim=-1)
+        return self.patchrecovery2d.forward_tokens(out[:, :Lat * Lon].reshape(B, Lat, Lon, -1))
 
     def forward(self, constants: torch.Tensor = None, prescribed: torch.Tensor = None,
                 prognostic: torch.Tensor = None) -> torch.Tensor:
