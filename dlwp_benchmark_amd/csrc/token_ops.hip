@@ -578,8 +578,10 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmDev a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nk = a.K / KD;
+    DLWP_STAMP(10);
     issue(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
+        if (kt == 1) DLWP_STAMP(11);
         if (kt + 1 < nk) {
             issue((kt + 1) & 1, (kt + 1) * KD);
             // this step's DMAs have landed; the next step's stay in flight
@@ -622,6 +624,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmDev a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                              // every wave has read this stage before it is refilled
     }
+    DLWP_STAMP(12);
     // ---- epilogue (two halves of 64 rows through the dead operand buffers; 16-byte global accesses)
     constexpr int LDE = GT + 4, C4 = GT / 4, RPP = 256 / C4, NPASS = 64 / RPP;
     float* tile = gsm;
@@ -690,6 +693,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmDev a) {
             }
         }
     }
+    DLWP_STAMP(13);
 }
 
 // ---- weight gradients ("TN": gW = g^T x, both operands [k = tokens][row]): both tiles are [KD k][128] images with the NN
