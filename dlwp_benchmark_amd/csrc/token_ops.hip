@@ -1657,7 +1657,10 @@ static int layernorm_bwd_impl(const float* x, const float* gamma, const float* m
     // each wave walks serially.
     // each wave then walks serially (one wave per SIMD hides no latency).  Large inputs get up to ~1024 workgroups.
     static const char* want_env = getenv("DLWP_LN_BWD_WANT");
-    const long long want = want_env ? atoi(want_env) : std::min<long long>(512, std::max<long long>(256, (long long)T * C / 16384));
+    // (measured, tools/probe_layernorm.py: 8192 x 256 wants 256 workgroups (14.7 vs 18.7 us at 128); the 1024 x 64 calls of the 64 x 64
+    // AFNO rollout want the fewer, longer ones: 128 -> 256 cost that step 4 %)
+    const long long want = want_env ? atoi(want_env)
+                                    : std::min<long long>(512, std::max<long long>((long long)T * C >= (1 << 21) ? 256 : 128, (long long)T * C / 16384));
     int rpb = 256;
     while (rpb > 4 && ceil_div(T, rpb) < want) rpb >>= 1;
     const dim3 grid(ceil_div(T, rpb));

@@ -1,4 +1,4 @@
 set -e
-python tools/bench_gemm.py 2>&1 | grep -E "C5.*(y=|gx=)" | cut -c1-150
-echo nostore
-DLWP_GEMM_EXP_NOSTORE=1 python tools/bench_gemm.py 2>&1 | grep -E "C5.*(y=|gx=)" | cut -c1-150
+python tools/bench_models.py afno --steps 20 2>&1 | grep -v amdgpu | cut -c1-200
+python bench.py --workload sfno --steps 40 --warmup 5 --no-roofline --no-cpu-baseline | cut -c1-200
+python tools/bench_models.py swin --steps 10 2>&1 | grep -v amdgpu | cut -c1-200

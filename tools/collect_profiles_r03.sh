@@ -31,6 +31,10 @@ else
   timeout 300 python3 $R/tools/bench_gemm.py > $O/gemm_bench.txt 2>&1
   timeout 600 python3 $R/tools/bench_models.py all --steps 10 > $O/models.jsonl 2> $O/models.err
   for m in afno pangu; do timeout 200 python3 $R/tools/aten_audit.py $m > $O/aten_audit_$m.txt 2>&1; done
+  for m in afno_fcn pangu_c4 swin_c4 sfno; do timeout 200 python3 $R/tools/aten_audit.py $m --precision bf16 --storage bf16 2>&1 | grep "^==\|^ " ; done > $O/aten_audit_big.txt
+  timeout 200 python3 $R/tools/probe_layernorm.py > $O/layernorm_probe.txt 2>&1
+  timeout 200 python3 $R/tools/probe_fft_ib.py > $O/fft_planar_probe.txt 2>&1
+  timeout 100 python3 $R/bench.py --workload sfno --batch 16 --steps 40 --warmup 5 --no-roofline --no-cpu-baseline > $O/bench_line_sfno_b16.json 2>> $O/bench_b.err
   for f in sfno swin pangu afno afno721; do cut -c1-220 $O/bench_line_$f.json; done
 fi
 echo "=== done $1"
