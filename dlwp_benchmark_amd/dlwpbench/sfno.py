@@ -35,8 +35,11 @@ class _SpectralFilter(nn.Module):
         self.weight = nn.Parameter(scale * torch.randn(in_channels, out_channels, inverse_transform.lmax, 2))
 
     def forward(self, x):
-        X = self.fwd(x)
-        residual = self.inv(X) if self.resample else x
+        if self.resample:
+            X = self.fwd(x)
+            residual = self.inv(X)
+        else:
+            X, residual = self.fwd(x, fork=True)      # x again: the skip's gradient joins inside the transform's backward GEMM
         return self.inv(dhconv(X, self.weight)), residual
 
 

@@ -103,8 +103,10 @@ class _TableGemm(torch.autograd.Function):
     accumulated (a contraction index spread over two planes of x).  The backward pass applies the transposed slices."""
 
     @staticmethod
-    def forward(ctx, x, table, spec, residual=None, out_dtype=torch.float32):
+    def forward(ctx, x, table, spec, residual=None, out_dtype=torch.float32, fork=False):
         # out_dtype bfloat16 (bf16 storage, lib.set_storage): the result only feeds another GEMM of the transform chain
+        # fork: also return x itself (a second use of the input, e.g. the skip connection around a spectral filter); the gradient
+        # arriving on that output is added in the epilogue of the input-gradient product instead of by an autograd accumulation
         x = x.contiguous()
         y = torch.empty(spec["out_shape"], device=x.device, dtype=out_dtype)
         passes = spec.get("passes", ((0, 0),))
@@ -115,24 +117,30 @@ class _TableGemm(torch.autograd.Function):
                           spec["nb1"], spec["nb2"], spec["sA"], spec["sX"], spec["sY"], accumulate=int(i > 0), oA=oA, oB=oX,
                           residual=residual.contiguous() if (residual is not None and last) else None, sR=spec["sY"])
         ctx.spec, ctx.table, ctx.in_shape, ctx.has_res, ctx.in_dtype = spec, table, x.shape, residual is not None, x.dtype
+        ctx.fork = bool(fork)
+        if fork:
+            assert len(passes) == 1 and not (spec["nb2"] > 1 and spec["sX"][1] == 0) and x.dtype == torch.float32
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gskip=None):
         s = ctx.spec
         gy = gy.contiguous()
         gx = torch.empty(ctx.in_shape, device=gy.device, dtype=ctx.in_dtype)      # the gradient has its tensor's storage type
         shared = s["nb2"] > 1 and s["sX"][1] == 0      # x[z1] feeds every z2: its gradient is a sum over z2
+        if gskip is not None:
+            gskip = gskip.contiguous().float()
         for oA, oX in s.get("passes", ((0, 0),)):
             if not shared:
                 _gemm_batched(ctx.table, gy, gx, s["K"], s["N"], s["M"], s["lda"], s["ldy"], s["ldx"], 1 - s["tA"], 0,
-                              s["nb1"], s["nb2"], s["sA"], s["sY"], s["sX"], oA=oA, oC=oX)
+                              s["nb1"], s["nb2"], s["sA"], s["sY"], s["sX"], oA=oA, oC=oX, residual=gskip, sR=s["sX"])
                 continue
             for z2 in range(s["nb2"]):
                 _gemm_batched(ctx.table, gy, gx, s["K"], s["N"], s["M"], s["lda"], s["ldy"], s["ldx"], 1 - s["tA"], 0,
                               s["nb1"], 1, (s["sA"][0], 0), (s["sY"][0], 0), (s["sX"][0], 0), accumulate=int(z2 > 0),
                               oA=oA + z2 * s["sA"][1], oB=z2 * s["sY"][1], oC=oX)
-        return gx, None, None, (gy if ctx.has_res else None), None
+        return gx, None, None, (gy if ctx.has_res else None), None, None
 
 
 def _chain_dtype():
@@ -227,19 +235,27 @@ class RealSHT(nn.Module):
         self.register_buffer("dft_t", torch.from_numpy(F.T.copy()).float().contiguous(), persistent=False)
         self.register_buffer("weights_t", torch.from_numpy(Wf.transpose(0, 2, 1).copy()).float().contiguous(), persistent=False)
 
-    def forward(self, x):
+    def forward(self, x, fork=False):
+        """fork=True: returns (X, x) -- x again, for a skip connection around the spectral filter; on the GEMM path the gradient
+        coming back along it is added in the epilogue of the transform's input-gradient product."""
         B, K, N, C = x.shape
         assert K == self.nlat and N == self.nlon, "input grid does not match the transform"
         M, Lm = self.mmax, self.lmax
         if self.fused and x.is_cuda and _fused_ok(K, N, C, M, Lm):
-            return _FusedAnalysis.apply(x, self.dft, self.weights, self.weights_t, self.dft_t, M, Lm)
+            X = _FusedAnalysis.apply(x, self.dft, self.weights, self.weights_t, self.dft_t, M, Lm)
+            return (X, x) if fork else X
         lon = dict(M=2 * M, N=C, K=N, lda=N, tA=0, ldx=C, ldy=C, nb1=B * K, nb2=1, sA=(0, 0), sX=(N * C, 0),
                    sY=(2 * M * C, 0), out_shape=(B, K, M, 2, C))
         cd = _chain_dtype()
-        t = _TableGemm.apply(x, _table(self, "dft", cd), lon, None, cd)
+        skip = None
+        if fork and x.dtype == torch.float32 and x.requires_grad:
+            t, skip = _TableGemm.apply(x, _table(self, "dft", cd), lon, None, cd, True)
+        else:
+            t = _TableGemm.apply(x, _table(self, "dft", cd), lon, None, cd)
         leg = dict(M=Lm, N=2 * C, K=K, lda=K, tA=0, ldx=2 * M * C, ldy=B * M * 2 * C, nb1=B, nb2=M, sA=(0, Lm * K),
                    sX=(K * 2 * M * C, 2 * C), sY=(M * 2 * C, 2 * C), out_shape=(Lm, B, M, 2, C))
-        return _TableGemm.apply(t, _table(self, "weights", cd), leg, None, cd)
+        X = _TableGemm.apply(t, _table(self, "weights", cd), leg, None, cd)
+        return (X, skip if skip is not None else x) if fork else X
 
 
 class InverseRealSHT(nn.Module):
