@@ -895,14 +895,18 @@ static int gemm_glds_tn_launch(const GemmDev& a_in, hipStream_t s) {
     const int kd = shallow ? 32 : 64;
     static const char* wg_env = getenv("DLWP_GEMM_GLDS_TN_WGS");
     const int slots = wg_env ? atoi(wg_env) : (shallow ? 768 : 448);
-    int splits = std::max(1, std::min(slots / (a.ntn * a.ntm), a.K / (4 * kd)));
+    // at least eight K-steps per slice: shorter slices only add partial tiles to combine (8192 tokens x 512 x 256, graph timing,
+    // tools/bench_gemm_graph.py: 32 slices 22.6 us, 16 slices 17.4 us)
+    int splits = std::max(1, std::min(slots / (a.ntn * a.ntm), a.K / (8 * kd)));
     a.kchunk = ceil_div(ceil_div(a.K, splits), kd) * kd;
     a.splits = std::max(2, ceil_div(a.K, a.kchunk));             // > 1: the atomic epilogue (the caller zeroed C for its own split)
     const size_t lds = (size_t)2 * 2 * GT * kd * 2;
     const dim3 grid(a.ntn * a.ntm, 1, ceil_div(a.K, a.kchunk));
     static const bool no_slab = getenv("DLWP_GEMM_TN_ATOMIC") != nullptr;
     // few output tiles cut into many slices (SFNO's 512 x 256: 8 tiles x 32) read more slab in the reduction than the atomics cost
-    a.slab = (no_slab || a.ntn * a.ntm < 24 || a.N % 4 || a.ldc % 4 || (uintptr_t)a.C % 16) ? nullptr
+    static const char* slab_min_env = getenv("DLWP_GEMM_TN_SLAB_MIN");
+    const int slab_min = slab_min_env ? atoi(slab_min_env) : 24;
+    a.slab = (no_slab || a.ntn * a.ntm < slab_min || a.N % 4 || a.ldc % 4 || (uintptr_t)a.C % 16) ? nullptr
                                                                          : tn_slab_for(s, sizeof(float) * grid.z * (size_t)a.M * a.N);
     int rc;
     if (shallow) {
