@@ -241,8 +241,11 @@ class _SkipMlpFn(torch.autograd.Function):
         Hd, N = w1.shape[0], w2.shape[0]
         (wsm, _), (w1m, _), (w2m, _) = _wmat(ws, C), _wmat(w1, Hd), _wmat(w2, N)
         adt = _act_dtype()                  # bf16 storage: the hidden-width tensors h, z1 (and gh) are bf16 in HBM
-        t = torch.empty(T, C, device=x.device)
-        z0 = torch.empty(T, C, device=x.device)
+        # t only feeds GEMMs (fc1 and gW1 = gh^T t), which round it to bf16 when they read it: under bf16 storage the epilogue
+        # writes that rounding once (same values, half the bytes, and both consumers become bf16 x bf16 products); the stored
+        # pre-activation z0 keeps t's type (a GEMM writes its output and pre-activation in one storage type)
+        t = torch.empty(T, C, device=x.device, dtype=adt)
+        z0 = torch.empty(T, C, device=x.device, dtype=adt)
         _gemm_batched(x2, wsm, t, T, C, C, C, C, C, 0, 1, bias=bs, act=1, preact=z0, residual=y2, res_pre=1)
         h = torch.empty(T, Hd, device=x.device, dtype=adt)
         z1 = torch.empty(T, Hd, device=x.device, dtype=adt)
