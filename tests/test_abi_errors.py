@@ -74,3 +74,17 @@ def test_window_attention_rejects_bad_shapes(h):
     assert "ntypes" in err(h)
     assert h.dlwp_window_attn_fwd_packed(*args(4, 2, 49, 169, 1, 4, 96)) < 0
     assert "head_dim" in err(h)
+
+
+def test_round3_entries_reject_bad_arguments(h):
+    """Round-3 entries: planar / block-planar transforms, the block-planar AFNO weight image, pad-aware window gather."""
+    # no plan / NULL buffers (a plan cannot be built without a GPU: its tables live in device memory)
+    assert h.dlwp_rfft2_planar(None, FAKE, FAKE, FAKE, 1, 8, 0, 4, 3, 0, 1, 0, None) < 0
+    assert "rfft2_planar" in err(h)
+    assert h.dlwp_irfft2_planar(None, FAKE, FAKE, FAKE, None, 1, 8, 0, 4, 3, 0, 1, 0, None) < 0
+    assert "irfft2_planar" in err(h)
+    assert h.dlwp_afno_wq_expand_bp(None, FAKE, FAKE, FAKE, 4, 8, 8, None) < 0
+    assert h.dlwp_afno_wq_expand_bp(FAKE, FAKE, FAKE, FAKE, 4, 1, 8, None) < 0          # the bias rides on the first 2 nb bs_out elements
+    assert "block size" in err(h)
+    assert h.dlwp_afno_wq_fold_bp(FAKE, None, FAKE, FAKE, 4, 8, 8, None) < 0
+    assert h.dlwp_afno_wq_fold_bp(FAKE, FAKE, FAKE, FAKE, 0, 8, 8, None) < 0
