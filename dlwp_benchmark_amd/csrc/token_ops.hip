@@ -1040,6 +1040,52 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
+// Wide rows (256 < C <= 1024, C % 4 == 0): the row is read ONCE into NV float4 groups per lane (the scalar kernel above walks it
+// three times with 4-byte loads), statistics in registers, 16-byte (bf16: 8-byte) stores.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_wide_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float* __restrict__ y,
+                                                                 float* __restrict__ mean, float* __restrict__ rstd, int T,
+                                                                 int C, float eps, int y_bf16) {
+    const int row = blockIdx.x * 4 + wave_id(), lane = lane_id();
+    if (row >= T) return;
+    const float* xr = x + (long long)row * C;
+    f32x4 v[NV];
+    bool ok[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const int c = 4 * lane + 256 * q;
+        ok[q] = c < C;
+        v[q] = *reinterpret_cast<const f32x4*>(xr + (ok[q] ? c : 0));
+        if (ok[q]) s += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
+    }
+    const float mu = wave_sum64(s) / C;
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+        if (ok[q]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float d = v[q][k] - mu; var += d * d; }
+        }
+    const float rs = rsqrtf(wave_sum64(var) / C + eps);
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+        if (ok[q]) {
+            const int c = 4 * lane + 256 * q;
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (v[q][k] - mu) * rs * gm[k] + bt[k];
+            if (y_bf16)
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(y) + (long long)row * C + c) =
+                    bf16x4{(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+            else
+                *reinterpret_cast<f32x4*>(y + (long long)row * C + c) = o;
+        }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
 // gx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)) (+ gadd: the gradient that reached x along the residual
 // branch of a pre-norm block, so the two paths meet here instead of in a separate add); ggamma/gbeta partials via atomics
 template <int NQ>
@@ -1636,6 +1682,16 @@ extern "C" int dlwp_layernorm_fwd_ex(const float* x, const float* gamma, const f
                                           x, gamma, beta, (float*)y, mean, rstd, T, C, eps, y_bf16 ? 1 : 0)
         if (lpr == 8) LN_FWD_V(8); else if (lpr == 16) LN_FWD_V(16); else if (lpr == 32) LN_FWD_V(32); else LN_FWD_V(64);
 #undef LN_FWD_V
+        DLWP_LAUNCH_CHECK();
+        return DLWP_OK;
+    }
+    const bool widef = C % 4 == 0 && C > 256 && C <= 1024 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % (y_bf16 ? 8 : 16) == 0 &&
+                       (uintptr_t)gamma % 16 == 0 && (uintptr_t)beta % 16 == 0;
+    if (widef) {
+#define LN_FWD_W(NV) hipLaunchKernelGGL(layernorm_fwd_wide_kernel<NV>, dim3(ceil_div(T, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, \
+                                        (float*)y, mean, rstd, T, C, eps, y_bf16)
+        if (C <= 512) LN_FWD_W(2); else if (C <= 768) LN_FWD_W(3); else LN_FWD_W(4);
+#undef LN_FWD_W
         DLWP_LAUNCH_CHECK();
         return DLWP_OK;
     }

@@ -37,7 +37,7 @@ def test_linear_fwd_bwd(cuda, T, K, N, act, res):
         assert rel(got.grad, ref.grad) <= 5e-4
 
 
-@pytest.mark.parametrize("T,C,eps", [(1024, 64, 1e-6), (333, 40, 1e-5), (50, 384, 1e-5)])
+@pytest.mark.parametrize("T,C,eps", [(1024, 64, 1e-6), (333, 40, 1e-5), (50, 384, 1e-5), (1001, 768, 1e-5), (77, 1000, 1e-6), (130, 260, 1e-5)])
 def test_layernorm_fwd_bwd(cuda, T, C, eps):
     from dlwp_benchmark_amd import token_ops
     g = torch.Generator().manual_seed(2)

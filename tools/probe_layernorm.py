@@ -39,6 +39,12 @@ def main():
         gam, gg, gb = torch.ones(C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
         mean, rstd = x.mean(1).contiguous(), (x.var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
         gx = torch.empty_like(x)
+        for name, dt in (("fwd fp32 out", torch.float32), ("fwd bf16 out", torch.bfloat16)):
+            y = torch.empty(T, C, device=dev, dtype=dt)
+            t = timeit(lambda: L.check(lib.dlwp_layernorm_fwd_ex(L.ptr(x), L.ptr(gam), L.ptr(gb), L.ptr(y), L.ptr(mean), L.ptr(rstd), T, C,
+                                                                  1e-5, int(dt == torch.bfloat16), L.stream())))
+            nbytes = T * C * (4 + y.element_size())
+            print(f"{label:18s} {T:6d} x {C:4d} {name:24s} {t:7.1f} us   {nbytes / t / 1e6:6.2f} TB/s")
         for name, gadd in (("bwd", None), ("bwd + residual gradient", ga)):
             t = timeit(lambda: L.check(lib.dlwp_layernorm_bwd_ex(L.ptr(x), L.ptr(gam), L.ptr(mean), L.ptr(rstd), L.ptr(gy), 0,
                                                                   L.ptr(gadd) if gadd is not None else None, L.ptr(gx), L.ptr(gg),
