@@ -132,10 +132,12 @@ def _bp_layer_forward(X, w, b, act, lam):
     return O, wq, P
 
 
-def _bp_layer_backward(X, wq, P, gO, act, lam, wshape, bshape, wslot, bslot):
+def _bp_layer_backward(X, wq, P, gO, act, lam, wshape, bshape, wslot, bslot, prev=None):
     """Gradients of _bp_layer_forward: one batched GEMM each for gX and the block weights, one column sum for the bias; the
-    parameter gradients are ACCUMULATED into the flat-gradient slots when the parameters have them.  Returns (gX, gw, gb) with
-    gw / gb None when they went into a slot."""
+    parameter gradients are ACCUMULATED into the flat-gradient slots when the parameters have them.  act = 0 with P None: gO is
+    already the gradient of the pre-activation.  prev = (act_prev, lam_prev, P_prev): X was act_prev(P_prev) -- the input-gradient
+    GEMM then multiplies by that activation's derivative in its epilogue (act 5 / 6 of dlwp_gemm_batched) and the returned gX is
+    the gradient of P_prev.  Returns (gX, gw, gb) with gw / gb None when they went into a slot."""
     lib = L.load()
     T = X.shape[0]
     _, nb, bsi, bso = wshape
@@ -146,7 +148,12 @@ def _bp_layer_backward(X, wq, P, gO, act, lam, wshape, bshape, wslot, bslot):
     else:
         gP = gO
     gX = torch.empty_like(X)                 # gX[:, blk] = gP[:, blk] . wq[blk]^T
-    _gemm_batched(gP, wq, gX, T, 2 * bsi, 2 * bso, 2 * Co, 2 * bso, 2 * C, 0, 1, nb, 1, (2 * bso, 0), (4 * bsi * bso, 0), (2 * bsi, 0))
+    extra = {}
+    if prev is not None:
+        act_prev, lam_prev, P_prev = prev
+        extra = dict(act={2: 5, 3: 6}[act_prev], act_param=lam_prev, residual=P_prev, sR=(2 * bsi, 0))
+    _gemm_batched(gP, wq, gX, T, 2 * bsi, 2 * bso, 2 * Co, 2 * bso, 2 * C, 0, 1, nb, 1, (2 * bso, 0), (4 * bsi * bso, 0), (2 * bsi, 0),
+                  **extra)
     nq = nb * 4 * bsi * bso
     gq = torch.zeros(nq + 2 * Co, device=X.device)      # [gwq | gbq]: one fill; split-K partial sums / column sums accumulate
     # gwq[blk] = X[:, blk]^T . gP[:, blk]   (K = tokens: split along K inside the kernel)
@@ -189,8 +196,9 @@ class _AfnoFftFilterFn(torch.autograd.Function):
         r0, r1, c1 = win
         gy = gy.contiguous().float()
         gO2 = fft._run_r2c_planar(gy, win, bs, fft.NORMS["ortho"], 1).view(X.shape[0], -1)
-        gO1, gw2, gb2 = _bp_layer_backward(O1, wq2, P2, gO2, 3, lam, w2s, b2s, ctx.slots[2], ctx.slots[3])
-        gX, gw1, gb1 = _bp_layer_backward(X, wq1, P1, gO1, 2, 0.0, w1s, b1s, ctx.slots[0], ctx.slots[1])
+        # layer 2's input-gradient GEMM multiplies by ReLU'(P1) in its epilogue: gP1 leaves it directly
+        gP1, gw2, gb2 = _bp_layer_backward(O1, wq2, P2, gO2, 3, lam, w2s, b2s, ctx.slots[2], ctx.slots[3], prev=(2, 0.0, P1))
+        gX, gw1, gb1 = _bp_layer_backward(X, wq1, None, gP1, 0, 0.0, w1s, b1s, ctx.slots[0], ctx.slots[1])
         gx = fft._run_c2r_planar(gX.view(B, r1 - r0, c1, C // bs, 2, bs), H, W, win, bs, fft.NORMS["ortho"], 1, residual=gy)
         return gx, gw1, gb1, gw2, gb2, None, None
 

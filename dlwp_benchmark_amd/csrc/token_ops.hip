@@ -72,6 +72,13 @@ constexpr int gemm_bf_kstep(int s16m, int T, bool akc, bool bkc) { return s16m =
 // v * GELU'(aux) with aux read through the `residual` view (the saved pre-activation): the product g W of a Linear layer
 // then leaves the kernel already multiplied by the derivative of the activation that fed it (no separate gelu_bwd pass)
 constexpr int ACT_GELU_GRAD_MUL = 4;
+// 5 / 6: the same for ReLU and soft-shrink(lambda) (the AFNO block MLP's activations): v * [aux > 0], v * [|aux| > lambda]
+constexpr int ACT_RELU_GRAD_MUL = 5, ACT_SHRINK_GRAD_MUL = 6;
+__device__ __forceinline__ float act_grad_mul(float v, float aux, int act, float lam) {
+    if (act == ACT_GELU_GRAD_MUL) return v * gelu_grad_f(aux);
+    if (act == ACT_RELU_GRAD_MUL) return aux > 0.f ? v : 0.f;
+    return (act == ACT_SHRINK_GRAD_MUL && fabsf(aux) > lam) ? v : 0.f;
+}
 __device__ __forceinline__ float apply_act(float v, int act, float lam) {
     if (act == 1) return gelu_f(v);
     if (act == 2) return fmaxf(v, 0.f);
@@ -427,9 +434,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
                         else
                             *reinterpret_cast<f32x4*>(dst + o) = val;
                     };
-                    if (a.act == ACT_GELU_GRAD_MUL) {
+                    if (a.act >= ACT_GELU_GRAD_MUL) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] *= gelu_grad_f(rv[k]);
+                        for (int k = 0; k < 4; ++k) v[k] = act_grad_mul(v[k], rv[k], a.act, a.act_param);
                     } else {
                         if (a.res_pre) {
 #pragma unroll
@@ -474,8 +481,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
                         if (a.dt & DT_C) reinterpret_cast<__bf16*>(dst)[o] = (__bf16)val;
                         else dst[o] = val;
                     };
-                    if (a.act == ACT_GELU_GRAD_MUL) {
-                        v *= gelu_grad_f(rres);
+                    if (a.act >= ACT_GELU_GRAD_MUL) {
+                        v = act_grad_mul(v, rres, a.act, a.act_param);
                     } else {
                         if (a.res_pre) v += rres;
                         if (a.preact) put1(a.preact, v);
@@ -668,9 +675,9 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmDev a) {
                     else
                         *reinterpret_cast<f32x4*>(dst + o) = val;
                 };
-                if (a.act == ACT_GELU_GRAD_MUL) {
+                if (a.act >= ACT_GELU_GRAD_MUL) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] *= gelu_grad_f(rv[k]);
+                    for (int k = 0; k < 4; ++k) v[k] = act_grad_mul(v[k], rv[k], a.act, a.act_param);
                 } else {
                     if (a.res_pre) {
 #pragma unroll
@@ -1604,10 +1611,11 @@ static int gemm_batched_impl(const float* A, const float* B, float* C, int M, in
     DLWP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && nb1 > 0 && nb2 > 0, DLWP_E_INVALID,
                  "gemm_batched: NULL argument or empty shape");
     if (int drc = dtypes_ok(dt, accumulate, "gemm_batched")) return drc;
-    DLWP_REQUIRE(act >= 0 && act <= 4, DLWP_E_INVALID,
-                 "gemm_batched: act must be 0 (none), 1 (gelu), 2 (relu), 3 (softshrink) or 4 (multiply by GELU'(residual))");
-    DLWP_REQUIRE(act != ACT_GELU_GRAD_MUL || (residual && !preact), DLWP_E_INVALID,
-                 "gemm_batched: act 4 reads the saved pre-activation through `residual` and writes no `preact`");
+    DLWP_REQUIRE(act >= 0 && act <= 6, DLWP_E_INVALID,
+                 "gemm_batched: act must be 0 (none), 1 (gelu), 2 (relu), 3 (softshrink) or 4 / 5 / 6 (multiply by GELU' / ReLU' / "
+                 "softshrink'(residual))");
+    DLWP_REQUIRE(act < ACT_GELU_GRAD_MUL || (residual && !preact), DLWP_E_INVALID,
+                 "gemm_batched: act 4-6 read the saved pre-activation through `residual` and write no `preact`");
     // reductions over a long K with few output tiles (weight gradients of block-diagonal layers): split K inside every
     // batch and combine with float atomics, like the plain entry
     const bool epilogue = bias || act || preact || residual || (dt & DT_C);

@@ -443,6 +443,8 @@ int dlwp_get_gemm_precision(void);
 /* act 4 is the backward form C = (A.B) * GELU'(z) with the saved pre-activation z passed as    */
 /* `residual` (preact must be NULL): gx = g W of a Linear layer arrives already multiplied by  */
 /* the derivative of the GELU that produced its input (token-MLP backward, no gelu_bwd pass).  */
+/* act 5 / 6: the same with ReLU' ([z > 0]) and soft-shrink' ([|z| > act_param]): the AFNO block */
+/* MLP's activations (fourcastnet.py:100-117, F.relu and F.softshrink).                        */
 /* Without an epilogue, long-K products with few output tiles are split along K (atomics).      */
 /* Used for the spherical transforms (per-order Legendre matrices) and the per-degree SFNO     */
 /* spectral weights, where one launch covers every (sample, order) or degree.                  */
