@@ -43,7 +43,7 @@ def _act_dtype():
     return _BF if (L.storage_bf16() and L.SHADOW_ACTIVE) else torch.float32
 
 
-LOWP_MIN_DEPTH = 768
+LOWP_MIN_DEPTH = int(__import__("os").environ.get("DLWP_LOWP_MIN_DEPTH", "768"))      # env: A/B runs of the break-even below
 
 
 def _lowp(t, depth):
