@@ -932,6 +932,236 @@ static int gemm_glds_tn_launch(const GemmDev& a_in, hipStream_t s) {
     return DLWP_OK;
 }
 
+// ---- (round 3) 256 x 256 x 64 tiles, eight waves in two groups half a phase apart (the CDNA guide's "8-phase" schedule, built
+// here from its description): y = x W^T, both operands bf16 arrays with k contiguous.
+// A wave (wr = w >> 2, wc = w & 3) owns rows wr * 128 .. + 128, columns wc * 64 .. + 64 of the tile = four quadrants
+// (mq, nq) of 64 x 32, sixteen 16x16x32 MFMAs each per K-tile.  A K-tile's operands live in LDS as four HALF-TILES of 16 KB:
+// A0 / A1 = the 128 rows every wave reads for mq = 0 / 1 (local row lr = wr * 64 + x <-> tile row wr * 128 + mq * 64 + x), B0 / B1
+// likewise for nq (local column wc * 32 + x <-> tile column wc * 64 + nq * 32 + x); two stages (K-tile parity) = 128 KB.
+// Per K-tile a wave runs eight half-phases, a barrier after each:
+//     0 read B0 (4 x b128, kept to the end) + A0 (8)         1 MFMA (mq0, nq0)
+//     2 read B1 (4); issue A0, B0 of tile t + 2               3 MFMA (mq0, nq1)
+//     4 read A1 (8); issue B1 of tile t + 2                   5 MFMA (mq1, nq1)
+//     6 vmcnt(6): tile t + 1 has landed; issue A1 of t + 2    7 MFMA (mq1, nq0)
+// Waves with wr = 1 take one extra barrier first, so they run one half-phase behind: while one group holds the matrix pipes the
+// other reads fragments and issues DMAs.  Hazards (g = group, global half-phase = local + g):
+//   WAR  a half-tile of stage t & 1 is refilled for tile t + 2 two half-phases after its local read slot, i.e. after the later
+//        group's read of it has completed (every read slot ends with lgkmcnt(0) before its barrier);
+//   RAW  tile t + 1's DMAs were issued during tile t - 1 (local slots 2, 4, 6); at slot 6 of tile t each wave waits until all but
+//        the six DMAs it issued during tile t have landed -- group 1 does so one global half-phase later, still before the
+//        barrier that precedes group 0's first read of tile t + 1 (global 8 t + 8).
+// A DMA instruction moves 64 consecutive 16-byte chunks = 8 rows of a half-tile image (lane-linear LDS side), chunk c of local row
+// lr stored at position c ^ ((lr >> 1) & 7); each group loads half of every half-tile (two DMAs per thread).
+constexpr int P8T = 256;
+// the barrier as inline assembly with a memory clobber: the compiler must not move LDS reads across it (the s_barrier builtin alone
+// does not order memory accesses for the optimiser; a read hoisted above the barrier that follows the other group's vmcnt wait
+// would see a half-tile before its DMA has landed)
+__device__ __forceinline__ void p8_barrier() { asm volatile("s_barrier" ::: "memory"); }
+__global__ __launch_bounds__(512) void gemm_p8_kernel(GemmDev a) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    __bf16* lds = reinterpret_cast<__bf16*>(gsm);          // [2 stages][A0 | A1 | B0 | B1][128][64]
+    constexpr int HT = 128 * 64;                            // bf16 elements of a half-tile image (16 KB)
+    const int lane = lane_id(), w = threadIdx.x >> 6, r = lane & 15, g = lane >> 4, tid = threadIdx.x;
+    const int wr = w >> 2, wc = w & 3;
+    int tile_id = blockIdx.x;
+    {
+        const int nt = gridDim.x, full = (nt / 8) * 8;     // XCD-aware order, as in gemm_kernel
+        if (tile_id < full) tile_id = (tile_id % 8) * (nt / 8) + tile_id / 8;
+    }
+    constexpr int GM = 4;
+    const int grp = tile_id / (GM * a.ntn), within = tile_id - grp * GM * a.ntn;
+    const int rows_in = min(GM, a.ntm - grp * GM);
+    const int nt_ = within / rows_in, mt = grp * GM + (within - nt_ * rows_in);
+    const int m0 = mt * P8T, n0 = nt_ * P8T;
+    const __bf16* A = reinterpret_cast<const __bf16*>(a.A);
+    const __bf16* B = reinterpret_cast<const __bf16*>(a.B);
+    // DMA sources: half-tile chunk p = i * 512 + tid (i = 0, 1): local row p >> 3, logical chunk (p & 7) ^ swizzle
+    const __bf16* asrc[2][2];        // [half][i]
+    const __bf16* bsrc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int p = i * 512 + tid, lr = p >> 3, c = (p & 7) ^ ((lr >> 1) & 7);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int trow = (lr >> 6) * 128 + h * 64 + (lr & 63);            // A: tile row of local row lr in half h
+            const int tcol = (lr >> 5) * 64 + h * 32 + (lr & 31);            // B: tile column of local column lr in half h
+            asrc[h][i] = A + (long long)min(m0 + trow, a.M - 1) * a.lda + 8 * c;
+            bsrc[h][i] = B + (long long)min(n0 + tcol, a.N - 1) * a.ldb + 8 * c;
+        }
+    }
+    // which: 0 A0, 1 A1, 2 B0, 3 B1
+    auto issue = [&](int stage, int which, int k0) {
+        __bf16* dst = lds + (stage * 4 + which) * HT;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const __bf16* src = (which < 2 ? asrc[which & 1][i] : bsrc[which & 1][i]) + k0;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + (i * 512 + w * 64) * 8), 16, 0, 0);
+        }
+    };
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = a.K / 64;
+    // prologue: tiles 0 and 1 in full
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+        if (t < nk) {
+#pragma unroll
+            for (int which = 0; which < 4; ++which) issue(t, which, t * 64);
+        }
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    p8_barrier();
+    if (wr == 1) p8_barrier();             // group 1 runs one half-phase behind
+    bf16x8 af[8], b0[4], b1[4];
+    auto read_a = [&](int stage, int mq) {
+        const __bf16* img = lds + (stage * 4 + mq) * HT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int lr = wr * 64 + 16 * i + r, c = (4 * kk + g) ^ ((lr >> 1) & 7);
+                af[2 * i + kk] = *reinterpret_cast<const bf16x8*>(img + lr * 64 + 8 * c);
+            }
+    };
+    auto read_b = [&](int stage, int nq, bf16x8 (&bf)[4]) {
+        const __bf16* img = lds + (stage * 4 + 2 + nq) * HT;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int lr = wc * 32 + 16 * j + r, c = (4 * kk + g) ^ ((lr >> 1) & 7);
+                bf[2 * j + kk] = *reinterpret_cast<const bf16x8*>(img + lr * 64 + 8 * c);
+            }
+    };
+    auto mma = [&](int mq, int nq, const bf16x8 (&bf)[4]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[4 * mq + i][2 * nq + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2 * i + kk], bf[2 * j + kk], acc[4 * mq + i][2 * nq + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto end_read = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        p8_barrier();
+    };
+    for (int t = 0; t < nk; ++t) {
+        const int st = t & 1, k2 = (t + 2) * 64;
+        const bool more = t + 2 < nk;
+        // 0
+        read_b(st, 0, b0);
+        read_a(st, 0);
+        end_read();
+        // 1
+        mma(0, 0, b0);
+        p8_barrier();
+        // 2
+        read_b(st, 1, b1);
+        if (more) { issue(st, 0, k2); issue(st, 2, k2); }
+        end_read();
+        // 3
+        mma(0, 1, b1);
+        p8_barrier();
+        // 4
+        read_a(st, 1);
+        if (more) issue(st, 3, k2);
+        end_read();
+        // 5
+        mma(1, 1, b1);
+        p8_barrier();
+        // 6: tile t + 1 must have landed (its DMAs are older than the six of this tile)
+        if (t + 1 < nk) {
+            if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (more) issue(st, 1, k2);
+        p8_barrier();
+        // 7
+        mma(1, 0, b0);
+        p8_barrier();
+    }
+    if (wr == 0) p8_barrier();             // group 0 catches up with group 1's last half-phase
+    // ---- epilogue: four passes of 64 tile rows through an fp32 LDS tile [64][260]; pass = 2 wr + mq
+    constexpr int LDE = P8T + 4, C4 = P8T / 4, RPP = 512 / C4, NPASS = 64 / RPP;
+    float* tile = gsm;
+    const int c4 = tid % C4, n = n0 + 4 * c4;
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias && n < a.N) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        __syncthreads();
+        if (wr == (pass >> 1)) {
+            const int mq = pass & 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        // acc[4 mq + i][j']: rows mq * 64 + 16 i + 4 g + q of the wave's 128, columns wc * 64 + (j' >> 1) * 32 + (j' & 1) * 16 + r
+                        tile[(16 * i + 4 * g + q) * LDE + wc * 64 + (j >> 1) * 32 + (j & 1) * 16 + r] = acc[4 * mq + i][j][q];
+                    }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int row = tid / C4 + RPP * ps, m = m0 + 64 * pass + row;
+            if (m < a.M && n < a.N) {
+                const long long o = (long long)m * a.ldc + n;
+                f32x4 v = *reinterpret_cast<const f32x4*>(&tile[row * LDE + 4 * c4]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] += bv[k];
+                f32x4 rv = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (a.residual) {
+                    if (a.dt & DT_R) {
+                        const bf16x4 hv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.residual) + o);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) rv[k] = (float)hv[k];
+                    } else {
+                        rv = *reinterpret_cast<const f32x4*>(a.residual + o);
+                    }
+                }
+                auto put = [&](float* dst, const f32x4& val) {
+                    if (a.dt & DT_C)
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(dst) + o) =
+                            bf16x4{(__bf16)val[0], (__bf16)val[1], (__bf16)val[2], (__bf16)val[3]};
+                    else
+                        *reinterpret_cast<f32x4*>(dst + o) = val;
+                };
+                if (a.act >= ACT_GELU_GRAD_MUL) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = act_grad_mul(v[k], rv[k], a.act, a.act_param);
+                } else {
+                    if (a.res_pre) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] += rv[k];
+                    }
+                    if (a.preact) put(a.preact, v);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], a.act, a.act_param);
+                    if (!a.res_pre) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] += rv[k];
+                    }
+                }
+                if (a.accumulate) {
+                    const f32x4 cv = *reinterpret_cast<const f32x4*>(a.C + o);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] += cv[k];
+                }
+                put(a.C, v);
+            }
+        }
+    }
+}
+
 // shapes the LDS-DMA kernel takes: both operands bf16 arrays with k contiguous and 16-byte aligned rows, K a multiple of 64, one
 // plain product (no split-K / batches / row sums / row bias), the aligned epilogue, enough tiles to be worth 128 x 128
 static bool gemm_glds_applies(const GemmDev& a, bool akc, bool bkc) {
@@ -971,8 +1201,32 @@ static int gemm_glds_launch(const GemmDev& a_in, bool bkc, hipStream_t s) {
 
 
 
+static int gemm_p8_launch(const GemmDev& a_in, hipStream_t s) {
+    GemmDev a = a_in;
+    a.ntn = ceil_div(a.N, P8T);
+    a.ntm = ceil_div(a.M, P8T);
+    const size_t lds = (size_t)2 * 4 * 128 * 64 * 2;          // 128 KB: two stages of four half-tile images (the epilogue's 64 x 260 fp32 tile fits inside)
+    int rc;
+    if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_p8_kernel), lds, "gemm_p8"))) return rc;
+    hipLaunchKernelGGL(gemm_p8_kernel, dim3(a.ntn * a.ntm), dim3(512), lds, s, a);
+    return DLWP_OK;
+}
+
+int g_gemm_tile256 = 0;    // dlwp_set_gemm_tile256: 0 by shape (below), 1 wherever the kernel applies, -1 never
+
+// the 256 x 256 kernel runs one workgroup per CU: nothing covers its prologue (two K-tiles of DMAs) and epilogue, so it needs a long K
+// to pay -- 8192^3: 1351 against 1017 TFLOP/s, 4096^3 1186 / 983, 16200 x 768 x 3072: 898 / 788, but 16200 x 3072 x 768: 686 / 693 and every
+// K <= 512 shape loses (profiles/r03_gemm_p8.txt): taken from K = 2048 with at least 128 tiles, or when forced
+static bool gemm_p8_applies(const GemmDev& a, bool akc, bool bkc) {
+    static const bool env_on = getenv("DLWP_GEMM_P8") != nullptr;
+    if (g_gemm_tile256 < 0 || !akc || !bkc || a.K % 64 || a.M < P8T || a.N < P8T) return false;
+    const long long tiles = (long long)ceil_div(a.M, P8T) * ceil_div(a.N, P8T);
+    return env_on || g_gemm_tile256 > 0 || (a.K >= 2048 && tiles >= 128);
+}
+
 template <bool AKC, bool BKC>
 int gemm_launch(const GemmDev& a_in, int vec, int T, hipStream_t s) {
+    if (gemm_glds_applies(a_in, AKC, BKC) && gemm_p8_applies(a_in, AKC, BKC)) return gemm_p8_launch(a_in, s);
     if (gemm_glds_applies(a_in, AKC, BKC)) return gemm_glds_launch(a_in, BKC, s);
     if (!AKC && !BKC && gemm_glds_tn_applies(a_in)) return gemm_glds_tn_launch(a_in, s);
     const int edge = 64 * T;
@@ -1560,6 +1814,11 @@ extern "C" int dlwp_set_gemm_precision(int mode) {
 }
 
 extern "C" int dlwp_get_gemm_precision(void) { return g_gemm_bf16; }
+extern "C" int dlwp_set_gemm_tile256(int mode) {
+    DLWP_REQUIRE(mode >= -1 && mode <= 1, DLWP_E_INVALID, "set_gemm_tile256: mode must be -1 (never), 0 (by shape) or 1 (wherever it applies)");
+    g_gemm_tile256 = mode;
+    return DLWP_OK;
+}
 
 static int dtypes_ok(int dt, int accumulate, const char* who) {
     DLWP_REQUIRE(dt >= 0 && dt < 16, DLWP_E_INVALID, "%s: dtypes is a mask of 1 (A) | 2 (B) | 4 (C, preact) | 8 (residual)", who);

@@ -66,6 +66,7 @@ SIGNATURES = {
     "dlwp_afno_wq_fold": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_set_gemm_precision": (_I, [_I]),
     "dlwp_get_gemm_precision": (_I, []),
+    "dlwp_set_gemm_tile256": (_I, [_I]),
     "dlwp_window_gather": (_I, [_V, _V, _I, _I] + [_V] * 7 + [_V]),
     "dlwp_window_gather_fill": (_I, [_V, _V, _V, _I, _I] + [_V] * 7 + [_V]),
     "dlwp_window_pad_colsum": (_I, [_V, _V, _I, _I] + [_V] * 7 + [_I, _V]),
@@ -194,6 +195,11 @@ class gemm_precision:
     def __exit__(self, *exc):
         check(load().dlwp_set_gemm_precision(self.prev))
         return False
+
+
+def set_gemm_tile256(mode):
+    """-1: never use the 256 x 256 bf16 GEMM kernel, 0: by shape (default), 1: wherever it applies (measurement / tests)."""
+    check(load().dlwp_set_gemm_tile256(int(mode)))
 
 
 def set_gemm_precision(mode):

@@ -435,6 +435,9 @@ int dlwp_gemm(const float* A, const float* B, float* C, int M, int N, int K, int
 /* fp32 either way.                                                                             */
 int dlwp_set_gemm_precision(int mode);
 int dlwp_get_gemm_precision(void);
+/* 256 x 256 x 64 tiles in two wave groups half a phase apart (bf16 arrays, y = x W^T): -1 never, 0 by shape (K >= 4096 and at    */
+/* least 512 tiles: one workgroup per CU leaves its prologue / epilogue uncovered), 1 wherever the kernel applies (measurement).   */
+int dlwp_set_gemm_tile256(int mode);
 /* Strided-batched form: batch z = z1*nb2 + z2 (z1 < nb1, z2 < nb2) works on A + z1*sA1 +      */
 /* z2*sA2, B + z1*sB1 + z2*sB2, C (and residual) likewise; strides in floats, 0 = shared.     */
 /* res_before_act != 0 adds the residual before the activation: C = act(A.B + bias + res);    */

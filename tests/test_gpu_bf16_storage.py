@@ -272,3 +272,46 @@ def test_clipping_norm_is_bit_reproducible(cuda):
         outs.append(o.item())
     assert len(set(outs)) == 1
     assert abs(outs[0] - float((g.double() ** 2).sum())) <= 1e-5 * outs[0]
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 520, 192), (1000, 768, 64), (4100, 768, 1024), (2048, 2048, 4096)])
+@pytest.mark.parametrize("epi", ["bias", "bias_gelu_preact_bf16", "residual_accumulate"])
+def test_tile256_two_group_gemm_matches_float64(cuda, M, N, K, epi):
+    """y = x W^T on the 256 x 256 x 64 kernel with the two wave groups half a phase apart (csrc/token_ops.hip, gemm_p8_kernel;
+    forced on through lib.set_gemm_tile256): one K-tile up to sixteen, edge tiles in M and N, the epilogues of the token layers;
+    repeated launches must agree bit for bit (a race between the LDS-DMA fills and the staggered readers would not)."""
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.token_ops import _gemm, _gemm_batched
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(cuda).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(cuda).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g).to(cuda)
+    ref = x.double() @ w.double().T
+    L.set_gemm_tile256(1)
+    try:
+        with L.gemm_precision("bf16"):
+            outs = []
+            for _ in range(3):
+                if epi == "bias":          # (a product without any epilogue may be cut along K by the dispatcher: float atomics)
+                    y = torch.empty(M, N, device=cuda)
+                    _gemm(x, w, y, M, N, K, K, K, N, 0, 1, bias, 0, None, None)
+                    want = ref + bias.double()
+                elif epi == "bias_gelu_preact_bf16":
+                    y = torch.empty(M, N, device=cuda, dtype=torch.bfloat16)
+                    z = torch.empty(M, N, device=cuda, dtype=torch.bfloat16)
+                    _gemm(x, w, y, M, N, K, K, K, N, 0, 1, bias, 1, z, None)
+                    pre = ref + bias.double()
+                    assert ((z.double() - pre).abs().max() / pre.abs().max()).item() <= 1e-2
+                    want = torch.nn.functional.gelu(pre)
+                else:
+                    r = torch.randn(M, N, generator=torch.Generator().manual_seed(5)).to(cuda)
+                    y = torch.ones(M, N, device=cuda)
+                    _gemm_batched(x, w, y, M, N, K, K, K, N, 0, 1, bias=bias, residual=r, accumulate=1)
+                    want = 1.0 + ref + bias.double() + r.double()
+                torch.cuda.synchronize()
+                outs.append(y.clone())
+        tol = 1e-2 if y.dtype == torch.bfloat16 else 2e-5
+        assert ((outs[0].double() - want).abs().max() / want.abs().max()).item() <= tol
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    finally:
+        L.set_gemm_tile256(0)
