@@ -508,6 +508,101 @@ int gemm_launch_t(const GemmDev& a, dim3 grid, hipStream_t s) {
 
 int g_gemm_bf16 = 0;    // dlwp_set_gemm_precision
 
+// Workgroup barrier for LDS hand-offs inside an epilogue: waits for this wave's LDS traffic only.  __syncthreads() also waits for
+// vmcnt(0), i.e. for every global STORE the wave has issued -- an epilogue that stages its tile through LDS in several passes then
+// pays a full store round trip per pass (stamps: 34 k cycles for the four passes of a 256 x 256 tile, as long as twelve K-tiles).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Store loop of an LDS-staged epilogue: NROWS tile rows per thread (row = tid / C4 + RPP * i, four consecutive columns each), in
+// groups of G rows: every LDS read and every residual / accumulate load of a group is issued before the first use, the options
+// are tested OUTSIDE the row loops (workgroup-uniform branches around whole loops), stores last.  The first form of this loop tested
+// every option per row: 35 branches and a serialised load -> use -> store chain per row -- 34 k cycles for a 256 x 256 tile against
+// 14.6 k for a bias-only loop (stamps, tools/probe_stamps_glds.py).
+template <int NROWS, int RPP, int C4, int LDE, int G>      // G rows in flight per thread (registers: ~14 G)
+__device__ __forceinline__ void epilogue_rows(const GemmDev& a, const float* tile, int tid, int m_base, int n, const f32x4& bv) {
+    static_assert(NROWS % G == 0, "rows per thread come in whole groups");
+    const int c4 = tid % C4;
+    const bool col_ok = n < a.N;
+    auto put = [&](float* dst, long long o, const f32x4& val) {
+        if (a.dt & DT_C)
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(dst) + o) = bf16x4{(__bf16)val[0], (__bf16)val[1], (__bf16)val[2], (__bf16)val[3]};
+        else
+            *reinterpret_cast<f32x4*>(dst + o) = val;
+    };
+#pragma unroll
+    for (int i0 = 0; i0 < NROWS; i0 += G) {
+        f32x4 v[G], rv[G];
+        long long o[G];
+        bool ok[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int row = tid / C4 + RPP * (i0 + i), m = m_base + row;
+            ok[i] = col_ok && m < a.M;
+            o[i] = ok[i] ? (long long)m * a.ldc + n : 0;            // masked rows read element 0 (valid memory) and store nothing
+            v[i] = *reinterpret_cast<const f32x4*>(&tile[row * LDE + 4 * c4]);
+            rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (a.residual) {
+            if (a.dt & DT_R) {
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    const bf16x4 hv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.residual) + o[i]);
+                    rv[i] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < G; ++i) rv[i] = *reinterpret_cast<const f32x4*>(a.residual + o[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[i][k] += bv[k];
+        if (a.act >= ACT_GELU_GRAD_MUL) {
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[i][k] = act_grad_mul(v[i][k], rv[i][k], a.act, a.act_param);
+        } else {
+            if (a.res_pre) {
+#pragma unroll
+                for (int i = 0; i < G; ++i)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[i][k] += rv[i][k];
+            }
+            if (a.preact) {
+#pragma unroll
+                for (int i = 0; i < G; ++i)
+                    if (ok[i]) put(a.preact, o[i], v[i]);
+            }
+            if (a.act) {
+#pragma unroll
+                for (int i = 0; i < G; ++i)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[i][k] = apply_act(v[i][k], a.act, a.act_param);
+            }
+            if (!a.res_pre && a.residual) {
+#pragma unroll
+                for (int i = 0; i < G; ++i)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[i][k] += rv[i][k];
+            }
+        }
+        if (a.accumulate) {
+            f32x4 cv[G];
+#pragma unroll
+            for (int i = 0; i < G; ++i) cv[i] = *reinterpret_cast<const f32x4*>(a.C + o[i]);
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[i][k] += cv[i][k];
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+            if (ok[i]) put(a.C, o[i], v[i]);
+    }
+}
+
 // ---- (round 3) both operands bf16 arrays, both k-contiguous ("NT": y = x W^T): 128 x 128 x 64 tiles staged by LDS-DMA.
 // The register-staged kernel above spends a K-step of 32 on 4 global loads + 4 ds_write_b128 + a barrier per 16 MFMAs and
 // reaches ~480 TFLOP/s at the FourCastNet shapes (19 % of the bf16 peak).  Here a K-step is 64 deep (32 MFMAs per wave), the
@@ -640,7 +735,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmDev a) {
     if (a.bias && n < a.N) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        if (half) __syncthreads();
+        if (half) lds_barrier();
         if (wm / 64 == half) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -649,56 +744,8 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmDev a) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) tile[(i * 16 + 4 * g + q) * LDE + wn + j * 16 + r] = acc[i][j][q];
         }
-        __syncthreads();
-#pragma unroll
-        for (int pass = 0; pass < NPASS; ++pass) {
-            const int row = tid / C4 + RPP * pass, m = m0 + 64 * half + row;
-            if (m < a.M && n < a.N) {
-                const long long o = (long long)m * a.ldc + n;
-                f32x4 v = *reinterpret_cast<const f32x4*>(&tile[row * LDE + 4 * c4]);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] += bv[k];
-                f32x4 rv = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (a.residual) {
-                    if (a.dt & DT_R) {
-                        const bf16x4 hv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.residual) + o);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) rv[k] = (float)hv[k];
-                    } else {
-                        rv = *reinterpret_cast<const f32x4*>(a.residual + o);
-                    }
-                }
-                auto put = [&](float* dst, const f32x4& val) {
-                    if (a.dt & DT_C)
-                        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(dst) + o) =
-                            bf16x4{(__bf16)val[0], (__bf16)val[1], (__bf16)val[2], (__bf16)val[3]};
-                    else
-                        *reinterpret_cast<f32x4*>(dst + o) = val;
-                };
-                if (a.act >= ACT_GELU_GRAD_MUL) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = act_grad_mul(v[k], rv[k], a.act, a.act_param);
-                } else {
-                    if (a.res_pre) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] += rv[k];
-                    }
-                    if (a.preact) put(a.preact, v);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], a.act, a.act_param);
-                    if (!a.res_pre) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] += rv[k];
-                    }
-                }
-                if (a.accumulate) {
-                    const f32x4 cv = *reinterpret_cast<const f32x4*>(a.C + o);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] += cv[k];
-                }
-                put(a.C, v);
-            }
-        }
+        lds_barrier();
+        epilogue_rows<NPASS, RPP, C4, LDE, 2>(a, tile, tid, m0 + 64 * half, n, bv);
     }
     DLWP_STAMP(13);
 }
@@ -963,18 +1010,22 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmDev a) {
     constexpr int HT = 128 * 64;                            // bf16 elements of a half-tile image (16 KB)
     const int lane = lane_id(), w = threadIdx.x >> 6, r = lane & 15, g = lane >> 4, tid = threadIdx.x;
     const int wr = w >> 2, wc = w & 3;
-    int tile_id = blockIdx.x;
+    const __bf16* A = reinterpret_cast<const __bf16*>(a.A);
+    const __bf16* B = reinterpret_cast<const __bf16*>(a.B);
+    // persistent: workgroup b takes tiles b, b + gridDim.x, ... (the global stores of a tile's epilogue drain while the next tile's
+    // DMAs and MFMAs run: with one workgroup per CU nothing else would cover them)
+    const int ntiles = a.ntm * a.ntn;
+    for (int raw = blockIdx.x; raw < ntiles; raw += gridDim.x) {
+    int tile_id = raw;
     {
-        const int nt = gridDim.x, full = (nt / 8) * 8;     // XCD-aware order, as in gemm_kernel
-        if (tile_id < full) tile_id = (tile_id % 8) * (nt / 8) + tile_id / 8;
+        const int full = (ntiles / 8) * 8;                  // XCD-aware order, as in gemm_kernel
+        if (tile_id < full) tile_id = (tile_id % 8) * (ntiles / 8) + tile_id / 8;
     }
     constexpr int GM = 4;
     const int grp = tile_id / (GM * a.ntn), within = tile_id - grp * GM * a.ntn;
     const int rows_in = min(GM, a.ntm - grp * GM);
     const int nt_ = within / rows_in, mt = grp * GM + (within - nt_ * rows_in);
     const int m0 = mt * P8T, n0 = nt_ * P8T;
-    const __bf16* A = reinterpret_cast<const __bf16*>(a.A);
-    const __bf16* B = reinterpret_cast<const __bf16*>(a.B);
     // DMA sources: half-tile chunk p = i * 512 + tid (i = 0, 1): local row p >> 3, logical chunk (p & 7) ^ swizzle
     const __bf16* asrc[2][2];        // [half][i]
     const __bf16* bsrc[2][2];
@@ -1005,6 +1056,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmDev a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nk = a.K / 64;
+    if (raw == blockIdx.x) DLWP_STAMP(14);
     // prologue: tiles 0 and 1 in full
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -1016,6 +1068,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmDev a) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     p8_barrier();
     if (wr == 1) p8_barrier();             // group 1 runs one half-phase behind
+    if (raw == blockIdx.x) DLWP_STAMP(15);
     bf16x8 af[8], b0[4], b1[4];
     auto read_a = [&](int stage, int mq) {
         const __bf16* img = lds + (stage * 4 + mq) * HT;
@@ -1088,6 +1141,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmDev a) {
         p8_barrier();
     }
     if (wr == 0) p8_barrier();             // group 0 catches up with group 1's last half-phase
+    if (raw == blockIdx.x) DLWP_STAMP(16);
     // ---- epilogue: four passes of 64 tile rows through an fp32 LDS tile [64][260]; pass = 2 wr + mq
     constexpr int LDE = P8T + 4, C4 = P8T / 4, RPP = 512 / C4, NPASS = 64 / RPP;
     float* tile = gsm;
@@ -1096,7 +1150,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmDev a) {
     if (a.bias && n < a.N) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
-        __syncthreads();
+        lds_barrier();
         if (wr == (pass >> 1)) {
             const int mq = pass & 1;
 #pragma unroll
@@ -1109,56 +1163,11 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmDev a) {
                         tile[(16 * i + 4 * g + q) * LDE + wc * 64 + (j >> 1) * 32 + (j & 1) * 16 + r] = acc[4 * mq + i][j][q];
                     }
         }
-        __syncthreads();
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            const int row = tid / C4 + RPP * ps, m = m0 + 64 * pass + row;
-            if (m < a.M && n < a.N) {
-                const long long o = (long long)m * a.ldc + n;
-                f32x4 v = *reinterpret_cast<const f32x4*>(&tile[row * LDE + 4 * c4]);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] += bv[k];
-                f32x4 rv = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (a.residual) {
-                    if (a.dt & DT_R) {
-                        const bf16x4 hv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.residual) + o);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) rv[k] = (float)hv[k];
-                    } else {
-                        rv = *reinterpret_cast<const f32x4*>(a.residual + o);
-                    }
-                }
-                auto put = [&](float* dst, const f32x4& val) {
-                    if (a.dt & DT_C)
-                        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(dst) + o) =
-                            bf16x4{(__bf16)val[0], (__bf16)val[1], (__bf16)val[2], (__bf16)val[3]};
-                    else
-                        *reinterpret_cast<f32x4*>(dst + o) = val;
-                };
-                if (a.act >= ACT_GELU_GRAD_MUL) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = act_grad_mul(v[k], rv[k], a.act, a.act_param);
-                } else {
-                    if (a.res_pre) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] += rv[k];
-                    }
-                    if (a.preact) put(a.preact, v);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], a.act, a.act_param);
-                    if (!a.res_pre) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] += rv[k];
-                    }
-                }
-                if (a.accumulate) {
-                    const f32x4 cv = *reinterpret_cast<const f32x4*>(a.C + o);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] += cv[k];
-                }
-                put(a.C, v);
-            }
-        }
+        lds_barrier();
+        epilogue_rows<NPASS, RPP, C4, LDE, 4>(a, tile, tid, m0 + 64 * pass, n, bv);
+    }
+        lds_barrier();          // the staging tile is read out before the next tile's DMAs land on it
+        if (raw == blockIdx.x) DLWP_STAMP(17);
     }
 }
 
@@ -1208,7 +1217,12 @@ static int gemm_p8_launch(const GemmDev& a_in, hipStream_t s) {
     const size_t lds = (size_t)2 * 4 * 128 * 64 * 2;          // 128 KB: two stages of four half-tile images (the epilogue's 64 x 260 fp32 tile fits inside)
     int rc;
     if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_p8_kernel), lds, "gemm_p8"))) return rc;
-    hipLaunchKernelGGL(gemm_p8_kernel, dim3(a.ntn * a.ntm), dim3(512), lds, s, a);
+    static const int ncu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    hipLaunchKernelGGL(gemm_p8_kernel, dim3(std::min(a.ntn * a.ntm, ncu)), dim3(512), lds, s, a);
     return DLWP_OK;
 }
 
