@@ -234,6 +234,113 @@ struct TileIO {
     }
 };
 
+// Workgroup barrier for LDS hand-offs inside an epilogue: waits for this wave's LDS traffic only.  __syncthreads() also waits for
+// vmcnt(0), i.e. for every global STORE the wave has issued -- an epilogue that stages its tile through LDS in several passes then
+// pays a full store round trip per pass (stamps: 34 k cycles for the four passes of a 256 x 256 tile, as long as twelve K-tiles).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Store loop of an LDS-staged epilogue: NROWS tile rows per thread (row = tid / C4 + RPP * i, four consecutive columns each), in
+// groups of G rows: every LDS read and every residual / accumulate load of a group is issued before the first use, the options
+// are tested OUTSIDE the row loops (workgroup-uniform branches around whole loops), stores last.  The first form of this loop tested
+// every option per row: 35 branches and a serialised load -> use -> store chain per row -- 34 k cycles for a 256 x 256 tile against
+// 14.6 k for a bias-only loop (stamps, tools/probe_stamps_glds.py).
+template <int NROWS, int RPP, int C4, int LDE, int G>      // G rows in flight per thread (registers: ~14 G)
+__device__ __forceinline__ void epilogue_rows(const GemmDev& a, const float* tile, int tid, int m_base, int n, const f32x4& bv) {
+    static_assert(NROWS % G == 0, "rows per thread come in whole groups");
+    const int c4 = tid % C4;
+    const bool col_ok = n < a.N;
+    auto put = [&](float* dst, long long o, const f32x4& val) {
+        if (a.dt & DT_C)
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(dst) + o) = bf16x4{(__bf16)val[0], (__bf16)val[1], (__bf16)val[2], (__bf16)val[3]};
+        else
+            *reinterpret_cast<f32x4*>(dst + o) = val;
+    };
+#pragma unroll
+    for (int i0 = 0; i0 < NROWS; i0 += G) {
+        f32x4 v[G], rv[G];
+        long long o[G];
+        int mrow[G];
+        bool ok[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int row = tid / C4 + RPP * (i0 + i), m = m_base + row;
+            ok[i] = col_ok && m < a.M;
+            o[i] = ok[i] ? (long long)m * a.ldc + n : 0;            // masked rows read element 0 (valid memory) and store nothing
+            v[i] = *reinterpret_cast<const f32x4*>(&tile[row * LDE + 4 * c4]);
+            rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mrow[i] = ok[i] ? m : 0;
+        }
+        if (a.residual) {
+            if (a.dt & DT_R) {
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    const bf16x4 hv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.residual) + o[i]);
+                    rv[i] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < G; ++i) rv[i] = *reinterpret_cast<const f32x4*>(a.residual + o[i]);
+            }
+        }
+        if (a.bias && a.bias_row) {                     // one bias value per output ROW (channels-first products)
+            float br[G];
+#pragma unroll
+            for (int i = 0; i < G; ++i) br[i] = a.bias[mrow[i]];
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[i][k] += br[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[i][k] += bv[k];
+        }
+        if (a.act >= ACT_GELU_GRAD_MUL) {
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[i][k] = act_grad_mul(v[i][k], rv[i][k], a.act, a.act_param);
+        } else {
+            if (a.res_pre) {
+#pragma unroll
+                for (int i = 0; i < G; ++i)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[i][k] += rv[i][k];
+            }
+            if (a.preact) {
+#pragma unroll
+                for (int i = 0; i < G; ++i)
+                    if (ok[i]) put(a.preact, o[i], v[i]);
+            }
+            if (a.act) {
+#pragma unroll
+                for (int i = 0; i < G; ++i)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[i][k] = apply_act(v[i][k], a.act, a.act_param);
+            }
+            if (!a.res_pre && a.residual) {
+#pragma unroll
+                for (int i = 0; i < G; ++i)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[i][k] += rv[i][k];
+            }
+        }
+        if (a.accumulate) {
+            f32x4 cv[G];
+#pragma unroll
+            for (int i = 0; i < G; ++i) cv[i] = *reinterpret_cast<const f32x4*>(a.C + o[i]);
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[i][k] += cv[i][k];
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+            if (ok[i]) put(a.C, o[i], v[i]);
+    }
+}
+
 // bias gradient by-product: sum over k of op(A) rows (see dlwp_gemm's rowsum)
 template <int T>
 __device__ __forceinline__ void gemm_rowsum_flush(const GemmDev& a, const float (&rsum)[2 * T], int m0, int n0, int wm, int w, int r, int g) {
@@ -397,7 +504,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
             if (a.bias && !a.bias_row && n < a.N) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
 #pragma unroll
             for (int half = 0; half < T; ++half) {
-                if (half) __syncthreads();              // the previous half has been read out
+                if (half) lds_barrier();                // the previous half has been read out
                 if (wm / 64 == half) {
                     const int wl = wm - 64 * half;
 #pragma unroll
@@ -407,57 +514,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q) tile[(wl + i * 16 + 4 * g + q) * LDE + wn + j * 16 + r] = acc[i][j][q];
                 }
-                __syncthreads();
-#pragma unroll
-            for (int pass = 0; pass < NPASS; ++pass) {
-                const int row = tid / C4 + RPP * pass, m = m0 + 64 * half + row;
-                if (m < a.M && n < a.N) {
-                    const long long o = (long long)m * a.ldc + n;
-                    f32x4 v = *reinterpret_cast<const f32x4*>(&tile[row * LDE + 4 * c4]);
-                    if (a.bias && a.bias_row) { const float br = a.bias[m]; bv = f32x4{br, br, br, br}; }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] += bv[k];
-                    f32x4 rv = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (a.residual) {
-                        if (a.dt & DT_R) {
-                            const bf16x4 hv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.residual) + o);
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) rv[k] = (float)hv[k];
-                        } else {
-                            rv = *reinterpret_cast<const f32x4*>(a.residual + o);
-                        }
-                    }
-                    auto put = [&](float* dst, const f32x4& val) {
-                        if (a.dt & DT_C)
-                            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(dst) + o) =
-                                bf16x4{(__bf16)val[0], (__bf16)val[1], (__bf16)val[2], (__bf16)val[3]};
-                        else
-                            *reinterpret_cast<f32x4*>(dst + o) = val;
-                    };
-                    if (a.act >= ACT_GELU_GRAD_MUL) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] = act_grad_mul(v[k], rv[k], a.act, a.act_param);
-                    } else {
-                        if (a.res_pre) {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) v[k] += rv[k];
-                        }
-                        if (a.preact) put(a.preact, v);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], a.act, a.act_param);
-                        if (!a.res_pre) {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) v[k] += rv[k];
-                        }
-                    }
-                    if (a.accumulate) {          // fp32 outputs only (checked on the host)
-                        const f32x4 cv = *reinterpret_cast<const f32x4*>(a.C + o);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] += cv[k];
-                    }
-                    put(a.C, v);
-                }
-            }
+                lds_barrier();
+                epilogue_rows<NPASS, RPP, C4, LDE, 2>(a, tile, tid, m0 + 64 * half, n, bv);
             }       // half
             DLWP_STAMP(5);
             return;
@@ -507,101 +565,6 @@ int gemm_launch_t(const GemmDev& a, dim3 grid, hipStream_t s) {
 }
 
 int g_gemm_bf16 = 0;    // dlwp_set_gemm_precision
-
-// Workgroup barrier for LDS hand-offs inside an epilogue: waits for this wave's LDS traffic only.  __syncthreads() also waits for
-// vmcnt(0), i.e. for every global STORE the wave has issued -- an epilogue that stages its tile through LDS in several passes then
-// pays a full store round trip per pass (stamps: 34 k cycles for the four passes of a 256 x 256 tile, as long as twelve K-tiles).
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// Store loop of an LDS-staged epilogue: NROWS tile rows per thread (row = tid / C4 + RPP * i, four consecutive columns each), in
-// groups of G rows: every LDS read and every residual / accumulate load of a group is issued before the first use, the options
-// are tested OUTSIDE the row loops (workgroup-uniform branches around whole loops), stores last.  The first form of this loop tested
-// every option per row: 35 branches and a serialised load -> use -> store chain per row -- 34 k cycles for a 256 x 256 tile against
-// 14.6 k for a bias-only loop (stamps, tools/probe_stamps_glds.py).
-template <int NROWS, int RPP, int C4, int LDE, int G>      // G rows in flight per thread (registers: ~14 G)
-__device__ __forceinline__ void epilogue_rows(const GemmDev& a, const float* tile, int tid, int m_base, int n, const f32x4& bv) {
-    static_assert(NROWS % G == 0, "rows per thread come in whole groups");
-    const int c4 = tid % C4;
-    const bool col_ok = n < a.N;
-    auto put = [&](float* dst, long long o, const f32x4& val) {
-        if (a.dt & DT_C)
-            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(dst) + o) = bf16x4{(__bf16)val[0], (__bf16)val[1], (__bf16)val[2], (__bf16)val[3]};
-        else
-            *reinterpret_cast<f32x4*>(dst + o) = val;
-    };
-#pragma unroll
-    for (int i0 = 0; i0 < NROWS; i0 += G) {
-        f32x4 v[G], rv[G];
-        long long o[G];
-        bool ok[G];
-#pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const int row = tid / C4 + RPP * (i0 + i), m = m_base + row;
-            ok[i] = col_ok && m < a.M;
-            o[i] = ok[i] ? (long long)m * a.ldc + n : 0;            // masked rows read element 0 (valid memory) and store nothing
-            v[i] = *reinterpret_cast<const f32x4*>(&tile[row * LDE + 4 * c4]);
-            rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (a.residual) {
-            if (a.dt & DT_R) {
-#pragma unroll
-                for (int i = 0; i < G; ++i) {
-                    const bf16x4 hv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.residual) + o[i]);
-                    rv[i] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < G; ++i) rv[i] = *reinterpret_cast<const f32x4*>(a.residual + o[i]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < G; ++i)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[i][k] += bv[k];
-        if (a.act >= ACT_GELU_GRAD_MUL) {
-#pragma unroll
-            for (int i = 0; i < G; ++i)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[i][k] = act_grad_mul(v[i][k], rv[i][k], a.act, a.act_param);
-        } else {
-            if (a.res_pre) {
-#pragma unroll
-                for (int i = 0; i < G; ++i)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[i][k] += rv[i][k];
-            }
-            if (a.preact) {
-#pragma unroll
-                for (int i = 0; i < G; ++i)
-                    if (ok[i]) put(a.preact, o[i], v[i]);
-            }
-            if (a.act) {
-#pragma unroll
-                for (int i = 0; i < G; ++i)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[i][k] = apply_act(v[i][k], a.act, a.act_param);
-            }
-            if (!a.res_pre && a.residual) {
-#pragma unroll
-                for (int i = 0; i < G; ++i)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[i][k] += rv[i][k];
-            }
-        }
-        if (a.accumulate) {
-            f32x4 cv[G];
-#pragma unroll
-            for (int i = 0; i < G; ++i) cv[i] = *reinterpret_cast<const f32x4*>(a.C + o[i]);
-#pragma unroll
-            for (int i = 0; i < G; ++i)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[i][k] += cv[i][k];
-        }
-#pragma unroll
-        for (int i = 0; i < G; ++i)
-            if (ok[i]) put(a.C, o[i], v[i]);
-    }
-}
 
 // ---- (round 3) both operands bf16 arrays, both k-contiguous ("NT": y = x W^T): 128 x 128 x 64 tiles staged by LDS-DMA.
 // The register-staged kernel above spends a K-step of 32 on 4 global loads + 4 ds_write_b128 + a barrier per 16 MFMAs and
