@@ -52,6 +52,17 @@ static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 #define WAVE 64
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// Workgroup barrier for hand-offs through LDS: waits for this wave's LDS traffic only.  __syncthreads() also waits for vmcnt(0), i.e. for
+// every global load still in flight and every global STORE the wave has issued (a store round trip is ~1 us under load): kernels whose
+// barriers only order LDS accesses use this one.  (Not for data exchanged through GLOBAL memory inside a workgroup.)
+// DLWP_PLAIN_BARRIERS builds fall back to __syncthreads() (A/B measurements).
+__device__ __forceinline__ void lds_barrier() {
+#ifdef DLWP_PLAIN_BARRIERS
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
 // D[m=4g+j][n=r] += sum_k A[m=r][k=g] * B[k=g][n=r]   (r = lane&15, g = lane>>4, j = reg)

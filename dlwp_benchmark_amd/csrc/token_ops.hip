@@ -234,11 +234,8 @@ struct TileIO {
     }
 };
 
-// Workgroup barrier for LDS hand-offs inside an epilogue: waits for this wave's LDS traffic only.  __syncthreads() also waits for
-// vmcnt(0), i.e. for every global STORE the wave has issued -- an epilogue that stages its tile through LDS in several passes then
-// pays a full store round trip per pass (stamps: 34 k cycles for the four passes of a 256 x 256 tile, as long as twelve K-tiles).
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
+// (lds_barrier(), common.cuh: __syncthreads() would wait for every global store of the previous pass -- stamps: 34 k cycles for the
+// four passes of a 256 x 256 tile, as long as twelve K-tiles)
 // Store loop of an LDS-staged epilogue: NROWS tile rows per thread (row = tid / C4 + RPP * i, four consecutive columns each), in
 // groups of G rows: every LDS read and every residual / accumulate load of a group is issued before the first use, the options
 // are tested OUTSIDE the row loops (workgroup-uniform branches around whole loops), stores last.  The first form of this loop tested
