@@ -1169,6 +1169,192 @@ static int gemm_glds_launch(const GemmDev& a_in, bool bkc, hipStream_t s) {
 }
 
 
+// ---- the same schedule for weight gradients ("TN": gW = g^T x, both operands [k = tokens][row] bf16 arrays): the half-tile images
+// are [64 k][128 local columns] (chunk cm of k-row kr at position cm ^ 2 (kr & 3), as the 128^2 kernels' [k][n] tile), every fragment
+// comes through two transposing reads.  Work items = (tile, K slice), dealt to the persistent workgroups; a slice is a whole number
+// of K-tiles, the last one may end inside a K-tile (the DMAs re-read row K - 1, the A fragments past the end are zeroed); every item
+// writes its 256 x 256 partial to the slab with plain stores through the staged epilogue and gemm_slab_reduce_kernel adds the slices
+// in order.  Bias gradient = row sums of the A fragments (each column tile takes every ntn-th K-tile).
+__global__ __launch_bounds__(512) void gemm_p8_tn_kernel(GemmDev a) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    __bf16* lds = reinterpret_cast<__bf16*>(gsm);          // [2 stages][A0 | A1 | B0 | B1][64 k][128]
+    constexpr int HT = 64 * 128;
+    const int lane = lane_id(), w = threadIdx.x >> 6, r = lane & 15, g = lane >> 4, tid = threadIdx.x;
+    const int wr = w >> 2, wc = w & 3;
+    const __bf16* A = reinterpret_cast<const __bf16*>(a.A);
+    const __bf16* B = reinterpret_cast<const __bf16*>(a.B);
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const int ntiles = a.ntm * a.ntn, nitems = ntiles * a.splits;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int zs = item / ntiles, tile_id = item - zs * ntiles;
+    const int mt = tile_id / a.ntn, nt_ = tile_id - mt * a.ntn;
+    const int m0 = mt * P8T, n0 = nt_ * P8T;
+    const int kbeg = zs * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
+    const int nk = (kend - kbeg + 63) / 64;
+    // DMA sources: chunk p = i * 512 + tid of a half-tile image: k-row p >> 4, position p & 15 holds logical chunk (p & 15) ^ 2 (kr & 3)
+    int krow[2], acol[2][2], bcol[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int p = i * 512 + tid, kr = p >> 4, lc = 8 * ((p & 15) ^ (2 * (kr & 3)));
+        krow[i] = kr;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            acol[h][i] = min(m0 + (lc >> 6) * 128 + h * 64 + (lc & 63), a.M - 8);
+            bcol[h][i] = min(n0 + (lc >> 5) * 64 + h * 32 + (lc & 31), a.N - 8);
+        }
+    }
+    auto issue = [&](int stage, int which, int k0) {        // which: 0 A0, 1 A1, 2 B0, 3 B1
+        __bf16* dst = lds + (stage * 4 + which) * HT;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long long kk = min(k0 + krow[i], a.K - 1);
+            const __bf16* src = which < 2 ? A + kk * a.lda + acol[which & 1][i] : B + kk * a.ldb + bcol[which & 1][i];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + (i * 512 + w * 64) * 8), 16, 0, 0);
+        }
+    };
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float rsum[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rsum[i] = 0.f;
+    const bool has_rsum = a.rowsum && wc == 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+        if (t < nk) {
+#pragma unroll
+            for (int which = 0; which < 4; ++which) issue(t, which, kbeg + t * 64);
+        }
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    p8_barrier();
+    if (wr == 1) p8_barrier();
+    bf16x8 af[8], b0[4], b1[4];
+    auto frag = [&](const __bf16* img, int cc, int kk) {      // local columns cc .. : lane (r, g) gets column cc' = cc + r... rows k = 32 kk + 8 g ..+7
+        const int kr = 32 * kk + 8 * g + (r >> 2), c2 = cc + 4 * (r & 3);
+        const __bf16* p0 = img + kr * 128 + 8 * ((c2 >> 3) ^ (2 * (kr & 3))) + (c2 & 4);
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * 128));
+        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    auto read_a = [&](int stage, int mq, int k0, int kt) {
+        const __bf16* img = lds + (stage * 4 + mq) * HT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) af[2 * i + kk] = frag(img, wr * 64 + 16 * i, kk);
+        if (k0 + 64 > kend) {                               // the slice ends inside this K-tile: zero the A elements past the end
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int kl = kend - (k0 + 32 * kk + 8 * g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (e >= kl) af[2 * i + kk][e] = (__bf16)0.f;
+            }
+        }
+        if (has_rsum && kt % a.ntn == nt_) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rsum[4 * mq + i] += (float)af[2 * i + kk][e];
+        }
+    };
+    auto read_b = [&](int stage, int nq, bf16x8 (&bf)[4]) {
+        const __bf16* img = lds + (stage * 4 + 2 + nq) * HT;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) bf[2 * j + kk] = frag(img, wc * 32 + 16 * j, kk);
+    };
+    auto mma = [&](int mq, int nq, const bf16x8 (&bf)[4]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[4 * mq + i][2 * nq + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2 * i + kk], bf[2 * j + kk], acc[4 * mq + i][2 * nq + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto end_read = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        p8_barrier();
+    };
+    for (int t = 0; t < nk; ++t) {
+        const int st = t & 1, k0 = kbeg + t * 64, k2 = k0 + 128;
+        const bool more = t + 2 < nk;
+        read_b(st, 0, b0);
+        read_a(st, 0, k0, t);
+        end_read();
+        mma(0, 0, b0);
+        p8_barrier();
+        read_b(st, 1, b1);
+        if (more) { issue(st, 0, k2); issue(st, 2, k2); }
+        end_read();
+        mma(0, 1, b1);
+        p8_barrier();
+        read_a(st, 1, k0, t);
+        if (more) issue(st, 3, k2);
+        end_read();
+        mma(1, 1, b1);
+        p8_barrier();
+        if (t + 1 < nk) {
+            if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (more) issue(st, 1, k2);
+        p8_barrier();
+        mma(1, 0, b0);
+        p8_barrier();
+    }
+    if (wr == 0) p8_barrier();
+    if (has_rsum) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float v = rsum[i];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            const int m = m0 + wr * 128 + (i >> 2) * 64 + 16 * (i & 3) + r;
+            if (g == 0 && m < a.M) atomic_add_f32(&a.rowsum[m], v);
+        }
+    }
+    // ---- epilogue: the partial tile to this slice's slab plane (plain stores, four passes of 64 rows through LDS)
+    constexpr int LDE = P8T + 4, C4 = P8T / 4, RPP = 512 / C4, NPASS = 64 / RPP;
+    float* tile = gsm;
+    GemmDev e = a;
+    e.C = a.slab + (long long)zs * a.M * a.N;
+    e.ldc = a.N;
+    e.bias = nullptr; e.residual = nullptr; e.preact = nullptr; e.act = 0; e.accumulate = 0; e.dt = 0; e.bias_row = 0;
+    const int n = n0 + 4 * (tid % C4);
+    const f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        lds_barrier();
+        if (wr == (pass >> 1)) {
+            const int mq = pass & 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        tile[(16 * i + 4 * g + q) * LDE + wc * 64 + (j >> 1) * 32 + (j & 1) * 16 + r] = acc[4 * mq + i][j][q];
+        }
+        lds_barrier();
+        epilogue_rows<NPASS, RPP, C4, LDE, 4>(e, tile, tid, m0 + 64 * pass, n, bv);
+    }
+    lds_barrier();
+    }
+}
+
 
 static int gemm_p8_launch(const GemmDev& a_in, hipStream_t s) {
     GemmDev a = a_in;
@@ -1188,6 +1374,43 @@ static int gemm_p8_launch(const GemmDev& a_in, hipStream_t s) {
 
 int g_gemm_tile256 = 0;    // dlwp_set_gemm_tile256: 0 by shape (below), 1 wherever the kernel applies, -1 never
 
+// weight gradients on the 256 x 256 two-group kernel.  Measured (profiles/r03_gemm_p8.txt): 4096^3 707 against 656 TFLOP/s for the
+// 128 x 128 sliced kernel, 8192^3 764 / 762, FourCastNet 3072 x 768 x 16200 639 / 689, 768 x 3072 x 16200 652 / 640 -- with every fragment
+// through two transposing reads the K loop does not reach the y = x W^T kernel's rate and the gain is within the noise: NOT taken by
+// shape, only when forced (dlwp_set_gemm_tile256(1) / DLWP_GEMM_P8: tests, measurements).  Needs the slab.
+static int gemm_p8_tn_launch(const GemmDev& a_in, hipStream_t s, bool* taken) {
+    *taken = false;
+    static const bool off = getenv("DLWP_GEMM_NOP8_TN") != nullptr;
+    if (off || g_gemm_tile256 < 0 || a_in.M < P8T || a_in.N < P8T || a_in.N % 4 || a_in.ldc % 4 || (uintptr_t)a_in.C % 16) return DLWP_OK;
+    GemmDev a = a_in;
+    a.ntn = ceil_div(a.N, P8T);
+    a.ntm = ceil_div(a.M, P8T);
+    static const int ncu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    const int tiles = a.ntn * a.ntm;
+    int splits = std::max(1, std::min(ncu / tiles, a.K / (16 * 64)));
+    a.kchunk = ceil_div(ceil_div(a.K, splits), 64) * 64;
+    splits = ceil_div(a.K, a.kchunk);
+    static const bool force = getenv("DLWP_GEMM_P8") != nullptr;
+    if (!force && g_gemm_tile256 <= 0) return DLWP_OK;
+    a.splits = splits;
+    a.slab = tn_slab_for(s, sizeof(float) * splits * (size_t)a.M * a.N);
+    if (!a.slab) return DLWP_OK;
+    const size_t lds = (size_t)2 * 4 * 128 * 64 * 2;
+    int rc;
+    if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_p8_tn_kernel), lds, "gemm_p8_tn"))) return rc;
+    hipLaunchKernelGGL(gemm_p8_tn_kernel, dim3(std::min(tiles * splits, ncu)), dim3(512), lds, s, a);
+    const long long units = (long long)a.M * (a.N / 4);
+    hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)std::min<long long>((units + 255) / 256, 2048)), dim3(256), 0, s,
+                       a.slab, a.C, a.M, a.N, a.ldc, splits, 1);
+    *taken = true;
+    return DLWP_OK;
+}
+
+
 // the 256 x 256 kernel runs one workgroup per CU: nothing covers its prologue (two K-tiles of DMAs) and epilogue, so it needs a long K
 // to pay -- 8192^3: 1351 against 1017 TFLOP/s, 4096^3 1186 / 983, 16200 x 768 x 3072: 898 / 788, but 16200 x 3072 x 768: 686 / 693 and every
 // K <= 512 shape loses (profiles/r03_gemm_p8.txt): taken from K = 2048 with at least 128 tiles, or when forced
@@ -1202,7 +1425,12 @@ template <bool AKC, bool BKC>
 int gemm_launch(const GemmDev& a_in, int vec, int T, hipStream_t s) {
     if (gemm_glds_applies(a_in, AKC, BKC) && gemm_p8_applies(a_in, AKC, BKC)) return gemm_p8_launch(a_in, s);
     if (gemm_glds_applies(a_in, AKC, BKC)) return gemm_glds_launch(a_in, BKC, s);
-    if (!AKC && !BKC && gemm_glds_tn_applies(a_in)) return gemm_glds_tn_launch(a_in, s);
+    if (!AKC && !BKC && gemm_glds_tn_applies(a_in)) {
+        bool taken = false;
+        if (int rc = gemm_p8_tn_launch(a_in, s, &taken)) return rc;
+        if (taken) return DLWP_OK;
+        return gemm_glds_tn_launch(a_in, s);
+    }
     const int edge = 64 * T;
     GemmDev a = a_in;
     a.ntn = ceil_div(a.N, edge);

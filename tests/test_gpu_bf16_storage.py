@@ -315,3 +315,33 @@ def test_tile256_two_group_gemm_matches_float64(cuda, M, N, K, epi):
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
     finally:
         L.set_gemm_tile256(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 2048), (768, 512, 4100), (3072, 768, 16200), (520, 264, 3000)])
+def test_tile256_weight_gradient_kernel(cuda, M, N, K):
+    """gW = g^T x on the 256 x 256 two-group kernel (gemm_p8_tn_kernel, forced through lib.set_gemm_tile256): K slices to a slab,
+    ordered reduction, a slice ending inside a K-tile, edge tiles, accumulation into an existing gradient, the bias gradient as a
+    by-product; repeated launches agree bit for bit on the weight gradient (the slices are added in order)."""
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.token_ops import _gemm
+    gen = torch.Generator().manual_seed(M + K)
+    g = torch.randn(K, M, generator=gen).to(cuda).to(torch.bfloat16)
+    x = torch.randn(K, N, generator=gen).to(cuda).to(torch.bfloat16)
+    gw0 = torch.randn(M, N, generator=gen).to(cuda)
+    gb0 = torch.randn(M, generator=gen).to(cuda)
+    want_w = gw0.double() + g.double().T @ x.double()
+    want_b = gb0.double() + g.double().sum(0)
+    L.set_gemm_tile256(1)
+    try:
+        outs = []
+        with L.gemm_precision("bf16"):
+            for _ in range(3):
+                gw, gb = gw0.clone(), gb0.clone()
+                _gemm(g, x, gw, M, N, K, M, N, N, 1, 0, accumulate=1, rowsum=gb)
+                torch.cuda.synchronize()
+                outs.append(gw.clone())
+        assert ((gw.double() - want_w).abs().max() / want_w.abs().max()).item() <= 2e-5
+        assert ((gb.double() - want_b).abs().max() / want_b.abs().max()).item() <= 2e-5
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    finally:
+        L.set_gemm_tile256(0)
