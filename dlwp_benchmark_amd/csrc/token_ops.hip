@@ -241,10 +241,9 @@ struct TileIO {
 // are tested OUTSIDE the row loops (workgroup-uniform branches around whole loops), stores last.  The first form of this loop tested
 // every option per row: 35 branches and a serialised load -> use -> store chain per row -- 34 k cycles for a 256 x 256 tile against
 // 14.6 k for a bias-only loop (stamps, tools/probe_stamps_glds.py).
-template <int NROWS, int RPP, int C4, int LDE, int G>      // G rows in flight per thread (registers: ~14 G)
-__device__ __forceinline__ void epilogue_rows(const GemmDev& a, const float* tile, int tid, int m_base, int n, const f32x4& bv) {
-    static_assert(NROWS % G == 0, "rows per thread come in whole groups");
-    const int c4 = tid % C4;
+// G values of four consecutive columns n .. n + 3 in rows m[0..G): the epilogue arithmetic and the stores
+template <int G>
+__device__ __forceinline__ void epilogue_group(const GemmDev& a, f32x4 (&v)[G], const int (&m)[G], int n, const f32x4& bv) {
     const bool col_ok = n < a.N;
     auto put = [&](float* dst, long long o, const f32x4& val) {
         if (a.dt & DT_C)
@@ -252,89 +251,102 @@ __device__ __forceinline__ void epilogue_rows(const GemmDev& a, const float* til
         else
             *reinterpret_cast<f32x4*>(dst + o) = val;
     };
+    f32x4 rv[G];
+    long long o[G];
+    int mrow[G];
+    bool ok[G];
 #pragma unroll
-    for (int i0 = 0; i0 < NROWS; i0 += G) {
-        f32x4 v[G], rv[G];
-        long long o[G];
-        int mrow[G];
-        bool ok[G];
+    for (int i = 0; i < G; ++i) {
+        ok[i] = col_ok && m[i] < a.M;
+        o[i] = ok[i] ? (long long)m[i] * a.ldc + n : 0;            // masked rows read element 0 (valid memory) and store nothing
+        rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mrow[i] = ok[i] ? m[i] : 0;
+    }
+    if (a.residual) {
+        if (a.dt & DT_R) {
 #pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const int row = tid / C4 + RPP * (i0 + i), m = m_base + row;
-            ok[i] = col_ok && m < a.M;
-            o[i] = ok[i] ? (long long)m * a.ldc + n : 0;            // masked rows read element 0 (valid memory) and store nothing
-            v[i] = *reinterpret_cast<const f32x4*>(&tile[row * LDE + 4 * c4]);
-            rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            mrow[i] = ok[i] ? m : 0;
-        }
-        if (a.residual) {
-            if (a.dt & DT_R) {
-#pragma unroll
-                for (int i = 0; i < G; ++i) {
-                    const bf16x4 hv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.residual) + o[i]);
-                    rv[i] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < G; ++i) rv[i] = *reinterpret_cast<const f32x4*>(a.residual + o[i]);
+            for (int i = 0; i < G; ++i) {
+                const bf16x4 hv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.residual) + o[i]);
+                rv[i] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
             }
-        }
-        if (a.bias && a.bias_row) {                     // one bias value per output ROW (channels-first products)
-            float br[G];
-#pragma unroll
-            for (int i = 0; i < G; ++i) br[i] = a.bias[mrow[i]];
-#pragma unroll
-            for (int i = 0; i < G; ++i)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[i][k] += br[i];
         } else {
 #pragma unroll
-            for (int i = 0; i < G; ++i)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[i][k] += bv[k];
+            for (int i = 0; i < G; ++i) rv[i] = *reinterpret_cast<const f32x4*>(a.residual + o[i]);
         }
-        if (a.act >= ACT_GELU_GRAD_MUL) {
+    }
+    if (a.bias && a.bias_row) {                     // one bias value per output ROW (channels-first products)
+        float br[G];
 #pragma unroll
-            for (int i = 0; i < G; ++i)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[i][k] = act_grad_mul(v[i][k], rv[i][k], a.act, a.act_param);
-        } else {
-            if (a.res_pre) {
-#pragma unroll
-                for (int i = 0; i < G; ++i)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[i][k] += rv[i][k];
-            }
-            if (a.preact) {
-#pragma unroll
-                for (int i = 0; i < G; ++i)
-                    if (ok[i]) put(a.preact, o[i], v[i]);
-            }
-            if (a.act) {
-#pragma unroll
-                for (int i = 0; i < G; ++i)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[i][k] = apply_act(v[i][k], a.act, a.act_param);
-            }
-            if (!a.res_pre && a.residual) {
-#pragma unroll
-                for (int i = 0; i < G; ++i)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[i][k] += rv[i][k];
-            }
-        }
-        if (a.accumulate) {
-            f32x4 cv[G];
-#pragma unroll
-            for (int i = 0; i < G; ++i) cv[i] = *reinterpret_cast<const f32x4*>(a.C + o[i]);
-#pragma unroll
-            for (int i = 0; i < G; ++i)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[i][k] += cv[i][k];
-        }
+        for (int i = 0; i < G; ++i) br[i] = a.bias[mrow[i]];
 #pragma unroll
         for (int i = 0; i < G; ++i)
-            if (ok[i]) put(a.C, o[i], v[i]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[i][k] += br[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[i][k] += bv[k];
+    }
+    if (a.act >= ACT_GELU_GRAD_MUL) {
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[i][k] = act_grad_mul(v[i][k], rv[i][k], a.act, a.act_param);
+    } else {
+        if (a.res_pre) {
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[i][k] += rv[i][k];
+        }
+        if (a.preact) {
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+                if (ok[i]) put(a.preact, o[i], v[i]);
+        }
+        if (a.act) {
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[i][k] = apply_act(v[i][k], a.act, a.act_param);
+        }
+        if (!a.res_pre && a.residual) {
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[i][k] += rv[i][k];
+        }
+    }
+    if (a.accumulate) {
+        f32x4 cv[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) cv[i] = *reinterpret_cast<const f32x4*>(a.C + o[i]);
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[i][k] += cv[i][k];
+    }
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+        if (ok[i]) put(a.C, o[i], v[i]);
+}
+
+template <int NROWS, int RPP, int C4, int LDE, int G>      // G rows in flight per thread (registers: ~14 G)
+__device__ __forceinline__ void epilogue_rows(const GemmDev& a, const float* tile, int tid, int m_base, int n, const f32x4& bv) {
+    static_assert(NROWS % G == 0, "rows per thread come in whole groups");
+    const int c4 = tid % C4;
+#pragma unroll
+    for (int i0 = 0; i0 < NROWS; i0 += G) {
+        f32x4 v[G];
+        int m[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int row = tid / C4 + RPP * (i0 + i);
+            m[i] = m_base + row;
+            v[i] = *reinterpret_cast<const f32x4*>(&tile[row * LDE + 4 * c4]);
+        }
+        epilogue_group<G>(a, v, m, n, bv);
     }
 }
 
@@ -964,6 +976,8 @@ constexpr int P8T = 256;
 // does not order memory accesses for the optimiser; a read hoisted above the barrier that follows the other group's vmcnt wait
 // would see a half-tile before its DMA has landed)
 __device__ __forceinline__ void p8_barrier() { asm volatile("s_barrier" ::: "memory"); }
+template <bool DIRECT>      // DIRECT: accumulate C^T fragments (operands swapped in the MFMA) so that a lane holds four consecutive COLUMNS of a
+                            // row and the epilogue stores straight from the registers (no LDS staging, no barriers)
 __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmDev a) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     __bf16* lds = reinterpret_cast<__bf16*>(gsm);          // [2 stages][A0 | A1 | B0 | B1][128][64]
@@ -1058,7 +1072,8 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmDev a) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[4 * mq + i][2 * nq + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2 * i + kk], bf[2 * j + kk], acc[4 * mq + i][2 * nq + j], 0, 0, 0);
+                    acc[4 * mq + i][2 * nq + j] = DIRECT ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[2 * j + kk], af[2 * i + kk], acc[4 * mq + i][2 * nq + j], 0, 0, 0)
+                                                         : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2 * i + kk], bf[2 * j + kk], acc[4 * mq + i][2 * nq + j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
     auto end_read = [&]() {
@@ -1102,6 +1117,27 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmDev a) {
     }
     if (wr == 0) p8_barrier();             // group 0 catches up with group 1's last half-phase
     if (raw == blockIdx.x) DLWP_STAMP(16);
+    if (DIRECT) {
+        // ---- epilogue straight from the registers: acc[I][J][q] = C[row wr * 128 + (I >> 2) * 64 + 16 (I & 3) + r][column wc * 64 + (J >> 1) * 32 + (J & 1) * 16 + 4 g + q]
+#pragma unroll
+        for (int J = 0; J < 4; ++J) {
+            const int n = n0 + wc * 64 + (J >> 1) * 32 + (J & 1) * 16 + 4 * g;
+            f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.bias && !a.bias_row && n < a.N) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+            for (int I0 = 0; I0 < 8; I0 += 4) {
+                f32x4 v[4];
+                int m[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int I = I0 + i;
+                    v[i] = acc[I][J];
+                    m[i] = m0 + wr * 128 + (I >> 2) * 64 + 16 * (I & 3) + r;
+                }
+                epilogue_group<4>(a, v, m, n, bv);
+            }
+        }
+    } else {
     // ---- epilogue: four passes of 64 tile rows through an fp32 LDS tile [64][260]; pass = 2 wr + mq
     constexpr int LDE = P8T + 4, C4 = P8T / 4, RPP = 512 / C4, NPASS = 64 / RPP;
     float* tile = gsm;
@@ -1125,6 +1161,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmDev a) {
         }
         lds_barrier();
         epilogue_rows<NPASS, RPP, C4, LDE, 4>(a, tile, tid, m0 + 64 * pass, n, bv);
+    }
     }
         lds_barrier();          // the staging tile is read out before the next tile's DMAs land on it
         if (raw == blockIdx.x) DLWP_STAMP(17);
@@ -1362,13 +1399,19 @@ static int gemm_p8_launch(const GemmDev& a_in, hipStream_t s) {
     a.ntm = ceil_div(a.M, P8T);
     const size_t lds = (size_t)2 * 4 * 128 * 64 * 2;          // 128 KB: two stages of four half-tile images (the epilogue's 64 x 260 fp32 tile fits inside)
     int rc;
-    if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_p8_kernel), lds, "gemm_p8"))) return rc;
+    static const bool direct = getenv("DLWP_GEMM_P8_STAGED") == nullptr;
     static const int ncu = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n > 0 ? n : 256;
     }();
-    hipLaunchKernelGGL(gemm_p8_kernel, dim3(std::min(a.ntn * a.ntm, ncu)), dim3(512), lds, s, a);
+    if (direct) {
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_p8_kernel<true>), lds, "gemm_p8"))) return rc;
+        hipLaunchKernelGGL(gemm_p8_kernel<true>, dim3(std::min(a.ntn * a.ntm, ncu)), dim3(512), lds, s, a);
+    } else {
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_p8_kernel<false>), lds, "gemm_p8"))) return rc;
+        hipLaunchKernelGGL(gemm_p8_kernel<false>, dim3(std::min(a.ntn * a.ntm, ncu)), dim3(512), lds, s, a);
+    }
     return DLWP_OK;
 }
 
@@ -1418,7 +1461,9 @@ static bool gemm_p8_applies(const GemmDev& a, bool akc, bool bkc) {
     static const bool env_on = getenv("DLWP_GEMM_P8") != nullptr;
     if (g_gemm_tile256 < 0 || !akc || !bkc || a.K % 64 || a.M < P8T || a.N < P8T) return false;
     const long long tiles = (long long)ceil_div(a.M, P8T) * ceil_div(a.N, P8T);
-    return env_on || g_gemm_tile256 > 0 || (a.K >= 2048 && tiles >= 128);
+    static const char* mink_env = getenv("DLWP_GEMM_P8_MINK");
+    const int mink = mink_env ? atoi(mink_env) : 2048;
+    return env_on || g_gemm_tile256 > 0 || (a.K >= mink && tiles >= 128);
 }
 
 template <bool AKC, bool BKC>
