@@ -976,7 +976,8 @@ constexpr int P8T = 256;
 // does not order memory accesses for the optimiser; a read hoisted above the barrier that follows the other group's vmcnt wait
 // would see a half-tile before its DMA has landed)
 __device__ __forceinline__ void p8_barrier() { asm volatile("s_barrier" ::: "memory"); }
-template <bool DIRECT>      // DIRECT: accumulate C^T fragments (operands swapped in the MFMA) so that a lane holds four consecutive COLUMNS of a
+template <bool DIRECT, bool BKC = true>      // BKC = false: B is [k][n] (gx = g W): its half-tile images are [64 k][128 local columns], fragments through the
+                                             // transposing read (as in gemm_p8_tn_kernel).  DIRECT: accumulate C^T fragments (operands swapped in the MFMA) so that a lane holds four consecutive COLUMNS of a
                             // row and the epilogue stores straight from the registers (no LDS staging, no barriers)
 __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmDev a) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
@@ -1011,7 +1012,13 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmDev a) {
             const int trow = (lr >> 6) * 128 + h * 64 + (lr & 63);            // A: tile row of local row lr in half h
             const int tcol = (lr >> 5) * 64 + h * 32 + (lr & 31);            // B: tile column of local column lr in half h
             asrc[h][i] = A + (long long)min(m0 + trow, a.M - 1) * a.lda + 8 * c;
-            bsrc[h][i] = B + (long long)min(n0 + tcol, a.N - 1) * a.ldb + 8 * c;
+            if (BKC) {
+                bsrc[h][i] = B + (long long)min(n0 + tcol, a.N - 1) * a.ldb + 8 * c;
+            } else {
+                // chunk p of a [64 k][128] image: k-row p >> 4, position p & 15 holds logical chunk (p & 15) ^ 2 (kr & 3)
+                const int kr = p >> 4, lc = 8 * ((p & 15) ^ (2 * (kr & 3)));
+                bsrc[h][i] = B + (long long)kr * a.ldb + min(n0 + (lc >> 5) * 64 + h * 32 + (lc & 31), a.N - 8);
+            }
         }
     }
     // which: 0 A0, 1 A1, 2 B0, 3 B1
@@ -1019,7 +1026,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmDev a) {
         __bf16* dst = lds + (stage * 4 + which) * HT;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const __bf16* src = (which < 2 ? asrc[which & 1][i] : bsrc[which & 1][i]) + k0;
+            const __bf16* src = which < 2 ? asrc[which & 1][i] + k0 : bsrc[which & 1][i] + (BKC ? (long long)k0 : (long long)k0 * a.ldb);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + (i * 512 + w * 64) * 8), 16, 0, 0);
         }
@@ -1060,8 +1067,17 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmDev a) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                const int lr = wc * 32 + 16 * j + r, c = (4 * kk + g) ^ ((lr >> 1) & 7);
-                bf[2 * j + kk] = *reinterpret_cast<const bf16x8*>(img + lr * 64 + 8 * c);
+                if (BKC) {
+                    const int lr = wc * 32 + 16 * j + r, c = (4 * kk + g) ^ ((lr >> 1) & 7);
+                    bf[2 * j + kk] = *reinterpret_cast<const bf16x8*>(img + lr * 64 + 8 * c);
+                } else {
+                    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+                    const int kr = 32 * kk + 8 * g + (r >> 2), c2 = wc * 32 + 16 * j + 4 * (r & 3);
+                    const __bf16* p0 = img + kr * 128 + 8 * ((c2 >> 3) ^ (2 * (kr & 3))) + (c2 & 4);
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * 128));
+                    bf[2 * j + kk] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
             }
     };
     auto mma = [&](int mq, int nq, const bf16x8 (&bf)[4]) {
@@ -1393,7 +1409,7 @@ __global__ __launch_bounds__(512) void gemm_p8_tn_kernel(GemmDev a) {
 }
 
 
-static int gemm_p8_launch(const GemmDev& a_in, hipStream_t s) {
+static int gemm_p8_launch(const GemmDev& a_in, bool bkc, hipStream_t s) {
     GemmDev a = a_in;
     a.ntn = ceil_div(a.N, P8T);
     a.ntm = ceil_div(a.M, P8T);
@@ -1405,13 +1421,14 @@ static int gemm_p8_launch(const GemmDev& a_in, hipStream_t s) {
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n > 0 ? n : 256;
     }();
-    if (direct) {
-        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_p8_kernel<true>), lds, "gemm_p8"))) return rc;
-        hipLaunchKernelGGL(gemm_p8_kernel<true>, dim3(std::min(a.ntn * a.ntm, ncu)), dim3(512), lds, s, a);
-    } else {
-        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_p8_kernel<false>), lds, "gemm_p8"))) return rc;
-        hipLaunchKernelGGL(gemm_p8_kernel<false>, dim3(std::min(a.ntn * a.ntm, ncu)), dim3(512), lds, s, a);
-    }
+#define P8_GO(D_, B_)                                                                                                   \
+    do {                                                                                                                \
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_p8_kernel<D_, B_>), lds, "gemm_p8"))) return rc;   \
+        hipLaunchKernelGGL((gemm_p8_kernel<D_, B_>), dim3(std::min(a.ntn * a.ntm, ncu)), dim3(512), lds, s, a);         \
+    } while (0)
+    if (bkc) { if (direct) P8_GO(true, true); else P8_GO(false, true); }
+    else     { if (direct) P8_GO(true, false); else P8_GO(false, false); }
+#undef P8_GO
     return DLWP_OK;
 }
 
@@ -1459,7 +1476,7 @@ static int gemm_p8_tn_launch(const GemmDev& a_in, hipStream_t s, bool* taken) {
 // K <= 512 shape loses (profiles/r03_gemm_p8.txt): taken from K = 2048 with at least 128 tiles, or when forced
 static bool gemm_p8_applies(const GemmDev& a, bool akc, bool bkc) {
     static const bool env_on = getenv("DLWP_GEMM_P8") != nullptr;
-    if (g_gemm_tile256 < 0 || !akc || !bkc || a.K % 64 || a.M < P8T || a.N < P8T) return false;
+    if (g_gemm_tile256 < 0 || !akc || a.K % 64 || a.M < P8T || a.N < P8T) return false;
     const long long tiles = (long long)ceil_div(a.M, P8T) * ceil_div(a.N, P8T);
     static const char* mink_env = getenv("DLWP_GEMM_P8_MINK");
     const int mink = mink_env ? atoi(mink_env) : 2048;
@@ -1468,7 +1485,7 @@ static bool gemm_p8_applies(const GemmDev& a, bool akc, bool bkc) {
 
 template <bool AKC, bool BKC>
 int gemm_launch(const GemmDev& a_in, int vec, int T, hipStream_t s) {
-    if (gemm_glds_applies(a_in, AKC, BKC) && gemm_p8_applies(a_in, AKC, BKC)) return gemm_p8_launch(a_in, s);
+    if (gemm_glds_applies(a_in, AKC, BKC) && gemm_p8_applies(a_in, AKC, BKC)) return gemm_p8_launch(a_in, BKC, s);
     if (gemm_glds_applies(a_in, AKC, BKC)) return gemm_glds_launch(a_in, BKC, s);
     if (!AKC && !BKC && gemm_glds_tn_applies(a_in)) {
         bool taken = false;

@@ -345,3 +345,31 @@ def test_tile256_weight_gradient_kernel(cuda, M, N, K):
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
     finally:
         L.set_gemm_tile256(0)
+
+
+@pytest.mark.parametrize("T,Nout,Kin", [(256, 128, 256), (1000, 192, 520), (4100, 1024, 768), (2048, 4096, 2048)])
+def test_tile256_input_gradient_form(cuda, T, Nout, Kin):
+    """gx = g W (B operand [k][n]: half-tile images [64 k][128], transposing reads) on the 256 x 256 two-group kernel, with the
+    GELU'(z) multiply of the token-MLP backward in its epilogue; bit-reproducible over repeated launches."""
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.token_ops import _gemm_batched
+    gen = torch.Generator().manual_seed(T + Nout)
+    g = torch.randn(T, Nout, generator=gen).to(cuda).to(torch.bfloat16)
+    w = (torch.randn(Nout, Kin, generator=gen) / Nout ** 0.5).to(cuda).to(torch.bfloat16)
+    z = torch.randn(T, Kin, generator=gen).to(cuda).to(torch.bfloat16)
+    zd = z.double().requires_grad_()
+    (gd,) = torch.autograd.grad(torch.nn.functional.gelu(zd).sum(), zd)
+    want = (g.double() @ w.double()) * gd
+    L.set_gemm_tile256(1)
+    try:
+        outs = []
+        with L.gemm_precision("bf16"):
+            for _ in range(3):
+                gx = torch.empty(T, Kin, device=cuda, dtype=torch.bfloat16)
+                _gemm_batched(g, w, gx, T, Kin, Nout, Nout, Kin, Kin, 0, 0, act=4, residual=z)
+                torch.cuda.synchronize()
+                outs.append(gx.clone())
+        assert ((gx.double() - want).abs().max() / want.abs().max()).item() <= 1e-2
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    finally:
+        L.set_gemm_tile256(0)
