@@ -366,8 +366,9 @@ __device__ __forceinline__ void gemm_rowsum_flush(const GemmDev& a, const float 
 
 // VEC bit 0: 16-byte loads for the A tile, bit 1: for the B tile (alignment checked per operand on the host)
 // S16M bit 0 / 1: operand A / B is an aligned bf16 array read through TileIO's 16-byte path (BF kernels only)
+// (the kernel body: workgroup bx of ntiles_grid tiles, slice / batch bz; gemm_kernel launches one product, gemm_group_kernel several)
 template <bool AKC, bool BKC, int VEC, int T, bool BF, int S16M = 0>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
+__device__ __forceinline__ void gemm_body(GemmDev a, const int bx, const int bz, const int ntiles_grid) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     constexpr int BMN = Tile<T>::ROWS, NT16 = 2 * T;   // 16-row MFMA tiles per wave and direction
     // K-step: 32, or 64 when both operands are bf16 arrays (S16M == 3: four staging registers per operand and K-step instead
@@ -381,9 +382,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
     // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so consecutive ids never
     // share an L2.  Remap so that every XCD walks a contiguous range of tiles, row-panel by row-panel: the A panel that the
     // ntn column tiles of one row panel share is then fetched into ONE L2 instead of eight.
-    int tile_id = blockIdx.x;
+    int tile_id = bx;
     {
-        const int nt = gridDim.x, full = (nt / 8) * 8;
+        const int nt = ntiles_grid, full = (nt / 8) * 8;
         if (tile_id < full) tile_id = (tile_id % 8) * (nt / 8) + tile_id / 8;
     }
     // inside an XCD's range: groups of 8 row panels, column tile by column tile, so that the ~128 workgroups an XCD runs
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
     const int rows_in = min(GM, a.ntm - grp * GM);
     const int nt_ = within / rows_in, mt = grp * GM + (within - nt_ * rows_in);
     const int m0 = mt * BMN, n0 = nt_ * BMN;
-    int zs = blockIdx.z;
+    int zs = bz;
     if (a.nbatch > 1) {
         const int zb = zs / a.splits;                 // batch index; zs % splits = K split within the batch
         zs -= zb * a.splits;
@@ -559,6 +560,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
                     put1(a.C, a.accumulate ? a.C[o] + v : v);
                 }
             }
+}
+
+template <bool AKC, bool BKC, int VEC, int T, bool BF, int S16M = 0>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
+    gemm_body<AKC, BKC, VEC, T, BF, S16M>(a, blockIdx.x, blockIdx.z, gridDim.x);
+}
+
+// up to three independent products in ONE launch (blockIdx.y picks the product): the weight gradients of a token MLP are three
+// small, latency-bound split-K products (SFNO C3: 512 workgroups of ~20 us each on a 1024-slot chip) that do not depend on each other
+struct GemmGroup { GemmDev g[3]; };
+template <bool AKC, bool BKC, int VEC, int T, bool BF, int S16M = 0>
+__global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup gg) {
+    const GemmDev a = gg.g[blockIdx.y];
+    const int nt = a.ntn * a.ntm;
+    if ((int)blockIdx.x >= nt || (long long)blockIdx.z >= a.nbatch * a.splits) return;
+    gemm_body<AKC, BKC, VEC, T, BF, S16M>(a, blockIdx.x, blockIdx.z, nt);
 }
 
 template <bool AKC, bool BKC, int VEC, int T, bool BF, int S16M = 0>
@@ -2111,6 +2128,74 @@ static int gemm_impl(const float* A, const float* B, float* C, int M, int N, int
               1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.f, 0, 0, 0};
     a.dt = dt;
     return gemm_dispatch(a, transA, transB, T, stream);
+}
+
+// Several weight-gradient products gW_i (+)= g_i^T x_i (K = tokens) with their bias gradients in ONE launch (gemm_group_kernel):
+// each is prepared exactly as dlwp_gemm_mixed(transA = 1) would (split-K over the tokens, zero fill when not accumulating,
+// row sums as the bias gradient) on the 64 x 64 register-staged kernel, which reads fp32 and bf16 operands alike.  Falls back to
+// one launch per product when a product does not fit the grouped form (unaligned operands, more than three, an empty one).
+extern "C" int dlwp_weight_grad_group(const dlwp_wgrad_desc* d, int n, void* stream) {
+    DLWP_REQUIRE(d && n >= 1, DLWP_E_INVALID, "weight_grad_group: no products");
+    for (int i = 0; i < n; ++i)
+        DLWP_REQUIRE(d[i].g && d[i].x && d[i].gw && d[i].T > 0 && d[i].N > 0 && d[i].K > 0, DLWP_E_INVALID,
+                     "weight_grad_group: product %d has a NULL operand or an empty shape", i);
+    auto single = [&](const dlwp_wgrad_desc& q) {
+        const int dt = (q.g_bf16 ? DT_A : 0) | (q.x_bf16 ? DT_B : 0);
+        return gemm_impl((const float*)q.g, (const float*)q.x, q.gw, q.N, q.K, q.T, q.N, q.K, q.K, 1, 0, nullptr, 0, nullptr, nullptr,
+                         q.accumulate, q.gb, dt, stream);
+    };
+    static const bool off = getenv("DLWP_GEMM_NOGROUP") != nullptr;
+    // worth it while the products are latency-bound (SFNO C3, 8192 tokens: 5.68 -> 5.49 ms per step); at 32768 tokens each product fills
+    // the chip by itself and the bf16 x bf16 one has a faster kernel of its own (11.5 -> 11.9 ms grouped)
+    bool grouped = !off && n >= 2 && n <= 3;
+    for (int i = 0; i < n; ++i) grouped = grouped && d[i].T <= 16384;
+    GemmGroup gg{};
+    unsigned gx = 0, gz = 0;
+    for (int i = 0; grouped && i < n; ++i) {
+        const dlwp_wgrad_desc& q = d[i];
+        const int M = q.N, N = q.K, K = q.T;                  // gW [N][K] = g^T [N][T] . x [T][K]
+        const int dt = (q.g_bf16 ? DT_A : 0) | (q.x_bf16 ? DT_B : 0);
+        const int tiles = ceil_div(N, 64) * ceil_div(M, 64);
+        int splits = 1;
+        if (tiles < 256 && K >= 8 * BK) splits = std::min(ceil_div(512, tiles), K / (4 * BK));
+        const int kchunk = ceil_div(ceil_div(K, splits), BK) * BK;
+        splits = ceil_div(K, kchunk);
+        GemmDev a{(const float*)q.g, (const float*)q.x, nullptr, nullptr, q.gw, nullptr, q.gb, M, N, K, M, N, N, 0, q.accumulate, kchunk, splits,
+                  1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.f, 0, 0, 0};
+        a.dt = dt;
+        a.ntn = ceil_div(N, 64);
+        a.ntm = ceil_div(M, 64);
+        const bool vecA = ((uintptr_t)a.A % ((dt & DT_A) ? 8 : 16) == 0) && a.lda % 4 == 0 && a.M % 4 == 0;
+        const bool vecB = ((uintptr_t)a.B % ((dt & DT_B) ? 8 : 16) == 0) && a.ldb % 4 == 0 && a.N % 4 == 0;
+        if (!vecA || !vecB || splits * 1LL > 65535) { grouped = false; break; }
+        a.vec_epi = splits == 1 && a.N % 4 == 0 && a.ldc % 4 == 0 && (uintptr_t)a.C % 16 == 0;
+        gg.g[i] = a;
+        gx = std::max(gx, (unsigned)(a.ntn * a.ntm));
+        gz = std::max(gz, (unsigned)splits);
+    }
+    if (!grouped) {
+        for (int i = 0; i < n; ++i)
+            if (int rc = single(d[i])) return rc;
+        return DLWP_OK;
+    }
+    for (int i = 0; i < n; ++i)
+        if (gg.g[i].splits > 1 && !gg.g[i].accumulate)
+            if (int zrc = dlwp_zero_2d_f32(gg.g[i].C, gg.g[i].ldc, gg.g[i].M, gg.g[i].N, stream)) return zrc;
+    const dim3 grid(gx, n, gz);
+    const hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (g_gemm_bf16) {
+        constexpr int KS = gemm_bf_kstep(0, 1, false, false);
+        const size_t lds = sizeof(float) * 4 * ((64 * (KS + 8) > KS * (64 + 8) ? 64 * (KS + 8) : KS * (64 + 8)) / 2);
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_group_kernel<false, false, 3, 1, true, 0>), lds, "gemm_group"))) return rc;
+        hipLaunchKernelGGL((gemm_group_kernel<false, false, 3, 1, true, 0>), grid, dim3(256), lds, s, gg);
+    } else {
+        const size_t lds = sizeof(float) * 4 * Tile<1>::FLOATS;
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_group_kernel<false, false, 3, 1, false, 0>), lds, "gemm_group"))) return rc;
+        hipLaunchKernelGGL((gemm_group_kernel<false, false, 3, 1, false, 0>), grid, dim3(256), lds, s, gg);
+    }
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
 }
 
 extern "C" int dlwp_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,

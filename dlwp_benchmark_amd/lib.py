@@ -67,6 +67,7 @@ SIGNATURES = {
     "dlwp_set_gemm_precision": (_I, [_I]),
     "dlwp_get_gemm_precision": (_I, []),
     "dlwp_set_gemm_tile256": (_I, [_I]),
+    "dlwp_weight_grad_group": (_I, [_V, _I, _V]),
     "dlwp_window_gather": (_I, [_V, _V, _I, _I] + [_V] * 7 + [_V]),
     "dlwp_window_gather_fill": (_I, [_V, _V, _V, _I, _I] + [_V] * 7 + [_V]),
     "dlwp_window_pad_colsum": (_I, [_V, _V, _I, _I] + [_V] * 7 + [_I, _V]),

@@ -4,6 +4,8 @@ keep parameter names (`weight`, `bias`) and initialisation identical to the refe
 (nsbench/models/fourcastnet/fourcastnet.py:40-56,213; swintransformer/swin_transformer.py:25-40,131,153).
 There is no torch fallback: CPU tensors are refused by lib.ptr().
 """
+import ctypes as C
+
 import torch
 import torch.nn as nn
 
@@ -170,6 +172,33 @@ def _weight_grad(g2, x2, weight_slot, bias_slot, has_bias, wshape):
     return gw, (None if bias_slot is not None else gb)
 
 
+class _WgradDesc(C.Structure):
+    """dlwp_wgrad_desc (include/dlwpmi.h)"""
+    _fields_ = [("g", C.c_void_p), ("x", C.c_void_p), ("gw", C.c_void_p), ("gb", C.c_void_p), ("T", C.c_int), ("N", C.c_int),
+                ("K", C.c_int), ("g_bf16", C.c_int), ("x_bf16", C.c_int), ("accumulate", C.c_int)]
+
+
+def _weight_grad_group(items):
+    """[_weight_grad(*item) for item in items] with the products of the whole list in ONE launch (dlwp_weight_grad_group): the
+    weight gradients of a block's layers are independent, small, latency-bound split-K products."""
+    n = len(items)
+    descs = (_WgradDesc * n)()
+    outs, keep = [], []
+    for i, (g2, x2, wslot, bslot, has_bias, wshape) in enumerate(items):
+        T, N = g2.shape
+        K = x2.shape[1]
+        gb = None
+        if has_bias:
+            gb = bslot if bslot is not None else torch.zeros(N, device=g2.device)
+        gw = wslot if wslot is not None else torch.empty(N, K, device=g2.device)
+        keep.append((g2, x2, gw, gb))
+        descs[i] = _WgradDesc(L.ptr(g2), L.ptr(x2), L.ptr(gw), L.ptr(gb), T, N, K, int(g2.dtype == _BF), int(x2.dtype == _BF),
+                              int(wslot is not None))
+        outs.append((None if wslot is not None else gw.reshape(wshape), None if (bslot is not None or gb is None) else gb))
+    L.check(L.load().dlwp_weight_grad_group(C.cast(descs, C.c_void_p), n, L.stream()))
+    return outs
+
+
 class _MlpFn(torch.autograd.Function):
     """y = fc2(GELU(fc1 x)) (+ residual) as ONE autograd node (reference: Mlp.forward, nsbench/models/fourcastnet/
     fourcastnet.py:50-56, swintransformer/swin_transformer.py:42-48).  Forward: two GEMMs (bias + GELU, bias + residual
@@ -268,13 +297,15 @@ class _SkipMlpFn(torch.autograd.Function):
         g2 = _lowp(g32, Hd) if h.dtype == _BF else g32      # read by gh = g W2 and gW2 = g^T h
         gh = torch.empty(T, Hd, device=g2.device, dtype=h.dtype)
         _gemm_batched(g2, w2m, gh, T, Hd, N, N, Hd, Hd, 0, 0, act=4, residual=z1)      # (g W2) * GELU'(z1)
-        gw2, gb2 = _weight_grad(g2, h, ctx.slots[4], ctx.slots[5], ctx.has_b[2], ctx.wshapes[2])
         gt = torch.empty(T, C, device=g2.device)
         _gemm_batched(gh, w1m, gt, T, C, Hd, Hd, C, C, 0, 0, act=4, residual=z0)       # (gh W1) * GELU'(z0) = d/d(y + skip)
-        gw1, gb1 = _weight_grad(gh, t, ctx.slots[2], ctx.slots[3], ctx.has_b[1], ctx.wshapes[1])
         gx = torch.empty(T, C, device=g2.device)
         _gemm_batched(gt, wsm, gx, T, C, C, C, C, C, 0, 0, residual=g32 if ctx.outer else None)   # + outer skip
-        gws, gbs = _weight_grad(gt, x2, ctx.slots[0], ctx.slots[1], ctx.has_b[0], ctx.wshapes[0])
+        # the three weight gradients (+ bias gradients) do not depend on each other: one launch
+        (gw2, gb2), (gw1, gb1), (gws, gbs) = _weight_grad_group([
+            (g2, h, ctx.slots[4], ctx.slots[5], ctx.has_b[2], ctx.wshapes[2]),
+            (gh, t, ctx.slots[2], ctx.slots[3], ctx.has_b[1], ctx.wshapes[1]),
+            (gt, x2, ctx.slots[0], ctx.slots[1], ctx.has_b[0], ctx.wshapes[0])])
         return gt.reshape(ctx.shape), gx.reshape(ctx.shape), gws, gbs, gw1, gb1, gw2, gb2, None
 
 

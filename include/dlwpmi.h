@@ -438,6 +438,21 @@ int dlwp_get_gemm_precision(void);
 /* 256 x 256 x 64 tiles in two wave groups half a phase apart (bf16 arrays, y = x W^T): -1 never, 0 by shape (K >= 4096 and at    */
 /* least 512 tiles: one workgroup per CU leaves its prologue / epilogue uncovered), 1 wherever the kernel applies (measurement).   */
 int dlwp_set_gemm_tile256(int mode);
+/* Weight gradients of a token MLP's layers in ONE launch: gw_i [N][K] (+)= g_i^T x_i with g_i [T][N] (the gradient of  */
+/* the layer's output), x_i [T][K] (its input), gb_i [N] += column sums of g_i (NULL: none) -- what                        */
+/* dlwp_gemm_mixed(transA = 1, rowsum = gb) computes per layer (torch.nn.Linear backward in Mlp / SFNO block tails,      */
+/* fourcastnet.py:50-56).  Operands fp32 or bf16 arrays (g_bf16 / x_bf16).  Up to three products are grouped;             */
+/* otherwise (or when an operand is not 16-byte aligned) they run one launch each.                                      */
+typedef struct dlwp_wgrad_desc {
+    const void* g;
+    const void* x;
+    float* gw;
+    float* gb;
+    int T, N, K;
+    int g_bf16, x_bf16, accumulate;
+} dlwp_wgrad_desc;
+int dlwp_weight_grad_group(const dlwp_wgrad_desc* products, int n, void* stream);
+
 /* Strided-batched form: batch z = z1*nb2 + z2 (z1 < nb1, z2 < nb2) works on A + z1*sA1 +      */
 /* z2*sA2, B + z1*sB1 + z2*sB2, C (and residual) likewise; strides in floats, 0 = shared.     */
 /* res_before_act != 0 adds the residual before the activation: C = act(A.B + bias + res);    */

@@ -88,3 +88,6 @@ def test_round3_entries_reject_bad_arguments(h):
     assert "block size" in err(h)
     assert h.dlwp_afno_wq_fold_bp(FAKE, None, FAKE, FAKE, 4, 8, 8, None) < 0
     assert h.dlwp_afno_wq_fold_bp(FAKE, FAKE, FAKE, FAKE, 0, 8, 8, None) < 0
+    assert h.dlwp_weight_grad_group(None, 2, None) < 0
+    assert h.dlwp_weight_grad_group(FAKE, 0, None) < 0
+    assert h.dlwp_set_gemm_tile256(2) < 0

@@ -248,3 +248,41 @@ def test_colsum_accumulates_the_column_sums(cuda, T, N):
     L.check(L.load().dlwp_colsum(L.ptr(x), L.ptr(out), T, N, L.stream()))
     torch.cuda.synchronize()
     assert ((out.double() - want).abs().max() / want.abs().max()).item() <= 2e-6
+
+
+def test_weight_gradients_of_three_layers_in_one_launch(cuda):
+    """dlwp_weight_grad_group: gW_i (+)= g_i^T x_i and the bias gradients of three layers in one launch (fp32 and bf16 operands
+    mixed, accumulation into existing gradients and a fresh output) against float64."""
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.token_ops import _weight_grad_group
+    gen = torch.Generator().manual_seed(11)
+    T = 2048
+    shapes = [(256, 512), (512, 256), (256, 256)]           # (N out, K in)
+    items, want = [], []
+    with L.gemm_precision("bf16"):
+        for i, (N, K) in enumerate(shapes):
+            g = torch.randn(T, N, generator=gen).to(cuda)
+            x = torch.randn(T, K, generator=gen).to(cuda)
+            if i == 0:
+                g = g.to(torch.bfloat16)
+            if i != 2:
+                x = x.to(torch.bfloat16)
+            wslot = torch.randn(N, K, generator=gen).to(cuda) if i < 2 else None
+            bslot = torch.randn(N, generator=gen).to(cuda) if i == 0 else None
+            has_bias = i != 1
+            # the matrix units round fp32 operands to bf16: the reference product uses the rounded values
+            gr, xr = g.to(torch.bfloat16).double(), x.to(torch.bfloat16).double()
+            want.append(((wslot.double() if wslot is not None else 0) + gr.T @ xr,
+                         ((bslot.double() if bslot is not None else 0) + gr.sum(0)) if has_bias else None))       # (row sums of the rounded operand)
+            items.append((g, x, wslot, bslot, has_bias, (N, K)))
+        outs = _weight_grad_group(items)
+    torch.cuda.synchronize()
+    for (g, x, wslot, bslot, has_bias, _), (gw, gb), (ww, wb) in zip(items, outs, want):
+        got_w = wslot if wslot is not None else gw
+        assert (gw is None) == (wslot is not None)
+        assert ((got_w.double() - ww).abs().max() / ww.abs().max()).item() <= 2e-5
+        if has_bias:
+            got_b = bslot if bslot is not None else gb
+            assert ((got_b.double() - wb).abs().max() / wb.abs().max()).item() <= 2e-5
+        else:
+            assert gb is None
