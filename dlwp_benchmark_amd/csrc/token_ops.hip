@@ -2148,7 +2148,9 @@ extern "C" int dlwp_weight_grad_group(const dlwp_wgrad_desc* d, int n, void* str
     // worth it while the products are latency-bound (SFNO C3, 8192 tokens: 5.68 -> 5.49 ms per step); at 32768 tokens each product fills
     // the chip by itself and the bf16 x bf16 one has a faster kernel of its own (11.5 -> 11.9 ms grouped)
     bool grouped = !off && n >= 2 && n <= 3;
-    for (int i = 0; i < n; ++i) grouped = grouped && d[i].T <= 16384;
+    // ... and only small outputs: a FourCastNet-scale product (3072 x 768 over 16200 tokens) belongs on the LDS-DMA kernels (grouped on the
+    // 64 x 64 kernel the C5 step went from 17.3 to 26.9 ms)
+    for (int i = 0; i < n; ++i) grouped = grouped && d[i].T <= 16384 && (long long)d[i].N * d[i].K <= 512 * 512;
     GemmGroup gg{};
     unsigned gx = 0, gz = 0;
     for (int i = 0; grouped && i < n; ++i) {

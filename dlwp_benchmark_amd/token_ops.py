@@ -243,10 +243,11 @@ class _MlpFn(torch.autograd.Function):
             g2 = _lowp(g2, Hd)                   # read by gh = g W2 and gW2 = g^T h
         gh = torch.empty(T, Hd, device=g2.device, dtype=h.dtype)
         _gemm_batched(g2, w2m, gh, T, Hd, N, N, Hd, Hd, 0, 0, act=4, residual=z)     # (g W2) * GELU'(z)
-        gw2, gb2 = _weight_grad(g2, h, ctx.slots[2], ctx.slots[3], ctx.has_b[1], ctx.w2shape)
         gx = torch.empty(T, K, device=g2.device, dtype=ctx.in_dtype)   # a bf16 input (LayerNorm output) takes a bf16 gradient
         _gemm(gh, w1m, gx, T, K, Hd, Hd, K, K, 0, 0)
-        gw1, gb1 = _weight_grad(gh, x2, ctx.slots[0], ctx.slots[1], ctx.has_b[0], ctx.w1shape)
+        # both weight gradients in one launch while they are latency-bound (dlwp_weight_grad_group groups up to 16384 tokens)
+        (gw2, gb2), (gw1, gb1) = _weight_grad_group([(g2, h, ctx.slots[2], ctx.slots[3], ctx.has_b[1], ctx.w2shape),
+                                                     (gh, x2, ctx.slots[0], ctx.slots[1], ctx.has_b[0], ctx.w1shape)])
         return gx.reshape(ctx.shape), gw1, gb1, gw2, gb2, (gy if ctx.has_res else None)
 
 

@@ -112,19 +112,24 @@ def test_train_step_with_bf16_storage_tracks_fp32_storage(cuda):
     y = torch.randn(4, 300, 8, generator=g).to(cuda)
     losses = {}
     seen = {"fp32": set(), "bf16": set()}
-    orig = token_ops._gemm
+    orig, orig_group = token_ops._gemm, token_ops._weight_grad_group
     mode = "fp32"
 
     def spy(A, B, C, *a, **kw):
         seen[mode].add((A.dtype, B.dtype, C.dtype))
         return orig(A, B, C, *a, **kw)
+
+    def spy_group(items):          # the weight gradients of the MLP's two layers go out as one grouped launch
+        for g2, x2, *_ in items:
+            seen[mode].add((g2.dtype, x2.dtype, torch.float32))
+        return orig_group(items)
     with L.gemm_precision("bf16"):
         for mode in ("fp32", "bf16"):
             L.set_storage(mode)
             try:
                 torch.manual_seed(0)
                 m = _Toy().to(cuda)
-                token_ops._gemm = spy
+                token_ops._gemm, token_ops._weight_grad_group = spy, spy_group
                 step = GraphedTrainStep(m, {"x": x}, y, lr=1e-2)
                 losses[mode] = [step().item() for _ in range(6)]
                 if mode == "bf16":
@@ -133,7 +138,7 @@ def test_train_step_with_bf16_storage_tracks_fp32_storage(cuda):
                     # the copy is refreshed at the top of a step: it holds the weights the LAST step started from
                     assert ((w._dlwp_bf16.float() - w.detach()).abs().max() < 0.05).item()
             finally:
-                token_ops._gemm = orig
+                token_ops._gemm, token_ops._weight_grad_group = orig, orig_group
                 L.set_storage("fp32")
     f32 = torch.float32
     assert seen["fp32"] == {(f32, f32, f32)}
