@@ -578,6 +578,22 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup gg) {
     gemm_body<AKC, BKC, VEC, T, BF, S16M>(a, blockIdx.x, blockIdx.z, nt);
 }
 
+// ... and products of ANY layout (dlwp_gemm_group_begin / _end: a queue of independent small products launched together): the four
+// layout bodies of the generic 64 x 64 configuration in one kernel, picked per product
+struct GemmGroupAny { GemmDev g[3]; int layout[3]; };      // layout: 2 (A k-contiguous) | 1 (B k-contiguous)
+template <bool BF>
+__global__ __launch_bounds__(256) void gemm_group_any_kernel(GemmGroupAny gg) {
+    const GemmDev a = gg.g[blockIdx.y];
+    const int nt = a.ntn * a.ntm;
+    if ((int)blockIdx.x >= nt || (long long)blockIdx.z >= a.nbatch * a.splits) return;
+    switch (gg.layout[blockIdx.y]) {
+        case 3: gemm_body<true, true, 3, 1, BF, 0>(a, blockIdx.x, blockIdx.z, nt); break;
+        case 2: gemm_body<true, false, 3, 1, BF, 0>(a, blockIdx.x, blockIdx.z, nt); break;
+        case 1: gemm_body<false, true, 3, 1, BF, 0>(a, blockIdx.x, blockIdx.z, nt); break;
+        default: gemm_body<false, false, 3, 1, BF, 0>(a, blockIdx.x, blockIdx.z, nt); break;
+    }
+}
+
 template <bool AKC, bool BKC, int VEC, int T, bool BF, int S16M = 0>
 int gemm_launch_t(const GemmDev& a, dim3 grid, hipStream_t s) {
     constexpr int RW = Tile<T>::ROWS;
@@ -1500,8 +1516,60 @@ static bool gemm_p8_applies(const GemmDev& a, bool akc, bool bkc) {
     return env_on || g_gemm_tile256 > 0 || (a.K >= mink && tiles >= 128);
 }
 
+// ---- a queue of independent small products (dlwp_gemm_group_begin ... dlwp_gemm_group_end): while it is open, every product
+// that fits the generic 64 x 64 configuration and is small (latency-bound by itself) is parked instead of launched; _end launches
+// up to three parked products as ONE grid (gemm_group_any_kernel).  Everything else launches at once, as usual -- the products
+// inside a begin / end pair must not depend on each other.
+struct GemmQueue { bool open = false; int n = 0; GemmGroupAny gg; };
+static GemmQueue g_queue;
+static int gemm_queue_flush(hipStream_t s) {
+    GemmQueue& q = g_queue;
+    if (q.n == 0) return DLWP_OK;
+    unsigned gx = 0, gz = 0;
+    for (int i = 0; i < q.n; ++i) {
+        gx = std::max(gx, (unsigned)(q.gg.g[i].ntn * q.gg.g[i].ntm));
+        gz = std::max(gz, (unsigned)(q.gg.g[i].nbatch * q.gg.g[i].splits));
+    }
+    const dim3 grid(gx, q.n, gz);
+    int rc;
+    if (g_gemm_bf16) {
+        constexpr int KS = gemm_bf_kstep(0, 1, false, false);
+        const size_t lds = sizeof(float) * 4 * ((64 * (KS + 8) > KS * (64 + 8) ? 64 * (KS + 8) : KS * (64 + 8)) / 2);
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_group_any_kernel<true>), lds, "gemm_group_any"))) return rc;
+        hipLaunchKernelGGL(gemm_group_any_kernel<true>, grid, dim3(256), lds, s, q.gg);
+    } else {
+        const size_t lds = sizeof(float) * 4 * Tile<1>::FLOATS;
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_group_any_kernel<false>), lds, "gemm_group_any"))) return rc;
+        hipLaunchKernelGGL(gemm_group_any_kernel<false>, grid, dim3(256), lds, s, q.gg);
+    }
+    q.n = 0;
+    return DLWP_OK;
+}
+// park a product if the queue is open and it qualifies; a full queue is flushed first
+static bool gemm_queue_take(const GemmDev& a_in, bool akc, bool bkc, int vec, int T, hipStream_t s, int* rc) {
+    *rc = DLWP_OK;
+    GemmQueue& q = g_queue;
+    if (!q.open || vec != 3 || T != 1 || a_in.act_b) return false;
+    // small, latency-bound products only: at most 2.2 GFLOP (the SFNO block-tail products are 2.1; Pangu's 8192 x 384 x 1152 input
+    // gradient at 7.2 GFLOP belongs on its own kernel: parked, the C4 step went from 14.3 to 15.1 ms)
+    const double flop = 2.0 * a_in.M * a_in.N * (double)a_in.K * a_in.nbatch;
+    if (flop > 2.2e9 || a_in.K > 16384) return false;
+    if (q.n == 3 && (*rc = gemm_queue_flush(s))) return true;
+    GemmDev a = a_in;
+    a.ntn = ceil_div(a.N, 64);
+    a.ntm = ceil_div(a.M, 64);
+    q.gg.g[q.n] = a;
+    q.gg.layout[q.n] = (akc ? 2 : 0) | (bkc ? 1 : 0);
+    ++q.n;
+    return true;
+}
+
 template <bool AKC, bool BKC>
 int gemm_launch(const GemmDev& a_in, int vec, int T, hipStream_t s) {
+    {
+        int qrc;
+        if (gemm_queue_take(a_in, AKC, BKC, vec, T, s, &qrc)) return qrc;
+    }
     if (gemm_glds_applies(a_in, AKC, BKC) && gemm_p8_applies(a_in, AKC, BKC)) return gemm_p8_launch(a_in, BKC, s);
     if (gemm_glds_applies(a_in, AKC, BKC)) return gemm_glds_launch(a_in, BKC, s);
     if (!AKC && !BKC && gemm_glds_tn_applies(a_in)) {
@@ -2095,6 +2163,20 @@ extern "C" int dlwp_set_gemm_precision(int mode) {
 }
 
 extern "C" int dlwp_get_gemm_precision(void) { return g_gemm_bf16; }
+extern "C" int dlwp_gemm_group_begin(void) {
+    DLWP_REQUIRE(!g_queue.open, DLWP_E_INVALID, "gemm_group_begin: a group is already open");
+    static const bool off = getenv("DLWP_GEMM_NOGROUP") != nullptr;
+    g_queue.open = !off;
+    g_queue.n = 0;
+    return DLWP_OK;
+}
+extern "C" int dlwp_gemm_group_end(void* stream) {
+    g_queue.open = false;
+    const int rc = gemm_queue_flush((hipStream_t)stream);
+    if (rc) return rc;
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
 extern "C" int dlwp_set_gemm_tile256(int mode) {
     DLWP_REQUIRE(mode >= -1 && mode <= 1, DLWP_E_INVALID, "set_gemm_tile256: mode must be -1 (never), 0 (by shape) or 1 (wherever it applies)");
     g_gemm_tile256 = mode;

@@ -68,6 +68,8 @@ SIGNATURES = {
     "dlwp_get_gemm_precision": (_I, []),
     "dlwp_set_gemm_tile256": (_I, [_I]),
     "dlwp_weight_grad_group": (_I, [_V, _I, _V]),
+    "dlwp_gemm_group_begin": (_I, []),
+    "dlwp_gemm_group_end": (_I, [_V]),
     "dlwp_window_gather": (_I, [_V, _V, _I, _I] + [_V] * 7 + [_V]),
     "dlwp_window_gather_fill": (_I, [_V, _V, _V, _I, _I] + [_V] * 7 + [_V]),
     "dlwp_window_pad_colsum": (_I, [_V, _V, _I, _I] + [_V] * 7 + [_I, _V]),
@@ -195,6 +197,19 @@ class gemm_precision:
 
     def __exit__(self, *exc):
         check(load().dlwp_set_gemm_precision(self.prev))
+        return False
+
+
+class gemm_group:
+    """with lib.gemm_group(): ...  -- the small, mutually INDEPENDENT GEMMs issued inside go out as one launch
+    (dlwp_gemm_group_begin / _end); large ones launch as usual."""
+
+    def __enter__(self):
+        check(load().dlwp_gemm_group_begin())
+        return self
+
+    def __exit__(self, *exc):
+        check(load().dlwp_gemm_group_end(stream()))
         return False
 
 

@@ -137,17 +137,21 @@ class _LinearFn(torch.autograd.Function):
         if w.dtype == _BF:
             g2 = _lowp(g2, K)                    # read by both products below
         gx = torch.empty(T, K, device=g2.device, dtype=ctx.in_dtype)   # a bf16 input (LayerNorm output) takes a bf16 gradient
-        _gemm(g2, w, gx, T, K, N, N, K, K, 0, 0)                 # gx = g W
-        # gW = g^T x, with the bias gradient (column sums of g) produced by the same kernel; both go straight
-        # into the parameters' gradient buffers when those exist (fused gradient accumulation)
         gw, gb = None, None
         if ctx.has_bias:
             gb = ctx.bslot if ctx.bslot is not None else torch.zeros(N, device=g2.device)
-        if ctx.wslot is not None:
-            _gemm(g2, x2, ctx.wslot, N, K, T, N, K, K, 1, 0, accumulate=1, rowsum=gb)
-        else:
+        if ctx.wslot is None:
             gw = torch.empty(N, K, device=g2.device)
-            _gemm(g2, x2, gw, N, K, T, N, K, K, 1, 0, rowsum=gb)
+        # the two products read the same g and do not depend on each other: one launch while they are small (lib.gemm_group)
+        with L.gemm_group():
+            _gemm(g2, w, gx, T, K, N, N, K, K, 0, 0)                 # gx = g W
+            # gW = g^T x, with the bias gradient (column sums of g) produced by the same kernel; both go straight
+            # into the parameters' gradient buffers when those exist (fused gradient accumulation)
+            if ctx.wslot is not None:
+                _gemm(g2, x2, ctx.wslot, N, K, T, N, K, K, 1, 0, accumulate=1, rowsum=gb)
+            else:
+                _gemm(g2, x2, gw, N, K, T, N, K, K, 1, 0, rowsum=gb)
+        if gw is not None:
             gw = gw.reshape(ctx.wshape)
         if ctx.bslot is not None:
             gb = None

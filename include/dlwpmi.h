@@ -452,6 +452,12 @@ typedef struct dlwp_wgrad_desc {
     int g_bf16, x_bf16, accumulate;
 } dlwp_wgrad_desc;
 int dlwp_weight_grad_group(const dlwp_wgrad_desc* products, int n, void* stream);
+/* Any INDEPENDENT small products: between _begin and _end, the dlwp_gemm* entries park products that fit the generic 64 x 64 kernel   */
+/* and are small (<= 16384 deep, latency-bound by themselves); _end launches up to three of them as one grid.  Everything else      */
+/* launches at once.  Used around the two gradient products of a Linear layer's backward pass (gx = g W and gW = g^T x read the     */
+/* same g and do not depend on each other).  One group per thread of control; not reentrant.                                        */
+int dlwp_gemm_group_begin(void);
+int dlwp_gemm_group_end(void* stream);
 
 /* Strided-batched form: batch z = z1*nb2 + z2 (z1 < nb1, z2 < nb2) works on A + z1*sA1 +      */
 /* z2*sA2, B + z1*sB1 + z2*sB2, C (and residual) likewise; strides in floats, 0 = shared.     */
