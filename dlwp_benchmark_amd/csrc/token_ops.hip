@@ -569,12 +569,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev a) {
 
 // up to three independent products in ONE launch (blockIdx.y picks the product): the weight gradients of a token MLP are three
 // small, latency-bound split-K products (SFNO C3: 512 workgroups of ~20 us each on a 1024-slot chip) that do not depend on each other
-struct GemmGroup { GemmDev g[3]; };
+struct GemmGroup { GemmDev g[3]; int s16m[3]; };      // s16m: bit 0 / 1 = operand A / B is an aligned bf16 array (16-byte loads, no widening)
 template <bool AKC, bool BKC, int VEC, int T, bool BF, int S16M = 0>
 __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup gg) {
     const GemmDev a = gg.g[blockIdx.y];
     const int nt = a.ntn * a.ntm;
     if ((int)blockIdx.x >= nt || (long long)blockIdx.z >= a.nbatch * a.splits) return;
+    if constexpr (BF) {
+        switch (gg.s16m[blockIdx.y]) {
+            case 3: gemm_body<AKC, BKC, VEC, T, true, 3>(a, blockIdx.x, blockIdx.z, nt); return;
+            case 2: gemm_body<AKC, BKC, VEC, T, true, 2>(a, blockIdx.x, blockIdx.z, nt); return;
+            case 1: gemm_body<AKC, BKC, VEC, T, true, 1>(a, blockIdx.x, blockIdx.z, nt); return;
+            default: break;
+        }
+    }
     gemm_body<AKC, BKC, VEC, T, BF, S16M>(a, blockIdx.x, blockIdx.z, nt);
 }
 
@@ -2232,7 +2240,9 @@ extern "C" int dlwp_weight_grad_group(const dlwp_wgrad_desc* d, int n, void* str
     bool grouped = !off && n >= 2 && n <= 3;
     // ... and only small outputs: a FourCastNet-scale product (3072 x 768 over 16200 tokens) belongs on the LDS-DMA kernels (grouped on the
     // 64 x 64 kernel the C5 step went from 17.3 to 26.9 ms)
-    for (int i = 0; i < n; ++i) grouped = grouped && d[i].T <= 16384 && (long long)d[i].N * d[i].K <= 512 * 512;
+    static const char* maxt_env = getenv("DLWP_WGRAD_GROUP_MAXT");
+    const int maxt = maxt_env ? atoi(maxt_env) : 65536;
+    for (int i = 0; i < n; ++i) grouped = grouped && d[i].T <= maxt && (long long)d[i].N * d[i].K <= 512 * 512;
     GemmGroup gg{};
     unsigned gx = 0, gz = 0;
     for (int i = 0; grouped && i < n; ++i) {
@@ -2254,6 +2264,9 @@ extern "C" int dlwp_weight_grad_group(const dlwp_wgrad_desc* d, int n, void* str
         if (!vecA || !vecB || splits * 1LL > 65535) { grouped = false; break; }
         a.vec_epi = splits == 1 && a.N % 4 == 0 && a.ldc % 4 == 0 && (uintptr_t)a.C % 16 == 0;
         gg.g[i] = a;
+        // bf16 arrays that allow the 16-byte path (as gemm_launch decides it for a single product); K-step 32 for every member
+        auto ok16 = [&](const float* p, int ld, int rows) { return (uintptr_t)p % 16 == 0 && ld % 8 == 0 && rows % 8 == 0; };
+        gg.s16m[i] = (((dt & DT_A) && ok16(a.A, a.lda, a.M)) ? 1 : 0) | (((dt & DT_B) && ok16(a.B, a.ldb, a.N)) ? 2 : 0);
         gx = std::max(gx, (unsigned)(a.ntn * a.ntm));
         gz = std::max(gz, (unsigned)splits);
     }
