@@ -588,13 +588,25 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup gg) {
 
 // ... and products of ANY layout (dlwp_gemm_group_begin / _end: a queue of independent small products launched together): the four
 // layout bodies of the generic 64 x 64 configuration in one kernel, picked per product
-struct GemmGroupAny { GemmDev g[3]; int layout[3]; };      // layout: 2 (A k-contiguous) | 1 (B k-contiguous)
+struct GemmGroupAny { GemmDev g[3]; int layout[3]; int s16m[3]; };      // layout: 2 (A k-contiguous) | 1 (B k-contiguous); s16m == 3: both operands
+                                                                         // aligned bf16 arrays (16-byte loads, no widening)
 template <bool BF>
 __global__ __launch_bounds__(256) void gemm_group_any_kernel(GemmGroupAny gg) {
     const GemmDev a = gg.g[blockIdx.y];
     const int nt = a.ntn * a.ntm;
     if ((int)blockIdx.x >= nt || (long long)blockIdx.z >= a.nbatch * a.splits) return;
-    switch (gg.layout[blockIdx.y]) {
+    const int layout = gg.layout[blockIdx.y];
+    if constexpr (BF) {
+        if (gg.s16m[blockIdx.y] == 3) {
+            switch (layout) {
+                case 3: gemm_body<true, true, 3, 1, true, 3>(a, blockIdx.x, blockIdx.z, nt); return;
+                case 2: gemm_body<true, false, 3, 1, true, 3>(a, blockIdx.x, blockIdx.z, nt); return;
+                case 0: gemm_body<false, false, 3, 1, true, 3>(a, blockIdx.x, blockIdx.z, nt); return;
+                default: break;
+            }
+        }
+    }
+    switch (layout) {
         case 3: gemm_body<true, true, 3, 1, BF, 0>(a, blockIdx.x, blockIdx.z, nt); break;
         case 2: gemm_body<true, false, 3, 1, BF, 0>(a, blockIdx.x, blockIdx.z, nt); break;
         case 1: gemm_body<false, true, 3, 1, BF, 0>(a, blockIdx.x, blockIdx.z, nt); break;
@@ -1568,6 +1580,15 @@ static bool gemm_queue_take(const GemmDev& a_in, bool akc, bool bkc, int vec, in
     a.ntm = ceil_div(a.M, 64);
     q.gg.g[q.n] = a;
     q.gg.layout[q.n] = (akc ? 2 : 0) | (bkc ? 1 : 0);
+    {   // both operands bf16 arrays on the 16-byte path (the conditions gemm_launch uses for a single product)
+        auto ok16 = [&](const float* p, int ld, bool kc, int rows, long long s1, long long s2) {
+            return (uintptr_t)p % 16 == 0 && ld % 8 == 0 && (kc ? a.K % 8 == 0 && a.kchunk % 8 == 0 : rows % 8 == 0) &&
+                   (a.nbatch == 1 || (s1 % 8 == 0 && s2 % 8 == 0));
+        };
+        q.gg.s16m[q.n] = g_gemm_bf16 ? ((((a.dt & DT_A) && ok16(a.A, a.lda, akc, a.M, a.sA1, a.sA2)) ? 1 : 0) |
+                                        (((a.dt & DT_B) && ok16(a.B, a.ldb, bkc, a.N, a.sB1, a.sB2)) ? 2 : 0))
+                                     : 0;
+    }
     ++q.n;
     return true;
 }
