@@ -2271,8 +2271,13 @@ extern "C" int dlwp_weight_grad_group(const dlwp_wgrad_desc* d, int n, void* str
         const int M = q.N, N = q.K, K = q.T;                  // gW [N][K] = g^T [N][T] . x [T][K]
         const int dt = (q.g_bf16 ? DT_A : 0) | (q.x_bf16 ? DT_B : 0);
         const int tiles = ceil_div(N, 64) * ceil_div(M, 64);
+        // slices: the products of the group share the chip, so the whole group gets the workgroups of one resident round
+        // (896 by default, DLWP_WGRAD_GROUP_WGS): with 512 per product as a lone launch would choose, three products ran a
+        // second partial round and twice the atomics (SFNO C3 step 5.33 -> 5.21 ms; neutral on Pangu / Swin / AFNO)
+        static const char* wgs_env = getenv("DLWP_WGRAD_GROUP_WGS");
+        const int per_product = std::max(1, (wgs_env ? atoi(wgs_env) : 896) / n);
         int splits = 1;
-        if (tiles < 256 && K >= 8 * BK) splits = std::min(ceil_div(512, tiles), K / (4 * BK));
+        if (tiles < 256 && K >= 8 * BK) splits = std::min(ceil_div(per_product, tiles), K / (4 * BK));
         const int kchunk = ceil_div(ceil_div(K, splits), BK) * BK;
         splits = ceil_div(K, kchunk);
         GemmDev a{(const float*)q.g, (const float*)q.x, nullptr, nullptr, q.gw, nullptr, q.gb, M, N, K, M, N, N, 0, q.accumulate, kchunk, splits,
