@@ -116,6 +116,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         modes = min(int(self.h * hard_thresholding_fraction), int(self.w // 2 * hard_thresholding_fraction))
         self.encoder = nn.ModuleList([Conv1x1(in_chans, embed_dim), nn.GELU(), Conv1x1(embed_dim, embed_dim, bias=False)])
         self.pos_embed = nn.Parameter(torch.zeros(1, embed_dim, H, W)) if pos_embed else None
+        self._wpad_cache = None
         down = RealSHT(H, W, modes, modes, grid)
         up = InverseRealSHT(H, W, modes, modes, grid)
         trans = RealSHT(self.h, self.w, modes, modes, "legendre-gauss")
@@ -138,9 +139,11 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         tok_in = F.pad(x.permute(0, 2, 3, 1), (0, pad)) if pad else x.permute(0, 2, 3, 1).contiguous()
         w_enc, w_dec = self.encoder[0].weight, self.decoder[0].weight
         if pad:
-            w_enc = F.pad(w_enc.reshape(E, Cin), (0, pad))
-            if self.big_skip:
-                w_dec = F.pad(w_dec.reshape(w_dec.shape[0], E + Cin), (0, pad))
+            cache = self._wpad_cache if self._wpad_cache is not None else {}
+            if "enc" not in cache:       # inside a rollout (SFNO2DModule.forward) the padded weights are built once per pass
+                cache["enc"] = F.pad(w_enc.reshape(E, Cin), (0, pad))
+                cache["dec"] = F.pad(w_dec.reshape(w_dec.shape[0], E + Cin), (0, pad)) if self.big_skip else w_dec
+            w_enc, w_dec = cache["enc"], cache["dec"]
         pos = None
         if self.pos_embed is not None:
             pos = self.pos_embed.permute(0, 2, 3, 1).expand(B, H, W, -1)
@@ -174,4 +177,8 @@ class SFNO2DModule(nn.Module):
     def forward(self, constants: torch.Tensor = None, prescribed: torch.Tensor = None,
                 prognostic: torch.Tensor = None) -> torch.Tensor:
         with spectral_weight_scope():      # every lead time applies the same weights: one expanded image per layer
-            return rollout(self.sfno, self.context_size, constants, prescribed, prognostic)
+            self.sfno._wpad_cache = {}     # ... and one zero-padded copy of the first encoder / decoder weights
+            try:
+                return rollout(self.sfno, self.context_size, constants, prescribed, prognostic)
+            finally:
+                self.sfno._wpad_cache = None
