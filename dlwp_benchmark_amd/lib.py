@@ -90,6 +90,10 @@ SIGNATURES = {
     "dlwp_sht_synthesis": (_I, [_V, _V, _V, _V] + [_I] * 6 + [_V]),
     "dlwp_cweight_expand": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_cweight_fold": (_I, [_V, _V, _I, _I, _I, _V]),
+    "dlwp_mlp_chain_supported": (_I, [_I, _I]),
+    "dlwp_mlp_chain_pack": (_I, [_V, _I, _I, _I, _V, _V]),
+    "dlwp_sfno_tail_fwd": (_I, [_V, _V]),
+    "dlwp_sfno_tail_bwd": (_I, [_V, _V]),
     "dlwp_layernorm_fwd": (_I, [_V] * 6 + [_I, _I, _F, _V]),
     "dlwp_layernorm_fwd_ex": (_I, [_V] * 6 + [_I, _I, _F, _I, _V]),
     "dlwp_layernorm_bwd": (_I, [_V] * 8 + [_I, _I, _V]),

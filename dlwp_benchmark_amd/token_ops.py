@@ -321,7 +321,104 @@ class _SkipMlpFn(torch.autograd.Function):
         return gt.reshape(ctx.shape), gx.reshape(ctx.shape), gws, gbs, gw1, gb1, gw2, gb2, None
 
 
+class _TailFwdArgs(C.Structure):
+    """dlwp_sfno_tail_fwd_args (include/dlwpmi.h)"""
+    _fields_ = [(n, C.c_void_p) for n in ("x", "y", "ws_img", "w1_img", "w2_img", "bs", "b1", "b2", "x_lp", "z0", "t", "z1", "h",
+                                          "out")] + [(n, C.c_int) for n in ("T", "C", "hidden", "outer")]
+
+
+class _TailBwdArgs(C.Structure):
+    """dlwp_sfno_tail_bwd_args (include/dlwpmi.h)"""
+    _fields_ = [(n, C.c_void_p) for n in ("g", "w2t_img", "w1t_img", "wst_img", "z1", "z0", "g_lp", "gh", "gt", "gt_lp", "gx")] + \
+               [(n, C.c_int) for n in ("T", "C", "hidden", "outer")]
+
+
+def _chain_images(ws, w1, w2):
+    """The six fragment-order bf16 images of an SFNO block tail's weights (dlwp_mlp_chain_pack: forward Ws, W1, W2; backward
+    W2^T, W1^T, Ws^T), built from the fp32 master weights.  Inside a sht.spectral_weight_scope (one rollout pass: the parameters
+    cannot change) they are built once and shared by every lead time."""
+    from . import sht
+    scope = sht._wexp_scope
+    key = ("chain", id(ws), id(w1), id(w2))
+    if scope is not None and key in scope:
+        return scope[key][0]
+    lib = L.load()
+    C_, Hd = ws.shape[0], w1.shape[0]
+    imgs = torch.empty(6, C_ * Hd, device=ws.device, dtype=_BF)       # (the two C x C images use the front of their rows)
+    plan = ((ws, C_, C_, 0), (w1, Hd, C_, 0), (w2, C_, Hd, 0), (w2, Hd, C_, 1), (w1, C_, Hd, 1), (ws, C_, C_, 1))
+    for i, (w, rows, cols, tr) in enumerate(plan):
+        L.check(lib.dlwp_mlp_chain_pack(L.ptr(w.detach().contiguous()), rows, cols, tr, L.ptr(imgs[i]), L.stream()))
+    if scope is not None:
+        scope[key] = (imgs, (ws, w1, w2))      # keeps the parameters alive: the ids stay unique inside the scope
+    return imgs
+
+
+CHAIN_TAIL = __import__("os").environ.get("DLWP_SFNO_CHAIN", "1") != "0"      # env: A/B runs against the three-GEMM tail
+
+
+class _SkipMlpChainFn(torch.autograd.Function):
+    """_SkipMlpFn with each direction as ONE launch (dlwp_sfno_tail_fwd / _bwd, csrc/mlp_chain.hip): bf16 operands and bf16
+    storage only (the arithmetic and the stored tensors are those of _SkipMlpFn under lib.set_storage("bf16")), widths with a
+    compiled kernel (dlwp_mlp_chain_supported)."""
+
+    @staticmethod
+    def applies(x, ws, w1, w2):
+        C_ = x.shape[-1]
+        return (CHAIN_TAIL and _act_dtype() == _BF and x.is_cuda and tuple(ws.shape[:2]) == (C_, C_) and w2.shape[0] == C_
+                and w1.shape[1] == C_ and w2.shape[1] == w1.shape[0]
+                and L.load().dlwp_mlp_chain_supported(C_, w1.shape[0]) == 1)
+
+    @staticmethod
+    def forward(ctx, y, x, ws, bs, w1, b1, w2, b2, outer):
+        shape = x.shape
+        C_ = shape[-1]
+        x2 = x.reshape(-1, C_).contiguous().float()
+        y2 = y.reshape(-1, C_).contiguous().float()
+        T, Hd = x2.shape[0], w1.shape[0]
+        imgs = _chain_images(ws, w1, w2)
+        dev = x.device
+        x_lp = torch.empty(T, C_, device=dev, dtype=_BF)
+        z0 = torch.empty(T, C_, device=dev, dtype=_BF)
+        t = torch.empty(T, C_, device=dev, dtype=_BF)
+        z1 = torch.empty(T, Hd, device=dev, dtype=_BF)
+        h = torch.empty(T, Hd, device=dev, dtype=_BF)
+        out = torch.empty(T, C_, device=dev)
+        a = _TailFwdArgs(L.ptr(x2), L.ptr(y2), L.ptr(imgs[0]), L.ptr(imgs[1]), L.ptr(imgs[2]), L.ptr(bs), L.ptr(b1), L.ptr(b2),
+                         L.ptr(x_lp), L.ptr(z0), L.ptr(t), L.ptr(z1), L.ptr(h), L.ptr(out), T, C_, Hd, int(bool(outer)))
+        L.check(L.load().dlwp_sfno_tail_fwd(C.byref(a), L.stream()))
+        ctx.save_for_backward(x_lp, z0, t, z1, h, imgs)
+        ctx.shape, ctx.outer = shape, bool(outer)
+        ctx.wshapes = (ws.shape, w1.shape, w2.shape)
+        ctx.slots = tuple(_grad_slot(p) if p is not None else None for p in (ws, bs, w1, b1, w2, b2))
+        ctx.has_b = (bs is not None, b1 is not None, b2 is not None)
+        return out.reshape(*shape[:-1], C_)
+
+    @staticmethod
+    def backward(ctx, gout):
+        x_lp, z0, t, z1, h, imgs = ctx.saved_tensors
+        T, C_ = x_lp.shape
+        Hd = h.shape[1]
+        dev = x_lp.device
+        g32 = gout.reshape(-1, C_).contiguous().float()
+        g_lp = torch.empty(T, C_, device=dev, dtype=_BF)
+        gh = torch.empty(T, Hd, device=dev, dtype=_BF)
+        gt = torch.empty(T, C_, device=dev)
+        gt_lp = torch.empty(T, C_, device=dev, dtype=_BF)
+        gx = torch.empty(T, C_, device=dev)
+        a = _TailBwdArgs(L.ptr(g32), L.ptr(imgs[3]), L.ptr(imgs[4]), L.ptr(imgs[5]), L.ptr(z1), L.ptr(z0), L.ptr(g_lp), L.ptr(gh),
+                         L.ptr(gt), L.ptr(gt_lp), L.ptr(gx), T, C_, Hd, int(ctx.outer))
+        L.check(L.load().dlwp_sfno_tail_bwd(C.byref(a), L.stream()))
+        # the three weight gradients (+ bias gradients): independent products of bf16 arrays, one launch
+        (gw2, gb2), (gw1, gb1), (gws, gbs) = _weight_grad_group([
+            (g_lp, h, ctx.slots[4], ctx.slots[5], ctx.has_b[2], ctx.wshapes[2]),
+            (gh, t, ctx.slots[2], ctx.slots[3], ctx.has_b[1], ctx.wshapes[1]),
+            (gt_lp, x_lp, ctx.slots[0], ctx.slots[1], ctx.has_b[0], ctx.wshapes[0])])
+        return gt.reshape(ctx.shape), gx.reshape(ctx.shape), gws, gbs, gw1, gb1, gw2, gb2, None
+
+
 def skip_mlp(y, x, ws, bs, w1, b1, w2, b2, outer=True):
+    if y.shape == x.shape and _SkipMlpChainFn.applies(x, ws, w1, w2):
+        return _SkipMlpChainFn.apply(y, x, ws, bs, w1, b1, w2, b2, outer)
     return _SkipMlpFn.apply(y, x, ws, bs, w1, b1, w2, b2, outer)
 
 

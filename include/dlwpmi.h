@@ -522,6 +522,48 @@ int dlwp_sht_synthesis(const float* X, const float* S1t, const float* S2t, float
 /* [Xr | Xi]; fold: gw += the complex gradient read back from the [L][2Cin][2Cout] GEMM result. */
 int dlwp_cweight_expand(const float* w, float* wexp, int Cin, int Cout, int L, void* stream);
 int dlwp_cweight_fold(const float* gexp, float* gw, int Cin, int Cout, int L, void* stream);
+/* The tail of an SFNO block as ONE launch per direction (csrc/mlp_chain.hip; the block is      */
+/* torch_harmonics' SphericalFourierNeuralOperatorBlock, constructed at                         */
+/* src/dlwpbench/models/fno/fno.py:183-200 and models/fourcastnet/fourcastnet.py:411-428,        */
+/* SURVEY.md App. A-2): with y = the spectral filter's output and x = the block input,           */
+/*     z0 = y + x Ws^T + bs,  t = GELU(z0),  z1 = t W1^T + b1,  h = GELU(z1),                     */
+/*     out = h W2^T + b2 (+ x when outer)                                                       */
+/* and, given g = d loss / d out,                                                               */
+/*     gh = (g W2) * GELU'(z1),  gt = (gh W1) * GELU'(z0) (= d / d y),  gx = gt Ws (+ g).        */
+/* Tokens are rows: x, y, out, g, gt, gx [T][C] fp32; z0, t [T][C] and z1, h, gh [T][hidden]    */
+/* bf16 arrays; x_lp / g_lp (nullable) and gt_lp receive bf16 copies of x / g / gt for the       */
+/* weight-gradient products.  Arithmetic: bf16 operands, fp32 accumulation and epilogues.        */
+/* The six weight matrices are read from fragment-order bf16 images built by                    */
+/* dlwp_mlp_chain_pack: image of W' [rows][cols] with W' = W (transpose 0, W row-major           */
+/* [rows][cols]) or W^T (transpose 1, W row-major [cols][rows]); rows % 16 == 0, cols % 32 == 0, */
+/* rows * cols bf16 elements.  Forward images: Ws [C][C], W1 [hidden][C], W2 [C][hidden] as they  */
+/* are; backward images: the transposes W2^T [hidden][C], W1^T [C][hidden], Ws^T [C][C].          */
+/* dlwp_mlp_chain_supported: (C, hidden) pairs with a compiled kernel (256/512, 128/256,         */
+/* 64/128); other widths use three dlwp_gemm_mixed calls per direction.                          */
+typedef struct dlwp_sfno_tail_fwd_args {
+    const float *x, *y;                     /* [T][C] */
+    const void *ws_img, *w1_img, *w2_img;   /* dlwp_mlp_chain_pack images */
+    const float *bs, *b1, *b2;              /* [C], [hidden], [C]; nullable */
+    void *x_lp;                             /* [T][C] bf16, nullable */
+    void *z0, *t, *z1, *h;                  /* bf16 outputs */
+    float *out;                             /* [T][C] */
+    int T, C, hidden, outer;
+} dlwp_sfno_tail_fwd_args;
+typedef struct dlwp_sfno_tail_bwd_args {
+    const float *g;                         /* [T][C] */
+    const void *w2t_img, *w1t_img, *wst_img;
+    const void *z1, *z0;                    /* bf16 pre-activations saved by the forward call */
+    void *g_lp;                             /* [T][C] bf16, nullable */
+    void *gh;                               /* [T][hidden] bf16 */
+    float *gt;                              /* [T][C] */
+    void *gt_lp;                            /* [T][C] bf16 */
+    float *gx;                              /* [T][C] */
+    int T, C, hidden, outer;
+} dlwp_sfno_tail_bwd_args;
+int dlwp_mlp_chain_supported(int C, int hidden);
+int dlwp_mlp_chain_pack(const float* W, int rows, int cols, int transpose, void* image, void* stream);
+int dlwp_sfno_tail_fwd(const dlwp_sfno_tail_fwd_args* args, void* stream);
+int dlwp_sfno_tail_bwd(const dlwp_sfno_tail_bwd_args* args, void* stream);
 /* LayerNorm over the last dimension of x [T,C]; mean/rstd [T] are saved for backward.       */
 int dlwp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                        float* mean, float* rstd, int T, int C, float eps, void* stream);
