@@ -21,6 +21,8 @@
 //     by the token row so that the ds_read_b128 fragment reads are conflict-free); the copies that the weight-gradient
 //     products need (x, t, h / g, gh, gt as bf16 arrays) and the pre-activations leave from registers.
 // Arithmetic = the bf16-operand token GEMM's: operands rounded to bf16, fp32 accumulation, fp32 epilogue, one rounding per store.
+#include <algorithm>
+#include <cstdlib>
 #include "common.cuh"
 #include "dlwpmi_internal.h"
 
@@ -46,6 +48,26 @@ __global__ __launch_bounds__(256) void chain_pack_kernel(const float* __restrict
     *reinterpret_cast<bf16x8*>(img + idx * 8) = v;
 }
 
+// the six images of a block tail in one launch: blockIdx.y = image (forward Ws, W1, W2; backward W2^T, W1^T, Ws^T)
+struct PackSix { const float* W[6]; int ld[6], rows[6], cols[6], tr[6]; __bf16* img[6]; };
+__global__ __launch_bounds__(256) void chain_pack6_kernel(PackSix a) {
+    const int i = blockIdx.y;
+    const int KS = a.cols[i] / 32;
+    const long long total = (long long)(a.rows[i] / 16) * KS * 64;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const long long f = idx >> 6;
+    const int kk = (int)(f % KS), tile = (int)(f / KS);
+    const int row = 16 * tile + (lane & 15), k0 = 32 * kk + 8 * (lane >> 4);
+    const float* W = a.W[i];
+    const int ld = a.ld[i];
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (__bf16)(a.tr[i] ? W[(long long)(k0 + e) * ld + row] : W[(long long)row * ld + k0 + e]);
+    *reinterpret_cast<bf16x8*>(a.img[i] + idx * 8) = v;
+}
+
 struct ChainDev {
     const float* in;              // [T][K1] fp32: forward x (block input = outer-skip residual); backward g (gradient of the block output)
     __bf16* in_lp;                // [T][K1] bf16 copy of it (operand of a weight-gradient product); nullable
@@ -57,6 +79,7 @@ struct ChainDev {
     float* a2f;                   // backward: gt in fp32 (the gradient that leaves through y)
     float* out;                   // [T][N3] fp32
     int T, outer;
+    int rot;                      // rotate the wave -> n-tile assignment by the workgroup index (spreads the L2 channels the CUs of an XCD hit at one time)
 };
 
 template <int L> constexpr int swm() { return (L / 8 >= 16 ? 16 : L / 8) - 1; }      // chunk-swizzle mask of an image with rows of L elements
@@ -122,8 +145,10 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainDev a) {
     __bf16* img0 = reinterpret_cast<__bf16*>(chain_smem);                   // [ROWS][K1]  stage-1 input
     __bf16* img1 = img0 + ROWS * K1;                                        // [ROWS][N1]  stage-1 output
     __bf16* img2 = img1 + ROWS * N1;                                        // [ROWS][N2]  stage-2 output
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
+    const int w = ((tid >> 6) + (a.rot ? (int)(blockIdx.x >> 3) : 0)) & 7;     // which n-tiles this wave owns (workgroups b, b + 8, .. share an XCD)
     const int m0 = blockIdx.x * ROWS;
+    DLWP_STAMP(0);
 
     // ---- requests of the prologue, oldest first: input tile, stage-1 weights, stage-1 epilogue operands, first half of stage 2
     constexpr int XU = (ROWS * K1 / 4 + 511) / 512;
@@ -142,7 +167,7 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainDev a) {
     for (int ni = 0; ni < NT1; ++ni) {
         const int n = 16 * min(w + 8 * ni, NTL1 - 1) + 4 * g;
         f32x4 bb = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!BWD && a.b1) bb = *reinterpret_cast<const f32x4*>(a.b1 + n);
+        if (!BWD) bb = *reinterpret_cast<const f32x4*>(a.b1 + n);          // (the host passes zeros for an absent bias)
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
             const long long m = min(m0 + 16 * mi + r, a.T - 1);
@@ -166,7 +191,9 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainDev a) {
             if (a.in_lp && m0 + row < a.T) *reinterpret_cast<bf16x4*>(a.in_lp + (long long)(m0 + row) * K1 + k) = b;
         }
     }
+    DLWP_STAMP(1);
     lds_barrier();
+    DLWP_STAMP(2);
 
     // ---- stage 1
     f32x4 acc1[MT][NT1];
@@ -174,6 +201,7 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainDev a) {
     mma<MT, NT1, KH1, K1>(acc1, w1a, img0, 0, r, g);
     if (!EARLY2) wload<NT2, KS2, KH2, NTL2>(w2a, a.w2, w, lane, 0);
     mma<MT, NT1, KH1, K1>(acc1, w1b, img0, KH1, r, g);
+    DLWP_STAMP(3);
     // requests for stage 2's epilogue and the rest of its weights go out before this stage's stores
     f32x4 e2b[NT2];
     bf16x4 e2z[MT][NT2];
@@ -181,7 +209,7 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainDev a) {
     for (int ni = 0; ni < NT2; ++ni) {
         const int n = 16 * min(w + 8 * ni, NTL2 - 1) + 4 * g;
         e2b[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!BWD && a.b2) e2b[ni] = *reinterpret_cast<const f32x4*>(a.b2 + n);
+        if (!BWD) e2b[ni] = *reinterpret_cast<const f32x4*>(a.b2 + n);
         if (BWD) {
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
@@ -216,25 +244,27 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainDev a) {
             }
         }
     }
+    DLWP_STAMP(4);
     lds_barrier();
+    DLWP_STAMP(5);
 
     // ---- stage 2
     f32x4 acc2[MT][NT2];
     zero_acc<MT, NT2>(acc2);
     mma<MT, NT2, KH2, N1>(acc2, w2a, img1, 0, r, g);
     mma<MT, NT2, KH2, N1>(acc2, w2b, img1, KH2, r, g);
+    DLWP_STAMP(6);
     WFrag<NT3, KH3> w3a, w3b;
     f32x4 e3f[MT][NT3];           // bias (+ outer skip)
 #pragma unroll
     for (int ni = 0; ni < NT3; ++ni) {
         const int n = 16 * min(w + 8 * ni, NTL3 - 1) + 4 * g;
         f32x4 bb = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!BWD && a.b3) bb = *reinterpret_cast<const f32x4*>(a.b3 + n);
+        if (!BWD) bb = *reinterpret_cast<const f32x4*>(a.b3 + n);
+        const float so = a.outer ? 1.f : 0.f;                              // the skip is always loaded (no branch around a load)
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-            e3f[mi][ni] = bb;
-            if (a.outer) e3f[mi][ni] += *reinterpret_cast<const f32x4*>(a.in + (long long)min(m0 + 16 * mi + r, a.T - 1) * K1 + n);
-        }
+        for (int mi = 0; mi < MT; ++mi)
+            e3f[mi][ni] = bb + so * *reinterpret_cast<const f32x4*>(a.in + (long long)min(m0 + 16 * mi + r, a.T - 1) * K1 + n);
     }
     wload<NT3, KS3, KH3, NTL3>(w3a, a.w3, w, lane, 0);
     wload<NT3, KS3, KH3, NTL3>(w3b, a.w3, w, lane, KH3);
@@ -266,13 +296,16 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainDev a) {
             }
         }
     }
+    DLWP_STAMP(7);
     lds_barrier();
+    DLWP_STAMP(8);
 
     // ---- stage 3
     f32x4 acc3[MT][NT3];
     zero_acc<MT, NT3>(acc3);
     mma<MT, NT3, KH3, N2>(acc3, w3a, img2, 0, r, g);
     mma<MT, NT3, KH3, N2>(acc3, w3b, img2, KH3, r, g);
+    DLWP_STAMP(9);
 #pragma unroll
     for (int ni = 0; ni < NT3; ++ni) {
         const int tile = w + 8 * ni, n = 16 * tile + 4 * g;
@@ -284,6 +317,11 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainDev a) {
             }
         }
     }
+    DLWP_STAMP(10);
+#ifdef DLWP_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DLWP_STAMP(11);
+#endif
 }
 
 template <int C, int HD, int MT, bool BWD>
@@ -293,7 +331,10 @@ int chain_launch(const ChainDev& a, hipStream_t s) {
     auto kern = mlp_chain_kernel<K1, N1, N2, N3, MT, BWD>;
     int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(kern), lds, "mlp_chain");
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(a.T, 16 * MT)), dim3(512), lds, s, a);
+    ChainDev b = a;
+    static const char* rot_env = getenv("DLWP_CHAIN_ROT");
+    b.rot = rot_env ? atoi(rot_env) : 1;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(a.T, 16 * MT)), dim3(512), lds, s, b);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }
@@ -308,6 +349,15 @@ int chain_dispatch(const ChainDev& a, int C, int HD, hipStream_t s) {
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// an absent bias is read as zeros from here (the kernel's bias loads are unconditional); sized for the widest compiled stage
+__device__ __attribute__((aligned(16))) float g_chain_zero_bias[512];
+const float* zero_bias() {
+    // per-device address, resolved on every call (hipGetSymbolAddress does not enqueue anything: capture-safe)
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_chain_zero_bias)) != hipSuccess) return nullptr;
+    return static_cast<const float*>(p);
+}
 
 }  // namespace
 
@@ -328,6 +378,28 @@ extern "C" int dlwp_mlp_chain_pack(const float* W, int rows, int cols, int trans
     return DLWP_OK;
 }
 
+extern "C" int dlwp_sfno_tail_pack(const float* ws, const float* w1, const float* w2, int C, int hidden, void* images, void* stream) {
+    DLWP_REQUIRE(ws && w1 && w2 && images, DLWP_E_INVALID, "sfno_tail_pack: null pointer");
+    DLWP_REQUIRE(C > 0 && hidden > 0 && C % 32 == 0 && hidden % 32 == 0 && aligned16(images), DLWP_E_INVALID,
+                 "sfno_tail_pack: C = %d and hidden = %d must be multiples of 32, the images 16-byte aligned", C, hidden);
+    PackSix a{};
+    const float* W[6] = {ws, w1, w2, w2, w1, ws};
+    const int rows[6] = {C, hidden, C, hidden, C, C}, cols[6] = {C, C, hidden, C, hidden, C}, tr[6] = {0, 0, 0, 1, 1, 1};
+    long long most = 0;
+    for (int i = 0; i < 6; ++i) {
+        a.W[i] = W[i];
+        a.rows[i] = rows[i];
+        a.cols[i] = cols[i];
+        a.tr[i] = tr[i];
+        a.ld[i] = tr[i] ? rows[i] : cols[i];
+        a.img[i] = reinterpret_cast<__bf16*>(images) + (long long)i * C * hidden;
+        most = std::max(most, (long long)(rows[i] / 16) * (cols[i] / 32) * 64);
+    }
+    hipLaunchKernelGGL(chain_pack6_kernel, dim3((unsigned)((most + 255) / 256), 6), dim3(256), 0, (hipStream_t)stream, a);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
 extern "C" int dlwp_sfno_tail_fwd(const dlwp_sfno_tail_fwd_args* p, void* stream) {
     DLWP_REQUIRE(p, DLWP_E_INVALID, "sfno_tail_fwd: null arguments");
     DLWP_REQUIRE(dlwp_mlp_chain_supported(p->C, p->hidden), DLWP_E_UNSUPPORTED, "sfno_tail_fwd: no kernel for C = %d, hidden = %d",
@@ -342,9 +414,11 @@ extern "C" int dlwp_sfno_tail_fwd(const dlwp_sfno_tail_fwd_args* p, void* stream
     a.w1 = reinterpret_cast<const __bf16*>(p->ws_img);
     a.w2 = reinterpret_cast<const __bf16*>(p->w1_img);
     a.w3 = reinterpret_cast<const __bf16*>(p->w2_img);
-    a.b1 = p->bs;
-    a.b2 = p->b1;
-    a.b3 = p->b2;
+    const float* zb = zero_bias();
+    DLWP_REQUIRE(zb, DLWP_E_HIP, "sfno_tail_fwd: hipGetSymbolAddress failed");
+    a.b1 = p->bs ? p->bs : zb;
+    a.b2 = p->b1 ? p->b1 : zb;
+    a.b3 = p->b2 ? p->b2 : zb;
     a.res1 = p->y;
     a.z1 = reinterpret_cast<__bf16*>(p->z0);
     a.a1 = reinterpret_cast<__bf16*>(p->t);
@@ -380,3 +454,10 @@ extern "C" int dlwp_sfno_tail_bwd(const dlwp_sfno_tail_bwd_args* p, void* stream
     a.outer = p->outer;
     return chain_dispatch<true>(a, p->C, p->hidden, (hipStream_t)stream);
 }
+
+#ifdef DLWP_STAMPS
+extern "C" int dlwp_debug_stamps_chain(unsigned long long* host_out) {
+    DLWP_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dlwp_stamps), sizeof(unsigned long long) * 32));
+    return DLWP_OK;
+}
+#endif

@@ -68,6 +68,8 @@ SIGNATURES = {
     "dlwp_get_gemm_precision": (_I, []),
     "dlwp_set_gemm_tile256": (_I, [_I]),
     "dlwp_weight_grad_group": (_I, [_V, _I, _V]),
+    "dlwp_wgrad_segments_workspace_bytes": (C.c_size_t, [_V, _I, _I, _I]),
+    "dlwp_wgrad_segments": (_I, [_V, _I, _I, _I, _V, C.c_size_t, _V]),
     "dlwp_gemm_group_begin": (_I, []),
     "dlwp_gemm_group_end": (_I, [_V]),
     "dlwp_window_gather": (_I, [_V, _V, _I, _I] + [_V] * 7 + [_V]),
@@ -92,6 +94,7 @@ SIGNATURES = {
     "dlwp_cweight_fold": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_mlp_chain_supported": (_I, [_I, _I]),
     "dlwp_mlp_chain_pack": (_I, [_V, _I, _I, _I, _V, _V]),
+    "dlwp_sfno_tail_pack": (_I, [_V, _V, _V, _I, _I, _V, _V]),
     "dlwp_sfno_tail_fwd": (_I, [_V, _V]),
     "dlwp_sfno_tail_bwd": (_I, [_V, _V]),
     "dlwp_layernorm_fwd": (_I, [_V] * 6 + [_I, _I, _F, _V]),

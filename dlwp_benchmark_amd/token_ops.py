@@ -203,6 +203,56 @@ def _weight_grad_group(items):
     return outs
 
 
+class _WgradSegProduct(C.Structure):
+    """dlwp_wgrad_seg_product (include/dlwpmi.h)"""
+    _fields_ = [("g", C.c_void_p * 8), ("x", C.c_void_p * 8), ("gw", C.c_void_p), ("gb", C.c_void_p), ("N", C.c_int), ("K", C.c_int)]
+
+
+_WGRAD_MAX_SEGMENTS = 8
+_workspaces = {}      # device -> [tensors]: the last one is current; earlier (smaller) ones stay alive for the graphs that captured them
+
+
+def _workspace(nbytes, device):
+    """Caller-side scratch of the library calls that ask for one (dlwp_*_workspace_bytes): grow-only per device, never freed while
+    the process lives -- a hipGraph that captured a launch keeps reading / writing the buffer it was captured with."""
+    held = _workspaces.setdefault(device, [])
+    if not held or held[-1].numel() < nbytes:
+        held.append(torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device))
+    return held[-1]
+
+
+def _weight_grad_segments(layers):
+    """gW_i += sum_s g_is^T x_is, gb_i += sum_s colsum(g_is) for up to four layers in one product launch + one reduction launch
+    (dlwp_wgrad_segments).  layers: [(g segments, x segments, weight slot or None, bias slot or None, has_bias, weight shape)],
+    every segment a bf16 [T][cols] array, the same number of segments and tokens for every layer.
+    Returns [(gw, gb)] for autograd (None where the slot was used)."""
+    lib = L.load()
+    n = len(layers)
+    nseg, T = len(layers[0][0]), layers[0][0][0].shape[0]
+    descs = (_WgradSegProduct * n)()
+    outs, keep = [], []
+    for i, (gs, xs, wslot, bslot, has_bias, wshape) in enumerate(layers):
+        N, K = gs[0].shape[1], xs[0].shape[1]
+        assert len(gs) == nseg and len(xs) == nseg and all(t.shape[0] == T and t.dtype == _BF for t in (*gs, *xs))
+        dev = gs[0].device
+        gw = wslot if wslot is not None else torch.zeros(N, K, device=dev)
+        gb = None
+        if has_bias:
+            gb = bslot if bslot is not None else torch.zeros(N, device=dev)
+        d = descs[i]
+        for s_ in range(nseg):
+            d.g[s_], d.x[s_] = L.ptr(gs[s_]), L.ptr(xs[s_])
+        d.gw, d.gb, d.N, d.K = L.ptr(gw), L.ptr(gb), N, K
+        keep.append((gw, gb))
+        outs.append((None if wslot is not None else gw.reshape(wshape), None if (bslot is not None or gb is None) else gb))
+    need = lib.dlwp_wgrad_segments_workspace_bytes(C.cast(descs, C.c_void_p), n, nseg, T)
+    if need == 0:
+        L.check(-1)
+    ws = _workspace(need, layers[0][0][0].device)
+    L.check(lib.dlwp_wgrad_segments(C.cast(descs, C.c_void_p), n, nseg, T, L.ptr(ws), ws.numel(), L.stream()))
+    return outs
+
+
 class _MlpFn(torch.autograd.Function):
     """y = fc2(GELU(fc1 x)) (+ residual) as ONE autograd node (reference: Mlp.forward, nsbench/models/fourcastnet/
     fourcastnet.py:50-56, swintransformer/swin_transformer.py:42-48).  Forward: two GEMMs (bias + GELU, bias + residual
@@ -336,21 +386,23 @@ class _TailBwdArgs(C.Structure):
 def _chain_images(ws, w1, w2):
     """The six fragment-order bf16 images of an SFNO block tail's weights (dlwp_mlp_chain_pack: forward Ws, W1, W2; backward
     W2^T, W1^T, Ws^T), built from the fp32 master weights.  Inside a sht.spectral_weight_scope (one rollout pass: the parameters
-    cannot change) they are built once and shared by every lead time."""
+    cannot change) they are built once and shared by every lead time, together with the list that collects the lead times'
+    weight-gradient operands (the last backward pass through these weights runs ONE product over all of them).  -> (images, state)"""
     from . import sht
     scope = sht._wexp_scope
     key = ("chain", id(ws), id(w1), id(w2))
     if scope is not None and key in scope:
-        return scope[key][0]
+        return scope[key][0], scope[key][2]
     lib = L.load()
     C_, Hd = ws.shape[0], w1.shape[0]
     imgs = torch.empty(6, C_ * Hd, device=ws.device, dtype=_BF)       # (the two C x C images use the front of their rows)
-    plan = ((ws, C_, C_, 0), (w1, Hd, C_, 0), (w2, C_, Hd, 0), (w2, Hd, C_, 1), (w1, C_, Hd, 1), (ws, C_, C_, 1))
-    for i, (w, rows, cols, tr) in enumerate(plan):
-        L.check(lib.dlwp_mlp_chain_pack(L.ptr(w.detach().contiguous()), rows, cols, tr, L.ptr(imgs[i]), L.stream()))
+    L.check(lib.dlwp_sfno_tail_pack(L.ptr(ws.detach().contiguous()), L.ptr(w1.detach().contiguous()), L.ptr(w2.detach().contiguous()),
+                                    C_, Hd, L.ptr(imgs), L.stream()))
+    # uses: applications of these weights whose backward pass is still to come; pending: their weight-gradient operands
+    state = {"uses": 0, "pending": []}
     if scope is not None:
-        scope[key] = (imgs, (ws, w1, w2))      # keeps the parameters alive: the ids stay unique inside the scope
-    return imgs
+        scope[key] = (imgs, (ws, w1, w2), state)      # keeps the parameters alive: the ids stay unique inside the scope
+    return imgs, state
 
 
 CHAIN_TAIL = __import__("os").environ.get("DLWP_SFNO_CHAIN", "1") != "0"      # env: A/B runs against the three-GEMM tail
@@ -375,7 +427,10 @@ class _SkipMlpChainFn(torch.autograd.Function):
         x2 = x.reshape(-1, C_).contiguous().float()
         y2 = y.reshape(-1, C_).contiguous().float()
         T, Hd = x2.shape[0], w1.shape[0]
-        imgs = _chain_images(ws, w1, w2)
+        imgs, state = _chain_images(ws, w1, w2)
+        if any(ctx.needs_input_grad):
+            state["uses"] += 1
+        ctx.state = state
         dev = x.device
         x_lp = torch.empty(T, C_, device=dev, dtype=_BF)
         z0 = torch.empty(T, C_, device=dev, dtype=_BF)
@@ -408,11 +463,20 @@ class _SkipMlpChainFn(torch.autograd.Function):
         a = _TailBwdArgs(L.ptr(g32), L.ptr(imgs[3]), L.ptr(imgs[4]), L.ptr(imgs[5]), L.ptr(z1), L.ptr(z0), L.ptr(g_lp), L.ptr(gh),
                          L.ptr(gt), L.ptr(gt_lp), L.ptr(gx), T, C_, Hd, int(ctx.outer))
         L.check(L.load().dlwp_sfno_tail_bwd(C.byref(a), L.stream()))
-        # the three weight gradients (+ bias gradients): independent products of bf16 arrays, one launch
-        (gw2, gb2), (gw1, gb1), (gws, gbs) = _weight_grad_group([
-            (g_lp, h, ctx.slots[4], ctx.slots[5], ctx.has_b[2], ctx.wshapes[2]),
-            (gh, t, ctx.slots[2], ctx.slots[3], ctx.has_b[1], ctx.wshapes[1]),
-            (gt_lp, x_lp, ctx.slots[0], ctx.slots[1], ctx.has_b[0], ctx.wshapes[0])])
+        # The three weight gradients (+ bias gradients).  A rollout applies these weights once per lead time: the operand pairs
+        # wait in the shared list and the LAST backward pass through the weights multiplies all of them in one product over the
+        # concatenated token axis (dlwp_wgrad_segments) -- one launch pair per block and step instead of one per lead time.
+        st = ctx.state
+        st["pending"].append((g_lp, h, gh, t, gt_lp, x_lp))
+        st["uses"] -= 1
+        if st["uses"] > 0 and len(st["pending"]) < _WGRAD_MAX_SEGMENTS:
+            return gt.reshape(ctx.shape), gx.reshape(ctx.shape), None, None, None, None, None, None, None
+        segs, st["pending"] = st["pending"], []
+        col = lambda i: [s_[i] for s_ in segs]
+        (gw2, gb2), (gw1, gb1), (gws, gbs) = _weight_grad_segments([
+            (col(0), col(1), ctx.slots[4], ctx.slots[5], ctx.has_b[2], ctx.wshapes[2]),
+            (col(2), col(3), ctx.slots[2], ctx.slots[3], ctx.has_b[1], ctx.wshapes[1]),
+            (col(4), col(5), ctx.slots[0], ctx.slots[1], ctx.has_b[0], ctx.wshapes[0])])
         return gt.reshape(ctx.shape), gx.reshape(ctx.shape), gws, gbs, gw1, gb1, gw2, gb2, None
 
 

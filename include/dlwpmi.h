@@ -452,6 +452,24 @@ typedef struct dlwp_wgrad_desc {
     int g_bf16, x_bf16, accumulate;
 } dlwp_wgrad_desc;
 int dlwp_weight_grad_group(const dlwp_wgrad_desc* products, int n, void* stream);
+/* The same gradients for a layer applied SEVERAL times with the same weights (the lead times of a rollout,                 */
+/* src/dlwpbench/models/fno/fno.py:217-259): gW += sum_s g_s^T x_s and gb += sum_s sum_t g_s[t] as ONE product over the            */
+/* concatenated token axis, up to DLWP_WGRAD_MAX_PRODUCTS layers per call (csrc/wgrad_multi.hip).  Every segment is T tokens;       */
+/* g_s [T][N], x_s [T][K] bf16 arrays (16-byte aligned, N and K multiples of 8), gw [N][K] and gb [N] fp32, accumulated into.       */
+/* The K slices go to the CALLER's workspace (dlwp_wgrad_segments_workspace_bytes) and are added in slice order by a second        */
+/* launch: no allocation, no synchronisation, bit-reproducible weight gradients.                                                   */
+#define DLWP_WGRAD_MAX_PRODUCTS 4
+#define DLWP_WGRAD_MAX_SEGMENTS 8
+typedef struct dlwp_wgrad_seg_product {
+    const void* g[DLWP_WGRAD_MAX_SEGMENTS];
+    const void* x[DLWP_WGRAD_MAX_SEGMENTS];
+    float* gw;
+    float* gb;                              /* nullable */
+    int N, K;
+} dlwp_wgrad_seg_product;
+size_t dlwp_wgrad_segments_workspace_bytes(const dlwp_wgrad_seg_product* products, int nprod, int nseg, int T);
+int dlwp_wgrad_segments(const dlwp_wgrad_seg_product* products, int nprod, int nseg, int T, void* workspace,
+                        size_t workspace_bytes, void* stream);
 /* Any INDEPENDENT small products: between _begin and _end, the dlwp_gemm* entries park products that fit the generic 64 x 64 kernel   */
 /* and are small (<= 16384 deep, latency-bound by themselves); _end launches up to three of them as one grid.  Everything else      */
 /* launches at once.  Used around the two gradient products of a Linear layer's backward pass (gx = g W and gW = g^T x read the     */
@@ -562,6 +580,9 @@ typedef struct dlwp_sfno_tail_bwd_args {
 } dlwp_sfno_tail_bwd_args;
 int dlwp_mlp_chain_supported(int C, int hidden);
 int dlwp_mlp_chain_pack(const float* W, int rows, int cols, int transpose, void* image, void* stream);
+/* all six images of a tail in one launch: images [6][C * hidden] bf16 = forward Ws, W1, W2, backward W2^T, W1^T, Ws^T  */
+/* (the two C x C images use the front of their slots); ws [C][C], w1 [hidden][C], w2 [C][hidden] fp32.               */
+int dlwp_sfno_tail_pack(const float* ws, const float* w1, const float* w2, int C, int hidden, void* images, void* stream);
 int dlwp_sfno_tail_fwd(const dlwp_sfno_tail_fwd_args* args, void* stream);
 int dlwp_sfno_tail_bwd(const dlwp_sfno_tail_bwd_args* args, void* stream);
 /* LayerNorm over the last dimension of x [T,C]; mean/rstd [T] are saved for backward.       */

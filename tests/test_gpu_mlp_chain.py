@@ -36,7 +36,8 @@ def test_pack_image_is_the_fragment_order_of_the_matrix(cuda, rows, cols, transp
     g = torch.Generator().manual_seed(1)
     W = torch.randn((cols, rows) if transpose else (rows, cols), generator=g)
     img = torch.empty(rows * cols, device=cuda, dtype=BF)
-    L.check(L.load().dlwp_mlp_chain_pack(L.ptr(W.to(cuda)), rows, cols, transpose, L.ptr(img), L.stream()))
+    Wd = W.to(cuda)
+    L.check(L.load().dlwp_mlp_chain_pack(L.ptr(Wd), rows, cols, transpose, L.ptr(img), L.stream()))
     Wp = (W.t() if transpose else W).to(BF)                       # the matrix the image describes, [rows][cols]
     KS = cols // 32
     want = Wp.reshape(rows // 16, 16, KS, 4, 8).permute(0, 2, 3, 1, 4).reshape(-1)      # [tile][kk][g][r][e]
@@ -57,8 +58,11 @@ def _images(L, dev, ws, w1, w2):
     C, Hd = ws.shape[0], w1.shape[0]
     imgs = torch.empty(6, C * Hd, device=dev, dtype=BF)
     plan = ((ws, C, C, 0), (w1, Hd, C, 0), (w2, C, Hd, 0), (w2, Hd, C, 1), (w1, C, Hd, 1), (ws, C, C, 1))
+    held = []
     for i, (w, rows, cols, tr) in enumerate(plan):
-        L.check(L.load().dlwp_mlp_chain_pack(L.ptr(w.to(dev).contiguous()), rows, cols, tr, L.ptr(imgs[i]), L.stream()))
+        held.append(w.to(dev).contiguous())
+        L.check(L.load().dlwp_mlp_chain_pack(L.ptr(held[-1]), rows, cols, tr, L.ptr(imgs[i]), L.stream()))
+    torch.cuda.synchronize()
     return imgs
 
 
@@ -133,3 +137,83 @@ def test_chain_node_equals_the_three_gemm_node(cuda, T, C, Hd):
             L.set_storage("fp32")
     for i, (a, b) in enumerate(zip(res["chain"], res["gemm"])):
         assert rel(a, b) <= 1e-2, (i, rel(a, b))
+
+
+def test_tail_pack_equals_six_single_packs(cuda):
+    from dlwp_benchmark_amd import lib as L
+    C, Hd = 128, 256
+    _, _, _, ws, _, w1, _, w2, _ = _tail_inputs(16, C, Hd, 3)
+    want = _images(L, cuda, ws, w1, w2)
+    got = torch.zeros(6, C * Hd, device=cuda, dtype=BF)
+    wsd, w1d, w2d = ws.to(cuda), w1.to(cuda), w2.to(cuda)
+    L.check(L.load().dlwp_sfno_tail_pack(L.ptr(wsd), L.ptr(w1d), L.ptr(w2d), C, Hd, L.ptr(got), L.stream()))
+    for i, n in enumerate((C * C, Hd * C, C * Hd, Hd * C, C * Hd, C * C)):
+        assert torch.equal(got[i, :n].cpu(), want[i, :n].cpu()), i
+
+
+@pytest.mark.parametrize("T,nseg,dims", [(8192, 4, ((256, 512), (512, 256), (256, 256))), (1000, 3, ((64, 128), (128, 64))),
+                                          (333, 1, ((256, 512),)), (4100, 8, ((136, 72), (8, 8), (512, 256), (256, 256)))])
+def test_segmented_weight_gradients_match_float64(cuda, T, nseg, dims):
+    """dlwp_wgrad_segments: gW += sum_s g_s^T x_s and gb += sum_s colsum(g_s) over bf16 operand segments, accumulated into
+    non-zero gradient buffers; ragged token counts (partial K-steps, partial slices) and ragged widths (tiles past the edge);
+    two runs agree bit for bit in the weight gradients (ordered slab reduction)."""
+    from dlwp_benchmark_amd import token_ops
+    g = torch.Generator().manual_seed(21)
+    layers, ref = [], []
+    for (N, K) in dims:
+        gs = [torch.randn(T, N, generator=g).to(BF) for _ in range(nseg)]
+        xs = [torch.randn(T, K, generator=g).to(BF) for _ in range(nseg)]
+        gw0, gb0 = torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+        ref.append((gw0.double() + sum(a.double().t() @ b.double() for a, b in zip(gs, xs)),
+                    gb0.double() + sum(a.double().sum(0) for a in gs)))
+        layers.append(([t.to(cuda) for t in gs], [t.to(cuda) for t in xs], gw0, gb0, N, K))
+    runs = []
+    for _ in range(2):
+        args = [(gs, xs, gw0.clone().to(cuda), gb0.clone().to(cuda), True, (N, K)) for gs, xs, gw0, gb0, N, K in layers]
+        outs = token_ops._weight_grad_segments(args)
+        assert all(o == (None, None) for o in outs)
+        torch.cuda.synchronize()
+        runs.append([(a[2].cpu(), a[3].cpu()) for a in args])
+    for (gw, gb), (gwr, gbr) in zip(runs[0], ref):
+        assert rel(gw, gwr) <= 2e-5, rel(gw, gwr)
+        assert rel(gb, gbr) <= 2e-5, rel(gb, gbr)
+    for (gw_a, _), (gw_b, _) in zip(*runs):
+        assert torch.equal(gw_a, gw_b)
+
+
+def test_rollout_scope_defers_the_tail_weight_gradients_to_the_last_lead_time(cuda):
+    """Three applications of one block tail inside a spectral_weight_scope: the weight gradients arrive in ONE segmented product
+    (launched by the last backward pass through the weights) and equal the sum of the per-application gradients of the
+    three-GEMM node."""
+    from dlwp_benchmark_amd import lib as L, sht, token_ops
+    T, C, Hd = 512, 64, 128
+    x, y, gout, ws, bs, w1, b1, w2, b2 = _tail_inputs(T, C, Hd, 13)
+    calls = []
+    orig = token_ops._weight_grad_segments
+
+    def spy(layers):
+        calls.append(len(layers[0][0]))
+        return orig(layers)
+    res = {}
+    with L.gemm_precision("bf16"):
+        L.set_storage("bf16")
+        L.SHADOW_ACTIVE = True
+        token_ops._weight_grad_segments = spy
+        try:
+            for name, fn in (("chain", token_ops._SkipMlpChainFn), ("gemm", token_ops._SkipMlpFn)):
+                P = [t.clone().to(cuda).requires_grad_(True) for t in (ws.reshape(C, C, 1, 1), bs, w1.reshape(Hd, C, 1, 1), b1,
+                                                                      w2.reshape(C, Hd, 1, 1), b2)]
+                xin = x.clone().to(cuda).requires_grad_(True)
+                with sht.spectral_weight_scope():
+                    t = xin
+                    for _ in range(3):                       # the block output feeds the next application (a rollout's lead times)
+                        t = fn.apply(y.to(cuda), t, *P, True)
+                    t.backward(gout.to(cuda))
+                res[name] = [t, xin.grad] + [p.grad for p in P]
+        finally:
+            token_ops._weight_grad_segments = orig
+            L.SHADOW_ACTIVE = False
+            L.set_storage("fp32")
+    assert calls == [3]
+    for i, (a, b) in enumerate(zip(res["chain"], res["gemm"])):
+        assert rel(a, b) <= 2e-2, (i, rel(a, b))
