@@ -23,13 +23,12 @@
 // Arithmetic = the bf16-operand token GEMM's: operands rounded to bf16, fp32 accumulation, fp32 epilogue, one rounding per store.
 #include <algorithm>
 #include <cstdlib>
-#include "common.cuh"
+#include "chain_frag.cuh"
 #include "dlwpmi_internal.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+using namespace chainfrag;
 
 // image[(tile * KS + kk) * 64 + lane][e] = W'[16 tile + (lane & 15)][32 kk + 8 (lane >> 4) + e],  W' = W or W^T
 __global__ __launch_bounds__(256) void chain_pack_kernel(const float* __restrict__ W, int ld, int rows, int cols, int transpose,
@@ -81,57 +80,6 @@ struct ChainDev {
     int T, outer;
     int rot;                      // rotate the wave -> n-tile assignment by the workgroup index (spreads the L2 channels the CUs of an XCD hit at one time)
 };
-
-template <int L> constexpr int swm() { return (L / 8 >= 16 ? 16 : L / 8) - 1; }      // chunk-swizzle mask of an image with rows of L elements
-
-template <int NT, int KH> struct WFrag { bf16x8 f[NT][KH]; };
-
-// the fragments of k-steps k0 .. k0 + KH of this wave's n-tiles (tile = w + 8 ni; clamped: surplus tiles repeat the last one)
-template <int NT, int KS, int KH, int NTL>
-__device__ __forceinline__ void wload(WFrag<NT, KH>& wf, const __bf16* __restrict__ img, int w, int lane, int k0) {
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni) {
-        const int tile = min(w + 8 * ni, NTL - 1);
-#pragma unroll
-        for (int kk = 0; kk < KH; ++kk)
-            wf.f[ni][kk] = *reinterpret_cast<const bf16x8*>(img + ((long long)(tile * KS + k0 + kk) * 64 + lane) * 8);
-    }
-}
-
-// acc[mi][ni] += W'[tile ni rows][k] . act[token tile mi][k] over k-steps k0 .. k0 + KH of the LDS image (rows of LROW elements)
-template <int MT, int NT, int KH, int LROW>
-__device__ __forceinline__ void mma(f32x4 (&acc)[MT][NT], const WFrag<NT, KH>& wf, const __bf16* img, int k0, int r, int g) {
-#pragma unroll
-    for (int kk = 0; kk < KH; ++kk) {
-        bf16x8 tf[MT];
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-            const int row = 16 * mi + r, c = (4 * (k0 + kk) + g) ^ (row & swm<LROW>());
-            tf[mi] = *reinterpret_cast<const bf16x8*>(img + row * LROW + 8 * c);
-        }
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf.f[ni][kk], tf[mi], acc[mi][ni], 0, 0, 0);
-    }
-}
-
-template <int MT, int NT>
-__device__ __forceinline__ void zero_acc(f32x4 (&acc)[MT][NT]) {
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-}
-
-__device__ __forceinline__ bf16x4 to_bf4(const float (&v)[4]) { return bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]}; }
-
-// four consecutive features n .. n + 3 of image row `row` (rows of LROW elements)
-template <int LROW>
-__device__ __forceinline__ void img_store(__bf16* img, int row, int n, bf16x4 v) {
-    *reinterpret_cast<bf16x4*>(img + row * LROW + 8 * ((n >> 3) ^ (row & swm<LROW>())) + (n & 7)) = v;
-}
 
 template <int K1, int N1, int N2, int N3, int MT, bool BWD>
 __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainDev a) {

@@ -21,6 +21,7 @@ from ..token_ops import Conv1x1, InstanceNorm, add_tokens, mlp, skip_mlp
 from .rollout import rollout
 
 PAD_FRAME_CHANNELS = os.environ.get("DLWP_SFNO_NO_CHANNEL_PAD", "0") != "1"     # env: A/B runs of the padding in forward()
+FAST_IO = os.environ.get("DLWP_SFNO_FAST_IO", "1") != "0"                       # env: A/B runs of the one-launch encoder / decoder
 
 
 class _SpectralFilter(nn.Module):
@@ -127,9 +128,25 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         self.decoder = nn.ModuleList([Conv1x1(embed_dim + self.big_skip * in_chans, embed_dim), nn.GELU(),
                                       Conv1x1(embed_dim, out_chans, bias=False)])
 
+    def forward_frames(self, sources, frame_index=None, residual=False):
+        """The network on an input given as plane groups ([B, c_i, H, W] each, at most three, in channel order) through the
+        one-launch encoder / decoder kernels (sfno_ops): no concatenated / padded / permuted copy of the input exists.
+        frame_index: the differentiable group; residual: out = sources[frame_index] + net(input) (the rollout's connection)."""
+        from .. import sfno_ops
+        t, tok_lp, link, alias = sfno_ops.encode(self, sources, frame_index)
+        for blk in self.blocks:
+            t = blk(t)
+        return sfno_ops.decode(self, t, tok_lp, link, alias if residual else None)
+
+    def fast_io(self, in_chans):
+        from .. import sfno_ops
+        return FAST_IO and sfno_ops.applies(self, in_chans, self.decoder[2].out_channels)
+
     def forward(self, x):
         """x [B, in_chans, H, W] -> [B, out_chans, H, W]."""
         B, Cin, H, W = x.shape
+        if x.is_cuda and self.fast_io(Cin):
+            return self.forward_frames([x], 0 if x.requires_grad else None)
         E = self.encoder[0].out_channels
         # Token rows of the input frame are zero-padded to a multiple of 8 channels (and the first encoder / decoder weights
         # with zero columns to match): the 10-channel frame and the 266-wide big-skip concatenation otherwise put every
@@ -177,8 +194,25 @@ class SFNO2DModule(nn.Module):
     def forward(self, constants: torch.Tensor = None, prescribed: torch.Tensor = None,
                 prognostic: torch.Tensor = None) -> torch.Tensor:
         with spectral_weight_scope():      # every lead time applies the same weights: one expanded image per layer
+            cin = self.sfno.encoder[0].in_channels
+            if self.context_size == 1 and prognostic.is_cuda and self.sfno.fast_io(cin):
+                return self._rollout_frames(constants, prescribed, prognostic)
             self.sfno._wpad_cache = {}     # ... and one zero-padded copy of the first encoder / decoder weights
             try:
                 return rollout(self.sfno, self.context_size, constants, prescribed, prognostic)
             finally:
                 self.sfno._wpad_cache = None
+
+    def _rollout_frames(self, constants, prescribed, prognostic):
+        """The loop of rollout.py at context_size 1 without any assembled input tensor: out_t = frame + net(constants[:, 0],
+        prescribed[:, t - 1], frame), frame = prognostic[:, 0] first and the previous prediction afterwards (fno.py:217-259 in
+        its working form, unet.py:64-111); the encoder gathers the planes, the decoder adds the frame and writes NCHW."""
+        outs, frame = [], prognostic[:, 0]
+        for t in range(1, prognostic.shape[1]):
+            sources = [] if constants is None else [constants[:, 0]]
+            if prescribed is not None:
+                sources.append(prescribed[:, t - 1])
+            sources.append(frame)
+            frame = self.sfno.forward_frames(sources, len(sources) - 1, residual=True)
+            outs.append(frame)
+        return torch.stack(outs, dim=1)

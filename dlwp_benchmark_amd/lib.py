@@ -95,6 +95,13 @@ SIGNATURES = {
     "dlwp_mlp_chain_supported": (_I, [_I, _I]),
     "dlwp_mlp_chain_pack": (_I, [_V, _I, _I, _I, _V, _V]),
     "dlwp_sfno_tail_pack": (_I, [_V, _V, _V, _I, _I, _V, _V]),
+    "dlwp_sfno_io_supported": (_I, [_I, _I, _I]),
+    "dlwp_sfno_io_image_elems": (_L, [_I]),
+    "dlwp_sfno_io_pack": (_I, [_V, _V, _V, _V, _I, _I, _I, _I, _V, _V]),
+    "dlwp_sfno_encode_fwd": (_I, [_V, _V]),
+    "dlwp_sfno_encode_bwd": (_I, [_V, _V]),
+    "dlwp_sfno_decode_fwd": (_I, [_V, _V]),
+    "dlwp_sfno_decode_bwd": (_I, [_V, _V]),
     "dlwp_sfno_tail_fwd": (_I, [_V, _V]),
     "dlwp_sfno_tail_bwd": (_I, [_V, _V]),
     "dlwp_layernorm_fwd": (_I, [_V] * 6 + [_I, _I, _F, _V]),

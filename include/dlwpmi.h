@@ -458,7 +458,7 @@ int dlwp_weight_grad_group(const dlwp_wgrad_desc* products, int n, void* stream)
 /* g_s [T][N], x_s [T][K] bf16 arrays (16-byte aligned, N and K multiples of 8), gw [N][K] and gb [N] fp32, accumulated into.       */
 /* The K slices go to the CALLER's workspace (dlwp_wgrad_segments_workspace_bytes) and are added in slice order by a second        */
 /* launch: no allocation, no synchronisation, bit-reproducible weight gradients.                                                   */
-#define DLWP_WGRAD_MAX_PRODUCTS 4
+#define DLWP_WGRAD_MAX_PRODUCTS 6
 #define DLWP_WGRAD_MAX_SEGMENTS 8
 typedef struct dlwp_wgrad_seg_product {
     const void* g[DLWP_WGRAD_MAX_SEGMENTS];
@@ -585,6 +585,51 @@ int dlwp_mlp_chain_pack(const float* W, int rows, int cols, int transpose, void*
 int dlwp_sfno_tail_pack(const float* ws, const float* w1, const float* w2, int C, int hidden, void* images, void* stream);
 int dlwp_sfno_tail_fwd(const dlwp_sfno_tail_fwd_args* args, void* stream);
 int dlwp_sfno_tail_bwd(const dlwp_sfno_tail_bwd_args* args, void* stream);
+/* SFNO encoder / decoder with the rollout's frame assembly, ONE launch per direction each (csrc/sfno_io.hip).  Reference:   */
+/* SphericalFourierNeuralOperatorNet's encoder / decoder 1x1-convolution MLPs, position embedding and big skip (constructed at */
+/* src/dlwpbench/models/fno/fno.py:183-200) inside SFNO2DModule.forward's loop (fno.py:217-259; clean form unet.py:64-111):    */
+/*   x_t = cat(constants[:, 0], prescribed[:, t-1], frame);  t0 = W2e GELU(W1e x_t + b1e) + pos;                               */
+/*   y = W2d GELU(Wd [t ; x_t] + bd);  out = frame + y.                                                                        */
+/* Token tensors are rows (tokens [T][E] fp32, T = B * HW); frames and gradients of frames are NCHW planes given by the        */
+/* pointer of sample 0 and a batch stride in floats; tok_lp [T][DLWP_SFNO_IO_KP] holds the gathered input channels of a token  */
+/* as bf16 (zero beyond the real channels).  z, h ([T][E] bf16): the hidden layer's pre-activation and activation (forward:   */
+/* written; backward: z read, h receives the hidden gradient gh).  One argument struct serves the four calls:                 */
+/*   encode_fwd  src* (up to three plane groups) -> tok_lp, z, h, tokens = t0 (+ pos [HW][E], nullable)                        */
+/*   encode_bwd  tokens = g (d loss / d t0) -> tokens_lp (bf16 copy of g), h = gh; the token gradient gh W1e (+ tok_grad, the   */
+/*               decoder's share, nullable) has its channels frame_c0 .. frame_c0 + frame_c - 1 written to `frame`             */
+/*               (+ frame_add, nullable: the gradient that reached the same frame through the decoder's residual)             */
+/*   decode_fwd  tokens = t, tok_lp -> tokens_lp (bf16 copy of t), z, h, frame[b][c] = frame_add[b][c] + y (c < frame_c)       */
+/*   decode_bwd  src[0] = g_out (src_c[0] planes) -> tok_lp (bf16 rows of g_out), h = gh, tokens = g_t, tok_grad = g_tok        */
+/* Weight images: dlwp_sfno_io_pack builds the eight zero-padded fragment-order images (slot i at images + i *                */
+/* dlwp_sfno_io_image_elems(E) bf16 elements: encode fwd 1 / 2, encode bwd 1 / 2, decode fwd 1 / 2, decode bwd 1 / 2) from     */
+/* enc_w1 [E][in], enc_w2 [E][E], dec_w1 [E][E (+ in with big_skip)], dec_w2 [out][E].  bf16 operands, fp32 accumulation.     */
+#define DLWP_SFNO_IO_KP 32
+typedef struct dlwp_sfno_io_args {
+    const float* src[3];
+    long long src_bs[3];
+    int src_c[3];
+    int HW, T, E;
+    float* tokens;
+    void* tokens_lp;
+    void* tok_lp;
+    const void *w1_img, *w2_img;
+    const float *bias, *pos;
+    void *z, *h;
+    float* frame;
+    long long frame_bs;
+    int frame_c, frame_c0;
+    const float* frame_add;
+    long long frame_add_bs;
+    float* tok_grad;
+} dlwp_sfno_io_args;
+int dlwp_sfno_io_supported(int E, int in_chans, int out_chans);
+long long dlwp_sfno_io_image_elems(int E);
+int dlwp_sfno_io_pack(const float* enc_w1, const float* enc_w2, const float* dec_w1, const float* dec_w2, int E, int in_chans,
+                      int out_chans, int big_skip, void* images, void* stream);
+int dlwp_sfno_encode_fwd(const dlwp_sfno_io_args* args, void* stream);
+int dlwp_sfno_encode_bwd(const dlwp_sfno_io_args* args, void* stream);
+int dlwp_sfno_decode_fwd(const dlwp_sfno_io_args* args, void* stream);
+int dlwp_sfno_decode_bwd(const dlwp_sfno_io_args* args, void* stream);
 /* LayerNorm over the last dimension of x [T,C]; mean/rstd [T] are saved for backward.       */
 int dlwp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                        float* mean, float* rstd, int T, int C, float eps, void* stream);
