@@ -90,6 +90,9 @@ SIGNATURES = {
     "dlwp_sht_fused_supported": (_I, [_I] * 5),
     "dlwp_sht_analysis": (_I, [_V, _V, _V, _V] + [_I] * 6 + [_V]),
     "dlwp_sht_synthesis": (_I, [_V, _V, _V, _V] + [_I] * 6 + [_V]),
+    "dlwp_sht_bf16_supported": (_I, [_I] * 5),
+    "dlwp_sht_analysis_bf16": (_I, [_V, _V, _V, _V] + [_I] * 6 + [_V]),
+    "dlwp_sht_synthesis_bf16": (_I, [_V, _V, _V, _V, _V] + [_I] * 6 + [_V]),
     "dlwp_cweight_expand": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_cweight_fold": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_mlp_chain_supported": (_I, [_I, _I]),

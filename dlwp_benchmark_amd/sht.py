@@ -219,6 +219,76 @@ class _FusedSynthesis(torch.autograd.Function):
         return gX, None, None, None, None, None, None
 
 
+def _bf16_fused_ok(nlat, nlon, C, mmax, lmax):
+    """One-launch bf16 kernels (csrc/sht_bf16.hip) for the bf16-storage chain: x fp32 -> X bf16 and back.  C3 step at B = 4 with the
+    two table GEMMs per transform: 3.25 ms; DLWP_SHT_BF16=0 keeps the GEMMs (A/B runs)."""
+    if _chain_dtype() != torch.bfloat16 or os.environ.get("DLWP_SHT_BF16", "1") == "0":
+        return False
+    return L.load().dlwp_sht_bf16_supported(nlat, nlon, C, mmax, lmax) == 1
+
+
+class _Bf16Analysis(torch.autograd.Function):
+    """X (bf16) = analysis(x fp32; A1, A2) in one launch; backward = bf16 synthesis with the transposed tables, the skip gradient
+    of a forked input (fork=True returns (X, x)) added in its output stage."""
+
+    @staticmethod
+    def forward(ctx, x, mod, names, dims, fork):
+        x = x.contiguous().float()
+        B, K, N, C = x.shape
+        M, Lm = dims
+        bf = torch.bfloat16
+        X = torch.empty(Lm, B, M, 2, C, device=x.device, dtype=bf)
+        L.check(L.load().dlwp_sht_analysis_bf16(L.ptr(x), L.ptr(_table(mod, names[0], bf)), L.ptr(_table(mod, names[1], bf)), L.ptr(X),
+                                                B, K, N, C, M, Lm, L.stream()))
+        ctx.mod, ctx.names, ctx.shape, ctx.dims, ctx.fork = mod, names, (B, K, N, C), dims, bool(fork)
+        if fork:
+            return X, x.view_as(x)
+        return X
+
+    @staticmethod
+    def backward(ctx, gX, gskip=None):
+        B, K, N, C = ctx.shape
+        M, Lm = ctx.dims
+        bf = torch.bfloat16
+        gX = gX.contiguous()
+        if gX.dtype != bf:
+            gX = gX.to(bf)
+        if gskip is not None:
+            gskip = gskip.contiguous().float()
+        gx = torch.empty(B, K, N, C, device=gX.device)
+        L.check(L.load().dlwp_sht_synthesis_bf16(L.ptr(gX), L.ptr(_table(ctx.mod, ctx.names[2], bf)), L.ptr(_table(ctx.mod, ctx.names[3], bf)),
+                                                 L.ptr(gskip), L.ptr(gx), B, K, N, C, M, Lm, L.stream()))
+        return gx, None, None, None, None
+
+
+class _Bf16Synthesis(torch.autograd.Function):
+    """x (fp32) = synthesis(X bf16; S1t, S2) in one launch; backward = bf16 analysis with the transposed tables."""
+
+    @staticmethod
+    def forward(ctx, X, mod, names, grid):
+        bf = torch.bfloat16
+        X = X.contiguous()
+        if X.dtype != bf:
+            X = X.to(bf)
+        Lm, B, M, _, C = X.shape
+        K, N = grid
+        x = torch.empty(B, K, N, C, device=X.device)
+        L.check(L.load().dlwp_sht_synthesis_bf16(L.ptr(X), L.ptr(_table(mod, names[0], bf)), L.ptr(_table(mod, names[1], bf)), None,
+                                                 L.ptr(x), B, K, N, C, M, Lm, L.stream()))
+        ctx.mod, ctx.names, ctx.dims = mod, names, (B, K, N, C, M, Lm)
+        return x
+
+    @staticmethod
+    def backward(ctx, gx):
+        B, K, N, C, M, Lm = ctx.dims
+        bf = torch.bfloat16
+        gx = gx.contiguous().float()
+        gX = torch.empty(Lm, B, M, 2, C, device=gx.device, dtype=bf)
+        L.check(L.load().dlwp_sht_analysis_bf16(L.ptr(gx), L.ptr(_table(ctx.mod, ctx.names[2], bf)), L.ptr(_table(ctx.mod, ctx.names[3], bf)),
+                                                L.ptr(gX), B, K, N, C, M, Lm, L.stream()))
+        return gX, None, None, None
+
+
 class RealSHT(nn.Module):
     """x [B, nlat, nlon, C] -> X [lmax, B, mmax, 2, C] (re, im planes).  One fused launch where the shape fits
     (dlwp_sht_fused_supported), two strided-batched GEMMs otherwise; `fused=False` forces the GEMM path."""
@@ -241,6 +311,13 @@ class RealSHT(nn.Module):
         B, K, N, C = x.shape
         assert K == self.nlat and N == self.nlon, "input grid does not match the transform"
         M, Lm = self.mmax, self.lmax
+        if self.fused and x.is_cuda and x.dtype == torch.float32 and _bf16_fused_ok(K, N, C, M, Lm):
+            # forward tables A1 = dft, A2 = weights; backward (a synthesis) S1t = weights_t, S2 = dft_t
+            do_fork = bool(fork and x.requires_grad)
+            res = _Bf16Analysis.apply(x, self, ("dft", "weights", "weights_t", "dft_t"), (M, Lm), do_fork)
+            if do_fork:
+                return res                                   # (X, x again: its gradient joins inside the backward synthesis)
+            return (res, x) if fork else res
         if self.fused and x.is_cuda and _fused_ok(K, N, C, M, Lm):
             X = _FusedAnalysis.apply(x, self.dft, self.weights, self.weights_t, self.dft_t, M, Lm)
             return (X, x) if fork else X
@@ -276,6 +353,9 @@ class InverseRealSHT(nn.Module):
         Lm, B, M, _, C = X.shape
         assert Lm == self.lmax and M == self.mmax, "spectrum does not match the transform"
         K, N = self.nlat, self.nlon
+        if self.fused and X.is_cuda and X.dtype == torch.bfloat16 and _bf16_fused_ok(K, N, C, M, Lm):
+            # forward tables S1t = pct_t, S2 = idft; backward (an analysis) A1 = idft_t, A2 = pct
+            return _Bf16Synthesis.apply(X, self, ("pct_t", "idft", "idft_t", "pct"), (K, N))
         if self.fused and X.is_cuda and _fused_ok(K, N, C, M, Lm):
             return _FusedSynthesis.apply(X, self.pct_t, self.idft, self.idft_t, self.pct, K, N)
         leg = dict(M=K, N=2 * C, K=Lm, lda=K, tA=1, ldx=B * M * 2 * C, ldy=2 * M * C, nb1=B, nb2=M, sA=(0, Lm * K),

@@ -533,6 +533,17 @@ int dlwp_sht_analysis(const float* x, const float* A1, const float* A2, float* X
                       int nlon, int C, int mmax, int lmax, void* stream);
 int dlwp_sht_synthesis(const float* X, const float* S1t, const float* S2t, float* x, int B, int nlat,
                        int nlon, int C, int mmax, int lmax, void* stream);
+/* The same two transforms on the bf16 matrix cores for the bf16-storage chain (csrc/sht_bf16.hip): x fp32, X bf16, tables    */
+/* bf16 with the contraction index contiguous: analysis A1 [2 mmax][nlon], A2 [mmax][lmax][nlat]; synthesis S1t                */
+/* [mmax][nlat][lmax] (note: the TRANSPOSED Legendre table) and S2 [nlon][2 mmax] (NOT transposed); `residual` (nullable,     */
+/* x's layout) is added to the synthesised field (the skip gradient in the backward pass of a forked analysis).               */
+/* dlwp_sht_bf16_supported: C % 16 == 0, nlat / nlon / lmax / 2 mmax multiples of 8, nlat <= 64, nlon <= 128, lmax <= 64 and    */
+/* the spectrum image within the LDS; other shapes use dlwp_gemm_batched_mixed.                                               */
+int dlwp_sht_bf16_supported(int nlat, int nlon, int C, int mmax, int lmax);
+int dlwp_sht_analysis_bf16(const float* x, const void* A1, const void* A2, void* X, int B, int nlat, int nlon, int C, int mmax,
+                           int lmax, void* stream);
+int dlwp_sht_synthesis_bf16(const void* X, const void* S1t, const void* S2, const float* residual, float* x, int B, int nlat,
+                            int nlon, int C, int mmax, int lmax, void* stream);
 /* SFNO "driscoll-healy" spectral weights (torch_harmonics, constructed at                    */
 /* src/dlwpbench/models/fno/fno.py:183-200): w [Cin][Cout][L][2] complex, one matrix per       */
 /* degree l.  expand: wexp[l] = [[Wr, Wi], [-Wi, Wr]] as a real [2Cin][2Cout] matrix, so that   */

@@ -190,7 +190,8 @@ def test_sfno_train_step_with_bf16_storage_tracks_fp32_storage(cuda):
                 L.set_storage("fp32")
     f32 = torch.float32
     assert seen["fp32"] == {(f32, f32, f32)}
-    assert (BF, BF, BF) in seen["bf16"] and (BF, f32, BF) in seen["bf16"] and (BF, BF, f32) in seen["bf16"]
+    # the per-degree weight products run on bf16 arrays; the transforms themselves are the one-launch bf16 kernels (csrc/sht_bf16.hip)
+    assert (BF, BF, BF) in seen["bf16"]
     a, b = torch.tensor(losses["fp32"]), torch.tensor(losses["bf16"])
     assert a[-1] < a[0]
     assert ((a - b).abs() / a).max().item() < 3e-2, (losses["fp32"], losses["bf16"])

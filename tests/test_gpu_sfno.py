@@ -74,6 +74,53 @@ def test_fused_sht_kernels_equal_the_gemm_path(cuda, nlat, nlon, lmax, grid, B, 
         assert rel(a_, b_) <= 2e-5
 
 
+
+@pytest.mark.parametrize("nlat,nlon,lmax,grid,B,C", [(32, 64, 32, "equiangular", 4, 256), (32, 64, 32, "legendre-gauss", 2, 64),
+                                                      (24, 48, 16, "legendre-gauss", 3, 32), (40, 96, 24, "equiangular", 1, 16),
+                                                      (64, 128, 32, "legendre-gauss", 1, 48)])
+def test_bf16_fused_sht_kernels_equal_the_bf16_gemm_path(cuda, monkeypatch, nlat, nlon, lmax, grid, B, C):
+    """csrc/sht_bf16.hip (one launch per transform, bf16 MFMA, intermediate plane in LDS) against the two bf16 table GEMMs of the
+    same chain (bf16 operands + bf16 storage in both): analysis, synthesis, both backward passes and the forked-input skip
+    gradient; padded latitude / longitude / degree counts included.  Tolerance 1e-2 (bf16 rounding of the intermediate plane may
+    fall on either side), and 2e-2 against the float64 transform of the bf16-rounded input."""
+    from dlwp_benchmark_amd import lib as L, sht
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(B, nlat, nlon, C, generator=g).to(cuda)
+    gX = torch.randn(lmax, B, lmax, 2, C, generator=g).to(cuda)
+    gs = torch.randn(B, nlat, nlon, C, generator=g).to(cuda)
+    fwd = sht.RealSHT(nlat, nlon, lmax, lmax, grid).to(cuda)
+    inv = sht.InverseRealSHT(nlat, nlon, lmax, lmax, grid).to(cuda)
+    res = {}
+    with L.gemm_precision("bf16"):
+        L.set_storage("bf16")
+        L.SHADOW_ACTIVE = True
+        try:
+            assert L.load().dlwp_sht_bf16_supported(nlat, nlon, C, lmax, lmax) == 1
+            for mode in ("1", "0"):
+                monkeypatch.setenv("DLWP_SHT_BF16", mode)
+                xa = x.clone().requires_grad_(True)
+                X, skip = fwd(xa, fork=True)
+                assert X.dtype == torch.bfloat16
+                (X.float() * gX).sum().backward(retain_graph=True)
+                g_plain = xa.grad.clone()
+                xa.grad = None
+                ((X.float() * gX).sum() + (skip * gs).sum()).backward()
+                Xl = X.detach().clone().requires_grad_(True)
+                y = inv(Xl)
+                y.backward(gs)
+                res[mode] = (X.detach().float(), g_plain, xa.grad.clone(), y.detach(), Xl.grad.float())
+        finally:
+            L.SHADOW_ACTIVE = False
+            L.set_storage("fp32")
+    for i, (a, b) in enumerate(zip(res["1"], res["0"])):
+        assert rel(a, b) <= 1e-2, (i, rel(a, b))
+    assert rel(res["1"][2] - res["1"][1], gs) <= 1e-2          # the skip gradient arrives unchanged on top of the transform's
+    # float64 transform of the rounded input
+    o = sfno_ref.SHT(nlat, nlon, lmax, lmax, grid)
+    Xr = o.forward(x.cpu().to(torch.bfloat16).double().permute(0, 3, 1, 2))
+    assert rel(torch.view_as_real(spec_to_complex(res["1"][0]).contiguous()), torch.view_as_real(Xr)) <= 2e-2
+
+
 def test_dhconv_matches_einsum(cuda):
     from dlwp_benchmark_amd import sht
     g = torch.Generator().manual_seed(6)
