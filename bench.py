@@ -45,6 +45,13 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
                     "single-GPU functional test of the N>1 code path)")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (functional test only)")
+    ap.add_argument("--reduce", default="auto", choices=["auto", "flat", "in-graph", "bucketed"],
+                    help="gradient reduction of the sfno / pangu / swin / afno workloads at N > 1.  flat: the step stays a hipGraph -- "
+                         "forward + backward | ONE all-reduce of the flat gradient buffer (torch.distributed, RCCL) | optimizer; "
+                         "in-graph: the same with the all-reduce captured inside the graph through the C ABI's own RCCL communicator "
+                         "(dlwp_comm_allreduce); bucketed: eager step, buckets all-reduced from backward hooks while backward runs "
+                         "(overlap instead of capture).  auto (default) = by measurement on one card (profiles/r04_nograph_lines.jsonl): "
+                         "sfno loses 41 %% of its rate without the graph -> flat; pangu / swin / afno lose <= 1.5 %% -> bucketed")
     ap.add_argument("--workload", default="fno", choices=["fno", "sfno", "pangu", "swin", "afno", "afno721"],
                     help="fno: BASELINE configs[1] (default, the headline line); sfno: configs[2], dlwpbench SFNO2DModule 32x64, "
                          "5 prognostic variables, sfno.yaml widths, sequence length 5 (4 lead times); pangu / swin: configs[3] "
@@ -319,6 +326,54 @@ def sfno_gemm_probe(device, B, precision, reps=100, storage="fp32", shape=(32 * 
     return out
 
 
+def sfno_tail_probe(device, B, reps=100, tokens_per_sample=32 * 64, C=256, hidden=512):
+    """Dominant kernel family of the SFNO step since round 4 (rocprof: mlp_chain_kernel, forward + backward 22 % of the step): the
+    block tail's forward launch (dlwp_sfno_tail_fwd: inner skip + GELU + fc1 + GELU + fc2 + outer skip over B * 2048 tokens), timed
+    with HIP events on its launch stream.  Algorithmic bytes = x, y read and out written in fp32, the five bf16 tensors kept for the
+    backward pass (x copy, z0, t, z1, h) written once, the three weight matrices read once; flops = the three products."""
+    import ctypes as C_
+    import torch
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.token_ops import _TailFwdArgs
+    lib = L.load()
+    T, bf = B * tokens_per_sample, torch.bfloat16
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.randn(T, C, generator=g).to(device), torch.randn(T, C, generator=g).to(device)
+    ws, w1, w2 = ((torch.randn(r, c, generator=g) / c ** 0.5).to(device) for r, c in ((C, C), (hidden, C), (C, hidden)))
+    bs, b1, b2 = torch.zeros(C, device=device), torch.zeros(hidden, device=device), torch.zeros(C, device=device)
+    imgs = torch.empty(6, C * hidden, device=device, dtype=bf)
+    L.check(lib.dlwp_sfno_tail_pack(L.ptr(ws), L.ptr(w1), L.ptr(w2), C, hidden, L.ptr(imgs), L.stream()))
+    e = lambda n, dt=bf: torch.empty(T, n, device=device, dtype=dt)
+    x_lp, z0, t, z1, h, out = e(C), e(C), e(C), e(hidden), e(hidden), e(C, torch.float32)
+    a = _TailFwdArgs(L.ptr(x), L.ptr(y), L.ptr(imgs[0]), L.ptr(imgs[1]), L.ptr(imgs[2]), L.ptr(bs), L.ptr(b1), L.ptr(b2), L.ptr(x_lp),
+                     L.ptr(z0), L.ptr(t), L.ptr(z1), L.ptr(h), L.ptr(out), T, C, hidden, 1)
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        for _ in range(10):
+            L.check(lib.dlwp_sfno_tail_fwd(C_.byref(a), stream.cuda_stream))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(reps):
+            L.check(lib.dlwp_sfno_tail_fwd(C_.byref(a), stream.cuda_stream))
+        e1.record(stream)
+        torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    flops = 2.0 * T * (C * C + 2 * C * hidden)
+    nbytes = float(T * C * (4 + 4 + 4) + T * C * 2 * 3 + T * hidden * 2 * 2 + 2 * (C * C + 2 * C * hidden) + 4 * (2 * C + hidden))
+    peak = PEAK_MFMA_TF["bf16"]
+    f_mfma, f_hbm = flops / sec / 1e12 / peak, nbytes / sec / 1e9 / PEAK_HBM_GBS
+    out_ = {"bound": "mfma" if f_mfma >= f_hbm else "hbm",
+            "kernel": f"mlp_chain_kernel<{C}, {C}, {hidden}, {C}, 2, false> (dlwp_sfno_tail_fwd): the SFNO block tail's three dependent "
+                      f"products in one launch over {T} tokens, bf16 operands, fp32 accumulation",
+            "flops_per_launch": flops, "bytes_per_launch": nbytes, "us_per_launch": round(sec * 1e6, 3), "traffic": None,
+            "mfma": {"achieved": round(flops / sec / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(f_mfma, 4)},
+            "hbm": {"achieved": round(nbytes / sec / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(f_hbm, 4)}}
+    out_.update(out_[out_["bound"]])
+    return out_
+
+
 def sfno_cpu_baseline(B, budget_s):
     """oracle/sfno_ref.py (CPU restatement; torch-harmonics is not installable here: kind="port") on the host cores."""
     import torch
@@ -359,6 +414,26 @@ def main_sfno(args):
         print(json.dumps(line), flush=True)
 
 
+def rank_evidence(dist, device, backend, dt, steps):
+    """What lets the reader see that N ranks really formed one communicator and ran in step: world size and backend as
+    torch.distributed reports them, the RCCL version, one (host, device index, PCI bus id) per rank gathered THROUGH the
+    communicator, and every rank's own wall time per step (the line's ms_per_step is their maximum)."""
+    import socket
+    import torch
+    world = dist.get_world_size()
+    prop = torch.cuda.get_device_properties(device)
+    me = {"rank": dist.get_rank(), "host": socket.gethostname(), "device": device.index, "name": prop.name,
+          "pci_bus_id": getattr(prop, "pci_bus_id", None), "ms_per_step": round(dt / steps * 1e3, 4)}
+    box = [None] * world
+    dist.all_gather_object(box, me)
+    ver = None
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:          # noqa: BLE001 -- evidence only
+        pass
+    return {"backend": backend, "rccl_ranks": world if backend == "nccl" else 0, "world_size": world, "rccl_version": ver, "ranks": box}
+
+
 def run_dlwp(args, workload, steps, warmup, init_dist, roofline=True, cpu=True):
     """BASELINE configs[2] (sfno) and the supplementary configs[3] / [4] lines (pangu, swin, afno): one step = rollout + MSE +
     backward + all-reduce (N>1) + fused Adam through train_engine.GraphedTrainStep (captured in a hipGraph at N = 1 and for the
@@ -395,11 +470,24 @@ def run_dlwp(args, workload, steps, warmup, init_dist, roofline=True, cpu=True):
               prescribed=torch.randn(B, T, 1, H, W_, generator=g).to(device),
               prognostic=torch.randn(B, T, Cg, H, W_, generator=g).to(device))
     target = torch.randn(B, T - 1, Cg, H, W_, generator=g).to(device)
-    # 114-288 MB of gradients: overlap the reduction with backward (the reducer itself holds every bucket back for models whose
-    # gradient writes are deferred to the end of backward, e.g. SFNO's spectral weights: ddp.BucketedGradAllReduce.deferred)
-    bucketed = world > 1 and workload != "sfno"
+    # N > 1, measured on one card (profiles/r04_nograph_lines.jsonl): without the hipGraph the SFNO step (221 launches of ~14 us)
+    # drops from 1254 to 739 samples/s, so it keeps the capture and reduces the flat gradient buffer once between the two graph
+    # replays; the Pangu / Swin / AFNO steps (kernels of 20 - 300 us) lose <= 1.5 % run eagerly, so they take the bucketed reducer
+    # whose all-reduces overlap backward.  --reduce in-graph captures the collective itself (C ABI communicator).
+    reduce = args.reduce if world > 1 else "none"
+    if reduce == "auto":
+        reduce = "flat" if workload == "sfno" else "bucketed"
+    bucketed = reduce == "bucketed"
+    allreduce, comm = None, None
+    if reduce == "flat":
+        allreduce = ddp.FlatGradAllReduceChecked()
+    elif reduce == "in-graph":
+        if args.share_device:
+            raise SystemExit("--reduce in-graph needs one GPU per rank (RCCL refuses two ranks on one device)")
+        comm = ddp.RcclComm(rank, world)
+        allreduce = comm
     step = GraphedTrainStep(model, kw, target, lr=w.get("lr", 1e-3), use_graph=not args.no_graph and not bucketed,
-                            allreduce=ddp.FlatGradAllReduce() if (world > 1 and not bucketed) else None, grad_scale=1.0 / world)
+                            allreduce=allreduce, grad_scale=1.0 / world)
     if bucketed:
         step.allreduce = ddp.BucketedGradAllReduce(model, step.grad)
     ddp.broadcast_parameters(step.flat, src=0)
@@ -417,7 +505,9 @@ def run_dlwp(args, workload, steps, warmup, init_dist, roofline=True, cpu=True):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    evidence = None
     if world > 1:
+        evidence = rank_evidence(dist, device, args.backend, dt, steps)
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -433,14 +523,25 @@ def run_dlwp(args, workload, steps, warmup, init_dist, roofline=True, cpu=True):
                            "n_params": sum(p.numel() for p in model.parameters()),
                            "gemm_operands": precision, "storage": storage, "accumulate": "fp32", "parallelism": f"dp{world}",
                            "hip_graph": not args.no_graph and not bucketed,
-                           "grad_reduce": "bucketed, from backward hooks" if bucketed else ("flat" if world > 1 else "none")},
+                           "grad_reduce": {"none": "none", "flat": "one all-reduce of the flat gradient buffer between the graph replays",
+                                           "in-graph": "one all-reduce captured inside the step's graph (dlwp_comm_allreduce)",
+                                           "bucketed": "buckets from backward hooks, overlapped with backward (eager step)"}[reduce]},
                 "backbone_calls_per_s": round(world * B * steps * (T - 1) / dt, 1), "final_loss": loss.item()}
+        if bucketed:
+            line["config"]["buckets_overlapped"] = getattr(step.allreduce, "overlapped", None)
+        if evidence is not None:
+            line["ranks"] = evidence
         if world == 1 and not args.no_roofline and roofline:
-            line["roofline"] = sfno_gemm_probe(device, B, precision, storage=storage, shape=w["gemm"])
+            if workload == "sfno" and precision == "bf16" and storage == "bf16":
+                line["roofline"] = sfno_tail_probe(device, B)
+            else:
+                line["roofline"] = sfno_gemm_probe(device, B, precision, storage=storage, shape=w["gemm"])
         if world == 1 and not args.no_cpu_baseline and cpu and workload == "sfno":
             line["cpu_baseline"] = sfno_cpu_baseline(B, args.cpu_seconds)
         elif world == 1 and cpu:
             line["cpu_baseline"] = None       # a CPU step of the 28-72 M parameter models at these grids takes minutes: not sampled
+    if comm is not None:
+        comm.close()
     if world > 1 and init_dist:
         dist.destroy_process_group()
     return line
@@ -514,7 +615,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    evidence = None
     if world > 1:
+        evidence = rank_evidence(dist, device, args.backend, dt, args.steps)
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -536,6 +639,9 @@ def main():
             "backbone_calls_per_s": round(world * B * args.steps * ncalls / dt, 1),
             "final_loss": final_loss,
         }
+        if evidence is not None:
+            line["ranks"] = evidence
+            line["config"]["grad_reduce"] = "one all-reduce of the flat gradient buffer between the graph replays"
         if world == 1 and not args.no_roofline:
             line["roofline"] = roofline_probe(device, B)
             if w["hidden_channels"] <= 64:          # the fused lifting kernel exists for narrow layers only
@@ -548,9 +654,19 @@ def main():
             # configs[2] with its own roofline object (python bench.py --workload sfno prints the full line)
             del model, opt
             torch.cuda.empty_cache()
-            sec = run_dlwp(args, "sfno", steps=40, warmup=5, init_dist=False, cpu=False)
-            line["secondary"] = {k: sec[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config",
-                                                     "roofline") if k in sec}
+            from dlwp_benchmark_amd import lib as L
+            prev_precision, prev_storage = L.load().dlwp_get_gemm_precision(), ("bf16" if L.storage_bf16() else "fp32")
+            try:
+                sec = run_dlwp(args, "sfno", steps=40, warmup=5, init_dist=False, cpu=False)
+                line["secondary"] = {k: sec[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config",
+                                                         "roofline") if k in sec}
+            except Exception as exc:          # noqa: BLE001 -- the headline record above is measured: never lose it to the extra run
+                line["secondary"] = {"error": f"{type(exc).__name__}: {exc}"}
+            finally:
+                L.set_storage("fp32")
+                L.set_gemm_precision("bf16" if prev_precision == 1 else "fp32")
+                if prev_storage == "bf16" and prev_precision == 1:
+                    L.set_storage("bf16")
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

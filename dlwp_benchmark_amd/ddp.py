@@ -147,12 +147,14 @@ class BucketedGradAllReduce:
         assert all(a[1] == b[0] for a, b in zip(cover, cover[1:])) and (not cover or (cover[0][0] == 0 and cover[-1][1] == total)), \
             "buckets + leftover must tile the flat gradient buffer exactly once"
         # Gradients must be FINAL when a unit's backward hook fires.  Two paths break that: modules that defer a gradient
-        # write to the end of the backward pass (class attribute `deferred_grad_writes`, e.g. the SFNO spectral filter whose
-        # expanded-weight gradient is folded by an engine callback, sht._fold_pending), and micro-batch accumulation (later
-        # micro-batches add local gradients on top of an already reduced sum).  In both cases `hold` keeps every bucket
-        # back and finish() reduces the whole buffer once.
-        self.deferred = any(getattr(m, "deferred_grad_writes", False) for m in model.modules())
-        self.hold = self.deferred
+        # write to the end of the backward pass (class attribute `deferred_grad_writes`: a gradient folded by an engine
+        # callback) -- only the buckets that CONTAIN such a module wait for finish() -- and micro-batch accumulation (later
+        # micro-batches add local gradients on top of an already reduced sum): `hold` keeps every bucket back and finish()
+        # reduces the whole buffer once.
+        self._bucket_deferred = [any(getattr(m, "deferred_grad_writes", False) for u in bk["units"] for m in u.modules())
+                                 for bk in self.buckets]
+        self.deferred = any(self._bucket_deferred)
+        self.hold = False
         self._unit_bucket, self._fwd, self._bwd = {}, {}, {}
         self._handles, self._works = [], []
         for j, bk in enumerate(self.buckets):
@@ -165,10 +167,15 @@ class BucketedGradAllReduce:
 
     @staticmethod
     def _units(model):
+        """Direct children, ModuleLists / Sequentials expanded; a module may name its own units (`ddp_units()`: e.g. the rollout
+        wrapper SFNO2DModule, whose only child is the whole network, hands out the network's encoder layers, blocks and decoder
+        layers), which are then used as they are."""
         import torch.nn as nn
+        if hasattr(model, "ddp_units"):
+            return list(model.ddp_units())
         out = []
         for child in model.children():
-            if isinstance(child, (nn.ModuleList, nn.Sequential)):
+            if isinstance(child, (nn.ModuleList, nn.Sequential)) or hasattr(child, "ddp_units"):
                 out.extend(BucketedGradAllReduce._units(child))
             else:
                 out.append(child)
@@ -186,7 +193,7 @@ class BucketedGradAllReduce:
         self._bwd[k] += 1
         j = self._unit_bucket[k]
         units = self.buckets[j]["units"]        # a unit the forward pass never entered (fwd == 0) receives no gradient at all
-        if not self.hold and not self._done[j] and all(self._bwd[id(u)] >= self._fwd[id(u)] for u in units):
+        if not self.hold and not self._bucket_deferred[j] and not self._done[j] and all(self._bwd[id(u)] >= self._fwd[id(u)] for u in units):
             self._launch(self.buckets[j]["lo"], self.buckets[j]["hi"])
             self._done[j] = True
 
@@ -201,7 +208,7 @@ class BucketedGradAllReduce:
     def finish(self):
         """Reduce what no hook released, wait for every reduction, reset the counters.  Returns Adam's scale 1 / world."""
         self.overlapped = sum(self._done)             # buckets that went out during backward (diagnostics / tests)
-        self.hold = self.deferred                     # a micro-batch hold ends with the reduction
+        self.hold = False                             # a micro-batch hold ends with the reduction
         for j, bk in enumerate(self.buckets):
             if not self._done[j]:
                 self._launch(bk["lo"], bk["hi"])
@@ -230,7 +237,11 @@ class BucketedGradAllReduce:
 class RcclComm:
     """The C ABI's own RCCL communicator (include/dlwpmi.h: dlwp_comm_*), for hosts that do not route the exchange through
     torch.distributed.  The 128-byte unique id travels over whatever side channel the host has; here: an already initialised
-    torch.distributed group of ANY backend (gloo is enough) or, at world 1, nothing at all."""
+    torch.distributed group of ANY backend (gloo is enough) or, at world 1, nothing at all.
+    `in_graph = True`: train_engine.GraphedTrainStep captures the all-reduce inside the step's hipGraph (the call only enqueues
+    ncclAllReduce on the current stream)."""
+
+    in_graph = True
 
     def __init__(self, rank=0, world=1, group=None):
         import ctypes as C

@@ -128,6 +128,11 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         self.decoder = nn.ModuleList([Conv1x1(embed_dim + self.big_skip * in_chans, embed_dim), nn.GELU(),
                                       Conv1x1(embed_dim, out_chans, bias=False)])
 
+    def ddp_units(self):
+        """Units of the bucketed gradient reducer (ddp.BucketedGradAllReduce): the encoder layers, every block, the decoder layers
+        (the position embedding belongs to none and is reduced by finish())."""
+        return [m for m in list(self.encoder) + list(self.blocks) + list(self.decoder) if any(True for _ in m.parameters())]
+
     def forward_frames(self, sources, frame_index=None, residual=False):
         """The network on an input given as plane groups ([B, c_i, H, W] each, at most three, in channel order) through the
         one-launch encoder / decoder kernels (sfno_ops): no concatenated / padded / permuted copy of the input exists.
@@ -202,6 +207,9 @@ class SFNO2DModule(nn.Module):
                 return rollout(self.sfno, self.context_size, constants, prescribed, prognostic)
             finally:
                 self.sfno._wpad_cache = None
+
+    def ddp_units(self):
+        return self.sfno.ddp_units()
 
     def _rollout_frames(self, constants, prescribed, prognostic):
         """The loop of rollout.py at context_size 1 without any assembled input tensor: out_t = frame + net(constants[:, 0],

@@ -83,6 +83,9 @@ class GraphedTrainStep:
     inputs/target given at construction fix the shapes; `__call__(inputs, target)` copies a new batch into the
     static buffers and replays.  With `allreduce` (ddp.FlatGradAllReduce) the capture is split into
     forward+backward | all-reduce (eager, RCCL) | optimizer so that the collective stays outside the graph.
+    A reducer with `in_graph = True` (ddp.RcclComm: the C ABI's communicator enqueues ncclAllReduce on the caller's stream,
+    which RCCL allows under stream capture) is captured INSIDE the one graph, between backward and the optimizer: a replay
+    is then the whole data-parallel step.
     """
 
     def __init__(self, model, inputs, target, lr=1e-3, clip_max_norm=None, allreduce=None, grad_scale=1.0,
@@ -99,6 +102,7 @@ class GraphedTrainStep:
         self.call = call or (lambda m, kw: m(**kw))
         self.loss = torch.zeros((), device=self.flat.device)
         self.use_graph = use_graph
+        self.collective_in_graph = False
         # graph_optimizer=False keeps clip + Adam outside the capture (two eager launches): the learning rate and the clip
         # threshold are launch arguments, so a schedule that changes them per epoch needs them re-read at every step
         self.graph_optimizer = graph_optimizer
@@ -135,11 +139,14 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.flat.copy_(flat0)
         self.g_fb = torch.cuda.CUDAGraph()
+        self.collective_in_graph = bool(getattr(self.allreduce, "in_graph", False)) and self.graph_optimizer
         with torch.cuda.graph(self.g_fb):
             self._fwd_bwd()
-            if self.allreduce is None and self.graph_optimizer:
+            if self.collective_in_graph:
+                self.allreduce(self.grad)
+            if (self.allreduce is None or self.collective_in_graph) and self.graph_optimizer:
                 self._optimize()
-        if self.allreduce is not None and self.graph_optimizer:
+        if self.allreduce is not None and self.graph_optimizer and not self.collective_in_graph:
             self.g_opt = torch.cuda.CUDAGraph()
             pool = self.g_fb.pool()
             with torch.cuda.graph(self.g_opt, pool=pool):
@@ -185,6 +192,8 @@ class GraphedTrainStep:
             self._optimize()
             return self.loss
         self.g_fb.replay()
+        if getattr(self, "collective_in_graph", False):
+            return self.loss
         if self.allreduce is not None:
             self.allreduce(self.grad)
         if self.g_opt is not None:

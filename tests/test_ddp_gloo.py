@@ -196,7 +196,7 @@ def test_bucketed_reducer_keeps_only_spans_disjoint_from_kept_ones_and_tiles_the
     assert cover[0][0] == 0 and cover[-1][1] == flat.numel() and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
 
 
-def test_bucketed_reducer_holds_every_bucket_for_deferred_gradient_writes_and_for_micro_batches():
+def test_bucketed_reducer_holds_deferred_buckets_only_and_every_bucket_for_micro_batches():
     x = torch.ones(3, requires_grad=True)
     net, flat = _flat_model()
     red = ddp.BucketedGradAllReduce(net, flat, bucket_bytes=1)
@@ -209,10 +209,35 @@ def test_bucketed_reducer_holds_every_bucket_for_deferred_gradient_writes_and_fo
     assert sum(red._done) == 0
     red.finish()
     assert red.overlapped == 0 and red.hold is False       # the hold ends with the reduction
+    # a module that writes its gradient after its backward hook (deferred_grad_writes) keeps ITS bucket for finish(); the
+    # other buckets still leave during backward
     net2, flat2 = _flat_model(deferred=True)
     red2 = ddp.BucketedGradAllReduce(net2, flat2, bucket_bytes=1)
-    assert red2.deferred and red2.hold
+    assert red2.deferred and not red2.hold and red2._bucket_deferred == [False, True, False]
     net2(x).sum().backward()
-    assert sum(red2._done) == 0
+    assert red2._done == [True, False, True]               # a and c left during backward, b (deferred) waits for finish()
     red2.finish()
-    assert red2.hold                                       # permanent for such models
+    assert red2.overlapped == 2 and not red2.hold
+
+
+def test_ddp_units_hook_replaces_the_child_walk():
+    """A rollout wrapper whose only child is the whole network hands out finer units (ddp_units): they become the buckets."""
+    import torch.nn as nn
+    net, flat = _flat_model()
+
+    class Wrapper(nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def ddp_units(self):
+            return [self.inner.a, self.inner.b, self.inner.c]
+
+        def forward(self, x):
+            return self.inner(x)
+    w = Wrapper(net)
+    red = ddp.BucketedGradAllReduce(w, flat, bucket_bytes=1)
+    assert [(b["lo"], b["hi"]) for b in red.buckets] == [(0, 100), (100, 110), (110, 120)]
+    w(torch.ones(3, requires_grad=True)).sum().backward()
+    assert sum(red._done) == 3                             # every unit's backward hook fired on exit (the input needs a gradient)
+    red.finish()

@@ -119,8 +119,46 @@ def test_bench_n_greater_than_one_branch_runs_as_two_ranks(cuda):
     assert line["config"]["global_batch"] == 2 * line["config"]["per_gpu_batch"] and line["config"]["parallelism"] == "dp2"
     assert abs(line["value"] - 2 * line["config"]["per_gpu_batch"] * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-2 * line["value"]
     assert "secondary" not in line and "roofline" not in line
-    # the autograd-driven models' branch (bucketed reducer from backward hooks; SFNO: held buckets)
+    # rank evidence gathered through the communicator: both ranks, each with its own step time (the line's is their maximum)
+    ev = line["ranks"]
+    assert ev["world_size"] == 2 and sorted(r["rank"] for r in ev["ranks"]) == [0, 1] and ev["backend"] == "gloo"
+    assert max(r["ms_per_step"] for r in ev["ranks"]) <= line["ms_per_step"] * 1.05 + 0.05
+    # the autograd-driven models' branch: the step stays a hipGraph at N > 1 (forward + backward | flat all-reduce | optimizer)
     outs = _run_ranks([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "2",
                        "--warmup", "1", "--workload", "sfno", "--no-cpu-baseline", "--no-roofline"], 29585)
     line = json.loads([l for l in outs[0].splitlines() if l.startswith("{")][0])
-    assert line["n_gpus"] == 2 and line["config"]["grad_reduce"] == "flat" and line["value"] > 0
+    assert line["n_gpus"] == 2 and line["config"]["hip_graph"] and "flat gradient buffer" in line["config"]["grad_reduce"]
+    assert line["value"] > 0 and line["ranks"]["world_size"] == 2
+    # ... and the eager variant with the reduction overlapped with backward: SFNO's units are its encoder layers, blocks and
+    # decoder layers (ddp_units); the blocks that hold a spectral filter wait for finish() (deferred gradient fold)
+    outs = _run_ranks([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "2",
+                       "--warmup", "1", "--workload", "sfno", "--reduce", "bucketed", "--no-cpu-baseline", "--no-roofline"], 29587)
+    line = json.loads([l for l in outs[0].splitlines() if l.startswith("{")][0])
+    assert line["n_gpus"] == 2 and not line["config"]["hip_graph"] and line["value"] > 0
+
+
+def test_collective_captured_inside_the_step_graph_at_world_one(cuda):
+    """GraphedTrainStep with the C ABI's RCCL communicator (ddp.RcclComm.in_graph): ncclAllReduce is captured between backward and
+    the optimizer; ten replays train exactly like the graph without a collective (at world 1 the sum over ranks is the identity)."""
+    import torch
+    from dlwp_benchmark_amd import ddp, nsbench
+    from dlwp_benchmark_amd.train_engine import GraphedTrainStep
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 5, 1, 16, 16, generator=g).to(cuda)
+    y = torch.randn(2, 5, 1, 16, 16, generator=g).to(cuda)
+    runs = {}
+    for name in ("plain", "in_graph"):
+        torch.manual_seed(11)
+        m = nsbench.AFNONet(img_height=16, img_width=16, patch_size=(2, 2), in_chans=1, out_chans=1, embed_dim=32, depth=2,
+                            mlp_ratio=2.0, num_blocks=4, context_size=2).to(cuda).train()
+        comm = ddp.RcclComm(0, 1) if name == "in_graph" else None
+        step = GraphedTrainStep(m, {"x": x}, y, lr=1e-3, allreduce=comm, call=lambda mod, kw: mod(kw["x"], 2))
+        assert step.collective_in_graph == (name == "in_graph")
+        losses = [step().item() for _ in range(10)]
+        runs[name] = (losses, step.flat.clone())
+        if comm is not None:
+            comm.close()
+    # (not bit for bit: the weight-gradient float atomics of these small products add in a run-dependent order)
+    a, b = torch.tensor(runs["plain"][0]), torch.tensor(runs["in_graph"][0])
+    assert a[-1] < a[0] and ((a - b).abs() / a).max().item() < 1e-4
+    assert ((runs["plain"][1] - runs["in_graph"][1]).abs().max() / runs["plain"][1].abs().max()).item() < 1e-3
