@@ -18,6 +18,7 @@
 // combined with float atomics into a zeroed C.
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include "common.cuh"
 #include "dlwpmi_internal.h"
 
@@ -934,23 +935,31 @@ __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float* __re
     }
 }
 
-// scratch for the slices: one per device context, grown outside stream captures only (a capture that would need a larger one
-// keeps the atomic epilogue).  As with dlwp_sumsq's partials, calls on different streams at the same time would share it: the
-// training paths issue their GEMMs on one stream (the warm-up steps before a graph capture size it).
-static float* g_tn_slab = nullptr;
-static size_t g_tn_slab_bytes = 0;
+// Scratch for the slices of the sliced weight-gradient kernel.  One slab per DEVICE, grow-only and never freed: a hipGraph captured
+// earlier keeps the pointer it was captured with, so a slab that was handed out once must stay valid for the life of the
+// process (the round-3 version freed and re-allocated it when a later, larger product came along, behind a
+// hipDeviceSynchronize -- a replay of an older graph then wrote into freed memory).  Growing allocates a NEW block (outside
+// stream captures only; a capture that would need a larger one keeps the float-atomic epilogue) and leaves the old ones
+// alone; at most log2(largest / smallest) blocks exist per device.  No synchronisation, nothing is ever released.
+// As with dlwp_sumsq's partials, calls on different streams of one device at the same time would share the slab: the training
+// paths issue their GEMMs on one stream.  dlwp_wgrad_segments (csrc/wgrad_multi.hip) takes its slab from the caller instead.
+struct TnSlab { float* p = nullptr; size_t bytes = 0; };
+static TnSlab g_tn_slabs[64];                              // indexed by device ordinal
+static std::mutex g_tn_slab_mutex;
 static float* tn_slab_for(hipStream_t s, size_t bytes) {
-    if (g_tn_slab && g_tn_slab_bytes >= bytes) return g_tn_slab;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(g_tn_slab_mutex);
+    TnSlab& slab = g_tn_slabs[dev];
+    if (slab.p && slab.bytes >= bytes) return slab.p;
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
-    if (g_tn_slab) {
-        if (hipDeviceSynchronize() != hipSuccess || hipFree(g_tn_slab) != hipSuccess) return nullptr;
-        g_tn_slab = nullptr;
-        g_tn_slab_bytes = 0;
-    }
-    if (hipMalloc(reinterpret_cast<void**>(&g_tn_slab), bytes) != hipSuccess) { (void)hipGetLastError(); g_tn_slab = nullptr; return nullptr; }
-    g_tn_slab_bytes = bytes;
-    return g_tn_slab;
+    const size_t want = std::max(bytes, 2 * slab.bytes);   // geometric growth bounds the number of retired blocks
+    float* p = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&p), want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    slab.p = p;                                            // the previous block (if any) stays allocated: graphs may hold it
+    slab.bytes = want;
+    return p;
 }
 
 // weight-gradient products the TN kernel takes: both operands bf16 arrays [k][row], fp32 output, no epilogue, one batch, the
@@ -1541,7 +1550,7 @@ static bool gemm_p8_applies(const GemmDev& a, bool akc, bool bkc) {
 // up to three parked products as ONE grid (gemm_group_any_kernel).  Everything else launches at once, as usual -- the products
 // inside a begin / end pair must not depend on each other.
 struct GemmQueue { bool open = false; int n = 0; GemmGroupAny gg; };
-static GemmQueue g_queue;
+static thread_local GemmQueue g_queue;      // per host thread: a backward pass on another autograd thread has its own (empty) queue
 static int gemm_queue_flush(hipStream_t s) {
     GemmQueue& q = g_queue;
     if (q.n == 0) return DLWP_OK;

@@ -337,8 +337,10 @@ extern "C" int dlwp_sumsq(const float* g, long long n, float* out, void* stream)
     DLWP_REQUIRE(g && out && n >= 0, DLWP_E_INVALID, "sumsq: NULL argument");
     if (n == 0) return DLWP_OK;
     const int blocks = std::min(stream_grid(n / 4 + 1), SUMSQ_MAX_BLOCKS);
-    static float* scratch = nullptr;                 // resolved once (never inside a stream capture after the first call)
-    if (!scratch) DLWP_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&scratch), HIP_SYMBOL(g_sumsq_partial)));
+    // the scratch is a __device__ array of the code object: its address is per device, so it is resolved on every call for the
+    // CURRENT device (hipGetSymbolAddress enqueues nothing: safe under stream capture)
+    float* scratch = nullptr;
+    DLWP_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&scratch), HIP_SYMBOL(g_sumsq_partial)));
     hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, scratch);
     hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, blocks, out);
     DLWP_LAUNCH_CHECK();

@@ -41,7 +41,10 @@ class _WindowAttnFn(torch.autograd.Function):
         table_param, table = table, table.contiguous()
         TB = table.shape[0]
         ntypes = table.shape[1] if table.dim() == 3 else 1
-        out = torch.empty(B_, N, heads * d, device=qkv.device)
+        # with a query range the kernels leave the rows outside it unwritten: they must read as zeros (the backward pass forms
+        # g * o on every row, and 0 * uninitialised bits may be NaN)
+        full = ctx.qrange == (0, N)
+        out = (torch.empty if full else torch.zeros)(B_, N, heads * d, device=qkv.device)
         ctx.aux, ctx.cfg = (ia, ib, labels), (B_, nW, N, TB, ntypes, heads, d, scale)
         ctx.tslot = _grad_slot(table_param)
         ctx.wide = d > 64
@@ -58,7 +61,7 @@ class _WindowAttnFn(torch.autograd.Function):
                           oB=2 * hd)                                               # o = p v
             ctx.save_for_backward(qkv, table, p)
             return out
-        lse = torch.empty(B_, heads, N, device=qkv.device)
+        lse = (torch.empty if full else torch.zeros)(B_, heads, N, device=qkv.device)
         # earth-specific tables ([TB, types, heads]): one transposed copy per call, so that the workgroups read their
         # (type, head) slice contiguously instead of one cache line per entry
         packed = None

@@ -14,7 +14,14 @@
  *     synchronisation (graph-capture safe) unless a function says otherwise;
  *   - return 0 on success, negative DLWP_E_* on failure; dlwp_last_error() gives the
  *     thread-local message;
- *   - all arithmetic is IEEE fp32 (exact-f32 MFMA), matching the reference's fp32 path.
+ *   - arithmetic: IEEE fp32 on the exact-f32 MFMA by default (the reference's fp32 path: the FNO rollout kernels, the GEMMs
+ *     under dlwp_set_gemm_precision(0), the FFT and SHT kernels without a _bf16 suffix); bf16 OPERANDS with fp32 accumulation,
+ *     epilogues and statistics where the reference trains under bf16 autocast (BASELINE configs C3-C5): dlwp_set_gemm_precision(1),
+ *     the *_mixed GEMM entries (bf16 arrays in HBM), and the entry points that say so (dlwp_sfno_tail_*, dlwp_sfno_encode_* /
+ *     _decode_*, dlwp_sht_*_bf16, dlwp_wgrad_segments);
+ *   - scratch: entry points that need a workspace take it from the caller (dlwp_*_workspace_bytes + a pointer).  Two older ones
+ *     keep a library-owned slab per device instead (the sliced weight-gradient GEMM, dlwp_sumsq's partials): grow-only,
+ *     allocated outside stream captures only, never freed or re-used for anything else while the process lives.
  */
 #ifndef DLWPMI_H
 #define DLWPMI_H
@@ -473,7 +480,9 @@ int dlwp_wgrad_segments(const dlwp_wgrad_seg_product* products, int nprod, int n
 /* Any INDEPENDENT small products: between _begin and _end, the dlwp_gemm* entries park products that fit the generic 64 x 64 kernel   */
 /* and are small (<= 16384 deep, latency-bound by themselves); _end launches up to three of them as one grid.  Everything else      */
 /* launches at once.  Used around the two gradient products of a Linear layer's backward pass (gx = g W and gW = g^T x read the     */
-/* same g and do not depend on each other).  One group per thread of control; not reentrant.                                        */
+/* same g and do not depend on each other).  One group per HOST THREAD (thread-local queue); not reentrant.  Contract: between       */
+/* _begin and _end the caller issues no kernel that depends on a parked product's output, and keeps every operand of a parked        */
+/* product alive and unmodified until _end returns (the launches happen there).                                                      */
 int dlwp_gemm_group_begin(void);
 int dlwp_gemm_group_end(void* stream);
 
