@@ -28,9 +28,16 @@ class _SpectralFilter(nn.Module):
     """SHT -> per-degree complex weight ("bixy,iox->boxy") -> inverse SHT; also returns the residual on the output
     grid (the input itself when both grids have the same size)."""
 
-    # the weight gradient reaches the flat buffer in an end-of-backward engine callback (sht._fold_pending), i.e. AFTER this
-    # module's backward hook: a bucketed gradient reducer must not release it early (ddp.BucketedGradAllReduce.deferred)
-    deferred_grad_writes = True
+    @property
+    def deferred_grad_writes(self):
+        """On the GEMM path the weight gradient reaches the flat buffer in an end-of-backward engine callback (sht._fold_pending),
+        i.e. AFTER this module's backward hook: a bucketed gradient reducer must not release its bucket early
+        (ddp.BucketedGradAllReduce).  The bf16 kernels (csrc/dhconv.hip) write it inside the block's last backward pass."""
+        from ..sht import DHCONV_NATIVE, _chain_dtype
+        from .. import lib as L
+        w = self.weight
+        return not (DHCONV_NATIVE and w.is_cuda and (L.storage_bf16() and _chain_dtype() is not None and L.storage_bf16())
+                    and L.load().dlwp_dhconv_supported(w.shape[0], w.shape[1], w.shape[2]) == 1)
 
     def __init__(self, forward_transform, inverse_transform, in_channels, out_channels, gain=2.0):
         super().__init__()
@@ -45,7 +52,7 @@ class _SpectralFilter(nn.Module):
             residual = self.inv(X)
         else:
             X, residual = self.fwd(x, fork=True)      # x again: the skip's gradient joins inside the transform's backward GEMM
-        return self.inv(dhconv(X, self.weight)), residual
+        return self.inv(dhconv(X, self.weight, triangular=True)), residual      # RealSHT output: orders m > l are exactly zero
 
 
 class _MLP(nn.Module):

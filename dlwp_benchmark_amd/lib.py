@@ -95,6 +95,12 @@ SIGNATURES = {
     "dlwp_sht_synthesis_bf16": (_I, [_V, _V, _V, _V, _V] + [_I] * 6 + [_V]),
     "dlwp_cweight_expand": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_cweight_fold": (_I, [_V, _V, _I, _I, _I, _V]),
+    "dlwp_dhconv_supported": (_I, [_I, _I, _I]),
+    "dlwp_dhconv_image_elems": (_L, [_I, _I, _I]),
+    "dlwp_dhconv_pack": (_I, [_V, _V, _V, _I, _I, _I, _V]),
+    "dlwp_dhconv_apply": (_I, [_V, _V, _V, _I, _I, _I, _I, _I, _I, _V]),
+    "dlwp_dhconv_wgrad": (_I, [_V, _V, _I, _V, _I, _I, _I, _I, _I, _V]),
+    "dlwp_dhconv_fold": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_mlp_chain_supported": (_I, [_I, _I]),
     "dlwp_mlp_chain_pack": (_I, [_V, _I, _I, _I, _V, _V]),
     "dlwp_sfno_tail_pack": (_I, [_V, _V, _V, _I, _I, _V, _V]),

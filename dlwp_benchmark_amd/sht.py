@@ -464,5 +464,82 @@ class _DHConvFn(torch.autograd.Function):
         return gX, gw
 
 
-def dhconv(X, w):
+DHCONV_NATIVE = os.environ.get("DLWP_DHCONV_NATIVE", "1") != "0"      # env: A/B runs against the expanded-image GEMMs
+
+
+def _dh_state(w):
+    """Per rollout pass (spectral_weight_scope): the two fragment-order images of a spectral weight and the list that collects
+    the lead times' (X, gY) pairs for the one weight-gradient product of the pass."""
+    key = ("dhconv", id(w))
+    if _wexp_scope is not None and key in _wexp_scope:
+        return _wexp_scope[key][0]
+    lib = L.load()
+    Cin, Cout, Lm, _ = w.shape
+    n = lib.dlwp_dhconv_image_elems(Cin, Cout, Lm)
+    imgs = torch.empty(2, n, device=w.device, dtype=torch.bfloat16)
+    L.check(lib.dlwp_dhconv_pack(L.ptr(w.detach().contiguous()), L.ptr(imgs[0]), L.ptr(imgs[1]), Cin, Cout, Lm, L.stream()))
+    st = {"imgs": imgs, "uses": 0, "pending": []}
+    if _wexp_scope is not None:
+        _wexp_scope[key] = (st, w)
+    return st
+
+
+class _DHConvNativeFn(torch.autograd.Function):
+    """dhconv on csrc/dhconv.hip (bf16 spectra): forward and input gradient one launch each on the un-expanded weight images; the
+    weight gradient of ALL lead times of a pass as one product per degree, launched by the last backward pass through the weight
+    and folded straight into the parameter's gradient."""
+
+    @staticmethod
+    def applies(X, w):
+        return (DHCONV_NATIVE and X.is_cuda and X.dtype == torch.bfloat16 and _chain_dtype() == torch.bfloat16
+                and L.load().dlwp_dhconv_supported(w.shape[0], w.shape[1], w.shape[2]) == 1)
+
+    @staticmethod
+    def forward(ctx, X, w, triangular):
+        Lm, B, M, _, Cin = X.shape
+        Cout = w.shape[1]
+        assert w.shape == (Cin, Cout, Lm, 2), f"weight {tuple(w.shape)} does not match spectrum {tuple(X.shape)}"
+        X = X.contiguous()
+        st = _dh_state(w)
+        Y = torch.empty(Lm, B, M, 2, Cout, device=X.device, dtype=torch.bfloat16)
+        ctx.mm = M if triangular else 0                     # orders m > l known to be zero: skipped (and produced as zeros)
+        L.check(L.load().dlwp_dhconv_apply(L.ptr(X), L.ptr(st["imgs"][0]), L.ptr(Y), Lm, B * M * 2, Cin, Cout, ctx.mm, 0, L.stream()))
+        ctx.save_for_backward(X)
+        if any(ctx.needs_input_grad):
+            st["uses"] += 1
+        ctx.st, ctx.wslot, ctx.wshape = st, _grad_slot(w), w.shape
+        return Y
+
+    @staticmethod
+    def backward(ctx, gY):
+        import ctypes as C
+        lib = L.load()
+        (X,) = ctx.saved_tensors
+        Lm, B, M, _, Cin = X.shape
+        Cout = ctx.wshape[1]
+        st = ctx.st
+        gY = gY.contiguous()
+        if gY.dtype != torch.bfloat16:
+            gY = gY.to(torch.bfloat16)
+        gX = torch.empty_like(X)
+        L.check(lib.dlwp_dhconv_apply(L.ptr(gY), L.ptr(st["imgs"][1]), L.ptr(gX), Lm, B * M * 2, Cout, Cin, ctx.mm, 1, L.stream()))
+        st["pending"].append((X, gY))
+        st["uses"] -= 1
+        if st["uses"] > 0 and len(st["pending"]) < 8:
+            return gX, None, None
+        segs, st["pending"] = st["pending"], []
+        xs = (C.c_void_p * len(segs))(*[L.ptr(a) for a, _ in segs])
+        gs = (C.c_void_p * len(segs))(*[L.ptr(b) for _, b in segs])
+        G = torch.empty(Lm, Cin, 2 * Cout, device=X.device)
+        L.check(lib.dlwp_dhconv_wgrad(xs, gs, len(segs), L.ptr(G), Lm, B * M * 2, Cin, Cout, ctx.mm, L.stream()))
+        gw = ctx.wslot if ctx.wslot is not None else torch.zeros(ctx.wshape, device=X.device)
+        L.check(lib.dlwp_dhconv_fold(L.ptr(G), L.ptr(gw), Cin, Cout, Lm, L.stream()))
+        return gX, (None if ctx.wslot is not None else gw), None
+
+
+def dhconv(X, w, triangular=False):
+    """Y[l, b, m, :, o] = sum_i X[l, b, m, :, i] * w[i, o, l] (complex).  triangular=True: the caller guarantees X[l, :, m] = 0 for
+    m > l (a spectrum produced by RealSHT; likewise its gradient) -- the bf16 kernels then skip those orders."""
+    if _DHConvNativeFn.applies(X, w):
+        return _DHConvNativeFn.apply(X, w, bool(triangular))
     return _DHConvFn.apply(X, w)

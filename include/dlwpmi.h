@@ -560,6 +560,26 @@ int dlwp_sht_synthesis_bf16(const void* X, const void* S1t, const void* S2, cons
 /* [Xr | Xi]; fold: gw += the complex gradient read back from the [L][2Cin][2Cout] GEMM result. */
 int dlwp_cweight_expand(const float* w, float* wexp, int Cin, int Cout, int L, void* stream);
 int dlwp_cweight_fold(const float* gexp, float* gw, int Cin, int Cout, int L, void* stream);
+/* The same contraction as dedicated bf16 kernels on spectra X [L][rows][C] whose rows are (sample, order, re | im) -- the        */
+/* (re, im) parts of a complex row are two consecutive rows -- without the expanded image (csrc/dhconv.hip):                    */
+/*   dlwp_dhconv_pack   w [Cin][Cout][L][2] fp32 -> the forward and the backward fragment-order bf16 images                      */
+/*                      (dlwp_dhconv_image_elems(Cin, Cout, L) elements each)                                                   */
+/*   dlwp_dhconv_apply  Y[l] = X[l] W[:, :, l] (transposed = 0, forward image, K = Cin, N = Cout) or                            */
+/*                      gX[l] = gY[l] conj(W[:, :, l])^T (transposed = 1, backward image, K = Cout, N = Cin); `rows` = B * mmax * 2; */
+/*                      mmax > 0: a sample's rows are its orders 0 .. mmax - 1 and orders m > l are KNOWN to be zero (spectra  */
+/*                      of the SHT): those row tiles are skipped and written as zeros; mmax = 0: dense rows                     */
+/*   dlwp_dhconv_wgrad  G [L][Cin][2 Cout] fp32 = sum over nseg (X, gY) pairs (the lead times of a rollout) of conj(X)^T gY     */
+/*                      per degree, real parts in columns [0, Cout), imaginary parts in [Cout, 2 Cout) (overwritten)           */
+/*   dlwp_dhconv_fold   gw [Cin][Cout][L][2] += G                                                                               */
+/* dlwp_dhconv_supported: Cin, Cout in {128, 256}, L <= 64; other widths use dlwp_cweight_expand + dlwp_gemm_batched_mixed.       */
+int dlwp_dhconv_supported(int Cin, int Cout, int L);
+long long dlwp_dhconv_image_elems(int Cin, int Cout, int L);
+int dlwp_dhconv_pack(const float* w, void* fwd_img, void* bwd_img, int Cin, int Cout, int L, void* stream);
+int dlwp_dhconv_apply(const void* X, const void* image, void* Y, int L, int rows, int K, int N, int mmax, int transposed,
+                      void* stream);
+int dlwp_dhconv_wgrad(const void* const* X, const void* const* gY, int nseg, float* G, int L, int rows, int Cin, int Cout,
+                      int mmax, void* stream);
+int dlwp_dhconv_fold(const float* G, float* gw, int Cin, int Cout, int L, void* stream);
 /* The tail of an SFNO block as ONE launch per direction (csrc/mlp_chain.hip; the block is      */
 /* torch_harmonics' SphericalFourierNeuralOperatorBlock, constructed at                         */
 /* src/dlwpbench/models/fno/fno.py:183-200 and models/fourcastnet/fourcastnet.py:411-428,        */

@@ -121,6 +121,47 @@ def test_bf16_fused_sht_kernels_equal_the_bf16_gemm_path(cuda, monkeypatch, nlat
     assert rel(torch.view_as_real(spec_to_complex(res["1"][0]).contiguous()), torch.view_as_real(Xr)) <= 2e-2
 
 
+
+@pytest.mark.parametrize("B,M,L,Ci,Co,tri", [(4, 32, 32, 256, 256, True), (2, 16, 24, 128, 256, True), (3, 32, 20, 256, 128, False),
+                                              (5, 12, 12, 128, 128, True)])
+def test_native_dhconv_kernels_match_the_complex_einsum(cuda, B, M, L, Ci, Co, tri):
+    """csrc/dhconv.hip: forward, input gradient and the weight gradient over THREE applications in one scope (one segmented product)
+    against the float64 complex einsum "bixy,iox->boxy" on bf16-rounded operands; triangular spectra (orders m > l zero, as RealSHT
+    produces them) with the skip on, dense spectra with it off, ragged row counts (partial 256-row chunks)."""
+    from dlwp_benchmark_amd import lib as L_, sht
+    g = torch.Generator().manual_seed(14)
+    bf = torch.bfloat16
+    w = (torch.randn(Ci, Co, L, 2, generator=g) / Ci ** 0.5)
+    mask = (torch.arange(M)[None, :] <= torch.arange(L)[:, None]).float() if tri else torch.ones(L, M)       # [L, M]
+    Xs = [(torch.randn(L, B, M, 2, Ci, generator=g) * mask[:, None, :, None, None]).to(bf) for _ in range(3)]
+    gYs = [(torch.randn(L, B, M, 2, Co, generator=g) * mask[:, None, :, None, None]).to(bf) for _ in range(3)]
+    wc = torch.complex(w[..., 0].to(bf).double(), w[..., 1].to(bf).double())                               # [Ci, Co, L]
+    with L_.gemm_precision("bf16"):
+        L_.set_storage("bf16")
+        L_.SHADOW_ACTIVE = True
+        try:
+            assert L_.load().dlwp_dhconv_supported(Ci, Co, L) == 1
+            wd = w.clone().to(cuda).requires_grad_(True)
+            xs = [x.clone().to(cuda).requires_grad_(True) for x in Xs]
+            with sht.spectral_weight_scope():
+                ys = [sht.dhconv(x, wd, triangular=tri) for x in xs]
+                assert all(y.dtype == bf for y in ys)
+                sum((y.float() * gy.to(cuda).float()).sum() for y, gy in zip(ys, gYs)).backward()
+        finally:
+            L_.SHADOW_ACTIVE = False
+            L_.set_storage("fp32")
+    gw_ref = torch.zeros(Ci, Co, L, dtype=torch.complex128)
+    for x, gy, y, xd in zip(Xs, gYs, ys, xs):
+        xc = torch.complex(x[..., 0, :].double(), x[..., 1, :].double())                                    # [L, B, M, Ci]
+        gc = torch.complex(gy[..., 0, :].double(), gy[..., 1, :].double())
+        yr = torch.einsum("lbmi,iol->lbmo", xc, wc)
+        assert rel(torch.stack([y[..., 0, :], y[..., 1, :]], -1).float(), torch.view_as_real(yr)) <= 1e-2
+        gxr = torch.einsum("lbmo,iol->lbmi", gc, wc.conj())
+        assert rel(torch.stack([xd.grad[..., 0, :], xd.grad[..., 1, :]], -1).float(), torch.view_as_real(gxr)) <= 1e-2
+        gw_ref += torch.einsum("lbmi,lbmo->iol", xc.conj(), gc)
+    assert rel(wd.grad, torch.view_as_real(gw_ref)) <= 1e-2
+
+
 def test_dhconv_matches_einsum(cuda):
     from dlwp_benchmark_amd import sht
     g = torch.Generator().manual_seed(6)
