@@ -33,10 +33,14 @@ constexpr int MAXS = DLWP_WGRAD_MAX_SEGMENTS;
 
 // ---- weight images: img[which][l][tile][kk][lane][8], which = 0 forward (tiles over o, k over i), 1 backward (tiles over i, k over o);
 // a tile's rows 0..7 are the real parts of its 8 channels, rows 8..15 the imaginary parts
-__global__ __launch_bounds__(256) void dhconv_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ fimg, __bf16* __restrict__ bimg,
-                                                         int Ci, int Co, int L) {
+constexpr int MAXW = 16;         // spectral weights per pack launch
+struct PackMany { const float* w[MAXW]; __bf16* fimg[MAXW]; __bf16* bimg[MAXW]; };
+__global__ __launch_bounds__(256) void dhconv_pack_kernel(PackMany pm, int Ci, int Co, int L) {
     extern __shared__ __attribute__((aligned(16))) float pk_smem[];      // [256 (i, o) pairs][2 L + 1]
-    const int which = blockIdx.z, tid = threadIdx.x, LD = 2 * L + 1;
+    const int which = blockIdx.z & 1, layer = blockIdx.z >> 1, tid = threadIdx.x, LD = 2 * L + 1;
+    const float* __restrict__ w = pm.w[layer];
+    __bf16* __restrict__ fimg = pm.fimg[layer];
+    __bf16* __restrict__ bimg = pm.bimg[layer];
     // forward: block (kk = 32 inputs, t = 8 outputs); backward: block (t = 8 inputs, kk = 32 outputs)
     const int kk = blockIdx.x, t = blockIdx.y;
     const int KS = (which ? Co : Ci) / 32, NT = (which ? Ci : Co) / 8;
@@ -262,17 +266,29 @@ extern "C" int dlwp_dhconv_supported(int Cin, int Cout, int L) {
 
 extern "C" long long dlwp_dhconv_image_elems(int Cin, int Cout, int L) { return (long long)L * 2 * Cin * Cout; }
 
-extern "C" int dlwp_dhconv_pack(const float* w, void* fwd_img, void* bwd_img, int Cin, int Cout, int L, void* stream) {
-    DLWP_REQUIRE(w && fwd_img && bwd_img && aligned16(fwd_img) && aligned16(bwd_img), DLWP_E_INVALID, "dhconv_pack: null / unaligned pointer");
+extern "C" int dlwp_dhconv_pack_many(const float* const* w, void* const* fwd_img, void* const* bwd_img, int n, int Cin, int Cout, int L,
+                                     void* stream) {
+    DLWP_REQUIRE(w && fwd_img && bwd_img && n >= 1 && n <= MAXW, DLWP_E_INVALID, "dhconv_pack: %d weights (1..%d) / null table", n, MAXW);
     DLWP_REQUIRE(dlwp_dhconv_supported(Cin, Cout, L), DLWP_E_UNSUPPORTED, "dhconv_pack: widths %d -> %d, %d degrees unsupported", Cin, Cout, L);
+    PackMany pm{};
+    for (int i = 0; i < n; ++i) {
+        DLWP_REQUIRE(w[i] && fwd_img[i] && bwd_img[i] && aligned16(fwd_img[i]) && aligned16(bwd_img[i]), DLWP_E_INVALID,
+                     "dhconv_pack: weight %d: null / unaligned pointer", i);
+        pm.w[i] = w[i];
+        pm.fimg[i] = static_cast<__bf16*>(fwd_img[i]);
+        pm.bimg[i] = static_cast<__bf16*>(bwd_img[i]);
+    }
     const size_t lds = (size_t)256 * (2 * L + 1) * sizeof(float);
     if (int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(dhconv_pack_kernel), lds, "dhconv_pack")) return rc;
-    // one grid for both images: x = 32-deep k blocks, y = 8-channel tiles (each image uses its own extents)
-    const dim3 grid(std::max(Cin, Cout) / 32, std::max(Cin, Cout) / 8, 2);
-    hipLaunchKernelGGL(dhconv_pack_kernel, grid, dim3(256), lds, (hipStream_t)stream, w, static_cast<__bf16*>(fwd_img),
-                       static_cast<__bf16*>(bwd_img), Cin, Cout, L);
+    // one grid for every image: x = 32-deep k blocks, y = 8-channel tiles (each image uses its own extents), z = (weight, image)
+    const dim3 grid(std::max(Cin, Cout) / 32, std::max(Cin, Cout) / 8, 2 * n);
+    hipLaunchKernelGGL(dhconv_pack_kernel, grid, dim3(256), lds, (hipStream_t)stream, pm, Cin, Cout, L);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
+}
+
+extern "C" int dlwp_dhconv_pack(const float* w, void* fwd_img, void* bwd_img, int Cin, int Cout, int L, void* stream) {
+    return dlwp_dhconv_pack_many(&w, &fwd_img, &bwd_img, 1, Cin, Cout, L, stream);
 }
 
 // Y[l][row][n] = sum_k X[l][row][k] (*) W   (transposed != 0: gX = gY conj(W)^T with the backward image)

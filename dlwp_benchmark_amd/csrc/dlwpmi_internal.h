@@ -1,7 +1,15 @@
 // Internal (non-exported) interfaces shared between the translation units of libdlwpmi.
 #pragma once
+#include <climits>
 #include <hip/hip_runtime.h>
 #include "../../include/dlwpmi.h"
+
+// tuning.hip -- the registry of measurement knobs: the override of knob `name` (dlwp_set_tuning, else the environment variable
+// DLWP_<name>, read at the time of the call) or DLWP_TUNE_UNSET = "the library's own choice"
+constexpr int DLWP_TUNE_UNSET = INT_MIN;
+int dlwp_tune(const char* name);
+inline bool dlwp_tune_on(const char* name) { const int v = dlwp_tune(name); return v != DLWP_TUNE_UNSET && v != 0; }
+inline int dlwp_tune_or(const char* name, int dflt) { const int v = dlwp_tune(name); return v == DLWP_TUNE_UNSET ? dflt : v; }
 
 // pwmlp.hip — strided/gathered channel views, optional residual and fused MSE gradient
 int dlwp_pwmlp_fwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, const float* w2,

@@ -684,10 +684,8 @@ extern "C" int dlwp_fft_plan_create(int H, int W, dlwp_fft_plan** out) {
     p->H = H; p->W = W; p->tabW = p->tabH = nullptr; p->amatW = p->amatH = nullptr;
     int rc;
     // inner lanes per workgroup: W axis 8 channel PAIRS = 64 bytes of a channels-last row per w, H axis 16 complex = 128 bytes
-    static const char* ibw = getenv("DLWP_FFT_IBW");
-    static const char* ibh = getenv("DLWP_FFT_IBH");
-    if ((rc = make_axis(p->axW, W, &p->tabW, &p->amatW, ibw ? atoi(ibw) : 8)) ||
-        (rc = make_axis(p->axH, H, &p->tabH, &p->amatH, ibh ? atoi(ibh) : 16))) {
+    if ((rc = make_axis(p->axW, W, &p->tabW, &p->amatW, dlwp_tune_or("FFT_IBW", 8))) ||
+        (rc = make_axis(p->axH, H, &p->tabH, &p->amatH, dlwp_tune_or("FFT_IBH", 16)))) {
         dlwp_fft_plan_destroy(p);
         return rc;
     }

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void fno_spatial_kernel(SpatialDev a) {
         const int u = tid + 256 * k, c = u / W4, x4 = u - c * W4;
         if (u < tile_units) {
             float4 v = tv[k];
-            if (a.act_tin) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
+            if (a.act_tin) { const f32x4 ga = gelu4(f32x4{v.x, v.y, v.z, v.w}); v = make_float4(ga[0], ga[1], ga[2], ga[3]); }
             *reinterpret_cast<float4*>(&tin_s[c * LDP + 4 * x4]) = v;
             if (need_prev) *reinterpret_cast<float4*>(&pprev_s[c * LDP + 4 * x4]) = pv[k];
         }
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void fno_spatial_kernel(SpatialDev a) {
         if (c < a.C) {
             const long long off = (((long long)b * a.C + c) * a.H + h) * a.W + 4 * x4;
             v = *reinterpret_cast<const float4*>(&a.tin[off]);
-            if (a.act_tin) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
+            if (a.act_tin) { const f32x4 ga = gelu4(f32x4{v.x, v.y, v.z, v.w}); v = make_float4(ga[0], ga[1], ga[2], ga[3]); }
             if (need_prev) pvv = *reinterpret_cast<const float4*>(&a.pprev[off]);
         }
         *reinterpret_cast<float4*>(&tin_s[c * LDP + 4 * x4]) = v;
@@ -256,15 +256,14 @@ __global__ __launch_bounds__(256) void fno_spatial_kernel(SpatialDev a) {
                 ep[cb][j] = MODE == 0 ? bias_s[o] : (MODE == 1 ? pprev_s[o * LDP + x] : 0.f);
             }
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
+        for (int cb = 0; cb < NCB; ++cb) {
+            f32x4 v4 = acc[cb];
+            const f32x4 e4 = f32x4{ep[cb][0], ep[cb][1], ep[cb][2], ep[cb][3]};
+            if (MODE == 0) v4 += e4;
+            else if (MODE == 1) v4 *= gelu_grad4(e4);              // packed fp32 polynomial
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int o = cb * 16 + 4 * g + j, x = wb * 16 + r;
-                float v = acc[cb][j];
-                if (MODE == 0) v += ep[cb][j];
-                else if (MODE == 1) v *= gelu_grad_f(ep[cb][j]);
-                tout_s[o * LDP + x] = v;
-            }
+            for (int j = 0; j < 4; ++j) tout_s[(cb * 16 + 4 * g + j) * LDP + wb * 16 + r] = v4[j];
+        }
     }
     DLWP_STAMP(6);
     __syncthreads();
@@ -291,8 +290,7 @@ __global__ __launch_bounds__(256) void fno_spatial_kernel(SpatialDev a) {
             for (int ib = 0; ib < NCB; ++ib) {
                 f32x4 b4 = *reinterpret_cast<const f32x4*>(&pprev_s[(ib * 16 + r) * LDP + kc * 16 + 4 * g]);
                 if (a.act_prev) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) b4[s] = gelu_f(b4[s]);
+                    b4 = gelu4(b4);
                 }
 #pragma unroll
                 for (int ob = 0; ob < NCB; ++ob) {

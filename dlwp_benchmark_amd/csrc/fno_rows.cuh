@@ -23,8 +23,7 @@ __device__ __forceinline__ void tile_rows_dft(const float* tile, const float* ft
         for (int cb = 0; cb < NCB; ++cb) {
             f32x4 a4 = *reinterpret_cast<const f32x4*>(&tile[(cb * 16 + r) * LDP + kc * 16 + 4 * g]);
             if (act) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) a4[s] = gelu_f(a4[s]);
+                a4 = gelu4(a4);
             }
 #pragma unroll
             for (int nb = 0; nb < NBN; ++nb) xacc[cb][nb] = mfma16_chunk(a4, b4[nb], xacc[cb][nb]);

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void fno_spatial_wide_kernel(WideSpatialDev a)
         for (int q = 0; q < 4; ++q) {
             const int u = tid + 256 * q, i = u / (WSEG / 4), p4 = u - i * (WSEG / 4);
             float4 v = tv[q];
-            if (a.act_tin) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
+            if (a.act_tin) { const f32x4 ga = gelu4(f32x4{v.x, v.y, v.z, v.w}); v = make_float4(ga[0], ga[1], ga[2], ga[3]); }
             *reinterpret_cast<float4*>(&tin_s[i * LDPW + 4 * p4]) = v;
         }
 #pragma unroll

@@ -280,8 +280,7 @@ int chain_launch(const ChainDev& a, hipStream_t s) {
     int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(kern), lds, "mlp_chain");
     if (rc) return rc;
     ChainDev b = a;
-    static const char* rot_env = getenv("DLWP_CHAIN_ROT");
-    b.rot = rot_env ? atoi(rot_env) : 1;
+    b.rot = dlwp_tune_or("CHAIN_ROT", 1);
     hipLaunchKernelGGL(kern, dim3(ceil_div(a.T, 16 * MT)), dim3(512), lds, s, b);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;

@@ -184,8 +184,11 @@ __device__ __forceinline__ void fwd_compute(const FwdArgs& a, const FwdLds& L) {
             for (int s = 0; s < 4; ++s) b4[s] = L.xs[(kc * 16 + 4 * g + s) * LDP + pw0 + r];
             z = mfma16_chunk(a4, b4, z);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) z[j] = gelu_f(z[j] + L.b1s[hb * 16 + 4 * g + j]);
+        {
+            const f32x4 zb = z + *reinterpret_cast<const f32x4*>(&L.b1s[hb * 16 + 4 * g]);
+            f32x4 dz;
+            gelu_both4(zb, z, dz);                      // packed fp32 polynomial (the derivative half is dead code here)
+        }
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
             const f32x4 w4 = *reinterpret_cast<const f32x4*>(&L.w2s[(ob * 16 + r) * LD2 + hb * 16 + 4 * g]);
@@ -505,15 +508,10 @@ __global__ __launch_bounds__(NW * 64) void pwmlp_bwd_kernel(BwdArgs a) {
             }
     };
     auto hb_stage_b = [&](HbState& st, const HbW& hw, int pb, const f32x4 zt, const f32x4 gat) {
-        f32x4 actt, gzt;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float av, dv;
-            gelu_both(zt[j] + hw.b1v, av, dv);
-            actt[j] = av;
-            gzt[j] = gat[j] * dv;
-            st.gb1acc += gzt[j];
-        }
+        f32x4 actt, gzt, dvt;
+        gelu_both4(zt + f32x4{hw.b1v, hw.b1v, hw.b1v, hw.b1v}, actt, dvt);      // packed fp32 polynomial
+        gzt = gat * dvt;
+        st.gb1acc += (gzt[0] + gzt[1]) + (gzt[2] + gzt[3]);
         // dW2[o][h] += sum_p gy[o][p] act^T[p][h];  dW1[h][i] += sum_p gz[h][p] x[i][p]  (gz^T registers read as an A operand
         // are gz);  gz[h][p] in accumulator layout = gz^T (as A operand) x identity
         f32x4 a2[NOB], b1f[NIB];

@@ -229,8 +229,7 @@ int io_launch(const IoDev& a_in, hipStream_t s) {
     auto kern = sfno_io_kernel<E, MODE>;
     if (int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(kern), lds, "sfno_io")) return rc;
     IoDev a = a_in;
-    static const char* rot_env = getenv("DLWP_CHAIN_ROT");
-    a.rot = rot_env ? atoi(rot_env) : 1;
+    a.rot = dlwp_tune_or("CHAIN_ROT", 1);
     hipLaunchKernelGGL(kern, dim3(ceil_div(a.T, ROWS)), dim3(512), lds, s, a);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;

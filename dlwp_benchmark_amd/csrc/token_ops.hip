@@ -965,7 +965,7 @@ static float* tn_slab_for(hipStream_t s, size_t bytes) {
 // weight-gradient products the TN kernel takes: both operands bf16 arrays [k][row], fp32 output, no epilogue, one batch, the
 // caller already prepared for split-K (zeroed or accumulating output)
 static bool gemm_glds_tn_applies(const GemmDev& a) {
-    static const bool off = getenv("DLWP_GEMM_NOGLDS") != nullptr || getenv("DLWP_GEMM_NOGLDS_TN") != nullptr;
+    const bool off = dlwp_tune_on("GEMM_NOGLDS") || dlwp_tune_on("GEMM_NOGLDS_TN");
     if (off || !g_gemm_bf16 || (a.dt & (DT_A | DT_B | DT_C | DT_R)) != (DT_A | DT_B)) return false;
     if (a.M % 8 || a.N % 8 || a.lda % 8 || a.ldb % 8 || (uintptr_t)a.A % 16 || (uintptr_t)a.B % 16) return false;
     if (a.nbatch != 1 || a.atomic_out || a.bias || a.residual || a.preact || a.act || a.act_b || a.bias_row) return false;
@@ -978,11 +978,11 @@ static int gemm_glds_tn_launch(const GemmDev& a_in, hipStream_t s) {
     // K-step depth and slices from the sweep in profiles/r03_gemm_glds_tn.txt: the grid should fill the resident slots once (a second,
     // partial round costs as much as a full one): 64 deep = 64 KB of LDS, two workgroups per CU; 32 deep = 32 KB and 160 VGPRs, three
     // per CU, which pays once there are enough output tiles (FourCastNet's 3072 x 768: 120 us against 133)
-    static const char* kd_env = getenv("DLWP_GEMM_GLDS_TN_KD");
-    const bool shallow = kd_env ? atoi(kd_env) == 32 : a.ntn * a.ntm >= 96;
+    const int kd_env = dlwp_tune("GEMM_GLDS_TN_KD");
+    const bool shallow = kd_env != DLWP_TUNE_UNSET ? kd_env == 32 : a.ntn * a.ntm >= 96;
     const int kd = shallow ? 32 : 64;
-    static const char* wg_env = getenv("DLWP_GEMM_GLDS_TN_WGS");
-    const int slots = wg_env ? atoi(wg_env) : (shallow ? 768 : 448);
+    const int wg_env = dlwp_tune("GEMM_GLDS_TN_WGS");
+    const int slots = wg_env != DLWP_TUNE_UNSET ? wg_env : (shallow ? 768 : 448);
     // at least eight K-steps per slice: shorter slices only add partial tiles to combine (8192 tokens x 512 x 256, graph timing,
     // tools/bench_gemm_graph.py: 32 slices 22.6 us, 16 slices 17.4 us)
     int splits = std::max(1, std::min(slots / (a.ntn * a.ntm), a.K / (8 * kd)));
@@ -990,10 +990,10 @@ static int gemm_glds_tn_launch(const GemmDev& a_in, hipStream_t s) {
     a.splits = std::max(2, ceil_div(a.K, a.kchunk));             // > 1: the atomic epilogue (the caller zeroed C for its own split)
     const size_t lds = (size_t)2 * 2 * GT * kd * 2;
     const dim3 grid(a.ntn * a.ntm, 1, ceil_div(a.K, a.kchunk));
-    static const bool no_slab = getenv("DLWP_GEMM_TN_ATOMIC") != nullptr;
+    const bool no_slab = dlwp_tune_on("GEMM_TN_ATOMIC");
     // few output tiles cut into many slices (SFNO's 512 x 256: 8 tiles x 32) read more slab in the reduction than the atomics cost
-    static const char* slab_min_env = getenv("DLWP_GEMM_TN_SLAB_MIN");
-    const int slab_min = slab_min_env ? atoi(slab_min_env) : 24;
+    const int slab_min_env = dlwp_tune("GEMM_TN_SLAB_MIN");
+    const int slab_min = slab_min_env != DLWP_TUNE_UNSET ? slab_min_env : 24;
     a.slab = (no_slab || a.ntn * a.ntm < slab_min || a.N % 4 || a.ldc % 4 || (uintptr_t)a.C % 16) ? nullptr
                                                                          : tn_slab_for(s, sizeof(float) * grid.z * (size_t)a.M * a.N);
     int rc;
@@ -1249,12 +1249,12 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmDev a) {
 // shapes the LDS-DMA kernel takes: both operands bf16 arrays with k contiguous and 16-byte aligned rows, K a multiple of 64, one
 // plain product (no split-K / batches / row sums / row bias), the aligned epilogue, enough tiles to be worth 128 x 128
 static bool gemm_glds_applies(const GemmDev& a, bool akc, bool bkc) {
-    static const bool off = getenv("DLWP_GEMM_NOGLDS") != nullptr;
+    const bool off = dlwp_tune_on("GEMM_NOGLDS");
     if (off || !g_gemm_bf16 || !akc || (a.dt & (DT_A | DT_B)) != (DT_A | DT_B)) return false;
     if (a.K % 32 || a.lda % 8 || a.ldb % 8 || (uintptr_t)a.A % 16 || (uintptr_t)a.B % 16) return false;
     if (!bkc && a.N % 8) return false;
     if (a.splits != 1 || a.nbatch != 1 || a.atomic_out || a.rowsum || a.bias_row || a.act_b || !a.vec_epi) return false;
-    static const bool force = getenv("DLWP_GEMM_GLDS_FORCE") != nullptr;          // measurement: skip the shape heuristic below
+    const bool force = dlwp_tune_on("GEMM_GLDS_FORCE");          // measurement: skip the shape heuristic below
     if (force) return a.M >= GT && a.N >= GT;
     // at least one workgroup per CU and four K-steps: below that the 64 x 64 kernel's shorter prologue wins (measured,
     // profiles/r03_gemm_bench.txt: Pangu 8192 x 192 x 768 104 vs 120 TFLOP/s, 2048 x 1536 x 384 77 vs 93)
@@ -1264,11 +1264,11 @@ static int gemm_glds_launch(const GemmDev& a_in, bool bkc, hipStream_t s) {
     GemmDev a = a_in;
     a.ntn = ceil_div(a.N, GT);
     a.ntm = ceil_div(a.M, GT);
-    static const char* kd_env = getenv("DLWP_GEMM_GLDS_KD");
+    const int kd_env = dlwp_tune("GEMM_GLDS_KD");
     // depth of a K-step (profiles/r03_gemm_glds_kd.txt): 32 deep leaves room for three or four workgroups per CU, which wins for
     // y = x W^T up to K ~ 1000 (16200 x 3072 x 768: 122 -> 110 us) and for gx = g W with at least four column tiles (16200 x 768 x 3072:
     // 122 -> 96 us, 8192^3: 841 -> 945 TFLOP/s); the deep, long products stay at 64 (8192^3 y: 1001 TFLOP/s against 828)
-    const bool shallow = a.K % GK != 0 || (kd_env ? atoi(kd_env) == 32 : (bkc ? a.K <= 1024 : a.N >= 512));
+    const bool shallow = a.K % GK != 0 || (kd_env != DLWP_TUNE_UNSET ? kd_env == 32 : (bkc ? a.K <= 1024 : a.N >= 512));
     // 64 KB at KD = 64 (the epilogue's 64 x 132 fp32 half tile fits inside); 33 KB (that half tile) at KD = 32
     const size_t lds = shallow ? sizeof(float) * 64 * (GT + 4) : (size_t)2 * 2 * GT * GK * 2;
     int rc;
@@ -1477,7 +1477,7 @@ static int gemm_p8_launch(const GemmDev& a_in, bool bkc, hipStream_t s) {
     a.ntm = ceil_div(a.M, P8T);
     const size_t lds = (size_t)2 * 4 * 128 * 64 * 2;          // 128 KB: two stages of four half-tile images (the epilogue's 64 x 260 fp32 tile fits inside)
     int rc;
-    static const bool direct = getenv("DLWP_GEMM_P8_STAGED") == nullptr;
+    const bool direct = !dlwp_tune_on("GEMM_P8_STAGED");
     static const int ncu = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1502,7 +1502,7 @@ int g_gemm_tile256 = 0;    // dlwp_set_gemm_tile256: 0 by shape (below), 1 where
 // shape, only when forced (dlwp_set_gemm_tile256(1) / DLWP_GEMM_P8: tests, measurements).  Needs the slab.
 static int gemm_p8_tn_launch(const GemmDev& a_in, hipStream_t s, bool* taken) {
     *taken = false;
-    static const bool off = getenv("DLWP_GEMM_NOP8_TN") != nullptr;
+    const bool off = dlwp_tune_on("GEMM_NOP8_TN");
     if (off || g_gemm_tile256 < 0 || a_in.M < P8T || a_in.N < P8T || a_in.N % 4 || a_in.ldc % 4 || (uintptr_t)a_in.C % 16) return DLWP_OK;
     GemmDev a = a_in;
     a.ntn = ceil_div(a.N, P8T);
@@ -1516,7 +1516,7 @@ static int gemm_p8_tn_launch(const GemmDev& a_in, hipStream_t s, bool* taken) {
     int splits = std::max(1, std::min(ncu / tiles, a.K / (16 * 64)));
     a.kchunk = ceil_div(ceil_div(a.K, splits), 64) * 64;
     splits = ceil_div(a.K, a.kchunk);
-    static const bool force = getenv("DLWP_GEMM_P8") != nullptr;
+    const bool force = dlwp_tune_on("GEMM_P8");
     if (!force && g_gemm_tile256 <= 0) return DLWP_OK;
     a.splits = splits;
     a.slab = tn_slab_for(s, sizeof(float) * splits * (size_t)a.M * a.N);
@@ -1537,11 +1537,11 @@ static int gemm_p8_tn_launch(const GemmDev& a_in, hipStream_t s, bool* taken) {
 // to pay -- 8192^3: 1351 against 1017 TFLOP/s, 4096^3 1186 / 983, 16200 x 768 x 3072: 898 / 788, but 16200 x 3072 x 768: 686 / 693 and every
 // K <= 512 shape loses (profiles/r03_gemm_p8.txt): taken from K = 2048 with at least 128 tiles, or when forced
 static bool gemm_p8_applies(const GemmDev& a, bool akc, bool bkc) {
-    static const bool env_on = getenv("DLWP_GEMM_P8") != nullptr;
+    const bool env_on = dlwp_tune_on("GEMM_P8");
     if (g_gemm_tile256 < 0 || !akc || a.K % 64 || a.M < P8T || a.N < P8T) return false;
     const long long tiles = (long long)ceil_div(a.M, P8T) * ceil_div(a.N, P8T);
-    static const char* mink_env = getenv("DLWP_GEMM_P8_MINK");
-    const int mink = mink_env ? atoi(mink_env) : 2048;
+    const int mink_env = dlwp_tune("GEMM_P8_MINK");
+    const int mink = mink_env != DLWP_TUNE_UNSET ? mink_env : 2048;
     return env_on || g_gemm_tile256 > 0 || (a.K >= mink && tiles >= 128);
 }
 
@@ -2129,7 +2129,7 @@ __global__ __launch_bounds__(256) void colsum_flat_kernel(const float* __restric
 // can_split: no epilogue, so a long K may be cut into slices (weight gradients: few output tiles, K = tokens) -- the slices
 // fill the chip where the tiles alone would not.
 static int gemm_tile_for(int M, int N, long long nbatch, int K = 0, int dt = 0, bool can_split = false) {
-    static const int forced = [] { const char* e = getenv("DLWP_GEMM_TILE"); return e ? (atoi(e) == 128 ? 2 : 1) : 0; }();
+    const int tile_env = dlwp_tune("GEMM_TILE"), forced = tile_env == DLWP_TUNE_UNSET ? 0 : (tile_env == 128 ? 2 : 1);
     if (M < 128 || N < 128) return 1;
     const long long tiles = (long long)ceil_div(M, 128) * ceil_div(N, 128) * nbatch;
     const bool fills = tiles * (can_split ? std::max(1, K / (4 * BK)) : 1) >= 224;
@@ -2155,7 +2155,7 @@ static int gemm_dispatch(GemmDev& a, int transA, int transB, int T, void* stream
                     (a.bias_row || (a.sBi1 % 4 == 0 && a.sBi2 % 4 == 0));
     const hipStream_t s = (hipStream_t)stream;
     int rc;
-    static const bool trace = getenv("DLWP_GEMM_TRACE") != nullptr;      // shape census of an eager step: sort | uniq -c
+    const bool trace = dlwp_tune_on("GEMM_TRACE");      // shape census of an eager step: sort | uniq -c
     if (trace)
         fprintf(stderr, "gemm %c%c M=%d N=%d K=%d nb=%lld splits=%d dt=%d vec=%d epi=%d bias=%d res=%d act=%d rowsum=%d\n", transA ? 'T' : 'N',
                 transB ? 'T' : 'N', a.M, a.N, a.K, (long long)a.nbatch, a.splits, a.dt, vec, (int)a.vec_epi, a.bias != nullptr,
@@ -2203,7 +2203,7 @@ extern "C" int dlwp_set_gemm_precision(int mode) {
 extern "C" int dlwp_get_gemm_precision(void) { return g_gemm_bf16; }
 extern "C" int dlwp_gemm_group_begin(void) {
     DLWP_REQUIRE(!g_queue.open, DLWP_E_INVALID, "gemm_group_begin: a group is already open");
-    static const bool off = getenv("DLWP_GEMM_NOGROUP") != nullptr;
+    const bool off = dlwp_tune_on("GEMM_NOGROUP");
     g_queue.open = !off;
     g_queue.n = 0;
     return DLWP_OK;
@@ -2264,14 +2264,14 @@ extern "C" int dlwp_weight_grad_group(const dlwp_wgrad_desc* d, int n, void* str
         return gemm_impl((const float*)q.g, (const float*)q.x, q.gw, q.N, q.K, q.T, q.N, q.K, q.K, 1, 0, nullptr, 0, nullptr, nullptr,
                          q.accumulate, q.gb, dt, stream);
     };
-    static const bool off = getenv("DLWP_GEMM_NOGROUP") != nullptr;
+    const bool off = dlwp_tune_on("GEMM_NOGROUP");
     // worth it while the products are latency-bound (SFNO C3, 8192 tokens: 5.68 -> 5.49 ms per step); at 32768 tokens each product fills
     // the chip by itself and the bf16 x bf16 one has a faster kernel of its own (11.5 -> 11.9 ms grouped)
     bool grouped = !off && n >= 2 && n <= 3;
     // ... and only small outputs: a FourCastNet-scale product (3072 x 768 over 16200 tokens) belongs on the LDS-DMA kernels (grouped on the
     // 64 x 64 kernel the C5 step went from 17.3 to 26.9 ms)
-    static const char* maxt_env = getenv("DLWP_WGRAD_GROUP_MAXT");
-    const int maxt = maxt_env ? atoi(maxt_env) : 65536;
+    const int maxt_env = dlwp_tune("WGRAD_GROUP_MAXT");
+    const int maxt = maxt_env != DLWP_TUNE_UNSET ? maxt_env : 65536;
     for (int i = 0; i < n; ++i) grouped = grouped && d[i].T <= maxt && (long long)d[i].N * d[i].K <= 512 * 512;
     GemmGroup gg{};
     unsigned gx = 0, gz = 0;
@@ -2283,8 +2283,8 @@ extern "C" int dlwp_weight_grad_group(const dlwp_wgrad_desc* d, int n, void* str
         // slices: the products of the group share the chip, so the whole group gets the workgroups of one resident round
         // (896 by default, DLWP_WGRAD_GROUP_WGS): with 512 per product as a lone launch would choose, three products ran a
         // second partial round and twice the atomics (SFNO C3 step 5.33 -> 5.21 ms; neutral on Pangu / Swin / AFNO)
-        static const char* wgs_env = getenv("DLWP_WGRAD_GROUP_WGS");
-        const int per_product = std::max(1, (wgs_env ? atoi(wgs_env) : 896) / n);
+        const int wgs_env = dlwp_tune("WGRAD_GROUP_WGS");
+        const int per_product = std::max(1, (wgs_env != DLWP_TUNE_UNSET ? wgs_env : 896) / n);
         int splits = 1;
         if (tiles < 256 && K >= 8 * BK) splits = std::min(ceil_div(per_product, tiles), K / (4 * BK));
         const int kchunk = ceil_div(ceil_div(K, splits), BK) * BK;
@@ -2464,10 +2464,10 @@ static int layernorm_bwd_impl(const float* x, const float* gamma, const float* m
     // tail costs (number of workgroups) x 25 ns whatever C is: ~128-256 workgroups balance that against the rows
     // each wave walks serially.
     // each wave then walks serially (one wave per SIMD hides no latency).  Large inputs get up to ~1024 workgroups.
-    static const char* want_env = getenv("DLWP_LN_BWD_WANT");
+    const int want_env = dlwp_tune("LN_BWD_WANT");
     // (measured, tools/probe_layernorm.py: 8192 x 256 wants 256 workgroups (14.7 vs 18.7 us at 128); the 1024 x 64 calls of the 64 x 64
     // AFNO rollout want the fewer, longer ones: 128 -> 256 cost that step 4 %)
-    const long long want = want_env ? atoi(want_env)
+    const long long want = want_env != DLWP_TUNE_UNSET ? want_env
                                     : std::min<long long>(512, std::max<long long>((long long)T * C >= (1 << 21) ? 256 : 128, (long long)T * C / 16384));
     int rpb = 256;
     while (rpb > 4 && ceil_div(T, rpb) < want) rpb >>= 1;
@@ -2477,11 +2477,11 @@ static int layernorm_bwd_impl(const float* x, const float* gamma, const float* m
                         (uintptr_t)gamma % 16 == 0 && (gy_bf16 || (uintptr_t)gy % 16 == 0) && (!gadd || (uintptr_t)gadd % 16 == 0);
     const bool wide = C % 4 == 0 && C > 256 && C <= 1024 && (uintptr_t)x % 16 == 0 && (uintptr_t)gx % 16 == 0 &&
                       (uintptr_t)gamma % 16 == 0 && (uintptr_t)gy % (gy_bf16 ? 8 : 16) == 0 && (!gadd || (uintptr_t)gadd % 16 == 0);
-    static const bool no_wide = getenv("DLWP_LN_BWD_NOWIDE") != nullptr;
+    const bool no_wide = dlwp_tune_on("LN_BWD_NOWIDE");
     if (wide && !no_wide) {
         // one round of resident workgroups (~110 VGPRs: four per CU at most; 512-768 keep the atomic tail short)
-        static const char* wg_env = getenv("DLWP_LN_BWD_WGS");
-        const int slots = wg_env ? atoi(wg_env) : 384;
+        const int wg_env = dlwp_tune("LN_BWD_WGS");
+        const int slots = wg_env != DLWP_TUNE_UNSET ? wg_env : 384;
         const int rpw = std::max(4, ceil_div(ceil_div(T, slots), 4) * 4);
         const dim3 gridw(ceil_div(T, rpw));
 #define LN_BWD_W(NV) hipLaunchKernelGGL(layernorm_bwd_wide_kernel<NV>, gridw, dim3(256), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, \

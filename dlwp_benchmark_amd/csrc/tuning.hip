@@ -1,0 +1,107 @@
+// Every override of a dispatch heuristic in one documented registry (round 4; the round-3 library read 28 environment variables
+// at 31 places).  A knob is identified by its name; its value comes from dlwp_set_tuning(name, value) or, when that was never
+// called for the name, from the environment variable DLWP_<NAME> (looked up at the time of use: measurement scripts and tests
+// may change it between calls; an integer is taken as it is, any other non-empty string as 1).  Unset knobs mean "the library's
+// own choice".  None of them changes results beyond summation order; they exist for A/B measurements and for tests that force a
+// kernel variant.  dlwp_tuning_list enumerates names and meanings.
+#include <climits>
+#include <cstdlib>
+#include <cstring>
+#include "common.cuh"
+#include "dlwpmi_internal.h"
+
+namespace {
+
+struct Knob {
+    const char* name;
+    const char* doc;
+    int value;
+    bool set;
+};
+
+Knob g_knobs[] = {
+    {"GEMM_NOGLDS", "1: never use the 128 x 128 LDS-DMA bf16 GEMM kernels (activation products and weight gradients)", 0, false},
+    {"GEMM_NOGLDS_TN", "1: never use the LDS-DMA weight-gradient kernel", 0, false},
+    {"GEMM_GLDS_FORCE", "1: use the LDS-DMA kernel wherever its operand layout allows (skip the shape heuristic)", 0, false},
+    {"GEMM_GLDS_KD", "K-step depth of the LDS-DMA activation kernels: 32 or 64 (default by shape)", 0, false},
+    {"GEMM_GLDS_TN_KD", "K-step depth of the LDS-DMA weight-gradient kernel: 32 or 64 (default by tile count)", 0, false},
+    {"GEMM_GLDS_TN_WGS", "resident workgroup slots the weight-gradient kernel sizes its K slices for", 0, false},
+    {"GEMM_TN_ATOMIC", "1: weight-gradient slices combined by float atomics instead of the slab + ordered reduction", 0, false},
+    {"GEMM_TN_SLAB_MIN", "least number of output tiles for the slab reduction (default 24)", 0, false},
+    {"GEMM_P8", "1: use the 256 x 256 two-group kernel wherever it applies", 0, false},
+    {"GEMM_P8_STAGED", "1: the 256 x 256 kernel's four-pass LDS-staged epilogue instead of the register epilogue", 0, false},
+    {"GEMM_P8_MINK", "least K for the 256 x 256 kernel (default 2048)", 0, false},
+    {"GEMM_NOP8_TN", "1: never use the 256 x 256 weight-gradient kernel", 0, false},
+    {"GEMM_TILE", "64 or 128: tile edge of the register-staged GEMM (default by shape)", 0, false},
+    {"GEMM_TRACE", "1: print one line per GEMM call (shape census of an eager step)", 0, false},
+    {"GEMM_NOGROUP", "1: products parked by dlwp_gemm_group_begin / dlwp_weight_grad_group launch one by one", 0, false},
+    {"WGRAD_GROUP_MAXT", "most tokens for the grouped weight-gradient launch (default 65536)", 0, false},
+    {"WGRAD_GROUP_WGS", "workgroups the grouped weight-gradient launch shares among its products (default 896)", 0, false},
+    {"WGRAD_MULTI_WGS", "resident workgroup slots dlwp_wgrad_segments sizes its K slices for (default 512)", 0, false},
+    {"LN_BWD_WANT", "workgroups of the scalar LayerNorm backward kernel", 0, false},
+    {"LN_BWD_NOWIDE", "1: never use the wide-row LayerNorm backward kernel", 0, false},
+    {"LN_BWD_WGS", "workgroups of the wide-row LayerNorm backward kernel (default 384)", 0, false},
+    {"WINATTN_TILED", "1: the tiled window-attention kernels also for many short windows", 0, false},
+    {"WINATTN_WG_BWD", "workgroup width selector of the wave-per-window attention backward", 0, false},
+    {"WINATTN_NOLDS", "1: the register-fragment attention backward instead of the LDS-staged one", 0, false},
+    {"FFT_IBW", "inner lanes of the W-axis FFT pass", 0, false},
+    {"FFT_IBH", "inner lanes of the H-axis FFT pass", 0, false},
+    {"CHAIN_ROT", "0: no rotation of the wave -> feature-tile assignment in the one-launch MLP chains (default 1)", 0, false},
+};
+constexpr int NKNOBS = sizeof(g_knobs) / sizeof(g_knobs[0]);
+
+Knob* find(const char* name) {
+    if (!name) return nullptr;
+    if (!strncmp(name, "DLWP_", 5)) name += 5;
+    for (int i = 0; i < NKNOBS; ++i)
+        if (!strcmp(g_knobs[i].name, name)) return &g_knobs[i];
+    return nullptr;
+}
+
+}  // namespace
+
+int dlwp_tune(const char* name) {
+    Knob* k = find(name);
+    if (!k) return DLWP_TUNE_UNSET;                       // (an unregistered name is a programming error: dlwp_set_tuning refuses it)
+    if (k->set) return k->value;
+    char env[96] = "DLWP_";
+    strncat(env, k->name, sizeof(env) - 6);
+    const char* e = getenv(env);
+    if (!e || !*e) return DLWP_TUNE_UNSET;
+    char* end = nullptr;
+    const long v = strtol(e, &end, 10);
+    return (end && *end == '\0') ? (int)v : 1;
+}
+
+extern "C" int dlwp_set_tuning(const char* name, int value) {
+    Knob* k = find(name);
+    DLWP_REQUIRE(k, DLWP_E_INVALID, "set_tuning: unknown knob '%s' (dlwp_tuning_list)", name ? name : "(null)");
+    k->value = value;
+    k->set = true;
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_clear_tuning(const char* name) {
+    if (!name) {
+        for (int i = 0; i < NKNOBS; ++i) g_knobs[i].set = false;
+        return DLWP_OK;
+    }
+    Knob* k = find(name);
+    DLWP_REQUIRE(k, DLWP_E_INVALID, "clear_tuning: unknown knob '%s'", name);
+    k->set = false;
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_get_tuning(const char* name, int* value) {
+    DLWP_REQUIRE(find(name) && value, DLWP_E_INVALID, "get_tuning: unknown knob '%s' / NULL result", name ? name : "(null)");
+    const int v = dlwp_tune(name);
+    *value = v == DLWP_TUNE_UNSET ? 0 : v;
+    return v == DLWP_TUNE_UNSET ? 0 : 1;                  // 1: an override is in force, 0: the library's own choice
+}
+
+extern "C" int dlwp_tuning_list(int index, const char** name, const char** doc) {
+    if (index < 0 || index >= NKNOBS) return 0;
+    if (name) *name = g_knobs[index].name;
+    if (doc) *doc = g_knobs[index].doc;
+    return 1;
+}

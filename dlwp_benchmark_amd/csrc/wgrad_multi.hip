@@ -206,8 +206,7 @@ int plan(const dlwp_wgrad_seg_product* p, int nprod, int nseg, int T, WgDev* dev
     a.tile0[nprod] = tiles;
     a.out_off[nprod] = off;
     // K slices per segment: the grid should fill the resident slots (two 64 KB workgroups per CU) once; at least eight K-steps per slice
-    static const char* wg_env = getenv("DLWP_WGRAD_MULTI_WGS");
-    const int slots = wg_env ? atoi(wg_env) : 512;
+    const int slots = dlwp_tune_or("WGRAD_MULTI_WGS", 512);
     int sps = std::max(1, std::min((slots + tiles * nseg / 2) / (tiles * nseg), std::max(1, T / (8 * KD))));
     a.kchunk = ceil_div(ceil_div(T, sps), KD) * KD;
     sps = ceil_div(T, a.kchunk);

@@ -622,7 +622,7 @@ extern "C" int dlwp_window_attn_fwd_qrange(const float* qkv, const float* bias_t
     a.table_t = packed_table;
     int rc = wa_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, "window_attn_fwd");
     if (rc) return rc;
-    if (dlwp_winattn_small_applies(N, d, (long long)B_ * heads) && !getenv("DLWP_WINATTN_TILED"))
+    if (dlwp_winattn_small_applies(N, d, (long long)B_ * heads) && !dlwp_tune_on("WINATTN_TILED"))
         return dlwp_winattn_small_fwd(qkv, bias_table, packed_table, ia, ib, labels, out, lse, B_, nW, N, TB, ntypes, heads, d,
                                       scale, q_lo, q_hi, stream);
     a.qkv = qkv; a.table = bias_table; a.ia = ia; a.ib = ib; a.labels = labels; a.out = out; a.lse = lse;
@@ -682,7 +682,7 @@ extern "C" int dlwp_window_attn_bwd_qrange(const float* qkv, const float* bias_t
     a.table_t = packed_table;
     int rc = wa_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, "window_attn_bwd");
     if (rc) return rc;
-    if (dlwp_winattn_small_applies(N, d, (long long)B_ * heads) && !getenv("DLWP_WINATTN_TILED"))
+    if (dlwp_winattn_small_applies(N, d, (long long)B_ * heads) && !dlwp_tune_on("WINATTN_TILED"))
         return dlwp_winattn_small_bwd(qkv, bias_table, packed_table, ia, ib, labels, out, lse, gout, gqkv, gbias_table, B_, nW, N,
                                       TB, ntypes, heads, d, scale, q_lo, q_hi, stream);
     a.qkv = qkv; a.table = bias_table; a.ia = ia; a.ib = ib; a.labels = labels; a.o = out; a.lse_in = lse; a.gout = gout; a.gqkv = gqkv;

@@ -660,14 +660,14 @@ __global__ __launch_bounds__(256) void winattn_lds_bwd_kernel(WsDev a) {
 // (Pangu C4 layer 1, 4218 (window, head) pairs, tools/probe_winattn_c4.py: 768 workgroups 277 us, 1536: 272, 3072: 288, one per
 // window: 370; the register-fragment kernel: 338)
 static int lds_groups(int M, int heads, int ntypes) {
-    static const int env = [] { const char* e = getenv("DLWP_WINATTN_WG_BWD"); return e ? atoi(e) : 0; }();
+    const int env = dlwp_tune_or("WINATTN_WG_BWD", 0);
     const long long g = ((long long)(env ? env : 1536) + heads * ntypes - 1) / (heads * ntypes);
     return g < 1 ? 1 : (g > M ? M : (int)g);
 }
 
 // the LDS-staged family takes the bf16 matrix mode with 16-byte loadable head slices
 static bool lds_family_applies(int N, int d) {
-    return dlwp_get_gemm_precision() == 1 && d % 4 == 0 && d <= 32 && N <= 128 && !getenv("DLWP_WINATTN_NOLDS");
+    return dlwp_get_gemm_precision() == 1 && d % 4 == 0 && d <= 32 && N <= 128 && !dlwp_tune_on("WINATTN_NOLDS");
 }
 
 int ws_setup(WsDev& a, int B_, int nW, int N, int TB, int ntypes, int heads, int d, float scale, int q_lo, int q_hi) {

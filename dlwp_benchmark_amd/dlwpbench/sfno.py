@@ -145,6 +145,8 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         one-launch encoder / decoder kernels (sfno_ops): no concatenated / padded / permuted copy of the input exists.
         frame_index: the differentiable group; residual: out = sources[frame_index] + net(input) (the rollout's connection)."""
         from .. import sfno_ops
+        from ..sht import prepack_spectral_weights
+        prepack_spectral_weights([blk.filter.weight for blk in self.blocks])      # all layers' images in one launch per pass
         t, tok_lp, link, alias = sfno_ops.encode(self, sources, frame_index)
         for blk in self.blocks:
             t = blk(t)
@@ -217,6 +219,27 @@ class SFNO2DModule(nn.Module):
 
     def ddp_units(self):
         return self.sfno.ddp_units()
+
+    def dlwp_skip_weight_shadow(self):
+        """train_engine.flatten_parameters: no bf16 shadow of the flat parameter buffer (one 112 MB cast per step) when every layer
+        reads a fragment-order image packed from the fp32 master weights: encoder / decoder (sfno_ops), block tails
+        (token_ops._SkipMlpChainFn) and spectral weights (sht._DHConvNativeFn) at the shipped sfno.yaml options."""
+        from ..sht import _DHConvNativeFn, DHCONV_NATIVE
+        from ..token_ops import CHAIN_TAIL
+        from .. import lib as L
+        net = self.sfno
+        if not (self.context_size == 1 and net.encoder[0].weight.is_cuda and net.fast_io(net.encoder[0].in_channels)):
+            return False
+        lib = L.load()
+        for blk in net.blocks:
+            if blk.norm0 is not None or blk.norm1 is not None or blk.mlp is None or blk.filter.resample:
+                return False
+            w, C_ = blk.filter.weight, blk.inner_skip.weight.shape[0]
+            if not (DHCONV_NATIVE and lib.dlwp_dhconv_supported(w.shape[0], w.shape[1], w.shape[2]) == 1):
+                return False
+            if not (CHAIN_TAIL and lib.dlwp_mlp_chain_supported(C_, blk.mlp.fc1.weight.shape[0]) == 1):
+                return False
+        return True
 
     def _rollout_frames(self, constants, prescribed, prognostic):
         """The loop of rollout.py at context_size 1 without any assembled input tensor: out_t = frame + net(constants[:, 0],

@@ -32,6 +32,10 @@ _V, _I, _L, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 SIGNATURES = {
     "dlwp_version": (_I, []),
     "dlwp_last_error": (C.c_char_p, []),
+    "dlwp_set_tuning": (_I, [C.c_char_p, _I]),
+    "dlwp_clear_tuning": (_I, [C.c_char_p]),
+    "dlwp_get_tuning": (_I, [C.c_char_p, C.POINTER(_I)]),
+    "dlwp_tuning_list": (_I, [_I, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]),
     "dlwp_pwmlp_fwd": (_I, [_V] * 6 + [_I] * 5 + [_V]),
     "dlwp_pwmlp_bwd": (_I, [_V] * 10 + [_I] * 5 + [_V]),
     "dlwp_pwmlp_slab_floats": (_L, [_I] * 5),
@@ -98,6 +102,7 @@ SIGNATURES = {
     "dlwp_dhconv_supported": (_I, [_I, _I, _I]),
     "dlwp_dhconv_image_elems": (_L, [_I, _I, _I]),
     "dlwp_dhconv_pack": (_I, [_V, _V, _V, _I, _I, _I, _V]),
+    "dlwp_dhconv_pack_many": (_I, [_V, _V, _V, _I, _I, _I, _I, _V]),
     "dlwp_dhconv_apply": (_I, [_V, _V, _V, _I, _I, _I, _I, _I, _I, _V]),
     "dlwp_dhconv_wgrad": (_I, [_V, _V, _I, _V, _I, _I, _I, _I, _I, _V]),
     "dlwp_dhconv_fold": (_I, [_V, _V, _I, _I, _I, _V]),
@@ -234,6 +239,23 @@ class gemm_group:
     def __exit__(self, *exc):
         check(load().dlwp_gemm_group_end(stream()))
         return False
+
+
+def set_tuning(name, value=None):
+    """Override (value) or release (None) a measurement knob of the library (include/dlwpmi.h: dlwp_set_tuning); names as in
+    tuning_knobs().  While no override is set the environment variable DLWP_<NAME> is consulted at the time of use."""
+    lib = load()
+    check(lib.dlwp_clear_tuning(name.encode()) if value is None else lib.dlwp_set_tuning(name.encode(), int(value)))
+
+
+def tuning_knobs():
+    """{name: meaning} of every knob."""
+    lib, out, i = load(), {}, 0
+    n, d = C.c_char_p(), C.c_char_p()
+    while lib.dlwp_tuning_list(i, C.byref(n), C.byref(d)):
+        out[n.value.decode()] = d.value.decode()
+        i += 1
+    return out
 
 
 def set_gemm_tile256(mode):

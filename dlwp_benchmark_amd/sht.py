@@ -484,6 +484,30 @@ def _dh_state(w):
     return st
 
 
+def prepack_spectral_weights(weights):
+    """Inside a spectral_weight_scope: build the images of every spectral weight of a network (same shape) that has none yet in
+    ONE launch (dlwp_dhconv_pack_many) instead of one per layer at its first use."""
+    import ctypes as C
+    if _wexp_scope is None or not weights or not DHCONV_NATIVE or _chain_dtype() != torch.bfloat16:
+        return
+    todo = [w for w in weights if ("dhconv", id(w)) not in _wexp_scope]
+    if not todo or any(w.shape != todo[0].shape or not w.is_cuda for w in todo):
+        return
+    lib = L.load()
+    Cin, Cout, Lm, _ = todo[0].shape
+    if lib.dlwp_dhconv_supported(Cin, Cout, Lm) != 1 or len(todo) > 16:
+        return
+    n = lib.dlwp_dhconv_image_elems(Cin, Cout, Lm)
+    imgs = torch.empty(len(todo), 2, n, device=todo[0].device, dtype=torch.bfloat16)
+    srcs = [w.detach().contiguous() for w in todo]
+    wp = (C.c_void_p * len(todo))(*[L.ptr(t) for t in srcs])
+    fp = (C.c_void_p * len(todo))(*[L.ptr(imgs[i, 0]) for i in range(len(todo))])
+    bp = (C.c_void_p * len(todo))(*[L.ptr(imgs[i, 1]) for i in range(len(todo))])
+    L.check(lib.dlwp_dhconv_pack_many(wp, fp, bp, len(todo), Cin, Cout, Lm, L.stream()))
+    for i, w in enumerate(todo):
+        _wexp_scope[("dhconv", id(w))] = ({"imgs": imgs[i], "uses": 0, "pending": []}, w)
+
+
 class _DHConvNativeFn(torch.autograd.Function):
     """dhconv on csrc/dhconv.hip (bf16 spectra): forward and input gradient one launch each on the un-expanded weight images; the
     weight gradient of ALL lead times of a pass as one product per degree, launched by the last backward pass through the weight

@@ -37,9 +37,11 @@ def flatten_parameters(module):
         flat[o:o + p.numel()].copy_(p.data.reshape(-1))
         p.data = flat[o:o + p.numel()].view(p.shape)
         p.grad = grad[o:o + p.numel()].view(p.shape)
-    if L.storage_bf16():
+    skip = getattr(module, "dlwp_skip_weight_shadow", False)
+    if L.storage_bf16() and not (skip() if callable(skip) else skip):
         # the bf16 copy the GEMMs read (lib.shadow): same offsets, refreshed from the fp32 master weights by one cast launch
-        # at the top of every step (refresh_bf16_weights)
+        # at the top of every step (refresh_bf16_weights).  A module whose kernels all read their own per-step weight images
+        # (packed from the fp32 master weights) opts out with `dlwp_skip_weight_shadow`.
         flat16 = torch.zeros(n, device=dev, dtype=torch.bfloat16)
         for p, o in zip(params, offs):
             p._dlwp_bf16 = flat16[o:o + p.numel()].view(p.shape)

@@ -43,6 +43,17 @@ extern "C" {
 int dlwp_version(void);
 const char* dlwp_last_error(void);
 
+/* Measurement knobs (csrc/tuning.hip): every override of a dispatch heuristic -- kernel family, tile size, workgroup count -- is a   */
+/* named entry of ONE registry.  dlwp_set_tuning(name, value) sets an override (name with or without the "DLWP_" prefix of the     */
+/* environment variable of the same meaning), dlwp_clear_tuning(name) removes it (NULL: all); while no override is set the            */
+/* environment variable DLWP_<NAME> is consulted at the time of use.  Unset = the library's own choice.  No knob changes results     */
+/* beyond summation order.  dlwp_get_tuning returns 1 and the value when an override (either kind) is in force, else 0;             */
+/* dlwp_tuning_list(i, &name, &doc) enumerates the registry (returns 0 past the end).                                               */
+int dlwp_set_tuning(const char* name, int value);
+int dlwp_clear_tuning(const char* name);
+int dlwp_get_tuning(const char* name, int* value);
+int dlwp_tuning_list(int index, const char** name, const char** doc);
+
 /* ------------------------------------------------------------------------------------ */
 /* Strided / gathered channel views.  A rollout step reads its input channels straight   */
 /* out of the trajectory buffers (observations or earlier predictions) instead of        */
@@ -575,6 +586,9 @@ int dlwp_cweight_fold(const float* gexp, float* gw, int Cin, int Cout, int L, vo
 int dlwp_dhconv_supported(int Cin, int Cout, int L);
 long long dlwp_dhconv_image_elems(int Cin, int Cout, int L);
 int dlwp_dhconv_pack(const float* w, void* fwd_img, void* bwd_img, int Cin, int Cout, int L, void* stream);
+/* the same for up to 16 weights of one shape (the layers of a network) in one launch; host arrays of n device pointers */
+int dlwp_dhconv_pack_many(const float* const* w, void* const* fwd_img, void* const* bwd_img, int n, int Cin, int Cout, int L,
+                          void* stream);
 int dlwp_dhconv_apply(const void* X, const void* image, void* Y, int L, int rows, int K, int N, int mmax, int transposed,
                       void* stream);
 int dlwp_dhconv_wgrad(const void* const* X, const void* const* gY, int nseg, float* G, int L, int rows, int Cin, int Cout,

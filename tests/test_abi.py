@@ -61,3 +61,28 @@ def test_product_has_no_cpu_fallback(lib):
     import torch
     with pytest.raises(lib.DlwpError):
         lib.ptr(torch.zeros(4))  # CPU tensors are refused, never silently computed on
+
+
+def test_tuning_registry_round_trip(monkeypatch):
+    """include/dlwpmi.h dlwp_set_tuning / _clear_ / _get_ / _list: the one documented registry behind every dispatch override
+    (host logic only: no GPU call).  An override set through the API wins over the environment variable of the same name; without
+    one the environment is consulted at the time of the call; unknown names are refused."""
+    import ctypes as C
+    from dlwp_benchmark_amd import lib as L
+    lib = L.load()
+    knobs = L.tuning_knobs()
+    assert len(knobs) >= 25 and "GEMM_NOGLDS" in knobs and "WGRAD_MULTI_WGS" in knobs and all(knobs.values())
+    v = C.c_int(-7)
+    monkeypatch.delenv("DLWP_GEMM_GLDS_KD", raising=False)
+    assert lib.dlwp_clear_tuning(b"GEMM_GLDS_KD") == 0
+    assert lib.dlwp_get_tuning(b"GEMM_GLDS_KD", C.byref(v)) == 0                      # unset: the library's own choice
+    monkeypatch.setenv("DLWP_GEMM_GLDS_KD", "32")
+    assert lib.dlwp_get_tuning(b"GEMM_GLDS_KD", C.byref(v)) == 1 and v.value == 32   # environment, read at the time of the call
+    L.set_tuning("DLWP_GEMM_GLDS_KD", 64)                                             # the prefix is optional
+    assert lib.dlwp_get_tuning(b"GEMM_GLDS_KD", C.byref(v)) == 1 and v.value == 64   # the API override wins
+    L.set_tuning("GEMM_GLDS_KD", None)
+    assert lib.dlwp_get_tuning(b"GEMM_GLDS_KD", C.byref(v)) == 1 and v.value == 32
+    monkeypatch.setenv("DLWP_GEMM_TRACE", "yes")                                      # a non-numeric value means "on"
+    assert lib.dlwp_get_tuning(b"GEMM_TRACE", C.byref(v)) == 1 and v.value == 1
+    assert lib.dlwp_set_tuning(b"NO_SUCH_KNOB", 1) != 0 and b"unknown knob" in lib.dlwp_last_error()
+    assert lib.dlwp_clear_tuning(None) == 0

@@ -379,3 +379,49 @@ def test_tile256_input_gradient_form(cuda, T, Nout, Kin):
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
     finally:
         L.set_gemm_tile256(0)
+
+
+def test_weight_gradient_slab_survives_growth_behind_a_captured_graph(cuda):
+    """The sliced weight-gradient GEMM's library-owned slab (csrc/token_ops.hip tn_slab_for): a hipGraph captured with a small
+    product keeps working after a later, larger product has grown the slab (the old block is never freed), and a capture that would
+    itself need a larger slab neither allocates nor synchronises (it takes the float-atomic epilogue) -- both replays reproduce
+    the eager results."""
+    from dlwp_benchmark_amd import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(4)
+
+    def operands(M, N, K):
+        return (torch.randn(K, M, generator=g).to(cuda).to(BF), torch.randn(K, N, generator=g).to(cuda).to(BF),
+                torch.zeros(M, N, device=cuda))
+
+    def run(gm, xm, out):
+        K, M = gm.shape
+        N = xm.shape[1]
+        L.check(lib.dlwp_gemm_mixed(L.ptr(gm), L.ptr(xm), L.ptr(out), M, N, K, M, N, N, 1, 0, None, 0, None, None, 0, None, 3, L.stream()))
+    with L.gemm_precision("bf16"):
+        small, big = operands(1024, 768, 4096), operands(3072, 768, 8192)
+        run(*small)                                   # eager warm-up sizes the slab for the small product
+        torch.cuda.synchronize()
+        want_small = small[2].clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        g_small, g_big = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g_small):
+                run(*small)
+            free0 = torch.cuda.mem_get_info()[0]
+            with torch.cuda.graph(g_big):             # needs more slab than exists: must not allocate while capturing
+                run(*big)
+            assert torch.cuda.mem_get_info()[0] == free0
+        torch.cuda.current_stream().wait_stream(s)
+        g_big.replay()
+        torch.cuda.synchronize()
+        big_captured = big[2].clone()
+        run(*big)                                     # eager: grows the slab (a new block; the old one stays)
+        torch.cuda.synchronize()
+        ref_big = (big[0].float().t() @ big[1].float())
+        assert ((big[2] - ref_big).abs().max() / ref_big.abs().max()).item() < 2e-3
+        assert ((big_captured - ref_big).abs().max() / ref_big.abs().max()).item() < 2e-3
+        g_small.replay()                              # recorded against the OLD slab
+        torch.cuda.synchronize()
+        assert torch.equal(small[2], want_small)

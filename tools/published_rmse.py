@@ -24,7 +24,7 @@ import torch  # noqa: E402
 
 from dlwp_benchmark_amd import evaluate, nsbench, nsdata, train_loop  # noqa: E402
 
-PUBLISHED = {"persistence": 0.5993, 8: 0.0139, 27: 0.0055, 2: 0.0632}
+PUBLISHED = {"persistence": 0.5993, 8: 0.0139, 27: 0.0055, 2: 0.0632, 38: 0.0046}
 SEEDS = {"train": 11, "val": 12, "test": 13}
 N = {"train": 1000, "val": 50, "test": 200}
 
@@ -39,8 +39,8 @@ def split(name, dev, n=None, alpha=2.0, seed=None):
     return u
 
 
-def model_of(hidden, dev):
-    torch.manual_seed(1234)
+def model_of(hidden, dev, seed=1234):
+    torch.manual_seed(seed)
     return nsbench.TFNO2DModule(n_modes=[12, 12], in_channels=1, hidden_channels=hidden, lifting_channels=256,
                                 projection_channels=256, out_channels=1, n_layers=4, context_size=10).to(dev)
 
@@ -56,12 +56,15 @@ def main():
                     "generate_data() default and its source comment 'a=2.5 for 64x64' (its argparse default is 2.0); the published "
                     "persistence RMSE 0.5993 is reproduced with 2.5 (closed-loop RMSE 0.603), not with 2.0 (0.618)")
     ap.add_argument("--seeds", type=int, default=1, help="persistence phase: that many independent test splits (sampling scatter)")
+    ap.add_argument("--seed", type=int, default=1234, help="seed of the weight initialisation and of the per-epoch sample order "
+                    "(reference default: configs/config.yaml:13, 1234); other seeds give the run-to-run scatter")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "published_rmse"))
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     os.makedirs(a.out, exist_ok=True)
     log = os.path.join(a.out, "published_rmse.jsonl")
-    name = f"tfno2d64_d{a.hidden}_12-12_l4_sl50_tf10_cl40_noise0"
+    name = f"tfno2d64_d{a.hidden}_12-12_l4_sl50_tf10_cl40_noise0" + ("" if a.seed == 1234 else f"_seed{a.seed}") + \
+        ("" if a.alpha == 2.5 else f"_alpha{a.alpha}")
 
     def emit(rec):
         print(json.dumps(rec), flush=True)
@@ -83,14 +86,14 @@ def main():
         # the splits stay ON the device: assembling a batch with torch.stack on the GPU box's host cores cost 14 ms per call
         # (60 ms per iteration against a 7 ms step)
         u_train, u_val = split("train", dev, a.n_train, alpha=a.alpha).to(dev), split("val", dev, alpha=a.alpha).to(dev)
-        model = model_of(a.hidden, dev)
+        model = model_of(a.hidden, dev, a.seed)
         cont = os.path.exists(os.path.join(a.out, name, "checkpoints", f"{name}_last.ckpt"))
         t0 = time.time()
         lg = train_loop.train_ns(model, u_train, u_val, name=name, epochs=a.epochs, batch_size=4, sequence_length=50, learning_rate=1e-3,
-                                 teacher_forcing_steps=10, noise=0.0, clip_gradients=False, out_dir=a.out, continue_training=cont,
+                                 teacher_forcing_steps=10, noise=0.0, clip_gradients=False, seed=a.seed, out_dir=a.out, continue_training=cont,
                                  verbose=False, log_scalars=False, stop_epoch=a.stop_epoch)
         dt = time.time() - t0
-        emit({"what": f"train {name}", "epochs_done": lg[-1]["epoch"] + 1 if lg else None, "of": a.epochs, "resumed": cont,
+        emit({"what": f"train {name}", "seed": a.seed, "alpha": a.alpha, "epochs_done": lg[-1]["epoch"] + 1 if lg else None, "of": a.epochs, "resumed": cont,
               "seconds": round(dt, 1), "s_per_epoch": round(dt / max(len(lg), 1), 2), "n_params": sum(p.numel() for p in model.parameters()),
               "train_mse": lg[-1]["train_mse"] if lg else None, "val_mse": lg[-1]["val_mse"] if lg else None})
         return
@@ -105,7 +108,8 @@ def main():
         model.load_state_dict(ck["model_state_dict"])
         batches = [(x[i:i + 8].to(dev), y[i:i + 8].to(dev)) for i in range(0, x.shape[0], 8)]
         m = evaluate.evaluate_ns(model, batches, 10)
-        emit({"what": f"test RMSE of {name} ({tag} checkpoint, epoch {ck['epoch']})", "published_rmse": PUBLISHED.get(a.hidden),
+        emit({"what": f"test RMSE of {name} ({tag} checkpoint, epoch {ck['epoch']})", "hidden": a.hidden, "seed": a.seed, "alpha": a.alpha,
+              "published_rmse": PUBLISHED.get(a.hidden),
               **{k: round(v, 5) for k, v in m.items()},
               "ratio_closed_loop_to_published": round(m["rmse_cl"] / PUBLISHED[a.hidden], 3) if a.hidden in PUBLISHED else None})
 
