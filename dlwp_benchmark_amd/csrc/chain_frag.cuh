@@ -33,8 +33,14 @@ __device__ __forceinline__ void wload(WFrag<NT, KH>& wf, const __bf16* __restric
     for (int ni = 0; ni < NT; ++ni) {
         const int tile = min(w + 8 * ni, NTL - 1);
 #pragma unroll
-        for (int kk = 0; kk < KH; ++kk)
-            wf.f[ni][kk] = *reinterpret_cast<const bf16x8*>(img + ((long long)(tile * KS + k0 + kk) * 64 + lane) * 8);
+        for (int kk = 0; kk < KH; ++kk) {
+            const bf16x8* p = reinterpret_cast<const bf16x8*>(img + ((long long)(tile * KS + k0 + kk) * 64 + lane) * 8);
+#ifdef DLWP_CHAIN_NT          // measurement build: weight fragments are read once per CU -- non-temporal loads (no L1 allocation)
+            wf.f[ni][kk] = __builtin_nontemporal_load(p);
+#else
+            wf.f[ni][kk] = *p;
+#endif
+        }
     }
 }
 

@@ -32,7 +32,7 @@ struct WgDev {
     const __bf16* B[MAXP][MAXS];      // x segments [T][N]
     float* rowsum[MAXP];              // += sum_t g[t][m] (nullable)
     float* C[MAXP];                   // [M][N] fp32, accumulated into by the reduction launch
-    int M[MAXP], N[MAXP], ntn[MAXP];
+    int M[MAXP], N[MAXP], ntn[MAXP], overwrite[MAXP];
     int tile0[MAXP + 1];              // first tile of each product in the 1-D tile grid
     long long out_off[MAXP + 1];      // element offset of each product inside one slab slice
     float* slab;                      // [slices][out_off[nprod]]
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void wgrad_multi_kernel(WgDev a) {
             }
 }
 
-// C_p += sum over the slices, in slice order
+// C_p (+)= sum over the slices, in slice order
 __global__ __launch_bounds__(256) void wgrad_multi_reduce_kernel(WgDev a, int slices) {
     const long long total4 = a.out_off[a.nprod] / 4, plane = a.out_off[a.nprod];
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long long)gridDim.x * 256) {
@@ -170,7 +170,8 @@ __global__ __launch_bounds__(256) void wgrad_multi_reduce_kernel(WgDev a, int sl
         f32x4 v = *reinterpret_cast<const f32x4*>(a.slab + off);
         for (int z = 1; z < slices; ++z) v += *reinterpret_cast<const f32x4*>(a.slab + z * plane + off);
         float* cp = a.C[p] + (off - a.out_off[p]);
-        *reinterpret_cast<f32x4*>(cp) = *reinterpret_cast<const f32x4*>(cp) + v;
+        if (!a.overwrite[p]) v += *reinterpret_cast<const f32x4*>(cp);
+        *reinterpret_cast<f32x4*>(cp) = v;
     }
 }
 
@@ -194,6 +195,7 @@ int plan(const dlwp_wgrad_seg_product* p, int nprod, int nseg, int T, WgDev* dev
         tiles += a.ntn[i] * ceil_div(p[i].N, GT);
         off += (long long)p[i].N * p[i].K;
         a.C[i] = p[i].gw;
+        a.overwrite[i] = p[i].overwrite != 0;
         a.rowsum[i] = p[i].gb;
         for (int s = 0; s < nseg; ++s) {
             DLWP_REQUIRE(p[i].g[s] && p[i].x[s] && (reinterpret_cast<uintptr_t>(p[i].g[s]) & 15) == 0 &&

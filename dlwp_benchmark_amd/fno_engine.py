@@ -125,7 +125,13 @@ class FnoParamLayout:
             for name, (o, n, shape) in self.entries.items():
                 dst = self.view(flat, name)
                 if ".convs.weight." in name or ".convs.bias." in name:
+                    # neuralop: init_std = sqrt(2 / (Cin + Cout)); the complex weight is drawn as a complex normal of that std, i.e.
+                    # its real and imaginary parts have init_std / sqrt(2) each; the (real) spectral bias has init_std.  (Round 4:
+                    # the weights used to be drawn with init_std per part; with the published command, hidden 27, the closed-loop test
+                    # RMSE went from 0.00804 to 0.00731 against the published 0.0055 -- profiles/r04_published_rmse.json.)
                     std = (2.0 / (2 * self.hidden)) ** 0.5
+                    if ".convs.weight." in name:
+                        std /= math.sqrt(2.0)
                     dst.copy_(torch.randn(shape, generator=generator) * std)
                 elif name.endswith("weight"):
                     bound = 1.0 / math.sqrt(shape[1])

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdlwpmi.so")
+# DLWP_LIB_FILE: another build of the SAME library next to this file (measurement builds, e.g. the in-kernel stamps); never a fallback
+LIB_PATH = os.path.join(_HERE, os.path.basename(os.environ.get("DLWP_LIB_FILE", "libdlwpmi.so")))
 
 c_float_p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -109,6 +110,10 @@ SIGNATURES = {
     "dlwp_mlp_chain_supported": (_I, [_I, _I]),
     "dlwp_mlp_chain_pack": (_I, [_V, _I, _I, _I, _V, _V]),
     "dlwp_sfno_tail_pack": (_I, [_V, _V, _V, _I, _I, _V, _V]),
+    "dlwp_mlp_stream_supported": (_I, [_I, _I]),
+    "dlwp_mlp_stream_pack": (_I, [_V, _V, _I, _I, _V, _V]),
+    "dlwp_mlp_stream_fwd": (_I, [_V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _I, _I, _V]),
+    "dlwp_mlp_stream_bwd": (_I, [_V, _V, _V, _V, _V, _V, _V, _I, _I, _I, _I, _V]),
     "dlwp_sfno_io_supported": (_I, [_I, _I, _I]),
     "dlwp_sfno_io_image_elems": (_L, [_I]),
     "dlwp_sfno_io_pack": (_I, [_V, _V, _V, _V, _I, _I, _I, _I, _V, _V]),

@@ -171,11 +171,15 @@ def _flush_weight_grads(st):
     dev = enc1.weight.device
     col = lambda k: [s[k] for s in segs]
     has_dec = all("gh_d" in s for s in segs)
-    t_e1 = torch.zeros(E, KP, device=dev)
+    def temp(*shape):
+        t = torch.empty(*shape, device=dev)
+        t._dlwp_overwrite = True              # _weight_grad_segments writes the sum instead of adding to it
+        return t
+    t_e1 = temp(E, KP)
     layers = [(col("g_lp"), col("h_e"), _grad_slot(enc2.weight), None, False, enc2.weight.shape),
               (col("gh_e"), col("tok_lp"), t_e1, _grad_slot(enc1.bias), True, (E, KP))]
     if has_dec:
-        t_da, t_db, t_d2 = torch.zeros(E, E, device=dev), torch.zeros(E, KP, device=dev), torch.zeros(KP, E, device=dev)
+        t_da, t_db, t_d2 = temp(E, E), temp(E, KP), temp(KP, E)
         layers += [(col("gh_d"), col("t_lp"), t_da, _grad_slot(dec1.bias) if dec1.bias is not None else None, dec1.bias is not None, (E, E)),
                    (col("gh_d"), col("tok_lp"), t_db, None, False, (E, KP)),
                    (col("g_lp_d"), col("h_d"), t_d2, None, False, (KP, E))]

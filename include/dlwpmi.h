@@ -484,6 +484,7 @@ typedef struct dlwp_wgrad_seg_product {
     float* gw;
     float* gb;                              /* nullable */
     int N, K;
+    int overwrite;                          /* != 0: gw = the sum (no read of its old contents); gb is always accumulated into */
 } dlwp_wgrad_seg_product;
 size_t dlwp_wgrad_segments_workspace_bytes(const dlwp_wgrad_seg_product* products, int nprod, int nseg, int T);
 int dlwp_wgrad_segments(const dlwp_wgrad_seg_product* products, int nprod, int nseg, int T, void* workspace,
@@ -639,6 +640,20 @@ int dlwp_mlp_chain_pack(const float* W, int rows, int cols, int transpose, void*
 int dlwp_sfno_tail_pack(const float* ws, const float* w1, const float* w2, int C, int hidden, void* images, void* stream);
 int dlwp_sfno_tail_fwd(const dlwp_sfno_tail_fwd_args* args, void* stream);
 int dlwp_sfno_tail_bwd(const dlwp_sfno_tail_bwd_args* args, void* stream);
+/* Token MLP y = fc2(GELU(fc1 x)) (+ residual) of the AFNO / Swin / Pangu blocks (nsbench/models/fourcastnet/fourcastnet.py:40-56, */
+/* swintransformer/swin_transformer.py:25-48) and its input-gradient chain as ONE launch per direction for wide hidden layers      */
+/* (csrc/mlp_stream.hip): a workgroup owns 64 tokens and walks the hidden layer in chunks of 128 with the output accumulators in    */
+/* registers; z, h ([T][hidden] bf16) are written for the other pass and the weight gradients but never read back as operands.     */
+/*   pack: images [4][E * hidden] bf16 = forward W1 [hidden][E], W2 [E][hidden], backward W2^T, W1^T (dlwp_mlp_chain_pack order)   */
+/*   fwd : x [T][E] (bf16 array when x_bf16, else fp32 with an optional bf16 copy x_lp) -> z, h, y [T][E] fp32 (+ residual)        */
+/*   bwd : g [T][E] fp32 (-> bf16 copy g_lp, nullable), z -> gh [T][hidden] bf16, gx [T][E] (bf16 array when gx_bf16)              */
+/* dlwp_mlp_stream_supported: E = 768, hidden a multiple of 128; other widths use two dlwp_gemm_mixed calls per direction.          */
+int dlwp_mlp_stream_supported(int E, int hidden);
+int dlwp_mlp_stream_pack(const float* w1, const float* w2, int E, int hidden, void* images, void* stream);
+int dlwp_mlp_stream_fwd(const void* x, int x_bf16, void* x_lp, const void* w1_img, const float* b1, const void* w2_img, const float* b2,
+                        const float* residual, void* z, void* h, float* y, int T, int E, int hidden, void* stream);
+int dlwp_mlp_stream_bwd(const float* g, void* g_lp, const void* w2t_img, const void* w1t_img, const void* z, void* gh, void* gx,
+                        int gx_bf16, int T, int E, int hidden, void* stream);
 /* SFNO encoder / decoder with the rollout's frame assembly, ONE launch per direction each (csrc/sfno_io.hip).  Reference:   */
 /* SphericalFourierNeuralOperatorNet's encoder / decoder 1x1-convolution MLPs, position embedding and big skip (constructed at */
 /* src/dlwpbench/models/fno/fno.py:183-200) inside SFNO2DModule.forward's loop (fno.py:217-259; clean form unet.py:64-111):    */

@@ -58,13 +58,16 @@ def main():
     ap.add_argument("--seeds", type=int, default=1, help="persistence phase: that many independent test splits (sampling scatter)")
     ap.add_argument("--seed", type=int, default=1234, help="seed of the weight initialisation and of the per-epoch sample order "
                     "(reference default: configs/config.yaml:13, 1234); other seeds give the run-to-run scatter")
+    ap.add_argument("--spectral-init-scale", type=float, default=1.0, help="multiply the initial spectral weights by this factor "
+                    "(the module draws real and imaginary parts with std sqrt(2 / (Cin + Cout)) each; a complex normal of that std "
+                    "has 1/sqrt(2) of it per part)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "published_rmse"))
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     os.makedirs(a.out, exist_ok=True)
     log = os.path.join(a.out, "published_rmse.jsonl")
     name = f"tfno2d64_d{a.hidden}_12-12_l4_sl50_tf10_cl40_noise0" + ("" if a.seed == 1234 else f"_seed{a.seed}") + \
-        ("" if a.alpha == 2.5 else f"_alpha{a.alpha}")
+        ("" if a.alpha == 2.5 else f"_alpha{a.alpha}") + ("" if a.spectral_init_scale == 1.0 else f"_sinit{a.spectral_init_scale:.3f}")
 
     def emit(rec):
         print(json.dumps(rec), flush=True)
@@ -87,13 +90,18 @@ def main():
         # (60 ms per iteration against a 7 ms step)
         u_train, u_val = split("train", dev, a.n_train, alpha=a.alpha).to(dev), split("val", dev, alpha=a.alpha).to(dev)
         model = model_of(a.hidden, dev, a.seed)
+        if a.spectral_init_scale != 1.0:
+            with torch.no_grad():
+                for pname in model.layout.entries:
+                    if ".convs.weight." in pname:
+                        model.layout.view(model.flat_params.data, pname).mul_(a.spectral_init_scale)
         cont = os.path.exists(os.path.join(a.out, name, "checkpoints", f"{name}_last.ckpt"))
         t0 = time.time()
         lg = train_loop.train_ns(model, u_train, u_val, name=name, epochs=a.epochs, batch_size=4, sequence_length=50, learning_rate=1e-3,
                                  teacher_forcing_steps=10, noise=0.0, clip_gradients=False, seed=a.seed, out_dir=a.out, continue_training=cont,
                                  verbose=False, log_scalars=False, stop_epoch=a.stop_epoch)
         dt = time.time() - t0
-        emit({"what": f"train {name}", "seed": a.seed, "alpha": a.alpha, "epochs_done": lg[-1]["epoch"] + 1 if lg else None, "of": a.epochs, "resumed": cont,
+        emit({"what": f"train {name}", "seed": a.seed, "alpha": a.alpha, "spectral_init_scale": a.spectral_init_scale, "epochs_done": lg[-1]["epoch"] + 1 if lg else None, "of": a.epochs, "resumed": cont,
               "seconds": round(dt, 1), "s_per_epoch": round(dt / max(len(lg), 1), 2), "n_params": sum(p.numel() for p in model.parameters()),
               "train_mse": lg[-1]["train_mse"] if lg else None, "val_mse": lg[-1]["val_mse"] if lg else None})
         return
@@ -108,7 +116,7 @@ def main():
         model.load_state_dict(ck["model_state_dict"])
         batches = [(x[i:i + 8].to(dev), y[i:i + 8].to(dev)) for i in range(0, x.shape[0], 8)]
         m = evaluate.evaluate_ns(model, batches, 10)
-        emit({"what": f"test RMSE of {name} ({tag} checkpoint, epoch {ck['epoch']})", "hidden": a.hidden, "seed": a.seed, "alpha": a.alpha,
+        emit({"what": f"test RMSE of {name} ({tag} checkpoint, epoch {ck['epoch']})", "hidden": a.hidden, "seed": a.seed, "alpha": a.alpha, "spectral_init_scale": a.spectral_init_scale,
               "published_rmse": PUBLISHED.get(a.hidden),
               **{k: round(v, 5) for k, v in m.items()},
               "ratio_closed_loop_to_published": round(m["rmse_cl"] / PUBLISHED[a.hidden], 3) if a.hidden in PUBLISHED else None})
