@@ -58,3 +58,16 @@ def test_real_token_flow_equals_reference_order(cuda, B, res, heads, dim, shifte
     names = ["x"] + [n for n, _ in blk.named_parameters()]
     for n, a, b in zip(names, outs[True][1], outs[False][1]):
         assert rel(a, b) <= 2e-4, n
+    if B > 2:
+        return
+    # ... and BOTH equal the CPU restatement of the reference block (oracle/pangu_ref.earth_block, pinned by
+    # tests/golden/pangu_golden.npz in tests/test_oracle_pangu.py), evaluated in float64 with autograd: output and every gradient
+    from oracle import pangu_ref
+    p64 = {n: t.detach().double().cpu().requires_grad_(True) for n, t in blk.named_parameters()}
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    y64 = pangu_ref.earth_block(x64, p64, "", res, heads, (2, 7, 7), pangu_ref.DEFAULT_SHIFT if shifted else (0, 0, 0))
+    g64 = torch.autograd.grad(y64, [x64] + [p64[n] for n in names[1:]], g.double().cpu())
+    for flow in (False, True):
+        assert rel(outs[flow][0], y64) <= 2e-5, flow
+        for n, a, b in zip(names, outs[flow][1], g64):
+            assert rel(a, b) <= 2e-4, (flow, n)

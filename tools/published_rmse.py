@@ -67,7 +67,9 @@ def main():
     os.makedirs(a.out, exist_ok=True)
     log = os.path.join(a.out, "published_rmse.jsonl")
     name = f"tfno2d64_d{a.hidden}_12-12_l4_sl50_tf10_cl40_noise0" + ("" if a.seed == 1234 else f"_seed{a.seed}") + \
-        ("" if a.alpha == 2.5 else f"_alpha{a.alpha}") + ("" if a.spectral_init_scale == 1.0 else f"_sinit{a.spectral_init_scale:.3f}")
+        ("" if a.alpha == 2.5 else f"_alpha{a.alpha}") + ("_cn" if a.spectral_init_scale == 1.0 else f"_cnx{a.spectral_init_scale:.3f}")
+    # "_cn": fno_engine draws the spectral weights as a complex normal (std / sqrt 2 per part) since round 4; "_cnx1.414" restores the
+    # round-3 draw (full std per part).  Round-4 logs named "_sinit0.707" were made before the engine changed and equal "_cn".
 
     def emit(rec):
         print(json.dumps(rec), flush=True)
