@@ -44,6 +44,8 @@ Knob g_knobs[] = {
     {"WINATTN_TILED", "1: the tiled window-attention kernels also for many short windows", 0, false},
     {"WINATTN_WG_BWD", "workgroup width selector of the wave-per-window attention backward", 0, false},
     {"WINATTN_NOLDS", "1: the register-fragment attention backward instead of the LDS-staged one", 0, false},
+    {"WINATTN_DBG", "measurement only (wrong results): bit switches that drop phases of the one-pass attention backward", 0, false},
+    {"WINATTN_BWD2PASS", "1: the two-pass LDS-staged attention backward instead of the one-pass kernel", 0, false},
     {"FFT_IBW", "inner lanes of the W-axis FFT pass", 0, false},
     {"FFT_IBH", "inner lanes of the H-axis FFT pass", 0, false},
     {"CHAIN_ROT", "0: no rotation of the wave -> feature-tile assignment in the one-launch MLP chains (default 1)", 0, false},

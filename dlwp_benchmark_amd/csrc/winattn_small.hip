@@ -36,6 +36,7 @@ struct WsDev {
     const float *lse_in, *gout, *o;
     float *gqkv, *gtable;
     int B_, nW, N, heads, d, TB, ntypes, M, groups;
+    int dbg;                   // measurement switches of the one-pass backward (DLWP_WINATTN_DBG): results are wrong when set
     int qc_lo, qc_hi;          // query chunks (of 16 tokens) to compute; the rest are padded positions whose outputs nobody reads
                                // and whose upstream gradient is zero (Pangu: half of every window, dlwp_window_attn_fwd_qrange)
     float scale;
@@ -656,6 +657,283 @@ __global__ __launch_bounds__(256) void winattn_lds_bwd_kernel(WsDev a) {
         if (L.gtb[i] != 0ull) atomic_add_f32(&a.gtable[(long long)i * w.tstr + w.tofs], (float)(long long)L.gtb[i] * (1.f / FXS));
 }
 
+// ---- (round 4) the same backward with ONE evaluation of every score tile.  The two-pass kernel above evaluates every score tile
+// twice (bias lookup, mask, exponential, packing: the bookkeeping that bounds it) because dQ wants dS with the queries on the
+// fragment's row lanes and dK / dV want it with the keys there, and it pays 4 LDS 64-bit atomics per lane and tile pair for the
+// bias gradient.  Here:
+//   pass 1   a wave owns a KEY chunk (NW waves, chunks kc = wave, wave + NW ...) and walks the query chunks once:
+//              S, dP         two MFMA pairs, rows = queries 4g + j, column = key r                     (as pass K above)
+//              P, dS         one exponential per element
+//              dV^T, dK^T    accumulate in registers (dO^T P, (scale Q)^T dS), stored by the owning wave at the end
+//              dBias         dS added into a DENSE [key][query] fp32 image of the window pairs in LDS: the tile (kc, qc) belongs
+//                            to one wave for every window of the workgroup, so the update is a plain 16-byte read-modify-write
+//                            per lane (no atomics; row pitch NR + 4: bank-conflict free); the image is folded into the table
+//                            slots (index ia[q] + ib[key], ~3.8 pairs per slot) ONCE per workgroup and flushed with float atomics
+//              dS (bf16)     written TRANSPOSED into a [query][key] LDS matrix (four 2-byte stores per lane)
+//            every operand of tile pair t + 1 (row / column fragments, index vectors, statistics, bias values, the dense tile) is
+//            read while tile pair t is computed: with two waves per SIMD the walk is bound by dependent LDS latencies otherwise;
+//   pass 2   a wave owns a QUERY chunk: dQ = dS K from the stored matrix, row fragments as one 8-byte read, two MFMAs per tile
+//            pair and no score arithmetic; scaled and stored straight from the registers.
+// (LDS float atomics for dQ instead of pass 2 were measured first: 8 ds_add_f32 per lane and tile pair cost 343 of 575 us at the
+// Pangu C4 layer-1 shape.)  Per tile pair: 10 MFMAs instead of 14 and one score evaluation instead of two.  NW = 8 (512 threads,
+// 5 - 8 key chunks: Pangu's 98 tokens) or 4 (<= 4 chunks: Swin's 49); LDS 127 KB (N = 98, table 2548) / 40 KB (N = 49).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+struct LdsWin2 {
+    LdsWin w;
+    float* dense;
+    bf16_t* dsm;
+};
+__host__ __device__ inline size_t lds2_bytes(int NR, int TB) {
+    return (size_t)4 * NR * LDB * 2 + (size_t)5 * NR * 4 + (size_t)((TB + 3) & ~3) * 4 + (size_t)NR * (NR + 4) * 4 + (size_t)NR * (NR + 4) * 2;
+}
+__device__ __forceinline__ LdsWin2 lds2_carve(void* smem, int NR, int TB) {
+    LdsWin2 L;
+    bf16_t* h = reinterpret_cast<bf16_t*>(smem);
+    L.w.Q = h; L.w.K = L.w.Q + NR * LDB; L.w.V = L.w.K + NR * LDB; L.w.G = L.w.V + NR * LDB;
+    float* f = reinterpret_cast<float*>(L.w.G + NR * LDB);
+    L.w.D = f; L.w.lse = f + NR;
+    L.w.ia = reinterpret_cast<int*>(f + 2 * NR); L.w.ib = L.w.ia + NR; L.w.lab = L.w.ib + NR;
+    L.w.tb = reinterpret_cast<float*>(L.w.lab + NR);
+    L.w.gtb = nullptr;
+    L.dense = L.w.tb + ((TB + 3) & ~3);
+    L.dsm = reinterpret_cast<bf16_t*>(L.dense + NR * (NR + 4));
+    return L;
+}
+// lds_stage<true> in two halves for a workgroup of NT threads: the global loads of window m + 1 (into registers) are issued before the
+// passes over window m and land under them; the conversion to the bf16 LDS image follows the barrier that ends window m.  (Measured
+// with the in-kernel stamps at the Pangu C4 layer-1 shape: staging in one piece took 7.9 k cycles per window, pass 1 8.1 k.)
+// Two (token, 4-channel group) items per thread cover NR <= 128 rows with 512 threads and NR <= 64 with 256.
+struct Stage2 {
+    f32x4 q[2], k[2], v[2], g[2], o[2];
+    float lse;
+    int lab;
+};
+template <int NT>
+__device__ __forceinline__ void lds2_load(Stage2& R, const WsDev& a, const Who& w, int NR) {
+    const int N = a.N, d = a.d, tid = threadIdx.x, ch = tid & 7;
+    const long long rs = 3LL * a.heads * d, os = (long long)a.heads * d;
+    const float* qb = a.qkv + (long long)w.b * N * rs + w.head * d;
+    const float* gb = a.gout + (long long)w.b * N * os + w.head * d;
+    const float* ob = a.o + (long long)w.b * N * os + w.head * d;
+    const int cc = 4 * ch < d ? 4 * ch : 0;              // clamped: unconditional loads
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int tok = (tid >> 3) + i * (NT / 8);
+        const int tc = tok < N ? tok : N - 1;
+        const float* row = qb + (long long)tc * rs + cc;
+        R.q[i] = *reinterpret_cast<const f32x4*>(row);
+        R.k[i] = *reinterpret_cast<const f32x4*>(row + a.heads * d);
+        R.v[i] = *reinterpret_cast<const f32x4*>(row + 2 * a.heads * d);
+        R.g[i] = *reinterpret_cast<const f32x4*>(gb + (long long)tc * os + cc);
+        R.o[i] = *reinterpret_cast<const f32x4*>(ob + (long long)tc * os + cc);
+    }
+    const int tc = tid < N ? tid : N - 1;
+    R.lse = a.lse_in[((long long)w.b * a.heads + w.head) * N + tc];
+    R.lab = a.labels ? a.labels[(long long)w.wdw * N + tc] : 0;
+}
+template <int NT>
+__device__ __forceinline__ void lds2_store(const Stage2& R, const WsDev& a, const LdsWin& L, int NR) {
+    const int N = a.N, d = a.d, tid = threadIdx.x, ch = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int tok = (tid >> 3) + i * (NT / 8);
+        if (tok < NR) {
+            const bool ok = tok < N && 4 * ch < d;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            f32x4 q = R.q[i], k = R.k[i], v = R.v[i], g = R.g[i], o = R.o[i];
+            if (!ok) { q = z; k = z; v = z; g = z; o = z; }
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) q[s2] *= a.scale;
+            *reinterpret_cast<s16x4*>(L.Q + tok * LDB + 4 * ch) = pack_bf(q);
+            *reinterpret_cast<s16x4*>(L.K + tok * LDB + 4 * ch) = pack_bf(k);
+            *reinterpret_cast<s16x4*>(L.V + tok * LDB + 4 * ch) = pack_bf(v);
+            *reinterpret_cast<s16x4*>(L.G + tok * LDB + 4 * ch) = pack_bf(g);
+            float dp = g[0] * o[0] + g[1] * o[1] + g[2] * o[2] + g[3] * o[3];
+            dp += __shfl_xor(dp, 1); dp += __shfl_xor(dp, 2); dp += __shfl_xor(dp, 4);
+            if (ch == 0) L.D[tok] = dp;
+        }
+    }
+    if (tid < NR) { L.lse[tid] = R.lse; L.lab[tid] = R.lab; }
+}
+
+template <int NDB, int NW>
+__global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
+    constexpr int NT = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int N = a.N, d = a.d, NCr = (N + 15) / 16, NR = 16 * NCr, LDD = NR + 4;
+    const LdsWin2 L2 = lds2_carve(smem, NR, a.TB);
+    const LdsWin& L = L2.w;
+    int grp;
+    Who w = who_lds(a, grp);
+    if (a.table_t) { for (int i = threadIdx.x; i < a.TB; i += NT) L.tb[i] = a.table_t[w.tofs * a.TB + i]; }
+    else { for (int i = threadIdx.x; i < a.TB; i += NT) L.tb[i] = a.table[(long long)i * w.tstr + w.tofs]; }
+    DLWP_STAMP(0);
+    Stage2 R;
+    who_window(a, w, grp);
+    lds2_load<NT>(R, a, w, NR);              // the first window's loads fly while tb / dense are initialised
+    for (int i = threadIdx.x; i < NR * LDD; i += NT) L2.dense[i] = 0.f;
+    for (int t = threadIdx.x; t < NR; t += NT) {      // the bias-index vectors do not depend on the window
+        const int tc = t < N ? t : N - 1;
+        L.ia[t] = a.ia[tc];
+        L.ib[t] = a.ib[tc];
+    }
+    const int lane = lane_id(), r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    const long long rs = 3LL * a.heads * d;
+    const bool masked = a.labels != nullptr;
+    const int qlo = a.qc_lo, qhi = min(a.qc_hi, NCr), nq = qhi - qlo;
+    // operands of one tile pair of pass 1 (everything that does not depend on the matrix products)
+    struct Pre {
+        s16x4 qr[NDB], gr[NDB], qcol[NDB], gcol[NDB];
+        i32x4 lab;
+        f32x4 lse, D, dense, tbv;
+    };
+    for (int m = grp; m < a.M; m += a.groups) {
+        who_window(a, w, m);
+        __syncthreads();                   // the previous window's fragments have been read (first turn: tb / dense are initialised)
+        if (m == grp) DLWP_STAMP(1);
+        lds2_store<NT>(R, a, L, NR);
+        float* gq = a.gqkv + (long long)w.b * N * rs + w.head * d;
+        __syncthreads();
+        if (m == grp) DLWP_STAMP(2);
+        if (m + a.groups < a.M) {
+            Who wn = w;
+            who_window(a, wn, m + a.groups);
+            lds2_load<NT>(R, a, wn, NR);
+        }
+        // ---- pass 1
+        for (int kc = wv; kc < ((a.dbg & 1) ? 0 : NCr); kc += NW) {
+            const int key = 16 * kc + r;
+            const int kbi = L.ib[key], kl = L.lab[key];
+            s16x4 kf[NDB], vf[NDB];
+            f32x4 dk[NDB], dv[NDB];
+#pragma unroll
+            for (int cc = 0; cc < NDB; ++cc) {
+                kf[cc] = lds_row(L.K, key, 16 * cc + 4 * g);
+                vf[cc] = lds_row(L.V, key, 16 * cc + 4 * g);
+                dk[cc] = dv[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            float* drow = L2.dense + (16 * kc + r) * LDD + 4 * g;
+            auto load = [&](Pre& P, int qc) {
+                const int q0 = 16 * qc + 4 * g;
+                const i32x4 qia = *reinterpret_cast<const i32x4*>(L.ia + q0);
+#pragma unroll
+                for (int cc = 0; cc < NDB; ++cc) {
+                    P.qr[cc] = lds_row(L.Q, 16 * qc + r, 16 * cc + 4 * g);
+                    P.gr[cc] = lds_row(L.G, 16 * qc + r, 16 * cc + 4 * g);
+                    P.qcol[cc] = lds_col(L.Q, q0, 16 * cc + r);
+                    P.gcol[cc] = lds_col(L.G, q0, 16 * cc + r);
+                }
+                P.lab = *reinterpret_cast<const i32x4*>(L.lab + q0);
+                P.lse = *reinterpret_cast<const f32x4*>(L.lse + q0);
+                P.D = *reinterpret_cast<const f32x4*>(L.D + q0);
+                P.dense = *reinterpret_cast<const f32x4*>(drow + 16 * qc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) P.tbv[j] = L.tb[qia[j] + kbi];
+            };
+            Pre cur, nxt;
+            if (nq > 0) load(cur, qlo);
+            nxt = cur;
+#pragma unroll 1
+            for (int qc = qlo; qc < qhi; ++qc) {
+                if (m == grp && kc == 0) DLWP_STAMP(24 + qc - qlo);
+                if (qc + 1 < qhi) load(nxt, qc + 1);
+                f32x4 sc4 = f32x4{0.f, 0.f, 0.f, 0.f}, dp = sc4;
+#pragma unroll
+                for (int cc = 0; cc < NDB; ++cc) {
+                    sc4 = mfma_bf(cur.qr[cc], kf[cc], sc4);      // rows = queries 16 qc + 4g + j, column = key r
+                    dp = mfma_bf(cur.gr[cc], vf[cc], dp);
+                }
+                const int q0 = 16 * qc + 4 * g;
+                f32x4 p, ds;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float sc = sc4[j] + cur.tbv[j];
+                    if (masked && cur.lab[j] != kl) sc -= 100.f;
+                    const float pv = (q0 + j < N && key < N) ? __expf(sc - cur.lse[j]) : 0.f;
+                    p[j] = pv;
+                    ds[j] = pv * (dp[j] - cur.D[j]);
+                }
+                if (!(a.dbg & 8)) *reinterpret_cast<f32x4*>(drow + 16 * qc) = cur.dense + ds;      // bias gradient: this wave's own tile
+                const s16x4 pb = pack_bf(p), dsb = pack_bf(ds);
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) {
+                    dv[db] = mfma_bf(cur.gcol[db], pb, dv[db]);      // dV^T += dO^T P
+                    dk[db] = mfma_bf(cur.qcol[db], dsb, dk[db]);     // dK^T += (scale Q)^T dS
+                }
+                if (!(a.dbg & 4)) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) L2.dsm[(q0 + j) * LDD + key] = (bf16_t)dsb[j];      // dS, queries on the rows
+                }
+                cur = nxt;
+            }
+            if (key < N) {
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) {
+                    const int dd = 16 * db + 4 * g;
+                    if (dd < d) {
+                        float* dst = gq + (long long)key * rs + dd;
+                        *reinterpret_cast<f32x4*>(dst + a.heads * d) = dk[db];
+                        *reinterpret_cast<f32x4*>(dst + 2 * a.heads * d) = dv[db];
+                    }
+                }
+            }
+        }
+        if (m == grp) DLWP_STAMP_WAVE(8);
+        __syncthreads();
+        if (m == grp) DLWP_STAMP(3);
+        // ---- pass 2: dQ = dS K for the computed query chunks (rows = queries 4g + j, column = channel 16 db + r), zeros elsewhere
+        for (int qc = wv; qc < ((a.dbg & 32) ? 0 : NCr); qc += NW) {
+            f32x4 dq[NDB];
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) dq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (qc >= qlo && qc < qhi) {
+                const bf16_t* srow = L2.dsm + (16 * qc + r) * LDD + 4 * g;
+                s16x4 sf = *reinterpret_cast<const s16x4*>(srow), sn = sf;
+                s16x4 kcol[NDB], kn[NDB];
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) kn[db] = kcol[db] = lds_col(L.K, 4 * g, 16 * db + r);
+#pragma unroll 1
+                for (int kc = 0; kc < NCr; ++kc) {
+                    if (kc + 1 < NCr) {
+                        sn = *reinterpret_cast<const s16x4*>(srow + 16 * (kc + 1));
+#pragma unroll
+                        for (int db = 0; db < NDB; ++db) kn[db] = lds_col(L.K, 16 * (kc + 1) + 4 * g, 16 * db + r);
+                    }
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db) dq[db] = mfma_bf(sf, kcol[db], dq[db]);
+                    sf = sn;
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db) kcol[db] = kn[db];
+                }
+            }
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int q = 16 * qc + 4 * g + j, dd = 16 * db + r;
+                    if (q < N && dd < d) gq[(long long)q * rs + dd] = dq[db][j] * a.scale;
+                }
+        }
+    }
+    DLWP_STAMP_WAVE(16);
+    __syncthreads();
+    DLWP_STAMP(4);
+    // fold the dense image into the table slots (the staging area is free now), then flush
+    float* tbg = reinterpret_cast<float*>(L.Q);
+    for (int i = threadIdx.x; i < a.TB; i += NT) tbg[i] = 0.f;
+    __syncthreads();
+    for (int e = threadIdx.x; e < ((a.dbg & 16) ? 0 : N * N); e += NT) {
+        const int key = e / N, q = e - key * N;
+        const float v = L2.dense[key * LDD + q];
+        if (v != 0.f) atomicAdd(tbg + L.ia[q] + L.ib[key], v);
+    }
+    __syncthreads();
+    DLWP_STAMP(5);
+    for (int i = threadIdx.x; i < a.TB; i += NT)
+        if (tbg[i] != 0.f) atomic_add_f32(&a.gtable[(long long)i * w.tstr + w.tofs], tbg[i]);
+    DLWP_STAMP(6);
+}
+
 // windows of one (type, head) per workgroup: enough workgroups to fill the chip about three times over
 // (Pangu C4 layer 1, 4218 (window, head) pairs, tools/probe_winattn_c4.py: 768 workgroups 277 us, 1536: 272, 3072: 288, one per
 // window: 370; the register-fragment kernel: 338)
@@ -742,6 +1020,37 @@ int dlwp_winattn_small_bwd(const float* qkv, const float* table, const float* pa
     a.gout = gout; a.gqkv = gqkv; a.gtable = gtable;
     if (lds_family_applies(N, d)) {
         const int nc = (N + 15) / 16;
+        // the one-pass kernel (round 4) wherever its LDS image fits and the table slice fits the staging area it is folded in
+        const int nw1 = nc > 4 ? 8 : 4;
+        const size_t lb1 = lds2_bytes(16 * nc, TB);
+        if (!dlwp_tune_on("WINATTN_BWD2PASS") && lb1 <= 160 * 1024 && (size_t)TB * 4 <= (size_t)4 * 16 * nc * LDB * 2) {
+            const int want = dlwp_tune_or("WINATTN_WG_BWD", 0);
+            a.dbg = dlwp_tune_or("WINATTN_DBG", 0);
+            // one round of workgroups: a workgroup's table staging, dense-image fold and flush cost ~36 k cycles (stamps), a window
+            // ~12 k, so the windows of a (type, head) are split over as many workgroups as fit on the chip at once and no more
+            // (Pangu C4 layer 1, 114 pairs x 37 windows: 228 workgroups 177 us, 456: 202, 798: 252)
+            static const int ncu = [] {
+                int dev = 0, n = 256;
+                if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+                return n > 0 ? n : 256;
+            }();
+            const int slots = ncu * (nw1 == 8 ? 1 : 2);
+            const long long per = want ? ((long long)want + heads * ntypes - 1) / (heads * ntypes) : slots / (heads * ntypes);
+            a.groups = per < 1 ? 1 : (per > a.M ? a.M : (int)per);
+            const dim3 grid((unsigned)(heads * ntypes * a.groups));
+            auto go1 = [&](auto knl, int nt) -> int {
+                int rc2 = dlwp_ensure_lds(reinterpret_cast<const void*>(knl), lb1, "winattn_lds_bwd1p");
+                if (rc2) return rc2;
+                hipLaunchKernelGGL(knl, grid, dim3(nt), lb1, (hipStream_t)stream, a);
+                return DLWP_OK;
+            };
+            int rc1;
+            if (nw1 == 8) rc1 = d <= 16 ? go1(winattn_lds_bwd1p_kernel<1, 8>, 512) : go1(winattn_lds_bwd1p_kernel<2, 8>, 512);
+            else rc1 = d <= 16 ? go1(winattn_lds_bwd1p_kernel<1, 4>, 256) : go1(winattn_lds_bwd1p_kernel<2, 4>, 256);
+            if (rc1) return rc1;
+            DLWP_LAUNCH_CHECK();
+            return DLWP_OK;
+        }
         const size_t lb = lds_bytes(16 * nc, TB, true);
         a.groups = lds_groups(a.M, heads, ntypes);
         const dim3 grid((unsigned)(heads * ntypes * a.groups)), block(256);
@@ -777,3 +1086,9 @@ int dlwp_winattn_small_bwd(const float* qkv, const float* table, const float* pa
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }
+
+#ifdef DLWP_STAMPS
+extern "C" int dlwp_debug_stamps_winattn_small(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dlwp_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -41,9 +41,11 @@ def run(B_, nW, N, heads, d, TB, ntypes, qr, iters=30):
         e1.record(); torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) / iters * 1e3)
     print(f"B_={B_} N={N} heads={heads} d={d} types={ntypes} qrange={qr}: fwd {res[0]:7.1f} us  bwd {res[1]:7.1f} us   "
-          f"[WG_BWD={os.environ.get('DLWP_WINATTN_WG_BWD', '-')} NOLDS={os.environ.get('DLWP_WINATTN_NOLDS', '-')}]", flush=True)
+          f"[WG_BWD={os.environ.get('DLWP_WINATTN_WG_BWD', '-')} NOLDS={os.environ.get('DLWP_WINATTN_NOLDS', '-')} DBG={os.environ.get('DLWP_WINATTN_DBG', '-')}]", flush=True)
 
 
-run(703, 703, 98, 6, 32, 2548, 19, (49, 98))
-run(190, 190, 98, 12, 32, 2548, 10, (49, 98))
-run(703, 703, 98, 6, 32, 2548, 19, (0, 98))
+SHAPES = [(703, 703, 98, 6, 32, 2548, 19, (49, 98)), (190, 190, 98, 12, 32, 2548, 10, (49, 98)), (703, 703, 98, 6, 32, 2548, 19, (0, 98))]
+for i, sh in enumerate(SHAPES):
+    if os.environ.get("PROBE_FIRST") and i:
+        break
+    run(*sh)
