@@ -36,6 +36,12 @@ struct WsDev {
     const float *lse_in, *gout, *o;
     float *gqkv, *gtable;
     int B_, nW, N, heads, d, TB, ntypes, M, groups;
+    // token-layout mode of the one-pass backward (dlwp_window_attn_bwd_tokens): the upstream gradient and the qkv gradient live in
+    // the UNPARTITIONED layout [batch][Ltok][.]; window position n of window `wdw` reads its gout row at token dst_map[wdw][n] and
+    // writes its gqkv row at token src_map[wdw][n] (-1: a padded position -- zero upstream gradient / its gradient is the fill's)
+    const int *src_map, *dst_map;
+    float* gfill;              // [3 heads d]: sum of the qkv gradient over the padded positions (accumulated)
+    int Ltok;
     int dbg;                   // measurement switches of the one-pass backward (DLWP_WINATTN_DBG): results are wrong when set
     int qc_lo, qc_hi;          // query chunks (of 16 tokens) to compute; the rest are padded positions whose outputs nobody reads
                                // and whose upstream gradient is zero (Pangu: half of every window, dlwp_window_attn_fwd_qrange)
@@ -682,9 +688,11 @@ struct LdsWin2 {
     LdsWin w;
     float* dense;
     bf16_t* dsm;
+    int* src;          // gqkv row of every window position (token-layout mode: the map's row; -1 = padded position)
 };
 __host__ __device__ inline size_t lds2_bytes(int NR, int TB) {
-    return (size_t)4 * NR * LDB * 2 + (size_t)5 * NR * 4 + (size_t)((TB + 3) & ~3) * 4 + (size_t)NR * (NR + 4) * 4 + (size_t)NR * (NR + 4) * 2;
+    return (size_t)4 * NR * LDB * 2 + (size_t)5 * NR * 4 + (size_t)((TB + 3) & ~3) * 4 + (size_t)NR * (NR + 4) * 4 + (size_t)NR * (NR + 4) * 2 +
+           (size_t)NR * 4;
 }
 __device__ __forceinline__ LdsWin2 lds2_carve(void* smem, int NR, int TB) {
     LdsWin2 L;
@@ -697,6 +705,7 @@ __device__ __forceinline__ LdsWin2 lds2_carve(void* smem, int NR, int TB) {
     L.w.gtb = nullptr;
     L.dense = L.w.tb + ((TB + 3) & ~3);
     L.dsm = reinterpret_cast<bf16_t*>(L.dense + NR * (NR + 4));
+    L.src = reinterpret_cast<int*>(L.dsm + NR * (NR + 4));
     return L;
 }
 // lds_stage<true> in two halves for a workgroup of NT threads: the global loads of window m + 1 (into registers) are issued before the
@@ -706,15 +715,36 @@ __device__ __forceinline__ LdsWin2 lds2_carve(void* smem, int NR, int TB) {
 struct Stage2 {
     f32x4 q[2], k[2], v[2], g[2], o[2];
     float lse;
-    int lab;
+    int lab, src, dst;
+};
+// token-layout mode: the map entries a thread needs for window m + 1 (gout rows of its two items; the LDS copies of both maps) are
+// fetched one window earlier still, so that the dependent gout loads do not wait on them
+struct Idx2 {
+    int d[2], src, dst;
 };
 template <int NT>
-__device__ __forceinline__ void lds2_load(Stage2& R, const WsDev& a, const Who& w, int NR) {
+__device__ __forceinline__ void lds2_index(Idx2& I, const WsDev& a, const Who& w) {
+    const int N = a.N, tid = threadIdx.x;
+    I.d[0] = I.d[1] = I.src = I.dst = 0;
+    if (!a.dst_map) return;
+    const int* dm = a.dst_map + (long long)w.wdw * N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int tok = (tid >> 3) + i * (NT / 8);
+        I.d[i] = dm[tok < N ? tok : N - 1];
+    }
+    const int tc = tid < N ? tid : N - 1;
+    I.dst = dm[tc];
+    I.src = a.src_map[(long long)w.wdw * N + tc];
+}
+template <int NT>
+__device__ __forceinline__ void lds2_load(Stage2& R, const Idx2& I, const WsDev& a, const Who& w, int NR) {
     const int N = a.N, d = a.d, tid = threadIdx.x, ch = tid & 7;
     const long long rs = 3LL * a.heads * d, os = (long long)a.heads * d;
     const float* qb = a.qkv + (long long)w.b * N * rs + w.head * d;
-    const float* gb = a.gout + (long long)w.b * N * os + w.head * d;
     const float* ob = a.o + (long long)w.b * N * os + w.head * d;
+    const bool tokm = a.dst_map != nullptr;
+    const float* gb = a.gout + (tokm ? (long long)(w.b / a.nW) * a.Ltok : (long long)w.b * N) * os + w.head * d;
     const int cc = 4 * ch < d ? 4 * ch : 0;              // clamped: unconditional loads
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -724,15 +754,19 @@ __device__ __forceinline__ void lds2_load(Stage2& R, const WsDev& a, const Who& 
         R.q[i] = *reinterpret_cast<const f32x4*>(row);
         R.k[i] = *reinterpret_cast<const f32x4*>(row + a.heads * d);
         R.v[i] = *reinterpret_cast<const f32x4*>(row + 2 * a.heads * d);
-        R.g[i] = *reinterpret_cast<const f32x4*>(gb + (long long)tc * os + cc);
+        const int gt = tokm ? (I.d[i] < 0 ? 0 : I.d[i]) : tc;
+        R.g[i] = *reinterpret_cast<const f32x4*>(gb + (long long)gt * os + cc);
+        if (tokm && I.d[i] < 0) R.g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         R.o[i] = *reinterpret_cast<const f32x4*>(ob + (long long)tc * os + cc);
     }
     const int tc = tid < N ? tid : N - 1;
     R.lse = a.lse_in[((long long)w.b * a.heads + w.head) * N + tc];
     R.lab = a.labels ? a.labels[(long long)w.wdw * N + tc] : 0;
+    R.src = tokm ? I.src : tc;
+    R.dst = I.dst;
 }
 template <int NT>
-__device__ __forceinline__ void lds2_store(const Stage2& R, const WsDev& a, const LdsWin& L, int NR) {
+__device__ __forceinline__ void lds2_store(const Stage2& R, const WsDev& a, const LdsWin& L, int* srcv, int NR) {
     const int N = a.N, d = a.d, tid = threadIdx.x, ch = tid & 7;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -753,7 +787,7 @@ __device__ __forceinline__ void lds2_store(const Stage2& R, const WsDev& a, cons
             if (ch == 0) L.D[tok] = dp;
         }
     }
-    if (tid < NR) { L.lse[tid] = R.lse; L.lab[tid] = R.lab; }
+    if (tid < NR) { L.lse[tid] = R.lse; L.lab[tid] = R.lab; srcv[tid] = R.src; }
 }
 
 template <int NDB, int NW>
@@ -769,8 +803,19 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
     else { for (int i = threadIdx.x; i < a.TB; i += NT) L.tb[i] = a.table[(long long)i * w.tstr + w.tofs]; }
     DLWP_STAMP(0);
     Stage2 R;
+    Idx2 I;
     who_window(a, w, grp);
-    lds2_load<NT>(R, a, w, NR);              // the first window's loads fly while tb / dense are initialised
+    lds2_index<NT>(I, a, w);
+    lds2_load<NT>(R, I, a, w, NR);           // the first window's loads fly while tb / dense are initialised
+    if (grp + a.groups < a.M) {
+        Who wn = w;
+        who_window(a, wn, grp + a.groups);
+        lds2_index<NT>(I, a, wn);
+    }
+    const bool tokm = a.dst_map != nullptr;
+    f32x4 padk[NDB], padv[NDB], padq[NDB];   // token-layout mode: this lane's share of the padded positions' gradient (all windows)
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) padk[db] = padv[db] = padq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int i = threadIdx.x; i < NR * LDD; i += NT) L2.dense[i] = 0.f;
     for (int t = threadIdx.x; t < NR; t += NT) {      // the bias-index vectors do not depend on the window
         const int tc = t < N ? t : N - 1;
@@ -791,14 +836,19 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
         who_window(a, w, m);
         __syncthreads();                   // the previous window's fragments have been read (first turn: tb / dense are initialised)
         if (m == grp) DLWP_STAMP(1);
-        lds2_store<NT>(R, a, L, NR);
-        float* gq = a.gqkv + (long long)w.b * N * rs + w.head * d;
+        lds2_store<NT>(R, a, L, L2.src, NR);
+        // gqkv rows: window layout [b][n], or token layout [batch][src token] (row index from the staged map)
+        float* gq = a.gqkv + (tokm ? (long long)(w.b / a.nW) * a.Ltok : (long long)w.b * N) * rs + w.head * d;
         __syncthreads();
         if (m == grp) DLWP_STAMP(2);
         if (m + a.groups < a.M) {
             Who wn = w;
             who_window(a, wn, m + a.groups);
-            lds2_load<NT>(R, a, wn, NR);
+            lds2_load<NT>(R, I, a, wn, NR);
+            if (m + 2 * a.groups < a.M) {
+                who_window(a, wn, m + 2 * a.groups);
+                lds2_index<NT>(I, a, wn);
+            }
         }
         // ---- pass 1
         for (int kc = wv; kc < ((a.dbg & 1) ? 0 : NCr); kc += NW) {
@@ -867,11 +917,15 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
                 cur = nxt;
             }
             if (key < N) {
+                const int krow = L2.src[key];
 #pragma unroll
                 for (int db = 0; db < NDB; ++db) {
                     const int dd = 16 * db + 4 * g;
-                    if (dd < d) {
-                        float* dst = gq + (long long)key * rs + dd;
+                    if (krow < 0) {
+                        padk[db] += dk[db];
+                        padv[db] += dv[db];
+                    } else if (dd < d) {
+                        float* dst = gq + (long long)krow * rs + dd;
                         *reinterpret_cast<f32x4*>(dst + a.heads * d) = dk[db];
                         *reinterpret_cast<f32x4*>(dst + 2 * a.heads * d) = dv[db];
                     }
@@ -906,13 +960,40 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
                     for (int db = 0; db < NDB; ++db) kcol[db] = kn[db];
                 }
             }
+            const i32x4 qrow = *reinterpret_cast<const i32x4*>(L2.src + 16 * qc + 4 * g);
 #pragma unroll
             for (int db = 0; db < NDB; ++db)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int q = 16 * qc + 4 * g + j, dd = 16 * db + r;
-                    if (q < N && dd < d) gq[(long long)q * rs + dd] = dq[db][j] * a.scale;
+                    if (q < N) {
+                        if (qrow[j] < 0) padq[db][j] += dq[db][j] * a.scale;
+                        else if (dd < d) gq[(long long)qrow[j] * rs + dd] = dq[db][j] * a.scale;
+                    }
                 }
+        }
+    }
+    if (tokm) {
+        // the padded positions' gradient = the fill's: dK^T / dV^T fragments hold channel 16 db + 4g + j of key r -> sum over r;
+        // dQ fragments hold channel 16 db + r of query 4g + j -> sum over j and g
+        float* gf = a.gfill + w.head * d;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float sk = padk[db][j], sv = padv[db][j];
+#pragma unroll
+                for (int sh = 1; sh < 16; sh <<= 1) { sk += __shfl_xor(sk, sh); sv += __shfl_xor(sv, sh); }
+                const int dd = 16 * db + 4 * g + j;
+                if (r == 0 && dd < d) {
+                    if (sk != 0.f) atomic_add_f32(gf + a.heads * d + dd, sk);
+                    if (sv != 0.f) atomic_add_f32(gf + 2 * a.heads * d + dd, sv);
+                }
+            }
+            float sq = padq[db][0] + padq[db][1] + padq[db][2] + padq[db][3];
+            sq += __shfl_xor(sq, 16);
+            sq += __shfl_xor(sq, 32);
+            if (g == 0 && 16 * db + r < d && sq != 0.f) atomic_add_f32(gf + 16 * db + r, sq);
         }
     }
     DLWP_STAMP_WAVE(16);
@@ -1011,6 +1092,42 @@ int dlwp_winattn_small_fwd(const float* qkv, const float* table, const float* pa
     return DLWP_OK;
 }
 
+// the one-pass kernel (round 4) wherever its LDS image fits and the table slice fits the staging area it is folded in
+static bool one_pass_applies(int N, int d, int TB) {
+    const int nc = (N + 15) / 16;
+    return lds_family_applies(N, d) && lds2_bytes(16 * nc, TB) <= 160 * 1024 && (size_t)TB * 4 <= (size_t)4 * 16 * nc * LDB * 2;
+}
+static int one_pass_launch(WsDev& a, void* stream) {
+    const int nc = (a.N + 15) / 16, nw1 = nc > 4 ? 8 : 4, heads = a.heads, ntypes = a.ntypes, d = a.d;
+    const size_t lb1 = lds2_bytes(16 * nc, a.TB);
+    const int want = dlwp_tune_or("WINATTN_WG_BWD", 0);
+    a.dbg = dlwp_tune_or("WINATTN_DBG", 0);
+    // one round of workgroups: a workgroup's table staging, dense-image fold and flush cost ~36 k cycles (stamps), a window
+    // ~12 k, so the windows of a (type, head) are split over as many workgroups as fit on the chip at once and no more
+    // (Pangu C4 layer 1, 114 pairs x 37 windows: 228 workgroups 177 us, 456: 202, 798: 252)
+    static const int ncu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    const int slots = ncu * (nw1 == 8 ? 1 : 2);
+    const long long per = want ? ((long long)want + heads * ntypes - 1) / (heads * ntypes) : slots / (heads * ntypes);
+    a.groups = per < 1 ? 1 : (per > a.M ? a.M : (int)per);
+    const dim3 grid((unsigned)(heads * ntypes * a.groups));
+    auto go1 = [&](auto knl, int nt) -> int {
+        int rc2 = dlwp_ensure_lds(reinterpret_cast<const void*>(knl), lb1, "winattn_lds_bwd1p");
+        if (rc2) return rc2;
+        hipLaunchKernelGGL(knl, grid, dim3(nt), lb1, (hipStream_t)stream, a);
+        return DLWP_OK;
+    };
+    int rc1;
+    if (nw1 == 8) rc1 = d <= 16 ? go1(winattn_lds_bwd1p_kernel<1, 8>, 512) : go1(winattn_lds_bwd1p_kernel<2, 8>, 512);
+    else rc1 = d <= 16 ? go1(winattn_lds_bwd1p_kernel<1, 4>, 256) : go1(winattn_lds_bwd1p_kernel<2, 4>, 256);
+    if (rc1) return rc1;
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
 int dlwp_winattn_small_bwd(const float* qkv, const float* table, const float* packed, const int* ia, const int* ib,
                            const int* labels, const float* out, const float* lse, const float* gout, float* gqkv, float* gtable,
                            int B_, int nW, int N, int TB, int ntypes, int heads, int d, float scale, int q_lo, int q_hi, void* stream) {
@@ -1020,37 +1137,7 @@ int dlwp_winattn_small_bwd(const float* qkv, const float* table, const float* pa
     a.gout = gout; a.gqkv = gqkv; a.gtable = gtable;
     if (lds_family_applies(N, d)) {
         const int nc = (N + 15) / 16;
-        // the one-pass kernel (round 4) wherever its LDS image fits and the table slice fits the staging area it is folded in
-        const int nw1 = nc > 4 ? 8 : 4;
-        const size_t lb1 = lds2_bytes(16 * nc, TB);
-        if (!dlwp_tune_on("WINATTN_BWD2PASS") && lb1 <= 160 * 1024 && (size_t)TB * 4 <= (size_t)4 * 16 * nc * LDB * 2) {
-            const int want = dlwp_tune_or("WINATTN_WG_BWD", 0);
-            a.dbg = dlwp_tune_or("WINATTN_DBG", 0);
-            // one round of workgroups: a workgroup's table staging, dense-image fold and flush cost ~36 k cycles (stamps), a window
-            // ~12 k, so the windows of a (type, head) are split over as many workgroups as fit on the chip at once and no more
-            // (Pangu C4 layer 1, 114 pairs x 37 windows: 228 workgroups 177 us, 456: 202, 798: 252)
-            static const int ncu = [] {
-                int dev = 0, n = 256;
-                if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-                return n > 0 ? n : 256;
-            }();
-            const int slots = ncu * (nw1 == 8 ? 1 : 2);
-            const long long per = want ? ((long long)want + heads * ntypes - 1) / (heads * ntypes) : slots / (heads * ntypes);
-            a.groups = per < 1 ? 1 : (per > a.M ? a.M : (int)per);
-            const dim3 grid((unsigned)(heads * ntypes * a.groups));
-            auto go1 = [&](auto knl, int nt) -> int {
-                int rc2 = dlwp_ensure_lds(reinterpret_cast<const void*>(knl), lb1, "winattn_lds_bwd1p");
-                if (rc2) return rc2;
-                hipLaunchKernelGGL(knl, grid, dim3(nt), lb1, (hipStream_t)stream, a);
-                return DLWP_OK;
-            };
-            int rc1;
-            if (nw1 == 8) rc1 = d <= 16 ? go1(winattn_lds_bwd1p_kernel<1, 8>, 512) : go1(winattn_lds_bwd1p_kernel<2, 8>, 512);
-            else rc1 = d <= 16 ? go1(winattn_lds_bwd1p_kernel<1, 4>, 256) : go1(winattn_lds_bwd1p_kernel<2, 4>, 256);
-            if (rc1) return rc1;
-            DLWP_LAUNCH_CHECK();
-            return DLWP_OK;
-        }
+        if (!dlwp_tune_on("WINATTN_BWD2PASS") && one_pass_applies(N, d, TB)) return one_pass_launch(a, stream);
         const size_t lb = lds_bytes(16 * nc, TB, true);
         a.groups = lds_groups(a.M, heads, ntypes);
         const dim3 grid((unsigned)(heads * ntypes * a.groups)), block(256);
@@ -1085,6 +1172,31 @@ int dlwp_winattn_small_bwd(const float* qkv, const float* table, const float* pa
     if (rc) return rc;
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
+}
+
+// ---- token-layout backward (include/dlwpmi.h: dlwp_window_attn_bwd_tokens)
+extern "C" int dlwp_window_attn_bwd_tokens_supported(int N, int d, int TB) {
+    return one_pass_applies(N, d, TB) && !dlwp_tune_on("WINATTN_BWD2PASS") ? 1 : 0;
+}
+extern "C" int dlwp_window_attn_bwd_tokens(const float* qkv, const float* bias_table, const float* packed_table, const int* ia,
+                                           const int* ib, const int* labels, const float* out, const float* lse,
+                                           const float* gout_tokens, const int* dst_map, const int* src_map, float* gqkv_tokens,
+                                           float* gfill, float* gbias_table, int B_, int nW, int N, int Ltok, int TB, int ntypes,
+                                           int heads, int d, float scale, int q_lo, int q_hi, void* stream) {
+    DLWP_REQUIRE(qkv && bias_table && ia && ib && out && lse && gout_tokens && dst_map && src_map && gqkv_tokens && gfill && gbias_table,
+                 DLWP_E_INVALID, "window_attn_bwd_tokens: NULL argument");
+    DLWP_REQUIRE(B_ > 0 && nW > 0 && B_ % nW == 0 && N > 0 && Ltok > 0 && heads > 0 && d > 0 && ntypes > 0 && TB > 0, DLWP_E_INVALID,
+                 "window_attn_bwd_tokens: bad shape (B_ %d, nW %d, N %d, Ltok %d, heads %d, d %d)", B_, nW, N, Ltok, heads, d);
+    DLWP_REQUIRE(B_ % ntypes == 0 && nW % ntypes == 0, DLWP_E_INVALID, "window_attn_bwd_tokens: %d window types do not divide nW = %d", ntypes, nW);
+    DLWP_REQUIRE(q_lo >= 0 && q_hi <= N && q_lo < q_hi, DLWP_E_INVALID, "window_attn_bwd_tokens: query range [%d, %d) outside [0, %d)", q_lo, q_hi, N);
+    DLWP_REQUIRE(dlwp_window_attn_bwd_tokens_supported(N, d, TB), DLWP_E_UNSUPPORTED,
+                 "window_attn_bwd_tokens: needs the bf16 matrix mode, N <= 128, head_dim <= 32 and %% 4 == 0 (N %d, d %d, table %d)", N, d, TB);
+    WsDev a{};
+    ws_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, q_lo, q_hi);
+    a.qkv = qkv; a.table = bias_table; a.table_t = packed_table; a.ia = ia; a.ib = ib; a.labels = labels; a.o = out; a.lse_in = lse;
+    a.gout = gout_tokens; a.gqkv = gqkv_tokens; a.gtable = gbias_table;
+    a.src_map = src_map; a.dst_map = dst_map; a.gfill = gfill; a.Ltok = Ltok;
+    return one_pass_launch(a, stream);
 }
 
 #ifdef DLWP_STAMPS

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..nsbench.swin_transformer import window_attention_core
+from ..nsbench.swin_transformer import _WindowAttnTokensFn, window_attention_core, window_attention_tokens
 from ..window_ops import WindowSpec, partition, reverse
 from .rollout import rollout
 from ..token_ops import DropPath, DropPathPool, LayerNorm, Linear, Mlp, PatchConv2d, UpConvT2d, norm_fork
@@ -157,7 +157,19 @@ class EarthSpecificBlock(nn.Module):
                 skip, t = norm_fork(self.norm1, x, gemm_input=True)
                 # (where the crop keeps exactly the positions of the real tokens, every padded row has a zero query gradient --
                 # its upstream gradient is zero -- and the fill's adjoint sums the k and v thirds only)
-                qkv = partition(self.attn.qkv(t), spec, fwd_shift, fill=self.attn.qkv.bias, fill_grad_from=C if self._kept_are_real else 0)
+                qkv_tok = self.attn.qkv(t)
+                if self.attn.qkv.bias is not None and _WindowAttnTokensFn.applies(qkv_tok, spec, self.attn.num_heads, self.attn.earth_position_bias_table):
+                    # partition + attention + reverse as one node whose backward is one launch (token-layout gradients)
+                    t = window_attention_tokens(qkv_tok, self.attn.qkv.bias, self.attn.earth_position_bias_table, self.attn._ia, self.attn._ib,
+                                                self._labels if self.roll else None, spec, fwd_shift, rev_shift, self.attn.num_heads,
+                                                float(self.attn.scale), self._qrange)
+                    if self.drop_path.active:
+                        t = self.attn.proj(t)
+                        skip, t = norm_fork(self.norm2, self.drop_path(t, residual=skip), gemm_input=True)
+                        return self.drop_path(self.mlp(t), residual=skip)
+                    skip, t = norm_fork(self.norm2, self.attn.proj(t, residual=skip), gemm_input=True)
+                    return self.mlp(t, residual=skip)
+                qkv = partition(qkv_tok, spec, fwd_shift, fill=self.attn.qkv.bias, fill_grad_from=C if self._kept_are_real else 0)
                 t = self.attn.core(qkv, self._labels if self.roll else None, spec.nW, self._qrange)
                 if self.drop_path.active:
                     t = self.attn.proj(reverse(t, spec, B, rev_shift))

@@ -124,6 +124,23 @@ def _identity(spec, shift):
     return spec.nW == 1 and spec.padded == spec.dims and not any(s % p for s, p in zip(shift, spec.padded))
 
 
+def position_maps(spec, fwd_shift, rev_shift, device):
+    """int32 [nW, N] pair for dlwp_window_attn_bwd_tokens: (src_map, dst_map) = the token a window position was gathered from by
+    partition(., spec, fwd_shift) and the token reverse(., spec, ., rev_shift) scatters it to; -1 = padding / cropped.  Built by
+    running the gather kernels themselves over the token numbers (exact in fp32 below 2^24 tokens) and cached on the spec."""
+    key = (tuple(fwd_shift), tuple(rev_shift), str(device))
+    cache = spec.__dict__.setdefault("_position_maps", {})
+    if key not in cache:
+        assert not any(spec.circ), "position maps describe constant padding (every token in exactly one window position)"
+        Ltok = spec.dims[0] * spec.dims[1] * spec.dims[2]
+        assert Ltok < (1 << 24)
+        idx = (torch.arange(Ltok, device=device, dtype=torch.float32) + 1.0).reshape(1, Ltok, 1).expand(1, Ltok, 4).contiguous()
+        src = _gather(idx, spec, tuple(fwd_shift))[..., 0].round().to(torch.int32) - 1
+        dst = _gather(idx, spec, tuple(rev_shift), circ_override=(0, 0, 0))[..., 0].round().to(torch.int32) - 1
+        cache[key] = (src.reshape(spec.nW, spec.N).contiguous(), dst.reshape(spec.nW, spec.N).contiguous())
+    return cache[key]
+
+
 def partition(x, spec, shift=None, fill=None, fill_grad_from=0):
     """fill [C]: value of the padded positions (a bias), see _PartitionFillFn; None: zero.  fill_grad_from: channels below it are
     known to receive zero gradient at the padded positions (skipped by the fill's adjoint)."""

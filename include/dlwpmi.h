@@ -302,6 +302,25 @@ int dlwp_window_attn_bwd_qrange(const float* qkv, const float* bias_table, const
                                 float* dsum, float* slab, int B_, int nW, int N, int TB, int ntypes,
                                 int heads, int d, float scale, int q_lo, int q_hi, void* stream);
 long long dlwp_window_attn_bwd_slab_floats(int B_, int N, int heads, int TB);
+/* Backward of  reverse(crop) . attention . partition(pad with `fill`)  in ONE launch, for a block whose qkv projection ran */
+/* on the real tokens (EarthSpecificBlock.forward, src/dlwpbench/models/panguweather/panguweather.py:283-317: ZeroPad3d ->   */
+/* roll -> window_partition -> attention -> window_reverse -> roll -> crop3d; SwinTransformerBlock likewise).  The upstream   */
+/* gradient and the qkv gradient stay in the UNPARTITIONED token layout:                                                     */
+/*   gout_tokens [B][Ltok][heads*d]   window position n of window w (of nW per sample) reads token dst_map[w*N + n]          */
+/*                                     (-1: the position is cropped, zero upstream gradient);                                */
+/*   gqkv_tokens [B][Ltok][3*heads*d] written at token src_map[w*N + n]; positions with src_map < 0 are padding that held    */
+/*                                     `fill` (the qkv bias): their gradient is summed into gfill [3*heads*d] (ACCUMULATED).  */
+/* Both maps are int32 [nW][N], the same for every sample; src_map must hit every token exactly once (constant padding,      */
+/* no circular copies).  qkv / out / lse are the window-layout tensors the forward produced (dlwp_window_attn_fwd_qrange).   */
+/* Replaces the gather of gout, dlwp_window_attn_bwd_qrange, dlwp_window_scatter and dlwp_window_pad_colsum of that chain.   */
+/* Needs the bf16 matrix mode, N <= 128, d <= 32, d % 4 == 0 (dlwp_window_attn_bwd_tokens_supported); otherwise              */
+/* DLWP_E_UNSUPPORTED and nothing is launched.                                                                               */
+int dlwp_window_attn_bwd_tokens_supported(int N, int d, int TB);
+int dlwp_window_attn_bwd_tokens(const float* qkv, const float* bias_table, const float* packed_table, const int* ia,
+                                const int* ib, const int* labels, const float* out, const float* lse,
+                                const float* gout_tokens, const int* dst_map, const int* src_map, float* gqkv_tokens,
+                                float* gfill, float* gbias_table, int B_, int nW, int N, int Ltok, int TB, int ntypes,
+                                int heads, int d, float scale, int q_lo, int q_hi, void* stream);
 int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, const int* ia, const int* ib,
                          const int* labels, const float* out, const float* lse, const float* gout,
                          float* gqkv, float* gbias_table, float* dsum, float* slab, int B_, int nW,

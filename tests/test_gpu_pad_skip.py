@@ -71,3 +71,49 @@ def test_real_token_flow_equals_reference_order(cuda, B, res, heads, dim, shifte
         assert rel(outs[flow][0], y64) <= 2e-5, flow
         for n, a, b in zip(names, outs[flow][1], g64):
             assert rel(a, b) <= 2e-4, (flow, n)
+
+
+@pytest.mark.parametrize("B,res,heads,dim", [(2, (1, 30, 60), 6, 96), (1, (2, 20, 30), 4, 64), (8, (1, 30, 60), 6, 192)])
+@pytest.mark.parametrize("shifted", [False, True])
+def test_token_layout_backward_equals_the_four_launch_chain(cuda, monkeypatch, B, res, heads, dim, shifted):
+    """bf16 matrix mode: partition + attention + reverse as one node with the one-launch backward (dlwp_window_attn_bwd_tokens:
+    gradients through the position maps, padded positions summed into the qkv bias) against the separate nodes (gather of gout,
+    dlwp_window_attn_bwd_qrange, scatter, pad column sum) -- the same kernel arithmetic: 2e-5 on the input gradient, 1e-4 on the
+    parameter gradients (column sums over all tokens: float atomics reorder them) -- and against the float64 reference block at
+    the bf16-operand tolerance."""
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.dlwpbench.panguweather import EarthSpecificBlock
+    from dlwp_benchmark_amd.nsbench import swin_transformer as st
+    from oracle import pangu_ref
+    torch.manual_seed(7)
+    blk = EarthSpecificBlock(dim, res, heads, (2, 7, 7), None if shifted else (0, 0, 0)).to(cuda)
+    with torch.no_grad():
+        blk.attn.earth_position_bias_table.normal_(0, 0.5)
+        blk.attn.qkv.bias.normal_(0, 0.5)
+    blk.real_token_flow = True
+    L_ = res[0] * res[1] * res[2]
+    x = torch.randn(B, L_, dim, device=cuda, requires_grad=True)
+    g = torch.randn(B, L_, dim, device=cuda)
+    names = ["x"] + [n for n, _ in blk.named_parameters()]
+    outs = {}
+    with L.gemm_precision("bf16"):
+        for fused in (True, False):
+            monkeypatch.setattr(st, "FUSED_BWD", fused)
+            qkv_probe = torch.empty(1, 1, 3 * dim, device=cuda)
+            assert st._WindowAttnTokensFn.applies(qkv_probe, blk._wspec, heads, blk.attn.earth_position_bias_table) == fused
+            y = blk(x)
+            grads = torch.autograd.grad(y, [x] + list(blk.parameters()), g)
+            outs[fused] = (y.detach().clone(), [t.clone() for t in grads])
+    assert rel(outs[True][0], outs[False][0]) <= 1e-6
+    # with fewer than 2048 (window, head) pairs the separate attention node runs the TILED backward kernels (other summation
+    # order on bf16 operands): compared at 1e-3 there, tightly where both sides run the wave-per-window family
+    same_kernel = B * blk._wspec.nW * heads >= 2048
+    for n, a, b in zip(names, outs[True][1], outs[False][1]):
+        assert rel(a, b) <= ((2e-5 if n == "x" else 1e-4) if same_kernel else 1e-3), n
+    p64 = {n: t.detach().double().cpu().requires_grad_(True) for n, t in blk.named_parameters()}
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    y64 = pangu_ref.earth_block(x64, p64, "", res, heads, (2, 7, 7), pangu_ref.DEFAULT_SHIFT if shifted else (0, 0, 0))
+    g64 = torch.autograd.grad(y64, [x64] + [p64[n] for n in names[1:]], g.double().cpu())
+    assert rel(outs[True][0], y64) <= 2e-2
+    for n, a, b in zip(names, outs[True][1], g64):
+        assert rel(a, b) <= 3e-2, n
