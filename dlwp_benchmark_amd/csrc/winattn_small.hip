@@ -42,6 +42,10 @@ struct WsDev {
     const int *src_map, *dst_map;
     float* gfill;              // [3 heads d]: sum of the qkv gradient over the padded positions (accumulated)
     int Ltok;
+    // `fill` != NULL: the OPERANDS live in the token layout too -- qkv [batch][Ltok][3 heads d] read through src_map (padded
+    // positions hold fill [3 heads d], the qkv bias), out [batch][Ltok][heads d] written / read through dst_map; no window-layout
+    // copy of either exists (dlwp_window_attn_fwd_tokens; dlwp_window_attn_bwd_tokens with fill)
+    const float* fill;
     int dbg;                   // measurement switches of the one-pass backward (DLWP_WINATTN_DBG): results are wrong when set
     int qc_lo, qc_hi;          // query chunks (of 16 tokens) to compute; the rest are padded positions whose outputs nobody reads
                                // and whose upstream gradient is zero (Pangu: half of every window, dlwp_window_attn_fwd_qrange)
@@ -111,20 +115,60 @@ __device__ __forceinline__ void stage_table(float* tb, const WsDev& a, const Who
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int NC, int NDB, bool VEC, bool BF>
+// TOK: operands in the token layout (WsDev::fill): a wave stages its window's two position-map rows in LDS; a fragment row is then
+// the token's row of the unpartitioned qkv tensor or, for a padded position, the fill vector; output rows go to the token the
+// reverse map names (positions it drops are not written).  Needs d % 4 == 0.
+template <bool TOK>
+__device__ __forceinline__ f32x4 frag_row(const float* __restrict__ base, long long stride, const float* __restrict__ fillp,
+                                          const int* __restrict__ srcl, int tok, int N, int dd0, int d) {
+    if (!TOK) return row_frag<true>(base, stride, tok, N, dd0, d);
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tok < N && dd0 < d) {
+        const int s_ = srcl[tok];
+        v = *reinterpret_cast<const f32x4*>(s_ >= 0 ? base + (long long)s_ * stride + dd0 : fillp + dd0);
+    }
+    return v;
+}
+template <bool TOK>
+__device__ __forceinline__ f32x4 frag_col(const float* __restrict__ base, long long stride, const float* __restrict__ fillp,
+                                          const int* __restrict__ srcl, int tok0, int N, int dd, int d) {
+    if (!TOK) return col_frag(base, stride, tok0, N, dd, d);
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (dd < d) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (tok0 + s < N) {
+                const int s_ = srcl[tok0 + s];
+                v[s] = s_ >= 0 ? base[(long long)s_ * stride + dd] : fillp[dd];
+            }
+    }
+    return v;
+}
+template <int NC, int NDB, bool VEC, bool BF, bool TOK = false>
 __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tb = smem;                                         // [TB] bias-table slice of this (type, head)
     const int lane = lane_id(), r = lane & 15, g = lane >> 4;
     const Who w = who_am_i(a);
     stage_table(tb, a, w);
+    int* srcl = reinterpret_cast<int*>(tb + ((a.TB + 3) & ~3)) + 256 * wave_id();      // TOK: [128] source rows | [128] destination rows
+    int* dstl = srcl + 128;
+    if (TOK && w.valid) {
+        for (int t = lane; t < a.N; t += 64) {
+            srcl[t] = a.src_map[(long long)w.wdw * a.N + t];
+            dstl[t] = a.dst_map[(long long)w.wdw * a.N + t];
+        }
+    }
     __syncthreads();
     if (!w.valid) return;
     const int N = a.N, d = a.d;
     const long long rs = 3LL * a.heads * d, os = (long long)a.heads * d;
-    const float* qb = a.qkv + (long long)w.b * N * rs + w.head * d;
+    const float* qb = TOK ? a.qkv + (long long)(w.b / a.nW) * a.Ltok * rs + w.head * d : a.qkv + (long long)w.b * N * rs + w.head * d;
     const float* kb = qb + a.heads * d;
     const float* vb = qb + 2 * a.heads * d;
+    const float* fq = TOK ? a.fill + w.head * d : nullptr;
+    const float* fk = TOK ? fq + a.heads * d : nullptr;
+    const float* fv = TOK ? fq + 2 * a.heads * d : nullptr;
     const int* labw = a.labels ? a.labels + (long long)w.wdw * N : nullptr;
 
     f32x4 kf[NC][NDB], vt[NDB][NC];
@@ -132,9 +176,10 @@ __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
 #pragma unroll
     for (int kc = 0; kc < NC; ++kc) {
 #pragma unroll
-        for (int cc = 0; cc < NDB; ++cc) kf[kc][cc] = row_frag<VEC>(kb, rs, 16 * kc + r, N, 16 * cc + 4 * g, d);
+        for (int cc = 0; cc < NDB; ++cc)
+            kf[kc][cc] = TOK ? frag_row<TOK>(kb, rs, fk, srcl, 16 * kc + r, N, 16 * cc + 4 * g, d) : row_frag<VEC>(kb, rs, 16 * kc + r, N, 16 * cc + 4 * g, d);
 #pragma unroll
-        for (int db = 0; db < NDB; ++db) vt[db][kc] = col_frag(vb, rs, 16 * kc + 4 * g, N, 16 * db + r, d);
+        for (int db = 0; db < NDB; ++db) vt[db][kc] = frag_col<TOK>(vb, rs, fv, srcl, 16 * kc + 4 * g, N, 16 * db + r, d);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int key = min(16 * kc + 4 * g + j, N - 1);
@@ -150,7 +195,7 @@ __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
         f32x4 qf[NDB];
 #pragma unroll
         for (int cc = 0; cc < NDB; ++cc) {
-            qf[cc] = row_frag<VEC>(qb, rs, q, N, 16 * cc + 4 * g, d);
+            qf[cc] = TOK ? frag_row<TOK>(qb, rs, fq, srcl, q, N, 16 * cc + 4 * g, d) : row_frag<VEC>(qb, rs, q, N, 16 * cc + 4 * g, d);
 #pragma unroll
             for (int s = 0; s < 4; ++s) qf[cc][s] *= a.scale;
         }
@@ -188,8 +233,9 @@ __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
 #pragma unroll
             for (int kc = 0; kc < NC; ++kc) o = mfma16_chunk_p<BF>(vt[db][kc], s[kc], o);
             const int dd = 16 * db + 4 * g;
-            if (q < N) {
-                float* dst = a.out + ((long long)w.b * N + q) * os + w.head * d + dd;
+            const int orow = TOK ? (q < N ? dstl[q] : -1) : q;
+            if (q < N && orow >= 0) {
+                float* dst = a.out + (TOK ? (long long)(w.b / a.nW) * a.Ltok + orow : (long long)w.b * N + q) * os + w.head * d + dd;
                 if (VEC) {
                     if (dd < d) *reinterpret_cast<f32x4*>(dst) = f32x4{o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
                 } else {
@@ -720,18 +766,19 @@ struct Stage2 {
 // token-layout mode: the map entries a thread needs for window m + 1 (gout rows of its two items; the LDS copies of both maps) are
 // fetched one window earlier still, so that the dependent gout loads do not wait on them
 struct Idx2 {
-    int d[2], src, dst;
+    int d[2], s[2], src, dst;
 };
 template <int NT>
 __device__ __forceinline__ void lds2_index(Idx2& I, const WsDev& a, const Who& w) {
     const int N = a.N, tid = threadIdx.x;
-    I.d[0] = I.d[1] = I.src = I.dst = 0;
+    I.d[0] = I.d[1] = I.s[0] = I.s[1] = I.src = I.dst = 0;
     if (!a.dst_map) return;
     const int* dm = a.dst_map + (long long)w.wdw * N;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int tok = (tid >> 3) + i * (NT / 8);
         I.d[i] = dm[tok < N ? tok : N - 1];
+        I.s[i] = a.src_map[(long long)w.wdw * N + (tok < N ? tok : N - 1)];
     }
     const int tc = tid < N ? tid : N - 1;
     I.dst = dm[tc];
@@ -743,21 +790,24 @@ __device__ __forceinline__ void lds2_load(Stage2& R, const Idx2& I, const WsDev&
     const long long rs = 3LL * a.heads * d, os = (long long)a.heads * d;
     const float* qb = a.qkv + (long long)w.b * N * rs + w.head * d;
     const float* ob = a.o + (long long)w.b * N * os + w.head * d;
-    const bool tokm = a.dst_map != nullptr;
-    const float* gb = a.gout + (tokm ? (long long)(w.b / a.nW) * a.Ltok : (long long)w.b * N) * os + w.head * d;
+    const bool tokm = a.dst_map != nullptr, full = a.fill != nullptr;
+    const long long tb0 = (long long)(w.b / a.nW) * a.Ltok;
+    const float* gb = a.gout + (tokm ? tb0 : (long long)w.b * N) * os + w.head * d;
     const int cc = 4 * ch < d ? 4 * ch : 0;              // clamped: unconditional loads
+    if (full) { qb = a.qkv + tb0 * rs + w.head * d; ob = a.o + tb0 * os + w.head * d; }
+    const float* fl = full ? a.fill + w.head * d + cc : nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int tok = (tid >> 3) + i * (NT / 8);
         const int tc = tok < N ? tok : N - 1;
-        const float* row = qb + (long long)tc * rs + cc;
+        const float* row = full ? (I.s[i] >= 0 ? qb + (long long)I.s[i] * rs + cc : fl) : qb + (long long)tc * rs + cc;
         R.q[i] = *reinterpret_cast<const f32x4*>(row);
         R.k[i] = *reinterpret_cast<const f32x4*>(row + a.heads * d);
         R.v[i] = *reinterpret_cast<const f32x4*>(row + 2 * a.heads * d);
         const int gt = tokm ? (I.d[i] < 0 ? 0 : I.d[i]) : tc;
         R.g[i] = *reinterpret_cast<const f32x4*>(gb + (long long)gt * os + cc);
-        if (tokm && I.d[i] < 0) R.g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        R.o[i] = *reinterpret_cast<const f32x4*>(ob + (long long)tc * os + cc);
+        R.o[i] = *reinterpret_cast<const f32x4*>(ob + (long long)(full ? gt : tc) * os + cc);
+        if (tokm && I.d[i] < 0) { R.g[i] = f32x4{0.f, 0.f, 0.f, 0.f}; if (full) R.o[i] = R.g[i]; }
     }
     const int tc = tid < N ? tid : N - 1;
     R.lse = a.lse_in[((long long)w.b * a.heads + w.head) * N + tc];
@@ -1174,27 +1224,65 @@ int dlwp_winattn_small_bwd(const float* qkv, const float* table, const float* pa
     return DLWP_OK;
 }
 
-// ---- token-layout backward (include/dlwpmi.h: dlwp_window_attn_bwd_tokens)
+// ---- token-layout entries (include/dlwpmi.h: dlwp_window_attn_fwd_tokens / dlwp_window_attn_bwd_tokens)
 extern "C" int dlwp_window_attn_bwd_tokens_supported(int N, int d, int TB) {
     return one_pass_applies(N, d, TB) && !dlwp_tune_on("WINATTN_BWD2PASS") ? 1 : 0;
 }
-extern "C" int dlwp_window_attn_bwd_tokens(const float* qkv, const float* bias_table, const float* packed_table, const int* ia,
-                                           const int* ib, const int* labels, const float* out, const float* lse,
+extern "C" int dlwp_window_attn_fwd_tokens_supported(int N, int d, long long pairs) {
+    return dlwp_winattn_small_applies(N, d, pairs) && d % 4 == 0 && dlwp_get_gemm_precision() == 1 && !dlwp_tune_on("WINATTN_TILED") ? 1 : 0;
+}
+static int tokens_check(const char* who, int B_, int nW, int N, int Ltok, int TB, int ntypes, int heads, int d, int q_lo, int q_hi) {
+    DLWP_REQUIRE(B_ > 0 && nW > 0 && B_ % nW == 0 && N > 0 && Ltok > 0 && heads > 0 && d > 0 && ntypes > 0 && TB > 0, DLWP_E_INVALID,
+                 "%s: bad shape (B_ %d, nW %d, N %d, Ltok %d, heads %d, d %d)", who, B_, nW, N, Ltok, heads, d);
+    DLWP_REQUIRE(B_ % ntypes == 0 && nW % ntypes == 0, DLWP_E_INVALID, "%s: %d window types do not divide nW = %d", who, ntypes, nW);
+    DLWP_REQUIRE(q_lo >= 0 && q_hi <= N && q_lo < q_hi, DLWP_E_INVALID, "%s: query range [%d, %d) outside [0, %d)", who, q_lo, q_hi, N);
+    return DLWP_OK;
+}
+extern "C" int dlwp_window_attn_fwd_tokens(const float* qkv_tokens, const float* fill, const float* bias_table, const float* packed_table,
+                                           const int* ia, const int* ib, const int* labels, const int* src_map, const int* dst_map,
+                                           float* out_tokens, float* lse, int B_, int nW, int N, int Ltok, int TB, int ntypes, int heads,
+                                           int d, float scale, int q_lo, int q_hi, void* stream) {
+    DLWP_REQUIRE(qkv_tokens && fill && bias_table && ia && ib && src_map && dst_map && out_tokens && lse, DLWP_E_INVALID,
+                 "window_attn_fwd_tokens: NULL argument");
+    int rc = tokens_check("window_attn_fwd_tokens", B_, nW, N, Ltok, TB, ntypes, heads, d, q_lo, q_hi);
+    if (rc) return rc;
+    DLWP_REQUIRE(dlwp_window_attn_fwd_tokens_supported(N, d, (long long)B_ * heads), DLWP_E_UNSUPPORTED,
+                 "window_attn_fwd_tokens: needs the bf16 matrix mode, N <= 128, head_dim <= 32 and %% 4 == 0, at least 2048 (window, head) pairs "
+                 "(N %d, d %d, pairs %lld)", N, d, (long long)B_ * heads);
+    WsDev a{};
+    ws_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, q_lo, q_hi);
+    a.qkv = qkv_tokens; a.fill = fill; a.table = bias_table; a.table_t = packed_table; a.ia = ia; a.ib = ib; a.labels = labels;
+    a.src_map = src_map; a.dst_map = dst_map; a.out = out_tokens; a.lse = lse; a.Ltok = Ltok;
+    const size_t lds = sizeof(float) * (size_t)((TB + 3) & ~3) + sizeof(int) * 4 * 256;
+    const int nc = (N + 15) / 16;
+    const dim3 grid((unsigned)(heads * ntypes * a.groups)), block(256);
+    auto go = [&](auto knl) -> int {
+        int rc2 = dlwp_ensure_lds(reinterpret_cast<const void*>(knl), lds, "winattn_small_fwd_tokens");
+        if (rc2) return rc2;
+        hipLaunchKernelGGL(knl, grid, block, lds, (hipStream_t)stream, a);
+        return DLWP_OK;
+    };
+    if (d <= 16) rc = nc <= 4 ? go(winattn_small_fwd_kernel<4, 1, true, true, true>) : go(winattn_small_fwd_kernel<8, 1, true, true, true>);
+    else rc = nc <= 4 ? go(winattn_small_fwd_kernel<4, 2, true, true, true>) : go(winattn_small_fwd_kernel<8, 2, true, true, true>);
+    if (rc) return rc;
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+extern "C" int dlwp_window_attn_bwd_tokens(const float* qkv, const float* fill, const float* bias_table, const float* packed_table,
+                                           const int* ia, const int* ib, const int* labels, const float* out, const float* lse,
                                            const float* gout_tokens, const int* dst_map, const int* src_map, float* gqkv_tokens,
                                            float* gfill, float* gbias_table, int B_, int nW, int N, int Ltok, int TB, int ntypes,
                                            int heads, int d, float scale, int q_lo, int q_hi, void* stream) {
     DLWP_REQUIRE(qkv && bias_table && ia && ib && out && lse && gout_tokens && dst_map && src_map && gqkv_tokens && gfill && gbias_table,
                  DLWP_E_INVALID, "window_attn_bwd_tokens: NULL argument");
-    DLWP_REQUIRE(B_ > 0 && nW > 0 && B_ % nW == 0 && N > 0 && Ltok > 0 && heads > 0 && d > 0 && ntypes > 0 && TB > 0, DLWP_E_INVALID,
-                 "window_attn_bwd_tokens: bad shape (B_ %d, nW %d, N %d, Ltok %d, heads %d, d %d)", B_, nW, N, Ltok, heads, d);
-    DLWP_REQUIRE(B_ % ntypes == 0 && nW % ntypes == 0, DLWP_E_INVALID, "window_attn_bwd_tokens: %d window types do not divide nW = %d", ntypes, nW);
-    DLWP_REQUIRE(q_lo >= 0 && q_hi <= N && q_lo < q_hi, DLWP_E_INVALID, "window_attn_bwd_tokens: query range [%d, %d) outside [0, %d)", q_lo, q_hi, N);
+    const int rc = tokens_check("window_attn_bwd_tokens", B_, nW, N, Ltok, TB, ntypes, heads, d, q_lo, q_hi);
+    if (rc) return rc;
     DLWP_REQUIRE(dlwp_window_attn_bwd_tokens_supported(N, d, TB), DLWP_E_UNSUPPORTED,
                  "window_attn_bwd_tokens: needs the bf16 matrix mode, N <= 128, head_dim <= 32 and %% 4 == 0 (N %d, d %d, table %d)", N, d, TB);
     WsDev a{};
     ws_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, q_lo, q_hi);
-    a.qkv = qkv; a.table = bias_table; a.table_t = packed_table; a.ia = ia; a.ib = ib; a.labels = labels; a.o = out; a.lse_in = lse;
-    a.gout = gout_tokens; a.gqkv = gqkv_tokens; a.gtable = gbias_table;
+    a.qkv = qkv; a.fill = fill; a.table = bias_table; a.table_t = packed_table; a.ia = ia; a.ib = ib; a.labels = labels; a.o = out;
+    a.lse_in = lse; a.gout = gout_tokens; a.gqkv = gqkv_tokens; a.gtable = gbias_table;
     a.src_map = src_map; a.dst_map = dst_map; a.gfill = gfill; a.Ltok = Ltok;
     return one_pass_launch(a, stream);
 }

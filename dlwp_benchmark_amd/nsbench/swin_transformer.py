@@ -108,12 +108,14 @@ class _WindowAttnFn(torch.autograd.Function):
 
 
 FUSED_BWD = __import__("os").environ.get("DLWP_WINATTN_TOKENS", "1") != "0"      # env: A/B runs against the four-launch backward
+FUSED_FWD = __import__("os").environ.get("DLWP_WINATTN_TOKENS_FWD", "1") != "0"  # env: ... and against gather + attention + scatter
 
 
 class _WindowAttnTokensFn(torch.autograd.Function):
     """reverse(crop) . attention . partition(pad with the qkv bias) of a block whose qkv projection ran on the real tokens, as ONE
-    autograd node: forward = the three launches of the separate nodes (dlwp_window_gather_fill, dlwp_window_attn_fwd_qrange,
-    dlwp_window_scatter_add); backward = ONE launch (dlwp_window_attn_bwd_tokens) that reads the upstream gradient and writes the
+    autograd node: forward = ONE launch on the token-layout qkv tensor where the wave-per-window family applies
+    (dlwp_window_attn_fwd_tokens; otherwise dlwp_window_gather_fill, dlwp_window_attn_fwd_qrange, dlwp_window_scatter_add);
+    backward = ONE launch (dlwp_window_attn_bwd_tokens) that reads the upstream gradient and writes the
     qkv gradient in the token layout through the two position maps and sums the padded positions' gradient into the bias's --
     instead of gather(gout) + attention backward + scatter(gqkv) + pad column sum (reference: EarthSpecificBlock.forward,
     src/dlwpbench/models/panguweather/panguweather.py:283-317)."""
@@ -132,42 +134,54 @@ class _WindowAttnTokensFn(torch.autograd.Function):
         N, nW = spec.N, spec.nW
         d = C3 // (3 * heads)
         x = qkv_tok.contiguous().float()
-        dd, pp, ff, ss, ww, sw, circ = spec.c_args(fwd_shift)
-        qkv = torch.empty(B * nW, N, C3, device=x.device)
         fl = fill.detach().contiguous().float()
-        L.check(lib.dlwp_window_gather_fill(L.ptr(x), L.ptr(fl), L.ptr(qkv), B, C3, dd, pp, ff, ss, ww, sw, circ, L.stream()))
         table_param, table = table, table.contiguous()
         TB, ntypes = table.shape[0], table.shape[1]
         qr = (0, N) if qrange is None else (int(qrange[0]), int(qrange[1]))
         full = qr == (0, N)
-        out = (torch.empty if full else torch.zeros)(B * nW, N, heads * d, device=x.device)
         lse = (torch.empty if full else torch.zeros)(B * nW, heads, N, device=x.device)
         packed = None
         if ntypes > 1:
             packed = torch.empty(ntypes * heads * TB, device=x.device)
             L.check(lib.dlwp_window_attn_pack_table(L.ptr(table), L.ptr(packed), TB, ntypes, heads, L.stream()))
-        L.check(lib.dlwp_window_attn_fwd_qrange(L.ptr(qkv), L.ptr(table), L.ptr(packed), L.ptr(ia), L.ptr(ib), L.ptr(labels), L.ptr(out),
-                                                L.ptr(lse), B * nW, nW, N, TB, ntypes, heads, d, scale, qr[0], qr[1], L.stream()))
-        y = _scatter(out, spec, rev_shift, B, sum_copies=False)
+        src_map, dst_map = position_maps(spec, fwd_shift, rev_shift, x.device)
+        ctx.in_tokens = FUSED_FWD and lib.dlwp_window_attn_fwd_tokens_supported(N, d, B * nW * heads) == 1
+        if ctx.in_tokens:
+            # ONE launch, no window-layout copy of qkv or of the output: the kernel reads token rows through src_map (padded
+            # positions: the bias) and writes its rows to the tokens dst_map names (every token exactly once)
+            y = torch.empty(B, Ltok, heads * d, device=x.device)
+            L.check(lib.dlwp_window_attn_fwd_tokens(L.ptr(x), L.ptr(fl), L.ptr(table), L.ptr(packed), L.ptr(ia), L.ptr(ib), L.ptr(labels),
+                                                    L.ptr(src_map), L.ptr(dst_map), L.ptr(y), L.ptr(lse), B * nW, nW, N, Ltok, TB, ntypes,
+                                                    heads, d, scale, qr[0], qr[1], L.stream()))
+            ctx.save_for_backward(x, table, y, lse, fl)
+        else:
+            dd, pp, ff, ss, ww, sw, circ = spec.c_args(fwd_shift)
+            qkv = torch.empty(B * nW, N, C3, device=x.device)
+            L.check(lib.dlwp_window_gather_fill(L.ptr(x), L.ptr(fl), L.ptr(qkv), B, C3, dd, pp, ff, ss, ww, sw, circ, L.stream()))
+            out = (torch.empty if full else torch.zeros)(B * nW, N, heads * d, device=x.device)
+            L.check(lib.dlwp_window_attn_fwd_qrange(L.ptr(qkv), L.ptr(table), L.ptr(packed), L.ptr(ia), L.ptr(ib), L.ptr(labels), L.ptr(out),
+                                                    L.ptr(lse), B * nW, nW, N, TB, ntypes, heads, d, scale, qr[0], qr[1], L.stream()))
+            y = _scatter(out, spec, rev_shift, B, sum_copies=False)
+            ctx.save_for_backward(qkv, table, out, lse, fl)
         ctx.cfg = (B, Ltok, nW, N, TB, ntypes, heads, d, scale, qr)
-        ctx.aux = (ia, ib, labels, packed) + position_maps(spec, fwd_shift, rev_shift, x.device)
+        ctx.aux = (ia, ib, labels, packed, src_map, dst_map)
         ctx.tslot, ctx.fslot = _grad_slot(table_param), _grad_slot(fill)
-        ctx.save_for_backward(qkv, table, out, lse)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         lib = L.load()
-        qkv, table, out, lse = ctx.saved_tensors
+        qkv, table, out, lse, fl = ctx.saved_tensors
         B, Ltok, nW, N, TB, ntypes, heads, d, scale, qr = ctx.cfg
         ia, ib, labels, packed, src_map, dst_map = ctx.aux
         g = gy.contiguous().float()
         gqkv = torch.empty(B, Ltok, 3 * heads * d, device=g.device)
         gtable = ctx.tslot if ctx.tslot is not None else torch.zeros_like(table)          # the kernel accumulates into both
         gfill = ctx.fslot if ctx.fslot is not None else torch.zeros(3 * heads * d, device=g.device)
-        L.check(lib.dlwp_window_attn_bwd_tokens(L.ptr(qkv), L.ptr(table), L.ptr(packed), L.ptr(ia), L.ptr(ib), L.ptr(labels), L.ptr(out),
-                                                L.ptr(lse), L.ptr(g), L.ptr(dst_map), L.ptr(src_map), L.ptr(gqkv), L.ptr(gfill),
-                                                L.ptr(gtable), B * nW, nW, N, Ltok, TB, ntypes, heads, d, scale, qr[0], qr[1], L.stream()))
+        L.check(lib.dlwp_window_attn_bwd_tokens(L.ptr(qkv), L.ptr(fl) if ctx.in_tokens else None, L.ptr(table), L.ptr(packed), L.ptr(ia),
+                                                L.ptr(ib), L.ptr(labels), L.ptr(out), L.ptr(lse), L.ptr(g), L.ptr(dst_map), L.ptr(src_map),
+                                                L.ptr(gqkv), L.ptr(gfill), L.ptr(gtable), B * nW, nW, N, Ltok, TB, ntypes, heads, d, scale,
+                                                qr[0], qr[1], L.stream()))
         return (gqkv, None if ctx.fslot is not None else gfill, None if ctx.tslot is not None else gtable) + (None,) * 9
 
 

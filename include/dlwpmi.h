@@ -311,16 +311,28 @@ long long dlwp_window_attn_bwd_slab_floats(int B_, int N, int heads, int TB);
 /*   gqkv_tokens [B][Ltok][3*heads*d] written at token src_map[w*N + n]; positions with src_map < 0 are padding that held    */
 /*                                     `fill` (the qkv bias): their gradient is summed into gfill [3*heads*d] (ACCUMULATED).  */
 /* Both maps are int32 [nW][N], the same for every sample; src_map must hit every token exactly once (constant padding,      */
-/* no circular copies).  qkv / out / lse are the window-layout tensors the forward produced (dlwp_window_attn_fwd_qrange).   */
+/* no circular copies).  fill == NULL: qkv / out are the window-layout tensors the forward produced                          */
+/* (dlwp_window_attn_fwd_qrange on a gathered qkv).  fill != NULL ([3*heads*d], the qkv bias): the OPERANDS are in the token   */
+/* layout too -- qkv [B][Ltok][3*heads*d] read through src_map (padded positions hold fill), out [B][Ltok][heads*d] through   */
+/* dst_map, as dlwp_window_attn_fwd_tokens left them; lse stays [B_][heads][N].                                              */
 /* Replaces the gather of gout, dlwp_window_attn_bwd_qrange, dlwp_window_scatter and dlwp_window_pad_colsum of that chain.   */
 /* Needs the bf16 matrix mode, N <= 128, d <= 32, d % 4 == 0 (dlwp_window_attn_bwd_tokens_supported); otherwise              */
 /* DLWP_E_UNSUPPORTED and nothing is launched.                                                                               */
 int dlwp_window_attn_bwd_tokens_supported(int N, int d, int TB);
-int dlwp_window_attn_bwd_tokens(const float* qkv, const float* bias_table, const float* packed_table, const int* ia,
-                                const int* ib, const int* labels, const float* out, const float* lse,
+int dlwp_window_attn_bwd_tokens(const float* qkv, const float* fill, const float* bias_table, const float* packed_table,
+                                const int* ia, const int* ib, const int* labels, const float* out, const float* lse,
                                 const float* gout_tokens, const int* dst_map, const int* src_map, float* gqkv_tokens,
                                 float* gfill, float* gbias_table, int B_, int nW, int N, int Ltok, int TB, int ntypes,
                                 int heads, int d, float scale, int q_lo, int q_hi, void* stream);
+/* The forward of the same chain in one launch: attention over the windows of a token-layout qkv tensor (no gathered copy),   */
+/* output rows written to the tokens dst_map names (positions it drops are computed only as keys / values).  Same shape       */
+/* family as the wave-per-window kernels: N <= 128, d <= 32, d % 4 == 0, at least 2048 (window, head) pairs, bf16 matrix mode  */
+/* (dlwp_window_attn_fwd_tokens_supported); otherwise DLWP_E_UNSUPPORTED.                                                     */
+int dlwp_window_attn_fwd_tokens_supported(int N, int d, long long pairs);
+int dlwp_window_attn_fwd_tokens(const float* qkv_tokens, const float* fill, const float* bias_table, const float* packed_table,
+                                const int* ia, const int* ib, const int* labels, const int* src_map, const int* dst_map,
+                                float* out_tokens, float* lse, int B_, int nW, int N, int Ltok, int TB, int ntypes, int heads,
+                                int d, float scale, int q_lo, int q_hi, void* stream);
 int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, const int* ia, const int* ib,
                          const int* labels, const float* out, const float* lse, const float* gout,
                          float* gqkv, float* gbias_table, float* dsum, float* slab, int B_, int nW,
