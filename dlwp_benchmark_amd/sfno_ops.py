@@ -110,6 +110,7 @@ class _EncodeFn(torch.autograd.Function):
         ctx.cf = sources[frame_index].shape[1] if frame_index is not None else 0
         ctx.params = (w1, b1, w2, pos)
         ctx.mark_non_differentiable(tok_lp)
+        ctx.set_materialize_grads(False)          # an unused link / alias output arrives as None instead of a zero-filled tensor
         alias = sources[frame_index].view_as(sources[frame_index]) if frame_index is not None else None
         return t0, tok_lp, link, alias
 
@@ -119,6 +120,8 @@ class _EncodeFn(torch.autograd.Function):
         st, rec = ctx.st, ctx.rec
         B, H, W, E, cin = ctx.dims
         HW, T = H * W, B * H * W
+        if g_t0 is None:                          # (the tokens were not used: only the link / alias carry a gradient)
+            g_t0 = torch.zeros(B, H, W, E, device=ctx.z.device)
         g = g_t0.contiguous().float()
         dev = g.device
         g_lp = torch.empty(T, E, device=dev, dtype=_BF)

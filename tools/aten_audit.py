@@ -55,10 +55,20 @@ def audit(name, model, make_batch, steps, warmup=3, use_graph=True, call=None, l
     from dlwp_benchmark_amd.train_engine import flatten_parameters
     flatten_parameters(model)
 
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.train_engine import mse_loss, refresh_bf16_weights
+
     def once():
-        out = call(model, inputs) if call is not None else model(**inputs)
-        loss = torch.nn.functional.mse_loss(out, target)
-        loss.backward()
+        # the body of train_engine.GraphedTrainStep._fwd_bwd: bf16 weight copies refreshed and marked live, the engine's loss node
+        # (an eager model(**inputs) under bf16 storage takes the per-layer GEMM paths of a model that is not being trained)
+        refresh_bf16_weights(model)
+        prev, L.SHADOW_ACTIVE = L.SHADOW_ACTIVE, True
+        try:
+            out = call(model, inputs) if call is not None else model(**inputs)
+            loss = mse_loss(out, target)
+            loss.backward()
+        finally:
+            L.SHADOW_ACTIVE = prev
     once()
     torch.cuda.synchronize()
     from torch.profiler import ProfilerActivity, profile
