@@ -1,0 +1,649 @@
+// Token-level normalisation and elementwise building blocks of the AFNO / Swin / Pangu blocks (split from token_ops.hip in round 4:
+// that file keeps the GEMM family): LayerNorm forward / backward (row, vector and wide kernels), activation backward, column sums
+// (bias gradients) and the fp32 -> bf16 cast of the bf16-storage mode.
+// Reference call sites (file:line under /root/reference/src/nsbench/models):
+//   nn.LayerNorm   fourcastnet/fourcastnet.py:213 (eps 1e-6), swintransformer/swin_transformer.py:187,194 (eps 1e-5)
+//   nn.GELU        fourcastnet.py:45, swin_transformer.py:37 (backward of the activation where it is not fused into a GEMM epilogue)
+//   bias gradients of nn.Linear / position embeddings: column sums over the token dimension
+#include <algorithm>
+#include <cstdlib>
+#include "common.cuh"
+#include "dlwpmi_internal.h"
+
+namespace {
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// ---- LayerNorm over the last dimension: one wave per row
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int T,
+                                                            int C, float eps, int y_bf16) {
+    const int row = blockIdx.x * 4 + wave_id(), lane = lane_id();
+    if (row >= T) return;
+    const float* xr = x + (long long)row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    const float mu = wave_sum64(s) / C;
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = xr[c] - mu; v += d * d; }
+    const float rs = rsqrtf(wave_sum64(v) / C + eps);
+    if (y_bf16) {         // the output feeds a GEMM under bf16 storage: rounded once here instead of in every tile load
+        __bf16* yh = reinterpret_cast<__bf16*>(y);
+        for (int c = lane; c < C; c += 64) yh[(long long)row * C + c] = (__bf16)((xr[c] - mu) * rs * gamma[c] + beta[c]);
+    } else {
+        for (int c = lane; c < C; c += 64) y[(long long)row * C + c] = (xr[c] - mu) * rs * gamma[c] + beta[c];
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// Wide rows (256 < C <= 1024, C % 4 == 0): the row is read ONCE into NV float4 groups per lane (the scalar kernel above walks it
+// three times with 4-byte loads), statistics in registers, 16-byte (bf16: 8-byte) stores.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_wide_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float* __restrict__ y,
+                                                                 float* __restrict__ mean, float* __restrict__ rstd, int T,
+                                                                 int C, float eps, int y_bf16) {
+    const int row = blockIdx.x * 4 + wave_id(), lane = lane_id();
+    if (row >= T) return;
+    const float* xr = x + (long long)row * C;
+    f32x4 v[NV];
+    bool ok[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const int c = 4 * lane + 256 * q;
+        ok[q] = c < C;
+        v[q] = *reinterpret_cast<const f32x4*>(xr + (ok[q] ? c : 0));
+        if (ok[q]) s += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
+    }
+    const float mu = wave_sum64(s) / C;
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+        if (ok[q]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float d = v[q][k] - mu; var += d * d; }
+        }
+    const float rs = rsqrtf(wave_sum64(var) / C + eps);
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+        if (ok[q]) {
+            const int c = 4 * lane + 256 * q;
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (v[q][k] - mu) * rs * gm[k] + bt[k];
+            if (y_bf16)
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(y) + (long long)row * C + c) =
+                    bf16x4{(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+            else
+                *reinterpret_cast<f32x4*>(y + (long long)row * C + c) = o;
+        }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// gx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)) (+ gadd: the gradient that reached x along the residual
+// branch of a pre-norm block, so the two paths meet here instead of in a separate add); ggamma/gbeta partials via atomics
+template <int NQ>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gy, const float* __restrict__ gadd,
+                                                            float* __restrict__ gx, float* ggamma, float* gbeta, int T, int C,
+                                                            int rows_per_block, int gy_bf16) {
+    extern __shared__ float sm[];            // [2][C] per-block partial of ggamma, gbeta
+    float* sg = sm;
+    float* sb = sm + C;
+    for (int c = threadIdx.x; c < 2 * C; c += 256) sm[c] = 0.f;
+    __syncthreads();
+    const int lane = lane_id(), w = wave_id();
+    const int row0 = blockIdx.x * rows_per_block;
+    // each wave owns the columns c = lane, lane+64, ... (C <= 64*NQ, checked by the host wrapper) of its rows and keeps the
+    // column partials in registers.  The next row's loads are in flight while the current row is reduced (one wave per SIMD
+    // would otherwise pay a full memory latency per row); loads use clamped addresses, masks are applied afterwards.
+    float pg[NQ], pb[NQ], gam[NQ], xv[NQ], gv[NQ], av[NQ], xn[NQ], gn[NQ], an[NQ];
+    bool okc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        pg[q] = 0.f; pb[q] = 0.f;
+        okc[q] = lane + 64 * q < C;
+        gam[q] = okc[q] ? gamma[min(lane + 64 * q, C - 1)] : 0.f;
+    }
+    auto load_row = [&](int row, float (&X)[NQ], float (&G)[NQ], float (&A)[NQ], float& mu, float& rs) {
+        const int rc = min(row, T - 1);
+        const float* xr = x + (long long)rc * C;
+        const float* gr = gy + (long long)rc * C;
+        const __bf16* gh = reinterpret_cast<const __bf16*>(gy) + (long long)rc * C;      // gy_bf16: the upstream gradient is a bf16 array
+        const float* ar = gadd ? gadd + (long long)rc * C : nullptr;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = min(lane + 64 * q, C - 1);
+            X[q] = xr[c];
+            G[q] = gy_bf16 ? (float)gh[c] : gr[c];
+            A[q] = ar ? ar[c] : 0.f;
+        }
+        mu = mean[rc];
+        rs = rstd[rc];
+    };
+    float mu, rs, mun = 0.f, rsn = 0.f;
+    load_row(row0 + w, xv, gv, av, mu, rs);
+    for (int rr = w; rr < rows_per_block; rr += 4) {
+        const int row = row0 + rr;
+        if (row >= T) break;
+        const bool more = rr + 4 < rows_per_block && row + 4 < T;
+        if (more) load_row(row + 4, xn, gn, an, mun, rsn);
+        float s1 = 0.f, s2 = 0.f, xh[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float g0 = okc[q] ? gv[q] : 0.f;
+            xh[q] = okc[q] ? (xv[q] - mu) * rs : 0.f;
+            const float gg = g0 * gam[q];
+            s1 += gg;
+            s2 += gg * xh[q];
+            pg[q] += g0 * xh[q];
+            pb[q] += g0;
+        }
+        s1 = wave_sum64(s1) / C;
+        s2 = wave_sum64(s2) / C;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (okc[q]) gx[(long long)row * C + lane + 64 * q] = rs * (gv[q] * gam[q] - s1 - xh[q] * s2) + av[q];
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { xv[q] = xn[q]; gv[q] = gn[q]; av[q] = an[q]; }
+            mu = mun; rs = rsn;
+        }
+    }
+    // combine the four waves' column partials one wave at a time (no LDS float atomics)
+    for (int ww = 0; ww < 4; ++ww) {
+        if (w == ww) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (okc[q]) { sg[lane + 64 * q] += pg[q]; sb[lane + 64 * q] += pb[q]; }
+        }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < C; c += 256) {
+        atomic_add_f32(&ggamma[c], sg[c]);
+        atomic_add_f32(&gbeta[c], sb[c]);
+    }
+}
+
+// gz = gy * act'(z): act 1 GELU, 2 ReLU, 3 soft-shrink(lam)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ z, const float* __restrict__ gy,
+                                                      float* __restrict__ gz, long long n, int act, float lam) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float v = z[i];
+        float d = 1.f;
+        if (act == 1) d = gelu_grad_f(v);
+        else if (act == 2) d = v > 0.f ? 1.f : 0.f;
+        else if (act == 3) d = (v > lam || v < -lam) ? 1.f : 0.f;
+        gz[i] = gy[i] * d;
+    }
+}
+
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ z, const float* __restrict__ gy,
+                                                       float* __restrict__ gz, long long n) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) gz[i] = gy[i] * gelu_grad_f(z[i]);
+}
+
+// ---- LayerNorm for narrow rows (C % 4 == 0, C <= 256): a lane owns four consecutive channels (16-byte accesses), LPR lanes
+// share a row and a wave works on 64 / LPR rows at once.  The wave-per-row kernels above leave 25-60 % of a wave idle at C = 40
+// ... 96 (Swin stages) and move 4 bytes per lane and instruction: 1.6 TB/s at 65536 x 96; this form reaches the HBM regime.
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ y,
+                                                                float* __restrict__ mean, float* __restrict__ rstd, int T, int C,
+                                                                float eps, int y_bf16) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = lane_id(), l = lane % LPR, rr = lane / LPR;
+    const long long row = ((long long)blockIdx.x * 4 + wave_id()) * RPW + rr;
+    const bool okc = 4 * l < C, ok = okc && row < T;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f}, gm = v, bt = v;
+    if (ok) v = *reinterpret_cast<const f32x4*>(x + row * C + 4 * l);
+    if (okc) { gm = *reinterpret_cast<const f32x4*>(gamma + 4 * l); bt = *reinterpret_cast<const f32x4*>(beta + 4 * l); }
+    const float mu = row_sum<LPR>((v[0] + v[1]) + (v[2] + v[3])) / C;
+    f32x4 d;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = okc ? v[k] - mu : 0.f;
+    const float rs = rsqrtf(row_sum<LPR>((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) / C + eps);
+    if (ok) {
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = d[k] * rs * gm[k] + bt[k];
+        if (y_bf16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(y) + row * C + 4 * l) = bf16x4{(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+        else *reinterpret_cast<f32x4*>(y + row * C + 4 * l) = o;
+        if (l == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gy, const float* __restrict__ gadd,
+                                                                float* __restrict__ gx, float* ggamma, float* gbeta, int T, int C,
+                                                                int rows_per_block, int gy_bf16) {
+    extern __shared__ float sm[];            // [2][C] per-block partial of ggamma, gbeta
+    constexpr int RPW = 64 / LPR;
+    for (int c = threadIdx.x; c < 2 * C; c += 256) sm[c] = 0.f;
+    __syncthreads();
+    const int lane = lane_id(), w = wave_id(), l = lane % LPR, rr = lane / LPR;
+    const bool okc = 4 * l < C;
+    f32x4 gm = f32x4{0.f, 0.f, 0.f, 0.f}, pg = gm, pb = gm;
+    if (okc) gm = *reinterpret_cast<const f32x4*>(gamma + 4 * l);
+    const long long row0 = (long long)blockIdx.x * rows_per_block;
+    const __bf16* gh = reinterpret_cast<const __bf16*>(gy);
+    for (int it = w * RPW; it < rows_per_block; it += 4 * RPW) {
+        const long long row = row0 + it + rr;
+        const bool ok = okc && row < T && it + rr < rows_per_block;
+        f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f}, gv = xv, av = xv;
+        float mu = 0.f, rs = 0.f;
+        if (ok) {
+            const long long o = row * C + 4 * l;
+            xv = *reinterpret_cast<const f32x4*>(x + o);
+            if (gy_bf16) {
+                const bf16x4 hv = *reinterpret_cast<const bf16x4*>(gh + o);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gv[k] = (float)hv[k];
+            } else {
+                gv = *reinterpret_cast<const f32x4*>(gy + o);
+            }
+            if (gadd) av = *reinterpret_cast<const f32x4*>(gadd + o);
+            mu = mean[row];
+            rs = rstd[row];
+        }
+        f32x4 xh, gg;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            xh[k] = ok ? (xv[k] - mu) * rs : 0.f;
+            gg[k] = gv[k] * gm[k];
+            s1 += gg[k];
+            s2 += gg[k] * xh[k];
+            pg[k] += gv[k] * xh[k];
+            pb[k] += gv[k];
+        }
+        s1 = row_sum<LPR>(s1) / C;
+        s2 = row_sum<LPR>(s2) / C;
+        if (ok) {
+            f32x4 o4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o4[k] = rs * (gg[k] - s1 - xh[k] * s2) + av[k];
+            *reinterpret_cast<f32x4*>(gx + row * C + 4 * l) = o4;
+        }
+    }
+    // fold the row slots of a wave (lanes l, l + LPR, ...), then the four waves one after the other (no LDS float atomics)
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { pg[k] += __shfl_xor(pg[k], o); pb[k] += __shfl_xor(pb[k], o); }
+    for (int ww = 0; ww < 4; ++ww) {
+        if (w == ww && rr == 0 && okc) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sm[4 * l + k] += pg[k]; sm[C + 4 * l + k] += pb[k]; }
+        }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < C; c += 256) {
+        atomic_add_f32(&ggamma[c], sm[c]);
+        atomic_add_f32(&gbeta[c], sm[C + c]);
+    }
+}
+
+// Wide rows (256 < C <= 1024, C % 4 == 0; FourCastNet's 768, Pangu's 384): a lane owns NV float4 groups of a row (16-byte accesses
+// instead of the scalar kernel's 4-byte ones), a wave walks its rows with the next row's loads in flight, and the grid is sized to
+// the resident slots (a workgroup's 2 C column partials end in float atomics on the same 2 C addresses: their number, not C, sets
+// the tail -- the scalar kernel's 1013 workgroups at 16200 x 768 spent a third of its 79 us there).
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                 const float* __restrict__ gy, const float* __restrict__ gadd,
+                                                                 float* __restrict__ gx, float* ggamma, float* gbeta, int T, int C,
+                                                                 int rows_per_block, int gy_bf16) {
+    extern __shared__ float sm[];            // [2][C] per-block partial of ggamma, gbeta
+    for (int c = threadIdx.x; c < 2 * C; c += 256) sm[c] = 0.f;
+    __syncthreads();
+    const int lane = lane_id(), w = wave_id();
+    const long long row0 = (long long)blockIdx.x * rows_per_block;
+    const __bf16* gh = reinterpret_cast<const __bf16*>(gy);
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 gm[NV], pg[NV], pb[NV], xv[NV], gv[NV], av[NV], xn[NV], gn[NV], an[NV];
+    bool okc[NV];
+    int col[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        okc[q] = 4 * lane + 256 * q < C;
+        col[q] = okc[q] ? 4 * lane + 256 * q : 0;          // clamped: loads of a masked group read (and ignore) column 0
+        gm[q] = okc[q] ? *reinterpret_cast<const f32x4*>(gamma + col[q]) : zero;
+        pg[q] = zero; pb[q] = zero;
+    }
+    auto load_row = [&](long long row, f32x4 (&X)[NV], f32x4 (&G)[NV], f32x4 (&A)[NV], float& mu, float& rs) {
+        const long long rc = min(row, (long long)T - 1) * C;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            X[q] = *reinterpret_cast<const f32x4*>(x + rc + col[q]);
+            if (gy_bf16) {
+                const bf16x4 hv = *reinterpret_cast<const bf16x4*>(gh + rc + col[q]);
+                G[q] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+            } else {
+                G[q] = *reinterpret_cast<const f32x4*>(gy + rc + col[q]);
+            }
+            A[q] = gadd ? *reinterpret_cast<const f32x4*>(gadd + rc + col[q]) : zero;
+        }
+        mu = mean[min(row, (long long)T - 1)];
+        rs = rstd[min(row, (long long)T - 1)];
+    };
+    float mu, rs, mun = 0.f, rsn = 0.f;
+    load_row(row0 + w, xv, gv, av, mu, rs);
+    const float invC = 1.f / C;
+    for (int rr = w; rr < rows_per_block; rr += 4) {
+        const long long row = row0 + rr;
+        if (row >= T) break;
+        const bool more = rr + 4 < rows_per_block && row + 4 < T;
+        if (more) load_row(row + 4, xn, gn, an, mun, rsn);
+        float s1 = 0.f, s2 = 0.f;
+        f32x4 xh[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float g0 = okc[q] ? gv[q][k] : 0.f;
+                xh[q][k] = okc[q] ? (xv[q][k] - mu) * rs : 0.f;
+                const float gg = g0 * gm[q][k];
+                s1 += gg;
+                s2 += gg * xh[q][k];
+                pg[q][k] += g0 * xh[q][k];
+                pb[q][k] += g0;
+            }
+        s1 = wave_sum64(s1) * invC;
+        s2 = wave_sum64(s2) * invC;
+#pragma unroll
+        for (int q = 0; q < NV; ++q)
+            if (okc[q]) {
+                f32x4 o4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o4[k] = rs * (gv[q][k] * gm[q][k] - s1 - xh[q][k] * s2) + av[q][k];
+                *reinterpret_cast<f32x4*>(gx + row * C + col[q]) = o4;
+            }
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) { xv[q] = xn[q]; gv[q] = gn[q]; av[q] = an[q]; }
+            mu = mun; rs = rsn;
+        }
+    }
+    for (int ww = 0; ww < 4; ++ww) {          // the four waves' column partials, one wave at a time (no LDS float atomics)
+        if (w == ww) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q)
+                if (okc[q]) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { sm[col[q] + k] += pg[q][k]; sm[C + col[q] + k] += pb[q][k]; }
+                }
+        }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < C; c += 256) {
+        atomic_add_f32(&ggamma[c], sm[c]);
+        atomic_add_f32(&gbeta[c], sm[C + c]);
+    }
+}
+
+// out[n] += sum_t g[t][n].  Tall matrices (T > 16): a workgroup sums a slab of rows for 256 columns -- 16-byte loads, eight
+// independent rows in flight per thread (the first version walked its rows one dependent-free but serial 4-byte load at a
+// time: 28 us per call at the FourCastNet-scale shapes, 4.9 % of that step) -- and adds its partial with float atomics.
+// Flat matrices (T <= 16: the batch sum behind a position embedding's gradient, N = tokens x channels in the millions): one
+// thread per four columns, no atomics at all (nothing else writes `out` in that launch).
+template <int VEC>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, float* out, int T, int N, int rows_per_block) {
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int n0 = (blockIdx.x * 64 + lane) * VEC;
+    const int row0 = blockIdx.y * rows_per_block, row1 = min(T, row0 + rows_per_block);
+    __shared__ float red[4][64 * VEC];
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    if (n0 < N) {
+        for (int r = row0 + part; r < row1; r += 32) {
+            float v[8][VEC];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int rr = r + 4 * u;
+                const float* p = g + (long long)(rr < row1 ? rr : r) * N + n0;
+                if (VEC == 4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) v[u][k] = t[k];
+                } else {
+                    v[u][0] = *p;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (r + 4 * u < row1) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] += v[u][k];
+                }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) red[part][lane * VEC + k] = acc[k];
+    __syncthreads();
+    if (part == 0 && n0 < N) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float t = (red[0][lane * VEC + k] + red[1][lane * VEC + k]) + (red[2][lane * VEC + k] + red[3][lane * VEC + k]);
+            if (n0 + k < N) atomic_add_f32(&out[n0 + k], t);
+        }
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void colsum_flat_kernel(const float* __restrict__ g, float* __restrict__ out, int T, long long N) {
+    const long long stride = (long long)gridDim.x * 256 * VEC;
+    for (long long n = ((long long)blockIdx.x * 256 + threadIdx.x) * VEC; n < N; n += stride) {
+        if (VEC == 4) {
+            f32x4 s = *reinterpret_cast<const f32x4*>(out + n);
+            for (int t = 0; t < T; ++t) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(g + (long long)t * N + n);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] += v[k];
+            }
+            *reinterpret_cast<f32x4*>(out + n) = s;
+        } else {
+            float s = out[n];
+            for (int t = 0; t < T; ++t) s += g[(long long)t * N + n];
+            out[n] = s;
+        }
+    }
+}
+
+}  // namespace
+
+namespace {
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long long n) {
+    const long long n4 = n / 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+        reinterpret_cast<bf16x4*>(dst)[i] = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    }
+    for (long long i = 4 * n4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = (__bf16)src[i];
+}
+}  // namespace
+
+extern "C" int dlwp_cast_bf16(const float* src, void* dst, long long n, void* stream) {
+    DLWP_REQUIRE(src && dst && n >= 0, DLWP_E_INVALID, "cast_bf16: bad argument");
+    DLWP_REQUIRE((uintptr_t)src % 16 == 0 && (uintptr_t)dst % 8 == 0, DLWP_E_INVALID, "cast_bf16: buffers must be 16 / 8 byte aligned");
+    if (n == 0) return DLWP_OK;
+    const long long blocks = std::min<long long>((n / 4 + 255) / 256 + 1, 4096);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, n);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_layernorm_fwd_ex(const float* x, const float* gamma, const float* beta, void* y, float* mean,
+                                     float* rstd, int T, int C, float eps, int y_bf16, void* stream) {
+    DLWP_REQUIRE(x && gamma && beta && y && mean && rstd && T > 0 && C > 0, DLWP_E_INVALID, "layernorm_fwd: bad argument");
+    const bool narrow = C % 4 == 0 && C <= 256 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 8 == 0 && (uintptr_t)gamma % 16 == 0 &&
+                        (uintptr_t)beta % 16 == 0 && (y_bf16 || (uintptr_t)y % 16 == 0);
+    if (narrow) {
+        const int lpr = C <= 32 ? 8 : C <= 64 ? 16 : C <= 128 ? 32 : 64;
+#define LN_FWD_V(LPR) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<LPR>, dim3(ceil_div(T, 4 * (64 / LPR))), dim3(256), 0, (hipStream_t)stream, \
+                                          x, gamma, beta, (float*)y, mean, rstd, T, C, eps, y_bf16 ? 1 : 0)
+        if (lpr == 8) LN_FWD_V(8); else if (lpr == 16) LN_FWD_V(16); else if (lpr == 32) LN_FWD_V(32); else LN_FWD_V(64);
+#undef LN_FWD_V
+        DLWP_LAUNCH_CHECK();
+        return DLWP_OK;
+    }
+    const bool widef = C % 4 == 0 && C > 256 && C <= 1024 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % (y_bf16 ? 8 : 16) == 0 &&
+                       (uintptr_t)gamma % 16 == 0 && (uintptr_t)beta % 16 == 0;
+    if (widef) {
+#define LN_FWD_W(NV) hipLaunchKernelGGL(layernorm_fwd_wide_kernel<NV>, dim3(ceil_div(T, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, \
+                                        (float*)y, mean, rstd, T, C, eps, y_bf16)
+        if (C <= 512) LN_FWD_W(2); else if (C <= 768) LN_FWD_W(3); else LN_FWD_W(4);
+#undef LN_FWD_W
+        DLWP_LAUNCH_CHECK();
+        return DLWP_OK;
+    }
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ceil_div(T, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (float*)y,
+                       mean, rstd, T, C, eps, y_bf16 ? 1 : 0);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                  float* rstd, int T, int C, float eps, void* stream) {
+    return dlwp_layernorm_fwd_ex(x, gamma, beta, y, mean, rstd, T, C, eps, 0, stream);
+}
+
+static int layernorm_bwd_impl(const float* x, const float* gamma, const float* mean, const float* rstd, const float* gy,
+                              const float* gadd, float* gx, float* ggamma, float* gbeta, int T, int C, int gy_bf16,
+                              void* stream) {
+    DLWP_REQUIRE(x && gamma && mean && rstd && gy && gx && ggamma && gbeta && T > 0 && C > 0, DLWP_E_INVALID,
+                 "layernorm_bwd: bad argument");
+    DLWP_REQUIRE(C <= 2048, DLWP_E_UNSUPPORTED, "layernorm_bwd: C <= 2048 supported (got %d)", C);
+    // Every workgroup ends with 2C float atomics on the same addresses, which serialise at ~25 ns each, so the
+    // tail costs (number of workgroups) x 25 ns whatever C is: ~128-256 workgroups balance that against the rows
+    // each wave walks serially.
+    // each wave then walks serially (one wave per SIMD hides no latency).  Large inputs get up to ~1024 workgroups.
+    const int want_env = dlwp_tune("LN_BWD_WANT");
+    // (measured, tools/probe_layernorm.py: 8192 x 256 wants 256 workgroups (14.7 vs 18.7 us at 128); the 1024 x 64 calls of the 64 x 64
+    // AFNO rollout want the fewer, longer ones: 128 -> 256 cost that step 4 %)
+    const long long want = want_env != DLWP_TUNE_UNSET ? want_env
+                                    : std::min<long long>(512, std::max<long long>((long long)T * C >= (1 << 21) ? 256 : 128, (long long)T * C / 16384));
+    int rpb = 256;
+    while (rpb > 4 && ceil_div(T, rpb) < want) rpb >>= 1;
+    const dim3 grid(ceil_div(T, rpb));
+    const size_t lds = 2 * C * sizeof(float);
+    const bool narrow = C % 4 == 0 && C <= 256 && (uintptr_t)x % 16 == 0 && (uintptr_t)gy % 8 == 0 && (uintptr_t)gx % 16 == 0 &&
+                        (uintptr_t)gamma % 16 == 0 && (gy_bf16 || (uintptr_t)gy % 16 == 0) && (!gadd || (uintptr_t)gadd % 16 == 0);
+    const bool wide = C % 4 == 0 && C > 256 && C <= 1024 && (uintptr_t)x % 16 == 0 && (uintptr_t)gx % 16 == 0 &&
+                      (uintptr_t)gamma % 16 == 0 && (uintptr_t)gy % (gy_bf16 ? 8 : 16) == 0 && (!gadd || (uintptr_t)gadd % 16 == 0);
+    const bool no_wide = dlwp_tune_on("LN_BWD_NOWIDE");
+    if (wide && !no_wide) {
+        // one round of resident workgroups (~110 VGPRs: four per CU at most; 512-768 keep the atomic tail short)
+        const int wg_env = dlwp_tune("LN_BWD_WGS");
+        const int slots = wg_env != DLWP_TUNE_UNSET ? wg_env : 384;
+        const int rpw = std::max(4, ceil_div(ceil_div(T, slots), 4) * 4);
+        const dim3 gridw(ceil_div(T, rpw));
+#define LN_BWD_W(NV) hipLaunchKernelGGL(layernorm_bwd_wide_kernel<NV>, gridw, dim3(256), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, \
+                                        gadd, gx, ggamma, gbeta, T, C, rpw, gy_bf16)
+        if (C <= 512) LN_BWD_W(2); else if (C <= 768) LN_BWD_W(3); else LN_BWD_W(4);
+#undef LN_BWD_W
+        DLWP_LAUNCH_CHECK();
+        return DLWP_OK;
+    }
+    if (narrow) {
+#define LN_BWD_V(LPR) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<LPR>, grid, dim3(256), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, \
+                                          gadd, gx, ggamma, gbeta, T, C, rpb, gy_bf16)
+        if (C <= 32) LN_BWD_V(8); else if (C <= 64) LN_BWD_V(16); else if (C <= 128) LN_BWD_V(32); else LN_BWD_V(64);
+#undef LN_BWD_V
+        DLWP_LAUNCH_CHECK();
+        return DLWP_OK;
+    }
+#define LN_BWD(NQ)                                                                                                   \
+    hipLaunchKernelGGL(layernorm_bwd_kernel<NQ>, grid, dim3(256), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, gadd, \
+                       gx, ggamma, gbeta, T, C, rpb, gy_bf16)
+    if (C <= 64) LN_BWD(1);
+    else if (C <= 128) LN_BWD(2);
+    else if (C <= 256) LN_BWD(4);
+    else if (C <= 512) LN_BWD(8);
+    else if (C <= 1024) LN_BWD(16);
+    else LN_BWD(32);
+#undef LN_BWD
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_layernorm_bwd_res(const float* x, const float* gamma, const float* mean, const float* rstd,
+                                      const float* gy, const float* gadd, float* gx, float* ggamma, float* gbeta, int T,
+                                      int C, void* stream) {
+    return layernorm_bwd_impl(x, gamma, mean, rstd, gy, gadd, gx, ggamma, gbeta, T, C, 0, stream);
+}
+
+extern "C" int dlwp_layernorm_bwd_ex(const float* x, const float* gamma, const float* mean, const float* rstd, const void* gy,
+                                     int gy_bf16, const float* gadd, float* gx, float* ggamma, float* gbeta, int T, int C,
+                                     void* stream) {
+    return layernorm_bwd_impl(x, gamma, mean, rstd, (const float*)gy, gadd, gx, ggamma, gbeta, T, C, gy_bf16 ? 1 : 0, stream);
+}
+
+extern "C" int dlwp_layernorm_bwd(const float* x, const float* gamma, const float* mean, const float* rstd,
+                                  const float* gy, float* gx, float* ggamma, float* gbeta, int T, int C, void* stream) {
+    return layernorm_bwd_impl(x, gamma, mean, rstd, gy, nullptr, gx, ggamma, gbeta, T, C, 0, stream);
+}
+
+extern "C" int dlwp_gelu_bwd(const float* z, const float* gy, float* gz, long long n, void* stream) {
+    DLWP_REQUIRE(z && gy && gz && n >= 0, DLWP_E_INVALID, "gelu_bwd: NULL argument");
+    if (n == 0) return DLWP_OK;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, z, gy, gz, n);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_act_bwd(const float* z, const float* gy, float* gz, long long n, int act, float act_param, void* stream) {
+    DLWP_REQUIRE(z && gy && gz && n >= 0 && act >= 1 && act <= 3, DLWP_E_INVALID, "act_bwd: bad argument");
+    if (n == 0) return DLWP_OK;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, z, gy, gz, n, act, act_param);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+extern "C" int dlwp_colsum(const float* g, float* out, int T, int N, void* stream) {
+    DLWP_REQUIRE(g && out && T > 0 && N > 0, DLWP_E_INVALID, "colsum: bad argument");
+    const bool vec = N % 4 == 0 && (uintptr_t)g % 16 == 0 && (uintptr_t)out % 16 == 0;
+    if (T <= 16) {
+        const long long units = vec ? N / 4 : N;
+        const int grid = (int)std::min<long long>((units + 255) / 256, 4096);
+        if (vec) hipLaunchKernelGGL(colsum_flat_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, out, T, (long long)N);
+        else hipLaunchKernelGGL(colsum_flat_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, out, T, (long long)N);
+    } else {
+        // row slabs sized so that the launch has ~2048 workgroups (fills the chip, bounds the atomics per column)
+        const int cols = ceil_div(N, vec ? 256 : 64);
+        int slabs = std::max(1, std::min(ceil_div(T, 64), ceil_div(2048, cols)));
+        const int rpb = ceil_div(T, slabs);
+        slabs = ceil_div(T, rpb);
+        if (vec) hipLaunchKernelGGL(colsum_kernel<4>, dim3(cols, slabs), dim3(256), 0, (hipStream_t)stream, g, out, T, N, rpb);
+        else hipLaunchKernelGGL(colsum_kernel<1>, dim3(cols, slabs), dim3(256), 0, (hipStream_t)stream, g, out, T, N, rpb);
+    }
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
