@@ -21,6 +21,7 @@
 // which costs matrix work that this regime has to spare and avoids any transposition through LDS:
 //   dP^T = V dO^T,  dS^T = P^T (dP^T - D),  dQ^T += K^T dS^T ;   dP = dO V^T,  dS = P (dP - D),  dV^T += dO^T P,  dK^T += Q^T dS.
 // dBias partials are summed per workgroup in LDS (64-bit fixed point, see winattn.hip) and flushed with float atomics.
+#include <type_traits>
 #include "common.cuh"
 #include "dlwpmi_internal.h"
 
@@ -46,6 +47,9 @@ struct WsDev {
     // positions hold fill [3 heads d], the qkv bias), out [batch][Ltok][heads d] written / read through dst_map; no window-layout
     // copy of either exists (dlwp_window_attn_fwd_tokens; dlwp_window_attn_bwd_tokens with fill)
     const float* fill;
+    // io_bf16 (token-layout mode with fill): out / gout / gqkv are bf16 arrays (the `float*` fields then point at bf16 storage):
+    // the proj and qkv Linear layers around the attention take their operands as bf16 without a cast pass
+    int io_bf16;
     int dbg;                   // measurement switches of the one-pass backward (DLWP_WINATTN_DBG): results are wrong when set
     int qc_lo, qc_hi;          // query chunks (of 16 tokens) to compute; the rest are padded positions whose outputs nobody reads
                                // and whose upstream gradient is zero (Pangu: half of every window, dlwp_window_attn_fwd_qrange)
@@ -118,18 +122,24 @@ __device__ __forceinline__ void stage_table(float* tb, const WsDev& a, const Who
 // TOK: operands in the token layout (WsDev::fill): a wave stages its window's two position-map rows in LDS; a fragment row is then
 // the token's row of the unpartitioned qkv tensor or, for a padded position, the fill vector; output rows go to the token the
 // reverse map names (positions it drops are not written).  Needs d % 4 == 0.
-template <bool TOK>
+template <bool TOK, bool IOBF = false>
 __device__ __forceinline__ f32x4 frag_row(const float* __restrict__ base, long long stride, const float* __restrict__ fillp,
                                           const int* __restrict__ srcl, int tok, int N, int dd0, int d) {
     if (!TOK) return row_frag<true>(base, stride, tok, N, dd0, d);
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
     if (tok < N && dd0 < d) {
         const int s_ = srcl[tok];
-        v = *reinterpret_cast<const f32x4*>(s_ >= 0 ? base + (long long)s_ * stride + dd0 : fillp + dd0);
+        if (IOBF && s_ >= 0) {          // the qkv tensor is a bf16 array: 8 bytes per fragment row
+            typedef __bf16 bh4 __attribute__((ext_vector_type(4)));
+            const bh4 h = *reinterpret_cast<const bh4*>(reinterpret_cast<const __bf16*>(base) + (long long)s_ * stride + dd0);
+            v = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        } else {
+            v = *reinterpret_cast<const f32x4*>(s_ >= 0 ? base + (long long)s_ * stride + dd0 : fillp + dd0);
+        }
     }
     return v;
 }
-template <bool TOK>
+template <bool TOK, bool IOBF = false>
 __device__ __forceinline__ f32x4 frag_col(const float* __restrict__ base, long long stride, const float* __restrict__ fillp,
                                           const int* __restrict__ srcl, int tok0, int N, int dd, int d) {
     if (!TOK) return col_frag(base, stride, tok0, N, dd, d);
@@ -139,12 +149,13 @@ __device__ __forceinline__ f32x4 frag_col(const float* __restrict__ base, long l
         for (int s = 0; s < 4; ++s)
             if (tok0 + s < N) {
                 const int s_ = srcl[tok0 + s];
-                v[s] = s_ >= 0 ? base[(long long)s_ * stride + dd] : fillp[dd];
+                if (IOBF) v[s] = s_ >= 0 ? (float)reinterpret_cast<const __bf16*>(base)[(long long)s_ * stride + dd] : fillp[dd];
+                else v[s] = s_ >= 0 ? base[(long long)s_ * stride + dd] : fillp[dd];
             }
     }
     return v;
 }
-template <int NC, int NDB, bool VEC, bool BF, bool TOK = false>
+template <int NC, int NDB, bool VEC, bool BF, bool TOK = false, bool IOBF = false>
 __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tb = smem;                                         // [TB] bias-table slice of this (type, head)
@@ -163,9 +174,11 @@ __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
     if (!w.valid) return;
     const int N = a.N, d = a.d;
     const long long rs = 3LL * a.heads * d, os = (long long)a.heads * d;
-    const float* qb = TOK ? a.qkv + (long long)(w.b / a.nW) * a.Ltok * rs + w.head * d : a.qkv + (long long)w.b * N * rs + w.head * d;
-    const float* kb = qb + a.heads * d;
-    const float* vb = qb + 2 * a.heads * d;
+    // IOBF: the three bases are bf16 addresses carried in float pointers (frag_row / frag_col index them in bf16 elements)
+    const long long qoff = TOK ? (long long)(w.b / a.nW) * a.Ltok * rs + w.head * d : (long long)w.b * N * rs + w.head * d;
+    const float* qb = IOBF ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(a.qkv) + qoff) : a.qkv + qoff;
+    const float* kb = IOBF ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(qb) + a.heads * d) : qb + a.heads * d;
+    const float* vb = IOBF ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(qb) + 2 * a.heads * d) : qb + 2 * a.heads * d;
     const float* fq = TOK ? a.fill + w.head * d : nullptr;
     const float* fk = TOK ? fq + a.heads * d : nullptr;
     const float* fv = TOK ? fq + 2 * a.heads * d : nullptr;
@@ -177,9 +190,9 @@ __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
     for (int kc = 0; kc < NC; ++kc) {
 #pragma unroll
         for (int cc = 0; cc < NDB; ++cc)
-            kf[kc][cc] = TOK ? frag_row<TOK>(kb, rs, fk, srcl, 16 * kc + r, N, 16 * cc + 4 * g, d) : row_frag<VEC>(kb, rs, 16 * kc + r, N, 16 * cc + 4 * g, d);
+            kf[kc][cc] = TOK ? frag_row<TOK, IOBF>(kb, rs, fk, srcl, 16 * kc + r, N, 16 * cc + 4 * g, d) : row_frag<VEC>(kb, rs, 16 * kc + r, N, 16 * cc + 4 * g, d);
 #pragma unroll
-        for (int db = 0; db < NDB; ++db) vt[db][kc] = frag_col<TOK>(vb, rs, fv, srcl, 16 * kc + 4 * g, N, 16 * db + r, d);
+        for (int db = 0; db < NDB; ++db) vt[db][kc] = frag_col<TOK, IOBF>(vb, rs, fv, srcl, 16 * kc + 4 * g, N, 16 * db + r, d);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int key = min(16 * kc + 4 * g + j, N - 1);
@@ -195,7 +208,7 @@ __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
         f32x4 qf[NDB];
 #pragma unroll
         for (int cc = 0; cc < NDB; ++cc) {
-            qf[cc] = TOK ? frag_row<TOK>(qb, rs, fq, srcl, q, N, 16 * cc + 4 * g, d) : row_frag<VEC>(qb, rs, q, N, 16 * cc + 4 * g, d);
+            qf[cc] = TOK ? frag_row<TOK, IOBF>(qb, rs, fq, srcl, q, N, 16 * cc + 4 * g, d) : row_frag<VEC>(qb, rs, q, N, 16 * cc + 4 * g, d);
 #pragma unroll
             for (int s = 0; s < 4; ++s) qf[cc][s] *= a.scale;
         }
@@ -234,7 +247,13 @@ __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
             for (int kc = 0; kc < NC; ++kc) o = mfma16_chunk_p<BF>(vt[db][kc], s[kc], o);
             const int dd = 16 * db + 4 * g;
             const int orow = TOK ? (q < N ? dstl[q] : -1) : q;
-            if (q < N && orow >= 0) {
+            if (TOK && IOBF) {
+                if (q < N && orow >= 0 && dd < d) {
+                    typedef __bf16 bh4 __attribute__((ext_vector_type(4)));
+                    __bf16* dst = reinterpret_cast<__bf16*>(a.out) + ((long long)(w.b / a.nW) * a.Ltok + orow) * os + w.head * d + dd;
+                    *reinterpret_cast<bh4*>(dst) = bh4{(__bf16)(o[0] * inv), (__bf16)(o[1] * inv), (__bf16)(o[2] * inv), (__bf16)(o[3] * inv)};
+                }
+            } else if (q < N && orow >= 0) {
                 float* dst = a.out + (TOK ? (long long)(w.b / a.nW) * a.Ltok + orow : (long long)w.b * N + q) * os + w.head * d + dd;
                 if (VEC) {
                     if (dd < d) *reinterpret_cast<f32x4*>(dst) = f32x4{o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
@@ -758,20 +777,22 @@ __device__ __forceinline__ LdsWin2 lds2_carve(void* smem, int NR, int TB) {
 // passes over window m and land under them; the conversion to the bf16 LDS image follows the barrier that ends window m.  (Measured
 // with the in-kernel stamps at the Pangu C4 layer-1 shape: staging in one piece took 7.9 k cycles per window, pass 1 8.1 k.)
 // Two (token, 4-channel group) items per thread cover NR <= 128 rows with 512 threads and NR <= 64 with 256.
+template <bool IOBF>
 struct Stage2 {
-    f32x4 q[2], k[2], v[2], g[2], o[2];
+    typedef typename std::conditional<IOBF, f32x2, f32x4>::type go_t;      // IOBF: four bf16 = 8 raw bytes per row piece
+    go_t q[2], k[2], v[2], g[2], o[2];
     float lse;
-    int lab, src, dst;
+    int lab, src;
 };
 // token-layout mode: the map entries a thread needs for window m + 1 (gout rows of its two items; the LDS copies of both maps) are
 // fetched one window earlier still, so that the dependent gout loads do not wait on them
 struct Idx2 {
-    int d[2], s[2], src, dst;
+    int d[2], s[2];
 };
 template <int NT>
 __device__ __forceinline__ void lds2_index(Idx2& I, const WsDev& a, const Who& w) {
     const int N = a.N, tid = threadIdx.x;
-    I.d[0] = I.d[1] = I.s[0] = I.s[1] = I.src = I.dst = 0;
+    I.d[0] = I.d[1] = I.s[0] = I.s[1] = 0;
     if (!a.dst_map) return;
     const int* dm = a.dst_map + (long long)w.wdw * N;
 #pragma unroll
@@ -780,12 +801,9 @@ __device__ __forceinline__ void lds2_index(Idx2& I, const WsDev& a, const Who& w
         I.d[i] = dm[tok < N ? tok : N - 1];
         I.s[i] = a.src_map[(long long)w.wdw * N + (tok < N ? tok : N - 1)];
     }
-    const int tc = tid < N ? tid : N - 1;
-    I.dst = dm[tc];
-    I.src = a.src_map[(long long)w.wdw * N + tc];
 }
-template <int NT>
-__device__ __forceinline__ void lds2_load(Stage2& R, const Idx2& I, const WsDev& a, const Who& w, int NR) {
+template <int NT, bool IOBF>
+__device__ __forceinline__ void lds2_load(Stage2<IOBF>& R, const Idx2& I, const WsDev& a, const Who& w, int NR) {
     const int N = a.N, d = a.d, tid = threadIdx.x, ch = tid & 7;
     const long long rs = 3LL * a.heads * d, os = (long long)a.heads * d;
     const float* qb = a.qkv + (long long)w.b * N * rs + w.head * d;
@@ -800,23 +818,45 @@ __device__ __forceinline__ void lds2_load(Stage2& R, const Idx2& I, const WsDev&
     for (int i = 0; i < 2; ++i) {
         const int tok = (tid >> 3) + i * (NT / 8);
         const int tc = tok < N ? tok : N - 1;
-        const float* row = full ? (I.s[i] >= 0 ? qb + (long long)I.s[i] * rs + cc : fl) : qb + (long long)tc * rs + cc;
-        R.q[i] = *reinterpret_cast<const f32x4*>(row);
-        R.k[i] = *reinterpret_cast<const f32x4*>(row + a.heads * d);
-        R.v[i] = *reinterpret_cast<const f32x4*>(row + 2 * a.heads * d);
+        if constexpr (IOBF) {
+            // bf16 qkv rows (8 raw bytes per piece); a padded position takes the fp32 fill vector, rounded here
+            if (I.s[i] >= 0) {
+                const __bf16* row = reinterpret_cast<const __bf16*>(a.qkv) + (tb0 + I.s[i]) * rs + w.head * d + cc;
+                R.q[i] = *reinterpret_cast<const f32x2*>(row);
+                R.k[i] = *reinterpret_cast<const f32x2*>(row + a.heads * d);
+                R.v[i] = *reinterpret_cast<const f32x2*>(row + 2 * a.heads * d);
+            } else {
+                R.q[i] = __builtin_bit_cast(f32x2, pack_bf(*reinterpret_cast<const f32x4*>(fl)));
+                R.k[i] = __builtin_bit_cast(f32x2, pack_bf(*reinterpret_cast<const f32x4*>(fl + a.heads * d)));
+                R.v[i] = __builtin_bit_cast(f32x2, pack_bf(*reinterpret_cast<const f32x4*>(fl + 2 * a.heads * d)));
+            }
+        } else {
+            const float* row = full ? (I.s[i] >= 0 ? qb + (long long)I.s[i] * rs + cc : fl) : qb + (long long)tc * rs + cc;
+            R.q[i] = *reinterpret_cast<const f32x4*>(row);
+            R.k[i] = *reinterpret_cast<const f32x4*>(row + a.heads * d);
+            R.v[i] = *reinterpret_cast<const f32x4*>(row + 2 * a.heads * d);
+        }
         const int gt = tokm ? (I.d[i] < 0 ? 0 : I.d[i]) : tc;
-        R.g[i] = *reinterpret_cast<const f32x4*>(gb + (long long)gt * os + cc);
-        R.o[i] = *reinterpret_cast<const f32x4*>(ob + (long long)(full ? gt : tc) * os + cc);
-        if (tokm && I.d[i] < 0) { R.g[i] = f32x4{0.f, 0.f, 0.f, 0.f}; if (full) R.o[i] = R.g[i]; }
+        if constexpr (IOBF) {
+            // 8-byte rows of bf16, kept raw (converted by lds2_store)
+            const __bf16* gh = reinterpret_cast<const __bf16*>(a.gout) + (tb0 + gt) * os + w.head * d + cc;
+            const __bf16* oh = reinterpret_cast<const __bf16*>(a.o) + (tb0 + gt) * os + w.head * d + cc;
+            R.g[i] = *reinterpret_cast<const f32x2*>(gh);
+            R.o[i] = *reinterpret_cast<const f32x2*>(oh);
+            if (I.d[i] < 0) { R.g[i] = f32x2{0.f, 0.f}; R.o[i] = R.g[i]; }
+        } else {
+            R.g[i] = *reinterpret_cast<const f32x4*>(gb + (long long)gt * os + cc);
+            R.o[i] = *reinterpret_cast<const f32x4*>(ob + (long long)(full ? gt : tc) * os + cc);
+            if (tokm && I.d[i] < 0) { R.g[i] = f32x4{0.f, 0.f, 0.f, 0.f}; if (full) R.o[i] = R.g[i]; }
+        }
     }
     const int tc = tid < N ? tid : N - 1;
     R.lse = a.lse_in[((long long)w.b * a.heads + w.head) * N + tc];
     R.lab = a.labels ? a.labels[(long long)w.wdw * N + tc] : 0;
-    R.src = tokm ? I.src : tc;
-    R.dst = I.dst;
+    R.src = tokm ? a.src_map[(long long)w.wdw * N + tc] : tc;
 }
-template <int NT>
-__device__ __forceinline__ void lds2_store(const Stage2& R, const WsDev& a, const LdsWin& L, int* srcv, int NR) {
+template <int NT, bool IOBF>
+__device__ __forceinline__ void lds2_store(const Stage2<IOBF>& R, const WsDev& a, const LdsWin& L, int* srcv, int NR) {
     const int N = a.N, d = a.d, tid = threadIdx.x, ch = tid & 7;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -824,7 +864,17 @@ __device__ __forceinline__ void lds2_store(const Stage2& R, const WsDev& a, cons
         if (tok < NR) {
             const bool ok = tok < N && 4 * ch < d;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            f32x4 q = R.q[i], k = R.k[i], v = R.v[i], g = R.g[i], o = R.o[i];
+            f32x4 q, k, v, g, o;
+            if constexpr (IOBF) {
+                typedef __bf16 bh4 __attribute__((ext_vector_type(4)));
+                auto widen = [](const f32x2 raw) {
+                    const bh4 h = __builtin_bit_cast(bh4, raw);
+                    return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+                };
+                q = widen(R.q[i]); k = widen(R.k[i]); v = widen(R.v[i]); g = widen(R.g[i]); o = widen(R.o[i]);
+            } else {
+                q = R.q[i]; k = R.k[i]; v = R.v[i]; g = R.g[i]; o = R.o[i];
+            }
             if (!ok) { q = z; k = z; v = z; g = z; o = z; }
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) q[s2] *= a.scale;
@@ -840,7 +890,7 @@ __device__ __forceinline__ void lds2_store(const Stage2& R, const WsDev& a, cons
     if (tid < NR) { L.lse[tid] = R.lse; L.lab[tid] = R.lab; srcv[tid] = R.src; }
 }
 
-template <int NDB, int NW>
+template <int NDB, int NW, bool IOBF = false>
 __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
     constexpr int NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -852,11 +902,11 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
     if (a.table_t) { for (int i = threadIdx.x; i < a.TB; i += NT) L.tb[i] = a.table_t[w.tofs * a.TB + i]; }
     else { for (int i = threadIdx.x; i < a.TB; i += NT) L.tb[i] = a.table[(long long)i * w.tstr + w.tofs]; }
     DLWP_STAMP(0);
-    Stage2 R;
+    Stage2<IOBF> R;
     Idx2 I;
     who_window(a, w, grp);
     lds2_index<NT>(I, a, w);
-    lds2_load<NT>(R, I, a, w, NR);           // the first window's loads fly while tb / dense are initialised
+    lds2_load<NT, IOBF>(R, I, a, w, NR);           // the first window's loads fly while tb / dense are initialised
     if (grp + a.groups < a.M) {
         Who wn = w;
         who_window(a, wn, grp + a.groups);
@@ -877,24 +927,27 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
     const bool masked = a.labels != nullptr;
     const int qlo = a.qc_lo, qhi = min(a.qc_hi, NCr), nq = qhi - qlo;
     // operands of one tile pair of pass 1 (everything that does not depend on the matrix products)
+    // (the fragments and the gathered bias values travel one tile pair ahead; the four 16-byte vectors of the pair itself -- labels,
+    // statistics, D, the dense tile -- are read at the top of its own step, ahead of the first MFMAs: 16 registers less than a full
+    // double buffer, which put the kernel at 256 VGPRs + scratch)
     struct Pre {
         s16x4 qr[NDB], gr[NDB], qcol[NDB], gcol[NDB];
-        i32x4 lab;
-        f32x4 lse, D, dense, tbv;
+        f32x4 tbv;
     };
     for (int m = grp; m < a.M; m += a.groups) {
         who_window(a, w, m);
         __syncthreads();                   // the previous window's fragments have been read (first turn: tb / dense are initialised)
         if (m == grp) DLWP_STAMP(1);
-        lds2_store<NT>(R, a, L, L2.src, NR);
+        lds2_store<NT, IOBF>(R, a, L, L2.src, NR);
         // gqkv rows: window layout [b][n], or token layout [batch][src token] (row index from the staged map)
-        float* gq = a.gqkv + (tokm ? (long long)(w.b / a.nW) * a.Ltok : (long long)w.b * N) * rs + w.head * d;
+        const long long gq_off = (tokm ? (long long)(w.b / a.nW) * a.Ltok : (long long)w.b * N) * rs + w.head * d;      // in elements
+        float* gq = a.gqkv + gq_off;
         __syncthreads();
         if (m == grp) DLWP_STAMP(2);
         if (m + a.groups < a.M) {
             Who wn = w;
             who_window(a, wn, m + a.groups);
-            lds2_load<NT>(R, I, a, wn, NR);
+            lds2_load<NT, IOBF>(R, I, a, wn, NR);
             if (m + 2 * a.groups < a.M) {
                 who_window(a, wn, m + 2 * a.groups);
                 lds2_index<NT>(I, a, wn);
@@ -923,10 +976,6 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
                     P.qcol[cc] = lds_col(L.Q, q0, 16 * cc + r);
                     P.gcol[cc] = lds_col(L.G, q0, 16 * cc + r);
                 }
-                P.lab = *reinterpret_cast<const i32x4*>(L.lab + q0);
-                P.lse = *reinterpret_cast<const f32x4*>(L.lse + q0);
-                P.D = *reinterpret_cast<const f32x4*>(L.D + q0);
-                P.dense = *reinterpret_cast<const f32x4*>(drow + 16 * qc);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) P.tbv[j] = L.tb[qia[j] + kbi];
             };
@@ -936,6 +985,10 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
 #pragma unroll 1
             for (int qc = qlo; qc < qhi; ++qc) {
                 if (m == grp && kc == 0) DLWP_STAMP(24 + qc - qlo);
+                const int q0 = 16 * qc + 4 * g;
+                const i32x4 qlab = *reinterpret_cast<const i32x4*>(L.lab + q0);
+                const f32x4 qlse = *reinterpret_cast<const f32x4*>(L.lse + q0), qD = *reinterpret_cast<const f32x4*>(L.D + q0);
+                const f32x4 dtile = *reinterpret_cast<const f32x4*>(drow + 16 * qc);
                 if (qc + 1 < qhi) load(nxt, qc + 1);
                 f32x4 sc4 = f32x4{0.f, 0.f, 0.f, 0.f}, dp = sc4;
 #pragma unroll
@@ -943,17 +996,16 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
                     sc4 = mfma_bf(cur.qr[cc], kf[cc], sc4);      // rows = queries 16 qc + 4g + j, column = key r
                     dp = mfma_bf(cur.gr[cc], vf[cc], dp);
                 }
-                const int q0 = 16 * qc + 4 * g;
                 f32x4 p, ds;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float sc = sc4[j] + cur.tbv[j];
-                    if (masked && cur.lab[j] != kl) sc -= 100.f;
-                    const float pv = (q0 + j < N && key < N) ? __expf(sc - cur.lse[j]) : 0.f;
+                    if (masked && qlab[j] != kl) sc -= 100.f;
+                    const float pv = (q0 + j < N && key < N) ? __expf(sc - qlse[j]) : 0.f;
                     p[j] = pv;
-                    ds[j] = pv * (dp[j] - cur.D[j]);
+                    ds[j] = pv * (dp[j] - qD[j]);
                 }
-                if (!(a.dbg & 8)) *reinterpret_cast<f32x4*>(drow + 16 * qc) = cur.dense + ds;      // bias gradient: this wave's own tile
+                if (!(a.dbg & 8)) *reinterpret_cast<f32x4*>(drow + 16 * qc) = dtile + ds;      // bias gradient: this wave's own tile
                 const s16x4 pb = pack_bf(p), dsb = pack_bf(ds);
 #pragma unroll
                 for (int db = 0; db < NDB; ++db) {
@@ -975,9 +1027,15 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
                         padk[db] += dk[db];
                         padv[db] += dv[db];
                     } else if (dd < d) {
-                        float* dst = gq + (long long)krow * rs + dd;
-                        *reinterpret_cast<f32x4*>(dst + a.heads * d) = dk[db];
-                        *reinterpret_cast<f32x4*>(dst + 2 * a.heads * d) = dv[db];
+                        if constexpr (IOBF) {
+                            bf16_t* dst = reinterpret_cast<bf16_t*>(a.gqkv) + gq_off + (long long)krow * rs + dd;
+                            *reinterpret_cast<s16x4*>(dst + a.heads * d) = pack_bf(dk[db]);
+                            *reinterpret_cast<s16x4*>(dst + 2 * a.heads * d) = pack_bf(dv[db]);
+                        } else {
+                            float* dst = gq + (long long)krow * rs + dd;
+                            *reinterpret_cast<f32x4*>(dst + a.heads * d) = dk[db];
+                            *reinterpret_cast<f32x4*>(dst + 2 * a.heads * d) = dv[db];
+                        }
                     }
                 }
             }
@@ -985,7 +1043,8 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
         if (m == grp) DLWP_STAMP_WAVE(8);
         __syncthreads();
         if (m == grp) DLWP_STAMP(3);
-        // ---- pass 2: dQ = dS K for the computed query chunks (rows = queries 4g + j, column = channel 16 db + r), zeros elsewhere
+        // ---- pass 2: dQ^T = K^T dS^T for the computed query chunks (rows = channels 16 db + 4g + j, column = query r: a lane
+        //      holds four consecutive channels of one query row -> one vector store), zeros elsewhere
         for (int qc = wv; qc < ((a.dbg & 32) ? 0 : NCr); qc += NW) {
             f32x4 dq[NDB];
 #pragma unroll
@@ -1004,46 +1063,45 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
                         for (int db = 0; db < NDB; ++db) kn[db] = lds_col(L.K, 16 * (kc + 1) + 4 * g, 16 * db + r);
                     }
 #pragma unroll
-                    for (int db = 0; db < NDB; ++db) dq[db] = mfma_bf(sf, kcol[db], dq[db]);
+                    for (int db = 0; db < NDB; ++db) dq[db] = mfma_bf(kcol[db], sf, dq[db]);
                     sf = sn;
 #pragma unroll
                     for (int db = 0; db < NDB; ++db) kcol[db] = kn[db];
                 }
             }
-            const i32x4 qrow = *reinterpret_cast<const i32x4*>(L2.src + 16 * qc + 4 * g);
+            const int q = 16 * qc + r;
+            if (q < N) {
+                const int qrow = L2.src[q];
 #pragma unroll
-            for (int db = 0; db < NDB; ++db)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int q = 16 * qc + 4 * g + j, dd = 16 * db + r;
-                    if (q < N) {
-                        if (qrow[j] < 0) padq[db][j] += dq[db][j] * a.scale;
-                        else if (dd < d) gq[(long long)qrow[j] * rs + dd] = dq[db][j] * a.scale;
+                for (int db = 0; db < NDB; ++db) {
+                    const int dd = 16 * db + 4 * g;
+                    const f32x4 v = dq[db] * a.scale;
+                    if (qrow < 0) padq[db] += v;
+                    else if (dd < d) {
+                        if constexpr (IOBF) *reinterpret_cast<s16x4*>(reinterpret_cast<bf16_t*>(a.gqkv) + gq_off + (long long)qrow * rs + dd) = pack_bf(v);
+                        else *reinterpret_cast<f32x4*>(gq + (long long)qrow * rs + dd) = v;
                     }
                 }
+            }
         }
     }
     if (tokm) {
-        // the padded positions' gradient = the fill's: dK^T / dV^T fragments hold channel 16 db + 4g + j of key r -> sum over r;
-        // dQ fragments hold channel 16 db + r of query 4g + j -> sum over j and g
+        // the padded positions' gradient = the fill's: every fragment holds channels 16 db + 4g + j of token r -> sum over r
         float* gf = a.gfill + w.head * d;
 #pragma unroll
         for (int db = 0; db < NDB; ++db) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float sk = padk[db][j], sv = padv[db][j];
+                float sq = padq[db][j], sk = padk[db][j], sv = padv[db][j];
 #pragma unroll
-                for (int sh = 1; sh < 16; sh <<= 1) { sk += __shfl_xor(sk, sh); sv += __shfl_xor(sv, sh); }
+                for (int sh = 1; sh < 16; sh <<= 1) { sq += __shfl_xor(sq, sh); sk += __shfl_xor(sk, sh); sv += __shfl_xor(sv, sh); }
                 const int dd = 16 * db + 4 * g + j;
                 if (r == 0 && dd < d) {
+                    if (sq != 0.f) atomic_add_f32(gf + dd, sq);
                     if (sk != 0.f) atomic_add_f32(gf + a.heads * d + dd, sk);
                     if (sv != 0.f) atomic_add_f32(gf + 2 * a.heads * d + dd, sv);
                 }
             }
-            float sq = padq[db][0] + padq[db][1] + padq[db][2] + padq[db][3];
-            sq += __shfl_xor(sq, 16);
-            sq += __shfl_xor(sq, 32);
-            if (g == 0 && 16 * db + r < d && sq != 0.f) atomic_add_f32(gf + 16 * db + r, sq);
         }
     }
     DLWP_STAMP_WAVE(16);
@@ -1171,8 +1229,13 @@ static int one_pass_launch(WsDev& a, void* stream) {
         return DLWP_OK;
     };
     int rc1;
-    if (nw1 == 8) rc1 = d <= 16 ? go1(winattn_lds_bwd1p_kernel<1, 8>, 512) : go1(winattn_lds_bwd1p_kernel<2, 8>, 512);
-    else rc1 = d <= 16 ? go1(winattn_lds_bwd1p_kernel<1, 4>, 256) : go1(winattn_lds_bwd1p_kernel<2, 4>, 256);
+    if (a.io_bf16) {
+        if (nw1 == 8) rc1 = d <= 16 ? go1(winattn_lds_bwd1p_kernel<1, 8, true>, 512) : go1(winattn_lds_bwd1p_kernel<2, 8, true>, 512);
+        else rc1 = d <= 16 ? go1(winattn_lds_bwd1p_kernel<1, 4, true>, 256) : go1(winattn_lds_bwd1p_kernel<2, 4, true>, 256);
+    } else {
+        if (nw1 == 8) rc1 = d <= 16 ? go1(winattn_lds_bwd1p_kernel<1, 8>, 512) : go1(winattn_lds_bwd1p_kernel<2, 8>, 512);
+        else rc1 = d <= 16 ? go1(winattn_lds_bwd1p_kernel<1, 4>, 256) : go1(winattn_lds_bwd1p_kernel<2, 4>, 256);
+    }
     if (rc1) return rc1;
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
@@ -1241,7 +1304,7 @@ static int tokens_check(const char* who, int B_, int nW, int N, int Ltok, int TB
 extern "C" int dlwp_window_attn_fwd_tokens(const float* qkv_tokens, const float* fill, const float* bias_table, const float* packed_table,
                                            const int* ia, const int* ib, const int* labels, const int* src_map, const int* dst_map,
                                            float* out_tokens, float* lse, int B_, int nW, int N, int Ltok, int TB, int ntypes, int heads,
-                                           int d, float scale, int q_lo, int q_hi, void* stream) {
+                                           int d, float scale, int q_lo, int q_hi, int io_bf16, void* stream) {
     DLWP_REQUIRE(qkv_tokens && fill && bias_table && ia && ib && src_map && dst_map && out_tokens && lse, DLWP_E_INVALID,
                  "window_attn_fwd_tokens: NULL argument");
     int rc = tokens_check("window_attn_fwd_tokens", B_, nW, N, Ltok, TB, ntypes, heads, d, q_lo, q_hi);
@@ -1252,7 +1315,7 @@ extern "C" int dlwp_window_attn_fwd_tokens(const float* qkv_tokens, const float*
     WsDev a{};
     ws_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, q_lo, q_hi);
     a.qkv = qkv_tokens; a.fill = fill; a.table = bias_table; a.table_t = packed_table; a.ia = ia; a.ib = ib; a.labels = labels;
-    a.src_map = src_map; a.dst_map = dst_map; a.out = out_tokens; a.lse = lse; a.Ltok = Ltok;
+    a.src_map = src_map; a.dst_map = dst_map; a.out = out_tokens; a.lse = lse; a.Ltok = Ltok; a.io_bf16 = io_bf16 != 0;
     const size_t lds = sizeof(float) * (size_t)((TB + 3) & ~3) + sizeof(int) * 4 * 256;
     const int nc = (N + 15) / 16;
     const dim3 grid((unsigned)(heads * ntypes * a.groups)), block(256);
@@ -1262,8 +1325,13 @@ extern "C" int dlwp_window_attn_fwd_tokens(const float* qkv_tokens, const float*
         hipLaunchKernelGGL(knl, grid, block, lds, (hipStream_t)stream, a);
         return DLWP_OK;
     };
-    if (d <= 16) rc = nc <= 4 ? go(winattn_small_fwd_kernel<4, 1, true, true, true>) : go(winattn_small_fwd_kernel<8, 1, true, true, true>);
-    else rc = nc <= 4 ? go(winattn_small_fwd_kernel<4, 2, true, true, true>) : go(winattn_small_fwd_kernel<8, 2, true, true, true>);
+    if (io_bf16) {
+        if (d <= 16) rc = nc <= 4 ? go(winattn_small_fwd_kernel<4, 1, true, true, true, true>) : go(winattn_small_fwd_kernel<8, 1, true, true, true, true>);
+        else rc = nc <= 4 ? go(winattn_small_fwd_kernel<4, 2, true, true, true, true>) : go(winattn_small_fwd_kernel<8, 2, true, true, true, true>);
+    } else {
+        if (d <= 16) rc = nc <= 4 ? go(winattn_small_fwd_kernel<4, 1, true, true, true>) : go(winattn_small_fwd_kernel<8, 1, true, true, true>);
+        else rc = nc <= 4 ? go(winattn_small_fwd_kernel<4, 2, true, true, true>) : go(winattn_small_fwd_kernel<8, 2, true, true, true>);
+    }
     if (rc) return rc;
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
@@ -1272,9 +1340,10 @@ extern "C" int dlwp_window_attn_bwd_tokens(const float* qkv, const float* fill, 
                                            const int* ia, const int* ib, const int* labels, const float* out, const float* lse,
                                            const float* gout_tokens, const int* dst_map, const int* src_map, float* gqkv_tokens,
                                            float* gfill, float* gbias_table, int B_, int nW, int N, int Ltok, int TB, int ntypes,
-                                           int heads, int d, float scale, int q_lo, int q_hi, void* stream) {
+                                           int heads, int d, float scale, int q_lo, int q_hi, int io_bf16, void* stream) {
     DLWP_REQUIRE(qkv && bias_table && ia && ib && out && lse && gout_tokens && dst_map && src_map && gqkv_tokens && gfill && gbias_table,
                  DLWP_E_INVALID, "window_attn_bwd_tokens: NULL argument");
+    DLWP_REQUIRE(!io_bf16 || fill, DLWP_E_INVALID, "window_attn_bwd_tokens: bf16 tensors need the token-layout operands (fill != NULL)");
     const int rc = tokens_check("window_attn_bwd_tokens", B_, nW, N, Ltok, TB, ntypes, heads, d, q_lo, q_hi);
     if (rc) return rc;
     DLWP_REQUIRE(dlwp_window_attn_bwd_tokens_supported(N, d, TB), DLWP_E_UNSUPPORTED,
@@ -1283,7 +1352,7 @@ extern "C" int dlwp_window_attn_bwd_tokens(const float* qkv, const float* fill, 
     ws_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, q_lo, q_hi);
     a.qkv = qkv; a.fill = fill; a.table = bias_table; a.table_t = packed_table; a.ia = ia; a.ib = ib; a.labels = labels; a.o = out;
     a.lse_in = lse; a.gout = gout_tokens; a.gqkv = gqkv_tokens; a.gtable = gbias_table;
-    a.src_map = src_map; a.dst_map = dst_map; a.gfill = gfill; a.Ltok = Ltok;
+    a.src_map = src_map; a.dst_map = dst_map; a.gfill = gfill; a.Ltok = Ltok; a.io_bf16 = io_bf16 != 0;
     return one_pass_launch(a, stream);
 }
 

@@ -157,8 +157,11 @@ class EarthSpecificBlock(nn.Module):
                 skip, t = norm_fork(self.norm1, x, gemm_input=True)
                 # (where the crop keeps exactly the positions of the real tokens, every padded row has a zero query gradient --
                 # its upstream gradient is zero -- and the fill's adjoint sums the k and v thirds only)
-                qkv_tok = self.attn.qkv(t)
-                if self.attn.qkv.bias is not None and _WindowAttnTokensFn.applies(qkv_tok, spec, self.attn.num_heads, self.attn.earth_position_bias_table):
+                fusable = self.attn.qkv.bias is not None and _WindowAttnTokensFn.applies(t, spec, C // self.attn.num_heads, self.attn.earth_position_bias_table)
+                # (bf16 storage: the projection writes bf16 rows for the attention kernels, which hand bf16 rows to proj)
+                lowp = fusable and _WindowAttnTokensFn.wants_bf16_qkv(B, spec, self.attn.num_heads, C // self.attn.num_heads)
+                qkv_tok = self.attn.qkv(t, out_lowp=lowp)
+                if fusable:
                     # partition + attention + reverse as one node whose backward is one launch (token-layout gradients)
                     t = window_attention_tokens(qkv_tok, self.attn.qkv.bias, self.attn.earth_position_bias_table, self.attn._ia, self.attn._ib,
                                                 self._labels if self.roll else None, spec, fwd_shift, rev_shift, self.attn.num_heads,

@@ -109,6 +109,7 @@ class _WindowAttnFn(torch.autograd.Function):
 
 FUSED_BWD = __import__("os").environ.get("DLWP_WINATTN_TOKENS", "1") != "0"      # env: A/B runs against the four-launch backward
 FUSED_FWD = __import__("os").environ.get("DLWP_WINATTN_TOKENS_FWD", "1") != "0"  # env: ... and against gather + attention + scatter
+IO_BF16 = __import__("os").environ.get("DLWP_WINATTN_IO_BF16", "1") != "0"       # env: ... and against fp32 qkv / output / gradient tensors
 
 
 class _WindowAttnTokensFn(torch.autograd.Function):
@@ -121,11 +122,17 @@ class _WindowAttnTokensFn(torch.autograd.Function):
     src/dlwpbench/models/panguweather/panguweather.py:283-317)."""
 
     @staticmethod
-    def applies(qkv_tok, spec, heads, table):
-        C3 = qkv_tok.shape[-1]
-        d = C3 // (3 * heads)
-        return (FUSED_BWD and qkv_tok.is_cuda and not any(spec.circ) and table.dim() == 3 and
+    def applies(x, spec, d, table):
+        """x: any CUDA tensor of the block (device check); d: head dimension"""
+        return (FUSED_BWD and x.is_cuda and not any(spec.circ) and table.dim() == 3 and
                 L.load().dlwp_window_attn_bwd_tokens_supported(spec.N, d, table.shape[0]) == 1)
+
+    @staticmethod
+    def wants_bf16_qkv(B, spec, heads, d):
+        """the qkv projection may write bf16 (token_ops.Linear out_lowp): bf16 storage live and the one-launch forward applies"""
+        from ..token_ops import _act_dtype
+        return (FUSED_FWD and IO_BF16 and _act_dtype() == torch.bfloat16
+                and L.load().dlwp_window_attn_fwd_tokens_supported(spec.N, d, B * spec.nW * heads) == 1)
 
     @staticmethod
     def forward(ctx, qkv_tok, fill, table, ia, ib, labels, spec, fwd_shift, rev_shift, heads, scale, qrange):
@@ -133,7 +140,8 @@ class _WindowAttnTokensFn(torch.autograd.Function):
         B, Ltok, C3 = qkv_tok.shape
         N, nW = spec.N, spec.nW
         d = C3 // (3 * heads)
-        x = qkv_tok.contiguous().float()
+        io = qkv_tok.dtype == torch.bfloat16          # bf16 tensors on all four sides (dlwp_window_attn_*_tokens io_bf16)
+        x = qkv_tok.contiguous() if io else qkv_tok.contiguous().float()
         fl = fill.detach().contiguous().float()
         table_param, table = table, table.contiguous()
         TB, ntypes = table.shape[0], table.shape[1]
@@ -146,13 +154,16 @@ class _WindowAttnTokensFn(torch.autograd.Function):
             L.check(lib.dlwp_window_attn_pack_table(L.ptr(table), L.ptr(packed), TB, ntypes, heads, L.stream()))
         src_map, dst_map = position_maps(spec, fwd_shift, rev_shift, x.device)
         ctx.in_tokens = FUSED_FWD and lib.dlwp_window_attn_fwd_tokens_supported(N, d, B * nW * heads) == 1
+        ctx.io = io
+        if io and not ctx.in_tokens:
+            raise L.DlwpError("window attention: a bf16 qkv tensor needs the token-layout forward (dlwp_window_attn_fwd_tokens_supported)")
         if ctx.in_tokens:
             # ONE launch, no window-layout copy of qkv or of the output: the kernel reads token rows through src_map (padded
             # positions: the bias) and writes its rows to the tokens dst_map names (every token exactly once)
-            y = torch.empty(B, Ltok, heads * d, device=x.device)
+            y = torch.empty(B, Ltok, heads * d, device=x.device, dtype=torch.bfloat16 if io else torch.float32)
             L.check(lib.dlwp_window_attn_fwd_tokens(L.ptr(x), L.ptr(fl), L.ptr(table), L.ptr(packed), L.ptr(ia), L.ptr(ib), L.ptr(labels),
                                                     L.ptr(src_map), L.ptr(dst_map), L.ptr(y), L.ptr(lse), B * nW, nW, N, Ltok, TB, ntypes,
-                                                    heads, d, scale, qr[0], qr[1], L.stream()))
+                                                    heads, d, scale, qr[0], qr[1], int(io), L.stream()))
             ctx.save_for_backward(x, table, y, lse, fl)
         else:
             dd, pp, ff, ss, ww, sw, circ = spec.c_args(fwd_shift)
@@ -174,14 +185,18 @@ class _WindowAttnTokensFn(torch.autograd.Function):
         qkv, table, out, lse, fl = ctx.saved_tensors
         B, Ltok, nW, N, TB, ntypes, heads, d, scale, qr = ctx.cfg
         ia, ib, labels, packed, src_map, dst_map = ctx.aux
-        g = gy.contiguous().float()
-        gqkv = torch.empty(B, Ltok, 3 * heads * d, device=g.device)
+        g = gy.contiguous()
+        if ctx.io:
+            g = g if g.dtype == torch.bfloat16 else g.to(torch.bfloat16)
+        else:
+            g = g.float()
+        gqkv = torch.empty(B, Ltok, 3 * heads * d, device=g.device, dtype=torch.bfloat16 if ctx.io else torch.float32)
         gtable = ctx.tslot if ctx.tslot is not None else torch.zeros_like(table)          # the kernel accumulates into both
         gfill = ctx.fslot if ctx.fslot is not None else torch.zeros(3 * heads * d, device=g.device)
         L.check(lib.dlwp_window_attn_bwd_tokens(L.ptr(qkv), L.ptr(fl) if ctx.in_tokens else None, L.ptr(table), L.ptr(packed), L.ptr(ia),
                                                 L.ptr(ib), L.ptr(labels), L.ptr(out), L.ptr(lse), L.ptr(g), L.ptr(dst_map), L.ptr(src_map),
                                                 L.ptr(gqkv), L.ptr(gfill), L.ptr(gtable), B * nW, nW, N, Ltok, TB, ntypes, heads, d, scale,
-                                                qr[0], qr[1], L.stream()))
+                                                qr[0], qr[1], int(ctx.io), L.stream()))
         return (gqkv, None if ctx.fslot is not None else gfill, None if ctx.tslot is not None else gtable) + (None,) * 9
 
 

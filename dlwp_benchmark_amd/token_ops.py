@@ -95,7 +95,10 @@ class _LinearFn(torch.autograd.Function):
     weight is [N, K] or a 1x1 convolution weight [N, K, 1, 1] (same memory)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act, residual, res_pre=False):
+    def forward(ctx, x, weight, bias, act, residual, res_pre=False, out_lowp=False):
+        """out_lowp (bf16 storage only, no activation / residual): y is written as bf16 for a consumer that reads bf16 rows (the
+        window-attention kernels in their token-layout bf16 mode); the upstream gradient then arrives as bf16 too and feeds both
+        backward products without a cast."""
         shape = x.shape
         x2 = x.reshape(-1, shape[-1]).contiguous()
         if x2.dtype != _BF:               # a bf16 input comes from a LayerNorm that wrote it for this GEMM (bf16 storage)
@@ -105,7 +108,8 @@ class _LinearFn(torch.autograd.Function):
         w, _ = _wmat(weight, N)             # the bf16 copy under bf16 storage (forward and input-gradient products)
         if w.dtype == _BF:
             x2 = _lowp(x2, N)               # read by the forward product and by gW = g^T x
-        y = torch.empty(T, N, device=x.device)
+        lowp_out = bool(out_lowp) and w.dtype == _BF and x2.dtype == _BF and not act and residual is None
+        y = torch.empty(T, N, device=x.device, dtype=_BF if lowp_out else torch.float32)
         z = torch.empty(T, N, device=x.device) if act else None
         r2 = residual.reshape(-1, N).contiguous() if residual is not None else None
         if res_pre:
@@ -126,7 +130,9 @@ class _LinearFn(torch.autograd.Function):
         x2, w, z = ctx.saved_tensors
         T, K = x2.shape
         N = w.shape[0]
-        g2 = gy.reshape(-1, N).contiguous().float()
+        g2 = gy.reshape(-1, N).contiguous()
+        if g2.dtype != _BF or w.dtype != _BF or ctx.act:      # (a bf16 gradient of a bf16 output feeds the bf16 products as it is)
+            g2 = g2.float()
         gres = gy if ctx.has_res else None
         if ctx.act:
             gz = torch.empty_like(g2)
@@ -155,7 +161,7 @@ class _LinearFn(torch.autograd.Function):
             gw = gw.reshape(ctx.wshape)
         if ctx.bslot is not None:
             gb = None
-        return gx.reshape(ctx.shape), gw, gb, None, gres, None
+        return gx.reshape(ctx.shape), gw, gb, None, gres, None, None
 
 
 def _weight_grad(g2, x2, weight_slot, bias_slot, has_bias, wshape):
@@ -809,8 +815,8 @@ class InstanceNorm(nn.Module):
 
 
 class Linear(nn.Linear):
-    def forward(self, x, act=0, residual=None):
-        return _LinearFn.apply(x, self.weight, self.bias, act, residual, False)
+    def forward(self, x, act=0, residual=None, out_lowp=False):
+        return _LinearFn.apply(x, self.weight, self.bias, act, residual, False, out_lowp)
 
 
 class LayerNorm(nn.LayerNorm):

@@ -323,7 +323,10 @@ int dlwp_window_attn_bwd_tokens(const float* qkv, const float* fill, const float
                                 const int* ia, const int* ib, const int* labels, const float* out, const float* lse,
                                 const float* gout_tokens, const int* dst_map, const int* src_map, float* gqkv_tokens,
                                 float* gfill, float* gbias_table, int B_, int nW, int N, int Ltok, int TB, int ntypes,
-                                int heads, int d, float scale, int q_lo, int q_hi, void* stream);
+                                int heads, int d, float scale, int q_lo, int q_hi, int io_bf16, void* stream);
+/* io_bf16 != 0 (both entries; needs fill != NULL): the four token-layout tensors -- qkv, out, gout_tokens, gqkv_tokens -- are  */
+/* bf16 arrays behind the float pointers (the qkv projection wrote bf16, the output projection reads bf16, and their backward   */
+/* GEMMs take the gradients as bf16 operands without a cast pass); fill / gfill / tables / lse stay fp32.                       */
 /* The forward of the same chain in one launch: attention over the windows of a token-layout qkv tensor (no gathered copy),   */
 /* output rows written to the tokens dst_map names (positions it drops are computed only as keys / values).  Same shape       */
 /* family as the wave-per-window kernels: N <= 128, d <= 32, d % 4 == 0, at least 2048 (window, head) pairs, bf16 matrix mode  */
@@ -332,7 +335,7 @@ int dlwp_window_attn_fwd_tokens_supported(int N, int d, long long pairs);
 int dlwp_window_attn_fwd_tokens(const float* qkv_tokens, const float* fill, const float* bias_table, const float* packed_table,
                                 const int* ia, const int* ib, const int* labels, const int* src_map, const int* dst_map,
                                 float* out_tokens, float* lse, int B_, int nW, int N, int Ltok, int TB, int ntypes, int heads,
-                                int d, float scale, int q_lo, int q_hi, void* stream);
+                                int d, float scale, int q_lo, int q_hi, int io_bf16, void* stream);
 int dlwp_window_attn_bwd(const float* qkv, const float* bias_table, const int* ia, const int* ib,
                          const int* labels, const float* out, const float* lse, const float* gout,
                          float* gqkv, float* gbias_table, float* dsum, float* slab, int B_, int nW,

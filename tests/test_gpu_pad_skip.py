@@ -101,8 +101,7 @@ def test_token_layout_backward_equals_the_four_launch_chain(cuda, monkeypatch, B
     with L.gemm_precision("bf16"):
         for fused in (True, False):
             monkeypatch.setattr(st, "FUSED_BWD", fused)
-            qkv_probe = torch.empty(1, 1, 3 * dim, device=cuda)
-            assert st._WindowAttnTokensFn.applies(qkv_probe, blk._wspec, heads, blk.attn.earth_position_bias_table) == fused
+            assert st._WindowAttnTokensFn.applies(x, blk._wspec, dim // heads, blk.attn.earth_position_bias_table) == fused
             y = blk(x)
             grads = torch.autograd.grad(y, [x] + list(blk.parameters()), g)
             outs[fused] = (y.detach().clone(), [t.clone() for t in grads])
@@ -118,4 +117,52 @@ def test_token_layout_backward_equals_the_four_launch_chain(cuda, monkeypatch, B
     g64 = torch.autograd.grad(y64, [x64] + [p64[n] for n in names[1:]], g.double().cpu())
     assert rel(outs[True][0], y64) <= 2e-2
     for n, a, b in zip(names, outs[True][1], g64):
+        assert rel(a, b) <= 3e-2, n
+
+
+@pytest.mark.parametrize("shifted", [False, True])
+def test_bf16_token_tensors_under_bf16_storage(cuda, shifted):
+    """bf16 storage live (the engine's state): the qkv projection writes bf16, the attention kernels read / write bf16 token rows
+    (dlwp_window_attn_fwd_tokens / _bwd_tokens with io_bf16) and proj reads them; output and every gradient against the float64
+    reference block at the bf16-storage tolerance (3e-2 of the max-norm; tests/test_gpu_bf16_storage.py uses the same)."""
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.dlwpbench.panguweather import EarthSpecificBlock
+    from dlwp_benchmark_amd.nsbench import swin_transformer as st
+    from dlwp_benchmark_amd.train_engine import flatten_parameters, refresh_bf16_weights
+    from oracle import pangu_ref
+    B, res, heads, dim = 8, (1, 30, 60), 6, 192
+    torch.manual_seed(11)
+    L.set_gemm_precision("bf16")
+    L.set_storage("bf16")
+    try:
+        blk = EarthSpecificBlock(dim, res, heads, (2, 7, 7), None if shifted else (0, 0, 0)).to(cuda)
+        with torch.no_grad():
+            blk.attn.earth_position_bias_table.normal_(0, 0.5)
+            blk.attn.qkv.bias.normal_(0, 0.5)
+        blk.real_token_flow = True
+        flatten_parameters(blk)                    # bf16 weight copies + gradient slots, as train_engine.GraphedTrainStep does
+        L_ = res[0] * res[1] * res[2]
+        x = torch.randn(B, L_, dim, device=cuda, requires_grad=True)
+        g = torch.randn(B, L_, dim, device=cuda)
+        assert st._WindowAttnTokensFn.wants_bf16_qkv(B, blk._wspec, heads, dim // heads) is False      # not inside a step yet
+        refresh_bf16_weights(blk)
+        prev, L.SHADOW_ACTIVE = L.SHADOW_ACTIVE, True
+        try:
+            assert st._WindowAttnTokensFn.wants_bf16_qkv(B, blk._wspec, heads, dim // heads)
+            y = blk(x)
+            y.backward(g)
+        finally:
+            L.SHADOW_ACTIVE = prev
+        names = [n for n, _ in blk.named_parameters()]
+        got = [x.grad] + [p.grad for p in blk.parameters()]
+    finally:
+        L.set_storage("fp32")
+        L.set_gemm_precision("fp32")
+    p64 = {n: t.detach().double().cpu().requires_grad_(True) for n, t in blk.named_parameters()}
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    y64 = pangu_ref.earth_block(x64, p64, "", res, heads, (2, 7, 7), pangu_ref.DEFAULT_SHIFT if shifted else (0, 0, 0))
+    g64 = torch.autograd.grad(y64, [x64] + [p64[n] for n in names], g.double().cpu())
+    assert rel(y, y64) <= 3e-2
+    for n, a, b in zip(["x"] + names, got, g64):
+        assert a is not None, n
         assert rel(a, b) <= 3e-2, n

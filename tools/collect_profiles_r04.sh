@@ -35,6 +35,12 @@ else
   for m in afno_fcn pangu_c4 swin_c4 sfno; do timeout 200 python3 $R/tools/aten_audit.py $m --precision bf16 --storage bf16 2>&1 | grep "^==\|^ " ; done > $O/aten_audit_big.txt
   timeout 200 python3 $R/tools/probe_layernorm.py > $O/layernorm_probe.txt 2>&1
   timeout 200 python3 $R/tools/probe_fft_ib.py > $O/fft_planar_probe.txt 2>&1
+  (for v in 1 0; do DLWP_WINATTN_BWD2PASS=$v timeout 100 python3 $R/tools/probe_winattn_c4.py 2>&1 | grep "B_=" | sed "s/$/ BWD2PASS=$v/"; done; for wg in 456 798; do PROBE_FIRST=1 DLWP_WINATTN_WG_BWD=$wg timeout 100 python3 $R/tools/probe_winattn_c4.py 2>&1 | grep "B_="; done; for dbg in 1 3 8 32; do PROBE_FIRST=1 DLWP_WINATTN_DBG=$dbg timeout 100 python3 $R/tools/probe_winattn_c4.py 2>&1 | grep "B_="; done) > $O/winattn_probe.txt
+  if [ -f $R/dlwp_benchmark_amd/libdlwpmi_stamps.so ]; then
+    timeout 100 python3 $R/tools/probe_stamps_winattn1p.py 2>&1 | grep -v amdgpu.ids > $O/winattn_1p_stamps.txt
+    timeout 100 python3 $R/tools/probe_stamps_chain.py 2>&1 | grep -v amdgpu.ids > $O/chain_stamps.txt
+  fi
+  timeout 200 python3 $R/tools/aten_audit.py sfno --precision bf16 --storage bf16 2>&1 | grep "^==\|^ " > $O/aten_audit_sfno.txt
   timeout 100 python3 $R/bench.py --workload sfno --batch 16 --steps 40 --warmup 5 --no-roofline --no-cpu-baseline > $O/bench_line_sfno_b16.json 2>> $O/bench_b.err
   for f in sfno swin pangu afno afno721; do cut -c1-220 $O/bench_line_$f.json; done
 fi

@@ -16,6 +16,10 @@ cpif "$F/models.jsonl" "$P/${T}_models_bench.jsonl"
 cpif "$F/fft_bench.txt" "$P/${T}_fft_bench.txt"
 cpif "$F/gemm_bench.txt" "$P/${T}_gemm_bench.txt"
 cpif "$F/gemm_epilogue.txt" "$P/${T}_gemm_epilogue.txt"
+cpif "$F/winattn_probe.txt" "$P/${T}_winattn_probe.txt"
+cpif "$F/winattn_1p_stamps.txt" "$P/${T}_winattn_1p_stamps.txt"
+cpif "$F/chain_stamps.txt" "$P/${T}_chain_stamps.txt"
+cpif "$F/aten_audit_sfno.txt" "$P/${T}_aten_audit_sfno.txt"
 cpif "$F/mfma_valu_coexec.txt" "$P/${T}_mfma_valu_coexec.txt"
 s=$(stats prof_bench); [ -n "$s" ] && cp "$s" "$P/${T}_bench_step_kernel_stats.csv"
 s=$(stats prof_probe); [ -n "$s" ] && cp "$s" "$P/${T}_spatial_probe_kernel_stats.csv"
