@@ -927,12 +927,16 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
     const bool masked = a.labels != nullptr;
     const int qlo = a.qc_lo, qhi = min(a.qc_hi, NCr), nq = qhi - qlo;
     // operands of one tile pair of pass 1 (everything that does not depend on the matrix products)
-    // (the fragments and the gathered bias values travel one tile pair ahead; the four 16-byte vectors of the pair itself -- labels,
-    // statistics, D, the dense tile -- are read at the top of its own step, ahead of the first MFMAs: 16 registers less than a full
-    // double buffer, which put the kernel at 256 VGPRs + scratch)
+    // The fragments and the gathered bias values travel one tile pair ahead.  The four 16-byte vectors of a pair -- labels,
+    // statistics, D, the dense tile -- travel with them in the 4-wave kernel (FULLPRE); in the 8-wave kernel they are read at the top
+    // of the pair's own step, ahead of its first MFMAs: 16 registers less, without which that kernel sits at 256 VGPRs + scratch
+    // (measured: 149 -> 199 us at the Pangu C4 layer-1 shape with 60 B of scratch per lane).
+    constexpr bool FULLPRE = NW == 4;
     struct Pre {
         s16x4 qr[NDB], gr[NDB], qcol[NDB], gcol[NDB];
         f32x4 tbv;
+        i32x4 lab;
+        f32x4 lse, D, dense;
     };
     for (int m = grp; m < a.M; m += a.groups) {
         who_window(a, w, m);
@@ -976,6 +980,12 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
                     P.qcol[cc] = lds_col(L.Q, q0, 16 * cc + r);
                     P.gcol[cc] = lds_col(L.G, q0, 16 * cc + r);
                 }
+                if constexpr (FULLPRE) {
+                    P.lab = *reinterpret_cast<const i32x4*>(L.lab + q0);
+                    P.lse = *reinterpret_cast<const f32x4*>(L.lse + q0);
+                    P.D = *reinterpret_cast<const f32x4*>(L.D + q0);
+                    P.dense = *reinterpret_cast<const f32x4*>(drow + 16 * qc);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) P.tbv[j] = L.tb[qia[j] + kbi];
             };
@@ -986,9 +996,16 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
             for (int qc = qlo; qc < qhi; ++qc) {
                 if (m == grp && kc == 0) DLWP_STAMP(24 + qc - qlo);
                 const int q0 = 16 * qc + 4 * g;
-                const i32x4 qlab = *reinterpret_cast<const i32x4*>(L.lab + q0);
-                const f32x4 qlse = *reinterpret_cast<const f32x4*>(L.lse + q0), qD = *reinterpret_cast<const f32x4*>(L.D + q0);
-                const f32x4 dtile = *reinterpret_cast<const f32x4*>(drow + 16 * qc);
+                i32x4 qlab;
+                f32x4 qlse, qD, dtile;
+                if constexpr (FULLPRE) {
+                    qlab = cur.lab; qlse = cur.lse; qD = cur.D; dtile = cur.dense;
+                } else {
+                    qlab = *reinterpret_cast<const i32x4*>(L.lab + q0);
+                    qlse = *reinterpret_cast<const f32x4*>(L.lse + q0);
+                    qD = *reinterpret_cast<const f32x4*>(L.D + q0);
+                    dtile = *reinterpret_cast<const f32x4*>(drow + 16 * qc);
+                }
                 if (qc + 1 < qhi) load(nxt, qc + 1);
                 f32x4 sc4 = f32x4{0.f, 0.f, 0.f, 0.f}, dp = sc4;
 #pragma unroll
@@ -1201,8 +1218,12 @@ int dlwp_winattn_small_fwd(const float* qkv, const float* table, const float* pa
 }
 
 // the one-pass kernel (round 4) wherever its LDS image fits and the table slice fits the staging area it is folded in
+// Windows of at most 64 tokens (Swin's 49: four key chunks, the 4-wave instantiation) stay on the two-pass kernel unless asked for:
+// with ~4 windows per workgroup the per-workgroup fold of the dense image (2401 LDS float atomics onto 169 table slots) outweighs
+// the saved score evaluations -- Swin C4 step 6.74 ms one-pass vs 6.59 ms two-pass, same box, back to back.
 static bool one_pass_applies(int N, int d, int TB) {
     const int nc = (N + 15) / 16;
+    if (nc <= 4 && !dlwp_tune_on("WINATTN_BWD1P_SMALL")) return false;
     return lds_family_applies(N, d) && lds2_bytes(16 * nc, TB) <= 160 * 1024 && (size_t)TB * 4 <= (size_t)4 * 16 * nc * LDB * 2;
 }
 static int one_pass_launch(WsDev& a, void* stream) {

@@ -166,3 +166,34 @@ def test_bf16_token_tensors_under_bf16_storage(cuda, shifted):
     for n, a, b in zip(["x"] + names, got, g64):
         assert a is not None, n
         assert rel(a, b) <= 3e-2, n
+
+
+@pytest.mark.parametrize("N,heads,d,TB,qr", [(49, 4, 32, 169, None), (49, 3, 24, 169, None), (64, 2, 16, 225, (16, 64))])
+def test_one_pass_backward_for_short_windows_equals_the_two_pass_kernel(cuda, N, heads, d, TB, qr):
+    """Windows of at most 64 tokens take the two-pass LDS kernel by default; the one-pass kernel's 4-wave instantiation (tuning knob
+    WINATTN_BWD1P_SMALL) must give the same gradients (bf16 operands on both sides: 2e-3 of the max-norm; float atomics reorder the
+    bias-table sums)."""
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.nsbench.swin_transformer import window_attention_core
+    torch.manual_seed(3)
+    nW, B_ = 8, 1024
+    qkv = torch.randn(B_, N, 3 * heads * d, device=cuda)
+    table = (torch.randn(TB, heads, device=cuda) * 0.5)
+    ia = torch.randint(0, TB // 2, (N,), device=cuda, dtype=torch.int32)
+    ib = torch.randint(0, TB // 2, (N,), device=cuda, dtype=torch.int32)
+    labels = torch.randint(0, 3, (nW, N), device=cuda, dtype=torch.int32)
+    g = torch.randn(B_, N, heads * d, device=cuda)
+    if qr is not None:
+        g[:, :qr[0]] = 0
+    res = {}
+    with L.gemm_precision("bf16"):
+        for small in (0, 1):
+            L.set_tuning("WINATTN_BWD1P_SMALL", small)
+            try:
+                q_, t_ = qkv.clone().requires_grad_(True), table.clone().requires_grad_(True)
+                y = window_attention_core(q_, t_, ia, ib, labels, nW, heads, d ** -0.5, qr)
+                res[small] = torch.autograd.grad(y, (q_, t_), g)
+            finally:
+                L.set_tuning("WINATTN_BWD1P_SMALL", None)
+    for a, b in zip(res[1], res[0]):
+        assert rel(a, b) <= 2e-3
