@@ -122,36 +122,41 @@ __device__ __forceinline__ void stage_table(float* tb, const WsDev& a, const Who
 // TOK: operands in the token layout (WsDev::fill): a wave stages its window's two position-map rows in LDS; a fragment row is then
 // the token's row of the unpartitioned qkv tensor or, for a padded position, the fill vector; output rows go to the token the
 // reverse map names (positions it drops are not written).  Needs d % 4 == 0.
+// (no branch around a load: a pointer select feeds ONE unconditional load per fragment -- a branch makes the compiler drain vmcnt at
+// its join, which serialises the fragment loads; padded positions take the fill vector from its LDS copy `fl` [d])
 template <bool TOK, bool IOBF = false>
-__device__ __forceinline__ f32x4 frag_row(const float* __restrict__ base, long long stride, const float* __restrict__ fillp,
+__device__ __forceinline__ f32x4 frag_row(const float* __restrict__ base, long long stride, const float* __restrict__ fl,
                                           const int* __restrict__ srcl, int tok, int N, int dd0, int d) {
     if (!TOK) return row_frag<true>(base, stride, tok, N, dd0, d);
-    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (tok < N && dd0 < d) {
-        const int s_ = srcl[tok];
-        if (IOBF && s_ >= 0) {          // the qkv tensor is a bf16 array: 8 bytes per fragment row
-            typedef __bf16 bh4 __attribute__((ext_vector_type(4)));
-            const bh4 h = *reinterpret_cast<const bh4*>(reinterpret_cast<const __bf16*>(base) + (long long)s_ * stride + dd0);
-            v = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
-        } else {
-            v = *reinterpret_cast<const f32x4*>(s_ >= 0 ? base + (long long)s_ * stride + dd0 : fillp + dd0);
-        }
+    const bool ok = tok < N && dd0 < d;
+    const int s_ = ok ? srcl[tok] : 0, sc = s_ < 0 ? 0 : s_, dc = ok ? dd0 : 0;
+    f32x4 v;
+    if (IOBF) {
+        typedef __bf16 bh4 __attribute__((ext_vector_type(4)));
+        const bh4 h = *reinterpret_cast<const bh4*>(reinterpret_cast<const __bf16*>(base) + (long long)sc * stride + dc);
+        v = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    } else {
+        v = *reinterpret_cast<const f32x4*>(base + (long long)sc * stride + dc);
     }
-    return v;
+    const f32x4 fv = *reinterpret_cast<const f32x4*>(fl + dc);      // (unconditional LDS read + select)
+    v = s_ < 0 ? fv : v;
+    return ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
 }
 template <bool TOK, bool IOBF = false>
-__device__ __forceinline__ f32x4 frag_col(const float* __restrict__ base, long long stride, const float* __restrict__ fillp,
+__device__ __forceinline__ f32x4 frag_col(const float* __restrict__ base, long long stride, const float* __restrict__ fl,
                                           const int* __restrict__ srcl, int tok0, int N, int dd, int d) {
     if (!TOK) return col_frag(base, stride, tok0, N, dd, d);
-    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (dd < d) {
+    f32x4 v;
+    const int dc = dd < d ? dd : 0;
+    const float fv = fl[dc];
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            if (tok0 + s < N) {
-                const int s_ = srcl[tok0 + s];
-                if (IOBF) v[s] = s_ >= 0 ? (float)reinterpret_cast<const __bf16*>(base)[(long long)s_ * stride + dd] : fillp[dd];
-                else v[s] = s_ >= 0 ? base[(long long)s_ * stride + dd] : fillp[dd];
-            }
+    for (int s = 0; s < 4; ++s) {
+        const bool ok = tok0 + s < N && dd < d;
+        const int s_ = ok ? srcl[tok0 + s] : 0, sc = s_ < 0 ? 0 : s_;
+        float x;
+        if (IOBF) x = (float)reinterpret_cast<const __bf16*>(base)[(long long)sc * stride + dc];
+        else x = base[(long long)sc * stride + dc];
+        v[s] = !ok ? 0.f : (s_ < 0 ? fv : x);
     }
     return v;
 }
@@ -164,10 +169,17 @@ __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
     stage_table(tb, a, w);
     int* srcl = reinterpret_cast<int*>(tb + ((a.TB + 3) & ~3)) + 256 * wave_id();      // TOK: [128] source rows | [128] destination rows
     int* dstl = srcl + 128;
-    if (TOK && w.valid) {
-        for (int t = lane; t < a.N; t += 64) {
-            srcl[t] = a.src_map[(long long)w.wdw * a.N + t];
-            dstl[t] = a.dst_map[(long long)w.wdw * a.N + t];
+    float* fills = reinterpret_cast<float*>(reinterpret_cast<int*>(tb + ((a.TB + 3) & ~3)) + 4 * 256);      // TOK: [3][32] fill of this head
+    if (TOK) {
+        if (w.valid) {
+            for (int t = lane; t < a.N; t += 64) {
+                srcl[t] = a.src_map[(long long)w.wdw * a.N + t];
+                dstl[t] = a.dst_map[(long long)w.wdw * a.N + t];
+            }
+        }
+        if (threadIdx.x < 96) {
+            const int part = threadIdx.x >> 5, c = threadIdx.x & 31;
+            fills[threadIdx.x] = c < a.d ? a.fill[part * a.heads * a.d + w.head * a.d + c] : 0.f;
         }
     }
     __syncthreads();
@@ -179,9 +191,9 @@ __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
     const float* qb = IOBF ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(a.qkv) + qoff) : a.qkv + qoff;
     const float* kb = IOBF ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(qb) + a.heads * d) : qb + a.heads * d;
     const float* vb = IOBF ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(qb) + 2 * a.heads * d) : qb + 2 * a.heads * d;
-    const float* fq = TOK ? a.fill + w.head * d : nullptr;
-    const float* fk = TOK ? fq + a.heads * d : nullptr;
-    const float* fv = TOK ? fq + 2 * a.heads * d : nullptr;
+    const float* fq = fills;            // LDS copies (TOK only)
+    const float* fk = fills + 32;
+    const float* fv = fills + 64;
     const int* labw = a.labels ? a.labels + (long long)w.wdw * N : nullptr;
 
     f32x4 kf[NC][NDB], vt[NDB][NC];
@@ -754,10 +766,11 @@ struct LdsWin2 {
     float* dense;
     bf16_t* dsm;
     int* src;          // gqkv row of every window position (token-layout mode: the map's row; -1 = padded position)
+    float* fillv;      // [3][32]: this head's slice of the fill vector (token-layout operands)
 };
 __host__ __device__ inline size_t lds2_bytes(int NR, int TB) {
     return (size_t)4 * NR * LDB * 2 + (size_t)5 * NR * 4 + (size_t)((TB + 3) & ~3) * 4 + (size_t)NR * (NR + 4) * 4 + (size_t)NR * (NR + 4) * 2 +
-           (size_t)NR * 4;
+           (size_t)NR * 4 + 96 * 4;
 }
 __device__ __forceinline__ LdsWin2 lds2_carve(void* smem, int NR, int TB) {
     LdsWin2 L;
@@ -771,6 +784,7 @@ __device__ __forceinline__ LdsWin2 lds2_carve(void* smem, int NR, int TB) {
     L.dense = L.w.tb + ((TB + 3) & ~3);
     L.dsm = reinterpret_cast<bf16_t*>(L.dense + NR * (NR + 4));
     L.src = reinterpret_cast<int*>(L.dsm + NR * (NR + 4));
+    L.fillv = reinterpret_cast<float*>(L.src + NR);
     return L;
 }
 // lds_stage<true> in two halves for a workgroup of NT threads: the global loads of window m + 1 (into registers) are issued before the
@@ -782,7 +796,7 @@ struct Stage2 {
     typedef typename std::conditional<IOBF, f32x2, f32x4>::type go_t;      // IOBF: four bf16 = 8 raw bytes per row piece
     go_t q[2], k[2], v[2], g[2], o[2];
     float lse;
-    int lab, src;
+    int lab, src, pad;      // pad (IOBF): bit i = item i is a padded position
 };
 // token-layout mode: the map entries a thread needs for window m + 1 (gout rows of its two items; the LDS copies of both maps) are
 // fetched one window earlier still, so that the dependent gout loads do not wait on them
@@ -792,71 +806,73 @@ struct Idx2 {
 template <int NT>
 __device__ __forceinline__ void lds2_index(Idx2& I, const WsDev& a, const Who& w) {
     const int N = a.N, tid = threadIdx.x;
-    I.d[0] = I.d[1] = I.s[0] = I.s[1] = 0;
-    if (!a.dst_map) return;
-    const int* dm = a.dst_map + (long long)w.wdw * N;
+    // (window-layout mode reads a.ia instead -- any valid int [N] array -- and ignores the values: no branch around the loads)
+    const int* dm = a.dst_map ? a.dst_map + (long long)w.wdw * N : a.ia;
+    const int* sm = a.src_map ? a.src_map + (long long)w.wdw * N : a.ia;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int tok = (tid >> 3) + i * (NT / 8);
         I.d[i] = dm[tok < N ? tok : N - 1];
-        I.s[i] = a.src_map[(long long)w.wdw * N + (tok < N ? tok : N - 1)];
+        I.s[i] = sm[tok < N ? tok : N - 1];
     }
 }
 template <int NT, bool IOBF>
 __device__ __forceinline__ void lds2_load(Stage2<IOBF>& R, const Idx2& I, const WsDev& a, const Who& w, int NR) {
+    // Addresses = a workgroup-uniform base (window / sample, head) + a 32-bit per-thread offset (row * pitch + channel): the loads
+    // take the scalar-base form and the per-thread arithmetic stays in 32 bits (a sample's qkv tensor is < 2^31 elements: checked
+    // by the launcher).  No branch around a load: clamped rows + selects.
     const int N = a.N, d = a.d, tid = threadIdx.x, ch = tid & 7;
-    const long long rs = 3LL * a.heads * d, os = (long long)a.heads * d;
-    const float* qb = a.qkv + (long long)w.b * N * rs + w.head * d;
-    const float* ob = a.o + (long long)w.b * N * os + w.head * d;
+    const int rs = 3 * a.heads * d, os = a.heads * d, hd = a.heads * d;
     const bool tokm = a.dst_map != nullptr, full = a.fill != nullptr;
-    const long long tb0 = (long long)(w.b / a.nW) * a.Ltok;
-    const float* gb = a.gout + (tokm ? tb0 : (long long)w.b * N) * os + w.head * d;
+    const long long tb0 = (long long)(w.b / a.nW) * a.Ltok, wb0 = (long long)w.b * N;
     const int cc = 4 * ch < d ? 4 * ch : 0;              // clamped: unconditional loads
-    if (full) { qb = a.qkv + tb0 * rs + w.head * d; ob = a.o + tb0 * os + w.head * d; }
-    const float* fl = full ? a.fill + w.head * d + cc : nullptr;
+    R.pad = 0;
+    if constexpr (IOBF) {
+        const __bf16* qb = reinterpret_cast<const __bf16*>(a.qkv) + tb0 * rs + w.head * d;
+        const __bf16* gb = reinterpret_cast<const __bf16*>(a.gout) + tb0 * os + w.head * d;
+        const __bf16* ob = reinterpret_cast<const __bf16*>(a.o) + tb0 * os + w.head * d;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int tok = (tid >> 3) + i * (NT / 8);
-        const int tc = tok < N ? tok : N - 1;
-        if constexpr (IOBF) {
-            // bf16 qkv rows (8 raw bytes per piece); a padded position takes the fp32 fill vector, rounded here
-            if (I.s[i] >= 0) {
-                const __bf16* row = reinterpret_cast<const __bf16*>(a.qkv) + (tb0 + I.s[i]) * rs + w.head * d + cc;
-                R.q[i] = *reinterpret_cast<const f32x2*>(row);
-                R.k[i] = *reinterpret_cast<const f32x2*>(row + a.heads * d);
-                R.v[i] = *reinterpret_cast<const f32x2*>(row + 2 * a.heads * d);
-            } else {
-                R.q[i] = __builtin_bit_cast(f32x2, pack_bf(*reinterpret_cast<const f32x4*>(fl)));
-                R.k[i] = __builtin_bit_cast(f32x2, pack_bf(*reinterpret_cast<const f32x4*>(fl + a.heads * d)));
-                R.v[i] = __builtin_bit_cast(f32x2, pack_bf(*reinterpret_cast<const f32x4*>(fl + 2 * a.heads * d)));
-            }
-        } else {
-            const float* row = full ? (I.s[i] >= 0 ? qb + (long long)I.s[i] * rs + cc : fl) : qb + (long long)tc * rs + cc;
-            R.q[i] = *reinterpret_cast<const f32x4*>(row);
-            R.k[i] = *reinterpret_cast<const f32x4*>(row + a.heads * d);
-            R.v[i] = *reinterpret_cast<const f32x4*>(row + 2 * a.heads * d);
-        }
-        const int gt = tokm ? (I.d[i] < 0 ? 0 : I.d[i]) : tc;
-        if constexpr (IOBF) {
-            // 8-byte rows of bf16, kept raw (converted by lds2_store)
-            const __bf16* gh = reinterpret_cast<const __bf16*>(a.gout) + (tb0 + gt) * os + w.head * d + cc;
-            const __bf16* oh = reinterpret_cast<const __bf16*>(a.o) + (tb0 + gt) * os + w.head * d + cc;
-            R.g[i] = *reinterpret_cast<const f32x2*>(gh);
-            R.o[i] = *reinterpret_cast<const f32x2*>(oh);
+        for (int i = 0; i < 2; ++i) {
+            // bf16 rows (8 raw bytes per piece); a padded position is flagged and takes the fill vector from its LDS copy in
+            // lds2_store; a dropped position gets zero gradient
+            const int qo = (I.s[i] < 0 ? 0 : I.s[i]) * rs + cc, go = (I.d[i] < 0 ? 0 : I.d[i]) * os + cc;
+            R.q[i] = *reinterpret_cast<const f32x2*>(qb + qo);
+            R.k[i] = *reinterpret_cast<const f32x2*>(qb + qo + hd);
+            R.v[i] = *reinterpret_cast<const f32x2*>(qb + qo + 2 * hd);
+            R.g[i] = *reinterpret_cast<const f32x2*>(gb + go);
+            R.o[i] = *reinterpret_cast<const f32x2*>(ob + go);
+            R.pad |= (I.s[i] < 0 ? 1 : 0) << i;
             if (I.d[i] < 0) { R.g[i] = f32x2{0.f, 0.f}; R.o[i] = R.g[i]; }
-        } else {
-            R.g[i] = *reinterpret_cast<const f32x4*>(gb + (long long)gt * os + cc);
-            R.o[i] = *reinterpret_cast<const f32x4*>(ob + (long long)(full ? gt : tc) * os + cc);
+        }
+    } else {
+        const float* qb = a.qkv + (full ? tb0 : wb0) * rs + w.head * d;
+        const float* gb = a.gout + (tokm ? tb0 : wb0) * os + w.head * d;
+        const float* ob = a.o + (full ? tb0 : wb0) * os + w.head * d;
+        const float* fl = a.fill ? a.fill + w.head * d : a.qkv;      // (never read through when !full)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int tok = (tid >> 3) + i * (NT / 8);
+            const int tc = tok < N ? tok : N - 1;
+            const bool padq = full && I.s[i] < 0;
+            const float* row = padq ? fl + cc : qb + ((full ? I.s[i] : tc) * rs + cc);
+            R.q[i] = *reinterpret_cast<const f32x4*>(row);
+            R.k[i] = *reinterpret_cast<const f32x4*>(row + hd);
+            R.v[i] = *reinterpret_cast<const f32x4*>(row + 2 * hd);
+            const int gt = tokm ? (I.d[i] < 0 ? 0 : I.d[i]) : tc;
+            R.g[i] = *reinterpret_cast<const f32x4*>(gb + (gt * os + cc));
+            R.o[i] = *reinterpret_cast<const f32x4*>(ob + ((full ? gt : tc) * os + cc));
             if (tokm && I.d[i] < 0) { R.g[i] = f32x4{0.f, 0.f, 0.f, 0.f}; if (full) R.o[i] = R.g[i]; }
         }
     }
     const int tc = tid < N ? tid : N - 1;
-    R.lse = a.lse_in[((long long)w.b * a.heads + w.head) * N + tc];
-    R.lab = a.labels ? a.labels[(long long)w.wdw * N + tc] : 0;
-    R.src = tokm ? a.src_map[(long long)w.wdw * N + tc] : tc;
+    R.lse = (a.lse_in + ((long long)w.b * a.heads + w.head) * N)[tc];
+    const int lab = (a.labels ? a.labels + (long long)w.wdw * N : a.ia)[tc];
+    R.lab = a.labels ? lab : 0;
+    const int srow = (tokm ? a.src_map + (long long)w.wdw * N : a.ia)[tc];
+    R.src = tokm ? srow : tc;
 }
 template <int NT, bool IOBF>
-__device__ __forceinline__ void lds2_store(const Stage2<IOBF>& R, const WsDev& a, const LdsWin& L, int* srcv, int NR) {
+__device__ __forceinline__ void lds2_store(const Stage2<IOBF>& R, const WsDev& a, const LdsWin& L, int* srcv, const float* fillv, int NR) {
     const int N = a.N, d = a.d, tid = threadIdx.x, ch = tid & 7;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -872,6 +888,11 @@ __device__ __forceinline__ void lds2_store(const Stage2<IOBF>& R, const WsDev& a
                     return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
                 };
                 q = widen(R.q[i]); k = widen(R.k[i]); v = widen(R.v[i]); g = widen(R.g[i]); o = widen(R.o[i]);
+                if ((R.pad >> i) & 1) {          // the fill (qkv bias) of this head: [3][32] floats in LDS, rounded to bf16 by pack_bf below
+                    q = *reinterpret_cast<const f32x4*>(fillv + 4 * ch);
+                    k = *reinterpret_cast<const f32x4*>(fillv + 32 + 4 * ch);
+                    v = *reinterpret_cast<const f32x4*>(fillv + 64 + 4 * ch);
+                }
             } else {
                 q = R.q[i]; k = R.k[i]; v = R.v[i]; g = R.g[i]; o = R.o[i];
             }
@@ -922,6 +943,10 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
         L.ia[t] = a.ia[tc];
         L.ib[t] = a.ib[tc];
     }
+    if (threadIdx.x < 96) {
+        const int part = threadIdx.x >> 5, c = threadIdx.x & 31;
+        L2.fillv[threadIdx.x] = (a.fill && c < d) ? a.fill[part * a.heads * d + w.head * d + c] : 0.f;
+    }
     const int lane = lane_id(), r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
     const long long rs = 3LL * a.heads * d;
     const bool masked = a.labels != nullptr;
@@ -942,7 +967,7 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
         who_window(a, w, m);
         __syncthreads();                   // the previous window's fragments have been read (first turn: tb / dense are initialised)
         if (m == grp) DLWP_STAMP(1);
-        lds2_store<NT, IOBF>(R, a, L, L2.src, NR);
+        lds2_store<NT, IOBF>(R, a, L, L2.src, L2.fillv, NR);
         // gqkv rows: window layout [b][n], or token layout [batch][src token] (row index from the staged map)
         const long long gq_off = (tokm ? (long long)(w.b / a.nW) * a.Ltok : (long long)w.b * N) * rs + w.head * d;      // in elements
         float* gq = a.gqkv + gq_off;
@@ -1228,6 +1253,8 @@ static bool one_pass_applies(int N, int d, int TB) {
 }
 static int one_pass_launch(WsDev& a, void* stream) {
     const int nc = (a.N + 15) / 16, nw1 = nc > 4 ? 8 : 4, heads = a.heads, ntypes = a.ntypes, d = a.d;
+    DLWP_REQUIRE((long long)(a.dst_map ? a.Ltok : a.N) * 3 * heads * d < (1LL << 31), DLWP_E_UNSUPPORTED,
+                 "window attention backward: a sample's qkv tensor must stay below 2^31 elements (32-bit row offsets)");
     const size_t lb1 = lds2_bytes(16 * nc, a.TB);
     const int want = dlwp_tune_or("WINATTN_WG_BWD", 0);
     a.dbg = dlwp_tune_or("WINATTN_DBG", 0);
@@ -1337,7 +1364,7 @@ extern "C" int dlwp_window_attn_fwd_tokens(const float* qkv_tokens, const float*
     ws_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, q_lo, q_hi);
     a.qkv = qkv_tokens; a.fill = fill; a.table = bias_table; a.table_t = packed_table; a.ia = ia; a.ib = ib; a.labels = labels;
     a.src_map = src_map; a.dst_map = dst_map; a.out = out_tokens; a.lse = lse; a.Ltok = Ltok; a.io_bf16 = io_bf16 != 0;
-    const size_t lds = sizeof(float) * (size_t)((TB + 3) & ~3) + sizeof(int) * 4 * 256;
+    const size_t lds = sizeof(float) * (size_t)((TB + 3) & ~3) + sizeof(int) * 4 * 256 + sizeof(float) * 96;
     const int nc = (N + 15) / 16;
     const dim3 grid((unsigned)(heads * ntypes * a.groups)), block(256);
     auto go = [&](auto knl) -> int {
