@@ -21,6 +21,14 @@
 // which costs matrix work that this regime has to spare and avoids any transposition through LDS:
 //   dP^T = V dO^T,  dS^T = P^T (dP^T - D),  dQ^T += K^T dS^T ;   dP = dO V^T,  dS = P (dP - D),  dV^T += dO^T P,  dK^T += Q^T dS.
 // dBias partials are summed per workgroup in LDS (64-bit fixed point, see winattn.hip) and flushed with float atomics.
+//
+// Families in this file (dispatch: dlwp_winattn_small_fwd / _bwd and the token-layout entries at the end):
+//   winattn_small_fwd_kernel<NC, NDB, VEC, BF, TOK, IOBF>   forward, one wave per (window, head); TOK: operands in the token layout
+//                                                           through position maps; IOBF: bf16 token tensors
+//   winattn_small_bwd_kernel                                backward, register fragments (fp32 mode, or forced)
+//   winattn_lds_bwd_kernel<NDB>             (round 3)       backward, LDS-staged, two passes: windows of <= 64 tokens (Swin)
+//   winattn_lds_bwd1p_kernel<NDB, NW, IOBF> (round 4)       backward, LDS-staged, every score tile evaluated once: 65 - 128 tokens
+//                                                           (Pangu); window- or token-layout gradients and operands
 #include <type_traits>
 #include "common.cuh"
 #include "dlwpmi_internal.h"
