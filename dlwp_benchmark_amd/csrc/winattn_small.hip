@@ -130,43 +130,68 @@ __device__ __forceinline__ void stage_table(float* tb, const WsDev& a, const Who
 // TOK: operands in the token layout (WsDev::fill): a wave stages its window's two position-map rows in LDS; a fragment row is then
 // the token's row of the unpartitioned qkv tensor or, for a padded position, the fill vector; output rows go to the token the
 // reverse map names (positions it drops are not written).  Needs d % 4 == 0.
-// (no branch around a load: a pointer select feeds ONE unconditional load per fragment -- a branch makes the compiler drain vmcnt at
-// its join, which serialises the fragment loads; padded positions take the fill vector from its LDS copy `fl` [d])
-template <bool TOK, bool IOBF = false>
-__device__ __forceinline__ f32x4 frag_row(const float* __restrict__ base, long long stride, const float* __restrict__ fl,
-                                          const int* __restrict__ srcl, int tok, int N, int dd0, int d) {
-    if (!TOK) return row_frag<true>(base, stride, tok, N, dd0, d);
-    const bool ok = tok < N && dd0 < d;
-    const int s_ = ok ? srcl[tok] : 0, sc = s_ < 0 ? 0 : s_, dc = ok ? dd0 : 0;
-    f32x4 v;
-    if (IOBF) {
-        typedef __bf16 bh4 __attribute__((ext_vector_type(4)));
-        const bh4 h = *reinterpret_cast<const bh4*>(reinterpret_cast<const __bf16*>(base) + (long long)sc * stride + dc);
-        v = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
-    } else {
-        v = *reinterpret_cast<const f32x4*>(base + (long long)sc * stride + dc);
-    }
-    const f32x4 fv = *reinterpret_cast<const f32x4*>(fl + dc);      // (unconditional LDS read + select)
-    v = s_ < 0 ? fv : v;
-    return ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ f32x4 mfma_bf(const s16x4 a, const s16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }
-template <bool TOK, bool IOBF = false>
-__device__ __forceinline__ f32x4 frag_col(const float* __restrict__ base, long long stride, const float* __restrict__ fl,
-                                          const int* __restrict__ srcl, int tok0, int N, int dd, int d) {
-    if (!TOK) return col_frag(base, stride, tok0, N, dd, d);
-    f32x4 v;
-    const int dc = dd < d ? dd : 0;
-    const float fv = fl[dc];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const bool ok = tok0 + s < N && dd < d;
-        const int s_ = ok ? srcl[tok0 + s] : 0, sc = s_ < 0 ? 0 : s_;
-        float x;
-        if (IOBF) x = (float)reinterpret_cast<const __bf16*>(base)[(long long)sc * stride + dc];
-        else x = base[(long long)sc * stride + dc];
-        v[s] = !ok ? 0.f : (s_ < 0 ? fv : x);
+__device__ __forceinline__ s16x4 pack_bf(const f32x4 v) {
+    typedef __bf16 bh4 __attribute__((ext_vector_type(4)));
+    const bh4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    return __builtin_bit_cast(s16x4, h);
+}
+// Token-layout fragments (TOK): a row is the token's row of the unpartitioned qkv tensor or, for a padded position, the fill vector
+// (LDS copy `fl` [d] of this head's slice).  IOBF: the tensor is bf16 and the fragment stays RAW bf16 (s16x4: no widening, the
+// bf16 MFMA takes it as it is; the softmax scale is applied to the scores instead of to q).  (A branch-free form of these loaders
+// -- clamped rows, unconditional fill reads, selects -- was measured: 83 - 87 us against 45 us for the forward at the Pangu C4
+// shapes; the wave-per-window forward has no loads in flight across these branches to protect.)
+template <bool IOBF> struct tokfrag { typedef f32x4 type; };
+template <> struct tokfrag<true> { typedef s16x4 type; };
+template <bool IOBF>
+__device__ __forceinline__ typename tokfrag<IOBF>::type tok_row(const float* __restrict__ base, long long stride, const float* __restrict__ fl,
+                                                                const int* __restrict__ srcl, int tok, int N, int dd0, int d) {
+    if constexpr (IOBF) {
+        s16x4 v = s16x4{0, 0, 0, 0};
+        if (tok < N && dd0 < d) {
+            const int s_ = srcl[tok];
+            if (s_ >= 0) v = *reinterpret_cast<const s16x4*>(reinterpret_cast<const short*>(base) + (long long)s_ * stride + dd0);
+            else v = pack_bf(*reinterpret_cast<const f32x4*>(fl + dd0));
+        }
+        return v;
+    } else {
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tok < N && dd0 < d) {
+            const int s_ = srcl[tok];
+            v = s_ >= 0 ? *reinterpret_cast<const f32x4*>(base + (long long)s_ * stride + dd0) : *reinterpret_cast<const f32x4*>(fl + dd0);
+        }
+        return v;
     }
-    return v;
+}
+template <bool IOBF>
+__device__ __forceinline__ typename tokfrag<IOBF>::type tok_col(const float* __restrict__ base, long long stride, const float* __restrict__ fl,
+                                                                const int* __restrict__ srcl, int tok0, int N, int dd, int d) {
+    if constexpr (IOBF) {
+        s16x4 v = s16x4{0, 0, 0, 0};
+        if (dd < d) {
+            const short fb = __builtin_bit_cast(short, (__bf16)fl[dd]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (tok0 + s < N) {
+                    const int s_ = srcl[tok0 + s];
+                    v[s] = s_ >= 0 ? reinterpret_cast<const short*>(base)[(long long)s_ * stride + dd] : fb;
+                }
+        }
+        return v;
+    } else {
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (dd < d) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (tok0 + s < N) {
+                    const int s_ = srcl[tok0 + s];
+                    v[s] = s_ >= 0 ? base[(long long)s_ * stride + dd] : fl[dd];
+                }
+        }
+        return v;
+    }
 }
 template <int NC, int NDB, bool VEC, bool BF, bool TOK = false, bool IOBF = false>
 __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
@@ -204,15 +229,21 @@ __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
     const float* fv = fills + 64;
     const int* labw = a.labels ? a.labels + (long long)w.wdw * N : nullptr;
 
-    f32x4 kf[NC][NDB], vt[NDB][NC];
+    typedef typename tokfrag<TOK && IOBF>::type frag_t;      // raw bf16 fragments when the token tensors are bf16
+    frag_t kf[NC][NDB], vt[NDB][NC];
     int kbi[NC][4], klb[NC][4];
 #pragma unroll
     for (int kc = 0; kc < NC; ++kc) {
 #pragma unroll
-        for (int cc = 0; cc < NDB; ++cc)
-            kf[kc][cc] = TOK ? frag_row<TOK, IOBF>(kb, rs, fk, srcl, 16 * kc + r, N, 16 * cc + 4 * g, d) : row_frag<VEC>(kb, rs, 16 * kc + r, N, 16 * cc + 4 * g, d);
+        for (int cc = 0; cc < NDB; ++cc) {
+            if constexpr (TOK) kf[kc][cc] = tok_row<IOBF>(kb, rs, fk, srcl, 16 * kc + r, N, 16 * cc + 4 * g, d);
+            else kf[kc][cc] = row_frag<VEC>(kb, rs, 16 * kc + r, N, 16 * cc + 4 * g, d);
+        }
 #pragma unroll
-        for (int db = 0; db < NDB; ++db) vt[db][kc] = frag_col<TOK, IOBF>(vb, rs, fv, srcl, 16 * kc + 4 * g, N, 16 * db + r, d);
+        for (int db = 0; db < NDB; ++db) {
+            if constexpr (TOK) vt[db][kc] = tok_col<IOBF>(vb, rs, fv, srcl, 16 * kc + 4 * g, N, 16 * db + r, d);
+            else vt[db][kc] = col_frag(vb, rs, 16 * kc + 4 * g, N, 16 * db + r, d);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int key = min(16 * kc + 4 * g + j, N - 1);
@@ -225,23 +256,31 @@ __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
         if (16 * qc >= N) break;
         const int q = 16 * qc + r, qcl = min(q, N - 1);
         const int qa = a.ia[qcl], qlab = labw ? labw[qcl] : 0;
-        f32x4 qf[NDB];
+        constexpr bool RAW = TOK && IOBF;
+        frag_t qf[NDB];
 #pragma unroll
         for (int cc = 0; cc < NDB; ++cc) {
-            qf[cc] = TOK ? frag_row<TOK, IOBF>(qb, rs, fq, srcl, q, N, 16 * cc + 4 * g, d) : row_frag<VEC>(qb, rs, q, N, 16 * cc + 4 * g, d);
+            if constexpr (TOK) qf[cc] = tok_row<IOBF>(qb, rs, fq, srcl, q, N, 16 * cc + 4 * g, d);
+            else qf[cc] = row_frag<VEC>(qb, rs, q, N, 16 * cc + 4 * g, d);
+            if constexpr (!RAW) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) qf[cc][s] *= a.scale;
+                for (int s = 0; s < 4; ++s) qf[cc][s] *= a.scale;
+            }
         }
+        const float sscale = RAW ? a.scale : 1.f;          // raw bf16 q: the scale goes on the fp32 scores
         f32x4 s[NC];
         float mx = -1e30f;
 #pragma unroll
         for (int kc = 0; kc < NC; ++kc) {
             s[kc] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int cc = 0; cc < NDB; ++cc) s[kc] = mfma16_chunk_p<BF>(kf[kc][cc], qf[cc], s[kc]);
+            for (int cc = 0; cc < NDB; ++cc) {
+                if constexpr (RAW) s[kc] = mfma_bf(kf[kc][cc], qf[cc], s[kc]);
+                else s[kc] = mfma16_chunk_p<BF>(kf[kc][cc], qf[cc], s[kc]);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float v = s[kc][j] + tb[qa + kbi[kc][j]];
+                float v = s[kc][j] * sscale + tb[qa + kbi[kc][j]];
                 if (labw && klb[kc][j] != qlab) v -= 100.f;
                 v = 16 * kc + 4 * g + j < N ? v : -1e30f;
                 s[kc][j] = v;
@@ -264,7 +303,10 @@ __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
         for (int db = 0; db < NDB; ++db) {
             f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kc = 0; kc < NC; ++kc) o = mfma16_chunk_p<BF>(vt[db][kc], s[kc], o);
+            for (int kc = 0; kc < NC; ++kc) {
+                if constexpr (RAW) o = mfma_bf(vt[db][kc], pack_bf(s[kc]), o);
+                else o = mfma16_chunk_p<BF>(vt[db][kc], s[kc], o);
+            }
             const int dd = 16 * db + 4 * g;
             const int orow = TOK ? (q < N ? dstl[q] : -1) : q;
             if (TOK && IOBF) {
@@ -521,14 +563,6 @@ __global__ __launch_bounds__(256) void winattn_small_bwd_kernel(WsDev a) {
 typedef unsigned short bf16_t;
 constexpr int LDB = 36;        // bf16 elements per staged row (32 + 4: 72 B, 8-byte aligned, rows 18 banks apart)
 
-__device__ __forceinline__ f32x4 mfma_bf(const s16x4 a, const s16x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ s16x4 pack_bf(const f32x4 v) {
-    typedef __bf16 bh4 __attribute__((ext_vector_type(4)));
-    const bh4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-    return __builtin_bit_cast(s16x4, h);
-}
 // row fragment: four consecutive channels of one staged row; column fragment: one channel of four consecutive rows
 __device__ __forceinline__ s16x4 lds_row(const bf16_t* m, int row, int c0) { return *reinterpret_cast<const s16x4*>(m + row * LDB + c0); }
 __device__ __forceinline__ s16x4 lds_col(const bf16_t* m, int row0, int c) {
@@ -888,29 +922,39 @@ __device__ __forceinline__ void lds2_store(const Stage2<IOBF>& R, const WsDev& a
         if (tok < NR) {
             const bool ok = tok < N && 4 * ch < d;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            f32x4 q, k, v, g, o;
+            f32x4 g, o;
             if constexpr (IOBF) {
+                // raw bf16 rows go to the LDS image as they are (q UNSCALED: the passes scale the scores and dK instead -- the same
+                // operands as the raw-fragment forward); only D = rowsum(dO o) needs floats
                 typedef __bf16 bh4 __attribute__((ext_vector_type(4)));
                 auto widen = [](const f32x2 raw) {
                     const bh4 h = __builtin_bit_cast(bh4, raw);
                     return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
                 };
-                q = widen(R.q[i]); k = widen(R.k[i]); v = widen(R.v[i]); g = widen(R.g[i]); o = widen(R.o[i]);
-                if ((R.pad >> i) & 1) {          // the fill (qkv bias) of this head: [3][32] floats in LDS, rounded to bf16 by pack_bf below
-                    q = *reinterpret_cast<const f32x4*>(fillv + 4 * ch);
-                    k = *reinterpret_cast<const f32x4*>(fillv + 32 + 4 * ch);
-                    v = *reinterpret_cast<const f32x4*>(fillv + 64 + 4 * ch);
+                s16x4 qh = __builtin_bit_cast(s16x4, R.q[i]), kh = __builtin_bit_cast(s16x4, R.k[i]), vh = __builtin_bit_cast(s16x4, R.v[i]);
+                s16x4 gh = __builtin_bit_cast(s16x4, R.g[i]);
+                if ((R.pad >> i) & 1) {          // the fill (qkv bias) of this head: [3][32] floats in LDS
+                    qh = pack_bf(*reinterpret_cast<const f32x4*>(fillv + 4 * ch));
+                    kh = pack_bf(*reinterpret_cast<const f32x4*>(fillv + 32 + 4 * ch));
+                    vh = pack_bf(*reinterpret_cast<const f32x4*>(fillv + 64 + 4 * ch));
                 }
+                g = widen(R.g[i]); o = widen(R.o[i]);
+                if (!ok) { qh = kh = vh = gh = s16x4{0, 0, 0, 0}; g = z; o = z; }
+                *reinterpret_cast<s16x4*>(L.Q + tok * LDB + 4 * ch) = qh;
+                *reinterpret_cast<s16x4*>(L.K + tok * LDB + 4 * ch) = kh;
+                *reinterpret_cast<s16x4*>(L.V + tok * LDB + 4 * ch) = vh;
+                *reinterpret_cast<s16x4*>(L.G + tok * LDB + 4 * ch) = gh;
             } else {
-                q = R.q[i]; k = R.k[i]; v = R.v[i]; g = R.g[i]; o = R.o[i];
-            }
-            if (!ok) { q = z; k = z; v = z; g = z; o = z; }
+                f32x4 q = R.q[i], k = R.k[i], v = R.v[i];
+                g = R.g[i]; o = R.o[i];
+                if (!ok) { q = z; k = z; v = z; g = z; o = z; }
 #pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) q[s2] *= a.scale;
-            *reinterpret_cast<s16x4*>(L.Q + tok * LDB + 4 * ch) = pack_bf(q);
-            *reinterpret_cast<s16x4*>(L.K + tok * LDB + 4 * ch) = pack_bf(k);
-            *reinterpret_cast<s16x4*>(L.V + tok * LDB + 4 * ch) = pack_bf(v);
-            *reinterpret_cast<s16x4*>(L.G + tok * LDB + 4 * ch) = pack_bf(g);
+                for (int s2 = 0; s2 < 4; ++s2) q[s2] *= a.scale;
+                *reinterpret_cast<s16x4*>(L.Q + tok * LDB + 4 * ch) = pack_bf(q);
+                *reinterpret_cast<s16x4*>(L.K + tok * LDB + 4 * ch) = pack_bf(k);
+                *reinterpret_cast<s16x4*>(L.V + tok * LDB + 4 * ch) = pack_bf(v);
+                *reinterpret_cast<s16x4*>(L.G + tok * LDB + 4 * ch) = pack_bf(g);
+            }
             float dp = g[0] * o[0] + g[1] * o[1] + g[2] * o[2] + g[3] * o[3];
             dp += __shfl_xor(dp, 1); dp += __shfl_xor(dp, 2); dp += __shfl_xor(dp, 4);
             if (ch == 0) L.D[tok] = dp;
@@ -942,6 +986,7 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
         lds2_index<NT>(I, a, wn);
     }
     const bool tokm = a.dst_map != nullptr;
+    const float sscale = IOBF ? a.scale : 1.f;      // IOBF: q is staged unscaled (raw bf16 rows), the scores take the scale
     f32x4 padk[NDB], padv[NDB], padq[NDB];   // token-layout mode: this lane's share of the padded positions' gradient (all windows)
 #pragma unroll
     for (int db = 0; db < NDB; ++db) padk[db] = padv[db] = padq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1049,7 +1094,7 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
                 f32x4 p, ds;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float sc = sc4[j] + cur.tbv[j];
+                    float sc = sc4[j] * sscale + cur.tbv[j];
                     if (masked && qlab[j] != kl) sc -= 100.f;
                     const float pv = (q0 + j < N && key < N) ? __expf(sc - qlse[j]) : 0.f;
                     p[j] = pv;
@@ -1073,6 +1118,7 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
 #pragma unroll
                 for (int db = 0; db < NDB; ++db) {
                     const int dd = 16 * db + 4 * g;
+                    if constexpr (IOBF) dk[db] *= a.scale;          // (the LDS image holds q unscaled)
                     if (krow < 0) {
                         padk[db] += dk[db];
                         padv[db] += dv[db];
