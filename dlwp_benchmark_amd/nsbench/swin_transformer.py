@@ -107,6 +107,9 @@ class _WindowAttnFn(torch.autograd.Function):
         return gqkv, (None if ctx.tslot is not None else gtable), None, None, None, None, None, None, None
 
 
+# opt-in (DLWP_SWIN_REAL_TOKENS=1): measured SLOWER on the Swin C4 step (6.92 vs 6.61 ms) -- with 5 % padding there are hardly any rows
+# to save, and the gather then moves the 3C-wide projected tensor instead of the C-wide normalised one
+REAL_TOKEN_FLOW = __import__("os").environ.get("DLWP_SWIN_REAL_TOKENS", "0") == "1"
 FUSED_BWD = __import__("os").environ.get("DLWP_WINATTN_TOKENS", "1") != "0"      # env: A/B runs against the four-launch backward
 FUSED_FWD = __import__("os").environ.get("DLWP_WINATTN_TOKENS_FWD", "1") != "0"  # env: ... and against gather + attention + scatter
 IO_BF16 = __import__("os").environ.get("DLWP_WINATTN_IO_BF16", "1") != "0"       # env: ... and against fp32 qkv / output / gradient tensors
@@ -267,6 +270,11 @@ class WindowAttention(nn.Module):
                                 self.num_heads, float(self.scale))
         return self.proj(y)
 
+    def core(self, qkv_windows, labels=None, nW=1):
+        """attention on windows of an already projected qkv tensor [nW*B, N, 3C] (SwinTransformerBlock's real-token flow)"""
+        return _WindowAttnFn.apply(qkv_windows, self.relative_position_bias_table, self._ia, self._ib, labels, nW, self.num_heads,
+                                   float(self.scale))
+
 
 class SwinTransformerBlock(nn.Module):
     def __init__(self, dim, num_heads, window_size=7, shift_size=0, mlp_ratio=4., qkv_bias=True, qk_scale=None,
@@ -285,6 +293,13 @@ class SwinTransformerBlock(nn.Module):
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
         self.H = self.W = None
+        # The reference pads / rolls / partitions norm1(x) and runs qkv and proj on every WINDOW token (:229-250).  Both are token-wise
+        # Linear layers and partition is a gather, so they commute with it exactly: qkv on the real tokens (a GEMM input straight from
+        # the LayerNorm: bf16 under bf16 storage), the projected tensor partitioned -- circular copies are copies of the projected rows,
+        # constant pads hold Linear(0) = the qkv bias (dlwp_window_gather_fill) -- attention, reverse, proj on the real tokens with the
+        # residual in its epilogue.  Same result (tests/test_gpu_swin.py); it pays where much of a window is padding (Pangu: half), not
+        # here -- see REAL_TOKEN_FLOW.
+        self.real_token_flow = REAL_TOKEN_FLOW
 
     def forward(self, x, labels):
         B, L_, C = x.shape
@@ -296,6 +311,17 @@ class SwinTransformerBlock(nn.Module):
             # the skip connections leave the LayerNorm nodes (norm_fork) so that their gradients join the LayerNorm backward
             # kernels; the first residual add rides the reverse kernel, the second fc2's epilogue
             spec = self._spec(H, W)
+            if self.real_token_flow:
+                skip, t = norm_fork(self.norm1, x, gemm_input=True)
+                const_pad = any((f or b) and not c for f, b, c in zip(spec.front, [p - f - d for p, f, d in zip(spec.padded, spec.front, spec.dims)], spec.circ))
+                qkv = partition(self.attn.qkv(t), spec, fill=self.attn.qkv.bias if const_pad else None)
+                t = self.attn.core(qkv, labels if shifted else None, spec.nW)
+                if self.drop_path.active:
+                    t = self.attn.proj(reverse(t, spec, B))
+                    skip, t = norm_fork(self.norm2, self.drop_path(t, residual=skip), gemm_input=True)
+                    return self.drop_path(self.mlp(t), residual=skip)
+                skip, t = norm_fork(self.norm2, self.attn.proj(reverse(t, spec, B), residual=skip), gemm_input=True)
+                return self.mlp(t, residual=skip)
             skip, t = norm_fork(self.norm1, x)
             t = self.attn(partition(t, spec), labels if shifted else None, spec.nW)
             if self.drop_path.active:        # training with stochastic depth (:255-256): per-sample scale + residual add

@@ -74,7 +74,8 @@ class _PartitionFillFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, fill, spec, shift, c_lo=0):
         ctx.spec, ctx.shift, ctx.B, ctx.c_lo = spec, shift, x.shape[0], int(c_lo)
-        assert not any(spec.circ), "fill applies to constant padding"
+        # (axes with circular padding wrap -- their copies are copies of x rows and their gradients are summed back by the scatter;
+        # the fill stands at the positions the CONSTANT axes pad)
         x = x.contiguous().float()
         B, Cc = x.shape[0], x.shape[-1]
         out = torch.empty(B * spec.nW, spec.N, Cc, device=x.device)
@@ -88,7 +89,7 @@ class _PartitionFillFn(torch.autograd.Function):
     def backward(ctx, g):
         g = g.contiguous()
         spec = ctx.spec
-        gx = _scatter(g, spec, ctx.shift, ctx.B, sum_copies=False)
+        gx = _scatter(g, spec, ctx.shift, ctx.B, sum_copies=any(spec.circ))
         gfill = ctx.fill_slot if ctx.fill_slot is not None else torch.zeros(g.shape[-1], device=g.device)
         d, p, f, s, w, sw, circ = spec.c_args(ctx.shift)
         L.check(L.load().dlwp_window_pad_colsum(L.ptr(g), L.ptr(gfill), ctx.B, g.shape[-1], d, p, f, s, w, sw, circ, ctx.c_lo,

@@ -266,3 +266,38 @@ def test_lds_staged_bf16_window_kernels_match_the_register_fragment_kernels(cuda
     if qrange is not None:
         q_part = res[1][1].reshape(B_, N, 3, heads * d)[:, :, 0]
         assert float(q_part[:, :clo].abs().max() if clo else 0.0) == 0.0 and float(q_part[:, chi:].abs().max() if chi < N else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("H,W,pm,shift", [(20, 30, ("constant", "circular"), 3), (20, 30, ("constant", "circular"), 0),
+                                          (28, 28, "constant", 3), (21, 35, ("constant", "circular"), 3)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_real_token_flow_equals_window_token_flow(cuda, H, W, pm, shift, bias):
+    """SwinTransformerBlock: qkv on the real tokens + partition of the projected tensor (circular copies; constant pads filled with
+    the qkv bias) + proj after reverse must equal the reference order (pad / roll / partition, then qkv and proj on every window
+    token: src/nsbench/models/swintransformer/swin_transformer.py:229-250) -- output and every gradient, fp32.  The reference-order
+    flow itself is pinned by the goldens above."""
+    from dlwp_benchmark_amd.nsbench.swin_transformer import SwinTransformerBlock
+    torch.manual_seed(9)
+    dim, heads, B = 32, 2, 2
+    blk = SwinTransformerBlock(dim, heads, window_size=7, shift_size=shift, qkv_bias=bias, padding_mode=pm).to(cuda)
+    blk.H, blk.W = H, W
+    with torch.no_grad():
+        blk.attn.relative_position_bias_table.normal_(0, 0.5)
+        if bias:
+            blk.attn.qkv.bias.normal_(0, 0.5)
+    labels = None
+    if shift:
+        import math
+        from dlwp_benchmark_amd.nsbench.swin_transformer import BasicLayer
+        layer = BasicLayer(dim, depth=2, num_heads=heads, window_size=7, padding_mode=pm)
+        labels = layer.shift_labels(math.ceil(H / 7) * 7, math.ceil(W / 7) * 7, cuda)
+    x = torch.randn(B, H * W, dim, device=cuda, requires_grad=True)
+    g = torch.randn(B, H * W, dim, device=cuda)
+    outs = {}
+    for flow in (True, False):
+        blk.real_token_flow = flow
+        y = blk(x, labels)
+        outs[flow] = (y.detach().clone(), torch.autograd.grad(y, [x] + list(blk.parameters()), g))
+    assert rel(outs[True][0], outs[False][0]) <= 2e-5
+    for n, a, b in zip(["x"] + [n for n, _ in blk.named_parameters()], outs[True][1], outs[False][1]):
+        assert rel(a, b) <= 2e-4, n
