@@ -45,6 +45,8 @@ Knob g_knobs[] = {
     {"WINATTN_WG_BWD", "workgroup width selector of the wave-per-window attention backward", 0, false},
     {"WINATTN_NOLDS", "1: the register-fragment attention backward instead of the LDS-staged one", 0, false},
     {"WINATTN_DBG", "measurement only (wrong results): bit switches that drop phases of the one-pass attention backward", 0, false},
+    {"WINATTN_FWD_LDS", "0: the wave-per-window token-layout attention forward instead of the LDS-staged one", 0, false},
+    {"WINATTN_WG_FWD", "workgroup count of the LDS-staged attention forward", 0, false},
     {"WINATTN_BWD1P_SMALL", "1: the one-pass attention backward also for windows of at most 64 tokens", 0, false},
     {"WINATTN_BWD2PASS", "1: the two-pass LDS-staged attention backward instead of the one-pass kernel", 0, false},
     {"FFT_IBW", "inner lanes of the W-axis FFT pass", 0, false},

@@ -27,8 +27,10 @@
 //                                                           through position maps; IOBF: bf16 token tensors
 //   winattn_small_bwd_kernel                                backward, register fragments (fp32 mode, or forced)
 //   winattn_lds_bwd_kernel<NDB>             (round 3)       backward, LDS-staged, two passes: windows of <= 64 tokens (Swin)
+//   winattn_lds_fwd_tok_kernel<NC, NDB, IOBF> (round 4)     forward, LDS-staged, next window's rows prefetched: token-layout operands
 //   winattn_lds_bwd1p_kernel<NDB, NW, IOBF> (round 4)       backward, LDS-staged, every score tile evaluated once: 65 - 128 tokens
 //                                                           (Pangu); window- or token-layout gradients and operands
+#include <algorithm>
 #include <type_traits>
 #include "common.cuh"
 #include "dlwpmi_internal.h"
@@ -1244,6 +1246,186 @@ int ws_setup(WsDev& a, int B_, int nW, int N, int TB, int ntypes, int heads, int
     return DLWP_OK;
 }
 
+// ---- (round 4) the forward pass on the same construction: a workgroup (four waves) walks the windows of ONE (window type, head);
+// the NEXT window's token rows (q, k, v through the source map) are loaded into registers while the current window is computed from
+// its bf16 LDS image; a wave owns the query chunks qc = wave, wave + 4 ... of the caller's range and keeps S^T = K Q^T of all key
+// chunks in registers (rows = keys 4g + j, column = query r: the softmax statistics of a query live in the four lanes sharing r),
+// O^T = V^T P^T comes out as four consecutive channels of one query per lane -> one vector store to the token the reverse map names.
+// Token-layout operands only (dlwp_window_attn_fwd_tokens); NC = key chunks (4 or 8).
+template <bool IOBF>
+struct FwdStage {
+    typedef typename std::conditional<IOBF, f32x2, f32x4>::type row_t;
+    row_t q[4], k[4], v[4];
+    int lab, dst, pad;
+};
+template <int NC, int NDB, bool IOBF>
+__global__ __launch_bounds__(256) void winattn_lds_fwd_tok_kernel(WsDev a) {
+    constexpr int NT = 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int N = a.N, d = a.d, NCr = (N + 15) / 16, NR = 16 * NCr;
+    bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* Ks = Qs + NR * LDB;
+    bf16_t* Vs = Ks + NR * LDB;
+    int* ias = reinterpret_cast<int*>(Vs + NR * LDB);
+    int* ibs = ias + NR;
+    int* labs = ibs + NR;
+    int* dsts = labs + NR;
+    float* tb = reinterpret_cast<float*>(dsts + NR);
+    float* fillv = tb + ((a.TB + 3) & ~3);
+    int grp;
+    Who w = who_lds(a, grp);
+    if (a.table_t) { for (int i = threadIdx.x; i < a.TB; i += NT) tb[i] = a.table_t[w.tofs * a.TB + i]; }
+    else { for (int i = threadIdx.x; i < a.TB; i += NT) tb[i] = a.table[(long long)i * w.tstr + w.tofs]; }
+    for (int t = threadIdx.x; t < NR; t += NT) {
+        const int tc = t < N ? t : N - 1;
+        ias[t] = a.ia[tc];
+        ibs[t] = a.ib[tc];
+    }
+    if (threadIdx.x < 96) {
+        const int part = threadIdx.x >> 5, c = threadIdx.x & 31;
+        fillv[threadIdx.x] = c < d ? a.fill[part * a.heads * d + w.head * d + c] : 0.f;
+    }
+    const int tid = threadIdx.x, lane = lane_id(), r = lane & 15, g = lane >> 4, wv = tid >> 6, ch = tid & 7;
+    const int rs = 3 * a.heads * d, os = a.heads * d, hd = a.heads * d;
+    const int cc = 4 * ch < d ? 4 * ch : 0;
+    const int qlo = a.qc_lo, qhi = min(a.qc_hi, NCr);
+    const float sscale = IOBF ? a.scale : 1.f;
+    const bool masked = a.labels != nullptr;
+    int sidx[4];
+    auto load_index = [&](int wdw) {
+        const int* sm = a.src_map + (long long)wdw * N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tok = (tid >> 3) + 32 * i;
+            sidx[i] = sm[tok < N ? tok : N - 1];
+        }
+    };
+    FwdStage<IOBF> R;
+    auto load_rows = [&](const Who& ww) {
+        const long long tb0 = (long long)(ww.b / a.nW) * a.Ltok;
+        R.pad = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int so = (sidx[i] < 0 ? 0 : sidx[i]) * rs + cc;
+            R.pad |= (sidx[i] < 0 ? 1 : 0) << i;
+            if constexpr (IOBF) {
+                const __bf16* qb = reinterpret_cast<const __bf16*>(a.qkv) + tb0 * rs + ww.head * d;
+                R.q[i] = *reinterpret_cast<const f32x2*>(qb + so);
+                R.k[i] = *reinterpret_cast<const f32x2*>(qb + so + hd);
+                R.v[i] = *reinterpret_cast<const f32x2*>(qb + so + 2 * hd);
+            } else {
+                const float* qb = a.qkv + tb0 * rs + ww.head * d;
+                R.q[i] = *reinterpret_cast<const f32x4*>(qb + so);
+                R.k[i] = *reinterpret_cast<const f32x4*>(qb + so + hd);
+                R.v[i] = *reinterpret_cast<const f32x4*>(qb + so + 2 * hd);
+            }
+        }
+        const int tc = tid < N ? tid : N - 1;
+        const int lab = (a.labels ? a.labels + (long long)ww.wdw * N : a.ia)[tc];
+        R.lab = a.labels ? lab : 0;
+        R.dst = a.dst_map[(long long)ww.wdw * N + tc];
+    };
+    auto store_rows = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tok = (tid >> 3) + 32 * i;
+            if (tok < NR) {
+                const bool ok = tok < N && 4 * ch < d;
+                s16x4 qh, kh, vh;
+                if constexpr (IOBF) {
+                    qh = __builtin_bit_cast(s16x4, R.q[i]); kh = __builtin_bit_cast(s16x4, R.k[i]); vh = __builtin_bit_cast(s16x4, R.v[i]);
+                    if ((R.pad >> i) & 1) qh = pack_bf(*reinterpret_cast<const f32x4*>(fillv + 4 * ch));
+                } else {
+                    f32x4 q = ((R.pad >> i) & 1) ? *reinterpret_cast<const f32x4*>(fillv + 4 * ch) : R.q[i];
+                    qh = pack_bf(q * a.scale); kh = pack_bf(R.k[i]); vh = pack_bf(R.v[i]);
+                }
+                if ((R.pad >> i) & 1) {
+                    kh = pack_bf(*reinterpret_cast<const f32x4*>(fillv + 32 + 4 * ch));
+                    vh = pack_bf(*reinterpret_cast<const f32x4*>(fillv + 64 + 4 * ch));
+                }
+                if (!ok) qh = kh = vh = s16x4{0, 0, 0, 0};
+                *reinterpret_cast<s16x4*>(Qs + tok * LDB + 4 * ch) = qh;
+                *reinterpret_cast<s16x4*>(Ks + tok * LDB + 4 * ch) = kh;
+                *reinterpret_cast<s16x4*>(Vs + tok * LDB + 4 * ch) = vh;
+            }
+        }
+        if (tid < NR) { labs[tid] = R.lab; dsts[tid] = R.dst; }
+    };
+    who_window(a, w, grp);
+    load_index(w.wdw);
+    load_rows(w);
+    if (grp + a.groups < a.M) { Who wn = w; who_window(a, wn, grp + a.groups); load_index(wn.wdw); }
+    for (int m = grp; m < a.M; m += a.groups) {
+        who_window(a, w, m);
+        __syncthreads();                   // the previous window's image has been read (first turn: tb / index vectors are staged)
+        store_rows();
+        __syncthreads();
+        if (m + a.groups < a.M) {
+            Who wn = w;
+            who_window(a, wn, m + a.groups);
+            load_rows(wn);
+            if (m + 2 * a.groups < a.M) { who_window(a, wn, m + 2 * a.groups); load_index(wn.wdw); }
+        }
+        const long long tb0 = (long long)(w.b / a.nW) * a.Ltok;
+        for (int qc = qlo + wv; qc < qhi; qc += 4) {
+            const int q = 16 * qc + r;
+            const int qa = ias[q], qlab = labs[q];
+            s16x4 qf[NDB];
+#pragma unroll
+            for (int c2 = 0; c2 < NDB; ++c2) qf[c2] = lds_row(Qs, q, 16 * c2 + 4 * g);
+            f32x4 s[NC];
+            float mx = -1e30f;
+#pragma unroll
+            for (int kc = 0; kc < NC; ++kc) {
+                s[kc] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (kc < NCr) {
+#pragma unroll
+                    for (int c2 = 0; c2 < NDB; ++c2) s[kc] = mfma_bf(lds_row(Ks, 16 * kc + r, 16 * c2 + 4 * g), qf[c2], s[kc]);
+                    const i32x4 kb4 = *reinterpret_cast<const i32x4*>(ibs + 16 * kc + 4 * g), kl4 = *reinterpret_cast<const i32x4*>(labs + 16 * kc + 4 * g);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = s[kc][j] * sscale + tb[qa + kb4[j]];
+                        if (masked && kl4[j] != qlab) v -= 100.f;
+                        v = 16 * kc + 4 * g + j < N ? v : -1e30f;
+                        s[kc][j] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s[kc][j] = -1e30f;
+                }
+            }
+            mx = col_max4(mx);
+            float l = 0.f;
+#pragma unroll
+            for (int kc = 0; kc < NC; ++kc)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float p = __expf(s[kc][j] - mx);
+                    s[kc][j] = p;
+                    l += p;
+                }
+            l = col_sum4(l);
+            const float inv = 1.f / l;
+            const int orow = q < N ? dsts[q] : -1;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kc = 0; kc < NC; ++kc)
+                    if (kc < NCr) o = mfma_bf(lds_col(Vs, 16 * kc + 4 * g, 16 * db + r), pack_bf(s[kc]), o);
+                const int dd = 16 * db + 4 * g;
+                if (orow >= 0 && dd < d) {
+                    const long long off = (tb0 + orow) * os + w.head * d + dd;
+                    if constexpr (IOBF) *reinterpret_cast<s16x4*>(reinterpret_cast<bf16_t*>(a.out) + off) = pack_bf(o * inv);
+                    else *reinterpret_cast<f32x4*>(a.out + off) = o * inv;
+                }
+            }
+            if (g == 0 && q < N) a.lse[((long long)w.b * a.heads + w.head) * N + q] = mx + __logf(l);
+        }
+    }
+}
+
 }  // namespace
 
 // Shapes this family takes: at most 128 tokens per window, head_dim <= 32, and enough (window, head) pairs that one wave per
@@ -1418,8 +1600,40 @@ extern "C" int dlwp_window_attn_fwd_tokens(const float* qkv_tokens, const float*
     ws_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, q_lo, q_hi);
     a.qkv = qkv_tokens; a.fill = fill; a.table = bias_table; a.table_t = packed_table; a.ia = ia; a.ib = ib; a.labels = labels;
     a.src_map = src_map; a.dst_map = dst_map; a.out = out_tokens; a.lse = lse; a.Ltok = Ltok; a.io_bf16 = io_bf16 != 0;
-    const size_t lds = sizeof(float) * (size_t)((TB + 3) & ~3) + sizeof(int) * 4 * 256 + sizeof(float) * 96;
     const int nc = (N + 15) / 16;
+    if (dlwp_tune_or("WINATTN_FWD_LDS", 1)) {
+        // the LDS-staged forward (winattn_lds_fwd_tok_kernel; default: 43 vs 56 us per launch in the Pangu C4 step): one round of
+        // four-wave workgroups, two per CU (Pangu C4 step: 228 workgroups 10.97 ms, 456: 10.58, 912: 10.64, 1824: 10.72)
+        const int NR = 16 * nc;
+        const size_t lb = (size_t)3 * NR * LDB * 2 + (size_t)4 * NR * 4 + (size_t)((TB + 3) & ~3) * 4 + 96 * 4;
+        static const int ncu = [] {
+            int dev = 0, n = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            return n > 0 ? n : 256;
+        }();
+        const int per_cu = std::max(1, std::min(2, (int)((size_t)150 * 1024 / lb)));
+        const int want = dlwp_tune_or("WINATTN_WG_FWD", 0);
+        const long long per = want ? ((long long)want + heads * ntypes - 1) / (heads * ntypes) : (long long)ncu * per_cu / (heads * ntypes);
+        a.groups = per < 1 ? 1 : (per > a.M ? a.M : (int)per);
+        const dim3 grid1((unsigned)(heads * ntypes * a.groups));
+        auto go1 = [&](auto knl) -> int {
+            int rc2 = dlwp_ensure_lds(reinterpret_cast<const void*>(knl), lb, "winattn_lds_fwd_tok");
+            if (rc2) return rc2;
+            hipLaunchKernelGGL(knl, grid1, dim3(256), lb, (hipStream_t)stream, a);
+            return DLWP_OK;
+        };
+        if (io_bf16) {
+            if (d <= 16) rc = nc <= 4 ? go1(winattn_lds_fwd_tok_kernel<4, 1, true>) : go1(winattn_lds_fwd_tok_kernel<8, 1, true>);
+            else rc = nc <= 4 ? go1(winattn_lds_fwd_tok_kernel<4, 2, true>) : go1(winattn_lds_fwd_tok_kernel<8, 2, true>);
+        } else {
+            if (d <= 16) rc = nc <= 4 ? go1(winattn_lds_fwd_tok_kernel<4, 1, false>) : go1(winattn_lds_fwd_tok_kernel<8, 1, false>);
+            else rc = nc <= 4 ? go1(winattn_lds_fwd_tok_kernel<4, 2, false>) : go1(winattn_lds_fwd_tok_kernel<8, 2, false>);
+        }
+        if (rc) return rc;
+        DLWP_LAUNCH_CHECK();
+        return DLWP_OK;
+    }
+    const size_t lds = sizeof(float) * (size_t)((TB + 3) & ~3) + sizeof(int) * 4 * 256 + sizeof(float) * 96;
     const dim3 grid((unsigned)(heads * ntypes * a.groups)), block(256);
     auto go = [&](auto knl) -> int {
         int rc2 = dlwp_ensure_lds(reinterpret_cast<const void*>(knl), lds, "winattn_small_fwd_tokens");

@@ -197,3 +197,41 @@ def test_one_pass_backward_for_short_windows_equals_the_two_pass_kernel(cuda, N,
                 L.set_tuning("WINATTN_BWD1P_SMALL", None)
     for a, b in zip(res[1], res[0]):
         assert rel(a, b) <= 2e-3
+
+
+@pytest.mark.parametrize("shifted", [False, True])
+@pytest.mark.parametrize("io", ["fp32", "bf16"])
+def test_lds_staged_token_forward_equals_the_wave_per_window_forward(cuda, shifted, io):
+    """dlwp_window_attn_fwd_tokens has two kernels (tuning knob WINATTN_FWD_LDS): same operands, same rounding points -> outputs,
+    row statistics (through the backward) and gradients agree to 2e-3 of the max-norm (bf16 products, different summation order)."""
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.dlwpbench.panguweather import EarthSpecificBlock
+    from dlwp_benchmark_amd.nsbench.swin_transformer import window_attention_tokens
+    torch.manual_seed(13)
+    B, res, heads, dim = 8, (1, 30, 60), 6, 192
+    blk = EarthSpecificBlock(dim, res, heads, (2, 7, 7), None if shifted else (0, 0, 0)).to(cuda)
+    spec = blk._wspec
+    sh = blk.shift_size
+    fwd_shift = (sh[0], sh[1], sh[1]) if blk.roll else (0, 0, 0)
+    rev_shift = sh if blk.roll else (0, 0, 0)
+    Ltok = res[0] * res[1] * res[2]
+    qkv = torch.randn(B, Ltok, 3 * dim, device=cuda)
+    fill = torch.randn(3 * dim, device=cuda) * 0.5
+    table = torch.randn_like(blk.attn.earth_position_bias_table) * 0.5
+    g = torch.randn(B, Ltok, dim, device=cuda)
+    if io == "bf16":
+        qkv, g = qkv.to(torch.bfloat16), g.to(torch.bfloat16)
+    res_ = {}
+    with L.gemm_precision("bf16"):
+        for knob in (0, 1):
+            L.set_tuning("WINATTN_FWD_LDS", knob)
+            try:
+                q_, f_, t_ = qkv.clone().requires_grad_(True), fill.clone().requires_grad_(True), table.clone().requires_grad_(True)
+                y = window_attention_tokens(q_, f_, t_, blk.attn._ia, blk.attn._ib, blk._labels if blk.roll else None, spec, fwd_shift,
+                                            rev_shift, heads, float(blk.attn.scale), blk._qrange)
+                res_[knob] = (y.detach().float(),) + tuple(t.float() for t in torch.autograd.grad(y, (q_, f_, t_), g))
+            finally:
+                L.set_tuning("WINATTN_FWD_LDS", None)
+    for a, b in zip(res_[1], res_[0]):
+        assert torch.isfinite(a).all()
+        assert rel(a, b) <= (1e-2 if io == "bf16" else 2e-3)
