@@ -40,11 +40,11 @@ def main():
                      "published": PUBLISHED[h], "ratio": round(v / PUBLISHED[h], 3)})
     groups = {}
     for r in runs:
-        groups.setdefault((r["hidden"], r["init"]), []).append(r["rmse_closed_loop"])
+        groups.setdefault((r["hidden"], r["alpha"], r["init"]), []).append(r["rmse_closed_loop"])
     summary = []
-    for (h, init), vals in sorted(groups.items()):
+    for (h, alpha, init), vals in sorted(groups.items()):
         mean = sum(vals) / len(vals)
-        summary.append({"hidden": h, "init": init, "n_runs": len(vals), "mean_rmse_closed_loop": round(mean, 5),
+        summary.append({"hidden": h, "grf_alpha": alpha, "init": init, "n_runs": len(vals), "mean_rmse_closed_loop": round(mean, 5),
                         "min": min(vals), "max": max(vals), "spread_rel": round((max(vals) - min(vals)) / mean, 3),
                         "published": PUBLISHED[h], "ratio_of_mean": round(mean / PUBLISHED[h], 3)})
     note = ("tools/published_rmse.py on one MI355X (round 4, tools/r04_anchor.sh): nsbench TFNO2D trained with the published command "
@@ -58,7 +58,8 @@ def main():
             "published numbers keep falling (0.0055 -> 0.0046): the gap GROWS with width, so it is systematic (an optimisation or "
             "initialisation detail of the third-party FNO that matters for the wider models, or the data generator's spectrum), not "
             "noise, and it is not explained; the published sweep is itself non-monotonic at larger widths (0.0043 -> 0.0054 -> 0.0041 "
-            "over 2 M -> 4 M -> 8 M parameters), about +-15 % run to run.  Protocol lines checked against src/nsbench/scripts/train.py:66-175 and evaluate.py:61-64: CosineAnnealingLR "
+            "over 2 M -> 4 M -> 8 M parameters), about +-15 % run to run; (4) GRF alpha 2.0 instead of 2.5 (hidden 27): 0.01153 = 2.1x -- alpha "
+            "2.5, which also reproduces the published persistence RMSE, is the published setting.  Protocol lines checked against src/nsbench/scripts/train.py:66-175 and evaluate.py:61-64: CosineAnnealingLR "
             "T_max = epochs, best checkpoint chosen on the validation loss, no noise, Adam defaults, batch order reshuffled per epoch.")
     out = {"_note": note, "summary": summary, "runs": runs}
     path = os.path.join(ROOT, "profiles", "r04_published_rmse.json")
