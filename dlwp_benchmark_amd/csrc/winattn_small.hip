@@ -1601,6 +1601,8 @@ extern "C" int dlwp_window_attn_fwd_tokens(const float* qkv_tokens, const float*
     a.qkv = qkv_tokens; a.fill = fill; a.table = bias_table; a.table_t = packed_table; a.ia = ia; a.ib = ib; a.labels = labels;
     a.src_map = src_map; a.dst_map = dst_map; a.out = out_tokens; a.lse = lse; a.Ltok = Ltok; a.io_bf16 = io_bf16 != 0;
     const int nc = (N + 15) / 16;
+    DLWP_REQUIRE((long long)Ltok * 3 * heads * d < (1LL << 31), DLWP_E_UNSUPPORTED,
+                 "window_attn_fwd_tokens: a sample's qkv tensor must stay below 2^31 elements (32-bit row offsets)");
     if (dlwp_tune_or("WINATTN_FWD_LDS", 1)) {
         // the LDS-staged forward (winattn_lds_fwd_tok_kernel; default: 43 vs 56 us per launch in the Pangu C4 step): one round of
         // four-wave workgroups, two per CU (Pangu C4 step: 228 workgroups 10.97 ms, 456: 10.58, 912: 10.64, 1824: 10.72)
