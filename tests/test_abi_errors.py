@@ -91,3 +91,27 @@ def test_round3_entries_reject_bad_arguments(h):
     assert h.dlwp_weight_grad_group(None, 2, None) < 0
     assert h.dlwp_weight_grad_group(FAKE, 0, None) < 0
     assert h.dlwp_set_gemm_tile256(2) < 0
+
+
+def test_token_layout_attention_entries_validate_before_launching(h):
+    """round 4: dlwp_window_attn_fwd_tokens / _bwd_tokens -- NULL operands, inconsistent window counts, query ranges, and (on a box
+    without the bf16 matrix mode set) the unsupported-shape path return negative codes with a message."""
+    F = C.c_float
+    # forward: qkv, fill, table, packed, ia, ib, labels, src_map, dst_map, out, lse, B_, nW, N, Ltok, TB, ntypes, heads, d, scale, q_lo, q_hi, io, stream
+    assert h.dlwp_window_attn_fwd_tokens(None, FAKE, FAKE, None, FAKE, FAKE, None, FAKE, FAKE, FAKE, FAKE, 8, 4, 49, 100, 169, 1, 2, 16, F(0.25), 0, 49, 0, None) < 0
+    assert "NULL" in err(h)
+    assert h.dlwp_window_attn_fwd_tokens(FAKE, FAKE, FAKE, None, FAKE, FAKE, None, FAKE, FAKE, FAKE, FAKE, 9, 4, 49, 100, 169, 1, 2, 16, F(0.25), 0, 49, 0, None) < 0
+    assert "bad shape" in err(h)                                               # B_ is not a multiple of nW
+    assert h.dlwp_window_attn_fwd_tokens(FAKE, FAKE, FAKE, None, FAKE, FAKE, None, FAKE, FAKE, FAKE, FAKE, 8, 4, 49, 100, 169, 1, 2, 16, F(0.25), 10, 60, 0, None) < 0
+    assert "query range" in err(h)
+    assert h.dlwp_window_attn_fwd_tokens(FAKE, FAKE, FAKE, None, FAKE, FAKE, None, FAKE, FAKE, FAKE, FAKE, 8, 4, 49, 100, 169, 1, 2, 16, F(0.25), 0, 49, 0, None) < 0
+    assert "2048" in err(h) or "bf16 matrix mode" in err(h)                    # 16 (window, head) pairs: not this family's shape
+    # backward: qkv, fill, table, packed, ia, ib, labels, out, lse, gout, dst_map, src_map, gqkv, gfill, gtable, B_, nW, N, Ltok, TB, ...
+    assert h.dlwp_window_attn_bwd_tokens(FAKE, None, FAKE, None, FAKE, FAKE, None, FAKE, FAKE, FAKE, None, FAKE, FAKE, FAKE, FAKE, 8, 4, 98, 100, 2548, 1, 2, 32,
+                                         F(0.2), 0, 98, 0, None) < 0
+    assert "NULL" in err(h)
+    assert h.dlwp_window_attn_bwd_tokens(FAKE, None, FAKE, None, FAKE, FAKE, None, FAKE, FAKE, FAKE, FAKE, FAKE, FAKE, FAKE, FAKE, 8, 4, 98, 100, 2548, 1, 2, 32,
+                                         F(0.2), 0, 98, 1, None) < 0
+    assert "fill" in err(h)                                                    # bf16 tensors without the token-layout operands
+    assert h.dlwp_window_attn_bwd_tokens_supported(200, 32, 2548) == 0 and h.dlwp_window_attn_bwd_tokens_supported(98, 48, 2548) == 0
+    assert h.dlwp_window_attn_fwd_tokens_supported(98, 32, 100) == 0           # too few (window, head) pairs
