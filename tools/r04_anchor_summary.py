@@ -53,7 +53,8 @@ def main():
             "numbers: src/nsbench/scripts/plot_results.py:76,82.  Findings: (1) hidden 27 with seeds 1 / 1234 under the round-3 "
             "initialisation: 0.00793 / 0.00804 -- the 1.44-1.46x is not seed scatter; (2) drawing the spectral weights as a complex "
             "normal (std / sqrt 2 per real / imaginary part instead of the full std per part; adopted as the engine's initialisation, "
-            "fno_engine.py) gives hidden 27: 0.00731 / 0.00784 (seeds 1234 / 1), hidden 8: 0.01445 / 0.0152 / 0.0145 = 1.04 / 1.09 / 1.04x over seeds 1234 / 1 / 2 (round 3: 1.08x); (3) hidden "
+            "fno_engine.py) gives hidden 27: 0.00731 / 0.00784 / 0.00812 (seeds 1234 / 1 / 2; mean 1.41x -- against the old draw's 1.45x the effect is "
+            "inside the +-5 % seed scatter), hidden 8: 0.01445 / 0.0152 / 0.0145 = 1.04 / 1.09 / 1.04x over seeds 1234 / 1 / 2 (round 3: 1.08x); (3) hidden "
             "38: 0.00726 = 1.58x -- in this build the closed-loop error stops improving near 0.0073 from hidden 27 on while the "
             "published numbers keep falling (0.0055 -> 0.0046): the gap GROWS with width, so it is systematic (an optimisation or "
             "initialisation detail of the third-party FNO that matters for the wider models, or the data generator's spectrum), not "
