@@ -253,6 +253,10 @@ __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
             klb[kc][j] = labw ? labw[key] : 0;
         }
     }
+    if (TOK) {          // token-layout entry: lse arrives uninitialised; rows outside the computed chunks read as zero in the backward
+        for (int t = lane; t < N; t += 64)
+            if ((t >> 4) < a.qc_lo || (t >> 4) >= a.qc_hi) a.lse[((long long)w.b * a.heads + w.head) * N + t] = 0.f;
+    }
 #pragma unroll 1
     for (int qc = a.qc_lo; qc < a.qc_hi; ++qc) {
         if (16 * qc >= N) break;
@@ -1367,6 +1371,8 @@ __global__ __launch_bounds__(256) void winattn_lds_fwd_tok_kernel(WsDev a) {
             if (m + 2 * a.groups < a.M) { who_window(a, wn, m + 2 * a.groups); load_index(wn.wdw); }
         }
         const long long tb0 = (long long)(w.b / a.nW) * a.Ltok;
+        if (tid < N && ((tid >> 4) < qlo || (tid >> 4) >= qhi))      // rows outside the computed chunks: the backward stages every row's lse
+            a.lse[((long long)w.b * a.heads + w.head) * N + tid] = 0.f;
         for (int qc = qlo + wv; qc < qhi; qc += 4) {
             const int q = 16 * qc + r;
             const int qa = ias[q], qlab = labs[q];

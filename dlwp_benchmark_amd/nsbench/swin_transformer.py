@@ -150,13 +150,14 @@ class _WindowAttnTokensFn(torch.autograd.Function):
         TB, ntypes = table.shape[0], table.shape[1]
         qr = (0, N) if qrange is None else (int(qrange[0]), int(qrange[1]))
         full = qr == (0, N)
-        lse = (torch.empty if full else torch.zeros)(B * nW, heads, N, device=x.device)
         packed = None
         if ntypes > 1:
             packed = torch.empty(ntypes * heads * TB, device=x.device)
             L.check(lib.dlwp_window_attn_pack_table(L.ptr(table), L.ptr(packed), TB, ntypes, heads, L.stream()))
         src_map, dst_map = position_maps(spec, fwd_shift, rev_shift, x.device)
         ctx.in_tokens = FUSED_FWD and lib.dlwp_window_attn_fwd_tokens_supported(N, d, B * nW * heads) == 1
+        # (dlwp_window_attn_fwd_tokens writes zeros into the statistics of the rows it skips; the window-layout entry leaves them alone)
+        lse = (torch.empty if (full or ctx.in_tokens) else torch.zeros)(B * nW, heads, N, device=x.device)
         ctx.io = io
         if io and not ctx.in_tokens:
             raise L.DlwpError("window attention: a bf16 qkv tensor needs the token-layout forward (dlwp_window_attn_fwd_tokens_supported)")

@@ -330,7 +330,8 @@ int dlwp_window_attn_bwd_tokens(const float* qkv, const float* fill, const float
 /* The forward of the same chain in one launch: attention over the windows of a token-layout qkv tensor (no gathered copy),   */
 /* output rows written to the tokens dst_map names (positions it drops are computed only as keys / values).  Same shape       */
 /* family as the wave-per-window kernels: N <= 128, d <= 32, d % 4 == 0, at least 2048 (window, head) pairs, bf16 matrix mode  */
-/* (dlwp_window_attn_fwd_tokens_supported); otherwise DLWP_E_UNSUPPORTED.                                                     */
+/* (dlwp_window_attn_fwd_tokens_supported); otherwise DLWP_E_UNSUPPORTED.  lse rows outside the computed query chunks are     */
+/* written as zero (the backward entry stages every row's statistic); out rows are written exactly once per token.            */
 int dlwp_window_attn_fwd_tokens_supported(int N, int d, long long pairs);
 int dlwp_window_attn_fwd_tokens(const float* qkv_tokens, const float* fill, const float* bias_table, const float* packed_table,
                                 const int* ia, const int* ib, const int* labels, const int* src_map, const int* dst_map,
