@@ -276,6 +276,15 @@ __device__ unsigned long long g_dlwp_stamps[32];
             g_dlwp_stamps[i] = t__;                                                           \
         }                                                                                     \
     } while (0)
+// the same for a workgroup chosen by the caller (wg = a workgroup-uniform predicate): thread 0 of that workgroup records
+#define DLWP_STAMP_IF(wg, i)                                                                  \
+    do {                                                                                      \
+        if ((wg) && threadIdx.x == 0) {                                                       \
+            unsigned long long t__;                                                           \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");      \
+            g_dlwp_stamps[i] = t__;                                                           \
+        }                                                                                     \
+    } while (0)
 // span of a whole launch on the constant-rate 100 MHz clock (comparable across XCDs): earliest first instruction and
 // latest last instruction over ALL workgroups (slots: begin = min, end = max)
 __device__ unsigned long long g_dlwp_span[2] = {~0ull, 0ull};
@@ -306,6 +315,7 @@ __device__ unsigned long long g_dlwp_span[2] = {~0ull, 0ull};
     } while (0)
 #else
 #define DLWP_STAMP(i)
+#define DLWP_STAMP_IF(wg, i)
 #define DLWP_STAMP_WAVE(base)
 #define DLWP_SPAN_BEGIN()
 #define DLWP_SPAN_END()

@@ -87,6 +87,10 @@ __global__ __launch_bounds__(512) void dhconv_apply_kernel(DhDev a) {
         if (row >= a.R2) return false;
         return !a.sparse || ((row % (2 * a.M)) >> 1) <= l;
     };
+#ifdef DLWP_STAMPS
+    const bool stamp_wg = blockIdx.x == 0 && blockIdx.y == gridDim.y - 1 && blockIdx.z == 0;      // the heaviest degree
+#endif
+    DLWP_STAMP_IF(stamp_wg, 0);
     // ---- spectrum rows of the live tiles -> LDS (LDS-DMA, swizzle on the source address)
     for (int q = w; q < RC / RPI; q += 8) {
         const int rowi = q * RPI;
@@ -97,9 +101,12 @@ __global__ __launch_bounds__(512) void dhconv_apply_kernel(DhDev a) {
                                          (__attribute__((address_space(3))) void*)(img + rowi * K), 16, 0, 0);
     }
     WFrag<1, KS> wf;
+    DLWP_STAMP_IF(stamp_wg, 1);
     if (tile < a.NT) wload<1, KS, KS, 1 << 30>(wf, a.img + (long long)l * a.NT * KS * 512, tile, lane, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DLWP_STAMP_IF(stamp_wg, 2);
     lds_barrier();
+    DLWP_STAMP_IF(stamp_wg, 3);
     if (tile >= a.NT) return;
     const int n = 8 * tile + 4 * g;                                     // lanes g < 2 store channels n .. n + 3 of their row
     const float sg = (r & 1) ? a.sgn : -a.sgn;
@@ -121,6 +128,137 @@ __global__ __launch_bounds__(512) void dhconv_apply_kernel(DhDev a) {
         }
         if (g < 2 && row < a.R2) *reinterpret_cast<bf16x4*>(a.Y + ((long long)l * a.R2 + row) * a.N + n) = out;
     }
+    DLWP_STAMP_IF(stamp_wg, 4);
+#ifdef DLWP_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DLWP_STAMP_IF(stamp_wg, 5);
+#endif
+}
+
+// Round 5: the same product as a pipeline.  Stamps of dhconv_apply_kernel at the C3 shape (profiles/r05_sfno_stamps.txt: 20 k cycles
+// for the heaviest degree) showed 9.9 k cycles of LDS-DMA issue + landing for the whole 160 KB of a workgroup before the first MFMA,
+// then 8 k cycles for eight row tiles in a serially dependent LDS read -> MFMA -> cross-lane read -> store chain, and the 8
+// workgroups that share the spectrum rows of a degree were dealt to 8 different XCDs (no L2 reuse).  Here
+//   * a workgroup owns (degree, four output tiles) for ALL row chunks and walks them with two LDS buffers: chunk c + 1 lands while
+//     chunk c is multiplied; the weight fragments stay in registers for the whole walk (B = 16: read once instead of four times);
+//   * a wave multiplies its TPW row tiles of a chunk together (independent accumulators: all fragment reads in flight at once);
+//   * the workgroups of one degree have equal blockIdx % 8, i.e. one XCD under round-robin placement (speed only): the rows of
+//     a degree come from that XCD's L2 after their first fetch, and every XCD gets degrees of all four truncation bands.
+template <int K, int RC>
+__global__ __launch_bounds__(512) void dhconv_apply2_kernel(DhDev a) {
+    constexpr int KS = K / 32, CPR = K / 8, RPI = 64 / CPR, RT = RC / 16, TPW = RT / 2;
+    extern __shared__ __attribute__((aligned(16))) float dh_smem[];
+    __bf16* img = reinterpret_cast<__bf16*>(dh_smem);                   // [2][RC][K], chunk c of row r at c ^ (r & cmask)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int NTG = a.NT / 4, L = gridDim.x / NTG;
+    int tg, l;
+    if (L % 8 == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        tg = j % NTG;
+        l = (j / NTG) * 8 + xcd;
+    } else {
+        tg = blockIdx.x % NTG;
+        l = blockIdx.x / NTG;
+    }
+    const int tile = 4 * tg + (w & 3), half = w >> 2;
+    const int nch = (a.R2 + RC - 1) / RC;
+    // truncation: the row tiles of a sample hold orders 0-7, 8-15, ...; with a power-of-two tile count per sample (the liveness test
+    // sits in front of every LDS-DMA: a division there cost 1.7 us per launch) tile t of the sample is live when 8 t <= l
+    const int tps = (2 * a.M) / 16;
+    const bool sparse = a.sparse && tps > 0 && (tps & (tps - 1)) == 0;
+    const int tmask = sparse ? tps - 1 : 0, lt8 = l >> 3;
+    auto tile_live = [&](int rt_abs) {                                  // does absolute row tile rt_abs hold any non-zero order?
+        if (16 * rt_abs >= a.R2) return false;
+        return !sparse || (rt_abs & tmask) <= lt8;
+    };
+#ifdef DLWP_STAMPS
+    const bool stamp_wg = tg == 0 && l == L - 1;                        // the heaviest degree
+#endif
+    DLWP_STAMP_IF(stamp_wg, 0);
+    auto issue = [&](int c) {
+        __bf16* buf = img + (c & 1) * RC * K;
+#pragma unroll
+        for (int i = 0; i < RC / RPI / 8; ++i) {
+            const int q = w + 8 * i, rowi = q * RPI;
+            if (!tile_live(c * RT + (rowi >> 4))) continue;
+            const int row = rowi + lane / CPR, pos = lane % CPR, cc = pos ^ (row & cmask<K>(pos));
+            const __bf16* src = a.X + ((long long)l * a.R2 + min(c * RC + row, a.R2 - 1)) * K + 8 * cc;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(buf + rowi * K), 16, 0, 0);
+        }
+    };
+    WFrag<1, KS> wf;
+    wload<1, KS, KS, 1 << 30>(wf, a.img + (long long)l * a.NT * KS * 512, tile, lane, 0);
+    issue(0);
+    DLWP_STAMP_IF(stamp_wg, 1);
+    const int n = 8 * tile + 4 * g;                                     // lanes g < 2 store channels n .. n + 3 of their row
+    const float sg = (r & 1) ? a.sgn : -a.sgn;
+    for (int c = 0; c < nch; ++c) {
+        // every vector-memory operation older than the previous chunk's TPW stores has landed: this chunk's rows (and the weights)
+        if (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TPW) : "memory");
+        lds_barrier();                                                  // ... for every wave; and all reads of the other buffer are over
+        if (c == 0) DLWP_STAMP_IF(stamp_wg, 2);
+        if (c + 1 < nch) issue(c + 1);
+        const __bf16* buf = img + (c & 1) * RC * K + 16 * half * TPW * K;
+        const int rt0 = c * RT + half * TPW;
+        // live tiles of a wave form a prefix when its tiles lie inside one sample (TPW divides the tiles per sample)
+        int nl = TPW;
+        const bool prefix = sparse && (tps % TPW) == 0;
+        if (prefix) {
+            nl = 0;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) nl += tile_live(rt0 + t) ? 1 : 0;
+        }
+        f32x4 acc[TPW][1];
+        zero_acc<TPW, 1>(acc);
+        if (nl == TPW) {
+            mma<TPW, 1, KS, K>(acc, wf, buf, 0, r, g);
+        } else if (nl > 0) {
+            if constexpr (TPW >= 4) {
+                if (nl > 2) {
+                    f32x4 a3[3][1];
+                    zero_acc<3, 1>(a3);
+                    mma<3, 1, KS, K>(a3, wf, buf, 0, r, g);
+                    acc[0][0] = a3[0][0]; acc[1][0] = a3[1][0]; acc[2][0] = a3[2][0];
+                } else if (nl > 1) {
+                    f32x4 a2[2][1];
+                    zero_acc<2, 1>(a2);
+                    mma<2, 1, KS, K>(a2, wf, buf, 0, r, g);
+                    acc[0][0] = a2[0][0]; acc[1][0] = a2[1][0];
+                } else {
+                    f32x4 a1[1][1];
+                    zero_acc<1, 1>(a1);
+                    mma<1, 1, KS, K>(a1, wf, buf, 0, r, g);
+                    acc[0][0] = a1[0][0];
+                }
+            } else {
+                f32x4 a1[1][1];
+                zero_acc<1, 1>(a1);
+                mma<1, 1, KS, K>(a1, wf, buf, 0, r, g);
+                acc[0][0] = a1[0][0];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const long long row = (long long)16 * (rt0 + t) + r;
+            const bool live = prefix ? t < nl : tile_live(rt0 + t);
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float oth = __shfl(acc[t][0][q], (lane ^ 1) + 32, 64);      // the other plane's product of the paired row
+                v[q] = live ? acc[t][0][q] + sg * oth : 0.f;
+            }
+            // (a row past the end exists only in the last chunk, after which nothing is counted any more)
+            if (g < 2 && row < a.R2) *reinterpret_cast<bf16x4*>(a.Y + ((long long)l * a.R2 + row) * a.N + n) = to_bf4(v);
+        }
+    }
+    DLWP_STAMP_IF(stamp_wg, 3);
+#ifdef DLWP_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DLWP_STAMP_IF(stamp_wg, 4);
+    DLWP_STAMP_IF(stamp_wg, 5);
+#endif
 }
 
 // ---- weight gradient: G[l][i][n] = sum over segments and rows of X[row][i] * gY~[row][n],  gY~ = [gY | gY'] (n < Co | n >= Co)
@@ -257,6 +395,13 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 }  // namespace
 
+#ifdef DLWP_STAMPS
+extern "C" int dlwp_debug_stamps_dhconv(unsigned long long* host_out) {
+    DLWP_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dlwp_stamps), sizeof(unsigned long long) * 32));
+    return DLWP_OK;
+}
+#endif
+
 extern "C" int dlwp_dhconv_supported(int Cin, int Cout, int L) {
     // apply kernel: contraction width with a compiled instantiation, output tiles in groups of four; weight gradient: 128-wide column
     // tiles must not straddle the [gY | gY'] halves; pack / fold slabs within the LDS
@@ -300,8 +445,10 @@ extern "C" int dlwp_dhconv_apply(const void* X, const void* image, void* Y, int 
     // mmax > 0: the rows of a sample are its orders m = 0 .. mmax - 1 and orders m > l are known to be zero (spectra of RealSHT)
     DhDev a{static_cast<const __bf16*>(X), static_cast<const __bf16*>(image), static_cast<__bf16*>(Y), rows, N, N / 8, std::max(mmax, 1),
             mmax > 0 && (2 * mmax) % 16 == 0 && rows % (2 * mmax) == 0, transposed ? -1.f : 1.f};
-    const dim3 grid(N / 32, L, ceil_div(rows, RC));
     const hipStream_t s = (hipStream_t)stream;
+    // DHCONV_APPLY = 1: the round-4 kernel (one 256-row chunk per workgroup); default: the pipelined kernel (chunks of 128 rows)
+    if (dlwp_tune_or("DHCONV_APPLY", 2) == 1) {
+        const dim3 grid(N / 32, L, ceil_div(rows, RC));
 #define DLWP_DH(KV)                                                                                                      \
     case KV: {                                                                                                           \
         const size_t lds = (size_t)RC * KV * sizeof(__bf16);                                                             \
@@ -309,11 +456,35 @@ extern "C" int dlwp_dhconv_apply(const void* X, const void* image, void* Y, int 
         hipLaunchKernelGGL(dhconv_apply_kernel<KV>, grid, dim3(512), lds, s, a);                                         \
         break;                                                                                                           \
     }
-    switch (K) {
-        DLWP_DH(64) DLWP_DH(128) DLWP_DH(256)
-        default: dlwp_set_error("dhconv_apply: contraction width %d has no kernel (64, 128, 256)", K); return DLWP_E_UNSUPPORTED;
-    }
+        switch (K) {
+            DLWP_DH(64) DLWP_DH(128) DLWP_DH(256)
+            default: dlwp_set_error("dhconv_apply: contraction width %d has no kernel (64, 128, 256)", K); return DLWP_E_UNSUPPORTED;
+        }
 #undef DLWP_DH
+    } else {
+        const dim3 grid((N / 32) * L);
+#define DLWP_DH2(KV, RCV)                                                                                                \
+    case KV: {                                                                                                           \
+        const size_t lds = (size_t)2 * RCV * KV * sizeof(__bf16);                                                        \
+        auto kern = dhconv_apply2_kernel<KV, RCV>;                                                                       \
+        if (int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(kern), lds, "dhconv_apply2")) return rc;              \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);                                                            \
+        break;                                                                                                           \
+    }
+        const int rcsel = dlwp_tune_or("DHCONV_RC", 128);
+        if (rcsel == 64) {
+            switch (K) {
+                DLWP_DH2(64, 64) DLWP_DH2(128, 64) DLWP_DH2(256, 64)
+                default: dlwp_set_error("dhconv_apply: contraction width %d has no kernel (64, 128, 256)", K); return DLWP_E_UNSUPPORTED;
+            }
+        } else {
+            switch (K) {
+                DLWP_DH2(64, 128) DLWP_DH2(128, 128) DLWP_DH2(256, 128)
+                default: dlwp_set_error("dhconv_apply: contraction width %d has no kernel (64, 128, 256)", K); return DLWP_E_UNSUPPORTED;
+            }
+        }
+#undef DLWP_DH2
+    }
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }

@@ -38,6 +38,7 @@ struct ShtB {
     const __bf16* T1;           // analysis: A1 [2M][N];   synthesis: S1t [M][K][L]
     const __bf16* T2;           // analysis: A2 [M][L][K]; synthesis: S2 [N][2M]
     int B, K, N, C, M, L, ncb, ngrp;
+    int tri;                    // synthesis: orders m > l of X are zero by spherical truncation and are not read
 };
 
 // 16 contiguous table elements row[col .. col + 7] or zeros (row_ok && col + 7 < ncols; ncols % 8 == 0); the load is unconditional
@@ -58,10 +59,34 @@ __device__ __forceinline__ bf16x8 field_frag(const __bf16* img, int kk, int r, i
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+// A fragment of plane q of the synthesis kernel's spectrum image [degree][position][16 channels] (rows of QP * 32 bytes, plane q of
+// degree l at position q ^ f(l)): rows = channels, k = degrees 32 kk + 8 g .. + 7
+template <int QP>
+__device__ __forceinline__ bf16x8 spec_frag(const __bf16* img, int q, int kk, int r, int g) {
+    const int l0 = 32 * kk + 8 * g + (r >> 2), f = (r >> 2) | ((g & 1) << 2);          // f(l0) = f(l0 + 4)
+    const __bf16* p0 = img + (l0 * QP + (q ^ f)) * CB + 4 * (r & 3);
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * QP * CB));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
 __device__ __forceinline__ void block_ids(const ShtB& a, int& b, int& cb, int& grp) {
-    // the workgroups (groups of orders / latitudes) of one (sample, channel block) read the same field (speed only: any mapping is correct)
+    // Speed only (any mapping is correct).  Workgroups i and i + 8 share an XCD under round-robin placement.  A 16-channel block
+    // of a channels-last tensor is a 32-byte (bf16 spectrum) or 64-byte (fp32 field) piece of a 128-byte line, so the FOUR
+    // channel blocks that share the lines of a spectrum go to one XCD (its L2 then fetches / writes whole lines once; dealt to
+    // four XCDs every line crossed the fabric four times), and so do the groups of orders / latitudes of a (sample, channel
+    // block), which read the same field: their workgroups run back to back on that XCD.
     const int per = a.B * a.ncb;
     int rest;
+    if (per % 32 == 0 && a.ncb % 4 == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;            // j: position in the XCD's own sequence
+        grp = j % a.ngrp;
+        const int t = j / a.ngrp, cbl = t & 3, sc = t >> 2;            // four channel blocks of one line group, then the next group
+        const int fid = sc * 8 + xcd, nq = a.ncb >> 2;                  // (sample, line group) index
+        b = fid / nq;
+        cb = 4 * (fid - b * nq) + cbl;
+        return;
+    }
     if (per % 8 == 0) {
         // eight fields (one per XCD under round-robin placement) at a time, their groups back to back: the groups of a field run on
         // one XCD and close in time, so the field is fetched from HBM once (B = 16: 1024 workgroups, four rounds)
@@ -89,6 +114,7 @@ __global__ __launch_bounds__(512) void sht_analysis_bf16_kernel(ShtB a) {
     const int c0 = cb * CB, q0 = 2 * GRP * mg, K = a.K, N = a.N, C = a.C, M = a.M, L = a.L;
     const float* x = static_cast<const float*>(a.in);
     __bf16* X = static_cast<__bf16*>(a.out);
+    DLWP_STAMP(0);
     if (K < KPAD) {                                                // padding latitudes meet zero table entries: no NaN garbage
         for (int e = tid; e < 16 * (KPAD - K) * CB / 4; e += 512) {
             const int per = (KPAD - K) * CB / 4, q = e / per, o = e - q * per;
@@ -108,26 +134,15 @@ __global__ __launch_bounds__(512) void sht_analysis_bf16_kernel(ShtB a) {
             v[i] = n < N ? u : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    f32x4 cur[NV], nxt[NV];
-    if (w < K) load_rows(w, cur);
-    for (int k = w; k < K; k += NW) {
-        if (k + NW < K) load_rows(k + NW, nxt);
+    // the wave's latitudes k = w, w + 8, ...: ALL their rows are requested before the first product where the registers allow
+    // (round 4 kept one latitude ahead: four dependent HBM round trips of ~1,900 cycles each in the stamps)
+    constexpr int NIT = 4 * KKS;                                   // latitudes per wave (K <= 32 KKS over NW = 8 waves)
+    constexpr int DA = NIT * NV <= 32 ? NIT : 2;
+    f32x4 rows[DA][NV];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int n = (lane >> 2) + 16 * i;
-            *reinterpret_cast<bf16x4*>(tile + n * CB + 4 * (lane & 3)) = bf16x4{(__bf16)cur[i][0], (__bf16)cur[i][1], (__bf16)cur[i][2], (__bf16)cur[i][3]};
-        }
-        __builtin_amdgcn_wave_barrier();
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < NKS; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(field_frag(tile, kk, r, g), t1[kk], acc, 0, 0, 0);
-        // lane (r, g): channels 4g .. 4g + 3 of column q0 + r
-        *reinterpret_cast<bf16x4*>(Timg + (r * KPAD + k) * CB + 4 * g) = bf16x4{(__bf16)acc[0], (__bf16)acc[1], (__bf16)acc[2], (__bf16)acc[3]};
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < NV; ++i) cur[i] = nxt[i];
-    }
-    // ---- stage 2: this wave's order m = GRP mg + w, both parts
+    for (int i = 0; i < DA; ++i)
+        if (w + NW * i < K) load_rows(w + NW * i, rows[i]);
+    // stage 2's table fragments (order m = GRP mg + w) travel during stage 1
     const int m = GRP * mg + w;
     bf16x8 t2[LT][KKS];
 #pragma unroll
@@ -137,7 +152,31 @@ __global__ __launch_bounds__(512) void sht_analysis_bf16_kernel(ShtB a) {
             const int l = 16 * lt + r;
             t2[lt][kk] = tab8(a.T2 + ((long long)min(m, M - 1) * L + min(l, L - 1)) * K, 32 * kk + 8 * g, K, m < M && l < L);
         }
+    DLWP_STAMP(1);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int k = w + NW * it;
+        if (k < K) {
+            const f32x4 (&cur)[NV] = rows[it % DA];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int n = (lane >> 2) + 16 * i;
+                *reinterpret_cast<bf16x4*>(tile + n * CB + 4 * (lane & 3)) = bf16x4{(__bf16)cur[i][0], (__bf16)cur[i][1], (__bf16)cur[i][2], (__bf16)cur[i][3]};
+            }
+            __builtin_amdgcn_wave_barrier();
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < NKS; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(field_frag(tile, kk, r, g), t1[kk], acc, 0, 0, 0);
+            // lane (r, g): channels 4g .. 4g + 3 of column q0 + r
+            *reinterpret_cast<bf16x4*>(Timg + (r * KPAD + k) * CB + 4 * g) = bf16x4{(__bf16)acc[0], (__bf16)acc[1], (__bf16)acc[2], (__bf16)acc[3]};
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (it + DA < NIT && w + NW * (it + DA) < K) load_rows(w + NW * (it + DA), rows[it % DA]);
+    }
+    DLWP_STAMP(2);
+    // ---- stage 2: this wave's order m = GRP mg + w, both parts (its table fragments were requested before stage 1)
     lds_barrier();
+    DLWP_STAMP(3);
     if (m < M) {
 #pragma unroll
         for (int ri = 0; ri < 2; ++ri) {
@@ -160,6 +199,11 @@ __global__ __launch_bounds__(512) void sht_analysis_bf16_kernel(ShtB a) {
             }
         }
     }
+    DLWP_STAMP(4);
+#ifdef DLWP_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DLWP_STAMP(5);
+#endif
 }
 
 // LKS: degree k-steps (L <= 32 LKS); QKS: order k-steps (2 M <= 32 QKS); NT: longitude tiles (N <= 16 NT)
@@ -167,20 +211,36 @@ template <int LKS, int QKS, int NT>
 __global__ __launch_bounds__(512) void sht_synthesis_bf16_kernel(ShtB a) {
     constexpr int LP = 32 * LKS, QP = 32 * QKS;
     extern __shared__ __attribute__((aligned(16))) float sht_smem[];
-    __bf16* Ximg = reinterpret_cast<__bf16*>(sht_smem);            // [2 M planes][LP degrees][CB]
+    __bf16* Ximg = reinterpret_cast<__bf16*>(sht_smem);            // [LP degrees][QP positions][CB]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
     int b, cb, kg;
     block_ids(a, b, cb, kg);
     const int c0 = cb * CB, k0 = GRP * kg, K = a.K, N = a.N, C = a.C, M = a.M, L = a.L;
-    __bf16* Timg = Ximg + 2 * M * LP * CB;                         // [GRP lat][QP][CB]
+    __bf16* Timg = Ximg + LP * QP * CB;                            // [GRP lat][QP][CB]
     const __bf16* X = static_cast<const __bf16*>(a.in);
     float* x = static_cast<float*>(a.out);
-    // ---- spectrum image by LDS-DMA: a wave-instruction moves 32 degrees x 32 bytes of one (order, part) plane
-    for (int p = w; p < 2 * M * LKS; p += NW) {
-        const int plane = p / LKS, part = p - plane * LKS, l = 32 * part + (lane >> 1);
-        const __bf16* src = X + (((long long)min(l, L - 1) * a.B + b) * 2 * M + plane) * C + c0 + 8 * (lane & 1);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(Ximg + (plane * LP + 32 * part) * CB), 16, 0, 0);
+    DLWP_STAMP(8);
+    // ---- spectrum image by LDS-DMA: a wave-instruction moves 32 planes x 32 bytes of ONE degree (round 4 moved 32 degrees of one
+    // plane: 32 pieces 2^17 bytes apart at B = 4 -- one memory channel per instruction; the pieces of a degree are 512 bytes apart).
+    // Image [degree][position][CB]; position p of degree l holds plane p ^ f(l), f(l) = (l & 3) | 4 (l >> 3 & 1): the eight degrees a
+    // transposing fragment read touches (l0 .. l0 + 3 and l0 + 8 .. l0 + 11) then sit in eight different 32-byte bank groups.
+    // Truncated spectra (tri): degree l has orders m <= l only -- 48 % of the (degree, plane) pairs at lmax = mmax = 32.  Their
+    // lanes issue no request (the image is filled at the L2 request rate: 32-byte pieces) and store zeros instead.
+    for (int p = w; p < L * QKS; p += NW) {
+        const int l = p / QKS, part = p - l * QKS, f = (l & 3) | (((l >> 3) & 1) << 2);
+        const int plane = (32 * part + (lane >> 1)) ^ f;
+        const __bf16* src = X + (((long long)l * a.B + b) * 2 * M + min(plane, 2 * M - 1)) * C + c0 + 8 * (lane & 1);
+        __bf16* dst = Ximg + (l * QP + 32 * part) * CB;
+        if (!a.tri || (plane >> 1) <= l) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        } else {
+            *reinterpret_cast<bf16x8*>(dst + 8 * lane) = bf16x8{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        }
+    }
+    if (L < LP) {                                                  // padding degrees meet zero table entries
+        for (int e = tid; e < (LP - L) * QP * CB / 4; e += 512)
+            *reinterpret_cast<bf16x4*>(Ximg + L * QP * CB + 4 * e) = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
     }
     if (2 * M < QP) {                                              // padding orders meet zero table entries
         for (int e = tid; e < GRP * (QP - 2 * M) * CB / 4; e += 512) {
@@ -188,7 +248,9 @@ __global__ __launch_bounds__(512) void sht_synthesis_bf16_kernel(ShtB a) {
             *reinterpret_cast<bf16x4*>(Timg + (kl * QP + 2 * M) * CB + 4 * o) = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
         }
     }
-    // stage-2 table (constant for the workgroup) and the first stage-1 fragments travel while the image lands
+    // everything else this wave will read from global memory is requested now, behind the image: the stage-2 table (constant for
+    // the workgroup), ALL stage-1 table fragments of the wave's planes (round 4 fetched them one plane ahead: eight dependent L2
+    // round trips of ~740 cycles each in the stamps), and the residual rows of the wave's output latitude
     bf16x8 t2[NT][QKS];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -197,43 +259,54 @@ __global__ __launch_bounds__(512) void sht_synthesis_bf16_kernel(ShtB a) {
             const int n = 16 * nt + r;
             t2[nt][kk] = tab8(a.T2 + (long long)min(n, N - 1) * 2 * M, 32 * kk + 8 * g, 2 * M, n < N);
         }
-    bf16x8 t1c[LKS], t1n[LKS];
-    {
-        const int kl = k0 + r;
-#pragma unroll
-        for (int kk = 0; kk < LKS; ++kk)
-            t1c[kk] = tab8(a.T1 + ((long long)min(w >> 1, M - 1) * K + min(kl, K - 1)) * L, 32 * kk + 8 * g, L, r < GRP && kl < K && w < 2 * M);
-#pragma unroll
-        for (int kk = 0; kk < LKS; ++kk) t1n[kk] = t1c[kk];
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_barrier();
-    // ---- stage 1: T[k0 + r][q][c] for the planes q = w, w + 8, ... (columns r >= GRP of the tile are not used)
+    constexpr int NQ = 4 * QKS;                                    // planes per wave: 2 M <= 32 QKS over NW = 8 waves
+    constexpr int D1 = NQ * LKS + NT * QKS + 2 * NT <= 40 ? NQ : 2;    // stage-1 fragments in flight (all of them where the registers allow)
     const int klat = k0 + r;
-    auto load_t1 = [&](int q, bf16x8 (&t)[LKS]) {
+    auto load_t1 = [&](int i, bf16x8 (&t)[LKS]) {
+        const int q = w + NW * i;
 #pragma unroll
         for (int kk = 0; kk < LKS; ++kk)
-            t[kk] = tab8(a.T1 + ((long long)min(q >> 1, M - 1) * K + min(klat, K - 1)) * L, 32 * kk + 8 * g, L, r < GRP && klat < K);
+            t[kk] = tab8(a.T1 + ((long long)min(q >> 1, M - 1) * K + min(klat, K - 1)) * L, 32 * kk + 8 * g, L,
+                         r < GRP && klat < K && q < 2 * M);
     };
-    asm volatile("" ::: "memory");
-    for (int q = w; q < 2 * M; q += NW) {
-        if (q + NW < 2 * M) load_t1(q + NW, t1n);                  // the next plane's table fragment travels during this plane's product
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 t1[D1][LKS];
 #pragma unroll
-        for (int kk = 0; kk < LKS; ++kk)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(field_frag(Ximg + q * LP * CB, kk, r, g), t1c[kk], acc, 0, 0, 0);
-        if (r < GRP)
-            *reinterpret_cast<bf16x4*>(Timg + (r * QP + q) * CB + 4 * g) = bf16x4{(__bf16)acc[0], (__bf16)acc[1], (__bf16)acc[2], (__bf16)acc[3]};
-#pragma unroll
-        for (int kk = 0; kk < LKS; ++kk) t1c[kk] = t1n[kk];
-    }
-    lds_barrier();
-    // ---- stage 2: latitude k0 + w, every longitude tile
+    for (int i = 0; i < D1; ++i) load_t1(i, t1[i]);
     const int k = k0 + w;
+    f32x4 rv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = 16 * nt + r;
+        rv[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.res) rv[nt] = *reinterpret_cast<const f32x4*>(a.res + (((long long)b * K + min(k, K - 1)) * N + min(n, N - 1)) * C + c0 + 4 * g);
+    }
+    DLWP_STAMP(9);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DLWP_STAMP(10);
+    lds_barrier();
+    DLWP_STAMP(11);
+    // ---- stage 1: T[k0 + r][q][c] for the planes q = w, w + 8, ... (columns r >= GRP of the tile are not used)
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int q = w + NW * i;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (q < 2 * M) {
+#pragma unroll
+            for (int kk = 0; kk < LKS; ++kk)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(spec_frag<QP>(Ximg, q, kk, r, g), t1[i % D1][kk], acc, 0, 0, 0);
+            if (r < GRP)
+                *reinterpret_cast<bf16x4*>(Timg + (r * QP + q) * CB + 4 * g) = bf16x4{(__bf16)acc[0], (__bf16)acc[1], (__bf16)acc[2], (__bf16)acc[3]};
+        }
+        if (i + D1 < NQ) load_t1(i + D1, t1[i % D1]);
+    }
+    DLWP_STAMP(12);
+    lds_barrier();
+    DLWP_STAMP(13);
+    // ---- stage 2: latitude k0 + w, every longitude tile
     if (k < K) {
         f32x4 acc[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = rv[nt];
 #pragma unroll
         for (int kk = 0; kk < QKS; ++kk) {
             const bf16x8 f = field_frag(Timg + w * QP * CB, kk, r, g);
@@ -243,14 +316,14 @@ __global__ __launch_bounds__(512) void sht_synthesis_bf16_kernel(ShtB a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int n = 16 * nt + r;
-            if (n < N) {
-                const long long o = (((long long)b * K + k) * N + n) * C + c0 + 4 * g;
-                f32x4 v = acc[nt];
-                if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + o);
-                *reinterpret_cast<f32x4*>(x + o) = v;
-            }
+            if (n < N) *reinterpret_cast<f32x4*>(x + (((long long)b * K + k) * N + n) * C + c0 + 4 * g) = acc[nt];
         }
     }
+    DLWP_STAMP(14);
+#ifdef DLWP_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DLWP_STAMP(15);
+#endif
 }
 
 bool shape_ok(int K, int N, int C, int M, int L) {
@@ -258,7 +331,7 @@ bool shape_ok(int K, int N, int C, int M, int L) {
     if (K < 1 || N < 8 || C < CB || M < 1 || L < 1) return false;
     if (C % CB || N % 8 || K % 8 || L % 8 || (2 * M) % 8) return false;
     if (N > 128 || K > 64 || L > 64 || 2 * M > 128) return false;
-    const size_t syn = (size_t)(2 * M * round_up(L, 32) + GRP * round_up(2 * M, 32)) * CB * 2;
+    const size_t syn = (size_t)(round_up(L, 32) * round_up(2 * M, 32) + GRP * round_up(2 * M, 32)) * CB * 2;
     const size_t ana = (size_t)(16 * round_up(K, 32) + NW * round_up(N, 32)) * CB * 2;
     return syn <= 150 * 1024 && ana <= 150 * 1024;
 }
@@ -303,6 +376,13 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 }  // namespace
 
+#ifdef DLWP_STAMPS
+extern "C" int dlwp_debug_stamps_sht(unsigned long long* host_out) {
+    DLWP_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dlwp_stamps), sizeof(unsigned long long) * 32));
+    return DLWP_OK;
+}
+#endif
+
 extern "C" int dlwp_sht_bf16_supported(int nlat, int nlon, int C, int mmax, int lmax) { return shape_ok(nlat, nlon, C, mmax, lmax) ? 1 : 0; }
 
 extern "C" int dlwp_sht_analysis_bf16(const float* x, const void* A1, const void* A2, void* X, int B, int nlat, int nlon, int C, int mmax,
@@ -312,7 +392,7 @@ extern "C" int dlwp_sht_analysis_bf16(const float* x, const void* A1, const void
                  "(dlwp_sht_bf16_supported)", nlat, nlon, C, mmax, lmax);
     DLWP_REQUIRE(aligned16(x) && aligned16(A1) && aligned16(A2) && aligned16(X), DLWP_E_INVALID, "sht_analysis_bf16: 16-byte alignment");
     ShtB a{x, X, nullptr, static_cast<const __bf16*>(A1), static_cast<const __bf16*>(A2), B, nlat, nlon, C, mmax, lmax, C / CB,
-           ceil_div(mmax, GRP)};
+           ceil_div(mmax, GRP), 0};
     const int NKS = ceil_div(nlon, 32), KKS = ceil_div(nlat, 32), LT = ceil_div(lmax, 16);
     const size_t lds = (size_t)(16 * 32 * KKS + NW * 32 * NKS) * CB * sizeof(__bf16);
     const dim3 grid(B * a.ncb * a.ngrp);
@@ -329,17 +409,18 @@ extern "C" int dlwp_sht_analysis_bf16(const float* x, const void* A1, const void
     return analysis_lt<4, 2>(a, LT, lds, grid, s);
 }
 
-extern "C" int dlwp_sht_synthesis_bf16(const void* X, const void* S1t, const void* S2, const float* residual, float* x, int B, int nlat,
-                                       int nlon, int C, int mmax, int lmax, void* stream) {
+extern "C" int dlwp_sht_synthesis_bf16_ex(const void* X, const void* S1t, const void* S2, const float* residual, float* x, int B, int nlat,
+                                          int nlon, int C, int mmax, int lmax, int flags, void* stream) {
     DLWP_REQUIRE(X && S1t && S2 && x && B > 0, DLWP_E_INVALID, "sht_synthesis_bf16: null pointer / empty batch");
     DLWP_REQUIRE(shape_ok(nlat, nlon, C, mmax, lmax), DLWP_E_UNSUPPORTED, "sht_synthesis_bf16: shape %d x %d, C %d, mmax %d, lmax %d unsupported "
                  "(dlwp_sht_bf16_supported)", nlat, nlon, C, mmax, lmax);
     DLWP_REQUIRE(aligned16(X) && aligned16(S1t) && aligned16(S2) && aligned16(x) && aligned16(residual), DLWP_E_INVALID,
                  "sht_synthesis_bf16: 16-byte alignment");
+    DLWP_REQUIRE((flags & ~DLWP_SHT_TRIANGULAR) == 0, DLWP_E_INVALID, "sht_synthesis_bf16: unknown flag bits %d", flags);
     ShtB a{X, x, residual, static_cast<const __bf16*>(S1t), static_cast<const __bf16*>(S2), B, nlat, nlon, C, mmax, lmax, C / CB,
-           ceil_div(nlat, GRP)};
+           ceil_div(nlat, GRP), (flags & DLWP_SHT_TRIANGULAR) ? 1 : 0};
     const int LKS = ceil_div(lmax, 32), QKS = ceil_div(2 * mmax, 32), NT = ceil_div(nlon, 16);
-    const size_t lds = (size_t)(2 * mmax * 32 * LKS + GRP * 32 * QKS) * CB * sizeof(__bf16);
+    const size_t lds = (size_t)(32 * LKS * 32 * QKS + GRP * 32 * QKS) * CB * sizeof(__bf16);
     const dim3 grid(B * a.ncb * a.ngrp);
     const hipStream_t s = (hipStream_t)stream;
     if (LKS == 1) {
@@ -352,4 +433,9 @@ extern "C" int dlwp_sht_synthesis_bf16(const void* X, const void* S1t, const voi
     if (QKS == 2) return synthesis_nt<2, 2>(a, NT, lds, grid, s);
     if (QKS == 3) return synthesis_nt<2, 3>(a, NT, lds, grid, s);
     return synthesis_nt<2, 4>(a, NT, lds, grid, s);
+}
+
+extern "C" int dlwp_sht_synthesis_bf16(const void* X, const void* S1t, const void* S2, const float* residual, float* x, int B, int nlat,
+                                       int nlon, int C, int mmax, int lmax, void* stream) {
+    return dlwp_sht_synthesis_bf16_ex(X, S1t, S2, residual, x, B, nlat, nlon, C, mmax, lmax, 0, stream);
 }

@@ -181,10 +181,18 @@ __global__ __launch_bounds__(256) void clip_scale_kernel(float* g, long long n, 
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] *= coef;
 }
 
+// sumsq != nullptr: the gradient is clipped on the way in (torch.nn.utils.clip_grad_norm_'s coefficient from the squared norm
+// dlwp_sumsq left there) -- the separate read-modify-write pass of dlwp_clip_scale over the gradient buffer is not needed
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    const int* step_ptr, long long n, float lr, float beta1,
-                                                   float beta2, float eps, float grad_scale, int zero_grad) {
+                                                   float beta2, float eps, float grad_scale, int zero_grad,
+                                                   const float* __restrict__ sumsq, float max_norm) {
+    if (sumsq) {
+        const float total = sqrtf(*sumsq) * fabsf(grad_scale);
+        const float coef = max_norm / (total + 1e-6f);
+        grad_scale *= coef < 1.f ? coef : 1.f;
+    }
     const int step = *step_ptr + 1;
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2 = 1.f - powf(beta2, (float)step);
@@ -357,20 +365,26 @@ extern "C" int dlwp_clip_scale(float* g, long long n, const float* sumsq, float 
     return DLWP_OK;
 }
 
-extern "C" int dlwp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int* step,
-                              long long n, float lr, float beta1, float beta2, float eps, float grad_scale,
-                              int zero_grad, void* stream) {
+extern "C" int dlwp_adam_step_clipped(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int* step,
+                                      long long n, float lr, float beta1, float beta2, float eps, float grad_scale,
+                                      int zero_grad, const float* sumsq, float max_norm, void* stream) {
     DLWP_REQUIRE(param && grad && exp_avg && exp_avg_sq && step && n >= 0, DLWP_E_INVALID,
                  "adam_step: NULL argument");
     DLWP_REQUIRE(n > 0, DLWP_E_INVALID, "adam_step: empty parameter buffer");
-    {
-        hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, param, grad,
-                           exp_avg, exp_avg_sq, step, n, lr, beta1, beta2, eps, grad_scale, zero_grad);
-        DLWP_LAUNCH_CHECK();
-    }
+    DLWP_REQUIRE(!sumsq || max_norm > 0.f, DLWP_E_INVALID, "adam_step_clipped: max_norm must be positive");
+    hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                       exp_avg, exp_avg_sq, step, n, lr, beta1, beta2, eps, grad_scale, zero_grad, sumsq, max_norm);
+    DLWP_LAUNCH_CHECK();
     hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
+}
+
+extern "C" int dlwp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int* step,
+                              long long n, float lr, float beta1, float beta2, float eps, float grad_scale,
+                              int zero_grad, void* stream) {
+    return dlwp_adam_step_clipped(param, grad, exp_avg, exp_avg_sq, step, n, lr, beta1, beta2, eps, grad_scale, zero_grad,
+                                  nullptr, 0.f, stream);
 }
 
 int dlwp_rollout_prep(float* loss, float* g_out, long long n, float* out, const float* x, long long out_bs, long long x_bs,

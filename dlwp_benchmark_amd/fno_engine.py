@@ -218,8 +218,16 @@ class FusedAdam:
         L.check(self.lib.dlwp_sumsq(L.ptr(self.grads), n, L.ptr(self.sumsq), L.stream()))
         L.check(self.lib.dlwp_clip_scale(L.ptr(self.grads), n, L.ptr(self.sumsq), grad_scale, max_norm, L.stream()))
 
-    def step(self, grad_scale=1.0, zero_grad=True):
-        L.check(self.lib.dlwp_adam_step(L.ptr(self.params), L.ptr(self.grads), L.ptr(self.exp_avg),
-                                        L.ptr(self.exp_avg_sq), L.ptr(self.step_count), self.params.numel(),
-                                        self.lr, self.betas[0], self.betas[1], self.eps, grad_scale,
-                                        int(zero_grad), L.stream()))
+    def step(self, grad_scale=1.0, zero_grad=True, clip_max_norm=None):
+        """clip_max_norm: clip_grad_norm_ folded into the update (dlwp_adam_step_clipped): one squared-norm pass, then Adam reads
+        the gradient through the clipping coefficient -- same parameters as clip_grad_norm_() followed by step(), one
+        read-modify-write pass over the gradient buffer less."""
+        sumsq = None
+        if clip_max_norm is not None:
+            self.sumsq.zero_()
+            L.check(self.lib.dlwp_sumsq(L.ptr(self.grads), self.grads.numel(), L.ptr(self.sumsq), L.stream()))
+            sumsq = self.sumsq
+        L.check(self.lib.dlwp_adam_step_clipped(L.ptr(self.params), L.ptr(self.grads), L.ptr(self.exp_avg),
+                                                L.ptr(self.exp_avg_sq), L.ptr(self.step_count), self.params.numel(),
+                                                self.lr, self.betas[0], self.betas[1], self.eps, grad_scale,
+                                                int(zero_grad), L.ptr(sumsq), float(clip_max_norm or 0.0), L.stream()))

@@ -52,6 +52,7 @@ SIGNATURES = {
     "dlwp_mse_fwd_bwd": (_I, [_V, _V, _L, _V, _V, _V]),
     "dlwp_error_moments": (_I, [_V, _V, _V, _V, _I, _I, _I, _I, _V, _V]),
     "dlwp_adam_step": (_I, [_V, _V, _V, _V, _V, _L, _F, _F, _F, _F, _F, _I, _V]),
+    "dlwp_adam_step_clipped": (_I, [_V, _V, _V, _V, _V, _L, _F, _F, _F, _F, _F, _I, _V, _F, _V]),
     "dlwp_sumsq": (_I, [_V, _L, _V, _V]),
     "dlwp_clip_scale": (_I, [_V, _L, _V, _F, _F, _V]),
     "dlwp_fno_param_offset": (_L, [C.POINTER(FnoCfg), _I, _I, C.POINTER(_L)]),
@@ -98,6 +99,7 @@ SIGNATURES = {
     "dlwp_sht_bf16_supported": (_I, [_I] * 5),
     "dlwp_sht_analysis_bf16": (_I, [_V, _V, _V, _V] + [_I] * 6 + [_V]),
     "dlwp_sht_synthesis_bf16": (_I, [_V, _V, _V, _V, _V] + [_I] * 6 + [_V]),
+    "dlwp_sht_synthesis_bf16_ex": (_I, [_V, _V, _V, _V, _V] + [_I] * 7 + [_V]),
     "dlwp_cweight_expand": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_cweight_fold": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_dhconv_supported": (_I, [_I, _I, _I]),

@@ -161,6 +161,21 @@ def _table(mod, name, dtype):
     return c
 
 
+def _triangular_flag(mod, name):
+    """DLWP_SHT_TRIANGULAR for the bf16 synthesis kernel when the Legendre table `name` ([mmax, nlat, lmax], the kernel's S1t) is
+    exactly zero for degrees l < m (associated Legendre functions: always, checked once per table on the host): every product with
+    a spectrum entry of order m > l is then zero whatever the entry holds, so the kernel does not read those entries."""
+    key = "_tri_" + name
+    flag = mod.__dict__.get(key)
+    if flag is None:
+        t = getattr(mod, name)                                   # [mmax, nlat, lmax]
+        M, _, Lm = t.shape
+        dead = torch.arange(Lm, device=t.device)[None, :] < torch.arange(M, device=t.device)[:, None]      # [M, L]: l < m
+        flag = 1 if bool((t.permute(0, 2, 1)[dead] == 0).all()) else 0
+        mod.__dict__[key] = flag
+    return flag
+
+
 def _fused_ok(nlat, nlon, C, mmax, lmax):
     """Single-launch kernels (csrc/sht_fused.hip, exact-f32 MFMA) or two strided-batched GEMMs?  Measured on the C3 step
     (B=4): with fp32 GEMM operands the fused transforms win (526 vs 512 samples/s); with bf16 GEMM operands the two table
@@ -256,8 +271,9 @@ class _Bf16Analysis(torch.autograd.Function):
         if gskip is not None:
             gskip = gskip.contiguous().float()
         gx = torch.empty(B, K, N, C, device=gX.device)
-        L.check(L.load().dlwp_sht_synthesis_bf16(L.ptr(gX), L.ptr(_table(ctx.mod, ctx.names[2], bf)), L.ptr(_table(ctx.mod, ctx.names[3], bf)),
-                                                 L.ptr(gskip), L.ptr(gx), B, K, N, C, M, Lm, L.stream()))
+        L.check(L.load().dlwp_sht_synthesis_bf16_ex(L.ptr(gX), L.ptr(_table(ctx.mod, ctx.names[2], bf)), L.ptr(_table(ctx.mod, ctx.names[3], bf)),
+                                                    L.ptr(gskip), L.ptr(gx), B, K, N, C, M, Lm, _triangular_flag(ctx.mod, ctx.names[2]),
+                                                    L.stream()))
         return gx, None, None, None, None
 
 
@@ -273,8 +289,8 @@ class _Bf16Synthesis(torch.autograd.Function):
         Lm, B, M, _, C = X.shape
         K, N = grid
         x = torch.empty(B, K, N, C, device=X.device)
-        L.check(L.load().dlwp_sht_synthesis_bf16(L.ptr(X), L.ptr(_table(mod, names[0], bf)), L.ptr(_table(mod, names[1], bf)), None,
-                                                 L.ptr(x), B, K, N, C, M, Lm, L.stream()))
+        L.check(L.load().dlwp_sht_synthesis_bf16_ex(L.ptr(X), L.ptr(_table(mod, names[0], bf)), L.ptr(_table(mod, names[1], bf)), None,
+                                                    L.ptr(x), B, K, N, C, M, Lm, _triangular_flag(mod, names[0]), L.stream()))
         ctx.mod, ctx.names, ctx.dims = mod, names, (B, K, N, C, M, Lm)
         return x
 

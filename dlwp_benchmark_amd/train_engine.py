@@ -124,9 +124,8 @@ class GraphedTrainStep:
         self.loss.copy_(loss.detach())
 
     def _optimize(self):
-        if self.clip is not None:
-            self.opt.clip_grad_norm_(self.clip, grad_scale=self.grad_scale)
-        self.opt.step(grad_scale=self.grad_scale)
+        # clip_grad_norm_ (dlwpbench train.py:133-135) is folded into the update: the norm pass, then Adam applies the coefficient
+        self.opt.step(grad_scale=self.grad_scale, clip_max_norm=self.clip)
 
     def _capture(self):
         # warm-up on a side stream (allocator + lazy initialisation), then restore the untouched state

@@ -149,6 +149,14 @@ int dlwp_error_moments(const float* out, const float* target, const float* clima
 int dlwp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int* step,
                    long long n, float lr, float beta1, float beta2, float eps, float grad_scale,
                    int zero_grad, void* stream);
+/* The same step with torch.nn.utils.clip_grad_norm_ folded in (dlwpbench scripts/train.py:133-135 clips at  */
+/* max_norm = learning rate before optimizer.step()): sumsq (device float, sum(g^2) of the UNSCALED gradient */
+/* as dlwp_sumsq leaves it; NULL = no clipping) gives the coefficient min(1, max_norm / (sqrt(*sumsq) *       */
+/* |grad_scale| + 1e-6)) that multiplies the gradient as Adam reads it -- the gradient buffer is not         */
+/* rewritten (no dlwp_clip_scale pass): use it when the clipped gradient itself is not needed afterwards.    */
+int dlwp_adam_step_clipped(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int* step,
+                           long long n, float lr, float beta1, float beta2, float eps, float grad_scale,
+                           int zero_grad, const float* sumsq, float max_norm, void* stream);
 /* out (device float) = sum(g^2)   (for clip_grad_norm_, train.py:123-125)                */
 int dlwp_sumsq(const float* g, long long n, float* out, void* stream);
 /* g *= min(1, max_norm / (sqrt(*sumsq * grad_scale^2) + 1e-6))  (torch clip_grad_norm_)  */
@@ -600,6 +608,12 @@ int dlwp_sht_analysis_bf16(const float* x, const void* A1, const void* A2, void*
                            int lmax, void* stream);
 int dlwp_sht_synthesis_bf16(const void* X, const void* S1t, const void* S2, const float* residual, float* x, int B, int nlat,
                             int nlon, int C, int mmax, int lmax, void* stream);
+/* The same with flags.  DLWP_SHT_TRIANGULAR: the caller guarantees X[l][.][m] = 0 for every order m > l (a spectrum that RealSHT  */
+/* produced, its image under the per-degree weights of dlwp_dhconv_apply, or the gradient of either): those entries are not     */
+/* read (48 % of the image at lmax = mmax = 32); with other spectra the flag gives wrong results.                               */
+#define DLWP_SHT_TRIANGULAR 1
+int dlwp_sht_synthesis_bf16_ex(const void* X, const void* S1t, const void* S2, const float* residual, float* x, int B, int nlat,
+                               int nlon, int C, int mmax, int lmax, int flags, void* stream);
 /* SFNO "driscoll-healy" spectral weights (torch_harmonics, constructed at                    */
 /* src/dlwpbench/models/fno/fno.py:183-200): w [Cin][Cout][L][2] complex, one matrix per       */
 /* degree l.  expand: wexp[l] = [[Wr, Wi], [-Wi, Wr]] as a real [2Cin][2Cout] matrix, so that   */

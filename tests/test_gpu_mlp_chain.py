@@ -66,13 +66,26 @@ def _images(L, dev, ws, w1, w2):
     return imgs
 
 
+@pytest.fixture
+def chain_mt(request):
+    """forces the tokens per workgroup of the C = 256 chain: 2 tiles (resident fragments) or 4 (fragment ring, the default from
+    16,384 tokens on)"""
+    from dlwp_benchmark_amd import lib as L
+    L.set_tuning("CHAIN_MT", request.param)
+    yield request.param
+    L.set_tuning("CHAIN_MT", None)
+
+
+@pytest.mark.parametrize("chain_mt", [2, 4], indirect=True)
 @pytest.mark.parametrize("T,C,Hd,outer", [(8192, 256, 512, 1), (1000, 256, 512, 0), (77, 64, 128, 1), (4096, 128, 256, 1),
-                                           (33, 256, 512, 1)])
-def test_tail_forward_and_backward_match_float64_with_the_kernels_rounding(cuda, T, C, Hd, outer):
+                                           (33, 256, 512, 1), (16421, 256, 512, 1)])
+def test_tail_forward_and_backward_match_float64_with_the_kernels_rounding(cuda, T, C, Hd, outer, chain_mt):
     from dlwp_benchmark_amd import lib as L
     from dlwp_benchmark_amd.token_ops import _TailBwdArgs, _TailFwdArgs
     import ctypes
     lib = L.load()
+    if C != 256 and chain_mt == 4:
+        pytest.skip("the fragment-ring kernel is instantiated for C = 256 only")
     assert lib.dlwp_mlp_chain_supported(C, Hd) == 1
     x, y, gout, ws, bs, w1, b1, w2, b2 = _tail_inputs(T, C, Hd, 11)
     d = lambda t: t.to(cuda).contiguous()

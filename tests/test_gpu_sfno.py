@@ -122,13 +122,17 @@ def test_bf16_fused_sht_kernels_equal_the_bf16_gemm_path(cuda, monkeypatch, nlat
 
 
 
+@pytest.mark.parametrize("variant", [{}, {"DHCONV_RC": 64}, {"DHCONV_APPLY": 1}], ids=["pipelined128", "pipelined64", "round4"])
 @pytest.mark.parametrize("B,M,L,Ci,Co,tri", [(4, 32, 32, 256, 256, True), (2, 16, 24, 128, 256, True), (3, 32, 20, 256, 128, False),
-                                              (5, 12, 12, 128, 128, True)])
-def test_native_dhconv_kernels_match_the_complex_einsum(cuda, B, M, L, Ci, Co, tri):
+                                              (5, 12, 12, 128, 128, True), (9, 32, 32, 128, 128, True), (1, 32, 32, 256, 256, True)])
+def test_native_dhconv_kernels_match_the_complex_einsum(cuda, B, M, L, Ci, Co, tri, variant):
     """csrc/dhconv.hip: forward, input gradient and the weight gradient over THREE applications in one scope (one segmented product)
     against the float64 complex einsum "bixy,iox->boxy" on bf16-rounded operands; triangular spectra (orders m > l zero, as RealSHT
-    produces them) with the skip on, dense spectra with it off, ragged row counts (partial 256-row chunks)."""
+    produces them) with the skip on, dense spectra with it off, ragged row counts (partial chunks), one to five chunks per
+    workgroup walk; every apply kernel variant (pipelined with 128- / 64-row chunks, the round-4 one-chunk kernel)."""
     from dlwp_benchmark_amd import lib as L_, sht
+    for k_, v_ in variant.items():
+        L_.set_tuning(k_, v_)
     g = torch.Generator().manual_seed(14)
     bf = torch.bfloat16
     w = (torch.randn(Ci, Co, L, 2, generator=g) / Ci ** 0.5)
@@ -150,6 +154,8 @@ def test_native_dhconv_kernels_match_the_complex_einsum(cuda, B, M, L, Ci, Co, t
         finally:
             L_.SHADOW_ACTIVE = False
             L_.set_storage("fp32")
+            for k_ in variant:
+                L_.set_tuning(k_, None)
     gw_ref = torch.zeros(Ci, Co, L, dtype=torch.complex128)
     for x, gy, y, xd in zip(Xs, gYs, ys, xs):
         xc = torch.complex(x[..., 0, :].double(), x[..., 1, :].double())                                    # [L, B, M, Ci]

@@ -165,3 +165,31 @@ def test_train_dlwp_with_fno_modules_reduces_loss(cuda):
         log = train_loop.train_dlwp(model, ds, ds, epochs=4, batch_size=4, learning_rate=2e-3, save_model=False)
         assert np.isfinite(log[-1]["train_mse"])
         assert log[-1]["train_mse"] < log[0]["train_mse"], (cls.__name__, log)
+
+
+def test_clip_folded_into_adam_matches_clip_then_step(cuda):
+    """FusedAdam.step(clip_max_norm=c) (dlwp_adam_step_clipped: the clipping coefficient applied while Adam reads the gradient)
+    against clip_grad_norm_() + step() and against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam
+    (dlwpbench scripts/train.py:133-136: max_norm = learning rate), with gradients both above and below the threshold."""
+    from dlwp_benchmark_amd.fno_engine import FusedAdam
+    g = torch.Generator().manual_seed(5)
+    n = 100003
+    for scale, grad_scale in ((1.0, 1.0), (1e-6, 1.0), (1.0, 0.5)):
+        p0 = torch.randn(n, generator=g).to(cuda)
+        gr = (torch.randn(n, generator=g) * scale).to(cuda)
+        a_p, a_g, b_p, b_g = p0.clone(), gr.clone(), p0.clone(), gr.clone()
+        a, b = FusedAdam(a_p, a_g, lr=1e-3), FusedAdam(b_p, b_g, lr=1e-3)
+        ref = torch.nn.Parameter(p0.clone())
+        opt = torch.optim.Adam([ref], lr=1e-3)
+        for _ in range(3):
+            a_g.copy_(gr)
+            b_g.copy_(gr)
+            a.step(grad_scale=grad_scale, clip_max_norm=1e-3)
+            b.clip_grad_norm_(1e-3, grad_scale=grad_scale)
+            b.step(grad_scale=grad_scale)
+            ref.grad = gr * grad_scale
+            torch.nn.utils.clip_grad_norm_([ref], 1e-3)
+            opt.step()
+        assert (a_g == 0).all()                                   # zero_grad semantics kept
+        assert (a_p - b_p).abs().max().item() <= 1e-6, (scale, grad_scale)
+        assert (a_p - ref.data).abs().max().item() <= 2e-6, (scale, grad_scale)
