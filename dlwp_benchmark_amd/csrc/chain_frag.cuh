@@ -84,4 +84,111 @@ __device__ __forceinline__ void img_store(__bf16* img, int row, int n, bf16x4 v)
     *reinterpret_cast<bf16x4*>(img + img_off<LROW>(row, n)) = v;
 }
 
+// ---- 16-byte epilogue pieces.  An accumulator lane (r, g) owns FOUR consecutive features of token r: 8-byte bf16 pieces, and the
+// epilogues of these chains are bound by the ISSUE of their stores (stamps: 64 KB of 8-byte stores per 32-token workgroup take
+// 9 - 10 k cycles, ~7 B / cycle / CU, whatever the memory system does).  v_permlane16_swap_b32 (gfx950) exchanges the odd 16-lane
+// rows of one register with the even rows of another: applied to the packed pieces of TWO token tiles (same features) it leaves
+// every lane with EIGHT consecutive features of one token -- lanes of even g: features 4 g .. 4 g + 7 of tile `mi`, lanes of odd g:
+// features 4 (g - 1) .. 4 g + 3 of tile `mi + 1` -- i.e. half as many, 16-byte, store instructions (global and LDS).
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 pair_rows(bf16x4 lo_tile, bf16x4 hi_tile) {
+    const u32x2 a = __builtin_bit_cast(u32x2, lo_tile), b = __builtin_bit_cast(u32x2, hi_tile);
+    const u32x2 s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+    return __builtin_bit_cast(bf16x8, (u32x4{s0[0], s1[0], s0[1], s1[1]}));
+}
+// after pair_rows on tiles (mi, mi + 1) of n-tile `tile`: the token row (inside the workgroup's tile) and first feature of this lane's piece
+__device__ __forceinline__ int pair_row(int mi, int r, int g) { return 16 * (mi + (g & 1)) + r; }
+__device__ __forceinline__ int pair_col(int tile, int g) { return 16 * tile + 8 * (g >> 1); }
+template <int LROW>
+__device__ __forceinline__ void img_store8(__bf16* img, int row, int n, bf16x8 v) {          // n % 8 == 0: one whole 16-byte chunk
+    const int c = n >> 3;
+    *reinterpret_cast<bf16x8*>(img + row * LROW + 8 * (c ^ (row & cmask<LROW>(c)))) = v;
+}
+
+// Epilogue of a hidden stage: activation (forward: GELU(acc + add); backward: acc * d) into the next stage's LDS image and to
+// global memory (`gact`); the forward pass stores d = GELU'(acc + add) to `gz` -- evaluated together with the activation from the
+// fp32 pre-activation (three more instructions), so that the backward pass multiplies by a stored factor instead of evaluating
+// an exponential and a reciprocal per element (its epilogues were VALU-bound on exactly that); the backward product also goes
+// out in fp32 to `gf32` (nullable).
+// add(mi, ni): the forward addend of tile (mi, ni) (bias, or bias + a per-token term)
+template <int MT, int NT, int N, int NTL, bool BWD, class AddFn>
+__device__ __forceinline__ void chain_epilogue(const f32x4 (&acc)[MT][NT], AddFn add, const bf16x4 (&ez)[MT][NT],
+                                               __bf16* img, __bf16* gact, __bf16* gz, float* gf32, int m0, int T, int w, int r, int g) {
+    static_assert(MT % 2 == 0, "token tiles are paired for the 16-byte stores");
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+        const int tile = w + 8 * ni;
+        if (tile < NTL) {
+#pragma unroll
+            for (int mp = 0; mp < MT; mp += 2) {
+                bf16x4 ab[2], zb[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int mi = mp + h;
+                    float d[4], act[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (BWD) {
+                            d[q] = 0.f;
+                            act[q] = acc[mi][ni][q] * (float)ez[mi][ni][q];
+                        } else {
+                            gelu_both(acc[mi][ni][q] + add(mi, ni)[q], act[q], d[q]);
+                        }
+                    }
+                    ab[h] = to_bf4(act);
+                    zb[h] = to_bf4(d);
+                    if (BWD && gf32) {
+                        const long long m = m0 + 16 * mi + r;
+                        if (m < T) *reinterpret_cast<f32x4*>(gf32 + m * N + 16 * tile + 4 * g) = f32x4{act[0], act[1], act[2], act[3]};
+                    }
+                }
+                const bf16x8 a8 = pair_rows(ab[0], ab[1]);
+                const int row = pair_row(mp, r, g), n = pair_col(tile, g);
+                const long long m = m0 + row;
+                img_store8<N>(img, row, n, a8);
+                if (m < T) *reinterpret_cast<bf16x8*>(gact + m * N + n) = a8;
+                if (!BWD) {
+                    const bf16x8 z8 = pair_rows(zb[0], zb[1]);
+                    if (m < T) *reinterpret_cast<bf16x8*>(gz + m * N + n) = z8;
+                }
+                // one tile pair at a time: left to itself the scheduler evaluates every GELU of the stage before the first store
+                // (128 more live registers at MT = 4: 156 bytes of scratch per lane)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+// Input tile [ROWS][K] fp32 -> swizzled bf16 LDS image (+ the bf16 copy a weight-gradient product reads), eight features per thread
+// and piece: 32-byte loads, 16-byte LDS / global stores
+template <int ROWS, int K>
+struct InTile {
+    static constexpr int XU = (ROWS * K / 8 + 511) / 512;
+    float4 lo[XU], hi[XU];
+    __device__ __forceinline__ void issue(const float* __restrict__ in, int m0, int T, int tid) {
+#pragma unroll
+        for (int i = 0; i < XU; ++i) {
+            const int u = min(tid + 512 * i, ROWS * K / 8 - 1), row = u / (K / 8), c8 = u - row * (K / 8);
+            const float4* p = reinterpret_cast<const float4*>(in + (long long)min(m0 + row, T - 1) * K + 8 * c8);
+            lo[i] = p[0];
+            hi[i] = p[1];
+        }
+    }
+    __device__ __forceinline__ void commit(__bf16* img, __bf16* in_lp, int m0, int T, int tid) const {
+#pragma unroll
+        for (int i = 0; i < XU; ++i) {
+            const int u = tid + 512 * i;
+            if (u < ROWS * K / 8) {
+                const int row = u / (K / 8), k = 8 * (u - row * (K / 8));
+                const bf16x8 b = bf16x8{(__bf16)lo[i].x, (__bf16)lo[i].y, (__bf16)lo[i].z, (__bf16)lo[i].w,
+                                        (__bf16)hi[i].x, (__bf16)hi[i].y, (__bf16)hi[i].z, (__bf16)hi[i].w};
+                img_store8<K>(img, row, k, b);
+                if (in_lp && m0 + row < T) *reinterpret_cast<bf16x8*>(in_lp + (long long)(m0 + row) * K + k) = b;
+            }
+        }
+    }
+};
+
 }  // namespace chainfrag

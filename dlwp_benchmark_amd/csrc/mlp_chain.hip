@@ -99,13 +99,8 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainDev a) {
     DLWP_STAMP(0);
 
     // ---- requests of the prologue, oldest first: input tile, stage-1 weights, stage-1 epilogue operands, first half of stage 2
-    constexpr int XU = (ROWS * K1 / 4 + 511) / 512;
-    float4 xv[XU];
-#pragma unroll
-    for (int i = 0; i < XU; ++i) {
-        const int u = min(tid + 512 * i, ROWS * K1 / 4 - 1), row = u / (K1 / 4), c4 = u - row * (K1 / 4);
-        xv[i] = *reinterpret_cast<const float4*>(a.in + (long long)min(m0 + row, a.T - 1) * K1 + 4 * c4);
-    }
+    InTile<ROWS, K1> xin;
+    xin.issue(a.in, m0, a.T, tid);
     WFrag<NT1, KH1> w1a, w1b;
     wload<NT1, KS1, KH1, NTL1>(w1a, a.w1, w, lane, 0);
     wload<NT1, KS1, KH1, NTL1>(w1b, a.w1, w, lane, KH1);
@@ -119,6 +114,8 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainDev a) {
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
             const long long m = min(m0 + 16 * mi + r, a.T - 1);
+            e1z[mi][ni] = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+            e1f[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (BWD) e1z[mi][ni] = *reinterpret_cast<const bf16x4*>(a.zin1 + m * N1 + n);
             else e1f[mi][ni] = *reinterpret_cast<const f32x4*>(a.res1 + m * N1 + n) + bb;
         }
@@ -128,17 +125,7 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainDev a) {
     if (EARLY2) wload<NT2, KS2, KH2, NTL2>(w2a, a.w2, w, lane, 0);
 
     // ---- input tile -> bf16 image (and the bf16 copy for the weight-gradient product)
-#pragma unroll
-    for (int i = 0; i < XU; ++i) {
-        const int u = tid + 512 * i;
-        if (u < ROWS * K1 / 4) {
-            const int row = u / (K1 / 4), k = 4 * (u - row * (K1 / 4));
-            const float v[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
-            const bf16x4 b = to_bf4(v);
-            img_store<K1>(img0, row, k, b);
-            if (a.in_lp && m0 + row < a.T) *reinterpret_cast<bf16x4*>(a.in_lp + (long long)(m0 + row) * K1 + k) = b;
-        }
-    }
+    xin.commit(img0, a.in_lp, m0, a.T, tid);
     DLWP_STAMP(1);
     lds_barrier();
     DLWP_STAMP(2);
@@ -158,40 +145,14 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainDev a) {
         const int n = 16 * min(w + 8 * ni, NTL2 - 1) + 4 * g;
         e2b[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!BWD) e2b[ni] = *reinterpret_cast<const f32x4*>(a.b2 + n);
-        if (BWD) {
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-                e2z[mi][ni] = *reinterpret_cast<const bf16x4*>(a.zin2 + (long long)min(m0 + 16 * mi + r, a.T - 1) * N2 + n);
+        for (int mi = 0; mi < MT; ++mi) {
+            e2z[mi][ni] = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+            if (BWD) e2z[mi][ni] = *reinterpret_cast<const bf16x4*>(a.zin2 + (long long)min(m0 + 16 * mi + r, a.T - 1) * N2 + n);
         }
     }
     wload<NT2, KS2, KH2, NTL2>(w2b, a.w2, w, lane, KH2);
-#pragma unroll
-    for (int ni = 0; ni < NT1; ++ni) {
-        const int tile = w + 8 * ni, n = 16 * tile + 4 * g;
-        if (tile < NTL1) {
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi) {
-                const int row = 16 * mi + r;
-                const long long m = m0 + row;
-                float v[4], act[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (BWD) {
-                        act[q] = acc1[mi][ni][q] * gelu_grad_f((float)e1z[mi][ni][q]);
-                    } else {
-                        v[q] = acc1[mi][ni][q] + e1f[mi][ni][q];
-                        act[q] = gelu_f(v[q]);
-                    }
-                }
-                const bf16x4 ab = to_bf4(act);
-                img_store<N1>(img1, row, n, ab);
-                if (m < a.T) {
-                    *reinterpret_cast<bf16x4*>(a.a1 + m * N1 + n) = ab;
-                    if (!BWD) *reinterpret_cast<bf16x4*>(a.z1 + m * N1 + n) = to_bf4(v);
-                }
-            }
-        }
-    }
+    chain_epilogue<MT, NT1, N1, NTL1, BWD>(acc1, [&](int mi, int ni) { return e1f[mi][ni]; }, e1z, img1, a.a1, a.z1, nullptr, m0, a.T, w, r, g);
     DLWP_STAMP(4);
     lds_barrier();
     DLWP_STAMP(5);
@@ -216,34 +177,7 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainDev a) {
     }
     wload<NT3, KS3, KH3, NTL3>(w3a, a.w3, w, lane, 0);
     wload<NT3, KS3, KH3, NTL3>(w3b, a.w3, w, lane, KH3);
-#pragma unroll
-    for (int ni = 0; ni < NT2; ++ni) {
-        const int tile = w + 8 * ni, n = 16 * tile + 4 * g;
-        if (tile < NTL2) {
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi) {
-                const int row = 16 * mi + r;
-                const long long m = m0 + row;
-                float v[4], act[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (BWD) {
-                        act[q] = acc2[mi][ni][q] * gelu_grad_f((float)e2z[mi][ni][q]);
-                    } else {
-                        v[q] = acc2[mi][ni][q] + e2b[ni][q];
-                        act[q] = gelu_f(v[q]);
-                    }
-                }
-                const bf16x4 ab = to_bf4(act);
-                img_store<N2>(img2, row, n, ab);
-                if (m < a.T) {
-                    *reinterpret_cast<bf16x4*>(a.a2 + m * N2 + n) = ab;
-                    if (BWD) *reinterpret_cast<f32x4*>(a.a2f + m * N2 + n) = f32x4{act[0], act[1], act[2], act[3]};
-                    else *reinterpret_cast<bf16x4*>(a.z2 + m * N2 + n) = to_bf4(v);
-                }
-            }
-        }
-    }
+    chain_epilogue<MT, NT2, N2, NTL2, BWD>(acc2, [&](int, int ni) { return e2b[ni]; }, e2z, img2, a.a2, a.z2, BWD ? a.a2f : nullptr, m0, a.T, w, r, g);
     DLWP_STAMP(7);
     lds_barrier();
     DLWP_STAMP(8);
@@ -272,222 +206,11 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainDev a) {
 #endif
 }
 
-// ---- Round 5: the same chain for MANY tokens (B = 16: 32,768 per launch).  mlp_chain_kernel streams all 655 KB of weight
-// fragments from L2 once per 32-token workgroup: at 1,024 workgroups that is 671 MB of L2 -> register traffic per launch, and the
-// launch ran at that rate (76 us, profiles/r05_sfno_b16_before_kernel_stats.csv).  64 tokens per workgroup halve it, but with a
-// whole stage's fragments resident (the structure above) MT = 4 needs 176 - 252 bytes of scratch per lane.  Here the fragments of
-// a stage pass through a register RING of D k-steps: a k-step's NT fragments are requested D k-steps before their MFMAs (each
-// k-step now carries MT x NT = 8 - 16 MFMAs, i.e. 256 - 512 cycles per SIMD, so a short ring covers the L2 latency), the next
-// stage's ring is primed before the current stage's epilogue, and the accumulators of the widest stage (64 registers) fit.
-template <int NT, int KS, int NTL>
-__device__ __forceinline__ void wfetch(bf16x8 (&dst)[NT], const __bf16* __restrict__ img, int w, int lane, int kk) {
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni) {
-        const int tile = min(w + 8 * ni, NTL - 1);
-        dst[ni] = *reinterpret_cast<const bf16x8*>(img + ((long long)(tile * KS + kk) * 64 + lane) * 8);
-    }
-}
-
-template <int MT, int NT, int KS, int LROW, int D, int NTL>
-__device__ __forceinline__ void mma_stream(f32x4 (&acc)[MT][NT], bf16x8 (&ring)[D][NT], const __bf16* __restrict__ wimg, const __bf16* lds,
-                                           int w, int lane, int r, int g) {
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-        bf16x8 tf[MT];
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-            const int row = 16 * mi + r, c0 = 4 * kk + g, c = c0 ^ (row & cmask<LROW>(c0));
-            tf[mi] = *reinterpret_cast<const bf16x8*>(lds + row * LROW + 8 * c);
-        }
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[kk % D][ni], tf[mi], acc[mi][ni], 0, 0, 0);
-        if (kk + D < KS) wfetch<NT, KS, NTL>(ring[kk % D], wimg, w, lane, kk + D);
-    }
-}
-
-template <int K1, int N1, int N2, int N3, int MT, bool BWD>
-__global__ __launch_bounds__(512) void mlp_chain_stream_kernel(ChainDev a) {
-    constexpr int ROWS = 16 * MT;
-    constexpr int KS1 = K1 / 32, KS2 = N1 / 32, KS3 = N2 / 32;
-    constexpr int NTL1 = N1 / 16, NTL2 = N2 / 16, NTL3 = N3 / 16;
-    constexpr int NT1 = (NTL1 + 7) / 8, NT2 = (NTL2 + 7) / 8, NT3 = (NTL3 + 7) / 8;
-    // (backward: 36 B of scratch per lane with 6-deep rings; at 4 two address pairs are spilled in the prologue and reloaded once)
-    constexpr auto depth = [](int nt, int ks) { const int d = (nt >= 4 || BWD) ? 4 : 6; return d < ks ? d : ks; };
-    constexpr int D1 = depth(NT1, KS1), D2 = depth(NT2, KS2), D3 = depth(NT3, KS3);         // ring depths (k-steps): <= 64 registers each
-    static_assert(K1 % 64 == 0 && N1 % 64 == 0 && N2 % 64 == 0 && N3 % 16 == 0, "stage widths");
-    static_assert(KS1 >= D1 && KS2 >= D2 && KS3 >= D3, "a ring must not be deeper than its stage");
-    extern __shared__ __attribute__((aligned(16))) float chain_smem[];
-    __bf16* img0 = reinterpret_cast<__bf16*>(chain_smem);                   // [ROWS][K1]  stage-1 input
-    __bf16* img1 = img0 + ROWS * K1;                                        // [ROWS][N1]  stage-1 output
-    __bf16* img2 = img1 + ROWS * N1;                                        // [ROWS][N2]  stage-2 output
-    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
-    const int w = ((tid >> 6) + (a.rot ? (int)(blockIdx.x >> 3) : 0)) & 7;
-    const int m0 = blockIdx.x * ROWS;
-
-    // ---- prologue requests, oldest first: input tile, the first ring, stage-1 epilogue operands
-    constexpr int XU = (ROWS * K1 / 4 + 511) / 512;
-    float4 xv[XU];
-#pragma unroll
-    for (int i = 0; i < XU; ++i) {
-        const int u = min(tid + 512 * i, ROWS * K1 / 4 - 1), row = u / (K1 / 4), c4 = u - row * (K1 / 4);
-        xv[i] = *reinterpret_cast<const float4*>(a.in + (long long)min(m0 + row, a.T - 1) * K1 + 4 * c4);
-    }
-    bf16x8 ring1[D1][NT1];
-#pragma unroll
-    for (int i = 0; i < D1; ++i) wfetch<NT1, KS1, NTL1>(ring1[i], a.w1, w, lane, i);
-    f32x4 e1f[MT][NT1];           // forward: y + bias
-    bf16x4 e1z[MT][NT1];          // backward: z1
-#pragma unroll
-    for (int ni = 0; ni < NT1; ++ni) {
-        const int n = 16 * min(w + 8 * ni, NTL1 - 1) + 4 * g;
-        f32x4 bb = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!BWD) bb = *reinterpret_cast<const f32x4*>(a.b1 + n);
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-            const long long m = min(m0 + 16 * mi + r, a.T - 1);
-            if (BWD) e1z[mi][ni] = *reinterpret_cast<const bf16x4*>(a.zin1 + m * N1 + n);
-            else e1f[mi][ni] = *reinterpret_cast<const f32x4*>(a.res1 + m * N1 + n) + bb;
-        }
-    }
-    // ---- input tile -> bf16 image (and the bf16 copy for the weight-gradient product)
-#pragma unroll
-    for (int i = 0; i < XU; ++i) {
-        const int u = tid + 512 * i;
-        if (u < ROWS * K1 / 4) {
-            const int row = u / (K1 / 4), k = 4 * (u - row * (K1 / 4));
-            const float v[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
-            const bf16x4 b = to_bf4(v);
-            img_store<K1>(img0, row, k, b);
-            if (a.in_lp && m0 + row < a.T) *reinterpret_cast<bf16x4*>(a.in_lp + (long long)(m0 + row) * K1 + k) = b;
-        }
-    }
-    lds_barrier();
-
-    // ---- stage 1
-    f32x4 acc1[MT][NT1];
-    zero_acc<MT, NT1>(acc1);
-    mma_stream<MT, NT1, KS1, K1, D1, NTL1>(acc1, ring1, a.w1, img0, w, lane, r, g);
-    // stage 2's ring and epilogue operands go out before this stage's epilogue
-    bf16x8 ring2[D2][NT2];
-#pragma unroll
-    for (int i = 0; i < D2; ++i) wfetch<NT2, KS2, NTL2>(ring2[i], a.w2, w, lane, i);
-    f32x4 e2b[NT2];
-    bf16x4 e2z[MT][NT2];
-#pragma unroll
-    for (int ni = 0; ni < NT2; ++ni) {
-        const int n = 16 * min(w + 8 * ni, NTL2 - 1) + 4 * g;
-        e2b[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!BWD) e2b[ni] = *reinterpret_cast<const f32x4*>(a.b2 + n);
-        if (BWD) {
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-                e2z[mi][ni] = *reinterpret_cast<const bf16x4*>(a.zin2 + (long long)min(m0 + 16 * mi + r, a.T - 1) * N2 + n);
-        }
-    }
-#pragma unroll
-    for (int ni = 0; ni < NT1; ++ni) {
-        const int tile = w + 8 * ni, n = 16 * tile + 4 * g;
-        if (tile < NTL1) {
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi) {
-                const int row = 16 * mi + r;
-                const long long m = m0 + row;
-                float v[4], act[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (BWD) {
-                        act[q] = acc1[mi][ni][q] * gelu_grad_f((float)e1z[mi][ni][q]);
-                    } else {
-                        v[q] = acc1[mi][ni][q] + e1f[mi][ni][q];
-                        act[q] = gelu_f(v[q]);
-                    }
-                }
-                const bf16x4 ab = to_bf4(act);
-                img_store<N1>(img1, row, n, ab);
-                if (m < a.T) {
-                    *reinterpret_cast<bf16x4*>(a.a1 + m * N1 + n) = ab;
-                    if (!BWD) *reinterpret_cast<bf16x4*>(a.z1 + m * N1 + n) = to_bf4(v);
-                }
-            }
-        }
-    }
-    lds_barrier();
-
-    // ---- stage 2
-    f32x4 acc2[MT][NT2];
-    zero_acc<MT, NT2>(acc2);
-    mma_stream<MT, NT2, KS2, N1, D2, NTL2>(acc2, ring2, a.w2, img1, w, lane, r, g);
-    bf16x8 ring3[D3][NT3];
-#pragma unroll
-    for (int i = 0; i < D3; ++i) wfetch<NT3, KS3, NTL3>(ring3[i], a.w3, w, lane, i);
-    f32x4 e3f[MT][NT3];           // bias (+ outer skip)
-#pragma unroll
-    for (int ni = 0; ni < NT3; ++ni) {
-        const int n = 16 * min(w + 8 * ni, NTL3 - 1) + 4 * g;
-        f32x4 bb = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!BWD) bb = *reinterpret_cast<const f32x4*>(a.b3 + n);
-        const float so = a.outer ? 1.f : 0.f;
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-            e3f[mi][ni] = bb + so * *reinterpret_cast<const f32x4*>(a.in + (long long)min(m0 + 16 * mi + r, a.T - 1) * K1 + n);
-    }
-#pragma unroll
-    for (int ni = 0; ni < NT2; ++ni) {
-        const int tile = w + 8 * ni, n = 16 * tile + 4 * g;
-        if (tile < NTL2) {
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi) {
-                const int row = 16 * mi + r;
-                const long long m = m0 + row;
-                float v[4], act[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (BWD) {
-                        act[q] = acc2[mi][ni][q] * gelu_grad_f((float)e2z[mi][ni][q]);
-                    } else {
-                        v[q] = acc2[mi][ni][q] + e2b[ni][q];
-                        act[q] = gelu_f(v[q]);
-                    }
-                }
-                const bf16x4 ab = to_bf4(act);
-                img_store<N2>(img2, row, n, ab);
-                if (m < a.T) {
-                    *reinterpret_cast<bf16x4*>(a.a2 + m * N2 + n) = ab;
-                    if (BWD) *reinterpret_cast<f32x4*>(a.a2f + m * N2 + n) = f32x4{act[0], act[1], act[2], act[3]};
-                    else *reinterpret_cast<bf16x4*>(a.z2 + m * N2 + n) = to_bf4(v);
-                }
-            }
-        }
-    }
-    lds_barrier();
-
-    // ---- stage 3
-    f32x4 acc3[MT][NT3];
-    zero_acc<MT, NT3>(acc3);
-    mma_stream<MT, NT3, KS3, N2, D3, NTL3>(acc3, ring3, a.w3, img2, w, lane, r, g);
-#pragma unroll
-    for (int ni = 0; ni < NT3; ++ni) {
-        const int tile = w + 8 * ni, n = 16 * tile + 4 * g;
-        if (tile < NTL3) {
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi) {
-                const long long m = m0 + 16 * mi + r;
-                if (m < a.T) *reinterpret_cast<f32x4*>(a.out + m * N3 + n) = acc3[mi][ni] + e3f[mi][ni];
-            }
-        }
-    }
-}
-
 template <int C, int HD, int MT, bool BWD>
 int chain_launch(const ChainDev& a, hipStream_t s) {
     constexpr int K1 = C, N1 = BWD ? HD : C, N2 = BWD ? C : HD, N3 = C;
     const size_t lds = (size_t)16 * MT * (K1 + N1 + N2) * sizeof(__bf16);
-    void (*kern)(ChainDev);
-    if constexpr (MT >= 4) kern = mlp_chain_stream_kernel<K1, N1, N2, N3, MT, BWD>;
-    else kern = mlp_chain_kernel<K1, N1, N2, N3, MT, BWD>;
+    auto kern = mlp_chain_kernel<K1, N1, N2, N3, MT, BWD>;
     int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(kern), lds, "mlp_chain");
     if (rc) return rc;
     ChainDev b = a;
@@ -499,11 +222,7 @@ int chain_launch(const ChainDev& a, hipStream_t s) {
 
 template <bool BWD>
 int chain_dispatch(const ChainDev& a, int C, int HD, hipStream_t s) {
-    if (C == 256 && HD == 512) {
-        // 64 tokens per workgroup (half the weight stream per token) once that still gives every CU a workgroup
-        const int mt = dlwp_tune_or("CHAIN_MT", a.T >= 16384 ? 4 : 2);
-        return mt >= 4 ? chain_launch<256, 512, 4, BWD>(a, s) : chain_launch<256, 512, 2, BWD>(a, s);
-    }
+    if (C == 256 && HD == 512) return chain_launch<256, 512, 2, BWD>(a, s);
     if (C == 128 && HD == 256) return chain_launch<128, 256, 2, BWD>(a, s);
     if (C == 64 && HD == 128) return chain_launch<64, 128, 2, BWD>(a, s);
     dlwp_set_error("mlp_chain: no kernel for C = %d, hidden = %d (dlwp_mlp_chain_supported)", C, HD);

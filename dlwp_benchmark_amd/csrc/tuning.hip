@@ -53,7 +53,6 @@ Knob g_knobs[] = {
     {"FFT_IBH", "inner lanes of the H-axis FFT pass", 0, false},
     {"DHCONV_APPLY", "1: the round-4 spectral-convolution kernel (one 256-row chunk per workgroup) instead of the pipelined one", 0, false},
     {"DHCONV_RC", "rows per chunk of the pipelined spectral-convolution kernel: 64 or 128 (default 128)", 0, false},
-    {"CHAIN_MT", "token tiles (of 16) per workgroup of the C = 256 MLP chain: 2 (resident fragments) or 4 (fragment ring); default by token count", 0, false},
     {"CHAIN_ROT", "0: no rotation of the wave -> feature-tile assignment in the one-launch MLP chains (default 1)", 0, false},
 };
 constexpr int NKNOBS = sizeof(g_knobs) / sizeof(g_knobs[0]);

@@ -655,6 +655,10 @@ int dlwp_dhconv_fold(const float* G, float* gw, int Cin, int Cout, int L, void* 
 /* Tokens are rows: x, y, out, g, gt, gx [T][C] fp32; z0, t [T][C] and z1, h, gh [T][hidden]    */
 /* bf16 arrays; x_lp / g_lp (nullable) and gt_lp receive bf16 copies of x / g / gt for the       */
 /* weight-gradient products.  Arithmetic: bf16 operands, fp32 accumulation and epilogues.        */
+/* Round 5: the arrays the argument structs call z0 / z1 hold the DERIVATIVES GELU'(z0) and      */
+/* GELU'(z1), evaluated by the forward call from the fp32 pre-activations together with the      */
+/* activations; the backward call multiplies by them (no exponential / reciprocal per element    */
+/* there).  They are opaque to the caller: forward output, backward input.                        */
 /* The six weight matrices are read from fragment-order bf16 images built by                    */
 /* dlwp_mlp_chain_pack: image of W' [rows][cols] with W' = W (transpose 0, W row-major           */
 /* [rows][cols]) or W^T (transpose 1, W row-major [cols][rows]); rows % 16 == 0, cols % 32 == 0, */
@@ -667,14 +671,14 @@ typedef struct dlwp_sfno_tail_fwd_args {
     const void *ws_img, *w1_img, *w2_img;   /* dlwp_mlp_chain_pack images */
     const float *bs, *b1, *b2;              /* [C], [hidden], [C]; nullable */
     void *x_lp;                             /* [T][C] bf16, nullable */
-    void *z0, *t, *z1, *h;                  /* bf16 outputs */
+    void *z0, *t, *z1, *h;                  /* bf16 outputs: GELU'(z0) [T][C], t [T][C], GELU'(z1) [T][hidden], h [T][hidden] */
     float *out;                             /* [T][C] */
     int T, C, hidden, outer;
 } dlwp_sfno_tail_fwd_args;
 typedef struct dlwp_sfno_tail_bwd_args {
     const float *g;                         /* [T][C] */
     const void *w2t_img, *w1t_img, *wst_img;
-    const void *z1, *z0;                    /* bf16 pre-activations saved by the forward call */
+    const void *z1, *z0;                    /* the forward call's z1 / z0 arrays (activation derivatives, bf16) */
     void *g_lp;                             /* [T][C] bf16, nullable */
     void *gh;                               /* [T][hidden] bf16 */
     float *gt;                              /* [T][C] */
