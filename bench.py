@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="fno workload at N=1: do not append the short SFNO (configs[2]) run "
                     "as the line's \"secondary\" object")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-clip", action="store_true", help="dlwpbench workloads: no gradient clipping (the reference's training protocol "
+                    "clips at max_norm = learning rate before every optimizer step: src/dlwpbench/configs/training/default.yaml:3, "
+                    "scripts/train.py:133-135; on by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
@@ -257,7 +260,9 @@ SFNO_WORKLOAD = dict(name="dlwpbench SFNO2DModule 32x64 WeatherBench shapes (BAS
 # BASELINE configs[3] and [4] as further --workload choices (supplementary lines: the headline is configs[1]).  model kwargs are the
 # shipped dlwpbench YAMLs at the grids BASELINE names; one lead time per step (sequence length 2), as the dlwpbench training runs.
 DLWP_WORKLOADS = {
-    "sfno": dict(cls="SFNO2DModule", name=SFNO_WORKLOAD["name"], model=SFNO_WORKLOAD["model"], T=5, H=32, W=64, Cg=5, batch=4,
+    # per-GPU batch 16 = the reference's own batch_size (src/dlwpbench/configs/training/default.yaml:4); --batch 4 --no-clip is the
+    # round 1 - 4 line
+    "sfno": dict(cls="SFNO2DModule", name=SFNO_WORKLOAD["name"], model=SFNO_WORKLOAD["model"], T=5, H=32, W=64, Cg=5, batch=16,
                  storage="bf16", gemm=(32 * 64, 512, 256), metric="train samples/sec (SFNO 32x64 rollout step: fwd + MSE + backward + Adam)"),
     "pangu": dict(cls="PanguWeather", name="dlwpbench PanguWeather 128x256 window (2,7,7) (BASELINE configs[3])",
                   model=dict(constant_channels=4, prescribed_channels=1, prognostic_channels=8, embed_dim=192, num_heads=(6, 12, 12, 6),
@@ -326,15 +331,45 @@ def sfno_gemm_probe(device, B, precision, reps=100, storage="fp32", shape=(32 * 
     return out
 
 
-def sfno_tail_probe(device, B, reps=100, tokens_per_sample=32 * 64, C=256, hidden=512):
-    """Dominant kernel family of the SFNO step since round 4 (rocprof: mlp_chain_kernel, forward + backward 22 % of the step): the
-    block tail's forward launch (dlwp_sfno_tail_fwd: inner skip + GELU + fc1 + GELU + fc2 + outer skip over B * 2048 tokens), timed
-    with HIP events on its launch stream.  Algorithmic bytes = x, y read and out written in fp32, the five bf16 tensors kept for the
-    backward pass (x copy, z0, t, z1, h) written once, the three weight matrices read once; flops = the three products."""
+def _time_on_stream(launch, reps):
+    """Average duration of `launch(stream_handle)` over `reps` back-to-back calls, HIP events on the launch stream."""
+    import torch
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        for _ in range(10):
+            launch(stream.cuda_stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(reps):
+            launch(stream.cuda_stream)
+        e1.record(stream)
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def _both_roofs(kernel, flops, nbytes, sec, traffic=None):
+    peak = PEAK_MFMA_TF["bf16"]
+    f_mfma, f_hbm = flops / sec / 1e12 / peak, nbytes / sec / 1e9 / PEAK_HBM_GBS
+    out = {"bound": "mfma" if f_mfma >= f_hbm else "hbm", "kernel": kernel, "flops_per_launch": flops, "bytes_per_launch": nbytes,
+           "us_per_launch": round(sec * 1e6, 3), "traffic": traffic,
+           "mfma": {"achieved": round(flops / sec / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(f_mfma, 4)},
+           "hbm": {"achieved": round(nbytes / sec / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(f_hbm, 4)}}
+    out.update(out[out["bound"]])          # the contract's achieved / peak / unit / frac = the roof that binds
+    return out
+
+
+def sfno_tail_probe(device, B, reps=100, tokens_per_sample=32 * 64, C=256, hidden=512, backward=False):
+    """The SFNO block tail (rocprof: mlp_chain_kernel, forward + backward 25 - 32 % of the step): one launch of dlwp_sfno_tail_fwd
+    (inner skip + GELU + fc1 + GELU + fc2 + outer skip over B * 2048 tokens) or of dlwp_sfno_tail_bwd, timed with HIP events on its
+    launch stream.  Algorithmic bytes forward = x, y read and out written in fp32, the five bf16 tensors kept for the backward
+    pass (x copy, GELU'(z0), t, GELU'(z1), h) written once, the three weight matrices read once; backward = g read, gt and gx
+    written in fp32, the two stored derivatives read, g / gh / gt bf16 copies written; flops = the three products."""
     import ctypes as C_
     import torch
     from dlwp_benchmark_amd import lib as L
-    from dlwp_benchmark_amd.token_ops import _TailFwdArgs
+    from dlwp_benchmark_amd.token_ops import _TailBwdArgs, _TailFwdArgs
     lib = L.load()
     T, bf = B * tokens_per_sample, torch.bfloat16
     g = torch.Generator().manual_seed(0)
@@ -345,37 +380,101 @@ def sfno_tail_probe(device, B, reps=100, tokens_per_sample=32 * 64, C=256, hidde
     L.check(lib.dlwp_sfno_tail_pack(L.ptr(ws), L.ptr(w1), L.ptr(w2), C, hidden, L.ptr(imgs), L.stream()))
     e = lambda n, dt=bf: torch.empty(T, n, device=device, dtype=dt)
     x_lp, z0, t, z1, h, out = e(C), e(C), e(C), e(hidden), e(hidden), e(C, torch.float32)
-    a = _TailFwdArgs(L.ptr(x), L.ptr(y), L.ptr(imgs[0]), L.ptr(imgs[1]), L.ptr(imgs[2]), L.ptr(bs), L.ptr(b1), L.ptr(b2), L.ptr(x_lp),
-                     L.ptr(z0), L.ptr(t), L.ptr(z1), L.ptr(h), L.ptr(out), T, C, hidden, 1)
-    torch.cuda.synchronize()
-    stream = torch.cuda.Stream()
-    with torch.cuda.stream(stream):
-        for _ in range(10):
-            L.check(lib.dlwp_sfno_tail_fwd(C_.byref(a), stream.cuda_stream))
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record(stream)
-        for _ in range(reps):
-            L.check(lib.dlwp_sfno_tail_fwd(C_.byref(a), stream.cuda_stream))
-        e1.record(stream)
-        torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    fa = _TailFwdArgs(L.ptr(x), L.ptr(y), L.ptr(imgs[0]), L.ptr(imgs[1]), L.ptr(imgs[2]), L.ptr(bs), L.ptr(b1), L.ptr(b2), L.ptr(x_lp),
+                      L.ptr(z0), L.ptr(t), L.ptr(z1), L.ptr(h), L.ptr(out), T, C, hidden, 1)
+    L.check(lib.dlwp_sfno_tail_fwd(C_.byref(fa), L.stream()))          # (the backward probe reads the derivatives this call stores)
     flops = 2.0 * T * (C * C + 2 * C * hidden)
-    nbytes = float(T * C * (4 + 4 + 4) + T * C * 2 * 3 + T * hidden * 2 * 2 + 2 * (C * C + 2 * C * hidden) + 4 * (2 * C + hidden))
-    peak = PEAK_MFMA_TF["bf16"]
-    f_mfma, f_hbm = flops / sec / 1e12 / peak, nbytes / sec / 1e9 / PEAK_HBM_GBS
-    out_ = {"bound": "mfma" if f_mfma >= f_hbm else "hbm",
-            "kernel": f"mlp_chain_kernel<{C}, {C}, {hidden}, {C}, 2, false> (dlwp_sfno_tail_fwd): the SFNO block tail's three dependent "
-                      f"products in one launch over {T} tokens, bf16 operands, fp32 accumulation",
-            "flops_per_launch": flops, "bytes_per_launch": nbytes, "us_per_launch": round(sec * 1e6, 3), "traffic": None,
-            "mfma": {"achieved": round(flops / sec / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(f_mfma, 4)},
-            "hbm": {"achieved": round(nbytes / sec / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(f_hbm, 4)}}
-    out_.update(out_[out_["bound"]])
-    return out_
+    wbytes = 2 * (C * C + 2 * C * hidden)
+    if backward:
+        g_lp, gh, gt, gt_lp, gx = e(C), e(hidden), e(C, torch.float32), e(C), e(C, torch.float32)
+        ba = _TailBwdArgs(L.ptr(y), L.ptr(imgs[3]), L.ptr(imgs[4]), L.ptr(imgs[5]), L.ptr(z1), L.ptr(z0), L.ptr(g_lp), L.ptr(gh),
+                          L.ptr(gt), L.ptr(gt_lp), L.ptr(gx), T, C, hidden, 1)
+        sec = _time_on_stream(lambda st: L.check(lib.dlwp_sfno_tail_bwd(C_.byref(ba), st)), reps)
+        nbytes = float(T * C * (4 + 4 + 4) + T * (C + hidden) * 2 + T * (2 * C + hidden) * 2 + wbytes)
+        name = f"mlp_chain_kernel<{C}, {hidden}, {C}, {C}, 2, true> (dlwp_sfno_tail_bwd)"
+    else:
+        sec = _time_on_stream(lambda st: L.check(lib.dlwp_sfno_tail_fwd(C_.byref(fa), st)), reps)
+        nbytes = float(T * C * (4 + 4 + 4) + T * C * 2 * 3 + T * hidden * 2 * 2 + wbytes + 4 * (2 * C + hidden))
+        name = f"mlp_chain_kernel<{C}, {C}, {hidden}, {C}, 2, false> (dlwp_sfno_tail_fwd)"
+    return _both_roofs(f"{name}: the SFNO block tail's three dependent products in one launch over {T} tokens, bf16 operands, "
+                       f"fp32 accumulation", flops, nbytes, sec)
 
 
-def sfno_cpu_baseline(B, budget_s):
-    """oracle/sfno_ref.py (CPU restatement; torch-harmonics is not installable here: kind="port") on the host cores."""
+def sfno_spectral_probe(device, B, kind, reps=100, K=32, N=64, C=256, M=32, Lm=32):
+    """The three spectral kernels of an SFNO block at the C3 shape (32 x 64 grid, lmax = mmax = 32, embed 256), one launch each
+    between HIP events on the launch stream.  kind: "synthesis" (sht_synthesis_bf16_kernel, truncated orders not read; the backward
+    half of its calls also adds a residual field: not in this probe), "analysis" (sht_analysis_bf16_kernel), "dhconv"
+    (dhconv_apply2_kernel, truncated).  Algorithmic bytes: the spectrum entries with m <= l (bf16, 33 / 64 of the array; dhconv
+    also writes the zero rows of its live 8-order tiles: counted as the array's 5 / 8) and the field read or written once in
+    fp32, the weights / tables once; flops = the two table products resp. the complex channel mixing on the live rows."""
+    import torch
+    from dlwp_benchmark_amd import lib as L
+    lib = L.load()
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(0)
+    tri = (torch.arange(M)[None, :] <= torch.arange(Lm)[:, None]).float()
+    X = (torch.randn(Lm, B, M, 2, C, generator=g) * tri[:, None, :, None, None]).to(device).to(bf).contiguous()
+    live = float(tri.sum()) / (Lm * M)
+    spec_bytes = 2.0 * Lm * B * M * 2 * C
+    field_bytes = 4.0 * B * K * N * C
+    if kind == "dhconv":
+        img = (torch.randn(Lm * 2 * C * C, generator=g) / 16).to(device).to(bf)
+        Y = torch.empty_like(X)
+        sec = _time_on_stream(lambda st: L.check(lib.dlwp_dhconv_apply(L.ptr(X), L.ptr(img), L.ptr(Y), Lm, B * M * 2, C, C, M, 0, st)), reps)
+        tiles = sum(min(M // 8, l // 8 + 1) for l in range(Lm)) / (Lm * (M // 8))          # live 8-order tiles
+        flops = 8.0 * C * C * B * M * Lm * tiles
+        nbytes = spec_bytes * tiles + spec_bytes + 2.0 * Lm * 2 * C * C
+        return _both_roofs(f"dhconv_apply2_kernel<{C}, 128> (dlwp_dhconv_apply): per-degree complex channel mixing of {B * M * 2} spectrum "
+                           f"rows x {Lm} degrees, bf16 operands, truncated orders skipped", flops, nbytes, sec)
+    if kind == "analysis":
+        x = torch.randn(B, K, N, C, generator=g).to(device)
+        A1 = (torch.randn(2 * M, N, generator=g) / 8).to(device).to(bf)
+        A2 = (torch.randn(M, Lm, K, generator=g) / 8).to(device).to(bf)
+        sec = _time_on_stream(lambda st: L.check(lib.dlwp_sht_analysis_bf16(L.ptr(x), L.ptr(A1), L.ptr(A2), L.ptr(X), B, K, N, C, M, Lm, st)),
+                              reps)
+        flops = 2.0 * B * C * K * N * 2 * M + 2.0 * B * C * 2 * M * Lm * K
+        return _both_roofs(f"sht_analysis_bf16_kernel<{(N + 31) // 32}, {(K + 31) // 32}, {(Lm + 15) // 16}> (dlwp_sht_analysis_bf16): "
+                           f"longitude DFT + Legendre transform of {B} x {C} fields {K} x {N}", flops, field_bytes + spec_bytes, sec)
+    out = torch.empty(B, K, N, C, device=device)
+    S1t = (torch.randn(M, K, Lm, generator=g) / 8).to(device).to(bf)
+    S2 = (torch.randn(N, 2 * M, generator=g) / 8).to(device).to(bf)
+    sec = _time_on_stream(lambda st: L.check(lib.dlwp_sht_synthesis_bf16_ex(L.ptr(X), L.ptr(S1t), L.ptr(S2), None, L.ptr(out), B, K, N, C,
+                                                                            M, Lm, 1, st)), reps)
+    flops = 2.0 * B * C * K * 2 * M * Lm * live + 2.0 * B * C * K * N * 2 * M
+    return _both_roofs(f"sht_synthesis_bf16_kernel<{(Lm + 31) // 32}, {(2 * M + 31) // 32}, {(N + 15) // 16}> (dlwp_sht_synthesis_bf16_ex): "
+                       f"Legendre synthesis + longitude inverse DFT of {B} x {C} fields {K} x {N}, truncated orders not read",
+                       flops, spec_bytes * live + field_bytes, sec)
+
+
+SFNO_PROFILE_CSV = {16: "r05_bf16_storage_sfno_b16_step_kernel_stats.csv", 4: "r05_bf16_storage_sfno_step_kernel_stats.csv"}
+
+
+def sfno_dominant_probe(device, B):
+    """secondary.roofline: the kernel with the largest share of the step's committed rocprof kernel-stats CSV (profiles/), probed
+    live.  Falls back to the block tail's forward launch when the CSV of this batch size is absent."""
+    import csv
+    share, top = None, "mlp_chain_kernel<256, 256, 512, 256, 2, false>"
+    path = os.path.join(ROOT, "profiles", SFNO_PROFILE_CSV.get(B, ""))
+    if os.path.isfile(path):
+        rows = list(csv.DictReader(open(path)))
+        if rows:
+            top, share = rows[0]["Name"], float(rows[0]["Percentage"])
+    if "sht_synthesis" in top:
+        r = sfno_spectral_probe(device, B, "synthesis")
+    elif "sht_analysis" in top:
+        r = sfno_spectral_probe(device, B, "analysis")
+    elif "dhconv_apply" in top:
+        r = sfno_spectral_probe(device, B, "dhconv")
+    else:
+        r = sfno_tail_probe(device, B, backward=", true>" in top)
+    r["share_of_step_pct"] = share
+    r["chosen_from"] = os.path.relpath(path, ROOT) if share is not None else "default (no committed CSV for this batch size)"
+    return r
+
+
+def sfno_cpu_baseline(B, budget_s, clip=None):
+    """oracle/sfno_ref.py (CPU restatement; torch-harmonics is not installable here: kind="port") on the host cores; clip: the
+    reference protocol's torch.nn.utils.clip_grad_norm_ threshold (dlwpbench scripts/train.py:133-135)."""
     import torch
     from oracle import sfno_ref
     from dlwp_benchmark_amd import dlwpbench
@@ -394,6 +493,8 @@ def sfno_cpu_baseline(B, budget_s):
         opt.zero_grad(set_to_none=True)
         loss = torch.nn.functional.mse_loss(sfno_ref.sfno2d_rollout(*kw, p, cfg), target)
         loss.backward()
+        if clip is not None:
+            torch.nn.utils.clip_grad_norm_(list(p.values()), clip)
         opt.step()
     step()
     t0, n = time.perf_counter(), 0
@@ -404,8 +505,8 @@ def sfno_cpu_baseline(B, budget_s):
             break
     dt = time.perf_counter() - t0
     return {"value": round(B * n / dt, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} train steps of the same workload (batch {B}, {T - 1} lead times) after 1 warm-up, torch "
-                      f"{torch.__version__} CPU fp32, oracle/sfno_ref.py"}
+            "sample": f"{n} train steps of the same workload (batch {B}, {T - 1} lead times{', clip_grad_norm_' if clip is not None else ''}) "
+                      f"after 1 warm-up, torch {torch.__version__} CPU fp32, oracle/sfno_ref.py"}
 
 
 def main_sfno(args):
@@ -434,7 +535,7 @@ def rank_evidence(dist, device, backend, dt, steps):
     return {"backend": backend, "rccl_ranks": world if backend == "nccl" else 0, "world_size": world, "rccl_version": ver, "ranks": box}
 
 
-def run_dlwp(args, workload, steps, warmup, init_dist, roofline=True, cpu=True):
+def run_dlwp(args, workload, steps, warmup, init_dist, roofline=True, cpu=True, batch=None, clip=None):
     """BASELINE configs[2] (sfno) and the supplementary configs[3] / [4] lines (pangu, swin, afno): one step = rollout + MSE +
     backward + all-reduce (N>1) + fused Adam through train_engine.GraphedTrainStep (captured in a hipGraph at N = 1 and for the
     flat reducer; the 28-72 M parameter models use the bucketed reducer launched from backward hooks at N > 1: eager step).
@@ -461,7 +562,11 @@ def run_dlwp(args, workload, steps, warmup, init_dist, roofline=True, cpu=True):
     # residual stream stay fp32.  --storage overrides
     storage = args.storage or (w["storage"] if precision == "bf16" else "fp32")
     L.set_storage(storage)
-    B = args.batch if (args.batch_given and workload == args.workload) else w["batch"]
+    B = batch if batch is not None else (args.batch if (args.batch_given and workload == args.workload) else w["batch"])
+    lr = w.get("lr", 1e-3)
+    if clip is None:
+        clip = not args.no_clip
+    clip_max_norm = lr if clip else None          # scripts/train.py:133-135: clip_grad_norm_(model.parameters(), current learning rate)
     H, W_, Cg, T = w["H"], w["W"], w["Cg"], w["T"]
     torch.manual_seed(1234)
     model = getattr(dlwpbench, w["cls"])(**w["model"]).to(device).train()
@@ -486,7 +591,7 @@ def run_dlwp(args, workload, steps, warmup, init_dist, roofline=True, cpu=True):
             raise SystemExit("--reduce in-graph needs one GPU per rank (RCCL refuses two ranks on one device)")
         comm = ddp.RcclComm(rank, world)
         allreduce = comm
-    step = GraphedTrainStep(model, kw, target, lr=w.get("lr", 1e-3), use_graph=not args.no_graph and not bucketed,
+    step = GraphedTrainStep(model, kw, target, lr=lr, clip_max_norm=clip_max_norm, use_graph=not args.no_graph and not bucketed,
                             allreduce=allreduce, grad_scale=1.0 / world)
     if bucketed:
         step.allreduce = ddp.BucketedGradAllReduce(model, step.grad)
@@ -516,12 +621,17 @@ def run_dlwp(args, workload, steps, warmup, init_dist, roofline=True, cpu=True):
         line = {"metric": w["metric"],
                 "value": round(world * B * steps / dt, 3), "unit": "samples/s", "n_gpus": world, "steps": steps,
                 "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if precision == "bf16" else "f32",
+                "scaling": "weak", "vs_baseline": None,
+                "dtype": ("bf16" if storage == "bf16" else "bf16 operands, fp32 storage") if precision == "bf16" else "f32",
                 "data": "synthetic N(0,1) fields (z-scored WeatherBench shapes), random-init weights (no dataset/checkpoint access)",
                 "config": {"workload": w["name"], "per_gpu_batch": B, "global_batch": B * world, "sequence_length": T,
                            "net_calls_per_sample": T - 1, "grid": [H, W_],
                            "n_params": sum(p.numel() for p in model.parameters()),
                            "gemm_operands": precision, "storage": storage, "accumulate": "fp32", "parallelism": f"dp{world}",
+                           "learning_rate": lr, "clip_grad_norm": clip_max_norm,
+                           "protocol": "src/dlwpbench/configs/training/default.yaml: batch_size 16, clip_gradients true at max_norm = "
+                                       "learning rate (scripts/train.py:133-135), Adam" + ("" if clip and B == 16 else
+                                       f"; THIS line: per-GPU batch {B}, clipping {'on' if clip else 'off'}"),
                            "hip_graph": not args.no_graph and not bucketed,
                            "grad_reduce": {"none": "none", "flat": "one all-reduce of the flat gradient buffer between the graph replays",
                                            "in-graph": "one all-reduce captured inside the step's graph (dlwp_comm_allreduce)",
@@ -533,11 +643,11 @@ def run_dlwp(args, workload, steps, warmup, init_dist, roofline=True, cpu=True):
             line["ranks"] = evidence
         if world == 1 and not args.no_roofline and roofline:
             if workload == "sfno" and precision == "bf16" and storage == "bf16":
-                line["roofline"] = sfno_tail_probe(device, B)
+                line["roofline"] = sfno_dominant_probe(device, B)
             else:
                 line["roofline"] = sfno_gemm_probe(device, B, precision, storage=storage, shape=w["gemm"])
         if world == 1 and not args.no_cpu_baseline and cpu and workload == "sfno":
-            line["cpu_baseline"] = sfno_cpu_baseline(B, args.cpu_seconds)
+            line["cpu_baseline"] = sfno_cpu_baseline(B, args.cpu_seconds, clip=clip_max_norm)
         elif world == 1 and cpu:
             line["cpu_baseline"] = None       # a CPU step of the 28-72 M parameter models at these grids takes minutes: not sampled
     if comm is not None:
@@ -644,6 +754,16 @@ def main():
             line["config"]["grad_reduce"] = "one all-reduce of the flat gradient buffer between the graph replays"
         if world == 1 and not args.no_roofline:
             line["roofline"] = roofline_probe(device, B)
+            if B <= 8 and args.hidden is None:
+                # how to read a fraction this low: at the reference's batch size the step is a serial chain of 215 launches of
+                # <= 256 workgroups each, so its time does not depend on the batch (profiles/r04_bench_batch_sweep.jsonl) and the
+                # dominant kernel moves 4.7 MB per launch; the same kernel at batch 64 is probed beside it
+                big = roofline_probe(device, 64, reps=100)
+                line["roofline"]["regime"] = ("launch-latency-bound at this batch size: per-GPU batch 1 / 2 / 4 -> 1.85 / 1.87 / 1.94 ms per "
+                                              "step, batch 64 -> 3574 samples/s (profiles/r04_bench_batch_sweep.jsonl); the fraction "
+                                              "says how much of HBM one launch of <= 256 workgroups can use, not that the kernel "
+                                              "re-reads data (traffic = 1.21 x the algorithmic bytes)")
+                line["roofline"]["at_batch_64"] = {k: big[k] for k in ("achieved", "peak", "unit", "frac", "bytes_per_launch", "us_per_launch")}
             if w["hidden_channels"] <= 64:          # the fused lifting kernel exists for narrow layers only
                 line["roofline_mfma"] = mfma_probe(device, B)
             line["roofline_mix"] = mix_probe(device, B)
@@ -657,9 +777,14 @@ def main():
             from dlwp_benchmark_amd import lib as L
             prev_precision, prev_storage = L.load().dlwp_get_gemm_precision(), ("bf16" if L.storage_bf16() else "fp32")
             try:
-                sec = run_dlwp(args, "sfno", steps=40, warmup=5, init_dist=False, cpu=False)
+                # the reference's own dlwpbench protocol: per-GPU batch 16, clip_grad_norm_ at max_norm = learning rate
+                sec = run_dlwp(args, "sfno", steps=40, warmup=5, init_dist=False, cpu=True, batch=16, clip=True)
                 line["secondary"] = {k: sec[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config",
-                                                         "roofline") if k in sec}
+                                                         "roofline", "cpu_baseline") if k in sec}
+                torch.cuda.empty_cache()
+                # ... and the round 1 - 4 form of this line (batch 4, no clipping) for continuity
+                b4 = run_dlwp(args, "sfno", steps=40, warmup=5, init_dist=False, roofline=False, cpu=False, batch=4, clip=False)
+                line["secondary"]["b4_noclip"] = {k: b4[k] for k in ("value", "unit", "steps", "ms_per_step")}
             except Exception as exc:          # noqa: BLE001 -- the headline record above is measured: never lose it to the extra run
                 line["secondary"] = {"error": f"{type(exc).__name__}: {exc}"}
             finally:
