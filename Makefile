@@ -11,16 +11,16 @@ LIB        := dlwp_benchmark_amd/libdlwpmi.so
 
 all: $(LIB)
 
-build/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.cuh) $(wildcard $(CSRC)/*.h) include/dlwpmi.h
+build/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.hip.h) $(wildcard $(CSRC)/*.h) include/dlwpmi.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -ldl -o $@
 
-# diagnostic build with in-kernel phase stamps (DLWP_STAMP in common.cuh); never loaded by the package
+# diagnostic build with in-kernel phase stamps (DLWP_STAMP in common.hip.h); never loaded by the package
 STAMP_OBJS := $(patsubst $(CSRC)/%.hip,build_stamps/%.o,$(SRCS))
-build_stamps/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.cuh) $(wildcard $(CSRC)/*.h) include/dlwpmi.h
+build_stamps/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.hip.h) $(wildcard $(CSRC)/*.h) include/dlwpmi.h
 	@mkdir -p build_stamps
 	$(HIPCC) $(HIPFLAGS) -DDLWP_STAMPS -c $< -o $@
 stamps: $(STAMP_OBJS)

@@ -39,6 +39,10 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="fno workload at N=1: do not append the short SFNO (configs[2]) run "
                     "as the line's \"secondary\" object")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--split-graph", action="store_true", help="N = 1 only: run the step with the graph structure of the N > 1 path "
+                    "(dlwpbench workloads: forward + backward graph | reducer call | optimizer graph, the reducer being a no-op at world "
+                    "1) -- what the data-parallel structure costs before any byte moves.  The fno workload's step has this structure "
+                    "at every N (forward + backward graph | reducer | Adam launch), so the flag changes nothing there")
     ap.add_argument("--no-clip", action="store_true", help="dlwpbench workloads: no gradient clipping (the reference's training protocol "
                     "clips at max_norm = learning rate before every optimizer step: src/dlwpbench/configs/training/default.yaml:3, "
                     "scripts/train.py:133-135; on by default)")
@@ -579,7 +583,7 @@ def run_dlwp(args, workload, steps, warmup, init_dist, roofline=True, cpu=True, 
     # drops from 1254 to 739 samples/s, so it keeps the capture and reduces the flat gradient buffer once between the two graph
     # replays; the Pangu / Swin / AFNO steps (kernels of 20 - 300 us) lose <= 1.5 % run eagerly, so they take the bucketed reducer
     # whose all-reduces overlap backward.  --reduce in-graph captures the collective itself (C ABI communicator).
-    reduce = args.reduce if world > 1 else "none"
+    reduce = args.reduce if world > 1 else ("flat" if getattr(args, "split_graph", False) else "none")
     if reduce == "auto":
         reduce = "flat" if workload == "sfno" else "bucketed"
     bucketed = reduce == "bucketed"
@@ -637,6 +641,8 @@ def run_dlwp(args, workload, steps, warmup, init_dist, roofline=True, cpu=True, 
                                            "in-graph": "one all-reduce captured inside the step's graph (dlwp_comm_allreduce)",
                                            "bucketed": "buckets from backward hooks, overlapped with backward (eager step)"}[reduce]},
                 "backbone_calls_per_s": round(world * B * steps * (T - 1) / dt, 1), "final_loss": loss.item()}
+        if world == 1 and reduce != "none":
+            line["config"]["split_graph"] = "N > 1 graph structure at world 1 (no-op reducer between the two graph replays)"
         if bucketed:
             line["config"]["buckets_overlapped"] = getattr(step.allreduce, "overlapped", None)
         if evidence is not None:

@@ -12,7 +12,7 @@
 // window are ever computed (pruned DFT).  Every stage is a small exact-f32 MFMA product: the DFT passes with transform
 // fragments built on the fly from LDS twiddle tables (N <= 64: no stored DFT matrices), the block-diagonal complex MLP on
 // real images of the weights.  The backward pass reuses the same chain on gy with the adjoint scalings.
-#include "common.cuh"
+#include "common.hip.h"
 #include "dlwpmi_internal.h"
 #include <cmath>
 

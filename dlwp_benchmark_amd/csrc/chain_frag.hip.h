@@ -5,7 +5,7 @@
 //   mask covers the aligned power-of-two group of chunks that contains c (15 for rows that are multiples of 128 elements), so a
 //   ds_read_b128 fragment read (16 rows x one chunk column per 16-lane group) touches 16 different 16-byte slots of a bank row.
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace chainfrag {
 

@@ -8,7 +8,7 @@
 //
 // librccl is bound lazily (dlopen at the first comm call): libdlwpmi keeps loading on machines without RCCL and single-GPU
 // runs never pay its load time; a missing library is reported loudly by the first call, there is no fallback.
-#include "common.cuh"
+#include "common.hip.h"
 #include "dlwpmi_internal.h"
 #include <dlfcn.h>
 #include <cstring>

@@ -21,7 +21,7 @@
 // the 3.2 ms C3 step): 16-K-step products on the generic register-staged kernel.
 #include <algorithm>
 #include <cstdlib>
-#include "chain_frag.cuh"
+#include "chain_frag.hip.h"
 #include "dlwpmi_internal.h"
 
 namespace {
@@ -63,6 +63,64 @@ __global__ __launch_bounds__(256) void dhconv_pack_kernel(PackMany pm, int Ci, i
             v[e] = (__bf16)pk_smem[pair * LD + 2 * l + part];
         }
         *reinterpret_cast<bf16x8*>(img + ((((long long)l * NT + t) * KS + kk) * 64 + lane) * 8) = v;
+    }
+}
+
+// Round 5: both images of a weight from ONE read of it.  dhconv_pack_kernel reads every weight twice (once per image, 256 (i, o)
+// pairs per workgroup): 83 us per step for the four C3 layers (201 MB moved).  Here a workgroup stages a 32 x 32 block of (i, o)
+// pairs (all degrees, 256 KB of fp32) as bf16 in LDS, transposed to [o][(l, part)][i] -- the forward image's eight consecutive
+// inputs are then one 16-byte piece -- and writes the block's 4 + 4 tiles of both images: 134 MB moved.
+constexpr int PK_PJ = 36;          // element pitch of one (o, l, part) row of 32 inputs (two 8-byte-aligned halves per fragment)
+__global__ __launch_bounds__(512) void dhconv_pack2_kernel(PackMany pm, int Ci, int Co, int L) {
+    extern __shared__ __attribute__((aligned(16))) float pk_smem[];
+    __bf16* sm = reinterpret_cast<__bf16*>(pk_smem);                     // [32 o][2 L][PK_PJ] (+ 2 elements per o: bank spread)
+    const int J = 2 * L, PO = J * PK_PJ + 2, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i0 = 32 * blockIdx.x, o0 = 32 * blockIdx.y, layer = blockIdx.z;
+    const float* __restrict__ w = pm.w[layer];
+    // ---- the block's 32 input rows: 32 outputs x 2 L floats contiguous each
+    const int per_i = 32 * J / 4;                                        // float4 pieces per input row
+    for (int ib = 0; ib < 32; ib += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4* row = reinterpret_cast<const float4*>(w + ((long long)(i0 + ib + u) * Co + o0) * J);
+            v[u] = tid < per_i ? row[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (tid < per_i) {
+            const int o = (4 * tid) / J, j = 4 * tid - o * J;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                __bf16* d = sm + o * PO + j * PK_PJ + ib + u;
+                d[0] = (__bf16)v[u].x; d[PK_PJ] = (__bf16)v[u].y; d[2 * PK_PJ] = (__bf16)v[u].z; d[3 * PK_PJ] = (__bf16)v[u].w;
+            }
+        }
+    }
+    __syncthreads();
+    const int r = lane & 15, g = lane >> 4, part = r >> 3, ch = r & 7;
+    // ---- forward image: tiles over o (8 per tile), k over i: lane holds inputs 8 g .. 8 g + 7 of output 8 t + ch
+    {
+        __bf16* __restrict__ img = pm.fimg[layer];
+        const int NT = Co / 8, KS = Ci / 32, kk = i0 / 32;
+        for (int e = wv; e < 4 * L; e += 8) {
+            const int l = e >> 2, t = e & 3;
+            const __bf16* src = sm + (8 * t + ch) * PO + (2 * l + part) * PK_PJ + 8 * g;
+            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(src), hi = *reinterpret_cast<const bf16x4*>(src + 4);
+            *reinterpret_cast<bf16x8*>(img + ((((long long)l * NT + o0 / 8 + t) * KS + kk) * 64 + lane) * 8) =
+                bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+    }
+    // ---- backward image: tiles over i, k over o: lane holds outputs 8 g .. 8 g + 7 of input 8 t + ch
+    {
+        __bf16* __restrict__ img = pm.bimg[layer];
+        const int NT = Ci / 8, KS = Co / 32, kk = o0 / 32;
+        for (int e = wv; e < 4 * L; e += 8) {
+            const int l = e >> 2, t = e & 3;
+            const __bf16* src = sm + (8 * g) * PO + (2 * l + part) * PK_PJ + 8 * t + ch;
+            bf16x8 v;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = src[q * PO];
+            *reinterpret_cast<bf16x8*>(img + ((((long long)l * NT + i0 / 8 + t) * KS + kk) * 64 + lane) * 8) = v;
+        }
     }
 }
 
@@ -422,6 +480,14 @@ extern "C" int dlwp_dhconv_pack_many(const float* const* w, void* const* fwd_img
         pm.w[i] = w[i];
         pm.fimg[i] = static_cast<__bf16*>(fwd_img[i]);
         pm.bimg[i] = static_cast<__bf16*>(bwd_img[i]);
+    }
+    // one read of every weight for both images where a 32 x 32 block of (i, o) pairs fits the LDS as bf16 (L <= 34, even)
+    const size_t lds2 = (size_t)32 * (2 * L * PK_PJ + 2) * sizeof(__bf16);
+    if (L % 2 == 0 && lds2 <= 150 * 1024 && dlwp_tune_or("DHCONV_PACK", 2) != 1) {
+        if (int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(dhconv_pack2_kernel), lds2, "dhconv_pack2")) return rc;
+        hipLaunchKernelGGL(dhconv_pack2_kernel, dim3(Cin / 32, Cout / 32, n), dim3(512), lds2, (hipStream_t)stream, pm, Cin, Cout, L);
+        DLWP_LAUNCH_CHECK();
+        return DLWP_OK;
     }
     const size_t lds = (size_t)256 * (2 * L + 1) * sizeof(float);
     if (int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(dhconv_pack_kernel), lds, "dhconv_pack")) return rc;

@@ -18,7 +18,7 @@
 //     packed sample; two adjacent rows channels-first) and split / merge the Hermitian halves on the way out / in;
 //   * normalisation, the Hermitian weights of the adjoint transforms (interior bins count twice) and the
 //     real-part selection ride in the store / load stages: no extra pass for the backward transforms.
-#include "common.cuh"
+#include "common.hip.h"
 #include "dlwpmi_internal.h"
 #include <cmath>
 #include <vector>

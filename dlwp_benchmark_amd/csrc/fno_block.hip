@@ -14,9 +14,9 @@
 //            GEMM  pre[o][w] = [Wskip | Y1(o,:)] . [x ; G]  (skip conv + inverse W-axis DFT),
 //            bias, and optionally the next block's `rows` stage fused on the result.
 // The backward pass reuses the same three kernels with adjoint tables.
-#include "common.cuh"
+#include "common.hip.h"
 #include "dlwpmi_internal.h"
-#include "fno_rows.cuh"
+#include "fno_rows.hip.h"
 #include <cmath>
 #include <vector>
 

@@ -1,7 +1,7 @@
 // W-axis pruned DFT of one image row held in LDS (shared by the FNO row / spatial kernels and by the lifting MLP, which
 // appends it to its epilogue so that the first spectral block needs no separate rows launch).
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 
 // x1s[wave][c][n] = partial over the wave's 16-pixel chunks (w, w+4, ...) of sum_w act(tile[c][w]) * ft[n][w];
 // store_x1 sums the four per-wave partials (no LDS float atomics: they run at <1 lane-op/clk/CU).

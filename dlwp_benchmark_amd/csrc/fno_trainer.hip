@@ -9,7 +9,7 @@
 // by pointer tables into the trajectory buffers (the lifting kernel gathers its input channels
 // from observations or earlier predictions in place); all T steps stay on device; activations
 // of every net call are kept in HBM (a few MB each, far below 288 GB) for BPTT.
-#include "common.cuh"
+#include "common.hip.h"
 #include "dlwpmi_internal.h"
 #include <algorithm>
 #include <vector>

@@ -12,9 +12,9 @@
 //             bias, GELU on the activated operand, bias gradients as row sums, batches combined with float atomics
 // Hidden activations of the MLPs ([B, 256, H*W]) are stored for the backward pass here (HBM is 288 GB; the fused narrow
 // kernels recompute them instead).
-#include "common.cuh"
+#include "common.hip.h"
 #include "dlwpmi_internal.h"
-#include "fno_rows.cuh"
+#include "fno_rows.hip.h"
 
 namespace {
 

@@ -7,7 +7,7 @@
 // Layout x [B][P][C] (C contiguous): lanes run along the channels (coalesced 256-byte rows), waves along the tokens.
 // Statistics are column sums over P, so they are split over many workgroups (grid.z) and combined with float atomics
 // into a [B][C][2] table; the streaming apply kernels read that table.  HBM-bound: x is read twice, y written once.
-#include "common.cuh"
+#include "common.hip.h"
 #include "dlwpmi_internal.h"
 
 namespace {

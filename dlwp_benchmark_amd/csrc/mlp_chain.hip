@@ -23,7 +23,7 @@
 // Arithmetic = the bf16-operand token GEMM's: operands rounded to bf16, fp32 accumulation, fp32 epilogue, one rounding per store.
 #include <algorithm>
 #include <cstdlib>
-#include "chain_frag.cuh"
+#include "chain_frag.hip.h"
 #include "dlwpmi_internal.h"
 
 namespace {

@@ -18,7 +18,7 @@
 // 253 workgroups x 9.4 MB = 2.4 GB per launch), 4608 MFMAs per wave (61 us of matrix pipe at two waves per SIMD).
 #include <algorithm>
 #include <cstdlib>
-#include "chain_frag.cuh"
+#include "chain_frag.hip.h"
 #include "dlwpmi_internal.h"
 
 namespace {
@@ -240,6 +240,11 @@ int stream_launch(const StreamDev& a_in, int E, hipStream_t s) {
         auto kern = mlp_stream_kernel<768, BWD>;
         if (int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(kern), lds, "mlp_stream")) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, s, a);
+    } else if (E == 384) {
+        const size_t lds = (size_t)ROWS * (384 + 2 * HC) * sizeof(__bf16);
+        auto kern = mlp_stream_kernel<384, BWD>;
+        if (int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(kern), lds, "mlp_stream")) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, s, a);
     } else {
         dlwp_set_error("mlp_stream: no kernel for width %d (dlwp_mlp_stream_supported)", E);
         return DLWP_E_UNSUPPORTED;
@@ -250,7 +255,9 @@ int stream_launch(const StreamDev& a_in, int E, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int dlwp_mlp_stream_supported(int E, int hidden) { return E == 768 && hidden >= HC && hidden % HC == 0 && hidden <= 8192; }
+extern "C" int dlwp_mlp_stream_supported(int E, int hidden) {
+    return (E == 768 || E == 384) && hidden >= HC && hidden % HC == 0 && hidden <= 8192;
+}
 
 // the four images of one MLP in one launch: forward W1 [Hd][E], W2 [E][Hd]; backward W2^T [Hd][E], W1^T [E][Hd]
 struct PackFour { const float* W[4]; int ld[4], rows[4], cols[4], tr[4]; __bf16* img[4]; };

@@ -7,7 +7,7 @@
 //   bias gradients of nn.Linear / position embeddings: column sums over the token dimension
 #include <algorithm>
 #include <cstdlib>
-#include "common.cuh"
+#include "common.hip.h"
 #include "dlwpmi_internal.h"
 
 namespace {

@@ -7,7 +7,7 @@
 // Both GEMMs run on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32); the hidden activations
 // (Ch x 64) never leave registers: the accumulator of GEMM1 (rows = hidden channel 4g+j,
 // col = pixel) is directly the B operand of GEMM2 when the A operand (W2) is read with the
-// matching permuted-k order (common.cuh: mfma16_chunk).  Backward recomputes the hidden
+// matching permuted-k order (common.hip.h: mfma16_chunk).  Backward recomputes the hidden
 // layer, keeps weight-gradient partials in registers over the 64 pixels and leaves them in a
 // per-workgroup slab in accumulator-tile order (plain 16-byte stores; one slab-parallel launch
 // folds every slab of a training step, fold_slabs_kernel below); without a slab they go out as
@@ -17,9 +17,9 @@
 // form re-read each fragment four times through L1: 14.9 / 12.4 us against 11.4 / 10.1).  The forward kernel can append the W-axis DFT of its output
 // rows (lifting -> first spectral block), the backward kernel the adjoint DFT of its input
 // gradient rows (projection backward -> last spectral block's backward).
-#include "common.cuh"
+#include "common.hip.h"
 #include "dlwpmi_internal.h"
-#include "fno_rows.cuh"
+#include "fno_rows.hip.h"
 
 namespace {
 

@@ -15,7 +15,7 @@
 // A frame is F = D*H*W floats, [D][H][W] row-major.  `delta` arrives either in frame layout or as the patch tokens of a
 // linear head, [B][H/ph][W/pw][ph][pw][D] (AFNONet.head, fourcastnet.py:233,296-298), which folds the un-patching permute
 // into this kernel.  Pure data movement: HBM-bound, 16-byte accesses when F % 4 == 0 and delta is in frame layout.
-#include "common.cuh"
+#include "common.hip.h"
 #include "dlwpmi_internal.h"
 
 namespace {

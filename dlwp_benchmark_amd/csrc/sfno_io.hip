@@ -22,7 +22,7 @@
 // leave from the kernel.  The narrow dimensions are zero-padded inside the weight images (dlwp_sfno_io_pack), never in HBM tensors.
 #include <algorithm>
 #include <cstdlib>
-#include "chain_frag.cuh"
+#include "chain_frag.hip.h"
 #include "dlwpmi_internal.h"
 
 namespace {

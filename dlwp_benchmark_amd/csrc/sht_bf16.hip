@@ -19,7 +19,7 @@
 // at a time, the next one's loads in flight); synthesis fills its spectrum image by LDS-DMA (global_load_lds_dwordx4).
 #include <algorithm>
 #include <cstdlib>
-#include "common.cuh"
+#include "common.hip.h"
 #include "dlwpmi_internal.h"
 
 namespace {

@@ -18,7 +18,7 @@
 // latitudes: stage 2 contracts over k), in synthesis, 8 latitudes k (all orders: stage 2 contracts over q) -- 256
 // workgroups at the C3 shape (B=4, 32x64, C=256).  Each wave streams its own 4 KB field tiles (next tile's 16-byte loads
 // in flight during the current tile's MFMAs, wave-private LDS: no workgroup barrier inside a stage).
-#include "common.cuh"
+#include "common.hip.h"
 #include "dlwpmi_internal.h"
 
 namespace {

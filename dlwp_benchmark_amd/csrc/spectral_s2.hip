@@ -12,7 +12,7 @@
 //     [-Wi   Wr ]
 // built by cweight_expand below (once per call: 2 * (2C)^2 * L floats).  The weight gradient comes back from the
 // GEMM in the same 2C x 2C form and cweight_fold reduces it to the complex parameter's gradient.
-#include "common.cuh"
+#include "common.hip.h"
 #include "dlwpmi_internal.h"
 
 namespace {

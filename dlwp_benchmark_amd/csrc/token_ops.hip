@@ -18,7 +18,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
-#include "common.cuh"
+#include "common.hip.h"
 #include "dlwpmi_internal.h"
 
 namespace {
@@ -74,7 +74,14 @@ constexpr int gemm_bf_kstep(int s16m, int T, bool akc, bool bkc) { return s16m =
 constexpr int ACT_GELU_GRAD_MUL = 4;
 // 5 / 6: the same for ReLU and soft-shrink(lambda) (the AFNO block MLP's activations): v * [aux > 0], v * [|aux| > lambda]
 constexpr int ACT_RELU_GRAD_MUL = 5, ACT_SHRINK_GRAD_MUL = 6;
+// 7 / 8 (round 5): GELU whose `preact` output receives the DERIVATIVE GELU'(v) instead of v (evaluated with the activation: three
+// more instructions), and the matching backward form v * aux -- the layer's backward product then multiplies by a stored factor
+// instead of evaluating an exponential and a reciprocal per element (its epilogue was VALU-bound on that: 131 vs 101 us for the
+// FourCastNet product, profiles/r04_gemm_epilogue_ab.txt)
+constexpr int ACT_GELU_STORE_D = 7, ACT_MUL = 8;
+__host__ __device__ __forceinline__ bool act_is_grad_mul(int act) { return (act >= ACT_GELU_GRAD_MUL && act <= ACT_SHRINK_GRAD_MUL) || act == ACT_MUL; }
 __device__ __forceinline__ float act_grad_mul(float v, float aux, int act, float lam) {
+    if (act == ACT_MUL) return v * aux;
     if (act == ACT_GELU_GRAD_MUL) return v * gelu_grad_f(aux);
     if (act == ACT_RELU_GRAD_MUL) return aux > 0.f ? v : 0.f;
     return (act == ACT_SHRINK_GRAD_MUL && fabsf(aux) > lam) ? v : 0.f;
@@ -234,7 +241,7 @@ struct TileIO {
     }
 };
 
-// (lds_barrier(), common.cuh: __syncthreads() would wait for every global store of the previous pass -- stamps: 34 k cycles for the
+// (lds_barrier(), common.hip.h: __syncthreads() would wait for every global store of the previous pass -- stamps: 34 k cycles for the
 // four passes of a 256 x 256 tile, as long as twelve K-tiles)
 // Store loop of an LDS-staged epilogue: NROWS tile rows per thread (row = tid / C4 + RPP * i, four consecutive columns each), in
 // groups of G rows: every LDS read and every residual / accumulate load of a group is issued before the first use, the options
@@ -288,7 +295,7 @@ __device__ __forceinline__ void epilogue_group(const GemmDev& a, f32x4 (&v)[G], 
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[i][k] += bv[k];
     }
-    if (a.act >= ACT_GELU_GRAD_MUL) {
+    if (act_is_grad_mul(a.act)) {
 #pragma unroll
         for (int i = 0; i < G; ++i)
 #pragma unroll
@@ -300,12 +307,19 @@ __device__ __forceinline__ void epilogue_group(const GemmDev& a, f32x4 (&v)[G], 
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[i][k] += rv[i][k];
         }
-        if (a.preact) {
+        if (a.act == ACT_GELU_STORE_D) {
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                f32x4 d;
+                gelu_both4(v[i], v[i], d);
+                if (ok[i] && a.preact) put(a.preact, o[i], d);
+            }
+        } else if (a.preact) {
 #pragma unroll
             for (int i = 0; i < G; ++i)
                 if (ok[i]) put(a.preact, o[i], v[i]);
         }
-        if (a.act) {
+        if (a.act && a.act != ACT_GELU_STORE_D) {
 #pragma unroll
             for (int i = 0; i < G; ++i)
 #pragma unroll
@@ -549,12 +563,19 @@ __device__ __forceinline__ void gemm_body(GemmDev a, const int bx, const int bz,
                         if (a.dt & DT_C) reinterpret_cast<__bf16*>(dst)[o] = (__bf16)val;
                         else dst[o] = val;
                     };
-                    if (a.act >= ACT_GELU_GRAD_MUL) {
+                    if (act_is_grad_mul(a.act)) {
                         v = act_grad_mul(v, rres, a.act, a.act_param);
                     } else {
                         if (a.res_pre) v += rres;
-                        if (a.preact) put1(a.preact, v);
-                        v = apply_act(v, a.act, a.act_param);
+                        if (a.act == ACT_GELU_STORE_D) {
+                            float gv, dv;
+                            gelu_both(v, gv, dv);
+                            if (a.preact) put1(a.preact, dv);
+                            v = gv;
+                        } else {
+                            if (a.preact) put1(a.preact, v);
+                            v = apply_act(v, a.act, a.act_param);
+                        }
                         if (!a.res_pre) v += rres;
                     }
                     put1(a.C, a.accumulate ? a.C[o] + v : v);
@@ -1772,7 +1793,8 @@ static int gemm_impl(const float* A, const float* B, float* C, int M, int N, int
                      int transA, int transB, const float* bias, int act, float* preact, const float* residual,
                      int accumulate, float* rowsum, int dt, void* stream) {
     DLWP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, DLWP_E_INVALID, "gemm: NULL argument or empty shape");
-    DLWP_REQUIRE(act == 0 || act == 1, DLWP_E_INVALID, "gemm: act must be 0 (none) or 1 (gelu)");
+    DLWP_REQUIRE(act == 0 || act == 1 || (act == ACT_GELU_STORE_D && preact), DLWP_E_INVALID,
+                 "gemm: act must be 0 (none), 1 (gelu) or 7 (gelu with GELU' stored to a non-NULL preact)");
     if (int drc = dtypes_ok(dt, accumulate, "gemm")) return drc;
     const bool epilogue = bias || act || preact || residual || (dt & DT_C);      // a bf16 output takes no split-K atomics
     const int T = gemm_tile_for(M, N, 1, K, dt, !epilogue);
@@ -1892,11 +1914,12 @@ static int gemm_batched_impl(const float* A, const float* B, float* C, int M, in
     DLWP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && nb1 > 0 && nb2 > 0, DLWP_E_INVALID,
                  "gemm_batched: NULL argument or empty shape");
     if (int drc = dtypes_ok(dt, accumulate, "gemm_batched")) return drc;
-    DLWP_REQUIRE(act >= 0 && act <= 6, DLWP_E_INVALID,
-                 "gemm_batched: act must be 0 (none), 1 (gelu), 2 (relu), 3 (softshrink) or 4 / 5 / 6 (multiply by GELU' / ReLU' / "
-                 "softshrink'(residual))");
-    DLWP_REQUIRE(act < ACT_GELU_GRAD_MUL || (residual && !preact), DLWP_E_INVALID,
-                 "gemm_batched: act 4-6 read the saved pre-activation through `residual` and write no `preact`");
+    DLWP_REQUIRE(act >= 0 && act <= ACT_MUL, DLWP_E_INVALID,
+                 "gemm_batched: act must be 0 (none), 1 (gelu), 2 (relu), 3 (softshrink), 4 / 5 / 6 (multiply by GELU' / ReLU' / "
+                 "softshrink'(residual)), 7 (gelu, preact receives GELU') or 8 (multiply by residual)");
+    DLWP_REQUIRE(!act_is_grad_mul(act) || (residual && !preact), DLWP_E_INVALID,
+                 "gemm_batched: act 4-6 and 8 read the saved pre-activation / factor through `residual` and write no `preact`");
+    DLWP_REQUIRE(act != ACT_GELU_STORE_D || preact, DLWP_E_INVALID, "gemm_batched: act 7 stores GELU' to `preact`: it must not be NULL");
     // reductions over a long K with few output tiles (weight gradients of block-diagonal layers): split K inside every
     // batch and combine with float atomics, like the plain entry
     const bool epilogue = bias || act || preact || residual || (dt & DT_C);

@@ -2,7 +2,7 @@
 // torch.optim.Adam at src/nsbench/scripts/train.py:72-74,118-127; dlwpbench train.py:126-139),
 // plus the thread-local error string and the contiguous-tensor wrappers of the C ABI.
 // All of these are HBM-bound streaming kernels: 16 B per lane, grid-stride, <= 2048 blocks.
-#include "common.cuh"
+#include "common.hip.h"
 #include "dlwpmi_internal.h"
 #include <algorithm>
 #include <string>

@@ -3,7 +3,7 @@
 // configs/model/fno.yaml:11) — third-party arithmetic (tltorch TuckerTensor), SURVEY.md App. A-1: parity
 // unpinned.  The factorised weight is expanded once per optimizer step into the dense mode-major layout
 // the spectral kernels consume; these products are tiny (<= a few MFLOP), one thread per output element.
-#include "common.cuh"
+#include "common.hip.h"
 #include "dlwpmi_internal.h"
 
 namespace {

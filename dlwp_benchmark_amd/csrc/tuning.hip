@@ -7,7 +7,7 @@
 #include <climits>
 #include <cstdlib>
 #include <cstring>
-#include "common.cuh"
+#include "common.hip.h"
 #include "dlwpmi_internal.h"
 
 namespace {
@@ -51,6 +51,7 @@ Knob g_knobs[] = {
     {"WINATTN_BWD2PASS", "1: the two-pass LDS-staged attention backward instead of the one-pass kernel", 0, false},
     {"FFT_IBW", "inner lanes of the W-axis FFT pass", 0, false},
     {"FFT_IBH", "inner lanes of the H-axis FFT pass", 0, false},
+    {"DHCONV_PACK", "1: the round-4 spectral-weight pack kernel (one read of the weight per image) instead of the block kernel", 0, false},
     {"DHCONV_APPLY", "1: the round-4 spectral-convolution kernel (one 256-row chunk per workgroup) instead of the pipelined one", 0, false},
     {"DHCONV_RC", "rows per chunk of the pipelined spectral-convolution kernel: 64 or 128 (default 128)", 0, false},
     {"CHAIN_ROT", "0: no rotation of the wave -> feature-tile assignment in the one-launch MLP chains (default 1)", 0, false},

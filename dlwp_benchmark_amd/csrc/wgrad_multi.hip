@@ -18,7 +18,7 @@
 // slices in order (bit-reproducible; no float atomics on the weight gradients).  The bias gradients (column sums of g) ride on
 // the A fragments as in that kernel.
 #include <algorithm>
-#include "common.cuh"
+#include "common.hip.h"
 #include "dlwpmi_internal.h"
 
 namespace {

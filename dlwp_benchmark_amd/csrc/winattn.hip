@@ -7,7 +7,7 @@
 // MI355X design: flash-style, S never leaves the CU.  One workgroup = 64 queries of one (window,
 // head); keys/values stream through LDS in tiles of 64.  All products run on the exact-f32 MFMA in
 // the TRANSPOSED orientation (S^T = K Q^T: rows = keys, columns = queries), so that the score
-// accumulator is directly the B operand of O^T = V^T P^T (permuted-k trick, common.cuh) and the
+// accumulator is directly the B operand of O^T = V^T P^T (permuted-k trick, common.hip.h) and the
 // softmax statistics of a query live in one lane.  The position bias is looked up from a per-(head,
 // window type) LDS copy of the table; its index is additive in the two tokens, idx = ia[q] + ib[k]
 // (Swin: relative offsets; Pangu: earth-specific absolute pressure/latitude + relative longitude), so
@@ -15,7 +15,7 @@
 // vector (no N x N mask tensor).  Backward: kernel Q (dQ, dBias, D = rowsum(dO*O)) and kernel KV
 // (dK, dV), each recomputing the score tile it needs.
 #include <cstdlib>
-#include "common.cuh"
+#include "common.hip.h"
 #include "dlwpmi_internal.h"
 
 namespace {

@@ -13,7 +13,7 @@
 // L1 / L2 resident after the first touch), there is no barrier after the shared bias-table slice is staged, a workgroup is
 // four independent waves = four windows of the same (window type, head), and LDS holds the table slice only.
 //
-// Products, all on v_mfma_f32_16x16x4_f32 through the permuted-k chunk of common.cuh, tokens padded to NC chunks of 16:
+// Products, all on v_mfma_f32_16x16x4_f32 through the permuted-k chunk of common.hip.h, tokens padded to NC chunks of 16:
 //   S^T[key][q] = K Q^T           A = K row fragment, B = Q row fragment          (accumulator: 4 keys x 1 query per lane)
 //   O^T[dd][q]  = V^T P^T         A = V column fragment (4 strided loads), B = the S^T accumulator itself
 // so that a query's softmax statistics live in the four lanes that share r = lane & 15.  The backward pass evaluates the score
@@ -32,7 +32,7 @@
 //                                                           (Pangu); window- or token-layout gradients and operands
 #include <algorithm>
 #include <type_traits>
-#include "common.cuh"
+#include "common.hip.h"
 #include "dlwpmi_internal.h"
 
 namespace {

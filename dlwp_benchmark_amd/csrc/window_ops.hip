@@ -11,7 +11,7 @@
 //   gather : windows[...] = rolled padded x           (forward of partition; also the adjoint of reverse)
 //   scatter: x[b][q] = windows at the rolled position of q + f   (forward of reverse + crop; with `dup` it sums every padded
 //            copy of q, which is the adjoint of a circularly padded gather)
-#include "common.cuh"
+#include "common.hip.h"
 #include "dlwpmi_internal.h"
 
 namespace {
@@ -309,7 +309,7 @@ int win_setup(WinDev& a, const float* src, float* dst, int B, int C, const int* 
     }
     const long long toks_w = (long long)B * a.nW * a.N, toks_x = (long long)B * D[0] * D[1] * D[2], C4 = C / 4;
     const long long total = std::max(toks_w, toks_x) * C4;
-    // the umulhi divisions are exact while numerator * divisor < 2^32 (common.cuh FastDiv)
+    // the umulhi divisions are exact while numerator * divisor < 2^32 (common.hip.h FastDiv)
     const long long lim = 1ll << 32;
     const bool fits = total < (1ll << 31) && total * C4 < lim && toks_w * a.N < lim && (long long)B * a.nW * a.nW < lim &&
                       toks_x * D[2] < lim && (long long)B * D[0] * D[1] * D[1] < lim && (long long)B * D[0] * D[0] < lim &&

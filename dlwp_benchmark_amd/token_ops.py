@@ -45,6 +45,9 @@ def _act_dtype():
     return _BF if (L.storage_bf16() and L.SHADOW_ACTIVE) else torch.float32
 
 
+# env: A/B runs of the stored-derivative GELU (act 7 forward / act 8 backward, round 5) against act 1 / act 4 (the backward
+# product evaluates GELU' from the stored pre-activation)
+_ACT_F, _ACT_B = ((7, 8) if __import__("os").environ.get("DLWP_MLP_STORE_D", "1") != "0" else (1, 4))
 LOWP_MIN_DEPTH = int(__import__("os").environ.get("DLWP_LOWP_MIN_DEPTH", "768"))      # env: A/B runs of the break-even below
 
 
@@ -282,7 +285,8 @@ class _MlpFn(torch.autograd.Function):
             x2 = _lowp(x2, Hd)              # read by fc1 and by gW1 = gh^T x
         h = torch.empty(T, Hd, device=x.device, dtype=adt)
         z = torch.empty(T, Hd, device=x.device, dtype=adt)
-        _gemm(x2, w1m, h, T, Hd, K, K, K, Hd, 0, 1, b1, 1, z, None)
+        # act 7: z receives GELU'(pre-activation), evaluated with the activation -- the backward product multiplies by it (act 8)
+        _gemm(x2, w1m, h, T, Hd, K, K, K, Hd, 0, 1, b1, _ACT_F, z, None)
         y = torch.empty(T, N, device=x.device)
         r2 = residual.reshape(-1, N).contiguous() if residual is not None else None
         _gemm(h, w2m, y, T, N, Hd, Hd, Hd, N, 0, 1, b2, 0, None, r2)
@@ -304,7 +308,7 @@ class _MlpFn(torch.autograd.Function):
         if h.dtype == _BF:
             g2 = _lowp(g2, Hd)                   # read by gh = g W2 and gW2 = g^T h
         gh = torch.empty(T, Hd, device=g2.device, dtype=h.dtype)
-        _gemm_batched(g2, w2m, gh, T, Hd, N, N, Hd, Hd, 0, 0, act=4, residual=z)     # (g W2) * GELU'(z)
+        _gemm_batched(g2, w2m, gh, T, Hd, N, N, Hd, Hd, 0, 0, act=_ACT_B, residual=z)     # (g W2) * GELU'(z), z = the stored derivative
         gx = torch.empty(T, K, device=g2.device, dtype=ctx.in_dtype)   # a bf16 input (LayerNorm output) takes a bf16 gradient
         # gx = gh W1 and the two weight gradients do not depend on each other: one launch while they are small (lib.gemm_group parks
         # products of at most 2.2 GFLOP; larger ones launch at once)
@@ -407,10 +411,10 @@ class _SkipMlpFn(torch.autograd.Function):
         # pre-activation z0 keeps t's type (a GEMM writes its output and pre-activation in one storage type)
         t = torch.empty(T, C, device=x.device, dtype=adt)
         z0 = torch.empty(T, C, device=x.device, dtype=adt)
-        _gemm_batched(x2, wsm, t, T, C, C, C, C, C, 0, 1, bias=bs, act=1, preact=z0, residual=y2, res_pre=1)
+        _gemm_batched(x2, wsm, t, T, C, C, C, C, C, 0, 1, bias=bs, act=_ACT_F, preact=z0, residual=y2, res_pre=1)     # z0, z1: GELU'(.)
         h = torch.empty(T, Hd, device=x.device, dtype=adt)
         z1 = torch.empty(T, Hd, device=x.device, dtype=adt)
-        _gemm(t, w1m, h, T, Hd, C, C, C, Hd, 0, 1, b1, 1, z1, None)
+        _gemm(t, w1m, h, T, Hd, C, C, C, Hd, 0, 1, b1, _ACT_F, z1, None)
         out = torch.empty(T, N, device=x.device)
         _gemm(h, w2m, out, T, N, Hd, Hd, Hd, N, 0, 1, b2, 0, None, x2 if outer else None)
         ctx.save_for_backward(x2, wsm, w1m, w2m, z0, t, z1, h)
@@ -428,9 +432,9 @@ class _SkipMlpFn(torch.autograd.Function):
         g32 = gout.reshape(-1, N).contiguous().float()
         g2 = _lowp(g32, Hd) if h.dtype == _BF else g32      # read by gh = g W2 and gW2 = g^T h
         gh = torch.empty(T, Hd, device=g2.device, dtype=h.dtype)
-        _gemm_batched(g2, w2m, gh, T, Hd, N, N, Hd, Hd, 0, 0, act=4, residual=z1)      # (g W2) * GELU'(z1)
+        _gemm_batched(g2, w2m, gh, T, Hd, N, N, Hd, Hd, 0, 0, act=_ACT_B, residual=z1)      # (g W2) * GELU'(z1)
         gt = torch.empty(T, C, device=g2.device)
-        _gemm_batched(gh, w1m, gt, T, C, Hd, Hd, C, C, 0, 0, act=4, residual=z0)       # (gh W1) * GELU'(z0) = d/d(y + skip)
+        _gemm_batched(gh, w1m, gt, T, C, Hd, Hd, C, C, 0, 0, act=_ACT_B, residual=z0)       # (gh W1) * GELU'(z0) = d/d(y + skip)
         gx = torch.empty(T, C, device=g2.device)
         _gemm_batched(gt, wsm, gx, T, C, C, C, C, C, 0, 0, residual=g32 if ctx.outer else None)   # + outer skip
         # the three weight gradients (+ bias gradients) do not depend on each other: one launch

@@ -551,6 +551,10 @@ int dlwp_gemm_group_end(void* stream);
 /* the derivative of the GELU that produced its input (token-MLP backward, no gelu_bwd pass).  */
 /* act 5 / 6: the same with ReLU' ([z > 0]) and soft-shrink' ([|z| > act_param]): the AFNO block */
 /* MLP's activations (fourcastnet.py:100-117, F.relu and F.softshrink).                        */
+/* act 7 (also in dlwp_gemm / dlwp_gemm_mixed): GELU whose `preact` output (required) receives  */
+/* the DERIVATIVE GELU'(A.B + bias (+ res)) instead of the pre-activation; act 8: the backward   */
+/* form C = (A.B) * f with the stored factor f passed as `residual` -- the token MLP's backward  */
+/* product then multiplies by what the forward call stored and evaluates no exponential.        */
 /* Without an epilogue, long-K products with few output tiles are split along K (atomics).      */
 /* Used for the spherical transforms (per-order Legendre matrices) and the per-degree SFNO     */
 /* spectral weights, where one launch covers every (sample, order) or degree.                  */

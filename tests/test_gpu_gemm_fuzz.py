@@ -48,10 +48,10 @@ def test_gemm_random_shapes_and_epilogues(cuda, seed, mode):
     opB = (B[..., :K].transpose(-1, -2) if tB else B[..., :N])           # [.., K, N]
     split = seed % 6 == 0
     use_bias = (not split) and bool(rng.integers(0, 2))
-    act = 0 if split else int(rng.integers(0, 5))
-    use_res = (not split) and (act == 4 or bool(rng.integers(0, 2)))
-    res_pre = int(rng.integers(0, 2)) if (use_res and act != 4) else 0
-    want_pre = (not split) and act in (1, 2, 3) and bool(rng.integers(0, 2))
+    act = 0 if split else int(rng.choice([0, 1, 2, 3, 4, 7, 8]))          # 7: GELU storing GELU' as "preact"; 8: multiply by the residual
+    use_res = (not split) and (act in (4, 8) or bool(rng.integers(0, 2)))
+    res_pre = int(rng.integers(0, 2)) if (use_res and act not in (4, 8)) else 0
+    want_pre = (not split) and (act == 7 or (act in (1, 2, 3) and bool(rng.integers(0, 2))))
     accumulate = int(rng.integers(0, 2))
     lam = 0.3
     bias = torch.randn(N, generator=g, dtype=torch.float64) if use_bias else None
@@ -66,6 +66,18 @@ def test_gemm_random_shapes_and_epilogues(cuda, seed, mode):
         F.gelu(zz).sum().backward()
         want = v * zz.grad
         pre_want = None
+    elif act == 8:
+        want = v * resid[..., :N].float().double()
+        pre_want = None
+    elif act == 7:
+        if use_res and res_pre:
+            v = v + resid[..., :N].float().double()
+        vv = v.clone().requires_grad_(True)
+        want = F.gelu(vv)
+        want.sum().backward()
+        want, pre_want = want.detach(), vv.grad                 # the "pre-activation" output holds the derivative
+        if use_res and not res_pre:
+            want = want + resid[..., :N].float().double()
     else:
         if use_res and res_pre:
             v = v + resid[..., :N].float().double()

@@ -122,14 +122,15 @@ def test_bf16_fused_sht_kernels_equal_the_bf16_gemm_path(cuda, monkeypatch, nlat
 
 
 
-@pytest.mark.parametrize("variant", [{}, {"DHCONV_RC": 64}, {"DHCONV_APPLY": 1}], ids=["pipelined128", "pipelined64", "round4"])
+@pytest.mark.parametrize("variant", [{}, {"DHCONV_RC": 64}, {"DHCONV_APPLY": 1, "DHCONV_PACK": 1}], ids=["pipelined128", "pipelined64", "round4"])
 @pytest.mark.parametrize("B,M,L,Ci,Co,tri", [(4, 32, 32, 256, 256, True), (2, 16, 24, 128, 256, True), (3, 32, 20, 256, 128, False),
                                               (5, 12, 12, 128, 128, True), (9, 32, 32, 128, 128, True), (1, 32, 32, 256, 256, True)])
 def test_native_dhconv_kernels_match_the_complex_einsum(cuda, B, M, L, Ci, Co, tri, variant):
     """csrc/dhconv.hip: forward, input gradient and the weight gradient over THREE applications in one scope (one segmented product)
     against the float64 complex einsum "bixy,iox->boxy" on bf16-rounded operands; triangular spectra (orders m > l zero, as RealSHT
     produces them) with the skip on, dense spectra with it off, ragged row counts (partial chunks), one to five chunks per
-    workgroup walk; every apply kernel variant (pipelined with 128- / 64-row chunks, the round-4 one-chunk kernel)."""
+    workgroup walk; every apply kernel variant (pipelined with 128- / 64-row chunks, the round-4 one-chunk kernel) and both
+    weight-image pack kernels (one read of the weight for both images; one read per image)."""
     from dlwp_benchmark_amd import lib as L_, sht
     for k_, v_ in variant.items():
         L_.set_tuning(k_, v_)
@@ -218,6 +219,34 @@ def test_sfno2d_rollout_matches_oracle(cuda, over):
     torch.nn.functional.mse_loss(y, target.to(cuda)).backward()
     for n, q in net.named_parameters():
         assert rel(q.grad, p[n[len("sfno."):]].grad) <= 2e-3, n
+
+
+def test_sfno2d_c3_widths_fp32_path_matches_oracle(cuda):
+    """The fp32 product path of the BENCHMARKED module -- sfno.yaml widths (embed 256, 4 layers, equiangular 32 x 64, big skip,
+    position embedding, MLP), BASELINE configs[2] channel counts, 2 lead times -- against oracle/sfno_ref.py: output 1e-4,
+    every parameter gradient 2e-3 (the bf16 path at this width is compared with this fp32 path in test_gpu_fullsize.py)."""
+    import bench
+    from dlwp_benchmark_amd import dlwpbench
+    cfg = dict(bench.SFNO_WORKLOAD["model"])
+    torch.manual_seed(31)
+    net = dlwpbench.SFNO2DModule(**cfg)
+    with torch.no_grad():
+        net.sfno.pos_embed.normal_(0, 0.5)
+    g = torch.Generator().manual_seed(32)
+    B, T, H, W = 2, 3, cfg["height"], cfg["width"]
+    constants = torch.randn(B, 1, cfg["constant_channels"], H, W, generator=g)
+    prescribed = torch.randn(B, T, cfg["prescribed_channels"], H, W, generator=g)
+    prognostic = torch.randn(B, T, cfg["prognostic_channels"], H, W, generator=g)
+    target = torch.randn(B, T - 1, cfg["prognostic_channels"], H, W, generator=g)
+    p = {k[len("sfno."):]: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    yr = sfno_ref.sfno2d_rollout(constants, prescribed, prognostic, p, cfg)
+    torch.nn.functional.mse_loss(yr, target).backward()
+    net = net.to(cuda).train()
+    y = net(constants=constants.to(cuda), prescribed=prescribed.to(cuda), prognostic=prognostic.to(cuda))
+    assert y.shape == yr.shape and rel(y, yr) <= 1e-4, rel(y, yr)
+    torch.nn.functional.mse_loss(y, target.to(cuda)).backward()
+    for n, q in net.named_parameters():
+        assert rel(q.grad, p[n[len("sfno."):]].grad) <= 2e-3, (n, rel(q.grad, p[n[len("sfno."):]].grad))
 
 
 def test_sfno_graphed_train_step(cuda):
