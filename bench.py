@@ -277,7 +277,7 @@ DLWP_WORKLOADS = {
                  model=dict(constant_channels=4, prescribed_channels=1, prognostic_channels=8, context_size=1, img_height=128,
                             img_width=256, patch_size=1, embed_dim=96, depths=[4, 4], num_heads=[4, 4], drop_path_rate=0.2,
                             window_size=7),
-                 T=2, H=128, W=256, Cg=8, batch=2, storage="fp32", gemm=(128 * 256, 384, 96),
+                 T=2, H=128, W=256, Cg=8, batch=2, storage="bf16", gemm=(128 * 256, 384, 96),      # (round 5: 6.47 vs 6.69 ms with fp32 storage)
                  metric="train samples/sec (Swin 128x256 window-7 step: fwd + MSE + backward + Adam)"),
     "afno": dict(cls="AFNONet", name="dlwpbench AFNONet (FourCastNet) 720x1440 patch 8 E768 depth 12 (BASELINE configs[4] grid)",
                  model=dict(img_height=720, img_width=1440, patch_size=(8, 8), constant_channels=4, prescribed_channels=1,
@@ -561,9 +561,8 @@ def run_dlwp(args, workload, steps, warmup, init_dist, roofline=True, cpu=True, 
     w = DLWP_WORKLOADS[workload]
     precision = args.precision or "bf16"
     L.set_gemm_precision(precision)
-    # bf16 arithmetic goes with bf16 storage of the GEMM-to-GEMM tensors and of the weight copy the GEMMs read (lib.set_storage)
-    # where the products are deep enough for it to pay (not at Swin's E = 96); fp32 master weights, gradients, statistics and the
-    # residual stream stay fp32.  --storage overrides
+    # bf16 arithmetic goes with bf16 storage of the GEMM-to-GEMM tensors and of the weight copy the GEMMs read (lib.set_storage);
+    # fp32 master weights, gradients, statistics and the residual stream stay fp32.  --storage overrides
     storage = args.storage or (w["storage"] if precision == "bf16" else "fp32")
     L.set_storage(storage)
     B = batch if batch is not None else (args.batch if (args.batch_given and workload == args.workload) else w["batch"])
