@@ -65,6 +65,26 @@ __device__ __forceinline__ void lds_barrier() {
 }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
+// ---- LDS-DMA the compiler does not see (round 5).  hipcc knows that __builtin_amdgcn_global_load_lds writes LDS and, with no
+// alias information for dynamic shared memory, puts `s_waitcnt vmcnt(0)` in front of the FIRST LDS read that follows one -- in
+// every double-buffered kernel here that is the read of the OTHER buffer, so the "next step's DMAs in flight" of the counted
+// vmcnt waits never were (ISA of wgrad_multi_kernel, dhconv_apply2_kernel, gemm_glds*: vmcnt(N) by hand, s_barrier, then the
+// compiler's vmcnt(0)).  This form issues the same instruction from inline assembly: lane i's 16 bytes at `gptr` go to LDS byte
+// address lds_base + 16 i (lds_base wave-uniform, M0 holds it).  The caller orders its LDS reads behind the data with an explicit
+// `s_waitcnt vmcnt(N)` (+ barrier for other waves' pieces), as it already does.  The compiler's own vmcnt counts for register
+// loads stay correct: vector-memory operations retire in order, so operations it does not know about can only make a wait
+// longer, never shorter.
+__device__ __forceinline__ void lds_dma16(const void* gptr, const void* lds_base) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)lds_base);
+    unsigned keep;          // M0 is a reserved register for the compiler (not allowed on a clobber list): saved and restored here
+    // (s_nop: an SALU write of M0 needs one wait state before an instruction that reads it; the hazard recogniser does not look
+    // inside inline assembly)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(m0v), "v"(gptr)
+                 : "memory");
+}
+
 // D[m=4g+j][n=r] += sum_k A[m=r][k=g] * B[k=g][n=r]   (r = lane&15, g = lane>>4, j = reg)
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);

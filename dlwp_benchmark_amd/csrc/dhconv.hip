@@ -155,8 +155,7 @@ __global__ __launch_bounds__(512) void dhconv_apply_kernel(DhDev a) {
         if (!tile_live(rowi >> 4)) continue;
         const int row = rowi + lane / CPR, pos = lane % CPR, c = pos ^ (row & cmask<K>(pos));
         const __bf16* src = a.X + ((long long)l * a.R2 + min(row0 + row, a.R2 - 1)) * K + 8 * c;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(img + rowi * K), 16, 0, 0);
+        lds_dma16(src, img + rowi * K);
     }
     WFrag<1, KS> wf;
     DLWP_STAMP_IF(stamp_wg, 1);
@@ -241,8 +240,7 @@ __global__ __launch_bounds__(512) void dhconv_apply2_kernel(DhDev a) {
             if (!tile_live(c * RT + (rowi >> 4))) continue;
             const int row = rowi + lane / CPR, pos = lane % CPR, cc = pos ^ (row & cmask<K>(pos));
             const __bf16* src = a.X + ((long long)l * a.R2 + min(c * RC + row, a.R2 - 1)) * K + 8 * cc;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(buf + rowi * K), 16, 0, 0);
+            lds_dma16(src, buf + rowi * K);
         }
     };
     WFrag<1, KS> wf;
@@ -355,10 +353,8 @@ __global__ __launch_bounds__(256) void dhconv_wgrad_kernel(DwDev a) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const long long kk = min(k0 + krow[i], a.R2 - 1);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + kk * Ci + acol[i]),
-                                             (__attribute__((address_space(3))) void*)(As + (4 * i + w) * 512), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + kk * Co + bcol[i]),
-                                             (__attribute__((address_space(3))) void*)(Bs + (4 * i + w) * 512), 16, 0, 0);
+            lds_dma16(A + kk * Ci + acol[i], As + (4 * i + w) * 512);
+            lds_dma16(B + kk * Co + bcol[i], Bs + (4 * i + w) * 512);
         }
     };
     const int wm = (w >> 1) * 64, wn = (w & 1) * 64;

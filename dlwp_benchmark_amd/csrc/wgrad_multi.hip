@@ -72,10 +72,8 @@ __global__ __launch_bounds__(256) void wgrad_multi_kernel(WgDev a) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const long long kk = min(k0 + krow[i], a.T - 1);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + kk * M + acol[i]),
-                                             (__attribute__((address_space(3))) void*)(As + (4 * i + w) * 512), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + kk * N + bcol[i]),
-                                             (__attribute__((address_space(3))) void*)(Bs + (4 * i + w) * 512), 16, 0, 0);
+            lds_dma16(A + kk * M + acol[i], As + (4 * i + w) * 512);      // (inline assembly: see common.hip.h -- the builtin form made
+            lds_dma16(B + kk * N + bcol[i], Bs + (4 * i + w) * 512);      // the compiler wait vmcnt(0) before this step's fragment reads)
         }
     };
     const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
