@@ -78,6 +78,7 @@ struct ChainDev {
     float* a2f;                   // backward: gt in fp32 (the gradient that leaves through y)
     float* out;                   // [T][N3] fp32
     int T, outer;
+    int res1_bf16;                // forward: res1 is a bf16 array
     int rot;                      // rotate the wave -> n-tile assignment by the workgroup index (spreads the L2 channels the CUs of an XCD hit at one time)
 };
 
@@ -117,7 +118,10 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainDev a) {
             e1z[mi][ni] = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
             e1f[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (BWD) e1z[mi][ni] = *reinterpret_cast<const bf16x4*>(a.zin1 + m * N1 + n);
-            else e1f[mi][ni] = *reinterpret_cast<const f32x4*>(a.res1 + m * N1 + n) + bb;
+            else if (a.res1_bf16) {
+                const bf16x4 yv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.res1) + m * N1 + n);
+                e1f[mi][ni] = f32x4{(float)yv[0], (float)yv[1], (float)yv[2], (float)yv[3]} + bb;
+            } else e1f[mi][ni] = *reinterpret_cast<const f32x4*>(a.res1 + m * N1 + n) + bb;
         }
     }
     WFrag<NT2, KH2> w2a, w2b;
@@ -301,6 +305,7 @@ extern "C" int dlwp_sfno_tail_fwd(const dlwp_sfno_tail_fwd_args* p, void* stream
     a.b2 = p->b1 ? p->b1 : zb;
     a.b3 = p->b2 ? p->b2 : zb;
     a.res1 = p->y;
+    a.res1_bf16 = p->y_bf16 != 0;
     a.z1 = reinterpret_cast<__bf16*>(p->z0);
     a.a1 = reinterpret_cast<__bf16*>(p->t);
     a.z2 = reinterpret_cast<__bf16*>(p->z1);
@@ -315,7 +320,7 @@ extern "C" int dlwp_sfno_tail_bwd(const dlwp_sfno_tail_bwd_args* p, void* stream
     DLWP_REQUIRE(p, DLWP_E_INVALID, "sfno_tail_bwd: null arguments");
     DLWP_REQUIRE(dlwp_mlp_chain_supported(p->C, p->hidden), DLWP_E_UNSUPPORTED, "sfno_tail_bwd: no kernel for C = %d, hidden = %d",
                  p->C, p->hidden);
-    DLWP_REQUIRE(p->T > 0 && p->g && p->w2t_img && p->w1t_img && p->wst_img && p->z1 && p->z0 && p->gh && p->gt && p->gt_lp && p->gx,
+    DLWP_REQUIRE(p->T > 0 && p->g && p->w2t_img && p->w1t_img && p->wst_img && p->z1 && p->z0 && p->gh && p->gt_lp && p->gx,
                  DLWP_E_INVALID, "sfno_tail_bwd: null tensor");
     const void* ptrs[] = {p->g, p->g_lp, p->w2t_img, p->w1t_img, p->wst_img, p->z1, p->z0, p->gh, p->gt, p->gt_lp, p->gx};
     for (const void* q : ptrs) DLWP_REQUIRE(aligned16(q), DLWP_E_INVALID, "sfno_tail_bwd: tensors must be 16-byte aligned");

@@ -39,6 +39,7 @@ struct ShtB {
     const __bf16* T2;           // analysis: A2 [M][L][K]; synthesis: S2 [N][2M]
     int B, K, N, C, M, L, ncb, ngrp;
     int tri;                    // synthesis: orders m > l of X are zero by spherical truncation and are not read
+    int field_bf16;             // the field tensor (analysis input / synthesis output) is a bf16 array instead of fp32
 };
 
 // 16 contiguous table elements row[col .. col + 7] or zeros (row_ok && col + 7 < ncols; ncols % 8 == 0); the load is unconditional
@@ -130,7 +131,14 @@ __global__ __launch_bounds__(512) void sht_analysis_bf16_kernel(ShtB a) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int n = (lane >> 2) + 16 * i;
-            const f32x4 u = *reinterpret_cast<const f32x4*>(x + (((long long)b * K + min(k, K - 1)) * N + min(n, N - 1)) * C + c0 + 4 * (lane & 3));
+            const long long o = (((long long)b * K + min(k, K - 1)) * N + min(n, N - 1)) * C + c0 + 4 * (lane & 3);
+            f32x4 u;
+            if (a.field_bf16) {          // (a gradient that the block tail left as a bf16 array: half the bytes, the same rounding as below)
+                const bf16x4 h = *reinterpret_cast<const bf16x4*>(static_cast<const __bf16*>(a.in) + o);
+                u = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+            } else {
+                u = *reinterpret_cast<const f32x4*>(x + o);
+            }
             v[i] = n < N ? u : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
@@ -313,10 +321,20 @@ __global__ __launch_bounds__(512) void sht_synthesis_bf16_kernel(ShtB a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, t2[nt][kk], acc[nt], 0, 0, 0);
         }
+        if (a.field_bf16) {              // y of an SFNO block: read once, by the block tail, as a bf16 operand addend
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n = 16 * nt + r;
-            if (n < N) *reinterpret_cast<f32x4*>(x + (((long long)b * K + k) * N + n) * C + c0 + 4 * g) = acc[nt];
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = 16 * nt + r;
+                if (n < N)
+                    *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(a.out) + (((long long)b * K + k) * N + n) * C + c0 + 4 * g) =
+                        bf16x4{(__bf16)acc[nt][0], (__bf16)acc[nt][1], (__bf16)acc[nt][2], (__bf16)acc[nt][3]};
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = 16 * nt + r;
+                if (n < N) *reinterpret_cast<f32x4*>(x + (((long long)b * K + k) * N + n) * C + c0 + 4 * g) = acc[nt];
+            }
         }
     }
     DLWP_STAMP(14);
@@ -385,14 +403,15 @@ extern "C" int dlwp_debug_stamps_sht(unsigned long long* host_out) {
 
 extern "C" int dlwp_sht_bf16_supported(int nlat, int nlon, int C, int mmax, int lmax) { return shape_ok(nlat, nlon, C, mmax, lmax) ? 1 : 0; }
 
-extern "C" int dlwp_sht_analysis_bf16(const float* x, const void* A1, const void* A2, void* X, int B, int nlat, int nlon, int C, int mmax,
-                                      int lmax, void* stream) {
+extern "C" int dlwp_sht_analysis_bf16_ex(const void* x, const void* A1, const void* A2, void* X, int B, int nlat, int nlon, int C, int mmax,
+                                         int lmax, int flags, void* stream) {
     DLWP_REQUIRE(x && A1 && A2 && X && B > 0, DLWP_E_INVALID, "sht_analysis_bf16: null pointer / empty batch");
     DLWP_REQUIRE(shape_ok(nlat, nlon, C, mmax, lmax), DLWP_E_UNSUPPORTED, "sht_analysis_bf16: shape %d x %d, C %d, mmax %d, lmax %d unsupported "
                  "(dlwp_sht_bf16_supported)", nlat, nlon, C, mmax, lmax);
     DLWP_REQUIRE(aligned16(x) && aligned16(A1) && aligned16(A2) && aligned16(X), DLWP_E_INVALID, "sht_analysis_bf16: 16-byte alignment");
+    DLWP_REQUIRE((flags & ~DLWP_SHT_FIELD_BF16) == 0, DLWP_E_INVALID, "sht_analysis_bf16: unknown flag bits %d", flags);
     ShtB a{x, X, nullptr, static_cast<const __bf16*>(A1), static_cast<const __bf16*>(A2), B, nlat, nlon, C, mmax, lmax, C / CB,
-           ceil_div(mmax, GRP), 0};
+           ceil_div(mmax, GRP), 0, (flags & DLWP_SHT_FIELD_BF16) ? 1 : 0};
     const int NKS = ceil_div(nlon, 32), KKS = ceil_div(nlat, 32), LT = ceil_div(lmax, 16);
     const size_t lds = (size_t)(16 * 32 * KKS + NW * 32 * NKS) * CB * sizeof(__bf16);
     const dim3 grid(B * a.ncb * a.ngrp);
@@ -409,16 +428,17 @@ extern "C" int dlwp_sht_analysis_bf16(const float* x, const void* A1, const void
     return analysis_lt<4, 2>(a, LT, lds, grid, s);
 }
 
-extern "C" int dlwp_sht_synthesis_bf16_ex(const void* X, const void* S1t, const void* S2, const float* residual, float* x, int B, int nlat,
+extern "C" int dlwp_sht_synthesis_bf16_ex(const void* X, const void* S1t, const void* S2, const float* residual, void* x, int B, int nlat,
                                           int nlon, int C, int mmax, int lmax, int flags, void* stream) {
     DLWP_REQUIRE(X && S1t && S2 && x && B > 0, DLWP_E_INVALID, "sht_synthesis_bf16: null pointer / empty batch");
     DLWP_REQUIRE(shape_ok(nlat, nlon, C, mmax, lmax), DLWP_E_UNSUPPORTED, "sht_synthesis_bf16: shape %d x %d, C %d, mmax %d, lmax %d unsupported "
                  "(dlwp_sht_bf16_supported)", nlat, nlon, C, mmax, lmax);
     DLWP_REQUIRE(aligned16(X) && aligned16(S1t) && aligned16(S2) && aligned16(x) && aligned16(residual), DLWP_E_INVALID,
                  "sht_synthesis_bf16: 16-byte alignment");
-    DLWP_REQUIRE((flags & ~DLWP_SHT_TRIANGULAR) == 0, DLWP_E_INVALID, "sht_synthesis_bf16: unknown flag bits %d", flags);
+    DLWP_REQUIRE((flags & ~(DLWP_SHT_TRIANGULAR | DLWP_SHT_FIELD_BF16)) == 0, DLWP_E_INVALID, "sht_synthesis_bf16: unknown flag bits %d", flags);
+    DLWP_REQUIRE(!(flags & DLWP_SHT_FIELD_BF16) || !residual, DLWP_E_INVALID, "sht_synthesis_bf16: a bf16 output takes no residual");
     ShtB a{X, x, residual, static_cast<const __bf16*>(S1t), static_cast<const __bf16*>(S2), B, nlat, nlon, C, mmax, lmax, C / CB,
-           ceil_div(nlat, GRP), (flags & DLWP_SHT_TRIANGULAR) ? 1 : 0};
+           ceil_div(nlat, GRP), (flags & DLWP_SHT_TRIANGULAR) ? 1 : 0, (flags & DLWP_SHT_FIELD_BF16) ? 1 : 0};
     const int LKS = ceil_div(lmax, 32), QKS = ceil_div(2 * mmax, 32), NT = ceil_div(nlon, 16);
     const size_t lds = (size_t)(32 * LKS * 32 * QKS + GRP * 32 * QKS) * CB * sizeof(__bf16);
     const dim3 grid(B * a.ncb * a.ngrp);
@@ -433,6 +453,11 @@ extern "C" int dlwp_sht_synthesis_bf16_ex(const void* X, const void* S1t, const 
     if (QKS == 2) return synthesis_nt<2, 2>(a, NT, lds, grid, s);
     if (QKS == 3) return synthesis_nt<2, 3>(a, NT, lds, grid, s);
     return synthesis_nt<2, 4>(a, NT, lds, grid, s);
+}
+
+extern "C" int dlwp_sht_analysis_bf16(const float* x, const void* A1, const void* A2, void* X, int B, int nlat, int nlon, int C, int mmax,
+                                      int lmax, void* stream) {
+    return dlwp_sht_analysis_bf16_ex(x, A1, A2, X, B, nlat, nlon, C, mmax, lmax, 0, stream);
 }
 
 extern "C" int dlwp_sht_synthesis_bf16(const void* X, const void* S1t, const void* S2, const float* residual, float* x, int B, int nlat,

@@ -100,6 +100,7 @@ SIGNATURES = {
     "dlwp_sht_analysis_bf16": (_I, [_V, _V, _V, _V] + [_I] * 6 + [_V]),
     "dlwp_sht_synthesis_bf16": (_I, [_V, _V, _V, _V, _V] + [_I] * 6 + [_V]),
     "dlwp_sht_synthesis_bf16_ex": (_I, [_V, _V, _V, _V, _V] + [_I] * 7 + [_V]),
+    "dlwp_sht_analysis_bf16_ex": (_I, [_V, _V, _V, _V] + [_I] * 7 + [_V]),
     "dlwp_cweight_expand": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_cweight_fold": (_I, [_V, _V, _I, _I, _I, _V]),
     "dlwp_dhconv_supported": (_I, [_I, _I, _I]),

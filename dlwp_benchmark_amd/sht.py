@@ -278,19 +278,22 @@ class _Bf16Analysis(torch.autograd.Function):
 
 
 class _Bf16Synthesis(torch.autograd.Function):
-    """x (fp32) = synthesis(X bf16; S1t, S2) in one launch; backward = bf16 analysis with the transposed tables."""
+    """x = synthesis(X bf16; S1t, S2) in one launch; backward = bf16 analysis with the transposed tables.  field_bf16: x is written
+    as a bf16 array (dlwp_sht_synthesis_bf16_ex, DLWP_SHT_FIELD_BF16) for a consumer that reads it once as a bf16 operand (the
+    SFNO block tail); its gradient then arrives as a bf16 array too and is read as such."""
 
     @staticmethod
-    def forward(ctx, X, mod, names, grid):
+    def forward(ctx, X, mod, names, grid, field_bf16=False):
         bf = torch.bfloat16
         X = X.contiguous()
         if X.dtype != bf:
             X = X.to(bf)
         Lm, B, M, _, C = X.shape
         K, N = grid
-        x = torch.empty(B, K, N, C, device=X.device)
+        x = torch.empty(B, K, N, C, device=X.device, dtype=bf if field_bf16 else torch.float32)
         L.check(L.load().dlwp_sht_synthesis_bf16_ex(L.ptr(X), L.ptr(_table(mod, names[0], bf)), L.ptr(_table(mod, names[1], bf)), None,
-                                                    L.ptr(x), B, K, N, C, M, Lm, _triangular_flag(mod, names[0]), L.stream()))
+                                                    L.ptr(x), B, K, N, C, M, Lm, _triangular_flag(mod, names[0]) | (2 if field_bf16 else 0),
+                                                    L.stream()))
         ctx.mod, ctx.names, ctx.dims = mod, names, (B, K, N, C, M, Lm)
         return x
 
@@ -298,11 +301,13 @@ class _Bf16Synthesis(torch.autograd.Function):
     def backward(ctx, gx):
         B, K, N, C, M, Lm = ctx.dims
         bf = torch.bfloat16
-        gx = gx.contiguous().float()
+        gx = gx.contiguous()
+        if gx.dtype != bf:
+            gx = gx.float()
         gX = torch.empty(Lm, B, M, 2, C, device=gx.device, dtype=bf)
-        L.check(L.load().dlwp_sht_analysis_bf16(L.ptr(gx), L.ptr(_table(ctx.mod, ctx.names[2], bf)), L.ptr(_table(ctx.mod, ctx.names[3], bf)),
-                                                L.ptr(gX), B, K, N, C, M, Lm, L.stream()))
-        return gX, None, None, None
+        L.check(L.load().dlwp_sht_analysis_bf16_ex(L.ptr(gx), L.ptr(_table(ctx.mod, ctx.names[2], bf)), L.ptr(_table(ctx.mod, ctx.names[3], bf)),
+                                                   L.ptr(gX), B, K, N, C, M, Lm, 2 if gx.dtype == bf else 0, L.stream()))
+        return gX, None, None, None, None
 
 
 class RealSHT(nn.Module):
@@ -365,13 +370,15 @@ class InverseRealSHT(nn.Module):
         self.register_buffer("pct_t", torch.from_numpy(P.transpose(0, 2, 1).copy()).float().contiguous(), persistent=False)
         self.register_buffer("idft_t", torch.from_numpy(G.T.copy()).float().contiguous(), persistent=False)
 
-    def forward(self, X):
+    def forward(self, X, field_bf16=False):
+        """field_bf16: where the one-launch bf16 kernel runs, return the field as a bf16 array (for a consumer that rounds it to
+        bf16 anyway: the SFNO block tail); the other paths ignore the request and return fp32."""
         Lm, B, M, _, C = X.shape
         assert Lm == self.lmax and M == self.mmax, "spectrum does not match the transform"
         K, N = self.nlat, self.nlon
         if self.fused and X.is_cuda and X.dtype == torch.bfloat16 and _bf16_fused_ok(K, N, C, M, Lm):
             # forward tables S1t = pct_t, S2 = idft; backward (an analysis) A1 = idft_t, A2 = pct
-            return _Bf16Synthesis.apply(X, self, ("pct_t", "idft", "idft_t", "pct"), (K, N))
+            return _Bf16Synthesis.apply(X, self, ("pct_t", "idft", "idft_t", "pct"), (K, N), bool(field_bf16))
         if self.fused and X.is_cuda and _fused_ok(K, N, C, M, Lm):
             return _FusedSynthesis.apply(X, self.pct_t, self.idft, self.idft_t, self.pct, K, N)
         leg = dict(M=K, N=2 * C, K=Lm, lda=K, tA=1, ldx=B * M * 2 * C, ldy=2 * M * C, nb1=B, nb2=M, sA=(0, Lm * K),

@@ -448,7 +448,7 @@ class _SkipMlpFn(torch.autograd.Function):
 class _TailFwdArgs(C.Structure):
     """dlwp_sfno_tail_fwd_args (include/dlwpmi.h)"""
     _fields_ = [(n, C.c_void_p) for n in ("x", "y", "ws_img", "w1_img", "w2_img", "bs", "b1", "b2", "x_lp", "z0", "t", "z1", "h",
-                                          "out")] + [(n, C.c_int) for n in ("T", "C", "hidden", "outer")]
+                                          "out")] + [(n, C.c_int) for n in ("T", "C", "hidden", "outer", "y_bf16")]
 
 
 class _TailBwdArgs(C.Structure):
@@ -499,7 +499,12 @@ class _SkipMlpChainFn(torch.autograd.Function):
         shape = x.shape
         C_ = shape[-1]
         x2 = x.reshape(-1, C_).contiguous().float()
-        y2 = y.reshape(-1, C_).contiguous().float()
+        # y as a bf16 array (the spectral filter's synthesis wrote it that way for this launch: sht.InverseRealSHT(field_bf16=True))
+        # is read as it is; its gradient then leaves as the bf16 copy the weight-gradient product needs anyway
+        y2 = y.reshape(-1, C_).contiguous()
+        if y2.dtype != _BF:
+            y2 = y2.float()
+        ctx.y_bf16 = y2.dtype == _BF
         T, Hd = x2.shape[0], w1.shape[0]
         imgs, state = _chain_images(ws, w1, w2)
         if any(ctx.needs_input_grad):
@@ -513,7 +518,8 @@ class _SkipMlpChainFn(torch.autograd.Function):
         h = torch.empty(T, Hd, device=dev, dtype=_BF)
         out = torch.empty(T, C_, device=dev)
         a = _TailFwdArgs(L.ptr(x2), L.ptr(y2), L.ptr(imgs[0]), L.ptr(imgs[1]), L.ptr(imgs[2]), L.ptr(bs), L.ptr(b1), L.ptr(b2),
-                         L.ptr(x_lp), L.ptr(z0), L.ptr(t), L.ptr(z1), L.ptr(h), L.ptr(out), T, C_, Hd, int(bool(outer)))
+                         L.ptr(x_lp), L.ptr(z0), L.ptr(t), L.ptr(z1), L.ptr(h), L.ptr(out), T, C_, Hd, int(bool(outer)),
+                         int(ctx.y_bf16))
         L.check(L.load().dlwp_sfno_tail_fwd(C.byref(a), L.stream()))
         ctx.save_for_backward(x_lp, z0, t, z1, h, imgs)
         ctx.shape, ctx.outer = shape, bool(outer)
@@ -531,11 +537,11 @@ class _SkipMlpChainFn(torch.autograd.Function):
         g32 = gout.reshape(-1, C_).contiguous().float()
         g_lp = torch.empty(T, C_, device=dev, dtype=_BF)
         gh = torch.empty(T, Hd, device=dev, dtype=_BF)
-        gt = torch.empty(T, C_, device=dev)
         gt_lp = torch.empty(T, C_, device=dev, dtype=_BF)
+        gt = gt_lp if ctx.y_bf16 else torch.empty(T, C_, device=dev)          # a bf16 y takes a bf16 gradient: no fp32 copy is written
         gx = torch.empty(T, C_, device=dev)
         a = _TailBwdArgs(L.ptr(g32), L.ptr(imgs[3]), L.ptr(imgs[4]), L.ptr(imgs[5]), L.ptr(z1), L.ptr(z0), L.ptr(g_lp), L.ptr(gh),
-                         L.ptr(gt), L.ptr(gt_lp), L.ptr(gx), T, C_, Hd, int(ctx.outer))
+                         None if ctx.y_bf16 else L.ptr(gt), L.ptr(gt_lp), L.ptr(gx), T, C_, Hd, int(ctx.outer))
         L.check(L.load().dlwp_sfno_tail_bwd(C.byref(a), L.stream()))
         # The three weight gradients (+ bias gradients).  A rollout applies these weights once per lead time: the operand pairs
         # wait in the shared list and the LAST backward pass through the weights multiplies all of them in one product over the

@@ -615,9 +615,15 @@ int dlwp_sht_synthesis_bf16(const void* X, const void* S1t, const void* S2, cons
 /* The same with flags.  DLWP_SHT_TRIANGULAR: the caller guarantees X[l][.][m] = 0 for every order m > l (a spectrum that RealSHT  */
 /* produced, its image under the per-degree weights of dlwp_dhconv_apply, or the gradient of either): those entries are not     */
 /* read (48 % of the image at lmax = mmax = 32); with other spectra the flag gives wrong results.                               */
+/* DLWP_SHT_FIELD_BF16: the FIELD tensor (the synthesis output x, which then takes no residual; the analysis input x) is a bf16  */
+/* array in x's layout instead of fp32 -- for fields whose only other user is a bf16-operand kernel (the output y of an SFNO      */
+/* block's spectral filter, read once by dlwp_sfno_tail_fwd; the gradient the tail's backward call leaves in gt_lp).             */
 #define DLWP_SHT_TRIANGULAR 1
-int dlwp_sht_synthesis_bf16_ex(const void* X, const void* S1t, const void* S2, const float* residual, float* x, int B, int nlat,
+#define DLWP_SHT_FIELD_BF16 2
+int dlwp_sht_synthesis_bf16_ex(const void* X, const void* S1t, const void* S2, const float* residual, void* x, int B, int nlat,
                                int nlon, int C, int mmax, int lmax, int flags, void* stream);
+int dlwp_sht_analysis_bf16_ex(const void* x, const void* A1, const void* A2, void* X, int B, int nlat, int nlon, int C, int mmax,
+                              int lmax, int flags, void* stream);
 /* SFNO "driscoll-healy" spectral weights (torch_harmonics, constructed at                    */
 /* src/dlwpbench/models/fno/fno.py:183-200): w [Cin][Cout][L][2] complex, one matrix per       */
 /* degree l.  expand: wexp[l] = [[Wr, Wi], [-Wi, Wr]] as a real [2Cin][2Cout] matrix, so that   */
@@ -678,6 +684,7 @@ typedef struct dlwp_sfno_tail_fwd_args {
     void *z0, *t, *z1, *h;                  /* bf16 outputs: GELU'(z0) [T][C], t [T][C], GELU'(z1) [T][hidden], h [T][hidden] */
     float *out;                             /* [T][C] */
     int T, C, hidden, outer;
+    int y_bf16;                             /* != 0: y is a bf16 array [T][C] (dlwp_sht_synthesis_bf16_ex with DLWP_SHT_FIELD_BF16) */
 } dlwp_sfno_tail_fwd_args;
 typedef struct dlwp_sfno_tail_bwd_args {
     const float *g;                         /* [T][C] */
@@ -685,7 +692,7 @@ typedef struct dlwp_sfno_tail_bwd_args {
     const void *z1, *z0;                    /* the forward call's z1 / z0 arrays (activation derivatives, bf16) */
     void *g_lp;                             /* [T][C] bf16, nullable */
     void *gh;                               /* [T][hidden] bf16 */
-    float *gt;                              /* [T][C] */
+    float *gt;                              /* [T][C]; nullable: only the bf16 copy gt_lp is written */
     void *gt_lp;                            /* [T][C] bf16 */
     float *gx;                              /* [T][C] */
     int T, C, hidden, outer;

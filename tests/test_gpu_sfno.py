@@ -347,3 +347,30 @@ def test_sfnonet_shipped_fourcastnetv2_options_match_oracle(cuda):
             assert q.grad.abs().max() < 1e-6, n    # instance norm): both sides hold rounding noise only
             continue
         assert rel(q.grad, sd[n].grad) <= 2e-3, n
+
+
+def test_sht_bf16_field_flag_is_the_fp32_path_rounded_once(cuda):
+    """DLWP_SHT_FIELD_BF16: the synthesis output as a bf16 array equals the fp32 output rounded to bf16 (bit for bit), and the
+    analysis of a bf16 field equals the analysis of the same values held in fp32 -- at the C3 shape and at a ragged one."""
+    from dlwp_benchmark_amd import lib as L
+    lib = L.load()
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(41)
+    for B, K, N, C, M, Lm in ((4, 32, 64, 256, 32, 32), (3, 24, 40, 32, 12, 16)):
+        assert lib.dlwp_sht_bf16_supported(K, N, C, M, Lm) == 1
+        X = torch.randn(Lm, B, M, 2, C, generator=g).to(cuda).to(bf)
+        S1t = (torch.randn(M, K, Lm, generator=g) / 8).to(cuda).to(bf)
+        S2 = (torch.randn(N, 2 * M, generator=g) / 8).to(cuda).to(bf)
+        y32 = torch.empty(B, K, N, C, device=cuda)
+        y16 = torch.empty(B, K, N, C, device=cuda, dtype=bf)
+        L.check(lib.dlwp_sht_synthesis_bf16_ex(L.ptr(X), L.ptr(S1t), L.ptr(S2), None, L.ptr(y32), B, K, N, C, M, Lm, 0, L.stream()))
+        L.check(lib.dlwp_sht_synthesis_bf16_ex(L.ptr(X), L.ptr(S1t), L.ptr(S2), None, L.ptr(y16), B, K, N, C, M, Lm, 2, L.stream()))
+        assert torch.equal(y16, y32.to(bf))
+        A1 = (torch.randn(2 * M, N, generator=g) / 8).to(cuda).to(bf)
+        A2 = (torch.randn(M, Lm, K, generator=g) / 8).to(cuda).to(bf)
+        Xa, Xb = torch.empty_like(X), torch.empty_like(X)
+        L.check(lib.dlwp_sht_analysis_bf16_ex(L.ptr(y16.float()), L.ptr(A1), L.ptr(A2), L.ptr(Xa), B, K, N, C, M, Lm, 0, L.stream()))
+        L.check(lib.dlwp_sht_analysis_bf16_ex(L.ptr(y16), L.ptr(A1), L.ptr(A2), L.ptr(Xb), B, K, N, C, M, Lm, 2, L.stream()))
+        assert torch.equal(Xa, Xb)
+    # a bf16 output takes no residual
+    assert lib.dlwp_sht_synthesis_bf16_ex(L.ptr(X), L.ptr(S1t), L.ptr(S2), L.ptr(y32), L.ptr(y16), B, K, N, C, M, Lm, 2, L.stream()) != 0
