@@ -49,7 +49,10 @@ __global__ __launch_bounds__(256) void chain_pack_kernel(const float* __restrict
 
 // the six images of a block tail in one launch: blockIdx.y = image (forward Ws, W1, W2; backward W2^T, W1^T, Ws^T)
 struct PackSix { const float* W[6]; int ld[6], rows[6], cols[6], tr[6]; __bf16* img[6]; };
-__global__ __launch_bounds__(256) void chain_pack6_kernel(PackSix a) {
+constexpr int PACK_MANY = 8;          // block tails per dlwp_sfno_tail_pack_many launch
+struct PackSixMany { PackSix b[PACK_MANY]; };
+__global__ __launch_bounds__(256) void chain_pack6_kernel(PackSixMany many) {
+    const PackSix& a = many.b[blockIdx.z];
     const int i = blockIdx.y;
     const int KS = a.cols[i] / 32;
     const long long total = (long long)(a.rows[i] / 16) * KS * 64;
@@ -263,26 +266,36 @@ extern "C" int dlwp_mlp_chain_pack(const float* W, int rows, int cols, int trans
     return DLWP_OK;
 }
 
-extern "C" int dlwp_sfno_tail_pack(const float* ws, const float* w1, const float* w2, int C, int hidden, void* images, void* stream) {
-    DLWP_REQUIRE(ws && w1 && w2 && images, DLWP_E_INVALID, "sfno_tail_pack: null pointer");
-    DLWP_REQUIRE(C > 0 && hidden > 0 && C % 32 == 0 && hidden % 32 == 0 && aligned16(images), DLWP_E_INVALID,
-                 "sfno_tail_pack: C = %d and hidden = %d must be multiples of 32, the images 16-byte aligned", C, hidden);
-    PackSix a{};
-    const float* W[6] = {ws, w1, w2, w2, w1, ws};
-    const int rows[6] = {C, hidden, C, hidden, C, C}, cols[6] = {C, C, hidden, C, hidden, C}, tr[6] = {0, 0, 0, 1, 1, 1};
+extern "C" int dlwp_sfno_tail_pack_many(const float* const* ws, const float* const* w1, const float* const* w2, int n, int C, int hidden,
+                                        void* const* images, void* stream) {
+    DLWP_REQUIRE(ws && w1 && w2 && images && n >= 1 && n <= PACK_MANY, DLWP_E_INVALID, "sfno_tail_pack: %d block tails (1..%d) / null table", n, PACK_MANY);
+    DLWP_REQUIRE(C > 0 && hidden > 0 && C % 32 == 0 && hidden % 32 == 0, DLWP_E_INVALID,
+                 "sfno_tail_pack: C = %d and hidden = %d must be multiples of 32", C, hidden);
+    PackSixMany many{};
     long long most = 0;
-    for (int i = 0; i < 6; ++i) {
-        a.W[i] = W[i];
-        a.rows[i] = rows[i];
-        a.cols[i] = cols[i];
-        a.tr[i] = tr[i];
-        a.ld[i] = tr[i] ? rows[i] : cols[i];
-        a.img[i] = reinterpret_cast<__bf16*>(images) + (long long)i * C * hidden;
-        most = std::max(most, (long long)(rows[i] / 16) * (cols[i] / 32) * 64);
+    for (int b = 0; b < n; ++b) {
+        DLWP_REQUIRE(ws[b] && w1[b] && w2[b] && images[b] && aligned16(images[b]), DLWP_E_INVALID, "sfno_tail_pack: block %d: null / unaligned pointer", b);
+        PackSix& a = many.b[b];
+        const float* W[6] = {ws[b], w1[b], w2[b], w2[b], w1[b], ws[b]};
+        const int rows[6] = {C, hidden, C, hidden, C, C}, cols[6] = {C, C, hidden, C, hidden, C}, tr[6] = {0, 0, 0, 1, 1, 1};
+        for (int i = 0; i < 6; ++i) {
+            a.W[i] = W[i];
+            a.rows[i] = rows[i];
+            a.cols[i] = cols[i];
+            a.tr[i] = tr[i];
+            a.ld[i] = tr[i] ? rows[i] : cols[i];
+            a.img[i] = reinterpret_cast<__bf16*>(images[b]) + (long long)i * C * hidden;
+            most = std::max(most, (long long)(rows[i] / 16) * (cols[i] / 32) * 64);
+        }
     }
-    hipLaunchKernelGGL(chain_pack6_kernel, dim3((unsigned)((most + 255) / 256), 6), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(chain_pack6_kernel, dim3((unsigned)((most + 255) / 256), 6, n), dim3(256), 0, (hipStream_t)stream, many);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
+}
+
+extern "C" int dlwp_sfno_tail_pack(const float* ws, const float* w1, const float* w2, int C, int hidden, void* images, void* stream) {
+    DLWP_REQUIRE(ws && w1 && w2 && images, DLWP_E_INVALID, "sfno_tail_pack: null pointer");
+    return dlwp_sfno_tail_pack_many(&ws, &w1, &w2, 1, C, hidden, &images, stream);
 }
 
 extern "C" int dlwp_sfno_tail_fwd(const dlwp_sfno_tail_fwd_args* p, void* stream) {

@@ -161,6 +161,9 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         from .. import sfno_ops
         from ..sht import prepack_spectral_weights
         prepack_spectral_weights([blk.filter.weight for blk in self.blocks])      # all layers' images in one launch per pass
+        from ..token_ops import prepack_chain_images
+        prepack_chain_images([(blk.inner_skip.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight) for blk in self.blocks
+                              if blk.mlp is not None and blk.norm1 is None])      # ... and every block tail's six images in another
         t, tok_lp, link, alias = sfno_ops.encode(self, sources, frame_index)
         for blk in self.blocks:
             t = blk(t)

@@ -113,6 +113,7 @@ SIGNATURES = {
     "dlwp_mlp_chain_supported": (_I, [_I, _I]),
     "dlwp_mlp_chain_pack": (_I, [_V, _I, _I, _I, _V, _V]),
     "dlwp_sfno_tail_pack": (_I, [_V, _V, _V, _I, _I, _V, _V]),
+    "dlwp_sfno_tail_pack_many": (_I, [_V, _V, _V, _I, _I, _I, _V, _V]),
     "dlwp_mlp_stream_supported": (_I, [_I, _I]),
     "dlwp_mlp_stream_pack": (_I, [_V, _V, _I, _I, _V, _V]),
     "dlwp_mlp_stream_fwd": (_I, [_V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _I, _I, _V]),

@@ -479,6 +479,29 @@ def _chain_images(ws, w1, w2):
     return imgs, state
 
 
+def prepack_chain_images(tails):
+    """Inside a sht.spectral_weight_scope: the images of every block tail in `tails` ([(ws, w1, w2)], equal widths) that has none
+    yet, in ONE launch (dlwp_sfno_tail_pack_many) instead of one per block at its first use."""
+    from . import sht
+    scope = sht._wexp_scope
+    if scope is None or not tails or not CHAIN_TAIL or _act_dtype() != _BF:
+        return
+    todo = [t for t in tails if ("chain", id(t[0]), id(t[1]), id(t[2])) not in scope]
+    if not todo or len(todo) > 8 or any(t[0].shape != todo[0][0].shape or t[1].shape != todo[0][1].shape or not t[0].is_cuda for t in todo):
+        return
+    lib = L.load()
+    C_, Hd = todo[0][0].shape[0], todo[0][1].shape[0]
+    if lib.dlwp_mlp_chain_supported(C_, Hd) != 1:
+        return
+    imgs = torch.empty(len(todo), 6, C_ * Hd, device=todo[0][0].device, dtype=_BF)
+    srcs = [[w.detach().contiguous() for w in t] for t in todo]
+    arr = lambda k: (C.c_void_p * len(todo))(*[L.ptr(s_[k]) for s_ in srcs])
+    ip = (C.c_void_p * len(todo))(*[L.ptr(imgs[i]) for i in range(len(todo))])
+    L.check(lib.dlwp_sfno_tail_pack_many(arr(0), arr(1), arr(2), len(todo), C_, Hd, ip, L.stream()))
+    for i, t in enumerate(todo):
+        scope[("chain", id(t[0]), id(t[1]), id(t[2]))] = (imgs[i], t, {"uses": 0, "pending": []})
+
+
 CHAIN_TAIL = __import__("os").environ.get("DLWP_SFNO_CHAIN", "1") != "0"      # env: A/B runs against the three-GEMM tail
 
 

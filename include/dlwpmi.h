@@ -702,6 +702,9 @@ int dlwp_mlp_chain_pack(const float* W, int rows, int cols, int transpose, void*
 /* all six images of a tail in one launch: images [6][C * hidden] bf16 = forward Ws, W1, W2, backward W2^T, W1^T, Ws^T  */
 /* (the two C x C images use the front of their slots); ws [C][C], w1 [hidden][C], w2 [C][hidden] fp32.               */
 int dlwp_sfno_tail_pack(const float* ws, const float* w1, const float* w2, int C, int hidden, void* images, void* stream);
+/* the same for up to 8 block tails of equal widths in ONE launch (images[b]: the 6-image slot of block b) */
+int dlwp_sfno_tail_pack_many(const float* const* ws, const float* const* w1, const float* const* w2, int n, int C, int hidden,
+                             void* const* images, void* stream);
 int dlwp_sfno_tail_fwd(const dlwp_sfno_tail_fwd_args* args, void* stream);
 int dlwp_sfno_tail_bwd(const dlwp_sfno_tail_bwd_args* args, void* stream);
 /* Token MLP y = fc2(GELU(fc1 x)) (+ residual) of the AFNO / Swin / Pangu blocks (nsbench/models/fourcastnet/fourcastnet.py:40-56, */
