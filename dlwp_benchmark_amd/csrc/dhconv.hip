@@ -322,7 +322,7 @@ struct DwDev {
     const __bf16* X[MAXS];       // [L][R2][Ci]
     const __bf16* G[MAXS];       // [L][R2][Co]
     float* out;                  // [L][Ci][2 Co]
-    int nseg, R2, Ci, Co, M, sparse, ntn;
+    int nseg, R2, Ci, Co, M, sparse, ntn, L;
 };
 constexpr int GT = 128, KD = 64;
 
@@ -331,7 +331,20 @@ __global__ __launch_bounds__(256) void dhconv_wgrad_kernel(DwDev a) {
     __bf16* lds = reinterpret_cast<__bf16*>(dw_smem);          // [2 stages][A | B][KD][128]
     constexpr int TILE = GT * KD, NI = KD / 16;
     const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
-    const int l = blockIdx.y, mt = blockIdx.x / a.ntn, nt_ = blockIdx.x - mt * a.ntn;
+    // (speed only) the tiles of one degree read the same spectrum rows: one XCD per degree group, as in the apply kernel
+    int l, tix;
+    {
+        const int ntile = gridDim.x / a.L, id = blockIdx.x;
+        if (a.L % 8 == 0) {
+            const int xcd = id & 7, j = id >> 3;
+            tix = j % ntile;
+            l = (j / ntile) * 8 + xcd;
+        } else {
+            tix = id % ntile;
+            l = id / ntile;
+        }
+    }
+    const int mt = tix / a.ntn, nt_ = tix - mt * a.ntn;
     const int m0 = mt * GT, n0 = nt_ * GT, Ci = a.Ci, Co = a.Co;
     const bool conj = n0 >= Co;                                // second half of the columns: gY' (pairs swapped, second negated)
     const int b0 = conj ? n0 - Co : n0;
@@ -565,9 +578,10 @@ extern "C" int dlwp_dhconv_wgrad(const void* const* X, const void* const* gY, in
     a.out = G; a.nseg = nseg; a.R2 = rows; a.Ci = Cin; a.Co = Cout; a.M = std::max(mmax, 1);
     a.sparse = mmax > 0 && (2 * mmax) % 32 == 0 && rows % (2 * mmax) == 0;
     a.ntn = 2 * Cout / GT;
+    a.L = L;
     const size_t lds = (size_t)2 * 2 * GT * KD * sizeof(__bf16);
     if (int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(dhconv_wgrad_kernel), lds, "dhconv_wgrad")) return rc;
-    hipLaunchKernelGGL(dhconv_wgrad_kernel, dim3((Cin / GT) * a.ntn, L), dim3(256), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(dhconv_wgrad_kernel, dim3((Cin / GT) * a.ntn * L), dim3(256), lds, (hipStream_t)stream, a);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }

@@ -37,6 +37,7 @@ struct WgDev {
     long long out_off[MAXP + 1];      // element offset of each product inside one slab slice
     float* slab;                      // [slices][out_off[nprod]]
     int nprod, T, kchunk, sps;        // sps = K slices per segment
+    int nslices;                      // segments x sps
 };
 
 __global__ __launch_bounds__(256) void wgrad_multi_kernel(WgDev a) {
@@ -44,17 +45,28 @@ __global__ __launch_bounds__(256) void wgrad_multi_kernel(WgDev a) {
     __bf16* lds = reinterpret_cast<__bf16*>(wsm);          // [2 stages][A | B][KD][128]
     constexpr int TILE = GT * KD, NI = KD / 16;
     const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
-    int tile_id = blockIdx.x;
+    // Speed only: the tiles of ONE K slice read the same token rows of up to six operand arrays (each 128-column piece by 2 - 4 of
+    // them), so a slice's tiles run on one XCD (equal blockIdx % 8 under round-robin placement), back to back: the rows come from
+    // that XCD's L2 after their first fetch.  Dealt over the XCDs (round 4) every tile fetched its own copy across the fabric:
+    // 2.4 x the unique bytes at the C3 shapes.
+    int tile_id, slice;
     {
-        const int nt = gridDim.x, full = (nt / 8) * 8;     // XCD-aware order: each XCD walks a contiguous range of tiles
-        if (tile_id < full) tile_id = (tile_id % 8) * (nt / 8) + tile_id / 8;
+        const int nt = a.tile0[a.nprod], id = blockIdx.x;
+        if (a.nslices % 8 == 0) {
+            const int xcd = id & 7, j = id >> 3;
+            tile_id = j % nt;
+            slice = (j / nt) * 8 + xcd;
+        } else {
+            tile_id = id % nt;
+            slice = id / nt;
+        }
     }
     int p = 0;
     while (p + 1 < a.nprod && tile_id >= a.tile0[p + 1]) ++p;
     const int local = tile_id - a.tile0[p], ntn = a.ntn[p];
     const int mt = local / ntn, nt_ = local - mt * ntn;
     const int m0 = mt * GT, n0 = nt_ * GT, M = a.M[p], N = a.N[p];
-    const int seg = blockIdx.z / a.sps, zz = blockIdx.z - seg * a.sps;
+    const int seg = slice / a.sps, zz = slice - seg * a.sps;
     const int kbeg = zz * a.kchunk, kend = min(a.T, kbeg + a.kchunk);
     const __bf16* A = a.A[p][seg];
     const __bf16* B = a.B[p][seg];
@@ -146,7 +158,7 @@ __global__ __launch_bounds__(256) void wgrad_multi_kernel(WgDev a) {
             if (g == 0 && m < M) atomic_add_f32(&a.rowsum[p][m], v);
         }
     }
-    float* out = a.slab + (long long)blockIdx.z * a.out_off[a.nprod] + a.out_off[p];
+    float* out = a.slab + (long long)slice * a.out_off[a.nprod] + a.out_off[p];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -238,7 +250,8 @@ extern "C" int dlwp_wgrad_segments(const dlwp_wgrad_seg_product* p, int nprod, i
     const size_t lds = (size_t)2 * 2 * GT * KD * sizeof(__bf16);
     if (int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(wgrad_multi_kernel), lds, "wgrad_multi")) return rc;
     const hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(wgrad_multi_kernel, dim3(a.tile0[nprod], 1, slices), dim3(256), lds, s, a);
+    a.nslices = slices;
+    hipLaunchKernelGGL(wgrad_multi_kernel, dim3(a.tile0[nprod] * slices), dim3(256), lds, s, a);
     DLWP_LAUNCH_CHECK();
     const long long units = a.out_off[nprod] / 4;
     hipLaunchKernelGGL(wgrad_multi_reduce_kernel, dim3((unsigned)std::min<long long>((units + 255) / 256, 2048)), dim3(256), 0, s, a, slices);
