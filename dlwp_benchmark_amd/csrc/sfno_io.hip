@@ -107,11 +107,12 @@ __global__ __launch_bounds__(512) void sfno_io_kernel(IoDev a) {
 #pragma unroll
     for (int ni = 0; ni < NT1; ++ni) {
         const int n = 16 * min(w + 8 * ni, NTL1 - 1) + 4 * g;
+        e1b[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (!BWD) e1b[ni] = *reinterpret_cast<const f32x4*>(a.b1 + n);
-        if constexpr (BWD) {
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-                e1z[mi][ni] = *reinterpret_cast<const bf16x4*>(a.zin + (long long)min(m0 + 16 * mi + r, a.T - 1) * N1 + n);
+        for (int mi = 0; mi < MT; ++mi) {
+            e1z[mi][ni] = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+            if constexpr (BWD) e1z[mi][ni] = *reinterpret_cast<const bf16x4*>(a.zin + (long long)min(m0 + 16 * mi + r, a.T - 1) * N1 + n);
         }
     }
     WFrag<NT2, KS2> wf2;
@@ -152,33 +153,9 @@ __global__ __launch_bounds__(512) void sfno_io_kernel(IoDev a) {
     f32x4 acc1[MT][NT1];
     zero_acc<MT, NT1>(acc1);
     mma<MT, NT1, KS1, K1>(acc1, wf1, img0, 0, r, g);
-#pragma unroll
-    for (int ni = 0; ni < NT1; ++ni) {
-        const int tile = w + 8 * ni, n = 16 * tile + 4 * g;
-        if (tile < NTL1) {
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi) {
-                const int row = 16 * mi + r;
-                const long long m = m0 + row;
-                float v[4], act[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if constexpr (BWD) {
-                        act[q] = acc1[mi][ni][q] * gelu_grad_f((float)e1z[mi][ni][q]);
-                    } else {
-                        v[q] = acc1[mi][ni][q] + e1b[ni][q];
-                        act[q] = gelu_f(v[q]);
-                    }
-                }
-                const bf16x4 ab = to_bf4(act);
-                img_store<N1>(img1, row, n, ab);
-                if (m < a.T) {
-                    *reinterpret_cast<bf16x4*>(a.a + m * N1 + n) = ab;
-                    if constexpr (!BWD) *reinterpret_cast<bf16x4*>(a.z + m * N1 + n) = to_bf4(v);
-                }
-            }
-        }
-    }
+    // (round 5) the block tail's epilogue: 16-byte pieces, and the forward stores GELU' (in the array called z) for the backward
+    // launch to multiply by
+    chain_epilogue<MT, NT1, N1, NTL1, BWD>(acc1, [&](int, int ni) { return e1b[ni]; }, e1z, img1, a.a, a.z, nullptr, m0, a.T, w, r, g);
     lds_barrier();
 
     // ---- stage 2

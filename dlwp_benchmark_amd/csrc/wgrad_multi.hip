@@ -220,6 +220,13 @@ int plan(const dlwp_wgrad_seg_product* p, int nprod, int nseg, int T, WgDev* dev
     // K slices per segment: the grid should fill the resident slots (two 64 KB workgroups per CU) once; at least eight K-steps per slice
     const int slots = dlwp_tune_or("WGRAD_MULTI_WGS", 512);
     int sps = std::max(1, std::min((slots + tiles * nseg / 2) / (tiles * nseg), std::max(1, T / (8 * KD))));
+    {   // a slice count that is a multiple of 8 lets the kernel keep a slice's tiles on one XCD: round sps up where that costs little
+        int q = 8;
+        for (int d = 8; d >= 1; d >>= 1)
+            if (nseg % d == 0) { q = 8 / d; break; }
+        const int up = ceil_div(sps, q) * q;
+        if (up <= 2 * sps && T / up >= 2 * KD) sps = up;
+    }
     a.kchunk = ceil_div(ceil_div(T, sps), KD) * KD;
     sps = ceil_div(T, a.kchunk);
     a.sps = sps;
