@@ -51,6 +51,7 @@ struct GemmDev {
     // above are then __bf16*, leading dimensions and batch strides stay in elements).  Accumulation and epilogue run in fp32.
     int dt;
     float* slab;               // gemm_glds_tn_kernel: [K slices][M][N] partial products (plain stores; gemm_slab_reduce_kernel adds them)
+    int xcd_splitk;            // gemm_kernel, nbatch == 1, splits % 8 == 0: the tiles of one K slice run on one XCD (see gemm_body)
 };
 constexpr int DT_A = 1, DT_B = 2, DT_C = 4, DT_R = 8;
 
@@ -396,8 +397,15 @@ __device__ __forceinline__ void gemm_body(GemmDev a, const int bx, const int bz,
     // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so consecutive ids never
     // share an L2.  Remap so that every XCD walks a contiguous range of tiles, row-panel by row-panel: the A panel that the
     // ntn column tiles of one row panel share is then fetched into ONE L2 instead of eight.
-    int tile_id = bx;
-    {
+    int tile_id = bx, bzz = bz;
+    if (a.nbatch == 1 && a.splits > 1 && a.splits % 8 == 0 && a.xcd_splitk) {
+        // split-K products with few tiles (weight gradients: K = tokens): the tiles of ONE K slice read the same token rows, so a
+        // slice's tiles run on one XCD, back to back (round 5; as in wgrad_multi_kernel).  The contiguous-range order below needs
+        // gridDim.x % 8 == 0 to mean anything; with 12 tiles x 43 slices every tile fetched its own copy of the rows across the fabric
+        const int id = bx + ntiles_grid * bz, xcd = id & 7, j = id >> 3;
+        tile_id = j % ntiles_grid;
+        bzz = (j / ntiles_grid) * 8 + xcd;
+    } else {
         const int nt = ntiles_grid, full = (nt / 8) * 8;
         if (tile_id < full) tile_id = (tile_id % 8) * (nt / 8) + tile_id / 8;
     }
@@ -408,7 +416,7 @@ __device__ __forceinline__ void gemm_body(GemmDev a, const int bx, const int bz,
     const int rows_in = min(GM, a.ntm - grp * GM);
     const int nt_ = within / rows_in, mt = grp * GM + (within - nt_ * rows_in);
     const int m0 = mt * BMN, n0 = nt_ * BMN;
-    int zs = bz;
+    int zs = bzz;
     if (a.nbatch > 1) {
         const int zb = zs / a.splits;                 // batch index; zs % splits = K split within the batch
         zs -= zb * a.splits;
@@ -807,14 +815,18 @@ __global__ __launch_bounds__(256) void gemm_glds_tn_kernel(GemmDev a) {
     __bf16* lds = reinterpret_cast<__bf16*>(gsm);          // [2 stages][A | B][KD][128]
     constexpr int TILE = GT * KD, NI = KD / 16;
     const int lane = lane_id(), w = wave_id(), r = lane & 15, g = lane >> 4;
-    int tile_id = blockIdx.x;
-    {
+    int tile_id = blockIdx.x, slice = blockIdx.z;
+    if (a.xcd_splitk) {                  // few tiles x (8 n) slices: the tiles of one slice on one XCD (see gemm_body)
+        const int nt = gridDim.x, id = blockIdx.x + nt * blockIdx.z, xcd = id & 7, j = id >> 3;
+        tile_id = j % nt;
+        slice = (j / nt) * 8 + xcd;
+    } else {
         const int nt = gridDim.x, full = (nt / 8) * 8;
         if (tile_id < full) tile_id = (tile_id % 8) * (nt / 8) + tile_id / 8;
     }
     const int mt = tile_id / a.ntn, nt_ = tile_id - mt * a.ntn;
     const int m0 = mt * GT, n0 = nt_ * GT;
-    const int kbeg = blockIdx.z * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
+    const int kbeg = slice * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
     const __bf16* A = reinterpret_cast<const __bf16*>(a.A);
     const __bf16* B = reinterpret_cast<const __bf16*>(a.B);
     int krow[NI], acol[NI], bcol[NI];
@@ -912,7 +924,7 @@ __global__ __launch_bounds__(256) void gemm_glds_tn_kernel(GemmDev a) {
         }
     }
     const bool atomic = a.splits > 1;
-    float* out = a.slab ? a.slab + (long long)blockIdx.z * a.M * a.N : a.C;
+    float* out = a.slab ? a.slab + (long long)slice * a.M * a.N : a.C;
     const int ldo = a.slab ? a.N : a.ldc;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1007,6 +1019,14 @@ static int gemm_glds_tn_launch(const GemmDev& a_in, hipStream_t s) {
     // tools/bench_gemm_graph.py: 32 slices 22.6 us, 16 slices 17.4 us)
     int splits = std::max(1, std::min(slots / (a.ntn * a.ntm), a.K / (8 * kd)));
     a.kchunk = ceil_div(ceil_div(a.K, splits), kd) * kd;
+    a.xcd_splitk = 0;
+    if (splits >= 8 && a.ntn * a.ntm < 64 && (dlwp_tune_or("GEMM_XCD_SPLITK", 1) & 2) != 0) {
+        // few tiles, many slices: a slice count that is a multiple of 8 keeps the tiles of a slice on one XCD (round 5)
+        for (int s8 = round_up(splits, 8); s8 >= 8 && s8 > splits / 2; s8 -= 8) {
+            const int kc = ceil_div(ceil_div(a.K, s8), kd) * kd;
+            if (ceil_div(a.K, kc) % 8 == 0) { a.kchunk = kc; a.xcd_splitk = 1; break; }
+        }
+    }
     a.splits = std::max(2, ceil_div(a.K, a.kchunk));             // > 1: the atomic epilogue (the caller zeroed C for its own split)
     const size_t lds = (size_t)2 * 2 * GT * kd * 2;
     const dim3 grid(a.ntn * a.ntm, 1, ceil_div(a.K, a.kchunk));
@@ -1803,6 +1823,15 @@ static int gemm_impl(const float* A, const float* B, float* C, int M, int N, int
     if (!epilogue && tiles < 256 && K >= 8 * BK) splits = std::min(ceil_div(512, tiles), K / (4 * BK));
     int kchunk = ceil_div(ceil_div(K, splits), BK) * BK;
     splits = ceil_div(K, kchunk);
+    // a slice count that is a multiple of 8 lets the kernel keep the tiles of a K slice on one XCD (round 5): the nearest such
+    // count at or above the heuristic's that survives the K-step rounding
+    bool xcd_splitk = false;
+    if (splits >= 8 && (dlwp_tune_or("GEMM_XCD_SPLITK", 1) & 1) != 0) {
+        for (int s8 = round_up(splits, 8); s8 >= 8 && s8 > splits / 2; s8 -= 8) {
+            const int kc = ceil_div(ceil_div(K, s8), BK) * BK, sp = ceil_div(K, kc);
+            if (sp % 8 == 0) { kchunk = kc; splits = sp; xcd_splitk = true; break; }
+        }
+    }
     if (splits > 1 && !accumulate) {
         const int zrc = dlwp_zero_2d_f32(C, ldc, M, N, stream);
         if (zrc) return zrc;
@@ -1810,6 +1839,7 @@ static int gemm_impl(const float* A, const float* B, float* C, int M, int N, int
     GemmDev a{A, B, bias, residual, C, preact, rowsum, M, N, K, lda, ldb, ldc, act, accumulate, kchunk, splits,
               1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.f, 0, 0, 0};
     a.dt = dt;
+    a.xcd_splitk = xcd_splitk ? 1 : 0;
     return gemm_dispatch(a, transA, transB, T, stream);
 }
 
