@@ -500,7 +500,30 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
     }
     for (long long i = 4 * n4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = (__bf16)src[i];
 }
+// dst = bf16(src * scale[sample]) for `per` elements per sample (per % 4 == 0): the gradient of a DropPath branch on its way into the
+// branch's bf16 backward products
+__global__ __launch_bounds__(256) void cast_bf16_scaled_kernel(const float* __restrict__ src, const float* __restrict__ scale,
+                                                               __bf16* __restrict__ dst, long long per4, long long n4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float sc = scale[i / per4];
+        const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+        reinterpret_cast<bf16x4*>(dst)[i] = bf16x4{(__bf16)(v[0] * sc), (__bf16)(v[1] * sc), (__bf16)(v[2] * sc), (__bf16)(v[3] * sc)};
+    }
+}
 }  // namespace
+
+extern "C" int dlwp_cast_bf16_scaled(const float* src, const float* scale, void* dst, int nsamples, long long per_sample, void* stream) {
+    DLWP_REQUIRE(src && scale && dst && nsamples >= 0 && per_sample >= 0, DLWP_E_INVALID, "cast_bf16_scaled: bad argument");
+    DLWP_REQUIRE((uintptr_t)src % 16 == 0 && (uintptr_t)dst % 8 == 0 && per_sample % 4 == 0, DLWP_E_INVALID,
+                 "cast_bf16_scaled: buffers must be 16 / 8 byte aligned and per_sample a multiple of 4");
+    const long long n4 = (long long)nsamples * (per_sample / 4);
+    if (n4 == 0) return DLWP_OK;
+    const long long blocks = std::min<long long>((n4 + 255) / 256, 4096);
+    hipLaunchKernelGGL(cast_bf16_scaled_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, scale, (__bf16*)dst,
+                       per_sample / 4, n4);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
 
 extern "C" int dlwp_cast_bf16(const float* src, void* dst, long long n, void* stream) {
     DLWP_REQUIRE(src && dst && n >= 0, DLWP_E_INVALID, "cast_bf16: bad argument");

@@ -52,6 +52,10 @@ struct GemmDev {
     int dt;
     float* slab;               // gemm_glds_tn_kernel: [K slices][M][N] partial products (plain stores; gemm_slab_reduce_kernel adds them)
     int xcd_splitk;            // gemm_kernel, nbatch == 1, splits % 8 == 0: the tiles of one K slice run on one XCD (see gemm_body)
+    // per-sample scale of the product before the residual joins (dlwp_gemm_rowscale): C = (A.B + bias) * row_scale[m / scale_rows]
+    // + residual -- stochastic depth (DropPath) of a residual branch inside the epilogue of the branch's last product
+    const float* row_scale = nullptr;
+    int scale_rows = 1;
 };
 constexpr int DT_A = 1, DT_B = 2, DT_C = 4, DT_R = 8;
 
@@ -326,6 +330,15 @@ __device__ __forceinline__ void epilogue_group(const GemmDev& a, f32x4 (&v)[G], 
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[i][k] = apply_act(v[i][k], a.act, a.act_param);
         }
+        if (a.row_scale) {
+            float sc[G];
+#pragma unroll
+            for (int i = 0; i < G; ++i) sc[i] = a.row_scale[mrow[i] / a.scale_rows];
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[i][k] *= sc[i];
+        }
         if (!a.res_pre && a.residual) {
 #pragma unroll
             for (int i = 0; i < G; ++i)
@@ -584,6 +597,7 @@ __device__ __forceinline__ void gemm_body(GemmDev a, const int bx, const int bz,
                             if (a.preact) put1(a.preact, v);
                             v = apply_act(v, a.act, a.act_param);
                         }
+                        if (a.row_scale) v *= a.row_scale[m / a.scale_rows];
                         if (!a.res_pre) v += rres;
                     }
                     put1(a.C, a.accumulate ? a.C[o] + v : v);
@@ -1811,12 +1825,12 @@ static int dtypes_ok(int dt, int accumulate, const char* who) {
 
 static int gemm_impl(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                      int transA, int transB, const float* bias, int act, float* preact, const float* residual,
-                     int accumulate, float* rowsum, int dt, void* stream) {
+                     int accumulate, float* rowsum, int dt, void* stream, const float* row_scale = nullptr, int scale_rows = 1) {
     DLWP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, DLWP_E_INVALID, "gemm: NULL argument or empty shape");
     DLWP_REQUIRE(act == 0 || act == 1 || (act == ACT_GELU_STORE_D && preact), DLWP_E_INVALID,
                  "gemm: act must be 0 (none), 1 (gelu) or 7 (gelu with GELU' stored to a non-NULL preact)");
     if (int drc = dtypes_ok(dt, accumulate, "gemm")) return drc;
-    const bool epilogue = bias || act || preact || residual || (dt & DT_C);      // a bf16 output takes no split-K atomics
+    const bool epilogue = bias || act || preact || residual || row_scale || (dt & DT_C);      // a bf16 output takes no split-K atomics
     const int T = gemm_tile_for(M, N, 1, K, dt, !epilogue);
     const int tiles = ceil_div(N, 64 * T) * ceil_div(M, 64 * T);
     int splits = 1;
@@ -1840,6 +1854,8 @@ static int gemm_impl(const float* A, const float* B, float* C, int M, int N, int
               1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.f, 0, 0, 0};
     a.dt = dt;
     a.xcd_splitk = xcd_splitk ? 1 : 0;
+    a.row_scale = row_scale;
+    a.scale_rows = scale_rows;
     return gemm_dispatch(a, transA, transB, T, stream);
 }
 
@@ -1934,6 +1950,14 @@ extern "C" int dlwp_gemm_mixed(const void* A, const void* B, void* C, int M, int
                                int accumulate, float* rowsum, int dtypes, void* stream) {
     return gemm_impl((const float*)A, (const float*)B, (float*)C, M, N, K, lda, ldb, ldc, transA, transB, bias, act,
                      (float*)preact, (const float*)residual, accumulate, rowsum, dtypes, stream);
+}
+
+extern "C" int dlwp_gemm_rowscale(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                  int transA, int transB, const float* bias, const void* residual, const float* row_scale,
+                                  int rows_per_scale, int dtypes, void* stream) {
+    DLWP_REQUIRE(row_scale && rows_per_scale > 0, DLWP_E_INVALID, "gemm_rowscale: row_scale is NULL or rows_per_scale < 1");
+    return gemm_impl((const float*)A, (const float*)B, (float*)C, M, N, K, lda, ldb, ldc, transA, transB, bias, 0, nullptr,
+                     (const float*)residual, 0, nullptr, dtypes, stream, row_scale, rows_per_scale);
 }
 
 static int gemm_batched_impl(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,

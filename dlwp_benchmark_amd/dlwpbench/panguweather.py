@@ -166,25 +166,23 @@ class EarthSpecificBlock(nn.Module):
                     t = window_attention_tokens(qkv_tok, self.attn.qkv.bias, self.attn.earth_position_bias_table, self.attn._ia, self.attn._ib,
                                                 self._labels if self.roll else None, spec, fwd_shift, rev_shift, self.attn.num_heads,
                                                 float(self.attn.scale), self._qrange)
-                    if self.drop_path.active:
-                        t = self.attn.proj(t)
-                        skip, t = norm_fork(self.norm2, self.drop_path(t, residual=skip), gemm_input=True)
-                        return self.drop_path(self.mlp(t), residual=skip)
+                    if self.drop_path.active:        # stochastic depth: the per-sample scale rides proj's / fc2's epilogue
+                        skip, t = norm_fork(self.norm2, self.drop_path.branch(self.attn.proj, t, skip), gemm_input=True)
+                        return self.drop_path.branch(self.mlp, t, skip)
                     skip, t = norm_fork(self.norm2, self.attn.proj(t, residual=skip), gemm_input=True)
                     return self.mlp(t, residual=skip)
                 qkv = partition(qkv_tok, spec, fwd_shift, fill=self.attn.qkv.bias, fill_grad_from=C if self._kept_are_real else 0)
                 t = self.attn.core(qkv, self._labels if self.roll else None, spec.nW, self._qrange)
                 if self.drop_path.active:
-                    t = self.attn.proj(reverse(t, spec, B, rev_shift))
-                    skip, t = norm_fork(self.norm2, self.drop_path(t, residual=skip), gemm_input=True)
-                    return self.drop_path(self.mlp(t), residual=skip)
+                    skip, t = norm_fork(self.norm2, self.drop_path.branch(self.attn.proj, reverse(t, spec, B, rev_shift), skip), gemm_input=True)
+                    return self.drop_path.branch(self.mlp, t, skip)
                 skip, t = norm_fork(self.norm2, self.attn.proj(reverse(t, spec, B, rev_shift), residual=skip), gemm_input=True)
                 return self.mlp(t, residual=skip)
             skip, t = norm_fork(self.norm1, x)
             t = self.attn(partition(t, spec, fwd_shift), self._labels if self.roll else None, spec.nW)
             if self.drop_path.active:            # stochastic depth: per-sample scale fused with the residual adds
                 skip, t = norm_fork(self.norm2, self.drop_path(reverse(t, spec, B, rev_shift), residual=skip), gemm_input=True)
-                return self.drop_path(self.mlp(t), residual=skip)
+                return self.drop_path.branch(self.mlp, t, skip)
             skip, t = norm_fork(self.norm2, reverse(t, spec, B, rev_shift, residual=skip), gemm_input=True)
             return self.mlp(t, residual=skip)
         t = self.norm1(x).view(B, Pl, Lat, Lon, C)
@@ -200,7 +198,7 @@ class EarthSpecificBlock(nn.Module):
         t = t[:, p[4]:Plp - p[5], p[2]:Latp - p[3], p[0]:Lonp - p[1], :].reshape(B, Pl * Lat * Lon, C)
         if self.drop_path.active:
             x = self.drop_path(t, residual=x)
-            return self.drop_path(self.mlp(self.norm2(x)), residual=x)
+            return self.drop_path.branch(self.mlp, self.norm2(x), x)
         x = x + t
         return self.mlp(self.norm2(x), residual=x)
 

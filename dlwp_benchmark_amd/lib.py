@@ -91,6 +91,8 @@ SIGNATURES = {
     "dlwp_gemm_mixed": (_I, [_V, _V, _V] + [_I] * 8 + [_V, _I, _V, _V, _I, _V, _I, _V]),
     "dlwp_gemm_batched_mixed": (_I, [_V, _V, _V] + [_I] * 10 + [_L] * 6 + [_V, _L, _L, _I, _F, _V, _V, _L, _L, _I, _I, _I, _V]),
     "dlwp_cast_bf16": (_I, [_V, _V, _L, _V]),
+    "dlwp_gemm_rowscale": (_I, [_V, _V, _V] + [_I] * 8 + [_V, _V, _V, _I, _I, _V]),
+    "dlwp_cast_bf16_scaled": (_I, [_V, _V, _V, _I, _L, _V]),
     "dlwp_gemm_batched": (_I, [_V, _V, _V] + [_I] * 10 + [_L] * 6 + [_V, _L, _L, _I, _F, _V, _V, _L, _L, _I, _I, _V]),
     "dlwp_act_bwd": (_I, [_V, _V, _V, _L, _I, _F, _V]),
     "dlwp_sht_fused_supported": (_I, [_I] * 5),

@@ -318,16 +318,15 @@ class SwinTransformerBlock(nn.Module):
                 qkv = partition(self.attn.qkv(t), spec, fill=self.attn.qkv.bias if const_pad else None)
                 t = self.attn.core(qkv, labels if shifted else None, spec.nW)
                 if self.drop_path.active:
-                    t = self.attn.proj(reverse(t, spec, B))
-                    skip, t = norm_fork(self.norm2, self.drop_path(t, residual=skip), gemm_input=True)
-                    return self.drop_path(self.mlp(t), residual=skip)
+                    skip, t = norm_fork(self.norm2, self.drop_path.branch(self.attn.proj, reverse(t, spec, B), skip), gemm_input=True)
+                    return self.drop_path.branch(self.mlp, t, skip)
                 skip, t = norm_fork(self.norm2, self.attn.proj(reverse(t, spec, B), residual=skip), gemm_input=True)
                 return self.mlp(t, residual=skip)
             skip, t = norm_fork(self.norm1, x)
             t = self.attn(partition(t, spec), labels if shifted else None, spec.nW)
             if self.drop_path.active:        # training with stochastic depth (:255-256): per-sample scale + residual add
                 skip, t = norm_fork(self.norm2, self.drop_path(reverse(t, spec, B), residual=skip), gemm_input=True)
-                return self.drop_path(self.mlp(t), residual=skip)
+                return self.drop_path.branch(self.mlp, t, skip)
             skip, t = norm_fork(self.norm2, reverse(t, spec, B, residual=skip), gemm_input=True)
             return self.mlp(t, residual=skip)
         t = self.norm1(x).view(B, H, W, C)
@@ -343,7 +342,7 @@ class SwinTransformerBlock(nn.Module):
         t = t[:, :H, :W, :].reshape(B, H * W, C)
         if self.drop_path.active:
             x = self.drop_path(t, residual=x)
-            return self.drop_path(self.mlp(self.norm2(x)), residual=x)
+            return self.drop_path.branch(self.mlp, self.norm2(x), x)
         x = x + t
         return self.mlp(self.norm2(x), residual=x)   # residual add fused into fc2's epilogue
 

@@ -34,6 +34,29 @@ def _gemm(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, bias=None, act=0, preact=None
                                L.ptr(preact), L.ptr(residual), accumulate, L.ptr(rowsum), L.stream()))
 
 
+def _gemm_rowscale(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, bias, residual, row_scale):
+    """C = (op(A) op(B) + bias) * row_scale[sample of the row] + residual (dlwp_gemm_rowscale): M rows = row_scale.numel() samples
+    of equally many tokens."""
+    nb = row_scale.numel()
+    if nb == 0 or M % nb or row_scale.dtype != torch.float32 or not row_scale.is_contiguous():
+        raise L.DlwpError("gemm_rowscale: one contiguous fp32 scale per sample, the rows a whole multiple of the samples")
+    L.check(L.load().dlwp_gemm_rowscale(L.ptr(A), L.ptr(B), L.ptr(C), M, N, K, lda, ldb, ldc, tA, tB, L.ptr(bias), L.ptr(residual),
+                                        L.ptr(row_scale), M // nb, _dtypes(A, B, C, None, residual), L.stream()))
+
+
+def _scaled_grad(g2, row_scale, lowp):
+    """row_scale[sample] * g2 for the backward of a product that applied the scale (g2 fp32 [T][N]): as bf16 when the backward
+    products read bf16 operands (cast and scale in one pass), else fp32 (dlwp_scale_rows_add without a residual)."""
+    nb = row_scale.numel()
+    out = torch.empty_like(g2, dtype=_BF if lowp else torch.float32)
+    if lowp and (g2.numel() // nb) % 4 == 0:
+        L.check(L.load().dlwp_cast_bf16_scaled(L.ptr(g2), L.ptr(row_scale), L.ptr(out), nb, g2.numel() // nb, L.stream()))
+        return out
+    out = torch.empty_like(g2)
+    L.check(L.load().dlwp_scale_rows_add(L.ptr(g2), L.ptr(row_scale), None, L.ptr(out), nb, g2.numel() // nb, L.stream()))
+    return out
+
+
 def _wmat(w, rows):
     """(matrix the forward / input-gradient GEMMs read, fp32 matrix): the bf16 shadow of `w` when the engine keeps one."""
     w32 = w.contiguous().reshape(rows, -1)
@@ -98,8 +121,10 @@ class _LinearFn(torch.autograd.Function):
     weight is [N, K] or a 1x1 convolution weight [N, K, 1, 1] (same memory)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act, residual, res_pre=False, out_lowp=False):
-        """out_lowp (bf16 storage only, no activation / residual): y is written as bf16 for a consumer that reads bf16 rows (the
+    def forward(ctx, x, weight, bias, act, residual, res_pre=False, out_lowp=False, row_scale=None):
+        """row_scale (fp32 [samples], no activation): y = (x W^T + b) * row_scale[sample] + residual -- stochastic depth of the branch
+        this product ends, inside its epilogue (DropPath.branch).
+        out_lowp (bf16 storage only, no activation / residual): y is written as bf16 for a consumer that reads bf16 rows (the
         window-attention kernels in their token-layout bf16 mode); the upstream gradient then arrives as bf16 too and feeds both
         backward products without a cast."""
         shape = x.shape
@@ -115,10 +140,15 @@ class _LinearFn(torch.autograd.Function):
         y = torch.empty(T, N, device=x.device, dtype=_BF if lowp_out else torch.float32)
         z = torch.empty(T, N, device=x.device) if act else None
         r2 = residual.reshape(-1, N).contiguous() if residual is not None else None
-        if res_pre:
+        if row_scale is not None:
+            if act or res_pre:
+                raise L.DlwpError("linear: row_scale goes with no activation")
+            _gemm_rowscale(x2, w, y, T, N, K, K, K, N, 0, 1, bias, r2, row_scale)
+        elif res_pre:
             _gemm_batched(x2, w, y, T, N, K, K, K, N, 0, 1, bias=bias, act=act, preact=z, residual=r2, res_pre=1)
         else:
             _gemm(x2, w, y, T, N, K, K, K, N, 0, 1, bias, act, z, r2)
+        ctx.row_scale = row_scale
         ctx.save_for_backward(x2, w, z)
         ctx.has_bias, ctx.has_res, ctx.act, ctx.shape = bias is not None, residual is not None, act, shape
         ctx.res_pre, ctx.wshape = bool(res_pre) and act, weight.shape
@@ -134,9 +164,11 @@ class _LinearFn(torch.autograd.Function):
         T, K = x2.shape
         N = w.shape[0]
         g2 = gy.reshape(-1, N).contiguous()
-        if g2.dtype != _BF or w.dtype != _BF or ctx.act:      # (a bf16 gradient of a bf16 output feeds the bf16 products as it is)
+        if g2.dtype != _BF or w.dtype != _BF or ctx.act or ctx.row_scale is not None:      # (a bf16 gradient of a bf16 output feeds the bf16 products as it is)
             g2 = g2.float()
         gres = gy if ctx.has_res else None
+        if ctx.row_scale is not None:            # the branch's gradient is the scaled one; the residual's (gres) is not
+            g2 = _scaled_grad(g2, ctx.row_scale, w.dtype == _BF)
         if ctx.act:
             gz = torch.empty_like(g2)
             L.check(lib.dlwp_gelu_bwd(L.ptr(z), L.ptr(g2), L.ptr(gz), g2.numel(), L.stream()))
@@ -164,7 +196,7 @@ class _LinearFn(torch.autograd.Function):
             gw = gw.reshape(ctx.wshape)
         if ctx.bslot is not None:
             gb = None
-        return gx.reshape(ctx.shape), gw, gb, None, gres, None, None
+        return gx.reshape(ctx.shape), gw, gb, None, gres, None, None, None
 
 
 def _weight_grad(g2, x2, weight_slot, bias_slot, has_bias, wshape):
@@ -271,7 +303,8 @@ class _MlpFn(torch.autograd.Function):
     GELU'(z) (epilogue act 4), so the hidden-width gradient is written once and never re-read by an elementwise pass."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, residual):
+    def forward(ctx, x, w1, b1, w2, b2, residual, row_scale=None):
+        """row_scale (fp32 [samples]): y = fc2(...) * row_scale[sample] + residual (DropPath.branch)."""
         shape = x.shape
         x2 = x.reshape(-1, shape[-1]).contiguous()
         if x2.dtype != _BF:               # a bf16 input comes from a LayerNorm that wrote it for this GEMM (bf16 storage)
@@ -289,7 +322,11 @@ class _MlpFn(torch.autograd.Function):
         _gemm(x2, w1m, h, T, Hd, K, K, K, Hd, 0, 1, b1, _ACT_F, z, None)
         y = torch.empty(T, N, device=x.device)
         r2 = residual.reshape(-1, N).contiguous() if residual is not None else None
-        _gemm(h, w2m, y, T, N, Hd, Hd, Hd, N, 0, 1, b2, 0, None, r2)
+        if row_scale is not None:
+            _gemm_rowscale(h, w2m, y, T, N, Hd, Hd, Hd, N, 0, 1, b2, r2, row_scale)
+        else:
+            _gemm(h, w2m, y, T, N, Hd, Hd, Hd, N, 0, 1, b2, 0, None, r2)
+        ctx.row_scale = row_scale
         ctx.save_for_backward(x2, w1m, w2m, z, h)
         ctx.shape, ctx.has_res = shape, residual is not None
         ctx.in_dtype = x.dtype if x.dtype == _BF else torch.float32
@@ -305,7 +342,9 @@ class _MlpFn(torch.autograd.Function):
         T, K = x2.shape
         Hd, N = w1m.shape[0], w2m.shape[0]
         g2 = gy.reshape(-1, N).contiguous().float()
-        if h.dtype == _BF:
+        if ctx.row_scale is not None:
+            g2 = _scaled_grad(g2, ctx.row_scale, h.dtype == _BF)
+        elif h.dtype == _BF:
             g2 = _lowp(g2, Hd)                   # read by gh = g W2 and gW2 = g^T h
         gh = torch.empty(T, Hd, device=g2.device, dtype=h.dtype)
         _gemm_batched(g2, w2m, gh, T, Hd, N, N, Hd, Hd, 0, 0, act=_ACT_B, residual=z)     # (g W2) * GELU'(z), z = the stored derivative
@@ -321,7 +360,7 @@ class _MlpFn(torch.autograd.Function):
             _gemm(gh, w1m, gx, T, K, Hd, Hd, K, K, 0, 0)
             (gw2, gb2), (gw1, gb1) = _weight_grad_group([(g2, h, ctx.slots[2], ctx.slots[3], ctx.has_b[1], ctx.w2shape),
                                                          (gh, x2, ctx.slots[0], ctx.slots[1], ctx.has_b[0], ctx.w1shape)])
-        return gx.reshape(ctx.shape), gw1, gb1, gw2, gb2, (gy if ctx.has_res else None)
+        return gx.reshape(ctx.shape), gw1, gb1, gw2, gb2, (gy if ctx.has_res else None), None
 
 
 # opt-in (DLWP_MLP_STREAM=1): measured 321 / 267 us forward / backward at T = 16200, E = 768 against 238 us for the forward's two GEMMs in
@@ -384,10 +423,10 @@ class _MlpStreamFn(torch.autograd.Function):
         return gx.reshape(ctx.shape), gw1, gb1, gw2, gb2, (gy if ctx.has_res else None)
 
 
-def mlp(x, w1, b1, w2, b2, residual=None):
-    if _MlpStreamFn.applies(x, w1, w2):
+def mlp(x, w1, b1, w2, b2, residual=None, row_scale=None):
+    if row_scale is None and _MlpStreamFn.applies(x, w1, w2):
         return _MlpStreamFn.apply(x, w1, b1, w2, b2, residual)
-    return _MlpFn.apply(x, w1, b1, w2, b2, residual)
+    return _MlpFn.apply(x, w1, b1, w2, b2, residual, row_scale)
 
 
 class _SkipMlpFn(torch.autograd.Function):
@@ -731,6 +770,10 @@ def norm_fork(norm, x, gemm_input=False):
     return norm.fork(x, gemm_input) if hasattr(norm, "fork") else (x, norm(x))
 
 
+# env: A/B runs of the DropPath scale inside the GEMM epilogues (round 5) against the separate dlwp_scale_rows_add pass
+DROPPATH_FUSED = __import__("os").environ.get("DLWP_DROPPATH_FUSED", "1") != "0"
+
+
 class DropPath(nn.Module):
     """Stochastic depth per sample (timm.models.layers.DropPath, used at nsbench/models/swintransformer/
     swin_transformer.py:193,255-256, dlwpbench twin :192,261-262 and panguweather.py:262-323): in training mode the whole
@@ -748,16 +791,29 @@ class DropPath(nn.Module):
     def active(self):
         return self.training and self.p > 0.0
 
+    def mask(self, batch, device):
+        """This call's per-sample scales (0 or 1 / keep), fp32 [batch]: from the model's pool when it drew for this call."""
+        mask = self._pool.take(self._pool_index, batch) if self._pool is not None else None
+        if mask is None:
+            keep = 1.0 - self.p
+            mask = torch.empty(batch, device=device, dtype=torch.float32).bernoulli_(keep)
+            if keep > 0.0 and self.scale_by_keep:
+                mask = mask / keep
+        return mask
+
     def forward(self, t, residual=None):
         if not self.active:
             return t if residual is None else residual + t
-        mask = self._pool.take(self._pool_index, t.shape[0]) if self._pool is not None else None
-        if mask is None:
-            keep = 1.0 - self.p
-            mask = torch.empty(t.shape[0], device=t.device, dtype=torch.float32).bernoulli_(keep)
-            if keep > 0.0 and self.scale_by_keep:
-                mask = mask / keep
-        return _ScaleRowsAddFn.apply(t, mask, residual)
+        return _ScaleRowsAddFn.apply(t, self.mask(t.shape[0], t.device), residual)
+
+    def branch(self, fn, t, residual):
+        """residual + drop_path(fn(t)) for a Linear / Mlp module `fn` (residual [batch, tokens, C]): the per-sample scale and the residual
+        add run in the epilogue of fn's last product (dlwp_gemm_rowscale) instead of a pass of their own over the tokens."""
+        if not self.active:
+            return fn(t, residual=residual)
+        if not DROPPATH_FUSED:
+            return self(fn(t), residual=residual)
+        return fn(t, residual=residual, row_scale=self.mask(residual.shape[0], t.device))
 
     def extra_repr(self):
         return f"drop_prob={self.p:0.3f}"
@@ -848,8 +904,8 @@ class InstanceNorm(nn.Module):
 
 
 class Linear(nn.Linear):
-    def forward(self, x, act=0, residual=None, out_lowp=False):
-        return _LinearFn.apply(x, self.weight, self.bias, act, residual, False, out_lowp)
+    def forward(self, x, act=0, residual=None, out_lowp=False, row_scale=None):
+        return _LinearFn.apply(x, self.weight, self.bias, act, residual, False, out_lowp, row_scale)
 
 
 class LayerNorm(nn.LayerNorm):
@@ -876,8 +932,8 @@ class Mlp(nn.Module):
         self.act = nn.GELU()   # kept for module-tree compatibility; applied inside fc1's epilogue
         self.fc2 = Linear(hidden_features or in_features, out_features or in_features)
 
-    def forward(self, x, residual=None):
-        return mlp(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, residual)
+    def forward(self, x, residual=None, row_scale=None):
+        return mlp(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, residual, row_scale)
 
 
 class PatchConv2d(nn.Conv2d):

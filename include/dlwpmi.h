@@ -580,8 +580,20 @@ int dlwp_gemm_batched_mixed(const void* A, const void* B, void* C, int M, int N,
                             long long sBi2, int act, float act_param, void* preact,
                             const void* residual, long long sR1, long long sR2, int res_before_act,
                             int accumulate, int dtypes, void* stream);
+/* Stochastic depth inside the last product of a residual branch (timm DropPath as the reference's Swin / Pangu */
+/* blocks apply it: x = shortcut + drop_path(branch(x)), nsbench swin_transformer.py:255-256, dlwpbench         */
+/* panguweather.py:317-323): C = (op(A) op(B) + bias) * row_scale[m / rows_per_scale] + residual, row_scale one   */
+/* fp32 number per sample (0 or 1 / keep), rows_per_scale = tokens per sample.  Storage mask as dlwp_gemm_mixed.  */
+/* No activation, pre-activation output, accumulation or row sums in this form.                                   */
+int dlwp_gemm_rowscale(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb,
+                       int ldc, int transA, int transB, const float* bias, const void* residual,
+                       const float* row_scale, int rows_per_scale, int dtypes, void* stream);
 /* dst[i] = bf16(src[i]) (round to nearest even): the per-step bf16 copy of the flat fp32 master weights.     */
 int dlwp_cast_bf16(const float* src, void* dst, long long n, void* stream);
+/* dst[s][i] = bf16(src[s][i] * scale[s]), i < per_sample (a multiple of 4): the backward of dlwp_gemm_rowscale's */
+/* scale on the way into the branch's bf16 products.                                                              */
+int dlwp_cast_bf16_scaled(const float* src, const float* scale, void* dst, int nsamples, long long per_sample,
+                          void* stream);
 /* Fused real spherical harmonic transforms on channels-last fields (torch_harmonics.RealSHT /  */
 /* InverseRealSHT, constructed at src/dlwpbench/models/fno/fno.py:183-200 and                   */
 /* models/fourcastnet/fourcastnet.py:411-428): longitude DFT and Legendre   */

@@ -113,6 +113,104 @@ def test_swin_eval_ignores_drop_path_and_train_uses_it(cuda):
         assert not torch.allclose(y1, b(x, 3))         # and the masks do something
 
 
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+@pytest.mark.parametrize("B,T,C,Hd", [(3, 40, 32, 64), (1, 200, 192, 768), (5, 13, 20, 36)])
+def test_drop_path_inside_the_product_epilogue_equals_the_separate_pass(cuda, storage, B, T, C, Hd):
+    """DropPath.branch (dlwp_gemm_rowscale: per-sample scale + residual in the epilogue of proj / fc2, scaled gradient cast by
+    dlwp_cast_bf16_scaled) against drop_path(fn(t), residual) with the same masks: forward and every gradient.  fp32 storage:
+    1e-5 of the max norm (same products, the scale applied to the fp32 accumulator instead of the stored fp32 value); bf16 storage:
+    2e-2 (the unfused backward rounds the unscaled gradient to bf16 where its depth says so, the fused one the scaled gradient)."""
+    import importlib
+    from dlwp_benchmark_amd import lib as L, token_ops as TO
+    g = torch.Generator().manual_seed(B * 100 + T)
+    lin, mlp = TO.Linear(C, C).to(cuda), TO.Mlp(C, Hd).to(cuda)
+    dp = TO.DropPath(0.4).to(cuda).train()
+    t0 = torch.randn(B, T, C, generator=g).to(cuda)
+    r0 = torch.randn(B, T, C, generator=g).to(cuda)
+    gy = torch.randn(B, T, C, generator=g).to(cuda)
+    masks = (torch.rand(2, B, generator=g) > 0.4).float().to(cuda) / 0.6
+    masks[0, 0], masks[1, -1] = 1 / 0.6, 0.0                # both kinds of sample present whatever the draw
+
+    def run(fused):
+        it = iter(masks)
+        dp.mask = lambda batch, device: next(it)
+        TO.DROPPATH_FUSED = fused
+        for m in (lin, mlp):
+            m.zero_grad(set_to_none=True)
+        t, r = t0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+        y = dp.branch(mlp, dp.branch(lin, t, r), r)
+        y.backward(gy)
+        return [y.detach(), t.grad, r.grad] + [p.grad.clone() for m in (lin, mlp) for p in m.parameters()]
+
+    try:
+        if storage == "bf16":
+            for m in (lin, mlp):             # the engine's bf16 weight copies (train_engine.flatten_parameters)
+                for q in m.parameters():
+                    q._dlwp_bf16 = q.detach().to(torch.bfloat16)
+            with L.gemm_precision("bf16"):
+                L.set_storage("bf16")
+                L.SHADOW_ACTIVE = True
+                try:
+                    a, b = run(True), run(False)
+                finally:
+                    L.SHADOW_ACTIVE = False
+                    L.set_storage("fp32")
+        else:
+            a, b = run(True), run(False)
+    finally:
+        TO.DROPPATH_FUSED = True
+    tol = 1e-5 if storage == "fp32" else 2e-2
+    for x, y in zip(a, b):
+        assert (x - y).abs().max().item() <= tol * y.abs().max().item() + 1e-12
+    # a dropped sample's branch contributes nothing: output = residual there, and no gradient reaches the branch input
+    assert torch.equal(a[0][-1], r0[-1]) if B > 1 else True
+
+
+@pytest.mark.parametrize("dt", [0, 3, 7, 15])
+@pytest.mark.parametrize("M,N,K,nb", [(256, 192, 128, 4), (90, 72, 52, 3), (77, 29, 13, 7), (512, 192, 768, 2)])
+def test_gemm_rowscale_matches_the_definition(cuda, M, N, K, nb, dt):
+    """C = (A B^T + bias) * s[m / rows_per_scale] + residual in float64 on the operands as stored; 1e-5 relative (fp32 operands),
+    the bf16 forms within one rounding of the output (4e-3)."""
+    from dlwp_benchmark_amd import lib as L
+    lib = L.load()
+    BF = torch.bfloat16
+    g = torch.Generator().manual_seed(M + N + K + dt)
+    A = torch.randn(M, K, generator=g).to(cuda)
+    B = torch.randn(N, K, generator=g).to(cuda)
+    bias = torch.randn(N, generator=g).to(cuda)
+    res = torch.randn(M, N, generator=g).to(cuda)
+    s = torch.randn(nb, generator=g).to(cuda)
+    s[0] = 0.0
+    rows = -(-M // nb)
+    a = A.to(BF) if dt & 1 else A
+    b = B.to(BF) if dt & 2 else B
+    r = res.to(BF) if dt & 8 else res
+    Cm = torch.empty(M, N, device=cuda, dtype=BF if dt & 4 else torch.float32)
+    sc = s[torch.arange(M, device=cuda) // rows]
+    ref = (a.double() @ b.double().T + bias.double()) * sc.double()[:, None] + r.double()
+    ctx = L.gemm_precision("bf16") if dt else __import__("contextlib").nullcontext()
+    with ctx:
+        L.check(lib.dlwp_gemm_rowscale(L.ptr(a), L.ptr(b), L.ptr(Cm), M, N, K, K, K, N, 0, 1, L.ptr(bias), L.ptr(r), L.ptr(s), rows,
+                                       dt, L.stream()))
+    if dt:      # operands rounded to bf16 by the matrix units (already exact for bf16 arrays)
+        ref = (a.to(BF).double() @ b.to(BF).double().T + bias.double()) * sc.double()[:, None] + r.double()
+    tol = 4e-3 if dt & 4 else 2e-5
+    assert ((Cm.double() - ref).abs().max() / ref.abs().max()).item() < tol
+    rc = lib.dlwp_gemm_rowscale(L.ptr(a), L.ptr(b), L.ptr(Cm), M, N, K, K, K, N, 0, 1, None, None, None, rows, dt, L.stream())
+    assert rc != 0 and b"row_scale" in lib.dlwp_last_error()
+
+
+def test_cast_bf16_scaled(cuda):
+    from dlwp_benchmark_amd import lib as L
+    lib = L.load()
+    x = torch.randn(5, 1000, device=cuda)
+    s = torch.tensor([0.0, 1.25, 1.0, -2.0, 1 / 0.8], device=cuda)
+    out = torch.empty(5, 1000, device=cuda, dtype=torch.bfloat16)
+    L.check(lib.dlwp_cast_bf16_scaled(L.ptr(x), L.ptr(s), L.ptr(out), 5, 1000, L.stream()))
+    assert torch.equal(out, (x * s[:, None]).to(torch.bfloat16))
+    assert lib.dlwp_cast_bf16_scaled(L.ptr(x), L.ptr(s), L.ptr(out), 5, 999, L.stream()) != 0
+
+
 @pytest.mark.parametrize("B,H,W,C", [(2, 16, 32, 16), (3, 32, 64, 64), (1, 7, 9, 5)])
 def test_instance_norm_matches_torch(cuda, B, H, W, C):
     """dlwp_instnorm_fwd/bwd vs torch.nn.functional.instance_norm on the CPU (fp32 reference of a floating-point kernel);
