@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from ..nsbench.swin_transformer import _WindowAttnTokensFn, window_attention_core, window_attention_tokens
 from ..window_ops import WindowSpec, partition, reverse
 from .rollout import rollout
-from ..token_ops import DropPath, DropPathPool, LayerNorm, Linear, Mlp, PatchConv2d, UpConvT2d, norm_fork
+from ..token_ops import DropPath, DropPathPool, LayerNorm, Linear, Mlp, PatchConv2d, UpConvT2d, WgradBatch, norm_fork
 
 _DEFAULT_SHIFT = (1, 3, 6)   # panguweather.py:243
 
@@ -153,6 +153,7 @@ class EarthSpecificBlock(nn.Module):
             fwd_shift = (sh[0], sh[1], sh[1]) if self.roll else (0, 0, 0)
             rev_shift = sh if self.roll else (0, 0, 0)
             # skip connections leave the LayerNorm nodes (norm_fork): their gradients join the LayerNorm backward kernels
+            wb = WgradBatch()        # this application's four weight gradients (qkv, proj, fc1, fc2) in one launch
             if self.real_token_flow:
                 skip, t = norm_fork(self.norm1, x, gemm_input=True)
                 # (where the crop keeps exactly the positions of the real tokens, every padded row has a zero query gradient --
@@ -160,31 +161,31 @@ class EarthSpecificBlock(nn.Module):
                 fusable = self.attn.qkv.bias is not None and _WindowAttnTokensFn.applies(t, spec, C // self.attn.num_heads, self.attn.earth_position_bias_table)
                 # (bf16 storage: the projection writes bf16 rows for the attention kernels, which hand bf16 rows to proj)
                 lowp = fusable and _WindowAttnTokensFn.wants_bf16_qkv(B, spec, self.attn.num_heads, C // self.attn.num_heads)
-                qkv_tok = self.attn.qkv(t, out_lowp=lowp)
+                qkv_tok = self.attn.qkv(t, out_lowp=lowp, wbatch=wb)
                 if fusable:
                     # partition + attention + reverse as one node whose backward is one launch (token-layout gradients)
                     t = window_attention_tokens(qkv_tok, self.attn.qkv.bias, self.attn.earth_position_bias_table, self.attn._ia, self.attn._ib,
                                                 self._labels if self.roll else None, spec, fwd_shift, rev_shift, self.attn.num_heads,
                                                 float(self.attn.scale), self._qrange)
                     if self.drop_path.active:        # stochastic depth: the per-sample scale rides proj's / fc2's epilogue
-                        skip, t = norm_fork(self.norm2, self.drop_path.branch(self.attn.proj, t, skip), gemm_input=True)
-                        return self.drop_path.branch(self.mlp, t, skip)
-                    skip, t = norm_fork(self.norm2, self.attn.proj(t, residual=skip), gemm_input=True)
-                    return self.mlp(t, residual=skip)
+                        skip, t = norm_fork(self.norm2, self.drop_path.branch(self.attn.proj, t, skip, wbatch=wb), gemm_input=True)
+                        return self.drop_path.branch(self.mlp, t, skip, wbatch=wb)
+                    skip, t = norm_fork(self.norm2, self.attn.proj(t, residual=skip, wbatch=wb), gemm_input=True)
+                    return self.mlp(t, residual=skip, wbatch=wb)
                 qkv = partition(qkv_tok, spec, fwd_shift, fill=self.attn.qkv.bias, fill_grad_from=C if self._kept_are_real else 0)
                 t = self.attn.core(qkv, self._labels if self.roll else None, spec.nW, self._qrange)
                 if self.drop_path.active:
-                    skip, t = norm_fork(self.norm2, self.drop_path.branch(self.attn.proj, reverse(t, spec, B, rev_shift), skip), gemm_input=True)
-                    return self.drop_path.branch(self.mlp, t, skip)
-                skip, t = norm_fork(self.norm2, self.attn.proj(reverse(t, spec, B, rev_shift), residual=skip), gemm_input=True)
-                return self.mlp(t, residual=skip)
+                    skip, t = norm_fork(self.norm2, self.drop_path.branch(self.attn.proj, reverse(t, spec, B, rev_shift), skip, wbatch=wb), gemm_input=True)
+                    return self.drop_path.branch(self.mlp, t, skip, wbatch=wb)
+                skip, t = norm_fork(self.norm2, self.attn.proj(reverse(t, spec, B, rev_shift), residual=skip, wbatch=wb), gemm_input=True)
+                return self.mlp(t, residual=skip, wbatch=wb)
             skip, t = norm_fork(self.norm1, x)
             t = self.attn(partition(t, spec, fwd_shift), self._labels if self.roll else None, spec.nW)
             if self.drop_path.active:            # stochastic depth: per-sample scale fused with the residual adds
                 skip, t = norm_fork(self.norm2, self.drop_path(reverse(t, spec, B, rev_shift), residual=skip), gemm_input=True)
-                return self.drop_path.branch(self.mlp, t, skip)
+                return self.drop_path.branch(self.mlp, t, skip, wbatch=wb)
             skip, t = norm_fork(self.norm2, reverse(t, spec, B, rev_shift, residual=skip), gemm_input=True)
-            return self.mlp(t, residual=skip)
+            return self.mlp(t, residual=skip, wbatch=wb)
         t = self.norm1(x).view(B, Pl, Lat, Lon, C)
         t = F.pad(t.permute(0, 4, 1, 2, 3), p).permute(0, 2, 3, 4, 1)
         Plp, Latp, Lonp = self.pad_resolution

@@ -121,7 +121,7 @@ class _LinearFn(torch.autograd.Function):
     weight is [N, K] or a 1x1 convolution weight [N, K, 1, 1] (same memory)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act, residual, res_pre=False, out_lowp=False, row_scale=None):
+    def forward(ctx, x, weight, bias, act, residual, res_pre=False, out_lowp=False, row_scale=None, wbatch=None):
         """row_scale (fp32 [samples], no activation): y = (x W^T + b) * row_scale[sample] + residual -- stochastic depth of the branch
         this product ends, inside its epilogue (DropPath.branch).
         out_lowp (bf16 storage only, no activation / residual): y is written as bf16 for a consumer that reads bf16 rows (the
@@ -134,8 +134,9 @@ class _LinearFn(torch.autograd.Function):
         T, K = x2.shape
         N = weight.shape[0]
         w, _ = _wmat(weight, N)             # the bf16 copy under bf16 storage (forward and input-gradient products)
+        wbatch = wbatch if (wbatch is not None and WGRAD_BATCH and w.dtype == _BF and ctx.needs_input_grad[1] and not act) else None
         if w.dtype == _BF:
-            x2 = _lowp(x2, N)               # read by the forward product and by gW = g^T x
+            x2 = _lowp(x2, N if wbatch is None else LOWP_MIN_DEPTH)               # read by the forward product and by gW = g^T x
         lowp_out = bool(out_lowp) and w.dtype == _BF and x2.dtype == _BF and not act and residual is None
         y = torch.empty(T, N, device=x.device, dtype=_BF if lowp_out else torch.float32)
         z = torch.empty(T, N, device=x.device) if act else None
@@ -148,7 +149,9 @@ class _LinearFn(torch.autograd.Function):
             _gemm_batched(x2, w, y, T, N, K, K, K, N, 0, 1, bias=bias, act=act, preact=z, residual=r2, res_pre=1)
         else:
             _gemm(x2, w, y, T, N, K, K, K, N, 0, 1, bias, act, z, r2)
-        ctx.row_scale = row_scale
+        ctx.row_scale, ctx.wbatch = row_scale, wbatch
+        if wbatch is not None:
+            wbatch.enrol()
         ctx.save_for_backward(x2, w, z)
         ctx.has_bias, ctx.has_res, ctx.act, ctx.shape = bias is not None, residual is not None, act, shape
         ctx.res_pre, ctx.wshape = bool(res_pre) and act, weight.shape
@@ -175,9 +178,15 @@ class _LinearFn(torch.autograd.Function):
             g2 = gz
             if ctx.res_pre and ctx.has_res:      # the residual sits inside the activation
                 gres = gz.reshape(gy.shape)
+        wb = ctx.wbatch
         if w.dtype == _BF:
-            g2 = _lowp(g2, K)                    # read by both products below
+            g2 = _lowp(g2, K if wb is None else LOWP_MIN_DEPTH)                    # read by both products below
         gx = torch.empty(T, K, device=g2.device, dtype=ctx.in_dtype)   # a bf16 input (LayerNorm output) takes a bf16 gradient
+        if wb is not None:
+            if wb.takes(g2, x2, ctx.wslot, ctx.bslot, ctx.has_bias):       # the weight gradient joins the block's one launch
+                _gemm(g2, w, gx, T, K, N, N, K, K, 0, 0)
+                wb.add(g2, x2, ctx.wslot, ctx.bslot, ctx.has_bias, ctx.wshape)
+                return gx.reshape(ctx.shape), None, None, None, gres, None, None, None, None
         gw, gb = None, None
         if ctx.has_bias:
             gb = ctx.bslot if ctx.bslot is not None else torch.zeros(N, device=g2.device)
@@ -196,7 +205,9 @@ class _LinearFn(torch.autograd.Function):
             gw = gw.reshape(ctx.wshape)
         if ctx.bslot is not None:
             gb = None
-        return gx.reshape(ctx.shape), gw, gb, None, gres, None, None, None
+        if wb is not None:
+            wb.done()
+        return gx.reshape(ctx.shape), gw, gb, None, gres, None, None, None, None
 
 
 def _weight_grad(g2, x2, weight_slot, bias_slot, has_bias, wshape):
@@ -296,6 +307,46 @@ def _weight_grad_segments(layers):
     return outs
 
 
+# env: A/B runs of the per-block weight-gradient launch (round 5) against one product launch per layer
+WGRAD_BATCH = __import__("os").environ.get("DLWP_WGRAD_BATCH", "1") != "0"
+
+
+class WgradBatch:
+    """The weight gradients of ONE application of a transformer block (qkv, proj, fc1, fc2: four products over the same tokens) in one
+    dlwp_wgrad_segments launch (+ its reduction) instead of a split-K launch and a slab reduction per layer -- each of those is a
+    5 - 10 GFLOP product that cannot fill the chip by itself.  The block's forward makes a fresh object and hands it to its Linear /
+    Mlp calls: a node that will compute weight gradients enrols in its forward, and in its backward either hands over its (g, x) pair
+    (bf16 arrays, gradient slots present) or computes the product at once and signs off; the launch happens when the last enrolled
+    node has reported.  Nothing global: an application whose backward never runs just drops its object with the graph."""
+
+    def __init__(self):
+        self.pending, self.items = 0, []
+
+    def enrol(self, n=1):
+        self.pending += n
+
+    @staticmethod
+    def takes(g2, x2, wslot, bslot, has_bias):
+        return (WGRAD_BATCH and g2.dtype == _BF and x2.dtype == _BF and wslot is not None and (bslot is not None or not has_bias)
+                and g2.shape[1] % 8 == 0 and x2.shape[1] % 8 == 0 and g2.is_contiguous() and x2.is_contiguous()
+                and L.ptr(g2) % 16 == 0 and L.ptr(x2) % 16 == 0 and L.ptr(wslot) % 16 == 0)
+
+    def add(self, g2, x2, wslot, bslot, has_bias, wshape):
+        self.items.append(([g2], [x2], wslot, bslot, has_bias, wshape))
+        self.done()
+
+    def done(self):
+        self.pending -= 1
+        if self.pending == 0 and self.items:
+            items, self.items = self.items, []
+            by_tokens = {}
+            for it in items:
+                by_tokens.setdefault(it[0][0].shape[0], []).append(it)
+            for group in by_tokens.values():
+                for i in range(0, len(group), 4):          # DLWP_WGRAD_MAX_PRODUCTS
+                    _weight_grad_segments(group[i:i + 4])
+
+
 class _MlpFn(torch.autograd.Function):
     """y = fc2(GELU(fc1 x)) (+ residual) as ONE autograd node (reference: Mlp.forward, nsbench/models/fourcastnet/
     fourcastnet.py:50-56, swintransformer/swin_transformer.py:42-48).  Forward: two GEMMs (bias + GELU, bias + residual
@@ -303,7 +354,7 @@ class _MlpFn(torch.autograd.Function):
     GELU'(z) (epilogue act 4), so the hidden-width gradient is written once and never re-read by an elementwise pass."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, residual, row_scale=None):
+    def forward(ctx, x, w1, b1, w2, b2, residual, row_scale=None, wbatch=None):
         """row_scale (fp32 [samples]): y = fc2(...) * row_scale[sample] + residual (DropPath.branch)."""
         shape = x.shape
         x2 = x.reshape(-1, shape[-1]).contiguous()
@@ -327,6 +378,9 @@ class _MlpFn(torch.autograd.Function):
         else:
             _gemm(h, w2m, y, T, N, Hd, Hd, Hd, N, 0, 1, b2, 0, None, r2)
         ctx.row_scale = row_scale
+        ctx.wbatch = wbatch if (wbatch is not None and WGRAD_BATCH and adt == _BF and ctx.needs_input_grad[1] and ctx.needs_input_grad[3]) else None
+        if ctx.wbatch is not None:
+            ctx.wbatch.enrol(2)
         ctx.save_for_backward(x2, w1m, w2m, z, h)
         ctx.shape, ctx.has_res = shape, residual is not None
         ctx.in_dtype = x.dtype if x.dtype == _BF else torch.float32
@@ -345,10 +399,18 @@ class _MlpFn(torch.autograd.Function):
         if ctx.row_scale is not None:
             g2 = _scaled_grad(g2, ctx.row_scale, h.dtype == _BF)
         elif h.dtype == _BF:
-            g2 = _lowp(g2, Hd)                   # read by gh = g W2 and gW2 = g^T h
+            g2 = _lowp(g2, Hd if ctx.wbatch is None else LOWP_MIN_DEPTH)                   # read by gh = g W2 and gW2 = g^T h
         gh = torch.empty(T, Hd, device=g2.device, dtype=h.dtype)
         _gemm_batched(g2, w2m, gh, T, Hd, N, N, Hd, Hd, 0, 0, act=_ACT_B, residual=z)     # (g W2) * GELU'(z), z = the stored derivative
         gx = torch.empty(T, K, device=g2.device, dtype=ctx.in_dtype)   # a bf16 input (LayerNorm output) takes a bf16 gradient
+        wb = ctx.wbatch
+        if wb is not None:
+            pairs = [(g2, h, ctx.slots[2], ctx.slots[3], ctx.has_b[1], ctx.w2shape), (gh, x2, ctx.slots[0], ctx.slots[1], ctx.has_b[0], ctx.w1shape)]
+            if all(wb.takes(*q[:5]) for q in pairs):       # the weight gradients join the block's one launch
+                _gemm(gh, w1m, gx, T, K, Hd, Hd, K, K, 0, 0)
+                for q in pairs:
+                    wb.add(*q)
+                return gx.reshape(ctx.shape), None, None, None, None, (gy if ctx.has_res else None), None, None
         # gx = gh W1 and the two weight gradients do not depend on each other: one launch while they are small (lib.gemm_group parks
         # products of at most 2.2 GFLOP; larger ones launch at once)
         if T <= 4096:          # (nsbench AFNO 64 x 64, 1024 tokens: 754 -> 796 samples/s)
@@ -360,7 +422,10 @@ class _MlpFn(torch.autograd.Function):
             _gemm(gh, w1m, gx, T, K, Hd, Hd, K, K, 0, 0)
             (gw2, gb2), (gw1, gb1) = _weight_grad_group([(g2, h, ctx.slots[2], ctx.slots[3], ctx.has_b[1], ctx.w2shape),
                                                          (gh, x2, ctx.slots[0], ctx.slots[1], ctx.has_b[0], ctx.w1shape)])
-        return gx.reshape(ctx.shape), gw1, gb1, gw2, gb2, (gy if ctx.has_res else None), None
+        if wb is not None:
+            wb.done()
+            wb.done()
+        return gx.reshape(ctx.shape), gw1, gb1, gw2, gb2, (gy if ctx.has_res else None), None, None
 
 
 # opt-in (DLWP_MLP_STREAM=1): measured 321 / 267 us forward / backward at T = 16200, E = 768 against 238 us for the forward's two GEMMs in
@@ -423,10 +488,10 @@ class _MlpStreamFn(torch.autograd.Function):
         return gx.reshape(ctx.shape), gw1, gb1, gw2, gb2, (gy if ctx.has_res else None)
 
 
-def mlp(x, w1, b1, w2, b2, residual=None, row_scale=None):
+def mlp(x, w1, b1, w2, b2, residual=None, row_scale=None, wbatch=None):
     if row_scale is None and _MlpStreamFn.applies(x, w1, w2):
         return _MlpStreamFn.apply(x, w1, b1, w2, b2, residual)
-    return _MlpFn.apply(x, w1, b1, w2, b2, residual, row_scale)
+    return _MlpFn.apply(x, w1, b1, w2, b2, residual, row_scale, wbatch)
 
 
 class _SkipMlpFn(torch.autograd.Function):
@@ -806,14 +871,14 @@ class DropPath(nn.Module):
             return t if residual is None else residual + t
         return _ScaleRowsAddFn.apply(t, self.mask(t.shape[0], t.device), residual)
 
-    def branch(self, fn, t, residual):
+    def branch(self, fn, t, residual, **kw):
         """residual + drop_path(fn(t)) for a Linear / Mlp module `fn` (residual [batch, tokens, C]): the per-sample scale and the residual
         add run in the epilogue of fn's last product (dlwp_gemm_rowscale) instead of a pass of their own over the tokens."""
         if not self.active:
-            return fn(t, residual=residual)
+            return fn(t, residual=residual, **kw)
         if not DROPPATH_FUSED:
-            return self(fn(t), residual=residual)
-        return fn(t, residual=residual, row_scale=self.mask(residual.shape[0], t.device))
+            return self(fn(t, **kw), residual=residual)
+        return fn(t, residual=residual, row_scale=self.mask(residual.shape[0], t.device), **kw)
 
     def extra_repr(self):
         return f"drop_prob={self.p:0.3f}"
@@ -904,8 +969,8 @@ class InstanceNorm(nn.Module):
 
 
 class Linear(nn.Linear):
-    def forward(self, x, act=0, residual=None, out_lowp=False, row_scale=None):
-        return _LinearFn.apply(x, self.weight, self.bias, act, residual, False, out_lowp, row_scale)
+    def forward(self, x, act=0, residual=None, out_lowp=False, row_scale=None, wbatch=None):
+        return _LinearFn.apply(x, self.weight, self.bias, act, residual, False, out_lowp, row_scale, wbatch)
 
 
 class LayerNorm(nn.LayerNorm):
@@ -932,8 +997,8 @@ class Mlp(nn.Module):
         self.act = nn.GELU()   # kept for module-tree compatibility; applied inside fc1's epilogue
         self.fc2 = Linear(hidden_features or in_features, out_features or in_features)
 
-    def forward(self, x, residual=None, row_scale=None):
-        return mlp(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, residual, row_scale)
+    def forward(self, x, residual=None, row_scale=None, wbatch=None):
+        return mlp(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, residual, row_scale, wbatch)
 
 
 class PatchConv2d(nn.Conv2d):

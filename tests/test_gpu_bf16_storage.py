@@ -4,6 +4,7 @@ way), outputs are the fp32 results rounded once, and a train step with bf16 hidd
 stays within bf16 rounding of the fp32-storage step."""
 import pytest
 import torch
+import torch.nn as nn
 
 pytestmark = pytest.mark.gpu
 
@@ -147,6 +148,76 @@ def test_train_step_with_bf16_storage_tracks_fp32_storage(cuda):
     a, b = torch.tensor(losses["fp32"]), torch.tensor(losses["bf16"])
     assert a[-1] < a[0]                       # it trains
     assert ((a - b).abs() / a).max().item() < 2e-2, (losses["fp32"], losses["bf16"])
+
+
+class _ToyBlock(nn.Module):
+    """A transformer block's GEMM skeleton (qkv -> a stand-in for attention -> proj + skip -> fc1 / fc2 + skip) with the four weight
+    gradients handed to one token_ops.WgradBatch per application, as the Pangu blocks do."""
+
+    def __init__(self, C, Hd, drop):
+        super().__init__()
+        from dlwp_benchmark_amd import token_ops as TO
+        self.norm1, self.norm2 = TO.LayerNorm(C), TO.LayerNorm(C)
+        self.qkv, self.proj, self.mlp = TO.Linear(C, 3 * C), TO.Linear(C, C), TO.Mlp(C, Hd)
+        self.drop_path = TO.DropPath(drop)
+
+    def forward(self, x):
+        from dlwp_benchmark_amd import token_ops as TO
+        C = x.shape[-1]
+        wb = TO.WgradBatch()
+        skip, t = TO.norm_fork(self.norm1, x, gemm_input=True)
+        q = self.qkv(t, wbatch=wb)
+        t = q[..., :C] * torch.tanh(q[..., C:2 * C]) + q[..., 2 * C:]
+        skip, t = TO.norm_fork(self.norm2, self.drop_path.branch(self.proj, t, skip, wbatch=wb), gemm_input=True)
+        return self.drop_path.branch(self.mlp, t, skip, wbatch=wb)
+
+
+@pytest.mark.parametrize("B,T,C,Hd,drop,applications", [(2, 1024, 192, 768, 0.3, 1), (1, 520, 96, 384, 0.0, 1), (3, 256, 64, 128, 0.2, 2)])
+def test_block_weight_gradients_in_one_launch_equal_the_per_layer_products(cuda, B, T, C, Hd, drop, applications):
+    """token_ops.WgradBatch (dlwp_wgrad_segments over the block's four (g, x) pairs, bf16 storage, gradient slots) against the
+    per-layer split-K products on the same bf16 operands: every parameter gradient within 2e-3 of the max norm (fp32 sums in a
+    different order; where the batch forces a bf16 copy of a gradient the per-layer path reads as fp32, one more bf16 rounding of
+    that operand: 1e-2), input gradient likewise."""
+    from dlwp_benchmark_amd import lib as L, token_ops as TO
+    from dlwp_benchmark_amd.train_engine import flatten_parameters, refresh_bf16_weights
+    g = torch.Generator().manual_seed(C + T)
+    x0 = torch.randn(B, T, C, generator=g).to(cuda)
+    gy = torch.randn(B, T, C, generator=g).to(cuda)
+    masks = [(torch.rand(B, generator=g) > drop).float().to(cuda) / (1 - drop) for _ in range(2 * applications)]
+    res, launches = {}, {}
+    orig = TO._weight_grad_segments
+    with L.gemm_precision("bf16"):
+        L.set_storage("bf16")
+        try:
+            for on in (True, False):
+                torch.manual_seed(1)
+                m = _ToyBlock(C, Hd, drop).to(cuda).train()
+                flat, grad = flatten_parameters(m)
+                refresh_bf16_weights(m)
+                it = iter(masks)
+                m.drop_path.mask = lambda batch, device: next(it)
+                count = []
+                TO._weight_grad_segments = lambda layers: (count.append(len(layers)), orig(layers))[1]
+                TO.WGRAD_BATCH = on
+                L.SHADOW_ACTIVE = True
+                try:
+                    x = x0.clone().requires_grad_(True)
+                    y = x
+                    for _ in range(applications):
+                        y = m(y)
+                    y.backward(gy)
+                finally:
+                    L.SHADOW_ACTIVE = False
+                    TO.WGRAD_BATCH = True
+                    TO._weight_grad_segments = orig
+                res[on] = [y.detach(), x.grad] + [p.grad.clone() for p in m.parameters()]
+                launches[on] = count
+        finally:
+            L.set_storage("fp32")
+    assert launches[True] == [4] * applications and launches[False] == []
+    for a, b in zip(res[True], res[False]):
+        assert (a - b).abs().max().item() <= 1e-2 * b.abs().max().item() + 1e-12
+    assert all(p.abs().sum().item() > 0 for p in res[True][2:])
 
 
 def test_bf16_storage_needs_bf16_operands(cuda):
