@@ -22,7 +22,7 @@ import torch.nn.functional as F
 
 from .. import lib as L
 from ..rollout_ops import ns_rollout
-from ..token_ops import _gemm_batched, _grad_slot, DropPath, DropPathPool, LayerNorm, Linear, Mlp, PatchConv2d, UpConvT2d, norm_fork
+from ..token_ops import _gemm_batched, _grad_slot, DropPath, DropPathPool, LayerNorm, Linear, Mlp, PatchConv2d, UpConvT2d, WgradBatch, norm_fork
 from ..window_ops import WindowSpec, _gather, _scatter, partition, patch_merge, position_maps, reverse
 
 
@@ -265,11 +265,12 @@ class WindowAttention(nn.Module):
         self.proj = Linear(dim, dim)
         nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
 
-    def forward(self, x, labels=None, nW=1):
-        """x [nW*B, N, C]; labels: int32 [nW, N] region labels of the shift mask (None: no mask)."""
-        y = _WindowAttnFn.apply(self.qkv(x), self.relative_position_bias_table, self._ia, self._ib, labels, nW,
+    def forward(self, x, labels=None, nW=1, wbatch=None):
+        """x [nW*B, N, C]; labels: int32 [nW, N] region labels of the shift mask (None: no mask); wbatch: the block's
+        token_ops.WgradBatch (the weight gradients of qkv and proj join the block's one launch)."""
+        y = _WindowAttnFn.apply(self.qkv(x, wbatch=wbatch), self.relative_position_bias_table, self._ia, self._ib, labels, nW,
                                 self.num_heads, float(self.scale))
-        return self.proj(y)
+        return self.proj(y, wbatch=wbatch)
 
     def core(self, qkv_windows, labels=None, nW=1):
         """attention on windows of an already projected qkv tensor [nW*B, N, 3C] (SwinTransformerBlock's real-token flow)"""
@@ -312,23 +313,24 @@ class SwinTransformerBlock(nn.Module):
             # the skip connections leave the LayerNorm nodes (norm_fork) so that their gradients join the LayerNorm backward
             # kernels; the first residual add rides the reverse kernel, the second fc2's epilogue
             spec = self._spec(H, W)
+            wb = WgradBatch()        # this application's four weight gradients (qkv, proj, fc1, fc2) in one launch
             if self.real_token_flow:
                 skip, t = norm_fork(self.norm1, x, gemm_input=True)
                 const_pad = any((f or b) and not c for f, b, c in zip(spec.front, [p - f - d for p, f, d in zip(spec.padded, spec.front, spec.dims)], spec.circ))
-                qkv = partition(self.attn.qkv(t), spec, fill=self.attn.qkv.bias if const_pad else None)
+                qkv = partition(self.attn.qkv(t, wbatch=wb), spec, fill=self.attn.qkv.bias if const_pad else None)
                 t = self.attn.core(qkv, labels if shifted else None, spec.nW)
                 if self.drop_path.active:
-                    skip, t = norm_fork(self.norm2, self.drop_path.branch(self.attn.proj, reverse(t, spec, B), skip), gemm_input=True)
-                    return self.drop_path.branch(self.mlp, t, skip)
-                skip, t = norm_fork(self.norm2, self.attn.proj(reverse(t, spec, B), residual=skip), gemm_input=True)
-                return self.mlp(t, residual=skip)
+                    skip, t = norm_fork(self.norm2, self.drop_path.branch(self.attn.proj, reverse(t, spec, B), skip, wbatch=wb), gemm_input=True)
+                    return self.drop_path.branch(self.mlp, t, skip, wbatch=wb)
+                skip, t = norm_fork(self.norm2, self.attn.proj(reverse(t, spec, B), residual=skip, wbatch=wb), gemm_input=True)
+                return self.mlp(t, residual=skip, wbatch=wb)
             skip, t = norm_fork(self.norm1, x)
-            t = self.attn(partition(t, spec), labels if shifted else None, spec.nW)
+            t = self.attn(partition(t, spec), labels if shifted else None, spec.nW, wbatch=wb)
             if self.drop_path.active:        # training with stochastic depth (:255-256): per-sample scale + residual add
                 skip, t = norm_fork(self.norm2, self.drop_path(reverse(t, spec, B), residual=skip), gemm_input=True)
-                return self.drop_path.branch(self.mlp, t, skip)
+                return self.drop_path.branch(self.mlp, t, skip, wbatch=wb)
             skip, t = norm_fork(self.norm2, reverse(t, spec, B, residual=skip), gemm_input=True)
-            return self.mlp(t, residual=skip)
+            return self.mlp(t, residual=skip, wbatch=wb)
         t = self.norm1(x).view(B, H, W, C)
         t = _pad_hw(t, (ws[0] - H % ws[0]) % ws[0], (ws[1] - W % ws[1]) % ws[1], self.padding_mode)
         Hp, Wp = t.shape[1], t.shape[2]
