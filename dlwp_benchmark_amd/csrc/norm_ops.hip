@@ -470,11 +470,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g
 }
 
 template <int VEC>
-__global__ __launch_bounds__(256) void colsum_flat_kernel(const float* __restrict__ g, float* __restrict__ out, int T, long long N) {
+__global__ __launch_bounds__(256) void colsum_flat_kernel(const float* __restrict__ g, float* __restrict__ out, int T, long long N, int overwrite) {
     const long long stride = (long long)gridDim.x * 256 * VEC;
     for (long long n = ((long long)blockIdx.x * 256 + threadIdx.x) * VEC; n < N; n += stride) {
         if (VEC == 4) {
-            f32x4 s = *reinterpret_cast<const f32x4*>(out + n);
+            f32x4 s = overwrite ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(out + n);
             for (int t = 0; t < T; ++t) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(g + (long long)t * N + n);
 #pragma unroll
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void colsum_flat_kernel(const float* __restric
             }
             *reinterpret_cast<f32x4*>(out + n) = s;
         } else {
-            float s = out[n];
+            float s = overwrite ? 0.f : out[n];
             for (int t = 0; t < T; ++t) s += g[(long long)t * N + n];
             out[n] = s;
         }
@@ -666,15 +666,25 @@ extern "C" int dlwp_act_bwd(const float* z, const float* gy, float* gz, long lon
     return DLWP_OK;
 }
 
-extern "C" int dlwp_colsum(const float* g, float* out, int T, int N, void* stream) {
+static int colsum_impl(const float* g, float* out, int T, int N, int overwrite, void* stream);
+extern "C" int dlwp_colsum(const float* g, float* out, int T, int N, void* stream) { return colsum_impl(g, out, T, N, 0, stream); }
+extern "C" int dlwp_colsum_ex(const float* g, float* out, int T, int N, int overwrite, void* stream) {
+    return colsum_impl(g, out, T, N, overwrite ? 1 : 0, stream);
+}
+
+static int colsum_impl(const float* g, float* out, int T, int N, int overwrite, void* stream) {
     DLWP_REQUIRE(g && out && T > 0 && N > 0, DLWP_E_INVALID, "colsum: bad argument");
     const bool vec = N % 4 == 0 && (uintptr_t)g % 16 == 0 && (uintptr_t)out % 16 == 0;
     if (T <= 16) {
         const long long units = vec ? N / 4 : N;
         const int grid = (int)std::min<long long>((units + 255) / 256, 4096);
-        if (vec) hipLaunchKernelGGL(colsum_flat_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, out, T, (long long)N);
-        else hipLaunchKernelGGL(colsum_flat_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, out, T, (long long)N);
+        if (vec) hipLaunchKernelGGL(colsum_flat_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, out, T, (long long)N, overwrite);
+        else hipLaunchKernelGGL(colsum_flat_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, out, T, (long long)N, overwrite);
     } else {
+        if (overwrite) {       // the slab kernel adds with atomics: start from zero
+            const hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, (hipStream_t)stream);
+            DLWP_REQUIRE(e == hipSuccess, DLWP_E_HIP, "colsum: hipMemsetAsync: %s", hipGetErrorString(e));
+        }
         // row slabs sized so that the launch has ~2048 workgroups (fills the chip, bounds the atomics per column)
         const int cols = ceil_div(N, vec ? 256 : 64);
         int slabs = std::max(1, std::min(ceil_div(T, 64), ceil_div(2048, cols)));

@@ -146,9 +146,10 @@ class _EncodeFn(torch.autograd.Function):
         L.check(lib.dlwp_sfno_encode_bwd(C.byref(a), L.stream()))
         # position embedding: batch sum of g, accumulated channels-last over the lead times of the pass
         if st["pos_cl"] is not None:
-            if st["gpos_cl"] is None:
-                st["gpos_cl"] = torch.zeros(HW * E, device=dev)
-            L.check(lib.dlwp_colsum(L.ptr(g), L.ptr(st["gpos_cl"]), B, HW * E, L.stream()))
+            first = st["gpos_cl"] is None          # the first lead time of the pass writes the sums, the later ones add to them
+            if first:
+                st["gpos_cl"] = torch.empty(HW * E, device=dev)
+            L.check(lib.dlwp_colsum_ex(L.ptr(g), L.ptr(st["gpos_cl"]), B, HW * E, int(first), L.stream()))
         rec.update(g_lp=g_lp, gh_e=gh)
         st["pending"].append(rec)
         st["uses"] -= 1

@@ -829,6 +829,8 @@ int dlwp_scale_rows_add(const float* t, const float* scale, const float* x, floa
 int dlwp_add_bcast(const float* t, const float* p, float* out, int B, long long n, void* stream);
 /* out[n] += sum_t g[t][n]   (bias gradients)                                                */
 int dlwp_colsum(const float* g, float* out, int T, int N, void* stream);
+/* the same with overwrite != 0: out[n] = sum_t g[t][n] (the first of several accumulating calls needs no zero fill) */
+int dlwp_colsum_ex(const float* g, float* out, int T, int N, int overwrite, void* stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* Complex mode-n product for Tucker-factorised spectral weights (TFNO, dlwpbench/models/   */
