@@ -25,10 +25,28 @@ struct WinDev {
     int B, C, D[3], P[3], f[3], s[3], w[3], nw[3], circ[3];
     long long sw[3];
     int nW, N, dup;
+    // round 5 (dlwp_window_gather_ex / dlwp_window_scatter_ex): src / dst are bf16 arrays (same layouts, 2-byte elements); scale
+    // [B]: the result of sample b is multiplied by scale[b] before the residual joins (stochastic depth of the branch, DropPath)
+    int src_bf16, dst_bf16;
+    const float* scale;
     FastDiv dC4, dN, dnW, dw12, dw2, dnw12, dnw2, dD2, dD1, dD0, dwd[3];   // umulhi divisions (index spaces < 2^31 / 256 per step)
 };
 
 __device__ __forceinline__ int pmod(int a, int m) { a %= m; return a < 0 ? a + m : a; }
+
+typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
+// four consecutive channels at element offset `o` of an fp32 or bf16 array
+__device__ __forceinline__ f32x4 win_load4(const float* base, long long o, int bf16) {
+    if (bf16) {
+        const wbf16x4 h = *reinterpret_cast<const wbf16x4*>(reinterpret_cast<const __bf16*>(base) + o);
+        return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    }
+    return *reinterpret_cast<const f32x4*>(base + o);
+}
+__device__ __forceinline__ void win_store4(float* base, long long o, int bf16, const f32x4& v) {
+    if (bf16) *reinterpret_cast<wbf16x4*>(reinterpret_cast<__bf16*>(base) + o) = wbf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    else *reinterpret_cast<f32x4*>(base + o) = v;
+}
 
 // one thread per (output token, 4 channels)
 __global__ __launch_bounds__(256) void win_gather_kernel(WinDev a) {
@@ -54,10 +72,15 @@ __global__ __launch_bounds__(256) void win_gather_kernel(WinDev a) {
             q[d] = v;
         }
         f32x4 val = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ok) val = *reinterpret_cast<const f32x4*>(a.src + ((((long long)b * a.D[0] + q[0]) * a.D[1] + q[1]) * a.D[2] + q[2]) * a.C + 4 * c4);
+        if (ok) val = win_load4(a.src, ((((long long)b * a.D[0] + q[0]) * a.D[1] + q[1]) * a.D[2] + q[2]) * a.C + 4 * c4, a.src_bf16);
         else if (a.fill) val = *reinterpret_cast<const f32x4*>(a.fill + 4 * c4);
+        if (a.scale) {
+            const float sc = a.scale[b];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) val[k] *= sc;
+        }
         const long long wout = (long long)b * a.nW + i0 * a.sw[0] + i1 * a.sw[1] + i2 * a.sw[2];
-        *reinterpret_cast<f32x4*>(a.dst + (wout * a.N + n) * a.C + 4 * c4) = val;
+        win_store4(a.dst, (wout * a.N + n) * a.C + 4 * c4, a.dst_bf16, val);
         (void)tok;
     }
 }
@@ -159,7 +182,7 @@ __device__ __forceinline__ f32x4 win_read(const WinDev& a, int b, const int (&p)
     }
     const long long wout = (long long)b * a.nW + i[0] * a.sw[0] + i[1] * a.sw[1] + i[2] * a.sw[2];
     const int n = (j[0] * a.w[1] + j[1]) * a.w[2] + j[2];
-    return *reinterpret_cast<const f32x4*>(a.src + (wout * a.N + n) * a.C + 4 * c4);
+    return win_load4(a.src, (wout * a.N + n) * a.C + 4 * c4, a.src_bf16);
 }
 
 __global__ __launch_bounds__(256) void win_scatter_kernel(WinDev a) {
@@ -193,12 +216,17 @@ __global__ __launch_bounds__(256) void win_scatter_kernel(WinDev a) {
                 if (!a.circ[0]) break;
             }
         }
+        if (a.scale) {
+            const float sc = a.scale[b];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] *= sc;
+        }
         if (a.res) {
             const f32x4 r = *reinterpret_cast<const f32x4*>(a.res + (long long)tok * a.C + 4 * c4);
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc[k] += r[k];
         }
-        *reinterpret_cast<f32x4*>(a.dst + (long long)tok * a.C + 4 * c4) = acc;
+        win_store4(a.dst, (long long)tok * a.C + 4 * c4, a.dst_bf16, acc);
     }
 }
 
@@ -337,6 +365,25 @@ extern "C" int dlwp_window_gather(const float* x, float* windows, int B, int C, 
     return DLWP_OK;
 }
 
+// dlwp_window_gather / dlwp_window_gather_fill with storage flags (bit 0: x is a bf16 array, bit 1: windows is one) and an optional
+// per-sample scale [B] applied to the gathered values (the adjoint of dlwp_window_scatter_ex's scale)
+extern "C" int dlwp_window_gather_ex(const void* x, const float* fill, const float* scale, void* windows, int B, int C, const int* dims,
+                                     const int* padded, const int* front, const int* shift, const int* window,
+                                     const long long* wstride, const int* circular, int flags, void* stream) {
+    WinDev a{};
+    int rc = win_setup(a, (const float*)x, (float*)windows, B, C, dims, padded, front, shift, window, wstride, circular, "window_gather_ex");
+    if (rc) return rc;
+    DLWP_REQUIRE(flags >= 0 && flags < 4, DLWP_E_INVALID, "window_gather_ex: flags is a mask of 1 (x bf16) | 2 (windows bf16)");
+    DLWP_REQUIRE(!fill || (reinterpret_cast<uintptr_t>(fill) & 15) == 0, DLWP_E_INVALID, "window_gather_ex: fill must be 16-byte aligned");
+    a.fill = fill;
+    a.scale = scale;
+    a.src_bf16 = flags & 1;
+    a.dst_bf16 = (flags >> 1) & 1;
+    hipLaunchKernelGGL(win_gather_kernel, dim3(grid_for((long long)B * a.nW * a.N * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
 // partition of a tensor that a token-wise Linear layer has ALREADY been applied to: the padded positions hold `fill` (= that
 // layer's bias) instead of zero.  Linear commutes with the gather, so "pad, then Linear over every window token" (reference:
 // panguweather.py:283-292, EarthAttention3D.qkv on the padded windows) equals "Linear over the real tokens, then pad with the
@@ -411,6 +458,26 @@ extern "C" int dlwp_patch_merge(const float* src, float* dst, int B, int H, int 
         if (vec) hipLaunchKernelGGL((patch_merge_kernel<false, 4>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, B, H, W, C);
         else hipLaunchKernelGGL((patch_merge_kernel<false, 1>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, B, H, W, C);
     }
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
+// dlwp_window_scatter_add with storage flags (bit 0: windows is a bf16 array, bit 1: x is one; the residual stays fp32) and an optional
+// per-sample scale [B]: x[b] = residual[b] + scale[b] * scatter(windows)[b] -- reverse + stochastic depth + skip connection in one pass
+extern "C" int dlwp_window_scatter_ex(const void* windows, const float* residual, const float* scale, void* x, int B, int C,
+                                      const int* dims, const int* padded, const int* front, const int* shift, const int* window,
+                                      const long long* wstride, const int* circular, int sum_copies, int flags, void* stream) {
+    WinDev a{};
+    int rc = win_setup(a, (const float*)windows, (float*)x, B, C, dims, padded, front, shift, window, wstride, circular, "window_scatter_ex");
+    if (rc) return rc;
+    DLWP_REQUIRE(flags >= 0 && flags < 4, DLWP_E_INVALID, "window_scatter_ex: flags is a mask of 1 (windows bf16) | 2 (x bf16)");
+    a.res = residual;
+    a.scale = scale;
+    a.dup = sum_copies != 0;
+    a.src_bf16 = flags & 1;
+    a.dst_bf16 = (flags >> 1) & 1;
+    hipLaunchKernelGGL(win_scatter_kernel, dim3(grid_for((long long)B * dims[0] * dims[1] * dims[2] * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, a);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
 }

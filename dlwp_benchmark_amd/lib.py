@@ -80,6 +80,8 @@ SIGNATURES = {
     "dlwp_gemm_group_end": (_I, [_V]),
     "dlwp_window_gather": (_I, [_V, _V, _I, _I] + [_V] * 7 + [_V]),
     "dlwp_window_gather_fill": (_I, [_V, _V, _V, _I, _I] + [_V] * 7 + [_V]),
+    "dlwp_window_gather_ex": (_I, [_V, _V, _V, _V, _I, _I] + [_V] * 7 + [_I, _V]),
+    "dlwp_window_scatter_ex": (_I, [_V, _V, _V, _V, _I, _I] + [_V] * 7 + [_I, _I, _V]),
     "dlwp_window_pad_colsum": (_I, [_V, _V, _I, _I] + [_V] * 7 + [_I, _V]),
     "dlwp_window_scatter": (_I, [_V, _V, _I, _I] + [_V] * 7 + [_I, _V]),
     "dlwp_window_scatter_add": (_I, [_V, _V, _V, _I, _I] + [_V] * 7 + [_I, _V]),

@@ -19,7 +19,9 @@ import torch.nn.functional as F
 
 from .. import lib as L
 from ..rollout_ops import ns_rollout
-from ..token_ops import LayerNorm, Linear, Mlp, PatchConv2d, _grad_slot, add_pos_embed, add_tokens, norm_fork
+from ..token_ops import LayerNorm, Linear, Mlp, PatchConv2d, WgradBatch, _grad_slot, add_pos_embed, add_tokens, norm_fork
+
+_AFNO_WGRAD_BATCH = __import__("os").environ.get("DLWP_AFNO_WGRAD_BATCH", "0") == "1"
 
 
 FFT_MIN_TOKENS = 262144     # token grids from this size on take the rFFT2 path in "auto" mode (see AFNO2D.forward)
@@ -136,7 +138,8 @@ class Block(nn.Module):
         else:
             residual, t = norm_fork(self.norm1, x)
             t = self.norm2(self.filter(t))
-        return self.mlp(t, residual=residual)
+        # (DLWP_AFNO_WGRAD_BATCH=1: the two MLP weight gradients in one dlwp_wgrad_segments launch, measurement knob)
+        return self.mlp(t, residual=residual, wbatch=WgradBatch() if _AFNO_WGRAD_BATCH else None)
 
 
 class PatchEmbed(nn.Module):

@@ -22,6 +22,7 @@ import torch.nn.functional as F
 
 from .. import lib as L
 from ..rollout_ops import ns_rollout
+from .. import token_ops as _TO
 from ..token_ops import _gemm_batched, _grad_slot, DropPath, DropPathPool, LayerNorm, Linear, Mlp, PatchConv2d, UpConvT2d, WgradBatch, norm_fork
 from ..window_ops import WindowSpec, _gather, _scatter, partition, patch_merge, position_maps, reverse
 
@@ -265,12 +266,13 @@ class WindowAttention(nn.Module):
         self.proj = Linear(dim, dim)
         nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
 
-    def forward(self, x, labels=None, nW=1, wbatch=None):
+    def forward(self, x, labels=None, nW=1, wbatch=None, out_lowp=False):
         """x [nW*B, N, C]; labels: int32 [nW, N] region labels of the shift mask (None: no mask); wbatch: the block's
-        token_ops.WgradBatch (the weight gradients of qkv and proj join the block's one launch)."""
+        token_ops.WgradBatch (the weight gradients of qkv and proj join the block's one launch); out_lowp: the projection is
+        written as bf16 where its operands are (bf16 storage) for a consumer that reads bf16 windows (window_ops.reverse)."""
         y = _WindowAttnFn.apply(self.qkv(x, wbatch=wbatch), self.relative_position_bias_table, self._ia, self._ib, labels, nW,
                                 self.num_heads, float(self.scale))
-        return self.proj(y, wbatch=wbatch)
+        return self.proj(y, wbatch=wbatch, out_lowp=out_lowp)
 
     def core(self, qkv_windows, labels=None, nW=1):
         """attention on windows of an already projected qkv tensor [nW*B, N, 3C] (SwinTransformerBlock's real-token flow)"""
@@ -324,10 +326,16 @@ class SwinTransformerBlock(nn.Module):
                     return self.drop_path.branch(self.mlp, t, skip, wbatch=wb)
                 skip, t = norm_fork(self.norm2, self.attn.proj(reverse(t, spec, B), residual=skip, wbatch=wb), gemm_input=True)
                 return self.mlp(t, residual=skip, wbatch=wb)
-            skip, t = norm_fork(self.norm1, x)
-            t = self.attn(partition(t, spec), labels if shifted else None, spec.nW, wbatch=wb)
+            # (bf16 storage: norm1 writes bf16 rows, the gather moves them as they are and qkv reads them; proj writes bf16 windows
+            # for the scatter, whose adjoint hands proj's backward products a bf16 gradient)
+            skip, t = norm_fork(self.norm1, x, gemm_input=True)
+            t = self.attn(partition(t, spec), labels if shifted else None, spec.nW, wbatch=wb, out_lowp=True)
             if self.drop_path.active:        # training with stochastic depth (:255-256): per-sample scale + residual add
-                skip, t = norm_fork(self.norm2, self.drop_path(reverse(t, spec, B), residual=skip), gemm_input=True)
+                if _TO.DROPPATH_FUSED:       # ... inside the scatter kernel
+                    mask = self.drop_path.mask(B, t.device)
+                    skip, t = norm_fork(self.norm2, reverse(t, spec, B, residual=skip, row_scale=mask), gemm_input=True)
+                else:
+                    skip, t = norm_fork(self.norm2, self.drop_path(reverse(t, spec, B), residual=skip), gemm_input=True)
                 return self.drop_path.branch(self.mlp, t, skip, wbatch=wb)
             skip, t = norm_fork(self.norm2, reverse(t, spec, B, residual=skip), gemm_input=True)
             return self.mlp(t, residual=skip, wbatch=wb)

@@ -767,7 +767,7 @@ class _ScaleRowsAddFn(torch.autograd.Function):
         out = torch.empty_like(t2)
         L.check(L.load().dlwp_scale_rows_add(L.ptr(t2), L.ptr(scale), L.ptr(r2), L.ptr(out), B, t2.numel() // B, L.stream()))
         ctx.save_for_backward(scale)
-        ctx.has_res = residual is not None
+        ctx.has_res, ctx.t_dtype = residual is not None, t.dtype
         return out
 
     @staticmethod
@@ -777,7 +777,7 @@ class _ScaleRowsAddFn(torch.autograd.Function):
         B = g2.shape[0]
         gt = torch.empty_like(g2)
         L.check(L.load().dlwp_scale_rows_add(L.ptr(g2), L.ptr(scale), None, L.ptr(gt), B, g2.numel() // B, L.stream()))
-        return gt, None, (g if ctx.has_res else None)
+        return gt.to(ctx.t_dtype), None, (g if ctx.has_res else None)
 
 
 class _AddFn(torch.autograd.Function):

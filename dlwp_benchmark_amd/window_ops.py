@@ -35,23 +35,42 @@ class WindowSpec:
         return d, p, f, (C.c_int * 3)(*shift), w, sw, circ
 
 
-def _gather(x, spec, shift, circ_override=None):
+_BF = torch.bfloat16
+
+
+def _gather(x, spec, shift, circ_override=None, scale=None, out_dtype=torch.float32):
+    """x (fp32 or bf16) -> windows of `out_dtype`; scale [B] fp32: sample b's values times scale[b]."""
     B, Cc = x.shape[0], x.shape[-1]
-    out = torch.empty(B * spec.nW, spec.N, Cc, device=x.device)
+    out = torch.empty(B * spec.nW, spec.N, Cc, device=x.device, dtype=out_dtype)
     d, p, f, s, w, sw, circ = spec.c_args(shift)
     if circ_override is not None:
         circ = (C.c_int * 3)(*circ_override)
+    if x.dtype == _BF or out_dtype == _BF or scale is not None:
+        L.check(L.load().dlwp_window_gather_ex(L.ptr(x), None, L.ptr(scale), L.ptr(out), B, Cc, d, p, f, s, w, sw, circ,
+                                               int(x.dtype == _BF) | (2 if out_dtype == _BF else 0), L.stream()))
+        return out
     L.check(L.load().dlwp_window_gather(L.ptr(x), L.ptr(out), B, Cc, d, p, f, s, w, sw, circ, L.stream()))
     return out
 
 
-def _scatter(wins, spec, shift, B, sum_copies, residual=None):
+def _scatter(wins, spec, shift, B, sum_copies, residual=None, scale=None, out_dtype=torch.float32):
+    """windows (fp32 or bf16) -> tokens of `out_dtype`: residual (fp32) + scale[b] * scatter."""
     Cc = wins.shape[-1]
-    out = torch.empty(B, spec.dims[0] * spec.dims[1] * spec.dims[2], Cc, device=wins.device)
+    out = torch.empty(B, spec.dims[0] * spec.dims[1] * spec.dims[2], Cc, device=wins.device, dtype=out_dtype)
     d, p, f, s, w, sw, circ = spec.c_args(shift)
+    if wins.dtype == _BF or out_dtype == _BF or scale is not None:
+        L.check(L.load().dlwp_window_scatter_ex(L.ptr(wins), L.ptr(residual), L.ptr(scale), L.ptr(out), B, Cc, d, p, f, s, w, sw, circ,
+                                                int(sum_copies), int(wins.dtype == _BF) | (2 if out_dtype == _BF else 0), L.stream()))
+        return out
     L.check(L.load().dlwp_window_scatter_add(L.ptr(wins), L.ptr(residual), L.ptr(out), B, Cc, d, p, f, s, w, sw, circ,
                                              int(sum_copies), L.stream()))
     return out
+
+
+def _keep(t):
+    """contiguous, fp32 unless it already is a bf16 array (bf16 storage: LayerNorm outputs, low-precision Linear outputs)"""
+    t = t.contiguous()
+    return t if t.dtype == _BF else t.float()
 
 
 class _PartitionFn(torch.autograd.Function):
@@ -60,11 +79,13 @@ class _PartitionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, spec, shift):
         ctx.spec, ctx.shift, ctx.B = spec, shift, x.shape[0]
-        return _gather(x.contiguous().float(), spec, shift)
+        x = _keep(x)               # a bf16 input (a LayerNorm output written for the GEMM that follows) stays bf16 through the gather
+        ctx.dtype = x.dtype
+        return _gather(x, spec, shift, out_dtype=x.dtype)
 
     @staticmethod
     def backward(ctx, g):
-        return _scatter(g.contiguous(), ctx.spec, ctx.shift, ctx.B, sum_copies=any(ctx.spec.circ)), None, None
+        return _scatter(_keep(g), ctx.spec, ctx.shift, ctx.B, sum_copies=any(ctx.spec.circ), out_dtype=ctx.dtype), None, None
 
 
 class _PartitionFillFn(torch.autograd.Function):
@@ -108,16 +129,20 @@ class _ReverseFn(torch.autograd.Function):
     connection, added by the same kernel; its gradient is the upstream gradient itself)."""
 
     @staticmethod
-    def forward(ctx, wins, spec, shift, B, residual=None):
-        ctx.spec, ctx.shift, ctx.has_res = spec, shift, residual is not None
+    def forward(ctx, wins, spec, shift, B, residual=None, row_scale=None):
+        """row_scale [B] fp32: tokens = residual + row_scale[b] * reverse(wins)[b] (stochastic depth of the attention branch in the
+        same pass); wins may be a bf16 array (a projection written with out_lowp), the tokens are fp32."""
+        ctx.spec, ctx.shift, ctx.has_res, ctx.row_scale = spec, shift, residual is not None, row_scale
         res = residual.reshape(B, -1, wins.shape[-1]).contiguous().float() if residual is not None else None
-        return _scatter(wins.contiguous().float(), spec, shift, B, sum_copies=False, residual=res)
+        wins = _keep(wins)
+        ctx.dtype = wins.dtype
+        return _scatter(wins, spec, shift, B, sum_copies=False, residual=res, scale=row_scale)
 
     @staticmethod
     def backward(ctx, g):
         # padded positions were dropped: they receive zero gradient whatever the padding mode of the forward partition
-        return (_gather(g.contiguous(), ctx.spec, ctx.shift, circ_override=(0, 0, 0)), None, None, None,
-                g if ctx.has_res else None)
+        return (_gather(g.contiguous().float(), ctx.spec, ctx.shift, circ_override=(0, 0, 0), scale=ctx.row_scale, out_dtype=ctx.dtype),
+                None, None, None, g if ctx.has_res else None, None)
 
 
 def _identity(spec, shift):
@@ -153,15 +178,18 @@ def partition(x, spec, shift=None, fill=None, fill_grad_from=0):
     return _PartitionFn.apply(x, spec, shift)
 
 
-def reverse(wins, spec, B, shift=None, residual=None):
+def reverse(wins, spec, B, shift=None, residual=None, row_scale=None):
     shift = tuple(spec.shift if shift is None else shift)
     if _identity(spec, shift):
         y = wins.reshape(B, spec.N, wins.shape[-1])
+        if row_scale is not None:
+            from .token_ops import _ScaleRowsAddFn
+            return _ScaleRowsAddFn.apply(y, row_scale, residual.reshape(y.shape) if residual is not None else None)
         if residual is None:
             return y
         from .token_ops import add_tokens
         return add_tokens(y, residual.reshape(y.shape))
-    return _ReverseFn.apply(wins, spec, shift, B, residual)
+    return _ReverseFn.apply(wins, spec, shift, B, residual, row_scale)
 
 
 class _PatchMergeFn(torch.autograd.Function):

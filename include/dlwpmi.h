@@ -445,6 +445,20 @@ int dlwp_window_scatter_add(const float* windows, const float* residual, float* 
                             const int* dims, const int* padded, const int* front, const int* shift,
                             const int* window, const long long* wstride, const int* circular,
                             int sum_copies, void* stream);
+/* Round 5: the gather / scatter pair on bf16 arrays and with the branch's stochastic depth folded in.            */
+/* dlwp_window_gather_ex: dlwp_window_gather_fill (fill nullable) with flags bit 0 = x is a bf16 array, bit 1 =     */
+/* windows is one, and scale [B] (nullable): the gathered values of sample b are multiplied by scale[b].            */
+/* dlwp_window_scatter_ex: x[b] = residual[b] + scale[b] * reverse(windows)[b] (`x = shortcut + drop_path(x)` after */
+/* window_reverse, swin_transformer.py:250-256): flags bit 0 = windows is a bf16 array, bit 1 = x is one; residual  */
+/* (fp32, nullable) and scale [B] (fp32, nullable).  Each is the other's adjoint with the same scale.               */
+int dlwp_window_gather_ex(const void* x, const float* fill, const float* scale, void* windows, int B, int C,
+                          const int* dims, const int* padded, const int* front, const int* shift,
+                          const int* window, const long long* wstride, const int* circular, int flags,
+                          void* stream);
+int dlwp_window_scatter_ex(const void* windows, const float* residual, const float* scale, void* x, int B, int C,
+                           const int* dims, const int* padded, const int* front, const int* shift,
+                           const int* window, const long long* wstride, const int* circular,
+                           int sum_copies, int flags, void* stream);
 /* Epilogue of a transposed convolution with kernel == stride on channels-last tokens (the Swin U-decoder's          */
 /* nn.ConvTranspose2d(k, stride k) + GELU, src/nsbench/models/swintransformer/swin_transformer.py:580-588, dlwpbench  */
 /* twin): y [B*H*W][O*kh*kw] is the GEMM x . W[Cin][O*kh*kw] in the weight's own layout; forward: dst[b][h kh+i][w kw+j] */

@@ -33,6 +33,41 @@ def test_partition_with_fill_and_its_adjoint(cuda, C):
         assert int(pads.sum()) > 0
 
 
+@pytest.mark.parametrize("modes", [("constant",) * 3, ("constant", "constant", "circular")])
+def test_partition_and_reverse_on_bf16_arrays_with_the_branch_scale(cuda, modes):
+    """dlwp_window_gather_ex / dlwp_window_scatter_ex: a bf16 array moves through partition bit for bit (and its adjoint sums the
+    copies in fp32, rounded once); reverse(bf16 windows, residual, row_scale) = residual + scale[b] * reverse(fp32 windows) within
+    one bf16 rounding of the windows, with the gradient of the windows = scale[b] * gather(g) in the windows' dtype."""
+    from dlwp_benchmark_amd.window_ops import WindowSpec, partition, reverse
+    BF = torch.bfloat16
+    spec = WindowSpec((1, 9, 12), (1, 4, 5), front=(0, 1, 1), back=(0, 2, 2), modes=modes)
+    torch.manual_seed(1)
+    B, C = 3, 24
+    for shift in ((0, 0, 0), (0, 2, 2)):
+        x = torch.randn(B, 9 * 12, C, device=cuda)
+        x16 = x.to(BF).requires_grad_(True)
+        x32 = x.to(BF).float().requires_grad_(True)
+        w16, w32 = partition(x16, spec, shift), partition(x32, spec, shift)
+        assert w16.dtype == BF and torch.equal(w16.float(), w32)
+        g = torch.randn_like(w32)
+        (g16,), (g32,) = torch.autograd.grad(w16, x16, g.to(BF)), torch.autograd.grad(w32, x32, g.to(BF).float())
+        assert g16.dtype == BF and torch.equal(g16, g32.to(BF))
+        # reverse with scale + residual
+        wins = torch.randn(B * spec.nW, spec.N, C, device=cuda)
+        res = torch.randn(B, 9 * 12, C, device=cuda, requires_grad=True)
+        sc = torch.tensor([0.0, 1.25, 1.0], device=cuda)
+        a16 = wins.to(BF).requires_grad_(True)
+        a32 = wins.to(BF).float().requires_grad_(True)
+        y16 = reverse(a16, spec, B, shift, residual=res, row_scale=sc)
+        y32 = res + sc[:, None, None] * reverse(a32, spec, B, shift)
+        assert y16.dtype == torch.float32 and rel(y16, y32) <= 1e-6
+        gy = torch.randn_like(y32)
+        ga16, gr16 = torch.autograd.grad(y16, (a16, res), gy)
+        ga32, gr32 = torch.autograd.grad(y32, (a32, res), gy)
+        assert ga16.dtype == BF and torch.equal(ga16, ga32.to(BF)) and torch.equal(gr16, gr32)
+        assert torch.equal(y16[0], res[0].detach())          # a dropped sample is its residual
+
+
 @pytest.mark.parametrize("B,res,heads,dim", [(8, (1, 30, 60), 6, 96),      # 8 * 45 windows * 6 heads: the wave-per-window kernels
                                               (1, (1, 30, 60), 6, 96),      # few windows: the tiled kernels (range ignored)
                                               (2, (2, 20, 30), 4, 64)])     # no pressure-level pad: lat / lon pads only

@@ -301,3 +301,51 @@ def test_real_token_flow_equals_window_token_flow(cuda, H, W, pm, shift, bias):
     assert rel(outs[True][0], outs[False][0]) <= 2e-5
     for n, a, b in zip(["x"] + [n for n, _ in blk.named_parameters()], outs[True][1], outs[False][1]):
         assert rel(a, b) <= 2e-4, n
+
+
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+@pytest.mark.parametrize("pm", ["constant", ("constant", "circular")])
+def test_swin_blocks_with_fused_stochastic_depth_and_bf16_window_moves_equal_the_separate_passes(cuda, storage, pm):
+    """BasicLayer (an unshifted and a shifted SwinTransformerBlock) in training mode with drop_path > 0: the per-sample scale inside the scatter kernel / fc2's epilogue, bf16
+    rows through the gather / scatter under bf16 storage and the four weight gradients in one launch, against the same block with
+    DLWP_DROPPATH_FUSED / DLWP_WGRAD_BATCH off (separate scale passes, per-layer products), same masks: forward and every gradient.
+    fp32 storage: 1e-5 of the max norm; bf16 storage: 2e-2 (bf16 roundings at different places of the backward chain)."""
+    from dlwp_benchmark_amd import lib as L, token_ops as TO
+    from dlwp_benchmark_amd.nsbench.swin_transformer import BasicLayer
+    from dlwp_benchmark_amd.train_engine import flatten_parameters, refresh_bf16_weights
+    B, H, W, C = 3, 12, 20, 32
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(B, H * W, C, generator=g).to(cuda)
+    gy = torch.randn(B, H * W, C, generator=g).to(cuda)
+    masks = [torch.tensor(m, device=cuda) for m in ([0.0, 1.25, 1.25], [1.25, 0.0, 1.25], [1.25, 1.25, 0.0], [1.25, 1.25, 1.25])]
+    res = {}
+
+    def run(fused):
+        torch.manual_seed(2)
+        blk = BasicLayer(C, depth=2, num_heads=4, window_size=7, mlp_ratio=2.0, drop_path=0.2, padding_mode=pm).to(cuda).train()
+        flat, grad = flatten_parameters(blk)
+        refresh_bf16_weights(blk)
+        it = iter(masks)
+        for b_ in blk.blocks:          # (unshifted block, shifted block) x (attention branch, MLP branch)
+            b_.drop_path.mask = lambda batch, device: next(it)
+        TO.DROPPATH_FUSED = TO.WGRAD_BATCH = fused
+        L.SHADOW_ACTIVE = True
+        try:
+            x = x0.clone().requires_grad_(True)
+            y = blk(x, H, W)[0]
+            y.backward(gy)
+        finally:
+            L.SHADOW_ACTIVE = False
+            TO.DROPPATH_FUSED = TO.WGRAD_BATCH = True
+        return [y.detach(), x.grad] + [p.grad.clone() for p in blk.parameters()]
+    ctx = L.gemm_precision("bf16") if storage == "bf16" else __import__("contextlib").nullcontext()
+    with ctx:
+        if storage == "bf16":
+            L.set_storage("bf16")
+        try:
+            a, b = run(True), run(False)
+        finally:
+            L.set_storage("fp32")
+    tol = 1e-5 if storage == "fp32" else 2e-2
+    for u, v in zip(a, b):
+        assert (u - v).abs().max().item() <= tol * v.abs().max().item() + 1e-12

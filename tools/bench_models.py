@@ -162,7 +162,7 @@ def main():
         # BASELINE C4 shapes: dlwpbench SwinTransformer 128x256, window 7 (extra kwarg), E=96, depths [4,4], heads [4,4]
         m = dlwpbench.SwinTransformer(constant_channels=4, prescribed_channels=1, prognostic_channels=8, context_size=1,
                                       img_height=128, img_width=256, patch_size=1, embed_dim=96, depths=[4, 4],
-                                      num_heads=[4, 4], drop_path_rate=0.0, window_size=7)
+                                      num_heads=[4, 4], drop_path_rate=0.2, window_size=7)      # (bench.py's configuration)
 
         def batch(dev):
             kw = dict(constants=torch.randn(2, 1, 4, 128, 256, generator=g).to(dev),
