@@ -119,7 +119,7 @@ class BucketedGradAllReduce:
                 continue
             lo = min((p.grad.data_ptr() - base) // 4 for p in ps)
             hi = max((p.grad.data_ptr() - base) // 4 + p.numel() for p in ps)
-            if 0 <= lo and hi <= total and sum(p.numel() for p in ps) + 4 * len(ps) >= hi - lo:     # contiguous up to padding
+            if 0 <= lo and hi <= total and sum(p.numel() for p in ps) + 8 * len(ps) >= hi - lo:     # contiguous up to padding
                 spans.append((lo, hi, unit))
         spans.sort(key=lambda t: t[0])
         kept, end = [], 0                             # drop units that overlap an already KEPT span (tied / shared parameters)
@@ -131,7 +131,7 @@ class BucketedGradAllReduce:
         self.buckets = []                             # dict(lo, hi, units)
         for lo, hi, unit in spans:
             last = self.buckets[-1] if self.buckets else None
-            if last and (last["hi"] - last["lo"]) * 4 < bucket_bytes and lo - last["hi"] <= 4:
+            if last and (last["hi"] - last["lo"]) * 4 < bucket_bytes and lo - last["hi"] <= 8:
                 last["hi"] = hi
                 last["units"].append(unit)
             else:

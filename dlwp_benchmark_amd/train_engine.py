@@ -17,6 +17,9 @@ from . import lib as L
 from .fno_engine import FusedAdam
 
 
+_FLAT_ALIGN = int(__import__("os").environ.get("DLWP_FLAT_ALIGN", "8"))      # env: A/B runs against the 4-element slices of rounds 1-4
+
+
 def flatten_parameters(module):
     """Re-point every parameter of `module` (and its .grad) at a slice of one flat buffer.
     Returns (flat_params, flat_grads).  Parameter names, shapes and values are unchanged."""
@@ -26,11 +29,13 @@ def flatten_parameters(module):
     dev = params[0].device
     if dev.type != "cuda":
         raise L.DlwpError("flatten_parameters: move the module to the GPU first (no CPU path)")
-    # 4-float (16-byte) aligned slices: the GEMM's vector loads need aligned weight matrices
+    # 8-element aligned slices: 32 bytes in the fp32 buffers and 16 bytes in the bf16 copy (same offsets), the alignment the GEMMs'
+    # 16-byte operand loads need -- with 4-element slices (rounds 1-4) a weight matrix that landed on an odd multiple of 4 had its
+    # bf16 copy 8-byte aligned only and its products fell back to the widening operand path
     offs, n = [], 0
     for p in params:
         offs.append(n)
-        n += (p.numel() + 3) // 4 * 4
+        n += (p.numel() + _FLAT_ALIGN - 1) // _FLAT_ALIGN * _FLAT_ALIGN
     flat = torch.zeros(n, device=dev)
     grad = torch.zeros(n, device=dev)
     for p, o in zip(params, offs):
