@@ -36,6 +36,7 @@ struct FftAxis {
     // (device; forward, inverse), the real image [[Fr, -Fi], [Fi, Fr]] of F[q][r] = e^{sg 2 pi i q r / R} padded to RP = 8-multiple
     const float* amat;
     int rp;
+    int sp;                          // compile-time plan (SPlan<sp>) this axis runs on, 0 = the run-time plan
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
@@ -79,6 +80,197 @@ __device__ __forceinline__ void dft_small(float2 (&u)[R], float sg) {
         u[2] = make_float2(m2.x + n2.x, m2.y + n2.y);
         u[3] = make_float2(m2.x - n2.x, m2.y - n2.y);
     }
+}
+
+// e^{2 pi i j / N} for the composite register butterflies (literals: the index is a compile-time constant after unrolling)
+template <int N> struct TwC;
+template <> struct TwC<6> {
+    static __device__ __forceinline__ float2 get(int j) {
+        switch (j) {
+            case 0: return make_float2(1.f, 0.f);
+            case 1: return make_float2(0.50000000000000011f, 0.8660254037844386f);
+            case 2: return make_float2(-0.49999999999999978f, 0.86602540378443871f);
+            case 3: return make_float2(-1.f, 0.f);
+            case 4: return make_float2(-0.50000000000000044f, -0.86602540378443837f);
+            case 5: return make_float2(0.50000000000000011f, -0.8660254037844386f);
+            default: return make_float2(1.f, 0.f);
+        }
+    }
+};
+template <> struct TwC<9> {
+    static __device__ __forceinline__ float2 get(int j) {
+        switch (j) {
+            case 0: return make_float2(1.f, 0.f);
+            case 1: return make_float2(0.76604444311897801f, 0.64278760968653925f);
+            case 2: return make_float2(0.17364817766693041f, 0.98480775301220802f);
+            case 3: return make_float2(-0.49999999999999978f, 0.86602540378443871f);
+            case 4: return make_float2(-0.93969262078590832f, 0.34202014332566888f);
+            case 5: return make_float2(-0.93969262078590843f, -0.34202014332566866f);
+            case 6: return make_float2(-0.50000000000000044f, -0.86602540378443837f);
+            case 7: return make_float2(0.17364817766692997f, -0.98480775301220813f);
+            case 8: return make_float2(0.76604444311897779f, -0.64278760968653958f);
+            default: return make_float2(1.f, 0.f);
+        }
+    }
+};
+template <> struct TwC<10> {
+    static __device__ __forceinline__ float2 get(int j) {
+        switch (j) {
+            case 0: return make_float2(1.f, 0.f);
+            case 1: return make_float2(0.80901699437494745f, 0.58778525229247314f);
+            case 2: return make_float2(0.30901699437494745f, 0.95105651629515353f);
+            case 3: return make_float2(-0.30901699437494734f, 0.95105651629515364f);
+            case 4: return make_float2(-0.80901699437494734f, 0.58778525229247325f);
+            case 5: return make_float2(-1.f, 0.f);
+            case 6: return make_float2(-0.80901699437494756f, -0.58778525229247303f);
+            case 7: return make_float2(-0.30901699437494756f, -0.95105651629515353f);
+            case 8: return make_float2(0.30901699437494723f, -0.95105651629515364f);
+            case 9: return make_float2(0.80901699437494734f, -0.58778525229247336f);
+            default: return make_float2(1.f, 0.f);
+        }
+    }
+};
+template <> struct TwC<12> {
+    static __device__ __forceinline__ float2 get(int j) {
+        switch (j) {
+            case 0: return make_float2(1.f, 0.f);
+            case 1: return make_float2(0.86602540378443871f, 0.49999999999999994f);
+            case 2: return make_float2(0.50000000000000011f, 0.8660254037844386f);
+            case 3: return make_float2(0.f, 1.f);
+            case 4: return make_float2(-0.49999999999999978f, 0.86602540378443871f);
+            case 5: return make_float2(-0.86602540378443871f, 0.49999999999999994f);
+            case 6: return make_float2(-1.f, 0.f);
+            case 7: return make_float2(-0.86602540378443882f, -0.49999999999999972f);
+            case 8: return make_float2(-0.50000000000000044f, -0.86602540378443837f);
+            case 9: return make_float2(0.f, -1.f);
+            case 10: return make_float2(0.50000000000000011f, -0.8660254037844386f);
+            case 11: return make_float2(0.86602540378443837f, -0.50000000000000044f);
+            default: return make_float2(1.f, 0.f);
+        }
+    }
+};
+template <> struct TwC<15> {
+    static __device__ __forceinline__ float2 get(int j) {
+        switch (j) {
+            case 0: return make_float2(1.f, 0.f);
+            case 1: return make_float2(0.91354545764260087f, 0.40673664307580015f);
+            case 2: return make_float2(0.66913060635885824f, 0.74314482547739413f);
+            case 3: return make_float2(0.30901699437494745f, 0.95105651629515353f);
+            case 4: return make_float2(-0.10452846326765333f, 0.9945218953682734f);
+            case 5: return make_float2(-0.49999999999999978f, 0.86602540378443871f);
+            case 6: return make_float2(-0.80901699437494734f, 0.58778525229247325f);
+            case 7: return make_float2(-0.97814760073380569f, 0.20791169081775931f);
+            case 8: return make_float2(-0.97814760073380569f, -0.20791169081775907f);
+            case 9: return make_float2(-0.80901699437494756f, -0.58778525229247303f);
+            case 10: return make_float2(-0.50000000000000044f, -0.86602540378443837f);
+            case 11: return make_float2(-0.10452846326765423f, -0.99452189536827329f);
+            case 12: return make_float2(0.30901699437494723f, -0.95105651629515364f);
+            case 13: return make_float2(0.66913060635885846f, -0.74314482547739402f);
+            case 14: return make_float2(0.91354545764260098f, -0.40673664307580015f);
+            default: return make_float2(1.f, 0.f);
+        }
+    }
+};
+
+// DFT of length A * B in registers from the two small ones (Cooley-Tukey inside the register file): n = B n1 + n2, k = k1 + A k2,
+//   X[k1 + A k2] = sum_{n2} W_B^{n2 k2} ( W_N^{n2 k1} sum_{n1} x[B n1 + n2] W_A^{n1 k1} ),   W_M = e^{sg 2 pi i / M}
+template <int A, int B>
+__device__ __forceinline__ void dft_comp(float2 (&u)[A * B], float sg) {
+    constexpr int N = A * B;
+    float2 y[N];
+#pragma unroll
+    for (int n2 = 0; n2 < B; ++n2) {
+        float2 t[A];
+#pragma unroll
+        for (int n1 = 0; n1 < A; ++n1) t[n1] = u[B * n1 + n2];
+        dft_small<A>(t, sg);
+#pragma unroll
+        for (int k1 = 0; k1 < A; ++k1) {
+            const int m = (n2 * k1) % N;
+            if (m == 0) {
+                y[k1 * B + n2] = t[k1];
+            } else {
+                float2 w = TwC<N>::get(m);
+                w.y *= sg;
+                y[k1 * B + n2] = cmul(t[k1], w);
+            }
+        }
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < A; ++k1) {
+        float2 t[B];
+#pragma unroll
+        for (int n2 = 0; n2 < B; ++n2) t[n2] = y[k1 * B + n2];
+        dft_small<B>(t, sg);
+#pragma unroll
+        for (int k2 = 0; k2 < B; ++k2) u[k1 + A * k2] = t[k2];
+    }
+}
+template <int R>
+__device__ __forceinline__ void dft_reg(float2 (&u)[R], float sg) {
+    if constexpr (R <= 5) dft_small<R>(u, sg);
+    else if constexpr (R == 6) dft_comp<2, 3>(u, sg);
+    else if constexpr (R == 9) dft_comp<3, 3>(u, sg);
+    else if constexpr (R == 10) dft_comp<2, 5>(u, sg);
+    else if constexpr (R == 12) dft_comp<3, 4>(u, sg);
+    else { static_assert(R == 15, "register butterflies: 2 - 6, 9, 10, 12, 15"); dft_comp<3, 5>(u, sg); }
+}
+
+// ---- plans fixed at compile time (round 5).  The run-time plan above costs ~27 VALU instructions per point and pass (index
+// arithmetic through FastDiv structures, a run-time radix switch inside the pass loop, 60 % of the lanes busy in the partial
+// rounds): with the butterfly passes skipped (DLWP_FFT_SKIP_PASSES) rfft2 of 90 x 180 x 768 takes 50.7 us of its 84.4.  For the
+// axis lengths of the FourCastNet token grid the whole plan is a template: signal length, inner lanes, thread count and two
+// large radices (composite register butterflies) are constants, every index is a shift / constant multiply, the first pass has
+// no twiddles, and lanes x butterflies per pass nearly fill the workgroup.
+template <int SP> struct SPlan;
+template <> struct SPlan<1> { static constexpr int N = 180, LOGIB = 4, NT = 256, R0 = 12, R1 = 15; };     // 15 x 16 = 240, 12 x 16 = 192 items
+template <> struct SPlan<2> { static constexpr int N = 90, LOGIB = 5, NT = 320, R0 = 9, R1 = 10; };       // 10 x 32 = 320, 9 x 32 = 288 items
+
+// one Stockham pass of radix R, P = product of the earlier radices (pass_small with every plan quantity a constant)
+template <int N, int LOGIB, int NT, int R, int P>
+__device__ __forceinline__ void pass_c(float2* buf, const float2* tabs, float sg) {
+    constexpr int IB = 1 << LOGIB, IBP = IB + 1, T = N / R, M = P * R, STEP = N / M, NITEMS = T * IB, NB = (NITEMS + NT - 1) / NT;
+    static_assert(N % (P * R) == 0, "radices must divide the signal length");
+    const int tid = threadIdx.x;
+    float2 u[NB][R];
+#pragma unroll
+    for (int ub = 0; ub < NB; ++ub) {
+        const int e = tid + ub * NT;
+        if ((ub + 1) * NT <= NITEMS || e < NITEMS) {
+            const int lane = e & (IB - 1), i = e >> LOGIB, blk = i / P, k = i - blk * P;
+            const float2* xin = buf + i * IBP + lane;
+#pragma unroll
+            for (int r = 0; r < R; ++r) u[ub][r] = xin[r * T * IBP];
+            if constexpr (P > 1) {
+#pragma unroll
+                for (int r = 1; r < R; ++r) {
+                    float2 w = tabs[r * k * STEP];
+                    w.y *= -sg;                                  // table holds e^{-i theta}
+                    u[ub][r] = cmul(u[ub][r], w);
+                }
+            }
+            dft_reg<R>(u[ub], sg);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ub = 0; ub < NB; ++ub) {
+        const int e = tid + ub * NT;
+        if ((ub + 1) * NT <= NITEMS || e < NITEMS) {
+            const int lane = e & (IB - 1), i = e >> LOGIB, blk = i / P, k = i - blk * P;
+            float2* yout = buf + (blk * M + k) * IBP + lane;
+#pragma unroll
+            for (int q = 0; q < R; ++q) yout[q * P * IBP] = u[ub][q];
+        }
+    }
+    __syncthreads();
+}
+template <int SP>
+__device__ __forceinline__ void lds_fft_static(float2* buf, const float2* tabs, float sg) {
+    using S = SPlan<SP>;
+    static_assert(S::R0 * S::R1 == S::N, "two-pass plans");
+    pass_c<S::N, S::LOGIB, S::NT, S::R0, 1>(buf, tabs, sg);
+    pass_c<S::N, S::LOGIB, S::NT, S::R1, S::R0>(buf, tabs, sg);
 }
 
 // One Stockham pass of radix R with the butterflies in registers: work item = (butterfly i < N / R, lane); inputs
@@ -227,10 +419,10 @@ __device__ __forceinline__ void lds_fft(float2* buf, const float2* tabs, const F
     int p = 1;
     for (int s = 0; s < f.nrad; ++s) {
         const int R = f.rad[s], t = f.N / R, M = p * R, step = f.N / M;
-        if (R == 4) { pass_small<4, OUTS, NT>(buf, tabs, f, s, p, sg); p = M; continue; }
-        if (R == 2) { pass_small<2, OUTS, NT>(buf, tabs, f, s, p, sg); p = M; continue; }
-        if (R == 3) { pass_small<3, OUTS, NT>(buf, tabs, f, s, p, sg); p = M; continue; }
-        if (R == 5) { pass_small<5, OUTS, NT>(buf, tabs, f, s, p, sg); p = M; continue; }
+        if (R == 4) { pass_small<4, OUTS, NT>(buf, tabs, f, s, p, sg); p = M; DLWP_STAMP(16 + s); continue; }
+        if (R == 2) { pass_small<2, OUTS, NT>(buf, tabs, f, s, p, sg); p = M; DLWP_STAMP(16 + s); continue; }
+        if (R == 3) { pass_small<3, OUTS, NT>(buf, tabs, f, s, p, sg); p = M; DLWP_STAMP(16 + s); continue; }
+        if (R == 5) { pass_small<5, OUTS, NT>(buf, tabs, f, s, p, sg); p = M; DLWP_STAMP(16 + s); continue; }
         if constexpr (PRIME) {      // instantiated only for plans with a large last prime: the pass costs 64 accumulator registers
             if (s == f.nrad - 1) { pass_prime_mfma<NT>(buf, tabs, f, s, p, sg); p = M; continue; }
         }
@@ -285,6 +477,7 @@ struct FftIO {
     // c % bs, im bs floats further (the operand layout of the one-GEMM-per-layer AFNO block MLP, afno_tiled._BlockComplexLinearBP)
     long long plane_in, plane_out, Jw;
     int r0, r1, bs;
+    int dbg_skip;             // measurement only (DLWP_FFT_SKIP_PASSES=1): the butterfly passes are skipped, the kernels move data only
 };
 
 __device__ __forceinline__ void load_table(float2* tabs, const FftAxis& f) {
@@ -293,13 +486,14 @@ __device__ __forceinline__ void load_table(float2* tabs, const FftAxis& f) {
 
 // ---- W-axis real -> complex.  CF = false: channels-last, lanes = channel pairs of row (b, h) = blockIdx.y;
 //      CF = true: channels-first, lanes = pairs of image rows (2 IB consecutive rows per workgroup, blockIdx.y).
-template <int OUTS, int NT, bool CF, bool PRIME = false>
+template <int OUTS, int NT, bool CF, bool PRIME = false, int SP = 0>
 __global__ __launch_bounds__(NT) void fft_r2c_kernel(FftIO a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const FftAxis& f = a.ax;
     const int IBP = f.IB + 1, W = f.N, Wh = W / 2;
     float2* buf = reinterpret_cast<float2*>(smem);   // [W][IBP]
     float2* tabs = buf + W * IBP;                    // [W]
+    DLWP_STAMP(0);
     load_table(tabs, f);
     const long long o = blockIdx.y;
     const int c0 = CF ? 0 : blockIdx.x * 2 * f.IB;
@@ -324,7 +518,10 @@ __global__ __launch_bounds__(NT) void fft_r2c_kernel(FftIO a) {
         }
     }
     __syncthreads();
-    lds_fft<OUTS, NT, PRIME>(buf, tabs, f, -1.f);
+    DLWP_STAMP(1);
+    if constexpr (SP != 0) { if (!a.dbg_skip) lds_fft_static<SP>(buf, tabs, -1.f); }
+    else if (!a.dbg_skip) lds_fft<OUTS, NT, PRIME>(buf, tabs, f, -1.f);
+    DLWP_STAMP(2);
     // split the two spectra: X1 = (Z_k + conj Z_{W-k}) / 2,  X2 = -i (Z_k - conj Z_{W-k}) / 2
     if (!CF) {
         const int nl = min(f.IB, (a.C - c0) / 2);
@@ -350,16 +547,18 @@ __global__ __launch_bounds__(NT) void fft_r2c_kernel(FftIO a) {
             reinterpret_cast<float2*>(a.out)[row * a.Wc + k] = v;
         }
     }
+    DLWP_STAMP(3);
 }
 
 // ---- W-axis complex (Hermitian half) -> real
-template <int OUTS, int NT, bool CF, bool PRIME = false>
+template <int OUTS, int NT, bool CF, bool PRIME = false, int SP = 0>
 __global__ __launch_bounds__(NT) void fft_c2r_kernel(FftIO a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const FftAxis& f = a.ax;
     const int IBP = f.IB + 1, W = f.N, Wh = W / 2;
     float2* buf = reinterpret_cast<float2*>(smem);
     float2* tabs = buf + W * IBP;
+    DLWP_STAMP(8);
     load_table(tabs, f);
     const long long o = blockIdx.y;
     const int c0 = CF ? 0 : blockIdx.x * 2 * f.IB;
@@ -406,7 +605,10 @@ __global__ __launch_bounds__(NT) void fft_c2r_kernel(FftIO a) {
         }
     }
     __syncthreads();
-    lds_fft<OUTS, NT, PRIME>(buf, tabs, f, +1.f);
+    DLWP_STAMP(9);
+    if constexpr (SP != 0) { if (!a.dbg_skip) lds_fft_static<SP>(buf, tabs, +1.f); }
+    else if (!a.dbg_skip) lds_fft<OUTS, NT, PRIME>(buf, tabs, f, +1.f);
+    DLWP_STAMP(10);
     if (!CF) {
         const int nl = min(f.IB, (a.C - c0) / 2);
         float* dst = a.out + o * W * a.C + c0;
@@ -428,16 +630,18 @@ __global__ __launch_bounds__(NT) void fft_c2r_kernel(FftIO a) {
             a.out[row * W + w] = a.scale * ((rr & 1) ? z.y : z.x);
         }
     }
+    DLWP_STAMP(11);
 }
 
 // ---- complex -> complex along an axis of stride J (the H axis of both layouts): element (o, n, j) at ((o * N + n) * J + j)
-template <int OUTS, int NT, bool PRIME = false>
+template <int OUTS, int NT, bool PRIME = false, int SP = 0>
 __global__ __launch_bounds__(NT) void fft_c2c_kernel(FftIO a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const FftAxis& f = a.ax;
     const int IBP = f.IB + 1, N = f.N;
     float2* buf = reinterpret_cast<float2*>(smem);
     float2* tabs = buf + N * IBP;
+    DLWP_STAMP(4);
     load_table(tabs, f);
     const long long o = blockIdx.y, j0 = (long long)blockIdx.x * f.IB;
     const int nl = (int)min((long long)f.IB, a.J - j0);
@@ -480,7 +684,10 @@ __global__ __launch_bounds__(NT) void fft_c2c_kernel(FftIO a) {
         buf[n * IBP + lane] = z;
     }
     __syncthreads();
-    lds_fft<OUTS, NT, PRIME>(buf, tabs, f, a.sg);
+    DLWP_STAMP(5);
+    if constexpr (SP != 0) { if (!a.dbg_skip) lds_fft_static<SP>(buf, tabs, a.sg); }
+    else if (!a.dbg_skip) lds_fft<OUTS, NT, PRIME>(buf, tabs, f, a.sg);
+    DLWP_STAMP(6);
     for (int e = threadIdx.x; e < N << f.logIB; e += NT) {
         const int lane = e & (f.IB - 1), n = e >> f.logIB;
         if (lane < nl) {
@@ -496,7 +703,17 @@ __global__ __launch_bounds__(NT) void fft_c2c_kernel(FftIO a) {
             }
         }
     }
+    DLWP_STAMP(7);
 }
+
+#ifdef DLWP_STAMPS
+}  // namespace
+extern "C" int dlwp_debug_stamps_fft(unsigned long long* host_out) {
+    DLWP_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dlwp_stamps), sizeof(unsigned long long) * 32));
+    return DLWP_OK;
+}
+namespace {
+#endif
 
 int factorise(int N, int* rad) {
     int n = 0;
@@ -517,10 +734,22 @@ struct dlwp_fft_plan {
 
 namespace {
 
-int make_axis(FftAxis& ax, int N, float2** tab_dev, float** amat_dev, int ib_cap) {
+// compile-time plan of an axis, or 0: SPlan<1> = a W axis of 180 (channels-last real passes), SPlan<2> = an H axis of 90 -- the
+// FourCastNet token grids 90 x 180 and 103 x 180 (DLWP_FFT_STATIC=0: the run-time plan everywhere)
+int static_plan_for(int N, bool w_axis) {
+    if (dlwp_tune_or("FFT_STATIC", 1) == 0) return 0;
+    if (w_axis && N == SPlan<1>::N) return 1;
+    if (!w_axis && N == SPlan<2>::N) return 2;
+    return 0;
+}
+
+int make_axis(FftAxis& ax, int N, float2** tab_dev, float** amat_dev, int ib_cap, bool w_axis) {
     ax.N = N;
     ax.amat = nullptr;
     ax.rp = 0;
+    ax.sp = static_plan_for(N, w_axis);
+    if (ax.sp == 1) ib_cap = 1 << SPlan<1>::LOGIB;
+    if (ax.sp == 2) ib_cap = 1 << SPlan<2>::LOGIB;
     ax.nrad = factorise(N, ax.rad);
     DLWP_REQUIRE(ax.nrad > 0, DLWP_E_UNSUPPORTED, "fft: cannot factorise %d into at most %d radices", N, MAXRAD);
     int p = 1;
@@ -580,7 +809,7 @@ size_t axis_lds(const FftAxis& ax) { return (size_t)ax.N * (ax.IB + 2) * sizeof(
 struct LaunchShape { int nt, outs; };
 LaunchShape shape_of(const FftAxis& ax) {
     const int total = ax.N * ax.IB;
-    const int nt = total > 4096 ? 512 : 256;
+    const int nt = total > dlwp_tune_or("FFT_NT512_FROM", 4096) ? 512 : 256;      // (knob: 512-thread workgroups for smaller tiles too)
     const int need = ceil_div(total, nt);
     const int buckets[] = {2, 4, 8, 16, 24, 32};
     for (int b : buckets)
@@ -610,6 +839,9 @@ LaunchShape shape_of(const FftAxis& ax) {
             }                                                                                                          \
         } else {                                                                                                       \
             switch (sh.outs) {                                                                                         \
+                case 2: go(KERNEL_T<2, 512 EXTRA>, 512); break;                                                        \
+                case 4: go(KERNEL_T<4, 512 EXTRA>, 512); break;                                                        \
+                case 8: go(KERNEL_T<8, 512 EXTRA>, 512); break;                                                        \
                 case 16: go(KERNEL_T<16, 512 EXTRA>, 512); break;                                                      \
                 case 24: go(KERNEL_T<24, 512 EXTRA>, 512); break;                                                      \
                 default: go(KERNEL_T<32, 512 EXTRA>, 512); break;                                                      \
@@ -624,6 +856,7 @@ LaunchShape shape_of(const FftAxis& ax) {
 int run_w_real(const dlwp_fft_plan* p, bool to_complex, bool cf, const float* in, float* out, int B, int C, float scale,
                float w_int, hipStream_t stream, const float* res = nullptr) {
     FftIO io{};
+    io.dbg_skip = dlwp_tune_on("FFT_SKIP_PASSES") ? 1 : 0;
     io.ax = p->axW; io.in = in; io.out = out; io.res = res; io.C = C; io.H = p->H; io.W = p->W; io.Wc = p->W / 2 + 1;
     io.scale = scale; io.w_int = w_int;
     dim3 grid;
@@ -641,6 +874,22 @@ int run_w_real(const dlwp_fft_plan* p, bool to_complex, bool cf, const float* in
     const LaunchShape sh = shape_of(io.ax);
     DLWP_REQUIRE(sh.outs > 0, DLWP_E_UNSUPPORTED, "fft: axis of length %d needs more than 32 outputs per thread", io.ax.N);
     const size_t lds = axis_lds(io.ax);
+    if (io.ax.sp == 1 && !cf) {            // channels-last W axis of 180 on its compile-time plan (OUTS covers N * IB / NT = 11.25)
+        using S = SPlan<1>;
+        static_assert(16 * S::NT >= S::N << S::LOGIB, "the c2r store loop walks OUTS * NT >= N * IB elements");
+        int rc;
+        if (to_complex) {
+            auto kern = fft_r2c_kernel<16, S::NT, false, false, 1>;
+            if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(kern), lds, "fft"))) return rc;
+            hipLaunchKernelGGL(kern, grid, dim3(S::NT), lds, stream, io);
+        } else {
+            auto kern = fft_c2r_kernel<16, S::NT, false, false, 1>;
+            if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(kern), lds, "fft"))) return rc;
+            hipLaunchKernelGGL(kern, grid, dim3(S::NT), lds, stream, io);
+        }
+        DLWP_LAUNCH_CHECK();
+        return DLWP_OK;
+    }
     if (to_complex) {
         if (cf) FFT_DISPATCH(fft_r2c_kernel, COMMA_TRUE, sh, grid, lds, stream, io);
         else FFT_DISPATCH(fft_r2c_kernel, COMMA_FALSE, sh, grid, lds, stream, io);
@@ -656,6 +905,7 @@ int run_h_c2c(const dlwp_fft_plan* p, const float* in, float* out, long long out
               hipStream_t stream, long long plane_in = 0, long long plane_out = 0, int r0 = 0, int r1 = 0, long long Jw = 0,
               int C = 0, int bs = 0) {
     FftIO io{};
+    io.dbg_skip = dlwp_tune_on("FFT_SKIP_PASSES") ? 1 : 0;
     io.ax = p->axH; io.in = in; io.out = out; io.J = J; io.sg = sg; io.scale = scale;
     io.plane_in = plane_in; io.plane_out = plane_out; io.r0 = r0; io.r1 = r1; io.Jw = Jw; io.C = C; io.bs = bs;
     if (plane_out) J = Jw;            // only the window's columns are transformed
@@ -664,6 +914,14 @@ int run_h_c2c(const dlwp_fft_plan* p, const float* in, float* out, long long out
     const LaunchShape sh = shape_of(io.ax);
     DLWP_REQUIRE(sh.outs > 0, DLWP_E_UNSUPPORTED, "fft: axis of length %d needs more than 32 outputs per thread", io.ax.N);
     const size_t lds = axis_lds(io.ax);
+    if (io.ax.sp == 2) {                   // H axis of 90 on its compile-time plan
+        using S = SPlan<2>;
+        auto kern = fft_c2c_kernel<16, S::NT, false, 2>;
+        if (int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(kern), lds, "fft")) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(S::NT), lds, stream, io);
+        DLWP_LAUNCH_CHECK();
+        return DLWP_OK;
+    }
     FFT_DISPATCH(fft_c2c_kernel, NOTHING, sh, grid, lds, stream, io);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
@@ -684,8 +942,8 @@ extern "C" int dlwp_fft_plan_create(int H, int W, dlwp_fft_plan** out) {
     p->H = H; p->W = W; p->tabW = p->tabH = nullptr; p->amatW = p->amatH = nullptr;
     int rc;
     // inner lanes per workgroup: W axis 8 channel PAIRS = 64 bytes of a channels-last row per w, H axis 16 complex = 128 bytes
-    if ((rc = make_axis(p->axW, W, &p->tabW, &p->amatW, dlwp_tune_or("FFT_IBW", 8))) ||
-        (rc = make_axis(p->axH, H, &p->tabH, &p->amatH, dlwp_tune_or("FFT_IBH", 16)))) {
+    if ((rc = make_axis(p->axW, W, &p->tabW, &p->amatW, dlwp_tune_or("FFT_IBW", 8), true)) ||
+        (rc = make_axis(p->axH, H, &p->tabH, &p->amatH, dlwp_tune_or("FFT_IBH", 16), false))) {
         dlwp_fft_plan_destroy(p);
         return rc;
     }

@@ -52,6 +52,9 @@ Knob g_knobs[] = {
     {"WINATTN_BWD2PASS", "1: the two-pass LDS-staged attention backward instead of the one-pass kernel", 0, false},
     {"FFT_IBW", "inner lanes of the W-axis FFT pass", 0, false},
     {"FFT_IBH", "inner lanes of the H-axis FFT pass", 0, false},
+    {"FFT_STATIC", "0: the run-time FFT plan also for the axis lengths that have a compile-time plan (W = 180, H = 90)", 0, false},
+    {"FFT_NT512_FROM", "FFT tiles (signal length x inner lanes) above this size run with 512-thread workgroups (default 4096)", 0, false},
+    {"FFT_SKIP_PASSES", "measurement only (wrong results): the FFT kernels skip their butterfly passes and only move data", 0, false},
     {"DHCONV_PACK", "1: the round-4 spectral-weight pack kernel (one read of the weight per image) instead of the block kernel", 0, false},
     {"DHCONV_APPLY", "1: the round-4 spectral-convolution kernel (one 256-row chunk per workgroup) instead of the pipelined one", 0, false},
     {"DHCONV_RC", "rows per chunk of the pipelined spectral-convolution kernel: 64 or 128 (default 128)", 0, false},

@@ -15,7 +15,10 @@ def rel(a, b):
 
 
 SHAPES = [(2, 64, 64, 8), (1, 128, 256, 16), (1, 32, 64, 6), (2, 30, 36, 4), (1, 103, 180, 4), (1, 45, 50, 2), (1, 721, 1440, 2),
-          (3, 16, 9, 2), (1, 7, 11, 4)]
+          (3, 16, 9, 2), (1, 7, 11, 4),
+          # the FourCastNet token grid 90 x 180 (C5): both axes on their compile-time plans (round 5), channel counts that leave
+          # partial lane groups; each plan next to the run-time plan of the other axis
+          (2, 90, 180, 70), (1, 90, 180, 768), (1, 90, 64, 6), (1, 36, 180, 34)]
 
 
 @pytest.mark.parametrize("B,H,W,C", SHAPES)
