@@ -225,6 +225,11 @@ __device__ __forceinline__ void dft_reg(float2 (&u)[R], float sg) {
 template <int SP> struct SPlan;
 template <> struct SPlan<1> { static constexpr int N = 180, LOGIB = 4, NT = 256, R0 = 12, R1 = 15; };     // 15 x 16 = 240, 12 x 16 = 192 items
 template <> struct SPlan<2> { static constexpr int N = 90, LOGIB = 5, NT = 320, R0 = 9, R1 = 10; };       // 10 x 32 = 320, 9 x 32 = 288 items
+// measured alternatives (DLWP_FFT_SPW / DLWP_FFT_SPH pick a plan by number)
+template <> struct SPlan<3> { static constexpr int N = 180, LOGIB = 4, NT = 256, R0 = 15, R1 = 12; };
+template <> struct SPlan<4> { static constexpr int N = 90, LOGIB = 5, NT = 320, R0 = 10, R1 = 9; };
+template <> struct SPlan<5> { static constexpr int N = 180, LOGIB = 5, NT = 512, R0 = 12, R1 = 15; };
+template <> struct SPlan<6> { static constexpr int N = 90, LOGIB = 4, NT = 192, R0 = 9, R1 = 10; };
 
 // one Stockham pass of radix R, P = product of the earlier radices (pass_small with every plan quantity a constant)
 template <int N, int LOGIB, int NT, int R, int P>
@@ -738,8 +743,10 @@ namespace {
 // FourCastNet token grids 90 x 180 and 103 x 180 (DLWP_FFT_STATIC=0: the run-time plan everywhere)
 int static_plan_for(int N, bool w_axis) {
     if (dlwp_tune_or("FFT_STATIC", 1) == 0) return 0;
-    if (w_axis && N == SPlan<1>::N) return 1;
-    if (!w_axis && N == SPlan<2>::N) return 2;
+    // defaults 3 / 4 (the larger radix first: it is the pass without twiddles): 48.3 / 51.5 us for rfft2 / irfft2 of 90 x 180 x 768
+    // against 50.5 / 53.0 (plans 1 / 2), 51.6 / 56.9 (5 / 2), 49.6 / 55.1 (1 / 6); the run-time plan: 83.5 / 79.2
+    if (w_axis && N == SPlan<1>::N) { const int v = dlwp_tune_or("FFT_SPW", 3); return v == 1 || v == 5 ? v : 3; }
+    if (!w_axis && N == SPlan<2>::N) { const int v = dlwp_tune_or("FFT_SPH", 4); return v == 2 || v == 6 ? v : 4; }
     return 0;
 }
 
@@ -748,8 +755,15 @@ int make_axis(FftAxis& ax, int N, float2** tab_dev, float** amat_dev, int ib_cap
     ax.amat = nullptr;
     ax.rp = 0;
     ax.sp = static_plan_for(N, w_axis);
-    if (ax.sp == 1) ib_cap = 1 << SPlan<1>::LOGIB;
-    if (ax.sp == 2) ib_cap = 1 << SPlan<2>::LOGIB;
+    switch (ax.sp) {
+        case 1: ib_cap = 1 << SPlan<1>::LOGIB; break;
+        case 2: ib_cap = 1 << SPlan<2>::LOGIB; break;
+        case 3: ib_cap = 1 << SPlan<3>::LOGIB; break;
+        case 4: ib_cap = 1 << SPlan<4>::LOGIB; break;
+        case 5: ib_cap = 1 << SPlan<5>::LOGIB; break;
+        case 6: ib_cap = 1 << SPlan<6>::LOGIB; break;
+        default: break;
+    }
     ax.nrad = factorise(N, ax.rad);
     DLWP_REQUIRE(ax.nrad > 0, DLWP_E_UNSUPPORTED, "fft: cannot factorise %d into at most %d radices", N, MAXRAD);
     int p = 1;
@@ -874,19 +888,25 @@ int run_w_real(const dlwp_fft_plan* p, bool to_complex, bool cf, const float* in
     const LaunchShape sh = shape_of(io.ax);
     DLWP_REQUIRE(sh.outs > 0, DLWP_E_UNSUPPORTED, "fft: axis of length %d needs more than 32 outputs per thread", io.ax.N);
     const size_t lds = axis_lds(io.ax);
-    if (io.ax.sp == 1 && !cf) {            // channels-last W axis of 180 on its compile-time plan (OUTS covers N * IB / NT = 11.25)
-        using S = SPlan<1>;
-        static_assert(16 * S::NT >= S::N << S::LOGIB, "the c2r store loop walks OUTS * NT >= N * IB elements");
-        int rc;
-        if (to_complex) {
-            auto kern = fft_r2c_kernel<16, S::NT, false, false, 1>;
-            if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(kern), lds, "fft"))) return rc;
-            hipLaunchKernelGGL(kern, grid, dim3(S::NT), lds, stream, io);
-        } else {
-            auto kern = fft_c2r_kernel<16, S::NT, false, false, 1>;
-            if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(kern), lds, "fft"))) return rc;
-            hipLaunchKernelGGL(kern, grid, dim3(S::NT), lds, stream, io);
+    if (io.ax.sp && !cf) {                 // channels-last W axis of 180 on a compile-time plan (OUTS covers N * IB / NT = 11.25)
+        int rc = DLWP_OK;
+        auto go = [&](auto r2c, auto c2r, int nt) {
+            if (to_complex) {
+                if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(r2c), lds, "fft"))) return;
+                hipLaunchKernelGGL(r2c, grid, dim3(nt), lds, stream, io);
+            } else {
+                if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(c2r), lds, "fft"))) return;
+                hipLaunchKernelGGL(c2r, grid, dim3(nt), lds, stream, io);
+            }
+        };
+        static_assert(16 * SPlan<1>::NT >= SPlan<1>::N << SPlan<1>::LOGIB && 16 * SPlan<5>::NT >= SPlan<5>::N << SPlan<5>::LOGIB,
+                      "the c2r store loop walks OUTS * NT >= N * IB elements");
+        switch (io.ax.sp) {
+            case 3: go(fft_r2c_kernel<16, SPlan<3>::NT, false, false, 3>, fft_c2r_kernel<16, SPlan<3>::NT, false, false, 3>, SPlan<3>::NT); break;
+            case 5: go(fft_r2c_kernel<16, SPlan<5>::NT, false, false, 5>, fft_c2r_kernel<16, SPlan<5>::NT, false, false, 5>, SPlan<5>::NT); break;
+            default: go(fft_r2c_kernel<16, SPlan<1>::NT, false, false, 1>, fft_c2r_kernel<16, SPlan<1>::NT, false, false, 1>, SPlan<1>::NT); break;
         }
+        if (rc) return rc;
         DLWP_LAUNCH_CHECK();
         return DLWP_OK;
     }
@@ -914,11 +934,18 @@ int run_h_c2c(const dlwp_fft_plan* p, const float* in, float* out, long long out
     const LaunchShape sh = shape_of(io.ax);
     DLWP_REQUIRE(sh.outs > 0, DLWP_E_UNSUPPORTED, "fft: axis of length %d needs more than 32 outputs per thread", io.ax.N);
     const size_t lds = axis_lds(io.ax);
-    if (io.ax.sp == 2) {                   // H axis of 90 on its compile-time plan
-        using S = SPlan<2>;
-        auto kern = fft_c2c_kernel<16, S::NT, false, 2>;
-        if (int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(kern), lds, "fft")) return rc;
-        hipLaunchKernelGGL(kern, grid, dim3(S::NT), lds, stream, io);
+    if (io.ax.sp) {                        // H axis of 90 on a compile-time plan
+        int rc = DLWP_OK;
+        auto go = [&](auto kern, int nt) {
+            if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(kern), lds, "fft"))) return;
+            hipLaunchKernelGGL(kern, grid, dim3(nt), lds, stream, io);
+        };
+        switch (io.ax.sp) {
+            case 4: go(fft_c2c_kernel<16, SPlan<4>::NT, false, 4>, SPlan<4>::NT); break;
+            case 6: go(fft_c2c_kernel<16, SPlan<6>::NT, false, 6>, SPlan<6>::NT); break;
+            default: go(fft_c2c_kernel<16, SPlan<2>::NT, false, 2>, SPlan<2>::NT); break;
+        }
+        if (rc) return rc;
         DLWP_LAUNCH_CHECK();
         return DLWP_OK;
     }

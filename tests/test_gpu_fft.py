@@ -110,3 +110,38 @@ def test_planar_window_transforms_match_torch(cuda, B, H, W, C, win, bs):
     (y * Gy.to(cuda)).sum().backward()
     assert rel(y, yr) <= TOL
     assert rel(from_layout(Yd.grad), Yr.grad) <= TOL
+
+
+@pytest.mark.parametrize("spw,sph", [(1, 2), (3, 4), (5, 6), (0, 0)])
+def test_every_compile_time_plan_matches_torch(cuda, spw, sph):
+    """The selectable compile-time plans of the 90 x 180 grid (DLWP_FFT_SPW / DLWP_FFT_SPH; 0 / 0 = DLWP_FFT_STATIC=0, the run-time
+    plan) through the C ABI with a plan made under that tuning: rfft2 and irfft2 against torch.fft, 1e-5 of the max norm."""
+    import ctypes as C
+    from dlwp_benchmark_amd import lib as L
+    lib = L.load()
+    lib.dlwp_set_tuning.argtypes = [C.c_char_p, C.c_int]
+    lib.dlwp_clear_tuning.argtypes = [C.c_char_p]
+    B, H, W, Cc = 2, 90, 180, 44
+    g = torch.Generator().manual_seed(spw * 10 + sph)
+    x = torch.randn(B, H, W, Cc, generator=g)
+    ref = torch.fft.rfft2(x.double(), dim=(1, 2), norm="ortho")
+    knobs = {b"FFT_SPW": spw, b"FFT_SPH": sph} if spw else {b"FFT_STATIC": 0}
+    plan = C.c_void_p()
+    try:
+        for k, v in knobs.items():
+            lib.dlwp_set_tuning(k, v)
+        L.check(lib.dlwp_fft_plan_create(H, W, C.byref(plan)))
+    finally:
+        for k in knobs:
+            lib.dlwp_clear_tuning(k)
+    try:
+        xd = x.to(cuda)
+        X = torch.empty(B, H, W // 2 + 1, Cc, 2, device=cuda)
+        L.check(lib.dlwp_rfft2(plan, L.ptr(xd), L.ptr(X), B, Cc, 0, 1, 0, L.stream()))
+        assert rel(torch.view_as_complex(X), ref) <= TOL
+        y, work = torch.empty_like(xd), torch.empty_like(X)
+        L.check(lib.dlwp_irfft2(plan, L.ptr(X), L.ptr(y), L.ptr(work), B, Cc, 0, 1, 0, L.stream()))
+        assert rel(y, x) <= TOL
+    finally:
+        torch.cuda.synchronize()
+        lib.dlwp_fft_plan_destroy(plan)
