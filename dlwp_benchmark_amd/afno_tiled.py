@@ -173,7 +173,8 @@ class _AfnoFftFilterFn(torch.autograd.Function):
     (reference: AFNO2D.forward, src/dlwpbench/models/fourcastnet/fourcastnet.py:77-126)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, win, lam):
+    def forward(ctx, x, w1, b1, w2, b2, win, lam, residual=None):
+        """residual: the block's outer skip (fourcastnet.py:156-165), added in the same store as the filter's own `+ x`"""
         from . import fft
         B, H, W, C = x.shape
         r0, r1, c1 = win
@@ -182,7 +183,9 @@ class _AfnoFftFilterFn(torch.autograd.Function):
         X = fft._run_r2c_planar(x, win, bs, fft.NORMS["ortho"], 0).view(B * (r1 - r0) * c1, 2 * C)
         O1, wq1, P1 = _bp_layer_forward(X, w1, b1, 2, 0.0)
         O2, wq2, P2 = _bp_layer_forward(O1, w2, b2, 3, lam)
-        y = fft._run_c2r_planar(O2.view(B, r1 - r0, c1, C // bs, 2, bs), H, W, win, bs, fft.NORMS["ortho"], 0, residual=x)
+        res2 = residual.reshape(x.shape).contiguous().float() if residual is not None else None
+        y = fft._run_c2r_planar(O2.view(B, r1 - r0, c1, C // bs, 2, bs), H, W, win, bs, fft.NORMS["ortho"], 0, residual=x, residual2=res2)
+        ctx.has_res = residual is not None
         ctx.save_for_backward(X, wq1, P1, O1, wq2, P2)
         ctx.cfg = (B, H, W, C, win, bs, lam, w1.shape, b1.shape, w2.shape, b2.shape)
         ctx.slots = tuple(_grad_slot(p) for p in (w1, b1, w2, b2))
@@ -200,7 +203,7 @@ class _AfnoFftFilterFn(torch.autograd.Function):
         gP1, gw2, gb2 = _bp_layer_backward(O1, wq2, P2, gO2, 3, lam, w2s, b2s, ctx.slots[2], ctx.slots[3], prev=(2, 0.0, P1))
         gX, gw1, gb1 = _bp_layer_backward(X, wq1, None, gP1, 0, 0.0, w1s, b1s, ctx.slots[0], ctx.slots[1])
         gx = fft._run_c2r_planar(gX.view(B, r1 - r0, c1, C // bs, 2, bs), H, W, win, bs, fft.NORMS["ortho"], 1, residual=gy)
-        return gx, gw1, gb1, gw2, gb2, None, None
+        return gx, gw1, gb1, gw2, gb2, None, None, (gy if ctx.has_res else None)
 
 
 def afno2d_tiled(x, w1, b1, w2, b2, num_blocks, sparsity_threshold=0.01, hard_thresholding_fraction=1.0):
@@ -228,7 +231,7 @@ def afno2d_tiled(x, w1, b1, w2, b2, num_blocks, sparsity_threshold=0.01, hard_th
     return _TableGemm.apply(t2, G4, g4, x)
 
 
-def afno2d_fft(x, w1, b1, w2, b2, num_blocks, sparsity_threshold=0.01, hard_thresholding_fraction=1.0):
+def afno2d_fft(x, w1, b1, w2, b2, num_blocks, sparsity_threshold=0.01, hard_thresholding_fraction=1.0, residual=None):
     """AFNO2D on the LDS-staged rFFT2 / irFFT2 kernels (fft.py, csrc/fft2d.hip) instead of dense DFT GEMMs: linear-ish in the
     grid size, so this is the path of patch-1 grids (dlwpbench fourcastnet.yaml: patch_size [1, 1]; 128 x 256, 721 x 1440).
     x [B, H, W, C] -> AFNO2D(x) including the residual `+ x`; the block-diagonal complex MLP on the kept modes is the same
@@ -246,8 +249,9 @@ def afno2d_fft(x, w1, b1, w2, b2, num_blocks, sparsity_threshold=0.01, hard_thre
     nb, bs = w1.shape[1], w1.shape[2]
     if bs >= 2 and w2.shape[3] == bs:
         # block-planar spectra: one batched GEMM per layer and gradient, the whole filter one autograd node
-        return _AfnoFftFilterFn.apply(x, w1, b1, w2, b2, win, float(sparsity_threshold))
+        return _AfnoFftFilterFn.apply(x, w1, b1, w2, b2, win, float(sparsity_threshold), residual)
     planar = fft.rfft2_planar(x, "ortho", win).view(2, B * R * c1, C)
     o1 = _BlockComplexLinear.apply(planar, w1, b1, 2, 0.0)
     o2 = _BlockComplexLinear.apply(o1, w2, b2, 3, float(sparsity_threshold))
-    return add_tokens(fft.irfft2_planar(o2.view(2, B, R, c1, C), H, W, "ortho", win), x)
+    y = add_tokens(fft.irfft2_planar(o2.view(2, B, R, c1, C), H, W, "ortho", win), x)
+    return y if residual is None else add_tokens(y, residual)

@@ -469,6 +469,7 @@ struct FftIO {
     FftAxis ax;
     const float* in; float* out;
     const float* res;         // channels-last C2R: added to the output (a residual connection around the transform pair), or null
+    const float* res2;        // ... a second field added as well (the block's outer skip, dlwp_irfft2_planar2), or null; needs res
     long long outer;          // number of outer units (grid.y)
     int C, H, W, Wc;          // C: channels (CL) / unused (CF)
     long long nrows;          // CF real passes: B * C * H rows
@@ -577,6 +578,18 @@ __global__ __launch_bounds__(NT) void fft_c2r_kernel(FftIO a) {
         for (int u = 0; u < OUTS; ++u) {
             const int e = threadIdx.x + u * NT, lane = e & (f.IB - 1), w = e >> f.logIB;
             resv[u] = (w < W && lane < nl) ? *reinterpret_cast<const float2*>(rsrc + (long long)w * a.C + 2 * lane) : make_float2(0.f, 0.f);
+        }
+        if (a.res2) {
+            const float* rsrc2 = a.res2 + o * W * a.C + c0;
+#pragma unroll
+            for (int u = 0; u < OUTS; ++u) {
+                const int e = threadIdx.x + u * NT, lane = e & (f.IB - 1), w = e >> f.logIB;
+                if (w < W && lane < nl) {
+                    const float2 r2 = *reinterpret_cast<const float2*>(rsrc2 + (long long)w * a.C + 2 * lane);
+                    resv[u].x += r2.x;
+                    resv[u].y += r2.y;
+                }
+            }
         }
     }
     // merge: Z_k = Y1_k + i Y2_k, Z_{W-k} = conj(Y1_k) + i conj(Y2_k); DC / Nyquist use the real parts only
@@ -868,8 +881,9 @@ LaunchShape shape_of(const FftAxis& ax) {
 #define NOTHING
 
 int run_w_real(const dlwp_fft_plan* p, bool to_complex, bool cf, const float* in, float* out, int B, int C, float scale,
-               float w_int, hipStream_t stream, const float* res = nullptr) {
+               float w_int, hipStream_t stream, const float* res = nullptr, const float* res2 = nullptr) {
     FftIO io{};
+    io.res2 = res2;
     io.dbg_skip = dlwp_tune_on("FFT_SKIP_PASSES") ? 1 : 0;
     io.ax = p->axW; io.in = in; io.out = out; io.res = res; io.C = C; io.H = p->H; io.W = p->W; io.Wc = p->W / 2 + 1;
     io.scale = scale; io.w_int = w_int;
@@ -1047,7 +1061,14 @@ extern "C" int dlwp_rfft2_planar(const dlwp_fft_plan* p, const float* x, float* 
 
 extern "C" int dlwp_irfft2_planar(const dlwp_fft_plan* p, const float* X, float* x, float* work, const float* residual, int B, int C,
                                   int r0, int r1, int c1, int bs, int norm, int adjoint, void* stream_) {
+    return dlwp_irfft2_planar2(p, X, x, work, residual, nullptr, B, C, r0, r1, c1, bs, norm, adjoint, stream_);
+}
+
+extern "C" int dlwp_irfft2_planar2(const dlwp_fft_plan* p, const float* X, float* x, float* work, const float* residual,
+                                   const float* residual2, int B, int C, int r0, int r1, int c1, int bs, int norm, int adjoint,
+                                   void* stream_) {
     DLWP_REQUIRE(p && x && X && work && B > 0 && C > 0 && norm >= 0 && norm <= 2, DLWP_E_INVALID, "irfft2_planar: bad argument");
+    DLWP_REQUIRE(!residual2 || residual, DLWP_E_INVALID, "irfft2_planar2: a second residual needs the first");
     const int Wc = p->W / 2 + 1;
     DLWP_REQUIRE(0 <= r0 && r0 < r1 && r1 <= p->H && c1 >= 1 && c1 <= Wc, DLWP_E_INVALID, "irfft2_planar: window [%d, %d) x %d outside %d x %d",
                  r0, r1, c1, p->H, Wc);
@@ -1058,5 +1079,5 @@ extern "C" int dlwp_irfft2_planar(const dlwp_fft_plan* p, const float* X, float*
     const long long J = (long long)Wc * C, Jw = (long long)c1 * C;
     int rc = run_h_c2c(p, X, work, B, J, +1.f, adjoint ? sHf : sHi, stream, (long long)B * (r1 - r0) * Jw, 0, r0, r1, Jw, C, bs);
     if (rc) return rc;
-    return run_w_real(p, false, false, work, x, B, C, adjoint ? sWf : sWi, adjoint ? 0.5f : 1.f, stream, residual);
+    return run_w_real(p, false, false, work, x, B, C, adjoint ? sWf : sWi, adjoint ? 0.5f : 1.f, stream, residual, residual2);
 }

@@ -105,14 +105,19 @@ def _run_r2c_planar(x, win, bs, norm, adjoint):
     return X
 
 
-def _run_c2r_planar(X, H, W, win, bs, norm, adjoint, residual=None):
+def _run_c2r_planar(X, H, W, win, bs, norm, adjoint, residual=None, residual2=None):
     B = X.shape[0] if bs else X.shape[1]
     Cc = X.shape[3] * bs if bs else X.shape[4]
     r0, r1, c1 = win
     x = torch.empty(B, H, W, Cc, device=X.device)
     work = torch.empty(B, H, W // 2 + 1, Cc, 2, device=X.device)
-    if residual is not None and (tuple(residual.shape) != (B, H, W, Cc) or residual.dtype != torch.float32 or not residual.is_contiguous()):
-        raise L.DlwpError("irfft2_planar: the residual must be a contiguous fp32 field of the output's shape")
+    for r in (residual, residual2):
+        if r is not None and (tuple(r.shape) != (B, H, W, Cc) or r.dtype != torch.float32 or not r.is_contiguous()):
+            raise L.DlwpError("irfft2_planar: a residual must be a contiguous fp32 field of the output's shape")
+    if residual2 is not None:          # both skips of an AFNO block (the filter's own `+ x` and the block's outer one) in the store
+        L.check(L.load().dlwp_irfft2_planar2(_plan(H, W), L.ptr(X), L.ptr(x), L.ptr(work), L.ptr(residual), L.ptr(residual2),
+                                             B, Cc, r0, r1, c1, bs, norm, adjoint, L.stream()))
+        return x
     L.check(L.load().dlwp_irfft2_planar(_plan(H, W), L.ptr(X), L.ptr(x), L.ptr(work), L.ptr(residual) if residual is not None else None,
                                         B, Cc, r0, r1, c1, bs, norm, adjoint, L.stream()))
     return x

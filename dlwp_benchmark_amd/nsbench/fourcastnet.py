@@ -22,6 +22,7 @@ from ..rollout_ops import ns_rollout
 from ..token_ops import LayerNorm, Linear, Mlp, PatchConv2d, WgradBatch, _grad_slot, add_pos_embed, add_tokens, norm_fork
 
 _AFNO_WGRAD_BATCH = __import__("os").environ.get("DLWP_AFNO_WGRAD_BATCH", "0") == "1"
+_AFNO_RES2 = __import__("os").environ.get("DLWP_AFNO_RES2", "1") != "0"
 
 
 FFT_MIN_TOKENS = 262144     # token grids from this size on take the rFFT2 path in "auto" mode (see AFNO2D.forward)
@@ -103,6 +104,11 @@ class AFNO2D(nn.Module):
             path = "fused" if fits else ("fft" if big and C % 2 == 0 else "tiled")
         if path == "fft":
             from ..afno_tiled import afno2d_fft
+            # (the block's outer skip rides the inverse transform's store together with the filter's own `+ x`;
+            # DLWP_AFNO_RES2=0: a separate add, for A/B runs)
+            if _AFNO_RES2:
+                return afno2d_fft(x, self.w1, self.b1, self.w2, self.b2, self.num_blocks, float(self.sparsity_threshold),
+                                  float(self.hard_thresholding_fraction), residual=residual).type(dtype)
             y = afno2d_fft(x, self.w1, self.b1, self.w2, self.b2, self.num_blocks, float(self.sparsity_threshold),
                            float(self.hard_thresholding_fraction))
         elif path == "tiled":

@@ -395,6 +395,11 @@ int dlwp_rfft2_planar(const dlwp_fft_plan* plan, const float* x, float* X, float
 /* (fourcastnet.py:126) in the forward pass, the gradient arriving along that skip in the backward pass.      */
 int dlwp_irfft2_planar(const dlwp_fft_plan* plan, const float* X, float* x, float* work, const float* residual, int B,
                        int C, int r0, int r1, int c1, int bs, int norm, int adjoint, void* stream);
+/* ... with a second field added in the same store (the AFNO block's outer skip around the filter,                 */
+/* fourcastnet.py:156-165 `x = self.filter(x); if self.double_skip: x = x + residual`); residual2 needs residual.   */
+int dlwp_irfft2_planar2(const dlwp_fft_plan* plan, const float* X, float* x, float* work, const float* residual,
+                        const float* residual2, int B, int C, int r0, int r1, int c1, int bs, int norm, int adjoint,
+                        void* stream);
 
 /* General-grid AFNO2D (grids whose block spectrum does not fit LDS): the transforms run as     */
 /* dlwp_gemm_batched against DFT tables and the per-mode block MLP as batched GEMMs over the     */
