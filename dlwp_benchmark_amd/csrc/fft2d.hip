@@ -37,6 +37,7 @@ struct FftAxis {
     const float* amat;
     int rp;
     int sp;                          // compile-time plan (SPlan<sp>) this axis runs on, 0 = the run-time plan
+    int sym;                         // a single odd prime radix <= 127 on pass_prime_sym (amat = its cos / sin matrices)
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
@@ -415,6 +416,81 @@ __device__ __forceinline__ void pass_prime_mfma(float2* buf, const float2* tabs,
     }
 }
 
+// ---- a whole axis of odd prime length N <= 127 as ONE dense pass that uses the symmetries of the DFT matrix (round 5).
+// pass_prime_mfma multiplies by the real image [[Fr, -Fi], [Fi, Fr]] of the full N x N matrix: 4 N^2 real multiply-adds per column.
+// With h = (N - 1) / 2, e[r] = x[r] + x[N - r], o[r] = x[r] - x[N - r] (r = 1 .. h), e[0] = x[0]:
+//     X[q]     = sum_{r <= h} cos(2 pi q r / N) e[r]  +  i sg sum_{r <= h} sin(2 pi q r / N) o[r]  =  C[q] + i sg S[q]
+//     X[N - q] =                                                                                      C[q] - i sg S[q]     (q = 0 .. h)
+// i.e. two REAL (h + 1) x (h + 1) matrices applied to the re and im planes: (h + 1)^2 * 4 multiply-adds per column, a quarter, and
+// the same two matrices serve both directions.  103 (= 721 / 7, the latitude axis of the 721 x 1440 patch grid): the pass went from
+// 56.5 k to [see profiles/r05_experiments.md] cycles per workgroup.
+// Layout: buf [N][IB + 1] complex, IB = 64 lanes, 512 threads = 8 waves; wave w owns lanes 16 (w & 3) .. + 15 (both planes) and the
+// 32 output rows q = 32 (w >> 2) .. + 31; amat = [2][64][64] floats: cos then sin matrix, rows q, columns r, zero beyond h.
+template <int NT>
+__device__ __forceinline__ void pass_prime_sym(float2* buf, const FftAxis& f, float sg) {
+    static_assert(NT == 512, "eight waves: four lane tiles x two row halves");
+    const int N = f.N, h = (N - 1) >> 1, IBP = f.IB + 1, tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6, rl = lane & 15, g = lane >> 4;
+    // fold in place: rows 1 .. h receive e, rows N - r receive o[r]; one thread per (r, lane) pair reads and writes both rows
+    for (int e = tid; e < h << 6; e += NT) {
+        const int ln = e & 63, r = 1 + (e >> 6);
+        const float2 a = buf[r * IBP + ln], b = buf[(N - r) * IBP + ln];
+        buf[r * IBP + ln] = make_float2(a.x + b.x, a.y + b.y);
+        buf[(N - r) * IBP + ln] = make_float2(a.x - b.x, a.y - b.y);
+    }
+    __syncthreads();
+    const int lt = wv & 3, mh = wv >> 2, ln = 16 * lt + rl;
+    const float* Cm = f.amat;
+    const float* Sm = f.amat + 64 * 64;
+    f32x4 acc[2][2][2];                       // [cos | sin][row tile of the half][re | im]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) acc[a][i][pl] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+        f32x4 ac[2], as_[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 16 * (2 * mh + i) + rl;
+            ac[i] = *reinterpret_cast<const f32x4*>(Cm + row * 64 + 16 * kc + 4 * g);
+            as_[i] = *reinterpret_cast<const f32x4*>(Sm + row * 64 + 16 * kc + 4 * g);
+        }
+        f32x4 be[2], bo[2];                   // [re | im] of e[k] and o[k], k = 16 kc + 4 g + q
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 16 * kc + 4 * g + q;
+            // rows beyond h meet zero matrix columns: any finite row will do
+            const float2 ev = buf[min(k, N - 1) * IBP + ln];
+            const float2 ov = buf[(k >= 1 && k <= h ? N - k : 0) * IBP + ln];
+            be[0][q] = ev.x; be[1][q] = ev.y;
+            bo[0][q] = ov.x; bo[1][q] = ov.y;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                acc[0][i][pl] = mfma16_chunk(ac[i], be[pl], acc[0][i][pl]);
+                acc[1][i][pl] = mfma16_chunk(as_[i], bo[pl], acc[1][i][pl]);
+            }
+    }
+    __syncthreads();                          // every wave has read its operands: the tile may be overwritten
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int q = 16 * (2 * mh + i) + 4 * g + jj;
+            if (q <= h) {
+                const float cx = acc[0][i][0][jj], cy = acc[0][i][1][jj], sx = sg * acc[1][i][0][jj], sy = sg * acc[1][i][1][jj];
+                buf[q * IBP + ln] = make_float2(cx - sy, cy + sx);                       // C + i sg S
+                if (q) buf[(N - q) * IBP + ln] = make_float2(cx + sy, cy - sx);          // C - i sg S
+            }
+        }
+    __syncthreads();
+}
+
 // In-place mixed-radix Stockham FFT of buf[N][IB + 1] (complex, LDS); tabs [N] twiddles in LDS; sg = -1 forward, +1 inverse.
 // Radices 2, 3, 4, 5 use register butterflies (pass_small); any other radix (7, 11, ... 103 ...) the generic pass: one output
 // per work item, m = blk * M + q * p + k  <-  sum_r in[(blk * p + k) + r * N / R] * w^(r * (k + q * p)),  w = e^{sg 2 pi i / M}.
@@ -429,6 +505,9 @@ __device__ __forceinline__ void lds_fft(float2* buf, const float2* tabs, const F
         if (R == 3) { pass_small<3, OUTS, NT>(buf, tabs, f, s, p, sg); p = M; DLWP_STAMP(16 + s); continue; }
         if (R == 5) { pass_small<5, OUTS, NT>(buf, tabs, f, s, p, sg); p = M; DLWP_STAMP(16 + s); continue; }
         if constexpr (PRIME) {      // instantiated only for plans with a large last prime: the pass costs 64 accumulator registers
+            if constexpr (NT == 512) {
+                if (f.sym) { pass_prime_sym<NT>(buf, f, sg); p = M; continue; }
+            }
             if (s == f.nrad - 1) { pass_prime_mfma<NT>(buf, tabs, f, s, p, sg); p = M; continue; }
         }
         float2 acc[OUTS];
@@ -703,7 +782,8 @@ __global__ __launch_bounds__(NT) void fft_c2c_kernel(FftIO a) {
     }
     __syncthreads();
     DLWP_STAMP(5);
-    if constexpr (SP != 0) { if (!a.dbg_skip) lds_fft_static<SP>(buf, tabs, a.sg); }
+    if constexpr (SP == -1) { if (!a.dbg_skip) pass_prime_sym<NT>(buf, f, a.sg); }      // the axis is one folded prime pass: a lean kernel
+    else if constexpr (SP != 0) { if (!a.dbg_skip) lds_fft_static<SP>(buf, tabs, a.sg); }
     else if (!a.dbg_skip) lds_fft<OUTS, NT, PRIME>(buf, tabs, f, a.sg);
     DLWP_STAMP(6);
     for (int e = threadIdx.x; e < N << f.logIB; e += NT) {
@@ -808,7 +888,23 @@ int make_axis(FftAxis& ax, int N, float2** tab_dev, float** amat_dev, int ib_cap
     // panels per wave (2 RP <= 16 panels with 512 threads: R <= 128)
     const int R = ax.rad[ax.nrad - 1];
     const int RP = (R + 7) / 8 * 8, nthreads = N * ib > 4096 ? 512 : 256;
-    if (R >= 16 && nthreads == 512 && 2 * RP / 16 <= 2 * (nthreads / 64)) {
+    ax.sym = 0;
+    if (ax.nrad == 1 && R >= 16 && R <= 127 && (R & 1) && ib == 64 && nthreads == 512 && dlwp_tune_or("FFT_PRIME_SYM", 1) != 0) {
+        // the whole axis is one odd prime: the folded form (pass_prime_sym) with its two real (h + 1) x (h + 1) matrices
+        const int h = (R - 1) / 2;
+        std::vector<float> am(2 * 64 * 64, 0.f);
+        for (int q = 0; q <= h; ++q)
+            for (int r = 0; r <= h; ++r) {
+                const double th = 2.0 * PI * (double)(((long long)q * r) % R) / R;
+                am[q * 64 + r] = (float)cos(th);
+                am[64 * 64 + q * 64 + r] = (float)sin(th);
+            }
+        DLWP_HIP(hipMalloc(reinterpret_cast<void**>(amat_dev), am.size() * sizeof(float)));
+        DLWP_HIP(hipMemcpy(*amat_dev, am.data(), am.size() * sizeof(float), hipMemcpyHostToDevice));
+        ax.amat = *amat_dev;
+        ax.rp = RP;
+        ax.sym = 1;
+    } else if (R >= 16 && nthreads == 512 && 2 * RP / 16 <= 2 * (nthreads / 64)) {
         const int K2 = 2 * RP;
         std::vector<float> am(2 * (size_t)K2 * K2, 0.f);
         for (int dir = 0; dir < 2; ++dir) {
@@ -948,6 +1044,14 @@ int run_h_c2c(const dlwp_fft_plan* p, const float* in, float* out, long long out
     const LaunchShape sh = shape_of(io.ax);
     DLWP_REQUIRE(sh.outs > 0, DLWP_E_UNSUPPORTED, "fft: axis of length %d needs more than 32 outputs per thread", io.ax.N);
     const size_t lds = axis_lds(io.ax);
+    if (io.ax.sym) {                       // the axis is one odd prime: the kernel that holds nothing but the folded pass (the general
+                                           // 512-thread kernel with every pass inlined needs 256 VGPRs + scratch: one workgroup per CU)
+        auto kern = fft_c2c_kernel<16, 512, false, -1>;
+        if (int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(kern), lds, "fft")) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, io);
+        DLWP_LAUNCH_CHECK();
+        return DLWP_OK;
+    }
     if (io.ax.sp) {                        // H axis of 90 on a compile-time plan
         int rc = DLWP_OK;
         auto go = [&](auto kern, int nt) {

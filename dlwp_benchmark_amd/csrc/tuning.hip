@@ -55,6 +55,7 @@ Knob g_knobs[] = {
     {"FFT_STATIC", "0: the run-time FFT plan also for the axis lengths that have a compile-time plan (W = 180, H = 90)", 0, false},
     {"FFT_SPW", "compile-time plan of a W axis of 180: 3 (15 x 12, 16 lanes, default), 1 (12 x 15), 5 (12 x 15, 32 lanes, 512 threads)", 0, false},
     {"FFT_SPH", "compile-time plan of an H axis of 90: 4 (10 x 9, 32 lanes, 320 threads, default), 2 (9 x 10), 6 (9 x 10, 16 lanes, 192 threads)", 0, false},
+    {"FFT_PRIME_SYM", "0: an axis that is one odd prime (103) on the full-matrix pass instead of the folded cos / sin form", 0, false},
     {"FFT_NT512_FROM", "FFT tiles (signal length x inner lanes) above this size run with 512-thread workgroups (default 4096)", 0, false},
     {"FFT_SKIP_PASSES", "measurement only (wrong results): the FFT kernels skip their butterfly passes and only move data", 0, false},
     {"DHCONV_PACK", "1: the round-4 spectral-weight pack kernel (one read of the weight per image) instead of the block kernel", 0, false},
