@@ -1726,7 +1726,7 @@ int gemm_launch(const GemmDev& a_in, int vec, int T, hipStream_t s) {
 // fill the chip where the tiles alone would not.
 static int gemm_tile_for(int M, int N, long long nbatch, int K = 0, int dt = 0, bool can_split = false) {
     const int tile_env = dlwp_tune("GEMM_TILE"), forced = tile_env == DLWP_TUNE_UNSET ? 0 : (tile_env == 128 ? 2 : 1);
-    if (M < 128 || N < 128) return 1;
+    if (M < 128 || N < dlwp_tune_or("GEMM_TILE128_MINN", 128)) return 1;      // (knob: 96-wide outputs on the 128 tile, measurement)
     const long long tiles = (long long)ceil_div(M, 128) * ceil_div(N, 128) * nbatch;
     const bool fills = tiles * (can_split ? std::max(1, K / (4 * BK)) : 1) >= 224;
     if (forced) return forced == 2 && fills ? 2 : 1;

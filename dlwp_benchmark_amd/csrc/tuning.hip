@@ -33,6 +33,7 @@ Knob g_knobs[] = {
     {"GEMM_P8_MINK", "least K for the 256 x 256 kernel (default 2048)", 0, false},
     {"GEMM_NOP8_TN", "1: never use the 256 x 256 weight-gradient kernel", 0, false},
     {"GEMM_TILE", "64 or 128: tile edge of the register-staged GEMM (default by shape)", 0, false},
+    {"GEMM_TILE128_MINN", "narrowest output the 128 x 128 GEMM tile is considered for (default 128)", 0, false},
     {"GEMM_XCD_SPLITK", "bit 0 (default on): split-K products of the register-staged GEMM get slice counts that are multiples of 8 and a slice's tiles on one XCD; bit 1 (off: measured -1.7 % on Pangu C4): the same for the LDS-DMA weight-gradient kernel", 0, false},
     {"GEMM_TRACE", "1: print one line per GEMM call (shape census of an eager step)", 0, false},
     {"GEMM_NOGROUP", "1: products parked by dlwp_gemm_group_begin / dlwp_weight_grad_group launch one by one", 0, false},
