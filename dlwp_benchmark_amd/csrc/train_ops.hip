@@ -291,6 +291,36 @@ int dlwp_zero_f32(float* p, long long n, void* stream) {
     return DLWP_OK;
 }
 
+namespace {
+struct AddManyDev { dlwp_add2d_desc d[DLWP_ADD2D_MAX]; };
+// dst[r][c] += src[r * sr + c * sc] for up to DLWP_ADD2D_MAX small matrices in one launch (blockIdx.y = matrix): the hand-over of
+// padded / transposed temporary weight gradients to the parameters' gradient slots (SFNO encoder / decoder / position embedding)
+__global__ __launch_bounds__(256) void add2d_many_kernel(AddManyDev a) {
+    const dlwp_add2d_desc d = a.d[blockIdx.y];
+    const long long n = (long long)d.rows * d.cols;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const long long r = e / d.cols, c = e - r * d.cols;
+        d.dst[r * d.dst_ld + c] += d.src[r * d.src_rs + c * d.src_cs];
+    }
+}
+}  // namespace
+
+extern "C" int dlwp_add2d_many(const dlwp_add2d_desc* descs, int n, void* stream) {
+    DLWP_REQUIRE(descs && n >= 1 && n <= DLWP_ADD2D_MAX, DLWP_E_INVALID, "add2d_many: 1 .. %d matrices", DLWP_ADD2D_MAX);
+    AddManyDev a{};
+    long long most = 0;
+    for (int i = 0; i < n; ++i) {
+        DLWP_REQUIRE(descs[i].dst && descs[i].src && descs[i].rows > 0 && descs[i].cols > 0, DLWP_E_INVALID,
+                     "add2d_many: matrix %d has a NULL pointer or an empty shape", i);
+        a.d[i] = descs[i];
+        most = std::max(most, (long long)descs[i].rows * descs[i].cols);
+    }
+    const dim3 grid((unsigned)std::min<long long>((most + 255) / 256, 1024), (unsigned)n);
+    hipLaunchKernelGGL(add2d_many_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    DLWP_LAUNCH_CHECK();
+    return DLWP_OK;
+}
+
 int dlwp_zero_2d_f32(float* p, long long ld, int rows, int cols, void* stream) {
     const long long n = (long long)rows * cols;
     if (n <= 0) return DLWP_OK;

@@ -141,6 +141,7 @@ SIGNATURES = {
     "dlwp_gelu_bwd": (_I, [_V, _V, _V, _L, _V]),
     "dlwp_colsum": (_I, [_V, _V, _I, _I, _V]),
     "dlwp_colsum_ex": (_I, [_V, _V, _I, _I, _I, _V]),
+    "dlwp_add2d_many": (_I, [_V, _I, _V]),
     "dlwp_scale_rows_add": (_I, [_V, _V, _V, _V, _I, _L, _V]),
     "dlwp_add_bcast": (_I, [_V, _V, _V, _I, _L, _V]),
     "dlwp_cmode_product": (_I, [_V, _V, _V, _I, _I, _I, _I, _V]),

@@ -163,6 +163,12 @@ class _EncodeFn(torch.autograd.Function):
         return tuple(grads)
 
 
+class _Add2dDesc(C.Structure):
+    """dlwp_add2d_desc (include/dlwpmi.h)"""
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("dst_ld", C.c_longlong), ("src_rs", C.c_longlong), ("src_cs", C.c_longlong),
+                ("rows", C.c_int), ("cols", C.c_int)]
+
+
 def _flush_weight_grads(st):
     """One segmented product launch for the encoder's and the decoder's weight gradients over every pending lead time; the
     decoder's parameters receive theirs through their gradient slots or, without slots, through `st["dec_grads"]` (returned by the
@@ -198,8 +204,30 @@ def _flush_weight_grads(st):
             return None
         return grad.reshape(param.shape)
     res["enc_w2"] = outs[0][0]
-    res["enc_w1"] = give(enc1.weight, t_e1[:, :cin])
     res["enc_b1"] = outs[1][1]
+    slots = [_grad_slot(p) for p in (enc1.weight, dec1.weight, dec2.weight)] + ([_grad_slot(net.pos_embed)] if st["gpos_cl"] is not None else [])
+    if has_dec and all(sl is not None for sl in slots) and (dec1.bias is None or outs[2][1] is None):
+        # every parameter has its gradient slot (the engine's flat buffer): the padded / split / channels-last temporaries join their
+        # slots in ONE launch (dlwp_add2d_many) instead of four add_ launches and a cat
+        descs, n = (_Add2dDesc * 8)(), 0
+        def put(dst, dst_ld, src, rs, cs, rows, cols):
+            nonlocal n
+            descs[n] = _Add2dDesc(dst, src, dst_ld, rs, cs, rows, cols)
+            n += 1
+        din = dec1.in_channels
+        put(L.ptr(slots[0]), cin, L.ptr(t_e1), KP, 1, E, cin)
+        put(L.ptr(slots[1]), din, L.ptr(t_da), E, 1, E, E)
+        if din > E:
+            put(L.ptr(slots[1]) + 4 * E, din, L.ptr(t_db), KP, 1, E, din - E)
+        put(L.ptr(slots[2]), E, L.ptr(t_d2), E, 1, cout, E)
+        if st["gpos_cl"] is not None:
+            HWp = net.pos_embed.shape[2] * net.pos_embed.shape[3]
+            put(L.ptr(slots[3]), HWp, L.ptr(st["gpos_cl"]), 1, E, E, HWp)           # [HW][E] -> [E][HW]
+            st["gpos_cl"] = None
+        L.check(L.load().dlwp_add2d_many(C.cast(descs, C.c_void_p), n, L.stream()))
+        res["enc_w1"] = res["pos"] = None
+        return res
+    res["enc_w1"] = give(enc1.weight, t_e1[:, :cin])
     if has_dec:
         gwd = torch.cat([t_da, t_db[:, :dec1.in_channels - E]], dim=1) if dec1.in_channels > E else t_da
         for p, gr in ((dec1.weight, gwd), (dec2.weight, t_d2[:cout])):

@@ -848,6 +848,17 @@ int dlwp_scale_rows_add(const float* t, const float* scale, const float* x, floa
 int dlwp_add_bcast(const float* t, const float* p, float* out, int B, long long n, void* stream);
 /* out[n] += sum_t g[t][n]   (bias gradients)                                                */
 int dlwp_colsum(const float* g, float* out, int T, int N, void* stream);
+/* dst[r][c] += src[r * src_rs + c * src_cs] (dst row pitch dst_ld) for up to DLWP_ADD2D_MAX small matrices in ONE launch: */
+/* padded, concatenated or transposed temporary gradients handed to the parameters' gradient buffers (the encoder's  */
+/* / decoder's 1x1 convolution weights and the position embedding of SFNO2DModule, dlwpbench fno.py:217-259).        */
+#define DLWP_ADD2D_MAX 8
+typedef struct dlwp_add2d_desc {
+    float* dst;
+    const float* src;
+    long long dst_ld, src_rs, src_cs;
+    int rows, cols;
+} dlwp_add2d_desc;
+int dlwp_add2d_many(const dlwp_add2d_desc* descs, int n, void* stream);
 /* the same with overwrite != 0: out[n] = sum_t g[t][n] (the first of several accumulating calls needs no zero fill) */
 int dlwp_colsum_ex(const float* g, float* out, int T, int N, int overwrite, void* stream);
 
