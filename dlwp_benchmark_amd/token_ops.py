@@ -136,7 +136,7 @@ class _LinearFn(torch.autograd.Function):
         w, _ = _wmat(weight, N)             # the bf16 copy under bf16 storage (forward and input-gradient products)
         wbatch = wbatch if (wbatch is not None and WGRAD_BATCH and w.dtype == _BF and ctx.needs_input_grad[1] and not act) else None
         if w.dtype == _BF:
-            x2 = _lowp(x2, N if wbatch is None else LOWP_MIN_DEPTH)               # read by the forward product and by gW = g^T x
+            x2 = _lowp(x2, N if (wbatch is None or not WGRAD_FORCE_CAST) else LOWP_MIN_DEPTH)               # read by the forward product and by gW = g^T x
         lowp_out = bool(out_lowp) and w.dtype == _BF and x2.dtype == _BF and not act and residual is None
         y = torch.empty(T, N, device=x.device, dtype=_BF if lowp_out else torch.float32)
         z = torch.empty(T, N, device=x.device) if act else None
@@ -180,7 +180,7 @@ class _LinearFn(torch.autograd.Function):
                 gres = gz.reshape(gy.shape)
         wb = ctx.wbatch
         if w.dtype == _BF:
-            g2 = _lowp(g2, K if wb is None else LOWP_MIN_DEPTH)                    # read by both products below
+            g2 = _lowp(g2, K if (wb is None or not WGRAD_FORCE_CAST) else LOWP_MIN_DEPTH)                    # read by both products below
         gx = torch.empty(T, K, device=g2.device, dtype=ctx.in_dtype)   # a bf16 input (LayerNorm output) takes a bf16 gradient
         if wb is not None:
             if wb.takes(g2, x2, ctx.wslot, ctx.bslot, ctx.has_bias):       # the weight gradient joins the block's one launch
@@ -309,6 +309,9 @@ def _weight_grad_segments(layers):
 
 # env: A/B runs of the per-block weight-gradient launch (round 5) against one product launch per layer
 WGRAD_BATCH = __import__("os").environ.get("DLWP_WGRAD_BATCH", "1") != "0"
+# env: 0 = a layer whose operands are not bf16 arrays already computes its weight gradient on its own instead of casting them for the
+# block's launch (A/B runs)
+WGRAD_FORCE_CAST = __import__("os").environ.get("DLWP_WGRAD_FORCE_CAST", "1") != "0"
 
 
 class WgradBatch:
@@ -399,7 +402,7 @@ class _MlpFn(torch.autograd.Function):
         if ctx.row_scale is not None:
             g2 = _scaled_grad(g2, ctx.row_scale, h.dtype == _BF)
         elif h.dtype == _BF:
-            g2 = _lowp(g2, Hd if ctx.wbatch is None else LOWP_MIN_DEPTH)                   # read by gh = g W2 and gW2 = g^T h
+            g2 = _lowp(g2, Hd if (ctx.wbatch is None or not WGRAD_FORCE_CAST) else LOWP_MIN_DEPTH)                   # read by gh = g W2 and gW2 = g^T h
         gh = torch.empty(T, Hd, device=g2.device, dtype=h.dtype)
         _gemm_batched(g2, w2m, gh, T, Hd, N, N, Hd, Hd, 0, 0, act=_ACT_B, residual=z)     # (g W2) * GELU'(z), z = the stored derivative
         gx = torch.empty(T, K, device=g2.device, dtype=ctx.in_dtype)   # a bf16 input (LayerNorm output) takes a bf16 gradient
