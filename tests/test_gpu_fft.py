@@ -145,3 +145,19 @@ def test_every_compile_time_plan_matches_torch(cuda, spw, sph):
     finally:
         torch.cuda.synchronize()
         lib.dlwp_fft_plan_destroy(plan)
+
+
+def test_irfft2_planar_with_two_residuals(cuda):
+    """dlwp_irfft2_planar2: both fields ride the inverse transform's store -- equal to the one-residual call plus the second field."""
+    from dlwp_benchmark_amd import fft, lib as L
+    g = torch.Generator().manual_seed(12)
+    B, H, W, Cc, bs = 1, 90, 180, 32, 8
+    win = (0, 90, 46)
+    X = torch.randn(B, 90, 46, Cc // bs, 2, bs, generator=g).to(cuda)
+    r1 = torch.randn(B, H, W, Cc, generator=g).to(cuda)
+    r2 = torch.randn(B, H, W, Cc, generator=g).to(cuda)
+    one = fft._run_c2r_planar(X, H, W, win, bs, fft.NORMS["ortho"], 0, residual=r1)
+    two = fft._run_c2r_planar(X, H, W, win, bs, fft.NORMS["ortho"], 0, residual=r1, residual2=r2)
+    assert rel(two, one + r2) <= 1e-6
+    with pytest.raises(L.DlwpError):
+        fft._run_c2r_planar(X, H, W, win, bs, fft.NORMS["ortho"], 0, residual=None, residual2=r2)

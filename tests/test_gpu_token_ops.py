@@ -286,3 +286,37 @@ def test_weight_gradients_of_three_layers_in_one_launch(cuda):
             assert ((got_b.double() - wb).abs().max() / wb.abs().max()).item() <= 2e-5
         else:
             assert gb is None
+
+
+def test_add2d_many_and_colsum_overwrite(cuda):
+    """dlwp_add2d_many: dst[r][c] += src[r * rs + c * cs] for several matrices in one launch (padded, column-offset and transposed
+    sources); dlwp_colsum_ex(overwrite = 1) writes the column sums where dlwp_colsum adds them.  Exact in fp32 (one add each)."""
+    import ctypes as C
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.sfno_ops import _Add2dDesc
+    lib = L.load()
+    g = torch.Generator().manual_seed(3)
+    E, cin, KP, HW = 24, 10, 32, 35
+    d0 = torch.randn(E, cin, generator=g).to(cuda)
+    s0 = torch.randn(E, KP, generator=g).to(cuda)                  # padded rows: the first cin columns count
+    d1 = torch.randn(E, E + 6, generator=g).to(cuda)               # two sources side by side in one destination
+    s1a, s1b = torch.randn(E, E, generator=g).to(cuda), torch.randn(E, KP, generator=g).to(cuda)
+    d2 = torch.randn(E, HW, generator=g).to(cuda)
+    s2 = torch.randn(HW, E, generator=g).to(cuda)                  # transposed source
+    want = [d0 + s0[:, :cin], torch.cat([d1[:, :E] + s1a, d1[:, E:] + s1b[:, :6]], dim=1), d2 + s2.t()]
+    descs = (_Add2dDesc * 8)()
+    descs[0] = _Add2dDesc(L.ptr(d0), L.ptr(s0), cin, KP, 1, E, cin)
+    descs[1] = _Add2dDesc(L.ptr(d1), L.ptr(s1a), E + 6, E, 1, E, E)
+    descs[2] = _Add2dDesc(L.ptr(d1) + 4 * E, L.ptr(s1b), E + 6, KP, 1, E, 6)
+    descs[3] = _Add2dDesc(L.ptr(d2), L.ptr(s2), HW, 1, E, E, HW)
+    L.check(lib.dlwp_add2d_many(C.cast(descs, C.c_void_p), 4, L.stream()))
+    for got, w in zip((d0, d1, d2), want):
+        assert torch.equal(got, w)
+    assert lib.dlwp_add2d_many(C.cast(descs, C.c_void_p), 9, L.stream()) != 0
+    x = torch.randn(5, 1000, generator=g).to(cuda)
+    out = torch.full((1000,), 7.0, device=cuda)
+    L.check(lib.dlwp_colsum_ex(L.ptr(x), L.ptr(out), 5, 1000, 1, L.stream()))
+    ref = x[0] + x[1] + x[2] + x[3] + x[4]
+    assert torch.allclose(out, ref, atol=1e-6)
+    L.check(lib.dlwp_colsum_ex(L.ptr(x), L.ptr(out), 5, 1000, 0, L.stream()))
+    assert torch.allclose(out, 2 * ref, atol=1e-5)
