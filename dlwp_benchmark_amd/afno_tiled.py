@@ -166,6 +166,10 @@ def _bp_layer_backward(X, wq, P, gO, act, lam, wshape, bshape, wslot, bslot, pre
     return gX, (None if wslot is not None else gw), (None if bslot is not None else gb)
 
 
+# env: A/B runs of the soft-shrink derivative inside the adjoint transform's store (round 5) against a dlwp_act_bwd pass
+_MASKED_R2C = __import__("os").environ.get("DLWP_AFNO_MASKED_R2C", "1") != "0"
+
+
 class _AfnoFftFilterFn(torch.autograd.Function):
     """AFNO2D on the FFT path as ONE autograd node: rfft2 (kept window, block-planar) -> complex block MLP (ReLU, soft-shrink) ->
     irfft2 + x, the skip added in the inverse transform's store; backward mirrors it and adds the gradient that arrived along the
@@ -198,9 +202,14 @@ class _AfnoFftFilterFn(torch.autograd.Function):
         B, H, W, C, win, bs, lam, w1s, b1s, w2s, b2s = ctx.cfg
         r0, r1, c1 = win
         gy = gy.contiguous().float()
-        gO2 = fft._run_r2c_planar(gy, win, bs, fft.NORMS["ortho"], 1).view(X.shape[0], -1)
-        # layer 2's input-gradient GEMM multiplies by ReLU'(P1) in its epilogue: gP1 leaves it directly
-        gP1, gw2, gb2 = _bp_layer_backward(O1, wq2, P2, gO2, 3, lam, w2s, b2s, ctx.slots[2], ctx.slots[3], prev=(2, 0.0, P1))
+        if _MASKED_R2C:
+            # the adjoint transform's store applies softshrink'(P2): gP2 leaves it directly (no activation-backward pass)
+            gP2 = fft._run_r2c_planar(gy, win, bs, fft.NORMS["ortho"], 1, mask=P2, lam=lam).view(X.shape[0], -1)
+            gP1, gw2, gb2 = _bp_layer_backward(O1, wq2, None, gP2, 0, lam, w2s, b2s, ctx.slots[2], ctx.slots[3], prev=(2, 0.0, P1))
+        else:
+            gO2 = fft._run_r2c_planar(gy, win, bs, fft.NORMS["ortho"], 1).view(X.shape[0], -1)
+            # layer 2's input-gradient GEMM multiplies by ReLU'(P1) in its epilogue: gP1 leaves it directly
+            gP1, gw2, gb2 = _bp_layer_backward(O1, wq2, P2, gO2, 3, lam, w2s, b2s, ctx.slots[2], ctx.slots[3], prev=(2, 0.0, P1))
         gX, gw1, gb1 = _bp_layer_backward(X, wq1, None, gP1, 0, 0.0, w1s, b1s, ctx.slots[0], ctx.slots[1])
         gx = fft._run_c2r_planar(gX.view(B, r1 - r0, c1, C // bs, 2, bs), H, W, win, bs, fft.NORMS["ortho"], 1, residual=gy)
         return gx, gw1, gb1, gw2, gb2, None, None, (gy if ctx.has_res else None)

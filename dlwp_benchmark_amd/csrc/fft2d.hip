@@ -563,6 +563,10 @@ struct FftIO {
     long long plane_in, plane_out, Jw;
     int r0, r1, bs;
     int dbg_skip;             // measurement only (DLWP_FFT_SKIP_PASSES=1): the butterfly passes are skipped, the kernels move data only
+    // C2C planar store with a soft-shrink derivative folded in (dlwp_rfft2_planar_masked): the stored component is zeroed where the
+    // same element of `mask_p` (the layer's saved pre-activation, the output's layout) has magnitude <= mask_lam
+    const float* mask_p;
+    float mask_lam;
 };
 
 __device__ __forceinline__ void load_table(float2* tabs, const FftAxis& f) {
@@ -793,8 +797,13 @@ __global__ __launch_bounds__(NT) void fft_c2c_kernel(FftIO a) {
             if (a.plane_out) {
                 if (n >= a.r0 && n < a.r1 && jj < a.Jw) {
                     const long long i = wrow0 + (long long)(n - a.r0) * a.Jw * wmul + wcol;
-                    a.out[i] = a.scale * z.x;
-                    a.out[wim + i] = a.scale * z.y;
+                    float ox = a.scale * z.x, oy = a.scale * z.y;
+                    if (a.mask_p) {
+                        if (!(fabsf(a.mask_p[i]) > a.mask_lam)) ox = 0.f;
+                        if (!(fabsf(a.mask_p[wim + i]) > a.mask_lam)) oy = 0.f;
+                    }
+                    a.out[i] = ox;
+                    a.out[wim + i] = oy;
                 }
             } else {
                 dst[(long long)n * a.J + lane] = make_float2(a.scale * z.x, a.scale * z.y);
@@ -1033,8 +1042,9 @@ int run_w_real(const dlwp_fft_plan* p, bool to_complex, bool cf, const float* in
 
 int run_h_c2c(const dlwp_fft_plan* p, const float* in, float* out, long long outer, long long J, float sg, float scale,
               hipStream_t stream, long long plane_in = 0, long long plane_out = 0, int r0 = 0, int r1 = 0, long long Jw = 0,
-              int C = 0, int bs = 0) {
+              int C = 0, int bs = 0, const float* mask_p = nullptr, float mask_lam = 0.f) {
     FftIO io{};
+    io.mask_p = mask_p; io.mask_lam = mask_lam;
     io.dbg_skip = dlwp_tune_on("FFT_SKIP_PASSES") ? 1 : 0;
     io.ax = p->axH; io.in = in; io.out = out; io.J = J; io.sg = sg; io.scale = scale;
     io.plane_in = plane_in; io.plane_out = plane_out; io.r0 = r0; io.r1 = r1; io.Jw = Jw; io.C = C; io.bs = bs;
@@ -1149,6 +1159,11 @@ extern "C" int dlwp_irfft2(const dlwp_fft_plan* p, const float* X, float* x, flo
 // reached the input along that skip.
 extern "C" int dlwp_rfft2_planar(const dlwp_fft_plan* p, const float* x, float* X, float* work, int B, int C, int r0, int r1, int c1,
                                  int bs, int norm, int adjoint, void* stream_) {
+    return dlwp_rfft2_planar_masked(p, x, X, work, nullptr, 0.f, B, C, r0, r1, c1, bs, norm, adjoint, stream_);
+}
+
+extern "C" int dlwp_rfft2_planar_masked(const dlwp_fft_plan* p, const float* x, float* X, float* work, const float* mask, float lam, int B,
+                                        int C, int r0, int r1, int c1, int bs, int norm, int adjoint, void* stream_) {
     DLWP_REQUIRE(p && x && X && work && B > 0 && C > 0 && norm >= 0 && norm <= 2, DLWP_E_INVALID, "rfft2_planar: bad argument");
     const int Wc = p->W / 2 + 1;
     DLWP_REQUIRE(0 <= r0 && r0 < r1 && r1 <= p->H && c1 >= 1 && c1 <= Wc, DLWP_E_INVALID, "rfft2_planar: window [%d, %d) x %d outside %d x %d",
@@ -1160,7 +1175,7 @@ extern "C" int dlwp_rfft2_planar(const dlwp_fft_plan* p, const float* x, float* 
     int rc = run_w_real(p, true, false, x, work, B, C, adjoint ? sWi : sWf, adjoint ? 2.f : 1.f, stream);
     if (rc) return rc;
     const long long J = (long long)Wc * C, Jw = (long long)c1 * C;
-    return run_h_c2c(p, work, X, B, J, -1.f, adjoint ? sHi : sHf, stream, 0, (long long)B * (r1 - r0) * Jw, r0, r1, Jw, C, bs);
+    return run_h_c2c(p, work, X, B, J, -1.f, adjoint ? sHi : sHf, stream, 0, (long long)B * (r1 - r0) * Jw, r0, r1, Jw, C, bs, mask, lam);
 }
 
 extern "C" int dlwp_irfft2_planar(const dlwp_fft_plan* p, const float* X, float* x, float* work, const float* residual, int B, int C,

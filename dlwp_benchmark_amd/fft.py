@@ -96,11 +96,18 @@ def irfft2(X, W, layout="channels_last", norm="ortho"):
 
 # ---- channels-last transforms with a planar WINDOW of the spectrum, [2 (re | im), B, r1 - r0, c1, C] (csrc/fft2d.hip,
 # dlwp_rfft2_planar): the kept modes in the layout the AFNO mixer's block GEMMs read and write (afno_tiled.afno2d_fft)
-def _run_r2c_planar(x, win, bs, norm, adjoint):
+def _run_r2c_planar(x, win, bs, norm, adjoint, mask=None, lam=0.0):
+    """mask (X's layout, fp32) / lam: components of X are zeroed where |mask| <= lam (a soft-shrink derivative folded into the store)."""
     B, H, W, Cc = x.shape
     r0, r1, c1 = win
     X = torch.empty((B, r1 - r0, c1, Cc // bs, 2, bs) if bs else (2, B, r1 - r0, c1, Cc), device=x.device)
     work = torch.empty(B, H, W // 2 + 1, Cc, 2, device=x.device)
+    if mask is not None:
+        if mask.numel() != X.numel() or mask.dtype != torch.float32 or not mask.is_contiguous():
+            raise L.DlwpError("rfft2_planar: the mask must be a contiguous fp32 tensor of the spectrum window's size")
+        L.check(L.load().dlwp_rfft2_planar_masked(_plan(H, W), L.ptr(x), L.ptr(X), L.ptr(work), L.ptr(mask), float(lam), B, Cc, r0, r1, c1,
+                                                  bs, norm, adjoint, L.stream()))
+        return X
     L.check(L.load().dlwp_rfft2_planar(_plan(H, W), L.ptr(x), L.ptr(X), L.ptr(work), B, Cc, r0, r1, c1, bs, norm, adjoint, L.stream()))
     return X
 

@@ -393,6 +393,12 @@ int dlwp_rfft2_planar(const dlwp_fft_plan* plan, const float* x, float* X, float
                       int c1, int bs, int norm, int adjoint, void* stream);
 /* residual (field-shaped [B][H][W][C], or NULL) is added to irfft2_planar's output: AFNO2D's `x + bias` skip    */
 /* (fourcastnet.py:126) in the forward pass, the gradient arriving along that skip in the backward pass.      */
+/* dlwp_rfft2_planar whose store folds in the derivative of a soft-shrink: a stored component is zeroed where the same   */
+/* element of `mask` (X's layout: the saved pre-activation of AFNO2D's second block layer, fourcastnet.py:117-121          */
+/* F.softshrink) has magnitude <= lam -- the backward transform of the filter then delivers the gradient of that           */
+/* pre-activation directly (no dlwp_act_bwd pass).  mask NULL: dlwp_rfft2_planar.                                          */
+int dlwp_rfft2_planar_masked(const dlwp_fft_plan* plan, const float* x, float* X, float* work, const float* mask, float lam,
+                             int B, int C, int r0, int r1, int c1, int bs, int norm, int adjoint, void* stream);
 int dlwp_irfft2_planar(const dlwp_fft_plan* plan, const float* X, float* x, float* work, const float* residual, int B,
                        int C, int r0, int r1, int c1, int bs, int norm, int adjoint, void* stream);
 /* ... with a second field added in the same store (the AFNO block's outer skip around the filter,                 */

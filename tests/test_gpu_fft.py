@@ -161,3 +161,22 @@ def test_irfft2_planar_with_two_residuals(cuda):
     assert rel(two, one + r2) <= 1e-6
     with pytest.raises(L.DlwpError):
         fft._run_c2r_planar(X, H, W, win, bs, fft.NORMS["ortho"], 0, residual=None, residual2=r2)
+
+
+@pytest.mark.parametrize("bs", [0, 8])
+def test_rfft2_planar_masked_store_is_the_softshrink_derivative(cuda, bs):
+    """dlwp_rfft2_planar_masked (adjoint transform of a gradient field, stored components zeroed where |mask| <= lam) equals the
+    plain adjoint transform followed by dlwp_act_bwd(act = 3): bit for bit (the same transform, then a select)."""
+    from dlwp_benchmark_amd import fft, lib as L
+    g = torch.Generator().manual_seed(21 + bs)
+    B, H, W, Cc = 2, 30, 36, 16
+    win = (3, 27, 12)
+    lam = 0.3
+    gy = torch.randn(B, H, W, Cc, generator=g).to(cuda)
+    plain = fft._run_r2c_planar(gy, win, bs, fft.NORMS["ortho"], 1)
+    P = torch.randn(plain.shape, generator=g).to(cuda)
+    masked = fft._run_r2c_planar(gy, win, bs, fft.NORMS["ortho"], 1, mask=P, lam=lam)
+    want = torch.empty_like(plain)
+    L.check(L.load().dlwp_act_bwd(L.ptr(P), L.ptr(plain), L.ptr(want), plain.numel(), 3, lam, L.stream()))
+    assert torch.equal(masked, want)
+    assert 0.1 < (masked == 0).float().mean().item() < 0.5          # |N(0,1)| <= 0.3 for ~24 % of the elements
