@@ -1596,7 +1596,11 @@ static bool gemm_p8_applies(const GemmDev& a, bool akc, bool bkc) {
     const long long tiles = (long long)ceil_div(a.M, P8T) * ceil_div(a.N, P8T);
     const int mink_env = dlwp_tune("GEMM_P8_MINK");
     const int mink = mink_env != DLWP_TUNE_UNSET ? mink_env : 2048;
-    return env_on || g_gemm_tile256 > 0 || (a.K >= mink && tiles >= 128);
+    // one workgroup per CU: the last round should be at least 80 % full (16200 x 768 x 3072: 192 tiles = 75 % of one round, the
+    // 128 x 128 LDS-DMA kernel is 0.4 % of the C5 step faster; 18540 rows: 219 tiles = 86 %, this kernel 4 % faster -- round 5)
+    const long long rounds = (tiles + 255) / 256;
+    const bool fills = tiles >= 128 && 5 * tiles >= 4 * rounds * 256;
+    return env_on || g_gemm_tile256 > 0 || (a.K >= mink && fills);
 }
 
 // ---- a queue of independent small products (dlwp_gemm_group_begin ... dlwp_gemm_group_end): while it is open, every product
