@@ -19,7 +19,7 @@ import torch
 
 from . import lib as L
 from .sht import _TableGemm
-from .token_ops import _gemm_batched, _grad_slot
+from .token_ops import _act_dtype, _gemm_batched, _grad_slot
 
 _TABLES = {}
 
@@ -125,8 +125,8 @@ def _bp_layer_forward(X, w, b, act, lam):
     wq = torch.empty(nb, 2 * bsi, 2 * bso, device=X.device)
     bq = torch.empty(2 * Co, device=X.device)
     L.check(lib.dlwp_afno_wq_expand_bp(L.ptr(w.contiguous()), L.ptr(b.contiguous()), L.ptr(wq), L.ptr(bq), nb, bsi, bso, L.stream()))
-    O = torch.empty(T, 2 * Co, device=X.device)
-    P = torch.empty(T, 2 * Co, device=X.device) if act else None
+    O = torch.empty(T, 2 * Co, device=X.device, dtype=X.dtype)          # (bf16 spectra under bf16 storage: same type throughout)
+    P = torch.empty(T, 2 * Co, device=X.device, dtype=X.dtype) if act else None
     _gemm_batched(X, wq, O, T, 2 * bso, 2 * bsi, 2 * C, 2 * bso, 2 * Co, 0, 0, nb, 1, (2 * bsi, 0), (4 * bsi * bso, 0), (2 * bso, 0),
                   bias=bq, sBi=(2 * bso, 0), act=act, act_param=lam, preact=P)
     return O, wq, P
@@ -143,6 +143,8 @@ def _bp_layer_backward(X, wq, P, gO, act, lam, wshape, bshape, wslot, bslot, pre
     _, nb, bsi, bso = wshape
     C, Co = nb * bsi, nb * bso
     if act:
+        if gO.dtype != torch.float32:
+            raise L.DlwpError("afno block layer backward: the separate activation pass takes fp32 spectra (bf16 spectra use the masked store)")
         gP = torch.empty_like(gO)
         L.check(lib.dlwp_act_bwd(L.ptr(P), L.ptr(gO), L.ptr(gP), gO.numel(), act, lam, L.stream()))
     else:
@@ -159,7 +161,10 @@ def _bp_layer_backward(X, wq, P, gO, act, lam, wshape, bshape, wslot, bslot, pre
     # gwq[blk] = X[:, blk]^T . gP[:, blk]   (K = tokens: split along K inside the kernel)
     _gemm_batched(X, gP, gq, 2 * bsi, 2 * bso, T, 2 * C, 2 * Co, 2 * bso, 1, 0, nb, 1, (2 * bsi, 0), (2 * bso, 0), (4 * bsi * bso, 0),
                   accumulate=1)
-    L.check(lib.dlwp_colsum(L.ptr(gP), L.ptr(gq) + 4 * nq, T, 2 * Co, L.stream()))
+    if gP.dtype == torch.bfloat16:
+        L.check(lib.dlwp_colsum_bf16(L.ptr(gP), L.ptr(gq) + 4 * nq, T, 2 * Co, L.stream()))
+    else:
+        L.check(lib.dlwp_colsum(L.ptr(gP), L.ptr(gq) + 4 * nq, T, 2 * Co, L.stream()))
     gw = wslot if wslot is not None else torch.zeros(wshape, device=X.device)
     gb = bslot if bslot is not None else torch.zeros(bshape, device=X.device)
     L.check(lib.dlwp_afno_wq_fold_bp(L.ptr(gq), L.ptr(gq) + 4 * nq, L.ptr(gw), L.ptr(gb), nb, bsi, bso, L.stream()))
@@ -168,6 +173,8 @@ def _bp_layer_backward(X, wq, P, gO, act, lam, wshape, bshape, wslot, bslot, pre
 
 # env: A/B runs of the soft-shrink derivative inside the adjoint transform's store (round 5) against a dlwp_act_bwd pass
 _MASKED_R2C = __import__("os").environ.get("DLWP_AFNO_MASKED_R2C", "1") != "0"
+# env: A/B runs of bf16 spectra under bf16 storage (round 5) against fp32 spectra
+_SPECTRA_BF16 = __import__("os").environ.get("DLWP_AFNO_SPECTRA_BF16", "1") != "0"
 
 
 class _AfnoFftFilterFn(torch.autograd.Function):
@@ -184,7 +191,10 @@ class _AfnoFftFilterFn(torch.autograd.Function):
         r0, r1, c1 = win
         bs = w1.shape[2]
         x = x.contiguous().float()
-        X = fft._run_r2c_planar(x, win, bs, fft.NORMS["ortho"], 0).view(B * (r1 - r0) * c1, 2 * C)
+        # bf16 storage (lib.set_storage under a train step): the spectrum window and every operand of the block MLP are bf16 arrays
+        # -- the reference's einsums run under bf16 autocast (fourcastnet.py:100-121); transforms, accumulation and epilogues stay fp32
+        lowp = _SPECTRA_BF16 and _act_dtype() == torch.bfloat16 and _MASKED_R2C
+        X = fft._run_r2c_planar(x, win, bs, fft.NORMS["ortho"], 0, out_bf16=lowp).view(B * (r1 - r0) * c1, 2 * C)
         O1, wq1, P1 = _bp_layer_forward(X, w1, b1, 2, 0.0)
         O2, wq2, P2 = _bp_layer_forward(O1, w2, b2, 3, lam)
         res2 = residual.reshape(x.shape).contiguous().float() if residual is not None else None
@@ -204,7 +214,8 @@ class _AfnoFftFilterFn(torch.autograd.Function):
         gy = gy.contiguous().float()
         if _MASKED_R2C:
             # the adjoint transform's store applies softshrink'(P2): gP2 leaves it directly (no activation-backward pass)
-            gP2 = fft._run_r2c_planar(gy, win, bs, fft.NORMS["ortho"], 1, mask=P2, lam=lam).view(X.shape[0], -1)
+            gP2 = fft._run_r2c_planar(gy, win, bs, fft.NORMS["ortho"], 1, mask=P2, lam=lam,
+                                      out_bf16=P2.dtype == torch.bfloat16).view(X.shape[0], -1)
             gP1, gw2, gb2 = _bp_layer_backward(O1, wq2, None, gP2, 0, lam, w2s, b2s, ctx.slots[2], ctx.slots[3], prev=(2, 0.0, P1))
         else:
             gO2 = fft._run_r2c_planar(gy, win, bs, fft.NORMS["ortho"], 1).view(X.shape[0], -1)

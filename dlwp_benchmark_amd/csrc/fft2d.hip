@@ -567,6 +567,7 @@ struct FftIO {
     // same element of `mask_p` (the layer's saved pre-activation, the output's layout) has magnitude <= mask_lam
     const float* mask_p;
     float mask_lam;
+    int plane_bf16;           // the planar side of a C2C pass (window read or written, and mask_p) is a bf16 array (dlwp_*_planar_ex)
 };
 
 __device__ __forceinline__ void load_table(float2* tabs, const FftAxis& f) {
@@ -776,7 +777,12 @@ __global__ __launch_bounds__(NT) void fft_c2c_kernel(FftIO a) {
             if (a.plane_in) {
                 if (n >= a.r0 && n < a.r1 && jj < a.Jw) {
                     const long long i = wrow0 + (long long)(n - a.r0) * a.Jw * wmul + wcol;
-                    z = make_float2(a.in[i], a.in[wim + i]);
+                    if (a.plane_bf16) {
+                        const __bf16* hin = reinterpret_cast<const __bf16*>(a.in);
+                        z = make_float2((float)hin[i], (float)hin[wim + i]);
+                    } else {
+                        z = make_float2(a.in[i], a.in[wim + i]);
+                    }
                 }
             } else {
                 z = src[(long long)n * a.J + lane];
@@ -798,12 +804,23 @@ __global__ __launch_bounds__(NT) void fft_c2c_kernel(FftIO a) {
                 if (n >= a.r0 && n < a.r1 && jj < a.Jw) {
                     const long long i = wrow0 + (long long)(n - a.r0) * a.Jw * wmul + wcol;
                     float ox = a.scale * z.x, oy = a.scale * z.y;
-                    if (a.mask_p) {
-                        if (!(fabsf(a.mask_p[i]) > a.mask_lam)) ox = 0.f;
-                        if (!(fabsf(a.mask_p[wim + i]) > a.mask_lam)) oy = 0.f;
+                    if (a.plane_bf16) {
+                        if (a.mask_p) {
+                            const __bf16* hm = reinterpret_cast<const __bf16*>(a.mask_p);
+                            if (!(fabsf((float)hm[i]) > a.mask_lam)) ox = 0.f;
+                            if (!(fabsf((float)hm[wim + i]) > a.mask_lam)) oy = 0.f;
+                        }
+                        __bf16* ho = reinterpret_cast<__bf16*>(a.out);
+                        ho[i] = (__bf16)ox;
+                        ho[wim + i] = (__bf16)oy;
+                    } else {
+                        if (a.mask_p) {
+                            if (!(fabsf(a.mask_p[i]) > a.mask_lam)) ox = 0.f;
+                            if (!(fabsf(a.mask_p[wim + i]) > a.mask_lam)) oy = 0.f;
+                        }
+                        a.out[i] = ox;
+                        a.out[wim + i] = oy;
                     }
-                    a.out[i] = ox;
-                    a.out[wim + i] = oy;
                 }
             } else {
                 dst[(long long)n * a.J + lane] = make_float2(a.scale * z.x, a.scale * z.y);
@@ -1042,9 +1059,9 @@ int run_w_real(const dlwp_fft_plan* p, bool to_complex, bool cf, const float* in
 
 int run_h_c2c(const dlwp_fft_plan* p, const float* in, float* out, long long outer, long long J, float sg, float scale,
               hipStream_t stream, long long plane_in = 0, long long plane_out = 0, int r0 = 0, int r1 = 0, long long Jw = 0,
-              int C = 0, int bs = 0, const float* mask_p = nullptr, float mask_lam = 0.f) {
+              int C = 0, int bs = 0, const float* mask_p = nullptr, float mask_lam = 0.f, int plane_bf16 = 0) {
     FftIO io{};
-    io.mask_p = mask_p; io.mask_lam = mask_lam;
+    io.mask_p = mask_p; io.mask_lam = mask_lam; io.plane_bf16 = plane_bf16;
     io.dbg_skip = dlwp_tune_on("FFT_SKIP_PASSES") ? 1 : 0;
     io.ax = p->axH; io.in = in; io.out = out; io.J = J; io.sg = sg; io.scale = scale;
     io.plane_in = plane_in; io.plane_out = plane_out; io.r0 = r0; io.r1 = r1; io.Jw = Jw; io.C = C; io.bs = bs;
@@ -1164,6 +1181,14 @@ extern "C" int dlwp_rfft2_planar(const dlwp_fft_plan* p, const float* x, float* 
 
 extern "C" int dlwp_rfft2_planar_masked(const dlwp_fft_plan* p, const float* x, float* X, float* work, const float* mask, float lam, int B,
                                         int C, int r0, int r1, int c1, int bs, int norm, int adjoint, void* stream_) {
+    return dlwp_rfft2_planar_ex(p, x, X, work, mask, lam, B, C, r0, r1, c1, bs, norm, adjoint, 0, stream_);
+}
+
+extern "C" int dlwp_rfft2_planar_ex(const dlwp_fft_plan* p, const float* x, void* X_, float* work, const void* mask_, float lam, int B,
+                                    int C, int r0, int r1, int c1, int bs, int norm, int adjoint, int flags, void* stream_) {
+    float* X = static_cast<float*>(X_);
+    const float* mask = static_cast<const float*>(mask_);
+    DLWP_REQUIRE(flags == 0 || flags == 1, DLWP_E_INVALID, "rfft2_planar_ex: flags is 0 or 1 (the window X and the mask are bf16 arrays)");
     DLWP_REQUIRE(p && x && X && work && B > 0 && C > 0 && norm >= 0 && norm <= 2, DLWP_E_INVALID, "rfft2_planar: bad argument");
     const int Wc = p->W / 2 + 1;
     DLWP_REQUIRE(0 <= r0 && r0 < r1 && r1 <= p->H && c1 >= 1 && c1 <= Wc, DLWP_E_INVALID, "rfft2_planar: window [%d, %d) x %d outside %d x %d",
@@ -1175,7 +1200,7 @@ extern "C" int dlwp_rfft2_planar_masked(const dlwp_fft_plan* p, const float* x, 
     int rc = run_w_real(p, true, false, x, work, B, C, adjoint ? sWi : sWf, adjoint ? 2.f : 1.f, stream);
     if (rc) return rc;
     const long long J = (long long)Wc * C, Jw = (long long)c1 * C;
-    return run_h_c2c(p, work, X, B, J, -1.f, adjoint ? sHi : sHf, stream, 0, (long long)B * (r1 - r0) * Jw, r0, r1, Jw, C, bs, mask, lam);
+    return run_h_c2c(p, work, X, B, J, -1.f, adjoint ? sHi : sHf, stream, 0, (long long)B * (r1 - r0) * Jw, r0, r1, Jw, C, bs, mask, lam, flags);
 }
 
 extern "C" int dlwp_irfft2_planar(const dlwp_fft_plan* p, const float* X, float* x, float* work, const float* residual, int B, int C,
@@ -1186,6 +1211,14 @@ extern "C" int dlwp_irfft2_planar(const dlwp_fft_plan* p, const float* X, float*
 extern "C" int dlwp_irfft2_planar2(const dlwp_fft_plan* p, const float* X, float* x, float* work, const float* residual,
                                    const float* residual2, int B, int C, int r0, int r1, int c1, int bs, int norm, int adjoint,
                                    void* stream_) {
+    return dlwp_irfft2_planar_ex(p, X, x, work, residual, residual2, B, C, r0, r1, c1, bs, norm, adjoint, 0, stream_);
+}
+
+extern "C" int dlwp_irfft2_planar_ex(const dlwp_fft_plan* p, const void* X_, float* x, float* work, const float* residual,
+                                     const float* residual2, int B, int C, int r0, int r1, int c1, int bs, int norm, int adjoint,
+                                     int flags, void* stream_) {
+    const float* X = static_cast<const float*>(X_);
+    DLWP_REQUIRE(flags == 0 || flags == 1, DLWP_E_INVALID, "irfft2_planar_ex: flags is 0 or 1 (the window X is a bf16 array)");
     DLWP_REQUIRE(p && x && X && work && B > 0 && C > 0 && norm >= 0 && norm <= 2, DLWP_E_INVALID, "irfft2_planar: bad argument");
     DLWP_REQUIRE(!residual2 || residual, DLWP_E_INVALID, "irfft2_planar2: a second residual needs the first");
     const int Wc = p->W / 2 + 1;
@@ -1196,7 +1229,8 @@ extern "C" int dlwp_irfft2_planar2(const dlwp_fft_plan* p, const float* X, float
     float sWf, sHf, sWi, sHi;
     norm_scales(norm, p->H, p->W, sWf, sHf, sWi, sHi);
     const long long J = (long long)Wc * C, Jw = (long long)c1 * C;
-    int rc = run_h_c2c(p, X, work, B, J, +1.f, adjoint ? sHf : sHi, stream, (long long)B * (r1 - r0) * Jw, 0, r0, r1, Jw, C, bs);
+    int rc = run_h_c2c(p, X, work, B, J, +1.f, adjoint ? sHf : sHi, stream, (long long)B * (r1 - r0) * Jw, 0, r0, r1, Jw, C, bs, nullptr, 0.f,
+                       flags);
     if (rc) return rc;
     return run_w_real(p, false, false, work, x, B, C, adjoint ? sWf : sWi, adjoint ? 0.5f : 1.f, stream, residual, residual2);
 }

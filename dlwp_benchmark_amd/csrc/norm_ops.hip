@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const float* __
 // Flat matrices (T <= 16: the batch sum behind a position embedding's gradient, N = tokens x channels in the millions): one
 // thread per four columns, no atomics at all (nothing else writes `out` in that launch).
 template <int VEC>
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, float* out, int T, int N, int rows_per_block) {
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, float* out, int T, int N, int rows_per_block, int g_bf16 = 0) {
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int n0 = (blockIdx.x * 64 + lane) * VEC;
     const int row0 = blockIdx.y * rows_per_block, row1 = min(T, row0 + rows_per_block);
@@ -440,8 +440,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int rr = r + 4 * u;
-                const float* p = g + (long long)(rr < row1 ? rr : r) * N + n0;
-                if (VEC == 4) {
+                const long long po = (long long)(rr < row1 ? rr : r) * N + n0;
+                const float* p = g + po;
+                if (g_bf16) {
+                    const __bf16* hp = reinterpret_cast<const __bf16*>(g) + po;
+                    if (VEC == 4) {
+                        const bf16x4 t = *reinterpret_cast<const bf16x4*>(hp);
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) v[u][k] = (float)t[k];
+                    } else {
+                        v[u][0] = (float)*hp;
+                    }
+                } else if (VEC == 4) {
                     const f32x4 t = *reinterpret_cast<const f32x4*>(p);
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) v[u][k] = t[k];
@@ -666,15 +676,19 @@ extern "C" int dlwp_act_bwd(const float* z, const float* gy, float* gz, long lon
     return DLWP_OK;
 }
 
-static int colsum_impl(const float* g, float* out, int T, int N, int overwrite, void* stream);
+static int colsum_impl(const float* g, float* out, int T, int N, int overwrite, void* stream, int g_bf16 = 0);
 extern "C" int dlwp_colsum(const float* g, float* out, int T, int N, void* stream) { return colsum_impl(g, out, T, N, 0, stream); }
 extern "C" int dlwp_colsum_ex(const float* g, float* out, int T, int N, int overwrite, void* stream) {
     return colsum_impl(g, out, T, N, overwrite ? 1 : 0, stream);
 }
+extern "C" int dlwp_colsum_bf16(const void* g, float* out, int T, int N, void* stream) {
+    DLWP_REQUIRE(T > 16, DLWP_E_UNSUPPORTED, "colsum_bf16: the tall form only (T > 16 rows)");
+    return colsum_impl(static_cast<const float*>(g), out, T, N, 0, stream, 1);
+}
 
-static int colsum_impl(const float* g, float* out, int T, int N, int overwrite, void* stream) {
+static int colsum_impl(const float* g, float* out, int T, int N, int overwrite, void* stream, int g_bf16) {
     DLWP_REQUIRE(g && out && T > 0 && N > 0, DLWP_E_INVALID, "colsum: bad argument");
-    const bool vec = N % 4 == 0 && (uintptr_t)g % 16 == 0 && (uintptr_t)out % 16 == 0;
+    const bool vec = N % 4 == 0 && (uintptr_t)g % (g_bf16 ? 8 : 16) == 0 && (uintptr_t)out % 16 == 0;
     if (T <= 16) {
         const long long units = vec ? N / 4 : N;
         const int grid = (int)std::min<long long>((units + 255) / 256, 4096);
@@ -690,8 +704,8 @@ static int colsum_impl(const float* g, float* out, int T, int N, int overwrite, 
         int slabs = std::max(1, std::min(ceil_div(T, 64), ceil_div(2048, cols)));
         const int rpb = ceil_div(T, slabs);
         slabs = ceil_div(T, rpb);
-        if (vec) hipLaunchKernelGGL(colsum_kernel<4>, dim3(cols, slabs), dim3(256), 0, (hipStream_t)stream, g, out, T, N, rpb);
-        else hipLaunchKernelGGL(colsum_kernel<1>, dim3(cols, slabs), dim3(256), 0, (hipStream_t)stream, g, out, T, N, rpb);
+        if (vec) hipLaunchKernelGGL(colsum_kernel<4>, dim3(cols, slabs), dim3(256), 0, (hipStream_t)stream, g, out, T, N, rpb, g_bf16);
+        else hipLaunchKernelGGL(colsum_kernel<1>, dim3(cols, slabs), dim3(256), 0, (hipStream_t)stream, g, out, T, N, rpb, g_bf16);
     }
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;

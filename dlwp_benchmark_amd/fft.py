@@ -96,17 +96,19 @@ def irfft2(X, W, layout="channels_last", norm="ortho"):
 
 # ---- channels-last transforms with a planar WINDOW of the spectrum, [2 (re | im), B, r1 - r0, c1, C] (csrc/fft2d.hip,
 # dlwp_rfft2_planar): the kept modes in the layout the AFNO mixer's block GEMMs read and write (afno_tiled.afno2d_fft)
-def _run_r2c_planar(x, win, bs, norm, adjoint, mask=None, lam=0.0):
-    """mask (X's layout, fp32) / lam: components of X are zeroed where |mask| <= lam (a soft-shrink derivative folded into the store)."""
+def _run_r2c_planar(x, win, bs, norm, adjoint, mask=None, lam=0.0, out_bf16=False):
+    """mask (X's layout and dtype) / lam: components of X are zeroed where |mask| <= lam (a soft-shrink derivative folded into the
+    store).  out_bf16: the window is written as a bf16 array (bf16 storage of the AFNO block MLP's operands)."""
     B, H, W, Cc = x.shape
     r0, r1, c1 = win
-    X = torch.empty((B, r1 - r0, c1, Cc // bs, 2, bs) if bs else (2, B, r1 - r0, c1, Cc), device=x.device)
+    dt = torch.bfloat16 if out_bf16 else torch.float32
+    X = torch.empty((B, r1 - r0, c1, Cc // bs, 2, bs) if bs else (2, B, r1 - r0, c1, Cc), device=x.device, dtype=dt)
     work = torch.empty(B, H, W // 2 + 1, Cc, 2, device=x.device)
-    if mask is not None:
-        if mask.numel() != X.numel() or mask.dtype != torch.float32 or not mask.is_contiguous():
-            raise L.DlwpError("rfft2_planar: the mask must be a contiguous fp32 tensor of the spectrum window's size")
-        L.check(L.load().dlwp_rfft2_planar_masked(_plan(H, W), L.ptr(x), L.ptr(X), L.ptr(work), L.ptr(mask), float(lam), B, Cc, r0, r1, c1,
-                                                  bs, norm, adjoint, L.stream()))
+    if mask is not None and (mask.numel() != X.numel() or mask.dtype != dt or not mask.is_contiguous()):
+        raise L.DlwpError("rfft2_planar: the mask must be a contiguous tensor of the spectrum window's size and storage type")
+    if mask is not None or out_bf16:
+        L.check(L.load().dlwp_rfft2_planar_ex(_plan(H, W), L.ptr(x), L.ptr(X), L.ptr(work), L.ptr(mask) if mask is not None else None,
+                                              float(lam), B, Cc, r0, r1, c1, bs, norm, adjoint, int(out_bf16), L.stream()))
         return X
     L.check(L.load().dlwp_rfft2_planar(_plan(H, W), L.ptr(x), L.ptr(X), L.ptr(work), B, Cc, r0, r1, c1, bs, norm, adjoint, L.stream()))
     return X
@@ -121,9 +123,13 @@ def _run_c2r_planar(X, H, W, win, bs, norm, adjoint, residual=None, residual2=No
     for r in (residual, residual2):
         if r is not None and (tuple(r.shape) != (B, H, W, Cc) or r.dtype != torch.float32 or not r.is_contiguous()):
             raise L.DlwpError("irfft2_planar: a residual must be a contiguous fp32 field of the output's shape")
-    if residual2 is not None:          # both skips of an AFNO block (the filter's own `+ x` and the block's outer one) in the store
-        L.check(L.load().dlwp_irfft2_planar2(_plan(H, W), L.ptr(X), L.ptr(x), L.ptr(work), L.ptr(residual), L.ptr(residual2),
-                                             B, Cc, r0, r1, c1, bs, norm, adjoint, L.stream()))
+    if X.dtype == torch.bfloat16 or residual2 is not None:
+        # (a bf16 spectrum window; both skips of an AFNO block -- the filter's own `+ x` and the block's outer one -- in the store)
+        if residual2 is not None and residual is None:
+            raise L.DlwpError("irfft2_planar: a second residual needs the first")
+        L.check(L.load().dlwp_irfft2_planar_ex(_plan(H, W), L.ptr(X), L.ptr(x), L.ptr(work), L.ptr(residual) if residual is not None else None,
+                                               L.ptr(residual2) if residual2 is not None else None, B, Cc, r0, r1, c1, bs, norm, adjoint,
+                                               int(X.dtype == torch.bfloat16), L.stream()))
         return x
     L.check(L.load().dlwp_irfft2_planar(_plan(H, W), L.ptr(X), L.ptr(x), L.ptr(work), L.ptr(residual) if residual is not None else None,
                                         B, Cc, r0, r1, c1, bs, norm, adjoint, L.stream()))

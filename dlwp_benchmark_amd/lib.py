@@ -167,6 +167,9 @@ SIGNATURES = {
     "dlwp_irfft2": (_I, [_V, _V, _V, _V, _I, _I, _I, _I, _I, _V]),
     "dlwp_rfft2_planar": (_I, [_V, _V, _V, _V] + [_I] * 8 + [_V]),
     "dlwp_rfft2_planar_masked": (_I, [_V, _V, _V, _V, _V, _F] + [_I] * 8 + [_V]),
+    "dlwp_rfft2_planar_ex": (_I, [_V, _V, _V, _V, _V, _F] + [_I] * 9 + [_V]),
+    "dlwp_irfft2_planar_ex": (_I, [_V, _V, _V, _V, _V, _V] + [_I] * 9 + [_V]),
+    "dlwp_colsum_bf16": (_I, [_V, _V, _I, _I, _V]),
     "dlwp_irfft2_planar": (_I, [_V, _V, _V, _V, _V] + [_I] * 8 + [_V]),
     "dlwp_irfft2_planar2": (_I, [_V, _V, _V, _V, _V, _V] + [_I] * 8 + [_V]),
     "dlwp_afno_wq_expand_bp": (_I, [_V, _V, _V, _V, _I, _I, _I, _V]),

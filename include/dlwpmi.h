@@ -399,6 +399,15 @@ int dlwp_rfft2_planar(const dlwp_fft_plan* plan, const float* x, float* X, float
 /* pre-activation directly (no dlwp_act_bwd pass).  mask NULL: dlwp_rfft2_planar.                                          */
 int dlwp_rfft2_planar_masked(const dlwp_fft_plan* plan, const float* x, float* X, float* work, const float* mask, float lam,
                              int B, int C, int r0, int r1, int c1, int bs, int norm, int adjoint, void* stream);
+/* The planar pair with the spectrum window as a bf16 array (flags = 1; bf16 storage of the AFNO block MLP's operands:  */
+/* the reference's einsums run under bf16 autocast, fourcastnet.py:100-121): dlwp_rfft2_planar_ex writes X (and reads    */
+/* the mask) as bf16, dlwp_irfft2_planar_ex reads X as bf16; fields, work and residuals stay fp32.  flags = 0: the      */
+/* entries above.                                                                                                        */
+int dlwp_rfft2_planar_ex(const dlwp_fft_plan* plan, const float* x, void* X, float* work, const void* mask, float lam, int B,
+                         int C, int r0, int r1, int c1, int bs, int norm, int adjoint, int flags, void* stream);
+int dlwp_irfft2_planar_ex(const dlwp_fft_plan* plan, const void* X, float* x, float* work, const float* residual,
+                          const float* residual2, int B, int C, int r0, int r1, int c1, int bs, int norm, int adjoint,
+                          int flags, void* stream);
 int dlwp_irfft2_planar(const dlwp_fft_plan* plan, const float* X, float* x, float* work, const float* residual, int B,
                        int C, int r0, int r1, int c1, int bs, int norm, int adjoint, void* stream);
 /* ... with a second field added in the same store (the AFNO block's outer skip around the filter,                 */
@@ -865,6 +874,8 @@ typedef struct dlwp_add2d_desc {
     int rows, cols;
 } dlwp_add2d_desc;
 int dlwp_add2d_many(const dlwp_add2d_desc* descs, int n, void* stream);
+/* out[n] += sum_t g[t][n] for a bf16 array g (tall form, T > 16)                                                      */
+int dlwp_colsum_bf16(const void* g, float* out, int T, int N, void* stream);
 /* the same with overwrite != 0: out[n] = sum_t g[t][n] (the first of several accumulating calls needs no zero fill) */
 int dlwp_colsum_ex(const float* g, float* out, int T, int N, int overwrite, void* stream);
 

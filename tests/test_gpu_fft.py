@@ -180,3 +180,26 @@ def test_rfft2_planar_masked_store_is_the_softshrink_derivative(cuda, bs):
     L.check(L.load().dlwp_act_bwd(L.ptr(P), L.ptr(plain), L.ptr(want), plain.numel(), 3, lam, L.stream()))
     assert torch.equal(masked, want)
     assert 0.1 < (masked == 0).float().mean().item() < 0.5          # |N(0,1)| <= 0.3 for ~24 % of the elements
+
+
+@pytest.mark.parametrize("bs", [0, 8])
+def test_planar_window_as_bf16_array(cuda, bs):
+    """dlwp_rfft2_planar_ex / dlwp_irfft2_planar_ex with flags = 1: the written window is the fp32 window rounded once (masked or
+    not, the mask read as bf16); the inverse transform of a bf16 window equals the fp32 entry on the same (widened) values."""
+    from dlwp_benchmark_amd import fft
+    BF = torch.bfloat16
+    g = torch.Generator().manual_seed(31 + bs)
+    B, H, W, Cc = 2, 30, 36, 16
+    win = (3, 27, 12)
+    x = torch.randn(B, H, W, Cc, generator=g).to(cuda)
+    X32 = fft._run_r2c_planar(x, win, bs, fft.NORMS["ortho"], 0)
+    X16 = fft._run_r2c_planar(x, win, bs, fft.NORMS["ortho"], 0, out_bf16=True)
+    assert X16.dtype == BF and torch.equal(X16, X32.to(BF))
+    P = torch.randn(X32.shape, generator=g).to(cuda).to(BF)
+    m16 = fft._run_r2c_planar(x, win, bs, fft.NORMS["ortho"], 1, mask=P, lam=0.3, out_bf16=True)
+    m32 = fft._run_r2c_planar(x, win, bs, fft.NORMS["ortho"], 1, mask=P.float(), lam=0.3)
+    assert torch.equal(m16, m32.to(BF))
+    r = torch.randn(B, H, W, Cc, generator=g).to(cuda)
+    y16 = fft._run_c2r_planar(X16, H, W, win, bs, fft.NORMS["ortho"], 0, residual=r)
+    y32 = fft._run_c2r_planar(X16.float(), H, W, win, bs, fft.NORMS["ortho"], 0, residual=r)
+    assert torch.equal(y16, y32)

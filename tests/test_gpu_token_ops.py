@@ -320,3 +320,13 @@ def test_add2d_many_and_colsum_overwrite(cuda):
     assert torch.allclose(out, ref, atol=1e-6)
     L.check(lib.dlwp_colsum_ex(L.ptr(x), L.ptr(out), 5, 1000, 0, L.stream()))
     assert torch.allclose(out, 2 * ref, atol=1e-5)
+
+
+def test_colsum_of_a_bf16_array(cuda):
+    from dlwp_benchmark_amd import lib as L
+    x = torch.randn(300, 1536, device=cuda).to(torch.bfloat16)
+    out = torch.ones(1536, device=cuda)
+    L.check(L.load().dlwp_colsum_bf16(L.ptr(x), L.ptr(out), 300, 1536, L.stream()))
+    ref = 1.0 + x.double().sum(0)
+    assert ((out.double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
+    assert L.load().dlwp_colsum_bf16(L.ptr(x), L.ptr(out), 8, 1536, L.stream()) != 0
