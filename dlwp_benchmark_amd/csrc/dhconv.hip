@@ -70,7 +70,9 @@ __global__ __launch_bounds__(256) void dhconv_pack_kernel(PackMany pm, int Ci, i
 // pairs per workgroup): 83 us per step for the four C3 layers (201 MB moved).  Here a workgroup stages a 32 x 32 block of (i, o)
 // pairs (all degrees, 256 KB of fp32) as bf16 in LDS, transposed to [o][(l, part)][i] -- the forward image's eight consecutive
 // inputs are then one 16-byte piece -- and writes the block's 4 + 4 tiles of both images: 134 MB moved.
-constexpr int PK_PJ = 36;          // element pitch of one (o, l, part) row of 32 inputs (two 8-byte-aligned halves per fragment)
+constexpr int PK_PJ = 36;          // element pitch of one (o, l, part) row of 32 inputs.  The forward image's bf16x4 reads start at
+                                   // (8 t + ch) * PO with PO = 72 L + 2 elements: 4-byte aligned for odd ch (LDS accesses of 8 bytes at
+                                   // 4-byte alignment are legal on gfx950 in the default unaligned-access mode; the + 2 spreads the banks)
 __global__ __launch_bounds__(512) void dhconv_pack2_kernel(PackMany pm, int Ci, int Co, int L) {
     extern __shared__ __attribute__((aligned(16))) float pk_smem[];
     __bf16* sm = reinterpret_cast<__bf16*>(pk_smem);                     // [32 o][2 L][PK_PJ] (+ 2 elements per o: bank spread)
@@ -490,9 +492,11 @@ extern "C" int dlwp_dhconv_pack_many(const float* const* w, void* const* fwd_img
         pm.fimg[i] = static_cast<__bf16*>(fwd_img[i]);
         pm.bimg[i] = static_cast<__bf16*>(bwd_img[i]);
     }
-    // one read of every weight for both images where a 32 x 32 block of (i, o) pairs fits the LDS as bf16 (L <= 34, even)
+    // one read of every weight for both images where a 32 x 32 block of (i, o) pairs fits the LDS as bf16.  The kernel loads the
+    // 16 L float4 pieces of an input row with ONE thread each (tid < per_i, 512 threads): L <= 32, stated here and not left to the
+    // LDS budget (L = 34 happens to exceed it today); 32-wide blocks need both channel counts to be multiples of 32
     const size_t lds2 = (size_t)32 * (2 * L * PK_PJ + 2) * sizeof(__bf16);
-    if (L % 2 == 0 && lds2 <= 150 * 1024 && dlwp_tune_or("DHCONV_PACK", 2) != 1) {
+    if (L % 2 == 0 && 16 * L <= 512 && Cin % 32 == 0 && Cout % 32 == 0 && lds2 <= 150 * 1024 && dlwp_tune_or("DHCONV_PACK", 2) != 1) {
         if (int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(dhconv_pack2_kernel), lds2, "dhconv_pack2")) return rc;
         hipLaunchKernelGGL(dhconv_pack2_kernel, dim3(Cin / 32, Cout / 32, n), dim3(512), lds2, (hipStream_t)stream, pm, Cin, Cout, L);
         DLWP_LAUNCH_CHECK();

@@ -11,6 +11,18 @@ int dlwp_tune(const char* name);
 inline bool dlwp_tune_on(const char* name) { const int v = dlwp_tune(name); return v != DLWP_TUNE_UNSET && v != 0; }
 inline int dlwp_tune_or(const char* name, int dflt) { const int v = dlwp_tune(name); return v == DLWP_TUNE_UNSET ? dflt : v; }
 
+// prof.hip -- live per-kernel accounting (dlwp_prof_enable / _collect / _get): a scope object around a launch records an event pair
+// on the launch stream plus the kernel's name and its algorithmic flops / HBM bytes; free when disabled or under stream capture
+bool dlwp_prof_on();
+struct dlwp_prof_scope {
+    int idx;
+    hipStream_t stream;
+    dlwp_prof_scope(hipStream_t s, double flops, double bytes, const char* fmt, ...) __attribute__((format(printf, 5, 6)));
+    ~dlwp_prof_scope();
+    dlwp_prof_scope(const dlwp_prof_scope&) = delete;
+    dlwp_prof_scope& operator=(const dlwp_prof_scope&) = delete;
+};
+
 // pwmlp.hip — strided/gathered channel views, optional residual and fused MSE gradient
 int dlwp_pwmlp_fwd_ex(const dlwp_chan_src* x, const float* w1, const float* b1, const float* w2,
                       const float* b2, const dlwp_chan_dst* y, const dlwp_chan_src* res, int B,

@@ -1024,6 +1024,10 @@ int run_w_real(const dlwp_fft_plan* p, bool to_complex, bool cf, const float* in
     const LaunchShape sh = shape_of(io.ax);
     DLWP_REQUIRE(sh.outs > 0, DLWP_E_UNSUPPORTED, "fft: axis of length %d needs more than 32 outputs per thread", io.ax.N);
     const size_t lds = axis_lds(io.ax);
+    // live accounting: B*C*H real rows of W floats on one side, W/2+1 complex bins on the other (+ the optional residual rows)
+    const double prows = (double)B * C * p->H;
+    dlwp_prof_scope prof(stream, prows * 2.5 * p->W * log2((double)p->W), prows * (4.0 * p->W * (1 + (res ? 1 : 0) + (res2 ? 1 : 0)) + 8.0 * io.Wc),
+                         to_complex ? "fft_r2c_kernel" : "fft_c2r_kernel");
     if (io.ax.sp && !cf) {                 // channels-last W axis of 180 on a compile-time plan (OUTS covers N * IB / NT = 11.25)
         int rc = DLWP_OK;
         auto go = [&](auto r2c, auto c2r, int nt) {
@@ -1071,6 +1075,9 @@ int run_h_c2c(const dlwp_fft_plan* p, const float* in, float* out, long long out
     const LaunchShape sh = shape_of(io.ax);
     DLWP_REQUIRE(sh.outs > 0, DLWP_E_UNSUPPORTED, "fft: axis of length %d needs more than 32 outputs per thread", io.ax.N);
     const size_t lds = axis_lds(io.ax);
+    // live accounting: outer * J complex columns of N points, read and written once (a bf16 plane side moves half the bytes)
+    const double pcols = (double)outer * J;
+    dlwp_prof_scope prof(stream, pcols * 5.0 * io.ax.N * log2((double)io.ax.N), pcols * io.ax.N * (8.0 + (plane_bf16 ? 4.0 : 8.0)), "fft_c2c_kernel");
     if (io.ax.sym) {                       // the axis is one odd prime: the kernel that holds nothing but the folded pass (the general
                                            // 512-thread kernel with every pass inlined needs 256 VGPRs + scratch: one workgroup per CU)
         auto kern = fft_c2c_kernel<16, 512, false, -1>;

@@ -550,8 +550,11 @@ extern "C" int dlwp_layernorm_fwd_ex(const float* x, const float* gamma, const f
     DLWP_REQUIRE(x && gamma && beta && y && mean && rstd && T > 0 && C > 0, DLWP_E_INVALID, "layernorm_fwd: bad argument");
     const bool narrow = C % 4 == 0 && C <= 256 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 8 == 0 && (uintptr_t)gamma % 16 == 0 &&
                         (uintptr_t)beta % 16 == 0 && (y_bf16 || (uintptr_t)y % 16 == 0);
+    // live accounting: x read, y written (fp32 or bf16), the two statistics written; ~8 flops per element
+    const double pbytes = (double)T * C * (4 + (y_bf16 ? 2 : 4)) + 8.0 * T, pflops = 8.0 * T * C;
     if (narrow) {
         const int lpr = C <= 32 ? 8 : C <= 64 ? 16 : C <= 128 ? 32 : 64;
+        dlwp_prof_scope prof((hipStream_t)stream, pflops, pbytes, "layernorm_fwd_vec_kernel<%d>", lpr);
 #define LN_FWD_V(LPR) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<LPR>, dim3(ceil_div(T, 4 * (64 / LPR))), dim3(256), 0, (hipStream_t)stream, \
                                           x, gamma, beta, (float*)y, mean, rstd, T, C, eps, y_bf16 ? 1 : 0)
         if (lpr == 8) LN_FWD_V(8); else if (lpr == 16) LN_FWD_V(16); else if (lpr == 32) LN_FWD_V(32); else LN_FWD_V(64);
@@ -562,6 +565,7 @@ extern "C" int dlwp_layernorm_fwd_ex(const float* x, const float* gamma, const f
     const bool widef = C % 4 == 0 && C > 256 && C <= 1024 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % (y_bf16 ? 8 : 16) == 0 &&
                        (uintptr_t)gamma % 16 == 0 && (uintptr_t)beta % 16 == 0;
     if (widef) {
+        dlwp_prof_scope prof((hipStream_t)stream, pflops, pbytes, "layernorm_fwd_wide_kernel<%d>", C <= 512 ? 2 : C <= 768 ? 3 : 4);
 #define LN_FWD_W(NV) hipLaunchKernelGGL(layernorm_fwd_wide_kernel<NV>, dim3(ceil_div(T, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, \
                                         (float*)y, mean, rstd, T, C, eps, y_bf16)
         if (C <= 512) LN_FWD_W(2); else if (C <= 768) LN_FWD_W(3); else LN_FWD_W(4);
@@ -569,6 +573,7 @@ extern "C" int dlwp_layernorm_fwd_ex(const float* x, const float* gamma, const f
         DLWP_LAUNCH_CHECK();
         return DLWP_OK;
     }
+    dlwp_prof_scope prof((hipStream_t)stream, pflops, pbytes, "layernorm_fwd_kernel");
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ceil_div(T, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (float*)y,
                        mean, rstd, T, C, eps, y_bf16 ? 1 : 0);
     DLWP_LAUNCH_CHECK();
@@ -604,7 +609,10 @@ static int layernorm_bwd_impl(const float* x, const float* gamma, const float* m
     const bool wide = C % 4 == 0 && C > 256 && C <= 1024 && (uintptr_t)x % 16 == 0 && (uintptr_t)gx % 16 == 0 &&
                       (uintptr_t)gamma % 16 == 0 && (uintptr_t)gy % (gy_bf16 ? 8 : 16) == 0 && (!gadd || (uintptr_t)gadd % 16 == 0);
     const bool no_wide = dlwp_tune_on("LN_BWD_NOWIDE");
+    // live accounting: x, gy (fp32 or bf16) and the optional residual gradient read, gx written, the statistics read; ~14 flops / element
+    const double pbytes = (double)T * C * (4 + (gy_bf16 ? 2 : 4) + (gadd ? 4 : 0) + 4) + 8.0 * T, pflops = 14.0 * T * C;
     if (wide && !no_wide) {
+        dlwp_prof_scope prof((hipStream_t)stream, pflops, pbytes, "layernorm_bwd_wide_kernel<%d>", C <= 512 ? 2 : C <= 768 ? 3 : 4);
         // one round of resident workgroups (~110 VGPRs: four per CU at most; 512-768 keep the atomic tail short)
         const int wg_env = dlwp_tune("LN_BWD_WGS");
         const int slots = wg_env != DLWP_TUNE_UNSET ? wg_env : 384;
@@ -618,6 +626,7 @@ static int layernorm_bwd_impl(const float* x, const float* gamma, const float* m
         return DLWP_OK;
     }
     if (narrow) {
+        dlwp_prof_scope prof((hipStream_t)stream, pflops, pbytes, "layernorm_bwd_vec_kernel<%d>", C <= 32 ? 8 : C <= 64 ? 16 : C <= 128 ? 32 : 64);
 #define LN_BWD_V(LPR) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<LPR>, grid, dim3(256), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, \
                                           gadd, gx, ggamma, gbeta, T, C, rpb, gy_bf16)
         if (C <= 32) LN_BWD_V(8); else if (C <= 64) LN_BWD_V(16); else if (C <= 128) LN_BWD_V(32); else LN_BWD_V(64);
@@ -628,6 +637,7 @@ static int layernorm_bwd_impl(const float* x, const float* gamma, const float* m
 #define LN_BWD(NQ)                                                                                                   \
     hipLaunchKernelGGL(layernorm_bwd_kernel<NQ>, grid, dim3(256), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, gadd, \
                        gx, ggamma, gbeta, T, C, rpb, gy_bf16)
+    dlwp_prof_scope prof((hipStream_t)stream, pflops, pbytes, "layernorm_bwd_kernel");
     if (C <= 64) LN_BWD(1);
     else if (C <= 128) LN_BWD(2);
     else if (C <= 256) LN_BWD(4);
@@ -695,9 +705,10 @@ static int colsum_impl(const float* g, float* out, int T, int N, int overwrite, 
         if (vec) hipLaunchKernelGGL(colsum_flat_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, out, T, (long long)N, overwrite);
         else hipLaunchKernelGGL(colsum_flat_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, out, T, (long long)N, overwrite);
     } else {
-        if (overwrite) {       // the slab kernel adds with atomics: start from zero
-            const hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, (hipStream_t)stream);
-            DLWP_REQUIRE(e == hipSuccess, DLWP_E_HIP, "colsum: hipMemsetAsync: %s", hipGetErrorString(e));
+        if (overwrite) {       // the slab kernel adds with atomics: start from zero.  A zero-fill KERNEL, not hipMemsetAsync: this path
+                               // is inside captured steps (SFNO position-embedding gradient at per-GPU batch > 16) and captured
+                               // memset nodes were seen writing garbage on later replays (common.hip.h)
+            if (int zrc = dlwp_zero_f32(out, N, stream)) return zrc;
         }
         // row slabs sized so that the launch has ~2048 workgroups (fills the chip, bounds the atomics per column)
         const int cols = ceil_div(N, vec ? 256 : 64);

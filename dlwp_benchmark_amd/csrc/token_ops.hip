@@ -59,6 +59,17 @@ struct GemmDev {
 };
 constexpr int DT_A = 1, DT_B = 2, DT_C = 4, DT_R = 8;
 
+// live accounting (prof.hip): algorithmic work of one product launch -- every operand read once, every output written once
+static inline double gemm_prof_flops(const GemmDev& a) { return 2.0 * a.M * a.N * (double)a.K * a.nbatch; }
+static inline double gemm_prof_bytes(const GemmDev& a) {
+    const double nbA = (a.nbatch > 1 && a.sA1 == 0 && a.sA2 == 0) ? 1 : a.nbatch, nbB = (a.nbatch > 1 && a.sB1 == 0 && a.sB2 == 0) ? 1 : a.nbatch;
+    const double nbC = (a.nbatch > 1 && a.sC1 == 0 && a.sC2 == 0) ? 1 : a.nbatch;
+    const double eA = (a.dt & DT_A) ? 2 : 4, eB = (a.dt & DT_B) ? 2 : 4, eC = (a.dt & DT_C) ? 2 : 4, eR = (a.dt & DT_R) ? 2 : 4;
+    const double mn = (double)a.M * a.N;
+    return nbA * eA * a.M * (double)a.K + nbB * eB * a.N * (double)a.K + nbC * mn * eC * (1 + (a.preact ? 1 : 0) + (a.accumulate ? 1 : 0)) +
+           (a.residual ? nbC * mn * eR : 0.0) + (a.bias ? 4.0 * (a.bias_row ? a.M : a.N) : 0.0);
+}
+
 // bf16-operand mode (dlwp_set_gemm_precision(1)): operands are rounded to bf16 when a tile is committed to LDS and
 // multiplied by v_mfma_f32_16x16x32_bf16 (16x the fp32 MFMA rate) with fp32 accumulation -- the arithmetic of the
 // reference's bf16-autocast runs (BASELINE configs C3-C5); tensors in HBM stay fp32.  LDS tiles are [row][k] bf16.
@@ -665,6 +676,8 @@ int gemm_launch_t(const GemmDev& a, dim3 grid, hipStream_t s) {
                           : sizeof(float) * 4 * Tile<T>::FLOATS;
     int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_kernel<AKC, BKC, VEC, T, BF, S16M>), lds, "gemm");
     if (rc) return rc;
+    dlwp_prof_scope prof(s, gemm_prof_flops(a), gemm_prof_bytes(a), "gemm_kernel<%s, %s, %d, %d, %s, %d>", AKC ? "true" : "false",
+                         BKC ? "true" : "false", VEC, T, BF ? "true" : "false", S16M);
     hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, T, BF, S16M>), grid, dim3(256), lds, s, a);
     return DLWP_OK;
 }
@@ -1051,12 +1064,15 @@ static int gemm_glds_tn_launch(const GemmDev& a_in, hipStream_t s) {
     a.slab = (no_slab || a.ntn * a.ntm < slab_min || a.N % 4 || a.ldc % 4 || (uintptr_t)a.C % 16) ? nullptr
                                                                          : tn_slab_for(s, sizeof(float) * grid.z * (size_t)a.M * a.N);
     int rc;
+    {
+    dlwp_prof_scope prof(s, gemm_prof_flops(a), gemm_prof_bytes(a), "gemm_glds_tn_kernel<%d>", kd);
     if (shallow) {
         if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_glds_tn_kernel<32>), lds, "gemm_glds_tn"))) return rc;
         hipLaunchKernelGGL(gemm_glds_tn_kernel<32>, grid, dim3(256), lds, s, a);
     } else {
         if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_glds_tn_kernel<64>), lds, "gemm_glds_tn"))) return rc;
         hipLaunchKernelGGL(gemm_glds_tn_kernel<64>, grid, dim3(256), lds, s, a);
+    }
     }
     if (a.slab) {
         // the caller zeroed C for its own split-K when it does not accumulate: adding to it is the same either way
@@ -1329,6 +1345,7 @@ static int gemm_glds_launch(const GemmDev& a_in, bool bkc, hipStream_t s) {
 #define GLDS_GO(BKC_, KD_)                                                                                              \
     do {                                                                                                                \
         if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_glds_kernel<BKC_, KD_>), lds, "gemm_glds"))) return rc; \
+        dlwp_prof_scope prof(s, gemm_prof_flops(a), gemm_prof_bytes(a), "gemm_glds_kernel<%s, %d>", BKC_ ? "true" : "false", KD_); \
         hipLaunchKernelGGL((gemm_glds_kernel<BKC_, KD_>), dim3(a.ntn * a.ntm), dim3(256), lds, s, a);                     \
     } while (0)
     if (bkc) { if (shallow) GLDS_GO(true, 32); else GLDS_GO(true, 64); }
@@ -1540,6 +1557,7 @@ static int gemm_p8_launch(const GemmDev& a_in, bool bkc, hipStream_t s) {
 #define P8_GO(D_, B_)                                                                                                   \
     do {                                                                                                                \
         if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_p8_kernel<D_, B_>), lds, "gemm_p8"))) return rc;   \
+        dlwp_prof_scope prof(s, gemm_prof_flops(a), gemm_prof_bytes(a), "gemm_p8_kernel<%s, %s>", D_ ? "true" : "false", B_ ? "true" : "false"); \
         hipLaunchKernelGGL((gemm_p8_kernel<D_, B_>), dim3(std::min(a.ntn * a.ntm, ncu)), dim3(512), lds, s, a);         \
     } while (0)
     if (bkc) { if (direct) P8_GO(true, true); else P8_GO(false, true); }

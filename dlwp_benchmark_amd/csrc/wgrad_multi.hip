@@ -273,9 +273,18 @@ extern "C" int dlwp_wgrad_segments(const dlwp_wgrad_seg_product* p, int nprod, i
     if (int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(wgrad_multi_kernel), lds, "wgrad_multi")) return rc;
     const hipStream_t s = (hipStream_t)stream;
     a.nslices = slices;
-    hipLaunchKernelGGL(wgrad_multi_kernel, dim3(a.tile0[nprod] * slices), dim3(256), lds, s, a);
+    double pflops = 0, pbytes = 0;         // live accounting: gW_i = g_i^T x_i over nseg x T tokens; operands bf16, read once
+    for (int i = 0; i < nprod; ++i) {
+        pflops += 2.0 * p[i].N * p[i].K * (double)T * nseg;
+        pbytes += 2.0 * (p[i].N + p[i].K) * (double)T * nseg;
+    }
+    {
+        dlwp_prof_scope prof(s, pflops, pbytes + 4.0 * slices * a.out_off[nprod], "wgrad_multi_kernel");
+        hipLaunchKernelGGL(wgrad_multi_kernel, dim3(a.tile0[nprod] * slices), dim3(256), lds, s, a);
+    }
     DLWP_LAUNCH_CHECK();
     const long long units = a.out_off[nprod] / 4;
+    dlwp_prof_scope prof2(s, (double)slices * a.out_off[nprod], 4.0 * (slices + 1) * a.out_off[nprod], "wgrad_multi_reduce_kernel");
     hipLaunchKernelGGL(wgrad_multi_reduce_kernel, dim3((unsigned)std::min<long long>((units + 63) / 64, 4096)), dim3(256), 0, s, a, slices);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;

@@ -633,6 +633,8 @@ extern "C" int dlwp_window_attn_fwd_qrange(const float* qkv, const float* bias_t
 #define WA_FWD_B(NDB, NB, BFV)                                                                                                \
     do {                                                                                                                  \
         if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_fwd_kernel<NDB, NB, BFV>), lds, "window_attn_fwd"))) return rc; \
+        dlwp_prof_scope prof((hipStream_t)stream, 2 * 2.0 * B_ * heads * (double)N * N * d, 4.0 * B_ * N * heads * d * 4 + 4.0 * B_ * heads * N, \
+                             "winattn_fwd_kernel<%d, %d, %s>", NDB, NB, BFV ? "true" : "false");                             \
         hipLaunchKernelGGL((winattn_fwd_kernel<NDB, NB, BFV>), grid, block, lds, (hipStream_t)stream, a);               \
     } while (0)
 #define WA_FWD(NDB)                                                                                                       \
@@ -697,8 +699,16 @@ extern "C" int dlwp_window_attn_bwd_qrange(const float* qkv, const float* bias_t
     do {                                                                                                                     \
         if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_bwd_q_kernel<NDB, NB, BFV>), lds_q, "window_attn_bwd"))) return rc;  \
         if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(winattn_bwd_kv_kernel<NDB, NB, BFV>), lds_kv, "window_attn_bwd"))) return rc; \
-        hipLaunchKernelGGL((winattn_bwd_q_kernel<NDB, NB, BFV>), grid, block, lds_q, (hipStream_t)stream, a);              \
-        hipLaunchKernelGGL((winattn_bwd_kv_kernel<NDB, NB, BFV>), grid, block, lds_kv, (hipStream_t)stream, a);            \
+        {   /* live accounting: the pair computes the five products of the backward once; q reads qkv, out, gout, writes gq */ \
+            dlwp_prof_scope prof((hipStream_t)stream, 2.5 * 2.0 * B_ * heads * (double)N * N * d, 4.0 * B_ * N * heads * d * 6,    \
+                                 "winattn_bwd_q_kernel<%d, %d, %s>", NDB, NB, BFV ? "true" : "false");                          \
+            hipLaunchKernelGGL((winattn_bwd_q_kernel<NDB, NB, BFV>), grid, block, lds_q, (hipStream_t)stream, a);          \
+        }                                                                                                                    \
+        {                                                                                                                    \
+            dlwp_prof_scope prof((hipStream_t)stream, 2.5 * 2.0 * B_ * heads * (double)N * N * d, 4.0 * B_ * N * heads * d * 6,    \
+                                 "winattn_bwd_kv_kernel<%d, %d, %s>", NDB, NB, BFV ? "true" : "false");                         \
+            hipLaunchKernelGGL((winattn_bwd_kv_kernel<NDB, NB, BFV>), grid, block, lds_kv, (hipStream_t)stream, a);        \
+        }                                                                                                                    \
     } while (0)
 #define WA_BWD(NDB)                                                                                                          \
     do {                                                                                                                     \

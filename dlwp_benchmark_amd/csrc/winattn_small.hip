@@ -1439,6 +1439,18 @@ __global__ __launch_bounds__(256) void winattn_lds_fwd_tok_kernel(WsDev a) {
 // so with few windows the tiled kernels of winattn.hip (a workgroup per 64 queries) finish sooner.  Measured
 // (profiles/r02_winattn_probe.txt, forward / backward us, tiled -> this family):  1406 windows x 4 heads, N = 49, d = 24:
 // 86 / 264 -> 54 / 249;  703 x 6, N = 98, d = 32: 193 / 727 -> 149 / 643;  100 x 4, N = 49, d = 10: 8 / 26 -> 11 / 51.
+// live accounting (prof.hip): products = 2 (forward: Q K^T, P V) or 5 (backward: the scores again, dP, dV, dQ, dK) over the
+// computed query chunks; bytes = the rows that exist in HBM read / written once (token layout: the unpartitioned tensors)
+static inline double ws_prof_flops(const WsDev& a, int products) {
+    const double q = 16.0 * (a.qc_hi - a.qc_lo) < a.N ? 16.0 * (a.qc_hi - a.qc_lo) : a.N;
+    return products * 2.0 * a.B_ * a.heads * q * a.N * a.d;
+}
+static inline double ws_prof_bytes(const WsDev& a, bool backward) {
+    const double rows = a.fill ? (double)(a.B_ / a.nW) * a.Ltok : (double)a.B_ * a.N;
+    const double C = (double)a.heads * a.d, e = a.io_bf16 ? 2 : 4;      // io_bf16: qkv, out, gout, gqkv are all bf16 arrays
+    // forward: qkv read, out + lse written; backward: qkv, out, gout, lse read, gqkv written
+    return rows * C * e * (backward ? 3 + 1 + 1 + 3 : 3 + 1) + 4.0 * a.B_ * a.heads * a.N;
+}
 bool dlwp_winattn_small_applies(int N, int d, long long pairs) { return N <= 128 && d <= 32 && pairs >= 2048; }
 
 #define WS_DISPATCH(KERNEL, lds)                                                                                          \
@@ -1449,6 +1461,7 @@ bool dlwp_winattn_small_applies(int N, int d, long long pairs) { return N <= 128
         auto go = [&](auto knl) -> int {                                                                                  \
             int rc2 = dlwp_ensure_lds(reinterpret_cast<const void*>(knl), lds, #KERNEL);                                  \
             if (rc2) return rc2;                                                                                          \
+            dlwp_prof_scope prof((hipStream_t)stream, ws_prof_flops(a, 2), ws_prof_bytes(a, false), #KERNEL "<%d, %d>", nc <= 4 ? 4 : 8, ndb); \
             hipLaunchKernelGGL(knl, grid, block, lds, (hipStream_t)stream, a);                                            \
             return DLWP_OK;                                                                                               \
         };                                                                                                                \
@@ -1515,6 +1528,8 @@ static int one_pass_launch(WsDev& a, void* stream) {
     auto go1 = [&](auto knl, int nt) -> int {
         int rc2 = dlwp_ensure_lds(reinterpret_cast<const void*>(knl), lb1, "winattn_lds_bwd1p");
         if (rc2) return rc2;
+        dlwp_prof_scope prof((hipStream_t)stream, ws_prof_flops(a, 5), ws_prof_bytes(a, true), "winattn_lds_bwd1p_kernel<%d, %d, %s>",
+                             d <= 16 ? 1 : 2, nw1, a.io_bf16 ? "true" : "false");
         hipLaunchKernelGGL(knl, grid, dim3(nt), lb1, (hipStream_t)stream, a);
         return DLWP_OK;
     };
@@ -1547,6 +1562,7 @@ int dlwp_winattn_small_bwd(const float* qkv, const float* table, const float* pa
         auto go = [&](auto knl) -> int {
             int rc2 = dlwp_ensure_lds(reinterpret_cast<const void*>(knl), lb, "winattn_lds_bwd");
             if (rc2) return rc2;
+            dlwp_prof_scope prof((hipStream_t)stream, ws_prof_flops(a, 5), ws_prof_bytes(a, true), "winattn_lds_bwd_kernel<%d>", d <= 16 ? 1 : 2);
             hipLaunchKernelGGL(knl, grid, block, lb, (hipStream_t)stream, a);
             return DLWP_OK;
         };
@@ -1561,6 +1577,7 @@ int dlwp_winattn_small_bwd(const float* qkv, const float* table, const float* pa
     auto go = [&](auto knl) -> int {
         int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(knl), lds, "winattn_small_bwd");
         if (rc) return rc;
+        dlwp_prof_scope prof((hipStream_t)stream, ws_prof_flops(a, 5), ws_prof_bytes(a, true), "winattn_small_bwd_kernel<%d>", d <= 16 ? 1 : 2);
         hipLaunchKernelGGL(knl, grid, block, lds, (hipStream_t)stream, a);
         return DLWP_OK;
     };
@@ -1627,6 +1644,8 @@ extern "C" int dlwp_window_attn_fwd_tokens(const float* qkv_tokens, const float*
         auto go1 = [&](auto knl) -> int {
             int rc2 = dlwp_ensure_lds(reinterpret_cast<const void*>(knl), lb, "winattn_lds_fwd_tok");
             if (rc2) return rc2;
+            dlwp_prof_scope prof((hipStream_t)stream, ws_prof_flops(a, 2), ws_prof_bytes(a, false), "winattn_lds_fwd_tok_kernel<%d, %d, %s>",
+                                 nc <= 4 ? 4 : 8, d <= 16 ? 1 : 2, io_bf16 ? "true" : "false");
             hipLaunchKernelGGL(knl, grid1, dim3(256), lb, (hipStream_t)stream, a);
             return DLWP_OK;
         };
@@ -1646,6 +1665,8 @@ extern "C" int dlwp_window_attn_fwd_tokens(const float* qkv_tokens, const float*
     auto go = [&](auto knl) -> int {
         int rc2 = dlwp_ensure_lds(reinterpret_cast<const void*>(knl), lds, "winattn_small_fwd_tokens");
         if (rc2) return rc2;
+        dlwp_prof_scope prof((hipStream_t)stream, ws_prof_flops(a, 2), ws_prof_bytes(a, false), "winattn_small_fwd_kernel<%d, %d> (tokens)",
+                             nc <= 4 ? 4 : 8, d <= 16 ? 1 : 2);
         hipLaunchKernelGGL(knl, grid, block, lds, (hipStream_t)stream, a);
         return DLWP_OK;
     };

@@ -121,6 +121,15 @@ class BucketedGradAllReduce:
             hi = max((p.grad.data_ptr() - base) // 4 + p.numel() for p in ps)
             if 0 <= lo and hi <= total and sum(p.numel() for p in ps) + 8 * len(ps) >= hi - lo:     # contiguous up to padding
                 spans.append((lo, hi, unit))
+        # a block that batches its weight gradients (token_ops.WgradBatch) writes them when its FIRST layer runs backward: its
+        # sub-modules' backward hooks fire before that, so no unit may be a proper part of such a block
+        unit_ids = {id(sp[2]) for sp in spans}
+        for blk in model.modules():
+            if getattr(blk, "wgrad_batch_block", False):
+                inner = [type(m).__name__ for m in blk.modules() if m is not blk and id(m) in unit_ids]
+                if inner:
+                    raise RuntimeError(f"BucketedGradAllReduce: units {inner} lie inside a {type(blk).__name__} whose weight gradients are "
+                                       "written together at the end of the block's backward: a unit must be the block or larger")
         spans.sort(key=lambda t: t[0])
         kept, end = [], 0                             # drop units that overlap an already KEPT span (tied / shared parameters)
         for sp in spans:

@@ -82,6 +82,8 @@ class EarthAttention3D(nn.Module):
 
 
 class EarthSpecificBlock(nn.Module):
+    wgrad_batch_block = True      # the block's weight-gradient writes land together at its first layer's backward (token_ops.WgradBatch)
+
     def __init__(self, dim, input_resolution, num_heads, window_size=None, shift_size=None, mlp_ratio=4., qkv_bias=True,
                  qk_scale=None, drop=0., attn_drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=LayerNorm):
         super().__init__()

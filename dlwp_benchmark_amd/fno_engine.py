@@ -224,6 +224,8 @@ class FusedAdam:
         read-modify-write pass over the gradient buffer less."""
         sumsq = None
         if clip_max_norm is not None:
+            if not clip_max_norm > 0:
+                raise L.DlwpError(f"FusedAdam.step: clip_max_norm must be positive or None (got {clip_max_norm!r})")
             self.sumsq.zero_()
             L.check(self.lib.dlwp_sumsq(L.ptr(self.grads), self.grads.numel(), L.ptr(self.sumsq), L.stream()))
             sumsq = self.sumsq

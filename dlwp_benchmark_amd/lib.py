@@ -37,6 +37,9 @@ SIGNATURES = {
     "dlwp_clear_tuning": (_I, [C.c_char_p]),
     "dlwp_get_tuning": (_I, [C.c_char_p, C.POINTER(_I)]),
     "dlwp_tuning_list": (_I, [_I, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]),
+    "dlwp_prof_enable": (_I, [_I]),
+    "dlwp_prof_collect": (_I, []),
+    "dlwp_prof_get": (_I, [_I, C.c_char_p, _I, C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dlwp_pwmlp_fwd": (_I, [_V] * 6 + [_I] * 5 + [_V]),
     "dlwp_pwmlp_bwd": (_I, [_V] * 10 + [_I] * 5 + [_V]),
     "dlwp_pwmlp_slab_floats": (_L, [_I] * 5),
@@ -280,6 +283,27 @@ def tuning_knobs():
         out[n.value.decode()] = d.value.decode()
         i += 1
     return out
+
+
+class kernel_accounting:
+    """with lib.kernel_accounting() as acc: <eager launches> ; acc.rows -- live per-kernel accounting (dlwp_prof_enable /
+    _collect / _get): one row per kernel name, sorted by total time, with the calls, the event-bracketed milliseconds and the
+    algorithmic flops / HBM bytes the launches' own arguments imply.  Launches inside a hipGraph capture are not recorded."""
+
+    def __enter__(self):
+        check(load().dlwp_prof_enable(1))
+        self.rows = []
+        return self
+
+    def __exit__(self, *exc):
+        lib = load()
+        n = lib.dlwp_prof_collect()
+        buf = C.create_string_buffer(160)
+        calls, ms, fl, by = _L(), C.c_double(), C.c_double(), C.c_double()
+        for i in range(max(n, 0)):
+            check(lib.dlwp_prof_get(i, buf, 160, C.byref(calls), C.byref(ms), C.byref(fl), C.byref(by)))
+            self.rows.append({"name": buf.value.decode(), "calls": calls.value, "ms": ms.value, "flops": fl.value, "bytes": by.value})
+        return False
 
 
 def set_gemm_tile256(mode):

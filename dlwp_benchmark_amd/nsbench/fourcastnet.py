@@ -124,6 +124,8 @@ class AFNO2D(nn.Module):
 
 
 class Block(nn.Module):
+    wgrad_batch_block = True      # the block's weight-gradient writes land together at its first layer's backward (token_ops.WgradBatch)
+
     def __init__(self, dim, mlp_ratio=4., drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=LayerNorm,
                  double_skip=True, num_blocks=8, sparsity_threshold=0.01, hard_thresholding_fraction=1.0):
         super().__init__()

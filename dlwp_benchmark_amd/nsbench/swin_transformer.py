@@ -281,6 +281,8 @@ class WindowAttention(nn.Module):
 
 
 class SwinTransformerBlock(nn.Module):
+    wgrad_batch_block = True      # the block's weight-gradient writes land together at its first layer's backward (token_ops.WgradBatch)
+
     def __init__(self, dim, num_heads, window_size=7, shift_size=0, mlp_ratio=4., qkv_bias=True, qk_scale=None,
                  drop=0., attn_drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=LayerNorm,
                  padding_mode: str = "constant"):

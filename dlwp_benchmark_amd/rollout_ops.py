@@ -21,7 +21,10 @@ def _batch_view(t):
         return None, 0
     if t.dtype != torch.float32:
         t = t.float()
-    if t.shape[0] == 1 or t[0].is_contiguous():
+    # the sample block itself must be dense whatever the batch size: at B = 1 a channels-last gradient (the patch embedding's input
+    # gradient seen through cat's narrow) used to slip through a `B == 1` shortcut and was read as if it were [C, H, W] -- wrong
+    # gradients for every multi-lead-time rollout at batch 1 (found by tests/test_gpu_round6.py, round 6)
+    if t[0].is_contiguous():
         return t, (t.stride(0) if t.shape[0] > 1 else t[0].numel())
     t = t.contiguous()
     return t, t[0].numel()

@@ -161,13 +161,21 @@ def _table(mod, name, dtype):
     return c
 
 
+def _triangular_host(table):
+    """1 when the host Legendre table [mmax, nlat, lmax] is exactly zero for degrees l < m, else 0 (see _triangular_flag)."""
+    import numpy as np
+    M, _, Lm = table.shape
+    dead = np.arange(Lm)[None, :] < np.arange(M)[:, None]           # [M, L]: l < m
+    return 1 if bool((np.transpose(table, (0, 2, 1))[dead] == 0).all()) else 0
+
+
 def _triangular_flag(mod, name):
     """DLWP_SHT_TRIANGULAR for the bf16 synthesis kernel when the Legendre table `name` ([mmax, nlat, lmax], the kernel's S1t) is
     exactly zero for degrees l < m (associated Legendre functions: always, checked once per table on the host): every product with
     a spectrum entry of order m > l is then zero whatever the entry holds, so the kernel does not read those entries."""
     key = "_tri_" + name
-    flag = mod.__dict__.get(key)
-    if flag is None:
+    flag = mod.__dict__.get(key)         # set by RealSHT / InverseRealSHT.__init__ from the host tables (no device sync, capture-safe)
+    if flag is None:                     # a module that did not go through __init__ (unpickled): one blocking check, then cached
         t = getattr(mod, name)                                   # [mmax, nlat, lmax]
         M, _, Lm = t.shape
         dead = torch.arange(Lm, device=t.device)[None, :] < torch.arange(M, device=t.device)[:, None]      # [M, L]: l < m
@@ -325,6 +333,7 @@ class RealSHT(nn.Module):
         # transposed copies for the fused backward (synthesis reads S1t [m][k][l], S2t [n][q])
         self.register_buffer("dft_t", torch.from_numpy(F.T.copy()).float().contiguous(), persistent=False)
         self.register_buffer("weights_t", torch.from_numpy(Wf.transpose(0, 2, 1).copy()).float().contiguous(), persistent=False)
+        self._tri_weights_t = _triangular_host(Wf.transpose(0, 2, 1))       # next to the (non-persistent, never reloaded) table it describes
 
     def forward(self, x, fork=False):
         """fork=True: returns (X, x) -- x again, for a skip connection around the spectral filter; on the GEMM path the gradient
@@ -368,6 +377,7 @@ class InverseRealSHT(nn.Module):
         self.register_buffer("pct", torch.from_numpy(P).float().contiguous(), persistent=False)
         self.register_buffer("idft", torch.from_numpy(G).float().contiguous(), persistent=False)
         self.register_buffer("pct_t", torch.from_numpy(P.transpose(0, 2, 1).copy()).float().contiguous(), persistent=False)
+        self._tri_pct_t = _triangular_host(P.transpose(0, 2, 1))
         self.register_buffer("idft_t", torch.from_numpy(G.T.copy()).float().contiguous(), persistent=False)
 
     def forward(self, X, field_bf16=False):

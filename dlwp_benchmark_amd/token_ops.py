@@ -320,12 +320,16 @@ class WgradBatch:
     5 - 10 GFLOP product that cannot fill the chip by itself.  The block's forward makes a fresh object and hands it to its Linear /
     Mlp calls: a node that will compute weight gradients enrols in its forward, and in its backward either hands over its (g, x) pair
     (bf16 arrays, gradient slots present) or computes the product at once and signs off; the launch happens when the last enrolled
-    node has reported.  Nothing global: an application whose backward never runs just drops its object with the graph."""
+    node has reported.  Nothing global: an application whose backward never runs just drops its object with the graph.
+    Gradient writes of the block therefore land when its FIRST layer (qkv) runs backward, i.e. before the block's own full-backward
+    hook but after the hooks of its sub-modules: a data-parallel unit must not be finer than the block (the block classes carry
+    `wgrad_batch_block = True`; ddp.BucketedGradAllReduce checks)."""
 
     def __init__(self):
-        self.pending, self.items = 0, []
+        self.enrolled, self.pending, self.items, self._armed = 0, 0, [], False
 
     def enrol(self, n=1):
+        self.enrolled += n
         self.pending += n
 
     @staticmethod
@@ -338,16 +342,36 @@ class WgradBatch:
         self.items.append(([g2], [x2], wslot, bslot, has_bias, wshape))
         self.done()
 
+    def _arm(self):
+        """Safety net, once per backward pass: when the pass ends (autograd's engine callback) whatever was handed over but never
+        launched -- an enrolled node whose backward did not run in this pass: torch.autograd.grad on a subset, a detached branch --
+        is launched then, and the counter is re-armed for another pass over a retained graph."""
+        if not self._armed:
+            self._armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+
+    def _end_of_backward(self):
+        self._armed = False
+        if self.items:
+            self._launch()
+        self.pending = self.enrolled
+
+    def _launch(self):
+        items, self.items = self.items, []
+        by_tokens = {}
+        for it in items:
+            by_tokens.setdefault(it[0][0].shape[0], []).append(it)
+        for group in by_tokens.values():
+            for i in range(0, len(group), 4):          # DLWP_WGRAD_MAX_PRODUCTS
+                _weight_grad_segments(group[i:i + 4])
+
     def done(self):
+        self._arm()
         self.pending -= 1
+        if self.pending < 0:
+            raise L.DlwpError("WgradBatch: more backward reports than enrolled nodes (a node's backward ran twice inside one pass)")
         if self.pending == 0 and self.items:
-            items, self.items = self.items, []
-            by_tokens = {}
-            for it in items:
-                by_tokens.setdefault(it[0][0].shape[0], []).append(it)
-            for group in by_tokens.values():
-                for i in range(0, len(group), 4):          # DLWP_WGRAD_MAX_PRODUCTS
-                    _weight_grad_segments(group[i:i + 4])
+            self._launch()
 
 
 class _MlpFn(torch.autograd.Function):

@@ -66,6 +66,9 @@ class _SqErr(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pred, target):
+        if pred.dtype != torch.float32 or target.dtype != torch.float32 or pred.shape != target.shape:
+            raise L.DlwpError(f"mse_loss: fp32 tensors of one shape needed (pred {pred.dtype} {tuple(pred.shape)}, target {target.dtype} "
+                              f"{tuple(target.shape)})")
         pred = pred.contiguous()
         target = target.contiguous()
         loss = torch.zeros(1, device=pred.device)
@@ -88,6 +91,11 @@ def mse_loss_and_grad(pred, target, loss_out=None):
     """(mean((pred - target)^2), its gradient with respect to pred) from the one dlwp_mse_fwd_bwd launch, for a caller that seeds
     the backward pass itself (torch.autograd.backward(pred, grad)): no ones_like seed, no seed x gradient product.  loss_out: a
     one-element fp32 tensor that receives the loss (zeroed here; the kernel accumulates into it)."""
+    # the kernel reads raw float pointers: what loss.backward() used to validate is checked here
+    if pred.dtype != torch.float32 or target.dtype != torch.float32:
+        raise L.DlwpError(f"mse_loss_and_grad: fp32 tensors needed (pred {pred.dtype}, target {target.dtype})")
+    if pred.shape != target.shape or pred.device != target.device:
+        raise L.DlwpError(f"mse_loss_and_grad: pred {tuple(pred.shape)} on {pred.device} vs target {tuple(target.shape)} on {target.device}")
     p2 = pred.detach().contiguous()
     loss = torch.zeros(1, device=pred.device) if loss_out is None else loss_out.zero_()
     g = torch.empty_like(p2)

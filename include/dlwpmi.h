@@ -54,6 +54,16 @@ int dlwp_clear_tuning(const char* name);
 int dlwp_get_tuning(const char* name, int* value);
 int dlwp_tuning_list(int index, const char** name, const char** doc);
 
+/* Live per-kernel accounting (csrc/prof.hip; measurement only, no reference counterpart: the reference times whole epochs with    */
+/* time.time(), src/nsbench/scripts/train.py:108,164).  Between dlwp_prof_enable(1) and dlwp_prof_collect() every instrumented      */
+/* launch (the GEMM families, window attention, LayerNorm, segmented weight gradients, FFT passes) is bracketed by two HIP events    */
+/* on its own stream and recorded with its kernel name, algorithmic flops and algorithmic HBM bytes (from the launch arguments).    */
+/* Not recorded under stream capture.  dlwp_prof_collect() blocks until the recorded events have completed, folds the records by    */
+/* kernel name, sorts by total time and returns the number of rows; dlwp_prof_get(i, ...) reads row i (name truncated to name_len). */
+int dlwp_prof_enable(int on);
+int dlwp_prof_collect(void);
+int dlwp_prof_get(int index, char* name, int name_len, long long* calls, double* ms, double* flops, double* bytes);
+
 /* ------------------------------------------------------------------------------------ */
 /* Strided / gathered channel views.  A rollout step reads its input channels straight   */
 /* out of the trajectory buffers (observations or earlier predictions) instead of        */

@@ -71,12 +71,25 @@ def mlp(x, p, pre):
     return F.linear(F.gelu(F.linear(x, p[pre + "fc1.weight"], p[pre + "fc1.bias"])), p[pre + "fc2.weight"], p[pre + "fc2.bias"])
 
 
+def pad_hw(x, pad_b, pad_r, padding_mode):
+    """x [B,H,W,C] padded at the bottom / right (SwinTransformerBlock.forward :219-221).  padding_mode: one mode for both axes
+    (the reference's argument) or a (latitude, longitude) pair -- the dlwpbench intent "constant latitude, circular longitude",
+    which the dlwpbench block itself applies to the wrong axes (:218-222)."""
+    if isinstance(padding_mode, str):
+        return F.pad(x, (0, 0, 0, pad_r, 0, pad_b), mode=padding_mode)
+    if pad_r:
+        x = F.pad(x, (0, 0, 0, pad_r, 0, 0), mode=padding_mode[1])
+    if pad_b:
+        x = F.pad(x, (0, 0, 0, 0, 0, pad_b), mode=padding_mode[0])
+    return x
+
+
 def swin_block(x, p, pre, H, W, ws, shift, heads, labels, padding_mode="constant"):
     B, L, C = x.shape
     shortcut = x
     x = F.layer_norm(x, (C,), p[pre + "norm1.weight"], p[pre + "norm1.bias"]).view(B, H, W, C)
     pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
-    x = F.pad(x, (0, 0, 0, pad_r, 0, pad_b), mode=padding_mode)
+    x = pad_hw(x, pad_b, pad_r, padding_mode)
     Hp, Wp = x.shape[1], x.shape[2]
     if shift > 0:
         x = torch.roll(x, shifts=(-shift, -shift), dims=(1, 2))
@@ -93,7 +106,7 @@ def patch_merging(x, p, pre, H, W, padding_mode="constant"):
     B, L, C = x.shape
     x = x.view(B, H, W, C)
     if H % 2 or W % 2:
-        x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2), mode=padding_mode)
+        x = pad_hw(x, H % 2, W % 2, padding_mode)
     x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1).reshape(B, -1, 4 * C)
     x = F.layer_norm(x, (4 * C,), p[pre + "norm.weight"], p[pre + "norm.bias"])
     return F.linear(x, p[pre + "reduction.weight"])
@@ -200,7 +213,10 @@ def dlwp_basic_layer(x, p, pre, H, W, ws, depth, heads, downsample):
 
 def dlwp_swin_one_step(x, p, cfg):
     """SwinTransformer.one_step (:645-677) with the dlwpbench constructor (:494-608): decoder stage 0 (the last
-    transposed convolution) has kernel = stride = patch_size, the others 2 (:593-594)."""
+    transposed convolution) has kernel = stride = patch_size, the others 2 (:593-594).
+    cfg["window_size"] (an int; NOT a reference key: the reference fixes window = stage resolution, :542,561): classic Swin
+    windows through the nsbench BasicLayer (pinned at window 7 on 32 x 64 / 128 x 256 by c4_window7_golden.npz) with constant
+    latitude / circular longitude padding -- BASELINE configs[3] ("window=7"), which the dlwpbench block cannot run (App. B-6)."""
     ps, E, depths, heads = cfg["patch_size"], cfg["embed_dim"], cfg["depths"], cfg["num_heads"]
     x = F.conv2d(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], stride=ps)
     Wh, Ww = x.shape[2], x.shape[3]
@@ -210,7 +226,11 @@ def dlwp_swin_one_step(x, p, cfg):
     res = (cfg["img_height"] // ps, cfg["img_width"] // ps)
     outs = []
     for i in range(len(depths)):
-        x_out, H, W, x, Wh, Ww = dlwp_basic_layer(x, p, f"layers.{i}.", Wh, Ww, res, depths[i], heads[i], i < len(depths) - 1)
+        if cfg.get("window_size"):
+            x_out, H, W, x, Wh, Ww = basic_layer(x, p, f"layers.{i}.", Wh, Ww, int(cfg["window_size"]), depths[i], heads[i],
+                                                 i < len(depths) - 1, ("constant", "circular"))
+        else:
+            x_out, H, W, x, Wh, Ww = dlwp_basic_layer(x, p, f"layers.{i}.", Wh, Ww, res, depths[i], heads[i], i < len(depths) - 1)
         C = E * 2 ** i
         x_out = F.layer_norm(x_out, (C,), p[f"norm{i}.weight"], p[f"norm{i}.bias"])
         outs.append(x_out.view(-1, H, W, C).permute(0, 3, 1, 2))

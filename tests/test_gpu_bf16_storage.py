@@ -496,3 +496,54 @@ def test_weight_gradient_slab_survives_growth_behind_a_captured_graph(cuda):
         g_small.replay()                              # recorded against the OLD slab
         torch.cuda.synchronize()
         assert torch.equal(small[2], want_small)
+
+
+def _toy_run(cuda, mode):
+    """One _ToyBlock under bf16 storage with gradient slots; mode: "full" (one ordinary backward), "partial" (torch.autograd.grad
+    towards fc2's weight only: the qkv / proj nodes of the block never run), "twice" (two backward passes over a retained graph)."""
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.train_engine import flatten_parameters, refresh_bf16_weights
+    B, T, C, Hd = 2, 256, 64, 128
+    g = torch.Generator().manual_seed(99)
+    x0 = torch.randn(B, T, C, generator=g).to(cuda)
+    gy = torch.randn(B, T, C, generator=g).to(cuda)
+    with L.gemm_precision("bf16"):
+        L.set_storage("bf16")
+        try:
+            torch.manual_seed(1)
+            m = _ToyBlock(C, Hd, 0.0).to(cuda).train()
+            flatten_parameters(m)
+            refresh_bf16_weights(m)
+            L.SHADOW_ACTIVE = True
+            try:
+                y = m(x0.clone())
+                if mode == "full":
+                    y.backward(gy)
+                elif mode == "partial":
+                    torch.autograd.grad(y, [m.mlp.fc2.weight], grad_outputs=gy, allow_unused=True)
+                else:
+                    y.backward(gy, retain_graph=True)
+                    y.backward(gy)
+            finally:
+                L.SHADOW_ACTIVE = False
+        finally:
+            L.set_storage("fp32")
+    torch.cuda.synchronize()
+    return {n: p.grad.clone() for n, p in m.named_parameters()}
+
+
+def test_wgrad_batch_flushes_what_was_reported_when_a_backward_pass_skips_enrolled_nodes(cuda):
+    """Advisor finding (round 5): the block's one weight-gradient launch waited for a counter to reach exactly zero; a pass in which
+    an enrolled node never runs (torch.autograd.grad on a subset) silently dropped the gradients of the layers that DID report.
+    Now the end-of-backward callback launches them."""
+    full, part = _toy_run(cuda, "full"), _toy_run(cuda, "partial")
+    for n in ("mlp.fc1.weight", "mlp.fc2.weight", "mlp.fc1.bias", "mlp.fc2.bias"):
+        assert full[n].abs().sum().item() > 0
+        assert (part[n] - full[n]).abs().max().item() <= 1e-5 * full[n].abs().max().item(), n
+    assert part["qkv.weight"].abs().sum().item() == 0 and part["proj.weight"].abs().sum().item() == 0      # those nodes did not run
+
+
+def test_wgrad_batch_is_rearmed_for_a_second_pass_over_a_retained_graph(cuda):
+    full, twice = _toy_run(cuda, "full"), _toy_run(cuda, "twice")
+    for n in full:          # slots accumulate: two passes leave twice the gradient
+        assert (twice[n] - 2 * full[n]).abs().max().item() <= 2e-3 * full[n].abs().max().item() + 1e-12, n

@@ -95,6 +95,39 @@ def test_dlwp_rollout_matches_reference_loop(ctx, T, cc, cp):
     assert torch.allclose(res[0][1], res[1][1], rtol=1e-4, atol=1e-5)
 
 
+class _NetChannelsLast(_Net):
+    """The same network computed on a channels-last copy of its input: the gradient it hands back for x is a PERMUTED view
+    (dense, but not [C, H, W]-contiguous inside a sample) -- what the patch embeddings of the token models return."""
+
+    def forward(self, x):
+        t = x.permute(0, 2, 3, 1).contiguous()                           # [B, H, W, C]
+        return torch.tanh(torch.einsum("oc,bhwc->bhwo", self.w, t)).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("B", [1, 2])
+@pytest.mark.parametrize("ctx,T", [(1, 4), (2, 5)])
+def test_dlwp_rollout_with_a_channels_last_network_at_any_batch_size(B, ctx, T):
+    """Round 6: at B = 1 the window advance took a channels-last gradient of its flattened window for a contiguous block (a
+    `B == 1` shortcut skipped the density test): every multi-lead-time rollout at batch 1 -- the batch size of the published
+    dlwpbench runs -- trained on wrong gradients."""
+    from dlwp_benchmark_amd.dlwpbench.rollout import rollout
+    dev = _dev()
+    g = torch.Generator().manual_seed(ctx * 10 + T + B)
+    cc, cp, Cg, H, W = 2, 1, 3, 6, 10
+    constants = torch.randn(B, 1, cc, H, W, generator=g).to(dev)
+    prescribed = torch.randn(B, T, cp, H, W, generator=g).to(dev)
+    prognostic = torch.randn(B, T, Cg, H, W, generator=g).to(dev)
+    wt = torch.randn(B, T - ctx, Cg, H, W, generator=g).to(dev)
+    res = []
+    for fn in (_legacy_dlwp, rollout):
+        net = _NetChannelsLast(cc + ctx * (cp + Cg), Cg, 9).to(dev)
+        out = fn(net, ctx, constants, prescribed, prognostic)
+        (out * wt).sum().backward()
+        res.append((out.detach(), net.w.grad.clone()))
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("D,H,W,ph,pw", [(1, 8, 12, 2, 4), (3, 6, 6, 3, 2), (2, 4, 8, 1, 1)])
 def test_advance_patch_layout(D, H, W, ph, pw):
     """delta given as the patch tokens of a linear head equals un-patching with permute + reshape (fourcastnet.py:296-298)."""
