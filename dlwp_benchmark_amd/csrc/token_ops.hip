@@ -56,6 +56,7 @@ struct GemmDev {
     // + residual -- stochastic depth (DropPath) of a residual branch inside the epilogue of the branch's last product
     const float* row_scale = nullptr;
     int scale_rows = 1;
+    int wide_epi = 0;          // gemm_p8_kernel: the register epilogue in 128-byte rows (p8_rows8; needs N % 8 == 0 and 16-byte aligned rows)
 };
 constexpr int DT_A = 1, DT_B = 2, DT_C = 4, DT_R = 8;
 
@@ -371,6 +372,184 @@ __device__ __forceinline__ void epilogue_group(const GemmDev& a, f32x4 (&v)[G], 
         if (ok[i]) put(a.C, o[i], v[i]);
 }
 
+// The same arithmetic on G row pieces of EIGHT consecutive columns n .. n + 7 (v[i][0]: columns n .. n + 3, v[i][1]: n + 4 .. n + 7): one
+// 16-byte piece per lane where the tensor is bf16, two adjacent ones where it is fp32 -- the 256 x 256 kernel's register epilogue
+// (round 6) after its cross-lane transposition, where eight lanes cover 128 bytes of one output row.
+// `fill(v)` produces the G pieces AFTER the residual loads have been issued: the cross-lane transposition of the accumulators then runs
+// under the latency of those loads (in the training step the stored derivative / residual comes from HBM, not from a cache: with two
+// pieces per load -> use -> store round the gh = (g W2) * GELU' product took 187 us in the C5 step against 116 us back to back)
+template <int G, class Fill>
+__device__ __forceinline__ void epilogue_group8(const GemmDev& a, f32x4 (&v)[G][2], const int (&m)[G], int n, const f32x4 (&bv)[2], Fill fill) {
+    const bool col_ok = n < a.N;                       // N % 8 == 0 on this path: a piece is whole or absent
+    auto get = [&](const float* src, int dtbit, long long o, f32x4 (&out)[2]) {
+        if (a.dt & dtbit) {
+            const bf16x8 hv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(src) + o);
+            out[0] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+            out[1] = f32x4{(float)hv[4], (float)hv[5], (float)hv[6], (float)hv[7]};
+        } else {
+            out[0] = *reinterpret_cast<const f32x4*>(src + o);
+            out[1] = *reinterpret_cast<const f32x4*>(src + o + 4);
+        }
+    };
+    auto put = [&](float* dst, long long o, const f32x4 (&val)[2]) {
+        if (a.dt & DT_C) {
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(dst) + o) =
+                bf16x8{(__bf16)val[0][0], (__bf16)val[0][1], (__bf16)val[0][2], (__bf16)val[0][3],
+                       (__bf16)val[1][0], (__bf16)val[1][1], (__bf16)val[1][2], (__bf16)val[1][3]};
+        } else {
+            *reinterpret_cast<f32x4*>(dst + o) = val[0];
+            *reinterpret_cast<f32x4*>(dst + o + 4) = val[1];
+        }
+    };
+    f32x4 rv[G][2];
+    long long o[G];
+    int mrow[G];
+    bool ok[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        ok[i] = col_ok && m[i] < a.M;
+        o[i] = ok[i] ? (long long)m[i] * a.ldc + n : 0;            // masked rows read element 0 (valid memory) and store nothing
+        rv[i][0] = rv[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mrow[i] = ok[i] ? m[i] : 0;
+    }
+    if (a.residual) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) get(a.residual, DT_R, o[i], rv[i]);
+    }
+    fill(v);
+    if (a.bias && a.bias_row) {
+        float br[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) br[i] = a.bias[mrow[i]];
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[i][h][k] += br[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[i][h][k] += bv[h][k];
+    }
+    if (act_is_grad_mul(a.act)) {
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[i][h][k] = act_grad_mul(v[i][h][k], rv[i][h][k], a.act, a.act_param);
+    } else {
+        if (a.res_pre) {
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[i][h][k] += rv[i][h][k];
+        }
+        if (a.act == ACT_GELU_STORE_D) {
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                f32x4 d[2];
+                gelu_both4(v[i][0], v[i][0], d[0]);
+                gelu_both4(v[i][1], v[i][1], d[1]);
+                if (ok[i] && a.preact) put(a.preact, o[i], d);
+            }
+        } else if (a.preact) {
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+                if (ok[i]) put(a.preact, o[i], v[i]);
+        }
+        if (a.act && a.act != ACT_GELU_STORE_D) {
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[i][h][k] = apply_act(v[i][h][k], a.act, a.act_param);
+        }
+        if (a.row_scale) {
+            float sc[G];
+#pragma unroll
+            for (int i = 0; i < G; ++i) sc[i] = a.row_scale[mrow[i] / a.scale_rows];
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[i][h][k] *= sc[i];
+        }
+        if (!a.res_pre && a.residual) {
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[i][h][k] += rv[i][h][k];
+        }
+    }
+    if (a.accumulate) {                                 // (fp32 output only: checked on the host)
+        f32x4 cv[G][2];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            cv[i][0] = *reinterpret_cast<const f32x4*>(a.C + o[i]);
+            cv[i][1] = *reinterpret_cast<const f32x4*>(a.C + o[i] + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[i][h][k] += cv[i][h][k];
+    }
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+        if (ok[i]) put(a.C, o[i], v[i]);
+}
+
+// Cross-lane transposition of one 16-row block of the 256 x 256 kernel's C^T accumulators (lane (r, g) holds, for each of the wave's
+// four 16-column blocks J, columns 16 J + 4 g .. + 3 of row r) into ROW pieces of eight consecutive columns, arranged so that the
+// eight lanes of a row cover its 64 columns (128 bytes of bf16) in ONE store instruction:
+//   step 1, v_permlane16_swap_b32 on (block 2 p, block 2 p + 1): lanes of even g end up with columns 4 g .. 4 g + 7 of block 2 p,
+//           lanes of odd g with columns 4 (g - 1) .. 4 g + 3 of block 2 p + 1 -- a piece X_p starting at column 32 p + 16 (g & 1) + 4 (g & ~1);
+//   step 2, two masked DPP moves (row_ror:8) per register: lanes r < 8 trade X_1 for row r + 8's X_0 -- afterwards
+//           ya = (row r & 7, piece r >> 3), yb = (row 8 + (r & 7), piece r >> 3) with piece columns 32 (r >> 3) + 16 (g & 1) + 4 (g & ~1).
+// 8 + 16 cross-lane instructions per block, no selects.  (round 6; stamps: the 8-byte / 32-bytes-per-row stores of the plain
+// register epilogue took 25 k cycles per 256 x 256 bf16 tile, 43 % of a K = 768 tile)
+#ifndef P8_WIDE_NI
+#define P8_WIDE_NI 1
+#endif
+__device__ __forceinline__ void p8_rows8(const f32x4 (&accI)[4], f32x4 (&ya)[2], f32x4 (&yb)[2]) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    // (whole-vector bit casts and constant element indices: with `v[q]` inside an unrolled loop hipcc (ROCm 7.2) kept only the q = 0
+    // exchange and stored it to every element -- tools/micro/p8_rows8_check.hip)
+    const u4 a0 = __builtin_bit_cast(u4, accI[0]), a1 = __builtin_bit_cast(u4, accI[1]);
+    const u4 a2 = __builtin_bit_cast(u4, accI[2]), a3 = __builtin_bit_cast(u4, accI[3]);
+#define P8_SWAP(A, B, q) const u2 s_##A##_##q = __builtin_amdgcn_permlane16_swap(A.q, B.q, false, false)
+    P8_SWAP(a0, a1, x); P8_SWAP(a0, a1, y); P8_SWAP(a0, a1, z); P8_SWAP(a0, a1, w);
+    P8_SWAP(a2, a3, x); P8_SWAP(a2, a3, y); P8_SWAP(a2, a3, z); P8_SWAP(a2, a3, w);
+#undef P8_SWAP
+    // X_p = {lo, hi}: lo = first operand after the swap, hi = second
+    const i4 x0lo = i4{(int)s_a0_x.x, (int)s_a0_y.x, (int)s_a0_z.x, (int)s_a0_w.x}, x0hi = i4{(int)s_a0_x.y, (int)s_a0_y.y, (int)s_a0_z.y, (int)s_a0_w.y};
+    const i4 x1lo = i4{(int)s_a2_x.x, (int)s_a2_y.x, (int)s_a2_z.x, (int)s_a2_w.x}, x1hi = i4{(int)s_a2_x.y, (int)s_a2_y.y, (int)s_a2_z.y, (int)s_a2_w.y};
+    // ya: lanes r >= 8 (banks 2, 3) take X_1 of lane r - 8, lanes r < 8 keep their X_0;  yb: lanes r < 8 take X_0 of lane r + 8, the others keep X_1
+#define P8_DPP(OLD, SRC, e, MASK) __builtin_amdgcn_update_dpp(OLD.e, SRC.e, 0x128, 0xf, MASK, false)
+    ya[0] = __builtin_bit_cast(f32x4, (i4{P8_DPP(x0lo, x1lo, x, 0xc), P8_DPP(x0lo, x1lo, y, 0xc), P8_DPP(x0lo, x1lo, z, 0xc), P8_DPP(x0lo, x1lo, w, 0xc)}));
+    ya[1] = __builtin_bit_cast(f32x4, (i4{P8_DPP(x0hi, x1hi, x, 0xc), P8_DPP(x0hi, x1hi, y, 0xc), P8_DPP(x0hi, x1hi, z, 0xc), P8_DPP(x0hi, x1hi, w, 0xc)}));
+    yb[0] = __builtin_bit_cast(f32x4, (i4{P8_DPP(x1lo, x0lo, x, 0x3), P8_DPP(x1lo, x0lo, y, 0x3), P8_DPP(x1lo, x0lo, z, 0x3), P8_DPP(x1lo, x0lo, w, 0x3)}));
+    yb[1] = __builtin_bit_cast(f32x4, (i4{P8_DPP(x1hi, x0hi, x, 0x3), P8_DPP(x1hi, x0hi, y, 0x3), P8_DPP(x1hi, x0hi, z, 0x3), P8_DPP(x1hi, x0hi, w, 0x3)}));
+#undef P8_DPP
+}
+
+#ifndef GLDS_EPI_G
+#define GLDS_EPI_G 2          // rows per thread in flight in the 128 x 128 LDS-DMA kernel's epilogue (8 rows per thread and half tile).  4 was measured
+#endif                        // in round 6 (114 -> 168 VGPRs at three waves per SIMD, 7 - 10 spilled): gh 164 -> 158 us, fc1 142 -> 147 us in the C5 step: no gain
 template <int NROWS, int RPP, int C4, int LDE, int G>      // G rows in flight per thread (registers: ~14 G)
 __device__ __forceinline__ void epilogue_rows(const GemmDev& a, const float* tile, int tid, int m_base, int n, const f32x4& bv) {
     static_assert(NROWS % G == 0, "rows per thread come in whole groups");
@@ -704,6 +883,7 @@ int g_gemm_bf16 = 0;    // dlwp_set_gemm_precision
 // chunk position c ^ (2 (kr & 3)); its MFMA fragments come through the hardware transpose read (ds_read_b64_tr_b16, as in
 // TileIO::frag_bf16): per 16-lane group four k-rows x 32 bytes, 32 different banks.
 constexpr int GT = 128, GK = 64;
+
 template <bool BKC, int KD>                                // KD = depth of a K-step: 64 (two workgroups per CU) or 32 (three / four)
 __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmDev a) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
@@ -826,7 +1006,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmDev a) {
                     for (int q = 0; q < 4; ++q) tile[(i * 16 + 4 * g + q) * LDE + wn + j * 16 + r] = acc[i][j][q];
         }
         lds_barrier();
-        epilogue_rows<NPASS, RPP, C4, LDE, 2>(a, tile, tid, m0 + 64 * half, n, bv);
+        epilogue_rows<NPASS, RPP, C4, LDE, GLDS_EPI_G>(a, tile, tid, m0 + 64 * half, n, bv);
     }
     DLWP_STAMP(13);
 }
@@ -1108,7 +1288,8 @@ constexpr int P8T = 256;
 // does not order memory accesses for the optimiser; a read hoisted above the barrier that follows the other group's vmcnt wait
 // would see a half-tile before its DMA has landed)
 __device__ __forceinline__ void p8_barrier() { asm volatile("s_barrier" ::: "memory"); }
-template <bool DIRECT, bool BKC = true>      // BKC = false: B is [k][n] (gx = g W): its half-tile images are [64 k][128 local columns], fragments through the
+template <bool DIRECT, bool BKC = true, bool WIDE = false>      // WIDE: the register epilogue in 128-byte rows (p8_rows8) -- its own instantiation: with both
+                                             // epilogue forms in one kernel the allocator spilled 120 VGPRs.  BKC = false: B is [k][n] (gx = g W): its half-tile images are [64 k][128 local columns], fragments through the
                                              // transposing read (as in gemm_p8_tn_kernel).  DIRECT: accumulate C^T fragments (operands swapped in the MFMA) so that a lane holds four consecutive COLUMNS of a
                             // row and the epilogue stores straight from the registers (no LDS staging, no barriers)
 __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmDev a) {
@@ -1265,7 +1446,31 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmDev a) {
     }
     if (wr == 0) p8_barrier();             // group 0 catches up with group 1's last half-phase
     if (raw == blockIdx.x) DLWP_STAMP(16);
-    if (DIRECT) {
+    if constexpr (DIRECT && WIDE) {
+        // ---- epilogue straight from the registers in 128-byte rows (p8_rows8): eight columns per lane, two pieces per 16-row block
+        const int nw = n0 + wc * 64 + 32 * (r >> 3) + 16 * (g & 1) + 4 * (g & ~1);
+        f32x4 bv8[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        if (a.bias && !a.bias_row && nw < a.N) {
+            bv8[0] = *reinterpret_cast<const f32x4*>(a.bias + nw);
+            bv8[1] = *reinterpret_cast<const f32x4*>(a.bias + nw + 4);
+        }
+        constexpr int NI = P8_WIDE_NI;                 // 16-row blocks per round: 2 NI pieces of eight columns in flight per lane
+#pragma unroll
+        for (int I0 = 0; I0 < 8; I0 += NI) {
+            f32x4 v[2 * NI][2];
+            int m[2 * NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int I = I0 + i;
+                m[2 * i] = m0 + wr * 128 + (I >> 2) * 64 + 16 * (I & 3) + (r & 7);
+                m[2 * i + 1] = m[2 * i] + 8;
+            }
+            epilogue_group8<2 * NI>(a, v, m, nw, bv8, [&](f32x4 (&vv)[2 * NI][2]) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) p8_rows8(acc[I0 + i], vv[2 * i], vv[2 * i + 1]);
+            });
+        }
+    } else if constexpr (DIRECT) {
         // ---- epilogue straight from the registers: acc[I][J][q] = C[row wr * 128 + (I >> 2) * 64 + 16 (I & 3) + r][column wc * 64 + (J >> 1) * 32 + (J & 1) * 16 + 4 g + q]
 #pragma unroll
         for (int J = 0; J < 4; ++J) {
@@ -1549,19 +1754,26 @@ static int gemm_p8_launch(const GemmDev& a_in, bool bkc, hipStream_t s) {
     const size_t lds = (size_t)2 * 4 * 128 * 64 * 2;          // 128 KB: two stages of four half-tile images (the epilogue's 64 x 260 fp32 tile fits inside)
     int rc;
     const bool direct = !dlwp_tune_on("GEMM_P8_STAGED");
+    {   // 128-byte-row register epilogue (round 6): every tensor the epilogue touches in whole, aligned 8-column pieces
+        auto al = [&](const void* p, bool bf) { return !p || (uintptr_t)p % (bf ? 16 : 32) == 0; };
+        a.wide_epi = dlwp_tune_or("GEMM_P8_WIDE", 1) != 0 && a.N % 8 == 0 && a.ldc % 8 == 0 && al(a.C, a.dt & DT_C) && al(a.preact, a.dt & DT_C) &&
+                     al(a.residual, a.dt & DT_R) && (!a.bias || a.bias_row || (uintptr_t)a.bias % 16 == 0);
+    }
     static const int ncu = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n > 0 ? n : 256;
     }();
-#define P8_GO(D_, B_)                                                                                                   \
+#define P8_GO(D_, B_, W_)                                                                                               \
     do {                                                                                                                \
-        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_p8_kernel<D_, B_>), lds, "gemm_p8"))) return rc;   \
-        dlwp_prof_scope prof(s, gemm_prof_flops(a), gemm_prof_bytes(a), "gemm_p8_kernel<%s, %s>", D_ ? "true" : "false", B_ ? "true" : "false"); \
-        hipLaunchKernelGGL((gemm_p8_kernel<D_, B_>), dim3(std::min(a.ntn * a.ntm, ncu)), dim3(512), lds, s, a);         \
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_p8_kernel<D_, B_, W_>), lds, "gemm_p8"))) return rc; \
+        dlwp_prof_scope prof(s, gemm_prof_flops(a), gemm_prof_bytes(a), "gemm_p8_kernel<%s, %s, %s>", D_ ? "true" : "false", B_ ? "true" : "false", \
+                             W_ ? "true" : "false");                                                                     \
+        hipLaunchKernelGGL((gemm_p8_kernel<D_, B_, W_>), dim3(std::min(a.ntn * a.ntm, ncu)), dim3(512), lds, s, a);     \
     } while (0)
-    if (bkc) { if (direct) P8_GO(true, true); else P8_GO(false, true); }
-    else     { if (direct) P8_GO(true, false); else P8_GO(false, false); }
+    if (direct && a.wide_epi) { if (bkc) P8_GO(true, true, true); else P8_GO(true, false, true); }
+    else if (bkc) { if (direct) P8_GO(true, true, false); else P8_GO(false, true, false); }
+    else          { if (direct) P8_GO(true, false, false); else P8_GO(false, false, false); }
 #undef P8_GO
     return DLWP_OK;
 }
@@ -1614,10 +1826,12 @@ static bool gemm_p8_applies(const GemmDev& a, bool akc, bool bkc) {
     const long long tiles = (long long)ceil_div(a.M, P8T) * ceil_div(a.N, P8T);
     const int mink_env = dlwp_tune("GEMM_P8_MINK");
     const int mink = mink_env != DLWP_TUNE_UNSET ? mink_env : 2048;
-    // one workgroup per CU: the last round should be at least 80 % full (16200 x 768 x 3072: 192 tiles = 75 % of one round, the
-    // 128 x 128 LDS-DMA kernel is 0.4 % of the C5 step faster; 18540 rows: 219 tiles = 86 %, this kernel 4 % faster -- round 5)
+    // one workgroup per CU: the last round should be at least 70 % full.  Round 5 asked for 80 % (16200 x 768 x 3072: 192 tiles = 75 % of one
+    // round, where the 128 x 128 LDS-DMA kernel was then 0.4 % of the C5 step faster); with the 128-byte-row epilogue (round 6) this kernel
+    // wins there: C5 720 x 1440 step 16.25 -> 16.08 ms, 721 x 1440 / Pangu / Swin unchanged (profiles/r06_gemm_p8_dispatch_sweep.txt)
     const long long rounds = (tiles + 255) / 256;
-    const bool fills = tiles >= 128 && 5 * tiles >= 4 * rounds * 256;
+    const int fill_pct = dlwp_tune_or("GEMM_P8_FILL", 70);
+    const bool fills = tiles >= 128 && 100 * tiles >= (long long)fill_pct * rounds * 256;
     return env_on || g_gemm_tile256 > 0 || (a.K >= mink && fills);
 }
 

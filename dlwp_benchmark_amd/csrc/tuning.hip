@@ -31,6 +31,8 @@ Knob g_knobs[] = {
     {"GEMM_P8", "1: use the 256 x 256 two-group kernel wherever it applies", 0, false},
     {"GEMM_P8_STAGED", "1: the 256 x 256 kernel's four-pass LDS-staged epilogue instead of the register epilogue", 0, false},
     {"GEMM_P8_MINK", "least K for the 256 x 256 kernel (default 2048)", 0, false},
+    {"GEMM_P8_FILL", "least fill (percent) of the 256 x 256 kernel's last round of workgroups for the kernel to be taken by shape (default 70)", 0, false},
+    {"GEMM_P8_WIDE", "0: the 256 x 256 kernel's register epilogue with 8-byte / 16-byte pieces per lane instead of 128-byte rows (round-5 form)", 0, false},
     {"GEMM_NOP8_TN", "1: never use the 256 x 256 weight-gradient kernel", 0, false},
     {"GEMM_TILE", "64 or 128: tile edge of the register-staged GEMM (default by shape)", 0, false},
     {"GEMM_TILE128_MINN", "narrowest output the 128 x 128 GEMM tile is considered for (default 128)", 0, false},

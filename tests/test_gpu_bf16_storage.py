@@ -547,3 +547,46 @@ def test_wgrad_batch_is_rearmed_for_a_second_pass_over_a_retained_graph(cuda):
     full, twice = _toy_run(cuda, "full"), _toy_run(cuda, "twice")
     for n in full:          # slots accumulate: two passes leave twice the gradient
         assert (twice[n] - 2 * full[n]).abs().max().item() <= 2e-3 * full[n].abs().max().item() + 1e-12, n
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 520, 192), (4100, 768, 1024), (16200, 3072, 768)])
+@pytest.mark.parametrize("form", ["fc1_gelu_stored_derivative", "gh_times_stored_derivative", "fc2_bias_residual_fp32", "plain_bf16"])
+def test_tile256_wide_row_epilogue_is_the_narrow_one_bit_for_bit(cuda, M, N, K, form):
+    """gemm_p8_kernel's register epilogue in 128-byte rows (round 6: v_permlane16_swap + masked DPP transposition of the C^T
+    accumulators, epilogue_group8) against the round-5 form (8-byte pieces, DLWP_GEMM_P8_WIDE=0): the same element-wise arithmetic on
+    the same accumulators, so every output -- activation, stored derivative, bf16 or fp32 -- must agree BIT FOR BIT, edge tiles
+    included."""
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.token_ops import _gemm, _gemm_batched
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(cuda).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(cuda).to(torch.bfloat16)
+    wt = w.t().contiguous()                                                  # [K][N]: the "NN" operand form
+    bias = torch.randn(N, generator=g).to(cuda)
+    zd = torch.randn(M, N, generator=g).to(cuda).to(torch.bfloat16)
+    res = torch.randn(M, N, generator=g).to(cuda)
+    outs = {}
+    L.set_gemm_tile256(1)
+    try:
+        with L.gemm_precision("bf16"):
+            for wide in (1, 0):
+                L.set_tuning("GEMM_P8_WIDE", wide)
+                y = torch.full((M, N), 3.0, device=cuda, dtype=torch.float32 if form == "fc2_bias_residual_fp32" else torch.bfloat16)
+                z = torch.full((M, N), 5.0, device=cuda, dtype=torch.bfloat16)
+                if form == "fc1_gelu_stored_derivative":
+                    _gemm(x, w, y, M, N, K, K, K, N, 0, 1, bias, 7, z, None)
+                elif form == "gh_times_stored_derivative":
+                    _gemm_batched(x, wt, y, M, N, K, K, N, N, 0, 0, act=8, residual=zd)
+                elif form == "fc2_bias_residual_fp32":
+                    _gemm(x, w, y, M, N, K, K, K, N, 0, 1, bias, 0, None, res)
+                else:
+                    _gemm(x, w, y, M, N, K, K, K, N, 0, 1)
+                torch.cuda.synchronize()
+                outs[wide] = (y.clone(), z.clone())
+    finally:
+        L.set_tuning("GEMM_P8_WIDE", None)
+        L.set_gemm_tile256(0)
+    assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1])
+    ref = x.double() @ w.double().T
+    if form == "plain_bf16":
+        assert ((outs[1][0].double() - ref).abs().max() / ref.abs().max()).item() <= 1e-2

@@ -78,7 +78,7 @@ def test_tall_column_sum_overwrite_is_correct_under_graph_replay(cuda, T, N):
         assert rel(out, x.double().sum(0)) <= 1e-5, rep
 
 
-@pytest.mark.parametrize("H,W,B", [(32, 64, 2), (20, 36, 1), (21, 42, 1)])
+@pytest.mark.parametrize("H,W,B", [(32, 64, 2), (20, 36, 1), (28, 42, 1)])
 def test_dlwp_swin_window7_matches_oracle(cuda, H, W, B):
     """dlwpbench SwinTransformer with the extra kwarg window_size = 7 (BASELINE configs[3]; the reference class fixes window = stage
     resolution and its block cannot pad) against oracle/swin_ref.dlwp_swin: nsbench BasicLayer arithmetic (pinned to

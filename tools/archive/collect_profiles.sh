@@ -2,7 +2,7 @@
 # Round-end evidence run on the GPU box (one gpurun call): bench line, rocprofv3 kernel statistics of the headline step and
 # of the roofline probe, PMC traffic passes, and the supplementary model benches.  Everything lands in gpurun_out/final/.
 #   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh'
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/final
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp

@@ -3,7 +3,7 @@
 # the headline step / the wide step / the probes / the FFT kernels, PMC traffic passes (FETCH_SIZE and WRITE_SIZE in SEPARATE
 # passes, MI355X_MICROARCH.md), supplementary model benches.  Everything lands in gpurun_out/final_r02/.
 #   gpurun --timeout 1190 -- 'bash tools/collect_profiles_r02.sh'
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/final_r02
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp

@@ -3,7 +3,7 @@
 # gpurun_out/final_r03/ and tools/publish_profiles_r03.sh copies the summaries into profiles/.
 #   gpurun --timeout 1190 -- 'bash tools/collect_profiles_r03.sh a'     headline: bench lines, step profile, PMC traffic, B sweep
 #   gpurun --timeout 1190 -- 'bash tools/collect_profiles_r03.sh b'     C3-C5 lines and step profiles, FFT / GEMM / attention probes
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/final_r03
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy the summaries of gpurun_out/final/ (tools/collect_profiles.sh) into profiles/ under the round's names.
 #   bash tools/publish_profiles.sh [round tag, default r01]
-R=$(cd "$(dirname "$0")/.." && pwd)
+R=$(cd "$(dirname "$0")/../.." && pwd)
 T=${1:-r01}
 F=$R/gpurun_out/final
 P=$R/profiles

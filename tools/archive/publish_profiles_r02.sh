@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy the summaries of gpurun_out/final_r02/ (tools/collect_profiles_r02.sh) into profiles/ under the round's names.
-R=$(cd "$(dirname "$0")/.." && pwd)
+R=$(cd "$(dirname "$0")/../.." && pwd)
 T=r02
 F=$R/gpurun_out/final_r02
 P=$R/profiles

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy the summaries of gpurun_out/final_r03/ (tools/collect_profiles_r03.sh a / b) into profiles/ under the round's names.
-R=$(cd "$(dirname "$0")/.." && pwd)
+R=$(cd "$(dirname "$0")/../.." && pwd)
 T=r03
 F=$R/gpurun_out/final_r03
 P=$R/profiles

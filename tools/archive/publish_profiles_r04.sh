@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy the summaries of gpurun_out/final_r04/ (tools/collect_profiles_r04.sh a / b) into profiles/ under the round's names.
-R=$(cd "$(dirname "$0")/.." && pwd)
+R=$(cd "$(dirname "$0")/../.." && pwd)
 T=r04
 F=$R/gpurun_out/final_r04
 P=$R/profiles

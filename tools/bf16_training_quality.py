@@ -14,13 +14,16 @@ family and seed the SAME data stream and the SAME initial weights are trained in
 
     fp32        the HIP fp32 path (exact-fp32 MFMA; oracle-equal at 1e-4, tests/test_gpu_sfno.py, test_gpu_afno.py)
     bf16        bf16 operands + bf16 storage: what bench.py measures for configs[2] - [4]
-    bf16_fp32spectra   (AFNO only) the same with DLWP_AFNO_SPECTRA_BF16 off: spectrum window fp32 between the transforms
+    bf16_fp32spectra   (AFNO only) the same with the spectrum window kept fp32 between the transforms (the default since round 6)
+    bf16_spectra       (AFNO only) bf16 storage INCLUDING the spectrum window (round 5's default, DLWP_AFNO_SPECTRA_BF16=1)
+    bf16_operands      (SFNO only) bf16 operands with fp32 storage: what the operand rounding alone costs
 
-and then rolled out closed loop on held-out fields (lead times 1 .. 4 from one observed frame).  Families: SFNO2DModule at the
-sfno.yaml widths on 32 x 64 (BASELINE configs[2]) and AFNONet with the benchmarked FourCastNet widths (E = 768, depth 12, 16 blocks,
-patch 8) on a 360 x 720 grid (45 x 90 tokens: the rFFT2 path of configs[4], a quarter of its tokens).
+and then rolled out closed loop on held-out fields (lead times 1 .. 4 from one observed frame) at several points of the training
+(the bf16 rounding floor only shows once the error is small).  Families: SFNO2DModule at the sfno.yaml widths on 32 x 64 (BASELINE
+configs[2]) and AFNONet with the benchmarked FourCastNet widths (E = 768, 16 blocks, patch 8; depth 6 of 12) on a 360 x 720 grid
+(45 x 90 tokens: the rFFT2 path of configs[4], a quarter of its tokens).
 
-    python tools/bf16_training_quality.py [--steps-sfno 1000 --steps-afno 600 --seeds 3]   -> profiles/r06_bf16_training_quality.json
+    python tools/bf16_training_quality.py [--steps-sfno 2000 --steps-afno 1500 --seeds 3]   -> profiles/r06_bf16_training_quality.json
 """
 import argparse
 import json
@@ -93,22 +96,22 @@ FAMILIES = {
                  model=dict(constant_channels=4, prescribed_channels=1, prognostic_channels=5, grid="equiangular", num_layers=4, scale_factor=1,
                             embed_dim=256, context_size=1, height=32, width=64, big_skip=True, pos_embed=True, use_mlp=True,
                             normalization_layer="none"),
-                 modes=("fp32", "bf16")),
-    "afno": dict(cls="AFNONet", H=360, W=720, Cg=8, B=4, T=2, lr=5e-4, shift=3.0,
+                 modes=("fp32", "bf16", "bf16_operands")),
+    # lr 2e-4: at 5e-4 (first run of this script, kept in the JSON as "first_run") the 72 M parameter network's loss jumped by 4 x between
+    # checkpoints and its closed-loop error sat ABOVE persistence in every arithmetic: nothing to compare
+    "afno": dict(cls="AFNONet", H=360, W=720, Cg=8, B=4, T=2, lr=2e-4, shift=3.0,
                  model=dict(img_height=360, img_width=720, patch_size=(8, 8), constant_channels=4, prescribed_channels=1,
-                            prognostic_channels=8, embed_dim=768, depth=12, mlp_ratio=4.0, num_blocks=16, context_size=1),
-                 modes=("fp32", "bf16", "bf16_fp32spectra")),
+                            prognostic_channels=8, embed_dim=768, depth=6, mlp_ratio=4.0, num_blocks=16, context_size=1),
+                 modes=("fp32", "bf16_fp32spectra", "bf16_spectra")),
 }
 
 
 def set_mode(mode):
-    if mode == "fp32":
-        L.set_storage("fp32")
-        L.set_gemm_precision("fp32")
-    else:
-        L.set_gemm_precision("bf16")
+    L.set_storage("fp32")
+    L.set_gemm_precision("fp32" if mode == "fp32" else "bf16")
+    if mode not in ("fp32", "bf16_operands"):
         L.set_storage("bf16")
-    afno_tiled._SPECTRA_BF16 = mode != "bf16_fp32spectra"
+    afno_tiled._SPECTRA_BF16 = mode == "bf16_spectra"
 
 
 def evaluate(model, task, batches, B, T_eval, seed):
@@ -134,7 +137,7 @@ def evaluate(model, task, batches, B, T_eval, seed):
     return (se / n).sqrt().tolist(), (se_p / n).sqrt().tolist()
 
 
-def run(family, mode, seed, steps, device, log_every=0):
+def run(family, mode, seed, steps, device, log_every=0, eval_at=()):
     cfg = FAMILIES[family]
     set_mode(mode)
     task = AdvectionTask(cfg["H"], cfg["W"], cfg["Cg"], device, shift=cfg["shift"])
@@ -143,7 +146,7 @@ def run(family, mode, seed, steps, device, log_every=0):
     gen = torch.Generator(device=device).manual_seed(seed)
     c, f, x = task.sample(cfg["B"], cfg["T"], gen)
     step = GraphedTrainStep(model, dict(constants=c, prescribed=f, prognostic=x), x[:, 1:].contiguous(), lr=cfg["lr"], clip_max_norm=None)
-    losses = []
+    losses, at = [], {}
     t0 = time.perf_counter()
     for i in range(steps):
         c, f, x = task.sample(cfg["B"], cfg["T"], gen)
@@ -152,52 +155,78 @@ def run(family, mode, seed, steps, device, log_every=0):
             losses.append(round(loss.item(), 6))
             if log_every and i % log_every == log_every - 1:
                 print(f"  {family} {mode} seed {seed} step {i + 1}: loss {losses[-1]:.5f}", flush=True)
+        if (i + 1) in eval_at and i + 1 < steps:
+            r_, _ = evaluate(model, task, batches=4, B=cfg["B"], T_eval=5, seed=seed)
+            at[str(i + 1)] = {"closed_loop_rmse": (sum(v * v for v in r_) / len(r_)) ** 0.5, "lead1_rmse": r_[0]}
+            model.train()
     torch.cuda.synchronize()
     train_s = time.perf_counter() - t0
     rmse, pers = evaluate(model, task, batches=4, B=cfg["B"], T_eval=5, seed=seed)
+    at[str(steps)] = {"closed_loop_rmse": (sum(v * v for v in rmse) / len(rmse)) ** 0.5, "lead1_rmse": rmse[0]}
     del step, model
     torch.cuda.empty_cache()
     return {"family": family, "mode": mode, "seed": seed, "steps": steps, "train_s": round(train_s, 2), "loss_every_50": losses,
             "closed_loop_rmse_per_lead": [round(v, 6) for v in rmse], "closed_loop_rmse": round(sum(v * v for v in rmse) / len(rmse), 8) ** 0.5,
-            "persistence_rmse": round(sum(v * v for v in pers) / len(pers), 8) ** 0.5}
+            "lead1_rmse": rmse[0], "at_step": at,
+            "persistence_rmse": round(sum(v * v for v in pers) / len(pers), 8) ** 0.5, "persistence_lead1_rmse": pers[0]}
 
 
 def summarise(runs):
+    """per family and training length: mean over seeds of each mode's closed-loop / lead-1 RMSE, its ratio to the fp32 mean and the
+    seed-paired ratios (same data stream, same initial weights)."""
     out = {}
     for fam in sorted({r["family"] for r in runs}):
         fr = [r for r in runs if r["family"] == fam]
         modes = sorted({r["mode"] for r in fr}, key=lambda m: (m != "fp32", m))
-        ref = {r["seed"]: r["closed_loop_rmse"] for r in fr if r["mode"] == "fp32"}
-        fam_out = {"persistence_rmse": fr[0]["persistence_rmse"]}
-        for m in modes:
-            vals = {r["seed"]: r["closed_loop_rmse"] for r in fr if r["mode"] == m}
-            v = list(vals.values())
-            mean = sum(v) / len(v)
-            sd = (sum((a - mean) ** 2 for a in v) / max(1, len(v) - 1)) ** 0.5
-            paired = [vals[s] / ref[s] for s in vals if s in ref]
-            fam_out[m] = {"closed_loop_rmse_by_seed": vals, "mean": mean, "sd_over_seeds": sd, "mean_over_fp32_mean": mean / (sum(ref.values()) / len(ref)),
-                          "paired_ratio_to_fp32_by_seed": paired, "paired_ratio_mean": sum(paired) / len(paired)}
+        fam_out = {"persistence_rmse": fr[0]["persistence_rmse"], "persistence_lead1_rmse": fr[0]["persistence_lead1_rmse"]}
+        for step in sorted({k for r in fr for k in r["at_step"]}, key=int):
+            for metric in ("closed_loop_rmse", "lead1_rmse"):
+                ref = {r["seed"]: r["at_step"][step][metric] for r in fr if r["mode"] == "fp32" and step in r["at_step"]}
+                row = {}
+                for m in modes:
+                    vals = {r["seed"]: r["at_step"][step][metric] for r in fr if r["mode"] == m and step in r["at_step"]}
+                    if not vals:
+                        continue
+                    v = list(vals.values())
+                    mean = sum(v) / len(v)
+                    sd = (sum((a - mean) ** 2 for a in v) / max(1, len(v) - 1)) ** 0.5
+                    row[m] = {"mean": mean, "sd_over_seeds": sd, "by_seed": vals}
+                    if ref:
+                        row[m]["over_fp32_mean"] = mean / (sum(ref.values()) / len(ref))
+                        row[m]["paired_ratio_by_seed"] = {s_: vals[s_] / ref[s_] for s_ in vals if s_ in ref}
+                fam_out[f"after_{step}_steps.{metric}"] = row
         out[fam] = fam_out
     return out
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--steps-sfno", type=int, default=1000)
-    ap.add_argument("--steps-afno", type=int, default=600)
+    ap.add_argument("--steps-sfno", type=int, default=2000)
+    ap.add_argument("--steps-afno", type=int, default=1500)
     ap.add_argument("--seeds", type=int, default=3)
     ap.add_argument("--families", default="sfno,afno")
+    ap.add_argument("--modes", default=None, help="comma list: only these modes (default: all of the family)")
+    ap.add_argument("--merge", default=None, help="a JSON written by an earlier call whose runs are kept (same protocol, other modes)")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06_bf16_training_quality.json"))
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     runs = []
+    if a.merge and os.path.isfile(a.merge):
+        runs = [r for r in json.load(open(a.merge))["runs"] if "at_step" in r]
     for fam in a.families.split(","):
         steps = a.steps_sfno if fam == "sfno" else a.steps_afno
+        eval_at = tuple(steps // d for d in (8, 4, 2))
         for seed in range(a.seeds):
             for mode in FAMILIES[fam]["modes"]:
-                r = run(fam, mode, seed, steps, dev, log_every=200)
+                if a.modes and mode not in a.modes.split(","):
+                    continue
+                if any(r["family"] == fam and r["mode"] == mode and r["seed"] == seed and r["steps"] == steps for r in runs):
+                    continue
+                r = run(fam, mode, seed, steps, dev, log_every=500, eval_at=eval_at)
                 runs.append(r)
-                print(json.dumps({k: r[k] for k in ("family", "mode", "seed", "train_s", "closed_loop_rmse", "persistence_rmse")}), flush=True)
+                print(json.dumps({k: r[k] for k in ("family", "mode", "seed", "train_s", "closed_loop_rmse", "lead1_rmse", "persistence_rmse")}),
+                      flush=True)
+                json.dump({"runs": runs}, open(a.out + ".partial", "w"))
     set_mode("fp32")
     doc = {"task": __doc__.split("\n\n")[1], "protocol": {"steps": {"sfno": a.steps_sfno, "afno": a.steps_afno}, "seeds": a.seeds,
                                                            "families": {k: {kk: vv for kk, vv in v.items() if kk != "modes"} for k, v in FAMILIES.items()},
@@ -205,6 +234,8 @@ def main():
                                                                          "all lead times; each mode evaluated in its own arithmetic"},
            "summary": summarise(runs), "runs": runs}
     json.dump(doc, open(a.out, "w"), indent=1)
+    if os.path.isfile(a.out + ".partial"):
+        os.remove(a.out + ".partial")
     print(json.dumps(doc["summary"], indent=1))
 
 
