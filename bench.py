@@ -490,7 +490,8 @@ def sfno_spectral_probe(device, B, kind, reps=100, K=32, N=64, C=256, M=32, Lm=3
                        flops, spec_bytes * live + field_bytes, sec)
 
 
-SFNO_PROFILE_CSV = {16: "r05_bf16_storage_sfno_b16_step_kernel_stats.csv", 4: "r05_bf16_storage_sfno_step_kernel_stats.csv"}
+SFNO_PROFILE_CSV = {16: ["r06_bf16_storage_sfno_b16_step_kernel_stats.csv", "r05_bf16_storage_sfno_b16_step_kernel_stats.csv"],
+                    4: ["r06_bf16_storage_sfno_step_kernel_stats.csv", "r05_bf16_storage_sfno_step_kernel_stats.csv"]}          # newest first
 
 
 def sfno_dominant_probe(device, B):
@@ -498,7 +499,11 @@ def sfno_dominant_probe(device, B):
     live.  Falls back to the block tail's forward launch when the CSV of this batch size is absent."""
     import csv
     share, top = None, "mlp_chain_kernel<256, 256, 512, 256, 2, false>"
-    path = os.path.join(ROOT, "profiles", SFNO_PROFILE_CSV.get(B, ""))
+    path = ""
+    for name in SFNO_PROFILE_CSV.get(B, []):
+        if os.path.isfile(os.path.join(ROOT, "profiles", name)):
+            path = os.path.join(ROOT, "profiles", name)
+            break
     if os.path.isfile(path):
         rows = list(csv.DictReader(open(path)))
         if rows:

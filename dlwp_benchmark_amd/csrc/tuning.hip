@@ -45,6 +45,8 @@ Knob g_knobs[] = {
     {"LN_BWD_WANT", "workgroups of the scalar LayerNorm backward kernel", 0, false},
     {"LN_BWD_NOWIDE", "1: never use the wide-row LayerNorm backward kernel", 0, false},
     {"LN_BWD_WGS", "workgroups of the wide-row LayerNorm backward kernel (default 384)", 0, false},
+    {"WINATTN_D48", "0: head dims 33 .. 48 stay on the tiled window-attention kernels (default 1: windows of at most 64 tokens take the wave-per-window forward and the LDS-staged two-pass backward in the bf16 matrix mode)", 0, false},
+    {"WINATTN_SMALL_MIN_PAIRS", "least (window, head) pairs for the head-dim-48 route of the wave-per-window family (default 1024)", 0, false},
     {"WINATTN_TILED", "1: the tiled window-attention kernels also for many short windows", 0, false},
     {"WINATTN_WG_BWD", "workgroup width selector of the wave-per-window attention backward", 0, false},
     {"WINATTN_NOLDS", "1: the register-fragment attention backward instead of the LDS-staged one", 0, false},

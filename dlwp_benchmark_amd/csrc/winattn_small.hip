@@ -570,11 +570,17 @@ typedef unsigned short bf16_t;
 constexpr int LDB = 36;        // bf16 elements per staged row (32 + 4: 72 B, 8-byte aligned, rows 18 banks apart)
 
 // row fragment: four consecutive channels of one staged row; column fragment: one channel of four consecutive rows
-__device__ __forceinline__ s16x4 lds_row(const bf16_t* m, int row, int c0) { return *reinterpret_cast<const s16x4*>(m + row * LDB + c0); }
+// LB = row pitch in bf16 elements: LDB for head dims up to 32; LDB48 (48 + 4: 104-byte rows, still 8-byte aligned) for head dims up to 48
+// (round 6: Swin C4 stage 1 has 192 channels on 4 heads -- the two-pass backward and the wave-per-window forward take it; the one-pass and
+// token-layout kernels stay at 32)
+constexpr int LDB48 = 52;
+template <int LB = LDB>
+__device__ __forceinline__ s16x4 lds_row(const bf16_t* m, int row, int c0) { return *reinterpret_cast<const s16x4*>(m + row * LB + c0); }
+template <int LB = LDB>
 __device__ __forceinline__ s16x4 lds_col(const bf16_t* m, int row0, int c) {
     s16x4 v;
 #pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) v[s2] = (short)m[(row0 + s2) * LDB + c];
+    for (int s2 = 0; s2 < 4; ++s2) v[s2] = (short)m[(row0 + s2) * LB + c];
     return v;
 }
 
@@ -584,19 +590,20 @@ struct LdsWin {
     int *ia, *ib, *lab;
     unsigned long long* gtb;
 };
+template <int LB = LDB>
 __device__ __forceinline__ LdsWin lds_carve(void* smem, int NR, int TB, bool bwd) {
     LdsWin L;
     bf16_t* h = reinterpret_cast<bf16_t*>(smem);
-    L.Q = h; L.K = L.Q + NR * LDB; L.V = L.K + NR * LDB; L.G = L.V + NR * LDB;
-    float* f = reinterpret_cast<float*>(L.G + (bwd ? NR * LDB : 0));
+    L.Q = h; L.K = L.Q + NR * LB; L.V = L.K + NR * LB; L.G = L.V + NR * LB;
+    float* f = reinterpret_cast<float*>(L.G + (bwd ? NR * LB : 0));
     L.D = f; L.lse = f + NR;
     L.ia = reinterpret_cast<int*>(f + 2 * NR); L.ib = L.ia + NR; L.lab = L.ib + NR;
     L.tb = reinterpret_cast<float*>(L.lab + NR);
     L.gtb = reinterpret_cast<unsigned long long*>(L.tb + ((TB + 1) & ~1));
     return L;
 }
-static size_t lds_bytes(int NR, int TB, bool bwd) {
-    return (size_t)(bwd ? 4 : 3) * NR * LDB * 2 + (size_t)5 * NR * 4 + (size_t)((TB + 1) & ~1) * 4 + (bwd ? (size_t)TB * 8 : 0);
+static size_t lds_bytes(int NR, int TB, bool bwd, int lb = LDB) {
+    return (size_t)(bwd ? 4 : 3) * NR * lb * 2 + (size_t)5 * NR * 4 + (size_t)((TB + 1) & ~1) * 4 + (bwd ? (size_t)TB * 8 : 0);
 }
 // A workgroup owns one (window type, head) and walks the windows m = grp, grp + groups, ... of that type one after the other:
 // the bias-table slice is staged once and the bias-gradient partials are flushed once per workgroup (one workgroup per window
@@ -619,17 +626,19 @@ __device__ __forceinline__ void who_window(const WsDev& a, Who& w, int m) {
     w.b = w.ty + a.ntypes * m;
     w.wdw = w.b % a.nW;
 }
-// stage the window: q (x scale), k, v [, dO, D = rowsum(dO o), lse] + index vectors; 8 threads per token (16 B each)
-template <bool BWD>
+// stage the window: q (x scale), k, v [, dO, D = rowsum(dO o), lse] + index vectors; TPT threads per token (16 B each): 8 for head dims up to
+// 32, 16 for head dims up to 48 (twelve of them carry channels)
+template <bool BWD, int LB = LDB, int TPT = 8>
 __device__ __forceinline__ void lds_stage(const WsDev& a, const Who& w, const LdsWin& L, int NR) {
-    const int N = a.N, d = a.d, tid = threadIdx.x, ch = tid & 7;
+    const int N = a.N, d = a.d, tid = threadIdx.x, ch = tid & (TPT - 1);
     const long long rs = 3LL * a.heads * d, os = (long long)a.heads * d;
     const float* qb = a.qkv + (long long)w.b * N * rs + w.head * d;
     const float* gb = BWD ? a.gout + (long long)w.b * N * os + w.head * d : nullptr;
     const float* ob = BWD ? a.o + (long long)w.b * N * os + w.head * d : nullptr;
     const long long stat = ((long long)w.b * a.heads + w.head) * N;
-    for (int tok = tid >> 3; tok < NR; tok += 32) {
+    for (int tok = tid / TPT; tok < NR; tok += 256 / TPT) {
         const bool ok = tok < N && 4 * ch < d;
+        const bool st = 4 * ch < LB - 4;                    // this lane's chunk exists in the row (TPT = 16: chunks 12 .. 15 do not)
         const int tc = tok < N ? tok : N - 1, cc = 4 * ch < d ? 4 * ch : 0;        // clamped: unconditional loads
         const float* row = qb + (long long)tc * rs + cc;
         f32x4 q = *reinterpret_cast<const f32x4*>(row);
@@ -644,13 +653,16 @@ __device__ __forceinline__ void lds_stage(const WsDev& a, const Who& w, const Ld
         if (!ok) { q = z; k = z; v = z; g = z; o = z; }
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) q[s2] *= a.scale;
-        *reinterpret_cast<s16x4*>(L.Q + tok * LDB + 4 * ch) = pack_bf(q);
-        *reinterpret_cast<s16x4*>(L.K + tok * LDB + 4 * ch) = pack_bf(k);
-        *reinterpret_cast<s16x4*>(L.V + tok * LDB + 4 * ch) = pack_bf(v);
+        if (st) {
+            *reinterpret_cast<s16x4*>(L.Q + tok * LB + 4 * ch) = pack_bf(q);
+            *reinterpret_cast<s16x4*>(L.K + tok * LB + 4 * ch) = pack_bf(k);
+            *reinterpret_cast<s16x4*>(L.V + tok * LB + 4 * ch) = pack_bf(v);
+        }
         if (BWD) {
-            *reinterpret_cast<s16x4*>(L.G + tok * LDB + 4 * ch) = pack_bf(g);
+            if (st) *reinterpret_cast<s16x4*>(L.G + tok * LB + 4 * ch) = pack_bf(g);
             float dp = g[0] * o[0] + g[1] * o[1] + g[2] * o[2] + g[3] * o[3];
             dp += __shfl_xor(dp, 1); dp += __shfl_xor(dp, 2); dp += __shfl_xor(dp, 4);
+            if (TPT == 16) dp += __shfl_xor(dp, 8);
             if (ch == 0) L.D[tok] = dp;
         }
     }
@@ -667,8 +679,9 @@ __device__ __forceinline__ void lds_stage(const WsDev& a, const Who& w, const Ld
 template <int NDB>
 __global__ __launch_bounds__(256) void winattn_lds_bwd_kernel(WsDev a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LB = NDB <= 2 ? LDB : LDB48, TPT = NDB <= 2 ? 8 : 16;
     const int N = a.N, d = a.d, NCr = (N + 15) / 16, NR = 16 * NCr;
-    const LdsWin L = lds_carve(smem, NR, a.TB, true);
+    const LdsWin L = lds_carve<LB>(smem, NR, a.TB, true);
     int grp;
     Who w = who_lds(a, grp);
     stage_table(L.tb, a, w);
@@ -680,7 +693,7 @@ __global__ __launch_bounds__(256) void winattn_lds_bwd_kernel(WsDev a) {
     for (int m = grp; m < a.M; m += a.groups) {
     who_window(a, w, m);
     __syncthreads();                       // the previous window's fragments have been read (and tb / gtb are initialised)
-    lds_stage<true>(a, w, L, NR);
+    lds_stage<true, LB, TPT>(a, w, L, NR);
     float* gq = a.gqkv + (long long)w.b * N * rs + w.head * d;
     // query rows outside the computed chunks: zero query gradient (they carry no upstream gradient)
     for (int e = threadIdx.x; e < N * (d >> 2); e += 256) {
@@ -697,8 +710,8 @@ __global__ __launch_bounds__(256) void winattn_lds_bwd_kernel(WsDev a) {
         f32x4 dq[NDB];
 #pragma unroll
         for (int cc = 0; cc < NDB; ++cc) {
-            qf[cc] = lds_row(L.Q, q, 16 * cc + 4 * g);
-            gf[cc] = lds_row(L.G, q, 16 * cc + 4 * g);
+            qf[cc] = lds_row<LB>(L.Q, q, 16 * cc + 4 * g);
+            gf[cc] = lds_row<LB>(L.G, q, 16 * cc + 4 * g);
             dq[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll 1
@@ -706,8 +719,8 @@ __global__ __launch_bounds__(256) void winattn_lds_bwd_kernel(WsDev a) {
             f32x4 sT = f32x4{0.f, 0.f, 0.f, 0.f}, dpT = sT;
 #pragma unroll
             for (int cc = 0; cc < NDB; ++cc) {
-                sT = mfma_bf(lds_row(L.K, 16 * kc + r, 16 * cc + 4 * g), qf[cc], sT);
-                dpT = mfma_bf(lds_row(L.V, 16 * kc + r, 16 * cc + 4 * g), gf[cc], dpT);
+                sT = mfma_bf(lds_row<LB>(L.K, 16 * kc + r, 16 * cc + 4 * g), qf[cc], sT);
+                dpT = mfma_bf(lds_row<LB>(L.V, 16 * kc + r, 16 * cc + 4 * g), gf[cc], dpT);
             }
             f32x4 dsT;
 #pragma unroll
@@ -723,7 +736,7 @@ __global__ __launch_bounds__(256) void winattn_lds_bwd_kernel(WsDev a) {
             }
             const s16x4 dsb = pack_bf(dsT);
 #pragma unroll
-            for (int db = 0; db < NDB; ++db) dq[db] = mfma_bf(lds_col(L.K, 16 * kc + 4 * g, 16 * db + r), dsb, dq[db]);
+            for (int db = 0; db < NDB; ++db) dq[db] = mfma_bf(lds_col<LB>(L.K, 16 * kc + 4 * g, 16 * db + r), dsb, dq[db]);
         }
         if (q < N) {
 #pragma unroll
@@ -741,8 +754,8 @@ __global__ __launch_bounds__(256) void winattn_lds_bwd_kernel(WsDev a) {
         f32x4 dk[NDB], dv[NDB];
 #pragma unroll
         for (int cc = 0; cc < NDB; ++cc) {
-            kf[cc] = lds_row(L.K, key, 16 * cc + 4 * g);
-            vf[cc] = lds_row(L.V, key, 16 * cc + 4 * g);
+            kf[cc] = lds_row<LB>(L.K, key, 16 * cc + 4 * g);
+            vf[cc] = lds_row<LB>(L.V, key, 16 * cc + 4 * g);
             dk[cc] = dv[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll 1
@@ -750,8 +763,8 @@ __global__ __launch_bounds__(256) void winattn_lds_bwd_kernel(WsDev a) {
             f32x4 sc4 = f32x4{0.f, 0.f, 0.f, 0.f}, dp = sc4;
 #pragma unroll
             for (int cc = 0; cc < NDB; ++cc) {
-                sc4 = mfma_bf(lds_row(L.Q, 16 * qc + r, 16 * cc + 4 * g), kf[cc], sc4);      // rows = queries 16 qc + 4g + j, column = key r
-                dp = mfma_bf(lds_row(L.G, 16 * qc + r, 16 * cc + 4 * g), vf[cc], dp);
+                sc4 = mfma_bf(lds_row<LB>(L.Q, 16 * qc + r, 16 * cc + 4 * g), kf[cc], sc4);      // rows = queries 16 qc + 4g + j, column = key r
+                dp = mfma_bf(lds_row<LB>(L.G, 16 * qc + r, 16 * cc + 4 * g), vf[cc], dp);
             }
             f32x4 p, ds;
 #pragma unroll
@@ -766,8 +779,8 @@ __global__ __launch_bounds__(256) void winattn_lds_bwd_kernel(WsDev a) {
             const s16x4 pb = pack_bf(p), dsb = pack_bf(ds);
 #pragma unroll
             for (int db = 0; db < NDB; ++db) {
-                dv[db] = mfma_bf(lds_col(L.G, 16 * qc + 4 * g, 16 * db + r), pb, dv[db]);      // dV^T += dO^T P
-                dk[db] = mfma_bf(lds_col(L.Q, 16 * qc + 4 * g, 16 * db + r), dsb, dk[db]);     // dK^T += (scale Q)^T dS
+                dv[db] = mfma_bf(lds_col<LB>(L.G, 16 * qc + 4 * g, 16 * db + r), pb, dv[db]);      // dV^T += dO^T P
+                dk[db] = mfma_bf(lds_col<LB>(L.Q, 16 * qc + 4 * g, 16 * db + r), dsb, dk[db]);     // dK^T += (scale Q)^T dS
             }
         }
         if (key < N) {
@@ -1228,15 +1241,30 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
 // windows of one (type, head) per workgroup: enough workgroups to fill the chip about three times over
 // (Pangu C4 layer 1, 4218 (window, head) pairs, tools/probe_winattn_c4.py: 768 workgroups 277 us, 1536: 272, 3072: 288, one per
 // window: 370; the register-fragment kernel: 338)
-static int lds_groups(int M, int heads, int ntypes) {
+// Workgroups of the two-pass LDS-staged backward: ONE resident round (occ workgroups per CU: the kernel's waves per SIMD), every workgroup
+// with the same number of windows.  Round 6, Swin C4 in the step: stage 0 (5624 (window, head) pairs) 112.6 us at the 1536 workgroups of
+// rounds 3 - 5 (1.5 rounds, 3 or 4 windows each), 101 - 102 us at 960 - 1024; stage 1 (1520 pairs, head dim 48, three waves per SIMD) 64 us
+// at 1520 (one window each: the table staging and flush of a workgroup paid per window, a partial second round), 59 at 768.
+static int lds_groups(int M, int heads, int ntypes, int occ) {
     const int env = dlwp_tune_or("WINATTN_WG_BWD", 0);
-    const long long g = ((long long)(env ? env : 1536) + heads * ntypes - 1) / (heads * ntypes);
-    return g < 1 ? 1 : (g > M ? M : (int)g);
+    if (env) {
+        const long long g = ((long long)env + heads * ntypes - 1) / (heads * ntypes);
+        return g < 1 ? 1 : (g > M ? M : (int)g);
+    }
+    static const int ncu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    const long long pairs = (long long)M * heads * ntypes, slots = (long long)ncu * occ;
+    const int per_wg = (int)((pairs + slots - 1) / slots);          // windows per workgroup
+    return (M + per_wg - 1) / per_wg;
 }
 
 // the LDS-staged family takes the bf16 matrix mode with 16-byte loadable head slices
 static bool lds_family_applies(int N, int d) {
-    return dlwp_get_gemm_precision() == 1 && d % 4 == 0 && d <= 32 && N <= 128 && !dlwp_tune_on("WINATTN_NOLDS");
+    // head dims 33 .. 48: the two-pass backward only (windows of at most 64 tokens), see LDB48
+    return dlwp_get_gemm_precision() == 1 && d % 4 == 0 && (d <= 32 || (d <= 48 && N <= 64)) && N <= 128 && !dlwp_tune_on("WINATTN_NOLDS");
 }
 
 int ws_setup(WsDev& a, int B_, int nW, int N, int TB, int ntypes, int heads, int d, float scale, int q_lo, int q_hi) {
@@ -1451,7 +1479,13 @@ static inline double ws_prof_bytes(const WsDev& a, bool backward) {
     // forward: qkv read, out + lse written; backward: qkv, out, gout, lse read, gqkv written
     return rows * C * e * (backward ? 3 + 1 + 1 + 3 : 3 + 1) + 4.0 * a.B_ * a.heads * a.N;
 }
-bool dlwp_winattn_small_applies(int N, int d, long long pairs) { return N <= 128 && d <= 32 && pairs >= 2048; }
+// Round 6: head dims up to 48 for windows of at most 64 tokens in the bf16 matrix mode (Swin C4 stage 1: 49 tokens, head dim 48, 1520 pairs at
+// batch 2: tiled kernels 36 + 106 us forward + backward per block, this family 12 + 31 us) -- from WINATTN_SMALL_MIN_PAIRS pairs (default 1024).
+bool dlwp_winattn_small_applies(int N, int d, long long pairs) {
+    if (N <= 128 && d <= 32 && pairs >= 2048) return true;
+    return dlwp_tune_or("WINATTN_D48", 1) != 0 && N <= 64 && d <= 48 && d % 4 == 0 && dlwp_get_gemm_precision() == 1 && !dlwp_tune_on("WINATTN_NOLDS") &&
+           pairs >= dlwp_tune_or("WINATTN_SMALL_MIN_PAIRS", 1024);
+}
 
 #define WS_DISPATCH(KERNEL, lds)                                                                                          \
     do {                                                                                                                  \
@@ -1467,7 +1501,9 @@ bool dlwp_winattn_small_applies(int N, int d, long long pairs) { return N <= 128
         };                                                                                                                \
         int rc3 = DLWP_OK;                                                                                                \
         const bool bf = dlwp_get_gemm_precision() == 1;      /* bf16 matrix arithmetic asked for: bf16 MFMA operands */   \
-        if (bf) {                                                                                                         \
+        if (bf && ndb == 3) {                       /* head dims 33 .. 48, windows of at most 64 tokens (small_applies) */  \
+            rc3 = go(KERNEL<4, 3, true, true>);                                                                           \
+        } else if (bf) {                                                                                                  \
             if (ndb == 1) {                                                                                               \
                 if (nc <= 4) rc3 = vec ? go(KERNEL<4, 1, true, true>) : go(KERNEL<4, 1, false, true>);                    \
                 else rc3 = vec ? go(KERNEL<8, 1, true, true>) : go(KERNEL<8, 1, false, true>);                            \
@@ -1503,6 +1539,7 @@ int dlwp_winattn_small_fwd(const float* qkv, const float* table, const float* pa
 // the saved score evaluations -- Swin C4 step 6.74 ms one-pass vs 6.59 ms two-pass, same box, back to back.
 static bool one_pass_applies(int N, int d, int TB) {
     const int nc = (N + 15) / 16;
+    if (d > 32) return false;
     if (nc <= 4 && !dlwp_tune_on("WINATTN_BWD1P_SMALL")) return false;
     return lds_family_applies(N, d) && lds2_bytes(16 * nc, TB) <= 160 * 1024 && (size_t)TB * 4 <= (size_t)4 * 16 * nc * LDB * 2;
 }
@@ -1556,17 +1593,17 @@ int dlwp_winattn_small_bwd(const float* qkv, const float* table, const float* pa
     if (lds_family_applies(N, d)) {
         const int nc = (N + 15) / 16;
         if (!dlwp_tune_on("WINATTN_BWD2PASS") && one_pass_applies(N, d, TB)) return one_pass_launch(a, stream);
-        const size_t lb = lds_bytes(16 * nc, TB, true);
-        a.groups = lds_groups(a.M, heads, ntypes);
+        const size_t lb = lds_bytes(16 * nc, TB, true, d <= 32 ? LDB : LDB48);
+        a.groups = lds_groups(a.M, heads, ntypes, d <= 32 ? 4 : 3);
         const dim3 grid((unsigned)(heads * ntypes * a.groups)), block(256);
         auto go = [&](auto knl) -> int {
             int rc2 = dlwp_ensure_lds(reinterpret_cast<const void*>(knl), lb, "winattn_lds_bwd");
             if (rc2) return rc2;
-            dlwp_prof_scope prof((hipStream_t)stream, ws_prof_flops(a, 5), ws_prof_bytes(a, true), "winattn_lds_bwd_kernel<%d>", d <= 16 ? 1 : 2);
+            dlwp_prof_scope prof((hipStream_t)stream, ws_prof_flops(a, 5), ws_prof_bytes(a, true), "winattn_lds_bwd_kernel<%d>", d <= 16 ? 1 : d <= 32 ? 2 : 3);
             hipLaunchKernelGGL(knl, grid, block, lb, (hipStream_t)stream, a);
             return DLWP_OK;
         };
-        const int rc3 = d <= 16 ? go(winattn_lds_bwd_kernel<1>) : go(winattn_lds_bwd_kernel<2>);
+        const int rc3 = d <= 16 ? go(winattn_lds_bwd_kernel<1>) : d <= 32 ? go(winattn_lds_bwd_kernel<2>) : go(winattn_lds_bwd_kernel<3>);
         if (rc3) return rc3;
         DLWP_LAUNCH_CHECK();
         return DLWP_OK;
@@ -1599,7 +1636,7 @@ extern "C" int dlwp_window_attn_bwd_tokens_supported(int N, int d, int TB) {
     return one_pass_applies(N, d, TB) && !dlwp_tune_on("WINATTN_BWD2PASS") ? 1 : 0;
 }
 extern "C" int dlwp_window_attn_fwd_tokens_supported(int N, int d, long long pairs) {
-    return dlwp_winattn_small_applies(N, d, pairs) && d % 4 == 0 && dlwp_get_gemm_precision() == 1 && !dlwp_tune_on("WINATTN_TILED") ? 1 : 0;
+    return d <= 32 && pairs >= 2048 && dlwp_winattn_small_applies(N, d, pairs) && d % 4 == 0 && dlwp_get_gemm_precision() == 1 && !dlwp_tune_on("WINATTN_TILED") ? 1 : 0;
 }
 static int tokens_check(const char* who, int B_, int nW, int N, int Ltok, int TB, int ntypes, int heads, int d, int q_lo, int q_hi) {
     DLWP_REQUIRE(B_ > 0 && nW > 0 && B_ % nW == 0 && N > 0 && Ltok > 0 && heads > 0 && d > 0 && ntypes > 0 && TB > 0, DLWP_E_INVALID,

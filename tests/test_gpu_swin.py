@@ -268,6 +268,46 @@ def test_lds_staged_bf16_window_kernels_match_the_register_fragment_kernels(cuda
         assert float(q_part[:, :clo].abs().max() if clo else 0.0) == 0.0 and float(q_part[:, chi:].abs().max() if chi < N else 0.0) == 0.0
 
 
+@pytest.mark.parametrize("d,heads,B_,nW,masked", [(48, 4, 380, 190, True), (40, 2, 600, 12, False), (36, 4, 512, 1, True)])
+def test_head_dims_33_to_48_on_the_wave_and_lds_families_in_bf16_mode(cuda, monkeypatch, d, heads, B_, nW, masked):
+    """Round 6: windows of at most 64 tokens with head dims 33 .. 48 (Swin C4 stage 1: 192 channels on 4 heads, 49 tokens, 1520 (window, head)
+    pairs at batch 2) take the wave-per-window forward (winattn_small_fwd_kernel<4, 3>) and the LDS-staged two-pass backward
+    (winattn_lds_bwd_kernel<3>, 104-byte rows) in the bf16 matrix mode instead of the tiled kernels.  Against the tiled kernels in the same
+    arithmetic (DLWP_WINATTN_D48=0; both round operands and probabilities to bf16, sums in fp32: 1e-2) and against the fp32 tiled kernels
+    (bf16 distance: 2e-2 / 3e-2, as test_window_attention_bf16_matrix_arithmetic_stays_close)."""
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.nsbench.swin_transformer import window_attention_core
+    assert B_ * heads >= 1024
+    N, TB = 49, 3 * 49
+    g = torch.Generator().manual_seed(d + heads)
+    qkv0 = torch.randn(B_, N, 3 * heads * d, generator=g).to(cuda)
+    table0 = (0.5 * torch.randn(TB, heads, generator=g)).to(cuda)
+    ia = torch.randint(0, TB // 2, (N,), generator=g, dtype=torch.int32).to(cuda)
+    ib = torch.randint(0, TB // 2, (N,), generator=g, dtype=torch.int32).to(cuda)
+    labels = torch.randint(0, 3, (nW, N), generator=g, dtype=torch.int32).to(cuda) if masked else None
+    gy = torch.randn(B_, N, heads * d, generator=g).to(cuda)
+
+    def run(mode, d48):
+        monkeypatch.setenv("DLWP_WINATTN_D48", "1" if d48 else "0")
+        with L.gemm_precision(mode):
+            qkv, table = qkv0.clone().requires_grad_(), table0.clone().requires_grad_()
+            with L.kernel_accounting() as acc:
+                y = window_attention_core(qkv, table, ia, ib, labels, nW, heads, d ** -0.5)
+                y.backward(gy)
+                torch.cuda.synchronize()
+        return (y.detach(), qkv.grad, table.grad), {r["name"] for r in acc.rows}
+    ref32, _ = run("fp32", False)
+    tiled, names_t = run("bf16", False)
+    new, names_n = run("bf16", True)
+    monkeypatch.delenv("DLWP_WINATTN_D48", raising=False)
+    assert any(n.startswith("winattn_lds_bwd_kernel<3>") for n in names_n) and any(n.startswith("winattn_small_fwd_kernel") for n in names_n), names_n
+    assert any(n.startswith("winattn_bwd_q_kernel") for n in names_t), names_t
+    for i, tol in enumerate((1e-2, 1e-2, 1e-2)):
+        assert rel(new[i], tiled[i]) <= tol, (i, rel(new[i], tiled[i]))
+    for i, tol in enumerate((2e-2, 3e-2, 3e-2)):
+        assert rel(new[i], ref32[i]) <= tol, (i, rel(new[i], ref32[i]))
+
+
 @pytest.mark.parametrize("H,W,pm,shift", [(20, 30, ("constant", "circular"), 3), (20, 30, ("constant", "circular"), 0),
                                           (28, 28, "constant", 3), (21, 35, ("constant", "circular"), 3)])
 @pytest.mark.parametrize("bias", [True, False])
