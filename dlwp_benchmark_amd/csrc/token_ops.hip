@@ -1531,9 +1531,13 @@ static bool gemm_glds_applies(const GemmDev& a, bool akc, bool bkc) {
     if (a.splits != 1 || a.nbatch != 1 || a.atomic_out || a.rowsum || a.bias_row || a.act_b || !a.vec_epi) return false;
     const bool force = dlwp_tune_on("GEMM_GLDS_FORCE");          // measurement: skip the shape heuristic below
     if (force) return a.M >= GT && a.N >= GT;
-    // at least one workgroup per CU and four K-steps: below that the 64 x 64 kernel's shorter prologue wins (measured,
-    // profiles/r03_gemm_bench.txt: Pangu 8192 x 192 x 768 104 vs 120 TFLOP/s, 2048 x 1536 x 384 77 vs 93)
-    return a.K >= 4 * GK && (long long)ceil_div(a.M, GT) * ceil_div(a.N, GT) >= 256;
+    // at least one workgroup per CU: below that the 64 x 64 kernel's shorter prologue wins (measured, profiles/r03_gemm_bench.txt: Pangu
+    // 8192 x 192 x 768 104 vs 120 TFLOP/s, 2048 x 1536 x 384 77 vs 93; round 6, in the step: 128 tiles instead of 256 costs Pangu C4 1.3 %).
+    // K: rounds 3 - 5 asked for four 64-deep K-steps; with >= 256 tiles the kernel wins from K = 96 on (three 32-deep steps) -- back to back
+    // 32768 x 768 x 192 36.2 -> 26.1 us, 65536 x 384 x 96 28.8 -> 21.7 us (profiles/r06_gemm_vs_vendor.txt), in the step Swin C4 390.5 -> 396.5,
+    // Pangu C4 107.0 -> 107.9 samples/s (profiles/r06_gemm_glds_threshold_sweep.txt)
+    const int mink = dlwp_tune_or("GEMM_GLDS_MINK", 96), mintiles = dlwp_tune_or("GEMM_GLDS_MINTILES", 256);
+    return a.K >= mink && (long long)ceil_div(a.M, GT) * ceil_div(a.N, GT) >= mintiles;
 }
 static int gemm_glds_launch(const GemmDev& a_in, bool bkc, hipStream_t s) {
     GemmDev a = a_in;

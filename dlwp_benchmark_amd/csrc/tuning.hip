@@ -23,6 +23,8 @@ Knob g_knobs[] = {
     {"GEMM_NOGLDS", "1: never use the 128 x 128 LDS-DMA bf16 GEMM kernels (activation products and weight gradients)", 0, false},
     {"GEMM_NOGLDS_TN", "1: never use the LDS-DMA weight-gradient kernel", 0, false},
     {"GEMM_GLDS_FORCE", "1: use the LDS-DMA kernel wherever its operand layout allows (skip the shape heuristic)", 0, false},
+    {"GEMM_GLDS_MINK", "least K for the 128 x 128 LDS-DMA activation kernels to be taken by shape (default 96)", 0, false},
+    {"GEMM_GLDS_MINTILES", "least number of 128 x 128 output tiles for those kernels to be taken by shape (default 256)", 0, false},
     {"GEMM_GLDS_KD", "K-step depth of the LDS-DMA activation kernels: 32 or 64 (default by shape)", 0, false},
     {"GEMM_GLDS_TN_KD", "K-step depth of the LDS-DMA weight-gradient kernel: 32 or 64 (default by tile count)", 0, false},
     {"GEMM_GLDS_TN_WGS", "resident workgroup slots the weight-gradient kernel sizes its K slices for", 0, false},
@@ -41,7 +43,7 @@ Knob g_knobs[] = {
     {"GEMM_NOGROUP", "1: products parked by dlwp_gemm_group_begin / dlwp_weight_grad_group launch one by one", 0, false},
     {"WGRAD_GROUP_MAXT", "most tokens for the grouped weight-gradient launch (default 65536)", 0, false},
     {"WGRAD_GROUP_WGS", "workgroups the grouped weight-gradient launch shares among its products (default 896)", 0, false},
-    {"WGRAD_MULTI_WGS", "resident workgroup slots dlwp_wgrad_segments sizes its K slices for (default 512)", 0, false},
+    {"WGRAD_MULTI_WGS", "resident workgroup slots dlwp_wgrad_segments sizes its K slices for (default 384)", 0, false},
     {"LN_BWD_WANT", "workgroups of the scalar LayerNorm backward kernel", 0, false},
     {"LN_BWD_NOWIDE", "1: never use the wide-row LayerNorm backward kernel", 0, false},
     {"LN_BWD_WGS", "workgroups of the wide-row LayerNorm backward kernel (default 384)", 0, false},

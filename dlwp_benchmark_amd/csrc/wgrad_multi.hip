@@ -233,7 +233,8 @@ int plan(const dlwp_wgrad_seg_product* p, int nprod, int nseg, int T, WgDev* dev
     a.tile0[nprod] = tiles;
     a.out_off[nprod] = off;
     // K slices per segment: the grid should fill the resident slots (two 64 KB workgroups per CU) once; at least eight K-steps per slice
-    const int slots = dlwp_tune_or("WGRAD_MULTI_WGS", 512);
+    // (round 6, in the step: 384 against round 5's 512 -- Swin C4 395.5 -> 400.3 samples/s, Pangu C4 and SFNO C3 unchanged; 256 / 768 / 1024 lose 1.5 - 2.5 %)
+    const int slots = dlwp_tune_or("WGRAD_MULTI_WGS", 384);
     int sps = std::max(1, std::min((slots + tiles * nseg / 2) / (tiles * nseg), std::max(1, T / (8 * KD))));
     {   // a slice count that is a multiple of 8 lets the kernel keep a slice's tiles on one XCD: round sps up where that costs little
         int q = 8;

@@ -268,7 +268,7 @@ def test_sfno_train_step_with_bf16_storage_tracks_fp32_storage(cuda):
     assert ((a - b).abs() / a).max().item() < 3e-2, (losses["fp32"], losses["bf16"])
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 384, 192), (8192, 576, 192), (130, 128, 64), (4100, 768, 3072)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 384, 192), (8192, 576, 192), (130, 128, 64), (4100, 768, 3072), (32768, 384, 96)])
 @pytest.mark.parametrize("epi", ["plain", "bias_gelu_preact_bf16", "residual_fp32", "gelu_grad_mul", "res_pre_accumulate"])
 def test_lds_dma_bf16_gemm_matches_the_register_staged_kernel(cuda, monkeypatch, M, N, K, epi):
     """y = x W^T with both operands bf16 arrays: the 128 x 128 x 64 LDS-DMA kernel (csrc/token_ops.hip, gemm_glds_nt_kernel)

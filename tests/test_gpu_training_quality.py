@@ -1,8 +1,10 @@
 """Short version of tools/bf16_training_quality.py (profiles/r06_bf16_training_quality.json): the benchmarked bf16 arithmetic (bf16
 operands + bf16 storage) must TRAIN like the fp32 path on a learnable synthetic forecasting task -- same data stream, same initial
 weights, closed-loop RMSE on held-out fields.  At this training length (250 steps, error ~ 15 % of the field's standard deviation)
-the full experiment found the seed-paired ratio at 0.98 - 1.00; the bar here is 3 %.  (At errors below ~ 2 % the 8-bit mantissa of
-the bf16 matrix operands starts to show: that regime is the experiment's job, not this test's.)"""
+the full experiment found the seed-paired ratio at 0.98 - 1.00 on average, but a SINGLE pair moves by +- 5 % from execution to execution
+(float atomics reorder the weight-gradient sums and the loss is falling fast at this point of the training: 0.126 after 250 steps, 0.041
+after 500), so the bar here is 10 % -- wide enough not to flake, narrow enough for a wrong gradient path (tens of per cent).  (At errors
+below ~ 2 % the 8-bit mantissa of the bf16 matrix operands starts to show: that regime is the experiment's job, not this test's.)"""
 import importlib.util
 import os
 
@@ -30,7 +32,7 @@ def test_sfno_c3_widths_bf16_path_trains_like_the_fp32_path(cuda):
     for mode, r in res.items():
         assert r["closed_loop_rmse"] < 0.3 * pers, (mode, r["closed_loop_rmse"], pers)          # the task is being learned
     ratio = res["bf16"]["closed_loop_rmse"] / res["fp32"]["closed_loop_rmse"]
-    assert 0.97 <= ratio <= 1.03, (ratio, res["bf16"]["closed_loop_rmse"], res["fp32"]["closed_loop_rmse"])
+    assert 0.90 <= ratio <= 1.10, (ratio, res["bf16"]["closed_loop_rmse"], res["fp32"]["closed_loop_rmse"])
 
 
 def test_afno_fcn_widths_bf16_storage_trains_like_the_fp32_path(cuda):
@@ -44,4 +46,4 @@ def test_afno_fcn_widths_bf16_storage_trains_like_the_fp32_path(cuda):
     for mode, r in res.items():
         assert r["lead1_rmse"] < 0.75 * r["persistence_lead1_rmse"], (mode, r["lead1_rmse"], r["persistence_lead1_rmse"])
     ratio = res["bf16_fp32spectra"]["lead1_rmse"] / res["fp32"]["lead1_rmse"]
-    assert 0.97 <= ratio <= 1.03, (ratio, res)          # (the full experiment: 1.003 after 187 steps, 1.007 after 375, over three seeds)
+    assert 0.93 <= ratio <= 1.07, (ratio, res)          # (the full experiment: 1.003 after 187 steps, 1.007 after 375, over three seeds)
