@@ -250,7 +250,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
     const __bf16* gh = reinterpret_cast<const __bf16*>(gy);
     // UB row groups of a wave in flight at once (round 5: the one-group loop was a chain of dependent HBM round trips -- 38 us for the
     // 100 MB of Swin's 65536 x 96 layers; the loads of four groups travel together now)
-    constexpr int UB = 4;
+#ifndef LN_BWD_UB
+#define LN_BWD_UB 4          // 8 was measured in round 6 (250 VGPRs, two waves per SIMD): <32> 37.4 -> 38.9 us, <64> unchanged
+#endif
+    constexpr int UB = LN_BWD_UB;
     for (int it0 = w * RPW; it0 < rows_per_block; it0 += 4 * RPW * UB) {
         f32x4 xv[UB], gv[UB], av[UB];
         float mu[UB], rs[UB];
