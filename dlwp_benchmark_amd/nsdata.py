@@ -165,12 +165,48 @@ def save(data, path):
     np.savez_compressed(path, a=data["a"], u=data["u"], t=data["t"], **{"attr_" + k.replace(" ", "_"): v for k, v in data["attrs"].items()})
 
 
+def save_netcdf(data, path):
+    """The reference's file layout (generate_ns_2d.py:223-260: coordinates sample / time / dim / height / width, variables a, u, t, the
+    attributes) as NetCDF-3 CLASSIC through scipy.io.netcdf_file -- what `xarray.Dataset.to_netcdf` itself writes where the netCDF4
+    library is absent, and what `xr.open_dataset` reads back either way.  (NetCDF-4 / HDF5 files need h5py or netCDF4: not in this image.)"""
+    from scipy.io import netcdf_file
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    u, a, t = np.asarray(data["u"], dtype=np.float32), np.asarray(data["a"], dtype=np.float32), np.asarray(data["t"], dtype=np.float32)
+    dims = dict(zip(("sample", "time", "dim", "height", "width"), u.shape))
+    with netcdf_file(path, "w", version=2) as f:          # 64-bit offsets: the 1000-sample files exceed 2 GiB
+        for name, n in dims.items():
+            f.createDimension(name, n)
+            v = f.createVariable(name, "i4", (name,))
+            v[:] = np.arange(n, dtype=np.int32)
+        f.createVariable("a", "f4", ("sample", "height", "width"))[:] = a
+        f.createVariable("u", "f4", tuple(dims))[:] = u
+        f.createVariable("t", "f4", ("time",))[:] = t
+        for k, val in {"info": "Incompressible Navier-Stokes data", "a": "Initial condition", "u": "Solution", "t": "Time step in simulation",
+                       **data.get("attrs", {})}.items():
+            if not isinstance(val, (str, bytes)):          # the classic format has no 64-bit integers
+                val = np.asarray(val)
+                val = val.astype(np.int32) if val.dtype.kind in "iu" else val.astype(np.float64) if val.dtype.kind == "f" else str(val)
+            setattr(f, k.replace(" ", "_"), val)
+
+
+def load_u(data_path):
+    """The solution array u [sample, time, dim, height, width] of a data file: .npz (this build's format) or NetCDF-3 classic (.nc)."""
+    if str(data_path).endswith(".npz"):
+        return np.load(data_path)["u"]
+    from scipy.io import netcdf_file
+    try:
+        with netcdf_file(data_path, "r", mmap=False) as f:
+            return np.array(f.variables["u"][:], dtype=np.float32)
+    except (TypeError, ValueError) as e:          # scipy: "... is not a valid NetCDF 3 file" for an HDF5-based NetCDF-4 file
+        raise OSError(f"{data_path}: only NetCDF-3 classic files can be read in this environment (scipy.io.netcdf_file; NetCDF-4 / HDF5 "
+                      f"needs h5py or netCDF4, which the image does not have): {e}") from e
+
+
 class NavierStokesNpz(torch.utils.data.Dataset):
-    """NavierStokesDataset (datasets.py:11-44) on the .npz file."""
+    """NavierStokesDataset (datasets.py:11-44) on the .npz file or on a NetCDF-3 classic file of the reference's layout (load_u)."""
 
     def __init__(self, data_path, sequence_length=15, noise=0.0, normalize=False, downscale_factor=None):
-        z = np.load(data_path)
-        self.u = z["u"]
+        self.u = load_u(data_path)
         self.sequence_length, self.noise, self.normalize = sequence_length, noise, normalize
         self.mean, self.std = self.u.mean(), self.u.std()
         if downscale_factor:

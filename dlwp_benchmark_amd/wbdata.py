@@ -11,8 +11,13 @@ Reproduced as is: `target = prognostic[1:]` and the method 
 the model's first output belongs to input frame `context_size`; the first prediction is therefore scored against the
 field two steps after the last input frame.
 
-Only the randomly-sampled-initialisation branch (`init_dates is None`, the training path, :327, :335, :368) is on the hot
-path; the `init_dates` branch (evaluation with calendar look-ups through pandas) is not built.
+Both branches of `__getitem__` are built: the randomly-sampled-initialisation branch (`init_dates is None`, the training path,
+:327, :335, :368) and -- round 6 -- the `init_dates` branch of the evaluation (:339-360, :373-377; bi-weekly initialisation dates from
+`make_biweekly_inits`, scripts/evaluate.py:56-68): xarray's label slices are INCLUSIVE on both ends, so `sel(time=slice(d, d + L dt))`
+yields L + 1 frames of the prescribed variables and `slice(d, d + (L + 1) dt)` L + 2 of the prognostic ones while the record lasts;
+prescribed frames past the end of the record are taken from the same calendar date of 2017 (29 February -> 28 February), prognostic
+frames past the end are NOT padded unless fewer than L exist (zero fill, :386-389).  The calendar arithmetic is numpy datetime64
+(the reference uses pandas; tests/test_wbdata.py checks this twin against pandas label slicing).
 """
 import math
 
@@ -49,8 +54,16 @@ class WeatherBenchArrays(torch.utils.data.Dataset):
     The other arguments are the reference constructor's (:236-255)."""
 
     def __init__(self, fields, prognostic_variable_names_and_levels, prescribed_variable_names=None, constant_names=None,
-                 sequence_length=15, noise=0.0, normalize=False, context_size=1, stats=None, seed=None, **kwargs):
+                 sequence_length=15, noise=0.0, normalize=False, context_size=1, stats=None, seed=None, times=None, init_dates=None,
+                 timedelta=6, **kwargs):
+        """times: np.datetime64 array, the time coordinate of every [time, ...] field (needed with init_dates); init_dates: array of
+        np.datetime64 initialisation dates (the evaluation branch, :257, :320-325); timedelta: hours between two frames (:246)."""
         self.fields = fields
+        self.times = None if times is None else np.asarray(times).astype("datetime64[h]")
+        self.init_dates = None if init_dates is None else np.asarray(init_dates).astype("datetime64[h]")
+        self.timedelta = int(timedelta)
+        if self.init_dates is not None and self.times is None:
+            raise ValueError("init_dates needs the time coordinate of the fields (times=...)")
         self.prognostic_variable_names_and_levels = dict(prognostic_variable_names_and_levels)
         self.prescribed_variable_names = list(prescribed_variable_names or [])
         self.constant_names = list(constant_names or [])
@@ -78,9 +91,64 @@ class WeatherBenchArrays(torch.utils.data.Dataset):
         self.epoch = int(epoch)
 
     def __len__(self):
+        if self.init_dates is not None:
+            return len(self.init_dates)                                                 # :324-325
         return (self.n_time - self.sequence_length) // self.sequence_length            # :322-323
 
+    def _label_slice(self, start, stop):
+        """Index range of `sel(time=slice(start, stop))`: xarray label slices include BOTH end points."""
+        return int(np.searchsorted(self.times, start, side="left")), int(np.searchsorted(self.times, stop, side="right"))
+
+    def _getitem_init_date(self, item):
+        L_, dt = self.sequence_length, np.timedelta64(self.timedelta, "h")
+        d0 = self.init_dates[item]
+        if self.prescribed_variable_names:
+            ps = []
+            for p in self.prescribed_variable_names:
+                a, b = self._label_slice(d0, d0 + L_ * dt)                              # :343-347 (inclusive: L + 1 frames while the record lasts)
+                data = np.asarray(self.fields[p][a:b])
+                if L_ > len(data):                                                      # :348-360: the record ends -- same calendar dates of 2017
+                    diff = L_ - len(data)
+                    dates = d0 + dt * np.arange(int((L_ * dt) / dt) + 1)                # pd.date_range(start, stop, freq = dt), inclusive
+                    extra = []
+                    for date in dates[-diff:]:
+                        day = date.astype("datetime64[D]")
+                        y, m, dd = str(day).split("-")
+                        if m == "02" and int(dd) > 28:
+                            dd = "28"
+                        rep = np.datetime64(f"2017-{m}-{dd}") + (date - day)            # date.replace(year = 2017 [, day = 28]), hour kept
+                        k = int(np.searchsorted(self.times, rep))
+                        if k >= len(self.times) or self.times[k] != rep:
+                            raise KeyError(f"prescribed variable {p!r}: {rep} is not in the record (the reference's ds.tisr.sel(time=date) raises too)")
+                        extra.append(np.asarray(self.fields["tisr"][k]))                # (:358 reads `tisr` whatever the variable is called)
+                    data = np.concatenate((data, np.asarray(extra)))
+                ps.append(self._norm(data, self.stats[p]) if self.normalize else data)
+            prescribed = np.float32(np.stack(ps, axis=1))
+        else:
+            prescribed = torch.nan
+        prog = []
+        a, b = self._label_slice(d0, d0 + (L_ + 1) * dt)                                # :374-377 (inclusive: L + 2 frames while the record lasts)
+        for p, levels in self.prognostic_variable_names_and_levels.items():
+            if levels:
+                for l in levels:
+                    x = np.asarray(self.fields[p][l][a:b])
+                    prog.append(self._norm(x, self.stats[p]["level"][l]) if self.normalize else x)
+            else:
+                x = np.asarray(self.fields[p][a:b])
+                prog.append(self._norm(x, self.stats[p]) if self.normalize else x)
+        prognostic = np.float32(np.stack(prog, axis=1))
+        if len(prognostic) < L_:                                                        # :386-389
+            fill = np.zeros((L_ - len(prognostic), *prognostic.shape[1:]), dtype=np.float32)
+            prognostic = np.concatenate((prognostic, fill), axis=0)
+        target = prognostic[1:]
+        eps = (np.random.randn(*prognostic[:-1].shape) if self.seed is None else
+               np.random.default_rng([self.seed, int(self.epoch), int(item)]).standard_normal(prognostic[:-1].shape))
+        prognostic = prognostic[:-1] + np.float32(eps * self.noise)
+        return self.constants, prescribed, prognostic, target[self.context_size:]
+
     def __getitem__(self, item):
+        if self.init_dates is not None:
+            return self._getitem_init_date(item)
         L_ = self.sequence_length
         t0 = item * L_                                                                  # :335
         if self.prescribed_variable_names:                                              # [L, #prescribed, lat, lon]
@@ -113,6 +181,77 @@ class WeatherBenchArrays(torch.utils.data.Dataset):
             eps = np.random.default_rng([self.seed, int(self.epoch), int(item)]).standard_normal(prognostic[:-1].shape)
         prognostic = prognostic[:-1] + np.float32(eps * self.noise)                     # :393
         return self.constants, prescribed, prognostic, target[self.context_size:]       # :395
+
+
+def make_biweekly_inits(start="2017-01-01", end="2018-12-31", sequence_length=57, timedelta=6):
+    """scripts/evaluate.py:56-68: two interleaved weekly series of initialisation dates (start and start + 3 days), each ending
+    sequence_length * timedelta hours before `end`, merged and sorted.  numpy datetime64[ns] like `DatetimeIndex.to_numpy()`."""
+    s0, e = np.datetime64(start, "h"), np.datetime64(end, "h") - np.timedelta64(int(sequence_length) * int(timedelta), "h")
+    week = np.timedelta64(7 * 24, "h")
+    series = []
+    for first in (s0, s0 + np.timedelta64(3 * 24, "h")):
+        n = int((e - first) / week) + 1 if e >= first else 0
+        series.append(first + week * np.arange(n))
+    return np.sort(np.concatenate(series)).astype("datetime64[ns]")
+
+
+def load_netcdf3_fields(paths, prognostic_variable_names_and_levels, prescribed_variable_names=None, constant_names=None,
+                        start_date=None, stop_date=None, timedelta=1):
+    """The `fields` / `times` arguments of WeatherBenchArrays from NetCDF-3 CLASSIC files of the WeatherBench layout (one variable per file
+    or several; dimensions time[, level], lat, lon; `time` in "hours since ..." as WeatherBench writes it) -- the part of
+    `xr.open_mfdataset(fpaths).sel(time=slice(start_date, stop_date, timedelta))` (datasets.py:284-287) that this image can do:
+    scipy.io.netcdf_file reads the classic format only; NetCDF-4 / HDF5 files and blosc-compressed zarr stores need netCDF4 / h5py / zarr,
+    none of which is installed (convert with `nccopy -k classic` or `xarray.to_netcdf(engine="scipy")`).
+    Returns (fields, times): surface variables [time, lat, lon], level-resolved ones {level: [time, lat, lon]}, constants [lat, lon]."""
+    import re
+    from scipy.io import netcdf_file
+    want_t = set(prognostic_variable_names_and_levels) | set(prescribed_variable_names or [])
+    want_c = set(constant_names or [])
+    fields, times = {}, None
+    for path in sorted(paths):
+        try:
+            f = netcdf_file(path, "r", mmap=False)
+        except (TypeError, ValueError) as e:
+            raise OSError(f"{path}: not a NetCDF-3 classic file (NetCDF-4 / HDF5 and zarr need libraries this image lacks): {e}") from e
+        with f:
+            tvals = None
+            if "time" in f.variables:
+                tv = f.variables["time"]
+                units = tv.units.decode() if isinstance(tv.units, bytes) else str(tv.units)
+                m = re.match(r"\s*(hours|days|seconds|minutes) since (\S+)(?:[ T](\S+))?", units)
+                if not m:
+                    raise OSError(f"{path}: time units {units!r} not understood")
+                step = {"hours": "h", "days": "D", "seconds": "s", "minutes": "m"}[m.group(1)]
+                origin = np.datetime64(m.group(2) + ("T" + m.group(3)[:8] if m.group(3) else ""))
+                tvals = (origin.astype("datetime64[s]") + (np.array(tv[:], dtype=np.float64) * {"h": 3600, "D": 86400, "s": 1, "m": 60}[step]
+                                                           ).astype("timedelta64[s]")).astype("datetime64[h]")
+            for name, var in f.variables.items():
+                if name not in want_t and name not in want_c:
+                    continue
+                data = np.array(var[:], dtype=np.float32)
+                if hasattr(var, "scale_factor") or hasattr(var, "add_offset"):          # packed shorts, as ERA5 downloads are
+                    data = data * np.float32(getattr(var, "scale_factor", 1.0)) + np.float32(getattr(var, "add_offset", 0.0))
+                if name in want_c:
+                    fields[name] = data.reshape(data.shape[-2:])
+                    continue
+                levels = np.array(f.variables["level"][:]).astype(int).tolist() if "level" in var.dimensions else None
+                if levels is not None:
+                    piece = {l: data[:, i] for i, l in enumerate(levels)}
+                    prev = fields.get(name)
+                    fields[name] = piece if prev is None else {l: np.concatenate((prev[l], piece[l])) for l in piece}
+                else:
+                    prev = fields.get(name)
+                    fields[name] = data if prev is None else np.concatenate((prev, data))
+                if tvals is not None and name == next(iter(prognostic_variable_names_and_levels)):
+                    times = tvals if times is None else np.concatenate((times, tvals))
+    if times is not None:                                                              # .sel(time=slice(start, stop, timedelta)): inclusive labels
+        a = 0 if start_date is None else int(np.searchsorted(times, np.datetime64(start_date, "h"), side="left"))
+        b = len(times) if stop_date is None else int(np.searchsorted(times, np.datetime64(stop_date, "h"), side="right"))
+        sl = slice(a, b, int(timedelta))
+        times = times[sl]
+        for name in want_t & set(fields):
+            fields[name] = {l: v[sl] for l, v in fields[name].items()} if isinstance(fields[name], dict) else fields[name][sl]
+    return fields, times
 
 
 def to_device_batch(items, device):

@@ -78,3 +78,22 @@ def test_generate_save_and_dataset_windowing(tmp_path):
     x, y = ds[1]
     assert x.shape == (2, 1, 16, 16) and y.shape == (2, 1, 16, 16)
     np.testing.assert_array_equal(x[1], y[0])       # y is x shifted by one frame
+
+
+def test_netcdf3_file_of_the_reference_layout_round_trips(tmp_path):
+    """nsdata.save_netcdf writes the reference's file layout (generate_ns_2d.py:223-260) as NetCDF-3 classic; NavierStokesNpz reads it back
+    (scipy.io.netcdf_file: the NetCDF flavour xarray itself falls back to without the netCDF4 library)."""
+    import numpy as np
+    from dlwp_benchmark_amd import nsdata
+    rng = np.random.default_rng(0)
+    data = {"a": rng.standard_normal((3, 8, 8)).astype(np.float32), "u": rng.standard_normal((3, 6, 1, 8, 8)).astype(np.float32),
+            "t": np.arange(6, dtype=np.float32), "attrs": {"viscosity": 1e-3, "simulation T": 6}}
+    path = str(tmp_path / "ns.nc")
+    nsdata.save_netcdf(data, path)
+    assert np.array_equal(nsdata.load_u(path), data["u"])
+    ds = nsdata.NavierStokesNpz(path, sequence_length=4)
+    x, y = ds[1]
+    assert len(ds) == 3 and x.shape == (3, 1, 8, 8) and y.shape == (3, 1, 8, 8)
+    from scipy.io import netcdf_file
+    with netcdf_file(path, "r", mmap=False) as f:
+        assert set(f.dimensions) == {"sample", "time", "dim", "height", "width"} and f.variables["u"].dimensions == ("sample", "time", "dim", "height", "width")

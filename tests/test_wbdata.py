@@ -116,3 +116,133 @@ def test_full_sample_equals_hand_built_tensors():
         assert np.allclose(p, exp_presc, atol=1e-6)
         assert np.allclose(g, window[:-1], atol=1e-6)
         assert np.allclose(t_, window[1:][ctx:], atol=1e-6) and t_.shape[0] == L - ctx
+
+
+# ---- the init_dates branch (evaluation): label-inclusive slices, 2017 fill of the prescribed variable, zero fill ---------------
+def _dated_fields(start, n_time, dt_h, H=2, W=3):
+    """coded fields on a real time axis: value = 1000 * variable + index along the time axis."""
+    import pandas as pd
+    times = pd.date_range(start=start, periods=n_time, freq=f"{dt_h}h")
+    return coded_fields(n_time, H, W), times
+
+
+def _restate_with_pandas(fields, times, init_date, L, dt_h, ctx, prog):
+    """What xarray does in datasets.py:339-395, with pandas label slicing (inclusive on both ends, like xarray's)."""
+    import pandas as pd
+    idx = pd.Series(np.arange(len(times)), index=times)
+    d0 = pd.Timestamp(init_date)
+    sel = idx.loc[d0:d0 + pd.Timedelta(f"{L * dt_h}h")].to_numpy()
+    presc = fields["tisr"][sel]
+    if L > len(sel):
+        diff = L - len(sel)
+        dates = pd.date_range(start=d0, end=d0 + pd.Timedelta(f"{L * dt_h}h"), freq=f"{dt_h}h")
+        tmp = []
+        for date in dates[-diff:]:
+            date = date.replace(year=2017, day=28) if date.month == 2 and date.day > 28 else date.replace(year=2017)
+            tmp.append(fields["tisr"][idx.loc[date]])
+        presc = np.concatenate((presc, np.array(tmp)))
+    sel2 = idx.loc[d0:d0 + pd.Timedelta(f"{(L + 1) * dt_h}h")].to_numpy()
+    chans = []
+    for p, levels in prog.items():
+        if levels:
+            chans += [fields[p][l][sel2] for l in levels]
+        else:
+            chans.append(fields[p][sel2])
+    prognostic = np.float32(np.stack(chans, axis=1))
+    if len(prognostic) < L:
+        prognostic = np.concatenate((prognostic, np.zeros((L - len(prognostic), *prognostic.shape[1:]), dtype=np.float32)), axis=0)
+    return np.float32(presc)[:, None], prognostic[:-1], prognostic[1:][ctx:]
+
+
+def test_init_dates_branch_matches_label_inclusive_slicing():
+    L, dt_h, ctx = 6, 6, 1
+    fields, times = _dated_fields("2017-01-01", 4 * 365 * 2, dt_h)          # 2017-01-01 ... 2018-12-31, 6-hourly
+    inits = wbdata.make_biweekly_inits("2017-01-01", "2018-12-31", sequence_length=L, timedelta=dt_h)
+    ds = wbdata.WeatherBenchArrays(fields, PROG, ["tisr"], ["orography"], sequence_length=L, context_size=ctx, times=times.to_numpy(),
+                                   init_dates=inits, timedelta=dt_h)
+    assert len(ds) == len(inits)
+    for item in (0, 1, len(inits) // 2, len(inits) - 1):
+        c, p, g, t = ds[item]
+        p_ref, g_ref, t_ref = _restate_with_pandas(fields, times, inits[item], L, dt_h, ctx, PROG)
+        assert p.shape == (L + 1, 1, 2, 3) and g.shape == (L + 1, 4, 2, 3) and t.shape == (L + 1 - ctx, 4, 2, 3)      # inclusive slices: one frame more
+        assert np.array_equal(p, p_ref) and np.array_equal(g, g_ref) and np.array_equal(t, t_ref)
+
+
+def test_make_biweekly_inits_equals_the_pandas_construction():
+    import pandas as pd
+    for start, end, L, dt_h in (("2017-01-01", "2018-12-31", 57, 6), ("2017-01-01", "2017-03-01", 15, 6), ("2016-02-25", "2016-06-30", 20, 12)):
+        t1 = pd.date_range(start=start, end=pd.Timestamp(end) - pd.Timedelta(hours=L * dt_h), freq="7D")
+        t2 = pd.date_range(start=pd.Timestamp(start) + pd.Timedelta(days=3), end=pd.Timestamp(end) - pd.Timedelta(hours=L * dt_h), freq="7D")
+        want = t1.append(t2).sort_values().to_numpy()
+        got = wbdata.make_biweekly_inits(start, end, L, dt_h)
+        assert np.array_equal(got.astype("datetime64[ns]"), want.astype("datetime64[ns]"))
+
+
+def test_init_dates_past_the_record_fills_prescribed_from_2017_and_prognostic_with_zeros():
+    """An initialisation date three frames before the record ends (2018-12-31 18:00): the prescribed variable continues with the same
+    calendar dates of 2017 (datasets.py:348-360), the prognostic window is zero-filled up to sequence_length frames (:386-389)."""
+    L, dt_h, ctx = 8, 6, 1
+    fields, times = _dated_fields("2017-01-01", 4 * 365 * 2, dt_h)
+    init = np.array([times[-3].to_numpy(), np.datetime64("2018-02-27T00")])
+    ds = wbdata.WeatherBenchArrays(fields, PROG, ["tisr"], None, sequence_length=L, context_size=ctx, times=times.to_numpy(), init_dates=init,
+                                   timedelta=dt_h)
+    for item in range(2):
+        c, p, g, t = ds[item]
+        p_ref, g_ref, t_ref = _restate_with_pandas(fields, times, init[item], L, dt_h, ctx, PROG)
+        assert np.array_equal(p, p_ref) and np.array_equal(g, g_ref) and np.array_equal(t, t_ref)
+    c, p, g, t = ds[0]
+    assert p.shape[0] == L                                            # 3 frames of the record + 5 from 2017
+    last = 4 * 365 * 2 - 1
+    assert p[0, 0, 0, 0] == 5000 + last - 2 and p[2, 0, 0, 0] == 5000 + last
+    assert p[3, 0, 0, 0] == 5000 + 1                                  # the LAST five dates of the inclusive range d0 .. d0 + 8 dt start at 2019-01-01 06:00 -> 2017-01-01 06:00 = index 1
+                                                                      # (the reference skips 2019-01-01 00:00 that way: reproduced, not fixed)
+    assert g.shape[0] == L - 1 and np.all(g[3:] == 0)                 # 3 real frames + zero fill to L, minus the shifted last one
+
+
+def test_netcdf3_files_of_the_weatherbench_layout_load_into_the_sample_assembly(tmp_path):
+    """Classic NetCDF files written with scipy (the one NetCDF flavour this image can read or write): two yearly files of a surface
+    variable, one level-resolved file, a constants file; time in "hours since 1900-01-01" as WeatherBench stores it."""
+    import pandas as pd
+    from scipy.io import netcdf_file
+    H, W = 3, 4
+
+    def write(path, name, times, data, levels=None):
+        with netcdf_file(str(path), "w") as f:
+            f.createDimension("time", len(times)); f.createDimension("lat", H); f.createDimension("lon", W)
+            tv = f.createVariable("time", "i4", ("time",))
+            tv[:] = ((times - pd.Timestamp("1900-01-01")) / pd.Timedelta("1h")).astype(np.int32)
+            tv.units = "hours since 1900-01-01 00:00:00.0"
+            if levels is None:
+                f.createVariable(name, "f4", ("time", "lat", "lon"))[:] = data
+            else:
+                f.createDimension("level", len(levels))
+                f.createVariable("level", "i4", ("level",))[:] = np.array(levels, dtype=np.int32)
+                f.createVariable(name, "f4", ("time", "level", "lat", "lon"))[:] = data
+    t16 = pd.date_range("2016-12-30", "2016-12-31 18:00", freq="6h")
+    t17 = pd.date_range("2017-01-01", "2017-01-03 18:00", freq="6h")
+    ones = np.ones((1, H, W), dtype=np.float32)
+    write(tmp_path / "t2m_2016.nc", "t2m", t16, (100 + np.arange(len(t16), dtype=np.float32))[:, None, None] * ones)
+    write(tmp_path / "t2m_2017.nc", "t2m", t17, (200 + np.arange(len(t17), dtype=np.float32))[:, None, None] * ones)
+    zz = np.stack([(300 + np.arange(len(t16) + len(t17), dtype=np.float32))[:, None, None] * ones,
+                   (400 + np.arange(len(t16) + len(t17), dtype=np.float32))[:, None, None] * ones], axis=1)
+    write(tmp_path / "z_all.nc", "z", t16.append(t17), zz, levels=[500, 700])
+    with netcdf_file(str(tmp_path / "constants.nc"), "w") as f:
+        f.createDimension("lat", H); f.createDimension("lon", W)
+        f.createVariable("orography", "f4", ("lat", "lon"))[:] = np.full((H, W), 7.0, dtype=np.float32)
+    prog = {"t2m": [], "z": [500, 700]}
+    paths = [str(p) for p in tmp_path.glob("*.nc")]
+    fields, times = wbdata.load_netcdf3_fields(paths, prog, [], ["orography"], start_date="2016-12-31", stop_date="2017-01-02T18", timedelta=2)
+    want_t = pd.date_range("2016-12-31", "2017-01-02 18:00", freq="12h").to_numpy().astype("datetime64[h]")
+    assert np.array_equal(times, want_t)                                  # label-inclusive, every second frame
+    assert np.array_equal(fields["t2m"][:, 0, 0], [104, 106, 200, 202, 204, 206])
+    assert np.array_equal(fields["z"][700][:, 0, 0], 400 + np.arange(4, 16, 2))
+    ds = wbdata.WeatherBenchArrays(fields, prog, None, ["orography"], sequence_length=2, context_size=1, times=times)
+    c, p, g, t = ds[0]
+    assert c.shape == (1, 1, H, W) and g.shape == (2, 3, H, W) and np.array_equal(g[:, 0, 0, 0], [104, 106])
+    # an HDF5-based NetCDF-4 file is refused with a message that says why
+    (tmp_path / "hdf5.nc").write_bytes(b"\\x89HDF\\r\\n\\x1a\\n" + b"\\0" * 64)
+    try:
+        wbdata.load_netcdf3_fields([str(tmp_path / "hdf5.nc")], prog)
+        assert False, "an HDF5 file must be refused"
+    except OSError as e:
+        assert "NetCDF-3" in str(e)
