@@ -11,7 +11,7 @@ longitude circularly and latitude with zeros (:446-451).  The rollout is the dlw
 import torch
 import torch.nn as nn
 
-from ..nsbench.swin_transformer import _NORMS, BasicLayer, PatchEmbed, PatchMerging
+from ..nsbench.swin_transformer import _NORMS, BasicLayer, PatchEmbed, PatchMerging, absolute_position_tokens
 from ..token_ops import DropPathPool, PatchConv2d, UpConvT2d
 from .rollout import rollout
 
@@ -28,8 +28,9 @@ class SwinTransformer(nn.Module):
         super().__init__()
         if mesh != "equirectangular":
             raise NotImplementedError("only the equirectangular mesh is on the MI355X hot path (healpix needs dgl)")
-        if ape:
-            raise NotImplementedError("absolute position embedding is not on the MI355X hot path")
+        if frozen_stages >= 0:
+            raise NotImplementedError("frozen_stages >= 0 (a fine-tuning option: stop gradients of the first stages) is not "
+                                      "built; the shipped configs use -1")
         if drop_rate or attn_drop_rate:
             raise NotImplementedError("dropout is not on the MI355X hot path (the shipped config uses drop_rate 0 and "
                                       "attn_drop_rate 0)")
@@ -41,6 +42,10 @@ class SwinTransformer(nn.Module):
         pad_modes = ("constant", "circular")     # (latitude, longitude)
         self.patch_embed = PatchEmbed(patch_size, in_chans, embed_dim, norm if patch_norm else None, pad_modes)
         res = (img_height // patch_size, img_width // patch_size)
+        self.ape = ape
+        if ape:     # learned [1, E, Wh0, Ww0] embedding added to the embedded patches (reference :540-547)
+            self.absolute_pos_embed = nn.Parameter(torch.zeros(1, embed_dim, res[0], res[1]))
+            nn.init.trunc_normal_(self.absolute_pos_embed, std=.02)
         self.layers = nn.ModuleList()
         for i in range(self.num_layers):
             if window_size is None and i < self.num_layers - 1 and (res[0] % 2 or res[1] % 2):
@@ -70,6 +75,8 @@ class SwinTransformer(nn.Module):
         x = self.patch_embed(x)
         Wh, Ww = x.shape[2], x.shape[3]
         x = x.flatten(2).transpose(1, 2)
+        if self.ape:
+            x = x + absolute_position_tokens(self.absolute_pos_embed, Wh, Ww).to(x.dtype)
         # U-decoder on channels-last tokens (reference :580-591 / one_step): stage outputs stay [B, H, W, C], the transposed
         # convolutions are a GEMM + one interleave kernel each, the 1 x 1 head is a GEMM; NCHW only for the returned frame
         feats = []

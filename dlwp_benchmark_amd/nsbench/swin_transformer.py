@@ -450,6 +450,14 @@ class PatchEmbed(nn.Module):
         return x
 
 
+def absolute_position_tokens(embed, Wh, Ww):
+    """`ape=True` (reference nsbench :640-643, dlwpbench :650-653): the [1, E, Wh0, Ww0] embedding as [1, Wh*Ww, E] tokens,
+    resized bicubically when the token grid is not the one it was built for (on the shipped grids the resize is the identity)."""
+    if embed.shape[2] != Wh or embed.shape[3] != Ww:
+        embed = F.interpolate(embed, size=(Wh, Ww), mode="bicubic")
+    return embed.flatten(2).transpose(1, 2)
+
+
 _NORMS = {"nn.LayerNorm": LayerNorm, "th.nn.LayerNorm": LayerNorm, "torch.nn.LayerNorm": LayerNorm}
 
 
@@ -462,8 +470,9 @@ class SwinTransformer(nn.Module):
         """window_size (extra kwarg, not in the reference): None = the reference behaviour (every stage attends over its
         whole feature map, :528); an int gives classic Swin windows (e.g. 7 for BASELINE C4) with padding to multiples."""
         super().__init__()
-        if ape:
-            raise NotImplementedError("absolute position embedding is not on the MI355X hot path")
+        if frozen_stages >= 0:
+            raise NotImplementedError("frozen_stages >= 0 (a fine-tuning option: stop gradients of the first stages) is not "
+                                      "built; the shipped configs use -1")
         if drop_rate or attn_drop_rate:
             raise NotImplementedError("dropout is not on the MI355X hot path (the shipped configs use drop_rate 0 and "
                                       "attn_drop_rate 0)")
@@ -473,6 +482,10 @@ class SwinTransformer(nn.Module):
         self.patch_embed = PatchEmbed(patch_size, in_chans * context_size, embed_dim, norm if patch_norm else None,
                                       padding_mode)
         resolution = pretrain_img_size // patch_size
+        self.ape = ape
+        if ape:     # learned [1, E, Wh0, Ww0] embedding added to the embedded patches (reference :530-537)
+            self.absolute_pos_embed = nn.Parameter(torch.zeros(1, embed_dim, resolution, resolution))
+            nn.init.trunc_normal_(self.absolute_pos_embed, std=.02)
         self.layers = nn.ModuleList()
         for i in range(self.num_layers):
             # window = the stage's whole feature map (reference :528): global attention with a half-map shift
@@ -503,6 +516,8 @@ class SwinTransformer(nn.Module):
         x = self.patch_embed(x)
         Wh, Ww = x.shape[2], x.shape[3]
         x = x.flatten(2).transpose(1, 2)
+        if self.ape:
+            x = x + absolute_position_tokens(self.absolute_pos_embed, Wh, Ww).to(x.dtype)
         # U-decoder on channels-last tokens (reference :580-591 / one_step): stage outputs stay [B, H, W, C], the transposed
         # convolutions are a GEMM + one interleave kernel each, the 1 x 1 head is a GEMM; NCHW only for the returned frame
         feats = []

@@ -122,6 +122,14 @@ def basic_layer(x, p, pre, H, W, ws, depth, heads, downsample, padding_mode="con
     return x, H, W, x, H, W
 
 
+def add_ape(x, p, Wh, Ww):
+    """`ape=True` (nsbench :640-643, dlwpbench :650-653): the learned [1, E, Wh0, Ww0] embedding, resized bicubically to the
+    token grid, added to the embedded patches (after the patch norm).  Present in `p` only when the model was built with it."""
+    if "absolute_pos_embed" not in p:
+        return x
+    return x + F.interpolate(p["absolute_pos_embed"], size=(Wh, Ww), mode="bicubic").flatten(2).transpose(1, 2)
+
+
 def swin_one_step(x, p, cfg):
     ps, E, depths, heads = cfg["patch_size"], cfg["embed_dim"], cfg["depths"], cfg["num_heads"]
     x = F.conv2d(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], stride=ps)
@@ -129,6 +137,7 @@ def swin_one_step(x, p, cfg):
     x = x.flatten(2).transpose(1, 2)
     if cfg.get("patch_norm", True):
         x = F.layer_norm(x, (E,), p["patch_embed.norm.weight"], p["patch_embed.norm.bias"])
+    x = add_ape(x, p, Wh, Ww)
     res = cfg["pretrain_img_size"] // ps
     outs = []
     for i in range(len(depths)):
@@ -223,6 +232,7 @@ def dlwp_swin_one_step(x, p, cfg):
     x = x.flatten(2).transpose(1, 2)
     if cfg.get("patch_norm", True):
         x = F.layer_norm(x, (E,), p["patch_embed.norm.weight"], p["patch_embed.norm.bias"])
+    x = add_ape(x, p, Wh, Ww)
     res = (cfg["img_height"] // ps, cfg["img_width"] // ps)
     outs = []
     for i in range(len(depths)):

@@ -389,3 +389,49 @@ def test_swin_blocks_with_fused_stochastic_depth_and_bf16_window_moves_equal_the
     tol = 1e-5 if storage == "fp32" else 2e-2
     for u, v in zip(a, b):
         assert (u - v).abs().max().item() <= tol * v.abs().max().item() + 1e-12
+
+
+# ---- ape=True (absolute position embedding; fixtures: tests/golden/make_swin_ape_golden.py) ----------------------------
+GA = np.load(os.path.join(os.path.dirname(__file__), "golden", "swin_ape_golden.npz"))
+
+
+def _load_ape(net, tag):
+    sd = {k[len(tag) + 3:]: torch.from_numpy(GA[k]) for k in GA.files if k.startswith(f"{tag}_p_")}
+    assert "absolute_pos_embed" in sd
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and all("relative_position_index" in m for m in missing), (missing, unexpected)
+
+
+@pytest.mark.parametrize("tag", ["ns", "ns_resized"])
+def test_ns_swin_ape_matches_reference_golden(cuda, tag):
+    """`ns`: frame = pretraining size; `ns_resized`: 24 x 24 frames on the 16 x 16 embedding (the bicubic resize is real)."""
+    from dlwp_benchmark_amd.nsbench.swin_transformer import SwinTransformer
+    ta = lambda n: torch.from_numpy(GA[f"{tag}_{n}"])   # noqa: E731
+    net = SwinTransformer(context_size=2, pretrain_img_size=32, patch_size=2, in_chans=1, out_chans=1, embed_dim=8,
+                          depths=[2, 2], num_heads=[2, 2], drop_path_rate=0.0, ape=True)
+    _load_ape(net, tag)
+    net = net.to(cuda)
+    y = net(ta("x").to(cuda), teacher_forcing_steps=2)
+    assert rel(y, ta("y")) <= 1e-4
+    loss = torch.nn.functional.mse_loss(y, ta("target").to(cuda))
+    loss.backward()
+    for n, p in net.named_parameters():
+        if f"{tag}_g_{n}" in GA.files:
+            assert rel(p.grad, ta(f"g_{n}")) <= 2e-3, n
+
+
+def test_dlwp_swin_ape_matches_reference_golden(cuda):
+    from dlwp_benchmark_amd import dlwpbench
+    ta = lambda n: torch.from_numpy(GA[f"dlwp_{n}"])   # noqa: E731
+    net = dlwpbench.SwinTransformer(**DLWP_CFG["multi"], ape=True)
+    _load_ape(net, "dlwp")
+    net = net.to(cuda).train()
+    y = net(constants=ta("constants").to(cuda), prescribed=ta("prescribed").to(cuda), prognostic=ta("prognostic").to(cuda))
+    assert rel(y, ta("y")) <= 1e-4
+    loss = torch.nn.functional.mse_loss(y, ta("target").to(cuda))
+    loss.backward()
+    for n, p in net.named_parameters():
+        if f"dlwp_g_{n}" in GA.files:
+            assert rel(p.grad, ta(f"g_{n}")) <= 2e-3, n
+    # the bf16 activation mode keeps the embedding add in the activation dtype
+    assert net.absolute_pos_embed.grad is not None and net.absolute_pos_embed.grad.shape == net.absolute_pos_embed.shape

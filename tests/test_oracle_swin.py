@@ -79,3 +79,37 @@ def test_dlwp_swin_matches_reference(tag):
     for n, v in p.items():
         if f"{tag}_g_{n}" in GD.files:
             assert rel(v.grad, td(f"g_{n}")) < 2e-4, n
+
+
+# ---- ape=True (absolute position embedding) ----------------------------------------------------------------
+GA = np.load(os.path.join(os.path.dirname(__file__), "golden", "swin_ape_golden.npz"))
+NS_APE_CFG = dict(context_size=2, pretrain_img_size=32, patch_size=2, embed_dim=8, depths=[2, 2], num_heads=[2, 2])
+
+
+def _ape_case(tag):
+    td = lambda n: torch.from_numpy(GA[f"{tag}_{n}"])   # noqa: E731
+    p = {k[len(tag) + 3:]: torch.from_numpy(GA[k]).clone().requires_grad_(True) for k in GA.files if k.startswith(f"{tag}_p_")}
+    assert "absolute_pos_embed" in p
+    return td, p
+
+
+@pytest.mark.parametrize("tag", ["ns", "ns_resized"])
+def test_ns_swin_ape_matches_reference(tag):
+    """`ns`: frame = pretraining size (the bicubic resize is the identity); `ns_resized`: a 24 x 24 frame on the 16 x 16 embedding."""
+    td, p = _ape_case(tag)
+    y = swin_ref.swin_rollout(td("x"), p, NS_APE_CFG, teacher_forcing_steps=2)
+    assert rel(y.detach(), td("y")) < 1e-5
+    loss = torch.nn.functional.mse_loss(y, td("target"))
+    loss.backward()
+    for n, v in p.items():
+        assert rel(v.grad, td(f"g_{n}")) < 2e-4, n
+
+
+def test_dlwp_swin_ape_matches_reference():
+    td, p = _ape_case("dlwp")
+    y = swin_ref.dlwp_swin(td("constants"), td("prescribed"), td("prognostic"), p, DLWP_CFG["multi"])
+    assert rel(y.detach(), td("y")) < 1e-5
+    loss = torch.nn.functional.mse_loss(y, td("target"))
+    loss.backward()
+    for n, v in p.items():
+        assert rel(v.grad, td(f"g_{n}")) < 2e-4, n
