@@ -14,6 +14,7 @@ inline int dlwp_tune_or(const char* name, int dflt) { const int v = dlwp_tune(na
 // prof.hip -- live per-kernel accounting (dlwp_prof_enable / _collect / _get): a scope object around a launch records an event pair
 // on the launch stream plus the kernel's name and its algorithmic flops / HBM bytes; free when disabled or under stream capture
 bool dlwp_prof_on();
+bool dlwp_prof_detail();     // dlwp_prof_enable(2): row names carry shapes (one row per distinct product / launch geometry)
 struct dlwp_prof_scope {
     int idx;
     hipStream_t stream;

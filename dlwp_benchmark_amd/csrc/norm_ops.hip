@@ -232,15 +232,15 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __r
     }
 }
 
-template <int LPR>
-__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+template <int LPR, int NW = 4>                 // NW waves per workgroup
+__global__ __launch_bounds__(64 * NW) void layernorm_bwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ gy, const float* __restrict__ gadd,
                                                                 float* __restrict__ gx, float* ggamma, float* gbeta, int T, int C,
                                                                 int rows_per_block, int gy_bf16) {
     extern __shared__ float sm[];            // [2][C] per-block partial of ggamma, gbeta
     constexpr int RPW = 64 / LPR;
-    for (int c = threadIdx.x; c < 2 * C; c += 256) sm[c] = 0.f;
+    for (int c = threadIdx.x; c < 2 * C; c += 64 * NW) sm[c] = 0.f;
     __syncthreads();
     const int lane = lane_id(), w = wave_id(), l = lane % LPR, rr = lane / LPR;
     const bool okc = 4 * l < C;
@@ -254,13 +254,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
 #define LN_BWD_UB 4          // 8 was measured in round 6 (250 VGPRs, two waves per SIMD): <32> 37.4 -> 38.9 us, <64> unchanged
 #endif
     constexpr int UB = LN_BWD_UB;
-    for (int it0 = w * RPW; it0 < rows_per_block; it0 += 4 * RPW * UB) {
+    for (int it0 = w * RPW; it0 < rows_per_block; it0 += NW * RPW * UB) {
         f32x4 xv[UB], gv[UB], av[UB];
         float mu[UB], rs[UB];
         bool ok[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            const int it = it0 + 4 * RPW * u;
+            const int it = it0 + NW * RPW * u;
             const long long row = row0 + it + rr;
             ok[u] = okc && row < T && it + rr < rows_per_block;
             xv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            const long long row = row0 + it0 + 4 * RPW * u + rr;
+            const long long row = row0 + it0 + NW * RPW * u + rr;
             f32x4 xh, gg;
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -312,14 +312,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
     for (int o = LPR; o < 64; o <<= 1)
 #pragma unroll
         for (int k = 0; k < 4; ++k) { pg[k] += __shfl_xor(pg[k], o); pb[k] += __shfl_xor(pb[k], o); }
-    for (int ww = 0; ww < 4; ++ww) {
-        if (w == ww && rr == 0 && okc) {
+    if (NW == 4) {
+        for (int ww = 0; ww < 4; ++ww) {
+            if (w == ww && rr == 0 && okc) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { sm[4 * l + k] += pg[k]; sm[C + 4 * l + k] += pb[k]; }
+                for (int k = 0; k < 4; ++k) { sm[4 * l + k] += pg[k]; sm[C + 4 * l + k] += pb[k]; }
+            }
+            __syncthreads();
+        }
+    } else {                                 // many waves: LDS float adds instead of one barrier per wave
+        if (rr == 0 && okc) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { atomicAdd(&sm[4 * l + k], pg[k]); atomicAdd(&sm[C + 4 * l + k], pb[k]); }
         }
         __syncthreads();
     }
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = threadIdx.x; c < C; c += 64 * NW) {
         atomic_add_f32(&ggamma[c], sm[c]);
         atomic_add_f32(&gbeta[c], sm[C + c]);
     }
@@ -588,6 +596,20 @@ extern "C" int dlwp_layernorm_fwd(const float* x, const float* gamma, const floa
     return dlwp_layernorm_fwd_ex(x, gamma, beta, y, mean, rstd, T, C, eps, 0, stream);
 }
 
+// waves per workgroup of layernorm_bwd_vec_kernel (round 6).  The launch ends with 2 C float atomics per workgroup on
+// the same 2 C addresses (~ 17 ns each: 8 - 10 us of a 512-workgroup launch, tools/probe_layernorm_bwd.py with the tail switched off), so
+// the large inputs run the same number of waves in HALF the workgroups: 256 workgroups of eight waves, one per CU (65536 x 96: 30.4 -> 25.8 us,
+// 32768 x 192: 30.8 -> 28.2 us, 16384 x 192: 22.2 -> 19.3 us back to back; Swin C4 398 -> 405 samples/s).  Sixteen waves (128 workgroups) leave
+// half the CUs idle and lose; the wide-row kernel (one row per wave and step) does not gain from eight waves (8192 x 384 21.3 -> 22.3 us,
+// 16200 x 768 39.6 -> 46.0 us) and stays at four.
+// A grouped slab + last-workgroup sum of the partials was measured as well: the returning atomics and the ticket cost more than the tail
+// they replace (profiles/r06_experiments.md section 8).  LN_BWD_NW: 4 or 8 overrides.
+static int ln_bwd_waves(int T, int C) {
+    const int env = dlwp_tune("LN_BWD_NW");
+    if (env == 4 || env == 8) return env;
+    return T >= 2048 && (long long)T * C >= (1 << 21) ? 8 : 4;
+}
+
 static int layernorm_bwd_impl(const float* x, const float* gamma, const float* mean, const float* rstd, const float* gy,
                               const float* gadd, float* gx, float* ggamma, float* gbeta, int T, int C, int gy_bf16,
                               void* stream) {
@@ -630,9 +652,14 @@ static int layernorm_bwd_impl(const float* x, const float* gamma, const float* m
     }
     if (narrow) {
         dlwp_prof_scope prof((hipStream_t)stream, pflops, pbytes, "layernorm_bwd_vec_kernel<%d>", C <= 32 ? 8 : C <= 64 ? 16 : C <= 128 ? 32 : 64);
-#define LN_BWD_V(LPR) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<LPR>, grid, dim3(256), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, \
-                                          gadd, gx, ggamma, gbeta, T, C, rpb, gy_bf16)
+        const int nw = ln_bwd_waves(T, C);
+        const int rpbn = nw == 8 ? std::max(8, ceil_div(ceil_div(T, 256), 8) * 8) : rpb;      // eight waves: one workgroup per CU
+        const dim3 gridn(ceil_div(T, rpbn));
+#define LN_BWD_V2(LPR, NW_) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<LPR, NW_>), gridn, dim3(64 * NW_), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, \
+                                          gadd, gx, ggamma, gbeta, T, C, rpbn, gy_bf16)
+#define LN_BWD_V(LPR) do { if (nw == 8) LN_BWD_V2(LPR, 8); else LN_BWD_V2(LPR, 4); } while (0)
         if (C <= 32) LN_BWD_V(8); else if (C <= 64) LN_BWD_V(16); else if (C <= 128) LN_BWD_V(32); else LN_BWD_V(64);
+#undef LN_BWD_V2
 #undef LN_BWD_V
         DLWP_LAUNCH_CHECK();
         return DLWP_OK;

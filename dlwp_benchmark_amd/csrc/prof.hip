@@ -40,6 +40,7 @@ std::vector<Row> g_rows;
 }  // namespace
 
 bool dlwp_prof_on() { return g_on.load(std::memory_order_relaxed) != 0; }
+bool dlwp_prof_detail() { return g_on.load(std::memory_order_relaxed) == 2; }
 
 dlwp_prof_scope::dlwp_prof_scope(hipStream_t s, double flops, double bytes, const char* fmt, ...) : idx(-1), stream(s) {
     if (!dlwp_prof_on()) return;
@@ -72,7 +73,7 @@ extern "C" int dlwp_prof_enable(int on) {
         g_recs.clear();
         g_rows.clear();
     }
-    g_on.store(on ? 1 : 0, std::memory_order_relaxed);
+    g_on.store(on == 2 ? 2 : on ? 1 : 0, std::memory_order_relaxed);
     return DLWP_OK;
 }
 

@@ -70,6 +70,15 @@ static inline double gemm_prof_bytes(const GemmDev& a) {
     return nbA * eA * a.M * (double)a.K + nbB * eB * a.N * (double)a.K + nbC * mn * eC * (1 + (a.preact ? 1 : 0) + (a.accumulate ? 1 : 0)) +
            (a.residual ? nbC * mn * eR : 0.0) + (a.bias ? 4.0 * (a.bias_row ? a.M : a.N) : 0.0);
 }
+// dlwp_prof_enable(2): the row names carry the product's shape and epilogue (one row per distinct product of the step)
+struct GemmProfTag { char s[96]; };
+static inline GemmProfTag gemm_prof_tag(const GemmDev& a) {
+    GemmProfTag t; t.s[0] = 0;
+    if (dlwp_prof_detail())
+        snprintf(t.s, sizeof t.s, " M%d N%d K%d x%d dt%d%s%s%s%s%s", a.M, a.N, a.K, a.nbatch, a.dt, a.bias ? " bias" : "", a.act ? " act" : "",
+                 a.preact ? " pre" : "", a.residual ? " res" : "", a.accumulate ? " acc" : "");
+    return t;
+}
 
 // bf16-operand mode (dlwp_set_gemm_precision(1)): operands are rounded to bf16 when a tile is committed to LDS and
 // multiplied by v_mfma_f32_16x16x32_bf16 (16x the fp32 MFMA rate) with fp32 accumulation -- the arithmetic of the
@@ -855,8 +864,8 @@ int gemm_launch_t(const GemmDev& a, dim3 grid, hipStream_t s) {
                           : sizeof(float) * 4 * Tile<T>::FLOATS;
     int rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_kernel<AKC, BKC, VEC, T, BF, S16M>), lds, "gemm");
     if (rc) return rc;
-    dlwp_prof_scope prof(s, gemm_prof_flops(a), gemm_prof_bytes(a), "gemm_kernel<%s, %s, %d, %d, %s, %d>", AKC ? "true" : "false",
-                         BKC ? "true" : "false", VEC, T, BF ? "true" : "false", S16M);
+    dlwp_prof_scope prof(s, gemm_prof_flops(a), gemm_prof_bytes(a), "gemm_kernel<%s, %s, %d, %d, %s, %d>%s", AKC ? "true" : "false",
+                         BKC ? "true" : "false", VEC, T, BF ? "true" : "false", S16M, gemm_prof_tag(a).s);
     hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, T, BF, S16M>), grid, dim3(256), lds, s, a);
     return DLWP_OK;
 }
@@ -884,7 +893,15 @@ int g_gemm_bf16 = 0;    // dlwp_set_gemm_precision
 // TileIO::frag_bf16): per 16-lane group four k-rows x 32 bytes, 32 different banks.
 constexpr int GT = 128, GK = 64;
 
-template <bool BKC, int KD>                                // KD = depth of a K-step: 64 (two workgroups per CU) or 32 (three / four)
+// GN = 96 (round 6): a 128 x 96 output tile.  Every feature width of the C4 models is a multiple of 96 (96 .. 1536) and several of their
+// products have just under one 128 x 128 tile per CU or pad a quarter of the last column tile (8192 x 384: 192 tiles -> 256 of 128 x 96;
+// N = 96 / 192 / 288: 25 % padding -> none).  The B tile is still staged 128 rows / columns wide (the loader, the swizzles and the LDS
+// image are the 128-wide kernel's; the rows past 96 re-read the next tile's or the clamped last rows and are never used); the wave grid
+// stays 2 x 2 with 64 x 48 per wave (4 x 3 MFMA tiles) and the epilogue runs on 192 of the 256 threads (24 float4 columns x 8 rows).
+// A ring of three / four stages with one barrier per step (loads of two / three K-steps in flight) was measured in round 6 for the products
+// with one workgroup per CU: bit-identical, 3 - 6 % faster back to back at K = 384, nothing in the Pangu / Swin C4 steps (a lone workgroup's
+// K-step is bound by its own LDS reads and MFMAs not overlapping, not by the latency of the next loads): not kept (profiles/r06_experiments.md).
+template <bool BKC, int KD, int GN = 128>                  // KD = depth of a K-step: 64 (two workgroups per CU) or 32 (three / four)
 __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmDev a) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     __bf16* lds = reinterpret_cast<__bf16*>(gsm);          // [2 stages][A | B][128][KD]
@@ -901,7 +918,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmDev a) {
     const int grp = tile_id / (GM * a.ntn), within = tile_id - grp * GM * a.ntn;
     const int rows_in = min(GM, a.ntm - grp * GM);
     const int nt_ = within / rows_in, mt = grp * GM + (within - nt_ * rows_in);
-    const int m0 = mt * GT, n0 = nt_ * GT;
+    const int m0 = mt * GT, n0 = nt_ * GN;
     const __bf16* A = reinterpret_cast<const __bf16*>(a.A);
     const __bf16* B = reinterpret_cast<const __bf16*>(a.B);
     // chunk swizzle of a k-contiguous row: a 16-lane group of a ds_read_b128 fragment read (16 rows, one chunk column) must
@@ -934,12 +951,13 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmDev a) {
                                              (__attribute__((address_space(3))) void*)(Bs + (4 * i + w) * 512), 16, 0, 0);
         }
     };
-    const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
-    f32x4 acc[4][4];
+    constexpr int NJ = GN / 32;                            // 16-column MFMA tiles per wave
+    const int wm = (w >> 1) * 64, wn = (w & 1) * (GN / 2);
+    f32x4 acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nk = a.K / KD;
     DLWP_STAMP(10);
     issue(0, 0);
@@ -959,14 +977,14 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmDev a) {
         const __bf16* Bs = As + TILE;
 #pragma unroll
         for (int kk = 0; kk < KD / 32; ++kk) {
-            bf16x8 af[4], bf[4];
+            bf16x8 af[4], bf[NJ];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = wm + 16 * i + r, c = (4 * kk + g) ^ sw(row);
                 af[i] = *reinterpret_cast<const bf16x8*>(As + row * KD + 8 * c);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 if (BKC) {
                     const int row = wn + 16 * j + r, c = (4 * kk + g) ^ sw(row);
                     bf[j] = *reinterpret_cast<const bf16x8*>(Bs + row * KD + 8 * c);
@@ -982,18 +1000,19 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmDev a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                              // every wave has read this stage before it is refilled
     }
     DLWP_STAMP(12);
     // ---- epilogue (two halves of 64 rows through the dead operand buffers; 16-byte global accesses)
-    constexpr int LDE = GT + 4, C4 = GT / 4, RPP = 256 / C4, NPASS = 64 / RPP;
+    constexpr int LDE = GT + 4, C4 = GN / 4, RPP = 8, NPASS = 64 / RPP;
     float* tile = gsm;
+    const bool epi_thread = tid < RPP * C4;                // GN = 96: 192 of the 256 threads
     const int c4 = tid % C4, n = n0 + 4 * c4;
     f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (a.bias && n < a.N) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+    if (a.bias && n < a.N && epi_thread) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         if (half) lds_barrier();
@@ -1001,12 +1020,12 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmDev a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) tile[(i * 16 + 4 * g + q) * LDE + wn + j * 16 + r] = acc[i][j][q];
         }
         lds_barrier();
-        epilogue_rows<NPASS, RPP, C4, LDE, GLDS_EPI_G>(a, tile, tid, m0 + 64 * half, n, bv);
+        if (epi_thread) epilogue_rows<NPASS, RPP, C4, LDE, GLDS_EPI_G>(a, tile, tid, m0 + 64 * half, n, bv);
     }
     DLWP_STAMP(13);
 }
@@ -1245,7 +1264,7 @@ static int gemm_glds_tn_launch(const GemmDev& a_in, hipStream_t s) {
                                                                          : tn_slab_for(s, sizeof(float) * grid.z * (size_t)a.M * a.N);
     int rc;
     {
-    dlwp_prof_scope prof(s, gemm_prof_flops(a), gemm_prof_bytes(a), "gemm_glds_tn_kernel<%d>", kd);
+    dlwp_prof_scope prof(s, gemm_prof_flops(a), gemm_prof_bytes(a), "gemm_glds_tn_kernel<%d>%s", kd, gemm_prof_tag(a).s);
     if (shallow) {
         if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_glds_tn_kernel<32>), lds, "gemm_glds_tn"))) return rc;
         hipLaunchKernelGGL(gemm_glds_tn_kernel<32>, grid, dim3(256), lds, s, a);
@@ -1523,6 +1542,17 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmDev a) {
 
 // shapes the LDS-DMA kernel takes: both operands bf16 arrays with k contiguous and 16-byte aligned rows, K a multiple of 64, one
 // plain product (no split-K / batches / row sums / row bias), the aligned epilogue, enough tiles to be worth 128 x 128
+// column-tile width of gemm_glds_kernel: 96 when N is a multiple of 96 and rounds x width (whole rounds of one workgroup per CU, work per
+// tile ~ its width) comes out lower than with 128-wide tiles; ties go to 128 when N is a multiple of 128.  GEMM_GLDS_N96: 0 never, 1 by
+// this rule (default), 2 wherever N % 96 == 0.
+static int gemm_glds_tile_n(const GemmDev& a) {
+    const int mode = dlwp_tune_or("GEMM_GLDS_N96", 1);
+    if (mode == 0 || a.N % 96 != 0) return GT;
+    if (mode == 2) return 96;
+    const long long ncu = 256, mt = ceil_div(a.M, GT);
+    const long long c128 = ceil_div(mt * ceil_div(a.N, GT), ncu) * 128, c96 = ceil_div(mt * (a.N / 96), ncu) * 96;
+    return c96 < c128 || (c96 == c128 && a.N % GT != 0) ? 96 : GT;
+}
 static bool gemm_glds_applies(const GemmDev& a, bool akc, bool bkc) {
     const bool off = dlwp_tune_on("GEMM_NOGLDS");
     if (off || !g_gemm_bf16 || !akc || (a.dt & (DT_A | DT_B)) != (DT_A | DT_B)) return false;
@@ -1530,18 +1560,19 @@ static bool gemm_glds_applies(const GemmDev& a, bool akc, bool bkc) {
     if (!bkc && a.N % 8) return false;
     if (a.splits != 1 || a.nbatch != 1 || a.atomic_out || a.rowsum || a.bias_row || a.act_b || !a.vec_epi) return false;
     const bool force = dlwp_tune_on("GEMM_GLDS_FORCE");          // measurement: skip the shape heuristic below
-    if (force) return a.M >= GT && a.N >= GT;
+    if (force) return a.M >= GT && a.N >= 64;
     // at least one workgroup per CU: below that the 64 x 64 kernel's shorter prologue wins (measured, profiles/r03_gemm_bench.txt: Pangu
     // 8192 x 192 x 768 104 vs 120 TFLOP/s, 2048 x 1536 x 384 77 vs 93; round 6, in the step: 128 tiles instead of 256 costs Pangu C4 1.3 %).
     // K: rounds 3 - 5 asked for four 64-deep K-steps; with >= 256 tiles the kernel wins from K = 96 on (three 32-deep steps) -- back to back
     // 32768 x 768 x 192 36.2 -> 26.1 us, 65536 x 384 x 96 28.8 -> 21.7 us (profiles/r06_gemm_vs_vendor.txt), in the step Swin C4 390.5 -> 396.5,
     // Pangu C4 107.0 -> 107.9 samples/s (profiles/r06_gemm_glds_threshold_sweep.txt)
     const int mink = dlwp_tune_or("GEMM_GLDS_MINK", 96), mintiles = dlwp_tune_or("GEMM_GLDS_MINTILES", 256);
-    return a.K >= mink && (long long)ceil_div(a.M, GT) * ceil_div(a.N, GT) >= mintiles;
+    return a.K >= mink && (long long)ceil_div(a.M, GT) * ceil_div(a.N, gemm_glds_tile_n(a)) >= mintiles;
 }
 static int gemm_glds_launch(const GemmDev& a_in, bool bkc, hipStream_t s) {
     GemmDev a = a_in;
-    a.ntn = ceil_div(a.N, GT);
+    const int gn = gemm_glds_tile_n(a);
+    a.ntn = ceil_div(a.N, gn);
     a.ntm = ceil_div(a.M, GT);
     const int kd_env = dlwp_tune("GEMM_GLDS_KD");
     // depth of a K-step (profiles/r03_gemm_glds_kd.txt): 32 deep leaves room for three or four workgroups per CU, which wins for
@@ -1551,14 +1582,17 @@ static int gemm_glds_launch(const GemmDev& a_in, bool bkc, hipStream_t s) {
     // 64 KB at KD = 64 (the epilogue's 64 x 132 fp32 half tile fits inside); 33 KB (that half tile) at KD = 32
     const size_t lds = shallow ? sizeof(float) * 64 * (GT + 4) : (size_t)2 * 2 * GT * GK * 2;
     int rc;
-#define GLDS_GO(BKC_, KD_)                                                                                              \
+#define GLDS_GO2(BKC_, KD_, GN_)                                                                                        \
     do {                                                                                                                \
-        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_glds_kernel<BKC_, KD_>), lds, "gemm_glds"))) return rc; \
-        dlwp_prof_scope prof(s, gemm_prof_flops(a), gemm_prof_bytes(a), "gemm_glds_kernel<%s, %d>", BKC_ ? "true" : "false", KD_); \
-        hipLaunchKernelGGL((gemm_glds_kernel<BKC_, KD_>), dim3(a.ntn * a.ntm), dim3(256), lds, s, a);                     \
+        if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_glds_kernel<BKC_, KD_, GN_>), lds, "gemm_glds"))) return rc; \
+        dlwp_prof_scope prof(s, gemm_prof_flops(a), gemm_prof_bytes(a), GN_ == 96 ? "gemm_glds_kernel<%s, %d, 96>%s" : "gemm_glds_kernel<%s, %d>%s", \
+                             BKC_ ? "true" : "false", KD_, gemm_prof_tag(a).s);                                          \
+        hipLaunchKernelGGL((gemm_glds_kernel<BKC_, KD_, GN_>), dim3(a.ntn * a.ntm), dim3(256), lds, s, a);               \
     } while (0)
+#define GLDS_GO(BKC_, KD_) do { if (gn == 96) GLDS_GO2(BKC_, KD_, 96); else GLDS_GO2(BKC_, KD_, 128); } while (0)
     if (bkc) { if (shallow) GLDS_GO(true, 32); else GLDS_GO(true, 64); }
     else     { if (shallow) GLDS_GO(false, 32); else GLDS_GO(false, 64); }
+#undef GLDS_GO2
 #undef GLDS_GO
     return DLWP_OK;
 }
@@ -1771,8 +1805,8 @@ static int gemm_p8_launch(const GemmDev& a_in, bool bkc, hipStream_t s) {
 #define P8_GO(D_, B_, W_)                                                                                               \
     do {                                                                                                                \
         if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_p8_kernel<D_, B_, W_>), lds, "gemm_p8"))) return rc; \
-        dlwp_prof_scope prof(s, gemm_prof_flops(a), gemm_prof_bytes(a), "gemm_p8_kernel<%s, %s, %s>", D_ ? "true" : "false", B_ ? "true" : "false", \
-                             W_ ? "true" : "false");                                                                     \
+        dlwp_prof_scope prof(s, gemm_prof_flops(a), gemm_prof_bytes(a), "gemm_p8_kernel<%s, %s, %s>%s", D_ ? "true" : "false", B_ ? "true" : "false", \
+                             W_ ? "true" : "false", gemm_prof_tag(a).s);                                                 \
         hipLaunchKernelGGL((gemm_p8_kernel<D_, B_, W_>), dim3(std::min(a.ntn * a.ntm, ncu)), dim3(512), lds, s, a);     \
     } while (0)
     if (direct && a.wide_epi) { if (bkc) P8_GO(true, true, true); else P8_GO(true, false, true); }

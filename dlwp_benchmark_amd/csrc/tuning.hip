@@ -25,6 +25,7 @@ Knob g_knobs[] = {
     {"GEMM_GLDS_FORCE", "1: use the LDS-DMA kernel wherever its operand layout allows (skip the shape heuristic)", 0, false},
     {"GEMM_GLDS_MINK", "least K for the 128 x 128 LDS-DMA activation kernels to be taken by shape (default 96)", 0, false},
     {"GEMM_GLDS_MINTILES", "least number of 128 x 128 output tiles for those kernels to be taken by shape (default 256)", 0, false},
+    {"GEMM_GLDS_N96", "128 x 96 output tiles in those kernels: 0 never, 1 when N % 96 == 0 and whole rounds x tile width is lower (default), 2 wherever N % 96 == 0", 0, false},
     {"GEMM_GLDS_KD", "K-step depth of the LDS-DMA activation kernels: 32 or 64 (default by shape)", 0, false},
     {"GEMM_GLDS_TN_KD", "K-step depth of the LDS-DMA weight-gradient kernel: 32 or 64 (default by tile count)", 0, false},
     {"GEMM_GLDS_TN_WGS", "resident workgroup slots the weight-gradient kernel sizes its K slices for", 0, false},
@@ -46,6 +47,7 @@ Knob g_knobs[] = {
     {"WGRAD_MULTI_WGS", "resident workgroup slots dlwp_wgrad_segments sizes its K slices for (default 384)", 0, false},
     {"LN_BWD_WANT", "workgroups of the scalar LayerNorm backward kernel", 0, false},
     {"LN_BWD_NOWIDE", "1: never use the wide-row LayerNorm backward kernel", 0, false},
+    {"LN_BWD_NW", "waves per workgroup of the narrow-row LayerNorm backward kernel: 4 or 8 (default: 8 for inputs of at least 2048 rows and 2 M elements, one workgroup per CU)", 0, false},
     {"LN_BWD_WGS", "workgroups of the wide-row LayerNorm backward kernel (default 384)", 0, false},
     {"WINATTN_D48", "0: head dims 33 .. 48 stay on the tiled window-attention kernels (default 1: windows of at most 64 tokens take the wave-per-window forward and the LDS-staged two-pass backward in the bf16 matrix mode)", 0, false},
     {"WINATTN_SMALL_MIN_PAIRS", "least (window, head) pairs for the head-dim-48 route of the wave-per-window family (default 1024)", 0, false},

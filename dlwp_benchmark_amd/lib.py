@@ -290,8 +290,11 @@ class kernel_accounting:
     _collect / _get): one row per kernel name, sorted by total time, with the calls, the event-bracketed milliseconds and the
     algorithmic flops / HBM bytes the launches' own arguments imply.  Launches inside a hipGraph capture are not recorded."""
 
+    def __init__(self, shapes=False):
+        self.shapes = shapes      # True: GEMM rows carry the product's shape and epilogue (one row per distinct product)
+
     def __enter__(self):
-        check(load().dlwp_prof_enable(1))
+        check(load().dlwp_prof_enable(2 if self.shapes else 1))
         self.rows = []
         return self
 

@@ -60,6 +60,7 @@ int dlwp_tuning_list(int index, const char** name, const char** doc);
 /* on its own stream and recorded with its kernel name, algorithmic flops and algorithmic HBM bytes (from the launch arguments).    */
 /* Not recorded under stream capture.  dlwp_prof_collect() blocks until the recorded events have completed, folds the records by    */
 /* kernel name, sorts by total time and returns the number of rows; dlwp_prof_get(i, ...) reads row i (name truncated to name_len). */
+/* dlwp_prof_enable(2): the GEMM rows also carry the product's shape and epilogue in their name (one row per distinct product).    */
 int dlwp_prof_enable(int on);
 int dlwp_prof_collect(void);
 int dlwp_prof_get(int index, char* name, int name_len, long long* calls, double* ms, double* flops, double* bytes);

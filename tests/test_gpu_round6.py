@@ -110,3 +110,107 @@ def test_dlwp_swin_window7_matches_oracle(cuda, H, W, B):
     for n, q in m.named_parameters():
         if q.grad is not None and p[n].grad is not None:
             assert rel(q.grad, p[n].grad) <= 2e-3, n
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 384, 1536), (8192, 384, 384), (8192, 1152, 384), (16384, 192, 768), (65536 + 70, 96, 288),
+                                   (4100, 288, 96), (1000, 576, 192)])
+@pytest.mark.parametrize("form", ["nt_bias_res", "nt_bias_gelu_pre", "nn_plain", "nn_gelu_grad"])
+def test_glds_gemm_96_wide_tiles_are_the_128_wide_ones_bit_for_bit(cuda, M, N, K, form):
+    """gemm_glds_kernel<.., .., 96> (128 x 96 output tiles: csrc/token_ops.hip) against the 128 x 128 tiles of the same kernel: the K
+    order of every output element is the same, so the results must be identical bits, for y = x W^T and gx = g W, both K-step depths,
+    edge tiles in M, and the epilogues of the token layers.  The result itself is held to a float64 product."""
+    import torch
+    from dlwp_benchmark_amd import lib as L
+    from dlwp_benchmark_amd.token_ops import _gemm, _gemm_batched
+    BF = torch.bfloat16
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(cuda).to(BF)
+    nt = form.startswith("nt")
+    w = ((torch.randn(N, K, generator=g) if nt else torch.randn(K, N, generator=g)) / K ** 0.5).to(cuda).to(BF)
+    bias = torch.randn(N, generator=g).to(cuda)
+    res = torch.randn(M, N, generator=g).to(cuda)
+    zz = torch.randn(M, N, generator=g).to(cuda).to(BF)
+    ref = x.double() @ (w.double().T if nt else w.double())
+    outs = {}
+    L.set_tuning("GEMM_GLDS_FORCE", 1)
+    variants = [0, 2]
+    try:
+        for mode in variants:
+            L.set_tuning("GEMM_GLDS_N96", mode)
+            with L.gemm_precision("bf16"), L.kernel_accounting(shapes=True) as acc:
+                if form == "nt_bias_res":
+                    y = torch.empty(M, N, device=cuda)
+                    _gemm(x, w, y, M, N, K, K, K, N, 0, 1, bias, 0, None, res)
+                    extra = None
+                elif form == "nt_bias_gelu_pre":
+                    y = torch.empty(M, N, device=cuda, dtype=BF)
+                    extra = torch.empty(M, N, device=cuda, dtype=BF)
+                    _gemm(x, w, y, M, N, K, K, K, N, 0, 1, bias, 1, extra, None)
+                elif form == "nn_plain":
+                    y = torch.empty(M, N, device=cuda, dtype=BF)
+                    _gemm(x, w, y, M, N, K, K, N, N, 0, 0)
+                    extra = None
+                else:
+                    y = torch.empty(M, N, device=cuda, dtype=BF)
+                    _gemm_batched(x, w, y, M, N, K, K, N, N, 0, 0, act=4, residual=zz)
+                    extra = None
+                torch.cuda.synchronize()
+            names = [r["name"] for r in acc.rows]
+            assert len(names) == 1 and names[0].startswith("gemm_glds_kernel"), names
+            assert names[0].split(">")[0].endswith(", 96") == (mode == 2), names
+            outs[mode] = (y, extra)
+    finally:
+        for k in ("GEMM_GLDS_N96", "GEMM_GLDS_FORCE"):
+            L.set_tuning(k, None)
+    first = outs[variants[0]]
+    for v in variants[1:]:
+        assert torch.equal(first[0], outs[v][0]), v
+        if first[1] is not None:
+            assert torch.equal(first[1], outs[v][1]), v
+    y = outs[variants[-1]][0].double()
+    if form == "nt_bias_res":
+        want, tol = ref + bias.double() + res.double(), 2e-5
+    elif form == "nt_bias_gelu_pre":
+        want, tol = torch.nn.functional.gelu(ref + bias.double()), 1e-2
+    elif form == "nn_plain":
+        want, tol = ref, 1e-2
+    else:
+        zd = zz.double().requires_grad_()
+        (gd,) = torch.autograd.grad(torch.nn.functional.gelu(zd).sum(), zd)
+        want, tol = ref * gd, 1e-2
+    assert ((y - want).abs().max() / want.abs().max()).item() <= tol
+
+
+@pytest.mark.parametrize("T,C", [(65536, 96), (16384, 192), (32768, 192), (9000, 200), (20000, 52), (2100, 256)])
+def test_layernorm_backward_eight_wave_workgroups(cuda, T, C):
+    """layernorm_bwd_vec_kernel runs the large inputs as 256 workgroups of eight waves (csrc/norm_ops.hip, ln_bwd_waves): gx and the
+    gradients of gamma / beta against a float64 reference for both workgroup sizes, with the residual gradient and a bf16 upstream
+    gradient as the C4 steps pass them, and row counts that are not multiples of the rows per workgroup."""
+    from dlwp_benchmark_amd import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(T + C)
+    x = torch.randn(T, C, generator=g).to(cuda)
+    gy = torch.randn(T, C, generator=g).to(cuda).bfloat16()
+    ga = torch.randn(T, C, generator=g).to(cuda)
+    gam = (1.0 + 0.1 * torch.randn(C, generator=g)).to(cuda)
+    mean = x.mean(1).contiguous()
+    rstd = (x.var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    xh = (x.double() - mean.double()[:, None]) * rstd.double()[:, None]
+    gyd = gy.double()
+    want_g, want_b = (gyd * xh).sum(0), gyd.sum(0)
+    gg_ = gyd * gam.double()
+    want_x = rstd.double()[:, None] * (gg_ - gg_.mean(1, keepdim=True) - xh * (gg_ * xh).mean(1, keepdim=True)) + ga.double()
+    tol = 2e-5 * T ** 0.5
+    for nw in (4, 8):
+        L.set_tuning("LN_BWD_NW", nw)
+        try:
+            gx = torch.empty_like(x)
+            gg, gb = torch.zeros(C, device=cuda), torch.zeros(C, device=cuda)
+            L.check(lib.dlwp_layernorm_bwd_ex(L.ptr(x), L.ptr(gam), L.ptr(mean), L.ptr(rstd), L.ptr(gy), 1, L.ptr(ga), L.ptr(gx), L.ptr(gg), L.ptr(gb),
+                                              T, C, L.stream()))
+            torch.cuda.synchronize()
+        finally:
+            L.set_tuning("LN_BWD_NW", None)
+        assert (gx.double() - want_x).abs().max().item() <= 1e-5 * want_x.abs().max().item(), nw
+        assert (gg.double() - want_g).abs().max().item() <= tol * want_g.abs().max().item(), nw
+        assert (gb.double() - want_b).abs().max().item() <= tol * want_b.abs().max().item(), nw
