@@ -576,12 +576,25 @@ constexpr int LDB = 36;        // bf16 elements per staged row (32 + 4: 72 B, 8-
 constexpr int LDB48 = 52;
 template <int LB = LDB>
 __device__ __forceinline__ s16x4 lds_row(const bf16_t* m, int row, int c0) { return *reinterpret_cast<const s16x4*>(m + row * LB + c0); }
+// Four consecutive rows row0 .. row0 + 3 of column c -- the A operand of the transposed products (dV^T += dO^T P, dK^T += Q^T dS,
+// dQ^T = K^T dS^T, O^T = V^T P^T), always called with row0 = (a 16-row chunk) + 4 g and c = 16 db + r.  Round 6: ONE transposing
+// read (ds_read_b64_tr_b16) instead of four 2-byte reads and three packs per fragment: within a 16-lane group lane r hands the
+// hardware the 8-byte piece [row0 + (r >> 2)][16 db + 4 (r & 3) .. + 3] of the 4 x 16 block and receives its column r.  All 64
+// lanes must be active (every call site sits under wave-uniform control flow); rows are 8-byte aligned (pitch 72 / 104 bytes).
 template <int LB = LDB>
 __device__ __forceinline__ s16x4 lds_col(const bf16_t* m, int row0, int c) {
-    s16x4 v;
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) v[s2] = (short)m[(row0 + s2) * LB + c];
-    return v;
+    static_assert((LB * 2) % 8 == 0, "8-byte aligned rows");
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int r = c & 15;
+    const bf16_t* p = m + (row0 + (r >> 2)) * LB + (c - r) + 4 * (r & 3);
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+}
+// the same with a run-time row pitch (elements; a multiple of 4)
+__device__ __forceinline__ s16x4 lds_col_pitch(const bf16_t* m, int pitch, int row0, int c) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int r = c & 15;
+    const bf16_t* p = m + (row0 + (r >> 2)) * pitch + (c - r) + 4 * (r & 3);
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
 }
 
 struct LdsWin {
@@ -1127,8 +1140,9 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
                     dk[db] = mfma_bf(cur.qcol[db], dsb, dk[db]);     // dK^T += (scale Q)^T dS
                 }
                 if (!(a.dbg & 4)) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) L2.dsm[(q0 + j) * LDD + key] = (bf16_t)dsb[j];      // dS, queries on the rows
+                    // dS with the KEYS on the rows: one 8-byte store of this lane's four queries (round 6; the [query][key] image took
+                    // four 2-byte stores); pass 2 gets its [key 4g .. 4g + 3][query r] operand through the transposing read
+                    *reinterpret_cast<s16x4*>(L2.dsm + key * LDD + q0) = dsb;
                 }
                 cur = nxt;
             }
@@ -1165,15 +1179,14 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
 #pragma unroll
             for (int db = 0; db < NDB; ++db) dq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (qc >= qlo && qc < qhi) {
-                const bf16_t* srow = L2.dsm + (16 * qc + r) * LDD + 4 * g;
-                s16x4 sf = *reinterpret_cast<const s16x4*>(srow), sn = sf;
+                s16x4 sf = lds_col_pitch(L2.dsm, LDD, 4 * g, 16 * qc + r), sn = sf;
                 s16x4 kcol[NDB], kn[NDB];
 #pragma unroll
                 for (int db = 0; db < NDB; ++db) kn[db] = kcol[db] = lds_col(L.K, 4 * g, 16 * db + r);
 #pragma unroll 1
                 for (int kc = 0; kc < NCr; ++kc) {
                     if (kc + 1 < NCr) {
-                        sn = *reinterpret_cast<const s16x4*>(srow + 16 * (kc + 1));
+                        sn = lds_col_pitch(L2.dsm, LDD, 16 * (kc + 1) + 4 * g, 16 * qc + r);
 #pragma unroll
                         for (int db = 0; db < NDB; ++db) kn[db] = lds_col(L.K, 16 * (kc + 1) + 4 * g, 16 * db + r);
                     }
