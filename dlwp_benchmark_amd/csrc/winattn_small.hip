@@ -915,8 +915,9 @@ __device__ __forceinline__ void lds2_load(Stage2<IOBF>& R, const Idx2& I, const 
             R.v[i] = *reinterpret_cast<const f32x2*>(qb + qo + 2 * hd);
             R.g[i] = *reinterpret_cast<const f32x2*>(gb + go);
             R.o[i] = *reinterpret_cast<const f32x2*>(ob + go);
-            R.pad |= (I.s[i] < 0 ? 1 : 0) << i;
-            if (I.d[i] < 0) { R.g[i] = f32x2{0.f, 0.f}; R.o[i] = R.g[i]; }
+            // flags only: a select on a value that has just been requested would make the wave wait for it HERE (round 6: the stamps
+            // showed 5.8 k cycles between the end of the staging and the first tile pair of every window); lds2_store applies them
+            R.pad |= ((I.s[i] < 0 ? 1 : 0) << i) | ((I.d[i] < 0 ? 4 : 0) << i);
         }
     } else {
         const float* qb = a.qkv + (full ? tb0 : wb0) * rs + w.head * d;
@@ -935,15 +936,13 @@ __device__ __forceinline__ void lds2_load(Stage2<IOBF>& R, const Idx2& I, const 
             const int gt = tokm ? (I.d[i] < 0 ? 0 : I.d[i]) : tc;
             R.g[i] = *reinterpret_cast<const f32x4*>(gb + (gt * os + cc));
             R.o[i] = *reinterpret_cast<const f32x4*>(ob + ((full ? gt : tc) * os + cc));
-            if (tokm && I.d[i] < 0) { R.g[i] = f32x4{0.f, 0.f, 0.f, 0.f}; if (full) R.o[i] = R.g[i]; }
+            R.pad |= ((tokm && I.d[i] < 0) ? 4 : 0) << i;      // bit 2 + i: a dropped position (zero gradient; applied in lds2_store)
         }
     }
     const int tc = tid < N ? tid : N - 1;
     R.lse = (a.lse_in + ((long long)w.b * a.heads + w.head) * N)[tc];
-    const int lab = (a.labels ? a.labels + (long long)w.wdw * N : a.ia)[tc];
-    R.lab = a.labels ? lab : 0;
-    const int srow = (tokm ? a.src_map + (long long)w.wdw * N : a.ia)[tc];
-    R.src = tokm ? srow : tc;
+    R.lab = (a.labels ? a.labels + (long long)w.wdw * N : a.ia)[tc];          // raw loads: lds2_store picks (labels ? lab : 0), (tokm ? src : token)
+    R.src = (tokm ? a.src_map + (long long)w.wdw * N : a.ia)[tc];
 }
 template <int NT, bool IOBF>
 __device__ __forceinline__ void lds2_store(const Stage2<IOBF>& R, const WsDev& a, const LdsWin& L, int* srcv, const float* fillv, int NR) {
@@ -971,6 +970,7 @@ __device__ __forceinline__ void lds2_store(const Stage2<IOBF>& R, const WsDev& a
                     vh = pack_bf(*reinterpret_cast<const f32x4*>(fillv + 64 + 4 * ch));
                 }
                 g = widen(R.g[i]); o = widen(R.o[i]);
+                if ((R.pad >> (2 + i)) & 1) { gh = s16x4{0, 0, 0, 0}; g = z; o = z; }      // a dropped position
                 if (!ok) { qh = kh = vh = gh = s16x4{0, 0, 0, 0}; g = z; o = z; }
                 *reinterpret_cast<s16x4*>(L.Q + tok * LDB + 4 * ch) = qh;
                 *reinterpret_cast<s16x4*>(L.K + tok * LDB + 4 * ch) = kh;
@@ -979,6 +979,7 @@ __device__ __forceinline__ void lds2_store(const Stage2<IOBF>& R, const WsDev& a
             } else {
                 f32x4 q = R.q[i], k = R.k[i], v = R.v[i];
                 g = R.g[i]; o = R.o[i];
+                if ((R.pad >> (2 + i)) & 1) { g = z; if (a.fill) o = z; }                 // a dropped position
                 if (!ok) { q = z; k = z; v = z; g = z; o = z; }
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2) q[s2] *= a.scale;
@@ -992,7 +993,7 @@ __device__ __forceinline__ void lds2_store(const Stage2<IOBF>& R, const WsDev& a
             if (ch == 0) L.D[tok] = dp;
         }
     }
-    if (tid < NR) { L.lse[tid] = R.lse; L.lab[tid] = R.lab; srcv[tid] = R.src; }
+    if (tid < NR) { L.lse[tid] = R.lse; L.lab[tid] = a.labels ? R.lab : 0; srcv[tid] = a.dst_map ? R.src : (tid < N ? tid : N - 1); }
 }
 
 template <int NDB, int NW, bool IOBF = false>
@@ -1062,10 +1063,14 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
             Who wn = w;
             who_window(a, wn, m + a.groups);
             lds2_load<NT, IOBF>(R, I, a, wn, NR);
-            if (m + 2 * a.groups < a.M) {
-                who_window(a, wn, m + 2 * a.groups);
-                lds2_index<NT>(I, a, wn);
-            }
+        }
+        {
+            // UNCONDITIONAL (a clamped window where there is none): under `if (m + 2 groups < M)` the compiler kept the new entries in
+            // temporaries and copied them into I's registers right behind the loads -- a wait for every load in flight, the window's
+            // rows included: 5.8 k cycles per window between the staging barrier and the first tile pair (stamps, round 6)
+            Who wn = w;
+            who_window(a, wn, min(m + 2 * a.groups, a.M - 1));
+            lds2_index<NT>(I, a, wn);
         }
         // ---- pass 1
         for (int kc = wv; kc < ((a.dbg & 1) ? 0 : NCr); kc += NW) {
@@ -1366,8 +1371,7 @@ __global__ __launch_bounds__(256) void winattn_lds_fwd_tok_kernel(WsDev a) {
             }
         }
         const int tc = tid < N ? tid : N - 1;
-        const int lab = (a.labels ? a.labels + (long long)ww.wdw * N : a.ia)[tc];
-        R.lab = a.labels ? lab : 0;
+        R.lab = (a.labels ? a.labels + (long long)ww.wdw * N : a.ia)[tc];      // raw: store_rows picks (labels ? lab : 0) -- no wait here
         R.dst = a.dst_map[(long long)ww.wdw * N + tc];
     };
     auto store_rows = [&]() {
@@ -1394,7 +1398,7 @@ __global__ __launch_bounds__(256) void winattn_lds_fwd_tok_kernel(WsDev a) {
                 *reinterpret_cast<s16x4*>(Vs + tok * LDB + 4 * ch) = vh;
             }
         }
-        if (tid < NR) { labs[tid] = R.lab; dsts[tid] = R.dst; }
+        if (tid < NR) { labs[tid] = a.labels ? R.lab : 0; dsts[tid] = R.dst; }
     };
     who_window(a, w, grp);
     load_index(w.wdw);
@@ -1409,7 +1413,11 @@ __global__ __launch_bounds__(256) void winattn_lds_fwd_tok_kernel(WsDev a) {
             Who wn = w;
             who_window(a, wn, m + a.groups);
             load_rows(wn);
-            if (m + 2 * a.groups < a.M) { who_window(a, wn, m + 2 * a.groups); load_index(wn.wdw); }
+        }
+        {   // unconditional, on a clamped window (see winattn_lds_bwd1p_kernel: a conditional prefetch ends in a wait for every load in flight)
+            Who wn = w;
+            who_window(a, wn, min(m + 2 * a.groups, a.M - 1));
+            load_index(wn.wdw);
         }
         const long long tb0 = (long long)(w.b / a.nW) * a.Ltok;
         if (tid < N && ((tid >> 4) < qlo || (tid >> 4) >= qhi))      // rows outside the computed chunks: the backward stages every row's lse
