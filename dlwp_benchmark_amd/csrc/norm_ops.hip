@@ -333,6 +333,108 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_vec_kernel(const float*
     }
 }
 
+// Rows whose width is EXACTLY 4 LPR NV floats (round 6: NV = 3 covers every feature width of the C4 / C5 token models -- 96, 192, 384, 768 --
+// with no idle lanes: the one-chunk kernel above runs 96 columns on 32 lanes per row with 8 of them idle, 192 on 64 with 16 idle, and the
+// wide-row kernel below runs 384 as two 256-column chunks with half of the second one idle).  A lane holds NV 16-byte chunks of a row
+// (columns 4 l + 4 LPR c: every load instruction of the 64 / LPR rows of a wave is a set of whole 16 LPR-byte segments), UB row groups of
+// a wave are in flight at once, eight waves per workgroup and one workgroup per CU (ln_bwd_waves), LDS float adds fold the waves' column
+// partials, then the 2 C float atomics.
+template <int LPR, int NV, int NW, int UB>
+__global__ __launch_bounds__(64 * NW) void layernorm_bwd_vecn_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                     const float* __restrict__ gy, const float* __restrict__ gadd,
+                                                                     float* __restrict__ gx, float* ggamma, float* gbeta, int T, int C,
+                                                                     int rows_per_block, int gy_bf16) {
+    extern __shared__ float sm[];            // [2][C] per-block partial of ggamma, gbeta
+    constexpr int RPW = 64 / LPR, CS = 4 * LPR;      // rows per wave and group; column stride between a lane's chunks
+    for (int c = threadIdx.x; c < 2 * C; c += 64 * NW) sm[c] = 0.f;
+    __syncthreads();
+    const int lane = lane_id(), w = wave_id(), l = lane % LPR, rr = lane / LPR;
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 gm[NV], pg[NV], pb[NV];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        gm[c] = *reinterpret_cast<const f32x4*>(gamma + 4 * l + CS * c);
+        pg[c] = zero; pb[c] = zero;
+    }
+    const long long row0 = (long long)blockIdx.x * rows_per_block;
+    const __bf16* gh = reinterpret_cast<const __bf16*>(gy);
+    const float invC = 1.f / C;
+    for (int it0 = w * RPW; it0 < rows_per_block; it0 += NW * RPW * UB) {
+        f32x4 xv[UB][NV], gv[UB][NV], av[UB][NV];
+        float mu[UB], rs[UB];
+        bool ok[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int it = it0 + NW * RPW * u;
+            const long long row = row0 + it + rr;
+            ok[u] = row < T && it + rr < rows_per_block;
+            const long long rc = ok[u] ? row : 0;                 // masked rows read row 0 (valid memory): no branch around the loads
+            const long long o = rc * C + 4 * l;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                xv[u][c] = *reinterpret_cast<const f32x4*>(x + o + CS * c);
+                if (gy_bf16) {
+                    const bf16x4 hv = *reinterpret_cast<const bf16x4*>(gh + o + CS * c);
+                    gv[u][c] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+                } else {
+                    gv[u][c] = *reinterpret_cast<const f32x4*>(gy + o + CS * c);
+                }
+                av[u][c] = gadd ? *reinterpret_cast<const f32x4*>(gadd + o + CS * c) : zero;
+            }
+            mu[u] = mean[rc];
+            rs[u] = rstd[rc];
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const long long row = row0 + it0 + NW * RPW * u + rr;
+            f32x4 xh[NV], gg[NV];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < NV; ++c)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float g0 = ok[u] ? gv[u][c][k] : 0.f;
+                    xh[c][k] = ok[u] ? (xv[u][c][k] - mu[u]) * rs[u] : 0.f;
+                    gg[c][k] = g0 * gm[c][k];
+                    s1 += gg[c][k];
+                    s2 += gg[c][k] * xh[c][k];
+                    pg[c][k] += g0 * xh[c][k];
+                    pb[c][k] += g0;
+                }
+            s1 = row_sum<LPR>(s1) * invC;
+            s2 = row_sum<LPR>(s2) * invC;
+            if (ok[u]) {
+#pragma unroll
+                for (int c = 0; c < NV; ++c) {
+                    f32x4 o4;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o4[k] = rs[u] * (gg[c][k] - s1 - xh[c][k] * s2) + av[u][c][k];
+                    *reinterpret_cast<f32x4*>(gx + row * C + 4 * l + CS * c) = o4;
+                }
+            }
+        }
+    }
+    // fold the row slots of a wave (lanes l, l + LPR, ...), then the waves through LDS float adds
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { pg[c][k] += __shfl_xor(pg[c][k], o); pb[c][k] += __shfl_xor(pb[c][k], o); }
+    if (rr == 0) {
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { atomicAdd(&sm[4 * l + CS * c + k], pg[c][k]); atomicAdd(&sm[C + 4 * l + CS * c + k], pb[c][k]); }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 64 * NW) {
+        atomic_add_f32(&ggamma[c], sm[c]);
+        atomic_add_f32(&gbeta[c], sm[C + c]);
+    }
+}
+
 // Wide rows (256 < C <= 1024, C % 4 == 0; FourCastNet's 768, Pangu's 384): a lane owns NV float4 groups of a row (16-byte accesses
 // instead of the scalar kernel's 4-byte ones), a wave walks its rows with the next row's loads in flight, and the grid is sized to
 // the resident slots (a workgroup's 2 C column partials end in float atomics on the same 2 C addresses: their number, not C, sets
@@ -636,6 +738,26 @@ static int layernorm_bwd_impl(const float* x, const float* gamma, const float* m
     const bool no_wide = dlwp_tune_on("LN_BWD_NOWIDE");
     // live accounting: x, gy (fp32 or bf16) and the optional residual gradient read, gx written, the statistics read; ~14 flops / element
     const double pbytes = (double)T * C * (4 + (gy_bf16 ? 2 : 4) + (gadd ? 4 : 0) + 4) + 8.0 * T, pflops = 14.0 * T * C;
+    // widths 96 / 192 / 384 / 768 (4 LPR x 3 floats per row): the three-chunk kernel, one workgroup of eight waves per CU
+    // (768 -- FourCastNet -- stays on the wide-row kernel: 16200 x 768 39.5 us there, 45 us here.)  Workgroups: one per CU, one per TWO CUs
+    // for inputs of at most 4 M elements -- the launch ends in (workgroups) x 17 ns of float atomics per gradient address, and these small
+    // inputs are bound by that and by the launch, not by bandwidth: 16384 x 192 19.4 -> 17.0 us, 8192 x 384 23.0 -> 20.5 us
+    // (tools/probe_layernorm_bwd.py; 384 workgroups and more lose everywhere)
+    const int v3_env = dlwp_tune_or("LN_BWD_V3", 1);
+    const int lpr3 = C == 96 ? 8 : C == 192 ? 16 : C == 384 ? 32 : (C == 768 && v3_env == 2) ? 64 : 0;
+    if (lpr3 && (narrow || wide) && T >= 2048 && v3_env != 0) {
+        dlwp_prof_scope prof((hipStream_t)stream, pflops, pbytes, "layernorm_bwd_vecn_kernel<%d, 3, 8, %d>", lpr3, lpr3 == 64 ? 2 : 4);
+        const int rpg = 8 * (64 / lpr3);                                           // rows of one workgroup-wide row group
+        const int wgs = dlwp_tune_or("LN_BWD_WGS", (long long)T * C <= (4 << 20) ? 128 : 256);
+        const int rpbn = std::max(rpg, ceil_div(ceil_div(T, wgs), rpg) * rpg);
+        const dim3 gridn(ceil_div(T, rpbn));
+#define LN_BWD_N(LPR, UB_) hipLaunchKernelGGL((layernorm_bwd_vecn_kernel<LPR, 3, 8, UB_>), gridn, dim3(512), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, \
+                                              gadd, gx, ggamma, gbeta, T, C, rpbn, gy_bf16)
+        if (lpr3 == 8) LN_BWD_N(8, 4); else if (lpr3 == 16) LN_BWD_N(16, 4); else if (lpr3 == 32) LN_BWD_N(32, 4); else LN_BWD_N(64, 2);
+#undef LN_BWD_N
+        DLWP_LAUNCH_CHECK();
+        return DLWP_OK;
+    }
     if (wide && !no_wide) {
         dlwp_prof_scope prof((hipStream_t)stream, pflops, pbytes, "layernorm_bwd_wide_kernel<%d>", C <= 512 ? 2 : C <= 768 ? 3 : 4);
         // one round of resident workgroups (~110 VGPRs: four per CU at most; 512-768 keep the atomic tail short)
@@ -651,8 +773,8 @@ static int layernorm_bwd_impl(const float* x, const float* gamma, const float* m
         return DLWP_OK;
     }
     if (narrow) {
-        dlwp_prof_scope prof((hipStream_t)stream, pflops, pbytes, "layernorm_bwd_vec_kernel<%d>", C <= 32 ? 8 : C <= 64 ? 16 : C <= 128 ? 32 : 64);
         const int nw = ln_bwd_waves(T, C);
+        dlwp_prof_scope prof((hipStream_t)stream, pflops, pbytes, "layernorm_bwd_vec_kernel<%d, %d>", C <= 32 ? 8 : C <= 64 ? 16 : C <= 128 ? 32 : 64, nw);
         const int rpbn = nw == 8 ? std::max(8, ceil_div(ceil_div(T, 256), 8) * 8) : rpb;      // eight waves: one workgroup per CU
         const dim3 gridn(ceil_div(T, rpbn));
 #define LN_BWD_V2(LPR, NW_) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<LPR, NW_>), gridn, dim3(64 * NW_), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, \

@@ -1585,8 +1585,8 @@ static int gemm_glds_launch(const GemmDev& a_in, bool bkc, hipStream_t s) {
 #define GLDS_GO2(BKC_, KD_, GN_)                                                                                        \
     do {                                                                                                                \
         if ((rc = dlwp_ensure_lds(reinterpret_cast<const void*>(gemm_glds_kernel<BKC_, KD_, GN_>), lds, "gemm_glds"))) return rc; \
-        dlwp_prof_scope prof(s, gemm_prof_flops(a), gemm_prof_bytes(a), GN_ == 96 ? "gemm_glds_kernel<%s, %d, 96>%s" : "gemm_glds_kernel<%s, %d>%s", \
-                             BKC_ ? "true" : "false", KD_, gemm_prof_tag(a).s);                                          \
+        dlwp_prof_scope prof(s, gemm_prof_flops(a), gemm_prof_bytes(a), "gemm_glds_kernel<%s, %d, %d>%s", BKC_ ? "true" : "false", KD_, GN_,    \
+                             gemm_prof_tag(a).s);                                                                        \
         hipLaunchKernelGGL((gemm_glds_kernel<BKC_, KD_, GN_>), dim3(a.ntn * a.ntm), dim3(256), lds, s, a);               \
     } while (0)
 #define GLDS_GO(BKC_, KD_) do { if (gn == 96) GLDS_GO2(BKC_, KD_, 96); else GLDS_GO2(BKC_, KD_, 128); } while (0)

@@ -181,10 +181,11 @@ def test_glds_gemm_96_wide_tiles_are_the_128_wide_ones_bit_for_bit(cuda, M, N, K
     assert ((y - want).abs().max() / want.abs().max()).item() <= tol
 
 
-@pytest.mark.parametrize("T,C", [(65536, 96), (16384, 192), (32768, 192), (9000, 200), (20000, 52), (2100, 256)])
+@pytest.mark.parametrize("T,C", [(65536, 96), (16384, 192), (32768, 192), (8192, 384), (16200, 768), (2049, 96), (9000, 200), (20000, 52), (2100, 256)])
 def test_layernorm_backward_eight_wave_workgroups(cuda, T, C):
-    """layernorm_bwd_vec_kernel runs the large inputs as 256 workgroups of eight waves (csrc/norm_ops.hip, ln_bwd_waves): gx and the
-    gradients of gamma / beta against a float64 reference for both workgroup sizes, with the residual gradient and a bf16 upstream
+    """layernorm_bwd_vec_kernel runs the large inputs as 256 workgroups of eight waves (csrc/norm_ops.hip, ln_bwd_waves) and the widths
+    96 / 192 / 384 / 768 take the three-chunk kernel (layernorm_bwd_vecn_kernel): gx and the gradients of gamma / beta against a float64
+    reference for every variant, with the residual gradient and a bf16 upstream
     gradient as the C4 steps pass them, and row counts that are not multiples of the rows per workgroup."""
     from dlwp_benchmark_amd import lib as L
     lib = L.load()
@@ -201,8 +202,10 @@ def test_layernorm_backward_eight_wave_workgroups(cuda, T, C):
     gg_ = gyd * gam.double()
     want_x = rstd.double()[:, None] * (gg_ - gg_.mean(1, keepdim=True) - xh * (gg_ * xh).mean(1, keepdim=True)) + ga.double()
     tol = 2e-5 * T ** 0.5
-    for nw in (4, 8):
+    # (waves per workgroup of the one-chunk kernel, three-chunk kernel for the widths 96 / 192 / 384 / 768 on or off)
+    for nw, v3 in ((4, 0), (8, 0), (8, 1)):
         L.set_tuning("LN_BWD_NW", nw)
+        L.set_tuning("LN_BWD_V3", v3)
         try:
             gx = torch.empty_like(x)
             gg, gb = torch.zeros(C, device=cuda), torch.zeros(C, device=cuda)
@@ -211,6 +214,7 @@ def test_layernorm_backward_eight_wave_workgroups(cuda, T, C):
             torch.cuda.synchronize()
         finally:
             L.set_tuning("LN_BWD_NW", None)
+            L.set_tuning("LN_BWD_V3", None)
         assert (gx.double() - want_x).abs().max().item() <= 1e-5 * want_x.abs().max().item(), nw
         assert (gg.double() - want_g).abs().max().item() <= tol * want_g.abs().max().item(), nw
         assert (gb.double() - want_b).abs().max().item() <= tol * want_b.abs().max().item(), nw
