@@ -232,6 +232,47 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __r
     }
 }
 
+// Forward for rows of exactly 4 LPR NV floats (round 6; see layernorm_bwd_vecn_kernel): a lane holds NV 16-byte chunks of a row, a wave
+// 64 / LPR rows, no idle lanes at the widths 96 / 192 / 384 / 768 (NV = 3).
+template <int LPR, int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_vecn_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float* __restrict__ y,
+                                                                 float* __restrict__ mean, float* __restrict__ rstd, int T, int C,
+                                                                 float eps, int y_bf16) {
+    constexpr int RPW = 64 / LPR, CS = 4 * LPR;
+    const int lane = lane_id(), l = lane % LPR, rr = lane / LPR;
+    const long long row = ((long long)blockIdx.x * 4 + wave_id()) * RPW + rr;
+    const bool ok = row < T;
+    const long long o = (ok ? row : 0) * C + 4 * l;             // masked rows read row 0
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        v[c] = *reinterpret_cast<const f32x4*>(x + o + CS * c);
+        s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+    }
+    const float invC = 1.f / C;
+    const float mu = row_sum<LPR>(s) * invC;
+    float var = 0.f;
+#pragma unroll
+    for (int c = 0; c < NV; ++c)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[c][k] -= mu; var += v[c][k] * v[c][k]; }
+    const float rs = rsqrtf(row_sum<LPR>(var) * invC + eps);
+    if (ok) {
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 4 * l + CS * c), bt = *reinterpret_cast<const f32x4*>(beta + 4 * l + CS * c);
+            f32x4 q;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = v[c][k] * rs * gm[k] + bt[k];
+            if (y_bf16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(y) + o + CS * c) = bf16x4{(__bf16)q[0], (__bf16)q[1], (__bf16)q[2], (__bf16)q[3]};
+            else *reinterpret_cast<f32x4*>(y + o + CS * c) = q;
+        }
+        if (l == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
 template <int LPR, int NW = 4>                 // NW waves per workgroup
 __global__ __launch_bounds__(64 * NW) void layernorm_bwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -665,6 +706,19 @@ extern "C" int dlwp_layernorm_fwd_ex(const float* x, const float* gamma, const f
                         (uintptr_t)beta % 16 == 0 && (y_bf16 || (uintptr_t)y % 16 == 0);
     // live accounting: x read, y written (fp32 or bf16), the two statistics written; ~8 flops per element
     const double pbytes = (double)T * C * (4 + (y_bf16 ? 2 : 4)) + 8.0 * T, pflops = 8.0 * T * C;
+    const int lpr3 = C == 96 ? 8 : C == 192 ? 16 : C == 384 ? 32 : C == 768 ? 64 : 0;
+    // (from 4 M elements: 65536 x 96 12.6 -> 10.3 us, 32768 x 192 12.3 -> 10.0 us on cold buffers; the smaller inputs sit at the ~ 8 us of a launch either way)
+    const int fv3 = dlwp_tune_or("LN_FWD_V3", 1);
+    if (lpr3 && T >= 2048 && (fv3 == 2 || (fv3 == 1 && (long long)T * C >= (4 << 20))) && (uintptr_t)x % 16 == 0 && (uintptr_t)y % (y_bf16 ? 8 : 16) == 0 &&
+        (uintptr_t)gamma % 16 == 0 && (uintptr_t)beta % 16 == 0) {
+        dlwp_prof_scope prof((hipStream_t)stream, pflops, pbytes, "layernorm_fwd_vecn_kernel<%d, 3>", lpr3);
+#define LN_FWD_N(LPR) hipLaunchKernelGGL((layernorm_fwd_vecn_kernel<LPR, 3>), dim3(ceil_div(T, 4 * (64 / LPR))), dim3(256), 0, (hipStream_t)stream, \
+                                          x, gamma, beta, (float*)y, mean, rstd, T, C, eps, y_bf16 ? 1 : 0)
+        if (lpr3 == 8) LN_FWD_N(8); else if (lpr3 == 16) LN_FWD_N(16); else if (lpr3 == 32) LN_FWD_N(32); else LN_FWD_N(64);
+#undef LN_FWD_N
+        DLWP_LAUNCH_CHECK();
+        return DLWP_OK;
+    }
     if (narrow) {
         const int lpr = C <= 32 ? 8 : C <= 64 ? 16 : C <= 128 ? 32 : 64;
         dlwp_prof_scope prof((hipStream_t)stream, pflops, pbytes, "layernorm_fwd_vec_kernel<%d>", lpr);

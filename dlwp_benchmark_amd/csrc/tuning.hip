@@ -48,6 +48,7 @@ Knob g_knobs[] = {
     {"LN_BWD_WANT", "workgroups of the scalar LayerNorm backward kernel", 0, false},
     {"LN_BWD_NOWIDE", "1: never use the wide-row LayerNorm backward kernel", 0, false},
     {"LN_BWD_NW", "waves per workgroup of the narrow-row LayerNorm backward kernel: 4 or 8 (default: 8 for inputs of at least 2048 rows and 2 M elements, one workgroup per CU)", 0, false},
+    {"LN_FWD_V3", "widths 96 / 192 / 384 / 768 on the three-chunk LayerNorm forward kernel: 0 never, 1 from 4 M elements (default), 2 from 2048 rows", 0, false},
     {"LN_BWD_V3", "0: widths 96 / 192 / 384 stay on the one-chunk / wide-row LayerNorm backward kernels instead of the three-chunk kernel; 2: width 768 takes it too", 0, false},
     {"LN_BWD_WGS", "workgroups of the wide-row LayerNorm backward kernel (default 384)", 0, false},
     {"WINATTN_D48", "0: head dims 33 .. 48 stay on the tiled window-attention kernels (default 1: windows of at most 64 tokens take the wave-per-window forward and the LDS-staged two-pass backward in the bf16 matrix mode)", 0, false},

@@ -37,7 +37,8 @@ def test_linear_fwd_bwd(cuda, T, K, N, act, res):
         assert rel(got.grad, ref.grad) <= 5e-4
 
 
-@pytest.mark.parametrize("T,C,eps", [(1024, 64, 1e-6), (333, 40, 1e-5), (50, 384, 1e-5), (1001, 768, 1e-5), (77, 1000, 1e-6), (130, 260, 1e-5)])
+@pytest.mark.parametrize("T,C,eps", [(1024, 64, 1e-6), (333, 40, 1e-5), (50, 384, 1e-5), (1001, 768, 1e-5), (77, 1000, 1e-6), (130, 260, 1e-5),
+                                     (4099, 96, 1e-5), (2050, 192, 1e-6), (8192, 384, 1e-5), (2051, 768, 1e-5)])     # the last four: the three-chunk kernels
 def test_layernorm_fwd_bwd(cuda, T, C, eps):
     from dlwp_benchmark_amd import token_ops
     g = torch.Generator().manual_seed(2)
@@ -53,7 +54,12 @@ def test_layernorm_fwd_bwd(cuda, T, C, eps):
     xr = x.clone().requires_grad_(True)
     ln_ref(xr).backward(gy)
     xd = x.to(cuda).requires_grad_(True)
-    y = ln(xd)
+    from dlwp_benchmark_amd import lib as L
+    L.set_tuning("LN_FWD_V3", 2)          # the three-chunk forward from 2048 rows on (by default from 4 M elements)
+    try:
+        y = ln(xd)
+    finally:
+        L.set_tuning("LN_FWD_V3", None)
     y.backward(gy.to(cuda))
     assert rel(y, ln_ref(x)) <= 1e-4
     assert rel(xd.grad, xr.grad) <= 5e-4
