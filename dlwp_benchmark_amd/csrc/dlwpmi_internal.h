@@ -169,7 +169,10 @@ int dlwp_cfmlp_bwd(const float* x, long long x_bs, const float* w1, const float*
 bool dlwp_winattn_small_applies(int N, int d, long long pairs);
 int dlwp_winattn_small_fwd(const float* qkv, const float* table, const float* packed, const int* ia, const int* ib,
                            const int* labels, float* out, float* lse, int B_, int nW, int N, int TB, int ntypes, int heads, int d,
-                           float scale, int q_lo, int q_hi, void* stream);
+                           float scale, int q_lo, int q_hi, void* stream, int io_bf16 = 0);
+// io_bf16: qkv, out (and gout, gqkv) are bf16 arrays in the window layout (dlwp_winattn_io_bf16_applies must hold)
+bool dlwp_winattn_io_bf16_applies(int N, int d, int TB, long long pairs);
 int dlwp_winattn_small_bwd(const float* qkv, const float* table, const float* packed, const int* ia, const int* ib,
                            const int* labels, const float* out, const float* lse, const float* gout, float* gqkv, float* gtable,
-                           int B_, int nW, int N, int TB, int ntypes, int heads, int d, float scale, int q_lo, int q_hi, void* stream);
+                           int B_, int nW, int N, int TB, int ntypes, int heads, int d, float scale, int q_lo, int q_hi, void* stream,
+                           int io_bf16 = 0);

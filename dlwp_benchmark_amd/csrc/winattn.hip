@@ -654,6 +654,41 @@ extern "C" int dlwp_window_attn_fwd_qrange(const float* qkv, const float* bias_t
     return DLWP_OK;
 }
 
+// bf16 tensors in the window layout (round 6): qkv [B_, N, 3, heads, d], out / gout [B_, N, heads, d] and the qkv gradient are bf16 arrays
+// (statistics, bias table and its gradient stay fp32) -- the projection that makes qkv writes bf16, the output projection reads bf16, and
+// the casts between them and the attention kernels disappear (Swin C4: eight cast launches over 20 - 80 MB each per step).  Where
+// dlwp_window_attn_io_bf16_supported() says so: windows of at most 64 tokens, head_dim % 4 == 0, bf16 matrix mode, the whole query range.
+extern "C" int dlwp_window_attn_io_bf16_supported(int N, int d, int TB, long long pairs) {
+    return dlwp_winattn_io_bf16_applies(N, d, TB, pairs) ? 1 : 0;
+}
+extern "C" int dlwp_window_attn_fwd_bf16(const void* qkv, const float* bias_table, const float* packed_table, const int* ia, const int* ib,
+                                         const int* labels, void* out, float* lse, int B_, int nW, int N, int TB, int ntypes, int heads,
+                                         int d, float scale, void* stream) {
+    DLWP_REQUIRE(qkv && bias_table && ia && ib && out && lse, DLWP_E_INVALID, "window_attn_fwd_bf16: NULL argument");
+    WaDev a{};
+    int rc = wa_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, "window_attn_fwd_bf16");
+    if (rc) return rc;
+    DLWP_REQUIRE(dlwp_winattn_io_bf16_applies(N, d, TB, (long long)B_ * heads), DLWP_E_UNSUPPORTED,
+                 "window_attn_fwd_bf16: needs windows of at most 64 tokens, head_dim %% 4 == 0 and the bf16 matrix mode (N %d, d %d)", N, d);
+    DLWP_REQUIRE((uintptr_t)qkv % 8 == 0 && (uintptr_t)out % 8 == 0, DLWP_E_INVALID, "window_attn_fwd_bf16: 8-byte aligned tensors");
+    return dlwp_winattn_small_fwd(static_cast<const float*>(qkv), bias_table, packed_table, ia, ib, labels, static_cast<float*>(out), lse, B_, nW, N,
+                                  TB, ntypes, heads, d, scale, 0, N, stream, 1);
+}
+extern "C" int dlwp_window_attn_bwd_bf16(const void* qkv, const float* bias_table, const float* packed_table, const int* ia, const int* ib,
+                                         const int* labels, const void* out, const float* lse, const void* gout, void* gqkv,
+                                         float* gbias_table, int B_, int nW, int N, int TB, int ntypes, int heads, int d, float scale,
+                                         void* stream) {
+    DLWP_REQUIRE(qkv && bias_table && ia && ib && out && lse && gout && gqkv && gbias_table, DLWP_E_INVALID, "window_attn_bwd_bf16: NULL argument");
+    WaDev a{};
+    int rc = wa_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, "window_attn_bwd_bf16");
+    if (rc) return rc;
+    DLWP_REQUIRE((uintptr_t)qkv % 8 == 0 && (uintptr_t)out % 8 == 0 && (uintptr_t)gout % 8 == 0 && (uintptr_t)gqkv % 8 == 0, DLWP_E_INVALID,
+                 "window_attn_bwd_bf16: 8-byte aligned tensors");
+    return dlwp_winattn_small_bwd(static_cast<const float*>(qkv), bias_table, packed_table, ia, ib, labels, static_cast<const float*>(out), lse,
+                                  static_cast<const float*>(gout), static_cast<float*>(gqkv), gbias_table, B_, nW, N, TB, ntypes, heads, d, scale,
+                                  0, N, stream, 1);
+}
+
 extern "C" int dlwp_window_attn_fwd(const float* qkv, const float* bias_table, const int* ia, const int* ib,
                                     const int* labels, float* out, float* lse, int B_, int nW, int N, int TB,
                                     int ntypes, int heads, int d, float scale, void* stream) {

@@ -96,6 +96,23 @@ __device__ __forceinline__ f32x4 col_frag(const float* __restrict__ base, long l
     return v;
 }
 
+// the same fragments of a bf16 tensor in the window layout (round 6: dlwp_window_attn_fwd_bf16 / _bwd_bf16), RAW: the four bf16 values
+// as they are (the bf16 MFMA takes them; the softmax scale goes on the fp32 scores).  base is a bf16 address, stride in elements, d % 4 == 0.
+__device__ __forceinline__ s16x4 row_frag_raw(const float* __restrict__ base, long long stride, int tok, int N, int dd0, int d) {
+    s16x4 v = s16x4{0, 0, 0, 0};
+    if (tok < N && dd0 < d) v = *reinterpret_cast<const s16x4*>(reinterpret_cast<const short*>(base) + (long long)tok * stride + dd0);
+    return v;
+}
+__device__ __forceinline__ s16x4 col_frag_raw(const float* __restrict__ base, long long stride, int tok0, int N, int dd, int d) {
+    s16x4 v = s16x4{0, 0, 0, 0};
+    if (dd < d) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (tok0 + s < N) v[s] = reinterpret_cast<const short*>(base)[(long long)(tok0 + s) * stride + dd];
+    }
+    return v;
+}
+
 constexpr float FXS = 1099511627776.f;   // 2^40 (fixed-point dBias partials, see winattn.hip)
 __device__ __forceinline__ void fx_add_s(unsigned long long* acc, float v) {
     atomicAdd(acc, (unsigned long long)(long long)llrintf(v * FXS));
@@ -231,7 +248,7 @@ __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
     const float* fv = fills + 64;
     const int* labw = a.labels ? a.labels + (long long)w.wdw * N : nullptr;
 
-    typedef typename tokfrag<TOK && IOBF>::type frag_t;      // raw bf16 fragments when the token tensors are bf16
+    typedef typename tokfrag<IOBF>::type frag_t;             // raw bf16 fragments when the tensors are bf16 (either layout)
     frag_t kf[NC][NDB], vt[NDB][NC];
     int kbi[NC][4], klb[NC][4];
 #pragma unroll
@@ -239,11 +256,13 @@ __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
 #pragma unroll
         for (int cc = 0; cc < NDB; ++cc) {
             if constexpr (TOK) kf[kc][cc] = tok_row<IOBF>(kb, rs, fk, srcl, 16 * kc + r, N, 16 * cc + 4 * g, d);
+            else if constexpr (IOBF) kf[kc][cc] = row_frag_raw(kb, rs, 16 * kc + r, N, 16 * cc + 4 * g, d);
             else kf[kc][cc] = row_frag<VEC>(kb, rs, 16 * kc + r, N, 16 * cc + 4 * g, d);
         }
 #pragma unroll
         for (int db = 0; db < NDB; ++db) {
             if constexpr (TOK) vt[db][kc] = tok_col<IOBF>(vb, rs, fv, srcl, 16 * kc + 4 * g, N, 16 * db + r, d);
+            else if constexpr (IOBF) vt[db][kc] = col_frag_raw(vb, rs, 16 * kc + 4 * g, N, 16 * db + r, d);
             else vt[db][kc] = col_frag(vb, rs, 16 * kc + 4 * g, N, 16 * db + r, d);
         }
 #pragma unroll
@@ -262,11 +281,12 @@ __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
         if (16 * qc >= N) break;
         const int q = 16 * qc + r, qcl = min(q, N - 1);
         const int qa = a.ia[qcl], qlab = labw ? labw[qcl] : 0;
-        constexpr bool RAW = TOK && IOBF;
+        constexpr bool RAW = IOBF;
         frag_t qf[NDB];
 #pragma unroll
         for (int cc = 0; cc < NDB; ++cc) {
             if constexpr (TOK) qf[cc] = tok_row<IOBF>(qb, rs, fq, srcl, q, N, 16 * cc + 4 * g, d);
+            else if constexpr (IOBF) qf[cc] = row_frag_raw(qb, rs, q, N, 16 * cc + 4 * g, d);
             else qf[cc] = row_frag<VEC>(qb, rs, q, N, 16 * cc + 4 * g, d);
             if constexpr (!RAW) {
 #pragma unroll
@@ -315,10 +335,10 @@ __global__ __launch_bounds__(256) void winattn_small_fwd_kernel(WsDev a) {
             }
             const int dd = 16 * db + 4 * g;
             const int orow = TOK ? (q < N ? dstl[q] : -1) : q;
-            if (TOK && IOBF) {
+            if (IOBF) {
                 if (q < N && orow >= 0 && dd < d) {
                     typedef __bf16 bh4 __attribute__((ext_vector_type(4)));
-                    __bf16* dst = reinterpret_cast<__bf16*>(a.out) + ((long long)(w.b / a.nW) * a.Ltok + orow) * os + w.head * d + dd;
+                    __bf16* dst = reinterpret_cast<__bf16*>(a.out) + (TOK ? (long long)(w.b / a.nW) * a.Ltok + orow : (long long)w.b * N + q) * os + w.head * d + dd;
                     *reinterpret_cast<bh4*>(dst) = bh4{(__bf16)(o[0] * inv), (__bf16)(o[1] * inv), (__bf16)(o[2] * inv), (__bf16)(o[3] * inv)};
                 }
             } else if (q < N && orow >= 0) {
@@ -653,14 +673,25 @@ __device__ __forceinline__ void lds_stage(const WsDev& a, const Who& w, const Ld
         const bool ok = tok < N && 4 * ch < d;
         const bool st = 4 * ch < LB - 4;                    // this lane's chunk exists in the row (TPT = 16: chunks 12 .. 15 do not)
         const int tc = tok < N ? tok : N - 1, cc = 4 * ch < d ? 4 * ch : 0;        // clamped: unconditional loads
-        const float* row = qb + (long long)tc * rs + cc;
-        f32x4 q = *reinterpret_cast<const f32x4*>(row);
-        f32x4 k = *reinterpret_cast<const f32x4*>(row + a.heads * d);
-        f32x4 v = *reinterpret_cast<const f32x4*>(row + 2 * a.heads * d);
-        f32x4 g = {0.f, 0.f, 0.f, 0.f}, o = g;
-        if (BWD) {
-            g = *reinterpret_cast<const f32x4*>(gb + (long long)tc * os + cc);
-            o = *reinterpret_cast<const f32x4*>(ob + (long long)tc * os + cc);
+        f32x4 q, k, v, g = {0.f, 0.f, 0.f, 0.f}, o = g;
+        if (a.io_bf16) {                                    // bf16 tensors (window layout, round 6): 8-byte pieces, widened for the scale and D
+            typedef __bf16 bh4 __attribute__((ext_vector_type(4)));
+            auto ld = [](const float* base, long long off) {
+                const bh4 h = *reinterpret_cast<const bh4*>(reinterpret_cast<const __bf16*>(base) + off);
+                return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+            };
+            const long long qo = ((long long)w.b * N + tc) * rs + w.head * d + cc, go = ((long long)w.b * N + tc) * os + w.head * d + cc;
+            q = ld(a.qkv, qo); k = ld(a.qkv, qo + a.heads * d); v = ld(a.qkv, qo + 2 * a.heads * d);
+            if (BWD) { g = ld(a.gout, go); o = ld(a.o, go); }
+        } else {
+            const float* row = qb + (long long)tc * rs + cc;
+            q = *reinterpret_cast<const f32x4*>(row);
+            k = *reinterpret_cast<const f32x4*>(row + a.heads * d);
+            v = *reinterpret_cast<const f32x4*>(row + 2 * a.heads * d);
+            if (BWD) {
+                g = *reinterpret_cast<const f32x4*>(gb + (long long)tc * os + cc);
+                o = *reinterpret_cast<const f32x4*>(ob + (long long)tc * os + cc);
+            }
         }
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         if (!ok) { q = z; k = z; v = z; g = z; o = z; }
@@ -708,10 +739,16 @@ __global__ __launch_bounds__(256) void winattn_lds_bwd_kernel(WsDev a) {
     __syncthreads();                       // the previous window's fragments have been read (and tb / gtb are initialised)
     lds_stage<true, LB, TPT>(a, w, L, NR);
     float* gq = a.gqkv + (long long)w.b * N * rs + w.head * d;
+    bf16_t* gqh = reinterpret_cast<bf16_t*>(a.gqkv) + (long long)w.b * N * rs + w.head * d;       // io_bf16: the gradient leaves as bf16
+    const bool iobf = a.io_bf16 != 0;
+    auto put = [&](long long off, const f32x4& val) {      // four channels of one row
+        if (iobf) *reinterpret_cast<s16x4*>(gqh + off) = pack_bf(val);
+        else *reinterpret_cast<f32x4*>(gq + off) = val;
+    };
     // query rows outside the computed chunks: zero query gradient (they carry no upstream gradient)
     for (int e = threadIdx.x; e < N * (d >> 2); e += 256) {
         const int tok = e / (d >> 2), c4 = e - tok * (d >> 2), qc = tok >> 4;
-        if (qc < qlo || qc >= qhi) *reinterpret_cast<f32x4*>(gq + (long long)tok * rs + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (qc < qlo || qc >= qhi) put((long long)tok * rs + 4 * c4, f32x4{0.f, 0.f, 0.f, 0.f});
     }
     __syncthreads();
     // ---- pass Q: dS^T = P^T (dP^T - D), dQ^T += K^T dS^T, dBias
@@ -755,7 +792,7 @@ __global__ __launch_bounds__(256) void winattn_lds_bwd_kernel(WsDev a) {
 #pragma unroll
             for (int db = 0; db < NDB; ++db) {
                 const int dd = 16 * db + 4 * g;
-                if (dd < d) *reinterpret_cast<f32x4*>(gq + (long long)q * rs + dd) = f32x4{dq[db][0] * a.scale, dq[db][1] * a.scale, dq[db][2] * a.scale, dq[db][3] * a.scale};
+                if (dd < d) put((long long)q * rs + dd, f32x4{dq[db][0] * a.scale, dq[db][1] * a.scale, dq[db][2] * a.scale, dq[db][3] * a.scale});
             }
         }
     }
@@ -801,9 +838,8 @@ __global__ __launch_bounds__(256) void winattn_lds_bwd_kernel(WsDev a) {
             for (int db = 0; db < NDB; ++db) {
                 const int dd = 16 * db + 4 * g;
                 if (dd < d) {
-                    float* dst = gq + (long long)key * rs + dd;
-                    *reinterpret_cast<f32x4*>(dst + a.heads * d) = dk[db];
-                    *reinterpret_cast<f32x4*>(dst + 2 * a.heads * d) = dv[db];
+                    put((long long)key * rs + dd + a.heads * d, dk[db]);
+                    put((long long)key * rs + dd + 2 * a.heads * d, dv[db]);
                 }
             }
         }
@@ -1544,11 +1580,28 @@ bool dlwp_winattn_small_applies(int N, int d, long long pairs) {
 
 int dlwp_winattn_small_fwd(const float* qkv, const float* table, const float* packed, const int* ia, const int* ib,
                            const int* labels, float* out, float* lse, int B_, int nW, int N, int TB, int ntypes, int heads, int d,
-                           float scale, int q_lo, int q_hi, void* stream) {
+                           float scale, int q_lo, int q_hi, void* stream, int io_bf16) {
     WsDev a{};
     ws_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, q_lo, q_hi);
     a.qkv = qkv; a.table = table; a.table_t = packed; a.ia = ia; a.ib = ib; a.labels = labels; a.out = out; a.lse = lse;
+    a.io_bf16 = io_bf16 != 0;
     const size_t lds = sizeof(float) * (size_t)TB;
+    if (io_bf16) {
+        const int ndb = (d + 15) / 16;
+        const dim3 grid((unsigned)(heads * ntypes * a.groups)), block(256);
+        auto go = [&](auto knl) -> int {
+            int rc2 = dlwp_ensure_lds(reinterpret_cast<const void*>(knl), lds, "winattn_small_fwd_kernel");
+            if (rc2) return rc2;
+            dlwp_prof_scope prof((hipStream_t)stream, ws_prof_flops(a, 2), ws_prof_bytes(a, false), "winattn_small_fwd_kernel<4, %d> (bf16)", ndb);
+            hipLaunchKernelGGL(knl, grid, block, lds, (hipStream_t)stream, a);
+            return DLWP_OK;
+        };
+        const int rc3 = ndb == 1 ? go(winattn_small_fwd_kernel<4, 1, true, true, false, true>)
+                      : ndb == 2 ? go(winattn_small_fwd_kernel<4, 2, true, true, false, true>) : go(winattn_small_fwd_kernel<4, 3, true, true, false, true>);
+        if (rc3) return rc3;
+        DLWP_LAUNCH_CHECK();
+        return DLWP_OK;
+    }
     WS_DISPATCH(winattn_small_fwd_kernel, lds);
     DLWP_LAUNCH_CHECK();
     return DLWP_OK;
@@ -1564,6 +1617,13 @@ static bool one_pass_applies(int N, int d, int TB) {
     if (nc <= 4 && !dlwp_tune_on("WINATTN_BWD1P_SMALL")) return false;
     return lds_family_applies(N, d) && lds2_bytes(16 * nc, TB) <= 160 * 1024 && (size_t)TB * 4 <= (size_t)4 * 16 * nc * LDB * 2;
 }
+// bf16 tensors in the WINDOW layout (round 6: qkv, out, gout, gqkv all bf16 arrays; dlwp_window_attn_fwd_bf16 / _bwd_bf16): windows of at
+// most 64 tokens in the bf16 matrix mode -- the wave-per-window forward with raw bf16 fragments and the two-pass LDS-staged backward
+bool dlwp_winattn_io_bf16_applies(int N, int d, int TB, long long pairs) {
+    return N <= 64 && d % 4 == 0 && dlwp_get_gemm_precision() == 1 && dlwp_winattn_small_applies(N, d, pairs) && lds_family_applies(N, d) &&
+           !(one_pass_applies(N, d, TB) && !dlwp_tune_on("WINATTN_BWD2PASS")) && !dlwp_tune_on("WINATTN_TILED");
+}
+
 static int one_pass_launch(WsDev& a, void* stream) {
     const int nc = (a.N + 15) / 16, nw1 = nc > 4 ? 8 : 4, heads = a.heads, ntypes = a.ntypes, d = a.d;
     DLWP_REQUIRE((long long)(a.dst_map ? a.Ltok : a.N) * 3 * heads * d < (1LL << 31), DLWP_E_UNSUPPORTED,
@@ -1606,14 +1666,17 @@ static int one_pass_launch(WsDev& a, void* stream) {
 
 int dlwp_winattn_small_bwd(const float* qkv, const float* table, const float* packed, const int* ia, const int* ib,
                            const int* labels, const float* out, const float* lse, const float* gout, float* gqkv, float* gtable,
-                           int B_, int nW, int N, int TB, int ntypes, int heads, int d, float scale, int q_lo, int q_hi, void* stream) {
+                           int B_, int nW, int N, int TB, int ntypes, int heads, int d, float scale, int q_lo, int q_hi, void* stream, int io_bf16) {
     WsDev a{};
     ws_setup(a, B_, nW, N, TB, ntypes, heads, d, scale, q_lo, q_hi);
     a.qkv = qkv; a.table = table; a.table_t = packed; a.ia = ia; a.ib = ib; a.labels = labels; a.o = out; a.lse_in = lse;
     a.gout = gout; a.gqkv = gqkv; a.gtable = gtable;
+    a.io_bf16 = io_bf16 != 0;
+    DLWP_REQUIRE(!io_bf16 || dlwp_winattn_io_bf16_applies(N, d, TB, (long long)B_ * heads), DLWP_E_UNSUPPORTED,
+                 "window attention backward: bf16 tensors in the window layout need windows of at most 64 tokens in the bf16 matrix mode (N %d, d %d)", N, d);
     if (lds_family_applies(N, d)) {
         const int nc = (N + 15) / 16;
-        if (!dlwp_tune_on("WINATTN_BWD2PASS") && one_pass_applies(N, d, TB)) return one_pass_launch(a, stream);
+        if (!io_bf16 && !dlwp_tune_on("WINATTN_BWD2PASS") && one_pass_applies(N, d, TB)) return one_pass_launch(a, stream);
         const size_t lb = lds_bytes(16 * nc, TB, true, d <= 32 ? LDB : LDB48);
         a.groups = lds_groups(a.M, heads, ntypes, d <= 32 ? 4 : 3);
         const dim3 grid((unsigned)(heads * ntypes * a.groups)), block(256);

@@ -156,6 +156,9 @@ SIGNATURES = {
     "dlwp_window_attn_bwd_packed": (_I, [_V] * 13 + [_I] * 7 + [_F, _V]),
     "dlwp_window_attn_fwd_qrange": (_I, [_V] * 8 + [_I] * 7 + [_F, _I, _I, _V]),
     "dlwp_window_attn_bwd_qrange": (_I, [_V] * 13 + [_I] * 7 + [_F, _I, _I, _V]),
+    "dlwp_window_attn_io_bf16_supported": (_I, [_I, _I, _I, C.c_longlong]),
+    "dlwp_window_attn_fwd_bf16": (_I, [_V] * 8 + [_I] * 7 + [_F, _V]),
+    "dlwp_window_attn_bwd_bf16": (_I, [_V] * 11 + [_I] * 7 + [_F, _V]),
     "dlwp_window_attn_bwd_tokens_supported": (_I, [_I] * 3),
     "dlwp_window_attn_bwd_tokens": (_I, [_V] * 15 + [_I] * 8 + [_F, _I, _I, _I, _V]),
     "dlwp_window_attn_fwd_tokens_supported": (_I, [_I, _I, C.c_longlong]),

@@ -38,14 +38,18 @@ class _WindowAttnFn(torch.autograd.Function):
         B_, N, C3 = qkv.shape
         ctx.qrange = (0, N) if qrange is None else (int(qrange[0]), int(qrange[1]))
         d = C3 // (3 * heads)
-        qkv = qkv.contiguous().float()
         table_param, table = table, table.contiguous()
         TB = table.shape[0]
         ntypes = table.shape[1] if table.dim() == 3 else 1
+        # a bf16 qkv tensor (the projection wrote it as bf16: WindowAttention.forward asked for it) stays bf16 through the kernels,
+        # and so do the output and both gradients (dlwp_window_attn_fwd_bf16 / _bwd_bf16)
+        ctx.io_bf16 = (qkv.dtype == torch.bfloat16 and IO_BF16 and ctx.qrange == (0, N) and d <= 64
+                       and lib.dlwp_window_attn_io_bf16_supported(N, d, TB, B_ * heads) == 1)
+        qkv = qkv.contiguous() if ctx.io_bf16 else qkv.contiguous().float()
         # with a query range the kernels leave the rows outside it unwritten: they must read as zeros (the backward pass forms
         # g * o on every row, and 0 * uninitialised bits may be NaN)
         full = ctx.qrange == (0, N)
-        out = (torch.empty if full else torch.zeros)(B_, N, heads * d, device=qkv.device)
+        out = (torch.empty if full else torch.zeros)(B_, N, heads * d, device=qkv.device, dtype=qkv.dtype)
         ctx.aux, ctx.cfg = (ia, ib, labels), (B_, nW, N, TB, ntypes, heads, d, scale)
         ctx.tslot = _grad_slot(table_param)
         ctx.wide = d > 64
@@ -69,9 +73,13 @@ class _WindowAttnFn(torch.autograd.Function):
         if ntypes > 1:
             packed = torch.empty(ntypes * heads * TB, device=qkv.device)
             L.check(lib.dlwp_window_attn_pack_table(L.ptr(table), L.ptr(packed), TB, ntypes, heads, L.stream()))
-        L.check(lib.dlwp_window_attn_fwd_qrange(L.ptr(qkv), L.ptr(table), L.ptr(packed), L.ptr(ia), L.ptr(ib), L.ptr(labels),
-                                                L.ptr(out), L.ptr(lse), B_, nW, N, TB, ntypes, heads, d, scale,
-                                                ctx.qrange[0], ctx.qrange[1], L.stream()))
+        if ctx.io_bf16:
+            L.check(lib.dlwp_window_attn_fwd_bf16(L.ptr(qkv), L.ptr(table), L.ptr(packed), L.ptr(ia), L.ptr(ib), L.ptr(labels),
+                                                  L.ptr(out), L.ptr(lse), B_, nW, N, TB, ntypes, heads, d, scale, L.stream()))
+        else:
+            L.check(lib.dlwp_window_attn_fwd_qrange(L.ptr(qkv), L.ptr(table), L.ptr(packed), L.ptr(ia), L.ptr(ib), L.ptr(labels),
+                                                    L.ptr(out), L.ptr(lse), B_, nW, N, TB, ntypes, heads, d, scale,
+                                                    ctx.qrange[0], ctx.qrange[1], L.stream()))
         ctx.packed = packed
         ctx.save_for_backward(qkv, table, out, lse)
         return out
@@ -81,7 +89,8 @@ class _WindowAttnFn(torch.autograd.Function):
         lib = L.load()
         ia, ib, labels = ctx.aux
         B_, nW, N, TB, ntypes, heads, d, scale = ctx.cfg
-        g = gout.contiguous().float()  # kept alive until the launch is enqueued
+        g = gout.contiguous()          # kept alive until the launch is enqueued
+        g = g.to(torch.bfloat16) if getattr(ctx, "io_bf16", False) else g.float()
         if ctx.wide:
             qkv, table, p = ctx.saved_tensors
             gtable = ctx.tslot if ctx.tslot is not None else torch.zeros_like(table)   # kernel accumulates
@@ -99,6 +108,11 @@ class _WindowAttnFn(torch.autograd.Function):
         qkv, table, out, lse = ctx.saved_tensors
         gqkv = torch.empty_like(qkv)
         gtable = ctx.tslot if ctx.tslot is not None else torch.zeros_like(table)   # kernel accumulates
+        if ctx.io_bf16:
+            L.check(lib.dlwp_window_attn_bwd_bf16(L.ptr(qkv), L.ptr(table), L.ptr(ctx.packed), L.ptr(ia), L.ptr(ib), L.ptr(labels),
+                                                  L.ptr(out), L.ptr(lse), L.ptr(g), L.ptr(gqkv), L.ptr(gtable), B_, nW, N, TB, ntypes,
+                                                  heads, d, scale, L.stream()))
+            return gqkv, (None if ctx.tslot is not None else gtable), None, None, None, None, None, None, None
         dsum = torch.empty_like(lse)
         slab = torch.empty(lib.dlwp_window_attn_bwd_slab_floats(B_, N, heads, TB), device=qkv.device)
         L.check(lib.dlwp_window_attn_bwd_qrange(L.ptr(qkv), L.ptr(table), L.ptr(ctx.packed), L.ptr(ia), L.ptr(ib), L.ptr(labels),
@@ -270,8 +284,14 @@ class WindowAttention(nn.Module):
         """x [nW*B, N, C]; labels: int32 [nW, N] region labels of the shift mask (None: no mask); wbatch: the block's
         token_ops.WgradBatch (the weight gradients of qkv and proj join the block's one launch); out_lowp: the projection is
         written as bf16 where its operands are (bf16 storage) for a consumer that reads bf16 windows (window_ops.reverse)."""
-        y = _WindowAttnFn.apply(self.qkv(x, wbatch=wbatch), self.relative_position_bias_table, self._ia, self._ib, labels, nW,
-                                self.num_heads, float(self.scale))
+        # bf16 storage: where the kernels take bf16 windows (dlwp_window_attn_io_bf16_supported) the projection writes qkv as bf16
+        # and the attention output, its gradient and the qkv gradient are bf16 arrays as well: no cast launch on either side
+        N, C = x.shape[-2], x.shape[-1]
+        lowp_qkv = (IO_BF16 and x.is_cuda and x.dtype == torch.bfloat16 and _TO._act_dtype() == torch.bfloat16 and (C // self.num_heads) <= 64
+                    and L.load().dlwp_window_attn_io_bf16_supported(N, C // self.num_heads, self.relative_position_bias_table.shape[0],
+                                                                    x.shape[0] * self.num_heads) == 1)
+        y = _WindowAttnFn.apply(self.qkv(x, wbatch=wbatch, out_lowp=lowp_qkv), self.relative_position_bias_table, self._ia, self._ib, labels,
+                                nW, self.num_heads, float(self.scale))
         return self.proj(y, wbatch=wbatch, out_lowp=out_lowp)
 
     def core(self, qkv_windows, labels=None, nW=1):

@@ -320,6 +320,19 @@ int dlwp_window_attn_bwd_qrange(const float* qkv, const float* bias_table, const
                                 const float* lse, const float* gout, float* gqkv, float* gbias_table,
                                 float* dsum, float* slab, int B_, int nW, int N, int TB, int ntypes,
                                 int heads, int d, float scale, int q_lo, int q_hi, void* stream);
+
+/* bf16 tensors in the window layout (round 6; reference: WindowAttention.forward, swin_transformer.py:123-155, under torch.autocast      */
+/* the qkv projection's output, the attention output and their gradients are bf16 tensors there too): qkv [B_, N, 3, heads, d], out and */
+/* gout [B_, N, heads, d] and gqkv are bf16 arrays; lse, the bias table and its gradient stay fp32.  Whole query range only.  Supported */
+/* where dlwp_window_attn_io_bf16_supported(N, d, TB, B_ * heads) returns 1 (windows of at most 64 tokens, head_dim % 4 == 0, bf16      */
+/* matrix mode); otherwise DLWP_E_UNSUPPORTED.                                                                                           */
+int dlwp_window_attn_io_bf16_supported(int N, int d, int TB, long long pairs);
+int dlwp_window_attn_fwd_bf16(const void* qkv, const float* bias_table, const float* packed_table, const int* ia, const int* ib,
+                              const int* labels, void* out, float* lse, int B_, int nW, int N, int TB, int ntypes, int heads, int d,
+                              float scale, void* stream);
+int dlwp_window_attn_bwd_bf16(const void* qkv, const float* bias_table, const float* packed_table, const int* ia, const int* ib,
+                              const int* labels, const void* out, const float* lse, const void* gout, void* gqkv, float* gbias_table,
+                              int B_, int nW, int N, int TB, int ntypes, int heads, int d, float scale, void* stream);
 long long dlwp_window_attn_bwd_slab_floats(int B_, int N, int heads, int TB);
 /* Backward of  reverse(crop) . attention . partition(pad with `fill`)  in ONE launch, for a block whose qkv projection ran */
 /* on the real tokens (EarthSpecificBlock.forward, src/dlwpbench/models/panguweather/panguweather.py:283-317: ZeroPad3d ->   */

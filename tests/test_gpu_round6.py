@@ -218,3 +218,49 @@ def test_layernorm_backward_eight_wave_workgroups(cuda, T, C):
         assert (gx.double() - want_x).abs().max().item() <= 1e-5 * want_x.abs().max().item(), nw
         assert (gg.double() - want_g).abs().max().item() <= tol * want_g.abs().max().item(), nw
         assert (gb.double() - want_b).abs().max().item() <= tol * want_b.abs().max().item(), nw
+
+
+@pytest.mark.parametrize("N,d,heads,B_,nW,masked", [(49, 24, 4, 1406, 703, True), (49, 48, 4, 380, 190, True), (49, 32, 6, 512, 64, False), (64, 16, 8, 300, 4, True)])
+def test_window_attention_bf16_tensors_in_the_window_layout(cuda, N, d, heads, B_, nW, masked):
+    """dlwp_window_attn_fwd_bf16 / _bwd_bf16 (qkv, out, gout, gqkv as bf16 arrays: the wave-per-window forward on raw bf16 fragments, the
+    two-pass LDS-staged backward reading / writing bf16 rows) against the fp32-tensor entries on the same bf16-rounded values.
+    Tolerance: the bf16 resolution of the outputs (4e-3 relative to the largest entry) plus the second rounding of the scaled q."""
+    from dlwp_benchmark_amd import lib as L
+    lib = L.load()
+    BF = torch.bfloat16
+    g = torch.Generator().manual_seed(N + d + heads)
+    TB = 3 * N
+    qkv = torch.randn(B_, N, 3 * heads * d, generator=g).to(cuda).to(BF)
+    table = (0.5 * torch.randn(TB, heads, generator=g)).to(cuda)
+    ia = torch.randint(0, TB // 2, (N,), generator=g, dtype=torch.int32).to(cuda)
+    ib = torch.randint(0, TB // 2, (N,), generator=g, dtype=torch.int32).to(cuda)
+    labels = torch.randint(0, 3, (nW, N), generator=g, dtype=torch.int32).to(cuda) if masked else None
+    gout = torch.randn(B_, N, heads * d, generator=g).to(cuda).to(BF)
+    scale = d ** -0.5
+    with L.gemm_precision("bf16"):
+        assert lib.dlwp_window_attn_io_bf16_supported(N, d, TB, B_ * heads) == 1
+        # fp32 tensors
+        q32 = qkv.float()
+        out32, lse32 = torch.empty(B_, N, heads * d, device=cuda), torch.empty(B_, heads, N, device=cuda)
+        L.check(lib.dlwp_window_attn_fwd_qrange(L.ptr(q32), L.ptr(table), None, L.ptr(ia), L.ptr(ib), L.ptr(labels), L.ptr(out32), L.ptr(lse32),
+                                                B_, nW, N, TB, 1, heads, d, scale, 0, N, L.stream()))
+        gq32, gt32 = torch.empty_like(q32), torch.zeros_like(table)
+        dsum = torch.empty_like(lse32)
+        slab = torch.empty(lib.dlwp_window_attn_bwd_slab_floats(B_, N, heads, TB), device=cuda)
+        o32r = out32.to(BF).float()          # the bf16 path's backward reads the ROUNDED output
+        L.check(lib.dlwp_window_attn_bwd_qrange(L.ptr(q32), L.ptr(table), None, L.ptr(ia), L.ptr(ib), L.ptr(labels), L.ptr(o32r), L.ptr(lse32),
+                                                L.ptr(gout.float()), L.ptr(gq32), L.ptr(gt32), L.ptr(dsum), L.ptr(slab), B_, nW, N, TB, 1, heads, d,
+                                                scale, 0, N, L.stream()))
+        # bf16 tensors
+        out16, lse16 = torch.empty(B_, N, heads * d, device=cuda, dtype=BF), torch.empty(B_, heads, N, device=cuda)
+        L.check(lib.dlwp_window_attn_fwd_bf16(L.ptr(qkv), L.ptr(table), None, L.ptr(ia), L.ptr(ib), L.ptr(labels), L.ptr(out16), L.ptr(lse16),
+                                              B_, nW, N, TB, 1, heads, d, scale, L.stream()))
+        gq16, gt16 = torch.empty_like(qkv), torch.zeros_like(table)
+        L.check(lib.dlwp_window_attn_bwd_bf16(L.ptr(qkv), L.ptr(table), None, L.ptr(ia), L.ptr(ib), L.ptr(labels), L.ptr(out16), L.ptr(lse16),
+                                              L.ptr(gout), L.ptr(gq16), L.ptr(gt16), B_, nW, N, TB, 1, heads, d, scale, L.stream()))
+        torch.cuda.synchronize()
+    rel = lambda a, b: ((a.double() - b.double()).abs().max() / b.double().abs().max()).item()   # noqa: E731
+    assert rel(out16, out32) <= 1e-2
+    assert rel(lse16, lse32) <= 2e-3
+    assert rel(gq16, gq32) <= 2e-2
+    assert rel(gt16, gt32) <= 2e-2
