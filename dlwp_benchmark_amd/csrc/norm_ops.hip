@@ -14,6 +14,26 @@ namespace {
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// Second output of the LayerNorm backward kernels (round 6): gx * row_scale[sample] as a bf16 array -- the operand the NEXT backward
+// products read (the branch that ends in this residual stream applied a per-sample stochastic-depth scale; its backward wants the scaled
+// gradient as bf16 for its two products).  Written from the registers that hold gx: the separate cast pass (19 MB at Pangu's 8192 x 384,
+// 5.9 us of launch 28 times per step) disappears.  out == nullptr: nothing.
+struct LnLowp {
+    __bf16* out;
+    const float* scale;      // [samples] or nullptr (1)
+    int rows_per_sample;
+};
+// the row's scale, once per row (a 32-bit division: T < 2^31 rows)
+__device__ __forceinline__ float ln_lowp_scale(const LnLowp& lp, long long row) {
+    return (lp.out && lp.scale) ? lp.scale[(unsigned)row / (unsigned)lp.rows_per_sample] : 1.f;
+}
+__device__ __forceinline__ void ln_lowp_store4(const LnLowp& lp, float sc, long long off, const f32x4& v) {
+    if (!lp.out) return;
+    *reinterpret_cast<bf16x4*>(lp.out + off) = bf16x4{(__bf16)(v[0] * sc), (__bf16)(v[1] * sc), (__bf16)(v[2] * sc), (__bf16)(v[3] * sc)};
+}
+
+
+
 // ---- LayerNorm over the last dimension: one wave per row
 __device__ __forceinline__ float wave_sum64(float v) {
 #pragma unroll
@@ -96,7 +116,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gy, const float* __restrict__ gadd,
                                                             float* __restrict__ gx, float* ggamma, float* gbeta, int T, int C,
-                                                            int rows_per_block, int gy_bf16) {
+                                                            int rows_per_block, int gy_bf16, LnLowp lp) {
     extern __shared__ float sm[];            // [2][C] per-block partial of ggamma, gbeta
     float* sg = sm;
     float* sb = sm + C;
@@ -153,7 +173,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         s2 = wave_sum64(s2) / C;
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
-            if (okc[q]) gx[(long long)row * C + lane + 64 * q] = rs * (gv[q] * gam[q] - s1 - xh[q] * s2) + av[q];
+            if (okc[q]) {
+                const float o1 = rs * (gv[q] * gam[q] - s1 - xh[q] * s2) + av[q];
+                gx[(long long)row * C + lane + 64 * q] = o1;
+                if (lp.out) lp.out[(long long)row * C + lane + 64 * q] = (__bf16)(o1 * ln_lowp_scale(lp, row));
+            }
         if (more) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) { xv[q] = xn[q]; gv[q] = gn[q]; av[q] = an[q]; }
@@ -278,7 +302,7 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_vec_kernel(const float*
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ gy, const float* __restrict__ gadd,
                                                                 float* __restrict__ gx, float* ggamma, float* gbeta, int T, int C,
-                                                                int rows_per_block, int gy_bf16) {
+                                                                int rows_per_block, int gy_bf16, LnLowp lp) {
     extern __shared__ float sm[];            // [2][C] per-block partial of ggamma, gbeta
     constexpr int RPW = 64 / LPR;
     for (int c = threadIdx.x; c < 2 * C; c += 64 * NW) sm[c] = 0.f;
@@ -345,6 +369,7 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_vec_kernel(const float*
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o4[k] = rs[u] * (gg[k] - s1 - xh[k] * s2) + av[u][k];
                 *reinterpret_cast<f32x4*>(gx + row * C + 4 * l) = o4;
+                ln_lowp_store4(lp, ln_lowp_scale(lp, row), row * C + 4 * l, o4);
             }
         }
     }
@@ -385,7 +410,7 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_vecn_kernel(const float
                                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                      const float* __restrict__ gy, const float* __restrict__ gadd,
                                                                      float* __restrict__ gx, float* ggamma, float* gbeta, int T, int C,
-                                                                     int rows_per_block, int gy_bf16) {
+                                                                     int rows_per_block, int gy_bf16, LnLowp lp) {
     extern __shared__ float sm[];            // [2][C] per-block partial of ggamma, gbeta
     constexpr int RPW = 64 / LPR, CS = 4 * LPR;      // rows per wave and group; column stride between a lane's chunks
     for (int c = threadIdx.x; c < 2 * C; c += 64 * NW) sm[c] = 0.f;
@@ -446,12 +471,14 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_vecn_kernel(const float
             s1 = row_sum<LPR>(s1) * invC;
             s2 = row_sum<LPR>(s2) * invC;
             if (ok[u]) {
+                const float lsc = ln_lowp_scale(lp, row);
 #pragma unroll
                 for (int c = 0; c < NV; ++c) {
                     f32x4 o4;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) o4[k] = rs[u] * (gg[c][k] - s1 - xh[c][k] * s2) + av[u][c][k];
                     *reinterpret_cast<f32x4*>(gx + row * C + 4 * l + CS * c) = o4;
+                    ln_lowp_store4(lp, lsc, row * C + 4 * l + CS * c, o4);
                 }
             }
         }
@@ -485,7 +512,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const float* __
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const float* __restrict__ gy, const float* __restrict__ gadd,
                                                                  float* __restrict__ gx, float* ggamma, float* gbeta, int T, int C,
-                                                                 int rows_per_block, int gy_bf16) {
+                                                                 int rows_per_block, int gy_bf16, LnLowp lp) {
     extern __shared__ float sm[];            // [2][C] per-block partial of ggamma, gbeta
     for (int c = threadIdx.x; c < 2 * C; c += 256) sm[c] = 0.f;
     __syncthreads();
@@ -543,6 +570,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const float* __
             }
         s1 = wave_sum64(s1) * invC;
         s2 = wave_sum64(s2) * invC;
+const float lsc = ln_lowp_scale(lp, row);
 #pragma unroll
         for (int q = 0; q < NV; ++q)
             if (okc[q]) {
@@ -550,6 +578,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const float* __
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o4[k] = rs * (gv[q][k] * gm[q][k] - s1 - xh[q][k] * s2) + av[q][k];
                 *reinterpret_cast<f32x4*>(gx + row * C + col[q]) = o4;
+                ln_lowp_store4(lp, lsc, row * C + col[q], o4);
             }
         if (more) {
 #pragma unroll
@@ -768,7 +797,7 @@ static int ln_bwd_waves(int T, int C) {
 
 static int layernorm_bwd_impl(const float* x, const float* gamma, const float* mean, const float* rstd, const float* gy,
                               const float* gadd, float* gx, float* ggamma, float* gbeta, int T, int C, int gy_bf16,
-                              void* stream) {
+                              void* stream, LnLowp lp = LnLowp{nullptr, nullptr, 1}) {
     DLWP_REQUIRE(x && gamma && mean && rstd && gy && gx && ggamma && gbeta && T > 0 && C > 0, DLWP_E_INVALID,
                  "layernorm_bwd: bad argument");
     DLWP_REQUIRE(C <= 2048, DLWP_E_UNSUPPORTED, "layernorm_bwd: C <= 2048 supported (got %d)", C);
@@ -806,7 +835,7 @@ static int layernorm_bwd_impl(const float* x, const float* gamma, const float* m
         const int rpbn = std::max(rpg, ceil_div(ceil_div(T, wgs), rpg) * rpg);
         const dim3 gridn(ceil_div(T, rpbn));
 #define LN_BWD_N(LPR, UB_) hipLaunchKernelGGL((layernorm_bwd_vecn_kernel<LPR, 3, 8, UB_>), gridn, dim3(512), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, \
-                                              gadd, gx, ggamma, gbeta, T, C, rpbn, gy_bf16)
+                                              gadd, gx, ggamma, gbeta, T, C, rpbn, gy_bf16, lp)
         if (lpr3 == 8) LN_BWD_N(8, 4); else if (lpr3 == 16) LN_BWD_N(16, 4); else if (lpr3 == 32) LN_BWD_N(32, 4); else LN_BWD_N(64, 2);
 #undef LN_BWD_N
         DLWP_LAUNCH_CHECK();
@@ -820,7 +849,7 @@ static int layernorm_bwd_impl(const float* x, const float* gamma, const float* m
         const int rpw = std::max(4, ceil_div(ceil_div(T, slots), 4) * 4);
         const dim3 gridw(ceil_div(T, rpw));
 #define LN_BWD_W(NV) hipLaunchKernelGGL(layernorm_bwd_wide_kernel<NV>, gridw, dim3(256), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, \
-                                        gadd, gx, ggamma, gbeta, T, C, rpw, gy_bf16)
+                                        gadd, gx, ggamma, gbeta, T, C, rpw, gy_bf16, lp)
         if (C <= 512) LN_BWD_W(2); else if (C <= 768) LN_BWD_W(3); else LN_BWD_W(4);
 #undef LN_BWD_W
         DLWP_LAUNCH_CHECK();
@@ -832,7 +861,7 @@ static int layernorm_bwd_impl(const float* x, const float* gamma, const float* m
         const int rpbn = nw == 8 ? std::max(8, ceil_div(ceil_div(T, 256), 8) * 8) : rpb;      // eight waves: one workgroup per CU
         const dim3 gridn(ceil_div(T, rpbn));
 #define LN_BWD_V2(LPR, NW_) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<LPR, NW_>), gridn, dim3(64 * NW_), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, \
-                                          gadd, gx, ggamma, gbeta, T, C, rpbn, gy_bf16)
+                                          gadd, gx, ggamma, gbeta, T, C, rpbn, gy_bf16, lp)
 #define LN_BWD_V(LPR) do { if (nw == 8) LN_BWD_V2(LPR, 8); else LN_BWD_V2(LPR, 4); } while (0)
         if (C <= 32) LN_BWD_V(8); else if (C <= 64) LN_BWD_V(16); else if (C <= 128) LN_BWD_V(32); else LN_BWD_V(64);
 #undef LN_BWD_V2
@@ -842,7 +871,7 @@ static int layernorm_bwd_impl(const float* x, const float* gamma, const float* m
     }
 #define LN_BWD(NQ)                                                                                                   \
     hipLaunchKernelGGL(layernorm_bwd_kernel<NQ>, grid, dim3(256), lds, (hipStream_t)stream, x, gamma, mean, rstd, gy, gadd, \
-                       gx, ggamma, gbeta, T, C, rpb, gy_bf16)
+                       gx, ggamma, gbeta, T, C, rpb, gy_bf16, lp)
     dlwp_prof_scope prof((hipStream_t)stream, pflops, pbytes, "layernorm_bwd_kernel");
     if (C <= 64) LN_BWD(1);
     else if (C <= 128) LN_BWD(2);
@@ -865,6 +894,15 @@ extern "C" int dlwp_layernorm_bwd_ex(const float* x, const float* gamma, const f
                                      int gy_bf16, const float* gadd, float* gx, float* ggamma, float* gbeta, int T, int C,
                                      void* stream) {
     return layernorm_bwd_impl(x, gamma, mean, rstd, (const float*)gy, gadd, gx, ggamma, gbeta, T, C, gy_bf16 ? 1 : 0, stream);
+}
+
+extern "C" int dlwp_layernorm_bwd_lowp(const float* x, const float* gamma, const float* mean, const float* rstd, const void* gy,
+                                       int gy_bf16, const float* gadd, float* gx, float* ggamma, float* gbeta, int T, int C,
+                                       void* gx_bf16, const float* row_scale, int rows_per_sample, void* stream) {
+    DLWP_REQUIRE(gx_bf16 && rows_per_sample > 0 && T % rows_per_sample == 0 && (uintptr_t)gx_bf16 % 8 == 0, DLWP_E_INVALID,
+                 "layernorm_bwd_lowp: a bf16 output (8-byte aligned) and whole samples of %d rows (T = %d)", rows_per_sample, T);
+    return layernorm_bwd_impl(x, gamma, mean, rstd, (const float*)gy, gadd, gx, ggamma, gbeta, T, C, gy_bf16 ? 1 : 0, stream,
+                              LnLowp{static_cast<__bf16*>(gx_bf16), row_scale, rows_per_sample});
 }
 
 extern "C" int dlwp_layernorm_bwd(const float* x, const float* gamma, const float* mean, const float* rstd,

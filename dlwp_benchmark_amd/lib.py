@@ -139,6 +139,7 @@ SIGNATURES = {
     "dlwp_layernorm_bwd": (_I, [_V] * 8 + [_I, _I, _V]),
     "dlwp_layernorm_bwd_res": (_I, [_V] * 9 + [_I, _I, _V]),
     "dlwp_layernorm_bwd_ex": (_I, [_V] * 5 + [_I] + [_V] * 4 + [_I, _I, _V]),
+    "dlwp_layernorm_bwd_lowp": (_I, [_V] * 5 + [_I] + [_V] * 4 + [_I, _I, _V, _V, _I, _V]),
     "dlwp_instnorm_fwd": (_I, [_V] * 6 + [_I, _I, _I, _F, _V]),
     "dlwp_instnorm_bwd": (_I, [_V] * 8 + [_I, _I, _I, _V]),
     "dlwp_gelu_bwd": (_I, [_V, _V, _V, _L, _V]),

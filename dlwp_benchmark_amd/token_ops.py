@@ -44,9 +44,34 @@ def _gemm_rowscale(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, bias, residual, row_
                                         L.ptr(row_scale), M // nb, _dtypes(A, B, C, None, residual), L.stream()))
 
 
+# The scaled bf16 gradient a LayerNorm backward has already written beside its fp32 gx (dlwp_layernorm_bwd_lowp) for the branch that ends
+# in its input: keyed by gx's address, valid inside one backward pass (cleared by an engine callback when the pass ends).
+# env DLWP_LN_BWD_LOWP=0: A/B runs against the separate cast launch
+LN_BWD_LOWP = __import__("os").environ.get("DLWP_LN_BWD_LOWP", "1") != "0"
+_GRAD_LOWP = {"map": {}, "armed": False, "hits": 0, "misses": 0}
+
+
+def _grad_lowp_clear():
+    _GRAD_LOWP["map"].clear()
+    _GRAD_LOWP["armed"] = False
+
+
+def _grad_lowp_put(gx, lowp, scale):
+    _GRAD_LOWP["map"][gx.data_ptr()] = (lowp, scale.data_ptr(), gx.numel())
+    if not _GRAD_LOWP["armed"]:
+        _GRAD_LOWP["armed"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_grad_lowp_clear)
+
+
 def _scaled_grad(g2, row_scale, lowp):
     """row_scale[sample] * g2 for the backward of a product that applied the scale (g2 fp32 [T][N]): as bf16 when the backward
     products read bf16 operands (cast and scale in one pass), else fp32 (dlwp_scale_rows_add without a residual)."""
+    if lowp:
+        hit = _GRAD_LOWP["map"].pop(g2.data_ptr(), None)
+        if hit is not None and hit[1] == row_scale.data_ptr() and hit[2] == g2.numel():
+            _GRAD_LOWP["hits"] += 1
+            return hit[0].reshape(g2.shape)          # the LayerNorm backward that produced g2 wrote it already
+        _GRAD_LOWP["misses"] += 1
     nb = row_scale.numel()
     out = torch.empty_like(g2, dtype=_BF if lowp else torch.float32)
     if lowp and (g2.numel() // nb) % 4 == 0:
@@ -756,6 +781,11 @@ class _LayerNormFn(torch.autograd.Function):
         ctx.save_for_backward(x2, gamma, mean, rstd)
         ctx.shape, ctx.fork = shape, fork
         ctx.slots = (_grad_slot(gamma), _grad_slot(beta))
+        # x is the output of a residual branch that applied a per-sample scale (DropPath.branch tags it): that branch's backward wants
+        # bf16(gx * scale) -- this node's backward kernel writes it beside gx
+        sc = getattr(x, "_dlwp_branch_scale", None) if LN_BWD_LOWP else None
+        ctx.next_scale = sc if (sc is not None and _act_dtype() == _BF and x.dim() == 3 and sc.numel() == shape[0] and sc.dtype == torch.float32
+                                and C_ % 4 == 0) else None
         if fork:
             return x.view_as(x), y.reshape(shape)
         return y.reshape(shape)
@@ -775,8 +805,15 @@ class _LayerNormFn(torch.autograd.Function):
         gx = torch.empty_like(x2)
         fused = ctx.slots[0] is not None and ctx.slots[1] is not None
         gg, gb = ctx.slots if fused else (torch.zeros_like(gamma), torch.zeros_like(gamma))
-        L.check(lib.dlwp_layernorm_bwd_ex(L.ptr(x2), L.ptr(gamma.contiguous()), L.ptr(mean), L.ptr(rstd), L.ptr(g2),
-                                          int(g2.dtype == _BF), L.ptr(r2), L.ptr(gx), L.ptr(gg), L.ptr(gb), T, C_, L.stream()))
+        if ctx.next_scale is not None:
+            lowp = torch.empty_like(gx, dtype=_BF)
+            L.check(lib.dlwp_layernorm_bwd_lowp(L.ptr(x2), L.ptr(gamma.contiguous()), L.ptr(mean), L.ptr(rstd), L.ptr(g2), int(g2.dtype == _BF),
+                                                L.ptr(r2), L.ptr(gx), L.ptr(gg), L.ptr(gb), T, C_, L.ptr(lowp), L.ptr(ctx.next_scale),
+                                                T // ctx.next_scale.numel(), L.stream()))
+            _grad_lowp_put(gx, lowp, ctx.next_scale)
+        else:
+            L.check(lib.dlwp_layernorm_bwd_ex(L.ptr(x2), L.ptr(gamma.contiguous()), L.ptr(mean), L.ptr(rstd), L.ptr(g2),
+                                              int(g2.dtype == _BF), L.ptr(r2), L.ptr(gx), L.ptr(gg), L.ptr(gb), T, C_, L.stream()))
         if fused:
             return gx.reshape(ctx.shape), None, None, None, None, None
         return gx.reshape(ctx.shape), gg, gb, None, None, None
@@ -905,7 +942,10 @@ class DropPath(nn.Module):
             return fn(t, residual=residual, **kw)
         if not DROPPATH_FUSED:
             return self(fn(t, **kw), residual=residual)
-        return fn(t, residual=residual, row_scale=self.mask(residual.shape[0], t.device), **kw)
+        mask = self.mask(residual.shape[0], t.device)
+        y = fn(t, residual=residual, row_scale=mask, **kw)
+        y._dlwp_branch_scale = mask      # a LayerNorm that reads y writes this branch's scaled bf16 gradient in its backward (_LayerNormFn)
+        return y
 
     def extra_repr(self):
         return f"drop_prob={self.p:0.3f}"

@@ -848,6 +848,14 @@ int dlwp_layernorm_fwd_ex(const float* x, const float* gamma, const float* beta,
 int dlwp_layernorm_bwd_ex(const float* x, const float* gamma, const float* mean, const float* rstd,
                           const void* gy, int gy_bf16, const float* gadd, float* gx, float* ggamma,
                           float* gbeta, int T, int C, void* stream);
+
+/* As dlwp_layernorm_bwd_ex, with a second output (round 6): gx_bf16[t][c] = bf16(gx[t][c] * row_scale[t / rows_per_sample]) -- the      */
+/* gradient the residual branch that ENDS in this stream wants for its backward products (per-sample stochastic-depth scale, bf16       */
+/* operands; reference: DropPath in Block.forward, swin_transformer.py:255-256, whose backward scales the branch gradient), written    */
+/* from the registers that hold gx instead of by a separate pass over it.  row_scale NULL: a plain bf16 copy.                           */
+int dlwp_layernorm_bwd_lowp(const float* x, const float* gamma, const float* mean, const float* rstd, const void* gy, int gy_bf16,
+                            const float* gadd, float* gx, float* ggamma, float* gbeta, int T, int C, void* gx_bf16,
+                            const float* row_scale, int rows_per_sample, void* stream);
 /* gx written; ggamma/gbeta ACCUMULATED into.  C <= 2048.                                    */
 int dlwp_layernorm_bwd(const float* x, const float* gamma, const float* mean, const float* rstd,
                        const float* gy, float* gx, float* ggamma, float* gbeta, int T, int C,

@@ -264,3 +264,31 @@ def test_window_attention_bf16_tensors_in_the_window_layout(cuda, N, d, heads, B
     assert rel(lse16, lse32) <= 2e-3
     assert rel(gq16, gq32) <= 2e-2
     assert rel(gt16, gt32) <= 2e-2
+
+
+@pytest.mark.parametrize("T,C,B", [(8192, 384, 1), (65536, 96, 2), (16384, 192, 4), (16200, 768, 2), (9000, 200, 3), (3000, 50, 2)])
+def test_layernorm_backward_second_output_is_the_scaled_bf16_gradient(cuda, T, C, B):
+    """dlwp_layernorm_bwd_lowp: gx_bf16 == bf16(gx * row_scale[sample]) for every LayerNorm backward kernel (three-chunk, one-chunk, wide-row,
+    scalar), gx itself and the column gradients unchanged against dlwp_layernorm_bwd_ex."""
+    from dlwp_benchmark_amd import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(T + C)
+    x = torch.randn(T, C, generator=g).to(cuda)
+    gy = torch.randn(T, C, generator=g).to(cuda).bfloat16()
+    ga = torch.randn(T, C, generator=g).to(cuda)
+    gam = (1.0 + 0.1 * torch.randn(C, generator=g)).to(cuda)
+    scale = torch.tensor([0.0, 1.25, 1.0, 1.1][:B], device=cuda)
+    mean = x.mean(1).contiguous()
+    rstd = (x.var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    gx0, gg0, gb0 = torch.empty_like(x), torch.zeros(C, device=cuda), torch.zeros(C, device=cuda)
+    L.check(lib.dlwp_layernorm_bwd_ex(L.ptr(x), L.ptr(gam), L.ptr(mean), L.ptr(rstd), L.ptr(gy), 1, L.ptr(ga), L.ptr(gx0), L.ptr(gg0), L.ptr(gb0),
+                                      T, C, L.stream()))
+    gx1, gg1, gb1 = torch.empty_like(x), torch.zeros(C, device=cuda), torch.zeros(C, device=cuda)
+    low = torch.empty(T, C, device=cuda, dtype=torch.bfloat16)
+    L.check(lib.dlwp_layernorm_bwd_lowp(L.ptr(x), L.ptr(gam), L.ptr(mean), L.ptr(rstd), L.ptr(gy), 1, L.ptr(ga), L.ptr(gx1), L.ptr(gg1), L.ptr(gb1),
+                                        T, C, L.ptr(low), L.ptr(scale), T // B, L.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(gx0, gx1)
+    assert (gg0 - gg1).abs().max().item() <= 1e-4 * gg0.abs().max().item() and (gb0 - gb1).abs().max().item() <= 1e-4 * gb0.abs().max().item()
+    want = (gx1.reshape(B, T // B, C) * scale[:, None, None]).reshape(T, C).bfloat16()
+    assert torch.equal(low, want)
