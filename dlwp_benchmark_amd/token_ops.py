@@ -57,7 +57,7 @@ def _grad_lowp_clear():
 
 
 def _grad_lowp_put(gx, lowp, scale):
-    _GRAD_LOWP["map"][gx.data_ptr()] = (lowp, scale.data_ptr(), gx.numel())
+    _GRAD_LOWP["map"][gx.data_ptr()] = (lowp, 0 if scale is None else scale.data_ptr(), gx.numel())
     if not _GRAD_LOWP["armed"]:
         _GRAD_LOWP["armed"] = True
         torch.autograd.Variable._execution_engine.queue_callback(_grad_lowp_clear)
@@ -100,12 +100,21 @@ LOWP_MIN_DEPTH = int(__import__("os").environ.get("DLWP_LOWP_MIN_DEPTH", "768"))
 
 
 def _lowp(t, depth):
+    return _lowp_impl(t, depth)
+
+
+def _lowp_impl(t, depth):
     """Under bf16 storage: a bf16 copy of an fp32 GEMM operand that is read by two products (one cast launch, then both
     products take the 16-byte bf16 path).  The matrix units round fp32 operands to bf16 anyway, so the results are unchanged.
     `depth` = the other dimension of those products: the cast is one more pass over t, the saving grows with depth -- measured
     break-even between 512 (SFNO MLP: 12.5 -> 13.2 ms with the casts) and 768 (Pangu C4: 22.9 -> 22.6; AFNO 3072: 30.3 -> 28.4)."""
     if t is None or t.dtype == _BF or _act_dtype() != _BF or depth < LOWP_MIN_DEPTH:
         return t
+    if _GRAD_LOWP["map"]:
+        hit = _GRAD_LOWP["map"].pop(t.data_ptr(), None)
+        if hit is not None and hit[1] == 0 and hit[2] == t.numel():
+            _GRAD_LOWP["hits"] += 1
+            return hit[0].reshape(t.shape)           # the LayerNorm backward that produced t wrote the copy already
     out = torch.empty_like(t, dtype=_BF)
     L.check(L.load().dlwp_cast_bf16(L.ptr(t), L.ptr(out), t.numel(), L.stream()))
     return out
@@ -543,7 +552,13 @@ class _MlpStreamFn(torch.autograd.Function):
 def mlp(x, w1, b1, w2, b2, residual=None, row_scale=None, wbatch=None):
     if row_scale is None and _MlpStreamFn.applies(x, w1, w2):
         return _MlpStreamFn.apply(x, w1, b1, w2, b2, residual)
-    return _MlpFn.apply(x, w1, b1, w2, b2, residual, row_scale, wbatch)
+    y = _MlpFn.apply(x, w1, b1, w2, b2, residual, row_scale, wbatch)
+    # this node's backward casts its upstream gradient to bf16 for its two products (_lowp): a LayerNorm that reads y writes that copy
+    # in its own backward instead (_LayerNormFn / dlwp_layernorm_bwd_lowp; with a stochastic-depth scale DropPath.branch tags y itself)
+    if (row_scale is None and LN_BWD_LOWP and _act_dtype() == _BF
+            and (w1.shape[0] >= LOWP_MIN_DEPTH or (wbatch is not None and WGRAD_BATCH and WGRAD_FORCE_CAST))):
+        y._dlwp_branch_scale = "plain"
+    return y
 
 
 class _SkipMlpFn(torch.autograd.Function):
@@ -784,8 +799,9 @@ class _LayerNormFn(torch.autograd.Function):
         # x is the output of a residual branch that applied a per-sample scale (DropPath.branch tags it): that branch's backward wants
         # bf16(gx * scale) -- this node's backward kernel writes it beside gx
         sc = getattr(x, "_dlwp_branch_scale", None) if LN_BWD_LOWP else None
-        ctx.next_scale = sc if (sc is not None and _act_dtype() == _BF and x.dim() == 3 and sc.numel() == shape[0] and sc.dtype == torch.float32
-                                and C_ % 4 == 0) else None
+        ctx.next_plain = isinstance(sc, str) and sc == "plain" and _act_dtype() == _BF and C_ % 4 == 0      # (an unscaled copy, see mlp())
+        ctx.next_scale = sc if (isinstance(sc, torch.Tensor) and _act_dtype() == _BF and x.dim() == 3 and sc.numel() == shape[0]
+                                and sc.dtype == torch.float32 and C_ % 4 == 0) else None
         if fork:
             return x.view_as(x), y.reshape(shape)
         return y.reshape(shape)
@@ -805,11 +821,12 @@ class _LayerNormFn(torch.autograd.Function):
         gx = torch.empty_like(x2)
         fused = ctx.slots[0] is not None and ctx.slots[1] is not None
         gg, gb = ctx.slots if fused else (torch.zeros_like(gamma), torch.zeros_like(gamma))
-        if ctx.next_scale is not None:
+        if ctx.next_scale is not None or ctx.next_plain:
             lowp = torch.empty_like(gx, dtype=_BF)
+            nb = ctx.next_scale.numel() if ctx.next_scale is not None else 1
             L.check(lib.dlwp_layernorm_bwd_lowp(L.ptr(x2), L.ptr(gamma.contiguous()), L.ptr(mean), L.ptr(rstd), L.ptr(g2), int(g2.dtype == _BF),
                                                 L.ptr(r2), L.ptr(gx), L.ptr(gg), L.ptr(gb), T, C_, L.ptr(lowp), L.ptr(ctx.next_scale),
-                                                T // ctx.next_scale.numel(), L.stream()))
+                                                T // nb, L.stream()))
             _grad_lowp_put(gx, lowp, ctx.next_scale)
         else:
             L.check(lib.dlwp_layernorm_bwd_ex(L.ptr(x2), L.ptr(gamma.contiguous()), L.ptr(mean), L.ptr(rstd), L.ptr(g2),
