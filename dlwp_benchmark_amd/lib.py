@@ -96,6 +96,7 @@ SIGNATURES = {
     "dlwp_gemm_mixed": (_I, [_V, _V, _V] + [_I] * 8 + [_V, _I, _V, _V, _I, _V, _I, _V]),
     "dlwp_gemm_batched_mixed": (_I, [_V, _V, _V] + [_I] * 10 + [_L] * 6 + [_V, _L, _L, _I, _F, _V, _V, _L, _L, _I, _I, _I, _V]),
     "dlwp_cast_bf16": (_I, [_V, _V, _L, _V]),
+    "dlwp_transpose_cast_bf16_many": (_I, [_V, _V, _V, _I, _I, _V]),
     "dlwp_gemm_rowscale": (_I, [_V, _V, _V] + [_I] * 8 + [_V, _V, _V, _I, _I, _V]),
     "dlwp_cast_bf16_scaled": (_I, [_V, _V, _V, _I, _L, _V]),
     "dlwp_gemm_batched": (_I, [_V, _V, _V] + [_I] * 10 + [_L] * 6 + [_V, _L, _L, _I, _F, _V, _V, _L, _L, _I, _I, _V]),
@@ -341,6 +342,14 @@ def set_storage(mode):
 
 def storage_bf16():
     return _STORAGE == "bf16"
+
+
+def shadow_t(p):
+    """The current TRANSPOSED bf16 copy ([in][out]) of a Linear weight `p` ([out][in]), or None (train_engine keeps them for the 2-D
+    weights whose input-gradient products read them)."""
+    if not (SHADOW_ACTIVE and _STORAGE == "bf16"):
+        return None
+    return getattr(p, "_dlwp_bf16_t", None)
 
 
 def shadow(p):

@@ -186,6 +186,8 @@ class _LinearFn(torch.autograd.Function):
         ctx.row_scale, ctx.wbatch = row_scale, wbatch
         if wbatch is not None:
             wbatch.enrol()
+        # the [in][out] bf16 copy (train_engine): the input-gradient product then runs in the k-contiguous form (see _input_grad)
+        ctx.wt = L.shadow_t(weight) if (w.dtype == _BF and weight.dim() == 2) else None
         ctx.save_for_backward(x2, w, z)
         ctx.has_bias, ctx.has_res, ctx.act, ctx.shape = bias is not None, residual is not None, act, shape
         ctx.res_pre, ctx.wshape = bool(res_pre) and act, weight.shape
@@ -218,7 +220,7 @@ class _LinearFn(torch.autograd.Function):
         gx = torch.empty(T, K, device=g2.device, dtype=ctx.in_dtype)   # a bf16 input (LayerNorm output) takes a bf16 gradient
         if wb is not None:
             if wb.takes(g2, x2, ctx.wslot, ctx.bslot, ctx.has_bias):       # the weight gradient joins the block's one launch
-                _gemm(g2, w, gx, T, K, N, N, K, K, 0, 0)
+                _input_grad(g2, w, ctx.wt, gx, T, K, N)
                 wb.add(g2, x2, ctx.wslot, ctx.bslot, ctx.has_bias, ctx.wshape)
                 return gx.reshape(ctx.shape), None, None, None, gres, None, None, None, None
         gw, gb = None, None
@@ -228,7 +230,7 @@ class _LinearFn(torch.autograd.Function):
             gw = torch.empty(N, K, device=g2.device)
         # the two products read the same g and do not depend on each other: one launch while they are small (lib.gemm_group)
         with L.gemm_group():
-            _gemm(g2, w, gx, T, K, N, N, K, K, 0, 0)                 # gx = g W
+            _input_grad(g2, w, ctx.wt, gx, T, K, N)                  # gx = g W
             # gW = g^T x, with the bias gradient (column sums of g) produced by the same kernel; both go straight
             # into the parameters' gradient buffers when those exist (fused gradient accumulation)
             if ctx.wslot is not None:
@@ -242,6 +244,25 @@ class _LinearFn(torch.autograd.Function):
         if wb is not None:
             wb.done()
         return gx.reshape(ctx.shape), gw, gb, None, gres, None, None, None, None
+
+
+def _input_grad(g2, w, wt, gx, T, K, N, **epi):
+    """gx [T][K] = g2 [T][N] W, W = w [N][K]: as y = g (W^T)^T on the transposed bf16 copy wt [K][N] when there is one and g2 is a bf16
+    array (both operands k-contiguous: the faster form of the LDS-DMA kernels), else on w in the [k][n] form.  epi: _gemm_batched
+    epilogue arguments (the MLP's hidden gradient multiplies by the stored GELU derivative)."""
+    if wt is not None and g2.dtype == _BF and wt.dtype == _BF and not INPUT_GRAD_NN:
+        if epi:
+            _gemm_batched(g2, wt, gx, T, K, N, N, N, K, 0, 1, **epi)
+        else:
+            _gemm(g2, wt, gx, T, K, N, N, N, K, 0, 1)
+    elif epi:
+        _gemm_batched(g2, w, gx, T, K, N, N, K, K, 0, 0, **epi)
+    else:
+        _gemm(g2, w, gx, T, K, N, N, K, K, 0, 0)
+
+
+# env: 1 = the input-gradient products stay in the [k][n] form even where a transposed weight copy exists (A/B runs)
+INPUT_GRAD_NN = __import__("os").environ.get("DLWP_INPUT_GRAD_NN", "0") == "1"
 
 
 def _weight_grad(g2, x2, weight_slot, bias_slot, has_bias, wshape):
@@ -442,6 +463,7 @@ class _MlpFn(torch.autograd.Function):
         ctx.wbatch = wbatch if (wbatch is not None and WGRAD_BATCH and adt == _BF and ctx.needs_input_grad[1] and ctx.needs_input_grad[3]) else None
         if ctx.wbatch is not None:
             ctx.wbatch.enrol(2)
+        ctx.wt = (L.shadow_t(w1), L.shadow_t(w2)) if (adt == _BF and w1.dim() == 2 and w2.dim() == 2) else (None, None)
         ctx.save_for_backward(x2, w1m, w2m, z, h)
         ctx.shape, ctx.has_res = shape, residual is not None
         ctx.in_dtype = x.dtype if x.dtype == _BF else torch.float32
@@ -462,13 +484,13 @@ class _MlpFn(torch.autograd.Function):
         elif h.dtype == _BF:
             g2 = _lowp(g2, Hd if (ctx.wbatch is None or not WGRAD_FORCE_CAST) else LOWP_MIN_DEPTH)                   # read by gh = g W2 and gW2 = g^T h
         gh = torch.empty(T, Hd, device=g2.device, dtype=h.dtype)
-        _gemm_batched(g2, w2m, gh, T, Hd, N, N, Hd, Hd, 0, 0, act=_ACT_B, residual=z)     # (g W2) * GELU'(z), z = the stored derivative
+        _input_grad(g2, w2m, ctx.wt[1], gh, T, Hd, N, act=_ACT_B, residual=z)             # (g W2) * GELU'(z), z = the stored derivative
         gx = torch.empty(T, K, device=g2.device, dtype=ctx.in_dtype)   # a bf16 input (LayerNorm output) takes a bf16 gradient
         wb = ctx.wbatch
         if wb is not None:
             pairs = [(g2, h, ctx.slots[2], ctx.slots[3], ctx.has_b[1], ctx.w2shape), (gh, x2, ctx.slots[0], ctx.slots[1], ctx.has_b[0], ctx.w1shape)]
             if all(wb.takes(*q[:5]) for q in pairs):       # the weight gradients join the block's one launch
-                _gemm(gh, w1m, gx, T, K, Hd, Hd, K, K, 0, 0)
+                _input_grad(gh, w1m, ctx.wt[0], gx, T, K, Hd)
                 for q in pairs:
                     wb.add(*q)
                 return gx.reshape(ctx.shape), None, None, None, None, (gy if ctx.has_res else None), None, None
@@ -476,11 +498,11 @@ class _MlpFn(torch.autograd.Function):
         # products of at most 2.2 GFLOP; larger ones launch at once)
         if T <= 4096:          # (nsbench AFNO 64 x 64, 1024 tokens: 754 -> 796 samples/s)
             with L.gemm_group():
-                _gemm(gh, w1m, gx, T, K, Hd, Hd, K, K, 0, 0)
+                _input_grad(gh, w1m, ctx.wt[0], gx, T, K, Hd)
                 gw2, gb2 = _weight_grad(g2, h, ctx.slots[2], ctx.slots[3], ctx.has_b[1], ctx.w2shape)
                 gw1, gb1 = _weight_grad(gh, x2, ctx.slots[0], ctx.slots[1], ctx.has_b[0], ctx.w1shape)
         else:                  # more tokens: the input gradient on its own kernel, the weight gradients on the dedicated grouped one
-            _gemm(gh, w1m, gx, T, K, Hd, Hd, K, K, 0, 0)
+            _input_grad(gh, w1m, ctx.wt[0], gx, T, K, Hd)
             (gw2, gb2), (gw1, gb1) = _weight_grad_group([(g2, h, ctx.slots[2], ctx.slots[3], ctx.has_b[1], ctx.w2shape),
                                                          (gh, x2, ctx.slots[0], ctx.slots[1], ctx.has_b[0], ctx.w1shape)])
         if wb is not None:

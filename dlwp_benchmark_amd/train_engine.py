@@ -17,6 +17,9 @@ from . import lib as L
 from .fno_engine import FusedAdam
 
 
+# env: A/B runs of the transposed bf16 weight copies for the input-gradient products (round 6); matrices below the size keep the [k][n] form
+_WEIGHT_T = __import__("os").environ.get("DLWP_WEIGHT_T", "1") != "0"
+_WEIGHT_T_MIN = int(__import__("os").environ.get("DLWP_WEIGHT_T_MIN", "16384"))
 _FLAT_ALIGN = int(__import__("os").environ.get("DLWP_FLAT_ALIGN", "8"))      # env: A/B runs against the 4-element slices of rounds 1-4
 
 
@@ -51,6 +54,21 @@ def flatten_parameters(module):
         for p, o in zip(params, offs):
             p._dlwp_bf16 = flat16[o:o + p.numel()].view(p.shape)
         module._dlwp_flat16 = (flat, flat16)
+        # transposed copies ([in][out]) of the 2-D weights for the input-gradient products (lib.shadow_t, dlwp_transpose_cast_bf16_many):
+        # one more flat bf16 buffer, one more launch per step
+        if _WEIGHT_T:
+            descs, nt, max_tiles = [], 0, 0
+            for p, o in zip(params, offs):
+                if p.dim() == 2 and p.shape[0] % 8 == 0 and p.shape[1] % 8 == 0 and p.numel() >= _WEIGHT_T_MIN:
+                    descs.append((o, nt, p.shape[0], p.shape[1], p))
+                    nt += (p.numel() + _FLAT_ALIGN - 1) // _FLAT_ALIGN * _FLAT_ALIGN
+                    max_tiles = max(max_tiles, ((p.shape[0] + 63) // 64) * ((p.shape[1] + 63) // 64))
+            if descs:
+                flat16t = torch.zeros(nt, device=dev, dtype=torch.bfloat16)
+                for so, do, r, c, p in descs:
+                    p._dlwp_bf16_t = flat16t[do:do + r * c].view(c, r)
+                table = torch.tensor([[so, do, r, c] for so, do, r, c, _ in descs], dtype=torch.int64).to(dev)
+                module._dlwp_flat16t = (flat, flat16t, table, len(descs), max_tiles)
     return flat, grad
 
 
@@ -59,6 +77,10 @@ def refresh_bf16_weights(module):
     if pair is not None:
         flat, flat16 = pair
         L.check(L.load().dlwp_cast_bf16(L.ptr(flat), L.ptr(flat16), flat.numel(), L.stream()))
+    tr = getattr(module, "_dlwp_flat16t", None)
+    if tr is not None:
+        flat, flat16t, table, n, max_tiles = tr
+        L.check(L.load().dlwp_transpose_cast_bf16_many(L.ptr(flat), L.ptr(flat16t), L.ptr(table), n, max_tiles, L.stream()))
 
 
 class _SqErr(torch.autograd.Function):

@@ -648,6 +648,12 @@ int dlwp_gemm_rowscale(const void* A, const void* B, void* C, int M, int N, int 
                        const float* row_scale, int rows_per_scale, int dtypes, void* stream);
 /* dst[i] = bf16(src[i]) (round to nearest even): the per-step bf16 copy of the flat fp32 master weights.     */
 int dlwp_cast_bf16(const float* src, void* dst, long long n, void* stream);
+/* Transposed bf16 copies of a list of fp32 matrices inside two flat buffers, one launch (round 6): matrix m is src_base[descs[4m]      */
+/* ...] viewed [rows = descs[4m+2]][cols = descs[4m+3]], its copy dst_base[descs[4m+1] ...] viewed [cols][rows] (bf16).  descs is a    */
+/* DEVICE array of n x 4 64-bit integers; max_tiles = the largest ceil(rows/64) * ceil(cols/64).  The per-step [in][out] copies of    */
+/* the Linear weights the input-gradient products read (reference: autograd's gx = g W for torch.nn.Linear, token layers of           */
+/* swin_transformer.py / panguweather.py / fourcastnet.py).                                                                             */
+int dlwp_transpose_cast_bf16_many(const float* src_base, void* dst_base, const long long* descs, int n, int max_tiles, void* stream);
 /* dst[s][i] = bf16(src[s][i] * scale[s]), i < per_sample (a multiple of 4): the backward of dlwp_gemm_rowscale's */
 /* scale on the way into the branch's bf16 products.                                                              */
 int dlwp_cast_bf16_scaled(const float* src, const float* scale, void* dst, int nsamples, long long per_sample,

@@ -292,3 +292,54 @@ def test_layernorm_backward_second_output_is_the_scaled_bf16_gradient(cuda, T, C
     assert (gg0 - gg1).abs().max().item() <= 1e-4 * gg0.abs().max().item() and (gb0 - gb1).abs().max().item() <= 1e-4 * gb0.abs().max().item()
     want = (gx1.reshape(B, T // B, C) * scale[:, None, None]).reshape(T, C).bfloat16()
     assert torch.equal(low, want)
+
+
+def test_transposed_weight_copies_and_the_input_gradient_products(cuda):
+    """train_engine keeps [in][out] bf16 copies of the 2-D weights (dlwp_transpose_cast_bf16_many, one launch per step) and the Linear /
+    Mlp backward computes gx = g W on them in the k-contiguous form: the copies are the transposes of the bf16 weights, bit for bit, and
+    the gradients of a small token model agree with the [k][n] form (same operands, another summation order)."""
+    import torch.nn as nn
+    from dlwp_benchmark_amd import lib as L, token_ops as TO, train_engine as TE
+    from dlwp_benchmark_amd.train_engine import GraphedTrainStep
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.norm = TO.LayerNorm(192)
+            self.qkv = TO.Linear(192, 576)
+            self.back = TO.Linear(576, 192)
+            self.norm2 = TO.LayerNorm(192)
+            self.mlp = TO.Mlp(192, 768)
+
+        def forward(self, x):
+            skip, t = TO.norm_fork(self.norm, x, gemm_input=True)
+            x = self.back(self.qkv(t), residual=skip)
+            skip, t = TO.norm_fork(self.norm2, x, gemm_input=True)
+            return self.mlp(t, residual=skip)
+
+    L.set_gemm_precision("bf16")
+    L.set_storage("bf16")
+    try:
+        torch.manual_seed(3)
+        net = Net().to(cuda).train()
+        x = torch.randn(2, 4096, 192, device=cuda)
+        target = torch.randn(2, 4096, 192, device=cuda)
+        step = GraphedTrainStep(net, {"x": x}, target, lr=1e-3, use_graph=False)
+        assert getattr(net, "_dlwp_flat16t", None) is not None
+        grads = {}
+        for nn_form in (True, False):
+            TO.INPUT_GRAD_NN = nn_form
+            step.grad.zero_()
+            step._fwd_bwd()
+            torch.cuda.synchronize()
+            grads[nn_form] = step.grad.clone()
+        for p in net.parameters():
+            if p.dim() == 2:
+                assert torch.equal(p._dlwp_bf16_t, p._dlwp_bf16.t().contiguous()), tuple(p.shape)
+        a, b = grads[True].double(), grads[False].double()
+        assert ((a - b).abs().max() / a.abs().max()).item() <= 2e-2
+        assert ((a - b).norm() / a.norm()).item() <= 3e-3
+    finally:
+        TO.INPUT_GRAD_NN = False
+        L.set_storage("fp32")
+        L.set_gemm_precision("fp32")
