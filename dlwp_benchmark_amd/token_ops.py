@@ -57,7 +57,9 @@ def _grad_lowp_clear():
 
 
 def _grad_lowp_put(gx, lowp, scale):
-    _GRAD_LOWP["map"][gx.data_ptr()] = (lowp, 0 if scale is None else scale.data_ptr(), gx.numel())
+    # the entry holds gx (and the scale) itself: while it is alive no other tensor can live at gx's address, so a hit by address IS gx
+    # (or a view of all of it) -- an unconsumed entry whose gx had been freed could otherwise match a later tensor at the recycled address
+    _GRAD_LOWP["map"][gx.data_ptr()] = (lowp, 0 if scale is None else scale.data_ptr(), gx.numel(), gx, scale)
     if not _GRAD_LOWP["armed"]:
         _GRAD_LOWP["armed"] = True
         torch.autograd.Variable._execution_engine.queue_callback(_grad_lowp_clear)
