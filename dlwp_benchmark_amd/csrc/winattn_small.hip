@@ -1032,6 +1032,27 @@ __device__ __forceinline__ void lds2_store(const Stage2<IOBF>& R, const WsDev& a
     if (tid < NR) { L.lse[tid] = R.lse; L.lab[tid] = a.labels ? R.lab : 0; srcv[tid] = a.dst_map ? R.src : (tid < N ? tid : N - 1); }
 }
 
+// The bias-table slice of a (type, head) into LDS with the loads of eight strides of the workgroup in flight at once (round 6: the plain
+// `for (i = tid; i < TB; i += NT) tb[i] = table[..]` loop is a chain of dependent load -> LDS-store round trips, five of them at
+// Pangu's 2548 entries and 512 threads -- part of the ~ 8.5 k cycles a workgroup spends before its first window)
+template <int NT>
+__device__ __forceinline__ void stage_table_batched(float* tb, const WsDev& a, const Who& w) {
+    const int TB = a.TB, tid = threadIdx.x;
+    for (int i0 = 0; i0 < TB; i0 += 8 * NT) {
+        float tv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(i0 + u * NT + tid, TB - 1);           // clamped: unconditional loads
+            tv[u] = a.table_t ? a.table_t[w.tofs * TB + i] : a.table[(long long)i * w.tstr + w.tofs];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * NT + tid;
+            if (i < TB) tb[i] = tv[u];
+        }
+    }
+}
+
 template <int NDB, int NW, bool IOBF = false>
 __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
     constexpr int NT = 64 * NW;
@@ -1041,8 +1062,7 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
     const LdsWin& L = L2.w;
     int grp;
     Who w = who_lds(a, grp);
-    if (a.table_t) { for (int i = threadIdx.x; i < a.TB; i += NT) L.tb[i] = a.table_t[w.tofs * a.TB + i]; }
-    else { for (int i = threadIdx.x; i < a.TB; i += NT) L.tb[i] = a.table[(long long)i * w.tstr + w.tofs]; }
+    stage_table_batched<NT>(L.tb, a, w);
     DLWP_STAMP(0);
     Stage2<IOBF> R;
     Idx2 I;
@@ -1280,6 +1300,8 @@ __global__ __launch_bounds__(64 * NW) void winattn_lds_bwd1p_kernel(WsDev a) {
     float* tbg = reinterpret_cast<float*>(L.Q);
     for (int i = threadIdx.x; i < a.TB; i += NT) tbg[i] = 0.f;
     __syncthreads();
+    // (four entries per thread in flight instead of one were measured in round 6: 18.6 k -> 17.4 k cycles -- the LDS float adds, not the
+    // latency of the index reads, bound the fold)
     for (int e = threadIdx.x; e < ((a.dbg & 16) ? 0 : N * N); e += NT) {
         const int key = e / N, q = e - key * N;
         const float v = L2.dense[key * LDD + q];
@@ -1360,8 +1382,7 @@ __global__ __launch_bounds__(256) void winattn_lds_fwd_tok_kernel(WsDev a) {
     float* fillv = tb + ((a.TB + 3) & ~3);
     int grp;
     Who w = who_lds(a, grp);
-    if (a.table_t) { for (int i = threadIdx.x; i < a.TB; i += NT) tb[i] = a.table_t[w.tofs * a.TB + i]; }
-    else { for (int i = threadIdx.x; i < a.TB; i += NT) tb[i] = a.table[(long long)i * w.tstr + w.tofs]; }
+    stage_table_batched<NT>(tb, a, w);
     for (int t = threadIdx.x; t < NR; t += NT) {
         const int tc = t < N ? t : N - 1;
         ias[t] = a.ia[tc];
