@@ -1544,14 +1544,16 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmDev a) {
 // plain product (no split-K / batches / row sums / row bias), the aligned epilogue, enough tiles to be worth 128 x 128
 // column-tile width of gemm_glds_kernel: 96 when N is a multiple of 96 and rounds x width (whole rounds of one workgroup per CU, work per
 // tile ~ its width) comes out lower than with 128-wide tiles; ties go to 128 when N is a multiple of 128.  GEMM_GLDS_N96: 0 never, 1 by
-// this rule (default), 2 wherever N % 96 == 0.
+// this rule (default), 2 wherever N % 96 == 0.  GEMM_GLDS_N96_TIE_K: ties go to 96 up to this K (default 192).
 static int gemm_glds_tile_n(const GemmDev& a) {
     const int mode = dlwp_tune_or("GEMM_GLDS_N96", 1);
     if (mode == 0 || a.N % 96 != 0) return GT;
     if (mode == 2) return 96;
     const long long ncu = 256, mt = ceil_div(a.M, GT);
     const long long c128 = ceil_div(mt * ceil_div(a.N, GT), ncu) * 128, c96 = ceil_div(mt * (a.N / 96), ncu) * 96;
-    return c96 < c128 || (c96 == c128 && a.N % GT != 0) ? 96 : GT;
+    // ties: 96 where 128 would pad, and for short products (K <= 192: launch / epilogue bound, the finer tiles fill the last round better --
+    // Swin C4 443 -> 449 samples/s with every tie at 96, AFNO 721 53.6 -> 52.3 with its K = 768 products there too)
+    return c96 < c128 || (c96 == c128 && (a.N % GT != 0 || a.K <= dlwp_tune_or("GEMM_GLDS_N96_TIE_K", 192))) ? 96 : GT;
 }
 static bool gemm_glds_applies(const GemmDev& a, bool akc, bool bkc) {
     const bool off = dlwp_tune_on("GEMM_NOGLDS");

@@ -26,6 +26,7 @@ Knob g_knobs[] = {
     {"GEMM_GLDS_MINK", "least K for the 128 x 128 LDS-DMA activation kernels to be taken by shape (default 96)", 0, false},
     {"GEMM_GLDS_MINTILES", "least number of 128 x 128 output tiles for those kernels to be taken by shape (default 256)", 0, false},
     {"GEMM_GLDS_N96", "128 x 96 output tiles in those kernels: 0 never, 1 when N % 96 == 0 and whole rounds x tile width is lower (default), 2 wherever N % 96 == 0", 0, false},
+    {"GEMM_GLDS_N96_TIE_K", "128 x 96 tiles also where rounds x width ties with 128-wide tiles, for products with K up to this (default 192)", 0, false},
     {"GEMM_GLDS_KD", "K-step depth of the LDS-DMA activation kernels: 32 or 64 (default by shape)", 0, false},
     {"GEMM_GLDS_TN_KD", "K-step depth of the LDS-DMA weight-gradient kernel: 32 or 64 (default by tile count)", 0, false},
     {"GEMM_GLDS_TN_WGS", "resident workgroup slots the weight-gradient kernel sizes its K slices for", 0, false},
