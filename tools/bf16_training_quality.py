@@ -103,6 +103,17 @@ FAMILIES = {
                  model=dict(img_height=360, img_width=720, patch_size=(8, 8), constant_channels=4, prescribed_channels=1,
                             prognostic_channels=8, embed_dim=768, depth=6, mlp_ratio=4.0, num_blocks=16, context_size=1),
                  modes=("fp32", "bf16_fp32spectra", "bf16_spectra")),
+    # round 6, second half: the C4 families with the bf16 tensor paths that were added then (window-layout bf16 attention tensors, the
+    # LayerNorm backward's scaled bf16 second output under stochastic depth, transposed weight copies): the benchmarked widths on a
+    # quarter-size grid whose stage maps are multiples of the window
+    "swin": dict(cls="SwinTransformer", H=56, W=112, Cg=8, B=4, T=2, lr=5e-4, shift=1.5,
+                 model=dict(constant_channels=4, prescribed_channels=1, prognostic_channels=8, context_size=1, img_height=56, img_width=112,
+                            patch_size=1, embed_dim=96, depths=[2, 2], num_heads=[4, 4], drop_path_rate=0.1, window_size=7),
+                 modes=("fp32", "bf16")),
+    "pangu": dict(cls="PanguWeather", H=56, W=112, Cg=8, B=2, T=2, lr=3e-4, shift=1.5,
+                  model=dict(constant_channels=4, prescribed_channels=1, prognostic_channels=8, embed_dim=96, num_heads=(3, 6, 6, 3),
+                             window_size=(2, 7, 7), patch_size=(1, 1), n_lat=56, n_lon=112, context_size=1),
+                  modes=("fp32", "bf16")),
 }
 
 
@@ -203,6 +214,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps-sfno", type=int, default=2000)
     ap.add_argument("--steps-afno", type=int, default=1500)
+    ap.add_argument("--steps-c4", type=int, default=800, help="training steps of the swin / pangu families")
     ap.add_argument("--seeds", type=int, default=3)
     ap.add_argument("--families", default="sfno,afno")
     ap.add_argument("--modes", default=None, help="comma list: only these modes (default: all of the family)")
@@ -214,7 +226,7 @@ def main():
     if a.merge and os.path.isfile(a.merge):
         runs = [r for r in json.load(open(a.merge))["runs"] if "at_step" in r]
     for fam in a.families.split(","):
-        steps = a.steps_sfno if fam == "sfno" else a.steps_afno
+        steps = a.steps_sfno if fam == "sfno" else a.steps_afno if fam == "afno" else a.steps_c4
         eval_at = tuple(steps // d for d in (8, 4, 2))
         for seed in range(a.seeds):
             for mode in FAMILIES[fam]["modes"]:
@@ -228,7 +240,7 @@ def main():
                       flush=True)
                 json.dump({"runs": runs}, open(a.out + ".partial", "w"))
     set_mode("fp32")
-    doc = {"task": __doc__.split("\n\n")[1], "protocol": {"steps": {"sfno": a.steps_sfno, "afno": a.steps_afno}, "seeds": a.seeds,
+    doc = {"task": __doc__.split("\n\n")[1], "protocol": {"steps": {"sfno": a.steps_sfno, "afno": a.steps_afno, "swin": a.steps_c4, "pangu": a.steps_c4}, "seeds": a.seeds,
                                                            "families": {k: {kk: vv for kk, vv in v.items() if kk != "modes"} for k, v in FAMILIES.items()},
                                                            "evaluation": "closed loop from ONE observed frame, lead times 1 - 4, 4 held-out batches, RMSE over "
                                                                          "all lead times; each mode evaluated in its own arithmetic"},
