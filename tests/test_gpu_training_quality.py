@@ -47,3 +47,19 @@ def test_afno_fcn_widths_bf16_storage_trains_like_the_fp32_path(cuda):
         assert r["lead1_rmse"] < 0.75 * r["persistence_lead1_rmse"], (mode, r["lead1_rmse"], r["persistence_lead1_rmse"])
     ratio = res["bf16_fp32spectra"]["lead1_rmse"] / res["fp32"]["lead1_rmse"]
     assert 0.93 <= ratio <= 1.07, (ratio, res)          # (the full experiment: 1.003 after 187 steps, 1.007 after 375, over three seeds)
+
+
+@pytest.mark.parametrize("family", ["swin", "pangu"])
+def test_c4_families_bf16_path_trains_like_the_fp32_path(cuda, family):
+    """The C4 families at their benchmarked widths on a 56 x 112 grid (profiles/r06_bf16_training_quality_c4.json: seed-paired ratios 0.97 -
+    1.04 at 500 steps, single pairs 0.94 - 1.04): bf16 window-attention tensors, the LayerNorm backward's scaled bf16 second output under
+    stochastic depth and the transposed weight copies are all on this path.  A wrong gradient path shows as tens of per cent."""
+    q = _tool()
+    try:
+        res = {mode: q.run(family, mode, seed=0, steps=500, device=cuda) for mode in ("fp32", "bf16")}
+    finally:
+        q.set_mode("fp32")
+    for mode, r in res.items():
+        assert r["closed_loop_rmse"] < 0.6 * r["persistence_rmse"], (mode, r["closed_loop_rmse"], r["persistence_rmse"])
+    ratio = res["bf16"]["closed_loop_rmse"] / res["fp32"]["closed_loop_rmse"]
+    assert 0.88 <= ratio <= 1.12, (ratio, res["bf16"]["closed_loop_rmse"], res["fp32"]["closed_loop_rmse"])
