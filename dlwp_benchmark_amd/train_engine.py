@@ -19,7 +19,7 @@ from .fno_engine import FusedAdam
 
 # env: A/B runs of the transposed bf16 weight copies for the input-gradient products (round 6); matrices below the size keep the [k][n] form
 _WEIGHT_T = __import__("os").environ.get("DLWP_WEIGHT_T", "1") != "0"
-_WEIGHT_T_MIN = int(__import__("os").environ.get("DLWP_WEIGHT_T_MIN", "16384"))
+_WEIGHT_T_MIN = int(__import__("os").environ.get("DLWP_WEIGHT_T_MIN", "4096"))
 _FLAT_ALIGN = int(__import__("os").environ.get("DLWP_FLAT_ALIGN", "8"))      # env: A/B runs against the 4-element slices of rounds 1-4
 
 
